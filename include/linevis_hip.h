@@ -1,0 +1,166 @@
+/*
+ * linevis_hip.h -- C-ABI of the MI355X-native line renderer hot path.
+ *
+ * Drop-in boundary for chrismile/LineVis' ray-traced line renderers.  The reference has no
+ * FFI of its own: its renderers (class LineRenderer, src/Renderers/LineRenderer.hpp:66-277) talk to the GPU through
+ * sgl/Vulkan objects.  Each entry point below names the reference interface it replaces; a maintainer binds them
+ * from a `LineRenderer` subclass as shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; every pointer is a HOST pointer borrowed for the duration of the call unless
+ *     the name says `device` (then it is a HIP device pointer, e.g. a torch tensor's data_ptr()).
+ *   - return value: LV_OK (0) or a negative LV_E_* code; lv_last_error(ctx) holds a message. No exceptions cross.
+ *   - one context = one HIP device = one calling thread at a time (the reference calls every renderer method from
+ *     its main thread, src/MainApp.cpp:914-1013).  Multi-GPU = one context per device / process.
+ *   - matrices are float32 column-major (GLM layout).  Camera convention owned by the build (sgl::Camera is not
+ *     in the reference tree): right-handed view space looking down -z, depth range [0,1], projection with
+ *     y flipped so that image row 0 is the top (see linevis_amd/camera.py).
+ *   - images are RGBA8, row-major, 4 bytes per pixel, row 0 = top.
+ *   - there is NO CPU fallback: every entry point that computes runs hand-written HIP kernels on gfx950 and fails
+ *     with LV_E_HIP if no device is present.
+ */
+#ifndef LINEVIS_HIP_H
+#define LINEVIS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LV_OK 0
+#define LV_E_INVALID (-1)   /* bad argument / unknown option / call order */
+#define LV_E_HIP (-2)       /* HIP runtime error (message has the hipError string) */
+#define LV_E_STATE (-3)     /* missing lines / camera / transfer function / accel */
+#define LV_E_CAPACITY (-4)  /* BVH deeper than the traversal stack, buffer too small */
+
+/* RenderingMode ids, src/Renderers/RenderingModes.hpp:32-53 */
+#define LV_RENDERING_MODE_PER_PIXEL_LINKED_LIST 2
+#define LV_RENDERING_MODE_VULKAN_RAY_TRACER 11
+
+/* struct LinePointDataUnified, src/LineData/LineRenderData.hpp:99-106 -- byte-identical (48 B). */
+typedef struct lv_line_point {
+    float linePosition[3];
+    float lineAttribute;
+    float lineTangent[3];
+    float lineRotation;
+    float lineNormal[3];
+    uint32_t lineStartIndex;
+} lv_line_point;
+
+/* Counters and timers.  Replaces the per-phase GPU timers of PerPixelLinkedListLineRenderer.cpp:411-420 and the
+ * buffer-size reporting of VulkanRayTracer.cpp:671-675.  Ray/node/primitive counters are only filled when the
+ * option "collect_stats" is "true" (instrumented kernels; not for timing runs). */
+typedef struct lv_stats {
+    uint64_t rays_traced;        /* primary + transparency continuation + AO rays */
+    uint64_t nodes_visited;      /* 64-byte BVH nodes fetched */
+    uint64_t prims_tested;       /* 32-byte segment records fetched + capsule tests */
+    uint64_t hits_shaded;        /* closest-hit / fragment shading invocations */
+    uint64_t fragments;          /* PPLL: value of fragCounter after gather */
+    uint64_t ao_hit_pixels;      /* RTAO: pixels whose primary ray hit (compacted list length) */
+    uint32_t max_depth_complexity; /* PPLL: longest per-pixel fragment list */
+    uint32_t bvh_depth;          /* height of the LBVH */
+    uint32_t num_segments;
+    uint32_t num_nodes;
+    float ms_accel_build;
+    float ms_depth_range;
+    float ms_ao;                 /* all RTAO kernels of the last lv_render* call */
+    float ms_color;              /* ray-tracer colour pass */
+    float ms_ppll_clear;
+    float ms_ppll_gather;
+    float ms_ppll_resolve;
+    float ms_total;              /* whole lv_render* call on the stream */
+    uint64_t device_bytes;       /* device memory owned by the context */
+} lv_stats;
+
+typedef struct lv_ctx lv_ctx;
+
+/* Renderer construction/destruction: `new VulkanRayTracer(&sceneData, tfWindow)` + initialize(),
+ * src/MainApp.cpp:811,840-846. */
+lv_ctx* lv_create(int device_ordinal, int* err);
+void lv_destroy(lv_ctx* ctx);
+const char* lv_last_error(const lv_ctx* ctx);
+const char* lv_version(void);
+
+/* Run all kernels of this context on `hip_stream` (a hipStream_t, e.g. torch.cuda.current_stream().cuda_stream);
+ * NULL selects the context's own stream.  No reference analogue (sgl owns the Vulkan queue). */
+int lv_set_stream(lv_ctx* ctx, void* hip_stream);
+
+/* LineRenderer::setLineData(LineDataPtr&, bool) (LineRenderer.hpp:98) fed by
+ * LineData::getLinePassTubeAabbRenderData (LineData.hpp:186): 48-byte point records + index pairs, copied to HBM. */
+int lv_set_lines(lv_ctx* ctx, const lv_line_point* points, uint32_t num_points,
+                 const uint32_t* segment_point_indices /* 2 per segment */, uint32_t num_segments);
+
+/* TransferFunctionWindow texture + MinMaxUniformBuffer (Data/Shaders/Utils/TransferFunction.glsl:60-71):
+ * n RGBA float texels, sampled with linear filtering at texel centres, clamp-to-edge. */
+int lv_set_transfer_function(lv_ctx* ctx, const float* rgba, uint32_t n, float attr_min, float attr_max);
+
+/* SceneData camera + viewport (src/Renderers/SceneData.hpp:49-85) and LineRenderer::onResolutionChanged
+ * (LineRenderer.hpp:127); inverses are taken inside as LineData::updateVulkanUniformBuffers does (LineData.cpp:1290-1291). */
+int lv_set_camera(lv_ctx* ctx, const float view[16], const float proj[16], float fov_y, float near_dist,
+                  float far_dist, uint32_t viewport_width, uint32_t viewport_height);
+
+/* SceneData::clearColor (SceneData.hpp); foreground = 1 - background (LineData.cpp:1282-1283). */
+int lv_set_background(lv_ctx* ctx, const float rgba[4]);
+
+/* LineRenderer::setNewSettings(const SettingsMap&) (LineRenderer.hpp:163): same string keys and encodings
+ * (InternalState.hpp:43-125; bools are "true"/"1").  Keys:
+ *   line_width, depth_cue_strength, ambient_occlusion_mode ("None" | "RTAO (Screen Space)"),
+ *   ambient_occlusion_strength, ambient_occlusion_gamma              (LineRenderer.cpp:433-498)
+ *   ambient_occlusion_iterations, ambient_occlusion_samples_per_frame, ambient_occlusion_radius,
+ *   ambient_occlusion_distance_based, use_jittered_primary_rays        (VulkanRayTracedAmbientOcclusion.cpp:115-144)
+ *   num_samples_per_frame, num_accumulated_frames (must be 1: offline frames use spp instead of 8-bit feedback),
+ *   use_deterministic_sampling, use_analytic_intersections (must be true), geometry_mode (must be "AABBs")
+ *                                                                       (VulkanRayTracer.cpp:226-278)
+ *   use_capped_tubes, use_halos, tube_num_subdivisions                  (LineData.cpp:87-181)
+ *   max_depth_complexity                                                (VulkanRayTracer.hpp:139)
+ *   ppll_max_num_frags, ppll_expected_avg_depth_complexity, ppll_tile_width, ppll_tile_height
+ *                                                                       (PerPixelLinkedListLineRenderer.cpp:144-209,251-357)
+ *   collect_stats (build-owned: run the instrumented kernels). */
+int lv_set_option(lv_ctx* ctx, const char* key, const char* value);
+
+/* LineData::getRayTracingTubeAabbTopLevelAS (LineData.cpp:1057-1075) + getTubeAabbBottomLevelAS (:879-907):
+ * builds the LBVH over segment AABBs min(p0,p1)-r .. max(p0,p1)+r (LineDataFlow.cpp:2230-2233) on the GPU.
+ * Called implicitly by lv_render* when lines or line_width changed. */
+int lv_build_accel(lv_ctx* ctx);
+
+/* LineRenderer::render() (LineRenderer.hpp:112) for mode 11 (VulkanRayTracer::render, VulkanRayTracer.cpp:131-154:
+ * depth range -> RTAO iterations -> colour pass) or mode 2 (PerPixelLinkedListLineRenderer::render,
+ * PerPixelLinkedListLineRenderer.cpp:399-427: clear -> gather -> resolve) restricted to the pixel rectangle
+ * [x0, x0+w) x [y0, y0+h) of the viewport.  out: w*h*4 bytes. */
+int lv_render(lv_ctx* ctx, int rendering_mode, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, uint8_t* out_rgba8);
+int lv_render_device(lv_ctx* ctx, int rendering_mode, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h,
+                     void* out_rgba8_device);
+
+/* Same for a list of equally sized tiles (screen-tile sharding).  tiles_xy: 2 uint32 per tile
+ * (pixel origin).  Output is tile-major: [num_tiles][tile_h][tile_w][4]; parts of a tile outside the viewport are
+ * written as the background colour. */
+int lv_render_tiles_device(lv_ctx* ctx, int rendering_mode, const uint32_t* tiles_xy, uint32_t num_tiles,
+                           uint32_t tile_w, uint32_t tile_h, void* out_rgba8_device);
+
+int lv_get_stats(lv_ctx* ctx, lv_stats* out);
+
+/* ---- inspection entry points used by the parity tests ---- */
+/* Closest hit of arbitrary rays (IntersectionTube + driver closest-hit semantics, TubeRayTracing.glsl:452-494).
+ * origins/dirs: 3 floats per ray; out_segment = 0xFFFFFFFF on miss; out_kind: 0 tube, 1 sphere p0, 2 sphere p1. */
+int lv_trace_rays(lv_ctx* ctx, const float* origins, const float* dirs, float t_min, float t_max, uint32_t n,
+                  float* out_t, uint32_t* out_segment, uint32_t* out_kind);
+/* LineRenderer::computeDepthRange (LineRenderer.cpp:410-431): min/max view depth of all line points. */
+int lv_compute_depth_range(lv_ctx* ctx, float out_min_max[2]);
+/* Full-viewport RTAO texture (.x channel of the RGBA32F accumulation image) after the last mode-11/2 render. */
+int lv_get_ao(lv_ctx* ctx, float* out /* viewport_width * viewport_height */);
+/* PPLL buffers after the last mode-2 render: nodes = 3 uint32 {rgba8, depth bits, next} per stored fragment,
+ * start_offset = padded_w * padded_h heads (0xFFFFFFFF = empty).  Either pointer may be NULL. */
+int lv_ppll_get_buffers(lv_ctx* ctx, uint32_t* out_nodes, uint64_t max_nodes, uint32_t* out_start_offset,
+                        uint64_t max_pixels, uint32_t* out_frag_counter);
+/* Resolve caller-supplied PPLL buffers (LinkedListResolve.glsl:57-105) with the current camera/options. */
+int lv_ppll_resolve_buffers(lv_ctx* ctx, const uint32_t* nodes, uint64_t num_nodes, const uint32_t* start_offset,
+                            uint64_t num_pixels, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h,
+                            uint8_t* out_rgba8);
+/* LBVH export for structural tests: nodes are 16 uint32/float words each, leaf order = Morton. */
+int lv_get_accel(lv_ctx* ctx, void* out_nodes, uint64_t max_nodes, uint32_t* out_leaf_segment, uint64_t max_leaves);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LINEVIS_HIP_H */

@@ -1,0 +1,227 @@
+"""ctypes binding of the C-ABI in include/linevis_hip.h (liblinevis_hip.so, HIP / gfx950).
+
+This is plumbing for tests, bench.py and the multi-GPU driver; the product is the shared library.  There is no
+CPU fallback: importing works anywhere, but `load()` raises if the library has not been built and every compute
+call fails with LV_E_HIP when no MI355X is visible.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_lib", "liblinevis_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "linevis_hip.h")
+
+LV_OK = 0
+MODE_PPLL = 2          # RENDERING_MODE_PER_PIXEL_LINKED_LIST, src/Renderers/RenderingModes.hpp:32-53
+MODE_RAY_TRACER = 11   # RENDERING_MODE_VULKAN_RAY_TRACER
+
+LINE_POINT_DTYPE = np.dtype([("linePosition", "<f4", 3), ("lineAttribute", "<f4"),
+                             ("lineTangent", "<f4", 3), ("lineRotation", "<f4"),
+                             ("lineNormal", "<f4", 3), ("lineStartIndex", "<u4")])
+assert LINE_POINT_DTYPE.itemsize == 48
+
+
+class Stats(C.Structure):
+    _fields_ = [("rays_traced", C.c_uint64), ("nodes_visited", C.c_uint64), ("prims_tested", C.c_uint64),
+                ("hits_shaded", C.c_uint64), ("fragments", C.c_uint64), ("ao_hit_pixels", C.c_uint64),
+                ("max_depth_complexity", C.c_uint32), ("bvh_depth", C.c_uint32), ("num_segments", C.c_uint32),
+                ("num_nodes", C.c_uint32),
+                ("ms_accel_build", C.c_float), ("ms_depth_range", C.c_float), ("ms_ao", C.c_float),
+                ("ms_color", C.c_float), ("ms_ppll_clear", C.c_float), ("ms_ppll_gather", C.c_float),
+                ("ms_ppll_resolve", C.c_float), ("ms_total", C.c_float), ("device_bytes", C.c_uint64)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class LineVisError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("linevis_hip error %d: %s" % (code, message))
+        self.code = code
+
+
+# every symbol include/linevis_hip.h declares (checked by tests/test_abi.py against the header text)
+SYMBOLS = ["lv_create", "lv_destroy", "lv_last_error", "lv_version", "lv_set_stream", "lv_set_lines",
+           "lv_set_transfer_function", "lv_set_camera", "lv_set_background", "lv_set_option", "lv_build_accel",
+           "lv_render", "lv_render_device", "lv_render_tiles_device", "lv_get_stats", "lv_trace_rays",
+           "lv_compute_depth_range", "lv_get_ao", "lv_ppll_get_buffers", "lv_ppll_resolve_buffers", "lv_get_accel"]
+
+_lib = None
+
+
+def load():
+    """Loads liblinevis_hip.so (built in-tree by linevis_amd/build.py); raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(hipcc, gfx950). There is no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, u32, u64, f32, i32, cp = C.c_void_p, C.c_uint32, C.c_uint64, C.c_float, C.c_int, C.c_char_p
+    L.lv_create.restype = vp
+    L.lv_create.argtypes = [i32, C.POINTER(i32)]
+    L.lv_destroy.restype = None
+    L.lv_destroy.argtypes = [vp]
+    L.lv_last_error.restype = cp
+    L.lv_last_error.argtypes = [vp]
+    L.lv_version.restype = cp
+    L.lv_version.argtypes = []
+    for name, args in [
+        ("lv_set_stream", [vp, vp]),
+        ("lv_set_lines", [vp, vp, u32, vp, u32]),
+        ("lv_set_transfer_function", [vp, vp, u32, f32, f32]),
+        ("lv_set_camera", [vp, vp, vp, f32, f32, f32, u32, u32]),
+        ("lv_set_background", [vp, vp]),
+        ("lv_set_option", [vp, cp, cp]),
+        ("lv_build_accel", [vp]),
+        ("lv_render", [vp, i32, u32, u32, u32, u32, vp]),
+        ("lv_render_device", [vp, i32, u32, u32, u32, u32, vp]),
+        ("lv_render_tiles_device", [vp, i32, vp, u32, u32, u32, vp]),
+        ("lv_get_stats", [vp, C.POINTER(Stats)]),
+        ("lv_trace_rays", [vp, vp, vp, f32, f32, u32, vp, vp, vp]),
+        ("lv_compute_depth_range", [vp, vp]),
+        ("lv_get_ao", [vp, vp]),
+        ("lv_ppll_get_buffers", [vp, vp, u64, vp, u64, C.POINTER(u32)]),
+        ("lv_ppll_resolve_buffers", [vp, vp, u64, vp, u64, u32, u32, u32, u32, vp]),
+        ("lv_get_accel", [vp, vp, u64, vp, u64]),
+    ]:
+        fn = getattr(L, name)
+        fn.restype = i32
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _fmt(v):
+    if isinstance(v, bool):
+        return "true" if v else "false"
+    if isinstance(v, (float, np.floating)):
+        return "%.9g" % float(v)  # round-trips float32
+    return str(v)
+
+
+class Context:
+    """One renderer context on one HIP device (thin OO veneer over the lv_* calls)."""
+
+    def __init__(self, device=0):
+        self.L = load()
+        err = C.c_int(0)
+        self.h = self.L.lv_create(int(device), C.byref(err))
+        if not self.h:
+            raise LineVisError(err.value, "lv_create(%d) failed: no usable HIP device (no CPU fallback)" % device)
+        self.width = self.height = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.lv_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != LV_OK:
+            raise LineVisError(rc, self.L.lv_last_error(self.h).decode("utf-8", "replace"))
+
+    def set_stream(self, stream_handle):
+        self._ck(self.L.lv_set_stream(self.h, C.c_void_p(stream_handle) if stream_handle else None))
+
+    def set_lines(self, points, seg_indices):
+        pts = np.ascontiguousarray(points, dtype=LINE_POINT_DTYPE)
+        seg = np.ascontiguousarray(seg_indices, dtype=np.uint32).reshape(-1, 2)
+        self._ck(self.L.lv_set_lines(self.h, _p(pts), len(pts), _p(seg), len(seg)))
+
+    def set_transfer_function(self, rgba, attr_min=0.0, attr_max=1.0):
+        tf = np.ascontiguousarray(rgba, dtype=np.float32).reshape(-1, 4)
+        self._ck(self.L.lv_set_transfer_function(self.h, _p(tf), tf.shape[0], attr_min, attr_max))
+
+    def set_camera(self, view, proj, fov_y, near, far, width, height):
+        v = np.ascontiguousarray(view, dtype=np.float32).reshape(16)
+        p = np.ascontiguousarray(proj, dtype=np.float32).reshape(16)
+        self._ck(self.L.lv_set_camera(self.h, _p(v), _p(p), fov_y, near, far, int(width), int(height)))
+        self.width, self.height = int(width), int(height)
+
+    def set_background(self, rgba):
+        b = np.ascontiguousarray(rgba, dtype=np.float32).reshape(4)
+        self._ck(self.L.lv_set_background(self.h, _p(b)))
+
+    def set_option(self, key, value):
+        self._ck(self.L.lv_set_option(self.h, key.encode(), _fmt(value).encode()))
+
+    def set_options(self, settings):
+        """LineRenderer::setNewSettings(const SettingsMap&): a dict of string keys."""
+        for k, v in settings.items():
+            self.set_option(k, v)
+
+    def build_accel(self):
+        self._ck(self.L.lv_build_accel(self.h))
+
+    def render(self, mode=MODE_RAY_TRACER, tile=None):
+        x0, y0, w, h = tile if tile is not None else (0, 0, self.width, self.height)
+        out = np.empty((h, w, 4), dtype=np.uint8)
+        self._ck(self.L.lv_render(self.h, mode, x0, y0, w, h, _p(out)))
+        return out
+
+    def render_device(self, out_ptr, mode=MODE_RAY_TRACER, tile=None):
+        x0, y0, w, h = tile if tile is not None else (0, 0, self.width, self.height)
+        self._ck(self.L.lv_render_device(self.h, mode, x0, y0, w, h, C.c_void_p(out_ptr)))
+
+    def render_tiles_device(self, out_ptr, tiles_xy, tile_w, tile_h, mode=MODE_RAY_TRACER):
+        t = np.ascontiguousarray(tiles_xy, dtype=np.uint32).reshape(-1, 2)
+        self._ck(self.L.lv_render_tiles_device(self.h, mode, _p(t), t.shape[0], tile_w, tile_h, C.c_void_p(out_ptr)))
+
+    def stats(self):
+        s = Stats()
+        self._ck(self.L.lv_get_stats(self.h, C.byref(s)))
+        return s
+
+    def trace_rays(self, origins, dirs, t_min, t_max):
+        o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(dirs, dtype=np.float32).reshape(-1, 3)
+        n = o.shape[0]
+        t = np.empty(n, dtype=np.float32)
+        seg = np.empty(n, dtype=np.uint32)
+        kind = np.empty(n, dtype=np.uint32)
+        self._ck(self.L.lv_trace_rays(self.h, _p(o), _p(d), t_min, t_max, n, _p(t), _p(seg), _p(kind)))
+        return t, seg, kind
+
+    def depth_range(self):
+        out = np.empty(2, dtype=np.float32)
+        self._ck(self.L.lv_compute_depth_range(self.h, _p(out)))
+        return out
+
+    def get_ao(self):
+        out = np.empty((self.height, self.width), dtype=np.float32)
+        self._ck(self.L.lv_get_ao(self.h, _p(out)))
+        return out
+
+    def ppll_buffers(self, padded_pixels, max_nodes):
+        nodes = np.zeros((max_nodes, 3), dtype=np.uint32)
+        start = np.zeros(padded_pixels, dtype=np.uint32)
+        cnt = C.c_uint32()
+        self._ck(self.L.lv_ppll_get_buffers(self.h, _p(nodes), max_nodes, _p(start), padded_pixels, C.byref(cnt)))
+        return nodes, start, cnt.value
+
+    def ppll_resolve(self, nodes, start_offset, tile=None):
+        x0, y0, w, h = tile if tile is not None else (0, 0, self.width, self.height)
+        n = np.ascontiguousarray(nodes, dtype=np.uint32).reshape(-1, 3)
+        s = np.ascontiguousarray(start_offset, dtype=np.uint32)
+        out = np.empty((h, w, 4), dtype=np.uint8)
+        self._ck(self.L.lv_ppll_resolve_buffers(self.h, _p(n), n.shape[0], _p(s), s.shape[0], x0, y0, w, h, _p(out)))
+        return out
+
+    def get_accel(self, num_nodes, num_leaves):
+        nodes = np.zeros((max(num_nodes, 1), 16), dtype=np.uint32)
+        leaf = np.zeros(max(num_leaves, 1), dtype=np.uint32)
+        self._ck(self.L.lv_get_accel(self.h, _p(nodes), nodes.shape[0], _p(leaf), leaf.shape[0]))
+        return nodes[:num_nodes], leaf[:num_leaves]

@@ -1,0 +1,484 @@
+// lv_api.hip -- extern "C" entry points of include/linevis_hip.h (context, settings, orchestration glue).
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+#include "lv_internal.h"
+
+int lv_fail(lv_ctx* ctx, int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->lastError = buf;
+    return code;
+}
+
+int lv_buf_reserve(lv_ctx* ctx, LvDeviceBuffer& b, size_t bytes) {
+    if (bytes == 0) bytes = 16;
+    if (b.ptr && b.bytes >= bytes) return LV_OK;
+    if (b.ptr) {
+        // the buffer may still be in use by work queued on the stream
+        LV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        (void)hipFree(b.ptr);
+        b.ptr = nullptr;
+        b.bytes = 0;
+    }
+    LV_HIP(ctx, hipMalloc(&b.ptr, bytes));
+    b.bytes = bytes;
+    return LV_OK;
+}
+
+void lv_buf_free(LvDeviceBuffer& b) {
+    if (b.ptr) (void)hipFree(b.ptr);
+    b.ptr = nullptr;
+    b.bytes = 0;
+}
+
+// 4x4 inverse by cofactor expansion (2x2 sub-determinants -> adjugate -> 1/det), the scheme of glm::inverse that
+// LineData::updateVulkanUniformBuffers applies (src/LineData/LineData.cpp:1290-1291).  Column-major.
+void lv_mat4_inverse(const float* m, float* inv) {
+    float c00 = m[10] * m[15] - m[14] * m[11];
+    float c02 = m[6] * m[15] - m[14] * m[7];
+    float c03 = m[6] * m[11] - m[10] * m[7];
+    float c04 = m[9] * m[15] - m[13] * m[11];
+    float c06 = m[5] * m[15] - m[13] * m[7];
+    float c07 = m[5] * m[11] - m[9] * m[7];
+    float c08 = m[9] * m[14] - m[13] * m[10];
+    float c10 = m[5] * m[14] - m[13] * m[6];
+    float c11 = m[5] * m[10] - m[9] * m[6];
+    float c12 = m[8] * m[15] - m[12] * m[11];
+    float c14 = m[4] * m[15] - m[12] * m[7];
+    float c15 = m[4] * m[11] - m[8] * m[7];
+    float c16 = m[8] * m[14] - m[12] * m[10];
+    float c18 = m[4] * m[14] - m[12] * m[6];
+    float c19 = m[4] * m[10] - m[8] * m[6];
+    float c20 = m[8] * m[13] - m[12] * m[9];
+    float c22 = m[4] * m[13] - m[12] * m[5];
+    float c23 = m[4] * m[9] - m[8] * m[5];
+
+    float i00 = +((m[5] * c00 - m[6] * c04) + m[7] * c08);
+    float i01 = -((m[1] * c00 - m[2] * c04) + m[3] * c08);
+    float i02 = +((m[1] * c02 - m[2] * c06) + m[3] * c10);
+    float i03 = -((m[1] * c03 - m[2] * c07) + m[3] * c11);
+    float i10 = -((m[4] * c00 - m[6] * c12) + m[7] * c16);
+    float i11 = +((m[0] * c00 - m[2] * c12) + m[3] * c16);
+    float i12 = -((m[0] * c02 - m[2] * c14) + m[3] * c18);
+    float i13 = +((m[0] * c03 - m[2] * c15) + m[3] * c19);
+    float i20 = +((m[4] * c04 - m[5] * c12) + m[7] * c20);
+    float i21 = -((m[0] * c04 - m[1] * c12) + m[3] * c20);
+    float i22 = +((m[0] * c06 - m[1] * c14) + m[3] * c22);
+    float i23 = -((m[0] * c07 - m[1] * c15) + m[3] * c23);
+    float i30 = -((m[4] * c08 - m[5] * c16) + m[6] * c20);
+    float i31 = +((m[0] * c08 - m[1] * c16) + m[2] * c20);
+    float i32 = -((m[0] * c10 - m[1] * c18) + m[2] * c22);
+    float i33 = +((m[0] * c11 - m[1] * c19) + m[2] * c23);
+
+    float det = ((m[0] * i00 + m[1] * i10) + m[2] * i20) + m[3] * i30;
+    float r = 1.0f / det;
+    inv[0] = i00 * r;  inv[1] = i01 * r;  inv[2] = i02 * r;  inv[3] = i03 * r;
+    inv[4] = i10 * r;  inv[5] = i11 * r;  inv[6] = i12 * r;  inv[7] = i13 * r;
+    inv[8] = i20 * r;  inv[9] = i21 * r;  inv[10] = i22 * r; inv[11] = i23 * r;
+    inv[12] = i30 * r; inv[13] = i31 * r; inv[14] = i32 * r; inv[15] = i33 * r;
+}
+
+namespace {
+
+struct LvDevCountersHost { // must match LvDevCounters in lv_render.hip
+    unsigned long long rays, nodes, prims, hits;
+    uint32_t fragCounter, aoCount, maxDepthComplexity, depthOrd[2], pad;
+};
+
+bool parseBool(const char* v) { return strcmp(v, "true") == 0 || strcmp(v, "1") == 0; } // InternalState.hpp:64-71
+
+bool parseFloat(const char* v, float& out) {
+    char* end = nullptr;
+    float f = strtof(v, &end);
+    if (end == v) return false;
+    out = f;
+    return true;
+}
+bool parseUint(const char* v, uint32_t& out) {
+    char* end = nullptr;
+    long long x = strtoll(v, &end, 10);
+    if (end == v || x < 0 || x > 0xFFFFFFFFll) return false;
+    out = uint32_t(x);
+    return true;
+}
+
+void updateAoMode(lv_ctx* ctx) {
+    // LineRenderer::setNewSettings, LineRenderer.cpp:462-488: AO is on iff a baker is set and strength > 0
+    ctx->opt.useAmbientOcclusion = ctx->opt.aoBakerIsRtao && ctx->opt.aoStrength > 0.0f;
+}
+
+} // namespace
+
+extern "C" {
+
+const char* lv_version(void) { return "linevis_hip 0.1 (gfx950)"; }
+
+lv_ctx* lv_create(int device_ordinal, int* err) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0 || device_ordinal < 0 || device_ordinal >= n) {
+        if (err) *err = LV_E_HIP;
+        return nullptr;
+    }
+    if (hipSetDevice(device_ordinal) != hipSuccess) {
+        if (err) *err = LV_E_HIP;
+        return nullptr;
+    }
+    lv_ctx* ctx = new lv_ctx();
+    ctx->device = device_ordinal;
+    memset(&ctx->stats, 0, sizeof(ctx->stats));
+    if (hipStreamCreateWithFlags(&ctx->ownStream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        if (err) *err = LV_E_HIP;
+        return nullptr;
+    }
+    ctx->stream = ctx->ownStream;
+    for (int i = 0; i < 16; i++) {
+        if (hipEventCreate(&ctx->ev[i]) != hipSuccess) {
+            if (err) *err = LV_E_HIP;
+            (void)hipStreamDestroy(ctx->ownStream);
+            delete ctx;
+            return nullptr;
+        }
+    }
+    ctx->evCreated = true;
+    if (err) *err = LV_OK;
+    return ctx;
+}
+
+void lv_destroy(lv_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (LvDeviceBuffer* b : {&ctx->points, &ctx->segIdx, &ctx->nodes, &ctx->segs, &ctx->leafSeg, &ctx->tf,
+                              &ctx->depthMinMax, &ctx->ao, &ctx->aoGbuf, &ctx->aoList, &ctx->aoSamples, &ctx->counters,
+                              &ctx->ppllNodes, &ctx->ppllStart, &ctx->ppllScratch, &ctx->tilesDev, &ctx->outDev,
+                              &ctx->scratchRays})
+        lv_buf_free(*b);
+    if (ctx->evCreated)
+        for (int i = 0; i < 16; i++) (void)hipEventDestroy(ctx->ev[i]);
+    if (ctx->ownStream) (void)hipStreamDestroy(ctx->ownStream);
+    delete ctx;
+}
+
+const char* lv_last_error(const lv_ctx* ctx) { return ctx ? ctx->lastError.c_str() : "null context"; }
+
+int lv_set_stream(lv_ctx* ctx, void* hip_stream) {
+    if (!ctx) return LV_E_INVALID;
+    (void)hipSetDevice(ctx->device);
+    LV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->ownStream;
+    ctx->evBuildValid = false;
+    ctx->evFrameValid = false;
+    return LV_OK;
+}
+
+int lv_set_lines(lv_ctx* ctx, const lv_line_point* points, uint32_t num_points, const uint32_t* seg, uint32_t num_segments) {
+    if (!ctx) return LV_E_INVALID;
+    if ((num_points && !points) || (num_segments && !seg)) return lv_fail(ctx, LV_E_INVALID, "null input array");
+    if (num_segments >= 0x7FFFFFFFu) return lv_fail(ctx, LV_E_CAPACITY, "at most 2^31-2 segments");
+    for (uint64_t i = 0; i < 2ull * num_segments; i++)
+        if (seg[i] >= num_points)
+            return lv_fail(ctx, LV_E_INVALID, "segment %llu references point %u >= num_points %u",
+                           (unsigned long long)(i / 2), seg[i], num_points);
+    (void)hipSetDevice(ctx->device);
+    int rc;
+    if ((rc = lv_buf_reserve(ctx, ctx->points, size_t(num_points) * sizeof(lv_line_point)))) return rc;
+    if ((rc = lv_buf_reserve(ctx, ctx->segIdx, size_t(num_segments) * 8))) return rc;
+    if (num_points)
+        LV_HIP(ctx, hipMemcpyAsync(ctx->points.ptr, points, size_t(num_points) * sizeof(lv_line_point),
+                                   hipMemcpyHostToDevice, ctx->stream));
+    if (num_segments)
+        LV_HIP(ctx, hipMemcpyAsync(ctx->segIdx.ptr, seg, size_t(num_segments) * 8, hipMemcpyHostToDevice, ctx->stream));
+    LV_HIP(ctx, hipStreamSynchronize(ctx->stream)); // host arrays are borrowed for the call only
+    ctx->numPoints = num_points;
+    ctx->numSegs = num_segments;
+    ctx->accelValid = false;
+    return LV_OK;
+}
+
+int lv_set_transfer_function(lv_ctx* ctx, const float* rgba, uint32_t n, float attr_min, float attr_max) {
+    if (!ctx) return LV_E_INVALID;
+    if (!rgba || n == 0) return lv_fail(ctx, LV_E_INVALID, "empty transfer function");
+    (void)hipSetDevice(ctx->device);
+    int rc;
+    if ((rc = lv_buf_reserve(ctx, ctx->tf, size_t(n) * 16))) return rc;
+    LV_HIP(ctx, hipMemcpyAsync(ctx->tf.ptr, rgba, size_t(n) * 16, hipMemcpyHostToDevice, ctx->stream));
+    LV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->tfN = n;
+    ctx->attrMin = attr_min;
+    ctx->attrMax = attr_max;
+    return LV_OK;
+}
+
+int lv_set_camera(lv_ctx* ctx, const float view[16], const float proj[16], float fov_y, float near_dist, float far_dist,
+                  uint32_t w, uint32_t h) {
+    if (!ctx) return LV_E_INVALID;
+    if (!view || !proj || w == 0 || h == 0) return lv_fail(ctx, LV_E_INVALID, "invalid camera / viewport");
+    memcpy(ctx->view, view, 64);
+    memcpy(ctx->proj, proj, 64);
+    lv_mat4_inverse(ctx->view, ctx->invView);
+    lv_mat4_inverse(ctx->proj, ctx->invProj);
+    ctx->fovY = fov_y;
+    ctx->nearDist = near_dist;
+    ctx->farDist = far_dist;
+    ctx->width = w;
+    ctx->height = h;
+    ctx->cameraSet = true;
+    return LV_OK;
+}
+
+int lv_set_background(lv_ctx* ctx, const float rgba[4]) {
+    if (!ctx || !rgba) return LV_E_INVALID;
+    memcpy(ctx->background, rgba, 16);
+    return LV_OK;
+}
+
+int lv_set_option(lv_ctx* ctx, const char* key, const char* value) {
+    if (!ctx) return LV_E_INVALID;
+    if (!key || !value) return lv_fail(ctx, LV_E_INVALID, "null key/value");
+    LvOptions& o = ctx->opt;
+    auto bad = [&]() { return lv_fail(ctx, LV_E_INVALID, "invalid value '%s' for option '%s'", value, key); };
+    std::string k(key);
+    float f;
+    uint32_t u;
+    if (k == "line_width") {
+        if (!parseFloat(value, f) || !(f > 0.0f)) return bad();
+        o.lineWidth = f; // accel rebuilt lazily (setTriangleRepresentationDirty, LineRenderer.cpp:436-441)
+    } else if (k == "depth_cue_strength") {
+        if (!parseFloat(value, f)) return bad();
+        o.depthCueStrength = f;
+    } else if (k == "ambient_occlusion_mode") {
+        // AMBIENT_OCCLUSION_BAKER_TYPE_NAMES, AmbientOcclusionBaker.hpp:78-95
+        if (strcmp(value, "RTAO (Screen Space)") == 0) o.aoBakerIsRtao = true;
+        else if (strcmp(value, "None") == 0) o.aoBakerIsRtao = false;
+        else return lv_fail(ctx, LV_E_INVALID, "ambient_occlusion_mode '%s' is not on the hot path (None | RTAO (Screen Space))", value);
+        updateAoMode(ctx);
+    } else if (k == "ambient_occlusion_strength") {
+        if (!parseFloat(value, f)) return bad();
+        o.aoStrength = f;
+        updateAoMode(ctx);
+    } else if (k == "ambient_occlusion_gamma") {
+        if (!parseFloat(value, f)) return bad();
+        o.aoGamma = f;
+    } else if (k == "ambient_occlusion_iterations") {
+        if (!parseUint(value, u) || u == 0) return bad();
+        o.aoIterations = u;
+    } else if (k == "ambient_occlusion_samples_per_frame") {
+        if (!parseUint(value, u) || u == 0) return bad();
+        o.aoSamplesPerFrame = u;
+    } else if (k == "ambient_occlusion_radius") {
+        if (!parseFloat(value, f) || !(f > 0.0f)) return bad();
+        o.aoRadius = f;
+    } else if (k == "ambient_occlusion_distance_based") {
+        o.aoUseDistance = parseBool(value);
+    } else if (k == "use_jittered_primary_rays") {
+        o.aoJitterPrimary = parseBool(value);
+    } else if (k == "ambient_occlusion_denoiser") {
+        if (strcmp(value, "None") != 0) return lv_fail(ctx, LV_E_INVALID, "denoisers are out of scope (None only)");
+    } else if (k == "num_samples_per_frame") {
+        if (!parseUint(value, u) || u == 0) return bad();
+        o.numSamplesPerFrame = u;
+    } else if (k == "num_accumulated_frames") {
+        if (!parseUint(value, u) || u != 1)
+            return lv_fail(ctx, LV_E_INVALID, "num_accumulated_frames must be 1: offline frames use num_samples_per_frame "
+                                              "(the reference's multi-frame mean round-trips through RGBA8)");
+    } else if (k == "use_deterministic_sampling") {
+        o.useDeterministicSampling = parseBool(value);
+    } else if (k == "use_analytic_intersections") {
+        if (!parseBool(value)) return lv_fail(ctx, LV_E_INVALID, "only analytic capsule intersections are implemented");
+    } else if (k == "geometry_mode") {
+        if (strcmp(value, "AABBs") != 0 && strcmp(value, "Analytic") != 0)
+            return lv_fail(ctx, LV_E_INVALID, "geometry_mode '%s' is not on the hot path (AABBs only)", value);
+    } else if (k == "use_mlat") {
+        if (parseBool(value)) return lv_fail(ctx, LV_E_INVALID, "MLAT is not implemented yet (SURVEY.md §8f)");
+    } else if (k == "max_depth_complexity") {
+        if (!parseUint(value, u) || u == 0) return bad();
+        o.maxDepthComplexity = u;
+    } else if (k == "use_capped_tubes") {
+        o.useCappedTubes = parseBool(value);
+    } else if (k == "use_halos") {
+        o.useHalos = parseBool(value);
+    } else if (k == "tube_num_subdivisions") {
+        if (!parseUint(value, u) || u < 3) return bad();
+        o.tubeNumSubdivisions = u;
+    } else if (k == "ppll_max_num_frags") {
+        if (!parseUint(value, u)) return bad();
+        o.ppllMaxNumFrags = u;
+    } else if (k == "ppll_expected_avg_depth_complexity") {
+        if (!parseUint(value, u)) return bad();
+        o.ppllExpectedAvgDepthComplexity = u;
+    } else if (k == "ppll_tile_width" || k == "ppll_tile_height") {
+        if (!parseUint(value, u) || u == 0 || (u & (u - 1)) != 0) return bad(); // power of two (TiledAddress.glsl uses &)
+        (k == "ppll_tile_width" ? o.ppllTileW : o.ppllTileH) = u;
+    } else if (k == "collect_stats") {
+        o.collectStats = parseBool(value);
+    } else {
+        return lv_fail(ctx, LV_E_INVALID, "unknown option '%s'", key);
+    }
+    return LV_OK;
+}
+
+int lv_build_accel(lv_ctx* ctx) {
+    if (!ctx) return LV_E_INVALID;
+    (void)hipSetDevice(ctx->device);
+    return lv_bvh_build(ctx);
+}
+
+int lv_render_tiles_device(lv_ctx* ctx, int mode, const uint32_t* tiles_xy, uint32_t num_tiles, uint32_t tile_w,
+                           uint32_t tile_h, void* out) {
+    if (!ctx) return LV_E_INVALID;
+    if (!tiles_xy || !out) return lv_fail(ctx, LV_E_INVALID, "null tile list / output");
+    (void)hipSetDevice(ctx->device);
+    return lv_frame_render(ctx, mode, tiles_xy, num_tiles, tile_w, tile_h, out);
+}
+
+int lv_render_device(lv_ctx* ctx, int mode, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, void* out) {
+    uint32_t xy[2] = {x0, y0};
+    return lv_render_tiles_device(ctx, mode, xy, 1, w, h, out);
+}
+
+int lv_render(lv_ctx* ctx, int mode, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, uint8_t* out) {
+    if (!ctx) return LV_E_INVALID;
+    if (!out || w == 0 || h == 0) return lv_fail(ctx, LV_E_INVALID, "null output / empty rectangle");
+    (void)hipSetDevice(ctx->device);
+    int rc;
+    if ((rc = lv_buf_reserve(ctx, ctx->outDev, size_t(w) * h * 4))) return rc;
+    if ((rc = lv_render_device(ctx, mode, x0, y0, w, h, ctx->outDev.ptr))) return rc;
+    LV_HIP(ctx, hipMemcpyAsync(out, ctx->outDev.ptr, size_t(w) * h * 4, hipMemcpyDeviceToHost, ctx->stream));
+    LV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return LV_OK;
+}
+
+int lv_get_stats(lv_ctx* ctx, lv_stats* out) {
+    if (!ctx || !out) return LV_E_INVALID;
+    (void)hipSetDevice(ctx->device);
+    LV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    lv_stats& s = ctx->stats;
+    s.bvh_depth = ctx->bvhDepth;
+    s.num_segments = ctx->numSegs;
+    s.num_nodes = ctx->numNodes;
+    auto ms = [&](int a, int b) {
+        float t = 0.0f;
+        if (hipEventElapsedTime(&t, ctx->ev[a], ctx->ev[b]) != hipSuccess) t = 0.0f;
+        return t;
+    };
+    if (ctx->evBuildValid) s.ms_accel_build = ms(0, 1);
+    if (ctx->evFrameValid) {
+        s.ms_total = ms(2, 3);
+        s.ms_depth_range = ms(4, 5);
+        s.ms_ao = ms(6, 7);
+        s.ms_color = s.ms_ppll_clear = s.ms_ppll_gather = s.ms_ppll_resolve = 0.0f;
+        if (ctx->lastMode == LV_RENDERING_MODE_VULKAN_RAY_TRACER) s.ms_color = ms(8, 9);
+        else { s.ms_ppll_clear = ms(10, 11); s.ms_ppll_gather = ms(12, 13); s.ms_ppll_resolve = ms(14, 15); }
+        LvDevCountersHost hc;
+        memset(&hc, 0, sizeof(hc));
+        if (ctx->counters.ptr) {
+            LV_HIP(ctx, hipMemcpy(&hc, ctx->counters.ptr, sizeof(hc), hipMemcpyDeviceToHost));
+        }
+        s.rays_traced = hc.rays;
+        s.nodes_visited = hc.nodes;
+        s.prims_tested = hc.prims;
+        s.hits_shaded = hc.hits;
+        s.fragments = hc.fragCounter;
+        s.ao_hit_pixels = hc.aoCount;
+        s.max_depth_complexity = hc.maxDepthComplexity;
+    }
+    uint64_t bytes = 0;
+    for (const LvDeviceBuffer* b : {&ctx->points, &ctx->segIdx, &ctx->nodes, &ctx->segs, &ctx->leafSeg, &ctx->tf,
+                                    &ctx->depthMinMax, &ctx->ao, &ctx->aoGbuf, &ctx->aoList, &ctx->aoSamples,
+                                    &ctx->counters, &ctx->ppllNodes, &ctx->ppllStart, &ctx->ppllScratch, &ctx->tilesDev,
+                                    &ctx->outDev, &ctx->scratchRays})
+        bytes += b->bytes;
+    s.device_bytes = bytes;
+    *out = s;
+    return LV_OK;
+}
+
+int lv_trace_rays(lv_ctx* ctx, const float* origins, const float* dirs, float t_min, float t_max, uint32_t n, float* out_t,
+                  uint32_t* out_segment, uint32_t* out_kind) {
+    if (!ctx) return LV_E_INVALID;
+    if (n && (!origins || !dirs || !out_t || !out_segment || !out_kind)) return lv_fail(ctx, LV_E_INVALID, "null array");
+    if (!ctx->points.ptr && ctx->numSegs == 0 && !ctx->accelValid && !ctx->segIdx.ptr)
+        return lv_fail(ctx, LV_E_STATE, "lv_set_lines has not been called");
+    (void)hipSetDevice(ctx->device);
+    return lv_frame_trace_rays(ctx, origins, dirs, t_min, t_max, n, out_t, out_segment, out_kind);
+}
+
+int lv_compute_depth_range(lv_ctx* ctx, float out_min_max[2]) {
+    if (!ctx || !out_min_max) return LV_E_INVALID;
+    if (!ctx->cameraSet) return lv_fail(ctx, LV_E_STATE, "lv_set_camera has not been called");
+    (void)hipSetDevice(ctx->device);
+    int rc;
+    if ((rc = lv_frame_depth_range(ctx))) return rc;
+    LV_HIP(ctx, hipMemcpyAsync(out_min_max, ctx->depthMinMax.ptr, 8, hipMemcpyDeviceToHost, ctx->stream));
+    LV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return LV_OK;
+}
+
+int lv_get_ao(lv_ctx* ctx, float* out) {
+    if (!ctx || !out) return LV_E_INVALID;
+    if (!ctx->ao.ptr || !ctx->cameraSet) return lv_fail(ctx, LV_E_STATE, "no AO texture (render with RTAO first)");
+    (void)hipSetDevice(ctx->device);
+    LV_HIP(ctx, hipMemcpyAsync(out, ctx->ao.ptr, size_t(ctx->width) * ctx->height * 4, hipMemcpyDeviceToHost, ctx->stream));
+    LV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return LV_OK;
+}
+
+int lv_ppll_get_buffers(lv_ctx* ctx, uint32_t* out_nodes, uint64_t max_nodes, uint32_t* out_start, uint64_t max_pixels,
+                        uint32_t* out_frag_counter) {
+    if (!ctx) return LV_E_INVALID;
+    if (!ctx->ppllNodes.ptr || !ctx->ppllStart.ptr || ctx->lastMode != LV_RENDERING_MODE_PER_PIXEL_LINKED_LIST)
+        return lv_fail(ctx, LV_E_STATE, "no PPLL buffers (render mode 2 first)");
+    (void)hipSetDevice(ctx->device);
+    LV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    LvDevCountersHost hc;
+    LV_HIP(ctx, hipMemcpy(&hc, ctx->counters.ptr, sizeof(hc), hipMemcpyDeviceToHost));
+    if (out_frag_counter) *out_frag_counter = hc.fragCounter;
+    uint64_t stored = hc.fragCounter < ctx->ppllPoolNodes ? hc.fragCounter : ctx->ppllPoolNodes;
+    if (out_nodes) {
+        if (max_nodes < stored) return lv_fail(ctx, LV_E_CAPACITY, "out_nodes holds %llu nodes, %llu stored",
+                                               (unsigned long long)max_nodes, (unsigned long long)stored);
+        if (stored) LV_HIP(ctx, hipMemcpy(out_nodes, ctx->ppllNodes.ptr, size_t(stored) * 12, hipMemcpyDeviceToHost));
+    }
+    if (out_start) {
+        LvUniforms U;
+        lv_fill_uniforms(ctx, U);
+        uint64_t np = uint64_t(U.ppllPaddedW) * U.ppllPaddedH;
+        if (max_pixels < np) return lv_fail(ctx, LV_E_CAPACITY, "out_start_offset holds %llu entries, need %llu",
+                                            (unsigned long long)max_pixels, (unsigned long long)np);
+        LV_HIP(ctx, hipMemcpy(out_start, ctx->ppllStart.ptr, size_t(np) * 4, hipMemcpyDeviceToHost));
+    }
+    return LV_OK;
+}
+
+int lv_ppll_resolve_buffers(lv_ctx* ctx, const uint32_t* nodes, uint64_t num_nodes, const uint32_t* start_offset,
+                            uint64_t num_pixels, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, uint8_t* out) {
+    if (!ctx) return LV_E_INVALID;
+    if ((num_nodes && !nodes) || !start_offset || !out || w == 0 || h == 0) return lv_fail(ctx, LV_E_INVALID, "null array");
+    (void)hipSetDevice(ctx->device);
+    return lv_frame_ppll_resolve_only(ctx, nodes, num_nodes, start_offset, num_pixels, x0, y0, w, h, out);
+}
+
+int lv_get_accel(lv_ctx* ctx, void* out_nodes, uint64_t max_nodes, uint32_t* out_leaf_segment, uint64_t max_leaves) {
+    if (!ctx) return LV_E_INVALID;
+    if (!ctx->accelValid) return lv_fail(ctx, LV_E_STATE, "no acceleration structure (lv_build_accel first)");
+    (void)hipSetDevice(ctx->device);
+    LV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (out_nodes) {
+        if (max_nodes < ctx->numNodes) return lv_fail(ctx, LV_E_CAPACITY, "out_nodes too small");
+        if (ctx->numNodes) LV_HIP(ctx, hipMemcpy(out_nodes, ctx->nodes.ptr, size_t(ctx->numNodes) * 64, hipMemcpyDeviceToHost));
+    }
+    if (out_leaf_segment) {
+        if (max_leaves < ctx->numSegs) return lv_fail(ctx, LV_E_CAPACITY, "out_leaf_segment too small");
+        if (ctx->numSegs) LV_HIP(ctx, hipMemcpy(out_leaf_segment, ctx->leafSeg.ptr, size_t(ctx->numSegs) * 4, hipMemcpyDeviceToHost));
+    }
+    return LV_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,333 @@
+// lv_bvh.hip -- GPU LBVH build over line-segment capsules.
+//
+// Replaces the driver-side acceleration-structure build of the reference:
+//   LineData::getTubeAabbBottomLevelAS      src/LineData/LineData.cpp:879-907
+//   LineData::getRayTracingTubeAabbTopLevelAS  src/LineData/LineData.cpp:1057-1075
+// over the per-segment AABBs min(p0,p1)-r .. max(p0,p1)+r of LineDataFlow.cpp:2223-2234.
+//
+// Pipeline (all on the context's stream):
+//   k_seg_boxes   segment AABBs (+ conservative pad) and scene bounds (wave reduce + 6 atomics per wave)
+//   k_morton      63-bit Morton keys of box centroids
+//   radix sort    rocprim::radix_sort_pairs (key, segment)
+//   k_leaves      32-byte segment records + leaf boxes written in Morton order
+//   k_karras      Karras 2012 topology: one thread per internal node
+//   k_refit       bottom-up AABB + height, second arriver continues (agent-scope release/acquire)
+//   k_pack        64-byte nodes holding both child boxes + child references
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "lv_internal.h"
+
+namespace {
+
+__global__ __launch_bounds__(LV_BLOCK) void k_seg_boxes(const lv_line_point* __restrict__ points,
+                                                        const uint32_t* __restrict__ segIdx, uint32_t nSeg, float radius,
+                                                        float pad, float* __restrict__ boxOrig,
+                                                        uint32_t* __restrict__ boundsOrd) {
+    uint32_t s = blockIdx.x * LV_BLOCK + threadIdx.x;
+    float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    if (s < nSeg) {
+        const float* p0 = points[segIdx[2 * s]].linePosition;
+        const float* p1 = points[segIdx[2 * s + 1]].linePosition;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            mn[k] = (fminf(p0[k], p1[k]) - radius) - pad;
+            mx[k] = (fmaxf(p0[k], p1[k]) + radius) + pad;
+            boxOrig[6 * size_t(s) + k] = mn[k];
+            boxOrig[6 * size_t(s) + 3 + k] = mx[k];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        float a = lv_wave_min(mn[k]), b = lv_wave_max(mx[k]);
+        if (lv_lane() == 0) {
+            atomicMin(&boundsOrd[k], lv_f2ord(a));
+            atomicMax(&boundsOrd[3 + k], lv_f2ord(b));
+        }
+    }
+}
+
+__device__ __forceinline__ uint64_t expandBits21(uint64_t v) {
+    v &= 0x1fffffull;
+    v = (v | v << 32) & 0x1f00000000ffffull;
+    v = (v | v << 16) & 0x1f0000ff0000ffull;
+    v = (v | v << 8) & 0x100f00f00f00f00full;
+    v = (v | v << 4) & 0x10c30c30c30c30c3ull;
+    v = (v | v << 2) & 0x1249249249249249ull;
+    return v;
+}
+
+__global__ __launch_bounds__(LV_BLOCK) void k_morton(const float* __restrict__ boxOrig, uint32_t nSeg,
+                                                     const uint32_t* __restrict__ boundsOrd,
+                                                     uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+    uint32_t s = blockIdx.x * LV_BLOCK + threadIdx.x;
+    if (s >= nSeg) return;
+    uint64_t q[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        float smin = lv_ord2f(boundsOrd[k]), smax = lv_ord2f(boundsOrd[3 + k]);
+        float c = 0.5f * (boxOrig[6 * size_t(s) + k] + boxOrig[6 * size_t(s) + 3 + k]);
+        float u = (c - smin) / fmaxf(smax - smin, 1e-30f);
+        u = fminf(fmaxf(u, 0.0f), 1.0f);
+        q[k] = uint64_t(fminf(2097151.0f, u * 2097152.0f));
+    }
+    keys[s] = (expandBits21(q[0]) << 2) | (expandBits21(q[1]) << 1) | expandBits21(q[2]);
+    vals[s] = s;
+}
+
+__global__ __launch_bounds__(LV_BLOCK) void k_leaves(const lv_line_point* __restrict__ points,
+                                                     const uint32_t* __restrict__ segIdx, const float* __restrict__ boxOrig,
+                                                     const uint32_t* __restrict__ sortedVals, uint32_t nSeg,
+                                                     float4* __restrict__ segs, uint32_t* __restrict__ leafSeg,
+                                                     float* __restrict__ leafBox) {
+    uint32_t i = blockIdx.x * LV_BLOCK + threadIdx.x;
+    if (i >= nSeg) return;
+    uint32_t s = sortedVals[i];
+    const lv_line_point& a = points[segIdx[2 * s]];
+    const lv_line_point& b = points[segIdx[2 * s + 1]];
+    segs[2 * size_t(i)] = make_float4(a.linePosition[0], a.linePosition[1], a.linePosition[2], a.lineAttribute);
+    segs[2 * size_t(i) + 1] = make_float4(b.linePosition[0], b.linePosition[1], b.linePosition[2], b.lineAttribute);
+    leafSeg[i] = s;
+#pragma unroll
+    for (int k = 0; k < 6; k++) leafBox[6 * size_t(i) + k] = boxOrig[6 * size_t(s) + k];
+}
+
+__device__ __forceinline__ int lv_delta(const uint64_t* __restrict__ keys, int n, int i, int j) {
+    if (j < 0 || j >= n) return -1;
+    uint64_t a = keys[i], b = keys[j];
+    if (a == b) return 64 + __clz(uint32_t(i) ^ uint32_t(j));
+    return __clzll((long long)(a ^ b));
+}
+
+// Karras, "Maximizing Parallelism in the Construction of BVHs, Octrees, and k-d Trees", HPG 2012.
+// Internal nodes 0..n-2 (root = 0); child reference = index | LEAF_BIT for leaves.
+__global__ __launch_bounds__(LV_BLOCK) void k_karras(const uint64_t* __restrict__ keys, int n, uint32_t* __restrict__ childL,
+                                                     uint32_t* __restrict__ childR, uint32_t* __restrict__ parentInternal,
+                                                     uint32_t* __restrict__ parentLeaf) {
+    int i = blockIdx.x * LV_BLOCK + threadIdx.x;
+    if (i >= n - 1) return;
+    int d = (lv_delta(keys, n, i, i + 1) - lv_delta(keys, n, i, i - 1)) >= 0 ? 1 : -1;
+    int dmin = lv_delta(keys, n, i, i - d);
+    int lmax = 2;
+    while (lv_delta(keys, n, i, i + lmax * d) > dmin) lmax *= 2;
+    int l = 0;
+    for (int t = lmax / 2; t >= 1; t /= 2)
+        if (lv_delta(keys, n, i, i + (l + t) * d) > dmin) l += t;
+    int j = i + l * d;
+    int dnode = lv_delta(keys, n, i, j);
+    int s = 0;
+    int t = l;
+    do {
+        t = (t + 1) / 2;
+        if (lv_delta(keys, n, i, i + (s + t) * d) > dnode) s += t;
+    } while (t > 1);
+    int gamma = i + s * d + min(d, 0);
+    int lo = min(i, j), hi = max(i, j);
+    uint32_t left, right;
+    if (lo == gamma) { left = uint32_t(gamma) | LV_LEAF_BIT; parentLeaf[gamma] = uint32_t(i); }
+    else { left = uint32_t(gamma); parentInternal[gamma] = uint32_t(i); }
+    if (hi == gamma + 1) { right = uint32_t(gamma + 1) | LV_LEAF_BIT; parentLeaf[gamma + 1] = uint32_t(i); }
+    else { right = uint32_t(gamma + 1); parentInternal[gamma + 1] = uint32_t(i); }
+    childL[i] = left;
+    childR[i] = right;
+    if (i == 0) parentInternal[0] = LV_INVALID;
+}
+
+__device__ __forceinline__ void lv_child_box(uint32_t c, const float* __restrict__ leafBox, const float* nodeBox,
+                                             const uint32_t* height, float b[6], uint32_t& hgt) {
+    // plain loads: callers issue an agent-scope acquire first
+    if (c & LV_LEAF_BIT) {
+        const float* p = leafBox + 6 * size_t(c & ~LV_LEAF_BIT);
+#pragma unroll
+        for (int k = 0; k < 6; k++) b[k] = p[k];
+        hgt = 0;
+    } else {
+        const float* p = nodeBox + 6 * size_t(c);
+#pragma unroll
+        for (int k = 0; k < 6; k++) b[k] = p[k];
+        hgt = height[c];
+    }
+}
+
+// One thread per leaf walks towards the root; the first thread to reach a node stops, the second one (which
+// finds flag == 1) owns it.  Cross-CU visibility: per-CU L1s are never refreshed by other CUs' stores and the
+// per-XCD L2s are not coherent, so the producer publishes with an agent-scope release before the counter RMW and
+// the consumer invalidates with an agent-scope acquire after it (cdna_hip_programming.md §6 Guideline 16).
+__global__ __launch_bounds__(LV_BLOCK) void k_refit(int n, const uint32_t* __restrict__ childL,
+                                                    const uint32_t* __restrict__ childR,
+                                                    const uint32_t* __restrict__ parentInternal,
+                                                    const uint32_t* __restrict__ parentLeaf,
+                                                    const float* __restrict__ leafBox, float* nodeBox, uint32_t* height,
+                                                    uint32_t* flags) {
+    int i = blockIdx.x * LV_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    uint32_t p = parentLeaf[i];
+    while (p != LV_INVALID) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        uint32_t old = __hip_atomic_fetch_add(&flags[p], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == 0) return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        float a[6], b[6];
+        uint32_t ha, hb;
+        lv_child_box(childL[p], leafBox, nodeBox, height, a, ha);
+        lv_child_box(childR[p], leafBox, nodeBox, height, b, hb);
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            nodeBox[6 * size_t(p) + k] = fminf(a[k], b[k]);
+            nodeBox[6 * size_t(p) + 3 + k] = fmaxf(a[k + 3], b[k + 3]);
+        }
+        height[p] = max(ha, hb) + 1;
+        p = parentInternal[p];
+    }
+}
+
+// 64-byte node: q0 = {c0.min.xyz, c0.max.x}, q1 = {c0.max.yz, c1.min.xy}, q2 = {c1.min.z, c1.max.xyz},
+//               q3 = {child0, child1, height, 0} (uint bits)
+__global__ __launch_bounds__(LV_BLOCK) void k_pack(int nInternal, const uint32_t* __restrict__ childL,
+                                                   const uint32_t* __restrict__ childR, const float* __restrict__ leafBox,
+                                                   const float* __restrict__ nodeBox, const uint32_t* __restrict__ height,
+                                                   float4* __restrict__ nodes) {
+    int i = blockIdx.x * LV_BLOCK + threadIdx.x;
+    if (i >= nInternal) return;
+    uint32_t c0 = childL[i], c1 = childR[i];
+    const float* a = (c0 & LV_LEAF_BIT) ? leafBox + 6 * size_t(c0 & ~LV_LEAF_BIT) : nodeBox + 6 * size_t(c0);
+    const float* b = (c1 & LV_LEAF_BIT) ? leafBox + 6 * size_t(c1 & ~LV_LEAF_BIT) : nodeBox + 6 * size_t(c1);
+    nodes[4 * size_t(i) + 0] = make_float4(a[0], a[1], a[2], a[3]);
+    nodes[4 * size_t(i) + 1] = make_float4(a[4], a[5], b[0], b[1]);
+    nodes[4 * size_t(i) + 2] = make_float4(b[2], b[3], b[4], b[5]);
+    nodes[4 * size_t(i) + 3] = make_float4(__uint_as_float(c0), __uint_as_float(c1), __uint_as_float(height[i]), 0.0f);
+}
+
+// single-segment scene: one node whose second child is invalid
+__global__ void k_single_node(const float* __restrict__ leafBox, float4* __restrict__ nodes) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    nodes[0] = make_float4(leafBox[0], leafBox[1], leafBox[2], leafBox[3]);
+    nodes[1] = make_float4(leafBox[4], leafBox[5], 0.0f, 0.0f);
+    nodes[2] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    nodes[3] = make_float4(__uint_as_float(0u | LV_LEAF_BIT), __uint_as_float(LV_INVALID), __uint_as_float(1u), 0.0f);
+}
+
+inline uint32_t nblocks(uint64_t n) { return uint32_t((n + LV_BLOCK - 1) / LV_BLOCK); }
+
+} // namespace
+
+int lv_bvh_build(lv_ctx* ctx) {
+    const uint32_t n = ctx->numSegs;
+    hipStream_t st = ctx->stream;
+    ctx->accelValid = false;
+    ctx->bvhDepth = 0;
+    ctx->numNodes = 0;
+    if (n == 0) {
+        ctx->accelValid = true;
+        ctx->accelLineWidth = ctx->opt.lineWidth;
+        return LV_OK;
+    }
+    const float radius = ctx->opt.lineWidth * 0.5f;
+    const float pad = radius * 1e-3f + 1e-6f;
+    const uint32_t nInternal = n > 1 ? n - 1 : 1;
+
+    int rc;
+    if ((rc = lv_buf_reserve(ctx, ctx->nodes, size_t(nInternal) * 64))) return rc;
+    if ((rc = lv_buf_reserve(ctx, ctx->segs, size_t(n) * 32))) return rc;
+    if ((rc = lv_buf_reserve(ctx, ctx->leafSeg, size_t(n) * 4))) return rc;
+
+    // temporaries
+    LvDeviceBuffer boxOrig, leafBox, nodeBox, keysA, keysB, valsA, valsB, childL, childR, parI, parL, height, flags, bounds,
+            sortTmp;
+    auto freeAll = [&]() {
+        for (LvDeviceBuffer* b : {&boxOrig, &leafBox, &nodeBox, &keysA, &keysB, &valsA, &valsB, &childL, &childR, &parI,
+                                  &parL, &height, &flags, &bounds, &sortTmp})
+            lv_buf_free(*b);
+    };
+#define LV_TRY(expr)                 \
+    do {                             \
+        int _rc = (expr);            \
+        if (_rc) { freeAll(); return _rc; } \
+    } while (0)
+#define LV_HIPF(expr)                                                                                     \
+    do {                                                                                                  \
+        hipError_t _e = (expr);                                                                           \
+        if (_e != hipSuccess) {                                                                           \
+            freeAll();                                                                                    \
+            return lv_fail(ctx, LV_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+        }                                                                                                 \
+    } while (0)
+
+    LV_TRY(lv_buf_reserve(ctx, boxOrig, size_t(n) * 24));
+    LV_TRY(lv_buf_reserve(ctx, leafBox, size_t(n) * 24));
+    LV_TRY(lv_buf_reserve(ctx, nodeBox, size_t(nInternal) * 24));
+    LV_TRY(lv_buf_reserve(ctx, keysA, size_t(n) * 8));
+    LV_TRY(lv_buf_reserve(ctx, keysB, size_t(n) * 8));
+    LV_TRY(lv_buf_reserve(ctx, valsA, size_t(n) * 4));
+    LV_TRY(lv_buf_reserve(ctx, valsB, size_t(n) * 4));
+    LV_TRY(lv_buf_reserve(ctx, childL, size_t(nInternal) * 4));
+    LV_TRY(lv_buf_reserve(ctx, childR, size_t(nInternal) * 4));
+    LV_TRY(lv_buf_reserve(ctx, parI, size_t(nInternal) * 4));
+    LV_TRY(lv_buf_reserve(ctx, parL, size_t(n) * 4));
+    LV_TRY(lv_buf_reserve(ctx, height, size_t(nInternal) * 4));
+    LV_TRY(lv_buf_reserve(ctx, flags, size_t(nInternal) * 4));
+    LV_TRY(lv_buf_reserve(ctx, bounds, 6 * 4));
+
+    LV_HIPF(hipEventRecord(ctx->ev[0], st));
+    // bounds: min slots start at ord(+big) = 0xFFFFFFFF-ish, max slots at 0
+    {
+        uint32_t init[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
+        LV_HIPF(hipMemcpyAsync(bounds.ptr, init, sizeof(init), hipMemcpyHostToDevice, st));
+        LV_HIPF(hipStreamSynchronize(st)); // init[] is a stack array
+    }
+    k_seg_boxes<<<nblocks(n), LV_BLOCK, 0, st>>>((const lv_line_point*)ctx->points.ptr, (const uint32_t*)ctx->segIdx.ptr, n,
+                                                 radius, pad, (float*)boxOrig.ptr, (uint32_t*)bounds.ptr);
+    k_morton<<<nblocks(n), LV_BLOCK, 0, st>>>((const float*)boxOrig.ptr, n, (const uint32_t*)bounds.ptr,
+                                              (uint64_t*)keysA.ptr, (uint32_t*)valsA.ptr);
+    {
+        size_t tmpBytes = 0;
+        LV_HIPF(rocprim::radix_sort_pairs(nullptr, tmpBytes, (uint64_t*)keysA.ptr, (uint64_t*)keysB.ptr,
+                                          (uint32_t*)valsA.ptr, (uint32_t*)valsB.ptr, n, 0, 63, st));
+        LV_TRY(lv_buf_reserve(ctx, sortTmp, tmpBytes ? tmpBytes : 16));
+        LV_HIPF(rocprim::radix_sort_pairs(sortTmp.ptr, tmpBytes, (uint64_t*)keysA.ptr, (uint64_t*)keysB.ptr,
+                                          (uint32_t*)valsA.ptr, (uint32_t*)valsB.ptr, n, 0, 63, st));
+    }
+    k_leaves<<<nblocks(n), LV_BLOCK, 0, st>>>((const lv_line_point*)ctx->points.ptr, (const uint32_t*)ctx->segIdx.ptr,
+                                              (const float*)boxOrig.ptr, (const uint32_t*)valsB.ptr, n,
+                                              (float4*)ctx->segs.ptr, (uint32_t*)ctx->leafSeg.ptr, (float*)leafBox.ptr);
+    if (n == 1) {
+        k_single_node<<<1, 64, 0, st>>>((const float*)leafBox.ptr, (float4*)ctx->nodes.ptr);
+        ctx->bvhDepth = 1;
+    } else {
+        LV_HIPF(hipMemsetAsync(flags.ptr, 0, size_t(nInternal) * 4, st));
+        k_karras<<<nblocks(nInternal), LV_BLOCK, 0, st>>>((const uint64_t*)keysB.ptr, int(n), (uint32_t*)childL.ptr,
+                                                          (uint32_t*)childR.ptr, (uint32_t*)parI.ptr,
+                                                          (uint32_t*)parL.ptr);
+        k_refit<<<nblocks(n), LV_BLOCK, 0, st>>>(int(n), (const uint32_t*)childL.ptr, (const uint32_t*)childR.ptr,
+                                                 (const uint32_t*)parI.ptr, (const uint32_t*)parL.ptr,
+                                                 (const float*)leafBox.ptr, (float*)nodeBox.ptr, (uint32_t*)height.ptr,
+                                                 (uint32_t*)flags.ptr);
+        k_pack<<<nblocks(nInternal), LV_BLOCK, 0, st>>>(int(nInternal), (const uint32_t*)childL.ptr,
+                                                        (const uint32_t*)childR.ptr, (const float*)leafBox.ptr,
+                                                        (const float*)nodeBox.ptr, (const uint32_t*)height.ptr,
+                                                        (float4*)ctx->nodes.ptr);
+    }
+    LV_HIPF(hipGetLastError());
+    LV_HIPF(hipEventRecord(ctx->ev[1], st));
+    if (n > 1) {
+        uint32_t h = 0;
+        LV_HIPF(hipMemcpyAsync(&h, height.ptr, 4, hipMemcpyDeviceToHost, st));
+        LV_HIPF(hipStreamSynchronize(st));
+        ctx->bvhDepth = h;
+    } else {
+        LV_HIPF(hipStreamSynchronize(st));
+    }
+    freeAll();
+#undef LV_TRY
+#undef LV_HIPF
+    if (ctx->bvhDepth > LV_STACK_LDS + LV_STACK_SPILL)
+        return lv_fail(ctx, LV_E_CAPACITY, "LBVH height %u exceeds the traversal stack (%d)", ctx->bvhDepth,
+                       LV_STACK_LDS + LV_STACK_SPILL);
+    ctx->numNodes = nInternal;
+    ctx->accelValid = true;
+    ctx->accelLineWidth = ctx->opt.lineWidth;
+    ctx->evBuildValid = true;
+    return LV_OK;
+}

@@ -1,0 +1,155 @@
+// lv_device.h -- shared device-side definitions of the HIP hot path (gfx950 only).
+//
+// Float32 arithmetic with a fixed evaluation order (the library is compiled with -ffp-contract=off): +,-,*,/ and
+// sqrt are IEEE-exact on gfx950, so ray generation, traversal and ray-capsule intersection produce bit-identical
+// (t, segment, kind) triples to any host evaluation of the same formulas in the same order.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/linevis_hip.h"
+
+#define LV_WAVE 64
+#define LV_BLOCK 256
+#define LV_LEAF_BIT 0x80000000u
+#define LV_INVALID 0xFFFFFFFFu
+#define LV_STACK_LDS 32     // per-thread traversal stack entries staged in LDS
+#define LV_STACK_SPILL 64   // further entries in private (scratch) memory; 96 >= max LBVH depth (63 key bits + 32)
+
+struct f3 { float x, y, z; };
+struct f4 { float x, y, z, w; };
+
+__device__ __forceinline__ f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ f3 operator+(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ f3 operator-(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ f3 operator*(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ f3 operator*(float s, f3 a) { return mk3(s * a.x, s * a.y, s * a.z); }
+__device__ __forceinline__ float dot3(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+// GLSL cross(x, y) = (x1*y2 - y1*x2, x2*y0 - y2*x0, x0*y1 - y0*x1)
+__device__ __forceinline__ f3 cross3(f3 a, f3 b) {
+    return mk3(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y);
+}
+__device__ __forceinline__ float len3(f3 a) { return sqrtf(dot3(a, a)); }
+__device__ __forceinline__ f3 norm3(f3 a) { float l = len3(a); return mk3(a.x / l, a.y / l, a.z / l); }
+__device__ __forceinline__ float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+__device__ __forceinline__ float mixf(float a, float b, float w) { return a * (1.0f - w) + b * w; }
+__device__ __forceinline__ float smoothstepf(float e0, float e1, float x) {
+    float t = clampf((x - e0) / (e1 - e0), 0.0f, 1.0f);
+    return t * t * (3.0f - 2.0f * t);
+}
+// column-major mat4 * vec4, columns summed left to right
+__device__ __forceinline__ f4 mulM4(const float* m, float x, float y, float z, float w) {
+    f4 r;
+    r.x = ((m[0] * x + m[4] * y) + m[8] * z) + m[12] * w;
+    r.y = ((m[1] * x + m[5] * y) + m[9] * z) + m[13] * w;
+    r.z = ((m[2] * x + m[6] * y) + m[10] * z) + m[14] * w;
+    r.w = ((m[3] * x + m[7] * y) + m[11] * z) + m[15] * w;
+    return r;
+}
+
+// Per-frame constants: LineUniformData (LineUniformData.glsl:24-70) + RayTracerSettingsBuffer
+// (TubeRayTracingHeader.glsl:33-42) + RTAO UniformsBuffer (VulkanRayTracedAmbientOcclusion.glsl:45-67) + PPLL
+// UniformDataBuffer (LinkedListHeader.glsl:45-52) + the preprocessor switches, flattened into one kernel argument.
+struct LvUniforms {
+    float view[16], proj[16], invView[16], invProj[16];
+    float camPos[3];
+    float fovY;
+    float background[4], foreground[4];
+    float lineWidth, radius, nearDist, farDist;
+    uint32_t width, height;
+    uint32_t maxDepthComplexity, numSamplesPerFrame, frameNumber, useJitteredRays, useDeterministicSampling;
+    uint32_t useCappedTubes, useHalos, useDepthCues, useAmbientOcclusion;
+    float depthCueStrength, aoStrength, aoGamma, attrMin, attrMax;
+    uint32_t tfN;
+    uint32_t aoSamplesPerFrame, aoUseDistance, aoJitterPrimary, aoFrameNumber;
+    float aoRadius, subdivisionCorrectionFactor;
+    uint32_t ppllMaxNumFrags, ppllLinkedListSize, ppllTileW, ppllTileH, ppllPaddedW, ppllPaddedH;
+};
+
+// HBM-resident scene (all read-only during rendering)
+struct LvSceneDev {
+    const float4* nodes;        // 64-B BVH2 nodes, 4 x float4 each (layout in DESIGN.md)
+    const float4* segs;         // 32-B segment records in Morton (leaf) order: {p0.xyz, attr0}, {p1.xyz, attr1}
+    const uint32_t* leafSeg;    // leaf position -> original segment index
+    const lv_line_point* points;// 48-B point records, input order
+    const uint32_t* segIdx;     // 2 point indices per original segment
+    const float4* tf;           // transfer function texels
+    const float* depthMinMax;   // {minDepth, maxDepth}, produced on device by the depth-range kernels
+    const float* ao;            // full-viewport AO factors
+    uint32_t numSegs;
+};
+
+// tile list of a launch: tiles are tileW x tileH pixel rectangles with origins tilesXY[2*i], tilesXY[2*i+1]
+struct LvTiles {
+    const uint32_t* tilesXY;
+    uint32_t numTiles, tileW, tileH, blocksX, blocksY; // 16x16-pixel blocks per tile
+};
+
+struct LvCounters {
+    unsigned long long rays, nodes, prims, hits;
+};
+
+// ---------------------------------------------------------------- RNG, RayTracingUtilities.glsl:134-181
+__device__ __forceinline__ uint32_t lv_tea(uint32_t val0, uint32_t val1) {
+    uint32_t v0 = val0, v1 = val1, s0 = 0;
+#pragma unroll
+    for (uint32_t n = 0; n < 16; n++) {
+        s0 += 0x9e3779b9u;
+        v0 += ((v1 << 4) + 0xa341316cu) ^ (v1 + s0) ^ ((v1 >> 5) + 0xc8013ea4u);
+        v1 += ((v0 << 4) + 0xad90777du) ^ (v0 + s0) ^ ((v0 >> 5) + 0x7e95761eu);
+    }
+    return v0;
+}
+__device__ __forceinline__ uint32_t lv_lcg(uint32_t& prev) {
+    prev = 1664525u * prev + 1013904223u;
+    return prev & 0x00FFFFFFu;
+}
+__device__ __forceinline__ float lv_rnd(uint32_t& seed) { return float(lv_lcg(seed)) / float(0x01000000); }
+
+// sin/cos(2*pi*xi) by exact quadrant reduction + fixed polynomial (definition owned by the build; GLSL leaves
+// sin/cos precision to the implementation).  Used for the AO hemisphere sample so directions are reproducible.
+__device__ __forceinline__ void lv_sincos2pi(float xi, float& s, float& c) {
+    float q = xi * 4.0f;
+    float fq = floorf(q);
+    int quad = int(fq) & 3;
+    float r = q - fq;
+    bool swp = r > 0.5f;
+    float rr = swp ? (1.0f - r) : r;
+    float a = rr * 1.57079632679489662f;
+    float a2 = a * a;
+    float sp = a * (1.0f + a2 * (-1.0f / 6.0f + a2 * (1.0f / 120.0f + a2 * (-1.0f / 5040.0f + a2 * (1.0f / 362880.0f)))));
+    float cp = 1.0f + a2 * (-0.5f + a2 * (1.0f / 24.0f + a2 * (-1.0f / 720.0f + a2 * (1.0f / 40320.0f + a2 * (-1.0f / 3628800.0f)))));
+    float sa = swp ? cp : sp;
+    float ca = swp ? sp : cp;
+    if (quad == 0) { s = sa; c = ca; }
+    else if (quad == 1) { s = ca; c = -sa; }
+    else if (quad == 2) { s = -sa; c = -ca; }
+    else { s = -ca; c = sa; }
+}
+
+// ---------------------------------------------------------------- wave helpers (wave64)
+__device__ __forceinline__ unsigned lv_lane() { return __lane_id(); }
+__device__ __forceinline__ unsigned long long lv_wave_sum_u64(unsigned long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float lv_wave_min(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float lv_wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// order-preserving float <-> uint encoding for atomicMin/atomicMax
+__device__ __forceinline__ uint32_t lv_f2ord(float f) {
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float lv_ord2f(uint32_t u) {
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u);
+}

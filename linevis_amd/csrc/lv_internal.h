@@ -1,0 +1,111 @@
+// lv_internal.h -- host-side context of the C-ABI library (not installed).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "lv_device.h"
+
+struct LvDeviceBuffer {
+    void* ptr = nullptr;
+    size_t bytes = 0;
+};
+
+// Settings with the reference's defaults (file:line next to each value).
+struct LvOptions {
+    float lineWidth = 0.002f;                 // src/Loaders/DataSetList.hpp:46
+    float depthCueStrength = 0.0f;            // reference default 0.8 (LineRenderer.hpp:220-221); off until set
+    bool useAmbientOcclusion = false;         // ambient_occlusion_mode == "RTAO (Screen Space)" && strength > 0
+    bool aoBakerIsRtao = false;
+    float aoStrength = 0.0f;                  // LineRenderer.hpp (0 = off)
+    float aoGamma = 1.0f;
+    uint32_t aoIterations = 64;               // VulkanRayTracedAmbientOcclusion.hpp:108
+    uint32_t aoSamplesPerFrame = 4;           // VulkanRayTracedAmbientOcclusion.hpp:150
+    float aoRadius = 0.1f;                    // :151
+    bool aoUseDistance = true;                // :152
+    bool aoJitterPrimary = true;              // :153
+    uint32_t numSamplesPerFrame = 1;          // VulkanRayTracer.hpp:137 has 2 (interactive); offline default 1
+    bool useDeterministicSampling = false;
+    uint32_t maxDepthComplexity = 1024;       // VulkanRayTracer.hpp:139
+    bool useCappedTubes = true;               // LineData.hpp:377-379
+    bool useHalos = true;
+    uint32_t tubeNumSubdivisions = 6;         // LineData.cpp:52
+    uint32_t ppllMaxNumFrags = 0;             // 0 = auto: 100 (<=1M segments) / 380, PerPixelLinkedListLineRenderer.hpp:45-49
+    uint32_t ppllExpectedAvgDepthComplexity = 0; // 0 = auto: 20 / 120
+    uint32_t ppllTileW = 2, ppllTileH = 8;    // LineRenderer.cpp:739-740
+    bool collectStats = false;
+};
+
+struct lv_ctx {
+    int device = 0;
+    hipStream_t ownStream = nullptr;
+    hipStream_t stream = nullptr;
+    std::string lastError;
+
+    // scene
+    uint32_t numPoints = 0, numSegs = 0, numNodes = 0;
+    LvDeviceBuffer points, segIdx;            // input order
+    LvDeviceBuffer nodes, segs, leafSeg;      // accel
+    LvDeviceBuffer tf;
+    uint32_t tfN = 0;
+    float attrMin = 0.0f, attrMax = 1.0f;
+    bool accelValid = false;
+    float accelLineWidth = -1.0f;
+    uint32_t bvhDepth = 0;
+
+    // camera
+    bool cameraSet = false;
+    float view[16], proj[16], invView[16], invProj[16];
+    float fovY = 0.0f, nearDist = 0.01f, farDist = 100.0f;
+    uint32_t width = 0, height = 0;
+    float background[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+
+    LvOptions opt;
+
+    // frame resources
+    LvDeviceBuffer depthMinMax;               // 2 floats (+2 encoded uints)
+    LvDeviceBuffer ao;                        // width*height floats
+    LvDeviceBuffer aoGbuf, aoList, aoSamples; // RTAO wavefront buffers
+    LvDeviceBuffer counters;                  // device counters (LvCounters + misc)
+    LvDeviceBuffer ppllNodes, ppllStart, ppllScratch;
+    LvDeviceBuffer tilesDev, outDev, scratchRays;
+    std::vector<uint32_t> tilesHost;          // staging copy: caller's tile list is borrowed for the call only
+    uint64_t ppllPoolNodes = 0;
+
+    // stats
+    lv_stats stats;
+    hipEvent_t ev[16];
+    bool evCreated = false;
+    bool evBuildValid = false, evFrameValid = false;
+    int lastMode = 0;
+};
+
+int lv_fail(lv_ctx* ctx, int code, const char* fmt, ...);
+
+#define LV_HIP(ctx, expr)                                                                          \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess)                                                                      \
+            return lv_fail(ctx, LV_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+int lv_buf_reserve(lv_ctx* ctx, LvDeviceBuffer& b, size_t bytes);
+void lv_buf_free(LvDeviceBuffer& b);
+
+// lv_bvh.hip
+int lv_bvh_build(lv_ctx* ctx);
+// lv_render.hip
+int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t numTiles, uint32_t tileW,
+                    uint32_t tileH, void* outDevice);
+int lv_frame_trace_rays(lv_ctx* ctx, const float* o, const float* d, float tMin, float tMax, uint32_t n, float* outT,
+                        uint32_t* outSeg, uint32_t* outKind);
+int lv_frame_depth_range(lv_ctx* ctx);
+int lv_frame_ppll_resolve_only(lv_ctx* ctx, const uint32_t* nodes, uint64_t numNodes, const uint32_t* start,
+                               uint64_t numPixels, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, uint8_t* out);
+void lv_fill_uniforms(const lv_ctx* ctx, LvUniforms& U);
+void lv_mat4_inverse(const float* m, float* inv);

@@ -1,0 +1,798 @@
+// lv_render.hip -- frame kernels of the hot path and their orchestration.
+//
+// Kernel                reference program it replaces
+//   k_render_rt         TubeRayTracing.RayGen/.Miss (+ driver traversal, IntersectionTube, ClosestHitTubeAnalytic)
+//                       Data/Shaders/Renderers/RayTracing/TubeRayTracing.glsl:61-82,198-298
+//   k_ao_primary        VulkanRayTracedAmbientOcclusion.Compute, primary-ray half (glsl:178-281) + wave compaction
+//   k_ao_rays           .. sample loop (glsl:288-306) as one thread per AO ray, fused per-pixel reduction
+//   k_ao_reduce         .. accumulate/store (glsl:309-319) for sample counts that do not tile a workgroup
+//   k_ppll_gather       tube rasterisation + gatherFragment, Data/Shaders/Renderers/PPLL/LinkedListGather.glsl:33-72
+//   k_ppll_resolve      LinkedListResolve.Fragment + frontToBackPQ, LinkedListResolve.glsl:57-105, LinkedListSort.glsl:177-238
+//   k_depth_minmax      ComputeDepthValues.Compute + MinMaxReduce.Compute, Data/Shaders/DepthCues/*.glsl
+// Host orchestration follows VulkanRayTracer::render (VulkanRayTracer.cpp:131-154), LineRenderer::renderBase
+// (LineRenderer.cpp:248-277) and PerPixelLinkedListLineRenderer::render (PerPixelLinkedListLineRenderer.cpp:399-427).
+#include <cmath>
+#include <cstring>
+
+#include "lv_internal.h"
+#include "lv_trace.h"
+
+namespace {
+
+// device-side counters block
+struct LvDevCounters {
+    unsigned long long rays, nodes, prims, hits;
+    uint32_t fragCounter;
+    uint32_t aoCount;
+    uint32_t maxDepthComplexity;
+    uint32_t depthOrd[2]; // encoded min / max for the depth-range reduction
+    uint32_t pad;
+};
+
+__device__ __forceinline__ void lv_flush_counters(const LvCounters& c, LvDevCounters* dc) {
+    unsigned long long r = lv_wave_sum_u64(c.rays), n = lv_wave_sum_u64(c.nodes), p = lv_wave_sum_u64(c.prims),
+                       h = lv_wave_sum_u64(c.hits);
+    if (lv_lane() == 0) {
+        atomicAdd(&dc->rays, r);
+        atomicAdd(&dc->nodes, n);
+        atomicAdd(&dc->prims, p);
+        atomicAdd(&dc->hits, h);
+    }
+}
+
+// Pixel of this thread.  A workgroup covers a 16x16 pixel block of one tile; each wave an 8x8 sub-block, so a
+// wave's primary rays stay coherent.  Workgroups are dealt to XCDs round-robin by the dispatcher (block b -> XCD
+// b % 8), so the block index is remapped to give every XCD one contiguous run of blocks and its private L2 one
+// compact part of the BVH (speed only; correctness does not depend on placement).
+struct LvPixel {
+    uint32_t x, y;       // viewport pixel
+    uint32_t outIndex;   // index into the tile-major output
+    bool inTile, inView;
+};
+
+__device__ __forceinline__ bool lv_block_pixel(const LvUniforms& U, const LvTiles& T, LvPixel& p) {
+    const uint32_t blocksPerTile = T.blocksX * T.blocksY;
+    const uint32_t nb = T.numTiles * blocksPerTile;
+    const uint32_t chunk = (nb + 7u) / 8u;
+    const uint32_t b = (blockIdx.x % 8u) * chunk + blockIdx.x / 8u;
+    if (b >= nb) { p.inTile = false; p.inView = false; return false; }
+    const uint32_t tile = b / blocksPerTile, rem = b % blocksPerTile;
+    const uint32_t by = rem / T.blocksX, bx = rem % T.blocksX;
+    const uint32_t w = threadIdx.x >> 6, l = threadIdx.x & 63u;
+    const uint32_t lx = bx * 16u + (w & 1u) * 8u + (l & 7u);
+    const uint32_t ly = by * 16u + (w >> 1) * 8u + (l >> 3);
+    p.inTile = lx < T.tileW && ly < T.tileH;
+    p.x = T.tilesXY[2 * tile] + lx;
+    p.y = T.tilesXY[2 * tile + 1] + ly;
+    p.inView = p.inTile && p.x < U.width && p.y < U.height;
+    p.outIndex = (tile * T.tileH + ly) * T.tileW + lx;
+    return true;
+}
+
+// ================================================================ ray tracer colour pass
+template <bool STATS>
+__global__ __launch_bounds__(LV_BLOCK) void k_render_rt(const LvUniforms U, const LvSceneDev S, const LvTiles T,
+                                                        uint32_t* __restrict__ out, LvDevCounters* dc) {
+    __shared__ unsigned s_stack[LV_STACK_LDS * LV_BLOCK];
+    LvPixel px;
+    if (!lv_block_pixel(U, T, px)) return;
+    LvCounters cnt = {0, 0, 0, 0};
+    if (px.inView) {
+        const bool capped = U.useCappedTubes != 0;
+        const float HIT_DISTANCE_EPSILON = 1e-5f;
+        const float aoTexel = U.useAmbientOcclusion ? S.ao[size_t(px.y) * U.width + px.x] : 1.0f;
+        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        const uint32_t nSamples = U.useJitteredRays ? U.numSamplesPerFrame : 1u;
+        for (uint32_t sampleIdx = 0; sampleIdx < nSamples; sampleIdx++) {
+            float xix = 0.5f, xiy = 0.5f;
+            if (U.useJitteredRays) {
+                uint32_t seed = U.useDeterministicSampling
+                        ? lv_tea(19u, U.frameNumber * U.numSamplesPerFrame + sampleIdx)
+                        : lv_tea(px.x + px.y * U.width, U.frameNumber * U.numSamplesPerFrame + sampleIdx);
+                xix = lv_rnd(seed);
+                xiy = lv_rnd(seed);
+            }
+            f3 o, d;
+            lv_primary_ray(U, px.x, px.y, xix, xiy, o, d);
+            // traceRayTransparent, TubeRayTracing.glsl:61-82
+            float fc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            float tMin = 0.0001f;
+            const float tMax = 1000.0f;
+            for (uint32_t hitIdx = 0; hitIdx < U.maxDepthComplexity; hitIdx++) {
+                LvHit h = lv_trace_closest<STATS, false>(S, U.radius, capped, o, d, tMin, tMax, &s_stack[threadIdx.x], cnt);
+                f4 hc;
+                float payloadHitT;
+                if (h.found) {
+                    hc = lv_shade_hit(S, U, aoTexel, o, d, h, payloadHitT);
+                    if (STATS) cnt.hits++;
+                } else { // Miss, TubeRayTracing.glsl:290-297
+                    hc.x = U.background[0]; hc.y = U.background[1]; hc.z = U.background[2]; hc.w = U.background[3];
+                    payloadHitT = 0.0f;
+                }
+                tMin = payloadHitT + fmaxf(payloadHitT * HIT_DISTANCE_EPSILON, 1e-7f);
+                fc[0] = fc[0] + ((1.0f - fc[3]) * hc.w) * hc.x;
+                fc[1] = fc[1] + ((1.0f - fc[3]) * hc.w) * hc.y;
+                fc[2] = fc[2] + ((1.0f - fc[3]) * hc.w) * hc.z;
+                fc[3] = fc[3] + (1.0f - fc[3]) * hc.w;
+                if (!h.found || fc[3] > 0.99f) break;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) acc[k] += fc[k];
+        }
+        if (U.useJitteredRays) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) acc[k] /= float(U.numSamplesPerFrame);
+        }
+        f4 c; c.x = acc[0]; c.y = acc[1]; c.z = acc[2]; c.w = acc[3];
+        out[px.outIndex] = lv_pack_unorm4x8(c);
+    } else if (px.inTile) {
+        f4 c; c.x = U.background[0]; c.y = U.background[1]; c.z = U.background[2]; c.w = U.background[3];
+        out[px.outIndex] = lv_pack_unorm4x8(c);
+    }
+    if (STATS) lv_flush_counters(cnt, dc);
+}
+
+// ================================================================ RTAO
+// G-buffer entry of a pixel whose primary ray hit: 3 x float4
+//   g0 = {hit position, offsetFactor}, g1 = {surface tangent, pixel index bits}, g2 = {surface normal, 0}
+template <bool STATS>
+__global__ __launch_bounds__(LV_BLOCK) void k_ao_primary(const LvUniforms U, const LvSceneDev S, const LvTiles T,
+                                                         float* __restrict__ ao, float4* __restrict__ gbuf,
+                                                         LvDevCounters* dc) {
+    __shared__ unsigned s_stack[LV_STACK_LDS * LV_BLOCK];
+    LvPixel px;
+    if (!lv_block_pixel(U, T, px)) return;
+    LvCounters cnt = {0, 0, 0, 0};
+    bool hasHit = false;
+    float4 g0, g1, g2;
+    if (px.inView) {
+        const uint32_t pix = px.x + px.y * U.width;
+        const uint32_t globalFrameNumber = U.aoFrameNumber; // VulkanRayTracedAmbientOcclusion.cpp:576-581
+        uint32_t seed = lv_tea(pix, globalFrameNumber);
+        float xix = 0.5f, xiy = 0.5f;
+        if (U.aoJitterPrimary) { xix = lv_rnd(seed); xiy = lv_rnd(seed); }
+        f3 o, d;
+        lv_primary_ray(U, px.x, px.y, xix, xiy, o, d);
+        LvHit h = lv_trace_closest<STATS, false>(S, U.radius, U.useCappedTubes != 0, o, d, 0.0001f, 1000.0f,
+                                                 &s_stack[threadIdx.x], cnt);
+        if (h.found) {
+            hasHit = true;
+            const float4 ra = S.segs[2 * h.leaf], rb = S.segs[2 * h.leaf + 1];
+            const uint32_t seg = S.leafSeg[h.leaf];
+            const lv_line_point& lp0 = S.points[S.segIdx[2 * seg]];
+            const lv_line_point& lp1 = S.points[S.segIdx[2 * seg + 1]];
+            const f3 P0 = mk3(ra.x, ra.y, ra.z), P1 = mk3(rb.x, rb.y, rb.z);
+            f3 vertexPositionWorld = o + d * h.t;
+            f3 v = P1 - P0;
+            float ts;
+            if (h.kind == 0) ts = dot3(v, vertexPositionWorld - P0) / dot3(v, v);
+            else ts = h.kind == 1 ? 0.0f : 1.0f;
+            f3 linePosition = h.kind == 0 ? P0 + ts * v : (h.kind == 1 ? P0 : P1);
+            f3 surfaceNormal = norm3(vertexPositionWorld - linePosition);
+            f3 t0 = mk3(lp0.lineTangent[0], lp0.lineTangent[1], lp0.lineTangent[2]);
+            f3 t1 = mk3(lp1.lineTangent[0], lp1.lineTangent[1], lp1.lineTangent[2]);
+            f3 surfaceTangent = norm3((1.0f - ts) * t0 + ts * t1);
+            float offsetFactor = len3(linePosition - vertexPositionWorld) / U.subdivisionCorrectionFactor;
+            g0 = make_float4(vertexPositionWorld.x, vertexPositionWorld.y, vertexPositionWorld.z, offsetFactor);
+            g1 = make_float4(surfaceTangent.x, surfaceTangent.y, surfaceTangent.z, __uint_as_float(pix));
+            g2 = make_float4(surfaceNormal.x, surfaceNormal.y, surfaceNormal.z, 0.0f);
+        } else {
+            // miss: aoFactor = 1, accumulate (glsl:311-319)
+            float aoFactor = 1.0f;
+            if (U.aoFrameNumber != 0) aoFactor = mixf(ao[pix], aoFactor, 1.0f / float(U.aoFrameNumber + 1));
+            ao[pix] = aoFactor;
+        }
+    }
+    // active-ray compaction: ballot + prefix popcount, one atomic per wave
+    const unsigned long long mask = __ballot(hasHit);
+    if (mask) {
+        const unsigned lane = lv_lane();
+        unsigned base = 0;
+        if (lane == 0) base = atomicAdd(&dc->aoCount, unsigned(__popcll(mask)));
+        base = __shfl(base, 0, 64);
+        if (hasHit) {
+            const unsigned slot = base + unsigned(__popcll(mask & ((1ull << lane) - 1ull)));
+            gbuf[3 * size_t(slot) + 0] = g0;
+            gbuf[3 * size_t(slot) + 1] = g1;
+            gbuf[3 * size_t(slot) + 2] = g2;
+        }
+    }
+    if (STATS) lv_flush_counters(cnt, dc);
+}
+
+// One thread per AO ray: ray r belongs to compacted pixel r / spp, sample r % spp (with spp = 64 a wavefront is
+// exactly one pixel's hemisphere).  FUSED: spp divides the workgroup size, so the per-pixel sum (in sample order,
+// like the reference's loop) is finished inside the workgroup through LDS.
+template <bool STATS, bool ANY_HIT, bool FUSED>
+__global__ __launch_bounds__(LV_BLOCK) void k_ao_rays(const LvUniforms U, const LvSceneDev S,
+                                                      const float4* __restrict__ gbuf, float* __restrict__ ao,
+                                                      float* __restrict__ samples, LvDevCounters* dc) {
+    __shared__ unsigned s_stack[LV_STACK_LDS * LV_BLOCK];
+    __shared__ float s_occ[LV_BLOCK];
+    const uint32_t spp = U.aoSamplesPerFrame;
+    const unsigned long long total = (unsigned long long)(dc->aoCount) * spp;
+    const unsigned long long r0 = (unsigned long long)(blockIdx.x) * LV_BLOCK;
+    if (r0 >= total) return;
+    const unsigned long long r = r0 + threadIdx.x;
+    const bool valid = r < total;
+    LvCounters cnt = {0, 0, 0, 0};
+    float occ = 1.0f;
+    if (valid) {
+        const uint32_t slot = uint32_t(r / spp), s = uint32_t(r % spp);
+        const float4 g0 = gbuf[3 * size_t(slot) + 0], g1 = gbuf[3 * size_t(slot) + 1], g2 = gbuf[3 * size_t(slot) + 2];
+        const uint32_t pix = __float_as_uint(g1.w);
+        const f3 pos = mk3(g0.x, g0.y, g0.z), T = mk3(g1.x, g1.y, g1.z), N = mk3(g2.x, g2.y, g2.z);
+        const f3 B = cross3(N, T);
+        uint32_t seed = lv_tea(pix, U.aoFrameNumber * spp + s);
+        const float xi0 = lv_rnd(seed), xi1 = lv_rnd(seed);
+        float sn, cs;
+        lv_sincos2pi(xi1, sn, cs);
+        const float rr = sqrtf(1.0f - xi0 * xi0);
+        const f3 smp = mk3(cs * rr, sn * rr, xi0);
+        const f3 dirU = mk3((T.x * smp.x + B.x * smp.y) + N.x * smp.z, (T.y * smp.x + B.y * smp.y) + N.y * smp.z,
+                            (T.z * smp.x + B.z * smp.y) + N.z * smp.z);
+        const f3 rd = norm3(dirU);
+        const f3 ro = pos + rd * g0.w;
+        LvHit h = lv_trace_closest<STATS, ANY_HIT>(S, U.radius, U.useCappedTubes != 0, ro, rd, 0.0f, U.aoRadius,
+                                                   &s_stack[threadIdx.x], cnt);
+        if (h.found) occ = U.aoUseDistance ? h.t / U.aoRadius : 0.0f;
+        if (!FUSED) samples[r] = occ;
+    }
+    if (FUSED) {
+        s_occ[threadIdx.x] = occ;
+        __syncthreads();
+        const uint32_t pixelsPerBlock = LV_BLOCK / spp;
+        if (threadIdx.x < pixelsPerBlock) {
+            const unsigned long long rp = r0 + (unsigned long long)(threadIdx.x) * spp;
+            if (rp < total) {
+                float aoFactor = 0.0f;
+                for (uint32_t s = 0; s < spp; s++) aoFactor += s_occ[threadIdx.x * spp + s];
+                aoFactor /= float(spp);
+                const uint32_t pix = __float_as_uint(gbuf[3 * size_t(rp / spp) + 1].w);
+                if (U.aoFrameNumber != 0) aoFactor = mixf(ao[pix], aoFactor, 1.0f / float(U.aoFrameNumber + 1));
+                ao[pix] = aoFactor;
+            }
+        }
+    }
+    if (STATS) lv_flush_counters(cnt, dc);
+}
+
+__global__ __launch_bounds__(LV_BLOCK) void k_ao_reduce(const LvUniforms U, const float4* __restrict__ gbuf,
+                                                        const float* __restrict__ samples, float* __restrict__ ao,
+                                                        const LvDevCounters* dc) {
+    const uint32_t slot = blockIdx.x * LV_BLOCK + threadIdx.x;
+    if (slot >= dc->aoCount) return;
+    const uint32_t spp = U.aoSamplesPerFrame;
+    float aoFactor = 0.0f;
+    for (uint32_t s = 0; s < spp; s++) aoFactor += samples[size_t(slot) * spp + s];
+    aoFactor /= float(spp);
+    const uint32_t pix = __float_as_uint(gbuf[3 * size_t(slot) + 1].w);
+    if (U.aoFrameNumber != 0) aoFactor = mixf(ao[pix], aoFactor, 1.0f / float(U.aoFrameNumber + 1));
+    ao[pix] = aoFactor;
+}
+
+__global__ __launch_bounds__(LV_BLOCK) void k_fill_f32(float* p, float v, size_t n) {
+    size_t i = size_t(blockIdx.x) * LV_BLOCK + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+// ================================================================ PPLL
+template <bool STATS>
+__global__ __launch_bounds__(LV_BLOCK) void k_ppll_gather(const LvUniforms U, const LvSceneDev S, const LvTiles T,
+                                                          uint32_t* __restrict__ nodes, uint32_t* __restrict__ startOffset,
+                                                          LvDevCounters* dc) {
+    __shared__ unsigned s_stack[LV_STACK_LDS * LV_BLOCK];
+    LvPixel px;
+    if (!lv_block_pixel(U, T, px)) return;
+    LvCounters cnt = {0, 0, 0, 0};
+    uint32_t numFrags = 0;
+    if (px.inView) {
+        const float aoTexel = U.useAmbientOcclusion ? S.ao[size_t(px.y) * U.width + px.x] : 1.0f;
+        f3 o, d;
+        lv_primary_ray(U, px.x, px.y, 0.5f, 0.5f, o, d);
+        uint32_t head = 0xFFFFFFFFu;
+        lv_trace_all<STATS>(S, U.radius, U.useCappedTubes != 0, o, d, 0.0001f, 1000.0f, &s_stack[threadIdx.x], cnt,
+                            [&](uint32_t leaf, float t, int kind) {
+            LvHit h; h.t = t; h.leaf = leaf; h.kind = kind; h.found = true;
+            float hitT;
+            f4 color = lv_shade_hit(S, U, aoTexel, o, d, h, hitT);
+            if (STATS) cnt.hits++;
+            if (color.w < 0.001f) return; // gatherFragment: discard, LinkedListGather.glsl:34
+            // wave-aggregated atomicAdd(fragCounter, 1): one atomic for all lanes that append right now
+            const unsigned long long mask = __ballot(1);
+            const unsigned lane = lv_lane();
+            const int leader = __ffsll((long long)mask) - 1;
+            unsigned base = 0;
+            if (int(lane) == leader) base = atomicAdd(&dc->fragCounter, unsigned(__popcll(mask)));
+            base = __shfl(base, leader, 64);
+            const uint32_t insertIndex = base + unsigned(__popcll(mask & ((1ull << lane) - 1ull)));
+            numFrags++;
+            if (insertIndex < U.ppllLinkedListSize) {
+                // this thread owns the pixel, so atomicExchange(startOffset[pixel]) reduces to a register
+                nodes[3 * size_t(insertIndex) + 0] = lv_pack_unorm4x8(color);
+                nodes[3 * size_t(insertIndex) + 1] = __float_as_uint(hitT);
+                nodes[3 * size_t(insertIndex) + 2] = head;
+                head = insertIndex;
+            }
+        });
+        startOffset[lv_ppll_addr(px.x, px.y, U.ppllPaddedW, U.ppllTileW, U.ppllTileH)] = head;
+    }
+    uint32_t m = numFrags;
+#pragma unroll
+    for (int ofs = 32; ofs > 0; ofs >>= 1) m = max(m, (uint32_t)__shfl_xor(m, ofs, 64));
+    if (lv_lane() == 0 && m > 0) atomicMax(&dc->maxDepthComplexity, m);
+    if (STATS) lv_flush_counters(cnt, dc);
+}
+
+// per-thread fragment arrays interleaved over the wave: entry i of lane l at [i * 64 + l]
+struct LvFragArrays {
+    uint32_t* col;
+    float* dep;
+    __device__ __forceinline__ uint32_t& c(uint32_t i) { return col[i * LV_WAVE]; }
+    __device__ __forceinline__ float& d(uint32_t i) { return dep[i * LV_WAVE]; }
+    // (depth, colour) key order: the reference compares depth only and leaves ties to rasterisation order
+    __device__ __forceinline__ bool gt(uint32_t a, uint32_t b) {
+        float da = d(a), db = d(b);
+        return da > db || (da == db && c(a) > c(b));
+    }
+    __device__ __forceinline__ void swap(uint32_t a, uint32_t b) {
+        uint32_t tc = c(a); c(a) = c(b); c(b) = tc;
+        float td = d(a); d(a) = d(b); d(b) = td;
+    }
+};
+
+// minHeapSink4, LinkedListSort.glsl:177-205
+__device__ __forceinline__ void lv_min_heap_sink4(LvFragArrays& A, uint32_t x, uint32_t fragsCount) {
+    uint32_t c, t;
+    while ((t = 4 * x + 1) < fragsCount) {
+        if (t + 1 < fragsCount && A.gt(t, t + 1)) c = t + 1; else c = t;
+        if (t + 2 < fragsCount && A.gt(c, t + 2)) c = t + 2;
+        if (t + 3 < fragsCount && A.gt(c, t + 3)) c = t + 3;
+        if (!A.gt(x, c)) return;
+        A.swap(x, c);
+        x = c;
+    }
+}
+
+// One wave per workgroup; fragment arrays in LDS when they fit, else in a global scratch slab.
+template <bool USE_LDS>
+__global__ __launch_bounds__(LV_WAVE) void k_ppll_resolve(const LvUniforms U, const LvTiles T,
+                                                          const uint32_t* __restrict__ nodes,
+                                                          const uint32_t* __restrict__ startOffset,
+                                                          uint32_t* __restrict__ out, uint32_t* __restrict__ scratch,
+                                                          uint32_t numGroups) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+    const uint32_t maxFrags = U.ppllMaxNumFrags;
+    const uint32_t lane = threadIdx.x;
+    LvFragArrays A;
+    if (USE_LDS) {
+        A.col = reinterpret_cast<uint32_t*>(s_dyn) + lane;
+        A.dep = reinterpret_cast<float*>(s_dyn) + size_t(maxFrags) * LV_WAVE + lane;
+    } else {
+        uint32_t* base = scratch + size_t(blockIdx.x) * 2 * maxFrags * LV_WAVE;
+        A.col = base + lane;
+        A.dep = reinterpret_cast<float*>(base) + size_t(maxFrags) * LV_WAVE + lane;
+    }
+    // group = 8x8 pixel block of a tile
+    const uint32_t gx = (T.tileW + 7u) / 8u, gy = (T.tileH + 7u) / 8u;
+    for (uint32_t g = blockIdx.x; g < numGroups; g += gridDim.x) {
+        const uint32_t tile = g / (gx * gy), rem = g % (gx * gy);
+        const uint32_t lx = (rem % gx) * 8u + (lane & 7u), ly = (rem / gx) * 8u + (lane >> 3);
+        if (lx >= T.tileW || ly >= T.tileH) continue;
+        const uint32_t x = T.tilesXY[2 * tile] + lx, y = T.tilesXY[2 * tile + 1] + ly;
+        const uint32_t outIndex = (tile * T.tileH + ly) * T.tileW + lx;
+        float res[4] = {U.background[0], U.background[1], U.background[2], U.background[3]};
+        if (x < U.width && y < U.height) {
+            uint32_t fragOffset = startOffset[lv_ppll_addr(x, y, U.ppllPaddedW, U.ppllTileW, U.ppllTileH)];
+            uint32_t numFrags = 0;
+            for (uint32_t i = 0; i < maxFrags; i++) {
+                if (fragOffset == 0xFFFFFFFFu) break;
+                A.c(i) = nodes[3 * size_t(fragOffset) + 0];
+                A.d(i) = __uint_as_float(nodes[3 * size_t(fragOffset) + 1]);
+                fragOffset = nodes[3 * size_t(fragOffset) + 2];
+                numFrags++;
+            }
+            if (numFrags > 0) {
+                // frontToBackPQ, LinkedListSort.glsl:207-238
+                uint32_t i;
+                for (i = numFrags / 4; i > 0; --i) lv_min_heap_sink4(A, i, numFrags);
+                float ray[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                i = 0;
+                while (i < numFrags && ray[3] < 0.99f) {
+                    lv_min_heap_sink4(A, 0, numFrags - i++);
+                    f4 src = lv_unpack_unorm4x8(A.c(0));
+                    ray[0] = ray[0] + ((1.0f - ray[3]) * src.w) * src.x;
+                    ray[1] = ray[1] + ((1.0f - ray[3]) * src.w) * src.y;
+                    ray[2] = ray[2] + ((1.0f - ray[3]) * src.w) * src.z;
+                    ray[3] = ray[3] + (1.0f - ray[3]) * src.w;
+                    A.c(0) = A.c(numFrags - i);
+                    A.d(0) = A.d(numFrags - i);
+                }
+                const float a = ray[3];
+                if (a > 0.0f) {
+                    // straight alpha rgb/A, then BACK_TO_FRONT_STRAIGHT_ALPHA over the clear colour
+                    // (LinkedListSort.glsl:236-237, PerPixelLinkedListLineRenderer.cpp:70,395-397)
+#pragma unroll
+                    for (int k = 0; k < 3; k++) res[k] = (ray[k] / a) * a + U.background[k] * (1.0f - a);
+                    res[3] = a + U.background[3] * (1.0f - a);
+                }
+            }
+        }
+        f4 c; c.x = res[0]; c.y = res[1]; c.z = res[2]; c.w = res[3];
+        out[outIndex] = lv_pack_unorm4x8(c);
+    }
+}
+
+// ================================================================ depth range
+__global__ __launch_bounds__(LV_BLOCK) void k_depth_minmax(const LvUniforms U, const lv_line_point* __restrict__ points,
+                                                           uint32_t numPoints, LvDevCounters* dc) {
+    // ComputeDepthValues.glsl:58-98; the 256-wide shared-memory tree + MinMaxReduce passes collapse into a wave
+    // reduction and two atomics per wave (min/max are order independent, so the result is identical).
+    const uint32_t i = blockIdx.x * LV_BLOCK + threadIdx.x;
+    const float EPSILON = 1e-2f;
+    float mn = U.farDist, mx = U.nearDist;
+    if (i < numPoints) {
+        const float* p = points[i].linePosition;
+        f4 ssp = mulM4(U.view, p[0], p[1], p[2], 1.0f);
+        f4 ndc = mulM4(U.proj, ssp.x, ssp.y, ssp.z, ssp.w);
+        float nx = ndc.x / ndc.w, ny = ndc.y / ndc.w, nz = ndc.z / ndc.w;
+        if (nx >= -1.0f && ny >= -1.0f && nz >= -1.0f && nx <= 1.0f && ny <= 1.0f && nz <= 1.0f) {
+            float depth = clampf(-ssp.z, U.nearDist, U.farDist);
+            mn = depth - EPSILON;
+            mx = depth + EPSILON;
+        }
+    }
+    mn = lv_wave_min(mn);
+    mx = lv_wave_max(mx);
+    if (lv_lane() == 0) {
+        atomicMin(&dc->depthOrd[0], lv_f2ord(mn));
+        atomicMax(&dc->depthOrd[1], lv_f2ord(mx));
+    }
+}
+__global__ void k_depth_init(const LvUniforms U, LvDevCounters* dc) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        dc->depthOrd[0] = lv_f2ord(U.farDist);
+        dc->depthOrd[1] = lv_f2ord(U.nearDist);
+    }
+}
+__global__ void k_depth_finalize(const LvDevCounters* dc, float* out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        out[0] = lv_ord2f(dc->depthOrd[0]);
+        out[1] = lv_ord2f(dc->depthOrd[1]);
+    }
+}
+
+// ================================================================ arbitrary rays (parity inspection)
+__global__ __launch_bounds__(LV_BLOCK) void k_trace_rays(const LvSceneDev S, float radius, uint32_t capped,
+                                                         const float* __restrict__ org, const float* __restrict__ dir,
+                                                         float tMin, float tMax, uint32_t n, float* __restrict__ outT,
+                                                         uint32_t* __restrict__ outSeg, uint32_t* __restrict__ outKind) {
+    __shared__ unsigned s_stack[LV_STACK_LDS * LV_BLOCK];
+    const uint32_t i = blockIdx.x * LV_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    LvCounters cnt = {0, 0, 0, 0};
+    f3 o = mk3(org[3 * i], org[3 * i + 1], org[3 * i + 2]);
+    f3 d = mk3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]);
+    LvHit h = lv_trace_closest<false, false>(S, radius, capped != 0, o, d, tMin, tMax, &s_stack[threadIdx.x], cnt);
+    outT[i] = h.found ? h.t : tMax;
+    outSeg[i] = h.found ? S.leafSeg[h.leaf] : 0xFFFFFFFFu;
+    outKind[i] = h.found ? uint32_t(h.kind) : 0u;
+}
+
+inline uint32_t nblocks(uint64_t n, uint32_t bs = LV_BLOCK) { return uint32_t((n + bs - 1) / bs); }
+
+void padTiling(uint32_t& w, uint32_t& h, uint32_t tw, uint32_t th) {
+    // LineRenderer::getScreenSizeWithTiling, LineRenderer.cpp:805-812
+    if (w % tw != 0) w = (w / tw + 1) * tw;
+    if (h % th != 0) h = (h / th + 1) * th;
+}
+
+LvSceneDev sceneDev(const lv_ctx* ctx) {
+    LvSceneDev S;
+    S.nodes = (const float4*)ctx->nodes.ptr;
+    S.segs = (const float4*)ctx->segs.ptr;
+    S.leafSeg = (const uint32_t*)ctx->leafSeg.ptr;
+    S.points = (const lv_line_point*)ctx->points.ptr;
+    S.segIdx = (const uint32_t*)ctx->segIdx.ptr;
+    S.tf = (const float4*)ctx->tf.ptr;
+    S.depthMinMax = (const float*)ctx->depthMinMax.ptr;
+    S.ao = (const float*)ctx->ao.ptr;
+    S.numSegs = ctx->numSegs;
+    return S;
+}
+
+} // namespace
+
+void lv_fill_uniforms(const lv_ctx* ctx, LvUniforms& U) {
+    memset(&U, 0, sizeof(U));
+    memcpy(U.view, ctx->view, 64);
+    memcpy(U.proj, ctx->proj, 64);
+    memcpy(U.invView, ctx->invView, 64);
+    memcpy(U.invProj, ctx->invProj, 64);
+    // rayOrigin = (inverseViewMatrix * vec4(0,0,0,1)).xyz, TubeRayTracing.glsl:202 (also used as cameraPosition)
+    const float* m = ctx->invView;
+    U.camPos[0] = ((m[0] * 0.0f + m[4] * 0.0f) + m[8] * 0.0f) + m[12] * 1.0f;
+    U.camPos[1] = ((m[1] * 0.0f + m[5] * 0.0f) + m[9] * 0.0f) + m[13] * 1.0f;
+    U.camPos[2] = ((m[2] * 0.0f + m[6] * 0.0f) + m[10] * 0.0f) + m[14] * 1.0f;
+    U.fovY = ctx->fovY;
+    for (int k = 0; k < 4; k++) {
+        U.background[k] = ctx->background[k];
+        U.foreground[k] = 1.0f - ctx->background[k]; // LineData.cpp:1282-1283
+    }
+    const LvOptions& o = ctx->opt;
+    U.lineWidth = o.lineWidth;
+    U.radius = o.lineWidth * 0.5f; // TubeRayTracing.glsl:453
+    U.nearDist = ctx->nearDist;
+    U.farDist = ctx->farDist;
+    U.width = ctx->width;
+    U.height = ctx->height;
+    U.maxDepthComplexity = o.maxDepthComplexity;
+    U.numSamplesPerFrame = o.numSamplesPerFrame;
+    U.frameNumber = 0;
+    U.useJitteredRays = o.numSamplesPerFrame > 1 ? 1u : 0u; // VulkanRayTracer.cpp:420-426 with maxNumFrames == 1
+    U.useDeterministicSampling = o.useDeterministicSampling;
+    U.useCappedTubes = o.useCappedTubes;
+    U.useHalos = o.useHalos;
+    U.useDepthCues = o.depthCueStrength > 0.0f;
+    U.useAmbientOcclusion = o.useAmbientOcclusion;
+    U.depthCueStrength = o.depthCueStrength;
+    U.aoStrength = o.aoStrength;
+    U.aoGamma = o.aoGamma;
+    U.attrMin = ctx->attrMin;
+    U.attrMax = ctx->attrMax;
+    U.tfN = ctx->tfN;
+    U.aoSamplesPerFrame = o.aoSamplesPerFrame;
+    U.aoUseDistance = o.aoUseDistance;
+    U.aoJitterPrimary = o.aoJitterPrimary;
+    U.aoFrameNumber = 0;
+    U.aoRadius = o.aoRadius;
+    // VulkanRayTracedAmbientOcclusion.cpp:588
+    U.subdivisionCorrectionFactor = cosf(3.1415926535897932f / float(o.tubeNumSubdivisions));
+    // PerPixelLinkedListLineRenderer.cpp:109-126,175,257
+    const bool large = ctx->numSegs > 1000000u;
+    U.ppllMaxNumFrags = o.ppllMaxNumFrags ? o.ppllMaxNumFrags : (large ? 380u : 100u);
+    const uint32_t avg = o.ppllExpectedAvgDepthComplexity ? o.ppllExpectedAvgDepthComplexity : (large ? 120u : 20u);
+    U.ppllTileW = o.ppllTileW;
+    U.ppllTileH = o.ppllTileH;
+    uint32_t pw = ctx->width, ph = ctx->height;
+    padTiling(pw, ph, o.ppllTileW, o.ppllTileH);
+    U.ppllPaddedW = pw;
+    U.ppllPaddedH = ph;
+    uint64_t pool = uint64_t(avg) * pw * ph;
+    if (pool > 0xFFFFFFF0ull) pool = 0xFFFFFFF0ull; // node indices are 32 bit
+    U.ppllLinkedListSize = uint32_t(pool);
+}
+
+int lv_frame_depth_range(lv_ctx* ctx) {
+    LvUniforms U;
+    lv_fill_uniforms(ctx, U);
+    hipStream_t st = ctx->stream;
+    int rc;
+    if ((rc = lv_buf_reserve(ctx, ctx->depthMinMax, 16))) return rc;
+    if ((rc = lv_buf_reserve(ctx, ctx->counters, sizeof(LvDevCounters)))) return rc;
+    LvDevCounters* dc = (LvDevCounters*)ctx->counters.ptr;
+    k_depth_init<<<1, 64, 0, st>>>(U, dc);
+    if (ctx->numPoints)
+        k_depth_minmax<<<nblocks(ctx->numPoints), LV_BLOCK, 0, st>>>(U, (const lv_line_point*)ctx->points.ptr,
+                                                                      ctx->numPoints, dc);
+    k_depth_finalize<<<1, 64, 0, st>>>(dc, (float*)ctx->depthMinMax.ptr);
+    LV_HIP(ctx, hipGetLastError());
+    return LV_OK;
+}
+
+static int lv_run_ao(lv_ctx* ctx, LvUniforms& U, const LvSceneDev& S, const LvTiles& T, uint32_t gridTiles,
+                     uint64_t maxPixels) {
+    hipStream_t st = ctx->stream;
+    LvDevCounters* dc = (LvDevCounters*)ctx->counters.ptr;
+    const uint32_t spp = U.aoSamplesPerFrame;
+    const bool fused = spp <= LV_BLOCK && (LV_BLOCK % spp) == 0;
+    int rc;
+    if ((rc = lv_buf_reserve(ctx, ctx->aoGbuf, size_t(maxPixels) * 48))) return rc;
+    if (!fused && (rc = lv_buf_reserve(ctx, ctx->aoSamples, size_t(maxPixels) * spp * 4))) return rc;
+    const uint64_t maxRays = maxPixels * spp;
+    const bool stats = ctx->opt.collectStats;
+    for (uint32_t iter = 0; iter < ctx->opt.aoIterations; iter++) {
+        U.aoFrameNumber = iter; // rtaoRenderPass->setFrameNumber(accumulatedFramesCounter), VulkanRayTracedAmbientOcclusion.cpp:92
+        LV_HIP(ctx, hipMemsetAsync(&dc->aoCount, 0, 4, st));
+        if (stats)
+            k_ao_primary<true><<<gridTiles, LV_BLOCK, 0, st>>>(U, S, T, (float*)ctx->ao.ptr, (float4*)ctx->aoGbuf.ptr, dc);
+        else
+            k_ao_primary<false><<<gridTiles, LV_BLOCK, 0, st>>>(U, S, T, (float*)ctx->ao.ptr, (float4*)ctx->aoGbuf.ptr, dc);
+        const uint32_t grid = nblocks(maxRays);
+        const float4* g = (const float4*)ctx->aoGbuf.ptr;
+        float* ao = (float*)ctx->ao.ptr;
+        float* smp = (float*)ctx->aoSamples.ptr;
+#define LV_LAUNCH_AO(ST, AH, FU) k_ao_rays<ST, AH, FU><<<grid, LV_BLOCK, 0, st>>>(U, S, g, ao, smp, dc)
+        const bool anyHit = !U.aoUseDistance;
+        if (stats) {
+            if (anyHit) { if (fused) LV_LAUNCH_AO(true, true, true); else LV_LAUNCH_AO(true, true, false); }
+            else { if (fused) LV_LAUNCH_AO(true, false, true); else LV_LAUNCH_AO(true, false, false); }
+        } else {
+            if (anyHit) { if (fused) LV_LAUNCH_AO(false, true, true); else LV_LAUNCH_AO(false, true, false); }
+            else { if (fused) LV_LAUNCH_AO(false, false, true); else LV_LAUNCH_AO(false, false, false); }
+        }
+#undef LV_LAUNCH_AO
+        if (!fused)
+            k_ao_reduce<<<nblocks(maxPixels), LV_BLOCK, 0, st>>>(U, g, smp, ao, dc);
+    }
+    LV_HIP(ctx, hipGetLastError());
+    return LV_OK;
+}
+
+int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t numTiles, uint32_t tileW,
+                    uint32_t tileH, void* outDevice) {
+    if (mode != LV_RENDERING_MODE_VULKAN_RAY_TRACER && mode != LV_RENDERING_MODE_PER_PIXEL_LINKED_LIST)
+        return lv_fail(ctx, LV_E_INVALID, "unsupported rendering mode %d (11 = ray tracer, 2 = PPLL)", mode);
+    if (!ctx->cameraSet) return lv_fail(ctx, LV_E_STATE, "lv_set_camera has not been called");
+    if (!ctx->tf.ptr || ctx->tfN == 0) return lv_fail(ctx, LV_E_STATE, "lv_set_transfer_function has not been called");
+    if (!ctx->points.ptr && ctx->numSegs) return lv_fail(ctx, LV_E_STATE, "lv_set_lines has not been called");
+    if (numTiles == 0 || tileW == 0 || tileH == 0) return lv_fail(ctx, LV_E_INVALID, "empty tile list");
+    int rc;
+    if (!ctx->accelValid || ctx->accelLineWidth != ctx->opt.lineWidth)
+        if ((rc = lv_bvh_build(ctx))) return rc;
+
+    hipStream_t st = ctx->stream;
+    LvUniforms U;
+    lv_fill_uniforms(ctx, U);
+    if ((rc = lv_buf_reserve(ctx, ctx->counters, sizeof(LvDevCounters)))) return rc;
+    if ((rc = lv_buf_reserve(ctx, ctx->depthMinMax, 16))) return rc;
+    if ((rc = lv_buf_reserve(ctx, ctx->tilesDev, size_t(numTiles) * 8))) return rc;
+    if ((rc = lv_buf_reserve(ctx, ctx->ao, size_t(ctx->width) * ctx->height * 4))) return rc;
+    LvDevCounters* dc = (LvDevCounters*)ctx->counters.ptr;
+
+    LV_HIP(ctx, hipEventRecord(ctx->ev[2], st));
+    if (!ctx->tilesHost.empty()) LV_HIP(ctx, hipStreamSynchronize(st)); // previous staging copy may still be in flight
+    ctx->tilesHost.assign(tilesXYHost, tilesXYHost + 2 * size_t(numTiles));
+    LV_HIP(ctx, hipMemcpyAsync(ctx->tilesDev.ptr, ctx->tilesHost.data(), size_t(numTiles) * 8, hipMemcpyHostToDevice, st));
+    LV_HIP(ctx, hipMemsetAsync(dc, 0, sizeof(LvDevCounters), st));
+
+    LvTiles T;
+    T.tilesXY = (const uint32_t*)ctx->tilesDev.ptr;
+    T.numTiles = numTiles;
+    T.tileW = tileW;
+    T.tileH = tileH;
+    T.blocksX = (tileW + 15u) / 16u;
+    T.blocksY = (tileH + 15u) / 16u;
+    const uint64_t nb = uint64_t(numTiles) * T.blocksX * T.blocksY;
+    if (nb > 0x7FFFFFF0ull) return lv_fail(ctx, LV_E_INVALID, "tile list too large");
+    const uint32_t gridTiles = uint32_t((nb + 7u) / 8u) * 8u;
+    const uint64_t maxPixels = uint64_t(numTiles) * tileW * tileH;
+    const bool stats = ctx->opt.collectStats;
+    LvSceneDev S = sceneDev(ctx);
+
+    // LineRenderer::renderBase: depth range, LineRenderer.cpp:248-256
+    LV_HIP(ctx, hipEventRecord(ctx->ev[4], st));
+    if (U.useDepthCues) {
+        k_depth_init<<<1, 64, 0, st>>>(U, dc);
+        if (ctx->numPoints)
+            k_depth_minmax<<<nblocks(ctx->numPoints), LV_BLOCK, 0, st>>>(U, S.points, ctx->numPoints, dc);
+        k_depth_finalize<<<1, 64, 0, st>>>(dc, (float*)ctx->depthMinMax.ptr);
+    }
+    LV_HIP(ctx, hipEventRecord(ctx->ev[5], st));
+
+    // ambientOcclusionBaker->updateIterative(), LineRenderer.cpp:257-264
+    LV_HIP(ctx, hipEventRecord(ctx->ev[6], st));
+    if (U.useAmbientOcclusion)
+        if ((rc = lv_run_ao(ctx, U, S, T, gridTiles, maxPixels))) return rc;
+    LV_HIP(ctx, hipEventRecord(ctx->ev[7], st));
+
+    uint32_t* out = (uint32_t*)outDevice;
+    if (mode == LV_RENDERING_MODE_VULKAN_RAY_TRACER) {
+        LV_HIP(ctx, hipEventRecord(ctx->ev[8], st));
+        if (stats) k_render_rt<true><<<gridTiles, LV_BLOCK, 0, st>>>(U, S, T, out, dc);
+        else k_render_rt<false><<<gridTiles, LV_BLOCK, 0, st>>>(U, S, T, out, dc);
+        LV_HIP(ctx, hipEventRecord(ctx->ev[9], st));
+    } else {
+        // reallocateFragmentBuffer, PerPixelLinkedListLineRenderer.cpp:251-357
+        if ((rc = lv_buf_reserve(ctx, ctx->ppllNodes, size_t(U.ppllLinkedListSize) * 12))) return rc;
+        if ((rc = lv_buf_reserve(ctx, ctx->ppllStart, size_t(U.ppllPaddedW) * U.ppllPaddedH * 4))) return rc;
+        ctx->ppllPoolNodes = U.ppllLinkedListSize;
+        // clear(): LinkedListClear.glsl:46-55 + fragmentCounterBuffer->fill(0)
+        LV_HIP(ctx, hipEventRecord(ctx->ev[10], st));
+        LV_HIP(ctx, hipMemsetAsync(ctx->ppllStart.ptr, 0xFF, size_t(U.ppllPaddedW) * U.ppllPaddedH * 4, st));
+        LV_HIP(ctx, hipMemsetAsync(&dc->fragCounter, 0, 4, st));
+        LV_HIP(ctx, hipEventRecord(ctx->ev[11], st));
+        // gather()
+        LV_HIP(ctx, hipEventRecord(ctx->ev[12], st));
+        if (stats)
+            k_ppll_gather<true><<<gridTiles, LV_BLOCK, 0, st>>>(U, S, T, (uint32_t*)ctx->ppllNodes.ptr,
+                                                                (uint32_t*)ctx->ppllStart.ptr, dc);
+        else
+            k_ppll_gather<false><<<gridTiles, LV_BLOCK, 0, st>>>(U, S, T, (uint32_t*)ctx->ppllNodes.ptr,
+                                                                 (uint32_t*)ctx->ppllStart.ptr, dc);
+        LV_HIP(ctx, hipEventRecord(ctx->ev[13], st));
+        // resolve()
+        LV_HIP(ctx, hipEventRecord(ctx->ev[14], st));
+        const uint32_t gx = (tileW + 7u) / 8u, gy = (tileH + 7u) / 8u;
+        const uint64_t groups64 = uint64_t(numTiles) * gx * gy;
+        const uint32_t numGroups = uint32_t(groups64);
+        const size_t ldsBytes = size_t(U.ppllMaxNumFrags) * LV_WAVE * 8;
+        if (ldsBytes <= 64 * 1024) {
+            k_ppll_resolve<true><<<numGroups, LV_WAVE, ldsBytes, st>>>(U, T, (const uint32_t*)ctx->ppllNodes.ptr,
+                                                                       (const uint32_t*)ctx->ppllStart.ptr, out, nullptr,
+                                                                       numGroups);
+        } else {
+            const uint32_t grid = numGroups < 4096u ? numGroups : 4096u;
+            if ((rc = lv_buf_reserve(ctx, ctx->ppllScratch, size_t(grid) * ldsBytes))) return rc;
+            k_ppll_resolve<false><<<grid, LV_WAVE, 0, st>>>(U, T, (const uint32_t*)ctx->ppllNodes.ptr,
+                                                            (const uint32_t*)ctx->ppllStart.ptr, out,
+                                                            (uint32_t*)ctx->ppllScratch.ptr, numGroups);
+        }
+        LV_HIP(ctx, hipEventRecord(ctx->ev[15], st));
+    }
+    LV_HIP(ctx, hipGetLastError());
+    LV_HIP(ctx, hipEventRecord(ctx->ev[3], st));
+    ctx->evFrameValid = true;
+    ctx->lastMode = mode;
+    return LV_OK;
+}
+
+int lv_frame_trace_rays(lv_ctx* ctx, const float* o, const float* d, float tMin, float tMax, uint32_t n, float* outT,
+                        uint32_t* outSeg, uint32_t* outKind) {
+    int rc;
+    if (!ctx->accelValid || ctx->accelLineWidth != ctx->opt.lineWidth)
+        if ((rc = lv_bvh_build(ctx))) return rc;
+    if (n == 0) return LV_OK;
+    hipStream_t st = ctx->stream;
+    const size_t rb = size_t(n) * 12;
+    if ((rc = lv_buf_reserve(ctx, ctx->scratchRays, 2 * rb + size_t(n) * 12))) return rc;
+    char* base = (char*)ctx->scratchRays.ptr;
+    float* dO = (float*)base;
+    float* dD = (float*)(base + rb);
+    float* dT = (float*)(base + 2 * rb);
+    uint32_t* dS = (uint32_t*)(base + 2 * rb + size_t(n) * 4);
+    uint32_t* dK = (uint32_t*)(base + 2 * rb + size_t(n) * 8);
+    LV_HIP(ctx, hipMemcpyAsync(dO, o, rb, hipMemcpyHostToDevice, st));
+    LV_HIP(ctx, hipMemcpyAsync(dD, d, rb, hipMemcpyHostToDevice, st));
+    LvSceneDev S = sceneDev(ctx);
+    k_trace_rays<<<nblocks(n), LV_BLOCK, 0, st>>>(S, ctx->opt.lineWidth * 0.5f, ctx->opt.useCappedTubes, dO, dD, tMin, tMax,
+                                                  n, dT, dS, dK);
+    LV_HIP(ctx, hipGetLastError());
+    LV_HIP(ctx, hipMemcpyAsync(outT, dT, size_t(n) * 4, hipMemcpyDeviceToHost, st));
+    LV_HIP(ctx, hipMemcpyAsync(outSeg, dS, size_t(n) * 4, hipMemcpyDeviceToHost, st));
+    LV_HIP(ctx, hipMemcpyAsync(outKind, dK, size_t(n) * 4, hipMemcpyDeviceToHost, st));
+    LV_HIP(ctx, hipStreamSynchronize(st));
+    return LV_OK;
+}
+
+int lv_frame_ppll_resolve_only(lv_ctx* ctx, const uint32_t* nodes, uint64_t numNodes, const uint32_t* start,
+                               uint64_t numPixels, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, uint8_t* out) {
+    if (!ctx->cameraSet) return lv_fail(ctx, LV_E_STATE, "lv_set_camera has not been called");
+    LvUniforms U;
+    lv_fill_uniforms(ctx, U);
+    if (numPixels != uint64_t(U.ppllPaddedW) * U.ppllPaddedH)
+        return lv_fail(ctx, LV_E_INVALID, "start_offset must hold padded_w * padded_h = %llu entries",
+                       (unsigned long long)(uint64_t(U.ppllPaddedW) * U.ppllPaddedH));
+    hipStream_t st = ctx->stream;
+    int rc;
+    if ((rc = lv_buf_reserve(ctx, ctx->ppllNodes, size_t(numNodes ? numNodes : 1) * 12))) return rc;
+    if ((rc = lv_buf_reserve(ctx, ctx->ppllStart, size_t(numPixels) * 4))) return rc;
+    if ((rc = lv_buf_reserve(ctx, ctx->tilesDev, 8))) return rc;
+    if ((rc = lv_buf_reserve(ctx, ctx->outDev, size_t(w) * h * 4))) return rc;
+    if (numNodes) LV_HIP(ctx, hipMemcpyAsync(ctx->ppllNodes.ptr, nodes, size_t(numNodes) * 12, hipMemcpyHostToDevice, st));
+    LV_HIP(ctx, hipMemcpyAsync(ctx->ppllStart.ptr, start, size_t(numPixels) * 4, hipMemcpyHostToDevice, st));
+    uint32_t txy[2] = {x0, y0};
+    LV_HIP(ctx, hipMemcpyAsync(ctx->tilesDev.ptr, txy, 8, hipMemcpyHostToDevice, st));
+    LV_HIP(ctx, hipStreamSynchronize(st));
+    LvTiles T;
+    T.tilesXY = (const uint32_t*)ctx->tilesDev.ptr;
+    T.numTiles = 1; T.tileW = w; T.tileH = h;
+    T.blocksX = (w + 15u) / 16u; T.blocksY = (h + 15u) / 16u;
+    const uint32_t numGroups = ((w + 7u) / 8u) * ((h + 7u) / 8u);
+    const size_t ldsBytes = size_t(U.ppllMaxNumFrags) * LV_WAVE * 8;
+    if (ldsBytes <= 64 * 1024) {
+        k_ppll_resolve<true><<<numGroups, LV_WAVE, ldsBytes, st>>>(U, T, (const uint32_t*)ctx->ppllNodes.ptr,
+                                                                   (const uint32_t*)ctx->ppllStart.ptr,
+                                                                   (uint32_t*)ctx->outDev.ptr, nullptr, numGroups);
+    } else {
+        const uint32_t grid = numGroups < 4096u ? numGroups : 4096u;
+        if ((rc = lv_buf_reserve(ctx, ctx->ppllScratch, size_t(grid) * ldsBytes))) return rc;
+        k_ppll_resolve<false><<<grid, LV_WAVE, 0, st>>>(U, T, (const uint32_t*)ctx->ppllNodes.ptr,
+                                                        (const uint32_t*)ctx->ppllStart.ptr, (uint32_t*)ctx->outDev.ptr,
+                                                        (uint32_t*)ctx->ppllScratch.ptr, numGroups);
+    }
+    LV_HIP(ctx, hipGetLastError());
+    LV_HIP(ctx, hipMemcpyAsync(out, ctx->outDev.ptr, size_t(w) * h * 4, hipMemcpyDeviceToHost, st));
+    LV_HIP(ctx, hipStreamSynchronize(st));
+    return LV_OK;
+}

@@ -1,0 +1,393 @@
+// lv_trace.h -- LBVH traversal, ray-capsule intersection and hit shading (device functions).
+//
+// Replaces the VK_KHR_ray_tracing traversal done by the Vulkan driver plus the GLSL programs
+//   IntersectionTube           Data/Shaders/Renderers/RayTracing/TubeRayTracing.glsl:452-494
+//   rayTubeIntersection        Data/Shaders/Renderers/RayTracing/RayIntersectionTestsVulkan.glsl:78-119
+//   raySphereIntersection      Data/Shaders/Renderers/RayTracing/RayIntersectionTestsVulkan.glsl:39-72
+//   ClosestHitTubeAnalytic     Data/Shaders/Renderers/RayTracing/TubeRayTracing.glsl:512-613
+//   computeFragmentColor       Data/Shaders/Renderers/RayTracing/RayHitCommon.glsl:74-543
+//   blinnPhongShadingTube      Data/Shaders/Utils/Lighting.glsl:100-191
+//   transferFunction           Data/Shaders/Utils/TransferFunction.glsl:66-71
+//   getAoFactor                Data/Shaders/Utils/AmbientOcclusion.glsl:84-99
+#pragma once
+
+#include "lv_device.h"
+
+// ---------------------------------------------------------------- ray-capsule
+__device__ __forceinline__ bool lv_ray_sphere(f3 o, f3 d, f3 ctr, float radius, float& hitT) {
+    float A = (d.x * d.x + d.y * d.y) + d.z * d.z;
+    float B = 2.0f * ((d.x * (o.x - ctr.x) + d.y * (o.y - ctr.y)) + d.z * (o.z - ctr.z));
+    float C = (((o.x - ctr.x) * (o.x - ctr.x) + (o.y - ctr.y) * (o.y - ctr.y)) + (o.z - ctr.z) * (o.z - ctr.z))
+              - radius * radius;
+    float disc = B * B - (4.0f * A) * C;
+    if (disc < 0.0f) return false;
+    float ds = sqrtf(disc);
+    float t0 = (-B - ds) / (2.0f * A);
+    float t1 = (-B + ds) / (2.0f * A);
+    hitT = t0;
+    if (t0 >= 0.0f) hitT = t0;
+    else if (t1 >= 0.0f) hitT = t1;
+    else return false;
+    return true;
+}
+
+__device__ __forceinline__ bool lv_ray_tube(f3 o, f3 d, f3 tubeStart, f3 tubeEnd, float radius, float& hitT) {
+    f3 td = norm3(tubeEnd - tubeStart);
+    f3 deltaP = o - tubeStart;
+    f3 av = d - dot3(d, td) * td;
+    f3 cv = deltaP - dot3(deltaP, td) * td;
+    float A = (av.x * av.x + av.y * av.y) + av.z * av.z;
+    float B = 2.0f * dot3(av, cv);
+    float C = ((cv.x * cv.x + cv.y * cv.y) + cv.z * cv.z) - radius * radius;
+    float disc = B * B - (4.0f * A) * C;
+    if (disc < 0.0f) return false;
+    float ds = sqrtf(disc);
+    float t0 = (-B - ds) / (2.0f * A);
+    if (t0 >= 0.0f) {
+        f3 ip = o + t0 * d;
+        if (dot3(td, ip - tubeStart) > 0.0f && dot3(td, ip - tubeEnd) < 0.0f) { hitT = t0; return true; }
+    }
+    float t1 = (-B + ds) / (2.0f * A);
+    if (t1 >= 0.0f) {
+        f3 ip = o + t1 * d;
+        if (dot3(td, ip - tubeStart) > 0.0f && dot3(td, ip - tubeEnd) < 0.0f) { hitT = t1; return true; }
+    }
+    return false;
+}
+
+// IntersectionTube main(): nearest of {cylinder, sphere(p0), sphere(p1)}; kind 0/1/2
+__device__ __forceinline__ bool lv_intersect_capsule(f3 o, f3 d, f3 p0, f3 p1, float radius, bool capped,
+                                                     float& hitTOut, int& kindOut) {
+    bool has = false;
+    float hitT = 1e7f;
+    int kind = 0;
+    float tubeT;
+    if (lv_ray_tube(o, d, p0, p1, radius, tubeT)) { hitT = tubeT; has = true; kind = 0; }
+    if (capped) {
+        float s0T, s1T;
+        bool h0 = lv_ray_sphere(o, d, p0, radius, s0T);
+        bool h1 = lv_ray_sphere(o, d, p1, radius, s1T);
+        if (h0 && s0T < hitT) { has = true; hitT = s0T; kind = 1; }
+        if (h1 && s1T < hitT) { has = true; hitT = s1T; kind = 2; }
+    }
+    hitTOut = hitT;
+    kindOut = kind;
+    return has;
+}
+
+// ---------------------------------------------------------------- traversal stack: LDS-staged, scratch overflow
+struct LvStack {
+    unsigned* lds;                      // &s_stack[threadIdx], entries strided by LV_BLOCK (conflict-free)
+    unsigned spill[LV_STACK_SPILL];
+    int sp;
+    __device__ __forceinline__ void init(unsigned* base) { lds = base; sp = 0; }
+    __device__ __forceinline__ void push(unsigned v) {
+        if (sp < LV_STACK_LDS) lds[sp * LV_BLOCK] = v; else spill[sp - LV_STACK_LDS] = v;
+        sp++;
+    }
+    __device__ __forceinline__ unsigned pop() {
+        sp--;
+        return sp < LV_STACK_LDS ? lds[sp * LV_BLOCK] : spill[sp - LV_STACK_LDS];
+    }
+};
+
+// slab test of one child box against the ray; conservative acceptance (boxes are padded at build time)
+__device__ __forceinline__ bool lv_slab(float bx0, float by0, float bz0, float bx1, float by1, float bz1, f3 o, f3 inv,
+                                        float tMin, float tMax, float& tNear) {
+    float tx0 = (bx0 - o.x) * inv.x, tx1 = (bx1 - o.x) * inv.x;
+    float ty0 = (by0 - o.y) * inv.y, ty1 = (by1 - o.y) * inv.y;
+    float tz0 = (bz0 - o.z) * inv.z, tz1 = (bz1 - o.z) * inv.z;
+    float tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), tMin));
+    float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), tMax));
+    tNear = tn;
+    return tn <= tf * 1.0000005f + 1e-7f;
+}
+
+struct LvHit {
+    float t;
+    uint32_t leaf; // leaf position (Morton order)
+    int kind;
+    bool found;
+};
+
+// Closest hit with reportIntersectionEXT semantics: accepted iff tMin <= t <= tMax; ties -> lowest original
+// segment index.  ANY_HIT: return at the first accepted hit (gl_RayFlagsTerminateOnFirstHitEXT).
+template <bool STATS, bool ANY_HIT>
+__device__ __forceinline__ LvHit lv_trace_closest(const LvSceneDev& S, float radius, bool capped, f3 o, f3 d, float tMin,
+                                                  float tMax, unsigned* ldsStack, LvCounters& cnt) {
+    LvHit h;
+    h.t = tMax; h.leaf = LV_INVALID; h.kind = 0; h.found = false;
+    if (STATS) cnt.rays++;
+    if (S.numSegs == 0) return h;
+    const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    LvStack st;
+    st.init(ldsStack);
+    unsigned node = 0;
+    while (true) {
+        const float4 q0 = S.nodes[4 * node + 0];
+        const float4 q1 = S.nodes[4 * node + 1];
+        const float4 q2 = S.nodes[4 * node + 2];
+        const float4 q3 = S.nodes[4 * node + 3];
+        if (STATS) cnt.nodes++;
+        const unsigned c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
+        float tn0, tn1;
+        bool hit0 = lv_slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, inv, tMin, h.t, tn0);
+        bool hit1 = lv_slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, inv, tMin, h.t, tn1) && (c1 != LV_INVALID);
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const unsigned c = k == 0 ? c0 : c1;
+            const bool hk = k == 0 ? hit0 : hit1;
+            if (hk && (c & LV_LEAF_BIT)) {
+                const unsigned leaf = c & ~LV_LEAF_BIT;
+                const float4 a = S.segs[2 * leaf], b = S.segs[2 * leaf + 1];
+                if (STATS) cnt.prims++;
+                float t; int kind;
+                if (lv_intersect_capsule(o, d, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), radius, capped, t, kind)) {
+                    if (t >= tMin && t <= tMax) {
+                        bool take = !h.found || t < h.t;
+                        if (!take && t == h.t) take = S.leafSeg[leaf] < S.leafSeg[h.leaf];
+                        if (take) { h.found = true; h.t = t; h.leaf = leaf; h.kind = kind; }
+                    }
+                }
+            }
+        }
+        if (ANY_HIT && h.found) return h;
+        const bool in0 = hit0 && !(c0 & LV_LEAF_BIT);
+        const bool in1 = hit1 && !(c1 & LV_LEAF_BIT);
+        if (in0 && in1) {
+            const bool swap = tn1 < tn0;
+            st.push(swap ? c0 : c1);
+            node = swap ? c1 : c0;
+        } else if (in0) {
+            node = c0;
+        } else if (in1) {
+            node = c1;
+        } else {
+            if (st.sp == 0) break;
+            node = st.pop();
+        }
+    }
+    return h;
+}
+
+// All capsule entry hits in [tMin, tMax] (PPLL fragment generation); f(leaf, t, kind) per hit.
+template <bool STATS, typename F>
+__device__ __forceinline__ void lv_trace_all(const LvSceneDev& S, float radius, bool capped, f3 o, f3 d, float tMin,
+                                             float tMax, unsigned* ldsStack, LvCounters& cnt, F&& f) {
+    if (STATS) cnt.rays++;
+    if (S.numSegs == 0) return;
+    const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    LvStack st;
+    st.init(ldsStack);
+    unsigned node = 0;
+    while (true) {
+        const float4 q0 = S.nodes[4 * node + 0];
+        const float4 q1 = S.nodes[4 * node + 1];
+        const float4 q2 = S.nodes[4 * node + 2];
+        const float4 q3 = S.nodes[4 * node + 3];
+        if (STATS) cnt.nodes++;
+        const unsigned c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
+        float tn0, tn1;
+        bool hit0 = lv_slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, inv, tMin, tMax, tn0);
+        bool hit1 = lv_slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, inv, tMin, tMax, tn1) && (c1 != LV_INVALID);
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const unsigned c = k == 0 ? c0 : c1;
+            const bool hk = k == 0 ? hit0 : hit1;
+            if (hk && (c & LV_LEAF_BIT)) {
+                const unsigned leaf = c & ~LV_LEAF_BIT;
+                const float4 a = S.segs[2 * leaf], b = S.segs[2 * leaf + 1];
+                if (STATS) cnt.prims++;
+                float t; int kind;
+                if (lv_intersect_capsule(o, d, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), radius, capped, t, kind)) {
+                    if (t >= tMin && t <= tMax) f(leaf, t, kind);
+                }
+            }
+        }
+        const bool in0 = hit0 && !(c0 & LV_LEAF_BIT);
+        const bool in1 = hit1 && !(c1 & LV_LEAF_BIT);
+        if (in0 && in1) {
+            st.push(c1);
+            node = c0;
+        } else if (in0) {
+            node = c0;
+        } else if (in1) {
+            node = c1;
+        } else {
+            if (st.sp == 0) break;
+            node = st.pop();
+        }
+    }
+}
+
+// ---------------------------------------------------------------- ray generation, TubeRayTracing.glsl:219-226
+__device__ __forceinline__ void lv_primary_ray(const LvUniforms& U, uint32_t x, uint32_t y, float xix, float xiy, f3& o,
+                                               f3& d) {
+    float ndcx = 2.0f * ((float(x) + xix) / float(U.width)) - 1.0f;
+    float ndcy = 2.0f * ((float(y) + xiy) / float(U.height)) - 1.0f;
+    f4 target = mulM4(U.invProj, ndcx, ndcy, 1.0f, 1.0f);
+    f3 tn = norm3(mk3(target.x, target.y, target.z));
+    f4 dir = mulM4(U.invView, tn.x, tn.y, tn.z, 0.0f);
+    o = mk3(U.camPos[0], U.camPos[1], U.camPos[2]);
+    d = mk3(dir.x, dir.y, dir.z);
+}
+
+// ---------------------------------------------------------------- shading
+__device__ __forceinline__ f4 lv_transfer_function(const LvSceneDev& S, const LvUniforms& U, float attr) {
+    float pos = clampf((attr - U.attrMin) / (U.attrMax - U.attrMin), 0.0f, 1.0f);
+    int n = int(U.tfN);
+    float u = pos * float(n) - 0.5f;
+    float fl = floorf(u);
+    float f = u - fl;
+    int i0 = int(fl), i1 = i0 + 1;
+    i0 = min(max(i0, 0), n - 1);
+    i1 = min(max(i1, 0), n - 1);
+    float4 c0 = S.tf[i0], c1 = S.tf[i1];
+    f4 r;
+    r.x = c0.x * (1.0f - f) + c1.x * f;
+    r.y = c0.y * (1.0f - f) + c1.y * f;
+    r.z = c0.z * (1.0f - f) + c1.z * f;
+    r.w = c0.w * (1.0f - f) + c1.w * f;
+    return r;
+}
+
+// ClosestHitTubeAnalytic + computeFragmentColor + blinnPhongShadingTube for flow lines.
+// aoTexel: AO factor of the pixel that launched the ray (lookup definition: DESIGN.md).  Returns payload.hitColor;
+// payloadHitT = length(hit - camera).
+__device__ __forceinline__ f4 lv_shade_hit(const LvSceneDev& S, const LvUniforms& U, float aoTexel, f3 o, f3 d,
+                                           const LvHit& h, float& payloadHitT) {
+    const float4 ra = S.segs[2 * h.leaf], rb = S.segs[2 * h.leaf + 1];
+    const f3 P0 = mk3(ra.x, ra.y, ra.z), P1 = mk3(rb.x, rb.y, rb.z);
+    const f3 cam = mk3(U.camPos[0], U.camPos[1], U.camPos[2]);
+    f3 fragPos = o + d * h.t;
+    f3 linePointInterpolated;
+    float fragmentAttribute;
+    f3 v = P1 - P0;
+    if (h.kind == 0) {
+        f3 u = fragPos - P0;
+        float t = dot3(v, u) / dot3(v, v);
+        linePointInterpolated = P0 + t * v;
+        fragmentAttribute = (1.0f - t) * ra.w + t * rb.w;
+    } else if (h.kind == 1) {
+        linePointInterpolated = P0;
+        fragmentAttribute = ra.w;
+    } else {
+        linePointInterpolated = P1;
+        fragmentAttribute = rb.w;
+    }
+    f3 fragmentTangent = norm3(v);
+    f3 fragmentNormal = norm3(fragPos - linePointInterpolated);
+    const bool isCap = h.kind != 0;
+
+    f4 fragmentColor = lv_transfer_function(S, U, fragmentAttribute);
+    f3 n = norm3(fragmentNormal);
+    f3 vv = norm3(cam - fragPos);
+    f3 t = norm3(fragmentTangent);
+    f3 helperVec = norm3(cross3(t, vv));
+    f3 newV = norm3(cross3(helperVec, t));
+
+    float ribbonPosition = 0.0f;
+    if (U.useHalos) {
+        if (U.useCappedTubes && isCap) {
+            f3 crossProdVn = cross3(vv, n);
+            ribbonPosition = len3(crossProdVn);
+            f3 crossProdVn2 = cross3(newV, n);
+            float ribbonPosition2 = len3(crossProdVn2);
+            if (dot3(t, crossProdVn) < 0.0f) ribbonPosition2 = -ribbonPosition2;
+            if (dot3(t, crossProdVn) < 0.0f) ribbonPosition = -ribbonPosition;
+            ribbonPosition2 = clampf(ribbonPosition2, -1.0f, 1.0f);
+            if (fabsf(ribbonPosition2) < fabsf(ribbonPosition)) ribbonPosition = ribbonPosition2;
+        } else {
+            f3 crossProdVn = cross3(newV, n);
+            ribbonPosition = len3(crossProdVn);
+            if (dot3(t, crossProdVn) < 0.0f) ribbonPosition = -ribbonPosition;
+            ribbonPosition = clampf(ribbonPosition, -1.0f, 1.0f);
+        }
+    }
+
+    // blinnPhongShadingTube
+    float kA, kD;
+    const float kS = 0.3f, s = 30.0f;
+    float aoF = 1.0f;
+    if (U.useAmbientOcclusion) {
+        float a = powf(aoTexel, U.aoGamma);
+        aoF = fmaxf(0.0f, (1.0f - U.aoStrength) + U.aoStrength * a);
+        kA = 0.2f + (1.0f - aoF) * 0.5f;
+        kD = 0.9f * aoF;
+    } else {
+        kA = 0.1f;
+        kD = 0.9f;
+    }
+    // blinnPhongShadingTube re-normalises its (already unit) arguments, Lighting.glsl:149-151
+    const f3 nB = norm3(n);
+    const f3 tB = norm3(t);
+    f3 l = vv;
+    f3 hh = norm3(vv + l);
+    f3 helperVecL = norm3(cross3(tB, l));
+    f3 newL = norm3(cross3(helperVecL, tB));
+    const float exponent = 1.7f;
+    float cosNormal1 = powf(clampf(fabsf(dot3(nB, l)), 0.0f, 1.0f), exponent);
+    float cosNormal2 = powf(clampf(fabsf(dot3(nB, newL)), 0.0f, 1.0f), exponent);
+    float cosNormalCombined = 0.3f * cosNormal1 + 0.7f * cosNormal2;
+    float spec = kS * powf(clampf(fabsf(dot3(nB, hh)), 0.0f, 1.0f), s);
+    float base[3] = {fragmentColor.x, fragmentColor.y, fragmentColor.z};
+    float phong[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        float Ia = kA * base[k];
+        float Id = (kD * cosNormalCombined) * base[k];
+        float Is = spec * 1.0f;
+        phong[k] = (Ia + Id) + Is;
+    }
+    if (U.useAmbientOcclusion) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) phong[k] *= aoF;
+    }
+    if (U.useDepthCues) {
+        f4 s4 = mulM4(U.view, fragPos.x, fragPos.y, fragPos.z, 1.0f);
+        float minDepth = S.depthMinMax[0], maxDepth = S.depthMinMax[1];
+        float dcf = clampf((-s4.z - minDepth) / (maxDepth - minDepth), 0.0f, 1.0f);
+        dcf = (dcf * dcf) * U.depthCueStrength;
+#pragma unroll
+        for (int k = 0; k < 3; k++) phong[k] = mixf(phong[k], 0.5f, dcf);
+    }
+
+    float absCoords = U.useHalos ? fabsf(ribbonPosition) : 0.0f;
+    float fragmentDepth = len3(fragPos - cam);
+    float aaO = ((fragmentDepth / U.lineWidth) * 0.05f) / float(U.height) * U.fovY;
+    float aaW = ((fragmentDepth / U.lineWidth) * 2.0f) / float(U.height) * U.fovY;
+    float EPSILON_OUTLINE = clampf(aaO, 0.0f, 0.49f);
+    float EPSILON_WHITE = clampf(aaW, 0.0f, 0.49f);
+    const float WHITE_THRESHOLD = 0.7f;
+    float coverage = U.useHalos ? 1.0f - smoothstepf(1.0f - EPSILON_OUTLINE, 1.0f, absCoords) : 1.0f;
+    float w = smoothstepf(WHITE_THRESHOLD - EPSILON_WHITE, WHITE_THRESHOLD + EPSILON_WHITE, absCoords);
+    f4 out;
+    out.x = mixf(phong[0], U.foreground[0], w);
+    out.y = mixf(phong[1], U.foreground[1], w);
+    out.z = mixf(phong[2], U.foreground[2], w);
+    out.w = fragmentColor.w * coverage;
+    payloadHitT = len3(fragPos - cam);
+    return out;
+}
+
+__device__ __forceinline__ uint32_t lv_unorm8(float c) { return uint32_t(floorf(clampf(c, 0.0f, 1.0f) * 255.0f + 0.5f)); }
+__device__ __forceinline__ uint32_t lv_pack_unorm4x8(f4 c) {
+    return lv_unorm8(c.x) | (lv_unorm8(c.y) << 8) | (lv_unorm8(c.z) << 16) | (lv_unorm8(c.w) << 24);
+}
+__device__ __forceinline__ f4 lv_unpack_unorm4x8(uint32_t p) {
+    f4 c;
+    c.x = float(p & 0xFFu) / 255.0f;
+    c.y = float((p >> 8) & 0xFFu) / 255.0f;
+    c.z = float((p >> 16) & 0xFFu) / 255.0f;
+    c.w = float((p >> 24) & 0xFFu) / 255.0f;
+    return c;
+}
+
+// TiledAddress.glsl:53-85
+__device__ __forceinline__ uint32_t lv_ppll_addr(uint32_t x, uint32_t y, uint32_t paddedW, uint32_t tileW, uint32_t tileH) {
+    if (tileW == 1 && tileH == 1) return x + paddedW * y;
+    uint32_t surfaceWidth = paddedW / tileW;
+    uint32_t tileAddr1D = (x / tileW + surfaceWidth * (y / tileH)) * (tileW * tileH);
+    uint32_t pixelAddr1D = (x & (tileW - 1)) + (y & (tileH - 1)) * tileW;
+    return tileAddr1D | pixelAddr1D;
+}

@@ -1,0 +1,1089 @@
+/*
+ * lv_oracle.cpp -- CPU ORACLE: restatement of the LineVis GLSL hot path.
+ *
+ * TEST INFRASTRUCTURE, NOT PRODUCT (see lv_oracle.h).  PARITY UNPINNED: the
+ * reference cannot be built in this image and holds no golden vectors for this
+ * path; this file follows the cited GLSL / C++ lines literally and its outputs
+ * are committed under tests/golden/ as regression pins.
+ *
+ * All paths are relative to /root/reference.  Arithmetic is float32 with a
+ * fixed evaluation order (compile with -ffp-contract=off): +,-,*,/,sqrt are
+ * IEEE-exact on host and device, so hits (t, segment, kind) are bit-comparable
+ * with the HIP path; only pow() in shading goes through libm.
+ *
+ * Definitions owned by the build because they live in un-vendored sgl / the
+ * Vulkan driver: camera conventions (right-handed view,
+ * depth 0..1, row 0 = top via a y-flipped projection), transfer-function
+ * texture (N texels, linear filter, texel centres (i+0.5)/N, clamp-to-edge),
+ * AO texture lookup (nearest texel), RGBA8 rounding floor(x*255+0.5), the BVH
+ * (ties -> lowest segment index), AO geometry (analytic capsules instead of
+ * the 6-gon triangle tubes), PPLL fragment source (entry hits of pixel-centre
+ * rays against capsules) and PPLL tie order ((depth, colour) key).
+ */
+#include "lv_oracle.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+namespace {
+
+// ---------------------------------------------------------------- vector helpers (fixed evaluation order)
+struct V3 { float x, y, z; };
+struct V4 { float x, y, z, w; };
+
+inline V3 v3(float x, float y, float z) { return V3{x, y, z}; }
+inline V3 operator+(V3 a, V3 b) { return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline V3 operator-(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline V3 operator*(V3 a, float s) { return V3{a.x * s, a.y * s, a.z * s}; }
+inline V3 operator*(float s, V3 a) { return V3{s * a.x, s * a.y, s * a.z}; }
+inline float dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+// GLSL cross(x, y) = (x1*y2 - y1*x2, x2*y0 - y2*x0, x0*y1 - y0*x1)
+inline V3 cross(V3 a, V3 b) { return V3{a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y}; }
+inline float length(V3 a) { return sqrtf(dot(a, a)); }
+inline V3 normalize(V3 a) { float l = length(a); return V3{a.x / l, a.y / l, a.z / l}; }
+inline float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+inline float mixf(float a, float b, float w) { return a * (1.0f - w) + b * w; }
+inline float smoothstepf(float e0, float e1, float x) {
+    float t = clampf((x - e0) / (e1 - e0), 0.0f, 1.0f);
+    return t * t * (3.0f - 2.0f * t);
+}
+inline V3 ld3(const float* p) { return V3{p[0], p[1], p[2]}; }
+
+// column-major mat4 * vec4, sum over columns left to right
+inline V4 mulM4(const float* m, V4 v) {
+    V4 r;
+    r.x = ((m[0] * v.x + m[4] * v.y) + m[8] * v.z) + m[12] * v.w;
+    r.y = ((m[1] * v.x + m[5] * v.y) + m[9] * v.z) + m[13] * v.w;
+    r.z = ((m[2] * v.x + m[6] * v.y) + m[10] * v.z) + m[14] * v.w;
+    r.w = ((m[3] * v.x + m[7] * v.y) + m[11] * v.z) + m[15] * v.w;
+    return r;
+}
+
+// ---------------------------------------------------------------- RNG, RayTracingUtilities.glsl:134-181
+inline uint32_t tea(uint32_t val0, uint32_t val1) {
+    uint32_t v0 = val0, v1 = val1, s0 = 0;
+    for (uint32_t n = 0; n < 16; n++) {
+        s0 += 0x9e3779b9u;
+        v0 += ((v1 << 4) + 0xa341316cu) ^ (v1 + s0) ^ ((v1 >> 5) + 0xc8013ea4u);
+        v1 += ((v0 << 4) + 0xad90777du) ^ (v0 + s0) ^ ((v0 >> 5) + 0x7e95761eu);
+    }
+    return v0;
+}
+inline uint32_t lcg(uint32_t& prev) {
+    prev = 1664525u * prev + 1013904223u;
+    return prev & 0x00FFFFFFu;
+}
+inline float rnd(uint32_t& seed) { return float(lcg(seed)) / float(0x01000000); }
+
+// sin/cos(2*pi*xi), xi in [0,1).  GLSL sin/cos precision is implementation defined (Vulkan allows
+// 2^-11 abs error); the build defines them by this fixed polynomial so that AO ray directions are
+// bit-identical on host and device.  Quadrant reduction on xi is exact (power-of-two scaling).
+inline void sincos2pi(float xi, float& s, float& c) {
+    float q = xi * 4.0f;
+    float fq = floorf(q);
+    int quad = int(fq) & 3;
+    float r = q - fq;                 // [0,1) exact
+    bool swap = r > 0.5f;
+    float rr = swap ? (1.0f - r) : r; // [0,0.5] exact
+    float a = rr * 1.57079632679489662f;
+    float a2 = a * a;
+    float sp = a * (1.0f + a2 * (-1.0f / 6.0f + a2 * (1.0f / 120.0f + a2 * (-1.0f / 5040.0f + a2 * (1.0f / 362880.0f)))));
+    float cp = 1.0f + a2 * (-0.5f + a2 * (1.0f / 24.0f + a2 * (-1.0f / 720.0f + a2 * (1.0f / 40320.0f + a2 * (-1.0f / 3628800.0f)))));
+    float sa = swap ? cp : sp;        // sin/cos of r*pi/2
+    float ca = swap ? sp : cp;
+    switch (quad) {
+        case 0: s = sa; c = ca; break;
+        case 1: s = ca; c = -sa; break;
+        case 2: s = -sa; c = -ca; break;
+        default: s = -ca; c = sa; break;
+    }
+}
+
+// ---------------------------------------------------------------- intersection tests
+// RayIntersectionTestsVulkan.glsl:39-72
+inline bool raySphereIntersection(V3 o, V3 d, V3 ctr, float radius, float& hitT) {
+    float A = (d.x * d.x + d.y * d.y) + d.z * d.z;
+    float B = 2.0f * ((d.x * (o.x - ctr.x) + d.y * (o.y - ctr.y)) + d.z * (o.z - ctr.z));
+    float C = (((o.x - ctr.x) * (o.x - ctr.x) + (o.y - ctr.y) * (o.y - ctr.y)) + (o.z - ctr.z) * (o.z - ctr.z))
+              - radius * radius;
+    float discriminant = B * B - (4.0f * A) * C;
+    if (discriminant < 0.0f) return false;
+    float ds = sqrtf(discriminant);
+    float t0 = (-B - ds) / (2.0f * A);
+    float t1 = (-B + ds) / (2.0f * A);
+    hitT = t0;
+    if (t0 >= 0.0f) hitT = t0;
+    else if (t1 >= 0.0f) hitT = t1;
+    else return false;
+    return true;
+}
+
+// RayIntersectionTestsVulkan.glsl:78-119
+inline bool rayTubeIntersection(V3 o, V3 d, V3 tubeStart, V3 tubeEnd, float radius, float& hitT) {
+    V3 tubeDirection = normalize(tubeEnd - tubeStart);
+    V3 deltaP = o - tubeStart;
+    V3 av = d - dot(d, tubeDirection) * tubeDirection;
+    V3 cv = deltaP - dot(deltaP, tubeDirection) * tubeDirection;
+    float A = (av.x * av.x + av.y * av.y) + av.z * av.z;
+    float B = 2.0f * dot(av, cv);
+    float C = ((cv.x * cv.x + cv.y * cv.y) + cv.z * cv.z) - radius * radius;
+    float discriminant = B * B - (4.0f * A) * C;
+    if (discriminant < 0.0f) return false;
+    float ds = sqrtf(discriminant);
+    float t0 = (-B - ds) / (2.0f * A);
+    if (t0 >= 0.0f) {
+        V3 ip = o + t0 * d;
+        if (dot(tubeDirection, ip - tubeStart) > 0.0f && dot(tubeDirection, ip - tubeEnd) < 0.0f) {
+            hitT = t0;
+            return true;
+        }
+    }
+    float t1 = (-B + ds) / (2.0f * A);
+    if (t1 >= 0.0f) {
+        V3 ip = o + t1 * d;
+        if (dot(tubeDirection, ip - tubeStart) > 0.0f && dot(tubeDirection, ip - tubeEnd) < 0.0f) {
+            hitT = t1;
+            return true;
+        }
+    }
+    return false;
+}
+
+// IntersectionTube main(), TubeRayTracing.glsl:452-494
+inline bool intersectCapsule(V3 o, V3 d, V3 p0, V3 p1, float radius, bool capped, float& hitTOut, int& hitKindOut) {
+    bool hasIntersection = false;
+    float hitT = 1e7f;
+    int hitKind = 0;
+    float tubeT, s0T, s1T;
+    if (rayTubeIntersection(o, d, p0, p1, radius, tubeT)) {
+        hitT = tubeT;
+        hasIntersection = true;
+        hitKind = 0;
+    }
+    if (capped) {
+        bool h0 = raySphereIntersection(o, d, p0, radius, s0T);
+        bool h1 = raySphereIntersection(o, d, p1, radius, s1T);
+        if (h0 && s0T < hitT) { hasIntersection = true; hitT = s0T; hitKind = 1; }
+        if (h1 && s1T < hitT) { hasIntersection = true; hitT = s1T; hitKind = 2; }
+    }
+    hitTOut = hitT;
+    hitKindOut = hitKind;
+    return hasIntersection;
+}
+
+// ---------------------------------------------------------------- scene + CPU LBVH
+struct BvhNode {
+    float bmin[3], bmax[3];
+    int32_t left, right; // >=0: internal node index; <0: leaf, segment = ~value
+};
+
+struct Counters { uint64_t rays = 0, nodes = 0, prims = 0, hits = 0; };
+
+} // namespace
+
+struct lvo_scene {
+    std::vector<lvo_line_point> pts;
+    std::vector<uint32_t> segIdx;
+    uint32_t nSeg = 0;
+    std::vector<float> tf; // rgba * n
+    uint32_t tfN = 0;
+    std::vector<BvhNode> nodes;
+    int32_t root = -1; // may be a leaf reference (<0 encoded) when nSeg == 1
+    bool rootIsLeaf = false;
+    uint32_t bvhDepth = 0;
+    float bvhLineWidth = -1.0f;
+};
+
+namespace {
+
+inline void segPoints(const lvo_scene& sc, uint32_t seg, V3& p0, V3& p1) {
+    p0 = ld3(sc.pts[sc.segIdx[2 * seg]].linePosition);
+    p1 = ld3(sc.pts[sc.segIdx[2 * seg + 1]].linePosition);
+}
+
+inline uint64_t expandBits21(uint64_t v) {
+    v &= 0x1fffffull;
+    v = (v | v << 32) & 0x1f00000000ffffull;
+    v = (v | v << 16) & 0x1f0000ff0000ffull;
+    v = (v | v << 8) & 0x100f00f00f00f00full;
+    v = (v | v << 4) & 0x10c30c30c30c30c3ull;
+    v = (v | v << 2) & 0x1249249249249249ull;
+    return v;
+}
+
+struct SegBox { float mn[3], mx[3]; };
+
+int32_t buildRange(lvo_scene& sc, const std::vector<uint64_t>& keys, const std::vector<uint32_t>& order,
+                   const std::vector<SegBox>& boxes, uint32_t lo, uint32_t hi, uint32_t depth, uint32_t& maxDepth) {
+    if (depth > maxDepth) maxDepth = depth;
+    if (hi - lo == 1) return ~int32_t(order[lo]);
+    uint64_t first = keys[lo], last = keys[hi - 1];
+    uint32_t split;
+    if (first == last) {
+        split = (lo + hi) / 2;
+    } else {
+        int commonPrefix = __builtin_clzll(first ^ last);
+        // largest index in [lo, hi-1) whose key shares more than commonPrefix bits with first
+        uint32_t a = lo, b = hi - 1;
+        while (b - a > 1) {
+            uint32_t mid = (a + b) / 2;
+            uint64_t x = first ^ keys[mid];
+            int pre = x == 0 ? 64 : __builtin_clzll(x);
+            if (pre > commonPrefix) a = mid; else b = mid;
+        }
+        split = a + 1;
+    }
+    int32_t idx = int32_t(sc.nodes.size());
+    sc.nodes.push_back(BvhNode{});
+    int32_t l = buildRange(sc, keys, order, boxes, lo, split, depth + 1, maxDepth);
+    int32_t r = buildRange(sc, keys, order, boxes, split, hi, depth + 1, maxDepth);
+    BvhNode nd;
+    nd.left = l; nd.right = r;
+    for (int k = 0; k < 3; k++) { nd.bmin[k] = 3.0e38f; nd.bmax[k] = -3.0e38f; }
+    auto merge = [&](int32_t c) {
+        const float *mn, *mx;
+        if (c < 0) { mn = boxes[~c].mn; mx = boxes[~c].mx; }
+        else { mn = sc.nodes[c].bmin; mx = sc.nodes[c].bmax; }
+        for (int k = 0; k < 3; k++) { nd.bmin[k] = fminf(nd.bmin[k], mn[k]); nd.bmax[k] = fmaxf(nd.bmax[k], mx[k]); }
+    };
+    merge(l); merge(r);
+    sc.nodes[idx] = nd;
+    return idx;
+}
+
+// conservative slab test (boxes are padded at build time)
+inline bool rayBox(const float* bmin, const float* bmax, V3 o, V3 inv, float tMin, float tMax) {
+    float tx0 = (bmin[0] - o.x) * inv.x, tx1 = (bmax[0] - o.x) * inv.x;
+    float ty0 = (bmin[1] - o.y) * inv.y, ty1 = (bmax[1] - o.y) * inv.y;
+    float tz0 = (bmin[2] - o.z) * inv.z, tz1 = (bmax[2] - o.z) * inv.z;
+    float tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), tMin));
+    float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), tMax));
+    return tn <= tf * 1.0000005f + 1e-7f;
+}
+
+struct Hit { float t; uint32_t seg; int kind; };
+
+// Closest hit over all capsules, hit accepted iff tMin <= t <= tMax (reportIntersectionEXT semantics),
+// ties -> lowest segment index (the driver's tie order is arbitrary).
+inline bool closestHit(const lvo_scene& sc, float radius, bool capped, bool useBvh, V3 o, V3 d, float tMin, float tMax,
+                       Hit& out, Counters& cnt) {
+    cnt.rays++;
+    bool found = false;
+    float best = tMax;
+    uint32_t bestSeg = 0xFFFFFFFFu;
+    int bestKind = 0;
+    auto testSeg = [&](uint32_t seg) {
+        cnt.prims++;
+        V3 p0, p1; segPoints(sc, seg, p0, p1);
+        float t; int kind;
+        if (intersectCapsule(o, d, p0, p1, radius, capped, t, kind)) {
+            if (t >= tMin && t <= tMax && (!found || t < best || (t == best && seg < bestSeg))) {
+                found = true; best = t; bestSeg = seg; bestKind = kind;
+            }
+        }
+    };
+    if (!useBvh || sc.root == -1) {
+        for (uint32_t seg = 0; seg < sc.nSeg; seg++) testSeg(seg);
+    } else if (sc.rootIsLeaf) {
+        testSeg(uint32_t(~sc.root));
+    } else {
+        V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+        int32_t stack[128];
+        int sp = 0;
+        stack[sp++] = sc.root;
+        while (sp > 0) {
+            int32_t n = stack[--sp];
+            if (n < 0) { testSeg(uint32_t(~n)); continue; }
+            const BvhNode& nd = sc.nodes[n];
+            cnt.nodes++;
+            if (!rayBox(nd.bmin, nd.bmax, o, inv, tMin, found ? best : tMax)) continue;
+            stack[sp++] = nd.right;
+            stack[sp++] = nd.left;
+        }
+    }
+    out.t = best; out.seg = bestSeg; out.kind = bestKind;
+    return found;
+}
+
+// All capsule entry hits in [tMin, tMax], ascending segment order.
+inline void allHits(const lvo_scene& sc, float radius, bool capped, bool useBvh, V3 o, V3 d, float tMin, float tMax,
+                    std::vector<Hit>& out, Counters& cnt) {
+    cnt.rays++;
+    out.clear();
+    auto testSeg = [&](uint32_t seg) {
+        cnt.prims++;
+        V3 p0, p1; segPoints(sc, seg, p0, p1);
+        float t; int kind;
+        if (intersectCapsule(o, d, p0, p1, radius, capped, t, kind)) {
+            if (t >= tMin && t <= tMax) out.push_back(Hit{t, seg, kind});
+        }
+    };
+    if (!useBvh || sc.root == -1) {
+        for (uint32_t seg = 0; seg < sc.nSeg; seg++) testSeg(seg);
+    } else if (sc.rootIsLeaf) {
+        testSeg(uint32_t(~sc.root));
+    } else {
+        V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+        std::vector<int32_t> stack;
+        stack.push_back(sc.root);
+        while (!stack.empty()) {
+            int32_t n = stack.back(); stack.pop_back();
+            if (n < 0) { testSeg(uint32_t(~n)); continue; }
+            const BvhNode& nd = sc.nodes[n];
+            cnt.nodes++;
+            if (!rayBox(nd.bmin, nd.bmax, o, inv, tMin, tMax)) continue;
+            stack.push_back(nd.right);
+            stack.push_back(nd.left);
+        }
+        std::sort(out.begin(), out.end(), [](const Hit& a, const Hit& b) { return a.seg < b.seg; });
+    }
+}
+
+// ---------------------------------------------------------------- per-frame constants
+struct Frame {
+    float invView[16], invProj[16];
+    V3 cameraPosition;
+    float foreground[4];
+    float radius;
+    float subdivisionCorrectionFactor;
+};
+
+void mat4Inverse(const float* m, float* inv) {
+    // cofactor expansion (same scheme as glm::inverse: 2x2 sub-determinants, adjugate, 1/det)
+    float c00 = m[10] * m[15] - m[14] * m[11];
+    float c02 = m[6] * m[15] - m[14] * m[7];
+    float c03 = m[6] * m[11] - m[10] * m[7];
+    float c04 = m[9] * m[15] - m[13] * m[11];
+    float c06 = m[5] * m[15] - m[13] * m[7];
+    float c07 = m[5] * m[11] - m[9] * m[7];
+    float c08 = m[9] * m[14] - m[13] * m[10];
+    float c10 = m[5] * m[14] - m[13] * m[6];
+    float c11 = m[5] * m[10] - m[9] * m[6];
+    float c12 = m[8] * m[15] - m[12] * m[11];
+    float c14 = m[4] * m[15] - m[12] * m[7];
+    float c15 = m[4] * m[11] - m[8] * m[7];
+    float c16 = m[8] * m[14] - m[12] * m[10];
+    float c18 = m[4] * m[14] - m[12] * m[6];
+    float c19 = m[4] * m[10] - m[8] * m[6];
+    float c20 = m[8] * m[13] - m[12] * m[9];
+    float c22 = m[4] * m[13] - m[12] * m[5];
+    float c23 = m[4] * m[9] - m[8] * m[5];
+
+    float i00 = +((m[5] * c00 - m[6] * c04) + m[7] * c08);
+    float i01 = -((m[1] * c00 - m[2] * c04) + m[3] * c08);
+    float i02 = +((m[1] * c02 - m[2] * c06) + m[3] * c10);
+    float i03 = -((m[1] * c03 - m[2] * c07) + m[3] * c11);
+    float i10 = -((m[4] * c00 - m[6] * c12) + m[7] * c16);
+    float i11 = +((m[0] * c00 - m[2] * c12) + m[3] * c16);
+    float i12 = -((m[0] * c02 - m[2] * c14) + m[3] * c18);
+    float i13 = +((m[0] * c03 - m[2] * c15) + m[3] * c19);
+    float i20 = +((m[4] * c04 - m[5] * c12) + m[7] * c20);
+    float i21 = -((m[0] * c04 - m[1] * c12) + m[3] * c20);
+    float i22 = +((m[0] * c06 - m[1] * c14) + m[3] * c22);
+    float i23 = -((m[0] * c07 - m[1] * c15) + m[3] * c23);
+    float i30 = -((m[4] * c08 - m[5] * c16) + m[6] * c20);
+    float i31 = +((m[0] * c08 - m[1] * c16) + m[2] * c20);
+    float i32 = -((m[0] * c10 - m[1] * c18) + m[2] * c22);
+    float i33 = +((m[0] * c11 - m[1] * c19) + m[2] * c23);
+
+    float det = ((m[0] * i00 + m[1] * i10) + m[2] * i20) + m[3] * i30;
+    float r = 1.0f / det;
+    inv[0] = i00 * r;  inv[1] = i01 * r;  inv[2] = i02 * r;  inv[3] = i03 * r;
+    inv[4] = i10 * r;  inv[5] = i11 * r;  inv[6] = i12 * r;  inv[7] = i13 * r;
+    inv[8] = i20 * r;  inv[9] = i21 * r;  inv[10] = i22 * r; inv[11] = i23 * r;
+    inv[12] = i30 * r; inv[13] = i31 * r; inv[14] = i32 * r; inv[15] = i33 * r;
+}
+
+Frame makeFrame(const lvo_params& P) {
+    Frame f;
+    // LineData.cpp:1290-1291
+    mat4Inverse(P.view, f.invView);
+    mat4Inverse(P.proj, f.invProj);
+    // rayOrigin = (inverseViewMatrix * vec4(0,0,0,1)).xyz, TubeRayTracing.glsl:202; used as cameraPosition too
+    V4 o = mulM4(f.invView, V4{0.0f, 0.0f, 0.0f, 1.0f});
+    f.cameraPosition = v3(o.x, o.y, o.z);
+    // LineData.cpp:1282-1283
+    for (int i = 0; i < 4; i++) f.foreground[i] = 1.0f - P.background[i];
+    f.radius = P.lineWidth * 0.5f; // TubeRayTracing.glsl:453
+    // VulkanRayTracedAmbientOcclusion.cpp:588
+    f.subdivisionCorrectionFactor = cosf(3.1415926535897932f / float(P.tubeNumSubdivisions));
+    return f;
+}
+
+// primary ray for launch id (x,y) with sub-pixel offset xi; TubeRayTracing.glsl:219-226
+inline void primaryRay(const lvo_params& P, const Frame& F, uint32_t x, uint32_t y, float xix, float xiy, V3& o, V3& d) {
+    float ndcx = 2.0f * ((float(x) + xix) / float(P.width)) - 1.0f;
+    float ndcy = 2.0f * ((float(y) + xiy) / float(P.height)) - 1.0f;
+    V4 target = mulM4(F.invProj, V4{ndcx, ndcy, 1.0f, 1.0f});
+    V3 tn = normalize(v3(target.x, target.y, target.z));
+    V4 dir = mulM4(F.invView, V4{tn.x, tn.y, tn.z, 0.0f});
+    o = F.cameraPosition;
+    d = v3(dir.x, dir.y, dir.z);
+}
+
+// TransferFunction.glsl:66-71 with the texture definition owned by the build
+inline void transferFunction(const lvo_scene& sc, const lvo_params& P, float attr, float out[4]) {
+    float pos = clampf((attr - P.attrMin) / (P.attrMax - P.attrMin), 0.0f, 1.0f);
+    int n = int(sc.tfN);
+    float u = pos * float(n) - 0.5f;
+    float fl = floorf(u);
+    float f = u - fl;
+    int i0 = int(fl), i1 = i0 + 1;
+    i0 = std::min(std::max(i0, 0), n - 1);
+    i1 = std::min(std::max(i1, 0), n - 1);
+    for (int k = 0; k < 4; k++) out[k] = sc.tf[4 * i0 + k] * (1.0f - f) + sc.tf[4 * i1 + k] * f;
+}
+
+// AmbientOcclusion.glsl:84-99 (non-SSAO branch).  The reference projects the hit back to the screen and samples the
+// AO texture there; a primary-ray hit projects into the launching pixel, so the build defines the lookup as "the
+// texel of the pixel that launched the ray" (nearest, halo-free for tiles).
+inline float getAoFactor(const lvo_params& P, float aoTexel) {
+    float aoFactor = powf(aoTexel, P.aoGamma);
+    return fmaxf(0.0f, (1.0f - P.aoStrength) + P.aoStrength * aoFactor);
+}
+
+// blinnPhongShadingTube, Lighting.glsl:100-191
+inline void blinnPhongShadingTube(const lvo_params& P, const Frame& F, float aoTexel, const float base[4], V3 fragPos,
+                                  V3 ssp, V3 fragmentNormal, V3 fragmentTangent, float out[4]) {
+    float kA, kD;
+    const float kS = 0.3f, s = 30.0f;
+    float aoF = 1.0f;
+    if (P.useAmbientOcclusion) {
+        aoF = getAoFactor(P, aoTexel);
+        kA = 0.2f + (1.0f - aoF) * 0.5f;
+        kD = 0.9f * aoF;
+    } else {
+        kA = 0.1f;
+        kD = 0.9f;
+    }
+    V3 n = normalize(fragmentNormal);
+    V3 t = normalize(fragmentTangent);
+    V3 v = normalize(F.cameraPosition - fragPos);
+    V3 l = v;
+    V3 h = normalize(v + l);
+    V3 helperVec = normalize(cross(t, l));
+    V3 newL = normalize(cross(helperVec, t));
+    const float exponent = 1.7f;
+    float cosNormal1 = powf(clampf(fabsf(dot(n, l)), 0.0f, 1.0f), exponent);
+    float cosNormal2 = powf(clampf(fabsf(dot(n, newL)), 0.0f, 1.0f), exponent);
+    float cosNormalCombined = 0.3f * cosNormal1 + 0.7f * cosNormal2;
+    float spec = kS * powf(clampf(fabsf(dot(n, h)), 0.0f, 1.0f), s);
+    float phong[3];
+    for (int k = 0; k < 3; k++) {
+        float Ia = kA * base[k];
+        float Id = (kD * cosNormalCombined) * base[k];
+        float Is = spec * 1.0f;
+        phong[k] = (Ia + Id) + Is;
+    }
+    if (P.useAmbientOcclusion) {
+        for (int k = 0; k < 3; k++) phong[k] *= aoF;
+    }
+    if (P.useDepthCues) {
+        float dcf = clampf((-ssp.z - P.minDepth) / (P.maxDepth - P.minDepth), 0.0f, 1.0f);
+        dcf = (dcf * dcf) * P.depthCueStrength;
+        for (int k = 0; k < 3; k++) phong[k] = mixf(phong[k], 0.5f, dcf);
+    }
+    out[0] = phong[0]; out[1] = phong[1]; out[2] = phong[2]; out[3] = base[3];
+}
+
+// ClosestHitTubeAnalytic main() (TubeRayTracing.glsl:512-613) + computeFragmentColor (RayHitCommon.glsl:74-543),
+// flow lines: USE_CAPPED_TUBES / USE_HALOS / USE_DEPTH_CUES / USE_AMBIENT_OCCLUSION switches only.
+// Writes payload {hitColor, hitT}.
+inline void shadeHit(const lvo_scene& sc, const lvo_params& P, const Frame& F, float aoTexel, V3 o, V3 d, const Hit& h,
+                     float hitColor[4], float& payloadHitT) {
+    uint32_t i0 = sc.segIdx[2 * h.seg], i1 = sc.segIdx[2 * h.seg + 1];
+    const lvo_line_point& lp0 = sc.pts[i0];
+    const lvo_line_point& lp1 = sc.pts[i1];
+    V3 P0 = ld3(lp0.linePosition), P1 = ld3(lp1.linePosition);
+    V3 fragPos = o + d * h.t;
+    V3 linePointInterpolated;
+    float fragmentAttribute;
+    V3 v = P1 - P0;
+    if (h.kind == 0) {
+        V3 u = fragPos - P0;
+        float t = dot(v, u) / dot(v, v);
+        linePointInterpolated = P0 + t * v;
+        fragmentAttribute = (1.0f - t) * lp0.lineAttribute + t * lp1.lineAttribute;
+    } else if (h.kind == 1) {
+        linePointInterpolated = P0;
+        fragmentAttribute = lp0.lineAttribute;
+    } else {
+        linePointInterpolated = P1;
+        fragmentAttribute = lp1.lineAttribute;
+    }
+    V3 fragmentTangent = normalize(v);
+    V3 fragmentNormal = normalize(fragPos - linePointInterpolated);
+    bool isCap = h.kind != 0;
+
+    // computeFragmentColor
+    float fragmentColor[4];
+    transferFunction(sc, P, fragmentAttribute, fragmentColor);
+    V3 n = normalize(fragmentNormal);
+    V3 vv = normalize(F.cameraPosition - fragPos);
+    V3 t = normalize(fragmentTangent);
+    V3 helperVec = normalize(cross(t, vv));
+    V3 newV = normalize(cross(helperVec, t));
+
+    float ribbonPosition = 0.0f;
+    if (P.useHalos) {
+        if (P.useCappedTubes && isCap) {
+            // RayHitCommon.glsl:195-229
+            V3 crossProdVn = cross(vv, n);
+            ribbonPosition = length(crossProdVn);
+            V3 crossProdVn2 = cross(newV, n);
+            float ribbonPosition2 = length(crossProdVn2);
+            if (dot(t, crossProdVn) < 0.0f) ribbonPosition2 = -ribbonPosition2;
+            if (dot(t, crossProdVn) < 0.0f) ribbonPosition = -ribbonPosition;
+            ribbonPosition2 = clampf(ribbonPosition2, -1.0f, 1.0f);
+            if (fabsf(ribbonPosition2) < fabsf(ribbonPosition)) ribbonPosition = ribbonPosition2;
+        } else {
+            // RayHitCommon.glsl:353-372
+            V3 crossProdVn = cross(newV, n);
+            ribbonPosition = length(crossProdVn);
+            if (dot(t, crossProdVn) < 0.0f) ribbonPosition = -ribbonPosition;
+            ribbonPosition = clampf(ribbonPosition, -1.0f, 1.0f);
+        }
+    }
+
+    V3 ssp = v3(0, 0, 0);
+    if (P.useDepthCues || P.useAmbientOcclusion) {
+        V4 s4 = mulM4(P.view, V4{fragPos.x, fragPos.y, fragPos.z, 1.0f});
+        ssp = v3(s4.x, s4.y, s4.z);
+    }
+
+    float shaded[4];
+    blinnPhongShadingTube(P, F, aoTexel, fragmentColor, fragPos, ssp, n, t, shaded);
+
+    float absCoords = P.useHalos ? fabsf(ribbonPosition) : 0.0f;
+    float fragmentDepth = length(fragPos - F.cameraPosition);
+    // Antialiasing.glsl:1-3; RayHitCommon.glsl:451-452
+    float aaO = ((fragmentDepth / P.lineWidth) * 0.05f) / float(P.height) * P.fovY;
+    float aaW = ((fragmentDepth / P.lineWidth) * 2.0f) / float(P.height) * P.fovY;
+    float EPSILON_OUTLINE = clampf(aaO, 0.0f, 0.49f);
+    float EPSILON_WHITE = clampf(aaW, 0.0f, 0.49f);
+    const float WHITE_THRESHOLD = 0.7f;
+    float coverage = P.useHalos ? 1.0f - smoothstepf(1.0f - EPSILON_OUTLINE, 1.0f, absCoords) : 1.0f;
+    float w = smoothstepf(WHITE_THRESHOLD - EPSILON_WHITE, WHITE_THRESHOLD + EPSILON_WHITE, absCoords);
+    for (int k = 0; k < 3; k++) hitColor[k] = mixf(shaded[k], F.foreground[k], w);
+    hitColor[3] = shaded[3] * coverage;
+    payloadHitT = length(fragPos - F.cameraPosition);
+}
+
+inline uint8_t toUnorm8(float c) { return uint8_t(floorf(clampf(c, 0.0f, 1.0f) * 255.0f + 0.5f)); }
+inline uint32_t packUnorm4x8(const float c[4]) {
+    return uint32_t(toUnorm8(c[0])) | (uint32_t(toUnorm8(c[1])) << 8) | (uint32_t(toUnorm8(c[2])) << 16)
+           | (uint32_t(toUnorm8(c[3])) << 24);
+}
+inline void unpackUnorm4x8(uint32_t p, float c[4]) {
+    c[0] = float(p & 0xFFu) / 255.0f;
+    c[1] = float((p >> 8) & 0xFFu) / 255.0f;
+    c[2] = float((p >> 16) & 0xFFu) / 255.0f;
+    c[3] = float((p >> 24) & 0xFFu) / 255.0f;
+}
+
+inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+inline void padTiling(uint32_t& w, uint32_t& h, uint32_t tw, uint32_t th) {
+    // LineRenderer::getScreenSizeWithTiling, LineRenderer.cpp:805-812
+    if (w % tw != 0) w = (w / tw + 1) * tw;
+    if (h % th != 0) h = (h / th + 1) * th;
+}
+
+// 4-ary min-heap on (depth[, colour]) ; LinkedListSort.glsl:177-205
+template <bool LITERAL>
+inline bool gt(const uint32_t* col, const float* dep, uint32_t a, uint32_t b) {
+    if (LITERAL) return dep[a] > dep[b];
+    return dep[a] > dep[b] || (dep[a] == dep[b] && col[a] > col[b]);
+}
+template <bool LITERAL>
+inline void minHeapSink4(uint32_t* col, float* dep, uint32_t x, uint32_t fragsCount) {
+    uint32_t c, t;
+    while ((t = 4 * x + 1) < fragsCount) {
+        if (t + 1 < fragsCount && gt<LITERAL>(col, dep, t, t + 1)) c = t + 1; else c = t;
+        if (t + 2 < fragsCount && gt<LITERAL>(col, dep, c, t + 2)) c = t + 2;
+        if (t + 3 < fragsCount && gt<LITERAL>(col, dep, c, t + 3)) c = t + 3;
+        if (!gt<LITERAL>(col, dep, x, c)) return;
+        std::swap(col[x], col[c]);
+        std::swap(dep[x], dep[c]);
+        x = c;
+    }
+}
+// frontToBackPQ, LinkedListSort.glsl:207-238
+template <bool LITERAL>
+inline void frontToBackPQ(uint32_t* col, float* dep, uint32_t fragsCount, float out[4]) {
+    uint32_t i;
+    for (i = fragsCount / 4; i > 0; --i) minHeapSink4<LITERAL>(col, dep, i, fragsCount);
+    float ray[4] = {0, 0, 0, 0};
+    i = 0;
+    while (i < fragsCount && ray[3] < 0.99f) {
+        minHeapSink4<LITERAL>(col, dep, 0, fragsCount - i++);
+        float src[4];
+        unpackUnorm4x8(col[0], src);
+        for (int k = 0; k < 3; k++) ray[k] = ray[k] + ((1.0f - ray[3]) * src[3]) * src[k];
+        ray[3] = ray[3] + (1.0f - ray[3]) * src[3];
+        col[0] = col[fragsCount - i];
+        dep[0] = dep[fragsCount - i];
+    }
+    out[0] = ray[0] / ray[3]; out[1] = ray[1] / ray[3]; out[2] = ray[2] / ray[3]; out[3] = ray[3];
+}
+
+} // namespace
+
+// ================================================================ exported API
+extern "C" {
+
+uint32_t lvo_tea(uint32_t a, uint32_t b) { return tea(a, b); }
+uint32_t lvo_lcg(uint32_t* s) { return lcg(*s); }
+float lvo_rnd(uint32_t* s) { return rnd(*s); }
+void lvo_sincos_2pi(float xi, float* s, float* c) { sincos2pi(xi, *s, *c); }
+void lvo_mat4_inverse(const float m[16], float out[16]) { mat4Inverse(m, out); }
+void lvo_set_num_threads(int n) {
+#ifdef _OPENMP
+    omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
+// TrajectoryFile.cpp:106-125 (AABB over all points, then v = (v + translation) * scale)
+void lvo_normalize_positions(float* p, uint64_t n) {
+    if (n == 0) return;
+    float mn[3] = {p[0], p[1], p[2]}, mx[3] = {p[0], p[1], p[2]};
+    for (uint64_t i = 0; i < n; i++)
+        for (int k = 0; k < 3; k++) { mn[k] = fminf(mn[k], p[3 * i + k]); mx[k] = fmaxf(mx[k], p[3 * i + k]); }
+    float tr[3], sc3[3];
+    for (int k = 0; k < 3; k++) { tr[k] = -((mn[k] + mx[k]) / 2.0f); sc3[k] = 0.5f / (mx[k] - mn[k]); }
+    float scale = std::min(sc3[0], std::min(sc3[1], sc3[2]));
+    for (uint64_t i = 0; i < n; i++)
+        for (int k = 0; k < 3; k++) p[3 * i + k] = (p[3 * i + k] + tr[k]) * scale;
+}
+
+// LineDataFlow.cpp:2112-2277
+void lvo_build_tube_aabb_render_data(
+        const float* positions, const float* attributes, const uint32_t* lineOffsets, uint32_t nLines, float lineWidth,
+        lvo_line_point* outPoints, uint32_t* outNumPoints, uint32_t* outSegIndices, float* outAabbs,
+        uint32_t* outNumSegments) {
+    float lwo = lineWidth * 0.5f;
+    uint32_t nOut = 0, nSeg = 0;
+    uint32_t lineSegmentIndexCounter = 0;
+    for (uint32_t li = 0; li < nLines; li++) {
+        uint32_t b = lineOffsets[li], e = lineOffsets[li + 1];
+        uint32_t n = e - b;
+        V3 lastLineNormal = v3(1.0f, 0.0f, 0.0f);
+        uint32_t numValidLinePoints = 0;
+        for (uint32_t i = 0; i < n; i++) {
+            if (n < 2) break; // a one-point trajectory has no neighbour to difference against
+            V3 tangent;
+            V3 pi = ld3(positions + 3 * (b + i));
+            if (i == 0) tangent = ld3(positions + 3 * (b + i + 1)) - pi;
+            else if (i + 1 == n) tangent = pi - ld3(positions + 3 * (b + i - 1));
+            else tangent = ld3(positions + 3 * (b + i + 1)) - ld3(positions + 3 * (b + i - 1));
+            float tangentLength = length(tangent);
+            if (tangentLength < 0.0001f) continue;
+            tangent = normalize(tangent);
+            V3 helperAxis = lastLineNormal;
+            if (length(cross(helperAxis, tangent)) < 0.01f) {
+                helperAxis = v3(0.0f, 1.0f, 0.0f);
+                if (length(cross(helperAxis, tangent)) < 0.01f) helperAxis = v3(0.0f, 0.0f, 1.0f);
+            }
+            V3 normal = normalize(helperAxis - dot(helperAxis, tangent) * tangent);
+            lastLineNormal = normal;
+            lvo_line_point lp;
+            memset(&lp, 0, sizeof(lp));
+            lp.linePosition[0] = pi.x; lp.linePosition[1] = pi.y; lp.linePosition[2] = pi.z;
+            lp.lineAttribute = attributes[b + i];
+            lp.lineTangent[0] = tangent.x; lp.lineTangent[1] = tangent.y; lp.lineTangent[2] = tangent.z;
+            lp.lineNormal[0] = normal.x; lp.lineNormal[1] = normal.y; lp.lineNormal[2] = normal.z;
+            outPoints[nOut++] = lp;
+            numValidLinePoints++;
+        }
+        if (numValidLinePoints == 1) nOut--;
+        if (numValidLinePoints <= 1) continue;
+        for (uint32_t pointIdx = 1; pointIdx < numValidLinePoints; pointIdx++) {
+            uint32_t a0 = lineSegmentIndexCounter + pointIdx - 1, a1 = lineSegmentIndexCounter + pointIdx;
+            outSegIndices[2 * nSeg] = a0;
+            outSegIndices[2 * nSeg + 1] = a1;
+            const float* p0 = outPoints[a0].linePosition;
+            const float* p1 = outPoints[a1].linePosition;
+            for (int k = 0; k < 3; k++) {
+                outAabbs[6 * nSeg + k] = fminf(p0[k], p1[k]) - lwo;
+                outAabbs[6 * nSeg + 3 + k] = fmaxf(p0[k], p1[k]) + lwo;
+            }
+            nSeg++;
+        }
+        lineSegmentIndexCounter += numValidLinePoints;
+    }
+    *outNumPoints = nOut;
+    *outNumSegments = nSeg;
+}
+
+lvo_scene* lvo_scene_create(const lvo_line_point* pts, uint32_t nPts, const uint32_t* segIdx, uint32_t nSeg) {
+    lvo_scene* sc = new lvo_scene();
+    sc->pts.assign(pts, pts + nPts);
+    sc->segIdx.assign(segIdx, segIdx + 2 * size_t(nSeg));
+    sc->nSeg = nSeg;
+    return sc;
+}
+void lvo_scene_destroy(lvo_scene* sc) { delete sc; }
+void lvo_scene_set_tf(lvo_scene* sc, const float* rgba, uint32_t n) {
+    sc->tf.assign(rgba, rgba + 4 * size_t(n));
+    sc->tfN = n;
+}
+
+void lvo_scene_build_bvh(lvo_scene* sc, float lineWidth) {
+    sc->nodes.clear();
+    sc->root = -1;
+    sc->rootIsLeaf = false;
+    sc->bvhDepth = 0;
+    sc->bvhLineWidth = lineWidth;
+    uint32_t n = sc->nSeg;
+    if (n == 0) return;
+    float r = lineWidth * 0.5f;
+    float pad = r * 1e-3f + 1e-6f;
+    std::vector<SegBox> boxes(n);
+    float smn[3] = {3e38f, 3e38f, 3e38f}, smx[3] = {-3e38f, -3e38f, -3e38f};
+    for (uint32_t s = 0; s < n; s++) {
+        V3 p0, p1; segPoints(*sc, s, p0, p1);
+        const float a[3] = {p0.x, p0.y, p0.z}, b[3] = {p1.x, p1.y, p1.z};
+        for (int k = 0; k < 3; k++) {
+            boxes[s].mn[k] = fminf(a[k], b[k]) - r - pad;
+            boxes[s].mx[k] = fmaxf(a[k], b[k]) + r + pad;
+            smn[k] = fminf(smn[k], boxes[s].mn[k]);
+            smx[k] = fmaxf(smx[k], boxes[s].mx[k]);
+        }
+    }
+    std::vector<uint64_t> keys(n);
+    std::vector<uint32_t> order(n);
+    for (uint32_t s = 0; s < n; s++) {
+        uint64_t q[3];
+        for (int k = 0; k < 3; k++) {
+            double c = 0.5 * (double(boxes[s].mn[k]) + double(boxes[s].mx[k]));
+            double u = (c - smn[k]) / std::max(1e-30, double(smx[k]) - double(smn[k]));
+            u = std::min(std::max(u, 0.0), 1.0);
+            q[k] = uint64_t(std::min(2097151.0, u * 2097152.0));
+        }
+        keys[s] = (expandBits21(q[0]) << 2) | (expandBits21(q[1]) << 1) | expandBits21(q[2]);
+        order[s] = s;
+    }
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+        return keys[a] < keys[b] || (keys[a] == keys[b] && a < b);
+    });
+    std::vector<uint64_t> sk(n);
+    for (uint32_t i = 0; i < n; i++) sk[i] = keys[order[i]];
+    sc->nodes.reserve(n);
+    uint32_t maxDepth = 0;
+    sc->root = buildRange(*sc, sk, order, boxes, 0, n, 0, maxDepth);
+    sc->rootIsLeaf = sc->root < 0;
+    sc->bvhDepth = maxDepth;
+}
+
+int lvo_intersect_capsule(const float o[3], const float d[3], const float p0[3], const float p1[3], float radius,
+                          int capped, float* outT, int* outKind) {
+    float t; int k;
+    bool h = intersectCapsule(ld3(o), ld3(d), ld3(p0), ld3(p1), radius, capped != 0, t, k);
+    *outT = t; *outKind = k;
+    return h ? 1 : 0;
+}
+
+void lvo_trace_rays(const lvo_scene* sc, float lineWidth, int capped, int useBvh, const float* origins,
+                    const float* dirs, float tMin, float tMax, uint32_t n, float* outT, uint32_t* outSeg,
+                    uint32_t* outKind) {
+    float radius = lineWidth * 0.5f;
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int64_t i = 0; i < int64_t(n); i++) {
+        Counters c;
+        Hit h;
+        bool f = closestHit(*sc, radius, capped != 0, useBvh != 0, ld3(origins + 3 * i), ld3(dirs + 3 * i), tMin, tMax, h, c);
+        outT[i] = f ? h.t : tMax;
+        outSeg[i] = f ? h.seg : 0xFFFFFFFFu;
+        outKind[i] = f ? uint32_t(h.kind) : 0u;
+    }
+}
+
+// ComputeDepthValues.glsl:58-98 + MinMaxReduce.glsl:64-103 (min/max are order independent)
+void lvo_compute_depth_range(const lvo_scene* sc, const lvo_params* P, float outMinMax[2]) {
+    float mn = P->farDist, mx = P->nearDist;
+    const float EPSILON = 1e-2f;
+    for (size_t i = 0; i < sc->pts.size(); i++) {
+        const float* p = sc->pts[i].linePosition;
+        V4 ssp = mulM4(P->view, V4{p[0], p[1], p[2], 1.0f});
+        V4 ndc = mulM4(P->proj, ssp);
+        float nx = ndc.x / ndc.w, ny = ndc.y / ndc.w, nz = ndc.z / ndc.w;
+        if (nx >= -1.0f && ny >= -1.0f && nz >= -1.0f && nx <= 1.0f && ny <= 1.0f && nz <= 1.0f) {
+            float depth = clampf(-ssp.z, P->nearDist, P->farDist);
+            mn = fminf(mn, depth - EPSILON);
+            mx = fmaxf(mx, depth + EPSILON);
+        }
+    }
+    outMinMax[0] = mn;
+    outMinMax[1] = mx;
+}
+
+// VulkanRayTracedAmbientOcclusion.glsl:178-319 restated over analytic capsules (documented deviation:
+// the reference traces AO against 6-gon triangle tubes; hit position/normal/tangent come from the
+// capsule hit instead of barycentric interpolation).
+void lvo_render_ao(const lvo_scene* sc, const lvo_params* Pp, int useBvh, uint32_t x0, uint32_t y0, uint32_t w,
+                   uint32_t h, float* aoOut, lvo_stats* stats) {
+    const lvo_params& P = *Pp;
+    Frame F = makeFrame(P);
+    const bool capped = P.useCappedTubes != 0;
+    uint64_t rays = 0, nodes = 0, prims = 0;
+    for (uint32_t iter = 0; iter < P.aoIterations; iter++) {
+        const uint32_t frameNumber = iter;
+        const uint32_t globalFrameNumber = frameNumber; // VulkanRayTracedAmbientOcclusion.cpp:576-581
+#pragma omp parallel for schedule(dynamic, 4) reduction(+ : rays, nodes, prims)
+        for (int64_t yy = 0; yy < int64_t(h); yy++) {
+            Counters cnt;
+            for (uint32_t xx = 0; xx < w; xx++) {
+                uint32_t x = x0 + xx, y = y0 + uint32_t(yy);
+                uint32_t pix = x + y * P.width;
+                uint32_t seed = tea(pix, globalFrameNumber);
+                float xix = 0.5f, xiy = 0.5f;
+                if (P.aoJitterPrimary) { xix = rnd(seed); xiy = rnd(seed); }
+                V3 o, d;
+                primaryRay(P, F, x, y, xix, xiy, o, d);
+                Hit hit;
+                float aoFactor = 1.0f;
+                if (closestHit(*sc, F.radius, capped, useBvh != 0, o, d, 0.0001f, 1000.0f, hit, cnt)) {
+                    const lvo_line_point& lp0 = sc->pts[sc->segIdx[2 * hit.seg]];
+                    const lvo_line_point& lp1 = sc->pts[sc->segIdx[2 * hit.seg + 1]];
+                    V3 P0 = ld3(lp0.linePosition), P1 = ld3(lp1.linePosition);
+                    V3 vertexPositionWorld = o + d * hit.t;
+                    V3 v = P1 - P0;
+                    float ts;
+                    if (hit.kind == 0) ts = dot(v, vertexPositionWorld - P0) / dot(v, v);
+                    else ts = hit.kind == 1 ? 0.0f : 1.0f;
+                    V3 linePosition = hit.kind == 0 ? P0 + ts * v : (hit.kind == 1 ? P0 : P1);
+                    V3 surfaceNormal = normalize(vertexPositionWorld - linePosition);
+                    V3 surfaceTangent = normalize((1.0f - ts) * ld3(lp0.lineTangent) + ts * ld3(lp1.lineTangent));
+                    V3 surfaceBitangent = cross(surfaceNormal, surfaceTangent);
+                    float offsetFactor = length(linePosition - vertexPositionWorld) / F.subdivisionCorrectionFactor;
+                    aoFactor = 0.0f;
+                    for (uint32_t s = 0; s < P.aoSamplesPerFrame; s++) {
+                        uint32_t sseed = tea(pix, globalFrameNumber * P.aoSamplesPerFrame + s);
+                        float xi0 = rnd(sseed), xi1 = rnd(sseed);
+                        // sampleHemisphere, glsl:151-156
+                        float sn, cs;
+                        sincos2pi(xi1, sn, cs);
+                        float r = sqrtf(1.0f - xi0 * xi0);
+                        V3 smp = v3(cs * r, sn * r, xi0);
+                        // frame * sample, frame = mat3(T, B, N)
+                        V3 dirU = v3((surfaceTangent.x * smp.x + surfaceBitangent.x * smp.y) + surfaceNormal.x * smp.z,
+                                     (surfaceTangent.y * smp.x + surfaceBitangent.y * smp.y) + surfaceNormal.y * smp.z,
+                                     (surfaceTangent.z * smp.x + surfaceBitangent.z * smp.y) + surfaceNormal.z * smp.z);
+                        V3 rd = normalize(dirU);
+                        V3 ro = vertexPositionWorld + rd * offsetFactor;
+                        Hit ah;
+                        float occ = 1.0f;
+                        // traceAoRay, glsl:158-175 (closest hit in [0, radius]; without useDistance any hit)
+                        if (closestHit(*sc, F.radius, capped, useBvh != 0, ro, rd, 0.0f, P.aoRadius, ah, cnt))
+                            occ = P.aoUseDistance ? ah.t / P.aoRadius : 0.0f;
+                        aoFactor += occ;
+                    }
+                    aoFactor /= float(P.aoSamplesPerFrame);
+                }
+                size_t idx = size_t(y) * P.width + x;
+                if (frameNumber != 0) aoFactor = mixf(aoOut[idx], aoFactor, 1.0f / float(frameNumber + 1));
+                aoOut[idx] = aoFactor;
+            }
+            rays += cnt.rays; nodes += cnt.nodes; prims += cnt.prims;
+        }
+    }
+    if (stats) { stats->raysTraced += rays; stats->nodesVisited += nodes; stats->primsTested += prims; stats->bvhDepth = sc->bvhDepth; }
+}
+
+// RayGen main() + traceRayTransparent + Miss, TubeRayTracing.glsl:61-82,198-298
+void lvo_render_rt(const lvo_scene* sc, const lvo_params* Pp, int useBvh, const float* ao, uint32_t x0, uint32_t y0,
+                   uint32_t w, uint32_t h, uint8_t* outRGBA8, lvo_stats* stats) {
+    const lvo_params& P = *Pp;
+    Frame F = makeFrame(P);
+    const bool capped = P.useCappedTubes != 0;
+    const float HIT_DISTANCE_EPSILON = 1e-5f;
+    uint64_t rays = 0, nodes = 0, prims = 0, hits = 0;
+#pragma omp parallel for schedule(dynamic, 4) reduction(+ : rays, nodes, prims, hits)
+    for (int64_t yy = 0; yy < int64_t(h); yy++) {
+        Counters cnt;
+        for (uint32_t xx = 0; xx < w; xx++) {
+            uint32_t x = x0 + xx, y = y0 + uint32_t(yy);
+            float fragmentColor[4] = {0, 0, 0, 0};
+            const float aoTexel = (P.useAmbientOcclusion && ao) ? ao[size_t(y) * P.width + x] : 1.0f;
+            uint32_t nSamples = P.useJitteredRays ? P.numSamplesPerFrame : 1u;
+            for (uint32_t sampleIdx = 0; sampleIdx < nSamples; sampleIdx++) {
+                float xix = 0.5f, xiy = 0.5f;
+                if (P.useJitteredRays) {
+                    uint32_t seed = P.useDeterministicSampling
+                            ? tea(19u, P.frameNumber * P.numSamplesPerFrame + sampleIdx)
+                            : tea(x + y * P.width, P.frameNumber * P.numSamplesPerFrame + sampleIdx);
+                    xix = rnd(seed); xiy = rnd(seed);
+                }
+                V3 o, d;
+                primaryRay(P, F, x, y, xix, xiy, o, d);
+                // traceRayTransparent
+                float fc[4] = {0, 0, 0, 0};
+                float tMin = 0.0001f, tMax = 1000.0f;
+                for (uint32_t hitIdx = 0; hitIdx < P.maxDepthComplexity; hitIdx++) {
+                    Hit hit;
+                    float hc[4]; float payloadHitT; bool hasHit;
+                    if (closestHit(*sc, F.radius, capped, useBvh != 0, o, d, tMin, tMax, hit, cnt)) {
+                        shadeHit(*sc, P, F, aoTexel, o, d, hit, hc, payloadHitT);
+                        hasHit = true;
+                        cnt.hits++;
+                    } else {
+                        for (int k = 0; k < 4; k++) hc[k] = P.background[k];
+                        payloadHitT = 0.0f;
+                        hasHit = false;
+                    }
+                    tMin = payloadHitT + fmaxf(payloadHitT * HIT_DISTANCE_EPSILON, 1e-7f);
+                    for (int k = 0; k < 3; k++) fc[k] = fc[k] + ((1.0f - fc[3]) * hc[3]) * hc[k];
+                    fc[3] = fc[3] + (1.0f - fc[3]) * hc[3];
+                    if (!hasHit || fc[3] > 0.99f) break;
+                }
+                for (int k = 0; k < 4; k++) fragmentColor[k] += fc[k];
+            }
+            if (P.useJitteredRays)
+                for (int k = 0; k < 4; k++) fragmentColor[k] /= float(P.numSamplesPerFrame);
+            uint8_t* px = outRGBA8 + 4 * (size_t(yy) * w + xx);
+            for (int k = 0; k < 4; k++) px[k] = toUnorm8(fragmentColor[k]);
+        }
+        rays += cnt.rays; nodes += cnt.nodes; prims += cnt.prims; hits += cnt.hits;
+    }
+    if (stats) {
+        stats->raysTraced += rays; stats->nodesVisited += nodes; stats->primsTested += prims; stats->hitsShaded += hits;
+        stats->bvhDepth = sc->bvhDepth;
+    }
+}
+
+// TiledAddress.glsl:53-85 (ADDRESSING_TILED_2x2 / 2x8 / NxM / linear)
+uint32_t lvo_ppll_addr(uint32_t x, uint32_t y, uint32_t viewportW, uint32_t tileW, uint32_t tileH) {
+    if (tileW == 1 && tileH == 1) return x + viewportW * y;
+    uint32_t surfaceWidth = viewportW / tileW;
+    uint32_t tx = x / tileW, ty = y / tileH;
+    uint32_t tileAddr1D = (tx + surfaceWidth * ty) * (tileW * tileH);
+    uint32_t px = x & (tileW - 1), py = y & (tileH - 1);
+    uint32_t pixelAddr1D = px + py * tileW;
+    return tileAddr1D | pixelAddr1D;
+}
+
+// gatherFragment, LinkedListGather.glsl:33-72; fragment source = capsule entry hits of the pixel-centre ray
+void lvo_ppll_gather(const lvo_scene* sc, const lvo_params* Pp, int useBvh, const float* ao, uint32_t x0, uint32_t y0,
+                     uint32_t w, uint32_t h, uint32_t* nodes, uint32_t* startOffset, uint32_t* fragCounter,
+                     lvo_stats* stats) {
+    const lvo_params& P = *Pp;
+    Frame F = makeFrame(P);
+    const bool capped = P.useCappedTubes != 0;
+    uint32_t pw = P.width, ph = P.height;
+    padTiling(pw, ph, P.ppllTileW, P.ppllTileH);
+    // clear: LinkedListClear.glsl:46-55
+    for (size_t i = 0; i < size_t(pw) * ph; i++) startOffset[i] = 0xFFFFFFFFu;
+    *fragCounter = 0;
+    // per-pixel fragment lists computed in parallel, inserted serially in raster order
+    std::vector<std::vector<std::pair<uint32_t, float>>> rows(h);
+    std::vector<std::vector<uint32_t>> rowCounts(h);
+    uint64_t rays = 0, nds = 0, prims = 0, hits = 0;
+#pragma omp parallel for schedule(dynamic, 4) reduction(+ : rays, nds, prims, hits)
+    for (int64_t yy = 0; yy < int64_t(h); yy++) {
+        Counters cnt;
+        std::vector<Hit> hl;
+        rowCounts[yy].assign(w, 0);
+        for (uint32_t xx = 0; xx < w; xx++) {
+            uint32_t x = x0 + xx, y = y0 + uint32_t(yy);
+            V3 o, d;
+            primaryRay(P, F, x, y, 0.5f, 0.5f, o, d);
+            const float aoTexel = (P.useAmbientOcclusion && ao) ? ao[size_t(y) * P.width + x] : 1.0f;
+            allHits(*sc, F.radius, capped, useBvh != 0, o, d, 0.0001f, 1000.0f, hl, cnt);
+            for (const Hit& hit : hl) {
+                float hc[4]; float hitT;
+                shadeHit(*sc, P, F, aoTexel, o, d, hit, hc, hitT);
+                cnt.hits++;
+                if (hc[3] < 0.001f) continue;
+                rows[yy].push_back(std::make_pair(packUnorm4x8(hc), hitT));
+                rowCounts[yy][xx]++;
+            }
+        }
+        rays += cnt.rays; nds += cnt.nodes; prims += cnt.prims; hits += cnt.hits;
+    }
+    uint32_t maxDc = 0;
+    for (uint32_t yy = 0; yy < h; yy++) {
+        size_t k = 0;
+        for (uint32_t xx = 0; xx < w; xx++) {
+            uint32_t pixelIndex = lvo_ppll_addr(x0 + xx, y0 + yy, pw, P.ppllTileW, P.ppllTileH);
+            maxDc = std::max(maxDc, rowCounts[yy][xx]);
+            for (uint32_t f = 0; f < rowCounts[yy][xx]; f++, k++) {
+                uint32_t insertIndex = (*fragCounter)++;
+                if (insertIndex < P.ppllLinkedListSize) {
+                    uint32_t next = startOffset[pixelIndex];
+                    startOffset[pixelIndex] = insertIndex;
+                    nodes[3 * size_t(insertIndex)] = rows[yy][k].first;
+                    nodes[3 * size_t(insertIndex) + 1] = f2u(rows[yy][k].second);
+                    nodes[3 * size_t(insertIndex) + 2] = next;
+                }
+            }
+        }
+    }
+    if (stats) {
+        stats->raysTraced += rays; stats->nodesVisited += nds; stats->primsTested += prims; stats->hitsShaded += hits;
+        stats->fragments = *fragCounter;
+        stats->maxDepthComplexity = maxDc;
+        stats->bvhDepth = sc->bvhDepth;
+    }
+}
+
+// LinkedListResolve.glsl:57-105 + frontToBackPQ; output blended BACK_TO_FRONT_STRAIGHT_ALPHA over the clear colour
+// (PerPixelLinkedListLineRenderer.cpp:70,395-397)
+void lvo_ppll_resolve(const lvo_params* Pp, const uint32_t* nodes, const uint32_t* startOffset, int literal, uint32_t x0,
+                      uint32_t y0, uint32_t w, uint32_t h, uint8_t* outRGBA8) {
+    const lvo_params& P = *Pp;
+    uint32_t pw = P.width, ph = P.height;
+    padTiling(pw, ph, P.ppllTileW, P.ppllTileH);
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int64_t yy = 0; yy < int64_t(h); yy++) {
+        std::vector<uint32_t> colorList(P.ppllMaxNumFrags);
+        std::vector<float> depthList(P.ppllMaxNumFrags);
+        for (uint32_t xx = 0; xx < w; xx++) {
+            uint32_t pixelIndex = lvo_ppll_addr(x0 + xx, y0 + uint32_t(yy), pw, P.ppllTileW, P.ppllTileH);
+            uint32_t fragOffset = startOffset[pixelIndex];
+            uint32_t numFrags = 0;
+            for (uint32_t i = 0; i < P.ppllMaxNumFrags; i++) {
+                if (fragOffset == 0xFFFFFFFFu) break;
+                colorList[i] = nodes[3 * size_t(fragOffset)];
+                depthList[i] = u2f(nodes[3 * size_t(fragOffset) + 1]);
+                fragOffset = nodes[3 * size_t(fragOffset) + 2];
+                numFrags++;
+            }
+            float out[4] = {P.background[0], P.background[1], P.background[2], P.background[3]};
+            if (numFrags > 0) {
+                float c[4];
+                if (literal) frontToBackPQ<true>(colorList.data(), depthList.data(), numFrags, c);
+                else frontToBackPQ<false>(colorList.data(), depthList.data(), numFrags, c);
+                if (c[3] > 0.0f) { // A == 0 (all alphas quantised to 0) is treated as "no fragments"
+                    for (int k = 0; k < 3; k++) out[k] = c[k] * c[3] + P.background[k] * (1.0f - c[3]);
+                    out[3] = c[3] + P.background[3] * (1.0f - c[3]);
+                }
+            }
+            uint8_t* px = outRGBA8 + 4 * (size_t(yy) * w + xx);
+            for (int k = 0; k < 4; k++) px[k] = toUnorm8(out[k]);
+        }
+    }
+}
+
+void lvo_render_ppll(const lvo_scene* sc, const lvo_params* P, int useBvh, const float* ao, uint32_t x0, uint32_t y0,
+                     uint32_t w, uint32_t h, uint8_t* outRGBA8, lvo_stats* stats) {
+    uint32_t pw = P->width, ph = P->height;
+    padTiling(pw, ph, P->ppllTileW, P->ppllTileH);
+    std::vector<uint32_t> nodes(3 * size_t(P->ppllLinkedListSize));
+    std::vector<uint32_t> startOffset(size_t(pw) * ph);
+    uint32_t fragCounter = 0;
+    lvo_ppll_gather(sc, P, useBvh, ao, x0, y0, w, h, nodes.data(), startOffset.data(), &fragCounter, stats);
+    lvo_ppll_resolve(P, nodes.data(), startOffset.data(), 0, x0, y0, w, h, outRGBA8);
+}
+
+} // extern "C"

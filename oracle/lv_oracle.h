@@ -1,0 +1,174 @@
+/*
+ * lv_oracle.h -- C interface of the CPU ORACLE.
+ *
+ * TEST INFRASTRUCTURE, NOT PRODUCT.  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may load this library.  The product path
+ * (linevis_amd/csrc, include/linevis_hip.h) never links, imports or calls it.
+ *
+ * PARITY UNPINNED: the reference (chrismile/LineVis) cannot be built here (no
+ * sgl / Vulkan / GLM) and none of its own tests touch this path, so there are
+ * no reference-held golden vectors.  This oracle is a CPU restatement of the
+ * reference's GLSL arithmetic; every function cites the file:line it follows.
+ * Its own outputs are committed under tests/golden/ as regression pins.
+ */
+#ifndef LV_ORACLE_H
+#define LV_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Mirrors struct LinePointDataUnified, src/LineData/LineRenderData.hpp:99-106 (48 B). */
+typedef struct {
+    float linePosition[3];
+    float lineAttribute;
+    float lineTangent[3];
+    float lineRotation;
+    float lineNormal[3];
+    uint32_t lineStartIndex;
+} lvo_line_point;
+
+/*
+ * Everything the shaders read from uniform buffers, flattened:
+ *   LineUniformData            Data/Shaders/Renderers/LineUniformData.glsl:24-70
+ *   RayTracerSettingsBuffer    Data/Shaders/Renderers/RayTracing/TubeRayTracingHeader.glsl:33-42
+ *   RTAO UniformsBuffer        Data/Shaders/AO/RTAO/VulkanRayTracedAmbientOcclusion.glsl:45-67
+ *   PPLL UniformDataBuffer     Data/Shaders/Renderers/PPLL/LinkedListHeader.glsl:45-52
+ * plus the preprocessor switches the host assembles (VulkanRayTracer.cpp:430-460,
+ * LineData.cpp:1209-1256, LineRenderer.cpp:129-179).
+ */
+typedef struct {
+    float view[16];          /* column-major, GLM layout */
+    float proj[16];
+    float fovY;
+    float nearDist, farDist;
+    uint32_t width, height;  /* full viewport */
+    float background[4];
+    float lineWidth;
+
+    /* ray tracer (TubeRayTracingHeader.glsl:33-42; defaults VulkanRayTracer.hpp:137-144) */
+    uint32_t maxDepthComplexity;
+    uint32_t numSamplesPerFrame;
+    uint32_t frameNumber;
+    uint32_t useJitteredRays;          /* USE_JITTERED_RAYS, VulkanRayTracer.cpp:420-426 */
+    uint32_t useDeterministicSampling; /* DETERMINISTIC_SAMPLING */
+
+    /* shading switches */
+    uint32_t useCappedTubes;  /* USE_CAPPED_TUBES */
+    uint32_t useHalos;        /* USE_HALOS */
+    uint32_t useDepthCues;    /* USE_DEPTH_CUES */
+    uint32_t useAmbientOcclusion; /* USE_AMBIENT_OCCLUSION + GEOMETRY_PASS_TUBE */
+    float depthCueStrength;
+    float minDepth, maxDepth; /* DepthMinMaxBuffer, Lighting.glsl:28-33 */
+    float aoStrength, aoGamma;
+
+    /* transfer function range (MinMaxUniformBuffer, TransferFunction.glsl:60-63) */
+    float attrMin, attrMax;
+
+    /* RTAO (VulkanRayTracedAmbientOcclusion.hpp:108,150-153) */
+    uint32_t aoSamplesPerFrame;
+    uint32_t aoIterations;
+    uint32_t aoUseDistance;
+    uint32_t aoJitterPrimary;
+    uint32_t tubeNumSubdivisions;
+    float aoRadius;
+
+    /* PPLL (PerPixelLinkedListLineRenderer.cpp:144-209,251-357) */
+    uint32_t ppllMaxNumFrags;      /* MAX_NUM_FRAGS */
+    uint32_t ppllLinkedListSize;   /* nodes in the pool */
+    uint32_t ppllTileW, ppllTileH; /* LineRenderer.cpp:739-740 */
+} lvo_params;
+
+typedef struct {
+    uint64_t raysTraced;
+    uint64_t nodesVisited;
+    uint64_t primsTested;
+    uint64_t hitsShaded;
+    uint64_t fragments;       /* PPLL: fragCounter after gather */
+    uint32_t maxDepthComplexity;
+    uint32_t bvhDepth;
+} lvo_stats;
+
+typedef struct lvo_scene lvo_scene;
+
+/* ---- a12: RNG (RayTracingUtilities.glsl:134-181) ---- */
+uint32_t lvo_tea(uint32_t val0, uint32_t val1);
+uint32_t lvo_lcg(uint32_t* state);
+float lvo_rnd(uint32_t* state);
+/* deterministic sin/cos of 2*pi*xi used by the hemisphere sample (definition owned by the build) */
+void lvo_sincos_2pi(float xi, float* s, float* c);
+
+/* ---- a1: normalisation (TrajectoryFile.cpp:106-125) ---- */
+void lvo_normalize_positions(float* positions /* n*3 in/out */, uint64_t n);
+
+/* ---- a2: LineDataFlow::getLinePassTubeAabbRenderData (LineDataFlow.cpp:2112-2277) ----
+ * positions: concatenated xyz of all lines; attributes: one float per point;
+ * lineOffsets[nLines+1]: start index of each line.
+ * Outputs must be sized for the worst case (nPoints, 2*nPoints, 6*nPoints).
+ * Returns number of output points via *outNumPoints and segments via *outNumSegments. */
+void lvo_build_tube_aabb_render_data(
+        const float* positions, const float* attributes, const uint32_t* lineOffsets, uint32_t nLines,
+        float lineWidth,
+        lvo_line_point* outPoints, uint32_t* outNumPoints,
+        uint32_t* outSegIndices, float* outAabbs, uint32_t* outNumSegments);
+
+/* ---- 4x4 inverse (cofactor expansion; stands in for glm::inverse, LineData.cpp:1290-1291) ---- */
+void lvo_mat4_inverse(const float m[16], float out[16]);
+
+/* ---- scene ---- */
+lvo_scene* lvo_scene_create(const lvo_line_point* pts, uint32_t nPts, const uint32_t* segIdx, uint32_t nSeg);
+void lvo_scene_destroy(lvo_scene*);
+void lvo_scene_set_tf(lvo_scene*, const float* rgba, uint32_t n);
+/* CPU LBVH (Morton order + highest-differing-bit splits); optional accelerator. */
+void lvo_scene_build_bvh(lvo_scene*, float lineWidth);
+void lvo_set_num_threads(int n);
+
+/* ---- a7 + closest hit: IntersectionTube (TubeRayTracing.glsl:452-494) over all segments ----
+ * useBvh=0: brute force in ascending segment order (ground truth).
+ * outKind: 0 tube, 1 sphere p0, 2 sphere p1; outSeg = 0xFFFFFFFF on miss. */
+void lvo_trace_rays(
+        const lvo_scene*, float lineWidth, int useCappedTubes, int useBvh,
+        const float* origins, const float* dirs, float tMin, float tMax, uint32_t n,
+        float* outT, uint32_t* outSeg, uint32_t* outKind);
+/* single-capsule test, for known-answer vectors */
+int lvo_intersect_capsule(
+        const float o[3], const float d[3], const float p0[3], const float p1[3], float radius,
+        int useCappedTubes, float* outT, int* outKind);
+
+/* ---- a18: depth range (ComputeDepthValues.glsl:58-98, MinMaxReduce.glsl:64-103) ---- */
+void lvo_compute_depth_range(const lvo_scene*, const lvo_params*, float outMinMax[2]);
+
+/* ---- a13: RTAO (VulkanRayTracedAmbientOcclusion.glsl:178-319), capsule geometry ----
+ * Fills aoOut[width*height] for the region [x0,x0+w) x [y0,y0+h). */
+void lvo_render_ao(
+        const lvo_scene*, const lvo_params*, int useBvh,
+        uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, float* aoOut, lvo_stats* stats);
+
+/* ---- a5,a6,a8-a11: ray tracer frame (TubeRayTracing.glsl RayGen + hit shaders) ----
+ * ao may be NULL unless useAmbientOcclusion.  outRGBA8: w*h*4 tile, row-major. */
+void lvo_render_rt(
+        const lvo_scene*, const lvo_params*, int useBvh, const float* ao,
+        uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, uint8_t* outRGBA8, lvo_stats* stats);
+
+/* ---- a15-a17: PPLL ---- */
+uint32_t lvo_ppll_addr(uint32_t x, uint32_t y, uint32_t viewportWPadded, uint32_t tileW, uint32_t tileH);
+/* gather: all-hits per pixel-centre ray, fragments appended in ascending segment order.
+ * nodes: linkedListSize*3 uint32 {color, depthBits, next}; startOffset: paddedW*paddedH. */
+void lvo_ppll_gather(
+        const lvo_scene*, const lvo_params*, int useBvh, const float* ao,
+        uint32_t x0, uint32_t y0, uint32_t w, uint32_t h,
+        uint32_t* nodes, uint32_t* startOffset, uint32_t* fragCounter, lvo_stats* stats);
+/* resolve one frame from given buffers; literal!=0 uses the reference's depth-only comparisons. */
+void lvo_ppll_resolve(
+        const lvo_params*, const uint32_t* nodes, const uint32_t* startOffset, int literal,
+        uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, uint8_t* outRGBA8);
+void lvo_render_ppll(
+        const lvo_scene*, const lvo_params*, int useBvh, const float* ao,
+        uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, uint8_t* outRGBA8, lvo_stats* stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,297 @@
+"""ctypes binding of the CPU oracle (oracle/lv_oracle.h).
+
+TEST INFRASTRUCTURE, NOT PRODUCT: only tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg may import this module.  PARITY UNPINNED (see lv_oracle.h): the reference
+holds no golden vectors for this path and cannot be built in this image.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "liblv_oracle.so")
+
+
+def build(force=False):
+    src = [os.path.join(_HERE, f) for f in ("lv_oracle.cpp", "lv_oracle.h", "Makefile")]
+    stale = (not os.path.exists(_SO)) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in src)
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    return _SO
+
+
+class LinePoint(C.Structure):
+    _fields_ = [("linePosition", C.c_float * 3), ("lineAttribute", C.c_float),
+                ("lineTangent", C.c_float * 3), ("lineRotation", C.c_float),
+                ("lineNormal", C.c_float * 3), ("lineStartIndex", C.c_uint32)]
+
+
+LINE_POINT_DTYPE = np.dtype([("linePosition", "<f4", 3), ("lineAttribute", "<f4"),
+                             ("lineTangent", "<f4", 3), ("lineRotation", "<f4"),
+                             ("lineNormal", "<f4", 3), ("lineStartIndex", "<u4")])
+assert LINE_POINT_DTYPE.itemsize == 48 and C.sizeof(LinePoint) == 48
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("view", C.c_float * 16), ("proj", C.c_float * 16),
+        ("fovY", C.c_float), ("nearDist", C.c_float), ("farDist", C.c_float),
+        ("width", C.c_uint32), ("height", C.c_uint32),
+        ("background", C.c_float * 4), ("lineWidth", C.c_float),
+        ("maxDepthComplexity", C.c_uint32), ("numSamplesPerFrame", C.c_uint32), ("frameNumber", C.c_uint32),
+        ("useJitteredRays", C.c_uint32), ("useDeterministicSampling", C.c_uint32),
+        ("useCappedTubes", C.c_uint32), ("useHalos", C.c_uint32), ("useDepthCues", C.c_uint32),
+        ("useAmbientOcclusion", C.c_uint32),
+        ("depthCueStrength", C.c_float), ("minDepth", C.c_float), ("maxDepth", C.c_float),
+        ("aoStrength", C.c_float), ("aoGamma", C.c_float),
+        ("attrMin", C.c_float), ("attrMax", C.c_float),
+        ("aoSamplesPerFrame", C.c_uint32), ("aoIterations", C.c_uint32), ("aoUseDistance", C.c_uint32),
+        ("aoJitterPrimary", C.c_uint32), ("tubeNumSubdivisions", C.c_uint32), ("aoRadius", C.c_float),
+        ("ppllMaxNumFrags", C.c_uint32), ("ppllLinkedListSize", C.c_uint32),
+        ("ppllTileW", C.c_uint32), ("ppllTileH", C.c_uint32),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [("raysTraced", C.c_uint64), ("nodesVisited", C.c_uint64), ("primsTested", C.c_uint64),
+                ("hitsShaded", C.c_uint64), ("fragments", C.c_uint64),
+                ("maxDepthComplexity", C.c_uint32), ("bvhDepth", C.c_uint32)]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    build()
+    L = C.CDLL(_SO)
+    vp, u32, f32, i32 = C.c_void_p, C.c_uint32, C.c_float, C.c_int
+    L.lvo_tea.restype = u32
+    L.lvo_tea.argtypes = [u32, u32]
+    L.lvo_lcg.restype = u32
+    L.lvo_lcg.argtypes = [C.POINTER(u32)]
+    L.lvo_rnd.restype = f32
+    L.lvo_rnd.argtypes = [C.POINTER(u32)]
+    L.lvo_sincos_2pi.argtypes = [f32, C.POINTER(f32), C.POINTER(f32)]
+    L.lvo_normalize_positions.argtypes = [vp, C.c_uint64]
+    L.lvo_build_tube_aabb_render_data.argtypes = [vp, vp, vp, u32, f32, vp, C.POINTER(u32), vp, vp, C.POINTER(u32)]
+    L.lvo_mat4_inverse.argtypes = [vp, vp]
+    L.lvo_scene_create.restype = vp
+    L.lvo_scene_create.argtypes = [vp, u32, vp, u32]
+    L.lvo_scene_destroy.argtypes = [vp]
+    L.lvo_scene_set_tf.argtypes = [vp, vp, u32]
+    L.lvo_scene_build_bvh.argtypes = [vp, f32]
+    L.lvo_set_num_threads.argtypes = [i32]
+    L.lvo_trace_rays.argtypes = [vp, f32, i32, i32, vp, vp, f32, f32, u32, vp, vp, vp]
+    L.lvo_intersect_capsule.restype = i32
+    L.lvo_intersect_capsule.argtypes = [vp, vp, vp, vp, f32, i32, C.POINTER(f32), C.POINTER(i32)]
+    L.lvo_compute_depth_range.argtypes = [vp, C.POINTER(Params), vp]
+    L.lvo_render_ao.argtypes = [vp, C.POINTER(Params), i32, u32, u32, u32, u32, vp, C.POINTER(Stats)]
+    L.lvo_render_rt.argtypes = [vp, C.POINTER(Params), i32, vp, u32, u32, u32, u32, vp, C.POINTER(Stats)]
+    L.lvo_ppll_addr.restype = u32
+    L.lvo_ppll_addr.argtypes = [u32, u32, u32, u32, u32]
+    L.lvo_ppll_gather.argtypes = [vp, C.POINTER(Params), i32, vp, u32, u32, u32, u32, vp, vp, C.POINTER(u32),
+                                  C.POINTER(Stats)]
+    L.lvo_ppll_resolve.argtypes = [C.POINTER(Params), vp, vp, i32, u32, u32, u32, u32, vp]
+    L.lvo_render_ppll.argtypes = [vp, C.POINTER(Params), i32, vp, u32, u32, u32, u32, vp, C.POINTER(Stats)]
+    _lib = L
+    return L
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def tea(a, b):
+    return int(lib().lvo_tea(a & 0xFFFFFFFF, b & 0xFFFFFFFF))
+
+
+def rnd_sequence(seed, n):
+    s = C.c_uint32(seed)
+    return np.array([lib().lvo_rnd(C.byref(s)) for _ in range(n)], dtype=np.float32)
+
+
+def sincos_2pi(xi):
+    s, c = C.c_float(), C.c_float()
+    lib().lvo_sincos_2pi(C.c_float(xi), C.byref(s), C.byref(c))
+    return s.value, c.value
+
+
+def mat4_inverse(m):
+    m = np.ascontiguousarray(m, dtype=np.float32).reshape(16)
+    out = np.empty(16, dtype=np.float32)
+    lib().lvo_mat4_inverse(_p(m), _p(out))
+    return out
+
+
+def normalize_positions(positions):
+    p = np.ascontiguousarray(positions, dtype=np.float32).copy()
+    lib().lvo_normalize_positions(_p(p), p.shape[0])
+    return p
+
+
+def build_tube_aabb_render_data(positions, attributes, line_offsets, line_width):
+    """a2 (LineDataFlow.cpp:2112-2277): returns (points[48B], seg_indices[S,2], aabbs[S,6])."""
+    pos = np.ascontiguousarray(positions, dtype=np.float32)
+    att = np.ascontiguousarray(attributes, dtype=np.float32)
+    off = np.ascontiguousarray(line_offsets, dtype=np.uint32)
+    n = pos.shape[0]
+    pts = np.zeros(max(n, 1), dtype=LINE_POINT_DTYPE)
+    seg = np.zeros((max(n, 1), 2), dtype=np.uint32)
+    aabb = np.zeros((max(n, 1), 6), dtype=np.float32)
+    npts, nseg = C.c_uint32(), C.c_uint32()
+    lib().lvo_build_tube_aabb_render_data(_p(pos), _p(att), _p(off), len(off) - 1, line_width, _p(pts),
+                                          C.byref(npts), _p(seg), _p(aabb), C.byref(nseg))
+    return pts[:npts.value].copy(), seg[:nseg.value].copy(), aabb[:nseg.value].copy()
+
+
+def intersect_capsule(o, d, p0, p1, radius, capped=True):
+    a = [np.ascontiguousarray(v, dtype=np.float32) for v in (o, d, p0, p1)]
+    t, k = C.c_float(), C.c_int()
+    hit = lib().lvo_intersect_capsule(_p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), radius, int(capped), C.byref(t),
+                                      C.byref(k))
+    return bool(hit), t.value, k.value
+
+
+DEFAULTS = dict(
+    fovY=float(np.float32(2.0 * np.arctan(0.5))), nearDist=0.01, farDist=100.0,
+    background=(1.0, 1.0, 1.0, 1.0), lineWidth=0.002,
+    maxDepthComplexity=1024, numSamplesPerFrame=1, frameNumber=0, useJitteredRays=0, useDeterministicSampling=0,
+    useCappedTubes=1, useHalos=1, useDepthCues=0, useAmbientOcclusion=0,
+    depthCueStrength=0.8, minDepth=0.0, maxDepth=1.0, aoStrength=1.0, aoGamma=1.0,
+    attrMin=0.0, attrMax=1.0,
+    aoSamplesPerFrame=4, aoIterations=1, aoUseDistance=1, aoJitterPrimary=1, tubeNumSubdivisions=6, aoRadius=0.1,
+    ppllMaxNumFrags=100, ppllLinkedListSize=0, ppllTileW=2, ppllTileH=8,
+)
+
+
+def make_params(view, proj, width, height, **kw):
+    cfg = dict(DEFAULTS)
+    for k in kw:
+        if k not in cfg:
+            raise KeyError(k)
+    cfg.update(kw)
+    P = Params()
+    P.view = (C.c_float * 16)(*np.asarray(view, dtype=np.float32).reshape(16))
+    P.proj = (C.c_float * 16)(*np.asarray(proj, dtype=np.float32).reshape(16))
+    P.width, P.height = int(width), int(height)
+    for k, v in cfg.items():
+        if k == "background":
+            P.background = (C.c_float * 4)(*v)
+        else:
+            setattr(P, k, v)
+    if P.ppllLinkedListSize == 0:
+        pw = -(-P.width // P.ppllTileW) * P.ppllTileW
+        ph = -(-P.height // P.ppllTileH) * P.ppllTileH
+        P.ppllLinkedListSize = 20 * pw * ph  # expectedAvgDepthComplexity = 20, PerPixelLinkedListLineRenderer.hpp:45-49
+    return P
+
+
+class Scene:
+    def __init__(self, points, seg_indices, tf_rgba):
+        self.points = np.ascontiguousarray(points, dtype=LINE_POINT_DTYPE)
+        self.seg = np.ascontiguousarray(seg_indices, dtype=np.uint32).reshape(-1, 2)
+        self.h = lib().lvo_scene_create(_p(self.points), len(self.points), _p(self.seg), len(self.seg))
+        tf = np.ascontiguousarray(tf_rgba, dtype=np.float32).reshape(-1, 4)
+        lib().lvo_scene_set_tf(self.h, _p(tf), tf.shape[0])
+        self.bvh_line_width = None
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().lvo_scene_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def build_bvh(self, line_width):
+        lib().lvo_scene_build_bvh(self.h, line_width)
+        self.bvh_line_width = line_width
+
+    def _use_bvh(self, P_or_lw, use_bvh):
+        lw = P_or_lw.lineWidth if isinstance(P_or_lw, Params) else P_or_lw
+        if use_bvh and self.bvh_line_width != lw:
+            self.build_bvh(lw)
+        return int(bool(use_bvh))
+
+    def trace_rays(self, origins, dirs, t_min, t_max, line_width, capped=True, use_bvh=False):
+        o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(dirs, dtype=np.float32).reshape(-1, 3)
+        n = o.shape[0]
+        t = np.empty(n, dtype=np.float32)
+        seg = np.empty(n, dtype=np.uint32)
+        kind = np.empty(n, dtype=np.uint32)
+        ub = self._use_bvh(line_width, use_bvh)
+        lib().lvo_trace_rays(self.h, line_width, int(capped), ub, _p(o), _p(d), t_min, t_max, n, _p(t), _p(seg),
+                             _p(kind))
+        return t, seg, kind
+
+    def depth_range(self, P):
+        out = np.empty(2, dtype=np.float32)
+        lib().lvo_compute_depth_range(self.h, C.byref(P), _p(out))
+        return out
+
+    def _tile(self, P, tile):
+        return tile if tile is not None else (0, 0, P.width, P.height)
+
+    def render_ao(self, P, tile=None, use_bvh=False, stats=None):
+        x0, y0, w, h = self._tile(P, tile)
+        ao = np.ones((P.height, P.width), dtype=np.float32)
+        st = stats if stats is not None else Stats()
+        lib().lvo_render_ao(self.h, C.byref(P), self._use_bvh(P, use_bvh), x0, y0, w, h, _p(ao), C.byref(st))
+        return ao
+
+    def render_rt(self, P, ao=None, tile=None, use_bvh=False, stats=None):
+        x0, y0, w, h = self._tile(P, tile)
+        out = np.empty((h, w, 4), dtype=np.uint8)
+        st = stats if stats is not None else Stats()
+        aop = _p(np.ascontiguousarray(ao, dtype=np.float32)) if ao is not None else None
+        if P.useAmbientOcclusion and ao is None:
+            raise ValueError("useAmbientOcclusion needs an ao buffer")
+        lib().lvo_render_rt(self.h, C.byref(P), self._use_bvh(P, use_bvh), aop, x0, y0, w, h, _p(out), C.byref(st))
+        return out
+
+    def ppll_gather(self, P, ao=None, tile=None, use_bvh=False, stats=None):
+        x0, y0, w, h = self._tile(P, tile)
+        pw = -(-P.width // P.ppllTileW) * P.ppllTileW
+        ph = -(-P.height // P.ppllTileH) * P.ppllTileH
+        nodes = np.zeros((P.ppllLinkedListSize, 3), dtype=np.uint32)
+        start = np.zeros(pw * ph, dtype=np.uint32)
+        cnt = C.c_uint32()
+        st = stats if stats is not None else Stats()
+        aop = _p(np.ascontiguousarray(ao, dtype=np.float32)) if ao is not None else None
+        lib().lvo_ppll_gather(self.h, C.byref(P), self._use_bvh(P, use_bvh), aop, x0, y0, w, h, _p(nodes), _p(start),
+                              C.byref(cnt), C.byref(st))
+        return nodes, start, cnt.value
+
+    def render_ppll(self, P, ao=None, tile=None, use_bvh=False, stats=None):
+        x0, y0, w, h = self._tile(P, tile)
+        out = np.empty((h, w, 4), dtype=np.uint8)
+        st = stats if stats is not None else Stats()
+        aop = _p(np.ascontiguousarray(ao, dtype=np.float32)) if ao is not None else None
+        lib().lvo_render_ppll(self.h, C.byref(P), self._use_bvh(P, use_bvh), aop, x0, y0, w, h, _p(out), C.byref(st))
+        return out
+
+
+def ppll_resolve(P, nodes, start_offset, tile=None, literal=False):
+    x0, y0, w, h = tile if tile is not None else (0, 0, P.width, P.height)
+    out = np.empty((h, w, 4), dtype=np.uint8)
+    n = np.ascontiguousarray(nodes, dtype=np.uint32)
+    s = np.ascontiguousarray(start_offset, dtype=np.uint32)
+    lib().lvo_ppll_resolve(C.byref(P), _p(n), _p(s), int(literal), x0, y0, w, h, _p(out))
+    return out
+
+
+def ppll_addr(x, y, padded_w, tile_w, tile_h):
+    return int(lib().lvo_ppll_addr(x, y, padded_w, tile_w, tile_h))
+
+
+def set_num_threads(n):
+    lib().lvo_set_num_threads(int(n))

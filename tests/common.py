@@ -1,0 +1,113 @@
+"""Shared helpers of the test-suite: one scene/config description drives both the CPU oracle (oracle/lvo.py) and
+the HIP library (linevis_amd/capi.py) so that parity tests read as "same inputs, compare outputs"."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from linevis_amd import camera, scenes, transfer_function as tfm  # noqa: E402
+from oracle import lvo  # noqa: E402
+
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+
+
+class Case:
+    """A scene + camera + settings, convertible to oracle params and to lv_set_option calls."""
+
+    def __init__(self, points, seg, tf, width, height, line_width, camera_pos=camera.DEFAULT_POSITION,
+                 background=(1.0, 1.0, 1.0, 1.0), **settings):
+        self.points = np.ascontiguousarray(points, dtype=lvo.LINE_POINT_DTYPE)
+        self.seg = np.ascontiguousarray(seg, dtype=np.uint32).reshape(-1, 2)
+        self.tf = np.ascontiguousarray(tf, dtype=np.float32).reshape(-1, 4)
+        self.width, self.height = int(width), int(height)
+        self.line_width = float(np.float32(line_width))
+        self.view, self.proj, self.fovy, self.near, self.far = camera.default_camera(width, height, camera_pos)
+        self.background = tuple(float(x) for x in background)
+        # reference SettingsMap keys (LineRenderer.cpp:433-498, VulkanRayTracer.cpp:226-278, ...)
+        self.settings = dict(settings)
+
+    # ---- oracle side
+    def oracle_scene(self):
+        return lvo.Scene(self.points, self.seg, self.tf)
+
+    def oracle_params(self, scene=None):
+        s = self.settings
+        spp = int(s.get("num_samples_per_frame", 1))
+        ao_on = s.get("ambient_occlusion_mode", "None") == "RTAO (Screen Space)" and \
+            float(s.get("ambient_occlusion_strength", 0.0)) > 0.0
+        dcs = float(s.get("depth_cue_strength", 0.0))
+        kw = dict(
+            fovY=self.fovy, nearDist=self.near, farDist=self.far, background=self.background,
+            lineWidth=self.line_width,
+            maxDepthComplexity=int(s.get("max_depth_complexity", 1024)),
+            numSamplesPerFrame=spp, frameNumber=0, useJitteredRays=int(spp > 1),
+            useDeterministicSampling=int(bool(s.get("use_deterministic_sampling", False))),
+            useCappedTubes=int(bool(s.get("use_capped_tubes", True))), useHalos=int(bool(s.get("use_halos", True))),
+            useDepthCues=int(dcs > 0.0), useAmbientOcclusion=int(ao_on), depthCueStrength=dcs,
+            aoStrength=float(s.get("ambient_occlusion_strength", 0.0)), aoGamma=float(s.get("ambient_occlusion_gamma", 1.0)),
+            aoSamplesPerFrame=int(s.get("ambient_occlusion_samples_per_frame", 4)),
+            aoIterations=int(s.get("ambient_occlusion_iterations", 64)),
+            aoUseDistance=int(bool(s.get("ambient_occlusion_distance_based", True))),
+            aoJitterPrimary=int(bool(s.get("use_jittered_primary_rays", True))),
+            tubeNumSubdivisions=int(s.get("tube_num_subdivisions", 6)),
+            aoRadius=float(s.get("ambient_occlusion_radius", 0.1)),
+            ppllTileW=int(s.get("ppll_tile_width", 2)), ppllTileH=int(s.get("ppll_tile_height", 8)),
+        )
+        large = len(self.seg) > 1000000
+        kw["ppllMaxNumFrags"] = int(s.get("ppll_max_num_frags", 0)) or (380 if large else 100)
+        P = lvo.make_params(self.view, self.proj, self.width, self.height, **kw)
+        avg = int(s.get("ppll_expected_avg_depth_complexity", 0)) or (120 if large else 20)
+        pw = -(-self.width // P.ppllTileW) * P.ppllTileW
+        ph = -(-self.height // P.ppllTileH) * P.ppllTileH
+        P.ppllLinkedListSize = avg * pw * ph
+        if P.useDepthCues and scene is not None:
+            mm = scene.depth_range(P)
+            P.minDepth, P.maxDepth = float(mm[0]), float(mm[1])
+        return P
+
+    def padded(self):
+        tw, th = int(self.settings.get("ppll_tile_width", 2)), int(self.settings.get("ppll_tile_height", 8))
+        return -(-self.width // tw) * tw, -(-self.height // th) * th
+
+    def oracle_render(self, mode, use_bvh=False, tile=None, stats=None):
+        """Full frame as the host orchestration defines it: depth range -> RTAO -> colour / PPLL."""
+        sc = self.oracle_scene()
+        P = self.oracle_params(sc)
+        ao = sc.render_ao(P, tile=tile, use_bvh=use_bvh, stats=stats) if P.useAmbientOcclusion else None
+        if mode == 11:
+            return sc.render_rt(P, ao=ao, tile=tile, use_bvh=use_bvh, stats=stats), ao
+        return sc.render_ppll(P, ao=ao, tile=tile, use_bvh=use_bvh, stats=stats), ao
+
+    # ---- HIP side
+    def hip_context(self, device=0):
+        from linevis_amd import capi
+        ctx = capi.Context(device)
+        ctx.set_lines(self.points, self.seg)
+        ctx.set_transfer_function(self.tf, 0.0, 1.0)
+        ctx.set_camera(self.view, self.proj, self.fovy, self.near, self.far, self.width, self.height)
+        ctx.set_background(self.background)
+        ctx.set_option("line_width", self.line_width)
+        ctx.set_options(self.settings)
+        return ctx
+
+
+def scene_arrays(tr, line_width):
+    """Trajectories -> (points, seg) through the a2 restatement."""
+    pts, seg, _ = lvo.build_tube_aabb_render_data(tr.positions, tr.attributes, tr.line_offsets, line_width)
+    return pts, seg
+
+
+def small_case(width=96, height=64, n_lines=30, pts_per_line=30, seed=7, line_width=0.02, transparent=False,
+               **settings):
+    tr = scenes.normalize(scenes.random_curves(n_lines=n_lines, points_per_line=pts_per_line, seed=seed))
+    pts, seg = scene_arrays(tr, line_width)
+    tf = tfm.standard_transparent() if transparent else tfm.standard()
+    return Case(pts, seg, tf, width, height, line_width, **settings)
+
+
+def max_lsb_diff(a, b):
+    return int(np.abs(a.astype(np.int32) - b.astype(np.int32)).max())
