@@ -62,5 +62,29 @@ def build(force=False, verbose=False):
     return LIB
 
 
+HOST_DIR = os.path.join(HERE, "host")
+HOST_LIB = os.path.join(OUT_DIR, "liblinevis_host.so")
+HOST_SOURCES = ["LineData.cpp", "LineRenderer.cpp", "HeadlessLineRenderer.cpp", "host_capi.cpp"]
+HOST_HEADERS = ["LvMath.hpp", "SettingsMap.hpp", "LineData.hpp", "LineRenderer.hpp", "HeadlessLineRenderer.hpp"]
+# -march=x86-64-v3: built in the CPU container, shipped to the GPU box; -ffp-contract=off: fixed float32 order
+HOST_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-shared", "-fopenmp", "-ffp-contract=off", "-fno-fast-math",
+              "-march=x86-64-v3", "-Wall", "-Wextra", "-Wno-unused-parameter"]
+
+
+def build_host(force=False, verbose=False):
+    """C++ host layer (LineData / LineRenderer-shaped classes) over the C-ABI: liblinevis_host.so."""
+    build(force=force, verbose=verbose)
+    srcs = [os.path.join(HOST_DIR, s) for s in HOST_SOURCES]
+    deps = srcs + [os.path.join(HOST_DIR, h) for h in HOST_HEADERS] + [LIB, os.path.abspath(__file__)]
+    if force or _stale(HOST_LIB, deps):
+        cmd = [os.environ.get("CXX", "g++")] + HOST_FLAGS + srcs + ["-L" + OUT_DIR, "-llinevis_hip",
+                                                                    "-Wl,-rpath,$ORIGIN", "-o", HOST_LIB]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+    return HOST_LIB
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_host(force="--force" in sys.argv, verbose=True))

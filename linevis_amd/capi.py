@@ -59,6 +59,15 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(hipcc, gfx950). There is no CPU fallback." % LIB_PATH)
+    # One HIP runtime per process: torch ships its own libamdhip64.so (SONAME libamdhip64.so.7).  Importing torch
+    # first makes the loader resolve this library's libamdhip64.so.7 dependency to the copy torch already mapped, so
+    # device pointers, streams and events are interchangeable with torch tensors / torch.distributed (RCCL).  If the
+    # library were loaded first, /opt/rocm's runtime would come in and torch would later map a second one that
+    # cannot see the GPU.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, u32, u64, f32, i32, cp = C.c_void_p, C.c_uint32, C.c_uint64, C.c_float, C.c_int, C.c_char_p
     L.lv_create.restype = vp

@@ -14,16 +14,20 @@
 #include "lv_device.h"
 
 // ---------------------------------------------------------------- ray-capsule
+// Both quadratics of RayIntersectionTestsVulkan.glsl are evaluated in the closest-approach form (t_c -+ h with
+// h = sqrt((r^2 - l.l) / A), l = perpendicular offset at t_c; Ray Tracing Gems ch. 7) instead of the reference's
+// (-B -+ sqrt(B^2 - 4AC)) / 2A: for r = 1e-3 at distance 1 the textbook discriminant keeps 1-2 digits in float32 and
+// t jitters by ~0.1 r, which no conservative BVH culling can reproduce.  Same roots, same selection logic.
 __device__ __forceinline__ bool lv_ray_sphere(f3 o, f3 d, f3 ctr, float radius, float& hitT) {
-    float A = (d.x * d.x + d.y * d.y) + d.z * d.z;
-    float B = 2.0f * ((d.x * (o.x - ctr.x) + d.y * (o.y - ctr.y)) + d.z * (o.z - ctr.z));
-    float C = (((o.x - ctr.x) * (o.x - ctr.x) + (o.y - ctr.y) * (o.y - ctr.y)) + (o.z - ctr.z) * (o.z - ctr.z))
-              - radius * radius;
-    float disc = B * B - (4.0f * A) * C;
+    f3 f = o - ctr;
+    float A = dot3(d, d);
+    float tc = -dot3(f, d) / A;
+    f3 l = f + tc * d;
+    float disc = radius * radius - dot3(l, l);
     if (disc < 0.0f) return false;
-    float ds = sqrtf(disc);
-    float t0 = (-B - ds) / (2.0f * A);
-    float t1 = (-B + ds) / (2.0f * A);
+    float h = sqrtf(disc / A);
+    float t0 = tc - h;
+    float t1 = tc + h;
     hitT = t0;
     if (t0 >= 0.0f) hitT = t0;
     else if (t1 >= 0.0f) hitT = t1;
@@ -36,18 +40,18 @@ __device__ __forceinline__ bool lv_ray_tube(f3 o, f3 d, f3 tubeStart, f3 tubeEnd
     f3 deltaP = o - tubeStart;
     f3 av = d - dot3(d, td) * td;
     f3 cv = deltaP - dot3(deltaP, td) * td;
-    float A = (av.x * av.x + av.y * av.y) + av.z * av.z;
-    float B = 2.0f * dot3(av, cv);
-    float C = ((cv.x * cv.x + cv.y * cv.y) + cv.z * cv.z) - radius * radius;
-    float disc = B * B - (4.0f * A) * C;
+    float A = dot3(av, av);
+    float tc = -dot3(av, cv) / A;
+    f3 l = cv + tc * av;
+    float disc = radius * radius - dot3(l, l);
     if (disc < 0.0f) return false;
-    float ds = sqrtf(disc);
-    float t0 = (-B - ds) / (2.0f * A);
+    float h = sqrtf(disc / A);
+    float t0 = tc - h;
     if (t0 >= 0.0f) {
         f3 ip = o + t0 * d;
         if (dot3(td, ip - tubeStart) > 0.0f && dot3(td, ip - tubeEnd) < 0.0f) { hitT = t0; return true; }
     }
-    float t1 = (-B + ds) / (2.0f * A);
+    float t1 = tc + h;
     if (t1 >= 0.0f) {
         f3 ip = o + t1 * d;
         if (dot3(td, ip - tubeStart) > 0.0f && dot3(td, ip - tubeEnd) < 0.0f) { hitT = t1; return true; }

@@ -1,0 +1,265 @@
+// LineData.cpp -- see LineData.hpp for the reference lines each function follows.
+#include "LineData.hpp"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+
+#include "LineRenderer.hpp"
+
+namespace lv {
+
+AABB3 computeTrajectoriesAABB3(const Trajectories& trajectories) {
+    AABB3 aabb;
+    for (const Trajectory& t : trajectories)
+        for (const vec3& p : t.positions) aabb.combine(p);
+    return aabb;
+}
+
+// TrajectoryFile.cpp:106-125: centre at the origin, uniform scale so that the largest extent becomes 0.5.
+void normalizeTrajectoriesVertexPositions(Trajectories& trajectories, const AABB3& aabb) {
+    vec3 translation = vec3(-((aabb.min.x + aabb.max.x) / 2.0f), -((aabb.min.y + aabb.max.y) / 2.0f),
+                            -((aabb.min.z + aabb.max.z) / 2.0f));
+    vec3 scale3D = 0.5f / aabb.getDimensions();
+    float scale = std::min(scale3D.x, std::min(scale3D.y, scale3D.z));
+#pragma omp parallel for
+    for (long i = 0; i < long(trajectories.size()); i++)
+        for (vec3& v : trajectories[size_t(i)].positions) v = (v + translation) * scale;
+}
+
+namespace {
+struct Reader {
+    const unsigned char* p;
+    size_t n, off = 0;
+    bool ok = true;
+    template <typename T>
+    T get() {
+        T v{};
+        if (off + sizeof(T) > n) { ok = false; return v; }
+        memcpy(&v, p + off, sizeof(T));
+        off += sizeof(T);
+        return v;
+    }
+    bool getArray(void* dst, size_t bytes) {
+        if (off + bytes > n) { ok = false; return false; }
+        memcpy(dst, p + off, bytes);
+        off += bytes;
+        return true;
+    }
+};
+} // namespace
+
+// BinLinesLoader.cpp:127-150 (version word) + :41-63 (v1 payload)
+bool loadTrajectoriesFromBinLines(const std::string& filename, Trajectories& trajectories) {
+    FILE* f = fopen(filename.c_str(), "rb");
+    if (!f) return false;
+    fseek(f, 0, SEEK_END);
+    long len = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    std::vector<unsigned char> buf(len > 0 ? size_t(len) : 0);
+    size_t rd = buf.empty() ? 0 : fread(buf.data(), 1, buf.size(), f);
+    fclose(f);
+    if (rd != buf.size()) return false;
+    Reader r{buf.data(), buf.size()};
+    uint32_t versionNumber = r.get<uint32_t>();
+    if (!r.ok || (versionNumber != 1u && versionNumber != 2u)) return false;
+    uint32_t numTrajectories = r.get<uint32_t>();
+    uint32_t numAttributes = r.get<uint32_t>();
+    if (!r.ok) return false;
+    trajectories.clear();
+    trajectories.resize(numTrajectories);
+    for (uint32_t i = 0; i < numTrajectories; i++) {
+        Trajectory& t = trajectories[i];
+        uint32_t n = r.get<uint32_t>();
+        if (!r.ok) return false;
+        t.positions.resize(n);
+        if (!r.getArray(t.positions.data(), sizeof(vec3) * n)) return false;
+        t.attributes.resize(numAttributes);
+        for (uint32_t a = 0; a < numAttributes; a++) {
+            t.attributes[a].resize(n);
+            if (!r.getArray(t.attributes[a].data(), sizeof(float) * n)) return false;
+        }
+    }
+    return true;
+}
+
+bool saveTrajectoriesAsBinLines(const std::string& filename, const Trajectories& trajectories) {
+    FILE* f = fopen(filename.c_str(), "wb");
+    if (!f) return false;
+    uint32_t hdr[3] = {1u, uint32_t(trajectories.size()),
+                       trajectories.empty() ? 0u : uint32_t(trajectories[0].attributes.size())};
+    fwrite(hdr, 4, 3, f);
+    for (const Trajectory& t : trajectories) {
+        uint32_t n = uint32_t(t.positions.size());
+        fwrite(&n, 4, 1, f);
+        fwrite(t.positions.data(), sizeof(vec3), n, f);
+        for (uint32_t a = 0; a < hdr[2]; a++) fwrite(t.attributes[a].data(), sizeof(float), n, f);
+    }
+    return fclose(f) == 0;
+}
+
+// ---------------------------------------------------------------- LineData
+void LineData::setSelectedAttributeIndex(int idx) {
+    if (idx != selectedAttributeIndex) {
+        selectedAttributeIndex = idx;
+        setTriangleRepresentationDirty();
+    }
+}
+
+void LineData::getMinMaxAttributeValues(float& minAttr, float& maxAttr) const {
+    if (selectedAttributeIndex >= 0 && size_t(selectedAttributeIndex) < minMaxAttributeValues.size()) {
+        minAttr = minMaxAttributeValues[size_t(selectedAttributeIndex)].first;
+        maxAttr = minMaxAttributeValues[size_t(selectedAttributeIndex)].second;
+    } else {
+        minAttr = 0.0f;
+        maxAttr = 1.0f;
+    }
+}
+
+bool LineData::setNewSettings(const SettingsMap& settings) {
+    bool shallReloadGatherShader = false;
+    std::string attributeName;
+    if (settings.getValueOpt("attribute", attributeName)) {
+        for (size_t i = 0; i < attributeNames.size(); i++) {
+            if (attributeNames[i] == attributeName) { setSelectedAttributeIndex(int(i)); break; }
+        }
+    }
+    int n = tubeNumSubdivisions;
+    if (settings.getValueOpt("tube_num_subdivisions", n) && n != tubeNumSubdivisions) {
+        tubeNumSubdivisions = n;
+        shallReloadGatherShader = true;
+    }
+    bool b = useCappedTubes;
+    if (settings.getValueOpt("use_capped_tubes", b) && b != useCappedTubes) {
+        useCappedTubes = b;
+        shallReloadGatherShader = true;
+    }
+    b = useHalos;
+    if (settings.getValueOpt("use_halos", b) && b != useHalos) {
+        useHalos = b;
+        shallReloadGatherShader = true;
+    }
+    return shallReloadGatherShader;
+}
+
+// ---------------------------------------------------------------- LineDataFlow
+bool LineDataFlow::loadFromFile(const std::string& filename) {
+    Trajectories loaded;
+    if (!loadTrajectoriesFromBinLines(filename, loaded)) return false;
+    AABB3 aabb = computeTrajectoriesAABB3(loaded);
+    normalizeTrajectoriesVertexPositions(loaded, aabb);
+    setTrajectoryData(loaded);
+    return true;
+}
+
+// LineDataFlow.cpp:468-578 (flow lines: counts, per-attribute min/max, model AABB)
+void LineDataFlow::setTrajectoryData(const Trajectories& newTrajectories, const std::vector<std::string>& names) {
+    trajectories = newTrajectories;
+    numTotalTrajectories = trajectories.size();
+    numTotalTrajectoryPoints = 0;
+    for (const Trajectory& t : trajectories) numTotalTrajectoryPoints += t.positions.size();
+    size_t numAttr = trajectories.empty() ? 0 : trajectories[0].attributes.size();
+    attributeNames = names;
+    for (size_t i = attributeNames.size(); i < numAttr; i++) attributeNames.push_back("Attribute #" + std::to_string(i + 1));
+    minMaxAttributeValues.clear();
+    for (size_t varIdx = 0; varIdx < numAttr; varIdx++) {
+        float minAttr = std::numeric_limits<float>::max();
+        float maxAttr = std::numeric_limits<float>::lowest();
+        for (const Trajectory& t : trajectories)
+            for (float val : t.attributes[varIdx]) { minAttr = std::min(minAttr, val); maxAttr = std::max(maxAttr, val); }
+        minMaxAttributeValues.emplace_back(minAttr, maxAttr);
+    }
+    modelBoundingBox = computeTrajectoriesAABB3(trajectories);
+    cachedAabbDataValid = false;
+    dirty = true;
+}
+
+size_t LineDataFlow::getNumLineSegments() {
+    size_t n = 0;
+    for (const Trajectory& t : trajectories) n += t.positions.empty() ? 0 : t.positions.size() - 1;
+    return n;
+}
+
+std::vector<std::vector<vec3>> LineDataFlow::getFilteredLines(LineRenderer*) {
+    std::vector<std::vector<vec3>> lines;
+    lines.reserve(trajectories.size());
+    for (const Trajectory& t : trajectories) lines.push_back(t.positions);
+    return lines;
+}
+
+// LineDataFlow.cpp:2112-2277.  The per-line loop carries lastLineNormal from point to point, so lines are the unit
+// of parallelism: every line is processed into its own vectors (OpenMP), then concatenated in line order.
+TubeAabbRenderData LineDataFlow::getLinePassTubeAabbRenderData(bool /*isRasterizer*/, bool /*ellipticTubes*/) {
+    const float lineWidth = LineRenderer::getLineWidth();
+    if (cachedAabbDataValid && cachedLineWidth == lineWidth) return cachedTubeAabbRenderData;
+    const vec3 lineWidthOffset(lineWidth * 0.5f);
+    const size_t numLines = trajectories.size();
+    std::vector<std::vector<LinePointDataUnified>> perLine(numLines);
+
+#pragma omp parallel for schedule(dynamic, 16)
+    for (long li = 0; li < long(numLines); li++) {
+        const Trajectory& trajectory = trajectories[size_t(li)];
+        std::vector<LinePointDataUnified>& out = perLine[size_t(li)];
+        const size_t n = trajectory.positions.size();
+        if (n < 2) continue;
+        out.reserve(n);
+        vec3 lastLineNormal(1.0f, 0.0f, 0.0f);
+        for (size_t i = 0; i < n; i++) {
+            vec3 tangent;
+            if (i == 0) tangent = trajectory.positions[i + 1] - trajectory.positions[i];
+            else if (i + 1 == n) tangent = trajectory.positions[i] - trajectory.positions[i - 1];
+            else tangent = trajectory.positions[i + 1] - trajectory.positions[i - 1];
+            float tangentLength = length(tangent);
+            if (tangentLength < 0.0001f) continue; // two (almost) identical vertices: skip this point
+            tangent = normalize(tangent);
+            vec3 helperAxis = lastLineNormal;
+            if (length(cross(helperAxis, tangent)) < 0.01f) {
+                helperAxis = vec3(0.0f, 1.0f, 0.0f);
+                if (length(cross(helperAxis, tangent)) < 0.01f) helperAxis = vec3(0.0f, 0.0f, 1.0f);
+            }
+            vec3 normal = normalize(helperAxis - dot(helperAxis, tangent) * tangent); // Gram-Schmidt
+            lastLineNormal = normal;
+            LinePointDataUnified lp;
+            memset(&lp, 0, sizeof(lp));
+            const vec3& p = trajectory.positions[i];
+            lp.linePosition[0] = p.x; lp.linePosition[1] = p.y; lp.linePosition[2] = p.z;
+            lp.lineAttribute = trajectory.attributes.empty()
+                    ? 0.0f : trajectory.attributes[size_t(selectedAttributeIndex)][i];
+            lp.lineTangent[0] = tangent.x; lp.lineTangent[1] = tangent.y; lp.lineTangent[2] = tangent.z;
+            lp.lineNormal[0] = normal.x; lp.lineNormal[1] = normal.y; lp.lineNormal[2] = normal.z;
+            out.push_back(lp);
+        }
+        if (out.size() <= 1) out.clear(); // a tube of one point is dropped
+    }
+
+    TubeAabbRenderData data;
+    size_t totalPoints = 0, totalSegs = 0;
+    for (const auto& l : perLine) { totalPoints += l.size(); totalSegs += l.empty() ? 0 : l.size() - 1; }
+    data.linePointDataBuffer.reserve(totalPoints);
+    data.indexBuffer.reserve(2 * totalSegs);
+    data.aabbBuffer.reserve(totalSegs);
+    uint32_t lineSegmentIndexCounter = 0;
+    for (const auto& l : perLine) {
+        if (l.empty()) continue;
+        data.linePointDataBuffer.insert(data.linePointDataBuffer.end(), l.begin(), l.end());
+        for (uint32_t pointIdx = 1; pointIdx < uint32_t(l.size()); pointIdx++) {
+            data.indexBuffer.push_back(lineSegmentIndexCounter + pointIdx - 1);
+            data.indexBuffer.push_back(lineSegmentIndexCounter + pointIdx);
+            const float* a = l[pointIdx - 1].linePosition;
+            const float* b = l[pointIdx].linePosition;
+            vec3 pt0(a[0], a[1], a[2]), pt1(b[0], b[1], b[2]);
+            AABB3 aabb;
+            aabb.min = lv::min(pt0, pt1) - lineWidthOffset;
+            aabb.max = lv::max(pt0, pt1) + lineWidthOffset;
+            data.aabbBuffer.push_back(aabb);
+        }
+        lineSegmentIndexCounter += uint32_t(l.size());
+    }
+    cachedTubeAabbRenderData = data;
+    cachedAabbDataValid = true;
+    cachedLineWidth = lineWidth;
+    return data;
+}
+
+} // namespace lv

@@ -1,0 +1,113 @@
+// LineData.hpp -- headless line-data model feeding the HIP renderers.
+//
+// Mirrors the part of the reference's data model the hot path consumes:
+//   struct Trajectory / Trajectories                       src/Loaders/TrajectoryFile.hpp:38-46
+//   normalizeTrajectoriesVertexPositions                   src/Loaders/TrajectoryFile.cpp:106-125
+//   loadTrajectoriesFromBinLines (v1 / v2 header)          src/Loaders/BinLinesLoader.cpp:41-63,127-150
+//   struct LinePointDataUnified (48 B), TubeAabbRenderData src/LineData/LineRenderData.hpp:99-106,203-210
+//   class LineData accessors                               src/LineData/LineData.hpp:149-262
+//   LineDataFlow::setTrajectoryData                        src/LineData/LineDataFlow.cpp:468-578
+//   LineDataFlow::getLinePassTubeAabbRenderData            src/LineData/LineDataFlow.cpp:2112-2277
+// Accessors return host-side POD arrays (byte-identical record layouts) instead of sgl::vk::BufferPtr.
+#pragma once
+
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/linevis_hip.h"
+#include "LvMath.hpp"
+#include "SettingsMap.hpp"
+
+namespace lv {
+
+struct Trajectory {
+    std::vector<vec3> positions;
+    std::vector<std::vector<float>> attributes;
+};
+typedef std::vector<Trajectory> Trajectories;
+
+AABB3 computeTrajectoriesAABB3(const Trajectories& trajectories);
+void normalizeTrajectoriesVertexPositions(Trajectories& trajectories, const AABB3& aabb);
+/// .binlines reader (version 1 payload; the trailing ribbon / hull-mesh part of version 2 files is ignored).
+bool loadTrajectoriesFromBinLines(const std::string& filename, Trajectories& trajectories);
+bool saveTrajectoriesAsBinLines(const std::string& filename, const Trajectories& trajectories);
+
+typedef lv_line_point LinePointDataUnified; // 48 bytes, src/LineData/LineRenderData.hpp:99-106
+static_assert(sizeof(LinePointDataUnified) == 48, "LinePointDataUnified must stay byte-identical to the reference");
+
+struct TubeAabbRenderData {
+    std::vector<uint32_t> indexBuffer;                     // two point indices per AABB / segment
+    std::vector<AABB3> aabbBuffer;                         // VkAabbPositionsKHR layout (6 floats)
+    std::vector<LinePointDataUnified> linePointDataBuffer;
+};
+
+enum DataSetType { DATA_SET_TYPE_NONE = 0, DATA_SET_TYPE_FLOW_LINES = 1 };
+
+class LineRenderer;
+
+class LineData {
+public:
+    explicit LineData(DataSetType type) : dataSetType(type) {}
+    virtual ~LineData() = default;
+    DataSetType getType() const { return dataSetType; }
+    const AABB3& getModelBoundingBox() const { return modelBoundingBox; }
+    const std::vector<std::string>& getAttributeNames() const { return attributeNames; }
+    int getSelectedAttributeIndex() const { return selectedAttributeIndex; }
+    void setSelectedAttributeIndex(int idx);
+    /// (min, max) of the selected attribute: the transfer-function range (LineDataFlow.cpp:511-530).
+    void getMinMaxAttributeValues(float& minAttr, float& maxAttr) const;
+    bool getUseCappedTubes() const { return useCappedTubes; }
+    bool getUseHalos() const { return useHalos; }
+    int getTubeNumSubdivisions() const { return tubeNumSubdivisions; }
+    bool isDirty() const { return dirty; }
+    void setDirty(bool d) { dirty = d; }
+
+    virtual size_t getNumLines() = 0;
+    virtual size_t getNumLinePoints() = 0;
+    virtual size_t getNumLineSegments() = 0;
+    virtual TubeAabbRenderData getLinePassTubeAabbRenderData(bool isRasterizer, bool ellipticTubes) = 0;
+    /// Points of all (unfiltered) lines, used for the depth-cue range (LineRenderer.cpp:365-408).
+    virtual std::vector<std::vector<vec3>> getFilteredLines(LineRenderer* lineRenderer) = 0;
+
+    /// dataset-side settings keys: attribute, tube_num_subdivisions, use_capped_tubes, use_halos
+    /// (src/LineData/LineData.cpp:87-181).  Returns true when renderers must re-fetch geometry/defines.
+    virtual bool setNewSettings(const SettingsMap& settings);
+    void setTriangleRepresentationDirty() { cachedAabbDataValid = false; dirty = true; }
+
+protected:
+    DataSetType dataSetType;
+    AABB3 modelBoundingBox;
+    std::vector<std::string> attributeNames;
+    std::vector<std::pair<float, float>> minMaxAttributeValues;
+    int selectedAttributeIndex = 0;
+    bool useCappedTubes = true;      // LineData.hpp:377-379
+    bool useHalos = true;
+    int tubeNumSubdivisions = 6;     // LineData.cpp:52
+    bool dirty = false;
+    bool cachedAabbDataValid = false;
+};
+typedef std::shared_ptr<LineData> LineDataPtr;
+
+class LineDataFlow : public LineData {
+public:
+    LineDataFlow() : LineData(DATA_SET_TYPE_FLOW_LINES) {}
+    /// loadFromFile (LineDataFlow.cpp:431-454) for .binlines; normalises positions like the reference loader.
+    bool loadFromFile(const std::string& filename);
+    void setTrajectoryData(const Trajectories& trajectories, const std::vector<std::string>& names = {});
+    const Trajectories& getTrajectories() const { return trajectories; }
+
+    size_t getNumLines() override { return numTotalTrajectories; }
+    size_t getNumLinePoints() override { return numTotalTrajectoryPoints; }
+    size_t getNumLineSegments() override;
+    TubeAabbRenderData getLinePassTubeAabbRenderData(bool isRasterizer, bool ellipticTubes) override;
+    std::vector<std::vector<vec3>> getFilteredLines(LineRenderer* lineRenderer) override;
+
+private:
+    Trajectories trajectories;
+    size_t numTotalTrajectories = 0, numTotalTrajectoryPoints = 0;
+    TubeAabbRenderData cachedTubeAabbRenderData;
+    float cachedLineWidth = -1.0f;
+};
+
+} // namespace lv

@@ -1,0 +1,305 @@
+// LineRenderer.cpp -- see LineRenderer.hpp for the reference classes mirrored here.
+#include "LineRenderer.hpp"
+
+#include <cstring>
+
+namespace lv {
+
+const char* const AMBIENT_OCCLUSION_BAKER_TYPE_NAMES[4] = {"RTAO (Prebaker)", "RTAO (Screen Space)", "SSAO",
+                                                           "GTAO (reference)"};
+
+float LineRenderer::lineWidth = 0.002f; // src/Loaders/DataSetList.hpp:46
+float LineRenderer::bandWidth = 0.005f;
+
+void Camera::overwriteMatrices(const float view[16], const float proj[16]) {
+    overwritten = true;
+    memcpy(viewOverride.m, view, 64);
+    memcpy(projOverride.m, proj, 64);
+}
+
+// ---------------------------------------------------------------- RTAO settings holder
+void HipRayTracedAmbientOcclusion::startAmbientOcclusionBaking(LineDataPtr&, bool) {
+    isDataReady = false;
+    hasComputationFinished = false;
+}
+
+// VulkanRayTracedAmbientOcclusion::setNewSettings, VulkanRayTracedAmbientOcclusion.cpp:115-144
+bool HipRayTracedAmbientOcclusion::setNewSettings(const SettingsMap& settings) {
+    bool optionChanged = false;
+    if (settings.getValueOpt("ambient_occlusion_iterations", maxNumAccumulatedFrames)) optionChanged = true;
+    if (settings.getValueOpt("ambient_occlusion_samples_per_frame", numAmbientOcclusionSamplesPerFrame)) optionChanged = true;
+    if (settings.getValueOpt("ambient_occlusion_radius", ambientOcclusionRadius)) optionChanged = true;
+    if (settings.getValueOpt("ambient_occlusion_distance_based", useDistance)) optionChanged = true;
+    if (settings.getValueOpt("use_jittered_primary_rays", useJitteredPrimaryRays)) optionChanged = true;
+    if (optionChanged) {
+        onHasMoved();
+        pushSettings();
+    }
+    return optionChanged;
+}
+
+void HipRayTracedAmbientOcclusion::pushSettings() {
+    SettingsMap m;
+    m.addKeyValue("ambient_occlusion_iterations", maxNumAccumulatedFrames);
+    m.addKeyValue("ambient_occlusion_samples_per_frame", numAmbientOcclusionSamplesPerFrame);
+    m.addKeyValue("ambient_occlusion_radius", ambientOcclusionRadius);
+    m.addKeyValue("ambient_occlusion_distance_based", useDistance);
+    m.addKeyValue("use_jittered_primary_rays", useJitteredPrimaryRays);
+    for (const auto& kv : m.getMap()) lv_set_option(ctx, kv.first.c_str(), kv.second.c_str());
+}
+
+// ---------------------------------------------------------------- LineRenderer
+LineRenderer::LineRenderer(std::string windowName, SceneData* sceneData, TransferFunctionWindow& tfw)
+        : windowName(std::move(windowName)), sceneData(sceneData), transferFunctionWindow(tfw) {}
+
+void LineRenderer::initialize() {
+    int err = 0;
+    ctx = lv_create(sceneData ? sceneData->deviceOrdinal : 0, &err);
+    if (!ctx) lastError = "lv_create failed (no HIP device; there is no CPU fallback)";
+}
+
+LineRenderer::~LineRenderer() {
+    if (ctx) lv_destroy(ctx);
+}
+
+bool LineRenderer::check(int rc, const char* what) {
+    if (rc == LV_OK) return true;
+    lastError = std::string(what) + ": " + (ctx ? lv_last_error(ctx) : "no context");
+    return false;
+}
+
+bool LineRenderer::setOption(const char* key, const std::string& value) {
+    if (!ctx) return false;
+    return check(lv_set_option(ctx, key, value.c_str()), key);
+}
+
+bool LineRenderer::needsReRender() {
+    bool tmp = reRender;
+    reRender = false;
+    return tmp;
+}
+
+void LineRenderer::onResolutionChanged() {
+    if (ambientOcclusionBaker) ambientOcclusionBaker->onResolutionChanged();
+    reRender = true;
+}
+
+void LineRenderer::onHasMoved() {
+    if (ambientOcclusionBaker) ambientOcclusionBaker->onHasMoved();
+    reRender = true;
+}
+
+// LineRenderer::setAmbientOcclusionBaker, LineRenderer.cpp:310-357 (only the screen-space RTAO baker exists here)
+void LineRenderer::setAmbientOcclusionBaker() {
+    ambientOcclusionBaker = {};
+    if (ambientOcclusionBakerType == AmbientOcclusionBakerType::RTAO && ctx) {
+        auto baker = std::make_shared<HipRayTracedAmbientOcclusion>(ctx);
+        baker->pushSettings();
+        ambientOcclusionBaker = baker;
+        setOption("ambient_occlusion_mode", AMBIENT_OCCLUSION_BAKER_TYPE_NAMES[1]);
+    } else {
+        if (ctx) setOption("ambient_occlusion_mode", "None");
+    }
+    reRender = true;
+    if (useAmbientOcclusion && ambientOcclusionBaker && lineData) ambientOcclusionBaker->startAmbientOcclusionBaking(lineData, true);
+}
+
+// LineRenderer::setNewSettings, LineRenderer.cpp:433-498
+bool LineRenderer::setNewSettings(const SettingsMap& settings) {
+    bool shallReloadGatherShader = false;
+    float newLineWidth = lineWidth;
+    if (settings.getValueOpt("line_width", lineWidth)) {
+        if (newLineWidth != lineWidth && lineData) {
+            lineData->setTriangleRepresentationDirty();
+            linesDirty = true;
+        }
+    }
+    settings.getValueOpt("band_width", bandWidth);
+
+    if (settings.getValueOpt("depth_cue_strength", depthCueStrength)) {
+        if (depthCueStrength <= 0.0f && useDepthCues) { useDepthCues = false; shallReloadGatherShader = true; }
+        if (depthCueStrength > 0.0f && !useDepthCues) { useDepthCues = true; shallReloadGatherShader = true; }
+        setOption("depth_cue_strength", settings.getValue("depth_cue_strength"));
+    }
+
+    std::string ambientOcclusionModeName;
+    if (settings.getValueOpt("ambient_occlusion_mode", ambientOcclusionModeName)) {
+        AmbientOcclusionBakerType newType = AmbientOcclusionBakerType::NONE;
+        for (int i = 0; i < 4; i++)
+            if (ambientOcclusionModeName == AMBIENT_OCCLUSION_BAKER_TYPE_NAMES[i]) newType = AmbientOcclusionBakerType(i);
+        if (newType != AmbientOcclusionBakerType::NONE && newType != AmbientOcclusionBakerType::RTAO) {
+            lastError = "ambient_occlusion_mode '" + ambientOcclusionModeName + "' is not provided by the HIP renderers";
+        } else if (newType != ambientOcclusionBakerType || !ambientOcclusionBaker) {
+            ambientOcclusionBakerType = newType;
+            setAmbientOcclusionBaker();
+        }
+    }
+    if (settings.getValueOpt("ambient_occlusion_strength", ambientOcclusionStrength)) {
+        if (ambientOcclusionStrength <= 0.0f && useAmbientOcclusion) { useAmbientOcclusion = false; shallReloadGatherShader = true; }
+        if (ambientOcclusionStrength > 0.0f && !useAmbientOcclusion) { useAmbientOcclusion = true; shallReloadGatherShader = true; }
+        setOption("ambient_occlusion_strength", settings.getValue("ambient_occlusion_strength"));
+    }
+    if (settings.getValueOpt("ambient_occlusion_gamma", ambientOcclusionGamma))
+        setOption("ambient_occlusion_gamma", settings.getValue("ambient_occlusion_gamma"));
+    if (ambientOcclusionBaker) ambientOcclusionBaker->setNewSettings(settings);
+    reRender = true;
+    return shallReloadGatherShader;
+}
+
+// LineRenderer::updateNewLineData, LineRenderer.cpp:676-708
+void LineRenderer::updateNewLineData(LineDataPtr& newLineData, bool isNewData) {
+    lineData = newLineData;
+    linesDirty = true;
+    if (useAmbientOcclusion && ambientOcclusionBaker) ambientOcclusionBaker->startAmbientOcclusionBaking(lineData, isNewData);
+    dirty = false;
+    reRender = true;
+}
+
+// camera / clear colour / transfer function / geometry -> context (LineData::updateVulkanUniformBuffers,
+// LineData.cpp:1275-1319, and the buffer fetches of RayTracingRenderPass::setLineData, VulkanRayTracer.cpp:370-411)
+bool LineRenderer::uploadFrameState() {
+    if (!ctx) { lastError = "renderer not initialised"; return false; }
+    if (!lineData) { lastError = "no line data"; return false; }
+    const uint32_t w = *sceneData->viewportWidth, h = *sceneData->viewportHeight;
+    Camera& cam = *sceneData->camera;
+    cam.setAspectRatio(float(w) / float(h));
+    mat4 view = cam.getViewMatrix(), proj = cam.getProjectionMatrix();
+    if (!check(lv_set_camera(ctx, view.m, proj.m, cam.getFOVy(), cam.getNearClipDistance(), cam.getFarClipDistance(), w, h),
+               "lv_set_camera"))
+        return false;
+    const Color& c = *sceneData->clearColor;
+    const float bg[4] = {c.r, c.g, c.b, c.a};
+    if (!check(lv_set_background(ctx, bg), "lv_set_background")) return false;
+    if (tfDirty || transferFunctionWindow.getIsDirty()) {
+        const std::vector<float>& t = transferFunctionWindow.getTable();
+        float mn = 0.0f, mx = 1.0f;
+        lineData->getMinMaxAttributeValues(mn, mx);
+        if (!check(lv_set_transfer_function(ctx, t.data(), uint32_t(t.size() / 4), mn, mx), "lv_set_transfer_function"))
+            return false;
+        transferFunctionWindow.resetDirty();
+        tfDirty = false;
+    }
+    if (linesDirty || lineData->isDirty()) {
+        char buf[64];
+        snprintf(buf, sizeof(buf), "%.9g", double(lineWidth));
+        if (!setOption("line_width", buf)) return false;
+        TubeAabbRenderData d = lineData->getLinePassTubeAabbRenderData(false, false);
+        if (!check(lv_set_lines(ctx, d.linePointDataBuffer.data(), uint32_t(d.linePointDataBuffer.size()),
+                                d.indexBuffer.data(), uint32_t(d.indexBuffer.size() / 2)), "lv_set_lines"))
+            return false;
+        // getVulkanShaderPreprocessorDefines, LineData.cpp:1209-1256
+        setOption("use_capped_tubes", lineData->getUseCappedTubes() ? "true" : "false");
+        setOption("use_halos", lineData->getUseHalos() ? "true" : "false");
+        setOption("tube_num_subdivisions", std::to_string(lineData->getTubeNumSubdivisions()));
+        lineData->setDirty(false);
+        linesDirty = false;
+        tfDirty = true; // attribute range may have changed with the data
+        return uploadFrameState();
+    }
+    return true;
+}
+
+// LineRenderer::renderBase (LineRenderer.cpp:248-277): depth range + AO iterations happen inside lv_render.
+void LineRenderer::renderBase() {}
+
+bool LineRenderer::renderMode(int mode) {
+    if (!uploadFrameState()) return false;
+    const uint32_t w = *sceneData->viewportWidth, h = *sceneData->viewportHeight;
+    sceneData->sceneTexture->resize(size_t(w) * h * 4);
+    if (!check(lv_render(ctx, mode, 0, 0, w, h, sceneData->sceneTexture->data()), "lv_render")) return false;
+    if (useAmbientOcclusion && ambientOcclusionBaker)
+        static_cast<HipRayTracedAmbientOcclusion*>(ambientOcclusionBaker.get())->notifyRendered();
+    return true;
+}
+
+lv_stats LineRenderer::getStatistics() {
+    lv_stats s;
+    memset(&s, 0, sizeof(s));
+    if (ctx) lv_get_stats(ctx, &s);
+    return s;
+}
+
+// ---------------------------------------------------------------- HipRayTracer
+HipRayTracer::HipRayTracer(SceneData* sceneData, TransferFunctionWindow& tfw)
+        : LineRenderer("Vulkan Ray Tracer", sceneData, tfw) {
+    isRasterizer = false;
+}
+
+void HipRayTracer::setLineData(LineDataPtr& newLineData, bool isNewData) {
+    updateNewLineData(newLineData, isNewData);
+    accumulatedFramesCounter = 0;
+}
+
+bool HipRayTracer::needsReRender() {
+    // VulkanRayTracer::needsReRender, VulkanRayTracer.cpp:330-336
+    if (accumulatedFramesCounter < maxNumAccumulatedFrames) return true;
+    return LineRenderer::needsReRender();
+}
+
+void HipRayTracer::onHasMoved() {
+    LineRenderer::onHasMoved();
+    accumulatedFramesCounter = 0; // VulkanRayTracer.cpp:343-346
+}
+
+void HipRayTracer::render() {
+    LineRenderer::renderBase();
+    if (renderMode(LV_RENDERING_MODE_VULKAN_RAY_TRACER)) accumulatedFramesCounter++;
+}
+
+// VulkanRayTracer::setNewSettings, VulkanRayTracer.cpp:226-278
+bool HipRayTracer::setNewSettings(const SettingsMap& settings) {
+    bool shallReloadGatherShader = LineRenderer::setNewSettings(settings);
+    std::string s;
+    if (settings.getValueOpt("geometry_mode", s)) setOption("geometry_mode", s);
+    else if (settings.getValueOpt("use_analytic_intersections", s)) setOption("use_analytic_intersections", s);
+    if (settings.getValueOpt("num_samples_per_frame", numSamplesPerFrame)) {
+        setOption("num_samples_per_frame", std::to_string(numSamplesPerFrame));
+        accumulatedFramesCounter = 0;
+    }
+    if (settings.getValueOpt("num_accumulated_frames", maxNumAccumulatedFrames)) {
+        setOption("num_accumulated_frames", std::to_string(maxNumAccumulatedFrames));
+        accumulatedFramesCounter = 0;
+    }
+    if (settings.getValueOpt("use_deterministic_sampling", useDeterministicSampling)) {
+        setOption("use_deterministic_sampling", useDeterministicSampling ? "true" : "false");
+        accumulatedFramesCounter = 0;
+    }
+    if (settings.getValueOpt("use_mlat", s)) setOption("use_mlat", s);
+    if (settings.getValueOpt("max_depth_complexity", maxDepthComplexity))
+        setOption("max_depth_complexity", std::to_string(maxDepthComplexity));
+    return shallReloadGatherShader;
+}
+
+// ---------------------------------------------------------------- PPLL
+HipPerPixelLinkedListLineRenderer::HipPerPixelLinkedListLineRenderer(SceneData* sceneData, TransferFunctionWindow& tfw)
+        : LineRenderer("Per-Pixel Linked List Renderer", sceneData, tfw) {
+    isRasterizer = true;
+}
+
+void HipPerPixelLinkedListLineRenderer::setLineData(LineDataPtr& newLineData, bool isNewData) {
+    updateNewLineData(newLineData, isNewData);
+    // updateLargeMeshMode (PerPixelLinkedListLineRenderer.cpp:109-126) is applied by the context from the
+    // segment count unless the ppll_* options override it.
+}
+
+void HipPerPixelLinkedListLineRenderer::render() {
+    LineRenderer::renderBase();
+    renderMode(LV_RENDERING_MODE_PER_PIXEL_LINKED_LIST); // clear -> gather -> resolve
+}
+
+bool HipPerPixelLinkedListLineRenderer::setNewSettings(const SettingsMap& settings) {
+    bool r = LineRenderer::setNewSettings(settings);
+    for (const char* key : {"ppll_max_num_frags", "ppll_expected_avg_depth_complexity", "ppll_tile_width", "ppll_tile_height"}) {
+        std::string s;
+        if (settings.getValueOpt(key, s)) setOption(key, s);
+    }
+    return r;
+}
+
+void HipPerPixelLinkedListLineRenderer::computeStatistics(uint64_t& totalNumFragments, uint32_t& maxComplexity) {
+    lv_stats s = getStatistics();
+    totalNumFragments = s.fragments;
+    maxComplexity = s.max_depth_complexity;
+}
+
+} // namespace lv

@@ -1,0 +1,225 @@
+// LineRenderer.hpp -- headless renderer plugins over the C-ABI (include/linevis_hip.h).
+//
+// Mirrors the reference's plugin surface without Vulkan / ImGui types:
+//   class LineRenderer                         src/Renderers/LineRenderer.hpp:66-277
+//   struct SceneData                           src/Renderers/SceneData.hpp:49-85
+//   enum RenderingMode                         src/Renderers/RenderingModes.hpp:32-53
+//   class AmbientOcclusionBaker (+ type enum)  src/Renderers/AmbientOcclusion/AmbientOcclusionBaker.hpp:78-141
+//   class VulkanRayTracedAmbientOcclusion      src/Renderers/AmbientOcclusion/VulkanRayTracedAmbientOcclusion.hpp:61-110
+//   class VulkanRayTracer                      src/Renderers/RayTracing/VulkanRayTracer.hpp:73-145
+//   class PerPixelLinkedListLineRenderer       src/Renderers/OIT/PerPixelLinkedListLineRenderer.hpp
+// A renderer owns one lv_ctx (one HIP device).  render() writes RGBA8 into SceneData::sceneTexture.
+#pragma once
+
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/linevis_hip.h"
+#include "LineData.hpp"
+#include "SettingsMap.hpp"
+
+namespace lv {
+
+enum RenderingMode : int32_t {
+    RENDERING_MODE_NONE = -1,
+    RENDERING_MODE_PER_PIXEL_LINKED_LIST = 2,
+    RENDERING_MODE_VULKAN_RAY_TRACER = 11,
+};
+
+/// Stand-in for sgl::Camera (not in the reference tree); conventions: LvMath.hpp / linevis_amd/camera.py.
+class Camera {
+public:
+    void setPosition(vec3 p) { position = p; }
+    void setLookAtLocation(vec3 c) { lookAtLocation = c; }
+    void setFOVy(float f) { fovy = f; }
+    void setNearClipDistance(float n) { nearDist = n; }
+    void setFarClipDistance(float f) { farDist = f; }
+    void setAspectRatio(float a) { aspect = a; }
+    vec3 getPosition() const { return position; }
+    float getFOVy() const { return fovy; }
+    float getNearClipDistance() const { return nearDist; }
+    float getFarClipDistance() const { return farDist; }
+    mat4 getViewMatrix() const { return overwritten ? viewOverride : lookAt(position, lookAtLocation, vec3(0.0f, 1.0f, 0.0f)); }
+    mat4 getProjectionMatrix() const { return overwritten ? projOverride : perspectiveVulkan(fovy, aspect, nearDist, farDist); }
+    /// LineRenderer::overwriteCameraMatrices (LineRenderer.cpp:814-819)
+    void overwriteMatrices(const float view[16], const float proj[16]);
+
+private:
+    vec3 position = vec3(0.0f, 0.0f, 0.8f); // test/VolumetricPathTracingTestRenderer.cpp:34-41
+    vec3 lookAtLocation = vec3(0.0f, 0.0f, 0.0f);
+    float fovy = 0.9272952180016122f;       // 2 * atan(1/2)
+    float nearDist = 0.01f, farDist = 100.0f, aspect = 1.0f;
+    bool overwritten = false;
+    mat4 viewOverride, projOverride;
+};
+typedef std::shared_ptr<Camera> CameraPtr;
+
+/// Stand-in for sgl::TransferFunctionWindow: the RGBA float table the renderers sample.
+class TransferFunctionWindow {
+public:
+    void setTable(const float* rgba, uint32_t n) { table.assign(rgba, rgba + 4 * size_t(n)); dirty = true; }
+    const std::vector<float>& getTable() const { return table; }
+    bool getIsDirty() const { return dirty; }
+    void resetDirty() { dirty = false; }
+
+private:
+    std::vector<float> table;
+    bool dirty = true;
+};
+
+struct Color { float r = 1.0f, g = 1.0f, b = 1.0f, a = 1.0f; };
+
+struct SceneData {
+    uint32_t* viewportWidth = nullptr;
+    uint32_t* viewportHeight = nullptr;
+    CameraPtr camera;
+    Color* clearColor = nullptr;
+    std::vector<uint8_t>* sceneTexture = nullptr; ///< RGBA8, viewportWidth * viewportHeight * 4, row 0 = top
+    int deviceOrdinal = 0;
+};
+
+// ---------------------------------------------------------------- ambient occlusion
+enum class AmbientOcclusionBakerType { NONE = -1, RTAO_PREBAKER = 0, RTAO = 1, SSAO = 2, GTAO = 3 };
+extern const char* const AMBIENT_OCCLUSION_BAKER_TYPE_NAMES[4];
+
+class AmbientOcclusionBaker {
+public:
+    virtual ~AmbientOcclusionBaker() = default;
+    virtual AmbientOcclusionBakerType getType() = 0;
+    virtual bool getIsStaticPrebaker() = 0;
+    virtual void startAmbientOcclusionBaking(LineDataPtr& lineData, bool isNewData) = 0;
+    virtual bool getIsDataReady() = 0;
+    virtual bool getHasComputationFinished() = 0;
+    virtual void onHasMoved() {}
+    virtual void onResolutionChanged() {}
+    virtual bool setNewSettings(const SettingsMap& settings) { (void)settings; return false; }
+};
+typedef std::shared_ptr<AmbientOcclusionBaker> AmbientOcclusionBakerPtr;
+
+/// "RTAO (Screen Space)".  The iterations run inside lv_render (k_ao_primary / k_ao_rays); this class holds the
+/// settings of VulkanRayTracedAmbientOcclusionPass (hpp:150-153,108) and forwards them to the context.
+class HipRayTracedAmbientOcclusion : public AmbientOcclusionBaker {
+public:
+    explicit HipRayTracedAmbientOcclusion(lv_ctx* ctx) : ctx(ctx) {}
+    AmbientOcclusionBakerType getType() override { return AmbientOcclusionBakerType::RTAO; }
+    bool getIsStaticPrebaker() override { return false; }
+    void startAmbientOcclusionBaking(LineDataPtr& lineData, bool isNewData) override;
+    bool getIsDataReady() override { return isDataReady; }
+    bool getHasComputationFinished() override { return hasComputationFinished; }
+    void onHasMoved() override { isDataReady = false; hasComputationFinished = false; }
+    void onResolutionChanged() override { onHasMoved(); }
+    bool setNewSettings(const SettingsMap& settings) override;
+    void pushSettings();
+    void notifyRendered() { isDataReady = true; hasComputationFinished = true; }
+
+    int maxNumAccumulatedFrames = 64;            // VulkanRayTracedAmbientOcclusion.hpp:108
+    int numAmbientOcclusionSamplesPerFrame = 4;  // :150
+    float ambientOcclusionRadius = 0.1f;         // :151
+    bool useDistance = true;                     // :152
+    bool useJitteredPrimaryRays = true;          // :153
+
+private:
+    lv_ctx* ctx;
+    bool isDataReady = false, hasComputationFinished = false;
+};
+
+// ---------------------------------------------------------------- renderers
+class LineRenderer {
+public:
+    LineRenderer(std::string windowName, SceneData* sceneData, TransferFunctionWindow& transferFunctionWindow);
+    virtual void initialize();
+    virtual ~LineRenderer();
+    virtual RenderingMode getRenderingMode() const = 0;
+    virtual bool getIsTransparencyUsed() { return true; }
+    bool isDirty() const { return dirty; }
+    virtual bool needsReRender();
+    virtual bool getIsTriangleRepresentationUsed() const { return false; }
+    bool getIsRasterizer() const { return isRasterizer; }
+
+    virtual void setLineData(LineDataPtr& lineData, bool isNewData) = 0;
+    virtual void renderBase();
+    virtual void render() = 0;
+    virtual void onResolutionChanged();
+    virtual void onClearColorChanged() {}
+    virtual void onHasMoved();
+    virtual void notifyReRenderTriggeredExternally() { internalReRender = false; }
+    virtual bool setNewSettings(const SettingsMap& settings);
+    virtual void onTransferFunctionMapRebuilt() { tfDirty = true; reRender = true; }
+
+    SceneData* getSceneData() { return sceneData; }
+    const std::string& getWindowName() const { return windowName; }
+    lv_ctx* getContext() { return ctx; }
+    /// last error reported by the C-ABI (empty when none)
+    const std::string& getLastError() const { return lastError; }
+    lv_stats getStatistics();
+
+    static float getLineWidth() { return lineWidth; }
+    static float getBandWidth() { return bandWidth; }
+    static void setLineWidth(float w) { lineWidth = w; }
+
+protected:
+    void updateNewLineData(LineDataPtr& lineData, bool isNewData);
+    void setAmbientOcclusionBaker();
+    bool check(int rc, const char* what);
+    bool uploadFrameState();
+    bool setOption(const char* key, const std::string& value);
+    bool renderMode(int mode);
+
+    std::string windowName;
+    SceneData* sceneData;
+    TransferFunctionWindow& transferFunctionWindow;
+    LineDataPtr lineData;
+    lv_ctx* ctx = nullptr;
+    std::string lastError;
+    bool isRasterizer = false;
+    bool dirty = true, reRender = true, internalReRender = false;
+    bool tfDirty = true, linesDirty = true;
+
+    // LineRenderer.hpp:220-231 (depth cues default on with strength 0.8 in the GUI application; the headless
+    // default is off until "depth_cue_strength" is set, like a fresh SettingsMap-driven benchmark state)
+    bool useDepthCues = false;
+    float depthCueStrength = 0.0f;
+    bool useAmbientOcclusion = false;
+    float ambientOcclusionStrength = 0.0f;
+    float ambientOcclusionGamma = 1.0f;
+    AmbientOcclusionBakerType ambientOcclusionBakerType = AmbientOcclusionBakerType::NONE;
+    AmbientOcclusionBakerPtr ambientOcclusionBaker;
+
+    static float lineWidth; // LineRenderer.hpp:266-269 (static: shared by all renderers, as in the reference)
+    static float bandWidth;
+};
+
+/// "Vulkan Ray Tracer" plugin re-hosted on HIP: analytic capsule intersections only.
+class HipRayTracer : public LineRenderer {
+public:
+    HipRayTracer(SceneData* sceneData, TransferFunctionWindow& transferFunctionWindow);
+    RenderingMode getRenderingMode() const override { return RENDERING_MODE_VULKAN_RAY_TRACER; }
+    bool getIsTransparencyUsed() override { return false; }
+    bool needsReRender() override;
+    void setLineData(LineDataPtr& lineData, bool isNewData) override;
+    void render() override;
+    void onHasMoved() override;
+    bool setNewSettings(const SettingsMap& settings) override;
+
+private:
+    uint32_t numSamplesPerFrame = 1;       // VulkanRayTracer.hpp:137 (2 in the interactive application)
+    uint32_t maxDepthComplexity = 1024;    // :139
+    uint32_t maxNumAccumulatedFrames = 1;  // :142 (32 interactive; offline frames use spp instead)
+    uint32_t accumulatedFramesCounter = 0; // :143
+    bool useDeterministicSampling = false;
+};
+
+/// "Per-Pixel Linked Lists" plugin re-hosted on HIP.
+class HipPerPixelLinkedListLineRenderer : public LineRenderer {
+public:
+    HipPerPixelLinkedListLineRenderer(SceneData* sceneData, TransferFunctionWindow& transferFunctionWindow);
+    RenderingMode getRenderingMode() const override { return RENDERING_MODE_PER_PIXEL_LINKED_LIST; }
+    void setLineData(LineDataPtr& lineData, bool isNewData) override;
+    void render() override;
+    bool setNewSettings(const SettingsMap& settings) override;
+    /// computeStatistics (PerPixelLinkedListLineRenderer.cpp:578-663): fragments, max depth complexity
+    void computeStatistics(uint64_t& totalNumFragments, uint32_t& maxComplexity);
+};
+
+} // namespace lv

@@ -1,0 +1,133 @@
+// host_capi.cpp -- flat C entry points over the C++ host layer so that the Python test-suite and bench.py can
+// drive the same classes a C++ embedder would use (LineDataFlow, HipRayTracer, HipPerPixelLinkedListLineRenderer,
+// HeadlessLineRenderer).  Not part of the drop-in boundary (that is include/linevis_hip.h).
+#include <cstring>
+
+#include "HeadlessLineRenderer.hpp"
+
+using namespace lv;
+
+namespace {
+struct FlowHandle {
+    LineDataPtr data;
+    LineDataFlow* flow() { return static_cast<LineDataFlow*>(data.get()); }
+    TubeAabbRenderData lastRenderData;
+};
+} // namespace
+
+extern "C" {
+
+void lvh_normalize_positions(float* positions, uint64_t n) {
+    Trajectories t(1);
+    t[0].positions.resize(n);
+    memcpy(t[0].positions.data(), positions, size_t(n) * 12);
+    normalizeTrajectoriesVertexPositions(t, computeTrajectoriesAABB3(t));
+    memcpy(positions, t[0].positions.data(), size_t(n) * 12);
+}
+
+void* lvh_flow_create() {
+    FlowHandle* h = new FlowHandle();
+    h->data = std::make_shared<LineDataFlow>();
+    return h;
+}
+void lvh_flow_destroy(void* h) { delete static_cast<FlowHandle*>(h); }
+
+void lvh_flow_set_trajectories(void* hp, const float* positions, const float* attributes, const uint32_t* lineOffsets,
+                               uint32_t nLines) {
+    FlowHandle* h = static_cast<FlowHandle*>(hp);
+    Trajectories tr(nLines);
+    for (uint32_t i = 0; i < nLines; i++) {
+        uint32_t b = lineOffsets[i], e = lineOffsets[i + 1];
+        tr[i].positions.resize(e - b);
+        memcpy(tr[i].positions.data(), positions + 3 * size_t(b), size_t(e - b) * 12);
+        tr[i].attributes.resize(1);
+        tr[i].attributes[0].assign(attributes + b, attributes + e);
+    }
+    h->flow()->setTrajectoryData(tr);
+}
+int lvh_flow_load_binlines(void* hp, const char* path) { return static_cast<FlowHandle*>(hp)->flow()->loadFromFile(path) ? 0 : -1; }
+int lvh_flow_save_binlines(void* hp, const char* path) {
+    return saveTrajectoriesAsBinLines(path, static_cast<FlowHandle*>(hp)->flow()->getTrajectories()) ? 0 : -1;
+}
+uint64_t lvh_flow_num_lines(void* hp) { return static_cast<FlowHandle*>(hp)->flow()->getNumLines(); }
+uint64_t lvh_flow_num_points(void* hp) { return static_cast<FlowHandle*>(hp)->flow()->getNumLinePoints(); }
+void lvh_flow_attribute_range(void* hp, float* out2) { static_cast<FlowHandle*>(hp)->data->getMinMaxAttributeValues(out2[0], out2[1]); }
+void lvh_flow_bounding_box(void* hp, float* out6) {
+    const AABB3& b = static_cast<FlowHandle*>(hp)->data->getModelBoundingBox();
+    out6[0] = b.min.x; out6[1] = b.min.y; out6[2] = b.min.z; out6[3] = b.max.x; out6[4] = b.max.y; out6[5] = b.max.z;
+}
+/// Flattened copy of the trajectories (positions n*3, attribute 0, offsets nLines+1); NULL pointers = query sizes only.
+void lvh_flow_get_trajectories(void* hp, float* positions, float* attributes, uint32_t* lineOffsets) {
+    const Trajectories& tr = static_cast<FlowHandle*>(hp)->flow()->getTrajectories();
+    uint32_t off = 0;
+    for (size_t i = 0; i < tr.size(); i++) {
+        if (lineOffsets) lineOffsets[i] = off;
+        uint32_t n = uint32_t(tr[i].positions.size());
+        if (positions) memcpy(positions + 3 * size_t(off), tr[i].positions.data(), size_t(n) * 12);
+        if (attributes && !tr[i].attributes.empty()) memcpy(attributes + off, tr[i].attributes[0].data(), size_t(n) * 4);
+        off += n;
+    }
+    if (lineOffsets) lineOffsets[tr.size()] = off;
+}
+
+/// getLinePassTubeAabbRenderData at the given line width; returns the counts, data fetched with lvh_flow_copy_render_data.
+void lvh_flow_build_render_data(void* hp, float lineWidth, uint32_t* outNumPoints, uint32_t* outNumSegments) {
+    FlowHandle* h = static_cast<FlowHandle*>(hp);
+    LineRenderer::setLineWidth(lineWidth);
+    h->lastRenderData = h->flow()->getLinePassTubeAabbRenderData(false, false);
+    *outNumPoints = uint32_t(h->lastRenderData.linePointDataBuffer.size());
+    *outNumSegments = uint32_t(h->lastRenderData.indexBuffer.size() / 2);
+}
+void lvh_flow_copy_render_data(void* hp, lv_line_point* points, uint32_t* segIndices, float* aabbs) {
+    FlowHandle* h = static_cast<FlowHandle*>(hp);
+    const TubeAabbRenderData& d = h->lastRenderData;
+    if (points) memcpy(points, d.linePointDataBuffer.data(), d.linePointDataBuffer.size() * sizeof(lv_line_point));
+    if (segIndices) memcpy(segIndices, d.indexBuffer.data(), d.indexBuffer.size() * 4);
+    if (aabbs) memcpy(aabbs, d.aabbBuffer.data(), d.aabbBuffer.size() * 24);
+}
+
+// ---- headless renderer harness
+void* lvh_renderer_create(int renderingMode, int deviceOrdinal) {
+    HeadlessLineRenderer* r = new HeadlessLineRenderer(RenderingMode(renderingMode), deviceOrdinal);
+    if (!r->isValid()) { delete r; return nullptr; }
+    return r;
+}
+void lvh_renderer_destroy(void* r) { delete static_cast<HeadlessLineRenderer*>(r); }
+void lvh_renderer_set_resolution(void* r, uint32_t w, uint32_t h) { static_cast<HeadlessLineRenderer*>(r)->setRenderingResolution(w, h); }
+void lvh_renderer_set_line_data(void* r, void* flow, int isNewData) {
+    static_cast<HeadlessLineRenderer*>(r)->setLineData(static_cast<FlowHandle*>(flow)->data, isNewData != 0);
+}
+void lvh_renderer_set_transfer_function(void* r, const float* rgba, uint32_t n) { static_cast<HeadlessLineRenderer*>(r)->setTransferFunction(rgba, n); }
+void lvh_renderer_set_clear_color(void* r, float cr, float cg, float cb, float ca) { static_cast<HeadlessLineRenderer*>(r)->setClearColor(cr, cg, cb, ca); }
+void lvh_renderer_set_camera(void* r, const float pos[3], const float lookAt[3]) {
+    static_cast<HeadlessLineRenderer*>(r)->setCameraPosition(vec3(pos[0], pos[1], pos[2]), vec3(lookAt[0], lookAt[1], lookAt[2]));
+}
+void lvh_renderer_set_settings(void* r, const char* const* keys, const char* const* values, uint32_t n) {
+    SettingsMap m;
+    for (uint32_t i = 0; i < n; i++) m.addKeyValue(std::string(keys[i]), values[i]);
+    static_cast<HeadlessLineRenderer*>(r)->setNewSettings(m);
+}
+int lvh_renderer_render(void* rp, uint8_t* outRGBA8) {
+    HeadlessLineRenderer* r = static_cast<HeadlessLineRenderer*>(rp);
+    const uint8_t* img = r->renderFrame();
+    if (!img) return -1;
+    memcpy(outRGBA8, img, size_t(r->getWidth()) * r->getHeight() * 4);
+    return 0;
+}
+/// Camera matrices the harness passes to lv_set_camera for a w x h viewport (column-major) + {fovy, near, far}.
+void lvh_renderer_get_camera(void* rp, float* view16, float* proj16, float* fovyNearFar) {
+    HeadlessLineRenderer* r = static_cast<HeadlessLineRenderer*>(rp);
+    Camera& cam = *r->getLineRenderer()->getSceneData()->camera;
+    cam.setAspectRatio(float(r->getWidth()) / float(r->getHeight()));
+    mat4 v = cam.getViewMatrix(), p = cam.getProjectionMatrix();
+    memcpy(view16, v.m, 64);
+    memcpy(proj16, p.m, 64);
+    fovyNearFar[0] = cam.getFOVy();
+    fovyNearFar[1] = cam.getNearClipDistance();
+    fovyNearFar[2] = cam.getFarClipDistance();
+}
+const char* lvh_renderer_last_error(void* r) { return static_cast<HeadlessLineRenderer*>(r)->getLastError().c_str(); }
+int lvh_renderer_rendering_mode(void* r) { return int(static_cast<HeadlessLineRenderer*>(r)->getLineRenderer()->getRenderingMode()); }
+void* lvh_renderer_context(void* r) { return static_cast<HeadlessLineRenderer*>(r)->getLineRenderer()->getContext(); }
+
+} // extern "C"

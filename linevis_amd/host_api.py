@@ -1,0 +1,211 @@
+"""ctypes binding of the C++ host layer (linevis_amd/host/*.cpp -> _lib/liblinevis_host.so).
+
+`LineDataFlow` and `HeadlessLineRenderer` are the C++ classes of the same name (LineData model and the
+test/benchmark harness around HipRayTracer / HipPerPixelLinkedListLineRenderer); Python only forwards calls.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import capi
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib", "liblinevis_host.so")
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("%s is missing: run __graft_entry__.build()" % LIB_PATH)
+    capi.load()  # dependency, loaded first so that the rpath-less case still resolves
+    L = C.CDLL(LIB_PATH)
+    vp, u32, u64, f32, i32, cp = C.c_void_p, C.c_uint32, C.c_uint64, C.c_float, C.c_int, C.c_char_p
+    sig = {
+        "lvh_normalize_positions": (None, [vp, u64]),
+        "lvh_flow_create": (vp, []),
+        "lvh_flow_destroy": (None, [vp]),
+        "lvh_flow_set_trajectories": (None, [vp, vp, vp, vp, u32]),
+        "lvh_flow_load_binlines": (i32, [vp, cp]),
+        "lvh_flow_save_binlines": (i32, [vp, cp]),
+        "lvh_flow_num_lines": (u64, [vp]),
+        "lvh_flow_num_points": (u64, [vp]),
+        "lvh_flow_attribute_range": (None, [vp, vp]),
+        "lvh_flow_bounding_box": (None, [vp, vp]),
+        "lvh_flow_get_trajectories": (None, [vp, vp, vp, vp]),
+        "lvh_flow_build_render_data": (None, [vp, f32, C.POINTER(u32), C.POINTER(u32)]),
+        "lvh_flow_copy_render_data": (None, [vp, vp, vp, vp]),
+        "lvh_renderer_create": (vp, [i32, i32]),
+        "lvh_renderer_destroy": (None, [vp]),
+        "lvh_renderer_set_resolution": (None, [vp, u32, u32]),
+        "lvh_renderer_set_line_data": (None, [vp, vp, i32]),
+        "lvh_renderer_set_transfer_function": (None, [vp, vp, u32]),
+        "lvh_renderer_set_clear_color": (None, [vp, f32, f32, f32, f32]),
+        "lvh_renderer_set_camera": (None, [vp, vp, vp]),
+        "lvh_renderer_set_settings": (None, [vp, C.POINTER(cp), C.POINTER(cp), u32]),
+        "lvh_renderer_render": (i32, [vp, vp]),
+        "lvh_renderer_get_camera": (None, [vp, vp, vp, vp]),
+        "lvh_renderer_last_error": (cp, [vp]),
+        "lvh_renderer_rendering_mode": (i32, [vp]),
+        "lvh_renderer_context": (vp, [vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def normalize_positions(positions):
+    p = np.ascontiguousarray(positions, dtype=np.float32).copy()
+    load().lvh_normalize_positions(_p(p), p.shape[0])
+    return p
+
+
+class LineDataFlow:
+    """lv::LineDataFlow (src/LineData/LineDataFlow.{hpp,cpp} counterpart)."""
+
+    def __init__(self):
+        self.L = load()
+        self.h = self.L.lvh_flow_create()
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.L.lvh_flow_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def set_trajectories(self, positions, attributes, line_offsets):
+        pos = np.ascontiguousarray(positions, dtype=np.float32)
+        att = np.ascontiguousarray(attributes, dtype=np.float32)
+        off = np.ascontiguousarray(line_offsets, dtype=np.uint32)
+        self.L.lvh_flow_set_trajectories(self.h, _p(pos), _p(att), _p(off), len(off) - 1)
+        return self
+
+    def load_binlines(self, path):
+        if self.L.lvh_flow_load_binlines(self.h, path.encode()) != 0:
+            raise IOError("loadTrajectoriesFromBinLines failed for %s" % path)
+        return self
+
+    def save_binlines(self, path):
+        if self.L.lvh_flow_save_binlines(self.h, path.encode()) != 0:
+            raise IOError("cannot write %s" % path)
+
+    @property
+    def num_lines(self):
+        return int(self.L.lvh_flow_num_lines(self.h))
+
+    @property
+    def num_points(self):
+        return int(self.L.lvh_flow_num_points(self.h))
+
+    def attribute_range(self):
+        out = np.empty(2, dtype=np.float32)
+        self.L.lvh_flow_attribute_range(self.h, _p(out))
+        return float(out[0]), float(out[1])
+
+    def bounding_box(self):
+        out = np.empty(6, dtype=np.float32)
+        self.L.lvh_flow_bounding_box(self.h, _p(out))
+        return out[:3].copy(), out[3:].copy()
+
+    def trajectories(self):
+        n, l = self.num_points, self.num_lines
+        pos = np.empty((n, 3), dtype=np.float32)
+        att = np.zeros(n, dtype=np.float32)
+        off = np.empty(l + 1, dtype=np.uint32)
+        self.L.lvh_flow_get_trajectories(self.h, _p(pos), _p(att), _p(off))
+        return pos, att, off
+
+    def tube_aabb_render_data(self, line_width):
+        """getLinePassTubeAabbRenderData: (points[48 B records], seg_indices[S,2], aabbs[S,6])."""
+        npts, nseg = C.c_uint32(), C.c_uint32()
+        self.L.lvh_flow_build_render_data(self.h, line_width, C.byref(npts), C.byref(nseg))
+        pts = np.zeros(npts.value, dtype=capi.LINE_POINT_DTYPE)
+        seg = np.zeros((nseg.value, 2), dtype=np.uint32)
+        aabb = np.zeros((nseg.value, 6), dtype=np.float32)
+        self.L.lvh_flow_copy_render_data(self.h, _p(pts), _p(seg), _p(aabb))
+        return pts, seg, aabb
+
+
+class HeadlessLineRenderer:
+    """lv::HeadlessLineRenderer: fixed-camera harness around one renderer plugin (mode 11 or 2)."""
+
+    def __init__(self, mode=capi.MODE_RAY_TRACER, device=0):
+        self.L = load()
+        self.h = self.L.lvh_renderer_create(int(mode), int(device))
+        if not self.h:
+            raise capi.LineVisError(capi.LV_OK - 2, "no usable HIP device (there is no CPU fallback)")
+        self.width = self.height = 128
+        self._keep = []
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.L.lvh_renderer_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def set_rendering_resolution(self, w, h):
+        self.width, self.height = int(w), int(h)
+        self.L.lvh_renderer_set_resolution(self.h, self.width, self.height)
+
+    def set_line_data(self, flow, is_new_data=True):
+        self._keep = [flow]
+        self.L.lvh_renderer_set_line_data(self.h, flow.h, int(is_new_data))
+
+    def set_transfer_function(self, rgba):
+        tf = np.ascontiguousarray(rgba, dtype=np.float32).reshape(-1, 4)
+        self.L.lvh_renderer_set_transfer_function(self.h, _p(tf), tf.shape[0])
+
+    def set_clear_color(self, r, g, b, a):
+        self.L.lvh_renderer_set_clear_color(self.h, r, g, b, a)
+
+    def set_camera(self, position, look_at=(0.0, 0.0, 0.0)):
+        p = np.ascontiguousarray(position, dtype=np.float32)
+        l = np.ascontiguousarray(look_at, dtype=np.float32)
+        self.L.lvh_renderer_set_camera(self.h, _p(p), _p(l))
+
+    def set_new_settings(self, settings):
+        keys = [k.encode() for k in settings]
+        vals = [capi._fmt(v).encode() for v in settings.values()]
+        n = len(keys)
+        ka = (C.c_char_p * n)(*keys)
+        va = (C.c_char_p * n)(*vals)
+        self.L.lvh_renderer_set_settings(self.h, ka, va, n)
+
+    def render_frame(self):
+        out = np.empty((self.height, self.width, 4), dtype=np.uint8)
+        if self.L.lvh_renderer_render(self.h, _p(out)) != 0:
+            raise capi.LineVisError(-1, self.L.lvh_renderer_last_error(self.h).decode("utf-8", "replace"))
+        return out
+
+    def camera(self):
+        """(view, proj, fovy, near, far) exactly as the C++ harness hands them to lv_set_camera."""
+        v = np.empty(16, dtype=np.float32)
+        p = np.empty(16, dtype=np.float32)
+        f = np.empty(3, dtype=np.float32)
+        self.L.lvh_renderer_get_camera(self.h, _p(v), _p(p), _p(f))
+        return v, p, float(f[0]), float(f[1]), float(f[2])
+
+    @property
+    def rendering_mode(self):
+        return int(self.L.lvh_renderer_rendering_mode(self.h))
+
+    def stats(self):
+        s = capi.Stats()
+        ctx = self.L.lvh_renderer_context(self.h)
+        rc = capi.load().lv_get_stats(ctx, C.byref(s))
+        if rc != 0:
+            raise capi.LineVisError(rc, "lv_get_stats")
+        return s

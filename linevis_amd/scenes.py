@@ -141,6 +141,7 @@ def tornado(n_lines=1000, points_per_line=1001, seed=12345, h=0.004):
     seeds = np.stack([rng.uniform(0.2, 0.8, n_lines), rng.uniform(0.2, 0.8, n_lines),
                       rng.uniform(0.02, 0.6, n_lines)], axis=1)
     out, mag = _rk4_lines(_tornado_velocity, seeds, points_per_line - 1, h)
+    out = out[:, :, [0, 2, 1]]  # height along +y: the default camera looks at the funnel from the side
     pos = out.reshape(-1, 3).astype(np.float32)
     att = normalize_attributes(np.log1p(mag.reshape(-1)))
     return Trajectories(pos, att, _uniform_offsets(n_lines, points_per_line))

@@ -108,8 +108,19 @@ inline void sincos2pi(float xi, float& s, float& c) {
 }
 
 // ---------------------------------------------------------------- intersection tests
-// RayIntersectionTestsVulkan.glsl:39-72
-inline bool raySphereIntersection(V3 o, V3 d, V3 ctr, float radius, float& hitT) {
+// The reference solves both quadratics in the textbook form t = (-B -+ sqrt(B^2 - 4AC)) / 2A
+// (RayIntersectionTestsVulkan.glsl:39-72 and :78-119).  For a tube of radius 1e-3 seen from distance ~1 the
+// discriminant B^2 - 4AC is a difference of two O(1) numbers whose result is O(r^2) = 1e-6, so float32 leaves it
+// 1-2 significant digits and the computed t jitters by up to ~25 % of the radius; GLSL compilers are moreover free
+// to contract these expressions, so the reference's bit-level behaviour is not defined.  The build evaluates THE SAME
+// quadratics in the closest-approach form (Haines et al., "Precision Improvements for Ray/Sphere Intersection",
+// Ray Tracing Gems ch. 7): t_c = closest-approach parameter, l = perpendicular offset at t_c, half chord
+// h = sqrt((r^2 - l.l) / A), roots t_c -+ h.  Same roots, same root selection and end-plane logic as the reference;
+// error ~1e-7 instead of ~1e-4, which is what makes BVH culling and brute force agree bit for bit.  The literal
+// forms are kept below (…Literal) and tests check both agree within the literal form's error bound.
+
+// RayIntersectionTestsVulkan.glsl:39-72, literal
+inline bool raySphereIntersectionLiteral(V3 o, V3 d, V3 ctr, float radius, float& hitT) {
     float A = (d.x * d.x + d.y * d.y) + d.z * d.z;
     float B = 2.0f * ((d.x * (o.x - ctr.x) + d.y * (o.y - ctr.y)) + d.z * (o.z - ctr.z));
     float C = (((o.x - ctr.x) * (o.x - ctr.x) + (o.y - ctr.y) * (o.y - ctr.y)) + (o.z - ctr.z) * (o.z - ctr.z))
@@ -126,8 +137,8 @@ inline bool raySphereIntersection(V3 o, V3 d, V3 ctr, float radius, float& hitT)
     return true;
 }
 
-// RayIntersectionTestsVulkan.glsl:78-119
-inline bool rayTubeIntersection(V3 o, V3 d, V3 tubeStart, V3 tubeEnd, float radius, float& hitT) {
+// RayIntersectionTestsVulkan.glsl:78-119, literal
+inline bool rayTubeIntersectionLiteral(V3 o, V3 d, V3 tubeStart, V3 tubeEnd, float radius, float& hitT) {
     V3 tubeDirection = normalize(tubeEnd - tubeStart);
     V3 deltaP = o - tubeStart;
     V3 av = d - dot(d, tubeDirection) * tubeDirection;
@@ -141,18 +152,55 @@ inline bool rayTubeIntersection(V3 o, V3 d, V3 tubeStart, V3 tubeEnd, float radi
     float t0 = (-B - ds) / (2.0f * A);
     if (t0 >= 0.0f) {
         V3 ip = o + t0 * d;
-        if (dot(tubeDirection, ip - tubeStart) > 0.0f && dot(tubeDirection, ip - tubeEnd) < 0.0f) {
-            hitT = t0;
-            return true;
-        }
+        if (dot(tubeDirection, ip - tubeStart) > 0.0f && dot(tubeDirection, ip - tubeEnd) < 0.0f) { hitT = t0; return true; }
     }
     float t1 = (-B + ds) / (2.0f * A);
     if (t1 >= 0.0f) {
         V3 ip = o + t1 * d;
-        if (dot(tubeDirection, ip - tubeStart) > 0.0f && dot(tubeDirection, ip - tubeEnd) < 0.0f) {
-            hitT = t1;
-            return true;
-        }
+        if (dot(tubeDirection, ip - tubeStart) > 0.0f && dot(tubeDirection, ip - tubeEnd) < 0.0f) { hitT = t1; return true; }
+    }
+    return false;
+}
+
+// raySphereIntersection (RayIntersectionTestsVulkan.glsl:39-72) in closest-approach form
+inline bool raySphereIntersection(V3 o, V3 d, V3 ctr, float radius, float& hitT) {
+    V3 f = o - ctr;
+    float A = dot(d, d);
+    float tc = -dot(f, d) / A;
+    V3 l = f + tc * d;
+    float discriminant = radius * radius - dot(l, l);
+    if (discriminant < 0.0f) return false;
+    float h = sqrtf(discriminant / A);
+    float t0 = tc - h;
+    float t1 = tc + h;
+    hitT = t0;
+    if (t0 >= 0.0f) hitT = t0;
+    else if (t1 >= 0.0f) hitT = t1;
+    else return false;
+    return true;
+}
+
+// rayTubeIntersection (RayIntersectionTestsVulkan.glsl:78-119) in closest-approach form
+inline bool rayTubeIntersection(V3 o, V3 d, V3 tubeStart, V3 tubeEnd, float radius, float& hitT) {
+    V3 tubeDirection = normalize(tubeEnd - tubeStart);
+    V3 deltaP = o - tubeStart;
+    V3 av = d - dot(d, tubeDirection) * tubeDirection;
+    V3 cv = deltaP - dot(deltaP, tubeDirection) * tubeDirection;
+    float A = dot(av, av);
+    float tc = -dot(av, cv) / A;
+    V3 l = cv + tc * av;
+    float discriminant = radius * radius - dot(l, l);
+    if (discriminant < 0.0f) return false;
+    float h = sqrtf(discriminant / A);
+    float t0 = tc - h;
+    if (t0 >= 0.0f) {
+        V3 ip = o + t0 * d;
+        if (dot(tubeDirection, ip - tubeStart) > 0.0f && dot(tubeDirection, ip - tubeEnd) < 0.0f) { hitT = t0; return true; }
+    }
+    float t1 = tc + h;
+    if (t1 >= 0.0f) {
+        V3 ip = o + t1 * d;
+        if (dot(tubeDirection, ip - tubeStart) > 0.0f && dot(tubeDirection, ip - tubeEnd) < 0.0f) { hitT = t1; return true; }
     }
     return false;
 }
@@ -171,6 +219,23 @@ inline bool intersectCapsule(V3 o, V3 d, V3 p0, V3 p1, float radius, bool capped
     if (capped) {
         bool h0 = raySphereIntersection(o, d, p0, radius, s0T);
         bool h1 = raySphereIntersection(o, d, p1, radius, s1T);
+        if (h0 && s0T < hitT) { hasIntersection = true; hitT = s0T; hitKind = 1; }
+        if (h1 && s1T < hitT) { hasIntersection = true; hitT = s1T; hitKind = 2; }
+    }
+    hitTOut = hitT;
+    hitKindOut = hitKind;
+    return hasIntersection;
+}
+
+inline bool intersectCapsuleLiteral(V3 o, V3 d, V3 p0, V3 p1, float radius, bool capped, float& hitTOut, int& hitKindOut) {
+    bool hasIntersection = false;
+    float hitT = 1e7f;
+    int hitKind = 0;
+    float tubeT, s0T, s1T;
+    if (rayTubeIntersectionLiteral(o, d, p0, p1, radius, tubeT)) { hitT = tubeT; hasIntersection = true; hitKind = 0; }
+    if (capped) {
+        bool h0 = raySphereIntersectionLiteral(o, d, p0, radius, s0T);
+        bool h1 = raySphereIntersectionLiteral(o, d, p1, radius, s1T);
         if (h0 && s0T < hitT) { hasIntersection = true; hitT = s0T; hitKind = 1; }
         if (h1 && s1T < hitT) { hasIntersection = true; hitT = s1T; hitKind = 2; }
     }
@@ -790,6 +855,14 @@ int lvo_intersect_capsule(const float o[3], const float d[3], const float p0[3],
                           int capped, float* outT, int* outKind) {
     float t; int k;
     bool h = intersectCapsule(ld3(o), ld3(d), ld3(p0), ld3(p1), radius, capped != 0, t, k);
+    *outT = t; *outKind = k;
+    return h ? 1 : 0;
+}
+
+int lvo_intersect_capsule_literal(const float o[3], const float d[3], const float p0[3], const float p1[3], float radius,
+                                  int capped, float* outT, int* outKind) {
+    float t; int k;
+    bool h = intersectCapsuleLiteral(ld3(o), ld3(d), ld3(p0), ld3(p1), radius, capped != 0, t, k);
     *outT = t; *outKind = k;
     return h ? 1 : 0;
 }

@@ -137,6 +137,11 @@ int lvo_intersect_capsule(
         const float o[3], const float d[3], const float p0[3], const float p1[3], float radius,
         int useCappedTubes, float* outT, int* outKind);
 
+/* the reference's literal textbook-quadratic form (RayIntersectionTestsVulkan.glsl:39-119), kept for cross-checks */
+int lvo_intersect_capsule_literal(
+        const float o[3], const float d[3], const float p0[3], const float p1[3], float radius,
+        int useCappedTubes, float* outT, int* outKind);
+
 /* ---- a18: depth range (ComputeDepthValues.glsl:58-98, MinMaxReduce.glsl:64-103) ---- */
 void lvo_compute_depth_range(const lvo_scene*, const lvo_params*, float outMinMax[2]);
 

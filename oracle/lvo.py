@@ -92,6 +92,8 @@ def lib():
     L.lvo_trace_rays.argtypes = [vp, f32, i32, i32, vp, vp, f32, f32, u32, vp, vp, vp]
     L.lvo_intersect_capsule.restype = i32
     L.lvo_intersect_capsule.argtypes = [vp, vp, vp, vp, f32, i32, C.POINTER(f32), C.POINTER(i32)]
+    L.lvo_intersect_capsule_literal.restype = i32
+    L.lvo_intersect_capsule_literal.argtypes = [vp, vp, vp, vp, f32, i32, C.POINTER(f32), C.POINTER(i32)]
     L.lvo_compute_depth_range.argtypes = [vp, C.POINTER(Params), vp]
     L.lvo_render_ao.argtypes = [vp, C.POINTER(Params), i32, u32, u32, u32, u32, vp, C.POINTER(Stats)]
     L.lvo_render_rt.argtypes = [vp, C.POINTER(Params), i32, vp, u32, u32, u32, u32, vp, C.POINTER(Stats)]
@@ -152,10 +154,11 @@ def build_tube_aabb_render_data(positions, attributes, line_offsets, line_width)
     return pts[:npts.value].copy(), seg[:nseg.value].copy(), aabb[:nseg.value].copy()
 
 
-def intersect_capsule(o, d, p0, p1, radius, capped=True):
+def intersect_capsule(o, d, p0, p1, radius, capped=True, literal=False):
     a = [np.ascontiguousarray(v, dtype=np.float32) for v in (o, d, p0, p1)]
     t, k = C.c_float(), C.c_int()
-    hit = lib().lvo_intersect_capsule(_p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), radius, int(capped), C.byref(t),
+    fn = lib().lvo_intersect_capsule_literal if literal else lib().lvo_intersect_capsule
+    hit = fn(_p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), radius, int(capped), C.byref(t),
                                       C.byref(k))
     return bool(hit), t.value, k.value
 

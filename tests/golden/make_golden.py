@@ -1,0 +1,235 @@
+"""Generates the committed golden fixtures from the CPU oracle (oracle/lv_oracle.cpp).
+
+PARITY UNPINNED: the reference's own tests hold no vectors for this path and the reference
+cannot be built here, so these vectors pin the oracle against regressions and travel to the GPU box where the
+HIP path is compared against them.  Fixtures are data only: inputs + expected outputs.
+
+Run from the repo root:  python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from common import Case, small_case, scene_arrays  # noqa: E402
+from linevis_amd import scenes, transfer_function as tfm  # noqa: E402
+from oracle import lvo  # noqa: E402
+
+
+def f2u(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def rng_kat():
+    tea_in = [(0, 0), (1, 0), (0, 1), (19, 0), (19, 1), (19, 7), (12345, 678), (1920 * 1080 - 1, 63),
+              (0xFFFFFFFF, 0xFFFFFFFF), (959 + 539 * 1920, 0)]
+    tea_out = np.array([lvo.tea(a, b) for a, b in tea_in], dtype=np.uint32)
+    seeds = np.array([0, 1, 0xDEADBEEF, int(tea_out[3]), int(tea_out[9])], dtype=np.uint32)
+    rnd = np.stack([lvo.rnd_sequence(int(s), 8) for s in seeds])
+    xi = np.array([0.0, 1.0 / 16777216.0, 0.125, 0.25, 0.3, 0.5, 0.62, 0.75, 0.875, 16777215.0 / 16777216.0],
+                  dtype=np.float32)
+    sc = np.array([lvo.sincos_2pi(float(x)) for x in xi], dtype=np.float32)
+    np.savez_compressed(os.path.join(HERE, "rng_kat.npz"), tea_in=np.array(tea_in, dtype=np.uint32), tea_out=tea_out,
+                        rnd_seeds=seeds, rnd_bits=f2u(rnd), sincos_xi=xi, sincos_bits=f2u(sc))
+
+
+def capsule_kat():
+    rng = np.random.default_rng(2024)
+    O, D, P0, P1, R = [], [], [], [], []
+
+    def add(o, d, p0, p1, r):
+        O.append(o); D.append(d); P0.append(p0); P1.append(p1); R.append(r)
+
+    for i in range(300):
+        p0 = rng.uniform(-0.3, 0.3, 3)
+        axis = rng.normal(size=3); axis /= np.linalg.norm(axis)
+        p1 = p0 + axis * rng.uniform(0.005, 0.2)
+        r = rng.uniform(0.001, 0.03)
+        kind = i % 10
+        mid = 0.5 * (p0 + p1)
+        perp = np.cross(axis, rng.normal(size=3)); perp /= np.linalg.norm(perp)
+        if kind == 0:      # generic ray towards the capsule
+            o = mid + rng.normal(size=3) * 0.5
+            d = (mid + perp * r * rng.uniform(-1.2, 1.2)) - o
+        elif kind == 1:    # grazing: aimed at the silhouette
+            o = mid + perp * 0.6
+            d = (mid + np.cross(axis, perp) * r * rng.uniform(0.999, 1.001)) - o
+        elif kind == 2:    # origin inside the cylinder part
+            o = mid + perp * r * 0.3
+            d = rng.normal(size=3)
+        elif kind == 3:    # origin inside an end sphere
+            o = p0 + rng.normal(size=3) * r * 0.2
+            d = rng.normal(size=3)
+        elif kind == 4:    # ray along the axis through the caps
+            o = p0 - axis * 0.4 + perp * r * rng.uniform(0, 0.9)
+            d = axis
+        elif kind == 5:    # ray exactly parallel to the axis but outside
+            o = p0 - axis * 0.4 + perp * r * 1.5
+            d = axis
+        elif kind == 6:    # hits near the end plane
+            o = p1 + perp * 0.5 + axis * r * rng.uniform(-0.5, 0.5)
+            d = -perp
+        elif kind == 7:    # cap only: aimed beyond the end plane
+            o = p1 + axis * 0.4 + perp * r * rng.uniform(-0.8, 0.8)
+            d = -axis
+        elif kind == 8:    # pointing away
+            o = mid + perp * 0.4
+            d = perp
+        else:              # unnormalised direction
+            o = mid + rng.normal(size=3) * 0.4
+            d = (mid - o) * rng.uniform(0.1, 5.0)
+        if kind != 9:
+            d = d / np.linalg.norm(d)
+        add(o, d, p0, p1, r)
+    O, D, P0, P1 = [np.array(a, dtype=np.float32) for a in (O, D, P0, P1)]
+    R = np.array(R, dtype=np.float32)
+    res = {}
+    for capped in (0, 1):
+        hit = np.zeros(len(R), dtype=np.uint8)
+        t = np.zeros(len(R), dtype=np.float32)
+        k = np.zeros(len(R), dtype=np.int32)
+        for i in range(len(R)):
+            h, tt, kk = lvo.intersect_capsule(O[i], D[i], P0[i], P1[i], float(R[i]), bool(capped))
+            hit[i], t[i], k[i] = h, tt, kk
+        res["hit%d" % capped] = hit
+        res["t_bits%d" % capped] = f2u(t)
+        res["kind%d" % capped] = k
+    np.savez_compressed(os.path.join(HERE, "capsule_kat.npz"), o=O, d=D, p0=P0, p1=P1, r=R, **res)
+
+
+def a2_cases():
+    lines = [
+        # duplicate vertices in the middle and at the end
+        [(0, 0, 0), (0.1, 0, 0), (0.1, 0, 0), (0.1, 0, 0), (0.2, 0.05, 0), (0.3, 0.1, 0.02), (0.3, 0.1, 0.02)],
+        # tangent parallel to the initial helper axis (1,0,0) -> falls back to (0,1,0)
+        [(0, 0.2, 0), (0.05, 0.2, 0), (0.1, 0.2, 0), (0.15, 0.2, 0)],
+        # tangent parallel to (0,1,0) after the normal has become (0,1,0)... forces the (0,0,1) fallback
+        [(0.2, 0, 0.1), (0.2, 0.05, 0.1), (0.2, 0.1, 0.1), (0.2, 0.15, 0.1)],
+        # single point (dropped) and a two-point line whose points coincide (dropped)
+        [(0.3, 0.3, 0.3)],
+        [(0.1, 0.1, 0.1), (0.1, 0.1, 0.1)],
+        # only one valid point survives -> dropped
+        [(0.4, 0, 0), (0.4, 0, 0), (0.4, 0.00001, 0)],
+        # ordinary curved line
+        [(-0.2, -0.2, 0), (-0.15, -0.18, 0.02), (-0.1, -0.12, 0.05), (-0.08, -0.05, 0.1), (-0.1, 0.0, 0.16)],
+        # sharp reversal
+        [(0, -0.3, 0), (0.1, -0.3, 0), (0.0, -0.3, 0.001), (0.1, -0.31, 0)],
+    ]
+    pos = np.concatenate([np.array(l, dtype=np.float32).reshape(-1, 3) for l in lines])
+    off = np.zeros(len(lines) + 1, dtype=np.uint32)
+    off[1:] = np.cumsum([len(l) for l in lines])
+    att = np.linspace(0.0, 1.0, len(pos)).astype(np.float32)
+    pts, seg, aabb = lvo.build_tube_aabb_render_data(pos, att, off, 0.01)
+    np.savez_compressed(os.path.join(HERE, "a2_cases.npz"), positions=pos, attributes=att, line_offsets=off,
+                        line_width=np.float32(0.01), points=pts.view(np.uint8).reshape(-1, 48), seg=seg,
+                        aabb_bits=f2u(aabb))
+
+
+def small_scene():
+    W, H = 128, 128
+    base = small_case(width=W, height=H, n_lines=36, pts_per_line=40, seed=11, line_width=0.015)
+    out = dict(points=base.points.view(np.uint8).reshape(-1, 48), seg=base.seg, tf=base.tf, width=W, height=H,
+               line_width=np.float32(base.line_width), tf_transparent=tfm.standard_transparent())
+    # 1. opaque, primary rays only, with depth cues
+    c = Case(base.points, base.seg, base.tf, W, H, base.line_width, depth_cue_strength=0.8)
+    out["rt_depthcue"], _ = c.oracle_render(11)
+    sc = c.oracle_scene()
+    out["depth_range_bits"] = f2u(sc.depth_range(c.oracle_params()))
+    # 2. transparent transfer function, 4 jittered samples per pixel
+    c = Case(base.points, base.seg, out["tf_transparent"], W, H, base.line_width, num_samples_per_frame=4)
+    out["rt_transparent_spp4"], _ = c.oracle_render(11)
+    # 3. RTAO: 2 iterations x 8 samples, distance based
+    ao_set = dict(ambient_occlusion_mode="RTAO (Screen Space)", ambient_occlusion_strength=0.9,
+                  ambient_occlusion_gamma=1.5, ambient_occlusion_iterations=2, ambient_occlusion_samples_per_frame=8,
+                  ambient_occlusion_radius=0.1)
+    c = Case(base.points, base.seg, base.tf, W, H, base.line_width, **ao_set)
+    img, ao = c.oracle_render(11)
+    out["rt_ao"], out["ao_bits"] = img, f2u(ao)
+    # 4. PPLL with the transparent transfer function
+    c = Case(base.points, base.seg, out["tf_transparent"], W, H, base.line_width)
+    st = lvo.Stats()
+    out["ppll"], _ = c.oracle_render(2, stats=st)
+    out["ppll_fragments"] = np.uint64(st.fragments)
+    out["ppll_max_depth_complexity"] = np.uint32(st.maxDepthComplexity)
+    # 5. ray known answers: pixel-centre primaries of a coarse grid + random rays from inside the scene
+    rng = np.random.default_rng(5)
+    o = np.concatenate([np.tile(np.array([[0.0, 0.0, 0.8]], dtype=np.float32), (300, 1)),
+                        rng.uniform(-0.3, 0.3, (212, 3)).astype(np.float32)])
+    d = rng.normal(size=(512, 3)).astype(np.float32)
+    d[:300, 2] = -np.abs(d[:300, 2]) * 4.0
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    t, s, k = base.oracle_scene().trace_rays(o, d, 1e-4, 1000.0, base.line_width)
+    out.update(ray_o=o, ray_d=d.astype(np.float32), ray_t_bits=f2u(t), ray_seg=s, ray_kind=k)
+    np.savez_compressed(os.path.join(HERE, "scene_small.npz"), **out)
+
+
+def ppll_lists():
+    """Hand-made fragment lists: depth ties with different colours, > MAX_NUM_FRAGS overflow, empty pixels,
+    fragments whose alpha quantises to 0."""
+    W, H = 8, 8
+    max_frags = 8
+    rng = np.random.default_rng(99)
+    pw, ph = 8, 8
+    nodes = []
+    start = np.full(pw * ph, 0xFFFFFFFF, dtype=np.uint32)
+
+    def push(x, y, rgba, depth):
+        idx = len(nodes)
+        a = lvo.ppll_addr(x, y, pw, 2, 8)
+        col = (int(rgba[0]) | (int(rgba[1]) << 8) | (int(rgba[2]) << 16) | (int(rgba[3]) << 24)) & 0xFFFFFFFF
+        nodes.append((col, int(np.float32(depth).view(np.uint32)), int(start[a])))
+        start[a] = idx
+
+    for y in range(H):
+        for x in range(W):
+            kind = (x + y * W) % 8
+            n = [0, 1, 3, 8, 12, 5, 6, 20][kind]
+            depths = rng.uniform(0.3, 1.2, n).astype(np.float32)
+            if kind in (5, 6) and n >= 4:
+                depths[1] = depths[0]
+                depths[3] = depths[2]
+            for i in range(n):
+                rgba = rng.integers(0, 256, 4)
+                if kind == 6 and i == 0:
+                    rgba[3] = 0
+                if kind == 2:
+                    rgba[3] = 255
+                push(x, y, rgba, depths[i])
+    nodes = np.array(nodes, dtype=np.uint32).reshape(-1, 3)
+    from linevis_amd import camera
+    view, proj, fovy, near, far = camera.default_camera(W, H)
+    P = lvo.make_params(view, proj, W, H, ppllMaxNumFrags=max_frags, ppllLinkedListSize=len(nodes),
+                        background=(0.2, 0.4, 0.6, 1.0))
+    img_key = lvo.ppll_resolve(P, nodes, start, literal=False)
+    img_lit = lvo.ppll_resolve(P, nodes, start, literal=True)
+    np.savez_compressed(os.path.join(HERE, "ppll_lists.npz"), nodes=nodes, start=start, width=W, height=H,
+                        max_frags=max_frags, background=np.array([0.2, 0.4, 0.6, 1.0], dtype=np.float32),
+                        resolved_key=img_key, resolved_literal=img_lit)
+
+
+def lattice_c1():
+    """Config 1 analogue: 32 x 32 lines through a uniform grid, 128 x 128, 4 spp, no AO."""
+    tr = scenes.normalize(scenes.lattice())
+    pts, seg = scene_arrays(tr, 0.004)
+    c = Case(pts, seg, tfm.standard(), 128, 128, 0.004, num_samples_per_frame=4)
+    img, _ = c.oracle_render(11, use_bvh=True)
+    np.savez_compressed(os.path.join(HERE, "lattice_c1.npz"), image=img, line_width=np.float32(0.004),
+                        num_points=np.uint32(len(pts)), num_segments=np.uint32(len(seg)),
+                        points_crc=np.uint32(np.bitwise_xor.reduce(pts.view(np.uint32))))
+
+
+if __name__ == "__main__":
+    rng_kat()
+    capsule_kat()
+    a2_cases()
+    small_scene()
+    ppll_lists()
+    lattice_c1()
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith(".npz"):
+            print("%-24s %8d bytes" % (f, os.path.getsize(os.path.join(HERE, f))))

@@ -1,0 +1,74 @@
+"""The C-ABI library loads on a machine without a GPU and exports every symbol include/linevis_hip.h declares
+(no compute calls here)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from common import ROOT
+from linevis_amd import capi, host_api
+
+
+def header_symbols():
+    text = open(capi.HEADER_PATH).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(lv_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_declares_what_the_binding_binds():
+    assert header_symbols() == sorted(capi.SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol():
+    L = capi.load()
+    for name in header_symbols():
+        assert hasattr(L, name), name
+    assert L.lv_version().startswith(b"linevis_hip")
+
+
+def test_header_cites_reference_interfaces():
+    text = open(capi.HEADER_PATH).read()
+    for needle in ("LineRenderer.hpp", "LineRenderData.hpp:99-106", "LineData.cpp:1057-1075", "InternalState.hpp",
+                   "VulkanRayTracer.cpp", "PerPixelLinkedListLineRenderer.cpp", "RenderingModes.hpp"):
+        assert needle in text
+
+
+def test_struct_layouts_match_the_header():
+    assert ctypes.sizeof(capi.Stats) == 6 * 8 + 4 * 4 + 8 * 4 + 8
+    assert capi.LINE_POINT_DTYPE.itemsize == 48
+    assert capi.LINE_POINT_DTYPE.fields["lineNormal"][1] == 32
+    assert capi.LINE_POINT_DTYPE.fields["lineStartIndex"][1] == 44
+
+
+def test_no_cpu_fallback_without_a_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present; the failure path needs a GPU-less machine")
+    with pytest.raises(capi.LineVisError):
+        capi.Context(0)
+    with pytest.raises(capi.LineVisError):
+        host_api.HeadlessLineRenderer()
+
+
+def test_host_library_loads():
+    L = host_api.load()
+    for name in ("lvh_flow_create", "lvh_flow_build_render_data", "lvh_renderer_create", "lvh_renderer_render"):
+        assert hasattr(L, name)
+
+
+def test_product_never_touches_the_oracle():
+    """The product path must not import, link or call anything under oracle/."""
+    bad = []
+    for base in ("linevis_amd", "include"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, base)):
+            if "_lib" in dirpath or "__pycache__" in dirpath:
+                continue
+            for f in files:
+                if f.endswith((".py", ".h", ".hpp", ".cpp", ".hip")):
+                    txt = open(os.path.join(dirpath, f), errors="replace").read()
+                    if re.search(r"\boracle\b|lv_oracle|lvo_", txt) and f != "LvMath.hpp":
+                        bad.append(os.path.join(dirpath, f))
+    # LvMath.hpp mentions the word in a comment only
+    assert bad == [], bad

@@ -1,0 +1,375 @@
+"""Parity tests proper: the HIP path (through the C-ABI) against the CPU oracle on the same seeded inputs, against
+the committed golden fixtures, and -- at BASELINE.json's full sizes -- through size-independent properties.
+
+Bars (north_star): RGBA8 frames within +-2 LSB per channel; everything that is pure +,-,*,/,sqrt (ray generation,
+traversal, ray-capsule hits, AO factors, PPLL fragment depths) and all integer work bit-exact.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from common import GOLDEN_DIR, Case, small_case, max_lsb_diff, scene_arrays
+from linevis_amd import capi, host_api, scenes, tiling, transfer_function as tfm
+from oracle import lvo
+
+pytestmark = pytest.mark.gpu
+
+LSB_TOL = 2  # north_star: "+-2 LSB per RGBA8 channel"
+RTAO = dict(ambient_occlusion_mode="RTAO (Screen Space)", ambient_occlusion_strength=1.0)
+
+
+def G(name):
+    return np.load(os.path.join(GOLDEN_DIR, name))
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def golden_base():
+    g = G("scene_small.npz")
+    pts = g["points"].reshape(-1).view(lvo.LINE_POINT_DTYPE)
+    return g, pts, int(g["width"]), int(g["height"]), float(g["line_width"])
+
+
+# ---------------------------------------------------------------- rays / BVH
+def test_rays_bit_exact_vs_golden_and_oracle(hip_lib):
+    g, pts, W, H, lw = golden_base()
+    c = Case(pts, g["seg"], g["tf"], W, H, lw)
+    ctx = c.hip_context()
+    t, s, k = ctx.trace_rays(g["ray_o"], g["ray_d"], 1e-4, 1000.0)
+    assert np.array_equal(bits(t), g["ray_t_bits"]) and np.array_equal(s, g["ray_seg"]) and np.array_equal(k, g["ray_kind"])
+    rng = np.random.default_rng(123)
+    o = rng.uniform(-0.35, 0.35, (20000, 3)).astype(np.float32)
+    d = rng.normal(size=(20000, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    for (tmin, tmax) in [(0.0, 0.1), (1e-4, 1000.0)]:
+        a = ctx.trace_rays(o, d, tmin, tmax)
+        b = c.oracle_scene().trace_rays(o, d, tmin, tmax, lw, use_bvh=False)  # brute force = ground truth
+        assert np.array_equal(bits(a[0]), bits(b[0])) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    assert (a[1] != 0xFFFFFFFF).sum() > 1000
+
+
+def test_tie_break_lowest_segment(hip_lib):
+    pts = np.zeros(3, dtype=lvo.LINE_POINT_DTYPE)
+    pts["linePosition"] = [[-0.1, 0, 0], [0, 0, 0], [0.1, 0.02, 0]]
+    pts["lineTangent"] = [[1, 0, 0]] * 3
+    pts["lineNormal"] = [[0, 1, 0]] * 3
+    c = Case(pts, np.array([[0, 1], [1, 2]], np.uint32), tfm.standard(), 32, 32, 0.02)
+    ctx = c.hip_context()
+    t, s, k = ctx.trace_rays(np.array([[0.0, -0.5, 0.0]], np.float32), np.array([[0.0, 1.0, 0.0]], np.float32), 1e-4, 10.0)
+    assert s[0] == 0 and k[0] == 2
+
+
+def test_lbvh_structure(hip_lib):
+    c = small_case(n_lines=60, pts_per_line=50, seed=5, line_width=0.01)
+    ctx = c.hip_context()
+    ctx.build_accel()
+    st = ctx.stats()
+    n = len(c.seg)
+    assert st.num_segments == n and st.num_nodes == n - 1 and 0 < st.bvh_depth <= 96
+    nodes, leaf_seg = ctx.get_accel(n - 1, n)
+    assert sorted(leaf_seg.tolist()) == list(range(n))          # every segment is exactly one leaf
+    f = nodes.view(np.float32)
+    child = nodes[:, 12:14]
+    LEAF = 0x80000000
+    # every node is referenced exactly once (except the root), every leaf exactly once
+    refs_internal = child[(child & LEAF) == 0]
+    refs_leaf = child[(child & LEAF) != 0] & 0x7FFFFFFF
+    assert sorted(refs_internal.tolist()) == list(range(1, n - 1))
+    assert sorted(refs_leaf.tolist()) == list(range(n))
+    # child boxes stored in the parent contain the capsule of every leaf child
+    p = c.points["linePosition"]
+    r = c.line_width * 0.5
+    for node in range(n - 1):
+        for ci, lo in ((0, 0), (1, 6)):
+            ref = int(child[node, ci])
+            if ref & LEAF:
+                seg = c.seg[leaf_seg[ref & 0x7FFFFFFF]]
+                mn = np.minimum(p[seg[0]], p[seg[1]]) - r
+                mx = np.maximum(p[seg[0]], p[seg[1]]) + r
+                assert np.all(f[node, lo:lo + 3] <= mn) and np.all(f[node, lo + 3:lo + 6] >= mx)
+
+
+# ---------------------------------------------------------------- golden frames
+def test_golden_frames_ray_tracer(hip_lib):
+    g, pts, W, H, lw = golden_base()
+    c = Case(pts, g["seg"], g["tf"], W, H, lw, depth_cue_strength=0.8)
+    ctx = c.hip_context()
+    assert max_lsb_diff(ctx.render(11), g["rt_depthcue"]) <= LSB_TOL
+    assert np.array_equal(bits(ctx.depth_range()), g["depth_range_bits"])
+    c = Case(pts, g["seg"], g["tf_transparent"], W, H, lw, num_samples_per_frame=4)
+    assert max_lsb_diff(c.hip_context().render(11), g["rt_transparent_spp4"]) <= LSB_TOL
+
+
+def test_golden_rtao(hip_lib):
+    g, pts, W, H, lw = golden_base()
+    c = Case(pts, g["seg"], g["tf"], W, H, lw, ambient_occlusion_mode="RTAO (Screen Space)",
+             ambient_occlusion_strength=0.9, ambient_occlusion_gamma=1.5, ambient_occlusion_iterations=2,
+             ambient_occlusion_samples_per_frame=8, ambient_occlusion_radius=0.1)
+    ctx = c.hip_context()
+    img = ctx.render(11)
+    assert np.array_equal(bits(ctx.get_ao()), g["ao_bits"])     # AO factors: bit-exact
+    assert max_lsb_diff(img, g["rt_ao"]) <= LSB_TOL
+
+
+def test_golden_ppll(hip_lib):
+    g, pts, W, H, lw = golden_base()
+    c = Case(pts, g["seg"], g["tf_transparent"], W, H, lw)
+    ctx = c.hip_context()
+    img = ctx.render(2)
+    st = ctx.stats()
+    assert st.fragments == int(g["ppll_fragments"]) and st.max_depth_complexity == int(g["ppll_max_depth_complexity"])
+    assert max_lsb_diff(img, g["ppll"]) <= LSB_TOL
+
+
+def test_golden_lattice_c1(hip_lib):
+    g = G("lattice_c1.npz")
+    tr = scenes.normalize(scenes.lattice())
+    flow = host_api.LineDataFlow().set_trajectories(tr.positions, tr.attributes, tr.line_offsets)
+    pts, seg, _ = flow.tube_aabb_render_data(float(g["line_width"]))
+    assert np.uint32(np.bitwise_xor.reduce(pts.view(np.uint32))) == g["points_crc"]
+    c = Case(pts, seg, tfm.standard(), 128, 128, float(g["line_width"]), num_samples_per_frame=4)
+    img = c.hip_context().render(11)
+    assert max_lsb_diff(img, g["image"]) <= LSB_TOL
+    # equal-mean check between two independent estimators (4 vs 16 spp), the reference's VPT test idea
+    c2 = Case(pts, seg, tfm.standard(), 128, 128, float(g["line_width"]), num_samples_per_frame=16)
+    img2 = c2.hip_context().render(11)
+    m1 = img.reshape(-1, 4).astype(np.float64).mean(axis=0) / 255.0
+    m2 = img2.reshape(-1, 4).astype(np.float64).mean(axis=0) / 255.0
+    assert np.abs(m1 - m2).max() < 2e-3 + 1.0 / 255.0
+
+
+# ---------------------------------------------------------------- live oracle comparisons
+@pytest.mark.parametrize("settings", [
+    dict(),
+    dict(use_halos=False, use_capped_tubes=False),
+    dict(num_samples_per_frame=3, use_deterministic_sampling=True),
+    dict(depth_cue_strength=0.5, max_depth_complexity=2),
+    dict(RTAO, ambient_occlusion_iterations=1, ambient_occlusion_samples_per_frame=64),
+    dict(RTAO, ambient_occlusion_iterations=3, ambient_occlusion_samples_per_frame=4, use_jittered_primary_rays=False),
+    dict(RTAO, ambient_occlusion_iterations=1, ambient_occlusion_samples_per_frame=5, ambient_occlusion_distance_based=False),
+    dict(RTAO, ambient_occlusion_iterations=2, ambient_occlusion_samples_per_frame=3, ambient_occlusion_radius=0.05,
+         tube_num_subdivisions=8, ambient_occlusion_gamma=2.0, ambient_occlusion_strength=0.7),
+])
+def test_ray_tracer_matches_oracle(hip_lib, settings):
+    transparent = settings.get("max_depth_complexity") == 2
+    c = small_case(width=112, height=80, seed=31, transparent=transparent, **settings)
+    ctx = c.hip_context()
+    img = ctx.render(11)
+    ref, ao_ref = c.oracle_render(11)
+    if ao_ref is not None:
+        assert np.array_equal(bits(ctx.get_ao()), bits(ao_ref))
+    assert max_lsb_diff(img, ref) <= LSB_TOL
+    assert (img != np.uint8(255)).any()
+
+
+@pytest.mark.parametrize("settings", [
+    dict(),
+    dict(ppll_tile_width=1, ppll_tile_height=1),
+    dict(ppll_tile_width=8, ppll_tile_height=8, depth_cue_strength=0.8),
+    dict(RTAO, ambient_occlusion_iterations=1, ambient_occlusion_samples_per_frame=8),
+    dict(ppll_max_num_frags=200),   # fragment arrays do not fit LDS -> global scratch variant
+])
+def test_ppll_matches_oracle(hip_lib, settings):
+    c = small_case(width=100, height=70, seed=17, transparent=True, **settings)   # not a multiple of the PPLL tile
+    ctx = c.hip_context()
+    img = ctx.render(2)
+    ref, _ = c.oracle_render(2)
+    assert max_lsb_diff(img, ref) <= LSB_TOL
+    # gather parity: per pixel the multiset of (colour, depth) fragments is identical, bit for bit
+    sc = c.oracle_scene()
+    P = c.oracle_params(sc)
+    ao = sc.render_ao(P) if P.useAmbientOcclusion else None
+    on, os_, ocnt = sc.ppll_gather(P, ao=ao)
+    pw, ph = c.padded()
+    hn, hs, hcnt = ctx.ppll_buffers(pw * ph, int(P.ppllLinkedListSize))
+    assert hcnt == ocnt and hs.shape == os_.shape
+
+    def lists(nodes, start):
+        out = {}
+        for pix in np.nonzero(start != 0xFFFFFFFF)[0]:
+            l, i = [], int(start[pix])
+            while i != 0xFFFFFFFF:
+                l.append((int(nodes[i, 1]), int(nodes[i, 0])))
+                i = int(nodes[i, 2])
+            out[int(pix)] = sorted(l)
+        return out
+    assert lists(hn, hs) == lists(on, os_)
+
+
+def test_ppll_resolve_given_lists(hip_lib):
+    g = G("ppll_lists.npz")
+    W, H = int(g["width"]), int(g["height"])
+    c = Case(np.zeros(0, dtype=lvo.LINE_POINT_DTYPE), np.zeros((0, 2), np.uint32), tfm.standard(), W, H, 0.01,
+             background=tuple(float(x) for x in g["background"]), ppll_max_num_frags=int(g["max_frags"]))
+    ctx = c.hip_context()
+    img = ctx.ppll_resolve(g["nodes"], g["start"])
+    assert np.array_equal(img, g["resolved_key"])      # identical lists -> identical bytes (ties, overflow, alpha 0)
+
+
+def test_ppll_pool_overflow(hip_lib):
+    c = small_case(width=64, height=48, n_lines=80, line_width=0.05, transparent=True,
+                   ppll_expected_avg_depth_complexity=1)
+    ctx = c.hip_context()
+    img = ctx.render(2)
+    st = ctx.stats()
+    pw, ph = c.padded()
+    assert st.fragments > pw * ph           # more fragments than pool nodes: the counter keeps counting
+    nodes, start, cnt = ctx.ppll_buffers(pw * ph, pw * ph)
+    stored = start[start != 0xFFFFFFFF]
+    assert stored.max() < pw * ph and img.shape == (48, 64, 4)
+
+
+# ---------------------------------------------------------------- edge cases
+def test_empty_scene_and_single_segment(hip_lib):
+    empty = Case(np.zeros(0, dtype=lvo.LINE_POINT_DTYPE), np.zeros((0, 2), np.uint32), tfm.standard(), 40, 24, 0.01,
+                 background=(0.25, 0.5, 0.75, 1.0))
+    ctx = empty.hip_context()
+    for mode in (11, 2):
+        img = ctx.render(mode)
+        assert np.array_equal(img, np.broadcast_to(np.array([64, 128, 191, 255], np.uint8), img.shape))
+    pts = np.zeros(2, dtype=lvo.LINE_POINT_DTYPE)
+    pts["linePosition"] = [[-0.2, 0.0, 0.0], [0.2, 0.05, 0.0]]
+    pts["lineTangent"] = [[1, 0, 0]] * 2
+    pts["lineNormal"] = [[0, 1, 0]] * 2
+    pts["lineAttribute"] = [0.1, 0.9]
+    one = Case(pts, np.array([[0, 1]], np.uint32), tfm.standard(), 64, 48, 0.05, **RTAO,
+               ambient_occlusion_iterations=1, ambient_occlusion_samples_per_frame=4)
+    img = one.hip_context().render(11)
+    ref, _ = one.oracle_render(11)
+    assert max_lsb_diff(img, ref) <= LSB_TOL and (img != 255).any()
+
+
+def test_duplicate_segments_and_fat_tubes(hip_lib):
+    # 64 identical segments: identical Morton keys exercise the duplicate-key path of the LBVH build
+    pts = np.zeros(128, dtype=lvo.LINE_POINT_DTYPE)
+    pts["linePosition"][0::2] = [-0.1, 0.0, 0.0]
+    pts["linePosition"][1::2] = [0.1, 0.0, 0.0]
+    pts["lineTangent"] = [1, 0, 0]
+    pts["lineNormal"] = [0, 1, 0]
+    seg = np.arange(128, dtype=np.uint32).reshape(64, 2)
+    c = Case(pts, seg, tfm.standard_transparent(), 48, 32, 0.1)
+    ctx = c.hip_context()
+    img = ctx.render(2)
+    ref, _ = c.oracle_render(2)
+    assert max_lsb_diff(img, ref) <= LSB_TOL
+    assert ctx.stats().max_depth_complexity == 64
+    t, s, k = ctx.trace_rays(np.array([[0, 0, 0.8]], np.float32), np.array([[0, 0, -1]], np.float32), 1e-4, 10.0)
+    assert s[0] == 0     # all 64 tie; lowest index wins
+
+
+def test_tile_list_equals_full_frame(hip_lib):
+    import torch
+    c = small_case(width=150, height=90, seed=3, num_samples_per_frame=2, **RTAO, ambient_occlusion_iterations=1,
+                   ambient_occlusion_samples_per_frame=4)
+    ctx = c.hip_context()
+    full = ctx.render(11)
+    part = ctx.render(11, tile=(37, 21, 50, 33))           # ragged rectangle, not aligned to 16
+    assert np.array_equal(part, full[21:54, 37:87])
+    for mode in (11, 2):
+        full = ctx.render(mode)
+        tiles = tiling.make_tiles(150, 90, 32)
+        out = torch.zeros((len(tiles), 32, 32, 4), dtype=torch.uint8, device="cuda")
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        ctx.render_tiles_device(out.data_ptr(), tiles, 32, 32, mode=mode)
+        torch.cuda.synchronize()
+        ctx.set_stream(None)
+        frame = tiling.detile(out.cpu().numpy(), tiles, 150, 90, 32)
+        assert np.array_equal(frame, full)
+
+
+def test_option_errors(hip_lib):
+    c = small_case(width=32, height=32)
+    ctx = c.hip_context()
+    for key, val in [("no_such_key", "1"), ("num_accumulated_frames", 2), ("ambient_occlusion_mode", "SSAO"),
+                     ("line_width", -1.0), ("geometry_mode", "Triangle Mesh"), ("use_mlat", True)]:
+        with pytest.raises(capi.LineVisError):
+            ctx.set_option(key, val)
+    with pytest.raises(capi.LineVisError):
+        ctx.render(7)
+    fresh = capi.Context(0)
+    with pytest.raises(capi.LineVisError):
+        fresh.render(11)                       # no camera / lines / transfer function yet
+
+
+def test_instrumented_counters(hip_lib):
+    c = small_case(width=64, height=64, **RTAO, ambient_occlusion_iterations=1, ambient_occlusion_samples_per_frame=8)
+    ctx = c.hip_context()
+    ctx.set_option("collect_stats", True)
+    img = ctx.render(11)
+    st = ctx.stats()
+    assert st.ao_hit_pixels > 0
+    # AO primaries + AO rays + colour-pass traces (one per pixel plus continuations)
+    assert st.rays_traced >= 64 * 64 * 2 + st.ao_hit_pixels * 8
+    assert st.nodes_visited > st.rays_traced and st.prims_tested > 0 and st.hits_shaded > 0
+    ctx.set_option("collect_stats", False)
+    assert np.array_equal(ctx.render(11), img)   # instrumentation does not change the image
+
+
+# ---------------------------------------------------------------- host layer (C++ classes) on the GPU
+def test_headless_renderer_plugins(hip_lib):
+    tr = scenes.normalize(scenes.random_curves(n_lines=30, points_per_line=30, seed=7))
+    flow = host_api.LineDataFlow().set_trajectories(tr.positions, tr.attributes, tr.line_offsets)
+    settings = dict(line_width=0.02, depth_cue_strength=0.8, num_samples_per_frame=2, **RTAO,
+                    ambient_occlusion_iterations=1, ambient_occlusion_samples_per_frame=4)
+    for mode, tf in ((11, tfm.standard()), (2, tfm.standard_transparent())):
+        r = host_api.HeadlessLineRenderer(mode)
+        assert r.rendering_mode == mode
+        r.set_rendering_resolution(96, 64)
+        r.set_transfer_function(tf)
+        r.set_line_data(flow)
+        r.set_new_settings(settings)
+        img = r.render_frame()
+        # the same frame through the C-ABI directly and through the oracle
+        pts, seg, _ = flow.tube_aabb_render_data(0.02)
+        lo, hi = flow.attribute_range()
+        c = Case(pts, seg, tf, 96, 64, 0.02, **{k: v for k, v in settings.items() if k != "line_width"})
+        ctx = c.hip_context()
+        ctx.set_transfer_function(tf, lo, hi)
+        view, proj, fovy, near, far = r.camera()   # the C++ Camera class builds its own (float32) matrices
+        assert np.allclose(view, c.view, atol=1e-6) and np.allclose(proj, c.proj, atol=1e-6)
+        ctx.set_camera(view, proj, fovy, near, far, 96, 64)
+        assert np.array_equal(img, ctx.render(mode))
+        # new settings through the plugin surface take effect
+        r.set_new_settings(dict(ambient_occlusion_strength=0.0, depth_cue_strength=0.0))
+        img2 = r.render_frame()
+        assert not np.array_equal(img, img2)
+
+
+# ---------------------------------------------------------------- full-size properties (BASELINE.json config 3)
+def test_full_size_properties(hip_lib):
+    tr = scenes.normalize(scenes.tornado())
+    flow = host_api.LineDataFlow().set_trajectories(tr.positions, tr.attributes, tr.line_offsets)
+    pts, seg, _ = flow.tube_aabb_render_data(0.002)
+    assert len(seg) == 1000000
+    c = Case(pts, seg, tfm.standard(), 1920, 1080, 0.002, **RTAO, ambient_occlusion_iterations=1,
+             ambient_occlusion_samples_per_frame=64)
+    ctx = c.hip_context()
+    full = ctx.render(11)
+    assert ctx.stats().ao_hit_pixels > 100000
+    # determinism / idempotence: a second render and a tile render reproduce the frame byte for byte
+    assert np.array_equal(ctx.render(11), full)
+    assert np.array_equal(ctx.render(11, tile=(701, 333, 257, 129)), full[333:462, 701:958])
+    # closest hits of the full-size LBVH against the oracle's own BVH (sampled primaries + random rays) ...
+    rng = np.random.default_rng(77)
+    o = np.concatenate([np.tile(np.array([[0, 0, 0.8]], np.float32), (20000, 1)),
+                        rng.uniform(-0.2, 0.2, (20000, 3)).astype(np.float32)])
+    d = rng.normal(size=(40000, 3)).astype(np.float32)
+    d[:20000, 2] = -np.abs(d[:20000, 2]) * 3
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    a = ctx.trace_rays(o, d, 1e-4, 1000.0)
+    sc = c.oracle_scene()
+    b = sc.trace_rays(o, d, 1e-4, 1000.0, 0.002, use_bvh=True)
+    assert np.array_equal(bits(a[0]), bits(b[0])) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    # ... and against brute force over all 1M capsules for a few hundred of them
+    idx = rng.choice(40000, 300, replace=False)
+    bf = sc.trace_rays(o[idx], d[idx], 1e-4, 1000.0, 0.002, use_bvh=False)
+    assert np.array_equal(bits(a[0][idx]), bits(bf[0])) and np.array_equal(a[1][idx], bf[1])
+    assert (a[1] != 0xFFFFFFFF).sum() > 5000
+    # a 160 x 90 crop of the frame against the oracle (CPU BVH), AO included
+    tile = (880, 495, 160, 90)
+    ref, _ = c.oracle_render(11, use_bvh=True, tile=tile)
+    x0, y0, w, h = tile
+    assert max_lsb_diff(full[y0:y0 + h, x0:x0 + w], ref) <= LSB_TOL

@@ -1,0 +1,92 @@
+"""Host C++ layer (linevis_amd/host): LineDataFlow geometry preparation, loaders, settings -- CPU only."""
+import os
+
+import numpy as np
+import pytest
+
+from common import GOLDEN_DIR
+from linevis_amd import host_api, scenes
+from oracle import lvo
+
+
+def test_host_a2_matches_golden_and_oracle():
+    g = np.load(os.path.join(GOLDEN_DIR, "a2_cases.npz"))
+    flow = host_api.LineDataFlow().set_trajectories(g["positions"], g["attributes"], g["line_offsets"])
+    pts, seg, aabb = flow.tube_aabb_render_data(float(g["line_width"]))
+    assert np.array_equal(pts.view(np.uint8).reshape(-1, 48), g["points"])
+    assert np.array_equal(seg, g["seg"])
+    assert np.array_equal(aabb.view(np.uint32), g["aabb_bits"])
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_host_a2_random_scenes_bit_identical(seed):
+    tr = scenes.normalize(scenes.random_curves(n_lines=50, points_per_line=37, seed=seed))
+    pos = tr.positions.copy()
+    rng = np.random.default_rng(seed)
+    dup = rng.integers(1, len(pos), 60)
+    pos[dup] = pos[dup - 1]  # degenerate points, also across line starts
+    flow = host_api.LineDataFlow().set_trajectories(pos, tr.attributes, tr.line_offsets)
+    a = flow.tube_aabb_render_data(0.01)
+    b = lvo.build_tube_aabb_render_data(pos, tr.attributes, tr.line_offsets, 0.01)
+    assert a[0].tobytes() == b[0].tobytes() and np.array_equal(a[1], b[1]) and a[2].tobytes() == b[2].tobytes()
+
+
+def test_host_line_width_changes_aabbs_only():
+    tr = scenes.normalize(scenes.random_curves(n_lines=6, points_per_line=12, seed=5))
+    flow = host_api.LineDataFlow().set_trajectories(tr.positions, tr.attributes, tr.line_offsets)
+    p1, s1, a1 = flow.tube_aabb_render_data(0.01)
+    p2, s2, a2 = flow.tube_aabb_render_data(0.02)
+    assert p1.tobytes() == p2.tobytes() and np.array_equal(s1, s2)
+    assert np.allclose(a2[:, 3:] - a1[:, 3:], 0.005, atol=1e-7)
+
+
+def test_normalize_matches_reference_rule():
+    tr = scenes.random_curves(n_lines=7, points_per_line=11, seed=9)
+    p = tr.positions * np.float32(7.0) + np.float32(3.0)
+    assert np.array_equal(host_api.normalize_positions(p), lvo.normalize_positions(p))
+
+
+def test_binlines_roundtrip(tmp_path):
+    tr = scenes.random_curves(n_lines=9, points_per_line=13, seed=4)
+    path = str(tmp_path / "lines.binlines")
+    scenes.write_binlines(path, tr)
+    # python reader
+    back = scenes.read_binlines(path)
+    assert np.array_equal(back.positions, tr.positions) and np.array_equal(back.attributes, tr.attributes)
+    assert np.array_equal(back.line_offsets, tr.line_offsets)
+    # C++ loader: applies the reference's normalisation on load (LineDataFlow::loadFromFile)
+    flow = host_api.LineDataFlow().load_binlines(path)
+    assert flow.num_lines == 9 and flow.num_points == 9 * 13
+    pos, att, off = flow.trajectories()
+    assert np.array_equal(pos, scenes.normalize(tr).positions)
+    assert np.array_equal(att, tr.attributes) and np.array_equal(off, tr.line_offsets)
+    lo, hi = flow.attribute_range()
+    assert lo == tr.attributes.min() and hi == tr.attributes.max()
+    # C++ writer -> python reader
+    path2 = str(tmp_path / "again.binlines")
+    flow.save_binlines(path2)
+    again = scenes.read_binlines(path2)
+    assert np.array_equal(again.positions, pos)
+
+
+def test_binlines_rejects_bad_version(tmp_path):
+    path = str(tmp_path / "bad.binlines")
+    open(path, "wb").write(b"\x07\x00\x00\x00" + b"\x00" * 32)
+    with pytest.raises(IOError):
+        host_api.LineDataFlow().load_binlines(path)
+    with pytest.raises(ValueError):
+        scenes.read_binlines(path)
+
+
+def test_scene_generators_shapes():
+    assert scenes.lattice().num_segments_upper == 31744
+    h = scenes.helix_bundle()
+    assert h.num_lines == 100 and h.num_points == 100100
+    t = scenes.tornado(n_lines=20, points_per_line=101)
+    assert t.positions.shape == (2020, 3) and np.isfinite(t.positions).all()
+    assert 0.0 <= t.attributes.min() and t.attributes.max() <= 1.0
+    r = scenes.rayleigh_benard(n_lines=10, points_per_line=51)
+    assert np.isfinite(r.positions).all()
+    # deterministic
+    assert np.array_equal(scenes.tornado(n_lines=5, points_per_line=21).positions,
+                          scenes.tornado(n_lines=5, points_per_line=21).positions)
