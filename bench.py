@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the hot path (BASELINE.json: Mrays/s + fps at 1920x1080, 1M-segment set,
+64 spp RTAO; 1/2/4/8 GPUs).
+
+One "step" = one complete frame of config 3: depth range -> RTAO (1 iteration x 64 samples per pixel, radius 0.1,
+distance based, jittered primaries) -> ray-tracer colour pass (1 spp), on the synthetic 1M-segment tornado-style
+streamline set, inputs resident in HBM.  With N > 1 the SAME frame is sharded by 64x64 screen tiles (Morton order,
+round robin) over one process per GPU and assembled on rank 0 by one RCCL gather (strong scaling: total work fixed).
+
+Prints ONE JSON line on rank 0.  `value` counts rays actually traced (primary + transparency continuation + AO), taken
+from an untimed instrumented frame (same kernels with counters), times steps, divided by the max-over-ranks wall time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+W, H = 1920, 1080
+TILE = 64
+LINE_WIDTH = 0.002
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E vendor peak (MI355X_MICROARCH.md; ~6.3 TB/s attainable)
+SETTINGS = {
+    "ambient_occlusion_mode": "RTAO (Screen Space)", "ambient_occlusion_strength": 1.0,
+    "ambient_occlusion_gamma": 1.0, "ambient_occlusion_iterations": 1, "ambient_occlusion_samples_per_frame": 64,
+    "ambient_occlusion_radius": 0.1, "ambient_occlusion_distance_based": True, "use_jittered_primary_rays": True,
+    "num_samples_per_frame": 1, "depth_cue_strength": 0.0,
+}
+WORKLOAD = ("C3: 1M-segment tornado-style streamlines (1000 lines x 1001 points, seed 12345), 1920x1080, "
+            "colour pass 1 spp + RTAO 64 spp (1 iteration x 64 samples, radius 0.1, distance based), line width 0.002")
+
+
+def cpu_baseline(pts, seg, tf, attr_range, view, proj, fovy, near, far, target_seconds=15.0):
+    """CPU restatement of the LineVis GLSL path (the oracle, NOT LineVis's own binary), all host cores (OpenMP), on a
+    centred crop of the same frame sized for ~target_seconds of work."""
+    from oracle import lvo
+    sc = lvo.Scene(pts, seg, tf)
+    P = lvo.make_params(view, proj, W, H, fovY=fovy, nearDist=near, farDist=far, lineWidth=LINE_WIDTH,
+                        useAmbientOcclusion=1, aoStrength=1.0, aoGamma=1.0, aoSamplesPerFrame=64, aoIterations=1,
+                        aoUseDistance=1, aoJitterPrimary=1, aoRadius=0.1, attrMin=attr_range[0], attrMax=attr_range[1])
+    t0 = time.time()
+    sc.build_bvh(LINE_WIDTH)
+    build_s = time.time() - t0
+
+    def run(cw, ch):
+        tile = ((W - cw) // 2, (H - ch) // 2, cw, ch)
+        st = lvo.Stats()
+        t = time.time()
+        ao = sc.render_ao(P, tile=tile, use_bvh=True, stats=st)
+        sc.render_rt(P, ao=ao, tile=tile, use_bvh=True, stats=st)
+        return time.time() - t, int(st.raysTraced)
+
+    cw, ch = 96, 54                             # calibration crop, then grow towards ~target_seconds of work
+    dt, rays = run(cw, ch)
+    for _ in range(3):
+        if dt >= 0.6 * target_seconds or (cw >= W and ch >= H):
+            break
+        grow = min((target_seconds / max(dt, 1e-3)) ** 0.5, 6.0)
+        cw = min(W, int(round(cw * grow / 16.0)) * 16)
+        ch = min(H, int(round(ch * grow / 9.0)) * 9)
+        dt, rays = run(cw, ch)
+    return {"value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": "centred %dx%d crop of the same frame (%.1f s, %d rays), CPU LBVH build %.1f s excluded; "
+                      "CPU restatement of the LineVis GLSL path (oracle), not LineVis's own binary" % (cw, ch, dt, rays, build_s),
+            "fps_extrapolated": round(1.0 / (dt * (W * H) / float(cw * ch)), 4)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--save-frame", default="")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`"
+                             % (args.gpus, args.gpus))
+        raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from linevis_amd import camera, capi, host_api, scenes, tiling, transfer_function as tfm
+
+    # ---- synthetic input (every rank builds the same replica; deterministic)
+    tr = scenes.normalize(scenes.tornado())
+    flow = host_api.LineDataFlow().set_trajectories(tr.positions, tr.attributes, tr.line_offsets)
+    pts, seg, _ = flow.tube_aabb_render_data(LINE_WIDTH)
+    tf = tfm.standard()
+    attr_range = flow.attribute_range()
+    view, proj, fovy, near, far = camera.default_camera(W, H)
+
+    ctx = capi.Context(local_rank)
+    ctx.set_lines(pts, seg)
+    ctx.set_transfer_function(tf, *attr_range)
+    ctx.set_camera(view, proj, fovy, near, far, W, H)
+    ctx.set_option("line_width", LINE_WIDTH)
+    ctx.set_options(SETTINGS)
+    render_fn = tiling.hip_render_tiles_fn(ctx, capi.MODE_RAY_TRACER)   # also moves the context onto torch's stream
+    ctx.build_accel()
+    build_ms = ctx.stats().ms_accel_build
+    sf = tiling.ShardedFrame(W, H, TILE, rank, world, device)
+
+    def step():
+        sf.render_local(render_fn)
+        sf.gather()
+        return sf.assemble_device()
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- untimed instrumented frame: rays traced + algorithmic traffic of this rank's tiles
+    ctx.set_option("collect_stats", True)
+    step()
+    torch.cuda.synchronize()
+    st = ctx.stats()
+    ctx.set_option("collect_stats", False)
+    counters = torch.tensor([st.rays_traced, st.nodes_visited, st.prims_tested, st.hits_shaded, st.ao_hit_pixels],
+                            dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(counters)
+    rays_per_frame = float(counters[0].item())
+    # algorithmic bytes of ONE k_ao_rays launch on this rank (DESIGN.md "Algorithmic bytes"):
+    # 64 B per BVH node visited + 32 B per segment record tested + 52 B per compacted pixel (48 B G-buffer read,
+    # 4 B AO factor write)
+    ao_bytes = st.ao_nodes_visited * 64 + st.ao_prims_tested * 32 + st.ao_hit_pixels * 52
+    frame_bytes = (st.nodes_visited * 64 + st.prims_tested * 32 + st.hits_shaded * 96 + st.ao_hit_pixels * 52
+                   + len(sf.local_tiles) * TILE * TILE * (4 + 4))
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    ctx.reset_timers()
+    sync_all()
+    t0 = time.perf_counter()
+    frame = None
+    for _ in range(args.steps):
+        frame = step()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    elapsed = float(tt.item())
+    st = ctx.stats()   # per-kernel HIP-event averages over the timed region (this rank)
+
+    if rank == 0:
+        ms_rays = float(st.ms_kernel_avg[capi.KERNEL_AO_RAYS])
+        achieved = ao_bytes / (ms_rays * 1e-3) / 1e9 if ms_rays > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
+        if os.path.exists(tpath) and world == 1:
+            try:
+                traffic = json.load(open(tpath)).get("k_ao_rays_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        result = {
+            "metric": "Mrays/s", "value": round(rays_per_frame * args.steps / elapsed / 1e6, 2), "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "fps": round(args.steps / elapsed, 3),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": WORKLOAD, "resolution": [W, H], "segments": int(len(seg)),
+                       "rays_per_frame": int(rays_per_frame), "ao_hit_pixels": int(counters[4].item()),
+                       "parallelism": "screen tiles %dx%d, Morton order, round robin over %d GPU(s), one RCCL gather"
+                                      % (TILE, TILE, world),
+                       "accel_build_ms": round(build_ms, 3), "bvh_depth": int(st.bvh_depth)},
+            "roofline": {"bound": "hbm", "kernel": "k_ao_rays", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": int(ao_bytes), "ms_per_launch": round(ms_rays, 4),
+                         "launches_timed": int(min(st.kernel_launches[capi.KERNEL_AO_RAYS], 128)),
+                         "frame_algorithmic_bytes_rank0": int(frame_bytes)},
+            "kernels_ms": {capi.KERNEL_NAMES[k]: round(float(st.ms_kernel_avg[k]), 4) for k in range(6)
+                           if st.kernel_launches[k]},
+        }
+        if args.save_frame and frame is not None:
+            from PIL import Image
+            Image.fromarray(frame.cpu().numpy()).save(args.save_frame)
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(pts, seg, tf, attr_range, view, proj, fovy, near, far)
+        else:
+            result["cpu_baseline"] = None
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -71,7 +71,22 @@ typedef struct lv_stats {
     float ms_ppll_resolve;
     float ms_total;              /* whole lv_render* call on the stream */
     uint64_t device_bytes;       /* device memory owned by the context */
+    /* Per-kernel launch durations from HIP events recorded around every launch on the context's stream, averaged over
+     * all launches since lv_reset_timers() (at most the last 128).  Index = LV_KERNEL_*. */
+    float ms_kernel_avg[8];
+    uint32_t kernel_launches[8];
+    /* share of the counters above that belongs to the RTAO sample kernel (k_ao_rays) */
+    uint64_t ao_rays_traced;
+    uint64_t ao_nodes_visited;
+    uint64_t ao_prims_tested;
 } lv_stats;
+
+#define LV_KERNEL_AO_PRIMARY 0
+#define LV_KERNEL_AO_RAYS 1
+#define LV_KERNEL_RENDER_RT 2
+#define LV_KERNEL_PPLL_GATHER 3
+#define LV_KERNEL_PPLL_RESOLVE 4
+#define LV_KERNEL_DEPTH_RANGE 5
 
 typedef struct lv_ctx lv_ctx;
 
@@ -139,6 +154,8 @@ int lv_render_tiles_device(lv_ctx* ctx, int rendering_mode, const uint32_t* tile
                            uint32_t tile_w, uint32_t tile_h, void* out_rgba8_device);
 
 int lv_get_stats(lv_ctx* ctx, lv_stats* out);
+/* Forget the per-kernel launch timings collected so far (start of a timed benchmark region). */
+int lv_reset_timers(lv_ctx* ctx);
 
 /* ---- inspection entry points used by the parity tests ---- */
 /* Closest hit of arbitrary rays (IntersectionTube + driver closest-hit semantics, TubeRayTracing.glsl:452-494).

@@ -30,10 +30,20 @@ class Stats(C.Structure):
                 ("num_nodes", C.c_uint32),
                 ("ms_accel_build", C.c_float), ("ms_depth_range", C.c_float), ("ms_ao", C.c_float),
                 ("ms_color", C.c_float), ("ms_ppll_clear", C.c_float), ("ms_ppll_gather", C.c_float),
-                ("ms_ppll_resolve", C.c_float), ("ms_total", C.c_float), ("device_bytes", C.c_uint64)]
+                ("ms_ppll_resolve", C.c_float), ("ms_total", C.c_float), ("device_bytes", C.c_uint64),
+                ("ms_kernel_avg", C.c_float * 8), ("kernel_launches", C.c_uint32 * 8),
+                ("ao_rays_traced", C.c_uint64), ("ao_nodes_visited", C.c_uint64), ("ao_prims_tested", C.c_uint64)]
 
     def as_dict(self):
-        return {n: getattr(self, n) for n, _ in self._fields_}
+        d = {}
+        for n, _ in self._fields_:
+            v = getattr(self, n)
+            d[n] = list(v) if hasattr(v, "__len__") else v
+        return d
+
+
+KERNEL_AO_PRIMARY, KERNEL_AO_RAYS, KERNEL_RENDER_RT, KERNEL_PPLL_GATHER, KERNEL_PPLL_RESOLVE, KERNEL_DEPTH_RANGE = range(6)
+KERNEL_NAMES = ["k_ao_primary", "k_ao_rays", "k_render_rt", "k_ppll_gather", "k_ppll_resolve", "k_depth_minmax"]
 
 
 class LineVisError(RuntimeError):
@@ -45,7 +55,7 @@ class LineVisError(RuntimeError):
 # every symbol include/linevis_hip.h declares (checked by tests/test_abi.py against the header text)
 SYMBOLS = ["lv_create", "lv_destroy", "lv_last_error", "lv_version", "lv_set_stream", "lv_set_lines",
            "lv_set_transfer_function", "lv_set_camera", "lv_set_background", "lv_set_option", "lv_build_accel",
-           "lv_render", "lv_render_device", "lv_render_tiles_device", "lv_get_stats", "lv_trace_rays",
+           "lv_render", "lv_render_device", "lv_render_tiles_device", "lv_get_stats", "lv_reset_timers", "lv_trace_rays",
            "lv_compute_depth_range", "lv_get_ao", "lv_ppll_get_buffers", "lv_ppll_resolve_buffers", "lv_get_accel"]
 
 _lib = None
@@ -90,6 +100,7 @@ def load():
         ("lv_render_device", [vp, i32, u32, u32, u32, u32, vp]),
         ("lv_render_tiles_device", [vp, i32, vp, u32, u32, u32, vp]),
         ("lv_get_stats", [vp, C.POINTER(Stats)]),
+        ("lv_reset_timers", [vp]),
         ("lv_trace_rays", [vp, vp, vp, f32, f32, u32, vp, vp, vp]),
         ("lv_compute_depth_range", [vp, vp]),
         ("lv_get_ao", [vp, vp]),
@@ -193,6 +204,9 @@ class Context:
         s = Stats()
         self._ck(self.L.lv_get_stats(self.h, C.byref(s)))
         return s
+
+    def reset_timers(self):
+        self._ck(self.L.lv_reset_timers(self.h))
 
     def trace_rays(self, origins, dirs, t_min, t_max):
         o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)

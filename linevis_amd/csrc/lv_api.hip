@@ -87,6 +87,7 @@ namespace {
 
 struct LvDevCountersHost { // must match LvDevCounters in lv_render.hip
     unsigned long long rays, nodes, prims, hits;
+    unsigned long long aoRays, aoNodes, aoPrims;
     uint32_t fragCounter, aoCount, maxDepthComplexity, depthOrd[2], pad;
 };
 
@@ -146,6 +147,12 @@ lv_ctx* lv_create(int device_ordinal, int* err) {
             return nullptr;
         }
     }
+    for (int k = 0; k < lv_ctx::kNumKernels; k++)
+        for (int i = 0; i < 2 * lv_ctx::kRing; i++)
+            if (hipEventCreate(&ctx->evKernel[k][i]) != hipSuccess) {
+                if (err) *err = LV_E_HIP;
+                return nullptr; // context leaked deliberately: the device is unusable
+            }
     ctx->evCreated = true;
     if (err) *err = LV_OK;
     return ctx;
@@ -160,8 +167,11 @@ void lv_destroy(lv_ctx* ctx) {
                               &ctx->ppllNodes, &ctx->ppllStart, &ctx->ppllScratch, &ctx->tilesDev, &ctx->outDev,
                               &ctx->scratchRays})
         lv_buf_free(*b);
-    if (ctx->evCreated)
+    if (ctx->evCreated) {
         for (int i = 0; i < 16; i++) (void)hipEventDestroy(ctx->ev[i]);
+        for (int k = 0; k < lv_ctx::kNumKernels; k++)
+            for (int i = 0; i < 2 * lv_ctx::kRing; i++) (void)hipEventDestroy(ctx->evKernel[k][i]);
+    }
     if (ctx->ownStream) (void)hipStreamDestroy(ctx->ownStream);
     delete ctx;
 }
@@ -175,6 +185,7 @@ int lv_set_stream(lv_ctx* ctx, void* hip_stream) {
     ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->ownStream;
     ctx->evBuildValid = false;
     ctx->evFrameValid = false;
+    for (int k = 0; k < lv_ctx::kNumKernels; k++) ctx->kernelLaunches[k] = 0;
     return LV_OK;
 }
 
@@ -388,6 +399,22 @@ int lv_get_stats(lv_ctx* ctx, lv_stats* out) {
         s.fragments = hc.fragCounter;
         s.ao_hit_pixels = hc.aoCount;
         s.max_depth_complexity = hc.maxDepthComplexity;
+        s.ao_rays_traced = hc.aoRays;
+        s.ao_nodes_visited = hc.aoNodes;
+        s.ao_prims_tested = hc.aoPrims;
+    }
+    for (int k = 0; k < 8; k++) { s.ms_kernel_avg[k] = 0.0f; s.kernel_launches[k] = 0; }
+    for (int k = 0; k < lv_ctx::kNumKernels; k++) {
+        const uint64_t n = ctx->kernelLaunches[k];
+        const uint64_t m = n < uint64_t(lv_ctx::kRing) ? n : uint64_t(lv_ctx::kRing);
+        double sum = 0.0;
+        for (uint64_t i = 0; i < m; i++) {
+            const uint64_t slot = (n - 1 - i) % lv_ctx::kRing;
+            float t = 0.0f;
+            if (hipEventElapsedTime(&t, ctx->evKernel[k][2 * slot], ctx->evKernel[k][2 * slot + 1]) == hipSuccess) sum += t;
+        }
+        s.ms_kernel_avg[k] = m ? float(sum / double(m)) : 0.0f;
+        s.kernel_launches[k] = uint32_t(n);
     }
     uint64_t bytes = 0;
     for (const LvDeviceBuffer* b : {&ctx->points, &ctx->segIdx, &ctx->nodes, &ctx->segs, &ctx->leafSeg, &ctx->tf,
@@ -397,6 +424,14 @@ int lv_get_stats(lv_ctx* ctx, lv_stats* out) {
         bytes += b->bytes;
     s.device_bytes = bytes;
     *out = s;
+    return LV_OK;
+}
+
+int lv_reset_timers(lv_ctx* ctx) {
+    if (!ctx) return LV_E_INVALID;
+    (void)hipSetDevice(ctx->device);
+    LV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < lv_ctx::kNumKernels; k++) ctx->kernelLaunches[k] = 0;
     return LV_OK;
 }
 

@@ -83,6 +83,11 @@ struct lv_ctx {
     bool evCreated = false;
     bool evBuildValid = false, evFrameValid = false;
     int lastMode = 0;
+    // per-kernel launch timers: ring of event pairs per kernel id (LV_KERNEL_*)
+    static constexpr int kNumKernels = 6;
+    static constexpr int kRing = 128;
+    hipEvent_t evKernel[kNumKernels][2 * kRing];
+    uint64_t kernelLaunches[kNumKernels] = {0, 0, 0, 0, 0, 0};
 };
 
 int lv_fail(lv_ctx* ctx, int code, const char* fmt, ...);
@@ -95,6 +100,17 @@ int lv_fail(lv_ctx* ctx, int code, const char* fmt, ...);
     } while (0)
 
 int lv_buf_reserve(lv_ctx* ctx, LvDeviceBuffer& b, size_t bytes);
+// event pair of the next launch of kernel `id`
+inline hipEvent_t lv_kernel_ev(lv_ctx* ctx, int id, int which) {
+    return ctx->evKernel[id][2 * (ctx->kernelLaunches[id] % lv_ctx::kRing) + which];
+}
+#define LV_TIMED_LAUNCH(ctx, id, launch)                                      \
+    do {                                                                      \
+        LV_HIP(ctx, hipEventRecord(lv_kernel_ev(ctx, id, 0), (ctx)->stream)); \
+        launch;                                                               \
+        LV_HIP(ctx, hipEventRecord(lv_kernel_ev(ctx, id, 1), (ctx)->stream)); \
+        (ctx)->kernelLaunches[id]++;                                          \
+    } while (0)
 void lv_buf_free(LvDeviceBuffer& b);
 
 // lv_bvh.hip

@@ -22,6 +22,7 @@ namespace {
 // device-side counters block
 struct LvDevCounters {
     unsigned long long rays, nodes, prims, hits;
+    unsigned long long aoRays, aoNodes, aoPrims; // share of k_ao_rays
     uint32_t fragCounter;
     uint32_t aoCount;
     uint32_t maxDepthComplexity;
@@ -29,7 +30,7 @@ struct LvDevCounters {
     uint32_t pad;
 };
 
-__device__ __forceinline__ void lv_flush_counters(const LvCounters& c, LvDevCounters* dc) {
+__device__ __forceinline__ void lv_flush_counters(const LvCounters& c, LvDevCounters* dc, bool aoRays = false) {
     unsigned long long r = lv_wave_sum_u64(c.rays), n = lv_wave_sum_u64(c.nodes), p = lv_wave_sum_u64(c.prims),
                        h = lv_wave_sum_u64(c.hits);
     if (lv_lane() == 0) {
@@ -37,6 +38,11 @@ __device__ __forceinline__ void lv_flush_counters(const LvCounters& c, LvDevCoun
         atomicAdd(&dc->nodes, n);
         atomicAdd(&dc->prims, p);
         atomicAdd(&dc->hits, h);
+        if (aoRays) {
+            atomicAdd(&dc->aoRays, r);
+            atomicAdd(&dc->aoNodes, n);
+            atomicAdd(&dc->aoPrims, p);
+        }
     }
 }
 
@@ -254,7 +260,7 @@ __global__ __launch_bounds__(LV_BLOCK) void k_ao_rays(const LvUniforms U, const 
             }
         }
     }
-    if (STATS) lv_flush_counters(cnt, dc);
+    if (STATS) lv_flush_counters(cnt, dc, true);
 }
 
 __global__ __launch_bounds__(LV_BLOCK) void k_ao_reduce(const LvUniforms U, const float4* __restrict__ gbuf,
@@ -595,14 +601,17 @@ static int lv_run_ao(lv_ctx* ctx, LvUniforms& U, const LvSceneDev& S, const LvTi
         U.aoFrameNumber = iter; // rtaoRenderPass->setFrameNumber(accumulatedFramesCounter), VulkanRayTracedAmbientOcclusion.cpp:92
         LV_HIP(ctx, hipMemsetAsync(&dc->aoCount, 0, 4, st));
         if (stats)
-            k_ao_primary<true><<<gridTiles, LV_BLOCK, 0, st>>>(U, S, T, (float*)ctx->ao.ptr, (float4*)ctx->aoGbuf.ptr, dc);
+            LV_TIMED_LAUNCH(ctx, LV_KERNEL_AO_PRIMARY, (k_ao_primary<true><<<gridTiles, LV_BLOCK, 0, st>>>(
+                    U, S, T, (float*)ctx->ao.ptr, (float4*)ctx->aoGbuf.ptr, dc)));
         else
-            k_ao_primary<false><<<gridTiles, LV_BLOCK, 0, st>>>(U, S, T, (float*)ctx->ao.ptr, (float4*)ctx->aoGbuf.ptr, dc);
+            LV_TIMED_LAUNCH(ctx, LV_KERNEL_AO_PRIMARY, (k_ao_primary<false><<<gridTiles, LV_BLOCK, 0, st>>>(
+                    U, S, T, (float*)ctx->ao.ptr, (float4*)ctx->aoGbuf.ptr, dc)));
         const uint32_t grid = nblocks(maxRays);
         const float4* g = (const float4*)ctx->aoGbuf.ptr;
         float* ao = (float*)ctx->ao.ptr;
         float* smp = (float*)ctx->aoSamples.ptr;
-#define LV_LAUNCH_AO(ST, AH, FU) k_ao_rays<ST, AH, FU><<<grid, LV_BLOCK, 0, st>>>(U, S, g, ao, smp, dc)
+#define LV_LAUNCH_AO(ST, AH, FU) \
+    LV_TIMED_LAUNCH(ctx, LV_KERNEL_AO_RAYS, (k_ao_rays<ST, AH, FU><<<grid, LV_BLOCK, 0, st>>>(U, S, g, ao, smp, dc)))
         const bool anyHit = !U.aoUseDistance;
         if (stats) {
             if (anyHit) { if (fused) LV_LAUNCH_AO(true, true, true); else LV_LAUNCH_AO(true, true, false); }
@@ -679,8 +688,8 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
     uint32_t* out = (uint32_t*)outDevice;
     if (mode == LV_RENDERING_MODE_VULKAN_RAY_TRACER) {
         LV_HIP(ctx, hipEventRecord(ctx->ev[8], st));
-        if (stats) k_render_rt<true><<<gridTiles, LV_BLOCK, 0, st>>>(U, S, T, out, dc);
-        else k_render_rt<false><<<gridTiles, LV_BLOCK, 0, st>>>(U, S, T, out, dc);
+        if (stats) LV_TIMED_LAUNCH(ctx, LV_KERNEL_RENDER_RT, (k_render_rt<true><<<gridTiles, LV_BLOCK, 0, st>>>(U, S, T, out, dc)));
+        else LV_TIMED_LAUNCH(ctx, LV_KERNEL_RENDER_RT, (k_render_rt<false><<<gridTiles, LV_BLOCK, 0, st>>>(U, S, T, out, dc)));
         LV_HIP(ctx, hipEventRecord(ctx->ev[9], st));
     } else {
         // reallocateFragmentBuffer, PerPixelLinkedListLineRenderer.cpp:251-357
@@ -695,11 +704,11 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
         // gather()
         LV_HIP(ctx, hipEventRecord(ctx->ev[12], st));
         if (stats)
-            k_ppll_gather<true><<<gridTiles, LV_BLOCK, 0, st>>>(U, S, T, (uint32_t*)ctx->ppllNodes.ptr,
-                                                                (uint32_t*)ctx->ppllStart.ptr, dc);
+            LV_TIMED_LAUNCH(ctx, LV_KERNEL_PPLL_GATHER, (k_ppll_gather<true><<<gridTiles, LV_BLOCK, 0, st>>>(
+                    U, S, T, (uint32_t*)ctx->ppllNodes.ptr, (uint32_t*)ctx->ppllStart.ptr, dc)));
         else
-            k_ppll_gather<false><<<gridTiles, LV_BLOCK, 0, st>>>(U, S, T, (uint32_t*)ctx->ppllNodes.ptr,
-                                                                 (uint32_t*)ctx->ppllStart.ptr, dc);
+            LV_TIMED_LAUNCH(ctx, LV_KERNEL_PPLL_GATHER, (k_ppll_gather<false><<<gridTiles, LV_BLOCK, 0, st>>>(
+                    U, S, T, (uint32_t*)ctx->ppllNodes.ptr, (uint32_t*)ctx->ppllStart.ptr, dc)));
         LV_HIP(ctx, hipEventRecord(ctx->ev[13], st));
         // resolve()
         LV_HIP(ctx, hipEventRecord(ctx->ev[14], st));
@@ -708,15 +717,14 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
         const uint32_t numGroups = uint32_t(groups64);
         const size_t ldsBytes = size_t(U.ppllMaxNumFrags) * LV_WAVE * 8;
         if (ldsBytes <= 64 * 1024) {
-            k_ppll_resolve<true><<<numGroups, LV_WAVE, ldsBytes, st>>>(U, T, (const uint32_t*)ctx->ppllNodes.ptr,
-                                                                       (const uint32_t*)ctx->ppllStart.ptr, out, nullptr,
-                                                                       numGroups);
+            LV_TIMED_LAUNCH(ctx, LV_KERNEL_PPLL_RESOLVE, (k_ppll_resolve<true><<<numGroups, LV_WAVE, ldsBytes, st>>>(
+                    U, T, (const uint32_t*)ctx->ppllNodes.ptr, (const uint32_t*)ctx->ppllStart.ptr, out, nullptr, numGroups)));
         } else {
             const uint32_t grid = numGroups < 4096u ? numGroups : 4096u;
             if ((rc = lv_buf_reserve(ctx, ctx->ppllScratch, size_t(grid) * ldsBytes))) return rc;
-            k_ppll_resolve<false><<<grid, LV_WAVE, 0, st>>>(U, T, (const uint32_t*)ctx->ppllNodes.ptr,
-                                                            (const uint32_t*)ctx->ppllStart.ptr, out,
-                                                            (uint32_t*)ctx->ppllScratch.ptr, numGroups);
+            LV_TIMED_LAUNCH(ctx, LV_KERNEL_PPLL_RESOLVE, (k_ppll_resolve<false><<<grid, LV_WAVE, 0, st>>>(
+                    U, T, (const uint32_t*)ctx->ppllNodes.ptr, (const uint32_t*)ctx->ppllStart.ptr, out,
+                    (uint32_t*)ctx->ppllScratch.ptr, numGroups)));
         }
         LV_HIP(ctx, hipEventRecord(ctx->ev[15], st));
     }

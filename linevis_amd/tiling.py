@@ -80,6 +80,25 @@ class ShardedFrame:
         import torch.distributed as dist
         dist.gather(self.out, gather_list=self.gathered if self.rank == 0 else None, dst=0)
 
+    def assemble_device(self):
+        """Rank 0: de-tile on the device with three tensor ops -> uint8 tensor [H, W, 4] (other ranks: None)."""
+        if self.rank != 0:
+            return None
+        import torch
+        t = self.tile
+        nx, ny = -(-self.width // t), -(-self.height // t)
+        if not hasattr(self, "_perm"):
+            # position of tile (gy, gx) inside the rank-major concatenation of the gathered pieces
+            perm = np.zeros(nx * ny, dtype=np.int64)
+            for r in range(self.world):
+                for i, (x0, y0) in enumerate(assign_tiles(self.all_tiles, r, self.world)):
+                    perm[(int(y0) // t) * nx + int(x0) // t] = r * self.slots + i
+            self._perm = torch.from_numpy(perm).to(self.device)
+        pieces = self.out if self.world == 1 else torch.cat(self.gathered, dim=0)
+        grid = pieces.index_select(0, self._perm).view(ny, nx, t, t, 4)
+        frame = grid.permute(0, 2, 1, 3, 4).reshape(ny * t, nx * t, 4)
+        return frame[:self.height, :self.width]
+
     def assemble(self):
         """Rank 0: de-tile the gathered pieces into the frame (numpy [H, W, 4]); other ranks: None."""
         if self.rank != 0:
@@ -97,10 +116,11 @@ class ShardedFrame:
 
 
 def hip_render_tiles_fn(ctx, mode):
-    """Adapter: renders tiles with a capi.Context into a torch uint8 tensor on the context's device."""
+    """Adapter: renders tiles with a capi.Context into a torch uint8 tensor on the context's device.  The context
+    is switched to torch's current stream once, so the gather that follows is ordered after the kernels."""
     import torch
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
 
     def fn(out_tensor, tiles_xy, tile_w, tile_h):
-        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
         ctx.render_tiles_device(out_tensor.data_ptr(), tiles_xy, tile_w, tile_h, mode=mode)
     return fn

@@ -261,6 +261,7 @@ struct lvo_scene {
     std::vector<float> tf; // rgba * n
     uint32_t tfN = 0;
     std::vector<BvhNode> nodes;
+    std::vector<float> leafBoxes; // 6 floats per segment (padded capsule AABB), only with a BVH
     int32_t root = -1; // may be a leaf reference (<0 encoded) when nSeg == 1
     bool rootIsLeaf = false;
     uint32_t bvhDepth = 0;
@@ -324,17 +325,27 @@ int32_t buildRange(lvo_scene& sc, const std::vector<uint64_t>& keys, const std::
     return idx;
 }
 
-// conservative slab test (boxes are padded at build time)
-inline bool rayBox(const float* bmin, const float* bmax, V3 o, V3 inv, float tMin, float tMax) {
+// conservative slab test (boxes are padded at build time); tNear = entry parameter
+inline bool rayBox(const float* bmin, const float* bmax, V3 o, V3 inv, float tMin, float tMax, float& tNear) {
     float tx0 = (bmin[0] - o.x) * inv.x, tx1 = (bmax[0] - o.x) * inv.x;
     float ty0 = (bmin[1] - o.y) * inv.y, ty1 = (bmax[1] - o.y) * inv.y;
     float tz0 = (bmin[2] - o.z) * inv.z, tz1 = (bmax[2] - o.z) * inv.z;
     float tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), tMin));
     float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), tMax));
+    tNear = tn;
     return tn <= tf * 1.0000005f + 1e-7f;
 }
+inline bool childBox(const lvo_scene& sc, int32_t c, V3 o, V3 inv, float tMin, float tMax, float& tNear);
 
 struct Hit { float t; uint32_t seg; int kind; };
+
+inline bool childBox(const lvo_scene& sc, int32_t c, V3 o, V3 inv, float tMin, float tMax, float& tNear) {
+    if (c < 0) {
+        const float* b = &sc.leafBoxes[6 * size_t(~c)];
+        return rayBox(b, b + 3, o, inv, tMin, tMax, tNear);
+    }
+    return rayBox(sc.nodes[c].bmin, sc.nodes[c].bmax, o, inv, tMin, tMax, tNear);
+}
 
 // Closest hit over all capsules, hit accepted iff tMin <= t <= tMax (reportIntersectionEXT semantics),
 // ties -> lowest segment index (the driver's tie order is arbitrary).
@@ -369,9 +380,19 @@ inline bool closestHit(const lvo_scene& sc, float radius, bool capped, bool useB
             if (n < 0) { testSeg(uint32_t(~n)); continue; }
             const BvhNode& nd = sc.nodes[n];
             cnt.nodes++;
-            if (!rayBox(nd.bmin, nd.bmax, o, inv, tMin, found ? best : tMax)) continue;
-            stack[sp++] = nd.right;
-            stack[sp++] = nd.left;
+            // test both children, descend into the nearer one first
+            float tl, tr;
+            const float limit = found ? best : tMax;
+            bool hl = childBox(sc, nd.left, o, inv, tMin, limit, tl);
+            bool hr = childBox(sc, nd.right, o, inv, tMin, limit, tr);
+            if (hl && hr) {
+                if (tr < tl) { stack[sp++] = nd.left; stack[sp++] = nd.right; }
+                else { stack[sp++] = nd.right; stack[sp++] = nd.left; }
+            } else if (hl) {
+                stack[sp++] = nd.left;
+            } else if (hr) {
+                stack[sp++] = nd.right;
+            }
         }
     }
     out.t = best; out.seg = bestSeg; out.kind = bestKind;
@@ -404,9 +425,9 @@ inline void allHits(const lvo_scene& sc, float radius, bool capped, bool useBvh,
             if (n < 0) { testSeg(uint32_t(~n)); continue; }
             const BvhNode& nd = sc.nodes[n];
             cnt.nodes++;
-            if (!rayBox(nd.bmin, nd.bmax, o, inv, tMin, tMax)) continue;
-            stack.push_back(nd.right);
-            stack.push_back(nd.left);
+            float tl, tr;
+            if (childBox(sc, nd.right, o, inv, tMin, tMax, tr)) stack.push_back(nd.right);
+            if (childBox(sc, nd.left, o, inv, tMin, tMax, tl)) stack.push_back(nd.left);
         }
         std::sort(out.begin(), out.end(), [](const Hit& a, const Hit& b) { return a.seg < b.seg; });
     }
@@ -849,6 +870,9 @@ void lvo_scene_build_bvh(lvo_scene* sc, float lineWidth) {
     sc->root = buildRange(*sc, sk, order, boxes, 0, n, 0, maxDepth);
     sc->rootIsLeaf = sc->root < 0;
     sc->bvhDepth = maxDepth;
+    sc->leafBoxes.resize(6 * size_t(n));
+    for (uint32_t s = 0; s < n; s++)
+        for (int k = 0; k < 3; k++) { sc->leafBoxes[6 * size_t(s) + k] = boxes[s].mn[k]; sc->leafBoxes[6 * size_t(s) + 3 + k] = boxes[s].mx[k]; }
 }
 
 int lvo_intersect_capsule(const float o[3], const float d[3], const float p0[3], const float p1[3], float radius,
