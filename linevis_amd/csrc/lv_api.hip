@@ -88,6 +88,7 @@ namespace {
 struct LvDevCountersHost { // must match LvDevCounters in lv_render.hip
     unsigned long long rays, nodes, prims, hits;
     unsigned long long aoRays, aoNodes, aoPrims;
+    unsigned long long aoQueueHead;
     uint32_t fragCounter, aoCount, maxDepthComplexity, depthOrd[2], pad;
 };
 
@@ -132,6 +133,11 @@ lv_ctx* lv_create(int device_ordinal, int* err) {
     }
     lv_ctx* ctx = new lv_ctx();
     ctx->device = device_ordinal;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess && prop.multiProcessorCount > 0)
+            ctx->numCUs = prop.multiProcessorCount;
+    }
     memset(&ctx->stats, 0, sizeof(ctx->stats));
     if (hipStreamCreateWithFlags(&ctx->ownStream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx;
@@ -165,7 +171,7 @@ void lv_destroy(lv_ctx* ctx) {
     for (LvDeviceBuffer* b : {&ctx->points, &ctx->segIdx, &ctx->nodes, &ctx->segs, &ctx->leafSeg, &ctx->tf,
                               &ctx->depthMinMax, &ctx->ao, &ctx->aoGbuf, &ctx->aoList, &ctx->aoSamples, &ctx->counters,
                               &ctx->ppllNodes, &ctx->ppllStart, &ctx->ppllScratch, &ctx->tilesDev, &ctx->outDev,
-                              &ctx->scratchRays})
+                              &ctx->scratchRays, &ctx->stackOverflow})
         lv_buf_free(*b);
     if (ctx->evCreated) {
         for (int i = 0; i < 16; i++) (void)hipEventDestroy(ctx->ev[i]);
@@ -420,7 +426,7 @@ int lv_get_stats(lv_ctx* ctx, lv_stats* out) {
     for (const LvDeviceBuffer* b : {&ctx->points, &ctx->segIdx, &ctx->nodes, &ctx->segs, &ctx->leafSeg, &ctx->tf,
                                     &ctx->depthMinMax, &ctx->ao, &ctx->aoGbuf, &ctx->aoList, &ctx->aoSamples,
                                     &ctx->counters, &ctx->ppllNodes, &ctx->ppllStart, &ctx->ppllScratch, &ctx->tilesDev,
-                                    &ctx->outDev, &ctx->scratchRays})
+                                    &ctx->outDev, &ctx->scratchRays, &ctx->stackOverflow})
         bytes += b->bytes;
     s.device_bytes = bytes;
     *out = s;

@@ -15,7 +15,8 @@
 #define LV_LEAF_BIT 0x80000000u
 #define LV_INVALID 0xFFFFFFFFu
 #define LV_STACK_LDS 32     // per-thread traversal stack entries staged in LDS
-#define LV_STACK_SPILL 64   // further entries in private (scratch) memory; 96 >= max LBVH depth (63 key bits + 32)
+#define LV_STACK_SPILL 64   // further entries in a global overflow slab; 96 >= max LBVH height (63 key bits + 32)
+#define LV_REFILL_THRESHOLD 16 // persistent AO waves fetch new rays once this many lanes are idle
 
 struct f3 { float x, y, z; };
 struct f4 { float x, y, z, w; };
@@ -77,6 +78,7 @@ struct LvSceneDev {
     const float4* tf;           // transfer function texels
     const float* depthMinMax;   // {minDepth, maxDepth}, produced on device by the depth-range kernels
     const float* ao;            // full-viewport AO factors
+    unsigned* stackOverflow;    // null unless the LBVH is higher than LV_STACK_LDS
     uint32_t numSegs;
 };
 

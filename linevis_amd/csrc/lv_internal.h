@@ -43,6 +43,7 @@ struct LvOptions {
 
 struct lv_ctx {
     int device = 0;
+    int numCUs = 256;
     hipStream_t ownStream = nullptr;
     hipStream_t stream = nullptr;
     std::string lastError;
@@ -73,7 +74,7 @@ struct lv_ctx {
     LvDeviceBuffer aoGbuf, aoList, aoSamples; // RTAO wavefront buffers
     LvDeviceBuffer counters;                  // device counters (LvCounters + misc)
     LvDeviceBuffer ppllNodes, ppllStart, ppllScratch;
-    LvDeviceBuffer tilesDev, outDev, scratchRays;
+    LvDeviceBuffer tilesDev, outDev, scratchRays, stackOverflow;
     std::vector<uint32_t> tilesHost;          // staging copy: caller's tile list is borrowed for the call only
     uint64_t ppllPoolNodes = 0;
 

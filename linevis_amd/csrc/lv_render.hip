@@ -4,8 +4,8 @@
 //   k_render_rt         TubeRayTracing.RayGen/.Miss (+ driver traversal, IntersectionTube, ClosestHitTubeAnalytic)
 //                       Data/Shaders/Renderers/RayTracing/TubeRayTracing.glsl:61-82,198-298
 //   k_ao_primary        VulkanRayTracedAmbientOcclusion.Compute, primary-ray half (glsl:178-281) + wave compaction
-//   k_ao_rays           .. sample loop (glsl:288-306) as one thread per AO ray, fused per-pixel reduction
-//   k_ao_reduce         .. accumulate/store (glsl:309-319) for sample counts that do not tile a workgroup
+//   k_ao_rays           .. sample loop (glsl:288-306) as persistent waves pulling AO rays from a global queue
+//   k_ao_reduce         .. per-pixel sum in sample order + accumulate/store (glsl:309-319)
 //   k_ppll_gather       tube rasterisation + gatherFragment, Data/Shaders/Renderers/PPLL/LinkedListGather.glsl:33-72
 //   k_ppll_resolve      LinkedListResolve.Fragment + frontToBackPQ, LinkedListResolve.glsl:57-105, LinkedListSort.glsl:177-238
 //   k_depth_minmax      ComputeDepthValues.Compute + MinMaxReduce.Compute, Data/Shaders/DepthCues/*.glsl
@@ -23,6 +23,7 @@ namespace {
 struct LvDevCounters {
     unsigned long long rays, nodes, prims, hits;
     unsigned long long aoRays, aoNodes, aoPrims; // share of k_ao_rays
+    unsigned long long aoQueueHead;              // next AO ray index handed to the persistent waves
     uint32_t fragCounter;
     uint32_t aoCount;
     uint32_t maxDepthComplexity;
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(LV_BLOCK) void k_render_rt(const LvUniforms U, cons
             float tMin = 0.0001f;
             const float tMax = 1000.0f;
             for (uint32_t hitIdx = 0; hitIdx < U.maxDepthComplexity; hitIdx++) {
-                LvHit h = lv_trace_closest<STATS, false>(S, U.radius, capped, o, d, tMin, tMax, &s_stack[threadIdx.x], cnt);
+                LvHit h = lv_trace_closest<STATS, false>(S, U.radius, capped, o, d, tMin, tMax, lv_stack_mem(s_stack, S.stackOverflow), cnt);
                 f4 hc;
                 float payloadHitT;
                 if (h.found) {
@@ -160,7 +161,7 @@ __global__ __launch_bounds__(LV_BLOCK) void k_ao_primary(const LvUniforms U, con
         f3 o, d;
         lv_primary_ray(U, px.x, px.y, xix, xiy, o, d);
         LvHit h = lv_trace_closest<STATS, false>(S, U.radius, U.useCappedTubes != 0, o, d, 0.0001f, 1000.0f,
-                                                 &s_stack[threadIdx.x], cnt);
+                                                 lv_stack_mem(s_stack, S.stackOverflow), cnt);
         if (h.found) {
             hasHit = true;
             const float4 ra = S.segs[2 * h.leaf], rb = S.segs[2 * h.leaf + 1];
@@ -206,58 +207,113 @@ __global__ __launch_bounds__(LV_BLOCK) void k_ao_primary(const LvUniforms U, con
     if (STATS) lv_flush_counters(cnt, dc);
 }
 
-// One thread per AO ray: ray r belongs to compacted pixel r / spp, sample r % spp (with spp = 64 a wavefront is
-// exactly one pixel's hemisphere).  FUSED: spp divides the workgroup size, so the per-pixel sum (in sample order,
-// like the reference's loop) is finished inside the workgroup through LDS.
-template <bool STATS, bool ANY_HIT, bool FUSED>
+// AO sample rays as a PERSISTENT, dynamically refilled wavefront kernel.  AO ray r belongs to compacted pixel r / spp,
+// sample r % spp (with spp = 64 the first fill of a wave is exactly one pixel's hemisphere).  Rays of one wave finish
+// after very different numbers of node steps (measured: 17 % mean lane utilisation with one ray per thread), so each
+// lane owns a ray only while it is alive: once LV_REFILL_THRESHOLD lanes are idle the wave pulls that many new ray
+// indices from a global queue head with ONE atomic (ballot + prefix popcount), sets them up together, and continues
+// traversing with all lanes busy.  Results go to samples[r]; k_ao_reduce sums them per pixel in sample order.
+template <bool STATS, bool ANY_HIT>
 __global__ __launch_bounds__(LV_BLOCK) void k_ao_rays(const LvUniforms U, const LvSceneDev S,
-                                                      const float4* __restrict__ gbuf, float* __restrict__ ao,
-                                                      float* __restrict__ samples, LvDevCounters* dc) {
+                                                      const float4* __restrict__ gbuf, float* __restrict__ samples,
+                                                      LvDevCounters* dc) {
     __shared__ unsigned s_stack[LV_STACK_LDS * LV_BLOCK];
-    __shared__ float s_occ[LV_BLOCK];
     const uint32_t spp = U.aoSamplesPerFrame;
     const unsigned long long total = (unsigned long long)(dc->aoCount) * spp;
-    const unsigned long long r0 = (unsigned long long)(blockIdx.x) * LV_BLOCK;
-    if (r0 >= total) return;
-    const unsigned long long r = r0 + threadIdx.x;
-    const bool valid = r < total;
+    const bool capped = U.useCappedTubes != 0;
+    const float radius = U.radius;
+    const unsigned lane = lv_lane();
+    const LvStackMem sm = lv_stack_mem(s_stack, S.stackOverflow);
+    LvStack st;
+    st.init(sm.lds, sm.ovf, sm.ovfStride);
     LvCounters cnt = {0, 0, 0, 0};
-    float occ = 1.0f;
-    if (valid) {
-        const uint32_t slot = uint32_t(r / spp), s = uint32_t(r % spp);
-        const float4 g0 = gbuf[3 * size_t(slot) + 0], g1 = gbuf[3 * size_t(slot) + 1], g2 = gbuf[3 * size_t(slot) + 2];
-        const uint32_t pix = __float_as_uint(g1.w);
-        const f3 pos = mk3(g0.x, g0.y, g0.z), T = mk3(g1.x, g1.y, g1.z), N = mk3(g2.x, g2.y, g2.z);
-        const f3 B = cross3(N, T);
-        uint32_t seed = lv_tea(pix, U.aoFrameNumber * spp + s);
-        const float xi0 = lv_rnd(seed), xi1 = lv_rnd(seed);
-        float sn, cs;
-        lv_sincos2pi(xi1, sn, cs);
-        const float rr = sqrtf(1.0f - xi0 * xi0);
-        const f3 smp = mk3(cs * rr, sn * rr, xi0);
-        const f3 dirU = mk3((T.x * smp.x + B.x * smp.y) + N.x * smp.z, (T.y * smp.x + B.y * smp.y) + N.y * smp.z,
-                            (T.z * smp.x + B.z * smp.y) + N.z * smp.z);
-        const f3 rd = norm3(dirU);
-        const f3 ro = pos + rd * g0.w;
-        LvHit h = lv_trace_closest<STATS, ANY_HIT>(S, U.radius, U.useCappedTubes != 0, ro, rd, 0.0f, U.aoRadius,
-                                                   &s_stack[threadIdx.x], cnt);
-        if (h.found) occ = U.aoUseDistance ? h.t / U.aoRadius : 0.0f;
-        if (!FUSED) samples[r] = occ;
-    }
-    if (FUSED) {
-        s_occ[threadIdx.x] = occ;
-        __syncthreads();
-        const uint32_t pixelsPerBlock = LV_BLOCK / spp;
-        if (threadIdx.x < pixelsPerBlock) {
-            const unsigned long long rp = r0 + (unsigned long long)(threadIdx.x) * spp;
-            if (rp < total) {
-                float aoFactor = 0.0f;
-                for (uint32_t s = 0; s < spp; s++) aoFactor += s_occ[threadIdx.x * spp + s];
-                aoFactor /= float(spp);
-                const uint32_t pix = __float_as_uint(gbuf[3 * size_t(rp / spp) + 1].w);
-                if (U.aoFrameNumber != 0) aoFactor = mixf(ao[pix], aoFactor, 1.0f / float(U.aoFrameNumber + 1));
-                ao[pix] = aoFactor;
+
+    // per-lane ray state
+    bool hasRay = false, exhausted = (S.numSegs == 0) || (total == 0);
+    unsigned long long r = 0;
+    f3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), inv = mk3(0, 0, 0);
+    float best = 0.0f;
+    uint32_t bestLeaf = LV_INVALID;
+    bool found = false;
+    unsigned cur = LV_INVALID, pending = LV_INVALID;
+
+    while (true) {
+        // ---- refill idle lanes from the global queue (whole wave is converged here)
+        const unsigned long long idleMask = __ballot(!hasRay && !exhausted);
+        const unsigned long long busyMask = __ballot(hasRay);
+        if (idleMask == 0 && busyMask == 0) break;
+        const int nIdle = __popcll(idleMask);
+        if (nIdle >= LV_REFILL_THRESHOLD || busyMask == 0) {
+            if (!hasRay && !exhausted) {
+                const int leader = __ffsll((long long)idleMask) - 1;
+                unsigned long long base = 0;
+                if (int(lane) == leader) base = atomicAdd(&dc->aoQueueHead, (unsigned long long)nIdle);
+                base = __shfl(base, leader, 64);
+                r = base + (unsigned long long)__popcll(idleMask & ((1ull << lane) - 1ull));
+                if (r < total) {
+                    const uint32_t slot = uint32_t(r / spp), smpIdx = uint32_t(r % spp);
+                    const float4 g0 = gbuf[3 * size_t(slot) + 0], g1 = gbuf[3 * size_t(slot) + 1],
+                                 g2 = gbuf[3 * size_t(slot) + 2];
+                    const uint32_t pix = __float_as_uint(g1.w);
+                    const f3 pos = mk3(g0.x, g0.y, g0.z), T = mk3(g1.x, g1.y, g1.z), N = mk3(g2.x, g2.y, g2.z);
+                    const f3 B = cross3(N, T);
+                    uint32_t seed = lv_tea(pix, U.aoFrameNumber * spp + smpIdx);
+                    const float xi0 = lv_rnd(seed), xi1 = lv_rnd(seed);
+                    float sn, cs;
+                    lv_sincos2pi(xi1, sn, cs); // sampleHemisphere, glsl:151-156
+                    const float rr = sqrtf(1.0f - xi0 * xi0);
+                    const f3 smp = mk3(cs * rr, sn * rr, xi0);
+                    const f3 dirU = mk3((T.x * smp.x + B.x * smp.y) + N.x * smp.z, (T.y * smp.x + B.y * smp.y) + N.y * smp.z,
+                                        (T.z * smp.x + B.z * smp.y) + N.z * smp.z);
+                    d = norm3(dirU);
+                    o = pos + d * g0.w;
+                    inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                    best = U.aoRadius;
+                    bestLeaf = LV_INVALID;
+                    found = false;
+                    cur = 0;
+                    pending = LV_INVALID;
+                    st.sp = 0;
+                    hasRay = true;
+                    if (STATS) cnt.rays++;
+                } else {
+                    exhausted = true;
+                }
             }
+        }
+        // ---- node loop: descend, park the first leaf, leave when every descending lane has one
+        while (!(cur & LV_LEAF_BIT)) {
+            cur = lv_node_step<STATS>(S, cur, o, inv, 0.0f, best, st, cnt);
+            if ((cur & LV_LEAF_BIT) && cur != LV_INVALID && pending == LV_INVALID) {
+                pending = cur;
+                cur = lv_pop_or_done(st);
+            }
+            if (!__any(pending == LV_INVALID)) break;
+        }
+        // ---- leaf loop: closest hit in [0, aoRadius] (traceAoRay, glsl:158-175), ties -> lowest segment index
+        while (pending != LV_INVALID) {
+            const unsigned leaf = pending & ~LV_LEAF_BIT;
+            const float4 a = S.segs[2 * leaf], b = S.segs[2 * leaf + 1];
+            if (STATS) cnt.prims++;
+            float t; int kind;
+            if (lv_intersect_capsule(o, d, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), radius, capped, t, kind)) {
+                if (t >= 0.0f && t <= U.aoRadius) {
+                    bool take = !found || t < best;
+                    if (!take && t == best) take = S.leafSeg[leaf] < S.leafSeg[bestLeaf];
+                    if (take) { found = true; best = t; bestLeaf = leaf; }
+                }
+            }
+            pending = LV_INVALID;
+            if ((cur & LV_LEAF_BIT) && cur != LV_INVALID) { pending = cur; cur = lv_pop_or_done(st); }
+        }
+        // ---- retire finished rays
+        if (hasRay && ((cur == LV_INVALID && pending == LV_INVALID) || (ANY_HIT && found))) {
+            float occ = 1.0f;
+            if (found) occ = U.aoUseDistance ? best / U.aoRadius : 0.0f;
+            samples[r] = occ;
+            hasRay = false;
+            cur = LV_INVALID;
+            pending = LV_INVALID;
         }
     }
     if (STATS) lv_flush_counters(cnt, dc, true);
@@ -297,7 +353,7 @@ __global__ __launch_bounds__(LV_BLOCK) void k_ppll_gather(const LvUniforms U, co
         f3 o, d;
         lv_primary_ray(U, px.x, px.y, 0.5f, 0.5f, o, d);
         uint32_t head = 0xFFFFFFFFu;
-        lv_trace_all<STATS>(S, U.radius, U.useCappedTubes != 0, o, d, 0.0001f, 1000.0f, &s_stack[threadIdx.x], cnt,
+        lv_trace_all<STATS>(S, U.radius, U.useCappedTubes != 0, o, d, 0.0001f, 1000.0f, lv_stack_mem(s_stack, S.stackOverflow), cnt,
                             [&](uint32_t leaf, float t, int kind) {
             LvHit h; h.t = t; h.leaf = leaf; h.kind = kind; h.found = true;
             float hitT;
@@ -479,7 +535,7 @@ __global__ __launch_bounds__(LV_BLOCK) void k_trace_rays(const LvSceneDev S, flo
     LvCounters cnt = {0, 0, 0, 0};
     f3 o = mk3(org[3 * i], org[3 * i + 1], org[3 * i + 2]);
     f3 d = mk3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]);
-    LvHit h = lv_trace_closest<false, false>(S, radius, capped != 0, o, d, tMin, tMax, &s_stack[threadIdx.x], cnt);
+    LvHit h = lv_trace_closest<false, false>(S, radius, capped != 0, o, d, tMin, tMax, lv_stack_mem(s_stack, S.stackOverflow), cnt);
     outT[i] = h.found ? h.t : tMax;
     outSeg[i] = h.found ? S.leafSeg[h.leaf] : 0xFFFFFFFFu;
     outKind[i] = h.found ? uint32_t(h.kind) : 0u;
@@ -503,6 +559,7 @@ LvSceneDev sceneDev(const lv_ctx* ctx) {
     S.tf = (const float4*)ctx->tf.ptr;
     S.depthMinMax = (const float*)ctx->depthMinMax.ptr;
     S.ao = (const float*)ctx->ao.ptr;
+    S.stackOverflow = nullptr;
     S.numSegs = ctx->numSegs;
     return S;
 }
@@ -586,43 +643,54 @@ int lv_frame_depth_range(lv_ctx* ctx) {
     return LV_OK;
 }
 
-static int lv_run_ao(lv_ctx* ctx, LvUniforms& U, const LvSceneDev& S, const LvTiles& T, uint32_t gridTiles,
+// the global part of the traversal stacks: only when the tree is higher than the LDS-staged part
+static int lv_prepare_overflow(lv_ctx* ctx, LvSceneDev& S, uint64_t gridBlocks) {
+    S.stackOverflow = nullptr;
+    if (ctx->bvhDepth <= LV_STACK_LDS) return LV_OK;
+    const uint64_t extra = ctx->bvhDepth - LV_STACK_LDS;
+    int rc = lv_buf_reserve(ctx, ctx->stackOverflow, size_t(gridBlocks) * LV_BLOCK * extra * 4);
+    if (rc) return rc;
+    S.stackOverflow = (unsigned*)ctx->stackOverflow.ptr;
+    return LV_OK;
+}
+
+static int lv_run_ao(lv_ctx* ctx, LvUniforms& U, LvSceneDev& S, const LvTiles& T, uint32_t gridTiles,
                      uint64_t maxPixels) {
     hipStream_t st = ctx->stream;
     LvDevCounters* dc = (LvDevCounters*)ctx->counters.ptr;
     const uint32_t spp = U.aoSamplesPerFrame;
-    const bool fused = spp <= LV_BLOCK && (LV_BLOCK % spp) == 0;
     int rc;
     if ((rc = lv_buf_reserve(ctx, ctx->aoGbuf, size_t(maxPixels) * 48))) return rc;
-    if (!fused && (rc = lv_buf_reserve(ctx, ctx->aoSamples, size_t(maxPixels) * spp * 4))) return rc;
+    if ((rc = lv_buf_reserve(ctx, ctx->aoSamples, size_t(maxPixels) * spp * 4))) return rc;
     const uint64_t maxRays = maxPixels * spp;
+    // persistent grid: enough workgroups to fill every CU at the kernel's LDS-limited residency (5 x 32 KiB)
+    uint64_t gridRays = uint64_t(ctx->numCUs) * 5u;
+    if (gridRays > (maxRays + LV_BLOCK - 1) / LV_BLOCK) gridRays = (maxRays + LV_BLOCK - 1) / LV_BLOCK;
+    if (gridRays == 0) gridRays = 1;
+    const uint64_t gridMax = gridRays > gridTiles ? gridRays : gridTiles;
+    if ((rc = lv_prepare_overflow(ctx, S, gridMax))) return rc;
     const bool stats = ctx->opt.collectStats;
     for (uint32_t iter = 0; iter < ctx->opt.aoIterations; iter++) {
         U.aoFrameNumber = iter; // rtaoRenderPass->setFrameNumber(accumulatedFramesCounter), VulkanRayTracedAmbientOcclusion.cpp:92
         LV_HIP(ctx, hipMemsetAsync(&dc->aoCount, 0, 4, st));
+        LV_HIP(ctx, hipMemsetAsync(&dc->aoQueueHead, 0, 8, st));
         if (stats)
             LV_TIMED_LAUNCH(ctx, LV_KERNEL_AO_PRIMARY, (k_ao_primary<true><<<gridTiles, LV_BLOCK, 0, st>>>(
                     U, S, T, (float*)ctx->ao.ptr, (float4*)ctx->aoGbuf.ptr, dc)));
         else
             LV_TIMED_LAUNCH(ctx, LV_KERNEL_AO_PRIMARY, (k_ao_primary<false><<<gridTiles, LV_BLOCK, 0, st>>>(
                     U, S, T, (float*)ctx->ao.ptr, (float4*)ctx->aoGbuf.ptr, dc)));
-        const uint32_t grid = nblocks(maxRays);
+        const uint32_t grid = uint32_t(gridRays);
         const float4* g = (const float4*)ctx->aoGbuf.ptr;
         float* ao = (float*)ctx->ao.ptr;
         float* smp = (float*)ctx->aoSamples.ptr;
-#define LV_LAUNCH_AO(ST, AH, FU) \
-    LV_TIMED_LAUNCH(ctx, LV_KERNEL_AO_RAYS, (k_ao_rays<ST, AH, FU><<<grid, LV_BLOCK, 0, st>>>(U, S, g, ao, smp, dc)))
+#define LV_LAUNCH_AO(ST, AH) \
+    LV_TIMED_LAUNCH(ctx, LV_KERNEL_AO_RAYS, (k_ao_rays<ST, AH><<<grid, LV_BLOCK, 0, st>>>(U, S, g, smp, dc)))
         const bool anyHit = !U.aoUseDistance;
-        if (stats) {
-            if (anyHit) { if (fused) LV_LAUNCH_AO(true, true, true); else LV_LAUNCH_AO(true, true, false); }
-            else { if (fused) LV_LAUNCH_AO(true, false, true); else LV_LAUNCH_AO(true, false, false); }
-        } else {
-            if (anyHit) { if (fused) LV_LAUNCH_AO(false, true, true); else LV_LAUNCH_AO(false, true, false); }
-            else { if (fused) LV_LAUNCH_AO(false, false, true); else LV_LAUNCH_AO(false, false, false); }
-        }
+        if (stats) { if (anyHit) LV_LAUNCH_AO(true, true); else LV_LAUNCH_AO(true, false); }
+        else { if (anyHit) LV_LAUNCH_AO(false, true); else LV_LAUNCH_AO(false, false); }
 #undef LV_LAUNCH_AO
-        if (!fused)
-            k_ao_reduce<<<nblocks(maxPixels), LV_BLOCK, 0, st>>>(U, g, smp, ao, dc);
+        k_ao_reduce<<<nblocks(maxPixels), LV_BLOCK, 0, st>>>(U, g, smp, ao, dc);
     }
     LV_HIP(ctx, hipGetLastError());
     return LV_OK;
@@ -668,6 +736,7 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
     const uint64_t maxPixels = uint64_t(numTiles) * tileW * tileH;
     const bool stats = ctx->opt.collectStats;
     LvSceneDev S = sceneDev(ctx);
+    if ((rc = lv_prepare_overflow(ctx, S, gridTiles))) return rc;
 
     // LineRenderer::renderBase: depth range, LineRenderer.cpp:248-256
     LV_HIP(ctx, hipEventRecord(ctx->ev[4], st));
@@ -753,6 +822,7 @@ int lv_frame_trace_rays(lv_ctx* ctx, const float* o, const float* d, float tMin,
     LV_HIP(ctx, hipMemcpyAsync(dO, o, rb, hipMemcpyHostToDevice, st));
     LV_HIP(ctx, hipMemcpyAsync(dD, d, rb, hipMemcpyHostToDevice, st));
     LvSceneDev S = sceneDev(ctx);
+    if ((rc = lv_prepare_overflow(ctx, S, nblocks(n)))) return rc;
     k_trace_rays<<<nblocks(n), LV_BLOCK, 0, st>>>(S, ctx->opt.lineWidth * 0.5f, ctx->opt.useCappedTubes, dO, dD, tMin, tMax,
                                                   n, dT, dS, dK);
     LV_HIP(ctx, hipGetLastError());

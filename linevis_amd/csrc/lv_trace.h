@@ -79,21 +79,42 @@ __device__ __forceinline__ bool lv_intersect_capsule(f3 o, f3 d, f3 p0, f3 p1, f
     return has;
 }
 
-// ---------------------------------------------------------------- traversal stack: LDS-staged, scratch overflow
+// ---------------------------------------------------------------- traversal stack: LDS-staged, HBM overflow
+// Entry i of a thread lives at lds[i * LV_BLOCK] (conflict-free ds_read/write_b32 across the wave).  An LBVH over
+// N segments is usually ~log2(N)+10 deep, so LV_STACK_LDS = 32 entries cover the common case entirely in LDS; deeper
+// trees (up to 63 key bits + 32 duplicate-index bits) continue in a per-thread column of a global overflow slab that is
+// only allocated when the built tree is that deep.  All members are scalars so the struct lives in registers.
 struct LvStack {
-    unsigned* lds;                      // &s_stack[threadIdx], entries strided by LV_BLOCK (conflict-free)
-    unsigned spill[LV_STACK_SPILL];
+    unsigned* lds;       // &s_stack[threadIdx.x]
+    unsigned* ovf;       // &overflow[global thread], entries strided by ovfStride; may be null if height <= LV_STACK_LDS
+    unsigned ovfStride;
     int sp;
-    __device__ __forceinline__ void init(unsigned* base) { lds = base; sp = 0; }
+    __device__ __forceinline__ void init(unsigned* ldsBase, unsigned* ovfBase, unsigned stride) {
+        lds = ldsBase; ovf = ovfBase; ovfStride = stride; sp = 0;
+    }
     __device__ __forceinline__ void push(unsigned v) {
-        if (sp < LV_STACK_LDS) lds[sp * LV_BLOCK] = v; else spill[sp - LV_STACK_LDS] = v;
+        if (sp < LV_STACK_LDS) lds[sp * LV_BLOCK] = v;
+        else ovf[size_t(sp - LV_STACK_LDS) * ovfStride] = v;
         sp++;
     }
     __device__ __forceinline__ unsigned pop() {
         sp--;
-        return sp < LV_STACK_LDS ? lds[sp * LV_BLOCK] : spill[sp - LV_STACK_LDS];
+        return sp < LV_STACK_LDS ? lds[sp * LV_BLOCK] : ovf[size_t(sp - LV_STACK_LDS) * ovfStride];
     }
 };
+// stack memory handed to the traversal routines by a kernel
+struct LvStackMem {
+    unsigned* lds;
+    unsigned* ovf;
+    unsigned ovfStride;
+};
+__device__ __forceinline__ LvStackMem lv_stack_mem(unsigned* sStack, unsigned* ovfSlab) {
+    LvStackMem m;
+    m.lds = sStack + threadIdx.x;
+    m.ovfStride = gridDim.x * LV_BLOCK;
+    m.ovf = ovfSlab ? ovfSlab + (size_t(blockIdx.x) * LV_BLOCK + threadIdx.x) : nullptr;
+    return m;
+}
 
 // slab test of one child box against the ray; conservative acceptance (boxes are padded at build time)
 __device__ __forceinline__ bool lv_slab(float bx0, float by0, float bz0, float bx1, float by1, float bz1, f3 o, f3 inv,
@@ -114,62 +135,75 @@ struct LvHit {
     bool found;
 };
 
+// Traversal is organised as "while-while" with postponed leaves (Aila & Laine, "Understanding the Efficiency of Ray
+// Traversal on GPUs", HPG 2009) for wave64: a lane that reaches a leaf parks it in `pending` and keeps descending;
+// the wave leaves the node loop only when every still-descending lane has parked a leaf, so the expensive capsule test
+// (8 IEEE divisions + 4 square roots) runs with most lanes active instead of once per node step for a handful of lanes.
+// Child references: index | LV_LEAF_BIT for leaves, LV_INVALID (which has the leaf bit set) = finished.
+__device__ __forceinline__ unsigned lv_pop_or_done(LvStack& st) { return st.sp == 0 ? LV_INVALID : st.pop(); }
+
+// one node step: fetch the 64-byte node, slab-test both child boxes, pick the next reference (near child first)
+template <bool STATS>
+__device__ __forceinline__ unsigned lv_node_step(const LvSceneDev& S, unsigned node, f3 o, f3 inv, float tMin, float tMax,
+                                                 LvStack& st, LvCounters& cnt) {
+    const float4 q0 = S.nodes[4 * node + 0];
+    const float4 q1 = S.nodes[4 * node + 1];
+    const float4 q2 = S.nodes[4 * node + 2];
+    const float4 q3 = S.nodes[4 * node + 3];
+    if (STATS) cnt.nodes++;
+    const unsigned c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
+    float tn0, tn1;
+    const bool hit0 = lv_slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, inv, tMin, tMax, tn0);
+    const bool hit1 = lv_slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, inv, tMin, tMax, tn1) && (c1 != LV_INVALID);
+    if (hit0 && hit1) {
+        const bool swap = tn1 < tn0;
+        st.push(swap ? c0 : c1);
+        return swap ? c1 : c0;
+    }
+    if (hit0) return c0;
+    if (hit1) return c1;
+    return lv_pop_or_done(st);
+}
+
 // Closest hit with reportIntersectionEXT semantics: accepted iff tMin <= t <= tMax; ties -> lowest original
 // segment index.  ANY_HIT: return at the first accepted hit (gl_RayFlagsTerminateOnFirstHitEXT).
 template <bool STATS, bool ANY_HIT>
 __device__ __forceinline__ LvHit lv_trace_closest(const LvSceneDev& S, float radius, bool capped, f3 o, f3 d, float tMin,
-                                                  float tMax, unsigned* ldsStack, LvCounters& cnt) {
+                                                  float tMax, const LvStackMem& sm, LvCounters& cnt) {
     LvHit h;
     h.t = tMax; h.leaf = LV_INVALID; h.kind = 0; h.found = false;
     if (STATS) cnt.rays++;
     if (S.numSegs == 0) return h;
     const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     LvStack st;
-    st.init(ldsStack);
-    unsigned node = 0;
-    while (true) {
-        const float4 q0 = S.nodes[4 * node + 0];
-        const float4 q1 = S.nodes[4 * node + 1];
-        const float4 q2 = S.nodes[4 * node + 2];
-        const float4 q3 = S.nodes[4 * node + 3];
-        if (STATS) cnt.nodes++;
-        const unsigned c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
-        float tn0, tn1;
-        bool hit0 = lv_slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, inv, tMin, h.t, tn0);
-        bool hit1 = lv_slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, inv, tMin, h.t, tn1) && (c1 != LV_INVALID);
-#pragma unroll
-        for (int k = 0; k < 2; k++) {
-            const unsigned c = k == 0 ? c0 : c1;
-            const bool hk = k == 0 ? hit0 : hit1;
-            if (hk && (c & LV_LEAF_BIT)) {
-                const unsigned leaf = c & ~LV_LEAF_BIT;
-                const float4 a = S.segs[2 * leaf], b = S.segs[2 * leaf + 1];
-                if (STATS) cnt.prims++;
-                float t; int kind;
-                if (lv_intersect_capsule(o, d, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), radius, capped, t, kind)) {
-                    if (t >= tMin && t <= tMax) {
-                        bool take = !h.found || t < h.t;
-                        if (!take && t == h.t) take = S.leafSeg[leaf] < S.leafSeg[h.leaf];
-                        if (take) { h.found = true; h.t = t; h.leaf = leaf; h.kind = kind; }
-                    }
+    st.init(sm.lds, sm.ovf, sm.ovfStride);
+    unsigned cur = 0;            // root
+    unsigned pending = LV_INVALID;
+    while (cur != LV_INVALID || pending != LV_INVALID) {
+        while (!(cur & LV_LEAF_BIT)) {
+            cur = lv_node_step<STATS>(S, cur, o, inv, tMin, h.t, st, cnt);
+            if ((cur & LV_LEAF_BIT) && cur != LV_INVALID && pending == LV_INVALID) {
+                pending = cur;                       // first leaf: park it and keep descending
+                cur = lv_pop_or_done(st);
+            }
+            if (!__any(pending == LV_INVALID)) break; // every descending lane has a leaf to test
+        }
+        while (pending != LV_INVALID) {
+            const unsigned leaf = pending & ~LV_LEAF_BIT;
+            const float4 a = S.segs[2 * leaf], b = S.segs[2 * leaf + 1];
+            if (STATS) cnt.prims++;
+            float t; int kind;
+            if (lv_intersect_capsule(o, d, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), radius, capped, t, kind)) {
+                if (t >= tMin && t <= tMax) {
+                    bool take = !h.found || t < h.t;
+                    if (!take && t == h.t) take = S.leafSeg[leaf] < S.leafSeg[h.leaf];
+                    if (take) { h.found = true; h.t = t; h.leaf = leaf; h.kind = kind; }
                 }
             }
+            pending = LV_INVALID;
+            if ((cur & LV_LEAF_BIT) && cur != LV_INVALID) { pending = cur; cur = lv_pop_or_done(st); }
         }
         if (ANY_HIT && h.found) return h;
-        const bool in0 = hit0 && !(c0 & LV_LEAF_BIT);
-        const bool in1 = hit1 && !(c1 & LV_LEAF_BIT);
-        if (in0 && in1) {
-            const bool swap = tn1 < tn0;
-            st.push(swap ? c0 : c1);
-            node = swap ? c1 : c0;
-        } else if (in0) {
-            node = c0;
-        } else if (in1) {
-            node = c1;
-        } else {
-            if (st.sp == 0) break;
-            node = st.pop();
-        }
     }
     return h;
 }
@@ -177,49 +211,33 @@ __device__ __forceinline__ LvHit lv_trace_closest(const LvSceneDev& S, float rad
 // All capsule entry hits in [tMin, tMax] (PPLL fragment generation); f(leaf, t, kind) per hit.
 template <bool STATS, typename F>
 __device__ __forceinline__ void lv_trace_all(const LvSceneDev& S, float radius, bool capped, f3 o, f3 d, float tMin,
-                                             float tMax, unsigned* ldsStack, LvCounters& cnt, F&& f) {
+                                             float tMax, const LvStackMem& sm, LvCounters& cnt, F&& f) {
     if (STATS) cnt.rays++;
     if (S.numSegs == 0) return;
     const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     LvStack st;
-    st.init(ldsStack);
-    unsigned node = 0;
-    while (true) {
-        const float4 q0 = S.nodes[4 * node + 0];
-        const float4 q1 = S.nodes[4 * node + 1];
-        const float4 q2 = S.nodes[4 * node + 2];
-        const float4 q3 = S.nodes[4 * node + 3];
-        if (STATS) cnt.nodes++;
-        const unsigned c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
-        float tn0, tn1;
-        bool hit0 = lv_slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, inv, tMin, tMax, tn0);
-        bool hit1 = lv_slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, inv, tMin, tMax, tn1) && (c1 != LV_INVALID);
-#pragma unroll
-        for (int k = 0; k < 2; k++) {
-            const unsigned c = k == 0 ? c0 : c1;
-            const bool hk = k == 0 ? hit0 : hit1;
-            if (hk && (c & LV_LEAF_BIT)) {
-                const unsigned leaf = c & ~LV_LEAF_BIT;
-                const float4 a = S.segs[2 * leaf], b = S.segs[2 * leaf + 1];
-                if (STATS) cnt.prims++;
-                float t; int kind;
-                if (lv_intersect_capsule(o, d, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), radius, capped, t, kind)) {
-                    if (t >= tMin && t <= tMax) f(leaf, t, kind);
-                }
+    st.init(sm.lds, sm.ovf, sm.ovfStride);
+    unsigned cur = 0;
+    unsigned pending = LV_INVALID;
+    while (cur != LV_INVALID || pending != LV_INVALID) {
+        while (!(cur & LV_LEAF_BIT)) {
+            cur = lv_node_step<STATS>(S, cur, o, inv, tMin, tMax, st, cnt);
+            if ((cur & LV_LEAF_BIT) && cur != LV_INVALID && pending == LV_INVALID) {
+                pending = cur;
+                cur = lv_pop_or_done(st);
             }
+            if (!__any(pending == LV_INVALID)) break;
         }
-        const bool in0 = hit0 && !(c0 & LV_LEAF_BIT);
-        const bool in1 = hit1 && !(c1 & LV_LEAF_BIT);
-        if (in0 && in1) {
-            st.push(c1);
-            node = c0;
-        } else if (in0) {
-            node = c0;
-        } else if (in1) {
-            node = c1;
-        } else {
-            if (st.sp == 0) break;
-            node = st.pop();
+        while (pending != LV_INVALID) {
+            const unsigned leaf = pending & ~LV_LEAF_BIT;
+            const float4 a = S.segs[2 * leaf], b = S.segs[2 * leaf + 1];
+            if (STATS) cnt.prims++;
+            float t; int kind;
+            if (lv_intersect_capsule(o, d, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), radius, capped, t, kind)) {
+                if (t >= tMin && t <= tMax) f(leaf, t, kind);
+            }
+            pending = LV_INVALID;
+            if ((cur & LV_LEAF_BIT) && cur != LV_INVALID) { pending = cur; cur = lv_pop_or_done(st); }
         }
     }
 }

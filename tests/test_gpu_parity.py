@@ -260,6 +260,45 @@ def test_duplicate_segments_and_fat_tubes(hip_lib):
     assert s[0] == 0     # all 64 tie; lowest index wins
 
 
+def test_deep_lbvh_uses_stack_overflow_slab(hip_lib):
+    """Segments clustered at geometrically shrinking scales give a Morton-split tree far higher than the 32 stack
+    entries staged in LDS; the traversal continues in the global overflow slab."""
+    rng = np.random.default_rng(4)
+    pts, seg = [], []
+    # segment k sits on axis k % 3 at distance 2^-(k // 3 + 1): its Morton key is the only one with bit k set first,
+    # so every split peels off a single leaf and the tree degenerates into a ~50-level chain
+    for k in range(54):
+        a = np.zeros(3)
+        a[k % 3] = 0.9 * 2.0 ** (-(k // 3 + 1))
+        b = a.copy()
+        b[(k + 1) % 3] += 0.3 * 2.0 ** (-(k // 3 + 1))
+        seg.append([len(pts), len(pts) + 1])
+        pts += [a, b]
+    P = np.zeros(len(pts), dtype=lvo.LINE_POINT_DTYPE)
+    P["linePosition"] = np.array(pts, dtype=np.float32)
+    P["lineTangent"] = [1, 0, 0]
+    P["lineNormal"] = [0, 1, 0]
+    P["lineAttribute"] = np.linspace(0, 1, len(pts))
+    c = Case(P, np.array(seg, np.uint32), tfm.standard_transparent(), 96, 96, 0.0004, camera_pos=(0.3, 0.3, 0.9), **RTAO,
+             ambient_occlusion_iterations=1, ambient_occlusion_samples_per_frame=8)
+    ctx = c.hip_context()
+    ctx.build_accel()
+    assert ctx.stats().bvh_depth > 32
+    for mode in (11, 2):
+        img = ctx.render(mode)
+        ref, ao_ref = c.oracle_render(mode)
+        assert np.array_equal(bits(ctx.get_ao()), bits(ao_ref))
+        assert max_lsb_diff(img, ref) <= LSB_TOL
+    tgt = np.array(pts, dtype=np.float64)[rng.integers(0, len(pts), 5000)] * (1.0 + 1e-3 * rng.normal(size=(5000, 3)))
+    o = rng.uniform(-0.1, 0.6, (5000, 3)).astype(np.float32)
+    d = (tgt - o).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    a = ctx.trace_rays(o, d, 0.0, 10.0)
+    assert (a[1] != 0xFFFFFFFF).sum() > 300
+    b = c.oracle_scene().trace_rays(o, d, 0.0, 10.0, c.line_width)
+    assert np.array_equal(bits(a[0]), bits(b[0])) and np.array_equal(a[1], b[1])
+
+
 def test_tile_list_equals_full_frame(hip_lib):
     import torch
     c = small_case(width=150, height=90, seed=3, num_samples_per_frame=2, **RTAO, ambient_occlusion_iterations=1,
