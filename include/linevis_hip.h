@@ -79,6 +79,10 @@ typedef struct lv_stats {
     uint64_t ao_rays_traced;
     uint64_t ao_nodes_visited;
     uint64_t ao_prims_tested;
+    /* k_ao_rays lane-utilisation diagnostics (collect_stats only): wave-level iterations and the sum of active lanes
+     * of the {refill/setup, node, leaf} phases: utilisation = lanes / (64 * iterations). */
+    uint64_t ao_phase_iterations[3];
+    uint64_t ao_phase_lanes[3];
 } lv_stats;
 
 #define LV_KERNEL_AO_PRIMARY 0

@@ -15,7 +15,7 @@ LIB = os.path.join(OUT_DIR, "liblinevis_hip.so")
 SOURCES = ["lv_api.hip", "lv_bvh.hip", "lv_render.hip"]
 HEADERS = ["lv_device.h", "lv_trace.h", "lv_internal.h", os.path.join("..", "..", "include", "linevis_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
-         "-fgpu-rdc" if False else "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-DNDEBUG"]
+         "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-DNDEBUG"] + os.environ.get("LV_EXTRA_HIPCC_FLAGS", "").split()
 
 
 def hipcc():

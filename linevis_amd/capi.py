@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "_lib", "liblinevis_hip.so")
+LIB_PATH = os.environ.get("LV_LIB_PATH") or os.path.join(_HERE, "_lib", "liblinevis_hip.so")  # override: kernel tuning builds
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "linevis_hip.h")
 
 LV_OK = 0
@@ -32,7 +32,8 @@ class Stats(C.Structure):
                 ("ms_color", C.c_float), ("ms_ppll_clear", C.c_float), ("ms_ppll_gather", C.c_float),
                 ("ms_ppll_resolve", C.c_float), ("ms_total", C.c_float), ("device_bytes", C.c_uint64),
                 ("ms_kernel_avg", C.c_float * 8), ("kernel_launches", C.c_uint32 * 8),
-                ("ao_rays_traced", C.c_uint64), ("ao_nodes_visited", C.c_uint64), ("ao_prims_tested", C.c_uint64)]
+                ("ao_rays_traced", C.c_uint64), ("ao_nodes_visited", C.c_uint64), ("ao_prims_tested", C.c_uint64),
+                ("ao_phase_iterations", C.c_uint64 * 3), ("ao_phase_lanes", C.c_uint64 * 3)]
 
     def as_dict(self):
         d = {}

@@ -89,6 +89,7 @@ struct LvDevCountersHost { // must match LvDevCounters in lv_render.hip
     unsigned long long rays, nodes, prims, hits;
     unsigned long long aoRays, aoNodes, aoPrims;
     unsigned long long aoQueueHead;
+    unsigned long long aoPhaseIters[3], aoPhaseLanes[3];
     uint32_t fragCounter, aoCount, maxDepthComplexity, depthOrd[2], pad;
 };
 
@@ -198,7 +199,7 @@ int lv_set_stream(lv_ctx* ctx, void* hip_stream) {
 int lv_set_lines(lv_ctx* ctx, const lv_line_point* points, uint32_t num_points, const uint32_t* seg, uint32_t num_segments) {
     if (!ctx) return LV_E_INVALID;
     if ((num_points && !points) || (num_segments && !seg)) return lv_fail(ctx, LV_E_INVALID, "null input array");
-    if (num_segments >= 0x7FFFFFFFu) return lv_fail(ctx, LV_E_CAPACITY, "at most 2^31-2 segments");
+    if (num_segments > 0x03FFFFFFu) return lv_fail(ctx, LV_E_CAPACITY, "at most 2^26-1 segments (leaf index field of the AO work queue)");
     for (uint64_t i = 0; i < 2ull * num_segments; i++)
         if (seg[i] >= num_points)
             return lv_fail(ctx, LV_E_INVALID, "segment %llu references point %u >= num_points %u",
@@ -408,6 +409,7 @@ int lv_get_stats(lv_ctx* ctx, lv_stats* out) {
         s.ao_rays_traced = hc.aoRays;
         s.ao_nodes_visited = hc.aoNodes;
         s.ao_prims_tested = hc.aoPrims;
+        for (int k = 0; k < 3; k++) { s.ao_phase_iterations[k] = hc.aoPhaseIters[k]; s.ao_phase_lanes[k] = hc.aoPhaseLanes[k]; }
     }
     for (int k = 0; k < 8; k++) { s.ms_kernel_avg[k] = 0.0f; s.kernel_launches[k] = 0; }
     for (int k = 0; k < lv_ctx::kNumKernels; k++) {

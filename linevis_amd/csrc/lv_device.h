@@ -16,7 +16,25 @@
 #define LV_INVALID 0xFFFFFFFFu
 #define LV_STACK_LDS 32     // per-thread traversal stack entries staged in LDS
 #define LV_STACK_SPILL 64   // further entries in a global overflow slab; 96 >= max LBVH height (63 key bits + 32)
-#define LV_REFILL_THRESHOLD 16 // persistent AO waves fetch new rays once this many lanes are idle
+#ifndef LV_REFILL_THRESHOLD
+#define LV_REFILL_THRESHOLD 8 // persistent AO waves fetch new rays once this many lanes are idle
+#endif
+#ifndef LV_AO_CHUNK
+#define LV_AO_CHUNK 1024        // AO rays a wave takes from the global queue per atomic
+#endif
+#ifndef LV_AO_STACK_LDS
+#define LV_AO_STACK_LDS 16      // LDS-staged stack entries per thread in k_ao_rays (deeper entries: HBM overflow slab)
+#endif
+#ifndef LV_AO_BLOCK
+#define LV_AO_BLOCK 256         // threads per workgroup of k_ao_rays
+#endif
+#ifndef LV_AO_BLOCKS_PER_CU
+#define LV_AO_BLOCKS_PER_CU 4
+#endif
+#define LV_AO_QCAP 256         // leaf FIFO entries per wave (>= 64 waiting + 2 x 64 new per step)
+#ifndef LV_NODE_MIN_ACTIVE
+#define LV_NODE_MIN_ACTIVE 24  // node loop yields to the leaf loop when fewer lanes than this are descending
+#endif
 
 struct f3 { float x, y, z; };
 struct f4 { float x, y, z, w; };

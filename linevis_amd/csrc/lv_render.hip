@@ -24,6 +24,7 @@ struct LvDevCounters {
     unsigned long long rays, nodes, prims, hits;
     unsigned long long aoRays, aoNodes, aoPrims; // share of k_ao_rays
     unsigned long long aoQueueHead;              // next AO ray index handed to the persistent waves
+    unsigned long long aoPhaseIters[3], aoPhaseLanes[3]; // {setup, node, leaf}: wave iterations / active lanes
     uint32_t fragCounter;
     uint32_t aoCount;
     uint32_t maxDepthComplexity;
@@ -48,9 +49,12 @@ __device__ __forceinline__ void lv_flush_counters(const LvCounters& c, LvDevCoun
 }
 
 // Pixel of this thread.  A workgroup covers a 16x16 pixel block of one tile; each wave an 8x8 sub-block, so a
-// wave's primary rays stay coherent.  Workgroups are dealt to XCDs round-robin by the dispatcher (block b -> XCD
-// b % 8), so the block index is remapped to give every XCD one contiguous run of blocks and its private L2 one
-// compact part of the BVH (speed only; correctness does not depend on placement).
+// wave's primary rays stay coherent.  The dispatcher deals workgroups to the 8 XCDs round-robin (block b -> XCD
+// b % 8, each with a private L2).  Blocks are regrouped so that runs of LV_XCD_GROUP consecutive logical blocks (one
+// 64x64 tile = 16 blocks) land on the same XCD, and consecutive groups go to consecutive XCDs: spatial neighbours share
+// an L2 while every XCD still gets an even share of the dense and the empty parts of the picture (a contiguous 1/8
+// of the frame per XCD left 7 XCDs idle behind the one that owned the centre).  Speed only; never correctness.
+#define LV_XCD_GROUP 16u
 struct LvPixel {
     uint32_t x, y;       // viewport pixel
     uint32_t outIndex;   // index into the tile-major output
@@ -60,8 +64,8 @@ struct LvPixel {
 __device__ __forceinline__ bool lv_block_pixel(const LvUniforms& U, const LvTiles& T, LvPixel& p) {
     const uint32_t blocksPerTile = T.blocksX * T.blocksY;
     const uint32_t nb = T.numTiles * blocksPerTile;
-    const uint32_t chunk = (nb + 7u) / 8u;
-    const uint32_t b = (blockIdx.x % 8u) * chunk + blockIdx.x / 8u;
+    const uint32_t xcd = blockIdx.x % 8u, j = blockIdx.x / 8u;   // j-th block this XCD receives
+    const uint32_t b = ((j / LV_XCD_GROUP) * 8u + xcd) * LV_XCD_GROUP + (j % LV_XCD_GROUP);
     if (b >= nb) { p.inTile = false; p.inView = false; return false; }
     const uint32_t tile = b / blocksPerTile, rem = b % blocksPerTile;
     const uint32_t by = rem / T.blocksX, bx = rem % T.blocksX;
@@ -207,51 +211,139 @@ __global__ __launch_bounds__(LV_BLOCK) void k_ao_primary(const LvUniforms U, con
     if (STATS) lv_flush_counters(cnt, dc);
 }
 
-// AO sample rays as a PERSISTENT, dynamically refilled wavefront kernel.  AO ray r belongs to compacted pixel r / spp,
-// sample r % spp (with spp = 64 the first fill of a wave is exactly one pixel's hemisphere).  Rays of one wave finish
-// after very different numbers of node steps (measured: 17 % mean lane utilisation with one ray per thread), so each
-// lane owns a ray only while it is alive: once LV_REFILL_THRESHOLD lanes are idle the wave pulls that many new ray
-// indices from a global queue head with ONE atomic (ballot + prefix popcount), sets them up together, and continues
-// traversing with all lanes busy.  Results go to samples[r]; k_ao_reduce sums them per pixel in sample order.
+// AO sample rays: PERSISTENT waves that keep three kinds of work apart and run each of them with (nearly) all
+// 64 lanes busy.  AO ray r belongs to compacted pixel r / spp, sample r % spp.
+//
+//   generate  a wave takes LV_AO_CHUNK consecutive ray indices from the global queue head with one atomic and turns
+//             them into rays 64 at a time -- TEA seed, hemisphere sample, frame transform, normalisation -- into an LDS
+//             buffer (s_gen); idle lanes later pick a ready ray from there (two ds_read_b128), so the ~330-instruction
+//             setup always runs at full width.
+//   descend   a lane owns a ray only while it is alive; every lane with an inner node does one node step per
+//             iteration (LDS-staged stack).  Leaves are NOT tested by the lane that meets them: (owner lane, leaf) is
+//             appended to a wave-local FIFO in LDS (ballot + prefix popcount, no atomics).
+//   test      as soon as 64 pairs wait, all 64 lanes take one pair each, read the owner's ray from LDS, run the
+//             capsule test (8 IEEE divisions + 4 square roots, ~350 instructions) and merge into the owner's best hit
+//             with one 64-bit LDS atomicMin on the key (t bits << 32 | original segment): exactly "closest hit, ties
+//             to the lowest segment index".  The leaf test is the expensive phase; with one ray per thread it ran at
+//             17-27 % lane utilisation (measured), here at ~100 %.
+// A finished ray is retired (samples[r] written, lane idle) once the FIFO head has passed its last queued leaf.
+// Scheduling inside a wave: test when >= 64 pairs wait; refill when >= LV_REFILL_THRESHOLD lanes are idle; otherwise
+// descend; flush partial batches only when nothing else can make progress.
 template <bool STATS, bool ANY_HIT>
-__global__ __launch_bounds__(LV_BLOCK) void k_ao_rays(const LvUniforms U, const LvSceneDev S,
-                                                      const float4* __restrict__ gbuf, float* __restrict__ samples,
-                                                      LvDevCounters* dc) {
-    __shared__ unsigned s_stack[LV_STACK_LDS * LV_BLOCK];
+__global__ __launch_bounds__(LV_AO_BLOCK) void k_ao_rays(const LvUniforms U, const LvSceneDev S,
+                                                         const float4* __restrict__ gbuf, float* __restrict__ samples,
+                                                         LvDevCounters* dc) {
+    __shared__ unsigned s_stack[LV_AO_STACK_LDS * LV_AO_BLOCK];
+    __shared__ float4 s_ray[2 * LV_AO_BLOCK];              // current ray of every lane: {o.xyz, -}{d.xyz, -}
+    __shared__ float4 s_gen[2 * LV_AO_BLOCK];              // generated rays waiting for a lane
+    __shared__ unsigned s_queue[LV_AO_BLOCK / LV_WAVE][LV_AO_QCAP];
+    __shared__ unsigned long long s_key[LV_AO_BLOCK];      // best hit of every lane's ray
+
     const uint32_t spp = U.aoSamplesPerFrame;
     const unsigned long long total = (unsigned long long)(dc->aoCount) * spp;
     const bool capped = U.useCappedTubes != 0;
     const float radius = U.radius;
-    const unsigned lane = lv_lane();
-    const LvStackMem sm = lv_stack_mem(s_stack, S.stackOverflow);
-    LvStack st;
-    st.init(sm.lds, sm.ovf, sm.ovfStride);
-    LvCounters cnt = {0, 0, 0, 0};
+    const unsigned lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    float4* rayW = &s_ray[2 * LV_WAVE * w];
+    float4* genW = &s_gen[2 * LV_WAVE * w];
+    unsigned* queueW = s_queue[w];
+    unsigned long long* keyW = &s_key[LV_WAVE * w];
+    const unsigned long long keyInit = ((unsigned long long)__float_as_uint(U.aoRadius) << 32) | 0xFFFFFFFFull;
 
-    // per-lane ray state
-    bool hasRay = false, exhausted = (S.numSegs == 0) || (total == 0);
+    LvStackT<LV_AO_STACK_LDS, LV_AO_BLOCK> st;
+    st.init(&s_stack[threadIdx.x], S.stackOverflow ? S.stackOverflow + (size_t(blockIdx.x) * LV_AO_BLOCK + threadIdx.x) : nullptr,
+            gridDim.x * LV_AO_BLOCK);
+    LvCounters cnt = {0, 0, 0, 0};
+    unsigned long long phIt[3] = {0, 0, 0}, phLn[3] = {0, 0, 0};
+
+    // wave-uniform state
+    unsigned long long chunkNext = 0, chunkEnd = 0, genBase = 0;
+    unsigned genCount = 0, genPos = 0;      // rays in s_gen: [genPos, genCount)
+    unsigned head = 0, tail = 0;            // leaf FIFO (absolute sequence numbers)
+    bool sourceDry = (S.numSegs == 0) || (total == 0);
+    // lane state
+    bool hasRay = false, enq = false;
     unsigned long long r = 0;
-    f3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), inv = mk3(0, 0, 0);
+    f3 inv = mk3(0, 0, 0), oi = mk3(0, 0, 0);
     float best = 0.0f;
-    uint32_t bestLeaf = LV_INVALID;
-    bool found = false;
-    unsigned cur = LV_INVALID, pending = LV_INVALID;
+    unsigned cur = LV_INVALID, lastSeq = 0;
 
     while (true) {
-        // ---- refill idle lanes from the global queue (whole wave is converged here)
-        const unsigned long long idleMask = __ballot(!hasRay && !exhausted);
-        const unsigned long long busyMask = __ballot(hasRay);
-        if (idleMask == 0 && busyMask == 0) break;
-        const int nIdle = __popcll(idleMask);
-        if (nIdle >= LV_REFILL_THRESHOLD || busyMask == 0) {
-            if (!hasRay && !exhausted) {
-                const int leader = __ffsll((long long)idleMask) - 1;
-                unsigned long long base = 0;
-                if (int(lane) == leader) base = atomicAdd(&dc->aoQueueHead, (unsigned long long)nIdle);
-                base = __shfl(base, leader, 64);
-                r = base + (unsigned long long)__popcll(idleMask & ((1ull << lane) - 1ull));
-                if (r < total) {
-                    const uint32_t slot = uint32_t(r / spp), smpIdx = uint32_t(r % spp);
+        // ---- leaves reached in the previous step join the FIFO
+        {
+            const bool isLeaf = hasRay && cur != LV_INVALID && (cur & LV_LEAF_BIT);
+            const unsigned long long mL = __ballot(isLeaf);
+            if (mL) {
+                if (isLeaf) {
+                    const unsigned idx = tail + unsigned(__popcll(mL & below));
+                    queueW[idx % LV_AO_QCAP] = (lane << 26) | (cur & 0x03FFFFFFu);
+                    lastSeq = idx;
+                    enq = true;
+                    cur = lv_pop_or_done(st);
+                }
+                tail += unsigned(__popcll(mL));
+                continue; // a popped reference may be a leaf again
+            }
+        }
+        // ---- retire rays whose traversal is finished and whose queued leaves have all been tested
+        if (hasRay && cur == LV_INVALID && (!enq || int(head - lastSeq) > 0)) {
+            const unsigned long long key = keyW[lane];
+            float occ = 1.0f;
+            if (key != keyInit) occ = U.aoUseDistance ? __uint_as_float(unsigned(key >> 32)) / U.aoRadius : 0.0f;
+            samples[r] = occ;
+            hasRay = false;
+        }
+        const unsigned long long mNode = __ballot(hasRay && !(cur & LV_LEAF_BIT));
+        const unsigned long long mIdle = __ballot(!hasRay);
+        const int nNode = __popcll(mNode), nIdle = __popcll(mIdle);
+        const unsigned q = tail - head;
+        const bool canRefill = (genPos < genCount) || !sourceDry;
+
+        if (q >= LV_WAVE || (q > 0 && nNode == 0 && !(canRefill && nIdle > 0))) {
+            // ---- test phase: one (owner, leaf) pair per lane
+            const unsigned n = q < LV_WAVE ? q : LV_WAVE;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (STATS && lane == 0) { phIt[2]++; phLn[2] += n; }
+            if (lane < n) {
+                const unsigned e = queueW[(head + lane) % LV_AO_QCAP];
+                const unsigned owner = e >> 26, leaf = e & 0x03FFFFFFu;
+                const float4 ro = rayW[2 * owner], rd = rayW[2 * owner + 1];
+                const float4 a = S.segs[2 * leaf], b = S.segs[2 * leaf + 1];
+                if (STATS) cnt.prims++;
+                float t; int kind;
+                if (lv_intersect_capsule(mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), mk3(a.x, a.y, a.z),
+                                         mk3(b.x, b.y, b.z), radius, capped, t, kind)) {
+                    if (t >= 0.0f && t <= U.aoRadius) // traceAoRay: closest hit in [0, aoRadius], glsl:158-175
+                        atomicMin(&keyW[owner], ((unsigned long long)__float_as_uint(t) << 32) | S.leafSeg[leaf]);
+                }
+            }
+            head += n;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (hasRay) {
+                const unsigned long long key = keyW[lane];
+                best = __uint_as_float(unsigned(key >> 32)); // shrinks the slab interval of the following node steps
+                if (ANY_HIT && key != keyInit) { cur = LV_INVALID; st.sp = 0; }
+            }
+            continue;
+        }
+        if (canRefill && nIdle > 0 && (nIdle >= LV_REFILL_THRESHOLD || nNode < LV_NODE_MIN_ACTIVE)) {
+            // ---- generate phase: keep s_gen stocked (all 64 lanes), then hand rays to the idle lanes
+            if (genPos >= genCount) {
+                if (chunkNext >= chunkEnd) {
+                    unsigned long long base = 0;
+                    if (lane == 0) base = atomicAdd(&dc->aoQueueHead, (unsigned long long)LV_AO_CHUNK);
+                    chunkNext = __shfl(base, 0, 64);
+                    chunkEnd = chunkNext + LV_AO_CHUNK;
+                    if (chunkEnd > total) chunkEnd = total;
+                    if (chunkNext >= total) { chunkNext = chunkEnd = total; sourceDry = true; }
+                }
+                const unsigned long long left = chunkEnd - chunkNext;
+                const unsigned n = left < LV_WAVE ? unsigned(left) : LV_WAVE;
+                if (STATS && lane == 0 && n) { phIt[0]++; phLn[0] += n; }
+                if (lane < n) {
+                    const unsigned long long rr = chunkNext + lane;
+                    const uint32_t slot = uint32_t(rr / spp), smpIdx = uint32_t(rr % spp);
                     const float4 g0 = gbuf[3 * size_t(slot) + 0], g1 = gbuf[3 * size_t(slot) + 1],
                                  g2 = gbuf[3 * size_t(slot) + 2];
                     const uint32_t pix = __float_as_uint(g1.w);
@@ -261,62 +353,81 @@ __global__ __launch_bounds__(LV_BLOCK) void k_ao_rays(const LvUniforms U, const 
                     const float xi0 = lv_rnd(seed), xi1 = lv_rnd(seed);
                     float sn, cs;
                     lv_sincos2pi(xi1, sn, cs); // sampleHemisphere, glsl:151-156
-                    const float rr = sqrtf(1.0f - xi0 * xi0);
-                    const f3 smp = mk3(cs * rr, sn * rr, xi0);
+                    const float rs = sqrtf(1.0f - xi0 * xi0);
+                    const f3 smp = mk3(cs * rs, sn * rs, xi0);
                     const f3 dirU = mk3((T.x * smp.x + B.x * smp.y) + N.x * smp.z, (T.y * smp.x + B.y * smp.y) + N.y * smp.z,
                                         (T.z * smp.x + B.z * smp.y) + N.z * smp.z);
-                    d = norm3(dirU);
-                    o = pos + d * g0.w;
-                    inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                    const f3 d = norm3(dirU);
+                    const f3 o = pos + d * g0.w;
+                    genW[2 * lane] = make_float4(o.x, o.y, o.z, 0.0f);
+                    genW[2 * lane + 1] = make_float4(d.x, d.y, d.z, 0.0f);
+                }
+                genBase = chunkNext;
+                chunkNext += n;
+                genCount = n;
+                genPos = 0;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            }
+            const unsigned avail = genCount - genPos;
+            const unsigned k = unsigned(nIdle) < avail ? unsigned(nIdle) : avail;
+            if (!hasRay) {
+                const unsigned rank = unsigned(__popcll(mIdle & below));
+                if (rank < k) {
+                    const unsigned gs = genPos + rank;
+                    const float4 ro = genW[2 * gs], rd = genW[2 * gs + 1];
+                    rayW[2 * lane] = ro;
+                    rayW[2 * lane + 1] = rd;
+                    keyW[lane] = keyInit;
+                    inv = mk3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+                    oi = mk3(ro.x * inv.x, ro.y * inv.y, ro.z * inv.z);
                     best = U.aoRadius;
-                    bestLeaf = LV_INVALID;
-                    found = false;
+                    r = genBase + gs;
                     cur = 0;
-                    pending = LV_INVALID;
                     st.sp = 0;
+                    enq = false;
                     hasRay = true;
                     if (STATS) cnt.rays++;
-                } else {
-                    exhausted = true;
                 }
             }
+            genPos += k;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            continue;
         }
-        // ---- node loop: descend, park the first leaf, leave when every descending lane has one
-        while (!(cur & LV_LEAF_BIT)) {
-            cur = lv_node_step<STATS>(S, cur, o, inv, 0.0f, best, st, cnt);
-            if ((cur & LV_LEAF_BIT) && cur != LV_INVALID && pending == LV_INVALID) {
-                pending = cur;
-                cur = lv_pop_or_done(st);
-            }
-            if (!__any(pending == LV_INVALID)) break;
-        }
-        // ---- leaf loop: closest hit in [0, aoRadius] (traceAoRay, glsl:158-175), ties -> lowest segment index
-        while (pending != LV_INVALID) {
-            const unsigned leaf = pending & ~LV_LEAF_BIT;
-            const float4 a = S.segs[2 * leaf], b = S.segs[2 * leaf + 1];
-            if (STATS) cnt.prims++;
-            float t; int kind;
-            if (lv_intersect_capsule(o, d, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), radius, capped, t, kind)) {
-                if (t >= 0.0f && t <= U.aoRadius) {
-                    bool take = !found || t < best;
-                    if (!take && t == best) take = S.leafSeg[leaf] < S.leafSeg[bestLeaf];
-                    if (take) { found = true; best = t; bestLeaf = leaf; }
+        if (nNode > 0) {
+            // ---- descend phase: tight loop of node steps; leaves met on the way join the FIFO.  Leave it when a full
+            // batch of leaf tests waits, when nobody descends any more, or when enough lanes ran dry to be worth a
+            // retire/refill pass.
+            const int stay = nNode > LV_REFILL_THRESHOLD ? nNode - LV_REFILL_THRESHOLD : 1;
+            int nNow;
+            do {
+                if (STATS && lane == 0) { phIt[1]++; }
+                if (STATS && hasRay && !(cur & LV_LEAF_BIT)) phLn[1]++;
+                if (hasRay && !(cur & LV_LEAF_BIT)) cur = lv_node_step<STATS>(S, cur, oi, inv, 0.0f, best, st, cnt);
+                const bool isLeaf = hasRay && cur != LV_INVALID && (cur & LV_LEAF_BIT);
+                const unsigned long long mL = __ballot(isLeaf);
+                if (mL) {
+                    if (isLeaf) {
+                        const unsigned idx = tail + unsigned(__popcll(mL & below));
+                        queueW[idx % LV_AO_QCAP] = (lane << 26) | (cur & 0x03FFFFFFu);
+                        lastSeq = idx;
+                        enq = true;
+                        cur = lv_pop_or_done(st);
+                    }
+                    tail += unsigned(__popcll(mL));
                 }
-            }
-            pending = LV_INVALID;
-            if ((cur & LV_LEAF_BIT) && cur != LV_INVALID) { pending = cur; cur = lv_pop_or_done(st); }
+                nNow = __popcll(__ballot(hasRay && !(cur & LV_LEAF_BIT)));
+            } while (tail - head < LV_WAVE && nNow >= stay);
+            continue;
         }
-        // ---- retire finished rays
-        if (hasRay && ((cur == LV_INVALID && pending == LV_INVALID) || (ANY_HIT && found))) {
-            float occ = 1.0f;
-            if (found) occ = U.aoUseDistance ? best / U.aoRadius : 0.0f;
-            samples[r] = occ;
-            hasRay = false;
-            cur = LV_INVALID;
-            pending = LV_INVALID;
+        if (nIdle == LV_WAVE && !canRefill) break; // nothing alive, nothing left to fetch
+    }
+    if (STATS) {
+        lv_flush_counters(cnt, dc, true);
+        for (int k = 0; k < 3; k++) {
+            const unsigned long long it = lv_wave_sum_u64(phIt[k]), ln = lv_wave_sum_u64(phLn[k]);
+            if (lane == 0) { atomicAdd(&dc->aoPhaseIters[k], it); atomicAdd(&dc->aoPhaseLanes[k], ln); }
         }
     }
-    if (STATS) lv_flush_counters(cnt, dc, true);
 }
 
 __global__ __launch_bounds__(LV_BLOCK) void k_ao_reduce(const LvUniforms U, const float4* __restrict__ gbuf,
@@ -644,10 +755,10 @@ int lv_frame_depth_range(lv_ctx* ctx) {
 }
 
 // the global part of the traversal stacks: only when the tree is higher than the LDS-staged part
-static int lv_prepare_overflow(lv_ctx* ctx, LvSceneDev& S, uint64_t gridBlocks) {
+static int lv_prepare_overflow(lv_ctx* ctx, LvSceneDev& S, uint64_t gridBlocks, uint32_t ldsEntries = LV_STACK_LDS) {
     S.stackOverflow = nullptr;
-    if (ctx->bvhDepth <= LV_STACK_LDS) return LV_OK;
-    const uint64_t extra = ctx->bvhDepth - LV_STACK_LDS;
+    if (ctx->bvhDepth <= ldsEntries) return LV_OK;
+    const uint64_t extra = ctx->bvhDepth - ldsEntries;
     int rc = lv_buf_reserve(ctx, ctx->stackOverflow, size_t(gridBlocks) * LV_BLOCK * extra * 4);
     if (rc) return rc;
     S.stackOverflow = (unsigned*)ctx->stackOverflow.ptr;
@@ -663,12 +774,12 @@ static int lv_run_ao(lv_ctx* ctx, LvUniforms& U, LvSceneDev& S, const LvTiles& T
     if ((rc = lv_buf_reserve(ctx, ctx->aoGbuf, size_t(maxPixels) * 48))) return rc;
     if ((rc = lv_buf_reserve(ctx, ctx->aoSamples, size_t(maxPixels) * spp * 4))) return rc;
     const uint64_t maxRays = maxPixels * spp;
-    // persistent grid: enough workgroups to fill every CU at the kernel's LDS-limited residency (5 x 32 KiB)
-    uint64_t gridRays = uint64_t(ctx->numCUs) * 5u;
-    if (gridRays > (maxRays + LV_BLOCK - 1) / LV_BLOCK) gridRays = (maxRays + LV_BLOCK - 1) / LV_BLOCK;
+    // persistent grid: enough workgroups to fill every CU at the kernel's LDS-limited residency
+    uint64_t gridRays = uint64_t(ctx->numCUs) * LV_AO_BLOCKS_PER_CU;
+    if (gridRays > (maxRays + LV_AO_BLOCK - 1) / LV_AO_BLOCK) gridRays = (maxRays + LV_AO_BLOCK - 1) / LV_AO_BLOCK;
     if (gridRays == 0) gridRays = 1;
     const uint64_t gridMax = gridRays > gridTiles ? gridRays : gridTiles;
-    if ((rc = lv_prepare_overflow(ctx, S, gridMax))) return rc;
+    if ((rc = lv_prepare_overflow(ctx, S, gridMax, LV_AO_STACK_LDS))) return rc;
     const bool stats = ctx->opt.collectStats;
     for (uint32_t iter = 0; iter < ctx->opt.aoIterations; iter++) {
         U.aoFrameNumber = iter; // rtaoRenderPass->setFrameNumber(accumulatedFramesCounter), VulkanRayTracedAmbientOcclusion.cpp:92
@@ -685,7 +796,7 @@ static int lv_run_ao(lv_ctx* ctx, LvUniforms& U, LvSceneDev& S, const LvTiles& T
         float* ao = (float*)ctx->ao.ptr;
         float* smp = (float*)ctx->aoSamples.ptr;
 #define LV_LAUNCH_AO(ST, AH) \
-    LV_TIMED_LAUNCH(ctx, LV_KERNEL_AO_RAYS, (k_ao_rays<ST, AH><<<grid, LV_BLOCK, 0, st>>>(U, S, g, smp, dc)))
+    LV_TIMED_LAUNCH(ctx, LV_KERNEL_AO_RAYS, (k_ao_rays<ST, AH><<<grid, LV_AO_BLOCK, 0, st>>>(U, S, g, smp, dc)))
         const bool anyHit = !U.aoUseDistance;
         if (stats) { if (anyHit) LV_LAUNCH_AO(true, true); else LV_LAUNCH_AO(true, false); }
         else { if (anyHit) LV_LAUNCH_AO(false, true); else LV_LAUNCH_AO(false, false); }
@@ -732,7 +843,7 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
     T.blocksY = (tileH + 15u) / 16u;
     const uint64_t nb = uint64_t(numTiles) * T.blocksX * T.blocksY;
     if (nb > 0x7FFFFFF0ull) return lv_fail(ctx, LV_E_INVALID, "tile list too large");
-    const uint32_t gridTiles = uint32_t((nb + 7u) / 8u) * 8u;
+    const uint32_t gridTiles = uint32_t((nb + 127u) / 128u) * 128u; // multiple of 8 XCDs x LV_XCD_GROUP (lv_block_pixel)
     const uint64_t maxPixels = uint64_t(numTiles) * tileW * tileH;
     const bool stats = ctx->opt.collectStats;
     LvSceneDev S = sceneDev(ctx);

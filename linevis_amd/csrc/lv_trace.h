@@ -84,24 +84,26 @@ __device__ __forceinline__ bool lv_intersect_capsule(f3 o, f3 d, f3 p0, f3 p1, f
 // N segments is usually ~log2(N)+10 deep, so LV_STACK_LDS = 32 entries cover the common case entirely in LDS; deeper
 // trees (up to 63 key bits + 32 duplicate-index bits) continue in a per-thread column of a global overflow slab that is
 // only allocated when the built tree is that deep.  All members are scalars so the struct lives in registers.
-struct LvStack {
+template <int NLDS, int STRIDE = LV_BLOCK>
+struct LvStackT {
     unsigned* lds;       // &s_stack[threadIdx.x]
-    unsigned* ovf;       // &overflow[global thread], entries strided by ovfStride; may be null if height <= LV_STACK_LDS
+    unsigned* ovf;       // &overflow[global thread], entries strided by ovfStride; may be null if height <= NLDS
     unsigned ovfStride;
     int sp;
     __device__ __forceinline__ void init(unsigned* ldsBase, unsigned* ovfBase, unsigned stride) {
         lds = ldsBase; ovf = ovfBase; ovfStride = stride; sp = 0;
     }
     __device__ __forceinline__ void push(unsigned v) {
-        if (sp < LV_STACK_LDS) lds[sp * LV_BLOCK] = v;
-        else ovf[size_t(sp - LV_STACK_LDS) * ovfStride] = v;
+        if (sp < NLDS) lds[sp * STRIDE] = v;
+        else ovf[size_t(sp - NLDS) * ovfStride] = v;
         sp++;
     }
     __device__ __forceinline__ unsigned pop() {
         sp--;
-        return sp < LV_STACK_LDS ? lds[sp * LV_BLOCK] : ovf[size_t(sp - LV_STACK_LDS) * ovfStride];
+        return sp < NLDS ? lds[sp * STRIDE] : ovf[size_t(sp - NLDS) * ovfStride];
     }
 };
+typedef LvStackT<LV_STACK_LDS> LvStack;
 // stack memory handed to the traversal routines by a kernel
 struct LvStackMem {
     unsigned* lds;
@@ -116,16 +118,18 @@ __device__ __forceinline__ LvStackMem lv_stack_mem(unsigned* sStack, unsigned* o
     return m;
 }
 
-// slab test of one child box against the ray; conservative acceptance (boxes are padded at build time)
-__device__ __forceinline__ bool lv_slab(float bx0, float by0, float bz0, float bx1, float by1, float bz1, f3 o, f3 inv,
+// Slab test of one child box against the ray.  Box culling only has to be conservative (boxes are padded at build
+// time and the acceptance test carries a relative + absolute margin), it never decides a hit, so it is the one place
+// that uses fused multiply-adds: t = b * (1/d) - o * (1/d) with oi = o * (1/d) precomputed per ray.
+__device__ __forceinline__ bool lv_slab(float bx0, float by0, float bz0, float bx1, float by1, float bz1, f3 oi, f3 inv,
                                         float tMin, float tMax, float& tNear) {
-    float tx0 = (bx0 - o.x) * inv.x, tx1 = (bx1 - o.x) * inv.x;
-    float ty0 = (by0 - o.y) * inv.y, ty1 = (by1 - o.y) * inv.y;
-    float tz0 = (bz0 - o.z) * inv.z, tz1 = (bz1 - o.z) * inv.z;
+    float tx0 = __builtin_fmaf(bx0, inv.x, -oi.x), tx1 = __builtin_fmaf(bx1, inv.x, -oi.x);
+    float ty0 = __builtin_fmaf(by0, inv.y, -oi.y), ty1 = __builtin_fmaf(by1, inv.y, -oi.y);
+    float tz0 = __builtin_fmaf(bz0, inv.z, -oi.z), tz1 = __builtin_fmaf(bz1, inv.z, -oi.z);
     float tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), tMin));
     float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), tMax));
     tNear = tn;
-    return tn <= tf * 1.0000005f + 1e-7f;
+    return tn <= __builtin_fmaf(tf, 1.000001f, 2e-7f);
 }
 
 struct LvHit {
@@ -140,12 +144,21 @@ struct LvHit {
 // the wave leaves the node loop only when every still-descending lane has parked a leaf, so the expensive capsule test
 // (8 IEEE divisions + 4 square roots) runs with most lanes active instead of once per node step for a handful of lanes.
 // Child references: index | LV_LEAF_BIT for leaves, LV_INVALID (which has the leaf bit set) = finished.
-__device__ __forceinline__ unsigned lv_pop_or_done(LvStack& st) { return st.sp == 0 ? LV_INVALID : st.pop(); }
+template <class STACK>
+__device__ __forceinline__ unsigned lv_pop_or_done(STACK& st) { return st.sp == 0 ? LV_INVALID : st.pop(); }
+
+// Evaluated by the lanes still inside the node loop: leave it when every one of them has parked a leaf, or when
+// fewer than LV_NODE_MIN_ACTIVE lanes are still descending (the others wait with a parked leaf and a second one in
+// hand; testing those now keeps both loops above ~50 % lane utilisation).
+__device__ __forceinline__ bool lv_leave_node_loop(unsigned pending) {
+    const unsigned long long descending = __ballot(1);
+    return !__any(pending == LV_INVALID) || __popcll(descending) < LV_NODE_MIN_ACTIVE;
+}
 
 // one node step: fetch the 64-byte node, slab-test both child boxes, pick the next reference (near child first)
-template <bool STATS>
-__device__ __forceinline__ unsigned lv_node_step(const LvSceneDev& S, unsigned node, f3 o, f3 inv, float tMin, float tMax,
-                                                 LvStack& st, LvCounters& cnt) {
+template <bool STATS, class STACK>
+__device__ __forceinline__ unsigned lv_node_step(const LvSceneDev& S, unsigned node, f3 oi, f3 inv, float tMin, float tMax,
+                                                 STACK& st, LvCounters& cnt) {
     const float4 q0 = S.nodes[4 * node + 0];
     const float4 q1 = S.nodes[4 * node + 1];
     const float4 q2 = S.nodes[4 * node + 2];
@@ -153,8 +166,8 @@ __device__ __forceinline__ unsigned lv_node_step(const LvSceneDev& S, unsigned n
     if (STATS) cnt.nodes++;
     const unsigned c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
     float tn0, tn1;
-    const bool hit0 = lv_slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, inv, tMin, tMax, tn0);
-    const bool hit1 = lv_slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, inv, tMin, tMax, tn1) && (c1 != LV_INVALID);
+    const bool hit0 = lv_slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, oi, inv, tMin, tMax, tn0);
+    const bool hit1 = lv_slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, oi, inv, tMin, tMax, tn1) && (c1 != LV_INVALID);
     if (hit0 && hit1) {
         const bool swap = tn1 < tn0;
         st.push(swap ? c0 : c1);
@@ -175,18 +188,19 @@ __device__ __forceinline__ LvHit lv_trace_closest(const LvSceneDev& S, float rad
     if (STATS) cnt.rays++;
     if (S.numSegs == 0) return h;
     const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    const f3 oi = mk3(o.x * inv.x, o.y * inv.y, o.z * inv.z);
     LvStack st;
     st.init(sm.lds, sm.ovf, sm.ovfStride);
     unsigned cur = 0;            // root
     unsigned pending = LV_INVALID;
     while (cur != LV_INVALID || pending != LV_INVALID) {
         while (!(cur & LV_LEAF_BIT)) {
-            cur = lv_node_step<STATS>(S, cur, o, inv, tMin, h.t, st, cnt);
+            cur = lv_node_step<STATS>(S, cur, oi, inv, tMin, h.t, st, cnt);
             if ((cur & LV_LEAF_BIT) && cur != LV_INVALID && pending == LV_INVALID) {
                 pending = cur;                       // first leaf: park it and keep descending
                 cur = lv_pop_or_done(st);
             }
-            if (!__any(pending == LV_INVALID)) break; // every descending lane has a leaf to test
+            if (lv_leave_node_loop(pending)) break;
         }
         while (pending != LV_INVALID) {
             const unsigned leaf = pending & ~LV_LEAF_BIT;
@@ -215,18 +229,19 @@ __device__ __forceinline__ void lv_trace_all(const LvSceneDev& S, float radius, 
     if (STATS) cnt.rays++;
     if (S.numSegs == 0) return;
     const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    const f3 oi = mk3(o.x * inv.x, o.y * inv.y, o.z * inv.z);
     LvStack st;
     st.init(sm.lds, sm.ovf, sm.ovfStride);
     unsigned cur = 0;
     unsigned pending = LV_INVALID;
     while (cur != LV_INVALID || pending != LV_INVALID) {
         while (!(cur & LV_LEAF_BIT)) {
-            cur = lv_node_step<STATS>(S, cur, o, inv, tMin, tMax, st, cnt);
+            cur = lv_node_step<STATS>(S, cur, oi, inv, tMin, tMax, st, cnt);
             if ((cur & LV_LEAF_BIT) && cur != LV_INVALID && pending == LV_INVALID) {
                 pending = cur;
                 cur = lv_pop_or_done(st);
             }
-            if (!__any(pending == LV_INVALID)) break;
+            if (lv_leave_node_loop(pending)) break;
         }
         while (pending != LV_INVALID) {
             const unsigned leaf = pending & ~LV_LEAF_BIT;

@@ -35,6 +35,9 @@ def run(ctx, mode, reps=3, label=''):
     d = s.as_dict()
     alg = d['nodes_visited'] * 64 + d['prims_tested'] * 32 + d['hits_shaded'] * 96
     print('  counters', {k: d[k] for k in ('rays_traced', 'nodes_visited', 'prims_tested', 'hits_shaded', 'fragments', 'ao_hit_pixels', 'max_depth_complexity')})
+    if s.ao_phase_iterations[1]:
+        print('  ao phases {setup,node,leaf}: iters', list(s.ao_phase_iterations), 'util',
+              [round(s.ao_phase_lanes[k] / (64.0 * max(1, s.ao_phase_iterations[k])), 3) for k in range(3)])
     print('  nodes/ray %.1f prims/ray %.2f  alg bytes %.3f GB' % (d['nodes_visited'] / max(1, d['rays_traced']), d['prims_tested'] / max(1, d['rays_traced']), alg / 1e9))
     return img
 
