@@ -83,6 +83,8 @@ typedef struct lv_stats {
      * of the {refill/setup, node, leaf} phases: utilisation = lanes / (64 * iterations). */
     uint64_t ao_phase_iterations[3];
     uint64_t ao_phase_lanes[3];
+    uint32_t max_nodes_per_pixel;  /* collect_stats: most BVH nodes fetched by one pixel of a tile kernel (tail latency) */
+    uint32_t reserved0;
 } lv_stats;
 
 #define LV_KERNEL_AO_PRIMARY 0

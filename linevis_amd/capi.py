@@ -33,7 +33,8 @@ class Stats(C.Structure):
                 ("ms_ppll_resolve", C.c_float), ("ms_total", C.c_float), ("device_bytes", C.c_uint64),
                 ("ms_kernel_avg", C.c_float * 8), ("kernel_launches", C.c_uint32 * 8),
                 ("ao_rays_traced", C.c_uint64), ("ao_nodes_visited", C.c_uint64), ("ao_prims_tested", C.c_uint64),
-                ("ao_phase_iterations", C.c_uint64 * 3), ("ao_phase_lanes", C.c_uint64 * 3)]
+                ("ao_phase_iterations", C.c_uint64 * 3), ("ao_phase_lanes", C.c_uint64 * 3),
+                ("max_nodes_per_pixel", C.c_uint32), ("reserved0", C.c_uint32)]
 
     def as_dict(self):
         d = {}

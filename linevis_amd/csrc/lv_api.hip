@@ -90,7 +90,7 @@ struct LvDevCountersHost { // must match LvDevCounters in lv_render.hip
     unsigned long long aoRays, aoNodes, aoPrims;
     unsigned long long aoQueueHead;
     unsigned long long aoPhaseIters[3], aoPhaseLanes[3];
-    uint32_t fragCounter, aoCount, maxDepthComplexity, depthOrd[2], pad;
+    uint32_t fragCounter, aoCount, maxDepthComplexity, depthOrd[2], maxNodesPerPixel;
 };
 
 bool parseBool(const char* v) { return strcmp(v, "true") == 0 || strcmp(v, "1") == 0; } // InternalState.hpp:64-71
@@ -409,6 +409,7 @@ int lv_get_stats(lv_ctx* ctx, lv_stats* out) {
         s.ao_rays_traced = hc.aoRays;
         s.ao_nodes_visited = hc.aoNodes;
         s.ao_prims_tested = hc.aoPrims;
+        s.max_nodes_per_pixel = hc.maxNodesPerPixel;
         for (int k = 0; k < 3; k++) { s.ao_phase_iterations[k] = hc.aoPhaseIters[k]; s.ao_phase_lanes[k] = hc.aoPhaseLanes[k]; }
     }
     for (int k = 0; k < 8; k++) { s.ms_kernel_avg[k] = 0.0f; s.kernel_launches[k] = 0; }

@@ -29,9 +29,15 @@ struct LvDevCounters {
     uint32_t aoCount;
     uint32_t maxDepthComplexity;
     uint32_t depthOrd[2]; // encoded min / max for the depth-range reduction
-    uint32_t pad;
+    uint32_t maxNodesPerPixel;
 };
 
+__device__ __forceinline__ void lv_flush_max_nodes(const LvCounters& c, LvDevCounters* dc) {
+    uint32_t m = uint32_t(c.nodes);
+#pragma unroll
+    for (int ofs = 32; ofs > 0; ofs >>= 1) m = max(m, (uint32_t)__shfl_xor(m, ofs, 64));
+    if (lv_lane() == 0) atomicMax(&dc->maxNodesPerPixel, m);
+}
 __device__ __forceinline__ void lv_flush_counters(const LvCounters& c, LvDevCounters* dc, bool aoRays = false) {
     unsigned long long r = lv_wave_sum_u64(c.rays), n = lv_wave_sum_u64(c.nodes), p = lv_wave_sum_u64(c.prims),
                        h = lv_wave_sum_u64(c.hits);
@@ -140,7 +146,7 @@ __global__ __launch_bounds__(LV_BLOCK) void k_render_rt(const LvUniforms U, cons
         f4 c; c.x = U.background[0]; c.y = U.background[1]; c.z = U.background[2]; c.w = U.background[3];
         out[px.outIndex] = lv_pack_unorm4x8(c);
     }
-    if (STATS) lv_flush_counters(cnt, dc);
+    if (STATS) { lv_flush_max_nodes(cnt, dc); lv_flush_counters(cnt, dc); }
 }
 
 // ================================================================ RTAO

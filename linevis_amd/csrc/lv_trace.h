@@ -84,14 +84,20 @@ __device__ __forceinline__ bool lv_intersect_capsule(f3 o, f3 d, f3 p0, f3 p1, f
 // N segments is usually ~log2(N)+10 deep, so LV_STACK_LDS = 32 entries cover the common case entirely in LDS; deeper
 // trees (up to 63 key bits + 32 duplicate-index bits) continue in a per-thread column of a global overflow slab that is
 // only allocated when the built tree is that deep.  All members are scalars so the struct lives in registers.
+// Pointers carry their address space so that pushes/pops compile to ds_write_b32 / ds_read_b32 and
+// global_store / global_load; with generic pointers the two pop paths were merged into one flat_load (which waits on
+// both the LDS and the vector-memory counter).
+typedef __attribute__((address_space(3))) unsigned lv_lds_u32;
+typedef __attribute__((address_space(1))) unsigned lv_glb_u32;
+
 template <int NLDS, int STRIDE = LV_BLOCK>
 struct LvStackT {
-    unsigned* lds;       // &s_stack[threadIdx.x]
-    unsigned* ovf;       // &overflow[global thread], entries strided by ovfStride; may be null if height <= NLDS
+    lv_lds_u32* lds;     // &s_stack[threadIdx.x]
+    lv_glb_u32* ovf;     // &overflow[global thread], entries strided by ovfStride; may be null if height <= NLDS
     unsigned ovfStride;
     int sp;
     __device__ __forceinline__ void init(unsigned* ldsBase, unsigned* ovfBase, unsigned stride) {
-        lds = ldsBase; ovf = ovfBase; ovfStride = stride; sp = 0;
+        lds = (lv_lds_u32*)ldsBase; ovf = (lv_glb_u32*)ovfBase; ovfStride = stride; sp = 0;
     }
     __device__ __forceinline__ void push(unsigned v) {
         if (sp < NLDS) lds[sp * STRIDE] = v;
@@ -100,7 +106,10 @@ struct LvStackT {
     }
     __device__ __forceinline__ unsigned pop() {
         sp--;
-        return sp < NLDS ? lds[sp * STRIDE] : ovf[size_t(sp - NLDS) * ovfStride];
+        unsigned v;
+        if (sp < NLDS) v = lds[sp * STRIDE];
+        else v = ovf[size_t(sp - NLDS) * ovfStride];
+        return v;
     }
 };
 typedef LvStackT<LV_STACK_LDS> LvStack;
@@ -193,8 +202,14 @@ __device__ __forceinline__ LvHit lv_trace_closest(const LvSceneDev& S, float rad
     st.init(sm.lds, sm.ovf, sm.ovfStride);
     unsigned cur = 0;            // root
     unsigned pending = LV_INVALID;
+#ifdef LV_DEBUG_MAXSTEPS
+    int dbgSteps = 0;
+#endif
     while (cur != LV_INVALID || pending != LV_INVALID) {
         while (!(cur & LV_LEAF_BIT)) {
+#ifdef LV_DEBUG_MAXSTEPS
+            if (++dbgSteps > LV_DEBUG_MAXSTEPS) { cur = LV_INVALID; st.sp = 0; break; }
+#endif
             cur = lv_node_step<STATS>(S, cur, oi, inv, tMin, h.t, st, cnt);
             if ((cur & LV_LEAF_BIT) && cur != LV_INVALID && pending == LV_INVALID) {
                 pending = cur;                       // first leaf: park it and keep descending
