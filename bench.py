@@ -140,10 +140,10 @@ def main():
         dist.all_reduce(counters)
     rays_per_frame = float(counters[0].item())
     # algorithmic bytes of ONE k_ao_rays launch on this rank (DESIGN.md "Algorithmic bytes"):
-    # 64 B per BVH node visited + 32 B per segment record tested + 52 B per compacted pixel (48 B G-buffer read,
+    # 128 B per 4-wide BVH node visited + 32 B per segment record tested + 52 B per compacted pixel (48 B G-buffer read,
     # 4 B AO factor write)
-    ao_bytes = st.ao_nodes_visited * 64 + st.ao_prims_tested * 32 + st.ao_hit_pixels * 52
-    frame_bytes = (st.nodes_visited * 64 + st.prims_tested * 32 + st.hits_shaded * 96 + st.ao_hit_pixels * 52
+    ao_bytes = st.ao_nodes_visited * 128 + st.ao_prims_tested * 32 + st.ao_hit_pixels * 52
+    frame_bytes = (st.nodes_visited * 128 + st.prims_tested * 32 + st.hits_shaded * 96 + st.ao_hit_pixels * 52
                    + len(sf.local_tiles) * TILE * TILE * (4 + 4))
 
     for _ in range(args.warmup):

@@ -12,10 +12,13 @@
 //   k_leaves      32-byte segment records + leaf boxes written in Morton order
 //   k_karras      Karras 2012 topology: one thread per internal node
 //   k_refit       bottom-up AABB + height, second arriver continues (agent-scope release/acquire)
-//   k_pack        64-byte nodes holding both child boxes + child references
+//   k_depth       depth of every binary node (walk to the root)
+//   scan          rocPRIM exclusive scan over "even depth" flags -> index of each 4-wide node
+//   k_pack4       collapse two binary levels into one 128-byte 4-wide node (child boxes SoA + child references)
 #include <cstring>
 
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 #include "lv_internal.h"
 
@@ -183,30 +186,75 @@ __global__ __launch_bounds__(LV_BLOCK) void k_refit(int n, const uint32_t* __res
     }
 }
 
-// 64-byte node: q0 = {c0.min.xyz, c0.max.x}, q1 = {c0.max.yz, c1.min.xy}, q2 = {c1.min.z, c1.max.xyz},
-//               q3 = {child0, child1, height, 0} (uint bits)
-__global__ __launch_bounds__(LV_BLOCK) void k_pack(int nInternal, const uint32_t* __restrict__ childL,
-                                                   const uint32_t* __restrict__ childR, const float* __restrict__ leafBox,
-                                                   const float* __restrict__ nodeBox, const uint32_t* __restrict__ height,
-                                                   float4* __restrict__ nodes) {
+// depth of every internal binary node: number of parent hops to the root
+__global__ __launch_bounds__(LV_BLOCK) void k_depth(int nInternal, const uint32_t* __restrict__ parentInternal,
+                                                    uint32_t* __restrict__ depth, uint32_t* __restrict__ evenFlag) {
     int i = blockIdx.x * LV_BLOCK + threadIdx.x;
     if (i >= nInternal) return;
-    uint32_t c0 = childL[i], c1 = childR[i];
-    const float* a = (c0 & LV_LEAF_BIT) ? leafBox + 6 * size_t(c0 & ~LV_LEAF_BIT) : nodeBox + 6 * size_t(c0);
-    const float* b = (c1 & LV_LEAF_BIT) ? leafBox + 6 * size_t(c1 & ~LV_LEAF_BIT) : nodeBox + 6 * size_t(c1);
-    nodes[4 * size_t(i) + 0] = make_float4(a[0], a[1], a[2], a[3]);
-    nodes[4 * size_t(i) + 1] = make_float4(a[4], a[5], b[0], b[1]);
-    nodes[4 * size_t(i) + 2] = make_float4(b[2], b[3], b[4], b[5]);
-    nodes[4 * size_t(i) + 3] = make_float4(__uint_as_float(c0), __uint_as_float(c1), __uint_as_float(height[i]), 0.0f);
+    uint32_t d = 0, p = parentInternal[i];
+    while (p != LV_INVALID) { d++; p = parentInternal[p]; }
+    depth[i] = d;
+    evenFlag[i] = (d & 1u) ? 0u : 1u;
 }
 
-// single-segment scene: one node whose second child is invalid
+// 128-byte 4-wide node = 8 x float4:
+//   q0..q2 = child box minima {x[4]}, {y[4]}, {z[4]};  q3..q5 = child box maxima;  q6 = child references (uint bits,
+//   index | LV_LEAF_BIT for leaves, LV_INVALID for an empty slot);  q7 = {#slots, binary node index, 0, 0}.
+// A wide node is a binary node of even depth together with its (odd-depth) internal children: its slots are the
+// grandchildren, or a child itself where that child is a leaf.
+__global__ __launch_bounds__(LV_BLOCK) void k_pack4(int nInternal, const uint32_t* __restrict__ childL,
+                                                    const uint32_t* __restrict__ childR, const float* __restrict__ leafBox,
+                                                    const float* __restrict__ nodeBox, const uint32_t* __restrict__ evenFlag,
+                                                    const uint32_t* __restrict__ wideIndex, float4* __restrict__ nodes) {
+    int i = blockIdx.x * LV_BLOCK + threadIdx.x;
+    if (i >= nInternal || !evenFlag[i]) return;
+    uint32_t slotRef[4] = {LV_INVALID, LV_INVALID, LV_INVALID, LV_INVALID};
+    float b[4][6];
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+#pragma unroll
+        for (int j = 0; j < 6; j++) b[k][j] = 0.0f;
+    int ns = 0;
+    auto addSlot = [&](uint32_t c) {
+        const float* src;
+        uint32_t ref;
+        if (c & LV_LEAF_BIT) { src = leafBox + 6 * size_t(c & ~LV_LEAF_BIT); ref = c; }
+        else { src = nodeBox + 6 * size_t(c); ref = wideIndex[c]; } // even-depth internal node -> its wide index
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (k == ns) {
+                slotRef[k] = ref;
+#pragma unroll
+                for (int j = 0; j < 6; j++) b[k][j] = src[j];
+            }
+        ns++;
+    };
+    const uint32_t two[2] = {childL[i], childR[i]};
+#pragma unroll
+    for (int side = 0; side < 2; side++) {
+        const uint32_t c = two[side];
+        if (c & LV_LEAF_BIT) addSlot(c);
+        else { addSlot(childL[c]); addSlot(childR[c]); }
+    }
+    float4* out = nodes + 8 * size_t(wideIndex[i]);
+    out[0] = make_float4(b[0][0], b[1][0], b[2][0], b[3][0]);
+    out[1] = make_float4(b[0][1], b[1][1], b[2][1], b[3][1]);
+    out[2] = make_float4(b[0][2], b[1][2], b[2][2], b[3][2]);
+    out[3] = make_float4(b[0][3], b[1][3], b[2][3], b[3][3]);
+    out[4] = make_float4(b[0][4], b[1][4], b[2][4], b[3][4]);
+    out[5] = make_float4(b[0][5], b[1][5], b[2][5], b[3][5]);
+    out[6] = make_float4(__uint_as_float(slotRef[0]), __uint_as_float(slotRef[1]), __uint_as_float(slotRef[2]),
+                         __uint_as_float(slotRef[3]));
+    out[7] = make_float4(__uint_as_float(uint32_t(ns)), __uint_as_float(uint32_t(i)), 0.0f, 0.0f);
+}
+
+// single-segment scene: one node with one occupied slot
 __global__ void k_single_node(const float* __restrict__ leafBox, float4* __restrict__ nodes) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    nodes[0] = make_float4(leafBox[0], leafBox[1], leafBox[2], leafBox[3]);
-    nodes[1] = make_float4(leafBox[4], leafBox[5], 0.0f, 0.0f);
-    nodes[2] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    nodes[3] = make_float4(__uint_as_float(0u | LV_LEAF_BIT), __uint_as_float(LV_INVALID), __uint_as_float(1u), 0.0f);
+    for (int j = 0; j < 6; j++) nodes[j] = make_float4(leafBox[j], 0.0f, 0.0f, 0.0f);
+    nodes[6] = make_float4(__uint_as_float(0u | LV_LEAF_BIT), __uint_as_float(LV_INVALID), __uint_as_float(LV_INVALID),
+                           __uint_as_float(LV_INVALID));
+    nodes[7] = make_float4(__uint_as_float(1u), 0.0f, 0.0f, 0.0f);
 }
 
 inline uint32_t nblocks(uint64_t n) { return uint32_t((n + LV_BLOCK - 1) / LV_BLOCK); }
@@ -229,16 +277,17 @@ int lv_bvh_build(lv_ctx* ctx) {
     const uint32_t nInternal = n > 1 ? n - 1 : 1;
 
     int rc;
-    if ((rc = lv_buf_reserve(ctx, ctx->nodes, size_t(nInternal) * 64))) return rc;
+    // 4-wide nodes: one per even-depth binary node; at most all of them (a degenerate chain has ~n/2)
+    if ((rc = lv_buf_reserve(ctx, ctx->nodes, size_t(nInternal) * 128))) return rc;
     if ((rc = lv_buf_reserve(ctx, ctx->segs, size_t(n) * 32))) return rc;
     if ((rc = lv_buf_reserve(ctx, ctx->leafSeg, size_t(n) * 4))) return rc;
 
     // temporaries
     LvDeviceBuffer boxOrig, leafBox, nodeBox, keysA, keysB, valsA, valsB, childL, childR, parI, parL, height, flags, bounds,
-            sortTmp;
+            sortTmp, depth, evenFlag, wideIndex;
     auto freeAll = [&]() {
         for (LvDeviceBuffer* b : {&boxOrig, &leafBox, &nodeBox, &keysA, &keysB, &valsA, &valsB, &childL, &childR, &parI,
-                                  &parL, &height, &flags, &bounds, &sortTmp})
+                                  &parL, &height, &flags, &bounds, &sortTmp, &depth, &evenFlag, &wideIndex})
             lv_buf_free(*b);
     };
 #define LV_TRY(expr)                 \
@@ -269,6 +318,9 @@ int lv_bvh_build(lv_ctx* ctx) {
     LV_TRY(lv_buf_reserve(ctx, height, size_t(nInternal) * 4));
     LV_TRY(lv_buf_reserve(ctx, flags, size_t(nInternal) * 4));
     LV_TRY(lv_buf_reserve(ctx, bounds, 6 * 4));
+    LV_TRY(lv_buf_reserve(ctx, depth, size_t(nInternal) * 4));
+    LV_TRY(lv_buf_reserve(ctx, evenFlag, size_t(nInternal) * 4));
+    LV_TRY(lv_buf_reserve(ctx, wideIndex, size_t(nInternal) * 4));
 
     LV_HIPF(hipEventRecord(ctx->ev[0], st));
     // bounds: min slots start at ord(+big) = 0xFFFFFFFF-ish, max slots at 0
@@ -304,28 +356,39 @@ int lv_bvh_build(lv_ctx* ctx) {
                                                  (const uint32_t*)parI.ptr, (const uint32_t*)parL.ptr,
                                                  (const float*)leafBox.ptr, (float*)nodeBox.ptr, (uint32_t*)height.ptr,
                                                  (uint32_t*)flags.ptr);
-        k_pack<<<nblocks(nInternal), LV_BLOCK, 0, st>>>(int(nInternal), (const uint32_t*)childL.ptr,
-                                                        (const uint32_t*)childR.ptr, (const float*)leafBox.ptr,
-                                                        (const float*)nodeBox.ptr, (const uint32_t*)height.ptr,
-                                                        (float4*)ctx->nodes.ptr);
+        k_depth<<<nblocks(nInternal), LV_BLOCK, 0, st>>>(int(nInternal), (const uint32_t*)parI.ptr, (uint32_t*)depth.ptr,
+                                                         (uint32_t*)evenFlag.ptr);
+        {
+            size_t tmpBytes = 0;
+            LV_HIPF(rocprim::exclusive_scan(nullptr, tmpBytes, (uint32_t*)evenFlag.ptr, (uint32_t*)wideIndex.ptr, 0u,
+                                            nInternal, rocprim::plus<uint32_t>(), st));
+            LV_TRY(lv_buf_reserve(ctx, sortTmp, tmpBytes ? tmpBytes : 16));
+            LV_HIPF(rocprim::exclusive_scan(sortTmp.ptr, tmpBytes, (uint32_t*)evenFlag.ptr, (uint32_t*)wideIndex.ptr, 0u,
+                                            nInternal, rocprim::plus<uint32_t>(), st));
+        }
+        k_pack4<<<nblocks(nInternal), LV_BLOCK, 0, st>>>(int(nInternal), (const uint32_t*)childL.ptr,
+                                                         (const uint32_t*)childR.ptr, (const float*)leafBox.ptr,
+                                                         (const float*)nodeBox.ptr, (const uint32_t*)evenFlag.ptr,
+                                                         (const uint32_t*)wideIndex.ptr, (float4*)ctx->nodes.ptr);
     }
     LV_HIPF(hipGetLastError());
     LV_HIPF(hipEventRecord(ctx->ev[1], st));
+    uint32_t numWide = 1;
     if (n > 1) {
-        uint32_t h = 0;
+        uint32_t h = 0, lastIdx = 0, lastFlag = 0;
         LV_HIPF(hipMemcpyAsync(&h, height.ptr, 4, hipMemcpyDeviceToHost, st));
+        LV_HIPF(hipMemcpyAsync(&lastIdx, (const uint32_t*)wideIndex.ptr + (nInternal - 1), 4, hipMemcpyDeviceToHost, st));
+        LV_HIPF(hipMemcpyAsync(&lastFlag, (const uint32_t*)evenFlag.ptr + (nInternal - 1), 4, hipMemcpyDeviceToHost, st));
         LV_HIPF(hipStreamSynchronize(st));
-        ctx->bvhDepth = h;
+        ctx->bvhDepth = h;            // height of the binary LBVH; the 4-wide tree is ceil(h / 2) levels high
+        numWide = lastIdx + lastFlag;
     } else {
         LV_HIPF(hipStreamSynchronize(st));
     }
     freeAll();
 #undef LV_TRY
 #undef LV_HIPF
-    if (ctx->bvhDepth > LV_STACK_LDS + LV_STACK_SPILL)
-        return lv_fail(ctx, LV_E_CAPACITY, "LBVH height %u exceeds the traversal stack (%d)", ctx->bvhDepth,
-                       LV_STACK_LDS + LV_STACK_SPILL);
-    ctx->numNodes = nInternal;
+    ctx->numNodes = numWide;
     ctx->accelValid = true;
     ctx->accelLineWidth = ctx->opt.lineWidth;
     ctx->evBuildValid = true;

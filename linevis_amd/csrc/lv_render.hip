@@ -763,8 +763,10 @@ int lv_frame_depth_range(lv_ctx* ctx) {
 // the global part of the traversal stacks: only when the tree is higher than the LDS-staged part
 static int lv_prepare_overflow(lv_ctx* ctx, LvSceneDev& S, uint64_t gridBlocks, uint32_t ldsEntries = LV_STACK_LDS) {
     S.stackOverflow = nullptr;
-    if (ctx->bvhDepth <= ldsEntries) return LV_OK;
-    const uint64_t extra = ctx->bvhDepth - ldsEntries;
+    // the 4-wide tree is ceil(height / 2) levels high and a step pushes at most 3 references
+    const uint64_t maxEntries = 3ull * ((uint64_t(ctx->bvhDepth) + 1) / 2) + 2;
+    if (maxEntries <= ldsEntries) return LV_OK;
+    const uint64_t extra = maxEntries - ldsEntries;
     int rc = lv_buf_reserve(ctx, ctx->stackOverflow, size_t(gridBlocks) * LV_BLOCK * extra * 4);
     if (rc) return rc;
     S.stackOverflow = (unsigned*)ctx->stackOverflow.ptr;

@@ -164,26 +164,49 @@ __device__ __forceinline__ bool lv_leave_node_loop(unsigned pending) {
     return !__any(pending == LV_INVALID) || __popcll(descending) < LV_NODE_MIN_ACTIVE;
 }
 
-// one node step: fetch the 64-byte node, slab-test both child boxes, pick the next reference (near child first)
-template <bool STATS, class STACK>
+// One node step on the 4-wide LBVH: fetch the 128-byte node (7 x dwordx4 of one cache line pair), slab-test the four
+// child boxes, continue with the nearest hit child and push the others far-to-near (ORDERED) so that they pop
+// near-first.  Children may be leaves; the caller looks at the leaf bit of what comes back / pops.
+__device__ __forceinline__ void lv_cswap(float& ka, unsigned& ca, float& kb, unsigned& cb) {
+    const bool sw = kb < ka;
+    const float tk = sw ? kb : ka, uk = sw ? ka : kb;
+    const unsigned tc = sw ? cb : ca, uc = sw ? ca : cb;
+    ka = tk; kb = uk; ca = tc; cb = uc;
+}
+
+template <bool STATS, bool ORDERED = true, class STACK>
 __device__ __forceinline__ unsigned lv_node_step(const LvSceneDev& S, unsigned node, f3 oi, f3 inv, float tMin, float tMax,
                                                  STACK& st, LvCounters& cnt) {
-    const float4 q0 = S.nodes[4 * node + 0];
-    const float4 q1 = S.nodes[4 * node + 1];
-    const float4 q2 = S.nodes[4 * node + 2];
-    const float4 q3 = S.nodes[4 * node + 3];
+    const float4* p = S.nodes + 8 * size_t(node);
+    const float4 mnx = p[0], mny = p[1], mnz = p[2], mxx = p[3], mxy = p[4], mxz = p[5], cf = p[6];
     if (STATS) cnt.nodes++;
-    const unsigned c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
-    float tn0, tn1;
-    const bool hit0 = lv_slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, oi, inv, tMin, tMax, tn0);
-    const bool hit1 = lv_slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, oi, inv, tMin, tMax, tn1) && (c1 != LV_INVALID);
-    if (hit0 && hit1) {
-        const bool swap = tn1 < tn0;
-        st.push(swap ? c0 : c1);
-        return swap ? c1 : c0;
+    unsigned c0 = __float_as_uint(cf.x), c1 = __float_as_uint(cf.y), c2 = __float_as_uint(cf.z), c3 = __float_as_uint(cf.w);
+    float k0, k1, k2, k3;
+    const bool h0 = lv_slab(mnx.x, mny.x, mnz.x, mxx.x, mxy.x, mxz.x, oi, inv, tMin, tMax, k0) && c0 != LV_INVALID;
+    const bool h1 = lv_slab(mnx.y, mny.y, mnz.y, mxx.y, mxy.y, mxz.y, oi, inv, tMin, tMax, k1) && c1 != LV_INVALID;
+    const bool h2 = lv_slab(mnx.z, mny.z, mnz.z, mxx.z, mxy.z, mxz.z, oi, inv, tMin, tMax, k2) && c2 != LV_INVALID;
+    const bool h3 = lv_slab(mnx.w, mny.w, mnz.w, mxx.w, mxy.w, mxz.w, oi, inv, tMin, tMax, k3) && c3 != LV_INVALID;
+    const float INF = __builtin_inff();
+    k0 = h0 ? k0 : INF; k1 = h1 ? k1 : INF; k2 = h2 ? k2 : INF; k3 = h3 ? k3 : INF;
+    c0 = h0 ? c0 : LV_INVALID; c1 = h1 ? c1 : LV_INVALID; c2 = h2 ? c2 : LV_INVALID; c3 = h3 ? c3 : LV_INVALID;
+    if (ORDERED) { // 5-comparator sorting network, misses (key = +inf) sink to the end
+        lv_cswap(k0, c0, k1, c1);
+        lv_cswap(k2, c2, k3, c3);
+        lv_cswap(k0, c0, k2, c2);
+        lv_cswap(k1, c1, k3, c3);
+        lv_cswap(k1, c1, k2, c2);
+    } else {       // any order: only compact the hits to the front
+        if (c0 == LV_INVALID) { c0 = c1; c1 = LV_INVALID; }
+        if (c1 == LV_INVALID) { c1 = c2; c2 = LV_INVALID; }
+        if (c2 == LV_INVALID) { c2 = c3; c3 = LV_INVALID; }
+        if (c0 == LV_INVALID) { c0 = c1; c1 = LV_INVALID; }
+        if (c1 == LV_INVALID) { c1 = c2; c2 = LV_INVALID; }
+        if (c0 == LV_INVALID) { c0 = c1; c1 = LV_INVALID; }
     }
-    if (hit0) return c0;
-    if (hit1) return c1;
+    if (c3 != LV_INVALID) st.push(c3);
+    if (c2 != LV_INVALID) st.push(c2);
+    if (c1 != LV_INVALID) st.push(c1);
+    if (c0 != LV_INVALID) return c0;
     return lv_pop_or_done(st);
 }
 
@@ -251,7 +274,7 @@ __device__ __forceinline__ void lv_trace_all(const LvSceneDev& S, float radius, 
     unsigned pending = LV_INVALID;
     while (cur != LV_INVALID || pending != LV_INVALID) {
         while (!(cur & LV_LEAF_BIT)) {
-            cur = lv_node_step<STATS>(S, cur, oi, inv, tMin, tMax, st, cnt);
+            cur = lv_node_step<STATS, false>(S, cur, oi, inv, tMin, tMax, st, cnt);
             if ((cur & LV_LEAF_BIT) && cur != LV_INVALID && pending == LV_INVALID) {
                 pending = cur;
                 cur = lv_pop_or_done(st);
