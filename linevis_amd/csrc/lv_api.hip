@@ -169,7 +169,7 @@ void lv_destroy(lv_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    for (LvDeviceBuffer* b : {&ctx->points, &ctx->segIdx, &ctx->nodes, &ctx->segs, &ctx->leafSeg, &ctx->tf,
+    for (LvDeviceBuffer* b : {&ctx->points, &ctx->segIdx, &ctx->nodes, &ctx->segs, &ctx->leafSeg, &ctx->segToLeaf, &ctx->tf,
                               &ctx->depthMinMax, &ctx->ao, &ctx->aoGbuf, &ctx->aoList, &ctx->aoSamples, &ctx->counters,
                               &ctx->ppllNodes, &ctx->ppllStart, &ctx->ppllScratch, &ctx->tilesDev, &ctx->outDev,
                               &ctx->scratchRays, &ctx->stackOverflow})
@@ -426,7 +426,7 @@ int lv_get_stats(lv_ctx* ctx, lv_stats* out) {
         s.kernel_launches[k] = uint32_t(n);
     }
     uint64_t bytes = 0;
-    for (const LvDeviceBuffer* b : {&ctx->points, &ctx->segIdx, &ctx->nodes, &ctx->segs, &ctx->leafSeg, &ctx->tf,
+    for (const LvDeviceBuffer* b : {&ctx->points, &ctx->segIdx, &ctx->nodes, &ctx->segs, &ctx->leafSeg, &ctx->segToLeaf, &ctx->tf,
                                     &ctx->depthMinMax, &ctx->ao, &ctx->aoGbuf, &ctx->aoList, &ctx->aoSamples,
                                     &ctx->counters, &ctx->ppllNodes, &ctx->ppllStart, &ctx->ppllScratch, &ctx->tilesDev,
                                     &ctx->outDev, &ctx->scratchRays, &ctx->stackOverflow})

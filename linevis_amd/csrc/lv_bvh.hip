@@ -83,7 +83,7 @@ __global__ __launch_bounds__(LV_BLOCK) void k_leaves(const lv_line_point* __rest
                                                      const uint32_t* __restrict__ segIdx, const float* __restrict__ boxOrig,
                                                      const uint32_t* __restrict__ sortedVals, uint32_t nSeg,
                                                      float4* __restrict__ segs, uint32_t* __restrict__ leafSeg,
-                                                     float* __restrict__ leafBox) {
+                                                     uint32_t* __restrict__ segToLeaf, float* __restrict__ leafBox) {
     uint32_t i = blockIdx.x * LV_BLOCK + threadIdx.x;
     if (i >= nSeg) return;
     uint32_t s = sortedVals[i];
@@ -92,6 +92,7 @@ __global__ __launch_bounds__(LV_BLOCK) void k_leaves(const lv_line_point* __rest
     segs[2 * size_t(i)] = make_float4(a.linePosition[0], a.linePosition[1], a.linePosition[2], a.lineAttribute);
     segs[2 * size_t(i) + 1] = make_float4(b.linePosition[0], b.linePosition[1], b.linePosition[2], b.lineAttribute);
     leafSeg[i] = s;
+    segToLeaf[s] = i;
 #pragma unroll
     for (int k = 0; k < 6; k++) leafBox[6 * size_t(i) + k] = boxOrig[6 * size_t(s) + k];
 }
@@ -281,6 +282,7 @@ int lv_bvh_build(lv_ctx* ctx) {
     if ((rc = lv_buf_reserve(ctx, ctx->nodes, size_t(nInternal) * 128))) return rc;
     if ((rc = lv_buf_reserve(ctx, ctx->segs, size_t(n) * 32))) return rc;
     if ((rc = lv_buf_reserve(ctx, ctx->leafSeg, size_t(n) * 4))) return rc;
+    if ((rc = lv_buf_reserve(ctx, ctx->segToLeaf, size_t(n) * 4))) return rc;
 
     // temporaries
     LvDeviceBuffer boxOrig, leafBox, nodeBox, keysA, keysB, valsA, valsB, childL, childR, parI, parL, height, flags, bounds,
@@ -343,7 +345,8 @@ int lv_bvh_build(lv_ctx* ctx) {
     }
     k_leaves<<<nblocks(n), LV_BLOCK, 0, st>>>((const lv_line_point*)ctx->points.ptr, (const uint32_t*)ctx->segIdx.ptr,
                                               (const float*)boxOrig.ptr, (const uint32_t*)valsB.ptr, n,
-                                              (float4*)ctx->segs.ptr, (uint32_t*)ctx->leafSeg.ptr, (float*)leafBox.ptr);
+                                              (float4*)ctx->segs.ptr, (uint32_t*)ctx->leafSeg.ptr, (uint32_t*)ctx->segToLeaf.ptr,
+                                              (float*)leafBox.ptr);
     if (n == 1) {
         k_single_node<<<1, 64, 0, st>>>((const float*)leafBox.ptr, (float4*)ctx->nodes.ptr);
         ctx->bvhDepth = 1;

@@ -22,6 +22,9 @@
 #ifndef LV_AO_CHUNK
 #define LV_AO_CHUNK 1024        // AO rays a wave takes from the global queue per atomic
 #endif
+#ifndef LV_SORT_CHILDREN
+#define LV_SORT_CHILDREN 0       // 1: fully sort the hit children of a node; 0: nearest first, rest unordered
+#endif
 #ifndef LV_AO_STACK_LDS
 #define LV_AO_STACK_LDS 16      // LDS-staged stack entries per thread in k_ao_rays (deeper entries: HBM overflow slab)
 #endif
@@ -91,6 +94,7 @@ struct LvSceneDev {
     const float4* nodes;        // 128-B 4-wide LBVH nodes, 8 x float4 each (layout: lv_bvh.hip k_pack4)
     const float4* segs;         // 32-B segment records in Morton (leaf) order: {p0.xyz, attr0}, {p1.xyz, attr1}
     const uint32_t* leafSeg;    // leaf position -> original segment index
+    const uint32_t* segToLeaf;  // original segment index -> leaf position
     const lv_line_point* points;// 48-B point records, input order
     const uint32_t* segIdx;     // 2 point indices per original segment
     const float4* tf;           // transfer function texels

@@ -87,36 +87,42 @@ __device__ __forceinline__ bool lv_block_pixel(const LvUniforms& U, const LvTile
 }
 
 // ================================================================ ray tracer colour pass
+// Control flow is wave-uniform around every trace (lv_trace_closest is a wave-cooperative routine): the sample loop and
+// the transparency loop run while ANY lane of the wave still needs a trace; lanes that are done pass active = false.
 template <bool STATS>
 __global__ __launch_bounds__(LV_BLOCK) void k_render_rt(const LvUniforms U, const LvSceneDev S, const LvTiles T,
                                                         uint32_t* __restrict__ out, LvDevCounters* dc) {
     __shared__ unsigned s_stack[LV_STACK_LDS * LV_BLOCK];
+    LV_COOP_SHARED(LV_BLOCK / LV_WAVE);
+    LV_COOP_MEM(cm);
     LvPixel px;
     if (!lv_block_pixel(U, T, px)) return;
+    const LvStackMem sm = lv_stack_mem(s_stack, S.stackOverflow);
     LvCounters cnt = {0, 0, 0, 0};
-    if (px.inView) {
-        const bool capped = U.useCappedTubes != 0;
-        const float HIT_DISTANCE_EPSILON = 1e-5f;
-        const float aoTexel = U.useAmbientOcclusion ? S.ao[size_t(px.y) * U.width + px.x] : 1.0f;
-        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-        const uint32_t nSamples = U.useJitteredRays ? U.numSamplesPerFrame : 1u;
-        for (uint32_t sampleIdx = 0; sampleIdx < nSamples; sampleIdx++) {
-            float xix = 0.5f, xiy = 0.5f;
-            if (U.useJitteredRays) {
-                uint32_t seed = U.useDeterministicSampling
-                        ? lv_tea(19u, U.frameNumber * U.numSamplesPerFrame + sampleIdx)
-                        : lv_tea(px.x + px.y * U.width, U.frameNumber * U.numSamplesPerFrame + sampleIdx);
-                xix = lv_rnd(seed);
-                xiy = lv_rnd(seed);
-            }
-            f3 o, d;
-            lv_primary_ray(U, px.x, px.y, xix, xiy, o, d);
-            // traceRayTransparent, TubeRayTracing.glsl:61-82
-            float fc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-            float tMin = 0.0001f;
-            const float tMax = 1000.0f;
-            for (uint32_t hitIdx = 0; hitIdx < U.maxDepthComplexity; hitIdx++) {
-                LvHit h = lv_trace_closest<STATS, false>(S, U.radius, capped, o, d, tMin, tMax, lv_stack_mem(s_stack, S.stackOverflow), cnt);
+    const bool capped = U.useCappedTubes != 0;
+    const float HIT_DISTANCE_EPSILON = 1e-5f;
+    const float aoTexel = (px.inView && U.useAmbientOcclusion) ? S.ao[size_t(px.y) * U.width + px.x] : 1.0f;
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    const uint32_t nSamples = U.useJitteredRays ? U.numSamplesPerFrame : 1u;
+    for (uint32_t sampleIdx = 0; sampleIdx < nSamples; sampleIdx++) { // uniform trip count
+        float xix = 0.5f, xiy = 0.5f;
+        if (U.useJitteredRays) {
+            uint32_t seed = U.useDeterministicSampling
+                    ? lv_tea(19u, U.frameNumber * U.numSamplesPerFrame + sampleIdx)
+                    : lv_tea(px.x + px.y * U.width, U.frameNumber * U.numSamplesPerFrame + sampleIdx);
+            xix = lv_rnd(seed);
+            xiy = lv_rnd(seed);
+        }
+        f3 o, d;
+        lv_primary_ray(U, px.x, px.y, xix, xiy, o, d);
+        // traceRayTransparent, TubeRayTracing.glsl:61-82
+        float fc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        float tMin = 0.0001f;
+        const float tMax = 1000.0f;
+        bool tracing = px.inView;
+        for (uint32_t hitIdx = 0; hitIdx < U.maxDepthComplexity && __any(tracing); hitIdx++) {
+            LvHit h = lv_trace_closest<STATS, false>(S, U.radius, capped, tracing, o, d, tMin, tMax, sm, cm, cnt);
+            if (tracing) {
                 f4 hc;
                 float payloadHitT;
                 if (h.found) {
@@ -131,11 +137,13 @@ __global__ __launch_bounds__(LV_BLOCK) void k_render_rt(const LvUniforms U, cons
                 fc[1] = fc[1] + ((1.0f - fc[3]) * hc.w) * hc.y;
                 fc[2] = fc[2] + ((1.0f - fc[3]) * hc.w) * hc.z;
                 fc[3] = fc[3] + (1.0f - fc[3]) * hc.w;
-                if (!h.found || fc[3] > 0.99f) break;
+                if (!h.found || fc[3] > 0.99f) tracing = false;
             }
-#pragma unroll
-            for (int k = 0; k < 4; k++) acc[k] += fc[k];
         }
+#pragma unroll
+        for (int k = 0; k < 4; k++) acc[k] += fc[k];
+    }
+    if (px.inView) {
         if (U.useJitteredRays) {
 #pragma unroll
             for (int k = 0; k < 4; k++) acc[k] /= float(U.numSamplesPerFrame);
@@ -157,21 +165,24 @@ __global__ __launch_bounds__(LV_BLOCK) void k_ao_primary(const LvUniforms U, con
                                                          float* __restrict__ ao, float4* __restrict__ gbuf,
                                                          LvDevCounters* dc) {
     __shared__ unsigned s_stack[LV_STACK_LDS * LV_BLOCK];
+    LV_COOP_SHARED(LV_BLOCK / LV_WAVE);
+    LV_COOP_MEM(cm);
     LvPixel px;
     if (!lv_block_pixel(U, T, px)) return;
     LvCounters cnt = {0, 0, 0, 0};
     bool hasHit = false;
     float4 g0, g1, g2;
+    const uint32_t pix = px.x + px.y * U.width;
+    const uint32_t globalFrameNumber = U.aoFrameNumber; // VulkanRayTracedAmbientOcclusion.cpp:576-581
+    uint32_t seed = lv_tea(pix, globalFrameNumber);
+    float xix = 0.5f, xiy = 0.5f;
+    if (U.aoJitterPrimary) { xix = lv_rnd(seed); xiy = lv_rnd(seed); }
+    f3 o, d;
+    lv_primary_ray(U, px.x, px.y, xix, xiy, o, d);
+    // wave-cooperative: every lane calls, lanes outside the viewport only help testing
+    const LvHit h = lv_trace_closest<STATS, false>(S, U.radius, U.useCappedTubes != 0, px.inView, o, d, 0.0001f, 1000.0f,
+                                                   lv_stack_mem(s_stack, S.stackOverflow), cm, cnt);
     if (px.inView) {
-        const uint32_t pix = px.x + px.y * U.width;
-        const uint32_t globalFrameNumber = U.aoFrameNumber; // VulkanRayTracedAmbientOcclusion.cpp:576-581
-        uint32_t seed = lv_tea(pix, globalFrameNumber);
-        float xix = 0.5f, xiy = 0.5f;
-        if (U.aoJitterPrimary) { xix = lv_rnd(seed); xiy = lv_rnd(seed); }
-        f3 o, d;
-        lv_primary_ray(U, px.x, px.y, xix, xiy, o, d);
-        LvHit h = lv_trace_closest<STATS, false>(S, U.radius, U.useCappedTubes != 0, o, d, 0.0001f, 1000.0f,
-                                                 lv_stack_mem(s_stack, S.stackOverflow), cnt);
         if (h.found) {
             hasHit = true;
             const float4 ra = S.segs[2 * h.leaf], rb = S.segs[2 * h.leaf + 1];
@@ -647,12 +658,17 @@ __global__ __launch_bounds__(LV_BLOCK) void k_trace_rays(const LvSceneDev S, flo
                                                          float tMin, float tMax, uint32_t n, float* __restrict__ outT,
                                                          uint32_t* __restrict__ outSeg, uint32_t* __restrict__ outKind) {
     __shared__ unsigned s_stack[LV_STACK_LDS * LV_BLOCK];
+    LV_COOP_SHARED(LV_BLOCK / LV_WAVE);
+    LV_COOP_MEM(cm);
     const uint32_t i = blockIdx.x * LV_BLOCK + threadIdx.x;
-    if (i >= n) return;
+    const bool valid = i < n;
     LvCounters cnt = {0, 0, 0, 0};
-    f3 o = mk3(org[3 * i], org[3 * i + 1], org[3 * i + 2]);
-    f3 d = mk3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]);
-    LvHit h = lv_trace_closest<false, false>(S, radius, capped != 0, o, d, tMin, tMax, lv_stack_mem(s_stack, S.stackOverflow), cnt);
+    const uint32_t j = valid ? i : 0u;
+    f3 o = mk3(org[3 * j], org[3 * j + 1], org[3 * j + 2]);
+    f3 d = mk3(dir[3 * j], dir[3 * j + 1], dir[3 * j + 2]);
+    LvHit h = lv_trace_closest<false, false>(S, radius, capped != 0, valid, o, d, tMin, tMax,
+                                             lv_stack_mem(s_stack, S.stackOverflow), cm, cnt);
+    if (!valid) return;
     outT[i] = h.found ? h.t : tMax;
     outSeg[i] = h.found ? S.leafSeg[h.leaf] : 0xFFFFFFFFu;
     outKind[i] = h.found ? uint32_t(h.kind) : 0u;
@@ -671,6 +687,7 @@ LvSceneDev sceneDev(const lv_ctx* ctx) {
     S.nodes = (const float4*)ctx->nodes.ptr;
     S.segs = (const float4*)ctx->segs.ptr;
     S.leafSeg = (const uint32_t*)ctx->leafSeg.ptr;
+    S.segToLeaf = (const uint32_t*)ctx->segToLeaf.ptr;
     S.points = (const lv_line_point*)ctx->points.ptr;
     S.segIdx = (const uint32_t*)ctx->segIdx.ptr;
     S.tf = (const float4*)ctx->tf.ptr;

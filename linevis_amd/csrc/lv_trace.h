@@ -92,6 +92,8 @@ typedef __attribute__((address_space(1))) unsigned lv_glb_u32;
 
 template <int NLDS, int STRIDE = LV_BLOCK>
 struct LvStackT {
+    static constexpr int kLds = NLDS;
+    static constexpr int kStride = STRIDE;
     lv_lds_u32* lds;     // &s_stack[threadIdx.x]
     lv_glb_u32* ovf;     // &overflow[global thread], entries strided by ovfStride; may be null if height <= NLDS
     unsigned ovfStride;
@@ -189,74 +191,149 @@ __device__ __forceinline__ unsigned lv_node_step(const LvSceneDev& S, unsigned n
     const float INF = __builtin_inff();
     k0 = h0 ? k0 : INF; k1 = h1 ? k1 : INF; k2 = h2 ? k2 : INF; k3 = h3 ? k3 : INF;
     c0 = h0 ? c0 : LV_INVALID; c1 = h1 ? c1 : LV_INVALID; c2 = h2 ? c2 : LV_INVALID; c3 = h3 ? c3 : LV_INVALID;
+#if LV_SORT_CHILDREN
     if (ORDERED) { // 5-comparator sorting network, misses (key = +inf) sink to the end
         lv_cswap(k0, c0, k1, c1);
         lv_cswap(k2, c2, k3, c3);
         lv_cswap(k0, c0, k2, c2);
         lv_cswap(k1, c1, k3, c3);
         lv_cswap(k1, c1, k2, c2);
-    } else {       // any order: only compact the hits to the front
-        if (c0 == LV_INVALID) { c0 = c1; c1 = LV_INVALID; }
-        if (c1 == LV_INVALID) { c1 = c2; c2 = LV_INVALID; }
-        if (c2 == LV_INVALID) { c2 = c3; c3 = LV_INVALID; }
-        if (c0 == LV_INVALID) { c0 = c1; c1 = LV_INVALID; }
-        if (c1 == LV_INVALID) { c1 = c2; c2 = LV_INVALID; }
-        if (c0 == LV_INVALID) { c0 = c1; c1 = LV_INVALID; }
     }
-    if (c3 != LV_INVALID) st.push(c3);
-    if (c2 != LV_INVALID) st.push(c2);
-    if (c1 != LV_INVALID) st.push(c1);
+#else
+    if (ORDERED) { // only the nearest hit child matters for "descend first"; the others are pushed as they come
+        lv_cswap(k0, c0, k1, c1);
+        lv_cswap(k2, c2, k3, c3);
+        lv_cswap(k0, c0, k2, c2);
+    }
+#endif
+    // Pushes: write unconditionally and advance the stack pointer only for real references (no branches) as long as
+    // the three slots are inside the LDS part; the rare deep case takes the checked path.
+    if (st.sp + 3 <= STACK::kLds) {
+        st.lds[st.sp * STACK::kStride] = c3; st.sp += (c3 != LV_INVALID) ? 1 : 0;
+        st.lds[st.sp * STACK::kStride] = c2; st.sp += (c2 != LV_INVALID) ? 1 : 0;
+        st.lds[st.sp * STACK::kStride] = c1; st.sp += (c1 != LV_INVALID) ? 1 : 0;
+    } else {
+        if (c3 != LV_INVALID) st.push(c3);
+        if (c2 != LV_INVALID) st.push(c2);
+        if (c1 != LV_INVALID) st.push(c1);
+    }
     if (c0 != LV_INVALID) return c0;
     return lv_pop_or_done(st);
 }
 
-// Closest hit with reportIntersectionEXT semantics: accepted iff tMin <= t <= tMax; ties -> lowest original
-// segment index.  ANY_HIT: return at the first accepted hit (gl_RayFlagsTerminateOnFirstHitEXT).
+// ---------------------------------------------------------------- wave-cooperative closest hit
+// Per-wave LDS scratch of the cooperative routines: the ray of every lane, its best-hit key and a FIFO of
+// (owner lane, leaf) pairs waiting for a capsule test.
+#define LV_QCAP 256u                      // FIFO entries per wave (< 64 waiting + up to 3 x 64 new per node step)
+struct LvCoopMem {
+    float4* ray;                   // [2 * 64]  {o.xyz, -}{d.xyz, -}
+    unsigned long long* key;       // [64]      (t bits << 32) | (original segment << 2) | kind
+    unsigned* queue;               // [LV_QCAP] (owner lane << 26) | leaf
+};
+#define LV_COOP_SHARED(NWAVES)                                   \
+    __shared__ float4 s_coopRay[2 * LV_WAVE * (NWAVES)];         \
+    __shared__ unsigned long long s_coopKey[LV_WAVE * (NWAVES)]; \
+    __shared__ unsigned s_coopQueue[(NWAVES)][LV_QCAP]
+#define LV_COOP_MEM(cm)                                          \
+    LvCoopMem cm;                                                \
+    cm.ray = &s_coopRay[2 * LV_WAVE * (threadIdx.x >> 6)];       \
+    cm.key = &s_coopKey[LV_WAVE * (threadIdx.x >> 6)];           \
+    cm.queue = s_coopQueue[threadIdx.x >> 6]
+
+// Closest hit with reportIntersectionEXT semantics (accepted iff tMin <= t <= tMax; ties -> lowest original segment
+// index), computed by the whole wave together: EVERY lane of the wave must call this function in convergent control
+// flow, lanes without a ray pass active = false and only lend their ALUs.
+//   descend  lanes with an inner node do node steps on the 4-wide LBVH (LDS-staged stack); a lane never tests the
+//            leaves it meets, it appends (lane, leaf) to the wave's FIFO (ballot + prefix popcount, no atomics);
+//   test     when 64 pairs wait (or nobody can descend) each lane takes one pair, reads the owner's ray from LDS,
+//            runs the capsule test and merges with one 64-bit LDS atomicMin on the owner's key.
+// So the expensive test (8 IEEE divisions + 4 square roots, ~350 instructions) always runs at full width, and a single
+// long ray that meets hundreds of leaves -- the tail that bounded the one-ray-per-thread kernels -- has them tested 64
+// at a time by the lanes that already finished.  ANY_HIT: gl_RayFlagsTerminateOnFirstHitEXT.
 template <bool STATS, bool ANY_HIT>
-__device__ __forceinline__ LvHit lv_trace_closest(const LvSceneDev& S, float radius, bool capped, f3 o, f3 d, float tMin,
-                                                  float tMax, const LvStackMem& sm, LvCounters& cnt) {
+__device__ __forceinline__ LvHit lv_trace_closest(const LvSceneDev& S, float radius, bool capped, bool active, f3 o, f3 d,
+                                                  float tMin, float tMax, const LvStackMem& sm, const LvCoopMem& cm,
+                                                  LvCounters& cnt) {
+    const unsigned lane = lv_lane();
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const unsigned long long keyInit = ((unsigned long long)__float_as_uint(tMax) << 32) | 0xFFFFFFFFull;
+    active = active && S.numSegs != 0;
     LvHit h;
     h.t = tMax; h.leaf = LV_INVALID; h.kind = 0; h.found = false;
-    if (STATS) cnt.rays++;
-    if (S.numSegs == 0) return h;
+    if (STATS && active) cnt.rays++;
     const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     const f3 oi = mk3(o.x * inv.x, o.y * inv.y, o.z * inv.z);
     LvStack st;
     st.init(sm.lds, sm.ovf, sm.ovfStride);
-    unsigned cur = 0;            // root
-    unsigned pending = LV_INVALID;
-#ifdef LV_DEBUG_MAXSTEPS
-    int dbgSteps = 0;
-#endif
-    while (cur != LV_INVALID || pending != LV_INVALID) {
-        while (!(cur & LV_LEAF_BIT)) {
-#ifdef LV_DEBUG_MAXSTEPS
-            if (++dbgSteps > LV_DEBUG_MAXSTEPS) { cur = LV_INVALID; st.sp = 0; break; }
-#endif
-            cur = lv_node_step<STATS>(S, cur, oi, inv, tMin, h.t, st, cnt);
-            if ((cur & LV_LEAF_BIT) && cur != LV_INVALID && pending == LV_INVALID) {
-                pending = cur;                       // first leaf: park it and keep descending
+    cm.ray[2 * lane] = make_float4(o.x, o.y, o.z, tMin);
+    cm.ray[2 * lane + 1] = make_float4(d.x, d.y, d.z, tMax);
+    cm.key[lane] = keyInit;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    unsigned cur = active ? 0u : LV_INVALID;
+    unsigned head = 0, tail = 0;
+    float best = tMax;
+    while (true) {
+        // leaves reached by the last step (or popped) join the FIFO
+        const bool isLeaf = cur != LV_INVALID && (cur & LV_LEAF_BIT);
+        const unsigned long long mL = __ballot(isLeaf);
+        if (mL) {
+            if (isLeaf) {
+                cm.queue[(tail + unsigned(__popcll(mL & below))) % LV_QCAP] = (lane << 26) | (cur & 0x03FFFFFFu);
                 cur = lv_pop_or_done(st);
             }
-            if (lv_leave_node_loop(pending)) break;
+            tail += unsigned(__popcll(mL));
+            if (tail - head < LV_WAVE) continue; // a popped reference may be a leaf again
         }
-        while (pending != LV_INVALID) {
-            const unsigned leaf = pending & ~LV_LEAF_BIT;
-            const float4 a = S.segs[2 * leaf], b = S.segs[2 * leaf + 1];
-            if (STATS) cnt.prims++;
-            float t; int kind;
-            if (lv_intersect_capsule(o, d, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), radius, capped, t, kind)) {
-                if (t >= tMin && t <= tMax) {
-                    bool take = !h.found || t < h.t;
-                    if (!take && t == h.t) take = S.leafSeg[leaf] < S.leafSeg[h.leaf];
-                    if (take) { h.found = true; h.t = t; h.leaf = leaf; h.kind = kind; }
+        const int nNode = __popcll(__ballot(!(cur & LV_LEAF_BIT)));
+        const unsigned q = tail - head;
+        if (q >= LV_WAVE || (q > 0 && nNode == 0)) {
+            const unsigned n = q < LV_WAVE ? q : LV_WAVE;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (lane < n) {
+                const unsigned e = cm.queue[(head + lane) % LV_QCAP];
+                const unsigned owner = e >> 26, leaf = e & 0x03FFFFFFu;
+                const float4 ro = cm.ray[2 * owner], rd = cm.ray[2 * owner + 1];
+                const float4 a = S.segs[2 * leaf], b = S.segs[2 * leaf + 1];
+                if (STATS) cnt.prims++;
+                float t; int kind;
+                if (lv_intersect_capsule(mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), mk3(a.x, a.y, a.z),
+                                         mk3(b.x, b.y, b.z), radius, capped, t, kind)) {
+                    if (t >= ro.w && t <= rd.w)
+                        atomicMin(&cm.key[owner], ((unsigned long long)__float_as_uint(t) << 32)
+                                                          | ((unsigned long long)S.leafSeg[leaf] << 2) | unsigned(kind));
                 }
             }
-            pending = LV_INVALID;
-            if ((cur & LV_LEAF_BIT) && cur != LV_INVALID) { pending = cur; cur = lv_pop_or_done(st); }
+            head += n;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            const unsigned long long key = cm.key[lane];
+            best = __uint_as_float(unsigned(key >> 32)); // shrinks the slab interval of the following node steps
+            if (ANY_HIT && key != keyInit) { cur = LV_INVALID; st.sp = 0; }
+            continue;
         }
-        if (ANY_HIT && h.found) return h;
+        if (nNode == 0) break;
+        int nNow;
+        do { // tight descend loop
+            if (!(cur & LV_LEAF_BIT)) cur = lv_node_step<STATS>(S, cur, oi, inv, tMin, best, st, cnt);
+            const bool lf = cur != LV_INVALID && (cur & LV_LEAF_BIT);
+            const unsigned long long m = __ballot(lf);
+            if (m) {
+                if (lf) {
+                    cm.queue[(tail + unsigned(__popcll(m & below))) % LV_QCAP] = (lane << 26) | (cur & 0x03FFFFFFu);
+                    cur = lv_pop_or_done(st);
+                }
+                tail += unsigned(__popcll(m));
+            }
+            nNow = __popcll(__ballot(!(cur & LV_LEAF_BIT)));
+        } while (tail - head < LV_WAVE && nNow > 0);
     }
+    const unsigned long long key = cm.key[lane];
+    if (active && key != keyInit) {
+        h.found = true;
+        h.t = __uint_as_float(unsigned(key >> 32));
+        h.kind = int(unsigned(key) & 3u);
+        h.leaf = S.segToLeaf[(unsigned(key) >> 2)];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // the scratch is reused by the next call
     return h;
 }
 
