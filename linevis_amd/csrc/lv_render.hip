@@ -472,41 +472,49 @@ __global__ __launch_bounds__(LV_BLOCK) void k_ppll_gather(const LvUniforms U, co
                                                           uint32_t* __restrict__ nodes, uint32_t* __restrict__ startOffset,
                                                           LvDevCounters* dc) {
     __shared__ unsigned s_stack[LV_STACK_LDS * LV_BLOCK];
+    __shared__ uint32_t s_head[LV_BLOCK];  // list head of every thread's pixel (startOffset[pixel] while gathering)
+    __shared__ uint32_t s_count[LV_BLOCK]; // fragments of every thread's pixel
+    LV_COOP_SHARED(LV_BLOCK / LV_WAVE);
+    LV_COOP_MEM(cm);
     LvPixel px;
     if (!lv_block_pixel(U, T, px)) return;
     LvCounters cnt = {0, 0, 0, 0};
-    uint32_t numFrags = 0;
-    if (px.inView) {
-        const float aoTexel = U.useAmbientOcclusion ? S.ao[size_t(px.y) * U.width + px.x] : 1.0f;
-        f3 o, d;
-        lv_primary_ray(U, px.x, px.y, 0.5f, 0.5f, o, d);
-        uint32_t head = 0xFFFFFFFFu;
-        lv_trace_all<STATS>(S, U.radius, U.useCappedTubes != 0, o, d, 0.0001f, 1000.0f, lv_stack_mem(s_stack, S.stackOverflow), cnt,
-                            [&](uint32_t leaf, float t, int kind) {
-            LvHit h; h.t = t; h.leaf = leaf; h.kind = kind; h.found = true;
-            float hitT;
-            f4 color = lv_shade_hit(S, U, aoTexel, o, d, h, hitT);
-            if (STATS) cnt.hits++;
-            if (color.w < 0.001f) return; // gatherFragment: discard, LinkedListGather.glsl:34
-            // wave-aggregated atomicAdd(fragCounter, 1): one atomic for all lanes that append right now
-            const unsigned long long mask = __ballot(1);
-            const unsigned lane = lv_lane();
-            const int leader = __ffsll((long long)mask) - 1;
-            unsigned base = 0;
-            if (int(lane) == leader) base = atomicAdd(&dc->fragCounter, unsigned(__popcll(mask)));
-            base = __shfl(base, leader, 64);
-            const uint32_t insertIndex = base + unsigned(__popcll(mask & ((1ull << lane) - 1ull)));
-            numFrags++;
-            if (insertIndex < U.ppllLinkedListSize) {
-                // this thread owns the pixel, so atomicExchange(startOffset[pixel]) reduces to a register
-                nodes[3 * size_t(insertIndex) + 0] = lv_pack_unorm4x8(color);
-                nodes[3 * size_t(insertIndex) + 1] = __float_as_uint(hitT);
-                nodes[3 * size_t(insertIndex) + 2] = head;
-                head = insertIndex;
-            }
-        });
-        startOffset[lv_ppll_addr(px.x, px.y, U.ppllPaddedW, U.ppllTileW, U.ppllTileH)] = head;
-    }
+    const unsigned waveBase = threadIdx.x & ~63u;
+    s_head[threadIdx.x] = 0xFFFFFFFFu;
+    s_count[threadIdx.x] = 0u;
+    const float aoTexel = (px.inView && U.useAmbientOcclusion) ? S.ao[size_t(px.y) * U.width + px.x] : 1.0f;
+    f3 o, d;
+    lv_primary_ray(U, px.x, px.y, 0.5f, 0.5f, o, d);
+    // Fragments of a pixel are produced by whichever lane tests the (pixel, segment) pair: the lane shades with the
+    // owner's ray + AO texel and links the node with an LDS atomic exchange on the owner's list head (the reference's
+    // atomicExchange(startOffset[pixel]), LinkedListGather.glsl:55, kept in LDS until the pixel is finished).
+    lv_trace_all<STATS>(S, U.radius, U.useCappedTubes != 0, px.inView, o, d, 0.0001f, 1000.0f, aoTexel, 0.0f,
+                        lv_stack_mem(s_stack, S.stackOverflow), cm, cnt,
+                        [&](unsigned owner, uint32_t leaf, float t, int kind, f3 ro, f3 rd, float ownerAo, float) {
+        LvHit h; h.t = t; h.leaf = leaf; h.kind = kind; h.found = true;
+        float hitT;
+        f4 color = lv_shade_hit(S, U, ownerAo, ro, rd, h, hitT);
+        if (STATS) cnt.hits++;
+        if (color.w < 0.001f) return; // gatherFragment: discard, LinkedListGather.glsl:34
+        // wave-aggregated atomicAdd(fragCounter, 1): one atomic for all lanes that append right now
+        const unsigned long long mask = __ballot(1);
+        const unsigned lane = lv_lane();
+        const int leader = __ffsll((long long)mask) - 1;
+        unsigned base = 0;
+        if (int(lane) == leader) base = atomicAdd(&dc->fragCounter, unsigned(__popcll(mask)));
+        base = __shfl(base, leader, 64);
+        const uint32_t insertIndex = base + unsigned(__popcll(mask & ((1ull << lane) - 1ull)));
+        atomicAdd(&s_count[waveBase + owner], 1u);
+        if (insertIndex < U.ppllLinkedListSize) {
+            const uint32_t next = atomicExch(&s_head[waveBase + owner], insertIndex);
+            nodes[3 * size_t(insertIndex) + 0] = lv_pack_unorm4x8(color);
+            nodes[3 * size_t(insertIndex) + 1] = __float_as_uint(hitT);
+            nodes[3 * size_t(insertIndex) + 2] = next;
+        }
+    });
+    uint32_t numFrags = s_count[threadIdx.x];
+    if (px.inView)
+        startOffset[lv_ppll_addr(px.x, px.y, U.ppllPaddedW, U.ppllTileW, U.ppllTileH)] = s_head[threadIdx.x];
     uint32_t m = numFrags;
 #pragma unroll
     for (int ofs = 32; ofs > 0; ofs >>= 1) m = max(m, (uint32_t)__shfl_xor(m, ofs, 64));

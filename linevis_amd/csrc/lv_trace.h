@@ -337,39 +337,76 @@ __device__ __forceinline__ LvHit lv_trace_closest(const LvSceneDev& S, float rad
     return h;
 }
 
-// All capsule entry hits in [tMin, tMax] (PPLL fragment generation); f(leaf, t, kind) per hit.
+// All capsule entry hits in [tMin, tMax] (PPLL fragment generation), wave-cooperative like lv_trace_closest: every
+// lane of the wave calls it; (owner, leaf) pairs are tested 64 at a time by whichever lanes are free, and the lane
+// that finds a hit calls f(owner, leaf, t, kind, o, d, w0, w1) with the OWNER's ray and its two payload words
+// (cm.ray[..].w), i.e. fragments of one pixel may be produced by any lane.
 template <bool STATS, typename F>
-__device__ __forceinline__ void lv_trace_all(const LvSceneDev& S, float radius, bool capped, f3 o, f3 d, float tMin,
-                                             float tMax, const LvStackMem& sm, LvCounters& cnt, F&& f) {
-    if (STATS) cnt.rays++;
-    if (S.numSegs == 0) return;
+__device__ __forceinline__ void lv_trace_all(const LvSceneDev& S, float radius, bool capped, bool active, f3 o, f3 d,
+                                             float tMin, float tMax, float w0, float w1, const LvStackMem& sm,
+                                             const LvCoopMem& cm, LvCounters& cnt, F&& f) {
+    const unsigned lane = lv_lane();
+    const unsigned long long below = (1ull << lane) - 1ull;
+    active = active && S.numSegs != 0;
+    if (STATS && active) cnt.rays++;
     const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     const f3 oi = mk3(o.x * inv.x, o.y * inv.y, o.z * inv.z);
     LvStack st;
     st.init(sm.lds, sm.ovf, sm.ovfStride);
-    unsigned cur = 0;
-    unsigned pending = LV_INVALID;
-    while (cur != LV_INVALID || pending != LV_INVALID) {
-        while (!(cur & LV_LEAF_BIT)) {
-            cur = lv_node_step<STATS, false>(S, cur, oi, inv, tMin, tMax, st, cnt);
-            if ((cur & LV_LEAF_BIT) && cur != LV_INVALID && pending == LV_INVALID) {
-                pending = cur;
+    cm.ray[2 * lane] = make_float4(o.x, o.y, o.z, w0);
+    cm.ray[2 * lane + 1] = make_float4(d.x, d.y, d.z, w1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    unsigned cur = active ? 0u : LV_INVALID;
+    unsigned head = 0, tail = 0;
+    while (true) {
+        const bool isLeaf = cur != LV_INVALID && (cur & LV_LEAF_BIT);
+        const unsigned long long mL = __ballot(isLeaf);
+        if (mL) {
+            if (isLeaf) {
+                cm.queue[(tail + unsigned(__popcll(mL & below))) % LV_QCAP] = (lane << 26) | (cur & 0x03FFFFFFu);
                 cur = lv_pop_or_done(st);
             }
-            if (lv_leave_node_loop(pending)) break;
+            tail += unsigned(__popcll(mL));
+            if (tail - head < LV_WAVE) continue;
         }
-        while (pending != LV_INVALID) {
-            const unsigned leaf = pending & ~LV_LEAF_BIT;
-            const float4 a = S.segs[2 * leaf], b = S.segs[2 * leaf + 1];
-            if (STATS) cnt.prims++;
-            float t; int kind;
-            if (lv_intersect_capsule(o, d, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), radius, capped, t, kind)) {
-                if (t >= tMin && t <= tMax) f(leaf, t, kind);
+        const int nNode = __popcll(__ballot(!(cur & LV_LEAF_BIT)));
+        const unsigned q = tail - head;
+        if (q >= LV_WAVE || (q > 0 && nNode == 0)) {
+            const unsigned n = q < LV_WAVE ? q : LV_WAVE;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (lane < n) {
+                const unsigned e = cm.queue[(head + lane) % LV_QCAP];
+                const unsigned owner = e >> 26, leaf = e & 0x03FFFFFFu;
+                const float4 ro = cm.ray[2 * owner], rd = cm.ray[2 * owner + 1];
+                const float4 a = S.segs[2 * leaf], b = S.segs[2 * leaf + 1];
+                if (STATS) cnt.prims++;
+                float t; int kind;
+                if (lv_intersect_capsule(mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), mk3(a.x, a.y, a.z),
+                                         mk3(b.x, b.y, b.z), radius, capped, t, kind)) {
+                    if (t >= tMin && t <= tMax)
+                        f(owner, leaf, t, kind, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), ro.w, rd.w);
+                }
             }
-            pending = LV_INVALID;
-            if ((cur & LV_LEAF_BIT) && cur != LV_INVALID) { pending = cur; cur = lv_pop_or_done(st); }
+            head += n;
+            continue;
         }
+        if (nNode == 0) break;
+        int nNow;
+        do {
+            if (!(cur & LV_LEAF_BIT)) cur = lv_node_step<STATS, false>(S, cur, oi, inv, tMin, tMax, st, cnt);
+            const bool lf = cur != LV_INVALID && (cur & LV_LEAF_BIT);
+            const unsigned long long m = __ballot(lf);
+            if (m) {
+                if (lf) {
+                    cm.queue[(tail + unsigned(__popcll(m & below))) % LV_QCAP] = (lane << 26) | (cur & 0x03FFFFFFu);
+                    cur = lv_pop_or_done(st);
+                }
+                tail += unsigned(__popcll(m));
+            }
+            nNow = __popcll(__ballot(!(cur & LV_LEAF_BIT)));
+        } while (tail - head < LV_WAVE && nNow > 0);
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
 
 // ---------------------------------------------------------------- ray generation, TubeRayTracing.glsl:219-226
