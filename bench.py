@@ -34,16 +34,28 @@ SETTINGS = {
 }
 WORKLOAD = ("C3: 1M-segment tornado-style streamlines (1000 lines x 1001 points, seed 12345), 1920x1080, "
             "colour pass 1 spp + RTAO 64 spp (1 iteration x 64 samples, radius 0.1, distance based), line width 0.002")
+# secondary workloads (documentation runs: --workload c2 / c4); the default and the driver's runs are C3
+WORKLOADS = {
+    "c3": dict(name=WORKLOAD, scene="tornado", mode=11, settings=SETTINGS, kernel="k_ao_rays"),
+    "c2": dict(name="C2: 100k-segment helix bundle (100 lines x 1001 points, seed 12345), 1920x1080, primary rays only "
+                    "(1 spp, pixel centres, AO off, depth cues off), line width 0.002",
+               scene="helix", mode=11, settings={"num_samples_per_frame": 1, "depth_cue_strength": 0.0}, kernel="k_render_rt"),
+    "c4": dict(name="C4: 1M-segment tornado-style streamlines, 1920x1080, PPLL OIT: all-hits gather + per-pixel 4-ary heap "
+                    "resolve, MAX_NUM_FRAGS 64, node pool 20/pixel, tiling 2x8, opacity ramp 0.1..0.6",
+               scene="tornado", mode=2, settings={"ppll_max_num_frags": 64, "ppll_expected_avg_depth_complexity": 20,
+                                                  "depth_cue_strength": 0.0}, kernel="k_ppll_gather"),
+}
 
 
-def cpu_baseline(pts, seg, tf, attr_range, view, proj, fovy, near, far, target_seconds=15.0):
+def cpu_baseline(pts, seg, tf, attr_range, view, proj, fovy, near, far, target_seconds=15.0, workload="c3"):
     """CPU restatement of the LineVis GLSL path (the oracle, NOT LineVis's own binary), all host cores (OpenMP), on a
     centred crop of the same frame sized for ~target_seconds of work."""
     from oracle import lvo
     sc = lvo.Scene(pts, seg, tf)
     P = lvo.make_params(view, proj, W, H, fovY=fovy, nearDist=near, farDist=far, lineWidth=LINE_WIDTH,
-                        useAmbientOcclusion=1, aoStrength=1.0, aoGamma=1.0, aoSamplesPerFrame=64, aoIterations=1,
-                        aoUseDistance=1, aoJitterPrimary=1, aoRadius=0.1, attrMin=attr_range[0], attrMax=attr_range[1])
+                        useAmbientOcclusion=int(workload == "c3"), aoStrength=1.0, aoGamma=1.0, aoSamplesPerFrame=64,
+                        aoIterations=1, aoUseDistance=1, aoJitterPrimary=1, aoRadius=0.1, attrMin=attr_range[0],
+                        attrMax=attr_range[1], ppllMaxNumFrags=64)
     t0 = time.time()
     sc.build_bvh(LINE_WIDTH)
     build_s = time.time() - t0
@@ -52,8 +64,11 @@ def cpu_baseline(pts, seg, tf, attr_range, view, proj, fovy, near, far, target_s
         tile = ((W - cw) // 2, (H - ch) // 2, cw, ch)
         st = lvo.Stats()
         t = time.time()
-        ao = sc.render_ao(P, tile=tile, use_bvh=True, stats=st)
-        sc.render_rt(P, ao=ao, tile=tile, use_bvh=True, stats=st)
+        if workload == "c4":
+            sc.render_ppll(P, tile=tile, use_bvh=True, stats=st)
+        else:
+            ao = sc.render_ao(P, tile=tile, use_bvh=True, stats=st) if workload == "c3" else None
+            sc.render_rt(P, ao=ao, tile=tile, use_bvh=True, stats=st)
         return time.time() - t, int(st.raysTraced)
 
     cw, ch = 96, 54                             # calibration crop, then grow towards ~target_seconds of work
@@ -78,6 +93,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--save-frame", default="")
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     args = ap.parse_args()
 
     import torch
@@ -98,11 +114,12 @@ def main():
 
     from linevis_amd import camera, capi, host_api, scenes, tiling, transfer_function as tfm
 
+    wl = WORKLOADS[args.workload]
     # ---- synthetic input (every rank builds the same replica; deterministic)
-    tr = scenes.normalize(scenes.tornado())
+    tr = scenes.normalize(scenes.tornado() if wl["scene"] == "tornado" else scenes.helix_bundle())
     flow = host_api.LineDataFlow().set_trajectories(tr.positions, tr.attributes, tr.line_offsets)
     pts, seg, _ = flow.tube_aabb_render_data(LINE_WIDTH)
-    tf = tfm.standard()
+    tf = tfm.standard_transparent() if args.workload == "c4" else tfm.standard()
     attr_range = flow.attribute_range()
     view, proj, fovy, near, far = camera.default_camera(W, H)
 
@@ -111,8 +128,8 @@ def main():
     ctx.set_transfer_function(tf, *attr_range)
     ctx.set_camera(view, proj, fovy, near, far, W, H)
     ctx.set_option("line_width", LINE_WIDTH)
-    ctx.set_options(SETTINGS)
-    render_fn = tiling.hip_render_tiles_fn(ctx, capi.MODE_RAY_TRACER)   # also moves the context onto torch's stream
+    ctx.set_options(wl["settings"])
+    render_fn = tiling.hip_render_tiles_fn(ctx, wl["mode"])   # also moves the context onto torch's stream
     ctx.build_accel()
     build_ms = ctx.stats().ms_accel_build
     sf = tiling.ShardedFrame(W, H, TILE, rank, world, device)
@@ -134,17 +151,19 @@ def main():
     torch.cuda.synchronize()
     st = ctx.stats()
     ctx.set_option("collect_stats", False)
-    counters = torch.tensor([st.rays_traced, st.nodes_visited, st.prims_tested, st.hits_shaded, st.ao_hit_pixels],
-                            dtype=torch.float64, device=device)
+    counters = torch.tensor([st.rays_traced, st.nodes_visited, st.prims_tested, st.hits_shaded, st.ao_hit_pixels,
+                             st.fragments], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(counters)
     rays_per_frame = float(counters[0].item())
     # algorithmic bytes of ONE k_ao_rays launch on this rank (DESIGN.md "Algorithmic bytes"):
-    # 128 B per 4-wide BVH node visited + 32 B per segment record tested + 52 B per compacted pixel (48 B G-buffer read,
+    # 64 B per compressed 4-wide BVH node visited + 32 B per segment record tested + 52 B per compacted pixel (48 B G-buffer read,
     # 4 B AO factor write)
-    ao_bytes = st.ao_nodes_visited * 128 + st.ao_prims_tested * 32 + st.ao_hit_pixels * 52
-    frame_bytes = (st.nodes_visited * 128 + st.prims_tested * 32 + st.hits_shaded * 96 + st.ao_hit_pixels * 52
-                   + len(sf.local_tiles) * TILE * TILE * (4 + 4))
+    ao_bytes = st.ao_nodes_visited * 64 + st.ao_prims_tested * 32 + st.ao_hit_pixels * 52
+    frame_bytes = (st.nodes_visited * 64 + st.prims_tested * 32 + st.hits_shaded * 96 + st.ao_hit_pixels * 52
+                   + len(sf.local_tiles) * TILE * TILE * (4 + 4) + st.fragments * (12 + 4 + 4 + 12))
+    kid = capi.KERNEL_NAMES.index(wl["kernel"])
+    kernel_bytes = ao_bytes if args.workload == "c3" else frame_bytes  # c2 / c4: one traversal kernel dominates
 
     for _ in range(args.warmup):
         step()
@@ -164,11 +183,11 @@ def main():
     st = ctx.stats()   # per-kernel HIP-event averages over the timed region (this rank)
 
     if rank == 0:
-        ms_rays = float(st.ms_kernel_avg[capi.KERNEL_AO_RAYS])
-        achieved = ao_bytes / (ms_rays * 1e-3) / 1e9 if ms_rays > 0 else 0.0
+        ms_rays = float(st.ms_kernel_avg[kid])
+        achieved = kernel_bytes / (ms_rays * 1e-3) / 1e9 if ms_rays > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
-        if os.path.exists(tpath) and world == 1:
+        if os.path.exists(tpath) and world == 1 and args.workload == "c3":
             try:
                 traffic = json.load(open(tpath)).get("k_ao_rays_hbm_bytes_per_launch")
             except Exception:
@@ -178,15 +197,16 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "fps": round(args.steps / elapsed, 3),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": WORKLOAD, "resolution": [W, H], "segments": int(len(seg)),
+            "config": {"workload": wl["name"], "resolution": [W, H], "segments": int(len(seg)),
                        "rays_per_frame": int(rays_per_frame), "ao_hit_pixels": int(counters[4].item()),
+                       "fragments_per_frame": int(counters[5].item()),
                        "parallelism": "screen tiles %dx%d, Morton order, round robin over %d GPU(s), one RCCL gather"
                                       % (TILE, TILE, world),
                        "accel_build_ms": round(build_ms, 3), "bvh_depth": int(st.bvh_depth)},
-            "roofline": {"bound": "hbm", "kernel": "k_ao_rays", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": wl["kernel"], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "algorithmic_bytes_per_launch": int(ao_bytes), "ms_per_launch": round(ms_rays, 4),
-                         "launches_timed": int(min(st.kernel_launches[capi.KERNEL_AO_RAYS], 128)),
+                         "algorithmic_bytes_per_launch": int(kernel_bytes), "ms_per_launch": round(ms_rays, 4),
+                         "launches_timed": int(min(st.kernel_launches[kid], 128)),
                          "frame_algorithmic_bytes_rank0": int(frame_bytes)},
             "kernels_ms": {capi.KERNEL_NAMES[k]: round(float(st.ms_kernel_avg[k]), 4) for k in range(6)
                            if st.kernel_launches[k]},
@@ -195,7 +215,8 @@ def main():
             from PIL import Image
             Image.fromarray(frame.cpu().numpy()).save(args.save_frame)
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(pts, seg, tf, attr_range, view, proj, fovy, near, far)
+            result["cpu_baseline"] = cpu_baseline(pts, seg, tf, attr_range, view, proj, fovy, near, far,
+                                                  workload=args.workload)
         else:
             result["cpu_baseline"] = None
         print(json.dumps(result), flush=True)

@@ -53,7 +53,7 @@ typedef struct lv_line_point {
  * option "collect_stats" is "true" (instrumented kernels; not for timing runs). */
 typedef struct lv_stats {
     uint64_t rays_traced;        /* primary + transparency continuation + AO rays */
-    uint64_t nodes_visited;      /* 128-byte 4-wide BVH nodes fetched */
+    uint64_t nodes_visited;      /* 64-byte compressed 4-wide BVH nodes fetched */
     uint64_t prims_tested;       /* 32-byte segment records fetched + capsule tests */
     uint64_t hits_shaded;        /* closest-hit / fragment shading invocations */
     uint64_t fragments;          /* PPLL: value of fragCounter after gather */
@@ -180,9 +180,10 @@ int lv_ppll_get_buffers(lv_ctx* ctx, uint32_t* out_nodes, uint64_t max_nodes, ui
 int lv_ppll_resolve_buffers(lv_ctx* ctx, const uint32_t* nodes, uint64_t num_nodes, const uint32_t* start_offset,
                             uint64_t num_pixels, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h,
                             uint8_t* out_rgba8);
-/* LBVH export for structural tests: 4-wide nodes of 32 uint32/float words (128 B) each -- words 0-23 child box
- * min.x[4] min.y[4] min.z[4] max.x[4] max.y[4] max.z[4], words 24-27 child references (bit 31 = leaf, 0xFFFFFFFF =
- * empty slot), word 28 = #slots; leaf order = Morton order; see DESIGN.md. */
+/* LBVH export for structural tests: compressed 4-wide nodes of 16 uint32/float words (64 B) each -- words 0-2 grid
+ * origin xyz, words 3-5 grid scale xyz (floats), words 6-8 qmin x/y/z and words 9-11 qmax x/y/z (byte k = child slot
+ * k; decoded plane = origin + q * scale), words 12-15 child references (bit 31 = leaf, 0xFFFFFFFF = empty slot);
+ * leaf order = Morton order; see DESIGN.md. */
 int lv_get_accel(lv_ctx* ctx, void* out_nodes, uint64_t max_nodes, uint32_t* out_leaf_segment, uint64_t max_leaves);
 
 #ifdef __cplusplus

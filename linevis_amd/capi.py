@@ -246,7 +246,7 @@ class Context:
         return out
 
     def get_accel(self, num_nodes, num_leaves):
-        nodes = np.zeros((max(num_nodes, 1), 32), dtype=np.uint32)
+        nodes = np.zeros((max(num_nodes, 1), 16), dtype=np.uint32)
         leaf = np.zeros(max(num_leaves, 1), dtype=np.uint32)
         self._ck(self.L.lv_get_accel(self.h, _p(nodes), nodes.shape[0], _p(leaf), leaf.shape[0]))
         return nodes[:num_nodes], leaf[:num_leaves]

@@ -516,7 +516,7 @@ int lv_get_accel(lv_ctx* ctx, void* out_nodes, uint64_t max_nodes, uint32_t* out
     LV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (out_nodes) {
         if (max_nodes < ctx->numNodes) return lv_fail(ctx, LV_E_CAPACITY, "out_nodes too small");
-        if (ctx->numNodes) LV_HIP(ctx, hipMemcpy(out_nodes, ctx->nodes.ptr, size_t(ctx->numNodes) * 128, hipMemcpyDeviceToHost));
+        if (ctx->numNodes) LV_HIP(ctx, hipMemcpy(out_nodes, ctx->nodes.ptr, size_t(ctx->numNodes) * 64, hipMemcpyDeviceToHost));
     }
     if (out_leaf_segment) {
         if (max_leaves < ctx->numSegs) return lv_fail(ctx, LV_E_CAPACITY, "out_leaf_segment too small");

@@ -14,7 +14,7 @@
 //   k_refit       bottom-up AABB + height, second arriver continues (agent-scope release/acquire)
 //   k_depth       depth of every binary node (walk to the root)
 //   scan          rocPRIM exclusive scan over "even depth" flags -> index of each 4-wide node
-//   k_pack4       collapse two binary levels into one 128-byte 4-wide node (child boxes SoA + child references)
+//   k_pack4       collapse two binary levels into one 64-byte compressed 4-wide node (8-bit child boxes + references)
 #include <cstring>
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -198,11 +198,21 @@ __global__ __launch_bounds__(LV_BLOCK) void k_depth(int nInternal, const uint32_
     evenFlag[i] = (d & 1u) ? 0u : 1u;
 }
 
-// 128-byte 4-wide node = 8 x float4:
-//   q0..q2 = child box minima {x[4]}, {y[4]}, {z[4]};  q3..q5 = child box maxima;  q6 = child references (uint bits,
-//   index | LV_LEAF_BIT for leaves, LV_INVALID for an empty slot);  q7 = {#slots, binary node index, 0, 0}.
+// 64-byte COMPRESSED 4-wide node = 4 x float4 (one dwordx4 load each):
+//   q0 = {origin.x, origin.y, origin.z, scale.x}
+//   q1 = {scale.y, scale.z, qmin.x[4 bytes], qmin.y[4 bytes]}
+//   q2 = {qmin.z[4], qmax.x[4], qmax.y[4], qmax.z[4]}            byte k of a word = child slot k
+//   q3 = {child0, child1, child2, child3}   index | LV_LEAF_BIT for leaves, LV_INVALID for an empty slot
+// Child boxes are stored as 8-bit offsets on the grid origin + q * scale spanned by the union of the children
+// (Ylitie et al., "Efficient Incoherent Ray Traversal on GPUs Through Compressed Wide BVHs", HPG 2017): decoded minima
+// never exceed and maxima never fall below the exact child box, so culling stays conservative and hits stay exact.
+// Why: with divergent rays every lane of a wave reads a different node, and the vector L1 serves a divergent dwordx4
+// load at one lane per cycle -- the 7 loads of an uncompressed 4-wide node made k_ao_rays L1-bound (4.4 G cache
+// accesses = 7.1 of its 7.6 ms).  4 loads per node cut that by 43 % and halve the node footprint (L2 / MALL hit rate).
 // A wide node is a binary node of even depth together with its (odd-depth) internal children: its slots are the
 // grandchildren, or a child itself where that child is a leaf.
+__device__ __forceinline__ float lv_dec(float origin, float scale, uint32_t q) { return __builtin_fmaf(float(q), scale, origin); }
+
 __global__ __launch_bounds__(LV_BLOCK) void k_pack4(int nInternal, const uint32_t* __restrict__ childL,
                                                     const uint32_t* __restrict__ childR, const float* __restrict__ leafBox,
                                                     const float* __restrict__ nodeBox, const uint32_t* __restrict__ evenFlag,
@@ -237,25 +247,56 @@ __global__ __launch_bounds__(LV_BLOCK) void k_pack4(int nInternal, const uint32_
         if (c & LV_LEAF_BIT) addSlot(c);
         else { addSlot(childL[c]); addSlot(childR[c]); }
     }
-    float4* out = nodes + 8 * size_t(wideIndex[i]);
-    out[0] = make_float4(b[0][0], b[1][0], b[2][0], b[3][0]);
-    out[1] = make_float4(b[0][1], b[1][1], b[2][1], b[3][1]);
-    out[2] = make_float4(b[0][2], b[1][2], b[2][2], b[3][2]);
-    out[3] = make_float4(b[0][3], b[1][3], b[2][3], b[3][3]);
-    out[4] = make_float4(b[0][4], b[1][4], b[2][4], b[3][4]);
-    out[5] = make_float4(b[0][5], b[1][5], b[2][5], b[3][5]);
-    out[6] = make_float4(__uint_as_float(slotRef[0]), __uint_as_float(slotRef[1]), __uint_as_float(slotRef[2]),
+    // quantisation grid: origin = min over children, scale = extent / 255 rounded up
+    float origin[3], scale[3];
+    uint32_t qmin[3] = {0, 0, 0}, qmax[3] = {0, 0, 0}; // byte k = slot k
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        float lo = 3.0e38f, hi = -3.0e38f;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (k < ns) { lo = fminf(lo, b[k][a]); hi = fmaxf(hi, b[k][3 + a]); }
+        origin[a] = lo;
+        float sc = (hi - lo) / 255.0f;
+        sc = sc * 1.000002f + 1e-30f;
+        scale[a] = sc;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (k >= ns) continue;
+            int q0 = int(floorf((b[k][a] - lo) / sc));
+            q0 = min(max(q0, 0), 255);
+            while (q0 > 0 && lv_dec(lo, sc, uint32_t(q0)) > b[k][a]) q0--;       // decoded min <= exact min
+            int q1 = int(ceilf((b[k][3 + a] - lo) / sc));
+            q1 = min(max(q1, 0), 255);
+            while (q1 < 255 && lv_dec(lo, sc, uint32_t(q1)) < b[k][3 + a]) q1++; // decoded max >= exact max
+            qmin[a] |= uint32_t(q0) << (8 * k);
+            qmax[a] |= uint32_t(q1) << (8 * k);
+        }
+        // q = 255 must still cover hi: widen the scale in the (rounding) case it does not
+        while (lv_dec(lo, scale[a], 255u) < hi) scale[a] = scale[a] * 1.00001f + 1e-30f;
+    }
+    float4* out = nodes + 4 * size_t(wideIndex[i]);
+    out[0] = make_float4(origin[0], origin[1], origin[2], scale[0]);
+    out[1] = make_float4(scale[1], scale[2], __uint_as_float(qmin[0]), __uint_as_float(qmin[1]));
+    out[2] = make_float4(__uint_as_float(qmin[2]), __uint_as_float(qmax[0]), __uint_as_float(qmax[1]),
+                         __uint_as_float(qmax[2]));
+    out[3] = make_float4(__uint_as_float(slotRef[0]), __uint_as_float(slotRef[1]), __uint_as_float(slotRef[2]),
                          __uint_as_float(slotRef[3]));
-    out[7] = make_float4(__uint_as_float(uint32_t(ns)), __uint_as_float(uint32_t(i)), 0.0f, 0.0f);
 }
 
 // single-segment scene: one node with one occupied slot
 __global__ void k_single_node(const float* __restrict__ leafBox, float4* __restrict__ nodes) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    for (int j = 0; j < 6; j++) nodes[j] = make_float4(leafBox[j], 0.0f, 0.0f, 0.0f);
-    nodes[6] = make_float4(__uint_as_float(0u | LV_LEAF_BIT), __uint_as_float(LV_INVALID), __uint_as_float(LV_INVALID),
+    float sc[3];
+    for (int a = 0; a < 3; a++) {
+        sc[a] = ((leafBox[3 + a] - leafBox[a]) / 255.0f) * 1.000002f + 1e-30f;
+        while (lv_dec(leafBox[a], sc[a], 255u) < leafBox[3 + a]) sc[a] = sc[a] * 1.00001f + 1e-30f;
+    }
+    nodes[0] = make_float4(leafBox[0], leafBox[1], leafBox[2], sc[0]);
+    nodes[1] = make_float4(sc[1], sc[2], __uint_as_float(0u), __uint_as_float(0u));
+    nodes[2] = make_float4(__uint_as_float(0u), __uint_as_float(255u), __uint_as_float(255u), __uint_as_float(255u));
+    nodes[3] = make_float4(__uint_as_float(0u | LV_LEAF_BIT), __uint_as_float(LV_INVALID), __uint_as_float(LV_INVALID),
                            __uint_as_float(LV_INVALID));
-    nodes[7] = make_float4(__uint_as_float(1u), 0.0f, 0.0f, 0.0f);
 }
 
 inline uint32_t nblocks(uint64_t n) { return uint32_t((n + LV_BLOCK - 1) / LV_BLOCK); }
@@ -279,7 +320,7 @@ int lv_bvh_build(lv_ctx* ctx) {
 
     int rc;
     // 4-wide nodes: one per even-depth binary node; at most all of them (a degenerate chain has ~n/2)
-    if ((rc = lv_buf_reserve(ctx, ctx->nodes, size_t(nInternal) * 128))) return rc;
+    if ((rc = lv_buf_reserve(ctx, ctx->nodes, size_t(nInternal) * 64))) return rc;
     if ((rc = lv_buf_reserve(ctx, ctx->segs, size_t(n) * 32))) return rc;
     if ((rc = lv_buf_reserve(ctx, ctx->leafSeg, size_t(n) * 4))) return rc;
     if ((rc = lv_buf_reserve(ctx, ctx->segToLeaf, size_t(n) * 4))) return rc;

@@ -91,7 +91,7 @@ struct LvUniforms {
 
 // HBM-resident scene (all read-only during rendering)
 struct LvSceneDev {
-    const float4* nodes;        // 128-B 4-wide LBVH nodes, 8 x float4 each (layout: lv_bvh.hip k_pack4)
+    const float4* nodes;        // 64-B compressed 4-wide LBVH nodes, 4 x float4 each (layout: lv_bvh.hip k_pack4)
     const float4* segs;         // 32-B segment records in Morton (leaf) order: {p0.xyz, attr0}, {p1.xyz, attr1}
     const uint32_t* leafSeg;    // leaf position -> original segment index
     const uint32_t* segToLeaf;  // original segment index -> leaf position

@@ -166,9 +166,9 @@ __device__ __forceinline__ bool lv_leave_node_loop(unsigned pending) {
     return !__any(pending == LV_INVALID) || __popcll(descending) < LV_NODE_MIN_ACTIVE;
 }
 
-// One node step on the 4-wide LBVH: fetch the 128-byte node (7 x dwordx4 of one cache line pair), slab-test the four
-// child boxes, continue with the nearest hit child and push the others far-to-near (ORDERED) so that they pop
-// near-first.  Children may be leaves; the caller looks at the leaf bit of what comes back / pops.
+// One node step on the compressed 4-wide LBVH: fetch the 64-byte node (4 x dwordx4), decode + slab-test the four child
+// boxes, continue with the nearest hit child and push the others.  Children may be leaves; the caller looks at the
+// leaf bit of what comes back / pops.
 __device__ __forceinline__ void lv_cswap(float& ka, unsigned& ca, float& kb, unsigned& cb) {
     const bool sw = kb < ka;
     const float tk = sw ? kb : ka, uk = sw ? ka : kb;
@@ -176,18 +176,38 @@ __device__ __forceinline__ void lv_cswap(float& ka, unsigned& ca, float& kb, uns
     ka = tk; kb = uk; ca = tc; cb = uc;
 }
 
+// slab test on decoded planes: t = plane * (1/d) - o/d with plane = origin + q * scale, folded into
+// t = q * (scale/d) + (origin/d - o/d): one fma per plane after the byte -> float conversion
+__device__ __forceinline__ bool lv_slab_q(uint32_t qnx, uint32_t qny, uint32_t qnz, uint32_t qxx, uint32_t qxy,
+                                          uint32_t qxz, int k, f3 A, f3 B, float tMin, float tMax, float& tNear) {
+    const float fx0 = float((qnx >> (8 * k)) & 0xFFu), fx1 = float((qxx >> (8 * k)) & 0xFFu);
+    const float fy0 = float((qny >> (8 * k)) & 0xFFu), fy1 = float((qxy >> (8 * k)) & 0xFFu);
+    const float fz0 = float((qnz >> (8 * k)) & 0xFFu), fz1 = float((qxz >> (8 * k)) & 0xFFu);
+    float tx0 = __builtin_fmaf(fx0, A.x, B.x), tx1 = __builtin_fmaf(fx1, A.x, B.x);
+    float ty0 = __builtin_fmaf(fy0, A.y, B.y), ty1 = __builtin_fmaf(fy1, A.y, B.y);
+    float tz0 = __builtin_fmaf(fz0, A.z, B.z), tz1 = __builtin_fmaf(fz1, A.z, B.z);
+    float tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), tMin));
+    float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), tMax));
+    tNear = tn;
+    return tn <= __builtin_fmaf(tf, 1.00001f, 4e-7f);
+}
+
 template <bool STATS, bool ORDERED = true, class STACK>
 __device__ __forceinline__ unsigned lv_node_step(const LvSceneDev& S, unsigned node, f3 oi, f3 inv, float tMin, float tMax,
                                                  STACK& st, LvCounters& cnt) {
-    const float4* p = S.nodes + 8 * size_t(node);
-    const float4 mnx = p[0], mny = p[1], mnz = p[2], mxx = p[3], mxy = p[4], mxz = p[5], cf = p[6];
+    const float4* p = S.nodes + 4 * size_t(node);
+    const float4 q0 = p[0], q1 = p[1], q2 = p[2], cf = p[3];
     if (STATS) cnt.nodes++;
     unsigned c0 = __float_as_uint(cf.x), c1 = __float_as_uint(cf.y), c2 = __float_as_uint(cf.z), c3 = __float_as_uint(cf.w);
+    const f3 A = mk3(q0.w * inv.x, q1.x * inv.y, q1.y * inv.z);
+    const f3 B = mk3(__builtin_fmaf(q0.x, inv.x, -oi.x), __builtin_fmaf(q0.y, inv.y, -oi.y), __builtin_fmaf(q0.z, inv.z, -oi.z));
+    const uint32_t qnx = __float_as_uint(q1.z), qny = __float_as_uint(q1.w), qnz = __float_as_uint(q2.x);
+    const uint32_t qxx = __float_as_uint(q2.y), qxy = __float_as_uint(q2.z), qxz = __float_as_uint(q2.w);
     float k0, k1, k2, k3;
-    const bool h0 = lv_slab(mnx.x, mny.x, mnz.x, mxx.x, mxy.x, mxz.x, oi, inv, tMin, tMax, k0) && c0 != LV_INVALID;
-    const bool h1 = lv_slab(mnx.y, mny.y, mnz.y, mxx.y, mxy.y, mxz.y, oi, inv, tMin, tMax, k1) && c1 != LV_INVALID;
-    const bool h2 = lv_slab(mnx.z, mny.z, mnz.z, mxx.z, mxy.z, mxz.z, oi, inv, tMin, tMax, k2) && c2 != LV_INVALID;
-    const bool h3 = lv_slab(mnx.w, mny.w, mnz.w, mxx.w, mxy.w, mxz.w, oi, inv, tMin, tMax, k3) && c3 != LV_INVALID;
+    const bool h0 = lv_slab_q(qnx, qny, qnz, qxx, qxy, qxz, 0, A, B, tMin, tMax, k0) && c0 != LV_INVALID;
+    const bool h1 = lv_slab_q(qnx, qny, qnz, qxx, qxy, qxz, 1, A, B, tMin, tMax, k1) && c1 != LV_INVALID;
+    const bool h2 = lv_slab_q(qnx, qny, qnz, qxx, qxy, qxz, 2, A, B, tMin, tMax, k2) && c2 != LV_INVALID;
+    const bool h3 = lv_slab_q(qnx, qny, qnz, qxx, qxy, qxz, 3, A, B, tMin, tMax, k3) && c3 != LV_INVALID;
     const float INF = __builtin_inff();
     k0 = h0 ? k0 : INF; k1 = h1 ? k1 : INF; k2 = h2 ? k2 : INF; k3 = h3 ? k3 : INF;
     c0 = h0 ? c0 : LV_INVALID; c1 = h1 ? c1 : LV_INVALID; c2 = h2 ? c2 : LV_INVALID; c3 = h3 ? c3 : LV_INVALID;

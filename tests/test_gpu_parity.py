@@ -73,18 +73,19 @@ def test_lbvh_structure(hip_lib):
     nodes, leaf_seg = ctx.get_accel(nw, n)
     assert sorted(leaf_seg.tolist()) == list(range(n))          # every segment is exactly one leaf
     f = nodes.view(np.float32)
-    child = nodes[:, 24:28]
-    nslots = nodes[:, 28]
+    child = nodes[:, 12:16]
     LEAF, INVALID = 0x80000000, 0xFFFFFFFF
     valid = child != INVALID
-    assert np.array_equal(valid.sum(axis=1), nslots) and nslots.min() >= 2 and nslots.max() <= 4
+    nslots = valid.sum(axis=1)
+    assert nslots.min() >= 2 and nslots.max() <= 4 and np.all(valid[:, 0] & valid[:, 1])
     # every wide node except the root is referenced exactly once, every leaf exactly once
     refs = child[valid]
     refs_internal = refs[(refs & LEAF) == 0]
     refs_leaf = refs[(refs & LEAF) != 0] & 0x7FFFFFFF
     assert sorted(refs_internal.tolist()) == list(range(1, nw))
     assert sorted(refs_leaf.tolist()) == list(range(n))
-    # child boxes stored in the parent contain the capsule of every leaf child
+    # decoded (8-bit quantised) child boxes contain the capsule of every leaf child: culling stays conservative
+    origin, scale = f[:, 0:3].astype(np.float64), f[:, 3:6].astype(np.float64)
     p = c.points["linePosition"]
     r = c.line_width * 0.5
     for node in range(nw):
@@ -94,7 +95,10 @@ def test_lbvh_structure(hip_lib):
                 seg = c.seg[leaf_seg[ref & 0x7FFFFFFF]]
                 mn = np.minimum(p[seg[0]], p[seg[1]]) - r
                 mx = np.maximum(p[seg[0]], p[seg[1]]) + r
-                assert np.all(f[node, [k, 4 + k, 8 + k]] <= mn) and np.all(f[node, [12 + k, 16 + k, 20 + k]] >= mx)
+                qmin = (nodes[node, 6:9] >> (8 * k)) & 0xFF
+                qmax = (nodes[node, 9:12] >> (8 * k)) & 0xFF
+                assert np.all(origin[node] + qmin * scale[node] <= mn + 1e-7)
+                assert np.all(origin[node] + qmax * scale[node] >= mx - 1e-7)
 
 
 # ---------------------------------------------------------------- golden frames

@@ -33,7 +33,7 @@ def run(ctx, mode, reps=3, label=''):
     s = ctx.stats()
     ctx.set_option('collect_stats', False)
     d = s.as_dict()
-    alg = d['nodes_visited'] * 128 + d['prims_tested'] * 32 + d['hits_shaded'] * 96
+    alg = d['nodes_visited'] * 64 + d['prims_tested'] * 32 + d['hits_shaded'] * 96
     print('  max nodes per pixel', d['max_nodes_per_pixel'])
     print('  counters', {k: d[k] for k in ('rays_traced', 'nodes_visited', 'prims_tested', 'hits_shaded', 'fragments', 'ao_hit_pixels', 'max_depth_complexity')})
     if s.ao_phase_iterations[1]:
