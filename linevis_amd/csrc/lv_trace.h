@@ -177,17 +177,18 @@ __device__ __forceinline__ void lv_cswap(float& ka, unsigned& ca, float& kb, uns
 }
 
 // slab test on decoded planes: t = plane * (1/d) - o/d with plane = origin + q * scale, folded into
-// t = q * (scale/d) + (origin/d - o/d): one fma per plane after the byte -> float conversion
-__device__ __forceinline__ bool lv_slab_q(uint32_t qnx, uint32_t qny, uint32_t qnz, uint32_t qxx, uint32_t qxy,
-                                          uint32_t qxz, int k, f3 A, f3 B, float tMin, float tMax, float& tNear) {
-    const float fx0 = float((qnx >> (8 * k)) & 0xFFu), fx1 = float((qxx >> (8 * k)) & 0xFFu);
-    const float fy0 = float((qny >> (8 * k)) & 0xFFu), fy1 = float((qxy >> (8 * k)) & 0xFFu);
-    const float fz0 = float((qnz >> (8 * k)) & 0xFFu), fz1 = float((qxz >> (8 * k)) & 0xFFu);
-    float tx0 = __builtin_fmaf(fx0, A.x, B.x), tx1 = __builtin_fmaf(fx1, A.x, B.x);
-    float ty0 = __builtin_fmaf(fy0, A.y, B.y), ty1 = __builtin_fmaf(fy1, A.y, B.y);
-    float tz0 = __builtin_fmaf(fz0, A.z, B.z), tz1 = __builtin_fmaf(fz1, A.z, B.z);
-    float tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), tMin));
-    float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), tMax));
+// t = q * (scale/d) + (origin/d - o/d): one fma per plane after the byte -> float conversion.  The words handed in
+// are already ordered by the ray's direction signs (near planes / far planes), so no per-plane min/max is needed.
+__device__ __forceinline__ bool lv_slab_q(uint32_t nearX, uint32_t nearY, uint32_t nearZ, uint32_t farX, uint32_t farY,
+                                          uint32_t farZ, int k, f3 A, f3 B, float tMin, float tMax, float& tNear) {
+    const float tx0 = __builtin_fmaf(float((nearX >> (8 * k)) & 0xFFu), A.x, B.x);
+    const float ty0 = __builtin_fmaf(float((nearY >> (8 * k)) & 0xFFu), A.y, B.y);
+    const float tz0 = __builtin_fmaf(float((nearZ >> (8 * k)) & 0xFFu), A.z, B.z);
+    const float tx1 = __builtin_fmaf(float((farX >> (8 * k)) & 0xFFu), A.x, B.x);
+    const float ty1 = __builtin_fmaf(float((farY >> (8 * k)) & 0xFFu), A.y, B.y);
+    const float tz1 = __builtin_fmaf(float((farZ >> (8 * k)) & 0xFFu), A.z, B.z);
+    const float tn = fmaxf(fmaxf(tx0, ty0), fmaxf(tz0, tMin));
+    const float tf = fminf(fminf(tx1, ty1), fminf(tz1, tMax));
     tNear = tn;
     return tn <= __builtin_fmaf(tf, 1.00001f, 4e-7f);
 }
@@ -201,13 +202,18 @@ __device__ __forceinline__ unsigned lv_node_step(const LvSceneDev& S, unsigned n
     unsigned c0 = __float_as_uint(cf.x), c1 = __float_as_uint(cf.y), c2 = __float_as_uint(cf.z), c3 = __float_as_uint(cf.w);
     const f3 A = mk3(q0.w * inv.x, q1.x * inv.y, q1.y * inv.z);
     const f3 B = mk3(__builtin_fmaf(q0.x, inv.x, -oi.x), __builtin_fmaf(q0.y, inv.y, -oi.y), __builtin_fmaf(q0.z, inv.z, -oi.z));
+    // a negative direction component enters through the max plane (loop-invariant per ray)
+    const bool sx = inv.x < 0.0f, sy = inv.y < 0.0f, sz = inv.z < 0.0f;
     const uint32_t qnx = __float_as_uint(q1.z), qny = __float_as_uint(q1.w), qnz = __float_as_uint(q2.x);
     const uint32_t qxx = __float_as_uint(q2.y), qxy = __float_as_uint(q2.z), qxz = __float_as_uint(q2.w);
+    const uint32_t nearX = sx ? qxx : qnx, farX = sx ? qnx : qxx;
+    const uint32_t nearY = sy ? qxy : qny, farY = sy ? qny : qxy;
+    const uint32_t nearZ = sz ? qxz : qnz, farZ = sz ? qnz : qxz;
     float k0, k1, k2, k3;
-    const bool h0 = lv_slab_q(qnx, qny, qnz, qxx, qxy, qxz, 0, A, B, tMin, tMax, k0) && c0 != LV_INVALID;
-    const bool h1 = lv_slab_q(qnx, qny, qnz, qxx, qxy, qxz, 1, A, B, tMin, tMax, k1) && c1 != LV_INVALID;
-    const bool h2 = lv_slab_q(qnx, qny, qnz, qxx, qxy, qxz, 2, A, B, tMin, tMax, k2) && c2 != LV_INVALID;
-    const bool h3 = lv_slab_q(qnx, qny, qnz, qxx, qxy, qxz, 3, A, B, tMin, tMax, k3) && c3 != LV_INVALID;
+    const bool h0 = lv_slab_q(nearX, nearY, nearZ, farX, farY, farZ, 0, A, B, tMin, tMax, k0) && c0 != LV_INVALID;
+    const bool h1 = lv_slab_q(nearX, nearY, nearZ, farX, farY, farZ, 1, A, B, tMin, tMax, k1) && c1 != LV_INVALID;
+    const bool h2 = lv_slab_q(nearX, nearY, nearZ, farX, farY, farZ, 2, A, B, tMin, tMax, k2) && c2 != LV_INVALID;
+    const bool h3 = lv_slab_q(nearX, nearY, nearZ, farX, farY, farZ, 3, A, B, tMin, tMax, k3) && c3 != LV_INVALID;
     const float INF = __builtin_inff();
     k0 = h0 ? k0 : INF; k1 = h1 ? k1 : INF; k2 = h2 ? k2 : INF; k3 = h3 ? k3 : INF;
     c0 = h0 ? c0 : LV_INVALID; c1 = h1 ? c1 : LV_INVALID; c2 = h2 ? c2 : LV_INVALID; c3 = h3 ? c3 : LV_INVALID;
