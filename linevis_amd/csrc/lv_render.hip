@@ -411,10 +411,10 @@ __global__ __launch_bounds__(LV_AO_BLOCK) void k_ao_rays(const LvUniforms U, con
             continue;
         }
         if (nNode > 0) {
-            // ---- descend phase: tight loop of node steps; leaves met on the way join the FIFO.  Leave it when a full
-            // batch of leaf tests waits, when nobody descends any more, or when enough lanes ran dry to be worth a
-            // retire/refill pass.
-            const int stay = nNode > LV_REFILL_THRESHOLD ? nNode - LV_REFILL_THRESHOLD : 1;
+            // ---- descend phase: tight loop of node steps; leaves met on the way join the FIFO.  Leave it only when a
+            // full batch of leaf tests waits or nobody descends any more (leaving earlier for a retire/refill pass
+            // was measured slower: the per-pass bookkeeping outweighs the idle lanes).
+            const int stay = 1;
             int nNow;
             do {
                 if (STATS && lane == 0) { phIt[1]++; }
@@ -453,8 +453,18 @@ __global__ __launch_bounds__(LV_BLOCK) void k_ao_reduce(const LvUniforms U, cons
     const uint32_t slot = blockIdx.x * LV_BLOCK + threadIdx.x;
     if (slot >= dc->aoCount) return;
     const uint32_t spp = U.aoSamplesPerFrame;
-    float aoFactor = 0.0f;
-    for (uint32_t s = 0; s < spp; s++) aoFactor += samples[size_t(slot) * spp + s];
+    float aoFactor = 0.0f; // summed strictly in sample order, like the reference's loop (glsl:288-306)
+    if ((spp & 3u) == 0u) {
+        // 16-byte loads: the lanes of a wave read rows that are spp * 4 bytes apart, so every load instruction touches
+        // 64 different cache lines whatever its width -- dwordx4 quarters the number of L1 accesses
+        const float4* row = reinterpret_cast<const float4*>(samples + size_t(slot) * spp);
+        for (uint32_t s = 0; s < spp / 4u; s++) {
+            const float4 v = row[s];
+            aoFactor += v.x; aoFactor += v.y; aoFactor += v.z; aoFactor += v.w;
+        }
+    } else {
+        for (uint32_t s = 0; s < spp; s++) aoFactor += samples[size_t(slot) * spp + s];
+    }
     aoFactor /= float(spp);
     const uint32_t pix = __float_as_uint(gbuf[3 * size_t(slot) + 1].w);
     if (U.aoFrameNumber != 0) aoFactor = mixf(ao[pix], aoFactor, 1.0f / float(U.aoFrameNumber + 1));
