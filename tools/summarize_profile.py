@@ -37,6 +37,7 @@ out = {"tag": tag, "kernel": "k_ao_rays", "FETCH_SIZE_kib_per_launch": fetch_kb,
        "collected_with": "rocprofv3 --pmc FETCH_SIZE --kernel-trace / rocprofv3 --pmc WRITE_SIZE --kernel-trace (separate passes), bench.py --steps 3 --warmup 1",
        "all_kernels": pmc}
 json.dump(out, open(os.path.join(dst, "traffic_%s.json" % tag), "w"), indent=1)
+bench["roofline"]["traffic"] = traffic  # same run as the kernel stats above
 json.dump(bench, open(os.path.join(dst, "bench_%s.json" % tag), "w"), indent=1)
 print(json.dumps({k: out[k] for k in ("k_ao_rays_hbm_bytes_per_launch", "algorithmic_bytes_per_launch")}))
 for r in rows[:6]:
