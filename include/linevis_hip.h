@@ -48,6 +48,14 @@ typedef struct lv_line_point {
     uint32_t lineStartIndex;
 } lv_line_point;
 
+/* struct TubeTriangleVertexData, src/LineData/LineRenderData.hpp:171-176 -- byte-identical (32 B). */
+typedef struct lv_tube_vertex {
+    float vertexPosition[3];
+    uint32_t vertexLinePointIndex; /* index into the line-point table; bit 31 set on cap vertices */
+    float vertexNormal[3];
+    float phi;
+} lv_tube_vertex;
+
 /* Counters and timers.  Replaces the per-phase GPU timers of PerPixelLinkedListLineRenderer.cpp:411-420 and the
  * buffer-size reporting of VulkanRayTracer.cpp:671-675.  Ray/node/primitive counters are only filled when the
  * option "collect_stats" is "true" (instrumented kernels; not for timing runs). */
@@ -84,7 +92,7 @@ typedef struct lv_stats {
     uint64_t ao_phase_iterations[3];
     uint64_t ao_phase_lanes[3];
     uint32_t max_nodes_per_pixel;  /* collect_stats: most BVH nodes fetched by one pixel of a tile kernel (tail latency) */
-    uint32_t reserved0;
+    uint32_t num_tube_triangles;   /* triangles of the tube mesh set with lv_set_tube_triangle_mesh */
 } lv_stats;
 
 #define LV_KERNEL_AO_PRIMARY 0
@@ -112,6 +120,14 @@ int lv_set_stream(lv_ctx* ctx, void* hip_stream);
 int lv_set_lines(lv_ctx* ctx, const lv_line_point* points, uint32_t num_points,
                  const uint32_t* segment_point_indices /* 2 per segment */, uint32_t num_segments);
 
+/* The triangle tubes the reference's RTAO pass traces against (VulkanRayTracedAmbientOcclusion.cpp:444-445 fetches
+ * LineData::getLinePassTubeTriangleMeshRenderData(false, true), LineData.hpp:182): index buffer (3 per triangle),
+ * 32-byte TubeTriangleVertexData and the 48-byte line-point table the vertices refer to, copied to HBM.  Used when the
+ * option rtao_geometry is "triangle_tubes"; the triangle LBVH is built on the next render. */
+int lv_set_tube_triangle_mesh(lv_ctx* ctx, const uint32_t* triangle_indices, uint32_t num_triangles,
+                              const lv_tube_vertex* vertices, uint32_t num_vertices,
+                              const lv_line_point* line_points, uint32_t num_line_points);
+
 /* TransferFunctionWindow texture + MinMaxUniformBuffer (Data/Shaders/Utils/TransferFunction.glsl:60-71):
  * n RGBA float texels, sampled with linear filtering at texel centres, clamp-to-edge. */
 int lv_set_transfer_function(lv_ctx* ctx, const float* rgba, uint32_t n, float attr_min, float attr_max);
@@ -137,7 +153,9 @@ int lv_set_background(lv_ctx* ctx, const float rgba[4]);
  *   max_depth_complexity                                                (VulkanRayTracer.hpp:139)
  *   ppll_max_num_frags, ppll_expected_avg_depth_complexity, ppll_tile_width, ppll_tile_height
  *                                                                       (PerPixelLinkedListLineRenderer.cpp:144-209,251-357)
- *   collect_stats (build-owned: run the instrumented kernels). */
+ *   collect_stats (build-owned: run the instrumented kernels),
+ *   rtao_geometry (build-owned): "capsules" (default: AO rays hit the analytic capsules of the colour pass) or
+ *   "triangle_tubes" (the reference's RTAO geometry: the mesh set with lv_set_tube_triangle_mesh). */
 int lv_set_option(lv_ctx* ctx, const char* key, const char* value);
 
 /* LineData::getRayTracingTubeAabbTopLevelAS (LineData.cpp:1057-1075) + getTubeAabbBottomLevelAS (:879-907):
@@ -168,6 +186,11 @@ int lv_reset_timers(lv_ctx* ctx);
  * origins/dirs: 3 floats per ray; out_segment = 0xFFFFFFFF on miss; out_kind: 0 tube, 1 sphere p0, 2 sphere p1. */
 int lv_trace_rays(lv_ctx* ctx, const float* origins, const float* dirs, float t_min, float t_max, uint32_t n,
                   float* out_t, uint32_t* out_segment, uint32_t* out_kind);
+/* Same against the triangle tubes (the driver's triangle test is restated as Moeller-Trumbore without culling + "t inside
+ * the triangle's own padded AABB interval").  out_triangle = 0xFFFFFFFF on miss, ties -> lowest triangle
+ * index; out_uv (2 floats per ray, may be NULL) = barycentrics as rayQueryGetIntersectionBarycentricsEXT. */
+int lv_trace_rays_triangles(lv_ctx* ctx, const float* origins, const float* dirs, float t_min, float t_max, uint32_t n,
+                            float* out_t, uint32_t* out_triangle, float* out_uv);
 /* LineRenderer::computeDepthRange (LineRenderer.cpp:410-431): min/max view depth of all line points. */
 int lv_compute_depth_range(lv_ctx* ctx, float out_min_max[2]);
 /* Full-viewport RTAO texture (.x channel of the RGBA32F accumulation image) after the last mode-11/2 render. */

@@ -21,6 +21,10 @@ LINE_POINT_DTYPE = np.dtype([("linePosition", "<f4", 3), ("lineAttribute", "<f4"
                              ("lineTangent", "<f4", 3), ("lineRotation", "<f4"),
                              ("lineNormal", "<f4", 3), ("lineStartIndex", "<u4")])
 assert LINE_POINT_DTYPE.itemsize == 48
+# struct TubeTriangleVertexData, src/LineData/LineRenderData.hpp:171-176
+TUBE_VERTEX_DTYPE = np.dtype([("vertexPosition", "<f4", 3), ("vertexLinePointIndex", "<u4"),
+                              ("vertexNormal", "<f4", 3), ("phi", "<f4")])
+assert TUBE_VERTEX_DTYPE.itemsize == 32
 
 
 class Stats(C.Structure):
@@ -34,7 +38,7 @@ class Stats(C.Structure):
                 ("ms_kernel_avg", C.c_float * 8), ("kernel_launches", C.c_uint32 * 8),
                 ("ao_rays_traced", C.c_uint64), ("ao_nodes_visited", C.c_uint64), ("ao_prims_tested", C.c_uint64),
                 ("ao_phase_iterations", C.c_uint64 * 3), ("ao_phase_lanes", C.c_uint64 * 3),
-                ("max_nodes_per_pixel", C.c_uint32), ("reserved0", C.c_uint32)]
+                ("max_nodes_per_pixel", C.c_uint32), ("num_tube_triangles", C.c_uint32)]
 
     def as_dict(self):
         d = {}
@@ -58,7 +62,8 @@ class LineVisError(RuntimeError):
 SYMBOLS = ["lv_create", "lv_destroy", "lv_last_error", "lv_version", "lv_set_stream", "lv_set_lines",
            "lv_set_transfer_function", "lv_set_camera", "lv_set_background", "lv_set_option", "lv_build_accel",
            "lv_render", "lv_render_device", "lv_render_tiles_device", "lv_get_stats", "lv_reset_timers", "lv_trace_rays",
-           "lv_compute_depth_range", "lv_get_ao", "lv_ppll_get_buffers", "lv_ppll_resolve_buffers", "lv_get_accel"]
+           "lv_compute_depth_range", "lv_get_ao", "lv_ppll_get_buffers", "lv_ppll_resolve_buffers", "lv_get_accel",
+           "lv_set_tube_triangle_mesh", "lv_trace_rays_triangles"]
 
 _lib = None
 
@@ -109,6 +114,8 @@ def load():
         ("lv_ppll_get_buffers", [vp, vp, u64, vp, u64, C.POINTER(u32)]),
         ("lv_ppll_resolve_buffers", [vp, vp, u64, vp, u64, u32, u32, u32, u32, vp]),
         ("lv_get_accel", [vp, vp, u64, vp, u64]),
+        ("lv_set_tube_triangle_mesh", [vp, vp, u32, vp, u32, vp, u32]),
+        ("lv_trace_rays_triangles", [vp, vp, vp, f32, f32, u32, vp, vp, vp]),
     ]:
         fn = getattr(L, name)
         fn.restype = i32
@@ -162,6 +169,12 @@ class Context:
         pts = np.ascontiguousarray(points, dtype=LINE_POINT_DTYPE)
         seg = np.ascontiguousarray(seg_indices, dtype=np.uint32).reshape(-1, 2)
         self._ck(self.L.lv_set_lines(self.h, _p(pts), len(pts), _p(seg), len(seg)))
+
+    def set_tube_triangle_mesh(self, triangle_indices, vertices, line_points):
+        idx = np.ascontiguousarray(triangle_indices, dtype=np.uint32).reshape(-1, 3)
+        v = np.ascontiguousarray(vertices, dtype=TUBE_VERTEX_DTYPE)
+        pts = np.ascontiguousarray(line_points, dtype=LINE_POINT_DTYPE)
+        self._ck(self.L.lv_set_tube_triangle_mesh(self.h, _p(idx), len(idx), _p(v), len(v), _p(pts), len(pts)))
 
     def set_transfer_function(self, rgba, attr_min=0.0, attr_max=1.0):
         tf = np.ascontiguousarray(rgba, dtype=np.float32).reshape(-1, 4)
@@ -219,6 +232,16 @@ class Context:
         kind = np.empty(n, dtype=np.uint32)
         self._ck(self.L.lv_trace_rays(self.h, _p(o), _p(d), t_min, t_max, n, _p(t), _p(seg), _p(kind)))
         return t, seg, kind
+
+    def trace_rays_triangles(self, origins, dirs, t_min, t_max):
+        o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(dirs, dtype=np.float32).reshape(-1, 3)
+        n = o.shape[0]
+        t = np.empty(n, dtype=np.float32)
+        tri = np.empty(n, dtype=np.uint32)
+        uv = np.empty((n, 2), dtype=np.float32)
+        self._ck(self.L.lv_trace_rays_triangles(self.h, _p(o), _p(d), t_min, t_max, n, _p(t), _p(tri), _p(uv)))
+        return t, tri, uv
 
     def depth_range(self):
         out = np.empty(2, dtype=np.float32)

@@ -172,7 +172,8 @@ void lv_destroy(lv_ctx* ctx) {
     for (LvDeviceBuffer* b : {&ctx->points, &ctx->segIdx, &ctx->nodes, &ctx->segs, &ctx->leafSeg, &ctx->segToLeaf, &ctx->tf,
                               &ctx->depthMinMax, &ctx->ao, &ctx->aoGbuf, &ctx->aoList, &ctx->aoSamples, &ctx->counters,
                               &ctx->ppllNodes, &ctx->ppllStart, &ctx->ppllScratch, &ctx->tilesDev, &ctx->outDev,
-                              &ctx->scratchRays, &ctx->stackOverflow})
+                              &ctx->scratchRays, &ctx->stackOverflow, &ctx->triIdx, &ctx->triVerts, &ctx->triPoints,
+                              &ctx->triNodes, &ctx->tris})
         lv_buf_free(*b);
     if (ctx->evCreated) {
         for (int i = 0; i < 16; i++) (void)hipEventDestroy(ctx->ev[i]);
@@ -217,6 +218,45 @@ int lv_set_lines(lv_ctx* ctx, const lv_line_point* points, uint32_t num_points, 
     ctx->numPoints = num_points;
     ctx->numSegs = num_segments;
     ctx->accelValid = false;
+    return LV_OK;
+}
+
+int lv_set_tube_triangle_mesh(lv_ctx* ctx, const uint32_t* triangle_indices, uint32_t num_triangles,
+                              const lv_tube_vertex* vertices, uint32_t num_vertices, const lv_line_point* line_points,
+                              uint32_t num_line_points) {
+    if (!ctx) return LV_E_INVALID;
+    if ((num_triangles && !triangle_indices) || (num_vertices && !vertices) || (num_line_points && !line_points))
+        return lv_fail(ctx, LV_E_INVALID, "null input array");
+    if (num_triangles > 0x03FFFFFFu)
+        return lv_fail(ctx, LV_E_CAPACITY, "at most 2^26-1 triangles (leaf index field of the AO work queue)");
+    for (uint64_t i = 0; i < 3ull * num_triangles; i++)
+        if (triangle_indices[i] >= num_vertices)
+            return lv_fail(ctx, LV_E_INVALID, "triangle %llu references vertex %u >= num_vertices %u",
+                           (unsigned long long)(i / 3), triangle_indices[i], num_vertices);
+    for (uint32_t i = 0; i < num_vertices; i++)
+        if ((vertices[i].vertexLinePointIndex & 0x7FFFFFFFu) >= num_line_points && num_triangles)
+            return lv_fail(ctx, LV_E_INVALID, "vertex %u references line point %u >= num_line_points %u", i,
+                           vertices[i].vertexLinePointIndex & 0x7FFFFFFFu, num_line_points);
+    (void)hipSetDevice(ctx->device);
+    int rc;
+    if ((rc = lv_buf_reserve(ctx, ctx->triIdx, size_t(num_triangles) * 12))) return rc;
+    if ((rc = lv_buf_reserve(ctx, ctx->triVerts, size_t(num_vertices) * sizeof(lv_tube_vertex)))) return rc;
+    if ((rc = lv_buf_reserve(ctx, ctx->triPoints, size_t(num_line_points) * sizeof(lv_line_point)))) return rc;
+    if (num_triangles)
+        LV_HIP(ctx, hipMemcpyAsync(ctx->triIdx.ptr, triangle_indices, size_t(num_triangles) * 12, hipMemcpyHostToDevice,
+                                   ctx->stream));
+    if (num_vertices)
+        LV_HIP(ctx, hipMemcpyAsync(ctx->triVerts.ptr, vertices, size_t(num_vertices) * sizeof(lv_tube_vertex),
+                                   hipMemcpyHostToDevice, ctx->stream));
+    if (num_line_points)
+        LV_HIP(ctx, hipMemcpyAsync(ctx->triPoints.ptr, line_points, size_t(num_line_points) * sizeof(lv_line_point),
+                                   hipMemcpyHostToDevice, ctx->stream));
+    LV_HIP(ctx, hipStreamSynchronize(ctx->stream)); // host arrays are borrowed for the call only
+    ctx->numTris = num_triangles;
+    ctx->numTriVerts = num_vertices;
+    ctx->numTriPoints = num_line_points;
+    ctx->triMeshSet = true;
+    ctx->triAccelValid = false;
     return LV_OK;
 }
 
@@ -336,6 +376,10 @@ int lv_set_option(lv_ctx* ctx, const char* key, const char* value) {
         (k == "ppll_tile_width" ? o.ppllTileW : o.ppllTileH) = u;
     } else if (k == "collect_stats") {
         o.collectStats = parseBool(value);
+    } else if (k == "rtao_geometry") {
+        if (std::string(value) == "capsules") o.aoTriangleTubes = false;
+        else if (std::string(value) == "triangle_tubes") o.aoTriangleTubes = true;
+        else return bad();
     } else {
         return lv_fail(ctx, LV_E_INVALID, "unknown option '%s'", key);
     }
@@ -381,6 +425,7 @@ int lv_get_stats(lv_ctx* ctx, lv_stats* out) {
     s.bvh_depth = ctx->bvhDepth;
     s.num_segments = ctx->numSegs;
     s.num_nodes = ctx->numNodes;
+    s.num_tube_triangles = ctx->numTris;
     auto ms = [&](int a, int b) {
         float t = 0.0f;
         if (hipEventElapsedTime(&t, ctx->ev[a], ctx->ev[b]) != hipSuccess) t = 0.0f;
@@ -429,7 +474,8 @@ int lv_get_stats(lv_ctx* ctx, lv_stats* out) {
     for (const LvDeviceBuffer* b : {&ctx->points, &ctx->segIdx, &ctx->nodes, &ctx->segs, &ctx->leafSeg, &ctx->segToLeaf, &ctx->tf,
                                     &ctx->depthMinMax, &ctx->ao, &ctx->aoGbuf, &ctx->aoList, &ctx->aoSamples,
                                     &ctx->counters, &ctx->ppllNodes, &ctx->ppllStart, &ctx->ppllScratch, &ctx->tilesDev,
-                                    &ctx->outDev, &ctx->scratchRays, &ctx->stackOverflow})
+                                    &ctx->outDev, &ctx->scratchRays, &ctx->stackOverflow, &ctx->triIdx, &ctx->triVerts,
+                                    &ctx->triPoints, &ctx->triNodes, &ctx->tris})
         bytes += b->bytes;
     s.device_bytes = bytes;
     *out = s;
@@ -452,6 +498,14 @@ int lv_trace_rays(lv_ctx* ctx, const float* origins, const float* dirs, float t_
         return lv_fail(ctx, LV_E_STATE, "lv_set_lines has not been called");
     (void)hipSetDevice(ctx->device);
     return lv_frame_trace_rays(ctx, origins, dirs, t_min, t_max, n, out_t, out_segment, out_kind);
+}
+
+int lv_trace_rays_triangles(lv_ctx* ctx, const float* origins, const float* dirs, float t_min, float t_max, uint32_t n,
+                            float* out_t, uint32_t* out_triangle, float* out_uv) {
+    if (!ctx) return LV_E_INVALID;
+    if (n && (!origins || !dirs || !out_t || !out_triangle)) return lv_fail(ctx, LV_E_INVALID, "null array");
+    (void)hipSetDevice(ctx->device);
+    return lv_frame_trace_rays_triangles(ctx, origins, dirs, t_min, t_max, n, out_t, out_triangle, out_uv);
 }
 
 int lv_compute_depth_range(lv_ctx* ctx, float out_min_max[2]) {

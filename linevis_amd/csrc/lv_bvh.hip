@@ -97,6 +97,53 @@ __global__ __launch_bounds__(LV_BLOCK) void k_leaves(const lv_line_point* __rest
     for (int k = 0; k < 6; k++) leafBox[6 * size_t(i) + k] = boxOrig[6 * size_t(s) + k];
 }
 
+// triangle tubes: padded AABB of every triangle (the same box the ray-triangle test clips t against)
+__global__ __launch_bounds__(LV_BLOCK) void k_tri_boxes(const lv_tube_vertex* __restrict__ verts,
+                                                        const uint32_t* __restrict__ triIdx, uint32_t nTri, float pad,
+                                                        float* __restrict__ boxOrig, uint32_t* __restrict__ boundsOrd) {
+    uint32_t s = blockIdx.x * LV_BLOCK + threadIdx.x;
+    float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    if (s < nTri) {
+        const float* a = verts[triIdx[3 * size_t(s)]].vertexPosition;
+        const float* b = verts[triIdx[3 * size_t(s) + 1]].vertexPosition;
+        const float* c = verts[triIdx[3 * size_t(s) + 2]].vertexPosition;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            mn[k] = fminf(fminf(a[k], b[k]), c[k]) - pad;
+            mx[k] = fmaxf(fmaxf(a[k], b[k]), c[k]) + pad;
+            boxOrig[6 * size_t(s) + k] = mn[k];
+            boxOrig[6 * size_t(s) + 3 + k] = mx[k];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        float a = lv_wave_min(mn[k]), b = lv_wave_max(mx[k]);
+        if (lv_lane() == 0) {
+            atomicMin(&boundsOrd[k], lv_f2ord(a));
+            atomicMax(&boundsOrd[3 + k], lv_f2ord(b));
+        }
+    }
+}
+
+// 48-byte triangle records in Morton order: {v0.xyz, original triangle index}{v1.xyz, 0}{v2.xyz, 0}
+__global__ __launch_bounds__(LV_BLOCK) void k_tri_leaves(const lv_tube_vertex* __restrict__ verts,
+                                                         const uint32_t* __restrict__ triIdx,
+                                                         const float* __restrict__ boxOrig,
+                                                         const uint32_t* __restrict__ sortedVals, uint32_t nTri,
+                                                         float4* __restrict__ tris, float* __restrict__ leafBox) {
+    uint32_t i = blockIdx.x * LV_BLOCK + threadIdx.x;
+    if (i >= nTri) return;
+    uint32_t s = sortedVals[i];
+    const float* a = verts[triIdx[3 * size_t(s)]].vertexPosition;
+    const float* b = verts[triIdx[3 * size_t(s) + 1]].vertexPosition;
+    const float* c = verts[triIdx[3 * size_t(s) + 2]].vertexPosition;
+    tris[3 * size_t(i)] = make_float4(a[0], a[1], a[2], __uint_as_float(s));
+    tris[3 * size_t(i) + 1] = make_float4(b[0], b[1], b[2], 0.0f);
+    tris[3 * size_t(i) + 2] = make_float4(c[0], c[1], c[2], 0.0f);
+#pragma unroll
+    for (int k = 0; k < 6; k++) leafBox[6 * size_t(i) + k] = boxOrig[6 * size_t(s) + k];
+}
+
 __device__ __forceinline__ int lv_delta(const uint64_t* __restrict__ keys, int n, int i, int j) {
     if (j < 0 || j >= n) return -1;
     uint64_t a = keys[i], b = keys[j];
@@ -303,27 +350,17 @@ inline uint32_t nblocks(uint64_t n) { return uint32_t((n + LV_BLOCK - 1) / LV_BL
 
 } // namespace
 
-int lv_bvh_build(lv_ctx* ctx) {
-    const uint32_t n = ctx->numSegs;
+// Shared build: `boxes(boxOrig, bounds)` fills the per-primitive AABBs + scene bounds, `leaves(sortedVals, boxOrig,
+// leafBox)` writes the primitive records and leaf boxes in Morton order; the topology / refit / collapse stages are the
+// same for capsules and triangles.
+template <class BOXES, class LEAVES>
+static int lv_bvh_build_core(lv_ctx* ctx, uint32_t n, LvDeviceBuffer& nodesOut, uint32_t& numNodesOut, uint32_t& depthOut,
+                             bool timed, BOXES&& boxes, LEAVES&& leaves) {
     hipStream_t st = ctx->stream;
-    ctx->accelValid = false;
-    ctx->bvhDepth = 0;
-    ctx->numNodes = 0;
-    if (n == 0) {
-        ctx->accelValid = true;
-        ctx->accelLineWidth = ctx->opt.lineWidth;
-        return LV_OK;
-    }
-    const float radius = ctx->opt.lineWidth * 0.5f;
-    const float pad = radius * 1e-3f + 1e-6f;
     const uint32_t nInternal = n > 1 ? n - 1 : 1;
-
     int rc;
     // 4-wide nodes: one per even-depth binary node; at most all of them (a degenerate chain has ~n/2)
-    if ((rc = lv_buf_reserve(ctx, ctx->nodes, size_t(nInternal) * 64))) return rc;
-    if ((rc = lv_buf_reserve(ctx, ctx->segs, size_t(n) * 32))) return rc;
-    if ((rc = lv_buf_reserve(ctx, ctx->leafSeg, size_t(n) * 4))) return rc;
-    if ((rc = lv_buf_reserve(ctx, ctx->segToLeaf, size_t(n) * 4))) return rc;
+    if ((rc = lv_buf_reserve(ctx, nodesOut, size_t(nInternal) * 64))) return rc;
 
     // temporaries
     LvDeviceBuffer boxOrig, leafBox, nodeBox, keysA, keysB, valsA, valsB, childL, childR, parI, parL, height, flags, bounds,
@@ -365,15 +402,14 @@ int lv_bvh_build(lv_ctx* ctx) {
     LV_TRY(lv_buf_reserve(ctx, evenFlag, size_t(nInternal) * 4));
     LV_TRY(lv_buf_reserve(ctx, wideIndex, size_t(nInternal) * 4));
 
-    LV_HIPF(hipEventRecord(ctx->ev[0], st));
+    if (timed) LV_HIPF(hipEventRecord(ctx->ev[0], st));
     // bounds: min slots start at ord(+big) = 0xFFFFFFFF-ish, max slots at 0
     {
         uint32_t init[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
         LV_HIPF(hipMemcpyAsync(bounds.ptr, init, sizeof(init), hipMemcpyHostToDevice, st));
         LV_HIPF(hipStreamSynchronize(st)); // init[] is a stack array
     }
-    k_seg_boxes<<<nblocks(n), LV_BLOCK, 0, st>>>((const lv_line_point*)ctx->points.ptr, (const uint32_t*)ctx->segIdx.ptr, n,
-                                                 radius, pad, (float*)boxOrig.ptr, (uint32_t*)bounds.ptr);
+    boxes((float*)boxOrig.ptr, (uint32_t*)bounds.ptr);
     k_morton<<<nblocks(n), LV_BLOCK, 0, st>>>((const float*)boxOrig.ptr, n, (const uint32_t*)bounds.ptr,
                                               (uint64_t*)keysA.ptr, (uint32_t*)valsA.ptr);
     {
@@ -384,13 +420,9 @@ int lv_bvh_build(lv_ctx* ctx) {
         LV_HIPF(rocprim::radix_sort_pairs(sortTmp.ptr, tmpBytes, (uint64_t*)keysA.ptr, (uint64_t*)keysB.ptr,
                                           (uint32_t*)valsA.ptr, (uint32_t*)valsB.ptr, n, 0, 63, st));
     }
-    k_leaves<<<nblocks(n), LV_BLOCK, 0, st>>>((const lv_line_point*)ctx->points.ptr, (const uint32_t*)ctx->segIdx.ptr,
-                                              (const float*)boxOrig.ptr, (const uint32_t*)valsB.ptr, n,
-                                              (float4*)ctx->segs.ptr, (uint32_t*)ctx->leafSeg.ptr, (uint32_t*)ctx->segToLeaf.ptr,
-                                              (float*)leafBox.ptr);
+    leaves((const uint32_t*)valsB.ptr, (const float*)boxOrig.ptr, (float*)leafBox.ptr);
     if (n == 1) {
-        k_single_node<<<1, 64, 0, st>>>((const float*)leafBox.ptr, (float4*)ctx->nodes.ptr);
-        ctx->bvhDepth = 1;
+        k_single_node<<<1, 64, 0, st>>>((const float*)leafBox.ptr, (float4*)nodesOut.ptr);
     } else {
         LV_HIPF(hipMemsetAsync(flags.ptr, 0, size_t(nInternal) * 4, st));
         k_karras<<<nblocks(nInternal), LV_BLOCK, 0, st>>>((const uint64_t*)keysB.ptr, int(n), (uint32_t*)childL.ptr,
@@ -413,18 +445,19 @@ int lv_bvh_build(lv_ctx* ctx) {
         k_pack4<<<nblocks(nInternal), LV_BLOCK, 0, st>>>(int(nInternal), (const uint32_t*)childL.ptr,
                                                          (const uint32_t*)childR.ptr, (const float*)leafBox.ptr,
                                                          (const float*)nodeBox.ptr, (const uint32_t*)evenFlag.ptr,
-                                                         (const uint32_t*)wideIndex.ptr, (float4*)ctx->nodes.ptr);
+                                                         (const uint32_t*)wideIndex.ptr, (float4*)nodesOut.ptr);
     }
     LV_HIPF(hipGetLastError());
-    LV_HIPF(hipEventRecord(ctx->ev[1], st));
+    if (timed) LV_HIPF(hipEventRecord(ctx->ev[1], st));
     uint32_t numWide = 1;
+    depthOut = 1;
     if (n > 1) {
         uint32_t h = 0, lastIdx = 0, lastFlag = 0;
         LV_HIPF(hipMemcpyAsync(&h, height.ptr, 4, hipMemcpyDeviceToHost, st));
         LV_HIPF(hipMemcpyAsync(&lastIdx, (const uint32_t*)wideIndex.ptr + (nInternal - 1), 4, hipMemcpyDeviceToHost, st));
         LV_HIPF(hipMemcpyAsync(&lastFlag, (const uint32_t*)evenFlag.ptr + (nInternal - 1), 4, hipMemcpyDeviceToHost, st));
         LV_HIPF(hipStreamSynchronize(st));
-        ctx->bvhDepth = h;            // height of the binary LBVH; the 4-wide tree is ceil(h / 2) levels high
+        depthOut = h;                 // height of the binary LBVH; the 4-wide tree is ceil(h / 2) levels high
         numWide = lastIdx + lastFlag;
     } else {
         LV_HIPF(hipStreamSynchronize(st));
@@ -432,9 +465,77 @@ int lv_bvh_build(lv_ctx* ctx) {
     freeAll();
 #undef LV_TRY
 #undef LV_HIPF
-    ctx->numNodes = numWide;
+    numNodesOut = numWide;
+    return LV_OK;
+}
+
+int lv_bvh_build(lv_ctx* ctx) {
+    const uint32_t n = ctx->numSegs;
+    hipStream_t st = ctx->stream;
+    ctx->accelValid = false;
+    ctx->bvhDepth = 0;
+    ctx->numNodes = 0;
+    if (n == 0) {
+        ctx->accelValid = true;
+        ctx->accelLineWidth = ctx->opt.lineWidth;
+        return LV_OK;
+    }
+    const float radius = ctx->opt.lineWidth * 0.5f;
+    const float pad = radius * 1e-3f + 1e-6f;
+    int rc;
+    if ((rc = lv_buf_reserve(ctx, ctx->segs, size_t(n) * 32))) return rc;
+    if ((rc = lv_buf_reserve(ctx, ctx->leafSeg, size_t(n) * 4))) return rc;
+    if ((rc = lv_buf_reserve(ctx, ctx->segToLeaf, size_t(n) * 4))) return rc;
+    const lv_line_point* points = (const lv_line_point*)ctx->points.ptr;
+    const uint32_t* segIdx = (const uint32_t*)ctx->segIdx.ptr;
+    rc = lv_bvh_build_core(
+            ctx, n, ctx->nodes, ctx->numNodes, ctx->bvhDepth, true,
+            [&](float* boxOrig, uint32_t* bounds) {
+                k_seg_boxes<<<nblocks(n), LV_BLOCK, 0, st>>>(points, segIdx, n, radius, pad, boxOrig, bounds);
+            },
+            [&](const uint32_t* sortedVals, const float* boxOrig, float* leafBox) {
+                k_leaves<<<nblocks(n), LV_BLOCK, 0, st>>>(points, segIdx, boxOrig, sortedVals, n, (float4*)ctx->segs.ptr,
+                                                          (uint32_t*)ctx->leafSeg.ptr, (uint32_t*)ctx->segToLeaf.ptr,
+                                                          leafBox);
+            });
+    if (rc) return rc;
     ctx->accelValid = true;
     ctx->accelLineWidth = ctx->opt.lineWidth;
     ctx->evBuildValid = true;
+    return LV_OK;
+}
+
+// LBVH over the triangle tubes (VulkanRayTracedAmbientOcclusion.cpp:444-456 builds a triangle BLAS/TLAS from the same
+// buffers).  The pad depends on the line width like the capsule pad, so the tree is rebuilt when it changes.
+int lv_bvh_build_triangles(lv_ctx* ctx) {
+    const uint32_t n = ctx->numTris;
+    hipStream_t st = ctx->stream;
+    ctx->triAccelValid = false;
+    ctx->triBvhDepth = 0;
+    ctx->numTriNodes = 0;
+    const float radius = ctx->opt.lineWidth * 0.5f;
+    ctx->triPad = radius * 1e-3f + 1e-6f;
+    if (n == 0) {
+        ctx->triAccelValid = true;
+        ctx->triAccelLineWidth = ctx->opt.lineWidth;
+        return LV_OK;
+    }
+    int rc;
+    if ((rc = lv_buf_reserve(ctx, ctx->tris, size_t(n) * 48))) return rc;
+    const lv_tube_vertex* verts = (const lv_tube_vertex*)ctx->triVerts.ptr;
+    const uint32_t* triIdx = (const uint32_t*)ctx->triIdx.ptr;
+    const float pad = ctx->triPad;
+    rc = lv_bvh_build_core(
+            ctx, n, ctx->triNodes, ctx->numTriNodes, ctx->triBvhDepth, false,
+            [&](float* boxOrig, uint32_t* bounds) {
+                k_tri_boxes<<<nblocks(n), LV_BLOCK, 0, st>>>(verts, triIdx, n, pad, boxOrig, bounds);
+            },
+            [&](const uint32_t* sortedVals, const float* boxOrig, float* leafBox) {
+                k_tri_leaves<<<nblocks(n), LV_BLOCK, 0, st>>>(verts, triIdx, boxOrig, sortedVals, n,
+                                                              (float4*)ctx->tris.ptr, leafBox);
+            });
+    if (rc) return rc;
+    ctx->triAccelValid = true;
+    ctx->triAccelLineWidth = ctx->opt.lineWidth;
     return LV_OK;
 }

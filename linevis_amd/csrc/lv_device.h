@@ -101,8 +101,17 @@ struct LvSceneDev {
     const float* depthMinMax;   // {minDepth, maxDepth}, produced on device by the depth-range kernels
     const float* ao;            // full-viewport AO factors
     unsigned* stackOverflow;    // null unless the LBVH is higher than LV_STACK_LDS
-    uint32_t numSegs;
+    uint32_t numSegs;           // primitives under `nodes` (segments, or triangles in a triangle-tube scene view)
+    // triangle tubes (the reference's RTAO geometry); in the scene view handed to the triangle kernels `nodes` is the
+    // triangle LBVH and numSegs the triangle count
+    const float4* tris;         // 48-B records in Morton order: {v0.xyz, triangle index bits}{v1.xyz, 0}{v2.xyz, 0}
+    const uint32_t* triIdx;     // 3 vertex indices per triangle, input order
+    const lv_tube_vertex* triVerts; // 32-B TubeTriangleVertexData, input order
+    const lv_line_point* triPoints; // line points referenced by the vertices
+    float triPad;               // padding of a triangle's own AABB (part of the ray-triangle test definition)
 };
+#define LV_PRIM_CAPSULE 0
+#define LV_PRIM_TRIANGLE 1
 
 // tile list of a launch: tiles are tileW x tileH pixel rectangles with origins tilesXY[2*i], tilesXY[2*i+1]
 struct LvTiles {

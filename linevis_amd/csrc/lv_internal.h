@@ -39,6 +39,7 @@ struct LvOptions {
     uint32_t ppllExpectedAvgDepthComplexity = 0; // 0 = auto: 20 / 120
     uint32_t ppllTileW = 2, ppllTileH = 8;    // LineRenderer.cpp:739-740
     bool collectStats = false;
+    bool aoTriangleTubes = false;             // rtao_geometry: false = capsules (build default), true = the reference's triangle tubes
 };
 
 struct lv_ctx {
@@ -58,6 +59,12 @@ struct lv_ctx {
     bool accelValid = false;
     float accelLineWidth = -1.0f;
     uint32_t bvhDepth = 0;
+    // triangle tubes (RTAO geometry of the reference), own LBVH
+    uint32_t numTris = 0, numTriVerts = 0, numTriPoints = 0, numTriNodes = 0, triBvhDepth = 0;
+    LvDeviceBuffer triIdx, triVerts, triPoints; // input order
+    LvDeviceBuffer triNodes, tris;              // accel
+    bool triMeshSet = false, triAccelValid = false;
+    float triAccelLineWidth = -1.0f, triPad = 0.0f;
 
     // camera
     bool cameraSet = false;
@@ -116,11 +123,14 @@ void lv_buf_free(LvDeviceBuffer& b);
 
 // lv_bvh.hip
 int lv_bvh_build(lv_ctx* ctx);
+int lv_bvh_build_triangles(lv_ctx* ctx);
 // lv_render.hip
 int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t numTiles, uint32_t tileW,
                     uint32_t tileH, void* outDevice);
 int lv_frame_trace_rays(lv_ctx* ctx, const float* o, const float* d, float tMin, float tMax, uint32_t n, float* outT,
                         uint32_t* outSeg, uint32_t* outKind);
+int lv_frame_trace_rays_triangles(lv_ctx* ctx, const float* o, const float* d, float tMin, float tMax, uint32_t n,
+                                  float* outT, uint32_t* outTri, float* outUV);
 int lv_frame_depth_range(lv_ctx* ctx);
 int lv_frame_ppll_resolve_only(lv_ctx* ctx, const uint32_t* nodes, uint64_t numNodes, const uint32_t* start,
                                uint64_t numPixels, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, uint8_t* out);

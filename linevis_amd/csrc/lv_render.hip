@@ -160,7 +160,7 @@ __global__ __launch_bounds__(LV_BLOCK) void k_render_rt(const LvUniforms U, cons
 // ================================================================ RTAO
 // G-buffer entry of a pixel whose primary ray hit: 3 x float4
 //   g0 = {hit position, offsetFactor}, g1 = {surface tangent, pixel index bits}, g2 = {surface normal, 0}
-template <bool STATS>
+template <bool STATS, int PRIM>
 __global__ __launch_bounds__(LV_BLOCK) void k_ao_primary(const LvUniforms U, const LvSceneDev S, const LvTiles T,
                                                          float* __restrict__ ao, float4* __restrict__ gbuf,
                                                          LvDevCounters* dc) {
@@ -180,10 +180,38 @@ __global__ __launch_bounds__(LV_BLOCK) void k_ao_primary(const LvUniforms U, con
     f3 o, d;
     lv_primary_ray(U, px.x, px.y, xix, xiy, o, d);
     // wave-cooperative: every lane calls, lanes outside the viewport only help testing
-    const LvHit h = lv_trace_closest<STATS, false>(S, U.radius, U.useCappedTubes != 0, px.inView, o, d, 0.0001f, 1000.0f,
-                                                   lv_stack_mem(s_stack, S.stackOverflow), cm, cnt);
+    const LvHit h = lv_trace_closest<STATS, false, PRIM>(S, U.radius, U.useCappedTubes != 0, px.inView, o, d, 0.0001f,
+                                                         1000.0f, lv_stack_mem(s_stack, S.stackOverflow), cm, cnt);
     if (px.inView) {
-        if (h.found) {
+        if (h.found && PRIM == LV_PRIM_TRIANGLE) {
+            // barycentric reconstruction, VulkanRayTracedAmbientOcclusion.glsl:219-263,280
+            hasHit = true;
+            const uint32_t i0 = S.triIdx[3 * size_t(h.leaf)], i1 = S.triIdx[3 * size_t(h.leaf) + 1],
+                           i2 = S.triIdx[3 * size_t(h.leaf) + 2];
+            const lv_tube_vertex& vd0 = S.triVerts[i0];
+            const lv_tube_vertex& vd1 = S.triVerts[i1];
+            const lv_tube_vertex& vd2 = S.triVerts[i2];
+            const f3 p0 = mk3(vd0.vertexPosition[0], vd0.vertexPosition[1], vd0.vertexPosition[2]);
+            const f3 p1 = mk3(vd1.vertexPosition[0], vd1.vertexPosition[1], vd1.vertexPosition[2]);
+            const f3 p2 = mk3(vd2.vertexPosition[0], vd2.vertexPosition[1], vd2.vertexPosition[2]);
+            float tt = 0.0f, bu = 0.0f, bv = 0.0f; // same function, same inputs as the winning test: identical (t, u, v)
+            lv_ray_triangle(o, d, mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z), p0, p1, p2, S.triPad, tt, bu, bv);
+            const float b0 = (1.0f - bu) - bv;
+            const lv_line_point& lp0 = S.triPoints[vd0.vertexLinePointIndex & 0x7FFFFFFFu];
+            const lv_line_point& lp1 = S.triPoints[vd1.vertexLinePointIndex & 0x7FFFFFFFu];
+            const lv_line_point& lp2 = S.triPoints[vd2.vertexLinePointIndex & 0x7FFFFFFFu];
+            auto lerp3 = [&](const float* a, const float* b, const float* c) {
+                return (mk3(a[0], a[1], a[2]) * b0 + mk3(b[0], b[1], b[2]) * bu) + mk3(c[0], c[1], c[2]) * bv;
+            };
+            const f3 vertexPositionWorld = lerp3(vd0.vertexPosition, vd1.vertexPosition, vd2.vertexPosition);
+            const f3 surfaceNormal = norm3(lerp3(vd0.vertexNormal, vd1.vertexNormal, vd2.vertexNormal));
+            const f3 linePosition = lerp3(lp0.linePosition, lp1.linePosition, lp2.linePosition);
+            const f3 surfaceTangent = norm3(lerp3(lp0.lineTangent, lp1.lineTangent, lp2.lineTangent));
+            const float offsetFactor = len3(linePosition - vertexPositionWorld) / U.subdivisionCorrectionFactor;
+            g0 = make_float4(vertexPositionWorld.x, vertexPositionWorld.y, vertexPositionWorld.z, offsetFactor);
+            g1 = make_float4(surfaceTangent.x, surfaceTangent.y, surfaceTangent.z, __uint_as_float(pix));
+            g2 = make_float4(surfaceNormal.x, surfaceNormal.y, surfaceNormal.z, 0.0f);
+        } else if (h.found) {
             hasHit = true;
             const float4 ra = S.segs[2 * h.leaf], rb = S.segs[2 * h.leaf + 1];
             const uint32_t seg = S.leafSeg[h.leaf];
@@ -246,7 +274,7 @@ __global__ __launch_bounds__(LV_BLOCK) void k_ao_primary(const LvUniforms U, con
 // A finished ray is retired (samples[r] written, lane idle) once the FIFO head has passed its last queued leaf.
 // Scheduling inside a wave: test when >= 64 pairs wait; refill when >= LV_REFILL_THRESHOLD lanes are idle; otherwise
 // descend; flush partial batches only when nothing else can make progress.
-template <bool STATS, bool ANY_HIT>
+template <bool STATS, bool ANY_HIT, int PRIM>
 __global__ __launch_bounds__(LV_AO_BLOCK) void k_ao_rays(const LvUniforms U, const LvSceneDev S,
                                                          const float4* __restrict__ gbuf, float* __restrict__ samples,
                                                          LvDevCounters* dc) {
@@ -326,13 +354,11 @@ __global__ __launch_bounds__(LV_AO_BLOCK) void k_ao_rays(const LvUniforms U, con
                 const unsigned e = queueW[(head + lane) % LV_AO_QCAP];
                 const unsigned owner = e >> 26, leaf = e & 0x03FFFFFFu;
                 const float4 ro = rayW[2 * owner], rd = rayW[2 * owner + 1];
-                const float4 a = S.segs[2 * leaf], b = S.segs[2 * leaf + 1];
                 if (STATS) cnt.prims++;
-                float t; int kind;
-                if (lv_intersect_capsule(mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), mk3(a.x, a.y, a.z),
-                                         mk3(b.x, b.y, b.z), radius, capped, t, kind)) {
+                float t; unsigned low;
+                if (lv_leaf_test<PRIM>(S, leaf, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), radius, capped, t, low)) {
                     if (t >= 0.0f && t <= U.aoRadius) // traceAoRay: closest hit in [0, aoRadius], glsl:158-175
-                        atomicMin(&keyW[owner], ((unsigned long long)__float_as_uint(t) << 32) | S.leafSeg[leaf]);
+                        atomicMin(&keyW[owner], ((unsigned long long)__float_as_uint(t) << 32) | low);
                 }
             }
             head += n;
@@ -692,6 +718,37 @@ __global__ __launch_bounds__(LV_BLOCK) void k_trace_rays(const LvSceneDev S, flo
     outKind[i] = h.found ? uint32_t(h.kind) : 0u;
 }
 
+__global__ __launch_bounds__(LV_BLOCK) void k_trace_rays_tri(const LvSceneDev S, const float* __restrict__ org,
+                                                             const float* __restrict__ dir, float tMin, float tMax,
+                                                             uint32_t n, float* __restrict__ outT,
+                                                             uint32_t* __restrict__ outTri, float* __restrict__ outUV) {
+    __shared__ unsigned s_stack[LV_STACK_LDS * LV_BLOCK];
+    LV_COOP_SHARED(LV_BLOCK / LV_WAVE);
+    LV_COOP_MEM(cm);
+    const uint32_t i = blockIdx.x * LV_BLOCK + threadIdx.x;
+    const bool valid = i < n;
+    LvCounters cnt = {0, 0, 0, 0};
+    const uint32_t j = valid ? i : 0u;
+    f3 o = mk3(org[3 * j], org[3 * j + 1], org[3 * j + 2]);
+    f3 d = mk3(dir[3 * j], dir[3 * j + 1], dir[3 * j + 2]);
+    LvHit h = lv_trace_closest<false, false, LV_PRIM_TRIANGLE>(S, 0.0f, false, valid, o, d, tMin, tMax,
+                                                               lv_stack_mem(s_stack, S.stackOverflow), cm, cnt);
+    if (!valid) return;
+    float t = tMax, u = 0.0f, v = 0.0f;
+    if (h.found) {
+        const uint32_t* ti = S.triIdx + 3 * size_t(h.leaf);
+        const float* a = S.triVerts[ti[0]].vertexPosition;
+        const float* b = S.triVerts[ti[1]].vertexPosition;
+        const float* c = S.triVerts[ti[2]].vertexPosition;
+        lv_ray_triangle(o, d, mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z), mk3(a[0], a[1], a[2]), mk3(b[0], b[1], b[2]),
+                        mk3(c[0], c[1], c[2]), S.triPad, t, u, v);
+    }
+    outT[i] = h.found ? h.t : tMax;
+    outTri[i] = h.found ? h.leaf : 0xFFFFFFFFu;
+    outUV[2 * size_t(i)] = u;
+    outUV[2 * size_t(i) + 1] = v;
+}
+
 inline uint32_t nblocks(uint64_t n, uint32_t bs = LV_BLOCK) { return uint32_t((n + bs - 1) / bs); }
 
 void padTiling(uint32_t& w, uint32_t& h, uint32_t tw, uint32_t th) {
@@ -713,6 +770,20 @@ LvSceneDev sceneDev(const lv_ctx* ctx) {
     S.ao = (const float*)ctx->ao.ptr;
     S.stackOverflow = nullptr;
     S.numSegs = ctx->numSegs;
+    S.tris = nullptr; S.triIdx = nullptr; S.triVerts = nullptr; S.triPoints = nullptr; S.triPad = 0.0f;
+    return S;
+}
+
+// scene view for the triangle-tube kernels: `nodes` = triangle LBVH, numSegs = triangle count
+LvSceneDev sceneDevTriangles(const lv_ctx* ctx) {
+    LvSceneDev S = sceneDev(ctx);
+    S.nodes = (const float4*)ctx->triNodes.ptr;
+    S.numSegs = ctx->numTris;
+    S.tris = (const float4*)ctx->tris.ptr;
+    S.triIdx = (const uint32_t*)ctx->triIdx.ptr;
+    S.triVerts = (const lv_tube_vertex*)ctx->triVerts.ptr;
+    S.triPoints = (const lv_line_point*)ctx->triPoints.ptr;
+    S.triPad = ctx->triPad;
     return S;
 }
 
@@ -796,10 +867,11 @@ int lv_frame_depth_range(lv_ctx* ctx) {
 }
 
 // the global part of the traversal stacks: only when the tree is higher than the LDS-staged part
-static int lv_prepare_overflow(lv_ctx* ctx, LvSceneDev& S, uint64_t gridBlocks, uint32_t ldsEntries = LV_STACK_LDS) {
+static int lv_prepare_overflow(lv_ctx* ctx, LvSceneDev& S, uint64_t gridBlocks, uint32_t ldsEntries = LV_STACK_LDS,
+                               bool triangles = false) {
     S.stackOverflow = nullptr;
     // the 4-wide tree is ceil(height / 2) levels high and a step pushes at most 3 references
-    const uint64_t maxEntries = 3ull * ((uint64_t(ctx->bvhDepth) + 1) / 2) + 2;
+    const uint64_t maxEntries = 3ull * ((uint64_t(triangles ? ctx->triBvhDepth : ctx->bvhDepth) + 1) / 2) + 2;
     if (maxEntries <= ldsEntries) return LV_OK;
     const uint64_t extra = maxEntries - ldsEntries;
     int rc = lv_buf_reserve(ctx, ctx->stackOverflow, size_t(gridBlocks) * LV_BLOCK * extra * 4);
@@ -822,28 +894,34 @@ static int lv_run_ao(lv_ctx* ctx, LvUniforms& U, LvSceneDev& S, const LvTiles& T
     if (gridRays > (maxRays + LV_AO_BLOCK - 1) / LV_AO_BLOCK) gridRays = (maxRays + LV_AO_BLOCK - 1) / LV_AO_BLOCK;
     if (gridRays == 0) gridRays = 1;
     const uint64_t gridMax = gridRays > gridTiles ? gridRays : gridTiles;
-    if ((rc = lv_prepare_overflow(ctx, S, gridMax, LV_AO_STACK_LDS))) return rc;
+    const bool tri = ctx->opt.aoTriangleTubes;
+    // RTAO geometry: the capsules of the colour pass, or the reference's triangle tubes (own LBVH, own scene view)
+    LvSceneDev SA = tri ? sceneDevTriangles(ctx) : S;
+    if ((rc = lv_prepare_overflow(ctx, SA, gridMax, LV_AO_STACK_LDS, tri))) return rc;
     const bool stats = ctx->opt.collectStats;
     for (uint32_t iter = 0; iter < ctx->opt.aoIterations; iter++) {
         U.aoFrameNumber = iter; // rtaoRenderPass->setFrameNumber(accumulatedFramesCounter), VulkanRayTracedAmbientOcclusion.cpp:92
         LV_HIP(ctx, hipMemsetAsync(&dc->aoCount, 0, 4, st));
         LV_HIP(ctx, hipMemsetAsync(&dc->aoQueueHead, 0, 8, st));
-        if (stats)
-            LV_TIMED_LAUNCH(ctx, LV_KERNEL_AO_PRIMARY, (k_ao_primary<true><<<gridTiles, LV_BLOCK, 0, st>>>(
-                    U, S, T, (float*)ctx->ao.ptr, (float4*)ctx->aoGbuf.ptr, dc)));
-        else
-            LV_TIMED_LAUNCH(ctx, LV_KERNEL_AO_PRIMARY, (k_ao_primary<false><<<gridTiles, LV_BLOCK, 0, st>>>(
-                    U, S, T, (float*)ctx->ao.ptr, (float4*)ctx->aoGbuf.ptr, dc)));
         const uint32_t grid = uint32_t(gridRays);
         const float4* g = (const float4*)ctx->aoGbuf.ptr;
         float* ao = (float*)ctx->ao.ptr;
         float* smp = (float*)ctx->aoSamples.ptr;
-#define LV_LAUNCH_AO(ST, AH) \
-    LV_TIMED_LAUNCH(ctx, LV_KERNEL_AO_RAYS, (k_ao_rays<ST, AH><<<grid, LV_AO_BLOCK, 0, st>>>(U, S, g, smp, dc)))
+#define LV_LAUNCH_AOP(ST, PR)                                                                                 \
+    LV_TIMED_LAUNCH(ctx, LV_KERNEL_AO_PRIMARY, (k_ao_primary<ST, PR><<<gridTiles, LV_BLOCK, 0, st>>>(        \
+            U, SA, T, ao, (float4*)ctx->aoGbuf.ptr, dc)))
+#define LV_LAUNCH_AO(ST, AH, PR) \
+    LV_TIMED_LAUNCH(ctx, LV_KERNEL_AO_RAYS, (k_ao_rays<ST, AH, PR><<<grid, LV_AO_BLOCK, 0, st>>>(U, SA, g, smp, dc)))
+#define LV_LAUNCH_AO2(ST, AH) \
+    do { if (tri) LV_LAUNCH_AO(ST, AH, LV_PRIM_TRIANGLE); else LV_LAUNCH_AO(ST, AH, LV_PRIM_CAPSULE); } while (0)
+        if (stats) { if (tri) LV_LAUNCH_AOP(true, LV_PRIM_TRIANGLE); else LV_LAUNCH_AOP(true, LV_PRIM_CAPSULE); }
+        else { if (tri) LV_LAUNCH_AOP(false, LV_PRIM_TRIANGLE); else LV_LAUNCH_AOP(false, LV_PRIM_CAPSULE); }
         const bool anyHit = !U.aoUseDistance;
-        if (stats) { if (anyHit) LV_LAUNCH_AO(true, true); else LV_LAUNCH_AO(true, false); }
-        else { if (anyHit) LV_LAUNCH_AO(false, true); else LV_LAUNCH_AO(false, false); }
+        if (stats) { if (anyHit) LV_LAUNCH_AO2(true, true); else LV_LAUNCH_AO2(true, false); }
+        else { if (anyHit) LV_LAUNCH_AO2(false, true); else LV_LAUNCH_AO2(false, false); }
+#undef LV_LAUNCH_AO2
 #undef LV_LAUNCH_AO
+#undef LV_LAUNCH_AOP
         k_ao_reduce<<<nblocks(maxPixels), LV_BLOCK, 0, st>>>(U, g, smp, ao, dc);
     }
     LV_HIP(ctx, hipGetLastError());
@@ -861,6 +939,12 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
     int rc;
     if (!ctx->accelValid || ctx->accelLineWidth != ctx->opt.lineWidth)
         if ((rc = lv_bvh_build(ctx))) return rc;
+    if (ctx->opt.useAmbientOcclusion && ctx->opt.aoTriangleTubes) {
+        if (!ctx->triMeshSet)
+            return lv_fail(ctx, LV_E_STATE, "rtao_geometry = triangle_tubes needs lv_set_tube_triangle_mesh");
+        if (!ctx->triAccelValid || ctx->triAccelLineWidth != ctx->opt.lineWidth)
+            if ((rc = lv_bvh_build_triangles(ctx))) return rc;
+    }
 
     hipStream_t st = ctx->stream;
     LvUniforms U;
@@ -1025,6 +1109,35 @@ int lv_frame_ppll_resolve_only(lv_ctx* ctx, const uint32_t* nodes, uint64_t numN
     }
     LV_HIP(ctx, hipGetLastError());
     LV_HIP(ctx, hipMemcpyAsync(out, ctx->outDev.ptr, size_t(w) * h * 4, hipMemcpyDeviceToHost, st));
+    LV_HIP(ctx, hipStreamSynchronize(st));
+    return LV_OK;
+}
+
+int lv_frame_trace_rays_triangles(lv_ctx* ctx, const float* o, const float* d, float tMin, float tMax, uint32_t n,
+                                  float* outT, uint32_t* outTri, float* outUV) {
+    int rc;
+    if (!ctx->triMeshSet) return lv_fail(ctx, LV_E_STATE, "lv_set_tube_triangle_mesh has not been called");
+    if (!ctx->triAccelValid || ctx->triAccelLineWidth != ctx->opt.lineWidth)
+        if ((rc = lv_bvh_build_triangles(ctx))) return rc;
+    if (n == 0) return LV_OK;
+    hipStream_t st = ctx->stream;
+    const size_t rb = size_t(n) * 12;
+    if ((rc = lv_buf_reserve(ctx, ctx->scratchRays, 2 * rb + size_t(n) * 16))) return rc;
+    char* base = (char*)ctx->scratchRays.ptr;
+    float* dO = (float*)base;
+    float* dD = (float*)(base + rb);
+    float* dT = (float*)(base + 2 * rb);
+    uint32_t* dS = (uint32_t*)(base + 2 * rb + size_t(n) * 4);
+    float* dUV = (float*)(base + 2 * rb + size_t(n) * 8);
+    LV_HIP(ctx, hipMemcpyAsync(dO, o, rb, hipMemcpyHostToDevice, st));
+    LV_HIP(ctx, hipMemcpyAsync(dD, d, rb, hipMemcpyHostToDevice, st));
+    LvSceneDev S = sceneDevTriangles(ctx);
+    if ((rc = lv_prepare_overflow(ctx, S, nblocks(n), LV_STACK_LDS, true))) return rc;
+    k_trace_rays_tri<<<nblocks(n), LV_BLOCK, 0, st>>>(S, dO, dD, tMin, tMax, n, dT, dS, dUV);
+    LV_HIP(ctx, hipGetLastError());
+    LV_HIP(ctx, hipMemcpyAsync(outT, dT, size_t(n) * 4, hipMemcpyDeviceToHost, st));
+    LV_HIP(ctx, hipMemcpyAsync(outTri, dS, size_t(n) * 4, hipMemcpyDeviceToHost, st));
+    if (outUV) LV_HIP(ctx, hipMemcpyAsync(outUV, dUV, size_t(n) * 8, hipMemcpyDeviceToHost, st));
     LV_HIP(ctx, hipStreamSynchronize(st));
     return LV_OK;
 }

@@ -79,6 +79,40 @@ __device__ __forceinline__ bool lv_intersect_capsule(f3 o, f3 d, f3 p0, f3 p1, f
     return has;
 }
 
+// ---------------------------------------------------------------- ray-triangle (triangle tubes of the reference's RTAO)
+// The driver's triangle test is unobservable; the build defines it (float32, fixed operation order):
+// Moeller-Trumbore without culling -- e1 = v1-v0, e2 = v2-v0, p = d x e2, det = e1.p (0 -> miss), u = ((o-v0).p)/det,
+// q = (o-v0) x e1, v = (d.q)/det, t = (e2.q)/det, accepted for u in [0,1], v >= 0, u+v <= 1 -- AND t inside the ray
+// interval of the triangle's own padded AABB.  The second rule is what an acceleration structure implies anyway (a
+// primitive is only tested when its box is hit); as part of the test it makes every conservative BVH agree with brute
+// force bit for bit, even where a grazing hit's t carries more float32 noise than the pad.
+__device__ __forceinline__ bool lv_ray_triangle(f3 o, f3 d, f3 inv, f3 v0, f3 v1, f3 v2, float pad, float& tOut, float& uOut,
+                                                float& vOut) {
+    const f3 e1 = v1 - v0, e2 = v2 - v0;
+    const f3 p = cross3(d, e2);
+    const float det = dot3(e1, p);
+    if (det == 0.0f) return false;
+    const float r = 1.0f / det;
+    const f3 tv = o - v0;
+    const float u = dot3(tv, p) * r;
+    if (!(u >= 0.0f && u <= 1.0f)) return false;
+    const f3 q = cross3(tv, e1);
+    const float v = dot3(d, q) * r;
+    if (!(v >= 0.0f && u + v <= 1.0f)) return false;
+    const float t = dot3(e2, q) * r;
+    const float mnx = fminf(fminf(v0.x, v1.x), v2.x) - pad, mxx = fmaxf(fmaxf(v0.x, v1.x), v2.x) + pad;
+    const float mny = fminf(fminf(v0.y, v1.y), v2.y) - pad, mxy = fmaxf(fmaxf(v0.y, v1.y), v2.y) + pad;
+    const float mnz = fminf(fminf(v0.z, v1.z), v2.z) - pad, mxz = fmaxf(fmaxf(v0.z, v1.z), v2.z) + pad;
+    const float tx0 = (mnx - o.x) * inv.x, tx1 = (mxx - o.x) * inv.x;
+    const float ty0 = (mny - o.y) * inv.y, ty1 = (mxy - o.y) * inv.y;
+    const float tz0 = (mnz - o.z) * inv.z, tz1 = (mxz - o.z) * inv.z;
+    const float tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fminf(tz0, tz1));
+    const float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fmaxf(tz0, tz1));
+    if (!(t >= tn && t <= tf)) return false;
+    tOut = t; uOut = u; vOut = v;
+    return true;
+}
+
 // ---------------------------------------------------------------- traversal stack: LDS-staged, HBM overflow
 // Entry i of a thread lives at lds[i * LV_BLOCK] (conflict-free ds_read/write_b32 across the wave).  An LBVH over
 // N segments is usually ~log2(N)+10 deep, so LV_STACK_LDS = 32 entries cover the common case entirely in LDS; deeper
@@ -145,7 +179,7 @@ __device__ __forceinline__ bool lv_slab(float bx0, float by0, float bz0, float b
 
 struct LvHit {
     float t;
-    uint32_t leaf; // leaf position (Morton order)
+    uint32_t leaf; // capsules: leaf position (Morton order); triangles: original triangle index
     int kind;
     bool found;
 };
@@ -247,6 +281,27 @@ __device__ __forceinline__ unsigned lv_node_step(const LvSceneDev& S, unsigned n
     return lv_pop_or_done(st);
 }
 
+// ---------------------------------------------------------------- leaf tests of the cooperative routines
+// One (ray, leaf) test.  Returns true with t and the low 32 bits of the merge key: capsules -> (original segment << 2)
+// | kind, triangles -> original triangle index; in both cases "smaller key = closer, ties to the lowest index".
+template <int PRIM>
+__device__ __forceinline__ bool lv_leaf_test(const LvSceneDev& S, unsigned leaf, f3 o, f3 d, float radius, bool capped,
+                                             float& t, unsigned& low) {
+    if (PRIM == LV_PRIM_TRIANGLE) {
+        const float4 a = S.tris[3 * size_t(leaf)], b = S.tris[3 * size_t(leaf) + 1], c = S.tris[3 * size_t(leaf) + 2];
+        const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+        float u, v;
+        low = __float_as_uint(a.w);
+        return lv_ray_triangle(o, d, inv, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), S.triPad, t, u, v);
+    } else {
+        const float4 a = S.segs[2 * size_t(leaf)], b = S.segs[2 * size_t(leaf) + 1];
+        int kind;
+        const bool hit = lv_intersect_capsule(o, d, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), radius, capped, t, kind);
+        if (hit) low = (S.leafSeg[leaf] << 2) | unsigned(kind);
+        return hit;
+    }
+}
+
 // ---------------------------------------------------------------- wave-cooperative closest hit
 // Per-wave LDS scratch of the cooperative routines: the ray of every lane, its best-hit key and a FIFO of
 // (owner lane, leaf) pairs waiting for a capsule test.
@@ -276,7 +331,7 @@ struct LvCoopMem {
 // So the expensive test (8 IEEE divisions + 4 square roots, ~350 instructions) always runs at full width, and a single
 // long ray that meets hundreds of leaves -- the tail that bounded the one-ray-per-thread kernels -- has them tested 64
 // at a time by the lanes that already finished.  ANY_HIT: gl_RayFlagsTerminateOnFirstHitEXT.
-template <bool STATS, bool ANY_HIT>
+template <bool STATS, bool ANY_HIT, int PRIM = LV_PRIM_CAPSULE>
 __device__ __forceinline__ LvHit lv_trace_closest(const LvSceneDev& S, float radius, bool capped, bool active, f3 o, f3 d,
                                                   float tMin, float tMax, const LvStackMem& sm, const LvCoopMem& cm,
                                                   LvCounters& cnt) {
@@ -319,14 +374,11 @@ __device__ __forceinline__ LvHit lv_trace_closest(const LvSceneDev& S, float rad
                 const unsigned e = cm.queue[(head + lane) % LV_QCAP];
                 const unsigned owner = e >> 26, leaf = e & 0x03FFFFFFu;
                 const float4 ro = cm.ray[2 * owner], rd = cm.ray[2 * owner + 1];
-                const float4 a = S.segs[2 * leaf], b = S.segs[2 * leaf + 1];
                 if (STATS) cnt.prims++;
-                float t; int kind;
-                if (lv_intersect_capsule(mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), mk3(a.x, a.y, a.z),
-                                         mk3(b.x, b.y, b.z), radius, capped, t, kind)) {
+                float t; unsigned low;
+                if (lv_leaf_test<PRIM>(S, leaf, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), radius, capped, t, low)) {
                     if (t >= ro.w && t <= rd.w)
-                        atomicMin(&cm.key[owner], ((unsigned long long)__float_as_uint(t) << 32)
-                                                          | ((unsigned long long)S.leafSeg[leaf] << 2) | unsigned(kind));
+                        atomicMin(&cm.key[owner], ((unsigned long long)__float_as_uint(t) << 32) | low);
                 }
             }
             head += n;
@@ -356,8 +408,13 @@ __device__ __forceinline__ LvHit lv_trace_closest(const LvSceneDev& S, float rad
     if (active && key != keyInit) {
         h.found = true;
         h.t = __uint_as_float(unsigned(key >> 32));
-        h.kind = int(unsigned(key) & 3u);
-        h.leaf = S.segToLeaf[(unsigned(key) >> 2)];
+        if (PRIM == LV_PRIM_TRIANGLE) {
+            h.kind = 0;
+            h.leaf = unsigned(key); // triangles: the ORIGINAL triangle index (callers read the index / vertex buffers)
+        } else {
+            h.kind = int(unsigned(key) & 3u);
+            h.leaf = S.segToLeaf[(unsigned(key) >> 2)];
+        }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // the scratch is reused by the next call
     return h;

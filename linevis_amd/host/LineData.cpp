@@ -128,6 +128,7 @@ bool LineData::setNewSettings(const SettingsMap& settings) {
     int n = tubeNumSubdivisions;
     if (settings.getValueOpt("tube_num_subdivisions", n) && n != tubeNumSubdivisions) {
         tubeNumSubdivisions = n;
+        cachedTriangleDataValid = false;
         shallReloadGatherShader = true;
     }
     bool b = useCappedTubes;
@@ -172,6 +173,7 @@ void LineDataFlow::setTrajectoryData(const Trajectories& newTrajectories, const 
     }
     modelBoundingBox = computeTrajectoriesAABB3(trajectories);
     cachedAabbDataValid = false;
+    cachedTriangleDataValid = false;
     dirty = true;
 }
 
@@ -259,6 +261,47 @@ TubeAabbRenderData LineDataFlow::getLinePassTubeAabbRenderData(bool /*isRasteriz
     cachedTubeAabbRenderData = data;
     cachedAabbDataValid = true;
     cachedLineWidth = lineWidth;
+    return data;
+}
+
+// LineDataFlow.cpp:1912-2110 for flow lines with capped tubes: tessellation (Tubes.cpp) + the line-point table the
+// vertices refer to (:1996-2020, including the way lineStartIndex only advances when the trajectory index changes).
+TubeTriangleRenderData LineDataFlow::getLinePassTubeTriangleMeshRenderData(bool /*isRasterizer*/, bool /*vulkanRayTracing*/) {
+    const float lineWidth = LineRenderer::getLineWidth();
+    if (cachedTriangleDataValid && cachedTriangleLineWidth == lineWidth && cachedTriangleSubdivisions == tubeNumSubdivisions)
+        return cachedTubeTriangleRenderData;
+    std::vector<std::vector<vec3>> lineCentersList(trajectories.size());
+    for (size_t i = 0; i < trajectories.size(); i++) lineCentersList[i] = trajectories[i].positions;
+
+    TubeTriangleRenderData data;
+    std::vector<LinePointReference> linePointReferences;
+    std::vector<vec3> lineTangents, lineNormals;
+    createCappedTriangleTubesRenderData(lineCentersList, lineWidth * 0.5f, tubeNumSubdivisions, data.indexBuffer,
+                                        data.vertexBuffer, linePointReferences, lineTangents, lineNormals);
+
+    data.linePointDataBuffer.resize(linePointReferences.size());
+    uint32_t lineStartIndex = 0, lastTrajectoryIndex = 0;
+    for (size_t i = 0; i < linePointReferences.size(); i++) {
+        const LinePointReference& ref = linePointReferences[i];
+        const Trajectory& trajectory = trajectories[ref.trajectoryIndex];
+        LinePointDataUnified& lp = data.linePointDataBuffer[i];
+        memset(&lp, 0, sizeof(lp));
+        const vec3& p = trajectory.positions[ref.linePointIndex];
+        lp.linePosition[0] = p.x; lp.linePosition[1] = p.y; lp.linePosition[2] = p.z;
+        lp.lineAttribute = trajectory.attributes.empty()
+                ? 0.0f : trajectory.attributes[size_t(selectedAttributeIndex)][ref.linePointIndex];
+        lp.lineTangent[0] = lineTangents[i].x; lp.lineTangent[1] = lineTangents[i].y; lp.lineTangent[2] = lineTangents[i].z;
+        lp.lineNormal[0] = lineNormals[i].x; lp.lineNormal[1] = lineNormals[i].y; lp.lineNormal[2] = lineNormals[i].z;
+        if (lastTrajectoryIndex != ref.trajectoryIndex) {
+            lastTrajectoryIndex = ref.trajectoryIndex;
+            lineStartIndex = uint32_t(i);
+        }
+        lp.lineStartIndex = lineStartIndex;
+    }
+    cachedTubeTriangleRenderData = data;
+    cachedTriangleDataValid = true;
+    cachedTriangleLineWidth = lineWidth;
+    cachedTriangleSubdivisions = tubeNumSubdivisions;
     return data;
 }
 

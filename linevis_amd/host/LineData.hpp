@@ -8,6 +8,7 @@
 //   class LineData accessors                               src/LineData/LineData.hpp:149-262
 //   LineDataFlow::setTrajectoryData                        src/LineData/LineDataFlow.cpp:468-578
 //   LineDataFlow::getLinePassTubeAabbRenderData            src/LineData/LineDataFlow.cpp:2112-2277
+//   LineDataFlow::getLinePassTubeTriangleMeshRenderDataPayload  src/LineData/LineDataFlow.cpp:1912-2110 (+ Tubes.cpp)
 // Accessors return host-side POD arrays (byte-identical record layouts) instead of sgl::vk::BufferPtr.
 #pragma once
 
@@ -18,6 +19,7 @@
 #include "../../include/linevis_hip.h"
 #include "LvMath.hpp"
 #include "SettingsMap.hpp"
+#include "Tubes.hpp"
 
 namespace lv {
 
@@ -40,6 +42,13 @@ struct TubeAabbRenderData {
     std::vector<uint32_t> indexBuffer;                     // two point indices per AABB / segment
     std::vector<AABB3> aabbBuffer;                         // VkAabbPositionsKHR layout (6 floats)
     std::vector<LinePointDataUnified> linePointDataBuffer;
+};
+
+/// src/LineData/LineRenderData.hpp:187-201, host vectors instead of sgl::vk::BufferPtr
+struct TubeTriangleRenderData {
+    std::vector<uint32_t> indexBuffer;                      // 3 vertex indices per triangle
+    std::vector<TubeTriangleVertexData> vertexBuffer;
+    std::vector<LinePointDataUnified> linePointDataBuffer;  // referenced by vertexLinePointIndex
 };
 
 enum DataSetType { DATA_SET_TYPE_NONE = 0, DATA_SET_TYPE_FLOW_LINES = 1 };
@@ -67,13 +76,15 @@ public:
     virtual size_t getNumLinePoints() = 0;
     virtual size_t getNumLineSegments() = 0;
     virtual TubeAabbRenderData getLinePassTubeAabbRenderData(bool isRasterizer, bool ellipticTubes) = 0;
+    /// LineData.hpp:182; consumed by the RTAO pass (VulkanRayTracedAmbientOcclusion.cpp:444-445)
+    virtual TubeTriangleRenderData getLinePassTubeTriangleMeshRenderData(bool isRasterizer, bool vulkanRayTracing) = 0;
     /// Points of all (unfiltered) lines, used for the depth-cue range (LineRenderer.cpp:365-408).
     virtual std::vector<std::vector<vec3>> getFilteredLines(LineRenderer* lineRenderer) = 0;
 
     /// dataset-side settings keys: attribute, tube_num_subdivisions, use_capped_tubes, use_halos
     /// (src/LineData/LineData.cpp:87-181).  Returns true when renderers must re-fetch geometry/defines.
     virtual bool setNewSettings(const SettingsMap& settings);
-    void setTriangleRepresentationDirty() { cachedAabbDataValid = false; dirty = true; }
+    void setTriangleRepresentationDirty() { cachedAabbDataValid = false; cachedTriangleDataValid = false; dirty = true; }
 
 protected:
     DataSetType dataSetType;
@@ -86,6 +97,7 @@ protected:
     int tubeNumSubdivisions = 6;     // LineData.cpp:52
     bool dirty = false;
     bool cachedAabbDataValid = false;
+    bool cachedTriangleDataValid = false;
 };
 typedef std::shared_ptr<LineData> LineDataPtr;
 
@@ -101,6 +113,7 @@ public:
     size_t getNumLinePoints() override { return numTotalTrajectoryPoints; }
     size_t getNumLineSegments() override;
     TubeAabbRenderData getLinePassTubeAabbRenderData(bool isRasterizer, bool ellipticTubes) override;
+    TubeTriangleRenderData getLinePassTubeTriangleMeshRenderData(bool isRasterizer, bool vulkanRayTracing) override;
     std::vector<std::vector<vec3>> getFilteredLines(LineRenderer* lineRenderer) override;
 
 private:
@@ -108,6 +121,9 @@ private:
     size_t numTotalTrajectories = 0, numTotalTrajectoryPoints = 0;
     TubeAabbRenderData cachedTubeAabbRenderData;
     float cachedLineWidth = -1.0f;
+    TubeTriangleRenderData cachedTubeTriangleRenderData;
+    float cachedTriangleLineWidth = -1.0f;
+    int cachedTriangleSubdivisions = -1;
 };
 
 } // namespace lv

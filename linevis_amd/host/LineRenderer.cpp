@@ -21,6 +21,20 @@ void Camera::overwriteMatrices(const float view[16], const float proj[16]) {
 void HipRayTracedAmbientOcclusion::startAmbientOcclusionBaking(LineDataPtr&, bool) {
     isDataReady = false;
     hasComputationFinished = false;
+    meshDirty = true;
+}
+
+// VulkanRayTracedAmbientOcclusionPass::setLineData (VulkanRayTracedAmbientOcclusion.cpp:437-456): fetch the triangle
+// tubes of the line data and hand them to the ray tracing back end; only when that geometry is selected.
+bool HipRayTracedAmbientOcclusion::uploadGeometry(LineDataPtr& lineData) {
+    if (!useTriangleTubes || !meshDirty) return true;
+    TubeTriangleRenderData d = lineData->getLinePassTubeTriangleMeshRenderData(false, true);
+    int rc = lv_set_tube_triangle_mesh(ctx, d.indexBuffer.data(), uint32_t(d.indexBuffer.size() / 3), d.vertexBuffer.data(),
+                                       uint32_t(d.vertexBuffer.size()), d.linePointDataBuffer.data(),
+                                       uint32_t(d.linePointDataBuffer.size()));
+    if (rc != LV_OK) return false;
+    meshDirty = false;
+    return true;
 }
 
 // VulkanRayTracedAmbientOcclusion::setNewSettings, VulkanRayTracedAmbientOcclusion.cpp:115-144
@@ -31,6 +45,12 @@ bool HipRayTracedAmbientOcclusion::setNewSettings(const SettingsMap& settings) {
     if (settings.getValueOpt("ambient_occlusion_radius", ambientOcclusionRadius)) optionChanged = true;
     if (settings.getValueOpt("ambient_occlusion_distance_based", useDistance)) optionChanged = true;
     if (settings.getValueOpt("use_jittered_primary_rays", useJitteredPrimaryRays)) optionChanged = true;
+    std::string geometry;
+    if (settings.getValueOpt("rtao_geometry", geometry)) {
+        const bool tri = geometry == "triangle_tubes";
+        if (tri != useTriangleTubes) { useTriangleTubes = tri; meshDirty = true; }
+        optionChanged = true;
+    }
     if (optionChanged) {
         onHasMoved();
         pushSettings();
@@ -45,6 +65,7 @@ void HipRayTracedAmbientOcclusion::pushSettings() {
     m.addKeyValue("ambient_occlusion_radius", ambientOcclusionRadius);
     m.addKeyValue("ambient_occlusion_distance_based", useDistance);
     m.addKeyValue("use_jittered_primary_rays", useJitteredPrimaryRays);
+    m.addKeyValue("rtao_geometry", useTriangleTubes ? "triangle_tubes" : "capsules");
     for (const auto& kv : m.getMap()) lv_set_option(ctx, kv.first.c_str(), kv.second.c_str());
 }
 
@@ -194,7 +215,12 @@ bool LineRenderer::uploadFrameState() {
         lineData->setDirty(false);
         linesDirty = false;
         tfDirty = true; // attribute range may have changed with the data
+        if (ambientOcclusionBaker) ambientOcclusionBaker->onGeometryChanged();
         return uploadFrameState();
+    }
+    if (useAmbientOcclusion && ambientOcclusionBaker && ambientOcclusionBaker->getType() == AmbientOcclusionBakerType::RTAO) {
+        auto* rtao = static_cast<HipRayTracedAmbientOcclusion*>(ambientOcclusionBaker.get());
+        if (!rtao->uploadGeometry(lineData)) { check(LV_E_INVALID, "lv_set_tube_triangle_mesh"); return false; }
     }
     return true;
 }

@@ -93,6 +93,7 @@ public:
     virtual bool getHasComputationFinished() = 0;
     virtual void onHasMoved() {}
     virtual void onResolutionChanged() {}
+    virtual void onGeometryChanged() {}
     virtual bool setNewSettings(const SettingsMap& settings) { (void)settings; return false; }
 };
 typedef std::shared_ptr<AmbientOcclusionBaker> AmbientOcclusionBakerPtr;
@@ -110,18 +111,23 @@ public:
     void onHasMoved() override { isDataReady = false; hasComputationFinished = false; }
     void onResolutionChanged() override { onHasMoved(); }
     bool setNewSettings(const SettingsMap& settings) override;
+    void onGeometryChanged() override { meshDirty = true; }
     void pushSettings();
     void notifyRendered() { isDataReady = true; hasComputationFinished = true; }
+    /// uploads the triangle tubes when rtao_geometry == "triangle_tubes" (the reference's RTAO geometry)
+    bool uploadGeometry(LineDataPtr& lineData);
 
     int maxNumAccumulatedFrames = 64;            // VulkanRayTracedAmbientOcclusion.hpp:108
     int numAmbientOcclusionSamplesPerFrame = 4;  // :150
     float ambientOcclusionRadius = 0.1f;         // :151
     bool useDistance = true;                     // :152
     bool useJitteredPrimaryRays = true;          // :153
+    bool useTriangleTubes = false;               // build-owned key "rtao_geometry": capsules | triangle_tubes
 
 private:
     lv_ctx* ctx;
     bool isDataReady = false, hasComputationFinished = false;
+    bool meshDirty = true;
 };
 
 // ---------------------------------------------------------------- renderers

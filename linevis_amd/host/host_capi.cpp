@@ -12,6 +12,7 @@ struct FlowHandle {
     LineDataPtr data;
     LineDataFlow* flow() { return static_cast<LineDataFlow*>(data.get()); }
     TubeAabbRenderData lastRenderData;
+    TubeTriangleRenderData lastTriangleData;
 };
 } // namespace
 
@@ -84,6 +85,26 @@ void lvh_flow_copy_render_data(void* hp, lv_line_point* points, uint32_t* segInd
     if (points) memcpy(points, d.linePointDataBuffer.data(), d.linePointDataBuffer.size() * sizeof(lv_line_point));
     if (segIndices) memcpy(segIndices, d.indexBuffer.data(), d.indexBuffer.size() * 4);
     if (aabbs) memcpy(aabbs, d.aabbBuffer.data(), d.aabbBuffer.size() * 24);
+}
+
+/// getLinePassTubeTriangleMeshRenderData at the given line width / subdivisions; counts first, then the copy.
+void lvh_flow_build_triangle_data(void* hp, float lineWidth, uint32_t numSubdivisions, uint64_t* outNumIndices,
+                                  uint64_t* outNumVertices, uint64_t* outNumPoints) {
+    FlowHandle* h = static_cast<FlowHandle*>(hp);
+    LineRenderer::setLineWidth(lineWidth);
+    SettingsMap m;
+    m.addKeyValue("tube_num_subdivisions", int(numSubdivisions));
+    h->data->setNewSettings(m);
+    h->lastTriangleData = h->flow()->getLinePassTubeTriangleMeshRenderData(false, true);
+    *outNumIndices = h->lastTriangleData.indexBuffer.size();
+    *outNumVertices = h->lastTriangleData.vertexBuffer.size();
+    *outNumPoints = h->lastTriangleData.linePointDataBuffer.size();
+}
+void lvh_flow_copy_triangle_data(void* hp, uint32_t* indices, lv_tube_vertex* vertices, lv_line_point* points) {
+    const TubeTriangleRenderData& d = static_cast<FlowHandle*>(hp)->lastTriangleData;
+    if (indices) memcpy(indices, d.indexBuffer.data(), d.indexBuffer.size() * 4);
+    if (vertices) memcpy(vertices, d.vertexBuffer.data(), d.vertexBuffer.size() * sizeof(lv_tube_vertex));
+    if (points) memcpy(points, d.linePointDataBuffer.data(), d.linePointDataBuffer.size() * sizeof(lv_line_point));
 }
 
 // ---- headless renderer harness

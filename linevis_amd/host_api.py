@@ -37,6 +37,8 @@ def load():
         "lvh_flow_get_trajectories": (None, [vp, vp, vp, vp]),
         "lvh_flow_build_render_data": (None, [vp, f32, C.POINTER(u32), C.POINTER(u32)]),
         "lvh_flow_copy_render_data": (None, [vp, vp, vp, vp]),
+        "lvh_flow_build_triangle_data": (None, [vp, f32, u32, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]),
+        "lvh_flow_copy_triangle_data": (None, [vp, vp, vp, vp]),
         "lvh_renderer_create": (vp, [i32, i32]),
         "lvh_renderer_destroy": (None, [vp]),
         "lvh_renderer_set_resolution": (None, [vp, u32, u32]),
@@ -135,6 +137,18 @@ class LineDataFlow:
         aabb = np.zeros((nseg.value, 6), dtype=np.float32)
         self.L.lvh_flow_copy_render_data(self.h, _p(pts), _p(seg), _p(aabb))
         return pts, seg, aabb
+
+
+    def tube_triangle_render_data(self, line_width, num_subdivisions=6):
+        """getLinePassTubeTriangleMeshRenderData: (triangle_indices[T,3], vertices[32 B], line_points[48 B])."""
+        ni, nv, npt = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self.L.lvh_flow_build_triangle_data(self.h, line_width, int(num_subdivisions), C.byref(ni), C.byref(nv),
+                                            C.byref(npt))
+        idx = np.zeros(ni.value, dtype=np.uint32)
+        verts = np.zeros(nv.value, dtype=capi.TUBE_VERTEX_DTYPE)
+        pts = np.zeros(npt.value, dtype=capi.LINE_POINT_DTYPE)
+        self.L.lvh_flow_copy_triangle_data(self.h, _p(idx), _p(verts), _p(pts))
+        return idx.reshape(-1, 3), verts, pts
 
 
 class HeadlessLineRenderer:

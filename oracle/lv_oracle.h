@@ -173,6 +173,37 @@ void lvo_render_ppll(
         const lvo_scene*, const lvo_params*, int useBvh, const float* ao,
         uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, uint8_t* outRGBA8, lvo_stats* stats);
 
+/* ---- a14: triangle tubes (CappedTriangleTubesCPU.cpp:214-383, Tubes.cpp:34-85, LineDataFlow.cpp:1912-2110) ---- */
+/* Mirrors struct TubeTriangleVertexData, src/LineData/LineRenderData.hpp:171-176 (32 B). */
+typedef struct {
+    float vertexPosition[3];
+    uint32_t vertexLinePointIndex; /* bit 31 set on cap vertices */
+    float vertexNormal[3];
+    float phi;
+} lvo_tube_vertex;
+/* Capped N-gon tubes of all lines (open tubes, hemisphere caps).  Output pointers may be NULL to query the sizes. */
+void lvo_build_tube_triangle_render_data(
+        const float* positions, const float* attributes, const uint32_t* lineOffsets, uint32_t nLines,
+        float lineWidth, uint32_t tubeNumSubdivisions,
+        uint32_t* outIndices, uint64_t* outNumIndices, lvo_tube_vertex* outVerts, uint64_t* outNumVerts,
+        lvo_line_point* outPoints, uint64_t* outNumPoints);
+
+typedef struct lvo_tri_scene lvo_tri_scene;
+lvo_tri_scene* lvo_tri_scene_create(const uint32_t* indices, uint32_t nTri, const lvo_tube_vertex* verts,
+                                    uint32_t nVerts, const lvo_line_point* pts, uint32_t nPts, float lineWidth);
+void lvo_tri_scene_destroy(lvo_tri_scene*);
+void lvo_tri_scene_build_bvh(lvo_tri_scene*);
+/* the build's ray-triangle test (definition: lv_oracle_tri.cpp header); pad = padding of the triangle's own AABB */
+int lvo_intersect_triangle(const float o[3], const float d[3], const float v0[3], const float v1[3],
+                           const float v2[3], float pad, float* outT, float* outU, float* outV);
+/* closest hit over all triangles; outTri = 0xFFFFFFFF on miss; outUV (2 floats per ray) may be NULL */
+void lvo_trace_rays_tri(const lvo_tri_scene*, int useBvh, const float* origins, const float* dirs, float tMin,
+                        float tMax, uint32_t n, float* outT, uint32_t* outTri, float* outUV);
+/* ---- a13 with the reference's own geometry: RTAO against the triangle tubes ---- */
+void lvo_render_ao_tri(
+        const lvo_tri_scene*, const lvo_params*, int useBvh,
+        uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, float* aoOut, lvo_stats* stats);
+
 #ifdef __cplusplus
 }
 #endif

@@ -15,7 +15,7 @@ _SO = os.path.join(_HERE, "_build", "liblv_oracle.so")
 
 
 def build(force=False):
-    src = [os.path.join(_HERE, f) for f in ("lv_oracle.cpp", "lv_oracle.h", "Makefile")]
+    src = [os.path.join(_HERE, f) for f in ("lv_oracle.cpp", "lv_oracle_tri.cpp", "lv_oracle_common.h", "lv_oracle.h", "Makefile")]
     stale = (not os.path.exists(_SO)) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in src)
     if force or stale:
         subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
@@ -32,6 +32,10 @@ LINE_POINT_DTYPE = np.dtype([("linePosition", "<f4", 3), ("lineAttribute", "<f4"
                              ("lineTangent", "<f4", 3), ("lineRotation", "<f4"),
                              ("lineNormal", "<f4", 3), ("lineStartIndex", "<u4")])
 assert LINE_POINT_DTYPE.itemsize == 48 and C.sizeof(LinePoint) == 48
+# TubeTriangleVertexData, LineRenderData.hpp:171-176
+TUBE_VERTEX_DTYPE = np.dtype([("vertexPosition", "<f4", 3), ("vertexLinePointIndex", "<u4"),
+                              ("vertexNormal", "<f4", 3), ("phi", "<f4")])
+assert TUBE_VERTEX_DTYPE.itemsize == 32
 
 
 class Params(C.Structure):
@@ -103,6 +107,16 @@ def lib():
                                   C.POINTER(Stats)]
     L.lvo_ppll_resolve.argtypes = [C.POINTER(Params), vp, vp, i32, u32, u32, u32, u32, vp]
     L.lvo_render_ppll.argtypes = [vp, C.POINTER(Params), i32, vp, u32, u32, u32, u32, vp, C.POINTER(Stats)]
+    u64p = C.POINTER(C.c_uint64)
+    L.lvo_build_tube_triangle_render_data.argtypes = [vp, vp, vp, u32, f32, u32, vp, u64p, vp, u64p, vp, u64p]
+    L.lvo_tri_scene_create.restype = vp
+    L.lvo_tri_scene_create.argtypes = [vp, u32, vp, u32, vp, u32, f32]
+    L.lvo_tri_scene_destroy.argtypes = [vp]
+    L.lvo_tri_scene_build_bvh.argtypes = [vp]
+    L.lvo_intersect_triangle.restype = i32
+    L.lvo_intersect_triangle.argtypes = [vp, vp, vp, vp, vp, f32, C.POINTER(f32), C.POINTER(f32), C.POINTER(f32)]
+    L.lvo_trace_rays_tri.argtypes = [vp, i32, vp, vp, f32, f32, u32, vp, vp, vp]
+    L.lvo_render_ao_tri.argtypes = [vp, C.POINTER(Params), i32, u32, u32, u32, u32, vp, C.POINTER(Stats)]
     _lib = L
     return L
 
@@ -152,6 +166,30 @@ def build_tube_aabb_render_data(positions, attributes, line_offsets, line_width)
     lib().lvo_build_tube_aabb_render_data(_p(pos), _p(att), _p(off), len(off) - 1, line_width, _p(pts),
                                           C.byref(npts), _p(seg), _p(aabb), C.byref(nseg))
     return pts[:npts.value].copy(), seg[:nseg.value].copy(), aabb[:nseg.value].copy()
+
+
+def build_tube_triangle_render_data(positions, attributes, line_offsets, line_width, num_subdivisions=6):
+    """a14 (CappedTriangleTubesCPU.cpp:214-383 + LineDataFlow.cpp:1912-2110): returns
+    (triangle_indices[T,3], vertices[32B], line_points[48B])."""
+    pos = np.ascontiguousarray(positions, dtype=np.float32)
+    att = np.ascontiguousarray(attributes, dtype=np.float32)
+    off = np.ascontiguousarray(line_offsets, dtype=np.uint32)
+    ni, nv, npt = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    args = (_p(pos), _p(att), _p(off), len(off) - 1, line_width, int(num_subdivisions))
+    lib().lvo_build_tube_triangle_render_data(*args, None, C.byref(ni), None, C.byref(nv), None, C.byref(npt))
+    idx = np.zeros(max(ni.value, 1), dtype=np.uint32)
+    verts = np.zeros(max(nv.value, 1), dtype=TUBE_VERTEX_DTYPE)
+    pts = np.zeros(max(npt.value, 1), dtype=LINE_POINT_DTYPE)
+    lib().lvo_build_tube_triangle_render_data(*args, _p(idx), C.byref(ni), _p(verts), C.byref(nv), _p(pts), C.byref(npt))
+    return idx[:ni.value].reshape(-1, 3).copy(), verts[:nv.value].copy(), pts[:npt.value].copy()
+
+
+def intersect_triangle(o, d, v0, v1, v2, pad):
+    a = [np.ascontiguousarray(v, dtype=np.float32) for v in (o, d, v0, v1, v2)]
+    t, u, v = C.c_float(), C.c_float(), C.c_float()
+    hit = lib().lvo_intersect_triangle(_p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), _p(a[4]), pad, C.byref(t), C.byref(u),
+                                       C.byref(v))
+    return bool(hit), t.value, u.value, v.value
 
 
 def intersect_capsule(o, d, p0, p1, radius, capped=True, literal=False):
@@ -281,6 +319,49 @@ class Scene:
         aop = _p(np.ascontiguousarray(ao, dtype=np.float32)) if ao is not None else None
         lib().lvo_render_ppll(self.h, C.byref(P), self._use_bvh(P, use_bvh), aop, x0, y0, w, h, _p(out), C.byref(st))
         return out
+
+
+class TriScene:
+    """Triangle-tube mesh (a14 output) + CPU BVH: the reference's RTAO geometry."""
+
+    def __init__(self, indices, vertices, line_points, line_width):
+        self.idx = np.ascontiguousarray(indices, dtype=np.uint32).reshape(-1, 3)
+        self.verts = np.ascontiguousarray(vertices, dtype=TUBE_VERTEX_DTYPE)
+        self.points = np.ascontiguousarray(line_points, dtype=LINE_POINT_DTYPE)
+        self.h = lib().lvo_tri_scene_create(_p(self.idx), len(self.idx), _p(self.verts), len(self.verts),
+                                            _p(self.points), len(self.points), line_width)
+        self.has_bvh = False
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().lvo_tri_scene_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def _use_bvh(self, use_bvh):
+        if use_bvh and not self.has_bvh:
+            lib().lvo_tri_scene_build_bvh(self.h)
+            self.has_bvh = True
+        return int(bool(use_bvh))
+
+    def trace_rays(self, origins, dirs, t_min, t_max, use_bvh=False):
+        o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(dirs, dtype=np.float32).reshape(-1, 3)
+        n = o.shape[0]
+        t = np.empty(n, dtype=np.float32)
+        tri = np.empty(n, dtype=np.uint32)
+        uv = np.empty((n, 2), dtype=np.float32)
+        lib().lvo_trace_rays_tri(self.h, self._use_bvh(use_bvh), _p(o), _p(d), t_min, t_max, n, _p(t), _p(tri), _p(uv))
+        return t, tri, uv
+
+    def render_ao(self, P, tile=None, use_bvh=False, stats=None):
+        x0, y0, w, h = tile if tile is not None else (0, 0, P.width, P.height)
+        ao = np.ones((P.height, P.width), dtype=np.float32)
+        st = stats if stats is not None else Stats()
+        lib().lvo_render_ao_tri(self.h, C.byref(P), self._use_bvh(use_bvh), x0, y0, w, h, _p(ao), C.byref(st))
+        return ao
 
 
 def ppll_resolve(P, nodes, start_offset, tile=None, literal=False):

@@ -223,13 +223,71 @@ def lattice_c1():
                         points_crc=np.uint32(np.bitwise_xor.reduce(pts.view(np.uint32))))
 
 
+def triangle_tubes():
+    """a14 + RTAO against the triangle tubes: tessellation of the a2 corner-case lines (byte level), ray-triangle
+    known answers (t, u, v bits) and one AO image of a small curved scene."""
+    a2 = np.load(os.path.join(HERE, "a2_cases.npz"))
+    out = {}
+    for n in (6, 4, 9):
+        idx, verts, pts = lvo.build_tube_triangle_render_data(a2["positions"], a2["attributes"], a2["line_offsets"],
+                                                              float(a2["line_width"]), n)
+        out["a2_idx_n%d" % n] = idx
+        out["a2_verts_n%d" % n] = verts.view(np.uint8).reshape(-1, 32)
+        out["a2_points_n%d" % n] = pts.view(np.uint8).reshape(-1, 48)
+    # ray-triangle known answers
+    rng = np.random.default_rng(77)
+    n = 400
+    v0 = rng.uniform(-0.3, 0.3, (n, 3)).astype(np.float32)
+    v1 = (v0 + rng.normal(scale=0.02, size=(n, 3))).astype(np.float32)
+    v2 = (v0 + rng.normal(scale=0.02, size=(n, 3))).astype(np.float32)
+    w = rng.dirichlet((1.0, 1.0, 1.0), n)
+    w[::7] = rng.dirichlet((1.0, 1.0, 1.0), len(w[::7])) * 1.3 - 0.1     # some targets just outside the triangle
+    w[::11, 0] = 0.0                                                      # some exactly on an edge
+    w[::11, 1:] = rng.dirichlet((1.0, 1.0), len(w[::11]))
+    target = (w[:, :1] * v0 + w[:, 1:2] * v1 + w[:, 2:] * v2)
+    o = (target + rng.normal(size=(n, 3)) * rng.uniform(0.01, 1.0, (n, 1))).astype(np.float32)
+    d = (target - o)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d = d.astype(np.float32)
+    d[5::13] = -d[5::13]                                                  # pointing away -> negative t
+    v2[3::17] = (v0[3::17] + 2.0 * (v1[3::17] - v0[3::17])).astype(np.float32)  # degenerate (collinear) triangles
+    o[1::19] = np.float32(0.0); d[1::19] = np.array([0, 0, 1], np.float32)      # axis-parallel rays (1/d = inf)
+    v0[1::19] = np.array([-0.1, -0.1, 0.2], np.float32) + v0[1::19] * 0
+    v1[1::19] = np.array([0.2, -0.1, 0.25], np.float32)
+    v2[1::19] = np.array([-0.1, 0.2, 0.22], np.float32)
+    pad = np.float32(0.001 * 1e-3 + 1e-6)
+    hit = np.zeros(n, np.uint8); t = np.zeros(n, np.float32); uv = np.zeros((n, 2), np.float32)
+    for i in range(n):
+        h, tt, uu, vv = lvo.intersect_triangle(o[i], d[i], v0[i], v1[i], v2[i], float(pad))
+        hit[i], t[i], uv[i] = h, tt, (uu, vv)
+    out.update(kat_o=o, kat_d=d, kat_v0=v0, kat_v1=v1, kat_v2=v2, kat_pad=pad, kat_hit=hit, kat_t_bits=f2u(t),
+               kat_uv_bits=f2u(uv))
+    # AO image: curved scene, 1 iteration x 8 samples + a second accumulation iteration
+    W, H, lw = 64, 64, 0.015
+    tr = scenes.normalize(scenes.random_curves(n_lines=36, points_per_line=40, seed=11))
+    mesh = lvo.build_tube_triangle_render_data(tr.positions, tr.attributes, tr.line_offsets, lw, 6)
+    base = small_case(width=W, height=H, n_lines=36, pts_per_line=40, seed=11, line_width=lw,
+                      ambient_occlusion_mode="RTAO (Screen Space)", ambient_occlusion_strength=1.0,
+                      ambient_occlusion_iterations=2, ambient_occlusion_samples_per_frame=8)
+    P = base.oracle_params()
+    ao = lvo.TriScene(*mesh, lw).render_ao(P, use_bvh=False)
+    out.update(ao_width=W, ao_height=H, ao_line_width=np.float32(lw), ao_bits=f2u(ao),
+               ao_num_triangles=np.uint32(len(mesh[0])),
+               ao_mesh_crc=np.uint32(np.bitwise_xor.reduce(mesh[1].view(np.uint32)) ^ np.bitwise_xor.reduce(mesh[0].reshape(-1))))
+    np.savez_compressed(os.path.join(HERE, "triangle_tubes.npz"), **out)
+
+
 if __name__ == "__main__":
+    if "--only-triangle-tubes" in sys.argv:
+        triangle_tubes()
+        sys.exit(0)
     rng_kat()
     capsule_kat()
     a2_cases()
     small_scene()
     ppll_lists()
     lattice_c1()
+    triangle_tubes()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print("%-24s %8d bytes" % (f, os.path.getsize(os.path.join(HERE, f))))

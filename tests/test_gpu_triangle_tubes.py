@@ -1,0 +1,225 @@
+"""Triangle-tube RTAO geometry (the reference traces AO against 6-gon triangle tubes): the HIP
+path through the C-ABI against the CPU oracle.  Everything here is +,-,*,/,sqrt on float32 in a fixed order, so hits
+(t, triangle, barycentrics) and AO factors are compared bit for bit; frames within +-2 LSB."""
+import numpy as np
+import pytest
+
+from common import Case, small_case, max_lsb_diff
+from linevis_amd import capi, host_api, scenes, transfer_function as tfm
+from oracle import lvo
+
+pytestmark = pytest.mark.gpu
+
+RTAO_TRI = dict(ambient_occlusion_mode="RTAO (Screen Space)", ambient_occlusion_strength=1.0,
+                rtao_geometry="triangle_tubes")
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def curves(n_lines=30, pts_per_line=30, seed=7):
+    return scenes.normalize(scenes.random_curves(n_lines=n_lines, points_per_line=pts_per_line, seed=seed))
+
+
+def mesh_of(tr, line_width, subdiv=6):
+    return lvo.build_tube_triangle_render_data(tr.positions, tr.attributes, tr.line_offsets, line_width, subdiv)
+
+
+def tri_context(case, mesh):
+    ctx = case.hip_context()
+    ctx.set_tube_triangle_mesh(*mesh)
+    return ctx
+
+
+def random_rays(n, seed, extent=0.35):
+    rng = np.random.default_rng(seed)
+    o = rng.uniform(-extent, extent, (n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    return o, d
+
+
+@pytest.mark.parametrize("subdiv,lw", [(6, 0.02), (8, 0.005), (4, 0.01)])
+def test_triangle_rays_bit_exact_vs_brute_force(hip_lib, subdiv, lw):
+    tr = curves()
+    mesh = mesh_of(tr, lw, subdiv)
+    case = small_case(line_width=lw)
+    ctx = tri_context(case, mesh)
+    ts = lvo.TriScene(*mesh, lw)
+    o, d = random_rays(20000, 11)
+    # axis-parallel directions exercise the 1/d = inf planes of the own-box rule
+    d[:300] = 0.0
+    d[:100, 0] = 1.0; d[100:200, 1] = -1.0; d[200:300, 2] = 1.0
+    hits = 0
+    for tmin, tmax in [(0.0, 0.1), (1e-4, 1000.0)]:
+        a = ctx.trace_rays_triangles(o, d, tmin, tmax)
+        b = ts.trace_rays(o, d, tmin, tmax, use_bvh=False)  # brute force = ground truth
+        assert np.array_equal(a[1], b[1])
+        assert np.array_equal(bits(a[0]), bits(b[0])) and np.array_equal(bits(a[2]), bits(b[2]))
+        hits += int((a[1] != 0xFFFFFFFF).sum())
+    assert hits > 500
+    assert ctx.stats().num_tube_triangles == len(mesh[0])
+
+
+def test_triangle_tie_goes_to_lowest_index(hip_lib):
+    # two coincident triangles + a third behind them
+    v = np.zeros(9, dtype=lvo.TUBE_VERTEX_DTYPE)
+    tri = np.array([[0, 0, 0], [0.1, 0, 0], [0, 0.1, 0]], np.float32)
+    v["vertexPosition"][0:3] = tri
+    v["vertexPosition"][3:6] = tri
+    v["vertexPosition"][6:9] = tri + np.array([0, 0, -0.05], np.float32)
+    v["vertexNormal"][:] = [0, 0, 1]
+    idx = np.array([[6, 7, 8], [3, 4, 5], [0, 1, 2]], np.uint32)
+    pts = np.zeros(1, dtype=lvo.LINE_POINT_DTYPE)
+    pts["lineTangent"] = [[1, 0, 0]]
+    case = small_case()
+    ctx = tri_context(case, (idx, v, pts))
+    o = np.array([[0.02, 0.02, 0.5]], np.float32)
+    d = np.array([[0.0, 0.0, -1.0]], np.float32)
+    t, tri_id, uv = ctx.trace_rays_triangles(o, d, 0.0, 10.0)
+    assert tri_id[0] == 1 and t[0] == np.float32(0.5)
+    tb, trib, _ = lvo.TriScene(idx, v, pts, case.line_width).trace_rays(o, d, 0.0, 10.0)
+    assert trib[0] == 1 and bits(tb)[0] == bits(t)[0]
+
+
+@pytest.mark.parametrize("settings", [
+    dict(ambient_occlusion_iterations=1, ambient_occlusion_samples_per_frame=16),
+    dict(ambient_occlusion_iterations=3, ambient_occlusion_samples_per_frame=4),
+    dict(ambient_occlusion_iterations=1, ambient_occlusion_samples_per_frame=8, ambient_occlusion_distance_based=False),
+    dict(ambient_occlusion_iterations=2, ambient_occlusion_samples_per_frame=5, use_jittered_primary_rays=False,
+         ambient_occlusion_radius=0.03),
+])
+def test_triangle_rtao_bit_exact_and_frame(hip_lib, settings):
+    lw = 0.02
+    tr = curves()
+    mesh = mesh_of(tr, lw)
+    case = small_case(line_width=lw, **RTAO_TRI, **settings)
+    ctx = tri_context(case, mesh)
+    img = ctx.render(capi.MODE_RAY_TRACER)
+    ao = ctx.get_ao()
+    sc = case.oracle_scene()
+    P = case.oracle_params(sc)
+    ao_ref = lvo.TriScene(*mesh, lw).render_ao(P, use_bvh=False)
+    assert np.array_equal(bits(ao), bits(ao_ref))
+    assert (ao_ref < 1.0).sum() > 200
+    img_ref = sc.render_rt(P, ao=ao_ref, use_bvh=True)
+    assert max_lsb_diff(img, img_ref) <= 2
+    # the capsule geometry gives a different (but statistically close) AO image
+    ctx.set_option("rtao_geometry", "capsules")
+    ctx.render(capi.MODE_RAY_TRACER)
+    ao_caps = ctx.get_ao()
+    assert not np.array_equal(bits(ao_caps), bits(ao))
+    both = (ao_caps < 1.0) & (ao < 1.0)
+    if settings.get("ambient_occlusion_distance_based", True):
+        assert abs(float(ao_caps[both].mean()) - float(ao[both].mean())) < 0.03
+
+
+def test_triangle_rtao_needs_a_mesh_and_rejects_bad_input(hip_lib):
+    case = small_case(**RTAO_TRI)
+    ctx = case.hip_context()
+    with pytest.raises(capi.LineVisError):
+        ctx.render(capi.MODE_RAY_TRACER)
+    idx, v, pts = mesh_of(curves(5, 10), 0.02)
+    bad = idx.copy(); bad[3, 1] = len(v)
+    with pytest.raises(capi.LineVisError):
+        ctx.set_tube_triangle_mesh(bad, v, pts)
+    with pytest.raises(capi.LineVisError):
+        ctx.set_option("rtao_geometry", "spheres")
+    # empty mesh: every primary ray misses -> AO factor 1 everywhere
+    ctx.set_tube_triangle_mesh(np.zeros((0, 3), np.uint32), v[:0], pts[:0])
+    ctx.render(capi.MODE_RAY_TRACER)
+    assert np.all(ctx.get_ao() == 1.0)
+
+
+def test_headless_renderer_uses_triangle_tubes(hip_lib):
+    """The plugin classes fetch the mesh from LineData like VulkanRayTracedAmbientOcclusionPass::setLineData."""
+    lw = 0.02
+    tr = curves(20, 40, seed=3)
+    flow = host_api.LineDataFlow()
+    flow.set_trajectories(tr.positions, tr.attributes, tr.line_offsets)
+    r = host_api.HeadlessLineRenderer(capi.MODE_RAY_TRACER)
+    r.set_rendering_resolution(96, 64)
+    r.set_transfer_function(tfm.standard())
+    r.set_line_data(flow)
+    settings = dict(line_width=lw, ambient_occlusion_iterations=1, ambient_occlusion_samples_per_frame=8, **RTAO_TRI)
+    r.set_new_settings(settings)
+    img = r.render_frame()
+    view, proj, fovy, near, far = r.camera()
+    pts, seg, _ = lvo.build_tube_aabb_render_data(tr.positions, tr.attributes, tr.line_offsets, lw)
+    case = Case(pts, seg, tfm.standard(), 96, 64, lw, **{k: v for k, v in settings.items() if k != "line_width"})
+    case.view, case.proj, case.fovy, case.near, case.far = view, proj, fovy, near, far
+    sc = case.oracle_scene()
+    P = case.oracle_params(sc)
+    P.attrMin, P.attrMax = flow.attribute_range()   # the plugin takes the transfer-function range from the data
+    ao_ref = lvo.TriScene(*mesh_of(tr, lw), lw).render_ao(P, use_bvh=True)
+    assert max_lsb_diff(img, sc.render_rt(P, ao=ao_ref, use_bvh=True)) <= 2
+    assert r.stats().num_tube_triangles == len(mesh_of(tr, lw)[0])
+
+
+def test_triangle_tubes_medium_scene_bvh_agreement(hip_lib):
+    """100 k segments / 1.2 M triangles: HIP LBVH (quantised 4-wide) vs the oracle's binary CPU BVH vs brute force on a
+    sample -- the own-box rule of the triangle test is what makes all three agree bit for bit."""
+    lw = 0.002
+    tr = scenes.normalize(scenes.helix_bundle())
+    flow = host_api.LineDataFlow()
+    flow.set_trajectories(tr.positions, tr.attributes, tr.line_offsets)
+    mesh = flow.tube_triangle_render_data(lw, 6)
+    assert len(mesh[0]) > 1200000
+    pts, seg, _ = flow.tube_aabb_render_data(lw)
+    case = Case(pts, seg, tfm.standard(), 256, 144, lw)
+    ctx = tri_context(case, mesh)
+    ts = lvo.TriScene(*mesh, lw)
+    # rays from the camera through the scene + short AO-like rays starting near the geometry
+    rng = np.random.default_rng(5)
+    n = 60000
+    o = np.tile(np.array([[0.0, 0.0, 0.8]], np.float32), (n, 1))
+    tgt = rng.uniform(-0.3, 0.3, (n, 3)).astype(np.float32)
+    d = tgt - o
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    a = ctx.trace_rays_triangles(o, d, 1e-4, 1000.0)
+    b = ts.trace_rays(o, d, 1e-4, 1000.0, use_bvh=True)
+    assert np.array_equal(a[1], b[1]) and np.array_equal(bits(a[0]), bits(b[0])) and np.array_equal(bits(a[2]), bits(b[2]))
+    hit = a[1] != 0xFFFFFFFF
+    assert hit.sum() > 10000
+    o2 = (o + d * a[0][:, None])[hit][:20000] + rng.normal(scale=0.003, size=(min(20000, int(hit.sum())), 3)).astype(np.float32)
+    d2 = rng.normal(size=o2.shape).astype(np.float32)
+    d2 /= np.linalg.norm(d2, axis=1, keepdims=True)
+    a2 = ctx.trace_rays_triangles(o2, d2, 0.0, 0.1)
+    b2 = ts.trace_rays(o2, d2, 0.0, 0.1, use_bvh=True)
+    assert np.array_equal(a2[1], b2[1]) and np.array_equal(bits(a2[0]), bits(b2[0]))
+    sub = slice(0, 300)
+    c2 = ts.trace_rays(o2[sub], d2[sub], 0.0, 0.1, use_bvh=False)
+    assert np.array_equal(a2[1][sub], c2[1]) and np.array_equal(bits(a2[0][sub]), bits(c2[0]))
+
+
+def test_triangle_golden_fixture(hip_lib):
+    """The committed triangle-tube fixture (tests/golden/triangle_tubes.npz): ray-triangle known answers through the
+    traversal kernel (one triangle per scene would be slow: all KAT triangles form one mesh, rays are checked where the
+    KAT triangle is also the scene's closest hit) and the AO image."""
+    import os
+    from common import GOLDEN_DIR
+    g = np.load(os.path.join(GOLDEN_DIR, "triangle_tubes.npz"))
+    W, H, lw = int(g["ao_width"]), int(g["ao_height"]), float(g["ao_line_width"])
+    tr = curves(36, 40, seed=11)
+    mesh = mesh_of(tr, lw)
+    assert len(mesh[0]) == int(g["ao_num_triangles"])
+    case = small_case(width=W, height=H, n_lines=36, pts_per_line=40, seed=11, line_width=lw, **RTAO_TRI,
+                      ambient_occlusion_iterations=2, ambient_occlusion_samples_per_frame=8)
+    ctx = tri_context(case, mesh)
+    ctx.render(capi.MODE_RAY_TRACER)
+    assert np.array_equal(bits(ctx.get_ao()), g["ao_bits"])
+    # KAT triangles as one mesh (pad of the fixture = pad of a context with line width 0.002)
+    n = len(g["kat_o"])
+    v = np.zeros(3 * n, dtype=lvo.TUBE_VERTEX_DTYPE)
+    v["vertexPosition"][0::3] = g["kat_v0"]; v["vertexPosition"][1::3] = g["kat_v1"]; v["vertexPosition"][2::3] = g["kat_v2"]
+    idx = np.arange(3 * n, dtype=np.uint32).reshape(-1, 3)
+    pts = np.zeros(1, dtype=lvo.LINE_POINT_DTYPE)
+    c2 = small_case(line_width=0.002)
+    ctx2 = tri_context(c2, (idx, v, pts))
+    assert np.float32(0.002 * 0.5) * np.float32(1e-3) + np.float32(1e-6) == g["kat_pad"]
+    t, tri, uv = ctx2.trace_rays_triangles(g["kat_o"], g["kat_d"], 0.0, 1000.0)
+    own = tri == np.arange(n)
+    assert own.sum() > 200                                   # most KAT rays hit their own triangle first
+    assert np.all(g["kat_hit"][own] == 1)
+    assert np.array_equal(bits(t)[own], g["kat_t_bits"][own]) and np.array_equal(bits(uv)[own], g["kat_uv_bits"][own])
