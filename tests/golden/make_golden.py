@@ -255,7 +255,8 @@ def triangle_tubes():
     v0[1::19] = np.array([-0.1, -0.1, 0.2], np.float32) + v0[1::19] * 0
     v1[1::19] = np.array([0.2, -0.1, 0.25], np.float32)
     v2[1::19] = np.array([-0.1, 0.2, 0.22], np.float32)
-    pad = np.float32(0.001 * 1e-3 + 1e-6)
+    # pad of a scene with line width 0.002, in float32 operations like the library: r * 1e-3f + 1e-6f
+    pad = np.float32(np.float32(0.002) * np.float32(0.5)) * np.float32(1e-3) + np.float32(1e-6)
     hit = np.zeros(n, np.uint8); t = np.zeros(n, np.float32); uv = np.zeros((n, 2), np.float32)
     for i in range(n):
         h, tt, uu, vv = lvo.intersect_triangle(o[i], d[i], v0[i], v1[i], v2[i], float(pad))

@@ -217,7 +217,7 @@ def test_triangle_golden_fixture(hip_lib):
     pts = np.zeros(1, dtype=lvo.LINE_POINT_DTYPE)
     c2 = small_case(line_width=0.002)
     ctx2 = tri_context(c2, (idx, v, pts))
-    assert np.float32(0.002 * 0.5) * np.float32(1e-3) + np.float32(1e-6) == g["kat_pad"]
+    assert np.float32(np.float32(0.002) * np.float32(0.5)) * np.float32(1e-3) + np.float32(1e-6) == g["kat_pad"]
     t, tri, uv = ctx2.trace_rays_triangles(g["kat_o"], g["kat_d"], 0.0, 1000.0)
     own = tri == np.arange(n)
     assert own.sum() > 200                                   # most KAT rays hit their own triangle first
