@@ -181,6 +181,31 @@ int lv_get_stats(lv_ctx* ctx, lv_stats* out);
 /* Forget the per-kernel launch timings collected so far (start of a timed benchmark region). */
 int lv_reset_timers(lv_ctx* ctx);
 
+/* ---- streamline tracing: the producer of the line sets ----
+ * StreamlineTracingGrid (src/LineData/Flow/StreamlineTracingGrid.cpp): regular grid of xs*ys*zs cells with spacing
+ * (dx, dy, dz) and origin 0 (setGridExtent, :81-116), one vector field (3 floats per cell, x fastest: IDXV of
+ * StreamlineTracingDefines.hpp:118) and any number of scalar fields sampled along the lines as attributes
+ * (_pushTrajectoryAttributes, :1012-1047).  max |v| (addVectorField, :189-216) is reduced on the GPU. */
+int lv_set_flow_grid(lv_ctx* ctx, const float* vector_field, uint32_t xs, uint32_t ys, uint32_t zs, float dx, float dy,
+                     float dz, const float* const* scalar_fields, uint32_t num_scalar_fields);
+/* StreamlineTracingSettings, StreamlineTracingDefines.hpp:144-177 (the fields _trace / traceStreamlines read). */
+typedef struct lv_streamline_settings {
+    uint32_t integration_method;    /* StreamlineIntegrationMethod :63-76: 0 explicit Euler, 2 Heun, 3 midpoint, 4 RK4 */
+    uint32_t integration_direction; /* StreamlineIntegrationDirection :82-84: 0 forward, 1 backward, 2 both */
+    float time_step_scale;          /* 1.0 */
+    int32_t max_num_iterations;     /* 2000 */
+    float termination_distance;     /* 1.0 (scaled by 1e-6 inside, :1199) */
+    float minimum_length;           /* 0.7: shorter lines are dropped (:413-425) */
+} lv_streamline_settings;
+/* StreamlineTracingGrid::traceStreamlines (:344-426) for caller-supplied seed points (3 floats each): one GPU thread per
+ * seed and direction integrates (_trace, :1193-1259), the host part reverses / merges / filters.  The result stays in the
+ * context until the next call; fetch it with lv_get_streamlines. */
+int lv_trace_streamlines(lv_ctx* ctx, const float* seed_points, uint32_t num_seeds, const lv_streamline_settings* settings,
+                         uint64_t* out_num_lines, uint64_t* out_num_points);
+/* positions: 3 floats per point; attributes: [num_scalar_fields][num_points]; line_offsets: num_lines + 1.  Any pointer
+ * may be NULL. */
+int lv_get_streamlines(lv_ctx* ctx, float* positions, float* attributes, uint32_t* line_offsets);
+
 /* ---- inspection entry points used by the parity tests ---- */
 /* Closest hit of arbitrary rays (IntersectionTube + driver closest-hit semantics, TubeRayTracing.glsl:452-494).
  * origins/dirs: 3 floats per ray; out_segment = 0xFFFFFFFF on miss; out_kind: 0 tube, 1 sphere p0, 2 sphere p1. */

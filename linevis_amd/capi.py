@@ -48,6 +48,25 @@ class Stats(C.Structure):
         return d
 
 
+class StreamlineSettings(C.Structure):
+    """lv_streamline_settings (StreamlineTracingSettings, StreamlineTracingDefines.hpp:144-177)."""
+    _fields_ = [("integration_method", C.c_uint32), ("integration_direction", C.c_uint32),
+                ("time_step_scale", C.c_float), ("max_num_iterations", C.c_int32),
+                ("termination_distance", C.c_float), ("minimum_length", C.c_float)]
+
+
+# STREAMLINE_INTEGRATION_METHOD_NAMES / ..._DIRECTION_NAMES, StreamlineTracingDefines.hpp:77-88
+INTEGRATION_METHODS = {"Explicit Euler": 0, "Implicit Euler": 1, "Heun": 2, "Midpoint": 3, "Runge-Kutta 4th Order": 4,
+                       "Runge-Kutta-Fehlberg": 5}
+INTEGRATION_DIRECTIONS = {"Forward": 0, "Backward": 1, "Forward & Backward": 2}
+
+
+def streamline_settings(method="Runge-Kutta 4th Order", direction="Forward & Backward", time_step_scale=1.0,
+                        max_num_iterations=2000, termination_distance=1.0, minimum_length=0.7):
+    return StreamlineSettings(INTEGRATION_METHODS[method], INTEGRATION_DIRECTIONS[direction], time_step_scale,
+                              max_num_iterations, termination_distance, minimum_length)
+
+
 KERNEL_AO_PRIMARY, KERNEL_AO_RAYS, KERNEL_RENDER_RT, KERNEL_PPLL_GATHER, KERNEL_PPLL_RESOLVE, KERNEL_DEPTH_RANGE = range(6)
 KERNEL_NAMES = ["k_ao_primary", "k_ao_rays", "k_render_rt", "k_ppll_gather", "k_ppll_resolve", "k_depth_minmax"]
 
@@ -63,7 +82,8 @@ SYMBOLS = ["lv_create", "lv_destroy", "lv_last_error", "lv_version", "lv_set_str
            "lv_set_transfer_function", "lv_set_camera", "lv_set_background", "lv_set_option", "lv_build_accel",
            "lv_render", "lv_render_device", "lv_render_tiles_device", "lv_get_stats", "lv_reset_timers", "lv_trace_rays",
            "lv_compute_depth_range", "lv_get_ao", "lv_ppll_get_buffers", "lv_ppll_resolve_buffers", "lv_get_accel",
-           "lv_set_tube_triangle_mesh", "lv_trace_rays_triangles"]
+           "lv_set_tube_triangle_mesh", "lv_trace_rays_triangles", "lv_set_flow_grid", "lv_trace_streamlines",
+           "lv_get_streamlines"]
 
 _lib = None
 
@@ -116,6 +136,9 @@ def load():
         ("lv_get_accel", [vp, vp, u64, vp, u64]),
         ("lv_set_tube_triangle_mesh", [vp, vp, u32, vp, u32, vp, u32]),
         ("lv_trace_rays_triangles", [vp, vp, vp, f32, f32, u32, vp, vp, vp]),
+        ("lv_set_flow_grid", [vp, vp, u32, u32, u32, f32, f32, f32, vp, u32]),
+        ("lv_trace_streamlines", [vp, vp, u32, C.POINTER(StreamlineSettings), C.POINTER(u64), C.POINTER(u64)]),
+        ("lv_get_streamlines", [vp, vp, vp, vp]),
     ]:
         fn = getattr(L, name)
         fn.restype = i32
@@ -242,6 +265,26 @@ class Context:
         uv = np.empty((n, 2), dtype=np.float32)
         self._ck(self.L.lv_trace_rays_triangles(self.h, _p(o), _p(d), t_min, t_max, n, _p(t), _p(tri), _p(uv)))
         return t, tri, uv
+
+    def set_flow_grid(self, vector_field, spacing, scalar_fields=()):
+        """vector_field [zs, ys, xs, 3] float32, scalar_fields: list of [zs, ys, xs] (sampled as line attributes)."""
+        v = np.ascontiguousarray(vector_field, dtype=np.float32)
+        zs, ys, xs = v.shape[:3]
+        sf = [np.ascontiguousarray(f, dtype=np.float32) for f in scalar_fields]
+        ptrs = (C.c_void_p * max(len(sf), 1))(*[f.ctypes.data for f in sf])
+        self._ck(self.L.lv_set_flow_grid(self.h, _p(v), xs, ys, zs, spacing[0], spacing[1], spacing[2], ptrs, len(sf)))
+        self._flow_scalars = len(sf)
+
+    def trace_streamlines(self, seeds, settings):
+        """-> (positions [P,3], attributes [k,P], line_offsets [L+1])"""
+        sd = np.ascontiguousarray(seeds, dtype=np.float32).reshape(-1, 3)
+        nl, npt = C.c_uint64(), C.c_uint64()
+        self._ck(self.L.lv_trace_streamlines(self.h, _p(sd), len(sd), C.byref(settings), C.byref(nl), C.byref(npt)))
+        pos = np.zeros((npt.value, 3), dtype=np.float32)
+        att = np.zeros((self._flow_scalars, npt.value), dtype=np.float32)
+        off = np.zeros(nl.value + 1, dtype=np.uint32)
+        self._ck(self.L.lv_get_streamlines(self.h, _p(pos), _p(att), _p(off)))
+        return pos, att, off
 
     def depth_range(self):
         out = np.empty(2, dtype=np.float32)

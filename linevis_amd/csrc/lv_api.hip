@@ -173,7 +173,8 @@ void lv_destroy(lv_ctx* ctx) {
                               &ctx->depthMinMax, &ctx->ao, &ctx->aoGbuf, &ctx->aoList, &ctx->aoSamples, &ctx->counters,
                               &ctx->ppllNodes, &ctx->ppllStart, &ctx->ppllScratch, &ctx->tilesDev, &ctx->outDev,
                               &ctx->scratchRays, &ctx->stackOverflow, &ctx->triIdx, &ctx->triVerts, &ctx->triPoints,
-                              &ctx->triNodes, &ctx->tris})
+                              &ctx->triNodes, &ctx->tris, &ctx->flowVectors, &ctx->flowScalars, &ctx->flowMisc,
+                              &ctx->flowSeeds, &ctx->flowOutPos, &ctx->flowOutAtt, &ctx->flowCounts})
         lv_buf_free(*b);
     if (ctx->evCreated) {
         for (int i = 0; i < 16; i++) (void)hipEventDestroy(ctx->ev[i]);
@@ -506,6 +507,51 @@ int lv_trace_rays_triangles(lv_ctx* ctx, const float* origins, const float* dirs
     if (n && (!origins || !dirs || !out_t || !out_triangle)) return lv_fail(ctx, LV_E_INVALID, "null array");
     (void)hipSetDevice(ctx->device);
     return lv_frame_trace_rays_triangles(ctx, origins, dirs, t_min, t_max, n, out_t, out_triangle, out_uv);
+}
+
+int lv_set_flow_grid(lv_ctx* ctx, const float* vector_field, uint32_t xs, uint32_t ys, uint32_t zs, float dx, float dy,
+                     float dz, const float* const* scalar_fields, uint32_t num_scalar_fields) {
+    if (!ctx) return LV_E_INVALID;
+    if (!vector_field || xs < 2 || ys < 2 || zs < 2 || !(dx > 0.0f) || !(dy > 0.0f) || !(dz > 0.0f))
+        return lv_fail(ctx, LV_E_INVALID, "flow grid needs a vector field, at least 2 cells per axis and positive spacing");
+    if (uint64_t(xs) * ys * zs > 0x7FFFFFFFull) return lv_fail(ctx, LV_E_CAPACITY, "flow grid too large");
+    if (num_scalar_fields && !scalar_fields) return lv_fail(ctx, LV_E_INVALID, "null scalar field table");
+    for (uint32_t a = 0; a < num_scalar_fields; a++)
+        if (!scalar_fields[a]) return lv_fail(ctx, LV_E_INVALID, "scalar field %u is null", a);
+    (void)hipSetDevice(ctx->device);
+    return lv_flow_set_grid(ctx, vector_field, xs, ys, zs, dx, dy, dz, scalar_fields, num_scalar_fields);
+}
+
+int lv_trace_streamlines(lv_ctx* ctx, const float* seed_points, uint32_t num_seeds, const lv_streamline_settings* settings,
+                         uint64_t* out_num_lines, uint64_t* out_num_points) {
+    if (!ctx) return LV_E_INVALID;
+    if (!ctx->flowGridSet) return lv_fail(ctx, LV_E_STATE, "lv_set_flow_grid has not been called");
+    if (!settings || (num_seeds && !seed_points)) return lv_fail(ctx, LV_E_INVALID, "null argument");
+    const uint32_t m = settings->integration_method;
+    if (m != 0u && m != 2u && m != 3u && m != 4u)
+        return lv_fail(ctx, LV_E_INVALID, "integration method %u is not provided (0 explicit Euler, 2 Heun, 3 midpoint, 4 RK4)", m);
+    if (settings->integration_direction > 2u) return lv_fail(ctx, LV_E_INVALID, "integration direction must be 0, 1 or 2");
+    if (!(settings->time_step_scale > 0.0f) || settings->max_num_iterations <= 0 || settings->max_num_iterations > 10000000)
+        return lv_fail(ctx, LV_E_INVALID, "time_step_scale must be > 0 and max_num_iterations in 1..1e7");
+    if (!(ctx->flowMaxMagnitude > 0.0f)) return lv_fail(ctx, LV_E_STATE, "the vector field is zero everywhere");
+    (void)hipSetDevice(ctx->device);
+    int rc = lv_flow_trace(ctx, seed_points, num_seeds, settings);
+    if (rc) return rc;
+    if (out_num_lines) *out_num_lines = ctx->flowOffsets.size() - 1;
+    if (out_num_points) *out_num_points = ctx->flowPositions.size() / 3;
+    return LV_OK;
+}
+
+int lv_get_streamlines(lv_ctx* ctx, float* positions, float* attributes, uint32_t* line_offsets) {
+    if (!ctx) return LV_E_INVALID;
+    if (ctx->flowOffsets.empty()) return lv_fail(ctx, LV_E_STATE, "lv_trace_streamlines has not been called");
+    const size_t n = ctx->flowPositions.size() / 3;
+    if (positions && n) memcpy(positions, ctx->flowPositions.data(), n * 12);
+    if (attributes)
+        for (size_t a = 0; a < ctx->flowAttributes.size(); a++)
+            if (n) memcpy(attributes + a * n, ctx->flowAttributes[a].data(), n * 4);
+    if (line_offsets) memcpy(line_offsets, ctx->flowOffsets.data(), ctx->flowOffsets.size() * 4);
+    return LV_OK;
 }
 
 int lv_compute_depth_range(lv_ctx* ctx, float out_min_max[2]) {

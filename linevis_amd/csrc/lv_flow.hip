@@ -1,0 +1,322 @@
+// lv_flow.hip -- streamline tracing through a regular grid on the GPU (the producer of the line sets the hot path renders).
+//
+// Replaces the OpenMP/TBB loop over seeds of the reference's flow tracer, src/LineData/Flow/StreamlineTracingGrid.cpp:
+//   setGridExtent / addVectorField (max |v|)          :81-218      -> lv_set_flow_grid (k_max_magnitude)
+//   _getVectorAtPosition, _getScalarFieldAtPosition   :857-913     -> lv_vector_at / lv_scalar_at (trilinear, 8 gathers)
+//   _rayBoxIntersection                               :949-1010    -> lv_ray_box
+//   _trace + _integrationStep{ExplicitEuler,Heun,Midpoint,RK4} :1193-1339 -> k_trace_streamlines (one thread per seed and
+//                                                                  direction; the steps of a line are inherently serial)
+//   traceStreamlines: backward reversal, forward/backward merge, minimum-length filter :344-426,1118-1166 -> host part of
+//                                                                  lv_trace_streamlines
+// float32, fixed evaluation order (library-wide -ffp-contract=off): positions and attributes are bit-identical to a
+// host evaluation of the same formulas.  Output of the kernel is [step][thread] so that the lanes of a wave, which
+// advance in lock step, write neighbouring addresses.
+#include <algorithm>
+#include <cstring>
+
+#include "lv_internal.h"
+
+namespace {
+
+struct LvFlowGrid {
+    const float* V;          // xs*ys*zs*3
+    const float* scalars;    // numScalars * xs*ys*zs
+    int xs, ys, zs;
+    float dx, dy, dz;
+    float bx, by, bz;        // box maximum (minimum is the origin), setGridExtent :113-115
+    uint32_t numScalars;
+};
+
+struct LvCell { int x, y, z; float fx, fy, fz, ix, iy, iz; };
+
+__device__ __forceinline__ LvCell lv_locate(const LvFlowGrid& g, f3 p) {
+    // gridPositionFloat = (p - box.min) * (1/dx, 1/dy, 1/dz); ivec3() truncates towards zero, fract() = x - floor(x)
+    const float qx = (p.x - 0.0f) * (1.0f / g.dx), qy = (p.y - 0.0f) * (1.0f / g.dy), qz = (p.z - 0.0f) * (1.0f / g.dz);
+    LvCell c;
+    c.x = int(qx); c.y = int(qy); c.z = int(qz);
+    c.fx = qx - floorf(qx); c.fy = qy - floorf(qy); c.fz = qz - floorf(qz);
+    c.ix = 1.0f - c.fx; c.iy = 1.0f - c.fy; c.iz = 1.0f - c.fz;
+    return c;
+}
+
+__device__ __forceinline__ f3 lv_vector_at_idx(const LvFlowGrid& g, int x, int y, int z, bool fw) {
+    if (x < 0 || y < 0 || z < 0 || x >= g.xs || y >= g.ys || z >= g.zs) return mk3(0.0f, 0.0f, 0.0f);
+    const float* p = g.V + 3 * (size_t(x) + size_t(y) * g.xs + size_t(z) * g.xs * g.ys);
+    return fw ? mk3(p[0], p[1], p[2]) : mk3(-p[0], -p[1], -p[2]);
+}
+
+__device__ __forceinline__ f3 lv_vector_at(const LvFlowGrid& g, f3 p, bool fw) {
+    const LvCell c = lv_locate(g, p);
+    f3 r = (c.ix * c.iy * c.iz) * lv_vector_at_idx(g, c.x, c.y, c.z, fw);
+    r = r + (c.fx * c.iy * c.iz) * lv_vector_at_idx(g, c.x + 1, c.y, c.z, fw);
+    r = r + (c.ix * c.fy * c.iz) * lv_vector_at_idx(g, c.x, c.y + 1, c.z, fw);
+    r = r + (c.fx * c.fy * c.iz) * lv_vector_at_idx(g, c.x + 1, c.y + 1, c.z, fw);
+    r = r + (c.ix * c.iy * c.fz) * lv_vector_at_idx(g, c.x, c.y, c.z + 1, fw);
+    r = r + (c.fx * c.iy * c.fz) * lv_vector_at_idx(g, c.x + 1, c.y, c.z + 1, fw);
+    r = r + (c.ix * c.fy * c.fz) * lv_vector_at_idx(g, c.x, c.y + 1, c.z + 1, fw);
+    r = r + (c.fx * c.fy * c.fz) * lv_vector_at_idx(g, c.x + 1, c.y + 1, c.z + 1, fw);
+    return r;
+}
+
+__device__ __forceinline__ float lv_scalar_at_idx(const LvFlowGrid& g, const float* f, int x, int y, int z) {
+    if (x < 0 || y < 0 || z < 0 || x >= g.xs || y >= g.ys || z >= g.zs) return 0.0f;
+    return f[size_t(x) + size_t(y) * g.xs + size_t(z) * g.xs * g.ys];
+}
+
+__device__ __forceinline__ float lv_scalar_at(const LvFlowGrid& g, const float* f, f3 p) {
+    const LvCell c = lv_locate(g, p);
+    float r = (c.ix * c.iy * c.iz) * lv_scalar_at_idx(g, f, c.x, c.y, c.z);
+    r = r + (c.fx * c.iy * c.iz) * lv_scalar_at_idx(g, f, c.x + 1, c.y, c.z);
+    r = r + (c.ix * c.fy * c.iz) * lv_scalar_at_idx(g, f, c.x, c.y + 1, c.z);
+    r = r + (c.fx * c.fy * c.iz) * lv_scalar_at_idx(g, f, c.x + 1, c.y + 1, c.z);
+    r = r + (c.ix * c.iy * c.fz) * lv_scalar_at_idx(g, f, c.x, c.y, c.z + 1);
+    r = r + (c.fx * c.iy * c.fz) * lv_scalar_at_idx(g, f, c.x + 1, c.y, c.z + 1);
+    r = r + (c.ix * c.fy * c.fz) * lv_scalar_at_idx(g, f, c.x, c.y + 1, c.z + 1);
+    r = r + (c.fx * c.fy * c.fz) * lv_scalar_at_idx(g, f, c.x + 1, c.y + 1, c.z + 1);
+    return r;
+}
+
+__device__ __forceinline__ bool lv_box_contains(const LvFlowGrid& g, f3 p) {
+    return p.x >= 0.0f && p.y >= 0.0f && p.z >= 0.0f && p.x <= g.bx && p.y <= g.by && p.z <= g.bz;
+}
+
+__device__ __forceinline__ bool lv_ray_box_plane(float o, float d, float lower, float upper, float& tNear, float& tFar) {
+    if (fabsf(d) < 0.00001f) {
+        if (o < lower || o > upper) return false;
+    } else {
+        float t0 = (lower - o) / d, t1 = (upper - o) / d;
+        if (t0 > t1) { float tmp = t0; t0 = t1; t1 = tmp; }
+        if (t0 > tNear) tNear = t0;
+        if (t1 < tFar) tFar = t1;
+        if (tNear > tFar) return false;
+        if (tFar < 0) return false;
+    }
+    return true;
+}
+__device__ __forceinline__ bool lv_ray_box(f3 o, f3 d, f3 upper, float& tNear, float& tFar) {
+    tNear = -3.402823466e+38f;
+    tFar = 3.402823466e+38f;
+    if (!lv_ray_box_plane(o.x, d.x, 0.0f, upper.x, tNear, tFar)) return false;
+    if (!lv_ray_box_plane(o.y, d.y, 0.0f, upper.y, tNear, tFar)) return false;
+    if (!lv_ray_box_plane(o.z, d.z, 0.0f, upper.z, tNear, tFar)) return false;
+    return true;
+}
+
+__device__ __forceinline__ void lv_integration_step(const LvFlowGrid& g, uint32_t method, f3& p0, float dt, bool fw) {
+    if (method == 0u) {
+        p0 = p0 + dt * lv_vector_at(g, p0, fw);
+    } else if (method == 2u) {
+        const f3 v0 = lv_vector_at(g, p0, fw);
+        const f3 p1 = p0 + dt * v0;
+        const f3 v1 = lv_vector_at(g, p1, fw);
+        p0 = p0 + (dt * 0.5f) * (v0 + v1);
+    } else if (method == 3u) {
+        const f3 pp = p0 + (dt * 0.5f) * lv_vector_at(g, p0, fw);
+        p0 = p0 + dt * lv_vector_at(g, pp, fw);
+    } else {
+        const f3 k1 = dt * lv_vector_at(g, p0, fw);
+        const f3 k2 = dt * lv_vector_at(g, p0 + k1 * 0.5f, fw);
+        const f3 k3 = dt * lv_vector_at(g, p0 + k2 * 0.5f, fw);
+        const f3 k4 = dt * lv_vector_at(g, p0 + k3, fw);
+        const float s6 = 6.0f, s3 = 3.0f;
+        const f3 a = mk3(k1.x / s6, k1.y / s6, k1.z / s6), b = mk3(k2.x / s3, k2.y / s3, k2.z / s3);
+        const f3 c = mk3(k3.x / s3, k3.y / s3, k3.z / s3), d = mk3(k4.x / s6, k4.y / s6, k4.z / s6);
+        p0 = p0 + (((a + b) + c) + d);
+    }
+}
+
+// thread t: seed t % numSeeds, forward for t < numForward else backward.  Point i of thread t is stored at
+// positions[(i * numThreads + t) * 3], attribute a at attributes[(a * capacity + i) * numThreads + t].
+__global__ __launch_bounds__(LV_WAVE) void k_trace_streamlines(const LvFlowGrid g, const float* __restrict__ seeds,
+                                                               uint32_t numSeeds, uint32_t numThreads,
+                                                               uint32_t firstBackward, uint32_t method, float dt,
+                                                               float terminationDistance, int maxIterations,
+                                                               float maxLineLength, uint32_t capacity,
+                                                               float* __restrict__ positions,
+                                                               float* __restrict__ attributes,
+                                                               uint32_t* __restrict__ counts) {
+    const uint32_t t = blockIdx.x * LV_WAVE + threadIdx.x;
+    if (t >= numThreads) return;
+    const bool fw = t < firstBackward;
+    const uint32_t s = t % numSeeds;
+    f3 p = mk3(seeds[3 * s], seeds[3 * s + 1], seeds[3 * s + 2]), old, last = p;
+    uint32_t n = 0;
+    auto push = [&](f3 q) {
+        if (n < capacity) {
+            float* o = positions + (size_t(n) * numThreads + t) * 3;
+            o[0] = q.x; o[1] = q.y; o[2] = q.z;
+            for (uint32_t a = 0; a < g.numScalars; a++)
+                attributes[(size_t(a) * capacity + n) * numThreads + t] =
+                        lv_scalar_at(g, g.scalars + size_t(a) * g.xs * g.ys * g.zs, q);
+        }
+        last = q;
+        n++;
+    };
+    int iterationCounter = 0;
+    float lineLength = 0.0f;
+    while (iterationCounter <= maxIterations && lineLength <= maxLineLength) {
+        old = p;
+        if (!lv_box_contains(g, p)) {
+            if (n != 0) { // clamp the position to the boundary, :1218-1233
+                const f3 ro = last, rd = norm3(p - ro);
+                float tNear, tFar;
+                lv_ray_box(ro, rd, mk3(g.bx, g.by, g.bz), tNear, tFar);
+                push(tNear > 0.0f ? ro + tNear * rd : ro + tFar * rd);
+            }
+            break;
+        }
+        push(p);
+        lv_integration_step(g, method, p, dt, fw);
+        const float segmentLength = len3(p - old);
+        lineLength += segmentLength;
+        if (segmentLength < terminationDistance) break;
+        iterationCounter++;
+    }
+    counts[t] = n;
+}
+
+// max |v| over the grid (addVectorField, :189-216): max of non-negative floats = max of their bit patterns
+__global__ __launch_bounds__(LV_BLOCK) void k_max_magnitude(const float* __restrict__ v, uint64_t numCells, uint32_t* out) {
+    float m = 0.0f;
+    for (uint64_t i = uint64_t(blockIdx.x) * LV_BLOCK + threadIdx.x; i < numCells; i += uint64_t(gridDim.x) * LV_BLOCK) {
+        const float vx = v[3 * i], vy = v[3 * i + 1], vz = v[3 * i + 2];
+        m = fmaxf(m, sqrtf((vx * vx + vy * vy) + vz * vz));
+    }
+    m = lv_wave_max(m);
+    if (lv_lane() == 0) atomicMax(out, __float_as_uint(m));
+}
+
+} // namespace
+
+int lv_flow_set_grid(lv_ctx* ctx, const float* vectorField, uint32_t xs, uint32_t ys, uint32_t zs, float dx, float dy,
+                     float dz, const float* const* scalarFields, uint32_t numScalarFields) {
+    const uint64_t cells = uint64_t(xs) * ys * zs;
+    hipStream_t st = ctx->stream;
+    int rc;
+    if ((rc = lv_buf_reserve(ctx, ctx->flowVectors, size_t(cells) * 12))) return rc;
+    if ((rc = lv_buf_reserve(ctx, ctx->flowScalars, size_t(cells) * 4 * (numScalarFields ? numScalarFields : 1)))) return rc;
+    if ((rc = lv_buf_reserve(ctx, ctx->flowMisc, 16))) return rc;
+    LV_HIP(ctx, hipMemcpyAsync(ctx->flowVectors.ptr, vectorField, size_t(cells) * 12, hipMemcpyHostToDevice, st));
+    for (uint32_t a = 0; a < numScalarFields; a++)
+        LV_HIP(ctx, hipMemcpyAsync((float*)ctx->flowScalars.ptr + size_t(a) * cells, scalarFields[a], size_t(cells) * 4,
+                                   hipMemcpyHostToDevice, st));
+    LV_HIP(ctx, hipMemsetAsync(ctx->flowMisc.ptr, 0, 16, st));
+    const uint32_t grid = uint32_t(std::min<uint64_t>((cells + LV_BLOCK - 1) / LV_BLOCK, 4096));
+    k_max_magnitude<<<grid, LV_BLOCK, 0, st>>>((const float*)ctx->flowVectors.ptr, cells, (uint32_t*)ctx->flowMisc.ptr);
+    LV_HIP(ctx, hipGetLastError());
+    uint32_t bitsMax = 0;
+    LV_HIP(ctx, hipMemcpyAsync(&bitsMax, ctx->flowMisc.ptr, 4, hipMemcpyDeviceToHost, st));
+    LV_HIP(ctx, hipStreamSynchronize(st)); // host arrays are borrowed for the call only
+    memcpy(&ctx->flowMaxMagnitude, &bitsMax, 4);
+    ctx->flowXs = xs; ctx->flowYs = ys; ctx->flowZs = zs;
+    ctx->flowDx = dx; ctx->flowDy = dy; ctx->flowDz = dz;
+    ctx->flowNumScalars = numScalarFields;
+    ctx->flowGridSet = true;
+    return LV_OK;
+}
+
+int lv_flow_trace(lv_ctx* ctx, const float* seeds, uint32_t numSeeds, const lv_streamline_settings* S) {
+    ctx->flowPositions.clear();
+    ctx->flowAttributes.clear();
+    ctx->flowOffsets.assign(1, 0u);
+    if (numSeeds == 0) return LV_OK;
+    hipStream_t st = ctx->stream;
+    LvFlowGrid g;
+    g.V = (const float*)ctx->flowVectors.ptr;
+    g.scalars = (const float*)ctx->flowScalars.ptr;
+    g.xs = int(ctx->flowXs); g.ys = int(ctx->flowYs); g.zs = int(ctx->flowZs);
+    g.dx = ctx->flowDx; g.dy = ctx->flowDy; g.dz = ctx->flowDz;
+    g.bx = float(g.xs - 1) * g.dx; g.by = float(g.ys - 1) * g.dy; g.bz = float(g.zs - 1) * g.dz;
+    g.numScalars = ctx->flowNumScalars;
+    // _trace, :1198-1213
+    const float dt = 1.0f / ctx->flowMaxMagnitude * std::min(g.dx, std::min(g.dy, g.dz)) * S->time_step_scale;
+    const float terminationDistance = 1e-6f * S->termination_distance;
+    const int maxIterations = std::min(int(roundf(float(S->max_num_iterations) / S->time_step_scale)),
+                                       S->max_num_iterations * 10);
+    const float diag = sqrtf((g.bx * g.bx + g.by * g.by) + g.bz * g.bz);
+    const float maxLineLength = diag * (float(S->max_num_iterations) / float(2000));
+    const uint32_t dirs = S->integration_direction == 2u ? 2u : 1u;
+    const uint32_t numThreads = numSeeds * dirs;
+    const uint32_t firstBackward = S->integration_direction == 0u ? numThreads : (S->integration_direction == 1u ? 0u : numSeeds);
+    const uint64_t capacity64 = uint64_t(maxIterations) + 2;
+    const uint32_t k = g.numScalars;
+    const uint64_t bytes = capacity64 * numThreads * (12 + 4 * uint64_t(k));
+    if (capacity64 > 0x7FFFFFFFull || bytes > (64ull << 30))
+        return lv_fail(ctx, LV_E_CAPACITY, "streamline buffers would need %llu bytes", (unsigned long long)bytes);
+    const uint32_t capacity = uint32_t(capacity64);
+    int rc;
+    if ((rc = lv_buf_reserve(ctx, ctx->flowSeeds, size_t(numSeeds) * 12))) return rc;
+    if ((rc = lv_buf_reserve(ctx, ctx->flowOutPos, size_t(capacity) * numThreads * 12))) return rc;
+    if ((rc = lv_buf_reserve(ctx, ctx->flowOutAtt, size_t(capacity) * numThreads * 4 * (k ? k : 1)))) return rc;
+    if ((rc = lv_buf_reserve(ctx, ctx->flowCounts, size_t(numThreads) * 4))) return rc;
+    LV_HIP(ctx, hipMemcpyAsync(ctx->flowSeeds.ptr, seeds, size_t(numSeeds) * 12, hipMemcpyHostToDevice, st));
+    k_trace_streamlines<<<(numThreads + LV_WAVE - 1) / LV_WAVE, LV_WAVE, 0, st>>>(
+            g, (const float*)ctx->flowSeeds.ptr, numSeeds, numThreads, firstBackward, S->integration_method, dt,
+            terminationDistance, maxIterations, maxLineLength, capacity, (float*)ctx->flowOutPos.ptr,
+            (float*)ctx->flowOutAtt.ptr, (uint32_t*)ctx->flowCounts.ptr);
+    LV_HIP(ctx, hipGetLastError());
+    std::vector<uint32_t> counts(numThreads);
+    LV_HIP(ctx, hipMemcpyAsync(counts.data(), ctx->flowCounts.ptr, size_t(numThreads) * 4, hipMemcpyDeviceToHost, st));
+    LV_HIP(ctx, hipStreamSynchronize(st));
+    uint32_t maxCount = 0;
+    for (uint32_t c : counts) maxCount = std::max(maxCount, c);
+    if (maxCount > capacity) return lv_fail(ctx, LV_E_CAPACITY, "streamline longer than its buffer (%u > %u)", maxCount, capacity);
+    // only the rows that hold points travel back: [step][thread] -> the first maxCount steps
+    std::vector<float> hp(size_t(maxCount) * numThreads * 3), ha(size_t(k) * maxCount * numThreads);
+    if (maxCount) {
+        LV_HIP(ctx, hipMemcpyAsync(hp.data(), ctx->flowOutPos.ptr, hp.size() * 4, hipMemcpyDeviceToHost, st));
+        for (uint32_t a = 0; a < k; a++)
+            LV_HIP(ctx, hipMemcpyAsync(ha.data() + size_t(a) * maxCount * numThreads,
+                                       (const float*)ctx->flowOutAtt.ptr + size_t(a) * capacity * numThreads,
+                                       size_t(maxCount) * numThreads * 4, hipMemcpyDeviceToHost, st));
+        LV_HIP(ctx, hipStreamSynchronize(st));
+    }
+    // traceStreamlines, :367-426: order forward / reversed backward, merge, drop lines that are too short
+    ctx->flowAttributes.assign(k, std::vector<float>());
+    std::vector<uint32_t> order; // (thread, step) pairs of one merged line, as step indices per part
+    for (uint32_t s = 0; s < numSeeds; s++) {
+        struct Part { uint32_t thread, begin, end; bool reversed; };
+        Part parts[2];
+        int np = 0;
+        if (S->integration_direction == 0u) {
+            parts[np++] = {s, 0u, counts[s], false};
+        } else if (S->integration_direction == 1u) {
+            parts[np++] = {s, 0u, counts[s], counts[s] > 1};
+        } else {
+            const uint32_t tb = numSeeds + s, nb = counts[tb];
+            // the reversed backward line without its last point (= the seed), then the forward line
+            if (nb > 1) parts[np++] = {tb, 1u, nb, true};
+            parts[np++] = {s, 0u, counts[s], false};
+        }
+        size_t total = 0;
+        for (int i = 0; i < np; i++) total += parts[i].end - parts[i].begin;
+        if (total == 0) continue;
+        auto at = [&](const Part& pt, uint32_t j) { // j-th point of the part in output order
+            const uint32_t step = pt.reversed ? (pt.end - 1 - j) : (pt.begin + j);
+            return size_t(step) * numThreads + pt.thread;
+        };
+        float len = 0.0f;
+        bool have = false;
+        float px = 0, py = 0, pz = 0;
+        for (int i = 0; i < np; i++)
+            for (uint32_t j = 0; j < parts[i].end - parts[i].begin; j++) {
+                const float* q = &hp[at(parts[i], j) * 3];
+                if (have) {
+                    const float ddx = q[0] - px, ddy = q[1] - py, ddz = q[2] - pz;
+                    len += sqrtf((ddx * ddx + ddy * ddy) + ddz * ddz);
+                }
+                px = q[0]; py = q[1]; pz = q[2];
+                have = true;
+            }
+        if (!(len > S->minimum_length)) continue;
+        for (int i = 0; i < np; i++)
+            for (uint32_t j = 0; j < parts[i].end - parts[i].begin; j++) {
+                const size_t src = at(parts[i], j);
+                ctx->flowPositions.insert(ctx->flowPositions.end(), &hp[src * 3], &hp[src * 3] + 3);
+                for (uint32_t a = 0; a < k; a++)
+                    ctx->flowAttributes[a].push_back(ha[size_t(a) * maxCount * numThreads + src]);
+            }
+        ctx->flowOffsets.push_back(uint32_t(ctx->flowPositions.size() / 3));
+    }
+    return LV_OK;
+}

@@ -66,6 +66,15 @@ struct lv_ctx {
     bool triMeshSet = false, triAccelValid = false;
     float triAccelLineWidth = -1.0f, triPad = 0.0f;
 
+    // streamline tracing (lv_flow.hip)
+    LvDeviceBuffer flowVectors, flowScalars, flowMisc, flowSeeds, flowOutPos, flowOutAtt, flowCounts;
+    uint32_t flowXs = 0, flowYs = 0, flowZs = 0, flowNumScalars = 0;
+    float flowDx = 1.0f, flowDy = 1.0f, flowDz = 1.0f, flowMaxMagnitude = 0.0f;
+    bool flowGridSet = false;
+    std::vector<float> flowPositions;                 // result of the last lv_trace_streamlines call (host side)
+    std::vector<std::vector<float>> flowAttributes;
+    std::vector<uint32_t> flowOffsets;
+
     // camera
     bool cameraSet = false;
     float view[16], proj[16], invView[16], invProj[16];
@@ -135,4 +144,8 @@ int lv_frame_depth_range(lv_ctx* ctx);
 int lv_frame_ppll_resolve_only(lv_ctx* ctx, const uint32_t* nodes, uint64_t numNodes, const uint32_t* start,
                                uint64_t numPixels, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, uint8_t* out);
 void lv_fill_uniforms(const lv_ctx* ctx, LvUniforms& U);
+// lv_flow.hip
+int lv_flow_set_grid(lv_ctx* ctx, const float* vectorField, uint32_t xs, uint32_t ys, uint32_t zs, float dx, float dy,
+                     float dz, const float* const* scalarFields, uint32_t numScalarFields);
+int lv_flow_trace(lv_ctx* ctx, const float* seeds, uint32_t numSeeds, const lv_streamline_settings* settings);
 void lv_mat4_inverse(const float* m, float* inv);

@@ -204,6 +204,25 @@ void lvo_render_ao_tri(
         const lvo_tri_scene*, const lvo_params*, int useBvh,
         uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, float* aoOut, lvo_stats* stats);
 
+/* ---- §8f: streamline tracing on a regular grid (StreamlineTracingGrid.cpp, see lv_oracle_flow.cpp) ---- */
+typedef struct {
+    uint32_t integrationMethod;     /* 0 explicit Euler, 2 Heun, 3 midpoint, 4 RK4 (StreamlineTracingDefines.hpp:63-76) */
+    uint32_t integrationDirection;  /* 0 forward, 1 backward, 2 both */
+    float timeStepScale;
+    int32_t maxNumIterations;
+    float terminationDistance;
+    float minimumLength;
+} lvo_streamline_settings;
+typedef struct lvo_streamlines lvo_streamlines;
+void lvo_generate_abc_flow(float* v, int xs, int ys, int zs, float A, float B, float C, float resScale);
+float lvo_max_vector_magnitude(const float* v, uint64_t numCells);
+lvo_streamlines* lvo_trace_streamlines(const float* vectorField, int xs, int ys, int zs, float dx, float dy, float dz,
+                                       const float* const* scalarFields, uint32_t numScalarFields, const float* seeds,
+                                       uint32_t numSeeds, const lvo_streamline_settings* settings);
+void lvo_streamlines_sizes(const lvo_streamlines*, uint64_t* numLines, uint64_t* numPoints);
+void lvo_streamlines_copy(const lvo_streamlines*, float* positions, float* attributes, uint32_t* offsets);
+void lvo_streamlines_destroy(lvo_streamlines*);
+
 #ifdef __cplusplus
 }
 #endif

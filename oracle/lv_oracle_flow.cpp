@@ -1,0 +1,292 @@
+/*
+ * lv_oracle_flow.cpp -- CPU ORACLE, streamline tracing on a regular grid (the step before the
+ * hot path).  TEST INFRASTRUCTURE, NOT PRODUCT (see lv_oracle.h).  PARITY UNPINNED.
+ *
+ * Restates, relative to /root/reference/src/LineData/Flow:
+ *   StreamlineTracingGrid::setGridExtent / addVectorField (max magnitude)   StreamlineTracingGrid.cpp:81-218
+ *   _getVectorAtIdx / _getVectorAtPosition (trilinear)                      :885-913
+ *   _getScalarFieldAtIdx / _pushTrajectoryAttributes                        :857-862,1012-1047
+ *   _rayBoxPlaneIntersection / _rayBoxIntersection                          :949-1010
+ *   _trace (time step, termination rules, boundary clamp)                   :1193-1259
+ *   _integrationStep{ExplicitEuler,Heun,Midpoint,RK4}                       :1278-1339
+ *   traceStreamlines (forward / backward / both, minimum-length filter)     :344-426, _reverseTrajectory :1118,
+ *                                                                           _insertBackwardTrajectory :1149
+ *   AbcFlowGenerator::generateAbcFlow                                       Loader/AbcFlowGenerator.cpp:41-72
+ * Seeds are inputs (the reference's random seeders draw from std::uniform_real_distribution, whose sequence is
+ * implementation defined).  Owned by the build: sgl::AABB3::contains (inclusive on both ends) and glm::normalize
+ * (stated here as v / length(v), like everywhere else in this oracle).
+ */
+#include "lv_oracle_common.h"
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+namespace {
+
+struct Grid {
+    int xs, ys, zs;
+    float dx, dy, dz;
+    V3 boxMin, boxMax;
+    const float* V;                       // xs*ys*zs*3
+    const float* const* scalars;          // numScalars pointers to xs*ys*zs floats
+    uint32_t numScalars;
+};
+
+inline V3 vectorAtIdx(const Grid& g, int x, int y, int z, bool forwardMode) {
+    if (x < 0 || y < 0 || z < 0 || x >= g.xs || y >= g.ys || z >= g.zs) return v3(0.0f, 0.0f, 0.0f);
+    const float* p = g.V + 3 * (size_t(x) + size_t(y) * g.xs + size_t(z) * g.xs * g.ys);
+    return forwardMode ? v3(p[0], p[1], p[2]) : v3(-p[0], -p[1], -p[2]);
+}
+
+struct Cell { int x, y, z; float fx, fy, fz, ix, iy, iz; };
+
+// gridPositionFloat = (p - box.min) * (1/dx, 1/dy, 1/dz); ivec3() truncates towards zero, fract() = x - floor(x)
+inline Cell locate(const Grid& g, V3 p) {
+    V3 q = p - g.boxMin;
+    q = v3(q.x * (1.0f / g.dx), q.y * (1.0f / g.dy), q.z * (1.0f / g.dz));
+    Cell c;
+    c.x = int(q.x); c.y = int(q.y); c.z = int(q.z);
+    c.fx = q.x - floorf(q.x); c.fy = q.y - floorf(q.y); c.fz = q.z - floorf(q.z);
+    c.ix = 1.0f - c.fx; c.iy = 1.0f - c.fy; c.iz = 1.0f - c.fz;
+    return c;
+}
+
+inline V3 vectorAtPosition(const Grid& g, V3 p, bool fw) {
+    const Cell c = locate(g, p);
+    V3 r = (c.ix * c.iy * c.iz) * vectorAtIdx(g, c.x, c.y, c.z, fw);
+    r = r + (c.fx * c.iy * c.iz) * vectorAtIdx(g, c.x + 1, c.y, c.z, fw);
+    r = r + (c.ix * c.fy * c.iz) * vectorAtIdx(g, c.x, c.y + 1, c.z, fw);
+    r = r + (c.fx * c.fy * c.iz) * vectorAtIdx(g, c.x + 1, c.y + 1, c.z, fw);
+    r = r + (c.ix * c.iy * c.fz) * vectorAtIdx(g, c.x, c.y, c.z + 1, fw);
+    r = r + (c.fx * c.iy * c.fz) * vectorAtIdx(g, c.x + 1, c.y, c.z + 1, fw);
+    r = r + (c.ix * c.fy * c.fz) * vectorAtIdx(g, c.x, c.y + 1, c.z + 1, fw);
+    r = r + (c.fx * c.fy * c.fz) * vectorAtIdx(g, c.x + 1, c.y + 1, c.z + 1, fw);
+    return r;
+}
+
+inline float scalarAtIdx(const Grid& g, const float* f, int x, int y, int z) {
+    if (x < 0 || y < 0 || z < 0 || x >= g.xs || y >= g.ys || z >= g.zs) return 0.0f;
+    return f[size_t(x) + size_t(y) * g.xs + size_t(z) * g.xs * g.ys];
+}
+
+inline float scalarAtPosition(const Grid& g, const float* f, V3 p) {
+    const Cell c = locate(g, p);
+    float r = (c.ix * c.iy * c.iz) * scalarAtIdx(g, f, c.x, c.y, c.z);
+    r = r + (c.fx * c.iy * c.iz) * scalarAtIdx(g, f, c.x + 1, c.y, c.z);
+    r = r + (c.ix * c.fy * c.iz) * scalarAtIdx(g, f, c.x, c.y + 1, c.z);
+    r = r + (c.fx * c.fy * c.iz) * scalarAtIdx(g, f, c.x + 1, c.y + 1, c.z);
+    r = r + (c.ix * c.iy * c.fz) * scalarAtIdx(g, f, c.x, c.y, c.z + 1);
+    r = r + (c.fx * c.iy * c.fz) * scalarAtIdx(g, f, c.x + 1, c.y, c.z + 1);
+    r = r + (c.ix * c.fy * c.fz) * scalarAtIdx(g, f, c.x, c.y + 1, c.z + 1);
+    r = r + (c.fx * c.fy * c.fz) * scalarAtIdx(g, f, c.x + 1, c.y + 1, c.z + 1);
+    return r;
+}
+
+inline bool contains(const Grid& g, V3 p) {
+    return p.x >= g.boxMin.x && p.y >= g.boxMin.y && p.z >= g.boxMin.z && p.x <= g.boxMax.x && p.y <= g.boxMax.y &&
+           p.z <= g.boxMax.z;
+}
+
+// :949-989
+inline bool rayBoxPlane(float o, float d, float lower, float upper, float& tNear, float& tFar) {
+    if (fabsf(d) < 0.00001f) {
+        if (o < lower || o > upper) return false;
+    } else {
+        float t0 = (lower - o) / d, t1 = (upper - o) / d;
+        if (t0 > t1) { float tmp = t0; t0 = t1; t1 = tmp; }
+        if (t0 > tNear) tNear = t0;
+        if (t1 < tFar) tFar = t1;
+        if (tNear > tFar) return false;
+        if (tFar < 0) return false;
+    }
+    return true;
+}
+inline bool rayBox(V3 o, V3 d, V3 lower, V3 upper, float& tNear, float& tFar) {
+    tNear = -3.402823466e+38f; // std::numeric_limits<float>::lowest()
+    tFar = 3.402823466e+38f;
+    if (!rayBoxPlane(o.x, d.x, lower.x, upper.x, tNear, tFar)) return false;
+    if (!rayBoxPlane(o.y, d.y, lower.y, upper.y, tNear, tFar)) return false;
+    if (!rayBoxPlane(o.z, d.z, lower.z, upper.z, tNear, tFar)) return false;
+    return true;
+}
+
+struct Line {
+    std::vector<V3> pos;
+    std::vector<std::vector<float>> att;
+};
+
+inline void pushPoint(const Grid& g, Line& l, V3 p) {
+    l.pos.push_back(p);
+    if (l.att.empty()) l.att.resize(g.numScalars);
+    for (uint32_t a = 0; a < g.numScalars; a++) l.att[a].push_back(scalarAtPosition(g, g.scalars[a], p));
+}
+
+inline void integrationStep(const Grid& g, uint32_t method, V3& p0, float dt, bool fw) {
+    switch (method) {
+        case 0: // explicit Euler, :1278-1283
+            p0 = p0 + dt * vectorAtPosition(g, p0, fw);
+            break;
+        case 2: { // Heun, :1309-1318
+            V3 v0 = vectorAtPosition(g, p0, fw);
+            V3 p1 = p0 + dt * v0;
+            V3 v1 = vectorAtPosition(g, p1, fw);
+            p0 = p0 + (dt * 0.5f) * (v0 + v1);
+            break;
+        }
+        case 3: { // midpoint, :1320-1327
+            V3 pp = p0 + (dt * 0.5f) * vectorAtPosition(g, p0, fw);
+            p0 = p0 + dt * vectorAtPosition(g, pp, fw);
+            break;
+        }
+        default: { // RK4, :1329-1339
+            V3 k1 = dt * vectorAtPosition(g, p0, fw);
+            V3 k2 = dt * vectorAtPosition(g, p0 + k1 * 0.5f, fw);
+            V3 k3 = dt * vectorAtPosition(g, p0 + k2 * 0.5f, fw);
+            V3 k4 = dt * vectorAtPosition(g, p0 + k3, fw);
+            const float s6 = 6.0f, s3 = 3.0f;
+            V3 a = v3(k1.x / s6, k1.y / s6, k1.z / s6), b = v3(k2.x / s3, k2.y / s3, k2.z / s3);
+            V3 c = v3(k3.x / s3, k3.y / s3, k3.z / s3), d = v3(k4.x / s6, k4.y / s6, k4.z / s6);
+            p0 = p0 + (((a + b) + c) + d);
+            break;
+        }
+    }
+}
+
+// :1193-1259
+void traceOne(const Grid& g, const lvo_streamline_settings& S, float maxVectorMagnitude, V3 seed, bool fw, Line& line) {
+    const float dt = 1.0f / maxVectorMagnitude * std::min(g.dx, std::min(g.dy, g.dz)) * S.timeStepScale;
+    const float terminationDistance = 1e-6f * S.terminationDistance;
+    V3 p = seed, old;
+    int iterationCounter = 0;
+    const int MAX_ITERATIONS = std::min(int(roundf(float(S.maxNumIterations) / S.timeStepScale)), S.maxNumIterations * 10);
+    float lineLength = 0.0f;
+    const V3 dim = g.boxMax - g.boxMin;
+    const float MAX_LINE_LENGTH = length(dim) * (float(S.maxNumIterations) / float(2000));
+    while (iterationCounter <= MAX_ITERATIONS && lineLength <= MAX_LINE_LENGTH) {
+        old = p;
+        if (!contains(g, p)) {
+            if (!line.pos.empty()) {
+                V3 ro = line.pos.back();
+                V3 rd = normalize(p - ro);
+                float tNear, tFar;
+                rayBox(ro, rd, g.boxMin, g.boxMax, tNear, tFar);
+                V3 b = tNear > 0.0f ? ro + tNear * rd : ro + tFar * rd;
+                pushPoint(g, line, b);
+            }
+            break;
+        }
+        pushPoint(g, line, p);
+        integrationStep(g, S.integrationMethod, p, dt, fw);
+        float segmentLength = length(p - old);
+        lineLength += segmentLength;
+        if (segmentLength < terminationDistance) break;
+        iterationCounter++;
+    }
+}
+
+inline void reverseLine(Line& l) {
+    if (l.pos.size() <= 1) return;
+    std::reverse(l.pos.begin(), l.pos.end());
+    for (auto& a : l.att) std::reverse(a.begin(), a.end());
+}
+
+} // namespace
+
+struct lvo_streamlines {
+    std::vector<float> positions;
+    std::vector<std::vector<float>> attributes;
+    std::vector<uint32_t> offsets;
+};
+
+extern "C" {
+
+// Loader/AbcFlowGenerator.cpp:41-72 (A = sqrt(3), B = sqrt(2), C = 1 at :41-45)
+void lvo_generate_abc_flow(float* v, int xs, int ys, int zs, float A, float B, float C, float resScale) {
+    for (int iz = 0; iz < zs; iz++)
+        for (int iy = 0; iy < ys; iy++)
+            for (int ix = 0; ix < xs; ix++) {
+                float x = float(ix) / float(xs - 1) * resScale;
+                float y = float(iy) / float(ys - 1) * resScale;
+                float z = float(iz) / float(zs - 1) * resScale;
+                size_t o = size_t(iz) * xs * ys * 3 + size_t(iy) * xs * 3 + size_t(ix) * 3;
+                v[o + 0] = A * sinf(z) + C * cosf(y);
+                v[o + 1] = B * sinf(x) + A * cosf(z);
+                v[o + 2] = C * sinf(y) + B * cosf(x);
+            }
+}
+
+// addVectorField's max-magnitude reduction, :189-216
+float lvo_max_vector_magnitude(const float* v, uint64_t numCells) {
+    float m = 0.0f;
+    for (uint64_t i = 0; i < numCells; i++) {
+        float vx = v[3 * i], vy = v[3 * i + 1], vz = v[3 * i + 2];
+        m = std::max(m, sqrtf(vx * vx + vy * vy + vz * vz));
+    }
+    return m;
+}
+
+lvo_streamlines* lvo_trace_streamlines(const float* vectorField, int xs, int ys, int zs, float dx, float dy, float dz,
+                                       const float* const* scalarFields, uint32_t numScalarFields, const float* seeds,
+                                       uint32_t numSeeds, const lvo_streamline_settings* settings) {
+    Grid g;
+    g.xs = xs; g.ys = ys; g.zs = zs; g.dx = dx; g.dy = dy; g.dz = dz;
+    g.boxMin = v3(0.0f, 0.0f, 0.0f);
+    g.boxMax = v3(float(xs - 1) * dx, float(ys - 1) * dy, float(zs - 1) * dz); // setGridExtent, :113-115
+    g.V = vectorField; g.scalars = scalarFields; g.numScalars = numScalarFields;
+    const lvo_streamline_settings& S = *settings;
+    const float maxMag = lvo_max_vector_magnitude(vectorField, uint64_t(xs) * ys * zs);
+    std::vector<Line> lines(numSeeds);
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int64_t i = 0; i < int64_t(numSeeds); i++) {
+        Line& line = lines[size_t(i)];
+        const V3 seed = ld3(seeds + 3 * i);
+        if (S.integrationDirection == 0) {
+            traceOne(g, S, maxMag, seed, true, line);
+        } else if (S.integrationDirection == 1) {
+            traceOne(g, S, maxMag, seed, false, line);
+            reverseLine(line);
+        } else {
+            Line back;
+            traceOne(g, S, maxMag, seed, true, line);
+            traceOne(g, S, maxMag, seed, false, back);
+            reverseLine(back);
+            if (back.pos.size() > 1) { // _insertBackwardTrajectory, :1149-1166
+                line.pos.insert(line.pos.begin(), back.pos.begin(), back.pos.end() - 1);
+                if (line.att.empty()) line.att.resize(numScalarFields);
+                for (uint32_t a = 0; a < numScalarFields; a++)
+                    line.att[a].insert(line.att[a].begin(), back.att[a].begin(), back.att[a].end() - 1);
+            }
+        }
+    }
+    lvo_streamlines* out = new lvo_streamlines();
+    out->attributes.resize(numScalarFields);
+    out->offsets.push_back(0);
+    for (const Line& l : lines) { // minimum-length filter, :413-425
+        if (l.pos.empty()) continue;
+        float len = 0.0f;
+        for (size_t i = 1; i < l.pos.size(); i++) len += length(l.pos[i] - l.pos[i - 1]);
+        if (!(len > S.minimumLength)) continue;
+        for (const V3& p : l.pos) { out->positions.push_back(p.x); out->positions.push_back(p.y); out->positions.push_back(p.z); }
+        for (uint32_t a = 0; a < numScalarFields; a++)
+            out->attributes[a].insert(out->attributes[a].end(), l.att[a].begin(), l.att[a].end());
+        out->offsets.push_back(uint32_t(out->positions.size() / 3));
+    }
+    return out;
+}
+
+void lvo_streamlines_sizes(const lvo_streamlines* s, uint64_t* numLines, uint64_t* numPoints) {
+    *numLines = s->offsets.size() - 1;
+    *numPoints = s->positions.size() / 3;
+}
+void lvo_streamlines_copy(const lvo_streamlines* s, float* positions, float* attributes /* [numScalars][numPoints] */,
+                          uint32_t* offsets) {
+    const size_t n = s->positions.size() / 3;
+    if (positions) memcpy(positions, s->positions.data(), s->positions.size() * 4);
+    if (attributes)
+        for (size_t a = 0; a < s->attributes.size(); a++) memcpy(attributes + a * n, s->attributes[a].data(), n * 4);
+    if (offsets) memcpy(offsets, s->offsets.data(), s->offsets.size() * 4);
+}
+void lvo_streamlines_destroy(lvo_streamlines* s) { delete s; }
+
+} // extern "C"

@@ -15,7 +15,7 @@ _SO = os.path.join(_HERE, "_build", "liblv_oracle.so")
 
 
 def build(force=False):
-    src = [os.path.join(_HERE, f) for f in ("lv_oracle.cpp", "lv_oracle_tri.cpp", "lv_oracle_common.h", "lv_oracle.h", "Makefile")]
+    src = [os.path.join(_HERE, f) for f in ("lv_oracle.cpp", "lv_oracle_tri.cpp", "lv_oracle_flow.cpp", "lv_oracle_common.h", "lv_oracle.h", "Makefile")]
     stale = (not os.path.exists(_SO)) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in src)
     if force or stale:
         subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
@@ -65,6 +65,22 @@ class Stats(C.Structure):
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+class StreamlineSettings(C.Structure):
+    """StreamlineTracingSettings (StreamlineTracingDefines.hpp:144-177), the fields the tracer reads."""
+    _fields_ = [("integrationMethod", C.c_uint32), ("integrationDirection", C.c_uint32), ("timeStepScale", C.c_float),
+                ("maxNumIterations", C.c_int32), ("terminationDistance", C.c_float), ("minimumLength", C.c_float)]
+
+
+INTEGRATION_METHODS = {"Explicit Euler": 0, "Heun": 2, "Midpoint": 3, "Runge-Kutta 4th Order": 4}
+INTEGRATION_DIRECTIONS = {"Forward": 0, "Backward": 1, "Forward & Backward": 2}
+
+
+def streamline_settings(method="Runge-Kutta 4th Order", direction="Forward & Backward", time_step_scale=1.0,
+                        max_num_iterations=2000, termination_distance=1.0, minimum_length=0.7):
+    return StreamlineSettings(INTEGRATION_METHODS[method], INTEGRATION_DIRECTIONS[direction], time_step_scale,
+                              max_num_iterations, termination_distance, minimum_length)
 
 
 _lib = None
@@ -117,6 +133,14 @@ def lib():
     L.lvo_intersect_triangle.argtypes = [vp, vp, vp, vp, vp, f32, C.POINTER(f32), C.POINTER(f32), C.POINTER(f32)]
     L.lvo_trace_rays_tri.argtypes = [vp, i32, vp, vp, f32, f32, u32, vp, vp, vp]
     L.lvo_render_ao_tri.argtypes = [vp, C.POINTER(Params), i32, u32, u32, u32, u32, vp, C.POINTER(Stats)]
+    L.lvo_generate_abc_flow.argtypes = [vp, i32, i32, i32, f32, f32, f32, f32]
+    L.lvo_max_vector_magnitude.restype = f32
+    L.lvo_max_vector_magnitude.argtypes = [vp, C.c_uint64]
+    L.lvo_trace_streamlines.restype = vp
+    L.lvo_trace_streamlines.argtypes = [vp, i32, i32, i32, f32, f32, f32, vp, u32, vp, u32, C.POINTER(StreamlineSettings)]
+    L.lvo_streamlines_sizes.argtypes = [vp, u64p, u64p]
+    L.lvo_streamlines_copy.argtypes = [vp, vp, vp, vp]
+    L.lvo_streamlines_destroy.argtypes = [vp]
     _lib = L
     return L
 
@@ -182,6 +206,34 @@ def build_tube_triangle_render_data(positions, attributes, line_offsets, line_wi
     pts = np.zeros(max(npt.value, 1), dtype=LINE_POINT_DTYPE)
     lib().lvo_build_tube_triangle_render_data(*args, _p(idx), C.byref(ni), _p(verts), C.byref(nv), _p(pts), C.byref(npt))
     return idx[:ni.value].reshape(-1, 3).copy(), verts[:nv.value].copy(), pts[:npt.value].copy()
+
+
+def generate_abc_flow(xs, ys, zs, A=float(np.sqrt(np.float32(3.0))), B=float(np.sqrt(np.float32(2.0))), Cc=1.0,
+                      res_scale=float(2.0 * np.pi)):
+    """AbcFlowGenerator::generateAbcFlow (Loader/AbcFlowGenerator.cpp:41-72): [zs, ys, xs, 3] float32."""
+    v = np.empty((zs, ys, xs, 3), dtype=np.float32)
+    lib().lvo_generate_abc_flow(_p(v), xs, ys, zs, A, B, Cc, res_scale)
+    return v
+
+
+def trace_streamlines(vector_field, spacing, scalar_fields, seeds, settings):
+    """StreamlineTracingGrid::traceStreamlines restated: vector_field [zs, ys, xs, 3], scalar_fields list of [zs, ys, xs].
+    Returns (positions [P,3], attributes [k,P], line_offsets [L+1])."""
+    v = np.ascontiguousarray(vector_field, dtype=np.float32)
+    zs, ys, xs = v.shape[:3]
+    sf = [np.ascontiguousarray(f, dtype=np.float32) for f in scalar_fields]
+    ptrs = (C.c_void_p * max(len(sf), 1))(*[f.ctypes.data for f in sf])
+    sd = np.ascontiguousarray(seeds, dtype=np.float32).reshape(-1, 3)
+    h = lib().lvo_trace_streamlines(_p(v), xs, ys, zs, spacing[0], spacing[1], spacing[2], ptrs, len(sf), _p(sd), len(sd),
+                                    C.byref(settings))
+    nl, npt = C.c_uint64(), C.c_uint64()
+    lib().lvo_streamlines_sizes(h, C.byref(nl), C.byref(npt))
+    pos = np.zeros((npt.value, 3), dtype=np.float32)
+    att = np.zeros((len(sf), npt.value), dtype=np.float32)
+    off = np.zeros(nl.value + 1, dtype=np.uint32)
+    lib().lvo_streamlines_copy(h, _p(pos), _p(att), _p(off))
+    lib().lvo_streamlines_destroy(h)
+    return pos, att, off
 
 
 def intersect_triangle(o, d, v0, v1, v2, pad):

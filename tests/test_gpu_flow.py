@@ -1,0 +1,113 @@
+"""Streamline tracing on the GPU (StreamlineTracingGrid::traceStreamlines) through the C-ABI against
+the CPU oracle: positions, attributes and line offsets bit for bit (float32 +,-,*,/,sqrt,floor in a fixed order)."""
+import numpy as np
+import pytest
+
+from common import small_case
+from linevis_amd import capi, host_api
+from oracle import lvo
+
+pytestmark = pytest.mark.gpu
+
+
+def abc_grid(n=32):
+    v = lvo.generate_abc_flow(n, n, n)
+    mag = np.sqrt((v[..., 0] * v[..., 0] + v[..., 1] * v[..., 1]) + v[..., 2] * v[..., 2]).astype(np.float32)
+    d = np.float32(1.0) / np.float32(n - 1)
+    return v, mag, (float(d), float(d), float(d))
+
+
+def swirl_grid(xs=48, ys=40, zs=56):
+    """A non-cubic grid with anisotropic spacing and a bounded swirl (lines stay inside for many steps)."""
+    z, y, x = np.meshgrid(np.linspace(0, 1, zs), np.linspace(0, 1, ys), np.linspace(0, 1, xs), indexing="ij")
+    u = -(y - 0.5) + 0.2 * (0.5 - x)
+    v = (x - 0.5) + 0.2 * (0.5 - y)
+    w = 0.3 * np.sin(2 * np.pi * x) * np.cos(2 * np.pi * y) + 0.05
+    vec = np.stack([u, v, w], axis=3).astype(np.float32)
+    s0 = np.sqrt(u * u + v * v + w * w).astype(np.float32)
+    s1 = (x + 2 * y + 3 * z).astype(np.float32)
+    return vec, [s0, s1], (0.02, 0.025, 0.0175)
+
+
+def same(a, b):
+    return (np.array_equal(a[2], b[2]) and np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32))
+            and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32)))
+
+
+@pytest.mark.parametrize("method", ["Explicit Euler", "Heun", "Midpoint", "Runge-Kutta 4th Order"])
+@pytest.mark.parametrize("direction", ["Forward", "Backward", "Forward & Backward"])
+def test_streamlines_bit_exact_abc_flow(hip_lib, method, direction):
+    v, mag, sp = abc_grid()
+    rng = np.random.default_rng(1)
+    seeds = rng.uniform(0.05, 0.95, (300, 3)).astype(np.float32)
+    seeds[:5] = [[0, 0, 0], [1, 1, 1], [1.5, 0.5, 0.5], [-0.1, 0.2, 0.3], [0.5, 0.5, 1.0]]   # corners / outside
+    ctx = capi.Context(0)
+    ctx.set_flow_grid(v, sp, [mag])
+    a = ctx.trace_streamlines(seeds, capi.streamline_settings(method, direction, minimum_length=0.3))
+    b = lvo.trace_streamlines(v, sp, [mag], seeds, lvo.streamline_settings(method, direction, minimum_length=0.3))
+    assert same(a, b)
+    assert len(a[2]) - 1 > 100 and len(a[0]) > 3000
+
+
+def test_streamlines_long_lines_termination_rules(hip_lib):
+    vec, scalars, sp = swirl_grid()
+    rng = np.random.default_rng(3)
+    seeds = rng.uniform(0.1, 0.7, (500, 3)).astype(np.float32) * np.array([47 * 0.02, 39 * 0.025, 55 * 0.0175], np.float32)
+    ctx = capi.Context(0)
+    ctx.set_flow_grid(vec, sp, scalars)
+    lens = []
+    for kw in (dict(max_num_iterations=500, time_step_scale=0.25, termination_distance=1500.0, minimum_length=0.0),
+               dict(max_num_iterations=300, time_step_scale=2.0, minimum_length=0.1),   # short line-length limit, bigger step
+               dict(max_num_iterations=2000, minimum_length=0.0)):                      # line-length limit
+        a = ctx.trace_streamlines(seeds, capi.streamline_settings(**kw))
+        b = lvo.trace_streamlines(vec, sp, scalars, seeds, lvo.streamline_settings(**kw))
+        assert same(a, b)
+        lens.append(len(a[0]))
+    assert lens[0] > 500 and lens[1] > 2000 and lens[2] > 20000
+    # "singular point" rule (segment shorter than 1e-6 * termination_distance): slow regions end lines early
+    assert lens[0] < 500 * 2000
+    # second attribute is linear in the position: trilinear sampling reproduces it along every line
+    pos, att, off = a
+    lin = pos[:, 0] / sp[0] / 47 + 2 * pos[:, 1] / sp[1] / 39 + 3 * pos[:, 2] / sp[2] / 55
+    inside = (pos.min(axis=1) > 0)
+    assert np.allclose(att[1][inside], lin[inside], atol=2e-4)
+
+
+def test_streamlines_feed_the_renderer(hip_lib):
+    """traced lines -> LineDataFlow -> frame: the widened path end to end."""
+    v, mag, sp = abc_grid(24)
+    rng = np.random.default_rng(2)
+    seeds = rng.uniform(0.2, 0.8, (64, 3)).astype(np.float32)
+    ctx = capi.Context(0)
+    ctx.set_flow_grid(v, sp, [mag])
+    pos, att, off = ctx.trace_streamlines(seeds, capi.streamline_settings(minimum_length=0.2))
+    assert len(off) - 1 > 20
+    flow = host_api.LineDataFlow().set_trajectories(host_api.normalize_positions(pos), att[0], off)
+    pts, seg, _ = flow.tube_aabb_render_data(0.01)
+    case = small_case(width=64, height=48, line_width=0.01)
+    ctx.set_lines(pts, seg)
+    ctx.set_transfer_function(case.tf, *flow.attribute_range())
+    ctx.set_camera(case.view, case.proj, case.fovy, case.near, case.far, 64, 48)
+    ctx.set_option("line_width", 0.01)
+    img = ctx.render(capi.MODE_RAY_TRACER)
+    assert (img[..., :3] != 255).any()
+
+
+def test_streamline_api_errors(hip_lib):
+    ctx = capi.Context(0)
+    with pytest.raises(capi.LineVisError):
+        ctx.trace_streamlines(np.zeros((1, 3), np.float32), capi.streamline_settings())       # no grid
+    v, mag, sp = abc_grid(8)
+    ctx.set_flow_grid(v, sp, [mag])
+    for bad in ("Implicit Euler", "Runge-Kutta-Fehlberg"):
+        with pytest.raises(capi.LineVisError):
+            ctx.trace_streamlines(np.zeros((1, 3), np.float32) + 0.5, capi.streamline_settings(bad))
+    with pytest.raises(capi.LineVisError):
+        ctx.trace_streamlines(np.zeros((1, 3), np.float32), capi.streamline_settings(time_step_scale=0.0))
+    with pytest.raises(capi.LineVisError):
+        ctx.set_flow_grid(np.zeros((1, 4, 4, 3), np.float32), sp)
+    pos, att, off = ctx.trace_streamlines(np.zeros((0, 3), np.float32), capi.streamline_settings())
+    assert len(pos) == 0 and list(off) == [0]
+    ctx.set_flow_grid(np.zeros((4, 4, 4, 3), np.float32), sp)
+    with pytest.raises(capi.LineVisError):
+        ctx.trace_streamlines(np.zeros((1, 3), np.float32) + 0.5, capi.streamline_settings())  # zero field: dt undefined
