@@ -1,0 +1,112 @@
+// Flow.hpp -- headless mirror of the reference's streamline tracer front end (src/LineData/Flow): the classes an embedder
+// drives to turn a vector field on a regular grid into the trajectories the renderers consume.
+//
+//   StreamlineTracingSettings        StreamlineTracingDefines.hpp:144-177 (the members the line tracer reads)
+//   StreamlineTracingGrid            StreamlineTracingGrid.hpp:51-76: setGridExtent / addVectorField / addScalarField /
+//                                    traceStreamlines; integration runs on the GPU through lv_trace_streamlines
+//   StreamlineVolumeSeeder           StreamlineSeeder.cpp:259-300 (regular grid of seeds; the random mode draws from
+//                                    std::uniform_real_distribution, whose sequence is implementation defined -- here a
+//                                    std::mt19937 mapped to [0,1) by x / 2^32, owned by the build)
+//   AbcFlowGenerator                 Loader/AbcFlowGenerator.{hpp,cpp}: analytic ABC flow sampled to a grid
+#pragma once
+
+#include <map>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "LineData.hpp"
+
+namespace lv {
+
+enum class StreamlineIntegrationMethod { EXPLICIT_EULER, IMPLICIT_EULER, HEUN, MIDPOINT, RK4, RKF45 };
+enum class StreamlineIntegrationDirection { FORWARD, BACKWARD, BOTH };
+extern const char* const STREAMLINE_INTEGRATION_METHOD_NAMES[6];
+extern const char* const STREAMLINE_INTEGRATION_DIRECTION_NAMES[3];
+
+struct StreamlineTracingSettings {
+    int numPrimitives = 1024;
+    float timeStepScale = 1.0f;
+    int maxNumIterations = 2000;
+    float terminationDistance = 1.0f;
+    float minimumLength = 0.7f;
+    StreamlineIntegrationMethod integrationMethod = StreamlineIntegrationMethod::RK4;
+    StreamlineIntegrationDirection integrationDirection = StreamlineIntegrationDirection::BOTH;
+    int vectorFieldIndex = 0;
+};
+
+class StreamlineTracingGrid {
+public:
+    explicit StreamlineTracingGrid(int deviceOrdinal = 0);
+    ~StreamlineTracingGrid();
+    bool isValid() const { return ctx != nullptr; }
+    const std::string& getLastError() const { return lastError; }
+
+    void setGridExtent(int xs, int ys, int zs, float dx, float dy, float dz);
+    /// The fields are copied (the reference takes ownership of the caller's new[] arrays).
+    void addVectorField(const float* vectorField, const std::string& vectorName);
+    void addScalarField(const float* scalarField, const std::string& scalarName);
+    std::vector<std::string> getVectorFieldNames();
+    std::vector<std::string> getScalarFieldNames();
+    const AABB3& getBox() const { return box; }
+    int getGridSizeX() const { return xs; }
+    int getGridSizeY() const { return ys; }
+    int getGridSizeZ() const { return zs; }
+    float getDx() const { return dx; }
+    float getDy() const { return dy; }
+    float getDz() const { return dz; }
+
+    /// traceStreamlines (StreamlineTracingGrid.cpp:344-426) for explicit seed points; attributes of the result are the
+    /// scalar fields in name order (std::map iteration, like the reference's scalarFields).
+    bool traceStreamlines(const StreamlineTracingSettings& tracingSettings, const std::vector<vec3>& seedPoints,
+                          Trajectories& filteredTrajectories);
+
+private:
+    bool uploadGrid(int vectorFieldIndex);
+    lv_ctx* ctx = nullptr;
+    std::string lastError;
+    int xs = 0, ys = 0, zs = 0;
+    float dx = 1.0f, dy = 1.0f, dz = 1.0f;
+    AABB3 box;
+    std::map<std::string, std::vector<float>> vectorFields, scalarFields;
+    int uploadedVectorFieldIndex = -1;
+    bool gridDirty = true;
+};
+
+class StreamlineVolumeSeeder {
+public:
+    void setRegular(int numSamplesX, int numSamplesY, int numSamplesZ);
+    void setRandom(uint32_t seed);
+    void reset(const StreamlineTracingGrid& grid);
+    vec3 getNextPoint();
+
+private:
+    bool regular = true;
+    int numSamplesX = 8, numSamplesY = 8, numSamplesZ = 8, currentSampleIdx = 0;
+    AABB3 box;
+    float maxDimension = 1.0f;
+    uint32_t seed = 12345;
+    std::mt19937 generator;
+};
+
+class AbcFlowGenerator {
+public:
+    AbcFlowGenerator();
+    void setGridSize(int xs_, int ys_, int zs_) { xs = xs_; ys = ys_; zs = zs_; }
+    void setResolutionScale(float s) { resScale = s; }
+    void setCoefficients(float a, float b, float c) { A = a; B = b; C = c; }
+    int getGridSizeX() const { return xs; }
+    int getGridSizeY() const { return ys; }
+    int getGridSizeZ() const { return zs; }
+    void generateAbcFlow(float* v) const;
+    /// "Velocity" + "Velocity Magnitude" on a grid whose longest axis spans [0, 1] (AbcFlowGenerator.cpp:74-103; the
+    /// vorticity / helicity fields of the reference's loader feed ribbons and helicity seeding, which are out of scope).
+    void load(StreamlineTracingGrid* grid) const;
+
+private:
+    int xs = 64, ys = 64, zs = 64;
+    float resScale = 6.0f;
+    float A, B, C;
+};
+
+} // namespace lv

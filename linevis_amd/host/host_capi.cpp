@@ -3,6 +3,7 @@
 // HeadlessLineRenderer).  Not part of the drop-in boundary (that is include/linevis_hip.h).
 #include <cstring>
 
+#include "Flow.hpp"
 #include "HeadlessLineRenderer.hpp"
 
 using namespace lv;
@@ -106,6 +107,87 @@ void lvh_flow_copy_triangle_data(void* hp, uint32_t* indices, lv_tube_vertex* ve
     if (vertices) memcpy(vertices, d.vertexBuffer.data(), d.vertexBuffer.size() * sizeof(lv_tube_vertex));
     if (points) memcpy(points, d.linePointDataBuffer.data(), d.linePointDataBuffer.size() * sizeof(lv_line_point));
 }
+
+// ---- streamline tracer front end (Flow.hpp)
+namespace {
+struct GridHandle {
+    StreamlineTracingGrid grid;
+    Trajectories result;
+    explicit GridHandle(int device) : grid(device) {}
+};
+} // namespace
+void* lvh_grid_create(int deviceOrdinal) {
+    GridHandle* h = new GridHandle(deviceOrdinal);
+    if (!h->grid.isValid()) { delete h; return nullptr; }
+    return h;
+}
+void lvh_grid_destroy(void* h) { delete static_cast<GridHandle*>(h); }
+void lvh_grid_set_extent(void* h, int xs, int ys, int zs, float dx, float dy, float dz) {
+    static_cast<GridHandle*>(h)->grid.setGridExtent(xs, ys, zs, dx, dy, dz);
+}
+void lvh_grid_add_vector_field(void* h, const float* f, const char* name) { static_cast<GridHandle*>(h)->grid.addVectorField(f, name); }
+void lvh_grid_add_scalar_field(void* h, const float* f, const char* name) { static_cast<GridHandle*>(h)->grid.addScalarField(f, name); }
+void lvh_grid_load_abc_flow(void* h, int xs, int ys, int zs, float resScale) {
+    AbcFlowGenerator gen;
+    gen.setGridSize(xs, ys, zs);
+    gen.setResolutionScale(resScale);
+    gen.load(&static_cast<GridHandle*>(h)->grid);
+}
+void lvh_grid_info(void* hp, int* sizes3, float* spacing3, float* box6) {
+    StreamlineTracingGrid& g = static_cast<GridHandle*>(hp)->grid;
+    sizes3[0] = g.getGridSizeX(); sizes3[1] = g.getGridSizeY(); sizes3[2] = g.getGridSizeZ();
+    spacing3[0] = g.getDx(); spacing3[1] = g.getDy(); spacing3[2] = g.getDz();
+    const AABB3& b = g.getBox();
+    box6[0] = b.min.x; box6[1] = b.min.y; box6[2] = b.min.z; box6[3] = b.max.x; box6[4] = b.max.y; box6[5] = b.max.z;
+}
+/// regular volume seeding (StreamlineVolumeSeeder): nx*ny*nz points into out (3 floats each)
+void lvh_grid_regular_seeds(void* hp, int nx, int ny, int nz, float* out) {
+    StreamlineVolumeSeeder seeder;
+    seeder.setRegular(nx, ny, nz);
+    seeder.reset(static_cast<GridHandle*>(hp)->grid);
+    for (int i = 0; i < nx * ny * nz; i++) {
+        vec3 p = seeder.getNextPoint();
+        out[3 * i] = p.x; out[3 * i + 1] = p.y; out[3 * i + 2] = p.z;
+    }
+}
+int lvh_grid_trace(void* hp, const float* seeds, uint32_t numSeeds, int method, int direction, float timeStepScale,
+                   int maxNumIterations, float terminationDistance, float minimumLength, uint64_t* outNumLines,
+                   uint64_t* outNumPoints) {
+    GridHandle* h = static_cast<GridHandle*>(hp);
+    StreamlineTracingSettings s;
+    s.integrationMethod = StreamlineIntegrationMethod(method);
+    s.integrationDirection = StreamlineIntegrationDirection(direction);
+    s.timeStepScale = timeStepScale;
+    s.maxNumIterations = maxNumIterations;
+    s.terminationDistance = terminationDistance;
+    s.minimumLength = minimumLength;
+    std::vector<vec3> seedPoints(numSeeds);
+    if (numSeeds) memcpy(seedPoints.data(), seeds, size_t(numSeeds) * 12);
+    h->result.clear();
+    if (!h->grid.traceStreamlines(s, seedPoints, h->result)) return -1;
+    uint64_t n = 0;
+    for (const Trajectory& t : h->result) n += t.positions.size();
+    *outNumLines = h->result.size();
+    *outNumPoints = n;
+    return 0;
+}
+/// positions n*3, attributes [k][n] (scalar fields in name order), offsets numLines+1
+void lvh_grid_copy_result(void* hp, float* positions, float* attributes, uint32_t* offsets) {
+    const Trajectories& tr = static_cast<GridHandle*>(hp)->result;
+    uint64_t n = 0;
+    for (const Trajectory& t : tr) n += t.positions.size();
+    uint32_t off = 0;
+    for (size_t i = 0; i < tr.size(); i++) {
+        offsets[i] = off;
+        const uint32_t m = uint32_t(tr[i].positions.size());
+        memcpy(positions + 3 * size_t(off), tr[i].positions.data(), size_t(m) * 12);
+        for (size_t a = 0; a < tr[i].attributes.size(); a++)
+            memcpy(attributes + a * n + off, tr[i].attributes[a].data(), size_t(m) * 4);
+        off += m;
+    }
+    offsets[tr.size()] = off;
+}
+const char* lvh_grid_last_error(void* h) { return static_cast<GridHandle*>(h)->grid.getLastError().c_str(); }
 
 // ---- headless renderer harness
 void* lvh_renderer_create(int renderingMode, int deviceOrdinal) {

@@ -39,6 +39,17 @@ def load():
         "lvh_flow_copy_render_data": (None, [vp, vp, vp, vp]),
         "lvh_flow_build_triangle_data": (None, [vp, f32, u32, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]),
         "lvh_flow_copy_triangle_data": (None, [vp, vp, vp, vp]),
+        "lvh_grid_create": (vp, [i32]),
+        "lvh_grid_destroy": (None, [vp]),
+        "lvh_grid_set_extent": (None, [vp, i32, i32, i32, f32, f32, f32]),
+        "lvh_grid_add_vector_field": (None, [vp, vp, cp]),
+        "lvh_grid_add_scalar_field": (None, [vp, vp, cp]),
+        "lvh_grid_load_abc_flow": (None, [vp, i32, i32, i32, f32]),
+        "lvh_grid_info": (None, [vp, vp, vp, vp]),
+        "lvh_grid_regular_seeds": (None, [vp, i32, i32, i32, vp]),
+        "lvh_grid_trace": (i32, [vp, vp, u32, i32, i32, f32, i32, f32, f32, C.POINTER(u64), C.POINTER(u64)]),
+        "lvh_grid_copy_result": (None, [vp, vp, vp, vp]),
+        "lvh_grid_last_error": (cp, [vp]),
         "lvh_renderer_create": (vp, [i32, i32]),
         "lvh_renderer_destroy": (None, [vp]),
         "lvh_renderer_set_resolution": (None, [vp, u32, u32]),
@@ -149,6 +160,74 @@ class LineDataFlow:
         pts = np.zeros(npt.value, dtype=capi.LINE_POINT_DTYPE)
         self.L.lvh_flow_copy_triangle_data(self.h, _p(idx), _p(verts), _p(pts))
         return idx.reshape(-1, 3), verts, pts
+
+
+class StreamlineTracingGrid:
+    """lv::StreamlineTracingGrid (+ AbcFlowGenerator, StreamlineVolumeSeeder): vector field on a regular grid ->
+    trajectories, integrated on the GPU."""
+
+    def __init__(self, device=0):
+        self.L = load()
+        self.h = self.L.lvh_grid_create(int(device))
+        if not self.h:
+            raise capi.LineVisError(capi.LV_OK - 2, "no usable HIP device (there is no CPU fallback)")
+        self.num_scalars = 0
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.L.lvh_grid_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def set_grid_extent(self, xs, ys, zs, dx, dy, dz):
+        self.L.lvh_grid_set_extent(self.h, xs, ys, zs, dx, dy, dz)
+        self.num_scalars = 0
+        return self
+
+    def add_vector_field(self, field, name="Velocity"):
+        f = np.ascontiguousarray(field, dtype=np.float32)
+        self.L.lvh_grid_add_vector_field(self.h, _p(f), name.encode())
+        return self
+
+    def add_scalar_field(self, field, name):
+        f = np.ascontiguousarray(field, dtype=np.float32)
+        self.L.lvh_grid_add_scalar_field(self.h, _p(f), name.encode())
+        self.num_scalars += 1
+        return self
+
+    def load_abc_flow(self, xs=64, ys=64, zs=64, res_scale=6.0):
+        self.L.lvh_grid_load_abc_flow(self.h, xs, ys, zs, res_scale)
+        self.num_scalars = 1
+        return self
+
+    def info(self):
+        sizes = np.zeros(3, dtype=np.int32)
+        spacing = np.zeros(3, dtype=np.float32)
+        box = np.zeros(6, dtype=np.float32)
+        self.L.lvh_grid_info(self.h, _p(sizes), _p(spacing), _p(box))
+        return sizes, spacing, box
+
+    def regular_seeds(self, nx, ny, nz):
+        out = np.zeros((nx * ny * nz, 3), dtype=np.float32)
+        self.L.lvh_grid_regular_seeds(self.h, nx, ny, nz, _p(out))
+        return out
+
+    def trace_streamlines(self, seeds, method="Runge-Kutta 4th Order", direction="Forward & Backward",
+                          time_step_scale=1.0, max_num_iterations=2000, termination_distance=1.0, minimum_length=0.7):
+        sd = np.ascontiguousarray(seeds, dtype=np.float32).reshape(-1, 3)
+        nl, npt = C.c_uint64(), C.c_uint64()
+        rc = self.L.lvh_grid_trace(self.h, _p(sd), len(sd), capi.INTEGRATION_METHODS[method],
+                                   capi.INTEGRATION_DIRECTIONS[direction], time_step_scale, max_num_iterations,
+                                   termination_distance, minimum_length, C.byref(nl), C.byref(npt))
+        if rc != 0:
+            raise capi.LineVisError(rc, self.L.lvh_grid_last_error(self.h).decode("utf-8", "replace"))
+        pos = np.zeros((npt.value, 3), dtype=np.float32)
+        att = np.zeros((self.num_scalars, npt.value), dtype=np.float32)
+        off = np.zeros(nl.value + 1, dtype=np.uint32)
+        self.L.lvh_grid_copy_result(self.h, _p(pos), _p(att), _p(off))
+        return pos, att, off
 
 
 class HeadlessLineRenderer:

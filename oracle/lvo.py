@@ -209,7 +209,7 @@ def build_tube_triangle_render_data(positions, attributes, line_offsets, line_wi
 
 
 def generate_abc_flow(xs, ys, zs, A=float(np.sqrt(np.float32(3.0))), B=float(np.sqrt(np.float32(2.0))), Cc=1.0,
-                      res_scale=float(2.0 * np.pi)):
+                      res_scale=6.0):
     """AbcFlowGenerator::generateAbcFlow (Loader/AbcFlowGenerator.cpp:41-72): [zs, ys, xs, 3] float32."""
     v = np.empty((zs, ys, xs, 3), dtype=np.float32)
     lib().lvo_generate_abc_flow(_p(v), xs, ys, zs, A, B, Cc, res_scale)

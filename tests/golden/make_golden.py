@@ -278,7 +278,30 @@ def triangle_tubes():
     np.savez_compressed(os.path.join(HERE, "triangle_tubes.npz"), **out)
 
 
+def flow_small():
+    """Streamline tracing known answers: ABC flow on a 16^3 grid (resScale 6), 40 seeds, every integrator."""
+    n = 16
+    v = lvo.generate_abc_flow(n, n, n)
+    mag = np.sqrt((v[..., 0] * v[..., 0] + v[..., 1] * v[..., 1]) + v[..., 2] * v[..., 2]).astype(np.float32)
+    d = float(np.float32(1.0) / np.float32(n - 1))
+    rng = np.random.default_rng(21)
+    seeds = rng.uniform(0.1, 0.9, (40, 3)).astype(np.float32)
+    out = dict(n=n, spacing=np.float32(d), seeds=seeds, field_crc=np.uint32(np.bitwise_xor.reduce(v.reshape(-1).view(np.uint32))))
+    for key, method, direction in (("rk4_both", "Runge-Kutta 4th Order", "Forward & Backward"),
+                                   ("euler_fwd", "Explicit Euler", "Forward"), ("heun_bwd", "Heun", "Backward"),
+                                   ("midpoint_both", "Midpoint", "Forward & Backward")):
+        S = lvo.streamline_settings(method, direction, minimum_length=0.25)
+        pos, att, off = lvo.trace_streamlines(v, (d, d, d), [mag], seeds, S)
+        out[key + "_pos_bits"] = f2u(pos)
+        out[key + "_att_bits"] = f2u(att)
+        out[key + "_off"] = off
+    np.savez_compressed(os.path.join(HERE, "flow_small.npz"), **out)
+
+
 if __name__ == "__main__":
+    if "--only-flow" in sys.argv:
+        flow_small()
+        sys.exit(0)
     if "--only-triangle-tubes" in sys.argv:
         triangle_tubes()
         sys.exit(0)
@@ -289,6 +312,7 @@ if __name__ == "__main__":
     ppll_lists()
     lattice_c1()
     triangle_tubes()
+    flow_small()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print("%-24s %8d bytes" % (f, os.path.getsize(os.path.join(HERE, f))))

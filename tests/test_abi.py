@@ -54,7 +54,8 @@ def test_no_cpu_fallback_without_a_device():
 
 def test_host_library_loads():
     L = host_api.load()
-    for name in ("lvh_flow_create", "lvh_flow_build_render_data", "lvh_renderer_create", "lvh_renderer_render"):
+    for name in ("lvh_flow_create", "lvh_flow_build_render_data", "lvh_flow_build_triangle_data", "lvh_grid_create",
+                 "lvh_grid_trace", "lvh_renderer_create", "lvh_renderer_render"):
         assert hasattr(L, name)
 
 

@@ -1,0 +1,127 @@
+"""Streamline tracing: the oracle's restatement of StreamlineTracingGrid against the committed fixture
+and against independent properties of the integrators and termination rules (CPU only)."""
+import os
+
+import numpy as np
+import pytest
+
+from common import GOLDEN_DIR
+from oracle import lvo
+
+G = np.load(os.path.join(GOLDEN_DIR, "flow_small.npz"))
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def test_abc_flow_generator_and_golden_traces():
+    n = int(G["n"])
+    v = lvo.generate_abc_flow(n, n, n)
+    assert np.uint32(np.bitwise_xor.reduce(v.reshape(-1).view(np.uint32))) == G["field_crc"]
+    # AbcFlowGenerator.cpp:56-64 in float64
+    g = np.arange(n) / (n - 1) * 6.0
+    z, y, x = np.meshgrid(g, g, g, indexing="ij")
+    A, B, Cc = np.sqrt(3.0), np.sqrt(2.0), 1.0
+    ref = np.stack([A * np.sin(z) + Cc * np.cos(y), B * np.sin(x) + A * np.cos(z), Cc * np.sin(y) + B * np.cos(x)], axis=3)
+    assert np.allclose(v, ref, atol=2e-6)
+    mag = np.sqrt((v[..., 0] * v[..., 0] + v[..., 1] * v[..., 1]) + v[..., 2] * v[..., 2]).astype(np.float32)
+    d = float(G["spacing"])
+    for key, method, direction in (("rk4_both", "Runge-Kutta 4th Order", "Forward & Backward"),
+                                   ("euler_fwd", "Explicit Euler", "Forward"), ("heun_bwd", "Heun", "Backward"),
+                                   ("midpoint_both", "Midpoint", "Forward & Backward")):
+        pos, att, off = lvo.trace_streamlines(v, (d, d, d), [mag], G["seeds"],
+                                              lvo.streamline_settings(method, direction, minimum_length=0.25))
+        assert np.array_equal(off, G[key + "_off"]) and np.array_equal(bits(pos), G[key + "_pos_bits"])
+        assert np.array_equal(bits(att), G[key + "_att_bits"])
+        assert len(off) > 10
+
+
+def uniform_field(n, vec):
+    v = np.zeros((n, n, n, 3), dtype=np.float32)
+    v[...] = np.asarray(vec, dtype=np.float32)
+    return v
+
+
+def test_uniform_field_time_step_and_boundary_clamp():
+    """dt = 1 / max|v| * min(dx,dy,dz) * timeStepScale (StreamlineTracingGrid.cpp:1198): in a uniform field every step is
+    one cell (times the scale); the line ends ON the box boundary (:1218-1233)."""
+    n, d = 11, 0.1
+    v = uniform_field(n, (2.0, 0.0, 0.0))
+    seed = np.array([[0.05, 0.5, 0.5]], np.float32)
+    for scale in (1.0, 0.5):
+        S = lvo.streamline_settings("Runge-Kutta 4th Order", "Forward", time_step_scale=scale, minimum_length=0.1)
+        pos, att, off = lvo.trace_streamlines(v, (d, d, d), [], seed, S)
+        assert list(off) == [0, len(pos)]
+        steps = np.diff(pos[:, 0])
+        assert np.allclose(steps[:-1], d * scale, rtol=1e-5)
+        assert np.allclose(pos[:, 1:], 0.5) and abs(pos[-1, 0] - 1.0) < 1e-6 and pos[-2, 0] < 1.0
+    S = lvo.streamline_settings("Runge-Kutta 4th Order", "Forward & Backward", minimum_length=0.1)
+    pos, _, off = lvo.trace_streamlines(v, (d, d, d), [], seed, S)
+    # backward part reversed in front, seed exactly once, both ends on the boundary
+    assert abs(pos[0, 0]) < 1e-6 and abs(pos[-1, 0] - 1.0) < 1e-6 and np.all(np.diff(pos[:, 0]) > 0)
+    assert (np.abs(pos[:, 0] - 0.05) < 1e-7).sum() == 1
+    S = lvo.streamline_settings("Runge-Kutta 4th Order", "Backward", minimum_length=0.01)
+    posb, _, _ = lvo.trace_streamlines(v, (d, d, d), [], seed, S)
+    assert np.array_equal(posb, pos[:len(posb)])          # the backward line alone is the reversed prefix
+
+
+def test_rotation_field_integrator_order():
+    """Rigid rotation about the box centre: exact solution is a circle; error after one revolution shrinks with the
+    integrator's order (Euler spirals out, RK4 stays on the circle)."""
+    n, d = 65, 1.0 / 64
+    g = np.arange(n) * d
+    z, y, x = np.meshgrid(g, g, g, indexing="ij")
+    v = np.stack([-(y - 0.5), (x - 0.5), np.zeros_like(x)], axis=3).astype(np.float32)
+    seed = np.array([[0.75, 0.5, 0.5]], np.float32)
+    err = {}
+    for method in ("Explicit Euler", "Heun", "Midpoint", "Runge-Kutta 4th Order"):
+        S = lvo.streamline_settings(method, "Forward", max_num_iterations=2000, minimum_length=0.1)
+        pos, _, _ = lvo.trace_streamlines(v, (d, d, d), [], seed, S)
+        r = np.linalg.norm(pos[:, :2] - 0.5, axis=1)
+        err[method] = float(np.abs(r - 0.25).max())
+        assert len(pos) > 50
+    assert err["Runge-Kutta 4th Order"] < 1e-5 < err["Heun"] * 50
+    assert err["Heun"] < err["Explicit Euler"] / 20 and err["Midpoint"] < err["Explicit Euler"] / 20
+
+
+def test_termination_rules_and_min_length_filter():
+    n, d = 17, 1.0 / 16
+    g = np.arange(n) * d
+    z, y, x = np.meshgrid(g, g, g, indexing="ij")
+    # converging field with a sink at the centre: lines slow down and stop at the "singular point"
+    v = np.stack([0.5 - x, 0.5 - y, 0.5 - z], axis=3).astype(np.float32)
+    seeds = np.array([[0.1, 0.2, 0.3], [0.9, 0.8, 0.6], [0.5, 0.5, 0.5]], np.float32)
+    S = lvo.streamline_settings("Runge-Kutta 4th Order", "Forward", termination_distance=100.0, minimum_length=0.05)
+    pos, _, off = lvo.trace_streamlines(v, (d, d, d), [], seeds, S)
+    assert len(off) == 3                      # the seed sitting on the sink yields a one-point line: dropped
+    for l in range(2):
+        p = pos[off[l]:off[l + 1]]
+        assert np.linalg.norm(p[-1] - 0.5) < 5e-3 and len(p) < 2000
+    # iteration limit: MAX_ITERATIONS = min(round(maxNumIterations / timeStepScale), 10 * maxNumIterations) (+1 start point)
+    vu = uniform_field(257, (1.0, 0.0, 0.0))
+    S = lvo.streamline_settings("Explicit Euler", "Forward", max_num_iterations=100, time_step_scale=0.1, minimum_length=0.0)
+    p2, _, _ = lvo.trace_streamlines(vu, (1.0 / 256,) * 3, [], np.array([[0.01, 0.5, 0.5]], np.float32), S)
+    # line-length limit diag * 100/2000 = 0.0866 is hit first here: 0.0866 / (0.1 / 256) = 222 steps
+    assert 215 < len(p2) < 230
+    S = lvo.streamline_settings("Explicit Euler", "Forward", max_num_iterations=100, time_step_scale=2.0, minimum_length=0.0)
+    p3, _, _ = lvo.trace_streamlines(vu, (1.0 / 256,) * 3, [], np.array([[0.01, 0.5, 0.5]], np.float32), S)
+    assert len(p3) <= 100 / 2.0 + 2 and len(p3) >= 12
+    # minimum length filter drops everything shorter
+    S = lvo.streamline_settings("Runge-Kutta 4th Order", "Forward", termination_distance=100.0, minimum_length=10.0)
+    assert len(lvo.trace_streamlines(v, (d, d, d), [], seeds, S)[0]) == 0
+
+
+def test_attributes_are_trilinear_samples():
+    n, d = 9, 0.125
+    g = np.arange(n) * d
+    z, y, x = np.meshgrid(g, g, g, indexing="ij")
+    v = uniform_field(n, (0.3, 0.2, 0.1))
+    f0 = (x + 2 * y + 3 * z).astype(np.float32)          # linear: reproduced exactly by trilinear interpolation
+    f1 = (x * y * z).astype(np.float32)                  # trilinear itself
+    seeds = np.array([[0.11, 0.23, 0.37], [0.5, 0.1, 0.9]], np.float32)
+    pos, att, off = lvo.trace_streamlines(v, (d, d, d), [f0, f1], seeds,
+                                          lvo.streamline_settings(minimum_length=0.05))
+    assert att.shape == (2, len(pos)) and len(off) == 3
+    assert np.allclose(att[0], pos[:, 0] + 2 * pos[:, 1] + 3 * pos[:, 2], atol=1e-5)
+    assert np.allclose(att[1], pos[:, 0] * pos[:, 1] * pos[:, 2], atol=1e-5)

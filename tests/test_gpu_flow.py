@@ -111,3 +111,50 @@ def test_streamline_api_errors(hip_lib):
     ctx.set_flow_grid(np.zeros((4, 4, 4, 3), np.float32), sp)
     with pytest.raises(capi.LineVisError):
         ctx.trace_streamlines(np.zeros((1, 3), np.float32) + 0.5, capi.streamline_settings())  # zero field: dt undefined
+
+
+def test_streamlines_golden_fixture(hip_lib):
+    import os
+    from common import GOLDEN_DIR
+    g = np.load(os.path.join(GOLDEN_DIR, "flow_small.npz"))
+    n, d = int(g["n"]), float(g["spacing"])
+    v = lvo.generate_abc_flow(n, n, n)
+    mag = np.sqrt((v[..., 0] * v[..., 0] + v[..., 1] * v[..., 1]) + v[..., 2] * v[..., 2]).astype(np.float32)
+    ctx = capi.Context(0)
+    ctx.set_flow_grid(v, (d, d, d), [mag])
+    for key, method, direction in (("rk4_both", "Runge-Kutta 4th Order", "Forward & Backward"),
+                                   ("euler_fwd", "Explicit Euler", "Forward"), ("heun_bwd", "Heun", "Backward"),
+                                   ("midpoint_both", "Midpoint", "Forward & Backward")):
+        pos, att, off = ctx.trace_streamlines(g["seeds"], capi.streamline_settings(method, direction, minimum_length=0.25))
+        assert np.array_equal(off, g[key + "_off"])
+        assert np.array_equal(pos.view(np.uint32), g[key + "_pos_bits"]) and np.array_equal(att.view(np.uint32), g[key + "_att_bits"])
+
+
+def test_host_tracer_classes(hip_lib):
+    """lv::StreamlineTracingGrid + AbcFlowGenerator + StreamlineVolumeSeeder (the plugin-side front end) against the
+    oracle: same field, same seeds, same lines."""
+    grid = host_api.StreamlineTracingGrid().load_abc_flow(24, 20, 28, 6.0)
+    sizes, spacing, box = grid.info()
+    assert list(sizes) == [24, 20, 28] and np.allclose(spacing, 1.0 / 27) and np.allclose(box[3:], np.array([23, 19, 27]) / 27.0)
+    seeds = grid.regular_seeds(5, 4, 3)
+    # StreamlineVolumeSeeder::getNextPoint (regular): boxMin + dimensions * (i + 1) / (n + 1), x fastest
+    exp = np.array([[box[3] * (x + 1) / 6, box[4] * (y + 1) / 5, box[5] * (z + 1) / 4]
+                    for z in range(3) for y in range(4) for x in range(5)], np.float32)
+    assert np.allclose(seeds, exp, atol=1e-6)
+    a = grid.trace_streamlines(seeds, minimum_length=0.3)
+    # the same through the oracle (AbcFlowGenerator restated; the host computes |v| as sqrt((xx + yy) + zz))
+    v = lvo.generate_abc_flow(24, 20, 28)
+    mag = np.sqrt((v[..., 0] * v[..., 0] + v[..., 1] * v[..., 1]) + v[..., 2] * v[..., 2]).astype(np.float32)
+    sp = tuple(float(s) for s in spacing)
+    b = lvo.trace_streamlines(v, sp, [mag], seeds, lvo.streamline_settings(minimum_length=0.3))
+    assert same(a, b) and len(a[2]) > 20
+    # a second vector field / scalar field set by hand, another integrator
+    vec, scalars, sp2 = swirl_grid(20, 24, 16)
+    grid.set_grid_extent(20, 24, 16, *sp2).add_vector_field(vec).add_scalar_field(scalars[1], "b").add_scalar_field(scalars[0], "a")
+    sd = grid.regular_seeds(4, 4, 4)
+    a = grid.trace_streamlines(sd, method="Heun", direction="Forward", minimum_length=0.05)
+    b = lvo.trace_streamlines(vec, sp2, [scalars[0], scalars[1]], sd,       # attributes come in NAME order: a, b
+                              lvo.streamline_settings("Heun", "Forward", minimum_length=0.05))
+    assert same(a, b) and len(a[0]) > 500
+    with pytest.raises(capi.LineVisError):
+        grid.trace_streamlines(sd, method="Runge-Kutta-Fehlberg")
