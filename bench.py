@@ -178,6 +178,8 @@ def main():
     if world > 1:
         dist.all_reduce(counters)
     rays_per_frame = float(counters[0].item())
+    counters_local = (st.nodes_visited, st.prims_tested, st.hits_shaded, st.ao_rays_traced, st.ao_nodes_visited,
+                      st.ao_prims_tested)
     # algorithmic bytes of ONE k_ao_rays launch on this rank (DESIGN.md "Algorithmic bytes"):
     # 64 B per compressed 4-wide BVH node visited + 32 B per segment record tested + 52 B per compacted pixel (48 B G-buffer read,
     # 4 B AO factor write)
@@ -232,6 +234,9 @@ def main():
                          "algorithmic_bytes_per_launch": int(kernel_bytes), "ms_per_launch": round(ms_rays, 4),
                          "launches_timed": int(min(st.kernel_launches[kid], 128)),
                          "frame_algorithmic_bytes_rank0": int(frame_bytes)},
+            "counters_rank0": {"nodes_visited": int(counters_local[0]), "prims_tested": int(counters_local[1]),
+                               "hits_shaded": int(counters_local[2]), "ao_rays": int(counters_local[3]),
+                               "ao_nodes_visited": int(counters_local[4]), "ao_prims_tested": int(counters_local[5])},
             "kernels_ms": {capi.KERNEL_NAMES[k]: round(float(st.ms_kernel_avg[k]), 4) for k in range(6)
                            if st.kernel_launches[k]},
         }

@@ -39,6 +39,10 @@
 #define LV_NODE_MIN_ACTIVE 24  // node loop yields to the leaf loop when fewer lanes than this are descending
 #endif
 
+#ifndef LV_HANDOVER_MAX_BUSY
+#define LV_HANDOVER_MAX_BUSY 48 // cooperative closest hit: idle lanes take over stacked subtrees once at most this many lanes descend
+#endif
+
 struct f3 { float x, y, z; };
 struct f4 { float x, y, z, w; };
 

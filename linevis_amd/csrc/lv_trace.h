@@ -310,16 +310,19 @@ struct LvCoopMem {
     float4* ray;                   // [2 * 64]  {o.xyz, -}{d.xyz, -}
     unsigned long long* key;       // [64]      (t bits << 32) | (original segment << 2) | kind
     unsigned* queue;               // [LV_QCAP] (owner lane << 26) | leaf
+    uint2* xchg;                   // [64]      subtree hand-over slots: {node reference, owner lane}
 };
 #define LV_COOP_SHARED(NWAVES)                                   \
     __shared__ float4 s_coopRay[2 * LV_WAVE * (NWAVES)];         \
     __shared__ unsigned long long s_coopKey[LV_WAVE * (NWAVES)]; \
-    __shared__ unsigned s_coopQueue[(NWAVES)][LV_QCAP]
+    __shared__ unsigned s_coopQueue[(NWAVES)][LV_QCAP];          \
+    __shared__ uint2 s_coopXchg[LV_WAVE * (NWAVES)]
 #define LV_COOP_MEM(cm)                                          \
     LvCoopMem cm;                                                \
     cm.ray = &s_coopRay[2 * LV_WAVE * (threadIdx.x >> 6)];       \
     cm.key = &s_coopKey[LV_WAVE * (threadIdx.x >> 6)];           \
-    cm.queue = s_coopQueue[threadIdx.x >> 6]
+    cm.queue = s_coopQueue[threadIdx.x >> 6];                    \
+    cm.xchg = &s_coopXchg[LV_WAVE * (threadIdx.x >> 6)]
 
 // Closest hit with reportIntersectionEXT semantics (accepted iff tMin <= t <= tMax; ties -> lowest original segment
 // index), computed by the whole wave together: EVERY lane of the wave must call this function in convergent control
@@ -342,8 +345,10 @@ __device__ __forceinline__ LvHit lv_trace_closest(const LvSceneDev& S, float rad
     LvHit h;
     h.t = tMax; h.leaf = LV_INVALID; h.kind = 0; h.found = false;
     if (STATS && active) cnt.rays++;
-    const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    const f3 oi = mk3(o.x * inv.x, o.y * inv.y, o.z * inv.z);
+    // the ray this lane currently descends for: its own at first, later possibly a subtree handed over by a busy lane
+    unsigned owner = lane;
+    f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    f3 oi = mk3(o.x * inv.x, o.y * inv.y, o.z * inv.z);
     LvStack st;
     st.init(sm.lds, sm.ovf, sm.ovfStride);
     cm.ray[2 * lane] = make_float4(o.x, o.y, o.z, tMin);
@@ -359,36 +364,71 @@ __device__ __forceinline__ LvHit lv_trace_closest(const LvSceneDev& S, float rad
         const unsigned long long mL = __ballot(isLeaf);
         if (mL) {
             if (isLeaf) {
-                cm.queue[(tail + unsigned(__popcll(mL & below))) % LV_QCAP] = (lane << 26) | (cur & 0x03FFFFFFu);
+                cm.queue[(tail + unsigned(__popcll(mL & below))) % LV_QCAP] = (owner << 26) | (cur & 0x03FFFFFFu);
                 cur = lv_pop_or_done(st);
             }
             tail += unsigned(__popcll(mL));
             if (tail - head < LV_WAVE) continue; // a popped reference may be a leaf again
         }
-        const int nNode = __popcll(__ballot(!(cur & LV_LEAF_BIT)));
+        const unsigned long long mNode = __ballot(!(cur & LV_LEAF_BIT));
+        const int nNode = __popcll(mNode);
         const unsigned q = tail - head;
         if (q >= LV_WAVE || (q > 0 && nNode == 0)) {
             const unsigned n = q < LV_WAVE ? q : LV_WAVE;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             if (lane < n) {
                 const unsigned e = cm.queue[(head + lane) % LV_QCAP];
-                const unsigned owner = e >> 26, leaf = e & 0x03FFFFFFu;
-                const float4 ro = cm.ray[2 * owner], rd = cm.ray[2 * owner + 1];
+                const unsigned ow = e >> 26, leaf = e & 0x03FFFFFFu;
+                const float4 ro = cm.ray[2 * ow], rd = cm.ray[2 * ow + 1];
                 if (STATS) cnt.prims++;
                 float t; unsigned low;
                 if (lv_leaf_test<PRIM>(S, leaf, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), radius, capped, t, low)) {
                     if (t >= ro.w && t <= rd.w)
-                        atomicMin(&cm.key[owner], ((unsigned long long)__float_as_uint(t) << 32) | low);
+                        atomicMin(&cm.key[ow], ((unsigned long long)__float_as_uint(t) << 32) | low);
                 }
             }
             head += n;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            const unsigned long long key = cm.key[lane];
+            const unsigned long long key = cm.key[owner];
             best = __uint_as_float(unsigned(key >> 32)); // shrinks the slab interval of the following node steps
             if (ANY_HIT && key != keyInit) { cur = LV_INVALID; st.sp = 0; }
             continue;
         }
         if (nNode == 0) break;
+        // ---- subtree hand-over: when at least half of the wave has nothing to descend, every idle lane takes the top
+        // stack entry of a lane that still has entries stacked and continues it FOR THAT LANE'S RAY (hits merge into the
+        // owner's key like any other).  A ray that needs hundreds of node steps -- the tail that bounds the tile kernels,
+        // whose time is otherwise the serial fetch chain of one lane -- is spread over the wave this way.  The closest hit
+        // is a minimum over all leaves reached under a monotonically shrinking bound, so the result does not depend on
+        // who visits which subtree.
+        if (nNode <= LV_HANDOVER_MAX_BUSY) {
+            const bool idle = cur == LV_INVALID;
+            const bool donor = !idle && st.sp > 0;
+            const unsigned long long mIdle = __ballot(idle), mDonor = __ballot(donor);
+            const unsigned nPairs = min(unsigned(__popcll(mIdle)), unsigned(__popcll(mDonor)));
+            if (nPairs) {
+                if (donor) {
+                    const unsigned r = unsigned(__popcll(mDonor & below));
+                    if (r < nPairs) cm.xchg[r] = make_uint2(st.pop(), owner);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                if (idle) {
+                    const unsigned r = unsigned(__popcll(mIdle & below));
+                    if (r < nPairs) {
+                        const uint2 x = cm.xchg[r];
+                        cur = x.x;
+                        owner = x.y;
+                        const float4 ro = cm.ray[2 * owner], rd = cm.ray[2 * owner + 1];
+                        inv = mk3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+                        oi = mk3(ro.x * inv.x, ro.y * inv.y, ro.z * inv.z);
+                        tMin = ro.w;
+                        best = __uint_as_float(unsigned(cm.key[owner] >> 32));
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                continue; // the reference taken over may be a leaf
+            }
+        }
         int nNow;
         do { // tight descend loop
             if (!(cur & LV_LEAF_BIT)) cur = lv_node_step<STATS>(S, cur, oi, inv, tMin, best, st, cnt);
@@ -396,13 +436,13 @@ __device__ __forceinline__ LvHit lv_trace_closest(const LvSceneDev& S, float rad
             const unsigned long long m = __ballot(lf);
             if (m) {
                 if (lf) {
-                    cm.queue[(tail + unsigned(__popcll(m & below))) % LV_QCAP] = (lane << 26) | (cur & 0x03FFFFFFu);
+                    cm.queue[(tail + unsigned(__popcll(m & below))) % LV_QCAP] = (owner << 26) | (cur & 0x03FFFFFFu);
                     cur = lv_pop_or_done(st);
                 }
                 tail += unsigned(__popcll(m));
             }
             nNow = __popcll(__ballot(!(cur & LV_LEAF_BIT)));
-        } while (tail - head < LV_WAVE && nNow > 0);
+        } while (tail - head < LV_WAVE && nNow > LV_HANDOVER_MAX_BUSY);
     }
     const unsigned long long key = cm.key[lane];
     if (active && key != keyInit) {
@@ -432,8 +472,9 @@ __device__ __forceinline__ void lv_trace_all(const LvSceneDev& S, float radius, 
     const unsigned long long below = (1ull << lane) - 1ull;
     active = active && S.numSegs != 0;
     if (STATS && active) cnt.rays++;
-    const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    const f3 oi = mk3(o.x * inv.x, o.y * inv.y, o.z * inv.z);
+    unsigned owner = lane; // the ray this lane descends for (see the subtree hand-over in lv_trace_closest)
+    f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    f3 oi = mk3(o.x * inv.x, o.y * inv.y, o.z * inv.z);
     LvStack st;
     st.init(sm.lds, sm.ovf, sm.ovfStride);
     cm.ray[2 * lane] = make_float4(o.x, o.y, o.z, w0);
@@ -446,7 +487,7 @@ __device__ __forceinline__ void lv_trace_all(const LvSceneDev& S, float radius, 
         const unsigned long long mL = __ballot(isLeaf);
         if (mL) {
             if (isLeaf) {
-                cm.queue[(tail + unsigned(__popcll(mL & below))) % LV_QCAP] = (lane << 26) | (cur & 0x03FFFFFFu);
+                cm.queue[(tail + unsigned(__popcll(mL & below))) % LV_QCAP] = (owner << 26) | (cur & 0x03FFFFFFu);
                 cur = lv_pop_or_done(st);
             }
             tail += unsigned(__popcll(mL));
@@ -459,21 +500,47 @@ __device__ __forceinline__ void lv_trace_all(const LvSceneDev& S, float radius, 
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             if (lane < n) {
                 const unsigned e = cm.queue[(head + lane) % LV_QCAP];
-                const unsigned owner = e >> 26, leaf = e & 0x03FFFFFFu;
-                const float4 ro = cm.ray[2 * owner], rd = cm.ray[2 * owner + 1];
+                const unsigned ow = e >> 26, leaf = e & 0x03FFFFFFu;
+                const float4 ro = cm.ray[2 * ow], rd = cm.ray[2 * ow + 1];
                 const float4 a = S.segs[2 * leaf], b = S.segs[2 * leaf + 1];
                 if (STATS) cnt.prims++;
                 float t; int kind;
                 if (lv_intersect_capsule(mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), mk3(a.x, a.y, a.z),
                                          mk3(b.x, b.y, b.z), radius, capped, t, kind)) {
                     if (t >= tMin && t <= tMax)
-                        f(owner, leaf, t, kind, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), ro.w, rd.w);
+                        f(ow, leaf, t, kind, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), ro.w, rd.w);
                 }
             }
             head += n;
             continue;
         }
         if (nNode == 0) break;
+        if (nNode <= LV_HANDOVER_MAX_BUSY) { // subtree hand-over, as in lv_trace_closest (all rays share tMin / tMax here)
+            const bool idle = cur == LV_INVALID;
+            const bool donor = !idle && st.sp > 0;
+            const unsigned long long mIdle = __ballot(idle), mDonor = __ballot(donor);
+            const unsigned nPairs = min(unsigned(__popcll(mIdle)), unsigned(__popcll(mDonor)));
+            if (nPairs) {
+                if (donor) {
+                    const unsigned r = unsigned(__popcll(mDonor & below));
+                    if (r < nPairs) cm.xchg[r] = make_uint2(st.pop(), owner);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                if (idle) {
+                    const unsigned r = unsigned(__popcll(mIdle & below));
+                    if (r < nPairs) {
+                        const uint2 x = cm.xchg[r];
+                        cur = x.x;
+                        owner = x.y;
+                        const float4 ro = cm.ray[2 * owner], rd = cm.ray[2 * owner + 1];
+                        inv = mk3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+                        oi = mk3(ro.x * inv.x, ro.y * inv.y, ro.z * inv.z);
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                continue;
+            }
+        }
         int nNow;
         do {
             if (!(cur & LV_LEAF_BIT)) cur = lv_node_step<STATS, false>(S, cur, oi, inv, tMin, tMax, st, cnt);
@@ -481,13 +548,13 @@ __device__ __forceinline__ void lv_trace_all(const LvSceneDev& S, float radius, 
             const unsigned long long m = __ballot(lf);
             if (m) {
                 if (lf) {
-                    cm.queue[(tail + unsigned(__popcll(m & below))) % LV_QCAP] = (lane << 26) | (cur & 0x03FFFFFFu);
+                    cm.queue[(tail + unsigned(__popcll(m & below))) % LV_QCAP] = (owner << 26) | (cur & 0x03FFFFFFu);
                     cur = lv_pop_or_done(st);
                 }
                 tail += unsigned(__popcll(m));
             }
             nNow = __popcll(__ballot(!(cur & LV_LEAF_BIT)));
-        } while (tail - head < LV_WAVE && nNow > 0);
+        } while (tail - head < LV_WAVE && nNow > LV_HANDOVER_MAX_BUSY);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
