@@ -92,6 +92,7 @@ struct lv_ctx {
     LvDeviceBuffer ppllNodes, ppllStart, ppllScratch;
     LvDeviceBuffer tilesDev, outDev, scratchRays, stackOverflow;
     std::vector<uint32_t> tilesHost;          // staging copy: caller's tile list is borrowed for the call only
+    bool tilesUploaded = false;               // tilesDev holds tilesHost
     uint64_t ppllPoolNodes = 0;
 
     // stats

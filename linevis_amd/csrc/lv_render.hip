@@ -956,9 +956,16 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
     LvDevCounters* dc = (LvDevCounters*)ctx->counters.ptr;
 
     LV_HIP(ctx, hipEventRecord(ctx->ev[2], st));
-    if (!ctx->tilesHost.empty()) LV_HIP(ctx, hipStreamSynchronize(st)); // previous staging copy may still be in flight
-    ctx->tilesHost.assign(tilesXYHost, tilesXYHost + 2 * size_t(numTiles));
-    LV_HIP(ctx, hipMemcpyAsync(ctx->tilesDev.ptr, ctx->tilesHost.data(), size_t(numTiles) * 8, hipMemcpyHostToDevice, st));
+    // The tile list is usually the same from frame to frame (a rank keeps its tiles): upload it only when it changes, so
+    // that consecutive frames need no host synchronisation and the CPU can enqueue frame k+1 while frame k runs.
+    const bool sameTiles = ctx->tilesUploaded && ctx->tilesHost.size() == 2 * size_t(numTiles) &&
+                           memcmp(ctx->tilesHost.data(), tilesXYHost, size_t(numTiles) * 8) == 0;
+    if (!sameTiles) {
+        if (!ctx->tilesHost.empty()) LV_HIP(ctx, hipStreamSynchronize(st)); // previous staging copy may still be in flight
+        ctx->tilesHost.assign(tilesXYHost, tilesXYHost + 2 * size_t(numTiles));
+        LV_HIP(ctx, hipMemcpyAsync(ctx->tilesDev.ptr, ctx->tilesHost.data(), size_t(numTiles) * 8, hipMemcpyHostToDevice, st));
+        ctx->tilesUploaded = true;
+    }
     LV_HIP(ctx, hipMemsetAsync(dc, 0, sizeof(LvDevCounters), st));
 
     LvTiles T;
@@ -1088,6 +1095,7 @@ int lv_frame_ppll_resolve_only(lv_ctx* ctx, const uint32_t* nodes, uint64_t numN
     if (numNodes) LV_HIP(ctx, hipMemcpyAsync(ctx->ppllNodes.ptr, nodes, size_t(numNodes) * 12, hipMemcpyHostToDevice, st));
     LV_HIP(ctx, hipMemcpyAsync(ctx->ppllStart.ptr, start, size_t(numPixels) * 4, hipMemcpyHostToDevice, st));
     uint32_t txy[2] = {x0, y0};
+    ctx->tilesUploaded = false; // tilesDev is overwritten below
     LV_HIP(ctx, hipMemcpyAsync(ctx->tilesDev.ptr, txy, 8, hipMemcpyHostToDevice, st));
     LV_HIP(ctx, hipStreamSynchronize(st));
     LvTiles T;
