@@ -40,6 +40,11 @@ WORKLOADS = {
     "c3t": dict(name=WORKLOAD + ", RTAO against the reference's 6-gon triangle tubes (12.06 M triangles, "
                      "rtao_geometry=triangle_tubes)",
                 scene="tornado", mode=11, settings=dict(SETTINGS, rtao_geometry="triangle_tubes"), kernel="k_ao_rays"),
+    "c5": dict(name="C5: 5M-segment Rayleigh-Benard-like convection rolls (5000 lines x 1001 points, seed 12345), 3840x2160, "
+                    "colour pass 1 spp + RTAO 256 spp (1 iteration x 256 samples, radius 0.1, distance based), line width "
+                    "0.002; BASELINE.json config 5 (meant for 8 GPUs; with fewer the same frame takes proportionally longer)",
+               scene="rayleigh_benard", mode=11, settings=dict(SETTINGS, ambient_occlusion_samples_per_frame=256),
+               kernel="k_ao_rays", resolution=(3840, 2160), ao_spp=256),
     "c2": dict(name="C2: 100k-segment helix bundle (100 lines x 1001 points, seed 12345), 1920x1080, primary rays only "
                     "(1 spp, pixel centres, AO off, depth cues off), line width 0.002",
                scene="helix", mode=11, settings={"num_samples_per_frame": 1, "depth_cue_strength": 0.0}, kernel="k_render_rt"),
@@ -50,13 +55,14 @@ WORKLOADS = {
 }
 
 
-def cpu_baseline(pts, seg, tf, attr_range, view, proj, fovy, near, far, target_seconds=15.0, workload="c3", mesh=None):
+def cpu_baseline(pts, seg, tf, attr_range, view, proj, fovy, near, far, target_seconds=15.0, workload="c3", mesh=None,
+                 ao_spp=64):
     """CPU restatement of the LineVis GLSL path (the oracle, NOT LineVis's own binary), all host cores (OpenMP), on a
     centred crop of the same frame sized for ~target_seconds of work."""
     from oracle import lvo
     sc = lvo.Scene(pts, seg, tf)
     P = lvo.make_params(view, proj, W, H, fovY=fovy, nearDist=near, farDist=far, lineWidth=LINE_WIDTH,
-                        useAmbientOcclusion=int(workload in ("c3", "c3t")), aoStrength=1.0, aoGamma=1.0, aoSamplesPerFrame=64,
+                        useAmbientOcclusion=int(workload in ("c3", "c3t", "c5")), aoStrength=1.0, aoGamma=1.0, aoSamplesPerFrame=ao_spp,
                         aoIterations=1, aoUseDistance=1, aoJitterPrimary=1, aoRadius=0.1, attrMin=attr_range[0],
                         attrMax=attr_range[1], ppllMaxNumFrags=64)
     t0 = time.time()
@@ -75,7 +81,7 @@ def cpu_baseline(pts, seg, tf, attr_range, view, proj, fovy, near, far, target_s
             sc.render_ppll(P, tile=tile, use_bvh=True, stats=st)
         else:
             ao = None
-            if workload == "c3":
+            if workload in ("c3", "c5"):
                 ao = sc.render_ao(P, tile=tile, use_bvh=True, stats=st)
             elif workload == "c3t":
                 ao = tsc.render_ao(P, tile=tile, use_bvh=True, stats=st)
@@ -133,8 +139,11 @@ def main():
     from linevis_amd import camera, capi, host_api, scenes, tiling, transfer_function as tfm
 
     wl = WORKLOADS[args.workload]
+    global W, H
+    W, H = wl.get("resolution", (1920, 1080))
     # ---- synthetic input (every rank builds the same replica; deterministic)
-    tr = scenes.normalize(scenes.tornado() if wl["scene"] == "tornado" else scenes.helix_bundle())
+    gen = {"tornado": scenes.tornado, "helix": scenes.helix_bundle, "rayleigh_benard": scenes.rayleigh_benard}[wl["scene"]]
+    tr = scenes.normalize(gen())
     flow = host_api.LineDataFlow().set_trajectories(tr.positions, tr.attributes, tr.line_offsets)
     pts, seg, _ = flow.tube_aabb_render_data(LINE_WIDTH)
     tf = tfm.standard_transparent() if args.workload == "c4" else tfm.standard()
@@ -188,7 +197,7 @@ def main():
     frame_bytes = (st.nodes_visited * 64 + st.prims_tested * 32 + st.hits_shaded * 96 + st.ao_hit_pixels * 52
                    + len(sf.local_tiles) * TILE * TILE * (4 + 4) + st.fragments * (12 + 4 + 4 + 12))
     kid = capi.KERNEL_NAMES.index(wl["kernel"])
-    kernel_bytes = ao_bytes if args.workload in ("c3", "c3t") else frame_bytes  # c2 / c4: one traversal kernel dominates
+    kernel_bytes = ao_bytes if args.workload in ("c3", "c3t", "c5") else frame_bytes  # c2 / c4: one traversal kernel dominates
 
     for _ in range(args.warmup):
         step()
@@ -245,7 +254,7 @@ def main():
             Image.fromarray(frame.cpu().numpy()).save(args.save_frame)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(pts, seg, tf, attr_range, view, proj, fovy, near, far,
-                                                  workload=args.workload, mesh=mesh)
+                                                  workload=args.workload, mesh=mesh, ao_spp=wl.get("ao_spp", 64))
         else:
             result["cpu_baseline"] = None
         print(json.dumps(result), flush=True)

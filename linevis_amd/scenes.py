@@ -161,10 +161,19 @@ def _rolls_velocity(p, k=8.0):
     return np.stack([u, v, w], axis=1)
 
 
+def _rolls_velocity_min_speed(p, min_speed=0.25):
+    """_rolls_velocity with its magnitude raised to at least min_speed (direction kept): near the stagnation lines of
+    the rolls consecutive points would otherwise fall below the 1e-4 degenerate-tangent threshold of
+    LineDataFlow.cpp:2160 and the set would lose segments (config 5 is specified as exactly 5 M)."""
+    v = _rolls_velocity(p) + np.array([1e-3, 7e-4, 0.0])
+    m = np.linalg.norm(v, axis=1, keepdims=True)
+    return v * np.maximum(1.0, min_speed / np.maximum(m, 1e-12))
+
+
 def rayleigh_benard(n_lines=5000, points_per_line=1001, seed=12345, h=0.002):
     rng = np.random.default_rng(seed)
     seeds = rng.uniform(0.02, 0.98, (n_lines, 3))
-    out, mag = _rk4_lines(_rolls_velocity, seeds, points_per_line - 1, h)
+    out, mag = _rk4_lines(_rolls_velocity_min_speed, seeds, points_per_line - 1, h)
     out = np.clip(out, -0.25, 1.25)
     pos = out.reshape(-1, 3).astype(np.float32)
     att = normalize_attributes(mag.reshape(-1))

@@ -421,3 +421,50 @@ def test_full_size_properties(hip_lib):
     ref, _ = c.oracle_render(11, use_bvh=True, tile=tile)
     x0, y0, w, h = tile
     assert max_lsb_diff(full[y0:y0 + h, x0:x0 + w], ref) <= LSB_TOL
+
+
+# ---------------------------------------------------------------- BASELINE.json config 5 at full scene size
+def test_config5_scale_tiles(hip_lib):
+    """5 M segments, 3840 x 2160, RTAO 256 spp: the tile list a rank of the 8-GPU run would own is rendered here for
+    two tiles and compared with the oracle (bit-exact AO, frame within 2 LSB); hits of the 5 M-leaf LBVH against the
+    oracle's BVH."""
+    tr = scenes.normalize(scenes.rayleigh_benard())
+    flow = host_api.LineDataFlow().set_trajectories(tr.positions, tr.attributes, tr.line_offsets)
+    pts, seg, _ = flow.tube_aabb_render_data(0.002)
+    assert len(seg) == 5000000
+    W5, H5 = 3840, 2160
+    c = Case(pts, seg, tfm.standard(), W5, H5, 0.002, **RTAO, ambient_occlusion_iterations=1,
+             ambient_occlusion_samples_per_frame=256)
+    ctx = c.hip_context()
+    all_tiles = tiling.make_tiles(W5, H5, 64)
+    mine = tiling.assign_tiles(all_tiles, 3, 8)                      # rank 3 of 8
+    centre = np.argsort(np.abs(mine[:, 0].astype(np.int64) - W5 // 2) + np.abs(mine[:, 1].astype(np.int64) - H5 // 2))[:2]
+    tiles = mine[centre]
+    import torch
+    out = torch.zeros((len(tiles), 64, 64, 4), dtype=torch.uint8, device="cuda:0")
+    ctx.render_tiles_device(out.data_ptr(), tiles, 64, 64, mode=11)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    ao = ctx.get_ao()
+    st = ctx.stats()
+    assert st.num_segments == 5000000 and st.bvh_depth < 96
+    sc = c.oracle_scene()
+    P = c.oracle_params(sc)
+    hit_pixels = 0
+    for i, (x0, y0) in enumerate(tiles):
+        tile = (int(x0), int(y0), 64, 64)
+        ao_ref = sc.render_ao(P, tile=tile, use_bvh=True)
+        sl = (slice(int(y0), int(y0) + 64), slice(int(x0), int(x0) + 64))
+        assert np.array_equal(bits(ao[sl]), bits(ao_ref[sl]))
+        hit_pixels += int((ao_ref[sl] < 1.0).sum())
+        ref = sc.render_rt(P, ao=ao_ref, tile=tile, use_bvh=True)
+        assert max_lsb_diff(got[i], ref) <= LSB_TOL
+    assert hit_pixels > 500
+    rng = np.random.default_rng(8)
+    o = rng.uniform(-0.25, 0.25, (20000, 3)).astype(np.float32)
+    d = rng.normal(size=(20000, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    a = ctx.trace_rays(o, d, 0.0, 0.1)
+    b = sc.trace_rays(o, d, 0.0, 0.1, 0.002, use_bvh=True)
+    assert np.array_equal(bits(a[0]), bits(b[0])) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    assert (a[1] != 0xFFFFFFFF).sum() > 2000
