@@ -147,7 +147,8 @@ int lv_set_background(lv_ctx* ctx, const float rgba[4]);
  *   ambient_occlusion_iterations, ambient_occlusion_samples_per_frame, ambient_occlusion_radius,
  *   ambient_occlusion_distance_based, use_jittered_primary_rays        (VulkanRayTracedAmbientOcclusion.cpp:115-144)
  *   num_samples_per_frame, num_accumulated_frames (must be 1: offline frames use spp instead of 8-bit feedback),
- *   use_deterministic_sampling, use_analytic_intersections (must be true), geometry_mode (must be "AABBs")
+ *   use_deterministic_sampling, geometry_mode ("AABBs (analytic)" = ray-capsule, default | "Triangle Mesh" = the tube
+ *   mesh set with lv_set_tube_triangle_mesh), use_analytic_intersections (bool form of the same switch)
  *                                                                       (VulkanRayTracer.cpp:226-278)
  *   use_capped_tubes, use_halos, tube_num_subdivisions                  (LineData.cpp:87-181)
  *   max_depth_complexity                                                (VulkanRayTracer.hpp:139)

@@ -350,10 +350,14 @@ int lv_set_option(lv_ctx* ctx, const char* key, const char* value) {
     } else if (k == "use_deterministic_sampling") {
         o.useDeterministicSampling = parseBool(value);
     } else if (k == "use_analytic_intersections") {
-        if (!parseBool(value)) return lv_fail(ctx, LV_E_INVALID, "only analytic capsule intersections are implemented");
+        o.rtTriangleMesh = !parseBool(value); // VulkanRayTracer.cpp:243-245
     } else if (k == "geometry_mode") {
-        if (strcmp(value, "AABBs") != 0 && strcmp(value, "Analytic") != 0)
-            return lv_fail(ctx, LV_E_INVALID, "geometry_mode '%s' is not on the hot path (AABBs only)", value);
+        // RAY_TRACING_GEOMETRY_MODE_NAMES, VulkanRayTracer.hpp:58-63 ("AABBs" / "Analytic" kept as short forms)
+        if (strcmp(value, "Triangle Mesh") == 0) o.rtTriangleMesh = true;
+        else if (strcmp(value, "AABBs (analytic)") == 0 || strcmp(value, "AABBs") == 0 || strcmp(value, "Analytic") == 0)
+            o.rtTriangleMesh = false;
+        else
+            return lv_fail(ctx, LV_E_INVALID, "geometry_mode '%s' is not provided (Triangle Mesh | AABBs (analytic))", value);
     } else if (k == "use_mlat") {
         if (parseBool(value)) return lv_fail(ctx, LV_E_INVALID, "MLAT is not implemented yet (SURVEY.md §8f)");
     } else if (k == "max_depth_complexity") {

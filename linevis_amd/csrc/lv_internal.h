@@ -39,6 +39,7 @@ struct LvOptions {
     uint32_t ppllExpectedAvgDepthComplexity = 0; // 0 = auto: 20 / 120
     uint32_t ppllTileW = 2, ppllTileH = 8;    // LineRenderer.cpp:739-740
     bool collectStats = false;
+    bool rtTriangleMesh = false;              // geometry_mode "Triangle Mesh" / use_analytic_intersections=false (VulkanRayTracer.cpp:226-250)
     bool aoTriangleTubes = false;             // rtao_geometry: false = capsules (build default), true = the reference's triangle tubes
 };
 

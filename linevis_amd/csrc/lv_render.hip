@@ -89,7 +89,7 @@ __device__ __forceinline__ bool lv_block_pixel(const LvUniforms& U, const LvTile
 // ================================================================ ray tracer colour pass
 // Control flow is wave-uniform around every trace (lv_trace_closest is a wave-cooperative routine): the sample loop and
 // the transparency loop run while ANY lane of the wave still needs a trace; lanes that are done pass active = false.
-template <bool STATS>
+template <bool STATS, int PRIM>
 __global__ __launch_bounds__(LV_BLOCK) void k_render_rt(const LvUniforms U, const LvSceneDev S, const LvTiles T,
                                                         uint32_t* __restrict__ out, LvDevCounters* dc) {
     __shared__ unsigned s_stack[LV_STACK_LDS * LV_BLOCK];
@@ -121,12 +121,13 @@ __global__ __launch_bounds__(LV_BLOCK) void k_render_rt(const LvUniforms U, cons
         const float tMax = 1000.0f;
         bool tracing = px.inView;
         for (uint32_t hitIdx = 0; hitIdx < U.maxDepthComplexity && __any(tracing); hitIdx++) {
-            LvHit h = lv_trace_closest<STATS, false>(S, U.radius, capped, tracing, o, d, tMin, tMax, sm, cm, cnt);
+            LvHit h = lv_trace_closest<STATS, false, PRIM>(S, U.radius, capped, tracing, o, d, tMin, tMax, sm, cm, cnt);
             if (tracing) {
                 f4 hc;
                 float payloadHitT;
                 if (h.found) {
-                    hc = lv_shade_hit(S, U, aoTexel, o, d, h, payloadHitT);
+                    hc = PRIM == LV_PRIM_TRIANGLE ? lv_shade_hit_triangle(S, U, aoTexel, o, d, h.leaf, payloadHitT)
+                                                  : lv_shade_hit(S, U, aoTexel, o, d, h, payloadHitT);
                     if (STATS) cnt.hits++;
                 } else { // Miss, TubeRayTracing.glsl:290-297
                     hc.x = U.background[0]; hc.y = U.background[1]; hc.z = U.background[2]; hc.w = U.background[3];
@@ -939,9 +940,12 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
     int rc;
     if (!ctx->accelValid || ctx->accelLineWidth != ctx->opt.lineWidth)
         if ((rc = lv_bvh_build(ctx))) return rc;
-    if (ctx->opt.useAmbientOcclusion && ctx->opt.aoTriangleTubes) {
+    const bool needTriangles = (ctx->opt.useAmbientOcclusion && ctx->opt.aoTriangleTubes) ||
+                               (ctx->opt.rtTriangleMesh && mode == LV_RENDERING_MODE_VULKAN_RAY_TRACER);
+    if (needTriangles) {
         if (!ctx->triMeshSet)
-            return lv_fail(ctx, LV_E_STATE, "rtao_geometry = triangle_tubes needs lv_set_tube_triangle_mesh");
+            return lv_fail(ctx, LV_E_STATE, "rtao_geometry = triangle_tubes / geometry_mode = Triangle Mesh need "
+                                            "lv_set_tube_triangle_mesh");
         if (!ctx->triAccelValid || ctx->triAccelLineWidth != ctx->opt.lineWidth)
             if ((rc = lv_bvh_build_triangles(ctx))) return rc;
     }
@@ -1002,8 +1006,15 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
     uint32_t* out = (uint32_t*)outDevice;
     if (mode == LV_RENDERING_MODE_VULKAN_RAY_TRACER) {
         LV_HIP(ctx, hipEventRecord(ctx->ev[8], st));
-        if (stats) LV_TIMED_LAUNCH(ctx, LV_KERNEL_RENDER_RT, (k_render_rt<true><<<gridTiles, LV_BLOCK, 0, st>>>(U, S, T, out, dc)));
-        else LV_TIMED_LAUNCH(ctx, LV_KERNEL_RENDER_RT, (k_render_rt<false><<<gridTiles, LV_BLOCK, 0, st>>>(U, S, T, out, dc)));
+        // geometry_mode (VulkanRayTracer.cpp:226-250): analytic capsules, or the triangle tubes with their own LBVH
+        const bool tri = ctx->opt.rtTriangleMesh;
+        LvSceneDev SC = tri ? sceneDevTriangles(ctx) : S;
+        if (tri && (rc = lv_prepare_overflow(ctx, SC, gridTiles, LV_STACK_LDS, true))) return rc;
+#define LV_LAUNCH_RT(ST, PR) \
+    LV_TIMED_LAUNCH(ctx, LV_KERNEL_RENDER_RT, (k_render_rt<ST, PR><<<gridTiles, LV_BLOCK, 0, st>>>(U, SC, T, out, dc)))
+        if (stats) { if (tri) LV_LAUNCH_RT(true, LV_PRIM_TRIANGLE); else LV_LAUNCH_RT(true, LV_PRIM_CAPSULE); }
+        else { if (tri) LV_LAUNCH_RT(false, LV_PRIM_TRIANGLE); else LV_LAUNCH_RT(false, LV_PRIM_CAPSULE); }
+#undef LV_LAUNCH_RT
         LV_HIP(ctx, hipEventRecord(ctx->ev[9], st));
     } else {
         // reallocateFragmentBuffer, PerPixelLinkedListLineRenderer.cpp:251-357

@@ -590,6 +590,10 @@ __device__ __forceinline__ f4 lv_transfer_function(const LvSceneDev& S, const Lv
     return r;
 }
 
+__device__ __forceinline__ f4 lv_compute_fragment_color(const LvSceneDev& S, const LvUniforms& U, float aoTexel, f3 fragPos,
+                                                        f3 fragmentNormal, f3 fragmentTangent, bool isCap,
+                                                        float fragmentAttribute, float& payloadHitT);
+
 // ClosestHitTubeAnalytic + computeFragmentColor + blinnPhongShadingTube for flow lines.
 // aoTexel: AO factor of the pixel that launched the ray (lookup definition: DESIGN.md).  Returns payload.hitColor;
 // payloadHitT = length(hit - camera).
@@ -597,7 +601,6 @@ __device__ __forceinline__ f4 lv_shade_hit(const LvSceneDev& S, const LvUniforms
                                            const LvHit& h, float& payloadHitT) {
     const float4 ra = S.segs[2 * h.leaf], rb = S.segs[2 * h.leaf + 1];
     const f3 P0 = mk3(ra.x, ra.y, ra.z), P1 = mk3(rb.x, rb.y, rb.z);
-    const f3 cam = mk3(U.camPos[0], U.camPos[1], U.camPos[2]);
     f3 fragPos = o + d * h.t;
     f3 linePointInterpolated;
     float fragmentAttribute;
@@ -617,7 +620,45 @@ __device__ __forceinline__ f4 lv_shade_hit(const LvSceneDev& S, const LvUniforms
     f3 fragmentTangent = norm3(v);
     f3 fragmentNormal = norm3(fragPos - linePointInterpolated);
     const bool isCap = h.kind != 0;
+    return lv_compute_fragment_color(S, U, aoTexel, fragPos, fragmentNormal, fragmentTangent, isCap, fragmentAttribute,
+                                     payloadHitT);
+}
 
+// ClosestHitTubeTriangles (TubeRayTracing.glsl:301-352) + LineAttributesBarycentric.glsl: the ray tracer's "Triangle
+// Mesh" geometry mode.  tri = original triangle index; (u, v) are recomputed with the test that won the traversal.
+__device__ __forceinline__ f4 lv_shade_hit_triangle(const LvSceneDev& S, const LvUniforms& U, float aoTexel, f3 o, f3 d,
+                                                    uint32_t tri, float& payloadHitT) {
+    const uint32_t i0 = S.triIdx[3 * size_t(tri)], i1 = S.triIdx[3 * size_t(tri) + 1], i2 = S.triIdx[3 * size_t(tri) + 2];
+    const lv_tube_vertex& vd0 = S.triVerts[i0];
+    const lv_tube_vertex& vd1 = S.triVerts[i1];
+    const lv_tube_vertex& vd2 = S.triVerts[i2];
+    const f3 p0 = mk3(vd0.vertexPosition[0], vd0.vertexPosition[1], vd0.vertexPosition[2]);
+    const f3 p1 = mk3(vd1.vertexPosition[0], vd1.vertexPosition[1], vd1.vertexPosition[2]);
+    const f3 p2 = mk3(vd2.vertexPosition[0], vd2.vertexPosition[1], vd2.vertexPosition[2]);
+    float tt = 0.0f, bu = 0.0f, bv = 0.0f;
+    lv_ray_triangle(o, d, mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z), p0, p1, p2, S.triPad, tt, bu, bv);
+    const float b0 = (1.0f - bu) - bv;
+    const lv_line_point& lp0 = S.triPoints[vd0.vertexLinePointIndex & 0x7FFFFFFFu];
+    const lv_line_point& lp1 = S.triPoints[vd1.vertexLinePointIndex & 0x7FFFFFFFu];
+    const lv_line_point& lp2 = S.triPoints[vd2.vertexLinePointIndex & 0x7FFFFFFFu];
+    auto lerp3 = [&](const float* a, const float* b, const float* c) {
+        return (mk3(a[0], a[1], a[2]) * b0 + mk3(b[0], b[1], b[2]) * bu) + mk3(c[0], c[1], c[2]) * bv;
+    };
+    const bool isCap = U.useCappedTubes &&
+            (((vd0.vertexLinePointIndex | vd1.vertexLinePointIndex | vd2.vertexLinePointIndex) >> 31) != 0u);
+    const f3 fragPos = (p0 * b0 + p1 * bu) + p2 * bv;
+    const f3 fragmentNormal = norm3(lerp3(vd0.vertexNormal, vd1.vertexNormal, vd2.vertexNormal));
+    const f3 fragmentTangent = norm3(lerp3(lp0.lineTangent, lp1.lineTangent, lp2.lineTangent));
+    const float fragmentAttribute = (lp0.lineAttribute * b0 + lp1.lineAttribute * bu) + lp2.lineAttribute * bv;
+    return lv_compute_fragment_color(S, U, aoTexel, fragPos, fragmentNormal, fragmentTangent, isCap, fragmentAttribute,
+                                     payloadHitT);
+}
+
+// computeFragmentColor (RayHitCommon.glsl:74-543) for tubes, shared by the analytic and the triangle closest-hit paths
+__device__ __forceinline__ f4 lv_compute_fragment_color(const LvSceneDev& S, const LvUniforms& U, float aoTexel, f3 fragPos,
+                                                        f3 fragmentNormal, f3 fragmentTangent, bool isCap,
+                                                        float fragmentAttribute, float& payloadHitT) {
+    const f3 cam = mk3(U.camPos[0], U.camPos[1], U.camPos[2]);
     f4 fragmentColor = lv_transfer_function(S, U, fragmentAttribute);
     f3 n = norm3(fragmentNormal);
     f3 vv = norm3(cam - fragPos);

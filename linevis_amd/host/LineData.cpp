@@ -129,6 +129,7 @@ bool LineData::setNewSettings(const SettingsMap& settings) {
     if (settings.getValueOpt("tube_num_subdivisions", n) && n != tubeNumSubdivisions) {
         tubeNumSubdivisions = n;
         cachedTriangleDataValid = false;
+        dirty = true; // renderers re-fetch the triangle representation (and the subdivision-dependent AO offset)
         shallReloadGatherShader = true;
     }
     bool b = useCappedTubes;

@@ -21,20 +21,6 @@ void Camera::overwriteMatrices(const float view[16], const float proj[16]) {
 void HipRayTracedAmbientOcclusion::startAmbientOcclusionBaking(LineDataPtr&, bool) {
     isDataReady = false;
     hasComputationFinished = false;
-    meshDirty = true;
-}
-
-// VulkanRayTracedAmbientOcclusionPass::setLineData (VulkanRayTracedAmbientOcclusion.cpp:437-456): fetch the triangle
-// tubes of the line data and hand them to the ray tracing back end; only when that geometry is selected.
-bool HipRayTracedAmbientOcclusion::uploadGeometry(LineDataPtr& lineData) {
-    if (!useTriangleTubes || !meshDirty) return true;
-    TubeTriangleRenderData d = lineData->getLinePassTubeTriangleMeshRenderData(false, true);
-    int rc = lv_set_tube_triangle_mesh(ctx, d.indexBuffer.data(), uint32_t(d.indexBuffer.size() / 3), d.vertexBuffer.data(),
-                                       uint32_t(d.vertexBuffer.size()), d.linePointDataBuffer.data(),
-                                       uint32_t(d.linePointDataBuffer.size()));
-    if (rc != LV_OK) return false;
-    meshDirty = false;
-    return true;
 }
 
 // VulkanRayTracedAmbientOcclusion::setNewSettings, VulkanRayTracedAmbientOcclusion.cpp:115-144
@@ -48,7 +34,7 @@ bool HipRayTracedAmbientOcclusion::setNewSettings(const SettingsMap& settings) {
     std::string geometry;
     if (settings.getValueOpt("rtao_geometry", geometry)) {
         const bool tri = geometry == "triangle_tubes";
-        if (tri != useTriangleTubes) { useTriangleTubes = tri; meshDirty = true; }
+        useTriangleTubes = tri;
         optionChanged = true;
     }
     if (optionChanged) {
@@ -215,12 +201,23 @@ bool LineRenderer::uploadFrameState() {
         lineData->setDirty(false);
         linesDirty = false;
         tfDirty = true; // attribute range may have changed with the data
-        if (ambientOcclusionBaker) ambientOcclusionBaker->onGeometryChanged();
+        triangleMeshDirty = true;
         return uploadFrameState();
     }
-    if (useAmbientOcclusion && ambientOcclusionBaker && ambientOcclusionBaker->getType() == AmbientOcclusionBakerType::RTAO) {
-        auto* rtao = static_cast<HipRayTracedAmbientOcclusion*>(ambientOcclusionBaker.get());
-        if (!rtao->uploadGeometry(lineData)) { check(LV_E_INVALID, "lv_set_tube_triangle_mesh"); return false; }
+    // Triangle tubes are fetched from the line data only by the consumers that trace them: the ray tracer in "Triangle
+    // Mesh" geometry mode (RayTracingRenderPass::setLineData, VulkanRayTracer.cpp:370-411) and the RTAO pass when it
+    // uses the reference's geometry (VulkanRayTracedAmbientOcclusionPass::setLineData, ...AmbientOcclusion.cpp:437-456).
+    bool wantMesh = getIsTriangleRepresentationUsed();
+    if (useAmbientOcclusion && ambientOcclusionBaker && ambientOcclusionBaker->getType() == AmbientOcclusionBakerType::RTAO)
+        wantMesh = wantMesh || static_cast<HipRayTracedAmbientOcclusion*>(ambientOcclusionBaker.get())->useTriangleTubes;
+    if (wantMesh && triangleMeshDirty) {
+        TubeTriangleRenderData d = lineData->getLinePassTubeTriangleMeshRenderData(false, true);
+        if (!check(lv_set_tube_triangle_mesh(ctx, d.indexBuffer.data(), uint32_t(d.indexBuffer.size() / 3),
+                                             d.vertexBuffer.data(), uint32_t(d.vertexBuffer.size()),
+                                             d.linePointDataBuffer.data(), uint32_t(d.linePointDataBuffer.size())),
+                   "lv_set_tube_triangle_mesh"))
+            return false;
+        triangleMeshDirty = false;
     }
     return true;
 }
@@ -276,8 +273,15 @@ void HipRayTracer::render() {
 bool HipRayTracer::setNewSettings(const SettingsMap& settings) {
     bool shallReloadGatherShader = LineRenderer::setNewSettings(settings);
     std::string s;
-    if (settings.getValueOpt("geometry_mode", s)) setOption("geometry_mode", s);
-    else if (settings.getValueOpt("use_analytic_intersections", s)) setOption("use_analytic_intersections", s);
+    bool useAnalyticIntersections = true;
+    if (settings.getValueOpt("geometry_mode", s)) {
+        if (setOption("geometry_mode", s)) useTriangleMesh = s == "Triangle Mesh";
+        accumulatedFramesCounter = 0;
+    } else if (settings.getValueOpt("use_analytic_intersections", useAnalyticIntersections)) {
+        if (setOption("use_analytic_intersections", useAnalyticIntersections ? "true" : "false"))
+            useTriangleMesh = !useAnalyticIntersections;
+        accumulatedFramesCounter = 0;
+    }
     if (settings.getValueOpt("num_samples_per_frame", numSamplesPerFrame)) {
         setOption("num_samples_per_frame", std::to_string(numSamplesPerFrame));
         accumulatedFramesCounter = 0;

@@ -93,7 +93,6 @@ public:
     virtual bool getHasComputationFinished() = 0;
     virtual void onHasMoved() {}
     virtual void onResolutionChanged() {}
-    virtual void onGeometryChanged() {}
     virtual bool setNewSettings(const SettingsMap& settings) { (void)settings; return false; }
 };
 typedef std::shared_ptr<AmbientOcclusionBaker> AmbientOcclusionBakerPtr;
@@ -111,11 +110,8 @@ public:
     void onHasMoved() override { isDataReady = false; hasComputationFinished = false; }
     void onResolutionChanged() override { onHasMoved(); }
     bool setNewSettings(const SettingsMap& settings) override;
-    void onGeometryChanged() override { meshDirty = true; }
     void pushSettings();
     void notifyRendered() { isDataReady = true; hasComputationFinished = true; }
-    /// uploads the triangle tubes when rtao_geometry == "triangle_tubes" (the reference's RTAO geometry)
-    bool uploadGeometry(LineDataPtr& lineData);
 
     int maxNumAccumulatedFrames = 64;            // VulkanRayTracedAmbientOcclusion.hpp:108
     int numAmbientOcclusionSamplesPerFrame = 4;  // :150
@@ -127,7 +123,6 @@ public:
 private:
     lv_ctx* ctx;
     bool isDataReady = false, hasComputationFinished = false;
-    bool meshDirty = true;
 };
 
 // ---------------------------------------------------------------- renderers
@@ -180,7 +175,7 @@ protected:
     std::string lastError;
     bool isRasterizer = false;
     bool dirty = true, reRender = true, internalReRender = false;
-    bool tfDirty = true, linesDirty = true;
+    bool tfDirty = true, linesDirty = true, triangleMeshDirty = true;
 
     // LineRenderer.hpp:220-231 (depth cues default on with strength 0.8 in the GUI application; the headless
     // default is off until "depth_cue_strength" is set, like a fresh SettingsMap-driven benchmark state)
@@ -202,6 +197,7 @@ public:
     HipRayTracer(SceneData* sceneData, TransferFunctionWindow& transferFunctionWindow);
     RenderingMode getRenderingMode() const override { return RENDERING_MODE_VULKAN_RAY_TRACER; }
     bool getIsTransparencyUsed() override { return false; }
+    bool getIsTriangleRepresentationUsed() const override { return useTriangleMesh; } // VulkanRayTracer.hpp: geometry mode
     bool needsReRender() override;
     void setLineData(LineDataPtr& lineData, bool isNewData) override;
     void render() override;
@@ -214,6 +210,7 @@ private:
     uint32_t maxNumAccumulatedFrames = 1;  // :142 (32 interactive; offline frames use spp instead)
     uint32_t accumulatedFramesCounter = 0; // :143
     bool useDeterministicSampling = false;
+    bool useTriangleMesh = false;          // RayTracingGeometryMode::TRIANGLE_MESH (VulkanRayTracer.hpp:52-63)
 };
 
 /// "Per-Pixel Linked Lists" plugin re-hosted on HIP.

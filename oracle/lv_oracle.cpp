@@ -21,6 +21,7 @@
  * rays against capsules) and PPLL tie order ((depth, colour) key).
  */
 #include "lv_oracle_common.h"
+#include "lv_oracle_tri.h"
 
 #include <algorithm>
 #include <cmath>
@@ -409,6 +410,10 @@ inline void blinnPhongShadingTube(const lvo_params& P, const Frame& F, float aoT
     out[0] = phong[0]; out[1] = phong[1]; out[2] = phong[2]; out[3] = base[3];
 }
 
+inline void computeFragmentColor(const lvo_scene& sc, const lvo_params& P, const Frame& F, float aoTexel, V3 fragPos,
+                                 V3 fragmentNormal, V3 fragmentTangent, bool isCap, float fragmentAttribute,
+                                 float hitColor[4], float& payloadHitT);
+
 // ClosestHitTubeAnalytic main() (TubeRayTracing.glsl:512-613) + computeFragmentColor (RayHitCommon.glsl:74-543),
 // flow lines: USE_CAPPED_TUBES / USE_HALOS / USE_DEPTH_CUES / USE_AMBIENT_OCCLUSION switches only.
 // Writes payload {hitColor, hitT}.
@@ -437,8 +442,14 @@ inline void shadeHit(const lvo_scene& sc, const lvo_params& P, const Frame& F, f
     V3 fragmentTangent = normalize(v);
     V3 fragmentNormal = normalize(fragPos - linePointInterpolated);
     bool isCap = h.kind != 0;
+    computeFragmentColor(sc, P, F, aoTexel, fragPos, fragmentNormal, fragmentTangent, isCap, fragmentAttribute, hitColor,
+                         payloadHitT);
+}
 
-    // computeFragmentColor
+// computeFragmentColor (RayHitCommon.glsl:74-543) for tubes: shared by the analytic and the triangle closest-hit shaders
+inline void computeFragmentColor(const lvo_scene& sc, const lvo_params& P, const Frame& F, float aoTexel, V3 fragPos,
+                                 V3 fragmentNormal, V3 fragmentTangent, bool isCap, float fragmentAttribute,
+                                 float hitColor[4], float& payloadHitT) {
     float fragmentColor[4];
     transferFunction(sc, P, fragmentAttribute, fragmentColor);
     V3 n = normalize(fragmentNormal);
@@ -885,6 +896,81 @@ void lvo_render_rt(const lvo_scene* sc, const lvo_params* Pp, int useBvh, const 
     if (stats) {
         stats->raysTraced += rays; stats->nodesVisited += nodes; stats->primsTested += prims; stats->hitsShaded += hits;
         stats->bvhDepth = sc->bvhDepth;
+    }
+}
+
+// The ray tracer's "Triangle Mesh" geometry mode: RayGen / traceRayTransparent / Miss as above, closest hit
+// ClosestHitTubeTriangles (TubeRayTracing.glsl:301-352) + LineAttributesBarycentric.glsl:1-52,140-170 -> computeFragmentColor.
+// sc supplies the transfer function, tsc the triangle tubes.
+void lvo_render_rt_tri(const lvo_scene* sc, const lvo_tri_scene* tsc, const lvo_params* Pp, int useBvh, const float* ao,
+                       uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, uint8_t* outRGBA8, lvo_stats* stats) {
+    const lvo_params& P = *Pp;
+    Frame F = makeFrame(P);
+    const float HIT_DISTANCE_EPSILON = 1e-5f;
+    uint64_t rays = 0, nodes = 0, prims = 0, hits = 0;
+#pragma omp parallel for schedule(dynamic, 4) reduction(+ : rays, nodes, prims, hits)
+    for (int64_t yy = 0; yy < int64_t(h); yy++) {
+        Counters cnt;
+        for (uint32_t xx = 0; xx < w; xx++) {
+            uint32_t x = x0 + xx, y = y0 + uint32_t(yy);
+            float fragmentColor[4] = {0, 0, 0, 0};
+            const float aoTexel = (P.useAmbientOcclusion && ao) ? ao[size_t(y) * P.width + x] : 1.0f;
+            uint32_t nSamples = P.useJitteredRays ? P.numSamplesPerFrame : 1u;
+            for (uint32_t sampleIdx = 0; sampleIdx < nSamples; sampleIdx++) {
+                float xix = 0.5f, xiy = 0.5f;
+                if (P.useJitteredRays) {
+                    uint32_t seed = P.useDeterministicSampling
+                            ? tea(19u, P.frameNumber * P.numSamplesPerFrame + sampleIdx)
+                            : tea(x + y * P.width, P.frameNumber * P.numSamplesPerFrame + sampleIdx);
+                    xix = rnd(seed); xiy = rnd(seed);
+                }
+                V3 o, d;
+                primaryRay(P, F, x, y, xix, xiy, o, d);
+                float fc[4] = {0, 0, 0, 0};
+                float tMin = 0.0001f, tMax = 1000.0f;
+                for (uint32_t hitIdx = 0; hitIdx < P.maxDepthComplexity; hitIdx++) {
+                    TriHit hit;
+                    float hc[4]; float payloadHitT; bool hasHit;
+                    if (closestTri(*tsc, useBvh != 0, o, d, tMin, tMax, hit, cnt)) {
+                        const uint32_t* ti = &tsc->idx[3 * size_t(hit.tri)];
+                        const lvo_tube_vertex& vd0 = tsc->verts[ti[0]];
+                        const lvo_tube_vertex& vd1 = tsc->verts[ti[1]];
+                        const lvo_tube_vertex& vd2 = tsc->verts[ti[2]];
+                        const V3 bc = v3((1.0f - hit.u) - hit.v, hit.u, hit.v);
+                        const lvo_line_point& lp0 = tsc->pts[vd0.vertexLinePointIndex & 0x7FFFFFFFu];
+                        const lvo_line_point& lp1 = tsc->pts[vd1.vertexLinePointIndex & 0x7FFFFFFFu];
+                        const lvo_line_point& lp2 = tsc->pts[vd2.vertexLinePointIndex & 0x7FFFFFFFu];
+                        const bool isCap = P.useCappedTubes && (((vd0.vertexLinePointIndex | vd1.vertexLinePointIndex |
+                                                                  vd2.vertexLinePointIndex) >> 31) != 0u);
+                        V3 fragPos = interpolateVec3(ld3(vd0.vertexPosition), ld3(vd1.vertexPosition), ld3(vd2.vertexPosition), bc);
+                        V3 fragmentNormal = normalize(interpolateVec3(ld3(vd0.vertexNormal), ld3(vd1.vertexNormal), ld3(vd2.vertexNormal), bc));
+                        V3 fragmentTangent = normalize(interpolateVec3(ld3(lp0.lineTangent), ld3(lp1.lineTangent), ld3(lp2.lineTangent), bc));
+                        float fragmentAttribute = (lp0.lineAttribute * bc.x + lp1.lineAttribute * bc.y) + lp2.lineAttribute * bc.z;
+                        computeFragmentColor(*sc, P, F, aoTexel, fragPos, fragmentNormal, fragmentTangent, isCap,
+                                             fragmentAttribute, hc, payloadHitT);
+                        hasHit = true;
+                        cnt.hits++;
+                    } else {
+                        for (int k = 0; k < 4; k++) hc[k] = P.background[k];
+                        payloadHitT = 0.0f;
+                        hasHit = false;
+                    }
+                    tMin = payloadHitT + fmaxf(payloadHitT * HIT_DISTANCE_EPSILON, 1e-7f);
+                    for (int k = 0; k < 3; k++) fc[k] = fc[k] + ((1.0f - fc[3]) * hc[3]) * hc[k];
+                    fc[3] = fc[3] + (1.0f - fc[3]) * hc[3];
+                    if (!hasHit || fc[3] > 0.99f) break;
+                }
+                for (int k = 0; k < 4; k++) fragmentColor[k] += fc[k];
+            }
+            if (P.useJitteredRays)
+                for (int k = 0; k < 4; k++) fragmentColor[k] /= float(P.numSamplesPerFrame);
+            uint8_t* px = outRGBA8 + 4 * (size_t(yy) * w + xx);
+            for (int k = 0; k < 4; k++) px[k] = toUnorm8(fragmentColor[k]);
+        }
+        rays += cnt.rays; nodes += cnt.nodes; prims += cnt.prims; hits += cnt.hits;
+    }
+    if (stats) {
+        stats->raysTraced += rays; stats->nodesVisited += nodes; stats->primsTested += prims; stats->hitsShaded += hits;
     }
 }
 

@@ -199,6 +199,11 @@ int lvo_intersect_triangle(const float o[3], const float d[3], const float v0[3]
 /* closest hit over all triangles; outTri = 0xFFFFFFFF on miss; outUV (2 floats per ray) may be NULL */
 void lvo_trace_rays_tri(const lvo_tri_scene*, int useBvh, const float* origins, const float* dirs, float tMin,
                         float tMax, uint32_t n, float* outT, uint32_t* outTri, float* outUV);
+/* ---- ray tracer colour pass in "Triangle Mesh" geometry mode (ClosestHitTubeTriangles, TubeRayTracing.glsl:301-352);
+ * the capsule scene supplies the transfer function ---- */
+void lvo_render_rt_tri(
+        const lvo_scene*, const lvo_tri_scene*, const lvo_params*, int useBvh, const float* ao,
+        uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, uint8_t* outRGBA8, lvo_stats* stats);
 /* ---- a13 with the reference's own geometry: RTAO against the triangle tubes ---- */
 void lvo_render_ao_tri(
         const lvo_tri_scene*, const lvo_params*, int useBvh,

@@ -15,7 +15,8 @@ _SO = os.path.join(_HERE, "_build", "liblv_oracle.so")
 
 
 def build(force=False):
-    src = [os.path.join(_HERE, f) for f in ("lv_oracle.cpp", "lv_oracle_tri.cpp", "lv_oracle_flow.cpp", "lv_oracle_common.h", "lv_oracle.h", "Makefile")]
+    src = [os.path.join(_HERE, f) for f in ("lv_oracle.cpp", "lv_oracle_tri.cpp", "lv_oracle_flow.cpp", "lv_oracle_common.h", "lv_oracle_tri.h", "lv_oracle.h",
+                                          "Makefile")]
     stale = (not os.path.exists(_SO)) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in src)
     if force or stale:
         subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
@@ -133,6 +134,7 @@ def lib():
     L.lvo_intersect_triangle.argtypes = [vp, vp, vp, vp, vp, f32, C.POINTER(f32), C.POINTER(f32), C.POINTER(f32)]
     L.lvo_trace_rays_tri.argtypes = [vp, i32, vp, vp, f32, f32, u32, vp, vp, vp]
     L.lvo_render_ao_tri.argtypes = [vp, C.POINTER(Params), i32, u32, u32, u32, u32, vp, C.POINTER(Stats)]
+    L.lvo_render_rt_tri.argtypes = [vp, vp, C.POINTER(Params), i32, vp, u32, u32, u32, u32, vp, C.POINTER(Stats)]
     L.lvo_generate_abc_flow.argtypes = [vp, i32, i32, i32, f32, f32, f32, f32]
     L.lvo_max_vector_magnitude.restype = f32
     L.lvo_max_vector_magnitude.argtypes = [vp, C.c_uint64]
@@ -407,6 +409,17 @@ class TriScene:
         uv = np.empty((n, 2), dtype=np.float32)
         lib().lvo_trace_rays_tri(self.h, self._use_bvh(use_bvh), _p(o), _p(d), t_min, t_max, n, _p(t), _p(tri), _p(uv))
         return t, tri, uv
+
+    def render_rt(self, scene, P, ao=None, tile=None, use_bvh=False, stats=None):
+        """Colour pass in "Triangle Mesh" geometry mode; `scene` (a capsule Scene) supplies the transfer function."""
+        x0, y0, w, h = tile if tile is not None else (0, 0, P.width, P.height)
+        out = np.empty((h, w, 4), dtype=np.uint8)
+        st = stats if stats is not None else Stats()
+        aop = _p(np.ascontiguousarray(ao, dtype=np.float32)) if ao is not None else None
+        if P.useAmbientOcclusion and ao is None:
+            raise ValueError("useAmbientOcclusion needs an ao buffer")
+        lib().lvo_render_rt_tri(scene.h, self.h, C.byref(P), self._use_bvh(use_bvh), aop, x0, y0, w, h, _p(out), C.byref(st))
+        return out
 
     def render_ao(self, P, tile=None, use_bvh=False, stats=None):
         x0, y0, w, h = tile if tile is not None else (0, 0, P.width, P.height)

@@ -223,3 +223,63 @@ def test_triangle_golden_fixture(hip_lib):
     assert own.sum() > 200                                   # most KAT rays hit their own triangle first
     assert np.all(g["kat_hit"][own] == 1)
     assert np.array_equal(bits(t)[own], g["kat_t_bits"][own]) and np.array_equal(bits(uv)[own], g["kat_uv_bits"][own])
+
+
+# ---------------------------------------------------------------- ray tracer "Triangle Mesh" geometry mode
+@pytest.mark.parametrize("settings,transparent", [
+    (dict(geometry_mode="Triangle Mesh"), False),
+    (dict(geometry_mode="Triangle Mesh", num_samples_per_frame=3, depth_cue_strength=0.7), True),
+    (dict(use_analytic_intersections=False, use_halos=False, use_capped_tubes=False), True),
+    (dict(geometry_mode="Triangle Mesh", ambient_occlusion_iterations=1, ambient_occlusion_samples_per_frame=8, **RTAO_TRI), False),
+])
+def test_triangle_mesh_geometry_mode_frames(hip_lib, settings, transparent):
+    """ClosestHitTubeTriangles + LineAttributesBarycentric (TubeRayTracing.glsl:301-352) through k_render_rt's triangle
+    instantiation vs the oracle."""
+    lw = 0.02
+    tr = curves()
+    mesh = mesh_of(tr, lw)
+    case = small_case(line_width=lw, transparent=transparent, **settings)
+    ctx = tri_context(case, mesh)
+    img = ctx.render(capi.MODE_RAY_TRACER)
+    sc = case.oracle_scene()
+    P = case.oracle_params(sc)
+    ts = lvo.TriScene(*mesh, lw)
+    ao_ref = ts.render_ao(P, use_bvh=True) if P.useAmbientOcclusion else None
+    ref = ts.render_rt(sc, P, ao=ao_ref, use_bvh=True)
+    assert max_lsb_diff(img, ref) <= 2
+    assert (ref[..., :3] != 255).any()
+    # back to the analytic mode: a different picture (round vs faceted tubes), the capsule oracle's picture
+    ctx.set_option("geometry_mode", "AABBs (analytic)")
+    ctx.set_option("rtao_geometry", "capsules")
+    img_c = ctx.render(capi.MODE_RAY_TRACER)
+    ao_c = sc.render_ao(P, use_bvh=True) if P.useAmbientOcclusion else None
+    assert max_lsb_diff(img_c, sc.render_rt(P, ao=ao_c, use_bvh=True)) <= 2
+    assert not np.array_equal(img, img_c)
+
+
+def test_triangle_mesh_mode_through_the_plugin(hip_lib):
+    lw = 0.02
+    tr = curves(20, 40, seed=3)
+    flow = host_api.LineDataFlow().set_trajectories(tr.positions, tr.attributes, tr.line_offsets)
+    r = host_api.HeadlessLineRenderer(capi.MODE_RAY_TRACER)
+    r.set_rendering_resolution(96, 64)
+    r.set_transfer_function(tfm.standard())
+    r.set_line_data(flow)
+    r.set_new_settings(dict(line_width=lw, geometry_mode="Triangle Mesh"))
+    img = r.render_frame()
+    view, proj, fovy, near, far = r.camera()
+    pts, seg, _ = lvo.build_tube_aabb_render_data(tr.positions, tr.attributes, tr.line_offsets, lw)
+    case = Case(pts, seg, tfm.standard(), 96, 64, lw)
+    case.view, case.proj, case.fovy, case.near, case.far = view, proj, fovy, near, far
+    sc = case.oracle_scene()
+    P = case.oracle_params(sc)
+    P.attrMin, P.attrMax = flow.attribute_range()
+    assert max_lsb_diff(img, lvo.TriScene(*mesh_of(tr, lw), lw).render_rt(sc, P, use_bvh=True)) <= 2
+    # 8 subdivisions: LineData re-tessellates, the renderer re-uploads
+    r.set_new_settings(dict(tube_num_subdivisions=8))
+    img8 = r.render_frame()
+    P.tubeNumSubdivisions = 8
+    assert max_lsb_diff(img8, lvo.TriScene(*mesh_of(tr, lw, 8), lw).render_rt(sc, P, use_bvh=True)) <= 2
+    assert not np.array_equal(img, img8)
+    r.set_new_settings(dict(use_analytic_intersections=True))
+    assert max_lsb_diff(r.render_frame(), sc.render_rt(P, use_bvh=True)) <= 2
