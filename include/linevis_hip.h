@@ -128,6 +128,19 @@ int lv_set_tube_triangle_mesh(lv_ctx* ctx, const uint32_t* triangle_indices, uin
                               const lv_tube_vertex* vertices, uint32_t num_vertices,
                               const lv_line_point* line_points, uint32_t num_line_points);
 
+/* Static RTAO prebaking (ambient_occlusion_mode = "RTAO (Prebaker)", VulkanAmbientOcclusionBaker.{hpp,cpp,glsl}): AO
+ * factors are baked once per geometry for num_parametrization_vertices points along the lines x
+ * rtao_prebaker_num_tube_subdivisions angles and looked up at render time (AmbientOcclusion.glsl:49-75), so AO costs
+ * nothing per frame and is view independent.  This call supplies the host-side parametrisation of
+ * AmbientOcclusionComputeRenderPass::recomputeStaticParametrization (VulkanAmbientOcclusionBaker.cpp:563-653):
+ * blending_weights[i] maps line vertex i (an entry of the mesh's line-point table) to a fractional parametrisation
+ * index, sampling_locations[j] is the fractional line-vertex position of parametrisation vertex j.  Baking runs lazily
+ * before the next frame (or lv_get_baked_ao) against the triangle tubes set with lv_set_tube_triangle_mesh. */
+int lv_set_ao_parametrization(lv_ctx* ctx, const float* blending_weights, uint32_t num_line_vertices,
+                              const float* sampling_locations, uint32_t num_parametrization_vertices);
+/* The baked table: ambientOcclusionFactors[subdivision + num_tube_subdivisions * parametrization_vertex]. */
+int lv_get_baked_ao(lv_ctx* ctx, float* out, uint64_t max_values);
+
 /* TransferFunctionWindow texture + MinMaxUniformBuffer (Data/Shaders/Utils/TransferFunction.glsl:60-71):
  * n RGBA float texels, sampled with linear filtering at texel centres, clamp-to-edge. */
 int lv_set_transfer_function(lv_ctx* ctx, const float* rgba, uint32_t n, float attr_min, float attr_max);
@@ -142,7 +155,7 @@ int lv_set_background(lv_ctx* ctx, const float rgba[4]);
 
 /* LineRenderer::setNewSettings(const SettingsMap&) (LineRenderer.hpp:163): same string keys and encodings
  * (InternalState.hpp:43-125; bools are "true"/"1").  Keys:
- *   line_width, depth_cue_strength, ambient_occlusion_mode ("None" | "RTAO (Screen Space)"),
+ *   line_width, depth_cue_strength, ambient_occlusion_mode ("None" | "RTAO (Screen Space)" | "RTAO (Prebaker)"),
  *   ambient_occlusion_strength, ambient_occlusion_gamma              (LineRenderer.cpp:433-498)
  *   ambient_occlusion_iterations, ambient_occlusion_samples_per_frame, ambient_occlusion_radius,
  *   ambient_occlusion_distance_based, use_jittered_primary_rays        (VulkanRayTracedAmbientOcclusion.cpp:115-144)
@@ -154,6 +167,9 @@ int lv_set_background(lv_ctx* ctx, const float rgba[4]);
  *   max_depth_complexity                                                (VulkanRayTracer.hpp:139)
  *   ppll_max_num_frags, ppll_expected_avg_depth_complexity, ppll_tile_width, ppll_tile_height
  *                                                                       (PerPixelLinkedListLineRenderer.cpp:144-209,251-357)
+ *   rtao_prebaker_iterations (128), rtao_prebaker_samples_per_frame (4), rtao_prebaker_num_tube_subdivisions (8): the
+ *   prebaker's settings, GUI-only in the reference (VulkanAmbientOcclusionBaker.hpp:108,165-166); radius / distance
+ *   based use the ambient_occlusion_* keys,
  *   collect_stats (build-owned: run the instrumented kernels),
  *   rtao_geometry (build-owned): "capsules" (default: AO rays hit the analytic capsules of the colour pass) or
  *   "triangle_tubes" (the reference's RTAO geometry: the mesh set with lv_set_tube_triangle_mesh). */

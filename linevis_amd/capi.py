@@ -83,7 +83,7 @@ SYMBOLS = ["lv_create", "lv_destroy", "lv_last_error", "lv_version", "lv_set_str
            "lv_render", "lv_render_device", "lv_render_tiles_device", "lv_get_stats", "lv_reset_timers", "lv_trace_rays",
            "lv_compute_depth_range", "lv_get_ao", "lv_ppll_get_buffers", "lv_ppll_resolve_buffers", "lv_get_accel",
            "lv_set_tube_triangle_mesh", "lv_trace_rays_triangles", "lv_set_flow_grid", "lv_trace_streamlines",
-           "lv_get_streamlines"]
+           "lv_get_streamlines", "lv_set_ao_parametrization", "lv_get_baked_ao"]
 
 _lib = None
 
@@ -139,6 +139,8 @@ def load():
         ("lv_set_flow_grid", [vp, vp, u32, u32, u32, f32, f32, f32, vp, u32]),
         ("lv_trace_streamlines", [vp, vp, u32, C.POINTER(StreamlineSettings), C.POINTER(u64), C.POINTER(u64)]),
         ("lv_get_streamlines", [vp, vp, vp, vp]),
+        ("lv_set_ao_parametrization", [vp, vp, u32, vp, u32]),
+        ("lv_get_baked_ao", [vp, vp, u64]),
     ]:
         fn = getattr(L, name)
         fn.restype = i32
@@ -265,6 +267,17 @@ class Context:
         uv = np.empty((n, 2), dtype=np.float32)
         self._ck(self.L.lv_trace_rays_triangles(self.h, _p(o), _p(d), t_min, t_max, n, _p(t), _p(tri), _p(uv)))
         return t, tri, uv
+
+    def set_ao_parametrization(self, blending_weights, sampling_locations):
+        bw = np.ascontiguousarray(blending_weights, dtype=np.float32)
+        sl = np.ascontiguousarray(sampling_locations, dtype=np.float32)
+        self._ck(self.L.lv_set_ao_parametrization(self.h, _p(bw), len(bw), _p(sl), len(sl)))
+        self._bake_shape = len(sl)
+
+    def get_baked_ao(self, num_tube_subdivisions=8):
+        out = np.zeros((self._bake_shape, num_tube_subdivisions), dtype=np.float32)
+        self._ck(self.L.lv_get_baked_ao(self.h, _p(out), out.size))
+        return out
 
     def set_flow_grid(self, vector_field, spacing, scalar_fields=()):
         """vector_field [zs, ys, xs, 3] float32, scalar_fields: list of [zs, ys, xs] (sampled as line attributes)."""

@@ -174,7 +174,8 @@ void lv_destroy(lv_ctx* ctx) {
                               &ctx->ppllNodes, &ctx->ppllStart, &ctx->ppllScratch, &ctx->tilesDev, &ctx->outDev,
                               &ctx->scratchRays, &ctx->stackOverflow, &ctx->triIdx, &ctx->triVerts, &ctx->triPoints,
                               &ctx->triNodes, &ctx->tris, &ctx->flowVectors, &ctx->flowScalars, &ctx->flowMisc,
-                              &ctx->flowSeeds, &ctx->flowOutPos, &ctx->flowOutAtt, &ctx->flowCounts})
+                              &ctx->flowSeeds, &ctx->flowOutPos, &ctx->flowOutAtt, &ctx->flowCounts, &ctx->bakeBlendingWeights,
+                              &ctx->bakeSamplingLocations, &ctx->bakedAo, &ctx->bakeLcgSkip})
         lv_buf_free(*b);
     if (ctx->evCreated) {
         for (int i = 0; i < 16; i++) (void)hipEventDestroy(ctx->ev[i]);
@@ -258,6 +259,50 @@ int lv_set_tube_triangle_mesh(lv_ctx* ctx, const uint32_t* triangle_indices, uin
     ctx->numTriPoints = num_line_points;
     ctx->triMeshSet = true;
     ctx->triAccelValid = false;
+    ctx->bakeValid = false;
+    return LV_OK;
+}
+
+int lv_set_ao_parametrization(lv_ctx* ctx, const float* blending_weights, uint32_t num_line_vertices,
+                              const float* sampling_locations, uint32_t num_parametrization_vertices) {
+    if (!ctx) return LV_E_INVALID;
+    if ((num_line_vertices && !blending_weights) || (num_parametrization_vertices && !sampling_locations))
+        return lv_fail(ctx, LV_E_INVALID, "null input array");
+    for (uint32_t i = 0; i < num_line_vertices; i++)
+        if (!(blending_weights[i] >= 0.0f) || !(blending_weights[i] < float(num_parametrization_vertices)))
+            return lv_fail(ctx, LV_E_INVALID, "blending weight %u = %g is outside [0, %u)", i, double(blending_weights[i]),
+                           num_parametrization_vertices);
+    for (uint32_t i = 0; i < num_parametrization_vertices; i++)
+        if (!(sampling_locations[i] >= 0.0f) || !(sampling_locations[i] < float(num_line_vertices)))
+            return lv_fail(ctx, LV_E_INVALID, "sampling location %u = %g is outside [0, %u)", i,
+                           double(sampling_locations[i]), num_line_vertices);
+    (void)hipSetDevice(ctx->device);
+    int rc;
+    if ((rc = lv_buf_reserve(ctx, ctx->bakeBlendingWeights, size_t(num_line_vertices ? num_line_vertices : 1) * 4))) return rc;
+    if ((rc = lv_buf_reserve(ctx, ctx->bakeSamplingLocations, size_t(num_parametrization_vertices ? num_parametrization_vertices : 1) * 4))) return rc;
+    if (num_line_vertices)
+        LV_HIP(ctx, hipMemcpyAsync(ctx->bakeBlendingWeights.ptr, blending_weights, size_t(num_line_vertices) * 4,
+                                   hipMemcpyHostToDevice, ctx->stream));
+    if (num_parametrization_vertices)
+        LV_HIP(ctx, hipMemcpyAsync(ctx->bakeSamplingLocations.ptr, sampling_locations, size_t(num_parametrization_vertices) * 4,
+                                   hipMemcpyHostToDevice, ctx->stream));
+    LV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->bakeNumLineVertices = num_line_vertices;
+    ctx->bakeNumParametrizationVertices = num_parametrization_vertices;
+    ctx->bakeParamSet = true;
+    ctx->bakeValid = false;
+    return LV_OK;
+}
+
+int lv_get_baked_ao(lv_ctx* ctx, float* out, uint64_t max_values) {
+    if (!ctx || !out) return LV_E_INVALID;
+    (void)hipSetDevice(ctx->device);
+    int rc;
+    if (!ctx->bakeValid && (rc = lv_bake_ambient_occlusion(ctx))) return rc;
+    const uint64_t n = uint64_t(ctx->bakeNumParametrizationVertices) * ctx->opt.bakeNumTubeSubdivisions;
+    if (max_values < n) return lv_fail(ctx, LV_E_CAPACITY, "baked AO table holds %llu values", (unsigned long long)n);
+    if (n) LV_HIP(ctx, hipMemcpyAsync(out, ctx->bakedAo.ptr, size_t(n) * 4, hipMemcpyDeviceToHost, ctx->stream));
+    LV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return LV_OK;
 }
 
@@ -308,15 +353,18 @@ int lv_set_option(lv_ctx* ctx, const char* key, const char* value) {
     uint32_t u;
     if (k == "line_width") {
         if (!parseFloat(value, f) || !(f > 0.0f)) return bad();
+        if (f != o.lineWidth) ctx->bakeValid = false;
         o.lineWidth = f; // accel rebuilt lazily (setTriangleRepresentationDirty, LineRenderer.cpp:436-441)
     } else if (k == "depth_cue_strength") {
         if (!parseFloat(value, f)) return bad();
         o.depthCueStrength = f;
     } else if (k == "ambient_occlusion_mode") {
         // AMBIENT_OCCLUSION_BAKER_TYPE_NAMES, AmbientOcclusionBaker.hpp:78-95
-        if (strcmp(value, "RTAO (Screen Space)") == 0) o.aoBakerIsRtao = true;
-        else if (strcmp(value, "None") == 0) o.aoBakerIsRtao = false;
-        else return lv_fail(ctx, LV_E_INVALID, "ambient_occlusion_mode '%s' is not on the hot path (None | RTAO (Screen Space))", value);
+        if (strcmp(value, "RTAO (Screen Space)") == 0) { o.aoBakerIsRtao = true; o.aoPrebaked = false; }
+        else if (strcmp(value, "RTAO (Prebaker)") == 0) { o.aoBakerIsRtao = true; o.aoPrebaked = true; }
+        else if (strcmp(value, "None") == 0) { o.aoBakerIsRtao = false; o.aoPrebaked = false; }
+        else return lv_fail(ctx, LV_E_INVALID, "ambient_occlusion_mode '%s' is not provided (None | RTAO (Screen Space) | "
+                                               "RTAO (Prebaker))", value);
         updateAoMode(ctx);
     } else if (k == "ambient_occlusion_strength") {
         if (!parseFloat(value, f)) return bad();
@@ -333,9 +381,23 @@ int lv_set_option(lv_ctx* ctx, const char* key, const char* value) {
         o.aoSamplesPerFrame = u;
     } else if (k == "ambient_occlusion_radius") {
         if (!parseFloat(value, f) || !(f > 0.0f)) return bad();
+        if (f != o.aoRadius) ctx->bakeValid = false;
         o.aoRadius = f;
     } else if (k == "ambient_occlusion_distance_based") {
+        if (parseBool(value) != o.aoUseDistance) ctx->bakeValid = false;
         o.aoUseDistance = parseBool(value);
+    } else if (k == "rtao_prebaker_iterations") {            // VulkanAmbientOcclusionBaker.hpp:108 (GUI-only there)
+        if (!parseUint(value, u) || u == 0) return bad();
+        if (u != o.bakeIterations) ctx->bakeValid = false;
+        o.bakeIterations = u;
+    } else if (k == "rtao_prebaker_samples_per_frame") {     // :166
+        if (!parseUint(value, u) || u == 0 || u > 4096) return bad();
+        if (u != o.bakeSamplesPerFrame) ctx->bakeValid = false;
+        o.bakeSamplesPerFrame = u;
+    } else if (k == "rtao_prebaker_num_tube_subdivisions") { // :165
+        if (!parseUint(value, u) || u < 3 || u > 64) return bad();
+        if (u != o.bakeNumTubeSubdivisions) ctx->bakeValid = false;
+        o.bakeNumTubeSubdivisions = u;
     } else if (k == "use_jittered_primary_rays") {
         o.aoJitterPrimary = parseBool(value);
     } else if (k == "ambient_occlusion_denoiser") {

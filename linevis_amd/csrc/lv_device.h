@@ -91,6 +91,8 @@ struct LvUniforms {
     uint32_t aoSamplesPerFrame, aoUseDistance, aoJitterPrimary, aoFrameNumber;
     float aoRadius, subdivisionCorrectionFactor;
     uint32_t ppllMaxNumFrags, ppllLinkedListSize, ppllTileW, ppllTileH, ppllPaddedW, ppllPaddedH;
+    // static RTAO prebaking (STATIC_AMBIENT_OCCLUSION_PREBAKING, AmbientOcclusion.glsl:29-38)
+    uint32_t aoPrebaked, bakeNumLineVertices, bakeNumParametrizationVertices, bakeNumTubeSubdivisions;
 };
 
 // HBM-resident scene (all read-only during rendering)
@@ -113,6 +115,10 @@ struct LvSceneDev {
     const lv_tube_vertex* triVerts; // 32-B TubeTriangleVertexData, input order
     const lv_line_point* triPoints; // line points referenced by the vertices
     float triPad;               // padding of a triangle's own AABB (part of the ray-triangle test definition)
+    // static RTAO prebaking: AO factor table [parametrisation vertex][tube subdivision] and the per-line-vertex blending
+    // weights (AmbientOcclusionFactorsBuffer / AmbientOcclusionBlendingWeightsBuffer, AmbientOcclusion.glsl:31-38)
+    const float* bakedAo;
+    const float* bakedBlendingWeights;
 };
 #define LV_PRIM_CAPSULE 0
 #define LV_PRIM_TRIANGLE 1

@@ -39,6 +39,10 @@ struct LvOptions {
     uint32_t ppllExpectedAvgDepthComplexity = 0; // 0 = auto: 20 / 120
     uint32_t ppllTileW = 2, ppllTileH = 8;    // LineRenderer.cpp:739-740
     bool collectStats = false;
+    bool aoPrebaked = false;                  // ambient_occlusion_mode == "RTAO (Prebaker)"
+    uint32_t bakeIterations = 128;            // VulkanAmbientOcclusionBaker.hpp:108
+    uint32_t bakeNumTubeSubdivisions = 8;     // :165
+    uint32_t bakeSamplesPerFrame = 4;         // :166 (radius / distance-based share the RTAO keys; same defaults :167-168)
     bool rtTriangleMesh = false;              // geometry_mode "Triangle Mesh" / use_analytic_intersections=false (VulkanRayTracer.cpp:226-250)
     bool aoTriangleTubes = false;             // rtao_geometry: false = capsules (build default), true = the reference's triangle tubes
 };
@@ -66,6 +70,11 @@ struct lv_ctx {
     LvDeviceBuffer triNodes, tris;              // accel
     bool triMeshSet = false, triAccelValid = false;
     float triAccelLineWidth = -1.0f, triPad = 0.0f;
+
+    // static RTAO prebaker
+    LvDeviceBuffer bakeBlendingWeights, bakeSamplingLocations, bakedAo, bakeLcgSkip;
+    uint32_t bakeNumLineVertices = 0, bakeNumParametrizationVertices = 0;
+    bool bakeParamSet = false, bakeValid = false;
 
     // streamline tracing (lv_flow.hip)
     LvDeviceBuffer flowVectors, flowScalars, flowMisc, flowSeeds, flowOutPos, flowOutAtt, flowCounts;
@@ -142,6 +151,7 @@ int lv_frame_trace_rays(lv_ctx* ctx, const float* o, const float* d, float tMin,
                         uint32_t* outSeg, uint32_t* outKind);
 int lv_frame_trace_rays_triangles(lv_ctx* ctx, const float* o, const float* d, float tMin, float tMax, uint32_t n,
                                   float* outT, uint32_t* outTri, float* outUV);
+int lv_bake_ambient_occlusion(lv_ctx* ctx);
 int lv_frame_depth_range(lv_ctx* ctx);
 int lv_frame_ppll_resolve_only(lv_ctx* ctx, const uint32_t* nodes, uint64_t numNodes, const uint32_t* start,
                                uint64_t numPixels, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, uint8_t* out);

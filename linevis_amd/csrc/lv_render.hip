@@ -275,10 +275,14 @@ __global__ __launch_bounds__(LV_BLOCK) void k_ao_primary(const LvUniforms U, con
 // A finished ray is retired (samples[r] written, lane idle) once the FIFO head has passed its last queued leaf.
 // Scheduling inside a wave: test when >= 64 pairs wait; refill when >= LV_REFILL_THRESHOLD lanes are idle; otherwise
 // descend; flush partial batches only when nothing else can make progress.
-template <bool STATS, bool ANY_HIT, int PRIM>
+// BAKE: the static prebaker's rays (VulkanAmbientOcclusionBaker.glsl:230-281).  G-buffer slot = parametrisation vertex *
+// numTubeSubdivisions + subdivision with g0 = {ray origin, -}, g1 = {tangent, vertex}, g2 = {surface normal, subdivision};
+// the reference draws the (subdivision, ray) samples of a vertex from ONE LCG stream seeded with tea(vertex, frame), so
+// sample j starts from the stream advanced by 2 j steps: seed_j = A_j * seed_0 + C_j (lcgSkip[j] = {A_j, C_j}).
+template <bool STATS, bool ANY_HIT, int PRIM, bool BAKE = false>
 __global__ __launch_bounds__(LV_AO_BLOCK) void k_ao_rays(const LvUniforms U, const LvSceneDev S,
                                                          const float4* __restrict__ gbuf, float* __restrict__ samples,
-                                                         LvDevCounters* dc) {
+                                                         LvDevCounters* dc, const uint2* __restrict__ lcgSkip = nullptr) {
     __shared__ unsigned s_stack[LV_AO_STACK_LDS * LV_AO_BLOCK];
     __shared__ float4 s_ray[2 * LV_AO_BLOCK];              // current ray of every lane: {o.xyz, -}{d.xyz, -}
     __shared__ float4 s_gen[2 * LV_AO_BLOCK];              // generated rays waiting for a lane
@@ -393,7 +397,14 @@ __global__ __launch_bounds__(LV_AO_BLOCK) void k_ao_rays(const LvUniforms U, con
                     const uint32_t pix = __float_as_uint(g1.w);
                     const f3 pos = mk3(g0.x, g0.y, g0.z), T = mk3(g1.x, g1.y, g1.z), N = mk3(g2.x, g2.y, g2.z);
                     const f3 B = cross3(N, T);
-                    uint32_t seed = lv_tea(pix, U.aoFrameNumber * spp + smpIdx);
+                    uint32_t seed;
+                    if (BAKE) {
+                        const uint32_t sub = __float_as_uint(g2.w);
+                        const uint2 skip = lcgSkip[2u * (sub * spp + smpIdx)];
+                        seed = skip.x * lv_tea(pix /* = vertex */, U.aoFrameNumber) + skip.y;
+                    } else {
+                        seed = lv_tea(pix, U.aoFrameNumber * spp + smpIdx);
+                    }
                     const float xi0 = lv_rnd(seed), xi1 = lv_rnd(seed);
                     float sn, cs;
                     lv_sincos2pi(xi1, sn, cs); // sampleHemisphere, glsl:151-156
@@ -402,7 +413,7 @@ __global__ __launch_bounds__(LV_AO_BLOCK) void k_ao_rays(const LvUniforms U, con
                     const f3 dirU = mk3((T.x * smp.x + B.x * smp.y) + N.x * smp.z, (T.y * smp.x + B.y * smp.y) + N.y * smp.z,
                                         (T.z * smp.x + B.z * smp.y) + N.z * smp.z);
                     const f3 d = norm3(dirU);
-                    const f3 o = pos + d * g0.w;
+                    const f3 o = BAKE ? pos : pos + d * g0.w;
                     genW[2 * lane] = make_float4(o.x, o.y, o.z, 0.0f);
                     genW[2 * lane + 1] = make_float4(d.x, d.y, d.z, 0.0f);
                 }
@@ -474,6 +485,7 @@ __global__ __launch_bounds__(LV_AO_BLOCK) void k_ao_rays(const LvUniforms U, con
     }
 }
 
+template <bool BAKE>
 __global__ __launch_bounds__(LV_BLOCK) void k_ao_reduce(const LvUniforms U, const float4* __restrict__ gbuf,
                                                         const float* __restrict__ samples, float* __restrict__ ao,
                                                         const LvDevCounters* dc) {
@@ -493,9 +505,42 @@ __global__ __launch_bounds__(LV_BLOCK) void k_ao_reduce(const LvUniforms U, cons
         for (uint32_t s = 0; s < spp; s++) aoFactor += samples[size_t(slot) * spp + s];
     }
     aoFactor /= float(spp);
-    const uint32_t pix = __float_as_uint(gbuf[3 * size_t(slot) + 1].w);
+    // screen space: the pixel of the compacted slot; prebaker: ambientOcclusionFactors[subdiv + N * vertex] = the slot
+    const uint32_t pix = BAKE ? slot : __float_as_uint(gbuf[3 * size_t(slot) + 1].w);
     if (U.aoFrameNumber != 0) aoFactor = mixf(ao[pix], aoFactor, 1.0f / float(U.aoFrameNumber + 1));
     ao[pix] = aoFactor;
+}
+
+// VulkanAmbientOcclusionBaker.glsl:110-131,231-262: interpolated line point of every parametrisation vertex and the ray
+// origin / frame of each of its tube subdivisions, written in the G-buffer format of k_ao_rays.
+__global__ __launch_bounds__(LV_BLOCK) void k_bake_setup(const lv_line_point* __restrict__ linePoints, uint32_t numLinePoints,
+                                                         const float* __restrict__ samplingLocations,
+                                                         uint32_t numParametrizationVertices, uint32_t numTubeSubdivisions,
+                                                         float lineRadius, float4* __restrict__ gbuf) {
+    const uint32_t slot = blockIdx.x * LV_BLOCK + threadIdx.x;
+    if (slot >= numParametrizationVertices * numTubeSubdivisions) return;
+    const uint32_t vertex = slot / numTubeSubdivisions, sub = slot % numTubeSubdivisions;
+    const float samplingLocation = samplingLocations[vertex];
+    const uint32_t lowerIdx = uint32_t(samplingLocation);
+    const uint32_t upperIdx = min(lowerIdx + 1u, numLinePoints - 1u);
+    const float f = samplingLocation - floorf(samplingLocation);
+    const lv_line_point& lo = linePoints[lowerIdx];
+    const lv_line_point& up = linePoints[upperIdx];
+    auto ld = [](const float* p) { return mk3(p[0], p[1], p[2]); };
+    auto mix3 = [&](f3 a, f3 b) { return mk3(mixf(a.x, b.x, f), mixf(a.y, b.y, f), mixf(a.z, b.z, f)); };
+    const f3 binormalLower = cross3(ld(lo.lineTangent), ld(lo.lineNormal));
+    const f3 binormalUpper = cross3(ld(up.lineTangent), ld(up.lineNormal));
+    const f3 position = mix3(ld(lo.linePosition), ld(up.linePosition));
+    const f3 tangent = norm3(mix3(ld(lo.lineTangent), ld(up.lineTangent)));
+    const f3 normal = norm3(mix3(ld(lo.lineNormal), ld(up.lineNormal)));
+    const f3 binormal = norm3(mix3(binormalLower, binormalUpper));
+    float sinAngle, cosAngle;
+    lv_sincos2pi(float(sub) / float(numTubeSubdivisions), sinAngle, cosAngle);
+    const f3 surfaceNormal = cosAngle * normal + sinAngle * binormal;
+    const f3 rayOrigin = position + (lineRadius + 1e-6f) * surfaceNormal;
+    gbuf[3 * size_t(slot) + 0] = make_float4(rayOrigin.x, rayOrigin.y, rayOrigin.z, 0.0f);
+    gbuf[3 * size_t(slot) + 1] = make_float4(tangent.x, tangent.y, tangent.z, __uint_as_float(vertex));
+    gbuf[3 * size_t(slot) + 2] = make_float4(surfaceNormal.x, surfaceNormal.y, surfaceNormal.z, __uint_as_float(sub));
 }
 
 __global__ __launch_bounds__(LV_BLOCK) void k_fill_f32(float* p, float v, size_t n) {
@@ -772,6 +817,8 @@ LvSceneDev sceneDev(const lv_ctx* ctx) {
     S.stackOverflow = nullptr;
     S.numSegs = ctx->numSegs;
     S.tris = nullptr; S.triIdx = nullptr; S.triVerts = nullptr; S.triPoints = nullptr; S.triPad = 0.0f;
+    S.bakedAo = (const float*)ctx->bakedAo.ptr;
+    S.bakedBlendingWeights = (const float*)ctx->bakeBlendingWeights.ptr;
     return S;
 }
 
@@ -848,6 +895,10 @@ void lv_fill_uniforms(const lv_ctx* ctx, LvUniforms& U) {
     uint64_t pool = uint64_t(avg) * pw * ph;
     if (pool > 0xFFFFFFF0ull) pool = 0xFFFFFFF0ull; // node indices are 32 bit
     U.ppllLinkedListSize = uint32_t(pool);
+    U.aoPrebaked = (o.useAmbientOcclusion && o.aoPrebaked) ? 1u : 0u;
+    U.bakeNumLineVertices = ctx->bakeNumLineVertices;
+    U.bakeNumParametrizationVertices = ctx->bakeNumParametrizationVertices;
+    U.bakeNumTubeSubdivisions = o.bakeNumTubeSubdivisions;
 }
 
 int lv_frame_depth_range(lv_ctx* ctx) {
@@ -923,7 +974,7 @@ static int lv_run_ao(lv_ctx* ctx, LvUniforms& U, LvSceneDev& S, const LvTiles& T
 #undef LV_LAUNCH_AO2
 #undef LV_LAUNCH_AO
 #undef LV_LAUNCH_AOP
-        k_ao_reduce<<<nblocks(maxPixels), LV_BLOCK, 0, st>>>(U, g, smp, ao, dc);
+        k_ao_reduce<false><<<nblocks(maxPixels), LV_BLOCK, 0, st>>>(U, g, smp, ao, dc);
     }
     LV_HIP(ctx, hipGetLastError());
     return LV_OK;
@@ -940,12 +991,15 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
     int rc;
     if (!ctx->accelValid || ctx->accelLineWidth != ctx->opt.lineWidth)
         if ((rc = lv_bvh_build(ctx))) return rc;
-    const bool needTriangles = (ctx->opt.useAmbientOcclusion && ctx->opt.aoTriangleTubes) ||
+    if (ctx->opt.useAmbientOcclusion && ctx->opt.aoPrebaked && mode != LV_RENDERING_MODE_VULKAN_RAY_TRACER)
+        return lv_fail(ctx, LV_E_INVALID, "the static RTAO prebaker is wired to the ray tracer (mode 11) only");
+    const bool needTriangles = (ctx->opt.useAmbientOcclusion && ctx->opt.aoPrebaked) ||
+                               (ctx->opt.useAmbientOcclusion && ctx->opt.aoTriangleTubes) ||
                                (ctx->opt.rtTriangleMesh && mode == LV_RENDERING_MODE_VULKAN_RAY_TRACER);
     if (needTriangles) {
         if (!ctx->triMeshSet)
-            return lv_fail(ctx, LV_E_STATE, "rtao_geometry = triangle_tubes / geometry_mode = Triangle Mesh need "
-                                            "lv_set_tube_triangle_mesh");
+            return lv_fail(ctx, LV_E_STATE, "rtao_geometry = triangle_tubes / geometry_mode = Triangle Mesh / the RTAO "
+                                            "prebaker need lv_set_tube_triangle_mesh");
         if (!ctx->triAccelValid || ctx->triAccelLineWidth != ctx->opt.lineWidth)
             if ((rc = lv_bvh_build_triangles(ctx))) return rc;
     }
@@ -999,8 +1053,17 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
 
     // ambientOcclusionBaker->updateIterative(), LineRenderer.cpp:257-264
     LV_HIP(ctx, hipEventRecord(ctx->ev[6], st));
-    if (U.useAmbientOcclusion)
+    if (U.useAmbientOcclusion && !U.aoPrebaked)
         if ((rc = lv_run_ao(ctx, U, S, T, gridTiles, maxPixels))) return rc;
+    if (U.aoPrebaked) {
+        // static prebaker: view independent, (re)baked only when geometry or baking settings changed
+        if (!ctx->bakeValid) {
+            if ((rc = lv_bake_ambient_occlusion(ctx))) return rc;
+            if ((rc = lv_prepare_overflow(ctx, S, gridTiles))) return rc; // the bake may have regrown the overflow slab
+        }
+        S.bakedAo = (const float*)ctx->bakedAo.ptr;
+        S.bakedBlendingWeights = (const float*)ctx->bakeBlendingWeights.ptr;
+    }
     LV_HIP(ctx, hipEventRecord(ctx->ev[7], st));
 
     uint32_t* out = (uint32_t*)outDevice;
@@ -1158,5 +1221,74 @@ int lv_frame_trace_rays_triangles(lv_ctx* ctx, const float* o, const float* d, f
     LV_HIP(ctx, hipMemcpyAsync(outTri, dS, size_t(n) * 4, hipMemcpyDeviceToHost, st));
     if (outUV) LV_HIP(ctx, hipMemcpyAsync(outUV, dUV, size_t(n) * 8, hipMemcpyDeviceToHost, st));
     LV_HIP(ctx, hipStreamSynchronize(st));
+    return LV_OK;
+}
+
+// VulkanAmbientOcclusionBaker::bakeAoTexture (VulkanAmbientOcclusionBaker.cpp:193-262): maxNumIterations passes of the
+// baking shader, each averaging numAmbientOcclusionSamplesPerFrame rays per (parametrisation vertex, tube subdivision),
+// accumulated as a running mean.  Rays hit the triangle tubes (the reference binds the triangle TLAS, cpp:480) and run
+// through the same persistent work-queue kernel as the screen-space pass.
+int lv_bake_ambient_occlusion(lv_ctx* ctx) {
+    const LvOptions& o = ctx->opt;
+    if (!ctx->triMeshSet) return lv_fail(ctx, LV_E_STATE, "the RTAO prebaker needs lv_set_tube_triangle_mesh");
+    if (!ctx->bakeParamSet) return lv_fail(ctx, LV_E_STATE, "the RTAO prebaker needs lv_set_ao_parametrization");
+    if (ctx->bakeNumLineVertices != ctx->numTriPoints)
+        return lv_fail(ctx, LV_E_INVALID, "blending weights (%u) must match the mesh's line points (%u)",
+                       ctx->bakeNumLineVertices, ctx->numTriPoints);
+    int rc;
+    if (!ctx->triAccelValid || ctx->triAccelLineWidth != o.lineWidth)
+        if ((rc = lv_bvh_build_triangles(ctx))) return rc;
+    hipStream_t st = ctx->stream;
+    const uint32_t N = o.bakeNumTubeSubdivisions, spp = o.bakeSamplesPerFrame, M = ctx->bakeNumParametrizationVertices;
+    const uint64_t slots = uint64_t(M) * N;
+    if (slots == 0) { ctx->bakeValid = true; return LV_OK; }
+    if (slots > 0x7FFFFFFFull) return lv_fail(ctx, LV_E_CAPACITY, "too many AO bake entries");
+    if ((rc = lv_buf_reserve(ctx, ctx->counters, sizeof(LvDevCounters)))) return rc;
+    if ((rc = lv_buf_reserve(ctx, ctx->bakedAo, size_t(slots) * 4))) return rc;
+    if ((rc = lv_buf_reserve(ctx, ctx->aoGbuf, size_t(slots) * 48))) return rc;
+    if ((rc = lv_buf_reserve(ctx, ctx->aoSamples, size_t(slots) * spp * 4))) return rc;
+    // LCG skip-ahead table: state after j steps = A_j * s + C_j (a = 1664525, c = 1013904223, RayTracingUtilities.glsl:169-175)
+    std::vector<uint32_t> skip(size_t(4) * N * spp);
+    {
+        uint32_t A = 1u, C = 0u;
+        for (size_t j = 0; j < size_t(2) * N * spp; j++) {
+            skip[2 * j] = A; skip[2 * j + 1] = C;
+            A = 1664525u * A;
+            C = 1664525u * C + 1013904223u;
+        }
+    }
+    if ((rc = lv_buf_reserve(ctx, ctx->bakeLcgSkip, skip.size() * 4))) return rc;
+    LV_HIP(ctx, hipMemcpyAsync(ctx->bakeLcgSkip.ptr, skip.data(), skip.size() * 4, hipMemcpyHostToDevice, st));
+    LvUniforms U;
+    lv_fill_uniforms(ctx, U);
+    U.aoSamplesPerFrame = spp;
+    LvSceneDev SA = sceneDevTriangles(ctx);
+    uint64_t gridRays = uint64_t(ctx->numCUs) * LV_AO_BLOCKS_PER_CU;
+    const uint64_t maxRays = slots * spp;
+    if (gridRays > (maxRays + LV_AO_BLOCK - 1) / LV_AO_BLOCK) gridRays = (maxRays + LV_AO_BLOCK - 1) / LV_AO_BLOCK;
+    if ((rc = lv_prepare_overflow(ctx, SA, gridRays, LV_AO_STACK_LDS, true))) return rc;
+    LvDevCounters* dc = (LvDevCounters*)ctx->counters.ptr;
+    float4* g = (float4*)ctx->aoGbuf.ptr;
+    float* smp = (float*)ctx->aoSamples.ptr;
+    float* out = (float*)ctx->bakedAo.ptr;
+    k_bake_setup<<<nblocks(slots), LV_BLOCK, 0, st>>>((const lv_line_point*)ctx->triPoints.ptr, ctx->numTriPoints,
+                                                      (const float*)ctx->bakeSamplingLocations.ptr, M, N,
+                                                      o.lineWidth * 0.5f, g);
+    const uint32_t slots32 = uint32_t(slots);
+    LV_HIP(ctx, hipMemcpyAsync(&dc->aoCount, &slots32, 4, hipMemcpyHostToDevice, st));
+    LV_HIP(ctx, hipStreamSynchronize(st)); // skip[] and slots32 live on this stack frame
+    for (uint32_t iter = 0; iter < o.bakeIterations; iter++) {
+        U.aoFrameNumber = iter;
+        LV_HIP(ctx, hipMemsetAsync(&dc->aoQueueHead, 0, 8, st));
+        if (U.aoUseDistance)
+            k_ao_rays<false, false, LV_PRIM_TRIANGLE, true><<<uint32_t(gridRays), LV_AO_BLOCK, 0, st>>>(
+                    U, SA, g, smp, dc, (const uint2*)ctx->bakeLcgSkip.ptr);
+        else
+            k_ao_rays<false, true, LV_PRIM_TRIANGLE, true><<<uint32_t(gridRays), LV_AO_BLOCK, 0, st>>>(
+                    U, SA, g, smp, dc, (const uint2*)ctx->bakeLcgSkip.ptr);
+        k_ao_reduce<true><<<nblocks(slots), LV_BLOCK, 0, st>>>(U, g, smp, out, dc);
+    }
+    LV_HIP(ctx, hipGetLastError());
+    ctx->bakeValid = true;
     return LV_OK;
 }

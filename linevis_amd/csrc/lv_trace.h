@@ -594,6 +594,32 @@ __device__ __forceinline__ f4 lv_compute_fragment_color(const LvSceneDev& S, con
                                                         f3 fragmentNormal, f3 fragmentTangent, bool isCap,
                                                         float fragmentAttribute, float& payloadHitT);
 
+// getAoFactor(interpolatedVertexId, phi) of the static prebaker, AmbientOcclusion.glsl:49-75, without its last two lines
+// (pow(gamma) and the strength mapping are the same as for the screen-space texture and applied by the shading code).
+__device__ __forceinline__ float lv_prebaked_ao_lookup(const LvSceneDev& S, const LvUniforms& U, float interpolatedVertexId,
+                                                       float phi) {
+    const uint32_t lastLinePointIdx = uint32_t(interpolatedVertexId);
+    const uint32_t nextLinePointIdx = min(lastLinePointIdx + 1u, U.bakeNumLineVertices - 1u);
+    const float interpolationFactor = interpolatedVertexId - floorf(interpolatedVertexId);
+    const float blendingWeight = mixf(S.bakedBlendingWeights[lastLinePointIdx], S.bakedBlendingWeights[nextLinePointIdx],
+                                      interpolationFactor);
+    const uint32_t lastVertexIdx = uint32_t(blendingWeight);
+    const uint32_t nextVertexIdx = min(lastVertexIdx + 1u, U.bakeNumParametrizationVertices - 1u);
+    const float interpolationFactorLine = blendingWeight - floorf(blendingWeight);
+    const uint32_t N = U.bakeNumTubeSubdivisions;
+    const float circleIdxFlt = clampf(phi / 6.28318530717958647692f * float(N), 0.0f, float(N));
+    const uint32_t circleIdxLast = (uint32_t(floorf(circleIdxFlt)) + N) % N;
+    const uint32_t circleIdxNext = (circleIdxLast + 1u) % N;
+    const float interpolationFactorCircle = circleIdxFlt - floorf(circleIdxFlt);
+    const float aoFactor00 = S.bakedAo[circleIdxLast + size_t(N) * lastVertexIdx];
+    const float aoFactor01 = S.bakedAo[circleIdxLast + size_t(N) * nextVertexIdx];
+    const float aoFactor10 = S.bakedAo[circleIdxNext + size_t(N) * lastVertexIdx];
+    const float aoFactor11 = S.bakedAo[circleIdxNext + size_t(N) * nextVertexIdx];
+    const float aoFactor0 = mixf(aoFactor00, aoFactor01, interpolationFactorLine);
+    const float aoFactor1 = mixf(aoFactor10, aoFactor11, interpolationFactorLine);
+    return mixf(aoFactor0, aoFactor1, interpolationFactorCircle);
+}
+
 // ClosestHitTubeAnalytic + computeFragmentColor + blinnPhongShadingTube for flow lines.
 // aoTexel: AO factor of the pixel that launched the ray (lookup definition: DESIGN.md).  Returns payload.hitColor;
 // payloadHitT = length(hit - camera).
@@ -620,6 +646,21 @@ __device__ __forceinline__ f4 lv_shade_hit(const LvSceneDev& S, const LvUniforms
     f3 fragmentTangent = norm3(v);
     f3 fragmentNormal = norm3(fragPos - linePointInterpolated);
     const bool isCap = h.kind != 0;
+    if (U.aoPrebaked) {
+        // TubeRayTracing.glsl:551-563: angle around the tube relative to the line normal + interpolated vertex id
+        const uint32_t seg = S.leafSeg[h.leaf];
+        const uint32_t i0 = S.segIdx[2 * seg], i1 = S.segIdx[2 * seg + 1];
+        const lv_line_point& lp0 = S.points[i0];
+        const lv_line_point& lp1 = S.points[i1];
+        const float ts = h.kind == 0 ? dot3(v, fragPos - P0) / dot3(v, v) : (h.kind == 1 ? 0.0f : 1.0f);
+        const f3 lineNormal = (1.0f - ts) * mk3(lp0.lineNormal[0], lp0.lineNormal[1], lp0.lineNormal[2]) +
+                              ts * mk3(lp1.lineNormal[0], lp1.lineNormal[1], lp1.lineNormal[2]);
+        float phi = acosf(clampf(dot3(fragmentNormal, lineNormal), -1.0f, 1.0f));
+        const float val = dot3(lineNormal, cross3(fragmentNormal, fragmentTangent));
+        if (val < 0.0f) phi = 2.0f * 3.14159265358979323846f - phi;
+        const float fragmentVertexId = (1.0f - ts) * float(i0) + ts * float(i1);
+        aoTexel = lv_prebaked_ao_lookup(S, U, fragmentVertexId, phi);
+    }
     return lv_compute_fragment_color(S, U, aoTexel, fragPos, fragmentNormal, fragmentTangent, isCap, fragmentAttribute,
                                      payloadHitT);
 }
@@ -650,6 +691,19 @@ __device__ __forceinline__ f4 lv_shade_hit_triangle(const LvSceneDev& S, const L
     const f3 fragmentNormal = norm3(lerp3(vd0.vertexNormal, vd1.vertexNormal, vd2.vertexNormal));
     const f3 fragmentTangent = norm3(lerp3(lp0.lineTangent, lp1.lineTangent, lp2.lineTangent));
     const float fragmentAttribute = (lp0.lineAttribute * b0 + lp1.lineAttribute * bu) + lp2.lineAttribute * bv;
+    if (U.aoPrebaked) {
+        // LineAttributesBarycentric.glsl:44-52: interpolateAngle (BarycentricInterpolation.glsl:43-55) + vertex id
+        const float PI = 3.14159265358979323846f;
+        float a0 = vd0.phi, a1 = vd1.phi, a2 = vd2.phi;
+        if (a1 - a0 > PI || a2 - a0 > PI) a0 += 2.0f * PI;
+        if (a0 - a1 > PI || a2 - a1 > PI) a1 += 2.0f * PI;
+        if (a0 - a2 > PI || a1 - a2 > PI) a2 += 2.0f * PI;
+        const float phi = (a0 * b0 + a1 * bu) + a2 * bv;
+        const float fragmentVertexId = (float(vd0.vertexLinePointIndex & 0x7FFFFFFFu) * b0 +
+                                        float(vd1.vertexLinePointIndex & 0x7FFFFFFFu) * bu) +
+                                       float(vd2.vertexLinePointIndex & 0x7FFFFFFFu) * bv;
+        aoTexel = lv_prebaked_ao_lookup(S, U, fragmentVertexId, phi);
+    }
     return lv_compute_fragment_color(S, U, aoTexel, fragPos, fragmentNormal, fragmentTangent, isCap, fragmentAttribute,
                                      payloadHitT);
 }

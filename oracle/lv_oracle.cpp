@@ -414,11 +414,43 @@ inline void computeFragmentColor(const lvo_scene& sc, const lvo_params& P, const
                                  V3 fragmentNormal, V3 fragmentTangent, bool isCap, float fragmentAttribute,
                                  float hitColor[4], float& payloadHitT);
 
+// Static RTAO prebaking: AO factors per (parametrisation vertex, angular subdivision) + the per-line-vertex blending
+// weights that map a line vertex id to the parametrisation (VulkanAmbientOcclusionBaker.cpp:563-653).
+struct PrebakedAo {
+    const float* factors;
+    const float* blendingWeights;
+    uint32_t numLineVertices, numParametrizationVertices, numAoTubeSubdivisions;
+};
+
+// getAoFactor(interpolatedVertexId, phi), AmbientOcclusion.glsl:49-75, WITHOUT its last two lines (pow(gamma) and the
+// strength mapping): those are the same as for the screen-space texture and are applied by getAoFactor(P, aoTexel).
+inline float prebakedAoLookup(const PrebakedAo& pb, float interpolatedVertexId, float phi) {
+    uint32_t lastLinePointIdx = uint32_t(interpolatedVertexId);
+    uint32_t nextLinePointIdx = std::min(lastLinePointIdx + 1u, pb.numLineVertices - 1u);
+    float interpolationFactor = interpolatedVertexId - floorf(interpolatedVertexId);
+    float blendingWeight = mixf(pb.blendingWeights[lastLinePointIdx], pb.blendingWeights[nextLinePointIdx], interpolationFactor);
+    uint32_t lastVertexIdx = uint32_t(blendingWeight);
+    uint32_t nextVertexIdx = std::min(lastVertexIdx + 1u, pb.numParametrizationVertices - 1u);
+    float interpolationFactorLine = blendingWeight - floorf(blendingWeight);
+    const uint32_t N = pb.numAoTubeSubdivisions;
+    float circleIdxFlt = clampf(phi / 6.28318530717958647692f * float(N), 0.0f, float(N));
+    uint32_t circleIdxLast = (uint32_t(floorf(circleIdxFlt)) + N) % N;
+    uint32_t circleIdxNext = (circleIdxLast + 1u) % N;
+    float interpolationFactorCircle = circleIdxFlt - floorf(circleIdxFlt);
+    float aoFactor00 = pb.factors[circleIdxLast + size_t(N) * lastVertexIdx];
+    float aoFactor01 = pb.factors[circleIdxLast + size_t(N) * nextVertexIdx];
+    float aoFactor10 = pb.factors[circleIdxNext + size_t(N) * lastVertexIdx];
+    float aoFactor11 = pb.factors[circleIdxNext + size_t(N) * nextVertexIdx];
+    float aoFactor0 = mixf(aoFactor00, aoFactor01, interpolationFactorLine);
+    float aoFactor1 = mixf(aoFactor10, aoFactor11, interpolationFactorLine);
+    return mixf(aoFactor0, aoFactor1, interpolationFactorCircle);
+}
+
 // ClosestHitTubeAnalytic main() (TubeRayTracing.glsl:512-613) + computeFragmentColor (RayHitCommon.glsl:74-543),
 // flow lines: USE_CAPPED_TUBES / USE_HALOS / USE_DEPTH_CUES / USE_AMBIENT_OCCLUSION switches only.
 // Writes payload {hitColor, hitT}.
 inline void shadeHit(const lvo_scene& sc, const lvo_params& P, const Frame& F, float aoTexel, V3 o, V3 d, const Hit& h,
-                     float hitColor[4], float& payloadHitT) {
+                     float hitColor[4], float& payloadHitT, const PrebakedAo* pb = nullptr) {
     uint32_t i0 = sc.segIdx[2 * h.seg], i1 = sc.segIdx[2 * h.seg + 1];
     const lvo_line_point& lp0 = sc.pts[i0];
     const lvo_line_point& lp1 = sc.pts[i1];
@@ -442,6 +474,17 @@ inline void shadeHit(const lvo_scene& sc, const lvo_params& P, const Frame& F, f
     V3 fragmentTangent = normalize(v);
     V3 fragmentNormal = normalize(fragPos - linePointInterpolated);
     bool isCap = h.kind != 0;
+    if (pb) {
+        // TubeRayTracing.glsl:551-563: angle around the tube relative to the line normal, interpolated vertex id.
+        // (acos argument clamped to [-1, 1]: GLSL leaves acos undefined outside, rounding can exceed it by an ulp.)
+        const float ts = h.kind == 0 ? dot(v, fragPos - P0) / dot(v, v) : (h.kind == 1 ? 0.0f : 1.0f);
+        V3 lineNormal = (1.0f - ts) * ld3(lp0.lineNormal) + ts * ld3(lp1.lineNormal);
+        float phi = acosf(clampf(dot(fragmentNormal, lineNormal), -1.0f, 1.0f));
+        float val = dot(lineNormal, cross(fragmentNormal, fragmentTangent));
+        if (val < 0.0f) phi = 2.0f * 3.14159265358979323846f - phi;
+        float fragmentVertexId = (1.0f - ts) * float(i0) + ts * float(i1);
+        aoTexel = prebakedAoLookup(*pb, fragmentVertexId, phi);
+    }
     computeFragmentColor(sc, P, F, aoTexel, fragPos, fragmentNormal, fragmentTangent, isCap, fragmentAttribute, hitColor,
                          payloadHitT);
 }
@@ -839,8 +882,8 @@ void lvo_render_ao(const lvo_scene* sc, const lvo_params* Pp, int useBvh, uint32
 }
 
 // RayGen main() + traceRayTransparent + Miss, TubeRayTracing.glsl:61-82,198-298
-void lvo_render_rt(const lvo_scene* sc, const lvo_params* Pp, int useBvh, const float* ao, uint32_t x0, uint32_t y0,
-                   uint32_t w, uint32_t h, uint8_t* outRGBA8, lvo_stats* stats) {
+static void renderRt(const lvo_scene* sc, const lvo_params* Pp, int useBvh, const float* ao, const PrebakedAo* pb,
+                     uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, uint8_t* outRGBA8, lvo_stats* stats) {
     const lvo_params& P = *Pp;
     Frame F = makeFrame(P);
     const bool capped = P.useCappedTubes != 0;
@@ -871,7 +914,7 @@ void lvo_render_rt(const lvo_scene* sc, const lvo_params* Pp, int useBvh, const 
                     Hit hit;
                     float hc[4]; float payloadHitT; bool hasHit;
                     if (closestHit(*sc, F.radius, capped, useBvh != 0, o, d, tMin, tMax, hit, cnt)) {
-                        shadeHit(*sc, P, F, aoTexel, o, d, hit, hc, payloadHitT);
+                        shadeHit(*sc, P, F, aoTexel, o, d, hit, hc, payloadHitT, pb);
                         hasHit = true;
                         cnt.hits++;
                     } else {
@@ -902,8 +945,9 @@ void lvo_render_rt(const lvo_scene* sc, const lvo_params* Pp, int useBvh, const 
 // The ray tracer's "Triangle Mesh" geometry mode: RayGen / traceRayTransparent / Miss as above, closest hit
 // ClosestHitTubeTriangles (TubeRayTracing.glsl:301-352) + LineAttributesBarycentric.glsl:1-52,140-170 -> computeFragmentColor.
 // sc supplies the transfer function, tsc the triangle tubes.
-void lvo_render_rt_tri(const lvo_scene* sc, const lvo_tri_scene* tsc, const lvo_params* Pp, int useBvh, const float* ao,
-                       uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, uint8_t* outRGBA8, lvo_stats* stats) {
+static void renderRtTri(const lvo_scene* sc, const lvo_tri_scene* tsc, const lvo_params* Pp, int useBvh, const float* ao,
+                        const PrebakedAo* pb, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, uint8_t* outRGBA8,
+                        lvo_stats* stats) {
     const lvo_params& P = *Pp;
     Frame F = makeFrame(P);
     const float HIT_DISTANCE_EPSILON = 1e-5f;
@@ -946,7 +990,22 @@ void lvo_render_rt_tri(const lvo_scene* sc, const lvo_tri_scene* tsc, const lvo_
                         V3 fragmentNormal = normalize(interpolateVec3(ld3(vd0.vertexNormal), ld3(vd1.vertexNormal), ld3(vd2.vertexNormal), bc));
                         V3 fragmentTangent = normalize(interpolateVec3(ld3(lp0.lineTangent), ld3(lp1.lineTangent), ld3(lp2.lineTangent), bc));
                         float fragmentAttribute = (lp0.lineAttribute * bc.x + lp1.lineAttribute * bc.y) + lp2.lineAttribute * bc.z;
-                        computeFragmentColor(*sc, P, F, aoTexel, fragPos, fragmentNormal, fragmentTangent, isCap,
+                        float aoT = aoTexel;
+                        if (pb) {
+                            // LineAttributesBarycentric.glsl:44-52: interpolateAngle (BarycentricInterpolation.glsl:43-55)
+                            // of the vertex angles, interpolated line-vertex id
+                            const float PI = 3.14159265358979323846f;
+                            float a0 = vd0.phi, a1 = vd1.phi, a2 = vd2.phi;
+                            if (a1 - a0 > PI || a2 - a0 > PI) a0 += 2.0f * PI;
+                            if (a0 - a1 > PI || a2 - a1 > PI) a1 += 2.0f * PI;
+                            if (a0 - a2 > PI || a1 - a2 > PI) a2 += 2.0f * PI;
+                            float phi = (a0 * bc.x + a1 * bc.y) + a2 * bc.z;
+                            float fragmentVertexId = (float(vd0.vertexLinePointIndex & 0x7FFFFFFFu) * bc.x +
+                                                      float(vd1.vertexLinePointIndex & 0x7FFFFFFFu) * bc.y) +
+                                                     float(vd2.vertexLinePointIndex & 0x7FFFFFFFu) * bc.z;
+                            aoT = prebakedAoLookup(*pb, fragmentVertexId, phi);
+                        }
+                        computeFragmentColor(*sc, P, F, aoT, fragPos, fragmentNormal, fragmentTangent, isCap,
                                              fragmentAttribute, hc, payloadHitT);
                         hasHit = true;
                         cnt.hits++;
@@ -971,6 +1030,147 @@ void lvo_render_rt_tri(const lvo_scene* sc, const lvo_tri_scene* tsc, const lvo_
     }
     if (stats) {
         stats->raysTraced += rays; stats->nodesVisited += nodes; stats->primsTested += prims; stats->hitsShaded += hits;
+    }
+}
+
+void lvo_render_rt(const lvo_scene* sc, const lvo_params* P, int useBvh, const float* ao, uint32_t x0, uint32_t y0,
+                   uint32_t w, uint32_t h, uint8_t* outRGBA8, lvo_stats* stats) {
+    renderRt(sc, P, useBvh, ao, nullptr, x0, y0, w, h, outRGBA8, stats);
+}
+void lvo_render_rt_tri(const lvo_scene* sc, const lvo_tri_scene* tsc, const lvo_params* P, int useBvh, const float* ao,
+                       uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, uint8_t* outRGBA8, lvo_stats* stats) {
+    renderRtTri(sc, tsc, P, useBvh, ao, nullptr, x0, y0, w, h, outRGBA8, stats);
+}
+// colour pass with STATIC_AMBIENT_OCCLUSION_PREBAKING: AO from the baked table instead of the screen-space texture
+void lvo_render_rt_prebaked(const lvo_scene* sc, const lvo_tri_scene* tscOrNull, const lvo_params* P, int useBvh,
+                            const float* factors, const float* blendingWeights, uint32_t numLineVertices,
+                            uint32_t numParametrizationVertices, uint32_t numAoTubeSubdivisions, uint32_t x0,
+                            uint32_t y0, uint32_t w, uint32_t h, uint8_t* outRGBA8, lvo_stats* stats) {
+    PrebakedAo pb{factors, blendingWeights, numLineVertices, numParametrizationVertices, numAoTubeSubdivisions};
+    if (tscOrNull) renderRtTri(sc, tscOrNull, P, useBvh, nullptr, &pb, x0, y0, w, h, outRGBA8, stats);
+    else renderRt(sc, P, useBvh, nullptr, &pb, x0, y0, w, h, outRGBA8, stats);
+}
+
+// AmbientOcclusionComputeRenderPass::generateBlendingWeightParametrization + recomputeStaticParametrization,
+// VulkanAmbientOcclusionBaker.cpp:513-653.  lines = the polylines as LineData::getFilteredLines returns them; the
+// reference indexes the blending weights by line VERTEX (valid line points), so lines must not contain points that the
+// tangent test of a2 drops.  outSamplingLocations needs room for sum(ceil(len/expected) + 1) entries: pass NULL to count.
+void lvo_ao_parametrization(const float* positions, const uint32_t* lineOffsets, uint32_t nLines,
+                            float expectedParamSegmentLength, float* outBlendingWeights, float* outSamplingLocations,
+                            uint64_t* outNumParametrizationVertices) {
+    const float EPSILON = 1e-5f;
+    size_t segmentVertexIdOffset = 0, vertexIdx = 0;
+    uint64_t numSampling = 0;
+    for (uint32_t lineIdx = 0; lineIdx < nLines; lineIdx++) {
+        const float* line = positions + 3 * size_t(lineOffsets[lineIdx]);
+        const size_t n = lineOffsets[lineIdx + 1] - lineOffsets[lineIdx];
+        auto P = [&](size_t i) { return ld3(line + 3 * i); };
+        float polylineLength = 0.0f;
+        for (size_t i = 1; i < n; i++) polylineLength += length(P(i) - P(i - 1));
+        uint32_t numLineSubdivs = std::max(1u, uint32_t(ceilf(polylineLength / expectedParamSegmentLength)));
+        float lineSubdivLength = polylineLength / float(numLineSubdivs);
+        uint32_t numSubdivVertices = numLineSubdivs + 1;
+        const uint32_t startVertexIdx = uint32_t(vertexIdx);
+        if (outBlendingWeights) outBlendingWeights[vertexIdx] = float(segmentVertexIdOffset);
+        vertexIdx++;
+        float currentLength = 0.0f;
+        for (size_t i = 1; i < n; i++) {
+            currentLength += length(P(i) - P(i - 1));
+            float wgt = currentLength / lineSubdivLength;
+            if (outBlendingWeights)
+                outBlendingWeights[vertexIdx] = float(segmentVertexIdOffset) + clampf(wgt, 0.0f, float(numLineSubdivs) - EPSILON);
+            vertexIdx++;
+        }
+        float lastLength = 0.0f;
+        currentLength = length(P(1) - P(0));
+        size_t currVertexIdx = 1;
+        if (outSamplingLocations) outSamplingLocations[numSampling] = float(startVertexIdx);
+        numSampling++;
+        for (uint32_t i = 1; i < numSubdivVertices; i++) {
+            uint32_t parametrizationIdx = uint32_t(currentLength / lineSubdivLength);
+            while (i > parametrizationIdx && currVertexIdx < n - 1) {
+                float segLength = length(P(currVertexIdx + 1) - P(currVertexIdx));
+                lastLength = currentLength;
+                currentLength += segLength;
+                parametrizationIdx = uint32_t(currentLength / lineSubdivLength);
+                currVertexIdx++;
+            }
+            float samplingLocation = float(currVertexIdx - 1) + (float(i) * lineSubdivLength - lastLength) / (currentLength - lastLength);
+            samplingLocation = float(startVertexIdx) + std::min(samplingLocation, float(uint32_t(n) - 1u) - EPSILON);
+            if (outSamplingLocations) outSamplingLocations[numSampling] = samplingLocation;
+            numSampling++;
+        }
+        segmentVertexIdOffset += numSubdivVertices;
+    }
+    *outNumParametrizationVertices = numSampling;
+}
+
+// VulkanAmbientOcclusionBaker.Compute (VulkanAmbientOcclusionBaker.glsl:190-282), iterated numIterations times
+// (bakeAoTexture, VulkanAmbientOcclusionBaker.cpp:193-262).  Rays are traced against the capsules of sc, or against the
+// triangle tubes when tscOrNull is given (the reference uses the triangle TLAS, cpp:480).  sin/cos of the tube angle
+// use the build's sincos2pi (like the hemisphere sample).  outFactors: numTubeSubdivisions * numSamplingLocations.
+void lvo_bake_ao(const lvo_scene* sc, const lvo_tri_scene* tscOrNull, float lineWidth, int useCappedTubes, int useBvh,
+                 const float* samplingLocations, uint32_t numParametrizationVertices, uint32_t numTubeSubdivisions,
+                 uint32_t numAmbientOcclusionSamples, uint32_t numIterations, float ambientOcclusionRadius, int useDistance,
+                 float* outFactors) {
+    const float lineRadius = lineWidth * 0.5f;
+    const uint32_t numLinePoints = uint32_t(sc->pts.size());
+    for (uint32_t frameNumber = 0; frameNumber < numIterations; frameNumber++) {
+#pragma omp parallel for schedule(dynamic, 16)
+        for (int64_t idx = 0; idx < int64_t(numParametrizationVertices); idx++) {
+            Counters cnt;
+            const uint32_t lineSamplingIdx = uint32_t(idx);
+            uint32_t seed = tea(lineSamplingIdx, frameNumber);
+            // getInterpolatedLinePoint, glsl:110-131
+            const float samplingLocation = samplingLocations[lineSamplingIdx];
+            const uint32_t lowerIdx = uint32_t(samplingLocation);
+            const uint32_t upperIdx = std::min(lowerIdx + 1u, numLinePoints - 1u);
+            const float f = samplingLocation - floorf(samplingLocation);
+            const lvo_line_point& lo = sc->pts[lowerIdx];
+            const lvo_line_point& up = sc->pts[upperIdx];
+            auto mix3 = [&](V3 a, V3 b) { return v3(mixf(a.x, b.x, f), mixf(a.y, b.y, f), mixf(a.z, b.z, f)); };
+            const V3 binormalLower = cross(ld3(lo.lineTangent), ld3(lo.lineNormal));
+            const V3 binormalUpper = cross(ld3(up.lineTangent), ld3(up.lineNormal));
+            const V3 position = mix3(ld3(lo.linePosition), ld3(up.linePosition));
+            const V3 tangent = normalize(mix3(ld3(lo.lineTangent), ld3(up.lineTangent)));
+            const V3 normal = normalize(mix3(ld3(lo.lineNormal), ld3(up.lineNormal)));
+            const V3 binormal = normalize(mix3(binormalLower, binormalUpper));
+            for (uint32_t sub = 0; sub < numTubeSubdivisions; sub++) {
+                float sinAngle, cosAngle;
+                sincos2pi(float(sub) / float(numTubeSubdivisions), sinAngle, cosAngle);
+                const V3 surfaceNormal = cosAngle * normal + sinAngle * binormal;
+                const V3 rayOrigin = position + (lineRadius + 1e-6f) * surfaceNormal;
+                const V3 surfaceBitangent = cross(surfaceNormal, tangent);
+                float acc = 0.0f;
+                for (uint32_t rayIdx = 0; rayIdx < numAmbientOcclusionSamples; rayIdx++) {
+                    const float xi0 = rnd(seed), xi1 = rnd(seed);
+                    float sn, cs;
+                    sincos2pi(xi1, sn, cs);
+                    const float r = sqrtf(1.0f - xi0 * xi0);
+                    const V3 smp = v3(cs * r, sn * r, xi0);
+                    const V3 dirU = v3((tangent.x * smp.x + surfaceBitangent.x * smp.y) + surfaceNormal.x * smp.z,
+                                       (tangent.y * smp.x + surfaceBitangent.y * smp.y) + surfaceNormal.y * smp.z,
+                                       (tangent.z * smp.x + surfaceBitangent.z * smp.y) + surfaceNormal.z * smp.z);
+                    const V3 rd = normalize(dirU);
+                    float occ = 1.0f;
+                    if (tscOrNull) {
+                        TriHit th;
+                        if (closestTri(*tscOrNull, useBvh != 0, rayOrigin, rd, 0.0f, ambientOcclusionRadius, th, cnt))
+                            occ = useDistance ? th.t / ambientOcclusionRadius : 0.0f;
+                    } else {
+                        Hit ah;
+                        if (closestHit(*sc, lineRadius, useCappedTubes != 0, useBvh != 0, rayOrigin, rd, 0.0f,
+                                       ambientOcclusionRadius, ah, cnt))
+                            occ = useDistance ? ah.t / ambientOcclusionRadius : 0.0f;
+                    }
+                    acc += occ;
+                }
+                acc /= float(numAmbientOcclusionSamples);
+                float& dst = outFactors[sub + size_t(numTubeSubdivisions) * lineSamplingIdx];
+                if (frameNumber != 0) acc = mixf(dst, acc, 1.0f / float(frameNumber + 1));
+                dst = acc;
+            }
+        }
     }
 }
 

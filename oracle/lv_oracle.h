@@ -204,6 +204,18 @@ void lvo_trace_rays_tri(const lvo_tri_scene*, int useBvh, const float* origins, 
 void lvo_render_rt_tri(
         const lvo_scene*, const lvo_tri_scene*, const lvo_params*, int useBvh, const float* ao,
         uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, uint8_t* outRGBA8, lvo_stats* stats);
+/* ---- §8f rank 2: static RTAO prebaking (VulkanAmbientOcclusionBaker.{cpp,glsl}, AmbientOcclusion.glsl:49-75) ---- */
+void lvo_ao_parametrization(const float* positions, const uint32_t* lineOffsets, uint32_t nLines,
+                            float expectedParamSegmentLength, float* outBlendingWeights, float* outSamplingLocations,
+                            uint64_t* outNumParametrizationVertices);
+void lvo_bake_ao(const lvo_scene*, const lvo_tri_scene* triSceneOrNull, float lineWidth, int useCappedTubes, int useBvh,
+                 const float* samplingLocations, uint32_t numParametrizationVertices, uint32_t numTubeSubdivisions,
+                 uint32_t numAmbientOcclusionSamples, uint32_t numIterations, float ambientOcclusionRadius, int useDistance,
+                 float* outFactors);
+void lvo_render_rt_prebaked(const lvo_scene*, const lvo_tri_scene* triSceneOrNull, const lvo_params*, int useBvh,
+                            const float* factors, const float* blendingWeights, uint32_t numLineVertices,
+                            uint32_t numParametrizationVertices, uint32_t numAoTubeSubdivisions, uint32_t x0,
+                            uint32_t y0, uint32_t w, uint32_t h, uint8_t* outRGBA8, lvo_stats* stats);
 /* ---- a13 with the reference's own geometry: RTAO against the triangle tubes ---- */
 void lvo_render_ao_tri(
         const lvo_tri_scene*, const lvo_params*, int useBvh,

@@ -135,6 +135,10 @@ def lib():
     L.lvo_trace_rays_tri.argtypes = [vp, i32, vp, vp, f32, f32, u32, vp, vp, vp]
     L.lvo_render_ao_tri.argtypes = [vp, C.POINTER(Params), i32, u32, u32, u32, u32, vp, C.POINTER(Stats)]
     L.lvo_render_rt_tri.argtypes = [vp, vp, C.POINTER(Params), i32, vp, u32, u32, u32, u32, vp, C.POINTER(Stats)]
+    L.lvo_ao_parametrization.argtypes = [vp, vp, u32, f32, vp, vp, u64p]
+    L.lvo_bake_ao.argtypes = [vp, vp, f32, i32, i32, vp, u32, u32, u32, u32, f32, i32, vp]
+    L.lvo_render_rt_prebaked.argtypes = [vp, vp, C.POINTER(Params), i32, vp, vp, u32, u32, u32, u32, u32, u32, u32, vp,
+                                         C.POINTER(Stats)]
     L.lvo_generate_abc_flow.argtypes = [vp, i32, i32, i32, f32, f32, f32, f32]
     L.lvo_max_vector_magnitude.restype = f32
     L.lvo_max_vector_magnitude.argtypes = [vp, C.c_uint64]
@@ -427,6 +431,46 @@ class TriScene:
         st = stats if stats is not None else Stats()
         lib().lvo_render_ao_tri(self.h, C.byref(P), self._use_bvh(use_bvh), x0, y0, w, h, _p(ao), C.byref(st))
         return ao
+
+
+def ao_parametrization(positions, line_offsets, expected_param_segment_length=0.001):
+    """recomputeStaticParametrization (VulkanAmbientOcclusionBaker.cpp:563-653): (blending_weights[P], sampling_locations[M])."""
+    pos = np.ascontiguousarray(positions, dtype=np.float32)
+    off = np.ascontiguousarray(line_offsets, dtype=np.uint32)
+    n = C.c_uint64()
+    lib().lvo_ao_parametrization(_p(pos), _p(off), len(off) - 1, expected_param_segment_length, None, None, C.byref(n))
+    bw = np.zeros(len(pos), dtype=np.float32)
+    sl = np.zeros(n.value, dtype=np.float32)
+    lib().lvo_ao_parametrization(_p(pos), _p(off), len(off) - 1, expected_param_segment_length, _p(bw), _p(sl), C.byref(n))
+    return bw, sl
+
+
+def bake_ao(scene, tri_scene, line_width, sampling_locations, num_tube_subdivisions=8, num_samples=4, num_iterations=128,
+            radius=0.1, use_distance=True, capped=True, use_bvh=True):
+    """VulkanAmbientOcclusionBaker.Compute iterated: factors [num_sampling_locations, num_tube_subdivisions]."""
+    sl = np.ascontiguousarray(sampling_locations, dtype=np.float32)
+    out = np.zeros((len(sl), num_tube_subdivisions), dtype=np.float32)
+    if use_bvh:
+        scene._use_bvh(line_width, True)
+        if tri_scene is not None:
+            tri_scene._use_bvh(True)
+    lib().lvo_bake_ao(scene.h, tri_scene.h if tri_scene is not None else None, line_width, int(capped), int(use_bvh), _p(sl),
+                      len(sl), num_tube_subdivisions, num_samples, num_iterations, radius, int(use_distance), _p(out))
+    return out
+
+
+def render_rt_prebaked(scene, tri_scene, P, factors, blending_weights, tile=None, use_bvh=True, stats=None):
+    x0, y0, w, h = tile if tile is not None else (0, 0, P.width, P.height)
+    out = np.empty((h, w, 4), dtype=np.uint8)
+    st = stats if stats is not None else Stats()
+    f = np.ascontiguousarray(factors, dtype=np.float32)
+    bw = np.ascontiguousarray(blending_weights, dtype=np.float32)
+    ub = scene._use_bvh(P, use_bvh)
+    if tri_scene is not None:
+        tri_scene._use_bvh(use_bvh)
+    lib().lvo_render_rt_prebaked(scene.h, tri_scene.h if tri_scene is not None else None, C.byref(P), ub, _p(f), _p(bw),
+                                 len(bw), f.shape[0], f.shape[1], x0, y0, w, h, _p(out), C.byref(st))
+    return out
 
 
 def ppll_resolve(P, nodes, start_offset, tile=None, literal=False):
