@@ -1,6 +1,8 @@
 // LineRenderer.cpp -- see LineRenderer.hpp for the reference classes mirrored here.
 #include "LineRenderer.hpp"
 
+#include <algorithm>
+#include <cmath>
 #include <cstring>
 
 namespace lv {
@@ -55,6 +57,117 @@ void HipRayTracedAmbientOcclusion::pushSettings() {
     for (const auto& kv : m.getMap()) lv_set_option(ctx, kv.first.c_str(), kv.second.c_str());
 }
 
+// ---------------------------------------------------------------- static RTAO prebaker
+void computeAmbientOcclusionParametrization(const std::vector<std::vector<vec3>>& lines, float expectedParamSegmentLength,
+                                            std::vector<float>& blendingWeights, std::vector<float>& samplingLocations) {
+    const float EPSILON = 1e-5f;
+    const size_t numLines = lines.size();
+    std::vector<float> polylineLengths(numLines);
+    std::vector<uint32_t> numSubdivs(numLines);
+    std::vector<size_t> vertexOffset(numLines + 1, 0), paramOffset(numLines + 1, 0);
+#pragma omp parallel for schedule(static)
+    for (long li = 0; li < long(numLines); li++) {
+        const std::vector<vec3>& line = lines[size_t(li)];
+        float polylineLength = 0.0f;
+        for (size_t i = 1; i < line.size(); i++) polylineLength += length(line[i] - line[i - 1]);
+        polylineLengths[size_t(li)] = polylineLength;
+        numSubdivs[size_t(li)] = std::max(1u, uint32_t(std::ceil(polylineLength / expectedParamSegmentLength)));
+    }
+    for (size_t li = 0; li < numLines; li++) {
+        vertexOffset[li + 1] = vertexOffset[li] + lines[li].size();
+        paramOffset[li + 1] = paramOffset[li] + numSubdivs[li] + 1;
+    }
+    blendingWeights.assign(vertexOffset[numLines], 0.0f);
+    samplingLocations.assign(paramOffset[numLines], 0.0f);
+#pragma omp parallel for schedule(dynamic, 16)
+    for (long lli = 0; lli < long(numLines); lli++) {
+        const size_t li = size_t(lli);
+        const std::vector<vec3>& line = lines[li];
+        const size_t n = line.size();
+        if (n < 2) continue;
+        const uint32_t numLineSubdivs = numSubdivs[li];
+        const float lineSubdivLength = polylineLengths[li] / float(numLineSubdivs);
+        const uint32_t numSubdivVertices = numLineSubdivs + 1;
+        const size_t segmentVertexIdOffset = paramOffset[li];
+        const uint32_t startVertexIdx = uint32_t(vertexOffset[li]);
+        float* bw = blendingWeights.data() + vertexOffset[li];
+        float* sl = samplingLocations.data() + paramOffset[li];
+        // blending weight of every line vertex: arc length in units of the subdivision length
+        bw[0] = float(segmentVertexIdOffset);
+        float currentLength = 0.0f;
+        for (size_t i = 1; i < n; i++) {
+            currentLength += length(line[i] - line[i - 1]);
+            float w = currentLength / lineSubdivLength;
+            bw[i] = float(segmentVertexIdOffset) + std::fmin(std::fmax(w, 0.0f), float(numLineSubdivs) - EPSILON);
+        }
+        // sampling location of every parametrisation vertex: walk the polyline to the segment holding arc length i * L
+        float lastLength = 0.0f;
+        currentLength = length(line[1] - line[0]);
+        size_t currVertexIdx = 1;
+        sl[0] = float(startVertexIdx);
+        for (uint32_t i = 1; i < numSubdivVertices; i++) {
+            uint32_t parametrizationIdx = uint32_t(currentLength / lineSubdivLength);
+            while (i > parametrizationIdx && currVertexIdx < n - 1) {
+                float segLength = length(line[currVertexIdx + 1] - line[currVertexIdx]);
+                lastLength = currentLength;
+                currentLength += segLength;
+                parametrizationIdx = uint32_t(currentLength / lineSubdivLength);
+                currVertexIdx++;
+            }
+            float samplingLocation = float(currVertexIdx - 1) + (float(i) * lineSubdivLength - lastLength) / (currentLength - lastLength);
+            sl[i] = float(startVertexIdx) + std::min(samplingLocation, float(uint32_t(n) - 1u) - EPSILON);
+        }
+    }
+}
+
+void HipAmbientOcclusionBaker::startAmbientOcclusionBaking(LineDataPtr&, bool) {
+    isDataReady = false;
+    parametrizationDirty = true;
+}
+
+bool HipAmbientOcclusionBaker::uploadParametrization(LineDataPtr& lineData) {
+    if (!parametrizationDirty) return true;
+    std::vector<std::vector<vec3>> lines = lineData->getFilteredLines(nullptr);
+    std::vector<float> blendingWeights, samplingLocations;
+    computeAmbientOcclusionParametrization(lines, expectedParamSegmentLength, blendingWeights, samplingLocations);
+    int rc = lv_set_ao_parametrization(ctx, blendingWeights.data(), uint32_t(blendingWeights.size()),
+                                       samplingLocations.data(), uint32_t(samplingLocations.size()));
+    if (rc != LV_OK) return false;
+    numParametrizationVertices = uint32_t(samplingLocations.size());
+    parametrizationDirty = false;
+    isDataReady = true; // baking itself runs inside the next lv_render call
+    return true;
+}
+
+// The reference exposes these only through its GUI (renderGuiPropertyEditorNodes, VulkanAmbientOcclusionBaker.cpp:412-470);
+// here they are SettingsMap keys so that a headless run can set them.
+bool HipAmbientOcclusionBaker::setNewSettings(const SettingsMap& settings) {
+    bool changed = false;
+    if (settings.getValueOpt("rtao_prebaker_iterations", maxNumIterations)) changed = true;
+    if (settings.getValueOpt("rtao_prebaker_samples_per_frame", numAmbientOcclusionSamplesPerFrame)) changed = true;
+    if (settings.getValueOpt("rtao_prebaker_num_tube_subdivisions", numTubeSubdivisions)) changed = true;
+    if (settings.getValueOpt("ambient_occlusion_radius", ambientOcclusionRadius)) changed = true;
+    if (settings.getValueOpt("ambient_occlusion_distance_based", useDistance)) changed = true;
+    float len = expectedParamSegmentLength;
+    if (settings.getValueOpt("rtao_prebaker_line_resolution", len) && len != expectedParamSegmentLength && len > 0.0f) {
+        expectedParamSegmentLength = len;
+        parametrizationDirty = true;
+        changed = true;
+    }
+    if (changed) pushSettings();
+    return changed;
+}
+
+void HipAmbientOcclusionBaker::pushSettings() {
+    SettingsMap m;
+    m.addKeyValue("rtao_prebaker_iterations", maxNumIterations);
+    m.addKeyValue("rtao_prebaker_samples_per_frame", numAmbientOcclusionSamplesPerFrame);
+    m.addKeyValue("rtao_prebaker_num_tube_subdivisions", numTubeSubdivisions);
+    m.addKeyValue("ambient_occlusion_radius", ambientOcclusionRadius);
+    m.addKeyValue("ambient_occlusion_distance_based", useDistance);
+    for (const auto& kv : m.getMap()) lv_set_option(ctx, kv.first.c_str(), kv.second.c_str());
+}
+
 // ---------------------------------------------------------------- LineRenderer
 LineRenderer::LineRenderer(std::string windowName, SceneData* sceneData, TransferFunctionWindow& tfw)
         : windowName(std::move(windowName)), sceneData(sceneData), transferFunctionWindow(tfw) {}
@@ -99,7 +212,12 @@ void LineRenderer::onHasMoved() {
 // LineRenderer::setAmbientOcclusionBaker, LineRenderer.cpp:310-357 (only the screen-space RTAO baker exists here)
 void LineRenderer::setAmbientOcclusionBaker() {
     ambientOcclusionBaker = {};
-    if (ambientOcclusionBakerType == AmbientOcclusionBakerType::RTAO && ctx) {
+    if (ambientOcclusionBakerType == AmbientOcclusionBakerType::RTAO_PREBAKER && ctx) {
+        auto baker = std::make_shared<HipAmbientOcclusionBaker>(ctx);
+        baker->pushSettings();
+        ambientOcclusionBaker = baker;
+        setOption("ambient_occlusion_mode", AMBIENT_OCCLUSION_BAKER_TYPE_NAMES[0]);
+    } else if (ambientOcclusionBakerType == AmbientOcclusionBakerType::RTAO && ctx) {
         auto baker = std::make_shared<HipRayTracedAmbientOcclusion>(ctx);
         baker->pushSettings();
         ambientOcclusionBaker = baker;
@@ -134,7 +252,8 @@ bool LineRenderer::setNewSettings(const SettingsMap& settings) {
         AmbientOcclusionBakerType newType = AmbientOcclusionBakerType::NONE;
         for (int i = 0; i < 4; i++)
             if (ambientOcclusionModeName == AMBIENT_OCCLUSION_BAKER_TYPE_NAMES[i]) newType = AmbientOcclusionBakerType(i);
-        if (newType != AmbientOcclusionBakerType::NONE && newType != AmbientOcclusionBakerType::RTAO) {
+        if (newType != AmbientOcclusionBakerType::NONE && newType != AmbientOcclusionBakerType::RTAO &&
+            newType != AmbientOcclusionBakerType::RTAO_PREBAKER) {
             lastError = "ambient_occlusion_mode '" + ambientOcclusionModeName + "' is not provided by the HIP renderers";
         } else if (newType != ambientOcclusionBakerType || !ambientOcclusionBaker) {
             ambientOcclusionBakerType = newType;
@@ -210,6 +329,8 @@ bool LineRenderer::uploadFrameState() {
     bool wantMesh = getIsTriangleRepresentationUsed();
     if (useAmbientOcclusion && ambientOcclusionBaker && ambientOcclusionBaker->getType() == AmbientOcclusionBakerType::RTAO)
         wantMesh = wantMesh || static_cast<HipRayTracedAmbientOcclusion*>(ambientOcclusionBaker.get())->useTriangleTubes;
+    const bool prebaker = useAmbientOcclusion && ambientOcclusionBaker && ambientOcclusionBaker->getIsStaticPrebaker();
+    wantMesh = wantMesh || prebaker; // the baker traces the triangle tubes (VulkanAmbientOcclusionBaker.cpp:480)
     if (wantMesh && triangleMeshDirty) {
         TubeTriangleRenderData d = lineData->getLinePassTubeTriangleMeshRenderData(false, true);
         if (!check(lv_set_tube_triangle_mesh(ctx, d.indexBuffer.data(), uint32_t(d.indexBuffer.size() / 3),
@@ -218,6 +339,10 @@ bool LineRenderer::uploadFrameState() {
                    "lv_set_tube_triangle_mesh"))
             return false;
         triangleMeshDirty = false;
+    }
+    if (prebaker && !static_cast<HipAmbientOcclusionBaker*>(ambientOcclusionBaker.get())->uploadParametrization(lineData)) {
+        check(LV_E_INVALID, "lv_set_ao_parametrization");
+        return false;
     }
     return true;
 }
@@ -230,7 +355,7 @@ bool LineRenderer::renderMode(int mode) {
     const uint32_t w = *sceneData->viewportWidth, h = *sceneData->viewportHeight;
     sceneData->sceneTexture->resize(size_t(w) * h * 4);
     if (!check(lv_render(ctx, mode, 0, 0, w, h, sceneData->sceneTexture->data()), "lv_render")) return false;
-    if (useAmbientOcclusion && ambientOcclusionBaker)
+    if (useAmbientOcclusion && ambientOcclusionBaker && ambientOcclusionBaker->getType() == AmbientOcclusionBakerType::RTAO)
         static_cast<HipRayTracedAmbientOcclusion*>(ambientOcclusionBaker.get())->notifyRendered();
     return true;
 }

@@ -125,6 +125,43 @@ private:
     bool isDataReady = false, hasComputationFinished = false;
 };
 
+/// "RTAO (Prebaker)": view-independent AO baked once per geometry (VulkanAmbientOcclusionBaker.{hpp,cpp}).  The host part
+/// is the blending-weight parametrisation of the polylines; baking and the render-time lookup run in the library.
+class HipAmbientOcclusionBaker : public AmbientOcclusionBaker {
+public:
+    explicit HipAmbientOcclusionBaker(lv_ctx* ctx) : ctx(ctx) {}
+    AmbientOcclusionBakerType getType() override { return AmbientOcclusionBakerType::RTAO_PREBAKER; }
+    bool getIsStaticPrebaker() override { return true; }
+    void startAmbientOcclusionBaking(LineDataPtr& lineData, bool isNewData) override;
+    bool getIsDataReady() override { return isDataReady; }
+    bool getHasComputationFinished() override { return isDataReady; }
+    bool setNewSettings(const SettingsMap& settings) override;
+    void pushSettings();
+    /// uploads the parametrisation when it is out of date (new data / new expectedParamSegmentLength)
+    bool uploadParametrization(LineDataPtr& lineData);
+    uint32_t getNumParametrizationVertices() const { return numParametrizationVertices; }
+
+    int maxNumIterations = 128;                       // VulkanAmbientOcclusionBaker.hpp:108
+    float expectedParamSegmentLength = 0.001f;        // :163
+    uint32_t numTubeSubdivisions = 8;                 // :165
+    uint32_t numAmbientOcclusionSamplesPerFrame = 4;  // :166
+    float ambientOcclusionRadius = 0.1f;              // :167
+    bool useDistance = true;                          // :168
+
+private:
+    lv_ctx* ctx;
+    bool isDataReady = false, parametrizationDirty = true;
+    uint32_t numParametrizationVertices = 0;
+};
+
+/// AmbientOcclusionComputeRenderPass::generateBlendingWeightParametrization + recomputeStaticParametrization
+/// (VulkanAmbientOcclusionBaker.cpp:513-653): per line vertex a fractional index into the parametrisation, per
+/// parametrisation vertex a fractional line-vertex position.  Lines are independent: lengths and counts first, a prefix
+/// sum over lines, then every line writes its own ranges (OpenMP).
+void computeAmbientOcclusionParametrization(const std::vector<std::vector<vec3>>& lines, float expectedParamSegmentLength,
+                                            std::vector<float>& blendingWeightParametrizationData,
+                                            std::vector<float>& samplingLocations);
+
 // ---------------------------------------------------------------- renderers
 class LineRenderer {
 public:

@@ -108,6 +108,18 @@ void lvh_flow_copy_triangle_data(void* hp, uint32_t* indices, lv_tube_vertex* ve
     if (points) memcpy(points, d.linePointDataBuffer.data(), d.linePointDataBuffer.size() * sizeof(lv_line_point));
 }
 
+/// AO prebaker parametrisation of the flow's lines (no GPU involved): counts first (NULL outputs), then the copy.
+void lvh_flow_ao_parametrization(void* hp, float expectedParamSegmentLength, float* blendingWeights, float* samplingLocations,
+                                 uint64_t* outNumLineVertices, uint64_t* outNumParametrizationVertices) {
+    FlowHandle* h = static_cast<FlowHandle*>(hp);
+    std::vector<float> bw, sl;
+    computeAmbientOcclusionParametrization(h->data->getFilteredLines(nullptr), expectedParamSegmentLength, bw, sl);
+    if (blendingWeights) memcpy(blendingWeights, bw.data(), bw.size() * 4);
+    if (samplingLocations) memcpy(samplingLocations, sl.data(), sl.size() * 4);
+    *outNumLineVertices = bw.size();
+    *outNumParametrizationVertices = sl.size();
+}
+
 // ---- streamline tracer front end (Flow.hpp)
 namespace {
 struct GridHandle {

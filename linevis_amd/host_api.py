@@ -39,6 +39,7 @@ def load():
         "lvh_flow_copy_render_data": (None, [vp, vp, vp, vp]),
         "lvh_flow_build_triangle_data": (None, [vp, f32, u32, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]),
         "lvh_flow_copy_triangle_data": (None, [vp, vp, vp, vp]),
+        "lvh_flow_ao_parametrization": (None, [vp, f32, vp, vp, C.POINTER(u64), C.POINTER(u64)]),
         "lvh_grid_create": (vp, [i32]),
         "lvh_grid_destroy": (None, [vp]),
         "lvh_grid_set_extent": (None, [vp, i32, i32, i32, f32, f32, f32]),
@@ -160,6 +161,19 @@ class LineDataFlow:
         pts = np.zeros(npt.value, dtype=capi.LINE_POINT_DTYPE)
         self.L.lvh_flow_copy_triangle_data(self.h, _p(idx), _p(verts), _p(pts))
         return idx.reshape(-1, 3), verts, pts
+
+
+def _flow_ao_parametrization(self, expected_param_segment_length=0.001):
+    """computeAmbientOcclusionParametrization: (blending_weights[num_line_vertices], sampling_locations[M])."""
+    nv, npv = C.c_uint64(), C.c_uint64()
+    self.L.lvh_flow_ao_parametrization(self.h, expected_param_segment_length, None, None, C.byref(nv), C.byref(npv))
+    bw = np.zeros(nv.value, dtype=np.float32)
+    sl = np.zeros(npv.value, dtype=np.float32)
+    self.L.lvh_flow_ao_parametrization(self.h, expected_param_segment_length, _p(bw), _p(sl), C.byref(nv), C.byref(npv))
+    return bw, sl
+
+
+LineDataFlow.ao_parametrization = _flow_ao_parametrization
 
 
 class StreamlineTracingGrid:

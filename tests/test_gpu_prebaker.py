@@ -117,3 +117,38 @@ def test_prebaker_state_errors_and_rebake(hip_lib):
         ctx2.render(capi.MODE_RAY_TRACER)
     ctx2.set_ao_parametrization(bw, sl)
     assert ctx2.render(capi.MODE_RAY_TRACER).shape == (case.height, case.width, 4)
+
+
+def test_prebaker_through_the_plugin(hip_lib):
+    """ambient_occlusion_mode = "RTAO (Prebaker)" on the LineRenderer surface: the plugin computes the parametrisation,
+    uploads the triangle tubes, the library bakes and shades."""
+    lw = 0.02
+    tr = scenes.normalize(scenes.random_curves(n_lines=20, points_per_line=40, seed=3))
+    flow = host_api.LineDataFlow().set_trajectories(tr.positions, tr.attributes, tr.line_offsets)
+    r = host_api.HeadlessLineRenderer(capi.MODE_RAY_TRACER)
+    r.set_rendering_resolution(96, 64)
+    r.set_transfer_function(tfm.standard())
+    r.set_line_data(flow)
+    r.set_new_settings(dict(line_width=lw, rtao_prebaker_iterations=2, rtao_prebaker_samples_per_frame=8,
+                            rtao_prebaker_line_resolution=0.01, **PREBAKE))
+    img = r.render_frame()
+    view, proj, fovy, near, far = r.camera()
+    pts, seg, _ = lvo.build_tube_aabb_render_data(tr.positions, tr.attributes, tr.line_offsets, lw)
+    case = Case(pts, seg, tfm.standard(), 96, 64, lw, **PREBAKE)
+    case.view, case.proj, case.fovy, case.near, case.far = view, proj, fovy, near, far
+    sc = case.oracle_scene()
+    P = case.oracle_params(sc)
+    P.useAmbientOcclusion = 1
+    P.attrMin, P.attrMax = flow.attribute_range()
+    mesh = lvo.build_tube_triangle_render_data(tr.positions, tr.attributes, tr.line_offsets, lw, 6)
+    bw, sl = lvo.ao_parametrization(tr.positions, tr.line_offsets, 0.01)
+    fac = lvo.bake_ao(sc, lvo.TriScene(*mesh, lw), lw, sl, 8, 8, 2)
+    assert max_lsb_diff(img, lvo.render_rt_prebaked(sc, None, P, fac, bw)) <= 2
+    # switching the baker type back and forth works
+    r.set_new_settings(dict(ambient_occlusion_mode="RTAO (Screen Space)", ambient_occlusion_iterations=1,
+                            ambient_occlusion_samples_per_frame=4))
+    img_ss = r.render_frame()
+    # a freshly created baker starts from its defaults (128 x 4 samples, line resolution 0.001), like the reference's
+    r.set_new_settings(dict(ambient_occlusion_mode="RTAO (Prebaker)", rtao_prebaker_iterations=2,
+                            rtao_prebaker_samples_per_frame=8, rtao_prebaker_line_resolution=0.01))
+    assert np.array_equal(r.render_frame(), img) and not np.array_equal(img_ss, img)

@@ -1,0 +1,79 @@
+"""Static RTAO prebaker, CPU side: the polyline parametrisation (host C++ vs the oracle's literal restatement of
+recomputeStaticParametrization) and properties of the oracle's bake / lookup."""
+import numpy as np
+import pytest
+
+from common import small_case
+from linevis_amd import host_api, scenes
+from oracle import lvo
+
+
+def curves(seed=7, n_lines=30, pts=30):
+    return scenes.normalize(scenes.random_curves(n_lines=n_lines, points_per_line=pts, seed=seed))
+
+
+@pytest.mark.parametrize("seed,expected", [(7, 0.01), (3, 0.001), (5, 0.05), (9, 0.3)])
+def test_host_parametrization_is_byte_identical_to_the_oracle(seed, expected):
+    tr = curves(seed)
+    flow = host_api.LineDataFlow().set_trajectories(tr.positions, tr.attributes, tr.line_offsets)
+    a = flow.ao_parametrization(expected)
+    b = lvo.ao_parametrization(tr.positions, tr.line_offsets, expected)
+    assert a[0].tobytes() == b[0].tobytes() and a[1].tobytes() == b[1].tobytes()
+
+
+def test_parametrization_properties():
+    """VulkanAmbientOcclusionBaker.cpp:563-653: per line ceil(length / expected) subdivisions of equal arc length; blending
+    weights grow monotonically along a line from the line's first parametrisation vertex; sampling locations point into
+    the line's own vertex range and land on the arc length i * L."""
+    tr = curves(11, n_lines=12, pts=40)
+    expected = 0.02
+    bw, sl = lvo.ao_parametrization(tr.positions, tr.line_offsets, expected)
+    assert len(bw) == len(tr.positions)
+    off = tr.line_offsets.astype(np.int64)
+    p0 = 0
+    for l in range(len(off) - 1):
+        pts = tr.positions[off[l]:off[l + 1]].astype(np.float64)
+        seg = np.linalg.norm(np.diff(pts, axis=0), axis=1)
+        length = seg.sum()
+        nsub = max(1, int(np.ceil(np.float32(length) / np.float32(expected))))
+        w = bw[off[l]:off[l + 1]]
+        assert w[0] == p0 and np.all(np.diff(w) >= 0) and w[-1] <= p0 + nsub and w[-1] > p0 + nsub - 1e-2
+        s = sl[p0:p0 + nsub + 1]
+        assert s[0] == off[l] and np.all(np.diff(s) > 0) and s[-1] < off[l + 1] - 1 + 1e-6
+        # arc length at sampling location i is i * length / nsub
+        cum = np.concatenate([[0.0], np.cumsum(seg)])
+        loc = s - off[l]
+        arc = np.interp(loc, np.arange(len(pts)), cum)
+        assert np.allclose(arc, np.arange(nsub + 1) * length / nsub, atol=2e-4 * max(1.0, length))
+        p0 += nsub + 1
+    assert p0 == len(sl)
+
+
+def test_bake_and_lookup_properties():
+    lw = 0.02
+    tr = curves(7)
+    mesh = lvo.build_tube_triangle_render_data(tr.positions, tr.attributes, tr.line_offsets, lw, 6)
+    bw, sl = lvo.ao_parametrization(tr.positions, tr.line_offsets, 0.01)
+    case = small_case(line_width=lw, ambient_occlusion_mode="RTAO (Screen Space)", ambient_occlusion_strength=1.0)
+    sc = case.oracle_scene()
+    ts = lvo.TriScene(*mesh, lw)
+    f1 = lvo.bake_ao(sc, ts, lw, sl, 8, 4, 2, use_bvh=True)
+    assert np.array_equal(f1, lvo.bake_ao(sc, ts, lw, sl, 8, 4, 2, use_bvh=False))      # BVH == brute force
+    assert f1.shape == (len(sl), 8) and 0.0 <= f1.min() and f1.max() <= 1.0 and 0.5 < f1.mean() < 1.0
+    # running mean over iterations: 2 iterations = mean of the two single passes only if they were independent frames;
+    # the first iteration alone equals a 1-iteration bake (frame 0 has no history)
+    f_first = lvo.bake_ao(sc, ts, lw, sl, 8, 4, 1)
+    assert not np.array_equal(f1, f_first) and np.abs(f1 - f_first).max() <= 0.5 + 1e-6
+    # any-hit variant only produces 0 / 1 samples -> multiples of 1 / (samples * iterations)
+    fa = lvo.bake_ao(sc, ts, lw, sl, 8, 4, 1, use_distance=False)
+    assert np.allclose(fa * 4, np.round(fa * 4), atol=1e-6)
+    # colour pass with the baked table: darker than with an all-ones table, which equals a screen-space pass whose
+    # AO texture is 1 everywhere (same kA / kD branch of blinnPhongShadingTube)
+    P = case.oracle_params(sc)
+    img = lvo.render_rt_prebaked(sc, None, P, f1, bw)
+    ones = np.ones_like(f1)
+    same = lvo.render_rt_prebaked(sc, None, P, ones, bw)
+    fg = (same[..., :3] != 255).any(axis=2)
+    assert img[fg][:, :3].astype(int).mean() < same[fg][:, :3].astype(int).mean() - 2
+    ao1 = np.ones((P.height, P.width), np.float32)
+    assert np.array_equal(same, sc.render_rt(P, ao=ao1, use_bvh=True))
