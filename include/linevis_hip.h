@@ -237,8 +237,9 @@ int lv_trace_rays_triangles(lv_ctx* ctx, const float* origins, const float* dirs
 int lv_compute_depth_range(lv_ctx* ctx, float out_min_max[2]);
 /* Full-viewport RTAO texture (.x channel of the RGBA32F accumulation image) after the last mode-11/2 render. */
 int lv_get_ao(lv_ctx* ctx, float* out /* viewport_width * viewport_height */);
-/* PPLL buffers after the last mode-2 render: nodes = 3 uint32 {rgba8, depth bits, next} per stored fragment,
- * start_offset = padded_w * padded_h heads (0xFFFFFFFF = empty).  Either pointer may be NULL. */
+/* PPLL buffers after the last mode-2 render: nodes = 3 uint32 {rgba8, depth bits, next} per node slot (slots are handed
+ * out to waves in chunks, so unreferenced slots may lie between the stored fragments), start_offset = padded_w * padded_h
+ * heads (0xFFFFFFFF = empty), frag_counter = number of fragments generated.  Either pointer may be NULL. */
 int lv_ppll_get_buffers(lv_ctx* ctx, uint32_t* out_nodes, uint64_t max_nodes, uint32_t* out_start_offset,
                         uint64_t max_pixels, uint32_t* out_frag_counter);
 /* Resolve caller-supplied PPLL buffers (LinkedListResolve.glsl:57-105) with the current camera/options. */

@@ -90,7 +90,7 @@ struct LvDevCountersHost { // must match LvDevCounters in lv_render.hip
     unsigned long long aoRays, aoNodes, aoPrims;
     unsigned long long aoQueueHead;
     unsigned long long aoPhaseIters[3], aoPhaseLanes[3];
-    uint32_t fragCounter, aoCount, maxDepthComplexity, depthOrd[2], maxNodesPerPixel;
+    uint32_t fragCounter, aoCount, maxDepthComplexity, depthOrd[2], maxNodesPerPixel, fragAlloc;
 };
 
 bool parseBool(const char* v) { return strcmp(v, "true") == 0 || strcmp(v, "1") == 0; } // InternalState.hpp:64-71
@@ -171,7 +171,7 @@ void lv_destroy(lv_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     for (LvDeviceBuffer* b : {&ctx->points, &ctx->segIdx, &ctx->nodes, &ctx->segs, &ctx->leafSeg, &ctx->segToLeaf, &ctx->tf,
                               &ctx->depthMinMax, &ctx->ao, &ctx->aoGbuf, &ctx->aoList, &ctx->aoSamples, &ctx->counters,
-                              &ctx->ppllNodes, &ctx->ppllStart, &ctx->ppllScratch, &ctx->tilesDev, &ctx->outDev,
+                              &ctx->ppllNodes, &ctx->ppllStart, &ctx->ppllCount, &ctx->ppllScratch, &ctx->tilesDev, &ctx->outDev,
                               &ctx->scratchRays, &ctx->stackOverflow, &ctx->triIdx, &ctx->triVerts, &ctx->triPoints,
                               &ctx->triNodes, &ctx->tris, &ctx->flowVectors, &ctx->flowScalars, &ctx->flowMisc,
                               &ctx->flowSeeds, &ctx->flowOutPos, &ctx->flowOutAtt, &ctx->flowCounts, &ctx->bakeBlendingWeights,
@@ -540,7 +540,7 @@ int lv_get_stats(lv_ctx* ctx, lv_stats* out) {
     uint64_t bytes = 0;
     for (const LvDeviceBuffer* b : {&ctx->points, &ctx->segIdx, &ctx->nodes, &ctx->segs, &ctx->leafSeg, &ctx->segToLeaf, &ctx->tf,
                                     &ctx->depthMinMax, &ctx->ao, &ctx->aoGbuf, &ctx->aoList, &ctx->aoSamples,
-                                    &ctx->counters, &ctx->ppllNodes, &ctx->ppllStart, &ctx->ppllScratch, &ctx->tilesDev,
+                                    &ctx->counters, &ctx->ppllNodes, &ctx->ppllStart, &ctx->ppllCount, &ctx->ppllScratch, &ctx->tilesDev,
                                     &ctx->outDev, &ctx->scratchRays, &ctx->stackOverflow, &ctx->triIdx, &ctx->triVerts,
                                     &ctx->triPoints, &ctx->triNodes, &ctx->tris})
         bytes += b->bytes;
@@ -650,7 +650,8 @@ int lv_ppll_get_buffers(lv_ctx* ctx, uint32_t* out_nodes, uint64_t max_nodes, ui
     LvDevCountersHost hc;
     LV_HIP(ctx, hipMemcpy(&hc, ctx->counters.ptr, sizeof(hc), hipMemcpyDeviceToHost));
     if (out_frag_counter) *out_frag_counter = hc.fragCounter;
-    uint64_t stored = hc.fragCounter < ctx->ppllPoolNodes ? hc.fragCounter : ctx->ppllPoolNodes;
+    // node slots are handed out to waves in chunks (k_ppll_gather): copy up to the allocator's high-water mark
+    uint64_t stored = hc.fragAlloc < ctx->ppllPoolNodes ? hc.fragAlloc : ctx->ppllPoolNodes;
     if (out_nodes) {
         if (max_nodes < stored) return lv_fail(ctx, LV_E_CAPACITY, "out_nodes holds %llu nodes, %llu stored",
                                                (unsigned long long)max_nodes, (unsigned long long)stored);

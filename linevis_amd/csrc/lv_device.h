@@ -43,6 +43,13 @@
 #define LV_HANDOVER_MAX_BUSY 48 // cooperative closest hit: idle lanes take over stacked subtrees once at most this many lanes descend
 #endif
 
+#ifndef LV_PPLL_CHUNK
+#define LV_PPLL_CHUNK 256       // PPLL node slots a wave reserves per global atomic (>= 64)
+#endif
+#ifndef LV_PPLL_SLICES
+#define LV_PPLL_SLICES 2        // depth slices per pixel block in k_ppll_gather (workgroups = pixel blocks x slices)
+#endif
+
 struct f3 { float x, y, z; };
 struct f4 { float x, y, z, w; };
 

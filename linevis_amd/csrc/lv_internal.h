@@ -99,7 +99,7 @@ struct lv_ctx {
     LvDeviceBuffer ao;                        // width*height floats
     LvDeviceBuffer aoGbuf, aoList, aoSamples; // RTAO wavefront buffers
     LvDeviceBuffer counters;                  // device counters (LvCounters + misc)
-    LvDeviceBuffer ppllNodes, ppllStart, ppllScratch;
+    LvDeviceBuffer ppllNodes, ppllStart, ppllCount, ppllScratch;
     LvDeviceBuffer tilesDev, outDev, scratchRays, stackOverflow;
     std::vector<uint32_t> tilesHost;          // staging copy: caller's tile list is borrowed for the call only
     bool tilesUploaded = false;               // tilesDev holds tilesHost

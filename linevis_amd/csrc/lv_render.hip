@@ -30,6 +30,7 @@ struct LvDevCounters {
     uint32_t maxDepthComplexity;
     uint32_t depthOrd[2]; // encoded min / max for the depth-range reduction
     uint32_t maxNodesPerPixel;
+    uint32_t fragAlloc;   // PPLL node-slot allocator (chunks); fragCounter stays the exact fragment count
 };
 
 __device__ __forceinline__ void lv_flush_max_nodes(const LvCounters& c, LvDevCounters* dc) {
@@ -67,10 +68,10 @@ struct LvPixel {
     bool inTile, inView;
 };
 
-__device__ __forceinline__ bool lv_block_pixel(const LvUniforms& U, const LvTiles& T, LvPixel& p) {
+__device__ __forceinline__ bool lv_block_pixel(const LvUniforms& U, const LvTiles& T, LvPixel& p, uint32_t blockId) {
     const uint32_t blocksPerTile = T.blocksX * T.blocksY;
     const uint32_t nb = T.numTiles * blocksPerTile;
-    const uint32_t xcd = blockIdx.x % 8u, j = blockIdx.x / 8u;   // j-th block this XCD receives
+    const uint32_t xcd = blockId % 8u, j = blockId / 8u;   // j-th block this XCD receives
     const uint32_t b = ((j / LV_XCD_GROUP) * 8u + xcd) * LV_XCD_GROUP + (j % LV_XCD_GROUP);
     if (b >= nb) { p.inTile = false; p.inView = false; return false; }
     const uint32_t tile = b / blocksPerTile, rem = b % blocksPerTile;
@@ -84,6 +85,10 @@ __device__ __forceinline__ bool lv_block_pixel(const LvUniforms& U, const LvTile
     p.inView = p.inTile && p.x < U.width && p.y < U.height;
     p.outIndex = (tile * T.tileH + ly) * T.tileW + lx;
     return true;
+}
+
+__device__ __forceinline__ bool lv_block_pixel(const LvUniforms& U, const LvTiles& T, LvPixel& p) {
+    return lv_block_pixel(U, T, p, blockIdx.x);
 }
 
 // ================================================================ ray tracer colour pass
@@ -549,28 +554,63 @@ __global__ __launch_bounds__(LV_BLOCK) void k_fill_f32(float* p, float v, size_t
 }
 
 // ================================================================ PPLL
+// The ray interval [tMin, tMax] of every pixel is cut into numSlices depth slices (boundaries spread evenly over the
+// ray's passage through the scene box); workgroup = (16x16 pixel block, slice).  All-hits traversal cannot cull, so the
+// slices cost no extra traversal, but a wave in front of the dense core of a data set -- hundreds of fragments per pixel,
+// each one shaded -- no longer forms a multi-millisecond critical path while the rest of the GPU idles: its work is spread
+// over numSlices workgroups.  A slice accepts t in [lo, hi) (the last one up to tMax inclusive), so every fragment is
+// produced exactly once; each workgroup builds partial lists in LDS and splices them into the pixel's global list.
 template <bool STATS>
 __global__ __launch_bounds__(LV_BLOCK) void k_ppll_gather(const LvUniforms U, const LvSceneDev S, const LvTiles T,
                                                           uint32_t* __restrict__ nodes, uint32_t* __restrict__ startOffset,
-                                                          LvDevCounters* dc) {
+                                                          uint32_t* __restrict__ fragCount, LvDevCounters* dc,
+                                                          uint32_t numSlices) {
     __shared__ unsigned s_stack[LV_STACK_LDS * LV_BLOCK];
-    __shared__ uint32_t s_head[LV_BLOCK];  // list head of every thread's pixel (startOffset[pixel] while gathering)
-    __shared__ uint32_t s_count[LV_BLOCK]; // fragments of every thread's pixel
+    __shared__ uint32_t s_head[LV_BLOCK];  // head of this workgroup's partial list of every thread's pixel
+    __shared__ uint32_t s_tail[LV_BLOCK];  // its first inserted node (whose `next` is patched when splicing)
+    __shared__ uint32_t s_count[LV_BLOCK]; // fragments of every thread's pixel in this slice
+    __shared__ unsigned s_allocBase[LV_BLOCK / LV_WAVE], s_allocLeft[LV_BLOCK / LV_WAVE]; // per-wave chunk of node slots
     LV_COOP_SHARED(LV_BLOCK / LV_WAVE);
     LV_COOP_MEM(cm);
     LvPixel px;
-    if (!lv_block_pixel(U, T, px)) return;
+    const uint32_t slice = blockIdx.x % numSlices;
+    if (!lv_block_pixel(U, T, px, blockIdx.x / numSlices)) return;
     LvCounters cnt = {0, 0, 0, 0};
+    // (the slices of a pixel are ONE ray: lv_trace_all counts a ray per active call, corrected below)
     const unsigned waveBase = threadIdx.x & ~63u;
     s_head[threadIdx.x] = 0xFFFFFFFFu;
+    s_tail[threadIdx.x] = 0xFFFFFFFFu;
     s_count[threadIdx.x] = 0u;
+    if ((threadIdx.x & 63u) == 0u) { s_allocBase[threadIdx.x >> 6] = 0u; s_allocLeft[threadIdx.x >> 6] = 0u; }
     const float aoTexel = (px.inView && U.useAmbientOcclusion) ? S.ao[size_t(px.y) * U.width + px.x] : 1.0f;
     f3 o, d;
     lv_primary_ray(U, px.x, px.y, 0.5f, 0.5f, o, d);
+    const float tMin = 0.0001f, tMax = 1000.0f;
+    float lo = tMin, hi = __uint_as_float(__float_as_uint(tMax) + 1u); // t <= tMax  <=>  t < nextafter(tMax)
+    if (numSlices > 1u && S.numSegs != 0) {
+        // passage of the ray through the scene box (= the root node's grid, origin + [0, 255] * scale)
+        const float4 q0 = S.nodes[0], q1 = S.nodes[1];
+        const f3 bmin = mk3(q0.x, q0.y, q0.z);
+        const f3 bmax = mk3(q0.x + 255.0f * q0.w, q0.y + 255.0f * q1.x, q0.z + 255.0f * q1.y);
+        const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+        const float tx0 = (bmin.x - o.x) * inv.x, tx1 = (bmax.x - o.x) * inv.x;
+        const float ty0 = (bmin.y - o.y) * inv.y, ty1 = (bmax.y - o.y) * inv.y;
+        const float tz0 = (bmin.z - o.z) * inv.z, tz1 = (bmax.z - o.z) * inv.z;
+        float tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fminf(tz0, tz1));
+        float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fmaxf(tz0, tz1));
+        tn = fminf(fmaxf(tn, tMin), tMax);
+        tf = fminf(fmaxf(tf, tn), tMax);
+        // interior boundaries only steer the load balance; b_0 = tMin and b_numSlices = tMax keep the partition exact
+        const float w = (tf - tn) / float(numSlices);
+        if (slice > 0u) lo = tn + w * float(slice);
+        if (slice + 1u < numSlices) hi = tn + w * float(slice + 1u);
+    }
+    const bool active = px.inView && lo < hi;
+    if (STATS && active && slice != 0u && S.numSegs != 0) cnt.rays--;
     // Fragments of a pixel are produced by whichever lane tests the (pixel, segment) pair: the lane shades with the
     // owner's ray + AO texel and links the node with an LDS atomic exchange on the owner's list head (the reference's
-    // atomicExchange(startOffset[pixel]), LinkedListGather.glsl:55, kept in LDS until the pixel is finished).
-    lv_trace_all<STATS>(S, U.radius, U.useCappedTubes != 0, px.inView, o, d, 0.0001f, 1000.0f, aoTexel, 0.0f,
+    // atomicExchange(startOffset[pixel]), LinkedListGather.glsl:55, kept in LDS until the slice is finished).
+    lv_trace_all<STATS>(S, U.radius, U.useCappedTubes != 0, active, o, d, lo, hi, aoTexel, 0.0f,
                         lv_stack_mem(s_stack, S.stackOverflow), cm, cnt,
                         [&](unsigned owner, uint32_t leaf, float t, int kind, f3 ro, f3 rd, float ownerAo, float) {
         LvHit h; h.t = t; h.leaf = leaf; h.kind = kind; h.found = true;
@@ -583,24 +623,47 @@ __global__ __launch_bounds__(LV_BLOCK) void k_ppll_gather(const LvUniforms U, co
         const unsigned lane = lv_lane();
         const int leader = __ffsll((long long)mask) - 1;
         unsigned base = 0;
-        if (int(lane) == leader) base = atomicAdd(&dc->fragCounter, unsigned(__popcll(mask)));
+        if (int(lane) == leader) {
+            // node slots come from a per-wave chunk; one global atomic per LV_PPLL_CHUNK fragments instead of one per
+            // batch (a returning atomic on one address costs microseconds under load and sat on the critical path of
+            // the waves in front of dense geometry).  Leftovers of a chunk stay unused: slots may have holes.
+            const unsigned n = unsigned(__popcll(mask)), w = threadIdx.x >> 6;
+            unsigned b = s_allocBase[w], left = s_allocLeft[w];
+            if (left < n) { b = atomicAdd(&dc->fragAlloc, (unsigned)LV_PPLL_CHUNK); left = LV_PPLL_CHUNK; }
+            base = b;
+            s_allocBase[w] = b + n;
+            s_allocLeft[w] = left - n;
+        }
         base = __shfl(base, leader, 64);
         const uint32_t insertIndex = base + unsigned(__popcll(mask & ((1ull << lane) - 1ull)));
         atomicAdd(&s_count[waveBase + owner], 1u);
         if (insertIndex < U.ppllLinkedListSize) {
             const uint32_t next = atomicExch(&s_head[waveBase + owner], insertIndex);
+            if (next == 0xFFFFFFFFu) s_tail[waveBase + owner] = insertIndex;
             nodes[3 * size_t(insertIndex) + 0] = lv_pack_unorm4x8(color);
             nodes[3 * size_t(insertIndex) + 1] = __float_as_uint(hitT);
             nodes[3 * size_t(insertIndex) + 2] = next;
         }
     });
-    uint32_t numFrags = s_count[threadIdx.x];
-    if (px.inView)
-        startOffset[lv_ppll_addr(px.x, px.y, U.ppllPaddedW, U.ppllTileW, U.ppllTileH)] = s_head[threadIdx.x];
-    uint32_t m = numFrags;
+    const uint32_t numFrags = s_count[threadIdx.x];
+    uint32_t total = 0;
+    if (px.inView && numFrags > 0u) {
+        const uint32_t addr = lv_ppll_addr(px.x, px.y, U.ppllPaddedW, U.ppllTileW, U.ppllTileH);
+        const uint32_t head = s_head[threadIdx.x], tail = s_tail[threadIdx.x];
+        if (head != 0xFFFFFFFFu) { // splice the partial list in front of what other slices linked so far
+            const uint32_t old = atomicExch(&startOffset[addr], head);
+            nodes[3 * size_t(tail) + 2] = old;
+        }
+        total = atomicAdd(&fragCount[addr], numFrags) + numFrags; // the last slice to arrive sees the pixel's total
+    }
+    uint32_t m = total, sum = px.inView ? numFrags : 0u;
 #pragma unroll
-    for (int ofs = 32; ofs > 0; ofs >>= 1) m = max(m, (uint32_t)__shfl_xor(m, ofs, 64));
+    for (int ofs = 32; ofs > 0; ofs >>= 1) {
+        m = max(m, (uint32_t)__shfl_xor(m, ofs, 64));
+        sum += (uint32_t)__shfl_xor(sum, ofs, 64);
+    }
     if (lv_lane() == 0 && m > 0) atomicMax(&dc->maxDepthComplexity, m);
+    if (lv_lane() == 0 && sum > 0) atomicAdd(&dc->fragCounter, sum); // fragCounter of the reference: every fragment counts
     if (STATS) lv_flush_counters(cnt, dc);
 }
 
@@ -1083,20 +1146,27 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
         // reallocateFragmentBuffer, PerPixelLinkedListLineRenderer.cpp:251-357
         if ((rc = lv_buf_reserve(ctx, ctx->ppllNodes, size_t(U.ppllLinkedListSize) * 12))) return rc;
         if ((rc = lv_buf_reserve(ctx, ctx->ppllStart, size_t(U.ppllPaddedW) * U.ppllPaddedH * 4))) return rc;
+        if ((rc = lv_buf_reserve(ctx, ctx->ppllCount, size_t(U.ppllPaddedW) * U.ppllPaddedH * 4))) return rc;
         ctx->ppllPoolNodes = U.ppllLinkedListSize;
         // clear(): LinkedListClear.glsl:46-55 + fragmentCounterBuffer->fill(0)
         LV_HIP(ctx, hipEventRecord(ctx->ev[10], st));
         LV_HIP(ctx, hipMemsetAsync(ctx->ppllStart.ptr, 0xFF, size_t(U.ppllPaddedW) * U.ppllPaddedH * 4, st));
+        LV_HIP(ctx, hipMemsetAsync(ctx->ppllCount.ptr, 0, size_t(U.ppllPaddedW) * U.ppllPaddedH * 4, st));
         LV_HIP(ctx, hipMemsetAsync(&dc->fragCounter, 0, 4, st));
+        LV_HIP(ctx, hipMemsetAsync(&dc->fragAlloc, 0, 4, st));
         LV_HIP(ctx, hipEventRecord(ctx->ev[11], st));
         // gather()
         LV_HIP(ctx, hipEventRecord(ctx->ev[12], st));
+        const uint32_t numSlices = LV_PPLL_SLICES;
+        if (uint64_t(gridTiles) * numSlices > 0x7FFFFFF0ull) return lv_fail(ctx, LV_E_INVALID, "tile list too large");
         if (stats)
-            LV_TIMED_LAUNCH(ctx, LV_KERNEL_PPLL_GATHER, (k_ppll_gather<true><<<gridTiles, LV_BLOCK, 0, st>>>(
-                    U, S, T, (uint32_t*)ctx->ppllNodes.ptr, (uint32_t*)ctx->ppllStart.ptr, dc)));
+            LV_TIMED_LAUNCH(ctx, LV_KERNEL_PPLL_GATHER, (k_ppll_gather<true><<<gridTiles * numSlices, LV_BLOCK, 0, st>>>(
+                    U, S, T, (uint32_t*)ctx->ppllNodes.ptr, (uint32_t*)ctx->ppllStart.ptr,
+                    (uint32_t*)ctx->ppllCount.ptr, dc, numSlices)));
         else
-            LV_TIMED_LAUNCH(ctx, LV_KERNEL_PPLL_GATHER, (k_ppll_gather<false><<<gridTiles, LV_BLOCK, 0, st>>>(
-                    U, S, T, (uint32_t*)ctx->ppllNodes.ptr, (uint32_t*)ctx->ppllStart.ptr, dc)));
+            LV_TIMED_LAUNCH(ctx, LV_KERNEL_PPLL_GATHER, (k_ppll_gather<false><<<gridTiles * numSlices, LV_BLOCK, 0, st>>>(
+                    U, S, T, (uint32_t*)ctx->ppllNodes.ptr, (uint32_t*)ctx->ppllStart.ptr,
+                    (uint32_t*)ctx->ppllCount.ptr, dc, numSlices)));
         LV_HIP(ctx, hipEventRecord(ctx->ev[13], st));
         // resolve()
         LV_HIP(ctx, hipEventRecord(ctx->ev[14], st));

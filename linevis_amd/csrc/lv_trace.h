@@ -460,7 +460,7 @@ __device__ __forceinline__ LvHit lv_trace_closest(const LvSceneDev& S, float rad
     return h;
 }
 
-// All capsule entry hits in [tMin, tMax] (PPLL fragment generation), wave-cooperative like lv_trace_closest: every
+// All capsule entry hits with t in [tMin, tMax) -- per lane -- (PPLL fragment generation), wave-cooperative like lv_trace_closest: every
 // lane of the wave calls it; (owner, leaf) pairs are tested 64 at a time by whichever lanes are free, and the lane
 // that finds a hit calls f(owner, leaf, t, kind, o, d, w0, w1) with the OWNER's ray and its two payload words
 // (cm.ray[..].w), i.e. fragments of one pixel may be produced by any lane.
@@ -477,8 +477,11 @@ __device__ __forceinline__ void lv_trace_all(const LvSceneDev& S, float radius, 
     f3 oi = mk3(o.x * inv.x, o.y * inv.y, o.z * inv.z);
     LvStack st;
     st.init(sm.lds, sm.ovf, sm.ovfStride);
-    cm.ray[2 * lane] = make_float4(o.x, o.y, o.z, w0);
-    cm.ray[2 * lane + 1] = make_float4(d.x, d.y, d.z, w1);
+    // every lane has its OWN interval [tMin, tMax) (depth slices): it travels with the ray, the payload words go in the
+    // key slot (unused by the all-hits routine)
+    cm.ray[2 * lane] = make_float4(o.x, o.y, o.z, tMin);
+    cm.ray[2 * lane + 1] = make_float4(d.x, d.y, d.z, tMax);
+    cm.key[lane] = ((unsigned long long)__float_as_uint(w1) << 32) | __float_as_uint(w0);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     unsigned cur = active ? 0u : LV_INVALID;
     unsigned head = 0, tail = 0;
@@ -507,15 +510,18 @@ __device__ __forceinline__ void lv_trace_all(const LvSceneDev& S, float radius, 
                 float t; int kind;
                 if (lv_intersect_capsule(mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), mk3(a.x, a.y, a.z),
                                          mk3(b.x, b.y, b.z), radius, capped, t, kind)) {
-                    if (t >= tMin && t <= tMax)
-                        f(ow, leaf, t, kind, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), ro.w, rd.w);
+                    if (t >= ro.w && t < rd.w) {
+                        const unsigned long long pw = cm.key[ow];
+                        f(ow, leaf, t, kind, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), __uint_as_float(unsigned(pw)),
+                          __uint_as_float(unsigned(pw >> 32)));
+                    }
                 }
             }
             head += n;
             continue;
         }
         if (nNode == 0) break;
-        if (nNode <= LV_HANDOVER_MAX_BUSY) { // subtree hand-over, as in lv_trace_closest (all rays share tMin / tMax here)
+        if (nNode <= LV_HANDOVER_MAX_BUSY) { // subtree hand-over, as in lv_trace_closest
             const bool idle = cur == LV_INVALID;
             const bool donor = !idle && st.sp > 0;
             const unsigned long long mIdle = __ballot(idle), mDonor = __ballot(donor);
@@ -535,6 +541,8 @@ __device__ __forceinline__ void lv_trace_all(const LvSceneDev& S, float radius, 
                         const float4 ro = cm.ray[2 * owner], rd = cm.ray[2 * owner + 1];
                         inv = mk3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
                         oi = mk3(ro.x * inv.x, ro.y * inv.y, ro.z * inv.z);
+                        tMin = ro.w;
+                        tMax = rd.w;
                     }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
