@@ -2,7 +2,10 @@
 #include "LineData.hpp"
 
 #include <algorithm>
+#include <cctype>
+#include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 
@@ -99,6 +102,91 @@ bool saveTrajectoriesAsBinLines(const std::string& filename, const Trajectories&
     return fclose(f) == 0;
 }
 
+// ObjLoader.cpp:36-186.  One pass over the text; a statement is identified by its first two characters.
+bool loadTrajectoriesFromObj(const std::string& filename, Trajectories& trajectories, std::vector<std::string>& attributeNames) {
+    FILE* f = fopen(filename.c_str(), "rb");
+    if (!f) return false;
+    fseek(f, 0, SEEK_END);
+    long len = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    std::string text(len > 0 ? size_t(len) : 0, '\0');
+    size_t rd = text.empty() ? 0 : fread(&text[0], 1, text.size(), f);
+    fclose(f);
+    if (rd != text.size()) return false;
+
+    std::vector<vec3> vertices;
+    std::vector<float> vertexAttributes;
+    size_t numAttributes = 0;
+    auto tokens = [](const std::string& line, size_t from, std::vector<std::string>& out) {
+        out.clear();
+        size_t i = from;
+        while (i < line.size()) {
+            while (i < line.size() && (line[i] == ' ' || line[i] == '\t')) i++;
+            size_t b = i;
+            while (i < line.size() && line[i] != ' ' && line[i] != '\t') i++;
+            if (i > b) out.push_back(line.substr(b, i - b));
+        }
+    };
+    std::vector<std::string> tok;
+    trajectories.clear();
+    size_t pos = 0;
+    while (pos < text.size()) {
+        size_t e = text.find_first_of("\r\n", pos);
+        if (e == std::string::npos) e = text.size();
+        const std::string line = text.substr(pos, e - pos);
+        pos = e + 1;
+        if (line.empty()) continue;
+        const char c0 = line[0], c1 = line.size() > 1 ? line[1] : ' ';
+        if (c0 == 'v' && c1 == 't') {
+            tokens(line, 2, tok);
+            for (const std::string& t : tok) vertexAttributes.push_back(float(atof(t.c_str())));
+            numAttributes = tok.size();
+        } else if (c0 == 'v' && c1 == 'n') {
+            // normals are not used
+        } else if (c0 == 'v') {
+            vec3 p(0.0f, 0.0f, 0.0f);
+            sscanf(line.c_str() + 2, "%f %f %f", &p.x, &p.y, &p.z);
+            vertices.push_back(p);
+        } else if (c0 == 'l') {
+            tokens(line, 2, tok);
+            Trajectory t;
+            t.attributes.resize(numAttributes);
+            for (const std::string& s : tok) {
+                const long idx = atol(s.c_str()) - 1;
+                if (idx < 0 || size_t(idx) >= vertices.size()) return false;
+                const vec3 p = vertices[size_t(idx)];
+                const float MAX_VAL = 1e10f; // markers of invalid points in scientific data sets
+                if (std::fabs(p.x) > MAX_VAL || std::fabs(p.y) > MAX_VAL || std::fabs(p.z) > MAX_VAL) continue;
+                t.positions.push_back(p);
+                for (size_t j = 0; j < numAttributes; j++) {
+                    const size_t a = size_t(idx) * numAttributes + j;
+                    t.attributes[j].push_back(a < vertexAttributes.size() ? vertexAttributes[a] : 0.0f);
+                }
+            }
+            trajectories.push_back(std::move(t));
+        } else if (c0 == 'a') {
+            if (attributeNames.empty()) {
+                tokens(line, 2, tok);
+                attributeNames = tok;
+            }
+        }
+        // 'g' (new path), '#' (comment) and unknown statements are skipped
+    }
+    return true;
+}
+
+bool loadFlowTrajectoriesFromFile(const std::string& filename, Trajectories& trajectories, std::vector<std::string>& attributeNames) {
+    std::string lower = filename;
+    for (char& c : lower) c = char(tolower(c));
+    auto endsWith = [&](const char* ext) {
+        const size_t n = strlen(ext);
+        return lower.size() >= n && lower.compare(lower.size() - n, n, ext) == 0;
+    };
+    if (endsWith(".obj")) return loadTrajectoriesFromObj(filename, trajectories, attributeNames);
+    if (endsWith(".binlines")) return loadTrajectoriesFromBinLines(filename, trajectories);
+    return false; // .nc needs NetCDF (out of scope), anything else is unknown
+}
+
 // ---------------------------------------------------------------- LineData
 void LineData::setSelectedAttributeIndex(int idx) {
     if (idx != selectedAttributeIndex) {
@@ -148,10 +236,11 @@ bool LineData::setNewSettings(const SettingsMap& settings) {
 // ---------------------------------------------------------------- LineDataFlow
 bool LineDataFlow::loadFromFile(const std::string& filename) {
     Trajectories loaded;
-    if (!loadTrajectoriesFromBinLines(filename, loaded)) return false;
+    std::vector<std::string> names;
+    if (!loadFlowTrajectoriesFromFile(filename, loaded, names)) return false;
     AABB3 aabb = computeTrajectoriesAABB3(loaded);
     normalizeTrajectoriesVertexPositions(loaded, aabb);
-    setTrajectoryData(loaded);
+    setTrajectoryData(loaded, names);
     return true;
 }
 

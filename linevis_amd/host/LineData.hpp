@@ -4,6 +4,7 @@
 //   struct Trajectory / Trajectories                       src/Loaders/TrajectoryFile.hpp:38-46
 //   normalizeTrajectoriesVertexPositions                   src/Loaders/TrajectoryFile.cpp:106-125
 //   loadTrajectoriesFromBinLines (v1 / v2 header)          src/Loaders/BinLinesLoader.cpp:41-63,127-150
+//   loadTrajectoriesFromObj, loadFlowTrajectoriesFromFile  src/Loaders/ObjLoader.cpp:36-186, TrajectoryFile.cpp:634-655
 //   struct LinePointDataUnified (48 B), TubeAabbRenderData src/LineData/LineRenderData.hpp:99-106,203-210
 //   class LineData accessors                               src/LineData/LineData.hpp:149-262
 //   LineDataFlow::setTrajectoryData                        src/LineData/LineDataFlow.cpp:468-578
@@ -34,6 +35,12 @@ void normalizeTrajectoriesVertexPositions(Trajectories& trajectories, const AABB
 /// .binlines reader (version 1 payload; the trailing ribbon / hull-mesh part of version 2 files is ignored).
 bool loadTrajectoriesFromBinLines(const std::string& filename, Trajectories& trajectories);
 bool saveTrajectoriesAsBinLines(const std::string& filename, const Trajectories& trajectories);
+/// Wavefront-OBJ polylines as LineVis reads them (src/Loaders/ObjLoader.cpp:36-186): "v x y z" positions, "vt a0 a1 .."
+/// per-vertex attributes (same count on every line), "l i j k .." one trajectory per line statement (1-based indices),
+/// "a name0 name1 .." attribute names; positions with a component above 1e10 are dropped.
+bool loadTrajectoriesFromObj(const std::string& filename, Trajectories& trajectories, std::vector<std::string>& attributeNames);
+/// loadFlowTrajectoriesFromFile (src/Loaders/TrajectoryFile.cpp:634-655): by extension, .obj or .binlines
+bool loadFlowTrajectoriesFromFile(const std::string& filename, Trajectories& trajectories, std::vector<std::string>& attributeNames);
 
 typedef lv_line_point LinePointDataUnified; // 48 bytes, src/LineData/LineRenderData.hpp:99-106
 static_assert(sizeof(LinePointDataUnified) == 48, "LinePointDataUnified must stay byte-identical to the reference");

@@ -236,3 +236,32 @@ def read_binlines(path, attribute_index=0):
                 sel = arr
         attrs.append(sel if sel is not None else np.zeros(n, dtype=np.float32))
     return _pack(lines, attrs)
+
+
+# ------------------------------------------------------------------ .obj polylines (ObjLoader.cpp:36-186)
+def write_obj(path, tr, attribute_name="attr"):
+    """One 'v' + 'vt' pair per point and one 'l' statement per trajectory (1-based indices), as LineVis exports them."""
+    with open(path, "w") as f:
+        f.write("# polylines\na %s\n" % attribute_name)
+        for p, a in zip(tr.positions, tr.attributes):
+            f.write("v %.9g %.9g %.9g\nvt %.9g\n" % (p[0], p[1], p[2], a))
+        for i in range(tr.num_lines):
+            b, e = int(tr.line_offsets[i]), int(tr.line_offsets[i + 1])
+            f.write("g line%d\nl %s\n" % (i, " ".join(str(k + 1) for k in range(b, e))))
+
+
+def read_obj(path, attribute_index=0):
+    verts, attrs, lines, lattr = [], [], [], []
+    for line in open(path).read().replace("\r", "\n").split("\n"):
+        if line.startswith("vt"):
+            attrs.append([float(x) for x in line[2:].split()])
+        elif line.startswith("vn"):
+            continue
+        elif line.startswith("v"):
+            verts.append([float(x) for x in line[2:].split()[:3]])
+        elif line.startswith("l"):
+            idx = [int(x) - 1 for x in line[2:].split()]
+            idx = [i for i in idx if max(abs(c) for c in verts[i]) <= 1e10]
+            lines.append(np.array([verts[i] for i in idx], dtype=np.float32).reshape(-1, 3))
+            lattr.append(np.array([attrs[i][attribute_index] if attrs else 0.0 for i in idx], dtype=np.float32))
+    return _pack(lines, lattr)

@@ -90,3 +90,33 @@ def test_scene_generators_shapes():
     # deterministic
     assert np.array_equal(scenes.tornado(n_lines=5, points_per_line=21).positions,
                           scenes.tornado(n_lines=5, points_per_line=21).positions)
+
+
+def test_obj_polylines_roundtrip(tmp_path):
+    """ObjLoader.cpp:36-186: v / vt / l / a statements, 1-based indices, invalid-marker positions dropped; the host
+    loader against the Python reader, and against the same set written as .binlines."""
+    tr = scenes.random_curves(n_lines=7, points_per_line=12, seed=4)
+    p = str(tmp_path / "lines.obj")
+    scenes.write_obj(p, tr, "Vorticity")
+    back = scenes.read_obj(p)
+    assert np.array_equal(back.line_offsets, tr.line_offsets)
+    assert np.allclose(back.positions, tr.positions, rtol=1e-7, atol=0) and np.allclose(back.attributes, tr.attributes, rtol=1e-7)
+    flow = host_api.LineDataFlow().load_file(p)
+    pos, att, off = flow.trajectories()
+    norm = scenes.normalize(back)
+    assert np.array_equal(off, tr.line_offsets) and np.array_equal(pos, norm.positions) and np.array_equal(att, back.attributes)
+    pb = str(tmp_path / "lines.binlines")
+    scenes.write_binlines(pb, back)
+    pos2, att2, off2 = host_api.LineDataFlow().load_file(pb).trajectories()
+    assert np.array_equal(pos2, pos) and np.array_equal(att2, att) and np.array_equal(off2, off)
+    # an invalid-marker vertex is skipped, CRLF line ends and tabs are accepted, unknown statements ignored
+    txt = "# test\r\nv 0 0 0\r\nvt 0.5\r\nv 1e11 0 0\r\nvt 0.1\r\nv\t1 0 0\r\nvt\t0.25\r\nv 1 1 0\r\nvt 1\r\ns off\r\nl 1 2 3 4\r\n"
+    p2 = str(tmp_path / "marker.OBJ")
+    open(p2, "w", newline="").write(txt)
+    pos3, att3, off3 = host_api.LineDataFlow().load_file(p2).trajectories()
+    assert list(off3) == [0, 3] and list(att3) == [0.5, 0.25, 1.0]
+    with pytest.raises(Exception):
+        host_api.LineDataFlow().load_file(str(tmp_path / "missing.obj"))
+    open(str(tmp_path / "lines.xyz"), "w").write("v 0 0 0\n")
+    with pytest.raises(Exception):
+        host_api.LineDataFlow().load_file(str(tmp_path / "lines.xyz"))
