@@ -468,3 +468,23 @@ def test_config5_scale_tiles(hip_lib):
     b = sc.trace_rays(o, d, 0.0, 0.1, 0.002, use_bvh=True)
     assert np.array_equal(bits(a[0]), bits(b[0])) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
     assert (a[1] != 0xFFFFFFFF).sum() > 2000
+
+
+def test_command_line_renderer(hip_lib, tmp_path):
+    """python -m linevis_amd: file in, PNG out, through the plugin classes."""
+    from linevis_amd.__main__ import main
+    from PIL import Image
+    tr = scenes.random_curves(n_lines=12, points_per_line=30, seed=2)
+    p = str(tmp_path / "in.binlines")
+    scenes.write_binlines(p, tr)
+    out = str(tmp_path / "out.png")
+    assert main([p, "-o", out, "--width", "96", "--height", "64", "line_width=0.02", "depth_cue_strength=0.5"]) == 0
+    img = np.array(Image.open(out))
+    assert img.shape == (64, 96, 4) and (img[..., :3] != 255).any()
+    flow = host_api.LineDataFlow().load_file(p)
+    r = host_api.HeadlessLineRenderer(11)
+    r.set_rendering_resolution(96, 64); r.set_transfer_function(tfm.standard()); r.set_camera((0.0, 0.0, 0.8)); r.set_line_data(flow)
+    r.set_new_settings(dict(line_width=0.02, depth_cue_strength=0.5))
+    assert np.array_equal(r.render_frame(), img)
+    assert main([p, "-o", out, "--mode", "ppll", "--width", "64", "--height", "48", "line_width=0.03"]) == 0
+    assert np.array(Image.open(out)).shape == (48, 64, 4)
