@@ -572,6 +572,8 @@ __global__ __launch_bounds__(LV_BLOCK) void k_ppll_gather(const LvUniforms U, co
     __shared__ unsigned s_allocBase[LV_BLOCK / LV_WAVE], s_allocLeft[LV_BLOCK / LV_WAVE]; // per-wave chunk of node slots
     LV_COOP_SHARED(LV_BLOCK / LV_WAVE);
     LV_COOP_MEM(cm);
+    LV_HITQ_SHARED(LV_BLOCK / LV_WAVE);
+    LV_HITQ_MEM(hq);
     LvPixel px;
     const uint32_t slice = blockIdx.x % numSlices;
     if (!lv_block_pixel(U, T, px, blockIdx.x / numSlices)) return;
@@ -607,11 +609,11 @@ __global__ __launch_bounds__(LV_BLOCK) void k_ppll_gather(const LvUniforms U, co
     }
     const bool active = px.inView && lo < hi;
     if (STATS && active && slice != 0u && S.numSegs != 0) cnt.rays--;
-    // Fragments of a pixel are produced by whichever lane tests the (pixel, segment) pair: the lane shades with the
+    // Fragments of a pixel are produced by whichever lane is handed the (pixel, segment) hit: the lane shades with the
     // owner's ray + AO texel and links the node with an LDS atomic exchange on the owner's list head (the reference's
     // atomicExchange(startOffset[pixel]), LinkedListGather.glsl:55, kept in LDS until the slice is finished).
     lv_trace_all<STATS>(S, U.radius, U.useCappedTubes != 0, active, o, d, lo, hi, aoTexel, 0.0f,
-                        lv_stack_mem(s_stack, S.stackOverflow), cm, cnt,
+                        lv_stack_mem(s_stack, S.stackOverflow), cm, hq, cnt,
                         [&](unsigned owner, uint32_t leaf, float t, int kind, f3 ro, f3 rd, float ownerAo, float) {
         LvHit h; h.t = t; h.leaf = leaf; h.kind = kind; h.found = true;
         float hitT;

@@ -324,6 +324,23 @@ struct LvCoopMem {
     cm.queue = s_coopQueue[threadIdx.x >> 6];                    \
     cm.xchg = &s_coopXchg[LV_WAVE * (threadIdx.x >> 6)]
 
+// Per-wave queue of hits waiting to be shaded (all-hits routine): < 64 waiting + <= 64 new per test batch
+#define LV_HITQ_CAP 128u
+struct LvHitQueue {
+    unsigned* ref;   // (owner lane << 26) | leaf
+    float* t;
+    unsigned* kind;
+};
+#define LV_HITQ_SHARED(NWAVES)                                \
+    __shared__ unsigned s_hitRef[(NWAVES)][LV_HITQ_CAP];      \
+    __shared__ float s_hitT[(NWAVES)][LV_HITQ_CAP];           \
+    __shared__ unsigned s_hitKind[(NWAVES)][LV_HITQ_CAP]
+#define LV_HITQ_MEM(hq)                                       \
+    LvHitQueue hq;                                            \
+    hq.ref = s_hitRef[threadIdx.x >> 6];                      \
+    hq.t = s_hitT[threadIdx.x >> 6];                          \
+    hq.kind = s_hitKind[threadIdx.x >> 6]
+
 // Closest hit with reportIntersectionEXT semantics (accepted iff tMin <= t <= tMax; ties -> lowest original segment
 // index), computed by the whole wave together: EVERY lane of the wave must call this function in convergent control
 // flow, lanes without a ray pass active = false and only lend their ALUs.
@@ -467,7 +484,7 @@ __device__ __forceinline__ LvHit lv_trace_closest(const LvSceneDev& S, float rad
 template <bool STATS, typename F>
 __device__ __forceinline__ void lv_trace_all(const LvSceneDev& S, float radius, bool capped, bool active, f3 o, f3 d,
                                              float tMin, float tMax, float w0, float w1, const LvStackMem& sm,
-                                             const LvCoopMem& cm, LvCounters& cnt, F&& f) {
+                                             const LvCoopMem& cm, const LvHitQueue& hq, LvCounters& cnt, F&& f) {
     const unsigned lane = lv_lane();
     const unsigned long long below = (1ull << lane) - 1ull;
     active = active && S.numSegs != 0;
@@ -485,6 +502,21 @@ __device__ __forceinline__ void lv_trace_all(const LvSceneDev& S, float radius, 
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     unsigned cur = active ? 0u : LV_INVALID;
     unsigned head = 0, tail = 0;
+    unsigned hHead = 0, hTail = 0; // hit queue: hits wait here until 64 of them can be shaded at full width
+    auto shadeBatch = [&](unsigned n) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (lane < n) {
+            const unsigned i = (hHead + lane) % LV_HITQ_CAP;
+            const unsigned e = hq.ref[i];
+            const unsigned ow = e >> 26, leaf = e & 0x03FFFFFFu;
+            const float4 ro = cm.ray[2 * ow], rd = cm.ray[2 * ow + 1];
+            const unsigned long long pw = cm.key[ow];
+            f(ow, leaf, hq.t[i], int(hq.kind[i]), mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), __uint_as_float(unsigned(pw)),
+              __uint_as_float(unsigned(pw >> 32)));
+        }
+        hHead += n;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    };
     while (true) {
         const bool isLeaf = cur != LV_INVALID && (cur & LV_LEAF_BIT);
         const unsigned long long mL = __ballot(isLeaf);
@@ -501,6 +533,9 @@ __device__ __forceinline__ void lv_trace_all(const LvSceneDev& S, float radius, 
         if (q >= LV_WAVE || (q > 0 && nNode == 0)) {
             const unsigned n = q < LV_WAVE ? q : LV_WAVE;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            bool hit = false;
+            unsigned hitRef = 0, hitKind = 0;
+            float hitT = 0.0f;
             if (lane < n) {
                 const unsigned e = cm.queue[(head + lane) % LV_QCAP];
                 const unsigned ow = e >> 26, leaf = e & 0x03FFFFFFu;
@@ -510,14 +545,22 @@ __device__ __forceinline__ void lv_trace_all(const LvSceneDev& S, float radius, 
                 float t; int kind;
                 if (lv_intersect_capsule(mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), mk3(a.x, a.y, a.z),
                                          mk3(b.x, b.y, b.z), radius, capped, t, kind)) {
-                    if (t >= ro.w && t < rd.w) {
-                        const unsigned long long pw = cm.key[ow];
-                        f(ow, leaf, t, kind, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), __uint_as_float(unsigned(pw)),
-                          __uint_as_float(unsigned(pw >> 32)));
-                    }
+                    if (t >= ro.w && t < rd.w) { hit = true; hitRef = e; hitT = t; hitKind = unsigned(kind); }
                 }
             }
             head += n;
+            // hits are not shaded by the lane that found them: they queue up (ballot + prefix popcount) and are shaded 64
+            // at a time -- a test batch in front of sparse geometry yields a handful of hits, and shading (~700
+            // instructions with three pow) for a handful of lanes per batch was the critical path of the gather
+            const unsigned long long mH = __ballot(hit);
+            if (mH) {
+                if (hit) {
+                    const unsigned i = (hTail + unsigned(__popcll(mH & below))) % LV_HITQ_CAP;
+                    hq.ref[i] = hitRef; hq.t[i] = hitT; hq.kind[i] = hitKind;
+                }
+                hTail += unsigned(__popcll(mH));
+                if (hTail - hHead >= LV_WAVE) shadeBatch(LV_WAVE);
+            }
             continue;
         }
         if (nNode == 0) break;
@@ -564,6 +607,7 @@ __device__ __forceinline__ void lv_trace_all(const LvSceneDev& S, float radius, 
             nNow = __popcll(__ballot(!(cur & LV_LEAF_BIT)));
         } while (tail - head < LV_WAVE && nNow > LV_HANDOVER_MAX_BUSY);
     }
+    if (hTail != hHead) shadeBatch(hTail - hHead); // the rest (< 64)
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
 
