@@ -9,6 +9,10 @@
 //   k_ppll_gather       tube rasterisation + gatherFragment, Data/Shaders/Renderers/PPLL/LinkedListGather.glsl:33-72
 //   k_ppll_resolve      LinkedListResolve.Fragment + frontToBackPQ, LinkedListResolve.glsl:57-105, LinkedListSort.glsl:177-238
 //   k_depth_minmax      ComputeDepthValues.Compute + MinMaxReduce.Compute, Data/Shaders/DepthCues/*.glsl
+//   k_bake_setup        VulkanAmbientOcclusionBaker.Compute, line-point interpolation + ray origins (glsl:110-131,231-262);
+//                       its sample loop runs as the BAKE instantiation of k_ao_rays, the running mean in k_ao_reduce<true>
+// The triangle instantiations (LV_PRIM_TRIANGLE) of k_ao_primary / k_ao_rays / k_render_rt trace the reference's
+// triangle tubes (RTAO geometry, "Triangle Mesh" geometry mode: ClosestHitTubeTriangles, TubeRayTracing.glsl:301-352).
 // Host orchestration follows VulkanRayTracer::render (VulkanRayTracer.cpp:131-154), LineRenderer::renderBase
 // (LineRenderer.cpp:248-277) and PerPixelLinkedListLineRenderer::render (PerPixelLinkedListLineRenderer.cpp:399-427).
 #include <cmath>
