@@ -12,10 +12,10 @@
 //   k_leaves      32-byte segment records + leaf boxes written in Morton order
 //   k_karras      Karras 2012 topology: one thread per internal node
 //   k_refit       bottom-up AABB + height, second arriver continues (agent-scope release/acquire)
-//   k_depth       depth of every binary node (walk to the root)
-//   scan          rocPRIM exclusive scan over "even depth" flags -> index of each 4-wide node
-//   k_pack4       collapse two binary levels into one 64-byte compressed 4-wide node (8-bit child boxes + references)
+//   k_collapse_*  greedy area-guided collapse into 64-byte compressed 4-wide nodes (8-bit child boxes + references), one
+//                 BFS level of the wide tree per pass, rocPRIM exclusive scan for the deterministic node numbering
 #include <cstring>
+#include <utility>
 
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
@@ -234,17 +234,6 @@ __global__ __launch_bounds__(LV_BLOCK) void k_refit(int n, const uint32_t* __res
     }
 }
 
-// depth of every internal binary node: number of parent hops to the root
-__global__ __launch_bounds__(LV_BLOCK) void k_depth(int nInternal, const uint32_t* __restrict__ parentInternal,
-                                                    uint32_t* __restrict__ depth, uint32_t* __restrict__ evenFlag) {
-    int i = blockIdx.x * LV_BLOCK + threadIdx.x;
-    if (i >= nInternal) return;
-    uint32_t d = 0, p = parentInternal[i];
-    while (p != LV_INVALID) { d++; p = parentInternal[p]; }
-    depth[i] = d;
-    evenFlag[i] = (d & 1u) ? 0u : 1u;
-}
-
 // 64-byte COMPRESSED 4-wide node = 4 x float4 (one dwordx4 load each):
 //   q0 = {origin.x, origin.y, origin.z, scale.x}
 //   q1 = {scale.y, scale.z, qmin.x[4 bytes], qmin.y[4 bytes]}
@@ -256,44 +245,9 @@ __global__ __launch_bounds__(LV_BLOCK) void k_depth(int nInternal, const uint32_
 // Why: with divergent rays every lane of a wave reads a different node, and the vector L1 serves a divergent dwordx4
 // load at one lane per cycle -- the 7 loads of an uncompressed 4-wide node made k_ao_rays L1-bound (4.4 G cache
 // accesses = 7.1 of its 7.6 ms).  4 loads per node cut that by 43 % and halve the node footprint (L2 / MALL hit rate).
-// A wide node is a binary node of even depth together with its (odd-depth) internal children: its slots are the
-// grandchildren, or a child itself where that child is a leaf.
 __device__ __forceinline__ float lv_dec(float origin, float scale, uint32_t q) { return __builtin_fmaf(float(q), scale, origin); }
 
-__global__ __launch_bounds__(LV_BLOCK) void k_pack4(int nInternal, const uint32_t* __restrict__ childL,
-                                                    const uint32_t* __restrict__ childR, const float* __restrict__ leafBox,
-                                                    const float* __restrict__ nodeBox, const uint32_t* __restrict__ evenFlag,
-                                                    const uint32_t* __restrict__ wideIndex, float4* __restrict__ nodes) {
-    int i = blockIdx.x * LV_BLOCK + threadIdx.x;
-    if (i >= nInternal || !evenFlag[i]) return;
-    uint32_t slotRef[4] = {LV_INVALID, LV_INVALID, LV_INVALID, LV_INVALID};
-    float b[4][6];
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-#pragma unroll
-        for (int j = 0; j < 6; j++) b[k][j] = 0.0f;
-    int ns = 0;
-    auto addSlot = [&](uint32_t c) {
-        const float* src;
-        uint32_t ref;
-        if (c & LV_LEAF_BIT) { src = leafBox + 6 * size_t(c & ~LV_LEAF_BIT); ref = c; }
-        else { src = nodeBox + 6 * size_t(c); ref = wideIndex[c]; } // even-depth internal node -> its wide index
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-            if (k == ns) {
-                slotRef[k] = ref;
-#pragma unroll
-                for (int j = 0; j < 6; j++) b[k][j] = src[j];
-            }
-        ns++;
-    };
-    const uint32_t two[2] = {childL[i], childR[i]};
-#pragma unroll
-    for (int side = 0; side < 2; side++) {
-        const uint32_t c = two[side];
-        if (c & LV_LEAF_BIT) addSlot(c);
-        else { addSlot(childL[c]); addSlot(childR[c]); }
-    }
+__device__ __forceinline__ void lv_write_wide_node(float4* out, int ns, const uint32_t slotRef[4], const float b[4][6]) {
     // quantisation grid: origin = min over children, scale = extent / 255 rounded up
     float origin[3], scale[3];
     uint32_t qmin[3] = {0, 0, 0}, qmax[3] = {0, 0, 0}; // byte k = slot k
@@ -322,13 +276,101 @@ __global__ __launch_bounds__(LV_BLOCK) void k_pack4(int nInternal, const uint32_
         // q = 255 must still cover hi: widen the scale in the (rounding) case it does not
         while (lv_dec(lo, scale[a], 255u) < hi) scale[a] = scale[a] * 1.00001f + 1e-30f;
     }
-    float4* out = nodes + 4 * size_t(wideIndex[i]);
     out[0] = make_float4(origin[0], origin[1], origin[2], scale[0]);
     out[1] = make_float4(scale[1], scale[2], __uint_as_float(qmin[0]), __uint_as_float(qmin[1]));
     out[2] = make_float4(__uint_as_float(qmin[2]), __uint_as_float(qmax[0]), __uint_as_float(qmax[1]),
                          __uint_as_float(qmax[2]));
     out[3] = make_float4(__uint_as_float(slotRef[0]), __uint_as_float(slotRef[1]), __uint_as_float(slotRef[2]),
                          __uint_as_float(slotRef[3]));
+}
+
+// Collapse of the binary LBVH into 4-wide nodes, one BFS level of the WIDE tree per pass.  A wide node starts from the
+// two children of its binary root and greedily replaces the internal slot with the largest surface area by that node's
+// two children until four slots are filled (the standard SAH-guided collapse for wide BVHs): slots that are cheap to hit
+// are opened first, and -- unlike "two binary levels per wide node" -- almost every node ends up with four children,
+// so a node step's four box tests are rarely wasted on empty slots (1 M segments: 0.50 M -> 0.34 M nodes).
+//   k_collapse_select  frontier item i (a binary node) -> its <= 4 slots as binary references + the number of internal ones
+//   exclusive scan     -> position of each item's internal slots in the next frontier (deterministic BFS numbering)
+//   k_collapse_emit    writes the compressed node (index base + i) and the next frontier
+__device__ __forceinline__ float lv_box_half_area(const float* b) {
+    const float dx = b[3] - b[0], dy = b[4] - b[1], dz = b[5] - b[2];
+    return (dx * dy + dy * dz) + dz * dx;
+}
+
+__global__ __launch_bounds__(LV_BLOCK) void k_collapse_select(const uint32_t* __restrict__ frontier, uint32_t count,
+                                                              const uint32_t* __restrict__ childL,
+                                                              const uint32_t* __restrict__ childR,
+                                                              const float* __restrict__ nodeBox,
+                                                              uint32_t* __restrict__ slots,
+                                                              uint32_t* __restrict__ internalCount) {
+    const uint32_t i = blockIdx.x * LV_BLOCK + threadIdx.x;
+    if (i >= count) return;
+    const uint32_t r = frontier[i];
+    uint32_t s0 = childL[r], s1 = childR[r], s2 = LV_INVALID, s3 = LV_INVALID;
+    int ns = 2;
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+        // internal slot with the largest area (first one on ties)
+        float best = -1.0f;
+        int bk = -1;
+        const uint32_t cur[4] = {s0, s1, s2, s3};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (k < ns && !(cur[k] & LV_LEAF_BIT)) {
+                const float a = lv_box_half_area(nodeBox + 6 * size_t(cur[k]));
+                if (a > best) { best = a; bk = k; }
+            }
+        }
+        if (bk < 0) break;
+        const uint32_t c = bk == 0 ? s0 : (bk == 1 ? s1 : s2); // bk < ns <= 3 here
+        const uint32_t cl = childL[c], cr = childR[c];
+        if (bk == 0) s0 = cl; else if (bk == 1) s1 = cl; else s2 = cl;
+        if (ns == 2) s2 = cr; else s3 = cr;
+        ns++;
+    }
+    slots[4 * size_t(i) + 0] = s0; slots[4 * size_t(i) + 1] = s1; slots[4 * size_t(i) + 2] = s2; slots[4 * size_t(i) + 3] = s3;
+    uint32_t ni = 0;
+    if (!(s0 & LV_LEAF_BIT)) ni++;
+    if (!(s1 & LV_LEAF_BIT)) ni++;
+    if (s2 != LV_INVALID && !(s2 & LV_LEAF_BIT)) ni++;
+    if (s3 != LV_INVALID && !(s3 & LV_LEAF_BIT)) ni++;
+    internalCount[i] = ni;
+}
+
+__global__ __launch_bounds__(LV_BLOCK) void k_collapse_emit(uint32_t count, uint32_t base, uint32_t nextBase,
+                                                            const uint32_t* __restrict__ slots,
+                                                            const uint32_t* __restrict__ offsets,
+                                                            const float* __restrict__ leafBox,
+                                                            const float* __restrict__ nodeBox,
+                                                            uint32_t* __restrict__ nextFrontier, float4* __restrict__ nodes) {
+    const uint32_t i = blockIdx.x * LV_BLOCK + threadIdx.x;
+    if (i >= count) return;
+    uint32_t slotRef[4];
+    float b[4][6];
+    int ns = 0;
+    uint32_t j = offsets[i];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t c = slots[4 * size_t(i) + k];
+        slotRef[k] = LV_INVALID;
+#pragma unroll
+        for (int a = 0; a < 6; a++) b[k][a] = 0.0f;
+        if (c == LV_INVALID) continue; // slots are filled from the front: ns == k here
+        const float* src;
+        if (c & LV_LEAF_BIT) {
+            src = leafBox + 6 * size_t(c & ~LV_LEAF_BIT);
+            slotRef[k] = c;
+        } else {
+            src = nodeBox + 6 * size_t(c);
+            nextFrontier[j] = c;
+            slotRef[k] = nextBase + j;
+            j++;
+        }
+#pragma unroll
+        for (int a = 0; a < 6; a++) b[k][a] = src[a];
+        ns = k + 1;
+    }
+    lv_write_wide_node(nodes + 4 * size_t(base + i), ns, slotRef, b);
 }
 
 // single-segment scene: one node with one occupied slot
@@ -355,19 +397,20 @@ inline uint32_t nblocks(uint64_t n) { return uint32_t((n + LV_BLOCK - 1) / LV_BL
 // same for capsules and triangles.
 template <class BOXES, class LEAVES>
 static int lv_bvh_build_core(lv_ctx* ctx, uint32_t n, LvDeviceBuffer& nodesOut, uint32_t& numNodesOut, uint32_t& depthOut,
-                             bool timed, BOXES&& boxes, LEAVES&& leaves) {
+                             uint32_t& wideDepthOut, bool timed, BOXES&& boxes, LEAVES&& leaves) {
     hipStream_t st = ctx->stream;
     const uint32_t nInternal = n > 1 ? n - 1 : 1;
+    uint32_t numWide = 1, wideLevels = 0;
     int rc;
     // 4-wide nodes: one per even-depth binary node; at most all of them (a degenerate chain has ~n/2)
     if ((rc = lv_buf_reserve(ctx, nodesOut, size_t(nInternal) * 64))) return rc;
 
     // temporaries
     LvDeviceBuffer boxOrig, leafBox, nodeBox, keysA, keysB, valsA, valsB, childL, childR, parI, parL, height, flags, bounds,
-            sortTmp, depth, evenFlag, wideIndex;
+            sortTmp, depth, evenFlag, wideIndex, slots;
     auto freeAll = [&]() {
         for (LvDeviceBuffer* b : {&boxOrig, &leafBox, &nodeBox, &keysA, &keysB, &valsA, &valsB, &childL, &childR, &parI,
-                                  &parL, &height, &flags, &bounds, &sortTmp, &depth, &evenFlag, &wideIndex})
+                                  &parL, &height, &flags, &bounds, &sortTmp, &depth, &evenFlag, &wideIndex, &slots})
             lv_buf_free(*b);
     };
 #define LV_TRY(expr)                 \
@@ -401,6 +444,7 @@ static int lv_bvh_build_core(lv_ctx* ctx, uint32_t n, LvDeviceBuffer& nodesOut, 
     LV_TRY(lv_buf_reserve(ctx, depth, size_t(nInternal) * 4));
     LV_TRY(lv_buf_reserve(ctx, evenFlag, size_t(nInternal) * 4));
     LV_TRY(lv_buf_reserve(ctx, wideIndex, size_t(nInternal) * 4));
+    LV_TRY(lv_buf_reserve(ctx, slots, size_t(nInternal) * 16));
 
     if (timed) LV_HIPF(hipEventRecord(ctx->ev[0], st));
     // bounds: min slots start at ord(+big) = 0xFFFFFFFF-ish, max slots at 0
@@ -432,33 +476,50 @@ static int lv_bvh_build_core(lv_ctx* ctx, uint32_t n, LvDeviceBuffer& nodesOut, 
                                                  (const uint32_t*)parI.ptr, (const uint32_t*)parL.ptr,
                                                  (const float*)leafBox.ptr, (float*)nodeBox.ptr, (uint32_t*)height.ptr,
                                                  (uint32_t*)flags.ptr);
-        k_depth<<<nblocks(nInternal), LV_BLOCK, 0, st>>>(int(nInternal), (const uint32_t*)parI.ptr, (uint32_t*)depth.ptr,
-                                                         (uint32_t*)evenFlag.ptr);
+        // collapse: one pass per BFS level of the wide tree (see k_collapse_select)
         {
-            size_t tmpBytes = 0;
-            LV_HIPF(rocprim::exclusive_scan(nullptr, tmpBytes, (uint32_t*)evenFlag.ptr, (uint32_t*)wideIndex.ptr, 0u,
-                                            nInternal, rocprim::plus<uint32_t>(), st));
-            LV_TRY(lv_buf_reserve(ctx, sortTmp, tmpBytes ? tmpBytes : 16));
-            LV_HIPF(rocprim::exclusive_scan(sortTmp.ptr, tmpBytes, (uint32_t*)evenFlag.ptr, (uint32_t*)wideIndex.ptr, 0u,
-                                            nInternal, rocprim::plus<uint32_t>(), st));
+            uint32_t zero = 0u;
+            LV_HIPF(hipMemcpyAsync(depth.ptr, &zero, 4, hipMemcpyHostToDevice, st)); // frontier A = {root}
+            LV_HIPF(hipStreamSynchronize(st));
+            uint32_t* frontier = (uint32_t*)depth.ptr;
+            uint32_t* nextFrontier = (uint32_t*)evenFlag.ptr;
+            uint32_t count = 1, base = 0;
+            size_t scanBytes = 0;
+            LV_HIPF(rocprim::exclusive_scan(nullptr, scanBytes, (uint32_t*)wideIndex.ptr, (uint32_t*)flags.ptr, 0u, nInternal,
+                                            rocprim::plus<uint32_t>(), st));
+            LV_TRY(lv_buf_reserve(ctx, sortTmp, scanBytes ? scanBytes : 16));
+            while (count > 0) {
+                k_collapse_select<<<nblocks(count), LV_BLOCK, 0, st>>>(frontier, count, (const uint32_t*)childL.ptr,
+                                                                       (const uint32_t*)childR.ptr, (const float*)nodeBox.ptr,
+                                                                       (uint32_t*)slots.ptr, (uint32_t*)wideIndex.ptr);
+                size_t tb = scanBytes;
+                LV_HIPF(rocprim::exclusive_scan(sortTmp.ptr, tb, (uint32_t*)wideIndex.ptr, (uint32_t*)flags.ptr, 0u, count,
+                                                rocprim::plus<uint32_t>(), st));
+                k_collapse_emit<<<nblocks(count), LV_BLOCK, 0, st>>>(count, base, base + count, (const uint32_t*)slots.ptr,
+                                                                     (const uint32_t*)flags.ptr, (const float*)leafBox.ptr,
+                                                                     (const float*)nodeBox.ptr, nextFrontier,
+                                                                     (float4*)nodesOut.ptr);
+                uint32_t lastOff = 0, lastCnt = 0;
+                LV_HIPF(hipMemcpyAsync(&lastOff, (const uint32_t*)flags.ptr + (count - 1), 4, hipMemcpyDeviceToHost, st));
+                LV_HIPF(hipMemcpyAsync(&lastCnt, (const uint32_t*)wideIndex.ptr + (count - 1), 4, hipMemcpyDeviceToHost, st));
+                LV_HIPF(hipStreamSynchronize(st));
+                base += count;
+                count = lastOff + lastCnt;
+                std::swap(frontier, nextFrontier);
+                wideLevels++;
+            }
+            numWide = base;
         }
-        k_pack4<<<nblocks(nInternal), LV_BLOCK, 0, st>>>(int(nInternal), (const uint32_t*)childL.ptr,
-                                                         (const uint32_t*)childR.ptr, (const float*)leafBox.ptr,
-                                                         (const float*)nodeBox.ptr, (const uint32_t*)evenFlag.ptr,
-                                                         (const uint32_t*)wideIndex.ptr, (float4*)nodesOut.ptr);
     }
     LV_HIPF(hipGetLastError());
     if (timed) LV_HIPF(hipEventRecord(ctx->ev[1], st));
-    uint32_t numWide = 1;
     depthOut = 1;
+    wideDepthOut = wideLevels ? wideLevels : 1u;
     if (n > 1) {
-        uint32_t h = 0, lastIdx = 0, lastFlag = 0;
+        uint32_t h = 0;
         LV_HIPF(hipMemcpyAsync(&h, height.ptr, 4, hipMemcpyDeviceToHost, st));
-        LV_HIPF(hipMemcpyAsync(&lastIdx, (const uint32_t*)wideIndex.ptr + (nInternal - 1), 4, hipMemcpyDeviceToHost, st));
-        LV_HIPF(hipMemcpyAsync(&lastFlag, (const uint32_t*)evenFlag.ptr + (nInternal - 1), 4, hipMemcpyDeviceToHost, st));
         LV_HIPF(hipStreamSynchronize(st));
-        depthOut = h;                 // height of the binary LBVH; the 4-wide tree is ceil(h / 2) levels high
-        numWide = lastIdx + lastFlag;
+        depthOut = h;                 // height of the binary LBVH (reported); the traversal stack is sized by wideDepthOut
     } else {
         LV_HIPF(hipStreamSynchronize(st));
     }
@@ -489,7 +550,7 @@ int lv_bvh_build(lv_ctx* ctx) {
     const lv_line_point* points = (const lv_line_point*)ctx->points.ptr;
     const uint32_t* segIdx = (const uint32_t*)ctx->segIdx.ptr;
     rc = lv_bvh_build_core(
-            ctx, n, ctx->nodes, ctx->numNodes, ctx->bvhDepth, true,
+            ctx, n, ctx->nodes, ctx->numNodes, ctx->bvhDepth, ctx->wideDepth, true,
             [&](float* boxOrig, uint32_t* bounds) {
                 k_seg_boxes<<<nblocks(n), LV_BLOCK, 0, st>>>(points, segIdx, n, radius, pad, boxOrig, bounds);
             },
@@ -526,7 +587,7 @@ int lv_bvh_build_triangles(lv_ctx* ctx) {
     const uint32_t* triIdx = (const uint32_t*)ctx->triIdx.ptr;
     const float pad = ctx->triPad;
     rc = lv_bvh_build_core(
-            ctx, n, ctx->triNodes, ctx->numTriNodes, ctx->triBvhDepth, false,
+            ctx, n, ctx->triNodes, ctx->numTriNodes, ctx->triBvhDepth, ctx->triWideDepth, false,
             [&](float* boxOrig, uint32_t* bounds) {
                 k_tri_boxes<<<nblocks(n), LV_BLOCK, 0, st>>>(verts, triIdx, n, pad, boxOrig, bounds);
             },

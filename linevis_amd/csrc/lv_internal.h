@@ -63,9 +63,9 @@ struct lv_ctx {
     float attrMin = 0.0f, attrMax = 1.0f;
     bool accelValid = false;
     float accelLineWidth = -1.0f;
-    uint32_t bvhDepth = 0;
+    uint32_t bvhDepth = 0, wideDepth = 0;     // height of the binary LBVH (reported) / levels of the 4-wide tree (stack size)
     // triangle tubes (RTAO geometry of the reference), own LBVH
-    uint32_t numTris = 0, numTriVerts = 0, numTriPoints = 0, numTriNodes = 0, triBvhDepth = 0;
+    uint32_t numTris = 0, numTriVerts = 0, numTriPoints = 0, numTriNodes = 0, triBvhDepth = 0, triWideDepth = 0;
     LvDeviceBuffer triIdx, triVerts, triPoints; // input order
     LvDeviceBuffer triNodes, tris;              // accel
     bool triMeshSet = false, triAccelValid = false;

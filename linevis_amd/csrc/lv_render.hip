@@ -991,8 +991,8 @@ int lv_frame_depth_range(lv_ctx* ctx) {
 static int lv_prepare_overflow(lv_ctx* ctx, LvSceneDev& S, uint64_t gridBlocks, uint32_t ldsEntries = LV_STACK_LDS,
                                bool triangles = false) {
     S.stackOverflow = nullptr;
-    // the 4-wide tree is ceil(height / 2) levels high and a step pushes at most 3 references
-    const uint64_t maxEntries = 3ull * ((uint64_t(triangles ? ctx->triBvhDepth : ctx->bvhDepth) + 1) / 2) + 2;
+    // a step of the 4-wide tree pushes at most 3 references per level
+    const uint64_t maxEntries = 3ull * uint64_t(triangles ? ctx->triWideDepth : ctx->wideDepth) + 2;
     if (maxEntries <= ldsEntries) return LV_OK;
     const uint64_t extra = maxEntries - ldsEntries;
     int rc = lv_buf_reserve(ctx, ctx->stackOverflow, size_t(gridBlocks) * LV_BLOCK * extra * 4);
