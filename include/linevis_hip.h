@@ -163,6 +163,8 @@ int lv_set_background(lv_ctx* ctx, const float rgba[4]);
  *   use_deterministic_sampling, geometry_mode ("AABBs (analytic)" = ray-capsule, default | "Triangle Mesh" = the tube
  *   mesh set with lv_set_tube_triangle_mesh), use_analytic_intersections (bool form of the same switch)
  *                                                                       (VulkanRayTracer.cpp:226-278)
+ *   use_mlat (multi-layer alpha tracing instead of the transparency loop; analytic tubes only), mlat_num_nodes
+ *   (power of two in [1, 32], default 8)                                (VulkanRayTracer.cpp:266-275, .hpp:133-134)
  *   use_capped_tubes, use_halos, tube_num_subdivisions                  (LineData.cpp:87-181)
  *   max_depth_complexity                                                (VulkanRayTracer.hpp:139)
  *   ppll_max_num_frags, ppll_expected_avg_depth_complexity, ppll_tile_width, ppll_tile_height
@@ -170,7 +172,8 @@ int lv_set_background(lv_ctx* ctx, const float rgba[4]);
  *   rtao_prebaker_iterations (128), rtao_prebaker_samples_per_frame (4), rtao_prebaker_num_tube_subdivisions (8): the
  *   prebaker's settings, GUI-only in the reference (VulkanAmbientOcclusionBaker.hpp:108,165-166); radius / distance
  *   based use the ambient_occlusion_* keys,
- *   collect_stats (build-owned: run the instrumented kernels),
+ *   collect_stats (build-owned: run the instrumented kernels), mlat_record_trace / mlat_trace_capacity (build-owned,
+ *   with collect_stats: record the candidate visiting order of an MLAT frame for lv_get_mlat_trace; records, 4 Mi),
  *   rtao_geometry (build-owned): "capsules" (default: AO rays hit the analytic capsules of the colour pass) or
  *   "triangle_tubes" (the reference's RTAO geometry: the mesh set with lv_set_tube_triangle_mesh). */
 int lv_set_option(lv_ctx* ctx, const char* key, const char* value);
@@ -237,6 +240,13 @@ int lv_trace_rays_triangles(lv_ctx* ctx, const float* origins, const float* dirs
 int lv_compute_depth_range(lv_ctx* ctx, float out_min_max[2]);
 /* Full-viewport RTAO texture (.x channel of the RGBA32F accumulation image) after the last mode-11/2 render. */
 int lv_get_ao(lv_ctx* ctx, float* out /* viewport_width * viewport_height */);
+/* MLAT (use_mlat) parity instrument: the order in which every pixel's candidates were handed to insertNodeMlat in the
+ * last mode-11 render (options collect_stats + mlat_record_trace).  4 uint32 per record {viewport pixel index y * W + x,
+ * sequence number within the pixel, original segment index, flag: 0 = inserted, 1 = dropped because an accepted hit had
+ * already shortened the ray interval}; records arrive in no particular order.  The reference's own order is the driver's
+ * BVH traversal order (undefined); a CPU replay of THIS order must reproduce the frame.  out_records may be NULL
+ * (query the count). */
+int lv_get_mlat_trace(lv_ctx* ctx, uint32_t* out_records, uint64_t max_records, uint64_t* out_count);
 /* PPLL buffers after the last mode-2 render: nodes = 3 uint32 {rgba8, depth bits, next} per node slot (slots are handed
  * out to waves in chunks, so unreferenced slots may lie between the stored fragments), start_offset = padded_w * padded_h
  * heads (0xFFFFFFFF = empty), frag_counter = number of fragments generated.  Either pointer may be NULL. */

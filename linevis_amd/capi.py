@@ -83,7 +83,7 @@ SYMBOLS = ["lv_create", "lv_destroy", "lv_last_error", "lv_version", "lv_set_str
            "lv_render", "lv_render_device", "lv_render_tiles_device", "lv_get_stats", "lv_reset_timers", "lv_trace_rays",
            "lv_compute_depth_range", "lv_get_ao", "lv_ppll_get_buffers", "lv_ppll_resolve_buffers", "lv_get_accel",
            "lv_set_tube_triangle_mesh", "lv_trace_rays_triangles", "lv_set_flow_grid", "lv_trace_streamlines",
-           "lv_get_streamlines", "lv_set_ao_parametrization", "lv_get_baked_ao"]
+           "lv_get_streamlines", "lv_set_ao_parametrization", "lv_get_baked_ao", "lv_get_mlat_trace"]
 
 _lib = None
 
@@ -141,6 +141,7 @@ def load():
         ("lv_get_streamlines", [vp, vp, vp, vp]),
         ("lv_set_ao_parametrization", [vp, vp, u32, vp, u32]),
         ("lv_get_baked_ao", [vp, vp, u64]),
+        ("lv_get_mlat_trace", [vp, vp, u64, C.POINTER(u64)]),
     ]:
         fn = getattr(L, name)
         fn.restype = i32
@@ -308,6 +309,15 @@ class Context:
         out = np.empty((self.height, self.width), dtype=np.float32)
         self._ck(self.L.lv_get_ao(self.h, _p(out)))
         return out
+
+    def mlat_trace(self):
+        """Candidate visiting order of the last MLAT frame (collect_stats + mlat_record_trace): (n, 4) uint32 records
+        {pixel index y * W + x, sequence number, segment, flag 0 = inserted / 1 = dropped (interval already shorter)}."""
+        cnt = C.c_uint64()
+        self._ck(self.L.lv_get_mlat_trace(self.h, None, 0, C.byref(cnt)))
+        rec = np.zeros((max(int(cnt.value), 1), 4), dtype=np.uint32)
+        self._ck(self.L.lv_get_mlat_trace(self.h, _p(rec), rec.shape[0], C.byref(cnt)))
+        return rec[:int(cnt.value)]
 
     def ppll_buffers(self, padded_pixels, max_nodes):
         nodes = np.zeros((max_nodes, 3), dtype=np.uint32)

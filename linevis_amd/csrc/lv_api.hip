@@ -85,13 +85,7 @@ void lv_mat4_inverse(const float* m, float* inv) {
 
 namespace {
 
-struct LvDevCountersHost { // must match LvDevCounters in lv_render.hip
-    unsigned long long rays, nodes, prims, hits;
-    unsigned long long aoRays, aoNodes, aoPrims;
-    unsigned long long aoQueueHead;
-    unsigned long long aoPhaseIters[3], aoPhaseLanes[3];
-    uint32_t fragCounter, aoCount, maxDepthComplexity, depthOrd[2], maxNodesPerPixel, fragAlloc;
-};
+typedef LvDevCounters LvDevCountersHost;
 
 bool parseBool(const char* v) { return strcmp(v, "true") == 0 || strcmp(v, "1") == 0; } // InternalState.hpp:64-71
 
@@ -175,7 +169,7 @@ void lv_destroy(lv_ctx* ctx) {
                               &ctx->scratchRays, &ctx->stackOverflow, &ctx->triIdx, &ctx->triVerts, &ctx->triPoints,
                               &ctx->triNodes, &ctx->tris, &ctx->flowVectors, &ctx->flowScalars, &ctx->flowMisc,
                               &ctx->flowSeeds, &ctx->flowOutPos, &ctx->flowOutAtt, &ctx->flowCounts, &ctx->bakeBlendingWeights,
-                              &ctx->bakeSamplingLocations, &ctx->bakedAo, &ctx->bakeLcgSkip})
+                              &ctx->bakeSamplingLocations, &ctx->bakedAo, &ctx->bakeLcgSkip, &ctx->mlatTrace})
         lv_buf_free(*b);
     if (ctx->evCreated) {
         for (int i = 0; i < 16; i++) (void)hipEventDestroy(ctx->ev[i]);
@@ -421,7 +415,16 @@ int lv_set_option(lv_ctx* ctx, const char* key, const char* value) {
         else
             return lv_fail(ctx, LV_E_INVALID, "geometry_mode '%s' is not provided (Triangle Mesh | AABBs (analytic))", value);
     } else if (k == "use_mlat") {
-        if (parseBool(value)) return lv_fail(ctx, LV_E_INVALID, "MLAT is not implemented yet (SURVEY.md §8f)");
+        o.useMlat = parseBool(value); // VulkanRayTracer.cpp:266-270
+    } else if (k == "mlat_num_nodes") {
+        // addSliderIntPowerOfTwo("#MLAT Nodes", 1, 32), VulkanRayTracer.cpp:218
+        if (!parseUint(value, u) || u == 0 || u > 32 || (u & (u - 1)) != 0) return bad();
+        o.mlatNumNodes = u;
+    } else if (k == "mlat_record_trace") {
+        o.mlatRecordTrace = parseBool(value);
+    } else if (k == "mlat_trace_capacity") {
+        if (!parseUint(value, u) || u == 0 || u > (1u << 28)) return bad();
+        o.mlatTraceCapacity = u;
     } else if (k == "max_depth_complexity") {
         if (!parseUint(value, u) || u == 0) return bad();
         o.maxDepthComplexity = u;
@@ -664,6 +667,29 @@ int lv_ppll_get_buffers(lv_ctx* ctx, uint32_t* out_nodes, uint64_t max_nodes, ui
         if (max_pixels < np) return lv_fail(ctx, LV_E_CAPACITY, "out_start_offset holds %llu entries, need %llu",
                                             (unsigned long long)max_pixels, (unsigned long long)np);
         LV_HIP(ctx, hipMemcpy(out_start, ctx->ppllStart.ptr, size_t(np) * 4, hipMemcpyDeviceToHost));
+    }
+    return LV_OK;
+}
+
+int lv_get_mlat_trace(lv_ctx* ctx, uint32_t* out_records, uint64_t max_records, uint64_t* out_count) {
+    if (!ctx) return LV_E_INVALID;
+    if (!ctx->mlatTrace.ptr || !ctx->counters.ptr || ctx->lastMode != LV_RENDERING_MODE_VULKAN_RAY_TRACER ||
+        !ctx->opt.useMlat || !ctx->opt.collectStats || !ctx->opt.mlatRecordTrace)
+        return lv_fail(ctx, LV_E_STATE, "no MLAT trace (render mode 11 with use_mlat, collect_stats and mlat_record_trace first)");
+    (void)hipSetDevice(ctx->device);
+    LV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    LvDevCountersHost hc;
+    LV_HIP(ctx, hipMemcpy(&hc, ctx->counters.ptr, sizeof(hc), hipMemcpyDeviceToHost));
+    if (out_count) *out_count = hc.mlatTraceCount;
+    if (hc.mlatTraceCount > ctx->opt.mlatTraceCapacity)
+        return lv_fail(ctx, LV_E_CAPACITY, "the frame produced %u trace records, mlat_trace_capacity is %u", hc.mlatTraceCount,
+                       ctx->opt.mlatTraceCapacity);
+    if (out_records) {
+        if (max_records < hc.mlatTraceCount)
+            return lv_fail(ctx, LV_E_CAPACITY, "out_records holds %llu records, %u stored", (unsigned long long)max_records,
+                           hc.mlatTraceCount);
+        if (hc.mlatTraceCount)
+            LV_HIP(ctx, hipMemcpy(out_records, ctx->mlatTrace.ptr, size_t(hc.mlatTraceCount) * 16, hipMemcpyDeviceToHost));
     }
     return LV_OK;
 }

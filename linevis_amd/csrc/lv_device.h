@@ -50,6 +50,21 @@
 #define LV_PPLL_SLICES 2        // depth slices per pixel block in k_ppll_gather (workgroups = pixel blocks x slices)
 #endif
 
+// device-side counters block of a frame (read back by lv_get_stats / lv_ppll_get_buffers)
+struct LvDevCounters {
+    unsigned long long rays, nodes, prims, hits;
+    unsigned long long aoRays, aoNodes, aoPrims; // share of k_ao_rays
+    unsigned long long aoQueueHead;              // next AO ray index handed to the persistent waves
+    unsigned long long aoPhaseIters[3], aoPhaseLanes[3]; // {setup, node, leaf}: wave iterations / active lanes
+    uint32_t fragCounter;
+    uint32_t aoCount;
+    uint32_t maxDepthComplexity;
+    uint32_t depthOrd[2]; // encoded min / max for the depth-range reduction
+    uint32_t maxNodesPerPixel;
+    uint32_t fragAlloc;   // PPLL node-slot allocator (chunks); fragCounter stays the exact fragment count
+    uint32_t mlatTraceCount; // records appended to the MLAT visiting-order trace (collect_stats)
+};
+
 struct f3 { float x, y, z; };
 struct f4 { float x, y, z, w; };
 

@@ -45,6 +45,10 @@ struct LvOptions {
     uint32_t bakeSamplesPerFrame = 4;         // :166 (radius / distance-based share the RTAO keys; same defaults :167-168)
     bool rtTriangleMesh = false;              // geometry_mode "Triangle Mesh" / use_analytic_intersections=false (VulkanRayTracer.cpp:226-250)
     bool aoTriangleTubes = false;             // rtao_geometry: false = capsules (build default), true = the reference's triangle tubes
+    bool useMlat = false;                     // VulkanRayTracer.hpp:133
+    uint32_t mlatNumNodes = 8;                // :134
+    bool mlatRecordTrace = false;             // with collect_stats: record every pixel's candidate visiting order
+    uint32_t mlatTraceCapacity = 1u << 22;    // records (16 B each)
 };
 
 struct lv_ctx {
@@ -100,7 +104,7 @@ struct lv_ctx {
     LvDeviceBuffer aoGbuf, aoList, aoSamples; // RTAO wavefront buffers
     LvDeviceBuffer counters;                  // device counters (LvCounters + misc)
     LvDeviceBuffer ppllNodes, ppllStart, ppllCount, ppllScratch;
-    LvDeviceBuffer tilesDev, outDev, scratchRays, stackOverflow;
+    LvDeviceBuffer tilesDev, outDev, scratchRays, stackOverflow, mlatTrace;
     std::vector<uint32_t> tilesHost;          // staging copy: caller's tile list is borrowed for the call only
     bool tilesUploaded = false;               // tilesDev holds tilesHost
     uint64_t ppllPoolNodes = 0;
@@ -144,6 +148,12 @@ void lv_buf_free(LvDeviceBuffer& b);
 // lv_bvh.hip
 int lv_bvh_build(lv_ctx* ctx);
 int lv_bvh_build_triangles(lv_ctx* ctx);
+// lv_mlat.hip
+struct LvUniforms;
+struct LvSceneDev;
+struct LvTiles;
+int lv_mlat_render(lv_ctx* ctx, const LvUniforms& U, const LvSceneDev& S, const LvTiles& T, uint32_t gridTiles,
+                   uint32_t* out, LvDevCounters* dc);
 // lv_render.hip
 int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t numTiles, uint32_t tileW,
                     uint32_t tileH, void* outDevice);

@@ -20,80 +20,9 @@
 
 #include "lv_internal.h"
 #include "lv_trace.h"
+#include "lv_tile.h"
 
 namespace {
-
-// device-side counters block
-struct LvDevCounters {
-    unsigned long long rays, nodes, prims, hits;
-    unsigned long long aoRays, aoNodes, aoPrims; // share of k_ao_rays
-    unsigned long long aoQueueHead;              // next AO ray index handed to the persistent waves
-    unsigned long long aoPhaseIters[3], aoPhaseLanes[3]; // {setup, node, leaf}: wave iterations / active lanes
-    uint32_t fragCounter;
-    uint32_t aoCount;
-    uint32_t maxDepthComplexity;
-    uint32_t depthOrd[2]; // encoded min / max for the depth-range reduction
-    uint32_t maxNodesPerPixel;
-    uint32_t fragAlloc;   // PPLL node-slot allocator (chunks); fragCounter stays the exact fragment count
-};
-
-__device__ __forceinline__ void lv_flush_max_nodes(const LvCounters& c, LvDevCounters* dc) {
-    uint32_t m = uint32_t(c.nodes);
-#pragma unroll
-    for (int ofs = 32; ofs > 0; ofs >>= 1) m = max(m, (uint32_t)__shfl_xor(m, ofs, 64));
-    if (lv_lane() == 0) atomicMax(&dc->maxNodesPerPixel, m);
-}
-__device__ __forceinline__ void lv_flush_counters(const LvCounters& c, LvDevCounters* dc, bool aoRays = false) {
-    unsigned long long r = lv_wave_sum_u64(c.rays), n = lv_wave_sum_u64(c.nodes), p = lv_wave_sum_u64(c.prims),
-                       h = lv_wave_sum_u64(c.hits);
-    if (lv_lane() == 0) {
-        atomicAdd(&dc->rays, r);
-        atomicAdd(&dc->nodes, n);
-        atomicAdd(&dc->prims, p);
-        atomicAdd(&dc->hits, h);
-        if (aoRays) {
-            atomicAdd(&dc->aoRays, r);
-            atomicAdd(&dc->aoNodes, n);
-            atomicAdd(&dc->aoPrims, p);
-        }
-    }
-}
-
-// Pixel of this thread.  A workgroup covers a 16x16 pixel block of one tile; each wave an 8x8 sub-block, so a
-// wave's primary rays stay coherent.  The dispatcher deals workgroups to the 8 XCDs round-robin (block b -> XCD
-// b % 8, each with a private L2).  Blocks are regrouped so that runs of LV_XCD_GROUP consecutive logical blocks (one
-// 64x64 tile = 16 blocks) land on the same XCD, and consecutive groups go to consecutive XCDs: spatial neighbours share
-// an L2 while every XCD still gets an even share of the dense and the empty parts of the picture (a contiguous 1/8
-// of the frame per XCD left 7 XCDs idle behind the one that owned the centre).  Speed only; never correctness.
-#define LV_XCD_GROUP 16u
-struct LvPixel {
-    uint32_t x, y;       // viewport pixel
-    uint32_t outIndex;   // index into the tile-major output
-    bool inTile, inView;
-};
-
-__device__ __forceinline__ bool lv_block_pixel(const LvUniforms& U, const LvTiles& T, LvPixel& p, uint32_t blockId) {
-    const uint32_t blocksPerTile = T.blocksX * T.blocksY;
-    const uint32_t nb = T.numTiles * blocksPerTile;
-    const uint32_t xcd = blockId % 8u, j = blockId / 8u;   // j-th block this XCD receives
-    const uint32_t b = ((j / LV_XCD_GROUP) * 8u + xcd) * LV_XCD_GROUP + (j % LV_XCD_GROUP);
-    if (b >= nb) { p.inTile = false; p.inView = false; return false; }
-    const uint32_t tile = b / blocksPerTile, rem = b % blocksPerTile;
-    const uint32_t by = rem / T.blocksX, bx = rem % T.blocksX;
-    const uint32_t w = threadIdx.x >> 6, l = threadIdx.x & 63u;
-    const uint32_t lx = bx * 16u + (w & 1u) * 8u + (l & 7u);
-    const uint32_t ly = by * 16u + (w >> 1) * 8u + (l >> 3);
-    p.inTile = lx < T.tileW && ly < T.tileH;
-    p.x = T.tilesXY[2 * tile] + lx;
-    p.y = T.tilesXY[2 * tile + 1] + ly;
-    p.inView = p.inTile && p.x < U.width && p.y < U.height;
-    p.outIndex = (tile * T.tileH + ly) * T.tileW + lx;
-    return true;
-}
-
-__device__ __forceinline__ bool lv_block_pixel(const LvUniforms& U, const LvTiles& T, LvPixel& p) {
-    return lv_block_pixel(U, T, p, blockIdx.x);
-}
 
 // ================================================================ ray tracer colour pass
 // Control flow is wave-uniform around every trace (lv_trace_closest is a wave-cooperative routine): the sample loop and
@@ -616,7 +545,7 @@ __global__ __launch_bounds__(LV_BLOCK) void k_ppll_gather(const LvUniforms U, co
     // Fragments of a pixel are produced by whichever lane is handed the (pixel, segment) hit: the lane shades with the
     // owner's ray + AO texel and links the node with an LDS atomic exchange on the owner's list head (the reference's
     // atomicExchange(startOffset[pixel]), LinkedListGather.glsl:55, kept in LDS until the slice is finished).
-    lv_trace_all<STATS>(S, U.radius, U.useCappedTubes != 0, active, o, d, lo, hi, aoTexel, 0.0f,
+    lv_trace_all<STATS, false>(S, U.radius, U.useCappedTubes != 0, active, o, d, lo, hi, aoTexel, 0.0f,
                         lv_stack_mem(s_stack, S.stackOverflow), cm, hq, cnt,
                         [&](unsigned owner, uint32_t leaf, float t, int kind, f3 ro, f3 rd, float ownerAo, float) {
         LvHit h; h.t = t; h.leaf = leaf; h.kind = kind; h.found = true;
@@ -650,7 +579,7 @@ __global__ __launch_bounds__(LV_BLOCK) void k_ppll_gather(const LvUniforms U, co
             nodes[3 * size_t(insertIndex) + 1] = __float_as_uint(hitT);
             nodes[3 * size_t(insertIndex) + 2] = next;
         }
-    });
+    }, [](unsigned) {});
     const uint32_t numFrags = s_count[threadIdx.x];
     uint32_t total = 0;
     if (px.inView && numFrags > 0u) {
@@ -1140,6 +1069,10 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
         LV_HIP(ctx, hipEventRecord(ctx->ev[8], st));
         // geometry_mode (VulkanRayTracer.cpp:226-250): analytic capsules, or the triangle tubes with their own LBVH
         const bool tri = ctx->opt.rtTriangleMesh;
+        if (ctx->opt.useMlat) { // use_mlat: single-pass approximate transparency (lv_mlat.hip)
+            if (tri) return lv_fail(ctx, LV_E_INVALID, "use_mlat is provided for the analytic tubes only (geometry_mode)");
+            if ((rc = lv_mlat_render(ctx, U, S, T, gridTiles, out, dc))) return rc;
+        } else {
         LvSceneDev SC = tri ? sceneDevTriangles(ctx) : S;
         if (tri && (rc = lv_prepare_overflow(ctx, SC, gridTiles, LV_STACK_LDS, true))) return rc;
 #define LV_LAUNCH_RT(ST, PR) \
@@ -1147,6 +1080,7 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
         if (stats) { if (tri) LV_LAUNCH_RT(true, LV_PRIM_TRIANGLE); else LV_LAUNCH_RT(true, LV_PRIM_CAPSULE); }
         else { if (tri) LV_LAUNCH_RT(false, LV_PRIM_TRIANGLE); else LV_LAUNCH_RT(false, LV_PRIM_CAPSULE); }
 #undef LV_LAUNCH_RT
+        }
         LV_HIP(ctx, hipEventRecord(ctx->ev[9], st));
     } else {
         // reallocateFragmentBuffer, PerPixelLinkedListLineRenderer.cpp:251-357

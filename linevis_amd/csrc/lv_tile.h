@@ -1,0 +1,70 @@
+// lv_tile.h -- what the tile kernels (lv_render.hip, lv_mlat.hip) share: counter flushes and the workgroup -> pixel map.
+#ifndef LV_TILE_H
+#define LV_TILE_H
+
+#include "lv_device.h"
+#include "lv_trace.h"
+
+namespace {
+
+__device__ __forceinline__ void lv_flush_max_nodes(const LvCounters& c, LvDevCounters* dc) {
+    uint32_t m = uint32_t(c.nodes);
+#pragma unroll
+    for (int ofs = 32; ofs > 0; ofs >>= 1) m = max(m, (uint32_t)__shfl_xor(m, ofs, 64));
+    if (lv_lane() == 0) atomicMax(&dc->maxNodesPerPixel, m);
+}
+__device__ __forceinline__ void lv_flush_counters(const LvCounters& c, LvDevCounters* dc, bool aoRays = false) {
+    unsigned long long r = lv_wave_sum_u64(c.rays), n = lv_wave_sum_u64(c.nodes), p = lv_wave_sum_u64(c.prims),
+                       h = lv_wave_sum_u64(c.hits);
+    if (lv_lane() == 0) {
+        atomicAdd(&dc->rays, r);
+        atomicAdd(&dc->nodes, n);
+        atomicAdd(&dc->prims, p);
+        atomicAdd(&dc->hits, h);
+        if (aoRays) {
+            atomicAdd(&dc->aoRays, r);
+            atomicAdd(&dc->aoNodes, n);
+            atomicAdd(&dc->aoPrims, p);
+        }
+    }
+}
+
+// Pixel of this thread.  A workgroup covers a 16x16 pixel block of one tile; each wave an 8x8 sub-block, so a
+// wave's primary rays stay coherent.  The dispatcher deals workgroups to the 8 XCDs round-robin (block b -> XCD
+// b % 8, each with a private L2).  Blocks are regrouped so that runs of LV_XCD_GROUP consecutive logical blocks (one
+// 64x64 tile = 16 blocks) land on the same XCD, and consecutive groups go to consecutive XCDs: spatial neighbours share
+// an L2 while every XCD still gets an even share of the dense and the empty parts of the picture (a contiguous 1/8
+// of the frame per XCD left 7 XCDs idle behind the one that owned the centre).  Speed only; never correctness.
+#define LV_XCD_GROUP 16u
+struct LvPixel {
+    uint32_t x, y;       // viewport pixel
+    uint32_t outIndex;   // index into the tile-major output
+    bool inTile, inView;
+};
+
+__device__ __forceinline__ bool lv_block_pixel(const LvUniforms& U, const LvTiles& T, LvPixel& p, uint32_t blockId) {
+    const uint32_t blocksPerTile = T.blocksX * T.blocksY;
+    const uint32_t nb = T.numTiles * blocksPerTile;
+    const uint32_t xcd = blockId % 8u, j = blockId / 8u;   // j-th block this XCD receives
+    const uint32_t b = ((j / LV_XCD_GROUP) * 8u + xcd) * LV_XCD_GROUP + (j % LV_XCD_GROUP);
+    if (b >= nb) { p.inTile = false; p.inView = false; return false; }
+    const uint32_t tile = b / blocksPerTile, rem = b % blocksPerTile;
+    const uint32_t by = rem / T.blocksX, bx = rem % T.blocksX;
+    const uint32_t w = threadIdx.x >> 6, l = threadIdx.x & 63u;
+    const uint32_t lx = bx * 16u + (w & 1u) * 8u + (l & 7u);
+    const uint32_t ly = by * 16u + (w >> 1) * 8u + (l >> 3);
+    p.inTile = lx < T.tileW && ly < T.tileH;
+    p.x = T.tilesXY[2 * tile] + lx;
+    p.y = T.tilesXY[2 * tile + 1] + ly;
+    p.inView = p.inTile && p.x < U.width && p.y < U.height;
+    p.outIndex = (tile * T.tileH + ly) * T.tileW + lx;
+    return true;
+}
+
+__device__ __forceinline__ bool lv_block_pixel(const LvUniforms& U, const LvTiles& T, LvPixel& p) {
+    return lv_block_pixel(U, T, p, blockIdx.x);
+}
+
+} // namespace
+
+#endif

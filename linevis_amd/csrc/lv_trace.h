@@ -477,14 +477,18 @@ __device__ __forceinline__ LvHit lv_trace_closest(const LvSceneDev& S, float rad
     return h;
 }
 
-// All capsule entry hits with t in [tMin, tMax) -- per lane -- (PPLL fragment generation), wave-cooperative like lv_trace_closest: every
+// All capsule entry hits with t in [tMin, tMax) -- per lane -- (PPLL fragment generation, MLAT), wave-cooperative like lv_trace_closest: every
 // lane of the wave calls it; (owner, leaf) pairs are tested 64 at a time by whichever lanes are free, and the lane
 // that finds a hit calls f(owner, leaf, t, kind, o, d, w0, w1) with the OWNER's ray and its two payload words
 // (cm.ray[..].w), i.e. fragments of one pixel may be produced by any lane.
-template <bool STATS, typename F>
+// DYN (multi-layer alpha tracing): the interval is [tMin, tMax] and its end may SHRINK while the ray is traced -- after
+// every shading batch all lanes call g(n) in convergent control flow (the per-pixel commit step, which may lower
+// cm.ray[2 * lane + 1].w of its own ray = "the any-hit shader accepted a hit"), and the descending lanes pick the new end
+// up for their culling.
+template <bool STATS, bool DYN, typename F, typename G>
 __device__ __forceinline__ void lv_trace_all(const LvSceneDev& S, float radius, bool capped, bool active, f3 o, f3 d,
                                              float tMin, float tMax, float w0, float w1, const LvStackMem& sm,
-                                             const LvCoopMem& cm, const LvHitQueue& hq, LvCounters& cnt, F&& f) {
+                                             const LvCoopMem& cm, const LvHitQueue& hq, LvCounters& cnt, F&& f, G&& g) {
     const unsigned lane = lv_lane();
     const unsigned long long below = (1ull << lane) - 1ull;
     active = active && S.numSegs != 0;
@@ -516,6 +520,11 @@ __device__ __forceinline__ void lv_trace_all(const LvSceneDev& S, float radius, 
         }
         hHead += n;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (DYN) {
+            g(n);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            tMax = cm.ray[2 * owner + 1].w;
+        }
     };
     while (true) {
         const bool isLeaf = cur != LV_INVALID && (cur & LV_LEAF_BIT);
@@ -545,7 +554,7 @@ __device__ __forceinline__ void lv_trace_all(const LvSceneDev& S, float radius, 
                 float t; int kind;
                 if (lv_intersect_capsule(mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), mk3(a.x, a.y, a.z),
                                          mk3(b.x, b.y, b.z), radius, capped, t, kind)) {
-                    if (t >= ro.w && t < rd.w) { hit = true; hitRef = e; hitT = t; hitKind = unsigned(kind); }
+                    if (t >= ro.w && (DYN ? t <= rd.w : t < rd.w)) { hit = true; hitRef = e; hitT = t; hitKind = unsigned(kind); }
                 }
             }
             head += n;

@@ -419,7 +419,14 @@ bool HipRayTracer::setNewSettings(const SettingsMap& settings) {
         setOption("use_deterministic_sampling", useDeterministicSampling ? "true" : "false");
         accumulatedFramesCounter = 0;
     }
-    if (settings.getValueOpt("use_mlat", s)) setOption("use_mlat", s);
+    if (settings.getValueOpt("use_mlat", useMlat)) { // VulkanRayTracer.cpp:266-275
+        setOption("use_mlat", useMlat ? "true" : "false");
+        accumulatedFramesCounter = 0;
+    }
+    if (settings.getValueOpt("mlat_num_nodes", mlatNumNodes)) {
+        setOption("mlat_num_nodes", std::to_string(mlatNumNodes));
+        accumulatedFramesCounter = 0;
+    }
     if (settings.getValueOpt("max_depth_complexity", maxDepthComplexity))
         setOption("max_depth_complexity", std::to_string(maxDepthComplexity));
     return shallReloadGatherShader;

@@ -247,6 +247,8 @@ private:
     uint32_t maxNumAccumulatedFrames = 1;  // :142 (32 interactive; offline frames use spp instead)
     uint32_t accumulatedFramesCounter = 0; // :143
     bool useDeterministicSampling = false;
+    bool useMlat = false;                  // multi-layer alpha tracing, VulkanRayTracer.hpp:133-134
+    int mlatNumNodes = 8;
     bool useTriangleMesh = false;          // RayTracingGeometryMode::TRIANGLE_MESH (VulkanRayTracer.hpp:52-63)
 };
 

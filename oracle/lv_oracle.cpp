@@ -1033,6 +1033,210 @@ static void renderRtTri(const lvo_scene* sc, const lvo_tri_scene* tsc, const lvo
     }
 }
 
+// ---------------------------------------------------------------- multi-layer alpha tracing (MLAT)
+// MlatNode / RayPayload, TubeRayTracingHeader.glsl:61-94
+struct MlatNode { float color[4]; float transmittance; float depth; };
+
+// merge(), MlatInsert.glsl:35-58
+static MlatNode mlatMerge(const MlatNode& a, const MlatNode& b, float& depth2, bool isFirst) {
+    MlatNode r;
+    r.transmittance = a.transmittance * b.transmittance;
+    float fa = 1.0f;
+    float fb = a.transmittance;
+    r.depth = a.depth;
+    depth2 = fmaxf(depth2, b.depth);
+    if (b.depth < depth2 && !isFirst) { // node b lies inside the span node a already covers
+        float d = (b.depth - a.depth);
+        d /= (depth2 - a.depth);
+        float a_pow_d = powf(a.transmittance, d);
+        fa = (a_pow_d - 1.0f);
+        fa += (a.transmittance - a_pow_d) * b.transmittance;
+        fa /= (a.transmittance - 1.0f);
+        fb = a_pow_d;
+    }
+    for (int k = 0; k < 4; k++) r.color[k] = fa * a.color[k] + fb * b.color[k];
+    return r;
+}
+
+// insertNodeMlat(), MlatInsert.glsl:66-221.  Returns true when the any-hit shader ACCEPTS the hit (opaque fragment or
+// enough absorption in front of it): the ray interval then ends at this depth.  false = ignoreIntersectionEXT.
+static bool mlatInsert(MlatNode* nodes, int numNodes, float& depth2, const float color[4], float depth, bool missShader) {
+    MlatNode newNode;
+    newNode.depth = depth;
+    const float alpha = color[3];
+    if (!missShader && alpha == 0.0f) return false;
+    newNode.transmittance = 1.0f - alpha;
+    newNode.color[0] = alpha * color[0]; newNode.color[1] = alpha * color[1]; newNode.color[2] = alpha * color[2];
+    newNode.color[3] = color[3];
+    for (int i = numNodes - 1; i >= 0; --i)
+        if (newNode.depth > nodes[i].depth) std::swap(newNode, nodes[i]);
+    // what fell off the front is merged with the first node (MLAB merges the last two instead)
+    if (newNode.depth > 0.0f) nodes[0] = mlatMerge(newNode, nodes[0], depth2, newNode.depth == depth);
+    if (alpha == 1.0f) return true;
+    float transmittance = 1.0f;
+    for (int i = 0; i < numNodes; ++i) transmittance *= nodes[i].transmittance;
+    if (transmittance <= 0.001f && nodes[numNodes - 1].depth <= depth) return true;
+    return false;
+}
+
+// RayGen main() + traceRayMlat (TubeRayTracing.glsl:86-192) with the any-hit shader AnyHitTubeAnalytic
+// (= ClosestHitTubeAnalytic + insertNodeMlat) and the MLAT miss shader (:290-293).
+// The ORDER in which the reference's any-hit shader meets the candidates is the driver's traversal order, i.e. undefined;
+// MLAT's result depends on it once more than numNodes layers exist or the early-termination rules fire.  Two orders here:
+//   traceOffsets == NULL  canonical: ascending segment index;
+//   traceOffsets != NULL  replay: pixel i (row-major in the tile) visits traceSegs[traceOffsets[i] .. traceOffsets[i+1])
+//                         in that order; traceFlags[j] = 0 inserted, 1 = dropped at insertion time because the ray
+//                         interval had already shrunk below its depth.  The replay also VALIDATES the order: every
+//                         listed segment must be a hit inside the interval valid at that moment, a dropped one must lie
+//                         beyond it, and every hit that is not listed must lie beyond the final interval (or be fully
+//                         transparent); *outViolations counts the entries that break these rules.
+// outNodesOrNull: per pixel numNodes * 6 floats {color[4], transmittance, depth} + depth2 (last sample).
+static void renderRtMlat(const lvo_scene* sc, const lvo_params* Pp, int useBvh, const float* ao, uint32_t x0, uint32_t y0,
+                         uint32_t w, uint32_t h, uint32_t numNodes, const uint64_t* traceOffsets,
+                         const uint32_t* traceSegs, const uint8_t* traceFlags, uint8_t* outRGBA8, float* outNodesOrNull,
+                         uint64_t* outViolations, lvo_stats* stats) {
+    const lvo_params& P = *Pp;
+    Frame F = makeFrame(P);
+    const bool capped = P.useCappedTubes != 0;
+    uint64_t rays = 0, nodesV = 0, prims = 0, hitsShaded = 0, violations = 0;
+#pragma omp parallel for schedule(dynamic, 4) reduction(+ : rays, nodesV, prims, hitsShaded, violations)
+    for (int64_t yy = 0; yy < int64_t(h); yy++) {
+        Counters cnt;
+        std::vector<Hit> hits;
+        std::vector<MlatNode> nodes(numNodes);
+        std::vector<uint32_t> listed;
+        for (uint32_t xx = 0; xx < w; xx++) {
+            uint32_t x = x0 + xx, y = y0 + uint32_t(yy);
+            const size_t pix = size_t(yy) * w + xx;
+            float fragmentColor[4] = {0, 0, 0, 0};
+            const float aoTexel = (P.useAmbientOcclusion && ao) ? ao[size_t(y) * P.width + x] : 1.0f;
+            uint32_t nSamples = P.useJitteredRays ? P.numSamplesPerFrame : 1u;
+            float depth2 = 0.0f;
+            for (uint32_t sampleIdx = 0; sampleIdx < nSamples; sampleIdx++) {
+                float xix = 0.5f, xiy = 0.5f;
+                if (P.useJitteredRays) {
+                    uint32_t seed = P.useDeterministicSampling
+                            ? tea(19u, P.frameNumber * P.numSamplesPerFrame + sampleIdx)
+                            : tea(x + y * P.width, P.frameNumber * P.numSamplesPerFrame + sampleIdx);
+                    xix = rnd(seed); xiy = rnd(seed);
+                }
+                V3 o, d;
+                primaryRay(P, F, x, y, xix, xiy, o, d);
+                for (auto& n : nodes) { n.color[0] = n.color[1] = n.color[2] = n.color[3] = 0.0f; n.transmittance = 1.0f; n.depth = 0.0f; }
+                depth2 = 0.0f;
+                const float tMin = 0.0001f;
+                float tMax = 1000.0f;
+                bool accepted = false;
+                auto visit = [&](const Hit& hit) {
+                    float hc[4], payloadHitT;
+                    shadeHit(*sc, P, F, aoTexel, o, d, hit, hc, payloadHitT);
+                    cnt.hits++;
+                    if (mlatInsert(nodes.data(), int(numNodes), depth2, hc, hit.t, false)) { accepted = true; tMax = hit.t; }
+                    return hc[3];
+                };
+                allHits(*sc, F.radius, capped, useBvh != 0, o, d, tMin, 1000.0f, hits, cnt); // ascending segment index
+                if (!traceOffsets) {
+                    for (const Hit& hit : hits)
+                        if (hit.t <= tMax) visit(hit);
+                } else {
+                    listed.clear();
+                    for (uint64_t j = traceOffsets[pix]; j < traceOffsets[pix + 1]; j++) {
+                        const uint32_t seg = traceSegs[j];
+                        listed.push_back(seg);
+                        auto it = std::lower_bound(hits.begin(), hits.end(), seg, [](const Hit& a, uint32_t s) { return a.seg < s; });
+                        if (it == hits.end() || it->seg != seg) { violations++; continue; } // not a hit of this ray at all
+                        if (traceFlags[j] == 0) {
+                            if (!(it->t <= tMax)) violations++;
+                            visit(*it);
+                        } else if (!(it->t > tMax)) {
+                            violations++;
+                        }
+                    }
+                    std::sort(listed.begin(), listed.end());
+                    for (size_t k = 1; k < listed.size(); k++) if (listed[k] == listed[k - 1]) violations++; // visited twice
+                    for (const Hit& hit : hits) {
+                        if (std::binary_search(listed.begin(), listed.end(), hit.seg)) continue;
+                        if (hit.t > tMax) continue; // culled by the shrunken interval
+                        float hc[4], payloadHitT;
+                        shadeHit(*sc, P, F, aoTexel, o, d, hit, hc, payloadHitT);
+                        if (hc[3] != 0.0f) violations++; // a visible layer inside the final interval was never visited
+                    }
+                }
+                if (!accepted) mlatInsert(nodes.data(), int(numNodes), depth2, P.background, 1e7f, true); // Miss
+                // front-to-back blending of the node list (pre-multiplied colours), TubeRayTracing.glsl:141-189
+                float fc[4] = {0, 0, 0, 0};
+                for (uint32_t i = 0; i < numNodes; i++) {
+                    const float* hc = nodes[i].color;
+                    for (int k = 0; k < 3; k++) fc[k] = fc[k] + (1.0f - fc[3]) * hc[k];
+                    fc[3] = fc[3] + (1.0f - fc[3]) * hc[3];
+                }
+                for (int k = 0; k < 4; k++) fragmentColor[k] += fc[k];
+            }
+            if (P.useJitteredRays)
+                for (int k = 0; k < 4; k++) fragmentColor[k] /= float(P.numSamplesPerFrame);
+            uint8_t* px = outRGBA8 + 4 * pix;
+            for (int k = 0; k < 4; k++) px[k] = toUnorm8(fragmentColor[k]);
+            if (outNodesOrNull) {
+                float* dst = outNodesOrNull + pix * (size_t(numNodes) * 6 + 1);
+                for (uint32_t i = 0; i < numNodes; i++) {
+                    for (int k = 0; k < 4; k++) dst[6 * i + k] = nodes[i].color[k];
+                    dst[6 * i + 4] = nodes[i].transmittance;
+                    dst[6 * i + 5] = nodes[i].depth;
+                }
+                dst[size_t(numNodes) * 6] = depth2;
+            }
+        }
+        rays += cnt.rays; nodesV += cnt.nodes; prims += cnt.prims; hitsShaded += cnt.hits;
+    }
+    if (outViolations) *outViolations = violations;
+    if (stats) {
+        stats->raysTraced += rays; stats->nodesVisited += nodesV; stats->primsTested += prims; stats->hitsShaded += hitsShaded;
+        stats->bvhDepth = sc->bvhDepth;
+    }
+}
+
+// All capsule entry hits of every pixel-centre ray of a tile (t in [1e-4, 1000], ascending segment index): offsets has
+// w*h+1 entries; segs / ts may be NULL (first pass: sizes only).
+void lvo_pixel_hits(const lvo_scene* sc, const lvo_params* Pp, int useBvh, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h,
+                    uint64_t* offsets, uint32_t* segs, float* ts) {
+    const lvo_params& P = *Pp;
+    Frame F = makeFrame(P);
+    std::vector<std::vector<Hit>> rows(size_t(w) * h);
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int64_t yy = 0; yy < int64_t(h); yy++) {
+        Counters cnt;
+        for (uint32_t xx = 0; xx < w; xx++) {
+            V3 o, d;
+            primaryRay(P, F, x0 + xx, y0 + uint32_t(yy), 0.5f, 0.5f, o, d);
+            allHits(*sc, F.radius, P.useCappedTubes != 0, useBvh != 0, o, d, 0.0001f, 1000.0f, rows[size_t(yy) * w + xx], cnt);
+        }
+    }
+    uint64_t n = 0;
+    for (size_t i = 0; i < rows.size(); i++) {
+        offsets[i] = n;
+        for (const Hit& hh : rows[i]) {
+            if (segs) segs[n] = hh.seg;
+            if (ts) ts[n] = hh.t;
+            n++;
+        }
+    }
+    offsets[rows.size()] = n;
+}
+
+void lvo_mlat_insert(float* nodes, int numNodes, float* depth2, const float color[4], float depth, int missShader,
+                     int* outAccepted) {
+    int acc = mlatInsert(reinterpret_cast<MlatNode*>(nodes), numNodes, *depth2, color, depth, missShader != 0) ? 1 : 0;
+    if (outAccepted) *outAccepted = acc;
+}
+
+void lvo_render_rt_mlat(const lvo_scene* sc, const lvo_params* P, int useBvh, const float* ao, uint32_t x0, uint32_t y0,
+                        uint32_t w, uint32_t h, uint32_t numNodes, const uint64_t* traceOffsets,
+                        const uint32_t* traceSegs, const uint8_t* traceFlags, uint8_t* outRGBA8, float* outNodesOrNull,
+                        uint64_t* outViolations, lvo_stats* stats) {
+    renderRtMlat(sc, P, useBvh, ao, x0, y0, w, h, numNodes, traceOffsets, traceSegs, traceFlags, outRGBA8, outNodesOrNull,
+                 outViolations, stats);
+}
+
 void lvo_render_rt(const lvo_scene* sc, const lvo_params* P, int useBvh, const float* ao, uint32_t x0, uint32_t y0,
                    uint32_t w, uint32_t h, uint8_t* outRGBA8, lvo_stats* stats) {
     renderRt(sc, P, useBvh, ao, nullptr, x0, y0, w, h, outRGBA8, stats);

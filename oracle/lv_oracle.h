@@ -157,6 +157,21 @@ void lvo_render_rt(
         const lvo_scene*, const lvo_params*, int useBvh, const float* ao,
         uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, uint8_t* outRGBA8, lvo_stats* stats);
 
+/* ---- f1: multi-layer alpha tracing (MlatInsert.glsl, traceRayMlat TubeRayTracing.glsl:86-192) ----
+ * lvo_mlat_insert: one insertNodeMlat() on a node array of numNodes x {color[4], transmittance, depth}.
+ * lvo_render_rt_mlat: the ray tracer frame with USE_MLAT.  traceOffsets == NULL: candidates visited in ascending
+ * segment order; else replay of a recorded visiting order, validated (see lv_oracle.cpp). */
+/* per pixel-centre ray of a tile: all capsule entry hits, ascending segment index (segs / ts may be NULL) */
+void lvo_pixel_hits(const lvo_scene*, const lvo_params*, int useBvh, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h,
+                    uint64_t* offsets, uint32_t* segs, float* ts);
+void lvo_mlat_insert(float* nodes, int numNodes, float* depth2, const float color[4], float depth, int missShader,
+                     int* outAccepted);
+void lvo_render_rt_mlat(
+        const lvo_scene*, const lvo_params*, int useBvh, const float* ao,
+        uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, uint32_t numNodes,
+        const uint64_t* traceOffsets, const uint32_t* traceSegs, const uint8_t* traceFlags,
+        uint8_t* outRGBA8, float* outNodesOrNull, uint64_t* outViolations, lvo_stats* stats);
+
 /* ---- a15-a17: PPLL ---- */
 uint32_t lvo_ppll_addr(uint32_t x, uint32_t y, uint32_t viewportWPadded, uint32_t tileW, uint32_t tileH);
 /* gather: all-hits per pixel-centre ray, fragments appended in ascending segment order.

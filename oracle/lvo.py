@@ -118,6 +118,10 @@ def lib():
     L.lvo_compute_depth_range.argtypes = [vp, C.POINTER(Params), vp]
     L.lvo_render_ao.argtypes = [vp, C.POINTER(Params), i32, u32, u32, u32, u32, vp, C.POINTER(Stats)]
     L.lvo_render_rt.argtypes = [vp, C.POINTER(Params), i32, vp, u32, u32, u32, u32, vp, C.POINTER(Stats)]
+    L.lvo_pixel_hits.argtypes = [vp, C.POINTER(Params), i32, u32, u32, u32, u32, vp, vp, vp]
+    L.lvo_mlat_insert.argtypes = [vp, i32, vp, vp, f32, i32, C.POINTER(i32)]
+    L.lvo_render_rt_mlat.argtypes = [vp, C.POINTER(Params), i32, vp, u32, u32, u32, u32, u32, vp, vp, vp, vp, vp,
+                                     C.POINTER(C.c_uint64), C.POINTER(Stats)]
     L.lvo_ppll_addr.restype = u32
     L.lvo_ppll_addr.argtypes = [u32, u32, u32, u32, u32]
     L.lvo_ppll_gather.argtypes = [vp, C.POINTER(Params), i32, vp, u32, u32, u32, u32, vp, vp, C.POINTER(u32),
@@ -153,6 +157,17 @@ def lib():
 
 def _p(a):
     return a.ctypes.data_as(C.c_void_p)
+
+
+def mlat_insert(nodes, depth2, color, depth, miss=False):
+    """One insertNodeMlat() on nodes (K, 6) float32 {premultiplied rgba, transmittance, depth}; returns
+    (nodes, depth2, accepted)."""
+    n = np.ascontiguousarray(nodes, dtype=np.float32).copy()
+    d2 = np.array([depth2], dtype=np.float32)
+    col = np.ascontiguousarray(color, dtype=np.float32)
+    acc = C.c_int32(0)
+    lib().lvo_mlat_insert(_p(n), int(n.shape[0]), _p(d2), _p(col), float(depth), int(miss), C.byref(acc))
+    return n, float(d2[0]), bool(acc.value)
 
 
 def tea(a, b):
@@ -356,6 +371,48 @@ class Scene:
             raise ValueError("useAmbientOcclusion needs an ao buffer")
         lib().lvo_render_rt(self.h, C.byref(P), self._use_bvh(P, use_bvh), aop, x0, y0, w, h, _p(out), C.byref(st))
         return out
+
+    def pixel_hits(self, P, tile=None, use_bvh=False):
+        """All capsule entry hits of every pixel-centre ray: (offsets (w*h+1), segments, t), ascending segment index."""
+        x0, y0, w, h = self._tile(P, tile)
+        offs = np.zeros(w * h + 1, dtype=np.uint64)
+        ub = self._use_bvh(P, use_bvh)
+        lib().lvo_pixel_hits(self.h, C.byref(P), ub, x0, y0, w, h, _p(offs), None, None)
+        segs = np.zeros(max(int(offs[-1]), 1), dtype=np.uint32)
+        ts = np.zeros(max(int(offs[-1]), 1), dtype=np.float32)
+        lib().lvo_pixel_hits(self.h, C.byref(P), ub, x0, y0, w, h, _p(offs), _p(segs), _p(ts))
+        return offs, segs[:int(offs[-1])], ts[:int(offs[-1])]
+
+    def render_rt_mlat(self, P, num_nodes, ao=None, tile=None, use_bvh=False, trace=None, stats=None):
+        """USE_MLAT frame.  trace = None: candidates visited in ascending segment order.  trace = (n, 4) uint32 records
+        {viewport pixel index y * W + x, sequence number, segment, flag} (any order): replayed per pixel in sequence
+        order and validated.  Returns (rgba8 tile, node states (h, w, num_nodes * 6 + 1), violations)."""
+        x0, y0, w, h = self._tile(P, tile)
+        out = np.empty((h, w, 4), dtype=np.uint8)
+        nodes = np.zeros((h, w, num_nodes * 6 + 1), dtype=np.float32)
+        st = stats if stats is not None else Stats()
+        aop = _p(np.ascontiguousarray(ao, dtype=np.float32)) if ao is not None else None
+        if P.useAmbientOcclusion and ao is None:
+            raise ValueError("useAmbientOcclusion needs an ao buffer")
+        viol = C.c_uint64(0)
+        offs = segs = flags = None
+        if trace is not None:
+            tr = np.asarray(trace, dtype=np.uint32).reshape(-1, 4)
+            px, py = tr[:, 0] % P.width, tr[:, 0] // P.width
+            inside = (px >= x0) & (px < x0 + w) & (py >= y0) & (py < y0 + h)
+            tr, px, py = tr[inside], px[inside], py[inside]
+            local = (py - y0).astype(np.int64) * w + (px - x0)
+            order = np.lexsort((tr[:, 1], local))
+            tr, local = tr[order], local[order]
+            offs = np.zeros(w * h + 1, dtype=np.uint64)
+            np.add.at(offs, local + 1, 1)
+            offs = np.cumsum(offs).astype(np.uint64)
+            segs = np.ascontiguousarray(tr[:, 2], dtype=np.uint32)
+            flags = np.ascontiguousarray(tr[:, 3], dtype=np.uint8)
+        lib().lvo_render_rt_mlat(self.h, C.byref(P), self._use_bvh(P, use_bvh), aop, x0, y0, w, h, int(num_nodes),
+                                 _p(offs) if offs is not None else None, _p(segs) if segs is not None else None,
+                                 _p(flags) if flags is not None else None, _p(out), _p(nodes), C.byref(viol), C.byref(st))
+        return out, nodes, int(viol.value)
 
     def ppll_gather(self, P, ao=None, tile=None, use_bvh=False, stats=None):
         x0, y0, w, h = self._tile(P, tile)

@@ -298,7 +298,24 @@ def flow_small():
     np.savez_compressed(os.path.join(HERE, "flow_small.npz"), **out)
 
 
+def mlat_small():
+    """MLAT frames + node lists (candidates visited in ascending segment order) of the small transparent scene."""
+    from common import small_case
+    c = small_case(width=48, height=32, transparent=True, n_lines=40)
+    sc = c.oracle_scene()
+    P = c.oracle_params(sc)
+    out = {}
+    for k in (2, 8):
+        img, nodes, _ = sc.render_rt_mlat(P, k)
+        out["frame_k%d" % k] = img
+        out["nodes_k%d" % k] = nodes
+    np.savez_compressed(os.path.join(HERE, "mlat_small.npz"), **out)
+
+
 if __name__ == "__main__":
+    if "--only-mlat" in sys.argv:
+        mlat_small()
+        sys.exit(0)
     if "--only-flow" in sys.argv:
         flow_small()
         sys.exit(0)
@@ -313,6 +330,7 @@ if __name__ == "__main__":
     lattice_c1()
     triangle_tubes()
     flow_small()
+    mlat_small()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print("%-24s %8d bytes" % (f, os.path.getsize(os.path.join(HERE, f))))

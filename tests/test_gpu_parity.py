@@ -332,7 +332,7 @@ def test_option_errors(hip_lib):
     c = small_case(width=32, height=32)
     ctx = c.hip_context()
     for key, val in [("no_such_key", "1"), ("num_accumulated_frames", 2), ("ambient_occlusion_mode", "SSAO"),
-                     ("line_width", -1.0), ("geometry_mode", "Linear Swept Spheres"), ("use_mlat", True)]:
+                     ("line_width", -1.0), ("geometry_mode", "Linear Swept Spheres"), ("mlat_num_nodes", 3)]:
         with pytest.raises(capi.LineVisError):
             ctx.set_option(key, val)
     with pytest.raises(capi.LineVisError):
