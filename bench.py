@@ -52,6 +52,15 @@ WORKLOADS = {
                     "resolve, MAX_NUM_FRAGS 64, node pool 20/pixel, tiling 2x8, opacity ramp 0.1..0.6",
                scene="tornado", mode=2, settings={"ppll_max_num_frags": 64, "ppll_expected_avg_depth_complexity": 20,
                                                   "depth_cue_strength": 0.0}, kernel="k_ppll_gather"),
+    # the same transparent scene through the ray tracer's two transparency paths (documentation runs)
+    "c4m": dict(name="C4 scene (1M-segment tornado, 1920x1080, opacity ramp 0.1..0.6) through the ray tracer with multi-layer "
+                     "alpha tracing, 8 nodes (use_mlat): single pass, approximate OIT",
+                scene="tornado", mode=11, settings={"use_mlat": True, "mlat_num_nodes": 8, "depth_cue_strength": 0.0,
+                                                    "num_samples_per_frame": 1}, kernel="k_render_rt"),
+    "c4l": dict(name="C4 scene (1M-segment tornado, 1920x1080, opacity ramp 0.1..0.6) through the ray tracer's transparency "
+                     "loop (closest hit, step behind it, repeat until alpha > 0.99)",
+                scene="tornado", mode=11, settings={"depth_cue_strength": 0.0, "num_samples_per_frame": 1},
+                kernel="k_render_rt"),
 }
 
 
@@ -79,6 +88,8 @@ def cpu_baseline(pts, seg, tf, attr_range, view, proj, fovy, near, far, target_s
         t = time.time()
         if workload == "c4":
             sc.render_ppll(P, tile=tile, use_bvh=True, stats=st)
+        elif workload == "c4m":
+            sc.render_rt_mlat(P, 8, tile=tile, use_bvh=True, stats=st)
         else:
             ao = None
             if workload in ("c3", "c5"):
@@ -146,7 +157,7 @@ def main():
     tr = scenes.normalize(gen())
     flow = host_api.LineDataFlow().set_trajectories(tr.positions, tr.attributes, tr.line_offsets)
     pts, seg, _ = flow.tube_aabb_render_data(LINE_WIDTH)
-    tf = tfm.standard_transparent() if args.workload == "c4" else tfm.standard()
+    tf = tfm.standard_transparent() if args.workload.startswith("c4") else tfm.standard()
     attr_range = flow.attribute_range()
     view, proj, fovy, near, far = camera.default_camera(W, H)
 

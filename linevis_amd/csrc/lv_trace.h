@@ -603,7 +603,7 @@ __device__ __forceinline__ void lv_trace_all(const LvSceneDev& S, float radius, 
         }
         int nNow;
         do {
-            if (!(cur & LV_LEAF_BIT)) cur = lv_node_step<STATS, false>(S, cur, oi, inv, tMin, tMax, st, cnt);
+            if (!(cur & LV_LEAF_BIT)) cur = lv_node_step<STATS, DYN>(S, cur, oi, inv, tMin, tMax, st, cnt);
             const bool lf = cur != LV_INVALID && (cur & LV_LEAF_BIT);
             const unsigned long long m = __ballot(lf);
             if (m) {
