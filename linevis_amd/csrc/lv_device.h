@@ -26,15 +26,15 @@
 #define LV_SORT_CHILDREN 0       // 1: fully sort the hit children of a node; 0: nearest first, rest unordered
 #endif
 #ifndef LV_AO_STACK_LDS
-#define LV_AO_STACK_LDS 16      // LDS-staged stack entries per thread in k_ao_rays (deeper entries: HBM overflow slab)
+#define LV_AO_STACK_LDS 15      // LDS-staged stack entries per thread in k_ao_rays (deeper entries: HBM overflow slab)
 #endif
 #ifndef LV_AO_BLOCK
 #define LV_AO_BLOCK 256         // threads per workgroup of k_ao_rays
 #endif
 #ifndef LV_AO_BLOCKS_PER_CU
-#define LV_AO_BLOCKS_PER_CU 4
+#define LV_AO_BLOCKS_PER_CU 5
 #endif
-#define LV_AO_QCAP 256         // leaf FIFO entries per wave (>= 64 waiting + 2 x 64 new per step)
+#define LV_AO_QCAP 128         // leaf FIFO entries per wave (<= 63 waiting + 64 new per step)
 #ifndef LV_NODE_MIN_ACTIVE
 #define LV_NODE_MIN_ACTIVE 24  // node loop yields to the leaf loop when fewer lanes than this are descending
 #endif

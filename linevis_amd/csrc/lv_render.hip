@@ -222,8 +222,10 @@ __global__ __launch_bounds__(LV_AO_BLOCK) void k_ao_rays(const LvUniforms U, con
                                                          const float4* __restrict__ gbuf, float* __restrict__ samples,
                                                          LvDevCounters* dc, const uint2* __restrict__ lcgSkip = nullptr) {
     __shared__ unsigned s_stack[LV_AO_STACK_LDS * LV_AO_BLOCK];
-    __shared__ float4 s_ray[2 * LV_AO_BLOCK];              // current ray of every lane: {o.xyz, -}{d.xyz, -}
-    __shared__ float4 s_gen[2 * LV_AO_BLOCK];              // generated rays waiting for a lane
+    // LDS budget: 15 KB + 6 + 6 + 2 + 2 = 31 KB per workgroup -> 5 workgroups (20 waves) per CU; the kernel hides the
+    // latency of its dependent node fetches with occupancy (measured: 12 -> 16 waves/CU -16 %, 16 -> 20 another -7 %)
+    __shared__ float2 s_ray[3 * LV_AO_BLOCK];              // current ray of every lane: {o.xy}{o.z, d.x}{d.yz} (24 B)
+    __shared__ float2 s_gen[3 * LV_AO_BLOCK];              // generated rays waiting for a lane
     __shared__ unsigned s_queue[LV_AO_BLOCK / LV_WAVE][LV_AO_QCAP];
     __shared__ unsigned long long s_key[LV_AO_BLOCK];      // best hit of every lane's ray
 
@@ -233,8 +235,8 @@ __global__ __launch_bounds__(LV_AO_BLOCK) void k_ao_rays(const LvUniforms U, con
     const float radius = U.radius;
     const unsigned lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
     const unsigned long long below = (1ull << lane) - 1ull;
-    float4* rayW = &s_ray[2 * LV_WAVE * w];
-    float4* genW = &s_gen[2 * LV_WAVE * w];
+    float2* rayW = &s_ray[3 * LV_WAVE * w];
+    float2* genW = &s_gen[3 * LV_WAVE * w];
     unsigned* queueW = s_queue[w];
     unsigned long long* keyW = &s_key[LV_WAVE * w];
     const unsigned long long keyInit = ((unsigned long long)__float_as_uint(U.aoRadius) << 32) | 0xFFFFFFFFull;
@@ -258,9 +260,10 @@ __global__ __launch_bounds__(LV_AO_BLOCK) void k_ao_rays(const LvUniforms U, con
     unsigned cur = LV_INVALID, lastSeq = 0;
 
     while (true) {
-        // ---- leaves reached in the previous step join the FIFO
+        // ---- leaves reached in the previous step join the FIFO -- while fewer than 64 pairs wait, so that it never holds
+        // more than 63 + 64 (LV_AO_QCAP = 128); with a full batch waiting the test phase below runs first
         {
-            const bool isLeaf = hasRay && cur != LV_INVALID && (cur & LV_LEAF_BIT);
+            const bool isLeaf = tail - head < LV_WAVE && hasRay && cur != LV_INVALID && (cur & LV_LEAF_BIT);
             const unsigned long long mL = __ballot(isLeaf);
             if (mL) {
                 if (isLeaf) {
@@ -271,7 +274,7 @@ __global__ __launch_bounds__(LV_AO_BLOCK) void k_ao_rays(const LvUniforms U, con
                     cur = lv_pop_or_done(st);
                 }
                 tail += unsigned(__popcll(mL));
-                continue; // a popped reference may be a leaf again
+                if (tail - head < LV_WAVE) continue; // a popped reference may be a leaf again
             }
         }
         // ---- retire rays whose traversal is finished and whose queued leaves have all been tested
@@ -296,10 +299,10 @@ __global__ __launch_bounds__(LV_AO_BLOCK) void k_ao_rays(const LvUniforms U, con
             if (lane < n) {
                 const unsigned e = queueW[(head + lane) % LV_AO_QCAP];
                 const unsigned owner = e >> 26, leaf = e & 0x03FFFFFFu;
-                const float4 ro = rayW[2 * owner], rd = rayW[2 * owner + 1];
+                const float2 r0 = rayW[3 * owner], r1 = rayW[3 * owner + 1], r2 = rayW[3 * owner + 2];
                 if (STATS) cnt.prims++;
                 float t; unsigned low;
-                if (lv_leaf_test<PRIM>(S, leaf, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), radius, capped, t, low)) {
+                if (lv_leaf_test<PRIM>(S, leaf, mk3(r0.x, r0.y, r1.x), mk3(r1.y, r2.x, r2.y), radius, capped, t, low)) {
                     if (t >= 0.0f && t <= U.aoRadius) // traceAoRay: closest hit in [0, aoRadius], glsl:158-175
                         atomicMin(&keyW[owner], ((unsigned long long)__float_as_uint(t) << 32) | low);
                 }
@@ -352,8 +355,9 @@ __global__ __launch_bounds__(LV_AO_BLOCK) void k_ao_rays(const LvUniforms U, con
                                         (T.z * smp.x + B.z * smp.y) + N.z * smp.z);
                     const f3 d = norm3(dirU);
                     const f3 o = BAKE ? pos : pos + d * g0.w;
-                    genW[2 * lane] = make_float4(o.x, o.y, o.z, 0.0f);
-                    genW[2 * lane + 1] = make_float4(d.x, d.y, d.z, 0.0f);
+                    genW[3 * lane] = make_float2(o.x, o.y);
+                    genW[3 * lane + 1] = make_float2(o.z, d.x);
+                    genW[3 * lane + 2] = make_float2(d.y, d.z);
                 }
                 genBase = chunkNext;
                 chunkNext += n;
@@ -367,12 +371,13 @@ __global__ __launch_bounds__(LV_AO_BLOCK) void k_ao_rays(const LvUniforms U, con
                 const unsigned rank = unsigned(__popcll(mIdle & below));
                 if (rank < k) {
                     const unsigned gs = genPos + rank;
-                    const float4 ro = genW[2 * gs], rd = genW[2 * gs + 1];
-                    rayW[2 * lane] = ro;
-                    rayW[2 * lane + 1] = rd;
+                    const float2 r0 = genW[3 * gs], r1 = genW[3 * gs + 1], r2 = genW[3 * gs + 2];
+                    rayW[3 * lane] = r0;
+                    rayW[3 * lane + 1] = r1;
+                    rayW[3 * lane + 2] = r2;
                     keyW[lane] = keyInit;
-                    inv = mk3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
-                    oi = mk3(ro.x * inv.x, ro.y * inv.y, ro.z * inv.z);
+                    inv = mk3(1.0f / r1.y, 1.0f / r2.x, 1.0f / r2.y);
+                    oi = mk3(r0.x * inv.x, r0.y * inv.y, r1.x * inv.z);
                     best = U.aoRadius;
                     r = genBase + gs;
                     cur = 0;
