@@ -218,7 +218,7 @@ __global__ __launch_bounds__(LV_BLOCK) void k_ao_primary(const LvUniforms U, con
 // the reference draws the (subdivision, ray) samples of a vertex from ONE LCG stream seeded with tea(vertex, frame), so
 // sample j starts from the stream advanced by 2 j steps: seed_j = A_j * seed_0 + C_j (lcgSkip[j] = {A_j, C_j}).
 template <bool STATS, bool ANY_HIT, int PRIM, bool BAKE = false>
-__global__ __launch_bounds__(LV_AO_BLOCK) void k_ao_rays(const LvUniforms U, const LvSceneDev S,
+__global__ __launch_bounds__(LV_AO_BLOCK, 5) void k_ao_rays(const LvUniforms U, const LvSceneDev S,
                                                          const float4* __restrict__ gbuf, float* __restrict__ samples,
                                                          LvDevCounters* dc, const uint2* __restrict__ lcgSkip = nullptr) {
     __shared__ unsigned s_stack[LV_AO_STACK_LDS * LV_AO_BLOCK];
@@ -258,17 +258,18 @@ __global__ __launch_bounds__(LV_AO_BLOCK) void k_ao_rays(const LvUniforms U, con
     f3 inv = mk3(0, 0, 0), oi = mk3(0, 0, 0);
     float best = 0.0f;
     unsigned cur = LV_INVALID, lastSeq = 0;
+    unsigned owner = lane; // lane whose ray this lane descends for: its own, except in the drain phase (below)
 
     while (true) {
         // ---- leaves reached in the previous step join the FIFO -- while fewer than 64 pairs wait, so that it never holds
         // more than 63 + 64 (LV_AO_QCAP = 128); with a full batch waiting the test phase below runs first
         {
-            const bool isLeaf = tail - head < LV_WAVE && hasRay && cur != LV_INVALID && (cur & LV_LEAF_BIT);
+            const bool isLeaf = tail - head < LV_WAVE && cur != LV_INVALID && (cur & LV_LEAF_BIT);
             const unsigned long long mL = __ballot(isLeaf);
             if (mL) {
                 if (isLeaf) {
                     const unsigned idx = tail + unsigned(__popcll(mL & below));
-                    queueW[idx % LV_AO_QCAP] = (lane << 26) | (cur & 0x03FFFFFFu);
+                    queueW[idx % LV_AO_QCAP] = (owner << 26) | (cur & 0x03FFFFFFu);
                     lastSeq = idx;
                     enq = true;
                     cur = lv_pop_or_done(st);
@@ -277,19 +278,25 @@ __global__ __launch_bounds__(LV_AO_BLOCK) void k_ao_rays(const LvUniforms U, con
                 if (tail - head < LV_WAVE) continue; // a popped reference may be a leaf again
             }
         }
+        const bool canRefill = (genPos < genCount) || !sourceDry;
+        // DRAIN phase: no ray is left to hand out.  What remains in the wave is finished together, like one call of
+        // lv_trace_closest: nobody retires early, lanes without work take over stacked subtrees of the lanes that still
+        // descend (for THEIR rays: hits merge into the owner's key), and all samples are written at the end.  Without
+        // it the kernel's last ~0.3 ms were a handful of lanes per wave walking their long rays alone -- a fixed cost that
+        // weighs more the fewer tiles a GPU owns.
+        const bool drain = !canRefill;
         // ---- retire rays whose traversal is finished and whose queued leaves have all been tested
-        if (hasRay && cur == LV_INVALID && (!enq || int(head - lastSeq) > 0)) {
+        if (!drain && hasRay && cur == LV_INVALID && (!enq || int(head - lastSeq) > 0)) {
             const unsigned long long key = keyW[lane];
             float occ = 1.0f;
             if (key != keyInit) occ = U.aoUseDistance ? __uint_as_float(unsigned(key >> 32)) / U.aoRadius : 0.0f;
             samples[r] = occ;
             hasRay = false;
         }
-        const unsigned long long mNode = __ballot(hasRay && !(cur & LV_LEAF_BIT));
+        const unsigned long long mNode = __ballot(cur != LV_INVALID && !(cur & LV_LEAF_BIT));
         const unsigned long long mIdle = __ballot(!hasRay);
         const int nNode = __popcll(mNode), nIdle = __popcll(mIdle);
         const unsigned q = tail - head;
-        const bool canRefill = (genPos < genCount) || !sourceDry;
 
         if (q >= LV_WAVE || (q > 0 && nNode == 0 && !(canRefill && nIdle > 0))) {
             // ---- test phase: one (owner, leaf) pair per lane
@@ -309,12 +316,51 @@ __global__ __launch_bounds__(LV_AO_BLOCK) void k_ao_rays(const LvUniforms U, con
             }
             head += n;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            if (hasRay) {
-                const unsigned long long key = keyW[lane];
+            {
+                const unsigned long long key = keyW[owner];
                 best = __uint_as_float(unsigned(key >> 32)); // shrinks the slab interval of the following node steps
                 if (ANY_HIT && key != keyInit) { cur = LV_INVALID; st.sp = 0; }
             }
             continue;
+        }
+        if (drain) {
+            if (nNode == 0) { // FIFO empty (q == 0 here), nobody descends: the wave is done
+                if (hasRay) {
+                    const unsigned long long key = keyW[lane];
+                    float occ = 1.0f;
+                    if (key != keyInit) occ = U.aoUseDistance ? __uint_as_float(unsigned(key >> 32)) / U.aoRadius : 0.0f;
+                    samples[r] = occ;
+                }
+                break;
+            }
+            if (nNode <= LV_HANDOVER_MAX_BUSY) { // subtree hand-over, as in lv_trace_closest (exchange slots: the idle s_gen)
+                const bool idle = cur == LV_INVALID;
+                const bool donor = !idle && st.sp > 0;
+                const unsigned long long mFree = __ballot(idle), mDonor = __ballot(donor);
+                const unsigned nPairs = min(unsigned(__popcll(mFree)), unsigned(__popcll(mDonor)));
+                if (nPairs) {
+                    if (donor) {
+                        const unsigned rk = unsigned(__popcll(mDonor & below));
+                        if (rk < nPairs) genW[rk] = make_float2(__uint_as_float(st.pop()), __uint_as_float(owner));
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    if (idle) {
+                        const unsigned rk = unsigned(__popcll(mFree & below));
+                        if (rk < nPairs) {
+                            const float2 x = genW[rk];
+                            cur = __float_as_uint(x.x);
+                            owner = __float_as_uint(x.y);
+                            const float2 r0 = rayW[3 * owner], r1 = rayW[3 * owner + 1], r2 = rayW[3 * owner + 2];
+                            inv = mk3(1.0f / r1.y, 1.0f / r2.x, 1.0f / r2.y);
+                            oi = mk3(r0.x * inv.x, r0.y * inv.y, r1.x * inv.z);
+                            best = __uint_as_float(unsigned(keyW[owner] >> 32));
+                            st.sp = 0;
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    continue; // the reference taken over may be a leaf
+                }
+            }
         }
         if (canRefill && nIdle > 0 && (nIdle >= LV_REFILL_THRESHOLD || nNode < LV_NODE_MIN_ACTIVE)) {
             // ---- generate phase: keep s_gen stocked (all 64 lanes), then hand rays to the idle lanes
@@ -380,6 +426,7 @@ __global__ __launch_bounds__(LV_AO_BLOCK) void k_ao_rays(const LvUniforms U, con
                     oi = mk3(r0.x * inv.x, r0.y * inv.y, r1.x * inv.z);
                     best = U.aoRadius;
                     r = genBase + gs;
+                    owner = lane;
                     cur = 0;
                     st.sp = 0;
                     enq = false;
@@ -399,22 +446,22 @@ __global__ __launch_bounds__(LV_AO_BLOCK) void k_ao_rays(const LvUniforms U, con
             int nNow;
             do {
                 if (STATS && lane == 0) { phIt[1]++; }
-                if (STATS && hasRay && !(cur & LV_LEAF_BIT)) phLn[1]++;
-                if (hasRay && !(cur & LV_LEAF_BIT)) cur = lv_node_step<STATS>(S, cur, oi, inv, 0.0f, best, st, cnt);
-                const bool isLeaf = hasRay && cur != LV_INVALID && (cur & LV_LEAF_BIT);
+                if (STATS && !(cur & LV_LEAF_BIT)) phLn[1]++;
+                if (!(cur & LV_LEAF_BIT)) cur = lv_node_step<STATS>(S, cur, oi, inv, 0.0f, best, st, cnt);
+                const bool isLeaf = cur != LV_INVALID && (cur & LV_LEAF_BIT);
                 const unsigned long long mL = __ballot(isLeaf);
                 if (mL) {
                     if (isLeaf) {
                         const unsigned idx = tail + unsigned(__popcll(mL & below));
-                        queueW[idx % LV_AO_QCAP] = (lane << 26) | (cur & 0x03FFFFFFu);
+                        queueW[idx % LV_AO_QCAP] = (owner << 26) | (cur & 0x03FFFFFFu);
                         lastSeq = idx;
                         enq = true;
                         cur = lv_pop_or_done(st);
                     }
                     tail += unsigned(__popcll(mL));
                 }
-                nNow = __popcll(__ballot(hasRay && !(cur & LV_LEAF_BIT)));
-            } while (tail - head < LV_WAVE && nNow >= stay);
+                nNow = __popcll(__ballot(!(cur & LV_LEAF_BIT)));
+            } while (tail - head < LV_WAVE && nNow >= (drain ? LV_HANDOVER_MAX_BUSY + 1 : stay));
             continue;
         }
         if (nIdle == LV_WAVE && !canRefill) break; // nothing alive, nothing left to fetch
@@ -1034,8 +1081,8 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
     T.numTiles = numTiles;
     T.tileW = tileW;
     T.tileH = tileH;
-    T.blocksX = (tileW + 15u) / 16u;
-    T.blocksY = (tileH + 15u) / 16u;
+    T.blocksX = ((tileW + 63u) / 64u) * 4u; // 16x16-pixel blocks, in whole 64x64 groups (lv_block_pixel)
+    T.blocksY = ((tileH + 63u) / 64u) * 4u;
     const uint64_t nb = uint64_t(numTiles) * T.blocksX * T.blocksY;
     if (nb > 0x7FFFFFF0ull) return lv_fail(ctx, LV_E_INVALID, "tile list too large");
     const uint32_t gridTiles = uint32_t((nb + 127u) / 128u) * 128u; // multiple of 8 XCDs x LV_XCD_GROUP (lv_block_pixel)
@@ -1190,7 +1237,7 @@ int lv_frame_ppll_resolve_only(lv_ctx* ctx, const uint32_t* nodes, uint64_t numN
     LvTiles T;
     T.tilesXY = (const uint32_t*)ctx->tilesDev.ptr;
     T.numTiles = 1; T.tileW = w; T.tileH = h;
-    T.blocksX = (w + 15u) / 16u; T.blocksY = (h + 15u) / 16u;
+    T.blocksX = ((w + 63u) / 64u) * 4u; T.blocksY = ((h + 63u) / 64u) * 4u;
     const uint32_t numGroups = ((w + 7u) / 8u) * ((h + 7u) / 8u);
     const size_t ldsBytes = size_t(U.ppllMaxNumFrags) * LV_WAVE * 8;
     if (ldsBytes <= 64 * 1024) {

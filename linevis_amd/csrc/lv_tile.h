@@ -29,9 +29,8 @@ __device__ __forceinline__ void lv_flush_counters(const LvCounters& c, LvDevCoun
     }
 }
 
-// Pixel of this thread.  A workgroup covers a 16x16 pixel block of one tile; each wave an 8x8 sub-block, so a
-// wave's primary rays stay coherent.  The dispatcher deals workgroups to the 8 XCDs round-robin (block b -> XCD
-// b % 8, each with a private L2).  Blocks are regrouped so that runs of LV_XCD_GROUP consecutive logical blocks (one
+// Pixel of this thread (see lv_block_pixel for the pixel <-> wave map).  The dispatcher deals workgroups to the 8 XCDs
+// round-robin (block b -> XCD b % 8, each with a private L2).  Blocks are regrouped so that runs of LV_XCD_GROUP consecutive logical blocks (one
 // 64x64 tile = 16 blocks) land on the same XCD, and consecutive groups go to consecutive XCDs: spatial neighbours share
 // an L2 while every XCD still gets an even share of the dense and the empty parts of the picture (a contiguous 1/8
 // of the frame per XCD left 7 XCDs idle behind the one that owned the centre).  Speed only; never correctness.
@@ -49,10 +48,17 @@ __device__ __forceinline__ bool lv_block_pixel(const LvUniforms& U, const LvTile
     const uint32_t b = ((j / LV_XCD_GROUP) * 8u + xcd) * LV_XCD_GROUP + (j % LV_XCD_GROUP);
     if (b >= nb) { p.inTile = false; p.inView = false; return false; }
     const uint32_t tile = b / blocksPerTile, rem = b % blocksPerTile;
-    const uint32_t by = rem / T.blocksX, bx = rem % T.blocksX;
-    const uint32_t w = threadIdx.x >> 6, l = threadIdx.x & 63u;
-    const uint32_t lx = bx * 16u + (w & 1u) * 8u + (l & 7u);
-    const uint32_t ly = by * 16u + (w >> 1) * 8u + (l >> 3);
+    // A tile is cut into 64x64-pixel groups of 16 blocks (T.blocksX / T.blocksY are multiples of 4).  Inside a group the
+    // 64 waves do NOT own 8x8 patches: wave W takes pixel (W & 7, W >> 3) of each of the group's 8x8 cells, i.e. 64 pixels
+    // spread over the whole group at stride 8.  The cost of a pixel varies by orders of magnitude over a few dozen
+    // pixels (a ray through the core of a bundle vs. one that misses it), and a wave runs as long as the SUM of its
+    // pixels' work / 64 -- with contiguous patches the waves over the core set the duration of the whole kernel however
+    // few tiles a GPU owns; interleaved, every wave of a group carries the same mix (measured: k_ao_primary 0.34 -> 0.27,
+    // k_render_rt 0.45 -> 0.37, k_ppll_gather 3.0 -> 2.0 ms; with 1/8 of the tiles 0.30 -> 0.13 and 0.45 -> 0.23 ms).
+    const uint32_t groupsX = T.blocksX / 4u;
+    const uint32_t group = rem / 16u, W = (rem % 16u) * 4u + (threadIdx.x >> 6), l = threadIdx.x & 63u;
+    const uint32_t lx = (group % groupsX) * 64u + (l & 7u) * 8u + (W & 7u);
+    const uint32_t ly = (group / groupsX) * 64u + (l >> 3) * 8u + (W >> 3);
     p.inTile = lx < T.tileW && ly < T.tileH;
     p.x = T.tilesXY[2 * tile] + lx;
     p.y = T.tilesXY[2 * tile + 1] + ly;
