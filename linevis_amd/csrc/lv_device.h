@@ -40,14 +40,14 @@
 #endif
 
 #ifndef LV_HANDOVER_MAX_BUSY
-#define LV_HANDOVER_MAX_BUSY 48 // cooperative closest hit: idle lanes take over stacked subtrees once at most this many lanes descend
+#define LV_HANDOVER_MAX_BUSY 32 // cooperative closest hit: idle lanes take over stacked subtrees once at most this many lanes descend
 #endif
 
 #ifndef LV_PPLL_CHUNK
 #define LV_PPLL_CHUNK 256       // PPLL node slots a wave reserves per global atomic (>= 64)
 #endif
 #ifndef LV_PPLL_SLICES
-#define LV_PPLL_SLICES 2        // depth slices per pixel block in k_ppll_gather (workgroups = pixel blocks x slices)
+#define LV_PPLL_SLICES 1        // depth slices per pixel block in k_ppll_gather (workgroups = pixel blocks x slices)
 #endif
 
 // device-side counters block of a frame (read back by lv_get_stats / lv_ppll_get_buffers)
