@@ -253,7 +253,11 @@ def main():
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(kernel_bytes), "ms_per_launch": round(ms_rays, 4),
                          "launches_timed": int(min(st.kernel_launches[kid], 128)),
-                         "frame_algorithmic_bytes_rank0": int(frame_bytes)},
+                         "frame_algorithmic_bytes_rank0": int(frame_bytes),
+                         "note": "achieved = algorithmic bytes (64 B per node visited + 32/48 B per primitive tested + per-pixel "
+                                 "records) / measured launch time; the scene + LBVH (~64 MB) live in L2 / Infinity Cache, so "
+                                 "most of these bytes never reach HBM ('traffic' = PMC-measured HBM bytes per launch) and frac "
+                                 "can exceed 1: the traversal kernels are VALU-issue-bound, not HBM-bound (DESIGN.md section 6)"},
             "counters_rank0": {"nodes_visited": int(counters_local[0]), "prims_tested": int(counters_local[1]),
                                "hits_shaded": int(counters_local[2]), "ao_rays": int(counters_local[3]),
                                "ao_nodes_visited": int(counters_local[4]), "ao_prims_tested": int(counters_local[5])},

@@ -210,7 +210,8 @@ int lv_set_flow_grid(lv_ctx* ctx, const float* vector_field, uint32_t xs, uint32
                      float dz, const float* const* scalar_fields, uint32_t num_scalar_fields);
 /* StreamlineTracingSettings, StreamlineTracingDefines.hpp:144-177 (the fields _trace / traceStreamlines read). */
 typedef struct lv_streamline_settings {
-    uint32_t integration_method;    /* StreamlineIntegrationMethod :63-76: 0 explicit Euler, 2 Heun, 3 midpoint, 4 RK4 */
+    uint32_t integration_method;    /* StreamlineIntegrationMethod :63-76: 0 explicit Euler, 1 implicit Euler, 2 Heun,
+                                     * 3 midpoint, 4 RK4, 5 Runge-Kutta-Fehlberg (double precision, adaptive step) */
     uint32_t integration_direction; /* StreamlineIntegrationDirection :82-84: 0 forward, 1 backward, 2 both */
     float time_step_scale;          /* 1.0 */
     int32_t max_num_iterations;     /* 2000 */

@@ -597,8 +597,9 @@ int lv_trace_streamlines(lv_ctx* ctx, const float* seed_points, uint32_t num_see
     if (!ctx->flowGridSet) return lv_fail(ctx, LV_E_STATE, "lv_set_flow_grid has not been called");
     if (!settings || (num_seeds && !seed_points)) return lv_fail(ctx, LV_E_INVALID, "null argument");
     const uint32_t m = settings->integration_method;
-    if (m != 0u && m != 2u && m != 3u && m != 4u)
-        return lv_fail(ctx, LV_E_INVALID, "integration method %u is not provided (0 explicit Euler, 2 Heun, 3 midpoint, 4 RK4)", m);
+    if (m > 5u)
+        return lv_fail(ctx, LV_E_INVALID, "integration method %u does not exist (0 explicit Euler, 1 implicit Euler, 2 Heun, "
+                                          "3 midpoint, 4 RK4, 5 Runge-Kutta-Fehlberg)", m);
     if (settings->integration_direction > 2u) return lv_fail(ctx, LV_E_INVALID, "integration direction must be 0, 1 or 2");
     if (!(settings->time_step_scale > 0.0f) || settings->max_num_iterations <= 0 || settings->max_num_iterations > 10000000)
         return lv_fail(ctx, LV_E_INVALID, "time_step_scale must be > 0 and max_num_iterations in 1..1e7");

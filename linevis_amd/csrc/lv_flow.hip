@@ -4,7 +4,8 @@
 //   setGridExtent / addVectorField (max |v|)          :81-218      -> lv_set_flow_grid (k_max_magnitude)
 //   _getVectorAtPosition, _getScalarFieldAtPosition   :857-913     -> lv_vector_at / lv_scalar_at (trilinear, 8 gathers)
 //   _rayBoxIntersection                               :949-1010    -> lv_ray_box
-//   _trace + _integrationStep{ExplicitEuler,Heun,Midpoint,RK4} :1193-1339 -> k_trace_streamlines (one thread per seed and
+//   _trace + _integrationStep{ExplicitEuler,ImplicitEuler,Heun,Midpoint,RK4,RKF45} :1193-1396
+//                                                                  -> k_trace_streamlines (one thread per seed and
 //                                                                  direction; the steps of a line are inherently serial)
 //   traceStreamlines: backward reversal, forward/backward merge, minimum-length filter :344-426,1118-1166 -> host part of
 //                                                                  lv_trace_streamlines
@@ -102,9 +103,89 @@ __device__ __forceinline__ bool lv_ray_box(f3 o, f3 d, f3 upper, float& tNear, f
     return true;
 }
 
-__device__ __forceinline__ void lv_integration_step(const LvFlowGrid& g, uint32_t method, f3& p0, float dt, bool fw) {
+// _getVectorAtIdxDouble / _getVectorAtPositionDouble, :915-944
+struct d3t { double x, y, z; };
+__device__ __forceinline__ d3t mkd3(double x, double y, double z) { d3t r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ d3t operator+(d3t a, d3t b) { return mkd3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ d3t operator-(d3t a, d3t b) { return mkd3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ d3t operator*(d3t a, double s) { return mkd3(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ d3t operator*(double s, d3t a) { return mkd3(s * a.x, s * a.y, s * a.z); }
+
+__device__ __forceinline__ d3t lv_vector_at_idx_d(const LvFlowGrid& g, int x, int y, int z, bool fw) {
+    const f3 v = lv_vector_at_idx(g, x, y, z, fw);
+    return mkd3(double(v.x), double(v.y), double(v.z));
+}
+
+__device__ __forceinline__ d3t lv_vector_at_d(const LvFlowGrid& g, d3t p, bool fw) {
+    const double qx = (p.x - 0.0) * (1.0 / double(g.dx)), qy = (p.y - 0.0) * (1.0 / double(g.dy)),
+                 qz = (p.z - 0.0) * (1.0 / double(g.dz));
+    const int x = int(qx), y = int(qy), z = int(qz);
+    const double fx = qx - floor(qx), fy = qy - floor(qy), fz = qz - floor(qz);
+    const double ix = 1.0 - fx, iy = 1.0 - fy, iz = 1.0 - fz;
+    d3t r = (ix * iy * iz) * lv_vector_at_idx_d(g, x, y, z, fw);
+    r = r + (fx * iy * iz) * lv_vector_at_idx_d(g, x + 1, y, z, fw);
+    r = r + (ix * fy * iz) * lv_vector_at_idx_d(g, x, y + 1, z, fw);
+    r = r + (fx * fy * iz) * lv_vector_at_idx_d(g, x + 1, y + 1, z, fw);
+    r = r + (ix * iy * fz) * lv_vector_at_idx_d(g, x, y, z + 1, fw);
+    r = r + (fx * iy * fz) * lv_vector_at_idx_d(g, x + 1, y, z + 1, fw);
+    r = r + (ix * fy * fz) * lv_vector_at_idx_d(g, x, y + 1, z + 1, fw);
+    r = r + (fx * fy * fz) * lv_vector_at_idx_d(g, x + 1, y + 1, z + 1, fw);
+    return r;
+}
+
+// _integrationStepRKF45, :1341-1396: double precision; the step only ever shrinks and stays shrunk (dt by reference)
+__device__ __forceinline__ void lv_integration_step_rkf45(const LvFlowGrid& g, float timeStepScale, f3& fP0, float& fDt,
+                                                          bool fw) {
+    const double EPSILON = double(2.0 * 1e-5) * double(fminf(g.dx, fminf(g.dy, g.dz))) * double(timeStepScale);
+    const int MAX_NUM_ITERATIONS = 100;
+    double dt = fDt;
+    int iteration = 0;
+    const d3t p0 = mkd3(fP0.x, fP0.y, fP0.z);
+    d3t rk5;
+    bool adapt;
+    do {
+        const d3t k1 = dt * lv_vector_at_d(g, p0, fw);
+        const d3t k2 = dt * lv_vector_at_d(g, p0 + k1 * double(1.0 / 4.0), fw);
+        const d3t k3 = dt * lv_vector_at_d(g, p0 + k1 * double(3.0 / 32.0) + k2 * double(9.0 / 32.0), fw);
+        const d3t k4 = dt * lv_vector_at_d(
+                g, p0 + k1 * double(1932.0 / 2197.0) - k2 * double(7200.0 / 2197.0) + k3 * double(7296.0 / 2197.0), fw);
+        const d3t k5 = dt * lv_vector_at_d(
+                g, p0 + k1 * double(439.0 / 216.0) - k2 * double(8.0) + k3 * double(3680.0 / 513.0) - k4 * double(845.0 / 4104.0), fw);
+        const d3t k6 = dt * lv_vector_at_d(
+                g, p0 - k1 * double(8.0 / 27.0) + k2 * double(2.0) - k3 * double(3544.0 / 2565.0) + k4 * double(1859.0 / 4104.0)
+                           - k5 * double(11.0 / 40.0), fw);
+        rk5 = p0 + k1 * double(16.0 / 135.0) + k3 * double(6656.0 / 12825.0) + k4 * double(28561.0 / 56430.0)
+              - k5 * double(9.0 / 50.0) + k6 * double(2.0 / 55.0);
+        const d3t e = k1 * double(1.0 / 360.0) + k3 * double(-128.0 / 4275.0) + k4 * double(-2197.0 / 75240.0)
+                      + k5 * (1.0 / 50.0) + k6 * double(2.0 / 55.0);
+        const double TE = sqrt(e.x * e.x + e.y * e.y + e.z * e.z);
+        adapt = TE > EPSILON;
+        if (adapt) dt = 0.9 * dt * pow(EPSILON / TE, double(1.0 / 5.0));
+        iteration++;
+    } while (adapt && iteration < MAX_NUM_ITERATIONS);
+    fP0 = mk3(float(rk5.x), float(rk5.y), float(rk5.z));
+    fDt = float(dt);
+}
+
+__device__ __forceinline__ void lv_integration_step(const LvFlowGrid& g, uint32_t method, f3& p0, float& dt, bool fw,
+                                                    float timeStepScale) {
     if (method == 0u) {
         p0 = p0 + dt * lv_vector_at(g, p0, fw);
+    } else if (method == 1u) { // implicit Euler by fixed-point iteration, :1285-1307
+        const float EPSILON = 1e-6f;
+        const int MAX_NUM_ITERATIONS = 100;
+        int iteration = 0;
+        f3 pLast = p0;
+        float diff;
+        do {
+            const f3 pNext = p0 + dt * lv_vector_at(g, pLast, fw);
+            diff = len3(pLast - pNext);
+            pLast = pNext;
+            iteration++;
+        } while (diff > EPSILON && iteration < MAX_NUM_ITERATIONS);
+        p0 = pLast;
+    } else if (method == 5u) {
+        lv_integration_step_rkf45(g, timeStepScale, p0, dt, fw);
     } else if (method == 2u) {
         const f3 v0 = lv_vector_at(g, p0, fw);
         const f3 p1 = p0 + dt * v0;
@@ -130,7 +211,8 @@ __device__ __forceinline__ void lv_integration_step(const LvFlowGrid& g, uint32_
 __global__ __launch_bounds__(LV_WAVE) void k_trace_streamlines(const LvFlowGrid g, const float* __restrict__ seeds,
                                                                uint32_t numSeeds, uint32_t numThreads,
                                                                uint32_t firstBackward, uint32_t method, float dt,
-                                                               float terminationDistance, int maxIterations,
+                                                               float timeStepScale, float terminationDistance,
+                                                               int maxIterations,
                                                                float maxLineLength, uint32_t capacity,
                                                                float* __restrict__ positions,
                                                                float* __restrict__ attributes,
@@ -166,7 +248,7 @@ __global__ __launch_bounds__(LV_WAVE) void k_trace_streamlines(const LvFlowGrid 
             break;
         }
         push(p);
-        lv_integration_step(g, method, p, dt, fw);
+        lv_integration_step(g, method, p, dt, fw, timeStepScale); // (RKF45 shrinks this thread's dt)
         const float segmentLength = len3(p - old);
         lineLength += segmentLength;
         if (segmentLength < terminationDistance) break;
@@ -252,7 +334,7 @@ int lv_flow_trace(lv_ctx* ctx, const float* seeds, uint32_t numSeeds, const lv_s
     LV_HIP(ctx, hipMemcpyAsync(ctx->flowSeeds.ptr, seeds, size_t(numSeeds) * 12, hipMemcpyHostToDevice, st));
     k_trace_streamlines<<<(numThreads + LV_WAVE - 1) / LV_WAVE, LV_WAVE, 0, st>>>(
             g, (const float*)ctx->flowSeeds.ptr, numSeeds, numThreads, firstBackward, S->integration_method, dt,
-            terminationDistance, maxIterations, maxLineLength, capacity, (float*)ctx->flowOutPos.ptr,
+            S->time_step_scale, terminationDistance, maxIterations, maxLineLength, capacity, (float*)ctx->flowOutPos.ptr,
             (float*)ctx->flowOutAtt.ptr, (uint32_t*)ctx->flowCounts.ptr);
     LV_HIP(ctx, hipGetLastError());
     std::vector<uint32_t> counts(numThreads);

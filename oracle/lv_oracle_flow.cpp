@@ -8,7 +8,7 @@
  *   _getScalarFieldAtIdx / _pushTrajectoryAttributes                        :857-862,1012-1047
  *   _rayBoxPlaneIntersection / _rayBoxIntersection                          :949-1010
  *   _trace (time step, termination rules, boundary clamp)                   :1193-1259
- *   _integrationStep{ExplicitEuler,Heun,Midpoint,RK4}                       :1278-1339
+ *   _integrationStep{ExplicitEuler,ImplicitEuler,Heun,Midpoint,RK4,RKF45}   :1278-1396
  *   traceStreamlines (forward / backward / both, minimum-length filter)     :344-426, _reverseTrajectory :1118,
  *                                                                           _insertBackwardTrajectory :1149
  *   AbcFlowGenerator::generateAbcFlow                                       Loader/AbcFlowGenerator.cpp:41-72
@@ -122,8 +122,90 @@ inline void pushPoint(const Grid& g, Line& l, V3 p) {
     for (uint32_t a = 0; a < g.numScalars; a++) l.att[a].push_back(scalarAtPosition(g, g.scalars[a], p));
 }
 
-inline void integrationStep(const Grid& g, uint32_t method, V3& p0, float dt, bool fw) {
+// _getVectorAtIdxDouble / _getVectorAtPositionDouble, :915-944
+struct D3 { double x, y, z; };
+inline D3 d3(double x, double y, double z) { return D3{x, y, z}; }
+inline D3 operator+(D3 a, D3 b) { return d3(a.x + b.x, a.y + b.y, a.z + b.z); }
+inline D3 operator-(D3 a, D3 b) { return d3(a.x - b.x, a.y - b.y, a.z - b.z); }
+inline D3 operator*(D3 a, double s) { return d3(a.x * s, a.y * s, a.z * s); }
+inline D3 operator*(double s, D3 a) { return d3(s * a.x, s * a.y, s * a.z); }
+
+inline D3 vectorAtIdxDouble(const Grid& g, int x, int y, int z, bool fw) {
+    const V3 v = vectorAtIdx(g, x, y, z, fw);
+    return d3(double(v.x), double(v.y), double(v.z));
+}
+
+inline D3 vectorAtPositionDouble(const Grid& g, D3 p, bool fw) {
+    D3 q = p - d3(double(g.boxMin.x), double(g.boxMin.y), double(g.boxMin.z));
+    q = d3(q.x * (1.0 / double(g.dx)), q.y * (1.0 / double(g.dy)), q.z * (1.0 / double(g.dz)));
+    const int x = int(q.x), y = int(q.y), z = int(q.z);
+    const double fx = q.x - floor(q.x), fy = q.y - floor(q.y), fz = q.z - floor(q.z);
+    const double ix = 1.0 - fx, iy = 1.0 - fy, iz = 1.0 - fz;
+    D3 r = (ix * iy * iz) * vectorAtIdxDouble(g, x, y, z, fw);
+    r = r + (fx * iy * iz) * vectorAtIdxDouble(g, x + 1, y, z, fw);
+    r = r + (ix * fy * iz) * vectorAtIdxDouble(g, x, y + 1, z, fw);
+    r = r + (fx * fy * iz) * vectorAtIdxDouble(g, x + 1, y + 1, z, fw);
+    r = r + (ix * iy * fz) * vectorAtIdxDouble(g, x, y, z + 1, fw);
+    r = r + (fx * iy * fz) * vectorAtIdxDouble(g, x + 1, y, z + 1, fw);
+    r = r + (ix * fy * fz) * vectorAtIdxDouble(g, x, y + 1, z + 1, fw);
+    r = r + (fx * fy * fz) * vectorAtIdxDouble(g, x + 1, y + 1, z + 1, fw);
+    return r;
+}
+
+// _integrationStepRKF45, :1341-1396: double precision, the step only ever shrinks (and stays shrunk: dt is passed by
+// reference); approximationRK4 of the reference is dead code and not restated.  pow() is libm's.
+inline void integrationStepRKF45(const Grid& g, float timeStepScale, V3& fP0, float& fDt, bool fw) {
+    const double EPSILON = double(2.0 * 1e-5) * double(std::min(g.dx, std::min(g.dy, g.dz))) * double(timeStepScale);
+    const int MAX_NUM_ITERATIONS = 100;
+    double dt = fDt;
+    int iteration = 0;
+    const D3 p0 = d3(fP0.x, fP0.y, fP0.z);
+    D3 rk5;
+    bool adapt;
+    do {
+        const D3 k1 = dt * vectorAtPositionDouble(g, p0, fw);
+        const D3 k2 = dt * vectorAtPositionDouble(g, p0 + k1 * double(1.0 / 4.0), fw);
+        const D3 k3 = dt * vectorAtPositionDouble(g, p0 + k1 * double(3.0 / 32.0) + k2 * double(9.0 / 32.0), fw);
+        const D3 k4 = dt * vectorAtPositionDouble(
+                g, p0 + k1 * double(1932.0 / 2197.0) - k2 * double(7200.0 / 2197.0) + k3 * double(7296.0 / 2197.0), fw);
+        const D3 k5 = dt * vectorAtPositionDouble(
+                g, p0 + k1 * double(439.0 / 216.0) - k2 * double(8.0) + k3 * double(3680.0 / 513.0) - k4 * double(845.0 / 4104.0), fw);
+        const D3 k6 = dt * vectorAtPositionDouble(
+                g, p0 - k1 * double(8.0 / 27.0) + k2 * double(2.0) - k3 * double(3544.0 / 2565.0) + k4 * double(1859.0 / 4104.0)
+                           - k5 * double(11.0 / 40.0), fw);
+        rk5 = p0 + k1 * double(16.0 / 135.0) + k3 * double(6656.0 / 12825.0) + k4 * double(28561.0 / 56430.0)
+              - k5 * double(9.0 / 50.0) + k6 * double(2.0 / 55.0);
+        const D3 e = k1 * double(1.0 / 360.0) + k3 * double(-128.0 / 4275.0) + k4 * double(-2197.0 / 75240.0)
+                     + k5 * (1.0 / 50.0) + k6 * double(2.0 / 55.0);
+        const double TE = sqrt(e.x * e.x + e.y * e.y + e.z * e.z);
+        adapt = TE > EPSILON;
+        if (adapt) dt = 0.9 * dt * pow(EPSILON / TE, double(1.0 / 5.0));
+        iteration++;
+    } while (adapt && iteration < MAX_NUM_ITERATIONS);
+    fP0 = v3(float(rk5.x), float(rk5.y), float(rk5.z));
+    fDt = float(dt);
+}
+
+inline void integrationStep(const Grid& g, uint32_t method, V3& p0, float& dt, bool fw, float timeStepScale) {
     switch (method) {
+        case 1: { // implicit Euler by fixed-point iteration, :1285-1307
+            const float EPSILON = 1e-6f;
+            const int MAX_NUM_ITERATIONS = 100;
+            int iteration = 0;
+            V3 pLast = p0;
+            float diff;
+            do {
+                V3 pNext = p0 + dt * vectorAtPosition(g, pLast, fw);
+                diff = length(pLast - pNext);
+                pLast = pNext;
+                iteration++;
+            } while (diff > EPSILON && iteration < MAX_NUM_ITERATIONS);
+            p0 = pLast;
+            break;
+        }
+        case 5:
+            integrationStepRKF45(g, timeStepScale, p0, dt, fw);
+            break;
         case 0: // explicit Euler, :1278-1283
             p0 = p0 + dt * vectorAtPosition(g, p0, fw);
             break;
@@ -155,7 +237,7 @@ inline void integrationStep(const Grid& g, uint32_t method, V3& p0, float dt, bo
 
 // :1193-1259
 void traceOne(const Grid& g, const lvo_streamline_settings& S, float maxVectorMagnitude, V3 seed, bool fw, Line& line) {
-    const float dt = 1.0f / maxVectorMagnitude * std::min(g.dx, std::min(g.dy, g.dz)) * S.timeStepScale;
+    float dt = 1.0f / maxVectorMagnitude * std::min(g.dx, std::min(g.dy, g.dz)) * S.timeStepScale; // RKF45 shrinks it
     const float terminationDistance = 1e-6f * S.terminationDistance;
     V3 p = seed, old;
     int iterationCounter = 0;
@@ -177,7 +259,7 @@ void traceOne(const Grid& g, const lvo_streamline_settings& S, float maxVectorMa
             break;
         }
         pushPoint(g, line, p);
-        integrationStep(g, S.integrationMethod, p, dt, fw);
+        integrationStep(g, S.integrationMethod, p, dt, fw, S.timeStepScale);
         float segmentLength = length(p - old);
         lineLength += segmentLength;
         if (segmentLength < terminationDistance) break;

@@ -74,7 +74,8 @@ class StreamlineSettings(C.Structure):
                 ("maxNumIterations", C.c_int32), ("terminationDistance", C.c_float), ("minimumLength", C.c_float)]
 
 
-INTEGRATION_METHODS = {"Explicit Euler": 0, "Heun": 2, "Midpoint": 3, "Runge-Kutta 4th Order": 4}
+INTEGRATION_METHODS = {"Explicit Euler": 0, "Implicit Euler": 1, "Heun": 2, "Midpoint": 3, "Runge-Kutta 4th Order": 4,
+                       "Runge-Kutta-Fehlberg": 5}
 INTEGRATION_DIRECTIONS = {"Forward": 0, "Backward": 1, "Forward & Backward": 2}
 
 

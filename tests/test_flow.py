@@ -83,6 +83,54 @@ def test_rotation_field_integrator_order():
         assert len(pos) > 50
     assert err["Runge-Kutta 4th Order"] < 1e-5 < err["Heun"] * 50
     assert err["Heun"] < err["Explicit Euler"] / 20 and err["Midpoint"] < err["Explicit Euler"] / 20
+    # implicit Euler spirals INWARDS by about as much as explicit Euler spirals outwards; RKF45 stays on the circle
+    for method in ("Implicit Euler", "Runge-Kutta-Fehlberg"):
+        S = lvo.streamline_settings(method, "Forward", max_num_iterations=2000, minimum_length=0.1)
+        pos, _, _ = lvo.trace_streamlines(v, (d, d, d), [], seed, S)
+        r = np.linalg.norm(pos[:, :2] - 0.5, axis=1)
+        err[method] = float(np.abs(r - 0.25).max())
+        assert len(pos) > 50
+        if method == "Implicit Euler":
+            assert r[-1] < 0.25 and 0.3 < err[method] / err["Explicit Euler"] < 3.0
+    assert err["Runge-Kutta-Fehlberg"] < 1e-5
+
+
+def test_rkf45_step_adaptation():
+    """The RKF45 step only shrinks, and only where the truncation error estimate exceeds 2e-5 * min spacing * scale: in
+    a field that is linear in the position (error estimate ~ 0) it never does, so the points are spaced like RK4's;
+    with a large step through the ABC flow it does, the lines get more points than RK4's and stay close to them."""
+    n, d = 33, 1.0 / 32
+    g = np.arange(n) * d
+    z, y, x = np.meshgrid(g, g, g, indexing="ij")
+    lin = np.stack([-(y - 0.5), (x - 0.5), 0.1 + 0 * x], axis=3).astype(np.float32)
+    seed = np.array([[0.7, 0.5, 0.1]], np.float32)
+    a = lvo.trace_streamlines(lin, (d, d, d), [], seed, lvo.streamline_settings("Runge-Kutta-Fehlberg", "Forward", minimum_length=0.1))
+    b = lvo.trace_streamlines(lin, (d, d, d), [], seed, lvo.streamline_settings("Runge-Kutta 4th Order", "Forward", minimum_length=0.1))
+    assert len(a[0]) == len(b[0]) and np.allclose(a[0], b[0], atol=2e-6)
+    v = lvo.generate_abc_flow(n, n, n)
+    rng = np.random.default_rng(4)
+    seeds = rng.uniform(0.2, 0.8, (40, 3)).astype(np.float32)
+    kw = dict(time_step_scale=8.0, minimum_length=0.0, max_num_iterations=400)
+    a = lvo.trace_streamlines(v, (d, d, d), [], seeds, lvo.streamline_settings("Runge-Kutta-Fehlberg", "Forward", **kw))
+    b = lvo.trace_streamlines(v, (d, d, d), [], seeds, lvo.streamline_settings("Runge-Kutta 4th Order", "Forward", **kw))
+    assert len(a[2]) == len(b[2]) == 41
+    assert len(a[0]) > 1.2 * len(b[0])                      # smaller steps -> more points for the same lines
+    # measured against a finely stepped RK4 solution the adaptive lines are far more accurate than RK4 at the same
+    # nominal step
+    kwf = dict(time_step_scale=0.125, minimum_length=0.0, max_num_iterations=400)
+    f = lvo.trace_streamlines(v, (d, d, d), [], seeds, lvo.streamline_settings("Runge-Kutta 4th Order", "Forward", **kwf))
+
+    def deviation(x):
+        worst = 0.0
+        for l in range(40):
+            px, pf = x[0][x[2][l]:x[2][l + 1]], f[0][f[2][l]:f[2][l + 1]]
+            assert np.array_equal(px[0], seeds[l])
+            n = min(len(px), 4)                                # the first few points (before the lines leave the box)
+            dist = np.linalg.norm(px[:n, None, :] - pf[None, :, :], axis=2).min(axis=1)
+            worst = max(worst, float(dist.max()))
+        return worst
+    da, db = deviation(a), deviation(b)
+    assert da < 0.004 and db > 2 * da
 
 
 def test_termination_rules_and_min_length_filter():

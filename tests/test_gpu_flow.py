@@ -49,6 +49,45 @@ def test_streamlines_bit_exact_abc_flow(hip_lib, method, direction):
     assert len(a[2]) - 1 > 100 and len(a[0]) > 3000
 
 
+@pytest.mark.parametrize("direction", ["Forward", "Forward & Backward"])
+def test_implicit_euler_bit_exact(hip_lib, direction):
+    """Fixed-point iteration in float32 (+, *, sqrt): bit-identical like the explicit integrators."""
+    v, mag, sp = abc_grid()
+    rng = np.random.default_rng(6)
+    seeds = rng.uniform(0.05, 0.95, (300, 3)).astype(np.float32)
+    ctx = capi.Context(0)
+    ctx.set_flow_grid(v, sp, [mag])
+    for scale in (1.0, 4.0):
+        S = dict(time_step_scale=scale, minimum_length=0.2)
+        a = ctx.trace_streamlines(seeds, capi.streamline_settings("Implicit Euler", direction, **S))
+        b = lvo.trace_streamlines(v, sp, [mag], seeds, lvo.streamline_settings("Implicit Euler", direction, **S))
+        assert same(a, b) and len(a[0]) > 1500
+
+
+def test_rkf45_matches_the_oracle(hip_lib):
+    """Runge-Kutta-Fehlberg runs in float64 with one pow() per step adaptation: the device's pow and libm's agree to the
+    last bit almost always, so almost every line is bit-identical; a line whose step once differed in the last place
+    stays within float32 rounding of the oracle's.  Line structure (offsets) must be identical."""
+    v, mag, sp = abc_grid()
+    rng = np.random.default_rng(9)
+    seeds = rng.uniform(0.05, 0.95, (400, 3)).astype(np.float32)
+    ctx = capi.Context(0)
+    ctx.set_flow_grid(v, sp, [mag])
+    for scale, direction in ((1.0, "Forward"), (6.0, "Forward & Backward")):
+        S = dict(time_step_scale=scale, minimum_length=0.2)
+        a = ctx.trace_streamlines(seeds, capi.streamline_settings("Runge-Kutta-Fehlberg", direction, **S))
+        b = lvo.trace_streamlines(v, sp, [mag], seeds, lvo.streamline_settings("Runge-Kutta-Fehlberg", direction, **S))
+        assert np.array_equal(a[2], b[2]) and len(a[0]) > 3000
+        assert np.allclose(a[0], b[0], rtol=0, atol=2e-6) and np.allclose(a[1], b[1], rtol=0, atol=2e-5)
+        off = a[2].astype(np.int64)
+        identical = sum(np.array_equal(a[0][off[l]:off[l + 1]].view(np.uint32), b[0][off[l]:off[l + 1]].view(np.uint32))
+                        for l in range(len(off) - 1))
+        assert identical >= 0.9 * (len(off) - 1)
+    # the step does adapt at scale 6: more points per line than RK4 with the same nominal step
+    r = ctx.trace_streamlines(seeds, capi.streamline_settings("Runge-Kutta 4th Order", "Forward & Backward", **S))
+    assert len(a[0]) > 1.1 * len(r[0])
+
+
 def test_streamlines_long_lines_termination_rules(hip_lib):
     vec, scalars, sp = swirl_grid()
     rng = np.random.default_rng(3)
@@ -99,9 +138,10 @@ def test_streamline_api_errors(hip_lib):
         ctx.trace_streamlines(np.zeros((1, 3), np.float32), capi.streamline_settings())       # no grid
     v, mag, sp = abc_grid(8)
     ctx.set_flow_grid(v, sp, [mag])
-    for bad in ("Implicit Euler", "Runge-Kutta-Fehlberg"):
-        with pytest.raises(capi.LineVisError):
-            ctx.trace_streamlines(np.zeros((1, 3), np.float32) + 0.5, capi.streamline_settings(bad))
+    bad = capi.streamline_settings()
+    bad.integration_method = 6
+    with pytest.raises(capi.LineVisError):
+        ctx.trace_streamlines(np.zeros((1, 3), np.float32) + 0.5, bad)
     with pytest.raises(capi.LineVisError):
         ctx.trace_streamlines(np.zeros((1, 3), np.float32), capi.streamline_settings(time_step_scale=0.0))
     with pytest.raises(capi.LineVisError):
@@ -156,5 +196,10 @@ def test_host_tracer_classes(hip_lib):
     b = lvo.trace_streamlines(vec, sp2, [scalars[0], scalars[1]], sd,       # attributes come in NAME order: a, b
                               lvo.streamline_settings("Heun", "Forward", minimum_length=0.05))
     assert same(a, b) and len(a[0]) > 500
-    with pytest.raises(capi.LineVisError):
-        grid.trace_streamlines(sd, method="Runge-Kutta-Fehlberg")
+    # every integrator of the reference is reachable through the plugin-side class
+    c = grid.trace_streamlines(sd, method="Implicit Euler", direction="Forward", minimum_length=0.05)
+    d = lvo.trace_streamlines(vec, sp2, [scalars[0], scalars[1]], sd,
+                              lvo.streamline_settings("Implicit Euler", "Forward", minimum_length=0.05))
+    assert same(c, d)
+    e = grid.trace_streamlines(sd, method="Runge-Kutta-Fehlberg", direction="Forward", minimum_length=0.05)
+    assert len(e[0]) > 500 and np.array_equal(e[2][:1], [0])
