@@ -163,7 +163,7 @@ int lv_set_background(lv_ctx* ctx, const float rgba[4]);
  *   use_deterministic_sampling, geometry_mode ("AABBs (analytic)" = ray-capsule, default | "Triangle Mesh" = the tube
  *   mesh set with lv_set_tube_triangle_mesh), use_analytic_intersections (bool form of the same switch)
  *                                                                       (VulkanRayTracer.cpp:226-278)
- *   use_mlat (multi-layer alpha tracing instead of the transparency loop; analytic tubes only), mlat_num_nodes
+ *   use_mlat (multi-layer alpha tracing instead of the transparency loop; either geometry mode), mlat_num_nodes
  *   (power of two in [1, 32], default 8)                                (VulkanRayTracer.cpp:266-275, .hpp:133-134)
  *   use_capped_tubes, use_halos, tube_num_subdivisions                  (LineData.cpp:87-181)
  *   max_depth_complexity                                                (VulkanRayTracer.hpp:139)
@@ -243,7 +243,7 @@ int lv_compute_depth_range(lv_ctx* ctx, float out_min_max[2]);
 int lv_get_ao(lv_ctx* ctx, float* out /* viewport_width * viewport_height */);
 /* MLAT (use_mlat) parity instrument: the order in which every pixel's candidates were handed to insertNodeMlat in the
  * last mode-11 render (options collect_stats + mlat_record_trace).  4 uint32 per record {viewport pixel index y * W + x,
- * sequence number within the pixel, original segment index, flag: 0 = inserted, 1 = dropped because an accepted hit had
+ * sequence number within the pixel, original segment index (triangle index in the Triangle Mesh mode), flag: 0 = inserted, 1 = dropped because an accepted hit had
  * already shortened the ray interval}; records arrive in no particular order.  The reference's own order is the driver's
  * BVH traversal order (undefined); a CPU replay of THIS order must reproduce the frame.  out_records may be NULL
  * (query the count). */

@@ -153,7 +153,7 @@ struct LvUniforms;
 struct LvSceneDev;
 struct LvTiles;
 int lv_mlat_render(lv_ctx* ctx, const LvUniforms& U, const LvSceneDev& S, const LvTiles& T, uint32_t gridTiles,
-                   uint32_t* out, LvDevCounters* dc);
+                   uint32_t* out, LvDevCounters* dc, bool triangles);
 // lv_render.hip
 int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t numTiles, uint32_t tileW,
                     uint32_t tileH, void* outDevice);

@@ -78,7 +78,7 @@ __device__ __forceinline__ bool lv_mlat_insert(float (&c)[K][4], float (&T)[K], 
     return transmittance <= 0.001f && D[K - 1] <= depth;
 }
 
-template <bool STATS, int K>
+template <bool STATS, int K, int PRIM>
 __global__ __launch_bounds__(LV_BLOCK) void k_render_rt_mlat(const LvUniforms U, const LvSceneDev S, const LvTiles T,
                                                              uint32_t* __restrict__ out, LvDevCounters* dc,
                                                              uint4* __restrict__ trace, uint32_t traceCap) {
@@ -121,17 +121,19 @@ __global__ __launch_bounds__(LV_BLOCK) void k_render_rt_mlat(const LvUniforms U,
         for (int i = 0; i < K; i++) { nc[i][0] = nc[i][1] = nc[i][2] = nc[i][3] = 0.0f; nT[i] = 1.0f; nD[i] = 0.0f; }
         float depth2 = 0.0f;
         bool accepted = false;
-        lv_trace_all<STATS, true>(S, U.radius, capped, px.inView, o, d, 0.0001f, 1000.0f, aoTexel, 0.0f, sm, cm, hq, cnt,
+        lv_trace_all<STATS, true, PRIM>(S, U.radius, capped, px.inView, o, d, 0.0001f, 1000.0f, aoTexel, 0.0f, sm, cm, hq, cnt,
             // any-hit, first half: shade (ClosestHitTubeAnalytic) on whichever lane holds the candidate
             [&](unsigned owner, uint32_t leaf, float t, int kind, f3 ro, f3 rd, float ownerAo, float) {
                 LvHit h; h.t = t; h.leaf = leaf; h.kind = kind; h.found = true;
                 float hitT;
-                const f4 color = lv_shade_hit(S, U, ownerAo, ro, rd, h, hitT);
+                // AnyHitTubeTriangles / AnyHitTubeAnalytic: the closest-hit shading of the geometry mode
+                const f4 color = PRIM == LV_PRIM_TRIANGLE ? lv_shade_hit_triangle(S, U, ownerAo, ro, rd, uint32_t(kind), hitT)
+                                                          : lv_shade_hit(S, U, ownerAo, ro, rd, h, hitT);
                 if (STATS) cnt.hits++;
                 if (color.w == 0.0f) return; // ignoreIntersectionEXT, MlatInsert.glsl:77-79
                 s_frag[w][0][lane] = color.x; s_frag[w][1][lane] = color.y; s_frag[w][2][lane] = color.z;
                 s_frag[w][3][lane] = color.w; s_frag[w][4][lane] = t; // depth = gl_HitTEXT
-                s_fragSeg[w][lane] = S.leafSeg[leaf];
+                s_fragSeg[w][lane] = PRIM == LV_PRIM_TRIANGLE ? uint32_t(kind) : S.leafSeg[leaf];
                 s_fragNext[w][lane] = atomicExch(&s_chain[waveBase + owner], lane);
             },
             // any-hit, second half: every pixel's own lane inserts its fragments of this batch one after the other
@@ -193,23 +195,37 @@ __global__ __launch_bounds__(LV_BLOCK) void k_render_rt_mlat(const LvUniforms U,
     if (STATS) { lv_flush_max_nodes(cnt, dc); lv_flush_counters(cnt, dc); }
 }
 
-template <int K>
+template <int K, int PRIM>
 int launchMlat(lv_ctx* ctx, const LvUniforms& U, const LvSceneDev& S, const LvTiles& T, uint32_t gridTiles, uint32_t* out,
                LvDevCounters* dc, uint4* trace, uint32_t traceCap) {
     hipStream_t st = ctx->stream;
     if (ctx->opt.collectStats)
         LV_TIMED_LAUNCH(ctx, LV_KERNEL_RENDER_RT,
-                        (k_render_rt_mlat<true, K><<<gridTiles, LV_BLOCK, 0, st>>>(U, S, T, out, dc, trace, traceCap)));
+                        (k_render_rt_mlat<true, K, PRIM><<<gridTiles, LV_BLOCK, 0, st>>>(U, S, T, out, dc, trace, traceCap)));
     else
         LV_TIMED_LAUNCH(ctx, LV_KERNEL_RENDER_RT,
-                        (k_render_rt_mlat<false, K><<<gridTiles, LV_BLOCK, 0, st>>>(U, S, T, out, dc, nullptr, 0u)));
+                        (k_render_rt_mlat<false, K, PRIM><<<gridTiles, LV_BLOCK, 0, st>>>(U, S, T, out, dc, nullptr, 0u)));
     return LV_OK;
+}
+
+template <int PRIM>
+int launchMlatK(lv_ctx* ctx, const LvUniforms& U, const LvSceneDev& S, const LvTiles& T, uint32_t gridTiles, uint32_t* out,
+                LvDevCounters* dc, uint4* trace, uint32_t traceCap) {
+    switch (ctx->opt.mlatNumNodes) {
+    case 1: return launchMlat<1, PRIM>(ctx, U, S, T, gridTiles, out, dc, trace, traceCap);
+    case 2: return launchMlat<2, PRIM>(ctx, U, S, T, gridTiles, out, dc, trace, traceCap);
+    case 4: return launchMlat<4, PRIM>(ctx, U, S, T, gridTiles, out, dc, trace, traceCap);
+    case 8: return launchMlat<8, PRIM>(ctx, U, S, T, gridTiles, out, dc, trace, traceCap);
+    case 16: return launchMlat<16, PRIM>(ctx, U, S, T, gridTiles, out, dc, trace, traceCap);
+    case 32: return launchMlat<32, PRIM>(ctx, U, S, T, gridTiles, out, dc, trace, traceCap);
+    default: return lv_fail(ctx, LV_E_INVALID, "mlat_num_nodes must be a power of two in [1, 32], got %u", ctx->opt.mlatNumNodes);
+    }
 }
 
 } // namespace
 
 int lv_mlat_render(lv_ctx* ctx, const LvUniforms& U, const LvSceneDev& S, const LvTiles& T, uint32_t gridTiles,
-                   uint32_t* out, LvDevCounters* dc) {
+                   uint32_t* out, LvDevCounters* dc, bool triangles) {
     uint4* trace = nullptr;
     uint32_t traceCap = 0;
     if (ctx->opt.collectStats && ctx->opt.mlatRecordTrace) {
@@ -218,13 +234,6 @@ int lv_mlat_render(lv_ctx* ctx, const LvUniforms& U, const LvSceneDev& S, const 
         trace = (uint4*)ctx->mlatTrace.ptr;
         traceCap = ctx->opt.mlatTraceCapacity;
     }
-    switch (ctx->opt.mlatNumNodes) {
-    case 1: return launchMlat<1>(ctx, U, S, T, gridTiles, out, dc, trace, traceCap);
-    case 2: return launchMlat<2>(ctx, U, S, T, gridTiles, out, dc, trace, traceCap);
-    case 4: return launchMlat<4>(ctx, U, S, T, gridTiles, out, dc, trace, traceCap);
-    case 8: return launchMlat<8>(ctx, U, S, T, gridTiles, out, dc, trace, traceCap);
-    case 16: return launchMlat<16>(ctx, U, S, T, gridTiles, out, dc, trace, traceCap);
-    case 32: return launchMlat<32>(ctx, U, S, T, gridTiles, out, dc, trace, traceCap);
-    default: return lv_fail(ctx, LV_E_INVALID, "mlat_num_nodes must be a power of two in [1, 32], got %u", ctx->opt.mlatNumNodes);
-    }
+    return triangles ? launchMlatK<LV_PRIM_TRIANGLE>(ctx, U, S, T, gridTiles, out, dc, trace, traceCap)
+                     : launchMlatK<LV_PRIM_CAPSULE>(ctx, U, S, T, gridTiles, out, dc, trace, traceCap);
 }

@@ -1122,8 +1122,9 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
         // geometry_mode (VulkanRayTracer.cpp:226-250): analytic capsules, or the triangle tubes with their own LBVH
         const bool tri = ctx->opt.rtTriangleMesh;
         if (ctx->opt.useMlat) { // use_mlat: single-pass approximate transparency (lv_mlat.hip)
-            if (tri) return lv_fail(ctx, LV_E_INVALID, "use_mlat is provided for the analytic tubes only (geometry_mode)");
-            if ((rc = lv_mlat_render(ctx, U, S, T, gridTiles, out, dc))) return rc;
+            LvSceneDev SM = tri ? sceneDevTriangles(ctx) : S;
+            if (tri && (rc = lv_prepare_overflow(ctx, SM, gridTiles, LV_STACK_LDS, true))) return rc;
+            if ((rc = lv_mlat_render(ctx, U, SM, T, gridTiles, out, dc, tri))) return rc;
         } else {
         LvSceneDev SC = tri ? sceneDevTriangles(ctx) : S;
         if (tri && (rc = lv_prepare_overflow(ctx, SC, gridTiles, LV_STACK_LDS, true))) return rc;

@@ -484,7 +484,8 @@ __device__ __forceinline__ LvHit lv_trace_closest(const LvSceneDev& S, float rad
 // every shading batch all lanes call g(n) in convergent control flow (the per-pixel commit step, which may lower
 // cm.ray[2 * lane + 1].w of its own ray = "the any-hit shader accepted a hit"), and the descending lanes pick the new end
 // up for their culling.
-template <bool STATS, bool DYN, typename F, typename G>
+// PRIM = LV_PRIM_TRIANGLE: S is the triangle scene view, f receives the ORIGINAL triangle index in `kind`.
+template <bool STATS, bool DYN, int PRIM = LV_PRIM_CAPSULE, typename F, typename G>
 __device__ __forceinline__ void lv_trace_all(const LvSceneDev& S, float radius, bool capped, bool active, f3 o, f3 d,
                                              float tMin, float tMax, float w0, float w1, const LvStackMem& sm,
                                              const LvCoopMem& cm, const LvHitQueue& hq, LvCounters& cnt, F&& f, G&& g) {
@@ -548,11 +549,19 @@ __device__ __forceinline__ void lv_trace_all(const LvSceneDev& S, float radius, 
                 const unsigned e = cm.queue[(head + lane) % LV_QCAP];
                 const unsigned ow = e >> 26, leaf = e & 0x03FFFFFFu;
                 const float4 ro = cm.ray[2 * ow], rd = cm.ray[2 * ow + 1];
-                const float4 a = S.segs[2 * leaf], b = S.segs[2 * leaf + 1];
                 if (STATS) cnt.prims++;
                 float t; int kind;
-                if (lv_intersect_capsule(mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), mk3(a.x, a.y, a.z),
-                                         mk3(b.x, b.y, b.z), radius, capped, t, kind)) {
+                bool found;
+                if (PRIM == LV_PRIM_TRIANGLE) {
+                    unsigned low;
+                    found = lv_leaf_test<LV_PRIM_TRIANGLE>(S, leaf, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), radius, capped, t, low);
+                    kind = int(low);
+                } else {
+                    const float4 a = S.segs[2 * leaf], b = S.segs[2 * leaf + 1];
+                    found = lv_intersect_capsule(mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), mk3(a.x, a.y, a.z),
+                                                 mk3(b.x, b.y, b.z), radius, capped, t, kind);
+                }
+                if (found) {
                     if (t >= ro.w && (DYN ? t <= rd.w : t < rd.w)) { hit = true; hitRef = e; hitT = t; hitKind = unsigned(kind); }
                 }
             }

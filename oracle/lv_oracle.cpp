@@ -942,6 +942,42 @@ static void renderRt(const lvo_scene* sc, const lvo_params* Pp, int useBvh, cons
     }
 }
 
+// ClosestHitTubeTriangles (TubeRayTracing.glsl:301-352) + LineAttributesBarycentric.glsl:1-52,140-170 -> computeFragmentColor
+inline void shadeHitTri(const lvo_scene& sc, const lvo_tri_scene& tsc, const lvo_params& P, const Frame& F, float aoTexel,
+                        const PrebakedAo* pb, const TriHit& hit, float hc[4], float& payloadHitT) {
+    const uint32_t* ti = &tsc.idx[3 * size_t(hit.tri)];
+    const lvo_tube_vertex& vd0 = tsc.verts[ti[0]];
+    const lvo_tube_vertex& vd1 = tsc.verts[ti[1]];
+    const lvo_tube_vertex& vd2 = tsc.verts[ti[2]];
+    const V3 bc = v3((1.0f - hit.u) - hit.v, hit.u, hit.v);
+    const lvo_line_point& lp0 = tsc.pts[vd0.vertexLinePointIndex & 0x7FFFFFFFu];
+    const lvo_line_point& lp1 = tsc.pts[vd1.vertexLinePointIndex & 0x7FFFFFFFu];
+    const lvo_line_point& lp2 = tsc.pts[vd2.vertexLinePointIndex & 0x7FFFFFFFu];
+    const bool isCap = P.useCappedTubes && (((vd0.vertexLinePointIndex | vd1.vertexLinePointIndex |
+                                              vd2.vertexLinePointIndex) >> 31) != 0u);
+    V3 fragPos = interpolateVec3(ld3(vd0.vertexPosition), ld3(vd1.vertexPosition), ld3(vd2.vertexPosition), bc);
+    V3 fragmentNormal = normalize(interpolateVec3(ld3(vd0.vertexNormal), ld3(vd1.vertexNormal), ld3(vd2.vertexNormal), bc));
+    V3 fragmentTangent = normalize(interpolateVec3(ld3(lp0.lineTangent), ld3(lp1.lineTangent), ld3(lp2.lineTangent), bc));
+    float fragmentAttribute = (lp0.lineAttribute * bc.x + lp1.lineAttribute * bc.y) + lp2.lineAttribute * bc.z;
+    float aoT = aoTexel;
+    if (pb) {
+        // LineAttributesBarycentric.glsl:44-52: interpolateAngle (BarycentricInterpolation.glsl:43-55)
+        // of the vertex angles, interpolated line-vertex id
+        const float PI = 3.14159265358979323846f;
+        float a0 = vd0.phi, a1 = vd1.phi, a2 = vd2.phi;
+        if (a1 - a0 > PI || a2 - a0 > PI) a0 += 2.0f * PI;
+        if (a0 - a1 > PI || a2 - a1 > PI) a1 += 2.0f * PI;
+        if (a0 - a2 > PI || a1 - a2 > PI) a2 += 2.0f * PI;
+        float phi = (a0 * bc.x + a1 * bc.y) + a2 * bc.z;
+        float fragmentVertexId = (float(vd0.vertexLinePointIndex & 0x7FFFFFFFu) * bc.x +
+                                  float(vd1.vertexLinePointIndex & 0x7FFFFFFFu) * bc.y) +
+                                 float(vd2.vertexLinePointIndex & 0x7FFFFFFFu) * bc.z;
+        aoT = prebakedAoLookup(*pb, fragmentVertexId, phi);
+    }
+    computeFragmentColor(sc, P, F, aoT, fragPos, fragmentNormal, fragmentTangent, isCap,
+                         fragmentAttribute, hc, payloadHitT);
+}
+
 // The ray tracer's "Triangle Mesh" geometry mode: RayGen / traceRayTransparent / Miss as above, closest hit
 // ClosestHitTubeTriangles (TubeRayTracing.glsl:301-352) + LineAttributesBarycentric.glsl:1-52,140-170 -> computeFragmentColor.
 // sc supplies the transfer function, tsc the triangle tubes.
@@ -976,37 +1012,7 @@ static void renderRtTri(const lvo_scene* sc, const lvo_tri_scene* tsc, const lvo
                     TriHit hit;
                     float hc[4]; float payloadHitT; bool hasHit;
                     if (closestTri(*tsc, useBvh != 0, o, d, tMin, tMax, hit, cnt)) {
-                        const uint32_t* ti = &tsc->idx[3 * size_t(hit.tri)];
-                        const lvo_tube_vertex& vd0 = tsc->verts[ti[0]];
-                        const lvo_tube_vertex& vd1 = tsc->verts[ti[1]];
-                        const lvo_tube_vertex& vd2 = tsc->verts[ti[2]];
-                        const V3 bc = v3((1.0f - hit.u) - hit.v, hit.u, hit.v);
-                        const lvo_line_point& lp0 = tsc->pts[vd0.vertexLinePointIndex & 0x7FFFFFFFu];
-                        const lvo_line_point& lp1 = tsc->pts[vd1.vertexLinePointIndex & 0x7FFFFFFFu];
-                        const lvo_line_point& lp2 = tsc->pts[vd2.vertexLinePointIndex & 0x7FFFFFFFu];
-                        const bool isCap = P.useCappedTubes && (((vd0.vertexLinePointIndex | vd1.vertexLinePointIndex |
-                                                                  vd2.vertexLinePointIndex) >> 31) != 0u);
-                        V3 fragPos = interpolateVec3(ld3(vd0.vertexPosition), ld3(vd1.vertexPosition), ld3(vd2.vertexPosition), bc);
-                        V3 fragmentNormal = normalize(interpolateVec3(ld3(vd0.vertexNormal), ld3(vd1.vertexNormal), ld3(vd2.vertexNormal), bc));
-                        V3 fragmentTangent = normalize(interpolateVec3(ld3(lp0.lineTangent), ld3(lp1.lineTangent), ld3(lp2.lineTangent), bc));
-                        float fragmentAttribute = (lp0.lineAttribute * bc.x + lp1.lineAttribute * bc.y) + lp2.lineAttribute * bc.z;
-                        float aoT = aoTexel;
-                        if (pb) {
-                            // LineAttributesBarycentric.glsl:44-52: interpolateAngle (BarycentricInterpolation.glsl:43-55)
-                            // of the vertex angles, interpolated line-vertex id
-                            const float PI = 3.14159265358979323846f;
-                            float a0 = vd0.phi, a1 = vd1.phi, a2 = vd2.phi;
-                            if (a1 - a0 > PI || a2 - a0 > PI) a0 += 2.0f * PI;
-                            if (a0 - a1 > PI || a2 - a1 > PI) a1 += 2.0f * PI;
-                            if (a0 - a2 > PI || a1 - a2 > PI) a2 += 2.0f * PI;
-                            float phi = (a0 * bc.x + a1 * bc.y) + a2 * bc.z;
-                            float fragmentVertexId = (float(vd0.vertexLinePointIndex & 0x7FFFFFFFu) * bc.x +
-                                                      float(vd1.vertexLinePointIndex & 0x7FFFFFFFu) * bc.y) +
-                                                     float(vd2.vertexLinePointIndex & 0x7FFFFFFFu) * bc.z;
-                            aoT = prebakedAoLookup(*pb, fragmentVertexId, phi);
-                        }
-                        computeFragmentColor(*sc, P, F, aoT, fragPos, fragmentNormal, fragmentTangent, isCap,
-                                             fragmentAttribute, hc, payloadHitT);
+                        shadeHitTri(*sc, *tsc, P, F, aoTexel, pb, hit, hc, payloadHitT);
                         hasHit = true;
                         cnt.hits++;
                     } else {
@@ -1091,7 +1097,9 @@ static bool mlatInsert(MlatNode* nodes, int numNodes, float& depth2, const float
 //                         beyond it, and every hit that is not listed must lie beyond the final interval (or be fully
 //                         transparent); *outViolations counts the entries that break these rules.
 // outNodesOrNull: per pixel numNodes * 6 floats {color[4], transmittance, depth} + depth2 (last sample).
-static void renderRtMlat(const lvo_scene* sc, const lvo_params* Pp, int useBvh, const float* ao, uint32_t x0, uint32_t y0,
+// tscOrNull: the "Triangle Mesh" geometry mode (AnyHitTubeTriangles): candidates are triangles, ids triangle indices.
+static void renderRtMlat(const lvo_scene* sc, const lvo_tri_scene* tscOrNull, const lvo_params* Pp, int useBvh,
+                         const float* ao, uint32_t x0, uint32_t y0,
                          uint32_t w, uint32_t h, uint32_t numNodes, const uint64_t* traceOffsets,
                          const uint32_t* traceSegs, const uint8_t* traceFlags, uint8_t* outRGBA8, float* outNodesOrNull,
                          uint64_t* outViolations, lvo_stats* stats) {
@@ -1102,7 +1110,8 @@ static void renderRtMlat(const lvo_scene* sc, const lvo_params* Pp, int useBvh, 
 #pragma omp parallel for schedule(dynamic, 4) reduction(+ : rays, nodesV, prims, hitsShaded, violations)
     for (int64_t yy = 0; yy < int64_t(h); yy++) {
         Counters cnt;
-        std::vector<Hit> hits;
+        std::vector<Hit> hits;   // triangles: seg = triangle index, kind unused
+        std::vector<TriHit> triHits;
         std::vector<MlatNode> nodes(numNodes);
         std::vector<uint32_t> listed;
         for (uint32_t xx = 0; xx < w; xx++) {
@@ -1127,14 +1136,42 @@ static void renderRtMlat(const lvo_scene* sc, const lvo_params* Pp, int useBvh, 
                 const float tMin = 0.0001f;
                 float tMax = 1000.0f;
                 bool accepted = false;
+                auto shade = [&](const Hit& hit, float hc[4]) {
+                    float payloadHitT;
+                    if (tscOrNull) {
+                        auto it = std::lower_bound(triHits.begin(), triHits.end(), hit.seg,
+                                                   [](const TriHit& a, uint32_t t) { return a.tri < t; });
+                        shadeHitTri(*sc, *tscOrNull, P, F, aoTexel, nullptr, *it, hc, payloadHitT);
+                    } else {
+                        shadeHit(*sc, P, F, aoTexel, o, d, hit, hc, payloadHitT);
+                    }
+                };
                 auto visit = [&](const Hit& hit) {
-                    float hc[4], payloadHitT;
-                    shadeHit(*sc, P, F, aoTexel, o, d, hit, hc, payloadHitT);
+                    float hc[4];
+                    shade(hit, hc);
                     cnt.hits++;
                     if (mlatInsert(nodes.data(), int(numNodes), depth2, hc, hit.t, false)) { accepted = true; tMax = hit.t; }
                     return hc[3];
                 };
-                allHits(*sc, F.radius, capped, useBvh != 0, o, d, tMin, 1000.0f, hits, cnt); // ascending segment index
+                if (tscOrNull) { // all triangle hits (brute force), ascending triangle index
+                    cnt.rays++;
+                    hits.clear();
+                    triHits.clear();
+                    const V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                    for (uint32_t tri = 0; tri < tscOrNull->nTri; tri++) {
+                        V3 a, b, c;
+                        triVerts(*tscOrNull, tri, a, b, c);
+                        TriHit th;
+                        cnt.prims++;
+                        if (rayTriangle(o, d, inv, a, b, c, tscOrNull->pad, th.t, th.u, th.v) && th.t >= tMin && th.t <= 1000.0f) {
+                            th.tri = tri;
+                            triHits.push_back(th);
+                            hits.push_back(Hit{th.t, tri, 0});
+                        }
+                    }
+                } else {
+                    allHits(*sc, F.radius, capped, useBvh != 0, o, d, tMin, 1000.0f, hits, cnt); // ascending segment index
+                }
                 if (!traceOffsets) {
                     for (const Hit& hit : hits)
                         if (hit.t <= tMax) visit(hit);
@@ -1157,8 +1194,8 @@ static void renderRtMlat(const lvo_scene* sc, const lvo_params* Pp, int useBvh, 
                     for (const Hit& hit : hits) {
                         if (std::binary_search(listed.begin(), listed.end(), hit.seg)) continue;
                         if (hit.t > tMax) continue; // culled by the shrunken interval
-                        float hc[4], payloadHitT;
-                        shadeHit(*sc, P, F, aoTexel, o, d, hit, hc, payloadHitT);
+                        float hc[4];
+                        shade(hit, hc);
                         if (hc[3] != 0.0f) violations++; // a visible layer inside the final interval was never visited
                     }
                 }
@@ -1233,7 +1270,14 @@ void lvo_render_rt_mlat(const lvo_scene* sc, const lvo_params* P, int useBvh, co
                         uint32_t w, uint32_t h, uint32_t numNodes, const uint64_t* traceOffsets,
                         const uint32_t* traceSegs, const uint8_t* traceFlags, uint8_t* outRGBA8, float* outNodesOrNull,
                         uint64_t* outViolations, lvo_stats* stats) {
-    renderRtMlat(sc, P, useBvh, ao, x0, y0, w, h, numNodes, traceOffsets, traceSegs, traceFlags, outRGBA8, outNodesOrNull,
+    renderRtMlat(sc, nullptr, P, useBvh, ao, x0, y0, w, h, numNodes, traceOffsets, traceSegs, traceFlags, outRGBA8,
+                 outNodesOrNull, outViolations, stats);
+}
+void lvo_render_rt_mlat_tri(const lvo_scene* sc, const lvo_tri_scene* tsc, const lvo_params* P, const float* ao, uint32_t x0,
+                            uint32_t y0, uint32_t w, uint32_t h, uint32_t numNodes, const uint64_t* traceOffsets,
+                            const uint32_t* traceTris, const uint8_t* traceFlags, uint8_t* outRGBA8, float* outNodesOrNull,
+                            uint64_t* outViolations, lvo_stats* stats) {
+    renderRtMlat(sc, tsc, P, 0, ao, x0, y0, w, h, numNodes, traceOffsets, traceTris, traceFlags, outRGBA8, outNodesOrNull,
                  outViolations, stats);
 }
 

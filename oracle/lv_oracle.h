@@ -172,6 +172,14 @@ void lvo_render_rt_mlat(
         const uint64_t* traceOffsets, const uint32_t* traceSegs, const uint8_t* traceFlags,
         uint8_t* outRGBA8, float* outNodesOrNull, uint64_t* outViolations, lvo_stats* stats);
 
+/* the same in the "Triangle Mesh" geometry mode: candidates = triangles of the tube mesh (brute force), ids = triangle indices */
+struct lvo_tri_scene;
+void lvo_render_rt_mlat_tri(
+        const lvo_scene*, const struct lvo_tri_scene*, const lvo_params*, const float* ao,
+        uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, uint32_t numNodes,
+        const uint64_t* traceOffsets, const uint32_t* traceTris, const uint8_t* traceFlags,
+        uint8_t* outRGBA8, float* outNodesOrNull, uint64_t* outViolations, lvo_stats* stats);
+
 /* ---- a15-a17: PPLL ---- */
 uint32_t lvo_ppll_addr(uint32_t x, uint32_t y, uint32_t viewportWPadded, uint32_t tileW, uint32_t tileH);
 /* gather: all-hits per pixel-centre ray, fragments appended in ascending segment order.

@@ -123,6 +123,8 @@ def lib():
     L.lvo_mlat_insert.argtypes = [vp, i32, vp, vp, f32, i32, C.POINTER(i32)]
     L.lvo_render_rt_mlat.argtypes = [vp, C.POINTER(Params), i32, vp, u32, u32, u32, u32, u32, vp, vp, vp, vp, vp,
                                      C.POINTER(C.c_uint64), C.POINTER(Stats)]
+    L.lvo_render_rt_mlat_tri.argtypes = [vp, vp, C.POINTER(Params), vp, u32, u32, u32, u32, u32, vp, vp, vp, vp, vp,
+                                         C.POINTER(C.c_uint64), C.POINTER(Stats)]
     L.lvo_ppll_addr.restype = u32
     L.lvo_ppll_addr.argtypes = [u32, u32, u32, u32, u32]
     L.lvo_ppll_gather.argtypes = [vp, C.POINTER(Params), i32, vp, u32, u32, u32, u32, vp, vp, C.POINTER(u32),
@@ -384,7 +386,7 @@ class Scene:
         lib().lvo_pixel_hits(self.h, C.byref(P), ub, x0, y0, w, h, _p(offs), _p(segs), _p(ts))
         return offs, segs[:int(offs[-1])], ts[:int(offs[-1])]
 
-    def render_rt_mlat(self, P, num_nodes, ao=None, tile=None, use_bvh=False, trace=None, stats=None):
+    def render_rt_mlat(self, P, num_nodes, ao=None, tile=None, use_bvh=False, trace=None, stats=None, tri_scene=None):
         """USE_MLAT frame.  trace = None: candidates visited in ascending segment order.  trace = (n, 4) uint32 records
         {viewport pixel index y * W + x, sequence number, segment, flag} (any order): replayed per pixel in sequence
         order and validated.  Returns (rgba8 tile, node states (h, w, num_nodes * 6 + 1), violations)."""
@@ -410,9 +412,12 @@ class Scene:
             offs = np.cumsum(offs).astype(np.uint64)
             segs = np.ascontiguousarray(tr[:, 2], dtype=np.uint32)
             flags = np.ascontiguousarray(tr[:, 3], dtype=np.uint8)
-        lib().lvo_render_rt_mlat(self.h, C.byref(P), self._use_bvh(P, use_bvh), aop, x0, y0, w, h, int(num_nodes),
-                                 _p(offs) if offs is not None else None, _p(segs) if segs is not None else None,
-                                 _p(flags) if flags is not None else None, _p(out), _p(nodes), C.byref(viol), C.byref(st))
+        tr_args = (_p(offs) if offs is not None else None, _p(segs) if segs is not None else None,
+                   _p(flags) if flags is not None else None, _p(out), _p(nodes), C.byref(viol), C.byref(st))
+        if tri_scene is not None:   # "Triangle Mesh" geometry mode: candidates / trace ids are triangles
+            lib().lvo_render_rt_mlat_tri(self.h, tri_scene.h, C.byref(P), aop, x0, y0, w, h, int(num_nodes), *tr_args)
+        else:
+            lib().lvo_render_rt_mlat(self.h, C.byref(P), self._use_bvh(P, use_bvh), aop, x0, y0, w, h, int(num_nodes), *tr_args)
         return out, nodes, int(viol.value)
 
     def ppll_gather(self, P, ao=None, tile=None, use_bvh=False, stats=None):

@@ -148,12 +148,36 @@ def test_options_and_errors(hip_lib):
         ctx.mlat_trace()                                   # more records than the capacity
     ctx.set_option("geometry_mode", "Triangle Mesh")
     with pytest.raises(capi.LineVisError):
-        ctx.render(capi.MODE_RAY_TRACER)
+        ctx.render(capi.MODE_RAY_TRACER)                   # no tube mesh set
     # PPLL ignores the ray tracer's switch
     ctx.set_option("geometry_mode", "AABBs (analytic)")
     a = ctx.render(capi.MODE_PPLL)
     ctx.set_option("use_mlat", False)
     assert np.array_equal(a, ctx.render(capi.MODE_PPLL))
+
+
+@pytest.mark.parametrize("k,transparent", [(2, True), (8, True), (4, False)])
+def test_triangle_mesh_geometry_mode_replay_parity(hip_lib, k, transparent):
+    """AnyHitTubeTriangles: the candidates are the triangles of the tube mesh (both faces of a tube are hit), shaded by
+    the barycentric closest-hit path; same replay contract, trace ids are triangle indices."""
+    lw = 0.02
+    tr = scenes.normalize(scenes.random_curves(n_lines=30, points_per_line=30, seed=7))
+    mesh = lvo.build_tube_triangle_render_data(tr.positions, tr.attributes, tr.line_offsets, lw, 6)
+    c = small_case(line_width=lw, transparent=transparent, geometry_mode="Triangle Mesh", mlat_num_nodes=k, **TRACE)
+    ctx = c.hip_context()
+    ctx.set_tube_triangle_mesh(*mesh)
+    img = ctx.render(capi.MODE_RAY_TRACER)
+    rec = ctx.mlat_trace()
+    sc = c.oracle_scene()
+    P = c.oracle_params(sc)
+    ts = lvo.TriScene(*mesh, lw)
+    ref, _, viol = sc.render_rt_mlat(P, k, trace=rec, tri_scene=ts)
+    assert viol == 0 and max_lsb_diff(img, ref) <= LSB_TOL
+    assert len(rec) > 3000 and rec[:, 2].max() < len(mesh[0])
+    # close to the exact transparency loop over the same mesh
+    ctx.set_option("use_mlat", False)
+    loop = ctx.render(capi.MODE_RAY_TRACER)
+    assert np.abs(img.astype(np.int32) - loop.astype(np.int32)).mean() < (5.0 if k < 4 else 2.5)
 
 
 def test_plugin_surface(hip_lib):
