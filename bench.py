@@ -34,9 +34,11 @@ SETTINGS = {
 }
 WORKLOAD = ("C3: 1M-segment tornado-style streamlines (1000 lines x 1001 points, seed 12345), 1920x1080, "
             "colour pass 1 spp + RTAO 64 spp (1 iteration x 64 samples, radius 0.1, distance based), line width 0.002")
+# AO rays hit the analytic capsules of the segment LBVH (north_star's hot path); "c3t" runs the reference's own RTAO geometry
+RTAO_CAPSULES = ", AO rays against the analytic capsules of the segment LBVH (rtao_geometry=capsules; workload c3t = triangle tubes)"
 # secondary workloads (documentation runs: --workload c2 / c4); the default and the driver's runs are C3
 WORKLOADS = {
-    "c3": dict(name=WORKLOAD, scene="tornado", mode=11, settings=SETTINGS, kernel="k_ao_rays"),
+    "c3": dict(name=WORKLOAD + RTAO_CAPSULES, scene="tornado", mode=11, settings=SETTINGS, kernel="k_ao_rays"),
     "c3t": dict(name=WORKLOAD + ", RTAO against the reference's 6-gon triangle tubes (12.06 M triangles, "
                      "rtao_geometry=triangle_tubes)",
                 scene="tornado", mode=11, settings=dict(SETTINGS, rtao_geometry="triangle_tubes"), kernel="k_ao_rays"),
