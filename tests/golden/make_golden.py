@@ -289,7 +289,8 @@ def flow_small():
     out = dict(n=n, spacing=np.float32(d), seeds=seeds, field_crc=np.uint32(np.bitwise_xor.reduce(v.reshape(-1).view(np.uint32))))
     for key, method, direction in (("rk4_both", "Runge-Kutta 4th Order", "Forward & Backward"),
                                    ("euler_fwd", "Explicit Euler", "Forward"), ("heun_bwd", "Heun", "Backward"),
-                                   ("midpoint_both", "Midpoint", "Forward & Backward")):
+                                   ("midpoint_both", "Midpoint", "Forward & Backward"),
+                                   ("implicit_fwd", "Implicit Euler", "Forward")):
         S = lvo.streamline_settings(method, direction, minimum_length=0.25)
         pos, att, off = lvo.trace_streamlines(v, (d, d, d), [mag], seeds, S)
         out[key + "_pos_bits"] = f2u(pos)

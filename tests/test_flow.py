@@ -29,7 +29,8 @@ def test_abc_flow_generator_and_golden_traces():
     d = float(G["spacing"])
     for key, method, direction in (("rk4_both", "Runge-Kutta 4th Order", "Forward & Backward"),
                                    ("euler_fwd", "Explicit Euler", "Forward"), ("heun_bwd", "Heun", "Backward"),
-                                   ("midpoint_both", "Midpoint", "Forward & Backward")):
+                                   ("midpoint_both", "Midpoint", "Forward & Backward"),
+                                   ("implicit_fwd", "Implicit Euler", "Forward")):
         pos, att, off = lvo.trace_streamlines(v, (d, d, d), [mag], G["seeds"],
                                               lvo.streamline_settings(method, direction, minimum_length=0.25))
         assert np.array_equal(off, G[key + "_off"]) and np.array_equal(bits(pos), G[key + "_pos_bits"])

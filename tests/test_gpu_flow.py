@@ -164,7 +164,8 @@ def test_streamlines_golden_fixture(hip_lib):
     ctx.set_flow_grid(v, (d, d, d), [mag])
     for key, method, direction in (("rk4_both", "Runge-Kutta 4th Order", "Forward & Backward"),
                                    ("euler_fwd", "Explicit Euler", "Forward"), ("heun_bwd", "Heun", "Backward"),
-                                   ("midpoint_both", "Midpoint", "Forward & Backward")):
+                                   ("midpoint_both", "Midpoint", "Forward & Backward"),
+                                   ("implicit_fwd", "Implicit Euler", "Forward")):
         pos, att, off = ctx.trace_streamlines(g["seeds"], capi.streamline_settings(method, direction, minimum_length=0.25))
         assert np.array_equal(off, g[key + "_off"])
         assert np.array_equal(pos.view(np.uint32), g[key + "_pos_bits"]) and np.array_equal(att.view(np.uint32), g[key + "_att_bits"])
