@@ -11,9 +11,10 @@
 //   radix sort    rocprim::radix_sort_pairs (key, segment)
 //   k_leaves      32-byte segment records + leaf boxes written in Morton order
 //   k_karras      Karras 2012 topology: one thread per internal node
-//   k_refit       bottom-up AABB + height, second arriver continues (agent-scope release/acquire)
+//   k_refit_pass  bottom-up AABB + height, one pass per tree level (kernel boundaries are the synchronisation)
 //   k_collapse_*  greedy area-guided collapse into 64-byte compressed 4-wide nodes (8-bit child boxes + references), one
 //                 BFS level of the wide tree per pass, rocPRIM exclusive scan for the deterministic node numbering
+#include <algorithm>
 #include <cstring>
 #include <utility>
 
@@ -24,31 +25,44 @@
 
 namespace {
 
+// Scene bounds: the box kernels run grid-stride and merge per WORKGROUP (wave reduce -> LDS -> 6 atomics on the six
+// encoded words); one set of atomics per wave of a one-primitive-per-thread launch was 94 k contended atomics = half of
+// k_seg_boxes at 1 M segments.  Every thread of the block must call it.
+__device__ __forceinline__ void lv_block_bounds(const float mn[3], const float mx[3], uint32_t* boundsOrd) {
+    __shared__ float s_red[6][LV_BLOCK / LV_WAVE];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float a = lv_wave_min(mn[k]), b = lv_wave_max(mx[k]);
+        if (lv_lane() == 0) { s_red[k][threadIdx.x >> 6] = a; s_red[3 + k][threadIdx.x >> 6] = b; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        float v = s_red[threadIdx.x][0];
+        for (int w = 1; w < LV_BLOCK / LV_WAVE; w++)
+            v = threadIdx.x < 3 ? fminf(v, s_red[threadIdx.x][w]) : fmaxf(v, s_red[threadIdx.x][w]);
+        if (threadIdx.x < 3) atomicMin(&boundsOrd[threadIdx.x], lv_f2ord(v));
+        else atomicMax(&boundsOrd[threadIdx.x], lv_f2ord(v));
+    }
+}
+
 __global__ __launch_bounds__(LV_BLOCK) void k_seg_boxes(const lv_line_point* __restrict__ points,
                                                         const uint32_t* __restrict__ segIdx, uint32_t nSeg, float radius,
                                                         float pad, float* __restrict__ boxOrig,
                                                         uint32_t* __restrict__ boundsOrd) {
-    uint32_t s = blockIdx.x * LV_BLOCK + threadIdx.x;
     float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
-    if (s < nSeg) {
+    for (uint32_t s = blockIdx.x * LV_BLOCK + threadIdx.x; s < nSeg; s += gridDim.x * LV_BLOCK) {
         const float* p0 = points[segIdx[2 * s]].linePosition;
         const float* p1 = points[segIdx[2 * s + 1]].linePosition;
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-            mn[k] = (fminf(p0[k], p1[k]) - radius) - pad;
-            mx[k] = (fmaxf(p0[k], p1[k]) + radius) + pad;
-            boxOrig[6 * size_t(s) + k] = mn[k];
-            boxOrig[6 * size_t(s) + 3 + k] = mx[k];
+            const float lo = (fminf(p0[k], p1[k]) - radius) - pad, hi = (fmaxf(p0[k], p1[k]) + radius) + pad;
+            boxOrig[6 * size_t(s) + k] = lo;
+            boxOrig[6 * size_t(s) + 3 + k] = hi;
+            mn[k] = fminf(mn[k], lo);
+            mx[k] = fmaxf(mx[k], hi);
         }
     }
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        float a = lv_wave_min(mn[k]), b = lv_wave_max(mx[k]);
-        if (lv_lane() == 0) {
-            atomicMin(&boundsOrd[k], lv_f2ord(a));
-            atomicMax(&boundsOrd[3 + k], lv_f2ord(b));
-        }
-    }
+    lv_block_bounds(mn, mx, boundsOrd);
 }
 
 __device__ __forceinline__ uint64_t expandBits21(uint64_t v) {
@@ -101,28 +115,21 @@ __global__ __launch_bounds__(LV_BLOCK) void k_leaves(const lv_line_point* __rest
 __global__ __launch_bounds__(LV_BLOCK) void k_tri_boxes(const lv_tube_vertex* __restrict__ verts,
                                                         const uint32_t* __restrict__ triIdx, uint32_t nTri, float pad,
                                                         float* __restrict__ boxOrig, uint32_t* __restrict__ boundsOrd) {
-    uint32_t s = blockIdx.x * LV_BLOCK + threadIdx.x;
     float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
-    if (s < nTri) {
+    for (uint32_t s = blockIdx.x * LV_BLOCK + threadIdx.x; s < nTri; s += gridDim.x * LV_BLOCK) {
         const float* a = verts[triIdx[3 * size_t(s)]].vertexPosition;
         const float* b = verts[triIdx[3 * size_t(s) + 1]].vertexPosition;
         const float* c = verts[triIdx[3 * size_t(s) + 2]].vertexPosition;
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-            mn[k] = fminf(fminf(a[k], b[k]), c[k]) - pad;
-            mx[k] = fmaxf(fmaxf(a[k], b[k]), c[k]) + pad;
-            boxOrig[6 * size_t(s) + k] = mn[k];
-            boxOrig[6 * size_t(s) + 3 + k] = mx[k];
+            const float lo = fminf(fminf(a[k], b[k]), c[k]) - pad, hi = fmaxf(fmaxf(a[k], b[k]), c[k]) + pad;
+            boxOrig[6 * size_t(s) + k] = lo;
+            boxOrig[6 * size_t(s) + 3 + k] = hi;
+            mn[k] = fminf(mn[k], lo);
+            mx[k] = fmaxf(mx[k], hi);
         }
     }
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        float a = lv_wave_min(mn[k]), b = lv_wave_max(mx[k]);
-        if (lv_lane() == 0) {
-            atomicMin(&boundsOrd[k], lv_f2ord(a));
-            atomicMax(&boundsOrd[3 + k], lv_f2ord(b));
-        }
-    }
+    lv_block_bounds(mn, mx, boundsOrd);
 }
 
 // 48-byte triangle records in Morton order: {v0.xyz, original triangle index}{v1.xyz, 0}{v2.xyz, 0}
@@ -154,8 +161,7 @@ __device__ __forceinline__ int lv_delta(const uint64_t* __restrict__ keys, int n
 // Karras, "Maximizing Parallelism in the Construction of BVHs, Octrees, and k-d Trees", HPG 2012.
 // Internal nodes 0..n-2 (root = 0); child reference = index | LEAF_BIT for leaves.
 __global__ __launch_bounds__(LV_BLOCK) void k_karras(const uint64_t* __restrict__ keys, int n, uint32_t* __restrict__ childL,
-                                                     uint32_t* __restrict__ childR, uint32_t* __restrict__ parentInternal,
-                                                     uint32_t* __restrict__ parentLeaf) {
+                                                     uint32_t* __restrict__ childR) {
     int i = blockIdx.x * LV_BLOCK + threadIdx.x;
     if (i >= n - 1) return;
     int d = (lv_delta(keys, n, i, i + 1) - lv_delta(keys, n, i, i - 1)) >= 0 ? 1 : -1;
@@ -176,62 +182,49 @@ __global__ __launch_bounds__(LV_BLOCK) void k_karras(const uint64_t* __restrict_
     int gamma = i + s * d + min(d, 0);
     int lo = min(i, j), hi = max(i, j);
     uint32_t left, right;
-    if (lo == gamma) { left = uint32_t(gamma) | LV_LEAF_BIT; parentLeaf[gamma] = uint32_t(i); }
-    else { left = uint32_t(gamma); parentInternal[gamma] = uint32_t(i); }
-    if (hi == gamma + 1) { right = uint32_t(gamma + 1) | LV_LEAF_BIT; parentLeaf[gamma + 1] = uint32_t(i); }
-    else { right = uint32_t(gamma + 1); parentInternal[gamma + 1] = uint32_t(i); }
+    if (lo == gamma) left = uint32_t(gamma) | LV_LEAF_BIT;
+    else left = uint32_t(gamma);
+    if (hi == gamma + 1) right = uint32_t(gamma + 1) | LV_LEAF_BIT;
+    else right = uint32_t(gamma + 1);
     childL[i] = left;
     childR[i] = right;
-    if (i == 0) parentInternal[0] = LV_INVALID;
 }
 
-__device__ __forceinline__ void lv_child_box(uint32_t c, const float* __restrict__ leafBox, const float* nodeBox,
-                                             const uint32_t* height, float b[6], uint32_t& hgt) {
-    // plain loads: callers issue an agent-scope acquire first
-    if (c & LV_LEAF_BIT) {
-        const float* p = leafBox + 6 * size_t(c & ~LV_LEAF_BIT);
-#pragma unroll
-        for (int k = 0; k < 6; k++) b[k] = p[k];
-        hgt = 0;
-    } else {
-        const float* p = nodeBox + 6 * size_t(c);
-#pragma unroll
-        for (int k = 0; k < 6; k++) b[k] = p[k];
-        hgt = height[c];
+// Bottom-up boxes + heights in PASSES: in pass k every internal node whose two children were finished in an EARLIER pass
+// (leaves always are) computes its box and height and stamps itself with k.  The kernel boundary between passes is the only
+// synchronisation -- per-CU L1s and per-XCD L2s are not coherent, and the classic "second thread to arrive continues"
+// refit needs an agent-scope release/acquire pair (an L2 write-back / invalidate) per node and thread: 3.8 ms for 1 M
+// segments against 0.5 ms for the ~30 passes a Morton-ordered tree of that size needs (one pass per tree level).
+__global__ __launch_bounds__(LV_BLOCK) void k_refit_pass(uint32_t nInternal, uint32_t pass, const uint32_t* __restrict__ childL,
+                                                         const uint32_t* __restrict__ childR,
+                                                         const float* __restrict__ leafBox, float* nodeBox,
+                                                         uint32_t* height, uint32_t* done) {
+    const uint32_t i = blockIdx.x * LV_BLOCK + threadIdx.x;
+    if (i >= nInternal || done[i] != 0u) return;
+    const uint32_t cl = childL[i], cr = childR[i];
+    uint32_t hl = 0, hr = 0;
+    const float *bl, *br;
+    if (cl & LV_LEAF_BIT) bl = leafBox + 6 * size_t(cl & ~LV_LEAF_BIT);
+    else {
+        const uint32_t d = done[cl];
+        if (d == 0u || d >= pass) return; // not finished, or finished in THIS pass (not visible yet)
+        bl = nodeBox + 6 * size_t(cl);
+        hl = height[cl];
     }
-}
-
-// One thread per leaf walks towards the root; the first thread to reach a node stops, the second one (which
-// finds flag == 1) owns it.  Cross-CU visibility: per-CU L1s are never refreshed by other CUs' stores and the
-// per-XCD L2s are not coherent, so the producer publishes with an agent-scope release before the counter RMW and
-// the consumer invalidates with an agent-scope acquire after it (cdna_hip_programming.md §6 Guideline 16).
-__global__ __launch_bounds__(LV_BLOCK) void k_refit(int n, const uint32_t* __restrict__ childL,
-                                                    const uint32_t* __restrict__ childR,
-                                                    const uint32_t* __restrict__ parentInternal,
-                                                    const uint32_t* __restrict__ parentLeaf,
-                                                    const float* __restrict__ leafBox, float* nodeBox, uint32_t* height,
-                                                    uint32_t* flags) {
-    int i = blockIdx.x * LV_BLOCK + threadIdx.x;
-    if (i >= n) return;
-    uint32_t p = parentLeaf[i];
-    while (p != LV_INVALID) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        uint32_t old = __hip_atomic_fetch_add(&flags[p], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (old == 0) return;
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        float a[6], b[6];
-        uint32_t ha, hb;
-        lv_child_box(childL[p], leafBox, nodeBox, height, a, ha);
-        lv_child_box(childR[p], leafBox, nodeBox, height, b, hb);
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            nodeBox[6 * size_t(p) + k] = fminf(a[k], b[k]);
-            nodeBox[6 * size_t(p) + 3 + k] = fmaxf(a[k + 3], b[k + 3]);
-        }
-        height[p] = max(ha, hb) + 1;
-        p = parentInternal[p];
+    if (cr & LV_LEAF_BIT) br = leafBox + 6 * size_t(cr & ~LV_LEAF_BIT);
+    else {
+        const uint32_t d = done[cr];
+        if (d == 0u || d >= pass) return;
+        br = nodeBox + 6 * size_t(cr);
+        hr = height[cr];
     }
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        nodeBox[6 * size_t(i) + k] = fminf(bl[k], br[k]);
+        nodeBox[6 * size_t(i) + 3 + k] = fmaxf(bl[k + 3], br[k + 3]);
+    }
+    height[i] = max(hl, hr) + 1u;
+    done[i] = pass;
 }
 
 // 64-byte COMPRESSED 4-wide node = 4 x float4 (one dwordx4 load each):
@@ -405,14 +398,12 @@ static int lv_bvh_build_core(lv_ctx* ctx, uint32_t n, LvDeviceBuffer& nodesOut, 
     // 4-wide nodes: one per even-depth binary node; at most all of them (a degenerate chain has ~n/2)
     if ((rc = lv_buf_reserve(ctx, nodesOut, size_t(nInternal) * 64))) return rc;
 
-    // temporaries
-    LvDeviceBuffer boxOrig, leafBox, nodeBox, keysA, keysB, valsA, valsB, childL, childR, parI, parL, height, flags, bounds,
-            sortTmp, depth, evenFlag, wideIndex, slots;
-    auto freeAll = [&]() {
-        for (LvDeviceBuffer* b : {&boxOrig, &leafBox, &nodeBox, &keysA, &keysB, &valsA, &valsB, &childL, &childR, &parI,
-                                  &parL, &height, &flags, &bounds, &sortTmp, &depth, &evenFlag, &wideIndex, &slots})
-            lv_buf_free(*b);
-    };
+    // temporaries: carved out of ONE arena that the context keeps between builds (≈ 200 B per primitive) -- seventeen
+    // hipMalloc / hipFree pairs per build cost more host time than the kernels of a 1 M-segment build take
+    struct Tmp { void* ptr = nullptr; };
+    Tmp boxOrig, leafBox, nodeBox, keysA, keysB, valsA, valsB, childL, childR, height, flags, bounds, sortTmp, depth, evenFlag,
+            wideIndex, slots;
+    auto freeAll = [&]() {};
 #define LV_TRY(expr)                 \
     do {                             \
         int _rc = (expr);            \
@@ -426,25 +417,26 @@ static int lv_bvh_build_core(lv_ctx* ctx, uint32_t n, LvDeviceBuffer& nodesOut, 
             return lv_fail(ctx, LV_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
         }                                                                                                 \
     } while (0)
-
-    LV_TRY(lv_buf_reserve(ctx, boxOrig, size_t(n) * 24));
-    LV_TRY(lv_buf_reserve(ctx, leafBox, size_t(n) * 24));
-    LV_TRY(lv_buf_reserve(ctx, nodeBox, size_t(nInternal) * 24));
-    LV_TRY(lv_buf_reserve(ctx, keysA, size_t(n) * 8));
-    LV_TRY(lv_buf_reserve(ctx, keysB, size_t(n) * 8));
-    LV_TRY(lv_buf_reserve(ctx, valsA, size_t(n) * 4));
-    LV_TRY(lv_buf_reserve(ctx, valsB, size_t(n) * 4));
-    LV_TRY(lv_buf_reserve(ctx, childL, size_t(nInternal) * 4));
-    LV_TRY(lv_buf_reserve(ctx, childR, size_t(nInternal) * 4));
-    LV_TRY(lv_buf_reserve(ctx, parI, size_t(nInternal) * 4));
-    LV_TRY(lv_buf_reserve(ctx, parL, size_t(n) * 4));
-    LV_TRY(lv_buf_reserve(ctx, height, size_t(nInternal) * 4));
-    LV_TRY(lv_buf_reserve(ctx, flags, size_t(nInternal) * 4));
-    LV_TRY(lv_buf_reserve(ctx, bounds, 6 * 4));
-    LV_TRY(lv_buf_reserve(ctx, depth, size_t(nInternal) * 4));
-    LV_TRY(lv_buf_reserve(ctx, evenFlag, size_t(nInternal) * 4));
-    LV_TRY(lv_buf_reserve(ctx, wideIndex, size_t(nInternal) * 4));
-    LV_TRY(lv_buf_reserve(ctx, slots, size_t(nInternal) * 16));
+    size_t sortBytes = 0, scanBytes = 0;
+    LV_HIPF(rocprim::radix_sort_pairs(nullptr, sortBytes, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr,
+                                      (uint32_t*)nullptr, n, 0, 63, st));
+    LV_HIPF(rocprim::exclusive_scan(nullptr, scanBytes, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, nInternal,
+                                    rocprim::plus<uint32_t>(), st));
+    {
+        struct Req { Tmp* t; size_t bytes; };
+        const Req reqs[] = {{&boxOrig, size_t(n) * 24}, {&leafBox, size_t(n) * 24}, {&nodeBox, size_t(nInternal) * 24},
+                            {&keysA, size_t(n) * 8}, {&keysB, size_t(n) * 8}, {&valsA, size_t(n) * 4}, {&valsB, size_t(n) * 4},
+                            {&childL, size_t(nInternal) * 4}, {&childR, size_t(nInternal) * 4},
+                            {&height, size_t(nInternal) * 4}, {&flags, size_t(nInternal) * 4}, {&bounds, 6 * 4},
+                            {&sortTmp, std::max<size_t>(std::max(sortBytes, scanBytes), 16)},
+                            {&depth, size_t(nInternal) * 4}, {&evenFlag, size_t(nInternal) * 4},
+                            {&wideIndex, size_t(nInternal) * 4}, {&slots, size_t(nInternal) * 16}};
+        size_t total = 0;
+        for (const Req& r : reqs) total += (r.bytes + 255) & ~size_t(255);
+        LV_TRY(lv_buf_reserve(ctx, ctx->buildArena, total));
+        size_t off = 0;
+        for (const Req& r : reqs) { r.t->ptr = (char*)ctx->buildArena.ptr + off; off += (r.bytes + 255) & ~size_t(255); }
+    }
 
     if (timed) LV_HIPF(hipEventRecord(ctx->ev[0], st));
     // bounds: min slots start at ord(+big) = 0xFFFFFFFF-ish, max slots at 0
@@ -457,10 +449,7 @@ static int lv_bvh_build_core(lv_ctx* ctx, uint32_t n, LvDeviceBuffer& nodesOut, 
     k_morton<<<nblocks(n), LV_BLOCK, 0, st>>>((const float*)boxOrig.ptr, n, (const uint32_t*)bounds.ptr,
                                               (uint64_t*)keysA.ptr, (uint32_t*)valsA.ptr);
     {
-        size_t tmpBytes = 0;
-        LV_HIPF(rocprim::radix_sort_pairs(nullptr, tmpBytes, (uint64_t*)keysA.ptr, (uint64_t*)keysB.ptr,
-                                          (uint32_t*)valsA.ptr, (uint32_t*)valsB.ptr, n, 0, 63, st));
-        LV_TRY(lv_buf_reserve(ctx, sortTmp, tmpBytes ? tmpBytes : 16));
+        size_t tmpBytes = sortBytes;
         LV_HIPF(rocprim::radix_sort_pairs(sortTmp.ptr, tmpBytes, (uint64_t*)keysA.ptr, (uint64_t*)keysB.ptr,
                                           (uint32_t*)valsA.ptr, (uint32_t*)valsB.ptr, n, 0, 63, st));
     }
@@ -470,12 +459,21 @@ static int lv_bvh_build_core(lv_ctx* ctx, uint32_t n, LvDeviceBuffer& nodesOut, 
     } else {
         LV_HIPF(hipMemsetAsync(flags.ptr, 0, size_t(nInternal) * 4, st));
         k_karras<<<nblocks(nInternal), LV_BLOCK, 0, st>>>((const uint64_t*)keysB.ptr, int(n), (uint32_t*)childL.ptr,
-                                                          (uint32_t*)childR.ptr, (uint32_t*)parI.ptr,
-                                                          (uint32_t*)parL.ptr);
-        k_refit<<<nblocks(n), LV_BLOCK, 0, st>>>(int(n), (const uint32_t*)childL.ptr, (const uint32_t*)childR.ptr,
-                                                 (const uint32_t*)parI.ptr, (const uint32_t*)parL.ptr,
-                                                 (const float*)leafBox.ptr, (float*)nodeBox.ptr, (uint32_t*)height.ptr,
-                                                 (uint32_t*)flags.ptr);
+                                                          (uint32_t*)childR.ptr);
+        // refit: one pass per level of the binary tree; the root's stamp is polled every 8 passes
+        for (uint32_t pass = 1;; pass++) {
+            k_refit_pass<<<nblocks(nInternal), LV_BLOCK, 0, st>>>(nInternal, pass, (const uint32_t*)childL.ptr,
+                                                                  (const uint32_t*)childR.ptr, (const float*)leafBox.ptr,
+                                                                  (float*)nodeBox.ptr, (uint32_t*)height.ptr,
+                                                                  (uint32_t*)flags.ptr);
+            if (pass % 8u == 0u) {
+                uint32_t rootDone = 0;
+                LV_HIPF(hipMemcpyAsync(&rootDone, flags.ptr, 4, hipMemcpyDeviceToHost, st));
+                LV_HIPF(hipStreamSynchronize(st));
+                if (rootDone) break;
+                if (pass > 4096u) { freeAll(); return lv_fail(ctx, LV_E_HIP, "LBVH refit did not converge"); }
+            }
+        }
         // collapse: one pass per BFS level of the wide tree (see k_collapse_select)
         {
             uint32_t zero = 0u;
@@ -484,10 +482,6 @@ static int lv_bvh_build_core(lv_ctx* ctx, uint32_t n, LvDeviceBuffer& nodesOut, 
             uint32_t* frontier = (uint32_t*)depth.ptr;
             uint32_t* nextFrontier = (uint32_t*)evenFlag.ptr;
             uint32_t count = 1, base = 0;
-            size_t scanBytes = 0;
-            LV_HIPF(rocprim::exclusive_scan(nullptr, scanBytes, (uint32_t*)wideIndex.ptr, (uint32_t*)flags.ptr, 0u, nInternal,
-                                            rocprim::plus<uint32_t>(), st));
-            LV_TRY(lv_buf_reserve(ctx, sortTmp, scanBytes ? scanBytes : 16));
             while (count > 0) {
                 k_collapse_select<<<nblocks(count), LV_BLOCK, 0, st>>>(frontier, count, (const uint32_t*)childL.ptr,
                                                                        (const uint32_t*)childR.ptr, (const float*)nodeBox.ptr,
@@ -552,7 +546,7 @@ int lv_bvh_build(lv_ctx* ctx) {
     rc = lv_bvh_build_core(
             ctx, n, ctx->nodes, ctx->numNodes, ctx->bvhDepth, ctx->wideDepth, true,
             [&](float* boxOrig, uint32_t* bounds) {
-                k_seg_boxes<<<nblocks(n), LV_BLOCK, 0, st>>>(points, segIdx, n, radius, pad, boxOrig, bounds);
+                k_seg_boxes<<<std::min(nblocks(n), 2048u), LV_BLOCK, 0, st>>>(points, segIdx, n, radius, pad, boxOrig, bounds);
             },
             [&](const uint32_t* sortedVals, const float* boxOrig, float* leafBox) {
                 k_leaves<<<nblocks(n), LV_BLOCK, 0, st>>>(points, segIdx, boxOrig, sortedVals, n, (float4*)ctx->segs.ptr,
@@ -589,7 +583,7 @@ int lv_bvh_build_triangles(lv_ctx* ctx) {
     rc = lv_bvh_build_core(
             ctx, n, ctx->triNodes, ctx->numTriNodes, ctx->triBvhDepth, ctx->triWideDepth, false,
             [&](float* boxOrig, uint32_t* bounds) {
-                k_tri_boxes<<<nblocks(n), LV_BLOCK, 0, st>>>(verts, triIdx, n, pad, boxOrig, bounds);
+                k_tri_boxes<<<std::min(nblocks(n), 2048u), LV_BLOCK, 0, st>>>(verts, triIdx, n, pad, boxOrig, bounds);
             },
             [&](const uint32_t* sortedVals, const float* boxOrig, float* leafBox) {
                 k_tri_leaves<<<nblocks(n), LV_BLOCK, 0, st>>>(verts, triIdx, boxOrig, sortedVals, n,

@@ -105,6 +105,7 @@ struct lv_ctx {
     LvDeviceBuffer counters;                  // device counters (LvCounters + misc)
     LvDeviceBuffer ppllNodes, ppllStart, ppllCount, ppllScratch;
     LvDeviceBuffer tilesDev, outDev, scratchRays, stackOverflow, mlatTrace;
+    LvDeviceBuffer buildArena;                // temporaries of the LBVH builds, kept between builds
     std::vector<uint32_t> tilesHost;          // staging copy: caller's tile list is borrowed for the call only
     bool tilesUploaded = false;               // tilesDev holds tilesHost
     uint64_t ppllPoolNodes = 0;
