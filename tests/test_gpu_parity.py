@@ -423,6 +423,44 @@ def test_full_size_properties(hip_lib):
     assert max_lsb_diff(full[y0:y0 + h, x0:x0 + w], ref) <= LSB_TOL
 
 
+def test_config3_whole_frame_against_the_oracle(hip_lib):
+    """The headline workload, every pixel: 1 M segments, 1920 x 1080, RTAO 64 spp -- AO factors of all 2 M pixels bit for
+    bit, the RGBA8 frame within the bar (the oracle traces the same 27 M rays on the host cores with its own BVH)."""
+    tr = scenes.normalize(scenes.tornado())
+    flow = host_api.LineDataFlow().set_trajectories(tr.positions, tr.attributes, tr.line_offsets)
+    pts, seg, _ = flow.tube_aabb_render_data(0.002)
+    c = Case(pts, seg, tfm.standard(), 1920, 1080, 0.002, **RTAO, ambient_occlusion_iterations=1,
+             ambient_occlusion_samples_per_frame=64)
+    ctx = c.hip_context()
+    img = ctx.render(11)
+    ao = ctx.get_ao()
+    sc = c.oracle_scene()
+    P = c.oracle_params(sc)
+    ao_ref = sc.render_ao(P, use_bvh=True)
+    assert np.array_equal(bits(ao), bits(ao_ref))
+    assert (ao_ref < 1.0).sum() > 300000
+    ref = sc.render_rt(P, ao=ao_ref, use_bvh=True)
+    assert max_lsb_diff(img, ref) <= LSB_TOL
+
+
+def test_config2_whole_frame_against_the_oracle(hip_lib):
+    """BASELINE.json config 2: 100 k-segment helix bundle, 1920 x 1080, primary rays only -- every pixel."""
+    tr = scenes.normalize(scenes.helix_bundle())
+    flow = host_api.LineDataFlow().set_trajectories(tr.positions, tr.attributes, tr.line_offsets)
+    pts, seg, _ = flow.tube_aabb_render_data(0.002)
+    assert len(seg) == 100000
+    c = Case(pts, seg, tfm.standard(), 1920, 1080, 0.002)
+    ctx = c.hip_context()
+    lo, hi = flow.attribute_range()
+    ctx.set_transfer_function(c.tf, lo, hi)
+    img = ctx.render(11)
+    sc = c.oracle_scene()
+    P = c.oracle_params(sc)
+    P.attrMin, P.attrMax = lo, hi
+    ref = sc.render_rt(P, use_bvh=True)
+    assert max_lsb_diff(img, ref) <= LSB_TOL and (ref[..., :3] != 255).any(axis=2).sum() > 50000
+
+
 # ---------------------------------------------------------------- BASELINE.json config 4 at full size
 def test_config4_full_size_ppll_and_mlat(hip_lib):
     """1 M transparent segments at 1920 x 1080: fragment lists of a crop against the oracle bit for bit, list lengths
