@@ -193,6 +193,28 @@ def test_triangle_tubes_medium_scene_bvh_agreement(hip_lib):
     assert np.array_equal(a2[1][sub], c2[1]) and np.array_equal(bits(a2[0][sub]), bits(c2[0]))
 
 
+def test_config3_whole_frame_with_the_reference_rtao_geometry(hip_lib):
+    """BASELINE.json config 3 with rtao_geometry = triangle_tubes (what the reference's RTAO pass traces): 1 M segments =
+    12.06 M triangles, 1920 x 1080, 64 spp -- the AO factors of every pixel bit for bit, the frame within the bar."""
+    lw = 0.002
+    tr = scenes.normalize(scenes.tornado())
+    flow = host_api.LineDataFlow().set_trajectories(tr.positions, tr.attributes, tr.line_offsets)
+    mesh = flow.tube_triangle_render_data(lw, 6)
+    assert len(mesh[0]) > 12000000
+    pts, seg, _ = flow.tube_aabb_render_data(lw)
+    case = Case(pts, seg, tfm.standard(), 1920, 1080, lw, ambient_occlusion_iterations=1,
+                ambient_occlusion_samples_per_frame=64, **RTAO_TRI)
+    ctx = tri_context(case, mesh)
+    img = ctx.render(capi.MODE_RAY_TRACER)
+    ao = ctx.get_ao()
+    sc = case.oracle_scene()
+    P = case.oracle_params(sc)
+    ts = lvo.TriScene(*mesh, lw)
+    ao_ref = ts.render_ao(P, use_bvh=True)
+    assert np.array_equal(bits(ao), bits(ao_ref)) and (ao_ref < 1.0).sum() > 300000
+    assert max_lsb_diff(img, sc.render_rt(P, ao=ao_ref, use_bvh=True)) <= 2
+
+
 def test_triangle_golden_fixture(hip_lib):
     """The committed triangle-tube fixture (tests/golden/triangle_tubes.npz): ray-triangle known answers through the
     traversal kernel (one triangle per scene would be slow: all KAT triangles form one mesh, rays are checked where the
