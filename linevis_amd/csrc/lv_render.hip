@@ -212,7 +212,10 @@ __global__ __launch_bounds__(LV_BLOCK) void k_ao_primary(const LvUniforms U, con
 //             17-27 % lane utilisation (measured), here at ~100 %.
 // A finished ray is retired (samples[r] written, lane idle) once the FIFO head has passed its last queued leaf.
 // Scheduling inside a wave: test when >= 64 pairs wait; refill when >= LV_REFILL_THRESHOLD lanes are idle; otherwise
-// descend; flush partial batches only when nothing else can make progress.
+// descend; flush partial batches only when nothing else can make progress.  Once the global queue is empty (drain) the
+// rays left in a wave are finished together: nobody retires early, idle lanes take over stacked subtrees of busy ones.
+// Resources: 31 KB LDS and <= 96 VGPRs -> 5 workgroups = 20 waves per CU; the kernel is VALU-issue-bound and needs that
+// occupancy to hide the dependent node fetches (12 -> 16 -> 20 waves per CU: -16 %, -7 %).
 // BAKE: the static prebaker's rays (VulkanAmbientOcclusionBaker.glsl:230-281).  G-buffer slot = parametrisation vertex *
 // numTubeSubdivisions + subdivision with g0 = {ray origin, -}, g1 = {tangent, vertex}, g2 = {surface normal, subdivision};
 // the reference draws the (subdivision, ray) samples of a vertex from ONE LCG stream seeded with tea(vertex, frame), so
