@@ -159,7 +159,10 @@ int lv_set_background(lv_ctx* ctx, const float rgba[4]);
  *   ambient_occlusion_strength, ambient_occlusion_gamma              (LineRenderer.cpp:433-498)
  *   ambient_occlusion_iterations, ambient_occlusion_samples_per_frame, ambient_occlusion_radius,
  *   ambient_occlusion_distance_based, use_jittered_primary_rays        (VulkanRayTracedAmbientOcclusion.cpp:115-144)
- *   num_samples_per_frame, num_accumulated_frames (must be 1: offline frames use spp instead of 8-bit feedback),
+ *   num_samples_per_frame, num_accumulated_frames (1 = one self-contained frame per lv_render call, the offline default;
+ *   N > 1 = the reference's progressive mode: the caller renders frame after frame with the build-owned key frame_number
+ *   = 0, 1, ... N-1, every frame is mixed into the previous one THROUGH RGBA8 exactly like TubeRayTracing.glsl:268-273,
+ *   and RTAO runs one iteration per frame while frame_number < ambient_occlusion_iterations),
  *   use_deterministic_sampling, geometry_mode ("AABBs (analytic)" = ray-capsule, default | "Triangle Mesh" = the tube
  *   mesh set with lv_set_tube_triangle_mesh), use_analytic_intersections (bool form of the same switch)
  *                                                                       (VulkanRayTracer.cpp:226-278)

@@ -169,7 +169,7 @@ void lv_destroy(lv_ctx* ctx) {
                               &ctx->scratchRays, &ctx->stackOverflow, &ctx->triIdx, &ctx->triVerts, &ctx->triPoints,
                               &ctx->triNodes, &ctx->tris, &ctx->flowVectors, &ctx->flowScalars, &ctx->flowMisc,
                               &ctx->flowSeeds, &ctx->flowOutPos, &ctx->flowOutAtt, &ctx->flowCounts, &ctx->bakeBlendingWeights,
-                              &ctx->bakeSamplingLocations, &ctx->bakedAo, &ctx->bakeLcgSkip, &ctx->mlatTrace, &ctx->buildArena})
+                              &ctx->bakeSamplingLocations, &ctx->bakedAo, &ctx->bakeLcgSkip, &ctx->mlatTrace, &ctx->buildArena, &ctx->accum})
         lv_buf_free(*b);
     if (ctx->evCreated) {
         for (int i = 0; i < 16; i++) (void)hipEventDestroy(ctx->ev[i]);
@@ -400,9 +400,12 @@ int lv_set_option(lv_ctx* ctx, const char* key, const char* value) {
         if (!parseUint(value, u) || u == 0) return bad();
         o.numSamplesPerFrame = u;
     } else if (k == "num_accumulated_frames") {
-        if (!parseUint(value, u) || u != 1)
-            return lv_fail(ctx, LV_E_INVALID, "num_accumulated_frames must be 1: offline frames use num_samples_per_frame "
-                                              "(the reference's multi-frame mean round-trips through RGBA8)");
+        if (!parseUint(value, u) || u == 0) return bad();
+        o.numAccumulatedFrames = u; // VulkanRayTracer.cpp:257-260
+        o.frameNumber = 0;
+    } else if (k == "frame_number") {
+        if (!parseUint(value, u)) return bad();
+        o.frameNumber = u;
     } else if (k == "use_deterministic_sampling") {
         o.useDeterministicSampling = parseBool(value);
     } else if (k == "use_analytic_intersections") {

@@ -129,6 +129,7 @@ struct LvSceneDev {
     const float* depthMinMax;   // {minDepth, maxDepth}, produced on device by the depth-range kernels
     const float* ao;            // full-viewport AO factors
     unsigned* stackOverflow;    // null unless the LBVH is higher than LV_STACK_LDS
+    uint32_t* accum;            // full-viewport rgba8 of the previous frame (num_accumulated_frames > 1), else null
     uint32_t numSegs;           // primitives under `nodes` (segments, or triangles in a triangle-tube scene view)
     // triangle tubes (the reference's RTAO geometry); in the scene view handed to the triangle kernels `nodes` is the
     // triangle LBVH and numSegs the triangle count

@@ -30,6 +30,8 @@ struct LvOptions {
     bool aoUseDistance = true;                // :152
     bool aoJitterPrimary = true;              // :153
     uint32_t numSamplesPerFrame = 1;          // VulkanRayTracer.hpp:137 has 2 (interactive); offline default 1
+    uint32_t numAccumulatedFrames = 1;        // :142 (32 interactive); > 1: the caller renders frame_number = 0, 1, ...
+    uint32_t frameNumber = 0;                 // accumulatedFramesCounter, VulkanRayTracer.cpp:141
     bool useDeterministicSampling = false;
     uint32_t maxDepthComplexity = 1024;       // VulkanRayTracer.hpp:139
     bool useCappedTubes = true;               // LineData.hpp:377-379
@@ -105,6 +107,7 @@ struct lv_ctx {
     LvDeviceBuffer counters;                  // device counters (LvCounters + misc)
     LvDeviceBuffer ppllNodes, ppllStart, ppllCount, ppllScratch;
     LvDeviceBuffer tilesDev, outDev, scratchRays, stackOverflow, mlatTrace;
+    LvDeviceBuffer accum;                     // rgba8 of the previous accumulated frame (full viewport)
     LvDeviceBuffer buildArena;                // temporaries of the LBVH builds, kept between builds
     std::vector<uint32_t> tilesHost;          // staging copy: caller's tile list is borrowed for the call only
     bool tilesUploaded = false;               // tilesDev holds tilesHost

@@ -187,7 +187,7 @@ __global__ __launch_bounds__(LV_BLOCK) void k_render_rt_mlat(const LvUniforms U,
             for (int k = 0; k < 4; k++) acc[k] /= float(U.numSamplesPerFrame);
         }
         f4 c; c.x = acc[0]; c.y = acc[1]; c.z = acc[2]; c.w = acc[3];
-        out[px.outIndex] = lv_pack_unorm4x8(c);
+        out[px.outIndex] = lv_store_color(S, U, px.x, px.y, c);
     } else if (px.inTile) {
         f4 c; c.x = U.background[0]; c.y = U.background[1]; c.z = U.background[2]; c.w = U.background[3];
         out[px.outIndex] = lv_pack_unorm4x8(c);

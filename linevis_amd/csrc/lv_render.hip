@@ -15,6 +15,7 @@
 // triangle tubes (RTAO geometry, "Triangle Mesh" geometry mode: ClosestHitTubeTriangles, TubeRayTracing.glsl:301-352).
 // Host orchestration follows VulkanRayTracer::render (VulkanRayTracer.cpp:131-154), LineRenderer::renderBase
 // (LineRenderer.cpp:248-277) and PerPixelLinkedListLineRenderer::render (PerPixelLinkedListLineRenderer.cpp:399-427).
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(LV_BLOCK) void k_render_rt(const LvUniforms U, cons
             for (int k = 0; k < 4; k++) acc[k] /= float(U.numSamplesPerFrame);
         }
         f4 c; c.x = acc[0]; c.y = acc[1]; c.z = acc[2]; c.w = acc[3];
-        out[px.outIndex] = lv_pack_unorm4x8(c);
+        out[px.outIndex] = lv_store_color(S, U, px.x, px.y, c);
     } else if (px.inTile) {
         f4 c; c.x = U.background[0]; c.y = U.background[1]; c.z = U.background[2]; c.w = U.background[3];
         out[px.outIndex] = lv_pack_unorm4x8(c);
@@ -868,6 +869,7 @@ LvSceneDev sceneDev(const lv_ctx* ctx) {
     S.depthMinMax = (const float*)ctx->depthMinMax.ptr;
     S.ao = (const float*)ctx->ao.ptr;
     S.stackOverflow = nullptr;
+    S.accum = nullptr;
     S.numSegs = ctx->numSegs;
     S.tris = nullptr; S.triIdx = nullptr; S.triVerts = nullptr; S.triPoints = nullptr; S.triPad = 0.0f;
     S.bakedAo = (const float*)ctx->bakedAo.ptr;
@@ -915,8 +917,9 @@ void lv_fill_uniforms(const lv_ctx* ctx, LvUniforms& U) {
     U.height = ctx->height;
     U.maxDepthComplexity = o.maxDepthComplexity;
     U.numSamplesPerFrame = o.numSamplesPerFrame;
-    U.frameNumber = 0;
-    U.useJitteredRays = o.numSamplesPerFrame > 1 ? 1u : 0u; // VulkanRayTracer.cpp:420-426 with maxNumFrames == 1
+    // multi-frame accumulation (num_accumulated_frames > 1): the caller renders frame after frame and passes frame_number
+    U.frameNumber = o.numAccumulatedFrames > 1u ? o.frameNumber : 0u;
+    U.useJitteredRays = (o.numAccumulatedFrames > 1u || o.numSamplesPerFrame > 1u) ? 1u : 0u; // VulkanRayTracer.cpp:420-426
     U.useDeterministicSampling = o.useDeterministicSampling;
     U.useCappedTubes = o.useCappedTubes;
     U.useHalos = o.useHalos;
@@ -1004,7 +1007,12 @@ static int lv_run_ao(lv_ctx* ctx, LvUniforms& U, LvSceneDev& S, const LvTiles& T
     LvSceneDev SA = tri ? sceneDevTriangles(ctx) : S;
     if ((rc = lv_prepare_overflow(ctx, SA, gridMax, LV_AO_STACK_LDS, tri))) return rc;
     const bool stats = ctx->opt.collectStats;
-    for (uint32_t iter = 0; iter < ctx->opt.aoIterations; iter++) {
+    // progressive mode (num_accumulated_frames > 1): one RTAO iteration per rendered frame while frame_number <
+    // ambient_occlusion_iterations (ambientOcclusionBaker->updateIterative(), LineRenderer.cpp:257-264), accumulated in ctx->ao
+    const bool progressive = ctx->opt.numAccumulatedFrames > 1u;
+    const uint32_t iterBegin = progressive ? ctx->opt.frameNumber : 0u;
+    const uint32_t iterEnd = progressive ? std::min(ctx->opt.frameNumber + 1u, ctx->opt.aoIterations) : ctx->opt.aoIterations;
+    for (uint32_t iter = iterBegin; iter < iterEnd; iter++) {
         U.aoFrameNumber = iter; // rtaoRenderPass->setFrameNumber(accumulatedFramesCounter), VulkanRayTracedAmbientOcclusion.cpp:92
         LV_HIP(ctx, hipMemsetAsync(&dc->aoCount, 0, 4, st));
         LV_HIP(ctx, hipMemsetAsync(&dc->aoQueueHead, 0, 8, st));
@@ -1120,16 +1128,22 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
     LV_HIP(ctx, hipEventRecord(ctx->ev[7], st));
 
     uint32_t* out = (uint32_t*)outDevice;
+    if (mode == LV_RENDERING_MODE_VULKAN_RAY_TRACER && ctx->opt.numAccumulatedFrames > 1u) {
+        if ((rc = lv_buf_reserve(ctx, ctx->accum, size_t(ctx->width) * ctx->height * 4))) return rc;
+        S.accum = (uint32_t*)ctx->accum.ptr;
+    }
     if (mode == LV_RENDERING_MODE_VULKAN_RAY_TRACER) {
         LV_HIP(ctx, hipEventRecord(ctx->ev[8], st));
         // geometry_mode (VulkanRayTracer.cpp:226-250): analytic capsules, or the triangle tubes with their own LBVH
         const bool tri = ctx->opt.rtTriangleMesh;
         if (ctx->opt.useMlat) { // use_mlat: single-pass approximate transparency (lv_mlat.hip)
             LvSceneDev SM = tri ? sceneDevTriangles(ctx) : S;
+            SM.accum = S.accum;
             if (tri && (rc = lv_prepare_overflow(ctx, SM, gridTiles, LV_STACK_LDS, true))) return rc;
             if ((rc = lv_mlat_render(ctx, U, SM, T, gridTiles, out, dc, tri))) return rc;
         } else {
         LvSceneDev SC = tri ? sceneDevTriangles(ctx) : S;
+        SC.accum = S.accum;
         if (tri && (rc = lv_prepare_overflow(ctx, SC, gridTiles, LV_STACK_LDS, true))) return rc;
 #define LV_LAUNCH_RT(ST, PR) \
     LV_TIMED_LAUNCH(ctx, LV_KERNEL_RENDER_RT, (k_render_rt<ST, PR><<<gridTiles, LV_BLOCK, 0, st>>>(U, SC, T, out, dc)))

@@ -886,6 +886,21 @@ __device__ __forceinline__ f4 lv_unpack_unorm4x8(uint32_t p) {
     return c;
 }
 
+// RayGen's final store (TubeRayTracing.glsl:268-274): with multi-frame accumulation the running mean round-trips through
+// the rgba8 image: out = pack(mix(unpack(previous), colour, 1 / (frameNumber + 1))).
+__device__ __forceinline__ uint32_t lv_store_color(const LvSceneDev& S, const LvUniforms& U, uint32_t x, uint32_t y, f4 c) {
+    if (!S.accum) return lv_pack_unorm4x8(c);
+    const size_t pi = size_t(y) * U.width + x;
+    if (U.frameNumber != 0u) {
+        const f4 prev = lv_unpack_unorm4x8(S.accum[pi]);
+        const float a = 1.0f / float(U.frameNumber + 1u);
+        c.x = mixf(prev.x, c.x, a); c.y = mixf(prev.y, c.y, a); c.z = mixf(prev.z, c.z, a); c.w = mixf(prev.w, c.w, a);
+    }
+    const uint32_t packed = lv_pack_unorm4x8(c);
+    S.accum[pi] = packed;
+    return packed;
+}
+
 // TiledAddress.glsl:53-85
 __device__ __forceinline__ uint32_t lv_ppll_addr(uint32_t x, uint32_t y, uint32_t paddedW, uint32_t tileW, uint32_t tileH) {
     if (tileW == 1 && tileH == 1) return x + paddedW * y;

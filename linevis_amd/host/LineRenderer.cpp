@@ -391,6 +391,8 @@ void HipRayTracer::onHasMoved() {
 
 void HipRayTracer::render() {
     LineRenderer::renderBase();
+    // rayTracingRenderPass->setFrameNumber(accumulatedFramesCounter), VulkanRayTracer.cpp:141
+    if (maxNumAccumulatedFrames > 1) setOption("frame_number", std::to_string(accumulatedFramesCounter));
     if (renderMode(LV_RENDERING_MODE_VULKAN_RAY_TRACER)) accumulatedFramesCounter++;
 }
 

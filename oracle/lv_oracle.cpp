@@ -882,8 +882,11 @@ void lvo_render_ao(const lvo_scene* sc, const lvo_params* Pp, int useBvh, uint32
 }
 
 // RayGen main() + traceRayTransparent + Miss, TubeRayTracing.glsl:61-82,198-298
+// prevRGBA8OrNull: the tile of the previous frame (multi-frame accumulation, TubeRayTracing.glsl:268-273: the running
+// mean round-trips through the rgba8 output image)
 static void renderRt(const lvo_scene* sc, const lvo_params* Pp, int useBvh, const float* ao, const PrebakedAo* pb,
-                     uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, uint8_t* outRGBA8, lvo_stats* stats) {
+                     uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, uint8_t* outRGBA8, lvo_stats* stats,
+                     const uint8_t* prevRGBA8OrNull = nullptr) {
     const lvo_params& P = *Pp;
     Frame F = makeFrame(P);
     const bool capped = P.useCappedTubes != 0;
@@ -931,6 +934,11 @@ static void renderRt(const lvo_scene* sc, const lvo_params* Pp, int useBvh, cons
             }
             if (P.useJitteredRays)
                 for (int k = 0; k < 4; k++) fragmentColor[k] /= float(P.numSamplesPerFrame);
+            if (P.frameNumber != 0 && prevRGBA8OrNull) {
+                const uint8_t* pv = prevRGBA8OrNull + 4 * (size_t(yy) * w + xx);
+                for (int k = 0; k < 4; k++)
+                    fragmentColor[k] = mixf(float(pv[k]) / 255.0f, fragmentColor[k], 1.0f / float(P.frameNumber + 1));
+            }
             uint8_t* px = outRGBA8 + 4 * (size_t(yy) * w + xx);
             for (int k = 0; k < 4; k++) px[k] = toUnorm8(fragmentColor[k]);
         }
@@ -1284,6 +1292,10 @@ void lvo_render_rt_mlat_tri(const lvo_scene* sc, const lvo_tri_scene* tsc, const
 void lvo_render_rt(const lvo_scene* sc, const lvo_params* P, int useBvh, const float* ao, uint32_t x0, uint32_t y0,
                    uint32_t w, uint32_t h, uint8_t* outRGBA8, lvo_stats* stats) {
     renderRt(sc, P, useBvh, ao, nullptr, x0, y0, w, h, outRGBA8, stats);
+}
+void lvo_render_rt_accumulate(const lvo_scene* sc, const lvo_params* P, int useBvh, const float* ao, uint32_t x0, uint32_t y0,
+                              uint32_t w, uint32_t h, const uint8_t* prevRGBA8, uint8_t* outRGBA8, lvo_stats* stats) {
+    renderRt(sc, P, useBvh, ao, nullptr, x0, y0, w, h, outRGBA8, stats, prevRGBA8);
 }
 void lvo_render_rt_tri(const lvo_scene* sc, const lvo_tri_scene* tsc, const lvo_params* P, int useBvh, const float* ao,
                        uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, uint8_t* outRGBA8, lvo_stats* stats) {

@@ -157,6 +157,11 @@ void lvo_render_rt(
         const lvo_scene*, const lvo_params*, int useBvh, const float* ao,
         uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, uint8_t* outRGBA8, lvo_stats* stats);
 
+/* frame P->frameNumber of a multi-frame accumulation: mixed with the previous frame's rgba8 tile (NULL for frame 0) */
+void lvo_render_rt_accumulate(
+        const lvo_scene*, const lvo_params*, int useBvh, const float* ao,
+        uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, const uint8_t* prevRGBA8, uint8_t* outRGBA8, lvo_stats* stats);
+
 /* ---- f1: multi-layer alpha tracing (MlatInsert.glsl, traceRayMlat TubeRayTracing.glsl:86-192) ----
  * lvo_mlat_insert: one insertNodeMlat() on a node array of numNodes x {color[4], transmittance, depth}.
  * lvo_render_rt_mlat: the ray tracer frame with USE_MLAT.  traceOffsets == NULL: candidates visited in ascending

@@ -125,6 +125,7 @@ def lib():
                                      C.POINTER(C.c_uint64), C.POINTER(Stats)]
     L.lvo_render_rt_mlat_tri.argtypes = [vp, vp, C.POINTER(Params), vp, u32, u32, u32, u32, u32, vp, vp, vp, vp, vp,
                                          C.POINTER(C.c_uint64), C.POINTER(Stats)]
+    L.lvo_render_rt_accumulate.argtypes = [vp, C.POINTER(Params), i32, vp, u32, u32, u32, u32, vp, vp, C.POINTER(Stats)]
     L.lvo_ppll_addr.restype = u32
     L.lvo_ppll_addr.argtypes = [u32, u32, u32, u32, u32]
     L.lvo_ppll_gather.argtypes = [vp, C.POINTER(Params), i32, vp, u32, u32, u32, u32, vp, vp, C.POINTER(u32),
@@ -365,13 +366,19 @@ class Scene:
         lib().lvo_render_ao(self.h, C.byref(P), self._use_bvh(P, use_bvh), x0, y0, w, h, _p(ao), C.byref(st))
         return ao
 
-    def render_rt(self, P, ao=None, tile=None, use_bvh=False, stats=None):
+    def render_rt(self, P, ao=None, tile=None, use_bvh=False, stats=None, prev=None):
         x0, y0, w, h = self._tile(P, tile)
         out = np.empty((h, w, 4), dtype=np.uint8)
         st = stats if stats is not None else Stats()
         aop = _p(np.ascontiguousarray(ao, dtype=np.float32)) if ao is not None else None
         if P.useAmbientOcclusion and ao is None:
             raise ValueError("useAmbientOcclusion needs an ao buffer")
+        if prev is not None:   # multi-frame accumulation: frame P.frameNumber mixed with the previous frame's tile
+            pv = np.ascontiguousarray(prev, dtype=np.uint8)
+            assert pv.shape == (h, w, 4)
+            lib().lvo_render_rt_accumulate(self.h, C.byref(P), self._use_bvh(P, use_bvh), aop, x0, y0, w, h, _p(pv), _p(out),
+                                           C.byref(st))
+            return out
         lib().lvo_render_rt(self.h, C.byref(P), self._use_bvh(P, use_bvh), aop, x0, y0, w, h, _p(out), C.byref(st))
         return out
 

@@ -44,7 +44,8 @@ class Case:
             fovY=self.fovy, nearDist=self.near, farDist=self.far, background=self.background,
             lineWidth=self.line_width,
             maxDepthComplexity=int(s.get("max_depth_complexity", 1024)),
-            numSamplesPerFrame=spp, frameNumber=0, useJitteredRays=int(spp > 1),
+            numSamplesPerFrame=spp, frameNumber=0,
+            useJitteredRays=int(spp > 1 or int(s.get("num_accumulated_frames", 1)) > 1),   # VulkanRayTracer.cpp:420-426
             useDeterministicSampling=int(bool(s.get("use_deterministic_sampling", False))),
             useCappedTubes=int(bool(s.get("use_capped_tubes", True))), useHalos=int(bool(s.get("use_halos", True))),
             useDepthCues=int(dcs > 0.0), useAmbientOcclusion=int(ao_on), depthCueStrength=dcs,
@@ -72,6 +73,23 @@ class Case:
     def padded(self):
         tw, th = int(self.settings.get("ppll_tile_width", 2)), int(self.settings.get("ppll_tile_height", 8))
         return -(-self.width // tw) * tw, -(-self.height // th) * th
+
+    def oracle_render_progressive(self, num_frames, use_bvh=False):
+        """The reference's interactive loop (VulkanRayTracer::render called num_frames times): per frame one RTAO iteration
+        while frame < ambient_occlusion_iterations, then the colour frame mixed into the previous one through RGBA8.
+        Returns the list of frames."""
+        sc = self.oracle_scene()
+        P = self.oracle_params(sc)
+        its = int(P.aoIterations)
+        frames, prev, ao = [], None, None
+        for f in range(num_frames):
+            if P.useAmbientOcclusion and f < its:
+                P.aoIterations = f + 1           # iterations 0..f accumulated = the state after frame f's update
+                ao = sc.render_ao(P, use_bvh=use_bvh)
+            P.frameNumber = f
+            prev = sc.render_rt(P, ao=ao, use_bvh=use_bvh, prev=prev) if f else sc.render_rt(P, ao=ao, use_bvh=use_bvh)
+            frames.append(prev)
+        return frames
 
     def oracle_render(self, mode, use_bvh=False, tile=None, stats=None):
         """Full frame as the host orchestration defines it: depth range -> RTAO -> colour / PPLL."""

@@ -328,10 +328,58 @@ def test_tile_list_equals_full_frame(hip_lib):
         assert np.array_equal(frame, full)
 
 
+def test_progressive_accumulation(hip_lib):
+    """num_accumulated_frames > 1: the reference's interactive mode -- frame after frame, each mixed into the previous one
+    through the rgba8 image (TubeRayTracing.glsl:268-273), RTAO one iteration per frame while frames < iterations."""
+    c = small_case(num_accumulated_frames=5, num_samples_per_frame=2, **RTAO, ambient_occlusion_iterations=3,
+                   ambient_occlusion_samples_per_frame=4)
+    ref = c.oracle_render_progressive(5)
+    ctx = c.hip_context()
+    frames = []
+    for f in range(5):
+        ctx.set_option("frame_number", f)
+        frames.append(ctx.render(11))
+        assert max_lsb_diff(frames[-1], ref[f]) <= LSB_TOL
+    assert not np.array_equal(frames[0], frames[4])
+    # the mean converges: late frames change less than early ones
+    d01 = np.abs(frames[1].astype(np.int32) - frames[0].astype(np.int32)).mean()
+    d34 = np.abs(frames[4].astype(np.int32) - frames[3].astype(np.int32)).mean()
+    assert d34 < d01
+    # a tile of frame 2 rendered on its own continues from the same accumulation image
+    ctx.set_option("frame_number", 0)
+    ctx.render(11)
+    ctx.set_option("frame_number", 1)
+    ctx.render(11)
+    ctx.set_option("frame_number", 2)
+    t = ctx.render(11, tile=(16, 16, 48, 32))
+    assert np.array_equal(t, frames[2][16:48, 16:64])
+    # the plugin drives the same loop: render() while needsReRender(), frame number = accumulatedFramesCounter
+    tr = scenes.normalize(scenes.random_curves(n_lines=30, points_per_line=30, seed=7))
+    flow = host_api.LineDataFlow().set_trajectories(tr.positions, tr.attributes, tr.line_offsets)
+    r = host_api.HeadlessLineRenderer(11)
+    r.set_rendering_resolution(c.width, c.height)
+    r.set_transfer_function(c.tf)
+    r.set_line_data(flow)
+    r.set_new_settings(dict(line_width=c.line_width, **c.settings))
+    view, proj, fovy, near, far = r.camera()
+    lo, hi = flow.attribute_range()
+    ctx2 = c.hip_context()
+    ctx2.set_transfer_function(c.tf, lo, hi)
+    ctx2.set_camera(view, proj, fovy, near, far, c.width, c.height)
+    for f in range(5):
+        ctx2.set_option("frame_number", f)
+        assert np.array_equal(r.render_frame(), ctx2.render(11))
+    # back to one self-contained frame per call
+    ctx.set_option("num_accumulated_frames", 1)
+    one = ctx.render(11)
+    c1 = small_case(num_samples_per_frame=2, **RTAO, ambient_occlusion_iterations=3, ambient_occlusion_samples_per_frame=4)
+    assert max_lsb_diff(one, c1.oracle_render(11)[0]) <= LSB_TOL
+
+
 def test_option_errors(hip_lib):
     c = small_case(width=32, height=32)
     ctx = c.hip_context()
-    for key, val in [("no_such_key", "1"), ("num_accumulated_frames", 2), ("ambient_occlusion_mode", "SSAO"),
+    for key, val in [("no_such_key", "1"), ("num_accumulated_frames", 0), ("ambient_occlusion_mode", "SSAO"),
                      ("line_width", -1.0), ("geometry_mode", "Linear Swept Spheres"), ("mlat_num_nodes", 3)]:
         with pytest.raises(capi.LineVisError):
             ctx.set_option(key, val)

@@ -361,3 +361,26 @@ def test_ppll_gather_overflow_and_discard():
     assert stored.max() < P.ppllLinkedListSize
     img = lvo.ppll_resolve(P, nodes, start)
     assert img.shape == (32, 48, 4)
+
+
+def test_multi_frame_accumulation_round_trips_through_rgba8():
+    """TubeRayTracing.glsl:268-273: frame f is mixed into the previous rgba8 frame with weight 1 / (f + 1).  With one
+    identical sample per frame (deterministic sampling) the running mean of identical frames is a fixed point of the
+    quantised recursion; with per-pixel seeds the chain converges towards the multi-sample frame."""
+    from common import small_case
+    c = small_case(width=64, height=48, num_accumulated_frames=6, num_samples_per_frame=1)
+    frames = c.oracle_render_progressive(6)
+    many = small_case(width=64, height=48, num_samples_per_frame=6)
+    sc = many.oracle_scene()
+    target = sc.render_rt(many.oracle_params(sc))
+    err = [np.abs(f.astype(np.int32) - target.astype(np.int32)).mean() for f in frames]
+    assert err[5] < err[0] and err[5] < 3.0
+    # frame 0 is the plain jittered frame
+    c0 = small_case(width=64, height=48, num_accumulated_frames=2, num_samples_per_frame=1)
+    sc0 = c0.oracle_scene()
+    P0 = c0.oracle_params(sc0)
+    assert P0.useJitteredRays == 1 and np.array_equal(frames[0], sc0.render_rt(P0))
+    # mixing a frame with itself is a fixed point: mix(q, x, a) with x == dequantised q re-quantises to q
+    P0.frameNumber = 0
+    again = sc0.render_rt(P0, prev=frames[0])
+    assert np.array_equal(again, frames[0])
