@@ -104,6 +104,60 @@ bool StreamlineTracingGrid::traceStreamlines(const StreamlineTracingSettings& tr
     return true;
 }
 
+// ---------------------------------------------------------------- StreamlinePlaneSeeder, StreamlineSeeder.cpp:52-135
+void StreamlinePlaneSeeder::reset(const StreamlineTracingGrid& grid) {
+    box = grid.getBox();
+    generator = std::mt19937(seed);
+    const vec3 dim = box.getDimensions();
+    maxDimension = std::max(dim.x, std::max(dim.y, dim.z));
+    const vec3 mn = box.min, mx = box.max, center = box.getCenter();
+    float minOffset = 3.402823466e+38f, maxOffset = -3.402823466e+38f;
+    for (int c = 0; c < 8; c++) {
+        const vec3 pt((c & 1) ? mx.x : mn.x, (c & 2) ? mx.y : mn.y, (c & 4) ? mx.z : mn.z);
+        const float offset = dot(planeNormal, pt - center);
+        minOffset = std::min(minOffset, offset);
+        maxOffset = std::max(maxOffset, offset);
+    }
+    planeOffset = minOffset + (maxOffset - minOffset) * planeSlice;
+    axis0 = vec3(1.0f, 0.0f, 0.0f);
+    axis1 = cross(axis0, planeNormal);
+    if (length(axis1) < 1e-3f) {
+        axis0 = vec3(0.0f, 1.0f, 0.0f);
+        axis1 = normalize(cross(axis0, planeNormal));
+    } else {
+        axis1 = normalize(axis1);
+    }
+    axis0 = cross(planeNormal, axis1);
+    currentSampleIdx = 0;
+}
+
+bool StreamlinePlaneSeeder::hasNextPoint() const {
+    return currentSampleIdx < (regular ? numSamplesX * numSamplesY : numSamplesRandom);
+}
+
+vec3 StreamlinePlaneSeeder::getNextPoint() {
+    if (regular) {
+        const int y = currentSampleIdx / numSamplesX, x = currentSampleIdx % numSamplesX;
+        currentSampleIdx++;
+        const float dx = 1.0f / float(numSamplesX + 1), dy = 1.0f / float(numSamplesY + 1);
+        vec3 p = box.getCenter() + planeNormal * planeOffset;
+        p = p + axis0 * maxDimension * dx * (float(x) - float(numSamplesX - 1) / 2.0f);
+        p = p + axis1 * maxDimension * dy * (float(y) - float(numSamplesY - 1) / 2.0f);
+        return p;
+    }
+    currentSampleIdx++;
+    for (int it = 0; it < 100; it++) { // (the reference scales the random offsets by 1 / maxDimension, :126-129)
+        const float r0 = uniformDistribution(generator), r1 = uniformDistribution(generator);
+        vec3 p = box.getCenter() + planeNormal * planeOffset;
+        const float dx = 1.0f / maxDimension, dy = 1.0f / maxDimension;
+        p = p + axis0 * dx * (r0 - 0.5f);
+        p = p + axis1 * dy * (r1 - 0.5f);
+        if (p.x >= box.min.x && p.y >= box.min.y && p.z >= box.min.z && p.x <= box.max.x && p.y <= box.max.y && p.z <= box.max.z)
+            return p;
+    }
+    return box.getCenter(); // fallback, :138
+}
+
 // ---------------------------------------------------------------- StreamlineVolumeSeeder, StreamlineSeeder.cpp:259-300
 void StreamlineVolumeSeeder::setRegular(int nx, int ny, int nz) {
     regular = true;

@@ -89,6 +89,28 @@ private:
     std::mt19937 generator;
 };
 
+/// Seeds on a plane through the grid box (StreamlinePlaneSeeder, StreamlineSeeder.cpp:52-135): plane normal + slice in
+/// [0, 1] between the box corners' extreme offsets; regular nx x ny pattern or uniform random points inside the box.
+class StreamlinePlaneSeeder {
+public:
+    void setPlane(vec3 normal, float slice) { planeNormal = normal; planeSlice = slice; }
+    void setRegular(int numSamplesX_, int numSamplesY_) { regular = true; numSamplesX = numSamplesX_; numSamplesY = numSamplesY_; }
+    void setRandom(int numSamples, int seed_) { regular = false; numSamplesRandom = numSamples; seed = seed_; }
+    void reset(const StreamlineTracingGrid& grid);
+    bool hasNextPoint() const;
+    vec3 getNextPoint();
+
+private:
+    AABB3 box;
+    std::mt19937 generator;
+    std::uniform_real_distribution<float> uniformDistribution = std::uniform_real_distribution<float>(0, 1);
+    float maxDimension = 0.0f, planeSlice = 0.5f, planeOffset = 0.0f;
+    vec3 planeNormal = vec3(0.0f, 1.0f, 0.0f), axis0, axis1;
+    int seed = 2;                      // StreamlineSeeder.hpp:134
+    bool regular = false;
+    int currentSampleIdx = 0, numSamplesX = 32, numSamplesY = 32, numSamplesRandom = 1024;
+};
+
 class AbcFlowGenerator {
 public:
     AbcFlowGenerator();

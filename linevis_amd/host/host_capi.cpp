@@ -162,6 +162,17 @@ void lvh_grid_regular_seeds(void* hp, int nx, int ny, int nz, float* out) {
         out[3 * i] = p.x; out[3 * i + 1] = p.y; out[3 * i + 2] = p.z;
     }
 }
+/// plane seeding (StreamlinePlaneSeeder): nx * ny regular points, or n random points (ny = 0, nx = n) into out
+void lvh_grid_plane_seeds(void* hp, const float* normal3, float slice, int nx, int ny, int seed, float* out) {
+    StreamlinePlaneSeeder seeder;
+    seeder.setPlane(vec3(normal3[0], normal3[1], normal3[2]), slice);
+    if (ny > 0) seeder.setRegular(nx, ny); else seeder.setRandom(nx, seed);
+    seeder.reset(static_cast<GridHandle*>(hp)->grid);
+    for (int i = 0; seeder.hasNextPoint(); i++) {
+        vec3 p = seeder.getNextPoint();
+        out[3 * i] = p.x; out[3 * i + 1] = p.y; out[3 * i + 2] = p.z;
+    }
+}
 int lvh_grid_trace(void* hp, const float* seeds, uint32_t numSeeds, int method, int direction, float timeStepScale,
                    int maxNumIterations, float terminationDistance, float minimumLength, uint64_t* outNumLines,
                    uint64_t* outNumPoints) {

@@ -48,6 +48,7 @@ def load():
         "lvh_grid_load_abc_flow": (None, [vp, i32, i32, i32, f32]),
         "lvh_grid_info": (None, [vp, vp, vp, vp]),
         "lvh_grid_regular_seeds": (None, [vp, i32, i32, i32, vp]),
+        "lvh_grid_plane_seeds": (None, [vp, vp, f32, i32, i32, i32, vp]),
         "lvh_grid_trace": (i32, [vp, vp, u32, i32, i32, f32, i32, f32, f32, C.POINTER(u64), C.POINTER(u64)]),
         "lvh_grid_copy_result": (None, [vp, vp, vp, vp]),
         "lvh_grid_last_error": (cp, [vp]),
@@ -230,6 +231,14 @@ class StreamlineTracingGrid:
     def regular_seeds(self, nx, ny, nz):
         out = np.zeros((nx * ny * nz, 3), dtype=np.float32)
         self.L.lvh_grid_regular_seeds(self.h, nx, ny, nz, _p(out))
+        return out
+
+    def plane_seeds(self, normal=(0.0, 1.0, 0.0), slice=0.5, nx=32, ny=32, seed=2):
+        """StreamlinePlaneSeeder: nx x ny regular seeds on the plane, or nx random ones (ny = 0)."""
+        n = nx * ny if ny > 0 else nx
+        out = np.zeros((n, 3), dtype=np.float32)
+        nrm = np.ascontiguousarray(normal, dtype=np.float32)
+        self.L.lvh_grid_plane_seeds(self.h, _p(nrm), C.c_float(slice), int(nx), int(ny), int(seed), _p(out))
         return out
 
     def trace_streamlines(self, seeds, method="Runge-Kutta 4th Order", direction="Forward & Backward",

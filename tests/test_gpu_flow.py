@@ -197,6 +197,34 @@ def test_host_tracer_classes(hip_lib):
     b = lvo.trace_streamlines(vec, sp2, [scalars[0], scalars[1]], sd,       # attributes come in NAME order: a, b
                               lvo.streamline_settings("Heun", "Forward", minimum_length=0.05))
     assert same(a, b) and len(a[0]) > 500
+    # StreamlinePlaneSeeder (StreamlineSeeder.cpp:52-135): regular pattern against a numpy restatement, random seeds on the plane
+    sizes, spacing, box = grid.info()
+    bmin, bmax = np.array(box[:3], np.float64), np.array(box[3:], np.float64)
+    center, maxdim = (bmin + bmax) * 0.5, float((bmax - bmin).max())
+    for normal, sl in (((0.0, 1.0, 0.0), 0.5), ((1.0, 0.0, 0.0), 0.25), ((0.0, 0.0, 1.0), 0.9)):
+        nrm = np.array(normal)
+        corners = np.array([[(bmax if c & 1 else bmin)[0], (bmax if c & 2 else bmin)[1], (bmax if c & 4 else bmin)[2]] for c in range(8)])
+        offs = (corners - center) @ nrm
+        off = offs.min() + (offs.max() - offs.min()) * sl
+        a0 = np.array([1.0, 0.0, 0.0])
+        a1 = np.cross(a0, nrm)
+        if np.linalg.norm(a1) < 1e-3:
+            a0 = np.array([0.0, 1.0, 0.0])
+            a1 = np.cross(a0, nrm)
+        a1 /= np.linalg.norm(a1)
+        a0 = np.cross(nrm, a1)
+        nx, ny = 5, 3
+        exp = np.array([center + off * nrm + a0 * maxdim / (nx + 1) * (x - (nx - 1) / 2.0) + a1 * maxdim / (ny + 1) * (y - (ny - 1) / 2.0)
+                        for y in range(ny) for x in range(nx)])
+        got = grid.plane_seeds(normal, sl, nx, ny)
+        assert got.shape == (15, 3) and np.allclose(got, exp, atol=1e-6)
+        rnd = grid.plane_seeds(normal, sl, 200, 0, seed=2)
+        fallback = np.all(np.abs(rnd - center) < 1e-7, axis=1)                        # 100 rejected tries -> box centre
+        assert fallback.sum() < 20
+        assert np.allclose(((rnd - center) @ nrm)[~fallback], off, atol=1e-5)         # on the plane
+        assert (rnd >= bmin - 1e-6).all() and (rnd <= bmax + 1e-6).all()              # inside the box
+        assert np.array_equal(rnd, grid.plane_seeds(normal, sl, 200, 0, seed=2))      # mt19937(seed): repeatable
+        assert len(np.unique(rnd, axis=0)) > 150
     # every integrator of the reference is reachable through the plugin-side class
     c = grid.trace_streamlines(sd, method="Implicit Euler", direction="Forward", minimum_length=0.05)
     d = lvo.trace_streamlines(vec, sp2, [scalars[0], scalars[1]], sd,
