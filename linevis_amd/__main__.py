@@ -66,7 +66,10 @@ def main(argv=None):
         settings[k] = _parse_value(v)
     if settings:
         r.set_new_settings(settings)
-    img = r.render_frame()
+    # progressive accumulation: render() while needsReRender() (VulkanRayTracer::needsReRender, VulkanRayTracer.cpp:330-336)
+    img = None
+    for _ in range(max(1, int(settings.get("num_accumulated_frames", 1)))):
+        img = r.render_frame()
     st = r.stats()
     from PIL import Image
     Image.fromarray(np.ascontiguousarray(img)).save(args.output)
