@@ -175,6 +175,8 @@ def main():
     ctx.set_options(wl["settings"])
     render_fn = tiling.hip_render_tiles_fn(ctx, wl["mode"])   # also moves the context onto torch's stream
     ctx.build_accel()
+    build_first_ms = ctx.stats().ms_accel_build   # includes the one-time load of the library's code object (~5 ms)
+    ctx.build_accel()                             # what a line-width change / new data costs from then on
     build_ms = ctx.stats().ms_accel_build
     sf = tiling.ShardedFrame(W, H, TILE, rank, world, device)
 
@@ -249,7 +251,8 @@ def main():
                        "fragments_per_frame": int(counters[5].item()),
                        "parallelism": "screen tiles %dx%d, Morton order, round robin over %d GPU(s), one RCCL gather"
                                       % (TILE, TILE, world),
-                       "accel_build_ms": round(build_ms, 3), "bvh_depth": int(st.bvh_depth),
+                       "accel_build_ms": round(build_ms, 3), "accel_build_first_ms": round(build_first_ms, 3),
+                       "bvh_depth": int(st.bvh_depth),
                        "tube_triangles": int(st.num_tube_triangles)},
             "roofline": {"bound": "hbm", "kernel": wl["kernel"], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,

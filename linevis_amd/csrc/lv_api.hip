@@ -176,6 +176,7 @@ void lv_destroy(lv_ctx* ctx) {
         for (int k = 0; k < lv_ctx::kNumKernels; k++)
             for (int i = 0; i < 2 * lv_ctx::kRing; i++) (void)hipEventDestroy(ctx->evKernel[k][i]);
     }
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->ownStream) (void)hipStreamDestroy(ctx->ownStream);
     delete ctx;
 }

@@ -417,6 +417,10 @@ static int lv_bvh_build_core(lv_ctx* ctx, uint32_t n, LvDeviceBuffer& nodesOut, 
             return lv_fail(ctx, LV_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
         }                                                                                                 \
     } while (0)
+    // small read-backs (refit / collapse progress) land in pinned memory: a 4-byte hipMemcpy into pageable memory costs
+    // 100+ us per round trip, and a build makes ~20 of them
+    if (!ctx->pinned) LV_HIPF(hipHostMalloc((void**)&ctx->pinned, 64, hipHostMallocDefault));
+    volatile uint32_t* pin = ctx->pinned;
     size_t sortBytes = 0, scanBytes = 0;
     LV_HIPF(rocprim::radix_sort_pairs(nullptr, sortBytes, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr,
                                       (uint32_t*)nullptr, n, 0, 63, st));
@@ -441,9 +445,10 @@ static int lv_bvh_build_core(lv_ctx* ctx, uint32_t n, LvDeviceBuffer& nodesOut, 
     if (timed) LV_HIPF(hipEventRecord(ctx->ev[0], st));
     // bounds: min slots start at ord(+big) = 0xFFFFFFFF-ish, max slots at 0
     {
-        uint32_t init[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
-        LV_HIPF(hipMemcpyAsync(bounds.ptr, init, sizeof(init), hipMemcpyHostToDevice, st));
-        LV_HIPF(hipStreamSynchronize(st)); // init[] is a stack array
+        uint32_t* init = ctx->pinned + 8; // words 8..13 of the pinned block (stays valid while the copy is in flight)
+        init[0] = init[1] = init[2] = 0xFFFFFFFFu;
+        init[3] = init[4] = init[5] = 0u;
+        LV_HIPF(hipMemcpyAsync(bounds.ptr, init, 24, hipMemcpyHostToDevice, st));
     }
     boxes((float*)boxOrig.ptr, (uint32_t*)bounds.ptr);
     k_morton<<<nblocks(n), LV_BLOCK, 0, st>>>((const float*)boxOrig.ptr, n, (const uint32_t*)bounds.ptr,
@@ -467,18 +472,15 @@ static int lv_bvh_build_core(lv_ctx* ctx, uint32_t n, LvDeviceBuffer& nodesOut, 
                                                                   (float*)nodeBox.ptr, (uint32_t*)height.ptr,
                                                                   (uint32_t*)flags.ptr);
             if (pass % 8u == 0u) {
-                uint32_t rootDone = 0;
-                LV_HIPF(hipMemcpyAsync(&rootDone, flags.ptr, 4, hipMemcpyDeviceToHost, st));
+                LV_HIPF(hipMemcpyAsync((void*)ctx->pinned, flags.ptr, 4, hipMemcpyDeviceToHost, st));
                 LV_HIPF(hipStreamSynchronize(st));
-                if (rootDone) break;
+                if (pin[0]) break;
                 if (pass > 4096u) { freeAll(); return lv_fail(ctx, LV_E_HIP, "LBVH refit did not converge"); }
             }
         }
-        // collapse: one pass per BFS level of the wide tree (see k_collapse_select)
+            // collapse: one pass per BFS level of the wide tree (see k_collapse_select)
         {
-            uint32_t zero = 0u;
-            LV_HIPF(hipMemcpyAsync(depth.ptr, &zero, 4, hipMemcpyHostToDevice, st)); // frontier A = {root}
-            LV_HIPF(hipStreamSynchronize(st));
+            LV_HIPF(hipMemsetAsync(depth.ptr, 0, 4, st)); // frontier A = {root = binary node 0}
             uint32_t* frontier = (uint32_t*)depth.ptr;
             uint32_t* nextFrontier = (uint32_t*)evenFlag.ptr;
             uint32_t count = 1, base = 0;
@@ -493,12 +495,12 @@ static int lv_bvh_build_core(lv_ctx* ctx, uint32_t n, LvDeviceBuffer& nodesOut, 
                                                                      (const uint32_t*)flags.ptr, (const float*)leafBox.ptr,
                                                                      (const float*)nodeBox.ptr, nextFrontier,
                                                                      (float4*)nodesOut.ptr);
-                uint32_t lastOff = 0, lastCnt = 0;
-                LV_HIPF(hipMemcpyAsync(&lastOff, (const uint32_t*)flags.ptr + (count - 1), 4, hipMemcpyDeviceToHost, st));
-                LV_HIPF(hipMemcpyAsync(&lastCnt, (const uint32_t*)wideIndex.ptr + (count - 1), 4, hipMemcpyDeviceToHost, st));
+                LV_HIPF(hipMemcpyAsync((void*)ctx->pinned, (const uint32_t*)flags.ptr + (count - 1), 4, hipMemcpyDeviceToHost, st));
+                LV_HIPF(hipMemcpyAsync((void*)(ctx->pinned + 1), (const uint32_t*)wideIndex.ptr + (count - 1), 4,
+                                       hipMemcpyDeviceToHost, st));
                 LV_HIPF(hipStreamSynchronize(st));
                 base += count;
-                count = lastOff + lastCnt;
+                count = pin[0] + pin[1];
                 std::swap(frontier, nextFrontier);
                 wideLevels++;
             }
@@ -510,10 +512,9 @@ static int lv_bvh_build_core(lv_ctx* ctx, uint32_t n, LvDeviceBuffer& nodesOut, 
     depthOut = 1;
     wideDepthOut = wideLevels ? wideLevels : 1u;
     if (n > 1) {
-        uint32_t h = 0;
-        LV_HIPF(hipMemcpyAsync(&h, height.ptr, 4, hipMemcpyDeviceToHost, st));
+        LV_HIPF(hipMemcpyAsync((void*)ctx->pinned, height.ptr, 4, hipMemcpyDeviceToHost, st));
         LV_HIPF(hipStreamSynchronize(st));
-        depthOut = h;                 // height of the binary LBVH (reported); the traversal stack is sized by wideDepthOut
+        depthOut = pin[0];                 // height of the binary LBVH (reported); the traversal stack is sized by wideDepthOut
     } else {
         LV_HIPF(hipStreamSynchronize(st));
     }

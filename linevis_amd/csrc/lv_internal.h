@@ -108,6 +108,7 @@ struct lv_ctx {
     LvDeviceBuffer ppllNodes, ppllStart, ppllCount, ppllScratch;
     LvDeviceBuffer tilesDev, outDev, scratchRays, stackOverflow, mlatTrace;
     LvDeviceBuffer accum;                     // rgba8 of the previous accumulated frame (full viewport)
+    uint32_t* pinned = nullptr;               // 64 B of pinned host memory for small read-backs (hipHostMalloc)
     LvDeviceBuffer buildArena;                // temporaries of the LBVH builds, kept between builds
     std::vector<uint32_t> tilesHost;          // staging copy: caller's tile list is borrowed for the call only
     bool tilesUploaded = false;               // tilesDev holds tilesHost
