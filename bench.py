@@ -123,6 +123,27 @@ def cpu_baseline(pts, seg, tf, attr_range, view, proj, fovy, near, far, target_s
             "fps_extrapolated": round(1.0 / (dt * (W * H) / float(cw * ch)), 4)}
 
 
+def measured_hbm_ceiling(device, torch):
+    """Attainable HBM bandwidth of this box: device-to-device copy of 1 GiB (read + write bytes / time), best of 5
+    (report against the vendor peak AND the measured ceiling)."""
+    n = 1 << 30
+    a = torch.empty(n, dtype=torch.uint8, device=device)
+    b = torch.empty(n, dtype=torch.uint8, device=device)
+    a.fill_(1)
+    b.copy_(a)
+    torch.cuda.synchronize()
+    best = 0.0
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        b.copy_(a)
+        e1.record()
+        torch.cuda.synchronize()
+        best = max(best, 2.0 * n / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+    del a, b
+    return best
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -269,6 +290,12 @@ def main():
             "kernels_ms": {capi.KERNEL_NAMES[k]: round(float(st.ms_kernel_avg[k]), 4) for k in range(6)
                            if st.kernel_launches[k]},
         }
+        if world == 1:
+            ceil = measured_hbm_ceiling(device, torch)
+            result["roofline"]["peak_measured"] = round(ceil, 1)          # copy bandwidth attainable on this box
+            result["roofline"]["frac_of_measured"] = round(achieved / ceil, 5)
+            if traffic:   # what actually crossed the HBM interface per launch (PMC) as a rate
+                result["roofline"]["traffic_GBs"] = round(traffic / (ms_rays * 1e-3) / 1e9, 1)
         if args.save_frame and frame is not None:
             from PIL import Image
             Image.fromarray(frame.cpu().numpy()).save(args.save_frame)
