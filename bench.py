@@ -280,6 +280,9 @@ def main():
                          "algorithmic_bytes_per_launch": int(kernel_bytes), "ms_per_launch": round(ms_rays, 4),
                          "launches_timed": int(min(st.kernel_launches[kid], 128)),
                          "frame_algorithmic_bytes_rank0": int(frame_bytes),
+                         # compulsory floor: every node, segment record and line point read once + the
+                         # frame's outputs -- what a perfect cache would leave of the algorithmic bytes
+                         "frame_compulsory_bytes": int(st.num_nodes * 64 + len(seg) * 32 + len(pts) * 48 + W * H * (4 + 4)),
                          "note": "achieved = algorithmic bytes (64 B per node visited + 32/48 B per primitive tested + per-pixel "
                                  "records) / measured launch time; the scene + LBVH (~64 MB) live in L2 / Infinity Cache, so "
                                  "most of these bytes never reach HBM ('traffic' = PMC-measured HBM bytes per launch) and frac "
