@@ -225,6 +225,8 @@ def main():
     rays_per_frame = float(counters[0].item())
     counters_local = (st.nodes_visited, st.prims_tested, st.hits_shaded, st.ao_rays_traced, st.ao_nodes_visited,
                       st.ao_prims_tested)
+    ao_diag = (st.ao_prim_hits, st.ao_prim_may_axis, st.ao_prim_may_both,
+               [round(st.ao_phase_lanes[k] / max(64.0 * st.ao_phase_iterations[k], 1.0), 4) for k in range(3)])
     # algorithmic bytes of ONE k_ao_rays launch on this rank (DESIGN.md "Algorithmic bytes"):
     # 64 B per compressed 4-wide BVH node visited + 32 B per segment record tested + 52 B per compacted pixel (48 B G-buffer read,
     # 4 B AO factor write)
@@ -289,7 +291,10 @@ def main():
                                  "can exceed 1: the traversal kernels are VALU-issue-bound, not HBM-bound (DESIGN.md section 6)"},
             "counters_rank0": {"nodes_visited": int(counters_local[0]), "prims_tested": int(counters_local[1]),
                                "hits_shaded": int(counters_local[2]), "ao_rays": int(counters_local[3]),
-                               "ao_nodes_visited": int(counters_local[4]), "ao_prims_tested": int(counters_local[5])},
+                               "ao_nodes_visited": int(counters_local[4]), "ao_prims_tested": int(counters_local[5]),
+                               "ao_prim_hits": int(ao_diag[0]), "ao_prim_may_axis": int(ao_diag[1]),
+                               "ao_prim_may_both": int(ao_diag[2]),
+                               "ao_phase_lane_utilisation": ao_diag[3]},
             "kernels_ms": {capi.KERNEL_NAMES[k]: round(float(st.ms_kernel_avg[k]), 4) for k in range(6)
                            if st.kernel_launches[k]},
         }

@@ -93,6 +93,12 @@ typedef struct lv_stats {
     uint64_t ao_phase_lanes[3];
     uint32_t max_nodes_per_pixel;  /* collect_stats: most BVH nodes fetched by one pixel of a tile kernel (tail latency) */
     uint32_t num_tube_triangles;   /* triangles of the tube mesh set with lv_set_tube_triangle_mesh */
+    uint64_t ppll_pool_nodes;      /* PPLL: physical node slots = linkedListSize + per-wave chunk slack of the gather */
+    /* k_ao_rays leaf-test diagnostics (collect_stats only): tests that found a hit inside [0, radius]; tests a
+     * conservative axis-distance pre-test would let through; tests axis + bounding-sphere pre-tests would let through */
+    uint64_t ao_prim_hits;
+    uint64_t ao_prim_may_axis;
+    uint64_t ao_prim_may_both;
 } lv_stats;
 
 #define LV_KERNEL_AO_PRIMARY 0

@@ -38,7 +38,9 @@ class Stats(C.Structure):
                 ("ms_kernel_avg", C.c_float * 8), ("kernel_launches", C.c_uint32 * 8),
                 ("ao_rays_traced", C.c_uint64), ("ao_nodes_visited", C.c_uint64), ("ao_prims_tested", C.c_uint64),
                 ("ao_phase_iterations", C.c_uint64 * 3), ("ao_phase_lanes", C.c_uint64 * 3),
-                ("max_nodes_per_pixel", C.c_uint32), ("num_tube_triangles", C.c_uint32)]
+                ("max_nodes_per_pixel", C.c_uint32), ("num_tube_triangles", C.c_uint32),
+                ("ppll_pool_nodes", C.c_uint64), ("ao_prim_hits", C.c_uint64), ("ao_prim_may_axis", C.c_uint64),
+                ("ao_prim_may_both", C.c_uint64)]
 
     def as_dict(self):
         d = {}

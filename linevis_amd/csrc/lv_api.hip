@@ -500,6 +500,7 @@ int lv_get_stats(lv_ctx* ctx, lv_stats* out) {
     s.num_segments = ctx->numSegs;
     s.num_nodes = ctx->numNodes;
     s.num_tube_triangles = ctx->numTris;
+    s.ppll_pool_nodes = ctx->ppllPoolNodes;
     auto ms = [&](int a, int b) {
         float t = 0.0f;
         if (hipEventElapsedTime(&t, ctx->ev[a], ctx->ev[b]) != hipSuccess) t = 0.0f;
@@ -529,6 +530,9 @@ int lv_get_stats(lv_ctx* ctx, lv_stats* out) {
         s.ao_nodes_visited = hc.aoNodes;
         s.ao_prims_tested = hc.aoPrims;
         s.max_nodes_per_pixel = hc.maxNodesPerPixel;
+        s.ao_prim_hits = hc.aoPrimHits;
+        s.ao_prim_may_axis = hc.aoPrimMayAxis;
+        s.ao_prim_may_both = hc.aoPrimMayBoth;
         for (int k = 0; k < 3; k++) { s.ao_phase_iterations[k] = hc.aoPhaseIters[k]; s.ao_phase_lanes[k] = hc.aoPhaseLanes[k]; }
     }
     for (int k = 0; k < 8; k++) { s.ms_kernel_avg[k] = 0.0f; s.kernel_launches[k] = 0; }
@@ -643,7 +647,10 @@ int lv_get_ao(lv_ctx* ctx, float* out) {
     if (!ctx || !out) return LV_E_INVALID;
     if (!ctx->ao.ptr || !ctx->cameraSet) return lv_fail(ctx, LV_E_STATE, "no AO texture (render with RTAO first)");
     (void)hipSetDevice(ctx->device);
-    LV_HIP(ctx, hipMemcpyAsync(out, ctx->ao.ptr, size_t(ctx->width) * ctx->height * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (ctx->aoW != ctx->width || ctx->aoH != ctx->height)
+        return lv_fail(ctx, LV_E_STATE, "the AO texture was rendered at %ux%u, the viewport is now %ux%u (render again)",
+                       ctx->aoW, ctx->aoH, ctx->width, ctx->height);
+    LV_HIP(ctx, hipMemcpyAsync(out, ctx->ao.ptr, size_t(ctx->aoW) * ctx->aoH * 4, hipMemcpyDeviceToHost, ctx->stream));
     LV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return LV_OK;
 }
@@ -666,9 +673,7 @@ int lv_ppll_get_buffers(lv_ctx* ctx, uint32_t* out_nodes, uint64_t max_nodes, ui
         if (stored) LV_HIP(ctx, hipMemcpy(out_nodes, ctx->ppllNodes.ptr, size_t(stored) * 12, hipMemcpyDeviceToHost));
     }
     if (out_start) {
-        LvUniforms U;
-        lv_fill_uniforms(ctx, U);
-        uint64_t np = uint64_t(U.ppllPaddedW) * U.ppllPaddedH;
+        const uint64_t np = uint64_t(ctx->ppllPaddedW) * ctx->ppllPaddedH; // extents of the last gather, not the current camera's
         if (max_pixels < np) return lv_fail(ctx, LV_E_CAPACITY, "out_start_offset holds %llu entries, need %llu",
                                             (unsigned long long)max_pixels, (unsigned long long)np);
         LV_HIP(ctx, hipMemcpy(out_start, ctx->ppllStart.ptr, size_t(np) * 4, hipMemcpyDeviceToHost));

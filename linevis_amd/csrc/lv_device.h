@@ -63,6 +63,9 @@ struct LvDevCounters {
     uint32_t maxNodesPerPixel;
     uint32_t fragAlloc;   // PPLL node-slot allocator (chunks); fragCounter stays the exact fragment count
     uint32_t mlatTraceCount; // records appended to the MLAT visiting-order trace (collect_stats)
+    // k_ao_rays leaf-test diagnostics (collect_stats): tests that found a hit inside the interval, tests the conservative
+    // axis-distance pre-test lets through, tests axis + bounding-sphere pre-tests let through
+    unsigned long long aoPrimHits, aoPrimMayAxis, aoPrimMayBoth;
 };
 
 struct f3 { float x, y, z; };

@@ -112,7 +112,9 @@ struct lv_ctx {
     LvDeviceBuffer buildArena;                // temporaries of the LBVH builds, kept between builds
     std::vector<uint32_t> tilesHost;          // staging copy: caller's tile list is borrowed for the call only
     bool tilesUploaded = false;               // tilesDev holds tilesHost
-    uint64_t ppllPoolNodes = 0;
+    uint64_t ppllPoolNodes = 0;               // physical node slots of the pool (logical size + per-wave chunk slack)
+    // viewport the per-frame buffers were last rendered with (read-backs copy these extents, not the current camera's)
+    uint32_t aoW = 0, aoH = 0, ppllPaddedW = 0, ppllPaddedH = 0, accumW = 0, accumH = 0;
 
     // stats
     lv_stats stats;

@@ -250,6 +250,7 @@ __global__ __launch_bounds__(LV_AO_BLOCK, 5) void k_ao_rays(const LvUniforms U, 
             gridDim.x * LV_AO_BLOCK);
     LvCounters cnt = {0, 0, 0, 0};
     unsigned long long phIt[3] = {0, 0, 0}, phLn[3] = {0, 0, 0};
+    unsigned long long mayAxis = 0, mayBoth = 0, primHits = 0;
 
     // wave-uniform state
     unsigned long long chunkNext = 0, chunkEnd = 0, genBase = 0;
@@ -314,8 +315,18 @@ __global__ __launch_bounds__(LV_AO_BLOCK, 5) void k_ao_rays(const LvUniforms U, 
                 if (STATS) cnt.prims++;
                 float t; unsigned low;
                 if (lv_leaf_test<PRIM>(S, leaf, mk3(r0.x, r0.y, r1.x), mk3(r1.y, r2.x, r2.y), radius, capped, t, low)) {
-                    if (t >= 0.0f && t <= U.aoRadius) // traceAoRay: closest hit in [0, aoRadius], glsl:158-175
+                    if (t >= 0.0f && t <= U.aoRadius) { // traceAoRay: closest hit in [0, aoRadius], glsl:158-175
                         atomicMin(&keyW[owner], ((unsigned long long)__float_as_uint(t) << 32) | low);
+                        if (STATS) primHits++;
+                    }
+                }
+                if (STATS && PRIM == LV_PRIM_CAPSULE) {
+                    const float4 sa = S.segs[2 * size_t(leaf)], sb = S.segs[2 * size_t(leaf) + 1];
+                    const f3 ro = mk3(r0.x, r0.y, r1.x), rd = mk3(r1.y, r2.x, r2.y);
+                    const bool ma = lv_capsule_may_hit_axis(ro, rd, mk3(sa.x, sa.y, sa.z), mk3(sb.x, sb.y, sb.z), radius);
+                    const bool mb = lv_capsule_may_hit_sphere(ro, rd, mk3(sa.x, sa.y, sa.z), mk3(sb.x, sb.y, sb.z), radius);
+                    mayAxis += ma ? 1u : 0u;
+                    mayBoth += (ma && mb) ? 1u : 0u;
                 }
             }
             head += n;
@@ -476,6 +487,8 @@ __global__ __launch_bounds__(LV_AO_BLOCK, 5) void k_ao_rays(const LvUniforms U, 
             const unsigned long long it = lv_wave_sum_u64(phIt[k]), ln = lv_wave_sum_u64(phLn[k]);
             if (lane == 0) { atomicAdd(&dc->aoPhaseIters[k], it); atomicAdd(&dc->aoPhaseLanes[k], ln); }
         }
+        const unsigned long long sa = lv_wave_sum_u64(mayAxis), sb = lv_wave_sum_u64(mayBoth), sh = lv_wave_sum_u64(primHits);
+        if (lane == 0) { atomicAdd(&dc->aoPrimMayAxis, sa); atomicAdd(&dc->aoPrimMayBoth, sb); atomicAdd(&dc->aoPrimHits, sh); }
     }
 }
 
@@ -553,7 +566,7 @@ template <bool STATS>
 __global__ __launch_bounds__(LV_BLOCK) void k_ppll_gather(const LvUniforms U, const LvSceneDev S, const LvTiles T,
                                                           uint32_t* __restrict__ nodes, uint32_t* __restrict__ startOffset,
                                                           uint32_t* __restrict__ fragCount, LvDevCounters* dc,
-                                                          uint32_t numSlices) {
+                                                          uint32_t numSlices, uint32_t poolSlots) {
     __shared__ unsigned s_stack[LV_STACK_LDS * LV_BLOCK];
     __shared__ uint32_t s_head[LV_BLOCK];  // head of this workgroup's partial list of every thread's pixel
     __shared__ uint32_t s_tail[LV_BLOCK];  // its first inserted node (whose `next` is patched when splicing)
@@ -609,26 +622,33 @@ __global__ __launch_bounds__(LV_BLOCK) void k_ppll_gather(const LvUniforms U, co
         f4 color = lv_shade_hit(S, U, ownerAo, ro, rd, h, hitT);
         if (STATS) cnt.hits++;
         if (color.w < 0.001f) return; // gatherFragment: discard, LinkedListGather.glsl:34
-        // wave-aggregated atomicAdd(fragCounter, 1): one atomic for all lanes that append right now
+        // wave-aggregated node allocation: slots come from a per-wave chunk; one global atomic per LV_PPLL_CHUNK fragments
+        // instead of one per batch (a returning atomic on one address costs microseconds under load and sat on the
+        // critical path of the waves in front of dense geometry).  A batch that does not fit takes the rest of the old
+        // chunk first and continues in a new one, so only the tail a wave leaves behind when it exits stays unused; the
+        // pool carries that much slack (poolSlots >= ppllLinkedListSize + waves * LV_PPLL_CHUNK), i.e. no fragment the
+        // reference's exact atomicAdd(fragCounter) allocator would have stored is dropped here.
         const unsigned long long mask = __ballot(1);
         const unsigned lane = lv_lane();
         const int leader = __ffsll((long long)mask) - 1;
-        unsigned base = 0;
+        unsigned base = 0, left = 0, base2 = 0;
         if (int(lane) == leader) {
-            // node slots come from a per-wave chunk; one global atomic per LV_PPLL_CHUNK fragments instead of one per
-            // batch (a returning atomic on one address costs microseconds under load and sat on the critical path of
-            // the waves in front of dense geometry).  Leftovers of a chunk stay unused: slots may have holes.
             const unsigned n = unsigned(__popcll(mask)), w = threadIdx.x >> 6;
-            unsigned b = s_allocBase[w], left = s_allocLeft[w];
-            if (left < n) { b = atomicAdd(&dc->fragAlloc, (unsigned)LV_PPLL_CHUNK); left = LV_PPLL_CHUNK; }
-            base = b;
-            s_allocBase[w] = b + n;
-            s_allocLeft[w] = left - n;
+            base = s_allocBase[w]; left = s_allocLeft[w];
+            if (left < n) {
+                base2 = atomicAdd(&dc->fragAlloc, (unsigned)LV_PPLL_CHUNK);
+                s_allocBase[w] = base2 + (n - left);
+                s_allocLeft[w] = LV_PPLL_CHUNK - (n - left);
+            } else {
+                s_allocBase[w] = base + n;
+                s_allocLeft[w] = left - n;
+            }
         }
-        base = __shfl(base, leader, 64);
-        const uint32_t insertIndex = base + unsigned(__popcll(mask & ((1ull << lane) - 1ull)));
+        base = __shfl(base, leader, 64); left = __shfl(left, leader, 64); base2 = __shfl(base2, leader, 64);
+        const unsigned rank = unsigned(__popcll(mask & ((1ull << lane) - 1ull)));
+        const uint32_t insertIndex = rank < left ? base + rank : base2 + (rank - left);
         atomicAdd(&s_count[waveBase + owner], 1u);
-        if (insertIndex < U.ppllLinkedListSize) {
+        if (insertIndex < poolSlots) {
             const uint32_t next = atomicExch(&s_head[waveBase + owner], insertIndex);
             if (next == 0xFFFFFFFFu) s_tail[waveBase + owner] = insertIndex;
             nodes[3 * size_t(insertIndex) + 0] = lv_pack_unorm4x8(color);
@@ -974,7 +994,23 @@ int lv_frame_depth_range(lv_ctx* ctx) {
     return LV_OK;
 }
 
-// the global part of the traversal stacks: only when the tree is higher than the LDS-staged part
+// bytes of the global part of the traversal stacks for one launch geometry (0: the LDS-staged part holds the whole stack)
+static size_t lv_overflow_bytes(const lv_ctx* ctx, uint64_t gridBlocks, uint32_t ldsEntries, bool triangles) {
+    const uint64_t maxEntries = 3ull * uint64_t(triangles ? ctx->triWideDepth : ctx->wideDepth) + 2;
+    if (maxEntries <= ldsEntries) return 0;
+    return size_t(gridBlocks) * LV_BLOCK * (maxEntries - ldsEntries) * 4;
+}
+
+// persistent grid of k_ao_rays: enough workgroups to fill every CU at the kernel's LDS-limited residency
+static uint64_t lv_ao_grid(const lv_ctx* ctx, uint64_t maxRays) {
+    uint64_t gridRays = uint64_t(ctx->numCUs) * LV_AO_BLOCKS_PER_CU;
+    if (gridRays > (maxRays + LV_AO_BLOCK - 1) / LV_AO_BLOCK) gridRays = (maxRays + LV_AO_BLOCK - 1) / LV_AO_BLOCK;
+    return gridRays ? gridRays : 1;
+}
+
+// the global part of the traversal stacks: only when the tree is higher than the LDS-staged part.  lv_frame_render
+// reserves the largest slab any kernel of the frame needs BEFORE it builds a scene view, so that the reserve below never
+// reallocates under a pointer an earlier view still holds.
 static int lv_prepare_overflow(lv_ctx* ctx, LvSceneDev& S, uint64_t gridBlocks, uint32_t ldsEntries = LV_STACK_LDS,
                                bool triangles = false) {
     S.stackOverflow = nullptr;
@@ -996,11 +1032,7 @@ static int lv_run_ao(lv_ctx* ctx, LvUniforms& U, LvSceneDev& S, const LvTiles& T
     int rc;
     if ((rc = lv_buf_reserve(ctx, ctx->aoGbuf, size_t(maxPixels) * 48))) return rc;
     if ((rc = lv_buf_reserve(ctx, ctx->aoSamples, size_t(maxPixels) * spp * 4))) return rc;
-    const uint64_t maxRays = maxPixels * spp;
-    // persistent grid: enough workgroups to fill every CU at the kernel's LDS-limited residency
-    uint64_t gridRays = uint64_t(ctx->numCUs) * LV_AO_BLOCKS_PER_CU;
-    if (gridRays > (maxRays + LV_AO_BLOCK - 1) / LV_AO_BLOCK) gridRays = (maxRays + LV_AO_BLOCK - 1) / LV_AO_BLOCK;
-    if (gridRays == 0) gridRays = 1;
+    const uint64_t gridRays = lv_ao_grid(ctx, maxPixels * spp);
     const uint64_t gridMax = gridRays > gridTiles ? gridRays : gridTiles;
     const bool tri = ctx->opt.aoTriangleTubes;
     // RTAO geometry: the capsules of the colour pass, or the reference's triangle tubes (own LBVH, own scene view)
@@ -1072,6 +1104,8 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
     if ((rc = lv_buf_reserve(ctx, ctx->depthMinMax, 16))) return rc;
     if ((rc = lv_buf_reserve(ctx, ctx->tilesDev, size_t(numTiles) * 8))) return rc;
     if ((rc = lv_buf_reserve(ctx, ctx->ao, size_t(ctx->width) * ctx->height * 4))) return rc;
+    ctx->aoW = ctx->width;
+    ctx->aoH = ctx->height;
     LvDevCounters* dc = (LvDevCounters*)ctx->counters.ptr;
 
     LV_HIP(ctx, hipEventRecord(ctx->ev[2], st));
@@ -1099,6 +1133,20 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
     const uint32_t gridTiles = uint32_t((nb + 127u) / 128u) * 128u; // multiple of 8 XCDs x LV_XCD_GROUP (lv_block_pixel)
     const uint64_t maxPixels = uint64_t(numTiles) * tileW * tileH;
     const bool stats = ctx->opt.collectStats;
+    {
+        // one reservation for every launch geometry of this frame (a later, larger request would free the slab under the
+        // scene views built before it)
+        const bool aoRun = U.useAmbientOcclusion && !U.aoPrebaked, aoBake = U.aoPrebaked && !ctx->bakeValid;
+        const bool triColour = ctx->opt.rtTriangleMesh && mode == LV_RENDERING_MODE_VULKAN_RAY_TRACER;
+        size_t need = lv_overflow_bytes(ctx, gridTiles, LV_STACK_LDS, false);
+        if (triColour) need = std::max(need, lv_overflow_bytes(ctx, gridTiles, LV_STACK_LDS, true));
+        if (aoRun)
+            need = std::max(need, lv_overflow_bytes(ctx, std::max<uint64_t>(lv_ao_grid(ctx, maxPixels * U.aoSamplesPerFrame), gridTiles),
+                                                    LV_AO_STACK_LDS, ctx->opt.aoTriangleTubes));
+        if (aoBake)
+            need = std::max(need, lv_overflow_bytes(ctx, uint64_t(ctx->numCUs) * LV_AO_BLOCKS_PER_CU, LV_AO_STACK_LDS, true));
+        if (need && (rc = lv_buf_reserve(ctx, ctx->stackOverflow, need))) return rc;
+    }
     LvSceneDev S = sceneDev(ctx);
     if ((rc = lv_prepare_overflow(ctx, S, gridTiles))) return rc;
 
@@ -1129,7 +1177,14 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
 
     uint32_t* out = (uint32_t*)outDevice;
     if (mode == LV_RENDERING_MODE_VULKAN_RAY_TRACER && ctx->opt.numAccumulatedFrames > 1u) {
+        // the running mean lives in a full-viewport rgba8 image: a resize restarts it (onResolutionChanged resets
+        // accumulatedFramesCounter, VulkanRayTracer.cpp:119-129)
+        if (U.frameNumber != 0u && (ctx->accumW != ctx->width || ctx->accumH != ctx->height))
+            return lv_fail(ctx, LV_E_STATE, "the viewport changed (%ux%u -> %ux%u): restart the accumulation with frame_number = 0",
+                           ctx->accumW, ctx->accumH, ctx->width, ctx->height);
         if ((rc = lv_buf_reserve(ctx, ctx->accum, size_t(ctx->width) * ctx->height * 4))) return rc;
+        ctx->accumW = ctx->width;
+        ctx->accumH = ctx->height;
         S.accum = (uint32_t*)ctx->accum.ptr;
     }
     if (mode == LV_RENDERING_MODE_VULKAN_RAY_TRACER) {
@@ -1154,10 +1209,20 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
         LV_HIP(ctx, hipEventRecord(ctx->ev[9], st));
     } else {
         // reallocateFragmentBuffer, PerPixelLinkedListLineRenderer.cpp:251-357
-        if ((rc = lv_buf_reserve(ctx, ctx->ppllNodes, size_t(U.ppllLinkedListSize) * 12))) return rc;
+        const uint32_t numSlices = LV_PPLL_SLICES;
+        if (uint64_t(gridTiles) * numSlices > 0x7FFFFFF0ull) return lv_fail(ctx, LV_E_INVALID, "tile list too large");
+        // physical pool = the reference's linkedListSize + the tail every wave of the gather may leave unused in its last
+        // chunk of node slots (k_ppll_gather), so that the effective capacity is never below the reference's
+        uint64_t poolSlots64 = uint64_t(U.ppllLinkedListSize) +
+                               uint64_t(gridTiles) * numSlices * (LV_BLOCK / LV_WAVE) * LV_PPLL_CHUNK;
+        if (poolSlots64 > 0xFFFFFFF0ull) poolSlots64 = 0xFFFFFFF0ull; // node indices are 32 bit
+        const uint32_t poolSlots = uint32_t(poolSlots64);
+        if ((rc = lv_buf_reserve(ctx, ctx->ppllNodes, size_t(poolSlots) * 12))) return rc;
         if ((rc = lv_buf_reserve(ctx, ctx->ppllStart, size_t(U.ppllPaddedW) * U.ppllPaddedH * 4))) return rc;
         if ((rc = lv_buf_reserve(ctx, ctx->ppllCount, size_t(U.ppllPaddedW) * U.ppllPaddedH * 4))) return rc;
-        ctx->ppllPoolNodes = U.ppllLinkedListSize;
+        ctx->ppllPoolNodes = poolSlots;
+        ctx->ppllPaddedW = U.ppllPaddedW;
+        ctx->ppllPaddedH = U.ppllPaddedH;
         // clear(): LinkedListClear.glsl:46-55 + fragmentCounterBuffer->fill(0)
         LV_HIP(ctx, hipEventRecord(ctx->ev[10], st));
         LV_HIP(ctx, hipMemsetAsync(ctx->ppllStart.ptr, 0xFF, size_t(U.ppllPaddedW) * U.ppllPaddedH * 4, st));
@@ -1167,16 +1232,14 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
         LV_HIP(ctx, hipEventRecord(ctx->ev[11], st));
         // gather()
         LV_HIP(ctx, hipEventRecord(ctx->ev[12], st));
-        const uint32_t numSlices = LV_PPLL_SLICES;
-        if (uint64_t(gridTiles) * numSlices > 0x7FFFFFF0ull) return lv_fail(ctx, LV_E_INVALID, "tile list too large");
         if (stats)
             LV_TIMED_LAUNCH(ctx, LV_KERNEL_PPLL_GATHER, (k_ppll_gather<true><<<gridTiles * numSlices, LV_BLOCK, 0, st>>>(
                     U, S, T, (uint32_t*)ctx->ppllNodes.ptr, (uint32_t*)ctx->ppllStart.ptr,
-                    (uint32_t*)ctx->ppllCount.ptr, dc, numSlices)));
+                    (uint32_t*)ctx->ppllCount.ptr, dc, numSlices, poolSlots)));
         else
             LV_TIMED_LAUNCH(ctx, LV_KERNEL_PPLL_GATHER, (k_ppll_gather<false><<<gridTiles * numSlices, LV_BLOCK, 0, st>>>(
                     U, S, T, (uint32_t*)ctx->ppllNodes.ptr, (uint32_t*)ctx->ppllStart.ptr,
-                    (uint32_t*)ctx->ppllCount.ptr, dc, numSlices)));
+                    (uint32_t*)ctx->ppllCount.ptr, dc, numSlices, poolSlots)));
         LV_HIP(ctx, hipEventRecord(ctx->ev[13], st));
         // resolve()
         LV_HIP(ctx, hipEventRecord(ctx->ev[14], st));
@@ -1343,9 +1406,7 @@ int lv_bake_ambient_occlusion(lv_ctx* ctx) {
     lv_fill_uniforms(ctx, U);
     U.aoSamplesPerFrame = spp;
     LvSceneDev SA = sceneDevTriangles(ctx);
-    uint64_t gridRays = uint64_t(ctx->numCUs) * LV_AO_BLOCKS_PER_CU;
-    const uint64_t maxRays = slots * spp;
-    if (gridRays > (maxRays + LV_AO_BLOCK - 1) / LV_AO_BLOCK) gridRays = (maxRays + LV_AO_BLOCK - 1) / LV_AO_BLOCK;
+    const uint64_t gridRays = lv_ao_grid(ctx, slots * spp);
     if ((rc = lv_prepare_overflow(ctx, SA, gridRays, LV_AO_STACK_LDS, true))) return rc;
     LvDevCounters* dc = (LvDevCounters*)ctx->counters.ptr;
     float4* g = (float4*)ctx->aoGbuf.ptr;

@@ -79,6 +79,28 @@ __device__ __forceinline__ bool lv_intersect_capsule(f3 o, f3 d, f3 p0, f3 p1, f
     return has;
 }
 
+// Conservative pre-tests in front of lv_intersect_capsule (they may only say "cannot hit"; fused math is fine because
+// they never decide a hit).  A capsule hit needs the ray LINE to pass within r of the segment's axis LINE
+// (|w . (d x v)| <= r |d x v|) and within R = |v|/2 + r of the segment's midpoint.  Margins: the products carry at most a
+// few ulps of |w||d||v| of rounding error; 4e-6 of that scale (and 1e-4 relative on the radius) is > 30 x that.
+__device__ __forceinline__ bool lv_capsule_may_hit_axis(f3 o, f3 d, f3 p0, f3 p1, float radius) {
+    const f3 v = p1 - p0, w = p0 - o;
+    const f3 n = cross3(d, v);
+    const float q = fabsf(dot3(w, n));
+    const float n2 = dot3(n, n), w2 = dot3(w, w), d2 = dot3(d, d), v2 = dot3(v, v);
+    const float lim = radius * 1.0001f * __builtin_sqrtf(n2) + 4e-6f * __builtin_sqrtf(w2 * d2 * v2) + 1e-30f;
+    return q <= lim;
+}
+__device__ __forceinline__ bool lv_capsule_may_hit_sphere(f3 o, f3 d, f3 p0, f3 p1, float radius) {
+    const f3 v = p1 - p0;
+    const f3 c = p0 + 0.5f * v;
+    const f3 w = c - o;
+    const f3 m = cross3(w, d);
+    const float d2 = dot3(d, d), w2 = dot3(w, w);
+    const float R = (0.5f * __builtin_sqrtf(dot3(v, v)) + radius) * 1.0001f;
+    return dot3(m, m) <= R * R * d2 + 1e-5f * (w2 * d2) * R + 1e-30f;
+}
+
 // ---------------------------------------------------------------- ray-triangle (triangle tubes of the reference's RTAO)
 // The driver's triangle test is unobservable; the build defines it (float32, fixed operation order):
 // Moeller-Trumbore without culling -- e1 = v1-v0, e2 = v2-v0, p = d x e2, det = e1.p (0 -> miss), u = ((o-v0).p)/det,

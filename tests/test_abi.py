@@ -36,7 +36,7 @@ def test_header_cites_reference_interfaces():
 
 
 def test_struct_layouts_match_the_header():
-    assert ctypes.sizeof(capi.Stats) == 6 * 8 + 4 * 4 + 8 * 4 + 8 + 8 * 4 + 8 * 4 + 3 * 8 + 6 * 8 + 8
+    assert ctypes.sizeof(capi.Stats) == 6 * 8 + 4 * 4 + 8 * 4 + 8 + 8 * 4 + 8 * 4 + 3 * 8 + 6 * 8 + 8 + 4 * 8
     assert capi.LINE_POINT_DTYPE.itemsize == 48
     assert capi.LINE_POINT_DTYPE.fields["lineNormal"][1] == 32
     assert capi.LINE_POINT_DTYPE.fields["lineStartIndex"][1] == 44

@@ -226,9 +226,22 @@ def test_ppll_pool_overflow(hip_lib):
     st = ctx.stats()
     pw, ph = c.padded()
     assert st.fragments > pw * ph           # more fragments than pool nodes: the counter keeps counting
-    nodes, start, cnt = ctx.ppll_buffers(pw * ph, pw * ph)
-    stored = start[start != 0xFFFFFFFF]
-    assert stored.max() < pw * ph and img.shape == (48, 64, 4)
+    # the physical pool = the reference's linkedListSize (1 node / pixel here) + the chunk tail every wave of the gather may
+    # leave unused, so the lists hold AT LEAST as many fragments as the reference's exact allocator would have stored
+    pool = int(st.ppll_pool_nodes)
+    assert pool > pw * ph
+    nodes, start, cnt = ctx.ppll_buffers(pw * ph, pool)
+    assert cnt == st.fragments
+    linked = 0
+    for head in start[start != 0xFFFFFFFF]:
+        n, guard = int(head), 0
+        while n != 0xFFFFFFFF:
+            assert n < pool
+            linked += 1
+            guard += 1
+            assert guard <= st.max_depth_complexity
+            n = int(nodes[n, 2])
+    assert min(int(st.fragments), pw * ph) <= linked <= min(int(st.fragments), pool) and img.shape == (48, 64, 4)
 
 
 # ---------------------------------------------------------------- edge cases
