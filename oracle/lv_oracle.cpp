@@ -820,10 +820,12 @@ void lvo_render_ao(const lvo_scene* sc, const lvo_params* Pp, int useBvh, uint32
     for (uint32_t iter = 0; iter < P.aoIterations; iter++) {
         const uint32_t frameNumber = iter;
         const uint32_t globalFrameNumber = frameNumber; // VulkanRayTracedAmbientOcclusion.cpp:576-581
-#pragma omp parallel for schedule(dynamic, 4) reduction(+ : rays, nodes, prims)
-        for (int64_t yy = 0; yy < int64_t(h); yy++) {
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : rays, nodes, prims)
+        for (int64_t tileIdx = 0; tileIdx < lvoTileCount(w, h); tileIdx++) { // 16x16-pixel tiles
             Counters cnt;
-            for (uint32_t xx = 0; xx < w; xx++) {
+            for (uint32_t tilePix = 0; tilePix < 256u; tilePix++) {
+                uint32_t xx, yy;
+                if (!lvoTilePixel(w, h, tileIdx, tilePix, xx, yy)) continue;
                 uint32_t x = x0 + xx, y = y0 + uint32_t(yy);
                 uint32_t pix = x + y * P.width;
                 uint32_t seed = tea(pix, globalFrameNumber);
@@ -892,10 +894,12 @@ static void renderRt(const lvo_scene* sc, const lvo_params* Pp, int useBvh, cons
     const bool capped = P.useCappedTubes != 0;
     const float HIT_DISTANCE_EPSILON = 1e-5f;
     uint64_t rays = 0, nodes = 0, prims = 0, hits = 0;
-#pragma omp parallel for schedule(dynamic, 4) reduction(+ : rays, nodes, prims, hits)
-    for (int64_t yy = 0; yy < int64_t(h); yy++) {
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : rays, nodes, prims, hits)
+    for (int64_t tileIdx = 0; tileIdx < lvoTileCount(w, h); tileIdx++) { // 16x16-pixel tiles
         Counters cnt;
-        for (uint32_t xx = 0; xx < w; xx++) {
+        for (uint32_t tilePix = 0; tilePix < 256u; tilePix++) {
+            uint32_t xx, yy;
+            if (!lvoTilePixel(w, h, tileIdx, tilePix, xx, yy)) continue;
             uint32_t x = x0 + xx, y = y0 + uint32_t(yy);
             float fragmentColor[4] = {0, 0, 0, 0};
             const float aoTexel = (P.useAmbientOcclusion && ao) ? ao[size_t(y) * P.width + x] : 1.0f;
@@ -996,10 +1000,12 @@ static void renderRtTri(const lvo_scene* sc, const lvo_tri_scene* tsc, const lvo
     Frame F = makeFrame(P);
     const float HIT_DISTANCE_EPSILON = 1e-5f;
     uint64_t rays = 0, nodes = 0, prims = 0, hits = 0;
-#pragma omp parallel for schedule(dynamic, 4) reduction(+ : rays, nodes, prims, hits)
-    for (int64_t yy = 0; yy < int64_t(h); yy++) {
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : rays, nodes, prims, hits)
+    for (int64_t tileIdx = 0; tileIdx < lvoTileCount(w, h); tileIdx++) { // 16x16-pixel tiles
         Counters cnt;
-        for (uint32_t xx = 0; xx < w; xx++) {
+        for (uint32_t tilePix = 0; tilePix < 256u; tilePix++) {
+            uint32_t xx, yy;
+            if (!lvoTilePixel(w, h, tileIdx, tilePix, xx, yy)) continue;
             uint32_t x = x0 + xx, y = y0 + uint32_t(yy);
             float fragmentColor[4] = {0, 0, 0, 0};
             const float aoTexel = (P.useAmbientOcclusion && ao) ? ao[size_t(y) * P.width + x] : 1.0f;
@@ -1115,7 +1121,7 @@ static void renderRtMlat(const lvo_scene* sc, const lvo_tri_scene* tscOrNull, co
     Frame F = makeFrame(P);
     const bool capped = P.useCappedTubes != 0;
     uint64_t rays = 0, nodesV = 0, prims = 0, hitsShaded = 0, violations = 0;
-#pragma omp parallel for schedule(dynamic, 4) reduction(+ : rays, nodesV, prims, hitsShaded, violations)
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : rays, nodesV, prims, hitsShaded, violations)
     for (int64_t yy = 0; yy < int64_t(h); yy++) {
         Counters cnt;
         std::vector<Hit> hits;   // triangles: seg = triangle index, kind unused
@@ -1247,10 +1253,12 @@ void lvo_pixel_hits(const lvo_scene* sc, const lvo_params* Pp, int useBvh, uint3
     const lvo_params& P = *Pp;
     Frame F = makeFrame(P);
     std::vector<std::vector<Hit>> rows(size_t(w) * h);
-#pragma omp parallel for schedule(dynamic, 4)
-    for (int64_t yy = 0; yy < int64_t(h); yy++) {
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int64_t tileIdx = 0; tileIdx < lvoTileCount(w, h); tileIdx++) { // 16x16-pixel tiles
         Counters cnt;
-        for (uint32_t xx = 0; xx < w; xx++) {
+        for (uint32_t tilePix = 0; tilePix < 256u; tilePix++) {
+            uint32_t xx, yy;
+            if (!lvoTilePixel(w, h, tileIdx, tilePix, xx, yy)) continue;
             V3 o, d;
             primaryRay(P, F, x0 + xx, y0 + uint32_t(yy), 0.5f, 0.5f, o, d);
             allHits(*sc, F.radius, P.useCappedTubes != 0, useBvh != 0, o, d, 0.0001f, 1000.0f, rows[size_t(yy) * w + xx], cnt);
@@ -1461,7 +1469,7 @@ void lvo_ppll_gather(const lvo_scene* sc, const lvo_params* Pp, int useBvh, cons
     std::vector<std::vector<std::pair<uint32_t, float>>> rows(h);
     std::vector<std::vector<uint32_t>> rowCounts(h);
     uint64_t rays = 0, nds = 0, prims = 0, hits = 0;
-#pragma omp parallel for schedule(dynamic, 4) reduction(+ : rays, nds, prims, hits)
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : rays, nds, prims, hits)
     for (int64_t yy = 0; yy < int64_t(h); yy++) {
         Counters cnt;
         std::vector<Hit> hl;
@@ -1556,6 +1564,15 @@ void lvo_render_ppll(const lvo_scene* sc, const lvo_params* P, int useBvh, const
     uint32_t fragCounter = 0;
     lvo_ppll_gather(sc, P, useBvh, ao, x0, y0, w, h, nodes.data(), startOffset.data(), &fragCounter, stats);
     lvo_ppll_resolve(P, nodes.data(), startOffset.data(), 0, x0, y0, w, h, outRGBA8);
+}
+
+// threads the OpenMP loops above run on (reported next to the CPU baseline)
+int lvo_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
 }
 
 } // extern "C"

@@ -268,6 +268,9 @@ void lvo_streamlines_sizes(const lvo_streamlines*, uint64_t* numLines, uint64_t*
 void lvo_streamlines_copy(const lvo_streamlines*, float* positions, float* attributes, uint32_t* offsets);
 void lvo_streamlines_destroy(lvo_streamlines*);
 
+/* threads the OpenMP loops run on */
+int lvo_num_threads(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -88,6 +88,18 @@ inline void sincos2pi(float xi, float& s, float& c) {
 
 struct Counters { uint64_t rays = 0, nodes = 0, prims = 0, hits = 0; };
 
+// Work decomposition of the frame loops: 16x16-pixel tiles handed out one at a time (schedule(dynamic, 1)), as
+// BASELINE.md section 2 specifies for the CPU baseline.  Rows in chunks of 4 gave 270 chunks for 256 threads with the work
+// concentrated in the middle rows, i.e. a few dozen busy threads.  Pixels are independent, so the decomposition does not
+// change any result.
+static inline int64_t lvoTileCount(uint32_t w, uint32_t h) { return int64_t((w + 15u) / 16u) * int64_t((h + 15u) / 16u); }
+static inline bool lvoTilePixel(uint32_t w, uint32_t h, int64_t tile, uint32_t k, uint32_t& xx, uint32_t& yy) {
+    const uint32_t tx = (w + 15u) / 16u;
+    xx = uint32_t(tile % tx) * 16u + (k & 15u);
+    yy = uint32_t(tile / tx) * 16u + (k >> 4);
+    return xx < w && yy < h;
+}
+
 inline uint64_t expandBits21(uint64_t v) {
     v &= 0x1fffffull;
     v = (v | v << 32) & 0x1f00000000ffffull;

@@ -364,10 +364,12 @@ void lvo_render_ao_tri(const lvo_tri_scene* sc, const lvo_params* Pp, int useBvh
     for (uint32_t iter = 0; iter < P.aoIterations; iter++) {
         const uint32_t frameNumber = iter;
         const uint32_t globalFrameNumber = frameNumber; // VulkanRayTracedAmbientOcclusion.cpp:576-581
-#pragma omp parallel for schedule(dynamic, 4) reduction(+ : rays, nodes, prims)
-        for (int64_t yy = 0; yy < int64_t(h); yy++) {
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : rays, nodes, prims)
+        for (int64_t tileIdx = 0; tileIdx < lvoTileCount(w, h); tileIdx++) { // 16x16-pixel tiles
             Counters cnt;
-            for (uint32_t xx = 0; xx < w; xx++) {
+            for (uint32_t tilePix = 0; tilePix < 256u; tilePix++) {
+                uint32_t xx, yy;
+                if (!lvoTilePixel(w, h, tileIdx, tilePix, xx, yy)) continue;
                 uint32_t x = x0 + xx, y = y0 + uint32_t(yy);
                 uint32_t pix = x + y * P.width;
                 uint32_t seed = tea(pix, globalFrameNumber);

@@ -95,6 +95,8 @@ def lib():
     build()
     L = C.CDLL(_SO)
     vp, u32, f32, i32 = C.c_void_p, C.c_uint32, C.c_float, C.c_int
+    L.lvo_num_threads.restype = i32
+    L.lvo_num_threads.argtypes = []
     L.lvo_tea.restype = u32
     L.lvo_tea.argtypes = [u32, u32]
     L.lvo_lcg.restype = u32
@@ -558,3 +560,8 @@ def ppll_addr(x, y, padded_w, tile_w, tile_h):
 
 def set_num_threads(n):
     lib().lvo_set_num_threads(int(n))
+
+
+def num_threads():
+    """Threads the oracle's OpenMP loops run on."""
+    return int(lib().lvo_num_threads())
