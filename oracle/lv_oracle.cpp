@@ -36,6 +36,15 @@
 
 namespace {
 
+// Deviation switches (lvo_set_deviation_switches): evaluate the REFERENCE's literal definitions where the build owns a
+// different one, so that tests can measure what each documented deviation does to whole frames.  Process-global, set
+// between (never during) render calls.
+//   literalIntersection  ray-capsule roots in the textbook form of RayIntersectionTestsVulkan.glsl:39-119 instead of the
+//                        closest-approach form
+//   referenceAoLookup    getAoFactor as AmbientOcclusion.glsl:84-99: project the hit with projectionMatrix and sample the
+//                        AO texture bilinearly (clamp to edge) instead of reading the launching pixel's texel
+struct DeviationSwitches { bool literalIntersection = false, referenceAoLookup = false; const float* aoImage = nullptr; };
+DeviationSwitches g_dev;
 
 // ---------------------------------------------------------------- intersection tests
 // The reference solves both quadratics in the textbook form t = (-B -+ sqrt(B^2 - 4AC)) / 2A
@@ -270,7 +279,8 @@ inline bool closestHit(const lvo_scene& sc, float radius, bool capped, bool useB
         cnt.prims++;
         V3 p0, p1; segPoints(sc, seg, p0, p1);
         float t; int kind;
-        if (intersectCapsule(o, d, p0, p1, radius, capped, t, kind)) {
+        if (g_dev.literalIntersection ? intersectCapsuleLiteral(o, d, p0, p1, radius, capped, t, kind)
+                                      : intersectCapsule(o, d, p0, p1, radius, capped, t, kind)) {
             if (t >= tMin && t <= tMax && (!found || t < best || (t == best && seg < bestSeg))) {
                 found = true; best = t; bestSeg = seg; bestKind = kind;
             }
@@ -292,7 +302,10 @@ inline bool closestHit(const lvo_scene& sc, float radius, bool capped, bool useB
             cnt.nodes++;
             // test both children, descend into the nearer one first
             float tl, tr;
-            const float limit = found ? best : tMax;
+            // the literal roots carry up to ~0.25 r of float32 noise in t (far more than the boxes' padding): cull against
+            // best + r there, so that the traversal still returns the brute-force minimum of the noisy values
+            const float slack = g_dev.literalIntersection ? radius / sqrtf(dot(d, d)) : 0.0f;
+            const float limit = found ? fminf(best + slack, tMax) : tMax;
             bool hl = childBox(sc, nd.left, o, inv, tMin, limit, tl);
             bool hr = childBox(sc, nd.right, o, inv, tMin, limit, tr);
             if (hl && hr) {
@@ -318,7 +331,8 @@ inline void allHits(const lvo_scene& sc, float radius, bool capped, bool useBvh,
         cnt.prims++;
         V3 p0, p1; segPoints(sc, seg, p0, p1);
         float t; int kind;
-        if (intersectCapsule(o, d, p0, p1, radius, capped, t, kind)) {
+        if (g_dev.literalIntersection ? intersectCapsuleLiteral(o, d, p0, p1, radius, capped, t, kind)
+                                      : intersectCapsule(o, d, p0, p1, radius, capped, t, kind)) {
             if (t >= tMin && t <= tMax) out.push_back(Hit{t, seg, kind});
         }
     };
@@ -361,7 +375,22 @@ inline void transferFunction(const lvo_scene& sc, const lvo_params& P, float att
 // AmbientOcclusion.glsl:84-99 (non-SSAO branch).  The reference projects the hit back to the screen and samples the
 // AO texture there; a primary-ray hit projects into the launching pixel, so the build defines the lookup as "the
 // texel of the pixel that launched the ray" (nearest, halo-free for tiles).
-inline float getAoFactor(const lvo_params& P, float aoTexel) {
+inline float getAoFactor(const lvo_params& P, float aoTexel, V3 ssp) {
+    if (g_dev.referenceAoLookup && g_dev.aoImage) {
+        // literal: ndc = projectionMatrix * vec4(screenSpacePosition, 1); texture(aoTexture, ndc.xy / ndc.w * 0.5 + 0.5).x
+        // with a linear, clamp-to-edge sampler (texel centres at (i + 0.5) / size)
+        const V4 ndc = mulM4(P.proj, V4{ssp.x, ssp.y, ssp.z, 1.0f});
+        const float u = (ndc.x / ndc.w) * 0.5f + 0.5f, v = (ndc.y / ndc.w) * 0.5f + 0.5f;
+        const float fx = u * float(P.width) - 0.5f, fy = v * float(P.height) - 0.5f;
+        const float x0f = floorf(fx), y0f = floorf(fy);
+        const float wx = fx - x0f, wy = fy - y0f;
+        auto cl = [](float c, uint32_t n) { return uint32_t(fminf(fmaxf(c, 0.0f), float(n - 1))); };
+        const uint32_t xa = cl(x0f, P.width), xb = cl(x0f + 1.0f, P.width), ya = cl(y0f, P.height), yb = cl(y0f + 1.0f, P.height);
+        const float* A = g_dev.aoImage;
+        const float top = A[size_t(ya) * P.width + xa] * (1.0f - wx) + A[size_t(ya) * P.width + xb] * wx;
+        const float bot = A[size_t(yb) * P.width + xa] * (1.0f - wx) + A[size_t(yb) * P.width + xb] * wx;
+        aoTexel = top * (1.0f - wy) + bot * wy;
+    }
     float aoFactor = powf(aoTexel, P.aoGamma);
     return fmaxf(0.0f, (1.0f - P.aoStrength) + P.aoStrength * aoFactor);
 }
@@ -373,7 +402,7 @@ inline void blinnPhongShadingTube(const lvo_params& P, const Frame& F, float aoT
     const float kS = 0.3f, s = 30.0f;
     float aoF = 1.0f;
     if (P.useAmbientOcclusion) {
-        aoF = getAoFactor(P, aoTexel);
+        aoF = getAoFactor(P, aoTexel, ssp);
         kA = 0.2f + (1.0f - aoF) * 0.5f;
         kD = 0.9f * aoF;
     } else {
@@ -894,6 +923,7 @@ static void renderRt(const lvo_scene* sc, const lvo_params* Pp, int useBvh, cons
     const bool capped = P.useCappedTubes != 0;
     const float HIT_DISTANCE_EPSILON = 1e-5f;
     uint64_t rays = 0, nodes = 0, prims = 0, hits = 0;
+    g_dev.aoImage = (P.useAmbientOcclusion && !pb) ? ao : nullptr; // full-viewport AO image for the reference lookup switch
 #pragma omp parallel for schedule(dynamic, 1) reduction(+ : rays, nodes, prims, hits)
     for (int64_t tileIdx = 0; tileIdx < lvoTileCount(w, h); tileIdx++) { // 16x16-pixel tiles
         Counters cnt;
@@ -1564,6 +1594,28 @@ void lvo_render_ppll(const lvo_scene* sc, const lvo_params* P, int useBvh, const
     uint32_t fragCounter = 0;
     lvo_ppll_gather(sc, P, useBvh, ao, x0, y0, w, h, nodes.data(), startOffset.data(), &fragCounter, stats);
     lvo_ppll_resolve(P, nodes.data(), startOffset.data(), 0, x0, y0, w, h, outRGBA8);
+}
+
+// Test hook: computeFragmentColor (RayHitCommon.glsl:74-543 + blinnPhongShadingTube, Lighting.glsl:100-191) on n
+// independent inputs -- fragPos / normal / tangent are n x 3, isCap / attribute / aoTexel n each; outputs hitColor n x 4 and
+// payload.hitT n.  Lets tests compare this restatement with an independently written one (tests/test_independent_*.py).
+void lvo_compute_fragment_color_batch(const lvo_scene* sc, const lvo_params* Pp, uint64_t n, const float* fragPos,
+                                      const float* normal, const float* tangent, const uint32_t* isCap, const float* attribute,
+                                      const float* aoTexel, float* outColor, float* outHitT) {
+    const lvo_params& P = *Pp;
+    Frame F = makeFrame(P);
+    for (uint64_t i = 0; i < n; i++) {
+        float c[4], hitT;
+        computeFragmentColor(*sc, P, F, aoTexel[i], ld3(fragPos + 3 * i), ld3(normal + 3 * i), ld3(tangent + 3 * i),
+                             isCap[i] != 0u, attribute[i], c, hitT);
+        for (int k = 0; k < 4; k++) outColor[4 * i + k] = c[k];
+        outHitT[i] = hitT;
+    }
+}
+
+void lvo_set_deviation_switches(int literalIntersection, int referenceAoLookup) {
+    g_dev.literalIntersection = literalIntersection != 0;
+    g_dev.referenceAoLookup = referenceAoLookup != 0;
 }
 
 // threads the OpenMP loops above run on (reported next to the CPU baseline)

@@ -268,6 +268,18 @@ void lvo_streamlines_sizes(const lvo_streamlines*, uint64_t* numLines, uint64_t*
 void lvo_streamlines_copy(const lvo_streamlines*, float* positions, float* attributes, uint32_t* offsets);
 void lvo_streamlines_destroy(lvo_streamlines*);
 
+/* Test hook: the restatement of computeFragmentColor + blinnPhongShadingTube on n independent inputs (n x 3 positions /
+ * normals / tangents, n flags / attributes / AO texels) -> n x 4 colours, n payload.hitT. */
+void lvo_compute_fragment_color_batch(const lvo_scene*, const lvo_params*, uint64_t n, const float* fragPos, const float* normal,
+                                      const float* tangent, const uint32_t* isCap, const float* attribute, const float* aoTexel,
+                                      float* outColor, float* outHitT);
+
+/* Deviation switches (tests only): evaluate the reference's literal ray-capsule roots (RayIntersectionTestsVulkan.glsl:
+ * 39-119) and / or its literal AO lookup (AmbientOcclusion.glsl:84-99: project + bilinear texture()) in the capsule ray
+ * tracer paths (lvo_trace_rays, lvo_render_ao, lvo_render_rt, ...), to measure the documented deviations on whole frames.
+ * Process-global; set between render calls. */
+void lvo_set_deviation_switches(int literalIntersection, int referenceAoLookup);
+
 /* threads the OpenMP loops run on */
 int lvo_num_threads(void);
 

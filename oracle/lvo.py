@@ -95,6 +95,8 @@ def lib():
     build()
     L = C.CDLL(_SO)
     vp, u32, f32, i32 = C.c_void_p, C.c_uint32, C.c_float, C.c_int
+    L.lvo_set_deviation_switches.argtypes = [i32, i32]
+    L.lvo_compute_fragment_color_batch.argtypes = [vp, vp, C.c_uint64] + [vp] * 8
     L.lvo_num_threads.restype = i32
     L.lvo_num_threads.argtypes = []
     L.lvo_tea.restype = u32
@@ -384,6 +386,21 @@ class Scene:
         lib().lvo_render_rt(self.h, C.byref(P), self._use_bvh(P, use_bvh), aop, x0, y0, w, h, _p(out), C.byref(st))
         return out
 
+    def compute_fragment_color(self, P, frag_pos, normal, tangent, is_cap, attribute, ao_texel):
+        """Test hook: the restatement of computeFragmentColor on n independent inputs -> (colours n x 4, payload.hitT n)."""
+        fp = np.ascontiguousarray(frag_pos, dtype=np.float32).reshape(-1, 3)
+        n = fp.shape[0]
+        nr = np.ascontiguousarray(normal, dtype=np.float32).reshape(n, 3)
+        tg = np.ascontiguousarray(tangent, dtype=np.float32).reshape(n, 3)
+        cap = np.ascontiguousarray(is_cap, dtype=np.uint32).reshape(n)
+        at = np.ascontiguousarray(attribute, dtype=np.float32).reshape(n)
+        ao = np.ascontiguousarray(ao_texel, dtype=np.float32).reshape(n)
+        col = np.empty((n, 4), dtype=np.float32)
+        ht = np.empty(n, dtype=np.float32)
+        lib().lvo_compute_fragment_color_batch(self.h, C.byref(P), n, _p(fp), _p(nr), _p(tg), _p(cap), _p(at), _p(ao), _p(col),
+                                               _p(ht))
+        return col, ht
+
     def pixel_hits(self, P, tile=None, use_bvh=False):
         """All capsule entry hits of every pixel-centre ray: (offsets (w*h+1), segments, t), ascending segment index."""
         x0, y0, w, h = self._tile(P, tile)
@@ -565,3 +582,18 @@ def set_num_threads(n):
 def num_threads():
     """Threads the oracle's OpenMP loops run on."""
     return int(lib().lvo_num_threads())
+
+
+class deviation_switches:
+    """Context manager: evaluate the reference's literal intersection roots / AO lookup inside the block."""
+
+    def __init__(self, literal_intersection=False, reference_ao_lookup=False):
+        self.args = (int(bool(literal_intersection)), int(bool(reference_ao_lookup)))
+
+    def __enter__(self):
+        lib().lvo_set_deviation_switches(*self.args)
+        return self
+
+    def __exit__(self, *exc):
+        lib().lvo_set_deviation_switches(0, 0)
+        return False

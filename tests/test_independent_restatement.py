@@ -1,0 +1,295 @@
+"""A SECOND, independent restatement of the three highest-risk pure functions of the hot path, written directly from the
+GLSL text in float64 numpy / plain Python -- NOT through oracle/ -- and compared with the oracle on >= 10 000 random inputs:
+
+  computeFragmentColor halo / outline block   Data/Shaders/Renderers/RayTracing/RayHitCommon.glsl:141-146,190-229,353-372,436-512
+  blinnPhongShadingTube                       Data/Shaders/Utils/Lighting.glsl:100-191 (+ getAoFactor, AmbientOcclusion.glsl:84-99,
+                                              getAntialiasingFactor, Antialiasing.glsl:1-3)
+  frontToBackPQ / minHeapSink4                Data/Shaders/Renderers/PPLL/LinkedListSort.glsl:177-238
+
+The oracle (oracle/lv_oracle.cpp) and the HIP kernels (csrc/lv_trace.h) were written by the same hand from the same
+reading; a shared misreading is invisible to the parity tests.  This file is still the builder's reading of the GLSL, but
+it is a separate text in another language and another precision: it breaks the single-source common mode.  The reference
+holds no vectors for this path, so parity stays "unpinned" (DESIGN.md section 7).
+
+The transfer-function texture and the camera are definitions the build owns; they are restated here
+from DESIGN.md section 1, not from the oracle.
+"""
+import numpy as np
+import pytest
+
+from common import small_case
+from oracle import lvo
+
+N = 12000
+
+
+# ---------------------------------------------------------------- GLSL built-ins in float64
+def normalize(v):
+    return v / np.sqrt((v * v).sum(axis=-1, keepdims=True))
+
+
+def clamp(x, lo, hi):
+    return np.minimum(np.maximum(x, lo), hi)
+
+
+def mix(a, b, w):
+    return a * (1.0 - w) + b * w
+
+
+def smoothstep(e0, e1, x):
+    t = clamp((x - e0) / (e1 - e0), 0.0, 1.0)
+    return t * t * (3.0 - 2.0 * t)
+
+
+def length(v):
+    return np.sqrt((v * v).sum(axis=-1))
+
+
+def dot(a, b):
+    return (a * b).sum(axis=-1)
+
+
+# ---------------------------------------------------------------- build-owned definitions
+def transfer_function(tf, attr, attr_min, attr_max):
+    """TransferFunction.glsl:60-71 with the build's texture: N RGBA texels, linear filter, centres (i + 0.5) / N, clamp."""
+    n = tf.shape[0]
+    pos = clamp((attr - attr_min) / (attr_max - attr_min), 0.0, 1.0)
+    u = pos * n - 0.5
+    i0 = np.floor(u)
+    f = (u - i0)[:, None]
+    a = np.clip(i0.astype(np.int64), 0, n - 1)
+    b = np.clip(i0.astype(np.int64) + 1, 0, n - 1)
+    return tf[a] * (1.0 - f) + tf[b] * f
+
+
+def camera_position(view):
+    """cameraPosition = (inverse(viewMatrix) * vec4(0, 0, 0, 1)).xyz; column-major 4x4."""
+    m = np.asarray(view, dtype=np.float64).reshape(4, 4).T      # row-major maths matrix
+    return np.linalg.inv(m)[:3, 3]
+
+
+# ---------------------------------------------------------------- Lighting.glsl:100-191
+def blinn_phong_shading_tube(base, frag_pos, ssp, n_in, t_in, cam, use_ao, ao_texel, ao_gamma, ao_strength, use_depth_cues,
+                             min_depth, max_depth, depth_cue_strength):
+    ambient = base[:, :3]
+    diffuse = ambient
+    if use_ao:
+        # getAoFactor (AmbientOcclusion.glsl:84-99, non-SSAO branch) on the sampled texel
+        ao = np.power(ao_texel, ao_gamma)
+        ao = np.maximum(0.0, 1.0 - ao_strength + ao_strength * ao)
+        kA = 0.2 + (1.0 - ao) * 0.5
+        kD = 0.9 * ao
+    else:
+        ao = np.ones(len(base))
+        kA = np.full(len(base), 0.1)
+        kD = np.full(len(base), 0.9)
+    kS, s = 0.3, 30.0
+    Ia = kA[:, None] * ambient
+    n = normalize(n_in)
+    t = normalize(t_in)
+    v = normalize(cam - frag_pos)
+    l = v
+    h = normalize(v + l)
+    helper = normalize(np.cross(t, l))
+    new_l = normalize(np.cross(helper, t))
+    exponent = 1.7
+    cos1 = np.power(clamp(np.abs(dot(n, l)), 0.0, 1.0), exponent)
+    cos2 = np.power(clamp(np.abs(dot(n, new_l)), 0.0, 1.0), exponent)
+    combined = 0.3 * cos1 + 0.7 * cos2
+    Id = (kD * combined)[:, None] * diffuse
+    Is = (kS * np.power(clamp(np.abs(dot(n, h)), 0.0, 1.0), s))[:, None] * np.ones(3)
+    phong = Ia + Id + Is
+    if use_ao:
+        phong = phong * ao[:, None]
+    if use_depth_cues:
+        f = clamp((-ssp[:, 2] - min_depth) / (max_depth - min_depth), 0.0, 1.0)
+        f = f * f * depth_cue_strength
+        phong = mix(phong, 0.5, f[:, None])
+    return np.concatenate([phong, base[:, 3:4]], axis=1)
+
+
+# ---------------------------------------------------------------- RayHitCommon.glsl (tubes, flow lines, no bands)
+def compute_fragment_color(tf, P, frag_pos, normal, tangent, is_cap, attribute, ao_texel):
+    view = np.asarray(P.view[:], dtype=np.float64)
+    cam = camera_position(view)
+    frag_color = transfer_function(tf, attribute, P.attrMin, P.attrMax)                         # :126
+    n = normalize(normal)                                                                       # :141
+    v = normalize(cam - frag_pos)                                                               # :142
+    t = normalize(tangent)                                                                      # :144
+    helper = normalize(np.cross(t, v))                                                          # :146
+    new_v = normalize(np.cross(helper, t))                                                      # :147
+    rp = np.zeros(len(frag_pos))
+    if P.useHalos:
+        # isCap branch, :195-229
+        c_vn = np.cross(v, n)
+        rp_cap = length(c_vn)
+        c_vn2 = np.cross(new_v, n)
+        rp2 = length(c_vn2)
+        neg = dot(t, c_vn) < 0.0
+        rp2 = np.where(neg, -rp2, rp2)
+        rp_cap = np.where(neg, -rp_cap, rp_cap)
+        rp2 = clamp(rp2, -1.0, 1.0)
+        rp_cap = np.where(np.abs(rp2) < np.abs(rp_cap), rp2, rp_cap)
+        # tube-mantle branch, :353-372
+        c_nv = np.cross(new_v, n)
+        rp_tube = length(c_nv)
+        rp_tube = np.where(dot(t, c_nv) < 0.0, -rp_tube, rp_tube)
+        rp_tube = clamp(rp_tube, -1.0, 1.0)
+        capped = bool(P.useCappedTubes)
+        rp = np.where(is_cap & capped, rp_cap, rp_tube)
+    m = view.reshape(4, 4).T
+    ssp = (m @ np.concatenate([frag_pos, np.ones((len(frag_pos), 1))], axis=1).T).T[:, :3]     # :390
+    shaded = blinn_phong_shading_tube(frag_color, frag_pos, ssp, n, t, cam, bool(P.useAmbientOcclusion), ao_texel,
+                                      P.aoGamma, P.aoStrength, bool(P.useDepthCues), P.minDepth, P.maxDepth,
+                                      P.depthCueStrength)                                       # :416-427
+    abs_coords = np.abs(rp) if P.useHalos else np.zeros(len(rp))                                # :438-442
+    depth = length(frag_pos - cam)                                                              # :444
+
+    def aaf(d):                                                                                 # Antialiasing.glsl:1-3
+        return d / float(P.height) * P.fovY
+    eps_outline = clamp(aaf(depth / P.lineWidth * 0.05), 0.0, 0.49)                             # :451
+    eps_white = clamp(aaf(depth / P.lineWidth * 2.0), 0.0, 0.49)                                # :452
+    white_threshold = 0.7                                                                       # :490
+    coverage = 1.0 - smoothstep(1.0 - eps_outline, 1.0, abs_coords) if P.useHalos else np.ones(len(rp))   # :494
+    fg = 1.0 - np.asarray(P.background[:], dtype=np.float64)                                    # LineData.cpp:1282-1283
+    w = smoothstep(white_threshold - eps_white, white_threshold + eps_white, abs_coords)        # :505-508
+    rgb = mix(shaded[:, :3], fg[:3], w[:, None])
+    a = shaded[:, 3] * coverage
+    return np.concatenate([rgb, a[:, None]], axis=1), depth                                     # :539-541
+
+
+def random_inputs(rng, n):
+    frag = rng.uniform(-0.25, 0.25, (n, 3))
+    normal = rng.normal(size=(n, 3)) * rng.uniform(0.2, 3.0, (n, 1))      # not unit: the shader normalises
+    tangent = rng.normal(size=(n, 3)) * rng.uniform(0.2, 3.0, (n, 1))
+    # make most normals roughly perpendicular to the tangent, as on a tube; keep some arbitrary ones
+    tt = tangent / np.linalg.norm(tangent, axis=1, keepdims=True)
+    perp = normal - (normal * tt).sum(axis=1, keepdims=True) * tt
+    normal = np.where(rng.uniform(size=(n, 1)) < 0.8, perp, normal)
+    is_cap = rng.uniform(size=n) < 0.3
+    attr = rng.uniform(-0.1, 1.1, n)
+    ao = rng.uniform(0.0, 1.0, n)
+    return frag, normal, tangent, is_cap, attr, ao
+
+
+@pytest.mark.parametrize("variant", ["plain", "ao", "ao_depthcue_gamma", "no_halos", "uncapped"])
+def test_compute_fragment_color_against_the_float64_restatement(variant):
+    settings = {
+        "plain": {},
+        "ao": dict(ambient_occlusion_mode="RTAO (Screen Space)", ambient_occlusion_strength=1.0),
+        "ao_depthcue_gamma": dict(ambient_occlusion_mode="RTAO (Screen Space)", ambient_occlusion_strength=0.7,
+                                  ambient_occlusion_gamma=2.2, depth_cue_strength=0.8),
+        "no_halos": dict(use_halos=False),
+        "uncapped": dict(use_capped_tubes=False),
+    }[variant]
+    c = small_case(width=160, height=90, line_width=0.004, background=(0.9, 0.95, 1.0, 1.0), **settings)
+    sc = c.oracle_scene()
+    P = c.oracle_params(sc)
+    if P.useDepthCues:
+        assert P.maxDepth > P.minDepth
+    rng = np.random.default_rng(20260928)
+    frag, normal, tangent, is_cap, attr, ao = random_inputs(rng, N)
+    got, got_t = sc.compute_fragment_color(P, frag, normal, tangent, is_cap, attr, ao)
+    f32 = lambda a: np.asarray(a, dtype=np.float32).astype(np.float64)   # the oracle sees float32 inputs
+    want, want_t = compute_fragment_color(c.tf.astype(np.float64), P, f32(frag), f32(normal), f32(tangent), is_cap, f32(attr),
+                                          f32(ao))
+    err = np.abs(got.astype(np.float64) - want)
+    # float32 evaluation of ~60 operations incl. three pow: a few 1e-6; 2e-4 is < 1/20 of an RGBA8 step
+    assert err.max() < 2e-4, (variant, err.max(), np.unravel_index(err.argmax(), err.shape))
+    assert np.abs(got_t.astype(np.float64) - want_t).max() < 1e-6
+    # the sample exercises every branch
+    assert is_cap.sum() > 1000 and (~is_cap).sum() > 1000
+    assert (want[:, 3] < 0.999).sum() > 50 or not P.useHalos       # outline coverage < 1 somewhere
+
+
+# ---------------------------------------------------------------- LinkedListSort.glsl:177-238 in plain Python
+def unpack_unorm4x8(p):
+    return [float((p >> s) & 0xFF) / 255.0 for s in (0, 8, 16, 24)]
+
+
+def min_heap_sink4(depth, color, x, count):
+    while True:
+        t = 4 * x + 1
+        if not t < count:
+            return
+        c = t + 1 if (t + 1 < count and depth[t] > depth[t + 1]) else t
+        if t + 2 < count and depth[c] > depth[t + 2]:
+            c = t + 2
+        if t + 3 < count and depth[c] > depth[t + 3]:
+            c = t + 3
+        if depth[x] <= depth[c]:
+            return
+        depth[x], depth[c] = depth[c], depth[x]
+        color[x], color[c] = color[c], color[x]
+        x = c
+
+
+def front_to_back_pq(color, depth):
+    count = len(color)
+    i = count // 4
+    while i > 0:
+        min_heap_sink4(depth, color, i, count)
+        i -= 1
+    ray = [0.0, 0.0, 0.0, 0.0]
+    i = 0
+    while i < count and ray[3] < 0.99:
+        min_heap_sink4(depth, color, 0, count - i)
+        i += 1
+        src = unpack_unorm4x8(color[0])
+        for k in range(3):
+            ray[k] = ray[k] + (1.0 - ray[3]) * src[3] * src[k]
+        ray[3] = ray[3] + (1.0 - ray[3]) * src[3]
+        color[0] = color[count - i]
+        depth[0] = depth[count - i]
+    a = ray[3]
+    return ([r / a for r in ray[:3]] + [a]) if a > 0.0 else None
+
+
+def test_front_to_back_pq_against_the_plain_python_restatement():
+    """10 000 pixels with random lists (0..MAX_NUM_FRAGS+ fragments, random depths incl. exact ties, random RGBA8): the oracle's
+    literal resolve (depth-only comparisons, as the GLSL) against the restatement above; float64 blend vs float32 blend
+    may differ by one RGBA8 step."""
+    rng = np.random.default_rng(4242)
+    W, H, max_frags = 100, 100, 24
+    c = small_case(width=W, height=H, transparent=True, ppll_max_num_frags=max_frags, background=(0.2, 0.4, 0.6, 1.0))
+    P = c.oracle_params()
+    pw, ph = c.padded()
+    start = np.full(pw * ph, 0xFFFFFFFF, dtype=np.uint32)
+    nodes = []
+    lists = {}
+    for y in range(H):
+        for x in range(W):
+            k = int(rng.integers(0, max_frags + 6))            # some lists are longer than MAX_NUM_FRAGS
+            if k == 0:
+                continue
+            depth = rng.uniform(0.3, 1.3, k).astype(np.float32)
+            if k > 3 and rng.uniform() < 0.3:
+                depth[rng.integers(0, k, 2)] = depth[0]        # exact ties
+            col = rng.integers(0, 1 << 32, k, dtype=np.uint64).astype(np.uint32)
+            if rng.uniform() < 0.2:
+                col |= np.uint32(0xFF000000)                   # opaque layers: early out at alpha >= 0.99
+            nxt = 0xFFFFFFFF
+            for j in range(k):                                 # list order = reverse insertion order
+                nodes.append((int(col[j]), int(depth[j].view(np.uint32)), nxt))
+                nxt = len(nodes) - 1
+            start[lvo.ppll_addr(x, y, pw, P.ppllTileW, P.ppllTileH)] = nxt
+            lists[(x, y)] = (col, depth)
+    nodes = np.asarray(nodes, dtype=np.uint32).reshape(-1, 3)
+    got = lvo.ppll_resolve(P, nodes, start, literal=True)
+    bg = [float(b) for b in P.background[:]]
+    worst = 0
+    for (x, y), (col, depth) in lists.items():
+        # the resolve reads the first MAX_NUM_FRAGS nodes in list order (LinkedListResolve.glsl:66-80)
+        order = list(range(len(col) - 1, -1, -1))[:max_frags]
+        res = front_to_back_pq([int(col[j]) for j in order], [float(depth[j]) for j in order])
+        if res is None:
+            want = bg
+        else:   # straight alpha, then BACK_TO_FRONT_STRAIGHT_ALPHA over the clear colour (PerPixelLinkedListLineRenderer.cpp:70)
+            a = res[3]
+            want = [res[k] * a + bg[k] * (1.0 - a) for k in range(3)] + [a + bg[3] * (1.0 - a)]
+        want8 = [int(np.floor(min(max(v, 0.0), 1.0) * 255.0 + 0.5)) for v in want]
+        worst = max(worst, max(abs(int(got[y, x, k]) - want8[k]) for k in range(4)))
+    assert len(lists) >= 9000 and worst <= 1, worst
+    empty = [(x, y) for y in range(H) for x in range(W) if (x, y) not in lists]
+    for x, y in empty[:50]:
+        assert list(got[y, x]) == [int(np.floor(b * 255.0 + 0.5)) for b in bg]
