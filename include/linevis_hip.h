@@ -80,7 +80,7 @@ typedef struct lv_stats {
     float ms_total;              /* whole lv_render* call on the stream */
     uint64_t device_bytes;       /* device memory owned by the context */
     /* Per-kernel launch durations from HIP events recorded around every launch on the context's stream, averaged over
-     * all launches since lv_reset_timers() (at most the last 128).  Index = LV_KERNEL_*. */
+     * all launches since lv_reset_timers() (at most the last 512).  Index = LV_KERNEL_*. */
     float ms_kernel_avg[8];
     uint32_t kernel_launches[8];
     /* share of the counters above that belongs to the RTAO sample kernel (k_ao_rays) */
@@ -209,6 +209,10 @@ int lv_render_tiles_device(lv_ctx* ctx, int rendering_mode, const uint32_t* tile
 int lv_get_stats(lv_ctx* ctx, lv_stats* out);
 /* Forget the per-kernel launch timings collected so far (start of a timed benchmark region). */
 int lv_reset_timers(lv_ctx* ctx);
+/* Individual launch durations (ms, oldest first) of kernel `kernel_id` (LV_KERNEL_*) since lv_reset_timers(), at most the
+ * last 512: what a benchmark needs for a median / p95 (the reference's analogue: the per-phase GPU timers of
+ * PerPixelLinkedListLineRenderer.cpp:411-420 / AutomaticPerformanceMeasurer).  Synchronises the stream. */
+int lv_get_kernel_times(lv_ctx* ctx, int kernel_id, float* out_ms, uint32_t capacity, uint32_t* out_count);
 
 /* ---- streamline tracing: the producer of the line sets ----
  * StreamlineTracingGrid (src/LineData/Flow/StreamlineTracingGrid.cpp): regular grid of xs*ys*zs cells with spacing

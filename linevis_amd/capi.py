@@ -82,7 +82,7 @@ class LineVisError(RuntimeError):
 # every symbol include/linevis_hip.h declares (checked by tests/test_abi.py against the header text)
 SYMBOLS = ["lv_create", "lv_destroy", "lv_last_error", "lv_version", "lv_set_stream", "lv_set_lines",
            "lv_set_transfer_function", "lv_set_camera", "lv_set_background", "lv_set_option", "lv_build_accel",
-           "lv_render", "lv_render_device", "lv_render_tiles_device", "lv_get_stats", "lv_reset_timers", "lv_trace_rays",
+           "lv_render", "lv_render_device", "lv_render_tiles_device", "lv_get_stats", "lv_reset_timers", "lv_get_kernel_times", "lv_trace_rays",
            "lv_compute_depth_range", "lv_get_ao", "lv_ppll_get_buffers", "lv_ppll_resolve_buffers", "lv_get_accel",
            "lv_set_tube_triangle_mesh", "lv_trace_rays_triangles", "lv_set_flow_grid", "lv_trace_streamlines",
            "lv_get_streamlines", "lv_set_ao_parametrization", "lv_get_baked_ao", "lv_get_mlat_trace"]
@@ -130,6 +130,7 @@ def load():
         ("lv_render_tiles_device", [vp, i32, vp, u32, u32, u32, vp]),
         ("lv_get_stats", [vp, C.POINTER(Stats)]),
         ("lv_reset_timers", [vp]),
+        ("lv_get_kernel_times", [vp, i32, vp, u32, C.POINTER(u32)]),
         ("lv_trace_rays", [vp, vp, vp, f32, f32, u32, vp, vp, vp]),
         ("lv_compute_depth_range", [vp, vp]),
         ("lv_get_ao", [vp, vp]),
@@ -320,6 +321,13 @@ class Context:
         rec = np.zeros((max(int(cnt.value), 1), 4), dtype=np.uint32)
         self._ck(self.L.lv_get_mlat_trace(self.h, _p(rec), rec.shape[0], C.byref(cnt)))
         return rec[:int(cnt.value)]
+
+    def kernel_times(self, kernel_id):
+        """Individual launch durations (ms) of one kernel since reset_timers(), oldest first (at most the last 512)."""
+        out = np.zeros(512, dtype=np.float32)
+        cnt = C.c_uint32()
+        self._ck(self.L.lv_get_kernel_times(self.h, int(kernel_id), _p(out), 512, C.byref(cnt)))
+        return out[:cnt.value].copy()
 
     def ppll_buffers(self, padded_pixels, max_nodes):
         nodes = np.zeros((max_nodes, 3), dtype=np.uint32)

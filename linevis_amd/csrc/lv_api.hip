@@ -164,7 +164,7 @@ void lv_destroy(lv_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (LvDeviceBuffer* b : {&ctx->points, &ctx->segIdx, &ctx->nodes, &ctx->segs, &ctx->leafSeg, &ctx->segToLeaf, &ctx->tf,
-                              &ctx->depthMinMax, &ctx->ao, &ctx->aoGbuf, &ctx->aoList, &ctx->aoSamples, &ctx->counters,
+                              &ctx->depthMinMax, &ctx->ao, &ctx->aoAlt, &ctx->tilesHaloDev, &ctx->aoGbuf, &ctx->aoList, &ctx->aoSamples, &ctx->counters,
                               &ctx->ppllNodes, &ctx->ppllStart, &ctx->ppllCount, &ctx->ppllScratch, &ctx->tilesDev, &ctx->outDev,
                               &ctx->scratchRays, &ctx->stackOverflow, &ctx->triIdx, &ctx->triVerts, &ctx->triPoints,
                               &ctx->triNodes, &ctx->tris, &ctx->flowVectors, &ctx->flowScalars, &ctx->flowMisc,
@@ -550,7 +550,7 @@ int lv_get_stats(lv_ctx* ctx, lv_stats* out) {
     }
     uint64_t bytes = 0;
     for (const LvDeviceBuffer* b : {&ctx->points, &ctx->segIdx, &ctx->nodes, &ctx->segs, &ctx->leafSeg, &ctx->segToLeaf, &ctx->tf,
-                                    &ctx->depthMinMax, &ctx->ao, &ctx->aoGbuf, &ctx->aoList, &ctx->aoSamples,
+                                    &ctx->depthMinMax, &ctx->ao, &ctx->aoAlt, &ctx->tilesHaloDev, &ctx->aoGbuf, &ctx->aoList, &ctx->aoSamples,
                                     &ctx->counters, &ctx->ppllNodes, &ctx->ppllStart, &ctx->ppllCount, &ctx->ppllScratch, &ctx->tilesDev,
                                     &ctx->outDev, &ctx->scratchRays, &ctx->stackOverflow, &ctx->triIdx, &ctx->triVerts,
                                     &ctx->triPoints, &ctx->triNodes, &ctx->tris})
@@ -565,6 +565,24 @@ int lv_reset_timers(lv_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     LV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     for (int k = 0; k < lv_ctx::kNumKernels; k++) ctx->kernelLaunches[k] = 0;
+    return LV_OK;
+}
+
+int lv_get_kernel_times(lv_ctx* ctx, int kernel_id, float* out_ms, uint32_t capacity, uint32_t* out_count) {
+    if (!ctx) return LV_E_INVALID;
+    if (kernel_id < 0 || kernel_id >= lv_ctx::kNumKernels || (!out_ms && capacity)) return lv_fail(ctx, LV_E_INVALID, "invalid kernel id / buffer");
+    (void)hipSetDevice(ctx->device);
+    LV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const uint64_t n = ctx->kernelLaunches[kernel_id];
+    uint64_t m = n < uint64_t(lv_ctx::kRing) ? n : uint64_t(lv_ctx::kRing);
+    if (m > capacity) m = capacity;
+    for (uint64_t i = 0; i < m; i++) {
+        const uint64_t slot = (n - m + i) % lv_ctx::kRing;
+        float t = 0.0f;
+        if (hipEventElapsedTime(&t, ctx->evKernel[kernel_id][2 * slot], ctx->evKernel[kernel_id][2 * slot + 1]) != hipSuccess) t = 0.0f;
+        out_ms[i] = t;
+    }
+    if (out_count) *out_count = uint32_t(m);
     return LV_OK;
 }
 

@@ -118,6 +118,9 @@ struct LvUniforms {
     uint32_t ppllMaxNumFrags, ppllLinkedListSize, ppllTileW, ppllTileH, ppllPaddedW, ppllPaddedH;
     // static RTAO prebaking (STATIC_AMBIENT_OCCLUSION_PREBAKING, AmbientOcclusion.glsl:29-38)
     uint32_t aoPrebaked, bakeNumLineVertices, bakeNumParametrizationVertices, bakeNumTubeSubdivisions;
+    // getAoFactor of the colour pass (AmbientOcclusion.glsl:84-99): 1 = project the hit and sample the AO image bilinearly
+    // (jittered primary rays), 0 = the launching pixel's own texel (pixel-centre rays project onto their texel centre)
+    uint32_t aoProjectLookup;
 };
 
 // HBM-resident scene (all read-only during rendering)

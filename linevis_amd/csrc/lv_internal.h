@@ -102,7 +102,11 @@ struct lv_ctx {
 
     // frame resources
     LvDeviceBuffer depthMinMax;               // 2 floats (+2 encoded uints)
-    LvDeviceBuffer ao;                        // width*height floats
+    LvDeviceBuffer ao;                        // width*height floats (the latest AO image)
+    LvDeviceBuffer aoAlt;                     // second image of the halo mode's ping-pong accumulation (lv_run_ao)
+    LvDeviceBuffer tilesHaloDev;              // tile origins - 1 (AO pass on dilated tiles)
+    std::vector<uint32_t> tilesHaloHost;
+    bool tilesHaloUploaded = false;
     LvDeviceBuffer aoGbuf, aoList, aoSamples; // RTAO wavefront buffers
     LvDeviceBuffer counters;                  // device counters (LvCounters + misc)
     LvDeviceBuffer ppllNodes, ppllStart, ppllCount, ppllScratch;
@@ -124,7 +128,7 @@ struct lv_ctx {
     int lastMode = 0;
     // per-kernel launch timers: ring of event pairs per kernel id (LV_KERNEL_*)
     static constexpr int kNumKernels = 6;
-    static constexpr int kRing = 128;
+    static constexpr int kRing = 512;
     hipEvent_t evKernel[kNumKernels][2 * kRing];
     uint64_t kernelLaunches[kNumKernels] = {0, 0, 0, 0, 0, 0};
 };

@@ -102,7 +102,7 @@ __global__ __launch_bounds__(LV_BLOCK) void k_render_rt(const LvUniforms U, cons
 //   g0 = {hit position, offsetFactor}, g1 = {surface tangent, pixel index bits}, g2 = {surface normal, 0}
 template <bool STATS, int PRIM>
 __global__ __launch_bounds__(LV_BLOCK) void k_ao_primary(const LvUniforms U, const LvSceneDev S, const LvTiles T,
-                                                         float* __restrict__ ao, float4* __restrict__ gbuf,
+                                                         const float* aoIn, float* ao, float4* __restrict__ gbuf,
                                                          LvDevCounters* dc) {
     __shared__ unsigned s_stack[LV_STACK_LDS * LV_BLOCK];
     LV_COOP_SHARED(LV_BLOCK / LV_WAVE);
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(LV_BLOCK) void k_ao_primary(const LvUniforms U, con
         } else {
             // miss: aoFactor = 1, accumulate (glsl:311-319)
             float aoFactor = 1.0f;
-            if (U.aoFrameNumber != 0) aoFactor = mixf(ao[pix], aoFactor, 1.0f / float(U.aoFrameNumber + 1));
+            if (U.aoFrameNumber != 0) aoFactor = mixf(aoIn[pix], aoFactor, 1.0f / float(U.aoFrameNumber + 1));
             ao[pix] = aoFactor;
         }
     }
@@ -494,7 +494,7 @@ __global__ __launch_bounds__(LV_AO_BLOCK, 5) void k_ao_rays(const LvUniforms U, 
 
 template <bool BAKE>
 __global__ __launch_bounds__(LV_BLOCK) void k_ao_reduce(const LvUniforms U, const float4* __restrict__ gbuf,
-                                                        const float* __restrict__ samples, float* __restrict__ ao,
+                                                        const float* __restrict__ samples, const float* aoIn, float* ao,
                                                         const LvDevCounters* dc) {
     const uint32_t slot = blockIdx.x * LV_BLOCK + threadIdx.x;
     if (slot >= dc->aoCount) return;
@@ -514,7 +514,9 @@ __global__ __launch_bounds__(LV_BLOCK) void k_ao_reduce(const LvUniforms U, cons
     aoFactor /= float(spp);
     // screen space: the pixel of the compacted slot; prebaker: ambientOcclusionFactors[subdiv + N * vertex] = the slot
     const uint32_t pix = BAKE ? slot : __float_as_uint(gbuf[3 * size_t(slot) + 1].w);
-    if (U.aoFrameNumber != 0) aoFactor = mixf(ao[pix], aoFactor, 1.0f / float(U.aoFrameNumber + 1));
+    // aoIn == ao except with a halo: the 1-pixel rings of neighbouring tiles overlap, a pixel may then be processed twice in
+    // one pass, and the running mean must read the PREVIOUS pass' image to stay idempotent (lv_run_ao)
+    if (U.aoFrameNumber != 0) aoFactor = mixf(aoIn[pix], aoFactor, 1.0f / float(U.aoFrameNumber + 1));
     ao[pix] = aoFactor;
 }
 
@@ -1024,12 +1026,41 @@ static int lv_prepare_overflow(lv_ctx* ctx, LvSceneDev& S, uint64_t gridBlocks, 
     return LV_OK;
 }
 
-static int lv_run_ao(lv_ctx* ctx, LvUniforms& U, LvSceneDev& S, const LvTiles& T, uint32_t gridTiles,
-                     uint64_t maxPixels) {
+static int lv_run_ao(lv_ctx* ctx, LvUniforms& U, LvSceneDev& S, const LvTiles& Tcolour, uint32_t gridTilesColour,
+                     uint64_t maxPixelsColour) {
     hipStream_t st = ctx->stream;
     LvDevCounters* dc = (LvDevCounters*)ctx->counters.ptr;
     const uint32_t spp = U.aoSamplesPerFrame;
     int rc;
+    // With jittered colour rays the AO lookup blends the four texels around the projected hit (AmbientOcclusion.glsl:84-99), so
+    // the AO image needs a 1-pixel halo around every rendered tile: the AO pass runs on the tiles dilated by one pixel
+    // (origins - 1, modulo 2^32: pixels left of / above the viewport fail the inView test; size + 2).  Rings of adjacent tiles
+    // overlap -- those pixels are simply computed twice, which is why the running mean below reads the previous pass' image
+    // (ping-pong) instead of updating in place.
+    LvTiles T = Tcolour;
+    uint32_t gridTiles = gridTilesColour;
+    uint64_t maxPixels = maxPixelsColour;
+    const bool halo = U.aoProjectLookup != 0u;
+    if (halo) {
+        const uint32_t n = Tcolour.numTiles;
+        if ((rc = lv_buf_reserve(ctx, ctx->tilesHaloDev, size_t(n) * 8))) return rc;
+        if (!ctx->tilesHaloUploaded) {
+            ctx->tilesHaloHost.resize(2 * size_t(n));
+            for (size_t i = 0; i < 2 * size_t(n); i++) ctx->tilesHaloHost[i] = ctx->tilesHost[i] - 1u;
+            LV_HIP(ctx, hipMemcpyAsync(ctx->tilesHaloDev.ptr, ctx->tilesHaloHost.data(), size_t(n) * 8, hipMemcpyHostToDevice, st));
+            ctx->tilesHaloUploaded = true;
+        }
+        T.tilesXY = (const uint32_t*)ctx->tilesHaloDev.ptr;
+        T.tileW = Tcolour.tileW + 2u;
+        T.tileH = Tcolour.tileH + 2u;
+        T.blocksX = ((T.tileW + 63u) / 64u) * 4u;
+        T.blocksY = ((T.tileH + 63u) / 64u) * 4u;
+        const uint64_t nb = uint64_t(n) * T.blocksX * T.blocksY;
+        if (nb > 0x7FFFFFF0ull) return lv_fail(ctx, LV_E_INVALID, "tile list too large");
+        gridTiles = uint32_t((nb + 127u) / 128u) * 128u;
+        maxPixels = uint64_t(n) * T.tileW * T.tileH;
+        if ((rc = lv_buf_reserve(ctx, ctx->aoAlt, size_t(ctx->width) * ctx->height * 4))) return rc;
+    }
     if ((rc = lv_buf_reserve(ctx, ctx->aoGbuf, size_t(maxPixels) * 48))) return rc;
     if ((rc = lv_buf_reserve(ctx, ctx->aoSamples, size_t(maxPixels) * spp * 4))) return rc;
     const uint64_t gridRays = lv_ao_grid(ctx, maxPixels * spp);
@@ -1050,11 +1081,13 @@ static int lv_run_ao(lv_ctx* ctx, LvUniforms& U, LvSceneDev& S, const LvTiles& T
         LV_HIP(ctx, hipMemsetAsync(&dc->aoQueueHead, 0, 8, st));
         const uint32_t grid = uint32_t(gridRays);
         const float4* g = (const float4*)ctx->aoGbuf.ptr;
-        float* ao = (float*)ctx->ao.ptr;
+        // halo: read the previous pass' image, write the other buffer, swap; otherwise update in place
+        const float* aoIn = (const float*)ctx->ao.ptr;
+        float* ao = halo ? (float*)ctx->aoAlt.ptr : (float*)ctx->ao.ptr;
         float* smp = (float*)ctx->aoSamples.ptr;
 #define LV_LAUNCH_AOP(ST, PR)                                                                                 \
     LV_TIMED_LAUNCH(ctx, LV_KERNEL_AO_PRIMARY, (k_ao_primary<ST, PR><<<gridTiles, LV_BLOCK, 0, st>>>(        \
-            U, SA, T, ao, (float4*)ctx->aoGbuf.ptr, dc)))
+            U, SA, T, aoIn, ao, (float4*)ctx->aoGbuf.ptr, dc)))
 #define LV_LAUNCH_AO(ST, AH, PR) \
     LV_TIMED_LAUNCH(ctx, LV_KERNEL_AO_RAYS, (k_ao_rays<ST, AH, PR><<<grid, LV_AO_BLOCK, 0, st>>>(U, SA, g, smp, dc)))
 #define LV_LAUNCH_AO2(ST, AH) \
@@ -1067,8 +1100,10 @@ static int lv_run_ao(lv_ctx* ctx, LvUniforms& U, LvSceneDev& S, const LvTiles& T
 #undef LV_LAUNCH_AO2
 #undef LV_LAUNCH_AO
 #undef LV_LAUNCH_AOP
-        k_ao_reduce<false><<<nblocks(maxPixels), LV_BLOCK, 0, st>>>(U, g, smp, ao, dc);
+        k_ao_reduce<false><<<nblocks(maxPixels), LV_BLOCK, 0, st>>>(U, g, smp, aoIn, ao, dc);
+        if (halo) std::swap(ctx->ao, ctx->aoAlt);
     }
+    S.ao = (const float*)ctx->ao.ptr;
     LV_HIP(ctx, hipGetLastError());
     return LV_OK;
 }
@@ -1100,6 +1135,9 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
     hipStream_t st = ctx->stream;
     LvUniforms U;
     lv_fill_uniforms(ctx, U);
+    // AO lookup of the colour pass: literal projection + bilinear sample for jittered primary rays (ray tracer only; the PPLL
+    // fragments sit at pixel centres), the pixel's own texel otherwise
+    U.aoProjectLookup = (mode == LV_RENDERING_MODE_VULKAN_RAY_TRACER && U.useJitteredRays && U.useAmbientOcclusion && !U.aoPrebaked) ? 1u : 0u;
     if ((rc = lv_buf_reserve(ctx, ctx->counters, sizeof(LvDevCounters)))) return rc;
     if ((rc = lv_buf_reserve(ctx, ctx->depthMinMax, 16))) return rc;
     if ((rc = lv_buf_reserve(ctx, ctx->tilesDev, size_t(numTiles) * 8))) return rc;
@@ -1118,6 +1156,7 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
         ctx->tilesHost.assign(tilesXYHost, tilesXYHost + 2 * size_t(numTiles));
         LV_HIP(ctx, hipMemcpyAsync(ctx->tilesDev.ptr, ctx->tilesHost.data(), size_t(numTiles) * 8, hipMemcpyHostToDevice, st));
         ctx->tilesUploaded = true;
+        ctx->tilesHaloUploaded = false;
     }
     LV_HIP(ctx, hipMemsetAsync(dc, 0, sizeof(LvDevCounters), st));
 
@@ -1140,9 +1179,14 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
         const bool triColour = ctx->opt.rtTriangleMesh && mode == LV_RENDERING_MODE_VULKAN_RAY_TRACER;
         size_t need = lv_overflow_bytes(ctx, gridTiles, LV_STACK_LDS, false);
         if (triColour) need = std::max(need, lv_overflow_bytes(ctx, gridTiles, LV_STACK_LDS, true));
-        if (aoRun)
-            need = std::max(need, lv_overflow_bytes(ctx, std::max<uint64_t>(lv_ao_grid(ctx, maxPixels * U.aoSamplesPerFrame), gridTiles),
+        if (aoRun) {
+            // with the AO halo the AO pass runs on tiles of (tileW + 2) x (tileH + 2) pixels (lv_run_ao)
+            const uint64_t tw = tileW + (U.aoProjectLookup ? 2u : 0u), th = tileH + (U.aoProjectLookup ? 2u : 0u);
+            const uint64_t nbAo = uint64_t(numTiles) * (((tw + 63u) / 64u) * 4u) * (((th + 63u) / 64u) * 4u);
+            const uint64_t gridAo = ((nbAo + 127u) / 128u) * 128u;
+            need = std::max(need, lv_overflow_bytes(ctx, std::max<uint64_t>(lv_ao_grid(ctx, uint64_t(numTiles) * tw * th * U.aoSamplesPerFrame), gridAo),
                                                     LV_AO_STACK_LDS, ctx->opt.aoTriangleTubes));
+        }
         if (aoBake)
             need = std::max(need, lv_overflow_bytes(ctx, uint64_t(ctx->numCUs) * LV_AO_BLOCKS_PER_CU, LV_AO_STACK_LDS, true));
         if (need && (rc = lv_buf_reserve(ctx, ctx->stackOverflow, need))) return rc;
@@ -1427,7 +1471,7 @@ int lv_bake_ambient_occlusion(lv_ctx* ctx) {
         else
             k_ao_rays<false, true, LV_PRIM_TRIANGLE, true><<<uint32_t(gridRays), LV_AO_BLOCK, 0, st>>>(
                     U, SA, g, smp, dc, (const uint2*)ctx->bakeLcgSkip.ptr);
-        k_ao_reduce<true><<<nblocks(slots), LV_BLOCK, 0, st>>>(U, g, smp, out, dc);
+        k_ao_reduce<true><<<nblocks(slots), LV_BLOCK, 0, st>>>(U, g, smp, out, out, dc);
     }
     LV_HIP(ctx, hipGetLastError());
     ctx->bakeValid = true;

@@ -835,6 +835,25 @@ __device__ __forceinline__ f4 lv_compute_fragment_color(const LvSceneDev& S, con
     const float kS = 0.3f, s = 30.0f;
     float aoF = 1.0f;
     if (U.useAmbientOcclusion) {
+        if (U.aoProjectLookup) {
+            // getAoFactor literally: ndc = projectionMatrix * vec4(screenSpacePosition, 1); texture(aoTexture, ndc.xy / ndc.w
+            // * 0.5 + 0.5).x with a linear, clamp-to-edge sampler (texel centres at (i + 0.5) / size).  A jittered sample's hit
+            // lies anywhere inside its pixel, so the neighbouring texels take part (S.ao then carries a 1-pixel halo around
+            // the rendered tiles, lv_run_ao).
+            const f4 s4 = mulM4(U.view, fragPos.x, fragPos.y, fragPos.z, 1.0f);
+            const f4 ndc = mulM4(U.proj, s4.x, s4.y, s4.z, 1.0f);
+            const float u = (ndc.x / ndc.w) * 0.5f + 0.5f, v = (ndc.y / ndc.w) * 0.5f + 0.5f;
+            const float fx = u * float(U.width) - 0.5f, fy = v * float(U.height) - 0.5f;
+            const float x0f = floorf(fx), y0f = floorf(fy);
+            const float wx = fx - x0f, wy = fy - y0f;
+            const uint32_t xa = uint32_t(fminf(fmaxf(x0f, 0.0f), float(U.width - 1u)));
+            const uint32_t xb = uint32_t(fminf(fmaxf(x0f + 1.0f, 0.0f), float(U.width - 1u)));
+            const uint32_t ya = uint32_t(fminf(fmaxf(y0f, 0.0f), float(U.height - 1u)));
+            const uint32_t yb = uint32_t(fminf(fmaxf(y0f + 1.0f, 0.0f), float(U.height - 1u)));
+            const float top = S.ao[size_t(ya) * U.width + xa] * (1.0f - wx) + S.ao[size_t(ya) * U.width + xb] * wx;
+            const float bot = S.ao[size_t(yb) * U.width + xa] * (1.0f - wx) + S.ao[size_t(yb) * U.width + xb] * wx;
+            aoTexel = top * (1.0f - wy) + bot * wy;
+        }
         float a = powf(aoTexel, U.aoGamma);
         aoF = fmaxf(0.0f, (1.0f - U.aoStrength) + U.aoStrength * a);
         kA = 0.2f + (1.0f - aoF) * 0.5f;

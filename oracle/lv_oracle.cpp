@@ -372,11 +372,15 @@ inline void transferFunction(const lvo_scene& sc, const lvo_params& P, float att
     for (int k = 0; k < 4; k++) out[k] = sc.tf[4 * i0 + k] * (1.0f - f) + sc.tf[4 * i1 + k] * f;
 }
 
-// AmbientOcclusion.glsl:84-99 (non-SSAO branch).  The reference projects the hit back to the screen and samples the
-// AO texture there; a primary-ray hit projects into the launching pixel, so the build defines the lookup as "the
-// texel of the pixel that launched the ray" (nearest, halo-free for tiles).
+// AmbientOcclusion.glsl:84-99 (non-SSAO branch): the reference projects the hit back to the screen and samples the AO
+// texture there (linear filter, clamp to edge -- sampler definition owned by the build).
 inline float getAoFactor(const lvo_params& P, float aoTexel, V3 ssp) {
-    if (g_dev.referenceAoLookup && g_dev.aoImage) {
+    // Jittered primary rays (several samples per frame / accumulated frames): the sample's hit projects to an arbitrary
+    // position inside its pixel, so the reference's lookup blends the neighbouring texels -> evaluated literally.
+    // Pixel-centre rays project onto their own texel centre (to float32 rounding: neighbour weights < 2e-4, measured in
+    // tests/test_deviations.py), where the build reads the launching pixel's texel directly -- which keeps screen tiles
+    // free of a halo; the deviation switch forces the literal evaluation there too.
+    if (g_dev.aoImage && (P.useJitteredRays || g_dev.referenceAoLookup)) {
         // literal: ndc = projectionMatrix * vec4(screenSpacePosition, 1); texture(aoTexture, ndc.xy / ndc.w * 0.5 + 0.5).x
         // with a linear, clamp-to-edge sampler (texel centres at (i + 0.5) / size)
         const V4 ndc = mulM4(P.proj, V4{ssp.x, ssp.y, ssp.z, 1.0f});
@@ -1030,6 +1034,7 @@ static void renderRtTri(const lvo_scene* sc, const lvo_tri_scene* tsc, const lvo
     Frame F = makeFrame(P);
     const float HIT_DISTANCE_EPSILON = 1e-5f;
     uint64_t rays = 0, nodes = 0, prims = 0, hits = 0;
+    g_dev.aoImage = (P.useAmbientOcclusion && !pb) ? ao : nullptr;
 #pragma omp parallel for schedule(dynamic, 1) reduction(+ : rays, nodes, prims, hits)
     for (int64_t tileIdx = 0; tileIdx < lvoTileCount(w, h); tileIdx++) { // 16x16-pixel tiles
         Counters cnt;
@@ -1151,6 +1156,7 @@ static void renderRtMlat(const lvo_scene* sc, const lvo_tri_scene* tscOrNull, co
     Frame F = makeFrame(P);
     const bool capped = P.useCappedTubes != 0;
     uint64_t rays = 0, nodesV = 0, prims = 0, hitsShaded = 0, violations = 0;
+    g_dev.aoImage = P.useAmbientOcclusion ? ao : nullptr;
 #pragma omp parallel for schedule(dynamic, 1) reduction(+ : rays, nodesV, prims, hitsShaded, violations)
     for (int64_t yy = 0; yy < int64_t(h); yy++) {
         Counters cnt;
@@ -1492,6 +1498,8 @@ void lvo_ppll_gather(const lvo_scene* sc, const lvo_params* Pp, int useBvh, cons
     const bool capped = P.useCappedTubes != 0;
     uint32_t pw = P.width, ph = P.height;
     padTiling(pw, ph, P.ppllTileW, P.ppllTileH);
+    // fragments are generated at pixel centres: own-texel AO lookup (the literal lookup only under the deviation switch)
+    g_dev.aoImage = (g_dev.referenceAoLookup && P.useAmbientOcclusion) ? ao : nullptr;
     // clear: LinkedListClear.glsl:46-55
     for (size_t i = 0; i < size_t(pw) * ph; i++) startOffset[i] = 0xFFFFFFFFu;
     *fragCounter = 0;

@@ -95,7 +95,13 @@ class Case:
         """Full frame as the host orchestration defines it: depth range -> RTAO -> colour / PPLL."""
         sc = self.oracle_scene()
         P = self.oracle_params(sc)
-        ao = sc.render_ao(P, tile=tile, use_bvh=use_bvh, stats=stats) if P.useAmbientOcclusion else None
+        ao_tile = tile
+        if tile is not None and mode == 11 and P.useJitteredRays:
+            # jittered colour rays sample the AO image bilinearly (AmbientOcclusion.glsl:84-99): 1-pixel halo around the tile
+            x0, y0, w, h = tile
+            xa, ya = max(x0 - 1, 0), max(y0 - 1, 0)
+            ao_tile = (xa, ya, min(x0 + w + 1, self.width) - xa, min(y0 + h + 1, self.height) - ya)
+        ao = sc.render_ao(P, tile=ao_tile, use_bvh=use_bvh, stats=stats) if P.useAmbientOcclusion else None
         if mode == 11:
             return sc.render_rt(P, ao=ao, tile=tile, use_bvh=use_bvh, stats=stats), ao
         return sc.render_ppll(P, ao=ao, tile=tile, use_bvh=use_bvh, stats=stats), ao

@@ -341,6 +341,38 @@ def test_tile_list_equals_full_frame(hip_lib):
         assert np.array_equal(frame, full)
 
 
+def test_jittered_colour_rays_sample_the_ao_image_bilinearly(hip_lib):
+    """getAoFactor (AmbientOcclusion.glsl:84-99) literally for jittered primaries: project the hit, sample the AO image
+    bilinearly.  Tiles then need a 1-pixel AO halo; the rings of adjacent tiles overlap, and with several AO iterations the
+    running mean must stay idempotent for the pixels computed twice (ping-pong accumulation in lv_run_ao)."""
+    import torch
+    c = small_case(width=150, height=90, seed=3, num_samples_per_frame=4, **RTAO, ambient_occlusion_iterations=3,
+                   ambient_occlusion_samples_per_frame=4, depth_cue_strength=0.8)
+    ctx = c.hip_context()
+    full = ctx.render(11)
+    ao = ctx.get_ao()
+    ref, ao_ref = c.oracle_render(11)
+    assert np.array_equal(bits(ao), bits(ao_ref))
+    assert max_lsb_diff(full, ref) <= LSB_TOL
+    # it is not the own-texel lookup: that one gives a visibly different frame here
+    sc = c.oracle_scene()
+    P = c.oracle_params(sc)
+    P.useJitteredRays = 0
+    P.numSamplesPerFrame = 1
+    assert max_lsb_diff(sc.render_rt(P, ao=ao_ref), ref) > LSB_TOL
+    # 32x32 tiles (rings overlap, 3 accumulated iterations) and a ragged rectangle reproduce the frame byte for byte
+    tiles = tiling.make_tiles(150, 90, 32)
+    out = torch.zeros((len(tiles), 32, 32, 4), dtype=torch.uint8, device="cuda")
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.render_tiles_device(out.data_ptr(), tiles, 32, 32, mode=11)
+    torch.cuda.synchronize()
+    ctx.set_stream(None)
+    assert np.array_equal(tiling.detile(out.cpu().numpy(), tiles, 150, 90, 32), full)
+    assert np.array_equal(ctx.render(11, tile=(37, 21, 50, 33)), full[21:54, 37:87])
+    part, _ = c.oracle_render(11, tile=(37, 21, 50, 33))
+    assert max_lsb_diff(part, full[21:54, 37:87]) <= LSB_TOL
+
+
 def test_progressive_accumulation(hip_lib):
     """num_accumulated_frames > 1: the reference's interactive mode -- frame after frame, each mixed into the previous one
     through the rgba8 image (TubeRayTracing.glsl:268-273), RTAO one iteration per frame while frames < iterations."""
