@@ -237,6 +237,20 @@ __device__ __forceinline__ void lv_cswap(float& ka, unsigned& ca, float& kb, uns
 // are already ordered by the ray's direction signs (near planes / far planes), so no per-plane min/max is needed.
 __device__ __forceinline__ bool lv_slab_q(uint32_t nearX, uint32_t nearY, uint32_t nearZ, uint32_t farX, uint32_t farY,
                                           uint32_t farZ, int k, f3 A, f3 B, float tMin, float tMax, float& tNear) {
+#ifdef LV_PK_FMA
+    // near and far plane of one axis in one v_pk_fma_f32 (two independent FMAs: culling only has to be conservative)
+    typedef float lv_v2f __attribute__((ext_vector_type(2)));
+    const lv_v2f qx = {float((nearX >> (8 * k)) & 0xFFu), float((farX >> (8 * k)) & 0xFFu)};
+    const lv_v2f qy = {float((nearY >> (8 * k)) & 0xFFu), float((farY >> (8 * k)) & 0xFFu)};
+    const lv_v2f qz = {float((nearZ >> (8 * k)) & 0xFFu), float((farZ >> (8 * k)) & 0xFFu)};
+    const lv_v2f px = __builtin_elementwise_fma(qx, lv_v2f{A.x, A.x}, lv_v2f{B.x, B.x});
+    const lv_v2f py = __builtin_elementwise_fma(qy, lv_v2f{A.y, A.y}, lv_v2f{B.y, B.y});
+    const lv_v2f pz = __builtin_elementwise_fma(qz, lv_v2f{A.z, A.z}, lv_v2f{B.z, B.z});
+    const float tnp = fmaxf(fmaxf(px.x, py.x), fmaxf(pz.x, tMin));
+    const float tfp = fminf(fminf(px.y, py.y), fminf(pz.y, tMax));
+    tNear = tnp;
+    return tnp <= __builtin_fmaf(tfp, 1.00001f, 4e-7f);
+#endif
     const float tx0 = __builtin_fmaf(float((nearX >> (8 * k)) & 0xFFu), A.x, B.x);
     const float ty0 = __builtin_fmaf(float((nearY >> (8 * k)) & 0xFFu), A.y, B.y);
     const float tz0 = __builtin_fmaf(float((nearZ >> (8 * k)) & 0xFFu), A.z, B.z);
@@ -258,6 +272,31 @@ __device__ __forceinline__ unsigned lv_node_step(const LvSceneDev& S, unsigned n
     const float4* p = S.nodes + 4 * size_t(node);
     const float4 q0 = p[0], q1 = p[1], q2 = p[2], cf = p[3];
     if (STATS) cnt.nodes++;
+#if defined(LV_EXP_EXTRA_LOADS) || defined(LV_EXP_EXTRA_VALU)
+    // sensitivity probes (tools/variants.py): what one more L1-hitting dwordx4 / one more VALU instruction per node step costs
+    {
+        float sink = 0.0f;
+#ifdef LV_EXP_EXTRA_LOADS
+#pragma unroll
+        for (int k = 0; k < LV_EXP_EXTRA_LOADS; k++) {
+            const float4 x = p[(k & 3) + 4 * int(S.numSegs >> 31)]; // numSegs < 2^31: same node, but not provably so
+            sink += (x.x + x.y) + (x.z + x.w);
+        }
+#endif
+#ifdef LV_EXP_EXTRA_VALU
+        float e0 = q0.x, e1 = q0.y, e2 = q0.z, e3 = q0.w;
+#pragma unroll
+        for (int k = 0; k < LV_EXP_EXTRA_VALU / 4; k++) {
+            asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(e0) : "v"(inv.x));
+            asm volatile("v_cvt_f32_ubyte1 %0, %0" : "+v"(e1));
+            asm volatile("v_max_f32 %0, %0, %1" : "+v"(e2) : "v"(inv.y));
+            asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(e3) : "v"(inv.z));
+        }
+        sink += (e0 + e1) + (e2 + e3);
+#endif
+        if (sink == 1.2345678e-30f) tMax = 0.0f; // keeps the probes alive; never true in practice
+    }
+#endif
     unsigned c0 = __float_as_uint(cf.x), c1 = __float_as_uint(cf.y), c2 = __float_as_uint(cf.z), c3 = __float_as_uint(cf.w);
     const f3 A = mk3(q0.w * inv.x, q1.x * inv.y, q1.y * inv.z);
     const f3 B = mk3(__builtin_fmaf(q0.x, inv.x, -oi.x), __builtin_fmaf(q0.y, inv.y, -oi.y), __builtin_fmaf(q0.z, inv.z, -oi.z));

@@ -85,7 +85,7 @@ int main() {
     hipDeviceProp_t prop;
     CHECK(hipGetDeviceProperties(&prop, 0));
     const int cus = prop.multiProcessorCount;
-    const size_t maxBytes = size_t(256) << 20;
+    const size_t maxBytes = size_t(64) << 20;
     float4* buf; float* out;
     CHECK(hipMalloc(&buf, maxBytes)); CHECK(hipMalloc(&out, 64));
     CHECK(hipMemset(buf, 0, maxBytes));
@@ -101,8 +101,9 @@ int main() {
     printf("{\"device\": \"%s\", \"cus\": %d, \"clock_mhz\": %d, \"waves_per_cu\": 20, \"rows\": [\n", prop.gcnArchName, cus,
            prop.clockRate / 1000);
     bool first = true;
-    for (size_t mb : {2, 32, 64, 256}) {
-        const unsigned mask16 = unsigned((mb << 20) / 16 - 1);
+    for (size_t kb : {16, 256, 2048, 32768, 65536}) {
+        const size_t mb = kb >> 10;
+        const unsigned mask16 = unsigned((kb << 10) / 16 - 1);
         for (auto& p : ps) {
             const int grid = cus * 5;
             p.fn<<<grid, 256>>>(buf, mask16, out);
@@ -113,9 +114,9 @@ int main() {
             float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
             const double laneReq = double(grid) * 256.0 * ITERS * p.reqPerIter;
             const double perCuPerNs = laneReq / (double(ms) * 1e6) / cus;
-            printf("%s  {\"pattern\": \"%s\", \"working_set_mb\": %zu, \"ms\": %.4f, \"lane_requests\": %.0f, "
+            printf("%s  {\"pattern\": \"%s\", \"working_set_kb\": %zu, \"ms\": %.4f, \"lane_requests\": %.0f, "
                    "\"lane_requests_per_cu_per_ns\": %.4f, \"bytes_per_cu_per_ns\": %.2f}",
-                   first ? "" : ",\n", p.name, mb, ms, laneReq, perCuPerNs, perCuPerNs * p.bytesPerReq);
+                   first ? "" : ",\n", p.name, kb, ms, laneReq, perCuPerNs, perCuPerNs * p.bytesPerReq);
             first = false;
         }
     }

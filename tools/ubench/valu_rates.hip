@@ -19,6 +19,7 @@
 // 8 independent chains v[k]; every asm statement reads and writes its own chain only
 #define BODY_BEGIN                                                                          \
     float v[8]; float a = p[threadIdx.x & 7], b = p[(threadIdx.x + 1) & 7];                 \
+    const unsigned long long msk = __ballot(p[threadIdx.x & 63] > 1.03f);  /* wave-uniform mask in SGPRs */ \
     for (int k = 0; k < 8; k++) v[k] = p[(threadIdx.x + k) & 63] + a;  /* loads retire here */ \
     unsigned long long t0 = __builtin_readcyclecounter();                                   \
     for (int it = 0; it < NITER; it++) {
@@ -44,7 +45,20 @@
 #define A_MIN3(k) asm volatile("v_min3_f32 %0, %0, %1, %2" : "+v"(v[k]) : "v"(a), "v"(b));
 #define A_CVTUB(k) asm volatile("v_cvt_f32_ubyte1 %0, %0" : "+v"(v[k]));
 #define A_CVTU(k) asm volatile("v_cvt_f32_u32 %0, %0" : "+v"(v[k]));
-#define A_CNDMASK(k) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(v[k]) : "v"(a) : );
+#define A_CNDMASK(k) asm volatile("s_mov_b64 vcc, %2\n v_cndmask_b32 %0, %0, %1, vcc" : "+v"(v[k]) : "v"(a), "s"(msk) : "vcc");
+#define A_CNDMASKS(k) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(v[k]) : "v"(a), "s"(msk));
+#define A_FMA_MAX3(k) asm volatile("v_fma_f32 %0, %0, %1, %2\n v_max3_f32 %0, %0, %1, %2" : "+v"(v[k]) : "v"(a), "v"(b));
+#define A_FMA_CMP(k) asm volatile("v_fma_f32 %0, %0, %1, %2\n v_cmp_lt_f32 s[20:21], %0, %1" : "+v"(v[k]) : "v"(a), "v"(b) : "s20", "s21");
+#define A_FMA_CND(k) asm volatile("v_fma_f32 %0, %0, %1, %2\n v_cndmask_b32_e64 %0, %0, %1, %3" : "+v"(v[k]) : "v"(a), "v"(b), "s"(msk));
+#define A_FMA_MUL(k) asm volatile("v_fma_f32 %0, %0, %1, %2\n v_mul_f32 %0, %0, %1" : "+v"(v[k]) : "v"(a), "v"(b));
+#define A_FMA_AND(k) asm volatile("v_fma_f32 %0, %0, %1, %2\n v_and_b32 %0, %0, %1" : "+v"(v[k]) : "v"(a), "v"(b));
+#define A_CVT_MAX(k) asm volatile("v_cvt_f32_ubyte1 %0, %0\n v_max_f32 %0, %0, %1" : "+v"(v[k]) : "v"(a));
+#define A_MAX_CMP(k) asm volatile("v_max_f32 %0, %0, %1\n v_cmp_lt_f32 s[20:21], %0, %1" : "+v"(v[k]) : "v"(a) : "s20", "s21");
+#define A_FMA_SALU(k) asm volatile("v_fma_f32 %0, %0, %1, %2\n s_add_u32 s20, s20, 1" : "+v"(v[k]) : "v"(a), "v"(b) : "s20", "scc");
+#define A_NODEMIX(k) asm volatile("v_cvt_f32_ubyte0 %0, %0\n v_fma_f32 %0, %0, %1, %2\n v_cvt_f32_ubyte2 %0, %0\n v_fma_f32 %0, %0, %1, %2\n " \
+                                  "v_max3_f32 %0, %0, %1, %2\n v_min3_f32 %0, %0, %1, %2\n v_cmp_le_f32 s[20:21], %0, %1\n "             \
+                                  "v_cndmask_b32_e64 %0, %0, %1, %3" : "+v"(v[k]) : "v"(a), "v"(b), "s"(msk) : "s20", "s21");
+#define A_FMAC(k) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(v[k]) : "v"(a), "v"(b));
 #define A_CMP(k) asm volatile("v_cmp_lt_f32 vcc, %0, %1" : : "v"(v[k]), "v"(a) : "vcc");
 #define A_CMPS(k) asm volatile("v_cmp_lt_f32 s[20:21], %0, %1" : : "v"(v[k]), "v"(a) : "s20", "s21");
 #define A_AND(k) asm volatile("v_and_b32 %0, %0, %1" : "+v"(v[k]) : "v"(a));
@@ -74,6 +88,9 @@ KERNEL(k_cmp_vcc, A_CMP) KERNEL(k_cmp_sgpr, A_CMPS) KERNEL(k_and, A_AND) KERNEL(
 KERNEL(k_add_u32, A_ADDU) KERNEL(k_mov, A_MOV) KERNEL(k_mov_dpp, A_MOVDPP) KERNEL(k_rcp, A_RCP) KERNEL(k_sqrt, A_SQRT)
 KERNEL(k_rsq, A_RSQ) KERNEL(k_mul_lo_u32, A_MULLO) KERNEL(k_lshl_add, A_LSHLADD) KERNEL(k_xor3, A_XOR3)
 KERNEL(k_div_scale, A_DIVSCALE) KERNEL(k_div_fixup, A_DIVFIXUP) KERNEL(k_div_fmas, A_DIVFMAS) KERNEL(k_perm, A_PERM)
+KERNEL(k_cndmask_sgpr, A_CNDMASKS) KERNEL(k_fma_max3, A_FMA_MAX3) KERNEL(k_fma_cmp, A_FMA_CMP) KERNEL(k_fma_cnd, A_FMA_CND)
+KERNEL(k_fma_mul, A_FMA_MUL) KERNEL(k_fma_and, A_FMA_AND) KERNEL(k_cvt_max, A_CVT_MAX) KERNEL(k_max_cmp, A_MAX_CMP)
+KERNEL(k_fma_salu, A_FMA_SALU) KERNEL(k_nodemix, A_NODEMIX) KERNEL(k_fmac, A_FMAC)
 KERNEL(k_readlane, A_READLANE) KERNEL(k_bpermute, A_BPERM) KERNEL(k_salu, A_SALU) KERNEL(k_cvt_fma_pair, A_MIX)
 
 // packed fp32: two chains per instruction (register pairs)
@@ -129,14 +146,18 @@ int main(int argc, char** argv) {
     Entry es[] = {
         {"v_fma_f32", k_fma, 1}, {"v_mul_f32", k_mul, 1}, {"v_add_f32", k_add, 1}, {"v_max_f32", k_max, 1},
         {"v_max3_f32", k_max3, 1}, {"v_min3_f32", k_min3, 1}, {"v_cvt_f32_ubyte1", k_cvt_ubyte, 1},
-        {"v_cvt_f32_u32", k_cvt_u32, 1}, {"v_cndmask_b32", k_cndmask, 1}, {"v_cmp_lt_f32(vcc)", k_cmp_vcc, 1},
+        {"v_cvt_f32_u32", k_cvt_u32, 1}, {"s_mov vcc + v_cndmask_b32(vcc)", k_cndmask, 1}, {"v_cmp_lt_f32(vcc)", k_cmp_vcc, 1},
         {"v_cmp_lt_f32(sgpr)", k_cmp_sgpr, 1}, {"v_and_b32", k_and, 1}, {"v_lshrrev_b32", k_lshr, 1}, {"v_bfe_u32", k_bfe, 1},
         {"v_add_u32", k_add_u32, 1}, {"v_mov_b32", k_mov, 1}, {"v_mov_b32_dpp(quad_perm)", k_mov_dpp, 1},
         {"v_rcp_f32", k_rcp, 1}, {"v_sqrt_f32", k_sqrt, 1}, {"v_rsq_f32", k_rsq, 1}, {"v_mul_lo_u32", k_mul_lo_u32, 1},
         {"v_lshl_add_u32", k_lshl_add, 1}, {"v_xad_u32", k_xor3, 1}, {"v_div_scale_f32", k_div_scale, 1},
         {"v_div_fixup_f32", k_div_fixup, 1}, {"v_div_fmas_f32", k_div_fmas, 1}, {"v_perm_b32", k_perm, 1},
         {"v_readlane_b32", k_readlane, 1}, {"ds_bpermute_b32+wait", k_bpermute, 1}, {"s_add_u32", k_salu, 1},
-        {"v_cvt_f32_ubyte1+v_fma_f32", k_cvt_fma_pair, 2}, {"v_pk_fma_f32", k_pk_fma, 1}, {"v_pk_mul_f32", k_pk_mul, 1},
+        {"v_cvt_f32_ubyte1+v_fma_f32", k_cvt_fma_pair, 2}, {"v_cndmask_b32_e64(sgpr mask)", k_cndmask_sgpr, 1},
+        {"v_fma_f32+v_max3_f32", k_fma_max3, 2}, {"v_fma_f32+v_cmp(sgpr)", k_fma_cmp, 2}, {"v_fma_f32+v_cndmask_e64", k_fma_cnd, 2},
+        {"v_fma_f32+v_mul_f32", k_fma_mul, 2}, {"v_fma_f32+v_and_b32", k_fma_and, 2}, {"v_cvt_f32_ubyte1+v_max_f32", k_cvt_max, 2},
+        {"v_max_f32+v_cmp(sgpr)", k_max_cmp, 2}, {"v_fma_f32+s_add_u32", k_fma_salu, 2},
+        {"node-step mix: cvt,fma,cvt,fma,max3,min3,cmp,cndmask", k_nodemix, 8}, {"v_fmac_f32", k_fmac, 1}, {"v_pk_fma_f32", k_pk_fma, 1}, {"v_pk_mul_f32", k_pk_mul, 1},
     };
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
