@@ -2,13 +2,22 @@
 """bench.py -- headline benchmark of the hot path (BASELINE.json: Mrays/s + fps at 1920x1080, 1M-segment set,
 64 spp RTAO; 1/2/4/8 GPUs).
 
-One "step" = one complete frame of config 3: depth range -> RTAO (1 iteration x 64 samples per pixel, radius 0.1,
-distance based, jittered primaries) -> ray-tracer colour pass (1 spp), on the synthetic 1M-segment tornado-style
-streamline set, inputs resident in HBM.  With N > 1 the SAME frame is sharded by 64x64 screen tiles (Morton order,
-round robin) over one process per GPU and assembled on rank 0 by one RCCL gather (strong scaling: total work fixed).
+One "step" = one complete frame of config 3: RTAO (1 iteration x 64 samples per pixel, radius 0.1, distance based,
+jittered primaries) -> ray-tracer colour pass (1 spp), on the synthetic 1M-segment tornado-style streamline set, inputs
+resident in HBM.  With N > 1 the SAME frame is sharded by 64x64 screen tiles over one process per GPU and assembled on rank 0
+by one RCCL gather (strong scaling: total work fixed).
+
+The timed headline (`value`) is the reference-faithful mode: AO rays against the reference's 6-gon triangle tubes
+(VulkanRayTracedAmbientOcclusion.cpp:444-445).  The same frame with AO rays against the analytic capsules of the colour
+pass (north_star's hot path, the library's default) is timed right after it and reported beside it (`value_capsules`).
 
 Prints ONE JSON line on rank 0.  `value` counts rays actually traced (primary + transparency continuation + AO), taken
 from an untimed instrumented frame (same kernels with counters), times steps, divided by the max-over-ranks wall time.
+`roofline` reports the dominant kernel against every candidate ceiling (VALU issue, vector L1, L2, fabric / HBM) from the
+PMC counters committed under profiles/ and the launch time measured live in this run; `bound` is the largest fraction.
+
+--dry-run: no GPU -- gloo on CPU tensors with a stand-in renderer; exercises exactly the collective sequence of a
+`--gpus N` run (tests/test_tiling_dist.py).
 """
 import argparse
 import json
@@ -22,29 +31,32 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-W, H = 1920, 1080
 TILE = 64
 LINE_WIDTH = 0.002
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E vendor peak (MI355X_MICROARCH.md; ~6.3 TB/s attainable)
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E vendor peak (MI355X_MICROARCH.md; ~6.3 TB/s attainable)
+L2_PEAK_GBS = 34500.0     # aggregate L2 bandwidth (MI355X_MICROARCH.md "L2")
+NUM_CUS, NUM_SIMDS = 256, 1024
+PROFILE_TAG = "r02"
 SETTINGS = {
     "ambient_occlusion_mode": "RTAO (Screen Space)", "ambient_occlusion_strength": 1.0,
     "ambient_occlusion_gamma": 1.0, "ambient_occlusion_iterations": 1, "ambient_occlusion_samples_per_frame": 64,
     "ambient_occlusion_radius": 0.1, "ambient_occlusion_distance_based": True, "use_jittered_primary_rays": True,
     "num_samples_per_frame": 1, "depth_cue_strength": 0.0,
 }
-WORKLOAD = ("C3: 1M-segment tornado-style streamlines (1000 lines x 1001 points, seed 12345), 1920x1080, "
-            "colour pass 1 spp + RTAO 64 spp (1 iteration x 64 samples, radius 0.1, distance based), line width 0.002")
-# AO rays hit the analytic capsules of the segment LBVH (north_star's hot path); "c3t" runs the reference's own RTAO geometry
-RTAO_CAPSULES = ", AO rays against the analytic capsules of the segment LBVH (rtao_geometry=capsules; workload c3t = triangle tubes)"
-# secondary workloads (documentation runs: --workload c2 / c4); the default and the driver's runs are C3
+C3 = ("C3: 1M-segment tornado-style streamlines (1000 lines x 1001 points, seed 12345), 1920x1080, "
+      "colour pass 1 spp + RTAO 64 spp (1 iteration x 64 samples, radius 0.1, distance based), line width 0.002")
+C3T = C3 + ", AO rays against the reference's 6-gon triangle tubes (12.06 M triangles, rtao_geometry=triangle_tubes)"
+C3C = C3 + ", AO rays against the analytic capsules of the segment LBVH (rtao_geometry=capsules)"
 WORKLOADS = {
-    "c3": dict(name=WORKLOAD + RTAO_CAPSULES, scene="tornado", mode=11, settings=SETTINGS, kernel="k_ao_rays"),
-    "c3t": dict(name=WORKLOAD + ", RTAO against the reference's 6-gon triangle tubes (12.06 M triangles, "
-                     "rtao_geometry=triangle_tubes)",
-                scene="tornado", mode=11, settings=dict(SETTINGS, rtao_geometry="triangle_tubes"), kernel="k_ao_rays"),
+    # the default: c3t timed as the headline, c3c timed right after it and reported beside it
+    "c3": dict(name=C3T + "; the same frame with rtao_geometry=capsules is reported as value_capsules", scene="tornado", mode=11,
+               settings=dict(SETTINGS, rtao_geometry="triangle_tubes"), kernel="k_ao_rays", mesh=True, pmc="c3t", also="c3c"),
+    "c3t": dict(name=C3T, scene="tornado", mode=11, settings=dict(SETTINGS, rtao_geometry="triangle_tubes"),
+                kernel="k_ao_rays", mesh=True),
+    "c3c": dict(name=C3C, scene="tornado", mode=11, settings=SETTINGS, kernel="k_ao_rays"),
     "c5": dict(name="C5: 5M-segment Rayleigh-Benard-like convection rolls (5000 lines x 1001 points, seed 12345), 3840x2160, "
-                    "colour pass 1 spp + RTAO 256 spp (1 iteration x 256 samples, radius 0.1, distance based), line width "
-                    "0.002; BASELINE.json config 5 (meant for 8 GPUs; with fewer the same frame takes proportionally longer)",
+                    "colour pass 1 spp + RTAO 256 spp (1 iteration x 256 samples, radius 0.1, distance based, capsules), line "
+                    "width 0.002; BASELINE.json config 5 (meant for 8 GPUs; with fewer the same frame takes proportionally longer)",
                scene="rayleigh_benard", mode=11, settings=dict(SETTINGS, ambient_occlusion_samples_per_frame=256),
                kernel="k_ao_rays", resolution=(3840, 2160), ao_spp=256),
     "c2": dict(name="C2: 100k-segment helix bundle (100 lines x 1001 points, seed 12345), 1920x1080, primary rays only "
@@ -53,27 +65,42 @@ WORKLOADS = {
     "c4": dict(name="C4: 1M-segment tornado-style streamlines, 1920x1080, PPLL OIT: all-hits gather + per-pixel 4-ary heap "
                     "resolve, MAX_NUM_FRAGS 64, node pool 20/pixel, tiling 2x8, opacity ramp 0.1..0.6",
                scene="tornado", mode=2, settings={"ppll_max_num_frags": 64, "ppll_expected_avg_depth_complexity": 20,
-                                                  "depth_cue_strength": 0.0}, kernel="k_ppll_gather"),
-    # the same transparent scene through the ray tracer's two transparency paths (documentation runs)
+                                                  "depth_cue_strength": 0.0}, kernel="k_ppll_gather", transparent=True),
     "c4m": dict(name="C4 scene (1M-segment tornado, 1920x1080, opacity ramp 0.1..0.6) through the ray tracer with multi-layer "
                      "alpha tracing, 8 nodes (use_mlat): single pass, approximate OIT",
                 scene="tornado", mode=11, settings={"use_mlat": True, "mlat_num_nodes": 8, "depth_cue_strength": 0.0,
-                                                    "num_samples_per_frame": 1}, kernel="k_render_rt"),
+                                                    "num_samples_per_frame": 1}, kernel="k_render_rt", transparent=True),
     "c4l": dict(name="C4 scene (1M-segment tornado, 1920x1080, opacity ramp 0.1..0.6) through the ray tracer's transparency "
                      "loop (closest hit, step behind it, repeat until alpha > 0.99)",
                 scene="tornado", mode=11, settings={"depth_cue_strength": 0.0, "num_samples_per_frame": 1},
-                kernel="k_render_rt"),
+                kernel="k_render_rt", transparent=True),
 }
 
 
-def cpu_baseline(pts, seg, tf, attr_range, view, proj, fovy, near, far, target_seconds=15.0, workload="c3", mesh=None,
+def host_cores():
+    """Host cores this process may actually use: min(affinity, cgroup CPU quota).  The GPU boxes of this pool show 256 logical
+    CPUs behind a 16-CPU quota (cpu.max 1600000 100000); oversubscribing the quota only adds throttling."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
+def cpu_baseline(W, H, pts, seg, tf, attr_range, view, proj, fovy, near, far, target_seconds=15.0, workload="c3c", mesh=None,
                  ao_spp=64):
-    """CPU restatement of the LineVis GLSL path (the oracle, NOT LineVis's own binary), all host cores (OpenMP), on a
-    centred crop of the same frame sized for ~target_seconds of work."""
+    """CPU restatement of the LineVis GLSL path (the oracle, NOT LineVis's own binary): 16x16-pixel tiles handed out dynamically
+    over the usable host cores (OpenMP), on a centred crop of the same frame sized for ~target_seconds of work."""
     from oracle import lvo
+    cores = host_cores()
+    lvo.set_num_threads(cores)
     sc = lvo.Scene(pts, seg, tf)
+    rtao = workload in ("c3c", "c3t", "c5")
     P = lvo.make_params(view, proj, W, H, fovY=fovy, nearDist=near, farDist=far, lineWidth=LINE_WIDTH,
-                        useAmbientOcclusion=int(workload in ("c3", "c3t", "c5")), aoStrength=1.0, aoGamma=1.0, aoSamplesPerFrame=ao_spp,
+                        useAmbientOcclusion=int(rtao), aoStrength=1.0, aoGamma=1.0, aoSamplesPerFrame=ao_spp,
                         aoIterations=1, aoUseDistance=1, aoJitterPrimary=1, aoRadius=0.1, attrMin=attr_range[0],
                         attrMax=attr_range[1], ppllMaxNumFrags=64)
     t0 = time.time()
@@ -94,7 +121,7 @@ def cpu_baseline(pts, seg, tf, attr_range, view, proj, fovy, near, far, target_s
             sc.render_rt_mlat(P, 8, tile=tile, use_bvh=True, stats=st)
         else:
             ao = None
-            if workload in ("c3", "c5"):
+            if workload in ("c3c", "c5"):
                 ao = sc.render_ao(P, tile=tile, use_bvh=True, stats=st)
             elif workload == "c3t":
                 ao = tsc.render_ao(P, tile=tile, use_bvh=True, stats=st)
@@ -116,10 +143,12 @@ def cpu_baseline(pts, seg, tf, attr_range, view, proj, fovy, near, far, target_s
         total += d2
         reps += 1
     dt = total / reps
-    return {"value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": lvo.num_threads(), "kind": "port",
-            "sample": "centred %dx%d crop of the same frame in 16x16-pixel tiles over all OpenMP threads (dynamic, 1), %d pass(es), "
-                      "%.1f s in total (%d rays per pass), CPU LBVH build %.1f s excluded; CPU restatement of the LineVis GLSL path (oracle), not LineVis's own binary"
-                      % (cw, ch, reps, total, rays, build_s),
+    return {"value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "logical_cpus_visible": os.cpu_count(),
+            "sample": "centred %dx%d crop of the same frame (%s) in 16x16-pixel tiles over %d OpenMP threads = the cores this "
+                      "process may use (cgroup quota), %d pass(es), %.1f s in total (%d rays per pass), CPU LBVH build %.1f s "
+                      "excluded; CPU restatement of the LineVis GLSL path (oracle), not LineVis's own binary"
+                      % (cw, ch, workload, cores, reps, total, rays, build_s),
             "fps_extrapolated": round(1.0 / (dt * (W * H) / float(cw * ch)), 4)}
 
 
@@ -144,14 +173,102 @@ def measured_hbm_ceiling(device, torch):
     return best
 
 
+def _stats(x):
+    x = np.sort(np.asarray(x, dtype=np.float64))
+    if not len(x):
+        return None
+    return {"median": round(float(np.median(x)), 4), "p95": round(float(x[min(len(x) - 1, int(0.95 * len(x)))]), 4),
+            "min": round(float(x[0]), 4), "max": round(float(x[-1]), 4), "mean": round(float(x.mean()), 4), "n": int(len(x))}
+
+
+def roofline(kernel, pmc_key, ms_launch, algorithmic_bytes, world):
+    """Every candidate ceiling of the dominant kernel: PMC counters of profiles/pmc_<tag>_<workload>.json (collected with
+    tools/pmc_collect.sh on this build, one pass per counter group) x the launch time measured in THIS run; the VALU and
+    vector-L1 ceilings are the rates measured by tools/ubench/ on the same hardware (profiles/ubench_<tag>.json)."""
+    out = {"kernel": kernel, "ms_per_launch": round(ms_launch, 4), "algorithmic_bytes_per_launch": int(algorithmic_bytes),
+           "algorithmic_GBs": round(algorithmic_bytes / (ms_launch * 1e-3) / 1e9, 1) if ms_launch > 0 else None,
+           "algorithmic_note": "SURVEY.md 8(d) byte model: 64 B per node visited + 32/48 B per primitive tested + per-pixel records, "
+                               "'every touch goes to memory'; most of these bytes are served by L1/L2 (see ceilings), so this rate "
+                               "is NOT bounded by the HBM peak"}
+    ppath = os.path.join(ROOT, "profiles", "pmc_%s_%s.json" % (PROFILE_TAG, pmc_key))
+    upath = os.path.join(ROOT, "profiles", "ubench_%s.json" % PROFILE_TAG)
+    if world != 1 or not (os.path.exists(ppath) and os.path.exists(upath)) or ms_launch <= 0:
+        out.update({"bound": None, "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
+                    "note": "ceilings need profiles/pmc_%s_%s.json + profiles/ubench_%s.json and a 1-GPU run" % (PROFILE_TAG, pmc_key, PROFILE_TAG)})
+        return out
+    pmc = json.load(open(ppath))
+    ub = json.load(open(upath))
+    kname = [k for k in pmc["kernels"] if k.startswith(kernel + "<") or k == kernel]
+    c = pmc["kernels"][kname[0]]
+    t_ns = ms_launch * 1e6
+    ceil = {}
+    # VALU issue: wave-instructions per SIMD per ns against the rate the VALU sustains on the node step's instruction mix
+    valu_rate = c["SQ_INSTS_VALU"] / NUM_SIMDS / t_ns
+    valu_peak = 1.0 / ub["valu_ns_per_inst_per_simd"]["node_step_mix"]
+    ceil["valu_issue"] = {"achieved": round(valu_rate, 4), "peak": round(valu_peak, 4), "unit": "wave-instructions/SIMD/ns",
+                          "frac": round(valu_rate / valu_peak, 4),
+                          "lane_utilisation": round(c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"]), 4),
+                          "source": "SQ_INSTS_VALU / 1024 SIMDs / launch time; peak = tools/ubench/valu_rates 'node-step mix'"}
+    # vector L1: lane requests per CU per ns against the all-hit rate of divergent dwordx4 gathers
+    tcp_rate = c["TCP_TOTAL_CACHE_ACCESSES_sum"] / NUM_CUS / t_ns
+    tcp_peak = ub["tcp_lane_requests_per_cu_per_ns"]["own64_l1_hit"]
+    ceil["vector_l1"] = {"achieved": round(tcp_rate, 4), "peak": round(tcp_peak, 4), "unit": "lane-requests/CU/ns",
+                         "frac": round(tcp_rate / tcp_peak, 4),
+                         "l1_hit_rate": round(1.0 - c["TCP_TCC_READ_REQ_sum"] / c["TCP_TOTAL_CACHE_ACCESSES_sum"], 4),
+                         "source": "TCP_TOTAL_CACHE_ACCESSES_sum / 256 CUs / launch time; peak = tools/ubench/tcp_rates own64, 16 KB set"}
+    # L2: requests x 128-B lines against the aggregate L2 bandwidth
+    l2_gbs = c["TCC_REQ_sum"] * 128.0 / t_ns
+    ceil["l2"] = {"achieved": round(l2_gbs, 1), "peak": L2_PEAK_GBS, "unit": "GB/s", "frac": round(l2_gbs / L2_PEAK_GBS, 4),
+                  "hit_rate": round(c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]), 4),
+                  "source": "TCC_REQ_sum x 128 B / launch time"}
+    # fabric / HBM: bytes that left the L2s (Infinity-Cache hits included), gfx950 FETCH_SIZE correction
+    traffic = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+    hbm_gbs = traffic / t_ns
+    ceil["hbm"] = {"achieved": round(hbm_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_gbs / HBM_PEAK_GBS, 4),
+                   "source": "(2 x FETCH_SIZE + WRITE_SIZE) x 1024 / launch time (MI355X_MICROARCH.md HBM: gfx950 FETCH_SIZE "
+                             "counts 128-B requests as 64 B; Infinity-Cache hits are included, so this is an upper bound on HBM)"}
+    bound = max(ceil, key=lambda k: ceil[k]["frac"])
+    out.update({"bound": bound, "achieved": ceil[bound]["achieved"], "peak": ceil[bound]["peak"], "unit": ceil[bound]["unit"],
+                "frac": ceil[bound]["frac"], "traffic": int(traffic), "ceilings": ceil,
+                "pmc_file": os.path.relpath(ppath, ROOT), "ubench_file": os.path.relpath(upath, ROOT)})
+    return out
+
+
+class DryRunContext:
+    """Stand-in for capi.Context in --dry-run: fills tiles with a position pattern, no GPU."""
+
+    class _S:
+        rays_traced = nodes_visited = prims_tested = hits_shaded = ao_hit_pixels = fragments = 0
+        ao_rays_traced = ao_nodes_visited = ao_prims_tested = ao_prim_hits = ao_prim_may_axis = ao_prim_may_both = 0
+        ao_phase_lanes = [0, 0, 0]
+        ao_phase_iterations = [1, 1, 1]
+        ms_kernel_avg = [0.0] * 8
+        kernel_launches = [0] * 8
+        num_nodes = bvh_depth = num_tube_triangles = 0
+        ms_accel_build = 0.0
+
+    def set_option(self, *a):
+        pass
+
+    def stats(self):
+        return self._S()
+
+    def reset_timers(self):
+        pass
+
+    def kernel_times(self, k):
+        return np.zeros(0, np.float32)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--save-frame", default="")
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--dry-run", action="store_true", help="no GPU: gloo + CPU tensors + a stand-in renderer (collective sequence only)")
     args = ap.parse_args()
 
     import torch
@@ -164,152 +281,202 @@ def main():
             raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`"
                              % (args.gpus, args.gpus))
         raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    dry = args.dry_run
+    if dry:
+        device = torch.device("cpu")
+    else:
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if dry:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
-    from linevis_amd import camera, capi, host_api, scenes, tiling, transfer_function as tfm
+    from linevis_amd import camera, tiling, transfer_function as tfm
 
     wl = WORKLOADS[args.workload]
-    global W, H
     W, H = wl.get("resolution", (1920, 1080))
-    # ---- synthetic input (every rank builds the same replica; deterministic)
-    gen = {"tornado": scenes.tornado, "helix": scenes.helix_bundle, "rayleigh_benard": scenes.rayleigh_benard}[wl["scene"]]
-    tr = scenes.normalize(gen())
-    flow = host_api.LineDataFlow().set_trajectories(tr.positions, tr.attributes, tr.line_offsets)
-    pts, seg, _ = flow.tube_aabb_render_data(LINE_WIDTH)
-    tf = tfm.standard_transparent() if args.workload.startswith("c4") else tfm.standard()
-    attr_range = flow.attribute_range()
-    view, proj, fovy, near, far = camera.default_camera(W, H)
-
-    ctx = capi.Context(local_rank)
-    ctx.set_lines(pts, seg)
-    ctx.set_transfer_function(tf, *attr_range)
-    ctx.set_camera(view, proj, fovy, near, far, W, H)
-    ctx.set_option("line_width", LINE_WIDTH)
-    mesh = None
-    if args.workload == "c3t":   # LineData::getLinePassTubeTriangleMeshRenderData -> the RTAO pass' geometry
-        mesh = flow.tube_triangle_render_data(LINE_WIDTH, 6)
-        ctx.set_tube_triangle_mesh(*mesh)
-    ctx.set_options(wl["settings"])
-    render_fn = tiling.hip_render_tiles_fn(ctx, wl["mode"])   # also moves the context onto torch's stream
-    ctx.build_accel()
-    build_first_ms = ctx.stats().ms_accel_build   # includes the one-time load of the library's code object (~5 ms)
-    ctx.build_accel()                             # what a line-width change / new data costs from then on
-    build_ms = ctx.stats().ms_accel_build
-    sf = tiling.ShardedFrame(W, H, TILE, rank, world, device)
-
-    def step():
-        sf.render_local(render_fn)
-        sf.gather()
-        return sf.assemble_device()
 
     def sync_all():
-        torch.cuda.synchronize()
+        if not dry:
+            torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not dry:
+            torch.cuda.synchronize()
 
-    # ---- untimed instrumented frame: rays traced + algorithmic traffic of this rank's tiles
-    ctx.set_option("collect_stats", True)
-    step()
-    torch.cuda.synchronize()
-    st = ctx.stats()
-    ctx.set_option("collect_stats", False)
-    counters = torch.tensor([st.rays_traced, st.nodes_visited, st.prims_tested, st.hits_shaded, st.ao_hit_pixels,
-                             st.fragments], dtype=torch.float64, device=device)
-    if world > 1:
-        dist.all_reduce(counters)
-    rays_per_frame = float(counters[0].item())
-    counters_local = (st.nodes_visited, st.prims_tested, st.hits_shaded, st.ao_rays_traced, st.ao_nodes_visited,
-                      st.ao_prims_tested)
-    ao_diag = (st.ao_prim_hits, st.ao_prim_may_axis, st.ao_prim_may_both,
-               [round(st.ao_phase_lanes[k] / max(64.0 * st.ao_phase_iterations[k], 1.0), 4) for k in range(3)])
-    # algorithmic bytes of ONE k_ao_rays launch on this rank (DESIGN.md "Algorithmic bytes"):
-    # 64 B per compressed 4-wide BVH node visited + 32 B per segment record tested + 52 B per compacted pixel (48 B G-buffer read,
-    # 4 B AO factor write)
-    prim_bytes = 48 if args.workload == "c3t" else 32   # 48-B triangle record / 32-B segment record
-    ao_bytes = st.ao_nodes_visited * 64 + st.ao_prims_tested * prim_bytes + st.ao_hit_pixels * 52
-    frame_bytes = (st.nodes_visited * 64 + st.prims_tested * 32 + st.hits_shaded * 96 + st.ao_hit_pixels * 52
-                   + len(sf.local_tiles) * TILE * TILE * (4 + 4) + st.fragments * (12 + 4 + 4 + 12))
-    kid = capi.KERNEL_NAMES.index(wl["kernel"])
-    kernel_bytes = ao_bytes if args.workload in ("c3", "c3t", "c5") else frame_bytes  # c2 / c4: one traversal kernel dominates
+    # ---- synthetic input (every rank builds the same replica; deterministic)
+    pts = seg = tf = attr_range = mesh = flow = None
+    view, proj, fovy, near, far = camera.default_camera(W, H)
+    if not dry:
+        from linevis_amd import capi, host_api, scenes
+        gen = {"tornado": scenes.tornado, "helix": scenes.helix_bundle, "rayleigh_benard": scenes.rayleigh_benard}[wl["scene"]]
+        tr = scenes.normalize(gen())
+        flow = host_api.LineDataFlow().set_trajectories(tr.positions, tr.attributes, tr.line_offsets)
+        pts, seg, _ = flow.tube_aabb_render_data(LINE_WIDTH)
+        tf = tfm.standard_transparent() if wl.get("transparent") else tfm.standard()
+        attr_range = flow.attribute_range()
+        if wl.get("mesh"):   # LineData::getLinePassTubeTriangleMeshRenderData -> the RTAO pass' geometry
+            mesh = flow.tube_triangle_render_data(LINE_WIDTH, 6)
 
-    for _ in range(args.warmup):
+    def make_context(w):
+        if dry:
+            return DryRunContext(), None
+        ctx = capi.Context(local_rank)
+        ctx.set_lines(pts, seg)
+        ctx.set_transfer_function(tf, *attr_range)
+        ctx.set_camera(view, proj, fovy, near, far, W, H)
+        ctx.set_option("line_width", LINE_WIDTH)
+        if w.get("mesh"):
+            ctx.set_tube_triangle_mesh(*mesh)
+        ctx.set_options(w["settings"])
+        fn = tiling.hip_render_tiles_fn(ctx, w["mode"])   # also moves the context onto torch's stream
+        ctx.build_accel()
+        return ctx, fn
+
+    sf = tiling.ShardedFrame(W, H, TILE, rank, world, device)
+
+    def dry_render(out, tiles_xy, tw, th):
+        for i, (x0, y0) in enumerate(tiles_xy):
+            out[i, :, :, 0] = int(x0) // tw % 256
+            out[i, :, :, 1] = int(y0) // th % 256
+            out[i, :, :, 2] = rank
+            out[i, :, :, 3] = 255
+
+    def measure(w, wkey):
+        """Instrumented frame (counters), warm-up, K timed frames; returns everything rank 0 reports for this workload."""
+        ctx, render_fn = make_context(w)
+        if dry:
+            render_fn = dry_render
+        build_first_ms = ctx.stats().ms_accel_build   # includes the one-time load of the library's code object (~5 ms)
+        if not dry:
+            ctx.build_accel()                         # what a line-width change / new data costs from then on
+        build_ms = ctx.stats().ms_accel_build
+
+        def step():
+            sf.render_local(render_fn)
+            sf.gather()
+            return sf.assemble_device()
+
+        # ---- untimed instrumented frame: rays traced + algorithmic traffic of this rank's tiles
+        ctx.set_option("collect_stats", True)
         step()
-    sync_all()
-    ctx.reset_timers()
-    sync_all()
-    t0 = time.perf_counter()
-    frame = None
-    for _ in range(args.steps):
-        frame = step()
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    if world > 1:
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    elapsed = float(tt.item())
-    st = ctx.stats()   # per-kernel HIP-event averages over the timed region (this rank)
+        sync_all()
+        st = ctx.stats()
+        ctx.set_option("collect_stats", False)
+        counters = torch.tensor([st.rays_traced, st.nodes_visited, st.prims_tested, st.hits_shaded, st.ao_hit_pixels,
+                                 st.fragments], dtype=torch.float64, device=device)
+        if world > 1:
+            dist.all_reduce(counters)
+        rays_per_frame = float(counters[0].item())
+        prim_bytes = 48 if w.get("mesh") else 32   # 48-B triangle record / 32-B segment record
+        ao_bytes = st.ao_nodes_visited * 64 + st.ao_prims_tested * prim_bytes + st.ao_hit_pixels * 52
+        frame_bytes = (st.nodes_visited * 64 + st.prims_tested * 32 + st.hits_shaded * 96 + st.ao_hit_pixels * 52
+                       + len(sf.local_tiles) * TILE * TILE * (4 + 4) + st.fragments * (12 + 4 + 4 + 12))
+        kernel_bytes = ao_bytes if w["kernel"] == "k_ao_rays" else frame_bytes   # c2 / c4: one traversal kernel dominates
+        local = dict(nodes_visited=int(st.nodes_visited), prims_tested=int(st.prims_tested), hits_shaded=int(st.hits_shaded),
+                     ao_rays=int(st.ao_rays_traced), ao_nodes_visited=int(st.ao_nodes_visited),
+                     ao_prims_tested=int(st.ao_prims_tested), ao_prim_hits=int(st.ao_prim_hits),
+                     ao_prim_may_axis=int(st.ao_prim_may_axis), ao_prim_may_both=int(st.ao_prim_may_both),
+                     ao_phase_lane_utilisation=[round(st.ao_phase_lanes[k] / max(64.0 * st.ao_phase_iterations[k], 1.0), 4)
+                                                for k in range(3)])
+        # ---- re-deal the tiles by the cost this frame measured (RTAO hit pixels per tile x samples + a fixed cost per tile):
+        # one small all-reduce outside the timed region; with one GPU the deal is trivial
+        if world > 1:
+            if dry:
+                local_cost = [float((int(x0) // TILE * 7 + int(y0) // TILE * 3) % 11) for x0, y0 in sf.local_tiles]
+            elif w["kernel"] == "k_ao_rays":
+                local_cost = ctx.ao_tile_costs().astype(np.float64) * float(w.get("ao_spp", 64))
+            else:
+                local_cost = None
+            if local_cost is not None:
+                sf.rebalance(local_cost, base_cost=4.0 * TILE * TILE)
+        for _ in range(args.warmup):
+            step()
+        sync_all()
+        ctx.reset_timers()
+        sync_all()
+        marks = []
+        if not dry:   # per-frame durations on the stream the kernels and the gather run on (no host sync inside the loop)
+            marks = [torch.cuda.Event(enable_timing=True) for _ in range(min(args.steps, 512) + 1)]
+            marks[0].record()
+        t0 = time.perf_counter()
+        frame = None
+        for i in range(args.steps):
+            frame = step()
+            if i + 1 < len(marks):
+                marks[i + 1].record()
+        sync_all()
+        elapsed = time.perf_counter() - t0
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        if world > 1:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        st = ctx.stats()
+        frame_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(len(marks) - 1)] if marks else []
+        kernels = {}
+        if not dry:
+            for k, name in enumerate(capi.KERNEL_NAMES[:6]):
+                ks = _stats(ctx.kernel_times(k))
+                if ks:
+                    kernels[name] = ks
+        return dict(ctx=ctx, frame=frame, elapsed=elapsed, rays_per_frame=rays_per_frame, counters=counters, local=local,
+                    kernel_bytes=kernel_bytes, frame_bytes=frame_bytes, kernels=kernels, frame_ms=_stats(frame_ms),
+                    build_ms=build_ms, build_first_ms=build_first_ms, st=st, wkey=wkey)
+
+    head = measure(wl, args.workload)
+    also = None
+    if wl.get("also") and not dry:
+        del head["ctx"]   # frees the triangle scene before the capsule context builds
+        also = measure(WORKLOADS[wl["also"]], wl["also"])
 
     if rank == 0:
-        ms_rays = float(st.ms_kernel_avg[kid])
-        achieved = kernel_bytes / (ms_rays * 1e-3) / 1e9 if ms_rays > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
-        if os.path.exists(tpath) and world == 1 and args.workload == "c3":
-            try:
-                traffic = json.load(open(tpath)).get("k_ao_rays_hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        kname = wl["kernel"]
+        ms_launch = head["kernels"].get(kname, {}).get("median", 0.0) if head["kernels"] else 0.0
+        st = head["st"]
         result = {
-            "metric": "Mrays/s", "value": round(rays_per_frame * args.steps / elapsed / 1e6, 2), "unit": "Mrays/s",
+            "metric": "Mrays/s", "value": round(head["rays_per_frame"] * args.steps / head["elapsed"] / 1e6, 2), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "fps": round(args.steps / elapsed, 3),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": wl["name"], "resolution": [W, H], "segments": int(len(seg)),
-                       "rays_per_frame": int(rays_per_frame), "ao_hit_pixels": int(counters[4].item()),
-                       "fragments_per_frame": int(counters[5].item()),
-                       "parallelism": "screen tiles %dx%d, Morton order, round robin over %d GPU(s), one RCCL gather"
+            "ms_per_step": round(head["elapsed"] / args.steps * 1e3, 4), "fps": round(args.steps / head["elapsed"], 3),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic" if not dry else "dry-run (no GPU, stand-in renderer)",
+            "config": {"workload": wl["name"], "resolution": [W, H], "segments": int(len(seg)) if seg is not None else 0,
+                       "rays_per_frame": int(head["rays_per_frame"]), "ao_hit_pixels": int(head["counters"][4].item()),
+                       "fragments_per_frame": int(head["counters"][5].item()),
+                       "parallelism": "screen tiles %dx%d in Morton order, dealt over %d GPU(s) by measured cost (RTAO hit pixels per tile "
+                                      "of the instrumented frame; round robin for workloads without RTAO), one RCCL gather per frame"
                                       % (TILE, TILE, world),
-                       "accel_build_ms": round(build_ms, 3), "accel_build_first_ms": round(build_first_ms, 3),
-                       "bvh_depth": int(st.bvh_depth),
-                       "tube_triangles": int(st.num_tube_triangles)},
-            "roofline": {"bound": "hbm", "kernel": wl["kernel"], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "algorithmic_bytes_per_launch": int(kernel_bytes), "ms_per_launch": round(ms_rays, 4),
-                         "launches_timed": int(min(st.kernel_launches[kid], 128)),
-                         "frame_algorithmic_bytes_rank0": int(frame_bytes),
-                         # compulsory floor: every node, segment record and line point read once + the
-                         # frame's outputs -- what a perfect cache would leave of the algorithmic bytes
-                         "frame_compulsory_bytes": int(st.num_nodes * 64 + len(seg) * 32 + len(pts) * 48 + W * H * (4 + 4)),
-                         "note": "achieved = algorithmic bytes (64 B per node visited + 32/48 B per primitive tested + per-pixel "
-                                 "records) / measured launch time; the scene + LBVH (~64 MB) live in L2 / Infinity Cache, so "
-                                 "most of these bytes never reach HBM ('traffic' = PMC-measured HBM bytes per launch) and frac "
-                                 "can exceed 1: the traversal kernels are VALU-issue-bound, not HBM-bound (DESIGN.md section 6)"},
-            "counters_rank0": {"nodes_visited": int(counters_local[0]), "prims_tested": int(counters_local[1]),
-                               "hits_shaded": int(counters_local[2]), "ao_rays": int(counters_local[3]),
-                               "ao_nodes_visited": int(counters_local[4]), "ao_prims_tested": int(counters_local[5]),
-                               "ao_prim_hits": int(ao_diag[0]), "ao_prim_may_axis": int(ao_diag[1]),
-                               "ao_prim_may_both": int(ao_diag[2]),
-                               "ao_phase_lane_utilisation": ao_diag[3]},
-            "kernels_ms": {capi.KERNEL_NAMES[k]: round(float(st.ms_kernel_avg[k]), 4) for k in range(6)
-                           if st.kernel_launches[k]},
+                       "accel_build_ms": round(head["build_ms"], 3), "accel_build_first_ms": round(head["build_first_ms"], 3),
+                       "bvh_depth": int(st.bvh_depth), "tube_triangles": int(st.num_tube_triangles)},
+            "frame_ms": head["frame_ms"],
+            "kernels_ms": head["kernels"],
+            "counters_rank0": head["local"],
+            "roofline": roofline(kname, wl.get("pmc", args.workload), ms_launch, head["kernel_bytes"], world),
         }
-        if world == 1:
+        result["roofline"]["frame_algorithmic_bytes_rank0"] = int(head["frame_bytes"])
+        if seg is not None:   # compulsory floor (SURVEY.md 8d): every node, primitive record and line point once + the outputs
+            result["roofline"]["frame_compulsory_bytes"] = int(st.num_nodes * 64 + len(seg) * 32 + len(pts) * 48 + W * H * (4 + 4)
+                                                               + (st.num_tube_triangles * (48 + 32) if wl.get("mesh") else 0))
+        if also is not None:
+            result["value_capsules"] = round(also["rays_per_frame"] * args.steps / also["elapsed"] / 1e6, 2)
+            result["ms_per_step_capsules"] = round(also["elapsed"] / args.steps * 1e3, 4)
+            result["fps_capsules"] = round(args.steps / also["elapsed"], 3)
+            result["capsules"] = {"workload": WORKLOADS[wl["also"]]["name"], "rays_per_frame": int(also["rays_per_frame"]),
+                                  "frame_ms": also["frame_ms"], "kernels_ms": also["kernels"], "counters_rank0": also["local"],
+                                  "roofline": roofline(kname, wl["also"], also["kernels"].get(kname, {}).get("median", 0.0),
+                                                       also["kernel_bytes"], world)}
+        if world == 1 and not dry:
             ceil = measured_hbm_ceiling(device, torch)
-            result["roofline"]["peak_measured"] = round(ceil, 1)          # copy bandwidth attainable on this box
-            result["roofline"]["frac_of_measured"] = round(achieved / ceil, 5)
-            if traffic:   # what actually crossed the HBM interface per launch (PMC) as a rate
-                result["roofline"]["traffic_GBs"] = round(traffic / (ms_rays * 1e-3) / 1e9, 1)
-        if args.save_frame and frame is not None:
+            result["roofline"]["hbm_peak_measured_GBs"] = round(ceil, 1)   # copy bandwidth attainable on this box
+        if args.save_frame and head["frame"] is not None and not dry:
             from PIL import Image
-            Image.fromarray(frame.cpu().numpy()).save(args.save_frame)
-        if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(pts, seg, tf, attr_range, view, proj, fovy, near, far,
-                                                  workload=args.workload, mesh=mesh, ao_spp=wl.get("ao_spp", 64))
+            Image.fromarray(head["frame"].cpu().numpy()).save(args.save_frame)
+        if world == 1 and not args.no_cpu_baseline and not dry:
+            cpu_wl = {"c3": "c3t"}.get(args.workload, args.workload)
+            result["cpu_baseline"] = cpu_baseline(W, H, pts, seg, tf, attr_range, view, proj, fovy, near, far,
+                                                  workload=cpu_wl, mesh=mesh, ao_spp=wl.get("ao_spp", 64))
         else:
             result["cpu_baseline"] = None
         print(json.dumps(result), flush=True)

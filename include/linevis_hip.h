@@ -214,6 +214,12 @@ int lv_reset_timers(lv_ctx* ctx);
  * PerPixelLinkedListLineRenderer.cpp:411-420 / AutomaticPerformanceMeasurer).  Synchronises the stream. */
 int lv_get_kernel_times(lv_ctx* ctx, int kernel_id, float* out_ms, uint32_t capacity, uint32_t* out_count);
 
+/* Hit pixels (primary rays of the RTAO pass that hit geometry) per 64x64-pixel group of the last lv_render* call's tile
+ * list, in tile-list order, `*out_groups_per_tile` consecutive entries per tile: a rank's per-tile AO cost (AO rays = hit
+ * pixels x samples), which the tile sharding uses to re-deal tiles by cost (linevis_amd/tiling.py; SURVEY.md 8e asks for
+ * load balance by tile dealing -- the reference itself is single-GPU).  LV_E_STATE unless the last call ran the RTAO pass. */
+int lv_get_ao_tile_costs(lv_ctx* ctx, uint32_t* out_counts, uint32_t capacity, uint32_t* out_count, uint32_t* out_groups_per_tile);
+
 /* ---- streamline tracing: the producer of the line sets ----
  * StreamlineTracingGrid (src/LineData/Flow/StreamlineTracingGrid.cpp): regular grid of xs*ys*zs cells with spacing
  * (dx, dy, dz) and origin 0 (setGridExtent, :81-116), one vector field (3 floats per cell, x fastest: IDXV of

@@ -82,7 +82,7 @@ class LineVisError(RuntimeError):
 # every symbol include/linevis_hip.h declares (checked by tests/test_abi.py against the header text)
 SYMBOLS = ["lv_create", "lv_destroy", "lv_last_error", "lv_version", "lv_set_stream", "lv_set_lines",
            "lv_set_transfer_function", "lv_set_camera", "lv_set_background", "lv_set_option", "lv_build_accel",
-           "lv_render", "lv_render_device", "lv_render_tiles_device", "lv_get_stats", "lv_reset_timers", "lv_get_kernel_times", "lv_trace_rays",
+           "lv_render", "lv_render_device", "lv_render_tiles_device", "lv_get_stats", "lv_reset_timers", "lv_get_kernel_times", "lv_get_ao_tile_costs", "lv_trace_rays",
            "lv_compute_depth_range", "lv_get_ao", "lv_ppll_get_buffers", "lv_ppll_resolve_buffers", "lv_get_accel",
            "lv_set_tube_triangle_mesh", "lv_trace_rays_triangles", "lv_set_flow_grid", "lv_trace_streamlines",
            "lv_get_streamlines", "lv_set_ao_parametrization", "lv_get_baked_ao", "lv_get_mlat_trace"]
@@ -131,6 +131,7 @@ def load():
         ("lv_get_stats", [vp, C.POINTER(Stats)]),
         ("lv_reset_timers", [vp]),
         ("lv_get_kernel_times", [vp, i32, vp, u32, C.POINTER(u32)]),
+        ("lv_get_ao_tile_costs", [vp, vp, u32, C.POINTER(u32), C.POINTER(u32)]),
         ("lv_trace_rays", [vp, vp, vp, f32, f32, u32, vp, vp, vp]),
         ("lv_compute_depth_range", [vp, vp]),
         ("lv_get_ao", [vp, vp]),
@@ -328,6 +329,14 @@ class Context:
         cnt = C.c_uint32()
         self._ck(self.L.lv_get_kernel_times(self.h, int(kernel_id), _p(out), 512, C.byref(cnt)))
         return out[:cnt.value].copy()
+
+    def ao_tile_costs(self):
+        """Hit pixels of the last RTAO pass per tile of the last tile list (64x64-pixel groups summed per tile)."""
+        n, g = C.c_uint32(), C.c_uint32()
+        self._ck(self.L.lv_get_ao_tile_costs(self.h, None, 0, C.byref(n), C.byref(g)))
+        out = np.zeros(n.value, dtype=np.uint32)
+        self._ck(self.L.lv_get_ao_tile_costs(self.h, _p(out), n.value, C.byref(n), C.byref(g)))
+        return out.reshape(-1, max(g.value, 1)).sum(axis=1)
 
     def ppll_buffers(self, padded_pixels, max_nodes):
         nodes = np.zeros((max_nodes, 3), dtype=np.uint32)

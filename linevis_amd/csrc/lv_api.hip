@@ -673,6 +673,20 @@ int lv_get_ao(lv_ctx* ctx, float* out) {
     return LV_OK;
 }
 
+int lv_get_ao_tile_costs(lv_ctx* ctx, uint32_t* out_counts, uint32_t capacity, uint32_t* out_count, uint32_t* out_groups_per_tile) {
+    if (!ctx) return LV_E_INVALID;
+    if (!ctx->aoNumGroups || !ctx->aoList.ptr) return lv_fail(ctx, LV_E_STATE, "no RTAO pass in the last render call");
+    if (out_count) *out_count = ctx->aoNumGroups;
+    if (out_groups_per_tile) *out_groups_per_tile = ctx->aoGroupsPerTile;
+    if (out_counts) {
+        if (capacity < ctx->aoNumGroups) return lv_fail(ctx, LV_E_CAPACITY, "out_counts holds %u entries, need %u", capacity, ctx->aoNumGroups);
+        (void)hipSetDevice(ctx->device);
+        LV_HIP(ctx, hipMemcpyAsync(out_counts, ctx->aoList.ptr, size_t(ctx->aoNumGroups) * 4, hipMemcpyDeviceToHost, ctx->stream));
+        LV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return LV_OK;
+}
+
 int lv_ppll_get_buffers(lv_ctx* ctx, uint32_t* out_nodes, uint64_t max_nodes, uint32_t* out_start, uint64_t max_pixels,
                         uint32_t* out_frag_counter) {
     if (!ctx) return LV_E_INVALID;

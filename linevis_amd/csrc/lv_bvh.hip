@@ -268,6 +268,12 @@ __device__ __forceinline__ void lv_write_wide_node(float4* out, int ns, const ui
         }
         // q = 255 must still cover hi: widen the scale in the (rounding) case it does not
         while (lv_dec(lo, scale[a], 255u) < hi) scale[a] = scale[a] * 1.00001f + 1e-30f;
+        // empty slots: inverted box (min plane 255, max plane 0 on every axis) -> the slab test of lv_node_step rejects them by
+        // itself (near plane behind far plane by the node's whole extent) and needs no explicit "slot occupied" test; their
+        // reference stays LV_INVALID, so even a false accept could only change the visiting order, never the result
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (k >= ns) qmin[a] |= 255u << (8 * k);
     }
     out[0] = make_float4(origin[0], origin[1], origin[2], scale[0]);
     out[1] = make_float4(scale[1], scale[2], __uint_as_float(qmin[0]), __uint_as_float(qmin[1]));
@@ -375,8 +381,9 @@ __global__ void k_single_node(const float* __restrict__ leafBox, float4* __restr
         while (lv_dec(leafBox[a], sc[a], 255u) < leafBox[3 + a]) sc[a] = sc[a] * 1.00001f + 1e-30f;
     }
     nodes[0] = make_float4(leafBox[0], leafBox[1], leafBox[2], sc[0]);
-    nodes[1] = make_float4(sc[1], sc[2], __uint_as_float(0u), __uint_as_float(0u));
-    nodes[2] = make_float4(__uint_as_float(0u), __uint_as_float(255u), __uint_as_float(255u), __uint_as_float(255u));
+    // slot 0 = the leaf (planes 0 .. 255), slots 1-3 empty = inverted boxes (min 255, max 0)
+    nodes[1] = make_float4(sc[1], sc[2], __uint_as_float(0xFFFFFF00u), __uint_as_float(0xFFFFFF00u));
+    nodes[2] = make_float4(__uint_as_float(0xFFFFFF00u), __uint_as_float(255u), __uint_as_float(255u), __uint_as_float(255u));
     nodes[3] = make_float4(__uint_as_float(0u | LV_LEAF_BIT), __uint_as_float(LV_INVALID), __uint_as_float(LV_INVALID),
                            __uint_as_float(LV_INVALID));
 }

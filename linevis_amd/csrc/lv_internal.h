@@ -107,6 +107,7 @@ struct lv_ctx {
     LvDeviceBuffer tilesHaloDev;              // tile origins - 1 (AO pass on dilated tiles)
     std::vector<uint32_t> tilesHaloHost;
     bool tilesHaloUploaded = false;
+    uint32_t aoNumGroups = 0, aoGroupsPerTile = 0; // geometry of the last RTAO pass' per-group counters (aoList)
     LvDeviceBuffer aoGbuf, aoList, aoSamples; // RTAO wavefront buffers
     LvDeviceBuffer counters;                  // device counters (LvCounters + misc)
     LvDeviceBuffer ppllNodes, ppllStart, ppllCount, ppllScratch;

@@ -38,6 +38,7 @@ __device__ __forceinline__ void lv_flush_counters(const LvCounters& c, LvDevCoun
 struct LvPixel {
     uint32_t x, y;       // viewport pixel
     uint32_t outIndex;   // index into the tile-major output
+    uint32_t group;      // 64x64-pixel group of the launch: tile index * groups per tile + group inside the tile
     bool inTile, inView;
 };
 
@@ -46,7 +47,7 @@ __device__ __forceinline__ bool lv_block_pixel(const LvUniforms& U, const LvTile
     const uint32_t nb = T.numTiles * blocksPerTile;
     const uint32_t xcd = blockId % 8u, j = blockId / 8u;   // j-th block this XCD receives
     const uint32_t b = ((j / LV_XCD_GROUP) * 8u + xcd) * LV_XCD_GROUP + (j % LV_XCD_GROUP);
-    if (b >= nb) { p.inTile = false; p.inView = false; return false; }
+    if (b >= nb) { p.inTile = false; p.inView = false; p.group = 0u; return false; }
     const uint32_t tile = b / blocksPerTile, rem = b % blocksPerTile;
     // A tile is cut into 64x64-pixel groups of 16 blocks (T.blocksX / T.blocksY are multiples of 4).  Inside a group the
     // 64 waves do NOT own 8x8 patches: wave W takes pixel (W & 7, W >> 3) of each of the group's 8x8 cells, i.e. 64 pixels
@@ -64,6 +65,7 @@ __device__ __forceinline__ bool lv_block_pixel(const LvUniforms& U, const LvTile
     p.y = T.tilesXY[2 * tile + 1] + ly;
     p.inView = p.inTile && p.x < U.width && p.y < U.height;
     p.outIndex = (tile * T.tileH + ly) * T.tileW + lx;
+    p.group = tile * (blocksPerTile / 16u) + group;
     return true;
 }
 

@@ -237,20 +237,6 @@ __device__ __forceinline__ void lv_cswap(float& ka, unsigned& ca, float& kb, uns
 // are already ordered by the ray's direction signs (near planes / far planes), so no per-plane min/max is needed.
 __device__ __forceinline__ bool lv_slab_q(uint32_t nearX, uint32_t nearY, uint32_t nearZ, uint32_t farX, uint32_t farY,
                                           uint32_t farZ, int k, f3 A, f3 B, float tMin, float tMax, float& tNear) {
-#ifdef LV_PK_FMA
-    // near and far plane of one axis in one v_pk_fma_f32 (two independent FMAs: culling only has to be conservative)
-    typedef float lv_v2f __attribute__((ext_vector_type(2)));
-    const lv_v2f qx = {float((nearX >> (8 * k)) & 0xFFu), float((farX >> (8 * k)) & 0xFFu)};
-    const lv_v2f qy = {float((nearY >> (8 * k)) & 0xFFu), float((farY >> (8 * k)) & 0xFFu)};
-    const lv_v2f qz = {float((nearZ >> (8 * k)) & 0xFFu), float((farZ >> (8 * k)) & 0xFFu)};
-    const lv_v2f px = __builtin_elementwise_fma(qx, lv_v2f{A.x, A.x}, lv_v2f{B.x, B.x});
-    const lv_v2f py = __builtin_elementwise_fma(qy, lv_v2f{A.y, A.y}, lv_v2f{B.y, B.y});
-    const lv_v2f pz = __builtin_elementwise_fma(qz, lv_v2f{A.z, A.z}, lv_v2f{B.z, B.z});
-    const float tnp = fmaxf(fmaxf(px.x, py.x), fmaxf(pz.x, tMin));
-    const float tfp = fminf(fminf(px.y, py.y), fminf(pz.y, tMax));
-    tNear = tnp;
-    return tnp <= __builtin_fmaf(tfp, 1.00001f, 4e-7f);
-#endif
     const float tx0 = __builtin_fmaf(float((nearX >> (8 * k)) & 0xFFu), A.x, B.x);
     const float ty0 = __builtin_fmaf(float((nearY >> (8 * k)) & 0xFFu), A.y, B.y);
     const float tz0 = __builtin_fmaf(float((nearZ >> (8 * k)) & 0xFFu), A.z, B.z);
@@ -308,10 +294,12 @@ __device__ __forceinline__ unsigned lv_node_step(const LvSceneDev& S, unsigned n
     const uint32_t nearY = sy ? qxy : qny, farY = sy ? qny : qxy;
     const uint32_t nearZ = sz ? qxz : qnz, farZ = sz ? qnz : qxz;
     float k0, k1, k2, k3;
-    const bool h0 = lv_slab_q(nearX, nearY, nearZ, farX, farY, farZ, 0, A, B, tMin, tMax, k0) && c0 != LV_INVALID;
-    const bool h1 = lv_slab_q(nearX, nearY, nearZ, farX, farY, farZ, 1, A, B, tMin, tMax, k1) && c1 != LV_INVALID;
-    const bool h2 = lv_slab_q(nearX, nearY, nearZ, farX, farY, farZ, 2, A, B, tMin, tMax, k2) && c2 != LV_INVALID;
-    const bool h3 = lv_slab_q(nearX, nearY, nearZ, farX, farY, farZ, 3, A, B, tMin, tMax, k3) && c3 != LV_INVALID;
+    // empty slots carry an inverted box (lv_write_wide_node) and fail the slab test by themselves; should one slip through,
+    // its reference is LV_INVALID and it is neither descended nor pushed
+    const bool h0 = lv_slab_q(nearX, nearY, nearZ, farX, farY, farZ, 0, A, B, tMin, tMax, k0);
+    const bool h1 = lv_slab_q(nearX, nearY, nearZ, farX, farY, farZ, 1, A, B, tMin, tMax, k1);
+    const bool h2 = lv_slab_q(nearX, nearY, nearZ, farX, farY, farZ, 2, A, B, tMin, tMax, k2);
+    const bool h3 = lv_slab_q(nearX, nearY, nearZ, farX, farY, farZ, 3, A, B, tMin, tMax, k3);
     const float INF = __builtin_inff();
     k0 = h0 ? k0 : INF; k1 = h1 ? k1 : INF; k2 = h2 ? k2 : INF; k3 = h3 ? k3 : INF;
     c0 = h0 ? c0 : LV_INVALID; c1 = h1 ? c1 : LV_INVALID; c2 = h2 ? c2 : LV_INVALID; c3 = h3 ? c3 : LV_INVALID;

@@ -3,7 +3,7 @@
 Every pixel depends only on the read-only scene and its own RNG seed tea(x + y * W, ...) with GLOBAL pixel
 coordinates (TubeRayTracing.glsl:215-217, VulkanRayTracedAmbientOcclusion.glsl:188,289-291), so tiles are
 independent units: each rank holds a full scene replica + LBVH, renders its tiles (dealt round-robin along a
-Morton order for load balance) with one `lv_render_tiles_device` call, and ONE gather of RGBA8 tiles over
+Morton order at first, then re-dealt by measured cost: ShardedFrame.rebalance) with one `lv_render_tiles_device` call, and ONE gather of RGBA8 tiles over
 RCCL/xGMI assembles the frame on rank 0.  There is no other data-path collective.
 
 torch is plumbing here: device buffers, the current HIP stream and torch.distributed (backend "nccl" = RCCL).
@@ -41,6 +41,23 @@ def tiles_per_rank(num_tiles, world_size):
     return -(-num_tiles // world_size)
 
 
+def assign_tiles_by_cost(costs, world_size):
+    """Cost-weighted deal (longest processing time first): tiles in order of falling cost, each to the rank with the least
+    cost so far (ties: fewer tiles, then lower rank).  Deterministic, so every rank computes the same answer from the same cost
+    vector.  Returns a list of index arrays into the tile list, each in ascending (= Morton) order."""
+    costs = np.asarray(costs, dtype=np.float64)
+    order = np.lexsort((np.arange(len(costs)), -costs))
+    load = np.zeros(world_size, dtype=np.float64)
+    count = np.zeros(world_size, dtype=np.int64)
+    owner = np.zeros(len(costs), dtype=np.int64)
+    for t in order:
+        r = int(np.lexsort((np.arange(world_size), count, load))[0])
+        owner[t] = r
+        load[r] += costs[t]
+        count[r] += 1
+    return [np.flatnonzero(owner == r) for r in range(world_size)]
+
+
 def detile(tile_pixels, tiles_xy, width, height, tile):
     """tile_pixels: [n, tile, tile, 4] uint8 (numpy) -> frame [height, width, 4]."""
     frame = np.zeros((height, width, 4), dtype=np.uint8)
@@ -53,20 +70,56 @@ def detile(tile_pixels, tiles_xy, width, height, tile):
 
 
 class ShardedFrame:
-    """Per-rank state of a tile-sharded frame: tile list, device output buffer, gather buffers."""
+    """Per-rank state of a tile-sharded frame: tile list, device output buffer, gather buffers.
+
+    The deal starts as round robin along the Morton order; `rebalance()` re-deals the tiles by measured cost (the RTAO hit
+    pixels per tile of the previous frame): the heavy tiles sit in the middle of the picture, and a frame is as slow as its
+    slowest rank."""
 
     def __init__(self, width, height, tile, rank, world_size, device):
-        import torch
         self.width, self.height, self.tile = int(width), int(height), int(tile)
         self.rank, self.world = int(rank), int(world_size)
         self.all_tiles = make_tiles(width, height, tile)
-        self.local_tiles = assign_tiles(self.all_tiles, rank, world_size)
-        self.slots = tiles_per_rank(len(self.all_tiles), world_size)  # equal-sized gather pieces
         self.device = device
-        self.out = torch.zeros((self.slots, tile, tile, 4), dtype=torch.uint8, device=device)
+        self._set_assignment([np.arange(r, len(self.all_tiles), self.world) for r in range(self.world)])
+
+    def _set_assignment(self, index_lists):
+        import torch
+        t = self.tile
+        self.assignment = [np.asarray(ix, dtype=np.int64) for ix in index_lists]
+        assert sorted(np.concatenate(self.assignment).tolist()) == list(range(len(self.all_tiles)))
+        self.local_tiles = np.ascontiguousarray(self.all_tiles[self.assignment[self.rank]])
+        self.slots = max(len(ix) for ix in self.assignment)  # equal-sized gather pieces (padded for ranks with fewer tiles)
+        self.out = torch.zeros((self.slots, t, t, 4), dtype=torch.uint8, device=self.device)
         self.gathered = None
-        if rank == 0 and world_size > 1:
-            self.gathered = [torch.zeros_like(self.out) for _ in range(world_size)]
+        if self.rank == 0 and self.world > 1:
+            self.gathered = [torch.zeros_like(self.out) for _ in range(self.world)]
+        # position of tile (gy, gx) inside the rank-major concatenation of the gathered pieces
+        nx = -(-self.width // t)
+        perm = np.zeros(len(self.all_tiles), dtype=np.int64)
+        for r, ix in enumerate(self.assignment):
+            for i, ti in enumerate(ix):
+                x0, y0 = self.all_tiles[ti]
+                perm[(int(y0) // t) * nx + int(x0) // t] = r * self.slots + i
+        self._perm = torch.from_numpy(perm).to(self.device)
+
+    def rebalance(self, local_costs, base_cost=1.0):
+        """Re-deal the tiles by cost.  local_costs[i] = measured cost of this rank's i-th tile (e.g. capi.Context.ao_tile_costs());
+        the per-tile vector is completed across ranks with ONE all-reduce (control plane, outside any timed region), then
+        every rank computes the same longest-processing-time-first assignment.  base_cost: fixed cost of a tile that traces
+        nothing but its primary rays, in the same unit."""
+        import torch
+        costs = np.zeros(len(self.all_tiles), dtype=np.float64)
+        lc = np.asarray(local_costs, dtype=np.float64)
+        assert len(lc) == len(self.assignment[self.rank])
+        costs[self.assignment[self.rank]] = lc
+        if self.world > 1:
+            import torch.distributed as dist
+            t = torch.from_numpy(costs).to(self.device)
+            dist.all_reduce(t)
+            costs = t.cpu().numpy()
+        self._set_assignment(assign_tiles_by_cost(costs + base_cost, self.world))
+        return costs
 
     def render_local(self, render_tiles_fn):
         """render_tiles_fn(out_tensor, tiles_xy[n,2], tile_w, tile_h) fills out_tensor[:n]."""
@@ -87,13 +140,6 @@ class ShardedFrame:
         import torch
         t = self.tile
         nx, ny = -(-self.width // t), -(-self.height // t)
-        if not hasattr(self, "_perm"):
-            # position of tile (gy, gx) inside the rank-major concatenation of the gathered pieces
-            perm = np.zeros(nx * ny, dtype=np.int64)
-            for r in range(self.world):
-                for i, (x0, y0) in enumerate(assign_tiles(self.all_tiles, r, self.world)):
-                    perm[(int(y0) // t) * nx + int(x0) // t] = r * self.slots + i
-            self._perm = torch.from_numpy(perm).to(self.device)
         pieces = self.out if self.world == 1 else torch.cat(self.gathered, dim=0)
         grid = pieces.index_select(0, self._perm).view(ny, nx, t, t, 4)
         frame = grid.permute(0, 2, 1, 3, 4).reshape(ny * t, nx * t, 4)
@@ -106,7 +152,7 @@ class ShardedFrame:
         pieces = [self.out] if self.world == 1 else self.gathered
         frame = np.zeros((self.height, self.width, 4), dtype=np.uint8)
         for r, piece in enumerate(pieces):
-            tiles = assign_tiles(self.all_tiles, r, self.world)
+            tiles = self.all_tiles[self.assignment[r]]
             px = piece[:len(tiles)].cpu().numpy()
             for i, (x0, y0) in enumerate(tiles):
                 x0, y0 = int(x0), int(y0)

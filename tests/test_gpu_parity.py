@@ -99,6 +99,9 @@ def test_lbvh_structure(hip_lib):
                 qmax = (nodes[node, 9:12] >> (8 * k)) & 0xFF
                 assert np.all(origin[node] + qmin * scale[node] <= mn + 1e-7)
                 assert np.all(origin[node] + qmax * scale[node] >= mx - 1e-7)
+            elif ref == INVALID:   # empty slot: inverted box, rejected by the slab test itself
+                assert np.all(((nodes[node, 6:9] >> (8 * k)) & 0xFF) == 255)
+                assert np.all(((nodes[node, 9:12] >> (8 * k)) & 0xFF) == 0)
 
 
 # ---------------------------------------------------------------- golden frames

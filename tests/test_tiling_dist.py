@@ -44,24 +44,41 @@ def _worker(rank, world, port, width, height, tile, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         sf = tiling.ShardedFrame(width, height, tile, rank, world, torch.device("cpu"))
+        yy, xx = np.meshgrid(np.arange(height), np.arange(width), indexing="ij")
+        want = _pattern(xx, yy)
 
         def fake_render(out, tiles_xy, tw, th):
             for i, (x0, y0) in enumerate(tiles_xy):
-                yy, xx = np.meshgrid(np.arange(th) + int(y0), np.arange(tw) + int(x0), indexing="ij")
-                out[i] = torch.from_numpy(_pattern(xx, yy))
-        sf.render_local(fake_render)
-        dist.barrier()
-        sf.gather()
-        frame = sf.assemble()
+                ty, tx = np.meshgrid(np.arange(th) + int(y0), np.arange(tw) + int(x0), indexing="ij")
+                out[i] = torch.from_numpy(_pattern(tx, ty))
+
+        def frame_ok():
+            sf.render_local(fake_render)
+            dist.barrier()
+            sf.gather()
+            a, b = sf.assemble(), sf.assemble_device()   # bench.py uses assemble_device()
+            if rank != 0:
+                return a is None and b is None
+            return bool(np.array_equal(a, want)) and bool(np.array_equal(b.numpy(), want))
+        ok = frame_ok()                                   # round robin along the Morton order (ragged last slot)
+        # re-deal by cost: a heavy blob in the middle of the picture, every rank reports the cost of its OWN tiles only
+        cx, cy = width / 2.0, height / 2.0
+        local = [1000.0 * np.exp(-(((x0 + tile / 2 - cx) / (0.2 * width)) ** 2 + ((y0 + tile / 2 - cy) / (0.2 * height)) ** 2))
+                 for x0, y0 in sf.local_tiles.astype(np.float64)]
+        costs = sf.rebalance(local, base_cost=1.0)
+        loads = [costs[ix].sum() + len(ix) for ix in sf.assignment]
+        balanced = max(loads) <= sum(loads) / world + costs.max() + 1.0     # the bound longest-processing-time-first guarantees
+        ok = ok and frame_ok() and balanced               # gather pieces are padded to the largest rank's tile count
         if rank == 0:
-            yy, xx = np.meshgrid(np.arange(height), np.arange(width), indexing="ij")
-            q.put(bool(np.array_equal(frame, _pattern(xx, yy))))
+            q.put(bool(ok))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("size", [(200, 120, 32), (96, 64, 64)])
-def test_gather_assembles_frame_world2(size):
+@pytest.mark.parametrize("world,size", [(2, (200, 120, 32)), (2, (96, 64, 64)), (4, (200, 120, 32)), (4, (130, 70, 64))])
+def test_gather_assembles_frame(world, size):
+    """assemble() and assemble_device() (the path bench.py uses) for world 2 and 4 under gloo, round robin and re-dealt by
+    cost, including tile counts that do not divide by the world size and ranks that own fewer tiles than others."""
     import torch.multiprocessing as mp
     width, height, tile = size
     s = socket.socket()
@@ -70,14 +87,46 @@ def test_gather_assembles_frame_world2(size):
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, width, height, tile, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, width, height, tile, q)) for r in range(world)]
     for p in procs:
         p.start()
-    ok = q.get(timeout=120)
+    ok = q.get(timeout=180)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     assert ok
+
+
+def test_cost_weighted_deal_balances_a_peaked_cost_map():
+    rng = np.random.default_rng(3)
+    costs = rng.exponential(1.0, 510) ** 3 + 0.05      # a few tiles carry most of the work, like the centre of config 3
+    for world in (2, 4, 8):
+        parts = tiling.assign_tiles_by_cost(costs, world)
+        assert sorted(np.concatenate(parts).tolist()) == list(range(510))
+        loads = np.array([costs[p].sum() for p in parts])
+        rr = np.array([costs[r::world].sum() for r in range(world)])
+        assert loads.max() <= max(rr.max(), costs.max()) + 1e-9
+        assert loads.max() <= 1.02 * max(loads.mean(), costs.max())
+        assert all(np.all(np.diff(p) > 0) for p in parts)                      # each rank's list stays in Morton order
+        assert [p.tolist() for p in tiling.assign_tiles_by_cost(costs, world)] == [p.tolist() for p in parts]   # deterministic
+
+
+def test_bench_dry_run_collective_sequence_world2():
+    """`bench.py --gpus 2 --dry-run` under torch.distributed.run: the exact collective sequence of a multi-GPU run (counter
+    all-reduce, cost all-reduce + re-deal, K x gather, max-over-ranks all-reduce, barriers) on gloo / CPU tensors."""
+    import json
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
+                        "--warmup", "1", "--dry-run"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["n_gpus"] == 2 and j["steps"] == 3 and j["scaling"] == "strong" and j["cpu_baseline"] is None
 
 
 def test_detile_helper():

@@ -54,7 +54,7 @@ def build(specs):
 
 
 def run(args):
-    workload, steps, names = "c3", "30", []
+    workload, steps, names = "c3c", "30", []
     it = iter(args)
     for a in it:
         if a == "--workload":
