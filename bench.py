@@ -321,7 +321,7 @@ def main():
         if wl.get("mesh"):   # LineData::getLinePassTubeTriangleMeshRenderData -> the RTAO pass' geometry
             mesh = flow.tube_triangle_render_data(LINE_WIDTH, 6)
 
-    def make_context(w):
+    def make_context(w, wait_for_consumer=True):
         if dry:
             return DryRunContext(), None
         ctx = capi.Context(local_rank)
@@ -332,7 +332,7 @@ def main():
         if w.get("mesh"):
             ctx.set_tube_triangle_mesh(*mesh)
         ctx.set_options(w["settings"])
-        fn = tiling.hip_render_tiles_fn(ctx, w["mode"])   # also moves the context onto torch's stream
+        fn = tiling.hip_render_tiles_fn(ctx, w["mode"], wait_for_consumer=wait_for_consumer)   # a torch stream per context
         ctx.build_accel()
         return ctx, fn
 
@@ -345,20 +345,31 @@ def main():
             out[i, :, :, 2] = rank
             out[i, :, :, 3] = 255
 
+    # frames in flight: with N > 1 every rank owns 1/N of the tiles and the latency-bound tile kernels of a frame no longer
+    # hide behind its AO kernel -- two scene replicas on two streams render alternate frames (tiling.FramePipeline;
+    # measured on one GPU with the tile lists of 8 ranks, slowest rank: 1.18 ms per frame with F = 1, 0.86 with 2, 0.73 with 4,
+    # profiles/shard_probe_*.json).  One GPU: the AO kernel fills the chip (5.08 vs 5.18 ms), F = 1.
+    frames_in_flight = 1 if world == 1 else min(4, world)
+
     def measure(w, wkey):
         """Instrumented frame (counters), warm-up, K timed frames; returns everything rank 0 reports for this workload."""
-        ctx, render_fn = make_context(w)
+        ctx, render_fn = make_context(w, wait_for_consumer=(frames_in_flight == 1))
         if dry:
             render_fn = dry_render
         build_first_ms = ctx.stats().ms_accel_build   # includes the one-time load of the library's code object (~5 ms)
         if not dry:
             ctx.build_accel()                         # what a line-width change / new data costs from then on
         build_ms = ctx.stats().ms_accel_build
+        slots = [(sf, render_fn)]
+        extra = []
+        for _ in range(frames_in_flight - 1):
+            c2, f2 = make_context(w, wait_for_consumer=False)
+            extra.append(c2)
+            slots.append((tiling.ShardedFrame(W, H, TILE, rank, world, device), dry_render if dry else f2))
+        pipe = tiling.FramePipeline(slots)
 
         def step():
-            sf.render_local(render_fn)
-            sf.gather()
-            return sf.assemble_device()
+            return pipe.submit()
 
         # ---- untimed instrumented frame: rays traced + algorithmic traffic of this rank's tiles
         ctx.set_option("collect_stats", True)
@@ -392,7 +403,9 @@ def main():
             else:
                 local_cost = None
             if local_cost is not None:
-                sf.rebalance(local_cost, base_cost=4.0 * TILE * TILE)
+                full = sf.rebalance(local_cost, base_cost=4.0 * TILE * TILE)
+                for sf2, _ in slots[1:]:
+                    sf2.redeal(full, base_cost=4.0 * TILE * TILE)
         for _ in range(args.warmup):
             step()
         sync_all()
@@ -422,6 +435,7 @@ def main():
                 ks = _stats(ctx.kernel_times(k))
                 if ks:
                     kernels[name] = ks
+        del extra
         return dict(ctx=ctx, frame=frame, elapsed=elapsed, rays_per_frame=rays_per_frame, counters=counters, local=local,
                     kernel_bytes=kernel_bytes, frame_bytes=frame_bytes, kernels=kernels, frame_ms=_stats(frame_ms),
                     build_ms=build_ms, build_first_ms=build_first_ms, st=st, wkey=wkey)
@@ -440,7 +454,7 @@ def main():
             "metric": "Mrays/s", "value": round(head["rays_per_frame"] * args.steps / head["elapsed"] / 1e6, 2), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(head["elapsed"] / args.steps * 1e3, 4), "fps": round(args.steps / head["elapsed"], 3),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "frames_in_flight": frames_in_flight,
             "data": "synthetic" if not dry else "dry-run (no GPU, stand-in renderer)",
             "config": {"workload": wl["name"], "resolution": [W, H], "segments": int(len(seg)) if seg is not None else 0,
                        "rays_per_frame": int(head["rays_per_frame"]), "ao_hit_pixels": int(head["counters"][4].item()),

@@ -176,6 +176,7 @@ class Context:
         if not self.h:
             raise LineVisError(err.value, "lv_create(%d) failed: no usable HIP device (no CPU fallback)" % device)
         self.width = self.height = 0
+        self.device = int(device)
 
     def close(self):
         if getattr(self, "h", None):

@@ -344,6 +344,27 @@ def test_tile_list_equals_full_frame(hip_lib):
         assert np.array_equal(frame, full)
 
 
+def test_tile_adapter_orders_the_consumer_after_the_kernels(hip_lib):
+    """tiling.hip_render_tiles_fn: what the caller queues on ITS stream right after the call (the gather, the de-tiling) sees
+    the finished tiles without any host synchronisation -- also when the caller runs on torch's default stream (handle 0)."""
+    import torch
+    c = small_case(width=192, height=128, seed=3, **RTAO, ambient_occlusion_iterations=1, ambient_occlusion_samples_per_frame=16)
+    ctx = c.hip_context()
+    full = ctx.render(11)
+    tiles = tiling.make_tiles(192, 128, 64)
+    fn = tiling.hip_render_tiles_fn(ctx, 11)
+    out = torch.zeros((len(tiles), 64, 64, 4), dtype=torch.uint8, device="cuda")
+    for side in (None, torch.cuda.Stream()):
+        for _ in range(10):
+            with torch.cuda.stream(side) if side is not None else torch.cuda.stream(torch.cuda.default_stream()):
+                out.zero_()
+                fn(out, tiles, 64, 64)
+                snap = out.clone()          # queued behind the render by the adapter's stream waits
+            torch.cuda.synchronize()
+            assert np.array_equal(tiling.detile(snap.cpu().numpy(), tiles, 192, 128, 64), full)
+    ctx.set_stream(None)
+
+
 def test_jittered_colour_rays_sample_the_ao_image_bilinearly(hip_lib):
     """getAoFactor (AmbientOcclusion.glsl:84-99) literally for jittered primaries: project the hit, sample the AO image
     bilinearly.  Tiles then need a 1-pixel AO halo; the rings of adjacent tiles overlap, and with several AO iterations the

@@ -4,6 +4,7 @@
 # (TA_* / TD_* groups are not collected: those passes hang on this pool until the timeout.)
 # Result: gpurun_out/pmc_<tag>/<workload>.json = {kernel: {counter: mean per launch of the non-instrumented kernel}}.
 TAG=$1; shift
+LITE=${LV_PMC_LITE:-0}   # 1: only the groups the roofline of bench.py needs (5 passes instead of 12)
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/pmc_$TAG
 mkdir -p $OUT
@@ -22,6 +23,15 @@ PASSES=(
  "FETCH_SIZE"
  "WRITE_SIZE"
 )
+if [ "$LITE" = "1" ]; then
+PASSES=(
+ "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY"
+ "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TOTAL_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_GATE_EN1_sum GRBM_GUI_ACTIVE"
+ "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum"
+ "FETCH_SIZE"
+ "WRITE_SIZE"
+)
+fi
 for W in "$@"; do
   i=0
   for C in "${PASSES[@]}"; do

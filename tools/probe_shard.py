@@ -1,35 +1,74 @@
-"""Dev tool: per-rank compute time of the config-3 frame when sharded over WORLD ranks (run on one GPU: rank's tile list only)."""
-import os, sys, time
+"""Dev tool: per-rank compute time of the config-3 frame when sharded over WORLD ranks, measured on ONE GPU by rendering only
+the tile list rank r of WORLD would own (no RCCL gather: that part needs the real node).  Compares the round-robin deal with the
+cost-weighted deal of tiling.assign_tiles_by_cost (costs = RTAO hit pixels per tile of a full frame).
+Usage: python tools/probe_shard.py [c3c|c3t] -> gpurun_out/shard_probe_<workload>.json"""
+import json, os, sys, time
 import numpy as np, torch
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R)
 import bench
 from linevis_amd import capi, host_api, scenes, camera, tiling, transfer_function as tfm
+wl = sys.argv[1] if len(sys.argv) > 1 else "c3c"
 W, H = 1920, 1080
 tr = scenes.normalize(scenes.tornado())
 flow = host_api.LineDataFlow().set_trajectories(tr.positions, tr.attributes, tr.line_offsets)
 pts, seg, _ = flow.tube_aabb_render_data(0.002)
 view, proj, fovy, near, far = camera.default_camera(W, H)
-ctx = capi.Context(0)
-ctx.set_lines(pts, seg); ctx.set_transfer_function(tfm.standard(), *flow.attribute_range())
-ctx.set_camera(view, proj, fovy, near, far, W, H); ctx.set_option("line_width", 0.002)
-ctx.set_options(bench.SETTINGS)
-ctx.build_accel()
+mesh = flow.tube_triangle_render_data(0.002, 6) if bench.WORKLOADS[wl].get("mesh") else None
+
+
+def make():
+    c = capi.Context(0)
+    c.set_lines(pts, seg); c.set_transfer_function(tfm.standard(), *flow.attribute_range())
+    c.set_camera(view, proj, fovy, near, far, W, H); c.set_option("line_width", 0.002)
+    if mesh is not None:
+        c.set_tube_triangle_mesh(*mesh)
+    c.set_options(bench.WORKLOADS[wl]["settings"])
+    c.build_accel()
+    return c
+
+
+ctx = make()
+DEPTHS = [int(x) for x in os.environ.get("LV_PROBE_DEPTHS", "1,2").split(",")]
+extra = [make() for _ in range(max(DEPTHS) - 1)]   # further scene replicas for frames in flight (tiling.FramePipeline)
+fns = [tiling.hip_render_tiles_fn(c, 11, wait_for_consumer=False) for c in [ctx] + extra]
 all_tiles = tiling.make_tiles(W, H, 64)
-for world in (1, 2, 4, 8):
-    res = []
-    for rank in range(world):
-        tiles = tiling.assign_tiles(all_tiles, rank, world)
-        out = torch.zeros((len(tiles), 64, 64, 4), dtype=torch.uint8, device="cuda:0")
-        for _ in range(3):
-            ctx.render_tiles_device(out.data_ptr(), tiles, 64, 64, mode=11)
-        torch.cuda.synchronize(); ctx.reset_timers()
-        t0 = time.perf_counter()
-        for _ in range(10):
-            ctx.render_tiles_device(out.data_ptr(), tiles, 64, 64, mode=11)
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / 10 * 1e3
-        st = ctx.stats()
-        res.append((dt, [round(x, 3) for x in st.ms_kernel_avg[:4]]))
-    worst = max(res)
-    print("world", world, "max rank ms %.3f" % worst[0], "kernels", worst[1], "all:", [round(r[0], 3) for r in res])
+out = torch.zeros((len(all_tiles), 64, 64, 4), dtype=torch.uint8, device="cuda:0")
+fns[0](out, all_tiles, 64, 64)
+torch.cuda.synchronize()
+costs = ctx.ao_tile_costs().astype(np.float64) * 64.0 + 4.0 * 64 * 64
+
+
+def time_tiles(tiles, depth, reps=40):
+    outs = [torch.zeros((len(tiles), 64, 64, 4), dtype=torch.uint8, device="cuda:0") for _ in range(depth)]
+    for k in range(4):
+        fns[k % depth](outs[k % depth], tiles, 64, 64)
+    torch.cuda.synchronize(); ctx.reset_timers()
+    t0 = time.perf_counter()
+    for k in range(reps):
+        fns[k % depth](outs[k % depth], tiles, 64, 64)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps * 1e3
+    st = ctx.stats()
+    return dt, [round(float(x), 3) for x in st.ms_kernel_avg[:3]]
+
+
+report = {"workload": wl, "what": "per-rank frame time (ms) on ONE MI355X rendering only the tiles that rank would own; the RCCL gather "
+          "is not included (unmeasured on hardware: no multi-GPU node)", "worlds": {}}
+t1, k1 = time_tiles(all_tiles, 1)
+report["one_gpu_ms"] = round(t1, 4)
+report["one_gpu_two_frames_in_flight_ms"] = round(time_tiles(all_tiles, 2)[0], 4)
+for world in [int(x) for x in os.environ.get("LV_PROBE_WORLDS", "2,4,8").split(",")]:
+    row = {}
+    for name, parts in (("round_robin", [np.arange(r, len(all_tiles), world) for r in range(world)]),
+                        ("cost_weighted", tiling.assign_tiles_by_cost(costs, world))):
+        for depth in DEPTHS:
+            res = [time_tiles(np.ascontiguousarray(all_tiles[ix]), depth) for ix in parts]
+            worst = max(r[0] for r in res)
+            key = "%s_frames_in_flight_%d" % (name, depth)
+            row[key] = {"rank_ms": [round(r[0], 4) for r in res], "slowest_ms": round(worst, 4), "tiles": [int(len(ix)) for ix in parts],
+                        "kernels_of_slowest": max(res)[1], "efficiency_vs_one_gpu": round(t1 / (world * worst), 4)}
+            print(world, key, row[key], flush=True)
+    report["worlds"][str(world)] = row
+os.makedirs(os.path.join(R, "gpurun_out"), exist_ok=True)
+json.dump(report, open(os.path.join(R, "gpurun_out", "shard_probe_%s.json" % wl), "w"), indent=1)
