@@ -164,7 +164,7 @@ void lv_destroy(lv_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (LvDeviceBuffer* b : {&ctx->points, &ctx->segIdx, &ctx->nodes, &ctx->segs, &ctx->leafSeg, &ctx->segToLeaf, &ctx->tf,
-                              &ctx->depthMinMax, &ctx->ao, &ctx->aoAlt, &ctx->tilesHaloDev, &ctx->aoGbuf, &ctx->aoList, &ctx->aoSamples, &ctx->counters,
+                              &ctx->depthMinMax, &ctx->ao, &ctx->aoAlt, &ctx->featNormal, &ctx->featNormalAlt, &ctx->featPosition, &ctx->featPositionAlt, &ctx->eawPing, &ctx->eawPong, &ctx->tilesHaloDev, &ctx->aoGbuf, &ctx->aoList, &ctx->aoSamples, &ctx->counters,
                               &ctx->ppllNodes, &ctx->ppllStart, &ctx->ppllCount, &ctx->ppllScratch, &ctx->tilesDev, &ctx->outDev,
                               &ctx->scratchRays, &ctx->stackOverflow, &ctx->triIdx, &ctx->triVerts, &ctx->triPoints,
                               &ctx->triNodes, &ctx->tris, &ctx->flowVectors, &ctx->flowScalars, &ctx->flowMisc,
@@ -396,7 +396,31 @@ int lv_set_option(lv_ctx* ctx, const char* key, const char* value) {
     } else if (k == "use_jittered_primary_rays") {
         o.aoJitterPrimary = parseBool(value);
     } else if (k == "ambient_occlusion_denoiser") {
-        if (strcmp(value, "None") != 0) return lv_fail(ctx, LV_E_INVALID, "denoisers are out of scope (None only)");
+        // DENOISER_NAMES, Denoiser.hpp:61-65,96-100 (VulkanRayTracedAmbientOcclusion.cpp:683-696)
+        if (strcmp(value, "None") == 0) o.eawEnabled = false;
+        else if (strcmp(value, "Edge-Avoiding \xC3\x80-Trous Wavelet Transform") == 0 || strcmp(value, "EAW") == 0) o.eawEnabled = true;
+        else return lv_fail(ctx, LV_E_INVALID, "ambient_occlusion_denoiser '%s' is not provided (None | Edge-Avoiding \xC3\x80-Trous "
+                                               "Wavelet Transform)", value);
+    } else if (k == "eaw_denoiser_iterations") {                 // EAWDenoiser.cpp:402-430
+        if (!parseUint(value, u) || u > 5) return bad();
+        o.eawIterations = u;
+    } else if (k == "eaw_denoiser_color_weights") {
+        o.eawColorWeights = parseBool(value);
+    } else if (k == "eaw_denoiser_position_weights") {
+        o.eawPositionWeights = parseBool(value);
+    } else if (k == "eaw_denoiser_normal_weights") {
+        o.eawNormalWeights = parseBool(value);
+    } else if (k == "eaw_denoiser_phi_color") {
+        if (!parseFloat(value, f) || !(f > 0.0f)) return bad();
+        o.eawPhiColor = f;
+    } else if (k == "eaw_denoiser_phi_position") {
+        if (!parseFloat(value, f) || !(f > 0.0f)) return bad();
+        o.eawPhiPosition = f;
+    } else if (k == "eaw_denoiser_phi_normal") {
+        if (!parseFloat(value, f) || !(f > 0.0f)) return bad();
+        o.eawPhiNormal = f;
+    } else if (k == "eaw_denoiser_use_shared_memory") {
+        o.eawUseSharedMemory = parseBool(value);
     } else if (k == "num_samples_per_frame") {
         if (!parseUint(value, u) || u == 0) return bad();
         o.numSamplesPerFrame = u;
@@ -668,7 +692,9 @@ int lv_get_ao(lv_ctx* ctx, float* out) {
     if (ctx->aoW != ctx->width || ctx->aoH != ctx->height)
         return lv_fail(ctx, LV_E_STATE, "the AO texture was rendered at %ux%u, the viewport is now %ux%u (render again)",
                        ctx->aoW, ctx->aoH, ctx->width, ctx->height);
-    LV_HIP(ctx, hipMemcpyAsync(out, ctx->ao.ptr, size_t(ctx->aoW) * ctx->aoH * 4, hipMemcpyDeviceToHost, ctx->stream));
+    // the image the colour pass samples: the accumulated AO factors, or their denoised version (ambient_occlusion_denoiser)
+    const void* src = ctx->aoResult ? (const void*)ctx->aoResult : ctx->ao.ptr;
+    LV_HIP(ctx, hipMemcpyAsync(out, src, size_t(ctx->aoW) * ctx->aoH * 4, hipMemcpyDeviceToHost, ctx->stream));
     LV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return LV_OK;
 }

@@ -49,6 +49,12 @@ struct LvOptions {
     bool aoTriangleTubes = false;             // rtao_geometry: false = capsules (build default), true = the reference's triangle tubes
     bool useMlat = false;                     // VulkanRayTracer.hpp:133
     uint32_t mlatNumNodes = 8;                // :134
+    // EAW denoiser of the RTAO pass (ambient_occlusion_denoiser; AO defaults of createDenoiserObject, Denoiser.cpp:54-62)
+    bool eawEnabled = false;
+    uint32_t eawIterations = 3;               // eaw_denoiser_iterations (GUI range 0..5, EAWDenoiser.cpp:437)
+    bool eawColorWeights = true, eawPositionWeights = true, eawNormalWeights = true;
+    float eawPhiColor = 0.49f, eawPhiPosition = 0.3f, eawPhiNormal = 0.1f;
+    bool eawUseSharedMemory = true;           // true: EAWDenoise.Compute (default), false: EAWDenoise.Fragment
     bool mlatRecordTrace = false;             // with collect_stats: record every pixel's candidate visiting order
     uint32_t mlatTraceCapacity = 1u << 22;    // records (16 B each)
 };
@@ -104,6 +110,10 @@ struct lv_ctx {
     LvDeviceBuffer depthMinMax;               // 2 floats (+2 encoded uints)
     LvDeviceBuffer ao;                        // width*height floats (the latest AO image)
     LvDeviceBuffer aoAlt;                     // second image of the halo mode's ping-pong accumulation (lv_run_ao)
+    LvDeviceBuffer featNormal, featNormalAlt, featPosition, featPositionAlt; // EAW feature maps (float4 per pixel) + ping-pong
+    LvDeviceBuffer eawPing, eawPong;          // a-trous passes
+    const float* aoResult = nullptr;          // what the colour pass samples: ao (raw) or the denoised image
+    uint32_t tilesHalo = 0;                   // halo the uploaded tilesHaloDev list was built for
     LvDeviceBuffer tilesHaloDev;              // tile origins - 1 (AO pass on dilated tiles)
     std::vector<uint32_t> tilesHaloHost;
     bool tilesHaloUploaded = false;

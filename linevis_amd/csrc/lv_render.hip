@@ -103,7 +103,9 @@ __global__ __launch_bounds__(LV_BLOCK) void k_render_rt(const LvUniforms U, cons
 template <bool STATS, int PRIM>
 __global__ __launch_bounds__(LV_BLOCK) void k_ao_primary(const LvUniforms U, const LvSceneDev S, const LvTiles T,
                                                          const float* aoIn, float* ao, float4* __restrict__ gbuf,
-                                                         uint32_t* __restrict__ groupCount, LvDevCounters* dc) {
+                                                         uint32_t* __restrict__ groupCount, LvDevCounters* dc,
+                                                         const float4* featNormalIn, float4* featNormal,
+                                                         const float4* featPositionIn, float4* featPosition) {
     __shared__ unsigned s_stack[LV_STACK_LDS * LV_BLOCK];
     LV_COOP_SHARED(LV_BLOCK / LV_WAVE);
     LV_COOP_MEM(cm);
@@ -178,6 +180,29 @@ __global__ __launch_bounds__(LV_BLOCK) void k_ao_primary(const LvUniforms U, con
             if (U.aoFrameNumber != 0) aoFactor = mixf(aoIn[pix], aoFactor, 1.0f / float(U.aoFrameNumber + 1));
             ao[pix] = aoFactor;
         }
+    }
+    // denoiser feature maps (VulkanRayTracedAmbientOcclusion.glsl:321-399, WRITE_NORMAL_MAP / WRITE_POSITION_MAP with
+    // accumulation): view-space normal {xyz, 0} and view-space position {xyz, 1} of the primary hit; a miss leaves
+    // surfaceNormal = vertexPositionWorld = 0 (glsl:211-212); running means over the iterations
+    if (featNormal && px.inView) {
+        const f3 sn = hasHit ? mk3(g2.x, g2.y, g2.z) : mk3(0.0f, 0.0f, 0.0f);
+        const f3 vp = hasHit ? mk3(g0.x, g0.y, g0.z) : mk3(0.0f, 0.0f, 0.0f);
+        // camNormal = (transpose(inverseViewMatrix) * vec4(surfaceNormal, 0)).xyz, VulkanRayTracedAmbientOcclusion.cpp:569
+        const float* m = U.invView;
+        f3 n = mk3(((m[0] * sn.x + m[1] * sn.y) + m[2] * sn.z) + m[3] * 0.0f, ((m[4] * sn.x + m[5] * sn.y) + m[6] * sn.z) + m[7] * 0.0f,
+                   ((m[8] * sn.x + m[9] * sn.y) + m[10] * sn.z) + m[11] * 0.0f);
+        const f4 pv = mulM4(U.view, vp.x, vp.y, vp.z, 1.0f);
+        f3 q = mk3(pv.x, pv.y, pv.z);
+        if (U.aoFrameNumber != 0) {
+            const float a = 1.0f / float(U.aoFrameNumber + 1);
+            const float4 on = featNormalIn[pix], op = featPositionIn[pix];
+            n = mk3(mixf(on.x, n.x, a), mixf(on.y, n.y, a), mixf(on.z, n.z, a));
+            const float len = len3(n);
+            if (len > 1e-5f) n = mk3(n.x / len, n.y / len, n.z / len);
+            q = mk3(mixf(op.x, q.x, a), mixf(op.y, q.y, a), mixf(op.z, q.z, a));
+        }
+        featNormal[pix] = make_float4(n.x, n.y, n.z, 0.0f);
+        featPosition[pix] = make_float4(q.x, q.y, q.z, 1.0f);
     }
     // active-ray compaction: ballot + prefix popcount, one atomic per wave -- PER 64x64-PIXEL GROUP (all pixels of a wave
     // belong to one group): the G-buffer is segmented by group, slot = group * 4096 + position inside the group's segment,
@@ -564,6 +589,87 @@ __global__ __launch_bounds__(LV_BLOCK) void k_ao_reduce(const LvUniforms U, cons
     ao[pix] = aoFactor;
 }
 
+// One a-trous pass of the EAW denoiser (EAWDenoise.glsl) over the AO image: colorTexture = vec4(ao, ao, ao, 1) -- the three
+// colour channels stay equal and alpha stays 1 through every pass, so one float per pixel carries the image.
+//   COMPUTE = true   EAWDenoise.Compute (:128-292; eaw_denoiser_use_shared_memory = true, the default): B-spline kernel
+//                    {1, 2/3, 1/6}, neighbours outside the image skipped, ONE exp of the summed exponents, colour term x step width
+//   COMPUTE = false  EAWDenoise.Fragment (:16-126): Gaussian kernel, clamp-to-edge sampling, min(exp(.), 1) per enabled feature
+// One thread per pixel of the (dilated) tiles; "inside" refers to the whole viewport, so tiles reproduce the full frame.
+struct LvEawParams {
+    float phiColor, phiPosition, phiNormal;
+    uint32_t useColor, usePosition, useNormal;
+    int stepWidth;
+};
+template <bool COMPUTE>
+__global__ __launch_bounds__(LV_BLOCK) void k_eaw_pass(const LvUniforms U, const LvTiles T, const LvEawParams E,
+                                                       const float* __restrict__ src, float* __restrict__ dst,
+                                                       const float4* __restrict__ featNormal,
+                                                       const float4* __restrict__ featPosition) {
+    const uint32_t perTile = T.tileW * T.tileH;
+    const uint64_t gid = uint64_t(blockIdx.x) * LV_BLOCK + threadIdx.x;
+    if (gid >= uint64_t(T.numTiles) * perTile) return;
+    const uint32_t tile = uint32_t(gid / perTile), rem = uint32_t(gid % perTile);
+    const uint32_t gxu = T.tilesXY[2 * tile] + rem % T.tileW, gyu = T.tilesXY[2 * tile + 1] + rem / T.tileW;
+    if (gxu >= U.width || gyu >= U.height) return;
+    const int gx = int(gxu), gy = int(gyu), W = int(U.width), H = int(U.height);
+    const size_t ci = size_t(gy) * U.width + gx;
+    const float centerColor = src[ci];
+    const float4 cP = E.usePosition ? featPosition[ci] : make_float4(0, 0, 0, 0);
+    const float4 cN = E.useNormal ? featNormal[ci] : make_float4(0, 0, 0, 0);
+    auto dist4 = [](float4 a, float4 b) {
+        const float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z, dw = a.w - b.w;
+        return ((dx * dx + dy * dy) + dz * dz) + dw * dw;
+    };
+    float sum, accumW;
+    if (COMPUTE) {
+        const float kernelValues[3] = {1.0f, 2.0f / 3.0f, 1.0f / 6.0f};
+        accumW = kernelValues[0] * kernelValues[0];
+        sum = centerColor * accumW;
+        for (int y = -2; y <= 2; ++y) {
+            for (int x = -2; x <= 2; ++x) {
+                const int ox = gx + x * E.stepWidth, oy = gy + y * E.stepWidth;
+                const bool inside = ox >= 0 && oy >= 0 && ox < W && oy < H;
+                if (!inside || (x == 0 && y == 0)) continue;
+                const size_t oi = size_t(oy) * U.width + ox;
+                const float kernelValue = kernelValues[x < 0 ? -x : x] * kernelValues[y < 0 ? -y : y];
+                const float offsetColor = src[oi];
+                float e = 0.0f;
+                if (E.useColor) {
+                    const float d = centerColor - offsetColor;
+                    const float distColor = ((d * d + d * d) + d * d) + 0.0f * 0.0f;
+                    e = e - (distColor * float(E.stepWidth)) / E.phiColor;
+                }
+                if (E.usePosition) e = e - dist4(cP, featPosition[oi]) / E.phiPosition;
+                if (E.useNormal) e = e - dist4(cN, featNormal[oi]) / E.phiNormal;
+                const float weight = expf(e);
+                sum += (offsetColor * weight) * kernelValue;
+                accumW += weight * kernelValue;
+            }
+        }
+    } else {
+        sum = 0.0f; accumW = 0.0f;
+        for (int i = 0; i < 25; i++) {
+            const float x = float(i % 5 - 2), y = float(i / 5 - 2);
+            const float kernelValue = expf(-(x * x + y * y) / 2.0f);
+            const int ox = min(max(gx + (i % 5 - 2) * E.stepWidth, 0), W - 1);
+            const int oy = min(max(gy + (i / 5 - 2) * E.stepWidth, 0), H - 1);
+            const size_t oi = size_t(oy) * U.width + ox;
+            const float offsetColor = src[oi];
+            float weight = 1.0f;
+            if (E.useColor) {
+                const float d = centerColor - offsetColor;
+                const float distColor = ((d * d + d * d) + d * d) + 0.0f * 0.0f;
+                weight *= fminf(expf(-distColor / E.phiColor), 1.0f);
+            }
+            if (E.usePosition) weight *= fminf(expf(-dist4(cP, featPosition[oi]) / E.phiPosition), 1.0f);
+            if (E.useNormal) weight *= fminf(expf(-dist4(cN, featNormal[oi]) / E.phiNormal), 1.0f);
+            sum += (offsetColor * weight) * kernelValue;
+            accumW += weight * kernelValue;
+        }
+    }
+    dst[ci] = sum / accumW;
+}
+
 // VulkanAmbientOcclusionBaker.glsl:110-131,231-262: interpolated line point of every parametrisation vertex and the ray
 // origin / frame of each of its tube subdivisions, written in the G-buffer format of k_ao_rays.
 __global__ __launch_bounds__(LV_BLOCK) void k_bake_setup(const lv_line_point* __restrict__ linePoints, uint32_t numLinePoints,
@@ -933,7 +1039,7 @@ LvSceneDev sceneDev(const lv_ctx* ctx) {
     S.segIdx = (const uint32_t*)ctx->segIdx.ptr;
     S.tf = (const float4*)ctx->tf.ptr;
     S.depthMinMax = (const float*)ctx->depthMinMax.ptr;
-    S.ao = (const float*)ctx->ao.ptr;
+    S.ao = ctx->aoResult ? ctx->aoResult : (const float*)ctx->ao.ptr;
     S.stackOverflow = nullptr;
     S.accum = nullptr;
     S.numSegs = ctx->numSegs;
@@ -1084,19 +1190,25 @@ static int lv_run_ao(lv_ctx* ctx, LvUniforms& U, LvSceneDev& S, const LvTiles& T
     LvTiles T = Tcolour;
     uint32_t gridTiles = gridTilesColour;
     uint64_t maxPixels = maxPixelsColour;
-    const bool halo = U.aoProjectLookup != 0u;
+    // ... and the EAW denoiser (ambient_occlusion_denoiser) reads 2 * (2^iterations - 1) pixels around every pixel it filters
+    // (a-trous passes with step widths 1, 2, 4, ...): the same mechanism with a wider halo.
+    const bool eaw = ctx->opt.eawEnabled && ctx->opt.eawIterations > 0u;
+    const uint32_t haloPx = (U.aoProjectLookup ? 1u : 0u) + (eaw ? 2u * ((1u << ctx->opt.eawIterations) - 1u) : 0u);
+    const bool halo = haloPx != 0u;
     if (halo) {
         const uint32_t n = Tcolour.numTiles;
         if ((rc = lv_buf_reserve(ctx, ctx->tilesHaloDev, size_t(n) * 8))) return rc;
-        if (!ctx->tilesHaloUploaded) {
+        if (!ctx->tilesHaloUploaded || ctx->tilesHalo != haloPx) {
+            if (ctx->tilesHaloUploaded) LV_HIP(ctx, hipStreamSynchronize(st)); // the staging copy may still be in flight
             ctx->tilesHaloHost.resize(2 * size_t(n));
-            for (size_t i = 0; i < 2 * size_t(n); i++) ctx->tilesHaloHost[i] = ctx->tilesHost[i] - 1u;
+            for (size_t i = 0; i < 2 * size_t(n); i++) ctx->tilesHaloHost[i] = ctx->tilesHost[i] - haloPx;
             LV_HIP(ctx, hipMemcpyAsync(ctx->tilesHaloDev.ptr, ctx->tilesHaloHost.data(), size_t(n) * 8, hipMemcpyHostToDevice, st));
             ctx->tilesHaloUploaded = true;
+            ctx->tilesHalo = haloPx;
         }
         T.tilesXY = (const uint32_t*)ctx->tilesHaloDev.ptr;
-        T.tileW = Tcolour.tileW + 2u;
-        T.tileH = Tcolour.tileH + 2u;
+        T.tileW = Tcolour.tileW + 2u * haloPx;
+        T.tileH = Tcolour.tileH + 2u * haloPx;
         T.blocksX = ((T.tileW + 63u) / 64u) * 4u;
         T.blocksY = ((T.tileH + 63u) / 64u) * 4u;
         const uint64_t nb = uint64_t(n) * T.blocksX * T.blocksY;
@@ -1104,6 +1216,13 @@ static int lv_run_ao(lv_ctx* ctx, LvUniforms& U, LvSceneDev& S, const LvTiles& T
         gridTiles = uint32_t((nb + 127u) / 128u) * 128u;
         maxPixels = uint64_t(n) * T.tileW * T.tileH;
         if ((rc = lv_buf_reserve(ctx, ctx->aoAlt, size_t(ctx->width) * ctx->height * 4))) return rc;
+    }
+    const size_t numPix = size_t(ctx->width) * ctx->height;
+    if (eaw) {
+        for (LvDeviceBuffer* b : {&ctx->featNormal, &ctx->featNormalAlt, &ctx->featPosition, &ctx->featPositionAlt})
+            if ((rc = lv_buf_reserve(ctx, *b, numPix * 16))) return rc;
+        if ((rc = lv_buf_reserve(ctx, ctx->eawPing, numPix * 4))) return rc;
+        if ((rc = lv_buf_reserve(ctx, ctx->eawPong, numPix * 4))) return rc;
     }
     // G-buffer: one segment of 4096 slots per 64x64-pixel group of the launch (k_ao_primary); samples: compact
     const uint64_t numGroups64 = uint64_t(T.numTiles) * (T.blocksX / 4u) * (T.blocksY / 4u);
@@ -1138,9 +1257,14 @@ static int lv_run_ao(lv_ctx* ctx, LvUniforms& U, LvSceneDev& S, const LvTiles& T
         const float* aoIn = (const float*)ctx->ao.ptr;
         float* ao = halo ? (float*)ctx->aoAlt.ptr : (float*)ctx->ao.ptr;
         float* smp = (float*)ctx->aoSamples.ptr;
+        // feature maps of the denoiser: same ping-pong as the AO image (the EAW halo makes the tiles overlap)
+        const float4* fnIn = eaw ? (const float4*)ctx->featNormal.ptr : nullptr;
+        float4* fnOut = eaw ? (float4*)ctx->featNormalAlt.ptr : nullptr;
+        const float4* fpIn = eaw ? (const float4*)ctx->featPosition.ptr : nullptr;
+        float4* fpOut = eaw ? (float4*)ctx->featPositionAlt.ptr : nullptr;
 #define LV_LAUNCH_AOP(ST, PR)                                                                                 \
     LV_TIMED_LAUNCH(ctx, LV_KERNEL_AO_PRIMARY, (k_ao_primary<ST, PR><<<gridTiles, LV_BLOCK, 0, st>>>(        \
-            U, SA, T, aoIn, ao, (float4*)ctx->aoGbuf.ptr, tileCount, dc)))
+            U, SA, T, aoIn, ao, (float4*)ctx->aoGbuf.ptr, tileCount, dc, fnIn, fnOut, fpIn, fpOut)))
 #define LV_LAUNCH_AO(ST, AH, PR) \
     LV_TIMED_LAUNCH(ctx, LV_KERNEL_AO_RAYS, (k_ao_rays<ST, AH, PR><<<grid, LV_AO_BLOCK, 0, st>>>(U, SA, g, smp, dc, tileBase, numGroups, tileCap)))
 #define LV_LAUNCH_AO2(ST, AH) \
@@ -1156,8 +1280,35 @@ static int lv_run_ao(lv_ctx* ctx, LvUniforms& U, LvSceneDev& S, const LvTiles& T
 #undef LV_LAUNCH_AOP
         k_ao_reduce<false><<<nblocks(maxPixels), LV_BLOCK, 0, st>>>(U, g, smp, aoIn, ao, dc, tileBase, numGroups, tileCap);
         if (halo) std::swap(ctx->ao, ctx->aoAlt);
+        if (eaw) { std::swap(ctx->featNormal, ctx->featNormalAlt); std::swap(ctx->featPosition, ctx->featPositionAlt); }
     }
-    S.ao = (const float*)ctx->ao.ptr;
+    if (iterEnd > iterBegin || !ctx->aoResult) ctx->aoResult = (const float*)ctx->ao.ptr;
+    if (eaw && iterEnd > iterBegin) {
+        // denoiser->denoise() after the RTAO pass (VulkanRayTracedAmbientOcclusion.cpp:633-651): the accumulation keeps running
+        // on the raw image, the colour pass samples the denoised one
+        LvEawParams E;
+        E.phiColor = ctx->opt.eawPhiColor * 1.0f;         // weight scales of the AO mode, Denoiser.cpp:59-61
+        E.phiPosition = ctx->opt.eawPhiPosition * 0.0001f;
+        E.phiNormal = ctx->opt.eawPhiNormal * 1.0f;
+        E.useColor = ctx->opt.eawColorWeights; E.usePosition = ctx->opt.eawPositionWeights; E.useNormal = ctx->opt.eawNormalWeights;
+        E.stepWidth = 1;
+        const uint64_t threads = uint64_t(T.numTiles) * T.tileW * T.tileH;
+        const float* src = (const float*)ctx->ao.ptr;
+        float* bufs[2] = {(float*)ctx->eawPing.ptr, (float*)ctx->eawPong.ptr};
+        for (uint32_t i = 0; i < ctx->opt.eawIterations; i++) {
+            float* dst = bufs[i & 1u];
+            if (ctx->opt.eawUseSharedMemory)
+                k_eaw_pass<true><<<nblocks(threads), LV_BLOCK, 0, st>>>(U, T, E, src, dst, (const float4*)ctx->featNormal.ptr,
+                                                                         (const float4*)ctx->featPosition.ptr);
+            else
+                k_eaw_pass<false><<<nblocks(threads), LV_BLOCK, 0, st>>>(U, T, E, src, dst, (const float4*)ctx->featNormal.ptr,
+                                                                          (const float4*)ctx->featPosition.ptr);
+            src = dst;
+            E.stepWidth *= 2;
+        }
+        ctx->aoResult = src;
+    }
+    S.ao = ctx->aoResult;
     LV_HIP(ctx, hipGetLastError());
     return LV_OK;
 }
@@ -1196,6 +1347,7 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
     if ((rc = lv_buf_reserve(ctx, ctx->depthMinMax, 16))) return rc;
     if ((rc = lv_buf_reserve(ctx, ctx->tilesDev, size_t(numTiles) * 8))) return rc;
     if ((rc = lv_buf_reserve(ctx, ctx->ao, size_t(ctx->width) * ctx->height * 4))) return rc;
+    if (ctx->aoW != ctx->width || ctx->aoH != ctx->height) ctx->aoResult = nullptr; // images of another viewport size
     ctx->aoW = ctx->width;
     ctx->aoH = ctx->height;
     LvDevCounters* dc = (LvDevCounters*)ctx->counters.ptr;
@@ -1235,7 +1387,9 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
         if (triColour) need = std::max(need, lv_overflow_bytes(ctx, gridTiles, LV_STACK_LDS, true));
         if (aoRun) {
             // with the AO halo the AO pass runs on tiles of (tileW + 2) x (tileH + 2) pixels (lv_run_ao)
-            const uint64_t tw = tileW + (U.aoProjectLookup ? 2u : 0u), th = tileH + (U.aoProjectLookup ? 2u : 0u);
+            const uint32_t haloPx = (U.aoProjectLookup ? 1u : 0u) +
+                                    ((ctx->opt.eawEnabled && ctx->opt.eawIterations) ? 2u * ((1u << ctx->opt.eawIterations) - 1u) : 0u);
+            const uint64_t tw = tileW + 2u * haloPx, th = tileH + 2u * haloPx;
             const uint64_t nbAo = uint64_t(numTiles) * (((tw + 63u) / 64u) * 4u) * (((th + 63u) / 64u) * 4u);
             const uint64_t gridAo = ((nbAo + 127u) / 128u) * 128u;
             need = std::max(need, lv_overflow_bytes(ctx, std::max<uint64_t>(lv_ao_grid(ctx, uint64_t(numTiles) * tw * th * U.aoSamplesPerFrame), gridAo),

@@ -34,6 +34,8 @@
 #include <omp.h>
 #endif
 
+LvoAoFeatureSink g_lvoAoFeatures = {nullptr, nullptr};
+
 namespace {
 
 // Deviation switches (lvo_set_deviation_switches): evaluate the REFERENCE's literal definitions where the build owns a
@@ -868,6 +870,7 @@ void lvo_render_ao(const lvo_scene* sc, const lvo_params* Pp, int useBvh, uint32
                 primaryRay(P, F, x, y, xix, xiy, o, d);
                 Hit hit;
                 float aoFactor = 1.0f;
+                V3 featNormal = v3(0, 0, 0), featPosition = v3(0, 0, 0); // surfaceNormal / vertexPositionWorld of a miss, glsl:211-212
                 if (closestHit(*sc, F.radius, capped, useBvh != 0, o, d, 0.0001f, 1000.0f, hit, cnt)) {
                     const lvo_line_point& lp0 = sc->pts[sc->segIdx[2 * hit.seg]];
                     const lvo_line_point& lp1 = sc->pts[sc->segIdx[2 * hit.seg + 1]];
@@ -882,6 +885,7 @@ void lvo_render_ao(const lvo_scene* sc, const lvo_params* Pp, int useBvh, uint32
                     V3 surfaceTangent = normalize((1.0f - ts) * ld3(lp0.lineTangent) + ts * ld3(lp1.lineTangent));
                     V3 surfaceBitangent = cross(surfaceNormal, surfaceTangent);
                     float offsetFactor = length(linePosition - vertexPositionWorld) / F.subdivisionCorrectionFactor;
+                    featNormal = surfaceNormal; featPosition = vertexPositionWorld;
                     aoFactor = 0.0f;
                     for (uint32_t s = 0; s < P.aoSamplesPerFrame; s++) {
                         uint32_t sseed = tea(pix, globalFrameNumber * P.aoSamplesPerFrame + s);
@@ -909,6 +913,7 @@ void lvo_render_ao(const lvo_scene* sc, const lvo_params* Pp, int useBvh, uint32
                 size_t idx = size_t(y) * P.width + x;
                 if (frameNumber != 0) aoFactor = mixf(aoOut[idx], aoFactor, 1.0f / float(frameNumber + 1));
                 aoOut[idx] = aoFactor;
+                writeAoFeatures(P, F, idx, frameNumber, featNormal, featPosition);
             }
             rays += cnt.rays; nodes += cnt.nodes; prims += cnt.prims;
         }
@@ -1619,6 +1624,102 @@ void lvo_compute_fragment_color_batch(const lvo_scene* sc, const lvo_params* Pp,
         for (int k = 0; k < 4; k++) outColor[4 * i + k] = c[k];
         outHitT[i] = hitT;
     }
+}
+
+void lvo_set_ao_feature_outputs(float* normalMap, float* positionMap) {
+    g_lvoAoFeatures.normal = normalMap;
+    g_lvoAoFeatures.position = positionMap;
+}
+
+// EAWDenoise.glsl on the AO image (colorTexture = vec4(ao, ao, ao, 1): the three colour channels stay equal and alpha stays 1
+// through every pass, so one float per pixel carries the image), feature maps as float4 per pixel.
+//   computeVariant != 0  EAWDenoise.Compute (:128-292, the default: eaw_denoiser_use_shared_memory = true): B-spline kernel
+//                        {1, 2/3, 1/6}, neighbours outside the image skipped, ONE exp of the summed exponents, the colour term
+//                        scaled by the step width;
+//   computeVariant == 0  EAWDenoise.Fragment (:16-126): Gaussian kernel exp(-(x^2 + y^2) / 2), clamp-to-edge sampling, one
+//                        min(exp(.), 1) per enabled feature.
+// Passes: step width 1, 2, 4, ... (EAWDenoiser.cpp:316-347,355-395), ping-pong; region = the pixels to compute (inputs must be
+// valid 2 * (2^iterations - 1) pixels around it); "inside" always refers to the whole viewport.
+void lvo_eaw_denoise(uint32_t width, uint32_t height, const float* ao, const float* normalMap, const float* positionMap,
+                     int iterations, float phiColor, float phiPosition, float phiNormal, int useColor, int usePosition,
+                     int useNormal, int computeVariant, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, float* out) {
+    const size_t n = size_t(width) * height;
+    std::vector<float> ping(ao, ao + n), pong(ao, ao + n);
+    const bool wC = useColor != 0, wP = usePosition != 0 && positionMap, wN = useNormal != 0 && normalMap;
+    int stepWidth = 1;
+    for (int it = 0; it < iterations; it++) {
+        const float* src = ping.data();
+        float* dst = pong.data();
+#pragma omp parallel for schedule(dynamic, 8)
+        for (int64_t yy = 0; yy < int64_t(h); yy++) {
+            for (uint32_t xx = 0; xx < w; xx++) {
+                const int gx = int(x0 + xx), gy = int(y0) + int(yy);
+                const size_t ci = size_t(gy) * width + gx;
+                const float centerColor = src[ci];
+                const float* cP = positionMap ? positionMap + 4 * ci : nullptr;
+                const float* cN = normalMap ? normalMap + 4 * ci : nullptr;
+                auto dist4 = [](const float* a, const float* b) {
+                    const float dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2], dw = a[3] - b[3];
+                    return ((dx * dx + dy * dy) + dz * dz) + dw * dw;
+                };
+                float sum, accumW;
+                if (computeVariant) {
+                    const float kernelValues[3] = {1.0f, 2.0f / 3.0f, 1.0f / 6.0f};
+                    accumW = kernelValues[0] * kernelValues[0];
+                    sum = centerColor * accumW;
+                    for (int y = -2; y <= 2; ++y) {
+                        for (int x = -2; x <= 2; ++x) {
+                            const int ox = gx + x * stepWidth, oy = gy + y * stepWidth;
+                            const bool inside = ox >= 0 && oy >= 0 && ox < int(width) && oy < int(height);
+                            if (!inside || (x == 0 && y == 0)) continue;
+                            const size_t oi = size_t(oy) * width + ox;
+                            const float kernelValue = kernelValues[std::abs(x)] * kernelValues[std::abs(y)];
+                            const float offsetColor = src[oi];
+                            float e = 0.0f;
+                            if (wC) {
+                                const float d = centerColor - offsetColor;
+                                const float distColor = ((d * d + d * d) + d * d) + 0.0f * 0.0f;
+                                e = e - (distColor * float(stepWidth)) / phiColor;
+                            }
+                            if (wP) e = e - dist4(cP, positionMap + 4 * oi) / phiPosition;
+                            if (wN) e = e - dist4(cN, normalMap + 4 * oi) / phiNormal;
+                            const float weight = expf(e);
+                            sum += (offsetColor * weight) * kernelValue;
+                            accumW += weight * kernelValue;
+                        }
+                    }
+                } else {
+                    sum = 0.0f; accumW = 0.0f;
+                    for (int i = 0; i < 25; i++) {
+                        const float x = float(i % 5 - 2), y = float(i / 5 - 2);
+                        const float kernelValue = expf(-(x * x + y * y) / 2.0f);
+                        const int ox = std::min(std::max(gx + (i % 5 - 2) * stepWidth, 0), int(width) - 1);
+                        const int oy = std::min(std::max(gy + (i / 5 - 2) * stepWidth, 0), int(height) - 1);
+                        const size_t oi = size_t(oy) * width + ox;
+                        const float offsetColor = src[oi];
+                        float weight = 1.0f;
+                        if (wC) {
+                            const float d = centerColor - offsetColor;
+                            const float distColor = ((d * d + d * d) + d * d) + 0.0f * 0.0f;
+                            weight *= fminf(expf(-distColor / phiColor), 1.0f);
+                        }
+                        if (wP) weight *= fminf(expf(-dist4(cP, positionMap + 4 * oi) / phiPosition), 1.0f);
+                        if (wN) weight *= fminf(expf(-dist4(cN, normalMap + 4 * oi) / phiNormal), 1.0f);
+                        sum += (offsetColor * weight) * kernelValue;
+                        accumW += weight * kernelValue;
+                    }
+                }
+                dst[ci] = sum / accumW;
+            }
+        }
+        ping.swap(pong);
+        stepWidth *= 2;
+    }
+    for (uint32_t yy = 0; yy < h; yy++)
+        for (uint32_t xx = 0; xx < w; xx++) {
+            const size_t ci = size_t(y0 + yy) * width + (x0 + xx);
+            out[ci] = ping[ci];
+        }
 }
 
 void lvo_set_deviation_switches(int literalIntersection, int referenceAoLookup) {

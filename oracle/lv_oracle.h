@@ -268,6 +268,17 @@ void lvo_streamlines_sizes(const lvo_streamlines*, uint64_t* numLines, uint64_t*
 void lvo_streamlines_copy(const lvo_streamlines*, float* positions, float* attributes, uint32_t* offsets);
 void lvo_streamlines_destroy(lvo_streamlines*);
 
+/* ---- f4: EAW denoiser of the RTAO pass (EAWDenoiser.cpp, EAWDenoise.glsl; AO defaults Denoiser.cpp:54-62) ----
+ * Feature maps: full-viewport float4 images the next lvo_render_ao / lvo_render_ao_tri calls fill (view-space normal {xyz,0},
+ * view-space position {xyz,1}; VulkanRayTracedAmbientOcclusion.glsl:321-399); NULL stops writing. */
+void lvo_set_ao_feature_outputs(float* normalMap, float* positionMap);
+/* `iterations` a-trous passes (step width 1, 2, 4, ...) over the AO image; phi* already multiplied by their scales
+ * (AO mode: 0.49, 0.3 * 1e-4, 0.1); computeVariant != 0 = EAWDenoise.Compute (default), 0 = EAWDenoise.Fragment.
+ * Computes the pixels of the rectangle; ao / maps / out are full-viewport images. */
+void lvo_eaw_denoise(uint32_t width, uint32_t height, const float* ao, const float* normalMap, const float* positionMap,
+                     int iterations, float phiColor, float phiPosition, float phiNormal, int useColor, int usePosition,
+                     int useNormal, int computeVariant, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, float* out);
+
 /* Test hook: the restatement of computeFragmentColor + blinnPhongShadingTube on n independent inputs (n x 3 positions /
  * normals / tangents, n flags / attributes / AO texels) -> n x 4 colours, n payload.hitT. */
 void lvo_compute_fragment_color_batch(const lvo_scene*, const lvo_params*, uint64_t n, const float* fragPos, const float* normal,

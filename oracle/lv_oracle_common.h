@@ -12,6 +12,9 @@
 #include <cstring>
 #include <vector>
 
+struct LvoAoFeatureSink { float* normal; float* position; };
+extern LvoAoFeatureSink g_lvoAoFeatures;   // defined in lv_oracle.cpp; set by lvo_set_ao_feature_outputs
+
 namespace {
 
 // ---------------------------------------------------------------- vector helpers (fixed evaluation order)
@@ -190,6 +193,42 @@ inline Frame makeFrame(const lvo_params& P) {
     // VulkanRayTracedAmbientOcclusion.cpp:588
     f.subdivisionCorrectionFactor = cosf(3.1415926535897932f / float(P.tubeNumSubdivisions));
     return f;
+}
+
+// Denoiser feature maps of the RTAO pass (VulkanRayTracedAmbientOcclusion.glsl:321-399, WRITE_NORMAL_MAP / WRITE_POSITION_MAP
+// with accumulation): view-space normal {xyz, 0} and view-space position {xyz, 1} of the primary hit (misses: surfaceNormal =
+// vertexPositionWorld = 0, glsl:211-212), running means over the iterations.  Full-viewport float4 images set through
+// lvo_set_ao_feature_outputs; null = not written.
+// (the sink itself has external linkage -- this header lives in an anonymous namespace per translation unit)
+
+inline void writeAoFeatures(const lvo_params& P, const Frame& F, size_t idx, uint32_t frameNumber, V3 surfaceNormal,
+                            V3 vertexPositionWorld) {
+    if (g_lvoAoFeatures.normal) {
+        // camNormal = (inverseTransposedViewMatrix * vec4(surfaceNormal, 0)).xyz, inverseTransposedViewMatrix =
+        // transpose(inverseViewMatrix) (VulkanRayTracedAmbientOcclusion.cpp:569): row i of the product uses COLUMN i of invView
+        const float* m = F.invView;
+        V3 n = v3(((m[0] * surfaceNormal.x + m[1] * surfaceNormal.y) + m[2] * surfaceNormal.z) + m[3] * 0.0f,
+                  ((m[4] * surfaceNormal.x + m[5] * surfaceNormal.y) + m[6] * surfaceNormal.z) + m[7] * 0.0f,
+                  ((m[8] * surfaceNormal.x + m[9] * surfaceNormal.y) + m[10] * surfaceNormal.z) + m[11] * 0.0f);
+        float* o = g_lvoAoFeatures.normal + 4 * idx;
+        if (frameNumber != 0) {
+            const float a = 1.0f / float(frameNumber + 1);
+            n = v3(mixf(o[0], n.x, a), mixf(o[1], n.y, a), mixf(o[2], n.z, a));
+            const float len = length(n);
+            if (len > 1e-5f) n = v3(n.x / len, n.y / len, n.z / len);
+        }
+        o[0] = n.x; o[1] = n.y; o[2] = n.z; o[3] = 0.0f;
+    }
+    if (g_lvoAoFeatures.position) {
+        const V4 pv = mulM4(P.view, V4{vertexPositionWorld.x, vertexPositionWorld.y, vertexPositionWorld.z, 1.0f});
+        V3 q = v3(pv.x, pv.y, pv.z);
+        float* o = g_lvoAoFeatures.position + 4 * idx;
+        if (frameNumber != 0) {
+            const float a = 1.0f / float(frameNumber + 1);
+            q = v3(mixf(o[0], q.x, a), mixf(o[1], q.y, a), mixf(o[2], q.z, a));
+        }
+        o[0] = q.x; o[1] = q.y; o[2] = q.z; o[3] = 1.0f;
+    }
 }
 
 // primary ray for launch id (x,y) with sub-pixel offset xi; TubeRayTracing.glsl:219-226

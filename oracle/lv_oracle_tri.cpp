@@ -379,6 +379,7 @@ void lvo_render_ao_tri(const lvo_tri_scene* sc, const lvo_params* Pp, int useBvh
                 primaryRay(P, F, x, y, xix, xiy, o, d);
                 TriHit hit;
                 float aoFactor = 1.0f;
+                V3 featNormal = v3(0, 0, 0), featPosition = v3(0, 0, 0); // surfaceNormal / vertexPositionWorld of a miss, glsl:211-212
                 if (closestTri(*sc, useBvh != 0, o, d, 0.0001f, 1000.0f, hit, cnt)) {
                     // glsl:219-263
                     const uint32_t* ti = &sc->idx[3 * size_t(hit.tri)];
@@ -395,6 +396,7 @@ void lvo_render_ao_tri(const lvo_tri_scene* sc, const lvo_params* Pp, int useBvh
                     V3 surfaceTangent = normalize(interpolateVec3(ld3(lp0.lineTangent), ld3(lp1.lineTangent), ld3(lp2.lineTangent), bc));
                     V3 surfaceBitangent = cross(surfaceNormal, surfaceTangent);
                     float offsetFactor = length(linePosition - vertexPositionWorld) / F.subdivisionCorrectionFactor; // glsl:280
+                    featNormal = surfaceNormal; featPosition = vertexPositionWorld;
                     aoFactor = 0.0f;
                     for (uint32_t s = 0; s < P.aoSamplesPerFrame; s++) {
                         uint32_t sseed = tea(pix, globalFrameNumber * P.aoSamplesPerFrame + s);
@@ -419,6 +421,7 @@ void lvo_render_ao_tri(const lvo_tri_scene* sc, const lvo_params* Pp, int useBvh
                 size_t idx = size_t(y) * P.width + x;
                 if (frameNumber != 0) aoFactor = mixf(aoOut[idx], aoFactor, 1.0f / float(frameNumber + 1));
                 aoOut[idx] = aoFactor;
+                writeAoFeatures(P, F, idx, frameNumber, featNormal, featPosition);
             }
             rays += cnt.rays; nodes += cnt.nodes; prims += cnt.prims;
         }

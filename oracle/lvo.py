@@ -96,6 +96,8 @@ def lib():
     L = C.CDLL(_SO)
     vp, u32, f32, i32 = C.c_void_p, C.c_uint32, C.c_float, C.c_int
     L.lvo_set_deviation_switches.argtypes = [i32, i32]
+    L.lvo_set_ao_feature_outputs.argtypes = [vp, vp]
+    L.lvo_eaw_denoise.argtypes = [u32, u32, vp, vp, vp, i32, f32, f32, f32, i32, i32, i32, i32, u32, u32, u32, u32, vp]
     L.lvo_compute_fragment_color_batch.argtypes = [vp, vp, C.c_uint64] + [vp] * 8
     L.lvo_num_threads.restype = i32
     L.lvo_num_threads.argtypes = []
@@ -597,3 +599,38 @@ class deviation_switches:
     def __exit__(self, *exc):
         lib().lvo_set_deviation_switches(0, 0)
         return False
+
+
+# EAW defaults of the RTAO pass (Denoiser.cpp:54-62): 3 iterations, phi x scale
+EAW_AO_DEFAULTS = dict(iterations=3, phi_color=0.49, phi_position=0.3 * 0.0001, phi_normal=0.1)
+
+
+class ao_features:
+    """Context manager: the RTAO passes inside the block also write the denoiser's feature maps (view-space normal and
+    position, float4 per pixel, full viewport) -> .normal, .position."""
+
+    def __init__(self, width, height):
+        self.normal = np.zeros((height, width, 4), dtype=np.float32)
+        self.position = np.zeros((height, width, 4), dtype=np.float32)
+
+    def __enter__(self):
+        lib().lvo_set_ao_feature_outputs(_p(self.normal), _p(self.position))
+        return self
+
+    def __exit__(self, *exc):
+        lib().lvo_set_ao_feature_outputs(None, None)
+        return False
+
+
+def eaw_denoise(ao, normal=None, position=None, iterations=3, phi_color=0.49, phi_position=0.3 * 0.0001, phi_normal=0.1,
+                use_color=True, use_position=True, use_normal=True, compute_variant=True, tile=None):
+    a = np.ascontiguousarray(ao, dtype=np.float32)
+    h, w = a.shape
+    nm = np.ascontiguousarray(normal, dtype=np.float32) if normal is not None else None
+    pm = np.ascontiguousarray(position, dtype=np.float32) if position is not None else None
+    x0, y0, tw, th = tile if tile is not None else (0, 0, w, h)
+    out = a.copy()
+    lib().lvo_eaw_denoise(w, h, _p(a), _p(nm) if nm is not None else None, _p(pm) if pm is not None else None, int(iterations),
+                          float(phi_color), float(phi_position), float(phi_normal), int(use_color), int(use_position),
+                          int(use_normal), int(compute_variant), x0, y0, tw, th, _p(out))
+    return out

@@ -91,17 +91,44 @@ class Case:
             frames.append(prev)
         return frames
 
+    def eaw_settings(self):
+        """EAW denoiser of the RTAO pass if enabled: kwargs of lvo.eaw_denoise (phi already x the AO-mode scales), else None."""
+        s = self.settings
+        if s.get("ambient_occlusion_denoiser", "None") == "None":
+            return None
+        its = int(s.get("eaw_denoiser_iterations", 3))
+        if its == 0:
+            return None
+        return dict(iterations=its, phi_color=float(s.get("eaw_denoiser_phi_color", 0.49)),
+                    phi_position=float(s.get("eaw_denoiser_phi_position", 0.3)) * 0.0001,
+                    phi_normal=float(s.get("eaw_denoiser_phi_normal", 0.1)),
+                    use_color=bool(s.get("eaw_denoiser_color_weights", True)),
+                    use_position=bool(s.get("eaw_denoiser_position_weights", True)),
+                    use_normal=bool(s.get("eaw_denoiser_normal_weights", True)),
+                    compute_variant=bool(s.get("eaw_denoiser_use_shared_memory", True)))
+
+    def oracle_ao(self, sc, P, tile=None, mode=11, use_bvh=False, stats=None, render_ao=None):
+        """The AO image the colour pass samples: RTAO over the tile (+ the halo the lookup / the denoiser read), denoised if
+        ambient_occlusion_denoiser is set.  render_ao: alternative RTAO function (triangle tubes)."""
+        eaw = self.eaw_settings()
+        halo = (1 if (mode == 11 and P.useJitteredRays) else 0) + (2 * (2 ** eaw["iterations"] - 1) if eaw else 0)
+        ao_tile = tile
+        if tile is not None and halo:
+            x0, y0, w, h = tile
+            xa, ya = max(x0 - halo, 0), max(y0 - halo, 0)
+            ao_tile = (xa, ya, min(x0 + w + halo, self.width) - xa, min(y0 + h + halo, self.height) - ya)
+        render_ao = render_ao or (lambda t: sc.render_ao(P, tile=t, use_bvh=use_bvh, stats=stats))
+        if not eaw:
+            return render_ao(ao_tile)
+        with lvo.ao_features(self.width, self.height) as f:
+            raw = render_ao(ao_tile)
+        return lvo.eaw_denoise(raw, f.normal, f.position, tile=ao_tile, **eaw)
+
     def oracle_render(self, mode, use_bvh=False, tile=None, stats=None):
-        """Full frame as the host orchestration defines it: depth range -> RTAO -> colour / PPLL."""
+        """Full frame as the host orchestration defines it: depth range -> RTAO (-> EAW) -> colour / PPLL."""
         sc = self.oracle_scene()
         P = self.oracle_params(sc)
-        ao_tile = tile
-        if tile is not None and mode == 11 and P.useJitteredRays:
-            # jittered colour rays sample the AO image bilinearly (AmbientOcclusion.glsl:84-99): 1-pixel halo around the tile
-            x0, y0, w, h = tile
-            xa, ya = max(x0 - 1, 0), max(y0 - 1, 0)
-            ao_tile = (xa, ya, min(x0 + w + 1, self.width) - xa, min(y0 + h + 1, self.height) - ya)
-        ao = sc.render_ao(P, tile=ao_tile, use_bvh=use_bvh, stats=stats) if P.useAmbientOcclusion else None
+        ao = self.oracle_ao(sc, P, tile=tile, mode=mode, use_bvh=use_bvh, stats=stats) if P.useAmbientOcclusion else None
         if mode == 11:
             return sc.render_rt(P, ao=ao, tile=tile, use_bvh=use_bvh, stats=stats), ao
         return sc.render_ppll(P, ao=ao, tile=tile, use_bvh=use_bvh, stats=stats), ao

@@ -1,0 +1,181 @@
+"""EAW denoiser of the RTAO pass: src/Renderers/Scattering/Denoiser/EAWDenoiser.cpp, Data/Shaders/Denoiser/
+EAWDenoise.glsl, feature maps of Data/Shaders/AO/RTAO/VulkanRayTracedAmbientOcclusion.glsl:321-399.
+
+CPU: the oracle's restatement against an independent float64 numpy restatement written from the GLSL (both shader variants).
+GPU: the HIP path (k_ao_primary feature outputs + k_eaw_pass) against the oracle; tiles reproduce the full frame."""
+import numpy as np
+import pytest
+
+from common import Case, small_case, max_lsb_diff
+from linevis_amd import scenes, tiling, transfer_function as tfm
+from oracle import lvo
+
+RTAO = dict(ambient_occlusion_mode="RTAO (Screen Space)", ambient_occlusion_strength=1.0, ambient_occlusion_gamma=1.0,
+            ambient_occlusion_radius=0.1, ambient_occlusion_distance_based=True, use_jittered_primary_rays=True)
+EAW = "Edge-Avoiding À-Trous Wavelet Transform"
+LSB_TOL = 2
+
+
+def eaw_numpy(ao, normal, position, iterations, phi_c, phi_p, phi_n, use_c, use_p, use_n, compute):
+    """EAWDenoise.glsl in float64, vectorised over the image: colorTexture = vec4(ao, ao, ao, 1)."""
+    H, W = ao.shape
+    img = ao.astype(np.float64)
+    N = normal.astype(np.float64)
+    Pm = position.astype(np.float64)
+    step = 1
+    yy, xx = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    for _ in range(iterations):
+        if compute:   # Compute variant: centre weight kernel[0]^2, neighbours outside the image skipped
+            kv = [1.0, 2.0 / 3.0, 1.0 / 6.0]
+            acc_w = np.full((H, W), kv[0] * kv[0])
+            acc = img * acc_w
+        else:
+            acc_w = np.zeros((H, W))
+            acc = np.zeros((H, W))
+        for y in range(-2, 3):
+            for x in range(-2, 3):
+                ox, oy = xx + x * step, yy + y * step
+                if compute:
+                    if x == 0 and y == 0:
+                        continue
+                    inside = (ox >= 0) & (oy >= 0) & (ox < W) & (oy < H)
+                    k = kv[abs(x)] * kv[abs(y)]
+                else:
+                    inside = np.ones((H, W), bool)
+                    k = np.exp(-(x * x + y * y) / 2.0)
+                cx, cy = np.clip(ox, 0, W - 1), np.clip(oy, 0, H - 1)
+                oc = img[cy, cx]
+                d_c = 3.0 * (img - oc) ** 2          # rgb equal, alpha difference 0
+                d_p = ((Pm - Pm[cy, cx]) ** 2).sum(axis=2)
+                d_n = ((N - N[cy, cx]) ** 2).sum(axis=2)
+                if compute:
+                    e = np.zeros((H, W))
+                    if use_c:
+                        e -= d_c * step / phi_c
+                    if use_p:
+                        e -= d_p / phi_p
+                    if use_n:
+                        e -= d_n / phi_n
+                    w = np.exp(e)
+                else:
+                    w = np.ones((H, W))
+                    if use_c:
+                        w *= np.minimum(np.exp(-d_c / phi_c), 1.0)
+                    if use_p:
+                        w *= np.minimum(np.exp(-d_p / phi_p), 1.0)
+                    if use_n:
+                        w *= np.minimum(np.exp(-d_n / phi_n), 1.0)
+                w = np.where(inside, w, 0.0)
+                acc += oc * w * k
+                acc_w += w * k
+        img = acc / acc_w
+        step *= 2
+    return img
+
+
+@pytest.mark.parametrize("compute", [True, False])
+def test_oracle_eaw_against_the_float64_restatement(compute):
+    rng = np.random.default_rng(11)
+    H, W = 70, 90
+    ao = rng.uniform(0.2, 1.0, (H, W)).astype(np.float32)
+    ao[:, 40:] = 1.0                                          # a background region, as in a real AO image
+    normal = rng.normal(size=(H, W, 4)).astype(np.float32)
+    normal[..., :3] /= np.linalg.norm(normal[..., :3], axis=2, keepdims=True)
+    normal[..., 3] = 0.0
+    normal[:20] = normal[0, 0]                                # smooth regions where the filter actually blends
+    position = np.zeros((H, W, 4), np.float32)
+    position[..., 0] = np.linspace(-0.3, 0.3, W, dtype=np.float32)[None, :] * 0.02
+    position[..., 1] = np.linspace(-0.2, 0.2, H, dtype=np.float32)[:, None] * 0.02
+    position[..., 2] = -0.8 + rng.uniform(0, 0.002, (H, W)).astype(np.float32)
+    position[..., 3] = 1.0
+    for flags in ((True, True, True), (True, False, False), (False, True, True)):
+        kw = dict(iterations=3, phi_color=0.49, phi_position=3e-5, phi_normal=0.1)
+        got = lvo.eaw_denoise(ao, normal, position, use_color=flags[0], use_position=flags[1], use_normal=flags[2],
+                              compute_variant=compute, **kw)
+        want = eaw_numpy(ao, normal, position, 3, 0.49, 3e-5, 0.1, flags[0], flags[1], flags[2], compute)
+        assert np.abs(got - want).max() < 2e-5, (compute, flags, np.abs(got - want).max())
+        assert np.abs(got - ao).max() > 1e-3                  # it does filter
+    # a tile computed with its halo equals the crop of the full image (the a-trous footprint is +-14 px for 3 passes)
+    full = lvo.eaw_denoise(ao, normal, position, compute_variant=compute)
+    x0, y0, w, h = 20, 10, 40, 30
+    ao_local = np.full_like(ao, 7.0)                          # garbage outside the dilated tile must not matter
+    ao_local[0:y0 + h + 14, x0 - 14:x0 + w + 14] = ao[0:y0 + h + 14, x0 - 14:x0 + w + 14]
+    part = lvo.eaw_denoise(ao_local, normal, position, compute_variant=compute, tile=(x0 - 14, 0, w + 28, y0 + h + 14))
+    assert np.array_equal(part[y0:y0 + h, x0:x0 + w], full[y0:y0 + h, x0:x0 + w])
+
+
+def test_oracle_feature_maps_and_zero_iterations():
+    c = small_case(width=96, height=64, **RTAO, ambient_occlusion_iterations=3, ambient_occlusion_samples_per_frame=2)
+    sc = c.oracle_scene()
+    P = c.oracle_params(sc)
+    with lvo.ao_features(96, 64) as f:
+        ao = sc.render_ao(P)
+    hit = ao < 1.0
+    nlen = np.linalg.norm(f.normal[..., :3], axis=2)
+    assert np.all(np.abs(nlen[hit] - 1.0) < 1e-4) and np.all(f.normal[..., 3] == 0.0) and np.all(f.position[..., 3] == 1.0)
+    miss = nlen == 0.0                                        # misses keep surfaceNormal = 0 and position = view * origin
+    assert miss.sum() > 100 and np.allclose(f.position[miss][:, :3], [0.0, 0.0, -0.8], atol=1e-6)
+    assert np.all(f.position[hit][:, 2] < -0.3)               # in front of the camera, view space looks down -z
+    assert np.array_equal(lvo.eaw_denoise(ao, f.normal, f.position, iterations=0), ao)
+
+
+# ---------------------------------------------------------------- GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["compute", "fragment", "triangle_tubes", "jittered"])
+def test_hip_eaw_against_the_oracle(hip_lib, variant):
+    import torch
+    settings = dict(RTAO, ambient_occlusion_iterations=16, ambient_occlusion_samples_per_frame=4,
+                    ambient_occlusion_denoiser=EAW, depth_cue_strength=0.8)
+    if variant == "fragment":
+        settings.update(eaw_denoiser_use_shared_memory=False, eaw_denoiser_iterations=2)
+    if variant == "jittered":
+        settings.update(num_samples_per_frame=2, ambient_occlusion_iterations=2)
+    tr = scenes.normalize(scenes.random_curves(n_lines=30, points_per_line=30, seed=3))
+    from linevis_amd import host_api
+    flow = host_api.LineDataFlow().set_trajectories(tr.positions, tr.attributes, tr.line_offsets)
+    pts, seg, _ = flow.tube_aabb_render_data(0.02)
+    c = Case(pts, seg, tfm.standard(), 150, 90, 0.02, **settings)
+    ctx = c.hip_context()
+    sc = c.oracle_scene()
+    P = c.oracle_params(sc)
+    render_ao = None
+    if variant == "triangle_tubes":
+        mesh = flow.tube_triangle_render_data(0.02, 6)
+        ctx.set_tube_triangle_mesh(*mesh)
+        ctx.set_option("rtao_geometry", "triangle_tubes")
+        tsc = lvo.TriScene(mesh[0], mesh[1], mesh[2], 0.02)
+        render_ao = lambda t: tsc.render_ao(P, tile=t)
+    full = ctx.render(11)
+    ao = ctx.get_ao()
+    ao_ref = c.oracle_ao(sc, P, render_ao=render_ao)
+    assert np.abs(ao - ao_ref).max() < 2e-5                   # exp() of libm vs the device library; everything else is exact
+    raw = (render_ao(None) if render_ao else sc.render_ao(P))
+    assert np.abs(ao_ref - raw).max() > 1e-3                  # the denoiser changed the image
+    ref = sc.render_rt(P, ao=ao_ref)
+    assert max_lsb_diff(full, ref) <= LSB_TOL
+    # tiles (halo 14 px + 1 for jittered colour rays, rings overlap, 16 accumulated iterations) reproduce the frame
+    tiles = tiling.make_tiles(150, 90, 32)
+    out = torch.zeros((len(tiles), 32, 32, 4), dtype=torch.uint8, device="cuda")
+    fn = tiling.hip_render_tiles_fn(ctx, 11)
+    fn(out, tiles, 32, 32)
+    torch.cuda.synchronize()
+    ctx.set_stream(None)
+    assert np.array_equal(tiling.detile(out.cpu().numpy(), tiles, 150, 90, 32), full)
+    assert np.array_equal(ctx.render(11, tile=(37, 21, 50, 33)), full[21:54, 37:87])
+    # PPLL samples the same denoised image; switching the denoiser off gives the raw one back
+    ctx.set_option("ambient_occlusion_denoiser", "None")
+    ctx.render(11)
+    assert np.abs(ctx.get_ao() - raw).max() == 0.0
+
+
+@pytest.mark.gpu
+def test_denoiser_option_errors(hip_lib):
+    from linevis_amd import capi
+    ctx = small_case(**RTAO).hip_context()
+    for key, val in (("ambient_occlusion_denoiser", "SVGF"), ("eaw_denoiser_iterations", 6), ("eaw_denoiser_phi_color", 0.0)):
+        with pytest.raises(capi.LineVisError):
+            ctx.set_option(key, val)
+    ctx.set_option("ambient_occlusion_denoiser", "EAW")
+    ctx.set_option("eaw_denoiser_iterations", 0)              # 0 iterations = a plain copy (EAWDenoiser.cpp:279-287)
+    ctx.set_options(dict(ambient_occlusion_iterations=1, ambient_occlusion_samples_per_frame=2))
+    ctx.render(11)
