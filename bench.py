@@ -198,8 +198,12 @@ def roofline(kernel, pmc_key, ms_launch, algorithmic_bytes, world):
         return out
     pmc = json.load(open(ppath))
     ub = json.load(open(upath))
-    kname = [k for k in pmc["kernels"] if k.startswith(kernel + "<") or k == kernel]
-    c = pmc["kernels"][kname[0]]
+    kname = [k for k in pmc["kernels"] if k.startswith((kernel + "<", kernel + "_mlat<")) or k == kernel]
+    if not kname:
+        out.update({"bound": None, "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
+                    "note": "kernel %s not in %s" % (kernel, os.path.basename(ppath))})
+        return out
+    c = max((pmc["kernels"][k] for k in kname), key=lambda d: d.get("SQ_INSTS_VALU", 0.0))   # the instantiation that ran
     t_ns = ms_launch * 1e6
     ceil = {}
     # VALU issue: wave-instructions per SIMD per ns against the rate the VALU sustains on the node step's instruction mix

@@ -10,6 +10,7 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 
 def pytest_configure(config):
+    config.addinivalue_line("markers", "slow: long-running (full-size soak)")
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run through gpurun / the round-end driver)")
 
 

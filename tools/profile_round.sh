@@ -1,0 +1,37 @@
+#!/bin/bash
+# Everything profiles/ needs for one round, on the GPU box:  bash tools/profile_round.sh <tag>
+#   bench lines of every workload          -> gpurun_out/prof_<tag>/bench_<workload>.json
+#   rocprofv3 --kernel-trace --stats       -> gpurun_out/prof_<tag>/<workload>_kernel_stats.csv  (same command as the bench line)
+#   PMC counter groups (tools/pmc_collect.sh: full set for c3c / c3t, roofline set for the others) -> gpurun_out/pmc_<tag>/
+#   shard / frames-in-flight probe          -> gpurun_out/shard_probe_<workload>.json
+TAG=${1:-r02}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$R/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+bash $R/tools/pmc_collect.sh $TAG c3c c3t > $OUT/pmc_full.log 2>&1
+LV_PMC_LITE=1 bash $R/tools/pmc_collect.sh $TAG c2 c4 c4m c4l > $OUT/pmc_lite.log 2>&1
+for f in $R/gpurun_out/pmc_$TAG/*.json; do cp $f $R/profiles/pmc_${TAG}_$(basename $f); done   # bench.py reads profiles/
+python $R/bench.py > $OUT/bench_c3.json 2> $OUT/bench_c3.err
+for w in c3c c3t c2 c4 c4m c4l c5; do
+  python $R/bench.py --workload $w --steps 100 --warmup 5 --no-cpu-baseline > $OUT/bench_$w.json 2> $OUT/bench_$w.err
+done
+for w in c3 c4 c4m c2; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$w -o bench -- python $R/bench.py --workload $w --steps 20 --warmup 3 --no-cpu-baseline > $OUT/rocprof_$w.json 2> $OUT/rocprof_$w.err
+  f=$(find $OUT/trace_$w -name "bench_kernel_stats.csv" | head -1)
+  python - <<PY
+import csv
+rows = list(csv.DictReader(open("$f")))
+def short(n):
+    return n.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0][:70]
+with open("$OUT/${w}_kernel_stats.csv", "w") as o:
+    o.write("# rocprofv3 --kernel-trace --stats -- python bench.py --workload $w --steps 20 --warmup 3 --no-cpu-baseline (MI355X)\n")
+    o.write("kernel,calls,total_ns,avg_ns,min_ns,max_ns,percent\n")
+    for r in rows[:30]:
+        o.write("%s,%s,%s,%.0f,%s,%s,%s\n" % (short(r["Name"]), r["Calls"], r["TotalDurationNs"], float(r["AverageNs"]), r["MinNs"], r["MaxNs"], r["Percentage"]))
+PY
+  rm -rf $OUT/trace_$w
+done
+cd $R
+LV_PROBE_DEPTHS=1,2,4 python tools/probe_shard.py c3c > $OUT/shard_c3c.txt 2>&1
+LV_PROBE_DEPTHS=1,2,4 python tools/probe_shard.py c3t > $OUT/shard_c3t.txt 2>&1
