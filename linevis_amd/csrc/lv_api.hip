@@ -474,6 +474,10 @@ int lv_set_option(lv_ctx* ctx, const char* key, const char* value) {
         (k == "ppll_tile_width" ? o.ppllTileW : o.ppllTileH) = u;
     } else if (k == "collect_stats") {
         o.collectStats = parseBool(value);
+    } else if (k == "intersection_form") {
+        if (std::string(value) == "closest_approach") o.literalIntersection = false;
+        else if (std::string(value) == "literal") o.literalIntersection = true;
+        else return bad();
     } else if (k == "rtao_geometry") {
         if (std::string(value) == "capsules") o.aoTriangleTubes = false;
         else if (std::string(value) == "triangle_tubes") o.aoTriangleTubes = true;

@@ -137,6 +137,7 @@ struct LvSceneDev {
     unsigned* stackOverflow;    // null unless the LBVH is higher than LV_STACK_LDS
     uint32_t* accum;            // full-viewport rgba8 of the previous frame (num_accumulated_frames > 1), else null
     uint32_t numSegs;           // primitives under `nodes` (segments, or triangles in a triangle-tube scene view)
+    uint32_t literalIntersection; // intersection_form = literal: the reference's textbook roots (lv_intersect_capsule_literal)
     // triangle tubes (the reference's RTAO geometry); in the scene view handed to the triangle kernels `nodes` is the
     // triangle LBVH and numSegs the triangle count
     const float4* tris;         // 48-B records in Morton order: {v0.xyz, triangle index bits}{v1.xyz, 0}{v2.xyz, 0}

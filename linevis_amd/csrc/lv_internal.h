@@ -55,6 +55,7 @@ struct LvOptions {
     bool eawColorWeights = true, eawPositionWeights = true, eawNormalWeights = true;
     float eawPhiColor = 0.49f, eawPhiPosition = 0.3f, eawPhiNormal = 0.1f;
     bool eawUseSharedMemory = true;           // true: EAWDenoise.Compute (default), false: EAWDenoise.Fragment
+    bool literalIntersection = false;         // intersection_form: false = closest approach (default), true = the reference's literal roots
     bool mlatRecordTrace = false;             // with collect_stats: record every pixel's candidate visiting order
     uint32_t mlatTraceCapacity = 1u << 22;    // records (16 B each)
 };

@@ -287,7 +287,7 @@ __device__ __forceinline__ size_t lv_ao_slot(const uint32_t* __restrict__ tileBa
 // numTubeSubdivisions + subdivision with g0 = {ray origin, -}, g1 = {tangent, vertex}, g2 = {surface normal, subdivision};
 // the reference draws the (subdivision, ray) samples of a vertex from ONE LCG stream seeded with tea(vertex, frame), so
 // sample j starts from the stream advanced by 2 j steps: seed_j = A_j * seed_0 + C_j (lcgSkip[j] = {A_j, C_j}).
-template <bool STATS, bool ANY_HIT, int PRIM, bool BAKE = false>
+template <bool STATS, bool ANY_HIT, int PRIM, bool BAKE = false, bool LIT = false>
 __global__ __launch_bounds__(LV_AO_BLOCK, 5) void k_ao_rays(const LvUniforms U, const LvSceneDev S,
                                                          const float4* __restrict__ gbuf, float* __restrict__ samples,
                                                          LvDevCounters* dc, const uint32_t* __restrict__ tileBase,
@@ -312,6 +312,8 @@ __global__ __launch_bounds__(LV_AO_BLOCK, 5) void k_ao_rays(const LvUniforms U, 
     unsigned* queueW = s_queue[w];
     unsigned long long* keyW = &s_key[LV_WAVE * w];
     const unsigned long long keyInit = ((unsigned long long)__float_as_uint(U.aoRadius) << 32) | 0xFFFFFFFFull;
+    // literal roots: cull against best + r / |d| (AO directions are normalised: |d| = 1 to rounding, 1.001 covers it)
+    const float litSlack = (PRIM == LV_PRIM_CAPSULE && LIT) ? radius * 1.001f : 0.0f;
 
     LvStackT<LV_AO_STACK_LDS, LV_AO_BLOCK> st;
     st.init(&s_stack[threadIdx.x], S.stackOverflow ? S.stackOverflow + (size_t(blockIdx.x) * LV_AO_BLOCK + threadIdx.x) : nullptr,
@@ -382,7 +384,7 @@ __global__ __launch_bounds__(LV_AO_BLOCK, 5) void k_ao_rays(const LvUniforms U, 
                 const float2 r0 = rayW[3 * owner], r1 = rayW[3 * owner + 1], r2 = rayW[3 * owner + 2];
                 if (STATS) cnt.prims++;
                 float t; unsigned low;
-                if (lv_leaf_test<PRIM>(S, leaf, mk3(r0.x, r0.y, r1.x), mk3(r1.y, r2.x, r2.y), radius, capped, t, low)) {
+                if (lv_leaf_test<PRIM, LIT ? 1 : 0>(S, leaf, mk3(r0.x, r0.y, r1.x), mk3(r1.y, r2.x, r2.y), radius, capped, t, low)) {
                     if (t >= 0.0f && t <= U.aoRadius) { // traceAoRay: closest hit in [0, aoRadius], glsl:158-175
                         atomicMin(&keyW[owner], ((unsigned long long)__float_as_uint(t) << 32) | low);
                         if (STATS) primHits++;
@@ -530,7 +532,7 @@ __global__ __launch_bounds__(LV_AO_BLOCK, 5) void k_ao_rays(const LvUniforms U, 
             do {
                 if (STATS && lane == 0) { phIt[1]++; }
                 if (STATS && !(cur & LV_LEAF_BIT)) phLn[1]++;
-                if (!(cur & LV_LEAF_BIT)) cur = lv_node_step<STATS>(S, cur, oi, inv, 0.0f, best, st, cnt);
+                if (!(cur & LV_LEAF_BIT)) cur = lv_node_step<STATS>(S, cur, oi, inv, 0.0f, best + litSlack, st, cnt);
                 const bool isLeaf = cur != LV_INVALID && (cur & LV_LEAF_BIT);
                 const unsigned long long mL = __ballot(isLeaf);
                 if (mL) {
@@ -1043,6 +1045,7 @@ LvSceneDev sceneDev(const lv_ctx* ctx) {
     S.stackOverflow = nullptr;
     S.accum = nullptr;
     S.numSegs = ctx->numSegs;
+    S.literalIntersection = ctx->opt.literalIntersection ? 1u : 0u;
     S.tris = nullptr; S.triIdx = nullptr; S.triVerts = nullptr; S.triPoints = nullptr; S.triPad = 0.0f;
     S.bakedAo = (const float*)ctx->bakedAo.ptr;
     S.bakedBlendingWeights = (const float*)ctx->bakeBlendingWeights.ptr;
@@ -1267,8 +1270,15 @@ static int lv_run_ao(lv_ctx* ctx, LvUniforms& U, LvSceneDev& S, const LvTiles& T
             U, SA, T, aoIn, ao, (float4*)ctx->aoGbuf.ptr, tileCount, dc, fnIn, fnOut, fpIn, fpOut)))
 #define LV_LAUNCH_AO(ST, AH, PR) \
     LV_TIMED_LAUNCH(ctx, LV_KERNEL_AO_RAYS, (k_ao_rays<ST, AH, PR><<<grid, LV_AO_BLOCK, 0, st>>>(U, SA, g, smp, dc, tileBase, numGroups, tileCap)))
-#define LV_LAUNCH_AO2(ST, AH) \
-    do { if (tri) LV_LAUNCH_AO(ST, AH, LV_PRIM_TRIANGLE); else LV_LAUNCH_AO(ST, AH, LV_PRIM_CAPSULE); } while (0)
+#define LV_LAUNCH_AO_LIT(ST, AH) \
+    LV_TIMED_LAUNCH(ctx, LV_KERNEL_AO_RAYS, (k_ao_rays<ST, AH, LV_PRIM_CAPSULE, false, true><<<grid, LV_AO_BLOCK, 0, st>>>( \
+            U, SA, g, smp, dc, tileBase, numGroups, tileCap)))
+#define LV_LAUNCH_AO2(ST, AH)                                          \
+    do {                                                               \
+        if (tri) LV_LAUNCH_AO(ST, AH, LV_PRIM_TRIANGLE);               \
+        else if (ctx->opt.literalIntersection) LV_LAUNCH_AO_LIT(ST, AH); \
+        else LV_LAUNCH_AO(ST, AH, LV_PRIM_CAPSULE);                    \
+    } while (0)
         if (stats) { if (tri) LV_LAUNCH_AOP(true, LV_PRIM_TRIANGLE); else LV_LAUNCH_AOP(true, LV_PRIM_CAPSULE); }
         else { if (tri) LV_LAUNCH_AOP(false, LV_PRIM_TRIANGLE); else LV_LAUNCH_AOP(false, LV_PRIM_CAPSULE); }
         k_ao_tile_scan<<<1, LV_BLOCK, 0, st>>>(tileCount, numGroups, tileBase, dc);
@@ -1276,6 +1286,7 @@ static int lv_run_ao(lv_ctx* ctx, LvUniforms& U, LvSceneDev& S, const LvTiles& T
         if (stats) { if (anyHit) LV_LAUNCH_AO2(true, true); else LV_LAUNCH_AO2(true, false); }
         else { if (anyHit) LV_LAUNCH_AO2(false, true); else LV_LAUNCH_AO2(false, false); }
 #undef LV_LAUNCH_AO2
+#undef LV_LAUNCH_AO_LIT
 #undef LV_LAUNCH_AO
 #undef LV_LAUNCH_AOP
         k_ao_reduce<false><<<nblocks(maxPixels), LV_BLOCK, 0, st>>>(U, g, smp, aoIn, ao, dc, tileBase, numGroups, tileCap);

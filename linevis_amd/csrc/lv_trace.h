@@ -79,6 +79,80 @@ __device__ __forceinline__ bool lv_intersect_capsule(f3 o, f3 d, f3 p0, f3 p1, f
     return has;
 }
 
+// intersection_form = literal: the reference's roots exactly as written -- t = (-B -+ sqrt(B^2 - 4AC)) / 2A,
+// RayIntersectionTestsVulkan.glsl:39-72 (sphere) and :78-119 (tube) -- in float32 without contraction.  For r = 1e-3 at
+// distance ~1 the discriminant keeps 1-2 digits, t carries up to ~0.25 r of noise and silhouettes flicker by hits that
+// should be misses and vice versa (tests/test_deviations.py: 34-43 % of the covered pixels of configs 2 / 3 differ by more
+// than 2 LSB between the two forms).  This mode reproduces the formula, noise included.
+__device__ __forceinline__ bool lv_ray_sphere_literal(f3 o, f3 d, f3 ctr, float radius, float& hitT) {
+    const float A = (d.x * d.x + d.y * d.y) + d.z * d.z;
+    const float B = 2.0f * ((d.x * (o.x - ctr.x) + d.y * (o.y - ctr.y)) + d.z * (o.z - ctr.z));
+    const float C = (((o.x - ctr.x) * (o.x - ctr.x) + (o.y - ctr.y) * (o.y - ctr.y)) + (o.z - ctr.z) * (o.z - ctr.z)) - radius * radius;
+    const float discriminant = B * B - (4.0f * A) * C;
+    if (discriminant < 0.0f) return false;
+    const float ds = sqrtf(discriminant);
+    const float t0 = (-B - ds) / (2.0f * A);
+    const float t1 = (-B + ds) / (2.0f * A);
+    hitT = t0;
+    if (t0 >= 0.0f) hitT = t0;
+    else if (t1 >= 0.0f) hitT = t1;
+    else return false;
+    return true;
+}
+__device__ __forceinline__ bool lv_ray_tube_literal(f3 o, f3 d, f3 tubeStart, f3 tubeEnd, float radius, float& hitT) {
+    const f3 td = norm3(tubeEnd - tubeStart);
+    const f3 deltaP = o - tubeStart;
+    const f3 av = d - dot3(d, td) * td;
+    const f3 cv = deltaP - dot3(deltaP, td) * td;
+    const float A = (av.x * av.x + av.y * av.y) + av.z * av.z;
+    const float B = 2.0f * dot3(av, cv);
+    const float C = ((cv.x * cv.x + cv.y * cv.y) + cv.z * cv.z) - radius * radius;
+    const float discriminant = B * B - (4.0f * A) * C;
+    if (discriminant < 0.0f) return false;
+    const float ds = sqrtf(discriminant);
+    const float t0 = (-B - ds) / (2.0f * A);
+    if (t0 >= 0.0f) {
+        const f3 ip = o + t0 * d;
+        if (dot3(td, ip - tubeStart) > 0.0f && dot3(td, ip - tubeEnd) < 0.0f) { hitT = t0; return true; }
+    }
+    const float t1 = (-B + ds) / (2.0f * A);
+    if (t1 >= 0.0f) {
+        const f3 ip = o + t1 * d;
+        if (dot3(td, ip - tubeStart) > 0.0f && dot3(td, ip - tubeEnd) < 0.0f) { hitT = t1; return true; }
+    }
+    return false;
+}
+// The intersection shader only runs for rays that hit the segment's AABB (min(p0, p1) - r .. max(p0, p1) + r,
+// LineDataFlow.cpp:2230-2233) -- and a root is only meaningful near that box.  Making this part of the test (own box hit by
+// the ray's line, t within r / |d| of the box interval) is what lets ANY conservative BVH that culls against best + r / |d|
+// return the brute-force minimum of the noisy roots bit for bit (the same device as lv_ray_triangle's own-box rule).
+__device__ __forceinline__ bool lv_intersect_capsule_literal(f3 o, f3 d, f3 p0, f3 p1, float radius, bool capped, float& hitTOut,
+                                                             int& kindOut) {
+    bool has = false;
+    float hitT = 1e7f;
+    int kind = 0;
+    float tubeT;
+    if (lv_ray_tube_literal(o, d, p0, p1, radius, tubeT)) { hitT = tubeT; has = true; kind = 0; }
+    if (capped) {
+        float s0T, s1T;
+        const bool h0 = lv_ray_sphere_literal(o, d, p0, radius, s0T);
+        const bool h1 = lv_ray_sphere_literal(o, d, p1, radius, s1T);
+        if (h0 && s0T < hitT) { has = true; hitT = s0T; kind = 1; }
+        if (h1 && s1T < hitT) { has = true; hitT = s1T; kind = 2; }
+    }
+    hitTOut = hitT;
+    kindOut = kind;
+    if (!has) return false;
+    const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    const float tx0 = ((fminf(p0.x, p1.x) - radius) - o.x) * inv.x, tx1 = ((fmaxf(p0.x, p1.x) + radius) - o.x) * inv.x;
+    const float ty0 = ((fminf(p0.y, p1.y) - radius) - o.y) * inv.y, ty1 = ((fmaxf(p0.y, p1.y) + radius) - o.y) * inv.y;
+    const float tz0 = ((fminf(p0.z, p1.z) - radius) - o.z) * inv.z, tz1 = ((fmaxf(p0.z, p1.z) + radius) - o.z) * inv.z;
+    const float tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fminf(tz0, tz1));
+    const float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fmaxf(tz0, tz1));
+    const float slack = radius / len3(d);
+    return tn <= tf && hitT >= tn - slack && hitT <= tf + slack;
+}
+
 // Conservative pre-tests in front of lv_intersect_capsule (they may only say "cannot hit"; fused math is fine because
 // they never decide a hit).  A capsule hit needs the ray LINE to pass within r of the segment's axis LINE
 // (|w . (d x v)| <= r |d x v|) and within R = |v|/2 + r of the segment's midpoint.  Margins: the products carry at most a
@@ -332,7 +406,9 @@ __device__ __forceinline__ unsigned lv_node_step(const LvSceneDev& S, unsigned n
 // ---------------------------------------------------------------- leaf tests of the cooperative routines
 // One (ray, leaf) test.  Returns true with t and the low 32 bits of the merge key: capsules -> (original segment << 2)
 // | kind, triangles -> original triangle index; in both cases "smaller key = closer, ties to the lowest index".
-template <int PRIM>
+// LIT: -1 = intersection form from S.literalIntersection at run time (tile kernels), 0 / 1 = fixed at compile time (k_ao_rays:
+// a run-time branch around both capsule tests costs the register that pushes the kernel over its 96-VGPR budget into scratch)
+template <int PRIM, int LIT = -1>
 __device__ __forceinline__ bool lv_leaf_test(const LvSceneDev& S, unsigned leaf, f3 o, f3 d, float radius, bool capped,
                                              float& t, unsigned& low) {
     if (PRIM == LV_PRIM_TRIANGLE) {
@@ -344,7 +420,9 @@ __device__ __forceinline__ bool lv_leaf_test(const LvSceneDev& S, unsigned leaf,
     } else {
         const float4 a = S.segs[2 * size_t(leaf)], b = S.segs[2 * size_t(leaf) + 1];
         int kind;
-        const bool hit = lv_intersect_capsule(o, d, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), radius, capped, t, kind);
+        const bool hit = (LIT == 1 || (LIT == -1 && S.literalIntersection))
+                ? lv_intersect_capsule_literal(o, d, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), radius, capped, t, kind)
+                : lv_intersect_capsule(o, d, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), radius, capped, t, kind);
         if (hit) low = (S.leafSeg[leaf] << 2) | unsigned(kind);
         return hit;
     }
@@ -423,6 +501,8 @@ __device__ __forceinline__ LvHit lv_trace_closest(const LvSceneDev& S, float rad
     unsigned cur = active ? 0u : LV_INVALID;
     unsigned head = 0, tail = 0;
     float best = tMax;
+    // literal roots: cull against best + r / |d| (lv_intersect_capsule_literal); 0 otherwise
+    float slack = (PRIM == LV_PRIM_CAPSULE && S.literalIntersection) ? radius / len3(d) : 0.0f;
     while (true) {
         // leaves reached by the last step (or popped) join the FIFO
         const bool isLeaf = cur != LV_INVALID && (cur & LV_LEAF_BIT);
@@ -488,6 +568,7 @@ __device__ __forceinline__ LvHit lv_trace_closest(const LvSceneDev& S, float rad
                         oi = mk3(ro.x * inv.x, ro.y * inv.y, ro.z * inv.z);
                         tMin = ro.w;
                         best = __uint_as_float(unsigned(cm.key[owner] >> 32));
+                        slack = (PRIM == LV_PRIM_CAPSULE && S.literalIntersection) ? radius / len3(mk3(rd.x, rd.y, rd.z)) : 0.0f;
                     }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -496,7 +577,7 @@ __device__ __forceinline__ LvHit lv_trace_closest(const LvSceneDev& S, float rad
         }
         int nNow;
         do { // tight descend loop
-            if (!(cur & LV_LEAF_BIT)) cur = lv_node_step<STATS>(S, cur, oi, inv, tMin, best, st, cnt);
+            if (!(cur & LV_LEAF_BIT)) cur = lv_node_step<STATS>(S, cur, oi, inv, tMin, best + slack, st, cnt);
             const bool lf = cur != LV_INVALID && (cur & LV_LEAF_BIT);
             const unsigned long long m = __ballot(lf);
             if (m) {
@@ -607,8 +688,11 @@ __device__ __forceinline__ void lv_trace_all(const LvSceneDev& S, float radius, 
                     kind = int(low);
                 } else {
                     const float4 a = S.segs[2 * leaf], b = S.segs[2 * leaf + 1];
-                    found = lv_intersect_capsule(mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), mk3(a.x, a.y, a.z),
-                                                 mk3(b.x, b.y, b.z), radius, capped, t, kind);
+                    found = S.literalIntersection
+                            ? lv_intersect_capsule_literal(mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), mk3(a.x, a.y, a.z),
+                                                           mk3(b.x, b.y, b.z), radius, capped, t, kind)
+                            : lv_intersect_capsule(mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), mk3(a.x, a.y, a.z),
+                                                   mk3(b.x, b.y, b.z), radius, capped, t, kind);
                 }
                 if (found) {
                     if (t >= ro.w && (DYN ? t <= rd.w : t < rd.w)) { hit = true; hitRef = e; hitT = t; hitKind = unsigned(kind); }
@@ -660,7 +744,11 @@ __device__ __forceinline__ void lv_trace_all(const LvSceneDev& S, float radius, 
         }
         int nNow;
         do {
-            if (!(cur & LV_LEAF_BIT)) cur = lv_node_step<STATS, DYN ? 2 : 0>(S, cur, oi, inv, tMin, tMax, st, cnt);
+            if (!(cur & LV_LEAF_BIT))
+                cur = lv_node_step<STATS, DYN ? 2 : 0>(S, cur, oi, inv, tMin,
+                                                       (PRIM == LV_PRIM_CAPSULE && S.literalIntersection)
+                                                               ? tMax + radius / len3(mk3(1.0f / inv.x, 1.0f / inv.y, 1.0f / inv.z)) : tMax,
+                                                       st, cnt);
             const bool lf = cur != LV_INVALID && (cur & LV_LEAF_BIT);
             const unsigned long long m = __ballot(lf);
             if (m) {

@@ -168,6 +168,21 @@ inline bool intersectCapsule(V3 o, V3 d, V3 p0, V3 p1, float radius, bool capped
     return hasIntersection;
 }
 
+// The intersection shader only runs for rays that hit the segment's AABB (min(p0, p1) - r .. max(p0, p1) + r,
+// LineDataFlow.cpp:2230-2233), and a root is only meaningful near that box: in the literal mode a hit counts iff the ray's
+// line hits that box and t lies within r / |d| of the box interval.  With this rule any conservative BVH that culls against
+// best + r / |d| returns the brute-force minimum of the noisy literal roots bit for bit.
+inline bool literalOwnBoxRule(V3 o, V3 d, V3 p0, V3 p1, float radius, float hitT) {
+    const V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    const float tx0 = ((fminf(p0.x, p1.x) - radius) - o.x) * inv.x, tx1 = ((fmaxf(p0.x, p1.x) + radius) - o.x) * inv.x;
+    const float ty0 = ((fminf(p0.y, p1.y) - radius) - o.y) * inv.y, ty1 = ((fmaxf(p0.y, p1.y) + radius) - o.y) * inv.y;
+    const float tz0 = ((fminf(p0.z, p1.z) - radius) - o.z) * inv.z, tz1 = ((fmaxf(p0.z, p1.z) + radius) - o.z) * inv.z;
+    const float tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fminf(tz0, tz1));
+    const float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fmaxf(tz0, tz1));
+    const float slack = radius / length(d);
+    return tn <= tf && hitT >= tn - slack && hitT <= tf + slack;
+}
+
 inline bool intersectCapsuleLiteral(V3 o, V3 d, V3 p0, V3 p1, float radius, bool capped, float& hitTOut, int& hitKindOut) {
     bool hasIntersection = false;
     float hitT = 1e7f;
@@ -281,7 +296,8 @@ inline bool closestHit(const lvo_scene& sc, float radius, bool capped, bool useB
         cnt.prims++;
         V3 p0, p1; segPoints(sc, seg, p0, p1);
         float t; int kind;
-        if (g_dev.literalIntersection ? intersectCapsuleLiteral(o, d, p0, p1, radius, capped, t, kind)
+        if (g_dev.literalIntersection ? (intersectCapsuleLiteral(o, d, p0, p1, radius, capped, t, kind) &&
+                                         literalOwnBoxRule(o, d, p0, p1, radius, t))
                                       : intersectCapsule(o, d, p0, p1, radius, capped, t, kind)) {
             if (t >= tMin && t <= tMax && (!found || t < best || (t == best && seg < bestSeg))) {
                 found = true; best = t; bestSeg = seg; bestKind = kind;
@@ -333,7 +349,8 @@ inline void allHits(const lvo_scene& sc, float radius, bool capped, bool useBvh,
         cnt.prims++;
         V3 p0, p1; segPoints(sc, seg, p0, p1);
         float t; int kind;
-        if (g_dev.literalIntersection ? intersectCapsuleLiteral(o, d, p0, p1, radius, capped, t, kind)
+        if (g_dev.literalIntersection ? (intersectCapsuleLiteral(o, d, p0, p1, radius, capped, t, kind) &&
+                                         literalOwnBoxRule(o, d, p0, p1, radius, t))
                                       : intersectCapsule(o, d, p0, p1, radius, capped, t, kind)) {
             if (t >= tMin && t <= tMax) out.push_back(Hit{t, seg, kind});
         }

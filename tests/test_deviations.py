@@ -82,6 +82,33 @@ def test_ao_lookup_pixel_centre_rays_equal_the_projected_bilinear_sample():
 
 
 @pytest.mark.gpu
+def test_literal_intersection_form_in_hip_matches_the_oracle(hip_lib):
+    """intersection_form = literal: the HIP path evaluates the reference's textbook roots (plus the own-box rule that makes
+    them BVH-independent); hits, AO factors and frames against the oracle's literal mode -- brute force over all segments."""
+    c = small_case(width=160, height=120, n_lines=40, pts_per_line=40, line_width=0.004, intersection_form="literal", **RTAO,
+                   ambient_occlusion_iterations=2, ambient_occlusion_samples_per_frame=8)
+    ctx = c.hip_context()
+    img = ctx.render(11)
+    ao = ctx.get_ao()
+    rng = np.random.default_rng(5)
+    o = np.concatenate([np.tile(np.array([[0, 0, 0.8]], np.float32), (3000, 1)), rng.uniform(-0.2, 0.2, (3000, 3)).astype(np.float32)])
+    d = rng.normal(size=(6000, 3)).astype(np.float32)
+    d[:3000, 2] = -np.abs(d[:3000, 2]) * 3
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    t, s, k = ctx.trace_rays(o, d, 1e-4, 1000.0)
+    sc = c.oracle_scene()
+    with lvo.deviation_switches(literal_intersection=True):
+        ref, ao_ref = c.oracle_render(11)                                   # brute force
+        t2, s2, k2 = sc.trace_rays(o, d, 1e-4, 1000.0, c.line_width)        # brute force
+    assert np.array_equal(t.view(np.uint32), t2.view(np.uint32)) and np.array_equal(s, s2) and np.array_equal(k, k2)
+    assert (s != 0xFFFFFFFF).sum() > 500
+    assert np.array_equal(ao.view(np.uint32), ao_ref.view(np.uint32))
+    assert np.abs(img.astype(np.int32) - ref.astype(np.int32)).max() <= 2
+    ctx.set_option("intersection_form", "closest_approach")
+    assert not np.array_equal(ctx.render(11), img)
+
+
+@pytest.mark.gpu
 def test_full_size_deviation_report(hip_lib):
     """BASELINE.json configs 2 and 3 at 1920 x 1080: the HIP frame (closest-approach roots) against the oracle's frame with the
     reference's literal roots.  Writes gpurun_out/deviations.json (copied to profiles/ by hand)."""
@@ -106,6 +133,10 @@ def test_full_size_deviation_report(hip_lib):
             ref = sc.render_rt(P, ao=ao, use_bvh=True)
         report[name] = diff_counts(img, ref)
         assert report[name]["covered"] > 50000
+        # the same formula on both sides: what is left is the pipeline, not the formula
+        ctx.set_option("intersection_form", "literal")
+        report[name + "__hip_literal_vs_oracle_literal"] = diff_counts(ctx.render(11), ref)
+        assert report[name + "__hip_literal_vs_oracle_literal"]["differ_gt_2lsb"] == 0
     out = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out, exist_ok=True)
     report["what"] = ("HIP frame (closest-approach ray-capsule roots) vs oracle frame evaluated with the reference's literal "
