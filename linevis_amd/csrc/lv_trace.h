@@ -501,7 +501,7 @@ __device__ __forceinline__ LvHit lv_trace_closest(const LvSceneDev& S, float rad
     unsigned cur = active ? 0u : LV_INVALID;
     unsigned head = 0, tail = 0;
     float best = tMax;
-    // literal roots: cull against best + r / |d| (lv_intersect_capsule_literal); 0 otherwise
+    // literal roots: cull against [tMin - r / |d|, best + r / |d|] (lv_intersect_capsule_literal); 0 otherwise
     float slack = (PRIM == LV_PRIM_CAPSULE && S.literalIntersection) ? radius / len3(d) : 0.0f;
     while (true) {
         // leaves reached by the last step (or popped) join the FIFO
@@ -577,7 +577,7 @@ __device__ __forceinline__ LvHit lv_trace_closest(const LvSceneDev& S, float rad
         }
         int nNow;
         do { // tight descend loop
-            if (!(cur & LV_LEAF_BIT)) cur = lv_node_step<STATS>(S, cur, oi, inv, tMin, best + slack, st, cnt);
+            if (!(cur & LV_LEAF_BIT)) cur = lv_node_step<STATS>(S, cur, oi, inv, tMin - slack, best + slack, st, cnt);
             const bool lf = cur != LV_INVALID && (cur & LV_LEAF_BIT);
             const unsigned long long m = __ballot(lf);
             if (m) {
@@ -744,11 +744,12 @@ __device__ __forceinline__ void lv_trace_all(const LvSceneDev& S, float radius, 
         }
         int nNow;
         do {
-            if (!(cur & LV_LEAF_BIT))
-                cur = lv_node_step<STATS, DYN ? 2 : 0>(S, cur, oi, inv, tMin,
-                                                       (PRIM == LV_PRIM_CAPSULE && S.literalIntersection)
-                                                               ? tMax + radius / len3(mk3(1.0f / inv.x, 1.0f / inv.y, 1.0f / inv.z)) : tMax,
-                                                       st, cnt);
+            if (!(cur & LV_LEAF_BIT)) {
+                // literal roots may lie up to r / |d| outside their segment's box interval (lv_intersect_capsule_literal)
+                const float sl = (PRIM == LV_PRIM_CAPSULE && S.literalIntersection)
+                        ? radius / len3(mk3(1.0f / inv.x, 1.0f / inv.y, 1.0f / inv.z)) : 0.0f;
+                cur = lv_node_step<STATS, DYN ? 2 : 0>(S, cur, oi, inv, tMin - sl, tMax + sl, st, cnt);
+            }
             const bool lf = cur != LV_INVALID && (cur & LV_LEAF_BIT);
             const unsigned long long m = __ballot(lf);
             if (m) {

@@ -322,10 +322,12 @@ inline bool closestHit(const lvo_scene& sc, float radius, bool capped, bool useB
             float tl, tr;
             // the literal roots carry up to ~0.25 r of float32 noise in t (far more than the boxes' padding): cull against
             // best + r there, so that the traversal still returns the brute-force minimum of the noisy values
+            // (and may lie up to r / |d| outside the segment's box interval, literalOwnBoxRule: both ends of the culling interval
+            // are widened by that much)
             const float slack = g_dev.literalIntersection ? radius / sqrtf(dot(d, d)) : 0.0f;
-            const float limit = found ? fminf(best + slack, tMax) : tMax;
-            bool hl = childBox(sc, nd.left, o, inv, tMin, limit, tl);
-            bool hr = childBox(sc, nd.right, o, inv, tMin, limit, tr);
+            const float limit = found ? fminf(best + slack, tMax + slack) : tMax + slack;
+            bool hl = childBox(sc, nd.left, o, inv, tMin - slack, limit, tl);
+            bool hr = childBox(sc, nd.right, o, inv, tMin - slack, limit, tr);
             if (hl && hr) {
                 if (tr < tl) { stack[sp++] = nd.left; stack[sp++] = nd.right; }
                 else { stack[sp++] = nd.right; stack[sp++] = nd.left; }
@@ -369,8 +371,9 @@ inline void allHits(const lvo_scene& sc, float radius, bool capped, bool useBvh,
             const BvhNode& nd = sc.nodes[n];
             cnt.nodes++;
             float tl, tr;
-            if (childBox(sc, nd.right, o, inv, tMin, tMax, tr)) stack.push_back(nd.right);
-            if (childBox(sc, nd.left, o, inv, tMin, tMax, tl)) stack.push_back(nd.left);
+            const float slack = g_dev.literalIntersection ? radius / sqrtf(dot(d, d)) : 0.0f; // see closestHit
+            if (childBox(sc, nd.right, o, inv, tMin - slack, tMax + slack, tr)) stack.push_back(nd.right);
+            if (childBox(sc, nd.left, o, inv, tMin - slack, tMax + slack, tl)) stack.push_back(nd.left);
         }
         std::sort(out.begin(), out.end(), [](const Hit& a, const Hit& b) { return a.seg < b.seg; });
     }
