@@ -273,6 +273,8 @@ def main():
     ap.add_argument("--save-frame", default="")
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--dry-run", action="store_true", help="no GPU: gloo + CPU tensors + a stand-in renderer (collective sequence only)")
+    ap.add_argument("--set", action="append", default=[], metavar="KEY=VALUE",
+                    help="extra renderer setting (SettingsMap key), e.g. --set intersection_form=literal; noted in config.workload")
     args = ap.parse_args()
 
     import torch
@@ -300,7 +302,12 @@ def main():
 
     from linevis_amd import camera, tiling, transfer_function as tfm
 
-    wl = WORKLOADS[args.workload]
+    wl = dict(WORKLOADS[args.workload])
+    extra_settings = dict(kv.split("=", 1) for kv in args.set)
+    if extra_settings:
+        wl["settings"] = dict(wl["settings"], **extra_settings)
+        wl["name"] += "; overrides: " + ", ".join("%s=%s" % kv for kv in sorted(extra_settings.items()))
+        wl.pop("also", None)
     W, H = wl.get("resolution", (1920, 1080))
 
     def sync_all():
