@@ -1,0 +1,179 @@
+"""Randomised differential test: random scenes, cameras, viewports, tile rectangles and setting combinations through the
+C-ABI against the oracle -- AO factors bit for bit, frames within the RGBA8 bar, PPLL fragment multisets identical.  The fixed
+cases of test_gpu_parity.py pin what was thought of; this pins combinations nobody thought of (seeded: failures reproduce)."""
+import numpy as np
+import pytest
+
+from common import Case, max_lsb_diff
+from linevis_amd import scenes, tiling, transfer_function as tfm
+from oracle import lvo
+
+RTAO = dict(ambient_occlusion_mode="RTAO (Screen Space)", ambient_occlusion_gamma=1.0, ambient_occlusion_radius=0.1)
+LSB_TOL = 2
+
+
+def random_case(rng):
+    n_lines = int(rng.integers(1, 40))
+    pts_per_line = int(rng.integers(2, 60))
+    tr = scenes.normalize(scenes.random_curves(n_lines=n_lines, points_per_line=pts_per_line, seed=int(rng.integers(1 << 30))))
+    lw = float(rng.choice([0.002, 0.004, 0.01, 0.02, 0.05]))
+    pts, seg, _ = lvo.build_tube_aabb_render_data(tr.positions, tr.attributes, tr.line_offsets, lw)
+    W, H = int(rng.integers(17, 200)), int(rng.integers(9, 130))
+    cam = (float(rng.uniform(-0.5, 0.5)), float(rng.uniform(-0.4, 0.4)), float(rng.uniform(0.5, 1.1)))
+    bg = tuple(float(x) for x in rng.choice([0.0, 0.25, 1.0], 3)) + (1.0,)
+    s = {}
+    if rng.uniform() < 0.7:
+        s.update(RTAO, ambient_occlusion_strength=float(rng.choice([0.5, 1.0])),
+                 ambient_occlusion_iterations=int(rng.integers(1, 4)), ambient_occlusion_samples_per_frame=int(rng.integers(1, 9)),
+                 ambient_occlusion_distance_based=bool(rng.integers(2)), use_jittered_primary_rays=bool(rng.integers(2)))
+        if rng.uniform() < 0.3:
+            s.update(ambient_occlusion_gamma=float(rng.choice([0.5, 2.0])), ambient_occlusion_radius=float(rng.choice([0.03, 0.2])))
+        if rng.uniform() < 0.35:
+            s.update(ambient_occlusion_denoiser="EAW", eaw_denoiser_iterations=int(rng.integers(0, 4)),
+                     eaw_denoiser_use_shared_memory=bool(rng.integers(2)), eaw_denoiser_normal_weights=bool(rng.integers(2)))
+    if rng.uniform() < 0.4:
+        s["num_samples_per_frame"] = int(rng.integers(2, 5))
+    if rng.uniform() < 0.4:
+        s["depth_cue_strength"] = float(rng.choice([0.3, 0.8]))
+    if rng.uniform() < 0.25:
+        s["use_halos"] = False
+    if rng.uniform() < 0.25:
+        s["use_capped_tubes"] = False
+    if rng.uniform() < 0.2:
+        s["use_deterministic_sampling"] = True
+    if rng.uniform() < 0.2:
+        s["intersection_form"] = "literal"
+    transparent = rng.uniform() < 0.4
+    if transparent and rng.uniform() < 0.5:
+        s["max_depth_complexity"] = int(rng.integers(1, 6))
+    tf = tfm.standard_transparent() if transparent else tfm.standard()
+    return Case(pts, seg, tf, W, H, lw, camera_pos=cam, background=bg, **s), transparent
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(8))
+def test_random_ray_tracer_cases(hip_lib, seed):
+    import torch
+    rng = np.random.default_rng(1000 + seed)
+    for k in range(12):
+        c, _ = random_case(rng)
+        tag = "seed %d case %d: %dx%d lw %g %s" % (seed, k, c.width, c.height, c.line_width, c.settings)
+        ctx = c.hip_context()
+        img = ctx.render(11)
+        literal = c.settings.get("intersection_form") == "literal"
+        with lvo.deviation_switches(literal_intersection=literal):
+            ref, ao_ref = c.oracle_render(11)
+        if ao_ref is not None:
+            ao = ctx.get_ao()
+            if c.eaw_settings():
+                assert np.abs(ao - ao_ref).max() < 2e-5, tag
+            else:
+                assert np.array_equal(ao.view(np.uint32), ao_ref.view(np.uint32)), tag
+        assert max_lsb_diff(img, ref) <= LSB_TOL, tag
+        # a random rectangle and a random tile size reproduce the frame byte for byte
+        x0, y0 = int(rng.integers(0, c.width)), int(rng.integers(0, c.height))
+        w, h = int(rng.integers(1, c.width - x0 + 1)), int(rng.integers(1, c.height - y0 + 1))
+        assert np.array_equal(ctx.render(11, tile=(x0, y0, w, h)), img[y0:y0 + h, x0:x0 + w]), tag
+        t = int(rng.choice([16, 32, 64]))
+        tiles = tiling.make_tiles(c.width, c.height, t)
+        out = torch.zeros((len(tiles), t, t, 4), dtype=torch.uint8, device="cuda")
+        fn = tiling.hip_render_tiles_fn(ctx, 11)
+        fn(out, tiles, t, t)
+        torch.cuda.synchronize()
+        ctx.set_stream(None)
+        assert np.array_equal(tiling.detile(out.cpu().numpy(), tiles, c.width, c.height, t), img), tag
+        ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(4))
+def test_random_ppll_cases(hip_lib, seed):
+    rng = np.random.default_rng(2000 + seed)
+    for k in range(10):
+        c, _ = random_case(rng)
+        c.tf = np.ascontiguousarray(tfm.standard_transparent(), dtype=np.float32).reshape(-1, 4)
+        for key in ("num_samples_per_frame", "intersection_form", "ambient_occlusion_denoiser", "max_depth_complexity"):
+            c.settings.pop(key, None)
+        c.settings.update(ppll_max_num_frags=int(rng.choice([8, 32, 100, 200])),
+                          ppll_tile_width=int(rng.choice([1, 2, 8])), ppll_tile_height=int(rng.choice([1, 8])))
+        tag = "seed %d case %d: %dx%d lw %g %s" % (seed, k, c.width, c.height, c.line_width, c.settings)
+        ctx = c.hip_context()
+        img = ctx.render(2)
+        sc = c.oracle_scene()
+        P = c.oracle_params(sc)
+        ao = sc.render_ao(P) if P.useAmbientOcclusion else None
+        on, os_, ocnt = sc.ppll_gather(P, ao=ao)
+        pw, ph = c.padded()
+        hn, hs, hcnt = ctx.ppll_buffers(pw * ph, int(ctx.stats().ppll_pool_nodes))
+        assert hcnt == ocnt, tag
+
+        def lists(nodes, start):
+            out = {}
+            for pix in np.nonzero(start != 0xFFFFFFFF)[0]:
+                l, i = [], int(start[pix])
+                while i != 0xFFFFFFFF:
+                    l.append((int(nodes[i, 1]), int(nodes[i, 0])))
+                    i = int(nodes[i, 2])
+                out[int(pix)] = sorted(l)
+            return out
+        hl, ol = lists(hn, hs), lists(on, os_)
+        # depths bit for bit; packed colours within one RGBA8 step per channel (pow() of the device library vs libm can flip
+        # the last bit of a channel -- the only inexact function on the path)
+        assert hl.keys() == ol.keys(), tag
+        for pix in hl:
+            a, b = hl[pix], ol[pix]
+            assert [d for d, _ in a] == [d for d, _ in b], tag
+            for (_, ca), (_, cb) in zip(a, b):
+                assert all(abs(((ca >> sh) & 0xFF) - ((cb >> sh) & 0xFF)) <= 1 for sh in (0, 8, 16, 24)), tag
+        # the resolve on the HIP lists (identical multisets, possibly another order): frames agree wherever no list is cut
+        if max((len(v) for v in hl.values()), default=0) <= int(c.settings["ppll_max_num_frags"]):
+            ref = lvo.ppll_resolve(P, hn, hs)
+            assert max_lsb_diff(img, ref) <= LSB_TOL, tag
+        ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(3))
+def test_random_triangle_tube_cases(hip_lib, seed):
+    """The reference's triangle tubes as RTAO geometry and / or as the ray tracer's "Triangle Mesh" geometry mode."""
+    rng = np.random.default_rng(3000 + seed)
+    for k in range(8):
+        c, _ = random_case(rng)
+        for key in ("intersection_form", "use_capped_tubes"):
+            c.settings.pop(key, None)
+        # rebuild the trajectories of this case for the tessellator (same generator arguments are not kept: make a new scene)
+        n_lines, ppl = int(rng.integers(1, 25)), int(rng.integers(2, 40))
+        tr = scenes.normalize(scenes.random_curves(n_lines=n_lines, points_per_line=ppl, seed=int(rng.integers(1 << 30))))
+        lw = c.line_width
+        pts, seg, _ = lvo.build_tube_aabb_render_data(tr.positions, tr.attributes, tr.line_offsets, lw)
+        c = Case(pts, seg, c.tf, c.width, c.height, lw, background=c.background, **c.settings)
+        subdiv = int(rng.choice([4, 6, 8]))
+        c.settings["tube_num_subdivisions"] = subdiv
+        mesh = lvo.build_tube_triangle_render_data(tr.positions, tr.attributes, tr.line_offsets, lw, subdiv)
+        tri_ao = bool(rng.integers(2)) and "ambient_occlusion_mode" in c.settings
+        tri_colour = bool(rng.integers(2)) or not tri_ao
+        tag = "seed %d case %d: %dx%d lw %g triAO %s triColour %s %s" % (seed, k, c.width, c.height, lw, tri_ao, tri_colour, c.settings)
+        ctx = c.hip_context()
+        ctx.set_tube_triangle_mesh(*mesh)
+        if tri_ao:
+            ctx.set_option("rtao_geometry", "triangle_tubes")
+        if tri_colour:
+            ctx.set_option("geometry_mode", "Triangle Mesh")
+        img = ctx.render(11)
+        sc = c.oracle_scene()
+        P = c.oracle_params(sc)
+        tsc = lvo.TriScene(mesh[0], mesh[1], mesh[2], lw)
+        ao_ref = None
+        if P.useAmbientOcclusion:
+            ao_ref = c.oracle_ao(sc, P, render_ao=(lambda t: tsc.render_ao(P, tile=t)) if tri_ao else None)
+            ao = ctx.get_ao()
+            if c.eaw_settings():
+                assert np.abs(ao - ao_ref).max() < 2e-5, tag
+            else:
+                assert np.array_equal(ao.view(np.uint32), ao_ref.view(np.uint32)), tag
+        ref = tsc.render_rt(sc, P, ao=ao_ref) if tri_colour else sc.render_rt(P, ao=ao_ref)
+        assert max_lsb_diff(img, ref) <= LSB_TOL, tag
+        x0, y0 = int(rng.integers(0, c.width)), int(rng.integers(0, c.height))
+        w, h = int(rng.integers(1, c.width - x0 + 1)), int(rng.integers(1, c.height - y0 + 1))
+        assert np.array_equal(ctx.render(11, tile=(x0, y0, w, h)), img[y0:y0 + h, x0:x0 + w]), tag
+        ctx.close()
