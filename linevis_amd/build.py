@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT_DIR = os.path.join(HERE, "_lib")
 LIB = os.path.join(OUT_DIR, "liblinevis_hip.so")
-SOURCES = ["lv_api.hip", "lv_bvh.hip", "lv_render.hip", "lv_flow.hip", "lv_mlat.hip"]
+SOURCES = ["lv_api.hip", "lv_bvh.hip", "lv_render.hip", "lv_flow.hip", "lv_mlat.hip", "lv_svgf.hip"]
 HEADERS = ["lv_device.h", "lv_trace.h", "lv_tile.h", "lv_internal.h", os.path.join("..", "..", "include", "linevis_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-DNDEBUG"] + os.environ.get("LV_EXTRA_HIPCC_FLAGS", "").split()

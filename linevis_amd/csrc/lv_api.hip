@@ -38,6 +38,15 @@ void lv_buf_free(LvDeviceBuffer& b) {
 
 // 4x4 inverse by cofactor expansion (2x2 sub-determinants -> adjugate -> 1/det), the scheme of glm::inverse that
 // LineData::updateVulkanUniformBuffers applies (src/LineData/LineData.cpp:1290-1291).  Column-major.
+// glm operator*(mat4, mat4), column major: column j of the product = sum over k of A's column k times B[j][k], left to right
+void lv_mat4_mul(const float* A, const float* B, float* out) {
+    float r[16];
+    for (int j = 0; j < 4; j++)
+        for (int i = 0; i < 4; i++)
+            r[4 * j + i] = ((A[i] * B[4 * j] + A[4 + i] * B[4 * j + 1]) + A[8 + i] * B[4 * j + 2]) + A[12 + i] * B[4 * j + 3];
+    memcpy(out, r, sizeof r);
+}
+
 void lv_mat4_inverse(const float* m, float* inv) {
     float c00 = m[10] * m[15] - m[14] * m[11];
     float c02 = m[6] * m[15] - m[14] * m[7];
@@ -164,7 +173,10 @@ void lv_destroy(lv_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (LvDeviceBuffer* b : {&ctx->points, &ctx->segIdx, &ctx->nodes, &ctx->segs, &ctx->leafSeg, &ctx->segToLeaf, &ctx->tf,
-                              &ctx->depthMinMax, &ctx->ao, &ctx->aoAlt, &ctx->featNormal, &ctx->featNormalAlt, &ctx->featPosition, &ctx->featPositionAlt, &ctx->eawPing, &ctx->eawPong, &ctx->tilesHaloDev, &ctx->aoGbuf, &ctx->aoList, &ctx->aoSamples, &ctx->counters,
+                              &ctx->depthMinMax, &ctx->ao, &ctx->aoAlt, &ctx->featNormal, &ctx->featNormalAlt, &ctx->featPosition, &ctx->featPositionAlt, &ctx->eawPing, &ctx->eawPong, &ctx->tilesHaloDev,
+                              &ctx->fullFrameTile, &ctx->svgf.normalDepth, &ctx->svgf.normalDepthHistory, &ctx->svgf.flowFwidth,
+                              &ctx->svgf.moments, &ctx->svgf.momentsHistory, &ctx->svgf.colorHistory, &ctx->svgf.tempAccum,
+                              &ctx->svgf.tempAccumFiltered, &ctx->svgf.ping, &ctx->svgf.pong, &ctx->svgf.result, &ctx->aoGbuf, &ctx->aoList, &ctx->aoSamples, &ctx->counters,
                               &ctx->ppllNodes, &ctx->ppllStart, &ctx->ppllCount, &ctx->ppllScratch, &ctx->tilesDev, &ctx->outDev,
                               &ctx->scratchRays, &ctx->stackOverflow, &ctx->triIdx, &ctx->triVerts, &ctx->triPoints,
                               &ctx->triNodes, &ctx->tris, &ctx->flowVectors, &ctx->flowScalars, &ctx->flowMisc,
@@ -215,6 +227,10 @@ int lv_set_lines(lv_ctx* ctx, const lv_line_point* points, uint32_t num_points, 
     ctx->numPoints = num_points;
     ctx->numSegs = num_segments;
     ctx->accelValid = false;
+    // VulkanRayTracedAmbientOcclusionPass::setLineData (.cpp:437-460): denoiser->resetFrameNumber(), globalFrameNumber = 0,
+    // lastFrameViewProjectionMatrix = the current camera's
+    ctx->aoGlobalFrameNumber = 0;
+    ctx->lastFrameViewProjValid = false;
     return LV_OK;
 }
 
@@ -397,10 +413,22 @@ int lv_set_option(lv_ctx* ctx, const char* key, const char* value) {
         o.aoJitterPrimary = parseBool(value);
     } else if (k == "ambient_occlusion_denoiser") {
         // DENOISER_NAMES, Denoiser.hpp:61-65,96-100 (VulkanRayTracedAmbientOcclusion.cpp:683-696)
-        if (strcmp(value, "None") == 0) o.eawEnabled = false;
-        else if (strcmp(value, "Edge-Avoiding \xC3\x80-Trous Wavelet Transform") == 0 || strcmp(value, "EAW") == 0) o.eawEnabled = true;
+        const bool wasSvgf = o.svgfEnabled;
+        if (strcmp(value, "None") == 0) { o.eawEnabled = false; o.svgfEnabled = false; }
+        else if (strcmp(value, "Edge-Avoiding \xC3\x80-Trous Wavelet Transform") == 0 || strcmp(value, "EAW") == 0) { o.eawEnabled = true; o.svgfEnabled = false; }
+        else if (strcmp(value, "SVGF") == 0) { o.eawEnabled = false; o.svgfEnabled = true; }
         else return lv_fail(ctx, LV_E_INVALID, "ambient_occlusion_denoiser '%s' is not provided (None | Edge-Avoiding \xC3\x80-Trous "
-                                               "Wavelet Transform)", value);
+                                               "Wavelet Transform | SVGF)", value);
+        if (o.svgfEnabled != wasSvgf) { ctx->svgf.historyValid = false; ctx->aoResult = nullptr; } // createDenoiser(): fresh history
+    } else if (k == "svgf_denoiser_iterations") {                // maxNumIterations, SVGF.cpp:427-436 (GUI only in the reference)
+        if (!parseUint(value, u) || u > 5) return bad();
+        o.svgfIterations = u;
+    } else if (k == "svgf_denoiser_allowed_z_dist") {            // SVGF.hpp:70
+        if (!parseFloat(value, f) || !(f >= 0.0f)) return bad();
+        o.svgfAllowedZDist = f;
+    } else if (k == "svgf_denoiser_allowed_normal_dist") {       // SVGF.hpp:71
+        if (!parseFloat(value, f) || !(f >= 0.0f)) return bad();
+        o.svgfAllowedNormalDist = f;
     } else if (k == "eaw_denoiser_iterations") {                 // EAWDenoiser.cpp:402-430
         if (!parseUint(value, u) || u > 5) return bad();
         o.eawIterations = u;

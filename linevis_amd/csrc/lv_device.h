@@ -114,6 +114,9 @@ struct LvUniforms {
     float depthCueStrength, aoStrength, aoGamma, attrMin, attrMax;
     uint32_t tfN;
     uint32_t aoSamplesPerFrame, aoUseDistance, aoJitterPrimary, aoFrameNumber;
+    // seeds of the RTAO pass: = aoFrameNumber, except under SVGF (useGlobalFrameNumber: a counter that camera moves do not
+    // reset, while aoFrameNumber stays 0 = DISABLE_ACCUMULATION), VulkanRayTracedAmbientOcclusion.cpp:415-421,576-581
+    uint32_t aoGlobalFrameNumber;
     float aoRadius, subdivisionCorrectionFactor;
     uint32_t ppllMaxNumFrags, ppllLinkedListSize, ppllTileW, ppllTileH, ppllPaddedW, ppllPaddedH;
     // static RTAO prebaking (STATIC_AMBIENT_OCCLUSION_PREBAKING, AmbientOcclusion.glsl:29-38)
@@ -121,6 +124,14 @@ struct LvUniforms {
     // getAoFactor of the colour pass (AmbientOcclusion.glsl:84-99): 1 = project the hit and sample the AO image bilinearly
     // (jittered primary rays), 0 = the launching pixel's own texel (pixel-centre rays project onto their texel centre)
     uint32_t aoProjectLookup;
+};
+
+// Feature maps SVGF asks the RTAO pass for (SVGF.cpp:88-96; VulkanRayTracedAmbientOcclusion.glsl:350-464, DISABLE_ACCUMULATION
+// branches), two float4 images: {world-space normal, depth} and {flow.xy, depth fwidth, 0}.  normalDepth == nullptr: not written.
+struct LvSvgfFeat {
+    float4* normalDepth;
+    float4* flowFwidth;
+    float lastFrameViewProj[16];
 };
 
 // HBM-resident scene (all read-only during rendering)

@@ -16,6 +16,19 @@ struct LvDeviceBuffer {
     size_t bytes = 0;
 };
 
+// Temporal state of the SVGF denoiser (lv_svgf.hip): SVGF_Texture_Pack, SVGF.hpp
+struct LvSvgfState {
+    LvDeviceBuffer normalDepth, normalDepthHistory;   // float4 {world normal, depth}: this frame / previous frame
+    LvDeviceBuffer flowFwidth;                        // float4 {flow.xy, depth fwidth, 0}
+    LvDeviceBuffer moments, momentsHistory;           // float4 {m1, m2, history length, 0}
+    LvDeviceBuffer colorHistory;                      // float: colour after the first a-trous pass of the previous frame
+    LvDeviceBuffer tempAccum, tempAccumFiltered;      // float2 {colour, variance}: reprojection output, after the moments filter
+    LvDeviceBuffer ping, pong;                        // float2: a-trous passes
+    LvDeviceBuffer result;                            // float: the denoised AO image
+    uint32_t width = 0, height = 0;
+    bool historyValid = false;                        // false: clear the history images before the next frame
+};
+
 // Settings with the reference's defaults (file:line next to each value).
 struct LvOptions {
     float lineWidth = 0.002f;                 // src/Loaders/DataSetList.hpp:46
@@ -55,6 +68,11 @@ struct LvOptions {
     bool eawColorWeights = true, eawPositionWeights = true, eawNormalWeights = true;
     float eawPhiColor = 0.49f, eawPhiPosition = 0.3f, eawPhiNormal = 0.1f;
     bool eawUseSharedMemory = true;           // true: EAWDenoise.Compute (default), false: EAWDenoise.Fragment
+    // ambient_occlusion_denoiser = "SVGF" (Denoiser.hpp:65).  The reference exposes these in the GUI only (SVGF.cpp:427-436,
+    // SVGF.hpp:70-72,115); the svgf_denoiser_* keys are this build's.
+    bool svgfEnabled = false;
+    uint32_t svgfIterations = 5;              // maxNumIterations, SVGF.hpp:115 (GUI range 0..5)
+    float svgfAllowedZDist = 0.002f, svgfAllowedNormalDist = 0.02f; // SVGF.hpp:70-71
     bool literalIntersection = false;         // intersection_form: false = closest approach (default), true = the reference's literal roots
     bool mlatRecordTrace = false;             // with collect_stats: record every pixel's candidate visiting order
     uint32_t mlatTraceCapacity = 1u << 22;    // records (16 B each)
@@ -114,6 +132,11 @@ struct lv_ctx {
     LvDeviceBuffer featNormal, featNormalAlt, featPosition, featPositionAlt; // EAW feature maps (float4 per pixel) + ping-pong
     LvDeviceBuffer eawPing, eawPong;          // a-trous passes
     const float* aoResult = nullptr;          // what the colour pass samples: ao (raw) or the denoised image
+    LvSvgfState svgf;
+    LvDeviceBuffer fullFrameTile;             // one tile origin (0, 0): the SVGF chain always covers the viewport
+    uint32_t aoGlobalFrameNumber = 0;         // RTAO iterations since lv_set_lines (globalFrameNumber, ...AmbientOcclusion.cpp:582)
+    float lastFrameViewProj[16];              // projection * view at the previous RTAO iteration (:456,631)
+    bool lastFrameViewProjValid = false;
     uint32_t tilesHalo = 0;                   // halo the uploaded tilesHaloDev list was built for
     LvDeviceBuffer tilesHaloDev;              // tile origins - 1 (AO pass on dilated tiles)
     std::vector<uint32_t> tilesHaloHost;
@@ -189,8 +212,12 @@ int lv_frame_depth_range(lv_ctx* ctx);
 int lv_frame_ppll_resolve_only(lv_ctx* ctx, const uint32_t* nodes, uint64_t numNodes, const uint32_t* start,
                                uint64_t numPixels, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, uint8_t* out);
 void lv_fill_uniforms(const lv_ctx* ctx, LvUniforms& U);
+// lv_svgf.hip
+int lv_svgf_prepare(lv_ctx* ctx);
+int lv_svgf_denoise(lv_ctx* ctx, const float* noisy);
 // lv_flow.hip
 int lv_flow_set_grid(lv_ctx* ctx, const float* vectorField, uint32_t xs, uint32_t ys, uint32_t zs, float dx, float dy,
                      float dz, const float* const* scalarFields, uint32_t numScalarFields);
 int lv_flow_trace(lv_ctx* ctx, const float* seeds, uint32_t numSeeds, const lv_streamline_settings* settings);
 void lv_mat4_inverse(const float* m, float* inv);
+void lv_mat4_mul(const float* A, const float* B, float* out);

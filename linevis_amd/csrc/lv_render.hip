@@ -105,7 +105,8 @@ __global__ __launch_bounds__(LV_BLOCK) void k_ao_primary(const LvUniforms U, con
                                                          const float* aoIn, float* ao, float4* __restrict__ gbuf,
                                                          uint32_t* __restrict__ groupCount, LvDevCounters* dc,
                                                          const float4* featNormalIn, float4* featNormal,
-                                                         const float4* featPositionIn, float4* featPosition) {
+                                                         const float4* featPositionIn, float4* featPosition,
+                                                         const LvSvgfFeat SF) {
     __shared__ unsigned s_stack[LV_STACK_LDS * LV_BLOCK];
     LV_COOP_SHARED(LV_BLOCK / LV_WAVE);
     LV_COOP_MEM(cm);
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(LV_BLOCK) void k_ao_primary(const LvUniforms U, con
     bool hasHit = false;
     float4 g0, g1, g2;
     const uint32_t pix = px.x + px.y * U.width;
-    const uint32_t globalFrameNumber = U.aoFrameNumber; // VulkanRayTracedAmbientOcclusion.cpp:576-581
+    const uint32_t globalFrameNumber = U.aoGlobalFrameNumber; // VulkanRayTracedAmbientOcclusion.cpp:576-581
     uint32_t seed = lv_tea(pix, globalFrameNumber);
     float xix = 0.5f, xiy = 0.5f;
     if (U.aoJitterPrimary) { xix = lv_rnd(seed); xiy = lv_rnd(seed); }
@@ -203,6 +204,27 @@ __global__ __launch_bounds__(LV_BLOCK) void k_ao_primary(const LvUniforms U, con
         }
         featNormal[pix] = make_float4(n.x, n.y, n.z, 0.0f);
         featPosition[pix] = make_float4(q.x, q.y, q.z, 1.0f);
+    }
+    if (SF.normalDepth && px.inView) {
+        // SVGF's maps, not accumulated: world-space normal (0 on a miss), depth = -z_view (farDistance on a miss), flow =
+        // writePos - the hit's pixel position under last frame's view-projection, depth fwidth = |cot| of the angles between
+        // the view-space normal and the camera x / y axes (glsl:350-464)
+        const f3 sn = hasHit ? mk3(g2.x, g2.y, g2.z) : mk3(0.0f, 0.0f, 0.0f);
+        const f3 vp = hasHit ? mk3(g0.x, g0.y, g0.z) : mk3(0.0f, 0.0f, 0.0f);
+        const f4 pv = mulM4(U.view, vp.x, vp.y, vp.z, 1.0f);
+        float fx = 0.0f, fy = 0.0f, fw = 0.0f;
+        if (hasHit) {
+            f4 ndc = mulM4(SF.lastFrameViewProj, vp.x, vp.y, vp.z, 1.0f);
+            ndc.x /= ndc.w; ndc.y /= ndc.w;
+            fx = float(px.x) - ((0.5f * ndc.x + 0.5f) * float(U.width) - 0.5f);
+            fy = float(px.y) - ((0.5f * ndc.y + 0.5f) * float(U.height) - 0.5f);
+            const float* m = U.invView;
+            const float A = ((m[0] * sn.x + m[1] * sn.y) + m[2] * sn.z) + m[3] * 0.0f;
+            const float B = ((m[4] * sn.x + m[5] * sn.y) + m[6] * sn.z) + m[7] * 0.0f;
+            fw = fabsf(A / sqrtf(1.0f - A * A)) + fabsf(B / sqrtf(1.0f - B * B));
+        }
+        SF.normalDepth[pix] = make_float4(sn.x, sn.y, sn.z, hasHit ? -pv.z : U.farDist);
+        SF.flowFwidth[pix] = make_float4(fx, fy, fw, 0.0f);
     }
     // active-ray compaction: ballot + prefix popcount, one atomic per wave -- PER 64x64-PIXEL GROUP (all pixels of a wave
     // belong to one group): the G-buffer is segmented by group, slot = group * 4096 + position inside the group's segment,
@@ -475,7 +497,7 @@ __global__ __launch_bounds__(LV_AO_BLOCK, 5) void k_ao_rays(const LvUniforms U, 
                         const uint2 skip = lcgSkip[2u * (sub * spp + smpIdx)];
                         seed = skip.x * lv_tea(pix /* = vertex */, U.aoFrameNumber) + skip.y;
                     } else {
-                        seed = lv_tea(pix, U.aoFrameNumber * spp + smpIdx);
+                        seed = lv_tea(pix, U.aoGlobalFrameNumber * spp + smpIdx);
                     }
                     const float xi0 = lv_rnd(seed), xi1 = lv_rnd(seed);
                     float sn, cs;
@@ -1110,6 +1132,7 @@ void lv_fill_uniforms(const lv_ctx* ctx, LvUniforms& U) {
     U.aoUseDistance = o.aoUseDistance;
     U.aoJitterPrimary = o.aoJitterPrimary;
     U.aoFrameNumber = 0;
+    U.aoGlobalFrameNumber = 0;
     U.aoRadius = o.aoRadius;
     // VulkanRayTracedAmbientOcclusion.cpp:588
     U.subdivisionCorrectionFactor = cosf(3.1415926535897932f / float(o.tubeNumSubdivisions));
@@ -1196,8 +1219,27 @@ static int lv_run_ao(lv_ctx* ctx, LvUniforms& U, LvSceneDev& S, const LvTiles& T
     // ... and the EAW denoiser (ambient_occlusion_denoiser) reads 2 * (2^iterations - 1) pixels around every pixel it filters
     // (a-trous passes with step widths 1, 2, 4, ...): the same mechanism with a wider halo.
     const bool eaw = ctx->opt.eawEnabled && ctx->opt.eawIterations > 0u;
-    const uint32_t haloPx = (U.aoProjectLookup ? 1u : 0u) + (eaw ? 2u * ((1u << ctx->opt.eawIterations) - 1u) : 0u);
+    // ... and SVGF is temporal: its history is read at reprojected positions anywhere in the picture, so the RTAO pass and the
+    // denoiser always cover the whole viewport (one tile at the origin, no halo needed), whatever tiles the call renders.
+    const bool svgf = ctx->opt.svgfEnabled;
+    const uint32_t haloPx = svgf ? 0u : (U.aoProjectLookup ? 1u : 0u) + (eaw ? 2u * ((1u << ctx->opt.eawIterations) - 1u) : 0u);
     const bool halo = haloPx != 0u;
+    if (svgf) {
+        if (!ctx->fullFrameTile.ptr) {
+            if ((rc = lv_buf_reserve(ctx, ctx->fullFrameTile, 8))) return rc;
+            LV_HIP(ctx, hipMemsetAsync(ctx->fullFrameTile.ptr, 0, 8, st));
+        }
+        T.tilesXY = (const uint32_t*)ctx->fullFrameTile.ptr;
+        T.numTiles = 1;
+        T.tileW = ctx->width;
+        T.tileH = ctx->height;
+        T.blocksX = ((T.tileW + 63u) / 64u) * 4u;
+        T.blocksY = ((T.tileH + 63u) / 64u) * 4u;
+        const uint64_t nb = uint64_t(T.blocksX) * T.blocksY;
+        gridTiles = uint32_t((nb + 127u) / 128u) * 128u;
+        maxPixels = uint64_t(T.tileW) * T.tileH;
+        if ((rc = lv_svgf_prepare(ctx))) return rc;
+    }
     if (halo) {
         const uint32_t n = Tcolour.numTiles;
         if ((rc = lv_buf_reserve(ctx, ctx->tilesHaloDev, size_t(n) * 8))) return rc;
@@ -1252,6 +1294,23 @@ static int lv_run_ao(lv_ctx* ctx, LvUniforms& U, LvSceneDev& S, const LvTiles& T
     const uint32_t iterEnd = progressive ? std::min(ctx->opt.frameNumber + 1u, ctx->opt.aoIterations) : ctx->opt.aoIterations;
     for (uint32_t iter = iterBegin; iter < iterEnd; iter++) {
         U.aoFrameNumber = iter; // rtaoRenderPass->setFrameNumber(accumulatedFramesCounter), VulkanRayTracedAmbientOcclusion.cpp:92
+        U.aoGlobalFrameNumber = iter;
+        LvSvgfFeat SF;
+        SF.normalDepth = nullptr;
+        SF.flowFwidth = nullptr;
+        if (svgf) {
+            // DISABLE_ACCUMULATION + useGlobalFrameNumber (SVGF.hpp:81-82; VulkanRayTracedAmbientOcclusion.cpp:415-421,576-581)
+            U.aoFrameNumber = 0;
+            U.aoGlobalFrameNumber = ctx->aoGlobalFrameNumber;
+            SF.normalDepth = (float4*)ctx->svgf.normalDepth.ptr;
+            SF.flowFwidth = (float4*)ctx->svgf.flowFwidth.ptr;
+            float vp[16];
+            lv_mat4_mul(ctx->proj, ctx->view, vp);
+            memcpy(SF.lastFrameViewProj, ctx->lastFrameViewProjValid ? ctx->lastFrameViewProj : vp, sizeof vp);
+            memcpy(ctx->lastFrameViewProj, vp, sizeof vp);
+            ctx->lastFrameViewProjValid = true;
+        }
+        ctx->aoGlobalFrameNumber++;
         LV_HIP(ctx, hipMemsetAsync(tileCount, 0, size_t(numGroups) * 4, st));
         LV_HIP(ctx, hipMemsetAsync(&dc->aoQueueHead, 0, 8, st));
         const uint32_t grid = uint32_t(gridRays);
@@ -1267,7 +1326,7 @@ static int lv_run_ao(lv_ctx* ctx, LvUniforms& U, LvSceneDev& S, const LvTiles& T
         float4* fpOut = eaw ? (float4*)ctx->featPositionAlt.ptr : nullptr;
 #define LV_LAUNCH_AOP(ST, PR)                                                                                 \
     LV_TIMED_LAUNCH(ctx, LV_KERNEL_AO_PRIMARY, (k_ao_primary<ST, PR><<<gridTiles, LV_BLOCK, 0, st>>>(        \
-            U, SA, T, aoIn, ao, (float4*)ctx->aoGbuf.ptr, tileCount, dc, fnIn, fnOut, fpIn, fpOut)))
+            U, SA, T, aoIn, ao, (float4*)ctx->aoGbuf.ptr, tileCount, dc, fnIn, fnOut, fpIn, fpOut, SF)))
 #define LV_LAUNCH_AO(ST, AH, PR) \
     LV_TIMED_LAUNCH(ctx, LV_KERNEL_AO_RAYS, (k_ao_rays<ST, AH, PR><<<grid, LV_AO_BLOCK, 0, st>>>(U, SA, g, smp, dc, tileBase, numGroups, tileCap)))
 #define LV_LAUNCH_AO_LIT(ST, AH) \
@@ -1292,8 +1351,11 @@ static int lv_run_ao(lv_ctx* ctx, LvUniforms& U, LvSceneDev& S, const LvTiles& T
         k_ao_reduce<false><<<nblocks(maxPixels), LV_BLOCK, 0, st>>>(U, g, smp, aoIn, ao, dc, tileBase, numGroups, tileCap);
         if (halo) std::swap(ctx->ao, ctx->aoAlt);
         if (eaw) { std::swap(ctx->featNormal, ctx->featNormalAlt); std::swap(ctx->featPosition, ctx->featPositionAlt); }
+        // temporal denoiser: denoise() belongs to every _render (VulkanRayTracedAmbientOcclusion.cpp:633-651), its history advances
+        // with every RTAO iteration
+        if (svgf && (rc = lv_svgf_denoise(ctx, (const float*)ctx->ao.ptr))) return rc;
     }
-    if (iterEnd > iterBegin || !ctx->aoResult) ctx->aoResult = (const float*)ctx->ao.ptr;
+    if (iterEnd > iterBegin || !ctx->aoResult) ctx->aoResult = svgf ? (const float*)ctx->svgf.result.ptr : (const float*)ctx->ao.ptr;
     if (eaw && iterEnd > iterBegin) {
         // denoiser->denoise() after the RTAO pass (VulkanRayTracedAmbientOcclusion.cpp:633-651): the accumulation keeps running
         // on the raw image, the colour pass samples the denoised one
@@ -1400,10 +1462,13 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
             // with the AO halo the AO pass runs on tiles of (tileW + 2) x (tileH + 2) pixels (lv_run_ao)
             const uint32_t haloPx = (U.aoProjectLookup ? 1u : 0u) +
                                     ((ctx->opt.eawEnabled && ctx->opt.eawIterations) ? 2u * ((1u << ctx->opt.eawIterations) - 1u) : 0u);
-            const uint64_t tw = tileW + 2u * haloPx, th = tileH + 2u * haloPx;
-            const uint64_t nbAo = uint64_t(numTiles) * (((tw + 63u) / 64u) * 4u) * (((th + 63u) / 64u) * 4u);
+            // ... and under SVGF on the whole viewport
+            const bool svgf = ctx->opt.svgfEnabled;
+            const uint64_t tw = svgf ? ctx->width : tileW + 2u * haloPx, th = svgf ? ctx->height : tileH + 2u * haloPx;
+            const uint64_t nAo = svgf ? 1u : numTiles;
+            const uint64_t nbAo = nAo * (((tw + 63u) / 64u) * 4u) * (((th + 63u) / 64u) * 4u);
             const uint64_t gridAo = ((nbAo + 127u) / 128u) * 128u;
-            need = std::max(need, lv_overflow_bytes(ctx, std::max<uint64_t>(lv_ao_grid(ctx, uint64_t(numTiles) * tw * th * U.aoSamplesPerFrame), gridAo),
+            need = std::max(need, lv_overflow_bytes(ctx, std::max<uint64_t>(lv_ao_grid(ctx, nAo * tw * th * U.aoSamplesPerFrame), gridAo),
                                                     LV_AO_STACK_LDS, ctx->opt.aoTriangleTubes));
         }
         if (aoBake)

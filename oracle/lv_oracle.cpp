@@ -34,7 +34,7 @@
 #include <omp.h>
 #endif
 
-LvoAoFeatureSink g_lvoAoFeatures = {nullptr, nullptr};
+LvoAoFeatureSink g_lvoAoFeatures = {};
 
 namespace {
 
@@ -873,8 +873,10 @@ void lvo_render_ao(const lvo_scene* sc, const lvo_params* Pp, int useBvh, uint32
     const bool capped = P.useCappedTubes != 0;
     uint64_t rays = 0, nodes = 0, prims = 0;
     for (uint32_t iter = 0; iter < P.aoIterations; iter++) {
-        const uint32_t frameNumber = iter;
-        const uint32_t globalFrameNumber = frameNumber; // VulkanRayTracedAmbientOcclusion.cpp:576-581
+        // SVGF: DISABLE_ACCUMULATION (no running means) + useGlobalFrameNumber (seeds from a counter that onHasMoved does not
+        // reset), VulkanRayTracedAmbientOcclusion.cpp:415-421,576-581
+        const uint32_t frameNumber = g_lvoAoFeatures.svgf ? 0u : iter;
+        const uint32_t globalFrameNumber = g_lvoAoFeatures.svgf ? g_lvoAoFeatures.globalFrameNumber + iter : frameNumber;
 #pragma omp parallel for schedule(dynamic, 1) reduction(+ : rays, nodes, prims)
         for (int64_t tileIdx = 0; tileIdx < lvoTileCount(w, h); tileIdx++) { // 16x16-pixel tiles
             Counters cnt;
@@ -890,6 +892,7 @@ void lvo_render_ao(const lvo_scene* sc, const lvo_params* Pp, int useBvh, uint32
                 primaryRay(P, F, x, y, xix, xiy, o, d);
                 Hit hit;
                 float aoFactor = 1.0f;
+                bool hasHitSurface = false;
                 V3 featNormal = v3(0, 0, 0), featPosition = v3(0, 0, 0); // surfaceNormal / vertexPositionWorld of a miss, glsl:211-212
                 if (closestHit(*sc, F.radius, capped, useBvh != 0, o, d, 0.0001f, 1000.0f, hit, cnt)) {
                     const lvo_line_point& lp0 = sc->pts[sc->segIdx[2 * hit.seg]];
@@ -905,7 +908,7 @@ void lvo_render_ao(const lvo_scene* sc, const lvo_params* Pp, int useBvh, uint32
                     V3 surfaceTangent = normalize((1.0f - ts) * ld3(lp0.lineTangent) + ts * ld3(lp1.lineTangent));
                     V3 surfaceBitangent = cross(surfaceNormal, surfaceTangent);
                     float offsetFactor = length(linePosition - vertexPositionWorld) / F.subdivisionCorrectionFactor;
-                    featNormal = surfaceNormal; featPosition = vertexPositionWorld;
+                    hasHitSurface = true; featNormal = surfaceNormal; featPosition = vertexPositionWorld;
                     aoFactor = 0.0f;
                     for (uint32_t s = 0; s < P.aoSamplesPerFrame; s++) {
                         uint32_t sseed = tea(pix, globalFrameNumber * P.aoSamplesPerFrame + s);
@@ -933,7 +936,7 @@ void lvo_render_ao(const lvo_scene* sc, const lvo_params* Pp, int useBvh, uint32
                 size_t idx = size_t(y) * P.width + x;
                 if (frameNumber != 0) aoFactor = mixf(aoOut[idx], aoFactor, 1.0f / float(frameNumber + 1));
                 aoOut[idx] = aoFactor;
-                writeAoFeatures(P, F, idx, frameNumber, featNormal, featPosition);
+                writeAoFeatures(P, F, x, y, idx, frameNumber, hasHitSurface, featNormal, featPosition);
             }
             rays += cnt.rays; nodes += cnt.nodes; prims += cnt.prims;
         }
@@ -1649,6 +1652,238 @@ void lvo_compute_fragment_color_batch(const lvo_scene* sc, const lvo_params* Pp,
 void lvo_set_ao_feature_outputs(float* normalMap, float* positionMap) {
     g_lvoAoFeatures.normal = normalMap;
     g_lvoAoFeatures.position = positionMap;
+}
+
+void lvo_set_svgf_feature_outputs(float* normalWorld, float* depth, float* flow, float* depthFwidth, int enable,
+                                  uint32_t globalFrameNumber, const float* lastFrameViewProj) {
+    g_lvoAoFeatures.normalWorld = normalWorld;
+    g_lvoAoFeatures.depth = depth;
+    g_lvoAoFeatures.flow = flow;
+    g_lvoAoFeatures.depthFwidth = depthFwidth;
+    g_lvoAoFeatures.svgf = enable;
+    g_lvoAoFeatures.globalFrameNumber = globalFrameNumber;
+    for (int i = 0; i < 16; i++) g_lvoAoFeatures.lastFrameViewProj[i] = lastFrameViewProj ? lastFrameViewProj[i] : 0.0f;
+}
+
+// glm operator*(mat4, mat4), column major: column j of the product = sum over k of A's column k times B[j][k], left to right
+// (lastFrameViewProjectionMatrix = projection * view, VulkanRayTracedAmbientOcclusion.cpp:456,631)
+void lvo_mat4_mul(const float* A, const float* B, float* out) {
+    float r[16];
+    for (int j = 0; j < 4; j++)
+        for (int i = 0; i < 4; i++)
+            r[4 * j + i] = ((A[i] * B[4 * j] + A[4 + i] * B[4 * j + 1]) + A[8 + i] * B[4 * j + 2]) + A[12 + i] * B[4 * j + 3];
+    memcpy(out, r, sizeof r);
+}
+
+// ---------------------------------------------------------------- SVGF (Data/Shaders/Denoiser/SVGF.glsl, svgf_common.glsl;
+// src/Renderers/Scattering/Denoiser/SVGF.cpp) on the AO image.  noisy_texture = vec4(ao, ao, ao, 1): the three colour channels
+// stay equal through every pass, so the colour images are {colour, variance} pairs.  One call = SVGFDenoiser::denoise():
+// reproject -> filter moments -> `iterations` a-trous passes -> history copies (SVGF.cpp:107-174).  The history images are the
+// caller's (cleared to 0 = recreateSwapchain, SVGF.cpp:181-286) and updated in place.
+// Build-owned definitions where the reference leaves the result open:
+//   * texelFetch outside the image (filter_variance at the image border, SVGF.glsl:368-391) returns 0;
+//   * the moments filter reads temp_accum while other invocations overwrite it (SVGF.glsl:300-352, a data race): every
+//     invocation reads the image as the reprojection pass left it;
+//   * `out` parameters the callee did not write (prev_moments when load_moments_and_history_length fails) are 0;
+//   * pow(x, 128) of compute_weight is seven squarings (exact products instead of exp2(128 log2 x)).
+namespace {
+inline float svgfPow128(float x) { for (int i = 0; i < 7; i++) x = x * x; return x; }
+// svgf_common.glsl:28-40
+inline float svgfComputeWeight(float centerDepth, float offsetDepth, float phiDepth, const float* centerNormal,
+                               const float* offsetNormal, float centerColor, float offsetColor, float phiColor) {
+    const float weightN = svgfPow128(fmaxf(0.0f, (centerNormal[0] * offsetNormal[0] + centerNormal[1] * offsetNormal[1]) +
+                                                     centerNormal[2] * offsetNormal[2]));
+    const float weightZ = (phiDepth == 0.0f) ? 0.0f : fabsf(centerDepth - offsetDepth) / phiDepth;
+    const float weightC = fabsf(centerColor - offsetColor) * 2.0f / phiColor;
+    return expf((0.0f - fmaxf(weightC, 0.0f)) - fmaxf(weightZ, 0.0f)) * weightN;
+}
+} // namespace
+
+void lvo_svgf_denoise(uint32_t width, uint32_t height, const float* noisy, const float* normalMap, const float* depthMap,
+                      const float* depthFwidthMap, const float* flowMap, int iterations, float allowedZDist,
+                      float allowedNormalDist, float* colorHistory, float* momentsHistory, float* normalHistory,
+                      float* depthHistory, float* out) {
+    const int W = int(width), H = int(height);
+    const size_t n = size_t(width) * height;
+    std::vector<float> tempAccum(2 * n), accumMoments(4 * n, 0.0f);
+    // is_reprj_valid, SVGF.glsl:72-86 (the bounds test comes first: the history texels of rejected coordinates are never used)
+    auto reprjValid = [&](int cx, int cy, float z, const float* normal) {
+        if (cx < 1 || cy < 1 || cx > W - 1 || cy > H - 1) return false;
+        const size_t oi = size_t(cy) * width + cx;
+        const float zPrev = depthHistory[oi];
+        const float* np = normalHistory + 4 * oi;
+        if (fabsf(zPrev - z) > allowedZDist) return false;
+        const float dx = np[0] - normal[0], dy = np[1] - normal[1], dz = np[2] - normal[2];
+        if (sqrtf((dx * dx + dy * dy) + dz * dz) > allowedNormalDist) return false;
+        return true;
+    };
+    // ---- Compute-Reproject, SVGF.glsl:201-261
+#pragma omp parallel for schedule(dynamic, 8)
+    for (int64_t yy = 0; yy < int64_t(H); yy++) {
+        for (int x = 0; x < W; x++) {
+            const int y = int(yy);
+            const size_t ci = size_t(y) * width + x;
+            const float mx = flowMap[2 * ci], my = flowMap[2 * ci + 1];
+            float prevM0 = 0.0f, prevM1 = 0.0f, historyLength = 0.0f;
+            const int ipx = int((0.5f + float(x)) - mx), ipy = int((0.5f + float(y)) - my);
+            bool success = !(ipx < 0 || ipy < 0 || ipx >= W || ipy >= H); // load_moments_and_history_length, :186-199
+            if (success) {
+                const float* mh = momentsHistory + 4 * (size_t(ipy) * width + ipx);
+                prevM0 = mh[0]; prevM1 = mh[1]; historyLength = mh[2];
+            }
+            const float color = noisy[ci];
+            float colorLastFrame = colorHistory[ci];
+            if (success) {
+                const float ppx = (0.01f + float(x)) - mx, ppy = (0.01f + float(y)) - my;
+                const int qx = int(ppx), qy = int(ppy);
+                const float depth = depthMap[ci];
+                const float* normal = normalMap + 4 * ci;
+                // try_2x2_tap, :88-139 (offsets and weights exactly as listed there)
+                const int offs[4][2] = {{0, 0}, {0, 1}, {1, 0}, {1, 1}};
+                bool valids[4], validFound = false;
+                for (int i = 0; i < 4; i++) {
+                    valids[i] = reprjValid(qx + offs[i][0], qy + offs[i][1], depth, normal);
+                    validFound = validFound || valids[i];
+                }
+                if (validFound) {
+                    const float fx = ppx - floorf(ppx), fy = ppy - floorf(ppy);
+                    const float w[4] = {(1.0f - fx) * (1.0f - fy), fx * (1.0f - fy), (1.0f - fx) * fy, fx * fy};
+                    float colorBilinear = 0.0f, m0 = 0.0f, m1 = 0.0f, sumW = 0.0f;
+                    for (int i = 0; i < 4; i++) {
+                        if (!valids[i]) continue;
+                        const size_t oi = size_t(qy + offs[i][1]) * width + (qx + offs[i][0]);
+                        m0 += w[i] * momentsHistory[4 * oi];
+                        m1 += w[i] * momentsHistory[4 * oi + 1];
+                        colorBilinear += w[i] * colorHistory[oi];
+                        sumW += w[i];
+                    }
+                    validFound = sumW >= 0.001f;
+                    if (validFound) { colorLastFrame = colorBilinear / sumW; prevM0 = m0 / sumW; prevM1 = m1 / sumW; }
+                }
+                success = validFound;
+                if (!success) {
+                    // try_3x3_bilat, :141-184
+                    float nValid = 0.0f, fc = 0.0f, f0 = 0.0f, f1 = 0.0f;
+                    for (int dy = -1; dy <= 1; dy++) {
+                        for (int dx = -1; dx <= 1; dx++) {
+                            const int ox = qx + dx, oy = qy + dy;
+                            if (ox < 1 || oy < 1 || ox >= W || oy >= H) continue;
+                            if (reprjValid(ox, oy, depth, normal)) {
+                                const size_t oi = size_t(oy) * width + ox;
+                                fc += colorHistory[oi];
+                                f0 += momentsHistory[4 * oi];
+                                f1 += momentsHistory[4 * oi + 1];
+                                nValid += 1.0f;
+                            }
+                        }
+                    }
+                    if (nValid > 0.0f) { colorLastFrame = fc / nValid; prevM0 = f0 / nValid; prevM1 = f1 / nValid; success = true; }
+                }
+            }
+            historyLength = fminf(success ? historyLength + 1.0f : 1.0f, 32.0f);
+            const float alphaColor = success ? fmaxf(0.01f, 1.0f / historyLength) : 1.0f;
+            const float alphaMoments = success ? fmaxf(0.2f, 1.0f / historyLength) : 1.0f;
+            const float r = mixf(prevM0, color, alphaMoments), g = mixf(prevM1, color * color, alphaMoments);
+            const float variance = fmaxf(0.0f, g - r * r);
+            float* am = accumMoments.data() + 4 * ci;
+            am[0] = r; am[1] = g; am[2] = historyLength; am[3] = 0.0f;
+            tempAccum[2 * ci] = mixf(colorLastFrame, color, alphaColor);
+            tempAccum[2 * ci + 1] = variance;
+        }
+    }
+    // ---- Compute-Filter-Moments, SVGF.glsl:282-352
+    {
+        const std::vector<float> src(tempAccum);
+#pragma omp parallel for schedule(dynamic, 8)
+        for (int64_t yy = 0; yy < int64_t(H); yy++) {
+            for (int x = 0; x < W; x++) {
+                const int y = int(yy);
+                const size_t ci = size_t(y) * width + x;
+                const float historyLength = accumMoments[4 * ci + 2];
+                if (historyLength >= 4.0f) continue;
+                float sumWeight = 0.0f, sumColor = 0.0f, sumM0 = 0.0f, sumM1 = 0.0f;
+                const float centerColor = src[2 * ci], centerDepth = depthMap[ci], centerFwidth = depthFwidthMap[ci];
+                const float* centerNormal = normalMap + 4 * ci;
+                for (int dy = -3; dy <= 3; dy++) {
+                    for (int dx = -3; dx <= 3; dx++) {
+                        const int ox = x + dx, oy = y + dy;
+                        if (!(ox >= 0 && oy >= 0 && ox < W && oy < H)) continue;
+                        const size_t oi = size_t(oy) * width + ox;
+                        const float weight = svgfComputeWeight(centerDepth, depthMap[oi], fabsf(centerFwidth) + 0.0001f, centerNormal,
+                                                               normalMap + 4 * oi, centerColor, src[2 * oi], 10.0f);
+                        sumWeight += weight;
+                        sumColor += weight * src[2 * oi];
+                        sumM0 += weight * accumMoments[4 * oi];
+                        sumM1 += weight * accumMoments[4 * oi + 1];
+                    }
+                }
+                sumWeight = fmaxf(sumWeight, 1e-6f);
+                sumColor /= sumWeight; sumM0 /= sumWeight; sumM1 /= sumWeight;
+                float variance = sumM1 - sumM0 * sumM0;
+                variance *= 4.0f / historyLength;
+                tempAccum[2 * ci] = sumColor;
+                tempAccum[2 * ci + 1] = variance;
+            }
+        }
+    }
+    // ---- Compute-ATrous x iterations, SVGF.glsl:393-495, SVGF.cpp:346-425
+    std::vector<float> ping(tempAccum), pong(2 * n);
+    if (iterations < 1) {
+        for (size_t i = 0; i < n; i++) colorHistory[i] = tempAccum[2 * i]; // blits, SVGF.cpp:347-360
+    }
+    for (int it = 0; it < iterations; it++) {
+        const int stepWidth = 1 << it;
+        const float* src = ping.data();
+        float* dst = pong.data();
+#pragma omp parallel for schedule(dynamic, 8)
+        for (int64_t yy = 0; yy < int64_t(H); yy++) {
+            for (int x = 0; x < W; x++) {
+                const int y = int(yy);
+                const size_t ci = size_t(y) * width + x;
+                const float centerColor = src[2 * ci], centerVar = src[2 * ci + 1];
+                // filter_variance: 3x3 Gaussian of the variance channel, :368-391
+                float fv = 0.0f;
+                const float vk[2][2] = {{1.0f / 4.0f, 1.0f / 8.0f}, {1.0f / 8.0f, 1.0f / 16.0f}};
+                for (int dy = -1; dy <= 1; dy++) {
+                    for (int dx = -1; dx <= 1; dx++) {
+                        const int px = x + dx, py = y + dy;
+                        const float v = (px >= 0 && py >= 0 && px < W && py < H) ? src[2 * (size_t(py) * width + px) + 1] : 0.0f;
+                        fv += v * vk[std::abs(dx)][std::abs(dy)];
+                    }
+                }
+                const float* centerNormal = normalMap + 4 * ci;
+                const float centerZ = depthMap[ci], centerFwidth = depthFwidthMap[ci];
+                const float phiColor = sqrtf(fmaxf(0.0f, 1e-10f + fv));
+                const float kv[3] = {1.0f, 2.0f / 3.0f, 1.0f / 6.0f};
+                float accumW = kv[0] * kv[0];
+                float sumC = centerColor * accumW, sumV = centerVar * accumW;
+                for (int dy = -2; dy <= 2; ++dy) {
+                    for (int dx = -2; dx <= 2; ++dx) {
+                        const int ox = x + dx * stepWidth, oy = y + dy * stepWidth;
+                        const bool inside = ox >= 0 && oy >= 0 && ox < W && oy < H;
+                        if (!inside || (dx == 0 && dy == 0)) continue;
+                        const size_t oi = size_t(oy) * width + ox;
+                        const float kernelValue = kv[std::abs(dx)] * kv[std::abs(dy)];
+                        const float len = sqrtf(float(dx) * float(dx) + float(dy) * float(dy));
+                        const float weight = svgfComputeWeight(centerZ, depthMap[oi], fabsf((centerFwidth * len) * float(stepWidth)) + 0.0001f,
+                                                               centerNormal, normalMap + 4 * oi, centerColor, src[2 * oi], phiColor) * kernelValue;
+                        sumC += weight * src[2 * oi];
+                        sumV += (weight * weight) * src[2 * oi + 1];
+                        accumW += weight;
+                    }
+                }
+                dst[2 * ci] = sumC / accumW;
+                dst[2 * ci + 1] = sumV / (accumW * accumW);
+                if (it == 0) colorHistory[ci] = dst[2 * ci];
+            }
+        }
+        ping.swap(pong);
+    }
+    for (size_t i = 0; i < n; i++) out[i] = ping[2 * i];
+    // "update previous frame images", SVGF.cpp:112-173
+    memcpy(normalHistory, normalMap, n * 16);
+    memcpy(depthHistory, depthMap, n * 4);
+    memcpy(momentsHistory, accumMoments.data(), n * 16);
 }
 
 // EAWDenoise.glsl on the AO image (colorTexture = vec4(ao, ao, ao, 1): the three colour channels stay equal and alpha stays 1

@@ -279,6 +279,21 @@ void lvo_eaw_denoise(uint32_t width, uint32_t height, const float* ao, const flo
                      int iterations, float phiColor, float phiPosition, float phiNormal, int useColor, int usePosition,
                      int useNormal, int computeVariant, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, float* out);
 
+/* SVGF (ambient_occlusion_denoiser = "SVGF"): while `enable` != 0 the RTAO passes run without running means and seed from
+ * globalFrameNumber (+ iteration), and fill the full-viewport maps normalWorld (float4), depth (float), flow (float2),
+ * depthFwidth (float) (VulkanRayTracedAmbientOcclusion.glsl:350-464, DISABLE_ACCUMULATION branches). */
+void lvo_set_svgf_feature_outputs(float* normalWorld, float* depth, float* flow, float* depthFwidth, int enable,
+                                  uint32_t globalFrameNumber, const float* lastFrameViewProj);
+/* out = A * B, column-major 4x4, glm's evaluation order */
+void lvo_mat4_mul(const float* A, const float* B, float* out);
+/* One SVGFDenoiser::denoise() (SVGF.glsl / SVGF.cpp): reproject, filter moments, `iterations` a-trous passes; the four
+ * history images (colour: float, moments: float4 {m1, m2, history length, 0}, normal: float4, depth: float; zero before the
+ * first call) are read and updated in place; out = the denoised AO image. */
+void lvo_svgf_denoise(uint32_t width, uint32_t height, const float* noisy, const float* normalMap, const float* depthMap,
+                      const float* depthFwidthMap, const float* flowMap, int iterations, float allowedZDist,
+                      float allowedNormalDist, float* colorHistory, float* momentsHistory, float* normalHistory,
+                      float* depthHistory, float* out);
+
 /* Test hook: the restatement of computeFragmentColor + blinnPhongShadingTube on n independent inputs (n x 3 positions /
  * normals / tangents, n flags / attributes / AO texels) -> n x 4 colours, n payload.hitT. */
 void lvo_compute_fragment_color_batch(const lvo_scene*, const lvo_params*, uint64_t n, const float* fragPos, const float* normal,

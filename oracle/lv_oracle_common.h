@@ -12,7 +12,17 @@
 #include <cstring>
 #include <vector>
 
-struct LvoAoFeatureSink { float* normal; float* position; };
+struct LvoAoFeatureSink {
+    float* normal; float* position;        // EAW: view-space normal / position, running means over the iterations
+    // SVGF (DISABLE_ACCUMULATION, useGlobalFrameNumber; SVGF.hpp:81-82): per-frame maps of the LAST RTAO iteration only
+    float* normalWorld;                    // float4 {surfaceNormal, 0}
+    float* depth;                          // float  -positionViewSpace.z, farDistance on a miss
+    float* flow;                           // float2 writePos - pixel position under the last frame's view-projection
+    float* depthFwidth;                    // float  |nabla.x| + |nabla.y|
+    int svgf;                              // != 0: no running means (AO image included), seeds from globalFrameNumber
+    uint32_t globalFrameNumber;
+    float lastFrameViewProj[16];
+};
 extern LvoAoFeatureSink g_lvoAoFeatures;   // defined in lv_oracle.cpp; set by lvo_set_ao_feature_outputs
 
 namespace {
@@ -201,15 +211,16 @@ inline Frame makeFrame(const lvo_params& P) {
 // lvo_set_ao_feature_outputs; null = not written.
 // (the sink itself has external linkage -- this header lives in an anonymous namespace per translation unit)
 
-inline void writeAoFeatures(const lvo_params& P, const Frame& F, size_t idx, uint32_t frameNumber, V3 surfaceNormal,
-                            V3 vertexPositionWorld) {
+inline void writeAoFeatures(const lvo_params& P, const Frame& F, uint32_t x, uint32_t y, size_t idx, uint32_t frameNumber,
+                            bool hasHitSurface, V3 surfaceNormal, V3 vertexPositionWorld) {
+    // camNormal = (inverseTransposedViewMatrix * vec4(surfaceNormal, 0)).xyz, inverseTransposedViewMatrix =
+    // transpose(inverseViewMatrix) (VulkanRayTracedAmbientOcclusion.cpp:569): row i of the product uses COLUMN i of invView
+    const float* m = F.invView;
+    const V3 camNormalHit = v3(((m[0] * surfaceNormal.x + m[1] * surfaceNormal.y) + m[2] * surfaceNormal.z) + m[3] * 0.0f,
+                               ((m[4] * surfaceNormal.x + m[5] * surfaceNormal.y) + m[6] * surfaceNormal.z) + m[7] * 0.0f,
+                               ((m[8] * surfaceNormal.x + m[9] * surfaceNormal.y) + m[10] * surfaceNormal.z) + m[11] * 0.0f);
     if (g_lvoAoFeatures.normal) {
-        // camNormal = (inverseTransposedViewMatrix * vec4(surfaceNormal, 0)).xyz, inverseTransposedViewMatrix =
-        // transpose(inverseViewMatrix) (VulkanRayTracedAmbientOcclusion.cpp:569): row i of the product uses COLUMN i of invView
-        const float* m = F.invView;
-        V3 n = v3(((m[0] * surfaceNormal.x + m[1] * surfaceNormal.y) + m[2] * surfaceNormal.z) + m[3] * 0.0f,
-                  ((m[4] * surfaceNormal.x + m[5] * surfaceNormal.y) + m[6] * surfaceNormal.z) + m[7] * 0.0f,
-                  ((m[8] * surfaceNormal.x + m[9] * surfaceNormal.y) + m[10] * surfaceNormal.z) + m[11] * 0.0f);
+        V3 n = camNormalHit;
         float* o = g_lvoAoFeatures.normal + 4 * idx;
         if (frameNumber != 0) {
             const float a = 1.0f / float(frameNumber + 1);
@@ -219,8 +230,8 @@ inline void writeAoFeatures(const lvo_params& P, const Frame& F, size_t idx, uin
         }
         o[0] = n.x; o[1] = n.y; o[2] = n.z; o[3] = 0.0f;
     }
+    const V4 pv = mulM4(P.view, V4{vertexPositionWorld.x, vertexPositionWorld.y, vertexPositionWorld.z, 1.0f});
     if (g_lvoAoFeatures.position) {
-        const V4 pv = mulM4(P.view, V4{vertexPositionWorld.x, vertexPositionWorld.y, vertexPositionWorld.z, 1.0f});
         V3 q = v3(pv.x, pv.y, pv.z);
         float* o = g_lvoAoFeatures.position + 4 * idx;
         if (frameNumber != 0) {
@@ -228,6 +239,35 @@ inline void writeAoFeatures(const lvo_params& P, const Frame& F, size_t idx, uin
             q = v3(mixf(o[0], q.x, a), mixf(o[1], q.y, a), mixf(o[2], q.z, a));
         }
         o[0] = q.x; o[1] = q.y; o[2] = q.z; o[3] = 1.0f;
+    }
+    // ---- the maps SVGF asks for (SVGF.cpp:88-96), DISABLE_ACCUMULATION branches of glsl:321-464
+    if (g_lvoAoFeatures.normalWorld) {
+        float* o = g_lvoAoFeatures.normalWorld + 4 * idx;
+        o[0] = surfaceNormal.x; o[1] = surfaceNormal.y; o[2] = surfaceNormal.z; o[3] = 0.0f;
+    }
+    if (g_lvoAoFeatures.depth) g_lvoAoFeatures.depth[idx] = hasHitSurface ? -pv.z : P.farDist;
+    if (g_lvoAoFeatures.flow) {
+        float fx = 0.0f, fy = 0.0f;
+        if (hasHitSurface) {
+            V4 ndc = mulM4(g_lvoAoFeatures.lastFrameViewProj, V4{vertexPositionWorld.x, vertexPositionWorld.y, vertexPositionWorld.z, 1.0f});
+            ndc.x /= ndc.w; ndc.y /= ndc.w;
+            const float plx = (0.5f * ndc.x + 0.5f) * float(P.width) - 0.5f;
+            const float ply = (0.5f * ndc.y + 0.5f) * float(P.height) - 0.5f;
+            fx = float(x) - plx;
+            fy = float(y) - ply;
+        }
+        g_lvoAoFeatures.flow[2 * idx] = fx;
+        g_lvoAoFeatures.flow[2 * idx + 1] = fy;
+    }
+    if (g_lvoAoFeatures.depthFwidth) {
+        // cot of the angle between the view-space normal and the camera x / y axis, glsl:435-442
+        float nx = 0.0f, ny = 0.0f;
+        if (hasHitSurface) {
+            const float A = camNormalHit.x, B = camNormalHit.y;
+            nx = A / sqrtf(1.0f - A * A);
+            ny = B / sqrtf(1.0f - B * B);
+        }
+        g_lvoAoFeatures.depthFwidth[idx] = fabsf(nx) + fabsf(ny);
     }
 }
 

@@ -362,8 +362,10 @@ void lvo_render_ao_tri(const lvo_tri_scene* sc, const lvo_params* Pp, int useBvh
     Frame F = makeFrame(P);
     uint64_t rays = 0, nodes = 0, prims = 0;
     for (uint32_t iter = 0; iter < P.aoIterations; iter++) {
-        const uint32_t frameNumber = iter;
-        const uint32_t globalFrameNumber = frameNumber; // VulkanRayTracedAmbientOcclusion.cpp:576-581
+        // SVGF: DISABLE_ACCUMULATION (no running means) + useGlobalFrameNumber (seeds from a counter that onHasMoved does not
+        // reset), VulkanRayTracedAmbientOcclusion.cpp:415-421,576-581
+        const uint32_t frameNumber = g_lvoAoFeatures.svgf ? 0u : iter;
+        const uint32_t globalFrameNumber = g_lvoAoFeatures.svgf ? g_lvoAoFeatures.globalFrameNumber + iter : frameNumber;
 #pragma omp parallel for schedule(dynamic, 1) reduction(+ : rays, nodes, prims)
         for (int64_t tileIdx = 0; tileIdx < lvoTileCount(w, h); tileIdx++) { // 16x16-pixel tiles
             Counters cnt;
@@ -379,6 +381,7 @@ void lvo_render_ao_tri(const lvo_tri_scene* sc, const lvo_params* Pp, int useBvh
                 primaryRay(P, F, x, y, xix, xiy, o, d);
                 TriHit hit;
                 float aoFactor = 1.0f;
+                bool hasHitSurface = false;
                 V3 featNormal = v3(0, 0, 0), featPosition = v3(0, 0, 0); // surfaceNormal / vertexPositionWorld of a miss, glsl:211-212
                 if (closestTri(*sc, useBvh != 0, o, d, 0.0001f, 1000.0f, hit, cnt)) {
                     // glsl:219-263
@@ -396,7 +399,7 @@ void lvo_render_ao_tri(const lvo_tri_scene* sc, const lvo_params* Pp, int useBvh
                     V3 surfaceTangent = normalize(interpolateVec3(ld3(lp0.lineTangent), ld3(lp1.lineTangent), ld3(lp2.lineTangent), bc));
                     V3 surfaceBitangent = cross(surfaceNormal, surfaceTangent);
                     float offsetFactor = length(linePosition - vertexPositionWorld) / F.subdivisionCorrectionFactor; // glsl:280
-                    featNormal = surfaceNormal; featPosition = vertexPositionWorld;
+                    hasHitSurface = true; featNormal = surfaceNormal; featPosition = vertexPositionWorld;
                     aoFactor = 0.0f;
                     for (uint32_t s = 0; s < P.aoSamplesPerFrame; s++) {
                         uint32_t sseed = tea(pix, globalFrameNumber * P.aoSamplesPerFrame + s);
@@ -421,7 +424,7 @@ void lvo_render_ao_tri(const lvo_tri_scene* sc, const lvo_params* Pp, int useBvh
                 size_t idx = size_t(y) * P.width + x;
                 if (frameNumber != 0) aoFactor = mixf(aoOut[idx], aoFactor, 1.0f / float(frameNumber + 1));
                 aoOut[idx] = aoFactor;
-                writeAoFeatures(P, F, idx, frameNumber, featNormal, featPosition);
+                writeAoFeatures(P, F, x, y, idx, frameNumber, hasHitSurface, featNormal, featPosition);
             }
             rays += cnt.rays; nodes += cnt.nodes; prims += cnt.prims;
         }

@@ -97,6 +97,9 @@ def lib():
     vp, u32, f32, i32 = C.c_void_p, C.c_uint32, C.c_float, C.c_int
     L.lvo_set_deviation_switches.argtypes = [i32, i32]
     L.lvo_set_ao_feature_outputs.argtypes = [vp, vp]
+    L.lvo_set_svgf_feature_outputs.argtypes = [vp, vp, vp, vp, i32, u32, vp]
+    L.lvo_mat4_mul.argtypes = [vp, vp, vp]
+    L.lvo_svgf_denoise.argtypes = [u32, u32, vp, vp, vp, vp, vp, i32, f32, f32, vp, vp, vp, vp, vp]
     L.lvo_eaw_denoise.argtypes = [u32, u32, vp, vp, vp, i32, f32, f32, f32, i32, i32, i32, i32, u32, u32, u32, u32, vp]
     L.lvo_compute_fragment_color_batch.argtypes = [vp, vp, C.c_uint64] + [vp] * 8
     L.lvo_num_threads.restype = i32
@@ -620,6 +623,54 @@ class ao_features:
     def __exit__(self, *exc):
         lib().lvo_set_ao_feature_outputs(None, None)
         return False
+
+
+def mat4_mul(a, b):
+    """a * b for column-major 4x4 float32 matrices (flat, 16 values) in glm's evaluation order."""
+    a = np.ascontiguousarray(a, dtype=np.float32).reshape(16)
+    b = np.ascontiguousarray(b, dtype=np.float32).reshape(16)
+    out = np.zeros(16, dtype=np.float32)
+    lib().lvo_mat4_mul(_p(a), _p(b), _p(out))
+    return out
+
+
+class Svgf:
+    """The temporal state of SVGFDenoiser + the RTAO pass around it (VulkanRayTracedAmbientOcclusionPass::_render with an
+    SVGF denoiser): global frame counter, last frame's view-projection, the four history images.  step(render_ao, P) runs ONE
+    RTAO iteration through `render_ao` (a callable returning the raw AO image, e.g. lambda: scene.render_ao(P)) followed by
+    one denoise() and returns the denoised AO image."""
+
+    def __init__(self, width, height, iterations=5, allowed_z_dist=0.002, allowed_normal_dist=0.02):
+        self.w, self.h = int(width), int(height)
+        self.iterations, self.allowed_z_dist, self.allowed_normal_dist = int(iterations), float(allowed_z_dist), float(allowed_normal_dist)
+        self.global_frame_number = 0
+        self.last_view_proj = None
+        z = lambda *c: np.zeros((self.h, self.w) + c, dtype=np.float32)
+        self.color_history, self.moments_history, self.normal_history, self.depth_history = z(), z(4), z(4), z()
+        self.normal, self.depth, self.flow, self.fwidth = z(4), z(), z(2), z()
+        self.raw = None
+
+    def step(self, render_ao, P):
+        view = np.array(P.view, dtype=np.float32)
+        proj = np.array(P.proj, dtype=np.float32)
+        vp = mat4_mul(proj, view)
+        last = self.last_view_proj if self.last_view_proj is not None else vp
+        its = P.aoIterations
+        P.aoIterations = 1
+        lib().lvo_set_svgf_feature_outputs(_p(self.normal), _p(self.depth), _p(self.flow), _p(self.fwidth), 1,
+                                           self.global_frame_number, _p(np.ascontiguousarray(last)))
+        try:
+            self.raw = np.ascontiguousarray(render_ao(), dtype=np.float32)
+        finally:
+            lib().lvo_set_svgf_feature_outputs(None, None, None, None, 0, 0, None)
+            P.aoIterations = its
+        self.global_frame_number += 1
+        self.last_view_proj = vp
+        out = np.zeros((self.h, self.w), dtype=np.float32)
+        lib().lvo_svgf_denoise(self.w, self.h, _p(self.raw), _p(self.normal), _p(self.depth), _p(self.fwidth), _p(self.flow),
+                               self.iterations, self.allowed_z_dist, self.allowed_normal_dist, _p(self.color_history),
+                               _p(self.moments_history), _p(self.normal_history), _p(self.depth_history), _p(out))
+        return out
 
 
 def eaw_denoise(ao, normal=None, position=None, iterations=3, phi_color=0.49, phi_position=0.3 * 0.0001, phi_normal=0.1,

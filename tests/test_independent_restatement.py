@@ -293,3 +293,91 @@ def test_front_to_back_pq_against_the_plain_python_restatement():
     empty = [(x, y) for y in range(H) for x in range(W) if (x, y) not in lists]
     for x, y in empty[:50]:
         assert list(got[y, x]) == [int(np.floor(b * 255.0 + 0.5)) for b in bg]
+
+
+# ------------------------------------------------------------------ SVGF: one a-trous pass (SVGF.glsl:393-495, svgf_common.glsl)
+def svgf_compute_weight(cd, od, phi_depth, cn, on, cc, oc, phi_color):
+    weight_n = max(0.0, float(np.dot(cn, on))) ** 128
+    weight_z = 0.0 if phi_depth == 0 else abs(cd - od) / phi_depth
+    weight_c = abs(cc - oc) * 2 / phi_color
+    return np.exp(0.0 - max(weight_c, 0.0) - max(weight_z, 0.0)) * weight_n
+
+
+def svgf_atrous_pass(color, normal, depth, fwidth, iteration):
+    """color: (H, W, 2) = {colour, variance}; texel fetches outside the image return 0."""
+    h, w = depth.shape
+    step = 1 << iteration
+    kv = [1.0, 2.0 / 3.0, 1.0 / 6.0]
+    vk = [[1.0 / 4.0, 1.0 / 8.0], [1.0 / 8.0, 1.0 / 16.0]]
+    out = np.zeros_like(color)
+    for y in range(h):
+        for x in range(w):
+            fv = 0.0
+            for yy in (-1, 0, 1):
+                for xx in (-1, 0, 1):
+                    px, py = x + xx, y + yy
+                    if 0 <= px < w and 0 <= py < h:
+                        fv += color[py, px, 1] * vk[abs(xx)][abs(yy)]
+            phi_color = np.sqrt(max(0.0, 1e-10 + fv))
+            acc = kv[0] * kv[0]
+            s = color[y, x] * acc
+            for yy in range(-2, 3):
+                for xx in range(-2, 3):
+                    ox, oy = x + xx * step, y + yy * step
+                    if not (0 <= ox < w and 0 <= oy < h) or (xx == 0 and yy == 0):
+                        continue
+                    k = kv[abs(xx)] * kv[abs(yy)]
+                    wgt = svgf_compute_weight(depth[y, x], depth[oy, ox], abs(fwidth[y, x] * np.hypot(xx, yy) * step) + 0.0001,
+                                              normal[y, x, :3], normal[oy, ox, :3], color[y, x, 0], color[oy, ox, 0], phi_color) * k
+                    s = s + np.array([wgt, wgt * wgt]) * color[oy, ox]
+                    acc += wgt
+            out[y, x] = s / np.array([acc, acc * acc])
+    return out
+
+
+def test_svgf_first_frame_against_the_float64_restatement():
+    """First frame (empty history): the reprojection fails everywhere, so temp_accum = {noisy, 0} and moments = {c, c^2, 1}; the
+    moments filter (history length < 4) then estimates a spatial variance, boosted by 4 / 1, and the a-trous passes follow."""
+    rng = np.random.default_rng(11)
+    h, w = 20, 26
+    normal = np.zeros((h, w, 4), np.float32)
+    ang = rng.uniform(-0.15, 0.15, (h, w, 2))
+    n3 = np.stack([np.sin(ang[..., 0]), np.sin(ang[..., 1]), np.ones((h, w))], axis=-1)
+    normal[..., :3] = (n3 / np.linalg.norm(n3, axis=-1, keepdims=True)).astype(np.float32)
+    normal[:, 13:, :3] = np.array([0.0, 1.0, 0.0], np.float32)             # an edge the filter must not cross
+    depth = (0.7 + 0.0005 * rng.standard_normal((h, w))).astype(np.float32)
+    fwidth = rng.uniform(0.0, 0.3, (h, w)).astype(np.float32)
+    noisy = np.clip(0.6 + 0.2 * rng.standard_normal((h, w)), 0, 1).astype(np.float32)
+    noisy[:, 13:] *= 0.5
+    flow = np.zeros((h, w, 2), np.float32)
+    # float64 restatement of the chain
+    n64, d64, f64, c64 = normal.astype(np.float64), depth.astype(np.float64), fwidth.astype(np.float64), noisy.astype(np.float64)
+    temp = np.stack([c64, np.zeros_like(c64)], axis=-1)
+    m = np.stack([c64, c64 * c64], axis=-1)
+    filt = np.zeros_like(temp)
+    for y in range(h):
+        for x in range(w):
+            sw, sc_, sm = 0.0, 0.0, np.zeros(2)
+            for yy in range(-3, 4):
+                for xx in range(-3, 4):
+                    ox, oy = x + xx, y + yy
+                    if 0 <= ox < w and 0 <= oy < h:
+                        wgt = svgf_compute_weight(d64[y, x], d64[oy, ox], abs(f64[y, x]) + 0.0001, n64[y, x, :3], n64[oy, ox, :3],
+                                                  temp[y, x, 0], temp[oy, ox, 0], 10)
+                        sw += wgt
+                        sc_ += wgt * temp[oy, ox, 0]
+                        sm += wgt * m[oy, ox]
+            sw = max(sw, 1e-6)
+            sm /= sw
+            filt[y, x] = (sc_ / sw, (sm[1] - sm[0] * sm[0]) * 4.0 / 1.0)
+    want = filt
+    for it in range(3):
+        want = svgf_atrous_pass(want, n64, d64, f64, it)
+    hist = [np.zeros((h, w), np.float32), np.zeros((h, w, 4), np.float32), np.zeros((h, w, 4), np.float32), np.zeros((h, w), np.float32)]
+    out = np.zeros((h, w), np.float32)
+    lvo.lib().lvo_svgf_denoise(w, h, lvo._p(noisy), lvo._p(normal), lvo._p(depth), lvo._p(fwidth), lvo._p(flow), 3, 0.002, 0.02,
+                               lvo._p(hist[0]), lvo._p(hist[1]), lvo._p(hist[2]), lvo._p(hist[3]), lvo._p(out))
+    assert np.abs(out - want[..., 0]).max() < 2e-5
+    assert np.all(hist[1][..., 2] == 1.0)
+    # the edge survives: pow(dot, 128) of perpendicular normals is 0
+    assert abs(out[:, :13].mean() - out[:, 13:].mean()) > 0.2
