@@ -16,7 +16,7 @@
 // neighbourhood that grows with every frame.  The whole chain therefore always runs on the full viewport, whatever tile
 // the render call asked for (lv_run_ao): tiles of one frame agree by construction because they share this image.
 //
-// Where the reference leaves the result open, the build defines it (same definitions in oracle/lv_oracle.cpp lvo_svgf_denoise):
+// Where the reference leaves the result open, the build defines it:
 // texel fetches outside the image return 0; the moments filter reads the image the reprojection pass wrote (the reference
 // filters temp_accum in place, a data race between invocations); unwritten `out` parameters are 0; pow(x, 128) is seven
 // squarings.
