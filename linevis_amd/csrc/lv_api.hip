@@ -420,6 +420,18 @@ int lv_set_option(lv_ctx* ctx, const char* key, const char* value) {
         else return lv_fail(ctx, LV_E_INVALID, "ambient_occlusion_denoiser '%s' is not provided (None | Edge-Avoiding \xC3\x80-Trous "
                                                "Wavelet Transform | SVGF)", value);
         if (o.svgfEnabled != wasSvgf) { ctx->svgf.historyValid = false; ctx->aoResult = nullptr; } // createDenoiser(): fresh history
+    } else if (k == "use_ribbons") {                              // LineDataFlow.cpp:588 (here: USE_BANDS = ribbons on AND band data set)
+        o.useRibbons = parseBool(value);
+    } else if (k == "thick_bands") {                              // :592
+        o.thickBands = parseBool(value);
+    } else if (k == "min_band_thickness") {                       // :596
+        if (!parseFloat(value, f) || !(f > 0.0f) || f > 1.0f) return bad();
+        o.minBandThickness = f;
+    } else if (k == "band_width") {                               // LineRenderer.cpp:443
+        if (!parseFloat(value, f) || !(f > 0.0f)) return bad();
+        o.bandWidth = f;
+    } else if (k == "use_analytic_elliptic_tubes") {              // "Elliptic Tubes" checkbox, VulkanRayTracer.cpp:198-201
+        o.ellipticTubes = parseBool(value);
     } else if (k == "svgf_denoiser_iterations") {                // maxNumIterations, SVGF.cpp:427-436 (GUI only in the reference)
         if (!parseUint(value, u) || u > 5) return bad();
         o.svgfIterations = u;

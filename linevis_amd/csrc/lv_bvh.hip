@@ -540,10 +540,10 @@ int lv_bvh_build(lv_ctx* ctx) {
     ctx->numNodes = 0;
     if (n == 0) {
         ctx->accelValid = true;
-        ctx->accelLineWidth = ctx->opt.lineWidth;
+        ctx->accelLineWidth = lv_accel_width(ctx);
         return LV_OK;
     }
-    const float radius = ctx->opt.lineWidth * 0.5f;
+    const float radius = lv_accel_width(ctx) * 0.5f;
     const float pad = radius * 1e-3f + 1e-6f;
     int rc;
     if ((rc = lv_buf_reserve(ctx, ctx->segs, size_t(n) * 32))) return rc;
@@ -563,7 +563,7 @@ int lv_bvh_build(lv_ctx* ctx) {
             });
     if (rc) return rc;
     ctx->accelValid = true;
-    ctx->accelLineWidth = ctx->opt.lineWidth;
+    ctx->accelLineWidth = lv_accel_width(ctx);
     ctx->evBuildValid = true;
     return LV_OK;
 }

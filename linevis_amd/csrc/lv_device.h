@@ -124,6 +124,11 @@ struct LvUniforms {
     // getAoFactor of the colour pass (AmbientOcclusion.glsl:84-99): 1 = project the hit and sample the AO image bilinearly
     // (jittered primary rays), 0 = the launching pixel's own texel (pixel-centre rays project onto their texel centre)
     uint32_t aoProjectLookup;
+    // band data (ribbons): USE_BANDS = use_ribbons && band data (LineDataFlow.cpp:2423-2431); the ray tracer's "Elliptic Tubes"
+    // switch (VulkanRayTracer.cpp:198-201,468-499); bandWidth / minBandThickness of LineUniformData (LineData.cpp:1297-1298);
+    // minThickness = the MIN_THICKNESS define (minBandThickness with thick bands, 1e-2 otherwise)
+    uint32_t useBands, useEllipticTubes;
+    float bandWidth, minBandThickness, minThickness;
 };
 
 // Feature maps SVGF asks the RTAO pass for (SVGF.cpp:88-96; VulkanRayTracedAmbientOcclusion.glsl:350-464, DISABLE_ACCUMULATION
@@ -144,6 +149,9 @@ struct LvSceneDev {
     const uint32_t* segIdx;     // 2 point indices per original segment
     const float4* tf;           // transfer function texels
     const float* depthMinMax;   // {minDepth, maxDepth}, produced on device by the depth-range kernels
+    // elliptic tubelets (LV_PRIM_ELLIPTIC): semi-axes from bandWidth / minBandThickness, camera position of the cutting-plane
+    // tolerances (EllipticTubeRayTracing.glsl:186-270)
+    float ellBandWidth, ellMinBandThickness, ellCamPos[3];
     const float* ao;            // full-viewport AO factors
     unsigned* stackOverflow;    // null unless the LBVH is higher than LV_STACK_LDS
     uint32_t* accum;            // full-viewport rgba8 of the previous frame (num_accumulated_frames > 1), else null
@@ -163,6 +171,7 @@ struct LvSceneDev {
 };
 #define LV_PRIM_CAPSULE 0
 #define LV_PRIM_TRIANGLE 1
+#define LV_PRIM_ELLIPTIC 2   // elliptic tubelets of band data (EllipticTubeRayTracing.glsl)
 
 // tile list of a launch: tiles are tileW x tileH pixel rectangles with origins tilesXY[2*i], tilesXY[2*i+1]
 struct LvTiles {
@@ -210,6 +219,34 @@ __device__ __forceinline__ void lv_sincos2pi(float xi, float& s, float& c) {
     else if (quad == 1) { s = ca; c = -sa; }
     else if (quad == 2) { s = -sa; c = -ca; }
     else { s = -ca; c = sa; }
+}
+
+// sin / cos / atan2 of the elliptic-tube shaders (EllipticTubeRayTracing.glsl).  GLSL leaves their precision to the
+// implementation and the sphere tracing loop takes discrete decisions on their results, so the build defines them by fixed
+// float32 formulas: sin / cos through lv_sincos2pi after reducing the angle to a fraction of the full turn, atan through an odd
+// polynomial on [-tan(pi/8), tan(pi/8)].
+__device__ __forceinline__ void lv_sincos_rad(float a, float& s, float& c) {
+    float u = a * 0.15915494309189535f;
+    u = u - floorf(u);
+    if (!(u < 1.0f)) u = 0.0f;
+    lv_sincos2pi(u, s, c);
+}
+__device__ __forceinline__ float lv_atan2_det(float y, float x) {
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    float r = 0.0f;
+    if (mx > 0.0f) {
+        float a = mn / mx;
+        float base = 0.0f;
+        if (a > 0.41421356237309503f) { a = (a - 1.0f) / (a + 1.0f); base = 0.78539816339744831f; }
+        const float s = a * a;
+        const float p = a * (1.0f + s * (-1.0f / 3.0f + s * (1.0f / 5.0f + s * (-1.0f / 7.0f + s * (1.0f / 9.0f + s * (-1.0f / 11.0f + s * (1.0f / 13.0f)))))));
+        r = base + p;
+        if (ay > ax) r = 1.57079632679489662f - r;
+    }
+    if (x < 0.0f) r = 3.14159265358979323846f - r;
+    if (y < 0.0f) r = -r;
+    return r;
 }
 
 // ---------------------------------------------------------------- wave helpers (wave64)

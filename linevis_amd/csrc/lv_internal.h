@@ -70,6 +70,11 @@ struct LvOptions {
     bool eawUseSharedMemory = true;           // true: EAWDenoise.Compute (default), false: EAWDenoise.Fragment
     // ambient_occlusion_denoiser = "SVGF" (Denoiser.hpp:65).  The reference exposes these in the GUI only (SVGF.cpp:427-436,
     // SVGF.hpp:70-72,115); the svgf_denoiser_* keys are this build's.
+    // band data (ribbons): use_ribbons / thick_bands / min_band_thickness (LineDataFlow.cpp:587-606), band_width
+    // (LineRenderer.cpp:442-449, STANDARD_BAND_WIDTH DataSetList.hpp:47), min band thickness LineData.cpp:54; the ray tracer's
+    // "Elliptic Tubes" switch has no settings key in the reference (VulkanRayTracer.cpp:198-201): use_analytic_elliptic_tubes
+    bool useRibbons = false, thickBands = true, ellipticTubes = false;
+    float bandWidth = 0.005f, minBandThickness = 0.15f;
     bool svgfEnabled = false;
     uint32_t svgfIterations = 5;              // maxNumIterations, SVGF.hpp:115 (GUI range 0..5)
     float svgfAllowedZDist = 0.002f, svgfAllowedNormalDist = 0.02f; // SVGF.hpp:70-71
@@ -169,6 +174,11 @@ struct lv_ctx {
 };
 
 int lv_fail(lv_ctx* ctx, int code, const char* fmt, ...);
+// width the capsule LBVH's leaf boxes are padded with: the band width for elliptic tubes (useRibbonNormals,
+// LineDataFlow.cpp:2120-2126), the line width otherwise
+inline float lv_accel_width(const lv_ctx* ctx) {
+    return (ctx->opt.useRibbons && ctx->opt.ellipticTubes) ? ctx->opt.bandWidth : ctx->opt.lineWidth;
+}
 
 #define LV_HIP(ctx, expr)                                                                          \
     do {                                                                                           \

@@ -28,7 +28,7 @@ namespace {
 // ================================================================ ray tracer colour pass
 // Control flow is wave-uniform around every trace (lv_trace_closest is a wave-cooperative routine): the sample loop and
 // the transparency loop run while ANY lane of the wave still needs a trace; lanes that are done pass active = false.
-template <bool STATS, int PRIM>
+template <bool STATS, int PRIM, bool BANDS = false>
 __global__ __launch_bounds__(LV_BLOCK) void k_render_rt(const LvUniforms U, const LvSceneDev S, const LvTiles T,
                                                         uint32_t* __restrict__ out, LvDevCounters* dc) {
     __shared__ unsigned s_stack[LV_STACK_LDS * LV_BLOCK];
@@ -65,8 +65,9 @@ __global__ __launch_bounds__(LV_BLOCK) void k_render_rt(const LvUniforms U, cons
                 f4 hc;
                 float payloadHitT;
                 if (h.found) {
-                    hc = PRIM == LV_PRIM_TRIANGLE ? lv_shade_hit_triangle(S, U, aoTexel, o, d, h.leaf, payloadHitT)
-                                                  : lv_shade_hit(S, U, aoTexel, o, d, h, payloadHitT);
+                    hc = PRIM == LV_PRIM_TRIANGLE   ? lv_shade_hit_triangle(S, U, aoTexel, o, d, h.leaf, payloadHitT)
+                         : PRIM == LV_PRIM_ELLIPTIC ? lv_shade_hit_elliptic(S, U, aoTexel, o, d, h, payloadHitT)
+                                                    : lv_shade_hit<BANDS>(S, U, aoTexel, o, d, h, payloadHitT);
                     if (STATS) cnt.hits++;
                 } else { // Miss, TubeRayTracing.glsl:290-297
                     hc.x = U.background[0]; hc.y = U.background[1]; hc.z = U.background[2]; hc.w = U.background[3];
@@ -154,6 +155,22 @@ __global__ __launch_bounds__(LV_BLOCK) void k_ao_primary(const LvUniforms U, con
             g0 = make_float4(vertexPositionWorld.x, vertexPositionWorld.y, vertexPositionWorld.z, offsetFactor);
             g1 = make_float4(surfaceTangent.x, surfaceTangent.y, surfaceTangent.z, __uint_as_float(pix));
             g2 = make_float4(surfaceNormal.x, surfaceNormal.y, surfaceNormal.z, 0.0f);
+        } else if (h.found && PRIM == LV_PRIM_ELLIPTIC) {
+            // band data: the reference's RTAO pass traces the elliptic TRIANGLE tubes (createCappedTriangleEllipticTubesRenderDataCPU);
+            // the build traces the analytic tubelets of the colour pass -- the same substitution as capsules for circular tubes
+            hasHit = true;
+            const uint32_t seg = S.leafSeg[h.leaf];
+            const lv_line_point& lp0 = S.points[S.segIdx[2 * seg]];
+            const lv_line_point& lp1 = S.points[S.segIdx[2 * seg + 1]];
+            const LvEllipticSurface E = lv_elliptic_surface(U, o, d, h.t, lp0, lp1);
+            const f3 vertexPositionWorld = o + d * h.t;
+            const f3 t0 = mk3(lp0.lineTangent[0], lp0.lineTangent[1], lp0.lineTangent[2]);
+            const f3 t1 = mk3(lp1.lineTangent[0], lp1.lineTangent[1], lp1.lineTangent[2]);
+            const f3 surfaceTangent = norm3((1.0f - E.t) * t0 + E.t * t1);
+            const float offsetFactor = len3(E.linePosition - vertexPositionWorld) / U.subdivisionCorrectionFactor;
+            g0 = make_float4(vertexPositionWorld.x, vertexPositionWorld.y, vertexPositionWorld.z, offsetFactor);
+            g1 = make_float4(surfaceTangent.x, surfaceTangent.y, surfaceTangent.z, __uint_as_float(pix));
+            g2 = make_float4(E.normal.x, E.normal.y, E.normal.z, 0.0f);
         } else if (h.found) {
             hasHit = true;
             const float4 ra = S.segs[2 * h.leaf], rb = S.segs[2 * h.leaf + 1];
@@ -335,7 +352,8 @@ __global__ __launch_bounds__(LV_AO_BLOCK, 5) void k_ao_rays(const LvUniforms U, 
     unsigned long long* keyW = &s_key[LV_WAVE * w];
     const unsigned long long keyInit = ((unsigned long long)__float_as_uint(U.aoRadius) << 32) | 0xFFFFFFFFull;
     // literal roots: cull against best + r / |d| (AO directions are normalised: |d| = 1 to rounding, 1.001 covers it)
-    const float litSlack = (PRIM == LV_PRIM_CAPSULE && LIT) ? radius * 1.001f : 0.0f;
+    // elliptic tubelets: bandWidth / |d| (lv_intersect_elliptic_tube's own-box rule)
+    const float litSlack = PRIM == LV_PRIM_ELLIPTIC ? S.ellBandWidth * 1.001f : (PRIM == LV_PRIM_CAPSULE && LIT) ? radius * 1.001f : 0.0f;
 
     LvStackT<LV_AO_STACK_LDS, LV_AO_BLOCK> st;
     st.init(&s_stack[threadIdx.x], S.stackOverflow ? S.stackOverflow + (size_t(blockIdx.x) * LV_AO_BLOCK + threadIdx.x) : nullptr,
@@ -993,6 +1011,7 @@ __global__ void k_depth_finalize(const LvDevCounters* dc, float* out) {
 }
 
 // ================================================================ arbitrary rays (parity inspection)
+template <int PRIM>
 __global__ __launch_bounds__(LV_BLOCK) void k_trace_rays(const LvSceneDev S, float radius, uint32_t capped,
                                                          const float* __restrict__ org, const float* __restrict__ dir,
                                                          float tMin, float tMax, uint32_t n, float* __restrict__ outT,
@@ -1006,8 +1025,8 @@ __global__ __launch_bounds__(LV_BLOCK) void k_trace_rays(const LvSceneDev S, flo
     const uint32_t j = valid ? i : 0u;
     f3 o = mk3(org[3 * j], org[3 * j + 1], org[3 * j + 2]);
     f3 d = mk3(dir[3 * j], dir[3 * j + 1], dir[3 * j + 2]);
-    LvHit h = lv_trace_closest<false, false>(S, radius, capped != 0, valid, o, d, tMin, tMax,
-                                             lv_stack_mem(s_stack, S.stackOverflow), cm, cnt);
+    LvHit h = lv_trace_closest<false, false, PRIM>(S, radius, capped != 0, valid, o, d, tMin, tMax,
+                                                   lv_stack_mem(s_stack, S.stackOverflow), cm, cnt);
     if (!valid) return;
     outT[i] = h.found ? h.t : tMax;
     outSeg[i] = h.found ? S.leafSeg[h.leaf] : 0xFFFFFFFFu;
@@ -1068,6 +1087,14 @@ LvSceneDev sceneDev(const lv_ctx* ctx) {
     S.accum = nullptr;
     S.numSegs = ctx->numSegs;
     S.literalIntersection = ctx->opt.literalIntersection ? 1u : 0u;
+    S.ellBandWidth = ctx->opt.bandWidth;
+    S.ellMinBandThickness = ctx->opt.minBandThickness;
+    {   // cameraPosition, as lv_fill_uniforms
+        const float* m = ctx->invView;
+        S.ellCamPos[0] = ((m[0] * 0.0f + m[4] * 0.0f) + m[8] * 0.0f) + m[12] * 1.0f;
+        S.ellCamPos[1] = ((m[1] * 0.0f + m[5] * 0.0f) + m[9] * 0.0f) + m[13] * 1.0f;
+        S.ellCamPos[2] = ((m[2] * 0.0f + m[6] * 0.0f) + m[10] * 0.0f) + m[14] * 1.0f;
+    }
     S.tris = nullptr; S.triIdx = nullptr; S.triVerts = nullptr; S.triPoints = nullptr; S.triPad = 0.0f;
     S.bakedAo = (const float*)ctx->bakedAo.ptr;
     S.bakedBlendingWeights = (const float*)ctx->bakeBlendingWeights.ptr;
@@ -1108,6 +1135,11 @@ void lv_fill_uniforms(const lv_ctx* ctx, LvUniforms& U) {
     const LvOptions& o = ctx->opt;
     U.lineWidth = o.lineWidth;
     U.radius = o.lineWidth * 0.5f; // TubeRayTracing.glsl:453
+    U.useBands = o.useRibbons ? 1u : 0u;
+    U.useEllipticTubes = (o.useRibbons && o.ellipticTubes) ? 1u : 0u;
+    U.bandWidth = o.bandWidth;
+    U.minBandThickness = o.minBandThickness;
+    U.minThickness = o.thickBands ? o.minBandThickness : 1e-2f; // MIN_THICKNESS, LineDataFlow.cpp:2425-2430
     U.nearDist = ctx->nearDist;
     U.farDist = ctx->farDist;
     U.width = ctx->width;
@@ -1335,11 +1367,13 @@ static int lv_run_ao(lv_ctx* ctx, LvUniforms& U, LvSceneDev& S, const LvTiles& T
 #define LV_LAUNCH_AO2(ST, AH)                                          \
     do {                                                               \
         if (tri) LV_LAUNCH_AO(ST, AH, LV_PRIM_TRIANGLE);               \
+        else if (U.useEllipticTubes) LV_LAUNCH_AO(ST, AH, LV_PRIM_ELLIPTIC); \
         else if (ctx->opt.literalIntersection) LV_LAUNCH_AO_LIT(ST, AH); \
         else LV_LAUNCH_AO(ST, AH, LV_PRIM_CAPSULE);                    \
     } while (0)
-        if (stats) { if (tri) LV_LAUNCH_AOP(true, LV_PRIM_TRIANGLE); else LV_LAUNCH_AOP(true, LV_PRIM_CAPSULE); }
-        else { if (tri) LV_LAUNCH_AOP(false, LV_PRIM_TRIANGLE); else LV_LAUNCH_AOP(false, LV_PRIM_CAPSULE); }
+        const bool ell = U.useEllipticTubes != 0u;
+        if (stats) { if (tri) LV_LAUNCH_AOP(true, LV_PRIM_TRIANGLE); else if (ell) LV_LAUNCH_AOP(true, LV_PRIM_ELLIPTIC); else LV_LAUNCH_AOP(true, LV_PRIM_CAPSULE); }
+        else { if (tri) LV_LAUNCH_AOP(false, LV_PRIM_TRIANGLE); else if (ell) LV_LAUNCH_AOP(false, LV_PRIM_ELLIPTIC); else LV_LAUNCH_AOP(false, LV_PRIM_CAPSULE); }
         k_ao_tile_scan<<<1, LV_BLOCK, 0, st>>>(tileCount, numGroups, tileBase, dc);
         const bool anyHit = !U.aoUseDistance;
         if (stats) { if (anyHit) LV_LAUNCH_AO2(true, true); else LV_LAUNCH_AO2(true, false); }
@@ -1395,7 +1429,17 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
     if (!ctx->points.ptr && ctx->numSegs) return lv_fail(ctx, LV_E_STATE, "lv_set_lines has not been called");
     if (numTiles == 0 || tileW == 0 || tileH == 0) return lv_fail(ctx, LV_E_INVALID, "empty tile list");
     int rc;
-    if (!ctx->accelValid || ctx->accelLineWidth != ctx->opt.lineWidth)
+    if (ctx->opt.useRibbons) {
+        // band data: the analytic paths of the ray tracer only (the triangle tubes of a band data set are the elliptic
+        // tessellation, the PPLL path its rasterised form -- neither is built)
+        if (mode != LV_RENDERING_MODE_VULKAN_RAY_TRACER || ctx->opt.rtTriangleMesh || ctx->opt.useMlat ||
+            (ctx->opt.useAmbientOcclusion && (ctx->opt.aoPrebaked || ctx->opt.aoTriangleTubes)))
+            return lv_fail(ctx, LV_E_INVALID, "use_ribbons: band data is rendered by the ray tracer's analytic geometry modes "
+                                              "only (no Triangle Mesh / MLAT / PPLL / prebaked or triangle-tube RTAO)");
+    } else if (ctx->opt.ellipticTubes) {
+        return lv_fail(ctx, LV_E_INVALID, "use_analytic_elliptic_tubes needs band data (use_ribbons)");
+    }
+    if (!ctx->accelValid || ctx->accelLineWidth != lv_accel_width(ctx))
         if ((rc = lv_bvh_build(ctx))) return rc;
     if (ctx->opt.useAmbientOcclusion && ctx->opt.aoPrebaked && mode != LV_RENDERING_MODE_VULKAN_RAY_TRACER)
         return lv_fail(ctx, LV_E_INVALID, "the static RTAO prebaker is wired to the ray tracer (mode 11) only");
@@ -1529,10 +1573,17 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
         LvSceneDev SC = tri ? sceneDevTriangles(ctx) : S;
         SC.accum = S.accum;
         if (tri && (rc = lv_prepare_overflow(ctx, SC, gridTiles, LV_STACK_LDS, true))) return rc;
-#define LV_LAUNCH_RT(ST, PR) \
-    LV_TIMED_LAUNCH(ctx, LV_KERNEL_RENDER_RT, (k_render_rt<ST, PR><<<gridTiles, LV_BLOCK, 0, st>>>(U, SC, T, out, dc)))
-        if (stats) { if (tri) LV_LAUNCH_RT(true, LV_PRIM_TRIANGLE); else LV_LAUNCH_RT(true, LV_PRIM_CAPSULE); }
-        else { if (tri) LV_LAUNCH_RT(false, LV_PRIM_TRIANGLE); else LV_LAUNCH_RT(false, LV_PRIM_CAPSULE); }
+#define LV_LAUNCH_RT(ST, PR, BA) \
+    LV_TIMED_LAUNCH(ctx, LV_KERNEL_RENDER_RT, (k_render_rt<ST, PR, BA><<<gridTiles, LV_BLOCK, 0, st>>>(U, SC, T, out, dc)))
+#define LV_LAUNCH_RT2(ST)                                                        \
+    do {                                                                         \
+        if (tri) LV_LAUNCH_RT(ST, LV_PRIM_TRIANGLE, false);                      \
+        else if (U.useEllipticTubes) LV_LAUNCH_RT(ST, LV_PRIM_ELLIPTIC, true);   \
+        else if (U.useBands) LV_LAUNCH_RT(ST, LV_PRIM_CAPSULE, true);            \
+        else LV_LAUNCH_RT(ST, LV_PRIM_CAPSULE, false);                           \
+    } while (0)
+        if (stats) LV_LAUNCH_RT2(true); else LV_LAUNCH_RT2(false);
+#undef LV_LAUNCH_RT2
 #undef LV_LAUNCH_RT
         }
         LV_HIP(ctx, hipEventRecord(ctx->ev[9], st));
@@ -1598,7 +1649,7 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
 int lv_frame_trace_rays(lv_ctx* ctx, const float* o, const float* d, float tMin, float tMax, uint32_t n, float* outT,
                         uint32_t* outSeg, uint32_t* outKind) {
     int rc;
-    if (!ctx->accelValid || ctx->accelLineWidth != ctx->opt.lineWidth)
+    if (!ctx->accelValid || ctx->accelLineWidth != lv_accel_width(ctx))
         if ((rc = lv_bvh_build(ctx))) return rc;
     if (n == 0) return LV_OK;
     hipStream_t st = ctx->stream;
@@ -1614,8 +1665,12 @@ int lv_frame_trace_rays(lv_ctx* ctx, const float* o, const float* d, float tMin,
     LV_HIP(ctx, hipMemcpyAsync(dD, d, rb, hipMemcpyHostToDevice, st));
     LvSceneDev S = sceneDev(ctx);
     if ((rc = lv_prepare_overflow(ctx, S, nblocks(n)))) return rc;
-    k_trace_rays<<<nblocks(n), LV_BLOCK, 0, st>>>(S, ctx->opt.lineWidth * 0.5f, ctx->opt.useCappedTubes, dO, dD, tMin, tMax,
-                                                  n, dT, dS, dK);
+    if (ctx->opt.useRibbons && ctx->opt.ellipticTubes) // the elliptic tubelets of the band data (kind = 0)
+        k_trace_rays<LV_PRIM_ELLIPTIC><<<nblocks(n), LV_BLOCK, 0, st>>>(S, ctx->opt.lineWidth * 0.5f, ctx->opt.useCappedTubes, dO,
+                                                                        dD, tMin, tMax, n, dT, dS, dK);
+    else
+        k_trace_rays<LV_PRIM_CAPSULE><<<nblocks(n), LV_BLOCK, 0, st>>>(S, ctx->opt.lineWidth * 0.5f, ctx->opt.useCappedTubes, dO,
+                                                                       dD, tMin, tMax, n, dT, dS, dK);
     LV_HIP(ctx, hipGetLastError());
     LV_HIP(ctx, hipMemcpyAsync(outT, dT, size_t(n) * 4, hipMemcpyDeviceToHost, st));
     LV_HIP(ctx, hipMemcpyAsync(outSeg, dS, size_t(n) * 4, hipMemcpyDeviceToHost, st));

@@ -406,6 +406,133 @@ __device__ __forceinline__ unsigned lv_node_step(const LvSceneDev& S, unsigned n
 // ---------------------------------------------------------------- leaf tests of the cooperative routines
 // One (ray, leaf) test.  Returns true with t and the low 32 bits of the merge key: capsules -> (original segment << 2)
 // | kind, triangles -> original triangle index; in both cases "smaller key = closer, ties to the lowest index".
+// ---------------------------------------------------------------- elliptic tubes (EllipticTubeRayTracing.glsl)
+// The ray tracer's "Elliptic Tubes" mode for band data: every segment is a tubelet with an elliptic cross-section (semi-axes
+// radius0 = bandWidth / 2 * minBandThickness along the line normal, radius1 = bandWidth / 2 along the binormal) that twists from
+// the normal at p0 to the normal at p1, found by sphere tracing in the tubelet's coordinate system (Reina et al. 2006).
+struct LvM3 { f3 c0, c1, c2; }; // columns, GLSL layout
+__device__ __forceinline__ f3 lv_mul_m3(const LvM3& m, f3 v) { return (m.c0 * v.x + m.c1 * v.y) + m.c2 * v.z; }
+// matrixAxisRotationCos, EllipticTubeRayTracing.glsl:69-91
+__device__ __forceinline__ LvM3 lv_matrix_axis_rotation_cos(f3 axis, float cosAngle) {
+    const float c = cosAngle;
+    const float s = sqrtf(1.0f - cosAngle * cosAngle);
+    axis = norm3(axis);
+    const f3 temp = (1.0f - c) * axis;
+    LvM3 R;
+    R.c0 = mk3(c + temp.x * axis.x, temp.x * axis.y + s * axis.z, temp.x * axis.z - s * axis.y);
+    R.c1 = mk3(temp.y * axis.x - s * axis.z, c + temp.y * axis.y, temp.y * axis.z + s * axis.x);
+    R.c2 = mk3(temp.z * axis.x + s * axis.y, temp.z * axis.y - s * axis.x, c + temp.z * axis.z);
+    return R;
+}
+// computeRadius, :3-7
+__device__ __forceinline__ float lv_ell_compute_radius(float r1, float r2, float phi, float rho) {
+    float sn, cs;
+    lv_sincos_rad(phi + rho, sn, cs);
+    return r1 * r2 / sqrtf(r1 * r1 * sn * sn + r2 * r2 * cs * cs);
+}
+// computeNormal, :22-41
+__device__ __forceinline__ f3 lv_ell_compute_normal(float r1, float r2, float phi, float rho) {
+    float sinphi, cosphi, sinphirho, cosphirho;
+    lv_sincos_rad(phi + rho, sinphi, cosphi);
+    lv_sincos_rad(phi, sinphirho, cosphirho);
+    const float r1sq = r1 * r1, r2sq = r2 * r2, r1r2 = r1 * r2;
+    const float rDenomSq = r1sq * sinphi * sinphi + r2sq * cosphi * cosphi;
+    const float rDenom = sqrtf(rDenomSq);
+    const float r = r1r2 / rDenom;
+    const float ddenomDphi = (r1sq - r2sq) * sinphi * cosphi / rDenom;
+    const float drDphi = -r1r2 * ddenomDphi / rDenomSq;
+    const f3 dxDphi = mk3(0.0f, drDphi * cosphirho - r * sinphirho, drDphi * sinphirho + r * cosphirho);
+    return cross3(dxDphi, mk3(1.0f, 0.0f, 0.0f));
+}
+// rayBoxPlaneIntersection, :126-163
+__device__ __forceinline__ bool lv_ell_ray_box_plane(float o, float d, float lower, float upper, float& tNear, float& tFar) {
+    if (fabsf(d) < 1e-3f) {
+        if (o < lower || o > upper) return false;
+    } else {
+        float t0 = (lower - o) / d, t1 = (upper - o) / d;
+        if (t0 > t1) { const float tmp = t0; t0 = t1; t1 = tmp; }
+        if (t0 > tNear) tNear = t0;
+        if (t1 < tFar) tFar = t1;
+        if (tNear > tFar) return false;
+        if (tFar < 0.0f) return false;
+    }
+    return true;
+}
+// the tubelet frame shared by the intersection and the closest-hit shader (:201-222 = :320-341)
+struct LvTubelet { f3 p0, p1, xt, yt, zt; float l, rhoR; };
+__device__ __forceinline__ LvTubelet lv_make_tubelet(const lv_line_point& lp0, const lv_line_point& lp1) {
+    LvTubelet T;
+    T.p0 = mk3(lp0.linePosition[0], lp0.linePosition[1], lp0.linePosition[2]);
+    T.p1 = mk3(lp1.linePosition[0], lp1.linePosition[1], lp1.linePosition[2]);
+    const f3 n0 = mk3(lp0.lineNormal[0], lp0.lineNormal[1], lp0.lineNormal[2]);
+    const f3 n1 = mk3(lp1.lineNormal[0], lp1.lineNormal[1], lp1.lineNormal[2]);
+    const f3 t0 = mk3(lp0.lineTangent[0], lp0.lineTangent[1], lp0.lineTangent[2]);
+    T.l = len3(T.p1 - T.p0);
+    T.xt = norm3(T.p1 - T.p0);
+    const f3 rotAxis = cross3(n0, T.xt);
+    const float rotCosAngle = dot3(n0, T.xt);
+    LvM3 R;
+    R.c0 = mk3(1.0f, 0.0f, 0.0f); R.c1 = mk3(0.0f, 1.0f, 0.0f); R.c2 = mk3(0.0f, 0.0f, 1.0f);
+    if (fabsf(rotCosAngle) > 0.999f) R = lv_matrix_axis_rotation_cos(rotAxis, rotCosAngle);
+    T.yt = lv_mul_m3(R, n0);
+    T.zt = lv_mul_m3(R, cross3(t0, n0));
+    T.rhoR = -lv_atan2_det(dot3(cross3(n0, n1), t0), dot3(n0, n1));
+    return T;
+}
+__device__ __forceinline__ f3 lv_to_tubelet(const LvTubelet& T, f3 w) { return mk3(dot3(T.xt, w), dot3(T.yt, w), dot3(T.zt, w)); }
+__device__ __forceinline__ f3 lv_from_tubelet(const LvTubelet& T, f3 p) { return (T.xt * p.x + T.yt * p.y) + T.zt * p.z; }
+
+// IntersectionEllipticTube main(), :186-270.  The reference reports the hit whenever the driver invokes the shader, i.e. whenever
+// the ray meets the segment's box; hitT itself may leave the box interval (a start point inside the surface steps backwards,
+// tilted cutting planes let the surface reach past the box).  To keep the result independent of the BVH a hit is accepted only
+// within bandWidth / |d| of the box interval (own-box rule, as for the literal capsule roots) and the traversal's culling
+// interval is widened by the same amount (lv_trace_closest).
+__device__ __forceinline__ bool lv_intersect_elliptic_tube(const LvSceneDev& S, f3 o, f3 d, const lv_line_point& lp0,
+                                                           const lv_line_point& lp1, float& hitTOut) {
+    const float radius0 = S.ellBandWidth * 0.5f * S.ellMinBandThickness;
+    const float radius1 = S.ellBandWidth * 0.5f;
+    const float lwo = S.ellBandWidth * 0.5f;
+    float tNear = -1e7f, tFar = 1e7f;
+    // the segment's box of TubeAabbRenderData, LineDataFlow.cpp:2223-2234
+    if (!lv_ell_ray_box_plane(o.x, d.x, fminf(lp0.linePosition[0], lp1.linePosition[0]) - lwo,
+                              fmaxf(lp0.linePosition[0], lp1.linePosition[0]) + lwo, tNear, tFar)) return false;
+    if (!lv_ell_ray_box_plane(o.y, d.y, fminf(lp0.linePosition[1], lp1.linePosition[1]) - lwo,
+                              fmaxf(lp0.linePosition[1], lp1.linePosition[1]) + lwo, tNear, tFar)) return false;
+    if (!lv_ell_ray_box_plane(o.z, d.z, fminf(lp0.linePosition[2], lp1.linePosition[2]) - lwo,
+                              fmaxf(lp0.linePosition[2], lp1.linePosition[2]) + lwo, tNear, tFar)) return false;
+    const f3 startPoint = o + tNear * d;
+    const LvTubelet T = lv_make_tubelet(lp0, lp1);
+    const f3 t0 = mk3(lp0.lineTangent[0], lp0.lineTangent[1], lp0.lineTangent[2]);
+    const f3 t1 = mk3(lp1.lineTangent[0], lp1.lineTangent[1], lp1.lineTangent[2]);
+    const f3 El = t0; const float Elw = -dot3(El, T.p0);             // left and right cutting planes
+    const f3 Er = mk3(-t1.x, -t1.y, -t1.z); const float Erw = -dot3(Er, T.p1);
+    f3 p = lv_to_tubelet(T, startPoint - T.p0);
+    const f3 dd = lv_to_tubelet(T, d);
+    float hitT = tNear, dTmp = 0.0f;
+    for (int i = 0; i < 80; i++) { // MAX_NUM_SPHERE_TRACING_ITERATIONS
+        const float t = clampf(p.x / T.l, 0.0f, 1.0f);
+        const float rhoX = t * T.rhoR;
+        const float phi = lv_atan2_det(p.z, p.y);
+        const float r = lv_ell_compute_radius(radius0, radius1, phi, rhoX);
+        dTmp = sqrtf(p.y * p.y + p.z * p.z) - r;
+        dTmp *= 0.25f;
+        p = p + dd * dTmp;
+        hitT += dTmp;
+        if (dTmp < 1e-5f) break; // EPSILON_SPHERE_TRACING_TERMINATION
+    }
+    const f3 pointWorld = lv_from_tubelet(T, p) + T.p0;
+    const f3 cam = mk3(S.ellCamPos[0], S.ellCamPos[1], S.ellCamPos[2]);
+    const float eps1 = fabsf(dot3(El, norm3(cam - T.p0))) * 5e-5f;
+    const float eps2 = fabsf(dot3(Er, norm3(cam - T.p1))) * 5e-5f;
+    const bool isNotCulledLeft = dot3(El, pointWorld) + Elw > -eps1;
+    const bool isNotCulledRight = dot3(Er, pointWorld) + Erw > -eps2;
+    if (!(dTmp < 1e-4f && hitT > 0.0f && isNotCulledLeft && isNotCulledRight)) return false;
+    const float slack = S.ellBandWidth / len3(d);
+    if (hitT < tNear - slack || hitT > tFar + slack) return false; // own-box rule
+    hitTOut = hitT;
+    return true;
+}
+
 // LIT: -1 = intersection form from S.literalIntersection at run time (tile kernels), 0 / 1 = fixed at compile time (k_ao_rays:
 // a run-time branch around both capsule tests costs the register that pushes the kernel over its 96-VGPR budget into scratch)
 template <int PRIM, int LIT = -1>
@@ -417,6 +544,10 @@ __device__ __forceinline__ bool lv_leaf_test(const LvSceneDev& S, unsigned leaf,
         float u, v;
         low = __float_as_uint(a.w);
         return lv_ray_triangle(o, d, inv, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), S.triPad, t, u, v);
+    } else if (PRIM == LV_PRIM_ELLIPTIC) {
+        const uint32_t seg = S.leafSeg[leaf];
+        low = seg << 2;
+        return lv_intersect_elliptic_tube(S, o, d, S.points[S.segIdx[2 * size_t(seg)]], S.points[S.segIdx[2 * size_t(seg) + 1]], t);
     } else {
         const float4 a = S.segs[2 * size_t(leaf)], b = S.segs[2 * size_t(leaf) + 1];
         int kind;
@@ -502,7 +633,9 @@ __device__ __forceinline__ LvHit lv_trace_closest(const LvSceneDev& S, float rad
     unsigned head = 0, tail = 0;
     float best = tMax;
     // literal roots: cull against [tMin - r / |d|, best + r / |d|] (lv_intersect_capsule_literal); 0 otherwise
-    float slack = (PRIM == LV_PRIM_CAPSULE && S.literalIntersection) ? radius / len3(d) : 0.0f;
+    // elliptic tubelets: [tMin - bandWidth / |d|, best + bandWidth / |d|] (lv_intersect_elliptic_tube's own-box rule)
+    float slack = PRIM == LV_PRIM_ELLIPTIC ? S.ellBandWidth / len3(d)
+                  : (PRIM == LV_PRIM_CAPSULE && S.literalIntersection) ? radius / len3(d) : 0.0f;
     while (true) {
         // leaves reached by the last step (or popped) join the FIFO
         const bool isLeaf = cur != LV_INVALID && (cur & LV_LEAF_BIT);
@@ -568,7 +701,8 @@ __device__ __forceinline__ LvHit lv_trace_closest(const LvSceneDev& S, float rad
                         oi = mk3(ro.x * inv.x, ro.y * inv.y, ro.z * inv.z);
                         tMin = ro.w;
                         best = __uint_as_float(unsigned(cm.key[owner] >> 32));
-                        slack = (PRIM == LV_PRIM_CAPSULE && S.literalIntersection) ? radius / len3(mk3(rd.x, rd.y, rd.z)) : 0.0f;
+                        slack = PRIM == LV_PRIM_ELLIPTIC ? S.ellBandWidth / len3(mk3(rd.x, rd.y, rd.z))
+                                : (PRIM == LV_PRIM_CAPSULE && S.literalIntersection) ? radius / len3(mk3(rd.x, rd.y, rd.z)) : 0.0f;
                     }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -797,9 +931,20 @@ __device__ __forceinline__ f4 lv_transfer_function(const LvSceneDev& S, const Lv
     return r;
 }
 
+// USE_BANDS arguments of computeFragmentColor (RayHitCommon.glsl:82-90,148-190)
+struct LvBandArgs { bool useBand; float phi; f3 linePosition, lineNormal; };
+template <bool BANDS>
+__device__ __forceinline__ f4 lv_compute_fragment_color_t(const LvSceneDev& S, const LvUniforms& U, float aoTexel, f3 fragPos,
+                                                          f3 fragmentNormal, f3 fragmentTangent, bool isCap,
+                                                          float fragmentAttribute, float& payloadHitT, const LvBandArgs& bands);
 __device__ __forceinline__ f4 lv_compute_fragment_color(const LvSceneDev& S, const LvUniforms& U, float aoTexel, f3 fragPos,
                                                         f3 fragmentNormal, f3 fragmentTangent, bool isCap,
-                                                        float fragmentAttribute, float& payloadHitT);
+                                                        float fragmentAttribute, float& payloadHitT) {
+    LvBandArgs none;
+    none.useBand = false; none.phi = 0.0f; none.linePosition = mk3(0.0f, 0.0f, 0.0f); none.lineNormal = mk3(0.0f, 0.0f, 0.0f);
+    return lv_compute_fragment_color_t<false>(S, U, aoTexel, fragPos, fragmentNormal, fragmentTangent, isCap, fragmentAttribute,
+                                              payloadHitT, none);
+}
 
 // getAoFactor(interpolatedVertexId, phi) of the static prebaker, AmbientOcclusion.glsl:49-75, without its last two lines
 // (pow(gamma) and the strength mapping are the same as for the screen-space texture and applied by the shading code).
@@ -830,6 +975,7 @@ __device__ __forceinline__ float lv_prebaked_ao_lookup(const LvSceneDev& S, cons
 // ClosestHitTubeAnalytic + computeFragmentColor + blinnPhongShadingTube for flow lines.
 // aoTexel: AO factor of the pixel that launched the ray (lookup definition: DESIGN.md).  Returns payload.hitColor;
 // payloadHitT = length(hit - camera).
+template <bool BANDS = false>
 __device__ __forceinline__ f4 lv_shade_hit(const LvSceneDev& S, const LvUniforms& U, float aoTexel, f3 o, f3 d,
                                            const LvHit& h, float& payloadHitT) {
     const float4 ra = S.segs[2 * h.leaf], rb = S.segs[2 * h.leaf + 1];
@@ -868,8 +1014,72 @@ __device__ __forceinline__ f4 lv_shade_hit(const LvSceneDev& S, const LvUniforms
         const float fragmentVertexId = (1.0f - ts) * float(i0) + ts * float(i1);
         aoTexel = lv_prebaked_ao_lookup(S, U, fragmentVertexId, phi);
     }
+    if (BANDS) {
+        // band data with the circular analytic tubes: USE_BANDS is defined, ANALYTIC_TUBE_INTERSECTIONS sets useBand = false
+        // (RayHitCommon.glsl:164-166); phi and the line normal as TubeRayTracing.glsl:551-560 (acos through the build's atan2)
+        const uint32_t seg = S.leafSeg[h.leaf];
+        const lv_line_point& lp0 = S.points[S.segIdx[2 * seg]];
+        const lv_line_point& lp1 = S.points[S.segIdx[2 * seg + 1]];
+        const float ts = h.kind == 0 ? dot3(v, fragPos - P0) / dot3(v, v) : (h.kind == 1 ? 0.0f : 1.0f);
+        LvBandArgs b;
+        b.useBand = false;
+        b.lineNormal = (1.0f - ts) * mk3(lp0.lineNormal[0], lp0.lineNormal[1], lp0.lineNormal[2]) +
+                       ts * mk3(lp1.lineNormal[0], lp1.lineNormal[1], lp1.lineNormal[2]);
+        const float cphi = clampf(dot3(fragmentNormal, b.lineNormal), -1.0f, 1.0f);
+        b.phi = lv_atan2_det(sqrtf((1.0f - cphi) * (1.0f + cphi)), cphi);
+        if (dot3(b.lineNormal, cross3(fragmentNormal, fragmentTangent)) < 0.0f) b.phi = 2.0f * 3.14159265358979323846f - b.phi;
+        b.linePosition = linePointInterpolated;
+        return lv_compute_fragment_color_t<true>(S, U, aoTexel, fragPos, fragmentNormal, fragmentTangent, isCap,
+                                                 fragmentAttribute, payloadHitT, b);
+    }
     return lv_compute_fragment_color(S, U, aoTexel, fragPos, fragmentNormal, fragmentTangent, isCap, fragmentAttribute,
                                      payloadHitT);
+}
+
+// ClosestHitEllipticTubeAnalytic main(), EllipticTubeRayTracing.glsl:303-441: position in the tubelet frame -> t, phi, rho ->
+// normal of the twisted elliptic surface; attribute and line normal interpolated with t; the angle in the ellipse's own
+// parametrisation p = (r1 cos, r2 sin) for the band shading.
+struct LvEllipticSurface { f3 fragPos, normal, tangent, linePosition, lineNormal; float t, phiLine, attribute; };
+__device__ __forceinline__ LvEllipticSurface lv_elliptic_surface(const LvUniforms& U, f3 o, f3 d, float hitT,
+                                                                 const lv_line_point& lp0, const lv_line_point& lp1) {
+    LvEllipticSurface E;
+    E.fragPos = o + d * hitT;
+    const LvTubelet T = lv_make_tubelet(lp0, lp1);
+    const f3 p = lv_to_tubelet(T, E.fragPos - T.p0);
+    const float radius0 = U.bandWidth * 0.5f * U.minBandThickness;
+    const float radius1 = U.bandWidth * 0.5f;
+    const float t = clampf(p.x / T.l, 0.0f, 1.0f);
+    const float phi = lv_atan2_det(p.z, p.y);
+    const float rho = t * T.rhoR;
+    E.t = t;
+    E.normal = norm3(lv_from_tubelet(T, lv_ell_compute_normal(radius0, radius1, phi, rho)));
+    E.attribute = (1.0f - t) * lp0.lineAttribute + t * lp1.lineAttribute;
+    E.linePosition = (1.0f - t) * T.p0 + t * T.p1;
+    E.tangent = T.xt;
+    E.lineNormal = norm3((1.0f - t) * mk3(lp0.lineNormal[0], lp0.lineNormal[1], lp0.lineNormal[2]) +
+                         t * mk3(lp1.lineNormal[0], lp1.lineNormal[1], lp1.lineNormal[2]));
+    float sinphi, cosphi;
+    lv_sincos_rad(phi + rho, sinphi, cosphi);
+    const float phiDenomInv = 1.0f / sqrtf(radius0 * radius0 * sinphi * sinphi + radius1 * radius1 * cosphi * cosphi);
+    const float sinPhiLine = radius0 * sinphi * phiDenomInv;
+    const float cosPhiLine = radius1 * cosphi * phiDenomInv;
+    const float TWO_PI = 6.283185307f; // M_TWO_PI as the shader spells it
+    const float a = lv_atan2_det(sinPhiLine, cosPhiLine) + TWO_PI;
+    E.phiLine = a - TWO_PI * floorf(a / TWO_PI); // mod(x, y) = x - y * floor(x / y)
+    return E;
+}
+__device__ __forceinline__ f4 lv_shade_hit_elliptic(const LvSceneDev& S, const LvUniforms& U, float aoTexel, f3 o, f3 d,
+                                                    const LvHit& h, float& payloadHitT) {
+    const uint32_t seg = S.leafSeg[h.leaf];
+    const lv_line_point& lp0 = S.points[S.segIdx[2 * seg]];
+    const lv_line_point& lp1 = S.points[S.segIdx[2 * seg + 1]];
+    const LvEllipticSurface E = lv_elliptic_surface(U, o, d, h.t, lp0, lp1);
+    LvBandArgs b;
+    b.useBand = true;
+    b.phi = E.phiLine;
+    b.linePosition = E.linePosition;
+    b.lineNormal = E.lineNormal;
+    return lv_compute_fragment_color_t<true>(S, U, aoTexel, E.fragPos, E.normal, E.tangent, false, E.attribute, payloadHitT, b);
 }
 
 // ClosestHitTubeTriangles (TubeRayTracing.glsl:301-352) + LineAttributesBarycentric.glsl: the ray tracer's "Triangle
@@ -916,9 +1126,10 @@ __device__ __forceinline__ f4 lv_shade_hit_triangle(const LvSceneDev& S, const L
 }
 
 // computeFragmentColor (RayHitCommon.glsl:74-543) for tubes, shared by the analytic and the triangle closest-hit paths
-__device__ __forceinline__ f4 lv_compute_fragment_color(const LvSceneDev& S, const LvUniforms& U, float aoTexel, f3 fragPos,
-                                                        f3 fragmentNormal, f3 fragmentTangent, bool isCap,
-                                                        float fragmentAttribute, float& payloadHitT) {
+template <bool BANDS>
+__device__ __forceinline__ f4 lv_compute_fragment_color_t(const LvSceneDev& S, const LvUniforms& U, float aoTexel, f3 fragPos,
+                                                          f3 fragmentNormal, f3 fragmentTangent, bool isCap,
+                                                          float fragmentAttribute, float& payloadHitT, const LvBandArgs& bands) {
     const f3 cam = mk3(U.camPos[0], U.camPos[1], U.camPos[2]);
     f4 fragmentColor = lv_transfer_function(S, U, fragmentAttribute);
     f3 n = norm3(fragmentNormal);
@@ -938,6 +1149,59 @@ __device__ __forceinline__ f4 lv_compute_fragment_color(const LvSceneDev& S, con
             if (dot3(t, crossProdVn) < 0.0f) ribbonPosition = -ribbonPosition;
             ribbonPosition2 = clampf(ribbonPosition2, -1.0f, 1.0f);
             if (fabsf(ribbonPosition2) < fabsf(ribbonPosition)) ribbonPosition = ribbonPosition2;
+        } else if (BANDS) {
+            // USE_BANDS, RayHitCommon.glsl:232-351: the fragment's position between the two silhouette points of the elliptic
+            // cross-section as the camera sees it -- tangent-plane coordinates, polar line of the camera point with respect to the
+            // conic x^2 / thickness^2 + y^2 = 1, its two intersections with the conic from the degenerate conic B + alpha M_l
+            const float thickness = bands.useBand ? U.minThickness : 1.0f;
+            const f3 lineN = norm3(bands.lineNormal);
+            const f3 lineB = cross3(t, lineN);
+            const f3 cNorm = cam - bands.linePosition;
+            const float dist = dot3(cNorm, fragmentTangent);
+            const f3 wv = cNorm - dist * fragmentTangent;
+            const f3 cHat = mk3(dot3(lineN, wv), dot3(lineB, wv), dot3(t, wv)); // transpose(mat3(lineN, lineB, t)) * w
+            const float lineRadius = (bands.useBand ? U.bandWidth : U.lineWidth) * 0.5f;
+            const f3 c = mk3(cHat.x / lineRadius, cHat.y / lineRadius, 1.0f);
+            const float a = 1.0f / (thickness * thickness);
+            const f3 l = mk3(a * c.x, c.y, -1.0f);
+            // M_l = shearSymmetricMatrix(l): columns (0, -l.z, l.y), (l.z, 0, -l.x), (-l.y, l.x, 0); B[column][row]
+            const float Ml[3][3] = {{0.0f, -l.z, l.y}, {l.z, 0.0f, -l.x}, {-l.y, l.x, 0.0f}};
+            const float B[3][3] = {{l.z * l.z - l.y * l.y, l.x * l.y, -l.x * l.z},
+                                   {l.x * l.y, a * l.z * l.z - l.x * l.x, -a * l.y * l.z},
+                                   {-l.x * l.z, -a * l.y * l.z, a * l.y * l.y + l.x * l.x}};
+            const float EPSILON = 1e-4f;
+            float alpha = 0.0f, discr = 0.0f;
+            if (fabsf(l.z) > EPSILON) {
+                discr = -B[0][0] * B[1][1] + B[0][1] * B[1][0];
+                alpha = sqrtf(discr) / l.z;
+            } else if (fabsf(l.y) > EPSILON) {
+                discr = -B[0][0] * B[2][2] + B[0][2] * B[2][0];
+                alpha = sqrtf(discr) / l.y;
+            } else if (fabsf(l.x) > EPSILON) {
+                discr = -B[1][1] * B[2][2] + B[1][2] * B[2][1];
+                alpha = sqrtf(discr) / l.x;
+            }
+            float Cm[3][3];
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+#pragma unroll
+                for (int j = 0; j < 3; j++) Cm[i][j] = B[i][j] + alpha * Ml[i][j];
+            float pm0x = 0.0f, pm0y = 0.0f, pm1x = 0.0f, pm1y = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                if (fabsf(Cm[i][i]) > EPSILON) {
+                    pm0x = Cm[i][0] / Cm[i][2]; pm0y = Cm[i][1] / Cm[i][2]; // column i
+                    pm1x = Cm[0][i] / Cm[2][i]; pm1y = Cm[1][i] / Cm[2][i]; // row i
+                }
+            }
+            float sp, cp;
+            lv_sincos_rad(bands.phi, sp, cp);
+            const f3 pH = mk3(thickness * cp, sp, 1.0f);
+            const f3 pLineH = cross3(l, cross3(c, pH));
+            const float plx = pLineH.x / pLineH.z, ply = pLineH.y / pLineH.z;
+            const float num = sqrtf((plx - pm0x) * (plx - pm0x) + (ply - pm0y) * (ply - pm0y));
+            const float den = sqrtf((pm1x - pm0x) * (pm1x - pm0x) + (pm1y - pm0y) * (pm1y - pm0y));
+            ribbonPosition = num / den * 2.0f - 1.0f;
         } else {
             f3 crossProdVn = cross3(newV, n);
             ribbonPosition = len3(crossProdVn);
@@ -985,7 +1249,7 @@ __device__ __forceinline__ f4 lv_compute_fragment_color(const LvSceneDev& S, con
     f3 hh = norm3(vv + l);
     f3 helperVecL = norm3(cross3(tB, l));
     f3 newL = norm3(cross3(helperVecL, tB));
-    const float exponent = 1.7f;
+    const float exponent = (BANDS && bands.useBand) ? 1.0f : 1.7f; // Lighting.glsl:158-162
     float cosNormal1 = powf(clampf(fabsf(dot3(nB, l)), 0.0f, 1.0f), exponent);
     float cosNormal2 = powf(clampf(fabsf(dot3(nB, newL)), 0.0f, 1.0f), exponent);
     float cosNormalCombined = 0.3f * cosNormal1 + 0.7f * cosNormal2;
@@ -1016,10 +1280,15 @@ __device__ __forceinline__ f4 lv_compute_fragment_color(const LvSceneDev& S, con
     float fragmentDepth = len3(fragPos - cam);
     float aaO = ((fragmentDepth / U.lineWidth) * 0.05f) / float(U.height) * U.fovY;
     float aaW = ((fragmentDepth / U.lineWidth) * 2.0f) / float(U.height) * U.fovY;
+    if (BANDS) { // RayHitCommon.glsl:445-448
+        const float wdt = bands.useBand ? U.bandWidth : U.lineWidth;
+        aaO = aaW = ((fragmentDepth / wdt) * 0.25f) / float(U.height) * U.fovY;
+    }
     float EPSILON_OUTLINE = clampf(aaO, 0.0f, 0.49f);
     float EPSILON_WHITE = clampf(aaW, 0.0f, 0.49f);
     const float WHITE_THRESHOLD = 0.7f;
     float coverage = U.useHalos ? 1.0f - smoothstepf(1.0f - EPSILON_OUTLINE, 1.0f, absCoords) : 1.0f;
+    if (BANDS && bands.useBand && U.useEllipticTubes) coverage = 1.0f; // ANALYTIC_ELLIPTIC_TUBE_INTERSECTIONS, :499-504
     float w = smoothstepf(WHITE_THRESHOLD - EPSILON_WHITE, WHITE_THRESHOLD + EPSILON_WHITE, absCoords);
     f4 out;
     out.x = mixf(phong[0], U.foreground[0], w);

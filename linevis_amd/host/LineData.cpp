@@ -53,8 +53,8 @@ struct Reader {
 };
 } // namespace
 
-// BinLinesLoader.cpp:127-150 (version word) + :41-63 (v1 payload)
-bool loadTrajectoriesFromBinLines(const std::string& filename, Trajectories& trajectories) {
+// BinLinesLoader.cpp:127-180 (version word), :41-63 (v1 payload), :68-125 (v2 trailer)
+bool loadTrajectoriesFromBinLines(const std::string& filename, BinLinesData& binLinesData) {
     FILE* f = fopen(filename.c_str(), "rb");
     if (!f) return false;
     fseek(f, 0, SEEK_END);
@@ -70,6 +70,7 @@ bool loadTrajectoriesFromBinLines(const std::string& filename, Trajectories& tra
     uint32_t numTrajectories = r.get<uint32_t>();
     uint32_t numAttributes = r.get<uint32_t>();
     if (!r.ok) return false;
+    Trajectories& trajectories = binLinesData.trajectories;
     trajectories.clear();
     trajectories.resize(numTrajectories);
     for (uint32_t i = 0; i < numTrajectories; i++) {
@@ -84,13 +85,49 @@ bool loadTrajectoriesFromBinLines(const std::string& filename, Trajectories& tra
             if (!r.getArray(t.attributes[a].data(), sizeof(float) * n)) return false;
         }
     }
+    binLinesData.attributeNames.clear();
+    binLinesData.ribbonsDirections.clear();
+    binLinesData.verticesNormalized = false;
+    if (versionNumber == 2u) {
+        binLinesData.verticesNormalized = r.get<uint32_t>() != 0u;
+        const uint32_t hasAttributeNames = r.get<uint32_t>();
+        if (!r.ok) return false;
+        if (hasAttributeNames != 0u) {
+            const uint32_t n = trajectories.empty() ? 0u : numAttributes;
+            for (uint32_t a = 0; a < n; a++) { // sgl::BinaryReadStream::read(std::string&): u32 length, then the characters
+                const uint32_t strLen = r.get<uint32_t>();
+                std::string name(strLen, '\0');
+                if (!r.ok || !r.getArray(strLen ? &name[0] : nullptr, strLen)) return false;
+                binLinesData.attributeNames.push_back(name);
+            }
+        }
+        const uint32_t hasRibbonData = r.get<uint32_t>();
+        if (!r.ok) return false;
+        if (hasRibbonData != 0u) {
+            binLinesData.ribbonsDirections.resize(numTrajectories);
+            for (uint32_t i = 0; i < numTrajectories; i++) {
+                std::vector<vec3>& dirs = binLinesData.ribbonsDirections[i];
+                dirs.resize(trajectories[i].positions.size());
+                if (!r.getArray(dirs.data(), sizeof(vec3) * dirs.size())) return false;
+            }
+        }
+        // numMeshOutlineTriangleIndices / Vertices / Normals and their arrays: not used by the line renderers
+    }
+    return true;
+}
+bool loadTrajectoriesFromBinLines(const std::string& filename, Trajectories& trajectories) {
+    BinLinesData d;
+    if (!loadTrajectoriesFromBinLines(filename, d)) return false;
+    trajectories.swap(d.trajectories);
     return true;
 }
 
-bool saveTrajectoriesAsBinLines(const std::string& filename, const Trajectories& trajectories) {
+bool saveTrajectoriesAsBinLines(const std::string& filename, const Trajectories& trajectories,
+                                const std::vector<std::vector<vec3>>& ribbonsDirections) {
     FILE* f = fopen(filename.c_str(), "wb");
     if (!f) return false;
-    uint32_t hdr[3] = {1u, uint32_t(trajectories.size()),
+    const bool v2 = !ribbonsDirections.empty();
+    uint32_t hdr[3] = {v2 ? 2u : 1u, uint32_t(trajectories.size()),
                        trajectories.empty() ? 0u : uint32_t(trajectories[0].attributes.size())};
     fwrite(hdr, 4, 3, f);
     for (const Trajectory& t : trajectories) {
@@ -98,6 +135,14 @@ bool saveTrajectoriesAsBinLines(const std::string& filename, const Trajectories&
         fwrite(&n, 4, 1, f);
         fwrite(t.positions.data(), sizeof(vec3), n, f);
         for (uint32_t a = 0; a < hdr[2]; a++) fwrite(t.attributes[a].data(), sizeof(float), n, f);
+    }
+    if (v2) { // BinLinesLoader.cpp:196-247: verticesNormalized, hasAttributeNames = 0, hasRibbonData = 1, no outline mesh
+        const uint32_t trailer[3] = {1u, 0u, 1u};
+        fwrite(trailer, 4, 3, f);
+        for (size_t i = 0; i < trajectories.size(); i++)
+            fwrite(ribbonsDirections[i].data(), sizeof(vec3), trajectories[i].positions.size(), f);
+        const uint32_t mesh[3] = {0u, 0u, 0u};
+        fwrite(mesh, 4, 3, f);
     }
     return fclose(f) == 0;
 }
@@ -237,16 +282,57 @@ bool LineData::setNewSettings(const SettingsMap& settings) {
 bool LineDataFlow::loadFromFile(const std::string& filename) {
     Trajectories loaded;
     std::vector<std::string> names;
-    if (!loadFlowTrajectoriesFromFile(filename, loaded, names)) return false;
+    std::vector<std::vector<vec3>> ribbons;
+    const size_t n = filename.size();
+    if (n >= 9 && filename.compare(n - 9, 9, ".binlines") == 0) { // LineDataFlow.cpp:436-446: band data comes with the file
+        BinLinesData d;
+        if (!loadTrajectoriesFromBinLines(filename, d)) return false;
+        loaded.swap(d.trajectories);
+        names = d.attributeNames;
+        ribbons.swap(d.ribbonsDirections);
+    } else if (!loadFlowTrajectoriesFromFile(filename, loaded, names)) {
+        return false;
+    }
     AABB3 aabb = computeTrajectoriesAABB3(loaded);
     normalizeTrajectoriesVertexPositions(loaded, aabb);
-    setTrajectoryData(loaded, names);
+    setTrajectoryData(loaded, names, ribbons);
     return true;
 }
 
+bool LineData::renderThickBands = true;
+float LineData::minBandThickness = 0.15f;
+bool LineDataFlow::useRibbons = true;
+
+// LineDataFlow::setNewSettings, LineDataFlow.cpp:584-610
+bool LineDataFlow::setNewSettings(const SettingsMap& settings) {
+    bool shallReloadGatherShader = LineData::setNewSettings(settings);
+    bool b = useRibbons;
+    if (settings.getValueOpt("use_ribbons", b) && b != useRibbons) {
+        useRibbons = b;
+        setTriangleRepresentationDirty();
+        shallReloadGatherShader = true;
+    }
+    b = renderThickBands;
+    if (settings.getValueOpt("thick_bands", b) && b != renderThickBands) {
+        renderThickBands = b;
+        dirty = true;
+        shallReloadGatherShader = true;
+    }
+    float f = minBandThickness;
+    if (settings.getValueOpt("min_band_thickness", f) && f != minBandThickness) {
+        minBandThickness = f;
+        dirty = true;
+        shallReloadGatherShader = true;
+    }
+    return shallReloadGatherShader;
+}
+
 // LineDataFlow.cpp:468-578 (flow lines: counts, per-attribute min/max, model AABB)
-void LineDataFlow::setTrajectoryData(const Trajectories& newTrajectories, const std::vector<std::string>& names) {
+void LineDataFlow::setTrajectoryData(const Trajectories& newTrajectories, const std::vector<std::string>& names,
+                                     const std::vector<std::vector<vec3>>& newRibbonsDirections) {
     trajectories = newTrajectories;
+    ribbonsDirections = newRibbonsDirections;
+    hasBandsData = !ribbonsDirections.empty(); // LineDataFlow.cpp:469
     numTotalTrajectories = trajectories.size();
     numTotalTrajectoryPoints = 0;
     for (const Trajectory& t : trajectories) numTotalTrajectoryPoints += t.positions.size();
@@ -282,9 +368,11 @@ std::vector<std::vector<vec3>> LineDataFlow::getFilteredLines(LineRenderer*) {
 
 // LineDataFlow.cpp:2112-2277.  The per-line loop carries lastLineNormal from point to point, so lines are the unit
 // of parallelism: every line is processed into its own vectors (OpenMP), then concatenated in line order.
-TubeAabbRenderData LineDataFlow::getLinePassTubeAabbRenderData(bool /*isRasterizer*/, bool /*ellipticTubes*/) {
-    const float lineWidth = LineRenderer::getLineWidth();
-    if (cachedAabbDataValid && cachedLineWidth == lineWidth) return cachedTubeAabbRenderData;
+TubeAabbRenderData LineDataFlow::getLinePassTubeAabbRenderData(bool /*isRasterizer*/, bool ellipticTubes) {
+    // elliptic tubes of a band data set: normals from the ribbon directions, boxes padded by half the band width (:2120-2126)
+    const bool useRibbonNormals = ellipticTubes && useRibbons && hasBandsData;
+    const float lineWidth = useRibbonNormals ? LineRenderer::getBandWidth() : LineRenderer::getLineWidth();
+    if (cachedAabbDataValid && cachedLineWidth == lineWidth && cachedEllipticTubes == useRibbonNormals) return cachedTubeAabbRenderData;
     const vec3 lineWidthOffset(lineWidth * 0.5f);
     const size_t numLines = trajectories.size();
     std::vector<std::vector<LinePointDataUnified>> perLine(numLines);
@@ -311,6 +399,7 @@ TubeAabbRenderData LineDataFlow::getLinePassTubeAabbRenderData(bool /*isRasteriz
                 if (length(cross(helperAxis, tangent)) < 0.01f) helperAxis = vec3(0.0f, 0.0f, 1.0f);
             }
             vec3 normal = normalize(helperAxis - dot(helperAxis, tangent) * tangent); // Gram-Schmidt
+            if (useRibbonNormals) normal = cross(ribbonsDirections[size_t(li)][i], tangent); // :2166-2168 (not normalised)
             lastLineNormal = normal;
             LinePointDataUnified lp;
             memset(&lp, 0, sizeof(lp));
@@ -351,6 +440,7 @@ TubeAabbRenderData LineDataFlow::getLinePassTubeAabbRenderData(bool /*isRasteriz
     cachedTubeAabbRenderData = data;
     cachedAabbDataValid = true;
     cachedLineWidth = lineWidth;
+    cachedEllipticTubes = useRibbonNormals;
     return data;
 }
 

@@ -32,9 +32,20 @@ typedef std::vector<Trajectory> Trajectories;
 
 AABB3 computeTrajectoriesAABB3(const Trajectories& trajectories);
 void normalizeTrajectoriesVertexPositions(Trajectories& trajectories, const AABB3& aabb);
-/// .binlines reader (version 1 payload; the trailing ribbon / hull-mesh part of version 2 files is ignored).
+/// BinLinesData (src/Loaders/TrajectoryFile.hpp:60-75): trajectories + what version 2 of the format adds; the outline mesh of
+/// the simulation grid is skipped.
+struct BinLinesData {
+    Trajectories trajectories;
+    std::vector<std::string> attributeNames;
+    std::vector<std::vector<vec3>> ribbonsDirections; // per trajectory, one direction per point; empty = no band data
+    bool verticesNormalized = false;
+};
+/// .binlines reader, versions 1 and 2 (BinLinesLoader.cpp:41-180)
+bool loadTrajectoriesFromBinLines(const std::string& filename, BinLinesData& binLinesData);
 bool loadTrajectoriesFromBinLines(const std::string& filename, Trajectories& trajectories);
-bool saveTrajectoriesAsBinLines(const std::string& filename, const Trajectories& trajectories);
+/// writer (BinLinesLoader.cpp:182-247): version 1 without, version 2 with ribbon directions
+bool saveTrajectoriesAsBinLines(const std::string& filename, const Trajectories& trajectories,
+                                const std::vector<std::vector<vec3>>& ribbonsDirections = {});
 /// Wavefront-OBJ polylines as LineVis reads them (src/Loaders/ObjLoader.cpp:36-186): "v x y z" positions, "vt a0 a1 .."
 /// per-vertex attributes (same count on every line), "l i j k .." one trajectory per line statement (1-based indices),
 /// "a name0 name1 .." attribute names; positions with a component above 1e10 are dropped.
@@ -75,6 +86,10 @@ public:
     void getMinMaxAttributeValues(float& minAttr, float& maxAttr) const;
     bool getUseCappedTubes() const { return useCappedTubes; }
     bool getUseHalos() const { return useHalos; }
+    /// USE_BANDS of the ray tracer's shaders (getVulkanShaderPreprocessorDefines with isRasterizer = false)
+    virtual bool getUseBands() const { return false; }
+    static bool getRenderThickBands() { return renderThickBands; }   // LineData.cpp:53
+    static float getMinBandThickness() { return minBandThickness; }  // LineData.cpp:54
     int getTubeNumSubdivisions() const { return tubeNumSubdivisions; }
     bool isDirty() const { return dirty; }
     void setDirty(bool d) { dirty = d; }
@@ -94,6 +109,8 @@ public:
     void setTriangleRepresentationDirty() { cachedAabbDataValid = false; cachedTriangleDataValid = false; dirty = true; }
 
 protected:
+    static bool renderThickBands;
+    static float minBandThickness;
     DataSetType dataSetType;
     AABB3 modelBoundingBox;
     std::vector<std::string> attributeNames;
@@ -113,8 +130,14 @@ public:
     LineDataFlow() : LineData(DATA_SET_TYPE_FLOW_LINES) {}
     /// loadFromFile (LineDataFlow.cpp:431-454) for .binlines; normalises positions like the reference loader.
     bool loadFromFile(const std::string& filename);
-    void setTrajectoryData(const Trajectories& trajectories, const std::vector<std::string>& names = {});
+    void setTrajectoryData(const Trajectories& trajectories, const std::vector<std::string>& names = {},
+                           const std::vector<std::vector<vec3>>& ribbonsDirections = {});
     const Trajectories& getTrajectories() const { return trajectories; }
+    const std::vector<std::vector<vec3>>& getRibbonsDirections() const { return ribbonsDirections; }
+    bool getHasBandsData() const { return hasBandsData; }
+    /// USE_BANDS: useRibbons && hasBandsData (LineDataFlow.cpp:2423); use_ribbons / thick_bands / min_band_thickness keys :587-606
+    bool getUseBands() const override { return useRibbons && hasBandsData; }
+    bool setNewSettings(const SettingsMap& settings) override;
 
     size_t getNumLines() override { return numTotalTrajectories; }
     size_t getNumLinePoints() override { return numTotalTrajectoryPoints; }
@@ -125,9 +148,13 @@ public:
 
 private:
     Trajectories trajectories;
+    std::vector<std::vector<vec3>> ribbonsDirections; // LineDataFlow.hpp:160
+    bool hasBandsData = false;
+    static bool useRibbons;                            // LineDataFlow.cpp:51
     size_t numTotalTrajectories = 0, numTotalTrajectoryPoints = 0;
     TubeAabbRenderData cachedTubeAabbRenderData;
     float cachedLineWidth = -1.0f;
+    bool cachedEllipticTubes = false;
     TubeTriangleRenderData cachedTubeTriangleRenderData;
     float cachedTriangleLineWidth = -1.0f;
     int cachedTriangleSubdivisions = -1;

@@ -239,7 +239,13 @@ bool LineRenderer::setNewSettings(const SettingsMap& settings) {
             linesDirty = true;
         }
     }
-    settings.getValueOpt("band_width", bandWidth);
+    float newBandWidth = bandWidth;
+    if (settings.getValueOpt("band_width", bandWidth)) { // LineRenderer.cpp:442-449
+        if (newBandWidth != bandWidth && lineData) {
+            lineData->setTriangleRepresentationDirty();
+            linesDirty = true;
+        }
+    }
 
     if (settings.getValueOpt("depth_cue_strength", depthCueStrength)) {
         if (depthCueStrength <= 0.0f && useDepthCues) { useDepthCues = false; shallReloadGatherShader = true; }
@@ -309,10 +315,21 @@ bool LineRenderer::uploadFrameState() {
         char buf[64];
         snprintf(buf, sizeof(buf), "%.9g", double(lineWidth));
         if (!setOption("line_width", buf)) return false;
-        TubeAabbRenderData d = lineData->getLinePassTubeAabbRenderData(false, false);
+        // band data: USE_BANDS + the "Elliptic Tubes" geometry of the ray tracer (RayTracingRenderPass::setLineData,
+        // VulkanRayTracer.cpp:370-381; LineDataFlow::getVulkanShaderPreprocessorDefines, LineDataFlow.cpp:2420-2431)
+        const bool bands = lineData->getUseBands();
+        const bool elliptic = bands && getUseAnalyticEllipticTubes();
+        TubeAabbRenderData d = lineData->getLinePassTubeAabbRenderData(false, elliptic);
         if (!check(lv_set_lines(ctx, d.linePointDataBuffer.data(), uint32_t(d.linePointDataBuffer.size()),
                                 d.indexBuffer.data(), uint32_t(d.indexBuffer.size() / 2)), "lv_set_lines"))
             return false;
+        setOption("use_ribbons", bands ? "true" : "false");
+        setOption("use_analytic_elliptic_tubes", elliptic ? "true" : "false");
+        setOption("thick_bands", LineData::getRenderThickBands() ? "true" : "false");
+        snprintf(buf, sizeof(buf), "%.9g", double(LineData::getMinBandThickness()));
+        setOption("min_band_thickness", buf);
+        snprintf(buf, sizeof(buf), "%.9g", double(bandWidth));
+        setOption("band_width", buf);
         // getVulkanShaderPreprocessorDefines, LineData.cpp:1209-1256
         setOption("use_capped_tubes", lineData->getUseCappedTubes() ? "true" : "false");
         setOption("use_halos", lineData->getUseHalos() ? "true" : "false");
@@ -407,6 +424,14 @@ bool HipRayTracer::setNewSettings(const SettingsMap& settings) {
     } else if (settings.getValueOpt("use_analytic_intersections", useAnalyticIntersections)) {
         if (setOption("use_analytic_intersections", useAnalyticIntersections ? "true" : "false"))
             useTriangleMesh = !useAnalyticIntersections;
+        accumulatedFramesCounter = 0;
+    }
+    // the "Elliptic Tubes" checkbox of the AABB geometry mode has no settings key in the reference (VulkanRayTracer.cpp:198-201)
+    bool elliptic = useAnalyticEllipticTubes;
+    if (settings.getValueOpt("use_analytic_elliptic_tubes", elliptic) && elliptic != useAnalyticEllipticTubes) {
+        useAnalyticEllipticTubes = elliptic;
+        if (lineData) lineData->setTriangleRepresentationDirty(); // other point normals, other boxes
+        linesDirty = true;
         accumulatedFramesCounter = 0;
     }
     if (settings.getValueOpt("num_samples_per_frame", numSamplesPerFrame)) {

@@ -173,6 +173,8 @@ public:
     bool isDirty() const { return dirty; }
     virtual bool needsReRender();
     virtual bool getIsTriangleRepresentationUsed() const { return false; }
+    /// the ray tracer's "Elliptic Tubes" switch for band data (VulkanRayTracer.hpp:127)
+    virtual bool getUseAnalyticEllipticTubes() const { return false; }
     bool getIsRasterizer() const { return isRasterizer; }
 
     virtual void setLineData(LineDataPtr& lineData, bool isNewData) = 0;
@@ -195,6 +197,7 @@ public:
     static float getLineWidth() { return lineWidth; }
     static float getBandWidth() { return bandWidth; }
     static void setLineWidth(float w) { lineWidth = w; }
+    static void setBandWidth(float w) { bandWidth = w; }
 
 protected:
     void updateNewLineData(LineDataPtr& lineData, bool isNewData);
@@ -235,6 +238,7 @@ public:
     RenderingMode getRenderingMode() const override { return RENDERING_MODE_VULKAN_RAY_TRACER; }
     bool getIsTransparencyUsed() override { return false; }
     bool getIsTriangleRepresentationUsed() const override { return useTriangleMesh; } // VulkanRayTracer.hpp: geometry mode
+    bool getUseAnalyticEllipticTubes() const override { return useAnalyticEllipticTubes; }
     bool needsReRender() override;
     void setLineData(LineDataPtr& lineData, bool isNewData) override;
     void render() override;
@@ -250,6 +254,7 @@ private:
     bool useMlat = false;                  // multi-layer alpha tracing, VulkanRayTracer.hpp:133-134
     int mlatNumNodes = 8;
     bool useTriangleMesh = false;          // RayTracingGeometryMode::TRIANGLE_MESH (VulkanRayTracer.hpp:52-63)
+    bool useAnalyticEllipticTubes = false; // VulkanRayTracer.hpp:127
 };
 
 /// "Per-Pixel Linked Lists" plugin re-hosted on HIP.

@@ -47,9 +47,45 @@ void lvh_flow_set_trajectories(void* hp, const float* positions, const float* at
     }
     h->flow()->setTrajectoryData(tr);
 }
+/// as above with band data: one ribbon direction (3 floats) per input point
+void lvh_flow_set_trajectories_ribbons(void* hp, const float* positions, const float* attributes, const uint32_t* lineOffsets,
+                                       uint32_t nLines, const float* ribbonDirections) {
+    FlowHandle* h = static_cast<FlowHandle*>(hp);
+    Trajectories tr(nLines);
+    std::vector<std::vector<vec3>> ribbons(nLines);
+    for (uint32_t i = 0; i < nLines; i++) {
+        uint32_t b = lineOffsets[i], e = lineOffsets[i + 1];
+        tr[i].positions.resize(e - b);
+        memcpy(tr[i].positions.data(), positions + 3 * size_t(b), size_t(e - b) * 12);
+        tr[i].attributes.resize(1);
+        tr[i].attributes[0].assign(attributes + b, attributes + e);
+        ribbons[i].resize(e - b);
+        memcpy(ribbons[i].data(), ribbonDirections + 3 * size_t(b), size_t(e - b) * 12);
+    }
+    h->flow()->setTrajectoryData(tr, {}, ribbons);
+}
+int lvh_flow_has_bands_data(void* hp) { return static_cast<FlowHandle*>(hp)->flow()->getHasBandsData() ? 1 : 0; }
+/// ribbon directions flattened like lvh_flow_get_trajectories' positions (n * 3 floats); no band data: nothing written
+void lvh_flow_get_ribbon_directions(void* hp, float* out) {
+    FlowHandle* h = static_cast<FlowHandle*>(hp);
+    size_t off = 0;
+    for (const auto& dirs : h->flow()->getRibbonsDirections()) {
+        memcpy(out + 3 * off, dirs.data(), dirs.size() * 12);
+        off += dirs.size();
+    }
+}
+/// getLinePassTubeAabbRenderData(false, true): elliptic tubes of the band data at the given band width
+void lvh_flow_build_render_data_elliptic(void* hp, float bandWidth, uint32_t* outNumPoints, uint32_t* outNumSegments) {
+    FlowHandle* h = static_cast<FlowHandle*>(hp);
+    LineRenderer::setBandWidth(bandWidth);
+    h->lastRenderData = h->flow()->getLinePassTubeAabbRenderData(false, true);
+    *outNumPoints = uint32_t(h->lastRenderData.linePointDataBuffer.size());
+    *outNumSegments = uint32_t(h->lastRenderData.indexBuffer.size() / 2);
+}
 int lvh_flow_load_binlines(void* hp, const char* path) { return static_cast<FlowHandle*>(hp)->flow()->loadFromFile(path) ? 0 : -1; }
 int lvh_flow_save_binlines(void* hp, const char* path) {
-    return saveTrajectoriesAsBinLines(path, static_cast<FlowHandle*>(hp)->flow()->getTrajectories()) ? 0 : -1;
+    LineDataFlow* fl = static_cast<FlowHandle*>(hp)->flow();
+    return saveTrajectoriesAsBinLines(path, fl->getTrajectories(), fl->getRibbonsDirections()) ? 0 : -1;
 }
 uint64_t lvh_flow_num_lines(void* hp) { return static_cast<FlowHandle*>(hp)->flow()->getNumLines(); }
 uint64_t lvh_flow_num_points(void* hp) { return static_cast<FlowHandle*>(hp)->flow()->getNumLinePoints(); }

@@ -28,6 +28,10 @@ def load():
         "lvh_flow_create": (vp, []),
         "lvh_flow_destroy": (None, [vp]),
         "lvh_flow_set_trajectories": (None, [vp, vp, vp, vp, u32]),
+        "lvh_flow_set_trajectories_ribbons": (None, [vp, vp, vp, vp, u32, vp]),
+        "lvh_flow_has_bands_data": (i32, [vp]),
+        "lvh_flow_get_ribbon_directions": (None, [vp, vp]),
+        "lvh_flow_build_render_data_elliptic": (None, [vp, f32, C.POINTER(u32), C.POINTER(u32)]),
         "lvh_flow_load_binlines": (i32, [vp, cp]),
         "lvh_flow_save_binlines": (i32, [vp, cp]),
         "lvh_flow_num_lines": (u64, [vp]),
@@ -99,12 +103,39 @@ class LineDataFlow:
         except Exception:
             pass
 
-    def set_trajectories(self, positions, attributes, line_offsets):
+    def set_trajectories(self, positions, attributes, line_offsets, ribbon_directions=None):
+        """setTrajectoryData; ribbon_directions (one vec3 per point) = band data (LineDataFlow::ribbonsDirections)."""
         pos = np.ascontiguousarray(positions, dtype=np.float32)
         att = np.ascontiguousarray(attributes, dtype=np.float32)
         off = np.ascontiguousarray(line_offsets, dtype=np.uint32)
-        self.L.lvh_flow_set_trajectories(self.h, _p(pos), _p(att), _p(off), len(off) - 1)
+        if ribbon_directions is None:
+            self.L.lvh_flow_set_trajectories(self.h, _p(pos), _p(att), _p(off), len(off) - 1)
+        else:
+            rib = np.ascontiguousarray(ribbon_directions, dtype=np.float32)
+            assert rib.shape == pos.shape
+            self.L.lvh_flow_set_trajectories_ribbons(self.h, _p(pos), _p(att), _p(off), len(off) - 1, _p(rib))
         return self
+
+    @property
+    def has_bands_data(self):
+        return bool(self.L.lvh_flow_has_bands_data(self.h))
+
+    def ribbon_directions(self):
+        if not self.has_bands_data:
+            return None
+        out = np.zeros((self.num_points, 3), dtype=np.float32)
+        self.L.lvh_flow_get_ribbon_directions(self.h, _p(out))
+        return out
+
+    def tube_aabb_render_data_elliptic(self, band_width):
+        """getLinePassTubeAabbRenderData(false, ellipticTubes=true): ribbon normals, boxes padded by band_width / 2."""
+        npts, nseg = C.c_uint32(), C.c_uint32()
+        self.L.lvh_flow_build_render_data_elliptic(self.h, band_width, C.byref(npts), C.byref(nseg))
+        pts = np.zeros(npts.value, dtype=capi.LINE_POINT_DTYPE)
+        seg = np.zeros((nseg.value, 2), dtype=np.uint32)
+        aabb = np.zeros((nseg.value, 6), dtype=np.float32)
+        self.L.lvh_flow_copy_render_data(self.h, _p(pts), _p(seg), _p(aabb))
+        return pts, seg, aabb
 
     def load_file(self, path):
         """LineDataFlow::loadFromFile: .obj or .binlines by extension, positions normalised like the reference loader."""

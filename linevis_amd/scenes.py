@@ -16,6 +16,7 @@ class Trajectories:
     positions: np.ndarray      # float32 [P, 3]
     attributes: np.ndarray     # float32 [P]
     line_offsets: np.ndarray   # uint32 [L + 1]
+    ribbon_directions: np.ndarray = None   # float32 [P, 3] or None: band data (LineDataFlow::ribbonsDirections)
 
     @property
     def num_lines(self):
@@ -51,7 +52,7 @@ def normalize(tr):
     scale3 = np.float32(0.5) / (mx - mn)
     scale = np.float32(scale3.min())
     out = ((p + translation) * scale).astype(np.float32)
-    return Trajectories(np.ascontiguousarray(out), tr.attributes, tr.line_offsets)
+    return Trajectories(np.ascontiguousarray(out), tr.attributes, tr.line_offsets, tr.ribbon_directions)
 
 
 def normalize_attributes(att):
@@ -200,21 +201,58 @@ def random_curves(n_lines=24, points_per_line=40, seed=7, extent=0.45, step=0.03
     return _pack(lines, attrs)
 
 
-# ------------------------------------------------------------------ .binlines (BinLinesLoader.cpp:41-63,127-150)
+def twisted_ribbons(tr, twist=6.0, seed=3):
+    """Synthetic band data for a set of trajectories: per point a unit ribbon direction perpendicular to the tangent, parallel
+    transported along the line and rotated about the tangent by `twist` radians per unit arc length (plus a random phase
+    per line) -- the role the vorticity-driven streamribbon tracer plays in the reference (StreamlineTracingGrid.cpp:451-530)."""
+    rng = np.random.default_rng(seed)
+    pos = tr.positions.astype(np.float64)
+    out = np.zeros_like(pos)
+    for li in range(tr.num_lines):
+        b, e = int(tr.line_offsets[li]), int(tr.line_offsets[li + 1])
+        n = e - b
+        if n < 2:
+            if n == 1:
+                out[b] = (0.0, 1.0, 0.0)
+            continue
+        p = pos[b:e]
+        t = np.empty_like(p)
+        t[0], t[-1], t[1:-1] = p[1] - p[0], p[-1] - p[-2], p[2:] - p[:-2]
+        ln = np.linalg.norm(t, axis=1, keepdims=True)
+        t = np.where(ln > 1e-12, t / np.maximum(ln, 1e-12), np.array([[1.0, 0.0, 0.0]]))
+        arc = np.concatenate([[0.0], np.cumsum(np.linalg.norm(p[1:] - p[:-1], axis=1))])
+        nrm = np.array([0.0, 1.0, 0.0]) if abs(t[0, 1]) < 0.9 else np.array([1.0, 0.0, 0.0])
+        phase = rng.uniform(0.0, 2.0 * np.pi)
+        for i in range(n):
+            nrm = nrm - np.dot(nrm, t[i]) * t[i]
+            nl = np.linalg.norm(nrm)
+            nrm = nrm / nl if nl > 1e-9 else np.cross(t[i], [0.0, 0.0, 1.0])
+            ang = phase + twist * arc[i]
+            out[b + i] = np.cos(ang) * nrm + np.sin(ang) * np.cross(t[i], nrm)
+    return Trajectories(tr.positions, tr.attributes, tr.line_offsets, out.astype(np.float32))
+
+
+# ------------------------------------------------------------------ .binlines (BinLinesLoader.cpp:41-125,127-247)
 def write_binlines(path, tr):
-    """Version-1 layout: u32 version, u32 numTrajectories, u32 numAttributes, then per trajectory
-    u32 numPoints, vec3[numPoints], float[numPoints] per attribute."""
+    """Version 1: u32 version, u32 numTrajectories, u32 numAttributes, then per trajectory u32 numPoints, vec3[numPoints],
+    float[numPoints] per attribute.  With band data version 2: the same, then u32 verticesNormalized, u32 hasAttributeNames (0),
+    u32 hasRibbonData (1), vec3[numPoints] ribbon directions per trajectory, three u32 zeros (no outline mesh)."""
+    v2 = tr.ribbon_directions is not None
     with open(path, "wb") as f:
-        f.write(struct.pack("<III", 1, tr.num_lines, 1))
+        f.write(struct.pack("<III", 2 if v2 else 1, tr.num_lines, 1))
         for i in range(tr.num_lines):
             b, e = int(tr.line_offsets[i]), int(tr.line_offsets[i + 1])
             f.write(struct.pack("<I", e - b))
             f.write(np.ascontiguousarray(tr.positions[b:e], dtype="<f4").tobytes())
             f.write(np.ascontiguousarray(tr.attributes[b:e], dtype="<f4").tobytes())
+        if v2:
+            f.write(struct.pack("<III", 1, 0, 1))
+            f.write(np.ascontiguousarray(tr.ribbon_directions, dtype="<f4").tobytes())   # stored per trajectory = contiguous
+            f.write(struct.pack("<III", 0, 0, 0))
 
 
 def read_binlines(path, attribute_index=0):
-    """Reads v1 files, and the v1-compatible leading part of v2 files (ribbon / hull-mesh trailer ignored)."""
+    """Reads v1 and v2 files (v2: ribbon directions kept, attribute names and the outline mesh skipped)."""
     with open(path, "rb") as f:
         data = f.read()
     (version,) = struct.unpack_from("<I", data, 0)
@@ -235,7 +273,21 @@ def read_binlines(path, attribute_index=0):
             if a == attribute_index:
                 sel = arr
         attrs.append(sel if sel is not None else np.zeros(n, dtype=np.float32))
-    return _pack(lines, attrs)
+    tr = _pack(lines, attrs)
+    if version == 2:
+        # loadTrajectoriesFromBinLinesV2, BinLinesLoader.cpp:68-125
+        _normalized, has_names = struct.unpack_from("<II", data, off)
+        off += 8
+        if has_names:
+            for _ in range(n_attr if n_traj else 0):       # sgl::BinaryReadStream::read(std::string&): u32 length + bytes
+                (ln,) = struct.unpack_from("<I", data, off)
+                off += 4 + ln
+        (has_ribbons,) = struct.unpack_from("<I", data, off)
+        off += 4
+        if has_ribbons:
+            rib = np.frombuffer(data, dtype="<f4", count=3 * tr.num_points, offset=off).reshape(-1, 3)
+            tr = Trajectories(tr.positions, tr.attributes, tr.line_offsets, np.array(rib, dtype=np.float32))
+    return tr
 
 
 # ------------------------------------------------------------------ .obj polylines (ObjLoader.cpp:36-186)

@@ -271,6 +271,137 @@ int32_t buildRange(lvo_scene& sc, const std::vector<uint64_t>& keys, const std::
     return idx;
 }
 
+// ---------------------------------------------------------------- elliptic tubes (EllipticTubeRayTracing.glsl)
+// The ray tracer's "Elliptic Tubes" mode for band data: every segment is a tubelet with an elliptic cross-section (semi-axes
+// radius0 = bandWidth / 2 * minBandThickness along the line normal, radius1 = bandWidth / 2 along the binormal) that twists
+// from the normal at p0 to the normal at p1, found by sphere tracing in the tubelet's coordinate system (Reina et al. 2006).
+struct EllipticState { bool enabled; float bandWidth, minBandThickness; V3 cameraPosition; };
+static EllipticState g_ell = {false, 0.0f, 0.0f, {0.0f, 0.0f, 0.0f}};
+
+struct EllipticScope {   // the render entry points switch the closest-hit routine to elliptic tubelets for their duration
+    EllipticState saved;
+    EllipticScope(bool on, float bandWidth, float minBandThickness, V3 cam) : saved(g_ell) {
+        g_ell.enabled = on; g_ell.bandWidth = bandWidth; g_ell.minBandThickness = minBandThickness; g_ell.cameraPosition = cam;
+    }
+    ~EllipticScope() { g_ell = saved; }
+};
+
+struct M3 { V3 c0, c1, c2; };                    // columns, GLSL layout
+inline V3 mulM3(const M3& m, V3 v) { return (m.c0 * v.x + m.c1 * v.y) + m.c2 * v.z; }
+// matrixAxisRotationCos, EllipticTubeRayTracing.glsl:69-91 (glm::rotate with a given cosine)
+inline M3 matrixAxisRotationCos(V3 axis, float cosAngle) {
+    const float c = cosAngle;
+    const float s = sqrtf(1.0f - cosAngle * cosAngle);
+    axis = normalize(axis);
+    const V3 temp = (1.0f - c) * axis;
+    M3 R;
+    R.c0 = v3(c + temp.x * axis.x, temp.x * axis.y + s * axis.z, temp.x * axis.z - s * axis.y);
+    R.c1 = v3(temp.y * axis.x - s * axis.z, c + temp.y * axis.y, temp.y * axis.z + s * axis.x);
+    R.c2 = v3(temp.z * axis.x + s * axis.y, temp.z * axis.y - s * axis.x, c + temp.z * axis.z);
+    return R;
+}
+// computeRadius, :3-7
+inline float ellComputeRadius(float r1, float r2, float phi, float rho) {
+    float sn, cs;
+    sincosRad(phi + rho, sn, cs);
+    return r1 * r2 / sqrtf(r1 * r1 * sn * sn + r2 * r2 * cs * cs);
+}
+// computeNormal, :22-41
+inline V3 ellComputeNormal(float r1, float r2, float phi, float rho) {
+    float sinphi, cosphi, sinphirho, cosphirho;
+    sincosRad(phi + rho, sinphi, cosphi);
+    sincosRad(phi, sinphirho, cosphirho);
+    const float r1sq = r1 * r1, r2sq = r2 * r2, r1r2 = r1 * r2;
+    const float rDenomSq = r1sq * sinphi * sinphi + r2sq * cosphi * cosphi;
+    const float rDenom = sqrtf(rDenomSq);
+    const float r = r1r2 / rDenom;
+    const float ddenomDphi = (r1sq - r2sq) * sinphi * cosphi / rDenom;
+    const float drDphi = -r1r2 * ddenomDphi / rDenomSq;
+    const V3 dxDphi = v3(0.0f, drDphi * cosphirho - r * sinphirho, drDphi * sinphirho + r * cosphirho);
+    return cross(dxDphi, v3(1.0f, 0.0f, 0.0f));
+}
+// rayBoxPlaneIntersection / rayBoxIntersectionRayCoords, :126-183
+inline bool ellRayBoxPlane(float o, float d, float lower, float upper, float& tNear, float& tFar) {
+    if (fabsf(d) < 1e-3f) {
+        if (o < lower || o > upper) return false;
+    } else {
+        float t0 = (lower - o) / d, t1 = (upper - o) / d;
+        if (t0 > t1) { const float tmp = t0; t0 = t1; t1 = tmp; }
+        if (t0 > tNear) tNear = t0;
+        if (t1 < tFar) tFar = t1;
+        if (tNear > tFar) return false;
+        if (tFar < 0.0f) return false;
+    }
+    return true;
+}
+// The tubelet frame shared by the intersection and the closest-hit shader (:201-222 = :320-341)
+struct Tubelet { V3 p0, p1, xt, yt, zt; float l, rhoR; };
+inline Tubelet makeTubelet(const lvo_line_point& lp0, const lvo_line_point& lp1) {
+    Tubelet T;
+    T.p0 = ld3(lp0.linePosition); T.p1 = ld3(lp1.linePosition);
+    const V3 n0 = ld3(lp0.lineNormal), n1 = ld3(lp1.lineNormal), t0 = ld3(lp0.lineTangent);
+    T.l = length(T.p1 - T.p0);
+    T.xt = normalize(T.p1 - T.p0);
+    const V3 rotAxis = cross(n0, T.xt);
+    const float rotCosAngle = dot(n0, T.xt);
+    M3 R = {v3(1, 0, 0), v3(0, 1, 0), v3(0, 0, 1)};
+    if (fabsf(rotCosAngle) > 0.999f) R = matrixAxisRotationCos(rotAxis, rotCosAngle);
+    T.yt = mulM3(R, n0);
+    T.zt = mulM3(R, cross(t0, n0));
+    T.rhoR = -atan2Det(dot(cross(n0, n1), t0), dot(n0, n1));
+    return T;
+}
+inline V3 toTubelet(const Tubelet& T, V3 w) { return v3(dot(T.xt, w), dot(T.yt, w), dot(T.zt, w)); } // transpose(frame) * w
+inline V3 fromTubelet(const Tubelet& T, V3 p) { return (T.xt * p.x + T.yt * p.y) + T.zt * p.z; }
+
+// IntersectionEllipticTube main(), :186-270.  The reference reports the hit whenever the driver invokes the shader, i.e. whenever
+// the ray meets the segment's box; hitT itself may leave the box interval (a start point inside the surface steps backwards,
+// tilted cutting planes let the surface reach past the box).  To keep the result independent of the BVH the build accepts a hit
+// only within bandWidth / |d| of the box interval (own-box rule, as for the literal capsule roots) and widens the traversal's
+// culling interval by the same amount.
+inline bool intersectEllipticTube(V3 o, V3 d, const lvo_line_point& lp0, const lvo_line_point& lp1, float& hitTOut) {
+    const float radius0 = g_ell.bandWidth * 0.5f * g_ell.minBandThickness;
+    const float radius1 = g_ell.bandWidth * 0.5f;
+    const float lwo = g_ell.bandWidth * 0.5f;
+    const float po[3] = {o.x, o.y, o.z}, pd[3] = {d.x, d.y, d.z};
+    float tNear = -1e7f, tFar = 1e7f;
+    for (int i = 0; i < 3; i++) {
+        const float lower = fminf(lp0.linePosition[i], lp1.linePosition[i]) - lwo;   // TubeAabbRenderData, LineDataFlow.cpp:2223-2234
+        const float upper = fmaxf(lp0.linePosition[i], lp1.linePosition[i]) + lwo;
+        if (!ellRayBoxPlane(po[i], pd[i], lower, upper, tNear, tFar)) return false;
+    }
+    const V3 startPoint = o + tNear * d;
+    const Tubelet T = makeTubelet(lp0, lp1);
+    const V3 t0 = ld3(lp0.lineTangent), t1 = ld3(lp1.lineTangent);
+    // left and right cutting planes
+    const V3 El = t0; const float Elw = -dot(El, T.p0);
+    const V3 Er = v3(-t1.x, -t1.y, -t1.z); const float Erw = -dot(Er, T.p1);
+    V3 p = toTubelet(T, startPoint - T.p0);
+    const V3 dd = toTubelet(T, d);
+    float hitT = tNear, dTmp = 0.0f;
+    for (int i = 0; i < 80; i++) {
+        const float t = clampf(p.x / T.l, 0.0f, 1.0f);
+        const float rhoX = t * T.rhoR;
+        const float phi = atan2Det(p.z, p.y);
+        const float r = ellComputeRadius(radius0, radius1, phi, rhoX);
+        dTmp = sqrtf(p.y * p.y + p.z * p.z) - r;
+        dTmp *= 0.25f;
+        p = p + dd * dTmp;
+        hitT += dTmp;
+        if (dTmp < 1e-5f) break;
+    }
+    const V3 pointWorld = fromTubelet(T, p) + T.p0;
+    const float eps1 = fabsf(dot(El, normalize(g_ell.cameraPosition - T.p0))) * 5e-5f;
+    const float eps2 = fabsf(dot(Er, normalize(g_ell.cameraPosition - T.p1))) * 5e-5f;
+    const bool isNotCulledLeft = dot(El, pointWorld) + Elw > -eps1;
+    const bool isNotCulledRight = dot(Er, pointWorld) + Erw > -eps2;
+    if (!(dTmp < 1e-4f && hitT > 0.0f && isNotCulledLeft && isNotCulledRight)) return false;
+    const float slack = g_ell.bandWidth / sqrtf(dot(d, d));
+    if (hitT < tNear - slack || hitT > tFar + slack) return false;   // own-box rule
+    hitTOut = hitT;
+    return true;
+}
+
 inline bool childBox(const lvo_scene& sc, int32_t c, V3 o, V3 inv, float tMin, float tMax, float& tNear);
 
 struct Hit { float t; uint32_t seg; int kind; };
@@ -295,10 +426,11 @@ inline bool closestHit(const lvo_scene& sc, float radius, bool capped, bool useB
     auto testSeg = [&](uint32_t seg) {
         cnt.prims++;
         V3 p0, p1; segPoints(sc, seg, p0, p1);
-        float t; int kind;
-        if (g_dev.literalIntersection ? (intersectCapsuleLiteral(o, d, p0, p1, radius, capped, t, kind) &&
-                                         literalOwnBoxRule(o, d, p0, p1, radius, t))
-                                      : intersectCapsule(o, d, p0, p1, radius, capped, t, kind)) {
+        float t; int kind = 0;
+        if (g_ell.enabled ? intersectEllipticTube(o, d, sc.pts[sc.segIdx[2 * seg]], sc.pts[sc.segIdx[2 * seg + 1]], t)
+            : g_dev.literalIntersection ? (intersectCapsuleLiteral(o, d, p0, p1, radius, capped, t, kind) &&
+                                           literalOwnBoxRule(o, d, p0, p1, radius, t))
+                                        : intersectCapsule(o, d, p0, p1, radius, capped, t, kind)) {
             if (t >= tMin && t <= tMax && (!found || t < best || (t == best && seg < bestSeg))) {
                 found = true; best = t; bestSeg = seg; bestKind = kind;
             }
@@ -324,7 +456,8 @@ inline bool closestHit(const lvo_scene& sc, float radius, bool capped, bool useB
             // best + r there, so that the traversal still returns the brute-force minimum of the noisy values
             // (and may lie up to r / |d| outside the segment's box interval, literalOwnBoxRule: both ends of the culling interval
             // are widened by that much)
-            const float slack = g_dev.literalIntersection ? radius / sqrtf(dot(d, d)) : 0.0f;
+            const float slack = g_ell.enabled ? g_ell.bandWidth / sqrtf(dot(d, d))   // intersectEllipticTube's own-box rule
+                                : g_dev.literalIntersection ? radius / sqrtf(dot(d, d)) : 0.0f;
             const float limit = found ? fminf(best + slack, tMax + slack) : tMax + slack;
             bool hl = childBox(sc, nd.left, o, inv, tMin - slack, limit, tl);
             bool hr = childBox(sc, nd.right, o, inv, tMin - slack, limit, tr);
@@ -423,7 +556,7 @@ inline float getAoFactor(const lvo_params& P, float aoTexel, V3 ssp) {
 
 // blinnPhongShadingTube, Lighting.glsl:100-191
 inline void blinnPhongShadingTube(const lvo_params& P, const Frame& F, float aoTexel, const float base[4], V3 fragPos,
-                                  V3 ssp, V3 fragmentNormal, V3 fragmentTangent, float out[4]) {
+                                  V3 ssp, V3 fragmentNormal, V3 fragmentTangent, float out[4], float exponent = 1.7f) {
     float kA, kD;
     const float kS = 0.3f, s = 30.0f;
     float aoF = 1.0f;
@@ -442,7 +575,7 @@ inline void blinnPhongShadingTube(const lvo_params& P, const Frame& F, float aoT
     V3 h = normalize(v + l);
     V3 helperVec = normalize(cross(t, l));
     V3 newL = normalize(cross(helperVec, t));
-    const float exponent = 1.7f;
+    // exponent: 1.7, or 1.0 on bands (USE_BANDS && useBand, Lighting.glsl:158-162)
     float cosNormal1 = powf(clampf(fabsf(dot(n, l)), 0.0f, 1.0f), exponent);
     float cosNormal2 = powf(clampf(fabsf(dot(n, newL)), 0.0f, 1.0f), exponent);
     float cosNormalCombined = 0.3f * cosNormal1 + 0.7f * cosNormal2;
@@ -465,9 +598,11 @@ inline void blinnPhongShadingTube(const lvo_params& P, const Frame& F, float aoT
     out[0] = phong[0]; out[1] = phong[1]; out[2] = phong[2]; out[3] = base[3];
 }
 
+// USE_BANDS arguments of computeFragmentColor (RayHitCommon.glsl:82-90,148-190)
+struct BandArgs { bool useBand; float phi; V3 linePosition, lineNormal; };
 inline void computeFragmentColor(const lvo_scene& sc, const lvo_params& P, const Frame& F, float aoTexel, V3 fragPos,
                                  V3 fragmentNormal, V3 fragmentTangent, bool isCap, float fragmentAttribute,
-                                 float hitColor[4], float& payloadHitT);
+                                 float hitColor[4], float& payloadHitT, const BandArgs* bands = nullptr);
 
 // Static RTAO prebaking: AO factors per (parametrisation vertex, angular subdivision) + the per-line-vertex blending
 // weights that map a line vertex id to the parametrisation (VulkanAmbientOcclusionBaker.cpp:563-653).
@@ -540,14 +675,73 @@ inline void shadeHit(const lvo_scene& sc, const lvo_params& P, const Frame& F, f
         float fragmentVertexId = (1.0f - ts) * float(i0) + ts * float(i1);
         aoTexel = prebakedAoLookup(*pb, fragmentVertexId, phi);
     }
+    if (P.useBands) {
+        // band data with the circular analytic tubes: USE_BANDS is defined, ANALYTIC_TUBE_INTERSECTIONS sets useBand = false
+        // (RayHitCommon.glsl:164-166); phi and the line normal as TubeRayTracing.glsl:551-560 (acos through the build's atan2)
+        const float ts = h.kind == 0 ? dot(v, fragPos - P0) / dot(v, v) : (h.kind == 1 ? 0.0f : 1.0f);
+        BandArgs b;
+        b.useBand = false;
+        b.lineNormal = (1.0f - ts) * ld3(lp0.lineNormal) + ts * ld3(lp1.lineNormal);
+        const float cphi = clampf(dot(fragmentNormal, b.lineNormal), -1.0f, 1.0f);
+        b.phi = atan2Det(sqrtf((1.0f - cphi) * (1.0f + cphi)), cphi);
+        if (dot(b.lineNormal, cross(fragmentNormal, fragmentTangent)) < 0.0f) b.phi = 2.0f * 3.14159265358979323846f - b.phi;
+        b.linePosition = linePointInterpolated;
+        computeFragmentColor(sc, P, F, aoTexel, fragPos, fragmentNormal, fragmentTangent, isCap, fragmentAttribute, hitColor,
+                             payloadHitT, &b);
+        return;
+    }
     computeFragmentColor(sc, P, F, aoTexel, fragPos, fragmentNormal, fragmentTangent, isCap, fragmentAttribute, hitColor,
                          payloadHitT);
+}
+
+// ClosestHitEllipticTubeAnalytic main(), EllipticTubeRayTracing.glsl:303-441: position in the tubelet frame -> t, phi, rho ->
+// normal of the twisted elliptic surface; attribute and line normal interpolated with t; the angle in the ellipse's own
+// parametrisation p = (r1 cos, r2 sin) for the band shading.
+struct EllipticSurface { V3 fragPos, normal, tangent, linePosition, lineNormal; float t, phiLine, attribute; };
+inline EllipticSurface ellipticSurface(const lvo_params& P, V3 o, V3 d, float hitT, const lvo_line_point& lp0, const lvo_line_point& lp1) {
+    EllipticSurface E;
+    E.fragPos = o + d * hitT;
+    const Tubelet T = makeTubelet(lp0, lp1);
+    const V3 p = toTubelet(T, E.fragPos - T.p0);
+    const float radius0 = P.bandWidth * 0.5f * P.minBandThickness;
+    const float radius1 = P.bandWidth * 0.5f;
+    const float t = clampf(p.x / T.l, 0.0f, 1.0f);
+    const float phi = atan2Det(p.z, p.y);
+    const float rho = t * T.rhoR;
+    E.t = t;
+    E.normal = normalize(fromTubelet(T, ellComputeNormal(radius0, radius1, phi, rho)));
+    E.attribute = (1.0f - t) * lp0.lineAttribute + t * lp1.lineAttribute;
+    E.linePosition = (1.0f - t) * T.p0 + t * T.p1;
+    E.tangent = T.xt;
+    E.lineNormal = normalize((1.0f - t) * ld3(lp0.lineNormal) + t * ld3(lp1.lineNormal));
+    float sinphi, cosphi;
+    sincosRad(phi + rho, sinphi, cosphi);
+    const float phiDenomInv = 1.0f / sqrtf(radius0 * radius0 * sinphi * sinphi + radius1 * radius1 * cosphi * cosphi);
+    const float sinPhiLine = radius0 * sinphi * phiDenomInv;
+    const float cosPhiLine = radius1 * cosphi * phiDenomInv;
+    const float TWO_PI = 6.283185307f;                     // M_TWO_PI as the shader spells it
+    float a = atan2Det(sinPhiLine, cosPhiLine) + TWO_PI;
+    E.phiLine = a - TWO_PI * floorf(a / TWO_PI);           // mod(x, y) = x - y * floor(x / y)
+    return E;
+}
+inline void shadeHitElliptic(const lvo_scene& sc, const lvo_params& P, const Frame& F, float aoTexel, V3 o, V3 d, const Hit& h,
+                             float hitColor[4], float& payloadHitT) {
+    const lvo_line_point& lp0 = sc.pts[sc.segIdx[2 * h.seg]];
+    const lvo_line_point& lp1 = sc.pts[sc.segIdx[2 * h.seg + 1]];
+    const EllipticSurface E = ellipticSurface(P, o, d, h.t, lp0, lp1);
+    BandArgs b;
+    b.useBand = true;
+    b.phi = E.phiLine;
+    b.linePosition = E.linePosition;
+    b.lineNormal = E.lineNormal;
+    computeFragmentColor(sc, P, F, aoTexel, E.fragPos, E.normal, E.tangent, false, E.attribute, hitColor, payloadHitT,
+                         P.useBands ? &b : nullptr);
 }
 
 // computeFragmentColor (RayHitCommon.glsl:74-543) for tubes: shared by the analytic and the triangle closest-hit shaders
 inline void computeFragmentColor(const lvo_scene& sc, const lvo_params& P, const Frame& F, float aoTexel, V3 fragPos,
                                  V3 fragmentNormal, V3 fragmentTangent, bool isCap, float fragmentAttribute,
-                                 float hitColor[4], float& payloadHitT) {
+                                 float hitColor[4], float& payloadHitT, const BandArgs* bands) {
     float fragmentColor[4];
     transferFunction(sc, P, fragmentAttribute, fragmentColor);
     V3 n = normalize(fragmentNormal);
@@ -568,6 +762,56 @@ inline void computeFragmentColor(const lvo_scene& sc, const lvo_params& P, const
             if (dot(t, crossProdVn) < 0.0f) ribbonPosition = -ribbonPosition;
             ribbonPosition2 = clampf(ribbonPosition2, -1.0f, 1.0f);
             if (fabsf(ribbonPosition2) < fabsf(ribbonPosition)) ribbonPosition = ribbonPosition2;
+        } else if (bands) {
+            // USE_BANDS, RayHitCommon.glsl:232-351: the fragment's position between the two silhouette points of the elliptic
+            // cross-section as the camera sees it -- tangent-plane coordinates, polar line of the camera point with respect to the
+            // conic x^2 / thickness^2 + y^2 = 1, its two intersections with the conic from the degenerate conic B + alpha M_l
+            const float thickness = bands->useBand ? P.minThickness : 1.0f;
+            const V3 lineN = normalize(bands->lineNormal);
+            const V3 lineB = cross(t, lineN);
+            const V3 cNorm = F.cameraPosition - bands->linePosition;
+            const float dist = dot(cNorm, fragmentTangent);
+            const V3 w = cNorm - dist * fragmentTangent;
+            const V3 cHat = v3(dot(lineN, w), dot(lineB, w), dot(t, w)); // transpose(mat3(lineN, lineB, t)) * w
+            const float lineRadius = (bands->useBand ? P.bandWidth : P.lineWidth) * 0.5f;
+            const V3 c = v3(cHat.x / lineRadius, cHat.y / lineRadius, 1.0f);
+            const float a = 1.0f / (thickness * thickness);
+            const V3 l = v3(a * c.x, c.y, -1.0f);
+            // M_l = shearSymmetricMatrix(l), columns (0, -l.z, l.y), (l.z, 0, -l.x), (-l.y, l.x, 0); B[col][row]
+            const float Ml[3][3] = {{0.0f, -l.z, l.y}, {l.z, 0.0f, -l.x}, {-l.y, l.x, 0.0f}};
+            const float B[3][3] = {{l.z * l.z - l.y * l.y, l.x * l.y, -l.x * l.z},
+                                   {l.x * l.y, a * l.z * l.z - l.x * l.x, -a * l.y * l.z},
+                                   {-l.x * l.z, -a * l.y * l.z, a * l.y * l.y + l.x * l.x}};
+            const float EPSILON = 1e-4f;
+            float alpha = 0.0f, discr = 0.0f;
+            if (fabsf(l.z) > EPSILON) {
+                discr = -B[0][0] * B[1][1] + B[0][1] * B[1][0];
+                alpha = sqrtf(discr) / l.z;
+            } else if (fabsf(l.y) > EPSILON) {
+                discr = -B[0][0] * B[2][2] + B[0][2] * B[2][0];
+                alpha = sqrtf(discr) / l.y;
+            } else if (fabsf(l.x) > EPSILON) {
+                discr = -B[1][1] * B[2][2] + B[1][2] * B[2][1];
+                alpha = sqrtf(discr) / l.x;
+            }
+            float Cm[3][3];
+            for (int i = 0; i < 3; i++)
+                for (int j = 0; j < 3; j++) Cm[i][j] = B[i][j] + alpha * Ml[i][j];
+            float pm0x = 0.0f, pm0y = 0.0f, pm1x = 0.0f, pm1y = 0.0f;
+            for (int i = 0; i < 2; ++i) {
+                if (fabsf(Cm[i][i]) > EPSILON) {
+                    pm0x = Cm[i][0] / Cm[i][2]; pm0y = Cm[i][1] / Cm[i][2];   // column i
+                    pm1x = Cm[0][i] / Cm[2][i]; pm1y = Cm[1][i] / Cm[2][i];   // row i
+                }
+            }
+            float sp, cp;
+            sincosRad(bands->phi, sp, cp);
+            const V3 pH = v3(thickness * cp, sp, 1.0f);
+            const V3 pLineH = cross(l, cross(c, pH));
+            const float plx = pLineH.x / pLineH.z, ply = pLineH.y / pLineH.z;
+            const float num = sqrtf((plx - pm0x) * (plx - pm0x) + (ply - pm0y) * (ply - pm0y));
+            const float den = sqrtf((pm1x - pm0x) * (pm1x - pm0x) + (pm1y - pm0y) * (pm1y - pm0y));
+            ribbonPosition = num / den * 2.0f - 1.0f;
         } else {
             // RayHitCommon.glsl:353-372
             V3 crossProdVn = cross(newV, n);
@@ -584,17 +828,22 @@ inline void computeFragmentColor(const lvo_scene& sc, const lvo_params& P, const
     }
 
     float shaded[4];
-    blinnPhongShadingTube(P, F, aoTexel, fragmentColor, fragPos, ssp, n, t, shaded);
+    blinnPhongShadingTube(P, F, aoTexel, fragmentColor, fragPos, ssp, n, t, shaded, (bands && bands->useBand) ? 1.0f : 1.7f);
 
     float absCoords = P.useHalos ? fabsf(ribbonPosition) : 0.0f;
     float fragmentDepth = length(fragPos - F.cameraPosition);
-    // Antialiasing.glsl:1-3; RayHitCommon.glsl:451-452
+    // Antialiasing.glsl:1-3; RayHitCommon.glsl:445-452 (USE_BANDS: both epsilons from depth / width * 0.25)
     float aaO = ((fragmentDepth / P.lineWidth) * 0.05f) / float(P.height) * P.fovY;
     float aaW = ((fragmentDepth / P.lineWidth) * 2.0f) / float(P.height) * P.fovY;
+    if (bands) {
+        const float wdt = bands->useBand ? P.bandWidth : P.lineWidth;
+        aaO = aaW = ((fragmentDepth / wdt) * 0.25f) / float(P.height) * P.fovY;
+    }
     float EPSILON_OUTLINE = clampf(aaO, 0.0f, 0.49f);
     float EPSILON_WHITE = clampf(aaW, 0.0f, 0.49f);
     const float WHITE_THRESHOLD = 0.7f;
     float coverage = P.useHalos ? 1.0f - smoothstepf(1.0f - EPSILON_OUTLINE, 1.0f, absCoords) : 1.0f;
+    if (bands && bands->useBand && P.useEllipticTubes) coverage = 1.0f; // ANALYTIC_ELLIPTIC_TUBE_INTERSECTIONS, :499-504
     float w = smoothstepf(WHITE_THRESHOLD - EPSILON_WHITE, WHITE_THRESHOLD + EPSILON_WHITE, absCoords);
     for (int k = 0; k < 3; k++) hitColor[k] = mixf(shaded[k], F.foreground[k], w);
     hitColor[3] = shaded[3] * coverage;
@@ -669,6 +918,8 @@ uint32_t lvo_tea(uint32_t a, uint32_t b) { return tea(a, b); }
 uint32_t lvo_lcg(uint32_t* s) { return lcg(*s); }
 float lvo_rnd(uint32_t* s) { return rnd(*s); }
 void lvo_sincos_2pi(float xi, float* s, float* c) { sincos2pi(xi, *s, *c); }
+void lvo_sincos_rad(float a, float* s, float* c) { sincosRad(a, *s, *c); }
+float lvo_atan2_det(float y, float x) { return atan2Det(y, x); }
 void lvo_mat4_inverse(const float m[16], float out[16]) { mat4Inverse(m, out); }
 void lvo_set_num_threads(int n) {
 #ifdef _OPENMP
@@ -692,10 +943,30 @@ void lvo_normalize_positions(float* p, uint64_t n) {
 }
 
 // LineDataFlow.cpp:2112-2277
+static void buildTubeAabbRenderData(
+        const float* positions, const float* attributes, const uint32_t* lineOffsets, uint32_t nLines, float lineWidth,
+        const float* ribbonDirections, lvo_line_point* outPoints, uint32_t* outNumPoints, uint32_t* outSegIndices,
+        float* outAabbs, uint32_t* outNumSegments);
 void lvo_build_tube_aabb_render_data(
         const float* positions, const float* attributes, const uint32_t* lineOffsets, uint32_t nLines, float lineWidth,
         lvo_line_point* outPoints, uint32_t* outNumPoints, uint32_t* outSegIndices, float* outAabbs,
         uint32_t* outNumSegments) {
+    buildTubeAabbRenderData(positions, attributes, lineOffsets, nLines, lineWidth, nullptr, outPoints, outNumPoints,
+                            outSegIndices, outAabbs, outNumSegments);
+}
+// getLinePassTubeAabbRenderData(false, ellipticTubes = true) with band data (useRibbonNormals, LineDataFlow.cpp:2120-2126,
+// 2166-2168): the line normal is cross(ribbon direction, tangent) -- not normalised -- and the boxes are padded by bandWidth / 2.
+void lvo_build_tube_aabb_render_data_ribbons(
+        const float* positions, const float* attributes, const uint32_t* lineOffsets, uint32_t nLines, float bandWidth,
+        const float* ribbonDirections, lvo_line_point* outPoints, uint32_t* outNumPoints, uint32_t* outSegIndices,
+        float* outAabbs, uint32_t* outNumSegments) {
+    buildTubeAabbRenderData(positions, attributes, lineOffsets, nLines, bandWidth, ribbonDirections, outPoints, outNumPoints,
+                            outSegIndices, outAabbs, outNumSegments);
+}
+static void buildTubeAabbRenderData(
+        const float* positions, const float* attributes, const uint32_t* lineOffsets, uint32_t nLines, float lineWidth,
+        const float* ribbonDirections, lvo_line_point* outPoints, uint32_t* outNumPoints, uint32_t* outSegIndices,
+        float* outAabbs, uint32_t* outNumSegments) {
     float lwo = lineWidth * 0.5f;
     uint32_t nOut = 0, nSeg = 0;
     uint32_t lineSegmentIndexCounter = 0;
@@ -720,6 +991,7 @@ void lvo_build_tube_aabb_render_data(
                 if (length(cross(helperAxis, tangent)) < 0.01f) helperAxis = v3(0.0f, 0.0f, 1.0f);
             }
             V3 normal = normalize(helperAxis - dot(helperAxis, tangent) * tangent);
+            if (ribbonDirections) normal = cross(ld3(ribbonDirections + 3 * (b + i)), tangent);
             lastLineNormal = normal;
             lvo_line_point lp;
             memset(&lp, 0, sizeof(lp));
@@ -844,6 +1116,21 @@ void lvo_trace_rays(const lvo_scene* sc, float lineWidth, int capped, int useBvh
     }
 }
 
+// Closest hit on the elliptic tubelets (IntersectionEllipticTube); cameraPosition enters the cutting-plane tolerances.
+void lvo_trace_rays_elliptic(const lvo_scene* sc, float bandWidth, float minBandThickness, const float* cameraPosition, int useBvh,
+                             const float* origins, const float* dirs, float tMin, float tMax, uint32_t n, float* outT,
+                             uint32_t* outSeg) {
+    EllipticScope ellScope(true, bandWidth, minBandThickness, ld3(cameraPosition));
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int64_t i = 0; i < int64_t(n); i++) {
+        Counters c;
+        Hit h;
+        bool f = closestHit(*sc, bandWidth * 0.5f, true, useBvh != 0, ld3(origins + 3 * i), ld3(dirs + 3 * i), tMin, tMax, h, c);
+        outT[i] = f ? h.t : tMax;
+        outSeg[i] = f ? h.seg : 0xFFFFFFFFu;
+    }
+}
+
 // ComputeDepthValues.glsl:58-98 + MinMaxReduce.glsl:64-103 (min/max are order independent)
 void lvo_compute_depth_range(const lvo_scene* sc, const lvo_params* P, float outMinMax[2]) {
     float mn = P->farDist, mx = P->nearDist;
@@ -872,6 +1159,10 @@ void lvo_render_ao(const lvo_scene* sc, const lvo_params* Pp, int useBvh, uint32
     Frame F = makeFrame(P);
     const bool capped = P.useCappedTubes != 0;
     uint64_t rays = 0, nodes = 0, prims = 0;
+    // Elliptic tubes: the reference's RTAO pass traces the elliptic triangle tubes (createCappedTriangleEllipticTubesRenderDataCPU);
+    // the build traces the analytic tubelets of the colour pass -- the same substitution as capsules for the circular tubes.
+    const bool elliptic = P.useEllipticTubes != 0;
+    EllipticScope ellScope(elliptic, P.bandWidth, P.minBandThickness, F.cameraPosition);
     for (uint32_t iter = 0; iter < P.aoIterations; iter++) {
         // SVGF: DISABLE_ACCUMULATION (no running means) + useGlobalFrameNumber (seeds from a counter that onHasMoved does not
         // reset), VulkanRayTracedAmbientOcclusion.cpp:415-421,576-581
@@ -905,6 +1196,10 @@ void lvo_render_ao(const lvo_scene* sc, const lvo_params* Pp, int useBvh, uint32
                     else ts = hit.kind == 1 ? 0.0f : 1.0f;
                     V3 linePosition = hit.kind == 0 ? P0 + ts * v : (hit.kind == 1 ? P0 : P1);
                     V3 surfaceNormal = normalize(vertexPositionWorld - linePosition);
+                    if (elliptic) {
+                        const EllipticSurface E = ellipticSurface(P, o, d, hit.t, lp0, lp1);
+                        ts = E.t; linePosition = E.linePosition; surfaceNormal = E.normal;
+                    }
                     V3 surfaceTangent = normalize((1.0f - ts) * ld3(lp0.lineTangent) + ts * ld3(lp1.lineTangent));
                     V3 surfaceBitangent = cross(surfaceNormal, surfaceTangent);
                     float offsetFactor = length(linePosition - vertexPositionWorld) / F.subdivisionCorrectionFactor;
@@ -956,6 +1251,8 @@ static void renderRt(const lvo_scene* sc, const lvo_params* Pp, int useBvh, cons
     const float HIT_DISTANCE_EPSILON = 1e-5f;
     uint64_t rays = 0, nodes = 0, prims = 0, hits = 0;
     g_dev.aoImage = (P.useAmbientOcclusion && !pb) ? ao : nullptr; // full-viewport AO image for the reference lookup switch
+    const bool elliptic = P.useEllipticTubes != 0;
+    EllipticScope ellScope(elliptic, P.bandWidth, P.minBandThickness, F.cameraPosition);
 #pragma omp parallel for schedule(dynamic, 1) reduction(+ : rays, nodes, prims, hits)
     for (int64_t tileIdx = 0; tileIdx < lvoTileCount(w, h); tileIdx++) { // 16x16-pixel tiles
         Counters cnt;
@@ -983,7 +1280,8 @@ static void renderRt(const lvo_scene* sc, const lvo_params* Pp, int useBvh, cons
                     Hit hit;
                     float hc[4]; float payloadHitT; bool hasHit;
                     if (closestHit(*sc, F.radius, capped, useBvh != 0, o, d, tMin, tMax, hit, cnt)) {
-                        shadeHit(*sc, P, F, aoTexel, o, d, hit, hc, payloadHitT, pb);
+                        if (elliptic) shadeHitElliptic(*sc, P, F, aoTexel, o, d, hit, hc, payloadHitT);
+                        else shadeHit(*sc, P, F, aoTexel, o, d, hit, hc, payloadHitT, pb);
                         hasHit = true;
                         cnt.hits++;
                     } else {

@@ -79,6 +79,13 @@ typedef struct {
     uint32_t ppllMaxNumFrags;      /* MAX_NUM_FRAGS */
     uint32_t ppllLinkedListSize;   /* nodes in the pool */
     uint32_t ppllTileW, ppllTileH; /* LineRenderer.cpp:739-740 */
+
+    /* band data (ribbons): USE_BANDS = useRibbons && hasBandsData (LineDataFlow.cpp:2423-2431); elliptic tubes = the ray
+     * tracer's "Elliptic Tubes" switch (VulkanRayTracer.cpp:198-201,468-499); LineUniformData bandWidth / minBandThickness
+     * (LineData.cpp:1297-1298); MIN_THICKNESS = minBandThickness with thick bands, 1e-2 otherwise */
+    uint32_t useBands;
+    uint32_t useEllipticTubes;
+    float bandWidth, minBandThickness, minThickness;
 } lvo_params;
 
 typedef struct {
@@ -278,6 +285,21 @@ void lvo_set_ao_feature_outputs(float* normalMap, float* positionMap);
 void lvo_eaw_denoise(uint32_t width, uint32_t height, const float* ao, const float* normalMap, const float* positionMap,
                      int iterations, float phiColor, float phiPosition, float phiNormal, int useColor, int usePosition,
                      int useNormal, int computeVariant, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, float* out);
+
+/* Test hooks: the build-owned sin / cos / atan2 of the elliptic-tube path */
+void lvo_sincos_rad(float a, float* s, float* c);
+float lvo_atan2_det(float y, float x);
+/* Band data: getLinePassTubeAabbRenderData(false, true) -- normals from the ribbon directions (3 floats per input point), boxes
+ * padded by bandWidth / 2 (LineDataFlow.cpp:2112-2277). */
+void lvo_build_tube_aabb_render_data_ribbons(
+        const float* positions, const float* attributes, const uint32_t* lineOffsets, uint32_t nLines, float bandWidth,
+        const float* ribbonDirections, lvo_line_point* outPoints, uint32_t* outNumPoints, uint32_t* outSegIndices,
+        float* outAabbs, uint32_t* outNumSegments);
+/* Closest hit of n rays on the elliptic tubelets (EllipticTubeRayTracing.glsl IntersectionEllipticTube); miss: outT = tMax,
+ * outSeg = 0xFFFFFFFF.  With useBvh the scene's BVH must have been built with lineWidth = bandWidth. */
+void lvo_trace_rays_elliptic(const lvo_scene* sc, float bandWidth, float minBandThickness, const float* cameraPosition, int useBvh,
+                             const float* origins, const float* dirs, float tMin, float tMax, uint32_t n, float* outT,
+                             uint32_t* outSeg);
 
 /* SVGF (ambient_occlusion_denoiser = "SVGF"): while `enable` != 0 the RTAO passes run without running means and seed from
  * globalFrameNumber (+ iteration), and fill the full-viewport maps normalWorld (float4), depth (float), flow (float2),

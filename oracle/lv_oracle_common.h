@@ -99,6 +99,34 @@ inline void sincos2pi(float xi, float& s, float& c) {
     }
 }
 
+// sin / cos / atan2 of the elliptic-tube shaders (EllipticTubeRayTracing.glsl).  GLSL leaves their precision to the
+// implementation; the sphere tracing loop takes discrete decisions on their results (termination, clipping planes), so the build
+// defines them by fixed float32 formulas that evaluate identically on host and device: sin / cos through sincos2pi after an
+// explicit reduction of the angle to a fraction of the full turn, atan through an odd polynomial on [-tan(pi/8), tan(pi/8)].
+inline void sincosRad(float a, float& s, float& c) {
+    float u = a * 0.15915494309189535f;   // a / (2 pi)
+    u = u - floorf(u);
+    if (!(u < 1.0f)) u = 0.0f;            // -tiny - floor(-tiny) rounds to 1
+    sincos2pi(u, s, c);
+}
+inline float atan2Det(float y, float x) {
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    float r = 0.0f;
+    if (mx > 0.0f) {
+        float a = mn / mx;                                   // [0, 1]
+        float base = 0.0f;
+        if (a > 0.41421356237309503f) { a = (a - 1.0f) / (a + 1.0f); base = 0.78539816339744831f; }
+        const float s = a * a;
+        const float p = a * (1.0f + s * (-1.0f / 3.0f + s * (1.0f / 5.0f + s * (-1.0f / 7.0f + s * (1.0f / 9.0f + s * (-1.0f / 11.0f + s * (1.0f / 13.0f)))))));
+        r = base + p;
+        if (ay > ax) r = 1.57079632679489662f - r;
+    }
+    if (x < 0.0f) r = 3.14159265358979323846f - r;
+    if (y < 0.0f) r = -r;
+    return r;
+}
+
 struct Counters { uint64_t rays = 0, nodes = 0, prims = 0, hits = 0; };
 
 // Work decomposition of the frame loops: 16x16-pixel tiles handed out one at a time (schedule(dynamic, 1)), as

@@ -56,6 +56,8 @@ class Params(C.Structure):
         ("aoJitterPrimary", C.c_uint32), ("tubeNumSubdivisions", C.c_uint32), ("aoRadius", C.c_float),
         ("ppllMaxNumFrags", C.c_uint32), ("ppllLinkedListSize", C.c_uint32),
         ("ppllTileW", C.c_uint32), ("ppllTileH", C.c_uint32),
+        ("useBands", C.c_uint32), ("useEllipticTubes", C.c_uint32),
+        ("bandWidth", C.c_float), ("minBandThickness", C.c_float), ("minThickness", C.c_float),
     ]
 
 
@@ -111,8 +113,13 @@ def lib():
     L.lvo_rnd.restype = f32
     L.lvo_rnd.argtypes = [C.POINTER(u32)]
     L.lvo_sincos_2pi.argtypes = [f32, C.POINTER(f32), C.POINTER(f32)]
+    L.lvo_sincos_rad.argtypes = [f32, C.POINTER(f32), C.POINTER(f32)]
+    L.lvo_atan2_det.restype = f32
+    L.lvo_atan2_det.argtypes = [f32, f32]
     L.lvo_normalize_positions.argtypes = [vp, C.c_uint64]
     L.lvo_build_tube_aabb_render_data.argtypes = [vp, vp, vp, u32, f32, vp, C.POINTER(u32), vp, vp, C.POINTER(u32)]
+    L.lvo_build_tube_aabb_render_data_ribbons.argtypes = [vp, vp, vp, u32, f32, vp, vp, C.POINTER(u32), vp, vp, C.POINTER(u32)]
+    L.lvo_trace_rays_elliptic.argtypes = [vp, f32, f32, vp, i32, vp, vp, f32, f32, u32, vp, vp]
     L.lvo_mat4_inverse.argtypes = [vp, vp]
     L.lvo_scene_create.restype = vp
     L.lvo_scene_create.argtypes = [vp, u32, vp, u32]
@@ -226,6 +233,24 @@ def build_tube_aabb_render_data(positions, attributes, line_offsets, line_width)
     return pts[:npts.value].copy(), seg[:nseg.value].copy(), aabb[:nseg.value].copy()
 
 
+def build_tube_aabb_render_data_ribbons(positions, attributes, line_offsets, band_width, ribbon_directions):
+    """a2 with band data (getLinePassTubeAabbRenderData(false, ellipticTubes=true)): normals = cross(ribbon direction, tangent),
+    boxes padded by band_width / 2."""
+    pos = np.ascontiguousarray(positions, dtype=np.float32)
+    att = np.ascontiguousarray(attributes, dtype=np.float32)
+    off = np.ascontiguousarray(line_offsets, dtype=np.uint32)
+    rib = np.ascontiguousarray(ribbon_directions, dtype=np.float32)
+    assert rib.shape == pos.shape
+    n = pos.shape[0]
+    pts = np.zeros(max(n, 1), dtype=LINE_POINT_DTYPE)
+    seg = np.zeros((max(n, 1), 2), dtype=np.uint32)
+    aabb = np.zeros((max(n, 1), 6), dtype=np.float32)
+    npts, nseg = C.c_uint32(), C.c_uint32()
+    lib().lvo_build_tube_aabb_render_data_ribbons(_p(pos), _p(att), _p(off), len(off) - 1, band_width, _p(rib), _p(pts),
+                                                  C.byref(npts), _p(seg), _p(aabb), C.byref(nseg))
+    return pts[:npts.value].copy(), seg[:nseg.value].copy(), aabb[:nseg.value].copy()
+
+
 def build_tube_triangle_render_data(positions, attributes, line_offsets, line_width, num_subdivisions=6):
     """a14 (CappedTriangleTubesCPU.cpp:214-383 + LineDataFlow.cpp:1912-2110): returns
     (triangle_indices[T,3], vertices[32B], line_points[48B])."""
@@ -296,6 +321,7 @@ DEFAULTS = dict(
     attrMin=0.0, attrMax=1.0,
     aoSamplesPerFrame=4, aoIterations=1, aoUseDistance=1, aoJitterPrimary=1, tubeNumSubdivisions=6, aoRadius=0.1,
     ppllMaxNumFrags=100, ppllLinkedListSize=0, ppllTileW=2, ppllTileH=8,
+    useBands=0, useEllipticTubes=0, bandWidth=0.005, minBandThickness=0.15, minThickness=0.15,
 )
 
 
@@ -343,7 +369,9 @@ class Scene:
         self.bvh_line_width = line_width
 
     def _use_bvh(self, P_or_lw, use_bvh):
-        lw = P_or_lw.lineWidth if isinstance(P_or_lw, Params) else P_or_lw
+        lw = P_or_lw
+        if isinstance(P_or_lw, Params):     # elliptic tubes: boxes of half the band width, LineDataFlow.cpp:2120-2126
+            lw = P_or_lw.bandWidth if P_or_lw.useEllipticTubes else P_or_lw.lineWidth
         if use_bvh and self.bvh_line_width != lw:
             self.build_bvh(lw)
         return int(bool(use_bvh))
@@ -359,6 +387,18 @@ class Scene:
         lib().lvo_trace_rays(self.h, line_width, int(capped), ub, _p(o), _p(d), t_min, t_max, n, _p(t), _p(seg),
                              _p(kind))
         return t, seg, kind
+
+    def trace_rays_elliptic(self, origins, dirs, t_min, t_max, band_width, min_band_thickness, camera_position, use_bvh=False):
+        o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(dirs, dtype=np.float32).reshape(-1, 3)
+        cam = np.ascontiguousarray(camera_position, dtype=np.float32).reshape(3)
+        n = o.shape[0]
+        t = np.empty(n, dtype=np.float32)
+        seg = np.empty(n, dtype=np.uint32)
+        ub = self._use_bvh(band_width, use_bvh)
+        lib().lvo_trace_rays_elliptic(self.h, band_width, min_band_thickness, _p(cam), ub, _p(o), _p(d), t_min, t_max, n,
+                                      _p(t), _p(seg))
+        return t, seg
 
     def depth_range(self, P):
         out = np.empty(2, dtype=np.float32)

@@ -57,6 +57,12 @@ class Case:
             tubeNumSubdivisions=int(s.get("tube_num_subdivisions", 6)),
             aoRadius=float(s.get("ambient_occlusion_radius", 0.1)),
             ppllTileW=int(s.get("ppll_tile_width", 2)), ppllTileH=int(s.get("ppll_tile_height", 8)),
+            # band data: USE_BANDS / elliptic tubes / MIN_THICKNESS (LineDataFlow.cpp:2423-2431, LineData.cpp:54,1297-1298)
+            useBands=int(bool(s.get("use_ribbons", False))),
+            useEllipticTubes=int(bool(s.get("use_ribbons", False)) and bool(s.get("use_analytic_elliptic_tubes", False))),
+            bandWidth=float(np.float32(s.get("band_width", 0.005))),
+            minBandThickness=float(np.float32(s.get("min_band_thickness", 0.15))),
+            minThickness=float(np.float32(s.get("min_band_thickness", 0.15))) if bool(s.get("thick_bands", True)) else float(np.float32(1e-2)),
         )
         large = len(self.seg) > 1000000
         kw["ppllMaxNumFrags"] = int(s.get("ppll_max_num_frags", 0)) or (380 if large else 100)

@@ -1,0 +1,144 @@
+"""Band data in the ray tracer: the "Elliptic Tubes" mode (EllipticTubeRayTracing.glsl -- sphere-traced
+twisted elliptic tubelets) and the USE_BANDS shading of computeFragmentColor (RayHitCommon.glsl), HIP against the oracle."""
+import numpy as np
+import pytest
+
+from common import Case, max_lsb_diff
+from linevis_amd import scenes, transfer_function as tfm
+from oracle import lvo
+
+BANDS = dict(use_ribbons=True, band_width=0.05, min_band_thickness=0.3)
+RTAO = dict(ambient_occlusion_mode="RTAO (Screen Space)", ambient_occlusion_strength=1.0, ambient_occlusion_gamma=1.0,
+            ambient_occlusion_radius=0.15, ambient_occlusion_distance_based=True, ambient_occlusion_iterations=2,
+            ambient_occlusion_samples_per_frame=4)
+
+
+def ribbon_scene(n_lines=5, pts=120, twist=8.0, seed=3):
+    return scenes.twisted_ribbons(scenes.normalize(scenes.helix_bundle(n_lines=n_lines, points_per_line=pts, seed=seed, turns=2.0)),
+                                  twist=twist)
+
+
+def band_case(width=200, height=150, elliptic=True, transparent=False, line_width=0.02, tr=None, **settings):
+    tr = tr or ribbon_scene()
+    s = dict(BANDS)
+    s.update(settings)
+    s["use_analytic_elliptic_tubes"] = elliptic
+    if elliptic:   # getLinePassTubeAabbRenderData(false, true): ribbon normals, band-width boxes
+        pts, seg, _ = lvo.build_tube_aabb_render_data_ribbons(tr.positions, tr.attributes, tr.line_offsets, s["band_width"],
+                                                              tr.ribbon_directions)
+    else:
+        pts, seg, _ = lvo.build_tube_aabb_render_data(tr.positions, tr.attributes, tr.line_offsets, line_width)
+    tf = tfm.standard_transparent() if transparent else tfm.standard()
+    return Case(pts, seg, tf, width, height, line_width, **s)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [dict(), dict(transparent=True), dict(thick_bands=False), dict(use_halos=False),
+                                dict(min_band_thickness=1.0), dict(num_samples_per_frame=3), dict(depth_cue_strength=0.7)])
+def test_elliptic_tubes_frame_matches_the_oracle(hip_lib, kw):
+    c = band_case(**kw)
+    img = c.hip_context().render(11)
+    ref, _ = c.oracle_render(11)             # brute force over all tubelets
+    assert max_lsb_diff(img, ref) <= 2
+    assert (img[..., :3] != 255).any(axis=2).sum() > 2000
+
+
+@pytest.mark.gpu
+def test_elliptic_trace_rays_bit_exact(hip_lib):
+    c = band_case()
+    ctx = c.hip_context()
+    rng = np.random.default_rng(9)
+    cam = np.array([0.0, 0.0, 0.8], np.float32)
+    o = np.concatenate([np.tile(cam[None], (4000, 1)), rng.uniform(-0.25, 0.25, (2000, 3)).astype(np.float32)])
+    d = rng.normal(size=(6000, 3)).astype(np.float32)
+    d[:4000, 2] = -np.abs(d[:4000, 2]) * 4
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    t, s, k = ctx.trace_rays(o, d, 1e-4, 1000.0)
+    sc = c.oracle_scene()
+    t2, s2 = sc.trace_rays_elliptic(o, d, 1e-4, 1000.0, 0.05, 0.3, cam, use_bvh=False)
+    t3, s3 = sc.trace_rays_elliptic(o, d, 1e-4, 1000.0, 0.05, 0.3, cam, use_bvh=True)
+    assert np.array_equal(t2.view(np.uint32), t3.view(np.uint32)) and np.array_equal(s2, s3)   # own-box rule: BVH == brute force
+    assert np.array_equal(t.view(np.uint32), t2.view(np.uint32)) and np.array_equal(s, s2)
+    assert (s != 0xFFFFFFFF).sum() > 800 and np.all(k == 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [dict(), dict(use_capped_tubes=False), dict(transparent=True), dict(depth_cue_strength=0.7)])
+def test_band_shading_on_circular_tubes(hip_lib, kw):
+    """Band data with "Elliptic Tubes" off: analytic capsules, USE_BANDS shading with useBand = false (conic halo with thickness 1,
+    outline widths from depth / lineWidth * 0.25)."""
+    c = band_case(elliptic=False, **kw)
+    img = c.hip_context().render(11)
+    ref, _ = c.oracle_render(11)
+    assert max_lsb_diff(img, ref) <= 2
+    plain = dict(c.settings)
+    plain["use_ribbons"] = False
+    c2 = Case(c.points, c.seg, c.tf, c.width, c.height, c.line_width, **plain)
+    assert not np.array_equal(c2.hip_context().render(11), img)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("jitter", [False, True])
+def test_elliptic_tubes_rtao(hip_lib, jitter):
+    c = band_case(**dict(RTAO, use_jittered_primary_rays=jitter))
+    ctx = c.hip_context()
+    img = ctx.render(11)
+    ao = ctx.get_ao()
+    ref, ao_ref = c.oracle_render(11)
+    assert np.array_equal(ao.view(np.uint32), ao_ref.view(np.uint32))
+    assert max_lsb_diff(img, ref) <= 2
+    assert (ao < 0.9).sum() > 500
+    tile = (60, 40, 64, 48)
+    assert np.array_equal(ctx.render(11, tile=tile), img[40:88, 60:124])
+
+
+@pytest.mark.gpu
+def test_band_options_are_validated(hip_lib):
+    c = band_case()
+    ctx = c.hip_context()
+    from linevis_amd import capi
+    with pytest.raises(capi.LineVisError):
+        ctx.render(2)                                   # PPLL with band data
+    ctx.set_option("use_ribbons", False)
+    with pytest.raises(capi.LineVisError):
+        ctx.render(11)                                  # elliptic tubes without band data
+    ctx.set_option("use_analytic_elliptic_tubes", False)
+    ctx.render(11)
+
+
+@pytest.mark.gpu
+def test_band_data_through_the_plugin_surface(hip_lib, tmp_path):
+    """LineDataFlow with ribbon directions (from a version-2 .binlines file) -> HipRayTracer: USE_BANDS is switched on by the data,
+    `use_analytic_elliptic_tubes` selects the tubelets; the frames equal the ones of a context fed by hand."""
+    from linevis_amd import host_api
+    tr = ribbon_scene()
+    path = str(tmp_path / "ribbons.binlines")
+    scenes.write_binlines(path, tr)
+    flow = host_api.LineDataFlow().load_binlines(path)
+    assert flow.has_bands_data
+    settings = dict(line_width=0.02, band_width=0.05, min_band_thickness=0.3, depth_cue_strength=0.5)
+    r = host_api.HeadlessLineRenderer(11)
+    r.set_rendering_resolution(160, 120)
+    r.set_transfer_function(tfm.standard())
+    r.set_line_data(flow)
+    r.set_new_settings(settings)
+    frames = {}
+    for elliptic in (False, True):
+        r.set_new_settings(dict(use_analytic_elliptic_tubes=elliptic))
+        frames[elliptic] = r.render_frame()
+        pos, att, off = flow.trajectories()
+        if elliptic:
+            pts, seg, _ = flow.tube_aabb_render_data_elliptic(0.05)
+        else:
+            pts, seg, _ = flow.tube_aabb_render_data(0.02)
+        c = Case(pts, seg, tfm.standard(), 160, 120, 0.02, use_ribbons=True, use_analytic_elliptic_tubes=elliptic,
+                 **{k: v for k, v in settings.items() if k != "line_width"})
+        ctx = c.hip_context()
+        lo, hi = flow.attribute_range()
+        ctx.set_transfer_function(c.tf, lo, hi)
+        view, proj, fovy, near, far = r.camera()
+        ctx.set_camera(view, proj, fovy, near, far, 160, 120)
+        assert np.array_equal(frames[elliptic], ctx.render(11))
+    assert not np.array_equal(frames[False], frames[True])
+    r.set_new_settings(dict(use_ribbons=False))      # the data keeps its ribbons, the renderer ignores them
+    assert not np.array_equal(r.render_frame(), frames[True])
