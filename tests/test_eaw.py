@@ -172,7 +172,7 @@ def test_hip_eaw_against_the_oracle(hip_lib, variant):
 def test_denoiser_option_errors(hip_lib):
     from linevis_amd import capi
     ctx = small_case(**RTAO).hip_context()
-    for key, val in (("ambient_occlusion_denoiser", "SVGF"), ("eaw_denoiser_iterations", 6), ("eaw_denoiser_phi_color", 0.0)):
+    for key, val in (("ambient_occlusion_denoiser", "OptiX Denoiser"), ("svgf_denoiser_iterations", 6), ("eaw_denoiser_iterations", 6), ("eaw_denoiser_phi_color", 0.0)):
         with pytest.raises(capi.LineVisError):
             ctx.set_option(key, val)
     ctx.set_option("ambient_occlusion_denoiser", "EAW")
