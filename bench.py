@@ -62,6 +62,12 @@ WORKLOADS = {
     "c2": dict(name="C2: 100k-segment helix bundle (100 lines x 1001 points, seed 12345), 1920x1080, primary rays only "
                     "(1 spp, pixel centres, AO off, depth cues off), line width 0.002",
                scene="helix", mode=11, settings={"num_samples_per_frame": 1, "depth_cue_strength": 0.0}, kernel="k_render_rt"),
+    "c2e": dict(name="C2 scene (100k-segment helix bundle) as band data: twisted ribbon directions (8 rad per unit length), the ray "
+                     "tracer's Elliptic Tubes (sphere-traced tubelets, band width 0.005, min thickness 0.15) + USE_BANDS shading, "
+                     "1920x1080, primary rays only",
+                scene="helix", mode=11, ribbons=True, kernel="k_render_rt",
+                settings={"num_samples_per_frame": 1, "depth_cue_strength": 0.0, "use_ribbons": True,
+                          "use_analytic_elliptic_tubes": True, "band_width": 0.005, "min_band_thickness": 0.15}),
     "c4": dict(name="C4: 1M-segment tornado-style streamlines, 1920x1080, PPLL OIT: all-hits gather + per-pixel 4-ary heap "
                     "resolve, MAX_NUM_FRAGS 64, node pool 20/pixel, tiling 2x8, opacity ramp 0.1..0.6",
                scene="tornado", mode=2, settings={"ppll_max_num_frags": 64, "ppll_expected_avg_depth_complexity": 20,
@@ -103,8 +109,10 @@ def cpu_baseline(W, H, pts, seg, tf, attr_range, view, proj, fovy, near, far, ta
                         useAmbientOcclusion=int(rtao), aoStrength=1.0, aoGamma=1.0, aoSamplesPerFrame=ao_spp,
                         aoIterations=1, aoUseDistance=1, aoJitterPrimary=1, aoRadius=0.1, attrMin=attr_range[0],
                         attrMax=attr_range[1], ppllMaxNumFrags=64)
+    if workload == "c2e":
+        P.useBands, P.useEllipticTubes, P.bandWidth, P.minBandThickness, P.minThickness = 1, 1, 0.005, 0.15, 0.15
     t0 = time.time()
-    sc.build_bvh(LINE_WIDTH)
+    sc.build_bvh(P.bandWidth if P.useEllipticTubes else LINE_WIDTH)
     tsc = None
     if workload == "c3t":
         tsc = lvo.TriScene(mesh[0], mesh[1], mesh[2], LINE_WIDTH)
@@ -325,8 +333,13 @@ def main():
         from linevis_amd import capi, host_api, scenes
         gen = {"tornado": scenes.tornado, "helix": scenes.helix_bundle, "rayleigh_benard": scenes.rayleigh_benard}[wl["scene"]]
         tr = scenes.normalize(gen())
-        flow = host_api.LineDataFlow().set_trajectories(tr.positions, tr.attributes, tr.line_offsets)
-        pts, seg, _ = flow.tube_aabb_render_data(LINE_WIDTH)
+        if wl.get("ribbons"):   # band data: getLinePassTubeAabbRenderData(false, ellipticTubes = true)
+            tr = scenes.twisted_ribbons(tr, twist=8.0)
+            flow = host_api.LineDataFlow().set_trajectories(tr.positions, tr.attributes, tr.line_offsets, tr.ribbon_directions)
+            pts, seg, _ = flow.tube_aabb_render_data_elliptic(float(wl["settings"]["band_width"]))
+        else:
+            flow = host_api.LineDataFlow().set_trajectories(tr.positions, tr.attributes, tr.line_offsets)
+            pts, seg, _ = flow.tube_aabb_render_data(LINE_WIDTH)
         tf = tfm.standard_transparent() if wl.get("transparent") else tfm.standard()
         attr_range = flow.attribute_range()
         if wl.get("mesh"):   # LineData::getLinePassTubeTriangleMeshRenderData -> the RTAO pass' geometry
