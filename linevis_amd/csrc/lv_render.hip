@@ -572,7 +572,7 @@ __global__ __launch_bounds__(LV_AO_BLOCK, 5) void k_ao_rays(const LvUniforms U, 
             do {
                 if (STATS && lane == 0) { phIt[1]++; }
                 if (STATS && !(cur & LV_LEAF_BIT)) phLn[1]++;
-                if (!(cur & LV_LEAF_BIT)) cur = lv_node_step<STATS>(S, cur, oi, inv, 0.0f - litSlack, best + litSlack, st, cnt);
+                if (!(cur & LV_LEAF_BIT)) cur = lv_node_step<STATS, LV_AO_ORDERED>(S, cur, oi, inv, 0.0f - litSlack, best + litSlack, st, cnt);
                 const bool isLeaf = cur != LV_INVALID && (cur & LV_LEAF_BIT);
                 const unsigned long long mL = __ballot(isLeaf);
                 if (mL) {
