@@ -484,9 +484,10 @@ __device__ __forceinline__ f3 lv_from_tubelet(const LvTubelet& T, f3 p) { return
 
 // IntersectionEllipticTube main(), :186-270.  The reference reports the hit whenever the driver invokes the shader, i.e. whenever
 // the ray meets the segment's box; hitT itself may leave the box interval (a start point inside the surface steps backwards,
-// tilted cutting planes let the surface reach past the box).  To keep the result independent of the BVH a hit is accepted only
-// within bandWidth / |d| of the box interval (own-box rule, as for the literal capsule roots) and the traversal's culling
-// interval is widened by the same amount (lv_trace_closest).
+// tilted cutting planes let the surface reach past the box), and the shader's own box test is looser than a slab test (it skips
+// axes with |d_i| < 1e-3).  To keep the result independent of the BVH a hit is accepted only if the ray meets the box in the
+// slab-test sense and hitT lies within bandWidth / |d| of that interval (own-box rule, as for the literal capsule roots); the
+// traversal's culling interval is widened by the same amount (lv_trace_closest).
 __device__ __forceinline__ bool lv_intersect_elliptic_tube(const LvSceneDev& S, f3 o, f3 d, const lv_line_point& lp0,
                                                            const lv_line_point& lp1, float& hitTOut) {
     const float radius0 = S.ellBandWidth * 0.5f * S.ellMinBandThickness;
@@ -527,8 +528,19 @@ __device__ __forceinline__ bool lv_intersect_elliptic_tube(const LvSceneDev& S, 
     const bool isNotCulledLeft = dot3(El, pointWorld) + Elw > -eps1;
     const bool isNotCulledRight = dot3(Er, pointWorld) + Erw > -eps2;
     if (!(dTmp < 1e-4f && hitT > 0.0f && isNotCulledLeft && isNotCulledRight)) return false;
-    const float slack = S.ellBandWidth / len3(d);
-    if (hitT < tNear - slack || hitT > tFar + slack) return false; // own-box rule
+    // own-box rule: the driver only invokes the shader for rays that meet the box (the shader's own test above treats
+    // directions with |d_i| < 1e-3 as parallel and is looser than that), and hitT must lie within bandWidth / |d| of the interval
+    {
+        const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+        const f3 p0 = T.p0, p1 = T.p1;
+        const float tx0 = ((fminf(p0.x, p1.x) - lwo) - o.x) * inv.x, tx1 = ((fmaxf(p0.x, p1.x) + lwo) - o.x) * inv.x;
+        const float ty0 = ((fminf(p0.y, p1.y) - lwo) - o.y) * inv.y, ty1 = ((fmaxf(p0.y, p1.y) + lwo) - o.y) * inv.y;
+        const float tz0 = ((fminf(p0.z, p1.z) - lwo) - o.z) * inv.z, tz1 = ((fmaxf(p0.z, p1.z) + lwo) - o.z) * inv.z;
+        const float tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fminf(tz0, tz1));
+        const float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fmaxf(tz0, tz1));
+        const float slack = S.ellBandWidth / len3(d);
+        if (!(tn <= tf && hitT >= tn - slack && hitT <= tf + slack)) return false;
+    }
     hitTOut = hitT;
     return true;
 }

@@ -356,9 +356,10 @@ inline V3 fromTubelet(const Tubelet& T, V3 p) { return (T.xt * p.x + T.yt * p.y)
 
 // IntersectionEllipticTube main(), :186-270.  The reference reports the hit whenever the driver invokes the shader, i.e. whenever
 // the ray meets the segment's box; hitT itself may leave the box interval (a start point inside the surface steps backwards,
-// tilted cutting planes let the surface reach past the box).  To keep the result independent of the BVH the build accepts a hit
-// only within bandWidth / |d| of the box interval (own-box rule, as for the literal capsule roots) and widens the traversal's
-// culling interval by the same amount.
+// tilted cutting planes let the surface reach past the box), and the shader's own box test is looser than a slab test (it skips
+// axes with |d_i| < 1e-3).  To keep the result independent of the BVH the build accepts a hit only if the ray meets the box in the
+// slab-test sense and hitT lies within bandWidth / |d| of that interval (own-box rule, as for the literal capsule roots), and
+// widens the traversal's culling interval by the same amount.
 inline bool intersectEllipticTube(V3 o, V3 d, const lvo_line_point& lp0, const lvo_line_point& lp1, float& hitTOut) {
     const float radius0 = g_ell.bandWidth * 0.5f * g_ell.minBandThickness;
     const float radius1 = g_ell.bandWidth * 0.5f;
@@ -396,8 +397,19 @@ inline bool intersectEllipticTube(V3 o, V3 d, const lvo_line_point& lp0, const l
     const bool isNotCulledLeft = dot(El, pointWorld) + Elw > -eps1;
     const bool isNotCulledRight = dot(Er, pointWorld) + Erw > -eps2;
     if (!(dTmp < 1e-4f && hitT > 0.0f && isNotCulledLeft && isNotCulledRight)) return false;
-    const float slack = g_ell.bandWidth / sqrtf(dot(d, d));
-    if (hitT < tNear - slack || hitT > tFar + slack) return false;   // own-box rule
+    // own-box rule: the driver only invokes the shader for rays that meet the box (the shader's own test above treats
+    // directions with |d_i| < 1e-3 as parallel and is looser than that), and hitT must lie within bandWidth / |d| of the interval
+    {
+        const V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+        const V3 p0 = ld3(lp0.linePosition), p1 = ld3(lp1.linePosition);
+        const float tx0 = ((fminf(p0.x, p1.x) - lwo) - o.x) * inv.x, tx1 = ((fmaxf(p0.x, p1.x) + lwo) - o.x) * inv.x;
+        const float ty0 = ((fminf(p0.y, p1.y) - lwo) - o.y) * inv.y, ty1 = ((fmaxf(p0.y, p1.y) + lwo) - o.y) * inv.y;
+        const float tz0 = ((fminf(p0.z, p1.z) - lwo) - o.z) * inv.z, tz1 = ((fmaxf(p0.z, p1.z) + lwo) - o.z) * inv.z;
+        const float tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fminf(tz0, tz1));
+        const float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fmaxf(tz0, tz1));
+        const float slack = g_ell.bandWidth / sqrtf(dot(d, d));
+        if (!(tn <= tf && hitT >= tn - slack && hitT <= tf + slack)) return false;
+    }
     hitTOut = hitT;
     return true;
 }

@@ -177,3 +177,83 @@ def test_random_triangle_tube_cases(hip_lib, seed):
         w, h = int(rng.integers(1, c.width - x0 + 1)), int(rng.integers(1, c.height - y0 + 1))
         assert np.array_equal(ctx.render(11, tile=(x0, y0, w, h)), img[y0:y0 + h, x0:x0 + w]), tag
         ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(6))
+def test_random_band_data_cases(hip_lib, seed):
+    """Band data: random smooth bundles with random twists, elliptic tubes or circular tubes with USE_BANDS shading, random band
+    widths / thicknesses / cameras / RTAO settings."""
+    rng = np.random.default_rng(4000 + seed)
+    for k in range(8):
+        tr = scenes.twisted_ribbons(scenes.normalize(scenes.helix_bundle(
+            n_lines=int(rng.integers(1, 9)), points_per_line=int(rng.integers(8, 120)), seed=int(rng.integers(1 << 30)),
+            turns=float(rng.uniform(0.5, 3.0)))), twist=float(rng.uniform(0.0, 25.0)), seed=int(rng.integers(1 << 30)))
+        elliptic = bool(rng.integers(2))
+        bw = float(rng.choice([0.01, 0.03, 0.06]))
+        lw = float(rng.choice([0.004, 0.01, 0.03]))
+        s = dict(use_ribbons=True, use_analytic_elliptic_tubes=elliptic, band_width=bw,
+                 min_band_thickness=float(rng.choice([0.05, 0.15, 0.5, 1.0])), thick_bands=bool(rng.integers(4) > 0))
+        if rng.uniform() < 0.6:
+            s.update(RTAO, ambient_occlusion_strength=1.0, ambient_occlusion_iterations=int(rng.integers(1, 3)),
+                     ambient_occlusion_samples_per_frame=int(rng.integers(1, 6)), ambient_occlusion_distance_based=bool(rng.integers(2)),
+                     use_jittered_primary_rays=bool(rng.integers(2)), ambient_occlusion_radius=float(rng.choice([0.05, 0.2])))
+        if rng.uniform() < 0.4:
+            s["num_samples_per_frame"] = int(rng.integers(2, 4))
+        if rng.uniform() < 0.4:
+            s["depth_cue_strength"] = 0.6
+        if rng.uniform() < 0.25:
+            s["use_halos"] = False
+        if not elliptic and rng.uniform() < 0.3:
+            s["use_capped_tubes"] = False
+        if elliptic:
+            pts, seg, _ = lvo.build_tube_aabb_render_data_ribbons(tr.positions, tr.attributes, tr.line_offsets, bw, tr.ribbon_directions)
+        else:
+            pts, seg, _ = lvo.build_tube_aabb_render_data(tr.positions, tr.attributes, tr.line_offsets, lw)
+        tf = tfm.standard_transparent() if rng.uniform() < 0.4 else tfm.standard()
+        cam = (float(rng.uniform(-0.4, 0.4)), float(rng.uniform(-0.3, 0.3)), float(rng.uniform(0.5, 1.0)))
+        c = Case(pts, seg, tf, int(rng.integers(40, 180)), int(rng.integers(30, 120)), lw, camera_pos=cam, **s)
+        tag = "seed %d case %d: %dx%d lw %g %s" % (seed, k, c.width, c.height, lw, s)
+        ctx = c.hip_context()
+        img = ctx.render(11)
+        ref, ao_ref = c.oracle_render(11)
+        if ao_ref is not None:
+            assert np.array_equal(ctx.get_ao().view(np.uint32), ao_ref.view(np.uint32)), tag
+        assert max_lsb_diff(img, ref) <= LSB_TOL, tag
+        x0, y0 = int(rng.integers(0, c.width)), int(rng.integers(0, c.height))
+        w, h = int(rng.integers(1, c.width - x0 + 1)), int(rng.integers(1, c.height - y0 + 1))
+        assert np.array_equal(ctx.render(11, tile=(x0, y0, w, h)), img[y0:y0 + h, x0:x0 + w]), tag
+        ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(3))
+def test_random_svgf_sequences(hip_lib, seed):
+    """SVGF over random camera walks: the temporal state of the HIP context follows the oracle's frame by frame."""
+    from linevis_amd import camera
+    rng = np.random.default_rng(5000 + seed)
+    for k in range(4):
+        c, _ = random_case(rng)
+        for key in ("intersection_form", "eaw_denoiser_iterations", "eaw_denoiser_use_shared_memory", "eaw_denoiser_normal_weights"):
+            c.settings.pop(key, None)
+        its = int(rng.integers(0, 6))
+        c.settings.update(RTAO, ambient_occlusion_strength=1.0, ambient_occlusion_iterations=int(rng.integers(1, 3)),
+                          ambient_occlusion_samples_per_frame=int(rng.integers(1, 5)), ambient_occlusion_denoiser="SVGF",
+                          svgf_denoiser_iterations=its, use_jittered_primary_rays=bool(rng.integers(2)))
+        tag = "seed %d case %d: %dx%d lw %g %s" % (seed, k, c.width, c.height, c.line_width, c.settings)
+        ctx = c.hip_context()
+        sc = c.oracle_scene()
+        sv = lvo.Svgf(c.width, c.height, iterations=its)
+        pos = np.array([0.0, 0.0, 0.8])
+        for f in range(int(rng.integers(2, 6))):
+            if rng.uniform() < 0.6:
+                pos = pos + rng.normal(scale=0.01, size=3)
+            c.view, c.proj, c.fovy, c.near, c.far = camera.default_camera(c.width, c.height, tuple(float(x) for x in pos))
+            ctx.set_camera(c.view, c.proj, c.fovy, c.near, c.far, c.width, c.height)
+            img = ctx.render(11)
+            P = c.oracle_params(sc)
+            for _ in range(int(c.settings["ambient_occlusion_iterations"])):
+                ao_ref = sv.step(lambda: sc.render_ao(P), P)
+            assert np.abs(ctx.get_ao() - ao_ref).max() < 5e-5, tag + " frame %d" % f
+            assert max_lsb_diff(img, sc.render_rt(P, ao=ao_ref)) <= LSB_TOL, tag + " frame %d" % f
+        ctx.close()
