@@ -165,3 +165,26 @@ def test_elliptic_frame_bvh_equals_brute_force_and_bands_change_the_shading():
     assert np.array_equal(a, b) and (a[..., :3] != 255).any(axis=2).sum() > 1500
     P.minBandThickness = 1.0          # circular cross-section of the band radius: another picture
     assert not np.array_equal(sc.render_rt(P, use_bvh=True), a)
+
+
+def test_elliptic_bvh_equals_brute_force_for_near_axis_parallel_rays():
+    """The shader's own box test ignores axes with |d_i| < 1e-3; the own-box rule (slab interval) keeps the closest hit
+    independent of the BVH for exactly those rays."""
+    tr = ribbon_scene(n_lines=4, pts=80)
+    bw, mbt = 0.01, 0.05
+    pts, seg, _ = lvo.build_tube_aabb_render_data_ribbons(tr.positions, tr.attributes, tr.line_offsets, bw, tr.ribbon_directions)
+    sc = lvo.Scene(pts, seg, tfm.standard())
+    rng = np.random.default_rng(8)
+    n = 40000
+    tgt = pts["linePosition"][rng.integers(0, len(pts), n)] + rng.normal(scale=0.004, size=(n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    tiny = rng.integers(0, 3, n)
+    d[np.arange(n), tiny] = rng.uniform(-2e-3, 2e-3, n).astype(np.float32)      # one component around the 1e-3 threshold
+    d[: n // 4, (tiny[: n // 4] + 1) % 3] = rng.uniform(-2e-3, 2e-3, n // 4).astype(np.float32)   # sometimes two
+    o = (tgt - 0.3 * d).astype(np.float32)
+    cam = np.array([0.0, 0.0, 0.8], np.float32)
+    a = sc.trace_rays_elliptic(o, d, 1e-4, 1000.0, bw, mbt, cam, use_bvh=False)
+    b = sc.trace_rays_elliptic(o, d, 1e-4, 1000.0, bw, mbt, cam, use_bvh=True)
+    assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32)) and np.array_equal(a[1], b[1])
+    assert (a[1] != 0xFFFFFFFF).sum() > 2000
