@@ -381,3 +381,145 @@ def test_svgf_first_frame_against_the_float64_restatement():
     assert np.all(hist[1][..., 2] == 1.0)
     # the edge survives: pow(dot, 128) of perpendicular normals is 0
     assert abs(out[:, :13].mean() - out[:, 13:].mean()) > 0.2
+
+
+# ------------------------------------------------------------------ the RTAO chain end to end (a5, a7, a12, a13) in float64
+def _tea(v0, v1):
+    M, s0 = 0xFFFFFFFF, 0
+    for _ in range(16):
+        s0 = (s0 + 0x9e3779b9) & M
+        v0 = (v0 + ((((v1 << 4) & M) + 0xa341316c) & M ^ ((v1 + s0) & M) ^ (((v1 >> 5) + 0xc8013ea4) & M))) & M
+        v1 = (v1 + ((((v0 << 4) & M) + 0xad90777d) & M ^ ((v0 + s0) & M) ^ (((v0 >> 5) + 0x7e95761e) & M))) & M
+    return v0
+
+
+def _rnd2(seed):
+    out = []
+    for _ in range(2):
+        seed = (1664525 * seed + 1013904223) & 0xFFFFFFFF
+        out.append((seed & 0x00FFFFFF) / float(0x01000000))
+    return out
+
+
+def _ray_sphere(o, d, c, r):
+    A = np.dot(d, d)
+    B = 2.0 * np.dot(d, o - c)
+    Cc = np.dot(o - c, o - c) - r * r
+    disc = B * B - 4 * A * Cc
+    if disc < 0:
+        return None
+    s = np.sqrt(disc)
+    t0, t1 = (-B - s) / (2 * A), (-B + s) / (2 * A)
+    return t0 if t0 >= 0 else (t1 if t1 >= 0 else None)
+
+
+def _ray_tube(o, d, p0, p1, r):
+    td = (p1 - p0) / np.linalg.norm(p1 - p0)
+    dp = o - p0
+    a = d - np.dot(d, td) * td
+    b = dp - np.dot(dp, td) * td
+    A, B, Cc = np.dot(a, a), 2.0 * np.dot(a, b), np.dot(b, b) - r * r
+    disc = B * B - 4 * A * Cc
+    if disc < 0 or A == 0:
+        return None
+    s = np.sqrt(disc)
+    for t in ((-B - s) / (2 * A), (-B + s) / (2 * A)):
+        if t >= 0:
+            pos = o + t * d
+            if np.dot(td, pos - p0) > 0 and np.dot(td, pos - p1) < 0:
+                return t
+    return None
+
+
+def _closest_hit(o, d, P0, P1, r, t_min, t_max):
+    """IntersectionTube (TubeRayTracing.glsl:452-494) over all segments + reportIntersectionEXT's interval; returns
+    (t, segment, kind, margin) with margin = how clearly the winner wins (for excluding borderline pixels)."""
+    best, second = None, np.inf
+    for k in range(len(P0)):
+        hit_t, kind = 1e7, 0
+        t = _ray_tube(o, d, P0[k], P1[k], r)
+        has = t is not None
+        if has:
+            hit_t = t
+        for kk, c in ((1, P0[k]), (2, P1[k])):
+            s = _ray_sphere(o, d, c, r)
+            if s is not None and s < hit_t:
+                has, hit_t, kind = True, s, kk
+        if has and t_min <= hit_t <= t_max:
+            if best is None or hit_t < best[0]:
+                second = best[0] if best is not None else second
+                best = (hit_t, k, kind)
+            else:
+                second = min(second, hit_t)
+    return best, second
+
+
+def test_rtao_chain_against_the_float64_restatement():
+    """Primary ray (jittered, seeded per pixel), capsule closest hit, hit frame, 4 hemisphere samples per pixel, AO rays in
+    [0, radius] with distance weighting, mean -- restated in float64 numpy from the GLSL for a 32 x 24 frame over 80 segments
+    and compared with the oracle's AO image wherever no decision along the way is borderline."""
+    from linevis_amd import camera
+    c = small_case(width=32, height=24, n_lines=8, pts_per_line=11, line_width=0.1, seed=5,
+                   ambient_occlusion_mode="RTAO (Screen Space)", ambient_occlusion_strength=1.0, ambient_occlusion_radius=0.2,
+                   ambient_occlusion_iterations=1, ambient_occlusion_samples_per_frame=4)
+    sc = c.oracle_scene()
+    P = c.oracle_params(sc)
+    ao = sc.render_ao(P)
+    W, H, r, spp, ao_radius = c.width, c.height, c.line_width * 0.5, 4, 0.2
+    pts, seg = c.points, c.seg
+    P0 = pts["linePosition"][seg[:, 0]].astype(np.float64)
+    P1 = pts["linePosition"][seg[:, 1]].astype(np.float64)
+    T0 = pts["lineTangent"][seg[:, 0]].astype(np.float64)
+    T1 = pts["lineTangent"][seg[:, 1]].astype(np.float64)
+    inv_view = np.linalg.inv(np.array(c.view, np.float64).reshape(4, 4).T)
+    inv_proj = np.linalg.inv(np.array(c.proj, np.float64).reshape(4, 4).T)
+    cam = (inv_view @ np.array([0, 0, 0, 1.0]))[:3]
+    corr = np.cos(np.pi / 6.0)                      # subdivisionCorrectionFactor, 6 tube subdivisions
+    checked = hits = 0
+    for y in range(H):
+        for x in range(W):
+            pix = x + y * W
+            xi = _rnd2(_tea(pix, 0))
+            ndc = np.array([2 * (x + xi[0]) / W - 1, 2 * (y + xi[1]) / H - 1, 1.0, 1.0])
+            tgt = (inv_proj @ ndc)[:3]
+            d = (inv_view @ np.append(tgt / np.linalg.norm(tgt), 0.0))[:3]
+            best, second = _closest_hit(cam, d, P0, P1, r, 1e-4, 1000.0)
+            if best is None:
+                if second == np.inf:
+                    assert ao[y, x] == 1.0
+                    checked += 1
+                continue
+            t, k, kind = best
+            if second - t < 1e-4:
+                continue                                        # two surfaces at (almost) the same depth
+            hits += 1
+            pos = cam + d * t
+            v = P1[k] - P0[k]
+            ts = np.dot(v, pos - P0[k]) / np.dot(v, v) if kind == 0 else (0.0 if kind == 1 else 1.0)
+            line_pos = P0[k] + ts * v if kind == 0 else (P0[k] if kind == 1 else P1[k])
+            n = (pos - line_pos) / np.linalg.norm(pos - line_pos)
+            tg = (1 - ts) * T0[k] + ts * T1[k]
+            tg /= np.linalg.norm(tg)
+            bt = np.cross(n, tg)
+            offset = np.linalg.norm(line_pos - pos) / corr
+            total, clear = 0.0, True
+            for s in range(spp):
+                xi0, xi1 = _rnd2(_tea(pix, 0 * spp + s))
+                rs = np.sqrt(1.0 - xi0 * xi0)
+                smp = np.array([np.cos(2 * np.pi * xi1) * rs, np.sin(2 * np.pi * xi1) * rs, xi0])
+                rd = tg * smp[0] + bt * smp[1] + n * smp[2]
+                rd /= np.linalg.norm(rd)
+                ah, asec = _closest_hit(pos + rd * offset, rd, P0, P1, r, 0.0, ao_radius)
+                if ah is None:
+                    total += 1.0
+                    # a miss is only clear if nothing ends just outside the interval
+                    far, _ = _closest_hit(pos + rd * offset, rd, P0, P1, r, 0.0, ao_radius * 1.01)
+                    clear = clear and far is None
+                else:
+                    total += ah[0] / ao_radius
+                    clear = clear and ah[0] > 1e-4
+            if clear:
+                assert abs(ao[y, x] - total / spp) < 2e-4, (x, y, ao[y, x], total / spp)
+                checked += 1
+    print('hit pixels', hits, 'checked', checked, 'of', W * H)
+    assert hits > 100 and checked > 0.85 * W * H

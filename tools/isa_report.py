@@ -144,7 +144,7 @@ def main():
                 lines.append("### %s: %d instructions (static)" % (p, sum(hist.values())))
                 lines.append("    " + ", ".join("%s %d" % kv for kv in g.items() if kv[1]))
                 loop = node_step_loop(body)
-                if loop and p.startswith(("k_ao_rays<false, false, 0, false>", "k_ao_rays<false, false, 1, false>")):
+                if loop and p.startswith(("k_ao_rays<false, false, 0, false, false>", "k_ao_rays<false, false, 1, false, false>")):
                     lh = collections.Counter(mnemonic(t) for _, t in loop if t)
                     lg = classify(lh)
                     lines.append("    descend loop (innermost loop holding the node fetch): %d instructions per iteration" % sum(lh.values()))

@@ -13,7 +13,7 @@ bash $R/tools/pmc_collect.sh $TAG c3c c3t > $OUT/pmc_full.log 2>&1
 LV_PMC_LITE=1 bash $R/tools/pmc_collect.sh $TAG c2 c4 c4m c4l > $OUT/pmc_lite.log 2>&1
 for f in $R/gpurun_out/pmc_$TAG/*.json; do cp $f $R/profiles/pmc_${TAG}_$(basename $f); done   # bench.py reads profiles/
 python $R/bench.py > $OUT/bench_c3.json 2> $OUT/bench_c3.err
-for w in c3c c3t c2 c4 c4m c4l c5; do
+for w in c3c c3t c2 c2e c4 c4m c4l c5; do
   python $R/bench.py --workload $w --steps 100 --warmup 5 --no-cpu-baseline > $OUT/bench_$w.json 2> $OUT/bench_$w.err
 done
 for w in c3 c4 c4m c2; do
@@ -32,6 +32,22 @@ with open("$OUT/${w}_kernel_stats.csv", "w") as o:
 PY
   rm -rf $OUT/trace_$w
 done
+# the SVGF passes next to the RTAO kernels they follow
+python $R/bench.py --workload c3c --steps 100 --warmup 5 --no-cpu-baseline --set ambient_occlusion_denoiser=SVGF > $OUT/bench_c3c_svgf.json 2> $OUT/bench_c3c_svgf.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_svgf -o bench -- python $R/bench.py --workload c3c --steps 20 --warmup 3 --no-cpu-baseline --set ambient_occlusion_denoiser=SVGF > $OUT/rocprof_svgf.json 2> $OUT/rocprof_svgf.err
+f=$(find $OUT/trace_svgf -name "bench_kernel_stats.csv" | head -1)
+python - <<PY
+import csv
+rows = list(csv.DictReader(open("$f")))
+def short(n):
+    return n.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0][:70]
+with open("$OUT/c3c_svgf_kernel_stats.csv", "w") as o:
+    o.write("# rocprofv3 --kernel-trace --stats -- python bench.py --workload c3c --steps 20 --warmup 3 --no-cpu-baseline --set ambient_occlusion_denoiser=SVGF (MI355X)\n")
+    o.write("kernel,calls,total_ns,avg_ns,min_ns,max_ns,percent\n")
+    for r in rows[:30]:
+        o.write("%s,%s,%s,%.0f,%s,%s,%s\n" % (short(r["Name"]), r["Calls"], r["TotalDurationNs"], float(r["AverageNs"]), r["MinNs"], r["MaxNs"], r["Percentage"]))
+PY
+rm -rf $OUT/trace_svgf
 cd $R
 LV_PROBE_DEPTHS=1,2,4 python tools/probe_shard.py c3c > $OUT/shard_c3c.txt 2>&1
 LV_PROBE_DEPTHS=1,2,4 python tools/probe_shard.py c3t > $OUT/shard_c3t.txt 2>&1
