@@ -184,7 +184,23 @@ int lv_set_background(lv_ctx* ctx, const float rgba[4]);
  *   collect_stats (build-owned: run the instrumented kernels), mlat_record_trace / mlat_trace_capacity (build-owned,
  *   with collect_stats: record the candidate visiting order of an MLAT frame for lv_get_mlat_trace; records, 4 Mi),
  *   rtao_geometry (build-owned): "capsules" (default: AO rays hit the analytic capsules of the colour pass) or
- *   "triangle_tubes" (the reference's RTAO geometry: the mesh set with lv_set_tube_triangle_mesh). */
+ *   "triangle_tubes" (the reference's RTAO geometry: the mesh set with lv_set_tube_triangle_mesh),
+ *   intersection_form (build-owned): "closest_approach" (default) | "literal" (the reference's textbook roots,
+ *   RayIntersectionTestsVulkan.glsl:39-119, with the own-box rule that keeps them independent of the BVH),
+ *   ambient_occlusion_denoiser ("None" | "Edge-Avoiding A-Trous Wavelet Transform" (UTF-8 A-grave as in Denoiser.hpp:66; "EAW"
+ *   is accepted too) | "SVGF")                                         (VulkanRayTracedAmbientOcclusion.cpp:683-696)
+ *   eaw_denoiser_iterations (0..5, default 3), eaw_denoiser_color_weights / _position_weights / _normal_weights,
+ *   eaw_denoiser_phi_color / _phi_position / _phi_normal, eaw_denoiser_use_shared_memory   (EAWDenoiser.cpp:400-432)
+ *   svgf_denoiser_iterations (0..5, default 5), svgf_denoiser_allowed_z_dist (0.002), svgf_denoiser_allowed_normal_dist
+ *   (0.02): build-owned keys for parameters the reference exposes in its GUI only (SVGF.hpp:70-72,115).  SVGF is
+ *   temporal: every lv_render* call advances its history (one step per RTAO iteration), always over the whole viewport;
+ *   lv_set_lines resets the global frame counter, a change of the denoiser or of the viewport size clears the history,
+ *   band data (ribbons; ray tracer, analytic geometry modes only): use_ribbons (= USE_BANDS: the line points passed to
+ *   lv_set_lines come from a data set with ribbon directions and ribbons are on, LineDataFlow.cpp:587-606,2423-2431),
+ *   thick_bands, min_band_thickness (0.15, LineData.cpp:54), band_width (0.005, LineRenderer.cpp:442-449,
+ *   DataSetList.hpp:47), use_analytic_elliptic_tubes (build-owned key for the ray tracer's "Elliptic Tubes" checkbox,
+ *   VulkanRayTracer.cpp:198-201: the points then carry the ribbon normals of getLinePassTubeAabbRenderData(false, true)
+ *   and every segment is a sphere-traced elliptic tubelet, EllipticTubeRayTracing.glsl). */
 int lv_set_option(lv_ctx* ctx, const char* key, const char* value);
 
 /* LineData::getRayTracingTubeAabbTopLevelAS (LineData.cpp:1057-1075) + getTubeAabbBottomLevelAS (:879-907):
