@@ -422,7 +422,8 @@ def main():
         if world > 1:
             if dry:
                 local_cost = [float((int(x0) // TILE * 7 + int(y0) // TILE * 3) % 11) for x0, y0 in sf.local_tiles]
-            elif w["kernel"] == "k_ao_rays":
+            elif w["kernel"] == "k_ao_rays" and w["settings"].get("ambient_occlusion_denoiser") != "SVGF":
+                # (under SVGF every rank runs the RTAO pass on the whole viewport: there is no per-tile AO cost to balance)
                 local_cost = ctx.ao_tile_costs().astype(np.float64) * float(w.get("ao_spp", 64))
             else:
                 local_cost = None

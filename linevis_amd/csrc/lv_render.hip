@@ -1310,7 +1310,7 @@ static int lv_run_ao(lv_ctx* ctx, LvUniforms& U, LvSceneDev& S, const LvTiles& T
     if ((rc = lv_buf_reserve(ctx, ctx->aoList, (2 * size_t(numGroups) + 1) * 4))) return rc; // per-group counts, then bases
     uint32_t* tileCount = (uint32_t*)ctx->aoList.ptr;
     uint32_t* tileBase = tileCount + numGroups;
-    ctx->aoNumGroups = numGroups;
+    ctx->aoNumGroups = svgf ? 0u : numGroups; // whole-viewport pass: no per-tile costs of the caller's tile list (lv_get_ao_tile_costs)
     ctx->aoGroupsPerTile = (T.blocksX / 4u) * (T.blocksY / 4u);
     const uint64_t gridRays = lv_ao_grid(ctx, maxPixels * spp);
     const uint64_t gridMax = gridRays > gridTiles ? gridRays : gridTiles;
