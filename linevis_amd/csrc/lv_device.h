@@ -22,6 +22,9 @@
 #ifndef LV_AO_CHUNK
 #define LV_AO_CHUNK 128         // AO rays a wave takes from the global queue per atomic (1024: -10 %, the last chunks' tail)
 #endif
+#ifndef LV_AO_STAY
+#define LV_AO_STAY 1            // k_ao_rays descend loop: stay while at least this many lanes descend (tools/variants.py experiment)
+#endif
 #ifndef LV_AO_ORDERED
 #define LV_AO_ORDERED 1         // k_ao_rays: 1 = nearest hit child first, 0 = children as stored (tools/variants.py experiment)
 #endif

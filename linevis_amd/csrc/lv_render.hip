@@ -567,7 +567,7 @@ __global__ __launch_bounds__(LV_AO_BLOCK, 5) void k_ao_rays(const LvUniforms U, 
             // ---- descend phase: tight loop of node steps; leaves met on the way join the FIFO.  Leave it only when a
             // full batch of leaf tests waits or nobody descends any more (leaving earlier for a retire/refill pass
             // was measured slower: the per-pass bookkeeping outweighs the idle lanes).
-            const int stay = 1;
+            const int stay = LV_AO_STAY;
             int nNow;
             do {
                 if (STATS && lane == 0) { phIt[1]++; }
