@@ -170,7 +170,9 @@ int lv_set_background(lv_ctx* ctx, const float rgba[4]);
  *   = 0, 1, ... N-1, every frame is mixed into the previous one THROUGH RGBA8 exactly like TubeRayTracing.glsl:268-273,
  *   and RTAO runs one iteration per frame while frame_number < ambient_occlusion_iterations),
  *   use_deterministic_sampling, geometry_mode ("AABBs (analytic)" = ray-capsule, default | "Triangle Mesh" = the tube
- *   mesh set with lv_set_tube_triangle_mesh), use_analytic_intersections (bool form of the same switch)
+ *   mesh set with lv_set_tube_triangle_mesh | "Linear Swept Spheres" = the capsules with their caps always in the geometry
+ *   and the exact roots: what the NVIDIA hardware primitive with chained end caps is, LineData.cpp:909-945),
+ *   use_analytic_intersections (bool form of the first two)
  *                                                                       (VulkanRayTracer.cpp:226-278)
  *   use_mlat (multi-layer alpha tracing instead of the transparency loop; either geometry mode), mlat_num_nodes
  *   (power of two in [1, 32], default 8)                                (VulkanRayTracer.cpp:266-275, .hpp:133-134)

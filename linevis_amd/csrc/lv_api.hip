@@ -475,13 +475,19 @@ int lv_set_option(lv_ctx* ctx, const char* key, const char* value) {
         o.useDeterministicSampling = parseBool(value);
     } else if (k == "use_analytic_intersections") {
         o.rtTriangleMesh = !parseBool(value); // VulkanRayTracer.cpp:243-245
+        o.rtLss = false;
     } else if (k == "geometry_mode") {
         // RAY_TRACING_GEOMETRY_MODE_NAMES, VulkanRayTracer.hpp:58-63 ("AABBs" / "Analytic" kept as short forms)
-        if (strcmp(value, "Triangle Mesh") == 0) o.rtTriangleMesh = true;
-        else if (strcmp(value, "AABBs (analytic)") == 0 || strcmp(value, "AABBs") == 0 || strcmp(value, "Analytic") == 0)
-            o.rtTriangleMesh = false;
-        else
-            return lv_fail(ctx, LV_E_INVALID, "geometry_mode '%s' is not provided (Triangle Mesh | AABBs (analytic))", value);
+        if (strcmp(value, "Triangle Mesh") == 0) { o.rtTriangleMesh = true; o.rtLss = false; }
+        else if (strcmp(value, "AABBs (analytic)") == 0 || strcmp(value, "AABBs") == 0 || strcmp(value, "Analytic") == 0) {
+            o.rtTriangleMesh = false; o.rtLss = false;
+        } else if (strcmp(value, "Linear Swept Spheres") == 0) {
+            // the NVIDIA hardware primitive (chained end caps) = the exact union of the segments' capsules: the capsule path with
+            // its caps always on and the exact roots; ClosestHitTubeLinearSweptSpheres (TubeRayTracing.glsl:621-737) is
+            // ClosestHitTubeAnalytic with isCap from the hit's position along the segment
+            o.rtTriangleMesh = false; o.rtLss = true;
+        } else
+            return lv_fail(ctx, LV_E_INVALID, "geometry_mode '%s' is not provided (Triangle Mesh | AABBs (analytic) | Linear Swept Spheres)", value);
     } else if (k == "use_mlat") {
         o.useMlat = parseBool(value); // VulkanRayTracer.cpp:266-270
     } else if (k == "mlat_num_nodes") {

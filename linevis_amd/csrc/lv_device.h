@@ -133,6 +133,10 @@ struct LvUniforms {
     // band data (ribbons): USE_BANDS = use_ribbons && band data (LineDataFlow.cpp:2423-2431); the ray tracer's "Elliptic Tubes"
     // switch (VulkanRayTracer.cpp:198-201,468-499); bandWidth / minBandThickness of LineUniformData (LineData.cpp:1297-1298);
     // minThickness = the MIN_THICKNESS define (minBandThickness with thick bands, 1e-2 otherwise)
+    // geometry_mode "Linear Swept Spheres" (VK_NV_ray_tracing_linear_swept_spheres, chained end caps, LineData.cpp:909-945): the
+    // hardware primitive is the exact union of capsules -- the colour pass traces the capsules with their caps whatever
+    // use_capped_tubes says (which then only decides whether the shading sees isCap) and with the exact closest-approach roots
+    uint32_t lssGeometry;
     uint32_t useBands, useEllipticTubes;
     float bandWidth, minBandThickness, minThickness;
 };

@@ -58,6 +58,7 @@ struct LvOptions {
     uint32_t bakeIterations = 128;            // VulkanAmbientOcclusionBaker.hpp:108
     uint32_t bakeNumTubeSubdivisions = 8;     // :165
     uint32_t bakeSamplesPerFrame = 4;         // :166 (radius / distance-based share the RTAO keys; same defaults :167-168)
+    bool rtLss = false;                       // geometry_mode "Linear Swept Spheres" (VulkanRayTracer.hpp:56-63)
     bool rtTriangleMesh = false;              // geometry_mode "Triangle Mesh" / use_analytic_intersections=false (VulkanRayTracer.cpp:226-250)
     bool aoTriangleTubes = false;             // rtao_geometry: false = capsules (build default), true = the reference's triangle tubes
     bool useMlat = false;                     // VulkanRayTracer.hpp:133

@@ -98,7 +98,7 @@ __global__ __launch_bounds__(LV_BLOCK) void k_render_rt_mlat(const LvUniforms U,
     LvCounters cnt = {0, 0, 0, 0};
     const unsigned w = threadIdx.x >> 6, lane = lv_lane();
     const unsigned waveBase = threadIdx.x & ~63u;
-    const bool capped = U.useCappedTubes != 0;
+    const bool capped = U.useCappedTubes != 0 || U.lssGeometry != 0;
     const float aoTexel = (px.inView && U.useAmbientOcclusion) ? S.ao[size_t(px.y) * U.width + px.x] : 1.0f;
     s_chain[threadIdx.x] = LV_MLAT_NONE;
     float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};

@@ -38,7 +38,7 @@ __global__ __launch_bounds__(LV_BLOCK) void k_render_rt(const LvUniforms U, cons
     if (!lv_block_pixel(U, T, px)) return;
     const LvStackMem sm = lv_stack_mem(s_stack, S.stackOverflow);
     LvCounters cnt = {0, 0, 0, 0};
-    const bool capped = U.useCappedTubes != 0;
+    const bool capped = U.useCappedTubes != 0 || U.lssGeometry != 0;
     const float HIT_DISTANCE_EPSILON = 1e-5f;
     const float aoTexel = (px.inView && U.useAmbientOcclusion) ? S.ao[size_t(px.y) * U.width + px.x] : 1.0f;
     float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -1135,6 +1135,7 @@ void lv_fill_uniforms(const lv_ctx* ctx, LvUniforms& U) {
     const LvOptions& o = ctx->opt;
     U.lineWidth = o.lineWidth;
     U.radius = o.lineWidth * 0.5f; // TubeRayTracing.glsl:453
+    U.lssGeometry = (o.rtLss && !o.rtTriangleMesh) ? 1u : 0u;
     U.useBands = o.useRibbons ? 1u : 0u;
     U.useEllipticTubes = (o.useRibbons && o.ellipticTubes) ? 1u : 0u;
     U.bandWidth = o.bandWidth;
@@ -1439,6 +1440,8 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
     } else if (ctx->opt.ellipticTubes) {
         return lv_fail(ctx, LV_E_INVALID, "use_analytic_elliptic_tubes needs band data (use_ribbons)");
     }
+    if (ctx->opt.rtLss && ctx->opt.useRibbons && ctx->opt.ellipticTubes)
+        return lv_fail(ctx, LV_E_INVALID, "Elliptic Tubes belong to the AABB geometry mode (VulkanRayTracer.cpp:198), not to Linear Swept Spheres");
     if (!ctx->accelValid || ctx->accelLineWidth != lv_accel_width(ctx))
         if ((rc = lv_bvh_build(ctx))) return rc;
     if (ctx->opt.useAmbientOcclusion && ctx->opt.aoPrebaked && mode != LV_RENDERING_MODE_VULKAN_RAY_TRACER)
@@ -1567,11 +1570,13 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
         if (ctx->opt.useMlat) { // use_mlat: single-pass approximate transparency (lv_mlat.hip)
             LvSceneDev SM = tri ? sceneDevTriangles(ctx) : S;
             SM.accum = S.accum;
+            if (U.lssGeometry) SM.literalIntersection = 0u; // the hardware primitive has no intersection shader
             if (tri && (rc = lv_prepare_overflow(ctx, SM, gridTiles, LV_STACK_LDS, true))) return rc;
             if ((rc = lv_mlat_render(ctx, U, SM, T, gridTiles, out, dc, tri))) return rc;
         } else {
         LvSceneDev SC = tri ? sceneDevTriangles(ctx) : S;
         SC.accum = S.accum;
+        if (U.lssGeometry) SC.literalIntersection = 0u; // the hardware primitive has no intersection shader
         if (tri && (rc = lv_prepare_overflow(ctx, SC, gridTiles, LV_STACK_LDS, true))) return rc;
 #define LV_LAUNCH_RT(ST, PR, BA) \
     LV_TIMED_LAUNCH(ctx, LV_KERNEL_RENDER_RT, (k_render_rt<ST, PR, BA><<<gridTiles, LV_BLOCK, 0, st>>>(U, SC, T, out, dc)))

@@ -1259,7 +1259,10 @@ static void renderRt(const lvo_scene* sc, const lvo_params* Pp, int useBvh, cons
                      const uint8_t* prevRGBA8OrNull = nullptr) {
     const lvo_params& P = *Pp;
     Frame F = makeFrame(P);
-    const bool capped = P.useCappedTubes != 0;
+    // Linear Swept Spheres: the capsules with their caps, exact roots (no intersection shader to be literal about)
+    const bool capped = P.useCappedTubes != 0 || P.lssGeometry != 0;
+    struct LiteralOff { bool saved; bool on; LiteralOff(bool o) : saved(g_dev.literalIntersection), on(o) { if (on) g_dev.literalIntersection = false; }
+                        ~LiteralOff() { if (on) g_dev.literalIntersection = saved; } } literalOff(P.lssGeometry != 0);
     const float HIT_DISTANCE_EPSILON = 1e-5f;
     uint64_t rays = 0, nodes = 0, prims = 0, hits = 0;
     g_dev.aoImage = (P.useAmbientOcclusion && !pb) ? ao : nullptr; // full-viewport AO image for the reference lookup switch
@@ -1492,7 +1495,7 @@ static void renderRtMlat(const lvo_scene* sc, const lvo_tri_scene* tscOrNull, co
                          uint64_t* outViolations, lvo_stats* stats) {
     const lvo_params& P = *Pp;
     Frame F = makeFrame(P);
-    const bool capped = P.useCappedTubes != 0;
+    const bool capped = P.useCappedTubes != 0 || P.lssGeometry != 0;
     uint64_t rays = 0, nodesV = 0, prims = 0, hitsShaded = 0, violations = 0;
     g_dev.aoImage = P.useAmbientOcclusion ? ao : nullptr;
 #pragma omp parallel for schedule(dynamic, 1) reduction(+ : rays, nodesV, prims, hitsShaded, violations)

@@ -86,6 +86,9 @@ typedef struct {
     uint32_t useBands;
     uint32_t useEllipticTubes;
     float bandWidth, minBandThickness, minThickness;
+    /* geometry_mode "Linear Swept Spheres": capsules with their caps whatever useCappedTubes says (it then only decides whether
+     * the shading sees isCap), exact closest-approach roots (TubeRayTracing.glsl:621-737, LineData.cpp:909-945) */
+    uint32_t lssGeometry;
 } lvo_params;
 
 typedef struct {

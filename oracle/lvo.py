@@ -58,6 +58,7 @@ class Params(C.Structure):
         ("ppllTileW", C.c_uint32), ("ppllTileH", C.c_uint32),
         ("useBands", C.c_uint32), ("useEllipticTubes", C.c_uint32),
         ("bandWidth", C.c_float), ("minBandThickness", C.c_float), ("minThickness", C.c_float),
+        ("lssGeometry", C.c_uint32),
     ]
 
 
@@ -321,7 +322,7 @@ DEFAULTS = dict(
     attrMin=0.0, attrMax=1.0,
     aoSamplesPerFrame=4, aoIterations=1, aoUseDistance=1, aoJitterPrimary=1, tubeNumSubdivisions=6, aoRadius=0.1,
     ppllMaxNumFrags=100, ppllLinkedListSize=0, ppllTileW=2, ppllTileH=8,
-    useBands=0, useEllipticTubes=0, bandWidth=0.005, minBandThickness=0.15, minThickness=0.15,
+    useBands=0, useEllipticTubes=0, bandWidth=0.005, minBandThickness=0.15, minThickness=0.15, lssGeometry=0,
 )
 
 

@@ -58,6 +58,7 @@ class Case:
             aoRadius=float(s.get("ambient_occlusion_radius", 0.1)),
             ppllTileW=int(s.get("ppll_tile_width", 2)), ppllTileH=int(s.get("ppll_tile_height", 8)),
             # band data: USE_BANDS / elliptic tubes / MIN_THICKNESS (LineDataFlow.cpp:2423-2431, LineData.cpp:54,1297-1298)
+            lssGeometry=int(s.get("geometry_mode") == "Linear Swept Spheres"),
             useBands=int(bool(s.get("use_ribbons", False))),
             useEllipticTubes=int(bool(s.get("use_ribbons", False)) and bool(s.get("use_analytic_elliptic_tubes", False))),
             bandWidth=float(np.float32(s.get("band_width", 0.005))),

@@ -449,7 +449,7 @@ def test_option_errors(hip_lib):
     c = small_case(width=32, height=32)
     ctx = c.hip_context()
     for key, val in [("no_such_key", "1"), ("num_accumulated_frames", 0), ("ambient_occlusion_mode", "SSAO"),
-                     ("line_width", -1.0), ("geometry_mode", "Linear Swept Spheres"), ("mlat_num_nodes", 3)]:
+                     ("line_width", -1.0), ("geometry_mode", "Curved Swept Spheres"), ("mlat_num_nodes", 3)]:
         with pytest.raises(capi.LineVisError):
             ctx.set_option(key, val)
     with pytest.raises(capi.LineVisError):
@@ -720,3 +720,23 @@ def test_command_line_renderer(hip_lib, tmp_path):
     assert np.array_equal(r.render_frame(), img)
     assert main([p, "-o", out, "--mode", "ppll", "--width", "64", "--height", "48", "line_width=0.03"]) == 0
     assert np.array(Image.open(out)).shape == (48, 64, 4)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(use_capped_tubes=False), dict(transparent=True, use_mlat=False),
+                                dict(intersection_form="literal", use_capped_tubes=False)])
+def test_linear_swept_spheres_geometry_mode(hip_lib, kw):
+    """geometry_mode = "Linear Swept Spheres": the hardware primitive (chained end caps) is the exact union of the capsules, so the
+    mode is the capsule path with the caps always in the geometry (use_capped_tubes only decides whether the shading sees
+    isCap, TubeRayTracing.glsl:621-737) and the exact roots whatever intersection_form says."""
+    c = small_case(width=128, height=96, line_width=0.03, geometry_mode="Linear Swept Spheres", **kw)
+    img = c.hip_context().render(11)
+    ref, _ = c.oracle_render(11)
+    assert max_lsb_diff(img, ref) <= LSB_TOL
+    plain = dict(c.settings)
+    plain["geometry_mode"] = "AABBs (analytic)"
+    plain.pop("intersection_form", None)
+    aabb = Case(c.points, c.seg, c.tf, c.width, c.height, c.line_width, **plain).hip_context().render(11)
+    if kw.get("use_capped_tubes", True):
+        assert np.array_equal(img, aabb)          # same surface, same shading
+    else:
+        assert not np.array_equal(img, aabb)      # the swept spheres keep their round ends
