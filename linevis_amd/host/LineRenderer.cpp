@@ -317,7 +317,8 @@ bool LineRenderer::uploadFrameState() {
         if (!setOption("line_width", buf)) return false;
         // band data: USE_BANDS + the "Elliptic Tubes" geometry of the ray tracer (RayTracingRenderPass::setLineData,
         // VulkanRayTracer.cpp:370-381; LineDataFlow::getVulkanShaderPreprocessorDefines, LineDataFlow.cpp:2420-2431)
-        const bool bands = lineData->getUseBands();
+        // (rasterisers define USE_BANDS only in the band primitive modes, LineDataFlow.cpp:2423: not for the PPLL renderer's default)
+        const bool bands = !isRasterizer && lineData->getUseBands();
         const bool elliptic = bands && getUseAnalyticEllipticTubes();
         TubeAabbRenderData d = lineData->getLinePassTubeAabbRenderData(false, elliptic);
         if (!check(lv_set_lines(ctx, d.linePointDataBuffer.data(), uint32_t(d.linePointDataBuffer.size()),

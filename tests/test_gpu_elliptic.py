@@ -142,3 +142,21 @@ def test_band_data_through_the_plugin_surface(hip_lib, tmp_path):
     assert not np.array_equal(frames[False], frames[True])
     r.set_new_settings(dict(use_ribbons=False))      # the data keeps its ribbons, the renderer ignores them
     assert not np.array_equal(r.render_frame(), frames[True])
+
+
+@pytest.mark.gpu
+def test_ppll_plugin_ignores_band_data(hip_lib):
+    """The PPLL renderer is a rasteriser: USE_BANDS is not defined for it outside the band primitive modes
+    (LineDataFlow.cpp:2423), so a band data set renders as plain tubes there."""
+    from linevis_amd import host_api
+    tr = ribbon_scene()
+    frames = []
+    for ribbons in (tr.ribbon_directions, None):
+        flow = host_api.LineDataFlow().set_trajectories(tr.positions, tr.attributes, tr.line_offsets, ribbons)
+        r = host_api.HeadlessLineRenderer(2)
+        r.set_rendering_resolution(96, 64)
+        r.set_transfer_function(tfm.standard_transparent())
+        r.set_line_data(flow)
+        r.set_new_settings(dict(line_width=0.02))
+        frames.append(r.render_frame())
+    assert np.array_equal(frames[0], frames[1]) and (frames[0][..., :3] != 255).any()
