@@ -263,6 +263,10 @@ int lv_trace_streamlines(lv_ctx* ctx, const float* seed_points, uint32_t num_see
 /* positions: 3 floats per point; attributes: [num_scalar_fields][num_points]; line_offsets: num_lines + 1.  Any pointer
  * may be NULL. */
 int lv_get_streamlines(lv_ctx* ctx, float* positions, float* attributes, uint32_t* line_offsets);
+/* Per line of the last result: the index of the seed point inside the merged line (0 for forward lines, the last point for
+ * backward ones, behind the reversed backward part otherwise).  Streamribbons carry their ribbon direction outwards from the
+ * seed in both parts (StreamlineTracingGrid::traceStreamribbons, StreamlineTracingGrid.cpp:428-530). */
+int lv_get_streamline_seed_indices(lv_ctx* ctx, uint32_t* out_seed_index);
 
 /* ---- inspection entry points used by the parity tests ---- */
 /* Closest hit of arbitrary rays (IntersectionTube + driver closest-hit semantics, TubeRayTracing.glsl:452-494).

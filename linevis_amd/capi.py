@@ -85,7 +85,7 @@ SYMBOLS = ["lv_create", "lv_destroy", "lv_last_error", "lv_version", "lv_set_str
            "lv_render", "lv_render_device", "lv_render_tiles_device", "lv_get_stats", "lv_reset_timers", "lv_get_kernel_times", "lv_get_ao_tile_costs", "lv_trace_rays",
            "lv_compute_depth_range", "lv_get_ao", "lv_ppll_get_buffers", "lv_ppll_resolve_buffers", "lv_get_accel",
            "lv_set_tube_triangle_mesh", "lv_trace_rays_triangles", "lv_set_flow_grid", "lv_trace_streamlines",
-           "lv_get_streamlines", "lv_set_ao_parametrization", "lv_get_baked_ao", "lv_get_mlat_trace"]
+           "lv_get_streamlines", "lv_get_streamline_seed_indices", "lv_set_ao_parametrization", "lv_get_baked_ao", "lv_get_mlat_trace"]
 
 _lib = None
 
@@ -143,6 +143,7 @@ def load():
         ("lv_set_flow_grid", [vp, vp, u32, u32, u32, f32, f32, f32, vp, u32]),
         ("lv_trace_streamlines", [vp, vp, u32, C.POINTER(StreamlineSettings), C.POINTER(u64), C.POINTER(u64)]),
         ("lv_get_streamlines", [vp, vp, vp, vp]),
+        ("lv_get_streamline_seed_indices", [vp, vp]),
         ("lv_set_ao_parametrization", [vp, vp, u32, vp, u32]),
         ("lv_get_baked_ao", [vp, vp, u64]),
         ("lv_get_mlat_trace", [vp, vp, u64, C.POINTER(u64)]),
@@ -304,6 +305,11 @@ class Context:
         off = np.zeros(nl.value + 1, dtype=np.uint32)
         self._ck(self.L.lv_get_streamlines(self.h, _p(pos), _p(att), _p(off)))
         return pos, att, off
+
+    def streamline_seed_indices(self, num_lines):
+        out = np.zeros(num_lines, dtype=np.uint32)
+        self._ck(self.L.lv_get_streamline_seed_indices(self.h, _p(out)))
+        return out
 
     def depth_range(self):
         out = np.empty(2, dtype=np.float32)

@@ -724,6 +724,13 @@ int lv_get_streamlines(lv_ctx* ctx, float* positions, float* attributes, uint32_
     return LV_OK;
 }
 
+int lv_get_streamline_seed_indices(lv_ctx* ctx, uint32_t* out_seed_index) {
+    if (!ctx || !out_seed_index) return LV_E_INVALID;
+    if (ctx->flowOffsets.empty()) return lv_fail(ctx, LV_E_STATE, "lv_trace_streamlines has not been called");
+    if (!ctx->flowSeedIndex.empty()) memcpy(out_seed_index, ctx->flowSeedIndex.data(), ctx->flowSeedIndex.size() * 4);
+    return LV_OK;
+}
+
 int lv_compute_depth_range(lv_ctx* ctx, float out_min_max[2]) {
     if (!ctx || !out_min_max) return LV_E_INVALID;
     if (!ctx->cameraSet) return lv_fail(ctx, LV_E_STATE, "lv_set_camera has not been called");

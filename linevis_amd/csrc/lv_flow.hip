@@ -301,6 +301,7 @@ int lv_flow_trace(lv_ctx* ctx, const float* seeds, uint32_t numSeeds, const lv_s
     ctx->flowPositions.clear();
     ctx->flowAttributes.clear();
     ctx->flowOffsets.assign(1, 0u);
+    ctx->flowSeedIndex.clear();
     if (numSeeds == 0) return LV_OK;
     hipStream_t st = ctx->stream;
     LvFlowGrid g;
@@ -399,6 +400,12 @@ int lv_flow_trace(lv_ctx* ctx, const float* seeds, uint32_t numSeeds, const lv_s
                     ctx->flowAttributes[a].push_back(ha[size_t(a) * maxCount * numThreads + src]);
             }
         ctx->flowOffsets.push_back(uint32_t(ctx->flowPositions.size() / 3));
+        // where the seed sits in the merged line: behind the reversed backward part (streamribbons carry their ribbon
+        // direction outwards from the seed in both parts, StreamlineTracingGrid.cpp:479-486)
+        uint32_t seedIndex = 0u;
+        if (S->integration_direction == 1u) seedIndex = counts[s] ? counts[s] - 1u : 0u;
+        else if (S->integration_direction == 2u) seedIndex = counts[numSeeds + s] > 1u ? counts[numSeeds + s] - 1u : 0u;
+        ctx->flowSeedIndex.push_back(seedIndex);
     }
     return LV_OK;
 }

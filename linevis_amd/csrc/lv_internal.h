@@ -121,6 +121,7 @@ struct lv_ctx {
     std::vector<float> flowPositions;                 // result of the last lv_trace_streamlines call (host side)
     std::vector<std::vector<float>> flowAttributes;
     std::vector<uint32_t> flowOffsets;
+    std::vector<uint32_t> flowSeedIndex;              // per line: index of the seed point inside the merged line
 
     // camera
     bool cameraSet = false;

@@ -74,6 +74,11 @@ bool StreamlineTracingGrid::uploadGrid(int vectorFieldIndex) {
 
 bool StreamlineTracingGrid::traceStreamlines(const StreamlineTracingSettings& tracingSettings,
                                              const std::vector<vec3>& seedPoints, Trajectories& filteredTrajectories) {
+    return traceLines(tracingSettings, seedPoints, filteredTrajectories, nullptr);
+}
+
+bool StreamlineTracingGrid::traceLines(const StreamlineTracingSettings& tracingSettings, const std::vector<vec3>& seedPoints,
+                                       Trajectories& filteredTrajectories, std::vector<uint32_t>* seedIndices) {
     if (!uploadGrid(tracingSettings.vectorFieldIndex)) return false;
     lv_streamline_settings s;
     s.integration_method = uint32_t(tracingSettings.integrationMethod);
@@ -91,6 +96,13 @@ bool StreamlineTracingGrid::traceStreamlines(const StreamlineTracingSettings& tr
     std::vector<uint32_t> offsets(numLines + 1);
     rc = lv_get_streamlines(ctx, positions.data(), attributes.data(), offsets.data());
     if (rc != LV_OK) { lastError = std::string("lv_get_streamlines: ") + lv_last_error(ctx); return false; }
+    if (seedIndices) {
+        seedIndices->assign(numLines, 0u);
+        if (numLines && lv_get_streamline_seed_indices(ctx, seedIndices->data()) != LV_OK) {
+            lastError = std::string("lv_get_streamline_seed_indices: ") + lv_last_error(ctx);
+            return false;
+        }
+    }
     for (uint64_t l = 0; l < numLines; l++) {
         Trajectory t;
         const uint32_t b = offsets[l], e = offsets[l + 1];
@@ -103,6 +115,170 @@ bool StreamlineTracingGrid::traceStreamlines(const StreamlineTracingSettings& tr
     }
     return true;
 }
+
+// ---------------------------------------------------------------- streamribbons
+// _getScalarFieldAtPosition (:863-913): trilinear, values outside the grid are 0
+float StreamlineTracingGrid::getScalarFieldAtPosition(const std::vector<float>& f, const vec3& p) const {
+    const vec3 q0 = p - box.min;
+    const vec3 q(q0.x * (1.0f / dx), q0.y * (1.0f / dy), q0.z * (1.0f / dz));
+    const int cx = int(q.x), cy = int(q.y), cz = int(q.z);
+    const float fx = q.x - std::floor(q.x), fy = q.y - std::floor(q.y), fz = q.z - std::floor(q.z);
+    const float ix = 1.0f - fx, iy = 1.0f - fy, iz = 1.0f - fz;
+    auto at = [&](int x, int y, int z) {
+        if (x < 0 || y < 0 || z < 0 || x >= xs || y >= ys || z >= zs) return 0.0f;
+        return f[size_t(x) + size_t(y) * xs + size_t(z) * xs * ys];
+    };
+    float r = (ix * iy * iz) * at(cx, cy, cz);
+    r = r + (fx * iy * iz) * at(cx + 1, cy, cz);
+    r = r + (ix * fy * iz) * at(cx, cy + 1, cz);
+    r = r + (fx * fy * iz) * at(cx + 1, cy + 1, cz);
+    r = r + (ix * iy * fz) * at(cx, cy, cz + 1);
+    r = r + (fx * iy * fz) * at(cx + 1, cy, cz + 1);
+    r = r + (ix * fy * fz) * at(cx, cy + 1, cz + 1);
+    r = r + (fx * fy * fz) * at(cx + 1, cy + 1, cz + 1);
+    return r;
+}
+
+namespace {
+// glm::rotate(v, angle, normal) (gtx/rotate_vector.inl): the axis-angle matrix of gtc/matrix_transform.inl applied to v
+inline vec3 rotateVector(vec3 v, float angle, vec3 normal) {
+    const float c = std::cos(angle), s = std::sin(angle);
+    const vec3 axis = normalize(normal);
+    const vec3 temp = (1.0f - c) * axis;
+    const vec3 c0(c + temp.x * axis.x, temp.x * axis.y + s * axis.z, temp.x * axis.z - s * axis.y);
+    const vec3 c1(temp.y * axis.x - s * axis.z, c + temp.y * axis.y, temp.y * axis.z + s * axis.x);
+    const vec3 c2(temp.z * axis.x + s * axis.y, temp.z * axis.y - s * axis.x, c + temp.z * axis.z);
+    return (c0 * v.x + c1 * v.y) + c2 * v.z;
+}
+} // namespace
+
+// _pushRibbonDirections, StreamlineTracingGrid.cpp:1049-1116 (positions in TRACE order: outwards from the seed)
+void StreamlineTracingGrid::pushRibbonDirections(const StreamlineTracingSettings& tracingSettings,
+                                                 const std::vector<float>& helicityField, float maxHelicityMagnitude,
+                                                 const vec3* positions, size_t n, std::vector<vec3>& ribbonDirections,
+                                                 bool forwardMode) const {
+    vec3 lastRibbonDirection = normalize(tracingSettings.initialRibbonDirection);
+    if (n == 1) { ribbonDirections.push_back(lastRibbonDirection); return; }
+    for (size_t i = 0; i < n; i++) {
+        vec3 tangent;
+        if (i == 0) tangent = positions[i + 1] - positions[i];
+        else if (i == n - 1) tangent = positions[i] - positions[i - 1];
+        else tangent = positions[i + 1] - positions[i - 1];
+        tangent = normalize(tangent);
+        vec3 helperAxis = lastRibbonDirection;
+        if (length(cross(helperAxis, tangent)) < 1e-2f) {
+            helperAxis = vec3(0.0f, 0.0f, 1.0f);
+            if (length(cross(helperAxis, tangent)) < 1e-2f) helperAxis = vec3(0.0f, 1.0f, 0.0f);
+        }
+        vec3 ribbonDirection = normalize(helperAxis - dot(helperAxis, tangent) * tangent); // Gram-Schmidt
+        if (tracingSettings.useHelicity) {
+            float helicity = getScalarFieldAtPosition(helicityField, positions[i]);
+            if (!forwardMode) helicity *= -1.0f;
+            float lineSegmentLength = 0.0f;
+            if (i < n - 1) lineSegmentLength = length(positions[i + 1] - positions[i]);
+            const float helicityAngle = helicity / maxHelicityMagnitude * 3.14159265358979323846f * tracingSettings.maxHelicityTwist
+                                        * lineSegmentLength / 0.005f;
+            ribbonDirection = rotateVector(ribbonDirection, helicityAngle, tangent);
+        }
+        ribbonDirections.push_back(ribbonDirection);
+        lastRibbonDirection = ribbonDirection;
+    }
+}
+
+bool StreamlineTracingGrid::traceStreamribbons(const StreamlineTracingSettings& tracingSettings,
+                                               const std::vector<vec3>& seedPoints, Trajectories& filteredTrajectories,
+                                               std::vector<std::vector<vec3>>& filteredRibbonsDirections) {
+    auto hel = scalarFields.find("Helicity");
+    if (tracingSettings.useHelicity && hel == scalarFields.end()) {
+        lastError = "traceStreamribbons: no scalar field named \"Helicity\" (StreamlineTracingGrid.cpp:299-320)";
+        return false;
+    }
+    static const std::vector<float> none;
+    const std::vector<float>& helicityField = tracingSettings.useHelicity ? hel->second : none;
+    float maxHelicityMagnitude = 0.0f; // addScalarField("Helicity"), :299-320
+    for (float h : helicityField) maxHelicityMagnitude = std::max(maxHelicityMagnitude, std::fabs(h));
+    const size_t first = filteredTrajectories.size();
+    std::vector<uint32_t> seedIndices;
+    if (!traceLines(tracingSettings, seedPoints, filteredTrajectories, &seedIndices)) return false;
+    filteredRibbonsDirections.resize(filteredTrajectories.size());
+    // The GPU returns the merged lines; the ribbon directions are carried outwards from the seed in each traced part
+    // (forward part as traced, backward part in its own trace order with the helicity's sign flipped, then reversed and put
+    // in front without its seed point: :479-486, _reverseRibbon, _insertBackwardRibbon).
+#pragma omp parallel for schedule(dynamic, 16)
+    for (long li = 0; li < long(seedIndices.size()); li++) {
+        const Trajectory& t = filteredTrajectories[first + size_t(li)];
+        std::vector<vec3>& out = filteredRibbonsDirections[first + size_t(li)];
+        const size_t n = t.positions.size(), s = seedIndices[size_t(li)];
+        if (tracingSettings.integrationDirection == StreamlineIntegrationDirection::FORWARD) {
+            pushRibbonDirections(tracingSettings, helicityField, maxHelicityMagnitude, t.positions.data(), n, out, true);
+        } else if (tracingSettings.integrationDirection == StreamlineIntegrationDirection::BACKWARD) {
+            std::vector<vec3> traced(t.positions.rbegin(), t.positions.rend());
+            if (n <= 1) traced.assign(t.positions.begin(), t.positions.end());
+            pushRibbonDirections(tracingSettings, helicityField, maxHelicityMagnitude, traced.data(), n, out, false);
+            if (n > 1) std::reverse(out.begin(), out.end());
+        } else {
+            std::vector<vec3> fwd, bwd;
+            pushRibbonDirections(tracingSettings, helicityField, maxHelicityMagnitude, t.positions.data() + s, n - s, fwd, true);
+            if (s > 0) {
+                std::vector<vec3> traced(t.positions.rend() - ptrdiff_t(s + 1), t.positions.rend()); // seed, then outwards
+                pushRibbonDirections(tracingSettings, helicityField, maxHelicityMagnitude, traced.data(), s + 1, bwd, false);
+                std::reverse(bwd.begin(), bwd.end());
+                out.assign(bwd.begin(), bwd.end() - 1);
+            }
+            out.insert(out.end(), fwd.begin(), fwd.end());
+        }
+    }
+    return true;
+}
+
+// ---------------------------------------------------------------- grid utilities, Loader/GridLoader.cpp:41-183
+void computeVectorMagnitudeField(const float* v, float* out, int xs, int ys, int zs) {
+    const size_t n = size_t(xs) * ys * zs;
+#pragma omp parallel for
+    for (long i = 0; i < long(n); i++) {
+        const float vx = v[3 * i], vy = v[3 * i + 1], vz = v[3 * i + 2];
+        out[i] = std::sqrt(vx * vx + vy * vy + vz * vz);
+    }
+}
+// every derivative is divided by dy, as the reference writes it (:81-98)
+void computeVorticityField(const float* v, float* out, int xs, int ys, int zs, float /*dx*/, float dy, float /*dz*/) {
+    auto V = [&](int x, int y, int z, int c) { return v[3 * (size_t(x) + size_t(y) * xs + size_t(z) * xs * ys) + c]; };
+#pragma omp parallel for
+    for (int z = 0; z < zs; z++)
+        for (int y = 0; y < ys; y++)
+            for (int x = 0; x < xs; x++) {
+                const int left = x > 0 ? -1 : 0, right = x < xs - 1 ? 1 : 0;
+                const int down = y > 0 ? -1 : 0, up = y < ys - 1 ? 1 : 0;
+                const int back = z > 0 ? -1 : 0, front = z < zs - 1 ? 1 : 0;
+                const float dVzdy = (V(x, y + up, z, 2) - V(x, y + down, z, 2)) / (dy * float(up - down));
+                const float dVydz = (V(x, y, z + front, 1) - V(x, y, z + back, 1)) / (dy * float(front - back));
+                const float dVxdz = (V(x, y, z + front, 0) - V(x, y, z + back, 0)) / (dy * float(front - back));
+                const float dVzdx = (V(x + right, y, z, 2) - V(x + left, y, z, 2)) / (dy * float(right - left));
+                const float dVydx = (V(x + right, y, z, 1) - V(x + left, y, z, 1)) / (dy * float(right - left));
+                const float dVxdy = (V(x, y + up, z, 0) - V(x, y + down, z, 0)) / (dy * float(up - down));
+                float* o = out + 3 * (size_t(x) + size_t(y) * xs + size_t(z) * xs * ys);
+                o[0] = dVzdy - dVydz; o[1] = dVxdz - dVzdx; o[2] = dVydx - dVxdy;
+            }
+}
+void computeHelicityFieldNormalized(const float* vel, const float* vort, float* out, int xs, int ys, int zs,
+                                    bool normalizeVelocity, bool normalizeVorticity) {
+    const size_t n = size_t(xs) * ys * zs;
+#pragma omp parallel for
+    for (long i = 0; i < long(n); i++) {
+        float wx = vort[3 * i], wy = vort[3 * i + 1], wz = vort[3 * i + 2];
+        float vx = vel[3 * i], vy = vel[3 * i + 1], vz = vel[3 * i + 2];
+        if (normalizeVelocity) {
+            const float m = std::sqrt(vx * vx + vy * vy + vz * vz);
+            if (m > 1e-6) { vx /= m; vy /= m; vz /= m; }
+        }
+        if (normalizeVorticity) {
+            const float m = std::sqrt(wx * wx + wy * wy + wz * wz);
+            if (m > 1e-6) { wx /= m; wy /= m; wz /= m; }
+        }
+        out[i] = vx * wx + vy * wy + vz * wz;
+    }
+}
+
 
 // ---------------------------------------------------------------- StreamlinePlaneSeeder, StreamlineSeeder.cpp:52-135
 void StreamlinePlaneSeeder::reset(const StreamlineTracingGrid& grid) {
@@ -221,18 +397,23 @@ void AbcFlowGenerator::generateAbcFlow(float* v) const {
             }
 }
 
-void AbcFlowGenerator::load(StreamlineTracingGrid* grid) const {
+void AbcFlowGenerator::load(StreamlineTracingGrid* grid, bool useNormalizedVelocity, bool useNormalizedVorticity) const {
     float maxDimension = float(std::max(xs - 1, std::max(ys - 1, zs - 1)));
     float cellStep = 1.0f / maxDimension;
-    std::vector<float> velocity(3 * size_t(xs) * ys * zs), magnitude(size_t(xs) * ys * zs);
+    const size_t n = size_t(xs) * ys * zs;
+    std::vector<float> velocity(3 * n), velocityMagnitude(n), vorticity(3 * n), vorticityMagnitude(n), helicity(n);
     generateAbcFlow(velocity.data());
-    for (size_t i = 0; i < magnitude.size(); i++) {
-        float vx = velocity[3 * i], vy = velocity[3 * i + 1], vz = velocity[3 * i + 2];
-        magnitude[i] = std::sqrt(vx * vx + vy * vy + vz * vz);
-    }
+    computeVectorMagnitudeField(velocity.data(), velocityMagnitude.data(), xs, ys, zs);
+    computeVorticityField(velocity.data(), vorticity.data(), xs, ys, zs, cellStep, cellStep, cellStep);
+    computeVectorMagnitudeField(vorticity.data(), vorticityMagnitude.data(), xs, ys, zs);
+    computeHelicityFieldNormalized(velocity.data(), vorticity.data(), helicity.data(), xs, ys, zs, useNormalizedVelocity,
+                                   useNormalizedVorticity);
     grid->setGridExtent(xs, ys, zs, cellStep, cellStep, cellStep);
     grid->addVectorField(velocity.data(), "Velocity");
-    grid->addScalarField(magnitude.data(), "Velocity Magnitude");
+    grid->addVectorField(vorticity.data(), "Vorticity");
+    grid->addScalarField(helicity.data(), "Helicity");
+    grid->addScalarField(velocityMagnitude.data(), "Velocity Magnitude");
+    grid->addScalarField(vorticityMagnitude.data(), "Vorticity Magnitude");
 }
 
 } // namespace lv

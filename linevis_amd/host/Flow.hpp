@@ -33,7 +33,17 @@ struct StreamlineTracingSettings {
     StreamlineIntegrationMethod integrationMethod = StreamlineIntegrationMethod::RK4;
     StreamlineIntegrationDirection integrationDirection = StreamlineIntegrationDirection::BOTH;
     int vectorFieldIndex = 0;
+    // flowPrimitives == STREAMRIBBONS (StreamlineTracingDefines.hpp:168-173)
+    bool useHelicity = true;
+    float maxHelicityTwist = 0.25f;
+    vec3 initialRibbonDirection = vec3(0.0f, 1.0f, 0.0f);
 };
+
+/// GridLoader.cpp:41-183: |v| per grid point, curl by central / one-sided differences, helicity v . curl v
+void computeVectorMagnitudeField(const float* vectorField, float* vectorMagnitudeField, int xs, int ys, int zs);
+void computeVorticityField(const float* velocityField, float* vorticityField, int xs, int ys, int zs, float dx, float dy, float dz);
+void computeHelicityFieldNormalized(const float* velocityField, const float* vorticityField, float* helicityField, int xs, int ys,
+                                    int zs, bool normalizeVelocity, bool normalizeVorticity);
 
 class StreamlineTracingGrid {
 public:
@@ -60,9 +70,20 @@ public:
     /// scalar fields in name order (std::map iteration, like the reference's scalarFields).
     bool traceStreamlines(const StreamlineTracingSettings& tracingSettings, const std::vector<vec3>& seedPoints,
                           Trajectories& filteredTrajectories);
+    /// traceStreamribbons (StreamlineTracingGrid.cpp:428-530): the streamlines (traced on the GPU) + one ribbon direction per
+    /// point (_pushRibbonDirections, :1049-1116: carried outwards from the seed along every traced part, twisted by the
+    /// "Helicity" scalar field) -- the band data LineDataFlow::setTrajectoryData takes.
+    bool traceStreamribbons(const StreamlineTracingSettings& tracingSettings, const std::vector<vec3>& seedPoints,
+                            Trajectories& filteredTrajectories, std::vector<std::vector<vec3>>& filteredRibbonsDirections);
 
 private:
     bool uploadGrid(int vectorFieldIndex);
+    bool traceLines(const StreamlineTracingSettings& tracingSettings, const std::vector<vec3>& seedPoints,
+                    Trajectories& filteredTrajectories, std::vector<uint32_t>* seedIndices);
+    float getScalarFieldAtPosition(const std::vector<float>& scalarField, const vec3& particlePosition) const;
+    void pushRibbonDirections(const StreamlineTracingSettings& tracingSettings, const std::vector<float>& helicityField,
+                              float maxHelicityMagnitude, const vec3* positions, size_t n, std::vector<vec3>& ribbonDirections,
+                              bool forwardMode) const;
     lv_ctx* ctx = nullptr;
     std::string lastError;
     int xs = 0, ys = 0, zs = 0;
@@ -121,9 +142,9 @@ public:
     int getGridSizeY() const { return ys; }
     int getGridSizeZ() const { return zs; }
     void generateAbcFlow(float* v) const;
-    /// "Velocity" + "Velocity Magnitude" on a grid whose longest axis spans [0, 1] (AbcFlowGenerator.cpp:74-103; the
-    /// vorticity / helicity fields of the reference's loader feed ribbons and helicity seeding, which are out of scope).
-    void load(StreamlineTracingGrid* grid) const;
+    /// "Velocity" / "Vorticity" vector fields and "Helicity" / "Velocity Magnitude" / "Vorticity Magnitude" scalar fields on a
+    /// grid whose longest axis spans [0, 1] (AbcFlowGenerator.cpp:74-103).
+    void load(StreamlineTracingGrid* grid, bool useNormalizedVelocity = false, bool useNormalizedVorticity = false) const;
 
 private:
     int xs = 64, ys = 64, zs = 64;

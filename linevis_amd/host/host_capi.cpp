@@ -161,6 +161,7 @@ namespace {
 struct GridHandle {
     StreamlineTracingGrid grid;
     Trajectories result;
+    std::vector<std::vector<vec3>> ribbons;
     explicit GridHandle(int device) : grid(device) {}
 };
 } // namespace
@@ -230,6 +231,41 @@ int lvh_grid_trace(void* hp, const float* seeds, uint32_t numSeeds, int method, 
     *outNumPoints = n;
     return 0;
 }
+/// traceStreamribbons: as lvh_grid_trace, plus one ribbon direction per point (fetched with lvh_grid_copy_ribbons)
+int lvh_grid_trace_ribbons(void* hp, const float* seeds, uint32_t numSeeds, int method, int direction, float timeStepScale,
+                           int maxNumIterations, float terminationDistance, float minimumLength, int useHelicity,
+                           float maxHelicityTwist, const float* initialRibbonDirection, uint64_t* outNumLines,
+                           uint64_t* outNumPoints) {
+    GridHandle* h = static_cast<GridHandle*>(hp);
+    StreamlineTracingSettings s;
+    s.integrationMethod = StreamlineIntegrationMethod(method);
+    s.integrationDirection = StreamlineIntegrationDirection(direction);
+    s.timeStepScale = timeStepScale;
+    s.maxNumIterations = maxNumIterations;
+    s.terminationDistance = terminationDistance;
+    s.minimumLength = minimumLength;
+    s.useHelicity = useHelicity != 0;
+    s.maxHelicityTwist = maxHelicityTwist;
+    s.initialRibbonDirection = vec3(initialRibbonDirection[0], initialRibbonDirection[1], initialRibbonDirection[2]);
+    std::vector<vec3> seedPoints(numSeeds);
+    if (numSeeds) memcpy(seedPoints.data(), seeds, size_t(numSeeds) * 12);
+    h->result.clear();
+    h->ribbons.clear();
+    if (!h->grid.traceStreamribbons(s, seedPoints, h->result, h->ribbons)) return -1;
+    uint64_t n = 0;
+    for (const Trajectory& t : h->result) n += t.positions.size();
+    *outNumLines = h->result.size();
+    *outNumPoints = n;
+    return 0;
+}
+void lvh_grid_copy_ribbons(void* hp, float* ribbonDirections) {
+    size_t off = 0;
+    for (const auto& dirs : static_cast<GridHandle*>(hp)->ribbons) {
+        memcpy(ribbonDirections + 3 * off, dirs.data(), dirs.size() * 12);
+        off += dirs.size();
+    }
+}
+int lvh_grid_num_scalar_fields(void* hp) { return int(static_cast<GridHandle*>(hp)->grid.getScalarFieldNames().size()); }
 /// positions n*3, attributes [k][n] (scalar fields in name order), offsets numLines+1
 void lvh_grid_copy_result(void* hp, float* positions, float* attributes, uint32_t* offsets) {
     const Trajectories& tr = static_cast<GridHandle*>(hp)->result;

@@ -55,6 +55,9 @@ def load():
         "lvh_grid_plane_seeds": (None, [vp, vp, f32, i32, i32, i32, vp]),
         "lvh_grid_trace": (i32, [vp, vp, u32, i32, i32, f32, i32, f32, f32, C.POINTER(u64), C.POINTER(u64)]),
         "lvh_grid_copy_result": (None, [vp, vp, vp, vp]),
+        "lvh_grid_trace_ribbons": (i32, [vp, vp, u32, i32, i32, f32, i32, f32, f32, i32, f32, vp, C.POINTER(u64), C.POINTER(u64)]),
+        "lvh_grid_copy_ribbons": (None, [vp, vp]),
+        "lvh_grid_num_scalar_fields": (i32, [vp]),
         "lvh_grid_last_error": (cp, [vp]),
         "lvh_renderer_create": (vp, [i32, i32]),
         "lvh_renderer_destroy": (None, [vp]),
@@ -248,8 +251,10 @@ class StreamlineTracingGrid:
         return self
 
     def load_abc_flow(self, xs=64, ys=64, zs=64, res_scale=6.0):
+        """AbcFlowGenerator::load: vector fields Velocity, Vorticity; scalar fields (name order) Helicity, Velocity Magnitude,
+        Vorticity Magnitude."""
         self.L.lvh_grid_load_abc_flow(self.h, xs, ys, zs, res_scale)
-        self.num_scalars = 1
+        self.num_scalars = int(self.L.lvh_grid_num_scalar_fields(self.h))
         return self
 
     def info(self):
@@ -286,6 +291,31 @@ class StreamlineTracingGrid:
         off = np.zeros(nl.value + 1, dtype=np.uint32)
         self.L.lvh_grid_copy_result(self.h, _p(pos), _p(att), _p(off))
         return pos, att, off
+
+
+def _trace_streamribbons(self, seeds, method="Runge-Kutta 4th Order", direction="Forward & Backward", time_step_scale=1.0,
+                         max_num_iterations=2000, termination_distance=1.0, minimum_length=0.7, use_helicity=True,
+                         max_helicity_twist=0.25, initial_ribbon_direction=(0.0, 1.0, 0.0)):
+    """traceStreamribbons: (positions, attributes, line_offsets, ribbon_directions [P,3]); needs a "Helicity" scalar field."""
+    sd = np.ascontiguousarray(seeds, dtype=np.float32).reshape(-1, 3)
+    ird = np.ascontiguousarray(initial_ribbon_direction, dtype=np.float32)
+    nl, npt = C.c_uint64(), C.c_uint64()
+    rc = self.L.lvh_grid_trace_ribbons(self.h, _p(sd), len(sd), capi.INTEGRATION_METHODS[method],
+                                       capi.INTEGRATION_DIRECTIONS[direction], time_step_scale, max_num_iterations,
+                                       termination_distance, minimum_length, int(use_helicity), max_helicity_twist, _p(ird),
+                                       C.byref(nl), C.byref(npt))
+    if rc != 0:
+        raise capi.LineVisError(rc, self.L.lvh_grid_last_error(self.h).decode("utf-8", "replace"))
+    pos = np.zeros((npt.value, 3), dtype=np.float32)
+    att = np.zeros((self.num_scalars, npt.value), dtype=np.float32)
+    off = np.zeros(nl.value + 1, dtype=np.uint32)
+    rib = np.zeros((npt.value, 3), dtype=np.float32)
+    self.L.lvh_grid_copy_result(self.h, _p(pos), _p(att), _p(off))
+    self.L.lvh_grid_copy_ribbons(self.h, _p(rib))
+    return pos, att, off, rib
+
+
+StreamlineTracingGrid.trace_streamribbons = _trace_streamribbons
 
 
 class HeadlessLineRenderer:

@@ -277,6 +277,18 @@ lvo_streamlines* lvo_trace_streamlines(const float* vectorField, int xs, int ys,
 void lvo_streamlines_sizes(const lvo_streamlines*, uint64_t* numLines, uint64_t* numPoints);
 void lvo_streamlines_copy(const lvo_streamlines*, float* positions, float* attributes, uint32_t* offsets);
 void lvo_streamlines_destroy(lvo_streamlines*);
+/* traceStreamribbons (StreamlineTracingGrid.cpp:428-530,1049-1116): the streamlines + one ribbon direction per point, carried
+ * along every traced part and twisted by the local helicity (scalar field `helicityFieldIndex`). */
+lvo_streamlines* lvo_trace_streamribbons(const float* vectorField, int xs, int ys, int zs, float dx, float dy, float dz,
+                                         const float* const* scalarFields, uint32_t numScalarFields, const float* seeds,
+                                         uint32_t numSeeds, const lvo_streamline_settings* settings, uint32_t helicityFieldIndex,
+                                         int useHelicity, float maxHelicityTwist, const float* initialRibbonDirection);
+void lvo_streamlines_copy_ribbons(const lvo_streamlines*, float* ribbonDirections);
+/* GridLoader.cpp:41-183 */
+void lvo_compute_vector_magnitude_field(const float* v, float* out, int xs, int ys, int zs);
+void lvo_compute_vorticity_field(const float* v, float* out, int xs, int ys, int zs, float dx, float dy, float dz);
+void lvo_compute_helicity_field_normalized(const float* vel, const float* vort, float* out, int xs, int ys, int zs,
+                                           int normalizeVelocity, int normalizeVorticity);
 
 /* ---- f4: EAW denoiser of the RTAO pass (EAWDenoiser.cpp, EAWDenoise.glsl; AO defaults Denoiser.cpp:54-62) ----
  * Feature maps: full-viewport float4 images the next lvo_render_ao / lvo_render_ao_tri calls fill (view-space normal {xyz,0},

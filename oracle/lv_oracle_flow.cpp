@@ -114,6 +114,7 @@ inline bool rayBox(V3 o, V3 d, V3 lower, V3 upper, float& tNear, float& tFar) {
 struct Line {
     std::vector<V3> pos;
     std::vector<std::vector<float>> att;
+    std::vector<V3> ribbon;   // streamribbons: one direction per point
 };
 
 inline void pushPoint(const Grid& g, Line& l, V3 p) {
@@ -267,9 +268,58 @@ void traceOne(const Grid& g, const lvo_streamline_settings& S, float maxVectorMa
     }
 }
 
-inline void reverseLine(Line& l) {
+// glm::rotate(v, angle, normal) (gtx/rotate_vector.inl): mat3(glm::rotate(angle, normal)) * v, the axis-angle matrix of
+// gtc/matrix_transform.inl
+inline V3 rotateVec(V3 v, float angle, V3 normal) {
+    const float c = cosf(angle), s = sinf(angle);
+    const V3 axis = normalize(normal);
+    const V3 temp = (1.0f - c) * axis;
+    const V3 c0 = v3(c + temp.x * axis.x, temp.x * axis.y + s * axis.z, temp.x * axis.z - s * axis.y);
+    const V3 c1 = v3(temp.y * axis.x - s * axis.z, c + temp.y * axis.y, temp.y * axis.z + s * axis.x);
+    const V3 c2 = v3(temp.z * axis.x + s * axis.y, temp.z * axis.y - s * axis.x, c + temp.z * axis.z);
+    return (c0 * v.x + c1 * v.y) + c2 * v.z;
+}
+
+struct RibbonSettings { bool useHelicity; float maxHelicityTwist; V3 initialRibbonDirection; const float* helicityField; float maxHelicityMagnitude; };
+
+// StreamlineTracingGrid::_pushRibbonDirections, StreamlineTracingGrid.cpp:1049-1116: the ribbon direction is carried from point
+// to point (Gram-Schmidt against the tangent, fallback axes z then y) and twisted about the tangent by the local helicity
+inline void pushRibbonDirections(const Grid& g, const RibbonSettings& R, const std::vector<V3>& positions, std::vector<V3>& dirs,
+                                 bool forwardMode) {
+    V3 lastRibbonDirection = normalize(R.initialRibbonDirection);
+    const size_t n = positions.size();
+    if (n == 1) { dirs.push_back(lastRibbonDirection); return; }
+    for (size_t i = 0; i < n; i++) {
+        V3 tangent;
+        if (i == 0) tangent = positions[i + 1] - positions[i];
+        else if (i == n - 1) tangent = positions[i] - positions[i - 1];
+        else tangent = positions[i + 1] - positions[i - 1];
+        tangent = normalize(tangent);
+        const V3 particlePosition = positions[i];
+        V3 helperAxis = lastRibbonDirection;
+        if (length(cross(helperAxis, tangent)) < 1e-2f) {
+            helperAxis = v3(0.0f, 0.0f, 1.0f);
+            if (length(cross(helperAxis, tangent)) < 1e-2f) helperAxis = v3(0.0f, 1.0f, 0.0f);
+        }
+        V3 ribbonDirection = normalize(helperAxis - dot(helperAxis, tangent) * tangent);
+        if (R.useHelicity) {
+            float helicity = scalarAtPosition(g, R.helicityField, particlePosition);
+            if (!forwardMode) helicity *= -1.0f;
+            float lineSegmentLength = 0.0f;
+            if (i < n - 1) lineSegmentLength = length(positions[i + 1] - positions[i]);
+            const float helicityAngle = helicity / R.maxHelicityMagnitude * 3.14159265358979323846f * R.maxHelicityTwist
+                                        * lineSegmentLength / 0.005f;
+            ribbonDirection = rotateVec(ribbonDirection, helicityAngle, tangent);
+        }
+        dirs.push_back(ribbonDirection);
+        lastRibbonDirection = ribbonDirection;
+    }
+}
+
+inline void reverseLine(Line& l) { // _reverseTrajectory / _reverseRibbon, :1118-1146
     if (l.pos.size() <= 1) return;
     std::reverse(l.pos.begin(), l.pos.end());
+    std::reverse(l.ribbon.begin(), l.ribbon.end());
     for (auto& a : l.att) std::reverse(a.begin(), a.end());
 }
 
@@ -279,6 +329,7 @@ struct lvo_streamlines {
     std::vector<float> positions;
     std::vector<std::vector<float>> attributes;
     std::vector<uint32_t> offsets;
+    std::vector<float> ribbonDirections; // streamribbons only
 };
 
 extern "C" {
@@ -299,6 +350,50 @@ void lvo_generate_abc_flow(float* v, int xs, int ys, int zs, float A, float B, f
 }
 
 // addVectorField's max-magnitude reduction, :189-216
+// GridLoader.cpp:41-183: |v| per grid point, curl by central / one-sided differences (every derivative divided by dy, as the
+// reference writes it), helicity v . curl v with optional normalisation of either factor
+void lvo_compute_vector_magnitude_field(const float* v, float* out, int xs, int ys, int zs) {
+    for (size_t i = 0; i < size_t(xs) * ys * zs; i++) {
+        const float vx = v[3 * i], vy = v[3 * i + 1], vz = v[3 * i + 2];
+        out[i] = std::sqrt(vx * vx + vy * vy + vz * vz);
+    }
+}
+void lvo_compute_vorticity_field(const float* v, float* out, int xs, int ys, int zs, float dx, float dy, float dz) {
+    (void)dx; (void)dz;
+    auto V = [&](int x, int y, int z, int c) { return v[3 * (size_t(x) + size_t(y) * xs + size_t(z) * xs * ys) + c]; };
+    for (int z = 0; z < zs; z++)
+        for (int y = 0; y < ys; y++)
+            for (int x = 0; x < xs; x++) {
+                const int left = x > 0 ? -1 : 0, right = x < xs - 1 ? 1 : 0;
+                const int down = y > 0 ? -1 : 0, up = y < ys - 1 ? 1 : 0;
+                const int back = z > 0 ? -1 : 0, front = z < zs - 1 ? 1 : 0;
+                const float dVzdy = (V(x, y + up, z, 2) - V(x, y + down, z, 2)) / (dy * float(up - down));
+                const float dVydz = (V(x, y, z + front, 1) - V(x, y, z + back, 1)) / (dy * float(front - back));
+                const float dVxdz = (V(x, y, z + front, 0) - V(x, y, z + back, 0)) / (dy * float(front - back));
+                const float dVzdx = (V(x + right, y, z, 2) - V(x + left, y, z, 2)) / (dy * float(right - left));
+                const float dVydx = (V(x + right, y, z, 1) - V(x + left, y, z, 1)) / (dy * float(right - left));
+                const float dVxdy = (V(x, y + up, z, 0) - V(x, y + down, z, 0)) / (dy * float(up - down));
+                float* o = out + 3 * (size_t(x) + size_t(y) * xs + size_t(z) * xs * ys);
+                o[0] = dVzdy - dVydz; o[1] = dVxdz - dVzdx; o[2] = dVydx - dVxdy;
+            }
+}
+void lvo_compute_helicity_field_normalized(const float* vel, const float* vort, float* out, int xs, int ys, int zs,
+                                           int normalizeVelocity, int normalizeVorticity) {
+    for (size_t i = 0; i < size_t(xs) * ys * zs; i++) {
+        float wx = vort[3 * i], wy = vort[3 * i + 1], wz = vort[3 * i + 2];
+        float vx = vel[3 * i], vy = vel[3 * i + 1], vz = vel[3 * i + 2];
+        if (normalizeVelocity) {
+            const float m = std::sqrt(vx * vx + vy * vy + vz * vz);
+            if (m > 1e-6) { vx /= m; vy /= m; vz /= m; }
+        }
+        if (normalizeVorticity) {
+            const float m = std::sqrt(wx * wx + wy * wy + wz * wz);
+            if (m > 1e-6) { wx /= m; wy /= m; wz /= m; }
+        }
+        out[i] = vx * wx + vy * wy + vz * wz;
+    }
+}
+
 float lvo_max_vector_magnitude(const float* v, uint64_t numCells) {
     float m = 0.0f;
     for (uint64_t i = 0; i < numCells; i++) {
@@ -308,9 +403,35 @@ float lvo_max_vector_magnitude(const float* v, uint64_t numCells) {
     return m;
 }
 
+static lvo_streamlines* traceLines(const float* vectorField, int xs, int ys, int zs, float dx, float dy, float dz,
+                                   const float* const* scalarFields, uint32_t numScalarFields, const float* seeds,
+                                   uint32_t numSeeds, const lvo_streamline_settings* settings, const RibbonSettings* ribbons);
 lvo_streamlines* lvo_trace_streamlines(const float* vectorField, int xs, int ys, int zs, float dx, float dy, float dz,
                                        const float* const* scalarFields, uint32_t numScalarFields, const float* seeds,
                                        uint32_t numSeeds, const lvo_streamline_settings* settings) {
+    return traceLines(vectorField, xs, ys, zs, dx, dy, dz, scalarFields, numScalarFields, seeds, numSeeds, settings, nullptr);
+}
+// traceStreamribbons (StreamlineTracingGrid.cpp:428-530): the streamlines + _pushRibbonDirections per traced part.
+// helicityFieldIndex: which of the scalar fields is "Helicity"; its maximum magnitude over the grid normalises the twist (:299-320)
+lvo_streamlines* lvo_trace_streamribbons(const float* vectorField, int xs, int ys, int zs, float dx, float dy, float dz,
+                                         const float* const* scalarFields, uint32_t numScalarFields, const float* seeds,
+                                         uint32_t numSeeds, const lvo_streamline_settings* settings, uint32_t helicityFieldIndex,
+                                         int useHelicity, float maxHelicityTwist, const float* initialRibbonDirection) {
+    RibbonSettings R;
+    R.useHelicity = useHelicity != 0;
+    R.maxHelicityTwist = maxHelicityTwist;
+    R.initialRibbonDirection = ld3(initialRibbonDirection);
+    R.helicityField = scalarFields[helicityFieldIndex];
+    R.maxHelicityMagnitude = 0.0f;
+    for (size_t i = 0; i < size_t(xs) * ys * zs; i++) R.maxHelicityMagnitude = std::max(R.maxHelicityMagnitude, fabsf(R.helicityField[i]));
+    return traceLines(vectorField, xs, ys, zs, dx, dy, dz, scalarFields, numScalarFields, seeds, numSeeds, settings, &R);
+}
+void lvo_streamlines_copy_ribbons(const lvo_streamlines* s, float* ribbonDirections) {
+    memcpy(ribbonDirections, s->ribbonDirections.data(), s->ribbonDirections.size() * 4);
+}
+static lvo_streamlines* traceLines(const float* vectorField, int xs, int ys, int zs, float dx, float dy, float dz,
+                                   const float* const* scalarFields, uint32_t numScalarFields, const float* seeds,
+                                   uint32_t numSeeds, const lvo_streamline_settings* settings, const RibbonSettings* ribbons) {
     Grid g;
     g.xs = xs; g.ys = ys; g.zs = zs; g.dx = dx; g.dy = dy; g.dz = dz;
     g.boxMin = v3(0.0f, 0.0f, 0.0f);
@@ -325,15 +446,22 @@ lvo_streamlines* lvo_trace_streamlines(const float* vectorField, int xs, int ys,
         const V3 seed = ld3(seeds + 3 * i);
         if (S.integrationDirection == 0) {
             traceOne(g, S, maxMag, seed, true, line);
+            if (ribbons) pushRibbonDirections(g, *ribbons, line.pos, line.ribbon, true);
         } else if (S.integrationDirection == 1) {
             traceOne(g, S, maxMag, seed, false, line);
+            if (ribbons) pushRibbonDirections(g, *ribbons, line.pos, line.ribbon, false);
             reverseLine(line);
         } else {
             Line back;
             traceOne(g, S, maxMag, seed, true, line);
             traceOne(g, S, maxMag, seed, false, back);
+            if (ribbons) {
+                pushRibbonDirections(g, *ribbons, line.pos, line.ribbon, true);
+                pushRibbonDirections(g, *ribbons, back.pos, back.ribbon, false);
+            }
             reverseLine(back);
-            if (back.pos.size() > 1) { // _insertBackwardTrajectory, :1149-1166
+            if (back.pos.size() > 1) { // _insertBackwardTrajectory / _insertBackwardRibbon, :1149-1191
+                if (ribbons) line.ribbon.insert(line.ribbon.begin(), back.ribbon.begin(), back.ribbon.end() - 1);
                 line.pos.insert(line.pos.begin(), back.pos.begin(), back.pos.end() - 1);
                 if (line.att.empty()) line.att.resize(numScalarFields);
                 for (uint32_t a = 0; a < numScalarFields; a++)
@@ -350,6 +478,7 @@ lvo_streamlines* lvo_trace_streamlines(const float* vectorField, int xs, int ys,
         for (size_t i = 1; i < l.pos.size(); i++) len += length(l.pos[i] - l.pos[i - 1]);
         if (!(len > S.minimumLength)) continue;
         for (const V3& p : l.pos) { out->positions.push_back(p.x); out->positions.push_back(p.y); out->positions.push_back(p.z); }
+        for (const V3& r : l.ribbon) { out->ribbonDirections.push_back(r.x); out->ribbonDirections.push_back(r.y); out->ribbonDirections.push_back(r.z); }
         for (uint32_t a = 0; a < numScalarFields; a++)
             out->attributes[a].insert(out->attributes[a].end(), l.att[a].begin(), l.att[a].end());
         out->offsets.push_back(uint32_t(out->positions.size() / 3));

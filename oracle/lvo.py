@@ -172,6 +172,12 @@ def lib():
     L.lvo_streamlines_sizes.argtypes = [vp, u64p, u64p]
     L.lvo_streamlines_copy.argtypes = [vp, vp, vp, vp]
     L.lvo_streamlines_destroy.argtypes = [vp]
+    L.lvo_trace_streamribbons.restype = vp
+    L.lvo_trace_streamribbons.argtypes = [vp, i32, i32, i32, f32, f32, f32, vp, u32, vp, u32, vp, u32, i32, f32, vp]
+    L.lvo_streamlines_copy_ribbons.argtypes = [vp, vp]
+    L.lvo_compute_vector_magnitude_field.argtypes = [vp, vp, i32, i32, i32]
+    L.lvo_compute_vorticity_field.argtypes = [vp, vp, i32, i32, i32, f32, f32, f32]
+    L.lvo_compute_helicity_field_normalized.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32]
     _lib = L
     return L
 
@@ -294,6 +300,56 @@ def trace_streamlines(vector_field, spacing, scalar_fields, seeds, settings):
     lib().lvo_streamlines_copy(h, _p(pos), _p(att), _p(off))
     lib().lvo_streamlines_destroy(h)
     return pos, att, off
+
+
+def trace_streamribbons(vector_field, spacing, scalar_fields, seeds, settings, helicity_index, use_helicity=True,
+                        max_helicity_twist=0.25, initial_ribbon_direction=(0.0, 1.0, 0.0)):
+    """traceStreamribbons restated: trace_streamlines + (ribbon_directions [P,3])."""
+    v = np.ascontiguousarray(vector_field, dtype=np.float32)
+    zs, ys, xs = v.shape[:3]
+    sf = [np.ascontiguousarray(f, dtype=np.float32) for f in scalar_fields]
+    ptrs = (C.c_void_p * max(len(sf), 1))(*[f.ctypes.data for f in sf])
+    sd = np.ascontiguousarray(seeds, dtype=np.float32).reshape(-1, 3)
+    ird = np.ascontiguousarray(initial_ribbon_direction, dtype=np.float32)
+    h = lib().lvo_trace_streamribbons(_p(v), xs, ys, zs, spacing[0], spacing[1], spacing[2], ptrs, len(sf), _p(sd), len(sd),
+                                      C.byref(settings), int(helicity_index), int(use_helicity), float(max_helicity_twist), _p(ird))
+    nl, npt = C.c_uint64(), C.c_uint64()
+    lib().lvo_streamlines_sizes(h, C.byref(nl), C.byref(npt))
+    pos = np.zeros((npt.value, 3), dtype=np.float32)
+    att = np.zeros((len(sf), npt.value), dtype=np.float32)
+    off = np.zeros(nl.value + 1, dtype=np.uint32)
+    rib = np.zeros((npt.value, 3), dtype=np.float32)
+    lib().lvo_streamlines_copy(h, _p(pos), _p(att), _p(off))
+    lib().lvo_streamlines_copy_ribbons(h, _p(rib))
+    lib().lvo_streamlines_destroy(h)
+    return pos, att, off, rib
+
+
+def vorticity_field(vector_field, spacing):
+    """computeVorticityField, GridLoader.cpp:64-112 (vector_field [zs, ys, xs, 3])."""
+    v = np.ascontiguousarray(vector_field, dtype=np.float32)
+    zs, ys, xs = v.shape[:3]
+    out = np.zeros_like(v)
+    lib().lvo_compute_vorticity_field(_p(v), _p(out), xs, ys, zs, spacing[0], spacing[1], spacing[2])
+    return out
+
+
+def vector_magnitude_field(vector_field):
+    v = np.ascontiguousarray(vector_field, dtype=np.float32)
+    zs, ys, xs = v.shape[:3]
+    out = np.zeros((zs, ys, xs), dtype=np.float32)
+    lib().lvo_compute_vector_magnitude_field(_p(v), _p(out), xs, ys, zs)
+    return out
+
+
+def helicity_field(velocity, vorticity, normalize_velocity=False, normalize_vorticity=False):
+    """computeHelicityFieldNormalized, GridLoader.cpp:140-183."""
+    v = np.ascontiguousarray(velocity, dtype=np.float32)
+    w = np.ascontiguousarray(vorticity, dtype=np.float32)
+    zs, ys, xs = v.shape[:3]
+    out = np.zeros((zs, ys, xs), dtype=np.float32)
+    lib().lvo_compute_helicity_field_normalized(_p(v), _p(w), _p(out), xs, ys, zs, int(normalize_velocity), int(normalize_vorticity))
+    return out
 
 
 def intersect_triangle(o, d, v0, v1, v2, pad):

@@ -174,3 +174,81 @@ def test_attributes_are_trilinear_samples():
     assert att.shape == (2, len(pos)) and len(off) == 3
     assert np.allclose(att[0], pos[:, 0] + 2 * pos[:, 1] + 3 * pos[:, 2], atol=1e-5)
     assert np.allclose(att[1], pos[:, 0] * pos[:, 1] * pos[:, 2], atol=1e-5)
+
+
+# ------------------------------------------------------------------ streamribbons (StreamlineTracingGrid.cpp:428-530,1049-1116)
+def _push_ribbon_directions(pos, helicity_at, max_hel, forward, twist=0.25, init=(0.0, 1.0, 0.0), use_helicity=True):
+    """float64 restatement of _pushRibbonDirections for one traced part (positions in trace order)."""
+    last = np.array(init, np.float64) / np.linalg.norm(init)
+    n = len(pos)
+    if n == 1:
+        return [last]
+    out = []
+    for i in range(n):
+        t = pos[1] - pos[0] if i == 0 else (pos[i] - pos[i - 1] if i == n - 1 else pos[i + 1] - pos[i - 1])
+        t = t / np.linalg.norm(t)
+        helper = last
+        if np.linalg.norm(np.cross(helper, t)) < 1e-2:
+            helper = np.array([0.0, 0.0, 1.0])
+            if np.linalg.norm(np.cross(helper, t)) < 1e-2:
+                helper = np.array([0.0, 1.0, 0.0])
+        d = helper - np.dot(helper, t) * t
+        d /= np.linalg.norm(d)
+        if use_helicity:
+            h = helicity_at(pos[i]) * (1.0 if forward else -1.0)
+            seg = np.linalg.norm(pos[i + 1] - pos[i]) if i < n - 1 else 0.0
+            ang = h / max_hel * np.pi * twist * seg / 0.005
+            d = d * np.cos(ang) + np.cross(t, d) * np.sin(ang) + t * np.dot(t, d) * (1.0 - np.cos(ang))   # Rodrigues
+        out.append(d)
+        last = d
+    return out
+
+
+def test_streamribbon_directions_against_the_float64_restatement():
+    n = 20
+    v = lvo.generate_abc_flow(n, n, n)
+    sp = (1.0 / (n - 1),) * 3
+    w = lvo.vorticity_field(v, sp)
+    hel = lvo.helicity_field(v, w)
+    # the curl of the ABC flow is the flow itself (Beltrami), scaled by the chain rule of the grid mapping: interior points only
+    h = 6.0 / (n - 1)                       # central differences of sin / cos: the derivative times sin(h) / h
+    assert np.allclose(w[2:-2, 2:-2, 2:-2], 6.0 * np.sin(h) / h * v[2:-2, 2:-2, 2:-2], atol=1e-3)
+    max_hel = float(np.abs(hel).max())
+
+    def helicity_at(p):
+        q = np.asarray(p, np.float64) / sp[0]
+        c = np.floor(q).astype(int)
+        f = q - c
+        r = 0.0
+        for dz in (0, 1):
+            for dy in (0, 1):
+                for dx in (0, 1):
+                    x, y, z = c[0] + dx, c[1] + dy, c[2] + dz
+                    val = hel[z, y, x] if 0 <= x < n and 0 <= y < n and 0 <= z < n else 0.0
+                    r += (f[0] if dx else 1 - f[0]) * (f[1] if dy else 1 - f[1]) * (f[2] if dz else 1 - f[2]) * val
+        return r
+
+    seeds = np.random.default_rng(3).uniform(0.25, 0.75, (6, 3)).astype(np.float32)
+    for direction, fwd in (("Forward", True), ("Backward", False)):
+        S = lvo.streamline_settings(direction=direction, minimum_length=0.1)
+        pos, att, off, rib = lvo.trace_streamribbons(v, sp, [hel], seeds, S, 0)
+        assert len(off) - 1 == 6
+        for l in range(6):
+            p = pos[off[l]:off[l + 1]].astype(np.float64)
+            traced = p if fwd else p[::-1]
+            want = _push_ribbon_directions(traced, helicity_at, max_hel, fwd)
+            want = np.array(want if fwd else want[::-1])
+            got = rib[off[l]:off[l + 1]]
+            # the direction is carried from point to point: float32 rounding accumulates along the line
+            assert np.abs(got - want).max() < 2e-3, (direction, l, np.abs(got - want).max())
+            t = np.gradient(p, axis=0)
+            t /= np.linalg.norm(t, axis=1, keepdims=True)
+            assert np.abs((got[1:-1] * t[1:-1]).sum(axis=1)).max() < 1e-3      # perpendicular to the tangent, unit length
+            assert np.abs(np.linalg.norm(got, axis=1) - 1).max() < 1e-5
+    # both directions: the two parts meet at the seed, the backward part without its seed point in front
+    S = lvo.streamline_settings(minimum_length=0.1)
+    pos, att, off, rib = lvo.trace_streamribbons(v, sp, [hel], seeds, S, 0)
+    pf, _, of, rf = lvo.trace_streamribbons(v, sp, [hel], seeds, lvo.streamline_settings(direction="Forward", minimum_length=0.0), 0)
+    for l in range(6):
+        nf = int(of[l + 1] - of[l])
+        assert np.array_equal(rib[off[l + 1] - nf:off[l + 1]], rf[of[l]:of[l + 1]])

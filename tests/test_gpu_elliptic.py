@@ -142,6 +142,7 @@ def test_band_data_through_the_plugin_surface(hip_lib, tmp_path):
     assert not np.array_equal(frames[False], frames[True])
     r.set_new_settings(dict(use_ribbons=False))      # the data keeps its ribbons, the renderer ignores them
     assert not np.array_equal(r.render_frame(), frames[True])
+    r.set_new_settings(dict(use_ribbons=True))       # LineDataFlow::useRibbons is static, as in the reference: leave it on
 
 
 @pytest.mark.gpu
@@ -160,3 +161,32 @@ def test_ppll_plugin_ignores_band_data(hip_lib):
         r.set_new_settings(dict(line_width=0.02))
         frames.append(r.render_frame())
     assert np.array_equal(frames[0], frames[1]) and (frames[0][..., :3] != 255).any()
+
+
+@pytest.mark.gpu
+def test_streamribbons_from_the_tracer_to_the_renderer(hip_lib):
+    """The producer side of band data: StreamlineTracingGrid::traceStreamribbons (lines on the GPU, ribbon directions from the
+    helicity field) -> LineDataFlow -> the ray tracer's elliptic tubes; the frame equals the oracle's on the same ribbons."""
+    from linevis_amd import host_api
+    grid = host_api.StreamlineTracingGrid().load_abc_flow(24, 24, 24, 6.0)
+    seeds = grid.regular_seeds(3, 3, 3)
+    pos, att, off, rib = grid.trace_streamribbons(seeds, minimum_length=0.5, max_helicity_twist=0.5)
+    assert len(off) - 1 >= 10 and rib.shape == pos.shape
+    npos = host_api.normalize_positions(pos)
+    flow = host_api.LineDataFlow().set_trajectories(npos, att[1], off, rib)      # attribute: Velocity Magnitude
+    assert flow.has_bands_data
+    bw = 0.03
+    pts, seg, _ = flow.tube_aabb_render_data_elliptic(bw)
+    ref_pts, ref_seg, _ = lvo.build_tube_aabb_render_data_ribbons(npos, att[1], off, bw, rib)
+    assert np.array_equal(pts.view(np.uint8), ref_pts.view(np.uint8)) and np.array_equal(seg, ref_seg)
+    c = Case(pts, seg, tfm.standard(), 200, 150, 0.01, use_ribbons=True, use_analytic_elliptic_tubes=True, band_width=bw,
+             min_band_thickness=0.2)
+    lo, hi = flow.attribute_range()
+    ctx = c.hip_context()
+    ctx.set_transfer_function(c.tf, lo, hi)
+    img = ctx.render(11)
+    sc = c.oracle_scene()
+    P = c.oracle_params(sc)
+    P.attrMin, P.attrMax = lo, hi
+    assert max_lsb_diff(img, sc.render_rt(P, use_bvh=True)) <= 2
+    assert (img[..., :3] != 255).any(axis=2).sum() > 3000

@@ -185,10 +185,19 @@ def test_host_tracer_classes(hip_lib):
     a = grid.trace_streamlines(seeds, minimum_length=0.3)
     # the same through the oracle (AbcFlowGenerator restated; the host computes |v| as sqrt((xx + yy) + zz))
     v = lvo.generate_abc_flow(24, 20, 28)
-    mag = np.sqrt((v[..., 0] * v[..., 0] + v[..., 1] * v[..., 1]) + v[..., 2] * v[..., 2]).astype(np.float32)
     sp = tuple(float(s) for s in spacing)
-    b = lvo.trace_streamlines(v, sp, [mag], seeds, lvo.streamline_settings(minimum_length=0.3))
-    assert same(a, b) and len(a[2]) > 20
+    # AbcFlowGenerator::load adds (name order) Helicity, Velocity Magnitude, Vorticity Magnitude (GridLoader.cpp:41-183)
+    w = lvo.vorticity_field(v, sp)
+    fields = [lvo.helicity_field(v, w), lvo.vector_magnitude_field(v), lvo.vector_magnitude_field(w)]
+    b = lvo.trace_streamlines(v, sp, fields, seeds, lvo.streamline_settings(minimum_length=0.3))
+    assert same(a, b) and len(a[2]) > 20 and a[1].shape[0] == 3
+    # traceStreamribbons: the same lines + ribbon directions carried outwards from the seed and twisted by the helicity
+    for direction in ("Forward", "Backward", "Forward & Backward"):
+        for kw in (dict(), dict(use_helicity=False), dict(max_helicity_twist=1.0, initial_ribbon_direction=(1.0, 0.0, 0.0))):
+            ra = grid.trace_streamribbons(seeds, direction=direction, minimum_length=0.3, **kw)
+            rb = lvo.trace_streamribbons(v, sp, fields, seeds, lvo.streamline_settings(direction=direction, minimum_length=0.3), 0, **kw)
+            assert same(ra[:3], rb[:3]) and np.array_equal(ra[3].view(np.uint32), rb[3].view(np.uint32)), (direction, kw)
+            assert len(ra[0]) > 200
     # a second vector field / scalar field set by hand, another integrator
     vec, scalars, sp2 = swirl_grid(20, 24, 16)
     grid.set_grid_extent(20, 24, 16, *sp2).add_vector_field(vec).add_scalar_field(scalars[1], "b").add_scalar_field(scalars[0], "a")
