@@ -47,8 +47,9 @@ def main(argv=None):
         flow.set_trajectories(tr.positions, tr.attributes, tr.line_offsets)
     elif args.input == "abc_flow":
         grid = host_api.StreamlineTracingGrid(args.device).load_abc_flow(64, 64, 64, 6.0)
-        pos, att, off = grid.trace_streamlines(grid.regular_seeds(10, 10, 10), minimum_length=0.3)
-        flow.set_trajectories(host_api.normalize_positions(pos), att[0], off)
+        # streamribbons (the reference's default flow primitive): attribute 1 = Velocity Magnitude (fields in name order)
+        pos, att, off, rib = grid.trace_streamribbons(grid.regular_seeds(10, 10, 10), minimum_length=0.3)
+        flow.set_trajectories(host_api.normalize_positions(pos), att[1], off, rib)
     else:
         flow.load_file(args.input)
     mode = capi.MODE_RAY_TRACER if args.mode == "rt" else capi.MODE_PPLL
