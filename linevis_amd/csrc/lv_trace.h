@@ -515,8 +515,14 @@ __device__ __forceinline__ bool lv_intersect_elliptic_tube(const LvSceneDev& S, 
         const float rhoX = t * T.rhoR;
         const float phi = lv_atan2_det(p.z, p.y);
         const float r = lv_ell_compute_radius(radius0, radius1, phi, rhoX);
-        dTmp = sqrtf(p.y * p.y + p.z * p.z) - r;
+        const float rad = sqrtf(p.y * p.y + p.z * p.z);
+        dTmp = rad - r;
         dTmp *= 0.25f;
+        // Result-preserving early out (not in the reference, which marches all 80 steps of a miss): the distance from the tubelet
+        // axis is a convex function of the ray parameter, so once it grows (p_yz . d_yz >= 0) it keeps growing; r never exceeds
+        // the larger semi-axis; hence if rad - radius1 exceeds 4e-4 now, every later step has dTmp >= 1e-4: the loop can neither
+        // terminate (< 1e-5) nor pass the final dTmp < 1e-4 test.  8e-4 leaves 4e-4 for float32 rounding of rad and r.
+        if (p.y * dd.y + p.z * dd.z >= 0.0f && rad - radius1 > 8e-4f) return false;
         p = p + dd * dTmp;
         hitT += dTmp;
         if (dTmp < 1e-5f) break; // EPSILON_SPHERE_TRACING_TERMINATION
