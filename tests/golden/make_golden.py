@@ -313,7 +313,81 @@ def mlat_small():
     np.savez_compressed(os.path.join(HERE, "mlat_small.npz"), **out)
 
 
+RTAO_R2 = dict(ambient_occlusion_mode="RTAO (Screen Space)", ambient_occlusion_strength=1.0, ambient_occlusion_gamma=1.0,
+               ambient_occlusion_radius=0.2, ambient_occlusion_distance_based=True, ambient_occlusion_iterations=2,
+               ambient_occlusion_samples_per_frame=4)
+
+
+def round2_case(kind):
+    """The small cases of the round-2 fixtures (shared with tests/test_golden_round2.py)."""
+    from linevis_amd import camera
+    if kind == "eaw":
+        return small_case(width=64, height=48, line_width=0.03, ambient_occlusion_denoiser="EAW", eaw_denoiser_iterations=2, **RTAO_R2)
+    if kind == "svgf":
+        return small_case(width=64, height=48, n_lines=6, pts_per_line=30, line_width=0.25, ambient_occlusion_denoiser="SVGF",
+                          svgf_denoiser_iterations=3, use_jittered_primary_rays=True, **dict(RTAO_R2, ambient_occlusion_iterations=1))
+    tr = scenes.twisted_ribbons(scenes.normalize(scenes.helix_bundle(n_lines=4, points_per_line=60, seed=3, turns=2.0)), twist=8.0)
+    s = dict(use_ribbons=True, band_width=0.05, min_band_thickness=0.3, use_analytic_elliptic_tubes=(kind == "elliptic"))
+    if kind == "elliptic":
+        pts, seg, _ = lvo.build_tube_aabb_render_data_ribbons(tr.positions, tr.attributes, tr.line_offsets, 0.05, tr.ribbon_directions)
+        s.update(RTAO_R2)
+    else:   # "bands": circular tubes of a band data set
+        pts, seg, _ = lvo.build_tube_aabb_render_data(tr.positions, tr.attributes, tr.line_offsets, 0.02)
+    return Case(pts, seg, tfm.standard(), 80, 60, 0.02, **s)
+
+
+SVGF_PATH = [(0.0, 0.0, 0.8), (0.0, 0.0, 0.8), (0.01, 0.0, 0.8), (0.02, 0.005, 0.79)]
+
+
+def round2():
+    """Round-2 features: EAW- and SVGF-denoised AO images (SVGF: after every frame of a short camera path), elliptic tubes and
+    USE_BANDS frames, streamribbon directions of a small ABC-flow grid."""
+    from linevis_amd import camera
+    out = {}
+    c = round2_case("eaw")
+    img, ao = c.oracle_render(11)
+    out["eaw_frame"], out["eaw_ao_bits"] = img, f2u(ao)
+    c = round2_case("svgf")
+    sc = c.oracle_scene()
+    sv = lvo.Svgf(c.width, c.height, iterations=3)
+    for f, pos in enumerate(SVGF_PATH):
+        c.view, c.proj, c.fovy, c.near, c.far = camera.default_camera(c.width, c.height, pos)
+        P = c.oracle_params(sc)
+        ao = sv.step(lambda: sc.render_ao(P), P)
+        out["svgf_ao_bits_%d" % f] = f2u(ao)
+        out["svgf_raw_bits_%d" % f] = f2u(sv.raw)
+        out["svgf_frame_%d" % f] = sc.render_rt(P, ao=ao)
+    for kind in ("elliptic", "bands"):
+        c = round2_case(kind)
+        img, ao = c.oracle_render(11)
+        out[kind + "_frame"] = img
+        if ao is not None:
+            out[kind + "_ao_bits"] = f2u(ao)
+    c = round2_case("elliptic")
+    rng = np.random.default_rng(9)
+    cam = np.array([0.0, 0.0, 0.8], np.float32)
+    d = rng.normal(size=(2000, 3)).astype(np.float32)
+    d[:, 2] = -np.abs(d[:, 2]) * 4
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    o = np.tile(cam[None], (2000, 1))
+    t, s = c.oracle_scene().trace_rays_elliptic(o, d, 1e-4, 1000.0, 0.05, 0.3, cam)
+    out["elliptic_rays_d"], out["elliptic_rays_t_bits"], out["elliptic_rays_seg"] = d, f2u(t), s
+    n = 16
+    v = lvo.generate_abc_flow(n, n, n)
+    sp = (1.0 / (n - 1),) * 3
+    w = lvo.vorticity_field(v, sp)
+    fields = [lvo.helicity_field(v, w), lvo.vector_magnitude_field(v), lvo.vector_magnitude_field(w)]
+    seeds = np.array([[x, y, z] for z in (0.3, 0.7) for y in (0.3, 0.7) for x in (0.3, 0.7)], np.float32)
+    pos, att, off, rib = lvo.trace_streamribbons(v, sp, fields, seeds, lvo.streamline_settings(minimum_length=0.2), 0)
+    out["ribbons_seeds"], out["ribbons_pos_bits"], out["ribbons_off"], out["ribbons_dir_bits"] = seeds, f2u(pos), off, f2u(rib)
+    out["ribbons_helicity_bits"] = f2u(fields[0])
+    np.savez_compressed(os.path.join(HERE, "round2.npz"), **out)
+
+
 if __name__ == "__main__":
+    if "--only-round2" in sys.argv:
+        round2()
+        sys.exit(0)
     if "--only-mlat" in sys.argv:
         mlat_small()
         sys.exit(0)
@@ -332,6 +406,7 @@ if __name__ == "__main__":
     triangle_tubes()
     flow_small()
     mlat_small()
+    round2()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print("%-24s %8d bytes" % (f, os.path.getsize(os.path.join(HERE, f))))
