@@ -125,7 +125,7 @@ struct lv_ctx {
 
     // camera
     bool cameraSet = false;
-    float view[16], proj[16], invView[16], invProj[16];
+    float view[16] = {}, proj[16] = {}, invView[16] = {}, invProj[16] = {};
     float fovY = 0.0f, nearDist = 0.01f, farDist = 100.0f;
     uint32_t width = 0, height = 0;
     float background[4] = {1.0f, 1.0f, 1.0f, 1.0f};
@@ -142,7 +142,7 @@ struct lv_ctx {
     LvSvgfState svgf;
     LvDeviceBuffer fullFrameTile;             // one tile origin (0, 0): the SVGF chain always covers the viewport
     uint32_t aoGlobalFrameNumber = 0;         // RTAO iterations since lv_set_lines (globalFrameNumber, ...AmbientOcclusion.cpp:582)
-    float lastFrameViewProj[16];              // projection * view at the previous RTAO iteration (:456,631)
+    float lastFrameViewProj[16] = {};         // projection * view at the previous RTAO iteration (:456,631)
     bool lastFrameViewProjValid = false;
     uint32_t tilesHalo = 0;                   // halo the uploaded tilesHaloDev list was built for
     LvDeviceBuffer tilesHaloDev;              // tile origins - 1 (AO pass on dilated tiles)
