@@ -1431,12 +1431,13 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
     if (numTiles == 0 || tileW == 0 || tileH == 0) return lv_fail(ctx, LV_E_INVALID, "empty tile list");
     int rc;
     if (ctx->opt.useRibbons) {
-        // band data: the analytic paths of the ray tracer only (the triangle tubes of a band data set are the elliptic
-        // tessellation, the PPLL path its rasterised form -- neither is built)
+        // band data: the analytic geometry modes of the ray tracer; RTAO over the analytic tubelets / capsules or over the triangle
+        // tubes the host layer tessellates for the data set (elliptic for band data, rtao_geometry = triangle_tubes).  The
+        // triangle-mesh shading of bands, MLAT, the prebaker's lookup and the rasterised (PPLL) form are not built.
         if (mode != LV_RENDERING_MODE_VULKAN_RAY_TRACER || ctx->opt.rtTriangleMesh || ctx->opt.useMlat ||
-            (ctx->opt.useAmbientOcclusion && (ctx->opt.aoPrebaked || ctx->opt.aoTriangleTubes)))
+            (ctx->opt.useAmbientOcclusion && ctx->opt.aoPrebaked))
             return lv_fail(ctx, LV_E_INVALID, "use_ribbons: band data is rendered by the ray tracer's analytic geometry modes "
-                                              "only (no Triangle Mesh / MLAT / PPLL / prebaked or triangle-tube RTAO)");
+                                              "only (no Triangle Mesh / MLAT / PPLL / prebaked RTAO)");
     } else if (ctx->opt.ellipticTubes) {
         return lv_fail(ctx, LV_E_INVALID, "use_analytic_elliptic_tubes needs band data (use_ribbons)");
     }

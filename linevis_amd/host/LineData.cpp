@@ -333,6 +333,7 @@ void LineDataFlow::setTrajectoryData(const Trajectories& newTrajectories, const 
     trajectories = newTrajectories;
     ribbonsDirections = newRibbonsDirections;
     hasBandsData = !ribbonsDirections.empty(); // LineDataFlow.cpp:469
+    if (hasBandsData) tubeNumSubdivisions = std::max(tubeNumSubdivisions, 8); // :482-484
     numTotalTrajectories = trajectories.size();
     numTotalTrajectoryPoints = 0;
     for (const Trajectory& t : trajectories) numTotalTrajectoryPoints += t.positions.size();
@@ -447,8 +448,12 @@ TubeAabbRenderData LineDataFlow::getLinePassTubeAabbRenderData(bool /*isRasteriz
 // LineDataFlow.cpp:1912-2110 for flow lines with capped tubes: tessellation (Tubes.cpp) + the line-point table the
 // vertices refer to (:1996-2020, including the way lineStartIndex only advances when the trajectory index changes).
 TubeTriangleRenderData LineDataFlow::getLinePassTubeTriangleMeshRenderData(bool /*isRasterizer*/, bool /*vulkanRayTracing*/) {
-    const float lineWidth = LineRenderer::getLineWidth();
-    if (cachedTriangleDataValid && cachedTriangleLineWidth == lineWidth && cachedTriangleSubdivisions == tubeNumSubdivisions)
+    // band data: the reference is in its ribbon primitive mode then (setTrajectoryData, LineDataFlow.cpp:476-481), so its triangle
+    // mesh is the elliptic tessellation with semi-axes bandWidth / 2 * minBandThickness and bandWidth / 2 (:1949-1975)
+    const bool bands = useRibbons && hasBandsData;
+    const float lineWidth = bands ? LineRenderer::getBandWidth() * minBandThickness : LineRenderer::getLineWidth();
+    if (cachedTriangleDataValid && cachedTriangleLineWidth == lineWidth && cachedTriangleSubdivisions == tubeNumSubdivisions &&
+        cachedTriangleBands == bands && (!bands || cachedTriangleBandWidth == LineRenderer::getBandWidth()))
         return cachedTubeTriangleRenderData;
     std::vector<std::vector<vec3>> lineCentersList(trajectories.size());
     for (size_t i = 0; i < trajectories.size(); i++) lineCentersList[i] = trajectories[i].positions;
@@ -456,8 +461,16 @@ TubeTriangleRenderData LineDataFlow::getLinePassTubeTriangleMeshRenderData(bool 
     TubeTriangleRenderData data;
     std::vector<LinePointReference> linePointReferences;
     std::vector<vec3> lineTangents, lineNormals;
-    createCappedTriangleTubesRenderData(lineCentersList, lineWidth * 0.5f, tubeNumSubdivisions, data.indexBuffer,
-                                        data.vertexBuffer, linePointReferences, lineTangents, lineNormals);
+    if (bands) {
+        const float binormalRadius = LineRenderer::getBandWidth() * 0.5f;
+        const float normalRadius = binormalRadius * minBandThickness;
+        createCappedTriangleEllipticTubesRenderData(lineCentersList, ribbonsDirections, normalRadius, binormalRadius,
+                                                    tubeNumSubdivisions, data.indexBuffer, data.vertexBuffer, linePointReferences,
+                                                    lineTangents, lineNormals);
+    } else {
+        createCappedTriangleTubesRenderData(lineCentersList, lineWidth * 0.5f, tubeNumSubdivisions, data.indexBuffer,
+                                            data.vertexBuffer, linePointReferences, lineTangents, lineNormals);
+    }
 
     data.linePointDataBuffer.resize(linePointReferences.size());
     uint32_t lineStartIndex = 0, lastTrajectoryIndex = 0;
@@ -482,6 +495,8 @@ TubeTriangleRenderData LineDataFlow::getLinePassTubeTriangleMeshRenderData(bool 
     cachedTriangleDataValid = true;
     cachedTriangleLineWidth = lineWidth;
     cachedTriangleSubdivisions = tubeNumSubdivisions;
+    cachedTriangleBands = bands;
+    cachedTriangleBandWidth = LineRenderer::getBandWidth();
     return data;
 }
 

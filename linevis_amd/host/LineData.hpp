@@ -158,6 +158,8 @@ private:
     TubeTriangleRenderData cachedTubeTriangleRenderData;
     float cachedTriangleLineWidth = -1.0f;
     int cachedTriangleSubdivisions = -1;
+    bool cachedTriangleBands = false;
+    float cachedTriangleBandWidth = -1.0f;
 };
 
 } // namespace lv

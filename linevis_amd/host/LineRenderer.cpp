@@ -317,7 +317,8 @@ bool LineRenderer::uploadFrameState() {
         if (!setOption("line_width", buf)) return false;
         // band data: USE_BANDS + the "Elliptic Tubes" geometry of the ray tracer (RayTracingRenderPass::setLineData,
         // VulkanRayTracer.cpp:370-381; LineDataFlow::getVulkanShaderPreprocessorDefines, LineDataFlow.cpp:2420-2431)
-        // (rasterisers define USE_BANDS only in the band primitive modes, LineDataFlow.cpp:2423: not for the PPLL renderer's default)
+        // (for band data the reference switches to the ribbon primitive mode, LineDataFlow.cpp:476-481, and its rasterisers then draw
+        // elliptic tubes with USE_BANDS; the ray-entry PPLL of this build has no elliptic fragments and renders the data as plain tubes)
         const bool bands = !isRasterizer && lineData->getUseBands();
         const bool elliptic = bands && getUseAnalyticEllipticTubes();
         TubeAabbRenderData d = lineData->getLinePassTubeAabbRenderData(false, elliptic);

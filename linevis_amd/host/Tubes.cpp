@@ -5,6 +5,9 @@
 //   addHemisphereToMeshStart / ...Stop          src/Renderers/Tubes/CappedTriangleTubesCPU.cpp:33-211
 //   initGlobalCircleVertexPositions             src/Renderers/Tubes/Tubes.cpp:34-51
 //   insertOrientedCirclePoints                  src/Renderers/Tubes/Tubes.cpp:53-85
+//   createCappedTriangleEllipticTubesRenderDataCPU, addEllipticHemisphereToMeshStart / ...Stop (band data)
+//                                               src/Renderers/Tubes/CappedTriangleTubesCPU.cpp:387-745
+//   initGlobalEllipseVertexPositions, insertOrientedEllipsePoints     src/Renderers/Tubes/Tubes.cpp:121-170
 // The reference appends line after line to growing vectors on one thread ("seconds at 1 M segments").  Here the work is
 // split so that lines are independent: pass 1 finds every line's valid points and their frames (the normal is carried
 // from point to point, so a line is the unit of parallelism), a serial prefix sum places each line's vertex / index /
@@ -68,11 +71,44 @@ struct CapTable {
 
 } // namespace
 
-void createCappedTriangleTubesRenderData(
-        const std::vector<std::vector<vec3>>& lineCentersList, float tubeRadius, int numCircleSubdivisions,
+namespace {
+// glm::inverse(mat3) in cofactor form, then transposed: the normal matrix of an elliptic cap's frame (columns a, b, c)
+struct NormalFrame {
+    float m[3][3]; // [column][row]
+    NormalFrame(vec3 a, vec3 b, vec3 c) {
+        const float f[3][3] = {{a.x, a.y, a.z}, {b.x, b.y, b.z}, {c.x, c.y, c.z}};
+        const float oneOverDeterminant = 1.0f / (+ f[0][0] * (f[1][1] * f[2][2] - f[2][1] * f[1][2])
+                                                  - f[1][0] * (f[0][1] * f[2][2] - f[2][1] * f[0][2])
+                                                  + f[2][0] * (f[0][1] * f[1][2] - f[1][1] * f[0][2]));
+        float inv[3][3];
+        inv[0][0] = +(f[1][1] * f[2][2] - f[2][1] * f[1][2]) * oneOverDeterminant;
+        inv[1][0] = -(f[1][0] * f[2][2] - f[2][0] * f[1][2]) * oneOverDeterminant;
+        inv[2][0] = +(f[1][0] * f[2][1] - f[2][0] * f[1][1]) * oneOverDeterminant;
+        inv[0][1] = -(f[0][1] * f[2][2] - f[2][1] * f[0][2]) * oneOverDeterminant;
+        inv[1][1] = +(f[0][0] * f[2][2] - f[2][0] * f[0][2]) * oneOverDeterminant;
+        inv[2][1] = -(f[0][0] * f[2][1] - f[2][0] * f[0][1]) * oneOverDeterminant;
+        inv[0][2] = +(f[0][1] * f[1][2] - f[1][1] * f[0][2]) * oneOverDeterminant;
+        inv[1][2] = -(f[0][0] * f[1][2] - f[1][0] * f[0][2]) * oneOverDeterminant;
+        inv[2][2] = +(f[0][0] * f[1][1] - f[1][0] * f[0][1]) * oneOverDeterminant;
+        for (int col = 0; col < 3; col++)
+            for (int row = 0; row < 3; row++) m[col][row] = inv[row][col];
+    }
+    vec3 mul(vec3 v) const {
+        return vec3((m[0][0] * v.x + m[1][0] * v.y) + m[2][0] * v.z, (m[0][1] * v.x + m[1][1] * v.y) + m[2][1] * v.z,
+                    (m[0][2] * v.x + m[1][2] * v.y) + m[2][2] * v.z);
+    }
+};
+
+// rightVectors == nullptr: circular tubes of radius `normalRadius`; otherwise the elliptic tubes of a band data set (semi-axes
+// normalRadius along cross(rightVector, tangent), binormalRadius across)
+void createTubes(
+        const std::vector<std::vector<vec3>>& lineCentersList, const std::vector<std::vector<vec3>>* rightVectors,
+        float normalRadius, float binormalRadius, int numCircleSubdivisions,
         std::vector<uint32_t>& triangleIndices, std::vector<TubeTriangleVertexData>& vertexDataList,
         std::vector<LinePointReference>& linePointReferenceList, std::vector<vec3>& lineTangents,
         std::vector<vec3>& lineNormals) {
+    const bool elliptic = rightVectors != nullptr;
+    const float tubeRadius = normalRadius;
     const int N = std::max(numCircleSubdivisions, 4);
     const int nLon = N, nLat = N / 2;
     const uint32_t capVerts = uint32_t(nLon * (nLat - 1) + 1);
@@ -90,6 +126,16 @@ void createCappedTriangleTubesRenderData(
             vec3 tangent(-position.y, position.x, 0.0f);
             position = position + tangentialFactor * tangent;
             position = position * radialFactor;
+        }
+    }
+    std::vector<vec3> ellipseNormals;
+    if (elliptic) { // initGlobalEllipseVertexPositions
+        circle.clear();
+        for (int i = 0; i < N; i++) {
+            const float t = float(i) / float(N) * kTwoPi;
+            const float cosAngle = std::cos(t), sinAngle = std::sin(t);
+            circle.push_back(vec3(normalRadius * cosAngle, binormalRadius * sinAngle, 0.0f));
+            ellipseNormals.push_back(normalize(vec3(binormalRadius * cosAngle, normalRadius * sinAngle, 0.0f)));
         }
     }
     const CapTable caps(nLon, nLat);
@@ -121,6 +167,7 @@ void createCappedTriangleTubesRenderData(
                 if (length(cross(helperAxis, tangent)) < 0.01f) helperAxis = vec3(0.0f, 0.0f, 1.0f);
             }
             vec3 normal = normalize(helperAxis - dot(helperAxis, tangent) * tangent);
+            if (elliptic) normal = cross((*rightVectors)[size_t(li)][i], tangent); // :640 (not normalised)
             lastLineNormal = normal;
             f.pointIndex.push_back(uint32_t(i));
             f.tangent.push_back(tangent);
@@ -176,7 +223,8 @@ void createCappedTriangleTubesRenderData(
             for (int j = 0; j < N; j++) {
                 vec3 off = combine(circle[size_t(j)], normal, binormal, tangent);
                 vec3 pos(off.x + center.x, off.y + center.y, off.z + center.z);
-                V[bodyV + k * N + j] = vertex(pos, p0 + uint32_t(k), normalize(pos - center), float(j) / float(N) * kTwoPi);
+                const vec3 nrm = elliptic ? combine(ellipseNormals[size_t(j)], normal, binormal, tangent) : normalize(pos - center);
+                V[bodyV + k * N + j] = vertex(pos, p0 + uint32_t(k), nrm, float(j) / float(N) * kTwoPi);
             }
             linePointReferenceList[p0 + k] = LinePointReference(uint32_t(li), f.pointIndex[k]);
             lineTangents[p0 + k] = tangent;
@@ -186,14 +234,20 @@ void createCappedTriangleTubesRenderData(
         // caps: rings between the pole and the tube's first / last circle
         auto capVertices = [&](bool start, uint32_t base, vec3 center, vec3 tangent, vec3 normal, uint32_t linePoint) {
             const vec3 binormal = cross(normal, tangent);
-            const vec3 sT = tubeRadius * tangent, sN = tubeRadius * normal, sB = tubeRadius * binormal;
+            const vec3 sT = (elliptic ? std::min(normalRadius, binormalRadius) : tubeRadius) * tangent, sN = normalRadius * normal,
+                       sB = (elliptic ? binormalRadius : tubeRadius) * binormal;
+            const NormalFrame normalFrame(sN, sB, sT);
             uint32_t w = base;
             auto put = [&](int lat, int lon) {
                 const size_t k = size_t(lat - 1) * nLon + lon;
                 const vec3 pt = start ? caps.startPt[k] : caps.stopPt[k];
                 vec3 off = combine(pt, sN, sB, sT);
                 vec3 pos(off.x + center.x, off.y + center.y, off.z + center.z);
-                V[w++] = vertex(pos, linePoint | 0x80000000u, normalize(off), start ? caps.startPhi[k] : caps.stopPhi[k]);
+                if (elliptic) // normal through the inverse-transposed frame, the ZENITH angle in phi (:425-432,:513-520)
+                    V[w++] = vertex(pos, linePoint | 0x80000000u, normalize(normalFrame.mul(pt)),
+                                    kHalfPi * (1.0f - float(lat) / float(nLat)));
+                else
+                    V[w++] = vertex(pos, linePoint | 0x80000000u, normalize(off), start ? caps.startPhi[k] : caps.stopPhi[k]);
             };
             if (start) {
                 put(nLat, 0); // pole first
@@ -246,6 +300,26 @@ void createCappedTriangleTubesRenderData(
                 }
             }
     }
+}
+} // namespace
+
+void createCappedTriangleTubesRenderData(
+        const std::vector<std::vector<vec3>>& lineCentersList, float tubeRadius, int numCircleSubdivisions,
+        std::vector<uint32_t>& triangleIndices, std::vector<TubeTriangleVertexData>& vertexDataList,
+        std::vector<LinePointReference>& linePointReferenceList, std::vector<vec3>& lineTangents,
+        std::vector<vec3>& lineNormals) {
+    createTubes(lineCentersList, nullptr, tubeRadius, tubeRadius, numCircleSubdivisions, triangleIndices, vertexDataList,
+                linePointReferenceList, lineTangents, lineNormals);
+}
+
+void createCappedTriangleEllipticTubesRenderData(
+        const std::vector<std::vector<vec3>>& lineCentersList, const std::vector<std::vector<vec3>>& lineRightVectorsList,
+        float tubeNormalRadius, float tubeBinormalRadius, int numEllipseSubdivisions,
+        std::vector<uint32_t>& triangleIndices, std::vector<TubeTriangleVertexData>& vertexDataList,
+        std::vector<LinePointReference>& linePointReferenceList, std::vector<vec3>& lineTangents,
+        std::vector<vec3>& lineNormals) {
+    createTubes(lineCentersList, &lineRightVectorsList, tubeNormalRadius, tubeBinormalRadius, numEllipseSubdivisions,
+                triangleIndices, vertexDataList, linePointReferenceList, lineTangents, lineNormals);
 }
 
 } // namespace lv

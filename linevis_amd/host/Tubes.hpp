@@ -28,4 +28,13 @@ void createCappedTriangleTubesRenderData(
         std::vector<LinePointReference>& linePointReferenceList, std::vector<vec3>& lineTangents,
         std::vector<vec3>& lineNormals);
 
+/// The elliptic tubes of a band data set (createCappedTriangleEllipticTubesRenderDataCPU, tubeClosed = false): line normal =
+/// cross(right vector, tangent), semi-axes tubeNormalRadius / tubeBinormalRadius.
+void createCappedTriangleEllipticTubesRenderData(
+        const std::vector<std::vector<vec3>>& lineCentersList, const std::vector<std::vector<vec3>>& lineRightVectorsList,
+        float tubeNormalRadius, float tubeBinormalRadius, int numEllipseSubdivisions,
+        std::vector<uint32_t>& triangleIndices, std::vector<TubeTriangleVertexData>& vertexDataList,
+        std::vector<LinePointReference>& linePointReferenceList, std::vector<vec3>& lineTangents,
+        std::vector<vec3>& lineNormals);
+
 } // namespace lv

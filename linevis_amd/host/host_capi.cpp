@@ -137,6 +137,21 @@ void lvh_flow_build_triangle_data(void* hp, float lineWidth, uint32_t numSubdivi
     *outNumVertices = h->lastTriangleData.vertexBuffer.size();
     *outNumPoints = h->lastTriangleData.linePointDataBuffer.size();
 }
+/// the same for a band data set: the elliptic tessellation at the given band width / minimum band thickness
+void lvh_flow_build_triangle_data_bands(void* hp, float bandWidth, float minBandThickness, uint32_t numSubdivisions,
+                                        uint64_t* outNumIndices, uint64_t* outNumVertices, uint64_t* outNumPoints) {
+    FlowHandle* h = static_cast<FlowHandle*>(hp);
+    LineRenderer::setBandWidth(bandWidth);
+    SettingsMap m;
+    m.addKeyValue("tube_num_subdivisions", int(numSubdivisions));
+    m.addKeyValue("min_band_thickness", minBandThickness);
+    m.addKeyValue("use_ribbons", true);
+    h->data->setNewSettings(m);
+    h->lastTriangleData = h->flow()->getLinePassTubeTriangleMeshRenderData(false, true);
+    *outNumIndices = h->lastTriangleData.indexBuffer.size();
+    *outNumVertices = h->lastTriangleData.vertexBuffer.size();
+    *outNumPoints = h->lastTriangleData.linePointDataBuffer.size();
+}
 void lvh_flow_copy_triangle_data(void* hp, uint32_t* indices, lv_tube_vertex* vertices, lv_line_point* points) {
     const TubeTriangleRenderData& d = static_cast<FlowHandle*>(hp)->lastTriangleData;
     if (indices) memcpy(indices, d.indexBuffer.data(), d.indexBuffer.size() * 4);

@@ -43,6 +43,7 @@ def load():
         "lvh_flow_copy_render_data": (None, [vp, vp, vp, vp]),
         "lvh_flow_build_triangle_data": (None, [vp, f32, u32, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]),
         "lvh_flow_copy_triangle_data": (None, [vp, vp, vp, vp]),
+        "lvh_flow_build_triangle_data_bands": (None, [vp, f32, f32, u32, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]),
         "lvh_flow_ao_parametrization": (None, [vp, f32, vp, vp, C.POINTER(u64), C.POINTER(u64)]),
         "lvh_grid_create": (vp, [i32]),
         "lvh_grid_destroy": (None, [vp]),
@@ -200,6 +201,21 @@ class LineDataFlow:
         pts = np.zeros(npt.value, dtype=capi.LINE_POINT_DTYPE)
         self.L.lvh_flow_copy_triangle_data(self.h, _p(idx), _p(verts), _p(pts))
         return idx.reshape(-1, 3), verts, pts
+
+
+def _tube_triangle_render_data_bands(self, band_width, min_band_thickness=0.15, num_subdivisions=8):
+    """getLinePassTubeTriangleMeshRenderData of a band data set: the elliptic triangle tubes."""
+    ni, nv, npt = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    self.L.lvh_flow_build_triangle_data_bands(self.h, band_width, min_band_thickness, int(num_subdivisions), C.byref(ni),
+                                              C.byref(nv), C.byref(npt))
+    idx = np.zeros(ni.value, dtype=np.uint32)
+    verts = np.zeros(nv.value, dtype=capi.TUBE_VERTEX_DTYPE)
+    pts = np.zeros(npt.value, dtype=capi.LINE_POINT_DTYPE)
+    self.L.lvh_flow_copy_triangle_data(self.h, _p(idx), _p(verts), _p(pts))
+    return idx.reshape(-1, 3), verts, pts
+
+
+LineDataFlow.tube_triangle_render_data_bands = _tube_triangle_render_data_bands
 
 
 def _flow_ao_parametrization(self, expected_param_segment_length=0.001):

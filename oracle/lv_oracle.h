@@ -220,6 +220,13 @@ typedef struct {
     float phi;
 } lvo_tube_vertex;
 /* Capped N-gon tubes of all lines (open tubes, hemisphere caps).  Output pointers may be NULL to query the sizes. */
+/* createCappedTriangleEllipticTubesRenderDataCPU (CappedTriangleTubesCPU.cpp:387-745) + the line-point table: the triangle
+ * tubes of a band data set (ribbonDirections: 3 floats per input point). */
+void lvo_build_tube_triangle_render_data_ribbons(
+        const float* positions, const float* attributes, const uint32_t* lineOffsets, uint32_t nLines,
+        const float* ribbonDirections, float bandWidth, float minBandThickness, uint32_t tubeNumSubdivisions,
+        uint32_t* outIndices, uint64_t* outNumIndices, lvo_tube_vertex* outVerts, uint64_t* outNumVerts,
+        lvo_line_point* outPoints, uint64_t* outNumPoints);
 void lvo_build_tube_triangle_render_data(
         const float* positions, const float* attributes, const uint32_t* lineOffsets, uint32_t nLines,
         float lineWidth, uint32_t tubeNumSubdivisions,

@@ -263,9 +263,213 @@ int32_t buildTriRange(lvo_tri_scene& sc, const std::vector<uint64_t>& keys, cons
     return idx;
 }
 
+// ---------------------------------------------------------------- elliptic tubes of band data
+// glm::inverse(mat3) (func_matrix.inl, cofactor form) followed by transpose: the normal matrix of the cap frame
+struct Mat3 { float m[3][3]; }; // m[column][row]
+inline Mat3 inverseTranspose(const Mat3& a) {
+    const float (*m)[3] = a.m;
+    const float oneOverDeterminant = 1.0f / (+ m[0][0] * (m[1][1] * m[2][2] - m[2][1] * m[1][2])
+                                              - m[1][0] * (m[0][1] * m[2][2] - m[2][1] * m[0][2])
+                                              + m[2][0] * (m[0][1] * m[1][2] - m[1][1] * m[0][2]));
+    Mat3 inv;
+    inv.m[0][0] = +(m[1][1] * m[2][2] - m[2][1] * m[1][2]) * oneOverDeterminant;
+    inv.m[1][0] = -(m[1][0] * m[2][2] - m[2][0] * m[1][2]) * oneOverDeterminant;
+    inv.m[2][0] = +(m[1][0] * m[2][1] - m[2][0] * m[1][1]) * oneOverDeterminant;
+    inv.m[0][1] = -(m[0][1] * m[2][2] - m[2][1] * m[0][2]) * oneOverDeterminant;
+    inv.m[1][1] = +(m[0][0] * m[2][2] - m[2][0] * m[0][2]) * oneOverDeterminant;
+    inv.m[2][1] = -(m[0][0] * m[2][1] - m[2][0] * m[0][1]) * oneOverDeterminant;
+    inv.m[0][2] = +(m[0][1] * m[1][2] - m[1][1] * m[0][2]) * oneOverDeterminant;
+    inv.m[1][2] = -(m[0][0] * m[1][2] - m[1][0] * m[0][2]) * oneOverDeterminant;
+    inv.m[2][2] = +(m[0][0] * m[1][1] - m[1][0] * m[0][1]) * oneOverDeterminant;
+    Mat3 t;
+    for (int c = 0; c < 3; c++)
+        for (int r = 0; r < 3; r++) t.m[c][r] = inv.m[r][c];
+    return t;
+}
+inline V3 mulMat3(const Mat3& a, V3 v) { // column 0 * v.x + column 1 * v.y + column 2 * v.z
+    return v3((a.m[0][0] * v.x + a.m[1][0] * v.y) + a.m[2][0] * v.z, (a.m[0][1] * v.x + a.m[1][1] * v.y) + a.m[2][1] * v.z,
+              (a.m[0][2] * v.x + a.m[1][2] * v.y) + a.m[2][2] * v.z);
+}
+
+// addEllipticHemisphereToMeshStart / ...Stop, CappedTriangleTubesCPU.cpp:387-568: as the circular caps with the frame scaled by
+// (normal radius, binormal radius, min of both), normals through the inverse-transposed frame, the ZENITH angle stored in phi
+void ellipticHemisphere(bool start, V3 center, V3 tangent, V3 normal, uint32_t indexOffset, uint32_t vertexOffsetCap,
+                        uint32_t triOffsetCap, uint32_t linePointIndex, float normalRadius, float binormalRadius, int nLon,
+                        int nLat, Mesh& m) {
+    const V3 binormal = cross(normal, tangent);
+    const V3 sT = std::min(normalRadius, binormalRadius) * tangent, sN = normalRadius * normal, sB = binormalRadius * binormal;
+    Mat3 frame;
+    frame.m[0][0] = sN.x; frame.m[0][1] = sN.y; frame.m[0][2] = sN.z;
+    frame.m[1][0] = sB.x; frame.m[1][1] = sB.y; frame.m[1][2] = sB.z;
+    frame.m[2][0] = sT.x; frame.m[2][1] = sT.y; frame.m[2][2] = sT.z;
+    const Mat3 normalFrame = inverseTranspose(frame);
+    uint32_t vo = vertexOffsetCap;
+    auto ringVertex = [&](int lat, int lon) {
+        const float phi = kHalfPi * (1.0f - float(lat) / float(nLat));
+        const float theta = (start ? kTwoPi : -kTwoPi) * float(lon) / float(nLon);
+        const V3 pt = v3(cosf(theta) * sinf(phi), sinf(theta) * sinf(phi), cosf(phi));
+        const V3 off = frameCombine(pt, sN, sB, sT);
+        const V3 pos = v3(off.x + center.x, off.y + center.y, off.z + center.z);
+        m.verts[vo++] = mkVertex(pos, linePointIndex | 0x80000000u, normalize(mulMat3(normalFrame, pt)), phi);
+    };
+    if (start) {
+        for (int lat = nLat; lat >= 1; lat--)
+            for (int lon = 0; lon < nLon; lon++) { ringVertex(lat, lon); if (lat == nLat) break; }
+        uint32_t ti = triOffsetCap, base = vertexOffsetCap + 1;
+        for (int lat = 0; lat < nLat; lat++)
+            for (int lon = 0; lon < nLon; lon++) {
+                uint32_t l0 = uint32_t(lon % nLon), l1 = uint32_t((lon + 1) % nLon);
+                if (lat > 0) {
+                    uint32_t r0 = uint32_t(lat - 1) * nLon, r1 = uint32_t(lat) * nLon;
+                    m.idx[ti++] = base + l0 + r0; m.idx[ti++] = base + l1 + r0; m.idx[ti++] = base + l0 + r1;
+                    m.idx[ti++] = base + l1 + r0; m.idx[ti++] = base + l1 + r1; m.idx[ti++] = base + l0 + r1;
+                } else {
+                    m.idx[ti++] = vertexOffsetCap; m.idx[ti++] = base + l1; m.idx[ti++] = base + l0;
+                }
+            }
+    } else {
+        uint32_t ringBase = indexOffset + (vertexOffsetCap - indexOffset - uint32_t(nLon));
+        for (int lat = 1; lat <= nLat; lat++)
+            for (int lon = 0; lon < nLon; lon++) { ringVertex(lat, lon); if (lat == nLat) break; }
+        uint32_t ti = triOffsetCap;
+        for (int lat = 0; lat < nLat; lat++)
+            for (int lon = 0; lon < nLon; lon++) {
+                uint32_t l0 = uint32_t(lon % nLon), l1 = uint32_t((lon + 1) % nLon);
+                uint32_t r0 = uint32_t(lat) * nLon, r1 = uint32_t(lat + 1) * nLon;
+                if (lat < nLat - 1) {
+                    m.idx[ti++] = ringBase + l0 + r0; m.idx[ti++] = ringBase + l1 + r0; m.idx[ti++] = ringBase + l0 + r1;
+                    m.idx[ti++] = ringBase + l1 + r0; m.idx[ti++] = ringBase + l1 + r1; m.idx[ti++] = ringBase + l0 + r1;
+                } else {
+                    m.idx[ti++] = ringBase + l0 + r0; m.idx[ti++] = ringBase + l1 + r0; m.idx[ti++] = ringBase + 0 + r1;
+                }
+            }
+    }
+}
+
+// createCappedTriangleEllipticTubesRenderDataCPU (open tubes), CappedTriangleTubesCPU.cpp:570-745, with
+// initGlobalEllipseVertexPositions / insertOrientedEllipsePoints (Tubes.cpp:121-170) and the line-point table of
+// getLinePassTubeTriangleMeshRenderDataPayload (LineDataFlow.cpp:1949-2020): what the reference's triangle-mesh consumers
+// (RTAO, "Triangle Mesh" geometry mode) get for a band data set.
+void tessellateElliptic(const float* positions, const float* attributes, const uint32_t* lineOffsets, uint32_t nLines,
+                        const float* ribbonDirections, float normalRadius, float binormalRadius, int numEllipseSubdivisions,
+                        Mesh& m) {
+    const int N = std::max(numEllipseSubdivisions, 4);
+    std::vector<V3> ellipsePos, ellipseNrm;
+    for (int i = 0; i < N; i++) {
+        const float t = float(i) / float(N) * kTwoPi;
+        const float cosAngle = cosf(t), sinAngle = sinf(t);
+        ellipsePos.push_back(v3(normalRadius * cosAngle, binormalRadius * sinAngle, 0.0f));
+        ellipseNrm.push_back(normalize(v3(binormalRadius * cosAngle, normalRadius * sinAngle, 0.0f)));
+    }
+    const int nLon = N, nLat = N / 2;
+    const uint32_t numCapVertices = uint32_t(nLon * (nLat - 1) + 1);
+    const uint32_t numCapIndices = uint32_t(nLon * (nLat - 1) * 6 + nLon * 3);
+    std::vector<V3> lineTangents, lineNormals;
+    std::vector<uint32_t> refLine, refPoint;
+    for (uint32_t lineId = 0; lineId < nLines; lineId++) {
+        const float* C = positions + 3 * size_t(lineOffsets[lineId]);
+        const float* R = ribbonDirections + 3 * size_t(lineOffsets[lineId]);
+        const size_t n = lineOffsets[lineId + 1] - lineOffsets[lineId];
+        const uint32_t lineIndexOffset = uint32_t(lineTangents.size());
+        if (n < 2) continue;
+        const uint32_t indexOffsetCapStart = uint32_t(m.verts.size());
+        const uint32_t triOffsetCapStart = uint32_t(m.idx.size());
+        m.verts.resize(m.verts.size() + numCapVertices, lvo_tube_vertex{});
+        m.idx.resize(m.idx.size() + numCapIndices, 0u);
+        const uint32_t indexOffset = uint32_t(m.verts.size());
+        int firstIdx = int(n) - 2, lastIdx = 1, numValid = 0;
+        for (size_t i = 0; i < n; i++) {
+            V3 tangent;
+            if (i == 0) tangent = ld3(C + 3 * (i + 1)) - ld3(C + 3 * i);
+            else if (i == n - 1) tangent = ld3(C + 3 * i) - ld3(C + 3 * (i - 1));
+            else tangent = ld3(C + 3 * ((i + 1) % n)) - ld3(C + 3 * ((i + n - 1) % n));
+            if (length(tangent) < 0.0001f) continue;
+            firstIdx = std::min(int(i), firstIdx);
+            lastIdx = std::max(int(i), lastIdx);
+            tangent = normalize(tangent);
+            const V3 normal = cross(ld3(R + 3 * i), tangent);
+            // insertOrientedEllipsePoints
+            const V3 center = ld3(C + 3 * i);
+            const V3 binormal = cross(tangent, normal);
+            const uint32_t linePointIndex = uint32_t(refLine.size());
+            for (int k = 0; k < N; k++) {
+                const V3 off = frameCombine(ellipsePos[size_t(k)], normal, binormal, tangent);
+                const V3 pos = v3(off.x + center.x, off.y + center.y, off.z + center.z);
+                m.verts.push_back(mkVertex(pos, linePointIndex, frameCombine(ellipseNrm[size_t(k)], normal, binormal, tangent),
+                                           float(k) / float(N) * kTwoPi));
+            }
+            lineTangents.push_back(tangent);
+            lineNormals.push_back(normal);
+            refLine.push_back(lineId);
+            refPoint.push_back(uint32_t(i));
+            numValid++;
+        }
+        if (numValid == 1) {
+            m.verts.resize(indexOffsetCapStart);
+            lineTangents.pop_back(); lineNormals.pop_back(); refLine.pop_back(); refPoint.pop_back();
+        }
+        if (numValid <= 1) continue;
+        for (int i = 0; i < numValid - 1; i++)
+            for (int j = 0; j < N; j++) {
+                uint32_t a = indexOffset + uint32_t(i * N + j), b = indexOffset + uint32_t(i * N + (j + 1) % N);
+                uint32_t c = indexOffset + uint32_t(((i + 1) % numValid) * N + (j + 1) % N);
+                uint32_t d = indexOffset + uint32_t(((i + 1) % numValid) * N + j);
+                m.idx.push_back(a); m.idx.push_back(b); m.idx.push_back(c);
+                m.idx.push_back(a); m.idx.push_back(c); m.idx.push_back(d);
+            }
+        const uint32_t indexOffsetCapEnd = uint32_t(m.verts.size());
+        const uint32_t triOffsetCapEnd = uint32_t(m.idx.size());
+        m.verts.resize(m.verts.size() + numCapVertices, lvo_tube_vertex{});
+        m.idx.resize(m.idx.size() + numCapIndices, 0u);
+        const V3 center0 = ld3(C + 3 * firstIdx);
+        const V3 tangent0 = normalize(ld3(C + 3 * firstIdx) - ld3(C + 3 * (firstIdx + 1)));
+        const V3 normal0 = lineNormals[lineIndexOffset];
+        const V3 center1 = ld3(C + 3 * lastIdx);
+        const V3 tangent1 = normalize(ld3(C + 3 * lastIdx) - ld3(C + 3 * (lastIdx - 1)));
+        const V3 normal1 = lineNormals[lineIndexOffset + uint32_t(numValid) - 1];
+        ellipticHemisphere(true, center0, tangent0, normal0, indexOffset, indexOffsetCapStart, triOffsetCapStart, lineIndexOffset,
+                           normalRadius, binormalRadius, nLon, nLat, m);
+        ellipticHemisphere(false, center1, tangent1, normal1, indexOffset, indexOffsetCapEnd, triOffsetCapEnd,
+                           uint32_t(lineTangents.size() - 1), normalRadius, binormalRadius, nLon, nLat, m);
+    }
+    m.pts.resize(refLine.size());
+    uint32_t lineStartIndex = 0, lastTrajectoryIndex = 0;
+    for (size_t i = 0; i < refLine.size(); i++) {
+        lvo_line_point lp;
+        memset(&lp, 0, sizeof(lp));
+        size_t src = size_t(lineOffsets[refLine[i]]) + refPoint[i];
+        for (int k = 0; k < 3; k++) lp.linePosition[k] = positions[3 * src + k];
+        lp.lineAttribute = attributes[src];
+        lp.lineTangent[0] = lineTangents[i].x; lp.lineTangent[1] = lineTangents[i].y; lp.lineTangent[2] = lineTangents[i].z;
+        lp.lineNormal[0] = lineNormals[i].x; lp.lineNormal[1] = lineNormals[i].y; lp.lineNormal[2] = lineNormals[i].z;
+        if (lastTrajectoryIndex != refLine[i]) { lastTrajectoryIndex = refLine[i]; lineStartIndex = uint32_t(i); }
+        lp.lineStartIndex = lineStartIndex;
+        m.pts[i] = lp;
+    }
+}
+
 } // namespace
 
 extern "C" {
+
+// band data: binormalRadius = bandWidth / 2, normalRadius = binormalRadius * minBandThickness (LineDataFlow.cpp:1959-1960)
+void lvo_build_tube_triangle_render_data_ribbons(
+        const float* positions, const float* attributes, const uint32_t* lineOffsets, uint32_t nLines,
+        const float* ribbonDirections, float bandWidth, float minBandThickness, uint32_t tubeNumSubdivisions,
+        uint32_t* outIndices, uint64_t* outNumIndices, lvo_tube_vertex* outVerts, uint64_t* outNumVerts,
+        lvo_line_point* outPoints, uint64_t* outNumPoints) {
+    Mesh m;
+    const float binormalRadius = bandWidth * 0.5f;
+    const float normalRadius = binormalRadius * minBandThickness;
+    tessellateElliptic(positions, attributes, lineOffsets, nLines, ribbonDirections, normalRadius, binormalRadius,
+                       int(tubeNumSubdivisions), m);
+    if (outIndices) memcpy(outIndices, m.idx.data(), m.idx.size() * sizeof(uint32_t));
+    if (outVerts) memcpy(outVerts, m.verts.data(), m.verts.size() * sizeof(lvo_tube_vertex));
+    if (outPoints) memcpy(outPoints, m.pts.data(), m.pts.size() * sizeof(lvo_line_point));
+    *outNumIndices = m.idx.size();
+    *outNumVerts = m.verts.size();
+    *outNumPoints = m.pts.size();
+}
 
 void lvo_build_tube_triangle_render_data(
         const float* positions, const float* attributes, const uint32_t* lineOffsets, uint32_t nLines, float lineWidth,

@@ -151,6 +151,7 @@ def lib():
     L.lvo_render_ppll.argtypes = [vp, C.POINTER(Params), i32, vp, u32, u32, u32, u32, vp, C.POINTER(Stats)]
     u64p = C.POINTER(C.c_uint64)
     L.lvo_build_tube_triangle_render_data.argtypes = [vp, vp, vp, u32, f32, u32, vp, u64p, vp, u64p, vp, u64p]
+    L.lvo_build_tube_triangle_render_data_ribbons.argtypes = [vp, vp, vp, u32, vp, f32, f32, u32, vp, u64p, vp, u64p, vp, u64p]
     L.lvo_tri_scene_create.restype = vp
     L.lvo_tri_scene_create.argtypes = [vp, u32, vp, u32, vp, u32, f32]
     L.lvo_tri_scene_destroy.argtypes = [vp]
@@ -271,6 +272,24 @@ def build_tube_triangle_render_data(positions, attributes, line_offsets, line_wi
     verts = np.zeros(max(nv.value, 1), dtype=TUBE_VERTEX_DTYPE)
     pts = np.zeros(max(npt.value, 1), dtype=LINE_POINT_DTYPE)
     lib().lvo_build_tube_triangle_render_data(*args, _p(idx), C.byref(ni), _p(verts), C.byref(nv), _p(pts), C.byref(npt))
+    return idx[:ni.value].reshape(-1, 3).copy(), verts[:nv.value].copy(), pts[:npt.value].copy()
+
+
+def build_tube_triangle_render_data_ribbons(positions, attributes, line_offsets, ribbon_directions, band_width,
+                                            min_band_thickness=0.15, num_subdivisions=8):
+    """The elliptic triangle tubes of a band data set (createCappedTriangleEllipticTubesRenderDataCPU): returns
+    (triangle_indices[T,3], vertices[32B], line_points[48B])."""
+    pos = np.ascontiguousarray(positions, dtype=np.float32)
+    att = np.ascontiguousarray(attributes, dtype=np.float32)
+    off = np.ascontiguousarray(line_offsets, dtype=np.uint32)
+    rib = np.ascontiguousarray(ribbon_directions, dtype=np.float32)
+    ni, nv, npt = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    args = (_p(pos), _p(att), _p(off), len(off) - 1, _p(rib), float(band_width), float(min_band_thickness), int(num_subdivisions))
+    lib().lvo_build_tube_triangle_render_data_ribbons(*args, None, C.byref(ni), None, C.byref(nv), None, C.byref(npt))
+    idx = np.zeros(max(ni.value, 1), dtype=np.uint32)
+    verts = np.zeros(max(nv.value, 1), dtype=TUBE_VERTEX_DTYPE)
+    pts = np.zeros(max(npt.value, 1), dtype=LINE_POINT_DTYPE)
+    lib().lvo_build_tube_triangle_render_data_ribbons(*args, _p(idx), C.byref(ni), _p(verts), C.byref(nv), _p(pts), C.byref(npt))
     return idx[:ni.value].reshape(-1, 3).copy(), verts[:nv.value].copy(), pts[:npt.value].copy()
 
 

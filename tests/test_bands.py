@@ -188,3 +188,34 @@ def test_elliptic_bvh_equals_brute_force_for_near_axis_parallel_rays():
     b = sc.trace_rays_elliptic(o, d, 1e-4, 1000.0, bw, mbt, cam, use_bvh=True)
     assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32)) and np.array_equal(a[1], b[1])
     assert (a[1] != 0xFFFFFFFF).sum() > 2000
+
+
+def test_elliptic_triangle_tubes_host_equals_oracle_and_lie_on_the_ellipse():
+    """createCappedTriangleEllipticTubesRenderDataCPU: what the reference's triangle-mesh consumers (RTAO) get for band data.  The
+    host's two-pass OpenMP tessellator against the oracle's append-as-you-go restatement, byte for byte; body vertices on the
+    ellipse around their line point, caps inside the smaller semi-axis along the tangent, all indices valid."""
+    tr = ribbon_scene(n_lines=5, pts=40)
+    fl = host_api.LineDataFlow().set_trajectories(tr.positions, tr.attributes, tr.line_offsets, tr.ribbon_directions)
+    for bw, mbt, n in ((0.05, 0.3, 8), (0.01, 0.15, 10), (0.03, 1.0, 5)):
+        a = fl.tube_triangle_render_data_bands(bw, mbt, n)
+        b = lvo.build_tube_triangle_render_data_ribbons(tr.positions, tr.attributes, tr.line_offsets, tr.ribbon_directions, bw, mbt, n)
+        assert all(np.array_equal(np.ascontiguousarray(x).view(np.uint8), np.ascontiguousarray(y).view(np.uint8)) for x, y in zip(a, b))
+        idx, verts, pts = a
+        assert idx.max() == len(verts) - 1 and len(pts) == tr.num_points
+        lpi = verts["vertexLinePointIndex"] & 0x7FFFFFFF
+        body = (verts["vertexLinePointIndex"] >> 31) == 0
+        d = (verts["vertexPosition"] - pts["linePosition"][lpi]).astype(np.float64)
+        nrm, tan = pts["lineNormal"][lpi].astype(np.float64), pts["lineTangent"][lpi].astype(np.float64)
+        bi = np.cross(tan, nrm)
+        rn, rb = bw / 2 * mbt, bw / 2
+        assert np.abs(((d * nrm).sum(1) / rn) ** 2 + ((d * bi).sum(1) / rb) ** 2 - 1)[body].max() < 1e-3
+        assert np.abs((d * tan).sum(1))[body].max() < 1e-6
+        assert np.linalg.norm(d[~body], axis=1).max() <= rb * 1.001
+        assert np.abs(np.linalg.norm(verts["vertexNormal"], axis=1) - 1).max() < 1e-3
+        # outward normals: the vertex normal points away from the line point
+        assert ((verts["vertexNormal"].astype(np.float64) * d).sum(1) > 0).all()
+    # without band data (or with use_ribbons off) the same accessor gives the circular tubes
+    fl2 = host_api.LineDataFlow().set_trajectories(tr.positions, tr.attributes, tr.line_offsets)
+    c = fl2.tube_triangle_render_data(0.02, 6)
+    ref = lvo.build_tube_triangle_render_data(tr.positions, tr.attributes, tr.line_offsets, 0.02, 6)
+    assert all(np.array_equal(np.ascontiguousarray(x).view(np.uint8), np.ascontiguousarray(y).view(np.uint8)) for x, y in zip(c, ref))

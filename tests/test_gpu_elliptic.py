@@ -147,8 +147,8 @@ def test_band_data_through_the_plugin_surface(hip_lib, tmp_path):
 
 @pytest.mark.gpu
 def test_ppll_plugin_ignores_band_data(hip_lib):
-    """The PPLL renderer is a rasteriser: USE_BANDS is not defined for it outside the band primitive modes
-    (LineDataFlow.cpp:2423), so a band data set renders as plain tubes there."""
+    """The reference's rasterisers draw band data as elliptic tubes (ribbon primitive mode, LineDataFlow.cpp:476-481); the ray-entry
+    PPLL of this build has no elliptic fragments: the plugin renders a band data set as plain tubes instead of failing."""
     from linevis_amd import host_api
     tr = ribbon_scene()
     frames = []
@@ -190,3 +190,36 @@ def test_streamribbons_from_the_tracer_to_the_renderer(hip_lib):
     P.attrMin, P.attrMax = lo, hi
     assert max_lsb_diff(img, sc.render_rt(P, use_bvh=True)) <= 2
     assert (img[..., :3] != 255).any(axis=2).sum() > 3000
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("elliptic", [True, False])
+def test_band_data_rtao_over_the_elliptic_triangle_tubes(hip_lib, elliptic):
+    """The reference's RTAO geometry for band data: the elliptic triangle tessellation (createCappedTriangleEllipticTubesRenderDataCPU;
+    the data set is in its ribbon primitive mode).  rtao_geometry = triangle_tubes with the mesh LineDataFlow tessellates: AO image bit
+    for bit against the oracle's triangle RTAO on the same mesh, colour pass (elliptic tubelets or circular tubes) within 2 LSB."""
+    from linevis_amd import host_api
+    tr = ribbon_scene()
+    flow = host_api.LineDataFlow().set_trajectories(tr.positions, tr.attributes, tr.line_offsets, tr.ribbon_directions)
+    mesh = flow.tube_triangle_render_data_bands(0.05, 0.3, 8)
+    ref_mesh = lvo.build_tube_triangle_render_data_ribbons(tr.positions, tr.attributes, tr.line_offsets, tr.ribbon_directions, 0.05, 0.3, 8)
+    assert all(np.array_equal(np.ascontiguousarray(a).view(np.uint8), np.ascontiguousarray(b).view(np.uint8)) for a, b in zip(mesh, ref_mesh))
+    c = band_case(elliptic=elliptic, tube_num_subdivisions=8, rtao_geometry="triangle_tubes", **RTAO)
+    ctx = c.hip_context()
+    ctx.set_tube_triangle_mesh(*mesh)
+    img = ctx.render(11)
+    ao = ctx.get_ao()
+    sc = c.oracle_scene()
+    P = c.oracle_params(sc)
+    tsc = lvo.TriScene(mesh[0], mesh[1], mesh[2], c.line_width)   # the pad of the triangle test follows line_width on both sides
+    ao_ref = c.oracle_ao(sc, P, render_ao=lambda t: tsc.render_ao(P, tile=t))
+    assert np.array_equal(ao.view(np.uint32), ao_ref.view(np.uint32)) and (ao < 0.9).sum() > 500
+    assert max_lsb_diff(img, sc.render_rt(P, ao=ao_ref)) <= 2
+    # the analytic-tubelet AO of the same frame differs per pixel but not systematically
+    c2 = band_case(elliptic=True, tube_num_subdivisions=8, **RTAO)
+    ctx2 = c2.hip_context()
+    ctx2.render(11)
+    ao2 = ctx2.get_ao()
+    both = (ao < 1.0) & (ao2 < 1.0)
+    if elliptic:
+        assert abs(float(ao[both].mean()) - float(ao2[both].mean())) < 0.05
