@@ -65,7 +65,7 @@ __global__ __launch_bounds__(LV_BLOCK) void k_render_rt(const LvUniforms U, cons
                 f4 hc;
                 float payloadHitT;
                 if (h.found) {
-                    hc = PRIM == LV_PRIM_TRIANGLE   ? lv_shade_hit_triangle(S, U, aoTexel, o, d, h.leaf, payloadHitT)
+                    hc = PRIM == LV_PRIM_TRIANGLE   ? lv_shade_hit_triangle<BANDS>(S, U, aoTexel, o, d, h.leaf, payloadHitT)
                          : PRIM == LV_PRIM_ELLIPTIC ? lv_shade_hit_elliptic(S, U, aoTexel, o, d, h, payloadHitT)
                                                     : lv_shade_hit<BANDS>(S, U, aoTexel, o, d, h, payloadHitT);
                     if (STATS) cnt.hits++;
@@ -1431,13 +1431,14 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
     if (numTiles == 0 || tileW == 0 || tileH == 0) return lv_fail(ctx, LV_E_INVALID, "empty tile list");
     int rc;
     if (ctx->opt.useRibbons) {
-        // band data: the analytic geometry modes of the ray tracer; RTAO over the analytic tubelets / capsules or over the triangle
-        // tubes the host layer tessellates for the data set (elliptic for band data, rtao_geometry = triangle_tubes).  The
-        // triangle-mesh shading of bands, MLAT, the prebaker's lookup and the rasterised (PPLL) form are not built.
-        if (mode != LV_RENDERING_MODE_VULKAN_RAY_TRACER || ctx->opt.rtTriangleMesh || ctx->opt.useMlat ||
-            (ctx->opt.useAmbientOcclusion && ctx->opt.aoPrebaked))
-            return lv_fail(ctx, LV_E_INVALID, "use_ribbons: band data is rendered by the ray tracer's analytic geometry modes "
-                                              "only (no Triangle Mesh / MLAT / PPLL / prebaked RTAO)");
+        // band data: the closest-hit paths of the ray tracer (analytic geometry modes, or "Triangle Mesh" on the elliptic triangle
+        // tubes the host layer tessellates for the data set); RTAO over the analytic tubelets / capsules or over those triangle
+        // tubes (rtao_geometry = triangle_tubes).  MLAT, the prebaker's lookup and the rasterised (PPLL) form are not built.
+        if (mode != LV_RENDERING_MODE_VULKAN_RAY_TRACER || ctx->opt.useMlat || (ctx->opt.useAmbientOcclusion && ctx->opt.aoPrebaked))
+            return lv_fail(ctx, LV_E_INVALID, "use_ribbons: band data is rendered by the ray tracer's closest-hit paths only "
+                                              "(no MLAT / PPLL / prebaked RTAO)");
+        if (ctx->opt.rtTriangleMesh && ctx->opt.ellipticTubes)
+            return lv_fail(ctx, LV_E_INVALID, "Elliptic Tubes belong to the AABB geometry mode (VulkanRayTracer.cpp:198), not to Triangle Mesh");
     } else if (ctx->opt.ellipticTubes) {
         return lv_fail(ctx, LV_E_INVALID, "use_analytic_elliptic_tubes needs band data (use_ribbons)");
     }
@@ -1583,7 +1584,8 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
     LV_TIMED_LAUNCH(ctx, LV_KERNEL_RENDER_RT, (k_render_rt<ST, PR, BA><<<gridTiles, LV_BLOCK, 0, st>>>(U, SC, T, out, dc)))
 #define LV_LAUNCH_RT2(ST)                                                        \
     do {                                                                         \
-        if (tri) LV_LAUNCH_RT(ST, LV_PRIM_TRIANGLE, false);                      \
+        if (tri && U.useBands) LV_LAUNCH_RT(ST, LV_PRIM_TRIANGLE, true);         \
+        else if (tri) LV_LAUNCH_RT(ST, LV_PRIM_TRIANGLE, false);                 \
         else if (U.useEllipticTubes) LV_LAUNCH_RT(ST, LV_PRIM_ELLIPTIC, true);   \
         else if (U.useBands) LV_LAUNCH_RT(ST, LV_PRIM_CAPSULE, true);            \
         else LV_LAUNCH_RT(ST, LV_PRIM_CAPSULE, false);                           \

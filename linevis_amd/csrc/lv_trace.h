@@ -1102,6 +1102,7 @@ __device__ __forceinline__ f4 lv_shade_hit_elliptic(const LvSceneDev& S, const L
 
 // ClosestHitTubeTriangles (TubeRayTracing.glsl:301-352) + LineAttributesBarycentric.glsl: the ray tracer's "Triangle
 // Mesh" geometry mode.  tri = original triangle index; (u, v) are recomputed with the test that won the traversal.
+template <bool BANDS = false>
 __device__ __forceinline__ f4 lv_shade_hit_triangle(const LvSceneDev& S, const LvUniforms& U, float aoTexel, f3 o, f3 d,
                                                     uint32_t tri, float& payloadHitT) {
     const uint32_t i0 = S.triIdx[3 * size_t(tri)], i1 = S.triIdx[3 * size_t(tri) + 1], i2 = S.triIdx[3 * size_t(tri) + 2];
@@ -1138,6 +1139,22 @@ __device__ __forceinline__ f4 lv_shade_hit_triangle(const LvSceneDev& S, const L
                                         float(vd1.vertexLinePointIndex & 0x7FFFFFFFu) * bu) +
                                        float(vd2.vertexLinePointIndex & 0x7FFFFFFFu) * bv;
         aoTexel = lv_prebaked_ao_lookup(S, U, fragmentVertexId, phi);
+    }
+    if (BANDS) {
+        // USE_BANDS in the triangle closest-hit shader (LineAttributesBarycentric.glsl:44-63): interpolated angle, line position and
+        // line normal; useBand = true (no ANALYTIC_TUBE_INTERSECTIONS here, RayHitCommon.glsl:164-172)
+        const float PI = 3.14159265358979323846f;
+        float a0 = vd0.phi, a1 = vd1.phi, a2 = vd2.phi;
+        if (a1 - a0 > PI || a2 - a0 > PI) a0 += 2.0f * PI;
+        if (a0 - a1 > PI || a2 - a1 > PI) a1 += 2.0f * PI;
+        if (a0 - a2 > PI || a1 - a2 > PI) a2 += 2.0f * PI;
+        LvBandArgs b;
+        b.useBand = true;
+        b.phi = (a0 * b0 + a1 * bu) + a2 * bv;
+        b.linePosition = lerp3(lp0.linePosition, lp1.linePosition, lp2.linePosition);
+        b.lineNormal = lerp3(lp0.lineNormal, lp1.lineNormal, lp2.lineNormal);
+        return lv_compute_fragment_color_t<true>(S, U, aoTexel, fragPos, fragmentNormal, fragmentTangent, isCap, fragmentAttribute,
+                                                 payloadHitT, b);
     }
     return lv_compute_fragment_color(S, U, aoTexel, fragPos, fragmentNormal, fragmentTangent, isCap, fragmentAttribute,
                                      payloadHitT);

@@ -1361,6 +1361,22 @@ inline void shadeHitTri(const lvo_scene& sc, const lvo_tri_scene& tsc, const lvo
                                  float(vd2.vertexLinePointIndex & 0x7FFFFFFFu) * bc.z;
         aoT = prebakedAoLookup(*pb, fragmentVertexId, phi);
     }
+    if (P.useBands) {
+        // USE_BANDS in the triangle closest-hit shader (LineAttributesBarycentric.glsl:44-63): interpolated angle, line position and
+        // line normal; useBand = true (no ANALYTIC_TUBE_INTERSECTIONS here, RayHitCommon.glsl:164-172)
+        const float PI = 3.14159265358979323846f;
+        float a0 = vd0.phi, a1 = vd1.phi, a2 = vd2.phi;
+        if (a1 - a0 > PI || a2 - a0 > PI) a0 += 2.0f * PI;
+        if (a0 - a1 > PI || a2 - a1 > PI) a1 += 2.0f * PI;
+        if (a0 - a2 > PI || a1 - a2 > PI) a2 += 2.0f * PI;
+        BandArgs b;
+        b.useBand = true;
+        b.phi = (a0 * bc.x + a1 * bc.y) + a2 * bc.z;
+        b.linePosition = interpolateVec3(ld3(lp0.linePosition), ld3(lp1.linePosition), ld3(lp2.linePosition), bc);
+        b.lineNormal = interpolateVec3(ld3(lp0.lineNormal), ld3(lp1.lineNormal), ld3(lp2.lineNormal), bc);
+        computeFragmentColor(sc, P, F, aoT, fragPos, fragmentNormal, fragmentTangent, isCap, fragmentAttribute, hc, payloadHitT, &b);
+        return;
+    }
     computeFragmentColor(sc, P, F, aoT, fragPos, fragmentNormal, fragmentTangent, isCap,
                          fragmentAttribute, hc, payloadHitT);
 }

@@ -223,3 +223,36 @@ def test_band_data_rtao_over_the_elliptic_triangle_tubes(hip_lib, elliptic):
     both = (ao < 1.0) & (ao2 < 1.0)
     if elliptic:
         assert abs(float(ao[both].mean()) - float(ao2[both].mean())) < 0.05
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [dict(), dict(transparent=True), dict(use_capped_tubes=False), dict(thick_bands=False),
+                                dict(rtao=True)])
+def test_band_data_in_triangle_mesh_geometry_mode(hip_lib, kw):
+    """geometry_mode = "Triangle Mesh" on a band data set: the elliptic triangle tubes, closest-hit shading with USE_BANDS
+    (interpolated angle / line position / line normal, useBand = true), optionally with RTAO on the same mesh."""
+    from linevis_amd import host_api
+    kw = dict(kw)
+    rtao = kw.pop("rtao", False)
+    tr = ribbon_scene()
+    flow = host_api.LineDataFlow().set_trajectories(tr.positions, tr.attributes, tr.line_offsets, tr.ribbon_directions)
+    mesh = flow.tube_triangle_render_data_bands(0.05, 0.3, 8)
+    s = dict(geometry_mode="Triangle Mesh", tube_num_subdivisions=8)
+    if rtao:
+        s.update(RTAO, rtao_geometry="triangle_tubes")
+    c = band_case(elliptic=False, **dict(s, **kw))
+    ctx = c.hip_context()
+    ctx.set_tube_triangle_mesh(*mesh)
+    img = ctx.render(11)
+    sc = c.oracle_scene()
+    P = c.oracle_params(sc)
+    tsc = lvo.TriScene(mesh[0], mesh[1], mesh[2], c.line_width)
+    ao_ref = None
+    if rtao:
+        ao_ref = c.oracle_ao(sc, P, render_ao=lambda t: tsc.render_ao(P, tile=t))
+        assert np.array_equal(ctx.get_ao().view(np.uint32), ao_ref.view(np.uint32))
+    ref = tsc.render_rt(sc, P, ao=ao_ref)
+    assert max_lsb_diff(img, ref) <= 2
+    assert (img[..., :3] != 255).any(axis=2).sum() > 2000
+    P.useBands = 0
+    assert not np.array_equal(tsc.render_rt(sc, P, ao=ao_ref), ref)     # the band shading is what is being compared
