@@ -189,7 +189,8 @@ def test_random_band_data_cases(hip_lib, seed):
         tr = scenes.twisted_ribbons(scenes.normalize(scenes.helix_bundle(
             n_lines=int(rng.integers(1, 9)), points_per_line=int(rng.integers(8, 120)), seed=int(rng.integers(1 << 30)),
             turns=float(rng.uniform(0.5, 3.0)))), twist=float(rng.uniform(0.0, 25.0)), seed=int(rng.integers(1 << 30)))
-        elliptic = bool(rng.integers(2))
+        geometry = str(rng.choice(["elliptic", "capsules", "triangles"]))
+        elliptic = geometry == "elliptic"
         bw = float(rng.choice([0.01, 0.03, 0.06]))
         lw = float(rng.choice([0.004, 0.01, 0.03]))
         s = dict(use_ribbons=True, use_analytic_elliptic_tubes=elliptic, band_width=bw,
@@ -212,13 +213,33 @@ def test_random_band_data_cases(hip_lib, seed):
             pts, seg, _ = lvo.build_tube_aabb_render_data(tr.positions, tr.attributes, tr.line_offsets, lw)
         tf = tfm.standard_transparent() if rng.uniform() < 0.4 else tfm.standard()
         cam = (float(rng.uniform(-0.4, 0.4)), float(rng.uniform(-0.3, 0.3)), float(rng.uniform(0.5, 1.0)))
+        # the elliptic triangle tubes of the data set: "Triangle Mesh" geometry mode and / or the reference's RTAO geometry
+        tri_ao = "ambient_occlusion_mode" in s and bool(rng.integers(2))
+        mesh = None
+        if geometry == "triangles" or tri_ao:
+            nsub = int(rng.choice([8, 10]))
+            s["tube_num_subdivisions"] = nsub
+            mesh = lvo.build_tube_triangle_render_data_ribbons(tr.positions, tr.attributes, tr.line_offsets, tr.ribbon_directions, bw,
+                                                               s["min_band_thickness"], nsub)
+        if geometry == "triangles":
+            s["geometry_mode"] = "Triangle Mesh"
+            s.pop("use_capped_tubes", None)
+        if tri_ao:
+            s["rtao_geometry"] = "triangle_tubes"
         c = Case(pts, seg, tf, int(rng.integers(40, 180)), int(rng.integers(30, 120)), lw, camera_pos=cam, **s)
         tag = "seed %d case %d: %dx%d lw %g %s" % (seed, k, c.width, c.height, lw, s)
         ctx = c.hip_context()
+        if mesh is not None:
+            ctx.set_tube_triangle_mesh(*mesh)
         img = ctx.render(11)
-        ref, ao_ref = c.oracle_render(11)
-        if ao_ref is not None:
+        sc = c.oracle_scene()
+        P = c.oracle_params(sc)
+        tsc = lvo.TriScene(mesh[0], mesh[1], mesh[2], lw) if mesh is not None else None
+        ao_ref = None
+        if P.useAmbientOcclusion:
+            ao_ref = c.oracle_ao(sc, P, render_ao=(lambda t: tsc.render_ao(P, tile=t)) if tri_ao else None)
             assert np.array_equal(ctx.get_ao().view(np.uint32), ao_ref.view(np.uint32)), tag
+        ref = tsc.render_rt(sc, P, ao=ao_ref) if geometry == "triangles" else sc.render_rt(P, ao=ao_ref)
         assert max_lsb_diff(img, ref) <= LSB_TOL, tag
         x0, y0 = int(rng.integers(0, c.width)), int(rng.integers(0, c.height))
         w, h = int(rng.integers(1, c.width - x0 + 1)), int(rng.integers(1, c.height - y0 + 1))
