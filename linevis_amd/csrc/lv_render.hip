@@ -756,7 +756,7 @@ __global__ __launch_bounds__(LV_BLOCK) void k_fill_f32(float* p, float v, size_t
 // each one shaded -- no longer forms a multi-millisecond critical path while the rest of the GPU idles: its work is spread
 // over numSlices workgroups.  A slice accepts t in [lo, hi) (the last one up to tMax inclusive), so every fragment is
 // produced exactly once; each workgroup builds partial lists in LDS and splices them into the pixel's global list.
-template <bool STATS>
+template <bool STATS, int PRIM = LV_PRIM_CAPSULE, bool BANDS = false>
 __global__ __launch_bounds__(LV_BLOCK) void k_ppll_gather(const LvUniforms U, const LvSceneDev S, const LvTiles T,
                                                           uint32_t* __restrict__ nodes, uint32_t* __restrict__ startOffset,
                                                           uint32_t* __restrict__ fragCount, LvDevCounters* dc,
@@ -808,12 +808,13 @@ __global__ __launch_bounds__(LV_BLOCK) void k_ppll_gather(const LvUniforms U, co
     // Fragments of a pixel are produced by whichever lane is handed the (pixel, segment) hit: the lane shades with the
     // owner's ray + AO texel and links the node with an LDS atomic exchange on the owner's list head (the reference's
     // atomicExchange(startOffset[pixel]), LinkedListGather.glsl:55, kept in LDS until the slice is finished).
-    lv_trace_all<STATS, false>(S, U.radius, U.useCappedTubes != 0, active, o, d, lo, hi, aoTexel, 0.0f,
+    lv_trace_all<STATS, false, PRIM>(S, U.radius, U.useCappedTubes != 0, active, o, d, lo, hi, aoTexel, 0.0f,
                         lv_stack_mem(s_stack, S.stackOverflow), cm, hq, cnt,
                         [&](unsigned owner, uint32_t leaf, float t, int kind, f3 ro, f3 rd, float ownerAo, float) {
         LvHit h; h.t = t; h.leaf = leaf; h.kind = kind; h.found = true;
         float hitT;
-        f4 color = lv_shade_hit(S, U, ownerAo, ro, rd, h, hitT);
+        f4 color = PRIM == LV_PRIM_ELLIPTIC ? lv_shade_hit_elliptic(S, U, ownerAo, ro, rd, h, hitT)
+                                            : lv_shade_hit<BANDS>(S, U, ownerAo, ro, rd, h, hitT);
         if (STATS) cnt.hits++;
         if (color.w < 0.001f) return; // gatherFragment: discard, LinkedListGather.glsl:34
         // wave-aggregated node allocation: slots come from a per-wave chunk; one global atomic per LV_PPLL_CHUNK fragments
@@ -1433,10 +1434,14 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
     if (ctx->opt.useRibbons) {
         // band data: the closest-hit paths of the ray tracer (analytic geometry modes, or "Triangle Mesh" on the elliptic triangle
         // tubes the host layer tessellates for the data set); RTAO over the analytic tubelets / capsules or over those triangle
-        // tubes (rtao_geometry = triangle_tubes).  MLAT, the prebaker's lookup and the rasterised (PPLL) form are not built.
-        if (mode != LV_RENDERING_MODE_VULKAN_RAY_TRACER || ctx->opt.useMlat || (ctx->opt.useAmbientOcclusion && ctx->opt.aoPrebaked))
-            return lv_fail(ctx, LV_E_INVALID, "use_ribbons: band data is rendered by the ray tracer's closest-hit paths only "
-                                              "(no MLAT / PPLL / prebaked RTAO)");
+        // tubes (rtao_geometry = triangle_tubes); the PPLL gather over the analytic tubelets / capsules.  MLAT and the prebaker's
+        // lookup are not built for band data.
+        if (ctx->opt.useMlat || (ctx->opt.useAmbientOcclusion && ctx->opt.aoPrebaked))
+            return lv_fail(ctx, LV_E_INVALID, "use_ribbons: band data is rendered by the ray tracer's closest-hit paths and the "
+                                              "PPLL gather only (no MLAT / prebaked RTAO)");
+        if (mode == LV_RENDERING_MODE_PER_PIXEL_LINKED_LIST && (ctx->opt.rtTriangleMesh || ctx->opt.rtLss))
+            return lv_fail(ctx, LV_E_INVALID, "use_ribbons: the PPLL gather of band data runs over the analytic tubelets / capsules "
+                                              "(geometry_mode \"AABBs\")");
         if (ctx->opt.rtTriangleMesh && ctx->opt.ellipticTubes)
             return lv_fail(ctx, LV_E_INVALID, "Elliptic Tubes belong to the AABB geometry mode (VulkanRayTracer.cpp:198), not to Triangle Mesh");
     } else if (ctx->opt.ellipticTubes) {
@@ -1620,14 +1625,19 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
         LV_HIP(ctx, hipEventRecord(ctx->ev[11], st));
         // gather()
         LV_HIP(ctx, hipEventRecord(ctx->ev[12], st));
-        if (stats)
-            LV_TIMED_LAUNCH(ctx, LV_KERNEL_PPLL_GATHER, (k_ppll_gather<true><<<gridTiles * numSlices, LV_BLOCK, 0, st>>>(
-                    U, S, T, (uint32_t*)ctx->ppllNodes.ptr, (uint32_t*)ctx->ppllStart.ptr,
-                    (uint32_t*)ctx->ppllCount.ptr, dc, numSlices, poolSlots)));
-        else
-            LV_TIMED_LAUNCH(ctx, LV_KERNEL_PPLL_GATHER, (k_ppll_gather<false><<<gridTiles * numSlices, LV_BLOCK, 0, st>>>(
-                    U, S, T, (uint32_t*)ctx->ppllNodes.ptr, (uint32_t*)ctx->ppllStart.ptr,
-                    (uint32_t*)ctx->ppllCount.ptr, dc, numSlices, poolSlots)));
+#define LV_LAUNCH_GATHER(ST, PR, BA)                                                                             \
+    LV_TIMED_LAUNCH(ctx, LV_KERNEL_PPLL_GATHER, (k_ppll_gather<ST, PR, BA><<<gridTiles * numSlices, LV_BLOCK, 0, st>>>( \
+            U, S, T, (uint32_t*)ctx->ppllNodes.ptr, (uint32_t*)ctx->ppllStart.ptr,                              \
+            (uint32_t*)ctx->ppllCount.ptr, dc, numSlices, poolSlots)))
+#define LV_LAUNCH_GATHER2(ST)                                                          \
+    do {                                                                               \
+        if (U.useBands && U.useEllipticTubes) LV_LAUNCH_GATHER(ST, LV_PRIM_ELLIPTIC, true); \
+        else if (U.useBands) LV_LAUNCH_GATHER(ST, LV_PRIM_CAPSULE, true);              \
+        else LV_LAUNCH_GATHER(ST, LV_PRIM_CAPSULE, false);                             \
+    } while (0)
+        if (stats) LV_LAUNCH_GATHER2(true); else LV_LAUNCH_GATHER2(false);
+#undef LV_LAUNCH_GATHER2
+#undef LV_LAUNCH_GATHER
         LV_HIP(ctx, hipEventRecord(ctx->ev[13], st));
         // resolve()
         LV_HIP(ctx, hipEventRecord(ctx->ev[14], st));

@@ -838,6 +838,10 @@ __device__ __forceinline__ void lv_trace_all(const LvSceneDev& S, float radius, 
                     unsigned low;
                     found = lv_leaf_test<LV_PRIM_TRIANGLE>(S, leaf, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), radius, capped, t, low);
                     kind = int(low);
+                } else if (PRIM == LV_PRIM_ELLIPTIC) {
+                    unsigned low;
+                    found = lv_leaf_test<LV_PRIM_ELLIPTIC>(S, leaf, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), radius, capped, t, low);
+                    kind = 0;
                 } else {
                     const float4 a = S.segs[2 * leaf], b = S.segs[2 * leaf + 1];
                     found = S.literalIntersection
@@ -898,7 +902,8 @@ __device__ __forceinline__ void lv_trace_all(const LvSceneDev& S, float radius, 
         do {
             if (!(cur & LV_LEAF_BIT)) {
                 // literal roots may lie up to r / |d| outside their segment's box interval (lv_intersect_capsule_literal)
-                const float sl = (PRIM == LV_PRIM_CAPSULE && S.literalIntersection)
+                const float sl = PRIM == LV_PRIM_ELLIPTIC ? S.ellBandWidth / len3(mk3(1.0f / inv.x, 1.0f / inv.y, 1.0f / inv.z))
+                        : (PRIM == LV_PRIM_CAPSULE && S.literalIntersection)
                         ? radius / len3(mk3(1.0f / inv.x, 1.0f / inv.y, 1.0f / inv.z)) : 0.0f;
                 cur = lv_node_step<STATS, DYN ? 2 : 0>(S, cur, oi, inv, tMin - sl, tMax + sl, st, cnt);
             }

@@ -318,8 +318,8 @@ bool LineRenderer::uploadFrameState() {
         // band data: USE_BANDS + the "Elliptic Tubes" geometry of the ray tracer (RayTracingRenderPass::setLineData,
         // VulkanRayTracer.cpp:370-381; LineDataFlow::getVulkanShaderPreprocessorDefines, LineDataFlow.cpp:2420-2431)
         // (for band data the reference switches to the ribbon primitive mode, LineDataFlow.cpp:476-481, and its rasterisers then draw
-        // elliptic tubes with USE_BANDS; the ray-entry PPLL of this build has no elliptic fragments and renders the data as plain tubes)
-        const bool bands = !isRasterizer && lineData->getUseBands();
+        // elliptic tubes with USE_BANDS; the ray-entry PPLL of this build gathers the entry hits of the analytic elliptic tubelets)
+        const bool bands = lineData->getUseBands();
         const bool elliptic = bands && getUseAnalyticEllipticTubes();
         TubeAabbRenderData d = lineData->getLinePassTubeAabbRenderData(false, elliptic);
         if (!check(lv_set_lines(ctx, d.linePointDataBuffer.data(), uint32_t(d.linePointDataBuffer.size()),

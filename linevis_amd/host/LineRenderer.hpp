@@ -265,6 +265,8 @@ public:
     void setLineData(LineDataPtr& lineData, bool isNewData) override;
     void render() override;
     bool setNewSettings(const SettingsMap& settings) override;
+    /// band data: the rasterisers always draw the elliptic tubes of the ribbon primitive mode (LineDataFlow.cpp:476-481)
+    bool getUseAnalyticEllipticTubes() const override { return true; }
     /// computeStatistics (PerPixelLinkedListLineRenderer.cpp:578-663): fragments, max depth complexity
     void computeStatistics(uint64_t& totalNumFragments, uint32_t& maxComplexity);
 };

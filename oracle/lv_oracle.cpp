@@ -495,10 +495,11 @@ inline void allHits(const lvo_scene& sc, float radius, bool capped, bool useBvh,
     auto testSeg = [&](uint32_t seg) {
         cnt.prims++;
         V3 p0, p1; segPoints(sc, seg, p0, p1);
-        float t; int kind;
-        if (g_dev.literalIntersection ? (intersectCapsuleLiteral(o, d, p0, p1, radius, capped, t, kind) &&
-                                         literalOwnBoxRule(o, d, p0, p1, radius, t))
-                                      : intersectCapsule(o, d, p0, p1, radius, capped, t, kind)) {
+        float t; int kind = 0;
+        if (g_ell.enabled ? intersectEllipticTube(o, d, sc.pts[sc.segIdx[2 * seg]], sc.pts[sc.segIdx[2 * seg + 1]], t)
+            : g_dev.literalIntersection ? (intersectCapsuleLiteral(o, d, p0, p1, radius, capped, t, kind) &&
+                                           literalOwnBoxRule(o, d, p0, p1, radius, t))
+                                        : intersectCapsule(o, d, p0, p1, radius, capped, t, kind)) {
             if (t >= tMin && t <= tMax) out.push_back(Hit{t, seg, kind});
         }
     };
@@ -516,7 +517,8 @@ inline void allHits(const lvo_scene& sc, float radius, bool capped, bool useBvh,
             const BvhNode& nd = sc.nodes[n];
             cnt.nodes++;
             float tl, tr;
-            const float slack = g_dev.literalIntersection ? radius / sqrtf(dot(d, d)) : 0.0f; // see closestHit
+            const float slack = g_ell.enabled ? g_ell.bandWidth / sqrtf(dot(d, d))
+                                : g_dev.literalIntersection ? radius / sqrtf(dot(d, d)) : 0.0f; // see closestHit
             if (childBox(sc, nd.right, o, inv, tMin - slack, tMax + slack, tr)) stack.push_back(nd.right);
             if (childBox(sc, nd.left, o, inv, tMin - slack, tMax + slack, tl)) stack.push_back(nd.left);
         }
@@ -1857,6 +1859,10 @@ void lvo_ppll_gather(const lvo_scene* sc, const lvo_params* Pp, int useBvh, cons
     padTiling(pw, ph, P.ppllTileW, P.ppllTileH);
     // fragments are generated at pixel centres: own-texel AO lookup (the literal lookup only under the deviation switch)
     g_dev.aoImage = (g_dev.referenceAoLookup && P.useAmbientOcclusion) ? ao : nullptr;
+    // band data: the reference's rasterisers draw elliptic tubes in the ribbon primitive mode; here the fragments are the entry
+    // hits of the analytic tubelets (or of the capsules with USE_BANDS shading), like the capsule entry hits of plain data
+    const bool elliptic = P.useEllipticTubes != 0;
+    EllipticScope ellScope(elliptic, P.bandWidth, P.minBandThickness, F.cameraPosition);
     // clear: LinkedListClear.glsl:46-55
     for (size_t i = 0; i < size_t(pw) * ph; i++) startOffset[i] = 0xFFFFFFFFu;
     *fragCounter = 0;
@@ -1877,7 +1883,8 @@ void lvo_ppll_gather(const lvo_scene* sc, const lvo_params* Pp, int useBvh, cons
             allHits(*sc, F.radius, capped, useBvh != 0, o, d, 0.0001f, 1000.0f, hl, cnt);
             for (const Hit& hit : hl) {
                 float hc[4]; float hitT;
-                shadeHit(*sc, P, F, aoTexel, o, d, hit, hc, hitT);
+                if (elliptic) shadeHitElliptic(*sc, P, F, aoTexel, o, d, hit, hc, hitT);
+                else shadeHit(*sc, P, F, aoTexel, o, d, hit, hc, hitT);
                 cnt.hits++;
                 if (hc[3] < 0.001f) continue;
                 rows[yy].push_back(std::make_pair(packUnorm4x8(hc), hitT));

@@ -97,8 +97,17 @@ def test_band_options_are_validated(hip_lib):
     c = band_case()
     ctx = c.hip_context()
     from linevis_amd import capi
+    ctx.set_option("use_mlat", True)
     with pytest.raises(capi.LineVisError):
-        ctx.render(2)                                   # PPLL with band data
+        ctx.render(11)                                  # MLAT with band data
+    ctx.set_option("use_mlat", False)
+    ctx.set_option("geometry_mode", "Triangle Mesh")
+    ctx.set_option("use_analytic_elliptic_tubes", False)
+    with pytest.raises(capi.LineVisError):
+        ctx.render(2)                                   # the PPLL gather of band data runs over the analytic geometry
+    ctx.set_option("geometry_mode", "AABBs")
+    ctx.set_option("use_analytic_elliptic_tubes", True)
+    ctx.render(2)
     ctx.set_option("use_ribbons", False)
     with pytest.raises(capi.LineVisError):
         ctx.render(11)                                  # elliptic tubes without band data
@@ -145,22 +154,72 @@ def test_band_data_through_the_plugin_surface(hip_lib, tmp_path):
     r.set_new_settings(dict(use_ribbons=True))       # LineDataFlow::useRibbons is static, as in the reference: leave it on
 
 
+def _fragment_lists(nodes, start):
+    out = {}
+    for pix in np.nonzero(start != 0xFFFFFFFF)[0]:
+        l, i = [], int(start[pix])
+        while i != 0xFFFFFFFF:
+            l.append((int(nodes[i, 1]), int(nodes[i, 0])))
+            i = int(nodes[i, 2])
+        out[int(pix)] = sorted(l)
+    return out
+
+
 @pytest.mark.gpu
-def test_ppll_plugin_ignores_band_data(hip_lib):
-    """The reference's rasterisers draw band data as elliptic tubes (ribbon primitive mode, LineDataFlow.cpp:476-481); the ray-entry
-    PPLL of this build has no elliptic fragments: the plugin renders a band data set as plain tubes instead of failing."""
+@pytest.mark.parametrize("kw", [dict(), dict(elliptic=False), dict(thick_bands=False, use_halos=False),
+                                dict(RTAO, ambient_occlusion_iterations=1), dict(ppll_tile_width=8, ppll_tile_height=8)])
+def test_ppll_of_band_data_matches_the_oracle(hip_lib, kw):
+    """PPLL of band data: the fragments are the entry hits of the elliptic tubelets (or of the capsules) shaded with USE_BANDS -- the
+    ray-entry form of the elliptic tubes the reference's rasterisers draw in the ribbon primitive mode.  Per pixel the multiset of
+    (colour, depth) fragments equals the oracle's bit for bit; the resolved frame within 2 LSB."""
+    c = band_case(width=100, height=70, transparent=True, **kw)
+    ctx = c.hip_context()
+    img = ctx.render(2)
+    ref, _ = c.oracle_render(2)
+    assert max_lsb_diff(img, ref) <= 2
+    sc = c.oracle_scene()
+    P = c.oracle_params(sc)
+    ao = sc.render_ao(P) if P.useAmbientOcclusion else None
+    on, os_, ocnt = sc.ppll_gather(P, ao=ao)
+    pw, ph = c.padded()
+    hn, hs, hcnt = ctx.ppll_buffers(pw * ph, int(P.ppllLinkedListSize))
+    assert hcnt == ocnt and hcnt > 1000
+    assert _fragment_lists(hn, hs) == _fragment_lists(on, os_)
+    on2, os2, ocnt2 = sc.ppll_gather(P, ao=ao, use_bvh=True)       # own-box rule: the tree finds what brute force finds
+    assert ocnt2 == ocnt and _fragment_lists(on2, os2) == _fragment_lists(on, os_)
+    if kw.get("elliptic", True):                                   # opaque tubelets (coverage 1): the front fragment is the ray
+        opaque = band_case(width=100, height=70, **kw)             # tracer's hit
+        a = opaque.hip_context().render(2)
+        b = opaque.hip_context().render(11)
+        assert max_lsb_diff(a, b) <= 2
+
+
+@pytest.mark.gpu
+def test_ppll_plugin_draws_band_data_as_elliptic_tubes(hip_lib):
+    """The reference's rasterisers draw band data as elliptic tubes with USE_BANDS (ribbon primitive mode, LineDataFlow.cpp:476-481):
+    the PPLL plugin uploads the tubelet geometry of the data set; its frame equals the one of a context fed by hand."""
     from linevis_amd import host_api
     tr = ribbon_scene()
-    frames = []
-    for ribbons in (tr.ribbon_directions, None):
-        flow = host_api.LineDataFlow().set_trajectories(tr.positions, tr.attributes, tr.line_offsets, ribbons)
-        r = host_api.HeadlessLineRenderer(2)
-        r.set_rendering_resolution(96, 64)
-        r.set_transfer_function(tfm.standard_transparent())
-        r.set_line_data(flow)
-        r.set_new_settings(dict(line_width=0.02))
-        frames.append(r.render_frame())
-    assert np.array_equal(frames[0], frames[1]) and (frames[0][..., :3] != 255).any()
+    flow = host_api.LineDataFlow().set_trajectories(tr.positions, tr.attributes, tr.line_offsets, tr.ribbon_directions)
+    settings = dict(line_width=0.02, band_width=0.05, min_band_thickness=0.3)
+    r = host_api.HeadlessLineRenderer(2)
+    r.set_rendering_resolution(96, 64)
+    r.set_transfer_function(tfm.standard_transparent())
+    r.set_line_data(flow)
+    r.set_new_settings(settings)
+    frame = r.render_frame()
+    pts, seg, _ = flow.tube_aabb_render_data_elliptic(0.05)
+    c = Case(pts, seg, tfm.standard_transparent(), 96, 64, 0.02, use_ribbons=True, use_analytic_elliptic_tubes=True,
+             band_width=0.05, min_band_thickness=0.3)
+    ctx = c.hip_context()
+    lo, hi = flow.attribute_range()
+    ctx.set_transfer_function(c.tf, lo, hi)
+    view, proj, fovy, near, far = r.camera()
+    ctx.set_camera(view, proj, fovy, near, far, 96, 64)
+    assert np.array_equal(frame, ctx.render(2)) and (frame[..., :3] != 255).any()
+    plain = host_api.LineDataFlow().set_trajectories(tr.positions, tr.attributes, tr.line_offsets, None)
+    r.set_line_data(plain)
+    assert not np.array_equal(r.render_frame(), frame)
 
 
 @pytest.mark.gpu

@@ -244,6 +244,11 @@ def test_random_band_data_cases(hip_lib, seed):
         x0, y0 = int(rng.integers(0, c.width)), int(rng.integers(0, c.height))
         w, h = int(rng.integers(1, c.width - x0 + 1)), int(rng.integers(1, c.height - y0 + 1))
         assert np.array_equal(ctx.render(11, tile=(x0, y0, w, h)), img[y0:y0 + h, x0:x0 + w]), tag
+        if geometry != "triangles" and "num_samples_per_frame" not in s:
+            # PPLL of the same band data: entry hits of the tubelets / capsules; AO from the pass above (same iterations)
+            ppll = ctx.render(2)
+            ref2 = sc.render_ppll(P, ao=ao_ref)
+            assert max_lsb_diff(ppll, ref2) <= LSB_TOL, tag
         ctx.close()
 
 
