@@ -198,8 +198,8 @@ int lv_set_background(lv_ctx* ctx, const float rgba[4]);
  *   temporal: every lv_render* call advances its history (one step per RTAO iteration), always over the whole viewport;
  *   lv_set_lines resets the global frame counter, a change of the denoiser or of the viewport size clears the history,
  *   band data (ribbons; the ray tracer's closest-hit paths: analytic geometry modes, or "Triangle Mesh" / rtao_geometry =
- *   triangle_tubes on the elliptic triangle tubes lv::LineDataFlow tessellates for such data; the PPLL gather over the
- *   analytic tubelets / capsules; not MLAT / prebaker):
+ *   triangle_tubes on the elliptic triangle tubes lv::LineDataFlow tessellates for such data; use_mlat over the same
+ *   geometries; the PPLL gather over the analytic tubelets / capsules; not the prebaker):
  *   use_ribbons (= USE_BANDS: the line points passed to
  *   lv_set_lines come from a data set with ribbon directions and ribbons are on, LineDataFlow.cpp:587-606,2423-2431),
  *   thick_bands, min_band_thickness (0.15, LineData.cpp:54), band_width (0.005, LineRenderer.cpp:442-449,

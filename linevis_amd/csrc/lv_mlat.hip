@@ -78,7 +78,7 @@ __device__ __forceinline__ bool lv_mlat_insert(float (&c)[K][4], float (&T)[K], 
     return transmittance <= 0.001f && D[K - 1] <= depth;
 }
 
-template <bool STATS, int K, int PRIM>
+template <bool STATS, int K, int PRIM, bool BANDS>
 __global__ __launch_bounds__(LV_BLOCK) void k_render_rt_mlat(const LvUniforms U, const LvSceneDev S, const LvTiles T,
                                                              uint32_t* __restrict__ out, LvDevCounters* dc,
                                                              uint4* __restrict__ trace, uint32_t traceCap) {
@@ -127,8 +127,10 @@ __global__ __launch_bounds__(LV_BLOCK) void k_render_rt_mlat(const LvUniforms U,
                 LvHit h; h.t = t; h.leaf = leaf; h.kind = kind; h.found = true;
                 float hitT;
                 // AnyHitTubeTriangles / AnyHitTubeAnalytic: the closest-hit shading of the geometry mode
-                const f4 color = PRIM == LV_PRIM_TRIANGLE ? lv_shade_hit_triangle(S, U, ownerAo, ro, rd, uint32_t(kind), hitT)
-                                                          : lv_shade_hit(S, U, ownerAo, ro, rd, h, hitT);
+                // (band data: AnyHitEllipticTubeAnalytic, EllipticTubeRayTracing.glsl:463-466, or the USE_BANDS variants)
+                const f4 color = PRIM == LV_PRIM_TRIANGLE ? lv_shade_hit_triangle<BANDS>(S, U, ownerAo, ro, rd, uint32_t(kind), hitT)
+                               : PRIM == LV_PRIM_ELLIPTIC ? lv_shade_hit_elliptic(S, U, ownerAo, ro, rd, h, hitT)
+                                                          : lv_shade_hit<BANDS>(S, U, ownerAo, ro, rd, h, hitT);
                 if (STATS) cnt.hits++;
                 if (color.w == 0.0f) return; // ignoreIntersectionEXT, MlatInsert.glsl:77-79
                 s_frag[w][0][lane] = color.x; s_frag[w][1][lane] = color.y; s_frag[w][2][lane] = color.z;
@@ -195,29 +197,29 @@ __global__ __launch_bounds__(LV_BLOCK) void k_render_rt_mlat(const LvUniforms U,
     if (STATS) { lv_flush_max_nodes(cnt, dc); lv_flush_counters(cnt, dc); }
 }
 
-template <int K, int PRIM>
+template <int K, int PRIM, bool BANDS>
 int launchMlat(lv_ctx* ctx, const LvUniforms& U, const LvSceneDev& S, const LvTiles& T, uint32_t gridTiles, uint32_t* out,
                LvDevCounters* dc, uint4* trace, uint32_t traceCap) {
     hipStream_t st = ctx->stream;
     if (ctx->opt.collectStats)
         LV_TIMED_LAUNCH(ctx, LV_KERNEL_RENDER_RT,
-                        (k_render_rt_mlat<true, K, PRIM><<<gridTiles, LV_BLOCK, 0, st>>>(U, S, T, out, dc, trace, traceCap)));
+                        (k_render_rt_mlat<true, K, PRIM, BANDS><<<gridTiles, LV_BLOCK, 0, st>>>(U, S, T, out, dc, trace, traceCap)));
     else
         LV_TIMED_LAUNCH(ctx, LV_KERNEL_RENDER_RT,
-                        (k_render_rt_mlat<false, K, PRIM><<<gridTiles, LV_BLOCK, 0, st>>>(U, S, T, out, dc, nullptr, 0u)));
+                        (k_render_rt_mlat<false, K, PRIM, BANDS><<<gridTiles, LV_BLOCK, 0, st>>>(U, S, T, out, dc, nullptr, 0u)));
     return LV_OK;
 }
 
-template <int PRIM>
+template <int PRIM, bool BANDS>
 int launchMlatK(lv_ctx* ctx, const LvUniforms& U, const LvSceneDev& S, const LvTiles& T, uint32_t gridTiles, uint32_t* out,
                 LvDevCounters* dc, uint4* trace, uint32_t traceCap) {
     switch (ctx->opt.mlatNumNodes) {
-    case 1: return launchMlat<1, PRIM>(ctx, U, S, T, gridTiles, out, dc, trace, traceCap);
-    case 2: return launchMlat<2, PRIM>(ctx, U, S, T, gridTiles, out, dc, trace, traceCap);
-    case 4: return launchMlat<4, PRIM>(ctx, U, S, T, gridTiles, out, dc, trace, traceCap);
-    case 8: return launchMlat<8, PRIM>(ctx, U, S, T, gridTiles, out, dc, trace, traceCap);
-    case 16: return launchMlat<16, PRIM>(ctx, U, S, T, gridTiles, out, dc, trace, traceCap);
-    case 32: return launchMlat<32, PRIM>(ctx, U, S, T, gridTiles, out, dc, trace, traceCap);
+    case 1: return launchMlat<1, PRIM, BANDS>(ctx, U, S, T, gridTiles, out, dc, trace, traceCap);
+    case 2: return launchMlat<2, PRIM, BANDS>(ctx, U, S, T, gridTiles, out, dc, trace, traceCap);
+    case 4: return launchMlat<4, PRIM, BANDS>(ctx, U, S, T, gridTiles, out, dc, trace, traceCap);
+    case 8: return launchMlat<8, PRIM, BANDS>(ctx, U, S, T, gridTiles, out, dc, trace, traceCap);
+    case 16: return launchMlat<16, PRIM, BANDS>(ctx, U, S, T, gridTiles, out, dc, trace, traceCap);
+    case 32: return launchMlat<32, PRIM, BANDS>(ctx, U, S, T, gridTiles, out, dc, trace, traceCap);
     default: return lv_fail(ctx, LV_E_INVALID, "mlat_num_nodes must be a power of two in [1, 32], got %u", ctx->opt.mlatNumNodes);
     }
 }
@@ -234,6 +236,11 @@ int lv_mlat_render(lv_ctx* ctx, const LvUniforms& U, const LvSceneDev& S, const 
         trace = (uint4*)ctx->mlatTrace.ptr;
         traceCap = ctx->opt.mlatTraceCapacity;
     }
-    return triangles ? launchMlatK<LV_PRIM_TRIANGLE>(ctx, U, S, T, gridTiles, out, dc, trace, traceCap)
-                     : launchMlatK<LV_PRIM_CAPSULE>(ctx, U, S, T, gridTiles, out, dc, trace, traceCap);
+    if (U.useBands) {
+        if (triangles) return launchMlatK<LV_PRIM_TRIANGLE, true>(ctx, U, S, T, gridTiles, out, dc, trace, traceCap);
+        if (U.useEllipticTubes) return launchMlatK<LV_PRIM_ELLIPTIC, true>(ctx, U, S, T, gridTiles, out, dc, trace, traceCap);
+        return launchMlatK<LV_PRIM_CAPSULE, true>(ctx, U, S, T, gridTiles, out, dc, trace, traceCap);
+    }
+    return triangles ? launchMlatK<LV_PRIM_TRIANGLE, false>(ctx, U, S, T, gridTiles, out, dc, trace, traceCap)
+                     : launchMlatK<LV_PRIM_CAPSULE, false>(ctx, U, S, T, gridTiles, out, dc, trace, traceCap);
 }

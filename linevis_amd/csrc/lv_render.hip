@@ -1434,11 +1434,11 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
     if (ctx->opt.useRibbons) {
         // band data: the closest-hit paths of the ray tracer (analytic geometry modes, or "Triangle Mesh" on the elliptic triangle
         // tubes the host layer tessellates for the data set); RTAO over the analytic tubelets / capsules or over those triangle
-        // tubes (rtao_geometry = triangle_tubes); the PPLL gather over the analytic tubelets / capsules.  MLAT and the prebaker's
-        // lookup are not built for band data.
-        if (ctx->opt.useMlat || (ctx->opt.useAmbientOcclusion && ctx->opt.aoPrebaked))
-            return lv_fail(ctx, LV_E_INVALID, "use_ribbons: band data is rendered by the ray tracer's closest-hit paths and the "
-                                              "PPLL gather only (no MLAT / prebaked RTAO)");
+        // tubes (rtao_geometry = triangle_tubes); MLAT over the same geometries; the PPLL gather over the analytic tubelets /
+        // capsules.  The prebaker's lookup is not built for band data.
+        if (ctx->opt.useAmbientOcclusion && ctx->opt.aoPrebaked)
+            return lv_fail(ctx, LV_E_INVALID, "use_ribbons: band data has no prebaked RTAO (its parametrisation follows the "
+                                              "circular tubes)");
         if (mode == LV_RENDERING_MODE_PER_PIXEL_LINKED_LIST && (ctx->opt.rtTriangleMesh || ctx->opt.rtLss))
             return lv_fail(ctx, LV_E_INVALID, "use_ribbons: the PPLL gather of band data runs over the analytic tubelets / capsules "
                                               "(geometry_mode \"AABBs\")");

@@ -1516,6 +1516,9 @@ static void renderRtMlat(const lvo_scene* sc, const lvo_tri_scene* tscOrNull, co
     const bool capped = P.useCappedTubes != 0 || P.lssGeometry != 0;
     uint64_t rays = 0, nodesV = 0, prims = 0, hitsShaded = 0, violations = 0;
     g_dev.aoImage = P.useAmbientOcclusion ? ao : nullptr;
+    // band data: AnyHitEllipticTubeAnalytic (EllipticTubeRayTracing.glsl:463-466) = ClosestHitEllipticTubeAnalytic + insertNodeMlat
+    const bool elliptic = P.useEllipticTubes != 0 && !tscOrNull;
+    EllipticScope ellScope(elliptic, P.bandWidth, P.minBandThickness, F.cameraPosition);
 #pragma omp parallel for schedule(dynamic, 1) reduction(+ : rays, nodesV, prims, hitsShaded, violations)
     for (int64_t yy = 0; yy < int64_t(h); yy++) {
         Counters cnt;
@@ -1551,6 +1554,8 @@ static void renderRtMlat(const lvo_scene* sc, const lvo_tri_scene* tscOrNull, co
                         auto it = std::lower_bound(triHits.begin(), triHits.end(), hit.seg,
                                                    [](const TriHit& a, uint32_t t) { return a.tri < t; });
                         shadeHitTri(*sc, *tscOrNull, P, F, aoTexel, nullptr, *it, hc, payloadHitT);
+                    } else if (elliptic) {
+                        shadeHitElliptic(*sc, P, F, aoTexel, o, d, hit, hc, payloadHitT);
                     } else {
                         shadeHit(*sc, P, F, aoTexel, o, d, hit, hc, payloadHitT);
                     }

@@ -97,10 +97,6 @@ def test_band_options_are_validated(hip_lib):
     c = band_case()
     ctx = c.hip_context()
     from linevis_amd import capi
-    ctx.set_option("use_mlat", True)
-    with pytest.raises(capi.LineVisError):
-        ctx.render(11)                                  # MLAT with band data
-    ctx.set_option("use_mlat", False)
     ctx.set_option("geometry_mode", "Triangle Mesh")
     ctx.set_option("use_analytic_elliptic_tubes", False)
     with pytest.raises(capi.LineVisError):
@@ -192,6 +188,39 @@ def test_ppll_of_band_data_matches_the_oracle(hip_lib, kw):
         a = opaque.hip_context().render(2)
         b = opaque.hip_context().render(11)
         assert max_lsb_diff(a, b) <= 2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("geometry,k,transparent", [("elliptic", 2, True), ("elliptic", 8, True), ("elliptic", 4, False),
+                                                     ("capsules", 4, True), ("triangles", 4, True)])
+def test_mlat_of_band_data_replay_parity(hip_lib, geometry, k, transparent):
+    """USE_MLAT on band data: AnyHitEllipticTubeAnalytic (EllipticTubeRayTracing.glsl:463-466) = the elliptic closest-hit shading +
+    insertNodeMlat, and the USE_BANDS variants of AnyHitTubeAnalytic / AnyHitTubeTriangles.  Same replay contract as
+    tests/test_gpu_mlat.py: the kernel's recorded visiting order is replayed and validated by the oracle."""
+    tr = ribbon_scene(n_lines=8)
+    kw = dict(use_mlat=True, collect_stats=True, mlat_record_trace=True, mlat_num_nodes=k)
+    mesh = None
+    if geometry == "triangles":
+        mesh = lvo.build_tube_triangle_render_data_ribbons(tr.positions, tr.attributes, tr.line_offsets, tr.ribbon_directions, 0.05,
+                                                           0.3, 8)
+        kw.update(geometry_mode="Triangle Mesh", tube_num_subdivisions=8)
+    c = band_case(width=120, height=90, elliptic=geometry == "elliptic", transparent=transparent, tr=tr, **kw)
+    ctx = c.hip_context()
+    if mesh is not None:
+        ctx.set_tube_triangle_mesh(*mesh)
+    img = ctx.render(11)
+    rec = ctx.mlat_trace()
+    sc = c.oracle_scene()
+    P = c.oracle_params(sc)
+    ts = lvo.TriScene(*mesh, c.line_width) if mesh is not None else None
+    ref, _, viol = sc.render_rt_mlat(P, k, trace=rec, tri_scene=ts)
+    assert viol == 0 and max_lsb_diff(img, ref) <= 2
+    assert len(rec) > 2000
+    ctx.set_option("use_mlat", False)                   # close to the exact transparency loop over the same geometry
+    loop = ctx.render(11)
+    assert np.abs(img.astype(np.int32) - loop.astype(np.int32)).mean() < (5.0 if k < 4 else 2.5)
+    if geometry == "elliptic" and not transparent:
+        assert max_lsb_diff(img, loop) <= 2             # opaque tubelets: the nearest layer is the closest hit
 
 
 @pytest.mark.gpu
