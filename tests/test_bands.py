@@ -167,6 +167,31 @@ def test_elliptic_frame_bvh_equals_brute_force_and_bands_change_the_shading():
     assert not np.array_equal(sc.render_rt(P, use_bvh=True), a)
 
 
+def test_elliptic_all_hits_consumers_agree_with_the_closest_hit_loop():
+    """The all-hits consumers of the oracle on band data (PPLL gather + resolve, MLAT with enough nodes) against its transparency
+    loop of closest hits: three independent walks over the same tubelets -- brute force and tree -- give the same picture."""
+    tr = ribbon_scene()
+    s = dict(use_ribbons=True, band_width=0.05, min_band_thickness=0.3, use_analytic_elliptic_tubes=True)
+    pts, seg, _ = lvo.build_tube_aabb_render_data_ribbons(tr.positions, tr.attributes, tr.line_offsets, 0.05, tr.ribbon_directions)
+    c = Case(pts, seg, tfm.standard_transparent(), 120, 90, 0.02, **s)
+    sc = c.oracle_scene()
+    P = c.oracle_params(sc)
+    loop = sc.render_rt(P, use_bvh=True).astype(np.int32)
+    ppll = sc.render_ppll(P, use_bvh=False)
+    assert np.array_equal(ppll, sc.render_ppll(P, use_bvh=True))
+    # exact sorting vs the closest-hit loop: the same layers front to back (the loop re-traces from hitT + eps, the lists sort by
+    # camera distance; both stop at alpha 0.99).  The lists hold packUnorm4x8 colours: a highlight above 1.0 is clamped per fragment
+    # there and only at the end in the loop -- those pixels (< 1 %) differ by more than the rounding
+    d = np.abs(ppll.astype(np.int32) - loop).max(axis=2)
+    assert (d > 2).mean() < 0.01 and d.max() < 32
+    mlat, _, _ = sc.render_rt_mlat(P, 32, use_bvh=True)
+    d = np.abs(mlat.astype(np.int32) - loop).max(axis=2)
+    assert (d > 2).sum() <= 3 and (loop[..., :3] != 255).any(axis=2).sum() > 1000
+    n1, s1, c1 = sc.ppll_gather(P, use_bvh=False)
+    n2, s2, c2 = sc.ppll_gather(P, use_bvh=True)
+    assert c1 == c2 and c1 > 2000
+
+
 def test_elliptic_bvh_equals_brute_force_for_near_axis_parallel_rays():
     """The shader's own box test ignores axes with |d_i| < 1e-3; the own-box rule (slab interval) keeps the closest hit
     independent of the BVH for exactly those rays."""
