@@ -20,6 +20,7 @@ PMC counters committed under profiles/ and the launch time measured live in this
 `--gpus N` run (tests/test_tiling_dist.py).
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -182,11 +183,13 @@ def measured_hbm_ceiling(device, torch):
 
 
 def _stats(x):
-    x = np.sort(np.asarray(x, dtype=np.float64))
+    raw = np.asarray(x, dtype=np.float64)
+    x = np.sort(raw)
     if not len(x):
         return None
     return {"median": round(float(np.median(x)), 4), "p95": round(float(x[min(len(x) - 1, int(0.95 * len(x)))]), 4),
-            "min": round(float(x[0]), 4), "max": round(float(x[-1]), 4), "mean": round(float(x.mean()), 4), "n": int(len(x))}
+            "min": round(float(x[0]), 4), "max": round(float(x[-1]), 4), "mean": round(float(x.mean()), 4), "n": int(len(x)),
+            "argmax": int(np.argmax(raw))}
 
 
 def roofline(kernel, pmc_key, ms_launch, algorithmic_bytes, world):
@@ -431,6 +434,11 @@ def main():
                 full = sf.rebalance(local_cost, base_cost=4.0 * TILE * TILE)
                 for sf2, _ in slots[1:]:
                     sf2.redeal(full, base_cost=4.0 * TILE * TILE)
+        # the scene's host arrays keep millions of objects alive: a generation-2 collection in the middle of the timed loop costs
+        # the host tens of ms.  Collect now, then keep the collector out of the warm-up and the timed frames.
+        gc.collect()
+        gc.freeze()
+        gc.disable()
         for _ in range(args.warmup):
             step()
         sync_all()
@@ -448,6 +456,7 @@ def main():
                 marks[i + 1].record()
         sync_all()
         elapsed = time.perf_counter() - t0
+        gc.enable()
         tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
         if world > 1:
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
