@@ -205,7 +205,10 @@ int lv_set_background(lv_ctx* ctx, const float rgba[4]);
  *   thick_bands, min_band_thickness (0.15, LineData.cpp:54), band_width (0.005, LineRenderer.cpp:442-449,
  *   DataSetList.hpp:47), use_analytic_elliptic_tubes (build-owned key for the ray tracer's "Elliptic Tubes" checkbox,
  *   VulkanRayTracer.cpp:198-201: the points then carry the ribbon normals of getLinePassTubeAabbRenderData(false, true)
- *   and every segment is a sphere-traced elliptic tubelet, EllipticTubeRayTracing.glsl). */
+ *   and every segment is a sphere-traced elliptic tubelet, EllipticTubeRayTracing.glsl).
+ *   rotating helicity bands of flow lines (USE_ROTATING_HELICITY_BANDS, LineDataFlow.cpp:601-624,2432-2440; excludes
+ *   use_ribbons): rotating_helicity_bands (the line points then carry lineRotation, LineDataFlow.cpp:2188-2197),
+ *   separator_width (0.2), band_subdivisions (6), helicity_rotation_factor (1). */
 int lv_set_option(lv_ctx* ctx, const char* key, const char* value);
 
 /* LineData::getRayTracingTubeAabbTopLevelAS (LineData.cpp:1057-1075) + getTubeAabbBottomLevelAS (:879-907):

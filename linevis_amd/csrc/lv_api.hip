@@ -432,6 +432,17 @@ int lv_set_option(lv_ctx* ctx, const char* key, const char* value) {
         o.bandWidth = f;
     } else if (k == "use_analytic_elliptic_tubes") {              // "Elliptic Tubes" checkbox, VulkanRayTracer.cpp:198-201
         o.ellipticTubes = parseBool(value);
+    } else if (k == "rotating_helicity_bands") {                  // LineDataFlow.cpp:601 (= USE_ROTATING_HELICITY_BANDS: the line
+        o.helicityBands = parseBool(value);                       // points then carry lineRotation)
+    } else if (k == "separator_width") {                          // :609
+        if (!parseFloat(value, f) || !(f >= 0.0f)) return bad();
+        o.separatorWidth = f;
+    } else if (k == "band_subdivisions") {                        // :613
+        if (!parseUint(value, u) || u == 0) return bad();
+        o.bandSubdivisions = u;
+    } else if (k == "helicity_rotation_factor") {                 // :622
+        if (!parseFloat(value, f)) return bad();
+        o.helicityRotationFactor = f;
     } else if (k == "svgf_denoiser_iterations") {                // maxNumIterations, SVGF.cpp:427-436 (GUI only in the reference)
         if (!parseUint(value, u) || u > 5) return bad();
         o.svgfIterations = u;

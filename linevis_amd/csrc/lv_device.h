@@ -139,6 +139,10 @@ struct LvUniforms {
     uint32_t lssGeometry;
     uint32_t useBands, useEllipticTubes;
     float bandWidth, minBandThickness, minThickness;
+    // USE_ROTATING_HELICITY_BANDS + LineUniformData numSubdivisionsBands / separatorBaseWidth / helicityRotationFactor
+    // (LineDataFlow.cpp:979-984,2432-2440)
+    uint32_t useHelicityBands, numSubdivisionsBands;
+    float separatorBaseWidth, helicityRotationFactor;
 };
 
 // Feature maps SVGF asks the RTAO pass for (SVGF.cpp:88-96; VulkanRayTracedAmbientOcclusion.glsl:350-464, DISABLE_ACCUMULATION
@@ -181,7 +185,12 @@ struct LvSceneDev {
 };
 #define LV_PRIM_CAPSULE 0
 #define LV_PRIM_TRIANGLE 1
-#define LV_PRIM_ELLIPTIC 2   // elliptic tubelets of band data (EllipticTubeRayTracing.glsl)
+#define LV_PRIM_ELLIPTIC 2
+// shading variant of computeFragmentColor (template parameter of the hit shading; `true` / `false` of the earlier bool still mean
+// USE_BANDS / plain): USE_BANDS and USE_ROTATING_HELICITY_BANDS never occur together (LineDataFlow.cpp:470,601-604,2423)
+#define LV_SHADE_PLAIN 0
+#define LV_SHADE_BANDS 1
+#define LV_SHADE_HELICITY 2   // elliptic tubelets of band data (EllipticTubeRayTracing.glsl)
 
 // tile list of a launch: tiles are tileW x tileH pixel rectangles with origins tilesXY[2*i], tilesXY[2*i+1]
 struct LvTiles {

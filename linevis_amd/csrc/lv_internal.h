@@ -76,6 +76,11 @@ struct LvOptions {
     // "Elliptic Tubes" switch has no settings key in the reference (VulkanRayTracer.cpp:198-201): use_analytic_elliptic_tubes
     bool useRibbons = false, thickBands = true, ellipticTubes = false;
     float bandWidth = 0.005f, minBandThickness = 0.15f;
+    // rotating helicity bands of flow lines with a helicity attribute: rotating_helicity_bands, separator_width (0.2,
+    // LineDataFlow.cpp:54), band_subdivisions (6, LineDataFlow.hpp:188), helicity_rotation_factor (1, :171); settings keys :601-624
+    bool helicityBands = false;
+    float separatorWidth = 0.2f, helicityRotationFactor = 1.0f;
+    uint32_t bandSubdivisions = 6;
     bool svgfEnabled = false;
     uint32_t svgfIterations = 5;              // maxNumIterations, SVGF.hpp:115 (GUI range 0..5)
     float svgfAllowedZDist = 0.002f, svgfAllowedNormalDist = 0.02f; // SVGF.hpp:70-71

@@ -78,7 +78,7 @@ __device__ __forceinline__ bool lv_mlat_insert(float (&c)[K][4], float (&T)[K], 
     return transmittance <= 0.001f && D[K - 1] <= depth;
 }
 
-template <bool STATS, int K, int PRIM, bool BANDS>
+template <bool STATS, int K, int PRIM, int BANDS>
 __global__ __launch_bounds__(LV_BLOCK) void k_render_rt_mlat(const LvUniforms U, const LvSceneDev S, const LvTiles T,
                                                              uint32_t* __restrict__ out, LvDevCounters* dc,
                                                              uint4* __restrict__ trace, uint32_t traceCap) {
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(LV_BLOCK) void k_render_rt_mlat(const LvUniforms U,
     if (STATS) { lv_flush_max_nodes(cnt, dc); lv_flush_counters(cnt, dc); }
 }
 
-template <int K, int PRIM, bool BANDS>
+template <int K, int PRIM, int BANDS>
 int launchMlat(lv_ctx* ctx, const LvUniforms& U, const LvSceneDev& S, const LvTiles& T, uint32_t gridTiles, uint32_t* out,
                LvDevCounters* dc, uint4* trace, uint32_t traceCap) {
     hipStream_t st = ctx->stream;
@@ -210,7 +210,7 @@ int launchMlat(lv_ctx* ctx, const LvUniforms& U, const LvSceneDev& S, const LvTi
     return LV_OK;
 }
 
-template <int PRIM, bool BANDS>
+template <int PRIM, int BANDS>
 int launchMlatK(lv_ctx* ctx, const LvUniforms& U, const LvSceneDev& S, const LvTiles& T, uint32_t gridTiles, uint32_t* out,
                 LvDevCounters* dc, uint4* trace, uint32_t traceCap) {
     switch (ctx->opt.mlatNumNodes) {
@@ -236,11 +236,14 @@ int lv_mlat_render(lv_ctx* ctx, const LvUniforms& U, const LvSceneDev& S, const 
         trace = (uint4*)ctx->mlatTrace.ptr;
         traceCap = ctx->opt.mlatTraceCapacity;
     }
+    if (U.useHelicityBands)
+        return triangles ? launchMlatK<LV_PRIM_TRIANGLE, LV_SHADE_HELICITY>(ctx, U, S, T, gridTiles, out, dc, trace, traceCap)
+                         : launchMlatK<LV_PRIM_CAPSULE, LV_SHADE_HELICITY>(ctx, U, S, T, gridTiles, out, dc, trace, traceCap);
     if (U.useBands) {
-        if (triangles) return launchMlatK<LV_PRIM_TRIANGLE, true>(ctx, U, S, T, gridTiles, out, dc, trace, traceCap);
-        if (U.useEllipticTubes) return launchMlatK<LV_PRIM_ELLIPTIC, true>(ctx, U, S, T, gridTiles, out, dc, trace, traceCap);
-        return launchMlatK<LV_PRIM_CAPSULE, true>(ctx, U, S, T, gridTiles, out, dc, trace, traceCap);
+        if (triangles) return launchMlatK<LV_PRIM_TRIANGLE, LV_SHADE_BANDS>(ctx, U, S, T, gridTiles, out, dc, trace, traceCap);
+        if (U.useEllipticTubes) return launchMlatK<LV_PRIM_ELLIPTIC, LV_SHADE_BANDS>(ctx, U, S, T, gridTiles, out, dc, trace, traceCap);
+        return launchMlatK<LV_PRIM_CAPSULE, LV_SHADE_BANDS>(ctx, U, S, T, gridTiles, out, dc, trace, traceCap);
     }
-    return triangles ? launchMlatK<LV_PRIM_TRIANGLE, false>(ctx, U, S, T, gridTiles, out, dc, trace, traceCap)
-                     : launchMlatK<LV_PRIM_CAPSULE, false>(ctx, U, S, T, gridTiles, out, dc, trace, traceCap);
+    return triangles ? launchMlatK<LV_PRIM_TRIANGLE, LV_SHADE_PLAIN>(ctx, U, S, T, gridTiles, out, dc, trace, traceCap)
+                     : launchMlatK<LV_PRIM_CAPSULE, LV_SHADE_PLAIN>(ctx, U, S, T, gridTiles, out, dc, trace, traceCap);
 }

@@ -28,7 +28,7 @@ namespace {
 // ================================================================ ray tracer colour pass
 // Control flow is wave-uniform around every trace (lv_trace_closest is a wave-cooperative routine): the sample loop and
 // the transparency loop run while ANY lane of the wave still needs a trace; lanes that are done pass active = false.
-template <bool STATS, int PRIM, bool BANDS = false>
+template <bool STATS, int PRIM, int BANDS = LV_SHADE_PLAIN>
 __global__ __launch_bounds__(LV_BLOCK) void k_render_rt(const LvUniforms U, const LvSceneDev S, const LvTiles T,
                                                         uint32_t* __restrict__ out, LvDevCounters* dc) {
     __shared__ unsigned s_stack[LV_STACK_LDS * LV_BLOCK];
@@ -756,7 +756,7 @@ __global__ __launch_bounds__(LV_BLOCK) void k_fill_f32(float* p, float v, size_t
 // each one shaded -- no longer forms a multi-millisecond critical path while the rest of the GPU idles: its work is spread
 // over numSlices workgroups.  A slice accepts t in [lo, hi) (the last one up to tMax inclusive), so every fragment is
 // produced exactly once; each workgroup builds partial lists in LDS and splices them into the pixel's global list.
-template <bool STATS, int PRIM = LV_PRIM_CAPSULE, bool BANDS = false>
+template <bool STATS, int PRIM = LV_PRIM_CAPSULE, int BANDS = LV_SHADE_PLAIN>
 __global__ __launch_bounds__(LV_BLOCK) void k_ppll_gather(const LvUniforms U, const LvSceneDev S, const LvTiles T,
                                                           uint32_t* __restrict__ nodes, uint32_t* __restrict__ startOffset,
                                                           uint32_t* __restrict__ fragCount, LvDevCounters* dc,
@@ -1142,6 +1142,10 @@ void lv_fill_uniforms(const lv_ctx* ctx, LvUniforms& U) {
     U.bandWidth = o.bandWidth;
     U.minBandThickness = o.minBandThickness;
     U.minThickness = o.thickBands ? o.minBandThickness : 1e-2f; // MIN_THICKNESS, LineDataFlow.cpp:2425-2430
+    U.useHelicityBands = o.helicityBands ? 1u : 0u;
+    U.numSubdivisionsBands = o.bandSubdivisions;
+    U.separatorBaseWidth = o.separatorWidth;
+    U.helicityRotationFactor = o.helicityRotationFactor;
     U.nearDist = ctx->nearDist;
     U.farDist = ctx->farDist;
     U.width = ctx->width;
@@ -1447,6 +1451,8 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
     } else if (ctx->opt.ellipticTubes) {
         return lv_fail(ctx, LV_E_INVALID, "use_analytic_elliptic_tubes needs band data (use_ribbons)");
     }
+    if (ctx->opt.helicityBands && ctx->opt.useRibbons)
+        return lv_fail(ctx, LV_E_INVALID, "rotating_helicity_bands and use_ribbons exclude each other (LineDataFlow.cpp:470,601-604)");
     if (ctx->opt.rtLss && ctx->opt.useRibbons && ctx->opt.ellipticTubes)
         return lv_fail(ctx, LV_E_INVALID, "Elliptic Tubes belong to the AABB geometry mode (VulkanRayTracer.cpp:198), not to Linear Swept Spheres");
     if (!ctx->accelValid || ctx->accelLineWidth != lv_accel_width(ctx))
@@ -1589,11 +1595,13 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
     LV_TIMED_LAUNCH(ctx, LV_KERNEL_RENDER_RT, (k_render_rt<ST, PR, BA><<<gridTiles, LV_BLOCK, 0, st>>>(U, SC, T, out, dc)))
 #define LV_LAUNCH_RT2(ST)                                                        \
     do {                                                                         \
-        if (tri && U.useBands) LV_LAUNCH_RT(ST, LV_PRIM_TRIANGLE, true);         \
-        else if (tri) LV_LAUNCH_RT(ST, LV_PRIM_TRIANGLE, false);                 \
-        else if (U.useEllipticTubes) LV_LAUNCH_RT(ST, LV_PRIM_ELLIPTIC, true);   \
-        else if (U.useBands) LV_LAUNCH_RT(ST, LV_PRIM_CAPSULE, true);            \
-        else LV_LAUNCH_RT(ST, LV_PRIM_CAPSULE, false);                           \
+        if (tri && U.useHelicityBands) LV_LAUNCH_RT(ST, LV_PRIM_TRIANGLE, LV_SHADE_HELICITY); \
+        else if (tri && U.useBands) LV_LAUNCH_RT(ST, LV_PRIM_TRIANGLE, LV_SHADE_BANDS); \
+        else if (tri) LV_LAUNCH_RT(ST, LV_PRIM_TRIANGLE, LV_SHADE_PLAIN);        \
+        else if (U.useHelicityBands) LV_LAUNCH_RT(ST, LV_PRIM_CAPSULE, LV_SHADE_HELICITY); \
+        else if (U.useEllipticTubes) LV_LAUNCH_RT(ST, LV_PRIM_ELLIPTIC, LV_SHADE_BANDS); \
+        else if (U.useBands) LV_LAUNCH_RT(ST, LV_PRIM_CAPSULE, LV_SHADE_BANDS);  \
+        else LV_LAUNCH_RT(ST, LV_PRIM_CAPSULE, LV_SHADE_PLAIN);                  \
     } while (0)
         if (stats) LV_LAUNCH_RT2(true); else LV_LAUNCH_RT2(false);
 #undef LV_LAUNCH_RT2
@@ -1631,9 +1639,10 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
             (uint32_t*)ctx->ppllCount.ptr, dc, numSlices, poolSlots)))
 #define LV_LAUNCH_GATHER2(ST)                                                          \
     do {                                                                               \
-        if (U.useBands && U.useEllipticTubes) LV_LAUNCH_GATHER(ST, LV_PRIM_ELLIPTIC, true); \
-        else if (U.useBands) LV_LAUNCH_GATHER(ST, LV_PRIM_CAPSULE, true);              \
-        else LV_LAUNCH_GATHER(ST, LV_PRIM_CAPSULE, false);                             \
+        if (U.useHelicityBands) LV_LAUNCH_GATHER(ST, LV_PRIM_CAPSULE, LV_SHADE_HELICITY); \
+        else if (U.useBands && U.useEllipticTubes) LV_LAUNCH_GATHER(ST, LV_PRIM_ELLIPTIC, LV_SHADE_BANDS); \
+        else if (U.useBands) LV_LAUNCH_GATHER(ST, LV_PRIM_CAPSULE, LV_SHADE_BANDS);    \
+        else LV_LAUNCH_GATHER(ST, LV_PRIM_CAPSULE, LV_SHADE_PLAIN);                    \
     } while (0)
         if (stats) LV_LAUNCH_GATHER2(true); else LV_LAUNCH_GATHER2(false);
 #undef LV_LAUNCH_GATHER2

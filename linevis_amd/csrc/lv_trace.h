@@ -955,8 +955,9 @@ __device__ __forceinline__ f4 lv_transfer_function(const LvSceneDev& S, const Lv
 }
 
 // USE_BANDS arguments of computeFragmentColor (RayHitCommon.glsl:82-90,148-190)
-struct LvBandArgs { bool useBand; float phi; f3 linePosition, lineNormal; };
-template <bool BANDS>
+// (LV_SHADE_HELICITY: phi and rotation = fragmentRotation of USE_ROTATING_HELICITY_BANDS, :91-93; the rest unused)
+struct LvBandArgs { bool useBand; float phi; f3 linePosition, lineNormal; float rotation; };
+template <int BANDS>
 __device__ __forceinline__ f4 lv_compute_fragment_color_t(const LvSceneDev& S, const LvUniforms& U, float aoTexel, f3 fragPos,
                                                           f3 fragmentNormal, f3 fragmentTangent, bool isCap,
                                                           float fragmentAttribute, float& payloadHitT, const LvBandArgs& bands);
@@ -965,7 +966,8 @@ __device__ __forceinline__ f4 lv_compute_fragment_color(const LvSceneDev& S, con
                                                         float fragmentAttribute, float& payloadHitT) {
     LvBandArgs none;
     none.useBand = false; none.phi = 0.0f; none.linePosition = mk3(0.0f, 0.0f, 0.0f); none.lineNormal = mk3(0.0f, 0.0f, 0.0f);
-    return lv_compute_fragment_color_t<false>(S, U, aoTexel, fragPos, fragmentNormal, fragmentTangent, isCap, fragmentAttribute,
+    none.rotation = 0.0f;
+    return lv_compute_fragment_color_t<LV_SHADE_PLAIN>(S, U, aoTexel, fragPos, fragmentNormal, fragmentTangent, isCap, fragmentAttribute,
                                               payloadHitT, none);
 }
 
@@ -998,7 +1000,7 @@ __device__ __forceinline__ float lv_prebaked_ao_lookup(const LvSceneDev& S, cons
 // ClosestHitTubeAnalytic + computeFragmentColor + blinnPhongShadingTube for flow lines.
 // aoTexel: AO factor of the pixel that launched the ray (lookup definition: DESIGN.md).  Returns payload.hitColor;
 // payloadHitT = length(hit - camera).
-template <bool BANDS = false>
+template <int BANDS = LV_SHADE_PLAIN>
 __device__ __forceinline__ f4 lv_shade_hit(const LvSceneDev& S, const LvUniforms& U, float aoTexel, f3 o, f3 d,
                                            const LvHit& h, float& payloadHitT) {
     const float4 ra = S.segs[2 * h.leaf], rb = S.segs[2 * h.leaf + 1];
@@ -1037,7 +1039,26 @@ __device__ __forceinline__ f4 lv_shade_hit(const LvSceneDev& S, const LvUniforms
         const float fragmentVertexId = (1.0f - ts) * float(i0) + ts * float(i1);
         aoTexel = lv_prebaked_ao_lookup(S, U, fragmentVertexId, phi);
     }
-    if (BANDS) {
+    if (BANDS == LV_SHADE_HELICITY) {
+        // USE_ROTATING_HELICITY_BANDS, TubeRayTracing.glsl:551-567: phi as for the AO lookup (acos through the build's atan2),
+        // fragmentRotation = lerp(lineRotation) * helicityRotationFactor
+        const uint32_t seg = S.leafSeg[h.leaf];
+        const lv_line_point& lp0 = S.points[S.segIdx[2 * seg]];
+        const lv_line_point& lp1 = S.points[S.segIdx[2 * seg + 1]];
+        const float ts = h.kind == 0 ? dot3(v, fragPos - P0) / dot3(v, v) : (h.kind == 1 ? 0.0f : 1.0f);
+        LvBandArgs b;
+        b.useBand = false;
+        b.lineNormal = (1.0f - ts) * mk3(lp0.lineNormal[0], lp0.lineNormal[1], lp0.lineNormal[2]) +
+                       ts * mk3(lp1.lineNormal[0], lp1.lineNormal[1], lp1.lineNormal[2]);
+        const float cphi = clampf(dot3(fragmentNormal, b.lineNormal), -1.0f, 1.0f);
+        b.phi = lv_atan2_det(sqrtf((1.0f - cphi) * (1.0f + cphi)), cphi);
+        if (dot3(b.lineNormal, cross3(fragmentNormal, fragmentTangent)) < 0.0f) b.phi = 2.0f * 3.14159265358979323846f - b.phi;
+        b.linePosition = linePointInterpolated;
+        b.rotation = ((1.0f - ts) * lp0.lineRotation + ts * lp1.lineRotation) * U.helicityRotationFactor;
+        return lv_compute_fragment_color_t<LV_SHADE_HELICITY>(S, U, aoTexel, fragPos, fragmentNormal, fragmentTangent, isCap,
+                                                              fragmentAttribute, payloadHitT, b);
+    }
+    if (BANDS == LV_SHADE_BANDS) {
         // band data with the circular analytic tubes: USE_BANDS is defined, ANALYTIC_TUBE_INTERSECTIONS sets useBand = false
         // (RayHitCommon.glsl:164-166); phi and the line normal as TubeRayTracing.glsl:551-560 (acos through the build's atan2)
         const uint32_t seg = S.leafSeg[h.leaf];
@@ -1052,8 +1073,9 @@ __device__ __forceinline__ f4 lv_shade_hit(const LvSceneDev& S, const LvUniforms
         b.phi = lv_atan2_det(sqrtf((1.0f - cphi) * (1.0f + cphi)), cphi);
         if (dot3(b.lineNormal, cross3(fragmentNormal, fragmentTangent)) < 0.0f) b.phi = 2.0f * 3.14159265358979323846f - b.phi;
         b.linePosition = linePointInterpolated;
-        return lv_compute_fragment_color_t<true>(S, U, aoTexel, fragPos, fragmentNormal, fragmentTangent, isCap,
-                                                 fragmentAttribute, payloadHitT, b);
+        b.rotation = 0.0f;
+        return lv_compute_fragment_color_t<LV_SHADE_BANDS>(S, U, aoTexel, fragPos, fragmentNormal, fragmentTangent, isCap,
+                                                           fragmentAttribute, payloadHitT, b);
     }
     return lv_compute_fragment_color(S, U, aoTexel, fragPos, fragmentNormal, fragmentTangent, isCap, fragmentAttribute,
                                      payloadHitT);
@@ -1102,12 +1124,13 @@ __device__ __forceinline__ f4 lv_shade_hit_elliptic(const LvSceneDev& S, const L
     b.phi = E.phiLine;
     b.linePosition = E.linePosition;
     b.lineNormal = E.lineNormal;
-    return lv_compute_fragment_color_t<true>(S, U, aoTexel, E.fragPos, E.normal, E.tangent, false, E.attribute, payloadHitT, b);
+    b.rotation = 0.0f;
+    return lv_compute_fragment_color_t<LV_SHADE_BANDS>(S, U, aoTexel, E.fragPos, E.normal, E.tangent, false, E.attribute, payloadHitT, b);
 }
 
 // ClosestHitTubeTriangles (TubeRayTracing.glsl:301-352) + LineAttributesBarycentric.glsl: the ray tracer's "Triangle
 // Mesh" geometry mode.  tri = original triangle index; (u, v) are recomputed with the test that won the traversal.
-template <bool BANDS = false>
+template <int BANDS = LV_SHADE_PLAIN>
 __device__ __forceinline__ f4 lv_shade_hit_triangle(const LvSceneDev& S, const LvUniforms& U, float aoTexel, f3 o, f3 d,
                                                     uint32_t tri, float& payloadHitT) {
     const uint32_t i0 = S.triIdx[3 * size_t(tri)], i1 = S.triIdx[3 * size_t(tri) + 1], i2 = S.triIdx[3 * size_t(tri) + 2];
@@ -1145,7 +1168,39 @@ __device__ __forceinline__ f4 lv_shade_hit_triangle(const LvSceneDev& S, const L
                                        float(vd2.vertexLinePointIndex & 0x7FFFFFFFu) * bv;
         aoTexel = lv_prebaked_ao_lookup(S, U, fragmentVertexId, phi);
     }
-    if (BANDS) {
+    if (BANDS == LV_SHADE_HELICITY) {
+        // USE_ROTATING_HELICITY_BANDS in the triangle closest-hit shader (LineAttributesBarycentric.glsl:43-92): interpolated angle,
+        // interpolated lineRotation x helicityRotationFactor; on the caps the rotation is continued linearly along the line
+        const float PI = 3.14159265358979323846f;
+        float a0 = vd0.phi, a1 = vd1.phi, a2 = vd2.phi;
+        if (a1 - a0 > PI || a2 - a0 > PI) a0 += 2.0f * PI;
+        if (a0 - a1 > PI || a2 - a1 > PI) a1 += 2.0f * PI;
+        if (a0 - a2 > PI || a1 - a2 > PI) a2 += 2.0f * PI;
+        LvBandArgs b;
+        b.useBand = false;
+        b.phi = (a0 * b0 + a1 * bu) + a2 * bv;
+        b.linePosition = mk3(0.0f, 0.0f, 0.0f);
+        b.lineNormal = mk3(0.0f, 0.0f, 0.0f);
+        const float f = U.helicityRotationFactor;
+        b.rotation = ((lp0.lineRotation * f) * b0 + (lp1.lineRotation * f) * bu) + (lp2.lineRotation * f) * bv;
+        if (isCap) {
+            const uint32_t li0 = vd0.vertexLinePointIndex & 0x7FFFFFFFu;
+            const lv_line_point* other = nullptr;
+            if (li0 != 0u && S.triPoints[li0 - 1u].lineStartIndex == lp0.lineStartIndex) other = &S.triPoints[li0 - 1u];
+            if (!other) other = &S.triPoints[li0 + 1u];
+            const float fragmentRotationDelta = (lp0.lineRotation - other->lineRotation) * f;
+            f3 planeNormal = mk3(lp0.linePosition[0], lp0.linePosition[1], lp0.linePosition[2]) -
+                             mk3(other->linePosition[0], other->linePosition[1], other->linePosition[2]);
+            const float segmentLength = len3(planeNormal);
+            planeNormal = mk3(planeNormal.x / segmentLength, planeNormal.y / segmentLength, planeNormal.z / segmentLength);
+            const float planeDist = -dot3(planeNormal, mk3(lp0.linePosition[0], lp0.linePosition[1], lp0.linePosition[2]));
+            const float distToPlane = dot3(planeNormal, fragPos) + planeDist;
+            b.rotation += fragmentRotationDelta * distToPlane / segmentLength;
+        }
+        return lv_compute_fragment_color_t<LV_SHADE_HELICITY>(S, U, aoTexel, fragPos, fragmentNormal, fragmentTangent, isCap,
+                                                              fragmentAttribute, payloadHitT, b);
+    }
+    if (BANDS == LV_SHADE_BANDS) {
         // USE_BANDS in the triangle closest-hit shader (LineAttributesBarycentric.glsl:44-63): interpolated angle, line position and
         // line normal; useBand = true (no ANALYTIC_TUBE_INTERSECTIONS here, RayHitCommon.glsl:164-172)
         const float PI = 3.14159265358979323846f;
@@ -1158,15 +1213,16 @@ __device__ __forceinline__ f4 lv_shade_hit_triangle(const LvSceneDev& S, const L
         b.phi = (a0 * b0 + a1 * bu) + a2 * bv;
         b.linePosition = lerp3(lp0.linePosition, lp1.linePosition, lp2.linePosition);
         b.lineNormal = lerp3(lp0.lineNormal, lp1.lineNormal, lp2.lineNormal);
-        return lv_compute_fragment_color_t<true>(S, U, aoTexel, fragPos, fragmentNormal, fragmentTangent, isCap, fragmentAttribute,
-                                                 payloadHitT, b);
+        b.rotation = 0.0f;
+        return lv_compute_fragment_color_t<LV_SHADE_BANDS>(S, U, aoTexel, fragPos, fragmentNormal, fragmentTangent, isCap, fragmentAttribute,
+                                                           payloadHitT, b);
     }
     return lv_compute_fragment_color(S, U, aoTexel, fragPos, fragmentNormal, fragmentTangent, isCap, fragmentAttribute,
                                      payloadHitT);
 }
 
 // computeFragmentColor (RayHitCommon.glsl:74-543) for tubes, shared by the analytic and the triangle closest-hit paths
-template <bool BANDS>
+template <int BANDS>
 __device__ __forceinline__ f4 lv_compute_fragment_color_t(const LvSceneDev& S, const LvUniforms& U, float aoTexel, f3 fragPos,
                                                           f3 fragmentNormal, f3 fragmentTangent, bool isCap,
                                                           float fragmentAttribute, float& payloadHitT, const LvBandArgs& bands) {
@@ -1189,7 +1245,7 @@ __device__ __forceinline__ f4 lv_compute_fragment_color_t(const LvSceneDev& S, c
             if (dot3(t, crossProdVn) < 0.0f) ribbonPosition = -ribbonPosition;
             ribbonPosition2 = clampf(ribbonPosition2, -1.0f, 1.0f);
             if (fabsf(ribbonPosition2) < fabsf(ribbonPosition)) ribbonPosition = ribbonPosition2;
-        } else if (BANDS) {
+        } else if (BANDS == LV_SHADE_BANDS) {
             // USE_BANDS, RayHitCommon.glsl:232-351: the fragment's position between the two silhouette points of the elliptic
             // cross-section as the camera sees it -- tangent-plane coordinates, polar line of the camera point with respect to the
             // conic x^2 / thickness^2 + y^2 = 1, its two intersections with the conic from the degenerate conic B + alpha M_l
@@ -1289,7 +1345,7 @@ __device__ __forceinline__ f4 lv_compute_fragment_color_t(const LvSceneDev& S, c
     f3 hh = norm3(vv + l);
     f3 helperVecL = norm3(cross3(tB, l));
     f3 newL = norm3(cross3(helperVecL, tB));
-    const float exponent = (BANDS && bands.useBand) ? 1.0f : 1.7f; // Lighting.glsl:158-162
+    const float exponent = (BANDS == LV_SHADE_BANDS && bands.useBand) ? 1.0f : 1.7f; // Lighting.glsl:158-162
     float cosNormal1 = powf(clampf(fabsf(dot3(nB, l)), 0.0f, 1.0f), exponent);
     float cosNormal2 = powf(clampf(fabsf(dot3(nB, newL)), 0.0f, 1.0f), exponent);
     float cosNormalCombined = 0.3f * cosNormal1 + 0.7f * cosNormal2;
@@ -1320,15 +1376,30 @@ __device__ __forceinline__ f4 lv_compute_fragment_color_t(const LvSceneDev& S, c
     float fragmentDepth = len3(fragPos - cam);
     float aaO = ((fragmentDepth / U.lineWidth) * 0.05f) / float(U.height) * U.fovY;
     float aaW = ((fragmentDepth / U.lineWidth) * 2.0f) / float(U.height) * U.fovY;
-    if (BANDS) { // RayHitCommon.glsl:445-448
+    if (BANDS == LV_SHADE_BANDS) { // RayHitCommon.glsl:445-448
         const float wdt = bands.useBand ? U.bandWidth : U.lineWidth;
         aaO = aaW = ((fragmentDepth / wdt) * 0.25f) / float(U.height) * U.fovY;
     }
     float EPSILON_OUTLINE = clampf(aaO, 0.0f, 0.49f);
     float EPSILON_WHITE = clampf(aaW, 0.0f, 0.49f);
-    const float WHITE_THRESHOLD = 0.7f;
+    float WHITE_THRESHOLD = 0.7f;
+    if (BANDS == LV_SHADE_HELICITY) {
+        // RayHitCommon.glsl:455-486 (no multi-var rendering, no twist-line texture, no UNIFORM_HELICITY_BAND_WIDTH):
+        // drawSeparatorStripe (:57-64) darkens the shaded colour where mod(phi + rotation + w / 2, 2 pi / n) falls into [0, w]
+        const float separatorWidth = U.separatorBaseWidth;
+        const float period = 2.0f / float(U.numSubdivisionsBands) * 3.14159265358979323846f;
+        const float x = bands.phi + bands.rotation + separatorWidth * 0.5f;
+        const float varFraction = x - period * floorf(x / period); // mod(x, y) = x - y * floor(x / y)
+        const float aaf = EPSILON_OUTLINE * 10.0f;
+        const float alphaBorder1 = smoothstepf(aaf, 0.0f, varFraction);
+        const float alphaBorder2 = smoothstepf(separatorWidth - aaf * 0.5f, separatorWidth + aaf * 0.5f, varFraction);
+        const float m = fmaxf(alphaBorder1, alphaBorder2);
+#pragma unroll
+        for (int k = 0; k < 3; k++) phong[k] = phong[k] * m;
+        WHITE_THRESHOLD = 0.8f; // :485-486
+    }
     float coverage = U.useHalos ? 1.0f - smoothstepf(1.0f - EPSILON_OUTLINE, 1.0f, absCoords) : 1.0f;
-    if (BANDS && bands.useBand && U.useEllipticTubes) coverage = 1.0f; // ANALYTIC_ELLIPTIC_TUBE_INTERSECTIONS, :499-504
+    if (BANDS == LV_SHADE_BANDS && bands.useBand && U.useEllipticTubes) coverage = 1.0f; // ANALYTIC_ELLIPTIC_TUBE_INTERSECTIONS, :499-504
     float w = smoothstepf(WHITE_THRESHOLD - EPSILON_WHITE, WHITE_THRESHOLD + EPSILON_WHITE, absCoords);
     f4 out;
     out.x = mixf(phong[0], U.foreground[0], w);

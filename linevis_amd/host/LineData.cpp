@@ -302,6 +302,8 @@ bool LineDataFlow::loadFromFile(const std::string& filename) {
 bool LineData::renderThickBands = true;
 float LineData::minBandThickness = 0.15f;
 bool LineDataFlow::useRibbons = true;
+bool LineDataFlow::useRotatingHelicityBands = false;
+float LineDataFlow::separatorWidth = 0.2f;
 
 // LineDataFlow::setNewSettings, LineDataFlow.cpp:584-610
 bool LineDataFlow::setNewSettings(const SettingsMap& settings) {
@@ -324,6 +326,23 @@ bool LineDataFlow::setNewSettings(const SettingsMap& settings) {
         dirty = true;
         shallReloadGatherShader = true;
     }
+    // :601-624.  The twist-line texture and UNIFORM_HELICITY_BAND_WIDTH (a triangle-mesh-only variant: ClosestHitTubeAnalytic does not
+    // pass rotationSeparatorScale, TubeRayTracing.glsl:512-613) are not built; their keys are accepted and ignored.
+    b = useRotatingHelicityBands;
+    if (settings.getValueOpt("rotating_helicity_bands", b) && b != useRotatingHelicityBands) {
+        useRotatingHelicityBands = b;
+        if (useRotatingHelicityBands) useRibbons = false;
+        cachedAabbDataValid = false;
+        setTriangleRepresentationDirty();
+        dirty = true;
+        shallReloadGatherShader = true;
+    }
+    f = separatorWidth;
+    if (settings.getValueOpt("separator_width", f) && f != separatorWidth) { separatorWidth = f; dirty = true; }
+    int n = int(numSubdivisionsBands);
+    if (settings.getValueOpt("band_subdivisions", n) && n != int(numSubdivisionsBands) && n > 0) { numSubdivisionsBands = uint32_t(n); dirty = true; }
+    f = helicityRotationFactor;
+    if (settings.getValueOpt("helicity_rotation_factor", f) && f != helicityRotationFactor) { helicityRotationFactor = f; dirty = true; }
     return shallReloadGatherShader;
 }
 
@@ -333,6 +352,7 @@ void LineDataFlow::setTrajectoryData(const Trajectories& newTrajectories, const 
     trajectories = newTrajectories;
     ribbonsDirections = newRibbonsDirections;
     hasBandsData = !ribbonsDirections.empty(); // LineDataFlow.cpp:469
+    useRibbons = !useRotatingHelicityBands && hasBandsData; // :470
     if (hasBandsData) tubeNumSubdivisions = std::max(tubeNumSubdivisions, 8); // :482-484
     numTotalTrajectories = trajectories.size();
     numTotalTrajectoryPoints = 0;
@@ -346,7 +366,26 @@ void LineDataFlow::setTrajectoryData(const Trajectories& newTrajectories, const 
         float maxAttr = std::numeric_limits<float>::lowest();
         for (const Trajectory& t : trajectories)
             for (float val : t.attributes[varIdx]) { minAttr = std::min(minAttr, val); maxAttr = std::max(maxAttr, val); }
+        if (attributeNames[varIdx] == "Helicity") { // a symmetric range for the signed quantity, :522-526
+            const float maxAbs = std::max(std::abs(minAttr), std::abs(maxAttr));
+            minAttr = -maxAbs;
+            maxAttr = maxAbs;
+        }
         minMaxAttributeValues.emplace_back(minAttr, maxAttr);
+    }
+    // :535-550: the first attribute whose lower-case name contains "helicity" drives the rotating helicity bands
+    helicityAttributeIndex = -1;
+    for (size_t attrIdx = 0; attrIdx < attributeNames.size() && attrIdx < numAttr; attrIdx++) {
+        std::string lower = attributeNames[attrIdx];
+        for (char& ch : lower) ch = char(std::tolower((unsigned char)ch));
+        if (lower.find("helicity") != std::string::npos) { helicityAttributeIndex = int(attrIdx); break; }
+    }
+    hasHelicity = helicityAttributeIndex != -1;
+    if (hasHelicity) {
+        const auto& mm = minMaxAttributeValues[size_t(helicityAttributeIndex)];
+        maxHelicity = std::max(std::abs(mm.first), std::abs(mm.second));
+    } else {
+        useRotatingHelicityBands = false;
     }
     modelBoundingBox = computeTrajectoriesAABB3(trajectories);
     cachedAabbDataValid = false;
@@ -373,7 +412,10 @@ TubeAabbRenderData LineDataFlow::getLinePassTubeAabbRenderData(bool /*isRasteriz
     // elliptic tubes of a band data set: normals from the ribbon directions, boxes padded by half the band width (:2120-2126)
     const bool useRibbonNormals = ellipticTubes && useRibbons && hasBandsData;
     const float lineWidth = useRibbonNormals ? LineRenderer::getBandWidth() : LineRenderer::getLineWidth();
-    if (cachedAabbDataValid && cachedLineWidth == lineWidth && cachedEllipticTubes == useRibbonNormals) return cachedTubeAabbRenderData;
+    const bool helicityBands = getUseRotatingHelicityBands();
+    if (cachedAabbDataValid && cachedLineWidth == lineWidth && cachedEllipticTubes == useRibbonNormals &&
+        cachedHelicityBands == helicityBands)
+        return cachedTubeAabbRenderData;
     const vec3 lineWidthOffset(lineWidth * 0.5f);
     const size_t numLines = trajectories.size();
     std::vector<std::vector<LinePointDataUnified>> perLine(numLines);
@@ -386,6 +428,7 @@ TubeAabbRenderData LineDataFlow::getLinePassTubeAabbRenderData(bool /*isRasteriz
         if (n < 2) continue;
         out.reserve(n);
         vec3 lastLineNormal(1.0f, 0.0f, 0.0f);
+        float rotation = 0.0f; // useRotatingHelicityBands, :2148
         for (size_t i = 0; i < n; i++) {
             vec3 tangent;
             if (i == 0) tangent = trajectory.positions[i + 1] - trajectory.positions[i];
@@ -410,6 +453,13 @@ TubeAabbRenderData LineDataFlow::getLinePassTubeAabbRenderData(bool /*isRasteriz
                     ? 0.0f : trajectory.attributes[size_t(selectedAttributeIndex)][i];
             lp.lineTangent[0] = tangent.x; lp.lineTangent[1] = tangent.y; lp.lineTangent[2] = tangent.z;
             lp.lineNormal[0] = normal.x; lp.lineNormal[1] = normal.y; lp.lineNormal[2] = normal.z;
+            if (helicityBands) { // :2188-2197
+                lp.lineRotation = rotation;
+                const float helicity = trajectory.attributes[size_t(helicityAttributeIndex)][i];
+                float lineSegmentLength = 0.0f;
+                if (i < n - 1) lineSegmentLength = length(trajectory.positions[i + 1] - trajectory.positions[i]);
+                rotation += helicity / maxHelicity * 3.1415926535897932f * lineSegmentLength / 0.005f;
+            }
             out.push_back(lp);
         }
         if (out.size() <= 1) out.clear(); // a tube of one point is dropped
@@ -442,6 +492,7 @@ TubeAabbRenderData LineDataFlow::getLinePassTubeAabbRenderData(bool /*isRasteriz
     cachedAabbDataValid = true;
     cachedLineWidth = lineWidth;
     cachedEllipticTubes = useRibbonNormals;
+    cachedHelicityBands = helicityBands;
     return data;
 }
 
@@ -451,9 +502,11 @@ TubeTriangleRenderData LineDataFlow::getLinePassTubeTriangleMeshRenderData(bool 
     // band data: the reference is in its ribbon primitive mode then (setTrajectoryData, LineDataFlow.cpp:476-481), so its triangle
     // mesh is the elliptic tessellation with semi-axes bandWidth / 2 * minBandThickness and bandWidth / 2 (:1949-1975)
     const bool bands = useRibbons && hasBandsData;
+    const bool helicityBands = getUseRotatingHelicityBands();
     const float lineWidth = bands ? LineRenderer::getBandWidth() * minBandThickness : LineRenderer::getLineWidth();
     if (cachedTriangleDataValid && cachedTriangleLineWidth == lineWidth && cachedTriangleSubdivisions == tubeNumSubdivisions &&
-        cachedTriangleBands == bands && (!bands || cachedTriangleBandWidth == LineRenderer::getBandWidth()))
+        cachedTriangleBands == bands && (!bands || cachedTriangleBandWidth == LineRenderer::getBandWidth()) &&
+        cachedTriangleHelicityBands == helicityBands)
         return cachedTubeTriangleRenderData;
     std::vector<std::vector<vec3>> lineCentersList(trajectories.size());
     for (size_t i = 0; i < trajectories.size(); i++) lineCentersList[i] = trajectories[i].positions;
@@ -474,11 +527,21 @@ TubeTriangleRenderData LineDataFlow::getLinePassTubeTriangleMeshRenderData(bool 
 
     data.linePointDataBuffer.resize(linePointReferences.size());
     uint32_t lineStartIndex = 0, lastTrajectoryIndex = 0;
+    float rotation = 0.0f; // useRotatingHelicityBands: runs on across the trajectories here (:1994)
     for (size_t i = 0; i < linePointReferences.size(); i++) {
         const LinePointReference& ref = linePointReferences[i];
         const Trajectory& trajectory = trajectories[ref.trajectoryIndex];
         LinePointDataUnified& lp = data.linePointDataBuffer[i];
         memset(&lp, 0, sizeof(lp));
+        if (helicityBands) { // :2014-2028
+            lp.lineRotation = rotation;
+            const float helicity = trajectory.attributes[size_t(helicityAttributeIndex)][ref.linePointIndex];
+            float lineSegmentLength = 0.0f;
+            if (i + 1 < linePointReferences.size() && linePointReferences[i + 1].trajectoryIndex == ref.trajectoryIndex)
+                lineSegmentLength = length(trajectory.positions[linePointReferences[i + 1].linePointIndex] -
+                                           trajectory.positions[ref.linePointIndex]);
+            rotation += helicity / maxHelicity * 3.1415926535897932f * lineSegmentLength / 0.005f;
+        }
         const vec3& p = trajectory.positions[ref.linePointIndex];
         lp.linePosition[0] = p.x; lp.linePosition[1] = p.y; lp.linePosition[2] = p.z;
         lp.lineAttribute = trajectory.attributes.empty()
@@ -496,6 +559,7 @@ TubeTriangleRenderData LineDataFlow::getLinePassTubeTriangleMeshRenderData(bool 
     cachedTriangleLineWidth = lineWidth;
     cachedTriangleSubdivisions = tubeNumSubdivisions;
     cachedTriangleBands = bands;
+    cachedTriangleHelicityBands = helicityBands;
     cachedTriangleBandWidth = LineRenderer::getBandWidth();
     return data;
 }

@@ -88,6 +88,11 @@ public:
     bool getUseHalos() const { return useHalos; }
     /// USE_BANDS of the ray tracer's shaders (getVulkanShaderPreprocessorDefines with isRasterizer = false)
     virtual bool getUseBands() const { return false; }
+    /// USE_ROTATING_HELICITY_BANDS + the LineUniformData members it reads (LineDataFlow.cpp:979-984,2432-2440)
+    virtual bool getUseRotatingHelicityBands() const { return false; }
+    virtual float getSeparatorWidth() const { return 0.2f; }
+    virtual uint32_t getNumSubdivisionsBands() const { return 6u; }
+    virtual float getHelicityRotationFactor() const { return 1.0f; }
     static bool getRenderThickBands() { return renderThickBands; }   // LineData.cpp:53
     static float getMinBandThickness() { return minBandThickness; }  // LineData.cpp:54
     int getTubeNumSubdivisions() const { return tubeNumSubdivisions; }
@@ -136,7 +141,15 @@ public:
     const std::vector<std::vector<vec3>>& getRibbonsDirections() const { return ribbonsDirections; }
     bool getHasBandsData() const { return hasBandsData; }
     /// USE_BANDS: useRibbons && hasBandsData (LineDataFlow.cpp:2423); use_ribbons / thick_bands / min_band_thickness keys :587-606
-    bool getUseBands() const override { return useRibbons && hasBandsData; }
+    /// (USE_BANDS also needs !useRotatingHelicityBands there; rotating_helicity_bands = true switches useRibbons off, :601-604)
+    bool getUseBands() const override { return useRibbons && hasBandsData && !getUseRotatingHelicityBands(); }
+    /// "Show Helicity Bands": rotating_helicity_bands, only for data with an attribute whose name contains "helicity" (:535-550)
+    bool getHasHelicity() const { return hasHelicity; }
+    float getMaxHelicity() const { return maxHelicity; }
+    bool getUseRotatingHelicityBands() const override { return useRotatingHelicityBands && hasHelicity; }
+    float getSeparatorWidth() const override { return separatorWidth; }
+    uint32_t getNumSubdivisionsBands() const override { return numSubdivisionsBands; }
+    float getHelicityRotationFactor() const override { return helicityRotationFactor; }
     bool setNewSettings(const SettingsMap& settings) override;
 
     size_t getNumLines() override { return numTotalTrajectories; }
@@ -151,6 +164,14 @@ private:
     std::vector<std::vector<vec3>> ribbonsDirections; // LineDataFlow.hpp:160
     bool hasBandsData = false;
     static bool useRibbons;                            // LineDataFlow.cpp:51
+    static bool useRotatingHelicityBands;              // LineDataFlow.cpp:52
+    static float separatorWidth;                       // LineDataFlow.cpp:54 (0.2)
+    int helicityAttributeIndex = -1;
+    bool hasHelicity = false;
+    float maxHelicity = 0.0f;
+    float helicityRotationFactor = 1.0f;               // LineDataFlow.hpp:171
+    uint32_t numSubdivisionsBands = 6;                 // LineDataFlow.hpp:188
+    bool cachedHelicityBands = false, cachedTriangleHelicityBands = false;
     size_t numTotalTrajectories = 0, numTotalTrajectoryPoints = 0;
     TubeAabbRenderData cachedTubeAabbRenderData;
     float cachedLineWidth = -1.0f;

@@ -332,6 +332,13 @@ bool LineRenderer::uploadFrameState() {
         setOption("min_band_thickness", buf);
         snprintf(buf, sizeof(buf), "%.9g", double(bandWidth));
         setOption("band_width", buf);
+        // USE_ROTATING_HELICITY_BANDS + its LineUniformData members (LineDataFlow.cpp:979-984,2432-2440); the points carry lineRotation
+        setOption("rotating_helicity_bands", lineData->getUseRotatingHelicityBands() ? "true" : "false");
+        snprintf(buf, sizeof(buf), "%.9g", double(lineData->getSeparatorWidth()));
+        setOption("separator_width", buf);
+        setOption("band_subdivisions", std::to_string(lineData->getNumSubdivisionsBands()));
+        snprintf(buf, sizeof(buf), "%.9g", double(lineData->getHelicityRotationFactor()));
+        setOption("helicity_rotation_factor", buf);
         // getVulkanShaderPreprocessorDefines, LineData.cpp:1209-1256
         setOption("use_capped_tubes", lineData->getUseCappedTubes() ? "true" : "false");
         setOption("use_halos", lineData->getUseHalos() ? "true" : "false");

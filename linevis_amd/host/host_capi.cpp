@@ -64,6 +64,40 @@ void lvh_flow_set_trajectories_ribbons(void* hp, const float* positions, const f
     }
     h->flow()->setTrajectoryData(tr, {}, ribbons);
 }
+/// several attributes per point (attributes: nAttributes arrays of n floats, one after the other) with their names -- an attribute
+/// whose name contains "helicity" enables the rotating helicity bands (LineDataFlow.cpp:535-550); ribbonDirections may be NULL
+void lvh_flow_set_trajectories_multi(void* hp, const float* positions, const float* attributes, uint32_t nAttributes,
+                                     const char* const* names, const uint32_t* lineOffsets, uint32_t nLines,
+                                     const float* ribbonDirections) {
+    FlowHandle* h = static_cast<FlowHandle*>(hp);
+    Trajectories tr(nLines);
+    std::vector<std::vector<vec3>> ribbons(ribbonDirections ? nLines : 0);
+    const size_t n = lineOffsets[nLines];
+    for (uint32_t i = 0; i < nLines; i++) {
+        uint32_t b = lineOffsets[i], e = lineOffsets[i + 1];
+        tr[i].positions.resize(e - b);
+        memcpy(tr[i].positions.data(), positions + 3 * size_t(b), size_t(e - b) * 12);
+        tr[i].attributes.resize(nAttributes);
+        for (uint32_t a = 0; a < nAttributes; a++) tr[i].attributes[a].assign(attributes + a * n + b, attributes + a * n + e);
+        if (ribbonDirections) {
+            ribbons[i].resize(e - b);
+            memcpy(ribbons[i].data(), ribbonDirections + 3 * size_t(b), size_t(e - b) * 12);
+        }
+    }
+    std::vector<std::string> nm;
+    for (uint32_t a = 0; a < nAttributes; a++) nm.push_back(names[a]);
+    h->flow()->setTrajectoryData(tr, nm, ribbons);
+}
+void lvh_flow_set_selected_attribute(void* hp, int idx) { static_cast<FlowHandle*>(hp)->data->setSelectedAttributeIndex(idx); }
+/// LineDataFlow::setNewSettings on the data set alone (the renderer's harness forwards its settings map too)
+void lvh_flow_set_settings(void* hp, const char* const* keys, const char* const* values, uint32_t n) {
+    SettingsMap m;
+    for (uint32_t i = 0; i < n; i++) m.addKeyValue(std::string(keys[i]), values[i]);
+    static_cast<FlowHandle*>(hp)->data->setNewSettings(m);
+}
+int lvh_flow_has_helicity(void* hp) { return static_cast<FlowHandle*>(hp)->flow()->getHasHelicity() ? 1 : 0; }
+float lvh_flow_max_helicity(void* hp) { return static_cast<FlowHandle*>(hp)->flow()->getMaxHelicity(); }
+int lvh_flow_use_rotating_helicity_bands(void* hp) { return static_cast<FlowHandle*>(hp)->flow()->getUseRotatingHelicityBands() ? 1 : 0; }
 int lvh_flow_has_bands_data(void* hp) { return static_cast<FlowHandle*>(hp)->flow()->getHasBandsData() ? 1 : 0; }
 /// ribbon directions flattened like lvh_flow_get_trajectories' positions (n * 3 floats); no band data: nothing written
 void lvh_flow_get_ribbon_directions(void* hp, float* out) {
@@ -281,6 +315,13 @@ void lvh_grid_copy_ribbons(void* hp, float* ribbonDirections) {
     }
 }
 int lvh_grid_num_scalar_fields(void* hp) { return int(static_cast<GridHandle*>(hp)->grid.getScalarFieldNames().size()); }
+/// name of the idx-th scalar field (= attribute idx of the traced lines); copied into out (capacity bytes incl. the terminator)
+int lvh_grid_scalar_field_name(void* hp, int idx, char* out, uint32_t capacity) {
+    const std::vector<std::string> names = static_cast<GridHandle*>(hp)->grid.getScalarFieldNames();
+    if (idx < 0 || size_t(idx) >= names.size() || capacity == 0) return -1;
+    snprintf(out, capacity, "%s", names[size_t(idx)].c_str());
+    return 0;
+}
 /// positions n*3, attributes [k][n] (scalar fields in name order), offsets numLines+1
 void lvh_grid_copy_result(void* hp, float* positions, float* attributes, uint32_t* offsets) {
     const Trajectories& tr = static_cast<GridHandle*>(hp)->result;

@@ -29,6 +29,12 @@ def load():
         "lvh_flow_destroy": (None, [vp]),
         "lvh_flow_set_trajectories": (None, [vp, vp, vp, vp, u32]),
         "lvh_flow_set_trajectories_ribbons": (None, [vp, vp, vp, vp, u32, vp]),
+        "lvh_flow_set_trajectories_multi": (None, [vp, vp, vp, u32, vp, vp, u32, vp]),
+        "lvh_flow_set_selected_attribute": (None, [vp, C.c_int]),
+        "lvh_flow_set_settings": (None, [vp, vp, vp, u32]),
+        "lvh_flow_has_helicity": (C.c_int, [vp]),
+        "lvh_flow_max_helicity": (C.c_float, [vp]),
+        "lvh_flow_use_rotating_helicity_bands": (C.c_int, [vp]),
         "lvh_flow_has_bands_data": (i32, [vp]),
         "lvh_flow_get_ribbon_directions": (None, [vp, vp]),
         "lvh_flow_build_render_data_elliptic": (None, [vp, f32, C.POINTER(u32), C.POINTER(u32)]),
@@ -59,6 +65,7 @@ def load():
         "lvh_grid_trace_ribbons": (i32, [vp, vp, u32, i32, i32, f32, i32, f32, f32, i32, f32, vp, C.POINTER(u64), C.POINTER(u64)]),
         "lvh_grid_copy_ribbons": (None, [vp, vp]),
         "lvh_grid_num_scalar_fields": (i32, [vp]),
+        "lvh_grid_scalar_field_name": (i32, [vp, i32, vp, u32]),
         "lvh_grid_last_error": (cp, [vp]),
         "lvh_renderer_create": (vp, [i32, i32]),
         "lvh_renderer_destroy": (None, [vp]),
@@ -119,6 +126,40 @@ class LineDataFlow:
             assert rib.shape == pos.shape
             self.L.lvh_flow_set_trajectories_ribbons(self.h, _p(pos), _p(att), _p(off), len(off) - 1, _p(rib))
         return self
+
+    def set_trajectories_multi(self, positions, attributes, names, line_offsets, ribbon_directions=None, selected=0):
+        """setTrajectoryData with several attributes per point (attributes[a][n]) and their names; an attribute whose name contains
+        "helicity" makes the rotating helicity bands available (LineDataFlow.cpp:535-550)."""
+        pos = np.ascontiguousarray(positions, dtype=np.float32)
+        att = np.ascontiguousarray(attributes, dtype=np.float32)
+        off = np.ascontiguousarray(line_offsets, dtype=np.uint32)
+        assert att.ndim == 2 and att.shape[1] == len(pos) and len(names) == att.shape[0]
+        nm = (C.c_char_p * len(names))(*[n.encode() for n in names])
+        rib = None if ribbon_directions is None else np.ascontiguousarray(ribbon_directions, dtype=np.float32)
+        self.L.lvh_flow_set_trajectories_multi(self.h, _p(pos), _p(att), att.shape[0], nm, _p(off), len(off) - 1,
+                                               _p(rib) if rib is not None else None)
+        self.L.lvh_flow_set_selected_attribute(self.h, int(selected))
+        return self
+
+    def set_new_settings(self, settings):
+        """LineDataFlow::setNewSettings (use_ribbons, thick_bands, rotating_helicity_bands, separator_width, ...)."""
+        keys = [k.encode() for k in settings]
+        vals = [capi._fmt(v).encode() for v in settings.values()]
+        n = len(keys)
+        self.L.lvh_flow_set_settings(self.h, (C.c_char_p * n)(*keys), (C.c_char_p * n)(*vals), n)
+        return self
+
+    @property
+    def has_helicity(self):
+        return bool(self.L.lvh_flow_has_helicity(self.h))
+
+    @property
+    def max_helicity(self):
+        return float(self.L.lvh_flow_max_helicity(self.h))
+
+    @property
+    def use_rotating_helicity_bands(self):
+        return bool(self.L.lvh_flow_use_rotating_helicity_bands(self.h))
 
     @property
     def has_bands_data(self):
@@ -279,6 +320,15 @@ class StreamlineTracingGrid:
         box = np.zeros(6, dtype=np.float32)
         self.L.lvh_grid_info(self.h, _p(sizes), _p(spacing), _p(box))
         return sizes, spacing, box
+
+    def attribute_names(self):
+        """Names of the scalar fields = the attributes of the traced lines, in attribute order."""
+        out = []
+        for i in range(int(self.L.lvh_grid_num_scalar_fields(self.h))):
+            buf = C.create_string_buffer(256)
+            self.L.lvh_grid_scalar_field_name(self.h, i, buf, 256)
+            out.append(buf.value.decode())
+        return out
 
     def regular_seeds(self, nx, ny, nz):
         out = np.zeros((nx * ny * nz, 3), dtype=np.float32)

@@ -614,9 +614,13 @@ inline void blinnPhongShadingTube(const lvo_params& P, const Frame& F, float aoT
 
 // USE_BANDS arguments of computeFragmentColor (RayHitCommon.glsl:82-90,148-190)
 struct BandArgs { bool useBand; float phi; V3 linePosition, lineNormal; };
+// USE_ROTATING_HELICITY_BANDS arguments of computeFragmentColor (RayHitCommon.glsl:82-93): the angle around the tube and the
+// interpolated lineRotation x helicityRotationFactor
+struct HelicityArgs { float phi, fragmentRotation; };
 inline void computeFragmentColor(const lvo_scene& sc, const lvo_params& P, const Frame& F, float aoTexel, V3 fragPos,
                                  V3 fragmentNormal, V3 fragmentTangent, bool isCap, float fragmentAttribute,
-                                 float hitColor[4], float& payloadHitT, const BandArgs* bands = nullptr);
+                                 float hitColor[4], float& payloadHitT, const BandArgs* bands = nullptr,
+                                 const HelicityArgs* hel = nullptr);
 
 // Static RTAO prebaking: AO factors per (parametrisation vertex, angular subdivision) + the per-line-vertex blending
 // weights that map a line vertex id to the parametrisation (VulkanAmbientOcclusionBaker.cpp:563-653).
@@ -689,6 +693,20 @@ inline void shadeHit(const lvo_scene& sc, const lvo_params& P, const Frame& F, f
         float fragmentVertexId = (1.0f - ts) * float(i0) + ts * float(i1);
         aoTexel = prebakedAoLookup(*pb, fragmentVertexId, phi);
     }
+    if (P.useHelicityBands) {
+        // USE_ROTATING_HELICITY_BANDS, TubeRayTracing.glsl:551-567: phi as for the AO lookup (acos through the build's atan2),
+        // fragmentRotation = lerp(lineRotation) * helicityRotationFactor
+        const float ts = h.kind == 0 ? dot(v, fragPos - P0) / dot(v, v) : (h.kind == 1 ? 0.0f : 1.0f);
+        const V3 lineNormal = (1.0f - ts) * ld3(lp0.lineNormal) + ts * ld3(lp1.lineNormal);
+        const float cphi = clampf(dot(fragmentNormal, lineNormal), -1.0f, 1.0f);
+        HelicityArgs hl;
+        hl.phi = atan2Det(sqrtf((1.0f - cphi) * (1.0f + cphi)), cphi);
+        if (dot(lineNormal, cross(fragmentNormal, fragmentTangent)) < 0.0f) hl.phi = 2.0f * 3.14159265358979323846f - hl.phi;
+        hl.fragmentRotation = ((1.0f - ts) * lp0.lineRotation + ts * lp1.lineRotation) * P.helicityRotationFactor;
+        computeFragmentColor(sc, P, F, aoTexel, fragPos, fragmentNormal, fragmentTangent, isCap, fragmentAttribute, hitColor,
+                             payloadHitT, nullptr, &hl);
+        return;
+    }
     if (P.useBands) {
         // band data with the circular analytic tubes: USE_BANDS is defined, ANALYTIC_TUBE_INTERSECTIONS sets useBand = false
         // (RayHitCommon.glsl:164-166); phi and the line normal as TubeRayTracing.glsl:551-560 (acos through the build's atan2)
@@ -755,7 +773,7 @@ inline void shadeHitElliptic(const lvo_scene& sc, const lvo_params& P, const Fra
 // computeFragmentColor (RayHitCommon.glsl:74-543) for tubes: shared by the analytic and the triangle closest-hit shaders
 inline void computeFragmentColor(const lvo_scene& sc, const lvo_params& P, const Frame& F, float aoTexel, V3 fragPos,
                                  V3 fragmentNormal, V3 fragmentTangent, bool isCap, float fragmentAttribute,
-                                 float hitColor[4], float& payloadHitT, const BandArgs* bands) {
+                                 float hitColor[4], float& payloadHitT, const BandArgs* bands, const HelicityArgs* hel) {
     float fragmentColor[4];
     transferFunction(sc, P, fragmentAttribute, fragmentColor);
     V3 n = normalize(fragmentNormal);
@@ -855,7 +873,21 @@ inline void computeFragmentColor(const lvo_scene& sc, const lvo_params& P, const
     }
     float EPSILON_OUTLINE = clampf(aaO, 0.0f, 0.49f);
     float EPSILON_WHITE = clampf(aaW, 0.0f, 0.49f);
-    const float WHITE_THRESHOLD = 0.7f;
+    float WHITE_THRESHOLD = 0.7f;
+    if (hel) {
+        // RayHitCommon.glsl:455-486 (no multi-var rendering, no twist-line texture, no UNIFORM_HELICITY_BAND_WIDTH):
+        // drawSeparatorStripe (:57-64) darkens the shaded colour where mod(phi + rotation + w / 2, 2 pi / n) falls into [0, w]
+        const float separatorWidth = P.separatorBaseWidth;
+        const float period = 2.0f / float(P.numSubdivisionsBands) * 3.14159265358979323846f;
+        const float x = hel->phi + hel->fragmentRotation + separatorWidth * 0.5f;
+        const float varFraction = x - period * floorf(x / period); // mod(x, y) = x - y * floor(x / y)
+        const float aaf = EPSILON_OUTLINE * 10.0f;
+        const float alphaBorder1 = smoothstepf(aaf, 0.0f, varFraction);
+        const float alphaBorder2 = smoothstepf(separatorWidth - aaf * 0.5f, separatorWidth + aaf * 0.5f, varFraction);
+        const float m = fmaxf(alphaBorder1, alphaBorder2);
+        for (int k = 0; k < 3; k++) shaded[k] = shaded[k] * m;
+        WHITE_THRESHOLD = 0.8f; // :485-486
+    }
     float coverage = P.useHalos ? 1.0f - smoothstepf(1.0f - EPSILON_OUTLINE, 1.0f, absCoords) : 1.0f;
     if (bands && bands->useBand && P.useEllipticTubes) coverage = 1.0f; // ANALYTIC_ELLIPTIC_TUBE_INTERSECTIONS, :499-504
     float w = smoothstepf(WHITE_THRESHOLD - EPSILON_WHITE, WHITE_THRESHOLD + EPSILON_WHITE, absCoords);
@@ -956,6 +988,17 @@ void lvo_normalize_positions(float* p, uint64_t n) {
         for (int k = 0; k < 3; k++) p[3 * i + k] = (p[3 * i + k] + tr[k]) * scale;
 }
 
+static const float* g_helicities = nullptr;
+static float g_maxHelicity = 1.0f;
+void lvo_set_helicity_source(const float* helicities, float maxHelicity) {
+    g_helicities = helicities;
+    g_maxHelicity = maxHelicity;
+}
+const float* lvo_get_helicity_source(float* maxHelicity) {
+    *maxHelicity = g_maxHelicity;
+    return g_helicities;
+}
+
 // LineDataFlow.cpp:2112-2277
 static void buildTubeAabbRenderData(
         const float* positions, const float* attributes, const uint32_t* lineOffsets, uint32_t nLines, float lineWidth,
@@ -989,6 +1032,7 @@ static void buildTubeAabbRenderData(
         uint32_t n = e - b;
         V3 lastLineNormal = v3(1.0f, 0.0f, 0.0f);
         uint32_t numValidLinePoints = 0;
+        float rotation = 0.0f; // useRotatingHelicityBands: restarts with every trajectory (:2148)
         for (uint32_t i = 0; i < n; i++) {
             if (n < 2) break; // a one-point trajectory has no neighbour to difference against
             V3 tangent;
@@ -1013,6 +1057,13 @@ static void buildTubeAabbRenderData(
             lp.lineAttribute = attributes[b + i];
             lp.lineTangent[0] = tangent.x; lp.lineTangent[1] = tangent.y; lp.lineTangent[2] = tangent.z;
             lp.lineNormal[0] = normal.x; lp.lineNormal[1] = normal.y; lp.lineNormal[2] = normal.z;
+            if (g_helicities) { // :2188-2197 (a point skipped above does not advance the rotation)
+                lp.lineRotation = rotation;
+                const float helicity = g_helicities[b + i];
+                float lineSegmentLength = 0.0f;
+                if (i < n - 1) lineSegmentLength = length(ld3(positions + 3 * (b + i + 1)) - pi);
+                rotation += helicity / g_maxHelicity * 3.1415926535897932f * lineSegmentLength / 0.005f;
+            }
             outPoints[nOut++] = lp;
             numValidLinePoints++;
         }
@@ -1362,6 +1413,36 @@ inline void shadeHitTri(const lvo_scene& sc, const lvo_tri_scene& tsc, const lvo
                                   float(vd1.vertexLinePointIndex & 0x7FFFFFFFu) * bc.y) +
                                  float(vd2.vertexLinePointIndex & 0x7FFFFFFFu) * bc.z;
         aoT = prebakedAoLookup(*pb, fragmentVertexId, phi);
+    }
+    if (P.useHelicityBands) {
+        // USE_ROTATING_HELICITY_BANDS in the triangle closest-hit shader (LineAttributesBarycentric.glsl:43-92): interpolated angle,
+        // interpolated lineRotation x helicityRotationFactor; on the caps the rotation is continued linearly along the line
+        // (distance of the fragment to the plane through the end point x the rotation per length of the end segment)
+        const float PI = 3.14159265358979323846f;
+        float a0 = vd0.phi, a1 = vd1.phi, a2 = vd2.phi;
+        if (a1 - a0 > PI || a2 - a0 > PI) a0 += 2.0f * PI;
+        if (a0 - a1 > PI || a2 - a1 > PI) a1 += 2.0f * PI;
+        if (a0 - a2 > PI || a1 - a2 > PI) a2 += 2.0f * PI;
+        HelicityArgs hl;
+        hl.phi = (a0 * bc.x + a1 * bc.y) + a2 * bc.z;
+        const float f = P.helicityRotationFactor;
+        hl.fragmentRotation = ((lp0.lineRotation * f) * bc.x + (lp1.lineRotation * f) * bc.y) + (lp2.lineRotation * f) * bc.z;
+        if (isCap) {
+            const uint32_t i0 = vd0.vertexLinePointIndex & 0x7FFFFFFFu;
+            const lvo_line_point* other = nullptr;
+            if (i0 != 0u && tsc.pts[i0 - 1].lineStartIndex == lp0.lineStartIndex) other = &tsc.pts[i0 - 1];
+            if (!other) other = &tsc.pts[i0 + 1];
+            const float fragmentRotationDelta = (lp0.lineRotation - other->lineRotation) * f;
+            V3 planeNormal = ld3(lp0.linePosition) - ld3(other->linePosition);
+            const float segmentLength = length(planeNormal);
+            planeNormal = v3(planeNormal.x / segmentLength, planeNormal.y / segmentLength, planeNormal.z / segmentLength);
+            const float planeDist = -dot(planeNormal, ld3(lp0.linePosition));
+            const float distToPlane = dot(planeNormal, fragPos) + planeDist;
+            hl.fragmentRotation += fragmentRotationDelta * distToPlane / segmentLength;
+        }
+        computeFragmentColor(sc, P, F, aoT, fragPos, fragmentNormal, fragmentTangent, isCap, fragmentAttribute, hc, payloadHitT,
+                             nullptr, &hl);
+        return;
     }
     if (P.useBands) {
         // USE_BANDS in the triangle closest-hit shader (LineAttributesBarycentric.glsl:44-63): interpolated angle, line position and

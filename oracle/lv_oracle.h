@@ -89,6 +89,12 @@ typedef struct {
     /* geometry_mode "Linear Swept Spheres": capsules with their caps whatever useCappedTubes says (it then only decides whether
      * the shading sees isCap), exact closest-approach roots (TubeRayTracing.glsl:621-737, LineData.cpp:909-945) */
     uint32_t lssGeometry;
+    /* USE_ROTATING_HELICITY_BANDS (LineDataFlow.cpp:2432-2440; never together with USE_BANDS, :470,601-604): separator stripes
+     * that rotate around the tube with lineRotation; LineUniformData separatorBaseWidth / helicityRotationFactor /
+     * numSubdivisionsBands (LineDataFlow.cpp:979-984, defaults 0.2 / 1 / 6) */
+    uint32_t useHelicityBands;
+    uint32_t numSubdivisionsBands;
+    float separatorBaseWidth, helicityRotationFactor;
 } lvo_params;
 
 typedef struct {
@@ -118,6 +124,13 @@ void lvo_normalize_positions(float* positions /* n*3 in/out */, uint64_t n);
  * lineOffsets[nLines+1]: start index of each line.
  * Outputs must be sized for the worst case (nPoints, 2*nPoints, 6*nPoints).
  * Returns number of output points via *outNumPoints and segments via *outNumSegments. */
+/* useRotatingHelicityBands of the render-data builders (LineDataFlow.cpp:2188-2196, 2014-2027): while a source is set,
+ * lineRotation of every emitted line point = the rotation accumulated so far, then += helicity / maxHelicity * PI * length of
+ * the segment to the next trajectory point / 0.005.  helicities is indexed like the trajectory points handed to the builders
+ * (tube AABB data: restarts per trajectory; triangle data: runs on across trajectories, as the reference's loop does).
+ * NULL switches it off. */
+void lvo_set_helicity_source(const float* helicities, float maxHelicity);
+const float* lvo_get_helicity_source(float* maxHelicity);
 void lvo_build_tube_aabb_render_data(
         const float* positions, const float* attributes, const uint32_t* lineOffsets, uint32_t nLines,
         float lineWidth,

@@ -210,10 +210,23 @@ void tessellate(const float* positions, const float* attributes, const uint32_t*
     // LineDataFlow.cpp:1996-2020
     m.pts.resize(refLine.size());
     uint32_t lineStartIndex = 0, lastTrajectoryIndex = 0;
+    float rotation = 0.0f; // useRotatingHelicityBands: NOT reset between trajectories here (LineDataFlow.cpp:1994)
+    float maxHelicity = 1.0f;
+    const float* helicities = lvo_get_helicity_source(&maxHelicity);
     for (size_t i = 0; i < refLine.size(); i++) {
         lvo_line_point lp;
         memset(&lp, 0, sizeof(lp));
         size_t src = size_t(lineOffsets[refLine[i]]) + refPoint[i];
+        if (helicities) { // :2014-2028
+            lp.lineRotation = rotation;
+            const float helicity = helicities[src];
+            float lineSegmentLength = 0.0f;
+            if (i + 1 < refLine.size() && refLine[i] == refLine[i + 1]) {
+                const size_t nxt = size_t(lineOffsets[refLine[i + 1]]) + refPoint[i + 1];
+                lineSegmentLength = length(ld3(positions + 3 * nxt) - ld3(positions + 3 * src));
+            }
+            rotation += helicity / maxHelicity * 3.1415926535897932f * lineSegmentLength / 0.005f;
+        }
         for (int k = 0; k < 3; k++) lp.linePosition[k] = positions[3 * src + k];
         lp.lineAttribute = attributes[src];
         lp.lineTangent[0] = lineTangents[i].x; lp.lineTangent[1] = lineTangents[i].y; lp.lineTangent[2] = lineTangents[i].z;

@@ -59,6 +59,8 @@ class Params(C.Structure):
         ("useBands", C.c_uint32), ("useEllipticTubes", C.c_uint32),
         ("bandWidth", C.c_float), ("minBandThickness", C.c_float), ("minThickness", C.c_float),
         ("lssGeometry", C.c_uint32),
+        ("useHelicityBands", C.c_uint32), ("numSubdivisionsBands", C.c_uint32),
+        ("separatorBaseWidth", C.c_float), ("helicityRotationFactor", C.c_float),
     ]
 
 
@@ -118,6 +120,7 @@ def lib():
     L.lvo_atan2_det.restype = f32
     L.lvo_atan2_det.argtypes = [f32, f32]
     L.lvo_normalize_positions.argtypes = [vp, C.c_uint64]
+    L.lvo_set_helicity_source.argtypes = [vp, f32]
     L.lvo_build_tube_aabb_render_data.argtypes = [vp, vp, vp, u32, f32, vp, C.POINTER(u32), vp, vp, C.POINTER(u32)]
     L.lvo_build_tube_aabb_render_data_ribbons.argtypes = [vp, vp, vp, u32, f32, vp, vp, C.POINTER(u32), vp, vp, C.POINTER(u32)]
     L.lvo_trace_rays_elliptic.argtypes = [vp, f32, f32, vp, i32, vp, vp, f32, f32, u32, vp, vp]
@@ -226,8 +229,27 @@ def normalize_positions(positions):
     return p
 
 
-def build_tube_aabb_render_data(positions, attributes, line_offsets, line_width):
-    """a2 (LineDataFlow.cpp:2112-2277): returns (points[48B], seg_indices[S,2], aabbs[S,6])."""
+class _HelicitySource:
+    """useRotatingHelicityBands of the render-data builders: lineRotation from a per-point helicity attribute
+    (LineDataFlow.cpp:2188-2196, 2014-2027); max_helicity = max |helicity| over the data set (:543-548)."""
+
+    def __init__(self, helicities, max_helicity):
+        self.h = None if helicities is None else np.ascontiguousarray(helicities, dtype=np.float32)
+        self.m = max_helicity
+
+    def __enter__(self):
+        if self.h is not None:
+            m = float(np.abs(self.h).max()) if self.m is None else float(self.m)
+            lib().lvo_set_helicity_source(_p(self.h), m)
+
+    def __exit__(self, *a):
+        if self.h is not None:
+            lib().lvo_set_helicity_source(None, 1.0)
+
+
+def build_tube_aabb_render_data(positions, attributes, line_offsets, line_width, helicities=None, max_helicity=None):
+    """a2 (LineDataFlow.cpp:2112-2277): returns (points[48B], seg_indices[S,2], aabbs[S,6]).  helicities: per-point helicity
+    attribute -> lineRotation (useRotatingHelicityBands)."""
     pos = np.ascontiguousarray(positions, dtype=np.float32)
     att = np.ascontiguousarray(attributes, dtype=np.float32)
     off = np.ascontiguousarray(line_offsets, dtype=np.uint32)
@@ -236,8 +258,9 @@ def build_tube_aabb_render_data(positions, attributes, line_offsets, line_width)
     seg = np.zeros((max(n, 1), 2), dtype=np.uint32)
     aabb = np.zeros((max(n, 1), 6), dtype=np.float32)
     npts, nseg = C.c_uint32(), C.c_uint32()
-    lib().lvo_build_tube_aabb_render_data(_p(pos), _p(att), _p(off), len(off) - 1, line_width, _p(pts),
-                                          C.byref(npts), _p(seg), _p(aabb), C.byref(nseg))
+    with _HelicitySource(helicities, max_helicity):
+        lib().lvo_build_tube_aabb_render_data(_p(pos), _p(att), _p(off), len(off) - 1, line_width, _p(pts),
+                                              C.byref(npts), _p(seg), _p(aabb), C.byref(nseg))
     return pts[:npts.value].copy(), seg[:nseg.value].copy(), aabb[:nseg.value].copy()
 
 
@@ -259,9 +282,10 @@ def build_tube_aabb_render_data_ribbons(positions, attributes, line_offsets, ban
     return pts[:npts.value].copy(), seg[:nseg.value].copy(), aabb[:nseg.value].copy()
 
 
-def build_tube_triangle_render_data(positions, attributes, line_offsets, line_width, num_subdivisions=6):
+def build_tube_triangle_render_data(positions, attributes, line_offsets, line_width, num_subdivisions=6, helicities=None,
+                                    max_helicity=None):
     """a14 (CappedTriangleTubesCPU.cpp:214-383 + LineDataFlow.cpp:1912-2110): returns
-    (triangle_indices[T,3], vertices[32B], line_points[48B])."""
+    (triangle_indices[T,3], vertices[32B], line_points[48B]).  helicities: per-point helicity attribute -> lineRotation."""
     pos = np.ascontiguousarray(positions, dtype=np.float32)
     att = np.ascontiguousarray(attributes, dtype=np.float32)
     off = np.ascontiguousarray(line_offsets, dtype=np.uint32)
@@ -271,7 +295,8 @@ def build_tube_triangle_render_data(positions, attributes, line_offsets, line_wi
     idx = np.zeros(max(ni.value, 1), dtype=np.uint32)
     verts = np.zeros(max(nv.value, 1), dtype=TUBE_VERTEX_DTYPE)
     pts = np.zeros(max(npt.value, 1), dtype=LINE_POINT_DTYPE)
-    lib().lvo_build_tube_triangle_render_data(*args, _p(idx), C.byref(ni), _p(verts), C.byref(nv), _p(pts), C.byref(npt))
+    with _HelicitySource(helicities, max_helicity):
+        lib().lvo_build_tube_triangle_render_data(*args, _p(idx), C.byref(ni), _p(verts), C.byref(nv), _p(pts), C.byref(npt))
     return idx[:ni.value].reshape(-1, 3).copy(), verts[:nv.value].copy(), pts[:npt.value].copy()
 
 
@@ -398,6 +423,7 @@ DEFAULTS = dict(
     aoSamplesPerFrame=4, aoIterations=1, aoUseDistance=1, aoJitterPrimary=1, tubeNumSubdivisions=6, aoRadius=0.1,
     ppllMaxNumFrags=100, ppllLinkedListSize=0, ppllTileW=2, ppllTileH=8,
     useBands=0, useEllipticTubes=0, bandWidth=0.005, minBandThickness=0.15, minThickness=0.15, lssGeometry=0,
+    useHelicityBands=0, numSubdivisionsBands=6, separatorBaseWidth=0.2, helicityRotationFactor=1.0,
 )
 
 

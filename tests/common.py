@@ -59,6 +59,10 @@ class Case:
             ppllTileW=int(s.get("ppll_tile_width", 2)), ppllTileH=int(s.get("ppll_tile_height", 8)),
             # band data: USE_BANDS / elliptic tubes / MIN_THICKNESS (LineDataFlow.cpp:2423-2431, LineData.cpp:54,1297-1298)
             lssGeometry=int(s.get("geometry_mode") == "Linear Swept Spheres"),
+            useHelicityBands=int(bool(s.get("rotating_helicity_bands", False))),
+            numSubdivisionsBands=int(s.get("band_subdivisions", 6)),
+            separatorBaseWidth=float(np.float32(s.get("separator_width", 0.2))),
+            helicityRotationFactor=float(np.float32(s.get("helicity_rotation_factor", 1.0))),
             useBands=int(bool(s.get("use_ribbons", False))),
             useEllipticTubes=int(bool(s.get("use_ribbons", False)) and bool(s.get("use_analytic_elliptic_tubes", False))),
             bandWidth=float(np.float32(s.get("band_width", 0.005))),

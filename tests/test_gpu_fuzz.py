@@ -283,3 +283,59 @@ def test_random_svgf_sequences(hip_lib, seed):
             assert np.abs(ctx.get_ao() - ao_ref).max() < 5e-5, tag + " frame %d" % f
             assert max_lsb_diff(img, sc.render_rt(P, ao=ao_ref)) <= LSB_TOL, tag + " frame %d" % f
         ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(4))
+def test_random_helicity_band_cases(hip_lib, seed):
+    """Rotating helicity bands: random curves with a random signed helicity attribute, random separator widths / subdivisions /
+    rotation factors, capsules (AABB or LSS geometry) or the triangle tubes, the ray tracer and the PPLL."""
+    rng = np.random.default_rng(7000 + seed)
+    for k in range(8):
+        tr = scenes.normalize(scenes.random_curves(n_lines=int(rng.integers(1, 20)), points_per_line=int(rng.integers(2, 50)),
+                                                   seed=int(rng.integers(1 << 30))))
+        hel = (rng.normal(size=len(tr.positions)) * float(rng.choice([0.001, 0.02, 1.0]))).astype(np.float32)
+        if not hel.any():
+            hel[0] = 1.0
+        lw = float(rng.choice([0.004, 0.01, 0.03, 0.06]))
+        geometry = str(rng.choice(["capsules", "lss", "triangles"]))
+        s = dict(rotating_helicity_bands=True, band_subdivisions=int(rng.integers(1, 9)),
+                 separator_width=float(rng.choice([0.0, 0.1, 0.2, 0.6])), helicity_rotation_factor=float(rng.choice([0.0, 0.01, 0.3, 1.0, -1.0])))
+        if rng.uniform() < 0.5:
+            s.update(RTAO, ambient_occlusion_strength=1.0, ambient_occlusion_iterations=int(rng.integers(1, 3)),
+                     ambient_occlusion_samples_per_frame=int(rng.integers(1, 6)))
+        if rng.uniform() < 0.4:
+            s["num_samples_per_frame"] = int(rng.integers(2, 4))
+        if rng.uniform() < 0.4:
+            s["depth_cue_strength"] = 0.6
+        if rng.uniform() < 0.25:
+            s["use_halos"] = False
+        if rng.uniform() < 0.3:
+            s["use_capped_tubes"] = False
+        pts, seg, _ = lvo.build_tube_aabb_render_data(tr.positions, tr.attributes, tr.line_offsets, lw, helicities=hel)
+        mesh = None
+        if geometry == "triangles":
+            nsub = int(rng.choice([4, 6, 8]))
+            s.update(geometry_mode="Triangle Mesh", tube_num_subdivisions=nsub)
+            mesh = lvo.build_tube_triangle_render_data(tr.positions, tr.attributes, tr.line_offsets, lw, nsub, helicities=hel)
+        elif geometry == "lss":
+            s["geometry_mode"] = "Linear Swept Spheres"
+        tf = tfm.standard_transparent() if rng.uniform() < 0.4 else tfm.standard()
+        cam = (float(rng.uniform(-0.4, 0.4)), float(rng.uniform(-0.3, 0.3)), float(rng.uniform(0.5, 1.0)))
+        c = Case(pts, seg, tf, int(rng.integers(40, 180)), int(rng.integers(30, 120)), lw, camera_pos=cam, **s)
+        tag = "seed %d case %d: %dx%d lw %g %s" % (seed, k, c.width, c.height, lw, s)
+        ctx = c.hip_context()
+        if mesh is not None:
+            ctx.set_tube_triangle_mesh(*mesh)
+        img = ctx.render(11)
+        sc = c.oracle_scene()
+        P = c.oracle_params(sc)
+        ao_ref = None
+        if P.useAmbientOcclusion:
+            ao_ref = c.oracle_ao(sc, P)
+            assert np.array_equal(ctx.get_ao().view(np.uint32), ao_ref.view(np.uint32)), tag
+        ref = lvo.TriScene(*mesh, lw).render_rt(sc, P, ao=ao_ref) if mesh is not None else sc.render_rt(P, ao=ao_ref)
+        assert max_lsb_diff(img, ref) <= LSB_TOL, tag
+        if mesh is None and "num_samples_per_frame" not in s:
+            assert max_lsb_diff(ctx.render(2), sc.render_ppll(P, ao=ao_ref)) <= LSB_TOL, tag
+        ctx.close()

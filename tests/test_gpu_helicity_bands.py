@@ -1,0 +1,127 @@
+"""Rotating helicity bands on the GPU (k_render_rt / k_ppll_gather / k_render_rt_mlat <..., LV_SHADE_HELICITY>) through the C-ABI and
+the plugin surface, against the oracle."""
+import numpy as np
+import pytest
+
+from common import Case, max_lsb_diff
+from linevis_amd import capi, host_api, scenes, transfer_function as tfm
+from oracle import lvo
+from test_helicity_bands import helix_with_helicity
+
+pytestmark = pytest.mark.gpu
+
+HEL = dict(rotating_helicity_bands=True, band_subdivisions=6, separator_width=0.2, helicity_rotation_factor=1.0)
+RTAO = dict(ambient_occlusion_mode="RTAO (Screen Space)", ambient_occlusion_strength=1.0, ambient_occlusion_gamma=1.0,
+            ambient_occlusion_radius=0.15, ambient_occlusion_distance_based=True, ambient_occlusion_iterations=2,
+            ambient_occlusion_samples_per_frame=4)
+
+
+def helicity_case(width=200, height=150, line_width=0.03, transparent=False, **settings):
+    tr, hel = helix_with_helicity()
+    pts, seg, _ = lvo.build_tube_aabb_render_data(tr.positions, tr.attributes, tr.line_offsets, line_width, helicities=hel)
+    s = dict(HEL)
+    s.update(settings)
+    tf = tfm.standard_transparent() if transparent else tfm.standard()
+    return Case(pts, seg, tf, width, height, line_width, **s), tr, hel
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(transparent=True), dict(use_halos=False), dict(use_capped_tubes=False),
+                                dict(band_subdivisions=3, separator_width=0.5, helicity_rotation_factor=0.3),
+                                dict(num_samples_per_frame=3), dict(depth_cue_strength=0.7), dict(RTAO),
+                                dict(geometry_mode="Linear Swept Spheres")])
+def test_ray_tracer_frame_matches_the_oracle(hip_lib, kw):
+    c, _, _ = helicity_case(**kw)
+    ctx = c.hip_context()
+    img = ctx.render(11)
+    ref, ao = c.oracle_render(11)
+    if ao is not None:
+        assert np.array_equal(ctx.get_ao().view(np.uint32), ao.view(np.uint32))
+    assert max_lsb_diff(img, ref) <= 2
+    c.settings["rotating_helicity_bands"] = False
+    assert (np.abs(c.hip_context().render(11).astype(np.int32) - img.astype(np.int32)).max(axis=2) > 20).sum() > 300   # stripes
+
+
+def test_triangle_mesh_geometry_mode(hip_lib):
+    """LineAttributesBarycentric.glsl:60-92: interpolated rotation, linear continuation on the caps; the triangle line-point table's
+    rotation runs on across the trajectories."""
+    tr, hel = helix_with_helicity()
+    lw = 0.03
+    mesh = lvo.build_tube_triangle_render_data(tr.positions, tr.attributes, tr.line_offsets, lw, 8, helicities=hel)
+    for transparent in (False, True):
+        c, _, _ = helicity_case(line_width=lw, transparent=transparent, geometry_mode="Triangle Mesh", tube_num_subdivisions=8)
+        ctx = c.hip_context()
+        ctx.set_tube_triangle_mesh(*mesh)
+        img = ctx.render(11)
+        sc = c.oracle_scene()
+        P = c.oracle_params(sc)
+        ref = lvo.TriScene(*mesh, lw).render_rt(sc, P)
+        assert max_lsb_diff(img, ref) <= 2
+    cap = np.zeros_like(img[..., 0], dtype=bool)
+    assert (img[..., :3] != 255).any(axis=2).sum() > 3000
+
+
+def test_ppll_and_mlat(hip_lib):
+    c, _, _ = helicity_case(width=120, height=90, transparent=True)
+    ctx = c.hip_context()
+    img = ctx.render(2)
+    ref, _ = c.oracle_render(2)
+    assert max_lsb_diff(img, ref) <= 2
+    c2, _, _ = helicity_case(width=120, height=90, transparent=True, use_mlat=True, collect_stats=True, mlat_record_trace=True,
+                             mlat_num_nodes=4)
+    ctx = c2.hip_context()
+    img = ctx.render(11)
+    rec = ctx.mlat_trace()
+    sc = c2.oracle_scene()
+    ref, _, viol = sc.render_rt_mlat(c2.oracle_params(sc), 4, trace=rec)
+    assert viol == 0 and max_lsb_diff(img, ref) <= 2 and len(rec) > 2000
+
+
+def test_options_are_validated(hip_lib):
+    c, _, _ = helicity_case()
+    ctx = c.hip_context()
+    for key, bad in (("band_subdivisions", 0), ("separator_width", -1.0), ("helicity_rotation_factor", "x")):
+        with pytest.raises(capi.LineVisError):
+            ctx.set_option(key, bad)
+    ctx.set_option("use_ribbons", True)
+    with pytest.raises(capi.LineVisError):
+        ctx.render(11)                       # USE_BANDS and USE_ROTATING_HELICITY_BANDS exclude each other
+
+
+def test_from_the_streamline_tracer_through_the_plugin_surface(hip_lib):
+    """ABC flow -> StreamlineTracingGrid (attributes incl. "Helicity") -> LineDataFlow -> HipRayTracer with rotating_helicity_bands:
+    the data set computes lineRotation, the renderer uploads the switches; the frame equals a context fed by hand and the oracle."""
+    grid = host_api.StreamlineTracingGrid().load_abc_flow(24, 24, 24, 6.0)
+    seeds = grid.regular_seeds(3, 3, 3)
+    pos, att, off = grid.trace_streamlines(seeds, minimum_length=0.5)
+    names = grid.attribute_names()
+    assert "Helicity" in names
+    npos = host_api.normalize_positions(pos)
+    flow = host_api.LineDataFlow().set_trajectories_multi(npos, att, names, off, selected=names.index("Velocity Magnitude"))
+    assert flow.has_helicity
+    settings = dict(line_width=0.02, rotating_helicity_bands=True, helicity_rotation_factor=0.05, depth_cue_strength=0.5)
+    frames = {}
+    for mode in (11, 2):
+        r = host_api.HeadlessLineRenderer(mode)
+        r.set_rendering_resolution(200, 150)
+        r.set_transfer_function(tfm.standard())
+        r.set_line_data(flow)
+        r.set_new_settings(settings)
+        frames[mode] = r.render_frame()
+        hel = att[names.index("Helicity")]
+        pts, seg, _ = lvo.build_tube_aabb_render_data(npos, att[names.index("Velocity Magnitude")], off, 0.02, helicities=hel,
+                                                      max_helicity=flow.max_helicity)
+        c = Case(pts, seg, tfm.standard(), 200, 150, 0.02, rotating_helicity_bands=True, helicity_rotation_factor=0.05,
+                 depth_cue_strength=0.5)
+        ctx = c.hip_context()
+        lo, hi = flow.attribute_range()
+        ctx.set_transfer_function(c.tf, lo, hi)
+        view, proj, fovy, near, far = r.camera()
+        ctx.set_camera(view, proj, fovy, near, far, 200, 150)
+        assert np.array_equal(frames[mode], ctx.render(mode))
+        if mode == 11:
+            sc = c.oracle_scene()
+            P = c.oracle_params(sc)
+            P.attrMin, P.attrMax = lo, hi
+            assert max_lsb_diff(frames[mode], sc.render_rt(P, use_bvh=True)) <= 2
+    r.set_new_settings(dict(rotating_helicity_bands=False))
+    assert not np.array_equal(r.render_frame(), frames[2])
