@@ -208,7 +208,8 @@ int lv_set_background(lv_ctx* ctx, const float rgba[4]);
  *   and every segment is a sphere-traced elliptic tubelet, EllipticTubeRayTracing.glsl).
  *   rotating helicity bands of flow lines (USE_ROTATING_HELICITY_BANDS, LineDataFlow.cpp:601-624,2432-2440; excludes
  *   use_ribbons): rotating_helicity_bands (the line points then carry lineRotation, LineDataFlow.cpp:2188-2197),
- *   separator_width (0.2), band_subdivisions (6), helicity_rotation_factor (1). */
+ *   separator_width (0.2), band_subdivisions (6), helicity_rotation_factor (1), use_uniform_twist_line_width (true;
+ *   UNIFORM_HELICITY_BAND_WIDTH, "Triangle Mesh" geometry only: LineAttributesBarycentric.glsl:94-112). */
 int lv_set_option(lv_ctx* ctx, const char* key, const char* value);
 
 /* LineData::getRayTracingTubeAabbTopLevelAS (LineData.cpp:1057-1075) + getTubeAabbBottomLevelAS (:879-907):

@@ -434,6 +434,8 @@ int lv_set_option(lv_ctx* ctx, const char* key, const char* value) {
         o.ellipticTubes = parseBool(value);
     } else if (k == "rotating_helicity_bands") {                  // LineDataFlow.cpp:601 (= USE_ROTATING_HELICITY_BANDS: the line
         o.helicityBands = parseBool(value);                       // points then carry lineRotation)
+    } else if (k == "use_uniform_twist_line_width") {             // :618 (UNIFORM_HELICITY_BAND_WIDTH; "Triangle Mesh" geometry only)
+        o.uniformTwistLineWidth = parseBool(value);
     } else if (k == "separator_width") {                          // :609
         if (!parseFloat(value, f) || !(f >= 0.0f)) return bad();
         o.separatorWidth = f;

@@ -143,6 +143,7 @@ struct LvUniforms {
     // (LineDataFlow.cpp:979-984,2432-2440)
     uint32_t useHelicityBands, numSubdivisionsBands;
     float separatorBaseWidth, helicityRotationFactor;
+    uint32_t uniformHelicityBandWidth; // UNIFORM_HELICITY_BAND_WIDTH: triangle closest-hit path only (LineAttributesBarycentric.glsl:94-112)
 };
 
 // Feature maps SVGF asks the RTAO pass for (SVGF.cpp:88-96; VulkanRayTracedAmbientOcclusion.glsl:350-464, DISABLE_ACCUMULATION

@@ -78,7 +78,7 @@ struct LvOptions {
     float bandWidth = 0.005f, minBandThickness = 0.15f;
     // rotating helicity bands of flow lines with a helicity attribute: rotating_helicity_bands, separator_width (0.2,
     // LineDataFlow.cpp:54), band_subdivisions (6, LineDataFlow.hpp:188), helicity_rotation_factor (1, :171); settings keys :601-624
-    bool helicityBands = false;
+    bool helicityBands = false, uniformTwistLineWidth = true; // use_uniform_twist_line_width, LineDataFlow.cpp:53
     float separatorWidth = 0.2f, helicityRotationFactor = 1.0f;
     uint32_t bandSubdivisions = 6;
     bool svgfEnabled = false;

@@ -1146,6 +1146,7 @@ void lv_fill_uniforms(const lv_ctx* ctx, LvUniforms& U) {
     U.numSubdivisionsBands = o.bandSubdivisions;
     U.separatorBaseWidth = o.separatorWidth;
     U.helicityRotationFactor = o.helicityRotationFactor;
+    U.uniformHelicityBandWidth = o.uniformTwistLineWidth ? 1u : 0u;
     U.nearDist = ctx->nearDist;
     U.farDist = ctx->farDist;
     U.width = ctx->width;

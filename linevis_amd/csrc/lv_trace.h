@@ -956,7 +956,7 @@ __device__ __forceinline__ f4 lv_transfer_function(const LvSceneDev& S, const Lv
 
 // USE_BANDS arguments of computeFragmentColor (RayHitCommon.glsl:82-90,148-190)
 // (LV_SHADE_HELICITY: phi and rotation = fragmentRotation of USE_ROTATING_HELICITY_BANDS, :91-93; the rest unused)
-struct LvBandArgs { bool useBand; float phi; f3 linePosition, lineNormal; float rotation; };
+struct LvBandArgs { bool useBand; float phi; f3 linePosition, lineNormal; float rotation, separatorScale; };
 template <int BANDS>
 __device__ __forceinline__ f4 lv_compute_fragment_color_t(const LvSceneDev& S, const LvUniforms& U, float aoTexel, f3 fragPos,
                                                           f3 fragmentNormal, f3 fragmentTangent, bool isCap,
@@ -966,7 +966,7 @@ __device__ __forceinline__ f4 lv_compute_fragment_color(const LvSceneDev& S, con
                                                         float fragmentAttribute, float& payloadHitT) {
     LvBandArgs none;
     none.useBand = false; none.phi = 0.0f; none.linePosition = mk3(0.0f, 0.0f, 0.0f); none.lineNormal = mk3(0.0f, 0.0f, 0.0f);
-    none.rotation = 0.0f;
+    none.rotation = 0.0f; none.separatorScale = 1.0f;
     return lv_compute_fragment_color_t<LV_SHADE_PLAIN>(S, U, aoTexel, fragPos, fragmentNormal, fragmentTangent, isCap, fragmentAttribute,
                                               payloadHitT, none);
 }
@@ -1055,6 +1055,7 @@ __device__ __forceinline__ f4 lv_shade_hit(const LvSceneDev& S, const LvUniforms
         if (dot3(b.lineNormal, cross3(fragmentNormal, fragmentTangent)) < 0.0f) b.phi = 2.0f * 3.14159265358979323846f - b.phi;
         b.linePosition = linePointInterpolated;
         b.rotation = ((1.0f - ts) * lp0.lineRotation + ts * lp1.lineRotation) * U.helicityRotationFactor;
+        b.separatorScale = 1.0f; // ClosestHitTubeAnalytic has no UNIFORM_HELICITY_BAND_WIDTH branch
         return lv_compute_fragment_color_t<LV_SHADE_HELICITY>(S, U, aoTexel, fragPos, fragmentNormal, fragmentTangent, isCap,
                                                               fragmentAttribute, payloadHitT, b);
     }
@@ -1073,7 +1074,7 @@ __device__ __forceinline__ f4 lv_shade_hit(const LvSceneDev& S, const LvUniforms
         b.phi = lv_atan2_det(sqrtf((1.0f - cphi) * (1.0f + cphi)), cphi);
         if (dot3(b.lineNormal, cross3(fragmentNormal, fragmentTangent)) < 0.0f) b.phi = 2.0f * 3.14159265358979323846f - b.phi;
         b.linePosition = linePointInterpolated;
-        b.rotation = 0.0f;
+        b.rotation = 0.0f; b.separatorScale = 1.0f;
         return lv_compute_fragment_color_t<LV_SHADE_BANDS>(S, U, aoTexel, fragPos, fragmentNormal, fragmentTangent, isCap,
                                                            fragmentAttribute, payloadHitT, b);
     }
@@ -1124,7 +1125,7 @@ __device__ __forceinline__ f4 lv_shade_hit_elliptic(const LvSceneDev& S, const L
     b.phi = E.phiLine;
     b.linePosition = E.linePosition;
     b.lineNormal = E.lineNormal;
-    b.rotation = 0.0f;
+    b.rotation = 0.0f; b.separatorScale = 1.0f;
     return lv_compute_fragment_color_t<LV_SHADE_BANDS>(S, U, aoTexel, E.fragPos, E.normal, E.tangent, false, E.attribute, payloadHitT, b);
 }
 
@@ -1197,6 +1198,27 @@ __device__ __forceinline__ f4 lv_shade_hit_triangle(const LvSceneDev& S, const L
             const float distToPlane = dot3(planeNormal, fragPos) + planeDist;
             b.rotation += fragmentRotationDelta * distToPlane / segmentLength;
         }
+        b.separatorScale = 1.0f;
+        if (U.uniformHelicityBandWidth) {
+            // UNIFORM_HELICITY_BAND_WIDTH, LineAttributesBarycentric.glsl:94-112: rotation per length along the line against the
+            // circumference per angle (r = lineWidth / 2)
+            const uint32_t li0 = vd0.vertexLinePointIndex & 0x7FFFFFFFu;
+            const lv_line_point* other = nullptr;
+            float rotDy = 0.0f;
+            if (li0 != 0u && S.triPoints[li0 - 1u].lineStartIndex == lp0.lineStartIndex) {
+                other = &S.triPoints[li0 - 1u];
+                rotDy = (lp0.lineRotation - other->lineRotation) * f;
+            }
+            if (!other) {
+                other = &S.triPoints[li0 + 1u];
+                rotDy = (other->lineRotation - lp0.lineRotation) * f;
+            }
+            const float rotDx = len3(mk3(lp0.linePosition[0], lp0.linePosition[1], lp0.linePosition[2]) -
+                                     mk3(other->linePosition[0], other->linePosition[1], other->linePosition[2]));
+            float sn, cs;
+            lv_sincos_rad(lv_atan2_det(rotDy * 0.5f * U.lineWidth, rotDx), sn, cs);
+            b.separatorScale = cs;
+        }
         return lv_compute_fragment_color_t<LV_SHADE_HELICITY>(S, U, aoTexel, fragPos, fragmentNormal, fragmentTangent, isCap,
                                                               fragmentAttribute, payloadHitT, b);
     }
@@ -1213,7 +1235,7 @@ __device__ __forceinline__ f4 lv_shade_hit_triangle(const LvSceneDev& S, const L
         b.phi = (a0 * b0 + a1 * bu) + a2 * bv;
         b.linePosition = lerp3(lp0.linePosition, lp1.linePosition, lp2.linePosition);
         b.lineNormal = lerp3(lp0.lineNormal, lp1.lineNormal, lp2.lineNormal);
-        b.rotation = 0.0f;
+        b.rotation = 0.0f; b.separatorScale = 1.0f;
         return lv_compute_fragment_color_t<LV_SHADE_BANDS>(S, U, aoTexel, fragPos, fragmentNormal, fragmentTangent, isCap, fragmentAttribute,
                                                            payloadHitT, b);
     }
@@ -1386,7 +1408,7 @@ __device__ __forceinline__ f4 lv_compute_fragment_color_t(const LvSceneDev& S, c
     if (BANDS == LV_SHADE_HELICITY) {
         // RayHitCommon.glsl:455-486 (no multi-var rendering, no twist-line texture, no UNIFORM_HELICITY_BAND_WIDTH):
         // drawSeparatorStripe (:57-64) darkens the shaded colour where mod(phi + rotation + w / 2, 2 pi / n) falls into [0, w]
-        const float separatorWidth = U.separatorBaseWidth;
+        const float separatorWidth = U.separatorBaseWidth / bands.separatorScale; // :456-459 (scale 1 without the define)
         const float period = 2.0f / float(U.numSubdivisionsBands) * 3.14159265358979323846f;
         const float x = bands.phi + bands.rotation + separatorWidth * 0.5f;
         const float varFraction = x - period * floorf(x / period); // mod(x, y) = x - y * floor(x / y)

@@ -304,6 +304,7 @@ float LineData::minBandThickness = 0.15f;
 bool LineDataFlow::useRibbons = true;
 bool LineDataFlow::useRotatingHelicityBands = false;
 float LineDataFlow::separatorWidth = 0.2f;
+bool LineDataFlow::useUniformTwistLineWidth = true;
 
 // LineDataFlow::setNewSettings, LineDataFlow.cpp:584-610
 bool LineDataFlow::setNewSettings(const SettingsMap& settings) {
@@ -326,14 +327,20 @@ bool LineDataFlow::setNewSettings(const SettingsMap& settings) {
         dirty = true;
         shallReloadGatherShader = true;
     }
-    // :601-624.  The twist-line texture and UNIFORM_HELICITY_BAND_WIDTH (a triangle-mesh-only variant: ClosestHitTubeAnalytic does not
-    // pass rotationSeparatorScale, TubeRayTracing.glsl:512-613) are not built; their keys are accepted and ignored.
+    // :601-624.  The twist-line texture is not built (its keys are accepted and ignored); UNIFORM_HELICITY_BAND_WIDTH exists in the
+    // triangle closest-hit path only (ClosestHitTubeAnalytic does not pass rotationSeparatorScale, TubeRayTracing.glsl:512-613).
     b = useRotatingHelicityBands;
     if (settings.getValueOpt("rotating_helicity_bands", b) && b != useRotatingHelicityBands) {
         useRotatingHelicityBands = b;
         if (useRotatingHelicityBands) useRibbons = false;
         cachedAabbDataValid = false;
         setTriangleRepresentationDirty();
+        dirty = true;
+        shallReloadGatherShader = true;
+    }
+    b = useUniformTwistLineWidth;
+    if (settings.getValueOpt("use_uniform_twist_line_width", b) && b != useUniformTwistLineWidth) {
+        useUniformTwistLineWidth = b;
         dirty = true;
         shallReloadGatherShader = true;
     }

@@ -93,6 +93,7 @@ public:
     virtual float getSeparatorWidth() const { return 0.2f; }
     virtual uint32_t getNumSubdivisionsBands() const { return 6u; }
     virtual float getHelicityRotationFactor() const { return 1.0f; }
+    virtual bool getUseUniformTwistLineWidth() const { return true; }
     static bool getRenderThickBands() { return renderThickBands; }   // LineData.cpp:53
     static float getMinBandThickness() { return minBandThickness; }  // LineData.cpp:54
     int getTubeNumSubdivisions() const { return tubeNumSubdivisions; }
@@ -150,6 +151,7 @@ public:
     float getSeparatorWidth() const override { return separatorWidth; }
     uint32_t getNumSubdivisionsBands() const override { return numSubdivisionsBands; }
     float getHelicityRotationFactor() const override { return helicityRotationFactor; }
+    bool getUseUniformTwistLineWidth() const override { return useUniformTwistLineWidth; }
     bool setNewSettings(const SettingsMap& settings) override;
 
     size_t getNumLines() override { return numTotalTrajectories; }
@@ -166,6 +168,7 @@ private:
     static bool useRibbons;                            // LineDataFlow.cpp:51
     static bool useRotatingHelicityBands;              // LineDataFlow.cpp:52
     static float separatorWidth;                       // LineDataFlow.cpp:54 (0.2)
+    static bool useUniformTwistLineWidth;              // LineDataFlow.cpp:53 (true)
     int helicityAttributeIndex = -1;
     bool hasHelicity = false;
     float maxHelicity = 0.0f;

@@ -337,6 +337,7 @@ bool LineRenderer::uploadFrameState() {
         snprintf(buf, sizeof(buf), "%.9g", double(lineData->getSeparatorWidth()));
         setOption("separator_width", buf);
         setOption("band_subdivisions", std::to_string(lineData->getNumSubdivisionsBands()));
+        setOption("use_uniform_twist_line_width", lineData->getUseUniformTwistLineWidth() ? "true" : "false");
         snprintf(buf, sizeof(buf), "%.9g", double(lineData->getHelicityRotationFactor()));
         setOption("helicity_rotation_factor", buf);
         // getVulkanShaderPreprocessorDefines, LineData.cpp:1209-1256

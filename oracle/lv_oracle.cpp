@@ -616,7 +616,7 @@ inline void blinnPhongShadingTube(const lvo_params& P, const Frame& F, float aoT
 struct BandArgs { bool useBand; float phi; V3 linePosition, lineNormal; };
 // USE_ROTATING_HELICITY_BANDS arguments of computeFragmentColor (RayHitCommon.glsl:82-93): the angle around the tube and the
 // interpolated lineRotation x helicityRotationFactor
-struct HelicityArgs { float phi, fragmentRotation; };
+struct HelicityArgs { float phi, fragmentRotation, rotationSeparatorScale; };
 inline void computeFragmentColor(const lvo_scene& sc, const lvo_params& P, const Frame& F, float aoTexel, V3 fragPos,
                                  V3 fragmentNormal, V3 fragmentTangent, bool isCap, float fragmentAttribute,
                                  float hitColor[4], float& payloadHitT, const BandArgs* bands = nullptr,
@@ -703,6 +703,7 @@ inline void shadeHit(const lvo_scene& sc, const lvo_params& P, const Frame& F, f
         hl.phi = atan2Det(sqrtf((1.0f - cphi) * (1.0f + cphi)), cphi);
         if (dot(lineNormal, cross(fragmentNormal, fragmentTangent)) < 0.0f) hl.phi = 2.0f * 3.14159265358979323846f - hl.phi;
         hl.fragmentRotation = ((1.0f - ts) * lp0.lineRotation + ts * lp1.lineRotation) * P.helicityRotationFactor;
+        hl.rotationSeparatorScale = 1.0f; // ClosestHitTubeAnalytic has no UNIFORM_HELICITY_BAND_WIDTH branch
         computeFragmentColor(sc, P, F, aoTexel, fragPos, fragmentNormal, fragmentTangent, isCap, fragmentAttribute, hitColor,
                              payloadHitT, nullptr, &hl);
         return;
@@ -877,7 +878,7 @@ inline void computeFragmentColor(const lvo_scene& sc, const lvo_params& P, const
     if (hel) {
         // RayHitCommon.glsl:455-486 (no multi-var rendering, no twist-line texture, no UNIFORM_HELICITY_BAND_WIDTH):
         // drawSeparatorStripe (:57-64) darkens the shaded colour where mod(phi + rotation + w / 2, 2 pi / n) falls into [0, w]
-        const float separatorWidth = P.separatorBaseWidth;
+        const float separatorWidth = P.separatorBaseWidth / hel->rotationSeparatorScale; // :456-459 (scale 1 without the define)
         const float period = 2.0f / float(P.numSubdivisionsBands) * 3.14159265358979323846f;
         const float x = hel->phi + hel->fragmentRotation + separatorWidth * 0.5f;
         const float varFraction = x - period * floorf(x / period); // mod(x, y) = x - y * floor(x / y)
@@ -1439,6 +1440,26 @@ inline void shadeHitTri(const lvo_scene& sc, const lvo_tri_scene& tsc, const lvo
             const float planeDist = -dot(planeNormal, ld3(lp0.linePosition));
             const float distToPlane = dot(planeNormal, fragPos) + planeDist;
             hl.fragmentRotation += fragmentRotationDelta * distToPlane / segmentLength;
+        }
+        hl.rotationSeparatorScale = 1.0f;
+        if (P.uniformHelicityBandWidth) {
+            // UNIFORM_HELICITY_BAND_WIDTH, LineAttributesBarycentric.glsl:94-112: the stripe keeps its width on the surface whatever
+            // the pitch of the helix it follows -- rotation per length along the line against the circumference per angle (r = lineWidth / 2)
+            const uint32_t i0 = vd0.vertexLinePointIndex & 0x7FFFFFFFu;
+            const lvo_line_point* other = nullptr;
+            float rotDy = 0.0f;
+            if (i0 != 0u && tsc.pts[i0 - 1].lineStartIndex == lp0.lineStartIndex) {
+                other = &tsc.pts[i0 - 1];
+                rotDy = (lp0.lineRotation - other->lineRotation) * f;
+            }
+            if (!other) {
+                other = &tsc.pts[i0 + 1];
+                rotDy = (other->lineRotation - lp0.lineRotation) * f;
+            }
+            const float rotDx = length(ld3(lp0.linePosition) - ld3(other->linePosition));
+            float sn, cs;
+            sincosRad(atan2Det(rotDy * 0.5f * P.lineWidth, rotDx), sn, cs);
+            hl.rotationSeparatorScale = cs;
         }
         computeFragmentColor(sc, P, F, aoT, fragPos, fragmentNormal, fragmentTangent, isCap, fragmentAttribute, hc, payloadHitT,
                              nullptr, &hl);

@@ -95,6 +95,10 @@ typedef struct {
     uint32_t useHelicityBands;
     uint32_t numSubdivisionsBands;
     float separatorBaseWidth, helicityRotationFactor;
+    /* UNIFORM_HELICITY_BAND_WIDTH (use_uniform_twist_line_width, default on, LineDataFlow.cpp:53,2434-2436): separator width /
+     * cos(atan(rotation per length x lineWidth / 2)).  Only the triangle closest-hit path computes rotationSeparatorScale
+     * (LineAttributesBarycentric.glsl:94-112); ClosestHitTubeAnalytic does not pass it, so the analytic paths ignore the switch. */
+    uint32_t uniformHelicityBandWidth;
 } lvo_params;
 
 typedef struct {

@@ -61,6 +61,7 @@ class Params(C.Structure):
         ("lssGeometry", C.c_uint32),
         ("useHelicityBands", C.c_uint32), ("numSubdivisionsBands", C.c_uint32),
         ("separatorBaseWidth", C.c_float), ("helicityRotationFactor", C.c_float),
+        ("uniformHelicityBandWidth", C.c_uint32),
     ]
 
 
@@ -424,6 +425,7 @@ DEFAULTS = dict(
     ppllMaxNumFrags=100, ppllLinkedListSize=0, ppllTileW=2, ppllTileH=8,
     useBands=0, useEllipticTubes=0, bandWidth=0.005, minBandThickness=0.15, minThickness=0.15, lssGeometry=0,
     useHelicityBands=0, numSubdivisionsBands=6, separatorBaseWidth=0.2, helicityRotationFactor=1.0,
+    uniformHelicityBandWidth=1,
 )
 
 

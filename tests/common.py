@@ -63,6 +63,7 @@ class Case:
             numSubdivisionsBands=int(s.get("band_subdivisions", 6)),
             separatorBaseWidth=float(np.float32(s.get("separator_width", 0.2))),
             helicityRotationFactor=float(np.float32(s.get("helicity_rotation_factor", 1.0))),
+            uniformHelicityBandWidth=int(bool(s.get("use_uniform_twist_line_width", True))),
             useBands=int(bool(s.get("use_ribbons", False))),
             useEllipticTubes=int(bool(s.get("use_ribbons", False)) and bool(s.get("use_analytic_elliptic_tubes", False))),
             bandWidth=float(np.float32(s.get("band_width", 0.005))),

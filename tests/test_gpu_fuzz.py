@@ -316,7 +316,7 @@ def test_random_helicity_band_cases(hip_lib, seed):
         mesh = None
         if geometry == "triangles":
             nsub = int(rng.choice([4, 6, 8]))
-            s.update(geometry_mode="Triangle Mesh", tube_num_subdivisions=nsub)
+            s.update(geometry_mode="Triangle Mesh", tube_num_subdivisions=nsub, use_uniform_twist_line_width=bool(rng.integers(2)))
             mesh = lvo.build_tube_triangle_render_data(tr.positions, tr.attributes, tr.line_offsets, lw, nsub, helicities=hel)
         elif geometry == "lss":
             s["geometry_mode"] = "Linear Swept Spheres"

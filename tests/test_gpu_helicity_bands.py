@@ -42,22 +42,32 @@ def test_ray_tracer_frame_matches_the_oracle(hip_lib, kw):
 
 
 def test_triangle_mesh_geometry_mode(hip_lib):
-    """LineAttributesBarycentric.glsl:60-92: interpolated rotation, linear continuation on the caps; the triangle line-point table's
-    rotation runs on across the trajectories."""
+    """LineAttributesBarycentric.glsl:60-112: interpolated rotation, linear continuation on the caps, and UNIFORM_HELICITY_BAND_WIDTH
+    (use_uniform_twist_line_width, the reference's default: separator width / cos(atan(rotation per length x r))); the triangle
+    line-point table's rotation runs on across the trajectories."""
     tr, hel = helix_with_helicity()
     lw = 0.03
     mesh = lvo.build_tube_triangle_render_data(tr.positions, tr.attributes, tr.line_offsets, lw, 8, helicities=hel)
+    frames = {}
     for transparent in (False, True):
-        c, _, _ = helicity_case(line_width=lw, transparent=transparent, geometry_mode="Triangle Mesh", tube_num_subdivisions=8)
-        ctx = c.hip_context()
-        ctx.set_tube_triangle_mesh(*mesh)
-        img = ctx.render(11)
-        sc = c.oracle_scene()
-        P = c.oracle_params(sc)
-        ref = lvo.TriScene(*mesh, lw).render_rt(sc, P)
-        assert max_lsb_diff(img, ref) <= 2
-    cap = np.zeros_like(img[..., 0], dtype=bool)
+        for uniform in (True, False):
+            c, _, _ = helicity_case(line_width=lw, transparent=transparent, geometry_mode="Triangle Mesh", tube_num_subdivisions=8,
+                                    helicity_rotation_factor=0.25, use_uniform_twist_line_width=uniform)
+            ctx = c.hip_context()
+            ctx.set_tube_triangle_mesh(*mesh)
+            img = ctx.render(11)
+            sc = c.oracle_scene()
+            P = c.oracle_params(sc)
+            assert P.uniformHelicityBandWidth == int(uniform)
+            ref = lvo.TriScene(*mesh, lw).render_rt(sc, P)
+            assert max_lsb_diff(img, ref) <= 2
+            frames[(transparent, uniform)] = img
+    assert not np.array_equal(frames[(False, True)], frames[(False, False)])     # wider stripes where the bands are steep
     assert (img[..., :3] != 255).any(axis=2).sum() > 3000
+    # the analytic closest-hit shader has no such branch: the switch changes nothing there
+    a, _, _ = helicity_case(use_uniform_twist_line_width=True)
+    b, _, _ = helicity_case(use_uniform_twist_line_width=False)
+    assert np.array_equal(a.hip_context().render(11), b.hip_context().render(11))
 
 
 def test_ppll_and_mlat(hip_lib):

@@ -51,6 +51,25 @@ def test_host_line_rotation_equals_the_oracle_and_the_switches_follow_the_refere
     flow2.set_new_settings(dict(rotating_helicity_bands=False))
 
 
+def test_separator_scale_of_the_uniform_band_width():
+    """UNIFORM_HELICITY_BAND_WIDTH: rotationSeparatorScale = cos(atan(rotDy * lineWidth / 2, rotDx)) through the build-owned atan2 and
+    cos = rotDx / hypot(...) to float32 accuracy (LineAttributesBarycentric.glsl:94-112)."""
+    import ctypes as C
+    L = lvo.lib()
+    L.lvo_atan2_det.restype = C.c_float
+    L.lvo_atan2_det.argtypes = [C.c_float, C.c_float]
+    L.lvo_sincos_rad.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    rng = np.random.default_rng(5)
+    worst = 0.0
+    for _ in range(2000):
+        y = float(np.float32(rng.normal() * 10.0 ** rng.uniform(-4, 1)))
+        x = float(np.float32(abs(rng.normal()) * 10.0 ** rng.uniform(-4, 0) + 1e-6))
+        s, c = C.c_float(), C.c_float()
+        L.lvo_sincos_rad(L.lvo_atan2_det(y, x), C.byref(s), C.byref(c))
+        worst = max(worst, abs(c.value - x / np.hypot(x, y)))
+    assert worst < 2e-6
+
+
 def _smoothstep(e0, e1, x):
     t = np.clip((x - e0) / (e1 - e0), 0.0, 1.0)
     return t * t * (3.0 - 2.0 * t)
