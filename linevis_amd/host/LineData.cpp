@@ -250,8 +250,30 @@ void LineData::getMinMaxAttributeValues(float& minAttr, float& maxAttr) const {
     }
 }
 
+LineData::LinePrimitiveMode LineData::linePrimitiveMode = LineData::LINE_PRIMITIVES_TUBE_PROGRAMMABLE_PULL;
+static const char* const LINE_PRIMITIVE_MODE_DISPLAYNAMES[] = { // LineData.cpp:56-74
+        "Quads (Programmable Pull)", "Quads (Geometry Shader)", "Tube (Programmable Pull)", "Tube (Geometry Shader)",
+        "Tube (Triangle Mesh)", "Tube (Mesh Shader)", "Tube (Mesh Shader NV)", "Ribbon Quads (Geometry Shader)",
+        "Tube Ribbons (Programmable Pull)", "Tube Ribbons (Geometry Shader)", "Tube Ribbons (Triangle Mesh)",
+        "Tube Ribbons (Mesh Shader)", "Tube Ribbons (Mesh Shader NV)"};
+
 bool LineData::setNewSettings(const SettingsMap& settings) {
     bool shallReloadGatherShader = false;
+    std::string linePrimitiveModeName; // :107-140
+    if (settings.getValueOpt("line_primitive_mode", linePrimitiveModeName)) {
+        for (int i = 0; i < int(LINE_PRIMITIVES_COUNT); i++)
+            if (linePrimitiveModeName == LINE_PRIMITIVE_MODE_DISPLAYNAMES[i]) {
+                if (linePrimitiveMode != LinePrimitiveMode(i)) { dirty = true; shallReloadGatherShader = true; }
+                linePrimitiveMode = LinePrimitiveMode(i);
+                break;
+            }
+    }
+    int linePrimitiveModeIndex = 0;
+    if (settings.getValueOpt("line_primitive_mode_index", linePrimitiveModeIndex) && linePrimitiveModeIndex >= 0 &&
+        linePrimitiveModeIndex < int(LINE_PRIMITIVES_COUNT)) {
+        if (linePrimitiveMode != LinePrimitiveMode(linePrimitiveModeIndex)) { dirty = true; shallReloadGatherShader = true; }
+        linePrimitiveMode = LinePrimitiveMode(linePrimitiveModeIndex);
+    }
     std::string attributeName;
     if (settings.getValueOpt("attribute", attributeName)) {
         for (size_t i = 0; i < attributeNames.size(); i++) {
@@ -360,6 +382,12 @@ void LineDataFlow::setTrajectoryData(const Trajectories& newTrajectories, const 
     ribbonsDirections = newRibbonsDirections;
     hasBandsData = !ribbonsDirections.empty(); // LineDataFlow.cpp:469
     useRibbons = !useRotatingHelicityBands && hasBandsData; // :470
+    if (ribbonsDirections.empty() && (linePrimitiveMode == LINE_PRIMITIVES_RIBBON_QUADS_GEOMETRY_SHADER ||
+                                      linePrimitiveMode == LINE_PRIMITIVES_TUBE_RIBBONS_GEOMETRY_SHADER))
+        linePrimitiveMode = LINE_PRIMITIVES_QUADS_PROGRAMMABLE_PULL; // :471-474
+    // "Use bands if possible", :476-481
+    if (hasBandsData && !getUseBandRendering()) linePrimitiveMode = LINE_PRIMITIVES_TUBE_RIBBONS_PROGRAMMABLE_PULL;
+    else if (!hasBandsData && getUseBandRendering()) linePrimitiveMode = LINE_PRIMITIVES_TUBE_PROGRAMMABLE_PULL;
     if (hasBandsData) tubeNumSubdivisions = std::max(tubeNumSubdivisions, 8); // :482-484
     numTotalTrajectories = trajectories.size();
     numTotalTrajectoryPoints = 0;

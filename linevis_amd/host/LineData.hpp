@@ -85,6 +85,31 @@ public:
     /// (min, max) of the selected attribute: the transfer-function range (LineDataFlow.cpp:511-530).
     void getMinMaxAttributeValues(float& minAttr, float& maxAttr) const;
     bool getUseCappedTubes() const { return useCappedTubes; }
+    /// LinePrimitiveMode (LineData.hpp:264-282, names LineData.cpp:56-74; settings keys line_primitive_mode / _index :108-140).  The
+    /// rasterised geometries themselves are not built (the PPLL plugin gathers ray-entry hits of tubes); the mode decides what the
+    /// reference derives from it: USE_CAPPED_TUBES of a rasteriser's shaders and the band-rendering switch.
+    enum LinePrimitiveMode {
+        LINE_PRIMITIVES_QUADS_PROGRAMMABLE_PULL, LINE_PRIMITIVES_QUADS_GEOMETRY_SHADER, LINE_PRIMITIVES_TUBE_PROGRAMMABLE_PULL,
+        LINE_PRIMITIVES_TUBE_GEOMETRY_SHADER, LINE_PRIMITIVES_TUBE_TRIANGLE_MESH, LINE_PRIMITIVES_TUBE_MESH_SHADER,
+        LINE_PRIMITIVES_TUBE_MESH_SHADER_NV, LINE_PRIMITIVES_RIBBON_QUADS_GEOMETRY_SHADER,
+        LINE_PRIMITIVES_TUBE_RIBBONS_PROGRAMMABLE_PULL, LINE_PRIMITIVES_TUBE_RIBBONS_GEOMETRY_SHADER,
+        LINE_PRIMITIVES_TUBE_RIBBONS_TRIANGLE_MESH, LINE_PRIMITIVES_TUBE_RIBBONS_MESH_SHADER,
+        LINE_PRIMITIVES_TUBE_RIBBONS_MESH_SHADER_NV, LINE_PRIMITIVES_COUNT
+    };
+    static LinePrimitiveMode getLinePrimitiveMode() { return linePrimitiveMode; }
+    static void setLinePrimitiveMode(LinePrimitiveMode mode) { linePrimitiveMode = mode; }
+    static bool getUseBandRendering() { // LineData.hpp:323-334
+        return linePrimitiveMode == LINE_PRIMITIVES_RIBBON_QUADS_GEOMETRY_SHADER || linePrimitiveMode == LINE_PRIMITIVES_TUBE_RIBBONS_PROGRAMMABLE_PULL ||
+               linePrimitiveMode == LINE_PRIMITIVES_TUBE_RIBBONS_GEOMETRY_SHADER || linePrimitiveMode == LINE_PRIMITIVES_TUBE_RIBBONS_TRIANGLE_MESH ||
+               linePrimitiveMode == LINE_PRIMITIVES_TUBE_RIBBONS_MESH_SHADER || linePrimitiveMode == LINE_PRIMITIVES_TUBE_RIBBONS_MESH_SHADER_NV;
+    }
+    /// USE_CAPPED_TUBES of getVulkanShaderPreprocessorDefines (LineData.cpp:1240-1244; no deferred renderer here): ray tracers always
+    /// follow use_capped_tubes, rasterisers only when the primitive mode is one of the triangle-mesh modes (the other tube
+    /// geometries have no caps)
+    bool getUseCappedTubesDefine(bool isRasterizer) const {
+        return useCappedTubes && (!isRasterizer || linePrimitiveMode == LINE_PRIMITIVES_TUBE_TRIANGLE_MESH ||
+                                  linePrimitiveMode == LINE_PRIMITIVES_TUBE_RIBBONS_TRIANGLE_MESH);
+    }
     bool getUseHalos() const { return useHalos; }
     /// USE_BANDS of the ray tracer's shaders (getVulkanShaderPreprocessorDefines with isRasterizer = false)
     virtual bool getUseBands() const { return false; }
@@ -115,6 +140,7 @@ public:
     void setTriangleRepresentationDirty() { cachedAabbDataValid = false; cachedTriangleDataValid = false; dirty = true; }
 
 protected:
+    static LinePrimitiveMode linePrimitiveMode; // LineData.cpp:51
     static bool renderThickBands;
     static float minBandThickness;
     DataSetType dataSetType;

@@ -341,7 +341,7 @@ bool LineRenderer::uploadFrameState() {
         snprintf(buf, sizeof(buf), "%.9g", double(lineData->getHelicityRotationFactor()));
         setOption("helicity_rotation_factor", buf);
         // getVulkanShaderPreprocessorDefines, LineData.cpp:1209-1256
-        setOption("use_capped_tubes", lineData->getUseCappedTubes() ? "true" : "false");
+        setOption("use_capped_tubes", lineData->getUseCappedTubesDefine(isRasterizer) ? "true" : "false");
         setOption("use_halos", lineData->getUseHalos() ? "true" : "false");
         setOption("tube_num_subdivisions", std::to_string(lineData->getTubeNumSubdivisions()));
         lineData->setDirty(false);

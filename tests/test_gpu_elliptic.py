@@ -239,7 +239,7 @@ def test_ppll_plugin_draws_band_data_as_elliptic_tubes(hip_lib):
     frame = r.render_frame()
     pts, seg, _ = flow.tube_aabb_render_data_elliptic(0.05)
     c = Case(pts, seg, tfm.standard_transparent(), 96, 64, 0.02, use_ribbons=True, use_analytic_elliptic_tubes=True,
-             band_width=0.05, min_band_thickness=0.3)
+             band_width=0.05, min_band_thickness=0.3, use_capped_tubes=False)
     ctx = c.hip_context()
     lo, hi = flow.attribute_range()
     ctx.set_transfer_function(c.tf, lo, hi)

@@ -121,7 +121,7 @@ def test_from_the_streamline_tracer_through_the_plugin_surface(hip_lib):
         pts, seg, _ = lvo.build_tube_aabb_render_data(npos, att[names.index("Velocity Magnitude")], off, 0.02, helicities=hel,
                                                       max_helicity=flow.max_helicity)
         c = Case(pts, seg, tfm.standard(), 200, 150, 0.02, rotating_helicity_bands=True, helicity_rotation_factor=0.05,
-                 depth_cue_strength=0.5)
+                 depth_cue_strength=0.5, use_capped_tubes=(mode == 11))   # rasterisers: no caps outside the triangle-mesh modes
         ctx = c.hip_context()
         lo, hi = flow.attribute_range()
         ctx.set_transfer_function(c.tf, lo, hi)

@@ -490,13 +490,23 @@ def test_headless_renderer_plugins(hip_lib):
         # the same frame through the C-ABI directly and through the oracle
         pts, seg, _ = flow.tube_aabb_render_data(0.02)
         lo, hi = flow.attribute_range()
-        c = Case(pts, seg, tf, 96, 64, 0.02, **{k: v for k, v in settings.items() if k != "line_width"})
+        # (a rasteriser's shaders get USE_CAPPED_TUBES only in the triangle-mesh primitive modes, LineData.cpp:1240-1244: the PPLL
+        # plugin in the default "Tube (Programmable Pull)" mode gathers uncapped tubes)
+        c = Case(pts, seg, tf, 96, 64, 0.02, use_capped_tubes=(mode == 11),
+                 **{k: v for k, v in settings.items() if k != "line_width"})
         ctx = c.hip_context()
         ctx.set_transfer_function(tf, lo, hi)
         view, proj, fovy, near, far = r.camera()   # the C++ Camera class builds its own (float32) matrices
         assert np.allclose(view, c.view, atol=1e-6) and np.allclose(proj, c.proj, atol=1e-6)
         ctx.set_camera(view, proj, fovy, near, far, 96, 64)
         assert np.array_equal(img, ctx.render(mode))
+        if mode == 2:
+            r.set_new_settings(dict(line_primitive_mode="Tube (Triangle Mesh)"))       # capped tubes for the rasteriser
+            ctx.set_option("use_capped_tubes", True)
+            capped = r.render_frame()
+            assert np.array_equal(capped, ctx.render(mode)) and not np.array_equal(capped, img)
+            r.set_new_settings(dict(line_primitive_mode_index=2))                      # back to "Tube (Programmable Pull)"
+            assert np.array_equal(r.render_frame(), img)
         # new settings through the plugin surface take effect
         r.set_new_settings(dict(ambient_occlusion_strength=0.0, depth_cue_strength=0.0))
         img2 = r.render_frame()
