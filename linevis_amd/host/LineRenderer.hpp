@@ -231,7 +231,8 @@ protected:
     static float bandWidth;
 };
 
-/// "Vulkan Ray Tracer" plugin re-hosted on HIP: analytic capsule intersections only.
+/// "Vulkan Ray Tracer" plugin re-hosted on HIP: the reference's three geometry modes (analytic AABBs -- the default here, the
+/// reference starts in "Triangle Mesh" --, triangle mesh, linear swept spheres), elliptic tubes for band data, MLAT.
 class HipRayTracer : public LineRenderer {
 public:
     HipRayTracer(SceneData* sceneData, TransferFunctionWindow& transferFunctionWindow);
