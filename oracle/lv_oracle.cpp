@@ -771,6 +771,55 @@ inline void shadeHitElliptic(const lvo_scene& sc, const lvo_params& P, const Fra
                          P.useBands ? &b : nullptr);
 }
 
+// USE_BANDS halo coordinate of computeFragmentColor (RayHitCommon.glsl:232-351), see the call site
+inline float bandsRibbonPosition(V3 cameraPosition, V3 linePosition, V3 lineNormal, V3 fragmentTangent, V3 t, float phi,
+                                 float lineRadius, float thickness) {
+    const V3 lineN = normalize(lineNormal);
+    const V3 lineB = cross(t, lineN);
+    const V3 cNorm = cameraPosition - linePosition;
+    const float dist = dot(cNorm, fragmentTangent);
+    const V3 w = cNorm - dist * fragmentTangent;
+    const V3 cHat = v3(dot(lineN, w), dot(lineB, w), dot(t, w)); // transpose(mat3(lineN, lineB, t)) * w
+    const V3 c = v3(cHat.x / lineRadius, cHat.y / lineRadius, 1.0f);
+    const float a = 1.0f / (thickness * thickness);
+    const V3 l = v3(a * c.x, c.y, -1.0f);
+    // M_l = shearSymmetricMatrix(l), columns (0, -l.z, l.y), (l.z, 0, -l.x), (-l.y, l.x, 0); B[col][row]
+    const float Ml[3][3] = {{0.0f, -l.z, l.y}, {l.z, 0.0f, -l.x}, {-l.y, l.x, 0.0f}};
+    const float B[3][3] = {{l.z * l.z - l.y * l.y, l.x * l.y, -l.x * l.z},
+                           {l.x * l.y, a * l.z * l.z - l.x * l.x, -a * l.y * l.z},
+                           {-l.x * l.z, -a * l.y * l.z, a * l.y * l.y + l.x * l.x}};
+    const float EPSILON = 1e-4f;
+    float alpha = 0.0f, discr = 0.0f;
+    if (fabsf(l.z) > EPSILON) {
+        discr = -B[0][0] * B[1][1] + B[0][1] * B[1][0];
+        alpha = sqrtf(discr) / l.z;
+    } else if (fabsf(l.y) > EPSILON) {
+        discr = -B[0][0] * B[2][2] + B[0][2] * B[2][0];
+        alpha = sqrtf(discr) / l.y;
+    } else if (fabsf(l.x) > EPSILON) {
+        discr = -B[1][1] * B[2][2] + B[1][2] * B[2][1];
+        alpha = sqrtf(discr) / l.x;
+    }
+    float Cm[3][3];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) Cm[i][j] = B[i][j] + alpha * Ml[i][j];
+    float pm0x = 0.0f, pm0y = 0.0f, pm1x = 0.0f, pm1y = 0.0f;
+    for (int i = 0; i < 2; ++i) {
+        if (fabsf(Cm[i][i]) > EPSILON) {
+            pm0x = Cm[i][0] / Cm[i][2]; pm0y = Cm[i][1] / Cm[i][2];   // column i
+            pm1x = Cm[0][i] / Cm[2][i]; pm1y = Cm[1][i] / Cm[2][i];   // row i
+        }
+    }
+    float sp, cp;
+    sincosRad(phi, sp, cp);
+    const V3 pH = v3(thickness * cp, sp, 1.0f);
+    const V3 pLineH = cross(l, cross(c, pH));
+    const float plx = pLineH.x / pLineH.z, ply = pLineH.y / pLineH.z;
+    const float num = sqrtf((plx - pm0x) * (plx - pm0x) + (ply - pm0y) * (ply - pm0y));
+    const float den = sqrtf((pm1x - pm0x) * (pm1x - pm0x) + (pm1y - pm0y) * (pm1y - pm0y));
+    return num / den * 2.0f - 1.0f;
+}
+
 // computeFragmentColor (RayHitCommon.glsl:74-543) for tubes: shared by the analytic and the triangle closest-hit shaders
 inline void computeFragmentColor(const lvo_scene& sc, const lvo_params& P, const Frame& F, float aoTexel, V3 fragPos,
                                  V3 fragmentNormal, V3 fragmentTangent, bool isCap, float fragmentAttribute,
@@ -799,52 +848,9 @@ inline void computeFragmentColor(const lvo_scene& sc, const lvo_params& P, const
             // USE_BANDS, RayHitCommon.glsl:232-351: the fragment's position between the two silhouette points of the elliptic
             // cross-section as the camera sees it -- tangent-plane coordinates, polar line of the camera point with respect to the
             // conic x^2 / thickness^2 + y^2 = 1, its two intersections with the conic from the degenerate conic B + alpha M_l
-            const float thickness = bands->useBand ? P.minThickness : 1.0f;
-            const V3 lineN = normalize(bands->lineNormal);
-            const V3 lineB = cross(t, lineN);
-            const V3 cNorm = F.cameraPosition - bands->linePosition;
-            const float dist = dot(cNorm, fragmentTangent);
-            const V3 w = cNorm - dist * fragmentTangent;
-            const V3 cHat = v3(dot(lineN, w), dot(lineB, w), dot(t, w)); // transpose(mat3(lineN, lineB, t)) * w
-            const float lineRadius = (bands->useBand ? P.bandWidth : P.lineWidth) * 0.5f;
-            const V3 c = v3(cHat.x / lineRadius, cHat.y / lineRadius, 1.0f);
-            const float a = 1.0f / (thickness * thickness);
-            const V3 l = v3(a * c.x, c.y, -1.0f);
-            // M_l = shearSymmetricMatrix(l), columns (0, -l.z, l.y), (l.z, 0, -l.x), (-l.y, l.x, 0); B[col][row]
-            const float Ml[3][3] = {{0.0f, -l.z, l.y}, {l.z, 0.0f, -l.x}, {-l.y, l.x, 0.0f}};
-            const float B[3][3] = {{l.z * l.z - l.y * l.y, l.x * l.y, -l.x * l.z},
-                                   {l.x * l.y, a * l.z * l.z - l.x * l.x, -a * l.y * l.z},
-                                   {-l.x * l.z, -a * l.y * l.z, a * l.y * l.y + l.x * l.x}};
-            const float EPSILON = 1e-4f;
-            float alpha = 0.0f, discr = 0.0f;
-            if (fabsf(l.z) > EPSILON) {
-                discr = -B[0][0] * B[1][1] + B[0][1] * B[1][0];
-                alpha = sqrtf(discr) / l.z;
-            } else if (fabsf(l.y) > EPSILON) {
-                discr = -B[0][0] * B[2][2] + B[0][2] * B[2][0];
-                alpha = sqrtf(discr) / l.y;
-            } else if (fabsf(l.x) > EPSILON) {
-                discr = -B[1][1] * B[2][2] + B[1][2] * B[2][1];
-                alpha = sqrtf(discr) / l.x;
-            }
-            float Cm[3][3];
-            for (int i = 0; i < 3; i++)
-                for (int j = 0; j < 3; j++) Cm[i][j] = B[i][j] + alpha * Ml[i][j];
-            float pm0x = 0.0f, pm0y = 0.0f, pm1x = 0.0f, pm1y = 0.0f;
-            for (int i = 0; i < 2; ++i) {
-                if (fabsf(Cm[i][i]) > EPSILON) {
-                    pm0x = Cm[i][0] / Cm[i][2]; pm0y = Cm[i][1] / Cm[i][2];   // column i
-                    pm1x = Cm[0][i] / Cm[2][i]; pm1y = Cm[1][i] / Cm[2][i];   // row i
-                }
-            }
-            float sp, cp;
-            sincosRad(bands->phi, sp, cp);
-            const V3 pH = v3(thickness * cp, sp, 1.0f);
-            const V3 pLineH = cross(l, cross(c, pH));
-            const float plx = pLineH.x / pLineH.z, ply = pLineH.y / pLineH.z;
-            const float num = sqrtf((plx - pm0x) * (plx - pm0x) + (ply - pm0y) * (ply - pm0y));
-            const float den = sqrtf((pm1x - pm0x) * (pm1x - pm0x) + (pm1y - pm0y) * (pm1y - pm0y));
-            ribbonPosition = num / den * 2.0f - 1.0f;
+            ribbonPosition = bandsRibbonPosition(F.cameraPosition, bands->linePosition, bands->lineNormal, fragmentTangent, t, bands->phi,
+                                                 (bands->useBand ? P.bandWidth : P.lineWidth) * 0.5f,
+                                                 bands->useBand ? P.minThickness : 1.0f);
         } else {
             // RayHitCommon.glsl:353-372
             V3 crossProdVn = cross(newV, n);
@@ -967,6 +973,11 @@ float lvo_rnd(uint32_t* s) { return rnd(*s); }
 void lvo_sincos_2pi(float xi, float* s, float* c) { sincos2pi(xi, *s, *c); }
 void lvo_sincos_rad(float a, float* s, float* c) { sincosRad(a, *s, *c); }
 float lvo_atan2_det(float y, float x) { return atan2Det(y, x); }
+// test hook: the USE_BANDS halo coordinate alone (tests/test_bands.py compares it with a geometric float64 construction)
+float lvo_bands_ribbon_position(const float cam[3], const float linePos[3], const float lineNormal[3], const float tangent[3],
+                                float phi, float lineRadius, float thickness) {
+    return bandsRibbonPosition(ld3(cam), ld3(linePos), ld3(lineNormal), ld3(tangent), normalize(ld3(tangent)), phi, lineRadius, thickness);
+}
 void lvo_mat4_inverse(const float m[16], float out[16]) { mat4Inverse(m, out); }
 void lvo_set_num_threads(int n) {
 #ifdef _OPENMP

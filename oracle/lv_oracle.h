@@ -328,6 +328,10 @@ void lvo_eaw_denoise(uint32_t width, uint32_t height, const float* ao, const flo
 /* Test hooks: the build-owned sin / cos / atan2 of the elliptic-tube path */
 void lvo_sincos_rad(float a, float* s, float* c);
 float lvo_atan2_det(float y, float x);
+/* test hook: the USE_BANDS halo coordinate of computeFragmentColor (RayHitCommon.glsl:232-351) for a fragment at angle phi on
+ * the cross-section x^2 / thickness^2 + y^2 = 1 (units of lineRadius, x along the line normal) seen from cam */
+float lvo_bands_ribbon_position(const float cam[3], const float linePos[3], const float lineNormal[3], const float tangent[3],
+                                float phi, float lineRadius, float thickness);
 /* Band data: getLinePassTubeAabbRenderData(false, true) -- normals from the ribbon directions (3 floats per input point), boxes
  * padded by bandWidth / 2 (LineDataFlow.cpp:2112-2277). */
 void lvo_build_tube_aabb_render_data_ribbons(
