@@ -12,7 +12,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT_DIR = os.path.join(HERE, "_lib")
 LIB = os.path.join(OUT_DIR, "liblinevis_hip.so")
-SOURCES = ["lv_api.hip", "lv_bvh.hip", "lv_render.hip", "lv_flow.hip", "lv_mlat.hip", "lv_svgf.hip"]
+# (source, object, extra flags): lv_mlat.hip is compiled in four parts (its kernel instantiations dominate the build time)
+SOURCES = [("lv_api.hip", "lv_api.o", []), ("lv_bvh.hip", "lv_bvh.o", []), ("lv_render.hip", "lv_render.o", []),
+           ("lv_flow.hip", "lv_flow.o", []), ("lv_svgf.hip", "lv_svgf.o", [])] + \
+          [("lv_mlat.hip", "lv_mlat_%d.o" % p, ["-DLV_MLAT_PART=%d" % p]) for p in range(4)]
 HEADERS = ["lv_device.h", "lv_trace.h", "lv_tile.h", "lv_internal.h", os.path.join("..", "..", "include", "linevis_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-DNDEBUG"] + os.environ.get("LV_EXTRA_HIPCC_FLAGS", "").split()
@@ -37,15 +40,15 @@ def build(force=False, verbose=False):
     headers = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
     objs = []
     procs = []
-    for s in SOURCES:
+    for s, oname, extra in SOURCES:
         src = os.path.join(CSRC, s)
-        obj = os.path.join(OUT_DIR, s.replace(".hip", ".o"))
+        obj = os.path.join(OUT_DIR, oname)
         objs.append(obj)
         if force or _stale(obj, [src] + headers):
-            cmd = [hipcc()] + FLAGS + ["-c", src, "-o", obj]
+            cmd = [hipcc()] + FLAGS + extra + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
-            procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+            procs.append((oname, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
     failed = False
     for s, p in procs:
         out, _ = p.communicate()

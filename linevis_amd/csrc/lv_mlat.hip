@@ -226,6 +226,44 @@ int launchMlatK(lv_ctx* ctx, const LvUniforms& U, const LvSceneDev& S, const LvT
 
 } // namespace
 
+// The (K x STATS x primitive x shading variant) instantiations of the kernel are what this file costs to compile (two minutes in
+// one piece): the build compiles it four times with -DLV_MLAT_PART=0..3, each part holding a quarter of them; part 0 also holds
+// the dispatcher.  Without the define everything lands in one object.
+#ifndef LV_MLAT_PART
+#define LV_MLAT_PART -1
+#endif
+#define LV_MLAT_HAS(p) (LV_MLAT_PART == -1 || LV_MLAT_PART == (p))
+#define LV_MLAT_ARGS lv_ctx *ctx, const LvUniforms &U, const LvSceneDev &S, const LvTiles &T, uint32_t gridTiles, uint32_t *out, \
+                     LvDevCounters *dc, uint4 *trace, uint32_t traceCap
+#define LV_MLAT_PASS ctx, U, S, T, gridTiles, out, dc, trace, traceCap
+int lv_mlat_launch_capsule_plain(LV_MLAT_ARGS);
+int lv_mlat_launch_capsule_shaded(LV_MLAT_ARGS, int shade);
+int lv_mlat_launch_triangle_plain_or_elliptic(LV_MLAT_ARGS, bool elliptic);
+int lv_mlat_launch_triangle_shaded(LV_MLAT_ARGS, int shade);
+
+#if LV_MLAT_HAS(0)
+int lv_mlat_launch_capsule_plain(LV_MLAT_ARGS) { return launchMlatK<LV_PRIM_CAPSULE, LV_SHADE_PLAIN>(LV_MLAT_PASS); }
+#endif
+#if LV_MLAT_HAS(1)
+int lv_mlat_launch_capsule_shaded(LV_MLAT_ARGS, int shade) {
+    return shade == LV_SHADE_HELICITY ? launchMlatK<LV_PRIM_CAPSULE, LV_SHADE_HELICITY>(LV_MLAT_PASS)
+                                      : launchMlatK<LV_PRIM_CAPSULE, LV_SHADE_BANDS>(LV_MLAT_PASS);
+}
+#endif
+#if LV_MLAT_HAS(2)
+int lv_mlat_launch_triangle_plain_or_elliptic(LV_MLAT_ARGS, bool elliptic) {
+    return elliptic ? launchMlatK<LV_PRIM_ELLIPTIC, LV_SHADE_BANDS>(LV_MLAT_PASS)
+                    : launchMlatK<LV_PRIM_TRIANGLE, LV_SHADE_PLAIN>(LV_MLAT_PASS);
+}
+#endif
+#if LV_MLAT_HAS(3)
+int lv_mlat_launch_triangle_shaded(LV_MLAT_ARGS, int shade) {
+    return shade == LV_SHADE_HELICITY ? launchMlatK<LV_PRIM_TRIANGLE, LV_SHADE_HELICITY>(LV_MLAT_PASS)
+                                      : launchMlatK<LV_PRIM_TRIANGLE, LV_SHADE_BANDS>(LV_MLAT_PASS);
+}
+#endif
+
+#if LV_MLAT_HAS(0)
 int lv_mlat_render(lv_ctx* ctx, const LvUniforms& U, const LvSceneDev& S, const LvTiles& T, uint32_t gridTiles,
                    uint32_t* out, LvDevCounters* dc, bool triangles) {
     uint4* trace = nullptr;
@@ -236,14 +274,11 @@ int lv_mlat_render(lv_ctx* ctx, const LvUniforms& U, const LvSceneDev& S, const 
         trace = (uint4*)ctx->mlatTrace.ptr;
         traceCap = ctx->opt.mlatTraceCapacity;
     }
-    if (U.useHelicityBands)
-        return triangles ? launchMlatK<LV_PRIM_TRIANGLE, LV_SHADE_HELICITY>(ctx, U, S, T, gridTiles, out, dc, trace, traceCap)
-                         : launchMlatK<LV_PRIM_CAPSULE, LV_SHADE_HELICITY>(ctx, U, S, T, gridTiles, out, dc, trace, traceCap);
-    if (U.useBands) {
-        if (triangles) return launchMlatK<LV_PRIM_TRIANGLE, LV_SHADE_BANDS>(ctx, U, S, T, gridTiles, out, dc, trace, traceCap);
-        if (U.useEllipticTubes) return launchMlatK<LV_PRIM_ELLIPTIC, LV_SHADE_BANDS>(ctx, U, S, T, gridTiles, out, dc, trace, traceCap);
-        return launchMlatK<LV_PRIM_CAPSULE, LV_SHADE_BANDS>(ctx, U, S, T, gridTiles, out, dc, trace, traceCap);
-    }
-    return triangles ? launchMlatK<LV_PRIM_TRIANGLE, LV_SHADE_PLAIN>(ctx, U, S, T, gridTiles, out, dc, trace, traceCap)
-                     : launchMlatK<LV_PRIM_CAPSULE, LV_SHADE_PLAIN>(ctx, U, S, T, gridTiles, out, dc, trace, traceCap);
+    const int shade = U.useHelicityBands ? LV_SHADE_HELICITY : U.useBands ? LV_SHADE_BANDS : LV_SHADE_PLAIN;
+    if (triangles)
+        return shade == LV_SHADE_PLAIN ? lv_mlat_launch_triangle_plain_or_elliptic(LV_MLAT_PASS, false)
+                                       : lv_mlat_launch_triangle_shaded(LV_MLAT_PASS, shade);
+    if (shade == LV_SHADE_BANDS && U.useEllipticTubes) return lv_mlat_launch_triangle_plain_or_elliptic(LV_MLAT_PASS, true);
+    return shade == LV_SHADE_PLAIN ? lv_mlat_launch_capsule_plain(LV_MLAT_PASS) : lv_mlat_launch_capsule_shaded(LV_MLAT_PASS, shade);
 }
+#endif

@@ -28,13 +28,13 @@ def build(specs):
         name, _, flags = spec.partition(":")
         flags = [f for f in flags.split(",") if f]
         objs = []
-        for s in B.SOURCES:
+        for s, oname, extra in B.SOURCES:
             if s in RECOMPILE:
-                obj = os.path.join(OUT, "%s.%s.o" % (name, s[:-4]))
-                procs.append((name, s, subprocess.Popen([B.hipcc()] + B.FLAGS + flags + ["-c", os.path.join(B.CSRC, s), "-o", obj],
+                obj = os.path.join(OUT, "%s.%s" % (name, oname))
+                procs.append((name, s, subprocess.Popen([B.hipcc()] + B.FLAGS + extra + flags + ["-c", os.path.join(B.CSRC, s), "-o", obj],
                                                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
             else:
-                obj = os.path.join(B.OUT_DIR, s.replace(".hip", ".o"))
+                obj = os.path.join(B.OUT_DIR, oname)
             objs.append(obj)
         procs.append((name, None, objs))
     pending = {}
