@@ -377,6 +377,8 @@ def main():
     # measured on one GPU with the tile lists of 8 ranks, slowest rank: 1.18 ms per frame with F = 1, 0.86 with 2, 0.73 with 4,
     # profiles/shard_probe_*.json).  One GPU: the AO kernel fills the chip (5.08 vs 5.18 ms), F = 1.
     frames_in_flight = 1 if world == 1 else min(4, world)
+    if os.environ.get("LV_FRAMES_IN_FLIGHT"):   # measurement knob (tools/probe_shard.py explores it per world size)
+        frames_in_flight = max(1, int(os.environ["LV_FRAMES_IN_FLIGHT"]))
 
     def measure(w, wkey):
         """Instrumented frame (counters), warm-up, K timed frames; returns everything rank 0 reports for this workload."""
