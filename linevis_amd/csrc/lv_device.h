@@ -14,8 +14,22 @@
 #define LV_BLOCK 256
 #define LV_LEAF_BIT 0x80000000u
 #define LV_INVALID 0xFFFFFFFFu
-#define LV_STACK_LDS 32     // per-thread traversal stack entries staged in LDS
+// per-thread traversal stack entries staged in LDS.  24 entries = 24 KB per workgroup: the tile kernels then need 40 KB
+// (k_ppll_gather 50 KB) and 4 (3) workgroups fit a CU instead of 3 (2) -- k_ao_primary -10 %, k_ppll_gather -11 % against 32 entries;
+// 14 entries fit one more but pay it back in overflow traffic (k_ppll_gather +5 %)
+#ifndef LV_STACK_LDS
+#define LV_STACK_LDS 24
+#endif
 #define LV_STACK_SPILL 64   // further entries in a global overflow slab; 96 >= max LBVH height (63 key bits + 32)
+// minimum waves per SIMD the register allocator must leave room for (hipcc's second __launch_bounds__ argument)
+// k_render_rt: 4 waves per SIMD (<= 128 VGPRs instead of 146; with the 40-KB workgroups that is 4 workgroups per CU): -6 % on
+// config 3's colour pass, -4.5 % on config 2.  The instrumented and the elliptic-tube instantiations keep their registers.
+#ifndef LV_RT_MIN_WAVES
+#define LV_RT_MIN_WAVES 4
+#endif
+#ifndef LV_GATHER_MIN_WAVES
+#define LV_GATHER_MIN_WAVES 1
+#endif
 #ifndef LV_REFILL_THRESHOLD
 #define LV_REFILL_THRESHOLD 8 // persistent AO waves fetch new rays once this many lanes are idle
 #endif

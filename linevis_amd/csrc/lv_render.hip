@@ -29,7 +29,7 @@ namespace {
 // Control flow is wave-uniform around every trace (lv_trace_closest is a wave-cooperative routine): the sample loop and
 // the transparency loop run while ANY lane of the wave still needs a trace; lanes that are done pass active = false.
 template <bool STATS, int PRIM, int BANDS = LV_SHADE_PLAIN>
-__global__ __launch_bounds__(LV_BLOCK) void k_render_rt(const LvUniforms U, const LvSceneDev S, const LvTiles T,
+__global__ __launch_bounds__(LV_BLOCK, (STATS || PRIM == LV_PRIM_ELLIPTIC) ? 1 : LV_RT_MIN_WAVES) void k_render_rt(const LvUniforms U, const LvSceneDev S, const LvTiles T,
                                                         uint32_t* __restrict__ out, LvDevCounters* dc) {
     __shared__ unsigned s_stack[LV_STACK_LDS * LV_BLOCK];
     LV_COOP_SHARED(LV_BLOCK / LV_WAVE);
@@ -757,7 +757,7 @@ __global__ __launch_bounds__(LV_BLOCK) void k_fill_f32(float* p, float v, size_t
 // over numSlices workgroups.  A slice accepts t in [lo, hi) (the last one up to tMax inclusive), so every fragment is
 // produced exactly once; each workgroup builds partial lists in LDS and splices them into the pixel's global list.
 template <bool STATS, int PRIM = LV_PRIM_CAPSULE, int BANDS = LV_SHADE_PLAIN>
-__global__ __launch_bounds__(LV_BLOCK) void k_ppll_gather(const LvUniforms U, const LvSceneDev S, const LvTiles T,
+__global__ __launch_bounds__(LV_BLOCK, LV_GATHER_MIN_WAVES) void k_ppll_gather(const LvUniforms U, const LvSceneDev S, const LvTiles T,
                                                           uint32_t* __restrict__ nodes, uint32_t* __restrict__ startOffset,
                                                           uint32_t* __restrict__ fragCount, LvDevCounters* dc,
                                                           uint32_t numSlices, uint32_t poolSlots) {
