@@ -48,6 +48,9 @@
 #ifndef LV_AO_STACK_LDS
 #define LV_AO_STACK_LDS 15      // LDS-staged stack entries per thread in k_ao_rays (deeper entries: HBM overflow slab)
 #endif
+#ifndef LV_AO_MIN_WAVES
+#define LV_AO_MIN_WAVES 5         // waves per SIMD k_ao_rays is compiled for (95 VGPRs; 6 would need <= 85 and 26 KB of LDS)
+#endif
 #ifndef LV_AO_BLOCK
 #define LV_AO_BLOCK 256         // threads per workgroup of k_ao_rays
 #endif

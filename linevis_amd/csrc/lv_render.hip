@@ -327,7 +327,7 @@ __device__ __forceinline__ size_t lv_ao_slot(const uint32_t* __restrict__ tileBa
 // the reference draws the (subdivision, ray) samples of a vertex from ONE LCG stream seeded with tea(vertex, frame), so
 // sample j starts from the stream advanced by 2 j steps: seed_j = A_j * seed_0 + C_j (lcgSkip[j] = {A_j, C_j}).
 template <bool STATS, bool ANY_HIT, int PRIM, bool BAKE = false, bool LIT = false>
-__global__ __launch_bounds__(LV_AO_BLOCK, 5) void k_ao_rays(const LvUniforms U, const LvSceneDev S,
+__global__ __launch_bounds__(LV_AO_BLOCK, LV_AO_MIN_WAVES) void k_ao_rays(const LvUniforms U, const LvSceneDev S,
                                                          const float4* __restrict__ gbuf, float* __restrict__ samples,
                                                          LvDevCounters* dc, const uint32_t* __restrict__ tileBase,
                                                          uint32_t numTiles, uint32_t tileCapacity,
