@@ -712,46 +712,63 @@ def test_config5_scale_tiles(hip_lib):
     assert (a[1] != 0xFFFFFFFF).sum() > 2000
 
 
-def test_config5_all_eight_tile_lists_reproduce_the_whole_frame(hip_lib):
-    """Config 5 as specified (5 M segments, 3840 x 2160, RTAO 256 spp, tiled for 8 ranks), every rank's tile list rendered in turn
-    on this one GPU through the path a rank uses (ShardedFrame.render_local with the cost-weighted deal) and de-tiled with the
-    device gather's code (assemble_device on the pieces): the sharded frame equals the frame rendered in one piece, byte for byte
-    -- seeds use global pixel coordinates, the AO of a pixel never depends on the tile list.  (The RCCL gather itself needs
-    the 8-GPU node; its collective sequence runs under gloo in tests/test_tiling_dist.py.)"""
+def _all_tile_lists_reproduce_the_whole_frame(c, mode, world, cost_scale):
+    """Every rank's tile list of a `world`-GPU run rendered in turn on this one GPU through the path a rank uses
+    (ShardedFrame.render_local, cost-weighted deal as bench.py applies it) and de-tiled with the device gather's code
+    (assemble_device on the pieces) = the frame rendered in one piece, byte for byte."""
     import torch
-    tr = scenes.normalize(scenes.rayleigh_benard())
-    flow = host_api.LineDataFlow().set_trajectories(tr.positions, tr.attributes, tr.line_offsets)
-    pts, seg, _ = flow.tube_aabb_render_data(0.002)
-    W5, H5 = 3840, 2160
-    c = Case(pts, seg, tfm.standard(), W5, H5, 0.002, **RTAO, ambient_occlusion_iterations=1,
-             ambient_occlusion_samples_per_frame=256)
     ctx = c.hip_context()
-    whole = ctx.render(11)
-    ao_whole = ctx.get_ao().copy()
-    assert (ao_whole < 1.0).sum() > 1000000
+    whole = ctx.render(mode)
     dev = torch.device("cuda", 0)
-    world = 8
-    frames = [tiling.ShardedFrame(W5, H5, 64, r, world, dev) for r in range(world)]
-    # the cost-weighted deal bench.py applies after its instrumented frame: every "rank" contributes the AO cost of its tiles
-    fn = tiling.hip_render_tiles_fn(ctx, 11)
-    costs = np.zeros(len(frames[0].all_tiles))
-    for sf in frames:
-        sf.render_local(fn)
-        torch.cuda.synchronize()
-        costs[sf.assignment[sf.rank]] = ctx.ao_tile_costs().astype(np.float64) * 256.0
-    for sf in frames:
-        sf.redeal(costs, base_cost=4.0 * 64 * 64)
+    frames = [tiling.ShardedFrame(c.width, c.height, 64, r, world, dev) for r in range(world)]
+    fn = tiling.hip_render_tiles_fn(ctx, mode)
+    if cost_scale:
+        costs = np.zeros(len(frames[0].all_tiles))
+        for sf in frames:
+            sf.render_local(fn)
+            torch.cuda.synchronize()
+            costs[sf.assignment[sf.rank]] = ctx.ao_tile_costs().astype(np.float64) * cost_scale
+        for sf in frames:
+            sf.redeal(costs, base_cost=4.0 * 64 * 64)
+        per_rank = np.array([costs[frames[0].assignment[r]].sum() for r in range(world)])
+        assert per_rank.max() < 1.1 * per_rank.mean()                  # the deal balances what it measured
     assert all(np.array_equal(np.sort(np.concatenate(sf.assignment)), np.arange(len(sf.all_tiles))) for sf in frames)
-    per_rank = np.array([costs[frames[0].assignment[r]].sum() for r in range(world)])
-    assert per_rank.max() < 1.1 * per_rank.mean()                      # the deal balances what it measured
     pieces = []
     for sf in frames:
         sf.render_local(fn)
         torch.cuda.synchronize()
         pieces.append(sf.out.clone())
     frames[0].gathered = pieces                                          # what dist.gather delivers on rank 0
-    sharded = frames[0].assemble_device().cpu().numpy()
-    assert np.array_equal(sharded, whole)
+    assert np.array_equal(frames[0].assemble_device().cpu().numpy(), whole)
+    return whole
+
+
+def test_config5_all_eight_tile_lists_reproduce_the_whole_frame(hip_lib):
+    """Config 5 as specified (5 M segments, 3840 x 2160, RTAO 256 spp, tiled for 8 ranks): seeds use global pixel coordinates, the
+    AO of a pixel never depends on the tile list.  (The RCCL gather itself needs the 8-GPU node; its collective sequence runs
+    under gloo in tests/test_tiling_dist.py.)"""
+    tr = scenes.normalize(scenes.rayleigh_benard())
+    flow = host_api.LineDataFlow().set_trajectories(tr.positions, tr.attributes, tr.line_offsets)
+    pts, seg, _ = flow.tube_aabb_render_data(0.002)
+    c = Case(pts, seg, tfm.standard(), 3840, 2160, 0.002, **RTAO, ambient_occlusion_iterations=1,
+             ambient_occlusion_samples_per_frame=256)
+    whole = _all_tile_lists_reproduce_the_whole_frame(c, 11, 8, 256.0)
+    assert (whole[..., :3] != 255).any(axis=2).sum() > 1000000
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_config3_and_4_tile_lists_reproduce_the_whole_frame(hip_lib, world):
+    """Configs 3 (RTAO 64 spp, here with the reference's triangle tubes for the AO rays) and 4 (PPLL, transparent) at full size,
+    sharded for 2 / 4 / 8 ranks."""
+    tr = scenes.normalize(scenes.tornado())
+    flow = host_api.LineDataFlow().set_trajectories(tr.positions, tr.attributes, tr.line_offsets)
+    pts, seg, _ = flow.tube_aabb_render_data(0.002)
+    c4 = Case(pts, seg, tfm.standard_transparent(), 1920, 1080, 0.002)
+    _all_tile_lists_reproduce_the_whole_frame(c4, 2, world, 0.0)
+    if world == 8:
+        c3 = Case(pts, seg, tfm.standard(), 1920, 1080, 0.002, **RTAO, ambient_occlusion_iterations=1,
+                  ambient_occlusion_samples_per_frame=64)
+        _all_tile_lists_reproduce_the_whole_frame(c3, 11, world, 64.0)
 
 
 def test_command_line_renderer(hip_lib, tmp_path):
