@@ -346,7 +346,7 @@ def main():
         tf = tfm.standard_transparent() if wl.get("transparent") else tfm.standard()
         attr_range = flow.attribute_range()
         if wl.get("mesh"):   # LineData::getLinePassTubeTriangleMeshRenderData -> the RTAO pass' geometry
-            mesh = flow.tube_triangle_render_data(LINE_WIDTH, 6)
+            mesh = flow.tube_triangle_render_data(LINE_WIDTH, int(wl["settings"].get("tube_num_subdivisions", 6)))
 
     def make_context(w, wait_for_consumer=True):
         if dry:
