@@ -384,7 +384,63 @@ def round2():
     np.savez_compressed(os.path.join(HERE, "round2.npz"), **out)
 
 
+def round2b_case(kind):
+    """The small cases of the second round-2 fixture set (shared with tests/test_golden_round2.py)."""
+    if kind in ("ppll_elliptic", "mlat_elliptic"):
+        c = round2_case("elliptic")
+        for k in list(c.settings):
+            if k.startswith("ambient_occlusion"):
+                del c.settings[k]
+        c.tf = tfm.standard_transparent()
+        if kind == "mlat_elliptic":
+            c.settings.update(use_mlat=True, mlat_num_nodes=4)
+        return c
+    # rotating helicity bands: capsules ("helicity") or the triangle tubes ("helicity_tri", mesh returned too)
+    tr = scenes.normalize(scenes.helix_bundle(n_lines=4, points_per_line=50, seed=4, turns=2.0))
+    s_ = np.linspace(0.0, 1.0, len(tr.positions)).astype(np.float32)
+    hel = (0.02 * np.sin(12.0 * s_ + 1.0) + 0.01).astype(np.float32)
+    lw = 0.03
+    pts, seg, _ = lvo.build_tube_aabb_render_data(tr.positions, tr.attributes, tr.line_offsets, lw, helicities=hel)
+    st = dict(rotating_helicity_bands=True, helicity_rotation_factor=0.25)
+    if kind == "helicity":
+        return Case(pts, seg, tfm.standard(), 80, 60, lw, **st)
+    mesh = lvo.build_tube_triangle_render_data(tr.positions, tr.attributes, tr.line_offsets, lw, 8, helicities=hel)
+    return Case(pts, seg, tfm.standard(), 80, 60, lw, geometry_mode="Triangle Mesh", tube_num_subdivisions=8, **st), mesh
+
+
+def round2b():
+    """Second set: PPLL fragment lists and MLAT (canonical order) of band data, rotating helicity bands on capsules and on the
+    triangle tubes (with UNIFORM_HELICITY_BAND_WIDTH)."""
+    out = {}
+    c = round2b_case("ppll_elliptic")
+    sc = c.oracle_scene()
+    P = c.oracle_params(sc)
+    out["ppll_elliptic_frame"] = sc.render_ppll(P)
+    nodes, start, cnt = sc.ppll_gather(P)
+    lists = []
+    for pix in np.nonzero(start != 0xFFFFFFFF)[0]:
+        i = int(start[pix])
+        while i != 0xFFFFFFFF:
+            lists.append((int(pix), int(nodes[i, 1]), int(nodes[i, 0])))
+            i = int(nodes[i, 2])
+    out["ppll_elliptic_fragments"] = np.array(sorted(lists), dtype=np.uint32)      # (pixel, depth bits, colour), sorted
+    c = round2b_case("mlat_elliptic")
+    sc = c.oracle_scene()
+    out["mlat_elliptic_frame"] = sc.render_rt_mlat(c.oracle_params(sc), 4)[0]
+    c = round2b_case("helicity")
+    out["helicity_frame"] = c.oracle_render(11)[0]
+    out["helicity_rotation_bits"] = f2u(c.points["lineRotation"])
+    c, mesh = round2b_case("helicity_tri")
+    sc = c.oracle_scene()
+    out["helicity_tri_frame"] = lvo.TriScene(*mesh, c.line_width).render_rt(sc, c.oracle_params(sc))
+    out["helicity_tri_rotation_bits"] = f2u(mesh[2]["lineRotation"])
+    np.savez_compressed(os.path.join(HERE, "round2b.npz"), **out)
+
+
 if __name__ == "__main__":
+    if "--only-round2b" in sys.argv:
+        round2b()
+        sys.exit(0)
     if "--only-round2" in sys.argv:
         round2()
         sys.exit(0)
@@ -407,6 +463,7 @@ if __name__ == "__main__":
     flow_small()
     mlat_small()
     round2()
+    round2b()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print("%-24s %8d bytes" % (f, os.path.getsize(os.path.join(HERE, f))))
