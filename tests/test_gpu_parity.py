@@ -588,6 +588,37 @@ def test_config2_whole_frame_against_the_oracle(hip_lib):
     assert max_lsb_diff(img, ref) <= LSB_TOL and (ref[..., :3] != 255).any(axis=2).sum() > 50000
 
 
+def test_config2_size_band_data_and_helicity_bands_whole_frames(hip_lib):
+    """The config-2 scene (100 k segments, 1920 x 1080) with the round-2 shading variants, every pixel: as band data through the
+    sphere-traced elliptic tubes (the bench's c2e workload; + RTAO over the tubelets, AO bit for bit) and with rotating helicity
+    bands on the capsules."""
+    base = scenes.normalize(scenes.helix_bundle())
+    tr = scenes.twisted_ribbons(base, twist=8.0)
+    flow = host_api.LineDataFlow().set_trajectories(tr.positions, tr.attributes, tr.line_offsets, tr.ribbon_directions)
+    pts, seg, _ = flow.tube_aabb_render_data_elliptic(0.005)
+    assert len(seg) == 100000
+    c = Case(pts, seg, tfm.standard(), 1920, 1080, 0.002, use_ribbons=True, use_analytic_elliptic_tubes=True, band_width=0.005,
+             min_band_thickness=0.15, **RTAO, ambient_occlusion_iterations=1, ambient_occlusion_samples_per_frame=4)
+    ctx = c.hip_context()
+    img = ctx.render(11)
+    sc = c.oracle_scene()
+    P = c.oracle_params(sc)
+    ao_ref = sc.render_ao(P, use_bvh=True)
+    assert np.array_equal(bits(ctx.get_ao()), bits(ao_ref)) and (ao_ref < 1.0).sum() > 100000
+    ref = sc.render_rt(P, ao=ao_ref, use_bvh=True)
+    assert max_lsb_diff(img, ref) <= LSB_TOL and (ref[..., :3] != 255).any(axis=2).sum() > 100000
+    # helicity bands: a smooth signed attribute along the lines drives lineRotation
+    hel = (0.03 * np.sin(np.linspace(0.0, 60.0, len(base.positions)))).astype(np.float32)
+    pts, seg, _ = lvo.build_tube_aabb_render_data(base.positions, base.attributes, base.line_offsets, 0.002, helicities=hel)
+    c = Case(pts, seg, tfm.standard(), 1920, 1080, 0.002, rotating_helicity_bands=True, helicity_rotation_factor=0.1)
+    img = c.hip_context().render(11)
+    sc = c.oracle_scene()
+    ref = sc.render_rt(c.oracle_params(sc), use_bvh=True)
+    assert max_lsb_diff(img, ref) <= LSB_TOL
+    plain = Case(pts, seg, tfm.standard(), 1920, 1080, 0.002).hip_context().render(11)
+    assert (np.abs(plain.astype(np.int32) - img.astype(np.int32)).max(axis=2) > 20).sum() > 5000       # the stripes are there
+
+
 # ---------------------------------------------------------------- BASELINE.json config 4 at full size
 def test_config4_full_size_ppll_and_mlat(hip_lib):
     """1 M transparent segments at 1920 x 1080: fragment lists of a crop against the oracle bit for bit, list lengths
