@@ -4,7 +4,7 @@ over frame sequences -- SVGF is temporal, so parity means the same images after 
 import numpy as np
 import pytest
 
-from common import small_case, max_lsb_diff
+from common import Case, small_case, max_lsb_diff
 from linevis_amd import camera
 from oracle import lvo
 
@@ -146,4 +146,30 @@ def test_switching_the_denoiser_clears_the_history(hip_lib):
     b0 = (ctx.render(11), ctx.get_ao())[1]
     b1 = (ctx.render(11), ctx.get_ao())[1]
     assert np.array_equal(a0, b0) and np.array_equal(a1, b1) and not np.array_equal(a0, a1)
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_svgf_full_size_sequence(hip_lib):
+    """The config-3 scene (1 M segments) at 1920 x 1080 through RTAO (8 spp per frame) + SVGF over a short camera path: every pixel
+    of the denoised AO image and of the frame, after every frame, against the oracle (its own BVH for the RTAO pass)."""
+    from linevis_amd import host_api, scenes, transfer_function as tfm
+    tr = scenes.normalize(scenes.tornado())
+    flow = host_api.LineDataFlow().set_trajectories(tr.positions, tr.attributes, tr.line_offsets)
+    pts, seg, _ = flow.tube_aabb_render_data(0.002)
+    c = Case(pts, seg, tfm.standard(), 1920, 1080, 0.002, **dict(RTAO, ambient_occlusion_iterations=1, ambient_occlusion_samples_per_frame=8,
+                                                                 ambient_occlusion_radius=0.1))
+    ctx = c.hip_context()
+    sc = c.oracle_scene()
+    sv = lvo.Svgf(c.width, c.height)
+    for f, pos in enumerate(camera_path()[1:4]):
+        c.view, c.proj, c.fovy, c.near, c.far = camera.default_camera(c.width, c.height, pos)
+        ctx.set_camera(c.view, c.proj, c.fovy, c.near, c.far, c.width, c.height)
+        img = ctx.render(11)
+        ao = ctx.get_ao()
+        P = c.oracle_params(sc)
+        ao_ref = sv.step(lambda: sc.render_ao(P, use_bvh=True), P)
+        assert np.abs(ao - ao_ref).max() < 3e-5, "frame %d" % f
+        assert max_lsb_diff(img, sc.render_rt(P, ao=ao_ref, use_bvh=True)) <= 2, "frame %d" % f
+    assert (ao_ref < 0.95).sum() > 100000
     ctx.close()
