@@ -1,6 +1,7 @@
 """Determinism soak (was tools/soak.py): 200 consecutive full-size frames of each headline path reproduce the first frame byte
 for byte -- a race in the wave-cooperative queues, the subtree hand-over, the drain phase, the tile-segmented G-buffer or the
 PPLL chunk allocator would show up as a rare difference."""
+import os
 import zlib
 
 import numpy as np
@@ -8,7 +9,7 @@ import pytest
 
 from linevis_amd import camera, scenes, tiling, transfer_function as tfm
 
-FRAMES = 200
+FRAMES = int(os.environ.get("LV_SOAK_FRAMES", "200"))   # one-off longer runs: LV_SOAK_FRAMES=5000
 
 
 @pytest.mark.gpu
