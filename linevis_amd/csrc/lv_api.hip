@@ -172,7 +172,7 @@ void lv_destroy(lv_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    for (LvDeviceBuffer* b : {&ctx->points, &ctx->segIdx, &ctx->nodes, &ctx->segs, &ctx->leafSeg, &ctx->segToLeaf, &ctx->tf,
+    for (LvDeviceBuffer* b : {&ctx->points, &ctx->segIdx, &ctx->nodes, &ctx->segs, &ctx->segAxis, &ctx->leafSeg, &ctx->segToLeaf, &ctx->tf,
                               &ctx->depthMinMax, &ctx->ao, &ctx->aoAlt, &ctx->featNormal, &ctx->featNormalAlt, &ctx->featPosition, &ctx->featPositionAlt, &ctx->eawPing, &ctx->eawPong, &ctx->tilesHaloDev,
                               &ctx->fullFrameTile, &ctx->svgf.normalDepth, &ctx->svgf.normalDepthHistory, &ctx->svgf.flowFwidth,
                               &ctx->svgf.moments, &ctx->svgf.momentsHistory, &ctx->svgf.colorHistory, &ctx->svgf.tempAccum,
@@ -636,7 +636,7 @@ int lv_get_stats(lv_ctx* ctx, lv_stats* out) {
         s.kernel_launches[k] = uint32_t(n);
     }
     uint64_t bytes = 0;
-    for (const LvDeviceBuffer* b : {&ctx->points, &ctx->segIdx, &ctx->nodes, &ctx->segs, &ctx->leafSeg, &ctx->segToLeaf, &ctx->tf,
+    for (const LvDeviceBuffer* b : {&ctx->points, &ctx->segIdx, &ctx->nodes, &ctx->segs, &ctx->segAxis, &ctx->leafSeg, &ctx->segToLeaf, &ctx->tf,
                                     &ctx->depthMinMax, &ctx->ao, &ctx->aoAlt, &ctx->tilesHaloDev, &ctx->aoGbuf, &ctx->aoList, &ctx->aoSamples,
                                     &ctx->counters, &ctx->ppllNodes, &ctx->ppllStart, &ctx->ppllCount, &ctx->ppllScratch, &ctx->tilesDev,
                                     &ctx->outDev, &ctx->scratchRays, &ctx->stackOverflow, &ctx->triIdx, &ctx->triVerts,

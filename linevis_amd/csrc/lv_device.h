@@ -48,6 +48,9 @@
 #ifndef LV_AO_STACK_LDS
 #define LV_AO_STACK_LDS 15      // LDS-staged stack entries per thread in k_ao_rays (deeper entries: HBM overflow slab)
 #endif
+#ifndef LV_PRECOMP_AXIS
+#define LV_PRECOMP_AXIS 1
+#endif
 #ifndef LV_AO_MIN_WAVES
 #define LV_AO_MIN_WAVES 5         // waves per SIMD k_ao_rays is compiled for (95 VGPRs; 6 would need <= 85 and 26 KB of LDS)
 #endif
@@ -175,6 +178,7 @@ struct LvSvgfFeat {
 struct LvSceneDev {
     const float4* nodes;        // 64-B compressed 4-wide LBVH nodes, 4 x float4 each (layout: lv_bvh.hip k_pack4)
     const float4* segs;         // 32-B segment records in Morton (leaf) order: {p0.xyz, attr0}, {p1.xyz, attr1}
+    const float4* segAxis;      // {normalize(p1 - p0), 0} per leaf: the tube axis of the capsule test, computed at build time
     const uint32_t* leafSeg;    // leaf position -> original segment index
     const uint32_t* segToLeaf;  // original segment index -> leaf position
     const lv_line_point* points;// 48-B point records, input order

@@ -99,7 +99,7 @@ struct lv_ctx {
     // scene
     uint32_t numPoints = 0, numSegs = 0, numNodes = 0;
     LvDeviceBuffer points, segIdx;            // input order
-    LvDeviceBuffer nodes, segs, leafSeg, segToLeaf; // accel
+    LvDeviceBuffer nodes, segs, segAxis, leafSeg, segToLeaf; // accel
     LvDeviceBuffer tf;
     uint32_t tfN = 0;
     float attrMin = 0.0f, attrMax = 1.0f;

@@ -1077,6 +1077,7 @@ LvSceneDev sceneDev(const lv_ctx* ctx) {
     LvSceneDev S;
     S.nodes = (const float4*)ctx->nodes.ptr;
     S.segs = (const float4*)ctx->segs.ptr;
+    S.segAxis = (const float4*)ctx->segAxis.ptr;
     S.leafSeg = (const uint32_t*)ctx->leafSeg.ptr;
     S.segToLeaf = (const uint32_t*)ctx->segToLeaf.ptr;
     S.points = (const lv_line_point*)ctx->points.ptr;

@@ -35,8 +35,8 @@ __device__ __forceinline__ bool lv_ray_sphere(f3 o, f3 d, f3 ctr, float radius, 
     return true;
 }
 
-__device__ __forceinline__ bool lv_ray_tube(f3 o, f3 d, f3 tubeStart, f3 tubeEnd, float radius, float& hitT) {
-    f3 td = norm3(tubeEnd - tubeStart);
+// td = normalize(tubeEnd - tubeStart): per test (lv_ray_tube) or precomputed per segment with the same norm3 (S.segAxis)
+__device__ __forceinline__ bool lv_ray_tube_td(f3 o, f3 d, f3 tubeStart, f3 tubeEnd, f3 td, float radius, float& hitT) {
     f3 deltaP = o - tubeStart;
     f3 av = d - dot3(d, td) * td;
     f3 cv = deltaP - dot3(deltaP, td) * td;
@@ -59,14 +59,18 @@ __device__ __forceinline__ bool lv_ray_tube(f3 o, f3 d, f3 tubeStart, f3 tubeEnd
     return false;
 }
 
+__device__ __forceinline__ bool lv_ray_tube(f3 o, f3 d, f3 tubeStart, f3 tubeEnd, float radius, float& hitT) {
+    return lv_ray_tube_td(o, d, tubeStart, tubeEnd, norm3(tubeEnd - tubeStart), radius, hitT);
+}
+
 // IntersectionTube main(): nearest of {cylinder, sphere(p0), sphere(p1)}; kind 0/1/2
-__device__ __forceinline__ bool lv_intersect_capsule(f3 o, f3 d, f3 p0, f3 p1, float radius, bool capped,
-                                                     float& hitTOut, int& kindOut) {
+__device__ __forceinline__ bool lv_intersect_capsule_td(f3 o, f3 d, f3 p0, f3 p1, f3 td, float radius, bool capped,
+                                                        float& hitTOut, int& kindOut) {
     bool has = false;
     float hitT = 1e7f;
     int kind = 0;
     float tubeT;
-    if (lv_ray_tube(o, d, p0, p1, radius, tubeT)) { hitT = tubeT; has = true; kind = 0; }
+    if (lv_ray_tube_td(o, d, p0, p1, td, radius, tubeT)) { hitT = tubeT; has = true; kind = 0; }
     if (capped) {
         float s0T, s1T;
         bool h0 = lv_ray_sphere(o, d, p0, radius, s0T);
@@ -77,6 +81,10 @@ __device__ __forceinline__ bool lv_intersect_capsule(f3 o, f3 d, f3 p0, f3 p1, f
     hitTOut = hitT;
     kindOut = kind;
     return has;
+}
+__device__ __forceinline__ bool lv_intersect_capsule(f3 o, f3 d, f3 p0, f3 p1, float radius, bool capped,
+                                                     float& hitTOut, int& kindOut) {
+    return lv_intersect_capsule_td(o, d, p0, p1, norm3(p1 - p0), radius, capped, hitTOut, kindOut);
 }
 
 // intersection_form = literal: the reference's roots exactly as written -- t = (-B -+ sqrt(B^2 - 4AC)) / 2A,
@@ -569,9 +577,17 @@ __device__ __forceinline__ bool lv_leaf_test(const LvSceneDev& S, unsigned leaf,
     } else {
         const float4 a = S.segs[2 * size_t(leaf)], b = S.segs[2 * size_t(leaf) + 1];
         int kind;
-        const bool hit = (LIT == 1 || (LIT == -1 && S.literalIntersection))
-                ? lv_intersect_capsule_literal(o, d, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), radius, capped, t, kind)
-                : lv_intersect_capsule(o, d, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), radius, capped, t, kind);
+        bool hit;
+        if (LIT == 1 || (LIT == -1 && S.literalIntersection)) {
+            hit = lv_intersect_capsule_literal(o, d, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), radius, capped, t, kind);
+        } else {
+#if LV_PRECOMP_AXIS
+            const float4 ax = S.segAxis[leaf];
+            hit = lv_intersect_capsule_td(o, d, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(ax.x, ax.y, ax.z), radius, capped, t, kind);
+#else
+            hit = lv_intersect_capsule(o, d, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), radius, capped, t, kind);
+#endif
+        }
         if (hit) low = (S.leafSeg[leaf] << 2) | unsigned(kind);
         return hit;
     }
