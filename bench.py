@@ -46,15 +46,19 @@ SETTINGS = {
 }
 C3 = ("C3: 1M-segment tornado-style streamlines (1000 lines x 1001 points, seed 12345), 1920x1080, "
       "colour pass 1 spp + RTAO 64 spp (1 iteration x 64 samples, radius 0.1, distance based), line width 0.002")
-C3T = C3 + ", AO rays against the reference's 6-gon triangle tubes (12.06 M triangles, rtao_geometry=triangle_tubes)"
-C3C = C3 + ", AO rays against the analytic capsules of the segment LBVH (rtao_geometry=capsules)"
+C3T = (C3 + ", AO rays against the reference's 6-gon triangle tubes (12.06 M triangles, rtao_geometry=triangle_tubes), colour pass "
+      "with the reference's literal ray-capsule roots (intersection_form=literal, RayIntersectionTestsVulkan.glsl:39-119)")
+C3C = (C3 + ", AO rays against the analytic capsules of the segment LBVH (rtao_geometry=capsules), closest-approach ray-capsule "
+      "roots in both passes (intersection_form=closest_approach: NOT the reference's formula, DESIGN.md section 4)")
 WORKLOADS = {
     # the default: c3t timed as the headline, c3c timed right after it and reported beside it
     "c3": dict(name=C3T + "; the same frame with rtao_geometry=capsules is reported as value_capsules", scene="tornado", mode=11,
-               settings=dict(SETTINGS, rtao_geometry="triangle_tubes"), kernel="k_ao_rays", mesh=True, pmc="c3t", also="c3c"),
-    "c3t": dict(name=C3T, scene="tornado", mode=11, settings=dict(SETTINGS, rtao_geometry="triangle_tubes"),
-                kernel="k_ao_rays", mesh=True),
-    "c3c": dict(name=C3C, scene="tornado", mode=11, settings=SETTINGS, kernel="k_ao_rays"),
+               settings=dict(SETTINGS, rtao_geometry="triangle_tubes", intersection_form="literal"), kernel="k_ao_rays", mesh=True,
+               pmc="c3t", also="c3c"),
+    "c3t": dict(name=C3T, scene="tornado", mode=11,
+                settings=dict(SETTINGS, rtao_geometry="triangle_tubes", intersection_form="literal"), kernel="k_ao_rays", mesh=True),
+    "c3c": dict(name=C3C, scene="tornado", mode=11, settings=dict(SETTINGS, intersection_form="closest_approach"),
+                kernel="k_ao_rays"),
     "c5": dict(name="C5: 5M-segment Rayleigh-Benard-like convection rolls (5000 lines x 1001 points, seed 12345), 3840x2160, "
                     "colour pass 1 spp + RTAO 256 spp (1 iteration x 256 samples, radius 0.1, distance based, capsules), line "
                     "width 0.002; BASELINE.json config 5 (meant for 8 GPUs; with fewer the same frame takes proportionally longer)",
@@ -137,6 +141,9 @@ def cpu_baseline(W, H, pts, seg, tf, attr_range, view, proj, fovy, near, far, ta
             sc.render_rt(P, ao=ao, tile=tile, use_bvh=True, stats=st)
         return time.time() - t, int(st.raysTraced)
 
+    t_all = time.time()
+    if workload == "c3t":   # the timed GPU frame uses the reference's literal roots in its colour pass: so does the CPU restatement
+        lvo.set_default_intersection_form(True)
     cw, ch = 96, 54                             # calibration crop, then grow towards ~target_seconds of work
     dt, rays = run(cw, ch)
     for _ in range(3):
@@ -152,7 +159,9 @@ def cpu_baseline(W, H, pts, seg, tf, attr_range, view, proj, fovy, near, far, ta
         total += d2
         reps += 1
     dt = total / reps
+    lvo.set_default_intersection_form(False)
     return {"value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "wall_seconds": round(time.time() - t_all + build_s, 2),
             "logical_cpus_visible": os.cpu_count(),
             "sample": "centred %dx%d crop of the same frame (%s) in 16x16-pixel tiles over %d OpenMP threads = the cores this "
                       "process may use (cgroup quota), %d pass(es), %.1f s in total (%d rays per pass), CPU LBVH build %.1f s "

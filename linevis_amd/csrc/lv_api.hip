@@ -534,8 +534,9 @@ int lv_set_option(lv_ctx* ctx, const char* key, const char* value) {
     } else if (k == "collect_stats") {
         o.collectStats = parseBool(value);
     } else if (k == "intersection_form") {
-        if (std::string(value) == "closest_approach") o.literalIntersection = false;
-        else if (std::string(value) == "literal") o.literalIntersection = true;
+        if (std::string(value) == "auto") o.intersectionForm = 0;
+        else if (std::string(value) == "closest_approach") o.intersectionForm = 1;
+        else if (std::string(value) == "literal") o.intersectionForm = 2;
         else return bad();
     } else if (k == "rtao_geometry") {
         if (std::string(value) == "capsules") o.aoTriangleTubes = false;

@@ -84,7 +84,10 @@ struct LvOptions {
     bool svgfEnabled = false;
     uint32_t svgfIterations = 5;              // maxNumIterations, SVGF.hpp:115 (GUI range 0..5)
     float svgfAllowedZDist = 0.002f, svgfAllowedNormalDist = 0.02f; // SVGF.hpp:70-71
-    bool literalIntersection = false;         // intersection_form: false = closest approach (default), true = the reference's literal roots
+    // intersection_form: 0 = auto (default): the reference's literal roots whenever the RTAO pass traces the reference's
+    // triangle tubes (rtao_geometry = triangle_tubes: the colour pass is then the only user of the capsule test and the
+    // literal form is nearly free), closest approach otherwise; 1 = closest_approach; 2 = literal
+    int intersectionForm = 0;
     bool mlatRecordTrace = false;             // with collect_stats: record every pixel's candidate visiting order
     uint32_t mlatTraceCapacity = 1u << 22;    // records (16 B each)
 };
@@ -183,6 +186,10 @@ struct lv_ctx {
 int lv_fail(lv_ctx* ctx, int code, const char* fmt, ...);
 // width the capsule LBVH's leaf boxes are padded with: the band width for elliptic tubes (useRibbonNormals,
 // LineDataFlow.cpp:2120-2126), the line width otherwise
+// the capsule roots in use: the reference's textbook form (RayIntersectionTestsVulkan.glsl:39-119) or the closest-approach form
+inline bool lv_literal_intersection(const lv_ctx* ctx) {
+    return ctx->opt.intersectionForm == 2 || (ctx->opt.intersectionForm == 0 && ctx->opt.aoTriangleTubes);
+}
 inline float lv_accel_width(const lv_ctx* ctx) {
     return (ctx->opt.useRibbons && ctx->opt.ellipticTubes) ? ctx->opt.bandWidth : ctx->opt.lineWidth;
 }

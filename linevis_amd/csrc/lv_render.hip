@@ -1088,7 +1088,7 @@ LvSceneDev sceneDev(const lv_ctx* ctx) {
     S.stackOverflow = nullptr;
     S.accum = nullptr;
     S.numSegs = ctx->numSegs;
-    S.literalIntersection = ctx->opt.literalIntersection ? 1u : 0u;
+    S.literalIntersection = lv_literal_intersection(ctx) ? 1u : 0u;
     S.ellBandWidth = ctx->opt.bandWidth;
     S.ellMinBandThickness = ctx->opt.minBandThickness;
     {   // cameraPosition, as lv_fill_uniforms
@@ -1376,7 +1376,7 @@ static int lv_run_ao(lv_ctx* ctx, LvUniforms& U, LvSceneDev& S, const LvTiles& T
     do {                                                               \
         if (tri) LV_LAUNCH_AO(ST, AH, LV_PRIM_TRIANGLE);               \
         else if (U.useEllipticTubes) LV_LAUNCH_AO(ST, AH, LV_PRIM_ELLIPTIC); \
-        else if (ctx->opt.literalIntersection) LV_LAUNCH_AO_LIT(ST, AH); \
+        else if (lv_literal_intersection(ctx)) LV_LAUNCH_AO_LIT(ST, AH); \
         else LV_LAUNCH_AO(ST, AH, LV_PRIM_CAPSULE);                    \
     } while (0)
         const bool ell = U.useEllipticTubes != 0u;

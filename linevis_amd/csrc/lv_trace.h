@@ -340,30 +340,8 @@ __device__ __forceinline__ unsigned lv_node_step(const LvSceneDev& S, unsigned n
     const float4* p = S.nodes + 4 * size_t(node);
     const float4 q0 = p[0], q1 = p[1], q2 = p[2], cf = p[3];
     if (STATS) cnt.nodes++;
-#if defined(LV_EXP_EXTRA_LOADS) || defined(LV_EXP_EXTRA_VALU)
-    // sensitivity probes (tools/variants.py): what one more L1-hitting dwordx4 / one more VALU instruction per node step costs
-    {
-        float sink = 0.0f;
-#ifdef LV_EXP_EXTRA_LOADS
-#pragma unroll
-        for (int k = 0; k < LV_EXP_EXTRA_LOADS; k++) {
-            const float4 x = p[(k & 3) + 4 * int(S.numSegs >> 31)]; // numSegs < 2^31: same node, but not provably so
-            sink += (x.x + x.y) + (x.z + x.w);
-        }
-#endif
-#ifdef LV_EXP_EXTRA_VALU
-        float e0 = q0.x, e1 = q0.y, e2 = q0.z, e3 = q0.w;
-#pragma unroll
-        for (int k = 0; k < LV_EXP_EXTRA_VALU / 4; k++) {
-            asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(e0) : "v"(inv.x));
-            asm volatile("v_cvt_f32_ubyte1 %0, %0" : "+v"(e1));
-            asm volatile("v_max_f32 %0, %0, %1" : "+v"(e2) : "v"(inv.y));
-            asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(e3) : "v"(inv.z));
-        }
-        sink += (e0 + e1) + (e2 + e3);
-#endif
-        if (sink == 1.2345678e-30f) tMax = 0.0f; // keeps the probes alive; never true in practice
-    }
+#ifdef LV_NODE_STEP_PROBE // sensitivity probes live in tools/variants_inc/probes.h (tools/variants.py force-includes it); never in the product
+    LV_NODE_STEP_PROBE(p, q0, inv, tMax, S);
 #endif
     unsigned c0 = __float_as_uint(cf.x), c1 = __float_as_uint(cf.y), c2 = __float_as_uint(cf.z), c3 = __float_as_uint(cf.w);
     const f3 A = mk3(q0.w * inv.x, q1.x * inv.y, q1.y * inv.z);
@@ -383,6 +361,33 @@ __device__ __forceinline__ unsigned lv_node_step(const LvSceneDev& S, unsigned n
     const bool h2 = lv_slab_q(nearX, nearY, nearZ, farX, farY, farZ, 2, A, B, tMin, tMax, k2);
     const bool h3 = lv_slab_q(nearX, nearY, nearZ, farX, farY, farZ, 3, A, B, tMin, tMax, k3);
     const float INF = __builtin_inff();
+    if (ORDERED == 3) {
+        // nearest hit child WITHOUT a sorting network: the minimum of the masked keys (min3 + min), the first slot that holds it
+        // (exact compare: the minimum IS one of the four), the other hit children pushed in stored order.  The hit / selected flags
+        // are lane masks (scalar registers, combined on the scalar unit), so the children themselves are never moved or masked.
+        k0 = h0 ? k0 : INF; k1 = h1 ? k1 : INF; k2 = h2 ? k2 : INF; k3 = h3 ? k3 : INF;
+        const float km = fminf(fminf(k0, k1), fminf(k2, k3));
+        const bool s0 = h0 && k0 == km;
+        const bool s1 = h1 && !s0 && k1 == km;
+        const bool s2 = h2 && !s0 && !s1 && k2 == km;
+        const bool s3 = h3 && !s0 && !s1 && !s2;
+        unsigned sel = LV_INVALID;
+        sel = s3 ? c3 : sel; sel = s2 ? c2 : sel; sel = s1 ? c1 : sel; sel = s0 ? c0 : sel;
+        const bool p0 = h0 && !s0, p1 = h1 && !s1, p2 = h2 && !s2, p3 = h3 && !s3;
+        if (st.sp + 4 <= STACK::kLds) { // four unconditional writes, at most three of them kept
+            st.lds[st.sp * STACK::kStride] = c3; st.sp += p3 ? 1 : 0;
+            st.lds[st.sp * STACK::kStride] = c2; st.sp += p2 ? 1 : 0;
+            st.lds[st.sp * STACK::kStride] = c1; st.sp += p1 ? 1 : 0;
+            st.lds[st.sp * STACK::kStride] = c0; st.sp += p0 ? 1 : 0;
+        } else {
+            if (p3) st.push(c3);
+            if (p2) st.push(c2);
+            if (p1) st.push(c1);
+            if (p0) st.push(c0);
+        }
+        if (sel != LV_INVALID) return sel;
+        return lv_pop_or_done(st);
+    }
     k0 = h0 ? k0 : INF; k1 = h1 ? k1 : INF; k2 = h2 ? k2 : INF; k3 = h3 ? k3 : INF;
     c0 = h0 ? c0 : LV_INVALID; c1 = h1 ? c1 : LV_INVALID; c2 = h2 ? c2 : LV_INVALID; c3 = h3 ? c3 : LV_INVALID;
     if (ORDERED == 2 || (ORDERED == 1 && LV_SORT_CHILDREN)) { // 5-comparator sorting network, misses (key = +inf) sink to the end

@@ -733,18 +733,45 @@ def num_threads():
     return int(lib().lvo_num_threads())
 
 
+_DEFAULT_SWITCHES = [0, 0]      # what the oracle evaluates outside every deviation_switches block
+_CURRENT_SWITCHES = [0, 0]
+_BLOCK_DEPTH = [0]
+
+
+def _apply_switches(lit, aol):
+    _CURRENT_SWITCHES[0], _CURRENT_SWITCHES[1] = int(lit), int(aol)
+    lib().lvo_set_deviation_switches(int(lit), int(aol))
+
+
+def set_default_intersection_form(literal):
+    """The ray-capsule roots the oracle evaluates from now on (outside deviation_switches blocks): False = closest-approach form,
+    True = the reference's textbook roots.  tests/common.py Case.oracle_params() calls this with what the case's settings select
+    (intersection_form; "auto" = literal with rtao_geometry = triangle_tubes, like the library); tests/conftest.py resets it
+    before every test."""
+    _DEFAULT_SWITCHES[0] = int(bool(literal))
+    if _BLOCK_DEPTH[0] == 0:    # an explicit deviation_switches block keeps what it asked for
+        _apply_switches(_DEFAULT_SWITCHES[0], _DEFAULT_SWITCHES[1])
+
+
 class deviation_switches:
-    """Context manager: evaluate the reference's literal intersection roots / AO lookup inside the block."""
+    """Context manager: evaluate the reference's literal intersection roots / AO lookup inside the block (nestable: leaving a
+    block restores what was in force when it was entered)."""
 
     def __init__(self, literal_intersection=False, reference_ao_lookup=False):
         self.args = (int(bool(literal_intersection)), int(bool(reference_ao_lookup)))
 
     def __enter__(self):
-        lib().lvo_set_deviation_switches(*self.args)
+        self.saved = tuple(_CURRENT_SWITCHES)
+        _BLOCK_DEPTH[0] += 1
+        _apply_switches(*self.args)
         return self
 
     def __exit__(self, *exc):
-        lib().lvo_set_deviation_switches(0, 0)
+        _BLOCK_DEPTH[0] -= 1
+        if _BLOCK_DEPTH[0] == 0:
+            _apply_switches(*_DEFAULT_SWITCHES)   # (the default may have changed inside the block)
+        else:
+            _apply_switches(*self.saved)
         return False
 
 

@@ -34,8 +34,15 @@ class Case:
     def oracle_scene(self):
         return lvo.Scene(self.points, self.seg, self.tf)
 
+    def literal_form(self):
+        """intersection_form as the library resolves it (lv_literal_intersection): "auto" = the reference's literal roots whenever
+        the RTAO pass traces the reference's triangle tubes, closest approach otherwise."""
+        f = self.settings.get("intersection_form", "auto")
+        return f == "literal" or (f == "auto" and self.settings.get("rtao_geometry") == "triangle_tubes")
+
     def oracle_params(self, scene=None):
         s = self.settings
+        lvo.set_default_intersection_form(self.literal_form())   # the oracle evaluates the form this case's settings select
         spp = int(s.get("num_samples_per_frame", 1))
         ao_on = s.get("ambient_occlusion_mode", "None") == "RTAO (Screen Space)" and \
             float(s.get("ambient_occlusion_strength", 0.0)) > 0.0

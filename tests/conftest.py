@@ -19,3 +19,13 @@ def hip_lib():
     """The HIP C-ABI library; GPU tests fail loudly (no skip, no fallback) when it is missing."""
     from linevis_amd import capi
     return capi.load()
+
+
+@pytest.fixture(autouse=True)
+def _oracle_default_form():
+    """Every test starts with the oracle on the closest-approach roots; Case.oracle_params() switches it to what the case's
+    settings select (common.Case.literal_form)."""
+    from oracle import lvo
+    lvo.set_default_intersection_form(False)
+    yield
+    lvo.set_default_intersection_form(False)

@@ -134,6 +134,8 @@ def test_hip_eaw_against_the_oracle(hip_lib, variant):
     from linevis_amd import host_api
     flow = host_api.LineDataFlow().set_trajectories(tr.positions, tr.attributes, tr.line_offsets)
     pts, seg, _ = flow.tube_aabb_render_data(0.02)
+    if variant == "triangle_tubes":
+        settings.update(rtao_geometry="triangle_tubes")   # (the colour pass then uses the reference's literal roots: Case.literal_form)
     c = Case(pts, seg, tfm.standard(), 150, 90, 0.02, **settings)
     ctx = c.hip_context()
     sc = c.oracle_scene()
@@ -142,7 +144,6 @@ def test_hip_eaw_against_the_oracle(hip_lib, variant):
     if variant == "triangle_tubes":
         mesh = flow.tube_triangle_render_data(0.02, 6)
         ctx.set_tube_triangle_mesh(*mesh)
-        ctx.set_option("rtao_geometry", "triangle_tubes")
         tsc = lvo.TriScene(mesh[0], mesh[1], mesh[2], 0.02)
         render_ao = lambda t: tsc.render_ao(P, tile=t)
     full = ctx.render(11)

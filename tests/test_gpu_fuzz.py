@@ -157,10 +157,10 @@ def test_random_triangle_tube_cases(hip_lib, seed):
         tri_ao = bool(rng.integers(2)) and "ambient_occlusion_mode" in c.settings
         tri_colour = bool(rng.integers(2)) or not tri_ao
         tag = "seed %d case %d: %dx%d lw %g triAO %s triColour %s %s" % (seed, k, c.width, c.height, lw, tri_ao, tri_colour, c.settings)
+        if tri_ao:
+            c.settings["rtao_geometry"] = "triangle_tubes"
         ctx = c.hip_context()
         ctx.set_tube_triangle_mesh(*mesh)
-        if tri_ao:
-            ctx.set_option("rtao_geometry", "triangle_tubes")
         if tri_colour:
             ctx.set_option("geometry_mode", "Triangle Mesh")
         img = ctx.render(11)

@@ -27,6 +27,8 @@ def build(specs):
     for spec in specs:
         name, _, flags = spec.partition(":")
         flags = [f for f in flags.split(",") if f]
+        if any(f.startswith("-DLV_EXP_EXTRA_") for f in flags):   # the node-step sensitivity probes live outside the product headers
+            flags += ["-include", os.path.join(R, "tools", "variants_inc", "probes.h")]
         objs = []
         for s, oname, extra in B.SOURCES:
             if s in RECOMPILE:
