@@ -538,6 +538,12 @@ int lv_set_option(lv_ctx* ctx, const char* key, const char* value) {
         else if (std::string(value) == "closest_approach") o.intersectionForm = 1;
         else if (std::string(value) == "literal") o.intersectionForm = 2;
         else return bad();
+    } else if (k == "ppll_fragment_colour") {
+        // which computeFragmentColor the PPLL gather runs: "raster" = the raster tube shader's (LinePassGeometryShaderTubes.glsl, what
+        // the reference's gather pass executes; default), "ray_tracer" = RayHitCommon.glsl's (rounds 1-2 of this build; deviation probe)
+        if (std::string(value) == "raster") o.ppllRayTracerColour = false;
+        else if (std::string(value) == "ray_tracer") o.ppllRayTracerColour = true;
+        else return bad();
     } else if (k == "rtao_geometry") {
         if (std::string(value) == "capsules") o.aoTriangleTubes = false;
         else if (std::string(value) == "triangle_tubes") o.aoTriangleTubes = true;

@@ -163,6 +163,9 @@ struct LvUniforms {
     // (LineDataFlow.cpp:979-984,2432-2440)
     uint32_t useHelicityBands, numSubdivisionsBands;
     float separatorBaseWidth, helicityRotationFactor;
+    // PPLL gather: 1 = fragments are shaded by the raster tube shader's variant (LinePassGeometryShaderTubes.glsl:785-815,1079-1087:
+    // EPSILON_OUTLINE = 0, EPSILON_WHITE = fwidth(ribbonPosition)), 0 = by RayHitCommon's (ppll_fragment_colour = ray_tracer)
+    uint32_t ppllRasterColour;
     uint32_t uniformHelicityBandWidth; // UNIFORM_HELICITY_BAND_WIDTH: triangle closest-hit path only (LineAttributesBarycentric.glsl:94-112)
 };
 

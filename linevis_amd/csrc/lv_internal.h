@@ -88,6 +88,7 @@ struct LvOptions {
     // triangle tubes (rtao_geometry = triangle_tubes: the colour pass is then the only user of the capsule test and the
     // literal form is nearly free), closest approach otherwise; 1 = closest_approach; 2 = literal
     int intersectionForm = 0;
+    bool ppllRayTracerColour = false;         // ppll_fragment_colour: false = "raster" (the reference's gather shader, default), true = "ray_tracer"
     bool mlatRecordTrace = false;             // with collect_stats: record every pixel's candidate visiting order
     uint32_t mlatTraceCapacity = 1u << 22;    // records (16 B each)
 };

@@ -808,13 +808,24 @@ __global__ __launch_bounds__(LV_BLOCK, LV_GATHER_MIN_WAVES) void k_ppll_gather(c
     // Fragments of a pixel are produced by whichever lane is handed the (pixel, segment) hit: the lane shades with the
     // owner's ray + AO texel and links the node with an LDS atomic exchange on the owner's list head (the reference's
     // atomicExchange(startOffset[pixel]), LinkedListGather.glsl:55, kept in LDS until the slice is finished).
-    lv_trace_all<STATS, false, PRIM>(S, U.radius, U.useCappedTubes != 0, active, o, d, lo, hi, aoTexel, 0.0f,
-                        lv_stack_mem(s_stack, S.stackOverflow), cm, hq, cnt,
-                        [&](unsigned owner, uint32_t leaf, float t, int kind, f3 ro, f3 rd, float ownerAo, float) {
+    // second payload word: the owner's pixel -- the lane that shades a fragment rebuilds the rays through the 2 x 2 quad partners
+    // for fwidth(ribbonPosition) of the raster fragment colour (LvRasterQuad)
+    lv_trace_all<STATS, false, PRIM>(S, U.radius, U.useCappedTubes != 0, active, o, d, lo, hi, aoTexel,
+                        __uint_as_float(px.x | (px.y << 16)), lv_stack_mem(s_stack, S.stackOverflow), cm, hq, cnt,
+                        [&](unsigned owner, uint32_t leaf, float t, int kind, f3 ro, f3 rd, float ownerAo, float ownerPixel) {
         LvHit h; h.t = t; h.leaf = leaf; h.kind = kind; h.found = true;
         float hitT;
-        f4 color = PRIM == LV_PRIM_ELLIPTIC ? lv_shade_hit_elliptic(S, U, ownerAo, ro, rd, h, hitT)
-                                            : lv_shade_hit<BANDS>(S, U, ownerAo, ro, rd, h, hitT);
+        LvRasterQuad rq;
+        const LvRasterQuad* rqp = nullptr;
+        if (U.ppllRasterColour) {
+            const uint32_t pxy = __float_as_uint(ownerPixel), qx = pxy & 0xFFFFu, qy = pxy >> 16;
+            f3 oq;
+            lv_primary_ray(U, qx ^ 1u, qy, 0.5f, 0.5f, oq, rq.dX);
+            lv_primary_ray(U, qx, qy ^ 1u, 0.5f, 0.5f, oq, rq.dY);
+            rqp = &rq;
+        }
+        f4 color = PRIM == LV_PRIM_ELLIPTIC ? lv_shade_hit_elliptic(S, U, ownerAo, ro, rd, h, hitT, rqp)
+                                            : lv_shade_hit<BANDS>(S, U, ownerAo, ro, rd, h, hitT, rqp);
         if (STATS) cnt.hits++;
         if (color.w < 0.001f) return; // gatherFragment: discard, LinkedListGather.glsl:34
         // wave-aggregated node allocation: slots come from a per-wave chunk; one global atomic per LV_PPLL_CHUNK fragments
@@ -1148,6 +1159,7 @@ void lv_fill_uniforms(const lv_ctx* ctx, LvUniforms& U) {
     U.separatorBaseWidth = o.separatorWidth;
     U.helicityRotationFactor = o.helicityRotationFactor;
     U.uniformHelicityBandWidth = o.uniformTwistLineWidth ? 1u : 0u;
+    U.ppllRasterColour = o.ppllRayTracerColour ? 0u : 1u;
     U.nearDist = ctx->nearDist;
     U.farDist = ctx->farDist;
     U.width = ctx->width;

@@ -977,7 +977,97 @@ __device__ __forceinline__ f4 lv_transfer_function(const LvSceneDev& S, const Lv
 
 // USE_BANDS arguments of computeFragmentColor (RayHitCommon.glsl:82-90,148-190)
 // (LV_SHADE_HELICITY: phi and rotation = fragmentRotation of USE_ROTATING_HELICITY_BANDS, :91-93; the rest unused)
-struct LvBandArgs { bool useBand; float phi; f3 linePosition, lineNormal; float rotation, separatorScale; };
+// rasterEpsWhite >= 0: the raster tube shader's variant of the outline (the PPLL gather, LinePassGeometryShaderTubes.glsl:785-815,
+// 1079-1087: EPSILON_OUTLINE = 0, EPSILON_WHITE = fwidth(ribbonPosition) = this value, cap halo min(rp, |rp2|)); < 0: RayHitCommon's
+struct LvBandArgs { bool useBand; float phi; f3 linePosition, lineNormal; float rotation, separatorScale; float rasterEpsWhite; };
+
+// Raster variant of the fragment colour: fwidth(ribbonPosition) over the 2 x 2 pixel quad.  The ribbon coordinate of a fragment is
+// a function of the VIEWING RAY (|cross(newV, n)| = distance between the ray and the tube axis over the radius; the USE_BANDS
+// coordinate = the position of the ray's trace in the cross-section plane between the two silhouette points), so the quad
+// partners' "helper invocations" are the rays through the pixels (x ^ 1, y) and (x, y ^ 1) evaluated against the fragment's segment,
+// whether or not they hit it: fwidth = |f(x ^ 1, y) - f(x, y)| + |f(x, y ^ 1) - f(x, y)|  (same operation order as the CPU checker).
+struct LvRasterQuad { f3 dX, dY; };
+__device__ __forceinline__ float lv_tube_ribbon_of_ray(f3 cam, f3 d, f3 axisPoint, f3 t, float radius) {
+    const f3 w = cam - axisPoint;
+    const f3 wp = w - dot3(w, t) * t;
+    const f3 dp = d - dot3(d, t) * t;
+    return clampf(dot3(t, cross3(wp, dp)) / (len3(dp) * radius), -1.0f, 1.0f);
+}
+// caps: the shader's cap coordinate where the ray meets the tangent plane of the cap at the fragment, sphere normal direction there
+__device__ __forceinline__ float lv_cap_ribbon_of_ray(f3 cam, f3 d, f3 hit, f3 hitNormal, f3 centre, f3 t) {
+    const float s = dot3(hit - cam, hitNormal) / dot3(d, hitNormal);
+    const f3 q = cam + d * s;
+    const f3 n = norm3(q - centre);
+    const f3 vv = norm3(cam - q);
+    const f3 helperVec = norm3(cross3(t, vv));
+    const f3 newV = norm3(cross3(helperVec, t));
+    const f3 crossProdVn = cross3(vv, n);
+    float ribbonPosition2 = len3(cross3(newV, n));
+    if (dot3(t, crossProdVn) < 0.0f) ribbonPosition2 = -ribbonPosition2;
+    ribbonPosition2 = clampf(ribbonPosition2, -1.0f, 1.0f);
+    return fminf(len3(crossProdVn), fabsf(ribbonPosition2));
+}
+// USE_BANDS halo coordinate (RayHitCommon.glsl:232-351 = LinePassGeometryShaderTubes.glsl:855-942): the position of the line
+// camera -> pH between the two silhouette points of the elliptic cross-section -- tangent-plane coordinates, polar line of the
+// camera point with respect to the conic x^2 / thickness^2 + y^2 = 1, its two intersections with the conic from the degenerate
+// conic B + alpha M_l.  pH = (thickness cos phi, sin phi, 1) for the fragment itself, any point of a viewing ray's trace otherwise.
+__device__ __forceinline__ float lv_bands_ribbon_of_point(f3 cam, f3 linePosition, f3 lineNormal, f3 fragmentTangent, f3 t, f3 pH,
+                                                          float lineRadius, float thickness) {
+    const f3 lineN = norm3(lineNormal);
+    const f3 lineB = cross3(t, lineN);
+    const f3 cNorm = cam - linePosition;
+    const float dist = dot3(cNorm, fragmentTangent);
+    const f3 wv = cNorm - dist * fragmentTangent;
+    const f3 cHat = mk3(dot3(lineN, wv), dot3(lineB, wv), dot3(t, wv)); // transpose(mat3(lineN, lineB, t)) * w
+    const f3 c = mk3(cHat.x / lineRadius, cHat.y / lineRadius, 1.0f);
+    const float a = 1.0f / (thickness * thickness);
+    const f3 l = mk3(a * c.x, c.y, -1.0f);
+    // M_l = shearSymmetricMatrix(l): columns (0, -l.z, l.y), (l.z, 0, -l.x), (-l.y, l.x, 0); B[column][row]
+    const float Ml[3][3] = {{0.0f, -l.z, l.y}, {l.z, 0.0f, -l.x}, {-l.y, l.x, 0.0f}};
+    const float B[3][3] = {{l.z * l.z - l.y * l.y, l.x * l.y, -l.x * l.z},
+                           {l.x * l.y, a * l.z * l.z - l.x * l.x, -a * l.y * l.z},
+                           {-l.x * l.z, -a * l.y * l.z, a * l.y * l.y + l.x * l.x}};
+    const float EPSILON = 1e-4f;
+    float alpha = 0.0f, discr = 0.0f;
+    if (fabsf(l.z) > EPSILON) {
+        discr = -B[0][0] * B[1][1] + B[0][1] * B[1][0];
+        alpha = sqrtf(discr) / l.z;
+    } else if (fabsf(l.y) > EPSILON) {
+        discr = -B[0][0] * B[2][2] + B[0][2] * B[2][0];
+        alpha = sqrtf(discr) / l.y;
+    } else if (fabsf(l.x) > EPSILON) {
+        discr = -B[1][1] * B[2][2] + B[1][2] * B[2][1];
+        alpha = sqrtf(discr) / l.x;
+    }
+    float Cm[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) Cm[i][j] = B[i][j] + alpha * Ml[i][j];
+    float pm0x = 0.0f, pm0y = 0.0f, pm1x = 0.0f, pm1y = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        if (fabsf(Cm[i][i]) > EPSILON) {
+            pm0x = Cm[i][0] / Cm[i][2]; pm0y = Cm[i][1] / Cm[i][2]; // column i
+            pm1x = Cm[0][i] / Cm[2][i]; pm1y = Cm[1][i] / Cm[2][i]; // row i
+        }
+    }
+    const f3 pLineH = cross3(l, cross3(c, pH));
+    const float plx = pLineH.x / pLineH.z, ply = pLineH.y / pLineH.z;
+    const float num = sqrtf((plx - pm0x) * (plx - pm0x) + (ply - pm0y) * (ply - pm0y));
+    const float den = sqrtf((pm1x - pm0x) * (pm1x - pm0x) + (pm1y - pm0y) * (pm1y - pm0y));
+    return num / den * 2.0f - 1.0f;
+}
+// the USE_BANDS coordinate of a VIEWING RAY: its trace in the cross-section plane through linePosition (normal fragmentTangent)
+__device__ __forceinline__ float lv_bands_ribbon_of_ray(f3 cam, f3 d, f3 linePosition, f3 lineNormal, f3 fragmentTangent, f3 t,
+                                                        float lineRadius, float thickness) {
+    const f3 lineN = norm3(lineNormal);
+    const f3 lineB = cross3(t, lineN);
+    const float s = dot3(linePosition - cam, fragmentTangent) / dot3(d, fragmentTangent);
+    const f3 wq = (cam + d * s) - linePosition;
+    return lv_bands_ribbon_of_point(cam, linePosition, lineNormal, fragmentTangent, t,
+                                    mk3(dot3(lineN, wq) / lineRadius, dot3(lineB, wq) / lineRadius, 1.0f), lineRadius, thickness);
+}
 template <int BANDS>
 __device__ __forceinline__ f4 lv_compute_fragment_color_t(const LvSceneDev& S, const LvUniforms& U, float aoTexel, f3 fragPos,
                                                           f3 fragmentNormal, f3 fragmentTangent, bool isCap,
@@ -987,7 +1077,7 @@ __device__ __forceinline__ f4 lv_compute_fragment_color(const LvSceneDev& S, con
                                                         float fragmentAttribute, float& payloadHitT) {
     LvBandArgs none;
     none.useBand = false; none.phi = 0.0f; none.linePosition = mk3(0.0f, 0.0f, 0.0f); none.lineNormal = mk3(0.0f, 0.0f, 0.0f);
-    none.rotation = 0.0f; none.separatorScale = 1.0f;
+    none.rotation = 0.0f; none.separatorScale = 1.0f; none.rasterEpsWhite = -1.0f;
     return lv_compute_fragment_color_t<LV_SHADE_PLAIN>(S, U, aoTexel, fragPos, fragmentNormal, fragmentTangent, isCap, fragmentAttribute,
                                               payloadHitT, none);
 }
@@ -1023,7 +1113,7 @@ __device__ __forceinline__ float lv_prebaked_ao_lookup(const LvSceneDev& S, cons
 // payloadHitT = length(hit - camera).
 template <int BANDS = LV_SHADE_PLAIN>
 __device__ __forceinline__ f4 lv_shade_hit(const LvSceneDev& S, const LvUniforms& U, float aoTexel, f3 o, f3 d,
-                                           const LvHit& h, float& payloadHitT) {
+                                           const LvHit& h, float& payloadHitT, const LvRasterQuad* rq = nullptr) {
     const float4 ra = S.segs[2 * h.leaf], rb = S.segs[2 * h.leaf + 1];
     const f3 P0 = mk3(ra.x, ra.y, ra.z), P1 = mk3(rb.x, rb.y, rb.z);
     f3 fragPos = o + d * h.t;
@@ -1045,6 +1135,19 @@ __device__ __forceinline__ f4 lv_shade_hit(const LvSceneDev& S, const LvUniforms
     f3 fragmentTangent = norm3(v);
     f3 fragmentNormal = norm3(fragPos - linePointInterpolated);
     const bool isCap = h.kind != 0;
+    // raster variant (PPLL gather): fwidth of the ribbon coordinate over the 2 x 2 quad (LvRasterQuad); circular tubes
+    float rasterEps = -1.0f;
+    if (rq && BANDS != LV_SHADE_BANDS) {
+        const f3 cam = mk3(U.camPos[0], U.camPos[1], U.camPos[2]);
+        const bool cap = U.useCappedTubes && isCap;
+        const float f0 = cap ? lv_cap_ribbon_of_ray(cam, d, fragPos, fragmentNormal, linePointInterpolated, fragmentTangent)
+                             : lv_tube_ribbon_of_ray(cam, d, linePointInterpolated, fragmentTangent, U.radius);
+        const float fx = cap ? lv_cap_ribbon_of_ray(cam, rq->dX, fragPos, fragmentNormal, linePointInterpolated, fragmentTangent)
+                             : lv_tube_ribbon_of_ray(cam, rq->dX, linePointInterpolated, fragmentTangent, U.radius);
+        const float fy = cap ? lv_cap_ribbon_of_ray(cam, rq->dY, fragPos, fragmentNormal, linePointInterpolated, fragmentTangent)
+                             : lv_tube_ribbon_of_ray(cam, rq->dY, linePointInterpolated, fragmentTangent, U.radius);
+        rasterEps = fabsf(fx - f0) + fabsf(fy - f0);
+    }
     if (U.aoPrebaked) {
         // TubeRayTracing.glsl:551-563: angle around the tube relative to the line normal + interpolated vertex id
         const uint32_t seg = S.leafSeg[h.leaf];
@@ -1077,6 +1180,7 @@ __device__ __forceinline__ f4 lv_shade_hit(const LvSceneDev& S, const LvUniforms
         b.linePosition = linePointInterpolated;
         b.rotation = ((1.0f - ts) * lp0.lineRotation + ts * lp1.lineRotation) * U.helicityRotationFactor;
         b.separatorScale = 1.0f; // ClosestHitTubeAnalytic has no UNIFORM_HELICITY_BAND_WIDTH branch
+        b.rasterEpsWhite = rasterEps;
         return lv_compute_fragment_color_t<LV_SHADE_HELICITY>(S, U, aoTexel, fragPos, fragmentNormal, fragmentTangent, isCap,
                                                               fragmentAttribute, payloadHitT, b);
     }
@@ -1096,11 +1200,30 @@ __device__ __forceinline__ f4 lv_shade_hit(const LvSceneDev& S, const LvUniforms
         if (dot3(b.lineNormal, cross3(fragmentNormal, fragmentTangent)) < 0.0f) b.phi = 2.0f * 3.14159265358979323846f - b.phi;
         b.linePosition = linePointInterpolated;
         b.rotation = 0.0f; b.separatorScale = 1.0f;
+        b.rasterEpsWhite = -1.0f;
+        if (rq) {
+            // raster variant with USE_BANDS: the band coordinate of the partner rays in the same cross-section plane; caps keep the
+            // cap coordinate (the isCap branch precedes the USE_BANDS branch, LinePassGeometryShaderTubes.glsl:785-818)
+            const f3 cam = mk3(U.camPos[0], U.camPos[1], U.camPos[2]);
+            const f3 tN = norm3(fragmentTangent);
+            const bool cap = U.useCappedTubes && isCap;
+            const float r = U.lineWidth * 0.5f;
+            const float f0 = cap ? lv_cap_ribbon_of_ray(cam, d, fragPos, fragmentNormal, linePointInterpolated, fragmentTangent)
+                                 : lv_bands_ribbon_of_ray(cam, d, b.linePosition, b.lineNormal, fragmentTangent, tN, r, 1.0f);
+            const float fx = cap ? lv_cap_ribbon_of_ray(cam, rq->dX, fragPos, fragmentNormal, linePointInterpolated, fragmentTangent)
+                                 : lv_bands_ribbon_of_ray(cam, rq->dX, b.linePosition, b.lineNormal, fragmentTangent, tN, r, 1.0f);
+            const float fy = cap ? lv_cap_ribbon_of_ray(cam, rq->dY, fragPos, fragmentNormal, linePointInterpolated, fragmentTangent)
+                                 : lv_bands_ribbon_of_ray(cam, rq->dY, b.linePosition, b.lineNormal, fragmentTangent, tN, r, 1.0f);
+            b.rasterEpsWhite = fabsf(fx - f0) + fabsf(fy - f0);
+        }
         return lv_compute_fragment_color_t<LV_SHADE_BANDS>(S, U, aoTexel, fragPos, fragmentNormal, fragmentTangent, isCap,
                                                            fragmentAttribute, payloadHitT, b);
     }
-    return lv_compute_fragment_color(S, U, aoTexel, fragPos, fragmentNormal, fragmentTangent, isCap, fragmentAttribute,
-                                     payloadHitT);
+    LvBandArgs none;
+    none.useBand = false; none.phi = 0.0f; none.linePosition = mk3(0.0f, 0.0f, 0.0f); none.lineNormal = mk3(0.0f, 0.0f, 0.0f);
+    none.rotation = 0.0f; none.separatorScale = 1.0f; none.rasterEpsWhite = rasterEps;
+    return lv_compute_fragment_color_t<LV_SHADE_PLAIN>(S, U, aoTexel, fragPos, fragmentNormal, fragmentTangent, isCap, fragmentAttribute,
+                                                       payloadHitT, none);
 }
 
 // ClosestHitEllipticTubeAnalytic main(), EllipticTubeRayTracing.glsl:303-441: position in the tubelet frame -> t, phi, rho ->
@@ -1136,7 +1259,7 @@ __device__ __forceinline__ LvEllipticSurface lv_elliptic_surface(const LvUniform
     return E;
 }
 __device__ __forceinline__ f4 lv_shade_hit_elliptic(const LvSceneDev& S, const LvUniforms& U, float aoTexel, f3 o, f3 d,
-                                                    const LvHit& h, float& payloadHitT) {
+                                                    const LvHit& h, float& payloadHitT, const LvRasterQuad* rq = nullptr) {
     const uint32_t seg = S.leafSeg[h.leaf];
     const lv_line_point& lp0 = S.points[S.segIdx[2 * seg]];
     const lv_line_point& lp1 = S.points[S.segIdx[2 * seg + 1]];
@@ -1147,6 +1270,16 @@ __device__ __forceinline__ f4 lv_shade_hit_elliptic(const LvSceneDev& S, const L
     b.linePosition = E.linePosition;
     b.lineNormal = E.lineNormal;
     b.rotation = 0.0f; b.separatorScale = 1.0f;
+    b.rasterEpsWhite = -1.0f;
+    if (rq) {
+        const f3 cam = mk3(U.camPos[0], U.camPos[1], U.camPos[2]);
+        const f3 tN = norm3(E.tangent);
+        const float r = U.bandWidth * 0.5f;
+        const float f0 = lv_bands_ribbon_of_ray(cam, d, b.linePosition, b.lineNormal, E.tangent, tN, r, U.minThickness);
+        const float fx = lv_bands_ribbon_of_ray(cam, rq->dX, b.linePosition, b.lineNormal, E.tangent, tN, r, U.minThickness);
+        const float fy = lv_bands_ribbon_of_ray(cam, rq->dY, b.linePosition, b.lineNormal, E.tangent, tN, r, U.minThickness);
+        b.rasterEpsWhite = fabsf(fx - f0) + fabsf(fy - f0);
+    }
     return lv_compute_fragment_color_t<LV_SHADE_BANDS>(S, U, aoTexel, E.fragPos, E.normal, E.tangent, false, E.attribute, payloadHitT, b);
 }
 
@@ -1240,6 +1373,7 @@ __device__ __forceinline__ f4 lv_shade_hit_triangle(const LvSceneDev& S, const L
             lv_sincos_rad(lv_atan2_det(rotDy * 0.5f * U.lineWidth, rotDx), sn, cs);
             b.separatorScale = cs;
         }
+        b.rasterEpsWhite = -1.0f;
         return lv_compute_fragment_color_t<LV_SHADE_HELICITY>(S, U, aoTexel, fragPos, fragmentNormal, fragmentTangent, isCap,
                                                               fragmentAttribute, payloadHitT, b);
     }
@@ -1256,7 +1390,7 @@ __device__ __forceinline__ f4 lv_shade_hit_triangle(const LvSceneDev& S, const L
         b.phi = (a0 * b0 + a1 * bu) + a2 * bv;
         b.linePosition = lerp3(lp0.linePosition, lp1.linePosition, lp2.linePosition);
         b.lineNormal = lerp3(lp0.lineNormal, lp1.lineNormal, lp2.lineNormal);
-        b.rotation = 0.0f; b.separatorScale = 1.0f;
+        b.rotation = 0.0f; b.separatorScale = 1.0f; b.rasterEpsWhite = -1.0f;
         return lv_compute_fragment_color_t<LV_SHADE_BANDS>(S, U, aoTexel, fragPos, fragmentNormal, fragmentTangent, isCap, fragmentAttribute,
                                                            payloadHitT, b);
     }
@@ -1288,59 +1422,16 @@ __device__ __forceinline__ f4 lv_compute_fragment_color_t(const LvSceneDev& S, c
             if (dot3(t, crossProdVn) < 0.0f) ribbonPosition = -ribbonPosition;
             ribbonPosition2 = clampf(ribbonPosition2, -1.0f, 1.0f);
             if (fabsf(ribbonPosition2) < fabsf(ribbonPosition)) ribbonPosition = ribbonPosition2;
+            // raster variant, LinePassGeometryShaderTubes.glsl:785-815: ribbonPosition = min(length(cross(v, n)), abs(ribbonPosition2))
+            if (bands.rasterEpsWhite >= 0.0f) ribbonPosition = fminf(len3(crossProdVn), fabsf(ribbonPosition2));
         } else if (BANDS == LV_SHADE_BANDS) {
-            // USE_BANDS, RayHitCommon.glsl:232-351: the fragment's position between the two silhouette points of the elliptic
-            // cross-section as the camera sees it -- tangent-plane coordinates, polar line of the camera point with respect to the
-            // conic x^2 / thickness^2 + y^2 = 1, its two intersections with the conic from the degenerate conic B + alpha M_l
+            // USE_BANDS, RayHitCommon.glsl:232-351 (lv_bands_ribbon_of_point)
             const float thickness = bands.useBand ? U.minThickness : 1.0f;
-            const f3 lineN = norm3(bands.lineNormal);
-            const f3 lineB = cross3(t, lineN);
-            const f3 cNorm = cam - bands.linePosition;
-            const float dist = dot3(cNorm, fragmentTangent);
-            const f3 wv = cNorm - dist * fragmentTangent;
-            const f3 cHat = mk3(dot3(lineN, wv), dot3(lineB, wv), dot3(t, wv)); // transpose(mat3(lineN, lineB, t)) * w
-            const float lineRadius = (bands.useBand ? U.bandWidth : U.lineWidth) * 0.5f;
-            const f3 c = mk3(cHat.x / lineRadius, cHat.y / lineRadius, 1.0f);
-            const float a = 1.0f / (thickness * thickness);
-            const f3 l = mk3(a * c.x, c.y, -1.0f);
-            // M_l = shearSymmetricMatrix(l): columns (0, -l.z, l.y), (l.z, 0, -l.x), (-l.y, l.x, 0); B[column][row]
-            const float Ml[3][3] = {{0.0f, -l.z, l.y}, {l.z, 0.0f, -l.x}, {-l.y, l.x, 0.0f}};
-            const float B[3][3] = {{l.z * l.z - l.y * l.y, l.x * l.y, -l.x * l.z},
-                                   {l.x * l.y, a * l.z * l.z - l.x * l.x, -a * l.y * l.z},
-                                   {-l.x * l.z, -a * l.y * l.z, a * l.y * l.y + l.x * l.x}};
-            const float EPSILON = 1e-4f;
-            float alpha = 0.0f, discr = 0.0f;
-            if (fabsf(l.z) > EPSILON) {
-                discr = -B[0][0] * B[1][1] + B[0][1] * B[1][0];
-                alpha = sqrtf(discr) / l.z;
-            } else if (fabsf(l.y) > EPSILON) {
-                discr = -B[0][0] * B[2][2] + B[0][2] * B[2][0];
-                alpha = sqrtf(discr) / l.y;
-            } else if (fabsf(l.x) > EPSILON) {
-                discr = -B[1][1] * B[2][2] + B[1][2] * B[2][1];
-                alpha = sqrtf(discr) / l.x;
-            }
-            float Cm[3][3];
-#pragma unroll
-            for (int i = 0; i < 3; i++)
-#pragma unroll
-                for (int j = 0; j < 3; j++) Cm[i][j] = B[i][j] + alpha * Ml[i][j];
-            float pm0x = 0.0f, pm0y = 0.0f, pm1x = 0.0f, pm1y = 0.0f;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                if (fabsf(Cm[i][i]) > EPSILON) {
-                    pm0x = Cm[i][0] / Cm[i][2]; pm0y = Cm[i][1] / Cm[i][2]; // column i
-                    pm1x = Cm[0][i] / Cm[2][i]; pm1y = Cm[1][i] / Cm[2][i]; // row i
-                }
-            }
             float sp, cp;
             lv_sincos_rad(bands.phi, sp, cp);
-            const f3 pH = mk3(thickness * cp, sp, 1.0f);
-            const f3 pLineH = cross3(l, cross3(c, pH));
-            const float plx = pLineH.x / pLineH.z, ply = pLineH.y / pLineH.z;
-            const float num = sqrtf((plx - pm0x) * (plx - pm0x) + (ply - pm0y) * (ply - pm0y));
-            const float den = sqrtf((pm1x - pm0x) * (pm1x - pm0x) + (pm1y - pm0y) * (pm1y - pm0y));
-            ribbonPosition = num / den * 2.0f - 1.0f;
+            ribbonPosition = lv_bands_ribbon_of_point(cam, bands.linePosition, bands.lineNormal, fragmentTangent, t,
+                                                      mk3(thickness * cp, sp, 1.0f),
+                                                      (bands.useBand ? U.bandWidth : U.lineWidth) * 0.5f, thickness);
         } else {
             f3 crossProdVn = cross3(newV, n);
             ribbonPosition = len3(crossProdVn);
@@ -1440,6 +1531,13 @@ __device__ __forceinline__ f4 lv_compute_fragment_color_t(const LvSceneDev& S, c
 #pragma unroll
         for (int k = 0; k < 3; k++) phong[k] = phong[k] * m;
         WHITE_THRESHOLD = 0.8f; // :485-486
+    }
+    if (bands.rasterEpsWhite >= 0.0f) {
+        // LinePassGeometryShaderTubes.glsl:1079-1087: EPSILON_OUTLINE = 0.0, EPSILON_WHITE = fwidth(ribbonPosition), no clamps.  (The
+        // separator stripes above keep the ray tracer's width; helicity bands are outside SURVEY.md 8's a9.)  smoothstep(1, 1, x)
+        // divides by zero: x < 1 -> -inf -> 0, x == 1 -> NaN -> 0 through fmaxf(NaN, 0) = 0: coverage 1, a hard silhouette edge.
+        EPSILON_OUTLINE = 0.0f;
+        EPSILON_WHITE = U.useHalos ? bands.rasterEpsWhite : 0.0f;
     }
     float coverage = U.useHalos ? 1.0f - smoothstepf(1.0f - EPSILON_OUTLINE, 1.0f, absCoords) : 1.0f;
     if (BANDS == LV_SHADE_BANDS && bands.useBand && U.useEllipticTubes) coverage = 1.0f; // ANALYTIC_ELLIPTIC_TUBE_INTERSECTIONS, :499-504

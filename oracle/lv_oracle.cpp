@@ -47,6 +47,9 @@ namespace {
 //                        AO texture bilinearly (clamp to edge) instead of reading the launching pixel's texel
 struct DeviationSwitches { bool literalIntersection = false, referenceAoLookup = false; const float* aoImage = nullptr; };
 DeviationSwitches g_dev;
+// deviation switch (lvo_set_ppll_fragment_colour_variant): 1 = shade the PPLL fragments with the RAY TRACER's computeFragmentColor
+// (RayHitCommon.glsl, what rounds 1-2 did), 0 = with the raster tube shader's variant (the reference, default)
+bool g_rtFragmentColourInPpll = false;
 
 // ---------------------------------------------------------------- intersection tests
 // The reference solves both quadratics in the textbook form t = (-B -+ sqrt(B^2 - 4AC)) / 2A
@@ -612,8 +615,45 @@ inline void blinnPhongShadingTube(const lvo_params& P, const Frame& F, float aoT
     out[0] = phong[0]; out[1] = phong[1]; out[2] = phong[2]; out[3] = base[3];
 }
 
+// Raster variant of the fragment colour (the PPLL gather runs the RASTER tube shader, LinePassGeometryShaderTubes.glsl:732-1129,
+// not RayHitCommon.glsl): EPSILON_OUTLINE = 0 and EPSILON_WHITE = fwidth(ribbonPosition) (:1079-1087), cap halo
+// min(ribbonPosition, abs(ribbonPosition2)) (:815).  fwidth needs the ribbon coordinate of the 2 x 2 quad partners' invocations of
+// the SAME primitive (helper invocations extrapolate a triangle's attributes beyond its edge); for ray-generated fragments the
+// analogue is exact: the ribbon coordinate of a fragment is a function of the VIEWING RAY alone -- |cross(newV, n)| is the
+// distance between the ray and the tube axis over the radius (chord geometry in the cross-section plane), the USE_BANDS
+// coordinate is the position of the ray's trace in the cross-section plane between the two silhouette points -- so it is
+// evaluated for the rays through the quad partners (x ^ 1, y) and (x, y ^ 1) with respect to the fragment's segment, whether or
+// not those rays hit it: fwidth = |f(x ^ 1, y) - f(x, y)| + |f(x, y ^ 1) - f(x, y)| (fine derivatives of the 2 x 2 quad).
+struct RasterQuad { V3 dX, dY; };   // directions of the partner rays (origin = camera, pixel centres)
+// ribbon coordinate of the ray (cam, d) with respect to a tube axis (point, unit direction t): signed ray-axis distance / radius,
+// clamped like the shader clamps ribbonPosition (:1-style clamp(ribbonPosition, -1, 1), :962)
+inline float tubeRibbonOfRay(V3 cam, V3 d, V3 axisPoint, V3 t, float radius) {
+    const V3 w = cam - axisPoint;
+    const V3 wp = w - dot(w, t) * t;
+    const V3 dp = d - dot(d, t) * t;
+    return clampf(dot(t, cross(wp, dp)) / (length(dp) * radius), -1.0f, 1.0f);
+}
+// cap variant (:785-815): ribbonPosition = min(|cross(v, n)|, |ribbonPosition2|) with the SPHERE's normal n.  |cross(newV, n)| of a
+// cap fragment depends on where along the axis the hit lies, not on the ray alone, so the partners' values are taken where
+// their rays meet the TANGENT PLANE of the cap at the fragment (the plane a rasterised cap triangle extrapolates on), with the
+// sphere's normal direction there: n' = normalize(point - centre).
+inline float capRibbonOfRay(V3 cam, V3 d, V3 hit, V3 hitNormal, V3 centre, V3 t) {
+    const float s = dot(hit - cam, hitNormal) / dot(d, hitNormal);
+    const V3 q = cam + d * s;
+    const V3 n = normalize(q - centre);
+    const V3 vv = normalize(cam - q);
+    const V3 helperVec = normalize(cross(t, vv));
+    const V3 newV = normalize(cross(helperVec, t));
+    const V3 crossProdVn = cross(vv, n);
+    float ribbonPosition2 = length(cross(newV, n));
+    if (dot(t, crossProdVn) < 0.0f) ribbonPosition2 = -ribbonPosition2;
+    ribbonPosition2 = clampf(ribbonPosition2, -1.0f, 1.0f);
+    return fminf(length(crossProdVn), fabsf(ribbonPosition2));
+}
+
 // USE_BANDS arguments of computeFragmentColor (RayHitCommon.glsl:82-90,148-190)
-struct BandArgs { bool useBand; float phi; V3 linePosition, lineNormal; };
+// rasterEpsWhite >= 0: raster variant of the outline (EPSILON_OUTLINE = 0, EPSILON_WHITE = this value); < 0: the ray tracer's
+struct BandArgs { bool useBand; float phi; V3 linePosition, lineNormal; float rasterEpsWhite = -1.0f; bool shadeBands = true; };
 // USE_ROTATING_HELICITY_BANDS arguments of computeFragmentColor (RayHitCommon.glsl:82-93): the angle around the tube and the
 // interpolated lineRotation x helicityRotationFactor
 struct HelicityArgs { float phi, fragmentRotation, rotationSeparatorScale; };
@@ -657,8 +697,10 @@ inline float prebakedAoLookup(const PrebakedAo& pb, float interpolatedVertexId, 
 // ClosestHitTubeAnalytic main() (TubeRayTracing.glsl:512-613) + computeFragmentColor (RayHitCommon.glsl:74-543),
 // flow lines: USE_CAPPED_TUBES / USE_HALOS / USE_DEPTH_CUES / USE_AMBIENT_OCCLUSION switches only.
 // Writes payload {hitColor, hitT}.
+inline float bandsRibbonOfRay(V3 cameraPosition, V3 d, V3 linePosition, V3 lineNormal, V3 fragmentTangent, V3 t, float lineRadius,
+                              float thickness);
 inline void shadeHit(const lvo_scene& sc, const lvo_params& P, const Frame& F, float aoTexel, V3 o, V3 d, const Hit& h,
-                     float hitColor[4], float& payloadHitT, const PrebakedAo* pb = nullptr) {
+                     float hitColor[4], float& payloadHitT, const PrebakedAo* pb = nullptr, const RasterQuad* rq = nullptr) {
     uint32_t i0 = sc.segIdx[2 * h.seg], i1 = sc.segIdx[2 * h.seg + 1];
     const lvo_line_point& lp0 = sc.pts[i0];
     const lvo_line_point& lp1 = sc.pts[i1];
@@ -682,6 +724,18 @@ inline void shadeHit(const lvo_scene& sc, const lvo_params& P, const Frame& F, f
     V3 fragmentTangent = normalize(v);
     V3 fragmentNormal = normalize(fragPos - linePointInterpolated);
     bool isCap = h.kind != 0;
+    // raster variant (PPLL gather): fwidth of the ribbon coordinate over the 2 x 2 quad (see RasterQuad); circular tubes
+    float rasterEps = -1.0f;
+    if (rq && !P.useBands) {
+        const bool cap = P.useCappedTubes && isCap;
+        const float f0 = cap ? capRibbonOfRay(F.cameraPosition, d, fragPos, fragmentNormal, linePointInterpolated, fragmentTangent)
+                             : tubeRibbonOfRay(F.cameraPosition, d, linePointInterpolated, fragmentTangent, F.radius);
+        const float fx = cap ? capRibbonOfRay(F.cameraPosition, rq->dX, fragPos, fragmentNormal, linePointInterpolated, fragmentTangent)
+                             : tubeRibbonOfRay(F.cameraPosition, rq->dX, linePointInterpolated, fragmentTangent, F.radius);
+        const float fy = cap ? capRibbonOfRay(F.cameraPosition, rq->dY, fragPos, fragmentNormal, linePointInterpolated, fragmentTangent)
+                             : tubeRibbonOfRay(F.cameraPosition, rq->dY, linePointInterpolated, fragmentTangent, F.radius);
+        rasterEps = fabsf(fx - f0) + fabsf(fy - f0);
+    }
     if (pb) {
         // TubeRayTracing.glsl:551-563: angle around the tube relative to the line normal, interpolated vertex id.
         // (acos argument clamped to [-1, 1]: GLSL leaves acos undefined outside, rounding can exceed it by an ulp.)
@@ -704,8 +758,10 @@ inline void shadeHit(const lvo_scene& sc, const lvo_params& P, const Frame& F, f
         if (dot(lineNormal, cross(fragmentNormal, fragmentTangent)) < 0.0f) hl.phi = 2.0f * 3.14159265358979323846f - hl.phi;
         hl.fragmentRotation = ((1.0f - ts) * lp0.lineRotation + ts * lp1.lineRotation) * P.helicityRotationFactor;
         hl.rotationSeparatorScale = 1.0f; // ClosestHitTubeAnalytic has no UNIFORM_HELICITY_BAND_WIDTH branch
+        BandArgs rb; rb.shadeBands = false; rb.useBand = false; rb.phi = 0.0f; rb.linePosition = rb.lineNormal = v3(0, 0, 0);
+        rb.rasterEpsWhite = rasterEps;
         computeFragmentColor(sc, P, F, aoTexel, fragPos, fragmentNormal, fragmentTangent, isCap, fragmentAttribute, hitColor,
-                             payloadHitT, nullptr, &hl);
+                             payloadHitT, rq ? &rb : nullptr, &hl);
         return;
     }
     if (P.useBands) {
@@ -719,12 +775,27 @@ inline void shadeHit(const lvo_scene& sc, const lvo_params& P, const Frame& F, f
         b.phi = atan2Det(sqrtf((1.0f - cphi) * (1.0f + cphi)), cphi);
         if (dot(b.lineNormal, cross(fragmentNormal, fragmentTangent)) < 0.0f) b.phi = 2.0f * 3.14159265358979323846f - b.phi;
         b.linePosition = linePointInterpolated;
+        if (rq) {
+            // raster variant with USE_BANDS (:1079-1083): the band coordinate of the partner rays in the same cross-section plane;
+            // caps keep the circular-tube cap coordinate (:785-815 precede the USE_BANDS branch)
+            const V3 tN = normalize(fragmentTangent);
+            const bool cap = P.useCappedTubes && isCap;
+            const float r = P.lineWidth * 0.5f;
+            auto f = [&](V3 dir) {
+                return cap ? capRibbonOfRay(F.cameraPosition, dir, fragPos, fragmentNormal, linePointInterpolated, fragmentTangent)
+                           : bandsRibbonOfRay(F.cameraPosition, dir, b.linePosition, b.lineNormal, fragmentTangent, tN, r, 1.0f);
+            };
+            const float f0 = f(d);
+            b.rasterEpsWhite = fabsf(f(rq->dX) - f0) + fabsf(f(rq->dY) - f0);
+        }
         computeFragmentColor(sc, P, F, aoTexel, fragPos, fragmentNormal, fragmentTangent, isCap, fragmentAttribute, hitColor,
                              payloadHitT, &b);
         return;
     }
+    BandArgs rb; rb.shadeBands = false; rb.useBand = false; rb.phi = 0.0f; rb.linePosition = rb.lineNormal = v3(0, 0, 0);
+    rb.rasterEpsWhite = rasterEps;
     computeFragmentColor(sc, P, F, aoTexel, fragPos, fragmentNormal, fragmentTangent, isCap, fragmentAttribute, hitColor,
-                         payloadHitT);
+                         payloadHitT, rq ? &rb : nullptr);
 }
 
 // ClosestHitEllipticTubeAnalytic main(), EllipticTubeRayTracing.glsl:303-441: position in the tubelet frame -> t, phi, rho ->
@@ -758,7 +829,7 @@ inline EllipticSurface ellipticSurface(const lvo_params& P, V3 o, V3 d, float hi
     return E;
 }
 inline void shadeHitElliptic(const lvo_scene& sc, const lvo_params& P, const Frame& F, float aoTexel, V3 o, V3 d, const Hit& h,
-                             float hitColor[4], float& payloadHitT) {
+                             float hitColor[4], float& payloadHitT, const RasterQuad* rq = nullptr) {
     const lvo_line_point& lp0 = sc.pts[sc.segIdx[2 * h.seg]];
     const lvo_line_point& lp1 = sc.pts[sc.segIdx[2 * h.seg + 1]];
     const EllipticSurface E = ellipticSurface(P, o, d, h.t, lp0, lp1);
@@ -767,13 +838,41 @@ inline void shadeHitElliptic(const lvo_scene& sc, const lvo_params& P, const Fra
     b.phi = E.phiLine;
     b.linePosition = E.linePosition;
     b.lineNormal = E.lineNormal;
+    if (rq && P.useBands) {
+        const V3 tN = normalize(E.tangent);
+        const float r = P.bandWidth * 0.5f;
+        const float f0 = bandsRibbonOfRay(F.cameraPosition, d, b.linePosition, b.lineNormal, E.tangent, tN, r, P.minThickness);
+        const float fx = bandsRibbonOfRay(F.cameraPosition, rq->dX, b.linePosition, b.lineNormal, E.tangent, tN, r, P.minThickness);
+        const float fy = bandsRibbonOfRay(F.cameraPosition, rq->dY, b.linePosition, b.lineNormal, E.tangent, tN, r, P.minThickness);
+        b.rasterEpsWhite = fabsf(fx - f0) + fabsf(fy - f0);
+    }
     computeFragmentColor(sc, P, F, aoTexel, E.fragPos, E.normal, E.tangent, false, E.attribute, hitColor, payloadHitT,
                          P.useBands ? &b : nullptr);
 }
 
 // USE_BANDS halo coordinate of computeFragmentColor (RayHitCommon.glsl:232-351), see the call site
+// pH = homogeneous point of the tangent plane (frame coordinates / lineRadius) the line camera -> pH is drawn through: the fragment's
+// own point (thickness cos phi, sin phi, 1) in the shader, any point of the viewing ray's trace for bandsRibbonOfRay
+inline float bandsRibbonOfPoint(V3 cameraPosition, V3 linePosition, V3 lineNormal, V3 fragmentTangent, V3 t, V3 pH, float lineRadius,
+                                float thickness);
 inline float bandsRibbonPosition(V3 cameraPosition, V3 linePosition, V3 lineNormal, V3 fragmentTangent, V3 t, float phi,
                                  float lineRadius, float thickness) {
+    float sp, cp;
+    sincosRad(phi, sp, cp);
+    return bandsRibbonOfPoint(cameraPosition, linePosition, lineNormal, fragmentTangent, t, v3(thickness * cp, sp, 1.0f), lineRadius, thickness);
+}
+// the USE_BANDS coordinate of a VIEWING RAY: its trace in the cross-section plane through linePosition (normal fragmentTangent)
+inline float bandsRibbonOfRay(V3 cameraPosition, V3 d, V3 linePosition, V3 lineNormal, V3 fragmentTangent, V3 t, float lineRadius,
+                              float thickness) {
+    const V3 lineN = normalize(lineNormal);
+    const V3 lineB = cross(t, lineN);
+    const float s = dot(linePosition - cameraPosition, fragmentTangent) / dot(d, fragmentTangent);
+    const V3 wq = (cameraPosition + d * s) - linePosition;
+    return bandsRibbonOfPoint(cameraPosition, linePosition, lineNormal, fragmentTangent, t,
+                              v3(dot(lineN, wq) / lineRadius, dot(lineB, wq) / lineRadius, 1.0f), lineRadius, thickness);
+}
+inline float bandsRibbonOfPoint(V3 cameraPosition, V3 linePosition, V3 lineNormal, V3 fragmentTangent, V3 t, V3 pH, float lineRadius,
+                                float thickness) {
     const V3 lineN = normalize(lineNormal);
     const V3 lineB = cross(t, lineN);
     const V3 cNorm = cameraPosition - linePosition;
@@ -810,9 +909,6 @@ inline float bandsRibbonPosition(V3 cameraPosition, V3 linePosition, V3 lineNorm
             pm1x = Cm[0][i] / Cm[2][i]; pm1y = Cm[1][i] / Cm[2][i];   // row i
         }
     }
-    float sp, cp;
-    sincosRad(phi, sp, cp);
-    const V3 pH = v3(thickness * cp, sp, 1.0f);
     const V3 pLineH = cross(l, cross(c, pH));
     const float plx = pLineH.x / pLineH.z, ply = pLineH.y / pLineH.z;
     const float num = sqrtf((plx - pm0x) * (plx - pm0x) + (ply - pm0y) * (ply - pm0y));
@@ -823,7 +919,9 @@ inline float bandsRibbonPosition(V3 cameraPosition, V3 linePosition, V3 lineNorm
 // computeFragmentColor (RayHitCommon.glsl:74-543) for tubes: shared by the analytic and the triangle closest-hit shaders
 inline void computeFragmentColor(const lvo_scene& sc, const lvo_params& P, const Frame& F, float aoTexel, V3 fragPos,
                                  V3 fragmentNormal, V3 fragmentTangent, bool isCap, float fragmentAttribute,
-                                 float hitColor[4], float& payloadHitT, const BandArgs* bands, const HelicityArgs* hel) {
+                                 float hitColor[4], float& payloadHitT, const BandArgs* bandsIn, const HelicityArgs* hel) {
+    const BandArgs* bands = (bandsIn && bandsIn->shadeBands) ? bandsIn : nullptr;   // USE_BANDS shading arguments, if any
+    const float rasterEpsWhite = bandsIn ? bandsIn->rasterEpsWhite : -1.0f;         // >= 0: raster variant of the outline
     float fragmentColor[4];
     transferFunction(sc, P, fragmentAttribute, fragmentColor);
     V3 n = normalize(fragmentNormal);
@@ -844,6 +942,8 @@ inline void computeFragmentColor(const lvo_scene& sc, const lvo_params& P, const
             if (dot(t, crossProdVn) < 0.0f) ribbonPosition = -ribbonPosition;
             ribbonPosition2 = clampf(ribbonPosition2, -1.0f, 1.0f);
             if (fabsf(ribbonPosition2) < fabsf(ribbonPosition)) ribbonPosition = ribbonPosition2;
+            // raster variant, LinePassGeometryShaderTubes.glsl:785-815: ribbonPosition = min(length(cross(v, n)), abs(ribbonPosition2))
+            if (rasterEpsWhite >= 0.0f) ribbonPosition = fminf(length(crossProdVn), fabsf(ribbonPosition2));
         } else if (bands) {
             // USE_BANDS, RayHitCommon.glsl:232-351: the fragment's position between the two silhouette points of the elliptic
             // cross-section as the camera sees it -- tangent-plane coordinates, polar line of the camera point with respect to the
@@ -894,6 +994,14 @@ inline void computeFragmentColor(const lvo_scene& sc, const lvo_params& P, const
         const float m = fmaxf(alphaBorder1, alphaBorder2);
         for (int k = 0; k < 3; k++) shaded[k] = shaded[k] * m;
         WHITE_THRESHOLD = 0.8f; // :485-486
+    }
+    if (rasterEpsWhite >= 0.0f) {
+        // LinePassGeometryShaderTubes.glsl:1079-1087: EPSILON_OUTLINE = 0.0, EPSILON_WHITE = fwidth(ribbonPosition); no clamps.
+        // (The separator stripes above keep the ray tracer's width: the raster shader's own drawSeparatorStripe differs and the
+        // helicity bands are outside SURVEY.md 8's a9.)  smoothstep(1, 1, x) divides by zero: x < 1 -> -inf -> 0; x == 1 -> NaN ->
+        // 0 through fmaxf(NaN, 0) = 0: coverage = 1 on the whole tube, i.e. a hard edge at the silhouette.
+        EPSILON_OUTLINE = 0.0f;
+        EPSILON_WHITE = P.useHalos ? rasterEpsWhite : 0.0f;
     }
     float coverage = P.useHalos ? 1.0f - smoothstepf(1.0f - EPSILON_OUTLINE, 1.0f, absCoords) : 1.0f;
     if (bands && bands->useBand && P.useEllipticTubes) coverage = 1.0f; // ANALYTIC_ELLIPTIC_TUBE_INTERSECTIONS, :499-504
@@ -1999,10 +2107,16 @@ void lvo_ppll_gather(const lvo_scene* sc, const lvo_params* Pp, int useBvh, cons
             primaryRay(P, F, x, y, 0.5f, 0.5f, o, d);
             const float aoTexel = (P.useAmbientOcclusion && ao) ? ao[size_t(y) * P.width + x] : 1.0f;
             allHits(*sc, F.radius, capped, useBvh != 0, o, d, 0.0001f, 1000.0f, hl, cnt);
+            // raster variant of the fragment colour: the rays through the 2 x 2 quad partners (see RasterQuad)
+            RasterQuad rq;
+            V3 oq;
+            primaryRay(P, F, x ^ 1u, y, 0.5f, 0.5f, oq, rq.dX);
+            primaryRay(P, F, x, y ^ 1u, 0.5f, 0.5f, oq, rq.dY);
+            const RasterQuad* rqp = g_rtFragmentColourInPpll ? nullptr : &rq;
             for (const Hit& hit : hl) {
                 float hc[4]; float hitT;
-                if (elliptic) shadeHitElliptic(*sc, P, F, aoTexel, o, d, hit, hc, hitT);
-                else shadeHit(*sc, P, F, aoTexel, o, d, hit, hc, hitT);
+                if (elliptic) shadeHitElliptic(*sc, P, F, aoTexel, o, d, hit, hc, hitT, rqp);
+                else shadeHit(*sc, P, F, aoTexel, o, d, hit, hc, hitT, nullptr, rqp);
                 cnt.hits++;
                 if (hc[3] < 0.001f) continue;
                 rows[yy].push_back(std::make_pair(packUnorm4x8(hc), hitT));
@@ -2102,6 +2216,33 @@ void lvo_compute_fragment_color_batch(const lvo_scene* sc, const lvo_params* Pp,
         outHitT[i] = hitT;
     }
 }
+
+// Test hooks of the raster fragment-colour variant (LinePassGeometryShaderTubes.glsl:785-815,1079-1087): computeFragmentColor with
+// EPSILON_OUTLINE = 0 and EPSILON_WHITE = epsWhite[i]; the ribbon coordinate of n viewing rays with respect to one tube axis
+// (capHit = null: tubeRibbonOfRay; else capRibbonOfRay about the cap fragment capHit / capNormal on the sphere at axisPoint) -- what
+// fwidth(ribbonPosition) is differenced from.
+void lvo_compute_fragment_color_raster_batch(const lvo_scene* sc, const lvo_params* Pp, uint64_t n, const float* fragPos,
+                                             const float* normal, const float* tangent, const uint32_t* isCap, const float* attribute,
+                                             const float* aoTexel, const float* epsWhite, float* outColor, float* outHitT) {
+    const lvo_params& P = *Pp;
+    Frame F = makeFrame(P);
+    for (uint64_t i = 0; i < n; i++) {
+        float c[4], hitT;
+        BandArgs rb; rb.shadeBands = false; rb.useBand = false; rb.phi = 0.0f; rb.linePosition = rb.lineNormal = v3(0, 0, 0);
+        rb.rasterEpsWhite = epsWhite[i];
+        computeFragmentColor(*sc, P, F, aoTexel[i], ld3(fragPos + 3 * i), ld3(normal + 3 * i), ld3(tangent + 3 * i),
+                             isCap[i] != 0u, attribute[i], c, hitT, &rb);
+        for (int k = 0; k < 4; k++) outColor[4 * i + k] = c[k];
+        outHitT[i] = hitT;
+    }
+}
+void lvo_ribbon_of_rays(const float* cam, const float* dirs, uint64_t n, const float* axisPoint, const float* axisDir, float radius,
+                        const float* capHit, const float* capNormal, float* out) {
+    for (uint64_t i = 0; i < n; i++)
+        out[i] = capHit ? capRibbonOfRay(ld3(cam), ld3(dirs + 3 * i), ld3(capHit), ld3(capNormal), ld3(axisPoint), ld3(axisDir))
+                        : tubeRibbonOfRay(ld3(cam), ld3(dirs + 3 * i), ld3(axisPoint), ld3(axisDir), radius);
+}
+void lvo_set_ppll_fragment_colour_variant(int rayTracerVariant) { g_rtFragmentColourInPpll = rayTracerVariant != 0; }
 
 void lvo_set_ao_feature_outputs(float* normalMap, float* positionMap) {
     g_lvoAoFeatures.normal = normalMap;

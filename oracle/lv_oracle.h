@@ -370,6 +370,14 @@ void lvo_compute_fragment_color_batch(const lvo_scene*, const lvo_params*, uint6
  * tracer paths (lvo_trace_rays, lvo_render_ao, lvo_render_rt, ...), to measure the documented deviations on whole frames.
  * Process-global; set between render calls. */
 void lvo_set_deviation_switches(int literalIntersection, int referenceAoLookup);
+/* 1: shade PPLL fragments with the ray tracer's computeFragmentColor (RayHitCommon.glsl; rounds 1-2), 0 (default): with the raster
+ * tube shader's variant (LinePassGeometryShaderTubes.glsl:785-815,1079-1087) */
+void lvo_set_ppll_fragment_colour_variant(int rayTracerVariant);
+void lvo_compute_fragment_color_raster_batch(const lvo_scene* sc, const lvo_params* P, uint64_t n, const float* fragPos,
+                                             const float* normal, const float* tangent, const uint32_t* isCap, const float* attribute,
+                                             const float* aoTexel, const float* epsWhite, float* outColor, float* outHitT);
+void lvo_ribbon_of_rays(const float* cam, const float* dirs, uint64_t n, const float* axisPoint, const float* axisDir, float radius,
+                        const float* capHit, const float* capNormal, float* out);
 
 /* threads the OpenMP loops run on */
 int lvo_num_threads(void);

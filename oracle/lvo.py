@@ -108,6 +108,9 @@ def lib():
     L.lvo_svgf_denoise.argtypes = [u32, u32, vp, vp, vp, vp, vp, i32, f32, f32, vp, vp, vp, vp, vp]
     L.lvo_eaw_denoise.argtypes = [u32, u32, vp, vp, vp, i32, f32, f32, f32, i32, i32, i32, i32, u32, u32, u32, u32, vp]
     L.lvo_compute_fragment_color_batch.argtypes = [vp, vp, C.c_uint64] + [vp] * 8
+    L.lvo_compute_fragment_color_raster_batch.argtypes = [vp, vp, C.c_uint64] + [vp] * 9
+    L.lvo_ribbon_of_rays.argtypes = [vp, vp, C.c_uint64, vp, vp, f32, vp, vp, vp]
+    L.lvo_set_ppll_fragment_colour_variant.argtypes = [i32]
     L.lvo_num_threads.restype = i32
     L.lvo_num_threads.argtypes = []
     L.lvo_tea.restype = u32
@@ -550,6 +553,23 @@ class Scene:
                                                _p(ht))
         return col, ht
 
+    def compute_fragment_color_raster(self, P, frag_pos, normal, tangent, is_cap, attribute, ao_texel, eps_white):
+        """Test hook: the raster variant of computeFragmentColor (EPSILON_OUTLINE = 0, EPSILON_WHITE = eps_white[i], cap halo
+        min(rp, |rp2|); LinePassGeometryShaderTubes.glsl:785-815,1079-1087) on n independent inputs."""
+        fp = np.ascontiguousarray(frag_pos, dtype=np.float32).reshape(-1, 3)
+        n = fp.shape[0]
+        nr = np.ascontiguousarray(normal, dtype=np.float32).reshape(n, 3)
+        tg = np.ascontiguousarray(tangent, dtype=np.float32).reshape(n, 3)
+        cap = np.ascontiguousarray(is_cap, dtype=np.uint32).reshape(n)
+        at = np.ascontiguousarray(attribute, dtype=np.float32).reshape(n)
+        ao = np.ascontiguousarray(ao_texel, dtype=np.float32).reshape(n)
+        ew = np.ascontiguousarray(eps_white, dtype=np.float32).reshape(n)
+        col = np.empty((n, 4), dtype=np.float32)
+        ht = np.empty(n, dtype=np.float32)
+        lib().lvo_compute_fragment_color_raster_batch(self.h, C.byref(P), n, _p(fp), _p(nr), _p(tg), _p(cap), _p(at), _p(ao), _p(ew),
+                                                      _p(col), _p(ht))
+        return col, ht
+
     def pixel_hits(self, P, tile=None, use_bvh=False):
         """All capsule entry hits of every pixel-centre ray: (offsets (w*h+1), segments, t), ascending segment index."""
         x0, y0, w, h = self._tile(P, tile)
@@ -731,6 +751,34 @@ def set_num_threads(n):
 def num_threads():
     """Threads the oracle's OpenMP loops run on."""
     return int(lib().lvo_num_threads())
+
+
+def ribbon_of_rays(cam, dirs, axis_point, axis_dir, radius, cap_hit=None, cap_normal=None):
+    """Test hook: the ribbon coordinate of n viewing rays (origin cam) with respect to a tube axis (tubeRibbonOfRay), or -- with
+    cap_hit / cap_normal -- about a cap fragment on the sphere at axis_point (capRibbonOfRay: tangent-plane extrapolation)."""
+    d = np.ascontiguousarray(dirs, dtype=np.float32).reshape(-1, 3)
+    out = np.empty(len(d), dtype=np.float32)
+    c = np.ascontiguousarray(cam, dtype=np.float32)
+    a = np.ascontiguousarray(axis_point, dtype=np.float32)
+    t = np.ascontiguousarray(axis_dir, dtype=np.float32)
+    ch = np.ascontiguousarray(cap_hit, dtype=np.float32) if cap_hit is not None else None
+    cn = np.ascontiguousarray(cap_normal, dtype=np.float32) if cap_normal is not None else None
+    lib().lvo_ribbon_of_rays(_p(c), _p(d), len(d), _p(a), _p(t), float(radius), _p(ch) if ch is not None else None,
+                             _p(cn) if cn is not None else None, _p(out))
+    return out
+
+
+class ppll_ray_tracer_fragment_colour:
+    """Context manager: inside the block the PPLL gather shades its fragments with the RAY TRACER's computeFragmentColor
+    (RayHitCommon.glsl -- what rounds 1-2 did) instead of the raster tube shader's variant (deviation measurement)."""
+
+    def __enter__(self):
+        lib().lvo_set_ppll_fragment_colour_variant(1)
+        return self
+
+    def __exit__(self, *exc):
+        lib().lvo_set_ppll_fragment_colour_variant(0)
+        return False
 
 
 _DEFAULT_SWITCHES = [0, 0]      # what the oracle evaluates outside every deviation_switches block

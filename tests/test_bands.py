@@ -242,8 +242,9 @@ def test_elliptic_all_hits_consumers_agree_with_the_closest_hit_loop():
     sc = c.oracle_scene()
     P = c.oracle_params(sc)
     loop = sc.render_rt(P, use_bvh=True).astype(np.int32)
-    ppll = sc.render_ppll(P, use_bvh=False)
-    assert np.array_equal(ppll, sc.render_ppll(P, use_bvh=True))
+    with lvo.ppll_ray_tracer_fragment_colour():   # the same fragment colour as the loop (the gather's own is the raster shader's)
+        ppll = sc.render_ppll(P, use_bvh=False)
+        assert np.array_equal(ppll, sc.render_ppll(P, use_bvh=True))
     # exact sorting vs the closest-hit loop: the same layers front to back (the loop re-traces from hitT + eps, the lists sort by
     # camera distance; both stop at alpha 0.99).  The lists hold packUnorm4x8 colours: a highlight above 1.0 is clamped per fragment
     # there and only at the end in the loop -- those pixels (< 1 %) differ by more than the rounding

@@ -185,7 +185,9 @@ def test_ppll_of_band_data_matches_the_oracle(hip_lib, kw):
     assert ocnt2 == ocnt and _fragment_lists(on2, os2) == _fragment_lists(on, os_)
     if kw.get("elliptic", True):                                   # opaque tubelets (coverage 1): the front fragment is the ray
         opaque = band_case(width=100, height=70, **kw)             # tracer's hit
-        a = opaque.hip_context().render(2)
+        pctx = opaque.hip_context()
+        pctx.set_option("ppll_fragment_colour", "ray_tracer")      # the ray tracer's fragment colour (the gather's own is the raster shader's)
+        a = pctx.render(2)
         b = opaque.hip_context().render(11)
         assert max_lsb_diff(a, b) <= 2
 

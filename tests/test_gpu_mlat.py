@@ -51,7 +51,9 @@ def test_replay_parity_dense_transparent_scene(hip_lib, k):
 def ctx2_render(c, mode):
     s = {k: v for k, v in c.settings.items() if not k.startswith("mlat") and k not in ("use_mlat", "collect_stats")}
     c2 = Case(c.points, c.seg, c.tf, c.width, c.height, c.line_width, **s)
-    return c2.hip_context().render(mode)
+    ctx = c2.hip_context()
+    ctx.set_option("ppll_fragment_colour", "ray_tracer")   # like for like: MLAT shades with the ray tracer's computeFragmentColor
+    return ctx.render(mode)
 
 
 def test_replay_parity_with_rtao_and_depth_cues(hip_lib):

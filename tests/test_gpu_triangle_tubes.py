@@ -273,6 +273,8 @@ def test_triangle_mesh_geometry_mode_frames(hip_lib, settings, transparent):
     # back to the analytic mode: a different picture (round vs faceted tubes), the capsule oracle's picture
     ctx.set_option("geometry_mode", "AABBs (analytic)")
     ctx.set_option("rtao_geometry", "capsules")
+    case.settings.pop("rtao_geometry", None)
+    case.oracle_params(sc)                # intersection_form "auto" is the closest-approach form again (Case.literal_form)
     img_c = ctx.render(capi.MODE_RAY_TRACER)
     ao_c = sc.render_ao(P, use_bvh=True) if P.useAmbientOcclusion else None
     assert max_lsb_diff(img_c, sc.render_rt(P, ao=ao_c, use_bvh=True)) <= 2
