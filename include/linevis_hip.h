@@ -231,6 +231,28 @@ int lv_render_device(lv_ctx* ctx, int rendering_mode, uint32_t x0, uint32_t y0, 
 int lv_render_tiles_device(lv_ctx* ctx, int rendering_mode, const uint32_t* tiles_xy, uint32_t num_tiles,
                            uint32_t tile_w, uint32_t tile_h, void* out_rgba8_device);
 
+/* ---- several GPUs behind one handle (SURVEY.md 8b "Multi-GPU = one context per device", 8e; the reference is single-GPU:
+ * sgl::AppSettings::getPrimaryDevice() everywhere, e.g. src/LineData/LineData.cpp:722) ----
+ * lv_create_multi: one context per listed device, driven through the returned handle (= rank 0, the first device) by the calling
+ * thread; every setter above is repeated on all ranks (full scene replica + LBVH per GPU), every lv_render* call deals the
+ * requested pixels as screen tiles over the ranks (64 x 64 along a Morton order for a rectangle; the caller's tiles for
+ * lv_render_tiles_device), renders them concurrently and assembles them on rank 0 with ONE gather of RGBA8 tiles:
+ * transport "rccl" (default; ncclSend / ncclRecv group over xGMI, librccl resolved at run time; distinct devices) or "memcpy"
+ * (hipMemcpyPeerAsync + events; no RCCL needed, the same device may appear several times).  The frame is byte-identical to the
+ * single-device frame.  Output pointers of lv_render_device / lv_render_tiles_device live on the first device.  Read-backs
+ * (lv_get_ao, lv_ppll_get_buffers, lv_get_kernel_times, ...) address rank 0; lv_get_stats sums the counters of all ranks.
+ * lv_multi_rebalance: re-deals the tiles of the last frame by measured cost (RTAO hit pixels x samples per tile + base_cost_per_tile,
+ * longest processing time first); synchronises all ranks, call it between frames (progressive accumulation: not while a
+ * num_accumulated_frames > 1 sequence is running -- the history stays on the rank that rendered it).
+ * lv_multi_deal: tile -> rank of the last frame.  lv_tile_deal / lv_make_tiles: the deal and the tile order as pure host
+ * functions (costs == NULL: round robin). */
+lv_ctx* lv_create_multi(const int* device_ordinals, int num_devices, const char* transport, int* err);
+int lv_multi_ranks(const lv_ctx* ctx);
+int lv_multi_rebalance(lv_ctx* ctx, double base_cost_per_tile);
+int lv_multi_deal(lv_ctx* ctx, uint32_t* out_owner, uint32_t capacity, uint32_t* out_count);
+int lv_tile_deal(const double* costs, uint32_t num_tiles, uint32_t num_ranks, uint32_t* out_owner);
+uint32_t lv_make_tiles(uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, uint32_t tile, uint32_t* out_xy, uint32_t capacity);
+
 int lv_get_stats(lv_ctx* ctx, lv_stats* out);
 /* Forget the per-kernel launch timings collected so far (start of a timed benchmark region). */
 int lv_reset_timers(lv_ctx* ctx);

@@ -85,7 +85,8 @@ SYMBOLS = ["lv_create", "lv_destroy", "lv_last_error", "lv_version", "lv_set_str
            "lv_render", "lv_render_device", "lv_render_tiles_device", "lv_get_stats", "lv_reset_timers", "lv_get_kernel_times", "lv_get_ao_tile_costs", "lv_trace_rays",
            "lv_compute_depth_range", "lv_get_ao", "lv_ppll_get_buffers", "lv_ppll_resolve_buffers", "lv_get_accel",
            "lv_set_tube_triangle_mesh", "lv_trace_rays_triangles", "lv_set_flow_grid", "lv_trace_streamlines",
-           "lv_get_streamlines", "lv_get_streamline_seed_indices", "lv_set_ao_parametrization", "lv_get_baked_ao", "lv_get_mlat_trace"]
+           "lv_get_streamlines", "lv_get_streamline_seed_indices", "lv_set_ao_parametrization", "lv_get_baked_ao", "lv_get_mlat_trace",
+           "lv_create_multi", "lv_multi_ranks", "lv_multi_rebalance", "lv_multi_deal", "lv_tile_deal", "lv_make_tiles"]
 
 _lib = None
 
@@ -117,7 +118,16 @@ def load():
     L.lv_last_error.argtypes = [vp]
     L.lv_version.restype = cp
     L.lv_version.argtypes = []
+    L.lv_create_multi.restype = vp
+    L.lv_create_multi.argtypes = [vp, i32, cp, C.POINTER(i32)]
+    L.lv_multi_ranks.restype = i32
+    L.lv_multi_ranks.argtypes = [vp]
+    L.lv_make_tiles.restype = u32
+    L.lv_make_tiles.argtypes = [u32, u32, u32, u32, u32, vp, u32]
     for name, args in [
+        ("lv_multi_rebalance", [vp, C.c_double]),
+        ("lv_multi_deal", [vp, vp, u32, C.POINTER(u32)]),
+        ("lv_tile_deal", [vp, u32, u32, vp]),
         ("lv_set_stream", [vp, vp]),
         ("lv_set_lines", [vp, vp, u32, vp, u32]),
         ("lv_set_transfer_function", [vp, vp, u32, f32, f32]),
@@ -159,6 +169,25 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+def tile_deal(costs, num_tiles, num_ranks):
+    """lv_tile_deal: tile -> rank, longest processing time first (costs None: round robin).  Pure host code."""
+    out = np.zeros(max(int(num_tiles), 1), dtype=np.uint32)
+    c = np.ascontiguousarray(costs, dtype=np.float64) if costs is not None else None
+    rc = load().lv_tile_deal(_p(c) if c is not None else None, int(num_tiles), int(num_ranks), _p(out))
+    if rc != LV_OK:
+        raise LineVisError(rc, "lv_tile_deal")
+    return out[:int(num_tiles)]
+
+
+def make_tiles(x0, y0, w, h, tile):
+    """lv_make_tiles: origins of the tile x tile squares covering the rectangle, along a Morton order.  Pure host code."""
+    L = load()
+    n = L.lv_make_tiles(int(x0), int(y0), int(w), int(h), int(tile), None, 0)
+    out = np.zeros((max(n, 1), 2), dtype=np.uint32)
+    L.lv_make_tiles(int(x0), int(y0), int(w), int(h), int(tile), _p(out), n)
+    return out[:n]
+
+
 def _fmt(v):
     if isinstance(v, bool):
         return "true" if v else "false"
@@ -170,14 +199,39 @@ def _fmt(v):
 class Context:
     """One renderer context on one HIP device (thin OO veneer over the lv_* calls)."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, devices=None, transport="rccl"):
+        """device: one HIP device.  devices = [d0, d1, ...]: lv_create_multi -- one context per device behind this handle, frames
+        sharded by screen tiles and gathered on d0 (transport "rccl" | "memcpy")."""
         self.L = load()
         err = C.c_int(0)
-        self.h = self.L.lv_create(int(device), C.byref(err))
-        if not self.h:
-            raise LineVisError(err.value, "lv_create(%d) failed: no usable HIP device (no CPU fallback)" % device)
+        if devices is not None:
+            devs = np.ascontiguousarray(devices, dtype=np.int32)
+            self.h = self.L.lv_create_multi(_p(devs), len(devs), transport.encode("utf-8"), C.byref(err))
+            if not self.h:
+                raise LineVisError(err.value, "lv_create_multi(%s, %s) failed" % (list(devs), transport))
+            device = int(devs[0])
+        else:
+            self.h = self.L.lv_create(int(device), C.byref(err))
+            if not self.h:
+                raise LineVisError(err.value, "lv_create(%d) failed: no usable HIP device (no CPU fallback)" % device)
         self.width = self.height = 0
         self.device = int(device)
+
+    @property
+    def num_ranks(self):
+        return int(self.L.lv_multi_ranks(self.h))
+
+    def rebalance(self, base_cost_per_tile=4.0 * 64 * 64):
+        """Multi-device handle: re-deal the tiles of the last frame by measured cost (lv_multi_rebalance)."""
+        self._ck(self.L.lv_multi_rebalance(self.h, float(base_cost_per_tile)))
+
+    def deal(self):
+        """tile -> rank of the last frame of a multi-device handle"""
+        n = C.c_uint32(0)
+        self._ck(self.L.lv_multi_deal(self.h, None, 0, C.byref(n)))
+        out = np.zeros(max(n.value, 1), dtype=np.uint32)
+        self._ck(self.L.lv_multi_deal(self.h, _p(out), len(out), C.byref(n)))
+        return out[:n.value]
 
     def close(self):
         if getattr(self, "h", None):

@@ -170,6 +170,7 @@ lv_ctx* lv_create(int device_ordinal, int* err) {
 
 void lv_destroy(lv_ctx* ctx) {
     if (!ctx) return;
+    if (ctx->multi) lv_multi_destroy(ctx); // the other ranks, the communicators and the gather buffers
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (LvDeviceBuffer* b : {&ctx->points, &ctx->segIdx, &ctx->nodes, &ctx->segs, &ctx->segAxis, &ctx->leafSeg, &ctx->segToLeaf, &ctx->tf,
@@ -231,7 +232,7 @@ int lv_set_lines(lv_ctx* ctx, const lv_line_point* points, uint32_t num_points, 
     // lastFrameViewProjectionMatrix = the current camera's
     ctx->aoGlobalFrameNumber = 0;
     ctx->lastFrameViewProjValid = false;
-    return LV_OK;
+    return lv_forward_to_ranks(ctx, [&](lv_ctx* p) { return lv_set_lines(p, points, num_points, seg, num_segments); });
 }
 
 int lv_set_tube_triangle_mesh(lv_ctx* ctx, const uint32_t* triangle_indices, uint32_t num_triangles,
@@ -271,7 +272,7 @@ int lv_set_tube_triangle_mesh(lv_ctx* ctx, const uint32_t* triangle_indices, uin
     ctx->triMeshSet = true;
     ctx->triAccelValid = false;
     ctx->bakeValid = false;
-    return LV_OK;
+    return lv_forward_to_ranks(ctx, [&](lv_ctx* p) { return lv_set_tube_triangle_mesh(p, triangle_indices, num_triangles, vertices, num_vertices, line_points, num_line_points); });
 }
 
 int lv_set_ao_parametrization(lv_ctx* ctx, const float* blending_weights, uint32_t num_line_vertices,
@@ -302,7 +303,7 @@ int lv_set_ao_parametrization(lv_ctx* ctx, const float* blending_weights, uint32
     ctx->bakeNumParametrizationVertices = num_parametrization_vertices;
     ctx->bakeParamSet = true;
     ctx->bakeValid = false;
-    return LV_OK;
+    return lv_forward_to_ranks(ctx, [&](lv_ctx* p) { return lv_set_ao_parametrization(p, blending_weights, num_line_vertices, sampling_locations, num_parametrization_vertices); });
 }
 
 int lv_get_baked_ao(lv_ctx* ctx, float* out, uint64_t max_values) {
@@ -328,7 +329,7 @@ int lv_set_transfer_function(lv_ctx* ctx, const float* rgba, uint32_t n, float a
     ctx->tfN = n;
     ctx->attrMin = attr_min;
     ctx->attrMax = attr_max;
-    return LV_OK;
+    return lv_forward_to_ranks(ctx, [&](lv_ctx* p) { return lv_set_transfer_function(p, rgba, n, attr_min, attr_max); });
 }
 
 int lv_set_camera(lv_ctx* ctx, const float view[16], const float proj[16], float fov_y, float near_dist, float far_dist,
@@ -345,13 +346,13 @@ int lv_set_camera(lv_ctx* ctx, const float view[16], const float proj[16], float
     ctx->width = w;
     ctx->height = h;
     ctx->cameraSet = true;
-    return LV_OK;
+    return lv_forward_to_ranks(ctx, [&](lv_ctx* p) { return lv_set_camera(p, view, proj, fov_y, near_dist, far_dist, w, h); });
 }
 
 int lv_set_background(lv_ctx* ctx, const float rgba[4]) {
     if (!ctx || !rgba) return LV_E_INVALID;
     memcpy(ctx->background, rgba, 16);
-    return LV_OK;
+    return lv_forward_to_ranks(ctx, [&](lv_ctx* p) { return lv_set_background(p, rgba); });
 }
 
 int lv_set_option(lv_ctx* ctx, const char* key, const char* value) {
@@ -551,13 +552,45 @@ int lv_set_option(lv_ctx* ctx, const char* key, const char* value) {
     } else {
         return lv_fail(ctx, LV_E_INVALID, "unknown option '%s'", key);
     }
-    return LV_OK;
+    return lv_forward_to_ranks(ctx, [&](lv_ctx* p) { return lv_set_option(p, key, value); });
 }
 
 int lv_build_accel(lv_ctx* ctx) {
     if (!ctx) return LV_E_INVALID;
     (void)hipSetDevice(ctx->device);
-    return lv_bvh_build(ctx);
+    int rc = lv_bvh_build(ctx);
+    if (rc) return rc;
+    return lv_forward_to_ranks(ctx, [&](lv_ctx* p) { return lv_build_accel(p); });
+}
+
+lv_ctx* lv_create_multi(const int* device_ordinals, int num_devices, const char* transport, int* err) {
+    if (!device_ordinals || num_devices <= 0) {
+        if (err) *err = LV_E_INVALID;
+        return nullptr;
+    }
+    lv_ctx* ctx = lv_create(device_ordinals[0], err);
+    if (!ctx) return nullptr;
+    const int rc = lv_multi_create(ctx, device_ordinals, num_devices, transport);
+    if (rc) {
+        fprintf(stderr, "lv_create_multi: %s\n", ctx->lastError.c_str());
+        lv_destroy(ctx);
+        if (err) *err = rc;
+        return nullptr;
+    }
+    if (err) *err = LV_OK;
+    return ctx;
+}
+
+int lv_multi_ranks(const lv_ctx* ctx) { return ctx ? lv_multi_num_ranks(ctx) : 0; }
+
+int lv_multi_rebalance(lv_ctx* ctx, double base_cost_per_tile) {
+    if (!ctx) return LV_E_INVALID;
+    return lv_multi_rebalance_impl(ctx, base_cost_per_tile);
+}
+
+int lv_multi_deal(lv_ctx* ctx, uint32_t* out_owner, uint32_t capacity, uint32_t* out_count) {
+    if (!ctx) return LV_E_INVALID;
+    return lv_multi_get_deal(ctx, out_owner, capacity, out_count);
 }
 
 int lv_render_tiles_device(lv_ctx* ctx, int mode, const uint32_t* tiles_xy, uint32_t num_tiles, uint32_t tile_w,
@@ -565,10 +598,19 @@ int lv_render_tiles_device(lv_ctx* ctx, int mode, const uint32_t* tiles_xy, uint
     if (!ctx) return LV_E_INVALID;
     if (!tiles_xy || !out) return lv_fail(ctx, LV_E_INVALID, "null tile list / output");
     (void)hipSetDevice(ctx->device);
+    if (ctx->multi) { // the caller's tiles dealt over the ranks, one gather, tile-major output on rank 0's device
+        if (num_tiles == 0 || tile_w == 0 || tile_h == 0) return lv_fail(ctx, LV_E_INVALID, "empty tile list");
+        return lv_multi_render(ctx, mode, tiles_xy, num_tiles, tile_w, tile_h, false, 0, 0, 0, 0, out);
+    }
     return lv_frame_render(ctx, mode, tiles_xy, num_tiles, tile_w, tile_h, out);
 }
 
 int lv_render_device(lv_ctx* ctx, int mode, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, void* out) {
+    if (ctx && ctx->multi) { // the rectangle in 64 x 64 tiles over the ranks
+        if (!out || w == 0 || h == 0) return lv_fail(ctx, LV_E_INVALID, "null output / empty rectangle");
+        (void)hipSetDevice(ctx->device);
+        return lv_multi_render_rect(ctx, mode, x0, y0, w, h, out);
+    }
     uint32_t xy[2] = {x0, y0};
     return lv_render_tiles_device(ctx, mode, xy, 1, w, h, out);
 }
@@ -651,6 +693,19 @@ int lv_get_stats(lv_ctx* ctx, lv_stats* out) {
         bytes += b->bytes;
     s.device_bytes = bytes;
     *out = s;
+    // a multi-device handle reports the work of all its ranks (counters and memory summed; times are rank 0's)
+    for (int r = 1; r < lv_multi_num_ranks(ctx); r++) {
+        lv_stats ps;
+        const int rc = lv_get_stats(lv_multi_rank(ctx, r), &ps);
+        if (rc) return lv_fail(ctx, rc, "rank %d: %s", r, lv_multi_rank(ctx, r)->lastError.c_str());
+        out->rays_traced += ps.rays_traced; out->nodes_visited += ps.nodes_visited; out->prims_tested += ps.prims_tested;
+        out->hits_shaded += ps.hits_shaded; out->fragments += ps.fragments; out->ao_hit_pixels += ps.ao_hit_pixels;
+        out->ao_rays_traced += ps.ao_rays_traced; out->ao_nodes_visited += ps.ao_nodes_visited; out->ao_prims_tested += ps.ao_prims_tested;
+        out->ao_prim_hits += ps.ao_prim_hits; out->ao_prim_may_axis += ps.ao_prim_may_axis; out->ao_prim_may_both += ps.ao_prim_may_both;
+        out->max_depth_complexity = ps.max_depth_complexity > out->max_depth_complexity ? ps.max_depth_complexity : out->max_depth_complexity;
+        out->device_bytes += ps.device_bytes;
+    }
+    (void)hipSetDevice(ctx->device);
     return LV_OK;
 }
 

@@ -93,7 +93,9 @@ struct LvOptions {
     uint32_t mlatTraceCapacity = 1u << 22;    // records (16 B each)
 };
 
+struct LvMulti;
 struct lv_ctx {
+    LvMulti* multi = nullptr;                 // lv_create_multi: the ranks this handle drives (lv_multi.hip); null = one device
     int device = 0;
     int numCUs = 256;
     hipStream_t ownStream = nullptr;
@@ -219,6 +221,27 @@ void lv_buf_free(LvDeviceBuffer& b);
 // lv_bvh.hip
 int lv_bvh_build(lv_ctx* ctx);
 int lv_bvh_build_triangles(lv_ctx* ctx);
+// lv_multi.hip: one frame over the GPUs of a node behind the same handle
+int lv_multi_create(lv_ctx* handle, const int* devices, int numDevices, const char* transport);
+void lv_multi_destroy(lv_ctx* handle);
+int lv_multi_num_ranks(const lv_ctx* handle);
+lv_ctx* lv_multi_rank(lv_ctx* handle, int r);
+int lv_multi_render(lv_ctx* handle, int mode, const uint32_t* tilesXY, uint32_t numTiles, uint32_t tileW, uint32_t tileH, bool image,
+                    uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, void* outDevice);
+int lv_multi_render_rect(lv_ctx* handle, int mode, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, void* outDevice);
+int lv_multi_rebalance_impl(lv_ctx* handle, double baseCostPerTile);
+int lv_multi_get_deal(lv_ctx* handle, uint32_t* outOwner, uint32_t capacity, uint32_t* outCount);
+// repeats a setter on the other ranks of a multi-device handle (no-op for a single-device context)
+template <class F>
+inline int lv_forward_to_ranks(lv_ctx* handle, F&& f) {
+    const int n = lv_multi_num_ranks(handle);
+    for (int r = 1; r < n; r++) {
+        lv_ctx* p = lv_multi_rank(handle, r);
+        const int rc = f(p);
+        if (rc) return lv_fail(handle, rc, "rank %d (device %d): %s", r, p->device, p->lastError.c_str());
+    }
+    return LV_OK;
+}
 // lv_mlat.hip
 struct LvUniforms;
 struct LvSceneDev;

@@ -818,10 +818,8 @@ __global__ __launch_bounds__(LV_BLOCK, LV_GATHER_MIN_WAVES) void k_ppll_gather(c
         LvRasterQuad rq;
         const LvRasterQuad* rqp = nullptr;
         if (U.ppllRasterColour) {
-            const uint32_t pxy = __float_as_uint(ownerPixel), qx = pxy & 0xFFFFu, qy = pxy >> 16;
-            f3 oq;
-            lv_primary_ray(U, qx ^ 1u, qy, 0.5f, 0.5f, oq, rq.dX);
-            lv_primary_ray(U, qx, qy ^ 1u, 0.5f, 0.5f, oq, rq.dY);
+            const uint32_t pxy = __float_as_uint(ownerPixel);
+            rq = lv_make_raster_quad(U, pxy & 0xFFFFu, pxy >> 16);
             rqp = &rq;
         }
         f4 color = PRIM == LV_PRIM_ELLIPTIC ? lv_shade_hit_elliptic(S, U, ownerAo, ro, rd, h, hitT, rqp)

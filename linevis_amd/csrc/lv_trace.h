@@ -986,7 +986,26 @@ struct LvBandArgs { bool useBand; float phi; f3 linePosition, lineNormal; float 
 // coordinate = the position of the ray's trace in the cross-section plane between the two silhouette points), so the quad
 // partners' "helper invocations" are the rays through the pixels (x ^ 1, y) and (x, y ^ 1) evaluated against the fragment's segment,
 // whether or not they hit it: fwidth = |f(x ^ 1, y) - f(x, y)| + |f(x, y ^ 1) - f(x, y)|  (same operation order as the CPU checker).
-struct LvRasterQuad { f3 dX, dY; };
+// The three rays come from the AFFINE ray generator (directions are only used up to their length): D(x, y) = invView * (invProj *
+// (ndc(x, y), 1, 1)).xyz without the normalisation of TubeRayTracing.glsl:225-226, D(x +- 1, y) = D +- dD/dx, D(x, y +- 1) = D +- dD/dy
+// with the per-frame steps dD/dx = invView * (invProj * (2 / W, 0, 0, 0)).xyz, dD/dy likewise (wave-uniform: scalar registers).
+struct LvRasterQuad { f3 d0, dX, dY; };
+__device__ __forceinline__ LvRasterQuad lv_make_raster_quad(const LvUniforms& U, uint32_t x, uint32_t y) {
+    const float ndcx = 2.0f * ((float(x) + 0.5f) / float(U.width)) - 1.0f;
+    const float ndcy = 2.0f * ((float(y) + 0.5f) / float(U.height)) - 1.0f;
+    const f4 target = mulM4(U.invProj, ndcx, ndcy, 1.0f, 1.0f);
+    const f4 dir = mulM4(U.invView, target.x, target.y, target.z, 0.0f);
+    const f4 gx = mulM4(U.invProj, 2.0f / float(U.width), 0.0f, 0.0f, 0.0f);
+    const f4 gy = mulM4(U.invProj, 0.0f, 2.0f / float(U.height), 0.0f, 0.0f);
+    const f4 Gx = mulM4(U.invView, gx.x, gx.y, gx.z, 0.0f);
+    const f4 Gy = mulM4(U.invView, gy.x, gy.y, gy.z, 0.0f);
+    const float sx = (x & 1u) ? -1.0f : 1.0f, sy = (y & 1u) ? -1.0f : 1.0f;
+    LvRasterQuad q;
+    q.d0 = mk3(dir.x, dir.y, dir.z);
+    q.dX = mk3(dir.x + sx * Gx.x, dir.y + sx * Gx.y, dir.z + sx * Gx.z);
+    q.dY = mk3(dir.x + sy * Gy.x, dir.y + sy * Gy.y, dir.z + sy * Gy.z);
+    return q;
+}
 __device__ __forceinline__ float lv_tube_ribbon_of_ray(f3 cam, f3 d, f3 axisPoint, f3 t, float radius) {
     const f3 w = cam - axisPoint;
     const f3 wp = w - dot3(w, t) * t;
@@ -1140,8 +1159,8 @@ __device__ __forceinline__ f4 lv_shade_hit(const LvSceneDev& S, const LvUniforms
     if (rq && BANDS != LV_SHADE_BANDS) {
         const f3 cam = mk3(U.camPos[0], U.camPos[1], U.camPos[2]);
         const bool cap = U.useCappedTubes && isCap;
-        const float f0 = cap ? lv_cap_ribbon_of_ray(cam, d, fragPos, fragmentNormal, linePointInterpolated, fragmentTangent)
-                             : lv_tube_ribbon_of_ray(cam, d, linePointInterpolated, fragmentTangent, U.radius);
+        const float f0 = cap ? lv_cap_ribbon_of_ray(cam, rq->d0, fragPos, fragmentNormal, linePointInterpolated, fragmentTangent)
+                             : lv_tube_ribbon_of_ray(cam, rq->d0, linePointInterpolated, fragmentTangent, U.radius);
         const float fx = cap ? lv_cap_ribbon_of_ray(cam, rq->dX, fragPos, fragmentNormal, linePointInterpolated, fragmentTangent)
                              : lv_tube_ribbon_of_ray(cam, rq->dX, linePointInterpolated, fragmentTangent, U.radius);
         const float fy = cap ? lv_cap_ribbon_of_ray(cam, rq->dY, fragPos, fragmentNormal, linePointInterpolated, fragmentTangent)
@@ -1208,8 +1227,8 @@ __device__ __forceinline__ f4 lv_shade_hit(const LvSceneDev& S, const LvUniforms
             const f3 tN = norm3(fragmentTangent);
             const bool cap = U.useCappedTubes && isCap;
             const float r = U.lineWidth * 0.5f;
-            const float f0 = cap ? lv_cap_ribbon_of_ray(cam, d, fragPos, fragmentNormal, linePointInterpolated, fragmentTangent)
-                                 : lv_bands_ribbon_of_ray(cam, d, b.linePosition, b.lineNormal, fragmentTangent, tN, r, 1.0f);
+            const float f0 = cap ? lv_cap_ribbon_of_ray(cam, rq->d0, fragPos, fragmentNormal, linePointInterpolated, fragmentTangent)
+                                 : lv_bands_ribbon_of_ray(cam, rq->d0, b.linePosition, b.lineNormal, fragmentTangent, tN, r, 1.0f);
             const float fx = cap ? lv_cap_ribbon_of_ray(cam, rq->dX, fragPos, fragmentNormal, linePointInterpolated, fragmentTangent)
                                  : lv_bands_ribbon_of_ray(cam, rq->dX, b.linePosition, b.lineNormal, fragmentTangent, tN, r, 1.0f);
             const float fy = cap ? lv_cap_ribbon_of_ray(cam, rq->dY, fragPos, fragmentNormal, linePointInterpolated, fragmentTangent)
@@ -1275,7 +1294,7 @@ __device__ __forceinline__ f4 lv_shade_hit_elliptic(const LvSceneDev& S, const L
         const f3 cam = mk3(U.camPos[0], U.camPos[1], U.camPos[2]);
         const f3 tN = norm3(E.tangent);
         const float r = U.bandWidth * 0.5f;
-        const float f0 = lv_bands_ribbon_of_ray(cam, d, b.linePosition, b.lineNormal, E.tangent, tN, r, U.minThickness);
+        const float f0 = lv_bands_ribbon_of_ray(cam, rq->d0, b.linePosition, b.lineNormal, E.tangent, tN, r, U.minThickness);
         const float fx = lv_bands_ribbon_of_ray(cam, rq->dX, b.linePosition, b.lineNormal, E.tangent, tN, r, U.minThickness);
         const float fy = lv_bands_ribbon_of_ray(cam, rq->dY, b.linePosition, b.lineNormal, E.tangent, tN, r, U.minThickness);
         b.rasterEpsWhite = fabsf(fx - f0) + fabsf(fy - f0);

@@ -624,7 +624,26 @@ inline void blinnPhongShadingTube(const lvo_params& P, const Frame& F, float aoT
 // coordinate is the position of the ray's trace in the cross-section plane between the two silhouette points -- so it is
 // evaluated for the rays through the quad partners (x ^ 1, y) and (x, y ^ 1) with respect to the fragment's segment, whether or
 // not those rays hit it: fwidth = |f(x ^ 1, y) - f(x, y)| + |f(x, y ^ 1) - f(x, y)| (fine derivatives of the 2 x 2 quad).
-struct RasterQuad { V3 dX, dY; };   // directions of the partner rays (origin = camera, pixel centres)
+// The three rays come from the AFFINE ray generator (ray directions are only used up to their length here): D(x, y) = invView *
+// (invProj * (ndc(x, y), 1, 1)).xyz without the normalisation of TubeRayTracing.glsl:225-226, and D(x +- 1, y) = D +- dD/dx,
+// D(x, y +- 1) = D +- dD/dy with the constant steps dD/dx = invView * (invProj * (2 / W, 0, 0, 0)).xyz, dD/dy likewise.
+struct RasterQuad { V3 d0, dX, dY; };   // un-normalised directions of the pixel's own ray and of its two quad partners (origin = camera)
+inline RasterQuad makeRasterQuad(const lvo_params& P, const Frame& F, uint32_t x, uint32_t y) {
+    const float ndcx = 2.0f * ((float(x) + 0.5f) / float(P.width)) - 1.0f;
+    const float ndcy = 2.0f * ((float(y) + 0.5f) / float(P.height)) - 1.0f;
+    const V4 target = mulM4(F.invProj, V4{ndcx, ndcy, 1.0f, 1.0f});
+    const V4 dir = mulM4(F.invView, V4{target.x, target.y, target.z, 0.0f});
+    const V4 gx = mulM4(F.invProj, V4{2.0f / float(P.width), 0.0f, 0.0f, 0.0f});
+    const V4 gy = mulM4(F.invProj, V4{0.0f, 2.0f / float(P.height), 0.0f, 0.0f});
+    const V4 Gx = mulM4(F.invView, V4{gx.x, gx.y, gx.z, 0.0f});
+    const V4 Gy = mulM4(F.invView, V4{gy.x, gy.y, gy.z, 0.0f});
+    const float sx = (x & 1u) ? -1.0f : 1.0f, sy = (y & 1u) ? -1.0f : 1.0f;
+    RasterQuad q;
+    q.d0 = v3(dir.x, dir.y, dir.z);
+    q.dX = v3(dir.x + sx * Gx.x, dir.y + sx * Gx.y, dir.z + sx * Gx.z);
+    q.dY = v3(dir.x + sy * Gy.x, dir.y + sy * Gy.y, dir.z + sy * Gy.z);
+    return q;
+}
 // ribbon coordinate of the ray (cam, d) with respect to a tube axis (point, unit direction t): signed ray-axis distance / radius,
 // clamped like the shader clamps ribbonPosition (:1-style clamp(ribbonPosition, -1, 1), :962)
 inline float tubeRibbonOfRay(V3 cam, V3 d, V3 axisPoint, V3 t, float radius) {
@@ -728,8 +747,8 @@ inline void shadeHit(const lvo_scene& sc, const lvo_params& P, const Frame& F, f
     float rasterEps = -1.0f;
     if (rq && !P.useBands) {
         const bool cap = P.useCappedTubes && isCap;
-        const float f0 = cap ? capRibbonOfRay(F.cameraPosition, d, fragPos, fragmentNormal, linePointInterpolated, fragmentTangent)
-                             : tubeRibbonOfRay(F.cameraPosition, d, linePointInterpolated, fragmentTangent, F.radius);
+        const float f0 = cap ? capRibbonOfRay(F.cameraPosition, rq->d0, fragPos, fragmentNormal, linePointInterpolated, fragmentTangent)
+                             : tubeRibbonOfRay(F.cameraPosition, rq->d0, linePointInterpolated, fragmentTangent, F.radius);
         const float fx = cap ? capRibbonOfRay(F.cameraPosition, rq->dX, fragPos, fragmentNormal, linePointInterpolated, fragmentTangent)
                              : tubeRibbonOfRay(F.cameraPosition, rq->dX, linePointInterpolated, fragmentTangent, F.radius);
         const float fy = cap ? capRibbonOfRay(F.cameraPosition, rq->dY, fragPos, fragmentNormal, linePointInterpolated, fragmentTangent)
@@ -785,7 +804,7 @@ inline void shadeHit(const lvo_scene& sc, const lvo_params& P, const Frame& F, f
                 return cap ? capRibbonOfRay(F.cameraPosition, dir, fragPos, fragmentNormal, linePointInterpolated, fragmentTangent)
                            : bandsRibbonOfRay(F.cameraPosition, dir, b.linePosition, b.lineNormal, fragmentTangent, tN, r, 1.0f);
             };
-            const float f0 = f(d);
+            const float f0 = f(rq->d0);
             b.rasterEpsWhite = fabsf(f(rq->dX) - f0) + fabsf(f(rq->dY) - f0);
         }
         computeFragmentColor(sc, P, F, aoTexel, fragPos, fragmentNormal, fragmentTangent, isCap, fragmentAttribute, hitColor,
@@ -841,7 +860,7 @@ inline void shadeHitElliptic(const lvo_scene& sc, const lvo_params& P, const Fra
     if (rq && P.useBands) {
         const V3 tN = normalize(E.tangent);
         const float r = P.bandWidth * 0.5f;
-        const float f0 = bandsRibbonOfRay(F.cameraPosition, d, b.linePosition, b.lineNormal, E.tangent, tN, r, P.minThickness);
+        const float f0 = bandsRibbonOfRay(F.cameraPosition, rq->d0, b.linePosition, b.lineNormal, E.tangent, tN, r, P.minThickness);
         const float fx = bandsRibbonOfRay(F.cameraPosition, rq->dX, b.linePosition, b.lineNormal, E.tangent, tN, r, P.minThickness);
         const float fy = bandsRibbonOfRay(F.cameraPosition, rq->dY, b.linePosition, b.lineNormal, E.tangent, tN, r, P.minThickness);
         b.rasterEpsWhite = fabsf(fx - f0) + fabsf(fy - f0);
@@ -2108,10 +2127,7 @@ void lvo_ppll_gather(const lvo_scene* sc, const lvo_params* Pp, int useBvh, cons
             const float aoTexel = (P.useAmbientOcclusion && ao) ? ao[size_t(y) * P.width + x] : 1.0f;
             allHits(*sc, F.radius, capped, useBvh != 0, o, d, 0.0001f, 1000.0f, hl, cnt);
             // raster variant of the fragment colour: the rays through the 2 x 2 quad partners (see RasterQuad)
-            RasterQuad rq;
-            V3 oq;
-            primaryRay(P, F, x ^ 1u, y, 0.5f, 0.5f, oq, rq.dX);
-            primaryRay(P, F, x, y ^ 1u, 0.5f, 0.5f, oq, rq.dY);
+            const RasterQuad rq = makeRasterQuad(P, F, x, y);
             const RasterQuad* rqp = g_rtFragmentColourInPpll ? nullptr : &rq;
             for (const Hit& hit : hl) {
                 float hc[4]; float hitT;

@@ -1,0 +1,108 @@
+"""Several GPUs behind one C-ABI handle (lv_create_multi, linevis_amd/csrc/lv_multi.hip).
+
+CPU tests: the deal (longest processing time first) and the Morton tile order as pure host functions of the library, against the
+Python tiling module the earlier rounds used.  GPU tests (one MI355X): a 1-rank RCCL communicator (ncclSend / ncclRecv to itself) and
+2-4 ranks on the same device over the memcpy transport reproduce the single-device frame byte for byte -- every part of the path
+except the xGMI wire itself."""
+import numpy as np
+import pytest
+
+from common import small_case
+from linevis_amd import capi, tiling
+
+
+def test_tile_deal_matches_the_python_deal():
+    rng = np.random.default_rng(3)
+    for n, world in [(1, 1), (7, 3), (510, 8), (64, 5), (3, 8)]:
+        costs = rng.uniform(0.0, 100.0, n)
+        costs[rng.integers(0, n, max(1, n // 4))] = 7.0          # ties
+        own = capi.tile_deal(costs, n, world)
+        want = np.zeros(n, dtype=np.uint32)
+        for r, ix in enumerate(tiling.assign_tiles_by_cost(costs, world)):
+            want[ix] = r
+        assert np.array_equal(own, want), (n, world)
+        assert np.array_equal(capi.tile_deal(None, n, world), np.arange(n) % world)      # no costs: round robin
+    # balance: 510 tiles with a heavy middle, 8 ranks -> within 2 % of the mean
+    c = np.exp(-np.linspace(-3, 3, 510) ** 2) * 1000 + 16
+    own = capi.tile_deal(c, 510, 8)
+    load = np.array([c[own == r].sum() for r in range(8)])
+    assert load.max() / load.mean() < 1.02
+
+
+def test_make_tiles_matches_the_python_morton_order():
+    for w, h, t in [(1920, 1080, 64), (100, 70, 32), (64, 64, 64), (65, 1, 64)]:
+        a = capi.make_tiles(0, 0, w, h, t)
+        assert np.array_equal(a, tiling.make_tiles(w, h, t))
+    b = capi.make_tiles(37, 21, 50, 33, 16)
+    assert np.array_equal(b - np.array([37, 21], np.uint32), tiling.make_tiles(50, 33, 16))
+
+
+RTAO = dict(ambient_occlusion_mode="RTAO (Screen Space)", ambient_occlusion_strength=1.0, ambient_occlusion_iterations=2,
+            ambient_occlusion_samples_per_frame=4, depth_cue_strength=0.6)
+
+
+def _setup(ctx, c):
+    ctx.set_lines(c.points, c.seg)
+    ctx.set_transfer_function(c.tf, 0.0, 1.0)
+    ctx.set_camera(c.view, c.proj, c.fovy, c.near, c.far, c.width, c.height)
+    ctx.set_background(c.background)
+    ctx.set_option("line_width", c.line_width)
+    ctx.set_options(c.settings)
+    return ctx
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("devices,transport", [([0], "rccl"), ([0], "memcpy"), ([0, 0], "memcpy"), ([0, 0, 0, 0], "memcpy")])
+def test_multi_handle_reproduces_the_single_device_frame(hip_lib, devices, transport):
+    c = small_case(width=200, height=136, n_lines=40, pts_per_line=40, line_width=0.012, **RTAO)
+    single = c.hip_context()
+    want = single.render(11)
+    multi = _setup(capi.Context(devices=devices, transport=transport), c)
+    assert multi.num_ranks == len(devices)
+    got = multi.render(11)
+    assert np.array_equal(got, want)
+    own = multi.deal()
+    assert len(own) == 4 * 3 and set(own.tolist()) == set(range(len(devices)))     # 64 x 64 tiles of 200 x 136, dealt round robin
+    # counters are summed over the ranks
+    multi.set_option("collect_stats", True); single.set_option("collect_stats", True)
+    multi.render(11); single.render(11)
+    sm, ss = multi.stats(), single.stats()
+    assert sm.rays_traced == ss.rays_traced and sm.ao_rays_traced == ss.ao_rays_traced and sm.ao_hit_pixels == ss.ao_hit_pixels
+    multi.set_option("collect_stats", False)
+    # re-dealt by measured cost: another deal, the same bytes
+    multi.rebalance()
+    assert np.array_equal(multi.render(11), want)
+    if len(devices) > 1:
+        own2 = multi.deal()
+        assert not np.array_equal(own2, own) and set(own2.tolist()) == set(range(len(devices)))
+    # a sub-rectangle and the caller's own tile list
+    assert np.array_equal(multi.render(11, tile=(37, 21, 90, 70)), want[21:91, 37:127])
+    import torch
+    tiles = tiling.make_tiles(200, 136, 32)
+    out = torch.zeros((len(tiles), 32, 32, 4), dtype=torch.uint8, device="cuda")
+    multi.render_tiles_device(out.data_ptr(), tiles, 32, 32, mode=11)
+    multi.stats()                                   # synchronises the handle's stream
+    torch.cuda.synchronize()
+    assert np.array_equal(tiling.detile(out.cpu().numpy(), tiles, 200, 136, 32), want)
+    # PPLL and MLAT through the same handle; consecutive frames reuse the buffers
+    ppll = c.hip_context().render(2)
+    for _ in range(3):
+        assert np.array_equal(multi.render(2), ppll)
+    multi.close()
+
+
+@pytest.mark.gpu
+def test_multi_handle_forwards_setters_and_reports_rank_errors(hip_lib):
+    c = small_case(width=96, height=64)
+    multi = _setup(capi.Context(devices=[0, 0, 0], transport="memcpy"), c)
+    a = multi.render(11)
+    multi.set_option("line_width", 0.05)            # every rank rebuilds its LBVH
+    b = multi.render(11)
+    single = c.hip_context()
+    single.set_option("line_width", 0.05)
+    assert not np.array_equal(a, b) and np.array_equal(b, single.render(11))
+    with pytest.raises(capi.LineVisError):
+        multi.set_option("no_such_option", 1)
+    with pytest.raises(capi.LineVisError):
+        capi.Context(devices=[0, 0], transport="rccl")          # RCCL needs distinct devices
+    multi.close()

@@ -254,7 +254,7 @@ def test_hip_ppll_gather_shades_with_the_raster_variant(hip_lib, variant):
     on, os_, ocnt = sc.ppll_gather(P, ao=ao)
     pw, ph = c.padded()
     hn, hs, hcnt = ctx.ppll_buffers(pw * ph, int(P.ppllLinkedListSize))
-    assert hcnt == ocnt and hcnt > 3000
+    assert hcnt == ocnt and hcnt > 1000
     assert _lists(hn, hs) == _lists(on, os_)
     ref = sc.render_ppll(P, ao=ao)
     assert np.abs(img.astype(np.int32) - ref.astype(np.int32)).max() <= 2
