@@ -68,7 +68,7 @@ def build(force=False, verbose=False):
 HOST_DIR = os.path.join(HERE, "host")
 HOST_LIB = os.path.join(OUT_DIR, "liblinevis_host.so")
 HOST_SOURCES = ["LineData.cpp", "Tubes.cpp", "Flow.cpp", "LineRenderer.cpp", "HeadlessLineRenderer.cpp", "host_capi.cpp"]
-HOST_HEADERS = ["LvMath.hpp", "SettingsMap.hpp", "LineData.hpp", "Tubes.hpp", "Flow.hpp", "LineRenderer.hpp", "HeadlessLineRenderer.hpp"]
+HOST_HEADERS = ["LvMath.hpp", "SettingsMap.hpp", "InternalState.hpp", "LineData.hpp", "Tubes.hpp", "Flow.hpp", "LineRenderer.hpp", "HeadlessLineRenderer.hpp"]
 # -march=x86-64-v3: built in the CPU container, shipped to the GPU box; -ffp-contract=off: fixed float32 order
 HOST_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-shared", "-fopenmp", "-ffp-contract=off", "-fno-fast-math",
               "-march=x86-64-v3", "-Wall", "-Wextra", "-Wno-unused-parameter"]

@@ -174,9 +174,35 @@ LineRenderer::LineRenderer(std::string windowName, SceneData* sceneData, Transfe
 
 void LineRenderer::initialize() {
     int err = 0;
+    if (sceneData && !sceneData->deviceOrdinals.empty()) {
+        ctx = lv_create_multi(sceneData->deviceOrdinals.data(), int(sceneData->deviceOrdinals.size()),
+                              sceneData->multiGpuTransport.c_str(), &err);
+        if (!ctx) lastError = "lv_create_multi failed (a listed HIP device or the gather transport is not usable)";
+        return;
+    }
     ctx = lv_create(sceneData ? sceneData->deviceOrdinal : 0, &err);
     if (!ctx) lastError = "lv_create failed (no HIP device; there is no CPU fallback)";
 }
+
+int LineRenderer::tileWidth = 2;
+int LineRenderer::tileHeight = 8;
+bool LineRenderer::tilingModeDirty = false;
+
+// LineRenderer::setNewTilingMode, LineRenderer.cpp:739-812 (the Morton variant of TiledAddress.glsl is not built: the flag is
+// accepted and ignored, the row-major tile order is used)
+void LineRenderer::setNewTilingMode(int newTileWidth, int newTileHeight, bool) {
+    if (newTileWidth <= 0 || newTileHeight <= 0) return;
+    if (newTileWidth != tileWidth || newTileHeight != tileHeight) tilingModeDirty = true;
+    tileWidth = newTileWidth;
+    tileHeight = newTileHeight;
+}
+
+bool LineRenderer::rebalanceTiles(double baseCostPerTile) {
+    if (!ctx) return false;
+    return check(lv_multi_rebalance(ctx, baseCostPerTile), "lv_multi_rebalance");
+}
+
+int LineRenderer::getNumDevices() const { return ctx ? lv_multi_ranks(ctx) : 0; }
 
 LineRenderer::~LineRenderer() {
     if (ctx) lv_destroy(ctx);
@@ -469,6 +495,25 @@ bool HipRayTracer::setNewSettings(const SettingsMap& settings) {
     return shallReloadGatherShader;
 }
 
+// VulkanRayTracer::setNewState, VulkanRayTracer.cpp:280-330: the camelCase keys the canned benchmark states carry
+// (InternalState.cpp:276-297), translated to the settings keys of setNewSettings
+void HipRayTracer::setNewState(const InternalState& newState) {
+    const SettingsMap& rs = newState.rendererSettings;
+    SettingsMap m;
+    std::string geometryModeString;
+    bool useAnalyticIntersections = true, b = false;
+    uint32_t u = 0;
+    if (rs.getValueOpt("geometryMode", geometryModeString)) m.addKeyValue("geometry_mode", geometryModeString);
+    else if (rs.getValueOpt("useAnalyticIntersections", useAnalyticIntersections)) m.addKeyValue("use_analytic_intersections", useAnalyticIntersections);
+    if (rs.getValueOpt("numSamplesPerFrame", u)) m.addKeyValue("num_samples_per_frame", u);
+    if (rs.getValueOpt("maxNumAccumulatedFrames", u)) m.addKeyValue("num_accumulated_frames", u);
+    if (rs.getValueOpt("useDeterministicSampling", b)) m.addKeyValue("use_deterministic_sampling", b);
+    if (rs.getValueOpt("useMlat", b)) m.addKeyValue("use_mlat", b);
+    if (rs.getValueOpt("mlatNumNodes", u)) m.addKeyValue("mlat_num_nodes", u);
+    if (!m.isEmpty()) setNewSettings(m);
+    accumulatedFramesCounter = 0;
+}
+
 // ---------------------------------------------------------------- PPLL
 HipPerPixelLinkedListLineRenderer::HipPerPixelLinkedListLineRenderer(SceneData* sceneData, TransferFunctionWindow& tfw)
         : LineRenderer("Per-Pixel Linked List Renderer", sceneData, tfw) {
@@ -481,7 +526,17 @@ void HipPerPixelLinkedListLineRenderer::setLineData(LineDataPtr& newLineData, bo
     // segment count unless the ppll_* options override it.
 }
 
+// PerPixelLinkedListLineRenderer::setNewState, .cpp:98-107: remember the state's name, start fresh per-phase timers (the
+// reference creates a new sgl::vk::Timer for "PPLLClear" / "FCGather" / "PPLLResolve"; here: the context's per-kernel event rings)
+void HipPerPixelLinkedListLineRenderer::setNewState(const InternalState& newState) {
+    currentStateName = newState.name;
+    if (ctx) lv_reset_timers(ctx);
+}
+
 void HipPerPixelLinkedListLineRenderer::render() {
+    // LineRenderer::setNewTilingMode -> the addressing of the per-pixel lists
+    setOption("ppll_tile_width", std::to_string(tileWidth));
+    setOption("ppll_tile_height", std::to_string(tileHeight));
     LineRenderer::renderBase();
     renderMode(LV_RENDERING_MODE_PER_PIXEL_LINKED_LIST); // clear -> gather -> resolve
 }

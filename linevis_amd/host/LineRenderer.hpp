@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "../../include/linevis_hip.h"
+#include "InternalState.hpp"
 #include "LineData.hpp"
 #include "SettingsMap.hpp"
 
@@ -77,6 +78,11 @@ struct SceneData {
     Color* clearColor = nullptr;
     std::vector<uint8_t>* sceneTexture = nullptr; ///< RGBA8, viewportWidth * viewportHeight * 4, row 0 = top
     int deviceOrdinal = 0;
+    /// Several GPUs behind one renderer (lv_create_multi): when not empty the plugin drives one context per listed device, the
+    /// frame is sharded by screen tiles and gathered on the first device (transport "rccl" or "memcpy").  The reference is
+    /// single-GPU (sgl::AppSettings::getPrimaryDevice()); this is north_star's multi-GPU requirement behind the plugin surface.
+    std::vector<int> deviceOrdinals;
+    std::string multiGpuTransport = "rccl";
 };
 
 // ---------------------------------------------------------------- ambient occlusion
@@ -184,7 +190,16 @@ public:
     virtual void onClearColorChanged() {}
     virtual void onHasMoved();
     virtual void notifyReRenderTriggeredExternally() { internalReRender = false; }
+    /// LineRenderer.hpp:162 -- called by setNewState of the application before setNewSettings(newState.rendererSettings)
+    virtual void setNewState(const InternalState& newState) { (void)newState; }
     virtual bool setNewSettings(const SettingsMap& settings);
+    /// LineRenderer::setNewTilingMode (LineRenderer.cpp:739-812): the pixel addressing of the per-pixel lists
+    static void setNewTilingMode(int newTileWidth, int newTileHeight, bool useMortonCode = false);
+    static int getTilingWidth() { return tileWidth; }
+    static int getTilingHeight() { return tileHeight; }
+    /// multi-GPU renderer: re-deal the screen tiles by the cost measured in the last frame (lv_multi_rebalance)
+    bool rebalanceTiles(double baseCostPerTile = 4.0 * 64 * 64);
+    int getNumDevices() const;
     virtual void onTransferFunctionMapRebuilt() { tfDirty = true; reRender = true; }
 
     SceneData* getSceneData() { return sceneData; }
@@ -229,6 +244,8 @@ protected:
 
     static float lineWidth; // LineRenderer.hpp:266-269 (static: shared by all renderers, as in the reference)
     static float bandWidth;
+    static int tileWidth, tileHeight; // LineRenderer.cpp:739-740 (2 x 8)
+    static bool tilingModeDirty;
 };
 
 /// "Vulkan Ray Tracer" plugin re-hosted on HIP: the reference's three geometry modes (analytic AABBs -- the default here, the
@@ -244,6 +261,8 @@ public:
     void setLineData(LineDataPtr& lineData, bool isNewData) override;
     void render() override;
     void onHasMoved() override;
+    /// VulkanRayTracer::setNewState (VulkanRayTracer.cpp:280-330): camelCase keys of the canned benchmark states
+    void setNewState(const InternalState& newState) override;
     bool setNewSettings(const SettingsMap& settings) override;
 
 private:
@@ -265,11 +284,17 @@ public:
     RenderingMode getRenderingMode() const override { return RENDERING_MODE_PER_PIXEL_LINKED_LIST; }
     void setLineData(LineDataPtr& lineData, bool isNewData) override;
     void render() override;
+    /// PerPixelLinkedListLineRenderer::setNewState (.cpp:98-107): a new state starts new per-phase timers
+    void setNewState(const InternalState& newState) override;
+    const std::string& getCurrentStateName() const { return currentStateName; }
     bool setNewSettings(const SettingsMap& settings) override;
     /// band data: the rasterisers always draw the elliptic tubes of the ribbon primitive mode (LineDataFlow.cpp:476-481)
     bool getUseAnalyticEllipticTubes() const override { return true; }
     /// computeStatistics (PerPixelLinkedListLineRenderer.cpp:578-663): fragments, max depth complexity
     void computeStatistics(uint64_t& totalNumFragments, uint32_t& maxComplexity);
+
+private:
+    std::string currentStateName;
 };
 
 } // namespace lv

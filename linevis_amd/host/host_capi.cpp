@@ -346,6 +346,45 @@ void* lvh_renderer_create(int renderingMode, int deviceOrdinal) {
     if (!r->isValid()) { delete r; return nullptr; }
     return r;
 }
+// several GPUs behind the plugin (SceneData::deviceOrdinals -> lv_create_multi); transport "rccl" | "memcpy"
+void* lvh_renderer_create_multi(int renderingMode, const int* deviceOrdinals, int numDevices, const char* transport) {
+    if (!deviceOrdinals || numDevices <= 0) return nullptr;
+    HeadlessLineRenderer* r = new HeadlessLineRenderer(RenderingMode(renderingMode), std::vector<int>(deviceOrdinals, deviceOrdinals + numDevices),
+                                                       transport ? transport : "rccl");
+    if (!r->isValid()) { delete r; return nullptr; }
+    return r;
+}
+int lvh_renderer_num_devices(void* r) { return static_cast<HeadlessLineRenderer*>(r)->getLineRenderer()->getNumDevices(); }
+int lvh_renderer_rebalance(void* r, double baseCostPerTile) {
+    return static_cast<HeadlessLineRenderer*>(r)->getLineRenderer()->rebalanceTiles(baseCostPerTile) ? 0 : -1;
+}
+// MainApp::setNewState for the harness: one InternalState (renderer settings carry the camelCase keys of the canned states)
+void lvh_renderer_set_state(void* r, const char* name, int renderingMode, const char* const* rendererKeys, const char* const* rendererValues,
+                            uint32_t numRenderer, const char* const* dataSetKeys, const char* const* dataSetValues, uint32_t numDataSet,
+                            int tilingWidth, int tilingHeight, int resolutionX, int resolutionY) {
+    InternalState st;
+    st.name = st.nameRaw = name ? name : "";
+    st.renderingMode = renderingMode;
+    for (uint32_t i = 0; i < numRenderer; i++) st.rendererSettings.addKeyValue(std::string(rendererKeys[i]), rendererValues[i]);
+    for (uint32_t i = 0; i < numDataSet; i++) st.dataSetSettings.addKeyValue(std::string(dataSetKeys[i]), dataSetValues[i]);
+    st.tilingWidth = tilingWidth;
+    st.tilingHeight = tilingHeight;
+    st.windowResolution[0] = resolutionX;
+    st.windowResolution[1] = resolutionY;
+    static_cast<HeadlessLineRenderer*>(r)->setNewState(st);
+}
+// the canned benchmark states (getTestModes): count, then per state "name\nmode\nresX\nresY\nkey=value\n..." into buf
+uint32_t lvh_test_modes_count(int twice) { return uint32_t(getTestModes(twice != 0).size()); }
+uint32_t lvh_test_mode(int twice, uint32_t index, char* buf, uint32_t capacity) {
+    const std::vector<InternalState> states = getTestModes(twice != 0);
+    if (index >= states.size()) return 0;
+    const InternalState& s = states[index];
+    std::string out = s.name + "\n" + std::to_string(s.renderingMode) + "\n" + std::to_string(s.windowResolution[0]) + "\n" +
+                      std::to_string(s.windowResolution[1]) + "\n";
+    for (const auto& kv : s.rendererSettings.getMap()) out += kv.first + "=" + kv.second + "\n";
+    if (buf && capacity > out.size()) memcpy(buf, out.c_str(), out.size() + 1);
+    return uint32_t(out.size());
+}
 void lvh_renderer_destroy(void* r) { delete static_cast<HeadlessLineRenderer*>(r); }
 void lvh_renderer_set_resolution(void* r, uint32_t w, uint32_t h) { static_cast<HeadlessLineRenderer*>(r)->setRenderingResolution(w, h); }
 void lvh_renderer_set_line_data(void* r, void* flow, int isNewData) {

@@ -68,6 +68,12 @@ def load():
         "lvh_grid_scalar_field_name": (i32, [vp, i32, vp, u32]),
         "lvh_grid_last_error": (cp, [vp]),
         "lvh_renderer_create": (vp, [i32, i32]),
+        "lvh_renderer_create_multi": (vp, [i32, vp, i32, cp]),
+        "lvh_renderer_num_devices": (i32, [vp]),
+        "lvh_renderer_rebalance": (i32, [vp, C.c_double]),
+        "lvh_renderer_set_state": (None, [vp, cp, i32, C.POINTER(cp), C.POINTER(cp), u32, C.POINTER(cp), C.POINTER(cp), u32, i32, i32, i32, i32]),
+        "lvh_test_modes_count": (u32, [i32]),
+        "lvh_test_mode": (u32, [i32, u32, vp, u32]),
         "lvh_renderer_destroy": (None, [vp]),
         "lvh_renderer_set_resolution": (None, [vp, u32, u32]),
         "lvh_renderer_set_line_data": (None, [vp, vp, i32]),
@@ -384,12 +390,32 @@ def _trace_streamribbons(self, seeds, method="Runge-Kutta 4th Order", direction=
 StreamlineTracingGrid.trace_streamribbons = _trace_streamribbons
 
 
+def get_test_modes(twice=True):
+    """The canned benchmark states of the hot path (lv::getTestModes = InternalState.cpp:46-51,276-297,187-197):
+    [(name, rendering_mode, (res_x, res_y), {renderer setting: value})]."""
+    L = load()
+    out = []
+    for i in range(L.lvh_test_modes_count(int(twice))):
+        n = L.lvh_test_mode(int(twice), i, None, 0)
+        buf = C.create_string_buffer(n + 1)
+        L.lvh_test_mode(int(twice), i, buf, n + 1)
+        lines = buf.value.decode().split("\n")
+        settings = dict(l.split("=", 1) for l in lines[4:] if "=" in l)
+        out.append((lines[0], int(lines[1]), (int(lines[2]), int(lines[3])), settings))
+    return out
+
+
 class HeadlessLineRenderer:
     """lv::HeadlessLineRenderer: fixed-camera harness around one renderer plugin (mode 11 or 2)."""
 
-    def __init__(self, mode=capi.MODE_RAY_TRACER, device=0):
+    def __init__(self, mode=capi.MODE_RAY_TRACER, device=0, devices=None, transport="rccl"):
+        """devices = [d0, d1, ...]: the plugin drives one context per device (SceneData::deviceOrdinals -> lv_create_multi)."""
         self.L = load()
-        self.h = self.L.lvh_renderer_create(int(mode), int(device))
+        if devices is not None:
+            devs = np.ascontiguousarray(devices, dtype=np.int32)
+            self.h = self.L.lvh_renderer_create_multi(int(mode), _p(devs), len(devs), transport.encode())
+        else:
+            self.h = self.L.lvh_renderer_create(int(mode), int(device))
         if not self.h:
             raise capi.LineVisError(capi.LV_OK - 2, "no usable HIP device (there is no CPU fallback)")
         self.width = self.height = 128
@@ -406,6 +432,29 @@ class HeadlessLineRenderer:
     def set_rendering_resolution(self, w, h):
         self.width, self.height = int(w), int(h)
         self.L.lvh_renderer_set_resolution(self.h, self.width, self.height)
+
+    @property
+    def num_devices(self):
+        return int(self.L.lvh_renderer_num_devices(self.h))
+
+    def rebalance(self, base_cost_per_tile=4.0 * 64 * 64):
+        if self.L.lvh_renderer_rebalance(self.h, float(base_cost_per_tile)) != 0:
+            raise capi.LineVisError(-1, "lv_multi_rebalance failed")
+
+    def set_new_state(self, name, rendering_mode, renderer_settings=None, data_set_settings=None, tiling=(2, 8), resolution=(0, 0)):
+        """MainApp::setNewState for the harness (lv::HeadlessLineRenderer::setNewState): renderer_settings carry the camelCase keys
+        of the canned states (VulkanRayTracer::setNewState) and / or the snake_case keys of setNewSettings."""
+        def arrays(d):
+            d = d or {}
+            ks = [str(k).encode() for k in d]
+            vs = [capi._fmt(v).encode() for v in d.values()]
+            return (C.c_char_p * max(len(ks), 1))(*ks), (C.c_char_p * max(len(vs), 1))(*vs), len(ks)
+        rk, rv, rn = arrays(renderer_settings)
+        dk, dv, dn = arrays(data_set_settings)
+        self.L.lvh_renderer_set_state(self.h, str(name).encode(), int(rendering_mode), rk, rv, rn, dk, dv, dn, int(tiling[0]),
+                                      int(tiling[1]), int(resolution[0]), int(resolution[1]))
+        if resolution[0] > 0 and resolution[1] > 0:
+            self.width, self.height = int(resolution[0]), int(resolution[1])
 
     def set_line_data(self, flow, is_new_data=True):
         self._keep = [flow]

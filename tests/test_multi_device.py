@@ -106,3 +106,81 @@ def test_multi_handle_forwards_setters_and_reports_rank_errors(hip_lib):
     with pytest.raises(capi.LineVisError):
         capi.Context(devices=[0, 0], transport="rccl")          # RCCL needs distinct devices
     multi.close()
+
+
+def test_canned_benchmark_states_table():
+    """lv::getTestModes: the hot-path subset of the reference's --perf states (InternalState.cpp:46-51,276-297), every state twice."""
+    from linevis_amd import host_api
+    m = host_api.get_test_modes()
+    assert [s[0] for s in m] == ["PPLL", "PPLL(2)", "VRT Analytic", "VRT Analytic(2)", "VRT Triangle Mesh", "VRT Triangle Mesh(2)"]
+    assert [s[1] for s in m] == [2, 2, 11, 11, 11, 11] and all(s[2] == (1920, 1080) for s in m)
+    assert m[0][3] == {} and m[4][3] == {"useAnalyticIntersections": "false", "numSamplesPerFrame": "1"}
+    assert len(host_api.get_test_modes(twice=False)) == 3
+
+
+@pytest.mark.gpu
+def test_plugin_walks_the_canned_states_like_the_perf_harness(hip_lib):
+    """AutomaticPerformanceMeasurer's loop on the headless harness: setNewState per canned state (mode switch PPLL <-> ray tracer,
+    camelCase renderer keys, tiling mode), each frame equal to a context driven through the C-ABI directly."""
+    from linevis_amd import host_api, scenes, transfer_function as tfm
+    from oracle import lvo
+    tr = scenes.normalize(scenes.random_curves(n_lines=25, points_per_line=30, seed=5))
+    lw = 0.02
+    flow = host_api.LineDataFlow().set_trajectories(tr.positions, tr.attributes, tr.line_offsets)
+    r = host_api.HeadlessLineRenderer(capi.MODE_RAY_TRACER)
+    r.set_rendering_resolution(64, 48)
+    r.set_transfer_function(tfm.standard_transparent())
+    r.set_line_data(flow)
+    r.set_new_settings(dict(line_width=lw))
+    pts, seg, _ = flow.tube_aabb_render_data(lw)
+    mesh = flow.tube_triangle_render_data(lw, 6)
+    lo, hi = flow.attribute_range()
+    frames = {}
+    for name, mode, res, settings in host_api.get_test_modes():
+        r.set_new_state(name, mode, settings, resolution=(160, 96))
+        assert r.rendering_mode == mode
+        img = r.render_frame()
+        assert img.shape == (96, 160, 4)
+        frames[name] = img
+        view, proj, fovy, near, far = r.camera()
+        ctx = capi.Context(0)
+        ctx.set_lines(pts, seg)
+        ctx.set_transfer_function(tfm.standard_transparent(), lo, hi)
+        ctx.set_camera(view, proj, fovy, near, far, 160, 96)
+        ctx.set_option("line_width", lw)
+        if mode == 11:
+            ctx.set_option("num_samples_per_frame", int(settings["numSamplesPerFrame"]))
+            ctx.set_option("use_analytic_intersections", settings["useAnalyticIntersections"])
+            ctx.set_tube_triangle_mesh(*mesh)
+        else:
+            ctx.set_option("use_capped_tubes", False)      # rasterisers: no caps in the programmable-pull mode (LineData.cpp:1240-1244)
+        assert np.array_equal(ctx.render(mode), img), name
+    assert np.array_equal(frames["PPLL"], frames["PPLL(2)"]) and np.array_equal(frames["VRT Analytic"], frames["VRT Analytic(2)"])
+    assert not np.array_equal(frames["VRT Analytic"], frames["VRT Triangle Mesh"])
+    # tiling mode of the state reaches the per-pixel lists (same picture, other addressing)
+    r.set_new_state("PPLL 1x1", 2, {}, tiling=(1, 1))
+    assert np.array_equal(r.render_frame(), frames["PPLL"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("devices,transport", [([0], "rccl"), ([0, 0, 0], "memcpy")])
+def test_plugin_on_several_devices(hip_lib, devices, transport):
+    """SceneData::deviceOrdinals: the same plugin classes drive one context per device; frame = the single-device frame."""
+    from linevis_amd import host_api, scenes, transfer_function as tfm
+    tr = scenes.normalize(scenes.random_curves(n_lines=25, points_per_line=30, seed=5))
+    flow = host_api.LineDataFlow().set_trajectories(tr.positions, tr.attributes, tr.line_offsets)
+    settings = dict(line_width=0.02, ambient_occlusion_mode="RTAO (Screen Space)", ambient_occlusion_strength=1.0,
+                    ambient_occlusion_iterations=2, ambient_occlusion_samples_per_frame=4)
+    imgs = []
+    for kw in (dict(device=0), dict(devices=devices, transport=transport)):
+        r = host_api.HeadlessLineRenderer(capi.MODE_RAY_TRACER, **kw)
+        r.set_rendering_resolution(200, 136)
+        r.set_transfer_function(tfm.standard())
+        r.set_line_data(flow)
+        r.set_new_settings(settings)
+        imgs.append(r.render_frame())
+        if "devices" in kw:
+            assert r.num_devices == len(devices)
+            r.rebalance()
+            assert np.array_equal(r.render_frame(), imgs[0])
+    assert np.array_equal(imgs[0], imgs[1]) and (imgs[0][..., :3] != 255).any()
