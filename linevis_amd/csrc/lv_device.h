@@ -293,6 +293,37 @@ __device__ __forceinline__ float lv_atan2_det(float y, float x) {
     return r;
 }
 
+// pow(x, y) of the shading code (Lighting.glsl:158-167,136-146 pow(|n.l|, 1.7), pow(|n.h|, 30); AmbientOcclusion.glsl:93 pow(ao, gamma);
+// MlatInsert.glsl pow(transmittance, d)) as a BUILD-OWNED float32 definition: exp2(y * log2(x)) -- the form GLSL itself derives
+// pow's precision from -- with log2 through the exponent bits + an atanh series on [sqrt(1/2), sqrt(2)] and exp2 through a 7th-order
+// series on [-1/2, 1/2], every operation in a fixed order: bit-identical on host and device (frames and PPLL fragment colours then
+// compare byte for byte instead of within the slack two different libm implementations need), relative error < 3e-6 wherever the
+// result exceeds 1e-4 (tests/test_oracle.py), and about a third of the instructions of the correctly rounded library powf.
+// x >= 0 (GLSL: undefined for x < 0); x == 0 -> 0 for y > 0, 1 for y == 0.
+__device__ __forceinline__ float lv_pow_det(float x, float y) {
+    if (!(x > 1.17549435e-38f)) return y > 0.0f ? 0.0f : (y == 0.0f ? 1.0f : __builtin_inff());
+    const uint32_t bits = __float_as_uint(x);
+    int e = int((bits >> 23) & 0xFFu) - 127;
+    float m = __uint_as_float((bits & 0x007FFFFFu) | 0x3F800000u); // [1, 2)
+    if (m > 1.41421356f) { m = m * 0.5f; e = e + 1; }               // [sqrt(1/2), sqrt(2)]
+    const float f = m - 1.0f;
+    const float s = f / (2.0f + f);
+    const float z = s * s;
+    const float P = 0.333333333f + z * (0.2f + z * (0.142857143f + z * 0.111111111f));
+    const float ln = 2.0f * s + (2.0f * s) * (z * P);              // ln(m) = 2 atanh(s)
+    const float L = float(e) + ln * 1.44269504f;                   // log2(x)
+    const float p = y * L;
+    if (p < -125.0f) return 0.0f;
+    if (p > 127.0f) return __builtin_inff();
+    const float n = floorf(p + 0.5f);
+    const float t = (p - n) * 0.693147181f;                        // |t| <= 0.3466
+    const float Q = 1.0f + t * (1.0f + t * (0.5f + t * (0.166666667f + t * (0.0416666667f + t * (0.00833333333f + t * (0.00138888889f + t * 0.000198412698f))))));
+    return __uint_as_float(__float_as_uint(Q) + (uint32_t(int(n)) << 23)); // Q * 2^n (Q in [0.70, 1.42], n >= -125: normal)
+}
+// normalize(v) of the shading code as v * (1 / length(v)): one IEEE division instead of three (GLSL does not say how normalize
+// divides; the twelve normalisations of computeFragmentColor + blinnPhongShadingTube were a third of the shading instructions)
+__device__ __forceinline__ f3 norm3s(f3 a) { const float r = 1.0f / len3(a); return mk3(a.x * r, a.y * r, a.z * r); }
+
 // ---------------------------------------------------------------- wave helpers (wave64)
 __device__ __forceinline__ unsigned lv_lane() { return __lane_id(); }
 __device__ __forceinline__ unsigned long long lv_wave_sum_u64(unsigned long long v) {

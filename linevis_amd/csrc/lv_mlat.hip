@@ -58,7 +58,7 @@ __device__ __forceinline__ bool lv_mlat_insert(float (&c)[K][4], float (&T)[K], 
         if (bD < depth2 && !isFirst) {
             float d = (bD - nD);
             d /= (depth2 - nD);
-            const float aPowD = powf(nT, d);
+            const float aPowD = lv_pow_det(nT, d);
             fa = (aPowD - 1.0f);
             fa += (nT - aPowD) * bT;
             fa /= (nT - 1.0f);

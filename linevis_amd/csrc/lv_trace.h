@@ -1424,11 +1424,11 @@ __device__ __forceinline__ f4 lv_compute_fragment_color_t(const LvSceneDev& S, c
                                                           float fragmentAttribute, float& payloadHitT, const LvBandArgs& bands) {
     const f3 cam = mk3(U.camPos[0], U.camPos[1], U.camPos[2]);
     f4 fragmentColor = lv_transfer_function(S, U, fragmentAttribute);
-    f3 n = norm3(fragmentNormal);
-    f3 vv = norm3(cam - fragPos);
-    f3 t = norm3(fragmentTangent);
-    f3 helperVec = norm3(cross3(t, vv));
-    f3 newV = norm3(cross3(helperVec, t));
+    f3 n = norm3s(fragmentNormal);
+    f3 vv = norm3s(cam - fragPos);
+    f3 t = norm3s(fragmentTangent);
+    f3 helperVec = norm3s(cross3(t, vv));
+    f3 newV = norm3s(cross3(helperVec, t));
 
     float ribbonPosition = 0.0f;
     if (U.useHalos) {
@@ -1483,7 +1483,7 @@ __device__ __forceinline__ f4 lv_compute_fragment_color_t(const LvSceneDev& S, c
             const float bot = S.ao[size_t(yb) * U.width + xa] * (1.0f - wx) + S.ao[size_t(yb) * U.width + xb] * wx;
             aoTexel = top * (1.0f - wy) + bot * wy;
         }
-        float a = powf(aoTexel, U.aoGamma);
+        float a = lv_pow_det(aoTexel, U.aoGamma);
         aoF = fmaxf(0.0f, (1.0f - U.aoStrength) + U.aoStrength * a);
         kA = 0.2f + (1.0f - aoF) * 0.5f;
         kD = 0.9f * aoF;
@@ -1492,17 +1492,17 @@ __device__ __forceinline__ f4 lv_compute_fragment_color_t(const LvSceneDev& S, c
         kD = 0.9f;
     }
     // blinnPhongShadingTube re-normalises its (already unit) arguments, Lighting.glsl:149-151
-    const f3 nB = norm3(n);
-    const f3 tB = norm3(t);
+    const f3 nB = norm3s(n);
+    const f3 tB = norm3s(t);
     f3 l = vv;
-    f3 hh = norm3(vv + l);
-    f3 helperVecL = norm3(cross3(tB, l));
-    f3 newL = norm3(cross3(helperVecL, tB));
+    f3 hh = norm3s(vv + l);
+    f3 helperVecL = norm3s(cross3(tB, l));
+    f3 newL = norm3s(cross3(helperVecL, tB));
     const float exponent = (BANDS == LV_SHADE_BANDS && bands.useBand) ? 1.0f : 1.7f; // Lighting.glsl:158-162
-    float cosNormal1 = powf(clampf(fabsf(dot3(nB, l)), 0.0f, 1.0f), exponent);
-    float cosNormal2 = powf(clampf(fabsf(dot3(nB, newL)), 0.0f, 1.0f), exponent);
+    float cosNormal1 = lv_pow_det(clampf(fabsf(dot3(nB, l)), 0.0f, 1.0f), exponent);
+    float cosNormal2 = lv_pow_det(clampf(fabsf(dot3(nB, newL)), 0.0f, 1.0f), exponent);
     float cosNormalCombined = 0.3f * cosNormal1 + 0.7f * cosNormal2;
-    float spec = kS * powf(clampf(fabsf(dot3(nB, hh)), 0.0f, 1.0f), s);
+    float spec = kS * lv_pow_det(clampf(fabsf(dot3(nB, hh)), 0.0f, 1.0f), s);
     float base[3] = {fragmentColor.x, fragmentColor.y, fragmentColor.z};
     float phong[3];
 #pragma unroll

@@ -567,7 +567,7 @@ inline float getAoFactor(const lvo_params& P, float aoTexel, V3 ssp) {
         const float bot = A[size_t(yb) * P.width + xa] * (1.0f - wx) + A[size_t(yb) * P.width + xb] * wx;
         aoTexel = top * (1.0f - wy) + bot * wy;
     }
-    float aoFactor = powf(aoTexel, P.aoGamma);
+    float aoFactor = powDet(aoTexel, P.aoGamma);
     return fmaxf(0.0f, (1.0f - P.aoStrength) + P.aoStrength * aoFactor);
 }
 
@@ -585,18 +585,18 @@ inline void blinnPhongShadingTube(const lvo_params& P, const Frame& F, float aoT
         kA = 0.1f;
         kD = 0.9f;
     }
-    V3 n = normalize(fragmentNormal);
-    V3 t = normalize(fragmentTangent);
-    V3 v = normalize(F.cameraPosition - fragPos);
+    V3 n = normalizeShade(fragmentNormal);
+    V3 t = normalizeShade(fragmentTangent);
+    V3 v = normalizeShade(F.cameraPosition - fragPos);
     V3 l = v;
-    V3 h = normalize(v + l);
-    V3 helperVec = normalize(cross(t, l));
-    V3 newL = normalize(cross(helperVec, t));
+    V3 h = normalizeShade(v + l);
+    V3 helperVec = normalizeShade(cross(t, l));
+    V3 newL = normalizeShade(cross(helperVec, t));
     // exponent: 1.7, or 1.0 on bands (USE_BANDS && useBand, Lighting.glsl:158-162)
-    float cosNormal1 = powf(clampf(fabsf(dot(n, l)), 0.0f, 1.0f), exponent);
-    float cosNormal2 = powf(clampf(fabsf(dot(n, newL)), 0.0f, 1.0f), exponent);
+    float cosNormal1 = powDet(clampf(fabsf(dot(n, l)), 0.0f, 1.0f), exponent);
+    float cosNormal2 = powDet(clampf(fabsf(dot(n, newL)), 0.0f, 1.0f), exponent);
     float cosNormalCombined = 0.3f * cosNormal1 + 0.7f * cosNormal2;
-    float spec = kS * powf(clampf(fabsf(dot(n, h)), 0.0f, 1.0f), s);
+    float spec = kS * powDet(clampf(fabsf(dot(n, h)), 0.0f, 1.0f), s);
     float phong[3];
     for (int k = 0; k < 3; k++) {
         float Ia = kA * base[k];
@@ -943,11 +943,11 @@ inline void computeFragmentColor(const lvo_scene& sc, const lvo_params& P, const
     const float rasterEpsWhite = bandsIn ? bandsIn->rasterEpsWhite : -1.0f;         // >= 0: raster variant of the outline
     float fragmentColor[4];
     transferFunction(sc, P, fragmentAttribute, fragmentColor);
-    V3 n = normalize(fragmentNormal);
-    V3 vv = normalize(F.cameraPosition - fragPos);
-    V3 t = normalize(fragmentTangent);
-    V3 helperVec = normalize(cross(t, vv));
-    V3 newV = normalize(cross(helperVec, t));
+    V3 n = normalizeShade(fragmentNormal);
+    V3 vv = normalizeShade(F.cameraPosition - fragPos);
+    V3 t = normalizeShade(fragmentTangent);
+    V3 helperVec = normalizeShade(cross(t, vv));
+    V3 newV = normalizeShade(cross(helperVec, t));
 
     float ribbonPosition = 0.0f;
     if (P.useHalos) {
@@ -1702,7 +1702,7 @@ static MlatNode mlatMerge(const MlatNode& a, const MlatNode& b, float& depth2, b
     if (b.depth < depth2 && !isFirst) { // node b lies inside the span node a already covers
         float d = (b.depth - a.depth);
         d /= (depth2 - a.depth);
-        float a_pow_d = powf(a.transmittance, d);
+        float a_pow_d = powDet(a.transmittance, d);
         fa = (a_pow_d - 1.0f);
         fa += (a.transmittance - a_pow_d) * b.transmittance;
         fa /= (a.transmittance - 1.0f);
@@ -2257,6 +2257,9 @@ void lvo_ribbon_of_rays(const float* cam, const float* dirs, uint64_t n, const f
     for (uint64_t i = 0; i < n; i++)
         out[i] = capHit ? capRibbonOfRay(ld3(cam), ld3(dirs + 3 * i), ld3(capHit), ld3(capNormal), ld3(axisPoint), ld3(axisDir))
                         : tubeRibbonOfRay(ld3(cam), ld3(dirs + 3 * i), ld3(axisPoint), ld3(axisDir), radius);
+}
+void lvo_pow_det(const float* x, const float* y, uint64_t n, float* out) {
+    for (uint64_t i = 0; i < n; i++) out[i] = powDet(x[i], y[i]);
 }
 void lvo_set_ppll_fragment_colour_variant(int rayTracerVariant) { g_rtFragmentColourInPpll = rayTracerVariant != 0; }
 

@@ -373,6 +373,8 @@ void lvo_set_deviation_switches(int literalIntersection, int referenceAoLookup);
 /* 1: shade PPLL fragments with the ray tracer's computeFragmentColor (RayHitCommon.glsl; rounds 1-2), 0 (default): with the raster
  * tube shader's variant (LinePassGeometryShaderTubes.glsl:785-815,1079-1087) */
 void lvo_set_ppll_fragment_colour_variant(int rayTracerVariant);
+/* the build-owned pow of the shading code (powDet = lv_pow_det of the HIP library) on n inputs */
+void lvo_pow_det(const float* x, const float* y, uint64_t n, float* out);
 void lvo_compute_fragment_color_raster_batch(const lvo_scene* sc, const lvo_params* P, uint64_t n, const float* fragPos,
                                              const float* normal, const float* tangent, const uint32_t* isCap, const float* attribute,
                                              const float* aoTexel, const float* epsWhite, float* outColor, float* outHitT);

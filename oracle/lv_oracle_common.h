@@ -42,6 +42,35 @@ inline V3 cross(V3 a, V3 b) { return V3{a.y * b.z - b.y * a.z, a.z * b.x - b.z *
 inline float length(V3 a) { return sqrtf(dot(a, a)); }
 inline V3 normalize(V3 a) { float l = length(a); return V3{a.x / l, a.y / l, a.z / l}; }
 inline float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+// pow(x, y) of the shading code as a build-owned float32 definition, bit-identical to lv_pow_det of the HIP library
+// (linevis_amd/csrc/lv_device.h): exp2(y * log2(x)), log2 through the exponent bits + an atanh series, exp2 through a 7th-order series.
+inline float powDet(float x, float y) {
+    if (!(x > 1.17549435e-38f)) return y > 0.0f ? 0.0f : (y == 0.0f ? 1.0f : INFINITY);
+    uint32_t bits; memcpy(&bits, &x, 4);
+    int e = int((bits >> 23) & 0xFFu) - 127;
+    uint32_t mb = (bits & 0x007FFFFFu) | 0x3F800000u;
+    float m; memcpy(&m, &mb, 4);
+    if (m > 1.41421356f) { m = m * 0.5f; e = e + 1; }
+    const float f = m - 1.0f;
+    const float s = f / (2.0f + f);
+    const float z = s * s;
+    const float P = 0.333333333f + z * (0.2f + z * (0.142857143f + z * 0.111111111f));
+    const float ln = 2.0f * s + (2.0f * s) * (z * P);
+    const float L = float(e) + ln * 1.44269504f;
+    const float p = y * L;
+    if (p < -125.0f) return 0.0f;
+    if (p > 127.0f) return INFINITY;
+    const float n = floorf(p + 0.5f);
+    const float t = (p - n) * 0.693147181f;
+    const float Q = 1.0f + t * (1.0f + t * (0.5f + t * (0.166666667f + t * (0.0416666667f + t * (0.00833333333f + t * (0.00138888889f + t * 0.000198412698f))))));
+    uint32_t qb; memcpy(&qb, &Q, 4);
+    qb += uint32_t(int(n)) << 23;
+    float r; memcpy(&r, &qb, 4);
+    return r;
+}
+// normalize(v) of the shading code as v * (1 / length(v)) (norm3s of the HIP library)
+inline V3 normalizeShade(V3 a) { const float r = 1.0f / length(a); return V3{a.x * r, a.y * r, a.z * r}; }
+
 inline float mixf(float a, float b, float w) { return a * (1.0f - w) + b * w; }
 inline float smoothstepf(float e0, float e1, float x) {
     float t = clampf((x - e0) / (e1 - e0), 0.0f, 1.0f);

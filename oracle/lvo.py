@@ -111,6 +111,7 @@ def lib():
     L.lvo_compute_fragment_color_raster_batch.argtypes = [vp, vp, C.c_uint64] + [vp] * 9
     L.lvo_ribbon_of_rays.argtypes = [vp, vp, C.c_uint64, vp, vp, f32, vp, vp, vp]
     L.lvo_set_ppll_fragment_colour_variant.argtypes = [i32]
+    L.lvo_pow_det.argtypes = [vp, vp, C.c_uint64, vp]
     L.lvo_num_threads.restype = i32
     L.lvo_num_threads.argtypes = []
     L.lvo_tea.restype = u32
@@ -751,6 +752,15 @@ def set_num_threads(n):
 def num_threads():
     """Threads the oracle's OpenMP loops run on."""
     return int(lib().lvo_num_threads())
+
+
+def pow_det(x, y):
+    """The build-owned pow of the shading code (bit-identical to lv_pow_det of the HIP library)."""
+    xx = np.ascontiguousarray(np.broadcast_to(np.asarray(x, dtype=np.float32), np.broadcast(x, y).shape), dtype=np.float32).reshape(-1)
+    yy = np.ascontiguousarray(np.broadcast_to(np.asarray(y, dtype=np.float32), np.broadcast(x, y).shape), dtype=np.float32).reshape(-1)
+    out = np.empty(len(xx), dtype=np.float32)
+    lib().lvo_pow_det(_p(xx), _p(yy), len(xx), _p(out))
+    return out
 
 
 def ribbon_of_rays(cam, dirs, axis_point, axis_dir, radius, cap_hit=None, cap_normal=None):
