@@ -74,9 +74,12 @@ WORKLOADS = {
                 settings={"num_samples_per_frame": 1, "depth_cue_strength": 0.0, "use_ribbons": True,
                           "use_analytic_elliptic_tubes": True, "band_width": 0.005, "min_band_thickness": 0.15}),
     "c4": dict(name="C4: 1M-segment tornado-style streamlines, 1920x1080, PPLL OIT: all-hits gather + per-pixel 4-ary heap "
-                    "resolve, MAX_NUM_FRAGS 64, node pool 20/pixel, tiling 2x8, opacity ramp 0.1..0.6",
+                    "resolve, MAX_NUM_FRAGS 64, node pool 20/pixel, tiling 2x8, opacity ramp 0.1..0.6, uncapped tubes (the rasterisers' "
+                    "default programmable-pull mode defines no USE_CAPPED_TUBES, LineData.cpp:1240-1244), fragment colour of the raster "
+                    "tube shader (ppll_fragment_colour=raster)",
                scene="tornado", mode=2, settings={"ppll_max_num_frags": 64, "ppll_expected_avg_depth_complexity": 20,
-                                                  "depth_cue_strength": 0.0}, kernel="k_ppll_gather", transparent=True),
+                                                  "depth_cue_strength": 0.0, "use_capped_tubes": False},
+               kernel="k_ppll_gather", transparent=True),
     "c4m": dict(name="C4 scene (1M-segment tornado, 1920x1080, opacity ramp 0.1..0.6) through the ray tracer with multi-layer "
                      "alpha tracing, 8 nodes (use_mlat): single pass, approximate OIT",
                 scene="tornado", mode=11, settings={"use_mlat": True, "mlat_num_nodes": 8, "depth_cue_strength": 0.0,
@@ -102,7 +105,7 @@ def host_cores():
 
 
 def cpu_baseline(W, H, pts, seg, tf, attr_range, view, proj, fovy, near, far, target_seconds=15.0, workload="c3c", mesh=None,
-                 ao_spp=64):
+                 ao_spp=64, capped=True):
     """CPU restatement of the LineVis GLSL path (the oracle, NOT LineVis's own binary): 16x16-pixel tiles handed out dynamically
     over the usable host cores (OpenMP), on a centred crop of the same frame sized for ~target_seconds of work."""
     from oracle import lvo
@@ -113,7 +116,7 @@ def cpu_baseline(W, H, pts, seg, tf, attr_range, view, proj, fovy, near, far, ta
     P = lvo.make_params(view, proj, W, H, fovY=fovy, nearDist=near, farDist=far, lineWidth=LINE_WIDTH,
                         useAmbientOcclusion=int(rtao), aoStrength=1.0, aoGamma=1.0, aoSamplesPerFrame=ao_spp,
                         aoIterations=1, aoUseDistance=1, aoJitterPrimary=1, aoRadius=0.1, attrMin=attr_range[0],
-                        attrMax=attr_range[1], ppllMaxNumFrags=64)
+                        attrMax=attr_range[1], ppllMaxNumFrags=64, useCappedTubes=int(bool(capped)))
     if workload == "c2e":
         P.useBands, P.useEllipticTubes, P.bandWidth, P.minBandThickness, P.minThickness = 1, 1, 0.005, 0.15, 0.15
     t0 = time.time()
@@ -535,7 +538,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline and not dry:
             cpu_wl = {"c3": "c3t"}.get(args.workload, args.workload)
             result["cpu_baseline"] = cpu_baseline(W, H, pts, seg, tf, attr_range, view, proj, fovy, near, far,
-                                                  workload=cpu_wl, mesh=mesh, ao_spp=wl.get("ao_spp", 64))
+                                                  workload=cpu_wl, mesh=mesh, ao_spp=wl.get("ao_spp", 64),
+                                                  capped=str(wl["settings"].get("use_capped_tubes", True)).lower() not in ("false", "0"))
         else:
             result["cpu_baseline"] = None
         print(json.dumps(result), flush=True)

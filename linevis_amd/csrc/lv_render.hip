@@ -815,15 +815,11 @@ __global__ __launch_bounds__(LV_BLOCK, LV_GATHER_MIN_WAVES) void k_ppll_gather(c
                         [&](unsigned owner, uint32_t leaf, float t, int kind, f3 ro, f3 rd, float ownerAo, float ownerPixel) {
         LvHit h; h.t = t; h.leaf = leaf; h.kind = kind; h.found = true;
         float hitT;
-        LvRasterQuad rq;
-        const LvRasterQuad* rqp = nullptr;
-        if (U.ppllRasterColour) {
-            const uint32_t pxy = __float_as_uint(ownerPixel);
-            rq = lv_make_raster_quad(U, pxy & 0xFFFFu, pxy >> 16);
-            rqp = &rq;
-        }
-        f4 color = PRIM == LV_PRIM_ELLIPTIC ? lv_shade_hit_elliptic(S, U, ownerAo, ro, rd, h, hitT, rqp)
-                                            : lv_shade_hit<BANDS>(S, U, ownerAo, ro, rd, h, hitT, rqp);
+        const bool rasterApply = U.ppllRasterColour != 0u;
+        const uint32_t pxy = __float_as_uint(ownerPixel);
+        const LvRasterQuad rq = lv_make_raster_quad(U, pxy & 0xFFFFu, pxy >> 16);
+        f4 color = PRIM == LV_PRIM_ELLIPTIC ? lv_shade_hit_elliptic(S, U, ownerAo, ro, rd, h, hitT, true, rq, rasterApply)
+                                            : lv_shade_hit<BANDS>(S, U, ownerAo, ro, rd, h, hitT, true, rq, rasterApply);
         if (STATS) cnt.hits++;
         if (color.w < 0.001f) return; // gatherFragment: discard, LinkedListGather.glsl:34
         // wave-aggregated node allocation: slots come from a per-wave chunk; one global atomic per LV_PPLL_CHUNK fragments

@@ -991,12 +991,13 @@ struct LvBandArgs { bool useBand; float phi; f3 linePosition, lineNormal; float 
 // with the per-frame steps dD/dx = invView * (invProj * (2 / W, 0, 0, 0)).xyz, dD/dy likewise (wave-uniform: scalar registers).
 struct LvRasterQuad { f3 d0, dX, dY; };
 __device__ __forceinline__ LvRasterQuad lv_make_raster_quad(const LvUniforms& U, uint32_t x, uint32_t y) {
-    const float ndcx = 2.0f * ((float(x) + 0.5f) / float(U.width)) - 1.0f;
-    const float ndcy = 2.0f * ((float(y) + 0.5f) / float(U.height)) - 1.0f;
+    const float sxp = 2.0f / float(U.width), syp = 2.0f / float(U.height);   // NDC step of one pixel (wave-uniform)
+    const float ndcx = (float(x) + 0.5f) * sxp - 1.0f;
+    const float ndcy = (float(y) + 0.5f) * syp - 1.0f;
     const f4 target = mulM4(U.invProj, ndcx, ndcy, 1.0f, 1.0f);
     const f4 dir = mulM4(U.invView, target.x, target.y, target.z, 0.0f);
-    const f4 gx = mulM4(U.invProj, 2.0f / float(U.width), 0.0f, 0.0f, 0.0f);
-    const f4 gy = mulM4(U.invProj, 0.0f, 2.0f / float(U.height), 0.0f, 0.0f);
+    const f4 gx = mulM4(U.invProj, sxp, 0.0f, 0.0f, 0.0f);
+    const f4 gy = mulM4(U.invProj, 0.0f, syp, 0.0f, 0.0f);
     const f4 Gx = mulM4(U.invView, gx.x, gx.y, gx.z, 0.0f);
     const f4 Gy = mulM4(U.invView, gy.x, gy.y, gy.z, 0.0f);
     const float sx = (x & 1u) ? -1.0f : 1.0f, sy = (y & 1u) ? -1.0f : 1.0f;
@@ -1007,19 +1008,21 @@ __device__ __forceinline__ LvRasterQuad lv_make_raster_quad(const LvUniforms& U,
     return q;
 }
 __device__ __forceinline__ float lv_tube_ribbon_of_ray(f3 cam, f3 d, f3 axisPoint, f3 t, float radius) {
+    // t . (wp x dp) = (t x wp) . d  and  |dp|^2 = |d|^2 - (d . t)^2  (t unit, wp and t x wp perpendicular to t)
     const f3 w = cam - axisPoint;
     const f3 wp = w - dot3(w, t) * t;
-    const f3 dp = d - dot3(d, t) * t;
-    return clampf(dot3(t, cross3(wp, dp)) / (len3(dp) * radius), -1.0f, 1.0f);
+    const f3 k = cross3(t, wp);
+    const float dt = dot3(d, t);
+    return clampf(dot3(k, d) / (sqrtf(dot3(d, d) - dt * dt) * radius), -1.0f, 1.0f);
 }
 // caps: the shader's cap coordinate where the ray meets the tangent plane of the cap at the fragment, sphere normal direction there
 __device__ __forceinline__ float lv_cap_ribbon_of_ray(f3 cam, f3 d, f3 hit, f3 hitNormal, f3 centre, f3 t) {
     const float s = dot3(hit - cam, hitNormal) / dot3(d, hitNormal);
     const f3 q = cam + d * s;
-    const f3 n = norm3(q - centre);
-    const f3 vv = norm3(cam - q);
-    const f3 helperVec = norm3(cross3(t, vv));
-    const f3 newV = norm3(cross3(helperVec, t));
+    const f3 n = norm3s(q - centre);
+    const f3 vv = norm3s(cam - q);
+    const f3 helperVec = norm3s(cross3(t, vv));
+    const f3 newV = norm3s(cross3(helperVec, t));
     const f3 crossProdVn = cross3(vv, n);
     float ribbonPosition2 = len3(cross3(newV, n));
     if (dot3(t, crossProdVn) < 0.0f) ribbonPosition2 = -ribbonPosition2;
@@ -1132,7 +1135,13 @@ __device__ __forceinline__ float lv_prebaked_ao_lookup(const LvSceneDev& S, cons
 // payloadHitT = length(hit - camera).
 template <int BANDS = LV_SHADE_PLAIN>
 __device__ __forceinline__ f4 lv_shade_hit(const LvSceneDev& S, const LvUniforms& U, float aoTexel, f3 o, f3 d,
-                                           const LvHit& h, float& payloadHitT, const LvRasterQuad* rq = nullptr) {
+                                           const LvHit& h, float& payloadHitT, bool raster = false, LvRasterQuad rqv = LvRasterQuad(),
+                                           bool rasterApply = true) {
+    // raster: compute fwidth(ribbonPosition) (a compile-time constant at every call site: the gather passes true, the ray tracer
+    // nothing); rasterApply: use it (run-time option ppll_fragment_colour) -- the computation itself is branch-free so that it
+    // interleaves with the rest of the shading instead of forming a serial tail of its own.  The quad travels by value: behind a
+    // conditionally null pointer it lived in scratch memory, one store + one dependent load per shading batch on the critical path.
+    const LvRasterQuad* rq = raster ? &rqv : nullptr;
     const float4 ra = S.segs[2 * h.leaf], rb = S.segs[2 * h.leaf + 1];
     const f3 P0 = mk3(ra.x, ra.y, ra.z), P1 = mk3(rb.x, rb.y, rb.z);
     f3 fragPos = o + d * h.t;
@@ -1165,7 +1174,7 @@ __device__ __forceinline__ f4 lv_shade_hit(const LvSceneDev& S, const LvUniforms
                              : lv_tube_ribbon_of_ray(cam, rq->dX, linePointInterpolated, fragmentTangent, U.radius);
         const float fy = cap ? lv_cap_ribbon_of_ray(cam, rq->dY, fragPos, fragmentNormal, linePointInterpolated, fragmentTangent)
                              : lv_tube_ribbon_of_ray(cam, rq->dY, linePointInterpolated, fragmentTangent, U.radius);
-        rasterEps = fabsf(fx - f0) + fabsf(fy - f0);
+        rasterEps = rasterApply ? fabsf(fx - f0) + fabsf(fy - f0) : -1.0f;
     }
     if (U.aoPrebaked) {
         // TubeRayTracing.glsl:551-563: angle around the tube relative to the line normal + interpolated vertex id
@@ -1233,7 +1242,7 @@ __device__ __forceinline__ f4 lv_shade_hit(const LvSceneDev& S, const LvUniforms
                                  : lv_bands_ribbon_of_ray(cam, rq->dX, b.linePosition, b.lineNormal, fragmentTangent, tN, r, 1.0f);
             const float fy = cap ? lv_cap_ribbon_of_ray(cam, rq->dY, fragPos, fragmentNormal, linePointInterpolated, fragmentTangent)
                                  : lv_bands_ribbon_of_ray(cam, rq->dY, b.linePosition, b.lineNormal, fragmentTangent, tN, r, 1.0f);
-            b.rasterEpsWhite = fabsf(fx - f0) + fabsf(fy - f0);
+            b.rasterEpsWhite = rasterApply ? fabsf(fx - f0) + fabsf(fy - f0) : -1.0f;
         }
         return lv_compute_fragment_color_t<LV_SHADE_BANDS>(S, U, aoTexel, fragPos, fragmentNormal, fragmentTangent, isCap,
                                                            fragmentAttribute, payloadHitT, b);
@@ -1278,7 +1287,13 @@ __device__ __forceinline__ LvEllipticSurface lv_elliptic_surface(const LvUniform
     return E;
 }
 __device__ __forceinline__ f4 lv_shade_hit_elliptic(const LvSceneDev& S, const LvUniforms& U, float aoTexel, f3 o, f3 d,
-                                                    const LvHit& h, float& payloadHitT, const LvRasterQuad* rq = nullptr) {
+                                                    const LvHit& h, float& payloadHitT, bool raster = false, LvRasterQuad rqv = LvRasterQuad(),
+                                           bool rasterApply = true) {
+    // raster: compute fwidth(ribbonPosition) (a compile-time constant at every call site: the gather passes true, the ray tracer
+    // nothing); rasterApply: use it (run-time option ppll_fragment_colour) -- the computation itself is branch-free so that it
+    // interleaves with the rest of the shading instead of forming a serial tail of its own.  The quad travels by value: behind a
+    // conditionally null pointer it lived in scratch memory, one store + one dependent load per shading batch on the critical path.
+    const LvRasterQuad* rq = raster ? &rqv : nullptr;
     const uint32_t seg = S.leafSeg[h.leaf];
     const lv_line_point& lp0 = S.points[S.segIdx[2 * seg]];
     const lv_line_point& lp1 = S.points[S.segIdx[2 * seg + 1]];
@@ -1297,7 +1312,7 @@ __device__ __forceinline__ f4 lv_shade_hit_elliptic(const LvSceneDev& S, const L
         const float f0 = lv_bands_ribbon_of_ray(cam, rq->d0, b.linePosition, b.lineNormal, E.tangent, tN, r, U.minThickness);
         const float fx = lv_bands_ribbon_of_ray(cam, rq->dX, b.linePosition, b.lineNormal, E.tangent, tN, r, U.minThickness);
         const float fy = lv_bands_ribbon_of_ray(cam, rq->dY, b.linePosition, b.lineNormal, E.tangent, tN, r, U.minThickness);
-        b.rasterEpsWhite = fabsf(fx - f0) + fabsf(fy - f0);
+        b.rasterEpsWhite = rasterApply ? fabsf(fx - f0) + fabsf(fy - f0) : -1.0f;
     }
     return lv_compute_fragment_color_t<LV_SHADE_BANDS>(S, U, aoTexel, E.fragPos, E.normal, E.tangent, false, E.attribute, payloadHitT, b);
 }

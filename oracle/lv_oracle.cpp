@@ -629,12 +629,13 @@ inline void blinnPhongShadingTube(const lvo_params& P, const Frame& F, float aoT
 // D(x, y +- 1) = D +- dD/dy with the constant steps dD/dx = invView * (invProj * (2 / W, 0, 0, 0)).xyz, dD/dy likewise.
 struct RasterQuad { V3 d0, dX, dY; };   // un-normalised directions of the pixel's own ray and of its two quad partners (origin = camera)
 inline RasterQuad makeRasterQuad(const lvo_params& P, const Frame& F, uint32_t x, uint32_t y) {
-    const float ndcx = 2.0f * ((float(x) + 0.5f) / float(P.width)) - 1.0f;
-    const float ndcy = 2.0f * ((float(y) + 0.5f) / float(P.height)) - 1.0f;
+    const float sxp = 2.0f / float(P.width), syp = 2.0f / float(P.height);   // NDC step of one pixel
+    const float ndcx = (float(x) + 0.5f) * sxp - 1.0f;
+    const float ndcy = (float(y) + 0.5f) * syp - 1.0f;
     const V4 target = mulM4(F.invProj, V4{ndcx, ndcy, 1.0f, 1.0f});
     const V4 dir = mulM4(F.invView, V4{target.x, target.y, target.z, 0.0f});
-    const V4 gx = mulM4(F.invProj, V4{2.0f / float(P.width), 0.0f, 0.0f, 0.0f});
-    const V4 gy = mulM4(F.invProj, V4{0.0f, 2.0f / float(P.height), 0.0f, 0.0f});
+    const V4 gx = mulM4(F.invProj, V4{sxp, 0.0f, 0.0f, 0.0f});
+    const V4 gy = mulM4(F.invProj, V4{0.0f, syp, 0.0f, 0.0f});
     const V4 Gx = mulM4(F.invView, V4{gx.x, gx.y, gx.z, 0.0f});
     const V4 Gy = mulM4(F.invView, V4{gy.x, gy.y, gy.z, 0.0f});
     const float sx = (x & 1u) ? -1.0f : 1.0f, sy = (y & 1u) ? -1.0f : 1.0f;
@@ -647,10 +648,12 @@ inline RasterQuad makeRasterQuad(const lvo_params& P, const Frame& F, uint32_t x
 // ribbon coordinate of the ray (cam, d) with respect to a tube axis (point, unit direction t): signed ray-axis distance / radius,
 // clamped like the shader clamps ribbonPosition (:1-style clamp(ribbonPosition, -1, 1), :962)
 inline float tubeRibbonOfRay(V3 cam, V3 d, V3 axisPoint, V3 t, float radius) {
+    // t . (wp x dp) = (t x wp) . d  and  |dp|^2 = |d|^2 - (d . t)^2  (t unit, wp and t x wp perpendicular to t)
     const V3 w = cam - axisPoint;
     const V3 wp = w - dot(w, t) * t;
-    const V3 dp = d - dot(d, t) * t;
-    return clampf(dot(t, cross(wp, dp)) / (length(dp) * radius), -1.0f, 1.0f);
+    const V3 k = cross(t, wp);
+    const float dt = dot(d, t);
+    return clampf(dot(k, d) / (sqrtf(dot(d, d) - dt * dt) * radius), -1.0f, 1.0f);
 }
 // cap variant (:785-815): ribbonPosition = min(|cross(v, n)|, |ribbonPosition2|) with the SPHERE's normal n.  |cross(newV, n)| of a
 // cap fragment depends on where along the axis the hit lies, not on the ray alone, so the partners' values are taken where
@@ -659,10 +662,10 @@ inline float tubeRibbonOfRay(V3 cam, V3 d, V3 axisPoint, V3 t, float radius) {
 inline float capRibbonOfRay(V3 cam, V3 d, V3 hit, V3 hitNormal, V3 centre, V3 t) {
     const float s = dot(hit - cam, hitNormal) / dot(d, hitNormal);
     const V3 q = cam + d * s;
-    const V3 n = normalize(q - centre);
-    const V3 vv = normalize(cam - q);
-    const V3 helperVec = normalize(cross(t, vv));
-    const V3 newV = normalize(cross(helperVec, t));
+    const V3 n = normalizeShade(q - centre);
+    const V3 vv = normalizeShade(cam - q);
+    const V3 helperVec = normalizeShade(cross(t, vv));
+    const V3 newV = normalizeShade(cross(helperVec, t));
     const V3 crossProdVn = cross(vv, n);
     float ribbonPosition2 = length(cross(newV, n));
     if (dot(t, crossProdVn) < 0.0f) ribbonPosition2 = -ribbonPosition2;
