@@ -37,7 +37,8 @@ LINE_WIDTH = 0.002
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E vendor peak (MI355X_MICROARCH.md; ~6.3 TB/s attainable)
 L2_PEAK_GBS = 34500.0     # aggregate L2 bandwidth (MI355X_MICROARCH.md "L2")
 NUM_CUS, NUM_SIMDS = 256, 1024
-PROFILE_TAG = "r02"
+PROFILE_TAGS = ("r03", "r02")   # counter files of the newest round that has them (profiles/pmc_<tag>_<workload>.json)
+CLOCK_GHZ = 2.4                  # MI355X peak engine clock (MI355X_MICROARCH.md)
 SETTINGS = {
     "ambient_occlusion_mode": "RTAO (Screen Space)", "ambient_occlusion_strength": 1.0,
     "ambient_occlusion_gamma": 1.0, "ambient_occlusion_iterations": 1, "ambient_occlusion_samples_per_frame": 64,
@@ -213,11 +214,18 @@ def roofline(kernel, pmc_key, ms_launch, algorithmic_bytes, world):
            "algorithmic_note": "SURVEY.md 8(d) byte model: 64 B per node visited + 32/48 B per primitive tested + per-pixel records, "
                                "'every touch goes to memory'; most of these bytes are served by L1/L2 (see ceilings), so this rate "
                                "is NOT bounded by the HBM peak"}
-    ppath = os.path.join(ROOT, "profiles", "pmc_%s_%s.json" % (PROFILE_TAG, pmc_key))
-    upath = os.path.join(ROOT, "profiles", "ubench_%s.json" % PROFILE_TAG)
-    if world != 1 or not (os.path.exists(ppath) and os.path.exists(upath)) or ms_launch <= 0:
+    ppath = upath = None
+    for tag in PROFILE_TAGS:
+        c1 = os.path.join(ROOT, "profiles", "pmc_%s_%s.json" % (tag, pmc_key))
+        if ppath is None and os.path.exists(c1):
+            ppath = c1
+        c2 = os.path.join(ROOT, "profiles", "ubench_%s.json" % tag)
+        if upath is None and os.path.exists(c2):
+            upath = c2
+    if world != 1 or ppath is None or upath is None or ms_launch <= 0:
         out.update({"bound": None, "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
-                    "note": "ceilings need profiles/pmc_%s_%s.json + profiles/ubench_%s.json and a 1-GPU run" % (PROFILE_TAG, pmc_key, PROFILE_TAG)})
+                    "note": "ceilings need profiles/pmc_<tag>_%s.json + profiles/ubench_<tag>.json (tags %s) and a 1-GPU run"
+                            % (pmc_key, "/".join(PROFILE_TAGS))})
         return out
     pmc = json.load(open(ppath))
     ub = json.load(open(upath))
@@ -235,6 +243,11 @@ def roofline(kernel, pmc_key, ms_launch, algorithmic_bytes, world):
     ceil["valu_issue"] = {"achieved": round(valu_rate, 4), "peak": round(valu_peak, 4), "unit": "wave-instructions/SIMD/ns",
                           "frac": round(valu_rate / valu_peak, 4),
                           "lane_utilisation": round(c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"]), 4),
+                          # the same count against the datasheet issue rate (one wave64 v_fma_f32 per 2 cycles per SIMD = the 157 TFLOP/s
+                          # vector peak of MI355X_MICROARCH.md): measured here, plain VALU instructions issue every ~3.5-4.1 cycles and only
+                          # v_pk_fma_f32 (two FMAs in 4.2 cycles) reaches that peak -- the kernel's compare / select / convert mix cannot
+                          # be packed, so `frac` (own mix ceiling) is the binding number and this one the distance to the marketing peak
+                          "frac_vs_datasheet_issue": round(valu_rate * 2.0 / CLOCK_GHZ, 4),
                           "source": "SQ_INSTS_VALU / 1024 SIMDs / launch time; peak = tools/ubench/valu_rates 'node-step mix'"}
     # vector L1: lane requests per CU per ns against the all-hit rate of divergent dwordx4 gathers
     tcp_rate = c["TCP_TOTAL_CACHE_ACCESSES_sum"] / NUM_CUS / t_ns
@@ -256,7 +269,8 @@ def roofline(kernel, pmc_key, ms_launch, algorithmic_bytes, world):
                              "counts 128-B requests as 64 B; Infinity-Cache hits are included, so this is an upper bound on HBM)"}
     bound = max(ceil, key=lambda k: ceil[k]["frac"])
     out.update({"bound": bound, "achieved": ceil[bound]["achieved"], "peak": ceil[bound]["peak"], "unit": ceil[bound]["unit"],
-                "frac": ceil[bound]["frac"], "traffic": int(traffic), "ceilings": ceil,
+                "frac": ceil[bound]["frac"], "frac_vs_datasheet_issue": ceil["valu_issue"]["frac_vs_datasheet_issue"],
+                "traffic": int(traffic), "ceilings": ceil,
                 "pmc_file": os.path.relpath(ppath, ROOT), "ubench_file": os.path.relpath(upath, ROOT)})
     return out
 
@@ -287,6 +301,87 @@ class DryRunContext:
         return np.zeros(0, np.float32)
 
 
+def main_one_process(args):
+    """All N GPUs behind one handle of the C-ABI (lv_create_multi): the path a C++ embedder takes.  Same frame, same counters;
+    the gather is the library's own ncclSend / ncclRecv group (no torch.distributed)."""
+    import torch
+    from linevis_amd import camera, capi, host_api, scenes, transfer_function as tfm
+    wl = dict(WORKLOADS[args.workload])
+    extra = dict(kv.split("=", 1) for kv in args.set)
+    if extra:
+        wl["settings"] = dict(wl["settings"], **extra)
+        wl["name"] += "; overrides: " + ", ".join("%s=%s" % kv for kv in sorted(extra.items()))
+    W, H = wl.get("resolution", (1920, 1080))
+    view, proj, fovy, near, far = camera.default_camera(W, H)
+    gen = {"tornado": scenes.tornado, "helix": scenes.helix_bundle, "rayleigh_benard": scenes.rayleigh_benard}[wl["scene"]]
+    tr = scenes.normalize(gen())
+    flow = host_api.LineDataFlow().set_trajectories(tr.positions, tr.attributes, tr.line_offsets)
+    pts, seg, _ = flow.tube_aabb_render_data(LINE_WIDTH)
+    ctx = capi.Context(devices=list(range(args.gpus)), transport=args.transport)
+    ctx.set_lines(pts, seg)
+    ctx.set_transfer_function(tfm.standard_transparent() if wl.get("transparent") else tfm.standard(), *flow.attribute_range())
+    ctx.set_camera(view, proj, fovy, near, far, W, H)
+    ctx.set_option("line_width", LINE_WIDTH)
+    if wl.get("mesh"):
+        ctx.set_tube_triangle_mesh(*flow.tube_triangle_render_data(LINE_WIDTH, 6))
+    ctx.set_options(wl["settings"])
+    ctx.build_accel()
+    torch.cuda.set_device(0)
+    out = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda:0")
+    ctx.set_option("collect_stats", True)
+    ctx.render_device(out.data_ptr(), mode=wl["mode"])
+    st = ctx.stats()                       # synchronises every rank; counters summed over the ranks
+    rays = float(st.rays_traced)
+    ctx.set_option("collect_stats", False)
+    ctx.rebalance()                        # tiles re-dealt by the cost this frame measured
+    gc.collect(); gc.freeze(); gc.disable()
+    for _ in range(args.warmup):
+        ctx.render_device(out.data_ptr(), mode=wl["mode"])
+    ctx.stats()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ctx.render_device(out.data_ptr(), mode=wl["mode"])
+    ctx.stats()
+    elapsed = time.perf_counter() - t0
+    gc.enable()
+    deal = ctx.deal()
+    result = {"metric": "Mrays/s", "value": round(rays * args.steps / elapsed / 1e6, 2), "unit": "Mrays/s", "n_gpus": args.gpus,
+              "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+              "fps": round(args.steps / elapsed, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+              "frames_in_flight": 1, "data": "synthetic",
+              "config": {"workload": wl["name"], "resolution": [W, H], "segments": int(len(seg)), "rays_per_frame": int(rays),
+                         "parallelism": "ONE process, lv_create_multi over %d device(s): 64x64 screen tiles in Morton order dealt by measured "
+                                        "cost, one %s gather per frame inside the library" % (args.gpus, args.transport),
+                         "tiles_per_rank": [int((deal == r).sum()) for r in range(args.gpus)]},
+              "roofline": {"bound": None, "note": "per-kernel ceilings are reported by the default (one process per GPU) mode"},
+              "cpu_baseline": None}
+    print(json.dumps(result), flush=True)
+
+
+def run_states(steps, device=0):
+    """AutomaticPerformanceMeasurer's loop on the headless harness: every canned state of lv::getTestModes (InternalState.cpp:46-51,
+    276-297, each twice) is applied with setNewState and rendered `steps` times on the config-3 scene; per state the mean frame time
+    (wall clock around render(), image read-back included, like the reference's "Average Time (ms)" column) and the fps."""
+    from linevis_amd import host_api, scenes, transfer_function as tfm
+    tr = scenes.normalize(scenes.tornado())
+    flow = host_api.LineDataFlow().set_trajectories(tr.positions, tr.attributes, tr.line_offsets)
+    r = host_api.HeadlessLineRenderer(11, device=device)
+    r.set_rendering_resolution(1920, 1080)
+    r.set_line_data(flow)
+    r.set_new_settings({"line_width": LINE_WIDTH})
+    rows = []
+    for name, mode, res, settings in host_api.get_test_modes():
+        r.set_transfer_function(tfm.standard_transparent() if mode == 2 else tfm.standard())   # Transparent_*.xml for the OIT states
+        r.set_new_state(name, mode, settings, resolution=res)
+        r.render_frame()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            r.render_frame()
+        dt = (time.perf_counter() - t0) / steps
+        rows.append({"name": name, "rendering_mode": mode, "avg_time_ms": round(dt * 1e3, 3), "fps": round(1.0 / dt, 2)})
+    return rows
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -296,6 +391,14 @@ def main():
     ap.add_argument("--save-frame", default="")
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--dry-run", action="store_true", help="no GPU: gloo + CPU tensors + a stand-in renderer (collective sequence only)")
+    ap.add_argument("--one-process", action="store_true",
+                    help="drive all --gpus N devices from THIS process through the library's multi-device handle (lv_create_multi: one "
+                         "context per device, tiles dealt by cost, one RCCL ncclSend/ncclRecv gather per frame) instead of one process "
+                         "per GPU + torch.distributed; launch as plain `python bench.py --gpus N --one-process`")
+    ap.add_argument("--transport", default="rccl", choices=["rccl", "memcpy"], help="gather transport of --one-process")
+    ap.add_argument("--states", action="store_true",
+                    help="also walk the canned benchmark states of the reference's --perf harness (InternalState.cpp:46-51,276-297 = "
+                         "lv::getTestModes) through the plugin surface and report ms / fps per state")
     ap.add_argument("--set", action="append", default=[], metavar="KEY=VALUE",
                     help="extra renderer setting (SettingsMap key), e.g. --set intersection_form=literal; noted in config.workload")
     args = ap.parse_args()
@@ -305,6 +408,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    one_process = args.one_process and not args.dry_run
+    if one_process:
+        if world != 1:
+            raise SystemExit("--one-process is launched as ONE process (no torch.distributed.run)")
+        return main_one_process(args)
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`"
@@ -542,6 +650,10 @@ def main():
                                                   capped=str(wl["settings"].get("use_capped_tubes", True)).lower() not in ("false", "0"))
         else:
             result["cpu_baseline"] = None
+        if args.states and world == 1 and not dry:
+            del head, also
+            gc.collect()
+            result["states"] = run_states(min(args.steps, 20), local_rank)
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

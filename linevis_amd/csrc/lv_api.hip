@@ -92,6 +92,20 @@ void lv_mat4_inverse(const float* m, float* inv) {
     inv[12] = i30 * r; inv[13] = i31 * r; inv[14] = i32 * r; inv[15] = i33 * r;
 }
 
+// every device buffer a context owns: freed by lv_destroy, summed by lv_get_stats (device_bytes)
+static std::vector<LvDeviceBuffer*> lv_all_buffers(lv_ctx* ctx) {
+    return {&ctx->points, &ctx->segIdx, &ctx->nodes, &ctx->segs, &ctx->segAxis, &ctx->leafSeg, &ctx->segToLeaf, &ctx->tf,
+            &ctx->depthMinMax, &ctx->ao, &ctx->aoAlt, &ctx->featNormal, &ctx->featNormalAlt, &ctx->featPosition, &ctx->featPositionAlt,
+            &ctx->eawPing, &ctx->eawPong, &ctx->tilesHaloDev, &ctx->fullFrameTile, &ctx->svgf.normalDepth, &ctx->svgf.normalDepthHistory,
+            &ctx->svgf.flowFwidth, &ctx->svgf.moments, &ctx->svgf.momentsHistory, &ctx->svgf.colorHistory, &ctx->svgf.tempAccum,
+            &ctx->svgf.tempAccumFiltered, &ctx->svgf.ping, &ctx->svgf.pong, &ctx->svgf.result, &ctx->aoGbuf, &ctx->aoList, &ctx->aoSamples,
+            &ctx->counters, &ctx->ppllNodes, &ctx->ppllStart, &ctx->ppllCount, &ctx->ppllScratch, &ctx->tilesDev, &ctx->outDev,
+            &ctx->scratchRays, &ctx->stackOverflow, &ctx->triIdx, &ctx->triVerts, &ctx->triPoints, &ctx->triNodes, &ctx->tris,
+            &ctx->flowVectors, &ctx->flowScalars, &ctx->flowMisc, &ctx->flowSeeds, &ctx->flowOutPos, &ctx->flowOutAtt, &ctx->flowCounts,
+            &ctx->bakeBlendingWeights, &ctx->bakeSamplingLocations, &ctx->bakedAo, &ctx->bakeLcgSkip, &ctx->mlatTrace, &ctx->buildArena,
+            &ctx->accum};
+}
+
 namespace {
 
 typedef LvDevCounters LvDevCountersHost;
@@ -173,16 +187,7 @@ void lv_destroy(lv_ctx* ctx) {
     if (ctx->multi) lv_multi_destroy(ctx); // the other ranks, the communicators and the gather buffers
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    for (LvDeviceBuffer* b : {&ctx->points, &ctx->segIdx, &ctx->nodes, &ctx->segs, &ctx->segAxis, &ctx->leafSeg, &ctx->segToLeaf, &ctx->tf,
-                              &ctx->depthMinMax, &ctx->ao, &ctx->aoAlt, &ctx->featNormal, &ctx->featNormalAlt, &ctx->featPosition, &ctx->featPositionAlt, &ctx->eawPing, &ctx->eawPong, &ctx->tilesHaloDev,
-                              &ctx->fullFrameTile, &ctx->svgf.normalDepth, &ctx->svgf.normalDepthHistory, &ctx->svgf.flowFwidth,
-                              &ctx->svgf.moments, &ctx->svgf.momentsHistory, &ctx->svgf.colorHistory, &ctx->svgf.tempAccum,
-                              &ctx->svgf.tempAccumFiltered, &ctx->svgf.ping, &ctx->svgf.pong, &ctx->svgf.result, &ctx->aoGbuf, &ctx->aoList, &ctx->aoSamples, &ctx->counters,
-                              &ctx->ppllNodes, &ctx->ppllStart, &ctx->ppllCount, &ctx->ppllScratch, &ctx->tilesDev, &ctx->outDev,
-                              &ctx->scratchRays, &ctx->stackOverflow, &ctx->triIdx, &ctx->triVerts, &ctx->triPoints,
-                              &ctx->triNodes, &ctx->tris, &ctx->flowVectors, &ctx->flowScalars, &ctx->flowMisc,
-                              &ctx->flowSeeds, &ctx->flowOutPos, &ctx->flowOutAtt, &ctx->flowCounts, &ctx->bakeBlendingWeights,
-                              &ctx->bakeSamplingLocations, &ctx->bakedAo, &ctx->bakeLcgSkip, &ctx->mlatTrace, &ctx->buildArena, &ctx->accum})
+    for (LvDeviceBuffer* b : lv_all_buffers(ctx))
         lv_buf_free(*b);
     if (ctx->evCreated) {
         for (int i = 0; i < 16; i++) (void)hipEventDestroy(ctx->ev[i]);
@@ -414,13 +419,20 @@ int lv_set_option(lv_ctx* ctx, const char* key, const char* value) {
         o.aoJitterPrimary = parseBool(value);
     } else if (k == "ambient_occlusion_denoiser") {
         // DENOISER_NAMES, Denoiser.hpp:61-65,96-100 (VulkanRayTracedAmbientOcclusion.cpp:683-696)
-        const bool wasSvgf = o.svgfEnabled;
+        const bool wasSvgf = o.svgfEnabled, wasEaw = o.eawEnabled;
         if (strcmp(value, "None") == 0) { o.eawEnabled = false; o.svgfEnabled = false; }
         else if (strcmp(value, "Edge-Avoiding \xC3\x80-Trous Wavelet Transform") == 0 || strcmp(value, "EAW") == 0) { o.eawEnabled = true; o.svgfEnabled = false; }
         else if (strcmp(value, "SVGF") == 0) { o.eawEnabled = false; o.svgfEnabled = true; }
         else return lv_fail(ctx, LV_E_INVALID, "ambient_occlusion_denoiser '%s' is not provided (None | Edge-Avoiding \xC3\x80-Trous "
                                                "Wavelet Transform | SVGF)", value);
-        if (o.svgfEnabled != wasSvgf) { ctx->svgf.historyValid = false; ctx->aoResult = nullptr; } // createDenoiser(): fresh history
+        if (o.svgfEnabled != wasSvgf) ctx->svgf.historyValid = false; // createDenoiser(): fresh history
+        if (o.svgfEnabled != wasSvgf || o.eawEnabled != wasEaw) {
+            // any change of the denoiser: the image the colour pass samples (raw / EAW ping-pong / SVGF result) is stale, and a
+            // running accumulation would mix feature maps that were never written -- setDenoiserType resets the frame number
+            // (VulkanRayTracedAmbientOcclusion.cpp:683-696 -> onHasMoved): the accumulation restarts with the next frame
+            ctx->aoResult = nullptr;
+            ctx->aoRestart = true;
+        }
     } else if (k == "use_ribbons") {                              // LineDataFlow.cpp:588 (here: USE_BANDS = ribbons on AND band data set)
         o.useRibbons = parseBool(value);
     } else if (k == "thick_bands") {                              // :592
@@ -685,12 +697,7 @@ int lv_get_stats(lv_ctx* ctx, lv_stats* out) {
         s.kernel_launches[k] = uint32_t(n);
     }
     uint64_t bytes = 0;
-    for (const LvDeviceBuffer* b : {&ctx->points, &ctx->segIdx, &ctx->nodes, &ctx->segs, &ctx->segAxis, &ctx->leafSeg, &ctx->segToLeaf, &ctx->tf,
-                                    &ctx->depthMinMax, &ctx->ao, &ctx->aoAlt, &ctx->tilesHaloDev, &ctx->aoGbuf, &ctx->aoList, &ctx->aoSamples,
-                                    &ctx->counters, &ctx->ppllNodes, &ctx->ppllStart, &ctx->ppllCount, &ctx->ppllScratch, &ctx->tilesDev,
-                                    &ctx->outDev, &ctx->scratchRays, &ctx->stackOverflow, &ctx->triIdx, &ctx->triVerts,
-                                    &ctx->triPoints, &ctx->triNodes, &ctx->tris})
-        bytes += b->bytes;
+    for (const LvDeviceBuffer* b : lv_all_buffers(ctx)) bytes += b->bytes; // the same list lv_destroy frees
     s.device_bytes = bytes;
     *out = s;
     // a multi-device handle reports the work of all its ranks (counters and memory summed; times are rank 0's)

@@ -150,6 +150,7 @@ struct lv_ctx {
     LvDeviceBuffer featNormal, featNormalAlt, featPosition, featPositionAlt; // EAW feature maps (float4 per pixel) + ping-pong
     LvDeviceBuffer eawPing, eawPong;          // a-trous passes
     const float* aoResult = nullptr;          // what the colour pass samples: ao (raw) or the denoised image
+    bool aoRestart = false;                   // the denoiser changed: a progressive RTAO accumulation may only continue from frame 0
     LvSvgfState svgf;
     LvDeviceBuffer fullFrameTile;             // one tile origin (0, 0): the SVGF chain always covers the viewport
     uint32_t aoGlobalFrameNumber = 0;         // RTAO iterations since lv_set_lines (globalFrameNumber, ...AmbientOcclusion.cpp:582)

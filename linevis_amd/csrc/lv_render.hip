@@ -99,6 +99,22 @@ __global__ __launch_bounds__(LV_BLOCK, (STATS || PRIM == LV_PRIM_ELLIPTIC) ? 1 :
 }
 
 // ================================================================ RTAO
+// G-buffer layout: the segment of 64x64-pixel group g holds exactly the pixels of its tile that fall into the group (a 66 x 66 tile
+// -- 64 + a one-pixel AO halo -- is cut into 2 x 2 groups of 64 x 64, 2 x 64, 64 x 2 and 2 x 2 pixels): tile-major, then group rows,
+// then groups of a row.  The buffer then has numTiles * tileW * tileH slots, not groups * 4096 (4 x the memory with any halo).
+struct LvAoLayout { uint32_t tileW, tileH, groupsX, groupsPerTile; };
+__device__ __host__ __forceinline__ LvAoLayout lv_ao_layout(const LvTiles& T) {
+    LvAoLayout L;
+    L.tileW = T.tileW; L.tileH = T.tileH; L.groupsX = T.blocksX / 4u; L.groupsPerTile = (T.blocksX / 4u) * (T.blocksY / 4u);
+    return L;
+}
+__device__ __forceinline__ size_t lv_ao_group_base(const LvAoLayout& L, uint32_t group) {
+    const uint32_t tile = group / L.groupsPerTile, gi = group % L.groupsPerTile;
+    const uint32_t gxi = gi % L.groupsX, gyi = gi / L.groupsX;
+    const uint32_t hrow = min(64u, L.tileH - 64u * gyi);
+    return size_t(tile) * L.tileW * L.tileH + size_t(gyi) * 64u * L.tileW + size_t(gxi) * 64u * hrow;
+}
+
 // G-buffer entry of a pixel whose primary ray hit: 3 x float4
 //   g0 = {hit position, offsetFactor}, g1 = {surface tangent, pixel index bits}, g2 = {surface normal, 0}
 template <bool STATS, int PRIM>
@@ -257,7 +273,7 @@ __global__ __launch_bounds__(LV_BLOCK) void k_ao_primary(const LvUniforms U, con
         if (lane == 0) base = atomicAdd(&groupCount[px.group], unsigned(__popcll(mask)));
         base = __shfl(base, 0, 64);
         if (hasHit) {
-            const size_t slot = size_t(px.group) * 4096u + base + unsigned(__popcll(mask & ((1ull << lane) - 1ull)));
+            const size_t slot = lv_ao_group_base(lv_ao_layout(T), px.group) + base + unsigned(__popcll(mask & ((1ull << lane) - 1ull)));
             gbuf[3 * size_t(slot) + 0] = g0;
             gbuf[3 * size_t(slot) + 1] = g1;
             gbuf[3 * size_t(slot) + 2] = g2;
@@ -288,9 +304,9 @@ __global__ __launch_bounds__(LV_BLOCK) void k_ao_tile_scan(const uint32_t* __res
     for (uint32_t i = b; i < e; i++) { tileBase[i] = run; run += tileCount[i]; }
 }
 
-// compacted-pixel ordinal -> G-buffer slot: tile t with tileBase[t] <= ordinal < tileBase[t + 1] (binary search; the table
-// is a few KB and stays in L1), slot = t * tileCapacity + (ordinal - tileBase[t]).  tileBase == nullptr: slot = ordinal.
-__device__ __forceinline__ size_t lv_ao_slot(const uint32_t* __restrict__ tileBase, uint32_t numTiles, uint32_t tileCapacity,
+// compacted-pixel ordinal -> G-buffer slot: group g with tileBase[g] <= ordinal < tileBase[g + 1] (binary search; the table
+// is a few KB and stays in L1), slot = first slot of the group's segment + (ordinal - tileBase[g]).  tileBase == nullptr: slot = ordinal.
+__device__ __forceinline__ size_t lv_ao_slot(const uint32_t* __restrict__ tileBase, uint32_t numTiles, const LvAoLayout& tileCapacity,
                                              uint32_t ordinal) {
     if (!tileBase) return ordinal;
     uint32_t lo = 0, hi = numTiles; // invariant: tileBase[lo] <= ordinal < tileBase[hi]
@@ -298,7 +314,7 @@ __device__ __forceinline__ size_t lv_ao_slot(const uint32_t* __restrict__ tileBa
         const uint32_t mid = (lo + hi) >> 1;
         if (tileBase[mid] <= ordinal) lo = mid; else hi = mid;
     }
-    return size_t(lo) * tileCapacity + (ordinal - tileBase[lo]);
+    return lv_ao_group_base(tileCapacity, lo) + (ordinal - tileBase[lo]);
 }
 
 // AO sample rays: PERSISTENT waves that keep three kinds of work apart and run each of them with (nearly) all
@@ -330,7 +346,7 @@ template <bool STATS, bool ANY_HIT, int PRIM, bool BAKE = false, bool LIT = fals
 __global__ __launch_bounds__(LV_AO_BLOCK, LV_AO_MIN_WAVES) void k_ao_rays(const LvUniforms U, const LvSceneDev S,
                                                          const float4* __restrict__ gbuf, float* __restrict__ samples,
                                                          LvDevCounters* dc, const uint32_t* __restrict__ tileBase,
-                                                         uint32_t numTiles, uint32_t tileCapacity,
+                                                         uint32_t numTiles, const LvAoLayout tileCapacity,
                                                          const uint2* __restrict__ lcgSkip = nullptr) {
     __shared__ unsigned s_stack[LV_AO_STACK_LDS * LV_AO_BLOCK];
     // LDS budget: 15 KB + 6 + 6 + 2 + 2 = 31 KB per workgroup -> 5 workgroups (20 waves) per CU; the kernel hides the
@@ -606,7 +622,7 @@ template <bool BAKE>
 __global__ __launch_bounds__(LV_BLOCK) void k_ao_reduce(const LvUniforms U, const float4* __restrict__ gbuf,
                                                         const float* __restrict__ samples, const float* aoIn, float* ao,
                                                         const LvDevCounters* dc, const uint32_t* __restrict__ tileBase,
-                                                        uint32_t numTiles, uint32_t tileCapacity) {
+                                                        uint32_t numTiles, const LvAoLayout tileCapacity) {
     const uint32_t slot = blockIdx.x * LV_BLOCK + threadIdx.x; // compacted-pixel ordinal (= row of `samples`)
     if (slot >= dc->aoCount) return;
     const uint32_t spp = U.aoSamplesPerFrame;
@@ -1318,8 +1334,9 @@ static int lv_run_ao(lv_ctx* ctx, LvUniforms& U, LvSceneDev& S, const LvTiles& T
     // G-buffer: one segment of 4096 slots per 64x64-pixel group of the launch (k_ao_primary); samples: compact
     const uint64_t numGroups64 = uint64_t(T.numTiles) * (T.blocksX / 4u) * (T.blocksY / 4u);
     if (numGroups64 > 0x000FFFFFull) return lv_fail(ctx, LV_E_INVALID, "tile list too large");
-    const uint32_t numGroups = uint32_t(numGroups64), tileCap = 4096u;
-    if ((rc = lv_buf_reserve(ctx, ctx->aoGbuf, size_t(numGroups) * tileCap * 48))) return rc;
+    const uint32_t numGroups = uint32_t(numGroups64);
+    const LvAoLayout tileCap = lv_ao_layout(T);   // segments sized by the pixels a group really holds
+    if ((rc = lv_buf_reserve(ctx, ctx->aoGbuf, size_t(maxPixels) * 48))) return rc;
     if ((rc = lv_buf_reserve(ctx, ctx->aoSamples, size_t(maxPixels) * spp * 4))) return rc;
     if ((rc = lv_buf_reserve(ctx, ctx->aoList, (2 * size_t(numGroups) + 1) * 4))) return rc; // per-group counts, then bases
     uint32_t* tileCount = (uint32_t*)ctx->aoList.ptr;
@@ -1336,6 +1353,12 @@ static int lv_run_ao(lv_ctx* ctx, LvUniforms& U, LvSceneDev& S, const LvTiles& T
     // progressive mode (num_accumulated_frames > 1): one RTAO iteration per rendered frame while frame_number <
     // ambient_occlusion_iterations (ambientOcclusionBaker->updateIterative(), LineRenderer.cpp:257-264), accumulated in ctx->ao
     const bool progressive = ctx->opt.numAccumulatedFrames > 1u;
+    if (ctx->aoRestart) {
+        // the denoiser changed (lv_set_option): the accumulated AO image and the feature maps belong to another pipeline
+        if (progressive && ctx->opt.frameNumber != 0u)
+            return lv_fail(ctx, LV_E_STATE, "ambient_occlusion_denoiser changed: restart the accumulation with frame_number = 0");
+        ctx->aoRestart = false;
+    }
     const uint32_t iterBegin = progressive ? ctx->opt.frameNumber : 0u;
     const uint32_t iterEnd = progressive ? std::min(ctx->opt.frameNumber + 1u, ctx->opt.aoIterations) : ctx->opt.aoIterations;
     for (uint32_t iter = iterBegin; iter < iterEnd; iter++) {
@@ -1842,11 +1865,11 @@ int lv_bake_ambient_occlusion(lv_ctx* ctx) {
         LV_HIP(ctx, hipMemsetAsync(&dc->aoQueueHead, 0, 8, st));
         if (U.aoUseDistance)
             k_ao_rays<false, false, LV_PRIM_TRIANGLE, true><<<uint32_t(gridRays), LV_AO_BLOCK, 0, st>>>(
-                    U, SA, g, smp, dc, nullptr, 0u, 0u, (const uint2*)ctx->bakeLcgSkip.ptr);
+                    U, SA, g, smp, dc, nullptr, 0u, LvAoLayout{0u, 0u, 1u, 1u}, (const uint2*)ctx->bakeLcgSkip.ptr);
         else
             k_ao_rays<false, true, LV_PRIM_TRIANGLE, true><<<uint32_t(gridRays), LV_AO_BLOCK, 0, st>>>(
-                    U, SA, g, smp, dc, nullptr, 0u, 0u, (const uint2*)ctx->bakeLcgSkip.ptr);
-        k_ao_reduce<true><<<nblocks(slots), LV_BLOCK, 0, st>>>(U, g, smp, out, out, dc, nullptr, 0u, 0u);
+                    U, SA, g, smp, dc, nullptr, 0u, LvAoLayout{0u, 0u, 1u, 1u}, (const uint2*)ctx->bakeLcgSkip.ptr);
+        k_ao_reduce<true><<<nblocks(slots), LV_BLOCK, 0, st>>>(U, g, smp, out, out, dc, nullptr, 0u, LvAoLayout{0u, 0u, 1u, 1u});
     }
     LV_HIP(ctx, hipGetLastError());
     ctx->bakeValid = true;

@@ -96,8 +96,9 @@ bool loadTrajectoriesFromBinLines(const std::string& filename, BinLinesData& bin
             const uint32_t n = trajectories.empty() ? 0u : numAttributes;
             for (uint32_t a = 0; a < n; a++) { // sgl::BinaryReadStream::read(std::string&): u32 length, then the characters
                 const uint32_t strLen = r.get<uint32_t>();
+                if (!r.ok || size_t(strLen) > r.n - r.off) return false; // truncated / corrupt: no allocation from a file-controlled length
                 std::string name(strLen, '\0');
-                if (!r.ok || !r.getArray(strLen ? &name[0] : nullptr, strLen)) return false;
+                if (strLen != 0u && !r.getArray(&name[0], strLen)) return false;
                 binLinesData.attributeNames.push_back(name);
             }
         }
@@ -123,7 +124,7 @@ bool loadTrajectoriesFromBinLines(const std::string& filename, Trajectories& tra
 }
 
 bool saveTrajectoriesAsBinLines(const std::string& filename, const Trajectories& trajectories,
-                                const std::vector<std::vector<vec3>>& ribbonsDirections) {
+                                const std::vector<std::vector<vec3>>& ribbonsDirections, bool verticesNormalized) {
     FILE* f = fopen(filename.c_str(), "wb");
     if (!f) return false;
     const bool v2 = !ribbonsDirections.empty();
@@ -137,7 +138,7 @@ bool saveTrajectoriesAsBinLines(const std::string& filename, const Trajectories&
         for (uint32_t a = 0; a < hdr[2]; a++) fwrite(t.attributes[a].data(), sizeof(float), n, f);
     }
     if (v2) { // BinLinesLoader.cpp:196-247: verticesNormalized, hasAttributeNames = 0, hasRibbonData = 1, no outline mesh
-        const uint32_t trailer[3] = {1u, 0u, 1u};
+        const uint32_t trailer[3] = {verticesNormalized ? 1u : 0u, 0u, 1u};
         fwrite(trailer, 4, 3, f);
         for (size_t i = 0; i < trajectories.size(); i++)
             fwrite(ribbonsDirections[i].data(), sizeof(vec3), trajectories[i].positions.size(), f);
@@ -305,6 +306,7 @@ bool LineDataFlow::loadFromFile(const std::string& filename) {
     Trajectories loaded;
     std::vector<std::string> names;
     std::vector<std::vector<vec3>> ribbons;
+    bool alreadyNormalized = false;
     const size_t n = filename.size();
     if (n >= 9 && filename.compare(n - 9, 9, ".binlines") == 0) { // LineDataFlow.cpp:436-446: band data comes with the file
         BinLinesData d;
@@ -312,11 +314,16 @@ bool LineDataFlow::loadFromFile(const std::string& filename) {
         loaded.swap(d.trajectories);
         names = d.attributeNames;
         ribbons.swap(d.ribbonsDirections);
+        alreadyNormalized = d.verticesNormalized; // version 2: StreamlineTracingRequester exports grid-normalised lines with the flag set
     } else if (!loadFlowTrajectoriesFromFile(filename, loaded, names)) {
         return false;
     }
-    AABB3 aabb = computeTrajectoriesAABB3(loaded);
-    normalizeTrajectoriesVertexPositions(loaded, aabb);
+    // loadFlowTrajectoriesFromFile, TrajectoryFile.cpp:656: "if (normalizeVertexPositions && !binLinesData.verticesNormalized)"
+    if (!alreadyNormalized) {
+        AABB3 aabb = computeTrajectoriesAABB3(loaded);
+        normalizeTrajectoriesVertexPositions(loaded, aabb);
+    }
+    verticesNormalized = true; // what this object holds from here on (written back by saveTrajectoriesAsBinLines)
     setTrajectoryData(loaded, names, ribbons);
     return true;
 }

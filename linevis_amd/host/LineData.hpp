@@ -45,7 +45,7 @@ bool loadTrajectoriesFromBinLines(const std::string& filename, BinLinesData& bin
 bool loadTrajectoriesFromBinLines(const std::string& filename, Trajectories& trajectories);
 /// writer (BinLinesLoader.cpp:182-247): version 1 without, version 2 with ribbon directions
 bool saveTrajectoriesAsBinLines(const std::string& filename, const Trajectories& trajectories,
-                                const std::vector<std::vector<vec3>>& ribbonsDirections = {});
+                                const std::vector<std::vector<vec3>>& ribbonsDirections = {}, bool verticesNormalized = false);
 /// Wavefront-OBJ polylines as LineVis reads them (src/Loaders/ObjLoader.cpp:36-186): "v x y z" positions, "vt a0 a1 .."
 /// per-vertex attributes (same count on every line), "l i j k .." one trajectory per line statement (1-based indices),
 /// "a name0 name1 .." attribute names; positions with a component above 1e10 are dropped.
@@ -166,6 +166,10 @@ public:
                            const std::vector<std::vector<vec3>>& ribbonsDirections = {});
     const Trajectories& getTrajectories() const { return trajectories; }
     const std::vector<std::vector<vec3>>& getRibbonsDirections() const { return ribbonsDirections; }
+    /// the positions this object holds went through normalizeTrajectoriesVertexPositions (loadFromFile) or the caller said so:
+    /// what the version-2 .binlines writer records as verticesNormalized (BinLinesLoader.cpp:196-247, TrajectoryFile.cpp:656)
+    bool getVerticesNormalized() const { return verticesNormalized; }
+    void setVerticesNormalized(bool v) { verticesNormalized = v; }
     bool getHasBandsData() const { return hasBandsData; }
     /// USE_BANDS: useRibbons && hasBandsData (LineDataFlow.cpp:2423); use_ribbons / thick_bands / min_band_thickness keys :587-606
     /// (USE_BANDS also needs !useRotatingHelicityBands there; rotating_helicity_bands = true switches useRibbons off, :601-604)
@@ -190,6 +194,7 @@ public:
 private:
     Trajectories trajectories;
     std::vector<std::vector<vec3>> ribbonsDirections; // LineDataFlow.hpp:160
+    bool verticesNormalized = false;
     bool hasBandsData = false;
     static bool useRibbons;                            // LineDataFlow.cpp:51
     static bool useRotatingHelicityBands;              // LineDataFlow.cpp:52

@@ -39,6 +39,15 @@ bool HipRayTracedAmbientOcclusion::setNewSettings(const SettingsMap& settings) {
         useTriangleTubes = tri;
         optionChanged = true;
     }
+    // the denoiser of the RTAO pass (VulkanRayTracedAmbientOcclusion::setNewSettings, .cpp:115-144,683-696) and its parameters
+    // (EAWDenoiser.cpp:400-432; the svgf_* keys are this build's): forwarded as they are, a change restarts the accumulation
+    for (const auto& kv : settings.getMap()) {
+        const std::string& k = kv.first;
+        if (k == "ambient_occlusion_denoiser" || k.rfind("eaw_denoiser_", 0) == 0 || k.rfind("svgf_denoiser_", 0) == 0) {
+            lv_set_option(ctx, k.c_str(), kv.second.c_str());
+            optionChanged = true;
+        }
+    }
     if (optionChanged) {
         onHasMoved();
         pushSettings();
@@ -452,6 +461,14 @@ void HipRayTracer::render() {
 // VulkanRayTracer::setNewSettings, VulkanRayTracer.cpp:226-278
 bool HipRayTracer::setNewSettings(const SettingsMap& settings) {
     bool shallReloadGatherShader = LineRenderer::setNewSettings(settings);
+    // any change of the AO pipeline (baker type, its sampling, its denoiser) restarts the progressive accumulation, like
+    // onHasMoved() does in the reference when the baker reports new settings
+    for (const auto& kv : settings.getMap()) {
+        const std::string& k = kv.first;
+        if (k.rfind("ambient_occlusion_", 0) == 0 || k.rfind("eaw_denoiser_", 0) == 0 || k.rfind("svgf_denoiser_", 0) == 0 ||
+            k == "rtao_geometry" || k == "use_jittered_primary_rays")
+            accumulatedFramesCounter = 0;
+    }
     std::string s;
     bool useAnalyticIntersections = true;
     if (settings.getValueOpt("geometry_mode", s)) {

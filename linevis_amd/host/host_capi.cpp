@@ -119,8 +119,11 @@ void lvh_flow_build_render_data_elliptic(void* hp, float bandWidth, uint32_t* ou
 int lvh_flow_load_binlines(void* hp, const char* path) { return static_cast<FlowHandle*>(hp)->flow()->loadFromFile(path) ? 0 : -1; }
 int lvh_flow_save_binlines(void* hp, const char* path) {
     LineDataFlow* fl = static_cast<FlowHandle*>(hp)->flow();
-    return saveTrajectoriesAsBinLines(path, fl->getTrajectories(), fl->getRibbonsDirections()) ? 0 : -1;
+    return saveTrajectoriesAsBinLines(path, fl->getTrajectories(), fl->getRibbonsDirections(), fl->getVerticesNormalized()) ? 0 : -1;
 }
+/// the verticesNormalized flag of version-2 .binlines files (read: honoured by loadFromFile; written from this state)
+void lvh_flow_set_vertices_normalized(void* hp, int flag) { static_cast<FlowHandle*>(hp)->flow()->setVerticesNormalized(flag != 0); }
+int lvh_flow_vertices_normalized(void* hp) { return static_cast<FlowHandle*>(hp)->flow()->getVerticesNormalized() ? 1 : 0; }
 uint64_t lvh_flow_num_lines(void* hp) { return static_cast<FlowHandle*>(hp)->flow()->getNumLines(); }
 uint64_t lvh_flow_num_points(void* hp) { return static_cast<FlowHandle*>(hp)->flow()->getNumLinePoints(); }
 void lvh_flow_attribute_range(void* hp, float* out2) { static_cast<FlowHandle*>(hp)->data->getMinMaxAttributeValues(out2[0], out2[1]); }

@@ -40,6 +40,8 @@ def load():
         "lvh_flow_build_render_data_elliptic": (None, [vp, f32, C.POINTER(u32), C.POINTER(u32)]),
         "lvh_flow_load_binlines": (i32, [vp, cp]),
         "lvh_flow_save_binlines": (i32, [vp, cp]),
+        "lvh_flow_set_vertices_normalized": (None, [vp, i32]),
+        "lvh_flow_vertices_normalized": (i32, [vp]),
         "lvh_flow_num_lines": (u64, [vp]),
         "lvh_flow_num_points": (u64, [vp]),
         "lvh_flow_attribute_range": (None, [vp, vp]),
@@ -196,6 +198,15 @@ class LineDataFlow:
         if self.L.lvh_flow_load_binlines(self.h, path.encode()) != 0:
             raise IOError("loadTrajectoriesFromBinLines failed for %s" % path)
         return self
+
+    def set_vertices_normalized(self, flag=True):
+        """Declare the positions handed to set_trajectories as already normalised: saved as verticesNormalized in v2 files."""
+        self.L.lvh_flow_set_vertices_normalized(self.h, int(bool(flag)))
+        return self
+
+    @property
+    def vertices_normalized(self):
+        return bool(self.L.lvh_flow_vertices_normalized(self.h))
 
     def save_binlines(self, path):
         if self.L.lvh_flow_save_binlines(self.h, path.encode()) != 0:

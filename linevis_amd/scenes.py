@@ -17,6 +17,7 @@ class Trajectories:
     attributes: np.ndarray     # float32 [P]
     line_offsets: np.ndarray   # uint32 [L + 1]
     ribbon_directions: np.ndarray = None   # float32 [P, 3] or None: band data (LineDataFlow::ribbonsDirections)
+    vertices_normalized: bool = False      # verticesNormalized of a version-2 .binlines file (TrajectoryFile.cpp:656 skips normalisation)
 
     @property
     def num_lines(self):
@@ -233,11 +234,13 @@ def twisted_ribbons(tr, twist=6.0, seed=3):
 
 
 # ------------------------------------------------------------------ .binlines (BinLinesLoader.cpp:41-125,127-247)
-def write_binlines(path, tr):
+def write_binlines(path, tr, vertices_normalized=None):
     """Version 1: u32 version, u32 numTrajectories, u32 numAttributes, then per trajectory u32 numPoints, vec3[numPoints],
     float[numPoints] per attribute.  With band data version 2: the same, then u32 verticesNormalized, u32 hasAttributeNames (0),
     u32 hasRibbonData (1), vec3[numPoints] ribbon directions per trajectory, three u32 zeros (no outline mesh)."""
     v2 = tr.ribbon_directions is not None
+    if vertices_normalized is None:
+        vertices_normalized = bool(getattr(tr, "vertices_normalized", False))
     with open(path, "wb") as f:
         f.write(struct.pack("<III", 2 if v2 else 1, tr.num_lines, 1))
         for i in range(tr.num_lines):
@@ -246,7 +249,7 @@ def write_binlines(path, tr):
             f.write(np.ascontiguousarray(tr.positions[b:e], dtype="<f4").tobytes())
             f.write(np.ascontiguousarray(tr.attributes[b:e], dtype="<f4").tobytes())
         if v2:
-            f.write(struct.pack("<III", 1, 0, 1))
+            f.write(struct.pack("<III", 1 if vertices_normalized else 0, 0, 1))   # verticesNormalized: the real state of the positions
             f.write(np.ascontiguousarray(tr.ribbon_directions, dtype="<f4").tobytes())   # stored per trajectory = contiguous
             f.write(struct.pack("<III", 0, 0, 0))
 
@@ -287,7 +290,18 @@ def read_binlines(path, attribute_index=0):
         if has_ribbons:
             rib = np.frombuffer(data, dtype="<f4", count=3 * tr.num_points, offset=off).reshape(-1, 3)
             tr = Trajectories(tr.positions, tr.attributes, tr.line_offsets, np.array(rib, dtype=np.float32))
+        tr.vertices_normalized = bool(_normalized)
     return tr
+
+
+def load_flow_trajectories(path):
+    """loadFlowTrajectoriesFromFile for .binlines (TrajectoryFile.cpp:634-668): normalised unless the file says it already is."""
+    tr = read_binlines(path)
+    if tr.vertices_normalized:
+        return tr
+    out = normalize(tr)
+    out.vertices_normalized = True
+    return out
 
 
 # ------------------------------------------------------------------ .obj polylines (ObjLoader.cpp:36-186)

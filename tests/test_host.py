@@ -120,3 +120,37 @@ def test_obj_polylines_roundtrip(tmp_path):
     open(str(tmp_path / "lines.xyz"), "w").write("v 0 0 0\n")
     with pytest.raises(Exception):
         host_api.LineDataFlow().load_file(str(tmp_path / "lines.xyz"))
+
+
+def test_binlines_v2_vertices_normalized_flag(tmp_path):
+    """Version-2 files carry verticesNormalized: the reference skips normalisation when it is set (TrajectoryFile.cpp:656 -- its
+    streamline tracer exports grid-normalised lines that way) and the writer records the real state of the positions."""
+    tr = scenes.twisted_ribbons(scenes.normalize(scenes.random_curves(n_lines=4, points_per_line=12, seed=2)))
+    tr.positions[:] = tr.positions * np.float32(0.3) + np.float32(0.05)          # deliberately not in normalised position
+    flagged, plain = str(tmp_path / "flagged.binlines"), str(tmp_path / "plain.binlines")
+    scenes.write_binlines(flagged, tr, vertices_normalized=True)
+    scenes.write_binlines(plain, tr, vertices_normalized=False)
+    assert scenes.read_binlines(flagged).vertices_normalized and not scenes.read_binlines(plain).vertices_normalized
+    a = host_api.LineDataFlow().load_binlines(flagged)
+    pa = a.trajectories()[0]
+    assert np.array_equal(pa.view(np.uint32), tr.positions.view(np.uint32))        # flag set: positions taken as they are
+    b = host_api.LineDataFlow().load_binlines(plain)
+    pb = b.trajectories()[0]
+    assert np.array_equal(pb.view(np.uint32), scenes.normalize(tr).positions.view(np.uint32))   # not set: normalised on load
+    assert np.array_equal(scenes.load_flow_trajectories(plain).positions, pb) and np.array_equal(scenes.load_flow_trajectories(flagged).positions, pa)
+    # what the C++ writer records: loaded data are normalised by then; hand-fed data only if the caller says so
+    out = str(tmp_path / "out.binlines")
+    b.save_binlines(out)
+    assert scenes.read_binlines(out).vertices_normalized
+    c = host_api.LineDataFlow().set_trajectories(tr.positions, tr.attributes, tr.line_offsets, tr.ribbon_directions)
+    c.save_binlines(out)
+    assert not scenes.read_binlines(out).vertices_normalized
+    c.set_vertices_normalized(True).save_binlines(out)
+    assert scenes.read_binlines(out).vertices_normalized
+    # a truncated attribute-name length must fail cleanly, not allocate 4 GB
+    data = bytearray(open(flagged, "rb").read())
+    ntr = 12 + sum(4 + 12 * 12 + 4 * 12 for _ in range(4))
+    bad = bytes(data[:ntr]) + (1).to_bytes(4, "little") + (1).to_bytes(4, "little") + (0xFFFFFFF0).to_bytes(4, "little")
+    open(str(tmp_path / "trunc.binlines"), "wb").write(bad)
+    with pytest.raises(Exception):
+        host_api.LineDataFlow().load_binlines(str(tmp_path / "trunc.binlines"))

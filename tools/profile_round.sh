@@ -9,8 +9,13 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+# issue-rate / gather-rate calibration of this box (tools/ubench: built in the CPU container, shipped with the snapshot)
+mkdir -p $R/gpurun_out/ubench_$TAG
+timeout 600 $R/tools/ubench/_build/valu_rates > $R/gpurun_out/ubench_$TAG/valu_rates.json 2> $OUT/valu_rates.err
+timeout 600 $R/tools/ubench/_build/tcp_rates > $R/gpurun_out/ubench_$TAG/tcp_rates.json 2> $OUT/tcp_rates.err
+python $R/tools/summarize_ubench.py ubench_$TAG $TAG > $OUT/ubench_summary.json 2>> $OUT/valu_rates.err
 bash $R/tools/pmc_collect.sh $TAG c3c c3t > $OUT/pmc_full.log 2>&1
-LV_PMC_LITE=1 bash $R/tools/pmc_collect.sh $TAG c2 c4 c4m c4l > $OUT/pmc_lite.log 2>&1
+LV_PMC_LITE=1 bash $R/tools/pmc_collect.sh $TAG c2 c2e c4 c4m c4l c5 > $OUT/pmc_lite.log 2>&1
 for f in $R/gpurun_out/pmc_$TAG/*.json; do cp $f $R/profiles/pmc_${TAG}_$(basename $f); done   # bench.py reads profiles/
 python $R/bench.py > $OUT/bench_c3.json 2> $OUT/bench_c3.err
 for w in c3c c3t c2 c2e c4 c4m c4l c5; do

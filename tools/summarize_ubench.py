@@ -39,6 +39,20 @@ out = {
         "v_pk_fma_f32": valu["v_pk_fma_f32"]["ns_per_inst_per_simd"]},
     "tcp_lane_requests_per_cu_per_ns": {"own64_l1_hit": rate("own64 (4 x dwordx4)", 16), "own64_l2_hit": rate("own64 (4 x dwordx4)", 2048),
                                         "own16_l2_hit": rate("own16", 2048)},
+    # dense FMA throughput of the whole chip from the two rows above (wave64: 64 lanes x 2 flops per FMA, 1024 SIMDs), next to the
+    # datasheet figure they have to be read against (MI355X_MICROARCH.md: 157.3 TFLOP/s vector FP32 = one wave64 FMA per 2 cycles
+    # per SIMD at 2.4 GHz)
+    "dense_fma_tflops": {
+        "v_fma_f32": round(64 * 2 * 1024 / valu["v_fma_f32"]["ns_per_inst_per_simd"] / 1e3, 1),
+        "v_pk_fma_f32": round(64 * 4 * 1024 / valu["v_pk_fma_f32"]["ns_per_inst_per_simd"] / 1e3, 1),
+        "datasheet_vector_fp32": 157.3,
+        "cycles_per_wave64_inst": {"v_fma_f32": valu["v_fma_f32"]["cycles"], "v_pk_fma_f32": valu["v_pk_fma_f32"]["cycles"],
+                                   "datasheet_v_fma_f32": 2.0},
+        "reading": "the datasheet's 2-cycle FMA is reached only by the PACKED form (two FMAs per lane in ~4.2 cycles); an unpacked "
+                   "v_fma_f32 -- and every compare / select / convert / min / max the traversal consists of -- issues once per "
+                   "~3.5-4.1 cycles.  bench.py therefore reports two VALU fractions: `frac` against the measured rate of the node "
+                   "step's own instruction mix (what can actually bind) and `frac_vs_datasheet_issue` against 2 cycles per "
+                   "instruction (the marketing peak, unreachable for unpackable code)"},
     "valu_all": valu, "tcp_all": tcp,
     "reading": "VALU: 'full' ops (fma, max, cvt, cmp, cndmask, bfe, dpp ...) issue at ~4.1 cycles per wave64 instruction, the simple "
                "ones (mul, add, and, shifts, mov) at ~2.3; an fma overlaps with a following cvt / cmp / cndmask / mul (pair ~5 "
