@@ -152,36 +152,44 @@ inline vec3 rotateVector(vec3 v, float angle, vec3 normal) {
 }
 } // namespace
 
-// _pushRibbonDirections, StreamlineTracingGrid.cpp:1049-1116 (positions in TRACE order: outwards from the seed)
+// _pushRibbonDirections (StreamlineTracingGrid.cpp:1049-1116; positions in TRACE order: outwards from the seed) in two passes with
+// the same result, bit for bit: everything that depends on the positions alone -- unit tangents, the helicity twist angle of every
+// point (field lookup, segment length) -- is computed for all points first; what remains sequential is the carry itself: the ribbon
+// direction of a point is the previous one made perpendicular to this point's tangent (Gram-Schmidt, fallback axes z then y) and
+// turned about the tangent by this point's twist angle.
 void StreamlineTracingGrid::pushRibbonDirections(const StreamlineTracingSettings& tracingSettings,
                                                  const std::vector<float>& helicityField, float maxHelicityMagnitude,
                                                  const vec3* positions, size_t n, std::vector<vec3>& ribbonDirections,
                                                  bool forwardMode) const {
-    vec3 lastRibbonDirection = normalize(tracingSettings.initialRibbonDirection);
-    if (n == 1) { ribbonDirections.push_back(lastRibbonDirection); return; }
+    vec3 carried = normalize(tracingSettings.initialRibbonDirection);
+    if (n == 1) { ribbonDirections.push_back(carried); return; }
+    // ---- pass 1: per-point quantities (no dependence between points)
+    std::vector<vec3> unitTangent(n);
+    std::vector<float> twist(tracingSettings.useHelicity ? n : 0);
     for (size_t i = 0; i < n; i++) {
-        vec3 tangent;
-        if (i == 0) tangent = positions[i + 1] - positions[i];
-        else if (i == n - 1) tangent = positions[i] - positions[i - 1];
-        else tangent = positions[i + 1] - positions[i - 1];
-        tangent = normalize(tangent);
-        vec3 helperAxis = lastRibbonDirection;
-        if (length(cross(helperAxis, tangent)) < 1e-2f) {
-            helperAxis = vec3(0.0f, 0.0f, 1.0f);
-            if (length(cross(helperAxis, tangent)) < 1e-2f) helperAxis = vec3(0.0f, 1.0f, 0.0f);
-        }
-        vec3 ribbonDirection = normalize(helperAxis - dot(helperAxis, tangent) * tangent); // Gram-Schmidt
+        const vec3& ahead = positions[i + 1 < n ? i + 1 : i];
+        const vec3& behind = positions[i > 0 ? i - 1 : i];
+        unitTangent[i] = normalize(ahead - behind);      // one-sided at the two ends, central in between
         if (tracingSettings.useHelicity) {
             float helicity = getScalarFieldAtPosition(helicityField, positions[i]);
             if (!forwardMode) helicity *= -1.0f;
-            float lineSegmentLength = 0.0f;
-            if (i < n - 1) lineSegmentLength = length(positions[i + 1] - positions[i]);
-            const float helicityAngle = helicity / maxHelicityMagnitude * 3.14159265358979323846f * tracingSettings.maxHelicityTwist
-                                        * lineSegmentLength / 0.005f;
-            ribbonDirection = rotateVector(ribbonDirection, helicityAngle, tangent);
+            const float step = i + 1 < n ? length(positions[i + 1] - positions[i]) : 0.0f;
+            twist[i] = helicity / maxHelicityMagnitude * 3.14159265358979323846f * tracingSettings.maxHelicityTwist * step / 0.005f;
         }
-        ribbonDirections.push_back(ribbonDirection);
-        lastRibbonDirection = ribbonDirection;
+    }
+    // ---- pass 2: the carry
+    const size_t first = ribbonDirections.size();
+    ribbonDirections.resize(first + n);
+    for (size_t i = 0; i < n; i++) {
+        const vec3 t = unitTangent[i];
+        vec3 axis = carried;
+        if (length(cross(axis, t)) < 1e-2f) {            // tangent (anti)parallel to the carried direction
+            axis = vec3(0.0f, 0.0f, 1.0f);
+            if (length(cross(axis, t)) < 1e-2f) axis = vec3(0.0f, 1.0f, 0.0f);
+        }
+        carried = normalize(axis - dot(axis, t) * t);    // Gram-Schmidt
+        if (tracingSettings.useHelicity) carried = rotateVector(carried, twist[i], t);
+        ribbonDirections[first + i] = carried;
     }
 }
 

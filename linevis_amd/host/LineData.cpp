@@ -448,87 +448,126 @@ std::vector<std::vector<vec3>> LineDataFlow::getFilteredLines(LineRenderer*) {
     return lines;
 }
 
-// LineDataFlow.cpp:2112-2277.  The per-line loop carries lastLineNormal from point to point, so lines are the unit
-// of parallelism: every line is processed into its own vectors (OpenMP), then concatenated in line order.
+// getLinePassTubeAabbRenderData (LineDataFlow.cpp:2112-2277) as three passes over SoA scratch arrays instead of the reference's one
+// append-as-you-go loop; the output is byte-identical to it (tests/test_host.py, tests/test_independent_restatement.py):
+//   pass 1 (per line, data parallel over the points)   central-difference tangents, their lengths, the "keep this point" flags
+//                                                      (|tangent| >= 1e-4, :2160) and the number of kept points per line
+//   prefix sum over the lines                          where each line's records, index pairs and boxes go -- a line that keeps
+//                                                      fewer than two points keeps none (:2209-2221)
+//   pass 2 (per line, one short sequential chain)      the only true recurrence: the line normal is carried from kept point to
+//                                                      kept point (Gram-Schmidt against the tangent with the fallback axes of
+//                                                      :2171-2177; band data: cross(ribbon direction, tangent), :2166-2168) and
+//                                                      the helicity rotation accumulates along the line (:2188-2197)
+//   pass 3 (per line, data parallel)                   48-byte records, index pairs and padded boxes written in place
+// Lines are independent, so every pass is an OpenMP loop over lines; nothing is concatenated afterwards.
 TubeAabbRenderData LineDataFlow::getLinePassTubeAabbRenderData(bool /*isRasterizer*/, bool ellipticTubes) {
-    // elliptic tubes of a band data set: normals from the ribbon directions, boxes padded by half the band width (:2120-2126)
     const bool useRibbonNormals = ellipticTubes && useRibbons && hasBandsData;
     const float lineWidth = useRibbonNormals ? LineRenderer::getBandWidth() : LineRenderer::getLineWidth();
     const bool helicityBands = getUseRotatingHelicityBands();
     if (cachedAabbDataValid && cachedLineWidth == lineWidth && cachedEllipticTubes == useRibbonNormals &&
         cachedHelicityBands == helicityBands)
         return cachedTubeAabbRenderData;
-    const vec3 lineWidthOffset(lineWidth * 0.5f);
+    const vec3 pad(lineWidth * 0.5f);
     const size_t numLines = trajectories.size();
-    std::vector<std::vector<LinePointDataUnified>> perLine(numLines);
 
+    // ---- pass 1: tangents + keep flags (SoA per line, flattened over all points)
+    std::vector<size_t> pointOffset(numLines + 1, 0);
+    for (size_t li = 0; li < numLines; li++) pointOffset[li + 1] = pointOffset[li] + trajectories[li].positions.size();
+    std::vector<vec3> unitTangent(pointOffset[numLines]);
+    std::vector<uint8_t> keep(pointOffset[numLines], 0);
+    std::vector<uint32_t> keptPerLine(numLines, 0);
 #pragma omp parallel for schedule(dynamic, 16)
-    for (long li = 0; li < long(numLines); li++) {
-        const Trajectory& trajectory = trajectories[size_t(li)];
-        std::vector<LinePointDataUnified>& out = perLine[size_t(li)];
-        const size_t n = trajectory.positions.size();
+    for (long lli = 0; lli < long(numLines); lli++) {
+        const size_t li = size_t(lli);
+        const std::vector<vec3>& P = trajectories[li].positions;
+        const size_t n = P.size();
         if (n < 2) continue;
-        out.reserve(n);
-        vec3 lastLineNormal(1.0f, 0.0f, 0.0f);
-        float rotation = 0.0f; // useRotatingHelicityBands, :2148
+        vec3* T = unitTangent.data() + pointOffset[li];
+        uint8_t* K = keep.data() + pointOffset[li];
+        uint32_t kept = 0;
         for (size_t i = 0; i < n; i++) {
-            vec3 tangent;
-            if (i == 0) tangent = trajectory.positions[i + 1] - trajectory.positions[i];
-            else if (i + 1 == n) tangent = trajectory.positions[i] - trajectory.positions[i - 1];
-            else tangent = trajectory.positions[i + 1] - trajectory.positions[i - 1];
-            float tangentLength = length(tangent);
-            if (tangentLength < 0.0001f) continue; // two (almost) identical vertices: skip this point
-            tangent = normalize(tangent);
-            vec3 helperAxis = lastLineNormal;
-            if (length(cross(helperAxis, tangent)) < 0.01f) {
-                helperAxis = vec3(0.0f, 1.0f, 0.0f);
-                if (length(cross(helperAxis, tangent)) < 0.01f) helperAxis = vec3(0.0f, 0.0f, 1.0f);
-            }
-            vec3 normal = normalize(helperAxis - dot(helperAxis, tangent) * tangent); // Gram-Schmidt
-            if (useRibbonNormals) normal = cross(ribbonsDirections[size_t(li)][i], tangent); // :2166-2168 (not normalised)
-            lastLineNormal = normal;
-            LinePointDataUnified lp;
-            memset(&lp, 0, sizeof(lp));
-            const vec3& p = trajectory.positions[i];
-            lp.linePosition[0] = p.x; lp.linePosition[1] = p.y; lp.linePosition[2] = p.z;
-            lp.lineAttribute = trajectory.attributes.empty()
-                    ? 0.0f : trajectory.attributes[size_t(selectedAttributeIndex)][i];
-            lp.lineTangent[0] = tangent.x; lp.lineTangent[1] = tangent.y; lp.lineTangent[2] = tangent.z;
-            lp.lineNormal[0] = normal.x; lp.lineNormal[1] = normal.y; lp.lineNormal[2] = normal.z;
-            if (helicityBands) { // :2188-2197
-                lp.lineRotation = rotation;
-                const float helicity = trajectory.attributes[size_t(helicityAttributeIndex)][i];
-                float lineSegmentLength = 0.0f;
-                if (i < n - 1) lineSegmentLength = length(trajectory.positions[i + 1] - trajectory.positions[i]);
-                rotation += helicity / maxHelicity * 3.1415926535897932f * lineSegmentLength / 0.005f;
-            }
-            out.push_back(lp);
+            const vec3& ahead = P[i + 1 < n ? i + 1 : i];
+            const vec3& behind = P[i > 0 ? i - 1 : i];
+            const vec3 d = ahead - behind;          // one-sided at the two ends, central in between
+            const float len = length(d);
+            const bool k = !(len < 0.0001f);
+            K[i] = k ? 1 : 0;
+            if (k) { T[i] = normalize(d); kept++; }
         }
-        if (out.size() <= 1) out.clear(); // a tube of one point is dropped
+        keptPerLine[li] = kept >= 2 ? kept : 0u;    // a tube of one point is dropped
     }
 
+    // ---- where every line's output goes
+    std::vector<uint32_t> recordOffset(numLines + 1, 0);
+    std::vector<size_t> segmentOffset(numLines + 1, 0);
+    for (size_t li = 0; li < numLines; li++) {
+        recordOffset[li + 1] = recordOffset[li] + keptPerLine[li];
+        segmentOffset[li + 1] = segmentOffset[li] + (keptPerLine[li] ? keptPerLine[li] - 1 : 0);
+    }
     TubeAabbRenderData data;
-    size_t totalPoints = 0, totalSegs = 0;
-    for (const auto& l : perLine) { totalPoints += l.size(); totalSegs += l.empty() ? 0 : l.size() - 1; }
-    data.linePointDataBuffer.reserve(totalPoints);
-    data.indexBuffer.reserve(2 * totalSegs);
-    data.aabbBuffer.reserve(totalSegs);
-    uint32_t lineSegmentIndexCounter = 0;
-    for (const auto& l : perLine) {
-        if (l.empty()) continue;
-        data.linePointDataBuffer.insert(data.linePointDataBuffer.end(), l.begin(), l.end());
-        for (uint32_t pointIdx = 1; pointIdx < uint32_t(l.size()); pointIdx++) {
-            data.indexBuffer.push_back(lineSegmentIndexCounter + pointIdx - 1);
-            data.indexBuffer.push_back(lineSegmentIndexCounter + pointIdx);
-            const float* a = l[pointIdx - 1].linePosition;
-            const float* b = l[pointIdx].linePosition;
-            vec3 pt0(a[0], a[1], a[2]), pt1(b[0], b[1], b[2]);
-            AABB3 aabb;
-            aabb.min = lv::min(pt0, pt1) - lineWidthOffset;
-            aabb.max = lv::max(pt0, pt1) + lineWidthOffset;
-            data.aabbBuffer.push_back(aabb);
+    data.linePointDataBuffer.assign(recordOffset[numLines], LinePointDataUnified{});
+    data.indexBuffer.assign(2 * segmentOffset[numLines], 0u);
+    data.aabbBuffer.assign(segmentOffset[numLines], AABB3{});
+
+#pragma omp parallel for schedule(dynamic, 16)
+    for (long lli = 0; lli < long(numLines); lli++) {
+        const size_t li = size_t(lli);
+        const uint32_t kept = keptPerLine[li];
+        if (!kept) continue;
+        const Trajectory& trajectory = trajectories[li];
+        const std::vector<vec3>& P = trajectory.positions;
+        const size_t n = P.size();
+        const vec3* T = unitTangent.data() + pointOffset[li];
+        const uint8_t* K = keep.data() + pointOffset[li];
+        LinePointDataUnified* rec = data.linePointDataBuffer.data() + recordOffset[li];
+        const float* attribute = trajectory.attributes.empty() ? nullptr : trajectory.attributes[size_t(selectedAttributeIndex)].data();
+        const float* helicity = helicityBands ? trajectory.attributes[size_t(helicityAttributeIndex)].data() : nullptr;
+        // ---- pass 2: the carried quantities, kept points only
+        vec3 carried(1.0f, 0.0f, 0.0f);             // lastLineNormal
+        float rotation = 0.0f;
+        uint32_t o = 0;
+        for (size_t i = 0; i < n; i++) {
+            if (!K[i]) continue;
+            const vec3 t = T[i];
+            if (useRibbonNormals) {
+                carried = cross(ribbonsDirections[li][i], t);                  // not normalised, as in the reference
+            } else {
+                vec3 axis = carried;
+                if (length(cross(axis, t)) < 0.01f) {                           // tangent (anti)parallel to the previous normal
+                    axis = vec3(0.0f, 1.0f, 0.0f);
+                    if (length(cross(axis, t)) < 0.01f) axis = vec3(0.0f, 0.0f, 1.0f);
+                }
+                carried = normalize(axis - dot(axis, t) * t);                   // Gram-Schmidt
+            }
+            LinePointDataUnified& r = rec[o++];
+            r.lineNormal[0] = carried.x; r.lineNormal[1] = carried.y; r.lineNormal[2] = carried.z;
+            if (helicityBands) {
+                r.lineRotation = rotation;
+                const float step = i + 1 < n ? length(P[i + 1] - P[i]) : 0.0f;
+                rotation += helicity[i] / maxHelicity * 3.1415926535897932f * step / 0.005f;
+            }
         }
-        lineSegmentIndexCounter += uint32_t(l.size());
+        // ---- pass 3: the rest of the records, the index pairs and the padded boxes
+        o = 0;
+        const uint32_t base = recordOffset[li];
+        uint32_t* idx = data.indexBuffer.data() + 2 * segmentOffset[li];
+        AABB3* box = data.aabbBuffer.data() + segmentOffset[li];
+        vec3 previous;
+        for (size_t i = 0; i < n; i++) {
+            if (!K[i]) continue;
+            LinePointDataUnified& r = rec[o];
+            r.linePosition[0] = P[i].x; r.linePosition[1] = P[i].y; r.linePosition[2] = P[i].z;
+            r.lineAttribute = attribute ? attribute[i] : 0.0f;
+            r.lineTangent[0] = T[i].x; r.lineTangent[1] = T[i].y; r.lineTangent[2] = T[i].z;
+            if (o > 0) {
+                idx[2 * (o - 1)] = base + o - 1;
+                idx[2 * (o - 1) + 1] = base + o;
+                box[o - 1].min = lv::min(previous, P[i]) - pad;
+                box[o - 1].max = lv::max(previous, P[i]) + pad;
+            }
+            previous = P[i];
+            o++;
+        }
     }
     cachedTubeAabbRenderData = data;
     cachedAabbDataValid = true;

@@ -2261,6 +2261,14 @@ void lvo_ribbon_of_rays(const float* cam, const float* dirs, uint64_t n, const f
         out[i] = capHit ? capRibbonOfRay(ld3(cam), ld3(dirs + 3 * i), ld3(capHit), ld3(capNormal), ld3(axisPoint), ld3(axisDir))
                         : tubeRibbonOfRay(ld3(cam), ld3(dirs + 3 * i), ld3(axisPoint), ld3(axisDir), radius);
 }
+// Test hook: getAoFactor(interpolatedVertexId, phi) of the static prebaker (AmbientOcclusion.glsl:49-75 up to the mix of the four
+// table entries; pow(gamma) / strength are applied by the shading code) on n inputs
+void lvo_prebaked_ao_lookup_batch(const float* factors, const float* blendingWeights, uint32_t numLineVertices,
+                                  uint32_t numParametrizationVertices, uint32_t numAoTubeSubdivisions, const float* vertexId,
+                                  const float* phi, uint64_t n, float* out) {
+    PrebakedAo pb{factors, blendingWeights, numLineVertices, numParametrizationVertices, numAoTubeSubdivisions};
+    for (uint64_t i = 0; i < n; i++) out[i] = prebakedAoLookup(pb, vertexId[i], phi[i]);
+}
 void lvo_pow_det(const float* x, const float* y, uint64_t n, float* out) {
     for (uint64_t i = 0; i < n; i++) out[i] = powDet(x[i], y[i]);
 }

@@ -375,6 +375,9 @@ void lvo_set_deviation_switches(int literalIntersection, int referenceAoLookup);
 void lvo_set_ppll_fragment_colour_variant(int rayTracerVariant);
 /* the build-owned pow of the shading code (powDet = lv_pow_det of the HIP library) on n inputs */
 void lvo_pow_det(const float* x, const float* y, uint64_t n, float* out);
+void lvo_prebaked_ao_lookup_batch(const float* factors, const float* blendingWeights, uint32_t numLineVertices,
+                                  uint32_t numParametrizationVertices, uint32_t numAoTubeSubdivisions, const float* vertexId,
+                                  const float* phi, uint64_t n, float* out);
 void lvo_compute_fragment_color_raster_batch(const lvo_scene* sc, const lvo_params* P, uint64_t n, const float* fragPos,
                                              const float* normal, const float* tangent, const uint32_t* isCap, const float* attribute,
                                              const float* aoTexel, const float* epsWhite, float* outColor, float* outHitT);

@@ -112,6 +112,7 @@ def lib():
     L.lvo_ribbon_of_rays.argtypes = [vp, vp, C.c_uint64, vp, vp, f32, vp, vp, vp]
     L.lvo_set_ppll_fragment_colour_variant.argtypes = [i32]
     L.lvo_pow_det.argtypes = [vp, vp, C.c_uint64, vp]
+    L.lvo_prebaked_ao_lookup_batch.argtypes = [vp, vp, u32, u32, u32, vp, vp, C.c_uint64, vp]
     L.lvo_num_threads.restype = i32
     L.lvo_num_threads.argtypes = []
     L.lvo_tea.restype = u32
@@ -752,6 +753,18 @@ def set_num_threads(n):
 def num_threads():
     """Threads the oracle's OpenMP loops run on."""
     return int(lib().lvo_num_threads())
+
+
+def prebaked_ao_lookup(factors, blending_weights, num_subdivisions, vertex_id, phi):
+    """Test hook: the static prebaker's table lookup (AmbientOcclusion.glsl:49-75 without pow / strength) on n inputs."""
+    f = np.ascontiguousarray(factors, dtype=np.float32).reshape(-1)
+    bw = np.ascontiguousarray(blending_weights, dtype=np.float32)
+    v = np.ascontiguousarray(vertex_id, dtype=np.float32)
+    p = np.ascontiguousarray(phi, dtype=np.float32)
+    out = np.empty(len(v), dtype=np.float32)
+    lib().lvo_prebaked_ao_lookup_batch(_p(f), _p(bw), len(bw), len(f) // int(num_subdivisions), int(num_subdivisions), _p(v), _p(p),
+                                       len(v), _p(out))
+    return out
 
 
 def pow_det(x, y):
