@@ -258,3 +258,81 @@ def test_prebaked_ao_lookup_against_the_float64_restatement():
     same = (np.floor(phi.astype(np.float64) / (2 * np.pi) * n_sub) == np.floor((phi / np.float32(2 * np.pi) * np.float32(n_sub)).astype(np.float64)))
     assert same.mean() > 0.999
     assert np.abs(got[same] - want[same]).max() < 5e-5
+
+
+# ---------------------------------------------------------------- ClosestHitTubeTriangles + LineAttributesBarycentric.glsl
+def render_rt_triangles_float64(c, P, mesh):
+    """The ray tracer's "Triangle Mesh" geometry mode in float64: closest Moeller-Trumbore hit over all triangles (the driver's test is
+    unobservable; any exact test gives the same closest hit away from edges), barycentric interpolation of position / vertex normal /
+    line tangent / attribute (TubeRayTracing.glsl:336-346, LineAttributesBarycentric.glsl:1-38), isCap from bit 31 of the vertices'
+    line-point indices, computeFragmentColor, opaque transfer function (one layer)."""
+    idx, verts, lpts = mesh
+    W, H = c.width, c.height
+    view = np.asarray(P.view[:], np.float64)
+    cam = ir.camera_position(view)
+    inv_proj = np.linalg.inv(np.asarray(P.proj[:], np.float64).reshape(4, 4).T)
+    inv_view = np.linalg.inv(view.reshape(4, 4).T)
+    ys, xs = np.mgrid[0:H, 0:W]
+    ndc = np.stack([2.0 * (xs + 0.5) / W - 1.0, 2.0 * (ys + 0.5) / H - 1.0, np.ones((H, W)), np.ones((H, W))], -1).reshape(-1, 4)
+    tgt = ndc @ inv_proj.T
+    dn = tgt[:, :3] / np.linalg.norm(tgt[:, :3], axis=1, keepdims=True)
+    d = (np.concatenate([dn, np.zeros((len(dn), 1))], 1) @ inv_view.T)[:, :3]
+    vp = verts["vertexPosition"].astype(np.float64)
+    v0, v1, v2 = vp[idx[:, 0]], vp[idx[:, 1]], vp[idx[:, 2]]
+    e1, e2 = v1 - v0, v2 - v0
+    best_t = np.full(len(d), np.inf); best_tri = np.full(len(d), -1); best_u = np.zeros(len(d)); best_v = np.zeros(len(d))
+    for k in range(len(idx)):
+        p = np.cross(d, e2[k])
+        det = p @ e1[k]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            inv = 1.0 / det
+            tv = cam - v0[k]
+            u = (p @ tv) * inv
+            q = np.cross(tv, e1[k])
+            v = (d @ q) * inv
+            t = (q @ e2[k]) * inv
+        ok = (det != 0) & (u >= 0) & (u <= 1) & (v >= 0) & (u + v <= 1) & (t >= 1e-4) & (t <= 1000.0) & (t < best_t)
+        best_t = np.where(ok, t, best_t); best_tri = np.where(ok, k, best_tri); best_u = np.where(ok, u, best_u); best_v = np.where(ok, v, best_v)
+    hit = best_tri >= 0
+    out = np.tile(np.asarray(P.background[:], np.float64), (len(d), 1))
+    ih = np.nonzero(hit)[0]
+    tri = idx[best_tri[ih]]
+    b = np.stack([1.0 - best_u[ih] - best_v[ih], best_u[ih], best_v[ih]], 1)      # barycentricCoordinates, :336
+    lin = lambda a0, a1, a2: a0 * b[:, :1] + a1 * b[:, 1:2] + a2 * b[:, 2:3]
+    li = verts["vertexLinePointIndex"][tri]
+    is_cap = ((li >> 31) != 0).any(axis=1) & bool(P.useCappedTubes)
+    lpi = li & 0x7FFFFFFF
+    fp = lin(vp[tri[:, 0]], vp[tri[:, 1]], vp[tri[:, 2]])
+    vn = verts["vertexNormal"].astype(np.float64)
+    normal = lin(vn[tri[:, 0]], vn[tri[:, 1]], vn[tri[:, 2]])
+    lt = lpts["lineTangent"].astype(np.float64)
+    tangent = lin(lt[lpi[:, 0]], lt[lpi[:, 1]], lt[lpi[:, 2]])
+    la = lpts["lineAttribute"].astype(np.float64)
+    attr = la[lpi[:, 0]] * b[:, 0] + la[lpi[:, 1]] * b[:, 1] + la[lpi[:, 2]] * b[:, 2]
+    col, _ = ir.compute_fragment_color(c.tf.astype(np.float64), P, fp, normal, tangent, is_cap, attr, np.ones(len(ih)))
+    # one opaque layer: traceRayTransparent stops after it (alpha 1 > 0.99); the silhouette coverage < 1 lets the next layer /
+    # the background through -- kept out of the comparison below
+    out[ih, :3] = col[:, 3:4] * col[:, :3]
+    out[ih, 3] = col[:, 3]
+    return out.reshape(H, W, 4), hit.reshape(H, W), (col[:, 3] > 0.999), ih
+
+
+def test_triangle_mesh_frame_against_the_float64_restatement():
+    lw = 0.05
+    tr = scenes.normalize(scenes.random_curves(n_lines=8, points_per_line=8, seed=4))
+    pts, seg, _ = lvo.build_tube_aabb_render_data(tr.positions, tr.attributes, tr.line_offsets, lw)
+    mesh = lvo.build_tube_triangle_render_data(tr.positions, tr.attributes, tr.line_offsets, lw, 6)
+    c = Case(pts, seg, tfm.standard(), 64, 48, lw, background=(0.9, 0.95, 1.0, 1.0))
+    sc = c.oracle_scene()
+    P = c.oracle_params(sc)
+    got = lvo.TriScene(*mesh, lw).render_rt(sc, P, use_bvh=False)
+    want, hit, solid, ih = render_rt_triangles_float64(c, P, mesh)
+    solid_px = np.zeros(64 * 48, bool); solid_px[ih[solid]] = True
+    solid_px = solid_px.reshape(48, 64)
+    assert solid_px.sum() > 150
+    want8 = np.floor(np.clip(want, 0.0, 1.0) * 255.0 + 0.5).astype(np.int32)
+    d = np.abs(got.astype(np.int32) - want8).max(axis=2)
+    # pixels whose front fragment is fully covered (coverage 1): the frame IS that fragment
+    assert (d[solid_px] <= 1).mean() > 0.99 and (d[solid_px] > 2).sum() <= 4, ((d[solid_px] > 1).sum(), d[solid_px].max())
+    # background pixels agree (a ray grazing a silhouette may hit in float32 and miss in float64 or vice versa)
+    assert (np.abs(got[~hit].astype(np.int32) - want8[~hit]).max(axis=1) == 0).mean() > 0.995
