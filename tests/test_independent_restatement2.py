@@ -335,4 +335,5 @@ def test_triangle_mesh_frame_against_the_float64_restatement():
     # pixels whose front fragment is fully covered (coverage 1): the frame IS that fragment
     assert (d[solid_px] <= 1).mean() > 0.99 and (d[solid_px] > 2).sum() <= 4, ((d[solid_px] > 1).sum(), d[solid_px].max())
     # background pixels agree (a ray grazing a silhouette may hit in float32 and miss in float64 or vice versa)
-    assert (np.abs(got[~hit].astype(np.int32) - want8[~hit]).max(axis=1) == 0).mean() > 0.995
+    # (<= 1: the background 0.9 * 255 + 0.5 rounds to 230.0 in float32 and to 229.99999 in float64)
+    assert (np.abs(got[~hit].astype(np.int32) - want8[~hit]).max(axis=1) <= 1).mean() > 0.995
