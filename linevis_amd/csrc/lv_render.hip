@@ -446,6 +446,7 @@ __global__ __launch_bounds__(LV_AO_BLOCK, LV_AO_MIN_WAVES) void k_ao_rays(const 
                         if (STATS) primHits++;
                     }
                 }
+#ifndef LV_AO_IDLE_PROBE
                 if (STATS && PRIM == LV_PRIM_CAPSULE) {
                     const float4 sa = S.segs[2 * size_t(leaf)], sb = S.segs[2 * size_t(leaf) + 1];
                     const f3 ro = mk3(r0.x, r0.y, r1.x), rd = mk3(r1.y, r2.x, r2.y);
@@ -454,6 +455,7 @@ __global__ __launch_bounds__(LV_AO_BLOCK, LV_AO_MIN_WAVES) void k_ao_rays(const 
                     mayAxis += ma ? 1u : 0u;
                     mayBoth += (ma && mb) ? 1u : 0u;
                 }
+#endif
             }
             head += n;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -588,6 +590,12 @@ __global__ __launch_bounds__(LV_AO_BLOCK, LV_AO_MIN_WAVES) void k_ao_rays(const 
             do {
                 if (STATS && lane == 0) { phIt[1]++; }
                 if (STATS && !(cur & LV_LEAF_BIT)) phLn[1]++;
+#ifdef LV_AO_IDLE_PROBE // tools/variants.py: why lanes idle in the descend loop -- (a) their ray waits for queued leaf tests, (b) no ray
+                if (STATS) {
+                    const unsigned long long mW = __ballot(hasRay && cur == LV_INVALID), mE = __ballot(!hasRay);
+                    if (lane == 0) { mayAxis += unsigned(__popcll(mW)); mayBoth += unsigned(__popcll(mE)); }
+                }
+#endif
                 if (!(cur & LV_LEAF_BIT)) cur = lv_node_step<STATS, LV_AO_ORDERED>(S, cur, oi, inv, 0.0f - litSlack, best + litSlack, st, cnt);
                 const bool isLeaf = cur != LV_INVALID && (cur & LV_LEAF_BIT);
                 const unsigned long long mL = __ballot(isLeaf);
