@@ -187,8 +187,13 @@ int lv_set_background(lv_ctx* ctx, const float rgba[4]);
  *   with collect_stats: record the candidate visiting order of an MLAT frame for lv_get_mlat_trace; records, 4 Mi),
  *   rtao_geometry (build-owned): "capsules" (default: AO rays hit the analytic capsules of the colour pass) or
  *   "triangle_tubes" (the reference's RTAO geometry: the mesh set with lv_set_tube_triangle_mesh),
- *   intersection_form (build-owned): "closest_approach" (default) | "literal" (the reference's textbook roots,
- *   RayIntersectionTestsVulkan.glsl:39-119, with the own-box rule that keeps them independent of the BVH),
+ *   intersection_form (build-owned): "auto" (default: "literal" whenever rtao_geometry = "triangle_tubes", i.e. whenever the
+ *   frame is the reference-faithful one and the colour pass is the only user of the capsule test; "closest_approach" otherwise) |
+ *   "literal" (the reference's textbook roots, RayIntersectionTestsVulkan.glsl:39-119, with the own-box rule that keeps them
+ *   independent of the BVH) | "closest_approach" (the same roots evaluated stably: NOT the reference's formula),
+ *   ppll_fragment_colour (build-owned): "raster" (default: the PPLL gather shades with the raster tube shader's variant of
+ *   computeFragmentColor, LinePassGeometryShaderTubes.glsl:785-815,1079-1087 -- EPSILON_OUTLINE = 0, EPSILON_WHITE =
+ *   fwidth(ribbonPosition) over the 2 x 2 pixel quad, cap halo min(rp, |rp2|)) | "ray_tracer" (RayHitCommon.glsl's, a probe),
  *   ambient_occlusion_denoiser ("None" | "Edge-Avoiding A-Trous Wavelet Transform" (UTF-8 A-grave as in Denoiser.hpp:66; "EAW"
  *   is accepted too) | "SVGF")                                         (VulkanRayTracedAmbientOcclusion.cpp:683-696)
  *   eaw_denoiser_iterations (0..5, default 3), eaw_denoiser_color_weights / _position_weights / _normal_weights,
