@@ -520,6 +520,18 @@ def main():
         def step():
             return pipe.submit()
 
+        # ONE GPU owns every tile: nothing to gather or de-tile -- the frame is one lv_render_device call straight into the
+        # [H, W, 4] image on the context's stream (LV_BENCH_TILED=1 keeps the N > 1 code path: tile list + de-tiling pass)
+        direct = world == 1 and not dry and not os.environ.get("LV_BENCH_TILED")
+        mark_stream = None
+        if direct:
+            image = torch.empty((H, W, 4), dtype=torch.uint8, device=device)
+            mark_stream = render_fn.stream
+
+            def step():   # noqa: F811
+                ctx.render_device(image.data_ptr(), mode=w["mode"])
+                return image
+
         # ---- untimed instrumented frame: rays traced + algorithmic traffic of this rank's tiles
         ctx.set_option("collect_stats", True)
         step()
@@ -569,13 +581,13 @@ def main():
         marks = []
         if not dry:   # per-frame durations on the stream the kernels and the gather run on (no host sync inside the loop)
             marks = [torch.cuda.Event(enable_timing=True) for _ in range(min(args.steps, 512) + 1)]
-            marks[0].record()
+            marks[0].record(mark_stream)
         t0 = time.perf_counter()
         frame = None
         for i in range(args.steps):
             frame = step()
             if i + 1 < len(marks):
-                marks[i + 1].record()
+                marks[i + 1].record(mark_stream)
         sync_all()
         elapsed = time.perf_counter() - t0
         gc.enable()
@@ -615,9 +627,11 @@ def main():
             "config": {"workload": wl["name"], "resolution": [W, H], "segments": int(len(seg)) if seg is not None else 0,
                        "rays_per_frame": int(head["rays_per_frame"]), "ao_hit_pixels": int(head["counters"][4].item()),
                        "fragments_per_frame": int(head["counters"][5].item()),
-                       "parallelism": "screen tiles %dx%d in Morton order, dealt over %d GPU(s) by measured cost (RTAO hit pixels per tile "
-                                      "of the instrumented frame; round robin for workloads without RTAO), one RCCL gather per frame"
-                                      % (TILE, TILE, world),
+                       "parallelism": ("one GPU: the whole frame in one lv_render_device call (no tiles to gather), 64x64-pixel groups "
+                                       "dispatched heaviest-of-the-previous-frame first" if world == 1 and not dry else
+                                       "screen tiles %dx%d in Morton order, dealt over %d GPU(s) by measured cost (RTAO hit pixels per "
+                                       "tile of the instrumented frame; round robin for workloads without RTAO), one RCCL gather per "
+                                       "frame" % (TILE, TILE, world)),
                        "accel_build_ms": round(head["build_ms"], 3), "accel_build_first_ms": round(head["build_first_ms"], 3),
                        "bvh_depth": int(st.bvh_depth), "tube_triangles": int(st.num_tube_triangles)},
             "frame_ms": head["frame_ms"],

@@ -272,6 +272,14 @@ int lv_get_kernel_times(lv_ctx* ctx, int kernel_id, float* out_ms, uint32_t capa
  * load balance by tile dealing -- the reference itself is single-GPU).  LV_E_STATE unless the last call ran the RTAO pass. */
 int lv_get_ao_tile_costs(lv_ctx* ctx, uint32_t* out_counts, uint32_t capacity, uint32_t* out_count, uint32_t* out_groups_per_tile);
 
+/* Dispatch order of the tile kernels (option dispatch_order = cost, the default): the 64x64-pixel groups of the last
+ * lv_render* call's tile list in the order their workgroups were started -- heaviest group of the frame before first (longest
+ * processing time first; groups are numbered tile-major, `groups per tile` consecutive entries per tile) -- and what every
+ * group cost in the last call (device clock ticks summed over its waves: the input of the next call's order).  No counterpart
+ * in the reference (the Vulkan driver schedules its ray-generation workgroups); which workgroup renders which group never
+ * shows in the image.  *out_count = 0 when the order is off or the launch has fewer than 2 / more than 8192 groups. */
+int lv_get_dispatch_order(lv_ctx* ctx, uint32_t* out_order, uint32_t* out_cost, uint32_t capacity, uint32_t* out_count);
+
 /* ---- streamline tracing: the producer of the line sets ----
  * StreamlineTracingGrid (src/LineData/Flow/StreamlineTracingGrid.cpp): regular grid of xs*ys*zs cells with spacing
  * (dx, dy, dz) and origin 0 (setGridExtent, :81-116), one vector field (3 floats per cell, x fastest: IDXV of

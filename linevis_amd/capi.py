@@ -82,7 +82,7 @@ class LineVisError(RuntimeError):
 # every symbol include/linevis_hip.h declares (checked by tests/test_abi.py against the header text)
 SYMBOLS = ["lv_create", "lv_destroy", "lv_last_error", "lv_version", "lv_set_stream", "lv_set_lines",
            "lv_set_transfer_function", "lv_set_camera", "lv_set_background", "lv_set_option", "lv_build_accel",
-           "lv_render", "lv_render_device", "lv_render_tiles_device", "lv_get_stats", "lv_reset_timers", "lv_get_kernel_times", "lv_get_ao_tile_costs", "lv_trace_rays",
+           "lv_render", "lv_render_device", "lv_render_tiles_device", "lv_get_stats", "lv_reset_timers", "lv_get_kernel_times", "lv_get_ao_tile_costs", "lv_get_dispatch_order", "lv_trace_rays",
            "lv_compute_depth_range", "lv_get_ao", "lv_ppll_get_buffers", "lv_ppll_resolve_buffers", "lv_get_accel",
            "lv_set_tube_triangle_mesh", "lv_trace_rays_triangles", "lv_set_flow_grid", "lv_trace_streamlines",
            "lv_get_streamlines", "lv_get_streamline_seed_indices", "lv_set_ao_parametrization", "lv_get_baked_ao", "lv_get_mlat_trace",
@@ -142,6 +142,7 @@ def load():
         ("lv_reset_timers", [vp]),
         ("lv_get_kernel_times", [vp, i32, vp, u32, C.POINTER(u32)]),
         ("lv_get_ao_tile_costs", [vp, vp, u32, C.POINTER(u32), C.POINTER(u32)]),
+        ("lv_get_dispatch_order", [vp, vp, vp, u32, C.POINTER(u32)]),
         ("lv_trace_rays", [vp, vp, vp, f32, f32, u32, vp, vp, vp]),
         ("lv_compute_depth_range", [vp, vp]),
         ("lv_get_ao", [vp, vp]),
@@ -398,6 +399,16 @@ class Context:
         out = np.zeros(n.value, dtype=np.uint32)
         self._ck(self.L.lv_get_ao_tile_costs(self.h, _p(out), n.value, C.byref(n), C.byref(g)))
         return out.reshape(-1, max(g.value, 1)).sum(axis=1)
+
+    def dispatch_order(self):
+        """(order, cost) of the last frame's 64x64-pixel groups: order[k] = group started k-th, cost[g] = ticks group g took."""
+        n = C.c_uint32(0)
+        self._ck(self.L.lv_get_dispatch_order(self.h, None, None, 0, C.byref(n)))
+        order = np.zeros(n.value, dtype=np.uint32)
+        cost = np.zeros(n.value, dtype=np.uint32)
+        if n.value:
+            self._ck(self.L.lv_get_dispatch_order(self.h, _p(order), _p(cost), n.value, C.byref(n)))
+        return order, cost
 
     def ppll_buffers(self, padded_pixels, max_nodes):
         nodes = np.zeros((max_nodes, 3), dtype=np.uint32)

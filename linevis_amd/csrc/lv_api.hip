@@ -103,7 +103,7 @@ static std::vector<LvDeviceBuffer*> lv_all_buffers(lv_ctx* ctx) {
             &ctx->scratchRays, &ctx->stackOverflow, &ctx->triIdx, &ctx->triVerts, &ctx->triPoints, &ctx->triNodes, &ctx->tris,
             &ctx->flowVectors, &ctx->flowScalars, &ctx->flowMisc, &ctx->flowSeeds, &ctx->flowOutPos, &ctx->flowOutAtt, &ctx->flowCounts,
             &ctx->bakeBlendingWeights, &ctx->bakeSamplingLocations, &ctx->bakedAo, &ctx->bakeLcgSkip, &ctx->mlatTrace, &ctx->buildArena,
-            &ctx->accum};
+            &ctx->accum, &ctx->groupOrder[0].cost, &ctx->groupOrder[0].order, &ctx->groupOrder[1].cost, &ctx->groupOrder[1].order};
 }
 
 namespace {
@@ -557,6 +557,12 @@ int lv_set_option(lv_ctx* ctx, const char* key, const char* value) {
         if (std::string(value) == "raster") o.ppllRayTracerColour = false;
         else if (std::string(value) == "ray_tracer") o.ppllRayTracerColour = true;
         else return bad();
+    } else if (k == "dispatch_order") {
+        // tile kernels: "cost" = the 64x64-pixel groups start in the order of what they cost in the previous frame, heaviest
+        // first (default); "as_numbered" = in tile-list order (measurement knob; the image is the same)
+        if (std::string(value) == "cost") o.dispatchByCost = true;
+        else if (std::string(value) == "as_numbered") o.dispatchByCost = false;
+        else return bad();
     } else if (k == "rtao_geometry") {
         if (std::string(value) == "capsules") o.aoTriangleTubes = false;
         else if (std::string(value) == "triangle_tubes") o.aoTriangleTubes = true;
@@ -656,12 +662,13 @@ int lv_get_stats(lv_ctx* ctx, lv_stats* out) {
     };
     if (ctx->evBuildValid) s.ms_accel_build = ms(0, 1);
     if (ctx->evFrameValid) {
+        // phase marks on the stream: 2 start, 5 depth range done, 7 RTAO done, 11 PPLL lists cleared, 13 gathered, 3 end
         s.ms_total = ms(2, 3);
-        s.ms_depth_range = ms(4, 5);
-        s.ms_ao = ms(6, 7);
+        s.ms_depth_range = ms(2, 5);
+        s.ms_ao = ms(5, 7);
         s.ms_color = s.ms_ppll_clear = s.ms_ppll_gather = s.ms_ppll_resolve = 0.0f;
-        if (ctx->lastMode == LV_RENDERING_MODE_VULKAN_RAY_TRACER) s.ms_color = ms(8, 9);
-        else { s.ms_ppll_clear = ms(10, 11); s.ms_ppll_gather = ms(12, 13); s.ms_ppll_resolve = ms(14, 15); }
+        if (ctx->lastMode == LV_RENDERING_MODE_VULKAN_RAY_TRACER) s.ms_color = ms(7, 3);
+        else { s.ms_ppll_clear = ms(7, 11); s.ms_ppll_gather = ms(11, 13); s.ms_ppll_resolve = ms(13, 3); }
         LvDevCountersHost hc;
         memset(&hc, 0, sizeof(hc));
         if (ctx->counters.ptr) {
@@ -847,6 +854,22 @@ int lv_get_ao_tile_costs(lv_ctx* ctx, uint32_t* out_counts, uint32_t capacity, u
         if (capacity < ctx->aoNumGroups) return lv_fail(ctx, LV_E_CAPACITY, "out_counts holds %u entries, need %u", capacity, ctx->aoNumGroups);
         (void)hipSetDevice(ctx->device);
         LV_HIP(ctx, hipMemcpyAsync(out_counts, ctx->aoList.ptr, size_t(ctx->aoNumGroups) * 4, hipMemcpyDeviceToHost, ctx->stream));
+        LV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return LV_OK;
+}
+
+int lv_get_dispatch_order(lv_ctx* ctx, uint32_t* out_order, uint32_t* out_cost, uint32_t capacity, uint32_t* out_count) {
+    if (!ctx) return LV_E_INVALID;
+    if (ctx->multi) ctx = lv_multi_rank(ctx, 0);
+    const lv_ctx::GroupOrder& G = ctx->groupOrder[0];
+    const uint32_t n = (G.active && ctx->evFrameValid) ? G.n : 0u;
+    if (out_count) *out_count = n;
+    if (n && (out_order || out_cost)) {
+        if (capacity < n) return lv_fail(ctx, LV_E_CAPACITY, "the launch has %u groups", n);
+        (void)hipSetDevice(ctx->device);
+        if (out_order) LV_HIP(ctx, hipMemcpyAsync(out_order, G.order.ptr, size_t(n) * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (out_cost) LV_HIP(ctx, hipMemcpyAsync(out_cost, G.cost.ptr, size_t(n) * 4, hipMemcpyDeviceToHost, ctx->stream));
         LV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     return LV_OK;

@@ -68,6 +68,12 @@
 #ifndef LV_HANDOVER_MAX_BUSY
 #define LV_HANDOVER_MAX_BUSY 32 // cooperative closest hit: idle lanes take over stacked subtrees once at most this many lanes descend
 #endif
+#ifndef LV_HANDOVER_MAX_BUSY_ALL
+#define LV_HANDOVER_MAX_BUSY_ALL 48 // same for the all-hits walk of the PPLL gather (r03: 40...52 = -5 % on config 4 against 32)
+#endif
+#ifndef LV_HANDOVER_MAX_BUSY_DYN
+#define LV_HANDOVER_MAX_BUSY_DYN 24 // ... and for the front-to-back ordered MLAT walk, where early hand-over shades fragments the closing interval would have culled (r03: 8 / 16 / 24 / 32 / 48 = 1.448 / 1.436 / 1.430 / 1.485 / 1.696 ms)
+#endif
 
 #ifndef LV_PPLL_CHUNK
 #define LV_PPLL_CHUNK 256       // PPLL node slots a wave reserves per global atomic (>= 64)
@@ -221,6 +227,11 @@ struct LvSceneDev {
 struct LvTiles {
     const uint32_t* tilesXY;
     uint32_t numTiles, tileW, tileH, blocksX, blocksY; // 16x16-pixel blocks per tile (multiples of 4: 64x64 groups)
+    // dispatch order of the 64x64-pixel groups (lv_group_order): slot -> group, most expensive group of the previous frame
+    // first; NULL = as numbered.  groupCost collects this frame's cost per group (device clock ticks summed over the group's
+    // workgroups).  Speed only: which workgroup renders which group never shows in the result.
+    const uint32_t* groupOrder;
+    uint32_t* groupCost;
 };
 
 struct LvCounters {

@@ -41,6 +41,7 @@ struct LvOptions {
     uint32_t aoSamplesPerFrame = 4;           // VulkanRayTracedAmbientOcclusion.hpp:150
     float aoRadius = 0.1f;                    // :151
     bool aoUseDistance = true;                // :152
+    bool dispatchByCost = true;               // dispatch_order = cost | as_numbered (tile kernels: heaviest 64x64 group of the last frame first)
     bool aoJitterPrimary = true;              // :153
     uint32_t numSamplesPerFrame = 1;          // VulkanRayTracer.hpp:137 has 2 (interactive); offline default 1
     uint32_t numAccumulatedFrames = 1;        // :142 (32 interactive); > 1: the caller renders frame_number = 0, 1, ...
@@ -168,6 +169,15 @@ struct lv_ctx {
     LvDeviceBuffer accum;                     // rgba8 of the previous accumulated frame (full viewport)
     uint32_t* pinned = nullptr;               // 64 B of pinned host memory for small read-backs (hipHostMalloc)
     LvDeviceBuffer buildArena;                // temporaries of the LBVH builds, kept between builds
+    // dispatch order of the 64x64-pixel groups of the tile kernels (lv_group_order_prepare): [0] colour pass, [1] RTAO pass geometry
+    struct GroupOrder {
+        LvDeviceBuffer cost, order;
+        uint32_t n = 0, tileW = 0, tileH = 0;
+        uint64_t generation = ~0ull;
+        bool active = false;                  // in use by the frame being queued
+    } groupOrder[2];
+    bool groupOrderSorted = false;            // this frame's k_group_order is queued
+    uint64_t tilesGeneration = 0;             // bumped whenever tilesDev receives another list
     std::vector<uint32_t> tilesHost;          // staging copy: caller's tile list is borrowed for the call only
     bool tilesUploaded = false;               // tilesDev holds tilesHost
     uint64_t ppllPoolNodes = 0;               // physical node slots of the pool (logical size + per-wave chunk slack)

@@ -94,6 +94,7 @@ __global__ __launch_bounds__(LV_BLOCK) void k_render_rt_mlat(const LvUniforms U,
     LV_HITQ_MEM(hq);
     LvPixel px;
     if (!lv_block_pixel(U, T, px)) return;
+    const unsigned long long tg0 = lv_group_clock();
     const LvStackMem sm = lv_stack_mem(s_stack, S.stackOverflow);
     LvCounters cnt = {0, 0, 0, 0};
     const unsigned w = threadIdx.x >> 6, lane = lv_lane();
@@ -194,6 +195,7 @@ __global__ __launch_bounds__(LV_BLOCK) void k_render_rt_mlat(const LvUniforms U,
         f4 c; c.x = U.background[0]; c.y = U.background[1]; c.z = U.background[2]; c.w = U.background[3];
         out[px.outIndex] = lv_pack_unorm4x8(c);
     }
+    lv_group_cost_add(T, px, tg0);
     if (STATS) { lv_flush_max_nodes(cnt, dc); lv_flush_counters(cnt, dc); }
 }
 

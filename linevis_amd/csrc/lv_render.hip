@@ -36,6 +36,7 @@ __global__ __launch_bounds__(LV_BLOCK, (STATS || PRIM == LV_PRIM_ELLIPTIC) ? 1 :
     LV_COOP_MEM(cm);
     LvPixel px;
     if (!lv_block_pixel(U, T, px)) return;
+    const unsigned long long tg0 = lv_group_clock();
     const LvStackMem sm = lv_stack_mem(s_stack, S.stackOverflow);
     LvCounters cnt = {0, 0, 0, 0};
     const bool capped = U.useCappedTubes != 0 || U.lssGeometry != 0;
@@ -95,6 +96,7 @@ __global__ __launch_bounds__(LV_BLOCK, (STATS || PRIM == LV_PRIM_ELLIPTIC) ? 1 :
         f4 c; c.x = U.background[0]; c.y = U.background[1]; c.z = U.background[2]; c.w = U.background[3];
         out[px.outIndex] = lv_pack_unorm4x8(c);
     }
+    lv_group_cost_add(T, px, tg0);
     if (STATS) { lv_flush_max_nodes(cnt, dc); lv_flush_counters(cnt, dc); }
 }
 
@@ -129,6 +131,7 @@ __global__ __launch_bounds__(LV_BLOCK) void k_ao_primary(const LvUniforms U, con
     LV_COOP_MEM(cm);
     LvPixel px;
     if (!lv_block_pixel(U, T, px)) return;
+    const unsigned long long tg0 = lv_group_clock();
     LvCounters cnt = {0, 0, 0, 0};
     bool hasHit = false;
     float4 g0, g1, g2;
@@ -279,6 +282,7 @@ __global__ __launch_bounds__(LV_BLOCK) void k_ao_primary(const LvUniforms U, con
             gbuf[3 * size_t(slot) + 2] = g2;
         }
     }
+    lv_group_cost_add(T, px, tg0);
     if (STATS) lv_flush_counters(cnt, dc);
 }
 
@@ -298,6 +302,7 @@ __global__ __launch_bounds__(LV_BLOCK) void k_ao_tile_scan(const uint32_t* __res
         for (uint32_t i = 0; i < LV_BLOCK; i++) { const uint32_t v = s_part[i]; s_part[i] = run; run += v; }
         tileBase[numTiles] = run;
         dc->aoCount = run;
+        dc->aoQueueHead = 0ull; // the ray queue of the k_ao_rays launch that follows
     }
     __syncthreads();
     uint32_t run = s_part[threadIdx.x];
@@ -797,6 +802,7 @@ __global__ __launch_bounds__(LV_BLOCK, LV_GATHER_MIN_WAVES) void k_ppll_gather(c
     LvPixel px;
     const uint32_t slice = blockIdx.x % numSlices;
     if (!lv_block_pixel(U, T, px, blockIdx.x / numSlices)) return;
+    const unsigned long long tg0 = lv_group_clock();
     LvCounters cnt = {0, 0, 0, 0};
     // (the slices of a pixel are ONE ray: lv_trace_all counts a ray per active call, corrected below)
     const unsigned waveBase = threadIdx.x & ~63u;
@@ -899,7 +905,19 @@ __global__ __launch_bounds__(LV_BLOCK, LV_GATHER_MIN_WAVES) void k_ppll_gather(c
     }
     if (lv_lane() == 0 && m > 0) atomicMax(&dc->maxDepthComplexity, m);
     if (lv_lane() == 0 && sum > 0) atomicAdd(&dc->fragCounter, sum); // fragCounter of the reference: every fragment counts
+    lv_group_cost_add(T, px, tg0);
     if (STATS) lv_flush_counters(cnt, dc);
+}
+
+// clear(): LinkedListClear.glsl:46-55 (start offsets = -1) + fragmentCounterBuffer->fill(0), and the per-pixel fragment counts
+__global__ __launch_bounds__(LV_BLOCK) void k_ppll_clear(uint4* __restrict__ startOffset, uint4* __restrict__ fragCount, size_t n4,
+                                                         LvDevCounters* dc) {
+    const size_t i = size_t(blockIdx.x) * LV_BLOCK + threadIdx.x;
+    if (i < n4) {
+        startOffset[i] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+        fragCount[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    if (i == 0) { dc->fragCounter = 0u; dc->fragAlloc = 0u; }
 }
 
 // per-thread fragment arrays interleaved over the wave: entry i of lane l at [i * 64 + l]
@@ -1256,6 +1274,82 @@ static uint64_t lv_ao_grid(const lv_ctx* ctx, uint64_t maxRays) {
     return gridRays ? gridRays : 1;
 }
 
+// ---------------------------------------------------------------- dispatch order of the tile kernels
+// A tile kernel lasts as long as its last workgroup, and the cost of a 64x64-pixel group spans orders of magnitude (a group over
+// the core of a bundle against one over the background).  In tile-list order the heavy groups start whenever their turn
+// comes and the launch ends with a tail of a few of them; started first (longest processing time first) the light groups fill
+// the gaps behind them.  The cost is what the group's waves took in the previous frame (LvTiles::groupCost) -- with a
+// camera that moves a little per frame a good predictor, and only a predictor: every order renders the same image.
+// One workgroup sorts (cost descending, group index ascending) with a bitonic network in LDS and clears the cost array.
+#define LV_ORDER_MAX_GROUPS 8192u
+__global__ __launch_bounds__(1024) void k_group_order(uint32_t* __restrict__ cost0, uint32_t* __restrict__ order0, uint32_t n0,
+                                                      uint32_t* __restrict__ cost1, uint32_t* __restrict__ order1, uint32_t n1) {
+    extern __shared__ unsigned long long s_keys[];
+    uint32_t* cost = blockIdx.x ? cost1 : cost0;
+    uint32_t* order = blockIdx.x ? order1 : order0;
+    const uint32_t n = blockIdx.x ? n1 : n0;
+    if (n == 0u) return;
+    uint32_t np = 1u;
+    while (np < n) np <<= 1;
+    for (uint32_t i = threadIdx.x; i < np; i += blockDim.x) {
+        s_keys[i] = i < n ? ((unsigned long long)(~cost[i]) << 32) | i : ~0ull;
+        if (i < n) cost[i] = 0u;
+    }
+    __syncthreads();
+    for (uint32_t k = 2u; k <= np; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0u; j >>= 1) {
+            for (uint32_t i = threadIdx.x; i < np; i += blockDim.x) {
+                const uint32_t l = i ^ j;
+                if (l > i) {
+                    const unsigned long long a = s_keys[i], b = s_keys[l];
+                    if ((a > b) == ((i & k) == 0u)) { s_keys[i] = b; s_keys[l] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) order[i] = uint32_t(s_keys[i]);
+}
+
+// Points T at the dispatch order / cost array of launch geometry `which` (0 colour pass, 1 RTAO pass); a new tile list or
+// geometry starts from zero cost (= tile-list order).  The sort itself is queued by lv_group_order_sort.
+static int lv_group_order_prepare(lv_ctx* ctx, LvTiles& T, int which) {
+    T.groupOrder = nullptr;
+    T.groupCost = nullptr;
+    lv_ctx::GroupOrder& G = ctx->groupOrder[which];
+    G.active = false;
+    const uint64_t n64 = uint64_t(T.numTiles) * (T.blocksX / 4u) * (T.blocksY / 4u);
+    if (!ctx->opt.dispatchByCost || n64 < 2u || n64 > LV_ORDER_MAX_GROUPS) { G.n = 0; return LV_OK; }
+    const uint32_t n = uint32_t(n64);
+    int rc;
+    if ((rc = lv_buf_reserve(ctx, G.cost, size_t(n) * 4))) return rc;
+    if ((rc = lv_buf_reserve(ctx, G.order, size_t(n) * 4))) return rc;
+    if (G.n != n || G.tileW != T.tileW || G.tileH != T.tileH || G.generation != ctx->tilesGeneration) {
+        LV_HIP(ctx, hipMemsetAsync(G.cost.ptr, 0, size_t(n) * 4, ctx->stream));
+        G.n = n; G.tileW = T.tileW; G.tileH = T.tileH; G.generation = ctx->tilesGeneration;
+    }
+    T.groupOrder = (const uint32_t*)G.order.ptr;
+    T.groupCost = (uint32_t*)G.cost.ptr;
+    G.active = true;
+    return LV_OK;
+}
+
+// Queued once per frame, in front of the frame's first tile kernel (every geometry of the frame is prepared by then).
+static int lv_group_order_sort(lv_ctx* ctx) {
+    if (ctx->groupOrderSorted) return LV_OK;
+    ctx->groupOrderSorted = true;
+    const lv_ctx::GroupOrder& A = ctx->groupOrder[0];
+    const lv_ctx::GroupOrder& B = ctx->groupOrder[1];
+    const uint32_t nA = A.active ? A.n : 0u, nB = B.active ? B.n : 0u;
+    const uint32_t nMax = nA > nB ? nA : nB;
+    if (nMax == 0u) return LV_OK;
+    uint32_t np = 1u;
+    while (np < nMax) np <<= 1;
+    k_group_order<<<nB ? 2 : 1, 1024, size_t(np) * 8, ctx->stream>>>((uint32_t*)A.cost.ptr, (uint32_t*)A.order.ptr, nA,
+                                                                    (uint32_t*)B.cost.ptr, (uint32_t*)B.order.ptr, nB);
+    LV_HIP(ctx, hipGetLastError());
+    return LV_OK;
+}
+
 // the global part of the traversal stacks: only when the tree is higher than the LDS-staged part.  lv_frame_render
 // reserves the largest slab any kernel of the frame needs BEFORE it builds a scene view, so that the reserve below never
 // reallocates under a pointer an earlier view still holds.
@@ -1343,6 +1437,10 @@ static int lv_run_ao(lv_ctx* ctx, LvUniforms& U, LvSceneDev& S, const LvTiles& T
     const uint64_t numGroups64 = uint64_t(T.numTiles) * (T.blocksX / 4u) * (T.blocksY / 4u);
     if (numGroups64 > 0x000FFFFFull) return lv_fail(ctx, LV_E_INVALID, "tile list too large");
     const uint32_t numGroups = uint32_t(numGroups64);
+    // dispatch order: the colour pass' (same launch geometry: both passes add to one cost array) or, on dilated tiles / the
+    // whole viewport, one of its own
+    if ((svgf || halo) && (rc = lv_group_order_prepare(ctx, T, 1))) return rc;
+    if ((rc = lv_group_order_sort(ctx))) return rc;
     const LvAoLayout tileCap = lv_ao_layout(T);   // segments sized by the pixels a group really holds
     if ((rc = lv_buf_reserve(ctx, ctx->aoGbuf, size_t(maxPixels) * 48))) return rc;
     if ((rc = lv_buf_reserve(ctx, ctx->aoSamples, size_t(maxPixels) * spp * 4))) return rc;
@@ -1389,7 +1487,6 @@ static int lv_run_ao(lv_ctx* ctx, LvUniforms& U, LvSceneDev& S, const LvTiles& T
         }
         ctx->aoGlobalFrameNumber++;
         LV_HIP(ctx, hipMemsetAsync(tileCount, 0, size_t(numGroups) * 4, st));
-        LV_HIP(ctx, hipMemsetAsync(&dc->aoQueueHead, 0, 8, st));
         const uint32_t grid = uint32_t(gridRays);
         const float4* g = (const float4*)ctx->aoGbuf.ptr;
         // halo: read the previous pass' image, write the other buffer, swap; otherwise update in place
@@ -1535,10 +1632,11 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
         LV_HIP(ctx, hipMemcpyAsync(ctx->tilesDev.ptr, ctx->tilesHost.data(), size_t(numTiles) * 8, hipMemcpyHostToDevice, st));
         ctx->tilesUploaded = true;
         ctx->tilesHaloUploaded = false;
+        ctx->tilesGeneration++;
     }
     LV_HIP(ctx, hipMemsetAsync(dc, 0, sizeof(LvDevCounters), st));
 
-    LvTiles T;
+    LvTiles T{};
     T.tilesXY = (const uint32_t*)ctx->tilesDev.ptr;
     T.numTiles = numTiles;
     T.tileW = tileW;
@@ -1547,6 +1645,9 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
     T.blocksY = ((tileH + 63u) / 64u) * 4u;
     const uint64_t nb = uint64_t(numTiles) * T.blocksX * T.blocksY;
     if (nb > 0x7FFFFFF0ull) return lv_fail(ctx, LV_E_INVALID, "tile list too large");
+    ctx->groupOrderSorted = false;
+    ctx->groupOrder[1].active = false;
+    if ((rc = lv_group_order_prepare(ctx, T, 0))) return rc;
     const uint32_t gridTiles = uint32_t((nb + 127u) / 128u) * 128u; // multiple of 8 XCDs x LV_XCD_GROUP (lv_block_pixel)
     const uint64_t maxPixels = uint64_t(numTiles) * tileW * tileH;
     const bool stats = ctx->opt.collectStats;
@@ -1578,7 +1679,6 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
     if ((rc = lv_prepare_overflow(ctx, S, gridTiles))) return rc;
 
     // LineRenderer::renderBase: depth range, LineRenderer.cpp:248-256
-    LV_HIP(ctx, hipEventRecord(ctx->ev[4], st));
     if (U.useDepthCues) {
         k_depth_init<<<1, 64, 0, st>>>(U, dc);
         if (ctx->numPoints)
@@ -1588,7 +1688,6 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
     LV_HIP(ctx, hipEventRecord(ctx->ev[5], st));
 
     // ambientOcclusionBaker->updateIterative(), LineRenderer.cpp:257-264
-    LV_HIP(ctx, hipEventRecord(ctx->ev[6], st));
     ctx->aoNumGroups = 0;
     if (U.useAmbientOcclusion && !U.aoPrebaked)
         if ((rc = lv_run_ao(ctx, U, S, T, gridTiles, maxPixels))) return rc;
@@ -1602,6 +1701,7 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
         S.bakedBlendingWeights = (const float*)ctx->bakeBlendingWeights.ptr;
     }
     LV_HIP(ctx, hipEventRecord(ctx->ev[7], st));
+    if ((rc = lv_group_order_sort(ctx))) return rc; // (queued by the RTAO pass already when that ran)
 
     uint32_t* out = (uint32_t*)outDevice;
     if (mode == LV_RENDERING_MODE_VULKAN_RAY_TRACER && ctx->opt.numAccumulatedFrames > 1u) {
@@ -1616,7 +1716,6 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
         S.accum = (uint32_t*)ctx->accum.ptr;
     }
     if (mode == LV_RENDERING_MODE_VULKAN_RAY_TRACER) {
-        LV_HIP(ctx, hipEventRecord(ctx->ev[8], st));
         // geometry_mode (VulkanRayTracer.cpp:226-250): analytic capsules, or the triangle tubes with their own LBVH
         const bool tri = ctx->opt.rtTriangleMesh;
         if (ctx->opt.useMlat) { // use_mlat: single-pass approximate transparency (lv_mlat.hip)
@@ -1646,7 +1745,6 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
 #undef LV_LAUNCH_RT2
 #undef LV_LAUNCH_RT
         }
-        LV_HIP(ctx, hipEventRecord(ctx->ev[9], st));
     } else {
         // reallocateFragmentBuffer, PerPixelLinkedListLineRenderer.cpp:251-357
         const uint32_t numSlices = LV_PPLL_SLICES;
@@ -1658,20 +1756,17 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
         if (poolSlots64 > 0xFFFFFFF0ull) poolSlots64 = 0xFFFFFFF0ull; // node indices are 32 bit
         const uint32_t poolSlots = uint32_t(poolSlots64);
         if ((rc = lv_buf_reserve(ctx, ctx->ppllNodes, size_t(poolSlots) * 12))) return rc;
-        if ((rc = lv_buf_reserve(ctx, ctx->ppllStart, size_t(U.ppllPaddedW) * U.ppllPaddedH * 4))) return rc;
-        if ((rc = lv_buf_reserve(ctx, ctx->ppllCount, size_t(U.ppllPaddedW) * U.ppllPaddedH * 4))) return rc;
+        const size_t padded4 = (size_t(U.ppllPaddedW) * U.ppllPaddedH + 3) / 4; // cleared as whole uint4s (k_ppll_clear)
+        if ((rc = lv_buf_reserve(ctx, ctx->ppllStart, padded4 * 16))) return rc;
+        if ((rc = lv_buf_reserve(ctx, ctx->ppllCount, padded4 * 16))) return rc;
         ctx->ppllPoolNodes = poolSlots;
         ctx->ppllPaddedW = U.ppllPaddedW;
         ctx->ppllPaddedH = U.ppllPaddedH;
         // clear(): LinkedListClear.glsl:46-55 + fragmentCounterBuffer->fill(0)
-        LV_HIP(ctx, hipEventRecord(ctx->ev[10], st));
-        LV_HIP(ctx, hipMemsetAsync(ctx->ppllStart.ptr, 0xFF, size_t(U.ppllPaddedW) * U.ppllPaddedH * 4, st));
-        LV_HIP(ctx, hipMemsetAsync(ctx->ppllCount.ptr, 0, size_t(U.ppllPaddedW) * U.ppllPaddedH * 4, st));
-        LV_HIP(ctx, hipMemsetAsync(&dc->fragCounter, 0, 4, st));
-        LV_HIP(ctx, hipMemsetAsync(&dc->fragAlloc, 0, 4, st));
+        k_ppll_clear<<<uint32_t((padded4 + LV_BLOCK - 1) / LV_BLOCK), LV_BLOCK, 0, st>>>((uint4*)ctx->ppllStart.ptr,
+                                                                                         (uint4*)ctx->ppllCount.ptr, padded4, dc);
         LV_HIP(ctx, hipEventRecord(ctx->ev[11], st));
         // gather()
-        LV_HIP(ctx, hipEventRecord(ctx->ev[12], st));
 #define LV_LAUNCH_GATHER(ST, PR, BA)                                                                             \
     LV_TIMED_LAUNCH(ctx, LV_KERNEL_PPLL_GATHER, (k_ppll_gather<ST, PR, BA><<<gridTiles * numSlices, LV_BLOCK, 0, st>>>( \
             U, S, T, (uint32_t*)ctx->ppllNodes.ptr, (uint32_t*)ctx->ppllStart.ptr,                              \
@@ -1688,7 +1783,6 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
 #undef LV_LAUNCH_GATHER
         LV_HIP(ctx, hipEventRecord(ctx->ev[13], st));
         // resolve()
-        LV_HIP(ctx, hipEventRecord(ctx->ev[14], st));
         const uint32_t gx = (tileW + 7u) / 8u, gy = (tileH + 7u) / 8u;
         const uint64_t groups64 = uint64_t(numTiles) * gx * gy;
         const uint32_t numGroups = uint32_t(groups64);
@@ -1703,7 +1797,6 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
                     U, T, (const uint32_t*)ctx->ppllNodes.ptr, (const uint32_t*)ctx->ppllStart.ptr, out,
                     (uint32_t*)ctx->ppllScratch.ptr, numGroups)));
         }
-        LV_HIP(ctx, hipEventRecord(ctx->ev[15], st));
     }
     LV_HIP(ctx, hipGetLastError());
     LV_HIP(ctx, hipEventRecord(ctx->ev[3], st));
@@ -1765,7 +1858,7 @@ int lv_frame_ppll_resolve_only(lv_ctx* ctx, const uint32_t* nodes, uint64_t numN
     ctx->tilesUploaded = false; // tilesDev is overwritten below
     LV_HIP(ctx, hipMemcpyAsync(ctx->tilesDev.ptr, txy, 8, hipMemcpyHostToDevice, st));
     LV_HIP(ctx, hipStreamSynchronize(st));
-    LvTiles T;
+    LvTiles T{};
     T.tilesXY = (const uint32_t*)ctx->tilesDev.ptr;
     T.numTiles = 1; T.tileW = w; T.tileH = h;
     T.blocksX = ((w + 63u) / 64u) * 4u; T.blocksY = ((h + 63u) / 64u) * 4u;

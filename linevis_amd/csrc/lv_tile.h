@@ -48,7 +48,9 @@ __device__ __forceinline__ bool lv_block_pixel(const LvUniforms& U, const LvTile
     const uint32_t xcd = blockId % 8u, j = blockId / 8u;   // j-th block this XCD receives
     const uint32_t b = ((j / LV_XCD_GROUP) * 8u + xcd) * LV_XCD_GROUP + (j % LV_XCD_GROUP);
     if (b >= nb) { p.inTile = false; p.inView = false; p.group = 0u; return false; }
-    const uint32_t tile = b / blocksPerTile, rem = b % blocksPerTile;
+    // the 16 blocks of slot b / 16 render the group the dispatch order names (heaviest first, LvTiles::groupOrder)
+    const uint32_t bg = T.groupOrder ? T.groupOrder[b / LV_XCD_GROUP] * LV_XCD_GROUP + (b % LV_XCD_GROUP) : b;
+    const uint32_t tile = bg / blocksPerTile, rem = bg % blocksPerTile;
     // A tile is cut into 64x64-pixel groups of 16 blocks (T.blocksX / T.blocksY are multiples of 4).  Inside a group the
     // 64 waves do NOT own 8x8 patches: wave W takes pixel (W & 7, W >> 3) of each of the group's 8x8 cells, i.e. 64 pixels
     // spread over the whole group at stride 8.  The cost of a pixel varies by orders of magnitude over a few dozen
@@ -71,6 +73,15 @@ __device__ __forceinline__ bool lv_block_pixel(const LvUniforms& U, const LvTile
 
 __device__ __forceinline__ bool lv_block_pixel(const LvUniforms& U, const LvTiles& T, LvPixel& p) {
     return lv_block_pixel(U, T, p, blockIdx.x);
+}
+
+// Cost of a group for the next frame's dispatch order: every wave adds the time it was resident.
+__device__ __forceinline__ unsigned long long lv_group_clock() { return wall_clock64(); }
+__device__ __forceinline__ void lv_group_cost_add(const LvTiles& T, const LvPixel& p, unsigned long long t0) {
+    if (T.groupCost && (threadIdx.x & 63u) == 0u) {
+        const unsigned long long dt = wall_clock64() - t0;
+        atomicAdd(&T.groupCost[p.group], uint32_t(dt > 0x00FFFFFFull ? 0x00FFFFFFull : dt));
+    }
 }
 
 } // namespace

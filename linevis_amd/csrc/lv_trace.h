@@ -792,6 +792,7 @@ template <bool STATS, bool DYN, int PRIM = LV_PRIM_CAPSULE, typename F, typename
 __device__ __forceinline__ void lv_trace_all(const LvSceneDev& S, float radius, bool capped, bool active, f3 o, f3 d,
                                              float tMin, float tMax, float w0, float w1, const LvStackMem& sm,
                                              const LvCoopMem& cm, const LvHitQueue& hq, LvCounters& cnt, F&& f, G&& g) {
+    constexpr unsigned HO_BUSY = DYN ? LV_HANDOVER_MAX_BUSY_DYN : LV_HANDOVER_MAX_BUSY_ALL;
     const unsigned lane = lv_lane();
     const unsigned long long below = (1ull << lane) - 1ull;
     active = active && S.numSegs != 0;
@@ -891,7 +892,7 @@ __device__ __forceinline__ void lv_trace_all(const LvSceneDev& S, float radius, 
             continue;
         }
         if (nNode == 0) break;
-        if (nNode <= LV_HANDOVER_MAX_BUSY) { // subtree hand-over, as in lv_trace_closest
+        if (nNode <= HO_BUSY) { // subtree hand-over, as in lv_trace_closest
             const bool idle = cur == LV_INVALID;
             const bool donor = !idle && st.sp > 0;
             const unsigned long long mIdle = __ballot(idle), mDonor = __ballot(donor);
@@ -938,7 +939,7 @@ __device__ __forceinline__ void lv_trace_all(const LvSceneDev& S, float radius, 
                 tail += unsigned(__popcll(m));
             }
             nNow = __popcll(__ballot(!(cur & LV_LEAF_BIT)));
-        } while (tail - head < LV_WAVE && nNow > LV_HANDOVER_MAX_BUSY);
+        } while (tail - head < LV_WAVE && nNow > HO_BUSY);
     }
     if (hTail != hHead) shadeBatch(hTail - hHead); // the rest (< 64)
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
