@@ -535,6 +535,15 @@ int lv_set_option(lv_ctx* ctx, const char* key, const char* value) {
     } else if (k == "tube_num_subdivisions") {
         if (!parseUint(value, u) || u < 3) return bad();
         o.tubeNumSubdivisions = u;
+    } else if (k == "sorting_mode") {
+        // the "Sorting Mode" combo box of the PPLL renderer (PerPixelLinkedListLineRenderer.cpp:470-475): a name of
+        // SORTING_MODE_NAMES (src/Renderers/PPLL.hpp:32-35) or its index
+        static const char* const names[] = {"Priority Queue", "Bubble Sort", "Insertion Sort", "Shell Sort", "Max Heap",
+                                            "Bitonic Sort", "Quicksort", "Quicksort Hybrid"};
+        uint32_t m = 8;
+        for (uint32_t i = 0; i < 8; i++) if (std::string(value) == names[i]) m = i;
+        if (m == 8 && (!parseUint(value, m) || m > 7)) return bad();
+        o.ppllSortingMode = m;
     } else if (k == "ppll_max_num_frags") {
         if (!parseUint(value, u)) return bad();
         o.ppllMaxNumFrags = u;

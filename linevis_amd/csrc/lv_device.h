@@ -151,6 +151,7 @@ struct LvUniforms {
     uint32_t aoGlobalFrameNumber;
     float aoRadius, subdivisionCorrectionFactor;
     uint32_t ppllMaxNumFrags, ppllLinkedListSize, ppllTileW, ppllTileH, ppllPaddedW, ppllPaddedH;
+    uint32_t ppllSortingMode; // SortingAlgorithmMode, src/Renderers/PPLL.hpp:41-50 (0 = priority queue)
     // static RTAO prebaking (STATIC_AMBIENT_OCCLUSION_PREBAKING, AmbientOcclusion.glsl:29-38)
     uint32_t aoPrebaked, bakeNumLineVertices, bakeNumParametrizationVertices, bakeNumTubeSubdivisions;
     // getAoFactor of the colour pass (AmbientOcclusion.glsl:84-99): 1 = project the hit and sample the AO image bilinearly

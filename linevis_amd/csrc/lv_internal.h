@@ -51,6 +51,7 @@ struct LvOptions {
     bool useCappedTubes = true;               // LineData.hpp:377-379
     bool useHalos = true;
     uint32_t tubeNumSubdivisions = 6;         // LineData.cpp:52
+    uint32_t ppllSortingMode = 0;             // sorting_mode: index into SORTING_MODE_NAMES (PPLL.hpp:32-35), PerPixelLinkedListLineRenderer.hpp:113
     uint32_t ppllMaxNumFrags = 0;             // 0 = auto: 100 (<=1M segments) / 380, PerPixelLinkedListLineRenderer.hpp:45-49
     uint32_t ppllExpectedAvgDepthComplexity = 0; // 0 = auto: 20 / 120
     uint32_t ppllTileW = 2, ppllTileH = 8;    // LineRenderer.cpp:739-740

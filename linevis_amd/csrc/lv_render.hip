@@ -660,6 +660,44 @@ __global__ __launch_bounds__(LV_BLOCK) void k_ao_reduce(const LvUniforms U, cons
     ao[pix] = aoFactor;
 }
 
+// The same reduction with coalesced loads (spp a multiple of 4): a workgroup of 128 threads owns 128 consecutive rows of
+// `samples`; per chunk of 64 samples the rows' 256-byte pieces are copied into LDS (16 lanes per row, one float4 each) with a row
+// pitch of 65 floats (conflict-free column walks), then every thread adds ITS row's chunk in sample order into its accumulator --
+// the same sequence of additions as the loop above, so the same bits.  (k_ao_reduce reads every row 16 B at a time with one
+// cache line per lane: 75 us for config 3's 91 MB, against 91 MB / HBM rate.)  Persistent: blocks stride over dc->aoCount.
+#define LV_REDUCE_ROWS 128u
+__global__ __launch_bounds__(LV_REDUCE_ROWS) void k_ao_reduce_rows(const LvUniforms U, const float4* __restrict__ gbuf,
+                                                                   const float* __restrict__ samples, const float* aoIn, float* ao,
+                                                                   const LvDevCounters* dc, const uint32_t* __restrict__ tileBase,
+                                                                   uint32_t numTiles, const LvAoLayout tileCapacity) {
+    __shared__ float s_rows[LV_REDUCE_ROWS * 65u];
+    const uint32_t count = dc->aoCount, spp = U.aoSamplesPerFrame, t = threadIdx.x;
+    for (uint32_t row0 = blockIdx.x * LV_REDUCE_ROWS; row0 < count; row0 += gridDim.x * LV_REDUCE_ROWS) {
+        const uint32_t rows = min(LV_REDUCE_ROWS, count - row0);
+        float aoFactor = 0.0f;
+        for (uint32_t c0 = 0; c0 < spp; c0 += 64u) {
+            const uint32_t cols4 = min(64u, spp - c0) / 4u; // float4s per row in this chunk
+            __syncthreads();
+            for (uint32_t idx = t; idx < rows * cols4; idx += LV_REDUCE_ROWS) {
+                const uint32_t r = idx / cols4, c4 = idx % cols4;
+                const float4 v = *reinterpret_cast<const float4*>(samples + size_t(row0 + r) * spp + c0 + 4u * c4);
+                float* d = s_rows + r * 65u + 4u * c4;
+                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            }
+            __syncthreads();
+            if (t < rows)
+                for (uint32_t j = 0; j < 4u * cols4; j++) aoFactor += s_rows[t * 65u + j];
+        }
+        if (t < rows) {
+            const uint32_t slot = row0 + t;
+            aoFactor /= float(spp);
+            const uint32_t pix = __float_as_uint(gbuf[3 * lv_ao_slot(tileBase, numTiles, tileCapacity, slot) + 1].w);
+            if (U.aoFrameNumber != 0) aoFactor = mixf(aoIn[pix], aoFactor, 1.0f / float(U.aoFrameNumber + 1));
+            ao[pix] = aoFactor;
+        }
+    }
+}
+
 // One a-trous pass of the EAW denoiser (EAWDenoise.glsl) over the AO image: colorTexture = vec4(ao, ao, ao, 1) -- the three
 // colour channels stay equal and alpha stays 1 through every pass, so one float per pixel carries the image.
 //   COMPUTE = true   EAWDenoise.Compute (:128-292; eaw_denoiser_use_shared_memory = true, the default): B-spline kernel
@@ -950,8 +988,123 @@ __device__ __forceinline__ void lv_min_heap_sink4(LvFragArrays& A, uint32_t x, u
     }
 }
 
+// ---- sorting_mode != "Priority Queue" (SORTING_MODE_NAMES, src/Renderers/PPLL.hpp:32-50): the whole list is sorted, then every
+// fragment is blended (blendFTB, LinkedListSort.glsl:45-59; the priority queue alone stops at alpha 0.99).  All comparisons
+// go through the (depth, colour) key like the heap's, so the seven modes differ in cost and -- bitonic sort on a list whose length
+// is no power of two, the quicksorts when their fixed stack overflows -- in what the shader's algorithm leaves unsorted.
+struct LvSortStack { // LinkedListQuicksort.glsl:30-55: pushes beyond STACK_SIZE are dropped, an empty stack pops 0
+    int mem[64];
+    int size, counter;
+    __device__ __forceinline__ void push(int v) { if (counter < size) mem[counter++] = v; }
+    __device__ __forceinline__ int pop() { return counter > 0 ? mem[--counter] : 0; }
+};
+__device__ __forceinline__ bool lv_key_less(float da, uint32_t ca, float db, uint32_t cb) {
+    return da < db || (da == db && ca < cb);
+}
+__device__ __forceinline__ void lv_gap_insertion_pass(LvFragArrays& A, uint32_t n, uint32_t gap) {
+    for (uint32_t i = gap; i < n; ++i) { // insertionSort (:80-104) is the pass with gap 1, shellSort (:107-137) four of them
+        const uint32_t fc = A.c(i);
+        const float fd = A.d(i);
+        uint32_t j = i;
+        while (j >= gap && lv_key_less(fd, fc, A.d(j - gap), A.c(j - gap))) {
+            A.c(j) = A.c(j - gap);
+            A.d(j) = A.d(j - gap);
+            j -= gap;
+        }
+        A.c(j) = fc;
+        A.d(j) = fd;
+    }
+}
+__device__ __forceinline__ void lv_max_heap_sink(LvFragArrays& A, uint32_t x, uint32_t n) { // :140-157
+    uint32_t c;
+    while ((c = 2 * x + 1) < n) {
+        if (c + 1 < n && A.gt(c + 1, c)) ++c;
+        if (!A.gt(c, x)) return;
+        A.swap(x, c);
+        x = c;
+    }
+}
+__device__ __forceinline__ int lv_sort_stack_size(uint32_t maxFrags) { // PerPixelLinkedListLineRenderer.cpp:178
+    const int s = int(ceil(log2(double(maxFrags))) * 2 + 4);
+    return s < 0 ? 0 : (s > 64 ? 64 : s);
+}
+__device__ void lv_sort_fragments(uint32_t mode, LvFragArrays& A, uint32_t n, uint32_t maxFrags) {
+    if (mode == 1u) { // bubbleSort :62-77
+        bool changed;
+        do {
+            changed = false;
+            for (uint32_t i = 0; i + 1 < n; ++i)
+                if (A.gt(i, i + 1)) { A.swap(i, i + 1); changed = true; }
+        } while (changed);
+    } else if (mode == 2u) {
+        lv_gap_insertion_pass(A, n, 1u);
+    } else if (mode == 3u) {
+        lv_gap_insertion_pass(A, n, 24u);
+        lv_gap_insertion_pass(A, n, 9u);
+        lv_gap_insertion_pass(A, n, 4u);
+        lv_gap_insertion_pass(A, n, 1u);
+    } else if (mode == 4u) { // heapSort :159-172
+        for (uint32_t i = (n + 1) / 2; i > 0; --i) lv_max_heap_sink(A, i - 1, n);
+        for (uint32_t i = 1; i < n; ++i) {
+            A.swap(0, n - i);
+            lv_max_heap_sink(A, 0, n - i);
+        }
+    } else if (mode == 5u) { // bitonicSort :241-262, with the reference's guards (no padding to a power of two)
+        for (uint32_t k = 2; k <= n; k *= 2)
+            for (uint32_t j = k / 2; j > 0; j /= 2)
+                for (uint32_t i = 0; i < n; i++) {
+                    const uint32_t l = i ^ j;
+                    if (l > i && l < n) {
+                        const bool up = (i & k) == 0u;
+                        if (up ? A.gt(i, l) : A.gt(l, i)) A.swap(i, l);
+                    }
+                }
+    } else {
+        LvSortStack st;
+        st.size = lv_sort_stack_size(maxFrags);
+        st.counter = 0;
+        st.push(0);
+        st.push(int(n) - 1);
+        if (mode == 6u) { // quicksort :93-114 with the Lomuto partition :57-68
+            while (st.counter != 0) {
+                const int high = st.pop(), low = st.pop();
+                const float pd = A.d(uint32_t(high));
+                const uint32_t pc = A.c(uint32_t(high));
+                int i = low;
+                for (int j = low; j <= high; j++)
+                    if (lv_key_less(A.d(uint32_t(j)), A.c(uint32_t(j)), pd, pc)) { A.swap(uint32_t(i), uint32_t(j)); i++; }
+                A.swap(uint32_t(i), uint32_t(high));
+                const int pivot = i;
+                if (low < pivot - 1) { st.push(low); st.push(pivot - 1); }
+                if (pivot + 1 < high) { st.push(pivot + 1); st.push(high); }
+            }
+        } else { // quicksortHybrid :116-141 with the Hoare partition :70-91, finished by an insertion sort
+            if (n > 16u)
+                while (st.counter != 0) {
+                    const int high = st.pop(), low = st.pop();
+                    const uint32_t a = uint32_t(low), m = uint32_t((low + high) / 2), b = uint32_t(high);
+                    const bool ab = A.gt(m, a), ba2 = A.gt(a, b), bm = A.gt(m, b); // a < m, b < a, b < m
+                    const uint32_t mnmb = A.gt(m, b) ? b : m, mnab = A.gt(a, b) ? b : a;
+                    const uint32_t p = ab ? (ba2 ? a : mnmb) : (bm ? m : mnab);
+                    const float pd = A.d(p);
+                    const uint32_t pc = A.c(p);
+                    int i = low - 1, j = high + 1, pivot;
+                    for (;;) {
+                        do { i = i + 1; } while (lv_key_less(A.d(uint32_t(i)), A.c(uint32_t(i)), pd, pc));
+                        do { j = j - 1; } while (lv_key_less(pd, pc, A.d(uint32_t(j)), A.c(uint32_t(j))));
+                        if (i >= j) { pivot = j; break; }
+                        A.swap(uint32_t(i), uint32_t(j));
+                    }
+                    if (low + 16 < pivot) { st.push(low); st.push(pivot - 1); }
+                    if (pivot + 16 < high) { st.push(pivot + 1); st.push(high); }
+                }
+            lv_gap_insertion_pass(A, n, 1u);
+        }
+    }
+}
+
 // One wave per workgroup; fragment arrays in LDS when they fit, else in a global scratch slab.
-template <bool USE_LDS>
+template <bool USE_LDS, bool PQ = true>
 __global__ __launch_bounds__(LV_WAVE) void k_ppll_resolve(const LvUniforms U, const LvTiles T,
                                                           const uint32_t* __restrict__ nodes,
                                                           const uint32_t* __restrict__ startOffset,
@@ -988,7 +1141,24 @@ __global__ __launch_bounds__(LV_WAVE) void k_ppll_resolve(const LvUniforms U, co
                 fragOffset = nodes[3 * size_t(fragOffset) + 2];
                 numFrags++;
             }
-            if (numFrags > 0) {
+            if (!PQ && numFrags > 0) {
+                lv_sort_fragments(U.ppllSortingMode, A, numFrags, maxFrags);
+                float ray[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                for (uint32_t i = 0; i < numFrags; i++) { // blendFTB
+                    f4 src = lv_unpack_unorm4x8(A.c(i));
+                    ray[0] = ray[0] + ((1.0f - ray[3]) * src.w) * src.x;
+                    ray[1] = ray[1] + ((1.0f - ray[3]) * src.w) * src.y;
+                    ray[2] = ray[2] + ((1.0f - ray[3]) * src.w) * src.z;
+                    ray[3] = ray[3] + (1.0f - ray[3]) * src.w;
+                }
+                const float a = ray[3];
+                if (a > 0.0f) {
+#pragma unroll
+                    for (int k = 0; k < 3; k++) res[k] = (ray[k] / a) * a + U.background[k] * (1.0f - a);
+                    res[3] = a + U.background[3] * (1.0f - a);
+                }
+            }
+            if (PQ && numFrags > 0) {
                 // frontToBackPQ, LinkedListSort.glsl:207-238
                 uint32_t i;
                 for (i = numFrags / 4; i > 0; --i) lv_min_heap_sink4(A, i, numFrags);
@@ -1229,6 +1399,7 @@ void lv_fill_uniforms(const lv_ctx* ctx, LvUniforms& U) {
     U.ppllMaxNumFrags = o.ppllMaxNumFrags ? o.ppllMaxNumFrags : (large ? 380u : 100u);
     const uint32_t avg = o.ppllExpectedAvgDepthComplexity ? o.ppllExpectedAvgDepthComplexity : (large ? 120u : 20u);
     U.ppllTileW = o.ppllTileW;
+    U.ppllSortingMode = o.ppllSortingMode;
     U.ppllTileH = o.ppllTileH;
     uint32_t pw = ctx->width, ph = ctx->height;
     padTiling(pw, ph, o.ppllTileW, o.ppllTileH);
@@ -1524,7 +1695,14 @@ static int lv_run_ao(lv_ctx* ctx, LvUniforms& U, LvSceneDev& S, const LvTiles& T
 #undef LV_LAUNCH_AO_LIT
 #undef LV_LAUNCH_AO
 #undef LV_LAUNCH_AOP
-        k_ao_reduce<false><<<nblocks(maxPixels), LV_BLOCK, 0, st>>>(U, g, smp, aoIn, ao, dc, tileBase, numGroups, tileCap);
+        if ((spp & 3u) == 0u) {
+            const uint64_t rowBlocks = (maxPixels + LV_REDUCE_ROWS - 1) / LV_REDUCE_ROWS;
+            const uint64_t cap = uint64_t(ctx->numCUs) * 16u;
+            k_ao_reduce_rows<<<uint32_t(rowBlocks < cap ? rowBlocks : cap), LV_REDUCE_ROWS, 0, st>>>(U, g, smp, aoIn, ao, dc, tileBase,
+                                                                                                      numGroups, tileCap);
+        } else {
+            k_ao_reduce<false><<<nblocks(maxPixels), LV_BLOCK, 0, st>>>(U, g, smp, aoIn, ao, dc, tileBase, numGroups, tileCap);
+        }
         if (halo) std::swap(ctx->ao, ctx->aoAlt);
         if (eaw) { std::swap(ctx->featNormal, ctx->featNormalAlt); std::swap(ctx->featPosition, ctx->featPositionAlt); }
         // temporal denoiser: denoise() belongs to every _render (VulkanRayTracedAmbientOcclusion.cpp:633-651), its history advances
@@ -1788,14 +1966,23 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
         const uint32_t numGroups = uint32_t(groups64);
         const size_t ldsBytes = size_t(U.ppllMaxNumFrags) * LV_WAVE * 8;
         if (ldsBytes <= 64 * 1024) {
-            LV_TIMED_LAUNCH(ctx, LV_KERNEL_PPLL_RESOLVE, (k_ppll_resolve<true><<<numGroups, LV_WAVE, ldsBytes, st>>>(
-                    U, T, (const uint32_t*)ctx->ppllNodes.ptr, (const uint32_t*)ctx->ppllStart.ptr, out, nullptr, numGroups)));
+            if (U.ppllSortingMode == 0u)
+                LV_TIMED_LAUNCH(ctx, LV_KERNEL_PPLL_RESOLVE, (k_ppll_resolve<true, true><<<numGroups, LV_WAVE, ldsBytes, st>>>(
+                        U, T, (const uint32_t*)ctx->ppllNodes.ptr, (const uint32_t*)ctx->ppllStart.ptr, out, nullptr, numGroups)));
+            else
+                LV_TIMED_LAUNCH(ctx, LV_KERNEL_PPLL_RESOLVE, (k_ppll_resolve<true, false><<<numGroups, LV_WAVE, ldsBytes, st>>>(
+                        U, T, (const uint32_t*)ctx->ppllNodes.ptr, (const uint32_t*)ctx->ppllStart.ptr, out, nullptr, numGroups)));
         } else {
             const uint32_t grid = numGroups < 4096u ? numGroups : 4096u;
             if ((rc = lv_buf_reserve(ctx, ctx->ppllScratch, size_t(grid) * ldsBytes))) return rc;
-            LV_TIMED_LAUNCH(ctx, LV_KERNEL_PPLL_RESOLVE, (k_ppll_resolve<false><<<grid, LV_WAVE, 0, st>>>(
-                    U, T, (const uint32_t*)ctx->ppllNodes.ptr, (const uint32_t*)ctx->ppllStart.ptr, out,
-                    (uint32_t*)ctx->ppllScratch.ptr, numGroups)));
+            if (U.ppllSortingMode == 0u)
+                LV_TIMED_LAUNCH(ctx, LV_KERNEL_PPLL_RESOLVE, (k_ppll_resolve<false, true><<<grid, LV_WAVE, 0, st>>>(
+                        U, T, (const uint32_t*)ctx->ppllNodes.ptr, (const uint32_t*)ctx->ppllStart.ptr, out,
+                        (uint32_t*)ctx->ppllScratch.ptr, numGroups)));
+            else
+                LV_TIMED_LAUNCH(ctx, LV_KERNEL_PPLL_RESOLVE, (k_ppll_resolve<false, false><<<grid, LV_WAVE, 0, st>>>(
+                        U, T, (const uint32_t*)ctx->ppllNodes.ptr, (const uint32_t*)ctx->ppllStart.ptr, out,
+                        (uint32_t*)ctx->ppllScratch.ptr, numGroups)));
         }
     }
     LV_HIP(ctx, hipGetLastError());
@@ -1864,16 +2051,19 @@ int lv_frame_ppll_resolve_only(lv_ctx* ctx, const uint32_t* nodes, uint64_t numN
     T.blocksX = ((w + 63u) / 64u) * 4u; T.blocksY = ((h + 63u) / 64u) * 4u;
     const uint32_t numGroups = ((w + 7u) / 8u) * ((h + 7u) / 8u);
     const size_t ldsBytes = size_t(U.ppllMaxNumFrags) * LV_WAVE * 8;
+    const uint32_t* nd = (const uint32_t*)ctx->ppllNodes.ptr;
+    const uint32_t* so = (const uint32_t*)ctx->ppllStart.ptr;
+    uint32_t* od = (uint32_t*)ctx->outDev.ptr;
+    const bool pq = U.ppllSortingMode == 0u;
     if (ldsBytes <= 64 * 1024) {
-        k_ppll_resolve<true><<<numGroups, LV_WAVE, ldsBytes, st>>>(U, T, (const uint32_t*)ctx->ppllNodes.ptr,
-                                                                   (const uint32_t*)ctx->ppllStart.ptr,
-                                                                   (uint32_t*)ctx->outDev.ptr, nullptr, numGroups);
+        if (pq) k_ppll_resolve<true, true><<<numGroups, LV_WAVE, ldsBytes, st>>>(U, T, nd, so, od, nullptr, numGroups);
+        else k_ppll_resolve<true, false><<<numGroups, LV_WAVE, ldsBytes, st>>>(U, T, nd, so, od, nullptr, numGroups);
     } else {
         const uint32_t grid = numGroups < 4096u ? numGroups : 4096u;
         if ((rc = lv_buf_reserve(ctx, ctx->ppllScratch, size_t(grid) * ldsBytes))) return rc;
-        k_ppll_resolve<false><<<grid, LV_WAVE, 0, st>>>(U, T, (const uint32_t*)ctx->ppllNodes.ptr,
-                                                        (const uint32_t*)ctx->ppllStart.ptr, (uint32_t*)ctx->outDev.ptr,
-                                                        (uint32_t*)ctx->ppllScratch.ptr, numGroups);
+        uint32_t* sc = (uint32_t*)ctx->ppllScratch.ptr;
+        if (pq) k_ppll_resolve<false, true><<<grid, LV_WAVE, 0, st>>>(U, T, nd, so, od, sc, numGroups);
+        else k_ppll_resolve<false, false><<<grid, LV_WAVE, 0, st>>>(U, T, nd, so, od, sc, numGroups);
     }
     LV_HIP(ctx, hipGetLastError());
     LV_HIP(ctx, hipMemcpyAsync(out, ctx->outDev.ptr, size_t(w) * h * 4, hipMemcpyDeviceToHost, st));

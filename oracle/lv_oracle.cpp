@@ -1092,6 +1092,177 @@ inline void frontToBackPQ(uint32_t* col, float* dep, uint32_t fragsCount, float 
     out[0] = ray[0] / ray[3]; out[1] = ray[1] / ray[3]; out[2] = ray[2] / ray[3]; out[3] = ray[3];
 }
 
+
+// ---- the other sorting modes of the resolve pass (SORTING_MODE_NAMES, src/Renderers/PPLL.hpp:32-50): each sorts the whole
+// list and blends ALL fragments front to back (blendFTB, LinkedListSort.glsl:45-59 -- no early out at alpha 0.99, unlike the
+// priority queue).  LITERAL compares depths only, like the shaders; otherwise the (depth, colour) key of the build (section 5).
+struct FragList {
+    uint32_t* col;
+    float* dep;
+};
+template <bool LITERAL>
+inline bool keyLess(float da, uint32_t ca, float db, uint32_t cb) {
+    if (LITERAL) return da < db;
+    return da < db || (da == db && ca < cb);
+}
+inline void swapFragments(FragList L, uint32_t i, uint32_t j) { // LinkedListSort.glsl:35-43
+    std::swap(L.col[i], L.col[j]);
+    std::swap(L.dep[i], L.dep[j]);
+}
+inline void blendFTB(FragList L, uint32_t fragsCount, float out[4]) {
+    float color[4] = {0, 0, 0, 0};
+    for (uint32_t i = 0; i < fragsCount; i++) {
+        float src[4];
+        unpackUnorm4x8(L.col[i], src);
+        for (int k = 0; k < 3; k++) color[k] = color[k] + ((1.0f - color[3]) * src[3]) * src[k];
+        color[3] = color[3] + (1.0f - color[3]) * src[3];
+    }
+    out[0] = color[0] / color[3]; out[1] = color[1] / color[3]; out[2] = color[2] / color[3]; out[3] = color[3];
+}
+template <bool LITERAL>
+inline void bubbleSort(FragList L, uint32_t n) { // LinkedListSort.glsl:62-77
+    bool changed;
+    do {
+        changed = false;
+        for (uint32_t i = 0; i + 1 < n; ++i)
+            if (gt<LITERAL>(L.col, L.dep, i, i + 1)) { swapFragments(L, i, i + 1); changed = true; }
+    } while (changed);
+}
+template <bool LITERAL>
+inline void gapInsertionPass(FragList L, uint32_t n, uint32_t gap) { // the loop insertionSort (gap 1) and shellSort share
+    for (uint32_t i = gap; i < n; ++i) {
+        const uint32_t fragColor = L.col[i];
+        const float fragDepth = L.dep[i];
+        uint32_t j = i;
+        while (j >= gap && keyLess<LITERAL>(fragDepth, fragColor, L.dep[j - gap], L.col[j - gap])) {
+            L.col[j] = L.col[j - gap];
+            L.dep[j] = L.dep[j - gap];
+            j -= gap;
+        }
+        L.col[j] = fragColor;
+        L.dep[j] = fragDepth;
+    }
+}
+template <bool LITERAL>
+inline void insertionSort(FragList L, uint32_t n) { gapInsertionPass<LITERAL>(L, n, 1u); } // :80-104
+template <bool LITERAL>
+inline void shellSort(FragList L, uint32_t n) { // :107-137, gap sequence 24, 9, 4, 1
+    const uint32_t gaps[4] = {24u, 9u, 4u, 1u};
+    for (uint32_t g = 0; g < 4; g++) gapInsertionPass<LITERAL>(L, n, gaps[g]);
+}
+template <bool LITERAL>
+inline void maxHeapSink(FragList L, uint32_t x, uint32_t n) { // :140-157
+    uint32_t c;
+    while ((c = 2 * x + 1) < n) {
+        if (c + 1 < n && gt<LITERAL>(L.col, L.dep, c + 1, c)) ++c;
+        if (!gt<LITERAL>(L.col, L.dep, c, x)) return; // depth[x] >= depth[c]
+        swapFragments(L, x, c);
+        x = c;
+    }
+}
+template <bool LITERAL>
+inline void heapSort(FragList L, uint32_t n) { // :159-172
+    for (uint32_t i = (n + 1) / 2; i > 0; --i) maxHeapSink<LITERAL>(L, i - 1, n);
+    for (uint32_t i = 1; i < n; ++i) {
+        swapFragments(L, 0, n - i);
+        maxHeapSink<LITERAL>(L, 0, n - i);
+    }
+}
+template <bool LITERAL>
+inline void bitonicSort(FragList L, uint32_t n) { // :241-262 -- as written: comparators that would reach past the list are
+    // skipped and the network stops at the largest power of two <= n, so a list whose length is no power of two stays partly
+    // unsorted (restated, not repaired)
+    for (uint32_t k = 2; k <= n; k *= 2)
+        for (uint32_t j = k / 2; j > 0; j /= 2)
+            for (uint32_t i = 0; i < n; i++) {
+                const uint32_t l = i ^ j;
+                if (l > i && l < n) {
+                    const bool up = (i & k) == 0;
+                    if ((up && gt<LITERAL>(L.col, L.dep, i, l)) || (!up && gt<LITERAL>(L.col, L.dep, l, i))) swapFragments(L, i, l);
+                }
+            }
+}
+// LinkedListQuicksort.glsl:30-55: a stack of STACK_SIZE ints that ignores pushes when full and pops 0 when empty
+struct SortStack {
+    int mem[64];
+    int size, counter = 0;
+    void push(int v) { if (counter < size) mem[counter++] = v; }
+    int pop() { return counter > 0 ? mem[--counter] : 0; }
+    bool empty() const { return counter == 0; }
+};
+template <bool LITERAL>
+inline int partitionLomuto(FragList L, int low, int high) { // :57-68
+    const float pd = L.dep[high];
+    const uint32_t pc = L.col[high];
+    int i = low;
+    for (int j = low; j <= high; j++)
+        if (keyLess<LITERAL>(L.dep[j], L.col[j], pd, pc)) { swapFragments(L, uint32_t(i), uint32_t(j)); i++; }
+    swapFragments(L, uint32_t(i), uint32_t(high));
+    return i;
+}
+template <bool LITERAL>
+inline int partitionHoare(FragList L, int low, int high) { // :70-91, pivot = median of first / middle / last
+    const int mid = (low + high) / 2;
+    auto lt = [&](int a, int b) { return keyLess<LITERAL>(L.dep[a], L.col[a], L.dep[b], L.col[b]); };
+    auto mn = [&](int a, int b) { return lt(b, a) ? b : a; };
+    const int p = lt(low, mid) ? (lt(high, low) ? low : mn(mid, high)) : (lt(high, mid) ? mid : mn(low, high));
+    const float pd = L.dep[p];
+    const uint32_t pc = L.col[p];
+    int i = low - 1, j = high + 1;
+    for (;;) {
+        do { i = i + 1; } while (keyLess<LITERAL>(L.dep[i], L.col[i], pd, pc));
+        do { j = j - 1; } while (keyLess<LITERAL>(pd, pc, L.dep[j], L.col[j]));
+        if (i >= j) return j;
+        swapFragments(L, uint32_t(i), uint32_t(j));
+    }
+}
+inline int sortStackSize(uint32_t maxNumFrags) { // PerPixelLinkedListLineRenderer.cpp:178
+    const int s = int(std::ceil(std::log2(double(maxNumFrags))) * 2 + 4);
+    return s < 0 ? 0 : (s > 64 ? 64 : s);
+}
+template <bool LITERAL>
+inline void quicksort(FragList L, uint32_t n, uint32_t maxNumFrags) { // :93-114
+    SortStack st;
+    st.size = sortStackSize(maxNumFrags);
+    st.push(0);
+    st.push(int(n) - 1);
+    while (!st.empty()) {
+        const int high = st.pop(), low = st.pop();
+        const int pivot = partitionLomuto<LITERAL>(L, low, high);
+        if (low < pivot - 1) { st.push(low); st.push(pivot - 1); }
+        if (pivot + 1 < high) { st.push(pivot + 1); st.push(high); }
+    }
+}
+template <bool LITERAL>
+inline void quicksortHybrid(FragList L, uint32_t n, uint32_t maxNumFrags) { // :116-141
+    SortStack st;
+    st.size = sortStackSize(maxNumFrags);
+    st.push(0);
+    st.push(int(n) - 1);
+    if (n > 16)
+        while (!st.empty()) {
+            const int high = st.pop(), low = st.pop();
+            const int pivot = partitionHoare<LITERAL>(L, low, high);
+            if (low + 16 < pivot) { st.push(low); st.push(pivot - 1); }
+            if (pivot + 16 < high) { st.push(pivot + 1); st.push(high); }
+        }
+    insertionSort<LITERAL>(L, n);
+}
+template <bool LITERAL>
+inline void sortAndBlend(uint32_t mode, uint32_t* col, float* dep, uint32_t n, uint32_t maxNumFrags, float out[4]) {
+    FragList L{col, dep};
+    switch (mode) {
+        case 1: bubbleSort<LITERAL>(L, n); break;
+        case 2: insertionSort<LITERAL>(L, n); break;
+        case 3: shellSort<LITERAL>(L, n); break;
+        case 4: heapSort<LITERAL>(L, n); break;
+        case 5: bitonicSort<LITERAL>(L, n); break;
+        case 6: quicksort<LITERAL>(L, n, maxNumFrags); break;
+        default: quicksortHybrid<LITERAL>(L, n, maxNumFrags); break;
+    }
+    blendFTB(L, n, out);
+}
+
 } // namespace
 
 // ================================================================ exported API
@@ -2195,8 +2366,14 @@ void lvo_ppll_resolve(const lvo_params* Pp, const uint32_t* nodes, const uint32_
             float out[4] = {P.background[0], P.background[1], P.background[2], P.background[3]};
             if (numFrags > 0) {
                 float c[4];
-                if (literal) frontToBackPQ<true>(colorList.data(), depthList.data(), numFrags, c);
-                else frontToBackPQ<false>(colorList.data(), depthList.data(), numFrags, c);
+                if (P.ppllSortingMode == 0u) {
+                    if (literal) frontToBackPQ<true>(colorList.data(), depthList.data(), numFrags, c);
+                    else frontToBackPQ<false>(colorList.data(), depthList.data(), numFrags, c);
+                } else if (literal) {
+                    sortAndBlend<true>(P.ppllSortingMode, colorList.data(), depthList.data(), numFrags, P.ppllMaxNumFrags, c);
+                } else {
+                    sortAndBlend<false>(P.ppllSortingMode, colorList.data(), depthList.data(), numFrags, P.ppllMaxNumFrags, c);
+                }
                 if (c[3] > 0.0f) { // A == 0 (all alphas quantised to 0) is treated as "no fragments"
                     for (int k = 0; k < 3; k++) out[k] = c[k] * c[3] + P.background[k] * (1.0f - c[3]);
                     out[3] = c[3] + P.background[3] * (1.0f - c[3]);

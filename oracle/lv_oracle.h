@@ -99,6 +99,7 @@ typedef struct {
      * cos(atan(rotation per length x lineWidth / 2)).  Only the triangle closest-hit path computes rotationSeparatorScale
      * (LineAttributesBarycentric.glsl:94-112); ClosestHitTubeAnalytic does not pass it, so the analytic paths ignore the switch. */
     uint32_t uniformHelicityBandWidth;
+    uint32_t ppllSortingMode;  /* SortingAlgorithmMode, src/Renderers/PPLL.hpp:41-50: 0 priority queue ... 7 quicksort hybrid */
 } lvo_params;
 
 typedef struct {

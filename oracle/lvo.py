@@ -62,6 +62,7 @@ class Params(C.Structure):
         ("useHelicityBands", C.c_uint32), ("numSubdivisionsBands", C.c_uint32),
         ("separatorBaseWidth", C.c_float), ("helicityRotationFactor", C.c_float),
         ("uniformHelicityBandWidth", C.c_uint32),
+        ("ppllSortingMode", C.c_uint32),
     ]
 
 
@@ -430,7 +431,7 @@ DEFAULTS = dict(
     ppllMaxNumFrags=100, ppllLinkedListSize=0, ppllTileW=2, ppllTileH=8,
     useBands=0, useEllipticTubes=0, bandWidth=0.005, minBandThickness=0.15, minThickness=0.15, lssGeometry=0,
     useHelicityBands=0, numSubdivisionsBands=6, separatorBaseWidth=0.2, helicityRotationFactor=1.0,
-    uniformHelicityBandWidth=1,
+    uniformHelicityBandWidth=1, ppllSortingMode=0,
 )
 
 

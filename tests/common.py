@@ -15,6 +15,10 @@ from oracle import lvo  # noqa: E402
 GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 
 
+SORTING_MODE_NAMES = ["Priority Queue", "Bubble Sort", "Insertion Sort", "Shell Sort", "Max Heap", "Bitonic Sort", "Quicksort",
+                      "Quicksort Hybrid"]   # src/Renderers/PPLL.hpp:32-35
+
+
 class Case:
     """A scene + camera + settings, convertible to oracle params and to lv_set_option calls."""
 
@@ -64,6 +68,7 @@ class Case:
             tubeNumSubdivisions=int(s.get("tube_num_subdivisions", 6)),
             aoRadius=float(s.get("ambient_occlusion_radius", 0.1)),
             ppllTileW=int(s.get("ppll_tile_width", 2)), ppllTileH=int(s.get("ppll_tile_height", 8)),
+            ppllSortingMode=SORTING_MODE_NAMES.index(s.get("sorting_mode", "Priority Queue")),
             # band data: USE_BANDS / elliptic tubes / MIN_THICKNESS (LineDataFlow.cpp:2423-2431, LineData.cpp:54,1297-1298)
             lssGeometry=int(s.get("geometry_mode") == "Linear Swept Spheres"),
             useHelicityBands=int(bool(s.get("rotating_helicity_bands", False))),
