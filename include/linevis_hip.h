@@ -180,6 +180,11 @@ int lv_set_background(lv_ctx* ctx, const float rgba[4]);
  *   max_depth_complexity                                                (VulkanRayTracer.hpp:139)
  *   ppll_max_num_frags, ppll_expected_avg_depth_complexity, ppll_tile_width, ppll_tile_height
  *                                                                       (PerPixelLinkedListLineRenderer.cpp:144-209,251-357)
+ *   sorting_mode: the "Sorting Mode" combo box of the PPLL renderer (.cpp:470-475, GUI-only in the reference): a name of
+ *   SORTING_MODE_NAMES -- "Priority Queue" (default) | "Bubble Sort" | "Insertion Sort" | "Shell Sort" | "Max Heap" |
+ *   "Bitonic Sort" | "Quicksort" | "Quicksort Hybrid" (src/Renderers/PPLL.hpp:32-50) -- or its index 0..7,
+ *   dispatch_order (build-owned, no counterpart): "cost" (default: the tile kernels start their 64x64-pixel groups heaviest-of-
+ *   the-previous-frame first, see lv_get_dispatch_order) | "as_numbered" (tile-list order); the image is the same,
  *   rtao_prebaker_iterations (128), rtao_prebaker_samples_per_frame (4), rtao_prebaker_num_tube_subdivisions (8): the
  *   prebaker's settings, GUI-only in the reference (VulkanAmbientOcclusionBaker.hpp:108,165-166); radius / distance
  *   based use the ambient_occlusion_* keys,

@@ -560,7 +560,8 @@ void HipPerPixelLinkedListLineRenderer::render() {
 
 bool HipPerPixelLinkedListLineRenderer::setNewSettings(const SettingsMap& settings) {
     bool r = LineRenderer::setNewSettings(settings);
-    for (const char* key : {"ppll_max_num_frags", "ppll_expected_avg_depth_complexity", "ppll_tile_width", "ppll_tile_height"}) {
+    for (const char* key : {"ppll_max_num_frags", "ppll_expected_avg_depth_complexity", "ppll_tile_width", "ppll_tile_height",
+                            "sorting_mode"}) { // sorting_mode: sortingAlgorithmMode, PerPixelLinkedListLineRenderer.hpp:113
         std::string s;
         if (settings.getValueOpt(key, s)) setOption(key, s);
     }
