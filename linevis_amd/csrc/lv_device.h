@@ -75,6 +75,12 @@
 #define LV_HANDOVER_MAX_BUSY_DYN 24 // ... and for the front-to-back ordered MLAT walk, where early hand-over shades fragments the closing interval would have culled (r03: 8 / 16 / 24 / 32 / 48 = 1.448 / 1.436 / 1.430 / 1.485 / 1.696 ms)
 #endif
 
+#ifndef LV_RESOLVE_LDS_MAX
+#define LV_RESOLVE_LDS_MAX (64 * 1024) // k_ppll_resolve: per-wave fragment arrays up to this size live in LDS, larger ones in a global slab
+#endif
+#ifndef LV_RESOLVE_SLAB_GRID
+#define LV_RESOLVE_SLAB_GRID 4096u      // ... worked through by this many persistent one-wave workgroups
+#endif
 #ifndef LV_PPLL_CHUNK
 #define LV_PPLL_CHUNK 256       // PPLL node slots a wave reserves per global atomic (>= 64)
 #endif

@@ -1965,7 +1965,7 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
         const uint64_t groups64 = uint64_t(numTiles) * gx * gy;
         const uint32_t numGroups = uint32_t(groups64);
         const size_t ldsBytes = size_t(U.ppllMaxNumFrags) * LV_WAVE * 8;
-        if (ldsBytes <= 64 * 1024) {
+        if (ldsBytes <= LV_RESOLVE_LDS_MAX) {
             if (U.ppllSortingMode == 0u)
                 LV_TIMED_LAUNCH(ctx, LV_KERNEL_PPLL_RESOLVE, (k_ppll_resolve<true, true><<<numGroups, LV_WAVE, ldsBytes, st>>>(
                         U, T, (const uint32_t*)ctx->ppllNodes.ptr, (const uint32_t*)ctx->ppllStart.ptr, out, nullptr, numGroups)));
@@ -1973,7 +1973,7 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
                 LV_TIMED_LAUNCH(ctx, LV_KERNEL_PPLL_RESOLVE, (k_ppll_resolve<true, false><<<numGroups, LV_WAVE, ldsBytes, st>>>(
                         U, T, (const uint32_t*)ctx->ppllNodes.ptr, (const uint32_t*)ctx->ppllStart.ptr, out, nullptr, numGroups)));
         } else {
-            const uint32_t grid = numGroups < 4096u ? numGroups : 4096u;
+            const uint32_t grid = numGroups < LV_RESOLVE_SLAB_GRID ? numGroups : LV_RESOLVE_SLAB_GRID;
             if ((rc = lv_buf_reserve(ctx, ctx->ppllScratch, size_t(grid) * ldsBytes))) return rc;
             if (U.ppllSortingMode == 0u)
                 LV_TIMED_LAUNCH(ctx, LV_KERNEL_PPLL_RESOLVE, (k_ppll_resolve<false, true><<<grid, LV_WAVE, 0, st>>>(
@@ -2055,11 +2055,11 @@ int lv_frame_ppll_resolve_only(lv_ctx* ctx, const uint32_t* nodes, uint64_t numN
     const uint32_t* so = (const uint32_t*)ctx->ppllStart.ptr;
     uint32_t* od = (uint32_t*)ctx->outDev.ptr;
     const bool pq = U.ppllSortingMode == 0u;
-    if (ldsBytes <= 64 * 1024) {
+    if (ldsBytes <= LV_RESOLVE_LDS_MAX) {
         if (pq) k_ppll_resolve<true, true><<<numGroups, LV_WAVE, ldsBytes, st>>>(U, T, nd, so, od, nullptr, numGroups);
         else k_ppll_resolve<true, false><<<numGroups, LV_WAVE, ldsBytes, st>>>(U, T, nd, so, od, nullptr, numGroups);
     } else {
-        const uint32_t grid = numGroups < 4096u ? numGroups : 4096u;
+        const uint32_t grid = numGroups < LV_RESOLVE_SLAB_GRID ? numGroups : LV_RESOLVE_SLAB_GRID;
         if ((rc = lv_buf_reserve(ctx, ctx->ppllScratch, size_t(grid) * ldsBytes))) return rc;
         uint32_t* sc = (uint32_t*)ctx->ppllScratch.ptr;
         if (pq) k_ppll_resolve<false, true><<<grid, LV_WAVE, 0, st>>>(U, T, nd, so, od, sc, numGroups);
