@@ -388,8 +388,12 @@ __device__ __forceinline__ unsigned lv_node_step(const LvSceneDev& S, unsigned n
         if (sel != LV_INVALID) return sel;
         return lv_pop_or_done(st);
     }
+    // a missed child keeps its reference and gets the key +inf: the key travels with the reference through the network and
+    // decides below whether the reference is pushed / descended (empty slots never hit: inverted boxes, lv_write_wide_node)
     k0 = h0 ? k0 : INF; k1 = h1 ? k1 : INF; k2 = h2 ? k2 : INF; k3 = h3 ? k3 : INF;
+#ifdef LV_NODE_STEP_MASK_REFS
     c0 = h0 ? c0 : LV_INVALID; c1 = h1 ? c1 : LV_INVALID; c2 = h2 ? c2 : LV_INVALID; c3 = h3 ? c3 : LV_INVALID;
+#endif
     if (ORDERED == 2 || (ORDERED == 1 && LV_SORT_CHILDREN)) { // 5-comparator sorting network, misses (key = +inf) sink to the end
         lv_cswap(k0, c0, k1, c1);
         lv_cswap(k2, c2, k3, c3);
@@ -404,15 +408,15 @@ __device__ __forceinline__ unsigned lv_node_step(const LvSceneDev& S, unsigned n
     // Pushes: write unconditionally and advance the stack pointer only for real references (no branches) as long as
     // the three slots are inside the LDS part; the rare deep case takes the checked path.
     if (st.sp + 3 <= STACK::kLds) {
-        st.lds[st.sp * STACK::kStride] = c3; st.sp += (c3 != LV_INVALID) ? 1 : 0;
-        st.lds[st.sp * STACK::kStride] = c2; st.sp += (c2 != LV_INVALID) ? 1 : 0;
-        st.lds[st.sp * STACK::kStride] = c1; st.sp += (c1 != LV_INVALID) ? 1 : 0;
+        st.lds[st.sp * STACK::kStride] = c3; st.sp += (k3 < INF) ? 1 : 0;
+        st.lds[st.sp * STACK::kStride] = c2; st.sp += (k2 < INF) ? 1 : 0;
+        st.lds[st.sp * STACK::kStride] = c1; st.sp += (k1 < INF) ? 1 : 0;
     } else {
-        if (c3 != LV_INVALID) st.push(c3);
-        if (c2 != LV_INVALID) st.push(c2);
-        if (c1 != LV_INVALID) st.push(c1);
+        if (k3 < INF) st.push(c3);
+        if (k2 < INF) st.push(c2);
+        if (k1 < INF) st.push(c1);
     }
-    if (c0 != LV_INVALID) return c0;
+    if (k0 < INF) return c0;
     return lv_pop_or_done(st);
 }
 
