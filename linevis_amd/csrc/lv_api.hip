@@ -566,6 +566,12 @@ int lv_set_option(lv_ctx* ctx, const char* key, const char* value) {
         if (std::string(value) == "raster") o.ppllRayTracerColour = false;
         else if (std::string(value) == "ray_tracer") o.ppllRayTracerColour = true;
         else return bad();
+    } else if (k == "triangle_leaf_size") {
+        // triangles per leaf of the triangle LBVH (build-owned; the hits do not depend on it)
+        uint32_t g;
+        if (!parseUint(value, g) || (g != 1 && g != 2 && g != 4)) return bad();
+        if (g != o.triLeafSize) { ctx->triAccelValid = false; ctx->bakeValid = false; }
+        o.triLeafSize = g;
     } else if (k == "dispatch_order") {
         // tile kernels: "cost" = the 64x64-pixel groups start in the order of what they cost in the previous frame, heaviest
         // first (default); "as_numbered" = in tile-list order (measurement knob; the image is the same)

@@ -216,6 +216,7 @@ struct LvSceneDev {
     const lv_tube_vertex* triVerts; // 32-B TubeTriangleVertexData, input order
     const lv_line_point* triPoints; // line points referenced by the vertices
     float triPad;               // padding of a triangle's own AABB (part of the ray-triangle test definition)
+    uint32_t triLeafSize;       // triangle records per leaf of the triangle LBVH (lv_bvh_build_triangles)
     // static RTAO prebaking: AO factor table [parametrisation vertex][tube subdivision] and the per-line-vertex blending
     // weights (AmbientOcclusionFactorsBuffer / AmbientOcclusionBlendingWeightsBuffer, AmbientOcclusion.glsl:31-38)
     const float* bakedAo;

@@ -443,9 +443,10 @@ __global__ __launch_bounds__(LV_AO_BLOCK, LV_AO_MIN_WAVES) void k_ao_rays(const 
                 const unsigned e = queueW[(head + lane) % LV_AO_QCAP];
                 const unsigned owner = e >> 26, leaf = e & 0x03FFFFFFu;
                 const float2 r0 = rayW[3 * owner], r1 = rayW[3 * owner + 1], r2 = rayW[3 * owner + 2];
-                if (STATS) cnt.prims++;
+                if (STATS) cnt.prims += PRIM == LV_PRIM_TRIANGLE ? S.triLeafSize : 1u; // primitives tested
                 float t; unsigned low;
-                if (lv_leaf_test<PRIM, LIT ? 1 : 0>(S, leaf, mk3(r0.x, r0.y, r1.x), mk3(r1.y, r2.x, r2.y), radius, capped, t, low)) {
+                if (lv_leaf_test<PRIM, LIT ? 1 : 0>(S, leaf, mk3(r0.x, r0.y, r1.x), mk3(r1.y, r2.x, r2.y), radius, capped, t, low, 0.0f,
+                                                    U.aoRadius)) {
                     if (t >= 0.0f && t <= U.aoRadius) { // traceAoRay: closest hit in [0, aoRadius], glsl:158-175
                         atomicMin(&keyW[owner], ((unsigned long long)__float_as_uint(t) << 32) | low);
                         if (STATS) primHits++;
@@ -1314,7 +1315,7 @@ LvSceneDev sceneDev(const lv_ctx* ctx) {
         S.ellCamPos[1] = ((m[1] * 0.0f + m[5] * 0.0f) + m[9] * 0.0f) + m[13] * 1.0f;
         S.ellCamPos[2] = ((m[2] * 0.0f + m[6] * 0.0f) + m[10] * 0.0f) + m[14] * 1.0f;
     }
-    S.tris = nullptr; S.triIdx = nullptr; S.triVerts = nullptr; S.triPoints = nullptr; S.triPad = 0.0f;
+    S.tris = nullptr; S.triIdx = nullptr; S.triVerts = nullptr; S.triPoints = nullptr; S.triPad = 0.0f; S.triLeafSize = 1u;
     S.bakedAo = (const float*)ctx->bakedAo.ptr;
     S.bakedBlendingWeights = (const float*)ctx->bakeBlendingWeights.ptr;
     return S;
@@ -1330,6 +1331,7 @@ LvSceneDev sceneDevTriangles(const lv_ctx* ctx) {
     S.triVerts = (const lv_tube_vertex*)ctx->triVerts.ptr;
     S.triPoints = (const lv_line_point*)ctx->triPoints.ptr;
     S.triPad = ctx->triPad;
+    S.triLeafSize = ctx->triLeafSize;
     return S;
 }
 

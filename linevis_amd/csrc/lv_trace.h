@@ -568,17 +568,35 @@ __device__ __forceinline__ bool lv_intersect_elliptic_tube(const LvSceneDev& S, 
     return true;
 }
 
+// one triangle record of the triangle LBVH (leaf * S.triLeafSize + slot); low = original triangle index
+__device__ __forceinline__ bool lv_tri_record_test(const LvSceneDev& S, size_t record, f3 o, f3 d, f3 inv, float& t, unsigned& low) {
+    const float4* rec = S.tris + 3 * record;
+    const float4 a = rec[0], b = rec[1], c = rec[2];
+    float u, v;
+    low = __float_as_uint(a.w);
+    return lv_ray_triangle(o, d, inv, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), S.triPad, t, u, v);
+}
+
 // LIT: -1 = intersection form from S.literalIntersection at run time (tile kernels), 0 / 1 = fixed at compile time (k_ao_rays:
 // a run-time branch around both capsule tests costs the register that pushes the kernel over its 96-VGPR budget into scratch)
 template <int PRIM, int LIT = -1>
 __device__ __forceinline__ bool lv_leaf_test(const LvSceneDev& S, unsigned leaf, f3 o, f3 d, float radius, bool capped,
-                                             float& t, unsigned& low) {
+                                             float& t, unsigned& low, float tLo = -3.0e38f, float tHi = 3.0e38f) {
     if (PRIM == LV_PRIM_TRIANGLE) {
-        const float4 a = S.tris[3 * size_t(leaf)], b = S.tris[3 * size_t(leaf) + 1], c = S.tris[3 * size_t(leaf) + 2];
+        // closest of the leaf's triangles INSIDE the caller's ray interval [tLo, tHi] (a nearer hit outside it must not hide a
+        // valid one of the same leaf); ties: lowest original index -- the merge key of the callers
         const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-        float u, v;
-        low = __float_as_uint(a.w);
-        return lv_ray_triangle(o, d, inv, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), S.triPad, t, u, v);
+        bool any = false;
+        t = 0.0f; low = 0u;
+        for (uint32_t j = 0; j < S.triLeafSize; j++) {
+            float tj;
+            unsigned idx;
+            if (lv_tri_record_test(S, size_t(leaf) * S.triLeafSize + j, o, d, inv, tj, idx) && tj >= tLo && tj <= tHi) {
+                if (!any || tj < t || (tj == t && idx < low)) { t = tj; low = idx; }
+                any = true;
+            }
+        }
+        return any;
     } else if (PRIM == LV_PRIM_ELLIPTIC) {
         const uint32_t seg = S.leafSeg[leaf];
         low = seg << 2;
@@ -701,9 +719,9 @@ __device__ __forceinline__ LvHit lv_trace_closest(const LvSceneDev& S, float rad
                 const unsigned e = cm.queue[(head + lane) % LV_QCAP];
                 const unsigned ow = e >> 26, leaf = e & 0x03FFFFFFu;
                 const float4 ro = cm.ray[2 * ow], rd = cm.ray[2 * ow + 1];
-                if (STATS) cnt.prims++;
+                if (STATS) cnt.prims += PRIM == LV_PRIM_TRIANGLE ? S.triLeafSize : 1u; // primitives tested
                 float t; unsigned low;
-                if (lv_leaf_test<PRIM>(S, leaf, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), radius, capped, t, low)) {
+                if (lv_leaf_test<PRIM>(S, leaf, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), radius, capped, t, low, ro.w, rd.w)) {
                     if (t >= ro.w && t <= rd.w)
                         atomicMin(&cm.key[ow], ((unsigned long long)__float_as_uint(t) << 32) | low);
                 }
@@ -850,6 +868,9 @@ __device__ __forceinline__ void lv_trace_all(const LvSceneDev& S, float radius, 
         if (q >= LV_WAVE || (q > 0 && nNode == 0)) {
             const unsigned n = q < LV_WAVE ? q : LV_WAVE;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            // a leaf of the triangle LBVH holds S.triLeafSize triangles: one round of tests + hit queueing per slot (wave-uniform)
+            const unsigned nSub = PRIM == LV_PRIM_TRIANGLE ? S.triLeafSize : 1u;
+            for (unsigned sub = 0; sub < nSub; sub++) {
             bool hit = false;
             unsigned hitRef = 0, hitKind = 0;
             float hitT = 0.0f;
@@ -862,7 +883,9 @@ __device__ __forceinline__ void lv_trace_all(const LvSceneDev& S, float radius, 
                 bool found;
                 if (PRIM == LV_PRIM_TRIANGLE) {
                     unsigned low;
-                    found = lv_leaf_test<LV_PRIM_TRIANGLE>(S, leaf, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), radius, capped, t, low);
+                    const f3 dd = mk3(rd.x, rd.y, rd.z);
+                    found = lv_tri_record_test(S, size_t(leaf) * S.triLeafSize + sub, mk3(ro.x, ro.y, ro.z), dd,
+                                               mk3(1.0f / dd.x, 1.0f / dd.y, 1.0f / dd.z), t, low);
                     kind = int(low);
                 } else if (PRIM == LV_PRIM_ELLIPTIC) {
                     unsigned low;
@@ -880,7 +903,6 @@ __device__ __forceinline__ void lv_trace_all(const LvSceneDev& S, float radius, 
                     if (t >= ro.w && (DYN ? t <= rd.w : t < rd.w)) { hit = true; hitRef = e; hitT = t; hitKind = unsigned(kind); }
                 }
             }
-            head += n;
             // hits are not shaded by the lane that found them: they queue up (ballot + prefix popcount) and are shaded 64
             // at a time -- a test batch in front of sparse geometry yields a handful of hits, and shading (~700
             // instructions with three pow) for a handful of lanes per batch was the critical path of the gather
@@ -893,6 +915,8 @@ __device__ __forceinline__ void lv_trace_all(const LvSceneDev& S, float radius, 
                 hTail += unsigned(__popcll(mH));
                 if (hTail - hHead >= LV_WAVE) shadeBatch(LV_WAVE);
             }
+            }
+            head += n;
             continue;
         }
         if (nNode == 0) break;

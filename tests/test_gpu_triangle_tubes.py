@@ -307,3 +307,40 @@ def test_triangle_mesh_mode_through_the_plugin(hip_lib):
     assert not np.array_equal(img, img8)
     r.set_new_settings(dict(use_analytic_intersections=True))
     assert max_lsb_diff(r.render_frame(), sc.render_rt(P, use_bvh=True)) <= 2
+
+
+@pytest.mark.parametrize("leaf_size", [1, 2, 4])
+def test_triangles_per_leaf_do_not_change_any_hit(hip_lib, leaf_size):
+    """triangle_leaf_size: the leaves of the triangle LBVH hold 1 / 2 (default) / 4 consecutive triangles.  The closest hit, the
+    AO factors and the all-hits traversal (MLAT over the mesh) must not depend on it -- including the case the first version got
+    wrong: the nearest triangle of a leaf lies outside the ray interval and a farther one of the same leaf inside."""
+    lw = 0.02
+    tr = curves(n_lines=31, pts_per_line=29)      # 31 * (28 * 12 + caps) triangles: the last leaf is incomplete for 4
+    mesh = mesh_of(tr, lw)
+    case = small_case(line_width=lw, **RTAO_TRI, ambient_occlusion_iterations=2, ambient_occlusion_samples_per_frame=6)
+    ctx = tri_context(case, mesh)
+    ctx.set_option("triangle_leaf_size", leaf_size)
+    ts = lvo.TriScene(*mesh, lw)
+    o, d = random_rays(20000, 5)
+    for tmin, tmax in [(0.0, 0.1), (0.02, 0.05), (1e-4, 1000.0)]:
+        a = ctx.trace_rays_triangles(o, d, tmin, tmax)
+        b = ts.trace_rays(o, d, tmin, tmax, use_bvh=False)
+        assert np.array_equal(a[1], b[1]) and np.array_equal(bits(a[0]), bits(b[0])) and np.array_equal(bits(a[2]), bits(b[2]))
+    ctx.render(capi.MODE_RAY_TRACER)
+    P = case.oracle_params(case.oracle_scene())
+    assert np.array_equal(bits(ctx.get_ao()), bits(ts.render_ao(P, use_bvh=False)))
+    # Triangle Mesh geometry mode with the transparency loop and with MLAT: the same frames for every leaf size
+    frames = []
+    for extra in (dict(), dict(use_mlat=True, mlat_num_nodes=4)):
+        c2 = small_case(line_width=lw, transparent=True, geometry_mode="Triangle Mesh", **extra)
+        x = tri_context(c2, mesh)
+        x.set_option("triangle_leaf_size", 1)
+        want = x.render(capi.MODE_RAY_TRACER)
+        x.set_option("triangle_leaf_size", leaf_size)
+        got = x.render(capi.MODE_RAY_TRACER)
+        if extra:   # MLAT depends on the visiting order of equal-depth candidates only through its merge rule: same tolerance as elsewhere
+            assert max_lsb_diff(got, want) <= 2
+        else:
+            assert np.array_equal(got, want)
+    with pytest.raises(Exception):
+        ctx.set_option("triangle_leaf_size", 3)
