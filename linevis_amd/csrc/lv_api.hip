@@ -569,7 +569,7 @@ int lv_set_option(lv_ctx* ctx, const char* key, const char* value) {
     } else if (k == "triangle_leaf_size") {
         // triangles per leaf of the triangle LBVH (build-owned; the hits do not depend on it)
         uint32_t g;
-        if (!parseUint(value, g) || (g != 1 && g != 2 && g != 4)) return bad();
+        if (!parseUint(value, g) || g < 1 || g > 8) return bad();
         if (g != o.triLeafSize) { ctx->triAccelValid = false; ctx->bakeValid = false; }
         o.triLeafSize = g;
     } else if (k == "dispatch_order") {

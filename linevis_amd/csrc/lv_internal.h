@@ -41,7 +41,7 @@ struct LvOptions {
     uint32_t aoSamplesPerFrame = 4;           // VulkanRayTracedAmbientOcclusion.hpp:150
     float aoRadius = 0.1f;                    // :151
     bool aoUseDistance = true;                // :152
-    uint32_t triLeafSize = 2;                 // triangle_leaf_size: consecutive triangles per leaf of the triangle LBVH (1, 2, 4)
+    uint32_t triLeafSize = 2;                 // triangle_leaf_size: consecutive triangles per leaf of the triangle LBVH (1 ... 8)
     bool dispatchByCost = true;               // dispatch_order = cost | as_numbered (tile kernels: heaviest 64x64 group of the last frame first)
     bool aoJitterPrimary = true;              // :153
     uint32_t numSamplesPerFrame = 1;          // VulkanRayTracer.hpp:137 has 2 (interactive); offline default 1
