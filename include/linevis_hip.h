@@ -183,6 +183,8 @@ int lv_set_background(lv_ctx* ctx, const float rgba[4]);
  *   sorting_mode: the "Sorting Mode" combo box of the PPLL renderer (.cpp:470-475, GUI-only in the reference): a name of
  *   SORTING_MODE_NAMES -- "Priority Queue" (default) | "Bubble Sort" | "Insertion Sort" | "Shell Sort" | "Max Heap" |
  *   "Bitonic Sort" | "Quicksort" | "Quicksort Hybrid" (src/Renderers/PPLL.hpp:32-50) -- or its index 0..7,
+ *   triangle_leaf_size (build-owned): consecutive triangles per leaf of the triangle LBVH, 1 ... 8 (default 2: a tube face);
+ *   changes the acceleration structure only, never a hit,
  *   dispatch_order (build-owned, no counterpart): "cost" (default: the tile kernels start their 64x64-pixel groups heaviest-of-
  *   the-previous-frame first, see lv_get_dispatch_order) | "as_numbered" (tile-list order); the image is the same,
  *   rtao_prebaker_iterations (128), rtao_prebaker_samples_per_frame (4), rtao_prebaker_num_tube_subdivisions (8): the
