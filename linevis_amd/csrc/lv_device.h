@@ -61,6 +61,12 @@
 #define LV_AO_BLOCKS_PER_CU 5
 #endif
 #define LV_AO_QCAP 128         // leaf FIFO entries per wave (<= 63 waiting + 64 new per step)
+#ifndef LV_AO_TEST_BATCH
+#define LV_AO_TEST_BATCH 56u      // k_ao_rays: queued leaf tests that end a descend stint (r03: 44 / 48 / 52 / 56 / 64 = 4.39 / 4.34 / 4.31 / 4.30 / 4.35 ms)
+#endif
+#ifndef LV_AO_TEST_BATCH_TRI
+#define LV_AO_TEST_BATCH_TRI 56u  // ... on the triangle tubes (5.20 / 5.18 / 5.17 / 5.16 / 5.23 ms)
+#endif
 #ifndef LV_NODE_MIN_ACTIVE
 #define LV_NODE_MIN_ACTIVE 24  // node loop yields to the leaf loop when fewer lanes than this are descending
 #endif

@@ -395,6 +395,9 @@ __global__ __launch_bounds__(LV_AO_BLOCK, LV_AO_MIN_WAVES) void k_ao_rays(const 
     float best = 0.0f;
     unsigned cur = LV_INVALID, lastSeq = 0;
     unsigned owner = lane; // lane whose ray this lane descends for: its own, except in the drain phase (below)
+    // queued (owner, leaf) pairs that start a test phase: a little less than a full wave -- the stint ends sooner for the lanes whose
+    // ray is finished and waits for it, at the price of test phases that run at 56 / 64 (LV_AO_TEST_BATCH*, measured)
+    constexpr unsigned TB = PRIM == LV_PRIM_TRIANGLE ? LV_AO_TEST_BATCH_TRI : LV_AO_TEST_BATCH;
 
     while (true) {
         // ---- leaves reached in the previous step join the FIFO -- while fewer than 64 pairs wait, so that it never holds
@@ -411,7 +414,7 @@ __global__ __launch_bounds__(LV_AO_BLOCK, LV_AO_MIN_WAVES) void k_ao_rays(const 
                     cur = lv_pop_or_done(st);
                 }
                 tail += unsigned(__popcll(mL));
-                if (tail - head < LV_WAVE) continue; // a popped reference may be a leaf again
+                if (tail - head < TB) continue; // a popped reference may be a leaf again
             }
         }
         const bool canRefill = (genPos < genCount) || !sourceDry;
@@ -434,7 +437,7 @@ __global__ __launch_bounds__(LV_AO_BLOCK, LV_AO_MIN_WAVES) void k_ao_rays(const 
         const int nNode = __popcll(mNode), nIdle = __popcll(mIdle);
         const unsigned q = tail - head;
 
-        if (q >= LV_WAVE || (q > 0 && nNode == 0 && !(canRefill && nIdle > 0))) {
+        if (q >= TB || (q > 0 && nNode == 0 && !(canRefill && nIdle > 0))) {
             // ---- test phase: one (owner, leaf) pair per lane
             const unsigned n = q < LV_WAVE ? q : LV_WAVE;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -616,7 +619,7 @@ __global__ __launch_bounds__(LV_AO_BLOCK, LV_AO_MIN_WAVES) void k_ao_rays(const 
                     tail += unsigned(__popcll(mL));
                 }
                 nNow = __popcll(__ballot(!(cur & LV_LEAF_BIT)));
-            } while (tail - head < LV_WAVE && nNow >= (drain ? LV_HANDOVER_MAX_BUSY + 1 : stay));
+            } while (tail - head < TB && nNow >= (drain ? LV_HANDOVER_MAX_BUSY + 1 : stay));
             continue;
         }
         if (nIdle == LV_WAVE && !canRefill) break; // nothing alive, nothing left to fetch
