@@ -67,6 +67,12 @@
 #ifndef LV_AO_TEST_BATCH_TRI
 #define LV_AO_TEST_BATCH_TRI 56u  // ... on the triangle tubes (5.20 / 5.18 / 5.17 / 5.16 / 5.23 ms)
 #endif
+#ifndef LV_TRACE_TEST_BATCH
+#define LV_TRACE_TEST_BATCH 64u     // lv_trace_closest (tile kernels): queued leaf tests that end a descend stint
+#endif
+#ifndef LV_TRACE_TEST_BATCH_ALL
+#define LV_TRACE_TEST_BATCH_ALL 64u // lv_trace_all (PPLL gather, MLAT)
+#endif
 #ifndef LV_NODE_MIN_ACTIVE
 #define LV_NODE_MIN_ACTIVE 24  // node loop yields to the leaf loop when fewer lanes than this are descending
 #endif

@@ -707,12 +707,12 @@ __device__ __forceinline__ LvHit lv_trace_closest(const LvSceneDev& S, float rad
                 cur = lv_pop_or_done(st);
             }
             tail += unsigned(__popcll(mL));
-            if (tail - head < LV_WAVE) continue; // a popped reference may be a leaf again
+            if (tail - head < LV_TRACE_TEST_BATCH) continue; // a popped reference may be a leaf again
         }
         const unsigned long long mNode = __ballot(!(cur & LV_LEAF_BIT));
         const int nNode = __popcll(mNode);
         const unsigned q = tail - head;
-        if (q >= LV_WAVE || (q > 0 && nNode == 0)) {
+        if (q >= LV_TRACE_TEST_BATCH || (q > 0 && nNode == 0)) {
             const unsigned n = q < LV_WAVE ? q : LV_WAVE;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             if (lane < n) {
@@ -783,7 +783,7 @@ __device__ __forceinline__ LvHit lv_trace_closest(const LvSceneDev& S, float rad
                 tail += unsigned(__popcll(m));
             }
             nNow = __popcll(__ballot(!(cur & LV_LEAF_BIT)));
-        } while (tail - head < LV_WAVE && nNow > LV_HANDOVER_MAX_BUSY);
+        } while (tail - head < LV_TRACE_TEST_BATCH && nNow > LV_HANDOVER_MAX_BUSY);
     }
     const unsigned long long key = cm.key[lane];
     if (active && key != keyInit) {
@@ -861,11 +861,11 @@ __device__ __forceinline__ void lv_trace_all(const LvSceneDev& S, float radius, 
                 cur = lv_pop_or_done(st);
             }
             tail += unsigned(__popcll(mL));
-            if (tail - head < LV_WAVE) continue;
+            if (tail - head < LV_TRACE_TEST_BATCH_ALL) continue;
         }
         const int nNode = __popcll(__ballot(!(cur & LV_LEAF_BIT)));
         const unsigned q = tail - head;
-        if (q >= LV_WAVE || (q > 0 && nNode == 0)) {
+        if (q >= LV_TRACE_TEST_BATCH_ALL || (q > 0 && nNode == 0)) {
             const unsigned n = q < LV_WAVE ? q : LV_WAVE;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             // a leaf of the triangle LBVH holds S.triLeafSize triangles: one round of tests + hit queueing per slot (wave-uniform)
@@ -967,7 +967,7 @@ __device__ __forceinline__ void lv_trace_all(const LvSceneDev& S, float radius, 
                 tail += unsigned(__popcll(m));
             }
             nNow = __popcll(__ballot(!(cur & LV_LEAF_BIT)));
-        } while (tail - head < LV_WAVE && nNow > HO_BUSY);
+        } while (tail - head < LV_TRACE_TEST_BATCH_ALL && nNow > HO_BUSY);
     }
     if (hTail != hHead) shadeBatch(hTail - hHead); // the rest (< 64)
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
