@@ -247,7 +247,7 @@ static double sahCost(const BTree& T) {
 }
 
 // ---------------------------------------------------------------- 4-wide collapse (k_collapse_select's greedy rule)
-struct WNode { Box cb[4]; int32_t c[4]; int n; int level; }; // child >= 0: wide node, < 0: ~prim, INT32_MIN: empty
+struct WNode { Box cb[8]; int32_t c[8]; int n; int level; }; // child >= 0: wide node, < 0: ~prim, INT32_MIN: empty (width 4 or 8)
 struct WTree { std::vector<WNode> nodes; int levels; };
 
 static WTree collapse(const BTree& T, int width = 4) {
@@ -268,7 +268,7 @@ static WTree collapse(const BTree& T, int width = 4) {
                 s[bk] = T.nodes[c].l; s[ns++] = T.nodes[c].r;
             }
             WNode wn; wn.n = ns; wn.level = W.levels;
-            for (int k = 0; k < 4; k++) wn.c[k] = INT32_MIN;
+            for (int k = 0; k < 8; k++) wn.c[k] = INT32_MIN;
             for (int k = 0; k < ns; k++) {
                 if (s[k] < 0) { wn.c[k] = s[k]; wn.cb[k] = g_boxes[~s[k]]; }
                 else { wn.cb[k] = T.nodes[s[k]].box; wn.c[k] = int32_t(W.nodes.size()); W.nodes.push_back(WNode{}); next.push_back({s[k], wn.c[k]}); }
@@ -311,7 +311,7 @@ static bool rayTri(V3 o, V3 d, const Tri& T, float& t) {
     const V3 q = cross(tv, e1); const float v = dot(d, q) * r; if (!(v >= 0.0f && u + v <= 1.0f)) return false;
     t = dot(e2, q) * r; return true;
 }
-struct Counters { uint64_t rays = 0, nodes = 0, prims = 0, hits = 0; uint64_t perLevel[48] = {0}; };
+struct Counters { uint64_t rays = 0, nodes = 0, prims = 0, hits = 0, boxes = 0; uint64_t perLevel[48] = {0}; };
 
 // closest hit with the kernel's visiting rule; immediate leaf tests (the kernel batches them: best shrinks a little later there)
 // g_order: 0 = the kernel's rule (nearest hit child first, the rest as stored), 1 = all hit children sorted front to back,
@@ -327,7 +327,8 @@ static bool trace(const WTree& W, V3 o, V3 d, float tMin, float tMax, float& tHi
         if (cur >= 0) {
             const WNode& n = W.nodes[cur];
             C.nodes++; C.perLevel[std::min(n.level, 47)]++;
-            float key[4]; int32_t ch[4]; int nh = 0;
+            float key[8]; int32_t ch[8]; int nh = 0;
+            C.boxes += uint64_t(n.n);
             for (int k = 0; k < n.n; k++) {
                 float tn = tMin, tf = best;
                 for (int a = 0; a < 3; a++) {
@@ -356,6 +357,17 @@ static bool trace(const WTree& W, V3 o, V3 d, float tMin, float tMax, float& tHi
                     float tn = tMin, tf = best;
                     for (int a = 0; a < 3; a++) { float t0 = (n.cb[k].mn[a] - oo[a]) * inv[a], t1 = (n.cb[k].mx[a] - oo[a]) * inv[a]; if (t0 > t1) std::swap(t0, t1); tn = std::max(tn, t0); tf = std::min(tf, t1); }
                     if (tn <= tf) { key[j] = sgn * (n.cb[k].mn[ax] + n.cb[k].mx[ax]); ch[j] = n.c[k]; j++; }
+                }
+                for (int a = 1; a < nh; a++) for (int b = a; b > 0 && key[b] < key[b - 1]; b--) { std::swap(key[b], key[b - 1]); std::swap(ch[b], ch[b - 1]); }
+                for (int k = nh - 1; k >= 1; k--) stack[sp++] = ch[k];
+                cur = ch[0];
+            } else if (g_order == 4) { // sort-free octant order (optimistic stand-in for the slot ^ octant order of compressed wide BVHs):
+                // hit children by the projection of their centroid on the ray's octant diagonal
+                int j = 0;
+                for (int k = 0; k < n.n; k++) {
+                    float tn = tMin, tf = best;
+                    for (int a = 0; a < 3; a++) { float t0 = (n.cb[k].mn[a] - oo[a]) * inv[a], t1 = (n.cb[k].mx[a] - oo[a]) * inv[a]; if (t0 > t1) std::swap(t0, t1); tn = std::max(tn, t0); tf = std::min(tf, t1); }
+                    if (tn <= tf) { float pr = 0; for (int a = 0; a < 3; a++) pr += (inv[a] < 0.0f ? -1.0f : 1.0f) * (n.cb[k].mn[a] + n.cb[k].mx[a]); key[j] = pr; ch[j] = n.c[k]; j++; }
                 }
                 for (int a = 1; a < nh; a++) for (int b = a; b > 0 && key[b] < key[b - 1]; b--) { std::swap(key[b], key[b - 1]); std::swap(ch[b], ch[b - 1]); }
                 for (int k = nh - 1; k >= 1; k--) stack[sp++] = ch[k];
@@ -442,7 +454,8 @@ int main(int argc, char** argv) {
         else if (name.rfind("hyb", 0) == 0) T = buildHybrid(uint32_t(atoi(name.c_str() + 3)));
         else { fprintf(stderr, "unknown builder %s\n", name.c_str()); continue; }
         const double tb = now() - t0;
-        WTree W = collapse(T);
+        const int width = getenv("LAB_WIDTH") ? atoi(getenv("LAB_WIDTH")) : 4;
+        WTree W = collapse(T, width);
         double fill = 0; for (auto& w : W.nodes) fill += w.n;
         printf("[%s] build %.1f s, binary SAH node cost %.2f, wide nodes %zu (%.2f children/node), %d wide levels\n", name.c_str(), tb,
                sahCost(T), W.nodes.size(), fill / W.nodes.size(), W.levels);
@@ -482,7 +495,7 @@ int main(int argc, char** argv) {
             printf("  primary: %llu rays, %.1f node steps and %.1f leaf tests per ray, %llu hit -> %zu AO rays\n", (unsigned long long)C.rays,
                    double(C.nodes) / C.rays, double(C.prims) / C.rays, (unsigned long long)C.hits, rays.size());
         }
-        for (g_order = 0; g_order < (getenv("LAB_ALL_ORDERS") ? 4 : 1); g_order++) {
+        for (g_order = 0; g_order < (getenv("LAB_ALL_ORDERS") ? 5 : 1); g_order++) {
         Counters C;
         t0 = now();
 #pragma omp parallel
@@ -491,11 +504,11 @@ int main(int argc, char** argv) {
 #pragma omp for schedule(dynamic, 4096)
             for (size_t i = 0; i < rays.size(); i++) { float t; uint32_t p = 0; int kind; trace(W, rays[i].o, rays[i].d, 0.0f, aoRadius, t, p, kind, L); }
 #pragma omp critical
-            { C.rays += L.rays; C.nodes += L.nodes; C.prims += L.prims; C.hits += L.hits; for (int k = 0; k < 48; k++) C.perLevel[k] += L.perLevel[k]; }
+            { C.rays += L.rays; C.nodes += L.nodes; C.prims += L.prims; C.hits += L.hits; C.boxes += L.boxes; for (int k = 0; k < 48; k++) C.perLevel[k] += L.perLevel[k]; }
         }
-        static const char* ORD[4] = {"nearest first (kernel)", "fully sorted", "as stored", "sign order along the node's widest axis"};
-        printf("  AO, %s: %.2f node steps, %.2f leaf tests per ray, %.1f %% of the rays hit (%.1f s)\n", ORD[g_order], double(C.nodes) / C.rays,
-               double(C.prims) / C.rays, 100.0 * C.hits / C.rays, now() - t0);
+        static const char* ORD[5] = {"nearest first (kernel)", "fully sorted", "as stored", "sign order along the node's widest axis", "octant-diagonal order"};
+        printf("  AO, %s: %.2f node steps, %.2f child boxes, %.2f leaf tests per ray, %.1f %% of the rays hit (%.1f s)\n", ORD[g_order], double(C.nodes) / C.rays,
+               double(C.boxes) / C.rays, double(C.prims) / C.rays, 100.0 * C.hits / C.rays, now() - t0);
         if (g_order == 0) {
             printf("    node steps per ray by wide level:");
             for (int k = 0; k < W.levels && k < 48; k++) printf(" %.2f", double(C.perLevel[k]) / C.rays);
