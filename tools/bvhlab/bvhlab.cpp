@@ -42,7 +42,9 @@ struct Seg { V3 p0, p1; };
 static std::vector<Seg> g_segs;       // capsule mode: g_segs.size() primitives
 struct Tri { V3 a, b, c; };
 static std::vector<Tri> g_tris;       // triangle mode (the reference's RTAO geometry): g_tris.size() primitives
-static uint32_t numPrims() { return uint32_t(g_tris.empty() ? g_segs.size() : g_tris.size()); }
+static uint32_t g_leaf = 1;            // consecutive primitives per leaf (LAB_LEAF)
+static uint32_t numRaw() { return uint32_t(g_tris.empty() ? g_segs.size() : g_tris.size()); }
+static uint32_t numPrims() { return (numRaw() + g_leaf - 1) / g_leaf; }
 static std::vector<Box> g_boxes;
 static float g_radius;
 
@@ -378,12 +380,13 @@ static bool trace(const WTree& W, V3 o, V3 d, float tMin, float tMax, float& tHi
                 cur = ch[m];
             }
         } else {
-            const uint32_t p = uint32_t(~cur);
-            C.prims++;
-            float t; int kind;
-            const bool hitp = g_tris.empty() ? capsule(o, d, g_segs[p], g_radius, t, kind) : (kind = 0, rayTri(o, d, g_tris[p], t));
-            if (hitp && t >= tMin && t <= best) {
-                if (t < best || !found || p < prim) { best = t; prim = p; kindOut = kind; found = true; }
+            for (uint32_t p = uint32_t(~cur) * g_leaf; p < std::min(numRaw(), (uint32_t(~cur) + 1u) * g_leaf); p++) {
+                C.prims++;
+                float t; int kind;
+                const bool hitp = g_tris.empty() ? capsule(o, d, g_segs[p], g_radius, t, kind) : (kind = 0, rayTri(o, d, g_tris[p], t));
+                if (hitp && t >= tMin && t <= best) {
+                    if (t < best || !found || p < prim) { best = t; prim = p; kindOut = kind; found = true; }
+                }
             }
             if (sp == 0) break;
             cur = stack[--sp];
@@ -435,7 +438,17 @@ int main(int argc, char** argv) {
         const float a[3] = {g_segs[i].p0.x, g_segs[i].p0.y, g_segs[i].p0.z}, b[3] = {g_segs[i].p1.x, g_segs[i].p1.y, g_segs[i].p1.z};
         for (int k = 0; k < 3; k++) { g_boxes[i].mn[k] = std::min(a[k], b[k]) - radius - pad; g_boxes[i].mx[k] = std::max(a[k], b[k]) + radius + pad; }
     }
-    printf("%u segments, radius %g, pixel stride %d, %d AO samples per hit pixel\n", n, radius, stride, spp);
+    if (getenv("LAB_LEAF") && atoi(getenv("LAB_LEAF")) > 1) {
+        g_leaf = uint32_t(atoi(getenv("LAB_LEAF")));
+        std::vector<Box> merged(numPrims());
+        for (uint32_t g = 0; g < numPrims(); g++) {
+            merged[g].reset();
+            for (uint32_t p = g * g_leaf; p < std::min(n, (g + 1) * g_leaf); p++)
+                for (int k = 0; k < 3; k++) { merged[g].mn[k] = std::min(merged[g].mn[k], g_boxes[p].mn[k]); merged[g].mx[k] = std::max(merged[g].mx[k], g_boxes[p].mx[k]); }
+        }
+        g_boxes.swap(merged);
+    }
+    printf("%u primitives, %u per leaf, radius %g, pixel stride %d, %d AO samples per hit pixel\n", n, g_leaf, radius, stride, spp);
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
 
     std::vector<AoRay> rays;   // generated once, with the first tree
