@@ -52,3 +52,24 @@ def test_dispatch_order_with_dilated_ao_tiles_and_the_whole_viewport_pass(hip_li
             frames[order] = [ctx.render(11) for _ in range(3)]
         for a, b in zip(frames["as_numbered"], frames["cost"]):
             assert np.array_equal(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [11, 2])
+def test_moving_camera_keeps_both_orders_identical(hip_lib, mode):
+    """A camera path: every frame is dispatched in the order the PREVIOUS view measured (a stale predictor by construction) and must
+    still equal the frame of the tile-list order, byte for byte; the order itself keeps changing along the path."""
+    from linevis_amd import camera
+    c = small_case(width=400, height=264, n_lines=60, pts_per_line=40, line_width=0.012, transparent=(mode == 2), **RTAO)
+    a, b = c.hip_context(), c.hip_context()
+    a.set_option("dispatch_order", "as_numbered")
+    b.set_option("dispatch_order", "cost")
+    orders = []
+    for k in range(6):
+        pos = (0.25 * np.sin(0.5 * k), 0.1 * k - 0.2, 0.8 - 0.05 * k)
+        view, proj, fovy, near, far = camera.default_camera(c.width, c.height, pos)
+        for ctx in (a, b):
+            ctx.set_camera(view, proj, fovy, near, far, c.width, c.height)
+        assert np.array_equal(a.render(mode), b.render(mode)), k
+        orders.append(b.dispatch_order()[0].copy())
+    assert any(not np.array_equal(orders[i], orders[i + 1]) for i in range(1, 5))
