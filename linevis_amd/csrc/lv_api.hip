@@ -572,6 +572,15 @@ int lv_set_option(lv_ctx* ctx, const char* key, const char* value) {
         if (!parseUint(value, g) || g < 1 || g > 8) return bad();
         if (g != o.triLeafSize) { ctx->triAccelValid = false; ctx->bakeValid = false; }
         o.triLeafSize = g;
+    } else if (k == "accel_build") {
+        // the analogue of the reference's VK_BUILD_ACCELERATION_STRUCTURE_PREFER_FAST_TRACE_BIT_KHR (LineData.cpp:740-741): "fast_trace"
+        // (default) rebuilds the LBVH's subtrees of <= 256 leaves with a binned SAH, "fast_build" keeps the plain LBVH
+        bool ft;
+        if (std::string(value) == "fast_trace") ft = true;
+        else if (std::string(value) == "fast_build") ft = false;
+        else return bad();
+        if (ft != o.accelFastTrace) { ctx->accelValid = false; ctx->triAccelValid = false; ctx->bakeValid = false; }
+        o.accelFastTrace = ft;
     } else if (k == "dispatch_order") {
         // tile kernels: "cost" = the 64x64-pixel groups start in the order of what they cost in the previous frame, heaviest
         // first (default); "as_numbered" = in tile-list order (measurement knob; the image is the same)

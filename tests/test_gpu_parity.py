@@ -307,6 +307,7 @@ def test_deep_lbvh_uses_stack_overflow_slab(hip_lib):
     c = Case(P, np.array(seg, np.uint32), tfm.standard_transparent(), 96, 96, 0.0004, camera_pos=(0.3, 0.3, 0.9), **RTAO,
              ambient_occlusion_iterations=1, ambient_occlusion_samples_per_frame=8)
     ctx = c.hip_context()
+    ctx.set_option("accel_build", "fast_build")   # the plain LBVH: the SAH treelets of the default build would balance these 54 leaves
     ctx.build_accel()
     assert ctx.stats().bvh_depth > 32   # binary height: 3 * ceil(h / 2) + 2 stack entries exceed the 32 kept in LDS
     for mode in (11, 2):

@@ -124,7 +124,9 @@ static const V3* centroids() {
     return cen.data();
 }
 
-// full-sweep SAH below `sweepBelow` primitives, 64-bin SAH above; leaves hold one primitive (like the library's)
+static int g_bins = 64;               // bins of the binned SAH split (LAB_BINS)
+static int g_hybSweepBelow = -1;      // hybrid builder: full sweep below this many leaves, binned above (LAB_HYB_SWEEP; -1 = always sweep)
+// full-sweep SAH below `sweepBelow` primitives, binned SAH above; leaves hold one primitive (like the library's)
 struct SahBuilder {
     BTree T;
     std::vector<uint32_t> idx;
@@ -152,17 +154,17 @@ struct SahBuilder {
             }
             if (bestAxis != 2) std::sort(idx.begin() + lo, idx.begin() + hi, [&](uint32_t x, uint32_t y) { return (&cen[x].x)[bestAxis] < (&cen[y].x)[bestAxis]; });
         } else {
-            const int NB = 64;
+            const int NB = g_bins;
             for (int a = 0; a < 3; a++) {
                 const float ext = cb.mx[a] - cb.mn[a];
                 if (!(ext > 0.0f)) continue;
-                Box bb[NB]; uint32_t cnt[NB];
+                Box bb[64]; uint32_t cnt[64];
                 for (int k = 0; k < NB; k++) { bb[k].reset(); cnt[k] = 0; }
                 for (uint32_t i = lo; i < hi; i++) {
                     int k = int(((&cen[idx[i]].x)[a] - cb.mn[a]) / ext * NB); k = std::min(std::max(k, 0), NB - 1);
                     bb[k].grow(g_boxes[idx[i]]); cnt[k]++;
                 }
-                float ra[NB]; uint32_t rc[NB]; Box b; b.reset(); uint32_t c = 0;
+                float ra[64]; uint32_t rc[64]; Box b; b.reset(); uint32_t c = 0;
                 for (int k = NB - 1; k > 0; k--) { b.grow(bb[k]); c += cnt[k]; ra[k] = b.halfArea(); rc[k] = c; }
                 b.reset(); c = 0;
                 for (int k = 1; k < NB; k++) {
@@ -222,7 +224,7 @@ static BTree buildHybrid(uint32_t K) {
     std::function<int32_t(int32_t)> rec = [&](int32_t c) -> int32_t {
         if (c < 0) return c;
         if (cnt[c] <= K) {
-            SahBuilder B; B.sweepBelow = K + 1;
+            SahBuilder B; B.sweepBelow = g_hybSweepBelow >= 0 ? uint32_t(g_hybSweepBelow) : K + 1;
             collectLeaves(L, c, B.idx);
             B.cen = centroids();
             const int32_t r = B.build(0, uint32_t(B.idx.size()));
@@ -438,6 +440,8 @@ int main(int argc, char** argv) {
         const float a[3] = {g_segs[i].p0.x, g_segs[i].p0.y, g_segs[i].p0.z}, b[3] = {g_segs[i].p1.x, g_segs[i].p1.y, g_segs[i].p1.z};
         for (int k = 0; k < 3; k++) { g_boxes[i].mn[k] = std::min(a[k], b[k]) - radius - pad; g_boxes[i].mx[k] = std::max(a[k], b[k]) + radius + pad; }
     }
+    if (getenv("LAB_BINS")) g_bins = std::min(64, std::max(2, atoi(getenv("LAB_BINS"))));
+    if (getenv("LAB_HYB_SWEEP")) g_hybSweepBelow = atoi(getenv("LAB_HYB_SWEEP"));
     if (getenv("LAB_LEAF") && atoi(getenv("LAB_LEAF")) > 1) {
         g_leaf = uint32_t(atoi(getenv("LAB_LEAF")));
         std::vector<Box> merged(numPrims());
