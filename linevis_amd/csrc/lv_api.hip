@@ -572,6 +572,11 @@ int lv_set_option(lv_ctx* ctx, const char* key, const char* value) {
         if (!parseUint(value, g) || g < 1 || g > 8) return bad();
         if (g != o.triLeafSize) { ctx->triAccelValid = false; ctx->bakeValid = false; }
         o.triLeafSize = g;
+    } else if (k == "treelet_leaves") {
+        uint32_t t;
+        if (!parseUint(value, t) || t < 3 || t > 1024) return bad();
+        if (t != o.treeletLeaves) { ctx->accelValid = false; ctx->triAccelValid = false; ctx->bakeValid = false; }
+        o.treeletLeaves = t;
     } else if (k == "accel_build") {
         // the analogue of the reference's VK_BUILD_ACCELERATION_STRUCTURE_PREFER_FAST_TRACE_BIT_KHR (LineData.cpp:740-741): "fast_trace"
         // (default) rebuilds the LBVH's subtrees of <= 256 leaves with a binned SAH, "fast_build" keeps the plain LBVH

@@ -224,32 +224,30 @@ __global__ __launch_bounds__(LV_BLOCK) void k_karras(const uint64_t* __restrict_
 
 // ---------------------------------------------------------------- treelet rebuild (accel_build = fast_trace)
 // The reference asks its driver for VK_BUILD_ACCELERATION_STRUCTURE_PREFER_FAST_TRACE (LineData.cpp:740-741,903,942,980): build time
-// is spent on trace speed.  Here: Morton order decides which leaves belong together down to subtrees of at most LV_TREELET_LEAVES
-// leaves, and every such subtree is rebuilt by ONE WAVE with a binned surface-area heuristic (16 bins per axis on the box centres,
+// is spent on trace speed.  Here: Morton order decides which leaves belong together down to subtrees of at most `treelet_leaves`
+// (256) leaves, and every such subtree is rebuilt by ONE WAVE with a binned surface-area heuristic (16 bins per axis on the box centres,
 // boxes and counts in LDS, the best of the 45 planes, stable partition, smaller half first).  The Karras numbering makes it an in-place
 // operation: a subtree over the sorted leaves lo ... hi owns the internal nodes lo + 1 ... hi - 1 and its root (lo or hi), so the new
 // topology is written into the old slots (the subtree's root keeps its index -- its parent points there) and refit / collapse run unchanged.
 // Measured on the CPU model first (tools/bvhlab, hyb256 with 16 bins): - 5.7 % node steps per AO ray on config 3's capsules,
 // - 7.2 % on its triangle tubes; closest hits do not depend on the topology.
-#ifndef LV_TREELET_LEAVES
-#define LV_TREELET_LEAVES 256u
-#endif
+// (the treelet size is a run-time value, treelet_leaves <= 1024: 32 bytes of LDS per leaf)
 #define LV_TREELET_BINS 16u
 
 __global__ __launch_bounds__(LV_BLOCK) void k_treelet_roots(uint32_t nInternal, const uint32_t* __restrict__ childL,
                                                             const uint32_t* __restrict__ childR, const uint32_t* __restrict__ rangeLo,
-                                                            const uint32_t* __restrict__ rangeHi, uint32_t* __restrict__ roots,
-                                                            uint32_t* __restrict__ count) {
+                                                            const uint32_t* __restrict__ rangeHi, uint32_t maxLeaves,
+                                                            uint32_t* __restrict__ roots, uint32_t* __restrict__ count) {
     const uint32_t i = blockIdx.x * LV_BLOCK + threadIdx.x;
     if (i >= nInternal) return;
     const uint32_t size = rangeHi[i] - rangeLo[i] + 1u;
-    if (i == 0u && size <= LV_TREELET_LEAVES) { if (size >= 3u) roots[atomicAdd(count, 1u)] = 0u; return; }
-    if (size <= LV_TREELET_LEAVES) return;
+    if (i == 0u && size <= maxLeaves) { if (size >= 3u) roots[atomicAdd(count, 1u)] = 0u; return; }
+    if (size <= maxLeaves) return;
     const uint32_t c[2] = {childL[i], childR[i]};
     for (int k = 0; k < 2; k++) {
         if (c[k] & LV_LEAF_BIT) continue;
         const uint32_t cs = rangeHi[c[k]] - rangeLo[c[k]] + 1u;
-        if (cs <= LV_TREELET_LEAVES && cs >= 3u) roots[atomicAdd(count, 1u)] = c[k]; // (two leaves have one topology)
+        if (cs <= maxLeaves && cs >= 3u) roots[atomicAdd(count, 1u)] = c[k]; // (two leaves have one topology)
     }
 }
 
@@ -266,9 +264,12 @@ __device__ __forceinline__ float lv_wave_max_f(float v) {
 
 __global__ __launch_bounds__(64) void k_treelet_rebuild(const uint32_t* __restrict__ roots, const uint32_t* __restrict__ rangeLo,
                                                         const uint32_t* __restrict__ rangeHi, const float* __restrict__ leafBox,
-                                                        uint32_t* __restrict__ childL, uint32_t* __restrict__ childR) {
-    __shared__ float s_box[LV_TREELET_LEAVES][6];
-    __shared__ uint32_t s_idx[LV_TREELET_LEAVES], s_tmp[LV_TREELET_LEAVES];
+                                                        uint32_t maxLeaves, uint32_t* __restrict__ childL,
+                                                        uint32_t* __restrict__ childR) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[]; // maxLeaves x (24-byte box + two index arrays)
+    float (*s_box)[6] = reinterpret_cast<float (*)[6]>(s_dyn);
+    uint32_t* s_idx = reinterpret_cast<uint32_t*>(s_dyn + size_t(maxLeaves) * 24);
+    uint32_t* s_tmp = s_idx + maxLeaves;
     __shared__ uint32_t s_bmin[3][LV_TREELET_BINS][3], s_bmax[3][LV_TREELET_BINS][3], s_bcnt[3][LV_TREELET_BINS];
     __shared__ uint32_t s_stack[3 * 16];
     const uint32_t lane = threadIdx.x;
@@ -729,14 +730,15 @@ static int lv_bvh_build_core(lv_ctx* ctx, uint32_t n, LvDeviceBuffer& nodesOut, 
             LV_HIPF(hipMemsetAsync(height.ptr, 0, 4, st));
             k_treelet_roots<<<nblocks(nInternal), LV_BLOCK, 0, st>>>(nInternal, (const uint32_t*)childL.ptr, (const uint32_t*)childR.ptr,
                                                                      (const uint32_t*)depth.ptr, (const uint32_t*)evenFlag.ptr,
-                                                                     (uint32_t*)wideIndex.ptr, (uint32_t*)height.ptr);
+                                                                     ctx->opt.treeletLeaves, (uint32_t*)wideIndex.ptr,
+                                                                     (uint32_t*)height.ptr);
             LV_HIPF(hipMemcpyAsync((void*)ctx->pinned, height.ptr, 4, hipMemcpyDeviceToHost, st));
             LV_HIPF(hipStreamSynchronize(st));
             const uint32_t numTreelets = pin[0];
             if (numTreelets)
-                k_treelet_rebuild<<<numTreelets, 64, 0, st>>>((const uint32_t*)wideIndex.ptr, (const uint32_t*)depth.ptr,
-                                                              (const uint32_t*)evenFlag.ptr, (const float*)leafBox.ptr,
-                                                              (uint32_t*)childL.ptr, (uint32_t*)childR.ptr);
+                k_treelet_rebuild<<<numTreelets, 64, size_t(ctx->opt.treeletLeaves) * 32, st>>>(
+                        (const uint32_t*)wideIndex.ptr, (const uint32_t*)depth.ptr, (const uint32_t*)evenFlag.ptr,
+                        (const float*)leafBox.ptr, ctx->opt.treeletLeaves, (uint32_t*)childL.ptr, (uint32_t*)childR.ptr);
         }
         // refit: one pass per level of the binary tree; the root's stamp is polled every 8 passes
         for (uint32_t pass = 1;; pass++) {
