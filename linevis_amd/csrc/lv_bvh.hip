@@ -412,6 +412,7 @@ __global__ __launch_bounds__(64) void k_treelet_rebuild(const uint32_t* __restri
                 __syncthreads();
                 for (uint32_t j = lo + lane; j < hi; j += 64u) s_idx[j] = s_tmp[j];
                 __syncthreads();
+                if (nl == 0u || nl == n) nl = n / 2u; // cannot happen with finite boxes (both sides of the chosen plane hold leaves); NaN input
             }
         }
         // children of `slot`: a single leaf becomes a leaf reference, a longer range gets a slot of its own
