@@ -62,9 +62,15 @@ def test_tie_break_lowest_segment(hip_lib):
     assert s[0] == 0 and k[0] == 2
 
 
-def test_lbvh_structure(hip_lib):
+@pytest.mark.parametrize("build", [dict(), dict(accel_build="fast_build"), dict(treelet_leaves=3), dict(treelet_leaves=7),
+                                   dict(treelet_leaves=64), dict(treelet_leaves=1024)])
+def test_lbvh_structure(hip_lib, build):
+    """default = fast_trace (every subtree of <= 512 leaves rebuilt by the binned SAH: here the 2940 segments form a handful of
+    treelets); 1024 >= n / 3 exercises big treelets, 3 and 7 the smallest ones, fast_build the plain LBVH"""
     c = small_case(n_lines=60, pts_per_line=50, seed=5, line_width=0.01)
     ctx = c.hip_context()
+    for k, v in build.items():
+        ctx.set_option(k, v)
     ctx.build_accel()
     st = ctx.stats()
     n = len(c.seg)
@@ -113,6 +119,41 @@ def test_golden_frames_ray_tracer(hip_lib):
     assert np.array_equal(bits(ctx.depth_range()), g["depth_range_bits"])
     c = Case(pts, g["seg"], g["tf_transparent"], W, H, lw, num_samples_per_frame=4)
     assert max_lsb_diff(c.hip_context().render(11), g["rt_transparent_spp4"]) <= LSB_TOL
+
+
+def test_every_build_gives_the_same_hits_and_frames(hip_lib):
+    """accel_build / treelet_leaves change the topology only: closest hits, AO factors and PPLL frames are identical -- also for a
+    scene smaller than one treelet (the whole tree is rebuilt) and for duplicate segments (all box centres in one bin)."""
+    rng = np.random.default_rng(12)
+    c = small_case(width=160, height=104, n_lines=40, pts_per_line=40, line_width=0.012, transparent=True, **RTAO,
+                   ambient_occlusion_iterations=1, ambient_occlusion_samples_per_frame=6)
+    o = rng.uniform(-0.4, 0.4, (20000, 3)).astype(np.float32)
+    d = rng.normal(size=(20000, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    want = None
+    for build in (dict(accel_build="fast_build"), dict(), dict(treelet_leaves=3), dict(treelet_leaves=100), dict(treelet_leaves=1024)):
+        ctx = c.hip_context()
+        for k, v in build.items():
+            ctx.set_option(k, v)
+        got = (ctx.trace_rays(o, d, 1e-4, 10.0), ctx.render(11), ctx.get_ao(), ctx.render(2))
+        if want is None:
+            want = got
+            assert (got[0][1] != 0xFFFFFFFF).sum() > 300
+        else:
+            assert np.array_equal(bits(got[0][0]), bits(want[0][0])) and np.array_equal(got[0][1], want[0][1]), build
+            assert np.array_equal(got[1], want[1]) and np.array_equal(bits(got[2]), bits(want[2])), build
+            assert np.array_equal(got[3], want[3]), build
+    # 64 identical segments: every split falls back to the middle of the range
+    pts = np.zeros(128, dtype=lvo.LINE_POINT_DTYPE)
+    pts["linePosition"][0::2] = [-0.1, 0.0, 0.0]
+    pts["linePosition"][1::2] = [0.1, 0.0, 0.0]
+    pts["lineTangent"] = [1, 0, 0]
+    pts["lineNormal"] = [0, 1, 0]
+    dup = Case(pts, np.arange(128, dtype=np.uint32).reshape(64, 2), tfm.standard_transparent(), 48, 32, 0.1)
+    a = dup.hip_context()
+    b = dup.hip_context()
+    b.set_option("accel_build", "fast_build")
+    assert np.array_equal(a.render(2), b.render(2))
 
 
 def test_golden_rtao(hip_lib):
