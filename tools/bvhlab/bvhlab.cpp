@@ -36,7 +36,10 @@ struct Box {
     void reset() { for (int k = 0; k < 3; k++) { mn[k] = 3e38f; mx[k] = -3e38f; } }
     void grow(const Box& b) { for (int k = 0; k < 3; k++) { mn[k] = std::min(mn[k], b.mn[k]); mx[k] = std::max(mx[k], b.mx[k]); } }
     float halfArea() const { float dx = mx[0] - mn[0], dy = mx[1] - mn[1], dz = mx[2] - mn[2]; return dx * dy + dy * dz + dz * dx; }
+    // measure of the rays of length L (random origin and direction) that meet the box: V + A L / 4 (LAB_RAYLEN; 0 = surface area)
+    float hitMeasure(float L) const { float dx = mx[0] - mn[0], dy = mx[1] - mn[1], dz = mx[2] - mn[2]; const float h = dx * dy + dy * dz + dz * dx; return L > 0.0f ? dx * dy * dz + h * 0.5f * L : h; }
 };
+static float g_rayLen = 0.0f;
 
 struct Seg { V3 p0, p1; };
 static std::vector<Seg> g_segs;       // capsule mode: g_segs.size() primitives
@@ -144,11 +147,11 @@ struct SahBuilder {
             for (int a = 0; a < 3; a++) {
                 std::sort(idx.begin() + lo, idx.begin() + hi, [&](uint32_t x, uint32_t y) { return (&cen[x].x)[a] < (&cen[y].x)[a]; });
                 Box b; b.reset();
-                for (uint32_t i = n - 1; i > 0; i--) { b.grow(g_boxes[idx[lo + i]]); rightArea[i] = b.halfArea(); }
+                for (uint32_t i = n - 1; i > 0; i--) { b.grow(g_boxes[idx[lo + i]]); rightArea[i] = b.hitMeasure(g_rayLen); }
                 b.reset();
                 for (uint32_t i = 1; i < n; i++) {
                     b.grow(g_boxes[idx[lo + i - 1]]);
-                    const float c = b.halfArea() * float(i) + rightArea[i] * float(n - i);
+                    const float c = b.hitMeasure(g_rayLen) * float(i) + rightArea[i] * float(n - i);
                     if (c < bestCost) { bestCost = c; bestAxis = a; bestSplit = i; }
                 }
             }
@@ -165,12 +168,12 @@ struct SahBuilder {
                     bb[k].grow(g_boxes[idx[i]]); cnt[k]++;
                 }
                 float ra[64]; uint32_t rc[64]; Box b; b.reset(); uint32_t c = 0;
-                for (int k = NB - 1; k > 0; k--) { b.grow(bb[k]); c += cnt[k]; ra[k] = b.halfArea(); rc[k] = c; }
+                for (int k = NB - 1; k > 0; k--) { b.grow(bb[k]); c += cnt[k]; ra[k] = b.hitMeasure(g_rayLen); rc[k] = c; }
                 b.reset(); c = 0;
                 for (int k = 1; k < NB; k++) {
                     b.grow(bb[k - 1]); c += cnt[k - 1];
                     if (c == 0 || rc[k] == 0) continue;
-                    const float cost = b.halfArea() * float(c) + ra[k] * float(rc[k]);
+                    const float cost = b.hitMeasure(g_rayLen) * float(c) + ra[k] * float(rc[k]);
                     if (cost < bestCost) { bestCost = cost; bestAxis = a; bestBin = k; bestSplit = c; }
                 }
             }
@@ -440,6 +443,7 @@ int main(int argc, char** argv) {
         const float a[3] = {g_segs[i].p0.x, g_segs[i].p0.y, g_segs[i].p0.z}, b[3] = {g_segs[i].p1.x, g_segs[i].p1.y, g_segs[i].p1.z};
         for (int k = 0; k < 3; k++) { g_boxes[i].mn[k] = std::min(a[k], b[k]) - radius - pad; g_boxes[i].mx[k] = std::max(a[k], b[k]) + radius + pad; }
     }
+    if (getenv("LAB_RAYLEN")) g_rayLen = float(atof(getenv("LAB_RAYLEN")));
     if (getenv("LAB_BINS")) g_bins = std::min(64, std::max(2, atoi(getenv("LAB_BINS"))));
     if (getenv("LAB_HYB_SWEEP")) g_hybSweepBelow = atoi(getenv("LAB_HYB_SWEEP"));
     if (getenv("LAB_LEAF") && atoi(getenv("LAB_LEAF")) > 1) {
