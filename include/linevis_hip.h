@@ -185,7 +185,7 @@ int lv_set_background(lv_ctx* ctx, const float rgba[4]);
  *   "Bitonic Sort" | "Quicksort" | "Quicksort Hybrid" (src/Renderers/PPLL.hpp:32-50) -- or its index 0..7,
  *   accel_build (build-owned; the reference builds its BLAS with VK_BUILD_ACCELERATION_STRUCTURE_PREFER_FAST_TRACE_BIT_KHR,
  *   LineData.cpp:740-741): "fast_trace" (default: LBVH whose subtrees of <= treelet_leaves leaves are rebuilt with a binned
- *   surface-area heuristic) | "fast_build" (the plain LBVH); treelet_leaves (3 ... 1024, default 512),
+ *   surface-area heuristic) | "fast_build" (the plain LBVH); treelet_leaves (3 ... 4096, default 512),
  *   triangle_leaf_size (build-owned): consecutive triangles per leaf of the triangle LBVH, 1 ... 8 (default 2: a tube face);
  *   changes the acceleration structure only, never a hit,
  *   dispatch_order (build-owned, no counterpart): "cost" (default: the tile kernels start their 64x64-pixel groups heaviest-of-

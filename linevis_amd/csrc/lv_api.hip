@@ -574,7 +574,7 @@ int lv_set_option(lv_ctx* ctx, const char* key, const char* value) {
         o.triLeafSize = g;
     } else if (k == "treelet_leaves") {
         uint32_t t;
-        if (!parseUint(value, t) || t < 3 || t > 1024) return bad();
+        if (!parseUint(value, t) || t < 3 || t > 4096) return bad();
         if (t != o.treeletLeaves) { ctx->accelValid = false; ctx->triAccelValid = false; ctx->bakeValid = false; }
         o.treeletLeaves = t;
     } else if (k == "accel_build") {

@@ -736,10 +736,14 @@ static int lv_bvh_build_core(lv_ctx* ctx, uint32_t n, LvDeviceBuffer& nodesOut, 
             LV_HIPF(hipMemcpyAsync((void*)ctx->pinned, height.ptr, 4, hipMemcpyDeviceToHost, st));
             LV_HIPF(hipStreamSynchronize(st));
             const uint32_t numTreelets = pin[0];
-            if (numTreelets)
-                k_treelet_rebuild<<<numTreelets, 64, size_t(ctx->opt.treeletLeaves) * 32, st>>>(
+            if (numTreelets) {
+                const size_t ldsBytes = size_t(ctx->opt.treeletLeaves) * 32;
+                if (ldsBytes > 48 * 1024) // beyond the default limit of dynamic LDS (gfx950: 160 KB per workgroup)
+                    LV_HIPF(hipFuncSetAttribute((const void*)k_treelet_rebuild, hipFuncAttributeMaxDynamicSharedMemorySize, int(ldsBytes)));
+                k_treelet_rebuild<<<numTreelets, 64, ldsBytes, st>>>(
                         (const uint32_t*)wideIndex.ptr, (const uint32_t*)depth.ptr, (const uint32_t*)evenFlag.ptr,
                         (const float*)leafBox.ptr, ctx->opt.treeletLeaves, (uint32_t*)childL.ptr, (uint32_t*)childR.ptr);
+            }
         }
         // refit: one pass per level of the binary tree; the root's stamp is polled every 8 passes
         for (uint32_t pass = 1;; pass++) {

@@ -42,7 +42,7 @@ struct LvOptions {
     float aoRadius = 0.1f;                    // :151
     bool aoUseDistance = true;                // :152
     uint32_t triLeafSize = 2;                 // triangle_leaf_size: consecutive triangles per leaf of the triangle LBVH (1 ... 8)
-    uint32_t treeletLeaves = 512;             // treelet_leaves: largest subtree the fast_trace build rebuilds (3 ... 1024)
+    uint32_t treeletLeaves = 512;             // treelet_leaves: largest subtree the fast_trace build rebuilds (3 ... 4096)
     bool accelFastTrace = true;               // accel_build = fast_trace (LBVH + SAH treelets, the reference's PREFER_FAST_TRACE) | fast_build (LBVH)
     bool dispatchByCost = true;               // dispatch_order = cost | as_numbered (tile kernels: heaviest 64x64 group of the last frame first)
     bool aoJitterPrimary = true;              // :153
