@@ -280,6 +280,18 @@ static WTree collapse(const BTree& T, int width = 4) {
                 if (s[k] < 0) { wn.c[k] = s[k]; wn.cb[k] = g_boxes[~s[k]]; }
                 else { wn.cb[k] = T.nodes[s[k]].box; wn.c[k] = int32_t(W.nodes.size()); W.nodes.push_back(WNode{}); next.push_back({s[k], wn.c[k]}); }
             }
+            if (getenv("LAB_QUANT")) { // the library's node format: child planes on the 8-bit grid of the node's own box, rounded outwards
+                Box U; U.reset();
+                for (int k = 0; k < ns; k++) U.grow(wn.cb[k]);
+                for (int a = 0; a < 3; a++) {
+                    const float step = (U.mx[a] - U.mn[a]) / 255.0f;
+                    if (!(step > 0.0f)) continue;
+                    for (int k = 0; k < ns; k++) {
+                        wn.cb[k].mn[a] = U.mn[a] + std::floor((wn.cb[k].mn[a] - U.mn[a]) / step) * step;
+                        wn.cb[k].mx[a] = U.mn[a] + std::min(255.0f, std::ceil((wn.cb[k].mx[a] - U.mn[a]) / step)) * step;
+                    }
+                }
+            }
             W.nodes[it.wide] = wn;
         }
         frontier.swap(next);
