@@ -330,7 +330,7 @@ static bool rayTri(V3 o, V3 d, const Tri& T, float& t) {
     const V3 q = cross(tv, e1); const float v = dot(d, q) * r; if (!(v >= 0.0f && u + v <= 1.0f)) return false;
     t = dot(e2, q) * r; return true;
 }
-struct Counters { uint64_t rays = 0, nodes = 0, prims = 0, hits = 0, boxes = 0; uint64_t perLevel[48] = {0}; };
+struct Counters { uint64_t rays = 0, nodes = 0, prims = 0, hits = 0, boxes = 0, barren = 0, stalePops = 0; uint64_t perLevel[48] = {0}; };
 
 // closest hit with the kernel's visiting rule; immediate leaf tests (the kernel batches them: best shrinks a little later there)
 // g_order: 0 = the kernel's rule (nearest hit child first, the rest as stored), 1 = all hit children sorted front to back,
@@ -339,7 +339,7 @@ struct Counters { uint64_t rays = 0, nodes = 0, prims = 0, hits = 0, boxes = 0; 
 static int g_order = 0;
 static bool trace(const WTree& W, V3 o, V3 d, float tMin, float tMax, float& tHit, uint32_t& prim, int& kindOut, Counters& C) {
     const float inv[3] = {1.0f / d.x, 1.0f / d.y, 1.0f / d.z}, oo[3] = {o.x, o.y, o.z};
-    int32_t stack[256]; int sp = 0;
+    int32_t stack[256]; float stackT[256]; int sp = 0;
     int32_t cur = 0; float best = tMax; bool found = false;
     C.rays++;
     while (true) {
@@ -357,7 +357,7 @@ static bool trace(const WTree& W, V3 o, V3 d, float tMin, float tMax, float& tHi
                 }
                 if (tn <= tf) { key[nh] = tn; ch[nh] = n.c[k]; nh++; }
             }
-            if (nh == 0) { if (sp == 0) break; cur = stack[--sp]; continue; }
+            if (nh == 0) { C.barren++; if (sp == 0) break; cur = stack[--sp]; if (g_order == 0 && stackT[sp] > best) C.stalePops++; continue; }
             if (g_order == 1) {
                 for (int a = 1; a < nh; a++) for (int b = a; b > 0 && key[b] < key[b - 1]; b--) { std::swap(key[b], key[b - 1]); std::swap(ch[b], ch[b - 1]); }
                 for (int k = nh - 1; k >= 1; k--) stack[sp++] = ch[k];
@@ -393,7 +393,7 @@ static bool trace(const WTree& W, V3 o, V3 d, float tMin, float tMax, float& tHi
                 cur = ch[0];
             } else {
                 int m = 0; for (int k = 1; k < nh; k++) if (key[k] < key[m]) m = k;
-                for (int k = nh - 1; k >= 0; k--) if (k != m) stack[sp++] = ch[k];
+                for (int k = nh - 1; k >= 0; k--) if (k != m) { stackT[sp] = key[k]; stack[sp++] = ch[k]; }
                 cur = ch[m];
             }
         } else {
@@ -407,6 +407,7 @@ static bool trace(const WTree& W, V3 o, V3 d, float tMin, float tMax, float& tHi
             }
             if (sp == 0) break;
             cur = stack[--sp];
+            if (g_order == 0 && stackT[sp] > best) C.stalePops++;
         }
     }
     tHit = best;
@@ -537,11 +538,11 @@ int main(int argc, char** argv) {
 #pragma omp for schedule(dynamic, 4096)
             for (size_t i = 0; i < rays.size(); i++) { float t; uint32_t p = 0; int kind; trace(W, rays[i].o, rays[i].d, 0.0f, aoRadius, t, p, kind, L); }
 #pragma omp critical
-            { C.rays += L.rays; C.nodes += L.nodes; C.prims += L.prims; C.hits += L.hits; C.boxes += L.boxes; for (int k = 0; k < 48; k++) C.perLevel[k] += L.perLevel[k]; }
+            { C.rays += L.rays; C.nodes += L.nodes; C.prims += L.prims; C.hits += L.hits; C.boxes += L.boxes; C.barren += L.barren; C.stalePops += L.stalePops; for (int k = 0; k < 48; k++) C.perLevel[k] += L.perLevel[k]; }
         }
         static const char* ORD[5] = {"nearest first (kernel)", "fully sorted", "as stored", "sign order along the node's widest axis", "octant-diagonal order"};
-        printf("  AO, %s: %.2f node steps, %.2f child boxes, %.2f leaf tests per ray, %.1f %% of the rays hit (%.1f s)\n", ORD[g_order], double(C.nodes) / C.rays,
-               double(C.boxes) / C.rays, double(C.prims) / C.rays, 100.0 * C.hits / C.rays, now() - t0);
+        printf("  AO, %s: %.2f node steps (%.2f of them with no child hit; %.2f pops whose entry distance lies beyond the hit found meanwhile), %.2f child boxes, %.2f leaf tests per ray, %.1f %% of the rays hit (%.1f s)\n", ORD[g_order], double(C.nodes) / C.rays,
+               double(C.barren) / C.rays, double(C.stalePops) / C.rays, double(C.boxes) / C.rays, double(C.prims) / C.rays, 100.0 * C.hits / C.rays, now() - t0);
         if (g_order == 0) {
             printf("    node steps per ray by wide level:");
             for (int k = 0; k < W.levels && k < 48; k++) printf(" %.2f", double(C.perLevel[k]) / C.rays);
