@@ -60,8 +60,13 @@ __device__ __forceinline__ bool lv_block_pixel(const LvUniforms& U, const LvTile
     // k_render_rt 0.45 -> 0.37, k_ppll_gather 3.0 -> 2.0 ms; with 1/8 of the tiles 0.30 -> 0.13 and 0.45 -> 0.23 ms).
     const uint32_t groupsX = T.blocksX / 4u;
     const uint32_t group = rem / 16u, W = (rem % 16u) * 4u + (threadIdx.x >> 6), l = threadIdx.x & 63u;
+#ifdef LV_PIXEL_PATCH // experiment: contiguous 8x8 patch per wave (coherent rays) instead of the stride-8 interleave (balanced waves)
+    const uint32_t lx = (group % groupsX) * 64u + (W & 7u) * 8u + (l & 7u);
+    const uint32_t ly = (group / groupsX) * 64u + (W >> 3) * 8u + (l >> 3);
+#else
     const uint32_t lx = (group % groupsX) * 64u + (l & 7u) * 8u + (W & 7u);
     const uint32_t ly = (group / groupsX) * 64u + (l >> 3) * 8u + (W >> 3);
+#endif
     p.inTile = lx < T.tileW && ly < T.tileH;
     p.x = T.tilesXY[2 * tile] + lx;
     p.y = T.tilesXY[2 * tile + 1] + ly;

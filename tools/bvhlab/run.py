@@ -8,7 +8,7 @@ from linevis_amd import scenes
 from oracle import lvo
 
 here = os.path.dirname(os.path.abspath(__file__))
-out = os.path.join(here, "_build")
+out = os.environ.get("LAB_OUT", "/tmp/bvhlab_build")   # scene dumps are hundreds of MB: never inside the repository snapshot
 os.makedirs(out, exist_ok=True)
 exe = os.path.join(out, "bvhlab")
 subprocess.check_call(["g++", "-O3", "-march=native", "-fopenmp", "-std=c++17", os.path.join(here, "bvhlab.cpp"), "-o", exe])
