@@ -74,13 +74,22 @@ WORKLOADS = {
                 scene="helix", mode=11, ribbons=True, kernel="k_render_rt",
                 settings={"num_samples_per_frame": 1, "depth_cue_strength": 0.0, "use_ribbons": True,
                           "use_analytic_elliptic_tubes": True, "band_width": 0.005, "min_band_thickness": 0.15}),
-    "c4": dict(name="C4: 1M-segment tornado-style streamlines, 1920x1080, PPLL OIT: all-hits gather + per-pixel 4-ary heap "
-                    "resolve, MAX_NUM_FRAGS 64, node pool 20/pixel, tiling 2x8, opacity ramp 0.1..0.6, uncapped tubes (the rasterisers' "
-                    "default programmable-pull mode defines no USE_CAPPED_TUBES, LineData.cpp:1240-1244), fragment colour of the raster "
-                    "tube shader (ppll_fragment_colour=raster)",
+    "c4": dict(name="C4: 1M-segment tornado-style streamlines, 1920x1080, PPLL OIT: gather + per-pixel 4-ary heap resolve, "
+                    "MAX_NUM_FRAGS 64, node pool 20/pixel, tiling 2x8, opacity ramp 0.1..0.6; fragments of the geometry the reference "
+                    "RASTERISES (ppll_fragment_source=raster_prism: the uncapped 6-gon prism of the default programmable-pull mode, "
+                    "LinePassProgrammablePullTubes.glsl:87-224, back faces culled, perspective-correct interpolated inputs), shaded "
+                    "by the raster tube shader (ppll_fragment_colour=raster); the same frame with ppll_fragment_source=capsule_entry "
+                    "(entry hits of analytic capsules: rounds 1-3) is reported as value_capsule_entry",
                scene="tornado", mode=2, settings={"ppll_max_num_frags": 64, "ppll_expected_avg_depth_complexity": 20,
-                                                  "depth_cue_strength": 0.0, "use_capped_tubes": False},
-               kernel="k_ppll_gather", transparent=True),
+                                                  "depth_cue_strength": 0.0, "use_capped_tubes": False,
+                                                  "ppll_fragment_source": "raster_prism"},
+               kernel="k_ppll_gather", transparent=True, also="c4c", also_suffix="capsule_entry"),
+    "c4c": dict(name="C4 scene and settings with ppll_fragment_source=capsule_entry: fragments = entry hits of the pixel-centre ray "
+                     "against the analytic (uncapped) capsules -- the probe of rounds 1-3, NOT the reference's geometry",
+                scene="tornado", mode=2, settings={"ppll_max_num_frags": 64, "ppll_expected_avg_depth_complexity": 20,
+                                                   "depth_cue_strength": 0.0, "use_capped_tubes": False,
+                                                   "ppll_fragment_source": "capsule_entry"},
+                kernel="k_ppll_gather", transparent=True),
     "c4m": dict(name="C4 scene (1M-segment tornado, 1920x1080, opacity ramp 0.1..0.6) through the ray tracer with multi-layer "
                      "alpha tracing, 8 nodes (use_mlat): single pass, approximate OIT",
                 scene="tornado", mode=11, settings={"use_mlat": True, "mlat_num_nodes": 8, "depth_cue_strength": 0.0,
@@ -132,7 +141,8 @@ def cpu_baseline(W, H, pts, seg, tf, attr_range, view, proj, fovy, near, far, ta
         tile = ((W - cw) // 2, (H - ch) // 2, cw, ch)
         st = lvo.Stats()
         t = time.time()
-        if workload == "c4":
+        if workload in ("c4", "c4c"):
+            P.ppllFragmentSource = 1 if workload == "c4" else 0
             sc.render_ppll(P, tile=tile, use_bvh=True, stats=st)
         elif workload == "c4m":
             sc.render_rt_mlat(P, 8, tile=tile, use_bvh=True, stats=st)
@@ -644,10 +654,11 @@ def main():
             result["roofline"]["frame_compulsory_bytes"] = int(st.num_nodes * 64 + len(seg) * 32 + len(pts) * 48 + W * H * (4 + 4)
                                                                + (st.num_tube_triangles * (48 + 32) if wl.get("mesh") else 0))
         if also is not None:
-            result["value_capsules"] = round(also["rays_per_frame"] * args.steps / also["elapsed"] / 1e6, 2)
-            result["ms_per_step_capsules"] = round(also["elapsed"] / args.steps * 1e3, 4)
-            result["fps_capsules"] = round(args.steps / also["elapsed"], 3)
-            result["capsules"] = {"workload": WORKLOADS[wl["also"]]["name"], "rays_per_frame": int(also["rays_per_frame"]),
+            sfx = wl.get("also_suffix", "capsules")
+            result["value_" + sfx] = round(also["rays_per_frame"] * args.steps / also["elapsed"] / 1e6, 2)
+            result["ms_per_step_" + sfx] = round(also["elapsed"] / args.steps * 1e3, 4)
+            result["fps_" + sfx] = round(args.steps / also["elapsed"], 3)
+            result[sfx] = {"workload": WORKLOADS[wl["also"]]["name"], "rays_per_frame": int(also["rays_per_frame"]),
                                   "frame_ms": also["frame_ms"], "kernels_ms": also["kernels"], "counters_rank0": also["local"],
                                   "roofline": roofline(kname, wl["also"], also["kernels"].get(kname, {}).get("median", 0.0),
                                                        also["kernel_bytes"], world)}

@@ -204,6 +204,13 @@ int lv_set_background(lv_ctx* ctx, const float rgba[4]);
  *   ppll_fragment_colour (build-owned): "raster" (default: the PPLL gather shades with the raster tube shader's variant of
  *   computeFragmentColor, LinePassGeometryShaderTubes.glsl:785-815,1079-1087 -- EPSILON_OUTLINE = 0, EPSILON_WHITE =
  *   fwidth(ribbonPosition) over the 2 x 2 pixel quad, cap halo min(rp, |rp2|)) | "ray_tracer" (RayHitCommon.glsl's, a probe),
+ *   ppll_fragment_source (build-owned): "raster_prism" -- the fragments of mode 2 are those of the geometry the reference
+ *   RASTERISES in its default "Tube (Programmable Pull)" mode: per segment the uncapped N-gon prism (N = tube_num_subdivisions) of
+ *   LinePassProgrammablePullTubes.glsl:87-224 / LineDataFlow.cpp:1698-1713, back faces culled (LineRasterPass.cpp:85-96), the
+ *   fragment shader fed with perspective-correct interpolated position / normal / tangent / attribute; the rasteriser is a
+ *   watertight edge-function rasteriser in the space of the pixel's viewing ray (linevis_amd/csrc/lv_prism.h) | "capsule_entry"
+ *   -- entry hits of the pixel-centre ray against the analytic capsules (rounds 1-3 of this build; a probe) | "auto" (default:
+ *   raster_prism for plain flow lines; capsule_entry for band data, rotating helicity bands and the prebaked AO lookup),
  *   ambient_occlusion_denoiser ("None" | "Edge-Avoiding A-Trous Wavelet Transform" (UTF-8 A-grave as in Denoiser.hpp:66; "EAW"
  *   is accepted too) | "SVGF")                                         (VulkanRayTracedAmbientOcclusion.cpp:683-696)
  *   eaw_denoiser_iterations (0..5, default 3), eaw_denoiser_color_weights / _position_weights / _normal_weights,

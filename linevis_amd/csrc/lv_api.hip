@@ -566,6 +566,14 @@ int lv_set_option(lv_ctx* ctx, const char* key, const char* value) {
         if (std::string(value) == "raster") o.ppllRayTracerColour = false;
         else if (std::string(value) == "ray_tracer") o.ppllRayTracerColour = true;
         else return bad();
+    } else if (k == "ppll_fragment_source") {
+        // where the PPLL gather's fragments come from: "raster_prism" = the rasterised N-gon prism of the reference's default "Tube
+        // (Programmable Pull)" mode (lv_prism.h), "capsule_entry" = entry hits of the pixel-centre ray against the analytic capsules
+        // (rounds 1-3; kept as the probe), "auto" (default) = raster_prism wherever it is built
+        if (std::string(value) == "auto") o.ppllFragmentSource = 0;
+        else if (std::string(value) == "capsule_entry") o.ppllFragmentSource = 1;
+        else if (std::string(value) == "raster_prism") o.ppllFragmentSource = 2;
+        else return bad();
     } else if (k == "triangle_leaf_size") {
         // triangles per leaf of the triangle LBVH (build-owned; the hits do not depend on it)
         uint32_t g;

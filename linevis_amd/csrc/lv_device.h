@@ -202,6 +202,19 @@ struct LvSvgfFeat {
     float lastFrameViewProj[16];
 };
 
+// Per-frame constants of the rasterised programmable-pull prism (ppll_fragment_source = raster_prism, lv_prism.h): cos / sin of the
+// ring angles circleIdx / N * 2 pi (LinePassProgrammablePullTubes.glsl:129-131; lv_sincos2pi of circleIdx / N, filled on the host by
+// the same formula), the camera's right axis (column 0 of inverse(viewMatrix)) that spans the ray-space basis, row 2 of the view
+// matrix + the clip distances (depth clipping of the fragments)
+#define LV_PRISM_MAX_SUBDIV 16
+struct LvPrismDev {
+    float c[LV_PRISM_MAX_SUBDIV], s[LV_PRISM_MAX_SUBDIV];
+    float right[3];
+    float viewZ[4];
+    float nearDist, farDist;
+    uint32_t n;
+};
+
 // HBM-resident scene (all read-only during rendering)
 struct LvSceneDev {
     const float4* nodes;        // 64-B compressed 4-wide LBVH nodes, 4 x float4 each (layout: lv_bvh.hip k_pack4)
@@ -233,10 +246,12 @@ struct LvSceneDev {
     // weights (AmbientOcclusionFactorsBuffer / AmbientOcclusionBlendingWeightsBuffer, AmbientOcclusion.glsl:31-38)
     const float* bakedAo;
     const float* bakedBlendingWeights;
+    LvPrismDev prism;           // PPLL gather with ppll_fragment_source = raster_prism
 };
 #define LV_PRIM_CAPSULE 0
 #define LV_PRIM_TRIANGLE 1
 #define LV_PRIM_ELLIPTIC 2
+#define LV_PRIM_PRISM 3         // the rasterised N-gon prism of the segment (all-hits walk of the PPLL gather only, lv_prism.h)
 // shading variant of computeFragmentColor (template parameter of the hit shading; `true` / `false` of the earlier bool still mean
 // USE_BANDS / plain): USE_BANDS and USE_ROTATING_HELICITY_BANDS never occur together (LineDataFlow.cpp:470,601-604,2423)
 #define LV_SHADE_PLAIN 0

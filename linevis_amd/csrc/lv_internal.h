@@ -93,6 +93,10 @@ struct LvOptions {
     // triangle tubes (rtao_geometry = triangle_tubes: the colour pass is then the only user of the capsule test and the
     // literal form is nearly free), closest approach otherwise; 1 = closest_approach; 2 = literal
     int intersectionForm = 0;
+    // ppll_fragment_source: 0 = auto (default): raster_prism for plain flow lines, capsule_entry for band data / helicity bands /
+    // the prebaked AO lookup (not built for the prism yet); 1 = capsule_entry (entry hits of the pixel-centre ray against the analytic
+    // capsules: the probe of rounds 1-3); 2 = raster_prism (the rasterised N-gon prism of the reference's default primitive mode)
+    int ppllFragmentSource = 0;
     bool ppllRayTracerColour = false;         // ppll_fragment_colour: false = "raster" (the reference's gather shader, default), true = "ray_tracer"
     bool mlatRecordTrace = false;             // with collect_stats: record every pixel's candidate visiting order
     uint32_t mlatTraceCapacity = 1u << 22;    // records (16 B each)
@@ -276,6 +280,7 @@ int lv_frame_depth_range(lv_ctx* ctx);
 int lv_frame_ppll_resolve_only(lv_ctx* ctx, const uint32_t* nodes, uint64_t numNodes, const uint32_t* start,
                                uint64_t numPixels, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, uint8_t* out);
 void lv_fill_uniforms(const lv_ctx* ctx, LvUniforms& U);
+bool lv_ppll_prism_source(const lv_ctx* ctx);
 // lv_svgf.hip
 int lv_svgf_prepare(lv_ctx* ctx);
 int lv_svgf_denoise(lv_ctx* ctx, const float* noisy);

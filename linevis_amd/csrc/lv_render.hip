@@ -890,8 +890,10 @@ __global__ __launch_bounds__(LV_BLOCK, LV_GATHER_MIN_WAVES) void k_ppll_gather(c
         const bool rasterApply = U.ppllRasterColour != 0u;
         const uint32_t pxy = __float_as_uint(ownerPixel);
         const LvRasterQuad rq = lv_make_raster_quad(U, pxy & 0xFFFFu, pxy >> 16);
-        f4 color = PRIM == LV_PRIM_ELLIPTIC ? lv_shade_hit_elliptic(S, U, ownerAo, ro, rd, h, hitT, true, rq, rasterApply)
-                                            : lv_shade_hit<BANDS>(S, U, ownerAo, ro, rd, h, hitT, true, rq, rasterApply);
+        f4 color;
+        if (PRIM == LV_PRIM_PRISM) color = lv_shade_prism(S, U, ownerAo, ro, rd, leaf, uint32_t(kind), rq, rasterApply, hitT);
+        else color = PRIM == LV_PRIM_ELLIPTIC ? lv_shade_hit_elliptic(S, U, ownerAo, ro, rd, h, hitT, true, rq, rasterApply)
+                                              : lv_shade_hit<BANDS>(S, U, ownerAo, ro, rd, h, hitT, true, rq, rasterApply);
         if (STATS) cnt.hits++;
         if (color.w < 0.001f) return; // gatherFragment: discard, LinkedListGather.glsl:34
         // wave-aggregated node allocation: slots come from a per-wave chunk; one global atomic per LV_PPLL_CHUNK fragments
@@ -1339,6 +1341,46 @@ LvSceneDev sceneDevTriangles(const lv_ctx* ctx) {
 }
 
 } // namespace
+
+// host copy of lv_sincos2pi (lv_device.h): the same float32 operations in the same order (the library is built with -ffp-contract=off)
+static void lv_sincos2pi_host(float xi, float& s, float& c) {
+    float q = xi * 4.0f;
+    float fq = floorf(q);
+    int quad = int(fq) & 3;
+    float r = q - fq;
+    bool swp = r > 0.5f;
+    float rr = swp ? (1.0f - r) : r;
+    float a = rr * 1.57079632679489662f;
+    float a2 = a * a;
+    float sp = a * (1.0f + a2 * (-1.0f / 6.0f + a2 * (1.0f / 120.0f + a2 * (-1.0f / 5040.0f + a2 * (1.0f / 362880.0f)))));
+    float cp = 1.0f + a2 * (-0.5f + a2 * (1.0f / 24.0f + a2 * (-1.0f / 720.0f + a2 * (1.0f / 40320.0f + a2 * (-1.0f / 3628800.0f)))));
+    float sa = swp ? cp : sp;
+    float ca = swp ? sp : cp;
+    if (quad == 0) { s = sa; c = ca; }
+    else if (quad == 1) { s = ca; c = -sa; }
+    else if (quad == 2) { s = -sa; c = -ca; }
+    else { s = -ca; c = sa; }
+}
+// ppll_fragment_source: "auto" = the rasterised prism wherever it is built (plain flow lines), the capsule probe for band data
+bool lv_ppll_prism_source(const lv_ctx* ctx) {
+    const LvOptions& o = ctx->opt;
+    if (o.ppllFragmentSource == 1) return false;
+    const bool plain = !o.useRibbons && !o.helicityBands && !(o.useAmbientOcclusion && o.aoPrebaked);
+    return o.ppllFragmentSource == 2 ? true : plain;
+}
+// per-frame constants of the rasterised prism (LvPrismDev)
+static void lv_fill_prism(const lv_ctx* ctx, const LvUniforms& U, LvPrismDev& R) {
+    uint32_t n = ctx->opt.tubeNumSubdivisions;
+    if (n < 3u) n = 3u;
+    if (n > LV_PRISM_MAX_SUBDIV) n = LV_PRISM_MAX_SUBDIV;
+    R.n = n;
+    for (uint32_t k = 0; k < LV_PRISM_MAX_SUBDIV; k++) { R.c[k] = 1.0f; R.s[k] = 0.0f; }
+    for (uint32_t k = 0; k < n; k++) lv_sincos2pi_host(float(k) / float(n), R.s[k], R.c[k]);
+    for (int k = 0; k < 3; k++) R.right[k] = U.invView[k];
+    R.viewZ[0] = U.view[2]; R.viewZ[1] = U.view[6]; R.viewZ[2] = U.view[10]; R.viewZ[3] = U.view[14];
+    R.nearDist = U.nearDist;
+    R.farDist = U.farDist;
+}
 
 void lv_fill_uniforms(const lv_ctx* ctx, LvUniforms& U) {
     memset(&U, 0, sizeof(U));
@@ -1949,14 +1991,17 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
         k_ppll_clear<<<uint32_t((padded4 + LV_BLOCK - 1) / LV_BLOCK), LV_BLOCK, 0, st>>>((uint4*)ctx->ppllStart.ptr,
                                                                                          (uint4*)ctx->ppllCount.ptr, padded4, dc);
         LV_HIP(ctx, hipEventRecord(ctx->ev[11], st));
-        // gather()
+        // gather(): fragments of the rasterised programmable-pull prism (the reference's geometry, default) or capsule entry hits
+        const bool prismSource = lv_ppll_prism_source(ctx);
+        if (prismSource) lv_fill_prism(ctx, U, S.prism);
 #define LV_LAUNCH_GATHER(ST, PR, BA)                                                                             \
     LV_TIMED_LAUNCH(ctx, LV_KERNEL_PPLL_GATHER, (k_ppll_gather<ST, PR, BA><<<gridTiles * numSlices, LV_BLOCK, 0, st>>>( \
             U, S, T, (uint32_t*)ctx->ppllNodes.ptr, (uint32_t*)ctx->ppllStart.ptr,                              \
             (uint32_t*)ctx->ppllCount.ptr, dc, numSlices, poolSlots)))
 #define LV_LAUNCH_GATHER2(ST)                                                          \
     do {                                                                               \
-        if (U.useHelicityBands) LV_LAUNCH_GATHER(ST, LV_PRIM_CAPSULE, LV_SHADE_HELICITY); \
+        if (prismSource) LV_LAUNCH_GATHER(ST, LV_PRIM_PRISM, LV_SHADE_PLAIN);          \
+        else if (U.useHelicityBands) LV_LAUNCH_GATHER(ST, LV_PRIM_CAPSULE, LV_SHADE_HELICITY); \
         else if (U.useBands && U.useEllipticTubes) LV_LAUNCH_GATHER(ST, LV_PRIM_ELLIPTIC, LV_SHADE_BANDS); \
         else if (U.useBands) LV_LAUNCH_GATHER(ST, LV_PRIM_CAPSULE, LV_SHADE_BANDS);    \
         else LV_LAUNCH_GATHER(ST, LV_PRIM_CAPSULE, LV_SHADE_PLAIN);                    \

@@ -801,6 +801,8 @@ __device__ __forceinline__ LvHit lv_trace_closest(const LvSceneDev& S, float rad
     return h;
 }
 
+#include "lv_prism.h"
+
 // All capsule entry hits with t in [tMin, tMax) -- per lane -- (PPLL fragment generation, MLAT), wave-cooperative like lv_trace_closest: every
 // lane of the wave calls it; (owner, leaf) pairs are tested 64 at a time by whichever lanes are free, and the lane
 // that finds a hit calls f(owner, leaf, t, kind, o, d, w0, w1) with the OWNER's ray and its two payload words
@@ -869,12 +871,29 @@ __device__ __forceinline__ void lv_trace_all(const LvSceneDev& S, float radius, 
             const unsigned n = q < LV_WAVE ? q : LV_WAVE;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             // a leaf of the triangle LBVH holds S.triLeafSize triangles: one round of tests + hit queueing per slot (wave-uniform)
+            // the rasterised prism: one test per (ray, segment) yields a mask of covered triangles; they are queued one per lane
+            // and round (usually one round), kind = the triangle of the segment's prism
+            unsigned prismMask = 0u, prismRef = 0u;
+            if (PRIM == LV_PRIM_PRISM && lane < n) {
+                const unsigned e = cm.queue[(head + lane) % LV_QCAP];
+                const unsigned ow = e >> 26, leaf = e & 0x03FFFFFFu;
+                const float4 ro = cm.ray[2 * ow], rd = cm.ray[2 * ow + 1];
+                if (STATS) cnt.prims++;
+                prismRef = e;
+                prismMask = S.prism.n == 6u ? lv_prism_test<6>(S, radius, leaf, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), ro.w, rd.w)
+                                            : lv_prism_test<0>(S, radius, leaf, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), ro.w, rd.w);
+            }
             const unsigned nSub = PRIM == LV_PRIM_TRIANGLE ? S.triLeafSize : 1u;
-            for (unsigned sub = 0; sub < nSub; sub++) {
+            for (unsigned sub = 0; PRIM == LV_PRIM_PRISM ? __ballot(prismMask != 0u) != 0ull : sub < nSub; sub++) {
             bool hit = false;
             unsigned hitRef = 0, hitKind = 0;
             float hitT = 0.0f;
-            if (lane < n) {
+            if (PRIM == LV_PRIM_PRISM) {
+                if (prismMask) {
+                    hit = true; hitRef = prismRef; hitKind = unsigned(__ffs(int(prismMask))) - 1u;
+                    prismMask &= prismMask - 1u;
+                }
+            } else if (lane < n) {
                 const unsigned e = cm.queue[(head + lane) % LV_QCAP];
                 const unsigned ow = e >> 26, leaf = e & 0x03FFFFFFu;
                 const float4 ro = cm.ray[2 * ow], rd = cm.ray[2 * ow + 1];
@@ -953,7 +972,7 @@ __device__ __forceinline__ void lv_trace_all(const LvSceneDev& S, float radius, 
             if (!(cur & LV_LEAF_BIT)) {
                 // literal roots may lie up to r / |d| outside their segment's box interval (lv_intersect_capsule_literal)
                 const float sl = PRIM == LV_PRIM_ELLIPTIC ? S.ellBandWidth / len3(mk3(1.0f / inv.x, 1.0f / inv.y, 1.0f / inv.z))
-                        : (PRIM == LV_PRIM_CAPSULE && S.literalIntersection)
+                        : ((PRIM == LV_PRIM_CAPSULE && S.literalIntersection) || PRIM == LV_PRIM_PRISM) // prism: own-box rule, lv_prism.h
                         ? radius / len3(mk3(1.0f / inv.x, 1.0f / inv.y, 1.0f / inv.z)) : 0.0f;
                 cur = lv_node_step<STATS, DYN ? 2 : 0>(S, cur, oi, inv, tMin - sl, tMax + sl, st, cnt);
             }
@@ -1281,6 +1300,40 @@ __device__ __forceinline__ f4 lv_shade_hit(const LvSceneDev& S, const LvUniforms
     none.rotation = 0.0f; none.separatorScale = 1.0f; none.rasterEpsWhite = rasterEps;
     return lv_compute_fragment_color_t<LV_SHADE_PLAIN>(S, U, aoTexel, fragPos, fragmentNormal, fragmentTangent, isCap, fragmentAttribute,
                                                        payloadHitT, none);
+}
+
+// Fragment stage of the rasterised programmable-pull prism (ppll_fragment_source = raster_prism; lv_prism.h, oracle prismShade):
+// LinePassGeometryShaderTubes.glsl:732-1129 on the perspective-correct inputs of triangle tt of the leaf's segment for the pixel's
+// viewing ray (o, d); fwidth(ribbonPosition) (:1079-1087) from the helper invocations of the 2 x 2 quad = the same triangle's
+// attribute planes at the quad partners' rays (LvRasterQuad).
+__device__ __forceinline__ f4 lv_shade_prism(const LvSceneDev& S, const LvUniforms& U, float aoTexel, f3 o, f3 d, uint32_t leaf,
+                                             uint32_t tt, const LvRasterQuad& rq, bool rasterApply, float& payloadHitT) {
+    const LvPrismDev& R = S.prism;
+    const uint32_t seg = S.leafSeg[leaf];
+    const uint32_t pi[2] = {S.segIdx[2 * seg], S.segIdx[2 * seg + 1]};
+    LvPrismPoint pt[2];
+    pt[0] = lv_prism_point(S.points, pi[0]);
+    pt[1] = lv_prism_point(S.points, pi[1]);
+    const LvPrismTri T = lv_prism_tri_setup(R, pt, pi, U.radius, tt);
+    f3 nrm[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) nrm[i] = norm3s(T.dir[i]);   // vertexNormal = normalize(tangentFrameMatrix * localNormal), :177
+    float e[3];
+    lv_prism_tri_edges(R, T, o, d, e);
+    const LvPrismInputs I = lv_prism_interpolate(T, nrm, e);
+    const f3 cam = mk3(U.camPos[0], U.camPos[1], U.camPos[2]);
+    float ex[3], ey[3];
+    lv_prism_tri_edges(R, T, cam, rq.dX, ex);
+    lv_prism_tri_edges(R, T, cam, rq.dY, ey);
+    const LvPrismInputs Ix = lv_prism_interpolate(T, nrm, ex), Iy = lv_prism_interpolate(T, nrm, ey);
+    const float f0 = lv_prism_ribbon(cam, I.pos, I.nrm, I.tan);
+    const float fx = lv_prism_ribbon(cam, Ix.pos, Ix.nrm, Ix.tan);
+    const float fy = lv_prism_ribbon(cam, Iy.pos, Iy.nrm, Iy.tan);
+    LvBandArgs none;
+    none.useBand = false; none.phi = 0.0f; none.linePosition = mk3(0.0f, 0.0f, 0.0f); none.lineNormal = mk3(0.0f, 0.0f, 0.0f);
+    none.rotation = 0.0f; none.separatorScale = 1.0f;
+    none.rasterEpsWhite = rasterApply ? fabsf(fx - f0) + fabsf(fy - f0) : -1.0f;
+    return lv_compute_fragment_color_t<LV_SHADE_PLAIN>(S, U, aoTexel, I.pos, I.nrm, I.tan, false, I.attr, payloadHitT, none);
 }
 
 // ClosestHitEllipticTubeAnalytic main(), EllipticTubeRayTracing.glsl:303-441: position in the tubelet frame -> t, phi, rho ->

@@ -1263,6 +1263,8 @@ inline void sortAndBlend(uint32_t mode, uint32_t* col, float* dep, uint32_t n, u
     blendFTB(L, n, out);
 }
 
+#include "lv_oracle_prism.h"
+
 } // namespace
 
 // ================================================================ exported API
@@ -2289,13 +2291,32 @@ void lvo_ppll_gather(const lvo_scene* sc, const lvo_params* Pp, int useBvh, cons
     std::vector<std::vector<std::pair<uint32_t, float>>> rows(h);
     std::vector<std::vector<uint32_t>> rowCounts(h);
     uint64_t rays = 0, nds = 0, prims = 0, hits = 0;
+    // ppll_fragment_source = raster_prism: the fragments of the rasterised programmable-pull prism (lv_oracle_prism.h)
+    const bool prism = P.ppllFragmentSource == 1u;
+    const PrismRing ring = prismRing(P.tubeNumSubdivisions);
 #pragma omp parallel for schedule(dynamic, 1) reduction(+ : rays, nds, prims, hits)
     for (int64_t yy = 0; yy < int64_t(h); yy++) {
         Counters cnt;
         std::vector<Hit> hl;
+        std::vector<uint32_t> cand;
+        std::vector<PrismFrag> pf;
         rowCounts[yy].assign(w, 0);
         for (uint32_t xx = 0; xx < w; xx++) {
             uint32_t x = x0 + xx, y = y0 + uint32_t(yy);
+            if (prism) {
+                const float aoTexelP = (P.useAmbientOcclusion && ao) ? ao[size_t(y) * P.width + x] : 1.0f;
+                prismPixelFragments(*sc, P, F, ring, useBvh != 0, x, y, cand, pf, cnt);
+                const RasterQuad rqP = makeRasterQuad(P, F, x, y);
+                for (const PrismFrag& f : pf) {
+                    float hc[4]; float hitT;
+                    prismShade(*sc, P, F, ring, aoTexelP, f, g_rtFragmentColourInPpll ? nullptr : &rqP, hc, hitT);
+                    cnt.hits++;
+                    if (hc[3] < 0.001f) continue;
+                    rows[yy].push_back(std::make_pair(packUnorm4x8(hc), hitT));
+                    rowCounts[yy][xx]++;
+                }
+                continue;
+            }
             V3 o, d;
             primaryRay(P, F, x, y, 0.5f, 0.5f, o, d);
             const float aoTexel = (P.useAmbientOcclusion && ao) ? ao[size_t(y) * P.width + x] : 1.0f;
@@ -2791,6 +2812,68 @@ int lvo_num_threads(void) {
 #else
     return 1;
 #endif
+}
+
+
+/* ---- a16: fragments of the rasterised programmable-pull prism (lv_oracle_prism.h), test hooks ---- */
+void lvo_prism_ring_vertices(const lvo_line_point* pts, uint64_t nPts, uint32_t numSubdivisions, float lineWidth, float* outPos,
+                             float* outNormal) {
+    const PrismRing R = prismRing(numSubdivisions);
+    for (uint64_t i = 0; i < nPts; i++)
+        for (uint32_t k = 0; k < R.n; k++) {
+            const PrismVtx v = prismVertex(pts[i], R.c[k], R.s[k], lineWidth * 0.5f);
+            const V3 n = normalizeShade(v.dir);
+            float* p = outPos + 3 * (i * R.n + k);
+            float* q = outNormal + 3 * (i * R.n + k);
+            p[0] = v.pos.x; p[1] = v.pos.y; p[2] = v.pos.z;
+            q[0] = n.x; q[1] = n.y; q[2] = n.z;
+        }
+}
+/* offsets[w * h + 1]; with segs == NULL only the offsets are filled (call twice).  Per fragment: segment, triangle (< 2 N), the three
+ * weights, depth, interpolated position / normal / tangent (3 floats each, may be NULL), attribute, packed colour and alpha. */
+void lvo_prism_fragments(const lvo_scene* sc, const lvo_params* Pp, int useBvh, const float* ao, uint32_t x0, uint32_t y0, uint32_t w,
+                         uint32_t h, uint64_t* offsets, uint32_t* segs, uint32_t* tris, float* weights, float* depth, float* pos,
+                         float* nrm, float* tan, float* attr, uint32_t* colour, float* rgba) {
+    const lvo_params& P = *Pp;
+    const Frame F = makeFrame(P);
+    const PrismRing ring = prismRing(P.tubeNumSubdivisions);
+    g_dev.aoImage = (g_dev.referenceAoLookup && P.useAmbientOcclusion) ? ao : nullptr;
+    std::vector<std::vector<PrismFrag>> rows(size_t(w) * h);
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int64_t yy = 0; yy < int64_t(h); yy++) {
+        Counters cnt;
+        std::vector<uint32_t> cand;
+        for (uint32_t xx = 0; xx < w; xx++)
+            prismPixelFragments(*sc, P, F, ring, useBvh != 0, x0 + xx, y0 + uint32_t(yy), cand, rows[size_t(yy) * w + xx], cnt);
+    }
+    uint64_t k = 0;
+    for (size_t i = 0; i < rows.size(); i++) {
+        offsets[i] = k;
+        if (segs) {
+            const uint32_t x = x0 + uint32_t(i % w), y = y0 + uint32_t(i / w);
+            const float aoTexel = (P.useAmbientOcclusion && ao) ? ao[size_t(y) * P.width + x] : 1.0f;
+            const RasterQuad rq = makeRasterQuad(P, F, x, y);
+            for (const PrismFrag& f : rows[i]) {
+                segs[k] = f.seg; tris[k] = f.tri;
+                for (int j = 0; j < 3; j++) weights[3 * k + j] = f.b[j];
+                depth[k] = f.depth;
+                if (pos) { pos[3 * k] = f.pos.x; pos[3 * k + 1] = f.pos.y; pos[3 * k + 2] = f.pos.z; }
+                if (nrm) { nrm[3 * k] = f.nrm.x; nrm[3 * k + 1] = f.nrm.y; nrm[3 * k + 2] = f.nrm.z; }
+                if (tan) { tan[3 * k] = f.tan.x; tan[3 * k + 1] = f.tan.y; tan[3 * k + 2] = f.tan.z; }
+                if (attr) attr[k] = f.attr;
+                if (colour || rgba) {
+                    float hc[4]; float hitT;
+                    prismShade(*sc, P, F, ring, aoTexel, f, g_rtFragmentColourInPpll ? nullptr : &rq, hc, hitT);
+                    if (colour) colour[k] = packUnorm4x8(hc);
+                    if (rgba) for (int j = 0; j < 4; j++) rgba[4 * k + j] = hc[j];
+                }
+                k++;
+            }
+        } else {
+            k += rows[i].size();
+        }
+    }
+    offsets[rows.size()] = k;
 }
 
 } // extern "C"

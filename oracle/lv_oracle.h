@@ -100,6 +100,10 @@ typedef struct {
      * (LineAttributesBarycentric.glsl:94-112); ClosestHitTubeAnalytic does not pass it, so the analytic paths ignore the switch. */
     uint32_t uniformHelicityBandWidth;
     uint32_t ppllSortingMode;  /* SortingAlgorithmMode, src/Renderers/PPLL.hpp:41-50: 0 priority queue ... 7 quicksort hybrid */
+    /* ppll_fragment_source: 0 = capsule_entry (entry hits of the pixel-centre ray against the analytic capsules: the probe of
+     * rounds 1-3), 1 = raster_prism (the fragments of the rasterised N-gon prism of the default "Tube (Programmable Pull)" mode,
+     * LinePassProgrammablePullTubes.glsl:87-224 + LineDataFlow.cpp:1698-1713; lv_oracle_prism.h) */
+    uint32_t ppllFragmentSource;
 } lvo_params;
 
 typedef struct {
@@ -228,6 +232,13 @@ void lvo_ppll_resolve(
 void lvo_render_ppll(
         const lvo_scene*, const lvo_params*, int useBvh, const float* ao,
         uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, uint8_t* outRGBA8, lvo_stats* stats);
+/* a16 test hooks: ring vertices (position, normal; nPts * N * 3 floats each) of the programmable-pull vertex stage, and the
+ * per-pixel fragments of the rasterised prism in ascending (segment, triangle) order (lv_oracle_prism.h) */
+void lvo_prism_ring_vertices(const lvo_line_point* pts, uint64_t nPts, uint32_t numSubdivisions, float lineWidth, float* outPos,
+                             float* outNormal);
+void lvo_prism_fragments(const lvo_scene* sc, const lvo_params* P, int useBvh, const float* ao, uint32_t x0, uint32_t y0, uint32_t w,
+                         uint32_t h, uint64_t* offsets, uint32_t* segs, uint32_t* tris, float* weights, float* depth, float* pos,
+                         float* nrm, float* tan, float* attr, uint32_t* colour, float* rgba);
 
 /* ---- a14: triangle tubes (CappedTriangleTubesCPU.cpp:214-383, Tubes.cpp:34-85, LineDataFlow.cpp:1912-2110) ---- */
 /* Mirrors struct TubeTriangleVertexData, src/LineData/LineRenderData.hpp:171-176 (32 B). */

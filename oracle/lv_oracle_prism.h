@@ -1,0 +1,273 @@
+// lv_oracle_prism.h -- CPU ORACLE (test infrastructure, not product), included by lv_oracle.cpp inside its anonymous namespace.
+//
+// PPLL fragments from the geometry the reference RASTERISES (ppll_fragment_source = raster_prism):
+// the default "Tube (Programmable Pull)" primitive mode (LINE_PRIMITIVES_TUBE_PROGRAMMABLE_PULL, src/LineData/LineData.cpp:51).
+//
+//  * vertex stage, Data/Shaders/Renderers/GeometryPass/LinePassProgrammablePullTubes.glsl:87-224: vertex gl_VertexIndex =
+//    linePointIdx * N + circleIdx is ring vertex circleIdx of line point linePointIdx in that point's OWN frame
+//    (normal, binormal = cross(tangent, normal), tangent) (:123-127): position = lineRadius * (frame * (cos t, sin t, 0)) + centre,
+//    vertex normal = normalize(frame * (cos t, sin t, 0)) (:174-177), t = circleIdx / N * 2 pi (:129-131);
+//  * index pattern, src/LineData/LineDataFlow.cpp:1698-1713: per segment (point i -> i + 1) and k < N, kn = (k + 1) % N the triangles
+//    (c_k, c_kn, n_k) and (n_k, c_kn, n_kn) with c = ring of point i, n = ring of point i + 1: an UNCAPPED N-gon prism
+//    (USE_CAPPED_TUBES is not defined for the rasterisers, LineData.cpp:1240-1244);
+//  * back faces culled (transparency is used: src/Renderers/LineRasterPass.cpp:85-96); the outward side is the front side (the
+//    geometric normal of both triangles of the pattern points away from the axis);
+//  * fragment stage, LinePassGeometryShaderTubes.glsl:732-1129, receives the perspective-correct interpolation of
+//    fragmentPositionWorld / fragmentNormal / fragmentTangent / fragmentAttribute (ProgrammablePull:212-223); its depth for the list
+//    node is length(fragmentPositionWorld - cameraPosition) (LinkedListGather.glsl:47);
+//  * point frames: the records of getLinePassTubeAabbRenderData (LineDataFlow.cpp:2112-2277) -- getLinePassTubeRenderDataGeneral
+//    (:1385-1444) computes the same tangents and Gram-Schmidt normals except for the fallback-axis test that reads an
+//    uninitialised `normal` (:1419, undefined behaviour); the AABB path's test on `tangent` (:2174) is the defined version.
+//
+// The fixed-function rasteriser between the two stages is not observable; the build defines it (float32, fixed operation order,
+// explicit fused multiply-adds where written as fmaf) as a rasteriser in the space of the pixel's viewing ray:
+//
+//   viewing ray      the pixel-centre ray (o, d) of the ray generator (TubeRayTracing.glsl:219-226: what gl_FragCoord = pixel + 0.5
+//                    unprojects to); basis P = cross(R, d), Q = cross(d, P) with R = the camera's right axis (column 0 of
+//                    inverse(viewMatrix)): P, Q, d are mutually orthogonal, so (A . P, A . Q) are -- up to positive factors -- the
+//                    coordinates of a vertex A - o in the plane perpendicular to the ray
+//   edge function    E(U, V) = yU * xV - xU * yV of two projected vertices = -(d . (U x V)) up to a positive factor: the
+//                    homogeneous edge function of the projected edge (Olano & Greer 1997), evaluated WITHOUT contraction so that
+//                    E(V, U) = -E(U, V) holds bit for bit -- two triangles sharing an edge see exactly opposite values
+//   coverage         triangle (V0, V1, V2) covers the pixel iff e0 = E(V1, V2), e1 = E(V2, V0), e2 = E(V0, V1) are all > 0, where an
+//                    edge with e == 0 counts as inside iff it is OWNED: the directed edge U -> V of the triangle's winding is owned
+//                    iff gl_VertexIndex(U) < gl_VertexIndex(V) (the neighbour runs through it the other way, so exactly one of the two
+//                    owns it: the fill rule), and (e0 + e1) + e2 > 0.  All e >= 0 is at the same time "the ray passes through the
+//                    triangle in front of the camera" and "the triangle is front-facing" (det[V0 - o, V1 - o, V2 - o] < 0).
+//   interpolation    b_i = e_i * (1 / ((e0 + e1) + e2)) are the barycentric coordinates of the point where the ray meets the triangle's
+//                    plane = the perspective-correct weights of the rasteriser: attribute = (b0 a0 + b1 a1) + b2 a2
+//   depth clipping   a fragment is kept iff nearDist <= -(viewMatrix * fragmentPositionWorld).z <= farDist (clip space 0 <= z <= w)
+//   own-box rule     and iff the ray meets the segment's box of TubeAabbRenderData (LineDataFlow.cpp:2223-2234) with the fragment
+//                    depth within r / |d| of the box interval: every ring vertex lies within r of its line point, so this only makes
+//                    the result independent of which conservative acceleration structure supplied the candidate segments
+//   helper lanes     fwidth(ribbonPosition) (LinePassGeometryShaderTubes.glsl:1079-1087) over the 2 x 2 quad: the quad partners
+//                    (x ^ 1, y), (x, y ^ 1) evaluate the SAME triangle's attribute planes at their own pixel centre, i.e. with the
+//                    (possibly outside [0, 1]) weights b_i of their own viewing ray, then the shader's ribbonPosition of the
+//                    interpolated inputs (RasterQuad: the affine ray generator's directions)
+#pragma once
+
+constexpr uint32_t kPrismMaxSubdiv = 16;   // a (ray, segment) test reports its covered triangles as a 2 N-bit mask on the device
+
+// cos / sin of the ring angle circleIdx / N * 2 pi (ProgrammablePull:129-131).  GLSL leaves their precision to the implementation;
+// the build defines them by sincos2pi (the fixed polynomial of the hemisphere sample) of the fraction circleIdx / N of the full turn.
+struct PrismRing { float c[kPrismMaxSubdiv], s[kPrismMaxSubdiv]; uint32_t n; };
+inline PrismRing prismRing(uint32_t N) {
+    PrismRing R;
+    R.n = std::min(std::max(N, 3u), kPrismMaxSubdiv);
+    for (uint32_t k = 0; k < R.n; k++) sincos2pi(float(k) / float(R.n), R.s[k], R.c[k]);
+    return R;
+}
+
+// ring vertex of a line point: dir = normal * cos + binormal * sin (the tangent column of the frame meets the 0 of the local
+// position), position = radius * dir + centre; vertexNormal = normalize(dir)
+struct PrismVtx { V3 pos, dir; };
+inline PrismVtx prismVertex(const lvo_line_point& lp, float c, float s, float radius) {
+    const V3 normal = ld3(lp.lineNormal), tangent = ld3(lp.lineTangent), centre = ld3(lp.linePosition);
+    const V3 binormal = cross(tangent, normal);
+    PrismVtx v;
+    v.dir = v3(fmaf(binormal.x, s, normal.x * c), fmaf(binormal.y, s, normal.y * c), fmaf(binormal.z, s, normal.z * c));
+    v.pos = v3(fmaf(radius, v.dir.x, centre.x), fmaf(radius, v.dir.y, centre.y), fmaf(radius, v.dir.z, centre.z));
+    return v;
+}
+
+// the two axes perpendicular to a viewing ray's direction
+struct PrismBasis { V3 P, Q; };
+inline PrismBasis prismBasis(const Frame& F, V3 d) {
+    const V3 R = v3(F.invView[0], F.invView[1], F.invView[2]);
+    PrismBasis B;
+    B.P = cross(R, d);
+    B.Q = cross(d, B.P);
+    return B;
+}
+inline void prismProject(V3 pos, V3 o, const PrismBasis& B, float& x, float& y) {
+    const V3 A = pos - o;
+    x = fmaf(A.z, B.P.z, fmaf(A.y, B.P.y, A.x * B.P.x));
+    y = fmaf(A.z, B.Q.z, fmaf(A.y, B.Q.y, A.x * B.Q.x));
+}
+inline float prismEdge(float xU, float yU, float xV, float yV) { return yU * xV - xU * yV; }
+
+// triangle tt < 2 N of a segment's prism: its three vertices as (ring 0 = first point / 1 = second point, circle index)
+inline void prismTriangle(uint32_t tt, uint32_t N, uint32_t ring[3], uint32_t circ[3]) {
+    const uint32_t k = tt >> 1, kn = (k + 1u) % N;
+    if ((tt & 1u) == 0u) { ring[0] = 0; circ[0] = k; ring[1] = 0; circ[1] = kn; ring[2] = 1; circ[2] = k; }
+    else { ring[0] = 1; circ[0] = k; ring[1] = 0; circ[1] = kn; ring[2] = 1; circ[2] = kn; }
+}
+
+// edge functions of a triangle from its projected vertices; true iff the pixel is covered (fill rule on e == 0 through the ids)
+inline bool prismCoverage(const float x[3], const float y[3], const uint32_t id[3], float e[3]) {
+    e[0] = prismEdge(x[1], y[1], x[2], y[2]);
+    e[1] = prismEdge(x[2], y[2], x[0], y[0]);
+    e[2] = prismEdge(x[0], y[0], x[1], y[1]);
+    for (int i = 0; i < 3; i++) {
+        const bool owned = id[(i + 1) % 3] < id[(i + 2) % 3];
+        if (!(e[i] > 0.0f || (e[i] == 0.0f && owned))) return false;
+    }
+    return (e[0] + e[1]) + e[2] > 0.0f;
+}
+inline void prismWeights(const float e[3], float b[3]) {
+    const float rs = 1.0f / ((e[0] + e[1]) + e[2]);   // one division (the rasteriser's set-up), three products
+    b[0] = e[0] * rs; b[1] = e[1] * rs; b[2] = e[2] * rs;
+}
+inline V3 prismMix3(const float b[3], V3 a0, V3 a1, V3 a2) { return (b[0] * a0 + b[1] * a1) + b[2] * a2; }
+
+// everything the fragment stage receives for one triangle of one segment
+struct PrismTri {
+    V3 pos[3], nrm[3], tan[3];   // vertexPosition, vertexNormal, fragmentTangent (= the line tangent of the vertex's point)
+    float attr[3];
+    uint32_t id[3];              // gl_VertexIndex = linePointIdx * N + circleIdx
+    uint32_t ring[3], circ[3];
+    float lineIdx[3];            // float(linePointIdx - lineStartIndex): interpolationFactorLine (ProgrammablePull:203-206)
+    uint32_t lineStart;          // fragmentVertexIdUint (flat: the provoking = first vertex)
+};
+inline PrismTri prismTriSetup(const lvo_scene& sc, const PrismRing& R, float radius, uint32_t seg, uint32_t tt) {
+    const uint32_t pi[2] = {sc.segIdx[2 * seg], sc.segIdx[2 * seg + 1]};
+    PrismTri T;
+    prismTriangle(tt, R.n, T.ring, T.circ);
+    for (int i = 0; i < 3; i++) {
+        const lvo_line_point& lp = sc.pts[pi[T.ring[i]]];
+        const PrismVtx v = prismVertex(lp, R.c[T.circ[i]], R.s[T.circ[i]], radius);
+        T.pos[i] = v.pos;
+        T.nrm[i] = normalizeShade(v.dir);   // normalize() as v * (1 / length(v)), like the shading code
+        T.tan[i] = ld3(lp.lineTangent);
+        T.attr[i] = lp.lineAttribute;
+        T.id[i] = pi[T.ring[i]] * R.n + T.circ[i];
+        T.lineIdx[i] = float(pi[T.ring[i]] - lp.lineStartIndex);
+    }
+    T.lineStart = sc.pts[pi[T.ring[0]]].lineStartIndex;
+    return T;
+}
+
+struct PrismFrag {
+    uint32_t seg, tri;
+    float b[3];
+    V3 pos, nrm, tan;   // interpolated fragmentPositionWorld / fragmentNormal / fragmentTangent (not normalised)
+    float attr, depth;
+};
+
+// the shader's ribbonPosition of interpolated inputs (no bands, no caps), LinePassGeometryShaderTubes.glsl:771-777,944-963
+inline float prismRibbon(V3 cam, V3 fragPos, V3 fragmentNormal, V3 fragmentTangent) {
+    const V3 n = normalizeShade(fragmentNormal);
+    const V3 v = normalizeShade(cam - fragPos);
+    const V3 t = normalizeShade(fragmentTangent);
+    const V3 helperVec = normalizeShade(cross(t, v));
+    const V3 newV = normalizeShade(cross(helperVec, t));
+    const V3 crossProdVn = cross(newV, n);
+    float ribbonPosition = length(crossProdVn);
+    if (dot(t, crossProdVn) < 0.0f) ribbonPosition = -ribbonPosition;
+    return clampf(ribbonPosition, -1.0f, 1.0f);
+}
+// ribbonPosition a helper invocation computes: the triangle's attribute planes at the weights of the ray (o, D)
+inline float prismRibbonOfRay(const Frame& F, const PrismTri& T, V3 o, V3 D) {
+    const PrismBasis B = prismBasis(F, D);
+    float x[3], y[3], e[3], b[3];
+    for (int i = 0; i < 3; i++) prismProject(T.pos[i], o, B, x[i], y[i]);
+    e[0] = prismEdge(x[1], y[1], x[2], y[2]);
+    e[1] = prismEdge(x[2], y[2], x[0], y[0]);
+    e[2] = prismEdge(x[0], y[0], x[1], y[1]);
+    prismWeights(e, b);
+    return prismRibbon(F.cameraPosition, prismMix3(b, T.pos[0], T.pos[1], T.pos[2]), prismMix3(b, T.nrm[0], T.nrm[1], T.nrm[2]),
+                       prismMix3(b, T.tan[0], T.tan[1], T.tan[2]));
+}
+
+// own-box rule (see the header): the ray meets the segment's box, depth within r / |d| of the interval
+inline bool prismOwnBox(V3 o, V3 d, V3 p0, V3 p1, float radius, float depth) {
+    const V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    const float tx0 = ((fminf(p0.x, p1.x) - radius) - o.x) * inv.x, tx1 = ((fmaxf(p0.x, p1.x) + radius) - o.x) * inv.x;
+    const float ty0 = ((fminf(p0.y, p1.y) - radius) - o.y) * inv.y, ty1 = ((fmaxf(p0.y, p1.y) + radius) - o.y) * inv.y;
+    const float tz0 = ((fminf(p0.z, p1.z) - radius) - o.z) * inv.z, tz1 = ((fmaxf(p0.z, p1.z) + radius) - o.z) * inv.z;
+    const float tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fminf(tz0, tz1));
+    const float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fmaxf(tz0, tz1));
+    const float slack = radius / length(d);
+    return tn <= tf && depth >= tn - slack && depth <= tf + slack;
+}
+
+// All fragments the pixel-centre ray (o, d) receives from the prism of segment `seg`, ascending triangle index; depth in [tLo, tHi).
+inline void prismSegmentFragments(const lvo_scene& sc, const lvo_params& P, const Frame& F, const PrismRing& R, V3 o, V3 d,
+                                  const PrismBasis& B, uint32_t seg, float tLo, float tHi, std::vector<PrismFrag>& out) {
+    const uint32_t N = R.n;
+    const uint32_t pi[2] = {sc.segIdx[2 * seg], sc.segIdx[2 * seg + 1]};
+    float vx[2][kPrismMaxSubdiv], vy[2][kPrismMaxSubdiv];
+    for (int r = 0; r < 2; r++)
+        for (uint32_t k = 0; k < N; k++) {
+            const PrismVtx v = prismVertex(sc.pts[pi[r]], R.c[k], R.s[k], F.radius);
+            prismProject(v.pos, o, B, vx[r][k], vy[r][k]);
+        }
+    for (uint32_t tt = 0; tt < 2u * N; tt++) {
+        uint32_t ring[3], circ[3], id[3];
+        prismTriangle(tt, N, ring, circ);
+        float x[3], y[3], e[3];
+        for (int i = 0; i < 3; i++) { x[i] = vx[ring[i]][circ[i]]; y[i] = vy[ring[i]][circ[i]]; id[i] = pi[ring[i]] * N + circ[i]; }
+        if (!prismCoverage(x, y, id, e)) continue;
+        const PrismTri T = prismTriSetup(sc, R, F.radius, seg, tt);
+        PrismFrag f;
+        f.seg = seg; f.tri = tt;
+        prismWeights(e, f.b);
+        f.pos = prismMix3(f.b, T.pos[0], T.pos[1], T.pos[2]);
+        f.nrm = prismMix3(f.b, T.nrm[0], T.nrm[1], T.nrm[2]);
+        f.tan = prismMix3(f.b, T.tan[0], T.tan[1], T.tan[2]);
+        f.attr = (f.b[0] * T.attr[0] + f.b[1] * T.attr[1]) + f.b[2] * T.attr[2];
+        f.depth = length(f.pos - F.cameraPosition);
+        if (!(f.depth >= tLo && f.depth < tHi)) continue;
+        if (!prismOwnBox(o, d, ld3(sc.pts[pi[0]].linePosition), ld3(sc.pts[pi[1]].linePosition), F.radius, f.depth)) continue;
+        const V4 s4 = mulM4(P.view, V4{f.pos.x, f.pos.y, f.pos.z, 1.0f});
+        if (!(-s4.z >= P.nearDist && -s4.z <= P.farDist)) continue;
+        out.push_back(f);
+    }
+}
+
+// candidate segments of a ray: every segment whose (padded) box the ray meets within [tMin - slack, tMax + slack], ascending
+inline void prismCandidates(const lvo_scene& sc, bool useBvh, V3 o, V3 d, float tMin, float tMax, float slack,
+                            std::vector<uint32_t>& out, Counters& cnt) {
+    out.clear();
+    if (!useBvh || sc.root == -1) {
+        for (uint32_t s = 0; s < sc.nSeg; s++) out.push_back(s);
+        return;
+    }
+    if (sc.rootIsLeaf) { out.push_back(uint32_t(~sc.root)); return; }
+    const V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    std::vector<int32_t> stack;
+    stack.push_back(sc.root);
+    while (!stack.empty()) {
+        const int32_t n = stack.back(); stack.pop_back();
+        if (n < 0) { out.push_back(uint32_t(~n)); continue; }
+        const BvhNode& nd = sc.nodes[n];
+        cnt.nodes++;
+        float tl, tr;
+        if (childBox(sc, nd.right, o, inv, tMin - slack, tMax + slack, tr)) stack.push_back(nd.right);
+        if (childBox(sc, nd.left, o, inv, tMin - slack, tMax + slack, tl)) stack.push_back(nd.left);
+    }
+    std::sort(out.begin(), out.end());
+}
+
+// all prism fragments of the pixel-centre ray of pixel (x, y), ascending (segment, triangle)
+inline void prismPixelFragments(const lvo_scene& sc, const lvo_params& P, const Frame& F, const PrismRing& R, bool useBvh,
+                                uint32_t x, uint32_t y, std::vector<uint32_t>& cand, std::vector<PrismFrag>& out, Counters& cnt) {
+    V3 o, d;
+    primaryRay(P, F, x, y, 0.5f, 0.5f, o, d);
+    cnt.rays++;
+    out.clear();
+    const PrismBasis B = prismBasis(F, d);
+    const float tMin = 0.0001f, tMax = 1000.0f;   // the gather's ray interval (depth clipping is the near / far test above)
+    prismCandidates(sc, useBvh, o, d, tMin, tMax, F.radius / length(d), cand, cnt);
+    for (uint32_t seg : cand) {
+        cnt.prims++;
+        prismSegmentFragments(sc, P, F, R, o, d, B, seg, tMin, nextafterf(tMax, INFINITY), out);
+    }
+}
+
+// fragment stage: LinePassGeometryShaderTubes.glsl:732-1129 on the interpolated inputs -> colour (raster variant of the outline)
+// rq == nullptr: the ray tracer's variant of computeFragmentColor (deviation switch ppll_fragment_colour = ray_tracer)
+inline void prismShade(const lvo_scene& sc, const lvo_params& P, const Frame& F, const PrismRing& R, float aoTexel, const PrismFrag& f,
+                       const RasterQuad* rq, float hitColor[4], float& payloadHitT) {
+    BandArgs rb;
+    rb.shadeBands = false; rb.useBand = false; rb.phi = 0.0f; rb.linePosition = rb.lineNormal = v3(0, 0, 0);
+    rb.rasterEpsWhite = -1.0f;
+    if (rq) {
+        const PrismTri T = prismTriSetup(sc, R, F.radius, f.seg, f.tri);
+        const float f0 = prismRibbon(F.cameraPosition, f.pos, f.nrm, f.tan);
+        const float fx = prismRibbonOfRay(F, T, F.cameraPosition, rq->dX);
+        const float fy = prismRibbonOfRay(F, T, F.cameraPosition, rq->dY);
+        rb.rasterEpsWhite = fabsf(fx - f0) + fabsf(fy - f0);
+    }
+    computeFragmentColor(sc, P, F, aoTexel, f.pos, f.nrm, f.tan, false, f.attr, hitColor, payloadHitT, &rb);
+}

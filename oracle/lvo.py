@@ -15,7 +15,7 @@ _SO = os.path.join(_HERE, "_build", "liblv_oracle.so")
 
 
 def build(force=False):
-    src = [os.path.join(_HERE, f) for f in ("lv_oracle.cpp", "lv_oracle_tri.cpp", "lv_oracle_flow.cpp", "lv_oracle_common.h", "lv_oracle_tri.h", "lv_oracle.h",
+    src = [os.path.join(_HERE, f) for f in ("lv_oracle.cpp", "lv_oracle_tri.cpp", "lv_oracle_flow.cpp", "lv_oracle_common.h", "lv_oracle_tri.h", "lv_oracle.h", "lv_oracle_prism.h",
                                           "Makefile")]
     stale = (not os.path.exists(_SO)) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in src)
     if force or stale:
@@ -63,6 +63,7 @@ class Params(C.Structure):
         ("separatorBaseWidth", C.c_float), ("helicityRotationFactor", C.c_float),
         ("uniformHelicityBandWidth", C.c_uint32),
         ("ppllSortingMode", C.c_uint32),
+        ("ppllFragmentSource", C.c_uint32),
     ]
 
 
@@ -159,6 +160,8 @@ def lib():
                                   C.POINTER(Stats)]
     L.lvo_ppll_resolve.argtypes = [C.POINTER(Params), vp, vp, i32, u32, u32, u32, u32, vp]
     L.lvo_render_ppll.argtypes = [vp, C.POINTER(Params), i32, vp, u32, u32, u32, u32, vp, C.POINTER(Stats)]
+    L.lvo_prism_ring_vertices.argtypes = [vp, C.c_uint64, u32, f32, vp, vp]
+    L.lvo_prism_fragments.argtypes = [vp, C.POINTER(Params), i32, vp, u32, u32, u32, u32] + [vp] * 11
     u64p = C.POINTER(C.c_uint64)
     L.lvo_build_tube_triangle_render_data.argtypes = [vp, vp, vp, u32, f32, u32, vp, u64p, vp, u64p, vp, u64p]
     L.lvo_build_tube_triangle_render_data_ribbons.argtypes = [vp, vp, vp, u32, vp, f32, f32, u32, vp, u64p, vp, u64p, vp, u64p]
@@ -431,7 +434,7 @@ DEFAULTS = dict(
     ppllMaxNumFrags=100, ppllLinkedListSize=0, ppllTileW=2, ppllTileH=8,
     useBands=0, useEllipticTubes=0, bandWidth=0.005, minBandThickness=0.15, minThickness=0.15, lssGeometry=0,
     useHelicityBands=0, numSubdivisionsBands=6, separatorBaseWidth=0.2, helicityRotationFactor=1.0,
-    uniformHelicityBandWidth=1, ppllSortingMode=0,
+    uniformHelicityBandWidth=1, ppllSortingMode=0, ppllFragmentSource=0,
 )
 
 
@@ -618,6 +621,27 @@ class Scene:
             lib().lvo_render_rt_mlat(self.h, C.byref(P), self._use_bvh(P, use_bvh), aop, x0, y0, w, h, int(num_nodes), *tr_args)
         return out, nodes, int(viol.value)
 
+    def prism_fragments(self, P, ao=None, tile=None, use_bvh=False):
+        """Fragments of the rasterised programmable-pull prism (ppll_fragment_source = raster_prism) of every pixel of the tile, in
+        ascending (segment, triangle) order: dict of offsets (w * h + 1) and per-fragment arrays."""
+        x0, y0, w, h = self._tile(P, tile)
+        offs = np.zeros(w * h + 1, dtype=np.uint64)
+        ub = self._use_bvh(P, use_bvh)
+        aop = _p(np.ascontiguousarray(ao, dtype=np.float32)) if ao is not None else None
+        lib().lvo_prism_fragments(self.h, C.byref(P), ub, aop, x0, y0, w, h, _p(offs), *([None] * 10))
+        n = int(offs[-1])
+        m = max(n, 1)
+        r = dict(seg=np.zeros(m, np.uint32), tri=np.zeros(m, np.uint32), weights=np.zeros((m, 3), np.float32),
+                 depth=np.zeros(m, np.float32), pos=np.zeros((m, 3), np.float32), normal=np.zeros((m, 3), np.float32),
+                 tangent=np.zeros((m, 3), np.float32), attr=np.zeros(m, np.float32), colour=np.zeros(m, np.uint32),
+                 rgba=np.zeros((m, 4), np.float32))
+        lib().lvo_prism_fragments(self.h, C.byref(P), ub, aop, x0, y0, w, h, _p(offs), _p(r["seg"]), _p(r["tri"]), _p(r["weights"]),
+                                  _p(r["depth"]), _p(r["pos"]), _p(r["normal"]), _p(r["tangent"]), _p(r["attr"]), _p(r["colour"]),
+                                  _p(r["rgba"]))
+        r = {k: v[:n] for k, v in r.items()}
+        r["offsets"] = offs
+        return r
+
     def ppll_gather(self, P, ao=None, tile=None, use_bvh=False, stats=None):
         x0, y0, w, h = self._tile(P, tile)
         pw = -(-P.width // P.ppllTileW) * P.ppllTileW
@@ -732,6 +756,16 @@ def render_rt_prebaked(scene, tri_scene, P, factors, blending_weights, tile=None
     lib().lvo_render_rt_prebaked(scene.h, tri_scene.h if tri_scene is not None else None, C.byref(P), ub, _p(f), _p(bw),
                                  len(bw), f.shape[0], f.shape[1], x0, y0, w, h, _p(out), C.byref(st))
     return out
+
+
+def prism_ring_vertices(points, num_subdivisions, line_width):
+    """Ring vertices of the programmable-pull vertex stage: (positions, normals), each (len(points), N, 3)."""
+    pts = np.ascontiguousarray(points, dtype=LINE_POINT_DTYPE)
+    n = min(max(int(num_subdivisions), 3), 16)
+    pos = np.zeros((len(pts), n, 3), dtype=np.float32)
+    nrm = np.zeros((len(pts), n, 3), dtype=np.float32)
+    lib().lvo_prism_ring_vertices(_p(pts), len(pts), int(num_subdivisions), float(line_width), _p(pos), _p(nrm))
+    return pos, nrm
 
 
 def ppll_resolve(P, nodes, start_offset, tile=None, literal=False):

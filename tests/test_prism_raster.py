@@ -1,0 +1,376 @@
+"""PPLL fragments from the geometry the reference rasterises: ppll_fragment_source = raster_prism.
+
+The oracle (oracle/lv_oracle_prism.h) states the programmable-pull vertex stage (LinePassProgrammablePullTubes.glsl:87-224), the index
+pattern (LineDataFlow.cpp:1698-1713), back-face culling (LineRasterPass.cpp:85-96) and the fixed-function rasteriser as a rasteriser in
+the space of the pixel's viewing ray.  The checks of this file are INDEPENDENT of it -- float64 numpy written from the GLSL and from
+the Vulkan rasterisation rules, in a different formulation:
+
+  * ring vertices with the true cos / sin;
+  * a SCREEN-SPACE rasteriser: vertices through projection * view to window coordinates, coverage by the signed areas of the
+    projected triangle at the pixel centre, perspective-correct weights (a_i / w_i) / sum(a_j / w_j) (Vulkan spec, "Basic Polygon
+    Rasterization"), front side = the side the outward geometric normal points to; fragments, weights, depths, interpolated
+    inputs and colours (raster tail of test_raster_fragment_colour.py, fwidth from the attribute planes at the quad partners'
+    pixel centres) must agree away from the measure-zero edge cases;
+  * the fill rule: a pixel centre EXACTLY on shared edges receives exactly one fragment.
+"""
+import numpy as np
+import pytest
+
+from common import Case, small_case
+from linevis_amd import camera, transfer_function as tfm
+from oracle import lvo
+import test_independent_restatement as ir
+from test_raster_fragment_colour import raster_colour
+
+N_SUB = 6
+
+
+def prism_params(c, sc=None, **kw):
+    sc = sc or c.oracle_scene()
+    P = c.oracle_params(sc)
+    P.ppllFragmentSource = 1
+    for k, v in kw.items():
+        setattr(P, k, v)
+    return sc, P
+
+
+def ring_vertices64(points, n_sub, radius):
+    """LinePassProgrammablePullTubes.glsl:123-177 in float64: (positions, normals) of shape (len(points), n_sub, 3)"""
+    c = points["linePosition"].astype(np.float64)
+    nrm = points["lineNormal"].astype(np.float64)
+    tan = points["lineTangent"].astype(np.float64)
+    binormal = np.cross(tan, nrm)
+    t = np.arange(n_sub, dtype=np.float64) / n_sub * 2.0 * np.pi
+    d = nrm[:, None, :] * np.cos(t)[None, :, None] + binormal[:, None, :] * np.sin(t)[None, :, None]
+    return radius * d + c[:, None, :], d / np.linalg.norm(d, axis=-1, keepdims=True)
+
+
+def test_ring_vertices_against_float64():
+    c = small_case(line_width=0.02)
+    for n_sub in (3, 4, 6, 8, 16):
+        pos, nrm = lvo.prism_ring_vertices(c.points, n_sub, c.line_width)
+        pos64, nrm64 = ring_vertices64(c.points, n_sub, c.line_width / 2)
+        assert np.abs(pos - pos64).max() < 2e-7          # positions of magnitude <= 0.5: a few float32 ulps
+        assert np.abs(nrm - nrm64).max() < 1e-6
+        # every ring vertex lies on the circle of its line point (the prism is inscribed in the tube)
+        r = np.linalg.norm(pos64 - c.points["linePosition"][:, None, :], axis=-1)
+        assert np.abs(r - c.line_width / 2).max() < 1e-7
+
+
+def triangles64(c, n_sub):
+    """index pattern of LineDataFlow.cpp:1698-1713 -> per triangle: segment, triangle-in-segment, 3 x (point index, circle index)"""
+    seg = c.seg.astype(np.int64)
+    out = []
+    for k in range(n_sub):
+        kn = (k + 1) % n_sub
+        out.append((2 * k, [(0, k), (0, kn), (1, k)]))
+        out.append((2 * k + 1, [(1, k), (0, kn), (1, kn)]))
+    return seg, out
+
+
+def screen_space_rasteriser(c, P, n_sub, tile=None):
+    """Independent float64 rasteriser; returns dict pixel -> list of fragments (seg, tri, weights(3), margin) where margin = the
+    smallest normalised screen-space barycentric (how far inside the triangle the pixel centre lies)."""
+    W, H = c.width, c.height
+    view = np.asarray(c.view, np.float64).reshape(4, 4).T
+    proj = np.asarray(c.proj, np.float64).reshape(4, 4).T
+    mvp = proj @ view
+    cam = np.linalg.inv(view)[:3, 3]
+    pos, nrm = ring_vertices64(c.points, n_sub, c.line_width / 2)
+    clip = np.concatenate([pos, np.ones(pos.shape[:2] + (1,))], -1) @ mvp.T          # (points, k, 4)
+    win = np.stack([(clip[..., 0] / clip[..., 3] + 1.0) * 0.5 * W, (clip[..., 1] / clip[..., 3] + 1.0) * 0.5 * H], -1)
+    seg, pattern = triangles64(c, n_sub)
+    frags = {}
+    x0, y0, w, h = tile or (0, 0, W, H)
+    for s in range(len(seg)):
+        for tt, verts in pattern:
+            pi = [seg[s, r] for r, _ in verts]
+            ki = [k for _, k in verts]
+            V = np.array([pos[p, k] for p, k in zip(pi, ki)])
+            S = np.array([win[p, k] for p, k in zip(pi, ki)])
+            wc = np.array([clip[p, k, 3] for p, k in zip(pi, ki)])
+            if np.any(wc <= 0):
+                continue                                   # (no test scene reaches behind the camera)
+            # front side = where the outward geometric normal points (both triangles of the pattern wind the same way)
+            g = np.cross(V[1] - V[0], V[2] - V[0])
+            if np.dot(g, cam - V[0]) <= 0:
+                continue
+            lo = np.floor(S.min(0) - 0.5).astype(int)
+            hi = np.ceil(S.max(0) - 0.5).astype(int)
+            for py in range(max(lo[1], y0), min(hi[1], y0 + h - 1) + 1):
+                for px in range(max(lo[0], x0), min(hi[0], x0 + w - 1) + 1):
+                    p = np.array([px + 0.5, py + 0.5])
+                    def area(a, b, q):
+                        return (b[0] - a[0]) * (q[1] - a[1]) - (b[1] - a[1]) * (q[0] - a[0])
+                    A = area(S[0], S[1], S[2])
+                    a = np.array([area(S[1], S[2], p), area(S[2], S[0], p), area(S[0], S[1], p)]) / A
+                    if a.min() < 0:
+                        continue
+                    pw = a / wc
+                    frags.setdefault((px, py), []).append((s, tt, pw / pw.sum(), float(a.min())))
+    return frags, pos, nrm, cam
+
+
+def small_prism_case(**kw):
+    # thick tubes on a small image: every triangle of the hexagon covers several pixels
+    return small_case(width=150, height=100, n_lines=10, pts_per_line=10, line_width=0.05, transparent=True, **kw)
+
+
+def test_prism_fragments_against_the_independent_screen_space_rasteriser():
+    c = small_prism_case()
+    sc, P = prism_params(c)
+    fr = sc.prism_fragments(P)
+    offs = fr["offsets"].astype(np.int64)
+    want, pos, nrm, cam = screen_space_rasteriser(c, P, N_SUB)
+    assert len(fr["seg"]) > 800
+    got = {}
+    for pix in range(c.width * c.height):
+        for i in range(offs[pix], offs[pix + 1]):
+            got.setdefault((pix % c.width, pix // c.width), {})[(int(fr["seg"][i]), int(fr["tri"][i]))] = i
+    n_checked = n_edge = 0
+    worst_w = worst_d = 0.0
+    tan = c.points["lineTangent"].astype(np.float64)
+    att = c.points["lineAttribute"].astype(np.float64)
+    _, pattern = triangles64(c, N_SUB)
+    pat = dict(pattern)
+    for key, lst in want.items():
+        for (s, tt, w64, margin) in lst:
+            i = got.get(key, {}).get((s, tt))
+            if margin < 1e-4:                       # pixel centre within 1e-4 of an edge (in barycentric units): either answer
+                n_edge += 1
+                continue
+            assert i is not None, ("missing fragment", key, s, tt, margin)
+            n_checked += 1
+            worst_w = max(worst_w, float(np.abs(fr["weights"][i] - w64).max()))
+            verts = pat[tt]
+            pi = [c.seg[s, r] for r, _ in verts]
+            V = np.array([pos[p, k] for p, (_, k) in zip(pi, verts)])
+            Nn = np.array([nrm[p, k] for p, (_, k) in zip(pi, verts)])
+            fp = w64 @ V
+            worst_d = max(worst_d, abs(float(fr["depth"][i]) - float(np.linalg.norm(fp - cam))))
+            assert np.abs(fr["pos"][i] - fp).max() < 1e-6
+            assert np.abs(fr["normal"][i] - w64 @ Nn).max() < 2e-5
+            assert np.abs(fr["tangent"][i] - w64 @ tan[pi]).max() < 2e-5
+            assert abs(float(fr["attr"][i]) - float(w64 @ att[pi])) < 2e-5
+    # ... and nothing else: every oracle fragment is one of the rasteriser's (edge cases aside)
+    extra = 0
+    for key, d in got.items():
+        ws = {(s, tt): m for (s, tt, _, m) in want.get(key, [])}
+        for (s, tt), i in d.items():
+            if (s, tt) not in ws:
+                assert fr["weights"][i].min() < 1e-4, ("fragment the rasteriser does not produce", key, s, tt, fr["weights"][i])
+                extra += 1
+    assert n_checked > 750 and n_edge < 0.02 * n_checked and extra <= n_edge + 2
+    assert worst_w < 1e-4 and worst_d < 1e-6, (worst_w, worst_d)   # weights: float32 edge functions of ~0.03-wide triangles
+
+
+def test_prism_fragment_colours_against_the_float64_raster_shader():
+    """colour of every fragment = the raster tube shader (float64 restatement) on the perspective-correct inputs, with
+    EPSILON_WHITE = fwidth(ribbonPosition) from the triangle's attribute planes at the quad partners' pixel centres"""
+    for settings in ({}, dict(depth_cue_strength=0.8)):
+        c = small_prism_case(**settings)
+        sc, P = prism_params(c)
+        fr = sc.prism_fragments(P)
+        offs = fr["offsets"].astype(np.int64)
+        W, H = c.width, c.height
+        view = np.asarray(c.view, np.float64).reshape(4, 4).T
+        proj = np.asarray(c.proj, np.float64).reshape(4, 4).T
+        mvp = proj @ view
+        cam = np.linalg.inv(view)[:3, 3]
+        pos, nrm = ring_vertices64(c.points, N_SUB, c.line_width / 2)
+        tan = c.points["lineTangent"].astype(np.float64)
+        _, pattern = triangles64(c, N_SUB)
+        pat = dict(pattern)
+        pix = np.repeat(np.arange(W * H), np.diff(offs))
+        n = len(pix)
+
+        def ribbon(fp, fn, ft):
+            nn = ir.normalize(fn); v = ir.normalize(cam - fp); t = ir.normalize(ft)
+            helper = ir.normalize(np.cross(t, v)); new_v = ir.normalize(np.cross(helper, t))
+            cvn = np.cross(new_v, nn)
+            rp = ir.length(cvn)
+            return ir.clamp(np.where(ir.dot(t, cvn) < 0, -rp, rp), -1.0, 1.0)
+
+        def inputs_at(px, py):
+            """perspective-correct interpolation of the fragments' triangles at window positions (px, py) (may lie outside)"""
+            fp = np.zeros((n, 3)); fn = np.zeros((n, 3)); ft = np.zeros((n, 3))
+            for i in range(n):
+                s, tt = int(fr["seg"][i]), int(fr["tri"][i])
+                verts = pat[tt]
+                pi = [c.seg[s, r] for r, _ in verts]
+                V = np.array([pos[p, k] for p, (_, k) in zip(pi, verts)])
+                Nn = np.array([nrm[p, k] for p, (_, k) in zip(pi, verts)])
+                cl = np.concatenate([V, np.ones((3, 1))], 1) @ mvp.T
+                S = np.stack([(cl[:, 0] / cl[:, 3] + 1) * 0.5 * W, (cl[:, 1] / cl[:, 3] + 1) * 0.5 * H], -1)
+                q = np.array([px[i], py[i]])
+                def area(a, b, qq):
+                    return (b[0] - a[0]) * (qq[1] - a[1]) - (b[1] - a[1]) * (qq[0] - a[0])
+                a = np.array([area(S[1], S[2], q), area(S[2], S[0], q), area(S[0], S[1], q)])
+                pw = a / cl[:, 3]
+                w = pw / pw.sum()
+                fp[i] = w @ V; fn[i] = w @ Nn; ft[i] = w @ tan[pi]
+            return fp, fn, ft
+
+        x = (pix % W).astype(np.float64); y = (pix // W).astype(np.float64)
+        xp = ((pix % W) ^ 1).astype(np.float64); yp = ((pix // W) ^ 1).astype(np.float64)
+        f0 = ribbon(*inputs_at(x + 0.5, y + 0.5))
+        fx = ribbon(*inputs_at(xp + 0.5, y + 0.5))
+        fy = ribbon(*inputs_at(x + 0.5, yp + 0.5))
+        eps = np.abs(fx - f0) + np.abs(fy - f0)
+        f32 = lambda a: np.asarray(a, dtype=np.float32).astype(np.float64)
+        want = raster_colour(c.tf.astype(np.float64), P, f32(fr["pos"]), f32(fr["normal"]), f32(fr["tangent"]),
+                             np.zeros(n, dtype=bool), f32(fr["attr"]), np.ones(n), eps)
+        err = np.abs(fr["rgba"].astype(np.float64) - want).max(axis=1)
+        # the white outline is a smoothstep of width 2 eps around |ribbonPosition| = 0.7: an input error delta moves it by delta / eps
+        steep = (np.abs(np.abs(f0) - 0.7) < eps + 1e-3) & (eps < 2e-2)
+        assert err[~steep].max() < 2e-3, err[~steep].max()
+        assert steep.sum() < 0.05 * n
+        assert eps.max() > 0.05 and (np.abs(f0) > 0.7).sum() > 50       # the outline exists in the picture
+
+
+def test_fill_rule_a_pixel_centre_exactly_on_shared_edges_receives_one_fragment():
+    """Straight square tube (N = 4: ring directions exactly +-normal / +-binormal) along y through the origin, camera on the z axis,
+    odd image width: the centre column's rays have x = 0 exactly and run along the ridge edge (the longitudinal edges c_k - n_k at
+    x = 0 and the ring edges' end points).  Exactly one triangle must own every such pixel -- `>=` would yield 2, `>` none."""
+    n = 9
+    pts = np.zeros(n, dtype=lvo.LINE_POINT_DTYPE)
+    pts["linePosition"][:, 1] = np.linspace(-0.25, 0.25, n).astype(np.float32)
+    pts["lineTangent"][:, 1] = 1.0
+    pts["lineNormal"][:, 2] = 1.0                       # ring vertex 0 points at the camera: a ridge at x = 0
+    pts["lineAttribute"] = 0.5
+    seg = np.stack([np.arange(n - 1), np.arange(1, n)], 1).astype(np.uint32)
+    c = Case(pts, seg, tfm.standard_transparent(), 33, 33, 0.0625, tube_num_subdivisions=4)
+    sc, P = prism_params(c)
+    fr = sc.prism_fragments(P)
+    cnt = np.diff(fr["offsets"].astype(np.int64)).reshape(33, 33)
+    pos, _ = lvo.prism_ring_vertices(pts, 4, 0.0625)
+    assert np.all(pos[:, 0, 0] == 0.0) and np.all(pos[:, 2, 0] == 0.0)     # the ridge and the far edge lie at x = 0 exactly
+    col = cnt[:, 16]
+    rows = np.nonzero(col)[0]
+    assert len(rows) >= 15
+    assert np.all(col[rows] == 1), col
+    # the fragments of the centre column do lie on an edge: one weight is exactly zero
+    offs = fr["offsets"].astype(np.int64)
+    on_edge = 0
+    for r in rows:
+        i = offs[r * 33 + 16]
+        on_edge += int(np.any(fr["weights"][i] == 0.0))
+    assert on_edge >= len(rows) - 2
+    # the whole silhouette of a convex, untwisted prism: exactly one front-facing crossing per covered pixel
+    assert set(np.unique(cnt)) <= {0, 1}
+
+
+def test_bvh_and_brute_force_candidates_give_identical_fragments():
+    c = small_case(width=96, height=64, transparent=True)
+    sc, P = prism_params(c)
+    a = sc.prism_fragments(P)
+    b = sc.prism_fragments(P, use_bvh=True)
+    assert len(a["seg"]) > 1000
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+
+
+def test_prism_frame_differs_from_the_capsule_probe_and_is_contained_in_it():
+    """the inscribed, uncapped prism covers a subset of the capsules' pixels, and joints yield one fragment instead of two"""
+    c = small_case(width=96, height=64, transparent=True)
+    sc, P = prism_params(c)
+    fr = sc.prism_fragments(P)
+    cnt_p = np.diff(fr["offsets"].astype(np.int64))
+    offs, _, _ = sc.pixel_hits(P)
+    cnt_c = np.diff(offs.astype(np.int64))
+    assert np.all(cnt_c[cnt_p > 0] > 0)
+    assert 0.8 * (cnt_c > 0).sum() < (cnt_p > 0).sum() < (cnt_c > 0).sum()
+    assert cnt_p.sum() < cnt_c.sum()
+    img_p = sc.render_ppll(P)
+    P.ppllFragmentSource = 0
+    img_c = sc.render_ppll(P)
+    assert not np.array_equal(img_p, img_c)
+
+
+# ---------------------------------------------------------------- GPU
+def _lists(nodes, start):
+    """per-pixel multisets {(colour, depth bits)} of a PPLL node pool"""
+    out = {}
+    for pix in np.nonzero(start != 0xFFFFFFFF)[0]:
+        i, l = int(start[pix]), []
+        while i != 0xFFFFFFFF:
+            l.append((int(nodes[i, 0]), int(nodes[i, 1])))
+            i = int(nodes[i, 2])
+        out[int(pix)] = sorted(l)
+    return out
+
+
+PRISM_VARIANTS = {
+    "hexagon": dict(),
+    "square": dict(tube_num_subdivisions=4),
+    "octagon": dict(tube_num_subdivisions=8),
+    "triangle": dict(tube_num_subdivisions=3),
+    "sixteen": dict(tube_num_subdivisions=16),
+    "ao_depthcue": dict(ambient_occlusion_mode="RTAO (Screen Space)", ambient_occlusion_strength=1.0, ambient_occlusion_iterations=2,
+                        ambient_occlusion_samples_per_frame=4, depth_cue_strength=0.8),
+    "no_halos": dict(use_halos=False),
+    "thin": dict(),
+    "ray_tracer_colour": dict(ppll_fragment_colour="ray_tracer"),
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", sorted(PRISM_VARIANTS))
+def test_hip_gather_of_the_rasterised_prism_against_the_oracle(hip_lib, variant):
+    """k_ppll_gather<LV_PRIM_PRISM> against the oracle's gather: fragment multisets (packed colour, depth bits) of every pixel bit for
+    bit, the fragment counter, frames <= 2 LSB (0 expected: the shading uses the build's deterministic pow); tiles reproduce the
+    frame; the capsule probe stays available."""
+    settings = dict(PRISM_VARIANTS[variant])
+    lw = 0.003 if variant == "thin" else 0.015
+    c = small_case(width=176, height=120, n_lines=40, pts_per_line=40, line_width=lw, transparent=True, **settings)
+    ctx = c.hip_context()
+    img = ctx.render(2)
+    sc = c.oracle_scene()
+    P = c.oracle_params(sc)
+    assert P.ppllFragmentSource == 1                                   # auto = raster_prism for plain flow lines
+    ao = sc.render_ao(P) if P.useAmbientOcclusion else None
+    if variant == "ray_tracer_colour":
+        with lvo.ppll_ray_tracer_fragment_colour():
+            on, os_, ocnt = sc.ppll_gather(P, ao=ao, use_bvh=True)
+            ref = sc.render_ppll(P, ao=ao, use_bvh=True)
+    else:
+        on, os_, ocnt = sc.ppll_gather(P, ao=ao, use_bvh=True)
+        ref = sc.render_ppll(P, ao=ao, use_bvh=True)
+    pw, ph = c.padded()
+    hn, hs, hcnt = ctx.ppll_buffers(pw * ph, int(P.ppllLinkedListSize))
+    assert hcnt == ocnt and hcnt > 500
+    assert _lists(hn, hs) == _lists(on, os_)
+    assert np.abs(img.astype(np.int32) - ref.astype(np.int32)).max() <= 2
+    assert np.array_equal(ctx.render(2, tile=(37, 21, 50, 33)), img[21:54, 37:87])
+    # the probe of rounds 1-3 is still there, and differs
+    ctx.set_option("ppll_fragment_source", "capsule_entry")
+    c.settings["ppll_fragment_source"] = "capsule_entry"
+    P0 = c.oracle_params(sc)
+    assert P0.ppllFragmentSource == 0
+    if variant != "ray_tracer_colour":
+        img0 = ctx.render(2)
+        assert np.abs(img0.astype(np.int32) - sc.render_ppll(P0, ao=ao, use_bvh=True).astype(np.int32)).max() <= 2
+        assert not np.array_equal(img0, img)
+
+
+@pytest.mark.gpu
+def test_hip_prism_fill_rule_on_exact_edges(hip_lib):
+    """the centre column of the square tube of test_fill_rule...: rays exactly on shared edges, one fragment each, on the device too"""
+    n = 9
+    pts = np.zeros(n, dtype=lvo.LINE_POINT_DTYPE)
+    pts["linePosition"][:, 1] = np.linspace(-0.25, 0.25, n).astype(np.float32)
+    pts["lineTangent"][:, 1] = 1.0
+    pts["lineNormal"][:, 2] = 1.0
+    pts["lineAttribute"] = 0.5
+    seg = np.stack([np.arange(n - 1), np.arange(1, n)], 1).astype(np.uint32)
+    c = Case(pts, seg, tfm.standard_transparent(), 33, 33, 0.0625, tube_num_subdivisions=4)
+    ctx = c.hip_context()
+    ctx.render(2)
+    sc, P = prism_params(c)
+    on, os_, ocnt = sc.ppll_gather(P)
+    pw, ph = c.padded()
+    hn, hs, hcnt = ctx.ppll_buffers(pw * ph, int(P.ppllLinkedListSize))
+    assert hcnt == ocnt
+    lh = _lists(hn, hs)
+    assert lh == _lists(on, os_)
+    assert all(len(v) == 1 for v in lh.values())
