@@ -609,7 +609,7 @@ def main():
         frame_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(len(marks) - 1)] if marks else []
         kernels = {}
         if not dry:
-            for k, name in enumerate(capi.KERNEL_NAMES[:6]):
+            for k, name in enumerate(capi.KERNEL_NAMES):
                 ks = _stats(ctx.kernel_times(k))
                 if ks:
                     kernels[name] = ks

@@ -107,6 +107,7 @@ typedef struct lv_stats {
 #define LV_KERNEL_PPLL_GATHER 3
 #define LV_KERNEL_PPLL_RESOLVE 4
 #define LV_KERNEL_DEPTH_RANGE 5
+#define LV_KERNEL_PPLL_SHADE 6   /* fragment stage of ppll_fragment_source = raster_prism (k_ppll_shade_prism) */
 
 typedef struct lv_ctx lv_ctx;
 

@@ -70,7 +70,7 @@ def streamline_settings(method="Runge-Kutta 4th Order", direction="Forward & Bac
 
 
 KERNEL_AO_PRIMARY, KERNEL_AO_RAYS, KERNEL_RENDER_RT, KERNEL_PPLL_GATHER, KERNEL_PPLL_RESOLVE, KERNEL_DEPTH_RANGE = range(6)
-KERNEL_NAMES = ["k_ao_primary", "k_ao_rays", "k_render_rt", "k_ppll_gather", "k_ppll_resolve", "k_depth_minmax"]
+KERNEL_NAMES = ["k_ao_primary", "k_ao_rays", "k_render_rt", "k_ppll_gather", "k_ppll_resolve", "k_depth_minmax", "k_ppll_shade_prism"]
 
 
 class LineVisError(RuntimeError):
@@ -411,6 +411,8 @@ class Context:
         return order, cost
 
     def ppll_buffers(self, padded_pixels, max_nodes):
+        # the library's physical pool may exceed the logical linkedListSize (chunk tails / sub-pools of the gather): room for it
+        max_nodes = max(int(max_nodes), int(self.stats().ppll_pool_nodes))
         nodes = np.zeros((max_nodes, 3), dtype=np.uint32)
         start = np.zeros(padded_pixels, dtype=np.uint32)
         cnt = C.c_uint32()

@@ -94,12 +94,12 @@ void lv_mat4_inverse(const float* m, float* inv) {
 
 // every device buffer a context owns: freed by lv_destroy, summed by lv_get_stats (device_bytes)
 static std::vector<LvDeviceBuffer*> lv_all_buffers(lv_ctx* ctx) {
-    return {&ctx->points, &ctx->segIdx, &ctx->nodes, &ctx->segs, &ctx->segAxis, &ctx->leafSeg, &ctx->segToLeaf, &ctx->tf,
+    return {&ctx->points, &ctx->segIdx, &ctx->nodes, &ctx->segs, &ctx->segAxis, &ctx->prismFrames, &ctx->leafSeg, &ctx->segToLeaf, &ctx->tf,
             &ctx->depthMinMax, &ctx->ao, &ctx->aoAlt, &ctx->featNormal, &ctx->featNormalAlt, &ctx->featPosition, &ctx->featPositionAlt,
             &ctx->eawPing, &ctx->eawPong, &ctx->tilesHaloDev, &ctx->fullFrameTile, &ctx->svgf.normalDepth, &ctx->svgf.normalDepthHistory,
             &ctx->svgf.flowFwidth, &ctx->svgf.moments, &ctx->svgf.momentsHistory, &ctx->svgf.colorHistory, &ctx->svgf.tempAccum,
             &ctx->svgf.tempAccumFiltered, &ctx->svgf.ping, &ctx->svgf.pong, &ctx->svgf.result, &ctx->aoGbuf, &ctx->aoList, &ctx->aoSamples,
-            &ctx->counters, &ctx->ppllNodes, &ctx->ppllStart, &ctx->ppllCount, &ctx->ppllScratch, &ctx->tilesDev, &ctx->outDev,
+            &ctx->counters, &ctx->ppllNodes, &ctx->ppllStart, &ctx->ppllCount, &ctx->ppllScratch, &ctx->prismRecords, &ctx->prismRegions, &ctx->tilesDev, &ctx->outDev,
             &ctx->scratchRays, &ctx->stackOverflow, &ctx->triIdx, &ctx->triVerts, &ctx->triPoints, &ctx->triNodes, &ctx->tris,
             &ctx->flowVectors, &ctx->flowScalars, &ctx->flowMisc, &ctx->flowSeeds, &ctx->flowOutPos, &ctx->flowOutAtt, &ctx->flowCounts,
             &ctx->bakeBlendingWeights, &ctx->bakeSamplingLocations, &ctx->bakedAo, &ctx->bakeLcgSkip, &ctx->mlatTrace, &ctx->buildArena,

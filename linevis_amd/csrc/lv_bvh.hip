@@ -98,7 +98,7 @@ __global__ __launch_bounds__(LV_BLOCK) void k_leaves(const lv_line_point* __rest
                                                      const uint32_t* __restrict__ sortedVals, uint32_t nSeg,
                                                      float4* __restrict__ segs, float4* __restrict__ segAxis,
                                                      uint32_t* __restrict__ leafSeg, uint32_t* __restrict__ segToLeaf,
-                                                     float* __restrict__ leafBox) {
+                                                     float* __restrict__ leafBox, float4* __restrict__ prismFrames) {
     uint32_t i = blockIdx.x * LV_BLOCK + threadIdx.x;
     if (i >= nSeg) return;
     uint32_t s = sortedVals[i];
@@ -112,6 +112,13 @@ __global__ __launch_bounds__(LV_BLOCK) void k_leaves(const lv_line_point* __rest
     segAxis[i] = make_float4(td.x, td.y, td.z, 0.0f);
     leafSeg[i] = s;
     segToLeaf[s] = i;
+    // frames of the two line points in leaf order, for the vertex stage of the rasterised prism (lv_prism.h): {tangent, point index}
+    // {normal, lineStartIndex} per point -- with `segs` the whole 48-B records, 96 contiguous bytes per (ray, segment) test
+    const uint32_t ia = segIdx[2 * s], ib = segIdx[2 * s + 1];
+    prismFrames[4 * size_t(i) + 0] = make_float4(a.lineTangent[0], a.lineTangent[1], a.lineTangent[2], __uint_as_float(ia));
+    prismFrames[4 * size_t(i) + 1] = make_float4(a.lineNormal[0], a.lineNormal[1], a.lineNormal[2], __uint_as_float(a.lineStartIndex));
+    prismFrames[4 * size_t(i) + 2] = make_float4(b.lineTangent[0], b.lineTangent[1], b.lineTangent[2], __uint_as_float(ib));
+    prismFrames[4 * size_t(i) + 3] = make_float4(b.lineNormal[0], b.lineNormal[1], b.lineNormal[2], __uint_as_float(b.lineStartIndex));
 #pragma unroll
     for (int k = 0; k < 6; k++) leafBox[6 * size_t(i) + k] = boxOrig[6 * size_t(s) + k];
 }
@@ -823,6 +830,7 @@ int lv_bvh_build(lv_ctx* ctx) {
     if ((rc = lv_buf_reserve(ctx, ctx->segAxis, size_t(n) * 16))) return rc;
     if ((rc = lv_buf_reserve(ctx, ctx->leafSeg, size_t(n) * 4))) return rc;
     if ((rc = lv_buf_reserve(ctx, ctx->segToLeaf, size_t(n) * 4))) return rc;
+    if ((rc = lv_buf_reserve(ctx, ctx->prismFrames, size_t(n) * 64))) return rc;
     const lv_line_point* points = (const lv_line_point*)ctx->points.ptr;
     const uint32_t* segIdx = (const uint32_t*)ctx->segIdx.ptr;
     rc = lv_bvh_build_core(
@@ -833,7 +841,7 @@ int lv_bvh_build(lv_ctx* ctx) {
             [&](const uint32_t* sortedVals, const float* boxOrig, float* leafBox) {
                 k_leaves<<<nblocks(n), LV_BLOCK, 0, st>>>(points, segIdx, boxOrig, sortedVals, n, (float4*)ctx->segs.ptr,
                                                           (float4*)ctx->segAxis.ptr, (uint32_t*)ctx->leafSeg.ptr, (uint32_t*)ctx->segToLeaf.ptr,
-                                                          leafBox);
+                                                          leafBox, (float4*)ctx->prismFrames.ptr);
             });
     if (rc) return rc;
     ctx->accelValid = true;

@@ -30,6 +30,17 @@
 #ifndef LV_GATHER_MIN_WAVES
 #define LV_GATHER_MIN_WAVES 1
 #endif
+#ifndef LV_PRISM_MIN_WAVES
+#define LV_PRISM_MIN_WAVES 3    // k_ppll_gather<LV_PRIM_PRISM>: waves per SIMD the register allocator leaves room for
+#endif
+#define LV_PRISM_REGIONS 64u         // regions of the record stream / sub-pools of the node pool, one counter each (power of two)
+#define LV_PRISM_REGION_STRIDE 32u   // uint32 between two counters (128 B: a cache line each)
+#ifndef LV_PRISM_SHADE_MIN_WAVES
+#define LV_PRISM_SHADE_MIN_WAVES 2   // k_ppll_shade_prism: waves per SIMD the register allocator leaves room for (4: 128 VGPRs + 248 B of scratch, 0.64 ms on config 4; 1 ... 3: no scratch, 0.49 ms)
+#endif
+#ifndef LV_PRISM_SHADE_BLOCKS_PER_CU
+#define LV_PRISM_SHADE_BLOCKS_PER_CU 8   // grid of the grid-stride fragment stage
+#endif
 #ifndef LV_REFILL_THRESHOLD
 #define LV_REFILL_THRESHOLD 8 // persistent AO waves fetch new rays once this many lanes are idle
 #endif
@@ -246,6 +257,7 @@ struct LvSceneDev {
     // weights (AmbientOcclusionFactorsBuffer / AmbientOcclusionBlendingWeightsBuffer, AmbientOcclusion.glsl:31-38)
     const float* bakedAo;
     const float* bakedBlendingWeights;
+    const float4* prismFrames;  // per leaf {tangent0, index0}{normal0, start0}{tangent1, index1}{normal1, start1} (k_leaves)
     LvPrismDev prism;           // PPLL gather with ppll_fragment_source = raster_prism
 };
 #define LV_PRIM_CAPSULE 0

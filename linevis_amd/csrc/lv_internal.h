@@ -115,6 +115,7 @@ struct lv_ctx {
     uint32_t numPoints = 0, numSegs = 0, numNodes = 0;
     LvDeviceBuffer points, segIdx;            // input order
     LvDeviceBuffer nodes, segs, segAxis, leafSeg, segToLeaf; // accel
+    LvDeviceBuffer prismFrames;               // per leaf: the frames of the segment's two line points (lv_prism.h), 64 B
     LvDeviceBuffer tf;
     uint32_t tfN = 0;
     float attrMin = 0.0f, attrMax = 1.0f;
@@ -174,6 +175,8 @@ struct lv_ctx {
     LvDeviceBuffer aoGbuf, aoList, aoSamples; // RTAO wavefront buffers
     LvDeviceBuffer counters;                  // device counters (LvCounters + misc)
     LvDeviceBuffer ppllNodes, ppllStart, ppllCount, ppllScratch;
+    LvDeviceBuffer prismRegions;              // raster_prism: record / node counters of the LV_PRISM_REGIONS regions (128 B apart)
+    LvDeviceBuffer prismRecords;              // raster_prism: covered (pixel, segment, triangle) records between the two gather kernels
     LvDeviceBuffer tilesDev, outDev, scratchRays, stackOverflow, mlatTrace;
     LvDeviceBuffer accum;                     // rgba8 of the previous accumulated frame (full viewport)
     uint32_t* pinned = nullptr;               // 64 B of pinned host memory for small read-backs (hipHostMalloc)
@@ -200,10 +203,10 @@ struct lv_ctx {
     bool evBuildValid = false, evFrameValid = false;
     int lastMode = 0;
     // per-kernel launch timers: ring of event pairs per kernel id (LV_KERNEL_*)
-    static constexpr int kNumKernels = 6;
+    static constexpr int kNumKernels = 7;
     static constexpr int kRing = 512;
     hipEvent_t evKernel[kNumKernels][2 * kRing];
-    uint64_t kernelLaunches[kNumKernels] = {0, 0, 0, 0, 0, 0};
+    uint64_t kernelLaunches[kNumKernels] = {0, 0, 0, 0, 0, 0, 0};
 };
 
 int lv_fail(lv_ctx* ctx, int code, const char* fmt, ...);

@@ -16,11 +16,13 @@
 // definition, with the reasons for every choice, is the header of oracle/lv_oracle_prism.h, which this file mirrors operation for
 // operation (float32, -ffp-contract=off, fused multiply-adds exactly where written as fmaf):
 //   P = cross(R, d), Q = cross(d, P)                        R = camera right axis
-//   (x, y) = ((V - o) . P, (V - o) . Q)                     fused dot products
+//   (x, y) = (fma(r, fma(b.P, sin, (n.P) cos), (c - o).P), same with Q)    ring vertex c + r (n cos + b sin), fused dot products
 //   E(U, V) = yU * xV - xU * yV                             unfused: E(V, U) == -E(U, V) bit for bit (shared edges)
 //   covered iff every e_i > 0, or == 0 on an edge the triangle owns (gl_VertexIndex(U) < gl_VertexIndex(V)), and sum > 0
 //   weights b_i = e_i * (1 / ((e0 + e1) + e2)); attribute = (b0 a0 + b1 a1) + b2 a2
 //   kept iff depth in the slice [tLo, tHi), within r / |d| of the segment's box interval, and near <= -view.z <= far
+// Three stages, each run at full wave width on its own queue (lv_trace_all): A capsule pre-test (32 B, ~70 instructions) -> B
+// coverage mask of the 2 N triangles (64 B more, ~350 instructions) -> C fragment stage (lv_shade_prism) incl. the three `kept` rules.
 #pragma once
 
 #include "lv_device.h"
@@ -34,15 +36,19 @@ __device__ __forceinline__ bool lv_prism_inside(float e, bool owned) { return e 
 
 // frame of a line point as the vertex stage uses it
 struct LvPrismPoint { f3 centre, normal, binormal, tangent; float attr; uint32_t start; };
-__device__ __forceinline__ LvPrismPoint lv_prism_point(const lv_line_point* __restrict__ points, uint32_t idx) {
-    const float4* q = (const float4*)(points + idx);    // 48-B records: three 16-B loads
-    const float4 a = q[0], b = q[1], c = q[2];
-    LvPrismPoint p;
-    p.centre = mk3(a.x, a.y, a.z); p.attr = a.w;
-    p.tangent = mk3(b.x, b.y, b.z);
-    p.normal = mk3(c.x, c.y, c.z); p.start = __float_as_uint(c.w);
-    p.binormal = cross3(p.tangent, p.normal);
-    return p;
+// the two line points of a leaf's segment from the leaf-ordered copies: S.segs {position, attribute} x 2 and S.prismFrames
+// {tangent, point index}{normal, lineStartIndex} x 2 (k_leaves) = the 48-B records of both points in 96 contiguous bytes
+__device__ __forceinline__ void lv_prism_frames(const LvSceneDev& S, uint32_t leaf, float4 pa, float4 pb, LvPrismPoint pt[2], uint32_t pi[2]) {
+    const float4* q = S.prismFrames + 4 * size_t(leaf);
+    const float4 t0 = q[0], n0 = q[1], t1 = q[2], n1 = q[3];
+    pt[0].centre = mk3(pa.x, pa.y, pa.z); pt[0].attr = pa.w;
+    pt[0].tangent = mk3(t0.x, t0.y, t0.z); pi[0] = __float_as_uint(t0.w);
+    pt[0].normal = mk3(n0.x, n0.y, n0.z); pt[0].start = __float_as_uint(n0.w);
+    pt[0].binormal = cross3(pt[0].tangent, pt[0].normal);
+    pt[1].centre = mk3(pb.x, pb.y, pb.z); pt[1].attr = pb.w;
+    pt[1].tangent = mk3(t1.x, t1.y, t1.z); pi[1] = __float_as_uint(t1.w);
+    pt[1].normal = mk3(n1.x, n1.y, n1.z); pt[1].start = __float_as_uint(n1.w);
+    pt[1].binormal = cross3(pt[1].tangent, pt[1].normal);
 }
 // ring vertex: dir = normal * cos + binormal * sin; position = radius * dir + centre
 __device__ __forceinline__ f3 lv_prism_dir(const LvPrismPoint& p, float c, float s) {
@@ -53,14 +59,22 @@ __device__ __forceinline__ f3 lv_prism_pos(const LvPrismPoint& p, f3 dir, float 
     return mk3(__builtin_fmaf(radius, dir.x, p.centre.x), __builtin_fmaf(radius, dir.y, p.centre.y),
                __builtin_fmaf(radius, dir.z, p.centre.z));
 }
-__device__ __forceinline__ void lv_prism_project(f3 pos, f3 o, f3 P, f3 Q, float& x, float& y) {
-    const f3 A = pos - o;
-    x = __builtin_fmaf(A.z, P.z, __builtin_fmaf(A.y, P.y, A.x * P.x));
-    y = __builtin_fmaf(A.z, Q.z, __builtin_fmaf(A.y, Q.y, A.x * Q.x));
+__device__ __forceinline__ float lv_prism_dot(f3 a, f3 b) { return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x)); }
+// projection of a line point's frame into the ray's plane (oracle: prismPointProj): six dot products per (ray, line point), then
+// two fused multiply-adds per coordinate of a ring vertex
+struct LvPrismProj { float X0, Y0, nP, bP, nQ, bQ; };
+__device__ __forceinline__ LvPrismProj lv_prism_point_proj(const LvPrismPoint& p, f3 o, f3 P, f3 Q) {
+    const f3 C = p.centre - o;
+    LvPrismProj pj;
+    pj.X0 = lv_prism_dot(C, P); pj.Y0 = lv_prism_dot(C, Q);
+    pj.nP = lv_prism_dot(p.normal, P); pj.bP = lv_prism_dot(p.binormal, P);
+    pj.nQ = lv_prism_dot(p.normal, Q); pj.bQ = lv_prism_dot(p.binormal, Q);
+    return pj;
 }
-__device__ __forceinline__ void lv_prism_vertex_xy(const LvPrismPoint& p, float c, float s, float radius, f3 o, f3 P, f3 Q, float& x,
-                                                   float& y) {
-    lv_prism_project(lv_prism_pos(p, lv_prism_dir(p, c, s), radius), o, P, Q, x, y);
+__device__ __forceinline__ void lv_prism_vertex_xy(const LvPrismProj& pj, float c, float s, float radius, float& x, float& y) {
+    const float u = __builtin_fmaf(pj.bP, s, pj.nP * c), v = __builtin_fmaf(pj.bQ, s, pj.nQ * c);
+    x = __builtin_fmaf(radius, u, pj.X0);
+    y = __builtin_fmaf(radius, v, pj.Y0);
 }
 
 // triangle tt < 2 N of a segment's prism: (ring 0 = first point / 1 = second point, circle index) of its three vertices
@@ -82,35 +96,48 @@ __device__ __forceinline__ bool lv_prism_own_box(f3 o, f3 d, f3 p0, f3 p1, float
     return tn <= tf && depth >= tn - slack && depth <= tf + slack;
 }
 
-// one triangle of one segment as the fragment stage sees it
+// one triangle of one segment as the fragment stage sees it.  `ring`: cos at [k], sin at [LV_PRISM_MAX_SUBDIV + k] (the kernel's LDS
+// copy of LvPrismDev's table: triangle indices are per-lane values)
 struct LvPrismTri {
     f3 pos[3], dir[3], tan[3];
-    float attr[3];
+    float attr[3], c[3], s[3];
     uint32_t id[3];
+    bool second[3];   // vertex belongs to the segment's second point
 };
-__device__ __forceinline__ LvPrismTri lv_prism_tri_setup(const LvPrismDev& R, const LvPrismPoint pt[2], const uint32_t pi[2],
+__device__ __forceinline__ LvPrismTri lv_prism_tri_setup(const float* ringTab, uint32_t N, const LvPrismPoint pt[2], const uint32_t pi[2],
                                                          float radius, uint32_t tt) {
     uint32_t ring[3], circ[3];
-    lv_prism_triangle(tt, R.n, ring, circ);
+    lv_prism_triangle(tt, N, ring, circ);
     LvPrismTri T;
 #pragma unroll
     for (int i = 0; i < 3; i++) {
         const LvPrismPoint& p = ring[i] ? pt[1] : pt[0];
-        T.dir[i] = lv_prism_dir(p, R.c[circ[i]], R.s[circ[i]]);
+        T.c[i] = ringTab[circ[i]];
+        T.s[i] = ringTab[LV_PRISM_MAX_SUBDIV + circ[i]];
+        T.dir[i] = lv_prism_dir(p, T.c[i], T.s[i]);
         T.pos[i] = lv_prism_pos(p, T.dir[i], radius);
         T.tan[i] = p.tangent;
         T.attr[i] = p.attr;
-        T.id[i] = (ring[i] ? pi[1] : pi[0]) * R.n + circ[i];
+        T.id[i] = (ring[i] ? pi[1] : pi[0]) * N + circ[i];
+        T.second[i] = ring[i] != 0u;
     }
     return T;
 }
 // edge functions of a triangle for the ray (o, D) (any length); returns the coverage decision
-__device__ __forceinline__ bool lv_prism_tri_edges(const LvPrismDev& R, const LvPrismTri& T, f3 o, f3 D, float e[3]) {
+__device__ __forceinline__ bool lv_prism_tri_edges(const LvPrismDev& R, const LvPrismPoint pt[2], const LvPrismTri& T, float radius, f3 o,
+                                                   f3 D, float e[3]) {
     f3 P, Q;
     lv_prism_basis(R, D, P, Q);
+    const LvPrismProj pj0 = lv_prism_point_proj(pt[0], o, P, Q), pj1 = lv_prism_point_proj(pt[1], o, P, Q);
     float x[3], y[3];
 #pragma unroll
-    for (int i = 0; i < 3; i++) lv_prism_project(T.pos[i], o, P, Q, x[i], y[i]);
+    for (int i = 0; i < 3; i++) {
+        float x0, y0, x1, y1;
+        lv_prism_vertex_xy(pj0, T.c[i], T.s[i], radius, x0, y0);
+        lv_prism_vertex_xy(pj1, T.c[i], T.s[i], radius, x1, y1);
+        x[i] = T.second[i] ? x1 : x0;
+        y[i] = T.second[i] ? y1 : y0;
+    }
     e[0] = lv_prism_edge(x[1], y[1], x[2], y[2]);
     e[1] = lv_prism_edge(x[2], y[2], x[0], y[0]);
     e[2] = lv_prism_edge(x[0], y[0], x[1], y[1]);
@@ -124,46 +151,46 @@ __device__ __forceinline__ void lv_prism_weights(const float e[3], float b[3]) {
 }
 __device__ __forceinline__ f3 lv_prism_mix3(const float b[3], f3 a0, f3 a1, f3 a2) { return (b[0] * a0 + b[1] * a1) + b[2] * a2; }
 
-// Acceptance of a covered triangle: depth in [tLo, tHi), own-box rule, depth clipping.  Recomputes the triangle (same operations
-// as the coverage pass -> same bits).
-__device__ __forceinline__ bool lv_prism_accept(const LvPrismDev& R, const LvPrismPoint pt[2], const uint32_t pi[2], float radius,
-                                                uint32_t tt, f3 o, f3 d, float tLo, float tHi) {
-    const LvPrismTri T = lv_prism_tri_setup(R, pt, pi, radius, tt);
-    float e[3], b[3];
-    if (!lv_prism_tri_edges(R, T, o, d, e)) return false; // (always true here: the coverage pass said so)
-    lv_prism_weights(e, b);
-    const f3 pos = lv_prism_mix3(b, T.pos[0], T.pos[1], T.pos[2]);
-    const float depth = len3(pos - o);
+// Acceptance of a covered triangle's fragment (evaluated by the shading stage, which has the interpolated position anyway): depth in
+// the ray's interval [tLo, tHi), own-box rule, depth clipping.
+__device__ __forceinline__ bool lv_prism_accept(const LvPrismDev& R, const LvPrismPoint pt[2], float radius, f3 o, f3 d, f3 pos,
+                                                float depth, float tLo, float tHi) {
     if (!(depth >= tLo && depth < tHi)) return false;
     if (!lv_prism_own_box(o, d, pt[0].centre, pt[1].centre, radius, depth)) return false;
     const float vz = ((R.viewZ[0] * pos.x + R.viewZ[1] * pos.y) + R.viewZ[2] * pos.z) + R.viewZ[3] * 1.0f;
     return -vz >= R.nearDist && -vz <= R.farDist;
 }
 
-// One (viewing ray, segment) test: bit tt of the result = triangle tt of the segment's prism yields a fragment for this ray.
+// Stage A of a (viewing ray, segment) test: conservative pre-tests of the capsule that contains the prism (they may only say
+// "cannot hit"); 32 B per candidate.  Only candidates that pass are queued for the coverage test.
+__device__ __forceinline__ bool lv_prism_pretest(const LvSceneDev& S, float radius, uint32_t leaf, f3 o, f3 d) {
+    const float4 pa = S.segs[2 * size_t(leaf)], pb = S.segs[2 * size_t(leaf) + 1];
+    return lv_capsule_may_hit_axis(o, d, mk3(pa.x, pa.y, pa.z), mk3(pb.x, pb.y, pb.z), radius) &&
+           lv_capsule_may_hit_sphere(o, d, mk3(pa.x, pa.y, pa.z), mk3(pb.x, pb.y, pb.z), radius);
+}
+
+// Stage B: coverage of the pixel by the 2 N triangles of the segment's prism -- bit tt of the result = triangle tt covers the
+// pixel (front face, fill rule); whether its fragment is kept (ray interval, own box, depth clipping) is decided where it is shaded.
 // NT > 0: N = NT known at compile time (ring in registers, everything unrolled); NT == 0: any N <= LV_PRISM_MAX_SUBDIV.
 template <int NT>
-__device__ __forceinline__ unsigned lv_prism_test(const LvSceneDev& S, float radius, uint32_t leaf, f3 o, f3 d, float tLo, float tHi) {
+__device__ __forceinline__ unsigned lv_prism_coverage(const LvSceneDev& S, float radius, uint32_t leaf, f3 o, f3 d) {
     const LvPrismDev& R = S.prism;
-    const uint32_t seg = S.leafSeg[leaf];
-    const uint32_t pi[2] = {S.segIdx[2 * seg], S.segIdx[2 * seg + 1]};
+    const float4 pa = S.segs[2 * size_t(leaf)], pb = S.segs[2 * size_t(leaf) + 1];
+    uint32_t pi[2];
     LvPrismPoint pt[2];
-    pt[0] = lv_prism_point(S.points, pi[0]);
-    pt[1] = lv_prism_point(S.points, pi[1]);
-    // conservative pre-tests of the capsule that contains the prism (they may only say "cannot hit")
-    if (!lv_capsule_may_hit_axis(o, d, pt[0].centre, pt[1].centre, radius)) return 0u;
-    if (!lv_capsule_may_hit_sphere(o, d, pt[0].centre, pt[1].centre, radius)) return 0u;
+    lv_prism_frames(S, leaf, pa, pb, pt, pi);
     f3 P, Q;
     lv_prism_basis(R, d, P, Q);
     const uint32_t N = NT > 0 ? uint32_t(NT) : R.n;
     const bool a01 = pi[0] < pi[1];       // point ids of the usual segment (i, i + 1)
+    const LvPrismProj pj0 = lv_prism_point_proj(pt[0], o, P, Q), pj1 = lv_prism_point_proj(pt[1], o, P, Q);
     unsigned mask = 0u;
     if (NT > 0) {
         float cx[NT > 0 ? NT : 1], cy[NT > 0 ? NT : 1], nx[NT > 0 ? NT : 1], ny[NT > 0 ? NT : 1], L[NT > 0 ? NT : 1];
 #pragma unroll
         for (int k = 0; k < NT; k++) {
-            lv_prism_vertex_xy(pt[0], R.c[k], R.s[k], radius, o, P, Q, cx[k], cy[k]);
-            lv_prism_vertex_xy(pt[1], R.c[k], R.s[k], radius, o, P, Q, nx[k], ny[k]);
+            lv_prism_vertex_xy(pj0, R.c[k], R.s[k], radius, cx[k], cy[k]);
+            lv_prism_vertex_xy(pj1, R.c[k], R.s[k], radius, nx[k], ny[k]);
             L[k] = lv_prism_edge(nx[k], ny[k], cx[k], cy[k]);           // E(n_k, c_k)
         }
 #pragma unroll
@@ -189,10 +216,10 @@ __device__ __forceinline__ unsigned lv_prism_test(const LvSceneDev& S, float rad
         for (uint32_t k = 0; k < N; k++) {
             const uint32_t kn = (k + 1u == N) ? 0u : k + 1u;
             float cxk, cyk, cxn, cyn, nxk, nyk, nxn, nyn;
-            lv_prism_vertex_xy(pt[0], R.c[k], R.s[k], radius, o, P, Q, cxk, cyk);
-            lv_prism_vertex_xy(pt[0], R.c[kn], R.s[kn], radius, o, P, Q, cxn, cyn);
-            lv_prism_vertex_xy(pt[1], R.c[k], R.s[k], radius, o, P, Q, nxk, nyk);
-            lv_prism_vertex_xy(pt[1], R.c[kn], R.s[kn], radius, o, P, Q, nxn, nyn);
+            lv_prism_vertex_xy(pj0, R.c[k], R.s[k], radius, cxk, cyk);
+            lv_prism_vertex_xy(pj0, R.c[kn], R.s[kn], radius, cxn, cyn);
+            lv_prism_vertex_xy(pj1, R.c[k], R.s[k], radius, nxk, nyk);
+            lv_prism_vertex_xy(pj1, R.c[kn], R.s[kn], radius, nxn, nyn);
             const float Lk = lv_prism_edge(nxk, nyk, cxk, cyk), Ln = lv_prism_edge(nxn, nyn, cxn, cyn);
             const float D = lv_prism_edge(cxn, cyn, nxk, nyk);
             const float R0 = lv_prism_edge(cxk, cyk, cxn, cyn);
@@ -209,14 +236,7 @@ __device__ __forceinline__ unsigned lv_prism_test(const LvSceneDev& S, float rad
             }
         }
     }
-    // acceptance of the covered triangles (usually one)
-    unsigned out = 0u;
-    while (mask) {
-        const uint32_t tt = uint32_t(__ffs(int(mask))) - 1u;
-        mask &= mask - 1u;
-        if (lv_prism_accept(R, pt, pi, radius, tt, o, d, tLo, tHi)) out |= 1u << tt;
-    }
-    return out;
+    return mask;
 }
 
 // the raster shader's ribbonPosition of interpolated inputs (no bands, no caps), LinePassGeometryShaderTubes.glsl:771-777,944-963
@@ -232,9 +252,29 @@ __device__ __forceinline__ float lv_prism_ribbon(f3 cam, f3 fragPos, f3 fragment
     return clampf(ribbonPosition, -1.0f, 1.0f);
 }
 
-// interpolated inputs of the fragment stage for the ray (o, D): weights of D in the triangle's planes (helper invocations: outside)
+// Perspective-correct weights of a ray direction in a triangle seen from o (oracle: prismPlanes / prismRayWeights): e_i = det[V_j - o,
+// V_k - o, ray direction] in the coordinates of the pixel's own ray basis (P, Q, d), where the triangle's X, Y are small and the
+// 2 x 2 minors c_i = (X, Y, Z)_j x (X, Y, Z)_k stay well conditioned; computed once per triangle, then six fused dot products per ray
+// -- the fragment's own ray and its two helper lanes.
+struct LvPrismPlanes { f3 P, Q, D, c0, c1, c2; };
+__device__ __forceinline__ LvPrismPlanes lv_prism_planes(const LvPrismDev& R, const LvPrismTri& T, f3 o, f3 d) {
+    LvPrismPlanes pl;
+    lv_prism_basis(R, d, pl.P, pl.Q);
+    pl.D = d;
+    f3 v[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const f3 A = T.pos[i] - o;
+        v[i] = mk3(lv_prism_dot(A, pl.P), lv_prism_dot(A, pl.Q), lv_prism_dot(A, d));
+    }
+    pl.c0 = cross3(v[1], v[2]); pl.c1 = cross3(v[2], v[0]); pl.c2 = cross3(v[0], v[1]);
+    return pl;
+}
+// interpolated inputs of the fragment stage for the ray direction D (helper invocations: weights outside [0, 1])
 struct LvPrismInputs { f3 pos, nrm, tan; float attr; };
-__device__ __forceinline__ LvPrismInputs lv_prism_interpolate(const LvPrismTri& T, const f3 nrm[3], const float e[3]) {
+__device__ __forceinline__ LvPrismInputs lv_prism_interpolate(const LvPrismTri& T, const f3 nrm[3], const LvPrismPlanes& pl, f3 Dr) {
+    const f3 abg = mk3(lv_prism_dot(Dr, pl.P), lv_prism_dot(Dr, pl.Q), lv_prism_dot(Dr, pl.D));
+    const float e[3] = {lv_prism_dot(abg, pl.c0), lv_prism_dot(abg, pl.c1), lv_prism_dot(abg, pl.c2)};
     float b[3];
     lv_prism_weights(e, b);
     LvPrismInputs I;

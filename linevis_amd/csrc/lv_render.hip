@@ -828,10 +828,11 @@ __global__ __launch_bounds__(LV_BLOCK) void k_fill_f32(float* p, float v, size_t
 // over numSlices workgroups.  A slice accepts t in [lo, hi) (the last one up to tMax inclusive), so every fragment is
 // produced exactly once; each workgroup builds partial lists in LDS and splices them into the pixel's global list.
 template <bool STATS, int PRIM = LV_PRIM_CAPSULE, int BANDS = LV_SHADE_PLAIN>
-__global__ __launch_bounds__(LV_BLOCK, LV_GATHER_MIN_WAVES) void k_ppll_gather(const LvUniforms U, const LvSceneDev S, const LvTiles T,
+__global__ __launch_bounds__(LV_BLOCK, PRIM == LV_PRIM_PRISM ? LV_PRISM_MIN_WAVES : LV_GATHER_MIN_WAVES) void k_ppll_gather(const LvUniforms U, const LvSceneDev S, const LvTiles T,
                                                           uint32_t* __restrict__ nodes, uint32_t* __restrict__ startOffset,
                                                           uint32_t* __restrict__ fragCount, LvDevCounters* dc,
-                                                          uint32_t numSlices, uint32_t poolSlots) {
+                                                          uint32_t numSlices, uint32_t poolSlots, uint2* __restrict__ prismRecords,
+                                                          uint32_t prismRegionCap, uint32_t* __restrict__ prismRegions) {
     __shared__ unsigned s_stack[LV_STACK_LDS * LV_BLOCK];
     __shared__ uint32_t s_head[LV_BLOCK];  // head of this workgroup's partial list of every thread's pixel
     __shared__ uint32_t s_tail[LV_BLOCK];  // its first inserted node (whose `next` is patched when splicing)
@@ -841,9 +842,11 @@ __global__ __launch_bounds__(LV_BLOCK, LV_GATHER_MIN_WAVES) void k_ppll_gather(c
     LV_COOP_MEM(cm);
     LV_HITQ_SHARED(LV_BLOCK / LV_WAVE);
     LV_HITQ_MEM(hq);
+    __shared__ unsigned s_prismQueue[PRIM == LV_PRIM_PRISM ? LV_BLOCK / LV_WAVE : 1][PRIM == LV_PRIM_PRISM ? LV_HITQ_CAP : 1];
     LvPixel px;
     const uint32_t slice = blockIdx.x % numSlices;
     if (!lv_block_pixel(U, T, px, blockIdx.x / numSlices)) return;
+    if (PRIM == LV_PRIM_PRISM) hq.prismQueue = s_prismQueue[threadIdx.x >> 6];
     const unsigned long long tg0 = lv_group_clock();
     LvCounters cnt = {0, 0, 0, 0};
     // (the slices of a pixel are ONE ray: lv_trace_all counts a ray per active call, corrected below)
@@ -876,6 +879,7 @@ __global__ __launch_bounds__(LV_BLOCK, LV_GATHER_MIN_WAVES) void k_ppll_gather(c
         if (slice + 1u < numSlices) hi = tn + w * float(slice + 1u);
     }
     const bool active = px.inView && lo < hi;
+    unsigned prismSeq = blockIdx.x * (LV_BLOCK / LV_WAVE) + (threadIdx.x >> 6); // region rotation of this wave's record batches
     if (STATS && active && slice != 0u && S.numSegs != 0) cnt.rays--;
     // Fragments of a pixel are produced by whichever lane is handed the (pixel, segment) hit: the lane shades with the
     // owner's ray + AO texel and links the node with an LDS atomic exchange on the owner's list head (the reference's
@@ -885,15 +889,35 @@ __global__ __launch_bounds__(LV_BLOCK, LV_GATHER_MIN_WAVES) void k_ppll_gather(c
     lv_trace_all<STATS, false, PRIM>(S, U.radius, U.useCappedTubes != 0, active, o, d, lo, hi, aoTexel,
                         __uint_as_float(px.x | (px.y << 16)), lv_stack_mem(s_stack, S.stackOverflow), cm, hq, cnt,
                         [&](unsigned owner, uint32_t leaf, float t, int kind, f3 ro, f3 rd, float ownerAo, float ownerPixel) {
+        if (PRIM == LV_PRIM_PRISM) {
+            // The rasterised prism: this kernel is the RASTERISER -- it finds which triangles cover which pixels -- and hands the
+            // covered (pixel, segment, triangle) records to the fragment stage k_ppll_shade_prism through HBM (8 B per fragment):
+            // a wave in front of the dense core covers two orders of magnitude more fragments than the average wave, and with the
+            // fragment stage (~2000 instructions) inline its serial shade batches WERE the kernel's duration (0.75 of 1.3 ms); as a
+            // stream of records the fragments are shaded one per lane, evenly over the whole GPU.
+            // The stream is cut into LV_PRISM_REGIONS regions with a counter each, and every batch of <= 64 records goes to the
+            // next region in turn: appends to ONE counter run at ~13 ns apiece on this GPU whichever wave issues them (70 k batches
+            // = 0.9 ms of a 1 ms kernel, measured); spread over 64 cache lines they vanish, and the rotation fills the regions evenly
+            // however unevenly the fragments are spread over the picture.
+            const unsigned long long m = __ballot(1);
+            const unsigned ln = lv_lane();
+            const int leader = __ffsll((long long)m) - 1;
+            const unsigned region = (prismSeq++) & (LV_PRISM_REGIONS - 1u);
+            unsigned base = 0u;
+            if (int(ln) == leader) base = atomicAdd(&prismRegions[region * LV_PRISM_REGION_STRIDE], unsigned(__popcll(m)));
+            base = __shfl(base, leader, 64);
+            const unsigned idx = base + unsigned(__popcll(m & ((1ull << ln) - 1ull)));
+            if (idx < prismRegionCap)
+                prismRecords[size_t(region) * prismRegionCap + idx] = make_uint2(__float_as_uint(ownerPixel), leaf | (unsigned(kind) << 26));
+            return;
+        }
         LvHit h; h.t = t; h.leaf = leaf; h.kind = kind; h.found = true;
         float hitT;
         const bool rasterApply = U.ppllRasterColour != 0u;
         const uint32_t pxy = __float_as_uint(ownerPixel);
         const LvRasterQuad rq = lv_make_raster_quad(U, pxy & 0xFFFFu, pxy >> 16);
-        f4 color;
-        if (PRIM == LV_PRIM_PRISM) color = lv_shade_prism(S, U, ownerAo, ro, rd, leaf, uint32_t(kind), rq, rasterApply, hitT);
-        else color = PRIM == LV_PRIM_ELLIPTIC ? lv_shade_hit_elliptic(S, U, ownerAo, ro, rd, h, hitT, true, rq, rasterApply)
-                                              : lv_shade_hit<BANDS>(S, U, ownerAo, ro, rd, h, hitT, true, rq, rasterApply);
+        f4 color = PRIM == LV_PRIM_ELLIPTIC ? lv_shade_hit_elliptic(S, U, ownerAo, ro, rd, h, hitT, true, rq, rasterApply)
+                                            : lv_shade_hit<BANDS>(S, U, ownerAo, ro, rd, h, hitT, true, rq, rasterApply);
         if (STATS) cnt.hits++;
         if (color.w < 0.001f) return; // gatherFragment: discard, LinkedListGather.glsl:34
         // wave-aggregated node allocation: slots come from a per-wave chunk; one global atomic per LV_PPLL_CHUNK fragments
@@ -953,10 +977,96 @@ __global__ __launch_bounds__(LV_BLOCK, LV_GATHER_MIN_WAVES) void k_ppll_gather(c
     if (STATS) lv_flush_counters(cnt, dc);
 }
 
+// Fragment stage of ppll_fragment_source = raster_prism: one lane per covered (pixel, segment, triangle) record of the coverage
+// kernel (k_ppll_gather<LV_PRIM_PRISM>), grid-stride over the record stream -- LinePassGeometryShaderTubes.glsl:732-1129 on the
+// perspective-correct inputs (lv_shade_prism) + gatherFragment (LinkedListGather.glsl:33-72): discard below alpha 0.001, node slot
+// from a wave-aggregated atomicAdd (one atomic per 64 fragments), atomicExchange on the pixel's list head, 12-B node.
+template <bool STATS>
+__global__ __launch_bounds__(LV_BLOCK, LV_PRISM_SHADE_MIN_WAVES) void k_ppll_shade_prism(const LvUniforms U, const LvSceneDev S,
+                                                                   const uint2* __restrict__ records, uint32_t regionCap,
+                                                                   uint32_t* __restrict__ regions, uint32_t* __restrict__ nodes,
+                                                                   uint32_t* __restrict__ startOffset, uint32_t* __restrict__ fragCount,
+                                                                   LvDevCounters* dc, uint32_t nodeRegionCap) {
+    __shared__ float s_prismRing[2 * LV_PRISM_MAX_SUBDIV];
+    if (threadIdx.x < LV_PRISM_MAX_SUBDIV) {   // ring table in LDS: the triangle a lane shades is a per-lane index
+        s_prismRing[threadIdx.x] = S.prism.c[threadIdx.x];
+        s_prismRing[LV_PRISM_MAX_SUBDIV + threadIdx.x] = S.prism.s[threadIdx.x];
+    }
+    __syncthreads();
+    // block b works through region b % R of the record stream together with the other blocks of that region (gridDim.x % R == 0)
+    const uint32_t region = blockIdx.x & (LV_PRISM_REGIONS - 1u);
+    const uint32_t numRecords = min(regions[region * LV_PRISM_REGION_STRIDE], regionCap);
+    const uint2* __restrict__ recs = records + size_t(region) * regionCap;
+    const uint32_t stride = (gridDim.x / LV_PRISM_REGIONS) * LV_BLOCK;
+    uint32_t* __restrict__ nodeCounters = regions + LV_PRISM_REGIONS * LV_PRISM_REGION_STRIDE;
+    const f3 o = mk3(U.camPos[0], U.camPos[1], U.camPos[2]);
+    const float tLo = 0.0001f, tHi = __uint_as_float(__float_as_uint(1000.0f) + 1u); // the gather's ray interval [tMin, tMax]
+    unsigned long long hits = 0;
+    uint32_t localMax = 0u, localSum = 0u;
+    unsigned seq = blockIdx.x * (LV_BLOCK / LV_WAVE) + (threadIdx.x >> 6);   // node-region rotation (as for the records)
+    for (uint32_t base = (blockIdx.x / LV_PRISM_REGIONS) * LV_BLOCK; base < numRecords; base += stride) {
+        const uint32_t i = base + threadIdx.x;
+        bool keep = false;
+        uint32_t px = 0u, py = 0u, packed = 0u;
+        float depth = 0.0f;
+        if (i < numRecords) {
+            const uint2 r = recs[i];
+            px = r.x & 0xFFFFu; py = r.x >> 16;
+            const uint32_t leaf = r.y & 0x03FFFFFFu, tt = r.y >> 26;
+            const float aoTexel = U.useAmbientOcclusion ? S.ao[size_t(py) * U.width + px] : 1.0f;
+            f3 oo, d;
+            lv_primary_ray(U, px, py, 0.5f, 0.5f, oo, d);
+            const LvRasterQuad rq = lv_make_raster_quad(U, px, py);
+            bool kept;
+            const f4 color = lv_shade_prism(S, U, s_prismRing, aoTexel, o, d, tLo, tHi, leaf, tt, rq, U.ppllRasterColour != 0u, depth, kept);
+            if (kept) {
+                if (STATS) hits++;
+                keep = color.w >= 0.001f;   // gatherFragment: discard, LinkedListGather.glsl:34
+                packed = lv_pack_unorm4x8(color);
+            }
+        }
+        const unsigned long long m = __ballot(keep);
+        if (m) {
+            const unsigned lane = lv_lane();
+            const int leader = __ffsll((long long)m) - 1;
+            const unsigned nodeRegion = (seq++) & (LV_PRISM_REGIONS - 1u);
+            unsigned slot = 0u;
+            if (int(lane) == leader) slot = atomicAdd(&nodeCounters[nodeRegion * LV_PRISM_REGION_STRIDE], unsigned(__popcll(m)));
+            slot = __shfl(slot, leader, 64);
+            if (keep) {
+                const uint32_t local = slot + unsigned(__popcll(m & ((1ull << lane) - 1ull)));
+                const uint32_t addr = lv_ppll_addr(px, py, U.ppllPaddedW, U.ppllTileW, U.ppllTileH);
+                localMax = max(localMax, atomicAdd(&fragCount[addr], 1u) + 1u);
+                localSum++;
+                if (local < nodeRegionCap) {
+                    const uint32_t insertIndex = nodeRegion * nodeRegionCap + local;
+                    const uint32_t next = atomicExch(&startOffset[addr], insertIndex);
+                    nodes[3 * size_t(insertIndex) + 0] = packed;
+                    nodes[3 * size_t(insertIndex) + 1] = __float_as_uint(depth);
+                    nodes[3 * size_t(insertIndex) + 2] = next;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int ofs = 32; ofs > 0; ofs >>= 1) {
+        localMax = max(localMax, (uint32_t)__shfl_xor(localMax, ofs, 64));
+        localSum += (uint32_t)__shfl_xor(localSum, ofs, 64);
+    }
+    if (lv_lane() == 0 && localMax > 0u) atomicMax(&dc->maxDepthComplexity, localMax);
+    if (lv_lane() == 0 && localSum > 0u) atomicAdd(&dc->fragCounter, localSum); // fragCounter of the reference: every fragment counts
+    if (blockIdx.x == 0 && threadIdx.x == 0) dc->fragAlloc = LV_PRISM_REGIONS * nodeRegionCap; // (lv_ppll_get_buffers: the whole pool)
+    if (STATS) {
+        hits = lv_wave_sum_u64(hits);
+        if (lv_lane() == 0 && hits) atomicAdd(&dc->hits, hits);
+    }
+}
+
 // clear(): LinkedListClear.glsl:46-55 (start offsets = -1) + fragmentCounterBuffer->fill(0), and the per-pixel fragment counts
 __global__ __launch_bounds__(LV_BLOCK) void k_ppll_clear(uint4* __restrict__ startOffset, uint4* __restrict__ fragCount, size_t n4,
-                                                         LvDevCounters* dc) {
+                                                         LvDevCounters* dc, uint32_t* __restrict__ prismRegions) {
     const size_t i = size_t(blockIdx.x) * LV_BLOCK + threadIdx.x;
+    if (prismRegions && i < 2u * LV_PRISM_REGIONS * LV_PRISM_REGION_STRIDE) prismRegions[i] = 0u;
     if (i < n4) {
         startOffset[i] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
         fragCount[i] = make_uint4(0u, 0u, 0u, 0u);
@@ -1301,6 +1411,7 @@ LvSceneDev sceneDev(const lv_ctx* ctx) {
     S.nodes = (const float4*)ctx->nodes.ptr;
     S.segs = (const float4*)ctx->segs.ptr;
     S.segAxis = (const float4*)ctx->segAxis.ptr;
+    S.prismFrames = (const float4*)ctx->prismFrames.ptr;
     S.leafSeg = (const uint32_t*)ctx->leafSeg.ptr;
     S.segToLeaf = (const uint32_t*)ctx->segToLeaf.ptr;
     S.points = (const lv_line_point*)ctx->points.ptr;
@@ -1972,13 +2083,20 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
         }
     } else {
         // reallocateFragmentBuffer, PerPixelLinkedListLineRenderer.cpp:251-357
-        const uint32_t numSlices = LV_PPLL_SLICES;
+        // gather(): fragments of the rasterised programmable-pull prism (the reference's geometry, default) or capsule entry hits
+        const bool prismSource = lv_ppll_prism_source(ctx);
+        if (prismSource) lv_fill_prism(ctx, U, S.prism);
+        const uint32_t numSlices = prismSource ? 1u : LV_PPLL_SLICES; // (the prism's coverage kernel has no depth: one slice)
         if (uint64_t(gridTiles) * numSlices > 0x7FFFFFF0ull) return lv_fail(ctx, LV_E_INVALID, "tile list too large");
         // physical pool = the reference's linkedListSize + the tail every wave of the gather may leave unused in its last
         // chunk of node slots (k_ppll_gather), so that the effective capacity is never below the reference's
+        // (raster_prism: node slots are handed out from LV_PRISM_REGIONS sub-pools in turn -- the slack covers the < 64 slots a sub-pool
+        // may leave unused when it runs full)
         uint64_t poolSlots64 = uint64_t(U.ppllLinkedListSize) +
-                               uint64_t(gridTiles) * numSlices * (LV_BLOCK / LV_WAVE) * LV_PPLL_CHUNK;
+                               uint64_t(gridTiles) * numSlices * (LV_BLOCK / LV_WAVE) * LV_PPLL_CHUNK +
+                               (prismSource ? uint64_t(LV_PRISM_REGIONS) * 2u * LV_WAVE : 0u);
         if (poolSlots64 > 0xFFFFFFF0ull) poolSlots64 = 0xFFFFFFF0ull; // node indices are 32 bit
+        if (prismSource) poolSlots64 -= poolSlots64 % LV_PRISM_REGIONS;   // equal sub-pools
         const uint32_t poolSlots = uint32_t(poolSlots64);
         if ((rc = lv_buf_reserve(ctx, ctx->ppllNodes, size_t(poolSlots) * 12))) return rc;
         const size_t padded4 = (size_t(U.ppllPaddedW) * U.ppllPaddedH + 3) / 4; // cleared as whole uint4s (k_ppll_clear)
@@ -1988,16 +2106,27 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
         ctx->ppllPaddedW = U.ppllPaddedW;
         ctx->ppllPaddedH = U.ppllPaddedH;
         // clear(): LinkedListClear.glsl:46-55 + fragmentCounterBuffer->fill(0)
-        k_ppll_clear<<<uint32_t((padded4 + LV_BLOCK - 1) / LV_BLOCK), LV_BLOCK, 0, st>>>((uint4*)ctx->ppllStart.ptr,
-                                                                                         (uint4*)ctx->ppllCount.ptr, padded4, dc);
+        if (prismSource && (rc = lv_buf_reserve(ctx, ctx->prismRegions, size_t(2) * LV_PRISM_REGIONS * LV_PRISM_REGION_STRIDE * 4))) return rc;
+        {
+            const size_t clearThreads = std::max<size_t>(padded4, prismSource ? 2u * LV_PRISM_REGIONS * LV_PRISM_REGION_STRIDE : 0u);
+            k_ppll_clear<<<uint32_t((clearThreads + LV_BLOCK - 1) / LV_BLOCK), LV_BLOCK, 0, st>>>(
+                    (uint4*)ctx->ppllStart.ptr, (uint4*)ctx->ppllCount.ptr, padded4, dc, prismSource ? (uint32_t*)ctx->prismRegions.ptr : nullptr);
+        }
         LV_HIP(ctx, hipEventRecord(ctx->ev[11], st));
-        // gather(): fragments of the rasterised programmable-pull prism (the reference's geometry, default) or capsule entry hits
-        const bool prismSource = lv_ppll_prism_source(ctx);
-        if (prismSource) lv_fill_prism(ctx, U, S.prism);
+        // raster_prism: the coverage kernel streams (pixel, segment, triangle) records to the fragment stage; room for twice the
+        // node pool (records whose fragment the shader discards take no node)
+        uint32_t prismRegionCap = 0u;
+        if (prismSource) {
+            uint64_t cap64 = 2ull * poolSlots64;
+            if (cap64 > 0xFFFFFFF0ull) cap64 = 0xFFFFFFF0ull;
+            prismRegionCap = uint32_t(cap64 / LV_PRISM_REGIONS);
+            if ((rc = lv_buf_reserve(ctx, ctx->prismRecords, size_t(prismRegionCap) * LV_PRISM_REGIONS * 8))) return rc;
+        }
 #define LV_LAUNCH_GATHER(ST, PR, BA)                                                                             \
     LV_TIMED_LAUNCH(ctx, LV_KERNEL_PPLL_GATHER, (k_ppll_gather<ST, PR, BA><<<gridTiles * numSlices, LV_BLOCK, 0, st>>>( \
             U, S, T, (uint32_t*)ctx->ppllNodes.ptr, (uint32_t*)ctx->ppllStart.ptr,                              \
-            (uint32_t*)ctx->ppllCount.ptr, dc, numSlices, poolSlots)))
+            (uint32_t*)ctx->ppllCount.ptr, dc, numSlices, poolSlots, (uint2*)ctx->prismRecords.ptr, prismRegionCap,        \
+            (uint32_t*)ctx->prismRegions.ptr)))
 #define LV_LAUNCH_GATHER2(ST)                                                          \
     do {                                                                               \
         if (prismSource) LV_LAUNCH_GATHER(ST, LV_PRIM_PRISM, LV_SHADE_PLAIN);          \
@@ -2009,6 +2138,17 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
         if (stats) LV_LAUNCH_GATHER2(true); else LV_LAUNCH_GATHER2(false);
 #undef LV_LAUNCH_GATHER2
 #undef LV_LAUNCH_GATHER
+        if (prismSource) {
+            uint32_t shadeGrid = uint32_t(ctx->numCUs) * LV_PRISM_SHADE_BLOCKS_PER_CU;
+            shadeGrid = std::max(shadeGrid - shadeGrid % LV_PRISM_REGIONS, (uint32_t)LV_PRISM_REGIONS); // a whole number of blocks per region
+#define LV_LAUNCH_SHADE(ST)                                                                                                     \
+    LV_TIMED_LAUNCH(ctx, LV_KERNEL_PPLL_SHADE, (k_ppll_shade_prism<ST><<<shadeGrid, LV_BLOCK, 0, st>>>(                         \
+            U, S, (const uint2*)ctx->prismRecords.ptr, prismRegionCap, (uint32_t*)ctx->prismRegions.ptr,                        \
+            (uint32_t*)ctx->ppllNodes.ptr, (uint32_t*)ctx->ppllStart.ptr, (uint32_t*)ctx->ppllCount.ptr, dc,                   \
+            poolSlots / LV_PRISM_REGIONS)))
+            if (stats) LV_LAUNCH_SHADE(true); else LV_LAUNCH_SHADE(false);
+#undef LV_LAUNCH_SHADE
+        }
         LV_HIP(ctx, hipEventRecord(ctx->ev[13], st));
         // resolve()
         const uint32_t gx = (tileW + 7u) / 8u, gy = (tileH + 7u) / 8u;

@@ -648,6 +648,8 @@ struct LvHitQueue {
     unsigned* ref;   // (owner lane << 26) | leaf
     float* t;
     unsigned* kind;
+    const float* prismRing; // LV_PRIM_PRISM: the workgroup's LDS copy of the ring table (cos [k], sin [LV_PRISM_MAX_SUBDIV + k])
+    unsigned* prismQueue;   // LV_PRIM_PRISM: [LV_HITQ_CAP] candidates that passed the pre-test and wait for the coverage test
 };
 #define LV_HITQ_SHARED(NWAVES)                                \
     __shared__ unsigned s_hitRef[(NWAVES)][LV_HITQ_CAP];      \
@@ -657,7 +659,9 @@ struct LvHitQueue {
     LvHitQueue hq;                                            \
     hq.ref = s_hitRef[threadIdx.x >> 6];                      \
     hq.t = s_hitT[threadIdx.x >> 6];                          \
-    hq.kind = s_hitKind[threadIdx.x >> 6]
+    hq.kind = s_hitKind[threadIdx.x >> 6];                    \
+    hq.prismRing = nullptr;                                   \
+    hq.prismQueue = nullptr
 
 // Closest hit with reportIntersectionEXT semantics (accepted iff tMin <= t <= tMax; ties -> lowest original segment
 // index), computed by the whole wave together: EVERY lane of the wave must call this function in convergent control
@@ -854,6 +858,33 @@ __device__ __forceinline__ void lv_trace_all(const LvSceneDev& S, float radius, 
             tMax = cm.ray[2 * owner + 1].w;
         }
     };
+    // the rasterised prism, stage B: coverage masks of nB (<= 64) pre-tested candidates; the covered triangles are queued as hits one
+    // per lane and round (usually one round), kind = the triangle of the segment's prism; stage C (fragment stage) = shadeBatch
+    unsigned pHead = 0, pTail = 0;
+    auto prismStageB = [&](unsigned nB) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        unsigned ref = 0u, mask = 0u;
+        if (lane < nB) {
+            ref = hq.prismQueue[(pHead + lane) % LV_HITQ_CAP];
+            const unsigned ow = ref >> 26, leaf = ref & 0x03FFFFFFu;
+            const float4 ro = cm.ray[2 * ow], rd = cm.ray[2 * ow + 1];
+            mask = S.prism.n == 6u ? lv_prism_coverage<6>(S, radius, leaf, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z))
+                                   : lv_prism_coverage<0>(S, radius, leaf, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z));
+        }
+        pHead += nB;
+        while (__ballot(mask != 0u)) {
+            const bool hit = mask != 0u;
+            unsigned tri = 0u;
+            if (hit) { tri = unsigned(__ffs(int(mask))) - 1u; mask &= mask - 1u; }
+            const unsigned long long mH = __ballot(hit);
+            if (hit) {
+                const unsigned i = (hTail + unsigned(__popcll(mH & below))) % LV_HITQ_CAP;
+                hq.ref[i] = ref; hq.t[i] = 0.0f; hq.kind[i] = tri;
+            }
+            hTail += unsigned(__popcll(mH));
+            if (hTail - hHead >= LV_WAVE) shadeBatch(LV_WAVE);
+        }
+    };
     while (true) {
         const bool isLeaf = cur != LV_INVALID && (cur & LV_LEAF_BIT);
         const unsigned long long mL = __ballot(isLeaf);
@@ -871,29 +902,31 @@ __device__ __forceinline__ void lv_trace_all(const LvSceneDev& S, float radius, 
             const unsigned n = q < LV_WAVE ? q : LV_WAVE;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             // a leaf of the triangle LBVH holds S.triLeafSize triangles: one round of tests + hit queueing per slot (wave-uniform)
-            // the rasterised prism: one test per (ray, segment) yields a mask of covered triangles; they are queued one per lane
-            // and round (usually one round), kind = the triangle of the segment's prism
-            unsigned prismMask = 0u, prismRef = 0u;
-            if (PRIM == LV_PRIM_PRISM && lane < n) {
-                const unsigned e = cm.queue[(head + lane) % LV_QCAP];
-                const unsigned ow = e >> 26, leaf = e & 0x03FFFFFFu;
-                const float4 ro = cm.ray[2 * ow], rd = cm.ray[2 * ow + 1];
-                if (STATS) cnt.prims++;
-                prismRef = e;
-                prismMask = S.prism.n == 6u ? lv_prism_test<6>(S, radius, leaf, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), ro.w, rd.w)
-                                            : lv_prism_test<0>(S, radius, leaf, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), ro.w, rd.w);
+            if (PRIM == LV_PRIM_PRISM) {
+                // the rasterised prism (lv_prism.h), stage A: capsule pre-test of the candidates; the ones that pass wait in a second
+                // queue until 64 of them can take stage B at full width
+                bool pass = false;
+                unsigned e = 0u;
+                if (lane < n) {
+                    e = cm.queue[(head + lane) % LV_QCAP];
+                    const unsigned ow = e >> 26, leaf = e & 0x03FFFFFFu;
+                    const float4 ro = cm.ray[2 * ow], rd = cm.ray[2 * ow + 1];
+                    if (STATS) cnt.prims++;
+                    pass = lv_prism_pretest(S, radius, leaf, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z));
+                }
+                const unsigned long long mP = __ballot(pass);
+                if (pass) hq.prismQueue[(pTail + unsigned(__popcll(mP & below))) % LV_HITQ_CAP] = e;
+                pTail += unsigned(__popcll(mP));
+                head += n;
+                if (pTail - pHead >= LV_WAVE) prismStageB(LV_WAVE);
+                continue;
             }
             const unsigned nSub = PRIM == LV_PRIM_TRIANGLE ? S.triLeafSize : 1u;
-            for (unsigned sub = 0; PRIM == LV_PRIM_PRISM ? __ballot(prismMask != 0u) != 0ull : sub < nSub; sub++) {
+            for (unsigned sub = 0; sub < nSub; sub++) {
             bool hit = false;
             unsigned hitRef = 0, hitKind = 0;
             float hitT = 0.0f;
-            if (PRIM == LV_PRIM_PRISM) {
-                if (prismMask) {
-                    hit = true; hitRef = prismRef; hitKind = unsigned(__ffs(int(prismMask))) - 1u;
-                    prismMask &= prismMask - 1u;
-                }
-            } else if (lane < n) {
+            if (lane < n) {
                 const unsigned e = cm.queue[(head + lane) % LV_QCAP];
                 const unsigned ow = e >> 26, leaf = e & 0x03FFFFFFu;
                 const float4 ro = cm.ray[2 * ow], rd = cm.ray[2 * ow + 1];
@@ -988,6 +1021,7 @@ __device__ __forceinline__ void lv_trace_all(const LvSceneDev& S, float radius, 
             nNow = __popcll(__ballot(!(cur & LV_LEAF_BIT)));
         } while (tail - head < LV_TRACE_TEST_BATCH_ALL && nNow > HO_BUSY);
     }
+    if (PRIM == LV_PRIM_PRISM && pTail != pHead) prismStageB(pTail - pHead); // the rest (< 64)
     if (hTail != hHead) shadeBatch(hTail - hHead); // the rest (< 64)
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
@@ -1306,26 +1340,22 @@ __device__ __forceinline__ f4 lv_shade_hit(const LvSceneDev& S, const LvUniforms
 // LinePassGeometryShaderTubes.glsl:732-1129 on the perspective-correct inputs of triangle tt of the leaf's segment for the pixel's
 // viewing ray (o, d); fwidth(ribbonPosition) (:1079-1087) from the helper invocations of the 2 x 2 quad = the same triangle's
 // attribute planes at the quad partners' rays (LvRasterQuad).
-__device__ __forceinline__ f4 lv_shade_prism(const LvSceneDev& S, const LvUniforms& U, float aoTexel, f3 o, f3 d, uint32_t leaf,
-                                             uint32_t tt, const LvRasterQuad& rq, bool rasterApply, float& payloadHitT) {
+__device__ __forceinline__ f4 lv_shade_prism(const LvSceneDev& S, const LvUniforms& U, const float* ringTab, float aoTexel, f3 o, f3 d,
+                                             float tLo, float tHi, uint32_t leaf, uint32_t tt, const LvRasterQuad& rq, bool rasterApply,
+                                             float& payloadHitT, bool& kept) {
     const LvPrismDev& R = S.prism;
-    const uint32_t seg = S.leafSeg[leaf];
-    const uint32_t pi[2] = {S.segIdx[2 * seg], S.segIdx[2 * seg + 1]};
+    uint32_t pi[2];
     LvPrismPoint pt[2];
-    pt[0] = lv_prism_point(S.points, pi[0]);
-    pt[1] = lv_prism_point(S.points, pi[1]);
-    const LvPrismTri T = lv_prism_tri_setup(R, pt, pi, U.radius, tt);
+    lv_prism_frames(S, leaf, S.segs[2 * size_t(leaf)], S.segs[2 * size_t(leaf) + 1], pt, pi);
+    const LvPrismTri T = lv_prism_tri_setup(ringTab, R.n, pt, pi, U.radius, tt);
     f3 nrm[3];
 #pragma unroll
     for (int i = 0; i < 3; i++) nrm[i] = norm3s(T.dir[i]);   // vertexNormal = normalize(tangentFrameMatrix * localNormal), :177
-    float e[3];
-    lv_prism_tri_edges(R, T, o, d, e);
-    const LvPrismInputs I = lv_prism_interpolate(T, nrm, e);
     const f3 cam = mk3(U.camPos[0], U.camPos[1], U.camPos[2]);
-    float ex[3], ey[3];
-    lv_prism_tri_edges(R, T, cam, rq.dX, ex);
-    lv_prism_tri_edges(R, T, cam, rq.dY, ey);
-    const LvPrismInputs Ix = lv_prism_interpolate(T, nrm, ex), Iy = lv_prism_interpolate(T, nrm, ey);
+    const LvPrismPlanes pl = lv_prism_planes(R, T, cam, d);   // (o == cam: the pixel's viewing ray starts at the camera)
+    const LvPrismInputs I = lv_prism_interpolate(T, nrm, pl, d);
+    kept = lv_prism_accept(R, pt, U.radius, o, d, I.pos, len3(I.pos - o), tLo, tHi);
+    const LvPrismInputs Ix = lv_prism_interpolate(T, nrm, pl, rq.dX), Iy = lv_prism_interpolate(T, nrm, pl, rq.dY);
     const float f0 = lv_prism_ribbon(cam, I.pos, I.nrm, I.tan);
     const float fx = lv_prism_ribbon(cam, Ix.pos, Ix.nrm, Ix.tan);
     const float fy = lv_prism_ribbon(cam, Iy.pos, Iy.nrm, Iy.tan);

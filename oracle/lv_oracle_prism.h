@@ -25,7 +25,10 @@
 //   viewing ray      the pixel-centre ray (o, d) of the ray generator (TubeRayTracing.glsl:219-226: what gl_FragCoord = pixel + 0.5
 //                    unprojects to); basis P = cross(R, d), Q = cross(d, P) with R = the camera's right axis (column 0 of
 //                    inverse(viewMatrix)): P, Q, d are mutually orthogonal, so (A . P, A . Q) are -- up to positive factors -- the
-//                    coordinates of a vertex A - o in the plane perpendicular to the ray
+//                    coordinates of a vertex A - o in the plane perpendicular to the ray; for the ring vertex V = centre + r (normal cos
+//                    + binormal sin): x = fma(r, fma(binormal . P, sin, (normal . P) cos), (centre - o) . P), y likewise with Q (dot
+//                    products fused: prismDot) -- a pure function of (line point, circle index, ray), so both triangles at an edge
+//                    and both segments at a line point see the same bits
 //   edge function    E(U, V) = yU * xV - xU * yV of two projected vertices = -(d . (U x V)) up to a positive factor: the
 //                    homogeneous edge function of the projected edge (Olano & Greer 1997), evaluated WITHOUT contraction so that
 //                    E(V, U) = -E(U, V) holds bit for bit -- two triangles sharing an edge see exactly opposite values
@@ -34,8 +37,10 @@
 //                    iff gl_VertexIndex(U) < gl_VertexIndex(V) (the neighbour runs through it the other way, so exactly one of the two
 //                    owns it: the fill rule), and (e0 + e1) + e2 > 0.  All e >= 0 is at the same time "the ray passes through the
 //                    triangle in front of the camera" and "the triangle is front-facing" (det[V0 - o, V1 - o, V2 - o] < 0).
-//   interpolation    b_i = e_i * (1 / ((e0 + e1) + e2)) are the barycentric coordinates of the point where the ray meets the triangle's
-//                    plane = the perspective-correct weights of the rasteriser: attribute = (b0 a0 + b1 a1) + b2 a2
+//   interpolation    the barycentric coordinates of the point where a ray meets the triangle's plane = the perspective-correct weights
+//                    of the rasteriser: b_i = e_i * (1 / ((e0 + e1) + e2)) with e_i = det[V_j - o, V_k - o, ray direction] evaluated in the
+//                    own ray's basis (prismPlanes: three 2 x 2-minor vectors once per triangle, then six dot products per ray);
+//                    attribute = (b0 a0 + b1 a1) + b2 a2
 //   depth clipping   a fragment is kept iff nearDist <= -(viewMatrix * fragmentPositionWorld).z <= farDist (clip space 0 <= z <= w)
 //   own-box rule     and iff the ray meets the segment's box of TubeAabbRenderData (LineDataFlow.cpp:2223-2234) with the fragment
 //                    depth within r / |d| of the box interval: every ring vertex lies within r of its line point, so this only makes
@@ -79,10 +84,24 @@ inline PrismBasis prismBasis(const Frame& F, V3 d) {
     B.Q = cross(d, B.P);
     return B;
 }
-inline void prismProject(V3 pos, V3 o, const PrismBasis& B, float& x, float& y) {
-    const V3 A = pos - o;
-    x = fmaf(A.z, B.P.z, fmaf(A.y, B.P.y, A.x * B.P.x));
-    y = fmaf(A.z, B.Q.z, fmaf(A.y, B.Q.y, A.x * B.Q.x));
+inline float prismDot(V3 a, V3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
+// projection of a line point's frame into the ray's plane: the ring vertex V = centre + r (normal cos + binormal sin) has
+// (V - o) . P = (centre - o) . P + r ((normal . P) cos + (binormal . P) sin) -- six dot products per (ray, line point), then two
+// fused multiply-adds per coordinate of a ring vertex
+struct PrismProj { float X0, Y0, nP, bP, nQ, bQ; };
+inline PrismProj prismPointProj(const lvo_line_point& lp, V3 o, const PrismBasis& B) {
+    const V3 normal = ld3(lp.lineNormal), tangent = ld3(lp.lineTangent), C = ld3(lp.linePosition) - o;
+    const V3 binormal = cross(tangent, normal);
+    PrismProj pj;
+    pj.X0 = prismDot(C, B.P); pj.Y0 = prismDot(C, B.Q);
+    pj.nP = prismDot(normal, B.P); pj.bP = prismDot(binormal, B.P);
+    pj.nQ = prismDot(normal, B.Q); pj.bQ = prismDot(binormal, B.Q);
+    return pj;
+}
+inline void prismVertexXY(const PrismProj& pj, float c, float s, float radius, float& x, float& y) {
+    const float u = fmaf(pj.bP, s, pj.nP * c), v = fmaf(pj.bQ, s, pj.nQ * c);
+    x = fmaf(radius, u, pj.X0);
+    y = fmaf(radius, v, pj.Y0);
 }
 inline float prismEdge(float xU, float yU, float xV, float yV) { return yU * xV - xU * yV; }
 
@@ -142,6 +161,7 @@ struct PrismFrag {
     float b[3];
     V3 pos, nrm, tan;   // interpolated fragmentPositionWorld / fragmentNormal / fragmentTangent (not normalised)
     float attr, depth;
+    V3 d;               // direction of the pixel's viewing ray
 };
 
 // the shader's ribbonPosition of interpolated inputs (no bands, no caps), LinePassGeometryShaderTubes.glsl:771-777,944-963
@@ -157,14 +177,35 @@ inline float prismRibbon(V3 cam, V3 fragPos, V3 fragmentNormal, V3 fragmentTange
     return clampf(ribbonPosition, -1.0f, 1.0f);
 }
 // ribbonPosition a helper invocation computes: the triangle's attribute planes at the weights of the ray (o, D)
-inline float prismRibbonOfRay(const Frame& F, const PrismTri& T, V3 o, V3 D) {
-    const PrismBasis B = prismBasis(F, D);
-    float x[3], y[3], e[3], b[3];
-    for (int i = 0; i < 3; i++) prismProject(T.pos[i], o, B, x[i], y[i]);
-    e[0] = prismEdge(x[1], y[1], x[2], y[2]);
-    e[1] = prismEdge(x[2], y[2], x[0], y[0]);
-    e[2] = prismEdge(x[0], y[0], x[1], y[1]);
+// Perspective-correct weights of a ray direction Dr (any length) in a triangle seen from o: Dr = alpha A0 + beta A1 + gamma A2 with
+// A_i = V_i - o  =>  det[A_j, A_k, Dr] = weight_i det[A0, A1, A2], so b_i = e_i / (e0 + e1 + e2) with e_i = det[A_j, A_k, Dr].  Evaluated
+// in the coordinates of the PIXEL'S OWN ray basis (P, Q, d) -- (X, Y, Z) = (A . P, A . Q, A . d): X and Y are small (the triangle lies
+// on the ray) and the 2 x 2 minors stay well conditioned, whereas A_j x A_k in world coordinates is a cross product of two nearly
+// parallel unit-length vectors -- as  e_i = (a, b, g) . c_i  with c_i = (X, Y, Z)_j x (X, Y, Z)_k computed ONCE per triangle and
+// (a, b, g) = (Dr . P, Dr . Q, Dr . d): the fragment's own ray and its two helper lanes cost six fused dot products each.
+// (Coverage keeps the exactly antisymmetric edge functions above: the fill rule needs bit-exact agreement between neighbouring
+// triangles, the interpolation does not.)
+struct PrismPlanes { V3 P, Q, D; V3 c[3]; };
+inline PrismPlanes prismPlanes(const Frame& F, const PrismTri& T, V3 o, V3 d) {
+    const PrismBasis B = prismBasis(F, d);
+    PrismPlanes pl;
+    pl.P = B.P; pl.Q = B.Q; pl.D = d;
+    V3 v[3];
+    for (int i = 0; i < 3; i++) {
+        const V3 A = T.pos[i] - o;
+        v[i] = v3(prismDot(A, B.P), prismDot(A, B.Q), prismDot(A, d));
+    }
+    pl.c[0] = cross(v[1], v[2]); pl.c[1] = cross(v[2], v[0]); pl.c[2] = cross(v[0], v[1]);
+    return pl;
+}
+inline void prismRayWeights(const PrismPlanes& pl, V3 Dr, float b[3]) {
+    const V3 abg = v3(prismDot(Dr, pl.P), prismDot(Dr, pl.Q), prismDot(Dr, pl.D));
+    const float e[3] = {prismDot(abg, pl.c[0]), prismDot(abg, pl.c[1]), prismDot(abg, pl.c[2])};
     prismWeights(e, b);
+}
+inline float prismRibbonOfRay(const Frame& F, const PrismTri& T, const PrismPlanes& pl, V3 D) {
+    float b[3];
+    prismRayWeights(pl, D, b);
     return prismRibbon(F.cameraPosition, prismMix3(b, T.pos[0], T.pos[1], T.pos[2]), prismMix3(b, T.nrm[0], T.nrm[1], T.nrm[2]),
                        prismMix3(b, T.tan[0], T.tan[1], T.tan[2]));
 }
@@ -187,11 +228,10 @@ inline void prismSegmentFragments(const lvo_scene& sc, const lvo_params& P, cons
     const uint32_t N = R.n;
     const uint32_t pi[2] = {sc.segIdx[2 * seg], sc.segIdx[2 * seg + 1]};
     float vx[2][kPrismMaxSubdiv], vy[2][kPrismMaxSubdiv];
-    for (int r = 0; r < 2; r++)
-        for (uint32_t k = 0; k < N; k++) {
-            const PrismVtx v = prismVertex(sc.pts[pi[r]], R.c[k], R.s[k], F.radius);
-            prismProject(v.pos, o, B, vx[r][k], vy[r][k]);
-        }
+    for (int r = 0; r < 2; r++) {
+        const PrismProj pj = prismPointProj(sc.pts[pi[r]], o, B);
+        for (uint32_t k = 0; k < N; k++) prismVertexXY(pj, R.c[k], R.s[k], F.radius, vx[r][k], vy[r][k]);
+    }
     for (uint32_t tt = 0; tt < 2u * N; tt++) {
         uint32_t ring[3], circ[3], id[3];
         prismTriangle(tt, N, ring, circ);
@@ -200,8 +240,8 @@ inline void prismSegmentFragments(const lvo_scene& sc, const lvo_params& P, cons
         if (!prismCoverage(x, y, id, e)) continue;
         const PrismTri T = prismTriSetup(sc, R, F.radius, seg, tt);
         PrismFrag f;
-        f.seg = seg; f.tri = tt;
-        prismWeights(e, f.b);
+        f.seg = seg; f.tri = tt; f.d = d;
+        prismRayWeights(prismPlanes(F, T, o, d), d, f.b);
         f.pos = prismMix3(f.b, T.pos[0], T.pos[1], T.pos[2]);
         f.nrm = prismMix3(f.b, T.nrm[0], T.nrm[1], T.nrm[2]);
         f.tan = prismMix3(f.b, T.tan[0], T.tan[1], T.tan[2]);
@@ -265,8 +305,9 @@ inline void prismShade(const lvo_scene& sc, const lvo_params& P, const Frame& F,
     if (rq) {
         const PrismTri T = prismTriSetup(sc, R, F.radius, f.seg, f.tri);
         const float f0 = prismRibbon(F.cameraPosition, f.pos, f.nrm, f.tan);
-        const float fx = prismRibbonOfRay(F, T, F.cameraPosition, rq->dX);
-        const float fy = prismRibbonOfRay(F, T, F.cameraPosition, rq->dY);
+        const PrismPlanes pl = prismPlanes(F, T, F.cameraPosition, f.d);   // the basis of the pixel's own viewing ray
+        const float fx = prismRibbonOfRay(F, T, pl, rq->dX);
+        const float fy = prismRibbonOfRay(F, T, pl, rq->dY);
         rb.rasterEpsWhite = fabsf(fx - f0) + fabsf(fy - f0);
     }
     computeFragmentColor(sc, P, F, aoTexel, f.pos, f.nrm, f.tan, false, f.attr, hitColor, payloadHitT, &rb);

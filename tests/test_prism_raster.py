@@ -161,7 +161,7 @@ def test_prism_fragments_against_the_independent_screen_space_rasteriser():
                 assert fr["weights"][i].min() < 1e-4, ("fragment the rasteriser does not produce", key, s, tt, fr["weights"][i])
                 extra += 1
     assert n_checked > 750 and n_edge < 0.02 * n_checked and extra <= n_edge + 2
-    assert worst_w < 1e-4 and worst_d < 1e-6, (worst_w, worst_d)   # weights: float32 edge functions of ~0.03-wide triangles
+    assert worst_w < 1e-4 and worst_d < 1e-6, (worst_w, worst_d)   # weights: float32 minors of ~0.03-wide triangles
 
 
 def test_prism_fragment_colours_against_the_float64_raster_shader():
