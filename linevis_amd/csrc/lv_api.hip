@@ -99,7 +99,7 @@ static std::vector<LvDeviceBuffer*> lv_all_buffers(lv_ctx* ctx) {
             &ctx->eawPing, &ctx->eawPong, &ctx->tilesHaloDev, &ctx->fullFrameTile, &ctx->svgf.normalDepth, &ctx->svgf.normalDepthHistory,
             &ctx->svgf.flowFwidth, &ctx->svgf.moments, &ctx->svgf.momentsHistory, &ctx->svgf.colorHistory, &ctx->svgf.tempAccum,
             &ctx->svgf.tempAccumFiltered, &ctx->svgf.ping, &ctx->svgf.pong, &ctx->svgf.result, &ctx->aoGbuf, &ctx->aoList, &ctx->aoSamples,
-            &ctx->counters, &ctx->ppllNodes, &ctx->ppllStart, &ctx->ppllCount, &ctx->ppllScratch, &ctx->prismRecords, &ctx->prismRegions, &ctx->tilesDev, &ctx->outDev,
+            &ctx->counters, &ctx->ppllNodes, &ctx->ppllStart, &ctx->ppllCount, &ctx->ppllScratch, &ctx->tilesDev, &ctx->outDev,
             &ctx->scratchRays, &ctx->stackOverflow, &ctx->triIdx, &ctx->triVerts, &ctx->triPoints, &ctx->triNodes, &ctx->tris,
             &ctx->flowVectors, &ctx->flowScalars, &ctx->flowMisc, &ctx->flowSeeds, &ctx->flowOutPos, &ctx->flowOutAtt, &ctx->flowCounts,
             &ctx->bakeBlendingWeights, &ctx->bakeSamplingLocations, &ctx->bakedAo, &ctx->bakeLcgSkip, &ctx->mlatTrace, &ctx->buildArena,
@@ -929,11 +929,36 @@ int lv_ppll_get_buffers(lv_ctx* ctx, uint32_t* out_nodes, uint64_t max_nodes, ui
                                                (unsigned long long)max_nodes, (unsigned long long)stored);
         if (stored) LV_HIP(ctx, hipMemcpy(out_nodes, ctx->ppllNodes.ptr, size_t(stored) * 12, hipMemcpyDeviceToHost));
     }
+    const uint64_t np = uint64_t(ctx->ppllPaddedW) * ctx->ppllPaddedH; // extents of the last gather, not the current camera's
     if (out_start) {
-        const uint64_t np = uint64_t(ctx->ppllPaddedW) * ctx->ppllPaddedH; // extents of the last gather, not the current camera's
         if (max_pixels < np) return lv_fail(ctx, LV_E_CAPACITY, "out_start_offset holds %llu entries, need %llu",
                                             (unsigned long long)max_pixels, (unsigned long long)np);
         LV_HIP(ctx, hipMemcpy(out_start, ctx->ppllStart.ptr, size_t(np) * 4, hipMemcpyDeviceToHost));
+    }
+    if (hc.prismDiscards && (out_nodes || out_start)) {
+        // raster_prism: fragments the fragment stage discarded sit in the device lists as dead nodes {0, LV_PPLL_DEAD} that the
+        // resolve pass steps over; the caller gets the reference's buffers (LinkedListHeader.glsl:36-85): unlink them in the copy
+        std::vector<uint32_t> tmpNodes, tmpStart;
+        uint32_t* nd = out_nodes;
+        uint32_t* so = out_start;
+        if (!nd) {
+            tmpNodes.resize(size_t(stored) * 3);
+            if (stored) LV_HIP(ctx, hipMemcpy(tmpNodes.data(), ctx->ppllNodes.ptr, size_t(stored) * 12, hipMemcpyDeviceToHost));
+            nd = tmpNodes.data();
+        }
+        if (!so) {
+            tmpStart.resize(size_t(np));
+            LV_HIP(ctx, hipMemcpy(tmpStart.data(), ctx->ppllStart.ptr, size_t(np) * 4, hipMemcpyDeviceToHost));
+            so = tmpStart.data();
+        }
+        for (uint64_t p = 0; p < np; p++) {
+            uint32_t* link = &so[p];
+            while (*link != 0xFFFFFFFFu && *link < stored) {
+                uint32_t* n = nd + 3 * size_t(*link);
+                if (n[0] == 0u && n[1] == LV_PPLL_DEAD) *link = n[2];
+                else link = &n[2];
+            }
+        }
     }
     return LV_OK;
 }

@@ -33,8 +33,9 @@
 #ifndef LV_PRISM_MIN_WAVES
 #define LV_PRISM_MIN_WAVES 3    // k_ppll_gather<LV_PRIM_PRISM>: waves per SIMD the register allocator leaves room for
 #endif
-#define LV_PRISM_REGIONS 64u         // regions of the record stream / sub-pools of the node pool, one counter each (power of two)
-#define LV_PRISM_REGION_STRIDE 32u   // uint32 between two counters (128 B: a cache line each)
+// PPLL node {0, LV_PPLL_DEAD, next}: a linked node whose fragment the fragment stage of the rasterised prism discarded (or a slot
+// of a chunk tail).  The depth word of a real node is length(fragmentPositionWorld - cameraPosition): never this NaN pattern.
+#define LV_PPLL_DEAD 0xFFFFFFFFu
 #ifndef LV_PRISM_SHADE_MIN_WAVES
 #define LV_PRISM_SHADE_MIN_WAVES 2   // k_ppll_shade_prism: waves per SIMD the register allocator leaves room for (4: 128 VGPRs + 248 B of scratch, 0.64 ms on config 4; 1 ... 3: no scratch, 0.49 ms)
 #endif
@@ -123,6 +124,7 @@ struct LvDevCounters {
     uint32_t depthOrd[2]; // encoded min / max for the depth-range reduction
     uint32_t maxNodesPerPixel;
     uint32_t fragAlloc;   // PPLL node-slot allocator (chunks); fragCounter stays the exact fragment count
+    uint32_t prismDiscards;  // raster_prism: linked nodes the fragment stage turned into dead nodes (discarded fragments)
     uint32_t mlatTraceCount; // records appended to the MLAT visiting-order trace (collect_stats)
     // k_ao_rays leaf-test diagnostics (collect_stats): tests that found a hit inside the interval, tests the conservative
     // axis-distance pre-test lets through, tests axis + bounding-sphere pre-tests let through

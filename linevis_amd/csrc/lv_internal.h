@@ -175,8 +175,6 @@ struct lv_ctx {
     LvDeviceBuffer aoGbuf, aoList, aoSamples; // RTAO wavefront buffers
     LvDeviceBuffer counters;                  // device counters (LvCounters + misc)
     LvDeviceBuffer ppllNodes, ppllStart, ppllCount, ppllScratch;
-    LvDeviceBuffer prismRegions;              // raster_prism: record / node counters of the LV_PRISM_REGIONS regions (128 B apart)
-    LvDeviceBuffer prismRecords;              // raster_prism: covered (pixel, segment, triangle) records between the two gather kernels
     LvDeviceBuffer tilesDev, outDev, scratchRays, stackOverflow, mlatTrace;
     LvDeviceBuffer accum;                     // rgba8 of the previous accumulated frame (full viewport)
     uint32_t* pinned = nullptr;               // 64 B of pinned host memory for small read-backs (hipHostMalloc)

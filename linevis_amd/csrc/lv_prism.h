@@ -12,17 +12,36 @@
 // the ray tracer supplies candidate segments (every ring vertex lies within r of its line point, i.e. inside the segment's box); a
 // lane then pulls the two 48-B line points, generates the 2 N ring vertices in registers, projects them into the plane
 // perpendicular to its pixel's viewing ray and evaluates the 4 N distinct edge functions of the 2 N triangles -- "programmable pull"
-// taken to the pixel.  The rasteriser itself (fixed function in the reference, unobservable) is defined by the build; the
-// definition, with the reasons for every choice, is the header of oracle/lv_oracle_prism.h, which this file mirrors operation for
-// operation (float32, -ffp-contract=off, fused multiply-adds exactly where written as fmaf):
-//   P = cross(R, d), Q = cross(d, P)                        R = camera right axis
-//   (x, y) = (fma(r, fma(b.P, sin, (n.P) cos), (c - o).P), same with Q)    ring vertex c + r (n cos + b sin), fused dot products
-//   E(U, V) = yU * xV - xU * yV                             unfused: E(V, U) == -E(U, V) bit for bit (shared edges)
-//   covered iff every e_i > 0, or == 0 on an edge the triangle owns (gl_VertexIndex(U) < gl_VertexIndex(V)), and sum > 0
-//   weights b_i = e_i * (1 / ((e0 + e1) + e2)); attribute = (b0 a0 + b1 a1) + b2 a2
-//   kept iff depth in the slice [tLo, tHi), within r / |d| of the segment's box interval, and near <= -view.z <= far
-// Three stages, each run at full wave width on its own queue (lv_trace_all): A capsule pre-test (32 B, ~70 instructions) -> B
-// coverage mask of the 2 N triangles (64 B more, ~350 instructions) -> C fragment stage (lv_shade_prism) incl. the three `kept` rules.
+// taken to the pixel.  The rasteriser itself (fixed function in the reference, unobservable) is defined by the build as a rasteriser
+// in the space of the pixel's viewing ray (float32, -ffp-contract=off, fused multiply-adds exactly where written as fmaf; the CPU
+// checker of the test-suite restates the same operations in the same order, an independent float64 screen-space rasteriser in
+// tests/test_prism_raster.py confirms fragments, weights and colours):
+//   viewing ray     the pixel-centre ray (o, d) of the ray generator (TubeRayTracing.glsl:219-226: what gl_FragCoord = pixel + 0.5
+//                   unprojects to); P = cross(R, d), Q = cross(d, P) with R = the camera's right axis: P, Q, d are mutually orthogonal,
+//                   (A . P, A . Q) are -- up to positive factors -- the coordinates of A in the plane perpendicular to the ray
+//   ring vertex     V = c + r (n cos + b sin) of a line point (c, n, b = cross(t, n)):  x = fma(r, fma(b . P, sin, (n . P) cos), (c - o) . P),
+//                   y likewise with Q (fused dot products): six dot products per (ray, line point), two fmas per coordinate -- a pure
+//                   function of (line point, circle index, ray): both triangles at an edge, both segments at a point see the same bits
+//   edge function   E(U, V) = yU * xV - xU * yV = -(d . (U x V)) up to a positive factor: the homogeneous edge function of the
+//                   projected edge, UNFUSED so that E(V, U) == -E(U, V) bit for bit
+//   coverage        triangle (V0, V1, V2) covers the pixel iff e0 = E(V1, V2), e1 = E(V2, V0), e2 = E(V0, V1) are all > 0, an edge with
+//                   e == 0 counting as inside iff the triangle OWNS it (directed edge U -> V owned iff gl_VertexIndex(U) <
+//                   gl_VertexIndex(V): the neighbour runs through it the other way, exactly one of the two owns it = the fill rule),
+//                   and (e0 + e1) + e2 > 0.  "All e >= 0" is at once "the ray passes through the triangle in front of the camera"
+//                   and "front-facing" (det[V0 - o, V1 - o, V2 - o] < 0: the outward side of the index pattern)
+//   weights         perspective-correct = barycentric coordinates of the point where a ray meets the triangle's plane: b_i = e_i *
+//                   (1 / ((e0 + e1) + e2)), e_i = det[V_j - o, V_k - o, ray direction] evaluated in the own ray's basis (lv_prism_planes:
+//                   well conditioned for thin tubes); attribute = (b0 a0 + b1 a1) + b2 a2
+//   kept iff        depth = |fragmentPositionWorld - o| in the ray interval, within r / |d| of the interval in which the ray meets the
+//                   segment's box of TubeAabbRenderData (LineDataFlow.cpp:2223-2234; every ring vertex lies within r of its line point,
+//                   so this only makes the result independent of which conservative BVH supplied the candidates), and
+//                   near <= -(viewMatrix * fragmentPositionWorld).z <= far (depth clipping)
+//   helper lanes    fwidth(ribbonPosition) (LinePassGeometryShaderTubes.glsl:1079-1087) over the 2 x 2 quad: the quad partners evaluate
+//                   the SAME triangle's attribute planes at their own pixel centre (weights of their own ray, outside [0, 1] if need
+//                   be), then the shader's ribbonPosition of the interpolated inputs
+// Pipeline (each stage at full wave width on its own queue): A capsule pre-test (32 B per candidate) -> B coverage mask of the 2 N
+// triangles (64 B more) [both inside the all-hits walk, k_ppll_gather<LV_PRIM_PRISM>] -> 8-B records through HBM -> C fragment stage,
+// one lane per covered triangle (k_ppll_shade_prism, lv_shade_prism) incl. the three `kept` rules.
 #pragma once
 
 #include "lv_device.h"
@@ -60,7 +79,7 @@ __device__ __forceinline__ f3 lv_prism_pos(const LvPrismPoint& p, f3 dir, float 
                __builtin_fmaf(radius, dir.z, p.centre.z));
 }
 __device__ __forceinline__ float lv_prism_dot(f3 a, f3 b) { return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x)); }
-// projection of a line point's frame into the ray's plane (oracle: prismPointProj): six dot products per (ray, line point), then
+// projection of a line point's frame into the ray's plane (same operations as the CPU checker): six dot products per (ray, line point), then
 // two fused multiply-adds per coordinate of a ring vertex
 struct LvPrismProj { float X0, Y0, nP, bP, nQ, bQ; };
 __device__ __forceinline__ LvPrismProj lv_prism_point_proj(const LvPrismPoint& p, f3 o, f3 P, f3 Q) {
@@ -252,7 +271,7 @@ __device__ __forceinline__ float lv_prism_ribbon(f3 cam, f3 fragPos, f3 fragment
     return clampf(ribbonPosition, -1.0f, 1.0f);
 }
 
-// Perspective-correct weights of a ray direction in a triangle seen from o (oracle: prismPlanes / prismRayWeights): e_i = det[V_j - o,
+// Perspective-correct weights of a ray direction in a triangle seen from o : e_i = det[V_j - o,
 // V_k - o, ray direction] in the coordinates of the pixel's own ray basis (P, Q, d), where the triangle's X, Y are small and the
 // 2 x 2 minors c_i = (X, Y, Z)_j x (X, Y, Z)_k stay well conditioned; computed once per triangle, then six fused dot products per ray
 // -- the fragment's own ray and its two helper lanes.

@@ -831,8 +831,7 @@ template <bool STATS, int PRIM = LV_PRIM_CAPSULE, int BANDS = LV_SHADE_PLAIN>
 __global__ __launch_bounds__(LV_BLOCK, PRIM == LV_PRIM_PRISM ? LV_PRISM_MIN_WAVES : LV_GATHER_MIN_WAVES) void k_ppll_gather(const LvUniforms U, const LvSceneDev S, const LvTiles T,
                                                           uint32_t* __restrict__ nodes, uint32_t* __restrict__ startOffset,
                                                           uint32_t* __restrict__ fragCount, LvDevCounters* dc,
-                                                          uint32_t numSlices, uint32_t poolSlots, uint2* __restrict__ prismRecords,
-                                                          uint32_t prismRegionCap, uint32_t* __restrict__ prismRegions) {
+                                                          uint32_t numSlices, uint32_t poolSlots) {
     __shared__ unsigned s_stack[LV_STACK_LDS * LV_BLOCK];
     __shared__ uint32_t s_head[LV_BLOCK];  // head of this workgroup's partial list of every thread's pixel
     __shared__ uint32_t s_tail[LV_BLOCK];  // its first inserted node (whose `next` is patched when splicing)
@@ -879,7 +878,7 @@ __global__ __launch_bounds__(LV_BLOCK, PRIM == LV_PRIM_PRISM ? LV_PRISM_MIN_WAVE
         if (slice + 1u < numSlices) hi = tn + w * float(slice + 1u);
     }
     const bool active = px.inView && lo < hi;
-    unsigned prismSeq = blockIdx.x * (LV_BLOCK / LV_WAVE) + (threadIdx.x >> 6); // region rotation of this wave's record batches
+    uint32_t prismDropped = 0u;
     if (STATS && active && slice != 0u && S.numSegs != 0) cnt.rays--;
     // Fragments of a pixel are produced by whichever lane is handed the (pixel, segment) hit: the lane shades with the
     // owner's ray + AO texel and links the node with an LDS atomic exchange on the owner's list head (the reference's
@@ -889,37 +888,29 @@ __global__ __launch_bounds__(LV_BLOCK, PRIM == LV_PRIM_PRISM ? LV_PRISM_MIN_WAVE
     lv_trace_all<STATS, false, PRIM>(S, U.radius, U.useCappedTubes != 0, active, o, d, lo, hi, aoTexel,
                         __uint_as_float(px.x | (px.y << 16)), lv_stack_mem(s_stack, S.stackOverflow), cm, hq, cnt,
                         [&](unsigned owner, uint32_t leaf, float t, int kind, f3 ro, f3 rd, float ownerAo, float ownerPixel) {
+        // The rasterised prism: this kernel is the RASTERISER -- it finds which triangles cover which pixels, gives every covered
+        // triangle its node and links it into the pixel's list (in the deterministic order of the owner's wave) -- and leaves the
+        // FRAGMENT STAGE to k_ppll_shade_prism: the node carries {pixel, segment leaf | triangle << 26} until that kernel replaces
+        // the two words by {colour, depth}.  A wave in front of the dense core covers two orders of magnitude more fragments than
+        // the average wave; with the fragment stage (~3000 instructions) inline its serial shade batches were the kernel's critical
+        // path, as a second pass over the node pool the fragments are shaded one per lane, evenly over the whole GPU.
+        uint32_t word0, word1;
         if (PRIM == LV_PRIM_PRISM) {
-            // The rasterised prism: this kernel is the RASTERISER -- it finds which triangles cover which pixels -- and hands the
-            // covered (pixel, segment, triangle) records to the fragment stage k_ppll_shade_prism through HBM (8 B per fragment):
-            // a wave in front of the dense core covers two orders of magnitude more fragments than the average wave, and with the
-            // fragment stage (~2000 instructions) inline its serial shade batches WERE the kernel's duration (0.75 of 1.3 ms); as a
-            // stream of records the fragments are shaded one per lane, evenly over the whole GPU.
-            // The stream is cut into LV_PRISM_REGIONS regions with a counter each, and every batch of <= 64 records goes to the
-            // next region in turn: appends to ONE counter run at ~13 ns apiece on this GPU whichever wave issues them (70 k batches
-            // = 0.9 ms of a 1 ms kernel, measured); spread over 64 cache lines they vanish, and the rotation fills the regions evenly
-            // however unevenly the fragments are spread over the picture.
-            const unsigned long long m = __ballot(1);
-            const unsigned ln = lv_lane();
-            const int leader = __ffsll((long long)m) - 1;
-            const unsigned region = (prismSeq++) & (LV_PRISM_REGIONS - 1u);
-            unsigned base = 0u;
-            if (int(ln) == leader) base = atomicAdd(&prismRegions[region * LV_PRISM_REGION_STRIDE], unsigned(__popcll(m)));
-            base = __shfl(base, leader, 64);
-            const unsigned idx = base + unsigned(__popcll(m & ((1ull << ln) - 1ull)));
-            if (idx < prismRegionCap)
-                prismRecords[size_t(region) * prismRegionCap + idx] = make_uint2(__float_as_uint(ownerPixel), leaf | (unsigned(kind) << 26));
-            return;
+            word0 = __float_as_uint(ownerPixel);
+            word1 = leaf | (unsigned(kind) << 26);
+        } else {
+            LvHit h; h.t = t; h.leaf = leaf; h.kind = kind; h.found = true;
+            float hitT;
+            const bool rasterApply = U.ppllRasterColour != 0u;
+            const uint32_t pxy = __float_as_uint(ownerPixel);
+            const LvRasterQuad rq = lv_make_raster_quad(U, pxy & 0xFFFFu, pxy >> 16);
+            f4 color = PRIM == LV_PRIM_ELLIPTIC ? lv_shade_hit_elliptic(S, U, ownerAo, ro, rd, h, hitT, true, rq, rasterApply)
+                                                : lv_shade_hit<BANDS>(S, U, ownerAo, ro, rd, h, hitT, true, rq, rasterApply);
+            if (STATS) cnt.hits++;
+            if (color.w < 0.001f) return; // gatherFragment: discard, LinkedListGather.glsl:34
+            word0 = lv_pack_unorm4x8(color);
+            word1 = __float_as_uint(hitT);
         }
-        LvHit h; h.t = t; h.leaf = leaf; h.kind = kind; h.found = true;
-        float hitT;
-        const bool rasterApply = U.ppllRasterColour != 0u;
-        const uint32_t pxy = __float_as_uint(ownerPixel);
-        const LvRasterQuad rq = lv_make_raster_quad(U, pxy & 0xFFFFu, pxy >> 16);
-        f4 color = PRIM == LV_PRIM_ELLIPTIC ? lv_shade_hit_elliptic(S, U, ownerAo, ro, rd, h, hitT, true, rq, rasterApply)
-                                            : lv_shade_hit<BANDS>(S, U, ownerAo, ro, rd, h, hitT, true, rq, rasterApply);
-        if (STATS) cnt.hits++;
-        if (color.w < 0.001f) return; // gatherFragment: discard, LinkedListGather.glsl:34
         // wave-aggregated node allocation: slots come from a per-wave chunk; one global atomic per LV_PPLL_CHUNK fragments
         // instead of one per batch (a returning atomic on one address costs microseconds under load and sat on the
         // critical path of the waves in front of dense geometry).  A batch that does not fit takes the rest of the old
@@ -949,11 +940,20 @@ __global__ __launch_bounds__(LV_BLOCK, PRIM == LV_PRIM_PRISM ? LV_PRISM_MIN_WAVE
         if (insertIndex < poolSlots) {
             const uint32_t next = atomicExch(&s_head[waveBase + owner], insertIndex);
             if (next == 0xFFFFFFFFu) s_tail[waveBase + owner] = insertIndex;
-            nodes[3 * size_t(insertIndex) + 0] = lv_pack_unorm4x8(color);
-            nodes[3 * size_t(insertIndex) + 1] = __float_as_uint(hitT);
+            nodes[3 * size_t(insertIndex) + 0] = word0;
+            nodes[3 * size_t(insertIndex) + 1] = word1;
             nodes[3 * size_t(insertIndex) + 2] = next;
+        } else if (PRIM == LV_PRIM_PRISM) {
+            prismDropped++;   // no node: the fragment stage never sees it, but the reference's fragCounter counts it
         }
     }, [](unsigned) {});
+    if (PRIM == LV_PRIM_PRISM) {
+        // the slots this wave reserved but did not use are part of the range the fragment stage walks: mark them dead
+        const unsigned w = threadIdx.x >> 6;
+        const unsigned base = s_allocBase[w], left = s_allocLeft[w];
+        for (unsigned k = lv_lane(); k < left; k += LV_WAVE)
+            if (base + k < poolSlots) { nodes[3 * size_t(base + k) + 0] = 0u; nodes[3 * size_t(base + k) + 1] = LV_PPLL_DEAD; }
+    }
     const uint32_t numFrags = s_count[threadIdx.x];
     uint32_t total = 0;
     if (px.inView && numFrags > 0u) {
@@ -971,91 +971,69 @@ __global__ __launch_bounds__(LV_BLOCK, PRIM == LV_PRIM_PRISM ? LV_PRISM_MIN_WAVE
         m = max(m, (uint32_t)__shfl_xor(m, ofs, 64));
         sum += (uint32_t)__shfl_xor(sum, ofs, 64);
     }
+    if (PRIM == LV_PRIM_PRISM) {
+        // fragCounter / maxDepthComplexity count KEPT fragments: the fragment stage adds the ones it keeps (and takes the ones it
+        // discards out of the per-pixel counts: the resolve pass reads their maximum), here only those that found no node
+        sum = prismDropped;
+#pragma unroll
+        for (int ofs = 32; ofs > 0; ofs >>= 1) sum += (uint32_t)__shfl_xor(sum, ofs, 64);
+        m = 0u;
+    }
     if (lv_lane() == 0 && m > 0) atomicMax(&dc->maxDepthComplexity, m);
     if (lv_lane() == 0 && sum > 0) atomicAdd(&dc->fragCounter, sum); // fragCounter of the reference: every fragment counts
     lv_group_cost_add(T, px, tg0);
     if (STATS) lv_flush_counters(cnt, dc);
 }
 
-// Fragment stage of ppll_fragment_source = raster_prism: one lane per covered (pixel, segment, triangle) record of the coverage
-// kernel (k_ppll_gather<LV_PRIM_PRISM>), grid-stride over the record stream -- LinePassGeometryShaderTubes.glsl:732-1129 on the
-// perspective-correct inputs (lv_shade_prism) + gatherFragment (LinkedListGather.glsl:33-72): discard below alpha 0.001, node slot
-// from a wave-aggregated atomicAdd (one atomic per 64 fragments), atomicExchange on the pixel's list head, 12-B node.
+// Fragment stage of ppll_fragment_source = raster_prism: one lane per node slot the coverage kernel (k_ppll_gather<LV_PRIM_PRISM>)
+// handed out, grid-stride over the pool -- LinePassGeometryShaderTubes.glsl:732-1129 on the perspective-correct inputs (lv_shade_prism)
+// + the store of gatherFragment (LinkedListGather.glsl:33-72): the node's {pixel, leaf | triangle << 26} become {colour, depth}.
+// The node is linked already; a fragment the shader discards (alpha < 0.001, :34) or the `kept` rules reject turns into a DEAD
+// node {0, LV_PPLL_DEAD} that the resolve pass steps over without counting it.  No atomics on the pool, none on the lists.
 template <bool STATS>
 __global__ __launch_bounds__(LV_BLOCK, LV_PRISM_SHADE_MIN_WAVES) void k_ppll_shade_prism(const LvUniforms U, const LvSceneDev S,
-                                                                   const uint2* __restrict__ records, uint32_t regionCap,
-                                                                   uint32_t* __restrict__ regions, uint32_t* __restrict__ nodes,
-                                                                   uint32_t* __restrict__ startOffset, uint32_t* __restrict__ fragCount,
-                                                                   LvDevCounters* dc, uint32_t nodeRegionCap) {
+                                                                   uint32_t* __restrict__ nodes, uint32_t* __restrict__ fragCount,
+                                                                   LvDevCounters* dc, uint32_t poolSlots) {
     __shared__ float s_prismRing[2 * LV_PRISM_MAX_SUBDIV];
     if (threadIdx.x < LV_PRISM_MAX_SUBDIV) {   // ring table in LDS: the triangle a lane shades is a per-lane index
         s_prismRing[threadIdx.x] = S.prism.c[threadIdx.x];
         s_prismRing[LV_PRISM_MAX_SUBDIV + threadIdx.x] = S.prism.s[threadIdx.x];
     }
     __syncthreads();
-    // block b works through region b % R of the record stream together with the other blocks of that region (gridDim.x % R == 0)
-    const uint32_t region = blockIdx.x & (LV_PRISM_REGIONS - 1u);
-    const uint32_t numRecords = min(regions[region * LV_PRISM_REGION_STRIDE], regionCap);
-    const uint2* __restrict__ recs = records + size_t(region) * regionCap;
-    const uint32_t stride = (gridDim.x / LV_PRISM_REGIONS) * LV_BLOCK;
-    uint32_t* __restrict__ nodeCounters = regions + LV_PRISM_REGIONS * LV_PRISM_REGION_STRIDE;
+    const uint32_t numSlots = min(dc->fragAlloc, poolSlots);   // the chunk allocator's high-water mark
     const f3 o = mk3(U.camPos[0], U.camPos[1], U.camPos[2]);
     const float tLo = 0.0001f, tHi = __uint_as_float(__float_as_uint(1000.0f) + 1u); // the gather's ray interval [tMin, tMax]
     unsigned long long hits = 0;
-    uint32_t localMax = 0u, localSum = 0u;
-    unsigned seq = blockIdx.x * (LV_BLOCK / LV_WAVE) + (threadIdx.x >> 6);   // node-region rotation (as for the records)
-    for (uint32_t base = (blockIdx.x / LV_PRISM_REGIONS) * LV_BLOCK; base < numRecords; base += stride) {
+    uint32_t localSum = 0u;
+    for (uint32_t base = blockIdx.x * LV_BLOCK; base < numSlots; base += gridDim.x * LV_BLOCK) {
         const uint32_t i = base + threadIdx.x;
-        bool keep = false;
-        uint32_t px = 0u, py = 0u, packed = 0u;
-        float depth = 0.0f;
-        if (i < numRecords) {
-            const uint2 r = recs[i];
-            px = r.x & 0xFFFFu; py = r.x >> 16;
-            const uint32_t leaf = r.y & 0x03FFFFFFu, tt = r.y >> 26;
-            const float aoTexel = U.useAmbientOcclusion ? S.ao[size_t(py) * U.width + px] : 1.0f;
-            f3 oo, d;
-            lv_primary_ray(U, px, py, 0.5f, 0.5f, oo, d);
-            const LvRasterQuad rq = lv_make_raster_quad(U, px, py);
-            bool kept;
-            const f4 color = lv_shade_prism(S, U, s_prismRing, aoTexel, o, d, tLo, tHi, leaf, tt, rq, U.ppllRasterColour != 0u, depth, kept);
-            if (kept) {
-                if (STATS) hits++;
-                keep = color.w >= 0.001f;   // gatherFragment: discard, LinkedListGather.glsl:34
-                packed = lv_pack_unorm4x8(color);
-            }
-        }
-        const unsigned long long m = __ballot(keep);
-        if (m) {
-            const unsigned lane = lv_lane();
-            const int leader = __ffsll((long long)m) - 1;
-            const unsigned nodeRegion = (seq++) & (LV_PRISM_REGIONS - 1u);
-            unsigned slot = 0u;
-            if (int(lane) == leader) slot = atomicAdd(&nodeCounters[nodeRegion * LV_PRISM_REGION_STRIDE], unsigned(__popcll(m)));
-            slot = __shfl(slot, leader, 64);
-            if (keep) {
-                const uint32_t local = slot + unsigned(__popcll(m & ((1ull << lane) - 1ull)));
-                const uint32_t addr = lv_ppll_addr(px, py, U.ppllPaddedW, U.ppllTileW, U.ppllTileH);
-                localMax = max(localMax, atomicAdd(&fragCount[addr], 1u) + 1u);
-                localSum++;
-                if (local < nodeRegionCap) {
-                    const uint32_t insertIndex = nodeRegion * nodeRegionCap + local;
-                    const uint32_t next = atomicExch(&startOffset[addr], insertIndex);
-                    nodes[3 * size_t(insertIndex) + 0] = packed;
-                    nodes[3 * size_t(insertIndex) + 1] = __float_as_uint(depth);
-                    nodes[3 * size_t(insertIndex) + 2] = next;
-                }
-            }
+        if (i >= numSlots) continue;
+        const uint32_t w0 = nodes[3 * size_t(i) + 0], w1 = nodes[3 * size_t(i) + 1];
+        if (w1 == LV_PPLL_DEAD) continue;   // slot of a chunk tail
+        const uint32_t px = w0 & 0xFFFFu, py = w0 >> 16;
+        const uint32_t leaf = w1 & 0x03FFFFFFu, tt = w1 >> 26;
+        const float aoTexel = U.useAmbientOcclusion ? S.ao[size_t(py) * U.width + px] : 1.0f;
+        f3 oo, d;
+        lv_primary_ray(U, px, py, 0.5f, 0.5f, oo, d);
+        const LvRasterQuad rq = lv_make_raster_quad(U, px, py);
+        bool kept;
+        float depth;
+        const f4 color = lv_shade_prism(S, U, s_prismRing, aoTexel, o, d, tLo, tHi, leaf, tt, rq, U.ppllRasterColour != 0u, depth, kept);
+        if (STATS && kept) hits++;
+        if (kept && color.w >= 0.001f) {   // gatherFragment: discard below, LinkedListGather.glsl:34
+            nodes[3 * size_t(i) + 0] = lv_pack_unorm4x8(color);
+            nodes[3 * size_t(i) + 1] = __float_as_uint(depth);
+            localSum++;
+        } else {
+            nodes[3 * size_t(i) + 0] = 0u;
+            nodes[3 * size_t(i) + 1] = LV_PPLL_DEAD;
+            atomicSub(&fragCount[lv_ppll_addr(px, py, U.ppllPaddedW, U.ppllTileW, U.ppllTileH)], 1u);
+            atomicAdd(&dc->prismDiscards, 1u);   // (rare: lv_ppll_get_buffers unlinks the dead nodes from its copy if there are any)
         }
     }
 #pragma unroll
-    for (int ofs = 32; ofs > 0; ofs >>= 1) {
-        localMax = max(localMax, (uint32_t)__shfl_xor(localMax, ofs, 64));
-        localSum += (uint32_t)__shfl_xor(localSum, ofs, 64);
-    }
-    if (lv_lane() == 0 && localMax > 0u) atomicMax(&dc->maxDepthComplexity, localMax);
+    for (int ofs = 32; ofs > 0; ofs >>= 1) localSum += (uint32_t)__shfl_xor(localSum, ofs, 64);
     if (lv_lane() == 0 && localSum > 0u) atomicAdd(&dc->fragCounter, localSum); // fragCounter of the reference: every fragment counts
-    if (blockIdx.x == 0 && threadIdx.x == 0) dc->fragAlloc = LV_PRISM_REGIONS * nodeRegionCap; // (lv_ppll_get_buffers: the whole pool)
     if (STATS) {
         hits = lv_wave_sum_u64(hits);
         if (lv_lane() == 0 && hits) atomicAdd(&dc->hits, hits);
@@ -1064,14 +1042,13 @@ __global__ __launch_bounds__(LV_BLOCK, LV_PRISM_SHADE_MIN_WAVES) void k_ppll_sha
 
 // clear(): LinkedListClear.glsl:46-55 (start offsets = -1) + fragmentCounterBuffer->fill(0), and the per-pixel fragment counts
 __global__ __launch_bounds__(LV_BLOCK) void k_ppll_clear(uint4* __restrict__ startOffset, uint4* __restrict__ fragCount, size_t n4,
-                                                         LvDevCounters* dc, uint32_t* __restrict__ prismRegions) {
+                                                         LvDevCounters* dc) {
     const size_t i = size_t(blockIdx.x) * LV_BLOCK + threadIdx.x;
-    if (prismRegions && i < 2u * LV_PRISM_REGIONS * LV_PRISM_REGION_STRIDE) prismRegions[i] = 0u;
     if (i < n4) {
         startOffset[i] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
         fragCount[i] = make_uint4(0u, 0u, 0u, 0u);
     }
-    if (i == 0) { dc->fragCounter = 0u; dc->fragAlloc = 0u; }
+    if (i == 0) { dc->fragCounter = 0u; dc->fragAlloc = 0u; dc->prismDiscards = 0u; }
 }
 
 // per-thread fragment arrays interleaved over the wave: entry i of lane l at [i * 64 + l]
@@ -1225,8 +1202,10 @@ __global__ __launch_bounds__(LV_WAVE) void k_ppll_resolve(const LvUniforms U, co
                                                           const uint32_t* __restrict__ nodes,
                                                           const uint32_t* __restrict__ startOffset,
                                                           uint32_t* __restrict__ out, uint32_t* __restrict__ scratch,
-                                                          uint32_t numGroups) {
+                                                          uint32_t numGroups, const uint32_t* __restrict__ fragCount,
+                                                          LvDevCounters* dc) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+    uint32_t maxCount = 0u;   // raster_prism frames: the largest per-pixel fragment count (kept fragments) is collected here
     const uint32_t maxFrags = U.ppllMaxNumFrags;
     const uint32_t lane = threadIdx.x;
     LvFragArrays A;
@@ -1248,13 +1227,20 @@ __global__ __launch_bounds__(LV_WAVE) void k_ppll_resolve(const LvUniforms U, co
         const uint32_t outIndex = (tile * T.tileH + ly) * T.tileW + lx;
         float res[4] = {U.background[0], U.background[1], U.background[2], U.background[3]};
         if (x < U.width && y < U.height) {
-            uint32_t fragOffset = startOffset[lv_ppll_addr(x, y, U.ppllPaddedW, U.ppllTileW, U.ppllTileH)];
+            const uint32_t addr = lv_ppll_addr(x, y, U.ppllPaddedW, U.ppllTileW, U.ppllTileH);
+            uint32_t fragOffset = startOffset[addr];
+            if (fragCount) maxCount = max(maxCount, fragCount[addr]);
             uint32_t numFrags = 0;
-            for (uint32_t i = 0; i < maxFrags; i++) {
+            while (numFrags < maxFrags) {
                 if (fragOffset == 0xFFFFFFFFu) break;
-                A.c(i) = nodes[3 * size_t(fragOffset) + 0];
-                A.d(i) = __uint_as_float(nodes[3 * size_t(fragOffset) + 1]);
+                const uint32_t c = nodes[3 * size_t(fragOffset) + 0], db = nodes[3 * size_t(fragOffset) + 1];
                 fragOffset = nodes[3 * size_t(fragOffset) + 2];
+                // dead node (LV_PPLL_DEAD): a linked slot whose fragment the fragment stage of the rasterised prism discarded; it is
+                // not part of the list (gatherFragment never stored it, LinkedListGather.glsl:34).  Lists of the reference cannot
+                // contain this pattern: a node's depth is a length.
+                if (db == LV_PPLL_DEAD && c == 0u) continue;
+                A.c(numFrags) = c;
+                A.d(numFrags) = __uint_as_float(db);
                 numFrags++;
             }
             if (!PQ && numFrags > 0) {
@@ -1302,6 +1288,11 @@ __global__ __launch_bounds__(LV_WAVE) void k_ppll_resolve(const LvUniforms U, co
         }
         f4 c; c.x = res[0]; c.y = res[1]; c.z = res[2]; c.w = res[3];
         out[outIndex] = lv_pack_unorm4x8(c);
+    }
+    if (fragCount) {
+#pragma unroll
+        for (int ofs = 32; ofs > 0; ofs >>= 1) maxCount = max(maxCount, (uint32_t)__shfl_xor(maxCount, ofs, 64));
+        if (lane == 0 && maxCount > 0u) atomicMax(&dc->maxDepthComplexity, maxCount);
     }
 }
 
@@ -2090,13 +2081,9 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
         if (uint64_t(gridTiles) * numSlices > 0x7FFFFFF0ull) return lv_fail(ctx, LV_E_INVALID, "tile list too large");
         // physical pool = the reference's linkedListSize + the tail every wave of the gather may leave unused in its last
         // chunk of node slots (k_ppll_gather), so that the effective capacity is never below the reference's
-        // (raster_prism: node slots are handed out from LV_PRISM_REGIONS sub-pools in turn -- the slack covers the < 64 slots a sub-pool
-        // may leave unused when it runs full)
         uint64_t poolSlots64 = uint64_t(U.ppllLinkedListSize) +
-                               uint64_t(gridTiles) * numSlices * (LV_BLOCK / LV_WAVE) * LV_PPLL_CHUNK +
-                               (prismSource ? uint64_t(LV_PRISM_REGIONS) * 2u * LV_WAVE : 0u);
+                               uint64_t(gridTiles) * numSlices * (LV_BLOCK / LV_WAVE) * LV_PPLL_CHUNK;
         if (poolSlots64 > 0xFFFFFFF0ull) poolSlots64 = 0xFFFFFFF0ull; // node indices are 32 bit
-        if (prismSource) poolSlots64 -= poolSlots64 % LV_PRISM_REGIONS;   // equal sub-pools
         const uint32_t poolSlots = uint32_t(poolSlots64);
         if ((rc = lv_buf_reserve(ctx, ctx->ppllNodes, size_t(poolSlots) * 12))) return rc;
         const size_t padded4 = (size_t(U.ppllPaddedW) * U.ppllPaddedH + 3) / 4; // cleared as whole uint4s (k_ppll_clear)
@@ -2106,27 +2093,13 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
         ctx->ppllPaddedW = U.ppllPaddedW;
         ctx->ppllPaddedH = U.ppllPaddedH;
         // clear(): LinkedListClear.glsl:46-55 + fragmentCounterBuffer->fill(0)
-        if (prismSource && (rc = lv_buf_reserve(ctx, ctx->prismRegions, size_t(2) * LV_PRISM_REGIONS * LV_PRISM_REGION_STRIDE * 4))) return rc;
-        {
-            const size_t clearThreads = std::max<size_t>(padded4, prismSource ? 2u * LV_PRISM_REGIONS * LV_PRISM_REGION_STRIDE : 0u);
-            k_ppll_clear<<<uint32_t((clearThreads + LV_BLOCK - 1) / LV_BLOCK), LV_BLOCK, 0, st>>>(
-                    (uint4*)ctx->ppllStart.ptr, (uint4*)ctx->ppllCount.ptr, padded4, dc, prismSource ? (uint32_t*)ctx->prismRegions.ptr : nullptr);
-        }
+        k_ppll_clear<<<uint32_t((padded4 + LV_BLOCK - 1) / LV_BLOCK), LV_BLOCK, 0, st>>>((uint4*)ctx->ppllStart.ptr,
+                                                                                         (uint4*)ctx->ppllCount.ptr, padded4, dc);
         LV_HIP(ctx, hipEventRecord(ctx->ev[11], st));
-        // raster_prism: the coverage kernel streams (pixel, segment, triangle) records to the fragment stage; room for twice the
-        // node pool (records whose fragment the shader discards take no node)
-        uint32_t prismRegionCap = 0u;
-        if (prismSource) {
-            uint64_t cap64 = 2ull * poolSlots64;
-            if (cap64 > 0xFFFFFFF0ull) cap64 = 0xFFFFFFF0ull;
-            prismRegionCap = uint32_t(cap64 / LV_PRISM_REGIONS);
-            if ((rc = lv_buf_reserve(ctx, ctx->prismRecords, size_t(prismRegionCap) * LV_PRISM_REGIONS * 8))) return rc;
-        }
 #define LV_LAUNCH_GATHER(ST, PR, BA)                                                                             \
     LV_TIMED_LAUNCH(ctx, LV_KERNEL_PPLL_GATHER, (k_ppll_gather<ST, PR, BA><<<gridTiles * numSlices, LV_BLOCK, 0, st>>>( \
             U, S, T, (uint32_t*)ctx->ppllNodes.ptr, (uint32_t*)ctx->ppllStart.ptr,                              \
-            (uint32_t*)ctx->ppllCount.ptr, dc, numSlices, poolSlots, (uint2*)ctx->prismRecords.ptr, prismRegionCap,        \
-            (uint32_t*)ctx->prismRegions.ptr)))
+            (uint32_t*)ctx->ppllCount.ptr, dc, numSlices, poolSlots)))
 #define LV_LAUNCH_GATHER2(ST)                                                          \
     do {                                                                               \
         if (prismSource) LV_LAUNCH_GATHER(ST, LV_PRIM_PRISM, LV_SHADE_PLAIN);          \
@@ -2139,18 +2112,16 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
 #undef LV_LAUNCH_GATHER2
 #undef LV_LAUNCH_GATHER
         if (prismSource) {
-            uint32_t shadeGrid = uint32_t(ctx->numCUs) * LV_PRISM_SHADE_BLOCKS_PER_CU;
-            shadeGrid = std::max(shadeGrid - shadeGrid % LV_PRISM_REGIONS, (uint32_t)LV_PRISM_REGIONS); // a whole number of blocks per region
+            const uint32_t shadeGrid = uint32_t(ctx->numCUs) * LV_PRISM_SHADE_BLOCKS_PER_CU;
 #define LV_LAUNCH_SHADE(ST)                                                                                                     \
     LV_TIMED_LAUNCH(ctx, LV_KERNEL_PPLL_SHADE, (k_ppll_shade_prism<ST><<<shadeGrid, LV_BLOCK, 0, st>>>(                         \
-            U, S, (const uint2*)ctx->prismRecords.ptr, prismRegionCap, (uint32_t*)ctx->prismRegions.ptr,                        \
-            (uint32_t*)ctx->ppllNodes.ptr, (uint32_t*)ctx->ppllStart.ptr, (uint32_t*)ctx->ppllCount.ptr, dc,                   \
-            poolSlots / LV_PRISM_REGIONS)))
+            U, S, (uint32_t*)ctx->ppllNodes.ptr, (uint32_t*)ctx->ppllCount.ptr, dc, poolSlots)))
             if (stats) LV_LAUNCH_SHADE(true); else LV_LAUNCH_SHADE(false);
 #undef LV_LAUNCH_SHADE
         }
         LV_HIP(ctx, hipEventRecord(ctx->ev[13], st));
         // resolve()
+        const uint32_t* prismCount = prismSource ? (const uint32_t*)ctx->ppllCount.ptr : nullptr; // (kept fragments per pixel -> max depth complexity)
         const uint32_t gx = (tileW + 7u) / 8u, gy = (tileH + 7u) / 8u;
         const uint64_t groups64 = uint64_t(numTiles) * gx * gy;
         const uint32_t numGroups = uint32_t(groups64);
@@ -2158,21 +2129,21 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
         if (ldsBytes <= LV_RESOLVE_LDS_MAX) {
             if (U.ppllSortingMode == 0u)
                 LV_TIMED_LAUNCH(ctx, LV_KERNEL_PPLL_RESOLVE, (k_ppll_resolve<true, true><<<numGroups, LV_WAVE, ldsBytes, st>>>(
-                        U, T, (const uint32_t*)ctx->ppllNodes.ptr, (const uint32_t*)ctx->ppllStart.ptr, out, nullptr, numGroups)));
+                        U, T, (const uint32_t*)ctx->ppllNodes.ptr, (const uint32_t*)ctx->ppllStart.ptr, out, nullptr, numGroups, prismCount, dc)));
             else
                 LV_TIMED_LAUNCH(ctx, LV_KERNEL_PPLL_RESOLVE, (k_ppll_resolve<true, false><<<numGroups, LV_WAVE, ldsBytes, st>>>(
-                        U, T, (const uint32_t*)ctx->ppllNodes.ptr, (const uint32_t*)ctx->ppllStart.ptr, out, nullptr, numGroups)));
+                        U, T, (const uint32_t*)ctx->ppllNodes.ptr, (const uint32_t*)ctx->ppllStart.ptr, out, nullptr, numGroups, prismCount, dc)));
         } else {
             const uint32_t grid = numGroups < LV_RESOLVE_SLAB_GRID ? numGroups : LV_RESOLVE_SLAB_GRID;
             if ((rc = lv_buf_reserve(ctx, ctx->ppllScratch, size_t(grid) * ldsBytes))) return rc;
             if (U.ppllSortingMode == 0u)
                 LV_TIMED_LAUNCH(ctx, LV_KERNEL_PPLL_RESOLVE, (k_ppll_resolve<false, true><<<grid, LV_WAVE, 0, st>>>(
                         U, T, (const uint32_t*)ctx->ppllNodes.ptr, (const uint32_t*)ctx->ppllStart.ptr, out,
-                        (uint32_t*)ctx->ppllScratch.ptr, numGroups)));
+                        (uint32_t*)ctx->ppllScratch.ptr, numGroups, prismCount, dc)));
             else
                 LV_TIMED_LAUNCH(ctx, LV_KERNEL_PPLL_RESOLVE, (k_ppll_resolve<false, false><<<grid, LV_WAVE, 0, st>>>(
                         U, T, (const uint32_t*)ctx->ppllNodes.ptr, (const uint32_t*)ctx->ppllStart.ptr, out,
-                        (uint32_t*)ctx->ppllScratch.ptr, numGroups)));
+                        (uint32_t*)ctx->ppllScratch.ptr, numGroups, prismCount, dc)));
         }
     }
     LV_HIP(ctx, hipGetLastError());
@@ -2246,14 +2217,14 @@ int lv_frame_ppll_resolve_only(lv_ctx* ctx, const uint32_t* nodes, uint64_t numN
     uint32_t* od = (uint32_t*)ctx->outDev.ptr;
     const bool pq = U.ppllSortingMode == 0u;
     if (ldsBytes <= LV_RESOLVE_LDS_MAX) {
-        if (pq) k_ppll_resolve<true, true><<<numGroups, LV_WAVE, ldsBytes, st>>>(U, T, nd, so, od, nullptr, numGroups);
-        else k_ppll_resolve<true, false><<<numGroups, LV_WAVE, ldsBytes, st>>>(U, T, nd, so, od, nullptr, numGroups);
+        if (pq) k_ppll_resolve<true, true><<<numGroups, LV_WAVE, ldsBytes, st>>>(U, T, nd, so, od, nullptr, numGroups, nullptr, nullptr);
+        else k_ppll_resolve<true, false><<<numGroups, LV_WAVE, ldsBytes, st>>>(U, T, nd, so, od, nullptr, numGroups, nullptr, nullptr);
     } else {
         const uint32_t grid = numGroups < LV_RESOLVE_SLAB_GRID ? numGroups : LV_RESOLVE_SLAB_GRID;
         if ((rc = lv_buf_reserve(ctx, ctx->ppllScratch, size_t(grid) * ldsBytes))) return rc;
         uint32_t* sc = (uint32_t*)ctx->ppllScratch.ptr;
-        if (pq) k_ppll_resolve<false, true><<<grid, LV_WAVE, 0, st>>>(U, T, nd, so, od, sc, numGroups);
-        else k_ppll_resolve<false, false><<<grid, LV_WAVE, 0, st>>>(U, T, nd, so, od, sc, numGroups);
+        if (pq) k_ppll_resolve<false, true><<<grid, LV_WAVE, 0, st>>>(U, T, nd, so, od, sc, numGroups, nullptr, nullptr);
+        else k_ppll_resolve<false, false><<<grid, LV_WAVE, 0, st>>>(U, T, nd, so, od, sc, numGroups, nullptr, nullptr);
     }
     LV_HIP(ctx, hipGetLastError());
     LV_HIP(ctx, hipMemcpyAsync(out, ctx->outDev.ptr, size_t(w) * h * 4, hipMemcpyDeviceToHost, st));

@@ -1336,7 +1336,7 @@ __device__ __forceinline__ f4 lv_shade_hit(const LvSceneDev& S, const LvUniforms
                                                        payloadHitT, none);
 }
 
-// Fragment stage of the rasterised programmable-pull prism (ppll_fragment_source = raster_prism; lv_prism.h, oracle prismShade):
+// Fragment stage of the rasterised programmable-pull prism (ppll_fragment_source = raster_prism; lv_prism.h):
 // LinePassGeometryShaderTubes.glsl:732-1129 on the perspective-correct inputs of triangle tt of the leaf's segment for the pixel's
 // viewing ray (o, d); fwidth(ribbonPosition) (:1079-1087) from the helper invocations of the 2 x 2 quad = the same triangle's
 // attribute planes at the quad partners' rays (LvRasterQuad).

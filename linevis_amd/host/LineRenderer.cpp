@@ -561,7 +561,8 @@ void HipPerPixelLinkedListLineRenderer::render() {
 bool HipPerPixelLinkedListLineRenderer::setNewSettings(const SettingsMap& settings) {
     bool r = LineRenderer::setNewSettings(settings);
     for (const char* key : {"ppll_max_num_frags", "ppll_expected_avg_depth_complexity", "ppll_tile_width", "ppll_tile_height",
-                            "sorting_mode"}) { // sorting_mode: sortingAlgorithmMode, PerPixelLinkedListLineRenderer.hpp:113
+                            "sorting_mode", // sortingAlgorithmMode, PerPixelLinkedListLineRenderer.hpp:113
+                            "ppll_fragment_source", "ppll_fragment_colour"}) { // build-owned probes (include/linevis_hip.h)
         std::string s;
         if (settings.getValueOpt(key, s)) setOption(key, s);
     }

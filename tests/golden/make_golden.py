@@ -150,8 +150,9 @@ def small_scene():
     c = Case(base.points, base.seg, base.tf, W, H, base.line_width, **ao_set)
     img, ao = c.oracle_render(11)
     out["rt_ao"], out["ao_bits"] = img, f2u(ao)
-    # 4. PPLL with the transparent transfer function
-    c = Case(base.points, base.seg, out["tf_transparent"], W, H, base.line_width)
+    # 4. PPLL with the transparent transfer function (fragments = capsule entry hits: the probe of rounds 1-3; the rasterised
+    #    prism has its own fixture, prism_small())
+    c = Case(base.points, base.seg, out["tf_transparent"], W, H, base.line_width, ppll_fragment_source="capsule_entry")
     st = lvo.Stats()
     out["ppll"], _ = c.oracle_render(2, stats=st)
     out["ppll_fragments"] = np.uint64(st.fragments)
@@ -437,7 +438,37 @@ def round2b():
     np.savez_compressed(os.path.join(HERE, "round2b.npz"), **out)
 
 
+def prism_small():
+    """PPLL fragments of the rasterised programmable-pull prism (ppll_fragment_source = raster_prism) on the small
+    scene of scene_small.npz: frame, fragment counter, and the sorted (pixel address, depth bits, packed colour) triples of every list;
+    hexagon (default) and square cross-section."""
+    g = np.load(os.path.join(HERE, "scene_small.npz"))
+    pts = g["points"].view(lvo.LINE_POINT_DTYPE).reshape(-1)
+    W, H, lw = int(g["width"]), int(g["height"]), float(g["line_width"])
+    out = {}
+    for name, settings in (("hex", {}), ("square_depthcue", dict(tube_num_subdivisions=4, depth_cue_strength=0.8))):
+        c = Case(pts, g["seg"], g["tf_transparent"], W, H, lw, ppll_fragment_source="raster_prism", **settings)
+        sc = c.oracle_scene()
+        P = c.oracle_params(sc)
+        st = lvo.Stats()
+        out[name + "_frame"] = sc.render_ppll(P, stats=st)
+        nodes, start, cnt = sc.ppll_gather(P)
+        lists = []
+        for pix in np.nonzero(start != 0xFFFFFFFF)[0]:
+            i = int(start[pix])
+            while i != 0xFFFFFFFF:
+                lists.append((int(pix), int(nodes[i, 1]), int(nodes[i, 0])))
+                i = int(nodes[i, 2])
+        out[name + "_fragments"] = np.array(sorted(lists), dtype=np.uint32)
+        out[name + "_count"] = np.uint64(cnt)
+        out[name + "_max_depth_complexity"] = np.uint32(st.maxDepthComplexity)
+    np.savez_compressed(os.path.join(HERE, "prism_small.npz"), **out)
+
+
 if __name__ == "__main__":
+    if "--only-prism" in sys.argv:
+        prism_small()
+        sys.exit(0)
     if "--only-round2b" in sys.argv:
         round2b()
         sys.exit(0)
@@ -464,6 +495,7 @@ if __name__ == "__main__":
     mlat_small()
     round2()
     round2b()
+    prism_small()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print("%-24s %8d bytes" % (f, os.path.getsize(os.path.join(HERE, f))))

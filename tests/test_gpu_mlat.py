@@ -53,6 +53,7 @@ def ctx2_render(c, mode):
     c2 = Case(c.points, c.seg, c.tf, c.width, c.height, c.line_width, **s)
     ctx = c2.hip_context()
     ctx.set_option("ppll_fragment_colour", "ray_tracer")   # like for like: MLAT shades with the ray tracer's computeFragmentColor
+    ctx.set_option("ppll_fragment_source", "capsule_entry")  # ... and traces the analytic capsules, not the rasterised prism
     return ctx.render(mode)
 
 
@@ -80,7 +81,7 @@ def test_opaque_scene_accepts_and_shrinks_the_interval(hip_lib):
     assert viol == 0 and max_lsb_diff(img, ref) <= LSB_TOL
     st = ctx.stats()
     # early termination pays: far fewer candidates shaded than the all-hits gather produces fragments
-    c2 = Case(c.points, c.seg, c.tf, c.width, c.height, c.line_width, collect_stats=True)
+    c2 = Case(c.points, c.seg, c.tf, c.width, c.height, c.line_width, collect_stats=True, ppll_fragment_source="capsule_entry")
     ctx2 = c2.hip_context()
     ctx2.render(capi.MODE_PPLL)
     assert st.hits_shaded < ctx2.stats().hits_shaded

@@ -169,7 +169,7 @@ def test_golden_rtao(hip_lib):
 
 def test_golden_ppll(hip_lib):
     g, pts, W, H, lw = golden_base()
-    c = Case(pts, g["seg"], g["tf_transparent"], W, H, lw)
+    c = Case(pts, g["seg"], g["tf_transparent"], W, H, lw, ppll_fragment_source="capsule_entry")   # the fixture of rounds 1-3
     ctx = c.hip_context()
     img = ctx.render(2)
     st = ctx.stats()
@@ -677,7 +677,7 @@ def test_config4_full_size_ppll_and_mlat(hip_lib):
     ctx.set_transfer_function(c.tf, lo, hi)
     full = ctx.render(2)
     st = ctx.stats()
-    assert st.fragments > 5000000 and st.max_depth_complexity > 100
+    assert st.fragments > 4000000 and st.max_depth_complexity > 100   # (rasterised prism: 4.46 M; the capsule probe 7.3 M)
     pw, ph = c.padded()
     sc = c.oracle_scene()
     P = c.oracle_params(sc)

@@ -283,7 +283,7 @@ def test_golden_small_scene_frames():
     assert np.array_equal(bits(ao), g["ao_bits"])       # pure +,-,*,/,sqrt: exact
     assert max_lsb_diff(img, g["rt_ao"]) <= 1
     assert 0.0 <= ao.min() < 0.9 and ao.max() == 1.0
-    c = Case(pts, g["seg"], g["tf_transparent"], W, H, lw)
+    c = Case(pts, g["seg"], g["tf_transparent"], W, H, lw, ppll_fragment_source="capsule_entry")   # the fixture of rounds 1-3
     st = lvo.Stats()
     img, _ = c.oracle_render(2, stats=st)
     assert max_lsb_diff(img, g["ppll"]) <= 1

@@ -287,7 +287,53 @@ def test_prism_frame_differs_from_the_capsule_probe_and_is_contained_in_it():
     assert not np.array_equal(img_p, img_c)
 
 
+def _golden_cases():
+    import os
+    from common import GOLDEN_DIR
+    g = np.load(os.path.join(GOLDEN_DIR, "scene_small.npz"))
+    gp = np.load(os.path.join(GOLDEN_DIR, "prism_small.npz"))
+    pts = g["points"].view(lvo.LINE_POINT_DTYPE).reshape(-1)
+    W, H, lw = int(g["width"]), int(g["height"]), float(g["line_width"])
+    for name, settings in (("hex", {}), ("square_depthcue", dict(tube_num_subdivisions=4, depth_cue_strength=0.8))):
+        yield name, gp, Case(pts, g["seg"], g["tf_transparent"], W, H, lw, ppll_fragment_source="raster_prism", **settings)
+
+
+def _sorted_triples(nodes, start):
+    out = []
+    for pix in np.nonzero(start != 0xFFFFFFFF)[0]:
+        i = int(start[pix])
+        while i != 0xFFFFFFFF:
+            out.append((int(pix), int(nodes[i, 1]), int(nodes[i, 0])))
+            i = int(nodes[i, 2])
+    return np.array(sorted(out), dtype=np.uint32)
+
+
+def test_golden_prism_fragments_of_the_small_scene():
+    """committed fixture tests/golden/prism_small.npz (make_golden.py --only-prism): frame, counter, every fragment"""
+    for name, gp, c in _golden_cases():
+        sc = c.oracle_scene()
+        P = c.oracle_params(sc)
+        st = lvo.Stats()
+        assert np.array_equal(sc.render_ppll(P, stats=st), gp[name + "_frame"])
+        nodes, start, cnt = sc.ppll_gather(P, use_bvh=True)
+        assert cnt == int(gp[name + "_count"]) and st.maxDepthComplexity == int(gp[name + "_max_depth_complexity"])
+        assert np.array_equal(_sorted_triples(nodes, start), gp[name + "_fragments"])
+
+
 # ---------------------------------------------------------------- GPU
+@pytest.mark.gpu
+def test_hip_golden_prism_fragments_of_the_small_scene(hip_lib):
+    for name, gp, c in _golden_cases():
+        ctx = c.hip_context()
+        img = ctx.render(2)
+        st = ctx.stats()
+        pw, ph = c.padded()
+        hn, hs, hcnt = ctx.ppll_buffers(pw * ph, 0)
+        assert hcnt == int(gp[name + "_count"]) and st.max_depth_complexity == int(gp[name + "_max_depth_complexity"])
+        assert np.array_equal(_sorted_triples(hn, hs), gp[name + "_fragments"])
+        assert np.abs(img.astype(np.int32) - gp[name + "_frame"].astype(np.int32)).max() <= 2
+
+
 def _lists(nodes, start):
     """per-pixel multisets {(colour, depth bits)} of a PPLL node pool"""
     out = {}
