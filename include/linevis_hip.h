@@ -266,7 +266,10 @@ int lv_render_tiles_device(lv_ctx* ctx, int rendering_mode, const uint32_t* tile
  * (lv_get_ao, lv_ppll_get_buffers, lv_get_kernel_times, ...) address rank 0; lv_get_stats sums the counters of all ranks.
  * lv_multi_rebalance: re-deals the tiles of the last frame by measured cost (RTAO hit pixels x samples per tile + base_cost_per_tile,
  * longest processing time first); synchronises all ranks, call it between frames (progressive accumulation: not while a
- * num_accumulated_frames > 1 sequence is running -- the history stays on the rank that rendered it).
+ * num_accumulated_frames > 1 sequence is running -- the history stays on the rank that rendered it).  A tile list that differs
+ * from the previous call's (another rectangle, other tiles) starts from a fresh round-robin deal: the cost-weighted deal belongs to
+ * the list it was measured on.  A rank that owns no tile of a frame (fewer tiles than ranks) renders the list's first tile for
+ * itself, so that its temporal state (RTAO seed counter, SVGF history) stays in step with the other ranks'.
  * lv_multi_deal: tile -> rank of the last frame.  lv_tile_deal / lv_make_tiles: the deal and the tile order as pure host
  * functions (costs == NULL: round robin). */
 lv_ctx* lv_create_multi(const int* device_ordinals, int num_devices, const char* transport, int* err);

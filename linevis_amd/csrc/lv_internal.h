@@ -261,6 +261,8 @@ inline int lv_forward_to_ranks(lv_ctx* handle, F&& f) {
         const int rc = f(p);
         if (rc) return lv_fail(handle, rc, "rank %d (device %d): %s", r, p->device, p->lastError.c_str());
     }
+    // the setters select their rank's device: leave the calling thread on the handle's (outputs live on the first device)
+    if (n > 1) (void)hipSetDevice(handle->device);
     return LV_OK;
 }
 // lv_mlat.hip

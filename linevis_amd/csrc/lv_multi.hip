@@ -168,6 +168,11 @@ int lv_multi_create(lv_ctx* handle, const int* devices, int numDevices, const ch
     handle->multi = M;
     M->ranks.push_back(handle);
     M->rcclTransport = !(transport && std::string(transport) == "memcpy");
+    // per-rank arrays sized before anything can fail: lv_multi_destroy walks them for every rank created so far
+    M->tileBuf.resize(size_t(numDevices));
+    M->owned.resize(size_t(numDevices));
+    M->ownedXY.resize(size_t(numDevices));
+    M->evRendered.assign(size_t(numDevices), nullptr);
     for (int r = 1; r < numDevices; r++) {
         int err = 0;
         lv_ctx* p = lv_create(devices[r], &err);
@@ -175,10 +180,6 @@ int lv_multi_create(lv_ctx* handle, const int* devices, int numDevices, const ch
         M->ranks.push_back(p);
     }
     const size_t n = M->ranks.size();
-    M->tileBuf.resize(n);
-    M->owned.resize(n);
-    M->ownedXY.resize(n);
-    M->evRendered.assign(n, nullptr);
     for (size_t r = 0; r < n; r++) {
         LV_HIP(handle, hipSetDevice(M->ranks[r]->device));
         LV_HIP(handle, hipEventCreateWithFlags(&M->evRendered[r], hipEventDisableTiming));
@@ -296,7 +297,17 @@ int lv_multi_render(lv_ctx* handle, int mode, const uint32_t* tilesXY, uint32_t 
     for (size_t r = 0; r < n; r++) {
         lv_ctx* c = M->ranks[r];
         const uint32_t cnt = uint32_t(M->owned[r].size());
-        if (cnt == 0) continue;
+        if (cnt == 0) {
+            // A rank without a tile in this frame (fewer tiles than ranks) still has temporal state that must stay in step with the
+            // other ranks': the RTAO seed counter aoGlobalFrameNumber, the SVGF history (every rank denoises the whole viewport),
+            // lastFrameViewProj.  It renders the list's first tile into its own buffer; the result is not gathered.
+            if (numTiles == 0) continue;
+            LV_HIP(handle, hipSetDevice(c->device));
+            if ((rc = lv_buf_reserve(c, M->tileBuf[r], tileBytes))) return lv_fail(handle, rc, "rank %zu: %s", r, c->lastError.c_str());
+            if ((rc = lv_frame_render(c, mode, tilesXY, 1u, tileW, tileH, M->tileBuf[r].ptr)))
+                return lv_fail(handle, rc, "rank %zu (device %d): %s", r, c->device, c->lastError.c_str());
+            continue;
+        }
         LV_HIP(handle, hipSetDevice(c->device));
         if ((rc = lv_buf_reserve(c, M->tileBuf[r], size_t(cnt) * tileBytes))) return lv_fail(handle, rc, "rank %zu: %s", r, c->lastError.c_str());
         if ((rc = lv_frame_render(c, mode, M->ownedXY[r].data(), cnt, tileW, tileH, M->tileBuf[r].ptr)))
@@ -370,10 +381,13 @@ int lv_multi_rebalance_impl(lv_ctx* handle, double baseCostPerTile) {
     for (size_t r = 0; r < M->ranks.size(); r++) {
         lv_ctx* c = M->ranks[r];
         if (M->owned[r].empty()) continue;
-        std::vector<uint32_t> counts(size_t(M->owned[r].size()) * 64u);
         uint32_t n = 0, per = 0;
-        const int rc = lv_get_ao_tile_costs(c, counts.data(), uint32_t(counts.size()), &n, &per);
+        int rc = lv_get_ao_tile_costs(c, nullptr, 0, &n, &per);   // how many counters (tiles with an EAW halo have more groups)
         if (rc == LV_E_STATE) continue; // the last frame ran no RTAO pass: nothing to weigh, keep the fixed cost
+        if (rc) return lv_fail(handle, rc, "rank %zu: %s", r, c->lastError.c_str());
+        std::vector<uint32_t> counts(std::max<size_t>(n, 1));
+        rc = lv_get_ao_tile_costs(c, counts.data(), uint32_t(counts.size()), &n, &per);
+        if (rc == LV_E_CAPACITY || rc == LV_E_STATE) continue;     // no usable cost data for this rank: its tiles keep the fixed cost
         if (rc) return lv_fail(handle, rc, "rank %zu: %s", r, c->lastError.c_str());
         if (per == 0 || n != per * M->owned[r].size()) continue;
         for (size_t i = 0; i < M->owned[r].size(); i++) {

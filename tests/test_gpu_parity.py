@@ -804,12 +804,14 @@ def test_config5_scale_tiles(hip_lib):
     assert (a[1] != 0xFFFFFFFF).sum() > 2000
 
 
-def _all_tile_lists_reproduce_the_whole_frame(c, mode, world, cost_scale):
+def _all_tile_lists_reproduce_the_whole_frame(c, mode, world, cost_scale, mesh=None):
     """Every rank's tile list of a `world`-GPU run rendered in turn on this one GPU through the path a rank uses
     (ShardedFrame.render_local, cost-weighted deal as bench.py applies it) and de-tiled with the device gather's code
     (assemble_device on the pieces) = the frame rendered in one piece, byte for byte."""
     import torch
     ctx = c.hip_context()
+    if mesh is not None:
+        ctx.set_tube_triangle_mesh(*mesh)      # rtao_geometry = triangle_tubes: the reference's RTAO geometry (the timed headline mode)
     whole = ctx.render(mode)
     dev = torch.device("cuda", 0)
     frames = [tiling.ShardedFrame(c.width, c.height, 64, r, world, dev) for r in range(world)]
@@ -850,17 +852,23 @@ def test_config5_all_eight_tile_lists_reproduce_the_whole_frame(hip_lib):
 
 @pytest.mark.parametrize("world", [2, 4, 8])
 def test_config3_and_4_tile_lists_reproduce_the_whole_frame(hip_lib, world):
-    """Configs 3 (RTAO 64 spp, here with the reference's triangle tubes for the AO rays) and 4 (PPLL, transparent) at full size,
-    sharded for 2 / 4 / 8 ranks."""
+    """Configs 3 (RTAO 64 spp with the reference's triangle tubes for the AO rays + literal roots in the colour pass: the mode
+    bench.py times as the headline; with the capsules for 8 ranks too) and 4 (PPLL of the rasterised prism, transparent) at full
+    size, sharded for 2 / 4 / 8 ranks."""
     tr = scenes.normalize(scenes.tornado())
     flow = host_api.LineDataFlow().set_trajectories(tr.positions, tr.attributes, tr.line_offsets)
     pts, seg, _ = flow.tube_aabb_render_data(0.002)
     c4 = Case(pts, seg, tfm.standard_transparent(), 1920, 1080, 0.002)
     _all_tile_lists_reproduce_the_whole_frame(c4, 2, world, 0.0)
+    mesh = flow.tube_triangle_render_data(0.002, 6)
+    c3t = Case(pts, seg, tfm.standard(), 1920, 1080, 0.002, **RTAO, ambient_occlusion_iterations=1,
+               ambient_occlusion_samples_per_frame=64, rtao_geometry="triangle_tubes")
+    whole = _all_tile_lists_reproduce_the_whole_frame(c3t, 11, world, 64.0, mesh=mesh)
+    assert (whole[..., :3] != 255).any(axis=2).sum() > 200000
     if world == 8:
         c3 = Case(pts, seg, tfm.standard(), 1920, 1080, 0.002, **RTAO, ambient_occlusion_iterations=1,
                   ambient_occlusion_samples_per_frame=64)
-        _all_tile_lists_reproduce_the_whole_frame(c3, 11, world, 64.0)
+        assert not np.array_equal(_all_tile_lists_reproduce_the_whole_frame(c3, 11, world, 64.0), whole)
 
 
 def test_command_line_renderer(hip_lib, tmp_path):

@@ -92,6 +92,57 @@ def test_multi_handle_reproduces_the_single_device_frame(hip_lib, devices, trans
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("devices", [[0, 0], [0, 0, 0, 0]])
+def test_multi_handle_with_the_reference_rtao_geometry(hip_lib, devices):
+    """the mode bench.py times as the headline (rtao_geometry = triangle_tubes, literal roots in the colour pass) through
+    lv_create_multi over the memcpy transport: the single-device frame byte for byte, also after a cost-weighted re-deal"""
+    from test_gpu_triangle_tubes import mesh_of
+    from linevis_amd import scenes
+    tr = scenes.normalize(scenes.random_curves(n_lines=40, points_per_line=40, seed=7))
+    lw = 0.012
+    from common import scene_arrays, Case
+    from linevis_amd import transfer_function as tfm
+    pts, seg = scene_arrays(tr, lw)
+    c = Case(pts, seg, tfm.standard(), 200, 136, lw, rtao_geometry="triangle_tubes", **RTAO)
+    mesh = mesh_of(tr, lw)
+    single = c.hip_context()
+    single.set_tube_triangle_mesh(*mesh)
+    want = single.render(11)
+    multi = _setup(capi.Context(devices=devices, transport="memcpy"), c)
+    multi.set_tube_triangle_mesh(*mesh)
+    assert np.array_equal(multi.render(11), want)
+    multi.rebalance()
+    assert np.array_equal(multi.render(11), want)
+    assert np.array_equal(multi.render(11, tile=(37, 21, 90, 70)), want[21:91, 37:127])
+    assert multi.stats().num_tube_triangles == len(mesh[0])
+    multi.close()
+
+
+@pytest.mark.gpu
+def test_multi_handle_with_a_bad_device_ordinal_fails_cleanly(hip_lib):
+    """lv_create fails for rank 1 -> lv_create_multi must return an error, not walk unsized per-rank arrays"""
+    with pytest.raises(capi.LineVisError):
+        capi.Context(devices=[0, 999], transport="memcpy")
+    with pytest.raises(capi.LineVisError):
+        capi.Context(devices=[999], transport="memcpy")
+
+
+@pytest.mark.gpu
+def test_idle_ranks_keep_their_temporal_state_in_step(hip_lib):
+    """a rank that owns no tile of a frame (fewer tiles than ranks) must still advance its SVGF / progressive state:
+    4 ranks render ONE tile, then the full frame with SVGF -> the single-device sequence byte for byte."""
+    settings = dict(RTAO, ambient_occlusion_denoiser="SVGF", ambient_occlusion_iterations=1)
+    c = small_case(width=200, height=136, n_lines=40, pts_per_line=40, line_width=0.012, **settings)
+    single = c.hip_context()
+    multi = _setup(capi.Context(devices=[0, 0, 0, 0], transport="memcpy"), c)
+    for tile in ((64, 64, 64, 64), None, (0, 0, 64, 64), None, None):
+        a = single.render(11, tile=tile) if tile else single.render(11)
+        b = multi.render(11, tile=tile) if tile else multi.render(11)
+        assert np.array_equal(a, b), tile
+    multi.close()
+
+
+@pytest.mark.gpu
 def test_multi_handle_forwards_setters_and_reports_rank_errors(hip_lib):
     c = small_case(width=96, height=64)
     multi = _setup(capi.Context(devices=[0, 0, 0], transport="memcpy"), c)
