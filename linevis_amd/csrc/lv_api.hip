@@ -587,7 +587,7 @@ int lv_set_option(lv_ctx* ctx, const char* key, const char* value) {
         o.treeletLeaves = t;
     } else if (k == "accel_build") {
         // the analogue of the reference's VK_BUILD_ACCELERATION_STRUCTURE_PREFER_FAST_TRACE_BIT_KHR (LineData.cpp:740-741): "fast_trace"
-        // (default) rebuilds the LBVH's subtrees of <= 256 leaves with a binned SAH, "fast_build" keeps the plain LBVH
+        // (default) rebuilds the LBVH's subtrees of <= treelet_leaves (512) leaves with a binned SAH, "fast_build" keeps the plain LBVH
         bool ft;
         if (std::string(value) == "fast_trace") ft = true;
         else if (std::string(value) == "fast_build") ft = false;

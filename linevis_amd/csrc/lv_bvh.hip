@@ -232,13 +232,14 @@ __global__ __launch_bounds__(LV_BLOCK) void k_karras(const uint64_t* __restrict_
 // ---------------------------------------------------------------- treelet rebuild (accel_build = fast_trace)
 // The reference asks its driver for VK_BUILD_ACCELERATION_STRUCTURE_PREFER_FAST_TRACE (LineData.cpp:740-741,903,942,980): build time
 // is spent on trace speed.  Here: Morton order decides which leaves belong together down to subtrees of at most `treelet_leaves`
-// (256) leaves, and every such subtree is rebuilt by ONE WAVE with a binned surface-area heuristic (16 bins per axis on the box centres,
+// (default 512, option treelet_leaves 3 ... 4096) leaves, and every such subtree is rebuilt by ONE WAVE with a binned surface-area heuristic (16 bins per axis on the box centres,
 // boxes and counts in LDS, the best of the 45 planes, stable partition, smaller half first).  The Karras numbering makes it an in-place
 // operation: a subtree over the sorted leaves lo ... hi owns the internal nodes lo + 1 ... hi - 1 and its root (lo or hi), so the new
 // topology is written into the old slots (the subtree's root keeps its index -- its parent points there) and refit / collapse run unchanged.
 // Measured on the CPU model first (tools/bvhlab, hyb256 with 16 bins): - 5.7 % node steps per AO ray on config 3's capsules,
 // - 7.2 % on its triangle tubes; closest hits do not depend on the topology.
-// (the treelet size is a run-time value, treelet_leaves <= 1024: 32 bytes of LDS per leaf)
+// (the treelet size is a run-time value: 32 bytes of dynamic LDS per leaf, i.e. 128 KB for 4096 leaves -- clamped at launch time to
+// what hipDeviceAttributeMaxSharedMemoryPerBlock of the device allows)
 #define LV_TREELET_BINS 16u
 
 __global__ __launch_bounds__(LV_BLOCK) void k_treelet_roots(uint32_t nInternal, const uint32_t* __restrict__ childL,
@@ -745,6 +746,13 @@ static int lv_bvh_build_core(lv_ctx* ctx, uint32_t n, LvDeviceBuffer& nodesOut, 
             const uint32_t numTreelets = pin[0];
             if (numTreelets) {
                 const size_t ldsBytes = size_t(ctx->opt.treeletLeaves) * 32;
+                int maxLds = 0;
+                LV_HIPF(hipDeviceGetAttribute(&maxLds, hipDeviceAttributeMaxSharedMemoryPerBlock, ctx->device));
+                if (ldsBytes > size_t(maxLds)) {
+                    freeAll();
+                    return lv_fail(ctx, LV_E_INVALID, "treelet_leaves = %u needs %zu bytes of LDS per workgroup, the device has %d",
+                                   ctx->opt.treeletLeaves, ldsBytes, maxLds);
+                }
                 if (ldsBytes > 48 * 1024) // beyond the default limit of dynamic LDS (gfx950: 160 KB per workgroup)
                     LV_HIPF(hipFuncSetAttribute((const void*)k_treelet_rebuild, hipFuncAttributeMaxDynamicSharedMemorySize, int(ldsBytes)));
                 k_treelet_rebuild<<<numTreelets, 64, ldsBytes, st>>>(

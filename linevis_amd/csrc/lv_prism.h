@@ -40,8 +40,9 @@
 //                   the SAME triangle's attribute planes at their own pixel centre (weights of their own ray, outside [0, 1] if need
 //                   be), then the shader's ribbonPosition of the interpolated inputs
 // Pipeline (each stage at full wave width on its own queue): A capsule pre-test (32 B per candidate) -> B coverage mask of the 2 N
-// triangles (64 B more) [both inside the all-hits walk, k_ppll_gather<LV_PRIM_PRISM>] -> 8-B records through HBM -> C fragment stage,
-// one lane per covered triangle (k_ppll_shade_prism, lv_shade_prism) incl. the three `kept` rules.
+// triangles (64 B more) [both inside the all-hits walk, k_ppll_gather<LV_PRIM_PRISM>, which also gives every covered triangle its
+// node and links it: the node's first two words carry {pixel, leaf | triangle << 26} through HBM] -> C fragment stage, one lane per
+// node (k_ppll_shade_prism, lv_shade_prism) incl. the three `kept` rules, replacing the two words by {colour, depth}.
 #pragma once
 
 #include "lv_device.h"

@@ -63,7 +63,7 @@ def test_tie_break_lowest_segment(hip_lib):
 
 
 @pytest.mark.parametrize("build", [dict(), dict(accel_build="fast_build"), dict(treelet_leaves=3), dict(treelet_leaves=7),
-                                   dict(treelet_leaves=64), dict(treelet_leaves=1024)])
+                                   dict(treelet_leaves=64), dict(treelet_leaves=1024), dict(treelet_leaves=4096)])
 def test_lbvh_structure(hip_lib, build):
     """default = fast_trace (every subtree of <= 512 leaves rebuilt by the binned SAH: here the 2940 segments form a handful of
     treelets); 1024 >= n / 3 exercises big treelets, 3 and 7 the smallest ones, fast_build the plain LBVH"""
