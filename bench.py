@@ -37,7 +37,7 @@ LINE_WIDTH = 0.002
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E vendor peak (MI355X_MICROARCH.md; ~6.3 TB/s attainable)
 L2_PEAK_GBS = 34500.0     # aggregate L2 bandwidth (MI355X_MICROARCH.md "L2")
 NUM_CUS, NUM_SIMDS = 256, 1024
-PROFILE_TAGS = ("r03", "r02")   # counter files of the newest round that has them (profiles/pmc_<tag>_<workload>.json)
+PROFILE_TAGS = ("r04", "r03", "r02")   # counter files of the newest round that has them (profiles/pmc_<tag>_<workload>.json)
 CLOCK_GHZ = 2.4                  # MI355X peak engine clock (MI355X_MICROARCH.md)
 SETTINGS = {
     "ambient_occlusion_mode": "RTAO (Screen Space)", "ambient_occlusion_strength": 1.0,
@@ -216,14 +216,26 @@ def _stats(x):
 
 
 def roofline(kernel, pmc_key, ms_launch, algorithmic_bytes, world):
-    """Every candidate ceiling of the dominant kernel: PMC counters of profiles/pmc_<tag>_<workload>.json (collected with
-    tools/pmc_collect.sh on this build, one pass per counter group) x the launch time measured in THIS run; the VALU and
-    vector-L1 ceilings are the rates measured by tools/ubench/ on the same hardware (profiles/ubench_<tag>.json)."""
+    """Roofline of the dominant kernel (north_star: "achieved fraction of the HBM roofline").
+
+    Top level, HBM: `achieved` = bytes that left the L2s per launch (PMC counters of profiles/pmc_<tag>_<workload>.json, gfx950
+    correction 2 x FETCH_SIZE + WRITE_SIZE, Infinity-Cache hits included: an upper bound on HBM traffic) / the launch time measured
+    live in THIS run, against the 8 TB/s vendor peak = `frac` = `hbm_frac`.  The kernels of this path are NOT bandwidth-bound (L1 /
+    L2 serve most node and primitive fetches): the ceiling that binds is VALU issue, reported beside it as `valu_frac_datasheet`
+    (wave-instructions against one wave64 VALU instruction per 2 cycles per SIMD at 2.4 GHz), `lane_utilisation`, and
+    `valu_frac_own_mix` (against the issue rate tools/ubench measured for the node step's instruction mix on this hardware).
+    SURVEY.md 8(d)'s byte MODEL ("every touch goes to memory") is kept as `algorithmic_bytes_per_launch` with its rate named
+    `algorithmic_touch_rate_GBs`: it counts cache hits as memory traffic, exceeds the HBM peak and is not a bandwidth.
+    `pmc_head` / `pmc_source_sha`: the commit and source hash the counters were collected on; `pmc_matches_build` compares the hash with
+    the tree this run uses."""
+    from linevis_amd import build as lv_build
+    sha = lv_build.source_sha()
     out = {"kernel": kernel, "ms_per_launch": round(ms_launch, 4), "algorithmic_bytes_per_launch": int(algorithmic_bytes),
-           "algorithmic_GBs": round(algorithmic_bytes / (ms_launch * 1e-3) / 1e9, 1) if ms_launch > 0 else None,
+           "algorithmic_touch_rate_GBs": round(algorithmic_bytes / (ms_launch * 1e-3) / 1e9, 1) if ms_launch > 0 else None,
            "algorithmic_note": "SURVEY.md 8(d) byte model: 64 B per node visited + 32/48 B per primitive tested + per-pixel records, "
-                               "'every touch goes to memory'; most of these bytes are served by L1/L2 (see ceilings), so this rate "
-                               "is NOT bounded by the HBM peak"}
+                               "'every touch goes to memory'; most of these bytes are served by L1/L2 (see ceilings): NOT a "
+                               "bandwidth and not bounded by the HBM peak",
+           "source_sha": sha}
     ppath = upath = None
     for tag in PROFILE_TAGS:
         c1 = os.path.join(ROOT, "profiles", "pmc_%s_%s.json" % (tag, pmc_key))
@@ -232,33 +244,36 @@ def roofline(kernel, pmc_key, ms_launch, algorithmic_bytes, world):
         c2 = os.path.join(ROOT, "profiles", "ubench_%s.json" % tag)
         if upath is None and os.path.exists(c2):
             upath = c2
+    none = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None, "hbm_frac": None,
+            "valu_frac_datasheet": None, "lane_utilisation": None, "valu_frac_own_mix": None, "pmc_head": None,
+            "pmc_matches_build": False}
     if world != 1 or ppath is None or upath is None or ms_launch <= 0:
-        out.update({"bound": None, "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
-                    "note": "ceilings need profiles/pmc_<tag>_%s.json + profiles/ubench_<tag>.json (tags %s) and a 1-GPU run"
-                            % (pmc_key, "/".join(PROFILE_TAGS))})
+        out.update(none)
+        out["note"] = ("counter-backed figures need profiles/pmc_<tag>_%s.json + profiles/ubench_<tag>.json (tags %s) and a 1-GPU run"
+                       % (pmc_key, "/".join(PROFILE_TAGS)))
         return out
     pmc = json.load(open(ppath))
     ub = json.load(open(upath))
     kname = [k for k in pmc["kernels"] if k.startswith((kernel + "<", kernel + "_mlat<")) or k == kernel]
     if not kname:
-        out.update({"bound": None, "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
-                    "note": "kernel %s not in %s" % (kernel, os.path.basename(ppath))})
+        out.update(none)
+        out["note"] = "kernel %s not in %s" % (kernel, os.path.basename(ppath))
         return out
     c = max((pmc["kernels"][k] for k in kname), key=lambda d: d.get("SQ_INSTS_VALU", 0.0))   # the instantiation that ran
     t_ns = ms_launch * 1e6
     ceil = {}
-    # VALU issue: wave-instructions per SIMD per ns against the rate the VALU sustains on the node step's instruction mix
+    # VALU issue: wave-instructions per SIMD per ns against (a) the datasheet issue rate, (b) the rate the VALU sustains on the node
+    # step's instruction mix (tools/ubench/valu_rates: plain VALU instructions issue every ~3.5-4.1 cycles, only v_pk_fma_f32 reaches
+    # the datasheet's two FMAs per 4 cycles; the kernel's compare / select / convert mix cannot be packed)
     valu_rate = c["SQ_INSTS_VALU"] / NUM_SIMDS / t_ns
     valu_peak = 1.0 / ub["valu_ns_per_inst_per_simd"]["node_step_mix"]
-    ceil["valu_issue"] = {"achieved": round(valu_rate, 4), "peak": round(valu_peak, 4), "unit": "wave-instructions/SIMD/ns",
-                          "frac": round(valu_rate / valu_peak, 4),
-                          "lane_utilisation": round(c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"]), 4),
-                          # the same count against the datasheet issue rate (one wave64 v_fma_f32 per 2 cycles per SIMD = the 157 TFLOP/s
-                          # vector peak of MI355X_MICROARCH.md): measured here, plain VALU instructions issue every ~3.5-4.1 cycles and only
-                          # v_pk_fma_f32 (two FMAs in 4.2 cycles) reaches that peak -- the kernel's compare / select / convert mix cannot
-                          # be packed, so `frac` (own mix ceiling) is the binding number and this one the distance to the marketing peak
-                          "frac_vs_datasheet_issue": round(valu_rate * 2.0 / CLOCK_GHZ, 4),
-                          "source": "SQ_INSTS_VALU / 1024 SIMDs / launch time; peak = tools/ubench/valu_rates 'node-step mix'"}
+    lane_util = c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"])
+    ceil["valu_issue"] = {"achieved": round(valu_rate, 4), "unit": "wave-instructions/SIMD/ns",
+                          "peak_datasheet": round(CLOCK_GHZ / 2.0, 4), "frac_datasheet": round(valu_rate * 2.0 / CLOCK_GHZ, 4),
+                          "peak_own_mix": round(valu_peak, 4), "frac_own_mix": round(valu_rate / valu_peak, 4),
+                          "lane_utilisation": round(lane_util, 4),
+                          "source": "SQ_INSTS_VALU / 1024 SIMDs / launch time; datasheet = one wave64 VALU instruction per 2 cycles per "
+                                    "SIMD at 2.4 GHz (the 157 TFLOP/s vector peak); own mix = tools/ubench/valu_rates 'node-step mix'"}
     # vector L1: lane requests per CU per ns against the all-hit rate of divergent dwordx4 gathers
     tcp_rate = c["TCP_TOTAL_CACHE_ACCESSES_sum"] / NUM_CUS / t_ns
     tcp_peak = ub["tcp_lane_requests_per_cu_per_ns"]["own64_l1_hit"]
@@ -277,11 +292,20 @@ def roofline(kernel, pmc_key, ms_launch, algorithmic_bytes, world):
     ceil["hbm"] = {"achieved": round(hbm_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_gbs / HBM_PEAK_GBS, 4),
                    "source": "(2 x FETCH_SIZE + WRITE_SIZE) x 1024 / launch time (MI355X_MICROARCH.md HBM: gfx950 FETCH_SIZE "
                              "counts 128-B requests as 64 B; Infinity-Cache hits are included, so this is an upper bound on HBM)"}
-    bound = max(ceil, key=lambda k: ceil[k]["frac"])
-    out.update({"bound": bound, "achieved": ceil[bound]["achieved"], "peak": ceil[bound]["peak"], "unit": ceil[bound]["unit"],
-                "frac": ceil[bound]["frac"], "frac_vs_datasheet_issue": ceil["valu_issue"]["frac_vs_datasheet_issue"],
-                "traffic": int(traffic), "ceilings": ceil,
-                "pmc_file": os.path.relpath(ppath, ROOT), "ubench_file": os.path.relpath(upath, ROOT)})
+    fracs = {"hbm": ceil["hbm"]["frac"], "l2": ceil["l2"]["frac"], "vector_l1": ceil["vector_l1"]["frac"],
+             "valu_issue": ceil["valu_issue"]["frac_own_mix"]}
+    pmc_sha = pmc.get("source_sha")
+    out.update({"bound": "hbm", "achieved": ceil["hbm"]["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ceil["hbm"]["frac"],
+                "traffic": int(traffic), "hbm_frac": ceil["hbm"]["frac"],
+                "valu_frac_datasheet": ceil["valu_issue"]["frac_datasheet"], "lane_utilisation": ceil["valu_issue"]["lane_utilisation"],
+                "valu_frac_own_mix": ceil["valu_issue"]["frac_own_mix"],
+                "binding_ceiling": max(fracs, key=lambda k: fracs[k]),
+                "traffic_over_algorithmic": round(traffic / algorithmic_bytes, 4) if algorithmic_bytes else None,
+                "ceilings": ceil, "pmc_file": os.path.relpath(ppath, ROOT), "ubench_file": os.path.relpath(upath, ROOT),
+                "pmc_head": pmc.get("git_head"), "pmc_source_sha": pmc_sha, "pmc_matches_build": bool(pmc_sha) and pmc_sha == sha})
+    if not out["pmc_matches_build"]:
+        out["pmc_warning"] = ("the counters of %s were collected on another build of the kernels (source hash %s, this tree %s): the "
+                              "counter-backed fractions combine two builds" % (os.path.basename(ppath), pmc_sha, sha))
     return out
 
 
@@ -355,6 +379,15 @@ def main_one_process(args):
     elapsed = time.perf_counter() - t0
     gc.enable()
     deal = ctx.deal()
+    per_rank = [ctx.rank_stats(r) for r in range(args.gpus)]
+    multi = {"ranks_observed": int(ctx.num_ranks), "transport": args.transport,
+             "tiles_per_rank": [int((deal == r).sum()) for r in range(args.gpus)],
+             "render_ms_per_rank": [round(float(s.ms_total), 4) for s in per_rank],
+             "ao_ms_per_rank": [round(float(s.ms_ao), 4) for s in per_rank],
+             "colour_ms_per_rank": [round(float(s.ms_color + s.ms_ppll_gather + s.ms_ppll_resolve), 4) for s in per_rank],
+             "gather_ms_estimate": round(elapsed / args.steps * 1e3 - max(float(s.ms_total) for s in per_rank), 4),
+             "note": "render_ms = the last frame's lv_frame_render of each rank on its own stream (HIP events); gather_ms_estimate = "
+                     "wall time per frame - the slowest rank's render (gather + scatter kernel + host queueing)"}
     result = {"metric": "Mrays/s", "value": round(rays * args.steps / elapsed / 1e6, 2), "unit": "Mrays/s", "n_gpus": args.gpus,
               "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
               "fps": round(args.steps / elapsed, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
@@ -363,6 +396,7 @@ def main_one_process(args):
                          "parallelism": "ONE process, lv_create_multi over %d device(s): 64x64 screen tiles in Morton order dealt by measured "
                                         "cost, one %s gather per frame inside the library" % (args.gpus, args.transport),
                          "tiles_per_rank": [int((deal == r).sum()) for r in range(args.gpus)]},
+              "multi_gpu": multi,
               "roofline": {"bound": None, "note": "per-kernel ceilings are reported by the default (one process per GPU) mode"},
               "cpu_baseline": None}
     print(json.dumps(result), flush=True)
@@ -606,6 +640,37 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
         st = ctx.stats()
+        # ---- N > 1: three untimed diagnostic frames, one at a time, so that the first SCALE record explains itself: per rank the
+        # time to render its tiles, the time it spends in the gather, the tiles it owns, and what torch.distributed reports
+        diag = None
+        if world > 1:
+            rec = []
+            for _ in range(3):
+                sync_all()
+                dist.barrier()
+                t_a = time.perf_counter()
+                sf.render_local(render_fn)
+                sync_all()
+                t_b = time.perf_counter()
+                sf.gather()
+                sync_all()
+                t_c = time.perf_counter()
+                sf.assemble_device()
+                sync_all()
+                t_d = time.perf_counter()
+                rec.append([(t_b - t_a) * 1e3, (t_c - t_b) * 1e3, (t_d - t_c) * 1e3])
+            mine = [float(np.median([r[k] for r in rec])) for k in range(3)] + [float(len(sf.local_tiles))]
+            allr = [None] * world
+            dist.all_gather_object(allr, mine)
+            diag = {"ranks_observed": int(dist.get_world_size()), "backend": str(dist.get_backend()),
+                    "tiles_per_rank": [int(a[3]) for a in allr],
+                    "render_ms_per_rank": [round(a[0], 4) for a in allr],
+                    "gather_ms_per_rank": [round(a[1], 4) for a in allr],
+                    "assemble_ms_rank0": round(allr[0][2], 4),
+                    "gather_bytes_per_rank": int(sf.out.numel()), "frames_in_flight_timed": frames_in_flight,
+                    "note": "medians of 3 untimed frames rendered ONE AT A TIME (host-synchronised between render, gather and "
+                            "de-tiling; the timed frames overlap these phases and keep frames_in_flight frames queued); gather_ms of a "
+                            "rank includes waiting for the slowest rank's render"}
         frame_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(len(marks) - 1)] if marks else []
         kernels = {}
         if not dry:
@@ -616,7 +681,7 @@ def main():
         del extra
         return dict(ctx=ctx, frame=frame, elapsed=elapsed, rays_per_frame=rays_per_frame, counters=counters, local=local,
                     kernel_bytes=kernel_bytes, frame_bytes=frame_bytes, kernels=kernels, frame_ms=_stats(frame_ms),
-                    build_ms=build_ms, build_first_ms=build_first_ms, st=st, wkey=wkey)
+                    build_ms=build_ms, build_first_ms=build_first_ms, st=st, wkey=wkey, diag=diag)
 
     head = measure(wl, args.workload)
     also = None
@@ -649,6 +714,8 @@ def main():
             "counters_rank0": head["local"],
             "roofline": roofline(kname, wl.get("pmc", args.workload), ms_launch, head["kernel_bytes"], world),
         }
+        if head.get("diag"):
+            result["multi_gpu"] = head["diag"]
         result["roofline"]["frame_algorithmic_bytes_rank0"] = int(head["frame_bytes"])
         if seg is not None:   # compulsory floor: every node, primitive record and line point once + the outputs
             result["roofline"]["frame_compulsory_bytes"] = int(st.num_nodes * 64 + len(seg) * 32 + len(pts) * 48 + W * H * (4 + 4)

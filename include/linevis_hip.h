@@ -274,6 +274,9 @@ int lv_render_tiles_device(lv_ctx* ctx, int rendering_mode, const uint32_t* tile
  * functions (costs == NULL: round robin). */
 lv_ctx* lv_create_multi(const int* device_ordinals, int num_devices, const char* transport, int* err);
 int lv_multi_ranks(const lv_ctx* ctx);
+/* lv_get_stats of ONE rank of a multi-device handle (its own counters, phase times and kernel timings, nothing summed): what a
+ * scaling run needs to see which rank a frame waited for.  rank 0 = the handle's own device; a single-device context has rank 0 only. */
+int lv_multi_rank_stats(lv_ctx* ctx, int rank, lv_stats* out);
 int lv_multi_rebalance(lv_ctx* ctx, double base_cost_per_tile);
 int lv_multi_deal(lv_ctx* ctx, uint32_t* out_owner, uint32_t capacity, uint32_t* out_count);
 int lv_tile_deal(const double* costs, uint32_t num_tiles, uint32_t num_ranks, uint32_t* out_owner);

@@ -21,6 +21,19 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
          "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-DNDEBUG"] + os.environ.get("LV_EXTRA_HIPCC_FLAGS", "").split()
 
 
+def source_sha():
+    """Content hash of everything the HIP library is built from (kernels, headers, C-ABI header, this file's flags): profiles record
+    it at collection time and bench.py compares it with the tree it runs on, so that a roofline is never stitched from two builds."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h")))
+    files += [os.path.join(HERE, "..", "include", "linevis_hip.h"), os.path.abspath(__file__)]
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def hipcc():
     for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if c and os.path.exists(c):

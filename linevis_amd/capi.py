@@ -86,7 +86,7 @@ SYMBOLS = ["lv_create", "lv_destroy", "lv_last_error", "lv_version", "lv_set_str
            "lv_compute_depth_range", "lv_get_ao", "lv_ppll_get_buffers", "lv_ppll_resolve_buffers", "lv_get_accel",
            "lv_set_tube_triangle_mesh", "lv_trace_rays_triangles", "lv_set_flow_grid", "lv_trace_streamlines",
            "lv_get_streamlines", "lv_get_streamline_seed_indices", "lv_set_ao_parametrization", "lv_get_baked_ao", "lv_get_mlat_trace",
-           "lv_create_multi", "lv_multi_ranks", "lv_multi_rebalance", "lv_multi_deal", "lv_tile_deal", "lv_make_tiles"]
+           "lv_create_multi", "lv_multi_ranks", "lv_multi_rank_stats", "lv_multi_rebalance", "lv_multi_deal", "lv_tile_deal", "lv_make_tiles"]
 
 _lib = None
 
@@ -126,6 +126,7 @@ def load():
     L.lv_make_tiles.argtypes = [u32, u32, u32, u32, u32, vp, u32]
     for name, args in [
         ("lv_multi_rebalance", [vp, C.c_double]),
+        ("lv_multi_rank_stats", [vp, i32, vp]),
         ("lv_multi_deal", [vp, vp, u32, C.POINTER(u32)]),
         ("lv_tile_deal", [vp, u32, u32, vp]),
         ("lv_set_stream", [vp, vp]),
@@ -409,6 +410,12 @@ class Context:
         if n.value:
             self._ck(self.L.lv_get_dispatch_order(self.h, _p(order), _p(cost), n.value, C.byref(n)))
         return order, cost
+
+    def rank_stats(self, rank):
+        """lv_stats of one rank of a multi-device handle (nothing summed)."""
+        s = Stats()
+        self._ck(self.L.lv_multi_rank_stats(self.h, int(rank), C.byref(s)))
+        return s
 
     def ppll_buffers(self, padded_pixels, max_nodes):
         # the library's physical pool may exceed the logical linkedListSize (chunk tails / sub-pools of the gather): room for it

@@ -682,7 +682,7 @@ int lv_render(lv_ctx* ctx, int mode, uint32_t x0, uint32_t y0, uint32_t w, uint3
     return LV_OK;
 }
 
-int lv_get_stats(lv_ctx* ctx, lv_stats* out) {
+static int lv_get_stats_impl(lv_ctx* ctx, lv_stats* out, bool aggregate) {
     if (!ctx || !out) return LV_E_INVALID;
     (void)hipSetDevice(ctx->device);
     LV_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -745,9 +745,9 @@ int lv_get_stats(lv_ctx* ctx, lv_stats* out) {
     s.device_bytes = bytes;
     *out = s;
     // a multi-device handle reports the work of all its ranks (counters and memory summed; times are rank 0's)
-    for (int r = 1; r < lv_multi_num_ranks(ctx); r++) {
+    for (int r = 1; aggregate && r < lv_multi_num_ranks(ctx); r++) {
         lv_stats ps;
-        const int rc = lv_get_stats(lv_multi_rank(ctx, r), &ps);
+        const int rc = lv_get_stats_impl(lv_multi_rank(ctx, r), &ps, false);
         if (rc) return lv_fail(ctx, rc, "rank %d: %s", r, lv_multi_rank(ctx, r)->lastError.c_str());
         out->rays_traced += ps.rays_traced; out->nodes_visited += ps.nodes_visited; out->prims_tested += ps.prims_tested;
         out->hits_shaded += ps.hits_shaded; out->fragments += ps.fragments; out->ao_hit_pixels += ps.ao_hit_pixels;
@@ -758,6 +758,18 @@ int lv_get_stats(lv_ctx* ctx, lv_stats* out) {
     }
     (void)hipSetDevice(ctx->device);
     return LV_OK;
+}
+
+int lv_get_stats(lv_ctx* ctx, lv_stats* out) { return lv_get_stats_impl(ctx, out, true); }
+
+int lv_multi_rank_stats(lv_ctx* ctx, int rank, lv_stats* out) {
+    if (!ctx || !out) return LV_E_INVALID;
+    lv_ctx* c = lv_multi_rank(ctx, rank);
+    if (!c) return lv_fail(ctx, LV_E_INVALID, "rank %d of %d", rank, lv_multi_num_ranks(ctx));
+    const int rc = lv_get_stats_impl(c, out, false);
+    if (rc && c != ctx) return lv_fail(ctx, rc, "rank %d: %s", rank, c->lastError.c_str());
+    (void)hipSetDevice(ctx->device);
+    return rc;
 }
 
 int lv_reset_timers(lv_ctx* ctx) {

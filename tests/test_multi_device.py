@@ -68,6 +68,11 @@ def test_multi_handle_reproduces_the_single_device_frame(hip_lib, devices, trans
     multi.render(11); single.render(11)
     sm, ss = multi.stats(), single.stats()
     assert sm.rays_traced == ss.rays_traced and sm.ao_rays_traced == ss.ao_rays_traced and sm.ao_hit_pixels == ss.ao_hit_pixels
+    # ... and every rank's own share is readable (lv_multi_rank_stats): the shares add up, every rank rendered something
+    shares = [multi.rank_stats(r) for r in range(len(devices))]
+    assert sum(s.rays_traced for s in shares) == sm.rays_traced and all(s.rays_traced > 0 and s.ms_total > 0.0 for s in shares)
+    with pytest.raises(capi.LineVisError):
+        multi.rank_stats(len(devices))
     multi.set_option("collect_stats", False)
     # re-dealt by measured cost: another deal, the same bytes
     multi.rebalance()

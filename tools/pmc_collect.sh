@@ -56,7 +56,10 @@ for f in sorted(glob.glob("$OUT/$W.p*/**/p_counter_collection.csv", recursive=Tr
         agg[n][r["Counter_Name"]].append(float(r["Counter_Value"]))
         seen.add(r["Counter_Name"])
     passes.append(sorted(seen))
-out = {"workload": "$W", "collected_with": "rocprofv3 --pmc <group> --kernel-trace -- python bench.py --workload $W --steps 2 "
+import sys
+sys.path.insert(0, "$R")
+from linevis_amd import build as _lvb
+out = {"workload": "$W", "git_head": os.environ.get("LV_GIT_HEAD", "unknown"), "source_sha": _lvb.source_sha(), "collected_with": "rocprofv3 --pmc <group> --kernel-trace -- python bench.py --workload $W --steps 2 "
        "--warmup 1 --no-cpu-baseline; one pass per group; mean per launch", "passes": passes,
        "kernels": {n: {c: sum(v) / len(v) for c, v in cs.items()} for n, cs in agg.items()},
        "launches": {n: max(len(v) for v in cs.values()) for n, cs in agg.items()}}
