@@ -99,7 +99,7 @@ static std::vector<LvDeviceBuffer*> lv_all_buffers(lv_ctx* ctx) {
             &ctx->eawPing, &ctx->eawPong, &ctx->tilesHaloDev, &ctx->fullFrameTile, &ctx->svgf.normalDepth, &ctx->svgf.normalDepthHistory,
             &ctx->svgf.flowFwidth, &ctx->svgf.moments, &ctx->svgf.momentsHistory, &ctx->svgf.colorHistory, &ctx->svgf.tempAccum,
             &ctx->svgf.tempAccumFiltered, &ctx->svgf.ping, &ctx->svgf.pong, &ctx->svgf.result, &ctx->aoGbuf, &ctx->aoList, &ctx->aoSamples,
-            &ctx->counters, &ctx->ppllNodes, &ctx->ppllStart, &ctx->ppllCount, &ctx->ppllScratch, &ctx->tilesDev, &ctx->outDev,
+            &ctx->counters, &ctx->ppllNodes, &ctx->ppllStart, &ctx->ppllCount, &ctx->ppllScratch, &ctx->prismRecords, &ctx->scanTemp, &ctx->tilesDev, &ctx->outDev,
             &ctx->scratchRays, &ctx->stackOverflow, &ctx->triIdx, &ctx->triVerts, &ctx->triPoints, &ctx->triNodes, &ctx->tris,
             &ctx->flowVectors, &ctx->flowScalars, &ctx->flowMisc, &ctx->flowSeeds, &ctx->flowOutPos, &ctx->flowOutAtt, &ctx->flowCounts,
             &ctx->bakeBlendingWeights, &ctx->bakeSamplingLocations, &ctx->bakedAo, &ctx->bakeLcgSkip, &ctx->mlatTrace, &ctx->buildArena,
@@ -934,6 +934,39 @@ int lv_ppll_get_buffers(lv_ctx* ctx, uint32_t* out_nodes, uint64_t max_nodes, ui
     LvDevCountersHost hc;
     LV_HIP(ctx, hipMemcpy(&hc, ctx->counters.ptr, sizeof(hc), hipMemcpyDeviceToHost));
     if (out_frag_counter) *out_frag_counter = hc.fragCounter;
+    if (ctx->ppllArrays) {
+        // raster_prism frames keep every pixel's fragments as ONE contiguous run of 8-B {colour, depth} entries (offsets = exclusive
+        // scan of the per-pixel counts) instead of a linked list; the caller gets the reference's buffers (LinkedListHeader.glsl:
+        // 36-85): node index = position in the fragment array, `next` chains a pixel's live entries from the last one down -- the
+        // order the resolve pass reads them in, i.e. the list a push-to-front gather would have built.  Dead entries (discarded
+        // fragments) come out as unlinked nodes.
+        const uint64_t np = uint64_t(ctx->ppllPaddedW) * ctx->ppllPaddedH;
+        std::vector<uint32_t> cnt(np), off(np);
+        if (np) {
+            LV_HIP(ctx, hipMemcpy(cnt.data(), ctx->ppllCount.ptr, size_t(np) * 4, hipMemcpyDeviceToHost));
+            LV_HIP(ctx, hipMemcpy(off.data(), ctx->ppllStart.ptr, size_t(np) * 4, hipMemcpyDeviceToHost));
+        }
+        const uint64_t total = np ? uint64_t(off[np - 1]) + (cnt[np - 1] & 0xFFFFu) : 0u;
+        if (out_nodes && max_nodes < total) return lv_fail(ctx, LV_E_CAPACITY, "out_nodes holds %llu nodes, %llu stored",
+                                                           (unsigned long long)max_nodes, (unsigned long long)total);
+        if (out_start && max_pixels < np) return lv_fail(ctx, LV_E_CAPACITY, "out_start_offset holds %llu entries, need %llu",
+                                                         (unsigned long long)max_pixels, (unsigned long long)np);
+        std::vector<uint32_t> fr(size_t(total) * 2);
+        if (total) LV_HIP(ctx, hipMemcpy(fr.data(), ctx->ppllNodes.ptr, size_t(total) * 8, hipMemcpyDeviceToHost));
+        for (uint64_t p = 0; p < np; p++) {
+            const uint32_t n = cnt[p] & 0xFFFFu;
+            uint32_t prev = 0xFFFFFFFFu;
+            for (uint32_t j = 0; j < n; j++) {
+                const uint64_t idx = uint64_t(off[p]) + j;
+                const uint32_t c = fr[2 * idx], d = fr[2 * idx + 1];
+                const bool dead = c == 0u && d == LV_PPLL_DEAD;
+                if (out_nodes) { out_nodes[3 * idx] = c; out_nodes[3 * idx + 1] = d; out_nodes[3 * idx + 2] = dead ? 0xFFFFFFFFu : prev; }
+                if (!dead) prev = uint32_t(idx);
+            }
+            if (out_start) out_start[p] = prev;
+        }
+        return LV_OK;
+    }
     // node slots are handed out to waves in chunks (k_ppll_gather): copy up to the allocator's high-water mark
     uint64_t stored = hc.fragAlloc < ctx->ppllPoolNodes ? hc.fragAlloc : ctx->ppllPoolNodes;
     if (out_nodes) {
@@ -946,31 +979,6 @@ int lv_ppll_get_buffers(lv_ctx* ctx, uint32_t* out_nodes, uint64_t max_nodes, ui
         if (max_pixels < np) return lv_fail(ctx, LV_E_CAPACITY, "out_start_offset holds %llu entries, need %llu",
                                             (unsigned long long)max_pixels, (unsigned long long)np);
         LV_HIP(ctx, hipMemcpy(out_start, ctx->ppllStart.ptr, size_t(np) * 4, hipMemcpyDeviceToHost));
-    }
-    if (hc.prismDiscards && (out_nodes || out_start)) {
-        // raster_prism: fragments the fragment stage discarded sit in the device lists as dead nodes {0, LV_PPLL_DEAD} that the
-        // resolve pass steps over; the caller gets the reference's buffers (LinkedListHeader.glsl:36-85): unlink them in the copy
-        std::vector<uint32_t> tmpNodes, tmpStart;
-        uint32_t* nd = out_nodes;
-        uint32_t* so = out_start;
-        if (!nd) {
-            tmpNodes.resize(size_t(stored) * 3);
-            if (stored) LV_HIP(ctx, hipMemcpy(tmpNodes.data(), ctx->ppllNodes.ptr, size_t(stored) * 12, hipMemcpyDeviceToHost));
-            nd = tmpNodes.data();
-        }
-        if (!so) {
-            tmpStart.resize(size_t(np));
-            LV_HIP(ctx, hipMemcpy(tmpStart.data(), ctx->ppllStart.ptr, size_t(np) * 4, hipMemcpyDeviceToHost));
-            so = tmpStart.data();
-        }
-        for (uint64_t p = 0; p < np; p++) {
-            uint32_t* link = &so[p];
-            while (*link != 0xFFFFFFFFu && *link < stored) {
-                uint32_t* n = nd + 3 * size_t(*link);
-                if (n[0] == 0u && n[1] == LV_PPLL_DEAD) *link = n[2];
-                else link = &n[2];
-            }
-        }
     }
     return LV_OK;
 }

@@ -30,6 +30,9 @@
 #ifndef LV_GATHER_MIN_WAVES
 #define LV_GATHER_MIN_WAVES 1
 #endif
+#ifndef LV_NODE_MIX
+#define LV_NODE_MIX 0            // node step: child planes as binary16 halves through v_perm_b32 + v_fma_mix_f32 (lv_slab_h)
+#endif
 #ifndef LV_PRISM_MIN_WAVES
 #define LV_PRISM_MIN_WAVES 3    // k_ppll_gather<LV_PRIM_PRISM>: waves per SIMD the register allocator leaves room for
 #endif

@@ -175,6 +175,8 @@ struct lv_ctx {
     LvDeviceBuffer aoGbuf, aoList, aoSamples; // RTAO wavefront buffers
     LvDeviceBuffer counters;                  // device counters (LvCounters + misc)
     LvDeviceBuffer ppllNodes, ppllStart, ppllCount, ppllScratch;
+    LvDeviceBuffer prismRecords, scanTemp;    // raster_prism: {pixel, leaf | triangle, rank} records of the coverage kernel; rocPRIM scan storage
+    bool ppllArrays = false;                  // the last PPLL frame left per-pixel runs (raster_prism), not linked lists
     LvDeviceBuffer tilesDev, outDev, scratchRays, stackOverflow, mlatTrace;
     LvDeviceBuffer accum;                     // rgba8 of the previous accumulated frame (full viewport)
     uint32_t* pinned = nullptr;               // 64 B of pinned host memory for small read-backs (hipHostMalloc)
@@ -242,6 +244,7 @@ void lv_buf_free(LvDeviceBuffer& b);
 // lv_bvh.hip
 int lv_bvh_build(lv_ctx* ctx);
 int lv_bvh_build_triangles(lv_ctx* ctx);
+int lv_scan_exclusive_u32(lv_ctx* ctx, const uint32_t* in, uint32_t* out, size_t n);
 // lv_multi.hip: one frame over the GPUs of a node behind the same handle
 int lv_multi_create(lv_ctx* handle, const int* devices, int numDevices, const char* transport);
 void lv_multi_destroy(lv_ctx* handle);

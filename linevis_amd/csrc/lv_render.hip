@@ -936,6 +936,28 @@ __global__ __launch_bounds__(LV_BLOCK, PRIM == LV_PRIM_PRISM ? LV_PRISM_MIN_WAVE
         base = __shfl(base, leader, 64); left = __shfl(left, leader, 64); base2 = __shfl(base2, leader, 64);
         const unsigned rank = unsigned(__popcll(mask & ((1ull << lane) - 1ull)));
         const uint32_t insertIndex = rank < left ? base + rank : base2 + (rank - left);
+        if (PRIM == LV_PRIM_PRISM) {
+            // record {pixel, leaf | triangle << 26, rank}: rank = how many fragments the pixel had before this one, in the
+            // deterministic order of the owner's wave -- the pixel's fragments end up in ONE contiguous run of the fragment array
+            // (exclusive scan of the per-pixel counts -> offset; k_ppll_shade_prism writes to offset + rank), not in a linked list
+            // whose 12-B nodes are scattered over 128-B lines (the resolve pass fetched 5.8 x the bytes it used)
+            bool stored = false;
+            if (insertIndex < poolSlots) {
+                const uint32_t rk = atomicAdd(&s_count[waveBase + owner], 1u);
+                if (rk < 0xFFFFu) {
+                    nodes[3 * size_t(insertIndex) + 0] = word0;
+                    nodes[3 * size_t(insertIndex) + 1] = word1;
+                    nodes[3 * size_t(insertIndex) + 2] = rk;
+                    stored = true;
+                } else {   // (the per-pixel count shares its word with the count of discarded fragments: 16 bits each)
+                    atomicSub(&s_count[waveBase + owner], 1u);
+                    nodes[3 * size_t(insertIndex) + 0] = 0u;
+                    nodes[3 * size_t(insertIndex) + 1] = LV_PPLL_DEAD;
+                }
+            }
+            if (!stored) prismDropped++;   // no record: the fragment stage never sees it, but the reference's fragCounter counts it
+            return;
+        }
         atomicAdd(&s_count[waveBase + owner], 1u);
         if (insertIndex < poolSlots) {
             const uint32_t next = atomicExch(&s_head[waveBase + owner], insertIndex);
@@ -943,8 +965,6 @@ __global__ __launch_bounds__(LV_BLOCK, PRIM == LV_PRIM_PRISM ? LV_PRISM_MIN_WAVE
             nodes[3 * size_t(insertIndex) + 0] = word0;
             nodes[3 * size_t(insertIndex) + 1] = word1;
             nodes[3 * size_t(insertIndex) + 2] = next;
-        } else if (PRIM == LV_PRIM_PRISM) {
-            prismDropped++;   // no node: the fragment stage never sees it, but the reference's fragCounter counts it
         }
     }, [](unsigned) {});
     if (PRIM == LV_PRIM_PRISM) {
@@ -956,7 +976,10 @@ __global__ __launch_bounds__(LV_BLOCK, PRIM == LV_PRIM_PRISM ? LV_PRISM_MIN_WAVE
     }
     const uint32_t numFrags = s_count[threadIdx.x];
     uint32_t total = 0;
-    if (px.inView && numFrags > 0u) {
+    if (PRIM == LV_PRIM_PRISM) {
+        // one slice, one workgroup per pixel: the count is final (k_ppll_clear zeroed the pixels without fragments)
+        if (px.inView && numFrags > 0u) fragCount[lv_ppll_addr(px.x, px.y, U.ppllPaddedW, U.ppllTileW, U.ppllTileH)] = numFrags;
+    } else if (px.inView && numFrags > 0u) {
         const uint32_t addr = lv_ppll_addr(px.x, px.y, U.ppllPaddedW, U.ppllTileW, U.ppllTileH);
         const uint32_t head = s_head[threadIdx.x], tail = s_tail[threadIdx.x];
         if (head != 0xFFFFFFFFu) { // splice the partial list in front of what other slices linked so far
@@ -972,8 +995,8 @@ __global__ __launch_bounds__(LV_BLOCK, PRIM == LV_PRIM_PRISM ? LV_PRISM_MIN_WAVE
         sum += (uint32_t)__shfl_xor(sum, ofs, 64);
     }
     if (PRIM == LV_PRIM_PRISM) {
-        // fragCounter / maxDepthComplexity count KEPT fragments: the fragment stage adds the ones it keeps (and takes the ones it
-        // discards out of the per-pixel counts: the resolve pass reads their maximum), here only those that found no node
+        // fragCounter / maxDepthComplexity count KEPT fragments: the fragment stage adds the ones it keeps (and counts the ones it
+        // discards in the upper half of the pixel's count word: the resolve pass reads the maximum), here only those without a record
         sum = prismDropped;
 #pragma unroll
         for (int ofs = 32; ofs > 0; ofs >>= 1) sum += (uint32_t)__shfl_xor(sum, ofs, 64);
@@ -985,14 +1008,16 @@ __global__ __launch_bounds__(LV_BLOCK, PRIM == LV_PRIM_PRISM ? LV_PRISM_MIN_WAVE
     if (STATS) lv_flush_counters(cnt, dc);
 }
 
-// Fragment stage of ppll_fragment_source = raster_prism: one lane per node slot the coverage kernel (k_ppll_gather<LV_PRIM_PRISM>)
-// handed out, grid-stride over the pool -- LinePassGeometryShaderTubes.glsl:732-1129 on the perspective-correct inputs (lv_shade_prism)
-// + the store of gatherFragment (LinkedListGather.glsl:33-72): the node's {pixel, leaf | triangle << 26} become {colour, depth}.
-// The node is linked already; a fragment the shader discards (alpha < 0.001, :34) or the `kept` rules reject turns into a DEAD
-// node {0, LV_PPLL_DEAD} that the resolve pass steps over without counting it.  No atomics on the pool, none on the lists.
+// Fragment stage of ppll_fragment_source = raster_prism: one lane per record of the coverage kernel (k_ppll_gather<LV_PRIM_PRISM>),
+// grid-stride over the record pool -- LinePassGeometryShaderTubes.glsl:732-1129 on the perspective-correct inputs (lv_shade_prism) +
+// the store of gatherFragment (LinkedListGather.glsl:33-72): {colour, depth} goes to slot pixelOffset[pixel] + rank of the fragment
+// array, so that every pixel's fragments form one contiguous run in the order the coverage kernel met them.  A fragment the shader
+// discards (alpha < 0.001, :34) or the `kept` rules reject leaves a DEAD entry {0, LV_PPLL_DEAD} that the resolve pass steps over,
+// and is counted in the upper 16 bits of the pixel's count word.  No atomics on the pool, none per kept fragment.
 template <bool STATS>
 __global__ __launch_bounds__(LV_BLOCK, LV_PRISM_SHADE_MIN_WAVES) void k_ppll_shade_prism(const LvUniforms U, const LvSceneDev S,
-                                                                   uint32_t* __restrict__ nodes, uint32_t* __restrict__ fragCount,
+                                                                   const uint32_t* __restrict__ records, uint2* __restrict__ frags,
+                                                                   const uint32_t* __restrict__ pixelOffset, uint32_t* __restrict__ fragCount,
                                                                    LvDevCounters* dc, uint32_t poolSlots) {
     __shared__ float s_prismRing[2 * LV_PRISM_MAX_SUBDIV];
     if (threadIdx.x < LV_PRISM_MAX_SUBDIV) {   // ring table in LDS: the triangle a lane shades is a per-lane index
@@ -1004,11 +1029,11 @@ __global__ __launch_bounds__(LV_BLOCK, LV_PRISM_SHADE_MIN_WAVES) void k_ppll_sha
     const f3 o = mk3(U.camPos[0], U.camPos[1], U.camPos[2]);
     const float tLo = 0.0001f, tHi = __uint_as_float(__float_as_uint(1000.0f) + 1u); // the gather's ray interval [tMin, tMax]
     unsigned long long hits = 0;
-    uint32_t localSum = 0u;
+    uint32_t localSum = 0u, localDead = 0u;
     for (uint32_t base = blockIdx.x * LV_BLOCK; base < numSlots; base += gridDim.x * LV_BLOCK) {
         const uint32_t i = base + threadIdx.x;
         if (i >= numSlots) continue;
-        const uint32_t w0 = nodes[3 * size_t(i) + 0], w1 = nodes[3 * size_t(i) + 1];
+        const uint32_t w0 = records[3 * size_t(i) + 0], w1 = records[3 * size_t(i) + 1], rank = records[3 * size_t(i) + 2];
         if (w1 == LV_PPLL_DEAD) continue;   // slot of a chunk tail
         const uint32_t px = w0 & 0xFFFFu, py = w0 >> 16;
         const uint32_t leaf = w1 & 0x03FFFFFFu, tt = w1 >> 26;
@@ -1020,20 +1045,24 @@ __global__ __launch_bounds__(LV_BLOCK, LV_PRISM_SHADE_MIN_WAVES) void k_ppll_sha
         float depth;
         const f4 color = lv_shade_prism(S, U, s_prismRing, aoTexel, o, d, tLo, tHi, leaf, tt, rq, U.ppllRasterColour != 0u, depth, kept);
         if (STATS && kept) hits++;
+        const uint32_t addr = lv_ppll_addr(px, py, U.ppllPaddedW, U.ppllTileW, U.ppllTileH);
+        const size_t dst = size_t(pixelOffset[addr]) + rank;
         if (kept && color.w >= 0.001f) {   // gatherFragment: discard below, LinkedListGather.glsl:34
-            nodes[3 * size_t(i) + 0] = lv_pack_unorm4x8(color);
-            nodes[3 * size_t(i) + 1] = __float_as_uint(depth);
+            frags[dst] = make_uint2(lv_pack_unorm4x8(color), __float_as_uint(depth));
             localSum++;
         } else {
-            nodes[3 * size_t(i) + 0] = 0u;
-            nodes[3 * size_t(i) + 1] = LV_PPLL_DEAD;
-            atomicSub(&fragCount[lv_ppll_addr(px, py, U.ppllPaddedW, U.ppllTileW, U.ppllTileH)], 1u);
-            atomicAdd(&dc->prismDiscards, 1u);   // (rare: lv_ppll_get_buffers unlinks the dead nodes from its copy if there are any)
+            frags[dst] = make_uint2(0u, LV_PPLL_DEAD);
+            atomicAdd(&fragCount[addr], 0x10000u);
+            localDead++;
         }
     }
 #pragma unroll
-    for (int ofs = 32; ofs > 0; ofs >>= 1) localSum += (uint32_t)__shfl_xor(localSum, ofs, 64);
+    for (int ofs = 32; ofs > 0; ofs >>= 1) {
+        localSum += (uint32_t)__shfl_xor(localSum, ofs, 64);
+        localDead += (uint32_t)__shfl_xor(localDead, ofs, 64);
+    }
     if (lv_lane() == 0 && localSum > 0u) atomicAdd(&dc->fragCounter, localSum); // fragCounter of the reference: every fragment counts
+    if (lv_lane() == 0 && localDead > 0u) atomicAdd(&dc->prismDiscards, localDead);
     if (STATS) {
         hits = lv_wave_sum_u64(hits);
         if (lv_lane() == 0 && hits) atomicAdd(&dc->hits, hits);
@@ -1197,7 +1226,10 @@ __device__ void lv_sort_fragments(uint32_t mode, LvFragArrays& A, uint32_t n, ui
 }
 
 // One wave per workgroup; fragment arrays in LDS when they fit, else in a global scratch slab.
-template <bool USE_LDS, bool PQ = true>
+// ARRAYS (frames of ppll_fragment_source = raster_prism): the pixel's fragments are the contiguous run frags[startOffset[pixel] ...
+// + count) of 8-B {colour, depth} entries (startOffset = exclusive scan of the counts), read from the LAST entry down = the order a
+// linked list built by pushing to the front would be walked in.
+template <bool USE_LDS, bool PQ = true, bool ARRAYS = false>
 __global__ __launch_bounds__(LV_WAVE) void k_ppll_resolve(const LvUniforms U, const LvTiles T,
                                                           const uint32_t* __restrict__ nodes,
                                                           const uint32_t* __restrict__ startOffset,
@@ -1229,9 +1261,21 @@ __global__ __launch_bounds__(LV_WAVE) void k_ppll_resolve(const LvUniforms U, co
         if (x < U.width && y < U.height) {
             const uint32_t addr = lv_ppll_addr(x, y, U.ppllPaddedW, U.ppllTileW, U.ppllTileH);
             uint32_t fragOffset = startOffset[addr];
-            if (fragCount) maxCount = max(maxCount, fragCount[addr]);
             uint32_t numFrags = 0;
-            while (numFrags < maxFrags) {
+            if (ARRAYS) {
+                const uint32_t v = fragCount[addr];
+                uint32_t j = v & 0xFFFFu;                      // entries of the run; v >> 16 of them are dead
+                maxCount = max(maxCount, j - (v >> 16));
+                const uint2* __restrict__ run = reinterpret_cast<const uint2*>(nodes) + fragOffset;
+                while (numFrags < maxFrags && j > 0u) {
+                    const uint2 e = run[--j];
+                    if (e.y == LV_PPLL_DEAD && e.x == 0u) continue;
+                    A.c(numFrags) = e.x;
+                    A.d(numFrags) = __uint_as_float(e.y);
+                    numFrags++;
+                }
+            }
+            while (!ARRAYS && numFrags < maxFrags) {
                 if (fragOffset == 0xFFFFFFFFu) break;
                 const uint32_t c = nodes[3 * size_t(fragOffset) + 0], db = nodes[3 * size_t(fragOffset) + 1];
                 fragOffset = nodes[3 * size_t(fragOffset) + 2];
@@ -1289,7 +1333,7 @@ __global__ __launch_bounds__(LV_WAVE) void k_ppll_resolve(const LvUniforms U, co
         f4 c; c.x = res[0]; c.y = res[1]; c.z = res[2]; c.w = res[3];
         out[outIndex] = lv_pack_unorm4x8(c);
     }
-    if (fragCount) {
+    if (ARRAYS) {
 #pragma unroll
         for (int ofs = 32; ofs > 0; ofs >>= 1) maxCount = max(maxCount, (uint32_t)__shfl_xor(maxCount, ofs, 64));
         if (lane == 0 && maxCount > 0u) atomicMax(&dc->maxDepthComplexity, maxCount);
@@ -2086,6 +2130,11 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
         if (poolSlots64 > 0xFFFFFFF0ull) poolSlots64 = 0xFFFFFFF0ull; // node indices are 32 bit
         const uint32_t poolSlots = uint32_t(poolSlots64);
         if ((rc = lv_buf_reserve(ctx, ctx->ppllNodes, size_t(poolSlots) * 12))) return rc;
+        // raster_prism: the coverage kernel writes 12-B records {pixel, leaf | triangle, rank} into a pool of their own; ppllNodes then
+        // holds the fragment array (8-B {colour, depth} entries, one contiguous run per pixel), ppllStart the runs' offsets
+        if (prismSource && (rc = lv_buf_reserve(ctx, ctx->prismRecords, size_t(poolSlots) * 12))) return rc;
+        ctx->ppllArrays = prismSource;
+        uint32_t* gatherPool = prismSource ? (uint32_t*)ctx->prismRecords.ptr : (uint32_t*)ctx->ppllNodes.ptr;
         const size_t padded4 = (size_t(U.ppllPaddedW) * U.ppllPaddedH + 3) / 4; // cleared as whole uint4s (k_ppll_clear)
         if ((rc = lv_buf_reserve(ctx, ctx->ppllStart, padded4 * 16))) return rc;
         if ((rc = lv_buf_reserve(ctx, ctx->ppllCount, padded4 * 16))) return rc;
@@ -2098,7 +2147,7 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
         LV_HIP(ctx, hipEventRecord(ctx->ev[11], st));
 #define LV_LAUNCH_GATHER(ST, PR, BA)                                                                             \
     LV_TIMED_LAUNCH(ctx, LV_KERNEL_PPLL_GATHER, (k_ppll_gather<ST, PR, BA><<<gridTiles * numSlices, LV_BLOCK, 0, st>>>( \
-            U, S, T, (uint32_t*)ctx->ppllNodes.ptr, (uint32_t*)ctx->ppllStart.ptr,                              \
+            U, S, T, gatherPool, (uint32_t*)ctx->ppllStart.ptr,                                                  \
             (uint32_t*)ctx->ppllCount.ptr, dc, numSlices, poolSlots)))
 #define LV_LAUNCH_GATHER2(ST)                                                          \
     do {                                                                               \
@@ -2112,10 +2161,14 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
 #undef LV_LAUNCH_GATHER2
 #undef LV_LAUNCH_GATHER
         if (prismSource) {
+            // per-pixel counts -> offsets of the pixels' runs (the counts are final: one workgroup per pixel)
+            if ((rc = lv_scan_exclusive_u32(ctx, (const uint32_t*)ctx->ppllCount.ptr, (uint32_t*)ctx->ppllStart.ptr,
+                                            size_t(U.ppllPaddedW) * U.ppllPaddedH))) return rc;
             const uint32_t shadeGrid = uint32_t(ctx->numCUs) * LV_PRISM_SHADE_BLOCKS_PER_CU;
 #define LV_LAUNCH_SHADE(ST)                                                                                                     \
     LV_TIMED_LAUNCH(ctx, LV_KERNEL_PPLL_SHADE, (k_ppll_shade_prism<ST><<<shadeGrid, LV_BLOCK, 0, st>>>(                         \
-            U, S, (uint32_t*)ctx->ppllNodes.ptr, (uint32_t*)ctx->ppllCount.ptr, dc, poolSlots)))
+            U, S, (const uint32_t*)ctx->prismRecords.ptr, (uint2*)ctx->ppllNodes.ptr, (const uint32_t*)ctx->ppllStart.ptr,      \
+            (uint32_t*)ctx->ppllCount.ptr, dc, poolSlots)))
             if (stats) LV_LAUNCH_SHADE(true); else LV_LAUNCH_SHADE(false);
 #undef LV_LAUNCH_SHADE
         }
@@ -2126,25 +2179,27 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
         const uint64_t groups64 = uint64_t(numTiles) * gx * gy;
         const uint32_t numGroups = uint32_t(groups64);
         const size_t ldsBytes = size_t(U.ppllMaxNumFrags) * LV_WAVE * 8;
+#define LV_LAUNCH_RESOLVE(LDS, PQ, GRID, BYTES, SCRATCH)                                                                        \
+    do {                                                                                                                       \
+        if (prismSource)                                                                                                       \
+            LV_TIMED_LAUNCH(ctx, LV_KERNEL_PPLL_RESOLVE, (k_ppll_resolve<LDS, PQ, true><<<GRID, LV_WAVE, BYTES, st>>>(        \
+                    U, T, (const uint32_t*)ctx->ppllNodes.ptr, (const uint32_t*)ctx->ppllStart.ptr, out, SCRATCH, numGroups,   \
+                    prismCount, dc)));                                                                                         \
+        else                                                                                                                   \
+            LV_TIMED_LAUNCH(ctx, LV_KERNEL_PPLL_RESOLVE, (k_ppll_resolve<LDS, PQ, false><<<GRID, LV_WAVE, BYTES, st>>>(       \
+                    U, T, (const uint32_t*)ctx->ppllNodes.ptr, (const uint32_t*)ctx->ppllStart.ptr, out, SCRATCH, numGroups,   \
+                    nullptr, dc)));                                                                                            \
+    } while (0)
         if (ldsBytes <= LV_RESOLVE_LDS_MAX) {
-            if (U.ppllSortingMode == 0u)
-                LV_TIMED_LAUNCH(ctx, LV_KERNEL_PPLL_RESOLVE, (k_ppll_resolve<true, true><<<numGroups, LV_WAVE, ldsBytes, st>>>(
-                        U, T, (const uint32_t*)ctx->ppllNodes.ptr, (const uint32_t*)ctx->ppllStart.ptr, out, nullptr, numGroups, prismCount, dc)));
-            else
-                LV_TIMED_LAUNCH(ctx, LV_KERNEL_PPLL_RESOLVE, (k_ppll_resolve<true, false><<<numGroups, LV_WAVE, ldsBytes, st>>>(
-                        U, T, (const uint32_t*)ctx->ppllNodes.ptr, (const uint32_t*)ctx->ppllStart.ptr, out, nullptr, numGroups, prismCount, dc)));
+            if (U.ppllSortingMode == 0u) LV_LAUNCH_RESOLVE(true, true, numGroups, ldsBytes, nullptr);
+            else LV_LAUNCH_RESOLVE(true, false, numGroups, ldsBytes, nullptr);
         } else {
             const uint32_t grid = numGroups < LV_RESOLVE_SLAB_GRID ? numGroups : LV_RESOLVE_SLAB_GRID;
             if ((rc = lv_buf_reserve(ctx, ctx->ppllScratch, size_t(grid) * ldsBytes))) return rc;
-            if (U.ppllSortingMode == 0u)
-                LV_TIMED_LAUNCH(ctx, LV_KERNEL_PPLL_RESOLVE, (k_ppll_resolve<false, true><<<grid, LV_WAVE, 0, st>>>(
-                        U, T, (const uint32_t*)ctx->ppllNodes.ptr, (const uint32_t*)ctx->ppllStart.ptr, out,
-                        (uint32_t*)ctx->ppllScratch.ptr, numGroups, prismCount, dc)));
-            else
-                LV_TIMED_LAUNCH(ctx, LV_KERNEL_PPLL_RESOLVE, (k_ppll_resolve<false, false><<<grid, LV_WAVE, 0, st>>>(
-                        U, T, (const uint32_t*)ctx->ppllNodes.ptr, (const uint32_t*)ctx->ppllStart.ptr, out,
-                        (uint32_t*)ctx->ppllScratch.ptr, numGroups, prismCount, dc)));
+            if (U.ppllSortingMode == 0u) LV_LAUNCH_RESOLVE(false, true, grid, 0, (uint32_t*)ctx->ppllScratch.ptr);
+            else LV_LAUNCH_RESOLVE(false, false, grid, 0, (uint32_t*)ctx->ppllScratch.ptr);
         }
+#undef LV_LAUNCH_RESOLVE
     }
     LV_HIP(ctx, hipGetLastError());
     LV_HIP(ctx, hipEventRecord(ctx->ev[3], st));

@@ -317,6 +317,30 @@ __device__ __forceinline__ void lv_cswap(float& ka, unsigned& ca, float& kb, uns
 // slab test on decoded planes: t = plane * (1/d) - o/d with plane = origin + q * scale, folded into
 // t = q * (scale/d) + (origin/d - o/d): one fma per plane after the byte -> float conversion.  The words handed in
 // are already ordered by the ray's direction signs (near planes / far planes), so no per-plane min/max is needed.
+#if LV_NODE_MIX
+// The same test with the plane bytes read as binary16: v_perm_b32 builds {0x6400 | q_k, 0x6400 | q_k+1} = the halves 1024 + q of two
+// children at once (binary16 has ulp 1 on [1024, 2048)), and t = (1024 + q) * A + (B - 1024 A) is ONE v_fma_mix_f32 per plane (the
+// binary16 operand is widened inside the instruction, the arithmetic is float32): 1.5 instructions per plane instead of the
+// v_cvt_f32_ubyte + v_fma_f32 pair.  B2 = B - 1024 A is computed once per node step (lv_node_step).
+typedef _Float16 lv_h2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ lv_h2 lv_plane_pair(uint32_t word, int pair) {
+    const uint32_t w = __builtin_amdgcn_perm(word, 0x64006400u, pair == 0 ? 0x03050104u : 0x03070106u);
+    return __builtin_bit_cast(lv_h2, w);
+}
+__device__ __forceinline__ bool lv_slab_h(_Float16 nx, _Float16 ny, _Float16 nz, _Float16 fx, _Float16 fy, _Float16 fz, f3 A, f3 B2,
+                                          float tMin, float tMax, float& tNear) {
+    const float tx0 = __builtin_fmaf(float(nx), A.x, B2.x);
+    const float ty0 = __builtin_fmaf(float(ny), A.y, B2.y);
+    const float tz0 = __builtin_fmaf(float(nz), A.z, B2.z);
+    const float tx1 = __builtin_fmaf(float(fx), A.x, B2.x);
+    const float ty1 = __builtin_fmaf(float(fy), A.y, B2.y);
+    const float tz1 = __builtin_fmaf(float(fz), A.z, B2.z);
+    const float tn = fmaxf(fmaxf(tx0, ty0), fmaxf(tz0, tMin));
+    const float tf = fminf(fminf(tx1, ty1), fminf(tz1, tMax));
+    tNear = tn;
+    return tn <= __builtin_fmaf(tf, 1.00001f, 4e-7f);
+}
+#endif
 __device__ __forceinline__ bool lv_slab_q(uint32_t nearX, uint32_t nearY, uint32_t nearZ, uint32_t farX, uint32_t farY,
                                           uint32_t farZ, int k, f3 A, f3 B, float tMin, float tMax, float& tNear) {
     const float tx0 = __builtin_fmaf(float((nearX >> (8 * k)) & 0xFFu), A.x, B.x);
@@ -356,10 +380,21 @@ __device__ __forceinline__ unsigned lv_node_step(const LvSceneDev& S, unsigned n
     float k0, k1, k2, k3;
     // empty slots carry an inverted box (lv_write_wide_node) and fail the slab test by themselves; should one slip through,
     // its reference is LV_INVALID and it is neither descended nor pushed
+#if LV_NODE_MIX
+    const f3 B2 = mk3(__builtin_fmaf(-1024.0f, A.x, B.x), __builtin_fmaf(-1024.0f, A.y, B.y), __builtin_fmaf(-1024.0f, A.z, B.z));
+    const lv_h2 nx01 = lv_plane_pair(nearX, 0), nx23 = lv_plane_pair(nearX, 1), ny01 = lv_plane_pair(nearY, 0), ny23 = lv_plane_pair(nearY, 1);
+    const lv_h2 nz01 = lv_plane_pair(nearZ, 0), nz23 = lv_plane_pair(nearZ, 1), fx01 = lv_plane_pair(farX, 0), fx23 = lv_plane_pair(farX, 1);
+    const lv_h2 fy01 = lv_plane_pair(farY, 0), fy23 = lv_plane_pair(farY, 1), fz01 = lv_plane_pair(farZ, 0), fz23 = lv_plane_pair(farZ, 1);
+    const bool h0 = lv_slab_h(nx01.x, ny01.x, nz01.x, fx01.x, fy01.x, fz01.x, A, B2, tMin, tMax, k0);
+    const bool h1 = lv_slab_h(nx01.y, ny01.y, nz01.y, fx01.y, fy01.y, fz01.y, A, B2, tMin, tMax, k1);
+    const bool h2 = lv_slab_h(nx23.x, ny23.x, nz23.x, fx23.x, fy23.x, fz23.x, A, B2, tMin, tMax, k2);
+    const bool h3 = lv_slab_h(nx23.y, ny23.y, nz23.y, fx23.y, fy23.y, fz23.y, A, B2, tMin, tMax, k3);
+#else
     const bool h0 = lv_slab_q(nearX, nearY, nearZ, farX, farY, farZ, 0, A, B, tMin, tMax, k0);
     const bool h1 = lv_slab_q(nearX, nearY, nearZ, farX, farY, farZ, 1, A, B, tMin, tMax, k1);
     const bool h2 = lv_slab_q(nearX, nearY, nearZ, farX, farY, farZ, 2, A, B, tMin, tMax, k2);
     const bool h3 = lv_slab_q(nearX, nearY, nearZ, farX, farY, farZ, 3, A, B, tMin, tMax, k3);
+#endif
     const float INF = __builtin_inff();
     if (ORDERED == 3) {
         // nearest hit child WITHOUT a sorting network: the minimum of the masked keys (min3 + min), the first slot that holds it

@@ -254,7 +254,7 @@ static double sahCost(const BTree& T) {
 }
 
 // ---------------------------------------------------------------- 4-wide collapse (k_collapse_select's greedy rule)
-struct WNode { Box cb[8]; int32_t c[8]; int n; int level; }; // child >= 0: wide node, < 0: ~prim, INT32_MIN: empty (width 4 or 8)
+struct WNode { Box cb[8]; int32_t c[8]; int n; int level; float umn[3], ustep[3]; uint8_t qmn[8][3], qmx[8][3]; }; // child >= 0: wide node, < 0: ~prim, INT32_MIN: empty (width 4 or 8)
 struct WTree { std::vector<WNode> nodes; int levels; };
 
 static WTree collapse(const BTree& T, int width = 4) {
@@ -285,10 +285,13 @@ static WTree collapse(const BTree& T, int width = 4) {
                 for (int k = 0; k < ns; k++) U.grow(wn.cb[k]);
                 for (int a = 0; a < 3; a++) {
                     const float step = (U.mx[a] - U.mn[a]) / 255.0f;
-                    if (!(step > 0.0f)) continue;
+                    if (!(step > 0.0f)) { wn.umn[a] = U.mn[a]; wn.ustep[a] = 0.0f; for (int k = 0; k < ns; k++) { wn.qmn[k][a] = 0; wn.qmx[k][a] = 0; } continue; }
+                    wn.umn[a] = U.mn[a]; wn.ustep[a] = step;
                     for (int k = 0; k < ns; k++) {
-                        wn.cb[k].mn[a] = U.mn[a] + std::floor((wn.cb[k].mn[a] - U.mn[a]) / step) * step;
-                        wn.cb[k].mx[a] = U.mn[a] + std::min(255.0f, std::ceil((wn.cb[k].mx[a] - U.mn[a]) / step)) * step;
+                        const float qa = std::floor((wn.cb[k].mn[a] - U.mn[a]) / step), qb = std::min(255.0f, std::ceil((wn.cb[k].mx[a] - U.mn[a]) / step));
+                        wn.qmn[k][a] = uint8_t(std::max(0.0f, qa)); wn.qmx[k][a] = uint8_t(qb);
+                        wn.cb[k].mn[a] = U.mn[a] + qa * step;
+                        wn.cb[k].mx[a] = U.mn[a] + qb * step;
                     }
                 }
             }
@@ -348,6 +351,41 @@ static bool trace(const WTree& W, V3 o, V3 d, float tMin, float tMax, float& tHi
             C.nodes++; C.perLevel[std::min(n.level, 47)]++;
             float key[8]; int32_t ch[8]; int nh = 0;
             C.boxes += uint64_t(n.n);
+            static const int f16mode = getenv("LAB_F16") ? atoi(getenv("LAB_F16")) : 0;
+            if (f16mode) {
+                // packed-f16 slab test: node-local time t' = t - c (c = the node's own entry time), planes q in
+                // f16 exactly, A = step / d and B' = (umn - o) / d - c rounded to f16, every fma result rounded to f16; boxes widened
+                // by LAB_F16 grid units on each side to stay conservative
+                auto h = [](float x) -> float {   // round to the nearest binary16 value (ties to even), overflow to infinity
+                    if (!(std::fabs(x) < 65520.0f)) return x > 0 ? INFINITY : (x < 0 ? -INFINITY : x);
+                    if (x == 0.0f) return x;
+                    int e; std::frexp(x, &e); e = std::max(e - 1, -14);
+                    const float quantum = std::ldexp(1.0f, e - 10);
+                    return std::nearbyint(x / quantum) * quantum;
+                };
+                float A[3], B[3], c = tMin;
+                for (int a = 0; a < 3; a++) {
+                    A[a] = n.ustep[a] * inv[a]; B[a] = (n.umn[a] - oo[a]) * inv[a];
+                    const float e0 = B[a], e1 = 255.0f * A[a] + B[a];
+                    c = std::max(c, std::min(e0, e1));
+                }
+                const float tMinL = h(tMin - c) , tMaxL = h(best - c);
+                for (int k = 0; k < n.n; k++) {
+                    float tn = tMinL - 0.0f, tf = tMaxL;
+                    for (int a = 0; a < 3; a++) {
+                        const float Ah = h(A[a]), Bh = h(B[a] - c);
+                        float qn = float(n.qmn[k][a]) - float(f16mode), qx = float(n.qmx[k][a]) + float(f16mode);
+                        float t0 = h(qn * Ah + Bh), t1 = h(qx * Ah + Bh);
+                        if (inv[a] < 0.0f) { t0 = h((float(n.qmx[k][a]) + float(f16mode)) * Ah + Bh); t1 = h((float(n.qmn[k][a]) - float(f16mode)) * Ah + Bh); }
+                        tn = std::max(tn, t0); tf = std::min(tf, t1);
+                    }
+                    // exact f32 test for the statistics of false negatives
+                    float en = tMin, ef = best;
+                    for (int a = 0; a < 3; a++) { float t0 = (n.cb[k].mn[a] - oo[a]) * inv[a], t1 = (n.cb[k].mx[a] - oo[a]) * inv[a]; if (t0 > t1) std::swap(t0, t1); en = std::max(en, t0); ef = std::min(ef, t1); }
+                    if (en <= ef && !(tn <= tf)) C.barren += 1000000ull;   // a box the exact test hits was culled: NOT conservative
+                    if (tn <= tf) { key[nh] = tn; ch[nh] = n.c[k]; nh++; }
+                }
+            } else
             for (int k = 0; k < n.n; k++) {
                 float tn = tMin, tf = best;
                 for (int a = 0; a < 3; a++) {
