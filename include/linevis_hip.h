@@ -211,7 +211,7 @@ int lv_set_background(lv_ctx* ctx, const float rgba[4]);
  *   fragment shader fed with perspective-correct interpolated position / normal / tangent / attribute; the rasteriser is a
  *   watertight edge-function rasteriser in the space of the pixel's viewing ray (linevis_amd/csrc/lv_prism.h) | "capsule_entry"
  *   -- entry hits of the pixel-centre ray against the analytic capsules (rounds 1-3 of this build; a probe) | "auto" (default:
- *   raster_prism for plain flow lines; capsule_entry for band data, rotating helicity bands and the prebaked AO lookup),
+ *   raster_prism for plain flow lines; capsule_entry for band data and rotating helicity bands),
  *   ambient_occlusion_denoiser ("None" | "Edge-Avoiding A-Trous Wavelet Transform" (UTF-8 A-grave as in Denoiser.hpp:66; "EAW"
  *   is accepted too) | "SVGF")                                         (VulkanRayTracedAmbientOcclusion.cpp:683-696)
  *   eaw_denoiser_iterations (0..5, default 3), eaw_denoiser_color_weights / _position_weights / _normal_weights,

@@ -93,8 +93,8 @@ struct LvOptions {
     // triangle tubes (rtao_geometry = triangle_tubes: the colour pass is then the only user of the capsule test and the
     // literal form is nearly free), closest approach otherwise; 1 = closest_approach; 2 = literal
     int intersectionForm = 0;
-    // ppll_fragment_source: 0 = auto (default): raster_prism for plain flow lines, capsule_entry for band data / helicity bands /
-    // the prebaked AO lookup (not built for the prism yet); 1 = capsule_entry (entry hits of the pixel-centre ray against the analytic
+    // ppll_fragment_source: 0 = auto (default): raster_prism for plain flow lines, capsule_entry for band data / helicity bands
+    // (not built for the prism yet); 1 = capsule_entry (entry hits of the pixel-centre ray against the analytic
     // capsules: the probe of rounds 1-3); 2 = raster_prism (the rasterised N-gon prism of the reference's default primitive mode)
     int ppllFragmentSource = 0;
     bool ppllRayTracerColour = false;         // ppll_fragment_colour: false = "raster" (the reference's gather shader, default), true = "ray_tracer"

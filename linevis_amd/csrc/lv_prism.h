@@ -121,7 +121,7 @@ __device__ __forceinline__ bool lv_prism_own_box(f3 o, f3 d, f3 p0, f3 p1, float
 struct LvPrismTri {
     f3 pos[3], dir[3], tan[3];
     float attr[3], c[3], s[3];
-    uint32_t id[3];
+    uint32_t id[3], circ[3];
     bool second[3];   // vertex belongs to the segment's second point
 };
 __device__ __forceinline__ LvPrismTri lv_prism_tri_setup(const float* ringTab, uint32_t N, const LvPrismPoint pt[2], const uint32_t pi[2],
@@ -140,6 +140,7 @@ __device__ __forceinline__ LvPrismTri lv_prism_tri_setup(const float* ringTab, u
         T.attr[i] = p.attr;
         T.id[i] = (ring[i] ? pi[1] : pi[0]) * N + circ[i];
         T.second[i] = ring[i] != 0u;
+        T.circ[i] = circ[i];
     }
     return T;
 }
@@ -291,16 +292,39 @@ __device__ __forceinline__ LvPrismPlanes lv_prism_planes(const LvPrismDev& R, co
     return pl;
 }
 // interpolated inputs of the fragment stage for the ray direction D (helper invocations: weights outside [0, 1])
-struct LvPrismInputs { f3 pos, nrm, tan; float attr; };
+struct LvPrismInputs { f3 pos, nrm, tan; float attr; float b[3]; };
 __device__ __forceinline__ LvPrismInputs lv_prism_interpolate(const LvPrismTri& T, const f3 nrm[3], const LvPrismPlanes& pl, f3 Dr) {
     const f3 abg = mk3(lv_prism_dot(Dr, pl.P), lv_prism_dot(Dr, pl.Q), lv_prism_dot(Dr, pl.D));
     const float e[3] = {lv_prism_dot(abg, pl.c0), lv_prism_dot(abg, pl.c1), lv_prism_dot(abg, pl.c2)};
-    float b[3];
-    lv_prism_weights(e, b);
     LvPrismInputs I;
+    float* b = I.b;
+    lv_prism_weights(e, b);
     I.pos = lv_prism_mix3(b, T.pos[0], T.pos[1], T.pos[2]);
     I.nrm = lv_prism_mix3(b, nrm[0], nrm[1], nrm[2]);
     I.tan = lv_prism_mix3(b, T.tan[0], T.tan[1], T.tan[2]);
     I.attr = (b[0] * T.attr[0] + b[1] * T.attr[1]) + b[2] * T.attr[2];
     return I;
+}
+
+// STATIC_AMBIENT_OCCLUSION_PREBAKING in the raster shaders: the inputs of getAoFactor(fragmentVertexId, phi) (Lighting.glsl:124-125) --
+// vertex stage LinePassProgrammablePullTubes.glsl:179-206 (phi = circleIdx * (2 pi / N); interpolateWrap and fragmentVertexIdUint =
+// lineStartIndex are FLAT = the provoking (first) vertex's; interpolationFactorLine = float(linePointIdx - lineStartIndex)), fragment
+// stage LinePassGeometryShaderTubes.glsl:753-770 (fragmentVertexId, the wrap-around of phi on the last facet)
+__device__ __forceinline__ void lv_prism_ao_inputs(const LvPrismTri& T, const LvPrismPoint pt[2], const uint32_t pi[2], const float b[3],
+                                                   uint32_t N, float& fragmentVertexId, float& phi) {
+    const float PI = 3.14159265358979323846f;
+    float li[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) li[i] = float((T.second[i] ? pi[1] : pi[0]) - (T.second[i] ? pt[1].start : pt[0].start));
+    const float interpolationFactorLine = (b[0] * li[0] + b[1] * li[1]) + b[2] * li[2];
+    fragmentVertexId = interpolationFactorLine + float(T.second[0] ? pt[1].start : pt[0].start);
+    const float factor = 2.0f * PI / float(N);
+    const float phiNotWrapInterpolated = (b[0] * (float(T.circ[0]) * factor) + b[1] * (float(T.circ[1]) * factor)) + b[2] * (float(T.circ[2]) * factor);
+    if (T.circ[0] != N - 1u) {
+        phi = phiNotWrapInterpolated;
+    } else {
+        const float lower = 2.0f * PI * float(N - 1u) / float(N);
+        const float upper = 2.0f * PI;
+        phi = lower + (phiNotWrapInterpolated - lower) / (-lower) * (upper - lower);
+    }
 }

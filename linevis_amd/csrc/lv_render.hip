@@ -41,7 +41,7 @@ __global__ __launch_bounds__(LV_BLOCK, (STATS || PRIM == LV_PRIM_ELLIPTIC) ? 1 :
     LvCounters cnt = {0, 0, 0, 0};
     const bool capped = U.useCappedTubes != 0 || U.lssGeometry != 0;
     const float HIT_DISTANCE_EPSILON = 1e-5f;
-    const float aoTexel = (px.inView && U.useAmbientOcclusion) ? S.ao[size_t(px.y) * U.width + px.x] : 1.0f;
+    const float aoTexel = (px.inView && U.useAmbientOcclusion && !U.aoPrebaked) ? S.ao[size_t(px.y) * U.width + px.x] : 1.0f;
     float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     const uint32_t nSamples = U.useJitteredRays ? U.numSamplesPerFrame : 1u;
     for (uint32_t sampleIdx = 0; sampleIdx < nSamples; sampleIdx++) { // uniform trip count
@@ -854,7 +854,7 @@ __global__ __launch_bounds__(LV_BLOCK, PRIM == LV_PRIM_PRISM ? LV_PRISM_MIN_WAVE
     s_tail[threadIdx.x] = 0xFFFFFFFFu;
     s_count[threadIdx.x] = 0u;
     if ((threadIdx.x & 63u) == 0u) { s_allocBase[threadIdx.x >> 6] = 0u; s_allocLeft[threadIdx.x >> 6] = 0u; }
-    const float aoTexel = (px.inView && U.useAmbientOcclusion) ? S.ao[size_t(px.y) * U.width + px.x] : 1.0f;
+    const float aoTexel = (px.inView && U.useAmbientOcclusion && !U.aoPrebaked) ? S.ao[size_t(px.y) * U.width + px.x] : 1.0f;
     f3 o, d;
     lv_primary_ray(U, px.x, px.y, 0.5f, 0.5f, o, d);
     const float tMin = 0.0001f, tMax = 1000.0f;
@@ -1037,7 +1037,7 @@ __global__ __launch_bounds__(LV_BLOCK, LV_PRISM_SHADE_MIN_WAVES) void k_ppll_sha
         if (w1 == LV_PPLL_DEAD) continue;   // slot of a chunk tail
         const uint32_t px = w0 & 0xFFFFu, py = w0 >> 16;
         const uint32_t leaf = w1 & 0x03FFFFFFu, tt = w1 >> 26;
-        const float aoTexel = U.useAmbientOcclusion ? S.ao[size_t(py) * U.width + px] : 1.0f;
+        const float aoTexel = (U.useAmbientOcclusion && !U.aoPrebaked) ? S.ao[size_t(py) * U.width + px] : 1.0f;
         f3 oo, d;
         lv_primary_ray(U, px, py, 0.5f, 0.5f, oo, d);
         const LvRasterQuad rq = lv_make_raster_quad(U, px, py);
@@ -1511,7 +1511,7 @@ static void lv_sincos2pi_host(float xi, float& s, float& c) {
 bool lv_ppll_prism_source(const lv_ctx* ctx) {
     const LvOptions& o = ctx->opt;
     if (o.ppllFragmentSource == 1) return false;
-    const bool plain = !o.useRibbons && !o.helicityBands && !(o.useAmbientOcclusion && o.aoPrebaked);
+    const bool plain = !o.useRibbons && !o.helicityBands;
     return o.ppllFragmentSource == 2 ? true : plain;
 }
 // per-frame constants of the rasterised prism (LvPrismDev)
@@ -1964,8 +1964,6 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
         return lv_fail(ctx, LV_E_INVALID, "Elliptic Tubes belong to the AABB geometry mode (VulkanRayTracer.cpp:198), not to Linear Swept Spheres");
     if (!ctx->accelValid || ctx->accelLineWidth != lv_accel_width(ctx))
         if ((rc = lv_bvh_build(ctx))) return rc;
-    if (ctx->opt.useAmbientOcclusion && ctx->opt.aoPrebaked && mode != LV_RENDERING_MODE_VULKAN_RAY_TRACER)
-        return lv_fail(ctx, LV_E_INVALID, "the static RTAO prebaker is wired to the ray tracer (mode 11) only");
     const bool needTriangles = (ctx->opt.useAmbientOcclusion && ctx->opt.aoPrebaked) ||
                                (ctx->opt.useAmbientOcclusion && ctx->opt.aoTriangleTubes) ||
                                (ctx->opt.rtTriangleMesh && mode == LV_RENDERING_MODE_VULKAN_RAY_TRACER);
@@ -2121,7 +2119,11 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
         // gather(): fragments of the rasterised programmable-pull prism (the reference's geometry, default) or capsule entry hits
         const bool prismSource = lv_ppll_prism_source(ctx);
         if (prismSource) lv_fill_prism(ctx, U, S.prism);
+#ifdef LV_PRISM_SLICES_PROBE
+        const uint32_t numSlices = LV_PRISM_SLICES_PROBE;
+#else
         const uint32_t numSlices = prismSource ? 1u : LV_PPLL_SLICES; // (the prism's coverage kernel has no depth: one slice)
+#endif
         if (uint64_t(gridTiles) * numSlices > 0x7FFFFFF0ull) return lv_fail(ctx, LV_E_INVALID, "tile list too large");
         // physical pool = the reference's linkedListSize + the tail every wave of the gather may leave unused in its last
         // chunk of node slots (k_ppll_gather), so that the effective capacity is never below the reference's

@@ -1390,6 +1390,11 @@ __device__ __forceinline__ f4 lv_shade_prism(const LvSceneDev& S, const LvUnifor
     const LvPrismPlanes pl = lv_prism_planes(R, T, cam, d);   // (o == cam: the pixel's viewing ray starts at the camera)
     const LvPrismInputs I = lv_prism_interpolate(T, nrm, pl, d);
     kept = lv_prism_accept(R, pt, U.radius, o, d, I.pos, len3(I.pos - o), tLo, tHi);
+    if (U.aoPrebaked) {   // getAoFactor(fragmentVertexId, phi) of the static prebaker instead of the screen-space texel
+        float fragmentVertexId, phi;
+        lv_prism_ao_inputs(T, pt, pi, I.b, R.n, fragmentVertexId, phi);
+        aoTexel = lv_prebaked_ao_lookup(S, U, fragmentVertexId, phi);
+    }
     const LvPrismInputs Ix = lv_prism_interpolate(T, nrm, pl, rq.dX), Iy = lv_prism_interpolate(T, nrm, pl, rq.dY);
     const float f0 = lv_prism_ribbon(cam, I.pos, I.nrm, I.tan);
     const float fx = lv_prism_ribbon(cam, Ix.pos, Ix.nrm, Ix.tan);

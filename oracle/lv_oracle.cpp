@@ -691,6 +691,9 @@ struct PrebakedAo {
     const float* blendingWeights;
     uint32_t numLineVertices, numParametrizationVertices, numAoTubeSubdivisions;
 };
+// the table the PPLL gather shades with while ambient_occlusion_mode = "RTAO (Prebaker)" (lvo_set_ppll_prebaked_ao; tests only)
+static PrebakedAo g_ppllPrebaked = {nullptr, nullptr, 0u, 0u, 0u};
+
 
 // getAoFactor(interpolatedVertexId, phi), AmbientOcclusion.glsl:49-75, WITHOUT its last two lines (pow(gamma) and the
 // strength mapping): those are the same as for the screen-space texture and are applied by getAoFactor(P, aoTexel).
@@ -2309,7 +2312,8 @@ void lvo_ppll_gather(const lvo_scene* sc, const lvo_params* Pp, int useBvh, cons
                 const RasterQuad rqP = makeRasterQuad(P, F, x, y);
                 for (const PrismFrag& f : pf) {
                     float hc[4]; float hitT;
-                    prismShade(*sc, P, F, ring, aoTexelP, f, g_rtFragmentColourInPpll ? nullptr : &rqP, hc, hitT);
+                    prismShade(*sc, P, F, ring, aoTexelP, f, g_rtFragmentColourInPpll ? nullptr : &rqP, hc, hitT,
+                               g_ppllPrebaked.factors ? &g_ppllPrebaked : nullptr);
                     cnt.hits++;
                     if (hc[3] < 0.001f) continue;
                     rows[yy].push_back(std::make_pair(packUnorm4x8(hc), hitT));
@@ -2327,7 +2331,7 @@ void lvo_ppll_gather(const lvo_scene* sc, const lvo_params* Pp, int useBvh, cons
             for (const Hit& hit : hl) {
                 float hc[4]; float hitT;
                 if (elliptic) shadeHitElliptic(*sc, P, F, aoTexel, o, d, hit, hc, hitT, rqp);
-                else shadeHit(*sc, P, F, aoTexel, o, d, hit, hc, hitT, nullptr, rqp);
+                else shadeHit(*sc, P, F, aoTexel, o, d, hit, hc, hitT, g_ppllPrebaked.factors ? &g_ppllPrebaked : nullptr, rqp);
                 cnt.hits++;
                 if (hc[3] < 0.001f) continue;
                 rows[yy].push_back(std::make_pair(packUnorm4x8(hc), hitT));
@@ -2471,6 +2475,10 @@ void lvo_pow_det(const float* x, const float* y, uint64_t n, float* out) {
     for (uint64_t i = 0; i < n; i++) out[i] = powDet(x[i], y[i]);
 }
 void lvo_set_ppll_fragment_colour_variant(int rayTracerVariant) { g_rtFragmentColourInPpll = rayTracerVariant != 0; }
+void lvo_set_ppll_prebaked_ao(const float* factors, const float* blendingWeights, uint32_t numLineVertices,
+                              uint32_t numParametrizationVertices, uint32_t numAoTubeSubdivisions) {
+    g_ppllPrebaked = PrebakedAo{factors, blendingWeights, numLineVertices, numParametrizationVertices, numAoTubeSubdivisions};
+}
 
 void lvo_set_ao_feature_outputs(float* normalMap, float* positionMap) {
     g_lvoAoFeatures.normal = normalMap;
@@ -2863,7 +2871,8 @@ void lvo_prism_fragments(const lvo_scene* sc, const lvo_params* Pp, int useBvh, 
                 if (attr) attr[k] = f.attr;
                 if (colour || rgba) {
                     float hc[4]; float hitT;
-                    prismShade(*sc, P, F, ring, aoTexel, f, g_rtFragmentColourInPpll ? nullptr : &rq, hc, hitT);
+                    prismShade(*sc, P, F, ring, aoTexel, f, g_rtFragmentColourInPpll ? nullptr : &rq, hc, hitT,
+                               g_ppllPrebaked.factors ? &g_ppllPrebaked : nullptr);
                     if (colour) colour[k] = packUnorm4x8(hc);
                     if (rgba) for (int j = 0; j < 4; j++) rgba[4 * k + j] = hc[j];
                 }

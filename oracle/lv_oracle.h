@@ -385,6 +385,11 @@ void lvo_set_deviation_switches(int literalIntersection, int referenceAoLookup);
 /* 1: shade PPLL fragments with the ray tracer's computeFragmentColor (RayHitCommon.glsl; rounds 1-2), 0 (default): with the raster
  * tube shader's variant (LinePassGeometryShaderTubes.glsl:785-815,1079-1087) */
 void lvo_set_ppll_fragment_colour_variant(int rayTracerVariant);
+/* ambient_occlusion_mode = "RTAO (Prebaker)" in the PPLL gather: while a table is set (factors != NULL; the arrays must stay alive)
+ * the fragments are shaded with getAoFactor(fragmentVertexId, phi) (AmbientOcclusion.glsl:49-75) -- raster_prism: the interpolated
+ * vertex-stage outputs (lv_oracle_prism.h prismAoInputs), capsule_entry: the closest-hit reconstruction of the ray tracer. */
+void lvo_set_ppll_prebaked_ao(const float* factors, const float* blendingWeights, uint32_t numLineVertices,
+                              uint32_t numParametrizationVertices, uint32_t numAoTubeSubdivisions);
 /* the build-owned pow of the shading code (powDet = lv_pow_det of the HIP library) on n inputs */
 void lvo_pow_det(const float* x, const float* y, uint64_t n, float* out);
 void lvo_prebaked_ao_lookup_batch(const float* factors, const float* blendingWeights, uint32_t numLineVertices,

@@ -297,8 +297,34 @@ inline void prismPixelFragments(const lvo_scene& sc, const lvo_params& P, const 
 
 // fragment stage: LinePassGeometryShaderTubes.glsl:732-1129 on the interpolated inputs -> colour (raster variant of the outline)
 // rq == nullptr: the ray tracer's variant of computeFragmentColor (deviation switch ppll_fragment_colour = ray_tracer)
+// STATIC_AMBIENT_OCCLUSION_PREBAKING in the raster shaders: the inputs of getAoFactor(fragmentVertexId, phi) (Lighting.glsl:124-125,
+// AmbientOcclusion.glsl:49-75) -- vertex stage LinePassProgrammablePullTubes.glsl:179-206 (phi = circleIdx * (2 pi / N),
+// interpolateWrap = circleIdx == N - 1 and fragmentVertexIdUint = lineStartIndex FLAT = of the provoking = first vertex,
+// interpolationFactorLine = float(linePointIdx - lineStartIndex) interpolated), fragment stage LinePassGeometryShaderTubes.glsl:
+// 753-770 (fragmentVertexId = interpolationFactorLine + float(fragmentVertexIdUint); the wrap-around of phi on the last facet)
+inline void prismAoInputs(const PrismTri& T, const float b[3], uint32_t N, float& fragmentVertexId, float& phi) {
+    const float PI = 3.14159265358979323846f;
+    const float interpolationFactorLine = (b[0] * T.lineIdx[0] + b[1] * T.lineIdx[1]) + b[2] * T.lineIdx[2];
+    fragmentVertexId = interpolationFactorLine + float(T.lineStart);
+    const float factor = 2.0f * PI / float(N);
+    const float phiNotWrapInterpolated = (b[0] * (float(T.circ[0]) * factor) + b[1] * (float(T.circ[1]) * factor)) + b[2] * (float(T.circ[2]) * factor);
+    if (T.circ[0] != N - 1u) {
+        phi = phiNotWrapInterpolated;
+    } else {
+        const float lower = 2.0f * PI * float(N - 1u) / float(N);
+        const float upper = 2.0f * PI;
+        phi = lower + (phiNotWrapInterpolated - lower) / (-lower) * (upper - lower);
+    }
+}
+
 inline void prismShade(const lvo_scene& sc, const lvo_params& P, const Frame& F, const PrismRing& R, float aoTexel, const PrismFrag& f,
-                       const RasterQuad* rq, float hitColor[4], float& payloadHitT) {
+                       const RasterQuad* rq, float hitColor[4], float& payloadHitT, const PrebakedAo* pb = nullptr) {
+    if (pb) {
+        const PrismTri T = prismTriSetup(sc, R, F.radius, f.seg, f.tri);
+        float fragmentVertexId, phi;
+        prismAoInputs(T, f.b, R.n, fragmentVertexId, phi);
+        aoTexel = prebakedAoLookup(*pb, fragmentVertexId, phi);
+    }
     BandArgs rb;
     rb.shadeBands = false; rb.useBand = false; rb.phi = 0.0f; rb.linePosition = rb.lineNormal = v3(0, 0, 0);
     rb.rasterEpsWhite = -1.0f;

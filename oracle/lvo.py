@@ -113,6 +113,7 @@ def lib():
     L.lvo_compute_fragment_color_raster_batch.argtypes = [vp, vp, C.c_uint64] + [vp] * 9
     L.lvo_ribbon_of_rays.argtypes = [vp, vp, C.c_uint64, vp, vp, f32, vp, vp, vp]
     L.lvo_set_ppll_fragment_colour_variant.argtypes = [i32]
+    L.lvo_set_ppll_prebaked_ao.argtypes = [vp, vp, u32, u32, u32]
     L.lvo_pow_det.argtypes = [vp, vp, C.c_uint64, vp]
     L.lvo_prebaked_ao_lookup_batch.argtypes = [vp, vp, u32, u32, u32, vp, vp, C.c_uint64, vp]
     L.lvo_num_threads.restype = i32
@@ -824,6 +825,22 @@ def ribbon_of_rays(cam, dirs, axis_point, axis_dir, radius, cap_hit=None, cap_no
     lib().lvo_ribbon_of_rays(_p(c), _p(d), len(d), _p(a), _p(t), float(radius), _p(ch) if ch is not None else None,
                              _p(cn) if cn is not None else None, _p(out))
     return out
+
+
+class ppll_prebaked_ao:
+    """with ppll_prebaked_ao(factors, blending_weights): the PPLL gather shades with the static prebaker's table"""
+
+    def __init__(self, factors, blending_weights):
+        self.f = np.ascontiguousarray(factors, dtype=np.float32)
+        self.w = np.ascontiguousarray(blending_weights, dtype=np.float32)
+
+    def __enter__(self):
+        lib().lvo_set_ppll_prebaked_ao(_p(self.f), _p(self.w), len(self.w), self.f.shape[0], self.f.shape[1])
+        return self
+
+    def __exit__(self, *exc):
+        lib().lvo_set_ppll_prebaked_ao(None, None, 0, 0, 0)
+        return False
 
 
 class ppll_ray_tracer_fragment_colour:

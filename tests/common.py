@@ -84,8 +84,7 @@ class Case:
         )
         # ppll_fragment_source as the library resolves it (lv_ppll_prism_source): auto = the rasterised prism for plain flow lines
         src = s.get("ppll_fragment_source", "auto")
-        plain = not (bool(s.get("use_ribbons", False)) or bool(s.get("rotating_helicity_bands", False))
-                     or s.get("ambient_occlusion_mode", "None") == "RTAO (Prebaker)")
+        plain = not (bool(s.get("use_ribbons", False)) or bool(s.get("rotating_helicity_bands", False)))
         kw["ppllFragmentSource"] = int(src == "raster_prism" or (src == "auto" and plain))
         large = len(self.seg) > 1000000
         kw["ppllMaxNumFrags"] = int(s.get("ppll_max_num_frags", 0)) or (380 if large else 100)
