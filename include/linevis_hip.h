@@ -147,6 +147,16 @@ int lv_set_ao_parametrization(lv_ctx* ctx, const float* blending_weights, uint32
                               const float* sampling_locations, uint32_t num_parametrization_vertices);
 /* The baked table: ambientOcclusionFactors[subdivision + num_tube_subdivisions * parametrization_vertex]. */
 int lv_get_baked_ao(lv_ctx* ctx, float* out, uint64_t max_values);
+/* Asynchronous baking (the reference's BakingMode::MULTI_THREADED, AmbientOcclusionBaker.hpp:66-73, VulkanAmbientOcclusionBaker.cpp:
+ * 266-346: a worker thread bakes while the application keeps rendering and shows the AO once baking has finished).  Here: a second
+ * HIP stream with scratch buffers of its own.  lv_bake_ao_start queues the bake and returns; frames rendered meanwhile with
+ * ambient_occlusion_mode = "RTAO (Prebaker)" come out WITHOUT ambient occlusion; lv_bake_ao_poll (never blocks) reports whether the
+ * bake still runs and whether a valid table is in place -- it and the next lv_render* call adopt a finished table.  Changing anything
+ * the table depends on (lines, mesh, parametrisation, line width, baker settings) waits for a running bake and discards its result:
+ * start again.  Without lv_bake_ao_start the first frame that needs the table bakes it on the context's stream (synchronously to the
+ * stream, as before).  lv_get_baked_ao waits for a started bake. */
+int lv_bake_ao_start(lv_ctx* ctx);
+int lv_bake_ao_poll(lv_ctx* ctx, int* out_running, int* out_ready);
 
 /* TransferFunctionWindow texture + MinMaxUniformBuffer (Data/Shaders/Utils/TransferFunction.glsl:60-71):
  * n RGBA float texels, sampled with linear filtering at texel centres, clamp-to-edge. */

@@ -85,7 +85,7 @@ SYMBOLS = ["lv_create", "lv_destroy", "lv_last_error", "lv_version", "lv_set_str
            "lv_render", "lv_render_device", "lv_render_tiles_device", "lv_get_stats", "lv_reset_timers", "lv_get_kernel_times", "lv_get_ao_tile_costs", "lv_get_dispatch_order", "lv_trace_rays",
            "lv_compute_depth_range", "lv_get_ao", "lv_ppll_get_buffers", "lv_ppll_resolve_buffers", "lv_get_accel",
            "lv_set_tube_triangle_mesh", "lv_trace_rays_triangles", "lv_set_flow_grid", "lv_trace_streamlines",
-           "lv_get_streamlines", "lv_get_streamline_seed_indices", "lv_set_ao_parametrization", "lv_get_baked_ao", "lv_get_mlat_trace",
+           "lv_get_streamlines", "lv_get_streamline_seed_indices", "lv_set_ao_parametrization", "lv_get_baked_ao", "lv_bake_ao_start", "lv_bake_ao_poll", "lv_get_mlat_trace",
            "lv_create_multi", "lv_multi_ranks", "lv_multi_rank_stats", "lv_multi_rebalance", "lv_multi_deal", "lv_tile_deal", "lv_make_tiles"]
 
 _lib = None
@@ -127,6 +127,8 @@ def load():
     for name, args in [
         ("lv_multi_rebalance", [vp, C.c_double]),
         ("lv_multi_rank_stats", [vp, i32, vp]),
+        ("lv_bake_ao_start", [vp]),
+        ("lv_bake_ao_poll", [vp, C.POINTER(i32), C.POINTER(i32)]),
         ("lv_multi_deal", [vp, vp, u32, C.POINTER(u32)]),
         ("lv_tile_deal", [vp, u32, u32, vp]),
         ("lv_set_stream", [vp, vp]),
@@ -410,6 +412,16 @@ class Context:
         if n.value:
             self._ck(self.L.lv_get_dispatch_order(self.h, _p(order), _p(cost), n.value, C.byref(n)))
         return order, cost
+
+    def bake_ao_start(self):
+        """queue the static RTAO bake on the context's second stream and return"""
+        self._ck(self.L.lv_bake_ao_start(self.h))
+
+    def bake_ao_poll(self):
+        """(running, ready) of the asynchronous bake; never blocks"""
+        a, b = C.c_int(0), C.c_int(0)
+        self._ck(self.L.lv_bake_ao_poll(self.h, C.byref(a), C.byref(b)))
+        return bool(a.value), bool(b.value)
 
     def rank_stats(self, rank):
         """lv_stats of one rank of a multi-device handle (nothing summed)."""

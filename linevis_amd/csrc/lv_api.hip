@@ -102,7 +102,8 @@ static std::vector<LvDeviceBuffer*> lv_all_buffers(lv_ctx* ctx) {
             &ctx->counters, &ctx->ppllNodes, &ctx->ppllStart, &ctx->ppllCount, &ctx->ppllScratch, &ctx->prismRecords, &ctx->scanTemp, &ctx->tilesDev, &ctx->outDev,
             &ctx->scratchRays, &ctx->stackOverflow, &ctx->triIdx, &ctx->triVerts, &ctx->triPoints, &ctx->triNodes, &ctx->tris,
             &ctx->flowVectors, &ctx->flowScalars, &ctx->flowMisc, &ctx->flowSeeds, &ctx->flowOutPos, &ctx->flowOutAtt, &ctx->flowCounts,
-            &ctx->bakeBlendingWeights, &ctx->bakeSamplingLocations, &ctx->bakedAo, &ctx->bakeLcgSkip, &ctx->mlatTrace, &ctx->buildArena,
+            &ctx->bakeBlendingWeights, &ctx->bakeSamplingLocations, &ctx->bakedAo, &ctx->bakeLcgSkip, &ctx->bakedAoPending, &ctx->bakeCounters,
+            &ctx->bakeGbuf, &ctx->bakeSamples, &ctx->bakeOverflow, &ctx->mlatTrace, &ctx->buildArena,
             &ctx->accum, &ctx->groupOrder[0].cost, &ctx->groupOrder[0].order, &ctx->groupOrder[1].cost, &ctx->groupOrder[1].order};
 }
 
@@ -187,6 +188,12 @@ void lv_destroy(lv_ctx* ctx) {
     if (ctx->multi) lv_multi_destroy(ctx); // the other ranks, the communicators and the gather buffers
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->bakeStream) {
+        (void)hipStreamSynchronize(ctx->bakeStream);
+        (void)hipStreamDestroy(ctx->bakeStream);
+        (void)hipEventDestroy(ctx->evBakePrereq);
+        (void)hipEventDestroy(ctx->evBakeDone);
+    }
     for (LvDeviceBuffer* b : lv_all_buffers(ctx))
         lv_buf_free(*b);
     if (ctx->evCreated) {
@@ -276,7 +283,7 @@ int lv_set_tube_triangle_mesh(lv_ctx* ctx, const uint32_t* triangle_indices, uin
     ctx->numTriPoints = num_line_points;
     ctx->triMeshSet = true;
     ctx->triAccelValid = false;
-    ctx->bakeValid = false;
+    lv_invalidate_bake(ctx);
     return lv_forward_to_ranks(ctx, [&](lv_ctx* p) { return lv_set_tube_triangle_mesh(p, triangle_indices, num_triangles, vertices, num_vertices, line_points, num_line_points); });
 }
 
@@ -307,7 +314,7 @@ int lv_set_ao_parametrization(lv_ctx* ctx, const float* blending_weights, uint32
     ctx->bakeNumLineVertices = num_line_vertices;
     ctx->bakeNumParametrizationVertices = num_parametrization_vertices;
     ctx->bakeParamSet = true;
-    ctx->bakeValid = false;
+    lv_invalidate_bake(ctx);
     return lv_forward_to_ranks(ctx, [&](lv_ctx* p) { return lv_set_ao_parametrization(p, blending_weights, num_line_vertices, sampling_locations, num_parametrization_vertices); });
 }
 
@@ -315,11 +322,41 @@ int lv_get_baked_ao(lv_ctx* ctx, float* out, uint64_t max_values) {
     if (!ctx || !out) return LV_E_INVALID;
     (void)hipSetDevice(ctx->device);
     int rc;
+    if (!ctx->bakeValid && ctx->bakeAsyncPending && (rc = lv_bake_poll(ctx, true))) return rc;   // a started bake: wait for it
     if (!ctx->bakeValid && (rc = lv_bake_ambient_occlusion(ctx))) return rc;
     const uint64_t n = uint64_t(ctx->bakeNumParametrizationVertices) * ctx->opt.bakeNumTubeSubdivisions;
     if (max_values < n) return lv_fail(ctx, LV_E_CAPACITY, "baked AO table holds %llu values", (unsigned long long)n);
     if (n) LV_HIP(ctx, hipMemcpyAsync(out, ctx->bakedAo.ptr, size_t(n) * 4, hipMemcpyDeviceToHost, ctx->stream));
     LV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return LV_OK;
+}
+
+int lv_bake_ao_start(lv_ctx* ctx) {
+    if (!ctx) return LV_E_INVALID;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->bakeAsyncPending && ctx->bakePendingGeneration == ctx->bakeGeneration) return LV_OK; // already on its way
+    int rc;
+    if (ctx->bakeAsyncPending && (rc = lv_bake_poll(ctx, true))) return rc;   // a stale one: let it finish, its table is dropped
+    if ((rc = lv_bake_ambient_occlusion(ctx, true))) return rc;
+    return lv_forward_to_ranks(ctx, [&](lv_ctx* p) { return lv_bake_ao_start(p); });
+}
+
+int lv_bake_ao_poll(lv_ctx* ctx, int* out_running, int* out_ready) {
+    if (!ctx) return LV_E_INVALID;
+    (void)hipSetDevice(ctx->device);
+    int running = 0, ready = 1;
+    const int n = lv_multi_num_ranks(ctx);
+    for (int r = 0; r < n; r++) {
+        lv_ctx* c = lv_multi_rank(ctx, r);
+        (void)hipSetDevice(c->device);
+        const int rc = lv_bake_poll(c, false);
+        if (rc) return c == ctx ? rc : lv_fail(ctx, rc, "rank %d: %s", r, c->lastError.c_str());
+        running |= c->bakeAsyncPending ? 1 : 0;
+        ready &= c->bakeValid ? 1 : 0;
+    }
+    (void)hipSetDevice(ctx->device);
+    if (out_running) *out_running = running;
+    if (out_ready) *out_ready = ready;
     return LV_OK;
 }
 
@@ -370,7 +407,7 @@ int lv_set_option(lv_ctx* ctx, const char* key, const char* value) {
     uint32_t u;
     if (k == "line_width") {
         if (!parseFloat(value, f) || !(f > 0.0f)) return bad();
-        if (f != o.lineWidth) ctx->bakeValid = false;
+        if (f != o.lineWidth) lv_invalidate_bake(ctx);
         o.lineWidth = f; // accel rebuilt lazily (setTriangleRepresentationDirty, LineRenderer.cpp:436-441)
     } else if (k == "depth_cue_strength") {
         if (!parseFloat(value, f)) return bad();
@@ -398,22 +435,22 @@ int lv_set_option(lv_ctx* ctx, const char* key, const char* value) {
         o.aoSamplesPerFrame = u;
     } else if (k == "ambient_occlusion_radius") {
         if (!parseFloat(value, f) || !(f > 0.0f)) return bad();
-        if (f != o.aoRadius) ctx->bakeValid = false;
+        if (f != o.aoRadius) lv_invalidate_bake(ctx);
         o.aoRadius = f;
     } else if (k == "ambient_occlusion_distance_based") {
-        if (parseBool(value) != o.aoUseDistance) ctx->bakeValid = false;
+        if (parseBool(value) != o.aoUseDistance) lv_invalidate_bake(ctx);
         o.aoUseDistance = parseBool(value);
     } else if (k == "rtao_prebaker_iterations") {            // VulkanAmbientOcclusionBaker.hpp:108 (GUI-only there)
         if (!parseUint(value, u) || u == 0) return bad();
-        if (u != o.bakeIterations) ctx->bakeValid = false;
+        if (u != o.bakeIterations) lv_invalidate_bake(ctx);
         o.bakeIterations = u;
     } else if (k == "rtao_prebaker_samples_per_frame") {     // :166
         if (!parseUint(value, u) || u == 0 || u > 4096) return bad();
-        if (u != o.bakeSamplesPerFrame) ctx->bakeValid = false;
+        if (u != o.bakeSamplesPerFrame) lv_invalidate_bake(ctx);
         o.bakeSamplesPerFrame = u;
     } else if (k == "rtao_prebaker_num_tube_subdivisions") { // :165
         if (!parseUint(value, u) || u < 3 || u > 64) return bad();
-        if (u != o.bakeNumTubeSubdivisions) ctx->bakeValid = false;
+        if (u != o.bakeNumTubeSubdivisions) lv_invalidate_bake(ctx);
         o.bakeNumTubeSubdivisions = u;
     } else if (k == "use_jittered_primary_rays") {
         o.aoJitterPrimary = parseBool(value);
@@ -578,12 +615,12 @@ int lv_set_option(lv_ctx* ctx, const char* key, const char* value) {
         // triangles per leaf of the triangle LBVH (build-owned; the hits do not depend on it)
         uint32_t g;
         if (!parseUint(value, g) || g < 1 || g > 8) return bad();
-        if (g != o.triLeafSize) { ctx->triAccelValid = false; ctx->bakeValid = false; }
+        if (g != o.triLeafSize) { ctx->triAccelValid = false; lv_invalidate_bake(ctx); }
         o.triLeafSize = g;
     } else if (k == "treelet_leaves") {
         uint32_t t;
         if (!parseUint(value, t) || t < 3 || t > 4096) return bad();
-        if (t != o.treeletLeaves) { ctx->accelValid = false; ctx->triAccelValid = false; ctx->bakeValid = false; }
+        if (t != o.treeletLeaves) { ctx->accelValid = false; ctx->triAccelValid = false; lv_invalidate_bake(ctx); }
         o.treeletLeaves = t;
     } else if (k == "accel_build") {
         // the analogue of the reference's VK_BUILD_ACCELERATION_STRUCTURE_PREFER_FAST_TRACE_BIT_KHR (LineData.cpp:740-741): "fast_trace"
@@ -592,7 +629,7 @@ int lv_set_option(lv_ctx* ctx, const char* key, const char* value) {
         if (std::string(value) == "fast_trace") ft = true;
         else if (std::string(value) == "fast_build") ft = false;
         else return bad();
-        if (ft != o.accelFastTrace) { ctx->accelValid = false; ctx->triAccelValid = false; ctx->bakeValid = false; }
+        if (ft != o.accelFastTrace) { ctx->accelValid = false; ctx->triAccelValid = false; lv_invalidate_bake(ctx); }
         o.accelFastTrace = ft;
     } else if (k == "dispatch_order") {
         // tile kernels: "cost" = the 64x64-pixel groups start in the order of what they cost in the previous frame, heaviest

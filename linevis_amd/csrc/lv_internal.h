@@ -134,6 +134,15 @@ struct lv_ctx {
     LvDeviceBuffer bakeBlendingWeights, bakeSamplingLocations, bakedAo, bakeLcgSkip;
     uint32_t bakeNumLineVertices = 0, bakeNumParametrizationVertices = 0;
     bool bakeParamSet = false, bakeValid = false;
+    // asynchronous bake (lv_bake_ao_start): the table is computed on a second stream with scratch buffers of its own while frames keep
+    // rendering on the context's stream; lv_bake_ao_poll / the next frame adopt it once the stream has finished
+    hipStream_t bakeStream = nullptr;
+    hipEvent_t evBakePrereq = nullptr, evBakeDone = nullptr;
+    bool bakeAsyncPending = false;            // a bake is queued / running on bakeStream
+    uint64_t bakeGeneration = 0, bakePendingGeneration = 0; // bumped by everything that invalidates a table
+    LvDeviceBuffer bakedAoPending, bakeCounters, bakeGbuf, bakeSamples, bakeOverflow;
+    std::vector<uint32_t> bakeSkipHost;       // LCG skip-ahead table (source of an asynchronous upload: must outlive the call)
+    uint32_t bakeSlotsHost = 0;
 
     // streamline tracing (lv_flow.hip)
     LvDeviceBuffer flowVectors, flowScalars, flowMisc, flowSeeds, flowOutPos, flowOutAtt, flowCounts;
@@ -281,7 +290,15 @@ int lv_frame_trace_rays(lv_ctx* ctx, const float* o, const float* d, float tMin,
                         uint32_t* outSeg, uint32_t* outKind);
 int lv_frame_trace_rays_triangles(lv_ctx* ctx, const float* o, const float* d, float tMin, float tMax, uint32_t n,
                                   float* outT, uint32_t* outTri, float* outUV);
-int lv_bake_ambient_occlusion(lv_ctx* ctx);
+int lv_bake_ambient_occlusion(lv_ctx* ctx, bool async = false);
+int lv_bake_poll(lv_ctx* ctx, bool wait);
+// everything that changes what a baked table depends on: a running asynchronous bake still reads the old inputs, so it is waited for
+// (and its result discarded: the generation no longer matches)
+inline void lv_invalidate_bake(lv_ctx* ctx) {
+    if (ctx->bakeAsyncPending) (void)hipEventSynchronize(ctx->evBakeDone);
+    ctx->bakeValid = false;
+    ctx->bakeGeneration++;
+}
 int lv_frame_depth_range(lv_ctx* ctx);
 int lv_frame_ppll_resolve_only(lv_ctx* ctx, const uint32_t* nodes, uint64_t numNodes, const uint32_t* start,
                                uint64_t numPixels, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, uint8_t* out);

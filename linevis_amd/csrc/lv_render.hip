@@ -2060,6 +2060,12 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
     ctx->aoNumGroups = 0;
     if (U.useAmbientOcclusion && !U.aoPrebaked)
         if ((rc = lv_run_ao(ctx, U, S, T, gridTiles, maxPixels))) return rc;
+    if (U.aoPrebaked && !ctx->bakeValid && ctx->bakeAsyncPending) {
+        // a bake is running on the second stream (lv_bake_ao_start): adopt its table if it has finished; otherwise this frame is
+        // rendered without ambient occlusion -- "display the AO once baking has finished" (AmbientOcclusionBaker.hpp:66-70)
+        if ((rc = lv_bake_poll(ctx, false))) return rc;
+        if (!ctx->bakeValid && ctx->bakeAsyncPending) { U.aoPrebaked = 0u; U.useAmbientOcclusion = 0u; }
+    }
     if (U.aoPrebaked) {
         // static prebaker: view independent, (re)baked only when geometry or baking settings changed
         if (!ctx->bakeValid) {
@@ -2322,7 +2328,11 @@ int lv_frame_trace_rays_triangles(lv_ctx* ctx, const float* o, const float* d, f
 // baking shader, each averaging numAmbientOcclusionSamplesPerFrame rays per (parametrisation vertex, tube subdivision),
 // accumulated as a running mean.  Rays hit the triangle tubes (the reference binds the triangle TLAS, cpp:480) and run
 // through the same persistent work-queue kernel as the screen-space pass.
-int lv_bake_ambient_occlusion(lv_ctx* ctx) {
+// async == false: on the context's stream with the frame's scratch buffers; the table is valid when the call returns (to the stream).
+// async == true (lv_bake_ao_start; the reference's BakingMode::MULTI_THREADED, VulkanAmbientOcclusionBaker.cpp:266-346): on a second
+// stream, into a second table, with scratch buffers and counters of its own -- frames keep rendering on the context's stream (without
+// AO, or with the previous table's AO while that is still valid) until lv_bake_poll finds the stream finished and swaps the tables.
+int lv_bake_ambient_occlusion(lv_ctx* ctx, bool async) {
     const LvOptions& o = ctx->opt;
     if (!ctx->triMeshSet) return lv_fail(ctx, LV_E_STATE, "the RTAO prebaker needs lv_set_tube_triangle_mesh");
     if (!ctx->bakeParamSet) return lv_fail(ctx, LV_E_STATE, "the RTAO prebaker needs lv_set_ao_parametrization");
@@ -2332,17 +2342,32 @@ int lv_bake_ambient_occlusion(lv_ctx* ctx) {
     int rc;
     if (!ctx->triAccelValid || ctx->triAccelLineWidth != o.lineWidth)
         if ((rc = lv_bvh_build_triangles(ctx))) return rc;
-    hipStream_t st = ctx->stream;
+    if (async && !ctx->bakeStream) {
+        LV_HIP(ctx, hipStreamCreateWithFlags(&ctx->bakeStream, hipStreamNonBlocking));
+        LV_HIP(ctx, hipEventCreateWithFlags(&ctx->evBakePrereq, hipEventDisableTiming));
+        LV_HIP(ctx, hipEventCreateWithFlags(&ctx->evBakeDone, hipEventDisableTiming));
+    }
+    hipStream_t st = async ? ctx->bakeStream : ctx->stream;
     const uint32_t N = o.bakeNumTubeSubdivisions, spp = o.bakeSamplesPerFrame, M = ctx->bakeNumParametrizationVertices;
     const uint64_t slots = uint64_t(M) * N;
-    if (slots == 0) { ctx->bakeValid = true; return LV_OK; }
     if (slots > 0x7FFFFFFFull) return lv_fail(ctx, LV_E_CAPACITY, "too many AO bake entries");
-    if ((rc = lv_buf_reserve(ctx, ctx->counters, sizeof(LvDevCounters)))) return rc;
-    if ((rc = lv_buf_reserve(ctx, ctx->bakedAo, size_t(slots) * 4))) return rc;
-    if ((rc = lv_buf_reserve(ctx, ctx->aoGbuf, size_t(slots) * 48))) return rc;
-    if ((rc = lv_buf_reserve(ctx, ctx->aoSamples, size_t(slots) * spp * 4))) return rc;
+    LvDeviceBuffer& counters = async ? ctx->bakeCounters : ctx->counters;
+    LvDeviceBuffer& gbuf = async ? ctx->bakeGbuf : ctx->aoGbuf;
+    LvDeviceBuffer& samples = async ? ctx->bakeSamples : ctx->aoSamples;
+    LvDeviceBuffer& table = async ? ctx->bakedAoPending : ctx->bakedAo;
+    if (slots == 0) {
+        if (async) { ctx->bakeAsyncPending = false; }
+        ctx->bakeValid = true;
+        return LV_OK;
+    }
+    if ((rc = lv_buf_reserve(ctx, counters, sizeof(LvDevCounters)))) return rc;
+    if ((rc = lv_buf_reserve(ctx, table, size_t(slots) * 4))) return rc;
+    if ((rc = lv_buf_reserve(ctx, gbuf, size_t(slots) * 48))) return rc;
+    if ((rc = lv_buf_reserve(ctx, samples, size_t(slots) * spp * 4))) return rc;
     // LCG skip-ahead table: state after j steps = A_j * s + C_j (a = 1664525, c = 1013904223, RayTracingUtilities.glsl:169-175)
-    std::vector<uint32_t> skip(size_t(4) * N * spp);
+    std::vector<uint32_t>& skip = ctx->bakeSkipHost;   // (kept in the context: source of an asynchronous upload)
+    if (ctx->bakeAsyncPending) LV_HIP(ctx, hipEventSynchronize(ctx->evBakeDone));   // the previous upload may still read it
+    skip.assign(size_t(4) * N * spp, 0u);
     {
         uint32_t A = 1u, C = 0u;
         for (size_t j = 0; j < size_t(2) * N * spp; j++) {
@@ -2352,23 +2377,35 @@ int lv_bake_ambient_occlusion(lv_ctx* ctx) {
         }
     }
     if ((rc = lv_buf_reserve(ctx, ctx->bakeLcgSkip, skip.size() * 4))) return rc;
-    LV_HIP(ctx, hipMemcpyAsync(ctx->bakeLcgSkip.ptr, skip.data(), skip.size() * 4, hipMemcpyHostToDevice, st));
     LvUniforms U;
     lv_fill_uniforms(ctx, U);
     U.aoSamplesPerFrame = spp;
     LvSceneDev SA = sceneDevTriangles(ctx);
     const uint64_t gridRays = lv_ao_grid(ctx, slots * spp);
-    if ((rc = lv_prepare_overflow(ctx, SA, gridRays, LV_AO_STACK_LDS, true))) return rc;
-    LvDevCounters* dc = (LvDevCounters*)ctx->counters.ptr;
-    float4* g = (float4*)ctx->aoGbuf.ptr;
-    float* smp = (float*)ctx->aoSamples.ptr;
-    float* out = (float*)ctx->bakedAo.ptr;
+    if (async) {
+        // stack overflow slab of its own (the frames' slab is in use on the other stream)
+        SA.stackOverflow = nullptr;
+        const uint64_t maxEntries = 3ull * uint64_t(ctx->triWideDepth) + 2;
+        if (maxEntries > LV_AO_STACK_LDS) {
+            if ((rc = lv_buf_reserve(ctx, ctx->bakeOverflow, size_t(gridRays) * LV_BLOCK * (maxEntries - LV_AO_STACK_LDS) * 4))) return rc;
+            SA.stackOverflow = (unsigned*)ctx->bakeOverflow.ptr;
+        }
+        // everything queued on the context's stream so far (mesh upload, triangle LBVH) comes first
+        LV_HIP(ctx, hipEventRecord(ctx->evBakePrereq, ctx->stream));
+        LV_HIP(ctx, hipStreamWaitEvent(st, ctx->evBakePrereq, 0));
+    } else if ((rc = lv_prepare_overflow(ctx, SA, gridRays, LV_AO_STACK_LDS, true))) {
+        return rc;
+    }
+    LV_HIP(ctx, hipMemcpyAsync(ctx->bakeLcgSkip.ptr, skip.data(), skip.size() * 4, hipMemcpyHostToDevice, st));
+    LvDevCounters* dc = (LvDevCounters*)counters.ptr;
+    float4* g = (float4*)gbuf.ptr;
+    float* smp = (float*)samples.ptr;
+    float* out = (float*)table.ptr;
     k_bake_setup<<<nblocks(slots), LV_BLOCK, 0, st>>>((const lv_line_point*)ctx->triPoints.ptr, ctx->numTriPoints,
                                                       (const float*)ctx->bakeSamplingLocations.ptr, M, N,
                                                       o.lineWidth * 0.5f, g);
-    const uint32_t slots32 = uint32_t(slots);
-    LV_HIP(ctx, hipMemcpyAsync(&dc->aoCount, &slots32, 4, hipMemcpyHostToDevice, st));
-    LV_HIP(ctx, hipStreamSynchronize(st)); // skip[] and slots32 live on this stack frame
+    ctx->bakeSlotsHost = uint32_t(slots);
+    LV_HIP(ctx, hipMemcpyAsync(&dc->aoCount, &ctx->bakeSlotsHost, 4, hipMemcpyHostToDevice, st));
     for (uint32_t iter = 0; iter < o.bakeIterations; iter++) {
         U.aoFrameNumber = iter;
         LV_HIP(ctx, hipMemsetAsync(&dc->aoQueueHead, 0, 8, st));
@@ -2381,6 +2418,33 @@ int lv_bake_ambient_occlusion(lv_ctx* ctx) {
         k_ao_reduce<true><<<nblocks(slots), LV_BLOCK, 0, st>>>(U, g, smp, out, out, dc, nullptr, 0u, LvAoLayout{0u, 0u, 1u, 1u});
     }
     LV_HIP(ctx, hipGetLastError());
-    ctx->bakeValid = true;
+    if (async) {
+        LV_HIP(ctx, hipEventRecord(ctx->evBakeDone, st));
+        ctx->bakeAsyncPending = true;
+        ctx->bakePendingGeneration = ctx->bakeGeneration;
+    } else {
+        ctx->bakeValid = true;
+    }
+    return LV_OK;
+}
+
+// Adopts the table of a finished asynchronous bake (wait == true: blocks until it has finished).  A table whose inputs changed while
+// it was being computed (lv_invalidate_bake) is dropped.
+int lv_bake_poll(lv_ctx* ctx, bool wait) {
+    if (!ctx->bakeAsyncPending) return LV_OK;
+    if (wait) {
+        LV_HIP(ctx, hipEventSynchronize(ctx->evBakeDone));
+    } else {
+        const hipError_t e = hipEventQuery(ctx->evBakeDone);
+        if (e == hipErrorNotReady) return LV_OK;
+        if (e != hipSuccess) return lv_fail(ctx, LV_E_HIP, "hipEventQuery failed: %s", hipGetErrorString(e));
+    }
+    ctx->bakeAsyncPending = false;
+    if (ctx->bakePendingGeneration == ctx->bakeGeneration) {
+        // the context's stream may still shade a frame with the old table: order the swap behind it
+        LV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        std::swap(ctx->bakedAo, ctx->bakedAoPending);
+        ctx->bakeValid = true;
+    }
     return LV_OK;
 }

@@ -132,6 +132,7 @@ void computeAmbientOcclusionParametrization(const std::vector<std::vector<vec3>>
 void HipAmbientOcclusionBaker::startAmbientOcclusionBaking(LineDataPtr&, bool) {
     isDataReady = false;
     parametrizationDirty = true;
+    bakeSettingsDirty = true;
 }
 
 bool HipAmbientOcclusionBaker::uploadParametrization(LineDataPtr& lineData) {
@@ -144,8 +145,36 @@ bool HipAmbientOcclusionBaker::uploadParametrization(LineDataPtr& lineData) {
     if (rc != LV_OK) return false;
     numParametrizationVertices = uint32_t(samplingLocations.size());
     parametrizationDirty = false;
-    isDataReady = true; // baking itself runs inside the next lv_render call
+    if (bakingMode == BakingMode::MULTI_THREADED) {
+        bakeSettingsDirty = true;   // started below, once mesh and parametrisation are both in place
+    } else {
+        isDataReady = true; // baking itself runs inside the next lv_render call
+    }
     return true;
+}
+
+bool HipAmbientOcclusionBaker::getIsComputationRunning() {
+    if (bakingMode != BakingMode::MULTI_THREADED || !bakeStarted) return false;
+    int running = 0, ready = 0;
+    if (lv_bake_ao_poll(ctx, &running, &ready) != LV_OK) return false;
+    return running != 0;
+}
+
+bool HipAmbientOcclusionBaker::getIsDataReady() {
+    if (bakingMode != BakingMode::MULTI_THREADED) return isDataReady;
+    if (!bakeStarted) return false;
+    int running = 0, ready = 0;
+    if (lv_bake_ao_poll(ctx, &running, &ready) != LV_OK) return false;
+    if (ready && !isDataReady) threadUpdatePending = true;
+    isDataReady = ready != 0;
+    return isDataReady;
+}
+
+bool HipAmbientOcclusionBaker::getHasThreadUpdate() {
+    getIsDataReady();
+    const bool u = threadUpdatePending;
+    threadUpdatePending = false;
+    return u;
 }
 
 // The reference exposes these only through its GUI (renderGuiPropertyEditorNodes, VulkanAmbientOcclusionBaker.cpp:412-470);
@@ -163,7 +192,12 @@ bool HipAmbientOcclusionBaker::setNewSettings(const SettingsMap& settings) {
         parametrizationDirty = true;
         changed = true;
     }
-    if (changed) pushSettings();
+    std::string mode;
+    if (settings.getValueOpt("rtao_prebaker_baking_mode", mode)) {
+        const BakingMode m = mode == BAKING_MODE_NAMES[2] ? BakingMode::MULTI_THREADED : BakingMode::IMMEDIATE;
+        if (m != bakingMode) { bakingMode = m; isDataReady = false; bakeStarted = false; bakeSettingsDirty = true; changed = true; }
+    }
+    if (changed) { pushSettings(); bakeSettingsDirty = true; isDataReady = bakingMode != BakingMode::MULTI_THREADED && !parametrizationDirty; }
     return changed;
 }
 
@@ -231,6 +265,10 @@ bool LineRenderer::setOption(const char* key, const std::string& value) {
 bool LineRenderer::needsReRender() {
     bool tmp = reRender;
     reRender = false;
+    // LineRenderer::renderBase, LineRenderer.cpp:265-269: a finished multi-threaded bake asks for one more frame (now with the AO)
+    if (useAmbientOcclusion && ambientOcclusionBaker && ambientOcclusionBaker->getIsStaticPrebaker() &&
+        static_cast<HipAmbientOcclusionBaker*>(ambientOcclusionBaker.get())->getHasThreadUpdate())
+        tmp = true;
     return tmp;
 }
 
@@ -401,11 +439,27 @@ bool LineRenderer::uploadFrameState() {
                    "lv_set_tube_triangle_mesh"))
             return false;
         triangleMeshDirty = false;
+        if (prebaker) static_cast<HipAmbientOcclusionBaker*>(ambientOcclusionBaker.get())->notifyInputsChanged();
     }
-    if (prebaker && !static_cast<HipAmbientOcclusionBaker*>(ambientOcclusionBaker.get())->uploadParametrization(lineData)) {
-        check(LV_E_INVALID, "lv_set_ao_parametrization");
-        return false;
+    if (prebaker) {
+        HipAmbientOcclusionBaker* baker = static_cast<HipAmbientOcclusionBaker*>(ambientOcclusionBaker.get());
+        if (!baker->uploadParametrization(lineData)) {
+            check(LV_E_INVALID, "lv_set_ao_parametrization");
+            return false;
+        }
+        // BakingMode::MULTI_THREADED: (re)start the bake on the second stream whenever its inputs changed; this frame and the
+        // following ones come out without AO until the table is in place
+        if (!baker->startAsyncBakeIfNeeded()) { check(LV_E_HIP, "lv_bake_ao_start"); return false; }
     }
+    return true;
+}
+
+bool HipAmbientOcclusionBaker::startAsyncBakeIfNeeded() {
+    if (bakingMode != BakingMode::MULTI_THREADED || !bakeSettingsDirty) return true;
+    bakeSettingsDirty = false;
+    isDataReady = false;
+    if (lv_bake_ao_start(ctx) != LV_OK) return false;
+    bakeStarted = true;
     return true;
 }
 

@@ -89,6 +89,10 @@ struct SceneData {
 enum class AmbientOcclusionBakerType { NONE = -1, RTAO_PREBAKER = 0, RTAO = 1, SSAO = 2, GTAO = 3 };
 extern const char* const AMBIENT_OCCLUSION_BAKER_TYPE_NAMES[4];
 
+/// AmbientOcclusionBaker.hpp:66-76
+enum class BakingMode { IMMEDIATE, ITERATIVE_UPDATE, MULTI_THREADED };
+const char* const BAKING_MODE_NAMES[] = {"Immediate", "Iterative", "Multi-Threaded"};
+
 class AmbientOcclusionBaker {
 public:
     virtual ~AmbientOcclusionBaker() = default;
@@ -139,12 +143,23 @@ public:
     AmbientOcclusionBakerType getType() override { return AmbientOcclusionBakerType::RTAO_PREBAKER; }
     bool getIsStaticPrebaker() override { return true; }
     void startAmbientOcclusionBaking(LineDataPtr& lineData, bool isNewData) override;
-    bool getIsDataReady() override { return isDataReady; }
-    bool getHasComputationFinished() override { return isDataReady; }
+    /// BakingMode::IMMEDIATE (default here): the table is baked on the context's stream by the first frame that needs it.
+    /// BakingMode::MULTI_THREADED (AmbientOcclusionBaker.hpp:66-73; the reference's worker thread, VulkanAmbientOcclusionBaker.cpp:
+    /// 266-346): lv_bake_ao_start on a second HIP stream -- frames rendered meanwhile show no AO, getIsDataReady() turns true (and
+    /// needsReRender() once) when the table is in place.  Settings key (build-owned): rtao_prebaker_baking_mode.
+    BakingMode getBakingMode() const { return bakingMode; }
+    bool getIsDataReady() override;
+    bool getIsComputationRunning();
+    bool getHasComputationFinished() override { return getIsDataReady(); }
+    /// true once after an asynchronous bake has finished (the frame has to be rendered again with the AO)
+    bool getHasThreadUpdate();
     bool setNewSettings(const SettingsMap& settings) override;
     void pushSettings();
-    /// uploads the parametrisation when it is out of date (new data / new expectedParamSegmentLength)
+    /// uploads the parametrisation when it is out of date (new data / new expectedParamSegmentLength); MULTI_THREADED: starts the bake
     bool uploadParametrization(LineDataPtr& lineData);
+    bool startAsyncBakeIfNeeded();
+    /// the mesh / line width changed: a MULTI_THREADED bake has to start again
+    void notifyInputsChanged() { bakeSettingsDirty = true; if (bakingMode == BakingMode::MULTI_THREADED) isDataReady = false; }
     uint32_t getNumParametrizationVertices() const { return numParametrizationVertices; }
 
     int maxNumIterations = 128;                       // VulkanAmbientOcclusionBaker.hpp:108
@@ -156,7 +171,8 @@ public:
 
 private:
     lv_ctx* ctx;
-    bool isDataReady = false, parametrizationDirty = true;
+    BakingMode bakingMode = BakingMode::IMMEDIATE;
+    bool isDataReady = false, parametrizationDirty = true, bakeStarted = false, threadUpdatePending = false, bakeSettingsDirty = false;
     uint32_t numParametrizationVertices = 0;
 };
 
@@ -213,6 +229,7 @@ public:
     static float getBandWidth() { return bandWidth; }
     static void setLineWidth(float w) { lineWidth = w; }
     static void setBandWidth(float w) { bandWidth = w; }
+    AmbientOcclusionBaker* getAmbientOcclusionBaker() { return ambientOcclusionBaker.get(); }
 
 protected:
     void updateNewLineData(LineDataPtr& lineData, bool isNewData);

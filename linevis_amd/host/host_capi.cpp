@@ -424,6 +424,15 @@ void lvh_renderer_get_camera(void* rp, float* view16, float* proj16, float* fovy
 }
 const char* lvh_renderer_last_error(void* r) { return static_cast<HeadlessLineRenderer*>(r)->getLastError().c_str(); }
 int lvh_renderer_rendering_mode(void* r) { return int(static_cast<HeadlessLineRenderer*>(r)->getLineRenderer()->getRenderingMode()); }
+int lvh_renderer_needs_re_render(void* r) { return static_cast<HeadlessLineRenderer*>(r)->getLineRenderer()->needsReRender() ? 1 : 0; }
+/// state of the static AO baker of the renderer: bit 0 = data ready, bit 1 = computation running; -1 = no static prebaker
+int lvh_renderer_ao_baker_state(void* r) {
+    LineRenderer* lr = static_cast<HeadlessLineRenderer*>(r)->getLineRenderer();
+    AmbientOcclusionBaker* b = lr->getAmbientOcclusionBaker();
+    if (!b || !b->getIsStaticPrebaker()) return -1;
+    HipAmbientOcclusionBaker* hb = static_cast<HipAmbientOcclusionBaker*>(b);
+    return (hb->getIsDataReady() ? 1 : 0) | (hb->getIsComputationRunning() ? 2 : 0);
+}
 void* lvh_renderer_context(void* r) { return static_cast<HeadlessLineRenderer*>(r)->getLineRenderer()->getContext(); }
 
 } // extern "C"

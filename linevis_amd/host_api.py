@@ -87,6 +87,8 @@ def load():
         "lvh_renderer_get_camera": (None, [vp, vp, vp, vp]),
         "lvh_renderer_last_error": (cp, [vp]),
         "lvh_renderer_rendering_mode": (i32, [vp]),
+        "lvh_renderer_needs_re_render": (i32, [vp]),
+        "lvh_renderer_ao_baker_state": (i32, [vp]),
         "lvh_renderer_context": (vp, [vp]),
     }
     for name, (res, args) in sig.items():
@@ -508,6 +510,14 @@ class HeadlessLineRenderer:
     @property
     def rendering_mode(self):
         return int(self.L.lvh_renderer_rendering_mode(self.h))
+
+    def needs_re_render(self):
+        return bool(self.L.lvh_renderer_needs_re_render(self.h))
+
+    def ao_baker_state(self):
+        """(data_ready, computation_running) of the static AO baker, or None without one"""
+        v = int(self.L.lvh_renderer_ao_baker_state(self.h))
+        return None if v < 0 else (bool(v & 1), bool(v & 2))
 
     def stats(self):
         s = capi.Stats()

