@@ -83,7 +83,7 @@ WORKLOADS = {
                scene="tornado", mode=2, settings={"ppll_max_num_frags": 64, "ppll_expected_avg_depth_complexity": 20,
                                                   "depth_cue_strength": 0.0, "use_capped_tubes": False,
                                                   "ppll_fragment_source": "raster_prism"},
-               kernel="k_ppll_gather", transparent=True, also="c4c", also_suffix="capsule_entry"),
+               kernel="k_ppll_raster_prism", also_kernel="k_ppll_gather", transparent=True, also="c4c", also_suffix="capsule_entry"),
     "c4c": dict(name="C4 scene and settings with ppll_fragment_source=capsule_entry: fragments = entry hits of the pixel-centre ray "
                      "against the analytic (uncapped) capsules -- the probe of rounds 1-3, NOT the reference's geometry",
                 scene="tornado", mode=2, settings={"ppll_max_num_frags": 64, "ppll_expected_avg_depth_complexity": 20,
@@ -232,9 +232,11 @@ def roofline(kernel, pmc_key, ms_launch, algorithmic_bytes, world):
     sha = lv_build.source_sha()
     out = {"kernel": kernel, "ms_per_launch": round(ms_launch, 4), "algorithmic_bytes_per_launch": int(algorithmic_bytes),
            "algorithmic_touch_rate_GBs": round(algorithmic_bytes / (ms_launch * 1e-3) / 1e9, 1) if ms_launch > 0 else None,
-           "algorithmic_note": "SURVEY.md 8(d) byte model: 64 B per node visited + 32/48 B per primitive tested + per-pixel records, "
-                               "'every touch goes to memory'; most of these bytes are served by L1/L2 (see ceilings): NOT a "
-                               "bandwidth and not bounded by the HBM peak",
+           "algorithmic_note": ("segment rasteriser: 96 B per segment (record + frames) + 4 B per coverage test + 16 B per fragment "
+                                "(12-B record, count update): compulsory bytes of the launch" if kernel == "k_ppll_raster_prism" else
+                                "SURVEY.md 8(d) byte model: 64 B per node visited + 32/48 B per primitive tested + per-pixel records, "
+                                "'every touch goes to memory'; most of these bytes are served by L1/L2 (see ceilings): NOT a "
+                                "bandwidth and not bounded by the HBM peak"),
            "source_sha": sha}
     ppath = upath = None
     for tag in PROFILE_TAGS:
@@ -591,7 +593,13 @@ def main():
         ao_bytes = st.ao_nodes_visited * 64 + st.ao_prims_tested * prim_bytes + st.ao_hit_pixels * 52
         frame_bytes = (st.nodes_visited * 64 + st.prims_tested * 32 + st.hits_shaded * 96 + st.ao_hit_pixels * 52
                        + len(sf.local_tiles) * TILE * TILE * (4 + 4) + st.fragments * (12 + 4 + 4 + 12))
-        kernel_bytes = ao_bytes if w["kernel"] == "k_ao_rays" else frame_bytes   # c2 / c4: one traversal kernel dominates
+        kernel_bytes = ao_bytes if w["kernel"] == "k_ao_rays" else frame_bytes   # c2 / c4c: one traversal kernel dominates
+        if w["kernel"] == "k_ppll_raster_prism":
+            # the segment rasteriser: every segment's 32-B record + 64-B frames once, 4 B (requested-pixel mask) per coverage test,
+            # 12-B record + 4-B count update per fragment; then the fragment stage (12 B record in, 8 B fragment out, 4 B offset) and
+            # the resolve pass (8 B per fragment, 4 + 4 B per pixel in, 4 B out)
+            kernel_bytes = len(seg) * 96 + st.prims_tested * 4 + st.fragments * 16
+            frame_bytes = kernel_bytes + st.fragments * (12 + 8 + 4 + 8) + len(sf.local_tiles) * TILE * TILE * (4 + 4 + 4)
         local = dict(nodes_visited=int(st.nodes_visited), prims_tested=int(st.prims_tested), hits_shaded=int(st.hits_shaded),
                      ao_rays=int(st.ao_rays_traced), ao_nodes_visited=int(st.ao_nodes_visited),
                      ao_prims_tested=int(st.ao_prims_tested), ao_prim_hits=int(st.ao_prim_hits),
@@ -727,7 +735,8 @@ def main():
             result["fps_" + sfx] = round(args.steps / also["elapsed"], 3)
             result[sfx] = {"workload": WORKLOADS[wl["also"]]["name"], "rays_per_frame": int(also["rays_per_frame"]),
                                   "frame_ms": also["frame_ms"], "kernels_ms": also["kernels"], "counters_rank0": also["local"],
-                                  "roofline": roofline(kname, wl["also"], also["kernels"].get(kname, {}).get("median", 0.0),
+                                  "roofline": roofline(wl.get("also_kernel", kname), wl["also"],
+                                                       also["kernels"].get(wl.get("also_kernel", kname), {}).get("median", 0.0),
                                                        also["kernel_bytes"], world)}
         if world == 1 and not dry:
             ceil = measured_hbm_ceiling(device, torch)

@@ -108,6 +108,7 @@ typedef struct lv_stats {
 #define LV_KERNEL_PPLL_RESOLVE 4
 #define LV_KERNEL_DEPTH_RANGE 5
 #define LV_KERNEL_PPLL_SHADE 6   /* fragment stage of ppll_fragment_source = raster_prism (k_ppll_shade_prism) */
+#define LV_KERNEL_PPLL_RASTER 7  /* segment rasteriser of raster_prism (k_ppll_raster_prism; ppll_prism_rasteriser = segments) */
 
 typedef struct lv_ctx lv_ctx;
 
@@ -222,6 +223,14 @@ int lv_set_background(lv_ctx* ctx, const float rgba[4]);
  *   watertight edge-function rasteriser in the space of the pixel's viewing ray (linevis_amd/csrc/lv_prism.h) | "capsule_entry"
  *   -- entry hits of the pixel-centre ray against the analytic capsules (rounds 1-3 of this build; a probe) | "auto" (default:
  *   raster_prism for plain flow lines; capsule_entry for band data and rotating helicity bands),
+ *   ppll_prism_rasteriser (build-owned): front end of raster_prism -- "segments" (default: one lane per line segment over the
+ *   screen rectangle of its ring vertices, like the hardware the reference draws with walks primitives, not pixels) | "lbvh"
+ *   (the all-hits walk of the viewing rays through the segment LBVH); both decide every (pixel, segment) pair by the same
+ *   coverage test and produce the same fragments.  The ORDER of a pixel's fragments is not defined (the reference's fragment
+ *   shader invocations race for the list heads, LinkedListGather.glsl:55); where a pixel keeps more fragments than
+ *   ppll_max_num_frags, this build resolves the NEAREST ones by the (depth, colour) key (one of the subsets the reference's
+ *   race can leave in the first MAX_NUM_FRAGS nodes), so frames do not depend on that order; lv_ppll_get_buffers returns
+ *   every list in ascending key order,
  *   ambient_occlusion_denoiser ("None" | "Edge-Avoiding A-Trous Wavelet Transform" (UTF-8 A-grave as in Denoiser.hpp:66; "EAW"
  *   is accepted too) | "SVGF")                                         (VulkanRayTracedAmbientOcclusion.cpp:683-696)
  *   eaw_denoiser_iterations (0..5, default 3), eaw_denoiser_color_weights / _position_weights / _normal_weights,

@@ -70,7 +70,8 @@ def streamline_settings(method="Runge-Kutta 4th Order", direction="Forward & Bac
 
 
 KERNEL_AO_PRIMARY, KERNEL_AO_RAYS, KERNEL_RENDER_RT, KERNEL_PPLL_GATHER, KERNEL_PPLL_RESOLVE, KERNEL_DEPTH_RANGE = range(6)
-KERNEL_NAMES = ["k_ao_primary", "k_ao_rays", "k_render_rt", "k_ppll_gather", "k_ppll_resolve", "k_depth_minmax", "k_ppll_shade_prism"]
+KERNEL_NAMES = ["k_ao_primary", "k_ao_rays", "k_render_rt", "k_ppll_gather", "k_ppll_resolve", "k_depth_minmax", "k_ppll_shade_prism",
+                "k_ppll_raster_prism"]
 
 
 class LineVisError(RuntimeError):

@@ -1,4 +1,5 @@
 // lv_api.hip -- extern "C" entry points of include/linevis_hip.h (context, settings, orchestration glue).
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -99,7 +100,7 @@ static std::vector<LvDeviceBuffer*> lv_all_buffers(lv_ctx* ctx) {
             &ctx->eawPing, &ctx->eawPong, &ctx->tilesHaloDev, &ctx->fullFrameTile, &ctx->svgf.normalDepth, &ctx->svgf.normalDepthHistory,
             &ctx->svgf.flowFwidth, &ctx->svgf.moments, &ctx->svgf.momentsHistory, &ctx->svgf.colorHistory, &ctx->svgf.tempAccum,
             &ctx->svgf.tempAccumFiltered, &ctx->svgf.ping, &ctx->svgf.pong, &ctx->svgf.result, &ctx->aoGbuf, &ctx->aoList, &ctx->aoSamples,
-            &ctx->counters, &ctx->ppllNodes, &ctx->ppllStart, &ctx->ppllCount, &ctx->ppllScratch, &ctx->prismRecords, &ctx->scanTemp, &ctx->tilesDev, &ctx->outDev,
+            &ctx->counters, &ctx->ppllNodes, &ctx->ppllStart, &ctx->ppllCount, &ctx->ppllScratch, &ctx->prismRecords, &ctx->scanTemp, &ctx->ppllOverflow, &ctx->tilesDev, &ctx->outDev,
             &ctx->scratchRays, &ctx->stackOverflow, &ctx->triIdx, &ctx->triVerts, &ctx->triPoints, &ctx->triNodes, &ctx->tris,
             &ctx->flowVectors, &ctx->flowScalars, &ctx->flowMisc, &ctx->flowSeeds, &ctx->flowOutPos, &ctx->flowOutAtt, &ctx->flowCounts,
             &ctx->bakeBlendingWeights, &ctx->bakeSamplingLocations, &ctx->bakedAo, &ctx->bakeLcgSkip, &ctx->bakedAoPending, &ctx->bakeCounters,
@@ -611,6 +612,11 @@ int lv_set_option(lv_ctx* ctx, const char* key, const char* value) {
         else if (std::string(value) == "capsule_entry") o.ppllFragmentSource = 1;
         else if (std::string(value) == "raster_prism") o.ppllFragmentSource = 2;
         else return bad();
+    } else if (k == "ppll_prism_rasteriser") {
+        // front end of ppll_fragment_source = raster_prism: which (pixel, segment) pairs the coverage test sees
+        if (std::string(value) == "segments") o.ppllPrismLbvhWalk = false;
+        else if (std::string(value) == "lbvh") o.ppllPrismLbvhWalk = true;
+        else return bad();
     } else if (k == "triangle_leaf_size") {
         // triangles per leaf of the triangle LBVH (build-owned; the hits do not depend on it)
         uint32_t g;
@@ -973,10 +979,10 @@ int lv_ppll_get_buffers(lv_ctx* ctx, uint32_t* out_nodes, uint64_t max_nodes, ui
     if (out_frag_counter) *out_frag_counter = hc.fragCounter;
     if (ctx->ppllArrays) {
         // raster_prism frames keep every pixel's fragments as ONE contiguous run of 8-B {colour, depth} entries (offsets = exclusive
-        // scan of the per-pixel counts) instead of a linked list; the caller gets the reference's buffers (LinkedListHeader.glsl:
-        // 36-85): node index = position in the fragment array, `next` chains a pixel's live entries from the last one down -- the
-        // order the resolve pass reads them in, i.e. the list a push-to-front gather would have built.  Dead entries (discarded
-        // fragments) come out as unlinked nodes.
+        // scan of the per-pixel counts) instead of a linked list, in no defined order; the caller gets the reference's buffers
+        // (LinkedListHeader.glsl:36-85): node index = position in the fragment array, `next` chains a pixel's live entries in
+        // ascending (depth, colour) key order -- the order the resolve pass gives them, so that a literal walk of these lists
+        // (first ppllMaxNumFrags nodes) sees what the resolve pass kept.  Dead entries (discarded fragments) come out as unlinked nodes.
         const uint64_t np = uint64_t(ctx->ppllPaddedW) * ctx->ppllPaddedH;
         std::vector<uint32_t> cnt(np), off(np);
         if (np) {
@@ -990,17 +996,28 @@ int lv_ppll_get_buffers(lv_ctx* ctx, uint32_t* out_nodes, uint64_t max_nodes, ui
                                                          (unsigned long long)max_pixels, (unsigned long long)np);
         std::vector<uint32_t> fr(size_t(total) * 2);
         if (total) LV_HIP(ctx, hipMemcpy(fr.data(), ctx->ppllNodes.ptr, size_t(total) * 8, hipMemcpyDeviceToHost));
+        std::vector<uint32_t> live;
         for (uint64_t p = 0; p < np; p++) {
             const uint32_t n = cnt[p] & 0xFFFFu;
-            uint32_t prev = 0xFFFFFFFFu;
+            live.clear();
             for (uint32_t j = 0; j < n; j++) {
                 const uint64_t idx = uint64_t(off[p]) + j;
                 const uint32_t c = fr[2 * idx], d = fr[2 * idx + 1];
                 const bool dead = c == 0u && d == LV_PPLL_DEAD;
-                if (out_nodes) { out_nodes[3 * idx] = c; out_nodes[3 * idx + 1] = d; out_nodes[3 * idx + 2] = dead ? 0xFFFFFFFFu : prev; }
-                if (!dead) prev = uint32_t(idx);
+                if (out_nodes) { out_nodes[3 * idx] = c; out_nodes[3 * idx + 1] = d; out_nodes[3 * idx + 2] = 0xFFFFFFFFu; }
+                if (!dead) live.push_back(uint32_t(idx));
             }
-            if (out_start) out_start[p] = prev;
+            std::sort(live.begin(), live.end(), [&](uint32_t a, uint32_t b) {
+                float da, db;
+                std::memcpy(&da, &fr[2 * size_t(a) + 1], 4);
+                std::memcpy(&db, &fr[2 * size_t(b) + 1], 4);
+                if (da != db) return da < db;
+                if (fr[2 * size_t(a)] != fr[2 * size_t(b)]) return fr[2 * size_t(a)] < fr[2 * size_t(b)];
+                return a < b;
+            });
+            if (out_nodes)
+                for (size_t k = 0; k + 1 < live.size(); k++) out_nodes[3 * size_t(live[k]) + 2] = live[k + 1];
+            if (out_start) out_start[p] = live.empty() ? 0xFFFFFFFFu : live[0];
         }
         return LV_OK;
     }

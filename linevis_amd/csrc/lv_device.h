@@ -129,6 +129,7 @@ struct LvDevCounters {
     uint32_t fragAlloc;   // PPLL node-slot allocator (chunks); fragCounter stays the exact fragment count
     uint32_t prismDiscards;  // raster_prism: linked nodes the fragment stage turned into dead nodes (discarded fragments)
     uint32_t mlatTraceCount; // records appended to the MLAT visiting-order trace (collect_stats)
+    uint32_t ppllOverflowPixels; // raster_prism: pixels with more kept fragments than the sort arrays (k_ppll_pixel_pass's list)
     // k_ao_rays leaf-test diagnostics (collect_stats): tests that found a hit inside the interval, tests the conservative
     // axis-distance pre-test lets through, tests axis + bounding-sphere pre-tests let through
     unsigned long long aoPrimHits, aoPrimMayAxis, aoPrimMayBoth;

@@ -97,6 +97,9 @@ struct LvOptions {
     // (not built for the prism yet); 1 = capsule_entry (entry hits of the pixel-centre ray against the analytic
     // capsules: the probe of rounds 1-3); 2 = raster_prism (the rasterised N-gon prism of the reference's default primitive mode)
     int ppllFragmentSource = 0;
+    // ppll_prism_rasteriser: false = "segments" (default: one lane per line segment over its screen rectangle, k_ppll_raster_prism),
+    // true = "lbvh" (the all-hits walk of the viewing rays through the segment LBVH, k_ppll_gather<LV_PRIM_PRISM>); same fragments
+    bool ppllPrismLbvhWalk = false;
     bool ppllRayTracerColour = false;         // ppll_fragment_colour: false = "raster" (the reference's gather shader, default), true = "ray_tracer"
     bool mlatRecordTrace = false;             // with collect_stats: record every pixel's candidate visiting order
     uint32_t mlatTraceCapacity = 1u << 22;    // records (16 B each)
@@ -185,6 +188,7 @@ struct lv_ctx {
     LvDeviceBuffer counters;                  // device counters (LvCounters + misc)
     LvDeviceBuffer ppllNodes, ppllStart, ppllCount, ppllScratch;
     LvDeviceBuffer prismRecords, scanTemp;    // raster_prism: {pixel, leaf | triangle, rank} records of the coverage kernel; rocPRIM scan storage
+    LvDeviceBuffer ppllOverflow;              // raster_prism: pixel addresses with more kept fragments than ppllMaxNumFrags (k_ppll_pixel_pass)
     bool ppllArrays = false;                  // the last PPLL frame left per-pixel runs (raster_prism), not linked lists
     LvDeviceBuffer tilesDev, outDev, scratchRays, stackOverflow, mlatTrace;
     LvDeviceBuffer accum;                     // rgba8 of the previous accumulated frame (full viewport)
@@ -212,10 +216,10 @@ struct lv_ctx {
     bool evBuildValid = false, evFrameValid = false;
     int lastMode = 0;
     // per-kernel launch timers: ring of event pairs per kernel id (LV_KERNEL_*)
-    static constexpr int kNumKernels = 7;
+    static constexpr int kNumKernels = 8;
     static constexpr int kRing = 512;
     hipEvent_t evKernel[kNumKernels][2 * kRing];
-    uint64_t kernelLaunches[kNumKernels] = {0, 0, 0, 0, 0, 0, 0};
+    uint64_t kernelLaunches[kNumKernels] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
 int lv_fail(lv_ctx* ctx, int code, const char* fmt, ...);

@@ -194,12 +194,8 @@ __device__ __forceinline__ bool lv_prism_pretest(const LvSceneDev& S, float radi
 // pixel (front face, fill rule); whether its fragment is kept (ray interval, own box, depth clipping) is decided where it is shaded.
 // NT > 0: N = NT known at compile time (ring in registers, everything unrolled); NT == 0: any N <= LV_PRISM_MAX_SUBDIV.
 template <int NT>
-__device__ __forceinline__ unsigned lv_prism_coverage(const LvSceneDev& S, float radius, uint32_t leaf, f3 o, f3 d) {
-    const LvPrismDev& R = S.prism;
-    const float4 pa = S.segs[2 * size_t(leaf)], pb = S.segs[2 * size_t(leaf) + 1];
-    uint32_t pi[2];
-    LvPrismPoint pt[2];
-    lv_prism_frames(S, leaf, pa, pb, pt, pi);
+__device__ __forceinline__ unsigned lv_prism_coverage_pts(const LvPrismDev& R, const LvPrismPoint pt[2], const uint32_t pi[2], float radius,
+                                                          f3 o, f3 d) {
     f3 P, Q;
     lv_prism_basis(R, d, P, Q);
     const uint32_t N = NT > 0 ? uint32_t(NT) : R.n;
@@ -258,6 +254,14 @@ __device__ __forceinline__ unsigned lv_prism_coverage(const LvSceneDev& S, float
         }
     }
     return mask;
+}
+template <int NT>
+__device__ __forceinline__ unsigned lv_prism_coverage(const LvSceneDev& S, float radius, uint32_t leaf, f3 o, f3 d) {
+    const float4 pa = S.segs[2 * size_t(leaf)], pb = S.segs[2 * size_t(leaf) + 1];
+    uint32_t pi[2];
+    LvPrismPoint pt[2];
+    lv_prism_frames(S, leaf, pa, pb, pt, pi);
+    return lv_prism_coverage_pts<NT>(S.prism, pt, pi, radius, o, d);
 }
 
 // the raster shader's ribbonPosition of interpolated inputs (no bands, no caps), LinePassGeometryShaderTubes.glsl:771-777,944-963

@@ -1069,6 +1069,321 @@ __global__ __launch_bounds__(LV_BLOCK, LV_PRISM_SHADE_MIN_WAVES) void k_ppll_sha
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The rasteriser front end of ppll_fragment_source = raster_prism (ppll_prism_rasteriser = "segments", default): like the hardware
+// the reference draws with, it walks the PRIMITIVES, not the pixels.  One lane per line segment (leaf order = Morton order: the 64
+// segments of a wave are neighbours on screen): the 2 N ring vertices are projected with the frame's view-projection matrix, their
+// bounding rectangle -- widened by LV_PRISM_BBOX_MARGIN pixels against the rounding of that projection -- gives the candidate pixels,
+// and each candidate (pixel, segment) pair is decided by EXACTLY the coverage test of the LBVH front end (lv_prism_coverage_pts on the
+// pixel-centre viewing ray: ray-space edge functions, fill rule), so both front ends produce the same fragments bit for bit; the
+// rectangle only has to be conservative.  Config 4: 1 M segments of ~1 x 3 pixels -> 9.4 M coverage tests, where the all-hits walk
+// of the 2.07 M viewing rays visited 41.9 M nodes and tested 19.7 M candidates (13.7 M of them up to the coverage stage).
+//   k_ppll_mark_tiles   startOffset[pixel] = 0 for the pixels of the requested tiles (k_ppll_clear left 0xFFFFFFFF everywhere):
+//                       a rank of a sharded frame rasterises into its own tiles only
+//   k_ppll_raster_prism coverage -> record {pixel, leaf | triangle << 26, rank}; rank = atomicAdd on the pixel's count.  The order of
+//                       a pixel's fragments is therefore not defined -- as in the reference, whose fragment shader invocations race
+//                       on atomicExchange(startOffset) -- and nothing downstream depends on it: the resolve pass orders by the
+//                       (depth, colour) key and, where a pixel holds more fragments than the sort arrays, keeps the nearest ones.
+#define LV_PRISM_BBOX_MARGIN 0.125f
+#ifndef LV_PRISM_RASTER_CHUNK
+#define LV_PRISM_RASTER_CHUNK 256u      // record slots a wave reserves per global atomic
+#endif
+#ifndef LV_PRISM_RASTER_MIN_WAVES
+#define LV_PRISM_RASTER_MIN_WAVES 3
+#endif
+#ifndef LV_PRISM_RASTER_BLOCKS_PER_CU
+#define LV_PRISM_RASTER_BLOCKS_PER_CU 8
+#endif
+template <bool STATS>
+__global__ __launch_bounds__(LV_BLOCK) void k_ppll_mark_tiles(const LvUniforms U, const LvTiles T, uint32_t* __restrict__ startOffset,
+                                                              LvDevCounters* dc) {
+    LvPixel px;
+    if (!lv_block_pixel(U, T, px)) return;
+    if (px.inView) startOffset[lv_ppll_addr(px.x, px.y, U.ppllPaddedW, U.ppllTileW, U.ppllTileH)] = 0u;
+    if (STATS) {   // one viewing ray per requested pixel: the rays whose coverage the rasteriser decides
+        const unsigned long long n = (unsigned long long)__popcll(__ballot(px.inView));
+        if (lv_lane() == 0 && n) atomicAdd(&dc->rays, n);
+    }
+}
+
+// After the fragment stage, one lane per requested pixel:
+//  - the cost of a 64 x 64-pixel group for the dispatch order of the next frame and the tile balance of a sharded frame is the number
+//    of fragments the fragment stage and the resolve pass handle there (the segment rasteriser walks segments, not tiles);
+//  - pixels that kept more fragments than the sort arrays hold (ppllMaxNumFrags) go on a list for k_ppll_select_nearest.
+__global__ __launch_bounds__(LV_BLOCK) void k_ppll_pixel_pass(const LvUniforms U, const LvTiles T, const uint32_t* __restrict__ fragCount,
+                                                              uint32_t* __restrict__ overflowList, LvDevCounters* dc) {
+    LvPixel px;
+    if (!lv_block_pixel(U, T, px)) return;
+    uint32_t n = 0u;
+    if (px.inView) {
+        const uint32_t addr = lv_ppll_addr(px.x, px.y, U.ppllPaddedW, U.ppllTileW, U.ppllTileH);
+        const uint32_t v = fragCount[addr];
+        n = v & 0xFFFFu;
+        if (n - (v >> 16) > U.ppllMaxNumFrags) overflowList[atomicAdd(&dc->ppllOverflowPixels, 1u)] = addr;
+    }
+#pragma unroll
+    for (int ofs = 32; ofs > 0; ofs >>= 1) n += (uint32_t)__shfl_xor(n, ofs, 64);
+    if (T.groupCost && lv_lane() == 0u && n) atomicAdd(&T.groupCost[px.group], n);
+}
+
+// Keep-the-nearest selection.  The order of a pixel's run is not defined (the rasteriser's lanes race for the ranks, as the reference's
+// fragment shader invocations race for the list heads), so nothing downstream may depend on it: a pixel with more kept fragments than
+// the sort arrays hold keeps the K = ppllMaxNumFrags NEAREST by the (depth, colour) key -- one of the subsets the reference's race
+// can leave in the first K nodes of a list, and the one that loses the least.  One wave per listed pixel permutes the run in place so
+// that those K come first (the resolve pass then reads the first K live entries of every run, in whatever order):
+//   the K-th smallest depth by a radix select over its 31 bits (a ballot + population count per 64 entries and bit), ties at that
+//   depth by the same select over the colour; then entries below the threshold key go to the front, the rest (dead entries included)
+//   behind them.  Runs of up to 64 * LV_SELECT_REGS entries live in registers throughout; longer ones are re-read from memory per bit
+//   and permuted through their slots of the (by then free) record pool.
+// In the resolve pass itself this selection sat on the critical path of the few hundred waves over the dense core (a max-heap per
+// lane: +0.23 ms on config 4 for 2 235 such pixels; the whole wave per pixel: +0.65 ms, every lane of those waves overflows); as a pass
+// of its own the pixels are spread over the whole GPU.
+#define LV_SELECT_REGS 8
+template <bool REGS>
+__device__ __forceinline__ void lv_select_nearest(uint2* __restrict__ run, uint2* __restrict__ temp, uint32_t n, uint32_t K,
+                                                  uint32_t lane) {
+    uint32_t kd[LV_SELECT_REGS], kc[LV_SELECT_REGS];
+    const uint32_t rounds = (n + LV_WAVE - 1u) / LV_WAVE;
+    if (REGS) {
+#pragma unroll
+        for (uint32_t r = 0; r < LV_SELECT_REGS; r++) {
+            const uint32_t i = r * LV_WAVE + lane;
+            uint2 e = make_uint2(0u, LV_PPLL_DEAD);
+            if (r < rounds && i < n) e = run[i];
+            kd[r] = e.y;   // live depths are positive floats (< 0x7F800000): ordered like their bits, below the dead pattern 0xFFFFFFFF
+            kc[r] = e.x;
+        }
+    } else {
+        for (uint32_t i = lane; i < n; i += LV_WAVE) temp[i] = run[i];   // (each lane reads back only what it wrote itself)
+    }
+    // number of entries with pred(depth bits, colour)
+#define LV_SELECT_COUNT(cnt, PRED)                                                                             \
+    do {                                                                                                       \
+        cnt = 0u;                                                                                              \
+        if (REGS) {                                                                                            \
+            _Pragma("unroll") for (uint32_t r = 0; r < LV_SELECT_REGS; r++)                                    \
+                if (r < rounds) { const uint32_t D = kd[r], C = kc[r]; (void)C; cnt += uint32_t(__popcll(__ballot(PRED))); } \
+        } else {                                                                                               \
+            for (uint32_t i0 = 0u; i0 < n; i0 += LV_WAVE) {                                                    \
+                const uint32_t i = i0 + lane;                                                                  \
+                const uint2 e = i < n ? temp[i] : make_uint2(0u, LV_PPLL_DEAD);                                \
+                const uint32_t D = e.y, C = e.x; (void)C;                                                      \
+                cnt += uint32_t(__popcll(__ballot(PRED)));                                                     \
+            }                                                                                                  \
+        }                                                                                                      \
+    } while (0)
+    uint32_t V = 0u;   // K-th smallest depth
+    for (int bit = 30; bit >= 0; --bit) {
+        const uint32_t cand = V | (1u << bit);
+        uint32_t cnt;
+        LV_SELECT_COUNT(cnt, D < cand);
+        if (cnt < K) V = cand;
+    }
+    uint32_t less;
+    LV_SELECT_COUNT(less, D < V);
+    const uint32_t need = K - less;   // >= 1 of the entries at depth V, smallest colours first
+    uint32_t W = 0u;   // need-th smallest colour among them
+    for (int bit = 31; bit >= 0; --bit) {
+        const uint32_t cand = W | (1u << bit);
+        uint32_t cnt;
+        LV_SELECT_COUNT(cnt, D == V && C < cand);
+        if (cnt < need) W = cand;
+    }
+#undef LV_SELECT_COUNT
+    uint32_t below;   // entries strictly below the threshold key (V, W); K - below of the entries equal to it are kept too
+    {
+        uint32_t c2;
+        if (REGS) {
+            c2 = 0u;
+#pragma unroll
+            for (uint32_t r = 0; r < LV_SELECT_REGS; r++)
+                if (r < rounds) c2 += uint32_t(__popcll(__ballot(kd[r] == V && kc[r] < W)));
+        } else {
+            c2 = 0u;
+            for (uint32_t i0 = 0u; i0 < n; i0 += LV_WAVE) {
+                const uint32_t i = i0 + lane;
+                const uint2 e = i < n ? temp[i] : make_uint2(0u, LV_PPLL_DEAD);
+                c2 += uint32_t(__popcll(__ballot(e.y == V && e.x < W)));
+            }
+        }
+        below = less + c2;
+    }
+    // destinations: [0, below) entries below the key, [below, K) the first K - below entries equal to it, [K, n) everything else
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    uint32_t posA = 0u, posB = below, posC = K;
+    auto place = [&](uint32_t D, uint32_t C, bool valid) {
+        const bool a = valid && (D < V || (D == V && C < W));
+        const bool b = valid && D == V && C == W;
+        const unsigned long long ma = __ballot(a), mb = __ballot(b);
+        const uint32_t rankB = posB + uint32_t(__popcll(mb & lt));
+        const bool bKept = b && rankB < K;
+        const bool c = valid && !a && !bKept;
+        const unsigned long long mc = __ballot(c);
+        uint32_t dst = 0u;
+        if (a) dst = posA + uint32_t(__popcll(ma & lt));
+        else if (bKept) dst = rankB;
+        else if (c) dst = posC + uint32_t(__popcll(mc & lt));
+        if (valid) run[dst] = make_uint2(C, D);
+        posA += uint32_t(__popcll(ma));
+        posB = min(K, posB + uint32_t(__popcll(mb)));
+        posC += uint32_t(__popcll(mc));
+    };
+    if (REGS) {
+#pragma unroll
+        for (uint32_t r = 0; r < LV_SELECT_REGS; r++)
+            if (r < rounds) place(kd[r], kc[r], r * LV_WAVE + lane < n);
+    } else {
+        for (uint32_t i0 = 0u; i0 < n; i0 += LV_WAVE) {
+            const uint32_t i = i0 + lane;
+            const uint2 e = i < n ? temp[i] : make_uint2(0u, LV_PPLL_DEAD);
+            place(e.y, e.x, i < n);
+        }
+    }
+}
+
+__global__ __launch_bounds__(LV_WAVE) void k_ppll_select_nearest(const LvUniforms U, uint2* __restrict__ frags, uint2* __restrict__ temp,
+                                                                 const uint32_t* __restrict__ startOffset,
+                                                                 const uint32_t* __restrict__ fragCount,
+                                                                 const uint32_t* __restrict__ overflowList, const LvDevCounters* dc) {
+    const uint32_t count = dc->ppllOverflowPixels, lane = threadIdx.x;
+    for (uint32_t p = blockIdx.x; p < count; p += gridDim.x) {
+        const uint32_t addr = overflowList[p];
+        const uint32_t off = startOffset[addr], n = fragCount[addr] & 0xFFFFu;
+        if (n <= LV_WAVE * LV_SELECT_REGS) lv_select_nearest<true>(frags + off, nullptr, n, U.ppllMaxNumFrags, lane);
+        else lv_select_nearest<false>(frags + off, temp + off, n, U.ppllMaxNumFrags, lane);
+    }
+}
+
+template <bool STATS, int NT>
+__global__ __launch_bounds__(LV_BLOCK, LV_PRISM_RASTER_MIN_WAVES) void k_ppll_raster_prism(const LvUniforms U, const LvSceneDev S,
+                                                                   uint32_t* __restrict__ records,
+                                                                   const uint32_t* __restrict__ startOffset,
+                                                                   uint32_t* __restrict__ fragCount, LvDevCounters* dc,
+                                                                   uint32_t poolSlots) {
+    const LvPrismDev& R = S.prism;
+    const uint32_t N = NT > 0 ? uint32_t(NT) : R.n;
+    const unsigned lane = lv_lane();
+    const f3 o = mk3(U.camPos[0], U.camPos[1], U.camPos[2]);
+    // rows of proj * view (clip = M * (p, 1)); x, y and w only
+    float mx[4], my[4], mw[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        mx[c] = 0.0f; my[c] = 0.0f; mw[c] = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {   // column-major 4 x 4
+            mx[c] += U.proj[4 * k + 0] * U.view[4 * c + k];
+            my[c] += U.proj[4 * k + 1] * U.view[4 * c + k];
+            mw[c] += U.proj[4 * k + 3] * U.view[4 * c + k];
+        }
+    }
+    const float halfW = 0.5f * float(U.width), halfH = 0.5f * float(U.height);
+    const float wEps = 1e-3f * U.nearDist;
+    unsigned allocBase = 0u, allocLeft = 0u;   // this wave's chunk of record slots (wave-uniform)
+    unsigned long long tests = 0;
+    uint32_t dropped = 0u;
+    const uint32_t waveId = blockIdx.x * (LV_BLOCK / LV_WAVE) + (threadIdx.x >> 6), numWaves = gridDim.x * (LV_BLOCK / LV_WAVE);
+    for (uint32_t leafBase = waveId * LV_WAVE; leafBase < S.numSegs; leafBase += numWaves * LV_WAVE) {
+        const uint32_t leaf = leafBase + lane;
+        const bool valid = leaf < S.numSegs;
+        uint32_t pi[2] = {0u, 0u};
+        LvPrismPoint pt[2];
+        int x0 = 0, x1 = -1, y0 = 0, y1 = -1;
+        if (valid) {
+            const float4 pa = S.segs[2 * size_t(leaf)], pb = S.segs[2 * size_t(leaf) + 1];
+            lv_prism_frames(S, leaf, pa, pb, pt, pi);
+            float lox = 3.0e38f, hix = -3.0e38f, loy = 3.0e38f, hiy = -3.0e38f;
+            bool anyFront = false, anyBehind = false;
+            for (uint32_t k = 0; k < N; k++) {
+#pragma unroll
+                for (int e = 0; e < 2; e++) {
+                    const f3 v = lv_prism_pos(pt[e], lv_prism_dir(pt[e], R.c[k], R.s[k]), U.radius);
+                    const float cw = ((mw[0] * v.x + mw[1] * v.y) + mw[2] * v.z) + mw[3];
+                    if (cw > wEps) {
+                        const float cx = ((mx[0] * v.x + mx[1] * v.y) + mx[2] * v.z) + mx[3];
+                        const float cy = ((my[0] * v.x + my[1] * v.y) + my[2] * v.z) + my[3];
+                        const float wx = (cx / cw + 1.0f) * halfW, wy = (cy / cw + 1.0f) * halfH;
+                        lox = fminf(lox, wx); hix = fmaxf(hix, wx); loy = fminf(loy, wy); hiy = fmaxf(hiy, wy);
+                        anyFront = true;
+                    } else anyBehind = true;
+                }
+            }
+            if (anyFront) {   // (all vertices behind the camera plane: no viewing ray meets the prism at a positive depth)
+                if (anyBehind) { lox = 0.0f; loy = 0.0f; hix = float(U.width); hiy = float(U.height); }   // straddles the camera plane
+                // pixel x is a candidate iff its centre x + 0.5 lies in [lo - margin, hi + margin]
+                const float fx0 = fmaxf(ceilf(lox - LV_PRISM_BBOX_MARGIN - 0.5f), 0.0f);
+                const float fy0 = fmaxf(ceilf(loy - LV_PRISM_BBOX_MARGIN - 0.5f), 0.0f);
+                const float fx1 = fminf(floorf(hix + LV_PRISM_BBOX_MARGIN - 0.5f), float(U.width) - 1.0f);
+                const float fy1 = fminf(floorf(hiy + LV_PRISM_BBOX_MARGIN - 0.5f), float(U.height) - 1.0f);
+                if (fx0 <= fx1 && fy0 <= fy1) { x0 = int(fx0); x1 = int(fx1); y0 = int(fy0); y1 = int(fy1); }
+            }
+        }
+        int px = x0, py = y0;
+        bool more = valid && x1 >= x0 && y1 >= y0;
+        while (__any(more)) {
+            unsigned mask = 0u;
+            uint32_t addr = 0u;
+            if (more) {
+                addr = lv_ppll_addr(uint32_t(px), uint32_t(py), U.ppllPaddedW, U.ppllTileW, U.ppllTileH);
+                if (startOffset[addr] == 0u) {   // pixel of a requested tile
+                    f3 oo, d;
+                    lv_primary_ray(U, uint32_t(px), uint32_t(py), 0.5f, 0.5f, oo, d);
+                    mask = lv_prism_coverage_pts<NT>(R, pt, pi, U.radius, o, d);
+                    if (STATS) tests++;
+                }
+            }
+            while (__any(mask != 0u)) {
+                const bool hit = mask != 0u;
+                const unsigned long long hm = __ballot(hit);
+                const unsigned n = unsigned(__popcll(hm));
+                const unsigned rankInBatch = unsigned(__popcll(hm & ((1ull << lane) - 1ull)));
+                unsigned base = allocBase, left = allocLeft, base2 = 0u;
+                if (left < n) {
+                    if (lane == 0u) base2 = atomicAdd(&dc->fragAlloc, (unsigned)LV_PRISM_RASTER_CHUNK);
+                    base2 = __builtin_amdgcn_readfirstlane(base2);
+                    allocBase = base2 + (n - left);
+                    allocLeft = LV_PRISM_RASTER_CHUNK - (n - left);
+                } else {
+                    allocBase = base + n;
+                    allocLeft = left - n;
+                }
+                if (hit) {
+                    const unsigned tt = unsigned(__ffs(int(mask))) - 1u;
+                    mask &= mask - 1u;
+                    const uint32_t insertIndex = rankInBatch < left ? base + rankInBatch : base2 + (rankInBatch - left);
+                    bool stored = false;
+                    if (insertIndex < poolSlots) {
+                        const uint32_t rk = atomicAdd(&fragCount[addr], 1u);
+                        if ((rk & 0xFFFFu) < 0xFFFFu) {
+                            records[3 * size_t(insertIndex) + 0] = uint32_t(px) | (uint32_t(py) << 16);
+                            records[3 * size_t(insertIndex) + 1] = leaf | (tt << 26);
+                            records[3 * size_t(insertIndex) + 2] = rk & 0xFFFFu;
+                            stored = true;
+                        } else {   // (the per-pixel count shares its word with the count of discarded fragments: 16 bits each)
+                            atomicSub(&fragCount[addr], 1u);
+                            records[3 * size_t(insertIndex) + 0] = 0u;
+                            records[3 * size_t(insertIndex) + 1] = LV_PPLL_DEAD;
+                        }
+                    }
+                    if (!stored) dropped++;   // no record: the fragment stage never sees it, but the reference's fragCounter counts it
+                }
+            }
+            if (more) {
+                if (++px > x1) { px = x0; more = ++py <= y1; }
+            }
+        }
+    }
+    // the slots this wave reserved but did not use are part of the range the fragment stage walks: mark them dead
+    for (unsigned k = lane; k < allocLeft; k += LV_WAVE)
+        if (allocBase + k < poolSlots) { records[3 * size_t(allocBase + k) + 0] = 0u; records[3 * size_t(allocBase + k) + 1] = LV_PPLL_DEAD; }
+#pragma unroll
+    for (int ofs = 32; ofs > 0; ofs >>= 1) dropped += (uint32_t)__shfl_xor(dropped, ofs, 64);
+    if (lane == 0u && dropped > 0u) atomicAdd(&dc->fragCounter, dropped);
+    if (STATS) {
+        tests = lv_wave_sum_u64(tests);
+        if (lane == 0u && tests) atomicAdd(&dc->prims, tests);
+    }
+}
+
 // clear(): LinkedListClear.glsl:46-55 (start offsets = -1) + fragmentCounterBuffer->fill(0), and the per-pixel fragment counts
 __global__ __launch_bounds__(LV_BLOCK) void k_ppll_clear(uint4* __restrict__ startOffset, uint4* __restrict__ fragCount, size_t n4,
                                                          LvDevCounters* dc) {
@@ -1077,7 +1392,7 @@ __global__ __launch_bounds__(LV_BLOCK) void k_ppll_clear(uint4* __restrict__ sta
         startOffset[i] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
         fragCount[i] = make_uint4(0u, 0u, 0u, 0u);
     }
-    if (i == 0) { dc->fragCounter = 0u; dc->fragAlloc = 0u; dc->prismDiscards = 0u; }
+    if (i == 0) { dc->fragCounter = 0u; dc->fragAlloc = 0u; dc->prismDiscards = 0u; dc->ppllOverflowPixels = 0u; }
 }
 
 // per-thread fragment arrays interleaved over the wave: entry i of lane l at [i * 64 + l]
@@ -1227,8 +1542,7 @@ __device__ void lv_sort_fragments(uint32_t mode, LvFragArrays& A, uint32_t n, ui
 
 // One wave per workgroup; fragment arrays in LDS when they fit, else in a global scratch slab.
 // ARRAYS (frames of ppll_fragment_source = raster_prism): the pixel's fragments are the contiguous run frags[startOffset[pixel] ...
-// + count) of 8-B {colour, depth} entries (startOffset = exclusive scan of the counts), read from the LAST entry down = the order a
-// linked list built by pushing to the front would be walked in.
+// + count) of 8-B {colour, depth} entries (startOffset = exclusive scan of the counts), in no defined order.
 template <bool USE_LDS, bool PQ = true, bool ARRAYS = false>
 __global__ __launch_bounds__(LV_WAVE) void k_ppll_resolve(const LvUniforms U, const LvTiles T,
                                                           const uint32_t* __restrict__ nodes,
@@ -1249,32 +1563,55 @@ __global__ __launch_bounds__(LV_WAVE) void k_ppll_resolve(const LvUniforms U, co
         A.col = base + lane;
         A.dep = reinterpret_cast<float*>(base) + size_t(maxFrags) * LV_WAVE + lane;
     }
-    // group = 8x8 pixel block of a tile
-    const uint32_t gx = (T.tileW + 7u) / 8u, gy = (T.tileH + 7u) / 8u;
+    // A wave resolves one 8 x 8 pixel cell; the 64 cells of a 64 x 64-pixel group are consecutive, and the groups come in the dispatch
+    // order of the tile kernels (LvTiles::groupOrder: most expensive group of the previous frame first), so that the long waves over
+    // the dense core of a data set start first.
+    const uint32_t groupsX = T.blocksX / 4u, groupsPerTile = groupsX * (T.blocksY / 4u);
     for (uint32_t g = blockIdx.x; g < numGroups; g += gridDim.x) {
-        const uint32_t tile = g / (gx * gy), rem = g % (gx * gy);
-        const uint32_t lx = (rem % gx) * 8u + (lane & 7u), ly = (rem / gx) * 8u + (lane >> 3);
-        if (lx >= T.tileW || ly >= T.tileH) continue;
+        const uint32_t slot = g >> 6, cell = g & 63u;
+        const uint32_t grp = T.groupOrder ? T.groupOrder[slot] : slot;
+        const uint32_t tile = grp / groupsPerTile, gi = grp % groupsPerTile;
+        const uint32_t lx = (gi % groupsX) * 64u + (cell & 7u) * 8u + (lane & 7u);
+        const uint32_t ly = (gi / groupsX) * 64u + (cell >> 3) * 8u + (lane >> 3);
+        const bool inTile = lx < T.tileW && ly < T.tileH;
+        if (!__any(inTile)) continue;
         const uint32_t x = T.tilesXY[2 * tile] + lx, y = T.tilesXY[2 * tile + 1] + ly;
         const uint32_t outIndex = (tile * T.tileH + ly) * T.tileW + lx;
+        const bool inView = inTile && x < U.width && y < U.height;
         float res[4] = {U.background[0], U.background[1], U.background[2], U.background[3]};
-        if (x < U.width && y < U.height) {
-            const uint32_t addr = lv_ppll_addr(x, y, U.ppllPaddedW, U.ppllTileW, U.ppllTileH);
-            uint32_t fragOffset = startOffset[addr];
-            uint32_t numFrags = 0;
-            if (ARRAYS) {
+        uint32_t fragOffset = 0xFFFFFFFFu;
+        uint32_t numFrags = 0;
+        if (ARRAYS) {
+            // the first maxFrags live entries of the run: where a pixel kept more, k_ppll_select_nearest moved the nearest to the front
+            if (inView) {
+                const uint32_t addr = lv_ppll_addr(x, y, U.ppllPaddedW, U.ppllTileW, U.ppllTileH);
+                fragOffset = startOffset[addr];
                 const uint32_t v = fragCount[addr];
-                uint32_t j = v & 0xFFFFu;                      // entries of the run; v >> 16 of them are dead
-                maxCount = max(maxCount, j - (v >> 16));
+                const uint32_t n = v & 0xFFFFu;                // entries of the run; v >> 16 of them are dead
+                maxCount = max(maxCount, n - (v >> 16));
                 const uint2* __restrict__ run = reinterpret_cast<const uint2*>(nodes) + fragOffset;
-                while (numFrags < maxFrags && j > 0u) {
-                    const uint2 e = run[--j];
-                    if (e.y == LV_PPLL_DEAD && e.x == 0u) continue;
-                    A.c(numFrags) = e.x;
-                    A.d(numFrags) = __uint_as_float(e.y);
-                    numFrags++;
+                for (uint32_t j = 0u; j < n && numFrags < maxFrags; j += 4u) {   // four independent loads in flight per step
+                    uint2 e[4];
+#pragma unroll
+                    for (uint32_t k = 0; k < 4u; k++) e[k] = j + k < n ? run[j + k] : make_uint2(0u, LV_PPLL_DEAD);
+#pragma unroll
+                    for (uint32_t k = 0; k < 4u; k++) {
+                        if ((e[k].y == LV_PPLL_DEAD && e[k].x == 0u) || numFrags >= maxFrags) continue;
+                        A.c(numFrags) = e[k].x;
+                        A.d(numFrags) = __uint_as_float(e[k].y);
+                        numFrags++;
+                    }
                 }
             }
+            // the whole-list sorts see the fragments in ascending key order (what they leave unsorted depends on their input)
+            if (!PQ && numFrags > 1u) {
+                for (uint32_t i = numFrags / 2u; i > 0u; --i) lv_max_heap_sink(A, i - 1u, numFrags);
+                for (uint32_t i = numFrags - 1u; i > 0u; --i) { A.swap(0u, i); lv_max_heap_sink(A, 0u, i); }
+            }
+        } else if (inView) {
+            fragOffset = startOffset[lv_ppll_addr(x, y, U.ppllPaddedW, U.ppllTileW, U.ppllTileH)];
+        }
+        if (inView) {
             while (!ARRAYS && numFrags < maxFrags) {
                 if (fragOffset == 0xFFFFFFFFu) break;
                 const uint32_t c = nodes[3 * size_t(fragOffset) + 0], db = nodes[3 * size_t(fragOffset) + 1];
@@ -1331,7 +1668,7 @@ __global__ __launch_bounds__(LV_WAVE) void k_ppll_resolve(const LvUniforms U, co
             }
         }
         f4 c; c.x = res[0]; c.y = res[1]; c.z = res[2]; c.w = res[3];
-        out[outIndex] = lv_pack_unorm4x8(c);
+        if (inTile) out[outIndex] = lv_pack_unorm4x8(c);
     }
     if (ARRAYS) {
 #pragma unroll
@@ -2125,16 +2462,17 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
         // gather(): fragments of the rasterised programmable-pull prism (the reference's geometry, default) or capsule entry hits
         const bool prismSource = lv_ppll_prism_source(ctx);
         if (prismSource) lv_fill_prism(ctx, U, S.prism);
-#ifdef LV_PRISM_SLICES_PROBE
-        const uint32_t numSlices = LV_PRISM_SLICES_PROBE;
-#else
         const uint32_t numSlices = prismSource ? 1u : LV_PPLL_SLICES; // (the prism's coverage kernel has no depth: one slice)
-#endif
+        // ppll_prism_rasteriser: "segments" (default) = one lane per segment over its screen rectangle, "lbvh" = the all-hits walk of
+        // the viewing rays (k_ppll_gather<LV_PRIM_PRISM>); same coverage test, same fragments
+        const bool segmentRaster = prismSource && !ctx->opt.ppllPrismLbvhWalk;
+        const uint32_t rasterGrid = uint32_t(ctx->numCUs) * LV_PRISM_RASTER_BLOCKS_PER_CU;
         if (uint64_t(gridTiles) * numSlices > 0x7FFFFFF0ull) return lv_fail(ctx, LV_E_INVALID, "tile list too large");
         // physical pool = the reference's linkedListSize + the tail every wave of the gather may leave unused in its last
-        // chunk of node slots (k_ppll_gather), so that the effective capacity is never below the reference's
+        // chunk of node slots (k_ppll_gather / k_ppll_raster_prism), so that the effective capacity is never below the reference's
         uint64_t poolSlots64 = uint64_t(U.ppllLinkedListSize) +
-                               uint64_t(gridTiles) * numSlices * (LV_BLOCK / LV_WAVE) * LV_PPLL_CHUNK;
+                               (segmentRaster ? uint64_t(rasterGrid) * (LV_BLOCK / LV_WAVE) * LV_PRISM_RASTER_CHUNK
+                                              : uint64_t(gridTiles) * numSlices * (LV_BLOCK / LV_WAVE) * LV_PPLL_CHUNK);
         if (poolSlots64 > 0xFFFFFFF0ull) poolSlots64 = 0xFFFFFFF0ull; // node indices are 32 bit
         const uint32_t poolSlots = uint32_t(poolSlots64);
         if ((rc = lv_buf_reserve(ctx, ctx->ppllNodes, size_t(poolSlots) * 12))) return rc;
@@ -2165,7 +2503,21 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
         else if (U.useBands) LV_LAUNCH_GATHER(ST, LV_PRIM_CAPSULE, LV_SHADE_BANDS);    \
         else LV_LAUNCH_GATHER(ST, LV_PRIM_CAPSULE, LV_SHADE_PLAIN);                    \
     } while (0)
+        if (segmentRaster) {
+            // the segment rasteriser (k_ppll_raster_prism): requested pixels marked, then one lane per segment
+#define LV_LAUNCH_RASTER(ST, NT)                                                                                              \
+    LV_TIMED_LAUNCH(ctx, LV_KERNEL_PPLL_RASTER, (k_ppll_raster_prism<ST, NT><<<rasterGrid, LV_BLOCK, 0, st>>>(                \
+            U, S, gatherPool, (const uint32_t*)ctx->ppllStart.ptr, (uint32_t*)ctx->ppllCount.ptr, dc, poolSlots)))
+            if (stats) k_ppll_mark_tiles<true><<<gridTiles, LV_BLOCK, 0, st>>>(U, T, (uint32_t*)ctx->ppllStart.ptr, dc);
+            else k_ppll_mark_tiles<false><<<gridTiles, LV_BLOCK, 0, st>>>(U, T, (uint32_t*)ctx->ppllStart.ptr, dc);
+            if (S.numSegs != 0) {
+                if (S.prism.n == 6u) { if (stats) LV_LAUNCH_RASTER(true, 6); else LV_LAUNCH_RASTER(false, 6); }
+                else { if (stats) LV_LAUNCH_RASTER(true, 0); else LV_LAUNCH_RASTER(false, 0); }
+            }
+#undef LV_LAUNCH_RASTER
+        } else {
         if (stats) LV_LAUNCH_GATHER2(true); else LV_LAUNCH_GATHER2(false);
+        }
 #undef LV_LAUNCH_GATHER2
 #undef LV_LAUNCH_GATHER
         if (prismSource) {
@@ -2179,12 +2531,19 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
             (uint32_t*)ctx->ppllCount.ptr, dc, poolSlots)))
             if (stats) LV_LAUNCH_SHADE(true); else LV_LAUNCH_SHADE(false);
 #undef LV_LAUNCH_SHADE
+            // group costs + the pixels that kept more fragments than the sort arrays hold; their nearest ppllMaxNumFrags to the front
+            if ((rc = lv_buf_reserve(ctx, ctx->ppllOverflow, padded4 * 16))) return rc;
+            k_ppll_pixel_pass<<<gridTiles, LV_BLOCK, 0, st>>>(U, T, (const uint32_t*)ctx->ppllCount.ptr,
+                                                             (uint32_t*)ctx->ppllOverflow.ptr, dc);
+            k_ppll_select_nearest<<<uint32_t(ctx->numCUs) * 16u, LV_WAVE, 0, st>>>(
+                    U, (uint2*)ctx->ppllNodes.ptr, (uint2*)ctx->prismRecords.ptr, (const uint32_t*)ctx->ppllStart.ptr,
+                    (const uint32_t*)ctx->ppllCount.ptr, (const uint32_t*)ctx->ppllOverflow.ptr, dc);
         }
         LV_HIP(ctx, hipEventRecord(ctx->ev[13], st));
         // resolve()
         const uint32_t* prismCount = prismSource ? (const uint32_t*)ctx->ppllCount.ptr : nullptr; // (kept fragments per pixel -> max depth complexity)
-        const uint32_t gx = (tileW + 7u) / 8u, gy = (tileH + 7u) / 8u;
-        const uint64_t groups64 = uint64_t(numTiles) * gx * gy;
+        const uint64_t groups64 = uint64_t(numTiles) * (T.blocksX / 4u) * (T.blocksY / 4u) * 64u;   // 8 x 8 cells of the 64 x 64 groups
+        if (groups64 > 0xFFFFFFF0ull) return lv_fail(ctx, LV_E_INVALID, "tile list too large");
         const uint32_t numGroups = uint32_t(groups64);
         const size_t ldsBytes = size_t(U.ppllMaxNumFrags) * LV_WAVE * 8;
 #define LV_LAUNCH_RESOLVE(LDS, PQ, GRID, BYTES, SCRATCH)                                                                        \
@@ -2273,7 +2632,7 @@ int lv_frame_ppll_resolve_only(lv_ctx* ctx, const uint32_t* nodes, uint64_t numN
     T.tilesXY = (const uint32_t*)ctx->tilesDev.ptr;
     T.numTiles = 1; T.tileW = w; T.tileH = h;
     T.blocksX = ((w + 63u) / 64u) * 4u; T.blocksY = ((h + 63u) / 64u) * 4u;
-    const uint32_t numGroups = ((w + 7u) / 8u) * ((h + 7u) / 8u);
+    const uint32_t numGroups = (T.blocksX / 4u) * (T.blocksY / 4u) * 64u;
     const size_t ldsBytes = size_t(U.ppllMaxNumFrags) * LV_WAVE * 8;
     const uint32_t* nd = (const uint32_t*)ctx->ppllNodes.ptr;
     const uint32_t* so = (const uint32_t*)ctx->ppllStart.ptr;

@@ -2310,6 +2310,7 @@ void lvo_ppll_gather(const lvo_scene* sc, const lvo_params* Pp, int useBvh, cons
                 const float aoTexelP = (P.useAmbientOcclusion && ao) ? ao[size_t(y) * P.width + x] : 1.0f;
                 prismPixelFragments(*sc, P, F, ring, useBvh != 0, x, y, cand, pf, cnt);
                 const RasterQuad rqP = makeRasterQuad(P, F, x, y);
+                const size_t first = rows[yy].size();
                 for (const PrismFrag& f : pf) {
                     float hc[4]; float hitT;
                     prismShade(*sc, P, F, ring, aoTexelP, f, g_rtFragmentColourInPpll ? nullptr : &rqP, hc, hitT,
@@ -2319,6 +2320,14 @@ void lvo_ppll_gather(const lvo_scene* sc, const lvo_params* Pp, int useBvh, cons
                     rows[yy].push_back(std::make_pair(packUnorm4x8(hc), hitT));
                     rowCounts[yy][xx]++;
                 }
+                // Order of a pixel's list: the rasteriser's fragment shader invocations race for the list head
+                // (LinkedListGather.glsl:55), the reference defines none.  Build-owned: inserted in DESCENDING (depth, colour) key
+                // order, so that the walk from the head -- and the first maxNumFrags nodes the resolve pass keeps
+                // (LinkedListResolve.glsl:66-79) -- sees the nearest fragments first.
+                std::sort(rows[yy].begin() + std::ptrdiff_t(first), rows[yy].end(),
+                          [](const std::pair<uint32_t, float>& a, const std::pair<uint32_t, float>& b) {
+                              return a.second > b.second || (a.second == b.second && a.first > b.first);
+                          });
                 continue;
             }
             V3 o, d;

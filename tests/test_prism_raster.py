@@ -399,6 +399,96 @@ def test_hip_gather_of_the_rasterised_prism_against_the_oracle(hip_lib, variant)
         assert not np.array_equal(img0, img)
 
 
+def _walk_order(nodes, start):
+    """per-pixel lists in walk order (from the head)"""
+    out = {}
+    for pix in np.nonzero(start != 0xFFFFFFFF)[0]:
+        i, l = int(start[pix]), []
+        while i != 0xFFFFFFFF:
+            l.append((int(nodes[i, 1]), int(nodes[i, 0])))       # (depth bits, colour): positive floats order like their bits
+            i = int(nodes[i, 2])
+        out[int(pix)] = l
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("max_frags,sorting", [(100, "Priority Queue"), (8, "Priority Queue"), (8, "Bitonic Sort"),
+                                               (8, "Quicksort"), (8, "Shell Sort")])
+def test_hip_segment_rasteriser_and_lbvh_walk_give_the_same_fragments(hip_lib, max_frags, sorting):
+    """The two front ends of raster_prism -- k_ppll_raster_prism (one lane per segment over its screen rectangle, default) and the
+    all-hits walk of the viewing rays (ppll_prism_rasteriser = lbvh) -- decide every (pixel, segment) pair by the same coverage test:
+    identical lists (exported in ascending key order), identical frames, also where pixels hold more fragments than the sort arrays
+    (max_frags = 8: the nearest 8 are kept, whatever order the lanes stored them in) and under the whole-list sorts; tiles and a
+    second frame reproduce the frame (the racing ranks never show)."""
+    c = small_case(width=176, height=120, n_lines=60, pts_per_line=40, line_width=0.02, transparent=True,
+                   ppll_max_num_frags=max_frags, sorting_mode=sorting)
+    ctx = c.hip_context()
+    img = ctx.render(2)
+    pw, ph = c.padded()
+    sc = c.oracle_scene()
+    P = c.oracle_params(sc)
+    assert P.ppllFragmentSource == 1
+    hn, hs, hcnt = ctx.ppll_buffers(pw * ph, int(P.ppllLinkedListSize))
+    walk = _walk_order(hn, hs)
+    assert all(l == sorted(l) for l in walk.values())
+    deepest = max(len(l) for l in walk.values())
+    assert deepest > 8 and (max_frags != 100 or deepest <= 100)
+    assert np.array_equal(ctx.render(2), img)
+    assert np.array_equal(ctx.render(2, tile=(37, 21, 50, 33)), img[21:54, 37:87])
+    # the oracle: same lists in the same order, the literal resolve of either gives the frame
+    on, os_, ocnt = sc.ppll_gather(P, use_bvh=True)
+    assert hcnt == ocnt
+    assert walk == _walk_order(on, os_)
+    ref = sc.render_ppll(P, use_bvh=True)
+    assert np.abs(img.astype(np.int32) - ref.astype(np.int32)).max() <= 2
+    assert np.array_equal(lvo.ppll_resolve(P, hn, hs), img)
+    # the other front end
+    ctx.set_option("ppll_prism_rasteriser", "lbvh")
+    img2 = ctx.render(2)
+    hn2, hs2, hcnt2 = ctx.ppll_buffers(pw * ph, int(P.ppllLinkedListSize))
+    assert hcnt2 == hcnt and _walk_order(hn2, hs2) == walk
+    assert np.array_equal(img2, img)
+    with pytest.raises(Exception):
+        ctx.set_option("ppll_prism_rasteriser", "tiles")
+
+
+@pytest.mark.gpu
+def test_hip_keep_the_nearest_selection_on_runs_longer_than_its_registers(hip_lib):
+    """800 lines stacked behind one another: pixels with ~700 fragments and sort arrays of 8 or 100 -- k_ppll_select_nearest's
+    memory variant (runs > 512 entries) and its register variant (the shallower pixels at the ends) against the oracle, whose
+    resolve keeps the first ppllMaxNumFrags nodes of lists it built nearest first."""
+    m, n = 800, 4
+    pts = np.zeros(m * n, dtype=lvo.LINE_POINT_DTYPE)
+    seg = []
+    rng = np.random.default_rng(5)
+    for k in range(m):
+        x0, x1 = (-0.3, 0.3) if k % 3 else (-0.12, 0.2)
+        sl = slice(k * n, (k + 1) * n)
+        pts["linePosition"][sl, 0] = np.linspace(x0, x1, n)
+        pts["linePosition"][sl, 1] = 0.002 * rng.standard_normal()
+        pts["linePosition"][sl, 2] = -0.4 + 0.001 * k
+        pts["lineTangent"][sl, 0] = 1.0
+        pts["lineNormal"][sl, 1] = 1.0
+        pts["lineAttribute"][sl] = rng.random()
+        seg += [(k * n + i, k * n + i + 1) for i in range(n - 1)]
+    seg = np.array(seg, dtype=np.uint32)
+    for max_frags in (8, 100):
+        c = Case(pts, seg, tfm.standard_transparent(), 96, 64, 0.02, ppll_max_num_frags=max_frags, ppll_expected_avg_depth_complexity=400)
+        ctx = c.hip_context()
+        img = ctx.render(2)
+        sc, P = prism_params(c)
+        pw, ph = c.padded()
+        hn, hs, hcnt = ctx.ppll_buffers(pw * ph, int(P.ppllLinkedListSize))
+        walk = _walk_order(hn, hs)
+        assert max(len(l) for l in walk.values()) > 512 and hcnt > 50000
+        on, os_, ocnt = sc.ppll_gather(P, use_bvh=True)
+        assert hcnt == ocnt and walk == _walk_order(on, os_)
+        assert np.array_equal(lvo.ppll_resolve(P, hn, hs), img)
+        assert np.abs(img.astype(np.int32) - sc.render_ppll(P, use_bvh=True).astype(np.int32)).max() <= 2
+        assert np.array_equal(ctx.render(2), img)
+        assert np.array_equal(ctx.render(2, tile=(30, 20, 40, 30)), img[20:50, 30:70])
+
+
 @pytest.mark.gpu
 def test_hip_prism_fill_rule_on_exact_edges(hip_lib):
     """the centre column of the square tube of test_fill_rule...: rays exactly on shared edges, one fragment each, on the device too"""
