@@ -203,6 +203,8 @@ struct lv_ctx {
     } groupOrder[2];
     bool groupOrderSorted = false;            // this frame's k_group_order is queued
     uint64_t tilesGeneration = 0;             // bumped whenever tilesDev receives another list
+    bool tilesCoverViewport = false;          // the uploaded tile list covers every pixel of the viewport (key: width, height, tile size)
+    uint32_t tilesCoverKey[4] = {0, 0, 0, 0};
     std::vector<uint32_t> tilesHost;          // staging copy: caller's tile list is borrowed for the call only
     bool tilesUploaded = false;               // tilesDev holds tilesHost
     uint64_t ppllPoolNodes = 0;               // physical node slots of the pool (logical size + per-wave chunk slack)

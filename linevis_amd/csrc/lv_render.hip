@@ -1084,7 +1084,7 @@ __global__ __launch_bounds__(LV_BLOCK, LV_PRISM_SHADE_MIN_WAVES) void k_ppll_sha
 //                       a pixel's fragments is therefore not defined -- as in the reference, whose fragment shader invocations race
 //                       on atomicExchange(startOffset) -- and nothing downstream depends on it: the resolve pass orders by the
 //                       (depth, colour) key and, where a pixel holds more fragments than the sort arrays, keeps the nearest ones.
-#define LV_PRISM_BBOX_MARGIN 0.125f
+#define LV_PRISM_BBOX_MARGIN 0.015625f   // 1/64 pixel: two orders of magnitude above the rounding of the projection at 4K
 #ifndef LV_PRISM_RASTER_CHUNK
 #define LV_PRISM_RASTER_CHUNK 256u      // record slots a wave reserves per global atomic
 #endif
@@ -1092,7 +1092,7 @@ __global__ __launch_bounds__(LV_BLOCK, LV_PRISM_SHADE_MIN_WAVES) void k_ppll_sha
 #define LV_PRISM_RASTER_MIN_WAVES 3
 #endif
 #ifndef LV_PRISM_RASTER_BLOCKS_PER_CU
-#define LV_PRISM_RASTER_BLOCKS_PER_CU 8
+#define LV_PRISM_RASTER_BLOCKS_PER_CU 3
 #endif
 template <bool STATS>
 __global__ __launch_bounds__(LV_BLOCK) void k_ppll_mark_tiles(const LvUniforms U, const LvTiles T, uint32_t* __restrict__ startOffset,
@@ -1254,15 +1254,32 @@ __global__ __launch_bounds__(LV_WAVE) void k_ppll_select_nearest(const LvUniform
     }
 }
 
+#define LV_PRISM_RASTER_QUEUE 128u   // (pixel, segment) pairs a wave holds between the two stages (>= 2 * LV_WAVE, power of two)
 template <bool STATS, int NT>
 __global__ __launch_bounds__(LV_BLOCK, LV_PRISM_RASTER_MIN_WAVES) void k_ppll_raster_prism(const LvUniforms U, const LvSceneDev S,
                                                                    uint32_t* __restrict__ records,
                                                                    const uint32_t* __restrict__ startOffset,
                                                                    uint32_t* __restrict__ fragCount, LvDevCounters* dc,
                                                                    uint32_t poolSlots) {
+    // Two stages per wave, joined by a queue in LDS:
+    //  A  one lane per segment: the candidate pixels of its screen rectangle that also lie in the ORIENTED box of the projected ring
+    //     vertices (axis = the projected segment; a 1 x 3-pixel segment at 45 degrees fills a third of its rectangle) and in a
+    //     requested tile are queued as (pixel, segment) pairs -- a dozen instructions per candidate;
+    //  B  whenever 64 pairs are waiting: one lane per pair, the coverage test of the pixel-centre viewing ray (~650 instructions,
+    //     all lanes busy whatever the shapes of the segments) and the records of the covered triangles.
+    // Both boxes only have to contain the prism's projection (widened by LV_PRISM_BBOX_MARGIN against rounding): the fragments are
+    // decided by the coverage test alone.  With the test inline in stage A (the first version) a wave iterated as long as its largest
+    // rectangle and two of three candidates missed: 0.39 ms on config 4; queued: see DESIGN.md.
+    __shared__ uint32_t s_qLeaf[LV_BLOCK / LV_WAVE][LV_PRISM_RASTER_QUEUE], s_qPix[LV_BLOCK / LV_WAVE][LV_PRISM_RASTER_QUEUE];
+    // the frames of the wave's 64 segments ({centre, normal, binormal} x 2 + the two point indices; [component][segment]): stage B
+    // reads them from here -- re-fetching 96 B per pair through L2 was what its waves waited for
+    __shared__ float s_seg[LV_BLOCK / LV_WAVE][20][LV_WAVE];
     const LvPrismDev& R = S.prism;
     const uint32_t N = NT > 0 ? uint32_t(NT) : R.n;
     const unsigned lane = lv_lane();
+    uint32_t* qLeaf = s_qLeaf[threadIdx.x >> 6];
+    uint32_t* qPix = s_qPix[threadIdx.x >> 6];
+    float (*segLds)[LV_WAVE] = s_seg[threadIdx.x >> 6];
     const f3 o = mk3(U.camPos[0], U.camPos[1], U.camPos[2]);
     // rows of proj * view (clip = M * (p, 1)); x, y and w only
     float mx[4], my[4], mw[4];
@@ -1279,19 +1296,122 @@ __global__ __launch_bounds__(LV_BLOCK, LV_PRISM_RASTER_MIN_WAVES) void k_ppll_ra
     const float halfW = 0.5f * float(U.width), halfH = 0.5f * float(U.height);
     const float wEps = 1e-3f * U.nearDist;
     unsigned allocBase = 0u, allocLeft = 0u;   // this wave's chunk of record slots (wave-uniform)
+    unsigned qHead = 0u, qCount = 0u;          // the queue (wave-uniform)
+    uint32_t leafBaseCur = 0u;                 // first segment of the wave's current 64
     unsigned long long tests = 0;
     uint32_t dropped = 0u;
+
+    // stage B on the m <= 64 oldest pairs of the queue
+    auto coverageStage = [&](unsigned m) {
+        unsigned mask = 0u;
+        uint32_t addr = 0u, leaf = 0u, pix = 0u;
+        if (lane < m) {
+            const unsigned q = (qHead + lane) & (LV_PRISM_RASTER_QUEUE - 1u);
+            leaf = qLeaf[q];
+            pix = qPix[q];
+            const uint32_t px = pix & 0xFFFFu, py = pix >> 16;
+            addr = lv_ppll_addr(px, py, U.ppllPaddedW, U.ppllTileW, U.ppllTileH);
+            // (the requested-tile test sits here, beside the segment's loads: in stage A every iteration would wait for it)
+            const uint32_t requested = startOffset[addr];
+            f3 oo, d;
+            lv_primary_ray(U, px, py, 0.5f, 0.5f, oo, d);
+            const uint32_t sl = leaf - leafBaseCur;   // the pair's segment among the wave's 64
+            LvPrismPoint pt[2];
+            uint32_t pi[2];
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                pt[e].centre = mk3(segLds[9 * e + 0][sl], segLds[9 * e + 1][sl], segLds[9 * e + 2][sl]);
+                pt[e].normal = mk3(segLds[9 * e + 3][sl], segLds[9 * e + 4][sl], segLds[9 * e + 5][sl]);
+                pt[e].binormal = mk3(segLds[9 * e + 6][sl], segLds[9 * e + 7][sl], segLds[9 * e + 8][sl]);
+                pi[e] = __float_as_uint(segLds[18 + e][sl]);
+            }
+            mask = lv_prism_coverage_pts<NT>(R, pt, pi, U.radius, o, d);
+            if (requested != 0u) mask = 0u;
+            else if (STATS) tests++;
+        }
+        while (__any(mask != 0u)) {
+            const bool hit = mask != 0u;
+            const unsigned long long hm = __ballot(hit);
+            const unsigned n = unsigned(__popcll(hm));
+            const unsigned rankInBatch = unsigned(__popcll(hm & ((1ull << lane) - 1ull)));
+            unsigned base = allocBase, left = allocLeft, base2 = 0u;
+            if (left < n) {
+                if (lane == 0u) base2 = atomicAdd(&dc->fragAlloc, (unsigned)LV_PRISM_RASTER_CHUNK);
+                base2 = __builtin_amdgcn_readfirstlane(base2);
+                allocBase = base2 + (n - left);
+                allocLeft = LV_PRISM_RASTER_CHUNK - (n - left);
+            } else {
+                allocBase = base + n;
+                allocLeft = left - n;
+            }
+            if (hit) {
+                const unsigned tt = unsigned(__ffs(int(mask))) - 1u;
+                mask &= mask - 1u;
+                const uint32_t insertIndex = rankInBatch < left ? base + rankInBatch : base2 + (rankInBatch - left);
+                bool stored = false;
+                if (insertIndex < poolSlots) {
+                    const uint32_t rk = atomicAdd(&fragCount[addr], 1u);
+                    if ((rk & 0xFFFFu) < 0xFFFFu) {
+                        records[3 * size_t(insertIndex) + 0] = pix;
+                        records[3 * size_t(insertIndex) + 1] = leaf | (tt << 26);
+                        records[3 * size_t(insertIndex) + 2] = rk & 0xFFFFu;
+                        stored = true;
+                    } else {   // (the per-pixel count shares its word with the count of discarded fragments: 16 bits each)
+                        atomicSub(&fragCount[addr], 1u);
+                        records[3 * size_t(insertIndex) + 0] = 0u;
+                        records[3 * size_t(insertIndex) + 1] = LV_PPLL_DEAD;
+                    }
+                }
+                if (!stored) dropped++;   // no record: the fragment stage never sees it, but the reference's fragCounter counts it
+            }
+        }
+        qHead = (qHead + m) & (LV_PRISM_RASTER_QUEUE - 1u);
+        qCount -= m;
+    };
+
+    // (static interleave: wave w takes segments [64 (w + k numWaves), + 64).  Handing out blocks of consecutive segments on demand was
+    // slower -- 0.42 ms with 256-segment blocks, 0.80 ms with 1024: consecutive = spatially clustered, the blocks of the dense core
+    // cost many times the average; with 64-segment blocks the single-address atomic per block took over, 0.48 ms)
     const uint32_t waveId = blockIdx.x * (LV_BLOCK / LV_WAVE) + (threadIdx.x >> 6), numWaves = gridDim.x * (LV_BLOCK / LV_WAVE);
     for (uint32_t leafBase = waveId * LV_WAVE; leafBase < S.numSegs; leafBase += numWaves * LV_WAVE) {
         const uint32_t leaf = leafBase + lane;
         const bool valid = leaf < S.numSegs;
-        uint32_t pi[2] = {0u, 0u};
-        LvPrismPoint pt[2];
+        leafBaseCur = leafBase;
         int x0 = 0, x1 = -1, y0 = 0, y1 = -1;
+        // oriented box: |(pixel centre - c) . a - aMid| <= aHalf and |(pixel centre - c) . n - nMid| <= nHalf, n = (-a.y, a.x)
+        float ax = 1.0f, ay = 0.0f, cx0 = 0.0f, cy0 = 0.0f, aMid = 0.0f, aHalf = 3.0e38f, nMid = 0.0f, nHalf = 3.0e38f;
         if (valid) {
             const float4 pa = S.segs[2 * size_t(leaf)], pb = S.segs[2 * size_t(leaf) + 1];
+            uint32_t pi[2];
+            LvPrismPoint pt[2];
             lv_prism_frames(S, leaf, pa, pb, pt, pi);
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                segLds[9 * e + 0][lane] = pt[e].centre.x; segLds[9 * e + 1][lane] = pt[e].centre.y; segLds[9 * e + 2][lane] = pt[e].centre.z;
+                segLds[9 * e + 3][lane] = pt[e].normal.x; segLds[9 * e + 4][lane] = pt[e].normal.y; segLds[9 * e + 5][lane] = pt[e].normal.z;
+                segLds[9 * e + 6][lane] = pt[e].binormal.x; segLds[9 * e + 7][lane] = pt[e].binormal.y; segLds[9 * e + 8][lane] = pt[e].binormal.z;
+                segLds[18 + e][lane] = __uint_as_float(pi[e]);
+            }
+            // axis of the oriented box: the projected centres (any direction gives a valid box; this one gives a tight one)
+            bool axisOk = true;
+            float wcx[2], wcy[2];
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                const f3 v = pt[e].centre;
+                const float cw = ((mw[0] * v.x + mw[1] * v.y) + mw[2] * v.z) + mw[3];
+                const float ccx = ((mx[0] * v.x + mx[1] * v.y) + mx[2] * v.z) + mx[3];
+                const float ccy = ((my[0] * v.x + my[1] * v.y) + my[2] * v.z) + my[3];
+                axisOk = axisOk && cw > wEps;
+                wcx[e] = (ccx / cw + 1.0f) * halfW;
+                wcy[e] = (ccy / cw + 1.0f) * halfH;
+            }
+            if (axisOk) {
+                const float dx = wcx[1] - wcx[0], dy = wcy[1] - wcy[0], l2 = dx * dx + dy * dy;
+                if (l2 > 1e-12f && l2 < 1e30f) { const float il = 1.0f / sqrtf(l2); ax = dx * il; ay = dy * il; }
+                cx0 = wcx[0]; cy0 = wcy[0];
+            }
             float lox = 3.0e38f, hix = -3.0e38f, loy = 3.0e38f, hiy = -3.0e38f;
+            float loa = 3.0e38f, hia = -3.0e38f, lon = 3.0e38f, hin = -3.0e38f;
             bool anyFront = false, anyBehind = false;
             for (uint32_t k = 0; k < N; k++) {
 #pragma unroll
@@ -1299,16 +1419,23 @@ __global__ __launch_bounds__(LV_BLOCK, LV_PRISM_RASTER_MIN_WAVES) void k_ppll_ra
                     const f3 v = lv_prism_pos(pt[e], lv_prism_dir(pt[e], R.c[k], R.s[k]), U.radius);
                     const float cw = ((mw[0] * v.x + mw[1] * v.y) + mw[2] * v.z) + mw[3];
                     if (cw > wEps) {
-                        const float cx = ((mx[0] * v.x + mx[1] * v.y) + mx[2] * v.z) + mx[3];
-                        const float cy = ((my[0] * v.x + my[1] * v.y) + my[2] * v.z) + my[3];
-                        const float wx = (cx / cw + 1.0f) * halfW, wy = (cy / cw + 1.0f) * halfH;
+                        const float ccx = ((mx[0] * v.x + mx[1] * v.y) + mx[2] * v.z) + mx[3];
+                        const float ccy = ((my[0] * v.x + my[1] * v.y) + my[2] * v.z) + my[3];
+                        const float wx = (ccx / cw + 1.0f) * halfW, wy = (ccy / cw + 1.0f) * halfH;
                         lox = fminf(lox, wx); hix = fmaxf(hix, wx); loy = fminf(loy, wy); hiy = fmaxf(hiy, wy);
+                        const float ta = (wx - cx0) * ax + (wy - cy0) * ay, tn = (wy - cy0) * ax - (wx - cx0) * ay;
+                        loa = fminf(loa, ta); hia = fmaxf(hia, ta); lon = fminf(lon, tn); hin = fmaxf(hin, tn);
                         anyFront = true;
                     } else anyBehind = true;
                 }
             }
             if (anyFront) {   // (all vertices behind the camera plane: no viewing ray meets the prism at a positive depth)
                 if (anyBehind) { lox = 0.0f; loy = 0.0f; hix = float(U.width); hiy = float(U.height); }   // straddles the camera plane
+                else if (axisOk) {
+                    // (the projected coordinates carry a relative rounding error of a few ulp: the margin also covers the box's own arithmetic)
+                    aMid = 0.5f * (loa + hia); aHalf = 0.5f * (hia - loa) + LV_PRISM_BBOX_MARGIN;
+                    nMid = 0.5f * (lon + hin); nHalf = 0.5f * (hin - lon) + LV_PRISM_BBOX_MARGIN;
+                }
                 // pixel x is a candidate iff its centre x + 0.5 lies in [lo - margin, hi + margin]
                 const float fx0 = fmaxf(ceilf(lox - LV_PRISM_BBOX_MARGIN - 0.5f), 0.0f);
                 const float fy0 = fmaxf(ceilf(loy - LV_PRISM_BBOX_MARGIN - 0.5f), 0.0f);
@@ -1320,57 +1447,24 @@ __global__ __launch_bounds__(LV_BLOCK, LV_PRISM_RASTER_MIN_WAVES) void k_ppll_ra
         int px = x0, py = y0;
         bool more = valid && x1 >= x0 && y1 >= y0;
         while (__any(more)) {
-            unsigned mask = 0u;
-            uint32_t addr = 0u;
+            bool cand = false;
             if (more) {
-                addr = lv_ppll_addr(uint32_t(px), uint32_t(py), U.ppllPaddedW, U.ppllTileW, U.ppllTileH);
-                if (startOffset[addr] == 0u) {   // pixel of a requested tile
-                    f3 oo, d;
-                    lv_primary_ray(U, uint32_t(px), uint32_t(py), 0.5f, 0.5f, oo, d);
-                    mask = lv_prism_coverage_pts<NT>(R, pt, pi, U.radius, o, d);
-                    if (STATS) tests++;
-                }
+                const float qx = (float(px) + 0.5f) - cx0, qy = (float(py) + 0.5f) - cy0;
+                cand = fabsf((qx * ax + qy * ay) - aMid) <= aHalf && fabsf((qy * ax - qx * ay) - nMid) <= nHalf;
             }
-            while (__any(mask != 0u)) {
-                const bool hit = mask != 0u;
-                const unsigned long long hm = __ballot(hit);
-                const unsigned n = unsigned(__popcll(hm));
-                const unsigned rankInBatch = unsigned(__popcll(hm & ((1ull << lane) - 1ull)));
-                unsigned base = allocBase, left = allocLeft, base2 = 0u;
-                if (left < n) {
-                    if (lane == 0u) base2 = atomicAdd(&dc->fragAlloc, (unsigned)LV_PRISM_RASTER_CHUNK);
-                    base2 = __builtin_amdgcn_readfirstlane(base2);
-                    allocBase = base2 + (n - left);
-                    allocLeft = LV_PRISM_RASTER_CHUNK - (n - left);
-                } else {
-                    allocBase = base + n;
-                    allocLeft = left - n;
-                }
-                if (hit) {
-                    const unsigned tt = unsigned(__ffs(int(mask))) - 1u;
-                    mask &= mask - 1u;
-                    const uint32_t insertIndex = rankInBatch < left ? base + rankInBatch : base2 + (rankInBatch - left);
-                    bool stored = false;
-                    if (insertIndex < poolSlots) {
-                        const uint32_t rk = atomicAdd(&fragCount[addr], 1u);
-                        if ((rk & 0xFFFFu) < 0xFFFFu) {
-                            records[3 * size_t(insertIndex) + 0] = uint32_t(px) | (uint32_t(py) << 16);
-                            records[3 * size_t(insertIndex) + 1] = leaf | (tt << 26);
-                            records[3 * size_t(insertIndex) + 2] = rk & 0xFFFFu;
-                            stored = true;
-                        } else {   // (the per-pixel count shares its word with the count of discarded fragments: 16 bits each)
-                            atomicSub(&fragCount[addr], 1u);
-                            records[3 * size_t(insertIndex) + 0] = 0u;
-                            records[3 * size_t(insertIndex) + 1] = LV_PPLL_DEAD;
-                        }
-                    }
-                    if (!stored) dropped++;   // no record: the fragment stage never sees it, but the reference's fragCounter counts it
-                }
+            const unsigned long long cm = __ballot(cand);
+            if (cand) {
+                const unsigned q = (qHead + qCount + unsigned(__popcll(cm & ((1ull << lane) - 1ull)))) & (LV_PRISM_RASTER_QUEUE - 1u);
+                qLeaf[q] = leaf;
+                qPix[q] = uint32_t(px) | (uint32_t(py) << 16);
             }
+            qCount += unsigned(__popcll(cm));
+            if (qCount >= LV_WAVE) coverageStage(LV_WAVE);
             if (more) {
                 if (++px > x1) { px = x0; more = ++py <= y1; }
             }
         }
+        while (qCount > 0u) coverageStage(qCount < LV_WAVE ? qCount : LV_WAVE);   // (the next 64 segments replace the frames in LDS)
     }
     // the slots this wave reserved but did not use are part of the range the fragment stage walks: mark them dead
     for (unsigned k = lane; k < allocLeft; k += LV_WAVE)
@@ -1385,14 +1479,19 @@ __global__ __launch_bounds__(LV_BLOCK, LV_PRISM_RASTER_MIN_WAVES) void k_ppll_ra
 }
 
 // clear(): LinkedListClear.glsl:46-55 (start offsets = -1) + fragmentCounterBuffer->fill(0), and the per-pixel fragment counts
+// (startValue: 0xFFFFFFFF = empty list / pixel not requested; the segment rasteriser of a frame whose tiles cover the whole viewport
+// passes 0 = every pixel requested and skips k_ppll_mark_tiles; viewingRays: those pixels' viewing rays for the statistics)
 __global__ __launch_bounds__(LV_BLOCK) void k_ppll_clear(uint4* __restrict__ startOffset, uint4* __restrict__ fragCount, size_t n4,
-                                                         LvDevCounters* dc) {
+                                                         LvDevCounters* dc, uint32_t startValue, unsigned long long viewingRays) {
     const size_t i = size_t(blockIdx.x) * LV_BLOCK + threadIdx.x;
     if (i < n4) {
-        startOffset[i] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+        startOffset[i] = make_uint4(startValue, startValue, startValue, startValue);
         fragCount[i] = make_uint4(0u, 0u, 0u, 0u);
     }
-    if (i == 0) { dc->fragCounter = 0u; dc->fragAlloc = 0u; dc->prismDiscards = 0u; dc->ppllOverflowPixels = 0u; }
+    if (i == 0) {
+        dc->fragCounter = 0u; dc->fragAlloc = 0u; dc->prismDiscards = 0u; dc->ppllOverflowPixels = 0u;
+        if (viewingRays) atomicAdd(&dc->rays, viewingRays);
+    }
 }
 
 // per-thread fragment arrays interleaved over the wave: entry i of lane l at [i * 64 + l]
@@ -2339,6 +2438,26 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
         ctx->tilesUploaded = true;
         ctx->tilesHaloUploaded = false;
         ctx->tilesGeneration++;
+        ctx->tilesCoverKey[0] = 0u;   // (tilesCoverViewport is recomputed below)
+    }
+    if (ctx->tilesCoverKey[0] != ctx->width || ctx->tilesCoverKey[1] != ctx->height || ctx->tilesCoverKey[2] != tileW ||
+        ctx->tilesCoverKey[3] != tileH) {
+        // do the tiles cover every pixel of the viewport?  (sufficient test: grid-aligned tiles, every grid cell present)
+        const uint32_t gx = (ctx->width + tileW - 1u) / tileW, gy = (ctx->height + tileH - 1u) / tileH;
+        bool cover = false;
+        if (uint64_t(gx) * gy <= uint64_t(numTiles)) {
+            std::vector<uint8_t> cell(size_t(gx) * gy, 0);
+            size_t present = 0;
+            for (uint32_t t = 0; t < numTiles; t++) {
+                const uint32_t tx = tilesXYHost[2 * t], ty = tilesXYHost[2 * t + 1];
+                if (tx % tileW || ty % tileH || tx / tileW >= gx || ty / tileH >= gy) continue;
+                uint8_t& c = cell[size_t(ty / tileH) * gx + tx / tileW];
+                if (!c) { c = 1; present++; }
+            }
+            cover = present == size_t(gx) * gy;
+        }
+        ctx->tilesCoverViewport = cover;
+        ctx->tilesCoverKey[0] = ctx->width; ctx->tilesCoverKey[1] = ctx->height; ctx->tilesCoverKey[2] = tileW; ctx->tilesCoverKey[3] = tileH;
     }
     LV_HIP(ctx, hipMemsetAsync(dc, 0, sizeof(LvDevCounters), st));
 
@@ -2488,8 +2607,10 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
         ctx->ppllPaddedW = U.ppllPaddedW;
         ctx->ppllPaddedH = U.ppllPaddedH;
         // clear(): LinkedListClear.glsl:46-55 + fragmentCounterBuffer->fill(0)
-        k_ppll_clear<<<uint32_t((padded4 + LV_BLOCK - 1) / LV_BLOCK), LV_BLOCK, 0, st>>>((uint4*)ctx->ppllStart.ptr,
-                                                                                         (uint4*)ctx->ppllCount.ptr, padded4, dc);
+        const bool allRequested = segmentRaster && ctx->tilesCoverViewport;
+        k_ppll_clear<<<uint32_t((padded4 + LV_BLOCK - 1) / LV_BLOCK), LV_BLOCK, 0, st>>>(
+                (uint4*)ctx->ppllStart.ptr, (uint4*)ctx->ppllCount.ptr, padded4, dc, allRequested ? 0u : 0xFFFFFFFFu,
+                (allRequested && stats) ? (unsigned long long)U.width * U.height : 0ull);
         LV_HIP(ctx, hipEventRecord(ctx->ev[11], st));
 #define LV_LAUNCH_GATHER(ST, PR, BA)                                                                             \
     LV_TIMED_LAUNCH(ctx, LV_KERNEL_PPLL_GATHER, (k_ppll_gather<ST, PR, BA><<<gridTiles * numSlices, LV_BLOCK, 0, st>>>( \
@@ -2508,7 +2629,8 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
 #define LV_LAUNCH_RASTER(ST, NT)                                                                                              \
     LV_TIMED_LAUNCH(ctx, LV_KERNEL_PPLL_RASTER, (k_ppll_raster_prism<ST, NT><<<rasterGrid, LV_BLOCK, 0, st>>>(                \
             U, S, gatherPool, (const uint32_t*)ctx->ppllStart.ptr, (uint32_t*)ctx->ppllCount.ptr, dc, poolSlots)))
-            if (stats) k_ppll_mark_tiles<true><<<gridTiles, LV_BLOCK, 0, st>>>(U, T, (uint32_t*)ctx->ppllStart.ptr, dc);
+            if (allRequested) {}   // (k_ppll_clear marked every pixel)
+            else if (stats) k_ppll_mark_tiles<true><<<gridTiles, LV_BLOCK, 0, st>>>(U, T, (uint32_t*)ctx->ppllStart.ptr, dc);
             else k_ppll_mark_tiles<false><<<gridTiles, LV_BLOCK, 0, st>>>(U, T, (uint32_t*)ctx->ppllStart.ptr, dc);
             if (S.numSegs != 0) {
                 if (S.prism.n == 6u) { if (stats) LV_LAUNCH_RASTER(true, 6); else LV_LAUNCH_RASTER(false, 6); }

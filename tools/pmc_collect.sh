@@ -51,7 +51,7 @@ for f in sorted(glob.glob("$OUT/$W.p*/**/p_counter_collection.csv", recursive=Tr
         n = r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
         if not n.startswith("k_"):
             continue   # foreign kernels (torch, rocPRIM)
-        if n.startswith(("k_render_rt", "k_ao_primary", "k_ao_rays", "k_ppll_gather")) and "<true" in n.split(",")[0]:
+        if n.startswith(("k_render_rt", "k_ao_primary", "k_ao_rays", "k_ppll_gather", "k_ppll_raster_prism", "k_ppll_shade_prism", "k_ppll_mark_tiles")) and "<true" in n.split(",")[0]:
             continue   # the instrumented (collect_stats) instances
         agg[n][r["Counter_Name"]].append(float(r["Counter_Value"]))
         seen.add(r["Counter_Name"])
