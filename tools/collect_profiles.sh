@@ -1,8 +1,8 @@
 #!/bin/bash
 # After `gpurun ... bash tools/profile_round.sh <tag>`: copy what the round produced under gpurun_out/ into profiles/ (tracked).
-TAG=${1:-r03}
+TAG=${1:-r04}
 cd "$(dirname "$0")/.."
-for w in c2 c2e c3 c3c c3c_svgf c3t c4 c4l c4m c5; do tail -1 gpurun_out/prof_$TAG/bench_$w.json > profiles/bench_${TAG}_$w.json; done
+for w in c2 c2e c3 c3c c3c_svgf c3t c4 c4c c4_lbvh c4l c4m c5; do tail -1 gpurun_out/prof_$TAG/bench_$w.json > profiles/bench_${TAG}_$w.json; done
 for w in c2 c3 c4 c4m c3c_svgf; do cp gpurun_out/prof_$TAG/${w}_kernel_stats.csv profiles/${TAG}_${w}_kernel_stats.csv; done
 for f in gpurun_out/pmc_$TAG/*.json; do cp $f profiles/pmc_${TAG}_$(basename $f); done
 cp gpurun_out/prof_$TAG/ubench_summary.json profiles/ubench_$TAG.json

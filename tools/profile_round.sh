@@ -2,9 +2,9 @@
 # Everything profiles/ needs for one round, on the GPU box:  bash tools/profile_round.sh <tag>
 #   bench lines of every workload          -> gpurun_out/prof_<tag>/bench_<workload>.json
 #   rocprofv3 --kernel-trace --stats       -> gpurun_out/prof_<tag>/<workload>_kernel_stats.csv  (same command as the bench line)
-#   PMC counter groups (tools/pmc_collect.sh: full set for c3c / c3t, roofline set for the others) -> gpurun_out/pmc_<tag>/
+#   PMC counter groups (tools/pmc_collect.sh: full set for c3c / c3t / c4, roofline set for the others) -> gpurun_out/pmc_<tag>/
 #   shard / frames-in-flight probe          -> gpurun_out/shard_probe_<workload>.json
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
@@ -14,11 +14,11 @@ mkdir -p $R/gpurun_out/ubench_$TAG
 timeout 600 $R/tools/ubench/_build/valu_rates > $R/gpurun_out/ubench_$TAG/valu_rates.json 2> $OUT/valu_rates.err
 timeout 600 $R/tools/ubench/_build/tcp_rates > $R/gpurun_out/ubench_$TAG/tcp_rates.json 2> $OUT/tcp_rates.err
 python $R/tools/summarize_ubench.py ubench_$TAG $TAG > $OUT/ubench_summary.json 2>> $OUT/valu_rates.err
-bash $R/tools/pmc_collect.sh $TAG c3c c3t > $OUT/pmc_full.log 2>&1
-LV_PMC_LITE=1 bash $R/tools/pmc_collect.sh $TAG c2 c2e c4 c4m c4l c5 > $OUT/pmc_lite.log 2>&1
+bash $R/tools/pmc_collect.sh $TAG c3c c3t c4 > $OUT/pmc_full.log 2>&1
+LV_PMC_LITE=1 bash $R/tools/pmc_collect.sh $TAG c2 c2e c4c c4m c4l c5 > $OUT/pmc_lite.log 2>&1
 for f in $R/gpurun_out/pmc_$TAG/*.json; do cp $f $R/profiles/pmc_${TAG}_$(basename $f); done   # bench.py reads profiles/
 python $R/bench.py > $OUT/bench_c3.json 2> $OUT/bench_c3.err
-for w in c3c c3t c2 c2e c4 c4m c4l c5; do
+for w in c3c c3t c2 c2e c4 c4c c4m c4l c5; do
   python $R/bench.py --workload $w --steps 100 --warmup 5 --no-cpu-baseline > $OUT/bench_$w.json 2> $OUT/bench_$w.err
 done
 for w in c3 c4 c4m c2; do
@@ -37,6 +37,7 @@ with open("$OUT/${w}_kernel_stats.csv", "w") as o:
 PY
   rm -rf $OUT/trace_$w
 done
+python $R/bench.py --workload c4 --steps 100 --warmup 5 --no-cpu-baseline --set ppll_prism_rasteriser=lbvh > $OUT/bench_c4_lbvh.json 2> $OUT/bench_c4_lbvh.err
 # the SVGF passes next to the RTAO kernels they follow
 python $R/bench.py --workload c3c --steps 100 --warmup 5 --no-cpu-baseline --set ambient_occlusion_denoiser=SVGF > $OUT/bench_c3c_svgf.json 2> $OUT/bench_c3c_svgf.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_svgf -o bench -- python $R/bench.py --workload c3c --steps 20 --warmup 3 --no-cpu-baseline --set ambient_occlusion_denoiser=SVGF > $OUT/rocprof_svgf.json 2> $OUT/rocprof_svgf.err
