@@ -549,7 +549,7 @@ __device__ __forceinline__ void lv_write_wide_node(float4* out, int ns, const ui
 // two children of its binary root and greedily replaces the internal slot with the largest surface area by that node's
 // two children until four slots are filled (the standard SAH-guided collapse for wide BVHs): slots that are cheap to hit
 // are opened first, and fewer slots stay empty than with "two binary levels per wide node" (1 M segments: 0.48 M nodes,
-// 3.1 children per node; an optimal dynamic-programming collapse reaches 3.5 but traces no faster).
+// 3.1 children per node; an optimal dynamic-programming collapse reaches 3.5 but traces no faster, EXPERIMENTS.md 3.1).
 //   k_collapse_select  frontier item i (a binary node) -> its <= 4 slots as binary references + the number of internal ones
 //   exclusive scan     -> position of each item's internal slots in the next frontier (deterministic BFS numbering)
 //   k_collapse_emit    writes the compressed node (index base + i) and the next frontier

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Where the idle lanes of k_ao_rays' descend loop come from.
+"""Where the idle lanes of k_ao_rays' descend loop come from (EXPERIMENTS.md 3.1, round 3).
 
   python tools/probe_idle.py build      (CPU container: compiles the instrumented variant, -DLV_AO_IDLE_PROBE=1)
   python tools/probe_idle.py            (GPU box: per RTAO geometry the descend loop's lane utilisation, the lane-slots of rays

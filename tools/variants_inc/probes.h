@@ -1,5 +1,5 @@
 // Sensitivity probes of the node step (tools/variants.py force-includes this file for variants that set -DLV_EXP_EXTRA_LOADS=n or
-// -DLV_EXP_EXTRA_VALU=n): what one more L1-hitting dwordx4 / one more VALU instruction per node step costs.
+// -DLV_EXP_EXTRA_VALU=n): what one more L1-hitting dwordx4 / one more VALU instruction per node step costs (EXPERIMENTS.md 3.1).
 // Expanded inside lv_node_step (linevis_amd/csrc/lv_trace.h); never part of the product build.
 #pragma once
 #if defined(LV_EXP_EXTRA_LOADS) || defined(LV_EXP_EXTRA_VALU)
