@@ -988,6 +988,13 @@ int lv_ppll_get_buffers(lv_ctx* ctx, uint32_t* out_nodes, uint64_t max_nodes, ui
         if (np) {
             LV_HIP(ctx, hipMemcpy(cnt.data(), ctx->ppllCount.ptr, size_t(np) * 4, hipMemcpyDeviceToHost));
             LV_HIP(ctx, hipMemcpy(off.data(), ctx->ppllStart.ptr, size_t(np) * 4, hipMemcpyDeviceToHost));
+            // run offsets are relative to the pixel's scan block (k_ppll_scan): add the blocks' bases
+            std::vector<uint32_t> base(ctx->ppllScanBlocks);
+            if (!base.empty())
+                LV_HIP(ctx, hipMemcpy(base.data(), (const uint32_t*)ctx->scanTemp.ptr + ctx->ppllScanBlocks, base.size() * 4, hipMemcpyDeviceToHost));
+            const uint64_t itemsPerBlock = LV_SCAN_ITEMS;
+            for (uint64_t p = 0; p < np; p++)
+                if (p / itemsPerBlock < base.size()) off[p] += base[p / itemsPerBlock];
         }
         const uint64_t total = np ? uint64_t(off[np - 1]) + (cnt[np - 1] & 0xFFFFu) : 0u;
         if (out_nodes && max_nodes < total) return lv_fail(ctx, LV_E_CAPACITY, "out_nodes holds %llu nodes, %llu stored",

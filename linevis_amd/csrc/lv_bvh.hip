@@ -860,18 +860,6 @@ int lv_bvh_build(lv_ctx* ctx) {
 
 // LBVH over the triangle tubes (VulkanRayTracedAmbientOcclusion.cpp:444-456 builds a triangle BLAS/TLAS from the same
 // buffers).  The pad depends on the line width like the capsule pad, so the tree is rebuilt when it changes.
-// Exclusive prefix sum of n uint32 on the context's stream (rocPRIM): per-pixel fragment counts -> offsets of the pixels' runs in the
-// fragment array of the PPLL frame path (lv_render.hip).  The temporary storage stays with the context.
-int lv_scan_exclusive_u32(lv_ctx* ctx, const uint32_t* in, uint32_t* out, size_t n) {
-    if (n == 0) return LV_OK;
-    size_t bytes = 0;
-    LV_HIP(ctx, rocprim::exclusive_scan(nullptr, bytes, in, out, 0u, n, rocprim::plus<uint32_t>(), ctx->stream));
-    int rc;
-    if ((rc = lv_buf_reserve(ctx, ctx->scanTemp, std::max<size_t>(bytes, 16)))) return rc;
-    LV_HIP(ctx, rocprim::exclusive_scan(ctx->scanTemp.ptr, bytes, in, out, 0u, n, rocprim::plus<uint32_t>(), ctx->stream));
-    return LV_OK;
-}
-
 int lv_bvh_build_triangles(lv_ctx* ctx) {
     const uint32_t n = ctx->numTris;
     hipStream_t st = ctx->stream;

@@ -223,6 +223,7 @@ struct LvSvgfFeat {
 // ring angles circleIdx / N * 2 pi (LinePassProgrammablePullTubes.glsl:129-131; lv_sincos2pi of circleIdx / N, filled on the host by
 // the same formula), the camera's right axis (column 0 of inverse(viewMatrix)) that spans the ray-space basis, row 2 of the view
 // matrix + the clip distances (depth clipping of the fragments)
+#define LV_SCAN_ITEMS 4096u      // pixel addresses per workgroup of k_ppll_scan (run offsets are relative to these blocks)
 #define LV_PRISM_MAX_SUBDIV 16
 struct LvPrismDev {
     float c[LV_PRISM_MAX_SUBDIV], s[LV_PRISM_MAX_SUBDIV];

@@ -187,7 +187,8 @@ struct lv_ctx {
     LvDeviceBuffer aoGbuf, aoList, aoSamples; // RTAO wavefront buffers
     LvDeviceBuffer counters;                  // device counters (LvCounters + misc)
     LvDeviceBuffer ppllNodes, ppllStart, ppllCount, ppllScratch;
-    LvDeviceBuffer prismRecords, scanTemp;    // raster_prism: {pixel, leaf | triangle, rank} records of the coverage kernel; rocPRIM scan storage
+    LvDeviceBuffer prismRecords, scanTemp;    // raster_prism: {pixel, leaf | triangle, rank} records of the coverage kernel; k_ppll_scan: block totals, block bases, completion counter
+    uint32_t ppllScanBlocks = 0;              // raster_prism: workgroups of the last k_ppll_scan (scanTemp = totals, bases, counter)
     LvDeviceBuffer ppllOverflow;              // raster_prism: pixel addresses with more kept fragments than ppllMaxNumFrags (k_ppll_pixel_pass)
     bool ppllArrays = false;                  // the last PPLL frame left per-pixel runs (raster_prism), not linked lists
     LvDeviceBuffer tilesDev, outDev, scratchRays, stackOverflow, mlatTrace;
@@ -259,7 +260,6 @@ void lv_buf_free(LvDeviceBuffer& b);
 // lv_bvh.hip
 int lv_bvh_build(lv_ctx* ctx);
 int lv_bvh_build_triangles(lv_ctx* ctx);
-int lv_scan_exclusive_u32(lv_ctx* ctx, const uint32_t* in, uint32_t* out, size_t n);
 // lv_multi.hip: one frame over the GPUs of a node behind the same handle
 int lv_multi_create(lv_ctx* handle, const int* devices, int numDevices, const char* transport);
 void lv_multi_destroy(lv_ctx* handle);

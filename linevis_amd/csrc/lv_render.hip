@@ -1008,6 +1008,12 @@ __global__ __launch_bounds__(LV_BLOCK, PRIM == LV_PRIM_PRISM ? LV_PRISM_MIN_WAVE
     if (STATS) lv_flush_counters(cnt, dc);
 }
 
+// start of a pixel's run in the fragment array (k_ppll_scan: offsets relative to the pixel's block of LV_SCAN_ITEMS addresses + the block's base)
+__device__ __forceinline__ uint32_t lv_run_start(const uint32_t* __restrict__ startOffset, const uint32_t* __restrict__ blockBase,
+                                                 uint32_t addr) {
+    return startOffset[addr] + blockBase[addr / LV_SCAN_ITEMS];
+}
+
 // Fragment stage of ppll_fragment_source = raster_prism: one lane per record of the coverage kernel (k_ppll_gather<LV_PRIM_PRISM>),
 // grid-stride over the record pool -- LinePassGeometryShaderTubes.glsl:732-1129 on the perspective-correct inputs (lv_shade_prism) +
 // the store of gatherFragment (LinkedListGather.glsl:33-72): {colour, depth} goes to slot pixelOffset[pixel] + rank of the fragment
@@ -1017,7 +1023,8 @@ __global__ __launch_bounds__(LV_BLOCK, PRIM == LV_PRIM_PRISM ? LV_PRISM_MIN_WAVE
 template <bool STATS>
 __global__ __launch_bounds__(LV_BLOCK, LV_PRISM_SHADE_MIN_WAVES) void k_ppll_shade_prism(const LvUniforms U, const LvSceneDev S,
                                                                    const uint32_t* __restrict__ records, uint2* __restrict__ frags,
-                                                                   const uint32_t* __restrict__ pixelOffset, uint32_t* __restrict__ fragCount,
+                                                                   const uint32_t* __restrict__ pixelOffset,
+                                                                   const uint32_t* __restrict__ blockBase, uint32_t* __restrict__ fragCount,
                                                                    LvDevCounters* dc, uint32_t poolSlots) {
     __shared__ float s_prismRing[2 * LV_PRISM_MAX_SUBDIV];
     if (threadIdx.x < LV_PRISM_MAX_SUBDIV) {   // ring table in LDS: the triangle a lane shades is a per-lane index
@@ -1030,8 +1037,12 @@ __global__ __launch_bounds__(LV_BLOCK, LV_PRISM_SHADE_MIN_WAVES) void k_ppll_sha
     const float tLo = 0.0001f, tHi = __uint_as_float(__float_as_uint(1000.0f) + 1u); // the gather's ray interval [tMin, tMax]
     unsigned long long hits = 0;
     uint32_t localSum = 0u, localDead = 0u;
-    for (uint32_t base = blockIdx.x * LV_BLOCK; base < numSlots; base += gridDim.x * LV_BLOCK) {
-        const uint32_t i = base + threadIdx.x;
+    // 256-slot items, item (sweep s, position p) to workgroup (p - 5 s) mod G: the dead tails of the rasteriser's record chunks end on
+    // chunk boundaries, i.e. at fixed positions modulo the chunk size -- a fixed position per workgroup gave some workgroups only tails
+    // and others none (chunks of 4096 slots: 0.71 instead of 0.29 ms)
+    const uint32_t G = gridDim.x;
+    for (uint32_t sweep = 0u, first = 0u; first < numSlots; sweep++, first += G * LV_BLOCK) {
+        const uint32_t i = first + ((blockIdx.x + 5u * sweep) % G) * LV_BLOCK + threadIdx.x;
         if (i >= numSlots) continue;
         const uint32_t w0 = records[3 * size_t(i) + 0], w1 = records[3 * size_t(i) + 1], rank = records[3 * size_t(i) + 2];
         if (w1 == LV_PPLL_DEAD) continue;   // slot of a chunk tail
@@ -1046,7 +1057,7 @@ __global__ __launch_bounds__(LV_BLOCK, LV_PRISM_SHADE_MIN_WAVES) void k_ppll_sha
         const f4 color = lv_shade_prism(S, U, s_prismRing, aoTexel, o, d, tLo, tHi, leaf, tt, rq, U.ppllRasterColour != 0u, depth, kept);
         if (STATS && kept) hits++;
         const uint32_t addr = lv_ppll_addr(px, py, U.ppllPaddedW, U.ppllTileW, U.ppllTileH);
-        const size_t dst = size_t(pixelOffset[addr]) + rank;
+        const size_t dst = size_t(lv_run_start(pixelOffset, blockBase, addr)) + rank;
         if (kept && color.w >= 0.001f) {   // gatherFragment: discard below, LinkedListGather.glsl:34
             frags[dst] = make_uint2(lv_pack_unorm4x8(color), __float_as_uint(depth));
             localSum++;
@@ -1086,7 +1097,7 @@ __global__ __launch_bounds__(LV_BLOCK, LV_PRISM_SHADE_MIN_WAVES) void k_ppll_sha
 //                       (depth, colour) key and, where a pixel holds more fragments than the sort arrays, keeps the nearest ones.
 #define LV_PRISM_BBOX_MARGIN 0.015625f   // 1/64 pixel: two orders of magnitude above the rounding of the projection at 4K
 #ifndef LV_PRISM_RASTER_CHUNK
-#define LV_PRISM_RASTER_CHUNK 256u      // record slots a wave reserves per global atomic
+#define LV_PRISM_RASTER_CHUNK 512u      // record slots a wave reserves per global atomic
 #endif
 #ifndef LV_PRISM_RASTER_MIN_WAVES
 #define LV_PRISM_RASTER_MIN_WAVES 3
@@ -1106,24 +1117,76 @@ __global__ __launch_bounds__(LV_BLOCK) void k_ppll_mark_tiles(const LvUniforms U
     }
 }
 
-// After the fragment stage, one lane per requested pixel:
-//  - the cost of a 64 x 64-pixel group for the dispatch order of the next frame and the tile balance of a sharded frame is the number
-//    of fragments the fragment stage and the resolve pass handle there (the segment rasteriser walks segments, not tiles);
-//  - pixels that kept more fragments than the sort arrays hold (ppllMaxNumFrags) go on a list for k_ppll_select_nearest.
-__global__ __launch_bounds__(LV_BLOCK) void k_ppll_pixel_pass(const LvUniforms U, const LvTiles T, const uint32_t* __restrict__ fragCount,
-                                                              uint32_t* __restrict__ overflowList, LvDevCounters* dc) {
-    LvPixel px;
-    if (!lv_block_pixel(U, T, px)) return;
-    uint32_t n = 0u;
-    if (px.inView) {
-        const uint32_t addr = lv_ppll_addr(px.x, px.y, U.ppllPaddedW, U.ppllTileW, U.ppllTileH);
-        const uint32_t v = fragCount[addr];
-        n = v & 0xFFFFu;
-        if (n - (v >> 16) > U.ppllMaxNumFrags) overflowList[atomicAdd(&dc->ppllOverflowPixels, 1u)] = addr;
-    }
+// Offsets of the pixels' runs: exclusive scan of the per-pixel record counts.  Workgroup b of k_ppll_scan scans its LV_SCAN_ITEMS counts
+// (in address order) and writes the offsets relative to its own first pixel and its total; k_ppll_scan_bases (one workgroup) turns the
+// totals into bases.  Run of pixel a = lv_run_start(...) = startOffset[a] + blockBase[a / LV_SCAN_ITEMS].  (rocPRIM's scan: three
+// launches, 24 us of a 0.85 ms frame.)  Pixels with more records than the sort arrays hold go on the list for k_ppll_select_nearest
+// -- records, not kept fragments: the fragment stage has not run yet; that kernel copes with the superset.
+#define LV_SCAN_ROUNDS (LV_SCAN_ITEMS / (4u * LV_BLOCK))   // uint4s per thread
+__device__ __forceinline__ uint32_t lv_block_exclusive_scan(uint32_t v, uint32_t* s_wave, uint32_t& total) {
+    const unsigned lane = lv_lane(), w = threadIdx.x >> 6;
+    uint32_t incl = v;
 #pragma unroll
-    for (int ofs = 32; ofs > 0; ofs >>= 1) n += (uint32_t)__shfl_xor(n, ofs, 64);
-    if (T.groupCost && lv_lane() == 0u && n) atomicAdd(&T.groupCost[px.group], n);
+    for (int ofs = 1; ofs < 64; ofs <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_up(int(incl), ofs, 64);
+        if (int(lane) >= ofs) incl += t;
+    }
+    __syncthreads();   // (s_wave may still be read from the previous call)
+    if (lane == 63u) s_wave[w] = incl;
+    __syncthreads();
+    uint32_t before = 0u;
+    total = 0u;
+#pragma unroll
+    for (uint32_t k = 0; k < LV_BLOCK / LV_WAVE; k++) {
+        const uint32_t t = s_wave[k];
+        if (k < w) before += t;
+        total += t;
+    }
+    return before + incl - v;
+}
+__global__ __launch_bounds__(LV_BLOCK) void k_ppll_scan(const uint32_t* __restrict__ fragCount, uint32_t* __restrict__ startOffset,
+                                                        uint32_t n, uint32_t* __restrict__ blockTotals, uint32_t maxFrags,
+                                                        uint32_t* __restrict__ overflowList, LvDevCounters* dc) {
+    __shared__ uint32_t s_wave[LV_BLOCK / LV_WAVE];
+    // round r: thread t owns the four addresses of uint4 number r * LV_BLOCK + t of the workgroup's block (coalesced)
+    uint4 v[LV_SCAN_ROUNDS];
+#pragma unroll
+    for (uint32_t r = 0; r < LV_SCAN_ROUNDS; r++) {
+        const uint32_t first = blockIdx.x * LV_SCAN_ITEMS + (r * LV_BLOCK + threadIdx.x) * 4u;
+        v[r] = first < n ? *reinterpret_cast<const uint4*>(fragCount + first) : make_uint4(0u, 0u, 0u, 0u);   // (n is a multiple of 4)
+    }
+    uint32_t carry = 0u;
+#pragma unroll
+    for (uint32_t r = 0; r < LV_SCAN_ROUNDS; r++) {
+        const uint32_t first = blockIdx.x * LV_SCAN_ITEMS + (r * LV_BLOCK + threadIdx.x) * 4u;
+        const uint32_t c0 = v[r].x & 0xFFFFu, c1 = v[r].y & 0xFFFFu, c2 = v[r].z & 0xFFFFu, c3 = v[r].w & 0xFFFFu;
+        if (max(max(c0, c1), max(c2, c3)) > maxFrags) {
+            if (c0 > maxFrags) overflowList[atomicAdd(&dc->ppllOverflowPixels, 1u)] = first;
+            if (c1 > maxFrags) overflowList[atomicAdd(&dc->ppllOverflowPixels, 1u)] = first + 1u;
+            if (c2 > maxFrags) overflowList[atomicAdd(&dc->ppllOverflowPixels, 1u)] = first + 2u;
+            if (c3 > maxFrags) overflowList[atomicAdd(&dc->ppllOverflowPixels, 1u)] = first + 3u;
+        }
+        uint32_t total;
+        const uint32_t before = carry + lv_block_exclusive_scan(((c0 + c1) + c2) + c3, s_wave, total);
+        if (first < n) *reinterpret_cast<uint4*>(startOffset + first) = make_uint4(before, before + c0, before + c0 + c1, before + c0 + c1 + c2);
+        carry += total;
+    }
+    if (threadIdx.x == 0u) blockTotals[blockIdx.x] = carry;
+}
+// second launch, one workgroup: the blocks' totals -> the blocks' bases.  (One launch with "the last workgroup to finish does this"
+// was slower than rocPRIM's three: 2 028 / 507 workgroups x a returning agent-scope atomic on one counter = 69 / 29 us.)
+__global__ __launch_bounds__(LV_BLOCK) void k_ppll_scan_bases(const uint32_t* __restrict__ blockTotals, uint32_t* __restrict__ blockBase,
+                                                              uint32_t numBlocks) {
+    __shared__ uint32_t s_wave[LV_BLOCK / LV_WAVE];
+    uint32_t carry = 0u;
+    for (uint32_t i0 = 0u; i0 < numBlocks; i0 += LV_BLOCK) {
+        const uint32_t i = i0 + threadIdx.x;
+        const uint32_t t = i < numBlocks ? blockTotals[i] : 0u;
+        uint32_t chunk;
+        const uint32_t ex = lv_block_exclusive_scan(t, s_wave, chunk);
+        if (i < numBlocks) blockBase[i] = carry + ex;
+        carry += chunk;
+    }
 }
 
 // Keep-the-nearest selection.  The order of a pixel's run is not defined (the rasteriser's lanes race for the ranks, as the reference's
@@ -1172,6 +1235,12 @@ __device__ __forceinline__ void lv_select_nearest(uint2* __restrict__ run, uint2
             }                                                                                                  \
         }                                                                                                      \
     } while (0)
+    {   // (the list holds the pixels with more than K RECORDS: where the fragment stage discarded enough of them, all live entries are kept)
+        uint32_t live;
+        LV_SELECT_COUNT(live, D < 0x80000000u);
+        K = min(K, live);
+        if (K == 0u) return;
+    }
     uint32_t V = 0u;   // K-th smallest depth
     for (int bit = 30; bit >= 0; --bit) {
         const uint32_t cand = V | (1u << bit);
@@ -1243,12 +1312,13 @@ __device__ __forceinline__ void lv_select_nearest(uint2* __restrict__ run, uint2
 
 __global__ __launch_bounds__(LV_WAVE) void k_ppll_select_nearest(const LvUniforms U, uint2* __restrict__ frags, uint2* __restrict__ temp,
                                                                  const uint32_t* __restrict__ startOffset,
+                                                                 const uint32_t* __restrict__ blockBase,
                                                                  const uint32_t* __restrict__ fragCount,
                                                                  const uint32_t* __restrict__ overflowList, const LvDevCounters* dc) {
     const uint32_t count = dc->ppllOverflowPixels, lane = threadIdx.x;
     for (uint32_t p = blockIdx.x; p < count; p += gridDim.x) {
         const uint32_t addr = overflowList[p];
-        const uint32_t off = startOffset[addr], n = fragCount[addr] & 0xFFFFu;
+        const uint32_t off = lv_run_start(startOffset, blockBase, addr), n = fragCount[addr] & 0xFFFFu;
         if (n <= LV_WAVE * LV_SELECT_REGS) lv_select_nearest<true>(frags + off, nullptr, n, U.ppllMaxNumFrags, lane);
         else lv_select_nearest<false>(frags + off, temp + off, n, U.ppllMaxNumFrags, lane);
     }
@@ -1369,9 +1439,11 @@ __global__ __launch_bounds__(LV_BLOCK, LV_PRISM_RASTER_MIN_WAVES) void k_ppll_ra
         qCount -= m;
     };
 
-    // (static interleave: wave w takes segments [64 (w + k numWaves), + 64).  Handing out blocks of consecutive segments on demand was
-    // slower -- 0.42 ms with 256-segment blocks, 0.80 ms with 1024: consecutive = spatially clustered, the blocks of the dense core
-    // cost many times the average; with 64-segment blocks the single-address atomic per block took over, 0.48 ms)
+    // (static interleave: wave w takes segments [64 (w + k numWaves), + 64).  Work queues were slower, whatever the order: tickets over
+    // consecutive blocks of 256 / 1024 segments 0.42 / 0.80 ms (consecutive = spatially clustered: the blocks of the dense core cost
+    // many times the average and end up as the tail), over blocks in a scrambled order (ticket * prime mod count) 0.38 / 0.33 / 0.37 /
+    // 0.49 ms for 64 / 128 / 256 / 512 segments per ticket -- small tickets pay the returning atomic on one address (13 ns each, 15.6 K
+    // of them), large ones the variance again -- against 0.29 ms)
     const uint32_t waveId = blockIdx.x * (LV_BLOCK / LV_WAVE) + (threadIdx.x >> 6), numWaves = gridDim.x * (LV_BLOCK / LV_WAVE);
     for (uint32_t leafBase = waveId * LV_WAVE; leafBase < S.numSegs; leafBase += numWaves * LV_WAVE) {
         const uint32_t leaf = leafBase + lane;
@@ -1648,7 +1720,7 @@ __global__ __launch_bounds__(LV_WAVE) void k_ppll_resolve(const LvUniforms U, co
                                                           const uint32_t* __restrict__ startOffset,
                                                           uint32_t* __restrict__ out, uint32_t* __restrict__ scratch,
                                                           uint32_t numGroups, const uint32_t* __restrict__ fragCount,
-                                                          LvDevCounters* dc) {
+                                                          LvDevCounters* dc, const uint32_t* __restrict__ blockBase) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
     uint32_t maxCount = 0u;   // raster_prism frames: the largest per-pixel fragment count (kept fragments) is collected here
     const uint32_t maxFrags = U.ppllMaxNumFrags;
@@ -1684,7 +1756,7 @@ __global__ __launch_bounds__(LV_WAVE) void k_ppll_resolve(const LvUniforms U, co
             // the first maxFrags live entries of the run: where a pixel kept more, k_ppll_select_nearest moved the nearest to the front
             if (inView) {
                 const uint32_t addr = lv_ppll_addr(x, y, U.ppllPaddedW, U.ppllTileW, U.ppllTileH);
-                fragOffset = startOffset[addr];
+                fragOffset = lv_run_start(startOffset, blockBase, addr);
                 const uint32_t v = fragCount[addr];
                 const uint32_t n = v & 0xFFFFu;                // entries of the run; v >> 16 of them are dead
                 maxCount = max(maxCount, n - (v >> 16));
@@ -2532,6 +2604,14 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
         S.bakedBlendingWeights = (const float*)ctx->bakeBlendingWeights.ptr;
     }
     LV_HIP(ctx, hipEventRecord(ctx->ev[7], st));
+    // The colour pass of a raster_prism frame with the segment rasteriser has no tile kernel: only its resolve pass could use the
+    // dispatch order, and measured it does not (config 4: 0.134 ms as numbered, 0.145 ms heaviest first + 11 us for k_group_order)
+    if (mode == LV_RENDERING_MODE_PER_PIXEL_LINKED_LIST && lv_ppll_prism_source(ctx) && !ctx->opt.ppllPrismLbvhWalk &&
+        !ctx->groupOrderSorted) {
+        T.groupOrder = nullptr;
+        T.groupCost = nullptr;
+        ctx->groupOrder[0].active = false;
+    }
     if ((rc = lv_group_order_sort(ctx))) return rc; // (queued by the RTAO pass already when that ran)
 
     uint32_t* out = (uint32_t*)outDevice;
@@ -2642,23 +2722,29 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
         }
 #undef LV_LAUNCH_GATHER2
 #undef LV_LAUNCH_GATHER
+        uint32_t* blockBase = nullptr;
         if (prismSource) {
-            // per-pixel counts -> offsets of the pixels' runs (the counts are final: one workgroup per pixel)
-            if ((rc = lv_scan_exclusive_u32(ctx, (const uint32_t*)ctx->ppllCount.ptr, (uint32_t*)ctx->ppllStart.ptr,
-                                            size_t(U.ppllPaddedW) * U.ppllPaddedH))) return rc;
+            // per-pixel counts -> offsets of the pixels' runs + the list of the pixels with more records than the sort arrays hold
+            const uint32_t numAddr = uint32_t(padded4 * 4);
+            const uint32_t scanBlocks = (numAddr + LV_SCAN_ITEMS - 1u) / LV_SCAN_ITEMS;
+            if ((rc = lv_buf_reserve(ctx, ctx->ppllOverflow, padded4 * 16))) return rc;
+            if ((rc = lv_buf_reserve(ctx, ctx->scanTemp, (2 * size_t(scanBlocks) + 1) * 4))) return rc;
+            uint32_t* blockTotals = (uint32_t*)ctx->scanTemp.ptr;
+            blockBase = blockTotals + scanBlocks;
+            k_ppll_scan<<<scanBlocks, LV_BLOCK, 0, st>>>((const uint32_t*)ctx->ppllCount.ptr, (uint32_t*)ctx->ppllStart.ptr, numAddr,
+                                                        blockTotals, U.ppllMaxNumFrags, (uint32_t*)ctx->ppllOverflow.ptr, dc);
+            k_ppll_scan_bases<<<1, LV_BLOCK, 0, st>>>(blockTotals, blockBase, scanBlocks);
+            ctx->ppllScanBlocks = scanBlocks;
             const uint32_t shadeGrid = uint32_t(ctx->numCUs) * LV_PRISM_SHADE_BLOCKS_PER_CU;
 #define LV_LAUNCH_SHADE(ST)                                                                                                     \
     LV_TIMED_LAUNCH(ctx, LV_KERNEL_PPLL_SHADE, (k_ppll_shade_prism<ST><<<shadeGrid, LV_BLOCK, 0, st>>>(                         \
             U, S, (const uint32_t*)ctx->prismRecords.ptr, (uint2*)ctx->ppllNodes.ptr, (const uint32_t*)ctx->ppllStart.ptr,      \
-            (uint32_t*)ctx->ppllCount.ptr, dc, poolSlots)))
+            blockBase, (uint32_t*)ctx->ppllCount.ptr, dc, poolSlots)))
             if (stats) LV_LAUNCH_SHADE(true); else LV_LAUNCH_SHADE(false);
 #undef LV_LAUNCH_SHADE
-            // group costs + the pixels that kept more fragments than the sort arrays hold; their nearest ppllMaxNumFrags to the front
-            if ((rc = lv_buf_reserve(ctx, ctx->ppllOverflow, padded4 * 16))) return rc;
-            k_ppll_pixel_pass<<<gridTiles, LV_BLOCK, 0, st>>>(U, T, (const uint32_t*)ctx->ppllCount.ptr,
-                                                             (uint32_t*)ctx->ppllOverflow.ptr, dc);
+            // the listed pixels: their nearest ppllMaxNumFrags fragments to the front of the run
             k_ppll_select_nearest<<<uint32_t(ctx->numCUs) * 16u, LV_WAVE, 0, st>>>(
-                    U, (uint2*)ctx->ppllNodes.ptr, (uint2*)ctx->prismRecords.ptr, (const uint32_t*)ctx->ppllStart.ptr,
+                    U, (uint2*)ctx->ppllNodes.ptr, (uint2*)ctx->prismRecords.ptr, (const uint32_t*)ctx->ppllStart.ptr, blockBase,
                     (const uint32_t*)ctx->ppllCount.ptr, (const uint32_t*)ctx->ppllOverflow.ptr, dc);
         }
         LV_HIP(ctx, hipEventRecord(ctx->ev[13], st));
@@ -2673,11 +2759,11 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
         if (prismSource)                                                                                                       \
             LV_TIMED_LAUNCH(ctx, LV_KERNEL_PPLL_RESOLVE, (k_ppll_resolve<LDS, PQ, true><<<GRID, LV_WAVE, BYTES, st>>>(        \
                     U, T, (const uint32_t*)ctx->ppllNodes.ptr, (const uint32_t*)ctx->ppllStart.ptr, out, SCRATCH, numGroups,   \
-                    prismCount, dc)));                                                                                         \
+                    prismCount, dc, blockBase)));                                                                              \
         else                                                                                                                   \
             LV_TIMED_LAUNCH(ctx, LV_KERNEL_PPLL_RESOLVE, (k_ppll_resolve<LDS, PQ, false><<<GRID, LV_WAVE, BYTES, st>>>(       \
                     U, T, (const uint32_t*)ctx->ppllNodes.ptr, (const uint32_t*)ctx->ppllStart.ptr, out, SCRATCH, numGroups,   \
-                    nullptr, dc)));                                                                                            \
+                    nullptr, dc, nullptr)));                                                                                   \
     } while (0)
         if (ldsBytes <= LV_RESOLVE_LDS_MAX) {
             if (U.ppllSortingMode == 0u) LV_LAUNCH_RESOLVE(true, true, numGroups, ldsBytes, nullptr);
@@ -2761,14 +2847,14 @@ int lv_frame_ppll_resolve_only(lv_ctx* ctx, const uint32_t* nodes, uint64_t numN
     uint32_t* od = (uint32_t*)ctx->outDev.ptr;
     const bool pq = U.ppllSortingMode == 0u;
     if (ldsBytes <= LV_RESOLVE_LDS_MAX) {
-        if (pq) k_ppll_resolve<true, true><<<numGroups, LV_WAVE, ldsBytes, st>>>(U, T, nd, so, od, nullptr, numGroups, nullptr, nullptr);
-        else k_ppll_resolve<true, false><<<numGroups, LV_WAVE, ldsBytes, st>>>(U, T, nd, so, od, nullptr, numGroups, nullptr, nullptr);
+        if (pq) k_ppll_resolve<true, true><<<numGroups, LV_WAVE, ldsBytes, st>>>(U, T, nd, so, od, nullptr, numGroups, nullptr, nullptr, nullptr);
+        else k_ppll_resolve<true, false><<<numGroups, LV_WAVE, ldsBytes, st>>>(U, T, nd, so, od, nullptr, numGroups, nullptr, nullptr, nullptr);
     } else {
         const uint32_t grid = numGroups < LV_RESOLVE_SLAB_GRID ? numGroups : LV_RESOLVE_SLAB_GRID;
         if ((rc = lv_buf_reserve(ctx, ctx->ppllScratch, size_t(grid) * ldsBytes))) return rc;
         uint32_t* sc = (uint32_t*)ctx->ppllScratch.ptr;
-        if (pq) k_ppll_resolve<false, true><<<grid, LV_WAVE, 0, st>>>(U, T, nd, so, od, sc, numGroups, nullptr, nullptr);
-        else k_ppll_resolve<false, false><<<grid, LV_WAVE, 0, st>>>(U, T, nd, so, od, sc, numGroups, nullptr, nullptr);
+        if (pq) k_ppll_resolve<false, true><<<grid, LV_WAVE, 0, st>>>(U, T, nd, so, od, sc, numGroups, nullptr, nullptr, nullptr);
+        else k_ppll_resolve<false, false><<<grid, LV_WAVE, 0, st>>>(U, T, nd, so, od, sc, numGroups, nullptr, nullptr, nullptr);
     }
     LV_HIP(ctx, hipGetLastError());
     LV_HIP(ctx, hipMemcpyAsync(out, ctx->outDev.ptr, size_t(w) * h * 4, hipMemcpyDeviceToHost, st));
