@@ -699,6 +699,8 @@ def main():
 
     if rank == 0:
         kname = wl["kernel"]
+        if head["kernels"] and kname not in head["kernels"] and wl.get("also_kernel") in head["kernels"]:
+            kname = wl["also_kernel"]   # e.g. c4 with --set ppll_prism_rasteriser=lbvh: the all-hits walk is the front end
         ms_launch = head["kernels"].get(kname, {}).get("median", 0.0) if head["kernels"] else 0.0
         st = head["st"]
         result = {
