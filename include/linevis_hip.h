@@ -241,7 +241,8 @@ int lv_set_background(lv_ctx* ctx, const float rgba[4]);
  *   lv_set_lines resets the global frame counter, a change of the denoiser or of the viewport size clears the history,
  *   band data (ribbons; the ray tracer's closest-hit paths: analytic geometry modes, or "Triangle Mesh" / rtao_geometry =
  *   triangle_tubes on the elliptic triangle tubes lv::LineDataFlow tessellates for such data; use_mlat over the same
- *   geometries; the PPLL gather over the analytic tubelets / capsules; not the prebaker):
+ *   geometries; the PPLL gather over the analytic tubelets / capsules; the static prebaker: ray origins on the elliptic cross-
+ *   section, traced against the elliptic triangle tubes passed to lv_set_tube_triangle_mesh, VulkanAmbientOcclusionBaker.glsl:200-257):
  *   use_ribbons (= USE_BANDS: the line points passed to
  *   lv_set_lines come from a data set with ribbon directions and ribbons are on, LineDataFlow.cpp:587-606,2423-2431),
  *   thick_bands, min_band_thickness (0.15, LineData.cpp:54), band_width (0.005, LineRenderer.cpp:442-449,

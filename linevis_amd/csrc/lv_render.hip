@@ -788,7 +788,8 @@ __global__ __launch_bounds__(LV_BLOCK) void k_eaw_pass(const LvUniforms U, const
 __global__ __launch_bounds__(LV_BLOCK) void k_bake_setup(const lv_line_point* __restrict__ linePoints, uint32_t numLinePoints,
                                                          const float* __restrict__ samplingLocations,
                                                          uint32_t numParametrizationVertices, uint32_t numTubeSubdivisions,
-                                                         float lineRadius, float4* __restrict__ gbuf) {
+                                                         float lineRadius, float4* __restrict__ gbuf, uint32_t useBands,
+                                                         float bandRadius, float minBandThickness) {
     const uint32_t slot = blockIdx.x * LV_BLOCK + threadIdx.x;
     if (slot >= numParametrizationVertices * numTubeSubdivisions) return;
     const uint32_t vertex = slot / numTubeSubdivisions, sub = slot % numTubeSubdivisions;
@@ -808,8 +809,12 @@ __global__ __launch_bounds__(LV_BLOCK) void k_bake_setup(const lv_line_point* __
     const f3 binormal = norm3(mix3(binormalLower, binormalUpper));
     float sinAngle, cosAngle;
     lv_sincos2pi(float(sub) / float(numTubeSubdivisions), sinAngle, cosAngle);
-    const f3 surfaceNormal = cosAngle * normal + sinAngle * binormal;
-    const f3 rayOrigin = position + (lineRadius + 1e-6f) * surfaceNormal;
+    f3 surfaceNormal = cosAngle * normal + sinAngle * binormal;
+    f3 rayOrigin = position + (lineRadius + 1e-6f) * surfaceNormal;
+    if (useBands) {   // USE_BANDS, "bands with minimum thickness" (glsl:233-256): elliptic cross-section, pushed out by 1e-3
+        surfaceNormal = norm3(cosAngle * normal + (minBandThickness * sinAngle) * binormal);
+        rayOrigin = position + (bandRadius + 1e-3f) * ((minBandThickness * cosAngle) * normal + sinAngle * binormal);
+    }
     gbuf[3 * size_t(slot) + 0] = make_float4(rayOrigin.x, rayOrigin.y, rayOrigin.z, 0.0f);
     gbuf[3 * size_t(slot) + 1] = make_float4(tangent.x, tangent.y, tangent.z, __uint_as_float(vertex));
     gbuf[3 * size_t(slot) + 2] = make_float4(surfaceNormal.x, surfaceNormal.y, surfaceNormal.z, __uint_as_float(sub));
@@ -2454,10 +2459,8 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
         // band data: the closest-hit paths of the ray tracer (analytic geometry modes, or "Triangle Mesh" on the elliptic triangle
         // tubes the host layer tessellates for the data set); RTAO over the analytic tubelets / capsules or over those triangle
         // tubes (rtao_geometry = triangle_tubes); MLAT over the same geometries; the PPLL gather over the analytic tubelets /
-        // capsules.  The prebaker's lookup is not built for band data.
-        if (ctx->opt.useAmbientOcclusion && ctx->opt.aoPrebaked)
-            return lv_fail(ctx, LV_E_INVALID, "use_ribbons: band data has no prebaked RTAO (its parametrisation follows the "
-                                              "circular tubes)");
+        // capsules.  The static prebaker bakes band data on the elliptic cross-section against the elliptic triangle tubes the caller
+        // passed (VulkanAmbientOcclusionBaker.glsl:200-257) and is looked up with the band's own angle (phiLine of the tubelets).
         if (mode == LV_RENDERING_MODE_PER_PIXEL_LINKED_LIST && (ctx->opt.rtTriangleMesh || ctx->opt.rtLss))
             return lv_fail(ctx, LV_E_INVALID, "use_ribbons: the PPLL gather of band data runs over the analytic tubelets / capsules "
                                               "(geometry_mode \"AABBs\")");
@@ -2970,7 +2973,8 @@ int lv_bake_ambient_occlusion(lv_ctx* ctx, bool async) {
     float* out = (float*)table.ptr;
     k_bake_setup<<<nblocks(slots), LV_BLOCK, 0, st>>>((const lv_line_point*)ctx->triPoints.ptr, ctx->numTriPoints,
                                                       (const float*)ctx->bakeSamplingLocations.ptr, M, N,
-                                                      o.lineWidth * 0.5f, g);
+                                                      o.lineWidth * 0.5f, g, o.useRibbons ? 1u : 0u, o.bandWidth * 0.5f,
+                                                      o.minBandThickness);
     ctx->bakeSlotsHost = uint32_t(slots);
     LV_HIP(ctx, hipMemcpyAsync(&dc->aoCount, &ctx->bakeSlotsHost, 4, hipMemcpyHostToDevice, st));
     for (uint32_t iter = 0; iter < o.bakeIterations; iter++) {

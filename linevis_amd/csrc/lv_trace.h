@@ -1450,6 +1450,10 @@ __device__ __forceinline__ f4 lv_shade_hit_elliptic(const LvSceneDev& S, const L
     const lv_line_point& lp0 = S.points[S.segIdx[2 * seg]];
     const lv_line_point& lp1 = S.points[S.segIdx[2 * seg + 1]];
     const LvEllipticSurface E = lv_elliptic_surface(U, o, d, h.t, lp0, lp1);
+    if (U.aoPrebaked) {   // getAoFactor(fragmentVertexId, phiLine), EllipticTubeRayTracing.glsl:393-395,420-431
+        const float fragmentVertexId = (1.0f - E.t) * float(S.segIdx[2 * seg]) + E.t * float(S.segIdx[2 * seg + 1]);
+        aoTexel = lv_prebaked_ao_lookup(S, U, fragmentVertexId, E.phiLine);
+    }
     LvBandArgs b;
     b.useBand = true;
     b.phi = E.phiLine;

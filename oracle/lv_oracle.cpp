@@ -854,10 +854,14 @@ inline EllipticSurface ellipticSurface(const lvo_params& P, V3 o, V3 d, float hi
     return E;
 }
 inline void shadeHitElliptic(const lvo_scene& sc, const lvo_params& P, const Frame& F, float aoTexel, V3 o, V3 d, const Hit& h,
-                             float hitColor[4], float& payloadHitT, const RasterQuad* rq = nullptr) {
+                             float hitColor[4], float& payloadHitT, const RasterQuad* rq = nullptr, const PrebakedAo* pb = nullptr) {
     const lvo_line_point& lp0 = sc.pts[sc.segIdx[2 * h.seg]];
     const lvo_line_point& lp1 = sc.pts[sc.segIdx[2 * h.seg + 1]];
     const EllipticSurface E = ellipticSurface(P, o, d, h.t, lp0, lp1);
+    if (pb) {   // STATIC_AMBIENT_OCCLUSION_PREBAKING: getAoFactor(fragmentVertexId, phiLine), EllipticTubeRayTracing.glsl:393-395,420-431
+        const float fragmentVertexId = (1.0f - E.t) * float(sc.segIdx[2 * h.seg]) + E.t * float(sc.segIdx[2 * h.seg + 1]);
+        aoTexel = prebakedAoLookup(*pb, fragmentVertexId, E.phiLine);
+    }
     BandArgs b;
     b.useBand = true;
     b.phi = E.phiLine;
@@ -1666,7 +1670,7 @@ static void renderRt(const lvo_scene* sc, const lvo_params* Pp, int useBvh, cons
                     Hit hit;
                     float hc[4]; float payloadHitT; bool hasHit;
                     if (closestHit(*sc, F.radius, capped, useBvh != 0, o, d, tMin, tMax, hit, cnt)) {
-                        if (elliptic) shadeHitElliptic(*sc, P, F, aoTexel, o, d, hit, hc, payloadHitT);
+                        if (elliptic) shadeHitElliptic(*sc, P, F, aoTexel, o, d, hit, hc, payloadHitT, nullptr, pb);
                         else shadeHit(*sc, P, F, aoTexel, o, d, hit, hc, payloadHitT, pb);
                         hasHit = true;
                         cnt.hits++;
@@ -2196,6 +2200,12 @@ void lvo_ao_parametrization(const float* positions, const uint32_t* lineOffsets,
 // (bakeAoTexture, VulkanAmbientOcclusionBaker.cpp:193-262).  Rays are traced against the capsules of sc, or against the
 // triangle tubes when tscOrNull is given (the reference uses the triangle TLAS, cpp:480).  sin/cos of the tube angle
 // use the build's sincos2pi (like the hemisphere sample).  outFactors: numTubeSubdivisions * numSamplingLocations.
+// USE_BANDS in the baker (VulkanAmbientOcclusionBaker.glsl:200-257, "bands with minimum thickness"): ray origins on the elliptic cross
+// section (bandRadius, minBandThickness), pushed out by 1e-3 instead of 1e-6.  Test hook: set before lvo_bake_ao.
+static struct { int use; float bandRadius, minBandThickness; } g_bakeBands = {0, 0.0f, 1.0f};
+void lvo_set_bake_bands(int useBands, float bandRadius, float minBandThickness) {
+    g_bakeBands.use = useBands; g_bakeBands.bandRadius = bandRadius; g_bakeBands.minBandThickness = minBandThickness;
+}
 void lvo_bake_ao(const lvo_scene* sc, const lvo_tri_scene* tscOrNull, float lineWidth, int useCappedTubes, int useBvh,
                  const float* samplingLocations, uint32_t numParametrizationVertices, uint32_t numTubeSubdivisions,
                  uint32_t numAmbientOcclusionSamples, uint32_t numIterations, float ambientOcclusionRadius, int useDistance,
@@ -2225,8 +2235,13 @@ void lvo_bake_ao(const lvo_scene* sc, const lvo_tri_scene* tscOrNull, float line
             for (uint32_t sub = 0; sub < numTubeSubdivisions; sub++) {
                 float sinAngle, cosAngle;
                 sincos2pi(float(sub) / float(numTubeSubdivisions), sinAngle, cosAngle);
-                const V3 surfaceNormal = cosAngle * normal + sinAngle * binormal;
-                const V3 rayOrigin = position + (lineRadius + 1e-6f) * surfaceNormal;
+                V3 surfaceNormal = cosAngle * normal + sinAngle * binormal;
+                V3 rayOrigin = position + (lineRadius + 1e-6f) * surfaceNormal;
+                if (g_bakeBands.use) {
+                    const float thickness = g_bakeBands.minBandThickness;
+                    surfaceNormal = normalize(cosAngle * normal + (thickness * sinAngle) * binormal);
+                    rayOrigin = position + (g_bakeBands.bandRadius + 1e-3f) * ((thickness * cosAngle) * normal + sinAngle * binormal);
+                }
                 const V3 surfaceBitangent = cross(surfaceNormal, tangent);
                 float acc = 0.0f;
                 for (uint32_t rayIdx = 0; rayIdx < numAmbientOcclusionSamples; rayIdx++) {
@@ -2339,7 +2354,7 @@ void lvo_ppll_gather(const lvo_scene* sc, const lvo_params* Pp, int useBvh, cons
             const RasterQuad* rqp = g_rtFragmentColourInPpll ? nullptr : &rq;
             for (const Hit& hit : hl) {
                 float hc[4]; float hitT;
-                if (elliptic) shadeHitElliptic(*sc, P, F, aoTexel, o, d, hit, hc, hitT, rqp);
+                if (elliptic) shadeHitElliptic(*sc, P, F, aoTexel, o, d, hit, hc, hitT, rqp, g_ppllPrebaked.factors ? &g_ppllPrebaked : nullptr);
                 else shadeHit(*sc, P, F, aoTexel, o, d, hit, hc, hitT, g_ppllPrebaked.factors ? &g_ppllPrebaked : nullptr, rqp);
                 cnt.hits++;
                 if (hc[3] < 0.001f) continue;

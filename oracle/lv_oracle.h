@@ -282,6 +282,7 @@ void lvo_render_rt_tri(
 void lvo_ao_parametrization(const float* positions, const uint32_t* lineOffsets, uint32_t nLines,
                             float expectedParamSegmentLength, float* outBlendingWeights, float* outSamplingLocations,
                             uint64_t* outNumParametrizationVertices);
+void lvo_set_bake_bands(int useBands, float bandRadius, float minBandThickness);
 void lvo_bake_ao(const lvo_scene*, const lvo_tri_scene* triSceneOrNull, float lineWidth, int useCappedTubes, int useBvh,
                  const float* samplingLocations, uint32_t numParametrizationVertices, uint32_t numTubeSubdivisions,
                  uint32_t numAmbientOcclusionSamples, uint32_t numIterations, float ambientOcclusionRadius, int useDistance,

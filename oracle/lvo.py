@@ -177,6 +177,7 @@ def lib():
     L.lvo_render_rt_tri.argtypes = [vp, vp, C.POINTER(Params), i32, vp, u32, u32, u32, u32, vp, C.POINTER(Stats)]
     L.lvo_ao_parametrization.argtypes = [vp, vp, u32, f32, vp, vp, u64p]
     L.lvo_bake_ao.argtypes = [vp, vp, f32, i32, i32, vp, u32, u32, u32, u32, f32, i32, vp]
+    L.lvo_set_bake_bands.argtypes = [i32, f32, f32]
     L.lvo_render_rt_prebaked.argtypes = [vp, vp, C.POINTER(Params), i32, vp, vp, u32, u32, u32, u32, u32, u32, u32, vp,
                                          C.POINTER(Stats)]
     L.lvo_generate_abc_flow.argtypes = [vp, i32, i32, i32, f32, f32, f32, f32]
@@ -732,8 +733,10 @@ def ao_parametrization(positions, line_offsets, expected_param_segment_length=0.
 
 
 def bake_ao(scene, tri_scene, line_width, sampling_locations, num_tube_subdivisions=8, num_samples=4, num_iterations=128,
-            radius=0.1, use_distance=True, capped=True, use_bvh=True):
-    """VulkanAmbientOcclusionBaker.Compute iterated: factors [num_sampling_locations, num_tube_subdivisions]."""
+            radius=0.1, use_distance=True, capped=True, use_bvh=True, bands=None):
+    """VulkanAmbientOcclusionBaker.Compute iterated: factors [num_sampling_locations, num_tube_subdivisions].
+    bands = (band_width, min_band_thickness): USE_BANDS ray origins (elliptic cross-section)."""
+    lib().lvo_set_bake_bands(int(bands is not None), float(bands[0]) * 0.5 if bands else 0.0, float(bands[1]) if bands else 1.0)
     sl = np.ascontiguousarray(sampling_locations, dtype=np.float32)
     out = np.zeros((len(sl), num_tube_subdivisions), dtype=np.float32)
     if use_bvh:

@@ -295,3 +295,39 @@ def test_multi_threaded_baking_mode_through_the_plugin(hip_lib):
     assert fired or np.array_equal(first, want)
     assert np.array_equal(r.render_frame(), want)
     assert not r.needs_re_render()
+
+
+@pytest.mark.parametrize("elliptic", [True, False])
+def test_band_data_with_the_prebaker(hip_lib, elliptic):
+    """USE_BANDS in the baker (VulkanAmbientOcclusionBaker.glsl:200-257): ray origins on the elliptic cross-section (band radius, minimum
+    band thickness, pushed out by 1e-3), traced against the elliptic triangle tubes the data set's triangle-mesh accessor gives; the table
+    bit for bit against the oracle, then the ray tracer's frames with the lookup by (fragmentVertexId, band angle) -- the analytic
+    elliptic tubes (phiLine) and the capsules with USE_BANDS shading -- within 2 LSB."""
+    from test_bands import ribbon_scene
+    from test_gpu_elliptic import band_case
+    lw, bwid, mbt, n_sub = 0.02, 0.05, 0.3, 8
+    tr = ribbon_scene()
+    kw = dict(rtao_prebaker_iterations=3, rtao_prebaker_samples_per_frame=6, rtao_prebaker_num_tube_subdivisions=n_sub)
+    case = band_case(width=120, height=90, elliptic=elliptic, tr=tr, line_width=lw, band_width=bwid, min_band_thickness=mbt, **PREBAKE, **kw)
+    mesh = lvo.build_tube_triangle_render_data_ribbons(tr.positions, tr.attributes, tr.line_offsets, tr.ribbon_directions, bwid, mbt, 6)
+    blend, sl = lvo.ao_parametrization(tr.positions, tr.line_offsets, 0.01)
+    ctx = case.hip_context()
+    ctx.set_tube_triangle_mesh(*mesh)
+    ctx.set_ao_parametrization(blend, sl)
+    got = ctx.get_baked_ao(n_sub)
+    sc = case.oracle_scene()
+    ts = lvo.TriScene(*mesh, lw)
+    # (the baker interpolates the line points of the triangle-mesh render data: for the capsule geometry of band data these carry the
+    # ribbon normals, the AABB render data's points do not)
+    bake_sc = lvo.Scene(mesh[2], case.seg, case.tf)
+    ref = lvo.bake_ao(bake_sc, ts, lw, sl, n_sub, 6, 3, use_bvh=True, bands=(bwid, mbt))
+    plain = lvo.bake_ao(bake_sc, ts, lw, sl, n_sub, 6, 3, use_bvh=True)
+    assert np.array_equal(bits(got), bits(ref)) and not np.array_equal(bits(ref), bits(plain))
+    assert 0.3 < float(ref.mean()) < 1.0 and float(ref.min()) < 0.9
+    img = ctx.render(capi.MODE_RAY_TRACER)
+    P = case.oracle_params(sc)
+    P.useAmbientOcclusion = 1
+    want = lvo.render_rt_prebaked(sc, None, P, ref, blend)
+    assert max_lsb_diff(img, want) <= 2
+    ctx.set_option("ambient_occlusion_strength", 0.0)
+    assert not np.array_equal(ctx.render(capi.MODE_RAY_TRACER), img)
