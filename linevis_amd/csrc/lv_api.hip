@@ -379,6 +379,8 @@ int lv_set_camera(lv_ctx* ctx, const float view[16], const float proj[16], float
                   uint32_t w, uint32_t h) {
     if (!ctx) return LV_E_INVALID;
     if (!view || !proj || w == 0 || h == 0) return lv_fail(ctx, LV_E_INVALID, "invalid camera / viewport");
+    // (pixel coordinates travel as 16-bit pairs through the wave-local queues and the PPLL fragment records)
+    if (w > 0xFFFFu || h > 0xFFFFu) return lv_fail(ctx, LV_E_CAPACITY, "viewport %u x %u: at most 65535 pixels per side", w, h);
     memcpy(ctx->view, view, 64);
     memcpy(ctx->proj, proj, 64);
     lv_mat4_inverse(ctx->view, ctx->invView);

@@ -490,6 +490,26 @@ def test_hip_keep_the_nearest_selection_on_runs_longer_than_its_registers(hip_li
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cam", [(0.02, 0.01, 0.03), (0.1, -0.05, 0.12)])
+def test_hip_segment_rasteriser_with_the_camera_inside_the_line_set(hip_lib, cam):
+    """Segments that straddle the camera plane have no bounded screen rectangle (stage A falls back to the whole viewport, the coverage
+    test decides), segments entirely behind it are skipped, near-plane clipping happens in the fragment stage: lists and frame against
+    the oracle and against the all-hits walk front end."""
+    c = small_case(width=128, height=96, n_lines=40, pts_per_line=30, line_width=0.02, transparent=True, camera_pos=cam)
+    ctx = c.hip_context()
+    img = ctx.render(2)
+    sc, P = prism_params(c)
+    pw, ph = c.padded()
+    hn, hs, hcnt = ctx.ppll_buffers(pw * ph, int(P.ppllLinkedListSize))
+    on, os_, ocnt = sc.ppll_gather(P, use_bvh=True)
+    assert hcnt == ocnt and hcnt > 2000
+    assert _walk_order(hn, hs) == _walk_order(on, os_)
+    assert np.abs(img.astype(np.int32) - sc.render_ppll(P, use_bvh=True).astype(np.int32)).max() <= 2
+    ctx.set_option("ppll_prism_rasteriser", "lbvh")
+    assert np.array_equal(ctx.render(2), img)
+
+
+@pytest.mark.gpu
 def test_hip_prism_fill_rule_on_exact_edges(hip_lib):
     """the centre column of the square tube of test_fill_rule...: rays exactly on shared edges, one fragment each, on the device too"""
     n = 9
