@@ -221,8 +221,11 @@ int lv_set_background(lv_ctx* ctx, const float rgba[4]);
  *   LinePassProgrammablePullTubes.glsl:87-224 / LineDataFlow.cpp:1698-1713, back faces culled (LineRasterPass.cpp:85-96), the
  *   fragment shader fed with perspective-correct interpolated position / normal / tangent / attribute; the rasteriser is a
  *   watertight edge-function rasteriser in the space of the pixel's viewing ray (linevis_amd/csrc/lv_prism.h) | "capsule_entry"
- *   -- entry hits of the pixel-centre ray against the analytic capsules (rounds 1-3 of this build; a probe) | "auto" (default:
- *   raster_prism for plain flow lines; capsule_entry for band data and rotating helicity bands),
+ *   -- entry hits of the pixel-centre ray against the analytic capsules / elliptic tubelets (rounds 1-3 of this build; a probe) |
+ *   "auto" (default: raster_prism wherever its fragment stage is built -- plain flow lines and band data, whose prism is the
+ *   elliptic ring of the USE_BANDS vertex stage, LinePassProgrammablePullTubes.glsl:112-116,166-171, radius band_width / 2,
+ *   shaded by the band branch of the raster fragment shader; capsule_entry for the rotating helicity bands and for band data
+ *   with the static prebaker),
  *   ppll_prism_rasteriser (build-owned): front end of raster_prism -- "segments" (default: one lane per line segment over the
  *   screen rectangle of its ring vertices, like the hardware the reference draws with walks primitives, not pixels) | "lbvh"
  *   (the all-hits walk of the viewing rays through the segment LBVH); both decide every (pixel, segment) pair by the same

@@ -227,6 +227,12 @@ struct LvSvgfFeat {
 #define LV_PRISM_MAX_SUBDIV 16
 struct LvPrismDev {
     float c[LV_PRISM_MAX_SUBDIV], s[LV_PRISM_MAX_SUBDIV];
+    // USE_BANDS ("bands with minimum thickness", LinePassProgrammablePullTubes.glsl:112-116,166-171): the ring is the ellipse
+    // localPosition = (thickness cos, sin, 0) with localNormal = (cos, thickness sin, 0) and lineRadius = bandWidth / 2; cp = thickness *
+    // cos feeds the positions, sn = thickness * sin the normals (thickness 1 for plain tubes: cp == c, sn == s bit for bit)
+    float cp[LV_PRISM_MAX_SUBDIV], sn[LV_PRISM_MAX_SUBDIV];
+    float radius, thickness;
+    uint32_t bands;
     float right[3];
     float viewZ[4];
     float nearDist, farDist;

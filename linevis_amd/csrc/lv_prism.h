@@ -120,10 +120,11 @@ __device__ __forceinline__ bool lv_prism_own_box(f3 o, f3 d, f3 p0, f3 p1, float
 // copy of LvPrismDev's table: triangle indices are per-lane values)
 struct LvPrismTri {
     f3 pos[3], dir[3], tan[3];
-    float attr[3], c[3], s[3];
+    float attr[3], c[3], s[3];   // c, s: the POSITION's ring coefficients (cp, s)
     uint32_t id[3], circ[3];
     bool second[3];   // vertex belongs to the segment's second point
 };
+// ringTab: the kernel's LDS copy of LvPrismDev's tables, [c | s | cp | sn]
 __device__ __forceinline__ LvPrismTri lv_prism_tri_setup(const float* ringTab, uint32_t N, const LvPrismPoint pt[2], const uint32_t pi[2],
                                                          float radius, uint32_t tt) {
     uint32_t ring[3], circ[3];
@@ -132,10 +133,10 @@ __device__ __forceinline__ LvPrismTri lv_prism_tri_setup(const float* ringTab, u
 #pragma unroll
     for (int i = 0; i < 3; i++) {
         const LvPrismPoint& p = ring[i] ? pt[1] : pt[0];
-        T.c[i] = ringTab[circ[i]];
+        T.c[i] = ringTab[2 * LV_PRISM_MAX_SUBDIV + circ[i]];
         T.s[i] = ringTab[LV_PRISM_MAX_SUBDIV + circ[i]];
-        T.dir[i] = lv_prism_dir(p, T.c[i], T.s[i]);
-        T.pos[i] = lv_prism_pos(p, T.dir[i], radius);
+        T.dir[i] = lv_prism_dir(p, ringTab[circ[i]], ringTab[3 * LV_PRISM_MAX_SUBDIV + circ[i]]);   // localNormal
+        T.pos[i] = lv_prism_pos(p, lv_prism_dir(p, T.c[i], T.s[i]), radius);                          // localPosition
         T.tan[i] = p.tangent;
         T.attr[i] = p.attr;
         T.id[i] = (ring[i] ? pi[1] : pi[0]) * N + circ[i];
@@ -206,8 +207,8 @@ __device__ __forceinline__ unsigned lv_prism_coverage_pts(const LvPrismDev& R, c
         float cx[NT > 0 ? NT : 1], cy[NT > 0 ? NT : 1], nx[NT > 0 ? NT : 1], ny[NT > 0 ? NT : 1], L[NT > 0 ? NT : 1];
 #pragma unroll
         for (int k = 0; k < NT; k++) {
-            lv_prism_vertex_xy(pj0, R.c[k], R.s[k], radius, cx[k], cy[k]);
-            lv_prism_vertex_xy(pj1, R.c[k], R.s[k], radius, nx[k], ny[k]);
+            lv_prism_vertex_xy(pj0, R.cp[k], R.s[k], radius, cx[k], cy[k]);
+            lv_prism_vertex_xy(pj1, R.cp[k], R.s[k], radius, nx[k], ny[k]);
             L[k] = lv_prism_edge(nx[k], ny[k], cx[k], cy[k]);           // E(n_k, c_k)
         }
 #pragma unroll
@@ -233,10 +234,10 @@ __device__ __forceinline__ unsigned lv_prism_coverage_pts(const LvPrismDev& R, c
         for (uint32_t k = 0; k < N; k++) {
             const uint32_t kn = (k + 1u == N) ? 0u : k + 1u;
             float cxk, cyk, cxn, cyn, nxk, nyk, nxn, nyn;
-            lv_prism_vertex_xy(pj0, R.c[k], R.s[k], radius, cxk, cyk);
-            lv_prism_vertex_xy(pj0, R.c[kn], R.s[kn], radius, cxn, cyn);
-            lv_prism_vertex_xy(pj1, R.c[k], R.s[k], radius, nxk, nyk);
-            lv_prism_vertex_xy(pj1, R.c[kn], R.s[kn], radius, nxn, nyn);
+            lv_prism_vertex_xy(pj0, R.cp[k], R.s[k], radius, cxk, cyk);
+            lv_prism_vertex_xy(pj0, R.cp[kn], R.s[kn], radius, cxn, cyn);
+            lv_prism_vertex_xy(pj1, R.cp[k], R.s[k], radius, nxk, nyk);
+            lv_prism_vertex_xy(pj1, R.cp[kn], R.s[kn], radius, nxn, nyn);
             const float Lk = lv_prism_edge(nxk, nyk, cxk, cyk), Ln = lv_prism_edge(nxn, nyn, cxn, cyn);
             const float D = lv_prism_edge(cxn, cyn, nxk, nyk);
             const float R0 = lv_prism_edge(cxk, cyk, cxn, cyn);

@@ -1025,16 +1025,18 @@ __device__ __forceinline__ uint32_t lv_run_start(const uint32_t* __restrict__ st
 // array, so that every pixel's fragments form one contiguous run in the order the coverage kernel met them.  A fragment the shader
 // discards (alpha < 0.001, :34) or the `kept` rules reject leaves a DEAD entry {0, LV_PPLL_DEAD} that the resolve pass steps over,
 // and is counted in the upper 16 bits of the pixel's count word.  No atomics on the pool, none per kept fragment.
-template <bool STATS>
+template <bool STATS, bool BANDS = false>
 __global__ __launch_bounds__(LV_BLOCK, LV_PRISM_SHADE_MIN_WAVES) void k_ppll_shade_prism(const LvUniforms U, const LvSceneDev S,
                                                                    const uint32_t* __restrict__ records, uint2* __restrict__ frags,
                                                                    const uint32_t* __restrict__ pixelOffset,
                                                                    const uint32_t* __restrict__ blockBase, uint32_t* __restrict__ fragCount,
                                                                    LvDevCounters* dc, uint32_t poolSlots) {
-    __shared__ float s_prismRing[2 * LV_PRISM_MAX_SUBDIV];
-    if (threadIdx.x < LV_PRISM_MAX_SUBDIV) {   // ring table in LDS: the triangle a lane shades is a per-lane index
+    __shared__ float s_prismRing[4 * LV_PRISM_MAX_SUBDIV];
+    if (threadIdx.x < LV_PRISM_MAX_SUBDIV) {   // ring tables [c | s | cp | sn] in LDS: the triangle a lane shades is a per-lane index
         s_prismRing[threadIdx.x] = S.prism.c[threadIdx.x];
         s_prismRing[LV_PRISM_MAX_SUBDIV + threadIdx.x] = S.prism.s[threadIdx.x];
+        s_prismRing[2 * LV_PRISM_MAX_SUBDIV + threadIdx.x] = S.prism.cp[threadIdx.x];
+        s_prismRing[3 * LV_PRISM_MAX_SUBDIV + threadIdx.x] = S.prism.sn[threadIdx.x];
     }
     __syncthreads();
     const uint32_t numSlots = min(dc->fragAlloc, poolSlots);   // the chunk allocator's high-water mark
@@ -1059,7 +1061,7 @@ __global__ __launch_bounds__(LV_BLOCK, LV_PRISM_SHADE_MIN_WAVES) void k_ppll_sha
         const LvRasterQuad rq = lv_make_raster_quad(U, px, py);
         bool kept;
         float depth;
-        const f4 color = lv_shade_prism(S, U, s_prismRing, aoTexel, o, d, tLo, tHi, leaf, tt, rq, U.ppllRasterColour != 0u, depth, kept);
+        const f4 color = lv_shade_prism<BANDS>(S, U, s_prismRing, aoTexel, o, d, tLo, tHi, leaf, tt, rq, U.ppllRasterColour != 0u, depth, kept);
         if (STATS && kept) hits++;
         const uint32_t addr = lv_ppll_addr(px, py, U.ppllPaddedW, U.ppllTileW, U.ppllTileH);
         const size_t dst = size_t(lv_run_start(pixelOffset, blockBase, addr)) + rank;
@@ -1400,7 +1402,7 @@ __global__ __launch_bounds__(LV_BLOCK, LV_PRISM_RASTER_MIN_WAVES) void k_ppll_ra
                 pt[e].binormal = mk3(segLds[9 * e + 6][sl], segLds[9 * e + 7][sl], segLds[9 * e + 8][sl]);
                 pi[e] = __float_as_uint(segLds[18 + e][sl]);
             }
-            mask = lv_prism_coverage_pts<NT>(R, pt, pi, U.radius, o, d);
+            mask = lv_prism_coverage_pts<NT>(R, pt, pi, R.radius, o, d);
             if (requested != 0u) mask = 0u;
             else if (STATS) tests++;
         }
@@ -1493,7 +1495,7 @@ __global__ __launch_bounds__(LV_BLOCK, LV_PRISM_RASTER_MIN_WAVES) void k_ppll_ra
             for (uint32_t k = 0; k < N; k++) {
 #pragma unroll
                 for (int e = 0; e < 2; e++) {
-                    const f3 v = lv_prism_pos(pt[e], lv_prism_dir(pt[e], R.c[k], R.s[k]), U.radius);
+                    const f3 v = lv_prism_pos(pt[e], lv_prism_dir(pt[e], R.cp[k], R.s[k]), R.radius);
                     const float cw = ((mw[0] * v.x + mw[1] * v.y) + mw[2] * v.z) + mw[3];
                     if (cw > wEps) {
                         const float ccx = ((mx[0] * v.x + mx[1] * v.y) + mx[2] * v.z) + mx[3];
@@ -2024,8 +2026,10 @@ static void lv_sincos2pi_host(float xi, float& s, float& c) {
 bool lv_ppll_prism_source(const lv_ctx* ctx) {
     const LvOptions& o = ctx->opt;
     if (o.ppllFragmentSource == 1) return false;
-    const bool plain = !o.useRibbons && !o.helicityBands;
-    return o.ppllFragmentSource == 2 ? true : plain;
+    // auto: the prism wherever its fragment stage is built -- plain tubes and band data (USE_BANDS); not the rotating helicity bands,
+    // not band data with the static prebaker (the raster shaders' NUM_TUBE_SUBDIVISIONS >= 8 && USE_AMBIENT_OCCLUSION && USE_BANDS path)
+    const bool built = !o.helicityBands && !(o.useRibbons && o.useAmbientOcclusion && o.aoPrebaked);
+    return o.ppllFragmentSource == 2 ? true : built;
 }
 // per-frame constants of the rasterised prism (LvPrismDev)
 static void lv_fill_prism(const lv_ctx* ctx, const LvUniforms& U, LvPrismDev& R) {
@@ -2035,6 +2039,11 @@ static void lv_fill_prism(const lv_ctx* ctx, const LvUniforms& U, LvPrismDev& R)
     R.n = n;
     for (uint32_t k = 0; k < LV_PRISM_MAX_SUBDIV; k++) { R.c[k] = 1.0f; R.s[k] = 0.0f; }
     for (uint32_t k = 0; k < n; k++) lv_sincos2pi_host(float(k) / float(n), R.s[k], R.c[k]);
+    // band data: the elliptic ring of the rasterisers' USE_BANDS vertex stage
+    R.bands = U.useBands ? 1u : 0u;
+    R.radius = U.useBands ? U.bandWidth * 0.5f : U.radius;
+    R.thickness = U.useBands ? U.minThickness : 1.0f;
+    for (uint32_t k = 0; k < LV_PRISM_MAX_SUBDIV; k++) { R.cp[k] = R.thickness * R.c[k]; R.sn[k] = R.thickness * R.s[k]; }
     for (int k = 0; k < 3; k++) R.right[k] = U.invView[k];
     R.viewZ[0] = U.view[2]; R.viewZ[1] = U.view[6]; R.viewZ[2] = U.view[10]; R.viewZ[3] = U.view[14];
     R.nearDist = U.nearDist;
@@ -2663,6 +2672,12 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
         // reallocateFragmentBuffer, PerPixelLinkedListLineRenderer.cpp:251-357
         // gather(): fragments of the rasterised programmable-pull prism (the reference's geometry, default) or capsule entry hits
         const bool prismSource = lv_ppll_prism_source(ctx);
+        if (prismSource && (ctx->opt.helicityBands || (ctx->opt.useRibbons && ctx->opt.useAmbientOcclusion && ctx->opt.aoPrebaked)))
+            return lv_fail(ctx, LV_E_INVALID, "ppll_fragment_source = raster_prism: the rotating helicity bands and band data with the "
+                                              "static prebaker have no prism fragment stage (use auto or capsule_entry)");
+        if (prismSource && ctx->opt.useRibbons && ctx->opt.ppllPrismLbvhWalk)
+            return lv_fail(ctx, LV_E_INVALID, "ppll_prism_rasteriser = lbvh: the segment boxes do not enclose the band prism "
+                                              "(band_width / 2); band data uses the segment rasteriser");
         if (prismSource) lv_fill_prism(ctx, U, S.prism);
         const uint32_t numSlices = prismSource ? 1u : LV_PPLL_SLICES; // (the prism's coverage kernel has no depth: one slice)
         // ppll_prism_rasteriser: "segments" (default) = one lane per segment over its screen rectangle, "lbvh" = the all-hits walk of
@@ -2740,6 +2755,11 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
             ctx->ppllScanBlocks = scanBlocks;
             const uint32_t shadeGrid = uint32_t(ctx->numCUs) * LV_PRISM_SHADE_BLOCKS_PER_CU;
 #define LV_LAUNCH_SHADE(ST)                                                                                                     \
+    if (S.prism.bands)                                                                                                          \
+    LV_TIMED_LAUNCH(ctx, LV_KERNEL_PPLL_SHADE, (k_ppll_shade_prism<ST, true><<<shadeGrid, LV_BLOCK, 0, st>>>(                   \
+            U, S, (const uint32_t*)ctx->prismRecords.ptr, (uint2*)ctx->ppllNodes.ptr, (const uint32_t*)ctx->ppllStart.ptr,      \
+            blockBase, (uint32_t*)ctx->ppllCount.ptr, dc, poolSlots)));                                                         \
+    else                                                                                                                        \
     LV_TIMED_LAUNCH(ctx, LV_KERNEL_PPLL_SHADE, (k_ppll_shade_prism<ST><<<shadeGrid, LV_BLOCK, 0, st>>>(                         \
             U, S, (const uint32_t*)ctx->prismRecords.ptr, (uint2*)ctx->ppllNodes.ptr, (const uint32_t*)ctx->ppllStart.ptr,      \
             blockBase, (uint32_t*)ctx->ppllCount.ptr, dc, poolSlots)))

@@ -1375,6 +1375,20 @@ __device__ __forceinline__ f4 lv_shade_hit(const LvSceneDev& S, const LvUniforms
 // LinePassGeometryShaderTubes.glsl:732-1129 on the perspective-correct inputs of triangle tt of the leaf's segment for the pixel's
 // viewing ray (o, d); fwidth(ribbonPosition) (:1079-1087) from the helper invocations of the 2 x 2 quad = the same triangle's
 // attribute planes at the quad partners' rays (LvRasterQuad).
+// USE_BANDS fragment stage (LinePassGeometryShaderTubes.glsl:819-936): the band's halo coordinate at interpolated varyings -- phi with the
+// wrap-around of the last facet (:761-775), linePosition, lineNormal, fragmentTangent; the polar construction of lv_bands_ribbon_of_point
+__device__ __forceinline__ float lv_prism_band_ribbon(const LvPrismDev& R, f3 cam, const LvPrismTri& T, const LvPrismPoint pt[2],
+                                                      const uint32_t pi[2], const LvPrismInputs& I) {
+    float fragmentVertexId, phi;
+    lv_prism_ao_inputs(T, pt, pi, I.b, R.n, fragmentVertexId, phi);
+    const f3 c0 = T.second[0] ? pt[1].centre : pt[0].centre, c1 = T.second[1] ? pt[1].centre : pt[0].centre, c2 = T.second[2] ? pt[1].centre : pt[0].centre;
+    const f3 n0 = T.second[0] ? pt[1].normal : pt[0].normal, n1 = T.second[1] ? pt[1].normal : pt[0].normal, n2 = T.second[2] ? pt[1].normal : pt[0].normal;
+    float sp, cp;
+    lv_sincos_rad(phi, sp, cp);
+    return lv_bands_ribbon_of_point(cam, lv_prism_mix3(I.b, c0, c1, c2), lv_prism_mix3(I.b, n0, n1, n2), I.tan, norm3s(I.tan),
+                                    mk3(R.thickness * cp, sp, 1.0f), R.radius, R.thickness);
+}
+template <bool BANDS = false>
 __device__ __forceinline__ f4 lv_shade_prism(const LvSceneDev& S, const LvUniforms& U, const float* ringTab, float aoTexel, f3 o, f3 d,
                                              float tLo, float tHi, uint32_t leaf, uint32_t tt, const LvRasterQuad& rq, bool rasterApply,
                                              float& payloadHitT, bool& kept) {
@@ -1382,14 +1396,30 @@ __device__ __forceinline__ f4 lv_shade_prism(const LvSceneDev& S, const LvUnifor
     uint32_t pi[2];
     LvPrismPoint pt[2];
     lv_prism_frames(S, leaf, S.segs[2 * size_t(leaf)], S.segs[2 * size_t(leaf) + 1], pt, pi);
-    const LvPrismTri T = lv_prism_tri_setup(ringTab, R.n, pt, pi, U.radius, tt);
+    const LvPrismTri T = lv_prism_tri_setup(ringTab, R.n, pt, pi, R.radius, tt);
     f3 nrm[3];
 #pragma unroll
     for (int i = 0; i < 3; i++) nrm[i] = norm3s(T.dir[i]);   // vertexNormal = normalize(tangentFrameMatrix * localNormal), :177
     const f3 cam = mk3(U.camPos[0], U.camPos[1], U.camPos[2]);
     const LvPrismPlanes pl = lv_prism_planes(R, T, cam, d);   // (o == cam: the pixel's viewing ray starts at the camera)
     const LvPrismInputs I = lv_prism_interpolate(T, nrm, pl, d);
-    kept = lv_prism_accept(R, pt, U.radius, o, d, I.pos, len3(I.pos - o), tLo, tHi);
+    kept = lv_prism_accept(R, pt, R.radius, o, d, I.pos, len3(I.pos - o), tLo, tHi);
+    if (BANDS) {
+        LvBandArgs b;
+        b.useBand = true;
+        float fragmentVertexId;
+        lv_prism_ao_inputs(T, pt, pi, I.b, R.n, fragmentVertexId, b.phi);
+        const f3 c0 = T.second[0] ? pt[1].centre : pt[0].centre, c1 = T.second[1] ? pt[1].centre : pt[0].centre, c2 = T.second[2] ? pt[1].centre : pt[0].centre;
+        const f3 n0 = T.second[0] ? pt[1].normal : pt[0].normal, n1 = T.second[1] ? pt[1].normal : pt[0].normal, n2 = T.second[2] ? pt[1].normal : pt[0].normal;
+        b.linePosition = lv_prism_mix3(I.b, c0, c1, c2);
+        b.lineNormal = lv_prism_mix3(I.b, n0, n1, n2);
+        b.rotation = 0.0f; b.separatorScale = 1.0f;
+        const LvPrismInputs Ix = lv_prism_interpolate(T, nrm, pl, rq.dX), Iy = lv_prism_interpolate(T, nrm, pl, rq.dY);
+        const float f0 = lv_prism_band_ribbon(R, cam, T, pt, pi, I), fx = lv_prism_band_ribbon(R, cam, T, pt, pi, Ix),
+                    fy = lv_prism_band_ribbon(R, cam, T, pt, pi, Iy);
+        b.rasterEpsWhite = rasterApply ? fabsf(fx - f0) + fabsf(fy - f0) : -1.0f;
+        return lv_compute_fragment_color_t<LV_SHADE_BANDS>(S, U, aoTexel, I.pos, I.nrm, I.tan, false, I.attr, payloadHitT, b);
+    }
     if (U.aoPrebaked) {   // getAoFactor(fragmentVertexId, phi) of the static prebaker instead of the screen-space texel
         float fragmentVertexId, phi;
         lv_prism_ao_inputs(T, pt, pi, I.b, R.n, fragmentVertexId, phi);

@@ -2311,7 +2311,7 @@ void lvo_ppll_gather(const lvo_scene* sc, const lvo_params* Pp, int useBvh, cons
     uint64_t rays = 0, nds = 0, prims = 0, hits = 0;
     // ppll_fragment_source = raster_prism: the fragments of the rasterised programmable-pull prism (lv_oracle_prism.h)
     const bool prism = P.ppllFragmentSource == 1u;
-    const PrismRing ring = prismRing(P.tubeNumSubdivisions);
+    const PrismRing ring = prismRingOf(P, F);
 #pragma omp parallel for schedule(dynamic, 1) reduction(+ : rays, nds, prims, hits)
     for (int64_t yy = 0; yy < int64_t(h); yy++) {
         Counters cnt;
@@ -2848,12 +2848,16 @@ int lvo_num_threads(void) {
 
 
 /* ---- a16: fragments of the rasterised programmable-pull prism (lv_oracle_prism.h), test hooks ---- */
+// test hook: the next lvo_prism_ring_vertices calls use the USE_BANDS ring (lineWidth then means the band width)
+static struct { int use; float thickness; } g_ringHookBands = {0, 1.0f};
+void lvo_set_prism_ring_bands(int useBands, float thickness) { g_ringHookBands.use = useBands; g_ringHookBands.thickness = thickness; }
 void lvo_prism_ring_vertices(const lvo_line_point* pts, uint64_t nPts, uint32_t numSubdivisions, float lineWidth, float* outPos,
                              float* outNormal) {
-    const PrismRing R = prismRing(numSubdivisions);
+    const PrismRing R = g_ringHookBands.use ? prismRing(numSubdivisions, lineWidth * 0.5f, true, g_ringHookBands.thickness)
+                                            : prismRing(numSubdivisions, lineWidth * 0.5f);
     for (uint64_t i = 0; i < nPts; i++)
         for (uint32_t k = 0; k < R.n; k++) {
-            const PrismVtx v = prismVertex(pts[i], R.c[k], R.s[k], lineWidth * 0.5f);
+            const PrismVtx v = prismVertex(pts[i], R, k, lineWidth * 0.5f);
             const V3 n = normalizeShade(v.dir);
             float* p = outPos + 3 * (i * R.n + k);
             float* q = outNormal + 3 * (i * R.n + k);
@@ -2868,7 +2872,7 @@ void lvo_prism_fragments(const lvo_scene* sc, const lvo_params* Pp, int useBvh, 
                          float* nrm, float* tan, float* attr, uint32_t* colour, float* rgba) {
     const lvo_params& P = *Pp;
     const Frame F = makeFrame(P);
-    const PrismRing ring = prismRing(P.tubeNumSubdivisions);
+    const PrismRing ring = prismRingOf(P, F);
     g_dev.aoImage = (g_dev.referenceAoLookup && P.useAmbientOcclusion) ? ao : nullptr;
     std::vector<std::vector<PrismFrag>> rows(size_t(w) * h);
 #pragma omp parallel for schedule(dynamic, 1)

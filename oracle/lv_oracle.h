@@ -234,6 +234,7 @@ void lvo_render_ppll(
         uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, uint8_t* outRGBA8, lvo_stats* stats);
 /* a16 test hooks: ring vertices (position, normal; nPts * N * 3 floats each) of the programmable-pull vertex stage, and the
  * per-pixel fragments of the rasterised prism in ascending (segment, triangle) order (lv_oracle_prism.h) */
+void lvo_set_prism_ring_bands(int useBands, float thickness);
 void lvo_prism_ring_vertices(const lvo_line_point* pts, uint64_t nPts, uint32_t numSubdivisions, float lineWidth, float* outPos,
                              float* outNormal);
 void lvo_prism_fragments(const lvo_scene* sc, const lvo_params* P, int useBvh, const float* ao, uint32_t x0, uint32_t y0, uint32_t w,

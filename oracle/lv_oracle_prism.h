@@ -55,23 +55,38 @@ constexpr uint32_t kPrismMaxSubdiv = 16;   // a (ray, segment) test reports its 
 
 // cos / sin of the ring angle circleIdx / N * 2 pi (ProgrammablePull:129-131).  GLSL leaves their precision to the implementation;
 // the build defines them by sincos2pi (the fixed polynomial of the hemisphere sample) of the fraction circleIdx / N of the full turn.
-struct PrismRing { float c[kPrismMaxSubdiv], s[kPrismMaxSubdiv]; uint32_t n; };
-inline PrismRing prismRing(uint32_t N) {
+// USE_BANDS ("bands with minimum thickness", ProgrammablePull:112-116,166-171): localPosition = (thickness cos, sin, 0), localNormal =
+// (cos, thickness sin, 0), lineRadius = bandWidth / 2 -- the ring is an ellipse; cp = thickness * cos feeds the positions, sn =
+// thickness * sin the normals (thickness 1: the products are exact, plain tubes keep their bits).
+struct PrismRing { float c[kPrismMaxSubdiv], s[kPrismMaxSubdiv], cp[kPrismMaxSubdiv], sn[kPrismMaxSubdiv]; uint32_t n; float radius, thickness; bool bands; };
+inline PrismRing prismRing(uint32_t N, float radius = 0.0f, bool bands = false, float thickness = 1.0f) {
     PrismRing R;
     R.n = std::min(std::max(N, 3u), kPrismMaxSubdiv);
-    for (uint32_t k = 0; k < R.n; k++) sincos2pi(float(k) / float(R.n), R.s[k], R.c[k]);
+    R.radius = radius; R.bands = bands; R.thickness = bands ? thickness : 1.0f;
+    for (uint32_t k = 0; k < R.n; k++) {
+        sincos2pi(float(k) / float(R.n), R.s[k], R.c[k]);
+        R.cp[k] = R.thickness * R.c[k];
+        R.sn[k] = R.thickness * R.s[k];
+    }
     return R;
+}
+// ring of a frame: radius and thickness of what the rasterised geometry is (bands: bandWidth / 2, MIN_THICKNESS)
+inline PrismRing prismRingOf(const lvo_params& P, const Frame& F) {
+    const bool bands = P.useBands != 0;
+    return prismRing(P.tubeNumSubdivisions, bands ? P.bandWidth * 0.5f : F.radius, bands, P.minThickness);
 }
 
 // ring vertex of a line point: dir = normal * cos + binormal * sin (the tangent column of the frame meets the 0 of the local
 // position), position = radius * dir + centre; vertexNormal = normalize(dir)
 struct PrismVtx { V3 pos, dir; };
-inline PrismVtx prismVertex(const lvo_line_point& lp, float c, float s, float radius) {
+inline PrismVtx prismVertex(const lvo_line_point& lp, const PrismRing& R, uint32_t k, float radius) {
     const V3 normal = ld3(lp.lineNormal), tangent = ld3(lp.lineTangent), centre = ld3(lp.linePosition);
     const V3 binormal = cross(tangent, normal);
     PrismVtx v;
-    v.dir = v3(fmaf(binormal.x, s, normal.x * c), fmaf(binormal.y, s, normal.y * c), fmaf(binormal.z, s, normal.z * c));
-    v.pos = v3(fmaf(radius, v.dir.x, centre.x), fmaf(radius, v.dir.y, centre.y), fmaf(radius, v.dir.z, centre.z));
+    // localNormal -> dir, localPosition -> pd (identical for plain tubes)
+    v.dir = v3(fmaf(binormal.x, R.sn[k], normal.x * R.c[k]), fmaf(binormal.y, R.sn[k], normal.y * R.c[k]), fmaf(binormal.z, R.sn[k], normal.z * R.c[k]));
+    const V3 pd = v3(fmaf(binormal.x, R.s[k], normal.x * R.cp[k]), fmaf(binormal.y, R.s[k], normal.y * R.cp[k]), fmaf(binormal.z, R.s[k], normal.z * R.cp[k]));
+    v.pos = v3(fmaf(radius, pd.x, centre.x), fmaf(radius, pd.y, centre.y), fmaf(radius, pd.z, centre.z));
     return v;
 }
 
@@ -137,6 +152,7 @@ struct PrismTri {
     uint32_t ring[3], circ[3];
     float lineIdx[3];            // float(linePointIdx - lineStartIndex): interpolationFactorLine (ProgrammablePull:203-206)
     uint32_t lineStart;          // fragmentVertexIdUint (flat: the provoking = first vertex)
+    V3 centre[3], lnrm[3];       // USE_BANDS varyings linePosition / lineNormal (ProgrammablePull:194-197)
 };
 inline PrismTri prismTriSetup(const lvo_scene& sc, const PrismRing& R, float radius, uint32_t seg, uint32_t tt) {
     const uint32_t pi[2] = {sc.segIdx[2 * seg], sc.segIdx[2 * seg + 1]};
@@ -144,7 +160,9 @@ inline PrismTri prismTriSetup(const lvo_scene& sc, const PrismRing& R, float rad
     prismTriangle(tt, R.n, T.ring, T.circ);
     for (int i = 0; i < 3; i++) {
         const lvo_line_point& lp = sc.pts[pi[T.ring[i]]];
-        const PrismVtx v = prismVertex(lp, R.c[T.circ[i]], R.s[T.circ[i]], radius);
+        const PrismVtx v = prismVertex(lp, R, T.circ[i], radius);
+        T.centre[i] = ld3(lp.linePosition);
+        T.lnrm[i] = ld3(lp.lineNormal);
         T.pos[i] = v.pos;
         T.nrm[i] = normalizeShade(v.dir);   // normalize() as v * (1 / length(v)), like the shading code
         T.tan[i] = ld3(lp.lineTangent);
@@ -230,7 +248,7 @@ inline void prismSegmentFragments(const lvo_scene& sc, const lvo_params& P, cons
     float vx[2][kPrismMaxSubdiv], vy[2][kPrismMaxSubdiv];
     for (int r = 0; r < 2; r++) {
         const PrismProj pj = prismPointProj(sc.pts[pi[r]], o, B);
-        for (uint32_t k = 0; k < N; k++) prismVertexXY(pj, R.c[k], R.s[k], F.radius, vx[r][k], vy[r][k]);
+        for (uint32_t k = 0; k < N; k++) prismVertexXY(pj, R.cp[k], R.s[k], R.radius, vx[r][k], vy[r][k]);
     }
     for (uint32_t tt = 0; tt < 2u * N; tt++) {
         uint32_t ring[3], circ[3], id[3];
@@ -238,7 +256,7 @@ inline void prismSegmentFragments(const lvo_scene& sc, const lvo_params& P, cons
         float x[3], y[3], e[3];
         for (int i = 0; i < 3; i++) { x[i] = vx[ring[i]][circ[i]]; y[i] = vy[ring[i]][circ[i]]; id[i] = pi[ring[i]] * N + circ[i]; }
         if (!prismCoverage(x, y, id, e)) continue;
-        const PrismTri T = prismTriSetup(sc, R, F.radius, seg, tt);
+        const PrismTri T = prismTriSetup(sc, R, R.radius, seg, tt);
         PrismFrag f;
         f.seg = seg; f.tri = tt; f.d = d;
         prismRayWeights(prismPlanes(F, T, o, d), d, f.b);
@@ -248,7 +266,7 @@ inline void prismSegmentFragments(const lvo_scene& sc, const lvo_params& P, cons
         f.attr = (f.b[0] * T.attr[0] + f.b[1] * T.attr[1]) + f.b[2] * T.attr[2];
         f.depth = length(f.pos - F.cameraPosition);
         if (!(f.depth >= tLo && f.depth < tHi)) continue;
-        if (!prismOwnBox(o, d, ld3(sc.pts[pi[0]].linePosition), ld3(sc.pts[pi[1]].linePosition), F.radius, f.depth)) continue;
+        if (!prismOwnBox(o, d, ld3(sc.pts[pi[0]].linePosition), ld3(sc.pts[pi[1]].linePosition), R.radius, f.depth)) continue;
         const V4 s4 = mulM4(P.view, V4{f.pos.x, f.pos.y, f.pos.z, 1.0f});
         if (!(-s4.z >= P.nearDist && -s4.z <= P.farDist)) continue;
         out.push_back(f);
@@ -288,7 +306,7 @@ inline void prismPixelFragments(const lvo_scene& sc, const lvo_params& P, const 
     out.clear();
     const PrismBasis B = prismBasis(F, d);
     const float tMin = 0.0001f, tMax = 1000.0f;   // the gather's ray interval (depth clipping is the near / far test above)
-    prismCandidates(sc, useBvh, o, d, tMin, tMax, F.radius / length(d), cand, cnt);
+    prismCandidates(sc, useBvh, o, d, tMin, tMax, R.radius / length(d), cand, cnt);
     for (uint32_t seg : cand) {
         cnt.prims++;
         prismSegmentFragments(sc, P, F, R, o, d, B, seg, tMin, nextafterf(tMax, INFINITY), out);
@@ -317,8 +335,40 @@ inline void prismAoInputs(const PrismTri& T, const float b[3], uint32_t N, float
     }
 }
 
+// USE_BANDS fragment stage (LinePassGeometryShaderTubes.glsl:819-936): the halo coordinate of the band at the interpolated varyings
+// (phi with the wrap-around of the last facet :761-775, linePosition, lineNormal, fragmentTangent) -- the same polar construction as
+// RayHitCommon's (bandsRibbonPosition)
+inline float prismBandRibbon(const lvo_params& P, const Frame& F, const PrismRing& R, const PrismTri& T, const float b[3]) {
+    float fragmentVertexId, phi;
+    prismAoInputs(T, b, R.n, fragmentVertexId, phi);
+    const V3 linePosition = prismMix3(b, T.centre[0], T.centre[1], T.centre[2]);
+    const V3 lineNormal = prismMix3(b, T.lnrm[0], T.lnrm[1], T.lnrm[2]);
+    const V3 fragmentTangent = prismMix3(b, T.tan[0], T.tan[1], T.tan[2]);
+    return bandsRibbonPosition(F.cameraPosition, linePosition, lineNormal, fragmentTangent, normalizeShade(fragmentTangent), phi, R.radius,
+                               R.thickness);
+}
 inline void prismShade(const lvo_scene& sc, const lvo_params& P, const Frame& F, const PrismRing& R, float aoTexel, const PrismFrag& f,
                        const RasterQuad* rq, float hitColor[4], float& payloadHitT, const PrebakedAo* pb = nullptr) {
+    if (R.bands) {
+        const PrismTri T = prismTriSetup(sc, R, R.radius, f.seg, f.tri);
+        BandArgs rb;
+        rb.shadeBands = true; rb.useBand = true;
+        float fragmentVertexId;
+        prismAoInputs(T, f.b, R.n, fragmentVertexId, rb.phi);
+        rb.linePosition = prismMix3(f.b, T.centre[0], T.centre[1], T.centre[2]);
+        rb.lineNormal = prismMix3(f.b, T.lnrm[0], T.lnrm[1], T.lnrm[2]);
+        rb.rasterEpsWhite = -1.0f;
+        if (rq) {
+            const PrismPlanes pl = prismPlanes(F, T, F.cameraPosition, f.d);
+            float bx[3], by[3];
+            prismRayWeights(pl, rq->dX, bx);
+            prismRayWeights(pl, rq->dY, by);
+            const float f0 = prismBandRibbon(P, F, R, T, f.b), fx = prismBandRibbon(P, F, R, T, bx), fy = prismBandRibbon(P, F, R, T, by);
+            rb.rasterEpsWhite = fabsf(fx - f0) + fabsf(fy - f0);
+        }
+        computeFragmentColor(sc, P, F, aoTexel, f.pos, f.nrm, f.tan, false, f.attr, hitColor, payloadHitT, &rb);
+        return;
+    }
     if (pb) {
         const PrismTri T = prismTriSetup(sc, R, F.radius, f.seg, f.tri);
         float fragmentVertexId, phi;

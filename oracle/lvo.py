@@ -178,6 +178,7 @@ def lib():
     L.lvo_ao_parametrization.argtypes = [vp, vp, u32, f32, vp, vp, u64p]
     L.lvo_bake_ao.argtypes = [vp, vp, f32, i32, i32, vp, u32, u32, u32, u32, f32, i32, vp]
     L.lvo_set_bake_bands.argtypes = [i32, f32, f32]
+    L.lvo_set_prism_ring_bands.argtypes = [i32, f32]
     L.lvo_render_rt_prebaked.argtypes = [vp, vp, C.POINTER(Params), i32, vp, vp, u32, u32, u32, u32, u32, u32, u32, vp,
                                          C.POINTER(Stats)]
     L.lvo_generate_abc_flow.argtypes = [vp, i32, i32, i32, f32, f32, f32, f32]
@@ -762,8 +763,10 @@ def render_rt_prebaked(scene, tri_scene, P, factors, blending_weights, tile=None
     return out
 
 
-def prism_ring_vertices(points, num_subdivisions, line_width):
-    """Ring vertices of the programmable-pull vertex stage: (positions, normals), each (len(points), N, 3)."""
+def prism_ring_vertices(points, num_subdivisions, line_width, band_thickness=None):
+    """Ring vertices of the programmable-pull vertex stage: (positions, normals), each (len(points), N, 3).
+    band_thickness: the USE_BANDS ring (line_width = the band width)."""
+    lib().lvo_set_prism_ring_bands(int(band_thickness is not None), float(band_thickness or 1.0))
     pts = np.ascontiguousarray(points, dtype=LINE_POINT_DTYPE)
     n = min(max(int(num_subdivisions), 3), 16)
     pos = np.zeros((len(pts), n, 3), dtype=np.float32)

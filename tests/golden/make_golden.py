@@ -395,6 +395,8 @@ def round2b_case(kind):
         c.tf = tfm.standard_transparent()
         if kind == "mlat_elliptic":
             c.settings.update(use_mlat=True, mlat_num_nodes=4)
+        else:   # the fixture holds the entry hits of the analytic tubelets (round 2); since round 4 auto = the rasterised band prism
+            c.settings["ppll_fragment_source"] = "capsule_entry"
         return c
     # rotating helicity bands: capsules ("helicity") or the triangle tubes ("helicity_tri", mesh returned too)
     tr = scenes.normalize(scenes.helix_bundle(n_lines=4, points_per_line=50, seed=4, turns=2.0))

@@ -236,7 +236,8 @@ def test_elliptic_all_hits_consumers_agree_with_the_closest_hit_loop():
     """The all-hits consumers of the oracle on band data (PPLL gather + resolve, MLAT with enough nodes) against its transparency
     loop of closest hits: three independent walks over the same tubelets -- brute force and tree -- give the same picture."""
     tr = ribbon_scene()
-    s = dict(use_ribbons=True, band_width=0.05, min_band_thickness=0.3, use_analytic_elliptic_tubes=True)
+    s = dict(use_ribbons=True, band_width=0.05, min_band_thickness=0.3, use_analytic_elliptic_tubes=True,
+             ppll_fragment_source="capsule_entry")   # (the same tubelets in all three walks; auto = the rasterised band prism)
     pts, seg, _ = lvo.build_tube_aabb_render_data_ribbons(tr.positions, tr.attributes, tr.line_offsets, 0.05, tr.ribbon_directions)
     c = Case(pts, seg, tfm.standard_transparent(), 120, 90, 0.02, **s)
     sc = c.oracle_scene()

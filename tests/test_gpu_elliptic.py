@@ -168,7 +168,7 @@ def test_ppll_of_band_data_matches_the_oracle(hip_lib, kw):
     """PPLL of band data: the fragments are the entry hits of the elliptic tubelets (or of the capsules) shaded with USE_BANDS -- the
     ray-entry form of the elliptic tubes the reference's rasterisers draw in the ribbon primitive mode.  Per pixel the multiset of
     (colour, depth) fragments equals the oracle's bit for bit; the resolved frame within 2 LSB."""
-    c = band_case(width=100, height=70, transparent=True, **kw)
+    c = band_case(width=100, height=70, transparent=True, ppll_fragment_source="capsule_entry", **kw)   # (auto = the rasterised prism)
     ctx = c.hip_context()
     img = ctx.render(2)
     ref, _ = c.oracle_render(2)
@@ -184,7 +184,7 @@ def test_ppll_of_band_data_matches_the_oracle(hip_lib, kw):
     on2, os2, ocnt2 = sc.ppll_gather(P, ao=ao, use_bvh=True)       # own-box rule: the tree finds what brute force finds
     assert ocnt2 == ocnt and _fragment_lists(on2, os2) == _fragment_lists(on, os_)
     if kw.get("elliptic", True):                                   # opaque tubelets (coverage 1): the front fragment is the ray
-        opaque = band_case(width=100, height=70, **kw)             # tracer's hit
+        opaque = band_case(width=100, height=70, ppll_fragment_source="capsule_entry", **kw)             # tracer's hit
         pctx = opaque.hip_context()
         pctx.set_option("ppll_fragment_colour", "ray_tracer")      # the ray tracer's fragment colour (the gather's own is the raster shader's)
         a = pctx.render(2)
@@ -240,8 +240,9 @@ def test_ppll_plugin_draws_band_data_as_elliptic_tubes(hip_lib):
     r.set_new_settings(settings)
     frame = r.render_frame()
     pts, seg, _ = flow.tube_aabb_render_data_elliptic(0.05)
+    # (tube_num_subdivisions: band data raises the data set's 6 to 8, LineDataFlow.cpp:482-484 -- the rasterised prism has that many sides)
     c = Case(pts, seg, tfm.standard_transparent(), 96, 64, 0.02, use_ribbons=True, use_analytic_elliptic_tubes=True,
-             band_width=0.05, min_band_thickness=0.3, use_capped_tubes=False)
+             band_width=0.05, min_band_thickness=0.3, use_capped_tubes=False, tube_num_subdivisions=8)
     ctx = c.hip_context()
     lo, hi = flow.attribute_range()
     ctx.set_transfer_function(c.tf, lo, hi)

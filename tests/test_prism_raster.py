@@ -571,3 +571,81 @@ def test_full_size_config4_prism_vs_capsule_probe(hip_lib):
     os.makedirs(out, exist_ok=True)
     json.dump(rep, open(os.path.join(out, "deviations_r04.json"), "w"), indent=1)
     print(rep)
+
+
+# ---------------------------------------------------------------- band data (USE_BANDS) on the rasterised prism
+def _band_prism_case(width=110, height=80, **kw):
+    from test_gpu_elliptic import band_case
+    return band_case(width=width, height=height, transparent=True, **kw)
+
+
+def test_band_ring_vertices_lie_on_the_ellipse():
+    """USE_BANDS vertex stage (LinePassProgrammablePullTubes.glsl:112-116,166-171): localPosition = (thickness cos, sin, 0), radius =
+    band width / 2 -> the ring vertices lie on the ellipse with semi-axes r * thickness (line normal) and r (binormal) around their
+    line point; vertexNormal = normalize(cos n + thickness sin b); thickness 1 gives the plain ring bit for bit."""
+    c = _band_prism_case()
+    bw, th, N = 0.05, 0.3, 8
+    pos, nrm = lvo.prism_ring_vertices(c.points, N, bw, band_thickness=th)
+    p = c.points
+    n, t = p["lineNormal"].astype(np.float64), p["lineTangent"].astype(np.float64)
+    b = np.cross(t, n)
+    d = pos.astype(np.float64) - p["linePosition"].astype(np.float64)[:, None, :]
+    r = bw / 2
+    un, ub = (d * n[:, None, :]).sum(2) / (r * th), (d * b[:, None, :]).sum(2) / r
+    assert np.abs(un ** 2 + ub ** 2 - 1).max() < 1e-5 and np.abs((d * t[:, None, :]).sum(2)).max() < 1e-6
+    ang = 2 * np.pi * np.arange(N) / N
+    want_n = np.cos(ang)[None, :, None] * n[:, None, :] + th * np.sin(ang)[None, :, None] * b[:, None, :]
+    want_n /= np.linalg.norm(want_n, axis=2, keepdims=True)
+    assert np.abs(nrm - want_n).max() < 2e-6
+    p1, n1 = lvo.prism_ring_vertices(c.points, N, bw, band_thickness=1.0)
+    p0, n0 = lvo.prism_ring_vertices(c.points, N, bw)
+    assert np.array_equal(p1.view(np.uint32), p0.view(np.uint32)) and np.array_equal(n1.view(np.uint32), n0.view(np.uint32))
+
+
+def test_band_prism_frame_lies_inside_the_analytic_elliptic_tubes():
+    """The rasterised band prism is inscribed in the elliptic tube the ray tracer intersects analytically: its coverage is a subset of
+    the probe's (capsule_entry over the tubelets) up to silhouette pixels, and the two frames are close where both cover."""
+    c = _band_prism_case()
+    sc = c.oracle_scene()
+    P = c.oracle_params(sc)
+    assert P.ppllFragmentSource == 1 and P.useBands == 1
+    a = sc.render_ppll(P)
+    c.settings["ppll_fragment_source"] = "capsule_entry"
+    P0 = c.oracle_params(sc)
+    b = sc.render_ppll(P0)
+    bg = a[0, 0]
+    cov_a, cov_b = (a != bg).any(axis=2), (b != bg).any(axis=2)
+    assert cov_a.sum() > 1000 and (cov_a & ~cov_b).sum() < 0.01 * cov_a.sum()
+    assert cov_a.sum() > 0.8 * cov_b.sum()
+    both = cov_a & cov_b
+    assert np.abs(a.astype(np.int32) - b.astype(np.int32))[both].mean() < 12.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [dict(), dict(elliptic=False), dict(thick_bands=False), dict(tube_num_subdivisions=8, use_halos=False),
+                                dict(min_band_thickness=1.0), dict(ppll_fragment_colour="ray_tracer")])
+def test_hip_band_data_on_the_rasterised_prism(hip_lib, kw):
+    """USE_BANDS through the segment rasteriser and k_ppll_shade_prism<BANDS>: per-pixel lists against the oracle bit for bit, frame
+    <= 2 LSB (0 expected), tiles reproduce the frame; the walk front end refuses band data (its boxes are the line width's)."""
+    c = _band_prism_case(**kw)
+    ctx = c.hip_context()
+    img = ctx.render(2)
+    sc = c.oracle_scene()
+    P = c.oracle_params(sc)
+    assert P.ppllFragmentSource == 1 and P.useBands == 1
+    if kw.get("ppll_fragment_colour") == "ray_tracer":
+        with lvo.ppll_ray_tracer_fragment_colour():
+            on, os_, ocnt = sc.ppll_gather(P)
+            ref = sc.render_ppll(P)
+    else:
+        on, os_, ocnt = sc.ppll_gather(P)
+        ref = sc.render_ppll(P)
+    pw, ph = c.padded()
+    hn, hs, hcnt = ctx.ppll_buffers(pw * ph, int(P.ppllLinkedListSize))
+    assert hcnt == ocnt and hcnt > 1000
+    assert _walk_order(hn, hs) == _walk_order(on, os_)
+    assert np.abs(img.astype(np.int32) - ref.astype(np.int32)).max() <= 2
+    assert np.array_equal(ctx.render(2, tile=(20, 10, 50, 40)), img[10:50, 20:70])
+    ctx.set_option("ppll_prism_rasteriser", "lbvh")
+    with pytest.raises(Exception):
+        ctx.render(2)
