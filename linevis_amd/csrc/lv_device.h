@@ -247,6 +247,7 @@ struct LvSceneDev {
     const uint32_t* leafSeg;    // leaf position -> original segment index
     const uint32_t* segToLeaf;  // original segment index -> leaf position
     const lv_line_point* points;// 48-B point records, input order
+    uint32_t numPoints;         // entries of `points`
     const uint32_t* segIdx;     // 2 point indices per original segment
     const float4* tf;           // transfer function texels
     const float* depthMinMax;   // {minDepth, maxDepth}, produced on device by the depth-range kernels

@@ -1025,7 +1025,7 @@ __device__ __forceinline__ uint32_t lv_run_start(const uint32_t* __restrict__ st
 // array, so that every pixel's fragments form one contiguous run in the order the coverage kernel met them.  A fragment the shader
 // discards (alpha < 0.001, :34) or the `kept` rules reject leaves a DEAD entry {0, LV_PPLL_DEAD} that the resolve pass steps over,
 // and is counted in the upper 16 bits of the pixel's count word.  No atomics on the pool, none per kept fragment.
-template <bool STATS, bool BANDS = false>
+template <bool STATS, int SHADE = LV_SHADE_PLAIN>
 __global__ __launch_bounds__(LV_BLOCK, LV_PRISM_SHADE_MIN_WAVES) void k_ppll_shade_prism(const LvUniforms U, const LvSceneDev S,
                                                                    const uint32_t* __restrict__ records, uint2* __restrict__ frags,
                                                                    const uint32_t* __restrict__ pixelOffset,
@@ -1061,7 +1061,7 @@ __global__ __launch_bounds__(LV_BLOCK, LV_PRISM_SHADE_MIN_WAVES) void k_ppll_sha
         const LvRasterQuad rq = lv_make_raster_quad(U, px, py);
         bool kept;
         float depth;
-        const f4 color = lv_shade_prism<BANDS>(S, U, s_prismRing, aoTexel, o, d, tLo, tHi, leaf, tt, rq, U.ppllRasterColour != 0u, depth, kept);
+        const f4 color = lv_shade_prism<SHADE>(S, U, s_prismRing, aoTexel, o, d, tLo, tHi, leaf, tt, rq, U.ppllRasterColour != 0u, depth, kept);
         if (STATS && kept) hits++;
         const uint32_t addr = lv_ppll_addr(px, py, U.ppllPaddedW, U.ppllTileW, U.ppllTileH);
         const size_t dst = size_t(lv_run_start(pixelOffset, blockBase, addr)) + rank;
@@ -1965,6 +1965,7 @@ LvSceneDev sceneDev(const lv_ctx* ctx) {
     S.leafSeg = (const uint32_t*)ctx->leafSeg.ptr;
     S.segToLeaf = (const uint32_t*)ctx->segToLeaf.ptr;
     S.points = (const lv_line_point*)ctx->points.ptr;
+    S.numPoints = ctx->numPoints;
     S.segIdx = (const uint32_t*)ctx->segIdx.ptr;
     S.tf = (const float4*)ctx->tf.ptr;
     S.depthMinMax = (const float*)ctx->depthMinMax.ptr;
@@ -2026,9 +2027,9 @@ static void lv_sincos2pi_host(float xi, float& s, float& c) {
 bool lv_ppll_prism_source(const lv_ctx* ctx) {
     const LvOptions& o = ctx->opt;
     if (o.ppllFragmentSource == 1) return false;
-    // auto: the prism wherever its fragment stage is built -- plain tubes and band data (USE_BANDS); not the rotating helicity bands,
-    // not band data with the static prebaker (the raster shaders' NUM_TUBE_SUBDIVISIONS >= 8 && USE_AMBIENT_OCCLUSION && USE_BANDS path)
-    const bool built = !o.helicityBands && !(o.useRibbons && o.useAmbientOcclusion && o.aoPrebaked);
+    // auto: the prism wherever its fragment stage is built -- plain tubes, band data (USE_BANDS), rotating helicity bands; not band
+    // data with helicity bands or with the static prebaker (the raster shaders' NUM_TUBE_SUBDIVISIONS >= 8 && USE_AMBIENT_OCCLUSION && USE_BANDS path)
+    const bool built = !(o.helicityBands && o.useRibbons) && !(o.useRibbons && o.useAmbientOcclusion && o.aoPrebaked);
     return o.ppllFragmentSource == 2 ? true : built;
 }
 // per-frame constants of the rasterised prism (LvPrismDev)
@@ -2672,9 +2673,9 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
         // reallocateFragmentBuffer, PerPixelLinkedListLineRenderer.cpp:251-357
         // gather(): fragments of the rasterised programmable-pull prism (the reference's geometry, default) or capsule entry hits
         const bool prismSource = lv_ppll_prism_source(ctx);
-        if (prismSource && (ctx->opt.helicityBands || (ctx->opt.useRibbons && ctx->opt.useAmbientOcclusion && ctx->opt.aoPrebaked)))
-            return lv_fail(ctx, LV_E_INVALID, "ppll_fragment_source = raster_prism: the rotating helicity bands and band data with the "
-                                              "static prebaker have no prism fragment stage (use auto or capsule_entry)");
+        if (prismSource && ctx->opt.useRibbons && (ctx->opt.helicityBands || (ctx->opt.useAmbientOcclusion && ctx->opt.aoPrebaked)))
+            return lv_fail(ctx, LV_E_INVALID, "ppll_fragment_source = raster_prism: band data with rotating helicity bands or with the "
+                                              "static prebaker has no prism fragment stage (use auto or capsule_entry)");
         if (prismSource && ctx->opt.useRibbons && ctx->opt.ppllPrismLbvhWalk)
             return lv_fail(ctx, LV_E_INVALID, "ppll_prism_rasteriser = lbvh: the segment boxes do not enclose the band prism "
                                               "(band_width / 2); band data uses the segment rasteriser");
@@ -2756,7 +2757,11 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
             const uint32_t shadeGrid = uint32_t(ctx->numCUs) * LV_PRISM_SHADE_BLOCKS_PER_CU;
 #define LV_LAUNCH_SHADE(ST)                                                                                                     \
     if (S.prism.bands)                                                                                                          \
-    LV_TIMED_LAUNCH(ctx, LV_KERNEL_PPLL_SHADE, (k_ppll_shade_prism<ST, true><<<shadeGrid, LV_BLOCK, 0, st>>>(                   \
+    LV_TIMED_LAUNCH(ctx, LV_KERNEL_PPLL_SHADE, (k_ppll_shade_prism<ST, LV_SHADE_BANDS><<<shadeGrid, LV_BLOCK, 0, st>>>(         \
+            U, S, (const uint32_t*)ctx->prismRecords.ptr, (uint2*)ctx->ppllNodes.ptr, (const uint32_t*)ctx->ppllStart.ptr,      \
+            blockBase, (uint32_t*)ctx->ppllCount.ptr, dc, poolSlots)));                                                         \
+    else if (U.useHelicityBands)                                                                                                \
+    LV_TIMED_LAUNCH(ctx, LV_KERNEL_PPLL_SHADE, (k_ppll_shade_prism<ST, LV_SHADE_HELICITY><<<shadeGrid, LV_BLOCK, 0, st>>>(      \
             U, S, (const uint32_t*)ctx->prismRecords.ptr, (uint2*)ctx->ppllNodes.ptr, (const uint32_t*)ctx->ppllStart.ptr,      \
             blockBase, (uint32_t*)ctx->ppllCount.ptr, dc, poolSlots)));                                                         \
     else                                                                                                                        \

@@ -1388,7 +1388,7 @@ __device__ __forceinline__ float lv_prism_band_ribbon(const LvPrismDev& R, f3 ca
     return lv_bands_ribbon_of_point(cam, lv_prism_mix3(I.b, c0, c1, c2), lv_prism_mix3(I.b, n0, n1, n2), I.tan, norm3s(I.tan),
                                     mk3(R.thickness * cp, sp, 1.0f), R.radius, R.thickness);
 }
-template <bool BANDS = false>
+template <int SHADE = LV_SHADE_PLAIN>
 __device__ __forceinline__ f4 lv_shade_prism(const LvSceneDev& S, const LvUniforms& U, const float* ringTab, float aoTexel, f3 o, f3 d,
                                              float tLo, float tHi, uint32_t leaf, uint32_t tt, const LvRasterQuad& rq, bool rasterApply,
                                              float& payloadHitT, bool& kept) {
@@ -1404,7 +1404,7 @@ __device__ __forceinline__ f4 lv_shade_prism(const LvSceneDev& S, const LvUnifor
     const LvPrismPlanes pl = lv_prism_planes(R, T, cam, d);   // (o == cam: the pixel's viewing ray starts at the camera)
     const LvPrismInputs I = lv_prism_interpolate(T, nrm, pl, d);
     kept = lv_prism_accept(R, pt, R.radius, o, d, I.pos, len3(I.pos - o), tLo, tHi);
-    if (BANDS) {
+    if (SHADE == LV_SHADE_BANDS) {
         LvBandArgs b;
         b.useBand = true;
         float fragmentVertexId;
@@ -1433,6 +1433,30 @@ __device__ __forceinline__ f4 lv_shade_prism(const LvSceneDev& S, const LvUnifor
     none.useBand = false; none.phi = 0.0f; none.linePosition = mk3(0.0f, 0.0f, 0.0f); none.lineNormal = mk3(0.0f, 0.0f, 0.0f);
     none.rotation = 0.0f; none.separatorScale = 1.0f;
     none.rasterEpsWhite = rasterApply ? fabsf(fx - f0) + fabsf(fy - f0) : -1.0f;
+    if (SHADE == LV_SHADE_HELICITY) {
+        // USE_ROTATING_HELICITY_BANDS in the raster shaders: fragmentRotation = lineRotation * helicityRotationFactor per vertex
+        // (LinePassProgrammablePullTubes.glsl:212-214), interpolated; phi as for the AO lookup; UNIFORM_HELICITY_BAND_WIDTH
+        // (LinePassGeometryShaderTubes.glsl:1017-1034): the two line points around floor(fragmentVertexId), zeros past the buffer
+        float fragmentVertexId;
+        lv_prism_ao_inputs(T, pt, pi, I.b, R.n, fragmentVertexId, none.phi);
+        const float fr = U.helicityRotationFactor;
+        const float r0 = S.points[pi[0]].lineRotation * fr, r1 = S.points[pi[1]].lineRotation * fr;
+        const float rot[3] = {T.second[0] ? r1 : r0, T.second[1] ? r1 : r0, T.second[2] ? r1 : r0};
+        none.rotation = (I.b[0] * rot[0] + I.b[1] * rot[1]) + I.b[2] * rot[2];
+        if (U.uniformHelicityBandWidth) {
+            const uint32_t i0 = uint32_t(floorf(fragmentVertexId)), i1 = i0 + 1u;
+            f3 p0 = mk3(0.0f, 0.0f, 0.0f), p1 = mk3(0.0f, 0.0f, 0.0f);
+            float q0 = 0.0f, q1 = 0.0f;
+            if (i0 < S.numPoints) { const lv_line_point& a = S.points[i0]; p0 = mk3(a.linePosition[0], a.linePosition[1], a.linePosition[2]); q0 = a.lineRotation; }
+            if (i1 < S.numPoints) { const lv_line_point& a = S.points[i1]; p1 = mk3(a.linePosition[0], a.linePosition[1], a.linePosition[2]); q1 = a.lineRotation; }
+            const float rotDx = len3(p1 - p0);
+            const float rotDy = (q1 - q0) * fr;
+            float sn, cs;
+            lv_sincos_rad(lv_atan2_det(rotDy * 0.5f * U.lineWidth, rotDx), sn, cs);
+            none.separatorScale = cs;
+        }
+        return lv_compute_fragment_color_t<LV_SHADE_HELICITY>(S, U, aoTexel, I.pos, I.nrm, I.tan, false, I.attr, payloadHitT, none);
+    }
     return lv_compute_fragment_color_t<LV_SHADE_PLAIN>(S, U, aoTexel, I.pos, I.nrm, I.tan, false, I.attr, payloadHitT, none);
 }
 

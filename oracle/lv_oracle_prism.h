@@ -386,5 +386,35 @@ inline void prismShade(const lvo_scene& sc, const lvo_params& P, const Frame& F,
         const float fy = prismRibbonOfRay(F, T, pl, rq->dY);
         rb.rasterEpsWhite = fabsf(fx - f0) + fabsf(fy - f0);
     }
+    if (P.useHelicityBands) {
+        // USE_ROTATING_HELICITY_BANDS in the raster shaders: vertex stage fragmentRotation = lineRotation * helicityRotationFactor
+        // (ProgrammablePull:212-214), interpolated; phi as for the AO lookup (:179-190, fragment stage :761-775); UNIFORM_HELICITY_BAND_WIDTH
+        // (LinePassGeometryShaderTubes.glsl:1017-1034): the two line points around floor(fragmentVertexId) (reads past the buffer give
+        // zeros: robust buffer access)
+        const PrismTri T = prismTriSetup(sc, R, F.radius, f.seg, f.tri);
+        const uint32_t pi[2] = {sc.segIdx[2 * f.seg], sc.segIdx[2 * f.seg + 1]};
+        HelicityArgs hl;
+        float fragmentVertexId;
+        prismAoInputs(T, f.b, R.n, fragmentVertexId, hl.phi);
+        const float fr = P.helicityRotationFactor;
+        float rot[3];
+        for (int i = 0; i < 3; i++) rot[i] = sc.pts[pi[T.ring[i]]].lineRotation * fr;
+        hl.fragmentRotation = (f.b[0] * rot[0] + f.b[1] * rot[1]) + f.b[2] * rot[2];
+        hl.rotationSeparatorScale = 1.0f;
+        if (P.uniformHelicityBandWidth) {
+            const uint32_t vertexIdx0 = uint32_t(floorf(fragmentVertexId)), vertexIdx1 = vertexIdx0 + 1u;
+            const uint32_t np = uint32_t(sc.pts.size());
+            const V3 p0 = vertexIdx0 < np ? ld3(sc.pts[vertexIdx0].linePosition) : v3(0, 0, 0);
+            const V3 p1 = vertexIdx1 < np ? ld3(sc.pts[vertexIdx1].linePosition) : v3(0, 0, 0);
+            const float r0 = vertexIdx0 < np ? sc.pts[vertexIdx0].lineRotation : 0.0f, r1 = vertexIdx1 < np ? sc.pts[vertexIdx1].lineRotation : 0.0f;
+            const float rotDx = length(p1 - p0);
+            const float rotDy = (r1 - r0) * fr;
+            float sn, cs;
+            sincosRad(atan2Det(rotDy * 0.5f * P.lineWidth, rotDx), sn, cs);
+            hl.rotationSeparatorScale = cs;
+        }
+        computeFragmentColor(sc, P, F, aoTexel, f.pos, f.nrm, f.tan, false, f.attr, hitColor, payloadHitT, &rb, &hl);
+        return;
+    }
     computeFragmentColor(sc, P, F, aoTexel, f.pos, f.nrm, f.tan, false, f.attr, hitColor, payloadHitT, &rb);
 }

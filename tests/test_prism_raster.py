@@ -649,3 +649,34 @@ def test_hip_band_data_on_the_rasterised_prism(hip_lib, kw):
     ctx.set_option("ppll_prism_rasteriser", "lbvh")
     with pytest.raises(Exception):
         ctx.render(2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [dict(), dict(use_uniform_twist_line_width=False), dict(helicity_rotation_factor=0.25, tube_num_subdivisions=8),
+                                dict(ppll_fragment_colour="ray_tracer")])
+def test_hip_rotating_helicity_bands_on_the_rasterised_prism(hip_lib, kw):
+    """USE_ROTATING_HELICITY_BANDS through k_ppll_shade_prism<HELICITY>: phi interpolated with the wrap-around of the last facet, fragmentRotation
+    = lineRotation x helicityRotationFactor interpolated, UNIFORM_HELICITY_BAND_WIDTH from the two line points around floor(fragmentVertexId):
+    per-pixel lists against the oracle bit for bit, frame <= 2 LSB; the stripes are there (the frame differs from the one without them)."""
+    from test_gpu_helicity_bands import helicity_case
+    c, _, _ = helicity_case(width=120, height=90, transparent=True, **kw)
+    ctx = c.hip_context()
+    img = ctx.render(2)
+    sc = c.oracle_scene()
+    P = c.oracle_params(sc)
+    assert P.ppllFragmentSource == 1 and P.useHelicityBands == 1
+    assert P.uniformHelicityBandWidth == int(kw.get("use_uniform_twist_line_width", True))
+    if kw.get("ppll_fragment_colour") == "ray_tracer":
+        with lvo.ppll_ray_tracer_fragment_colour():
+            on, os_, ocnt = sc.ppll_gather(P)
+            ref = sc.render_ppll(P)
+    else:
+        on, os_, ocnt = sc.ppll_gather(P)
+        ref = sc.render_ppll(P)
+    pw, ph = c.padded()
+    hn, hs, hcnt = ctx.ppll_buffers(pw * ph, int(P.ppllLinkedListSize))
+    assert hcnt == ocnt and hcnt > 1000
+    assert _walk_order(hn, hs) == _walk_order(on, os_)
+    assert np.abs(img.astype(np.int32) - ref.astype(np.int32)).max() <= 2
+    ctx.set_option("rotating_helicity_bands", False)
+    assert not np.array_equal(ctx.render(2), img)
