@@ -226,7 +226,7 @@ int lv_set_background(lv_ctx* ctx, const float rgba[4]);
  *   elliptic ring of the USE_BANDS vertex stage, LinePassProgrammablePullTubes.glsl:112-116,166-171, radius band_width / 2,
  *   shaded by the band branch of the raster fragment shader, and the rotating helicity bands (interpolated phi / fragmentRotation,
  *   UNIFORM_HELICITY_BAND_WIDTH from the line points around floor(fragmentVertexId), LinePassGeometryShaderTubes.glsl:1017-1052);
- *   capsule_entry for band data with helicity bands or with the static prebaker),
+ *   capsule_entry for band data with helicity bands),
  *   ppll_prism_rasteriser (build-owned): front end of raster_prism -- "segments" (default: one lane per line segment over the
  *   screen rectangle of its ring vertices, like the hardware the reference draws with walks primitives, not pixels) | "lbvh"
  *   (the all-hits walk of the viewing rays through the segment LBVH); both decide every (pixel, segment) pair by the same

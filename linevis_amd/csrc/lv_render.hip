@@ -2027,9 +2027,9 @@ static void lv_sincos2pi_host(float xi, float& s, float& c) {
 bool lv_ppll_prism_source(const lv_ctx* ctx) {
     const LvOptions& o = ctx->opt;
     if (o.ppllFragmentSource == 1) return false;
-    // auto: the prism wherever its fragment stage is built -- plain tubes, band data (USE_BANDS), rotating helicity bands; not band
-    // data with helicity bands or with the static prebaker (the raster shaders' NUM_TUBE_SUBDIVISIONS >= 8 && USE_AMBIENT_OCCLUSION && USE_BANDS path)
-    const bool built = !(o.helicityBands && o.useRibbons) && !(o.useRibbons && o.useAmbientOcclusion && o.aoPrebaked);
+    // auto: the prism wherever its fragment stage is built -- plain tubes, band data (USE_BANDS), rotating helicity bands, each with
+    // the screen-space or the prebaked AO; not band data with helicity bands (the raster shaders' NUM_TUBE_SUBDIVISIONS >= 8 && USE_AMBIENT_OCCLUSION && USE_BANDS path)
+    const bool built = !(o.helicityBands && o.useRibbons);
     return o.ppllFragmentSource == 2 ? true : built;
 }
 // per-frame constants of the rasterised prism (LvPrismDev)
@@ -2673,9 +2673,9 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
         // reallocateFragmentBuffer, PerPixelLinkedListLineRenderer.cpp:251-357
         // gather(): fragments of the rasterised programmable-pull prism (the reference's geometry, default) or capsule entry hits
         const bool prismSource = lv_ppll_prism_source(ctx);
-        if (prismSource && ctx->opt.useRibbons && (ctx->opt.helicityBands || (ctx->opt.useAmbientOcclusion && ctx->opt.aoPrebaked)))
-            return lv_fail(ctx, LV_E_INVALID, "ppll_fragment_source = raster_prism: band data with rotating helicity bands or with the "
-                                              "static prebaker has no prism fragment stage (use auto or capsule_entry)");
+        if (prismSource && ctx->opt.useRibbons && ctx->opt.helicityBands)
+            return lv_fail(ctx, LV_E_INVALID, "ppll_fragment_source = raster_prism: band data with rotating helicity bands has no prism "
+                                              "fragment stage (use auto or capsule_entry)");
         if (prismSource && ctx->opt.useRibbons && ctx->opt.ppllPrismLbvhWalk)
             return lv_fail(ctx, LV_E_INVALID, "ppll_prism_rasteriser = lbvh: the segment boxes do not enclose the band prism "
                                               "(band_width / 2); band data uses the segment rasteriser");

@@ -1409,6 +1409,7 @@ __device__ __forceinline__ f4 lv_shade_prism(const LvSceneDev& S, const LvUnifor
         b.useBand = true;
         float fragmentVertexId;
         lv_prism_ao_inputs(T, pt, pi, I.b, R.n, fragmentVertexId, b.phi);
+        if (U.aoPrebaked) aoTexel = lv_prebaked_ao_lookup(S, U, fragmentVertexId, b.phi);   // getAoFactor(fragmentVertexId, phi), Lighting.glsl:124-125
         const f3 c0 = T.second[0] ? pt[1].centre : pt[0].centre, c1 = T.second[1] ? pt[1].centre : pt[0].centre, c2 = T.second[2] ? pt[1].centre : pt[0].centre;
         const f3 n0 = T.second[0] ? pt[1].normal : pt[0].normal, n1 = T.second[1] ? pt[1].normal : pt[0].normal, n2 = T.second[2] ? pt[1].normal : pt[0].normal;
         b.linePosition = lv_prism_mix3(I.b, c0, c1, c2);

@@ -355,6 +355,7 @@ inline void prismShade(const lvo_scene& sc, const lvo_params& P, const Frame& F,
         rb.shadeBands = true; rb.useBand = true;
         float fragmentVertexId;
         prismAoInputs(T, f.b, R.n, fragmentVertexId, rb.phi);
+        if (pb) aoTexel = prebakedAoLookup(*pb, fragmentVertexId, rb.phi);
         rb.linePosition = prismMix3(f.b, T.centre[0], T.centre[1], T.centre[2]);
         rb.lineNormal = prismMix3(f.b, T.lnrm[0], T.lnrm[1], T.lnrm[2]);
         rb.rasterEpsWhite = -1.0f;

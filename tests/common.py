@@ -83,10 +83,9 @@ class Case:
             minThickness=float(np.float32(s.get("min_band_thickness", 0.15))) if bool(s.get("thick_bands", True)) else float(np.float32(1e-2)),
         )
         # ppll_fragment_source as the library resolves it (lv_ppll_prism_source): auto = the rasterised prism wherever its fragment
-        # stage is built (plain flow lines, band data, helicity bands; not band data with helicity bands or the static prebaker)
+        # stage is built (plain flow lines, band data, helicity bands; not band data with helicity bands)
         src = s.get("ppll_fragment_source", "auto")
-        prebaked = s.get("ambient_occlusion_mode", "") == "RTAO (Prebaker)"
-        built = not (bool(s.get("use_ribbons", False)) and (bool(s.get("rotating_helicity_bands", False)) or prebaked))
+        built = not (bool(s.get("use_ribbons", False)) and bool(s.get("rotating_helicity_bands", False)))
         kw["ppllFragmentSource"] = int(src == "raster_prism" or (src == "auto" and built))
         large = len(self.seg) > 1000000
         kw["ppllMaxNumFrags"] = int(s.get("ppll_max_num_frags", 0)) or (380 if large else 100)

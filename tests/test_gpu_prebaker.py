@@ -311,6 +311,14 @@ def test_band_data_with_the_prebaker(hip_lib, elliptic):
     case = band_case(width=120, height=90, elliptic=elliptic, tr=tr, line_width=lw, band_width=bwid, min_band_thickness=mbt, **PREBAKE, **kw)
     mesh = lvo.build_tube_triangle_render_data_ribbons(tr.positions, tr.attributes, tr.line_offsets, tr.ribbon_directions, bwid, mbt, 6)
     blend, sl = lvo.ao_parametrization(tr.positions, tr.line_offsets, 0.01)
+    start = np.zeros(len(case.points), np.uint32)   # lineStartIndex of the programmable-pull records (LineDataFlow.cpp:1655-1690)
+    first = 0
+    for k in range(len(case.seg)):
+        if k == 0 or case.seg[k, 0] != case.seg[k - 1, 1]:
+            first = case.seg[k, 0]
+        start[case.seg[k, 0]] = first
+        start[case.seg[k, 1]] = first
+    case.points["lineStartIndex"] = start
     ctx = case.hip_context()
     ctx.set_tube_triangle_mesh(*mesh)
     ctx.set_ao_parametrization(blend, sl)
@@ -329,5 +337,29 @@ def test_band_data_with_the_prebaker(hip_lib, elliptic):
     P.useAmbientOcclusion = 1
     want = lvo.render_rt_prebaked(sc, None, P, ref, blend)
     assert max_lsb_diff(img, want) <= 2
+    # mode 2: the rasterised band prism (auto) with the lookup by the interpolated (fragmentVertexId, phi)
+    pimg = ctx.render(capi.MODE_PPLL)
+    assert P.ppllFragmentSource == 1
+    with lvo.ppll_prebaked_ao(ref, blend):
+        on, os_, ocnt = sc.ppll_gather(P)
+        pref = sc.render_ppll(P)
+    pw, ph = case.padded()
+    hn, hs, hcnt = ctx.ppll_buffers(pw * ph, 0)
+    assert hcnt == ocnt and hcnt > 500
+
+    def lists(nodes, st):
+        out = {}
+        for pix in np.nonzero(st != 0xFFFFFFFF)[0]:
+            i, l = int(st[pix]), []
+            while i != 0xFFFFFFFF:
+                l.append((int(nodes[i, 1]), int(nodes[i, 0]) & 0xFF000000, int(nodes[i, 0])))
+                i = int(nodes[i, 2])
+            out[int(pix)] = sorted(l)
+        return out
+    a, b = lists(hn, hs), lists(on, os_)
+    assert a.keys() == b.keys()
+    for k in a:     # depths and alpha exactly; colour channels <= 1 (the lookup blends with the build's acos-free arithmetic: exact expected)
+        assert [(d, al) for d, al, _ in a[k]] == [(d, al) for d, al, _ in b[k]]
+    assert max_lsb_diff(pimg, pref) <= 2
     ctx.set_option("ambient_occlusion_strength", 0.0)
     assert not np.array_equal(ctx.render(capi.MODE_RAY_TRACER), img)
