@@ -1096,7 +1096,9 @@ __device__ __forceinline__ f4 lv_transfer_function(const LvSceneDev& S, const Lv
 // (LV_SHADE_HELICITY: phi and rotation = fragmentRotation of USE_ROTATING_HELICITY_BANDS, :91-93; the rest unused)
 // rasterEpsWhite >= 0: the raster tube shader's variant of the outline (the PPLL gather, LinePassGeometryShaderTubes.glsl:785-815,
 // 1079-1087: EPSILON_OUTLINE = 0, EPSILON_WHITE = fwidth(ribbonPosition) = this value, cap halo min(rp, |rp2|)); < 0: RayHitCommon's
-struct LvBandArgs { bool useBand; float phi; f3 linePosition, lineNormal; float rotation, separatorScale; float rasterEpsWhite; };
+// stripeAaf >= 0: the raster shader's helicity stripe (LinePassGeometryShaderTubes.glsl:716-721,1046-1052): offset 0.1 instead of w / 2,
+// aaf = fwidth(phi + fragmentRotation) over the pixel quad instead of 10 EPSILON_OUTLINE (the rasterised prism supplies it)
+struct LvBandArgs { bool useBand; float phi; f3 linePosition, lineNormal; float rotation, separatorScale; float rasterEpsWhite; float stripeAaf = -1.0f; };
 
 // Raster variant of the fragment colour: fwidth(ribbonPosition) over the 2 x 2 pixel quad.  The ribbon coordinate of a fragment is
 // a function of the VIEWING RAY (|cross(newV, n)| = distance between the ray and the tube axis over the radius; the USE_BANDS
@@ -1444,6 +1446,15 @@ __device__ __forceinline__ f4 lv_shade_prism(const LvSceneDev& S, const LvUnifor
         const float r0 = S.points[pi[0]].lineRotation * fr, r1 = S.points[pi[1]].lineRotation * fr;
         const float rot[3] = {T.second[0] ? r1 : r0, T.second[1] ? r1 : r0, T.second[2] ? r1 : r0};
         none.rotation = (I.b[0] * rot[0] + I.b[1] * rot[1]) + I.b[2] * rot[2];
+        if (rasterApply) {   // the raster shader's stripe: aaf = fwidth(phi + fragmentRotation) from the quad partners' interpolated varyings
+            float vid, phx, phy;
+            lv_prism_ao_inputs(T, pt, pi, Ix.b, R.n, vid, phx);
+            lv_prism_ao_inputs(T, pt, pi, Iy.b, R.n, vid, phy);
+            const float gx = phx + ((Ix.b[0] * rot[0] + Ix.b[1] * rot[1]) + Ix.b[2] * rot[2]);
+            const float gy = phy + ((Iy.b[0] * rot[0] + Iy.b[1] * rot[1]) + Iy.b[2] * rot[2]);
+            const float g0 = none.phi + none.rotation;
+            none.stripeAaf = fabsf(gx - g0) + fabsf(gy - g0);
+        }
         if (U.uniformHelicityBandWidth) {
             const uint32_t i0 = uint32_t(floorf(fragmentVertexId)), i1 = i0 + 1u;
             f3 p0 = mk3(0.0f, 0.0f, 0.0f), p1 = mk3(0.0f, 0.0f, 0.0f);
@@ -1767,9 +1778,10 @@ __device__ __forceinline__ f4 lv_compute_fragment_color_t(const LvSceneDev& S, c
         // drawSeparatorStripe (:57-64) darkens the shaded colour where mod(phi + rotation + w / 2, 2 pi / n) falls into [0, w]
         const float separatorWidth = U.separatorBaseWidth / bands.separatorScale; // :456-459 (scale 1 without the define)
         const float period = 2.0f / float(U.numSubdivisionsBands) * 3.14159265358979323846f;
-        const float x = bands.phi + bands.rotation + separatorWidth * 0.5f;
+        const bool rasterStripe = bands.stripeAaf >= 0.0f;
+        const float x = bands.phi + bands.rotation + (rasterStripe ? 0.1f : separatorWidth * 0.5f);
         const float varFraction = x - period * floorf(x / period); // mod(x, y) = x - y * floor(x / y)
-        const float aaf = EPSILON_OUTLINE * 10.0f;
+        const float aaf = rasterStripe ? bands.stripeAaf : EPSILON_OUTLINE * 10.0f;
         const float alphaBorder1 = smoothstepf(aaf, 0.0f, varFraction);
         const float alphaBorder2 = smoothstepf(separatorWidth - aaf * 0.5f, separatorWidth + aaf * 0.5f, varFraction);
         const float m = fmaxf(alphaBorder1, alphaBorder2);

@@ -678,7 +678,9 @@ inline float capRibbonOfRay(V3 cam, V3 d, V3 hit, V3 hitNormal, V3 centre, V3 t)
 struct BandArgs { bool useBand; float phi; V3 linePosition, lineNormal; float rasterEpsWhite = -1.0f; bool shadeBands = true; };
 // USE_ROTATING_HELICITY_BANDS arguments of computeFragmentColor (RayHitCommon.glsl:82-93): the angle around the tube and the
 // interpolated lineRotation x helicityRotationFactor
-struct HelicityArgs { float phi, fragmentRotation, rotationSeparatorScale; };
+// rasterAaf >= 0: the raster shader's stripe (LinePassGeometryShaderTubes.glsl:716-721,1046-1052): offset 0.1 instead of w / 2, aaf =
+// fwidth(phi + fragmentRotation) over the pixel quad instead of 10 EPSILON_OUTLINE
+struct HelicityArgs { float phi, fragmentRotation, rotationSeparatorScale; float rasterAaf = -1.0f; };
 inline void computeFragmentColor(const lvo_scene& sc, const lvo_params& P, const Frame& F, float aoTexel, V3 fragPos,
                                  V3 fragmentNormal, V3 fragmentTangent, bool isCap, float fragmentAttribute,
                                  float hitColor[4], float& payloadHitT, const BandArgs* bands = nullptr,
@@ -1015,9 +1017,10 @@ inline void computeFragmentColor(const lvo_scene& sc, const lvo_params& P, const
         // drawSeparatorStripe (:57-64) darkens the shaded colour where mod(phi + rotation + w / 2, 2 pi / n) falls into [0, w]
         const float separatorWidth = P.separatorBaseWidth / hel->rotationSeparatorScale; // :456-459 (scale 1 without the define)
         const float period = 2.0f / float(P.numSubdivisionsBands) * 3.14159265358979323846f;
-        const float x = hel->phi + hel->fragmentRotation + separatorWidth * 0.5f;
+        const bool rasterStripe = hel->rasterAaf >= 0.0f;
+        const float x = hel->phi + hel->fragmentRotation + (rasterStripe ? 0.1f : separatorWidth * 0.5f);
         const float varFraction = x - period * floorf(x / period); // mod(x, y) = x - y * floor(x / y)
-        const float aaf = EPSILON_OUTLINE * 10.0f;
+        const float aaf = rasterStripe ? hel->rasterAaf : EPSILON_OUTLINE * 10.0f;
         const float alphaBorder1 = smoothstepf(aaf, 0.0f, varFraction);
         const float alphaBorder2 = smoothstepf(separatorWidth - aaf * 0.5f, separatorWidth + aaf * 0.5f, varFraction);
         const float m = fmaxf(alphaBorder1, alphaBorder2);

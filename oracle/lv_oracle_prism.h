@@ -401,6 +401,19 @@ inline void prismShade(const lvo_scene& sc, const lvo_params& P, const Frame& F,
         float rot[3];
         for (int i = 0; i < 3; i++) rot[i] = sc.pts[pi[T.ring[i]]].lineRotation * fr;
         hl.fragmentRotation = (f.b[0] * rot[0] + f.b[1] * rot[1]) + f.b[2] * rot[2];
+        if (rq) {   // the raster shader's stripe: aaf = fwidth(phi + fragmentRotation) from the quad partners' interpolated varyings
+            const PrismPlanes pl = prismPlanes(F, T, F.cameraPosition, f.d);
+            float g[2];
+            const V3 dirs[2] = {rq->dX, rq->dY};
+            for (int k = 0; k < 2; k++) {
+                float bq[3], vid, ph;
+                prismRayWeights(pl, dirs[k], bq);
+                prismAoInputs(T, bq, R.n, vid, ph);
+                g[k] = ph + ((bq[0] * rot[0] + bq[1] * rot[1]) + bq[2] * rot[2]);
+            }
+            const float g0 = hl.phi + hl.fragmentRotation;
+            hl.rasterAaf = fabsf(g[0] - g0) + fabsf(g[1] - g0);
+        }
         hl.rotationSeparatorScale = 1.0f;
         if (P.uniformHelicityBandWidth) {
             const uint32_t vertexIdx0 = uint32_t(floorf(fragmentVertexId)), vertexIdx1 = vertexIdx0 + 1u;
