@@ -163,6 +163,15 @@ int lv_bake_ao_poll(lv_ctx* ctx, int* out_running, int* out_ready);
  * n RGBA float texels, sampled with linear filtering at texel centres, clamp-to-edge. */
 int lv_set_transfer_function(lv_ctx* ctx, const float* rgba, uint32_t n, float attr_min, float attr_max);
 
+/* LineDataFlow::loadTwistLineTexture (LineDataFlow.cpp:93-171; the "twist_line_texture" file is decoded by the embedder): RGBA8
+ * pixels, row-major; sampled with REPEAT addressing at (u, 0.5) where the separator stripes of the rotating helicity bands would be
+ * drawn (option use_twist_line_texture = USE_HELICITY_BANDS_TEXTURE, twist_line_texture_filtering_mode[_index] = the six names of
+ * LineDataFlow.cpp:55-57; twist_line_texture_max_anisotropy must be 1).  The ray tracer samples level 0 (texture() without
+ * derivatives, RayHitCommon.glsl:66-72), the rasterised prism of mode 2 textureGrad with the quad's derivatives of (phi +
+ * fragmentRotation) / 2 pi (LinePassGeometryShaderTubes.glsl:724-730).  Texel centres, linear weights, level-of-detail formula and
+ * the mip chain (2 x 2 box averages in float) are build-owned.  rgba8 == NULL unloads. */
+int lv_set_twist_line_texture(lv_ctx* ctx, const uint8_t* rgba8, uint32_t width, uint32_t height);
+
 /* SceneData camera + viewport (src/Renderers/SceneData.hpp:49-85) and LineRenderer::onResolutionChanged
  * (LineRenderer.hpp:127); inverses are taken inside as LineData::updateVulkanUniformBuffers does (LineData.cpp:1290-1291). */
 int lv_set_camera(lv_ctx* ctx, const float view[16], const float proj[16], float fov_y, float near_dist,

@@ -82,7 +82,7 @@ class LineVisError(RuntimeError):
 
 # every symbol include/linevis_hip.h declares (checked by tests/test_abi.py against the header text)
 SYMBOLS = ["lv_create", "lv_destroy", "lv_last_error", "lv_version", "lv_set_stream", "lv_set_lines",
-           "lv_set_transfer_function", "lv_set_camera", "lv_set_background", "lv_set_option", "lv_build_accel",
+           "lv_set_transfer_function", "lv_set_twist_line_texture", "lv_set_camera", "lv_set_background", "lv_set_option", "lv_build_accel",
            "lv_render", "lv_render_device", "lv_render_tiles_device", "lv_get_stats", "lv_reset_timers", "lv_get_kernel_times", "lv_get_ao_tile_costs", "lv_get_dispatch_order", "lv_trace_rays",
            "lv_compute_depth_range", "lv_get_ao", "lv_ppll_get_buffers", "lv_ppll_resolve_buffers", "lv_get_accel",
            "lv_set_tube_triangle_mesh", "lv_trace_rays_triangles", "lv_set_flow_grid", "lv_trace_streamlines",
@@ -135,6 +135,7 @@ def load():
         ("lv_set_stream", [vp, vp]),
         ("lv_set_lines", [vp, vp, u32, vp, u32]),
         ("lv_set_transfer_function", [vp, vp, u32, f32, f32]),
+        ("lv_set_twist_line_texture", [vp, vp, u32, u32]),
         ("lv_set_camera", [vp, vp, vp, f32, f32, f32, u32, u32]),
         ("lv_set_background", [vp, vp]),
         ("lv_set_option", [vp, cp, cp]),
@@ -270,6 +271,14 @@ class Context:
     def set_transfer_function(self, rgba, attr_min=0.0, attr_max=1.0):
         tf = np.ascontiguousarray(rgba, dtype=np.float32).reshape(-1, 4)
         self._ck(self.L.lv_set_transfer_function(self.h, _p(tf), tf.shape[0], attr_min, attr_max))
+
+    def set_twist_line_texture(self, rgba8):
+        """Twist-line texture of the rotating helicity bands: (h, w, 4) uint8, or None to unload."""
+        if rgba8 is None:
+            self._ck(self.L.lv_set_twist_line_texture(self.h, None, 0, 0))
+            return
+        img = np.ascontiguousarray(rgba8, dtype=np.uint8)
+        self._ck(self.L.lv_set_twist_line_texture(self.h, _p(img), img.shape[1], img.shape[0]))
 
     def set_camera(self, view, proj, fov_y, near, far, width, height):
         v = np.ascontiguousarray(view, dtype=np.float32).reshape(16)

@@ -100,7 +100,7 @@ static std::vector<LvDeviceBuffer*> lv_all_buffers(lv_ctx* ctx) {
             &ctx->eawPing, &ctx->eawPong, &ctx->tilesHaloDev, &ctx->fullFrameTile, &ctx->svgf.normalDepth, &ctx->svgf.normalDepthHistory,
             &ctx->svgf.flowFwidth, &ctx->svgf.moments, &ctx->svgf.momentsHistory, &ctx->svgf.colorHistory, &ctx->svgf.tempAccum,
             &ctx->svgf.tempAccumFiltered, &ctx->svgf.ping, &ctx->svgf.pong, &ctx->svgf.result, &ctx->aoGbuf, &ctx->aoList, &ctx->aoSamples,
-            &ctx->counters, &ctx->ppllNodes, &ctx->ppllStart, &ctx->ppllCount, &ctx->ppllScratch, &ctx->prismRecords, &ctx->scanTemp, &ctx->ppllOverflow, &ctx->tilesDev, &ctx->outDev,
+            &ctx->counters, &ctx->ppllNodes, &ctx->ppllStart, &ctx->ppllCount, &ctx->ppllScratch, &ctx->prismRecords, &ctx->scanTemp, &ctx->ppllOverflow, &ctx->twistTex, &ctx->tilesDev, &ctx->outDev,
             &ctx->scratchRays, &ctx->stackOverflow, &ctx->triIdx, &ctx->triVerts, &ctx->triPoints, &ctx->triNodes, &ctx->tris,
             &ctx->flowVectors, &ctx->flowScalars, &ctx->flowMisc, &ctx->flowSeeds, &ctx->flowOutPos, &ctx->flowOutAtt, &ctx->flowCounts,
             &ctx->bakeBlendingWeights, &ctx->bakeSamplingLocations, &ctx->bakedAo, &ctx->bakeLcgSkip, &ctx->bakedAoPending, &ctx->bakeCounters,
@@ -375,6 +375,47 @@ int lv_set_transfer_function(lv_ctx* ctx, const float* rgba, uint32_t n, float a
     return lv_forward_to_ranks(ctx, [&](lv_ctx* p) { return lv_set_transfer_function(p, rgba, n, attr_min, attr_max); });
 }
 
+// LineDataFlow::loadTwistLineTexture (LineDataFlow.cpp:93-171) without the PNG decoder: level 0 = the RGBA8 pixels as UNORM floats, then
+// intlog2(max(w, h)) levels in all (:161-163) of 2 x 2 box averages -- in float, (a + b) + (c + d) times 0.25, odd extents clamp the second
+// texel (sgl generates the chain with linear blits, whose rounding Vulkan leaves open).  rgba8 == NULL unloads the texture.
+int lv_set_twist_line_texture(lv_ctx* ctx, const uint8_t* rgba8, uint32_t width, uint32_t height) {
+    if (!ctx) return LV_E_INVALID;
+    (void)hipSetDevice(ctx->device);
+    if (!rgba8) {
+        ctx->twistW = ctx->twistH = ctx->twistLevels = 0;
+        return lv_forward_to_ranks(ctx, [&](lv_ctx* p) { return lv_set_twist_line_texture(p, nullptr, 0, 0); });
+    }
+    if (width == 0 || height == 0 || width > 16384 || height > 16384) return lv_fail(ctx, LV_E_INVALID, "twist-line texture extent");
+    uint32_t levels = 0;
+    for (uint32_t m = std::max(width, height); m > 1; m >>= 1) levels++;   // intlog2
+    if (levels == 0) levels = 1;
+    std::vector<float> tex;
+    tex.reserve(size_t(width) * height * 4 * 2);
+    for (size_t i = 0; i < size_t(width) * height * 4; i++) tex.push_back(float(rgba8[i]) / 255.0f);
+    size_t prev = 0;
+    uint32_t w = width, h = height;
+    for (uint32_t l = 1; l < levels; l++) {
+        const uint32_t nw = std::max(w >> 1, 1u), nh = std::max(h >> 1, 1u);
+        const size_t cur = tex.size();
+        tex.resize(cur + size_t(nw) * nh * 4);
+        for (uint32_t j = 0; j < nh; j++)
+            for (uint32_t i = 0; i < nw; i++)
+                for (uint32_t c = 0; c < 4; c++) {
+                    const uint32_t i0 = std::min(2 * i, w - 1), i1 = std::min(2 * i + 1, w - 1), j0 = std::min(2 * j, h - 1), j1 = std::min(2 * j + 1, h - 1);
+                    const float a = tex[prev + (size_t(j0) * w + i0) * 4 + c], b = tex[prev + (size_t(j0) * w + i1) * 4 + c];
+                    const float cc = tex[prev + (size_t(j1) * w + i0) * 4 + c], d = tex[prev + (size_t(j1) * w + i1) * 4 + c];
+                    tex[cur + (size_t(j) * nw + i) * 4 + c] = ((a + b) + (cc + d)) * 0.25f;
+                }
+        prev = cur; w = nw; h = nh;
+    }
+    int rc;
+    if ((rc = lv_buf_reserve(ctx, ctx->twistTex, tex.size() * 4))) return rc;
+    LV_HIP(ctx, hipMemcpyAsync(ctx->twistTex.ptr, tex.data(), tex.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    LV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->twistW = width; ctx->twistH = height; ctx->twistLevels = levels;
+    return lv_forward_to_ranks(ctx, [&](lv_ctx* p) { return lv_set_twist_line_texture(p, rgba8, width, height); });
+}
+
 int lv_set_camera(lv_ctx* ctx, const float view[16], const float proj[16], float fov_y, float near_dist, float far_dist,
                   uint32_t w, uint32_t h) {
     if (!ctx) return LV_E_INVALID;
@@ -489,6 +530,18 @@ int lv_set_option(lv_ctx* ctx, const char* key, const char* value) {
         o.helicityBands = parseBool(value);                       // points then carry lineRotation)
     } else if (k == "use_uniform_twist_line_width") {             // :618 (UNIFORM_HELICITY_BAND_WIDTH; "Triangle Mesh" geometry only)
         o.uniformTwistLineWidth = parseBool(value);
+    } else if (k == "use_twist_line_texture") {                   // :626 (the texture itself: lv_set_twist_line_texture)
+        o.useTwistLineTexture = parseBool(value);
+    } else if (k == "twist_line_texture_filtering_mode" || k == "twist_line_texture_filtering_mode_index") {   // :640-669
+        static const char* const names[] = {"Nearest", "Linear", "Nearest Mipmap Nearest", "Linear Mipmap Nearest",
+                                            "Nearest Mipmap Linear", "Linear Mipmap Linear"};
+        uint32_t mode = 6;
+        if (k == "twist_line_texture_filtering_mode") { for (uint32_t i = 0; i < 6; i++) if (std::string(value) == names[i]) mode = i; }
+        else if (!parseUint(value, mode)) return bad();
+        if (mode >= 6) return bad();
+        o.twistFilterMode = mode;
+    } else if (k == "twist_line_texture_max_anisotropy") {        // :671 (anisotropic filtering is implementation-defined: 1 only)
+        if (!parseUint(value, u) || u != 1) return bad();
     } else if (k == "separator_width") {                          // :609
         if (!parseFloat(value, f) || !(f >= 0.0f)) return bad();
         o.separatorWidth = f;

@@ -208,6 +208,9 @@ struct LvUniforms {
     // PPLL gather: 1 = fragments are shaded by the raster tube shader's variant (LinePassGeometryShaderTubes.glsl:785-815,1079-1087:
     // EPSILON_OUTLINE = 0, EPSILON_WHITE = fwidth(ribbonPosition)), 0 = by RayHitCommon's (ppll_fragment_colour = ray_tracer)
     uint32_t ppllRasterColour;
+    // USE_HELICITY_BANDS_TEXTURE (LineDataFlow.cpp:93-171,2437-2439): the twist-line texture replaces the separator stripes; filter
+    // mode index of textureFilteringModeNames (:55-60), extent of level 0, number of mip levels (intlog2(max(w, h)), :161-163)
+    uint32_t useTwistTexture, twistFilterMode, twistW, twistH, twistLevels;
     uint32_t uniformHelicityBandWidth; // UNIFORM_HELICITY_BAND_WIDTH: triangle closest-hit path only (LineAttributesBarycentric.glsl:94-112)
 };
 
@@ -250,6 +253,7 @@ struct LvSceneDev {
     uint32_t numPoints;         // entries of `points`
     const uint32_t* segIdx;     // 2 point indices per original segment
     const float4* tf;           // transfer function texels
+    const float4* twistTex;     // twist-line texture: float RGBA, mip levels one after the other (lv_set_twist_line_texture)
     const float* depthMinMax;   // {minDepth, maxDepth}, produced on device by the depth-range kernels
     // elliptic tubelets (LV_PRIM_ELLIPTIC): semi-axes from bandWidth / minBandThickness, camera position of the cutting-plane
     // tolerances (EllipticTubeRayTracing.glsl:186-270)
@@ -391,6 +395,19 @@ __device__ __forceinline__ float lv_pow_det(float x, float y) {
     const float t = (p - n) * 0.693147181f;                        // |t| <= 0.3466
     const float Q = 1.0f + t * (1.0f + t * (0.5f + t * (0.166666667f + t * (0.0416666667f + t * (0.00833333333f + t * (0.00138888889f + t * 0.000198412698f))))));
     return __uint_as_float(__float_as_uint(Q) + (uint32_t(int(n)) << 23)); // Q * 2^n (Q in [0.70, 1.42], n >= -125: normal)
+}
+// log2(x), x > 0 and normal: the first half of lv_pow_det (exponent bits + atanh series); the mip level selection of the twist-line texture
+__device__ __forceinline__ float lv_log2_det(float x) {
+    const uint32_t bits = __float_as_uint(x);
+    int e = int((bits >> 23) & 0xFFu) - 127;
+    float m = __uint_as_float((bits & 0x007FFFFFu) | 0x3F800000u);
+    if (m > 1.41421356f) { m = m * 0.5f; e = e + 1; }
+    const float f = m - 1.0f;
+    const float s = f / (2.0f + f);
+    const float z = s * s;
+    const float P = 0.333333333f + z * (0.2f + z * (0.142857143f + z * 0.111111111f));
+    const float ln = 2.0f * s + (2.0f * s) * (z * P);
+    return float(e) + ln * 1.44269504f;
 }
 // normalize(v) of the shading code as v * (1 / length(v)): one IEEE division instead of three (GLSL does not say how normalize
 // divides; the twelve normalisations of computeFragmentColor + blinnPhongShadingTube were a third of the shading instructions)

@@ -85,6 +85,8 @@ struct LvOptions {
     // LineDataFlow.cpp:54), band_subdivisions (6, LineDataFlow.hpp:188), helicity_rotation_factor (1, :171); settings keys :601-624
     bool helicityBands = false, uniformTwistLineWidth = true; // use_uniform_twist_line_width, LineDataFlow.cpp:53
     float separatorWidth = 0.2f, helicityRotationFactor = 1.0f;
+    bool useTwistLineTexture = false;         // use_twist_line_texture (USE_HELICITY_BANDS_TEXTURE once a texture is loaded, LineDataFlow.cpp:2437)
+    uint32_t twistFilterMode = 5;             // twist_line_texture_filtering_mode[_index]: "Linear Mipmap Linear" (LineDataFlow.hpp default)
     uint32_t bandSubdivisions = 6;
     bool svgfEnabled = false;
     uint32_t svgfIterations = 5;              // maxNumIterations, SVGF.hpp:115 (GUI range 0..5)
@@ -189,6 +191,8 @@ struct lv_ctx {
     LvDeviceBuffer ppllNodes, ppllStart, ppllCount, ppllScratch;
     LvDeviceBuffer prismRecords, scanTemp;    // raster_prism: {pixel, leaf | triangle, rank} records of the coverage kernel; k_ppll_scan: block totals, block bases, completion counter
     uint32_t ppllScanBlocks = 0;              // raster_prism: workgroups of the last k_ppll_scan (scanTemp = totals, bases, counter)
+    LvDeviceBuffer twistTex;                  // twist-line texture: float4 texels, mip levels back to back
+    uint32_t twistW = 0, twistH = 0, twistLevels = 0;
     LvDeviceBuffer ppllOverflow;              // raster_prism: pixel addresses with more kept fragments than ppllMaxNumFrags (k_ppll_pixel_pass)
     bool ppllArrays = false;                  // the last PPLL frame left per-pixel runs (raster_prism), not linked lists
     LvDeviceBuffer tilesDev, outDev, scratchRays, stackOverflow, mlatTrace;

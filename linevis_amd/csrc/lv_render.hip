@@ -1968,6 +1968,7 @@ LvSceneDev sceneDev(const lv_ctx* ctx) {
     S.numPoints = ctx->numPoints;
     S.segIdx = (const uint32_t*)ctx->segIdx.ptr;
     S.tf = (const float4*)ctx->tf.ptr;
+    S.twistTex = (const float4*)ctx->twistTex.ptr;
     S.depthMinMax = (const float*)ctx->depthMinMax.ptr;
     S.ao = ctx->aoResult ? ctx->aoResult : (const float*)ctx->ao.ptr;
     S.stackOverflow = nullptr;
@@ -2080,6 +2081,9 @@ void lv_fill_uniforms(const lv_ctx* ctx, LvUniforms& U) {
     U.numSubdivisionsBands = o.bandSubdivisions;
     U.separatorBaseWidth = o.separatorWidth;
     U.helicityRotationFactor = o.helicityRotationFactor;
+    U.useTwistTexture = (o.helicityBands && o.useTwistLineTexture && ctx->twistLevels != 0u) ? 1u : 0u;   // LineDataFlow.cpp:2437
+    U.twistFilterMode = o.twistFilterMode;
+    U.twistW = ctx->twistW; U.twistH = ctx->twistH; U.twistLevels = ctx->twistLevels;
     U.uniformHelicityBandWidth = o.uniformTwistLineWidth ? 1u : 0u;
     U.ppllRasterColour = o.ppllRayTracerColour ? 0u : 1u;
     U.nearDist = ctx->nearDist;

@@ -1098,7 +1098,54 @@ __device__ __forceinline__ f4 lv_transfer_function(const LvSceneDev& S, const Lv
 // 1079-1087: EPSILON_OUTLINE = 0, EPSILON_WHITE = fwidth(ribbonPosition) = this value, cap halo min(rp, |rp2|)); < 0: RayHitCommon's
 // stripeAaf >= 0: the raster shader's helicity stripe (LinePassGeometryShaderTubes.glsl:716-721,1046-1052): offset 0.1 instead of w / 2,
 // aaf = fwidth(phi + fragmentRotation) over the pixel quad instead of 10 EPSILON_OUTLINE (the rasterised prism supplies it)
-struct LvBandArgs { bool useBand; float phi; f3 linePosition, lineNormal; float rotation, separatorScale; float rasterEpsWhite; float stripeAaf = -1.0f; };
+// stripeDx / stripeDy: dFdx / dFdy of globalPos = (phi + fragmentRotation) / 2 pi for the textureGrad of the twist-line texture
+struct LvBandArgs { bool useBand; float phi; f3 linePosition, lineNormal; float rotation, separatorScale; float rasterEpsWhite; float stripeAaf = -1.0f;
+                    float stripeDx = 0.0f, stripeDy = 0.0f; };
+
+// The twist-line texture (USE_HELICITY_BANDS_TEXTURE): sampler2D with REPEAT addressing, sampled at (u, 0.5).  The ray tracer's shaders
+// call texture() without derivatives = level 0 (RayHitCommon.glsl:66-72); the raster shader textureGrad(.., (dFdx(globalPos), 0),
+// (dFdy(globalPos), 0)) (LinePassGeometryShaderTubes.glsl:724-730).  Build-owned where Vulkan leaves room: texel centres at
+// (i + 0.5) / size, linear weights in full float, level of detail lambda = log2(max(|dudx|, |dudy|) * width) clamped to the chain,
+// nearest mip = ceil(lambda + 0.5) - 1, mip chain = 2 x 2 box averages in float (lv_set_twist_line_texture); no anisotropic filtering.
+__device__ __forceinline__ f4 lv_twist_level(const LvSceneDev& S, const LvUniforms& U, uint32_t level, float u, float v, bool linear) {
+    uint32_t w = U.twistW, h = U.twistH;
+    size_t base = 0;
+    for (uint32_t l = 0; l < level; l++) { base += size_t(w) * h; w = max(w >> 1, 1u); h = max(h >> 1, 1u); }
+    const float4* __restrict__ T = S.twistTex + base;
+    auto wrap = [](int i, uint32_t n) { int m = i % int(n); return uint32_t(m < 0 ? m + int(n) : m); };
+    auto texel = [&](uint32_t i, uint32_t j) { const float4 t = T[size_t(j) * w + i]; f4 r; r.x = t.x; r.y = t.y; r.z = t.z; r.w = t.w; return r; };
+    if (!linear) return texel(wrap(int(floorf(u * float(w))), w), wrap(int(floorf(v * float(h))), h));
+    const float x = u * float(w) - 0.5f, y = v * float(h) - 0.5f;
+    const float fx0 = floorf(x), fy0 = floorf(y);
+    const float a = x - fx0, b = y - fy0;
+    const uint32_t i0 = wrap(int(fx0), w), i1 = wrap(int(fx0) + 1, w), j0 = wrap(int(fy0), h), j1 = wrap(int(fy0) + 1, h);
+    const f4 t00 = texel(i0, j0), t10 = texel(i1, j0), t01 = texel(i0, j1), t11 = texel(i1, j1);
+    f4 r;
+    r.x = mixf(mixf(t00.x, t10.x, a), mixf(t01.x, t11.x, a), b);
+    r.y = mixf(mixf(t00.y, t10.y, a), mixf(t01.y, t11.y, a), b);
+    r.z = mixf(mixf(t00.z, t10.z, a), mixf(t01.z, t11.z, a), b);
+    r.w = mixf(mixf(t00.w, t10.w, a), mixf(t01.w, t11.w, a), b);
+    return r;
+}
+__device__ __forceinline__ f4 lv_twist_sample(const LvSceneDev& S, const LvUniforms& U, float u, float dudx, float dudy, bool useGrad) {
+    const uint32_t mode = U.twistFilterMode;          // Nearest, Linear, Nearest Mipmap Nearest, Linear M. Nearest, Nearest M. Linear, Linear M. Linear
+    const bool linear = mode == 1u || mode == 3u || mode == 5u;
+    const float v = 0.5f;
+    if (mode < 2u || !useGrad || U.twistLevels <= 1u) return lv_twist_level(S, U, 0u, u, v, linear);
+    const float rho = fmaxf(fabsf(dudx), fabsf(dudy)) * float(U.twistW);
+    const float maxLevel = float(U.twistLevels - 1u);
+    const float lambda = rho > 1.0f ? fminf(lv_log2_det(rho), maxLevel) : 0.0f;
+    if (mode == 2u || mode == 3u) {                   // mipmap mode NEAREST
+        const float d = fminf(fmaxf(ceilf(lambda + 0.5f) - 1.0f, 0.0f), maxLevel);
+        return lv_twist_level(S, U, uint32_t(d), u, v, linear);
+    }
+    const float dhi = floorf(lambda), delta = lambda - dhi;
+    const uint32_t lhi = uint32_t(dhi), llo = min(lhi + 1u, U.twistLevels - 1u);
+    const f4 a = lv_twist_level(S, U, lhi, u, v, linear), b = lv_twist_level(S, U, llo, u, v, linear);
+    f4 r;
+    r.x = mixf(a.x, b.x, delta); r.y = mixf(a.y, b.y, delta); r.z = mixf(a.z, b.z, delta); r.w = mixf(a.w, b.w, delta);
+    return r;
+}
 
 // Raster variant of the fragment colour: fwidth(ribbonPosition) over the 2 x 2 pixel quad.  The ribbon coordinate of a fragment is
 // a function of the VIEWING RAY (|cross(newV, n)| = distance between the ray and the tube axis over the radius; the USE_BANDS
@@ -1454,6 +1501,9 @@ __device__ __forceinline__ f4 lv_shade_prism(const LvSceneDev& S, const LvUnifor
             const float gy = phy + ((Iy.b[0] * rot[0] + Iy.b[1] * rot[1]) + Iy.b[2] * rot[2]);
             const float g0 = none.phi + none.rotation;
             none.stripeAaf = fabsf(gx - g0) + fabsf(gy - g0);
+            const float twoPi = 2.0f * 3.14159265358979323846f;
+            none.stripeDx = gx / twoPi - g0 / twoPi;   // dFdx / dFdy of globalPos = (phi + fragmentRotation) / twoPi
+            none.stripeDy = gy / twoPi - g0 / twoPi;
         }
         if (U.uniformHelicityBandWidth) {
             const uint32_t i0 = uint32_t(floorf(fragmentVertexId)), i1 = i0 + 1u;
@@ -1782,11 +1832,21 @@ __device__ __forceinline__ f4 lv_compute_fragment_color_t(const LvSceneDev& S, c
         const float x = bands.phi + bands.rotation + (rasterStripe ? 0.1f : separatorWidth * 0.5f);
         const float varFraction = x - period * floorf(x / period); // mod(x, y) = x - y * floor(x / y)
         const float aaf = rasterStripe ? bands.stripeAaf : EPSILON_OUTLINE * 10.0f;
+        if (U.useTwistTexture) {
+            // USE_HELICITY_BANDS_TEXTURE (RayHitCommon.glsl:465-469, LinePassGeometryShaderTubes.glsl:1043-1047): fragmentColor *=
+            // texture at u = mod(phi + rotation + offset, 2 pi) / 2 pi (all four components: the alpha too)
+            const float twoPi = 2.0f * 3.14159265358979323846f;
+            const float tu = (x - twoPi * floorf(x / twoPi)) / twoPi;
+            const f4 tex = lv_twist_sample(S, U, tu, bands.stripeDx, bands.stripeDy, rasterStripe);
+            phong[0] = phong[0] * tex.x; phong[1] = phong[1] * tex.y; phong[2] = phong[2] * tex.z;
+            fragmentColor.w = fragmentColor.w * tex.w;
+        } else {
         const float alphaBorder1 = smoothstepf(aaf, 0.0f, varFraction);
         const float alphaBorder2 = smoothstepf(separatorWidth - aaf * 0.5f, separatorWidth + aaf * 0.5f, varFraction);
         const float m = fmaxf(alphaBorder1, alphaBorder2);
 #pragma unroll
         for (int k = 0; k < 3; k++) phong[k] = phong[k] * m;
+        }
         WHITE_THRESHOLD = 0.8f; // :485-486
     }
     if (bands.rasterEpsWhite >= 0.0f) {

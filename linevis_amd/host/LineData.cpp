@@ -356,8 +356,21 @@ bool LineDataFlow::setNewSettings(const SettingsMap& settings) {
         dirty = true;
         shallReloadGatherShader = true;
     }
-    // :601-624.  The twist-line texture is not built (its keys are accepted and ignored); UNIFORM_HELICITY_BAND_WIDTH exists in the
-    // triangle closest-hit path only (ClosestHitTubeAnalytic does not pass rotationSeparatorScale, TubeRayTracing.glsl:512-613).
+    // :601-672.  UNIFORM_HELICITY_BAND_WIDTH exists in the triangle closest-hit path and in the raster shaders (ClosestHitTubeAnalytic
+    // does not pass rotationSeparatorScale, TubeRayTracing.glsl:512-613).  Twist-line texture: :626-672 (the file name key is the
+    // embedder's business: setTwistLineTexture takes the decoded pixels)
+    b = useTwistLineTexture;
+    if (settings.getValueOpt("use_twist_line_texture", b) && b != useTwistLineTexture) { useTwistLineTexture = b; dirty = true; shallReloadGatherShader = true; }
+    {
+        static const char* const names[] = {"Nearest", "Linear", "Nearest Mipmap Nearest", "Linear Mipmap Nearest",
+                                            "Nearest Mipmap Linear", "Linear Mipmap Linear"};
+        std::string name;
+        int idx = textureFilteringModeIndex;
+        if (settings.getValueOpt("twist_line_texture_filtering_mode", name))
+            for (int i = 0; i < 6; i++) if (name == names[i]) idx = i;
+        settings.getValueOpt("twist_line_texture_filtering_mode_index", idx);
+        if (idx >= 0 && idx < 6 && idx != textureFilteringModeIndex) { textureFilteringModeIndex = idx; dirty = true; }
+    }
     b = useRotatingHelicityBands;
     if (settings.getValueOpt("rotating_helicity_bands", b) && b != useRotatingHelicityBands) {
         useRotatingHelicityBands = b;
@@ -380,6 +393,16 @@ bool LineDataFlow::setNewSettings(const SettingsMap& settings) {
     f = helicityRotationFactor;
     if (settings.getValueOpt("helicity_rotation_factor", f) && f != helicityRotationFactor) { helicityRotationFactor = f; dirty = true; }
     return shallReloadGatherShader;
+}
+
+void LineDataFlow::setTwistLineTexture(const uint8_t* rgba8, uint32_t width, uint32_t height) {
+    twistLineTexture.clear();
+    twistW = twistH = 0;
+    if (rgba8 && width && height) {
+        twistLineTexture.assign(rgba8, rgba8 + size_t(width) * height * 4);
+        twistW = width; twistH = height;
+    }
+    dirty = true;
 }
 
 // LineDataFlow.cpp:468-578 (flow lines: counts, per-attribute min/max, model AABB)

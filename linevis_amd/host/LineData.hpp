@@ -119,6 +119,10 @@ public:
     virtual uint32_t getNumSubdivisionsBands() const { return 6u; }
     virtual float getHelicityRotationFactor() const { return 1.0f; }
     virtual bool getUseUniformTwistLineWidth() const { return true; }
+    /// USE_HELICITY_BANDS_TEXTURE: use_twist_line_texture && a loaded texture (LineDataFlow.cpp:2437); RGBA8 pixels, filtering mode index
+    virtual bool getUseTwistLineTexture() const { return false; }
+    virtual const std::vector<uint8_t>* getTwistLineTexture(uint32_t& width, uint32_t& height) const { width = height = 0; return nullptr; }
+    virtual int getTwistLineTextureFilteringModeIndex() const { return 5; }
     static bool getRenderThickBands() { return renderThickBands; }   // LineData.cpp:53
     static float getMinBandThickness() { return minBandThickness; }  // LineData.cpp:54
     int getTubeNumSubdivisions() const { return tubeNumSubdivisions; }
@@ -182,6 +186,14 @@ public:
     uint32_t getNumSubdivisionsBands() const override { return numSubdivisionsBands; }
     float getHelicityRotationFactor() const override { return helicityRotationFactor; }
     bool getUseUniformTwistLineWidth() const override { return useUniformTwistLineWidth; }
+    /// LineDataFlow::loadTwistLineTexture (LineDataFlow.cpp:93-171) without the PNG decoder: the embedder hands over the RGBA8 pixels
+    /// (the "twist_line_texture" key of the reference names a file); empty = unloaded
+    void setTwistLineTexture(const uint8_t* rgba8, uint32_t width, uint32_t height);
+    bool getUseTwistLineTexture() const override { return useTwistLineTexture && !twistLineTexture.empty(); }
+    const std::vector<uint8_t>* getTwistLineTexture(uint32_t& width, uint32_t& height) const override {
+        width = twistW; height = twistH; return twistLineTexture.empty() ? nullptr : &twistLineTexture;
+    }
+    int getTwistLineTextureFilteringModeIndex() const override { return textureFilteringModeIndex; }
     bool setNewSettings(const SettingsMap& settings) override;
 
     size_t getNumLines() override { return numTotalTrajectories; }
@@ -198,6 +210,10 @@ private:
     bool hasBandsData = false;
     static bool useRibbons;                            // LineDataFlow.cpp:51
     static bool useRotatingHelicityBands;              // LineDataFlow.cpp:52
+    bool useTwistLineTexture = false;                  // LineDataFlow.hpp: use_twist_line_texture
+    int textureFilteringModeIndex = 5;                 // "Linear Mipmap Linear"
+    std::vector<uint8_t> twistLineTexture;
+    uint32_t twistW = 0, twistH = 0;
     static float separatorWidth;                       // LineDataFlow.cpp:54 (0.2)
     static bool useUniformTwistLineWidth;              // LineDataFlow.cpp:53 (true)
     int helicityAttributeIndex = -1;

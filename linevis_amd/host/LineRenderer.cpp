@@ -411,6 +411,13 @@ bool LineRenderer::uploadFrameState() {
         setOption("separator_width", buf);
         setOption("band_subdivisions", std::to_string(lineData->getNumSubdivisionsBands()));
         setOption("use_uniform_twist_line_width", lineData->getUseUniformTwistLineWidth() ? "true" : "false");
+        {   // USE_HELICITY_BANDS_TEXTURE (LineDataFlow.cpp:974-977,2437-2439)
+            uint32_t tw = 0, th = 0;
+            const std::vector<uint8_t>* tex = lineData->getTwistLineTexture(tw, th);
+            if (!check(lv_set_twist_line_texture(ctx, tex ? tex->data() : nullptr, tw, th), "lv_set_twist_line_texture")) return false;
+            setOption("use_twist_line_texture", lineData->getUseTwistLineTexture() ? "true" : "false");
+            setOption("twist_line_texture_filtering_mode_index", std::to_string(lineData->getTwistLineTextureFilteringModeIndex()));
+        }
         snprintf(buf, sizeof(buf), "%.9g", double(lineData->getHelicityRotationFactor()));
         setOption("helicity_rotation_factor", buf);
         // getVulkanShaderPreprocessorDefines, LineData.cpp:1209-1256

@@ -98,6 +98,9 @@ void lvh_flow_set_settings(void* hp, const char* const* keys, const char* const*
 int lvh_flow_has_helicity(void* hp) { return static_cast<FlowHandle*>(hp)->flow()->getHasHelicity() ? 1 : 0; }
 float lvh_flow_max_helicity(void* hp) { return static_cast<FlowHandle*>(hp)->flow()->getMaxHelicity(); }
 int lvh_flow_use_rotating_helicity_bands(void* hp) { return static_cast<FlowHandle*>(hp)->flow()->getUseRotatingHelicityBands() ? 1 : 0; }
+void lvh_flow_set_twist_line_texture(void* hp, const uint8_t* rgba8, uint32_t w, uint32_t h) {
+    static_cast<FlowHandle*>(hp)->flow()->setTwistLineTexture(rgba8, w, h);
+}
 int lvh_flow_has_bands_data(void* hp) { return static_cast<FlowHandle*>(hp)->flow()->getHasBandsData() ? 1 : 0; }
 /// ribbon directions flattened like lvh_flow_get_trajectories' positions (n * 3 floats); no band data: nothing written
 void lvh_flow_get_ribbon_directions(void* hp, float* out) {

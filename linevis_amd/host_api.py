@@ -35,6 +35,7 @@ def load():
         "lvh_flow_has_helicity": (C.c_int, [vp]),
         "lvh_flow_max_helicity": (C.c_float, [vp]),
         "lvh_flow_use_rotating_helicity_bands": (C.c_int, [vp]),
+        "lvh_flow_set_twist_line_texture": (None, [vp, vp, C.c_uint32, C.c_uint32]),
         "lvh_flow_has_bands_data": (i32, [vp]),
         "lvh_flow_get_ribbon_directions": (None, [vp, vp]),
         "lvh_flow_build_render_data_elliptic": (None, [vp, f32, C.POINTER(u32), C.POINTER(u32)]),
@@ -166,6 +167,15 @@ class LineDataFlow:
     @property
     def max_helicity(self):
         return float(self.L.lvh_flow_max_helicity(self.h))
+
+    def set_twist_line_texture(self, rgba8):
+        """LineDataFlow::loadTwistLineTexture with decoded pixels: (h, w, 4) uint8, or None to unload."""
+        if rgba8 is None:
+            self.L.lvh_flow_set_twist_line_texture(self.h, None, 0, 0)
+        else:
+            img = np.ascontiguousarray(rgba8, dtype=np.uint8)
+            self.L.lvh_flow_set_twist_line_texture(self.h, img.ctypes.data_as(C.c_void_p), img.shape[1], img.shape[0])
+        return self
 
     @property
     def use_rotating_helicity_bands(self):

@@ -678,9 +678,58 @@ inline float capRibbonOfRay(V3 cam, V3 d, V3 hit, V3 hitNormal, V3 centre, V3 t)
 struct BandArgs { bool useBand; float phi; V3 linePosition, lineNormal; float rasterEpsWhite = -1.0f; bool shadeBands = true; };
 // USE_ROTATING_HELICITY_BANDS arguments of computeFragmentColor (RayHitCommon.glsl:82-93): the angle around the tube and the
 // interpolated lineRotation x helicityRotationFactor
+// USE_HELICITY_BANDS_TEXTURE: the twist-line texture (LineDataFlow.cpp:93-171), a test hook like the other global switches.  sampler2D
+// with REPEAT addressing sampled at (u, 0.5): level 0 in the ray tracer's shaders (texture() without derivatives, RayHitCommon.glsl:
+// 66-72), textureGrad(.., (dFdx(globalPos), 0), (dFdy(globalPos), 0)) in the raster shader (LinePassGeometryShaderTubes.glsl:724-730).
+// Build-owned where Vulkan leaves room: texel centres (i + 0.5) / size, linear weights in full float, lambda = log2(max(|dudx|, |dudy|)
+// * width) clamped to the chain, nearest mip = ceil(lambda + 0.5) - 1, chain = intlog2(max(w, h)) levels of 2 x 2 box averages in float.
+static struct TwistTexture {
+    std::vector<float> texels;   // RGBA float, levels back to back
+    uint32_t w = 0, h = 0, levels = 0, mode = 5;
+    bool use = false;
+} g_twist;
+static void twistLevel(uint32_t level, float u, float v, bool linear, float out[4]) {
+    uint32_t w = g_twist.w, h = g_twist.h;
+    size_t base = 0;
+    for (uint32_t l = 0; l < level; l++) { base += size_t(w) * h * 4; w = std::max(w >> 1, 1u); h = std::max(h >> 1, 1u); }
+    const float* T = g_twist.texels.data() + base;
+    auto wrap = [](int i, uint32_t n) { int m = i % int(n); return uint32_t(m < 0 ? m + int(n) : m); };
+    if (!linear) {
+        const uint32_t i = wrap(int(floorf(u * float(w))), w), j = wrap(int(floorf(v * float(h))), h);
+        for (int c = 0; c < 4; c++) out[c] = T[(size_t(j) * w + i) * 4 + c];
+        return;
+    }
+    const float x = u * float(w) - 0.5f, y = v * float(h) - 0.5f;
+    const float fx0 = floorf(x), fy0 = floorf(y);
+    const float a = x - fx0, b = y - fy0;
+    const uint32_t i0 = wrap(int(fx0), w), i1 = wrap(int(fx0) + 1, w), j0 = wrap(int(fy0), h), j1 = wrap(int(fy0) + 1, h);
+    for (int c = 0; c < 4; c++)
+        out[c] = mixf(mixf(T[(size_t(j0) * w + i0) * 4 + c], T[(size_t(j0) * w + i1) * 4 + c], a),
+                      mixf(T[(size_t(j1) * w + i0) * 4 + c], T[(size_t(j1) * w + i1) * 4 + c], a), b);
+}
+static void twistSample(float u, float dudx, float dudy, bool useGrad, float out[4]) {
+    const uint32_t mode = g_twist.mode;
+    const bool linear = mode == 1u || mode == 3u || mode == 5u;
+    const float v = 0.5f;
+    if (mode < 2u || !useGrad || g_twist.levels <= 1u) { twistLevel(0u, u, v, linear, out); return; }
+    const float rho = fmaxf(fabsf(dudx), fabsf(dudy)) * float(g_twist.w);
+    const float maxLevel = float(g_twist.levels - 1u);
+    const float lambda = rho > 1.0f ? fminf(log2Det(rho), maxLevel) : 0.0f;
+    if (mode == 2u || mode == 3u) {
+        const float d = fminf(fmaxf(ceilf(lambda + 0.5f) - 1.0f, 0.0f), maxLevel);
+        twistLevel(uint32_t(d), u, v, linear, out);
+        return;
+    }
+    const float dhi = floorf(lambda), delta = lambda - dhi;
+    const uint32_t lhi = uint32_t(dhi), llo = std::min(lhi + 1u, g_twist.levels - 1u);
+    float a[4], b[4];
+    twistLevel(lhi, u, v, linear, a);
+    twistLevel(llo, u, v, linear, b);
+    for (int c = 0; c < 4; c++) out[c] = mixf(a[c], b[c], delta);
+}
 // rasterAaf >= 0: the raster shader's stripe (LinePassGeometryShaderTubes.glsl:716-721,1046-1052): offset 0.1 instead of w / 2, aaf =
 // fwidth(phi + fragmentRotation) over the pixel quad instead of 10 EPSILON_OUTLINE
-struct HelicityArgs { float phi, fragmentRotation, rotationSeparatorScale; float rasterAaf = -1.0f; };
+struct HelicityArgs { float phi, fragmentRotation, rotationSeparatorScale; float rasterAaf = -1.0f; float dx = 0.0f, dy = 0.0f; };
 inline void computeFragmentColor(const lvo_scene& sc, const lvo_params& P, const Frame& F, float aoTexel, V3 fragPos,
                                  V3 fragmentNormal, V3 fragmentTangent, bool isCap, float fragmentAttribute,
                                  float hitColor[4], float& payloadHitT, const BandArgs* bands = nullptr,
@@ -1021,10 +1070,20 @@ inline void computeFragmentColor(const lvo_scene& sc, const lvo_params& P, const
         const float x = hel->phi + hel->fragmentRotation + (rasterStripe ? 0.1f : separatorWidth * 0.5f);
         const float varFraction = x - period * floorf(x / period); // mod(x, y) = x - y * floor(x / y)
         const float aaf = rasterStripe ? hel->rasterAaf : EPSILON_OUTLINE * 10.0f;
+        if (g_twist.use) {
+            // USE_HELICITY_BANDS_TEXTURE (RayHitCommon.glsl:465-469, LinePassGeometryShaderTubes.glsl:1043-1047): fragmentColor *= texture
+            const float twoPi = 2.0f * 3.14159265358979323846f;
+            const float tu = (x - twoPi * floorf(x / twoPi)) / twoPi;
+            float tex[4];
+            twistSample(tu, hel->dx, hel->dy, rasterStripe, tex);
+            for (int k = 0; k < 3; k++) shaded[k] = shaded[k] * tex[k];
+            shaded[3] = shaded[3] * tex[3];
+        } else {
         const float alphaBorder1 = smoothstepf(aaf, 0.0f, varFraction);
         const float alphaBorder2 = smoothstepf(separatorWidth - aaf * 0.5f, separatorWidth + aaf * 0.5f, varFraction);
         const float m = fmaxf(alphaBorder1, alphaBorder2);
         for (int k = 0; k < 3; k++) shaded[k] = shaded[k] * m;
+        }
         WHITE_THRESHOLD = 0.8f; // :485-486
     }
     if (rasterEpsWhite >= 0.0f) {
@@ -1279,6 +1338,39 @@ inline void sortAndBlend(uint32_t mode, uint32_t* col, float* dep, uint32_t n, u
 
 // ================================================================ exported API
 extern "C" {
+
+void lvo_set_twist_line_texture(const uint8_t* rgba8, uint32_t width, uint32_t height, uint32_t filterMode) {
+    g_twist.use = rgba8 != nullptr;
+    g_twist.texels.clear();
+    if (!rgba8) return;
+    g_twist.w = width; g_twist.h = height; g_twist.mode = filterMode;
+    uint32_t levels = 0;
+    for (uint32_t m = std::max(width, height); m > 1; m >>= 1) levels++;
+    if (levels == 0) levels = 1;
+    g_twist.levels = levels;
+    std::vector<float>& tex = g_twist.texels;
+    for (size_t i = 0; i < size_t(width) * height * 4; i++) tex.push_back(float(rgba8[i]) / 255.0f);
+    size_t prev = 0;
+    uint32_t w = width, h = height;
+    for (uint32_t l = 1; l < levels; l++) {
+        const uint32_t nw = std::max(w >> 1, 1u), nh = std::max(h >> 1, 1u);
+        const size_t cur = tex.size();
+        tex.resize(cur + size_t(nw) * nh * 4);
+        for (uint32_t j = 0; j < nh; j++)
+            for (uint32_t i = 0; i < nw; i++)
+                for (uint32_t c = 0; c < 4; c++) {
+                    const uint32_t i0 = std::min(2 * i, w - 1), i1 = std::min(2 * i + 1, w - 1), j0 = std::min(2 * j, h - 1), j1 = std::min(2 * j + 1, h - 1);
+                    const float a = tex[prev + (size_t(j0) * w + i0) * 4 + c], b = tex[prev + (size_t(j0) * w + i1) * 4 + c];
+                    const float cc = tex[prev + (size_t(j1) * w + i0) * 4 + c], d = tex[prev + (size_t(j1) * w + i1) * 4 + c];
+                    tex[cur + (size_t(j) * nw + i) * 4 + c] = ((a + b) + (cc + d)) * 0.25f;
+                }
+        prev = cur; w = nw; h = nh;
+    }
+}
+void lvo_twist_line_sample(const float* u, const float* dudx, const float* dudy, int useGrad, uint64_t n, float* outRGBA) {
+    for (uint64_t i = 0; i < n; i++) twistSample(u[i], dudx[i], dudy[i], useGrad != 0, outRGBA + 4 * i);
+}
+
 
 uint32_t lvo_tea(uint32_t a, uint32_t b) { return tea(a, b); }
 uint32_t lvo_lcg(uint32_t* s) { return lcg(*s); }

@@ -234,6 +234,10 @@ void lvo_render_ppll(
         uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, uint8_t* outRGBA8, lvo_stats* stats);
 /* a16 test hooks: ring vertices (position, normal; nPts * N * 3 floats each) of the programmable-pull vertex stage, and the
  * per-pixel fragments of the rasterised prism in ascending (segment, triangle) order (lv_oracle_prism.h) */
+/* test hook: the twist-line texture of the rotating helicity bands (USE_HELICITY_BANDS_TEXTURE); rgba8 == NULL switches it off.
+ * filterMode = index into LineDataFlow.cpp:55-57's names. */
+void lvo_set_twist_line_texture(const uint8_t* rgba8, uint32_t width, uint32_t height, uint32_t filterMode);
+void lvo_twist_line_sample(const float* u, const float* dudx, const float* dudy, int useGrad, uint64_t n, float* outRGBA);
 void lvo_set_prism_ring_bands(int useBands, float thickness);
 void lvo_prism_ring_vertices(const lvo_line_point* pts, uint64_t nPts, uint32_t numSubdivisions, float lineWidth, float* outPos,
                              float* outNormal);

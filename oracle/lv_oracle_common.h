@@ -68,6 +68,20 @@ inline float powDet(float x, float y) {
     float r; memcpy(&r, &qb, 4);
     return r;
 }
+// log2(x), x > 0 and normal: the first half of powDet (lv_log2_det of the HIP library)
+inline float log2Det(float x) {
+    uint32_t bits; memcpy(&bits, &x, 4);
+    int e = int((bits >> 23) & 0xFFu) - 127;
+    uint32_t mb = (bits & 0x007FFFFFu) | 0x3F800000u;
+    float m; memcpy(&m, &mb, 4);
+    if (m > 1.41421356f) { m = m * 0.5f; e = e + 1; }
+    const float f = m - 1.0f;
+    const float s = f / (2.0f + f);
+    const float z = s * s;
+    const float P = 0.333333333f + z * (0.2f + z * (0.142857143f + z * 0.111111111f));
+    const float ln = 2.0f * s + (2.0f * s) * (z * P);
+    return float(e) + ln * 1.44269504f;
+}
 // normalize(v) of the shading code as v * (1 / length(v)) (norm3s of the HIP library)
 inline V3 normalizeShade(V3 a) { const float r = 1.0f / length(a); return V3{a.x * r, a.y * r, a.z * r}; }
 

@@ -413,6 +413,9 @@ inline void prismShade(const lvo_scene& sc, const lvo_params& P, const Frame& F,
             }
             const float g0 = hl.phi + hl.fragmentRotation;
             hl.rasterAaf = fabsf(g[0] - g0) + fabsf(g[1] - g0);
+            const float twoPi = 2.0f * 3.14159265358979323846f;
+            hl.dx = g[0] / twoPi - g0 / twoPi;   // dFdx / dFdy of globalPos = (phi + fragmentRotation) / twoPi
+            hl.dy = g[1] / twoPi - g0 / twoPi;
         }
         hl.rotationSeparatorScale = 1.0f;
         if (P.uniformHelicityBandWidth) {

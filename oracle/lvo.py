@@ -179,6 +179,8 @@ def lib():
     L.lvo_bake_ao.argtypes = [vp, vp, f32, i32, i32, vp, u32, u32, u32, u32, f32, i32, vp]
     L.lvo_set_bake_bands.argtypes = [i32, f32, f32]
     L.lvo_set_prism_ring_bands.argtypes = [i32, f32]
+    L.lvo_set_twist_line_texture.argtypes = [vp, u32, u32, u32]
+    L.lvo_twist_line_sample.argtypes = [vp, vp, vp, i32, C.c_uint64, vp]
     L.lvo_render_rt_prebaked.argtypes = [vp, vp, C.POINTER(Params), i32, vp, vp, u32, u32, u32, u32, u32, u32, u32, vp,
                                          C.POINTER(Stats)]
     L.lvo_generate_abc_flow.argtypes = [vp, i32, i32, i32, f32, f32, f32, f32]
@@ -760,6 +762,34 @@ def render_rt_prebaked(scene, tri_scene, P, factors, blending_weights, tile=None
         tri_scene._use_bvh(use_bvh)
     lib().lvo_render_rt_prebaked(scene.h, tri_scene.h if tri_scene is not None else None, C.byref(P), ub, _p(f), _p(bw),
                                  len(bw), f.shape[0], f.shape[1], x0, y0, w, h, _p(out), C.byref(st))
+    return out
+
+
+TWIST_FILTER_MODES = ["Nearest", "Linear", "Nearest Mipmap Nearest", "Linear Mipmap Nearest", "Nearest Mipmap Linear", "Linear Mipmap Linear"]
+
+
+class twist_line_texture:
+    """Context manager: USE_HELICITY_BANDS_TEXTURE with the given RGBA8 image (h, w, 4) and filtering mode name."""
+    def __init__(self, rgba8, mode="Linear Mipmap Linear"):
+        self.img = np.ascontiguousarray(rgba8, dtype=np.uint8)
+        self.mode = TWIST_FILTER_MODES.index(mode)
+
+    def __enter__(self):
+        lib().lvo_set_twist_line_texture(_p(self.img), self.img.shape[1], self.img.shape[0], self.mode)
+        return self
+
+    def __exit__(self, *a):
+        lib().lvo_set_twist_line_texture(None, 0, 0, 0)
+
+
+def twist_line_sample(u, dudx=None, dudy=None):
+    """Samples of the currently set twist-line texture at (u, 0.5): without derivatives level 0, else textureGrad."""
+    u = np.ascontiguousarray(u, dtype=np.float32)
+    grad = dudx is not None
+    dx = np.ascontiguousarray(dudx if grad else np.zeros_like(u), dtype=np.float32)
+    dy = np.ascontiguousarray(dudy if grad else np.zeros_like(u), dtype=np.float32)
+    out = np.empty((len(u), 4), dtype=np.float32)
+    lib().lvo_twist_line_sample(_p(u), _p(dx), _p(dy), int(grad), len(u), _p(out))
     return out
 
 

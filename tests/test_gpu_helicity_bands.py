@@ -133,5 +133,50 @@ def test_from_the_streamline_tracer_through_the_plugin_surface(hip_lib):
             P = c.oracle_params(sc)
             P.attrMin, P.attrMax = lo, hi
             assert max_lsb_diff(frames[mode], sc.render_rt(P, use_bvh=True)) <= 2
+    # the twist-line texture through the plugin: the data set holds the pixels, the renderer uploads them with the switches
+    from test_helicity_bands import _twist_image
+    tex = _twist_image(w=64, h=4)
+    flow.set_twist_line_texture(tex)
+    r.set_line_data(flow)
+    r.set_new_settings(dict(use_twist_line_texture=True, twist_line_texture_filtering_mode="Linear Mipmap Nearest"))
+    textured = r.render_frame()
+    ctx.set_twist_line_texture(tex)
+    ctx.set_options(dict(use_twist_line_texture=True, twist_line_texture_filtering_mode="Linear Mipmap Nearest"))
+    assert np.array_equal(textured, ctx.render(2)) and not np.array_equal(textured, frames[2])
     r.set_new_settings(dict(rotating_helicity_bands=False))
     assert not np.array_equal(r.render_frame(), frames[2])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["Nearest", "Linear", "Nearest Mipmap Nearest", "Linear Mipmap Nearest", "Nearest Mipmap Linear",
+                                  "Linear Mipmap Linear"])
+def test_twist_line_texture(hip_lib, mode):
+    """USE_HELICITY_BANDS_TEXTURE: lv_set_twist_line_texture + use_twist_line_texture replace the separator stripes by the texture
+    (all four components).  Ray tracer: level 0 (texture() without derivatives); mode 2 on the rasterised prism: textureGrad with the
+    quad's derivatives of (phi + fragmentRotation) / 2 pi -- per-pixel lists bit for bit, frames <= 2 LSB, for every filtering mode."""
+    from test_helicity_bands import _twist_image
+    from test_prism_raster import _walk_order
+    img_tex = _twist_image(w=128, h=8)
+    c, _, _ = helicity_case(width=120, height=90, transparent=True, use_twist_line_texture=True, twist_line_texture_filtering_mode=mode)
+    ctx = c.hip_context()
+    ctx.set_twist_line_texture(img_tex)
+    sc = c.oracle_scene()
+    P = c.oracle_params(sc)
+    rt = ctx.render(11)
+    with lvo.twist_line_texture(img_tex, mode):
+        ref = sc.render_rt(P)
+        on, os_, ocnt = sc.ppll_gather(P)
+        pref = sc.render_ppll(P)
+    assert max_lsb_diff(rt, ref) <= 2
+    pimg = ctx.render(2)
+    pw, ph = c.padded()
+    hn, hs, hcnt = ctx.ppll_buffers(pw * ph, int(P.ppllLinkedListSize))
+    assert hcnt == ocnt and _walk_order(hn, hs) == _walk_order(on, os_)
+    assert max_lsb_diff(pimg, pref) <= 2
+    ctx.set_option("use_twist_line_texture", False)            # back to the stripes
+    assert not np.array_equal(ctx.render(11), rt)
+    ctx.set_option("use_twist_line_texture", True)
+    ctx.set_twist_line_texture(None)                            # unloaded: the define is off (LineDataFlow.cpp:2437), stripes again
+    assert not np.array_equal(ctx.render(11), rt)
+    with pytest.raises(Exception):
+        ctx.set_option("twist_line_texture_max_anisotropy", 4)

@@ -143,3 +143,64 @@ def test_oracle_stripes_against_a_float64_restatement():
     assert checked > 250
     dark = (a[..., :3].sum(axis=2) < 0.5 * b[..., :3].sum(axis=2)).sum()
     assert dark > 100                                                     # the separators are there
+
+
+def _twist_image(w=64, h=4, seed=2):
+    rng = np.random.default_rng(seed)
+    img = rng.integers(0, 256, size=(h, w, 4), dtype=np.uint8)
+    img[..., 3] = rng.integers(128, 256, size=(h, w))
+    return img
+
+
+def test_twist_line_texture_sampling_against_numpy():
+    """The build-owned sampler of the twist-line texture (USE_HELICITY_BANDS_TEXTURE): REPEAT addressing, texel centres at (i + 0.5) / size,
+    v = 0.5; level 0 for the ray tracer; textureGrad: lambda = log2(max(|dudx|, |dudy|) w), nearest mip = ceil(lambda + 0.5) - 1, the
+    chain = 2 x 2 box averages -- against a float64 restatement."""
+    img = _twist_image()
+    h, w = img.shape[:2]
+    levels = [img.astype(np.float64) / 255.0]
+    while len(levels) < int(np.log2(max(w, h))):
+        a = levels[-1]
+        hh, ww = max(a.shape[0] // 2, 1), max(a.shape[1] // 2, 1)
+        ii = np.minimum(np.arange(ww)[:, None] * 2 + np.arange(2)[None, :], a.shape[1] - 1)
+        jj = np.minimum(np.arange(hh)[:, None] * 2 + np.arange(2)[None, :], a.shape[0] - 1)
+        levels.append(np.stack([[a[jj[j]][:, ii[i]].mean(axis=(0, 1)) for i in range(ww)] for j in range(hh)]))
+
+    def level(l, u, linear):
+        a = levels[l]
+        hh, ww = a.shape[:2]
+        if not linear:
+            return a[int(np.floor(0.5 * hh)) % hh, np.floor(u * ww).astype(int) % ww]
+        x, y = u * ww - 0.5, 0.5 * hh - 0.5
+        i0, j0 = np.floor(x).astype(int), int(np.floor(y))
+        fx, fy = (x - i0)[:, None], y - j0
+        r0 = a[j0 % hh, i0 % ww] * (1 - fx) + a[j0 % hh, (i0 + 1) % ww] * fx
+        r1 = a[(j0 + 1) % hh, i0 % ww] * (1 - fx) + a[(j0 + 1) % hh, (i0 + 1) % ww] * fx
+        return r0 * (1 - fy) + r1 * fy
+
+    rng = np.random.default_rng(4)
+    u = rng.random(400).astype(np.float32)
+    dx = (rng.random(400) * 0.2).astype(np.float32) * (rng.random(400) < 0.8)
+    dy = (rng.random(400) * 0.05).astype(np.float32)
+    for mode in lvo.TWIST_FILTER_MODES:
+        linear = mode.startswith("Linear")
+        with lvo.twist_line_texture(img, mode):
+            got0 = lvo.twist_line_sample(u)
+            got = lvo.twist_line_sample(u, dx, dy)
+        assert np.abs(got0 - level(0, u.astype(np.float64), linear)).max() < 2e-6
+        rho = np.maximum(np.abs(dx), np.abs(dy)).astype(np.float64) * w
+        lam = np.clip(np.log2(np.maximum(rho, 1.0)), 0, len(levels) - 1)
+        if "Mipmap" not in mode:
+            want = level(0, u.astype(np.float64), linear)
+        elif mode.endswith("Mipmap Nearest"):
+            d = np.clip(np.ceil(lam + 0.5) - 1, 0, len(levels) - 1).astype(int)
+            edge = np.abs((lam + 0.5) - np.round(lam + 0.5)) < 1e-4       # level switches: float32 log2 may fall on the other side
+            want = np.stack([level(int(d[k]), u[k:k + 1].astype(np.float64), linear)[0] for k in range(len(u))])
+            got, want = got[~edge], want[~edge]
+        else:
+            lo = np.floor(lam).astype(int)
+            hi = np.minimum(lo + 1, len(levels) - 1)
+            t = (lam - lo)[:, None]
+            want = np.stack([level(int(lo[k]), u[k:k + 1].astype(np.float64), linear)[0] for k in range(len(u))]) * (1 - t) + \
+                np.stack([level(int(hi[k]), u[k:k + 1].astype(np.float64), linear)[0] for k in range(len(u))]) * t
+        assert np.abs(got - want).max() < 5e-5, mode
