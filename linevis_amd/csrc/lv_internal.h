@@ -193,6 +193,7 @@ struct lv_ctx {
     uint32_t ppllScanBlocks = 0;              // raster_prism: workgroups of the last k_ppll_scan (scanTemp = totals, bases, counter)
     LvDeviceBuffer twistTex;                  // twist-line texture: float4 texels, mip levels back to back
     uint32_t twistW = 0, twistH = 0, twistLevels = 0;
+    LvDeviceBuffer ppllCoarse;                // raster_prism, sharded frames: 32 x 32-pixel cells that hold requested pixels (k_ppll_mark_tiles)
     LvDeviceBuffer ppllOverflow;              // raster_prism: pixel addresses with more kept fragments than ppllMaxNumFrags (k_ppll_pixel_pass)
     bool ppllArrays = false;                  // the last PPLL frame left per-pixel runs (raster_prism), not linked lists
     LvDeviceBuffer tilesDev, outDev, scratchRays, stackOverflow, mlatTrace;

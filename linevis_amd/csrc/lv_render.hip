@@ -1102,6 +1102,7 @@ __global__ __launch_bounds__(LV_BLOCK, LV_PRISM_SHADE_MIN_WAVES) void k_ppll_sha
 //                       a pixel's fragments is therefore not defined -- as in the reference, whose fragment shader invocations race
 //                       on atomicExchange(startOffset) -- and nothing downstream depends on it: the resolve pass orders by the
 //                       (depth, colour) key and, where a pixel holds more fragments than the sort arrays, keeps the nearest ones.
+#define LV_PRISM_COARSE 32u
 #define LV_PRISM_BBOX_MARGIN 0.015625f   // 1/64 pixel: two orders of magnitude above the rounding of the projection at 4K
 #ifndef LV_PRISM_RASTER_CHUNK
 #define LV_PRISM_RASTER_CHUNK 512u      // record slots a wave reserves per global atomic
@@ -1114,10 +1115,15 @@ __global__ __launch_bounds__(LV_BLOCK, LV_PRISM_SHADE_MIN_WAVES) void k_ppll_sha
 #endif
 template <bool STATS>
 __global__ __launch_bounds__(LV_BLOCK) void k_ppll_mark_tiles(const LvUniforms U, const LvTiles T, uint32_t* __restrict__ startOffset,
-                                                              LvDevCounters* dc) {
+                                                              uint32_t* __restrict__ coarse, LvDevCounters* dc) {
     LvPixel px;
     if (!lv_block_pixel(U, T, px)) return;
-    if (px.inView) startOffset[lv_ppll_addr(px.x, px.y, U.ppllPaddedW, U.ppllTileW, U.ppllTileH)] = 0u;
+    if (px.inView) {
+        startOffset[lv_ppll_addr(px.x, px.y, U.ppllPaddedW, U.ppllTileW, U.ppllTileH)] = 0u;
+        // coarse map (LV_PRISM_COARSE-pixel cells): which parts of the viewport hold requested pixels at all -- the segment rasteriser of a
+        // rank of a sharded frame drops the segments that project elsewhere before their set-up
+        coarse[(px.y / LV_PRISM_COARSE) * ((U.width + LV_PRISM_COARSE - 1u) / LV_PRISM_COARSE) + px.x / LV_PRISM_COARSE] = 1u;
+    }
     if (STATS) {   // one viewing ray per requested pixel: the rays whose coverage the rasteriser decides
         const unsigned long long n = (unsigned long long)__popcll(__ballot(px.inView));
         if (lv_lane() == 0 && n) atomicAdd(&dc->rays, n);
@@ -1337,7 +1343,8 @@ __global__ __launch_bounds__(LV_BLOCK, LV_PRISM_RASTER_MIN_WAVES) void k_ppll_ra
                                                                    uint32_t* __restrict__ records,
                                                                    const uint32_t* __restrict__ startOffset,
                                                                    uint32_t* __restrict__ fragCount, LvDevCounters* dc,
-                                                                   uint32_t poolSlots) {
+                                                                   uint32_t poolSlots, uint32_t allRequested,
+                                                                   const uint32_t* __restrict__ coarse) {
     // Two stages per wave, joined by a queue in LDS:
     //  A  one lane per segment: the candidate pixels of its screen rectangle that also lie in the ORIENTED box of the projected ring
     //     vertices (axis = the projected segment; a 1 x 3-pixel segment at 45 degrees fills a third of its rectangle) and in a
@@ -1388,8 +1395,7 @@ __global__ __launch_bounds__(LV_BLOCK, LV_PRISM_RASTER_MIN_WAVES) void k_ppll_ra
             pix = qPix[q];
             const uint32_t px = pix & 0xFFFFu, py = pix >> 16;
             addr = lv_ppll_addr(px, py, U.ppllPaddedW, U.ppllTileW, U.ppllTileH);
-            // (the requested-tile test sits here, beside the segment's loads: in stage A every iteration would wait for it)
-            const uint32_t requested = startOffset[addr];
+            // (no requested-tile test here: a whole-viewport frame requests every pixel, a rank of a sharded frame filters in stage A)
             f3 oo, d;
             lv_primary_ray(U, px, py, 0.5f, 0.5f, oo, d);
             const uint32_t sl = leaf - leafBaseCur;   // the pair's segment among the wave's 64
@@ -1403,8 +1409,7 @@ __global__ __launch_bounds__(LV_BLOCK, LV_PRISM_RASTER_MIN_WAVES) void k_ppll_ra
                 pi[e] = __float_as_uint(segLds[18 + e][sl]);
             }
             mask = lv_prism_coverage_pts<NT>(R, pt, pi, R.radius, o, d);
-            if (requested != 0u) mask = 0u;
-            else if (STATS) tests++;
+            if (STATS) tests++;
         }
         while (__any(mask != 0u)) {
             const bool hit = mask != 0u;
@@ -1464,6 +1469,38 @@ __global__ __launch_bounds__(LV_BLOCK, LV_PRISM_RASTER_MIN_WAVES) void k_ppll_ra
             uint32_t pi[2];
             LvPrismPoint pt[2];
             lv_prism_frames(S, leaf, pa, pb, pt, pi);
+            bool mine = true;
+            if (!allRequested) {
+                // sharded frame: does the segment project into a coarse cell with requested pixels?  Both line points with a generous
+                // bound of the projected radius (the prism lies within `radius` of the segment); near the camera plane: undecided = yes
+                float lo[2] = {3.0e38f, 3.0e38f}, hi[2] = {-3.0e38f, -3.0e38f};
+                bool decided = true;
+#pragma unroll
+                for (int e = 0; e < 2; e++) {
+                    const f3 v = pt[e].centre;
+                    const float cw = ((mw[0] * v.x + mw[1] * v.y) + mw[2] * v.z) + mw[3];
+                    if (!(cw > 4.0f * R.radius + wEps)) { decided = false; continue; }
+                    const float ccx = ((mx[0] * v.x + mx[1] * v.y) + mx[2] * v.z) + mx[3];
+                    const float ccy = ((my[0] * v.x + my[1] * v.y) + my[2] * v.z) + my[3];
+                    const float sx = (ccx / cw + 1.0f) * halfW, sy = (ccy / cw + 1.0f) * halfH;
+                    // |d screen| <= f r / (w - r) (1 + |x / w|) for a point within r of the centre: tangent of the off-axis angle from the
+                    // centre's own clip coordinates, 25 % and 2 pixels on top
+                    const float tanOff = fabsf(ccx / cw) / fabsf(U.proj[0]) + fabsf(ccy / cw) / fabsf(U.proj[5]);
+                    const float rp = 1.25f * (1.0f + tanOff) * R.radius * fmaxf(fabsf(U.proj[0]) * halfW, fabsf(U.proj[5]) * halfH) / (cw - R.radius) + 2.0f;
+                    lo[0] = fminf(lo[0], sx - rp); hi[0] = fmaxf(hi[0], sx + rp); lo[1] = fminf(lo[1], sy - rp); hi[1] = fmaxf(hi[1], sy + rp);
+                }
+                if (decided) {
+                    const float cwid = float((U.width + LV_PRISM_COARSE - 1u) / LV_PRISM_COARSE), chgt = float((U.height + LV_PRISM_COARSE - 1u) / LV_PRISM_COARSE);
+                    const float c0x = fmaxf(floorf(lo[0] / float(LV_PRISM_COARSE)), 0.0f), c1x = fminf(floorf(hi[0] / float(LV_PRISM_COARSE)), cwid - 1.0f);
+                    const float c0y = fmaxf(floorf(lo[1] / float(LV_PRISM_COARSE)), 0.0f), c1y = fminf(floorf(hi[1] / float(LV_PRISM_COARSE)), chgt - 1.0f);
+                    mine = false;
+                    if (c1x - c0x <= 3.0f && c1y - c0y <= 3.0f) {
+                        for (float cy = c0y; cy <= c1y; cy += 1.0f)
+                            for (float cx = c0x; cx <= c1x; cx += 1.0f) mine = mine || coarse[uint32_t(cy) * uint32_t(cwid) + uint32_t(cx)] != 0u;
+                    } else mine = c0x <= c1x && c0y <= c1y;   // (a large footprint: not worth the look-ups)
+                }
+            }
+            if (mine) {
 #pragma unroll
             for (int e = 0; e < 2; e++) {
                 segLds[9 * e + 0][lane] = pt[e].centre.x; segLds[9 * e + 1][lane] = pt[e].centre.y; segLds[9 * e + 2][lane] = pt[e].centre.z;
@@ -1522,6 +1559,7 @@ __global__ __launch_bounds__(LV_BLOCK, LV_PRISM_RASTER_MIN_WAVES) void k_ppll_ra
                 const float fy1 = fminf(floorf(hiy + LV_PRISM_BBOX_MARGIN - 0.5f), float(U.height) - 1.0f);
                 if (fx0 <= fx1 && fy0 <= fy1) { x0 = int(fx0); x1 = int(fx1); y0 = int(fy0); y1 = int(fy1); }
             }
+            }   // mine
         }
         int px = x0, py = y0;
         bool more = valid && x1 >= x0 && y1 >= y0;
@@ -1530,6 +1568,8 @@ __global__ __launch_bounds__(LV_BLOCK, LV_PRISM_RASTER_MIN_WAVES) void k_ppll_ra
             if (more) {
                 const float qx = (float(px) + 0.5f) - cx0, qy = (float(py) + 0.5f) - cy0;
                 cand = fabsf((qx * ax + qy * ay) - aMid) <= aHalf && fabsf((qy * ax - qx * ay) - nMid) <= nHalf;
+                if (cand && !allRequested)
+                    cand = startOffset[lv_ppll_addr(uint32_t(px), uint32_t(py), U.ppllPaddedW, U.ppllTileW, U.ppllTileH)] == 0u;
             }
             const unsigned long long cm = __ballot(cand);
             if (cand) {
@@ -2729,12 +2769,20 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
     } while (0)
         if (segmentRaster) {
             // the segment rasteriser (k_ppll_raster_prism): requested pixels marked, then one lane per segment
+            uint32_t* coarse = nullptr;
+            if (!allRequested) {
+                const size_t cells = size_t((U.width + LV_PRISM_COARSE - 1u) / LV_PRISM_COARSE) * ((U.height + LV_PRISM_COARSE - 1u) / LV_PRISM_COARSE);
+                if ((rc = lv_buf_reserve(ctx, ctx->ppllCoarse, cells * 4))) return rc;
+                coarse = (uint32_t*)ctx->ppllCoarse.ptr;
+                LV_HIP(ctx, hipMemsetAsync(coarse, 0, cells * 4, st));
+            }
 #define LV_LAUNCH_RASTER(ST, NT)                                                                                              \
     LV_TIMED_LAUNCH(ctx, LV_KERNEL_PPLL_RASTER, (k_ppll_raster_prism<ST, NT><<<rasterGrid, LV_BLOCK, 0, st>>>(                \
-            U, S, gatherPool, (const uint32_t*)ctx->ppllStart.ptr, (uint32_t*)ctx->ppllCount.ptr, dc, poolSlots)))
+            U, S, gatherPool, (const uint32_t*)ctx->ppllStart.ptr, (uint32_t*)ctx->ppllCount.ptr, dc, poolSlots,                \
+            allRequested ? 1u : 0u, coarse)))
             if (allRequested) {}   // (k_ppll_clear marked every pixel)
-            else if (stats) k_ppll_mark_tiles<true><<<gridTiles, LV_BLOCK, 0, st>>>(U, T, (uint32_t*)ctx->ppllStart.ptr, dc);
-            else k_ppll_mark_tiles<false><<<gridTiles, LV_BLOCK, 0, st>>>(U, T, (uint32_t*)ctx->ppllStart.ptr, dc);
+            else if (stats) k_ppll_mark_tiles<true><<<gridTiles, LV_BLOCK, 0, st>>>(U, T, (uint32_t*)ctx->ppllStart.ptr, coarse, dc);
+            else k_ppll_mark_tiles<false><<<gridTiles, LV_BLOCK, 0, st>>>(U, T, (uint32_t*)ctx->ppllStart.ptr, coarse, dc);
             if (S.numSegs != 0) {
                 if (S.prism.n == 6u) { if (stats) LV_LAUNCH_RASTER(true, 6); else LV_LAUNCH_RASTER(false, 6); }
                 else { if (stats) LV_LAUNCH_RASTER(true, 0); else LV_LAUNCH_RASTER(false, 0); }
