@@ -362,6 +362,27 @@ int lv_trace_streamlines(lv_ctx* ctx, const float* seed_points, uint32_t num_see
 /* positions: 3 floats per point; attributes: [num_scalar_fields][num_points]; line_offsets: num_lines + 1.  Any pointer
  * may be NULL. */
 int lv_get_streamlines(lv_ctx* ctx, float* positions, float* attributes, uint32_t* line_offsets);
+
+/* StreamlineMaxHelicityFirstSeeder + StreamlineTracingGrid::_traceStreamribbonsDecreasingHelicity (StreamlineSeeder.cpp:360-529,
+ * StreamlineTracingGrid.cpp:546-860; Rees et al., "A stream ribbon seeding strategy", EuroVis 2017): the grid points (or, with a
+ * subsampling factor, the centres of blocks of cells) are seeded in the order of falling helicity; a line ends where it enters a
+ * cell within minimum_separation_distance of an earlier line's point, and a sample whose cell is taken is skipped.  The reference
+ * traces these lines one after the other on the CPU; here batches of the next seeds are traced speculatively in parallel on the GPU
+ * and committed in seeding order on the host, each line cut where an earlier line of its batch claimed the cell first -- the same
+ * lines, point for point.  Built: termination_check_type 1 (grid-based, the reference's default), loop_check_mode 0 (none) / 1 (start
+ * point, the default); not built: the naive / k-d tree / hashed-grid checks, the other loop checks, Runge-Kutta-Fehlberg (its step
+ * width carries over from line to line in the reference).  helicity_field: xs * ys * zs floats (computeHelicityFieldNormalized).
+ * The result is fetched with lv_get_streamlines like lv_trace_streamlines'. */
+typedef struct lv_helicity_seeding_settings {
+    float minimum_separation_distance;   /* 0.08, StreamlineTracingDefines.hpp:158 */
+    uint32_t termination_check_type;      /* TerminationCheckType :89-94: 1 = grid-based */
+    uint32_t loop_check_mode;             /* LoopCheckMode :99-101: 0 none, 1 start point */
+    float termination_distance_self;      /* 1.0 (:156): start-point loop check within |box| / 100 times this */
+    int32_t seeding_subsampling_factor;   /* 1 (:174) */
+} lv_helicity_seeding_settings;
+int lv_trace_streamlines_max_helicity_first(lv_ctx* ctx, const float* helicity_field, const lv_streamline_settings* settings,
+                                            const lv_helicity_seeding_settings* seeding, uint64_t* out_num_lines,
+                                            uint64_t* out_num_points);
 /* Per line of the last result: the index of the seed point inside the merged line (0 for forward lines, the last point for
  * backward ones, behind the reversed backward part otherwise).  Streamribbons carry their ribbon direction outwards from the
  * seed in both parts (StreamlineTracingGrid::traceStreamribbons, StreamlineTracingGrid.cpp:428-530). */

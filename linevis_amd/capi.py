@@ -57,6 +57,17 @@ class StreamlineSettings(C.Structure):
                 ("termination_distance", C.c_float), ("minimum_length", C.c_float)]
 
 
+class HelicitySeedingSettings(C.Structure):
+    """lv_helicity_seeding_settings (the seeder-related members of StreamlineTracingSettings, StreamlineTracingDefines.hpp:156-174)."""
+    _fields_ = [("minimum_separation_distance", C.c_float), ("termination_check_type", C.c_uint32), ("loop_check_mode", C.c_uint32),
+                ("termination_distance_self", C.c_float), ("seeding_subsampling_factor", C.c_int32)]
+
+    def __init__(self, minimum_separation_distance=0.08, termination_check_type=1, loop_check_mode=1, termination_distance_self=1.0,
+                 seeding_subsampling_factor=1):
+        super().__init__(minimum_separation_distance, termination_check_type, loop_check_mode, termination_distance_self,
+                         seeding_subsampling_factor)
+
+
 # STREAMLINE_INTEGRATION_METHOD_NAMES / ..._DIRECTION_NAMES, StreamlineTracingDefines.hpp:77-88
 INTEGRATION_METHODS = {"Explicit Euler": 0, "Implicit Euler": 1, "Heun": 2, "Midpoint": 3, "Runge-Kutta 4th Order": 4,
                        "Runge-Kutta-Fehlberg": 5}
@@ -85,7 +96,7 @@ SYMBOLS = ["lv_create", "lv_destroy", "lv_last_error", "lv_version", "lv_set_str
            "lv_set_transfer_function", "lv_set_twist_line_texture", "lv_set_camera", "lv_set_background", "lv_set_option", "lv_build_accel",
            "lv_render", "lv_render_device", "lv_render_tiles_device", "lv_get_stats", "lv_reset_timers", "lv_get_kernel_times", "lv_get_ao_tile_costs", "lv_get_dispatch_order", "lv_trace_rays",
            "lv_compute_depth_range", "lv_get_ao", "lv_ppll_get_buffers", "lv_ppll_resolve_buffers", "lv_get_accel",
-           "lv_set_tube_triangle_mesh", "lv_trace_rays_triangles", "lv_set_flow_grid", "lv_trace_streamlines",
+           "lv_set_tube_triangle_mesh", "lv_trace_rays_triangles", "lv_set_flow_grid", "lv_trace_streamlines", "lv_trace_streamlines_max_helicity_first",
            "lv_get_streamlines", "lv_get_streamline_seed_indices", "lv_set_ao_parametrization", "lv_get_baked_ao", "lv_bake_ao_start", "lv_bake_ao_poll", "lv_get_mlat_trace",
            "lv_create_multi", "lv_multi_ranks", "lv_multi_rank_stats", "lv_multi_rebalance", "lv_multi_deal", "lv_tile_deal", "lv_make_tiles"]
 
@@ -158,6 +169,8 @@ def load():
         ("lv_trace_rays_triangles", [vp, vp, vp, f32, f32, u32, vp, vp, vp]),
         ("lv_set_flow_grid", [vp, vp, u32, u32, u32, f32, f32, f32, vp, u32]),
         ("lv_trace_streamlines", [vp, vp, u32, C.POINTER(StreamlineSettings), C.POINTER(u64), C.POINTER(u64)]),
+        ("lv_trace_streamlines_max_helicity_first", [vp, vp, C.POINTER(StreamlineSettings), C.POINTER(HelicitySeedingSettings),
+                                                     C.POINTER(u64), C.POINTER(u64)]),
         ("lv_get_streamlines", [vp, vp, vp, vp]),
         ("lv_get_streamline_seed_indices", [vp, vp]),
         ("lv_set_ao_parametrization", [vp, vp, u32, vp, u32]),
@@ -368,6 +381,19 @@ class Context:
         sd = np.ascontiguousarray(seeds, dtype=np.float32).reshape(-1, 3)
         nl, npt = C.c_uint64(), C.c_uint64()
         self._ck(self.L.lv_trace_streamlines(self.h, _p(sd), len(sd), C.byref(settings), C.byref(nl), C.byref(npt)))
+        pos = np.zeros((npt.value, 3), dtype=np.float32)
+        att = np.zeros((self._flow_scalars, npt.value), dtype=np.float32)
+        off = np.zeros(nl.value + 1, dtype=np.uint32)
+        self._ck(self.L.lv_get_streamlines(self.h, _p(pos), _p(att), _p(off)))
+        return pos, att, off
+
+    def trace_streamlines_max_helicity_first(self, helicity_field, settings, seeding=None):
+        """StreamlineMaxHelicityFirstSeeder: helicity_field [zs, ys, xs] -> (positions [P,3], attributes [k,P], line_offsets [L+1])"""
+        hf = np.ascontiguousarray(helicity_field, dtype=np.float32)
+        seeding = seeding or HelicitySeedingSettings()
+        nl, npt = C.c_uint64(), C.c_uint64()
+        self._ck(self.L.lv_trace_streamlines_max_helicity_first(self.h, _p(hf), C.byref(settings), C.byref(seeding), C.byref(nl),
+                                                                C.byref(npt)))
         pos = np.zeros((npt.value, 3), dtype=np.float32)
         att = np.zeros((self._flow_scalars, npt.value), dtype=np.float32)
         off = np.zeros(nl.value + 1, dtype=np.uint32)

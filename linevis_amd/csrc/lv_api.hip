@@ -100,7 +100,7 @@ static std::vector<LvDeviceBuffer*> lv_all_buffers(lv_ctx* ctx) {
             &ctx->eawPing, &ctx->eawPong, &ctx->tilesHaloDev, &ctx->fullFrameTile, &ctx->svgf.normalDepth, &ctx->svgf.normalDepthHistory,
             &ctx->svgf.flowFwidth, &ctx->svgf.moments, &ctx->svgf.momentsHistory, &ctx->svgf.colorHistory, &ctx->svgf.tempAccum,
             &ctx->svgf.tempAccumFiltered, &ctx->svgf.ping, &ctx->svgf.pong, &ctx->svgf.result, &ctx->aoGbuf, &ctx->aoList, &ctx->aoSamples,
-            &ctx->counters, &ctx->ppllNodes, &ctx->ppllStart, &ctx->ppllCount, &ctx->ppllScratch, &ctx->prismRecords, &ctx->scanTemp, &ctx->ppllOverflow, &ctx->ppllCoarse, &ctx->twistTex, &ctx->tilesDev, &ctx->outDev,
+            &ctx->counters, &ctx->ppllNodes, &ctx->ppllStart, &ctx->ppllCount, &ctx->ppllScratch, &ctx->prismRecords, &ctx->scanTemp, &ctx->ppllOverflow, &ctx->ppllCoarse, &ctx->flowOccupancy, &ctx->twistTex, &ctx->tilesDev, &ctx->outDev,
             &ctx->scratchRays, &ctx->stackOverflow, &ctx->triIdx, &ctx->triVerts, &ctx->triPoints, &ctx->triNodes, &ctx->tris,
             &ctx->flowVectors, &ctx->flowScalars, &ctx->flowMisc, &ctx->flowSeeds, &ctx->flowOutPos, &ctx->flowOutAtt, &ctx->flowCounts,
             &ctx->bakeBlendingWeights, &ctx->bakeSamplingLocations, &ctx->bakedAo, &ctx->bakeLcgSkip, &ctx->bakedAoPending, &ctx->bakeCounters,
@@ -942,6 +942,34 @@ int lv_trace_streamlines(lv_ctx* ctx, const float* seed_points, uint32_t num_see
     if (!(ctx->flowMaxMagnitude > 0.0f)) return lv_fail(ctx, LV_E_STATE, "the vector field is zero everywhere");
     (void)hipSetDevice(ctx->device);
     int rc = lv_flow_trace(ctx, seed_points, num_seeds, settings);
+    if (rc) return rc;
+    if (out_num_lines) *out_num_lines = ctx->flowOffsets.size() - 1;
+    if (out_num_points) *out_num_points = ctx->flowPositions.size() / 3;
+    return LV_OK;
+}
+
+int lv_trace_streamlines_max_helicity_first(lv_ctx* ctx, const float* helicity_field, const lv_streamline_settings* settings,
+                                            const lv_helicity_seeding_settings* seeding, uint64_t* out_num_lines,
+                                            uint64_t* out_num_points) {
+    if (!ctx) return LV_E_INVALID;
+    if (!ctx->flowGridSet) return lv_fail(ctx, LV_E_STATE, "lv_set_flow_grid has not been called");
+    if (!settings || !seeding || !helicity_field) return lv_fail(ctx, LV_E_INVALID, "null argument");
+    if (settings->integration_method > 4u)
+        return lv_fail(ctx, LV_E_INVALID, "max-helicity-first seeding: integration method %u is not built (0 ... 4; the adaptive step "
+                                          "of Runge-Kutta-Fehlberg carries over from line to line)", settings->integration_method);
+    if (settings->integration_direction > 2u) return lv_fail(ctx, LV_E_INVALID, "integration direction must be 0, 1 or 2");
+    if (!(settings->time_step_scale > 0.0f) || settings->max_num_iterations <= 0 || settings->max_num_iterations > 1000000)
+        return lv_fail(ctx, LV_E_INVALID, "time_step_scale must be > 0 and max_num_iterations in 1..1e6");
+    if (seeding->termination_check_type != 1u)
+        return lv_fail(ctx, LV_E_INVALID, "termination_check_type %u is not built (1 = grid-based)", seeding->termination_check_type);
+    if (seeding->loop_check_mode > 1u)
+        return lv_fail(ctx, LV_E_INVALID, "loop_check_mode %u is not built (0 none, 1 start point)", seeding->loop_check_mode);
+    if (!(seeding->minimum_separation_distance >= 0.0f) || seeding->seeding_subsampling_factor < 1)
+        return lv_fail(ctx, LV_E_INVALID, "minimum_separation_distance must be >= 0 and seeding_subsampling_factor >= 1");
+    if (!(ctx->flowMaxMagnitude > 0.0f)) return lv_fail(ctx, LV_E_STATE, "the vector field is zero everywhere");
+    if (ctx->flowXs < 3 || ctx->flowYs < 3 || ctx->flowZs < 3) return lv_fail(ctx, LV_E_STATE, "the grid needs at least 3 points per axis");
+    (void)hipSetDevice(ctx->device);
+    int rc = lv_flow_trace_max_helicity_first(ctx, helicity_field, settings, seeding);
     if (rc) return rc;
     if (out_num_lines) *out_num_lines = ctx->flowOffsets.size() - 1;
     if (out_num_points) *out_num_points = ctx->flowPositions.size() / 3;

@@ -257,6 +257,87 @@ __global__ __launch_bounds__(LV_WAVE) void k_trace_streamlines(const LvFlowGrid 
     counts[t] = n;
 }
 
+// Cell of the seeder's occupancy grid (StreamlineMaxHelicityFirstSeeder::isPointTerminated, StreamlineSeeder.cpp:514-523): (xs - 1) x
+// (ys - 1) x (zs - 1) cells, position / cell size truncated towards zero, clamped
+__host__ __device__ __forceinline__ uint32_t lv_occupancy_cell(int xs, int ys, int zs, float dx, float dy, float dz, float px, float py,
+                                                               float pz) {
+    int x = int(px * (1.0f / dx)), y = int(py * (1.0f / dy)), z = int(pz * (1.0f / dz));
+    x = x < 0 ? 0 : (x > xs - 2 ? xs - 2 : x);
+    y = y < 0 ? 0 : (y > ys - 2 ? ys - 2 : y);
+    z = z < 0 ? 0 : (z > zs - 2 ? zs - 2 : z);
+    return uint32_t(x) + uint32_t(y) * uint32_t(xs - 1) + uint32_t(z) * uint32_t(xs - 1) * uint32_t(ys - 1);
+}
+
+// _traceStreamlineDecreasingHelicity + _isTerminated (StreamlineTracingGrid.cpp:546-738) for a batch of seeds, traced SPECULATIVELY
+// against the occupancy grid as it stood when the batch was formed (lv_flow_trace_max_helicity_first commits the lines in seeding
+// order and cuts each one where a line committed before it has claimed the cell: a point is pushed after its own termination
+// test, so the part of a line in front of the cut is what the sequential algorithm would have traced).  Order of the tests as in
+// the reference: iteration limit, cumulated length below the termination distance, leaving the box (boundary point appended, flagged
+// in bit 31 of the count), loop check "Start Point", occupied cell.
+__global__ __launch_bounds__(LV_WAVE) void k_trace_streamlines_seeded(const LvFlowGrid g, const float* __restrict__ seeds,
+                                                                      uint32_t numSeeds, uint32_t numThreads, uint32_t firstBackward,
+                                                                      uint32_t method, float dt, float timeStepScale,
+                                                                      float terminationDistance, int maxIterations,
+                                                                      uint32_t loopCheckMode, float terminationDistanceStart,
+                                                                      const uint8_t* __restrict__ occupancy, uint32_t capacity,
+                                                                      float* __restrict__ positions, float* __restrict__ attributes,
+                                                                      uint32_t* __restrict__ counts) {
+    const uint32_t t = blockIdx.x * LV_WAVE + threadIdx.x;
+    if (t >= numThreads) return;
+    const bool fw = t < firstBackward;
+    const uint32_t s = t % numSeeds;
+    f3 cur = mk3(seeds[3 * s], seeds[3 * s + 1], seeds[3 * s + 2]), lastPoint = cur, back = cur, pt0 = cur, pt1 = cur;
+    uint32_t n = 0;
+    bool boundary = false;
+    auto push = [&](f3 q) {
+        if (n < capacity) {
+            float* o = positions + (size_t(n) * numThreads + t) * 3;
+            o[0] = q.x; o[1] = q.y; o[2] = q.z;
+            for (uint32_t a = 0; a < g.numScalars; a++)
+                attributes[(size_t(a) * capacity + n) * numThreads + t] =
+                        lv_scalar_at(g, g.scalars + size_t(a) * g.xs * g.ys * g.zs, q);
+        }
+        if (n == 0) pt0 = q;
+        if (n == 1) pt1 = q;
+        back = q;
+        n++;
+    };
+    float segmentLength = 0.0f;   // (the reference's name: the length of the whole line so far)
+    int iterationCounter = 0;
+    for (;;) {
+        if (iterationCounter > maxIterations) break;
+        if (n != 0 && segmentLength < terminationDistance) break;
+        if (!lv_box_contains(g, cur)) {
+            if (n != 0) {
+                const f3 ro = back, rd = norm3(cur - ro);
+                float tNear, tFar;
+                lv_ray_box(ro, rd, mk3(g.bx, g.by, g.bz), tNear, tFar);
+                push(tNear > 0.0f ? ro + tNear * rd : ro + tFar * rd);
+                boundary = true;
+            }
+            break;
+        }
+        if (n > 1 && loopCheckMode == 1u) {   // LoopCheckMode::START_POINT, :590-607
+            f3 dir0 = pt1 - pt0;
+            const float dist0 = len3(dir0);
+            dir0 = mk3(dir0.x / dist0, dir0.y / dist0, dir0.z / dist0);
+            f3 dirNow = cur - back;
+            const float distNow = len3(dirNow);
+            dirNow = mk3(dirNow.x / distNow, dirNow.y / distNow, dirNow.z / distNow);
+            const float distToStart = len3(cur - pt0);
+            const float planeDistance = dot3(dir0, cur) + (-dot3(dir0, pt0));   // sgl::Plane(normal, point).getDistance
+            if (planeDistance < 0.0f && distToStart < terminationDistanceStart && dot3(dir0, dirNow) > 0.0f) break;
+        }
+        if (occupancy[lv_occupancy_cell(g.xs, g.ys, g.zs, g.dx, g.dy, g.dz, cur.x, cur.y, cur.z)]) break;
+        push(cur);
+        lv_integration_step(g, method, cur, dt, fw, timeStepScale);
+        iterationCounter++;
+        segmentLength += len3(cur - lastPoint);
+        lastPoint = cur;
+    }
+    counts[t] = n | (boundary ? 0x80000000u : 0u);
+}
+
 // max |v| over the grid (addVectorField, :189-216): max of non-negative floats = max of their bit patterns
 __global__ __launch_bounds__(LV_BLOCK) void k_max_magnitude(const float* __restrict__ v, uint64_t numCells, uint32_t* out) {
     float m = 0.0f;
@@ -409,3 +490,199 @@ int lv_flow_trace(lv_ctx* ctx, const float* seeds, uint32_t numSeeds, const lv_s
     }
     return LV_OK;
 }
+
+// StreamlineTracingGrid::_traceStreamribbonsDecreasingHelicity with StreamlineMaxHelicityFirstSeeder (see include/linevis_hip.h):
+// sample queue on the host, batches of LV_HELICITY_BATCH seeds traced speculatively by k_trace_streamlines_seeded, sequential commit.
+#define LV_HELICITY_BATCH 256u
+int lv_flow_trace_max_helicity_first(lv_ctx* ctx, const float* helicityField, const lv_streamline_settings* S,
+                                     const lv_helicity_seeding_settings* H) {
+    ctx->flowPositions.clear();
+    ctx->flowAttributes.clear();
+    ctx->flowOffsets.assign(1, 0u);
+    ctx->flowSeedIndex.clear();
+    hipStream_t st = ctx->stream;
+    LvFlowGrid g;
+    g.V = (const float*)ctx->flowVectors.ptr;
+    g.scalars = (const float*)ctx->flowScalars.ptr;
+    g.xs = int(ctx->flowXs); g.ys = int(ctx->flowYs); g.zs = int(ctx->flowZs);
+    g.dx = ctx->flowDx; g.dy = ctx->flowDy; g.dz = ctx->flowDz;
+    g.bx = float(g.xs - 1) * g.dx; g.by = float(g.ys - 1) * g.dy; g.bz = float(g.zs - 1) * g.dz;
+    g.numScalars = ctx->flowNumScalars;
+    const int xs = g.xs, ys = g.ys, zs = g.zs;
+    const uint32_t k = g.numScalars;
+    ctx->flowAttributes.assign(k, std::vector<float>());
+    // ---- StreamlineMaxHelicityFirstSeeder::reset, StreamlineSeeder.cpp:364-426 (box minimum = origin, dimensions = (bx, by, bz))
+    struct Sample { float value; float px, py, pz; uint32_t index; };
+    std::vector<Sample> queue;
+    const int f = H->seeding_subsampling_factor;
+    if (f == 1) {
+        for (int z = 1; z < zs - 1; z++)
+            for (int y = 1; y < ys - 1; y++)
+                for (int x = 1; x < xs - 1; x++)
+                    queue.push_back({helicityField[size_t(x) + size_t(y) * xs + size_t(z) * xs * ys], g.bx * float(x) / float(xs),
+                                     g.by * float(y) / float(ys), g.bz * float(z) / float(zs), uint32_t(queue.size())});
+    } else {
+        const int ncx = (xs - 1) / f, ncy = (ys - 1) / f, ncz = (zs - 1) / f;
+        for (int z = 0; z < ncz; z++)
+            for (int y = 0; y < ncy; y++)
+                for (int x = 0; x < ncx; x++) {
+                    const int xg = std::min(x * f, xs - 1), yg = std::min(y * f, ys - 1), zg = std::min(z * f, zs - 1);
+                    queue.push_back({fabsf(helicityField[size_t(xg) + size_t(yg) * xs + size_t(zg) * xs * ys]),
+                                     g.bx * (float(x) + 0.5f) / float(ncx), g.by * (float(y) + 0.5f) / float(ncy),
+                                     g.bz * (float(z) + 0.5f) / float(ncz), uint32_t(queue.size())});
+                }
+    }
+    // ascending, taken from the back (std::sort in the reference: the order of equal values is unspecified there; here: creation order)
+    std::stable_sort(queue.begin(), queue.end(), [](const Sample& a, const Sample& b) { return a.value < b.value; });
+    const size_t numCells = size_t(xs - 1) * (ys - 1) * (zs - 1);
+    std::vector<uint8_t> occupancy(numCells, 0);
+    int rc;
+    if ((rc = lv_buf_reserve(ctx, ctx->flowOccupancy, numCells))) return rc;
+    LV_HIP(ctx, hipMemsetAsync(ctx->flowOccupancy.ptr, 0, numCells, st));
+    // ---- constants of _traceStreamribbonsDecreasingHelicity / _isTerminated, StreamlineTracingGrid.cpp:553-557,767-773
+    const float dt = 1.0f / ctx->flowMaxMagnitude * std::min(g.dx, std::min(g.dy, g.dz)) * S->time_step_scale;
+    const float terminationDistance = 1e-6f * S->termination_distance;
+    const int maxIterations = std::min(int(roundf(float(S->max_num_iterations) / S->time_step_scale)), S->max_num_iterations * 10) * 10;
+    const float diag = sqrtf((g.bx * g.bx + g.by * g.by) + g.bz * g.bz);
+    const float terminationDistanceStart = diag / 100.0f * H->termination_distance_self;
+    const uint32_t dirs = S->integration_direction == 2u ? 2u : 1u;
+    const uint64_t capacity64 = uint64_t(maxIterations) + 3;
+    const uint64_t bytes = capacity64 * LV_HELICITY_BATCH * dirs * (12 + 4 * uint64_t(k));
+    if (capacity64 > 0x7FFFFFFFull || bytes > (64ull << 30))
+        return lv_fail(ctx, LV_E_CAPACITY, "streamline buffers would need %llu bytes", (unsigned long long)bytes);
+    const uint32_t capacity = uint32_t(capacity64);
+    const uint32_t maxThreads = LV_HELICITY_BATCH * dirs;
+    if ((rc = lv_buf_reserve(ctx, ctx->flowSeeds, size_t(LV_HELICITY_BATCH) * 12))) return rc;
+    if ((rc = lv_buf_reserve(ctx, ctx->flowOutPos, size_t(capacity) * maxThreads * 12))) return rc;
+    if ((rc = lv_buf_reserve(ctx, ctx->flowOutAtt, size_t(capacity) * maxThreads * 4 * (k ? k : 1)))) return rc;
+    if ((rc = lv_buf_reserve(ctx, ctx->flowCounts, size_t(maxThreads) * 4))) return rc;
+    auto cellOf = [&](const float* q) { return lv_occupancy_cell(xs, ys, zs, g.dx, g.dy, g.dz, q[0], q[1], q[2]); };
+    std::vector<float> seeds, hp, ha;
+    std::vector<uint32_t> counts;
+    const float r = H->minimum_separation_distance;
+    while (!queue.empty()) {
+        // the next seeds whose cell is free now (hasNextPoint, :428-458); taken cells can only become more
+        seeds.clear();
+        while (!queue.empty() && seeds.size() < size_t(LV_HELICITY_BATCH) * 3) {
+            const Sample sm = queue.back();
+            queue.pop_back();
+            const float q[3] = {sm.px, sm.py, sm.pz};
+            if (!occupancy[cellOf(q)]) seeds.insert(seeds.end(), q, q + 3);
+        }
+        const uint32_t numSeeds = uint32_t(seeds.size() / 3);
+        if (numSeeds == 0) break;
+        const uint32_t numThreads = numSeeds * dirs;
+        const uint32_t firstBackward = S->integration_direction == 0u ? numThreads : (S->integration_direction == 1u ? 0u : numSeeds);
+        LV_HIP(ctx, hipMemcpyAsync(ctx->flowSeeds.ptr, seeds.data(), seeds.size() * 4, hipMemcpyHostToDevice, st));
+        k_trace_streamlines_seeded<<<(numThreads + LV_WAVE - 1) / LV_WAVE, LV_WAVE, 0, st>>>(
+                g, (const float*)ctx->flowSeeds.ptr, numSeeds, numThreads, firstBackward, S->integration_method, dt, S->time_step_scale,
+                terminationDistance, maxIterations, H->loop_check_mode, terminationDistanceStart, (const uint8_t*)ctx->flowOccupancy.ptr,
+                capacity, (float*)ctx->flowOutPos.ptr, (float*)ctx->flowOutAtt.ptr, (uint32_t*)ctx->flowCounts.ptr);
+        LV_HIP(ctx, hipGetLastError());
+        counts.resize(numThreads);
+        LV_HIP(ctx, hipMemcpyAsync(counts.data(), ctx->flowCounts.ptr, size_t(numThreads) * 4, hipMemcpyDeviceToHost, st));
+        LV_HIP(ctx, hipStreamSynchronize(st));
+        uint32_t maxCount = 0;
+        for (uint32_t c : counts) maxCount = std::max(maxCount, c & 0x7FFFFFFFu);
+        if (maxCount > capacity) return lv_fail(ctx, LV_E_CAPACITY, "streamline longer than its buffer (%u > %u)", maxCount, capacity);
+        hp.resize(size_t(maxCount) * numThreads * 3);
+        ha.resize(size_t(k) * maxCount * numThreads);
+        if (maxCount) {
+            LV_HIP(ctx, hipMemcpyAsync(hp.data(), ctx->flowOutPos.ptr, hp.size() * 4, hipMemcpyDeviceToHost, st));
+            for (uint32_t a = 0; a < k; a++)
+                LV_HIP(ctx, hipMemcpyAsync(ha.data() + size_t(a) * maxCount * numThreads,
+                                           (const float*)ctx->flowOutAtt.ptr + size_t(a) * capacity * numThreads,
+                                           size_t(maxCount) * numThreads * 4, hipMemcpyDeviceToHost, st));
+            LV_HIP(ctx, hipStreamSynchronize(st));
+        }
+        // ---- commit in seeding order
+        bool dirty = false;
+        for (uint32_t s = 0; s < numSeeds; s++) {
+            if (occupancy[cellOf(&seeds[3 * size_t(s)])]) continue;   // an earlier line of this batch took the seed's cell: hasNextPoint skips it
+            // length of a thread's part as the sequential tracer would have produced it: up to the first point in a taken cell
+            // (the boundary point is appended without that test)
+            auto cut = [&](uint32_t thread) {
+                const uint32_t n = counts[thread] & 0x7FFFFFFFu, tested = (counts[thread] >> 31) ? n - 1u : n;
+                for (uint32_t i = 0; i < tested; i++)
+                    if (occupancy[cellOf(&hp[(size_t(i) * numThreads + thread) * 3])]) return i;
+                return n;
+            };
+            struct Part { uint32_t thread, begin, end; bool reversed; };
+            Part parts[2];
+            int np = 0;
+            uint32_t seedIndex = 0u;
+            uint32_t nPart[2] = {0u, 0u};   // points of each direction's part after the cut
+            for (uint32_t d = 0; d < dirs; d++) nPart[d] = cut(d * numSeeds + s);
+            if (S->integration_direction == 0u) {
+                parts[np++] = {s, 0u, nPart[0], false};
+            } else if (S->integration_direction == 1u) {
+                parts[np++] = {s, 0u, nPart[0], true};            // _reverseTrajectory
+                seedIndex = nPart[0] ? nPart[0] - 1u : 0u;
+            } else {
+                // _reverseTrajectory(backward) + _insertBackwardTrajectory: the reversed backward line without its last point (= the
+                // seed), then the forward line (:1118-1160, as lv_flow_trace)
+                if (nPart[1] > 1) parts[np++] = {numSeeds + s, 1u, nPart[1], true};
+                parts[np++] = {s, 0u, nPart[0], false};
+                seedIndex = nPart[1] > 1u ? nPart[1] - 1u : 0u;
+            }
+            auto at = [&](const Part& pt, uint32_t j) {
+                const uint32_t step = pt.reversed ? (pt.end - 1 - j) : (pt.begin + j);
+                return size_t(step) * numThreads + pt.thread;
+            };
+            // isValid: _computeTrajectoryLength(forward) [+ _computeTrajectoryLength(backward)] >= minimumLength, :783-823
+            float total = 0.0f;
+            for (uint32_t d = 0; d < dirs; d++) {
+                const uint32_t thread = d * numSeeds + s;
+                float len = 0.0f;
+                for (uint32_t i = 0; i + 1 < nPart[d]; i++) {
+                    const float* pa = &hp[(size_t(i) * numThreads + thread) * 3];
+                    const float* pb = &hp[(size_t(i + 1) * numThreads + thread) * 3];
+                    const float ddx = pa[0] - pb[0], ddy = pa[1] - pb[1], ddz = pa[2] - pb[2];
+                    len += sqrtf((ddx * ddx + ddy * ddy) + ddz * ddz);
+                }
+                total += len;
+            }
+            if (!(total >= S->minimum_length)) continue;
+            size_t points = 0;
+            for (int i = 0; i < np; i++) points += parts[i].end - parts[i].begin;
+            if (points == 0) continue;
+            const size_t firstPoint = ctx->flowPositions.size() / 3;
+            for (int i = 0; i < np; i++)
+                for (uint32_t j = 0; j < parts[i].end - parts[i].begin; j++) {
+                    const size_t src = at(parts[i], j);
+                    ctx->flowPositions.insert(ctx->flowPositions.end(), &hp[src * 3], &hp[src * 3] + 3);
+                    for (uint32_t a = 0; a < k; a++) ctx->flowAttributes[a].push_back(ha[size_t(a) * maxCount * numThreads + src]);
+                }
+            ctx->flowOffsets.push_back(uint32_t(ctx->flowPositions.size() / 3));
+            ctx->flowSeedIndex.push_back(seedIndex);
+            // addFinishedTrajectory, StreamlineSeeder.cpp:464-502: every cell the sphere (point, minimumSeparationDistance) touches
+            // (sgl::Sphere::intersects(AABB) is un-vendored; build-owned: squared distance from the centre to the box <= r^2)
+            for (size_t pnt = firstPoint; pnt < ctx->flowPositions.size() / 3; pnt++) {
+                const float* q = &ctx->flowPositions[pnt * 3];
+                auto cellCoord = [](float v, float cell, int hi) { int c = int(v * (1.0f / cell)); return c < 0 ? 0 : (c > hi ? hi : c); };
+                const int x0 = cellCoord(q[0] - r, g.dx, xs - 2), x1 = cellCoord(q[0] + r, g.dx, xs - 2);
+                const int y0 = cellCoord(q[1] - r, g.dy, ys - 2), y1 = cellCoord(q[1] + r, g.dy, ys - 2);
+                const int z0 = cellCoord(q[2] - r, g.dz, zs - 2), z1 = cellCoord(q[2] + r, g.dz, zs - 2);
+                for (int z = z0; z <= z1; z++)
+                    for (int y = y0; y <= y1; y++)
+                        for (int x = x0; x <= x1; x++) {
+                            const float lo[3] = {float(x) * g.dx, float(y) * g.dy, float(z) * g.dz};
+                            const float hi[3] = {float(x + 1) * g.dx, float(y + 1) * g.dy, float(z + 1) * g.dz};
+                            float d2 = 0.0f;
+                            for (int c = 0; c < 3; c++) {
+                                const float dd = q[c] < lo[c] ? lo[c] - q[c] : (q[c] > hi[c] ? q[c] - hi[c] : 0.0f);
+                                d2 += dd * dd;
+                            }
+                            if (d2 <= r * r) occupancy[size_t(x) + size_t(y) * (xs - 1) + size_t(z) * (xs - 1) * (ys - 1)] = 1;
+                        }
+            }
+            dirty = true;
+        }
+        if (dirty) {
+            LV_HIP(ctx, hipMemcpyAsync(ctx->flowOccupancy.ptr, occupancy.data(), numCells, hipMemcpyHostToDevice, st));
+            LV_HIP(ctx, hipStreamSynchronize(st));
+        }
+    }
+    return LV_OK;
+}
+

@@ -193,6 +193,7 @@ struct lv_ctx {
     uint32_t ppllScanBlocks = 0;              // raster_prism: workgroups of the last k_ppll_scan (scanTemp = totals, bases, counter)
     LvDeviceBuffer twistTex;                  // twist-line texture: float4 texels, mip levels back to back
     uint32_t twistW = 0, twistH = 0, twistLevels = 0;
+    LvDeviceBuffer flowOccupancy;             // max-helicity-first seeding: the occupancy grid, one byte per cell
     LvDeviceBuffer ppllCoarse;                // raster_prism, sharded frames: 32 x 32-pixel cells that hold requested pixels (k_ppll_mark_tiles)
     LvDeviceBuffer ppllOverflow;              // raster_prism: pixel addresses with more kept fragments than ppllMaxNumFrags (k_ppll_pixel_pass)
     bool ppllArrays = false;                  // the last PPLL frame left per-pixel runs (raster_prism), not linked lists
@@ -322,5 +323,7 @@ int lv_svgf_denoise(lv_ctx* ctx, const float* noisy);
 int lv_flow_set_grid(lv_ctx* ctx, const float* vectorField, uint32_t xs, uint32_t ys, uint32_t zs, float dx, float dy,
                      float dz, const float* const* scalarFields, uint32_t numScalarFields);
 int lv_flow_trace(lv_ctx* ctx, const float* seeds, uint32_t numSeeds, const lv_streamline_settings* settings);
+int lv_flow_trace_max_helicity_first(lv_ctx* ctx, const float* helicityField, const lv_streamline_settings* settings,
+                                     const lv_helicity_seeding_settings* seeding);
 void lv_mat4_inverse(const float* m, float* inv);
 void lv_mat4_mul(const float* A, const float* B, float* out);

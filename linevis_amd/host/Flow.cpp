@@ -116,6 +116,45 @@ bool StreamlineTracingGrid::traceLines(const StreamlineTracingSettings& tracingS
     return true;
 }
 
+bool StreamlineTracingGrid::traceStreamlinesDecreasingHelicity(const StreamlineTracingSettings& tracingSettings,
+                                                               Trajectories& filteredTrajectories) {
+    auto it = scalarFields.find("Helicity");
+    if (it == scalarFields.end()) { lastError = "_traceStreamribbonsDecreasingHelicity: no helicity field was found"; return false; }
+    if (!uploadGrid(tracingSettings.vectorFieldIndex)) return false;
+    lv_streamline_settings s;
+    s.integration_method = uint32_t(tracingSettings.integrationMethod);
+    s.integration_direction = uint32_t(tracingSettings.integrationDirection);
+    s.time_step_scale = tracingSettings.timeStepScale;
+    s.max_num_iterations = tracingSettings.maxNumIterations;
+    s.termination_distance = tracingSettings.terminationDistance;
+    s.minimum_length = tracingSettings.minimumLength;
+    lv_helicity_seeding_settings hs;
+    hs.minimum_separation_distance = tracingSettings.minimumSeparationDistance;
+    hs.termination_check_type = uint32_t(tracingSettings.terminationCheckType);
+    hs.loop_check_mode = uint32_t(tracingSettings.loopCheckMode);
+    hs.termination_distance_self = tracingSettings.terminationDistanceSelf;
+    hs.seeding_subsampling_factor = tracingSettings.seedingSubsamplingFactor;
+    uint64_t numLines = 0, numPoints = 0;
+    int rc = lv_trace_streamlines_max_helicity_first(ctx, it->second.data(), &s, &hs, &numLines, &numPoints);
+    if (rc != LV_OK) { lastError = std::string("lv_trace_streamlines_max_helicity_first: ") + lv_last_error(ctx); return false; }
+    const size_t k = scalarFields.size();
+    std::vector<float> positions(3 * numPoints), attributes(k * numPoints);
+    std::vector<uint32_t> offsets(numLines + 1);
+    rc = lv_get_streamlines(ctx, positions.data(), attributes.data(), offsets.data());
+    if (rc != LV_OK) { lastError = std::string("lv_get_streamlines: ") + lv_last_error(ctx); return false; }
+    for (uint64_t l = 0; l < numLines; l++) {
+        Trajectory t;
+        const uint32_t b = offsets[l], e = offsets[l + 1];
+        t.positions.resize(e - b);
+        memcpy(t.positions.data(), positions.data() + 3 * size_t(b), size_t(e - b) * 12);
+        t.attributes.resize(k);
+        for (size_t a = 0; a < k; a++)
+            t.attributes[a].assign(attributes.begin() + a * numPoints + b, attributes.begin() + a * numPoints + e);
+        filteredTrajectories.push_back(std::move(t));
+    }
+    return true;
+}
+
 // ---------------------------------------------------------------- streamribbons
 // _getScalarFieldAtPosition (:863-913): trilinear, values outside the grid are 0
 float StreamlineTracingGrid::getScalarFieldAtPosition(const std::vector<float>& f, const vec3& p) const {

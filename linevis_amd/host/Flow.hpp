@@ -37,6 +37,13 @@ struct StreamlineTracingSettings {
     bool useHelicity = true;
     float maxHelicityTwist = 0.25f;
     vec3 initialRibbonDirection = vec3(0.0f, 1.0f, 0.0f);
+    // StreamlineMaxHelicityFirstSeeder (StreamlineTracingDefines.hpp:89-101,156-174): termination check 1 = grid-based and loop check
+    // 0 = none / 1 = start point are built
+    float minimumSeparationDistance = 0.08f;
+    int terminationCheckType = 1;
+    int loopCheckMode = 1;
+    float terminationDistanceSelf = 1.0f;
+    int seedingSubsamplingFactor = 1;
 };
 
 /// GridLoader.cpp:41-183: |v| per grid point, curl by central / one-sided differences, helicity v . curl v
@@ -75,6 +82,11 @@ public:
     /// "Helicity" scalar field) -- the band data LineDataFlow::setTrajectoryData takes.
     bool traceStreamribbons(const StreamlineTracingSettings& tracingSettings, const std::vector<vec3>& seedPoints,
                             Trajectories& filteredTrajectories, std::vector<std::vector<vec3>>& filteredRibbonsDirections);
+    /// _traceStreamlinesDecreasingHelicity with the StreamlineMaxHelicityFirstSeeder (StreamlineTracingGrid.cpp:740-860,
+    /// StreamlineSeeder.cpp:360-529): seeds in the order of falling helicity ("Helicity" scalar field), lines end where they come within
+    /// minimumSeparationDistance of an earlier one.  Traced in speculative batches on the GPU, committed in seeding order
+    /// (lv_trace_streamlines_max_helicity_first).
+    bool traceStreamlinesDecreasingHelicity(const StreamlineTracingSettings& tracingSettings, Trajectories& filteredTrajectories);
 
 private:
     bool uploadGrid(int vectorFieldIndex);

@@ -286,6 +286,32 @@ int lvh_grid_trace(void* hp, const float* seeds, uint32_t numSeeds, int method, 
     *outNumPoints = n;
     return 0;
 }
+/// traceStreamlinesDecreasingHelicity (the max-helicity-first seeder); result fetched like lvh_grid_trace's
+int lvh_grid_trace_max_helicity_first(void* hp, int method, int direction, float timeStepScale, int maxNumIterations,
+                                      float terminationDistance, float minimumLength, float minimumSeparationDistance,
+                                      int terminationCheckType, int loopCheckMode, float terminationDistanceSelf,
+                                      int seedingSubsamplingFactor, uint64_t* outNumLines, uint64_t* outNumPoints) {
+    GridHandle* h = static_cast<GridHandle*>(hp);
+    StreamlineTracingSettings s;
+    s.integrationMethod = StreamlineIntegrationMethod(method);
+    s.integrationDirection = StreamlineIntegrationDirection(direction);
+    s.timeStepScale = timeStepScale;
+    s.maxNumIterations = maxNumIterations;
+    s.terminationDistance = terminationDistance;
+    s.minimumLength = minimumLength;
+    s.minimumSeparationDistance = minimumSeparationDistance;
+    s.terminationCheckType = terminationCheckType;
+    s.loopCheckMode = loopCheckMode;
+    s.terminationDistanceSelf = terminationDistanceSelf;
+    s.seedingSubsamplingFactor = seedingSubsamplingFactor;
+    h->result.clear();
+    if (!h->grid.traceStreamlinesDecreasingHelicity(s, h->result)) return -1;
+    uint64_t n = 0;
+    for (const Trajectory& t : h->result) n += t.positions.size();
+    *outNumLines = h->result.size();
+    *outNumPoints = n;
+    return 0;
+}
 /// traceStreamribbons: as lvh_grid_trace, plus one ribbon direction per point (fetched with lvh_grid_copy_ribbons)
 int lvh_grid_trace_ribbons(void* hp, const float* seeds, uint32_t numSeeds, int method, int direction, float timeStepScale,
                            int maxNumIterations, float terminationDistance, float minimumLength, int useHelicity,

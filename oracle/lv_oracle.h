@@ -313,6 +313,11 @@ typedef struct {
 typedef struct lvo_streamlines lvo_streamlines;
 void lvo_generate_abc_flow(float* v, int xs, int ys, int zs, float A, float B, float C, float resScale);
 float lvo_max_vector_magnitude(const float* v, uint64_t numCells);
+/* max-helicity-first seeding (StreamlineMaxHelicityFirstSeeder + _traceStreamribbonsDecreasingHelicity), sequential restatement */
+lvo_streamlines* lvo_trace_streamlines_max_helicity_first(
+        const float* vectorField, int xs, int ys, int zs, float dx, float dy, float dz, const float* const* scalarFields,
+        uint32_t numScalarFields, const float* helicityField, const lvo_streamline_settings* settings, float minimumSeparationDistance,
+        uint32_t loopCheckMode, float terminationDistanceSelf, int seedingSubsamplingFactor);
 lvo_streamlines* lvo_trace_streamlines(const float* vectorField, int xs, int ys, int zs, float dx, float dy, float dz,
                                        const float* const* scalarFields, uint32_t numScalarFields, const float* seeds,
                                        uint32_t numSeeds, const lvo_streamline_settings* settings);

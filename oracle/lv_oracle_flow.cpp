@@ -486,6 +486,162 @@ static lvo_streamlines* traceLines(const float* vectorField, int xs, int ys, int
     return out;
 }
 
+// StreamlineMaxHelicityFirstSeeder (StreamlineSeeder.cpp:360-529) + StreamlineTracingGrid::_traceStreamribbonsDecreasingHelicity /
+// _traceStreamlineDecreasingHelicity / _isTerminated (StreamlineTracingGrid.cpp:546-860), literally and sequentially: one line after
+// the other, each terminated where it enters a cell an earlier line has claimed.  Grid-based termination check, loop check none (0) or
+// start point (1), integrators 0 ... 4 (the Runge-Kutta-Fehlberg step width carries over from line to line in the reference).
+// Build-owned where the reference leaves it open: samples of equal helicity keep their creation order (std::sort is unstable);
+// sgl::Sphere::intersects(AABB) = squared distance from the centre to the box <= r^2; sgl::Plane(n, p).getDistance(q) = n.q - n.p.
+lvo_streamlines* lvo_trace_streamlines_max_helicity_first(
+        const float* vectorField, int xs, int ys, int zs, float dx, float dy, float dz, const float* const* scalarFields,
+        uint32_t numScalarFields, const float* helicityField, const lvo_streamline_settings* settings, float minimumSeparationDistance,
+        uint32_t loopCheckMode, float terminationDistanceSelf, int seedingSubsamplingFactor) {
+    Grid g;
+    g.xs = xs; g.ys = ys; g.zs = zs; g.dx = dx; g.dy = dy; g.dz = dz;
+    g.boxMin = v3(0.0f, 0.0f, 0.0f);
+    g.boxMax = v3(float(xs - 1) * dx, float(ys - 1) * dy, float(zs - 1) * dz);
+    g.V = vectorField; g.scalars = scalarFields; g.numScalars = numScalarFields;
+    const lvo_streamline_settings& S = *settings;
+    const float maxMag = lvo_max_vector_magnitude(vectorField, uint64_t(xs) * ys * zs);
+    struct Sample { float value; V3 pos; };
+    std::vector<Sample> queue;
+    const V3 dims = g.boxMax - g.boxMin;
+    const int f = seedingSubsamplingFactor;
+    if (f == 1) {
+        for (int z = 1; z < zs - 1; z++)
+            for (int y = 1; y < ys - 1; y++)
+                for (int x = 1; x < xs - 1; x++)
+                    queue.push_back({helicityField[size_t(x) + size_t(y) * xs + size_t(z) * xs * ys],
+                                     v3(g.boxMin.x + dims.x * float(x) / float(xs), g.boxMin.y + dims.y * float(y) / float(ys),
+                                        g.boxMin.z + dims.z * float(z) / float(zs))});
+    } else {
+        const int ncx = (xs - 1) / f, ncy = (ys - 1) / f, ncz = (zs - 1) / f;
+        for (int z = 0; z < ncz; z++)
+            for (int y = 0; y < ncy; y++)
+                for (int x = 0; x < ncx; x++) {
+                    const int xg = std::min(x * f, xs - 1), yg = std::min(y * f, ys - 1), zg = std::min(z * f, zs - 1);
+                    queue.push_back({fabsf(helicityField[size_t(xg) + size_t(yg) * xs + size_t(zg) * xs * ys]),
+                                     v3(g.boxMin.x + dims.x * (float(x) + 0.5f) / float(ncx), g.boxMin.y + dims.y * (float(y) + 0.5f) / float(ncy),
+                                        g.boxMin.z + dims.z * (float(z) + 0.5f) / float(ncz))});
+                }
+    }
+    std::stable_sort(queue.begin(), queue.end(), [](const Sample& a, const Sample& b) { return a.value < b.value; });
+    std::vector<bool> occupancy(size_t(xs - 1) * (ys - 1) * (zs - 1), false);
+    auto cellOf = [&](V3 p) {
+        V3 q = p - g.boxMin;
+        q = v3(q.x * (1.0f / dx), q.y * (1.0f / dy), q.z * (1.0f / dz));
+        int x = int(q.x), y = int(q.y), z = int(q.z);
+        x = std::min(std::max(x, 0), xs - 2); y = std::min(std::max(y, 0), ys - 2); z = std::min(std::max(z, 0), zs - 2);
+        return size_t(x) + size_t(y) * (xs - 1) + size_t(z) * (xs - 1) * (ys - 1);
+    };
+    const float dt0 = 1.0f / maxMag * std::min(dx, std::min(dy, dz)) * S.timeStepScale;
+    const int MAX_ITERATIONS = std::min(int(roundf(float(S.maxNumIterations) / S.timeStepScale)), S.maxNumIterations * 10) * 10;
+    const float terminationDistance = 1e-6f * S.terminationDistance;
+    const float terminationDistanceStart = length(dims) / 100.0f * terminationDistanceSelf;
+    auto traceDecreasing = [&](V3 seed, bool fw, Line& line) {
+        float dt = dt0;
+        V3 currentPoint = seed, lastPoint = seed;
+        float segmentLength = 0.0f;
+        int iterationCounter = 0;
+        for (;;) {
+            // _isTerminated
+            if (iterationCounter > MAX_ITERATIONS) break;
+            if (!line.pos.empty() && segmentLength < terminationDistance) break;
+            if (!contains(g, currentPoint)) {
+                if (!line.pos.empty()) {
+                    const V3 ro = line.pos.back(), rd = normalize(currentPoint - ro);
+                    float tNear, tFar;
+                    rayBox(ro, rd, g.boxMin, g.boxMax, tNear, tFar);
+                    pushPoint(g, line, tNear > 0.0f ? ro + tNear * rd : ro + tFar * rd);
+                }
+                break;
+            }
+            if (line.pos.size() > 1 && loopCheckMode == 1u) {
+                const V3 pt0 = line.pos[0], pt1 = line.pos[1];
+                V3 dir0 = pt1 - pt0;
+                const float dist0 = length(dir0);
+                dir0 = v3(dir0.x / dist0, dir0.y / dist0, dir0.z / dist0);
+                V3 dirNow = currentPoint - line.pos.back();
+                const float distNow = length(dirNow);
+                dirNow = v3(dirNow.x / distNow, dirNow.y / distNow, dirNow.z / distNow);
+                const float distToStart = length(currentPoint - pt0);
+                const float planeDistance = dot(dir0, currentPoint) + (-dot(dir0, pt0));
+                if (planeDistance < 0.0f && distToStart < terminationDistanceStart && dot(dir0, dirNow) > 0.0f) break;
+            }
+            if (occupancy[cellOf(currentPoint)]) break;
+            pushPoint(g, line, currentPoint);
+            integrationStep(g, S.integrationMethod, currentPoint, dt, fw, S.timeStepScale);
+            iterationCounter++;
+            segmentLength += length(currentPoint - lastPoint);
+            lastPoint = currentPoint;
+        }
+    };
+    auto lengthOf = [](const Line& l) {
+        float len = 0.0f;
+        for (size_t i = 0; i + 1 < l.pos.size(); i++) len += length(l.pos[i] - l.pos[i + 1]);
+        return len;
+    };
+    lvo_streamlines* out = new lvo_streamlines();
+    out->attributes.resize(numScalarFields);
+    out->offsets.push_back(0);
+    while (!queue.empty()) {
+        const Sample sm = queue.back();      // hasNextPoint
+        queue.pop_back();
+        if (occupancy[cellOf(sm.pos)]) continue;
+        Line line;
+        bool valid;
+        if (S.integrationDirection == 0) {
+            traceDecreasing(sm.pos, true, line);
+            valid = lengthOf(line) >= S.minimumLength;
+        } else if (S.integrationDirection == 1) {
+            traceDecreasing(sm.pos, false, line);
+            valid = lengthOf(line) >= S.minimumLength;
+            if (valid) reverseLine(line);
+        } else {
+            Line back;
+            traceDecreasing(sm.pos, true, line);
+            traceDecreasing(sm.pos, false, back);
+            valid = lengthOf(line) + lengthOf(back) >= S.minimumLength;
+            if (valid) {
+                reverseLine(back);
+                if (back.pos.size() > 1) {
+                    line.pos.insert(line.pos.begin(), back.pos.begin(), back.pos.end() - 1);
+                    if (line.att.empty()) line.att.resize(numScalarFields);
+                    for (uint32_t a = 0; a < numScalarFields; a++)
+                        line.att[a].insert(line.att[a].begin(), back.att[a].begin(), back.att[a].end() - 1);
+                }
+            }
+        }
+        if (!valid || line.pos.empty()) continue;
+        for (const V3& p : line.pos) { out->positions.push_back(p.x); out->positions.push_back(p.y); out->positions.push_back(p.z); }
+        for (uint32_t a = 0; a < numScalarFields; a++)
+            out->attributes[a].insert(out->attributes[a].end(), line.att[a].begin(), line.att[a].end());
+        out->offsets.push_back(uint32_t(out->positions.size() / 3));
+        // addFinishedTrajectory
+        const float r = minimumSeparationDistance;
+        for (const V3& q : line.pos) {
+            auto coord = [](float v, float cell, int hi) { int c = int(v * (1.0f / cell)); return std::min(std::max(c, 0), hi); };
+            const int x0 = coord((q.x - r) - g.boxMin.x, dx, xs - 2), x1 = coord((q.x + r) - g.boxMin.x, dx, xs - 2);
+            const int y0 = coord((q.y - r) - g.boxMin.y, dy, ys - 2), y1 = coord((q.y + r) - g.boxMin.y, dy, ys - 2);
+            const int z0 = coord((q.z - r) - g.boxMin.z, dz, zs - 2), z1 = coord((q.z + r) - g.boxMin.z, dz, zs - 2);
+            for (int z = z0; z <= z1; z++)
+                for (int y = y0; y <= y1; y++)
+                    for (int x = x0; x <= x1; x++) {
+                        const float lo[3] = {float(x) * dx, float(y) * dy, float(z) * dz};
+                        const float hi[3] = {float(x + 1) * dx, float(y + 1) * dy, float(z + 1) * dz};
+                        const float qq[3] = {q.x, q.y, q.z};
+                        float d2 = 0.0f;
+                        for (int c = 0; c < 3; c++) {
+                            const float dd = qq[c] < lo[c] ? lo[c] - qq[c] : (qq[c] > hi[c] ? qq[c] - hi[c] : 0.0f);
+                            d2 += dd * dd;
+                        }
+                        if (d2 <= r * r) occupancy[size_t(x) + size_t(y) * (xs - 1) + size_t(z) * (xs - 1) * (ys - 1)] = true;
+                    }
+        }
+    }
+    return out;
+}
+
 void lvo_streamlines_sizes(const lvo_streamlines* s, uint64_t* numLines, uint64_t* numPoints) {
     *numLines = s->offsets.size() - 1;
     *numPoints = s->positions.size() / 3;

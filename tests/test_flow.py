@@ -252,3 +252,49 @@ def test_streamribbon_directions_against_the_float64_restatement():
     for l in range(6):
         nf = int(of[l + 1] - of[l])
         assert np.array_equal(rib[off[l + 1] - nf:off[l + 1]], rf[of[l]:of[l + 1]])
+
+
+def test_max_helicity_first_seeding_properties():
+    """StreamlineMaxHelicityFirstSeeder + the decreasing-helicity tracer (the oracle's sequential restatement): the first line starts
+    at the interior grid sample of largest helicity; every line's seed cell was free when it was seeded and no line runs through a cell
+    an EARLIER line has claimed (checked by replaying the occupancy grid in float64 with the cells recomputed independently); a
+    larger separation distance gives fewer lines; the sub-sampled seeder seeds block centres."""
+    n = 20
+    v = lvo.generate_abc_flow(n, n, n)
+    d = 1.0 / (n - 1)
+    sp = (d, d, d)
+    hel = lvo.helicity_field(v, lvo.vorticity_field(v, sp))
+    mag = np.sqrt((v * v).sum(axis=3)).astype(np.float32)
+    S = lvo.streamline_settings("Runge-Kutta 4th Order", "Forward & Backward", minimum_length=0.3)
+    r = 0.08
+    pos, att, off = lvo.trace_streamlines_max_helicity_first(v, sp, [mag], hel, S, minimum_separation_distance=r)
+    assert 10 < len(off) - 1 < 400 and att.shape == (1, len(pos))
+    # the first seed: the largest helicity among the interior samples, at boxMin + dims * index / n
+    inner = hel[1:-1, 1:-1, 1:-1]
+    z, y, x = np.unravel_index(np.argmax(inner), inner.shape)
+    seed0 = np.array([x + 1, y + 1, z + 1], np.float32) / np.float32(n) * np.float32((n - 1) * d)
+    first = pos[off[0]:off[1]]
+    assert np.abs(first - seed0).sum(axis=1).min() < 1e-6
+    # replay: the cells within r of every earlier line's points are taken; a later line never has a point in a taken cell, except the
+    # boundary point it may end with (appended without the test)
+    cells = np.zeros((n - 1, n - 1, n - 1), dtype=bool)          # [z, y, x]
+    lo = np.arange(n - 1) * d
+    for l in range(len(off) - 1):
+        p = pos[off[l]:off[l + 1]].astype(np.float64)
+        c = np.clip((p / d).astype(int), 0, n - 2)
+        taken = cells[c[:, 2], c[:, 1], c[:, 0]]
+        on_boundary = ((p <= 1e-6) | (p >= (n - 1) * d - 1e-6)).any(axis=1)
+        assert not (taken & ~on_boundary).any(), l
+        for q in p:
+            dist = [np.maximum(np.maximum(lo - q[a], q[a] - (lo + d)), 0.0) for a in range(3)]
+            d2 = dist[2][:, None, None] ** 2 + dist[1][None, :, None] ** 2 + dist[0][None, None, :] ** 2
+            cells |= d2 <= np.float64(np.float32(r)) ** 2 * (1 + 1e-6)
+    fewer = lvo.trace_streamlines_max_helicity_first(v, sp, [mag], hel, S, minimum_separation_distance=0.2)
+    assert len(fewer[2]) < len(off)
+    sub = lvo.trace_streamlines_max_helicity_first(v, sp, [mag], hel, S, minimum_separation_distance=r, seeding_subsampling_factor=4)
+    nc = (n - 1) // 4
+    centres = (np.arange(nc) + 0.5) / nc * (n - 1) * d
+    s0 = sub[0][sub[2][0]:sub[2][1]]
+    assert min(np.abs(q[:, None] - centres[None, :]).min(axis=1).max() for q in s0) < 1e-5     # one point of the first line is a block centre
+    none = lvo.trace_streamlines_max_helicity_first(v, sp, [mag], hel, S, minimum_separation_distance=r, loop_check_mode=0)
+    assert len(none[0]) >= len(pos)                                                               # no loop check: lines only get longer

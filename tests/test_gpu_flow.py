@@ -198,6 +198,11 @@ def test_host_tracer_classes(hip_lib):
             rb = lvo.trace_streamribbons(v, sp, fields, seeds, lvo.streamline_settings(direction=direction, minimum_length=0.3), 0, **kw)
             assert same(ra[:3], rb[:3]) and np.array_equal(ra[3].view(np.uint32), rb[3].view(np.uint32)), (direction, kw)
             assert len(ra[0]) > 200
+    # the max-helicity-first seeder through the host class (it reads the "Helicity" scalar field AbcFlowGenerator::load added)
+    ha = grid.trace_streamlines_max_helicity_first(minimum_length=0.3, minimum_separation_distance=0.1)
+    hb = lvo.trace_streamlines_max_helicity_first(v, sp, fields, fields[0], lvo.streamline_settings(minimum_length=0.3),
+                                                  minimum_separation_distance=0.1)
+    assert same(ha, hb) and len(ha[2]) > 10
     # a second vector field / scalar field set by hand, another integrator
     vec, scalars, sp2 = swirl_grid(20, 24, 16)
     grid.set_grid_extent(20, 24, 16, *sp2).add_vector_field(vec).add_scalar_field(scalars[1], "b").add_scalar_field(scalars[0], "a")
@@ -241,3 +246,32 @@ def test_host_tracer_classes(hip_lib):
     assert same(c, d)
     e = grid.trace_streamlines(sd, method="Runge-Kutta-Fehlberg", direction="Forward", minimum_length=0.05)
     assert len(e[0]) > 500 and np.array_equal(e[2][:1], [0])
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(direction="Forward"), dict(direction="Backward", method="Heun"),
+                                dict(loop_check_mode=0, minimum_separation_distance=0.12), dict(seeding_subsampling_factor=3),
+                                dict(method="Explicit Euler", minimum_separation_distance=0.05)])
+def test_max_helicity_first_seeding_bit_exact(hip_lib, kw):
+    """lv_trace_streamlines_max_helicity_first: batches of seeds traced speculatively in parallel, committed in seeding order and cut
+    where an earlier line claimed the cell -- against the oracle's literal one-line-after-the-other restatement: the same lines in the
+    same order, positions / attributes / offsets bit for bit."""
+    kw = dict(kw)
+    n = 28
+    v, mag, sp = abc_grid(n)
+    hel = lvo.helicity_field(v, lvo.vorticity_field(v, sp))
+    method, direction = kw.pop("method", "Runge-Kutta 4th Order"), kw.pop("direction", "Forward & Backward")
+    ctx = capi.Context(0)
+    ctx.set_flow_grid(v, sp, [mag, hel])
+    seeding = capi.HelicitySeedingSettings(**kw)
+    a = ctx.trace_streamlines_max_helicity_first(hel, capi.streamline_settings(method, direction, minimum_length=0.3), seeding)
+    b = lvo.trace_streamlines_max_helicity_first(v, sp, [mag, hel], hel, lvo.streamline_settings(method, direction, minimum_length=0.3),
+                                                 minimum_separation_distance=seeding.minimum_separation_distance,
+                                                 loop_check_mode=seeding.loop_check_mode,
+                                                 termination_distance_self=seeding.termination_distance_self,
+                                                 seeding_subsampling_factor=seeding.seeding_subsampling_factor)
+    assert same(a, b)
+    assert len(a[2]) - 1 > 10 and len(a[0]) > 500
+    with pytest.raises(Exception):
+        ctx.trace_streamlines_max_helicity_first(hel, capi.streamline_settings("Runge-Kutta-Fehlberg", direction), seeding)
+    with pytest.raises(Exception):
+        ctx.trace_streamlines_max_helicity_first(hel, capi.streamline_settings(method, direction), capi.HelicitySeedingSettings(termination_check_type=0))
