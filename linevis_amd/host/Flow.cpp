@@ -118,6 +118,11 @@ bool StreamlineTracingGrid::traceLines(const StreamlineTracingSettings& tracingS
 
 bool StreamlineTracingGrid::traceStreamlinesDecreasingHelicity(const StreamlineTracingSettings& tracingSettings,
                                                                Trajectories& filteredTrajectories) {
+    return traceLinesDecreasingHelicity(tracingSettings, filteredTrajectories, nullptr);
+}
+
+bool StreamlineTracingGrid::traceLinesDecreasingHelicity(const StreamlineTracingSettings& tracingSettings,
+                                                         Trajectories& filteredTrajectories, std::vector<uint32_t>* seedIndices) {
     auto it = scalarFields.find("Helicity");
     if (it == scalarFields.end()) { lastError = "_traceStreamribbonsDecreasingHelicity: no helicity field was found"; return false; }
     if (!uploadGrid(tracingSettings.vectorFieldIndex)) return false;
@@ -142,6 +147,13 @@ bool StreamlineTracingGrid::traceStreamlinesDecreasingHelicity(const StreamlineT
     std::vector<uint32_t> offsets(numLines + 1);
     rc = lv_get_streamlines(ctx, positions.data(), attributes.data(), offsets.data());
     if (rc != LV_OK) { lastError = std::string("lv_get_streamlines: ") + lv_last_error(ctx); return false; }
+    if (seedIndices) {
+        seedIndices->assign(numLines, 0u);
+        if (numLines && lv_get_streamline_seed_indices(ctx, seedIndices->data()) != LV_OK) {
+            lastError = std::string("lv_get_streamline_seed_indices: ") + lv_last_error(ctx);
+            return false;
+        }
+    }
     for (uint64_t l = 0; l < numLines; l++) {
         Trajectory t;
         const uint32_t b = offsets[l], e = offsets[l + 1];
@@ -247,6 +259,37 @@ bool StreamlineTracingGrid::traceStreamribbons(const StreamlineTracingSettings& 
     const size_t first = filteredTrajectories.size();
     std::vector<uint32_t> seedIndices;
     if (!traceLines(tracingSettings, seedPoints, filteredTrajectories, &seedIndices)) return false;
+    pushRibbonsOfLines(tracingSettings, helicityField, maxHelicityMagnitude, first, seedIndices, filteredTrajectories,
+                       filteredRibbonsDirections, false);
+    return true;
+}
+
+// _traceStreamribbonsDecreasingHelicity with flowPrimitives == STREAMRIBBONS (:783-823): the max-helicity-first lines + their ribbon
+// directions; the reference pushes them with forwardMode = true for the backward part as well
+bool StreamlineTracingGrid::traceStreamribbonsDecreasingHelicity(const StreamlineTracingSettings& tracingSettings,
+                                                                 Trajectories& filteredTrajectories,
+                                                                 std::vector<std::vector<vec3>>& filteredRibbonsDirections) {
+    auto hel = scalarFields.find("Helicity");
+    if (hel == scalarFields.end()) { lastError = "_traceStreamribbonsDecreasingHelicity: no helicity field was found"; return false; }
+    static const std::vector<float> none;
+    const std::vector<float>& helicityField = tracingSettings.useHelicity ? hel->second : none;
+    float maxHelicityMagnitude = 0.0f;
+    for (float h : hel->second) maxHelicityMagnitude = std::max(maxHelicityMagnitude, std::fabs(h));
+    const size_t first = filteredTrajectories.size();
+    std::vector<uint32_t> seedIndices;
+    if (!traceLinesDecreasingHelicity(tracingSettings, filteredTrajectories, &seedIndices)) return false;
+    pushRibbonsOfLines(tracingSettings, helicityField, maxHelicityMagnitude, first, seedIndices, filteredTrajectories,
+                       filteredRibbonsDirections, true);
+    return true;
+}
+
+// ribbon directions of merged lines: carried outwards from the seed in each traced part; backwardPartForwardMode = the forwardMode
+// argument of _pushRibbonDirections for the backward part (false in traceStreamribbons, true in the decreasing-helicity tracer)
+void StreamlineTracingGrid::pushRibbonsOfLines(const StreamlineTracingSettings& tracingSettings, const std::vector<float>& helicityField,
+                                               float maxHelicityMagnitude, size_t first, const std::vector<uint32_t>& seedIndices,
+                                               const Trajectories& filteredTrajectories,
+                                               std::vector<std::vector<vec3>>& filteredRibbonsDirections,
+                                               bool backwardPartForwardMode) const {
     filteredRibbonsDirections.resize(filteredTrajectories.size());
     // The GPU returns the merged lines; the ribbon directions are carried outwards from the seed in each traced part
     // (forward part as traced, backward part in its own trace order with the helicity's sign flipped, then reversed and put
@@ -261,21 +304,20 @@ bool StreamlineTracingGrid::traceStreamribbons(const StreamlineTracingSettings& 
         } else if (tracingSettings.integrationDirection == StreamlineIntegrationDirection::BACKWARD) {
             std::vector<vec3> traced(t.positions.rbegin(), t.positions.rend());
             if (n <= 1) traced.assign(t.positions.begin(), t.positions.end());
-            pushRibbonDirections(tracingSettings, helicityField, maxHelicityMagnitude, traced.data(), n, out, false);
+            pushRibbonDirections(tracingSettings, helicityField, maxHelicityMagnitude, traced.data(), n, out, backwardPartForwardMode);
             if (n > 1) std::reverse(out.begin(), out.end());
         } else {
             std::vector<vec3> fwd, bwd;
             pushRibbonDirections(tracingSettings, helicityField, maxHelicityMagnitude, t.positions.data() + s, n - s, fwd, true);
             if (s > 0) {
                 std::vector<vec3> traced(t.positions.rend() - ptrdiff_t(s + 1), t.positions.rend()); // seed, then outwards
-                pushRibbonDirections(tracingSettings, helicityField, maxHelicityMagnitude, traced.data(), s + 1, bwd, false);
+                pushRibbonDirections(tracingSettings, helicityField, maxHelicityMagnitude, traced.data(), s + 1, bwd, backwardPartForwardMode);
                 std::reverse(bwd.begin(), bwd.end());
                 out.assign(bwd.begin(), bwd.end() - 1);
             }
             out.insert(out.end(), fwd.begin(), fwd.end());
         }
     }
-    return true;
 }
 
 // ---------------------------------------------------------------- grid utilities, Loader/GridLoader.cpp:41-183

@@ -87,11 +87,20 @@ public:
     /// minimumSeparationDistance of an earlier one.  Traced in speculative batches on the GPU, committed in seeding order
     /// (lv_trace_streamlines_max_helicity_first).
     bool traceStreamlinesDecreasingHelicity(const StreamlineTracingSettings& tracingSettings, Trajectories& filteredTrajectories);
+    /// the same with flowPrimitives == STREAMRIBBONS: + one ribbon direction per point
+    bool traceStreamribbonsDecreasingHelicity(const StreamlineTracingSettings& tracingSettings, Trajectories& filteredTrajectories,
+                                              std::vector<std::vector<vec3>>& filteredRibbonsDirections);
 
 private:
     bool uploadGrid(int vectorFieldIndex);
     bool traceLines(const StreamlineTracingSettings& tracingSettings, const std::vector<vec3>& seedPoints,
                     Trajectories& filteredTrajectories, std::vector<uint32_t>* seedIndices);
+    bool traceLinesDecreasingHelicity(const StreamlineTracingSettings& tracingSettings, Trajectories& filteredTrajectories,
+                                      std::vector<uint32_t>* seedIndices);
+    void pushRibbonsOfLines(const StreamlineTracingSettings& tracingSettings, const std::vector<float>& helicityField,
+                            float maxHelicityMagnitude, size_t first, const std::vector<uint32_t>& seedIndices,
+                            const Trajectories& filteredTrajectories, std::vector<std::vector<vec3>>& filteredRibbonsDirections,
+                            bool backwardPartForwardMode) const;
     float getScalarFieldAtPosition(const std::vector<float>& scalarField, const vec3& particlePosition) const;
     void pushRibbonDirections(const StreamlineTracingSettings& tracingSettings, const std::vector<float>& helicityField,
                               float maxHelicityMagnitude, const vec3* positions, size_t n, std::vector<vec3>& ribbonDirections,

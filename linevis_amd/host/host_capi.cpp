@@ -290,7 +290,8 @@ int lvh_grid_trace(void* hp, const float* seeds, uint32_t numSeeds, int method, 
 int lvh_grid_trace_max_helicity_first(void* hp, int method, int direction, float timeStepScale, int maxNumIterations,
                                       float terminationDistance, float minimumLength, float minimumSeparationDistance,
                                       int terminationCheckType, int loopCheckMode, float terminationDistanceSelf,
-                                      int seedingSubsamplingFactor, uint64_t* outNumLines, uint64_t* outNumPoints) {
+                                      int seedingSubsamplingFactor, int ribbons, int useHelicity, float maxHelicityTwist,
+                                      const float* initialRibbonDirection, uint64_t* outNumLines, uint64_t* outNumPoints) {
     GridHandle* h = static_cast<GridHandle*>(hp);
     StreamlineTracingSettings s;
     s.integrationMethod = StreamlineIntegrationMethod(method);
@@ -305,7 +306,12 @@ int lvh_grid_trace_max_helicity_first(void* hp, int method, int direction, float
     s.terminationDistanceSelf = terminationDistanceSelf;
     s.seedingSubsamplingFactor = seedingSubsamplingFactor;
     h->result.clear();
-    if (!h->grid.traceStreamlinesDecreasingHelicity(s, h->result)) return -1;
+    h->ribbons.clear();
+    s.useHelicity = useHelicity != 0;
+    s.maxHelicityTwist = maxHelicityTwist;
+    if (initialRibbonDirection) s.initialRibbonDirection = vec3(initialRibbonDirection[0], initialRibbonDirection[1], initialRibbonDirection[2]);
+    if (ribbons ? !h->grid.traceStreamribbonsDecreasingHelicity(s, h->result, h->ribbons)
+                : !h->grid.traceStreamlinesDecreasingHelicity(s, h->result)) return -1;
     uint64_t n = 0;
     for (const Trajectory& t : h->result) n += t.positions.size();
     *outNumLines = h->result.size();

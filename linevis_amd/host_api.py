@@ -64,8 +64,8 @@ def load():
         "lvh_grid_regular_seeds": (None, [vp, i32, i32, i32, vp]),
         "lvh_grid_plane_seeds": (None, [vp, vp, f32, i32, i32, i32, vp]),
         "lvh_grid_trace": (i32, [vp, vp, u32, i32, i32, f32, i32, f32, f32, C.POINTER(u64), C.POINTER(u64)]),
-        "lvh_grid_trace_max_helicity_first": (i32, [vp, i32, i32, f32, i32, f32, f32, f32, i32, i32, f32, i32, C.POINTER(u64),
-                                                    C.POINTER(u64)]),
+        "lvh_grid_trace_max_helicity_first": (i32, [vp, i32, i32, f32, i32, f32, f32, f32, i32, i32, f32, i32, i32, i32, f32, vp,
+                                                    C.POINTER(u64), C.POINTER(u64)]),
         "lvh_grid_copy_result": (None, [vp, vp, vp, vp]),
         "lvh_grid_trace_ribbons": (i32, [vp, vp, u32, i32, i32, f32, i32, f32, f32, i32, f32, vp, C.POINTER(u64), C.POINTER(u64)]),
         "lvh_grid_copy_ribbons": (None, [vp, vp]),
@@ -393,20 +393,28 @@ class StreamlineTracingGrid:
 def _trace_streamlines_max_helicity_first(self, method="Runge-Kutta 4th Order", direction="Forward & Backward", time_step_scale=1.0,
                                           max_num_iterations=2000, termination_distance=1.0, minimum_length=0.7,
                                           minimum_separation_distance=0.08, termination_check_type=1, loop_check_mode=1,
-                                          termination_distance_self=1.0, seeding_subsampling_factor=1):
-    """traceStreamlinesDecreasingHelicity (StreamlineMaxHelicityFirstSeeder): needs a "Helicity" scalar field."""
+                                          termination_distance_self=1.0, seeding_subsampling_factor=1, ribbons=False,
+                                          use_helicity=True, max_helicity_twist=0.25, initial_ribbon_direction=(0.0, 1.0, 0.0)):
+    """traceStreamlinesDecreasingHelicity / traceStreamribbonsDecreasingHelicity (StreamlineMaxHelicityFirstSeeder): needs a
+    "Helicity" scalar field; ribbons=True also returns the ribbon directions [P,3]."""
     nl, npt = C.c_uint64(), C.c_uint64()
+    ird = np.ascontiguousarray(initial_ribbon_direction, dtype=np.float32)
     rc = self.L.lvh_grid_trace_max_helicity_first(self.h, capi.INTEGRATION_METHODS[method], capi.INTEGRATION_DIRECTIONS[direction],
                                                   time_step_scale, max_num_iterations, termination_distance, minimum_length,
                                                   minimum_separation_distance, termination_check_type, loop_check_mode,
-                                                  termination_distance_self, seeding_subsampling_factor, C.byref(nl), C.byref(npt))
+                                                  termination_distance_self, seeding_subsampling_factor, int(ribbons), int(use_helicity),
+                                                  max_helicity_twist, _p(ird), C.byref(nl), C.byref(npt))
     if rc != 0:
         raise capi.LineVisError(rc, self.L.lvh_grid_last_error(self.h).decode("utf-8", "replace"))
     pos = np.zeros((npt.value, 3), dtype=np.float32)
     att = np.zeros((self.num_scalars, npt.value), dtype=np.float32)
     off = np.zeros(nl.value + 1, dtype=np.uint32)
     self.L.lvh_grid_copy_result(self.h, _p(pos), _p(att), _p(off))
-    return pos, att, off
+    if not ribbons:
+        return pos, att, off
+    rib = np.zeros((npt.value, 3), dtype=np.float32)
+    self.L.lvh_grid_copy_ribbons(self.h, _p(rib))
+    return pos, att, off, rib
 
 
 StreamlineTracingGrid.trace_streamlines_max_helicity_first = _trace_streamlines_max_helicity_first

@@ -318,6 +318,11 @@ lvo_streamlines* lvo_trace_streamlines_max_helicity_first(
         const float* vectorField, int xs, int ys, int zs, float dx, float dy, float dz, const float* const* scalarFields,
         uint32_t numScalarFields, const float* helicityField, const lvo_streamline_settings* settings, float minimumSeparationDistance,
         uint32_t loopCheckMode, float terminationDistanceSelf, int seedingSubsamplingFactor);
+lvo_streamlines* lvo_trace_streamribbons_max_helicity_first(
+        const float* vectorField, int xs, int ys, int zs, float dx, float dy, float dz, const float* const* scalarFields,
+        uint32_t numScalarFields, const float* helicityField, const lvo_streamline_settings* settings, float minimumSeparationDistance,
+        uint32_t loopCheckMode, float terminationDistanceSelf, int seedingSubsamplingFactor, int useHelicity, float maxHelicityTwist,
+        const float* initialRibbonDirection);
 lvo_streamlines* lvo_trace_streamlines(const float* vectorField, int xs, int ys, int zs, float dx, float dy, float dz,
                                        const float* const* scalarFields, uint32_t numScalarFields, const float* seeds,
                                        uint32_t numSeeds, const lvo_streamline_settings* settings);

@@ -492,10 +492,39 @@ static lvo_streamlines* traceLines(const float* vectorField, int xs, int ys, int
 // start point (1), integrators 0 ... 4 (the Runge-Kutta-Fehlberg step width carries over from line to line in the reference).
 // Build-owned where the reference leaves it open: samples of equal helicity keep their creation order (std::sort is unstable);
 // sgl::Sphere::intersects(AABB) = squared distance from the centre to the box <= r^2; sgl::Plane(n, p).getDistance(q) = n.q - n.p.
+static lvo_streamlines* traceMaxHelicityFirst(
+        const float* vectorField, int xs, int ys, int zs, float dx, float dy, float dz, const float* const* scalarFields,
+        uint32_t numScalarFields, const float* helicityField, const lvo_streamline_settings* settings, float minimumSeparationDistance,
+        uint32_t loopCheckMode, float terminationDistanceSelf, int seedingSubsamplingFactor, const RibbonSettings* ribbons);
 lvo_streamlines* lvo_trace_streamlines_max_helicity_first(
         const float* vectorField, int xs, int ys, int zs, float dx, float dy, float dz, const float* const* scalarFields,
         uint32_t numScalarFields, const float* helicityField, const lvo_streamline_settings* settings, float minimumSeparationDistance,
         uint32_t loopCheckMode, float terminationDistanceSelf, int seedingSubsamplingFactor) {
+    return traceMaxHelicityFirst(vectorField, xs, ys, zs, dx, dy, dz, scalarFields, numScalarFields, helicityField, settings,
+                                 minimumSeparationDistance, loopCheckMode, terminationDistanceSelf, seedingSubsamplingFactor, nullptr);
+}
+// flowPrimitives == STREAMRIBBONS in _traceStreamribbonsDecreasingHelicity (:783-823): _pushRibbonDirections of every valid line's
+// parts -- with forwardMode = true for the backward part too (unlike traceStreamribbons, :479-486) -- then _reverseRibbon /
+// _insertBackwardRibbon.  The twist uses the same helicity field, normalised by its maximum magnitude.
+lvo_streamlines* lvo_trace_streamribbons_max_helicity_first(
+        const float* vectorField, int xs, int ys, int zs, float dx, float dy, float dz, const float* const* scalarFields,
+        uint32_t numScalarFields, const float* helicityField, const lvo_streamline_settings* settings, float minimumSeparationDistance,
+        uint32_t loopCheckMode, float terminationDistanceSelf, int seedingSubsamplingFactor, int useHelicity, float maxHelicityTwist,
+        const float* initialRibbonDirection) {
+    RibbonSettings R;
+    R.useHelicity = useHelicity != 0;
+    R.maxHelicityTwist = maxHelicityTwist;
+    R.initialRibbonDirection = ld3(initialRibbonDirection);
+    R.helicityField = helicityField;
+    R.maxHelicityMagnitude = 0.0f;
+    for (size_t i = 0; i < size_t(xs) * ys * zs; i++) R.maxHelicityMagnitude = std::max(R.maxHelicityMagnitude, fabsf(helicityField[i]));
+    return traceMaxHelicityFirst(vectorField, xs, ys, zs, dx, dy, dz, scalarFields, numScalarFields, helicityField, settings,
+                                 minimumSeparationDistance, loopCheckMode, terminationDistanceSelf, seedingSubsamplingFactor, &R);
+}
+static lvo_streamlines* traceMaxHelicityFirst(
+        const float* vectorField, int xs, int ys, int zs, float dx, float dy, float dz, const float* const* scalarFields,
+        uint32_t numScalarFields, const float* helicityField, const lvo_streamline_settings* settings, float minimumSeparationDistance,
+        uint32_t loopCheckMode, float terminationDistanceSelf, int seedingSubsamplingFactor, const RibbonSettings* ribbons) {
     Grid g;
     g.xs = xs; g.ys = ys; g.zs = zs; g.dx = dx; g.dy = dy; g.dz = dz;
     g.boxMin = v3(0.0f, 0.0f, 0.0f);
@@ -593,9 +622,11 @@ lvo_streamlines* lvo_trace_streamlines_max_helicity_first(
         if (S.integrationDirection == 0) {
             traceDecreasing(sm.pos, true, line);
             valid = lengthOf(line) >= S.minimumLength;
+            if (valid && ribbons) pushRibbonDirections(g, *ribbons, line.pos, line.ribbon, true);
         } else if (S.integrationDirection == 1) {
             traceDecreasing(sm.pos, false, line);
             valid = lengthOf(line) >= S.minimumLength;
+            if (valid && ribbons) pushRibbonDirections(g, *ribbons, line.pos, line.ribbon, true);
             if (valid) reverseLine(line);
         } else {
             Line back;
@@ -603,8 +634,13 @@ lvo_streamlines* lvo_trace_streamlines_max_helicity_first(
             traceDecreasing(sm.pos, false, back);
             valid = lengthOf(line) + lengthOf(back) >= S.minimumLength;
             if (valid) {
+                if (ribbons) {
+                    pushRibbonDirections(g, *ribbons, line.pos, line.ribbon, true);
+                    pushRibbonDirections(g, *ribbons, back.pos, back.ribbon, true);
+                }
                 reverseLine(back);
                 if (back.pos.size() > 1) {
+                    if (ribbons) line.ribbon.insert(line.ribbon.begin(), back.ribbon.begin(), back.ribbon.end() - 1);
                     line.pos.insert(line.pos.begin(), back.pos.begin(), back.pos.end() - 1);
                     if (line.att.empty()) line.att.resize(numScalarFields);
                     for (uint32_t a = 0; a < numScalarFields; a++)
@@ -614,6 +650,7 @@ lvo_streamlines* lvo_trace_streamlines_max_helicity_first(
         }
         if (!valid || line.pos.empty()) continue;
         for (const V3& p : line.pos) { out->positions.push_back(p.x); out->positions.push_back(p.y); out->positions.push_back(p.z); }
+        for (const V3& rb : line.ribbon) { out->ribbonDirections.push_back(rb.x); out->ribbonDirections.push_back(rb.y); out->ribbonDirections.push_back(rb.z); }
         for (uint32_t a = 0; a < numScalarFields; a++)
             out->attributes[a].insert(out->attributes[a].end(), line.att[a].begin(), line.att[a].end());
         out->offsets.push_back(uint32_t(out->positions.size() / 3));

@@ -188,6 +188,9 @@ def lib():
     L.lvo_max_vector_magnitude.argtypes = [vp, C.c_uint64]
     L.lvo_trace_streamlines.restype = vp
     L.lvo_trace_streamlines_max_helicity_first.restype = vp
+    L.lvo_trace_streamribbons_max_helicity_first.restype = vp
+    L.lvo_trace_streamribbons_max_helicity_first.argtypes = [vp, i32, i32, i32, f32, f32, f32, vp, u32, vp, C.POINTER(StreamlineSettings),
+                                                             f32, u32, f32, i32, i32, f32, vp]
     L.lvo_trace_streamlines_max_helicity_first.argtypes = [vp, i32, i32, i32, f32, f32, f32, vp, u32, vp, C.POINTER(StreamlineSettings),
                                                            f32, u32, f32, i32]
     L.lvo_trace_streamlines.argtypes = [vp, i32, i32, i32, f32, f32, f32, vp, u32, vp, u32, C.POINTER(StreamlineSettings)]
@@ -365,24 +368,36 @@ def trace_streamlines(vector_field, spacing, scalar_fields, seeds, settings):
 
 
 def trace_streamlines_max_helicity_first(vector_field, spacing, scalar_fields, helicity_field, settings, minimum_separation_distance=0.08,
-                                         loop_check_mode=1, termination_distance_self=1.0, seeding_subsampling_factor=1):
+                                         loop_check_mode=1, termination_distance_self=1.0, seeding_subsampling_factor=1, ribbons=None):
     """StreamlineMaxHelicityFirstSeeder + _traceStreamribbonsDecreasingHelicity, sequential: (positions, attributes, line_offsets)."""
     v = np.ascontiguousarray(vector_field, dtype=np.float32)
     zs, ys, xs = v.shape[:3]
     sf = [np.ascontiguousarray(f, dtype=np.float32) for f in scalar_fields]
     ptrs = (C.c_void_p * max(len(sf), 1))(*[f.ctypes.data for f in sf])
     hf = np.ascontiguousarray(helicity_field, dtype=np.float32)
-    h = lib().lvo_trace_streamlines_max_helicity_first(_p(v), xs, ys, zs, spacing[0], spacing[1], spacing[2], ptrs, len(sf), _p(hf),
-                                                       C.byref(settings), float(minimum_separation_distance), int(loop_check_mode),
-                                                       float(termination_distance_self), int(seeding_subsampling_factor))
+    if ribbons is None:
+        h = lib().lvo_trace_streamlines_max_helicity_first(_p(v), xs, ys, zs, spacing[0], spacing[1], spacing[2], ptrs, len(sf), _p(hf),
+                                                           C.byref(settings), float(minimum_separation_distance), int(loop_check_mode),
+                                                           float(termination_distance_self), int(seeding_subsampling_factor))
+    else:   # ribbons = dict(use_helicity=, max_helicity_twist=, initial_ribbon_direction=): the STREAMRIBBONS form, + ribbon directions
+        ird = np.ascontiguousarray(ribbons.get("initial_ribbon_direction", (0.0, 1.0, 0.0)), dtype=np.float32)
+        h = lib().lvo_trace_streamribbons_max_helicity_first(_p(v), xs, ys, zs, spacing[0], spacing[1], spacing[2], ptrs, len(sf), _p(hf),
+                                                             C.byref(settings), float(minimum_separation_distance), int(loop_check_mode),
+                                                             float(termination_distance_self), int(seeding_subsampling_factor),
+                                                             int(ribbons.get("use_helicity", True)), float(ribbons.get("max_helicity_twist", 0.25)),
+                                                             _p(ird))
     nl, npt = C.c_uint64(), C.c_uint64()
     lib().lvo_streamlines_sizes(h, C.byref(nl), C.byref(npt))
     pos = np.zeros((npt.value, 3), dtype=np.float32)
     att = np.zeros((len(sf), npt.value), dtype=np.float32)
     off = np.zeros(nl.value + 1, dtype=np.uint32)
     lib().lvo_streamlines_copy(h, _p(pos), _p(att), _p(off))
+    rib = None
+    if ribbons is not None:
+        rib = np.zeros((npt.value, 3), dtype=np.float32)
+        lib().lvo_streamlines_copy_ribbons(h, _p(rib))
     lib().lvo_streamlines_destroy(h)
-    return pos, att, off
+    return (pos, att, off) if ribbons is None else (pos, att, off, rib)
 
 
 def trace_streamribbons(vector_field, spacing, scalar_fields, seeds, settings, helicity_index, use_helicity=True,

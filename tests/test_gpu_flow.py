@@ -203,6 +203,13 @@ def test_host_tracer_classes(hip_lib):
     hb = lvo.trace_streamlines_max_helicity_first(v, sp, fields, fields[0], lvo.streamline_settings(minimum_length=0.3),
                                                   minimum_separation_distance=0.1)
     assert same(ha, hb) and len(ha[2]) > 10
+    for direction in ("Forward", "Backward", "Forward & Backward"):       # ... and its streamribbon form
+        ra = grid.trace_streamlines_max_helicity_first(direction=direction, minimum_length=0.3, minimum_separation_distance=0.1, ribbons=True,
+                                                       max_helicity_twist=0.5)
+        rb = lvo.trace_streamlines_max_helicity_first(v, sp, fields, fields[0], lvo.streamline_settings(direction=direction, minimum_length=0.3),
+                                                      minimum_separation_distance=0.1, ribbons=dict(max_helicity_twist=0.5))
+        assert same(ra[:3], rb[:3]) and np.array_equal(ra[3].view(np.uint32), rb[3].view(np.uint32)), direction
+        assert np.abs(np.linalg.norm(ra[3], axis=1) - 1).max() < 1e-3
     # a second vector field / scalar field set by hand, another integrator
     vec, scalars, sp2 = swirl_grid(20, 24, 16)
     grid.set_grid_extent(20, 24, 16, *sp2).add_vector_field(vec).add_scalar_field(scalars[1], "b").add_scalar_field(scalars[0], "a")
