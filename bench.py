@@ -58,15 +58,15 @@ WORKLOADS = {
                pmc="c3t", also="c3c"),
     "c3t": dict(name=C3T, scene="tornado", mode=11,
                 settings=dict(SETTINGS, rtao_geometry="triangle_tubes", intersection_form="literal"), kernel="k_ao_rays", mesh=True),
-    "c3c": dict(name=C3C, scene="tornado", mode=11, settings=dict(SETTINGS, intersection_form="closest_approach"),
+    "c3c": dict(name=C3C, scene="tornado", mode=11, settings=dict(SETTINGS, rtao_geometry="capsules", intersection_form="closest_approach"),
                 kernel="k_ao_rays"),
     "c5": dict(name="C5: 5M-segment Rayleigh-Benard-like convection rolls (5000 lines x 1001 points, seed 12345), 3840x2160, "
                     "colour pass 1 spp + RTAO 256 spp (1 iteration x 256 samples, radius 0.1, distance based, capsules), line "
                     "width 0.002; BASELINE.json config 5 (meant for 8 GPUs; with fewer the same frame takes proportionally longer)",
-               scene="rayleigh_benard", mode=11, settings=dict(SETTINGS, ambient_occlusion_samples_per_frame=256),
+               scene="rayleigh_benard", mode=11, settings=dict(SETTINGS, rtao_geometry="capsules", ambient_occlusion_samples_per_frame=256),
                kernel="k_ao_rays", resolution=(3840, 2160), ao_spp=256),
     "c2": dict(name="C2: 100k-segment helix bundle (100 lines x 1001 points, seed 12345), 1920x1080, primary rays only "
-                    "(1 spp, pixel centres, AO off, depth cues off), line width 0.002",
+                    "(1 spp, pixel centres, AO off, depth cues off), line width 0.002, the reference's literal ray-capsule roots (the default)",
                scene="helix", mode=11, settings={"num_samples_per_frame": 1, "depth_cue_strength": 0.0}, kernel="k_render_rt"),
     "c2e": dict(name="C2 scene (100k-segment helix bundle) as band data: twisted ribbon directions (8 rad per unit length), the ray "
                      "tracer's Elliptic Tubes (sphere-traced tubelets, band width 0.005, min thickness 0.15) + USE_BANDS shading, "
@@ -156,8 +156,9 @@ def cpu_baseline(W, H, pts, seg, tf, attr_range, view, proj, fovy, near, far, ta
         return time.time() - t, int(st.raysTraced)
 
     t_all = time.time()
-    if workload == "c3t":   # the timed GPU frame uses the reference's literal roots in its colour pass: so does the CPU restatement
-        lvo.set_default_intersection_form(True)
+    # the CPU restatement evaluates the capsule roots the timed GPU frame does: the reference's literal ones (intersection_form
+    # "auto") except where the frame's RTAO rays hit the analytic capsules (c3c asks for closest_approach, c5 gets it from "auto")
+    lvo.set_default_intersection_form(workload not in ("c3c", "c5"))
     cw, ch = 96, 54                             # calibration crop, then grow towards ~target_seconds of work
     dt, rays = run(cw, ch)
     for _ in range(3):

@@ -130,8 +130,9 @@ int lv_set_lines(lv_ctx* ctx, const lv_line_point* points, uint32_t num_points,
 
 /* The triangle tubes the reference's RTAO pass traces against (VulkanRayTracedAmbientOcclusion.cpp:444-445 fetches
  * LineData::getLinePassTubeTriangleMeshRenderData(false, true), LineData.hpp:182): index buffer (3 per triangle),
- * 32-byte TubeTriangleVertexData and the 48-byte line-point table the vertices refer to, copied to HBM.  Used when the
- * option rtao_geometry is "triangle_tubes"; the triangle LBVH is built on the next render. */
+ * 32-byte TubeTriangleVertexData and the 48-byte line-point table the vertices refer to, copied to HBM.  Belongs to the
+ * lines of the last lv_set_lines (a later lv_set_lines drops it); with it the option rtao_geometry = "auto" traces the RTAO rays
+ * against these triangles like the reference; the triangle LBVH is built on the next render that needs it. */
 int lv_set_tube_triangle_mesh(lv_ctx* ctx, const uint32_t* triangle_indices, uint32_t num_triangles,
                               const lv_tube_vertex* vertices, uint32_t num_vertices,
                               const lv_line_point* line_points, uint32_t num_line_points);
@@ -216,10 +217,13 @@ int lv_set_background(lv_ctx* ctx, const float rgba[4]);
  *   based use the ambient_occlusion_* keys,
  *   collect_stats (build-owned: run the instrumented kernels), mlat_record_trace / mlat_trace_capacity (build-owned,
  *   with collect_stats: record the candidate visiting order of an MLAT frame for lv_get_mlat_trace; records, 4 Mi),
- *   rtao_geometry (build-owned): "capsules" (default: AO rays hit the analytic capsules of the colour pass) or
- *   "triangle_tubes" (the reference's RTAO geometry: the mesh set with lv_set_tube_triangle_mesh),
- *   intersection_form (build-owned): "auto" (default: "literal" whenever rtao_geometry = "triangle_tubes", i.e. whenever the
- *   frame is the reference-faithful one and the colour pass is the only user of the capsule test; "closest_approach" otherwise) |
+ *   rtao_geometry (build-owned): "auto" (default: "triangle_tubes" -- the only geometry the reference's RTAO pass traces,
+ *   VulkanRayTracedAmbientOcclusion.cpp:437-456 -- once lv_set_tube_triangle_mesh has been called for the current lines,
+ *   "capsules" before that) | "triangle_tubes" (fails without the mesh) | "capsules" (AO rays hit the analytic capsules of the
+ *   colour pass: not a mode of the reference),
+ *   intersection_form (build-owned): "auto" (default: "literal", the reference's formula, in every frame the reference can
+ *   render; "closest_approach" only where the RTAO rays of the frame are traced against the analytic capsules, a mode the
+ *   reference does not have -- rays that start on a capsule need the stable roots) |
  *   "literal" (the reference's textbook roots, RayIntersectionTestsVulkan.glsl:39-119, with the own-box rule that keeps them
  *   independent of the BVH) | "closest_approach" (the same roots evaluated stably: NOT the reference's formula),
  *   ppll_fragment_colour (build-owned): "raster" (default: the PPLL gather shades with the raster tube shader's variant of

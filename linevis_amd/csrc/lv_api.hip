@@ -241,6 +241,10 @@ int lv_set_lines(lv_ctx* ctx, const lv_line_point* points, uint32_t num_points, 
     ctx->numPoints = num_points;
     ctx->numSegs = num_segments;
     ctx->accelValid = false;
+    // the triangle tubes belong to the lines they were tessellated from (the reference's passes fetch both in setLineData): new
+    // lines need lv_set_tube_triangle_mesh again before rtao_geometry = auto / triangle_tubes, Triangle Mesh or the prebaker use it
+    ctx->triMeshSet = false;
+    ctx->triAccelValid = false;
     // VulkanRayTracedAmbientOcclusionPass::setLineData (.cpp:437-460): denoiser->resetFrameNumber(), globalFrameNumber = 0,
     // lastFrameViewProjectionMatrix = the current camera's
     ctx->aoGlobalFrameNumber = 0;
@@ -699,8 +703,9 @@ int lv_set_option(lv_ctx* ctx, const char* key, const char* value) {
         else if (std::string(value) == "as_numbered") o.dispatchByCost = false;
         else return bad();
     } else if (k == "rtao_geometry") {
-        if (std::string(value) == "capsules") o.aoTriangleTubes = false;
-        else if (std::string(value) == "triangle_tubes") o.aoTriangleTubes = true;
+        if (std::string(value) == "auto") o.rtaoGeometry = 0;
+        else if (std::string(value) == "capsules") o.rtaoGeometry = 1;
+        else if (std::string(value) == "triangle_tubes") o.rtaoGeometry = 2;
         else return bad();
     } else {
         return lv_fail(ctx, LV_E_INVALID, "unknown option '%s'", key);

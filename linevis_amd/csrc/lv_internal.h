@@ -65,7 +65,7 @@ struct LvOptions {
     uint32_t bakeSamplesPerFrame = 4;         // :166 (radius / distance-based share the RTAO keys; same defaults :167-168)
     bool rtLss = false;                       // geometry_mode "Linear Swept Spheres" (VulkanRayTracer.hpp:56-63)
     bool rtTriangleMesh = false;              // geometry_mode "Triangle Mesh" / use_analytic_intersections=false (VulkanRayTracer.cpp:226-250)
-    bool aoTriangleTubes = false;             // rtao_geometry: false = capsules (build default), true = the reference's triangle tubes
+    int rtaoGeometry = 0;                     // rtao_geometry: 0 = auto (the reference's triangle tubes once lv_set_tube_triangle_mesh was called), 1 = capsules, 2 = triangle_tubes
     bool useMlat = false;                     // VulkanRayTracer.hpp:133
     uint32_t mlatNumNodes = 8;                // :134
     // EAW denoiser of the RTAO pass (ambient_occlusion_denoiser; AO defaults of createDenoiserObject, Denoiser.cpp:54-62)
@@ -234,9 +234,17 @@ struct lv_ctx {
 int lv_fail(lv_ctx* ctx, int code, const char* fmt, ...);
 // width the capsule LBVH's leaf boxes are padded with: the band width for elliptic tubes (useRibbonNormals,
 // LineDataFlow.cpp:2120-2126), the line width otherwise
-// the capsule roots in use: the reference's textbook form (RayIntersectionTestsVulkan.glsl:39-119) or the closest-approach form
+// RTAO geometry of the frame: the reference's triangle tubes (VulkanRayTracedAmbientOcclusion traces nothing else) whenever the mesh
+// is there, the analytic capsules of the colour pass otherwise / on request
+inline bool lv_ao_triangle_tubes(const lv_ctx* ctx) {
+    return ctx->opt.rtaoGeometry == 2 || (ctx->opt.rtaoGeometry == 0 && ctx->triMeshSet);
+}
+// the capsule roots in use: the reference's textbook form (RayIntersectionTestsVulkan.glsl:39-119) -- the default -- or the
+// closest-approach form; "auto" leaves the reference's form only where this build traces AO rays against the analytic capsules
+// (a mode the reference does not have: rays that start on a capsule need the stable roots)
 inline bool lv_literal_intersection(const lv_ctx* ctx) {
-    return ctx->opt.intersectionForm == 2 || (ctx->opt.intersectionForm == 0 && ctx->opt.aoTriangleTubes);
+    if (ctx->opt.intersectionForm != 0) return ctx->opt.intersectionForm == 2;
+    return !(ctx->opt.useAmbientOcclusion && !ctx->opt.aoPrebaked && !lv_ao_triangle_tubes(ctx));
 }
 inline float lv_accel_width(const lv_ctx* ctx) {
     return (ctx->opt.useRibbons && ctx->opt.ellipticTubes) ? ctx->opt.bandWidth : ctx->opt.lineWidth;

@@ -2382,7 +2382,7 @@ static int lv_run_ao(lv_ctx* ctx, LvUniforms& U, LvSceneDev& S, const LvTiles& T
     ctx->aoGroupsPerTile = (T.blocksX / 4u) * (T.blocksY / 4u);
     const uint64_t gridRays = lv_ao_grid(ctx, maxPixels * spp);
     const uint64_t gridMax = gridRays > gridTiles ? gridRays : gridTiles;
-    const bool tri = ctx->opt.aoTriangleTubes;
+    const bool tri = lv_ao_triangle_tubes(ctx);
     // RTAO geometry: the capsules of the colour pass, or the reference's triangle tubes (own LBVH, own scene view)
     LvSceneDev SA = tri ? sceneDevTriangles(ctx) : S;
     if ((rc = lv_prepare_overflow(ctx, SA, gridMax, LV_AO_STACK_LDS, tri))) return rc;
@@ -2530,7 +2530,7 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
     if (!ctx->accelValid || ctx->accelLineWidth != lv_accel_width(ctx))
         if ((rc = lv_bvh_build(ctx))) return rc;
     const bool needTriangles = (ctx->opt.useAmbientOcclusion && ctx->opt.aoPrebaked) ||
-                               (ctx->opt.useAmbientOcclusion && ctx->opt.aoTriangleTubes) ||
+                               (ctx->opt.useAmbientOcclusion && lv_ao_triangle_tubes(ctx)) ||
                                (ctx->opt.rtTriangleMesh && mode == LV_RENDERING_MODE_VULKAN_RAY_TRACER);
     if (needTriangles) {
         if (!ctx->triMeshSet)
@@ -2623,7 +2623,7 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
             const uint64_t nbAo = nAo * (((tw + 63u) / 64u) * 4u) * (((th + 63u) / 64u) * 4u);
             const uint64_t gridAo = ((nbAo + 127u) / 128u) * 128u;
             need = std::max(need, lv_overflow_bytes(ctx, std::max<uint64_t>(lv_ao_grid(ctx, nAo * tw * th * U.aoSamplesPerFrame), gridAo),
-                                                    LV_AO_STACK_LDS, ctx->opt.aoTriangleTubes));
+                                                    LV_AO_STACK_LDS, lv_ao_triangle_tubes(ctx)));
         }
         if (aoBake)
             need = std::max(need, lv_overflow_bytes(ctx, uint64_t(ctx->numCUs) * LV_AO_BLOCKS_PER_CU, LV_AO_STACK_LDS, true));

@@ -128,7 +128,7 @@ public:
     float ambientOcclusionRadius = 0.1f;         // :151
     bool useDistance = true;                     // :152
     bool useJitteredPrimaryRays = true;          // :153
-    bool useTriangleTubes = false;               // build-owned key "rtao_geometry": capsules | triangle_tubes
+    bool useTriangleTubes = true;                // build-owned key "rtao_geometry": triangle_tubes (the reference's RTAO geometry) | capsules
 
 private:
     lv_ctx* ctx;

@@ -39,10 +39,14 @@ class Case:
         return lvo.Scene(self.points, self.seg, self.tf)
 
     def literal_form(self):
-        """intersection_form as the library resolves it (lv_literal_intersection): "auto" = the reference's literal roots whenever
-        the RTAO pass traces the reference's triangle tubes, closest approach otherwise."""
-        f = self.settings.get("intersection_form", "auto")
-        return f == "literal" or (f == "auto" and self.settings.get("rtao_geometry") == "triangle_tubes")
+        """intersection_form as the library resolves it (lv_literal_intersection): "auto" = the reference's literal roots, except
+        in frames whose RTAO rays are traced against the analytic capsules (a mode the reference does not have)."""
+        s = self.settings
+        f = s.get("intersection_form", "auto")
+        if f != "auto":
+            return f == "literal"
+        ao_on = s.get("ambient_occlusion_mode", "None") == "RTAO (Screen Space)" and float(s.get("ambient_occlusion_strength", 0.0)) > 0.0
+        return not (ao_on and s.get("rtao_geometry", "capsules") != "triangle_tubes")
 
     def oracle_params(self, scene=None):
         s = self.settings

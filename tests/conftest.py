@@ -23,9 +23,9 @@ def hip_lib():
 
 @pytest.fixture(autouse=True)
 def _oracle_default_form():
-    """Every test starts with the oracle on the closest-approach roots; Case.oracle_params() switches it to what the case's
-    settings select (common.Case.literal_form)."""
+    """Every test starts with the oracle on the reference's literal roots (the library's default form); Case.oracle_params()
+    switches it to what the case's settings select (common.Case.literal_form)."""
     from oracle import lvo
-    lvo.set_default_intersection_form(False)
+    lvo.set_default_intersection_form(True)
     yield
-    lvo.set_default_intersection_form(False)
+    lvo.set_default_intersection_form(True)

@@ -35,7 +35,7 @@ def diff_counts(a, b):
 def test_literal_roots_bvh_equals_brute_force_and_switches_reset():
     """In literal mode the traversal culls against best + r, so it still returns the brute-force minimum of the noisy roots;
     leaving the context restores the default evaluation."""
-    c = small_case(width=96, height=64, line_width=0.004)
+    c = small_case(width=96, height=64, line_width=0.004, intersection_form="closest_approach")
     sc = c.oracle_scene()
     P = c.oracle_params(sc)
     base = sc.render_rt(P, use_bvh=True)
@@ -53,7 +53,7 @@ def test_literal_roots_small_frames(line_width, max_frac_gt2):
     more of its silhouette and shading is float32 noise.  Measured (320 x 240, 3540 segments): > 2 LSB on 0.7 % of the covered
     pixels at line width 0.02, 7.6 % at 0.004, 40 % at 0.002 -- the reference's default width.  The bounds pin the order
     of magnitude; the point is the number, not the assert."""
-    c = small_case(width=320, height=240, n_lines=60, pts_per_line=60, line_width=line_width)
+    c = small_case(width=320, height=240, n_lines=60, pts_per_line=60, line_width=line_width, intersection_form="closest_approach")
     sc = c.oracle_scene()
     P = c.oracle_params(sc)
     a = sc.render_rt(P, use_bvh=True)

@@ -64,7 +64,7 @@ def test_random_ray_tracer_cases(hip_lib, seed):
         tag = "seed %d case %d: %dx%d lw %g %s" % (seed, k, c.width, c.height, c.line_width, c.settings)
         ctx = c.hip_context()
         img = ctx.render(11)
-        literal = c.settings.get("intersection_form") == "literal"
+        literal = c.literal_form()
         with lvo.deviation_switches(literal_intersection=literal):
             ref, ao_ref = c.oracle_render(11)
         if ao_ref is not None:
@@ -157,8 +157,8 @@ def test_random_triangle_tube_cases(hip_lib, seed):
         tri_ao = bool(rng.integers(2)) and "ambient_occlusion_mode" in c.settings
         tri_colour = bool(rng.integers(2)) or not tri_ao
         tag = "seed %d case %d: %dx%d lw %g triAO %s triColour %s %s" % (seed, k, c.width, c.height, lw, tri_ao, tri_colour, c.settings)
-        if tri_ao:
-            c.settings["rtao_geometry"] = "triangle_tubes"
+        # the mesh is always there: pin the geometry ("auto" would trace the triangles whenever they are)
+        c.settings["rtao_geometry"] = "triangle_tubes" if tri_ao else "capsules"
         ctx = c.hip_context()
         ctx.set_tube_triangle_mesh(*mesh)
         if tri_colour:
@@ -228,8 +228,7 @@ def test_random_band_data_cases(hip_lib, seed):
         if geometry == "triangles":
             s["geometry_mode"] = "Triangle Mesh"
             s.pop("use_capped_tubes", None)
-        if tri_ao:
-            s["rtao_geometry"] = "triangle_tubes"
+        s["rtao_geometry"] = "triangle_tubes" if tri_ao else "capsules"   # ("auto" = the triangles whenever the mesh is set)
         c = Case(pts, seg, tf, int(rng.integers(40, 180)), int(rng.integers(30, 120)), lw, camera_pos=cam, **s)
         tag = "seed %d case %d: %dx%d lw %g %s" % (seed, k, c.width, c.height, lw, s)
         ctx = c.hip_context()
@@ -324,6 +323,7 @@ def test_random_helicity_band_cases(hip_lib, seed):
             mesh = lvo.build_tube_triangle_render_data(tr.positions, tr.attributes, tr.line_offsets, lw, nsub, helicities=hel)
         elif geometry == "lss":
             s["geometry_mode"] = "Linear Swept Spheres"
+        s["rtao_geometry"] = "capsules"        # the AO of these cases is the capsules' also where the triangle mesh is set
         tf = tfm.standard_transparent() if rng.uniform() < 0.4 else tfm.standard()
         cam = (float(rng.uniform(-0.4, 0.4)), float(rng.uniform(-0.3, 0.3)), float(rng.uniform(0.5, 1.0)))
         c = Case(pts, seg, tf, int(rng.integers(40, 180)), int(rng.integers(30, 120)), lw, camera_pos=cam, **s)

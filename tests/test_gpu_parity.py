@@ -443,7 +443,7 @@ def test_progressive_accumulation(hip_lib):
     """num_accumulated_frames > 1: the reference's interactive mode -- frame after frame, each mixed into the previous one
     through the rgba8 image (TubeRayTracing.glsl:268-273), RTAO one iteration per frame while frames < iterations."""
     c = small_case(num_accumulated_frames=5, num_samples_per_frame=2, **RTAO, ambient_occlusion_iterations=3,
-                   ambient_occlusion_samples_per_frame=4)
+                   ambient_occlusion_samples_per_frame=4, rtao_geometry="capsules")   # (the plugin below would tessellate the tubes)
     ref = c.oracle_render_progressive(5)
     ctx = c.hip_context()
     frames = []
@@ -520,7 +520,8 @@ def test_headless_renderer_plugins(hip_lib):
     tr = scenes.normalize(scenes.random_curves(n_lines=30, points_per_line=30, seed=7))
     flow = host_api.LineDataFlow().set_trajectories(tr.positions, tr.attributes, tr.line_offsets)
     settings = dict(line_width=0.02, depth_cue_strength=0.8, num_samples_per_frame=2, **RTAO,
-                    ambient_occlusion_iterations=1, ambient_occlusion_samples_per_frame=4)
+                    ambient_occlusion_iterations=1, ambient_occlusion_samples_per_frame=4,
+                    rtao_geometry="capsules")   # the plugin's default is the reference's triangle tubes: tests/test_gpu_triangle_tubes.py
     for mode, tf in ((11, tfm.standard()), (2, tfm.standard_transparent())):
         r = host_api.HeadlessLineRenderer(mode)
         assert r.rendering_mode == mode
@@ -578,6 +579,7 @@ def test_full_size_properties(hip_lib):
     d /= np.linalg.norm(d, axis=1, keepdims=True)
     a = ctx.trace_rays(o, d, 1e-4, 1000.0)
     sc = c.oracle_scene()
+    c.oracle_params(sc)                   # the oracle on the roots this case's settings select (RTAO against the capsules)
     b = sc.trace_rays(o, d, 1e-4, 1000.0, 0.002, use_bvh=True)
     assert np.array_equal(bits(a[0]), bits(b[0])) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
     # ... and against brute force over all 1M capsules for a few hundred of them
@@ -903,7 +905,7 @@ def test_linear_swept_spheres_geometry_mode(hip_lib, kw):
     assert max_lsb_diff(img, ref) <= LSB_TOL
     plain = dict(c.settings)
     plain["geometry_mode"] = "AABBs (analytic)"
-    plain.pop("intersection_form", None)
+    plain["intersection_form"] = "closest_approach"
     aabb = Case(c.points, c.seg, c.tf, c.width, c.height, c.line_width, **plain).hip_context().render(11)
     if kw.get("use_capped_tubes", True):
         assert np.array_equal(img, aabb)          # same surface, same shading

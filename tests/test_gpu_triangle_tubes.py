@@ -339,3 +339,55 @@ def test_triangles_per_leaf_do_not_change_any_hit(hip_lib, leaf_size):
     assert np.array_equal(x.render(capi.MODE_RAY_TRACER), want)
     with pytest.raises(Exception):
         ctx.set_option("triangle_leaf_size", 9)
+
+
+def test_defaults_are_the_reference_geometry_and_roots(hip_lib):
+    """Library defaults: rtao_geometry = "auto" traces the reference's triangle tubes as soon as the mesh of the current lines is there
+    (capsules before, and again after new lines), intersection_form = "auto" is the reference's literal roots in every frame the
+    reference can render -- the closest-approach form only where the RTAO rays hit the analytic capsules.  Each default frame is
+    byte-identical to the frame with the resolved values spelled out."""
+    lw = 0.004
+    tr = curves(20, 40, seed=3)
+    pts, seg, _ = lvo.build_tube_aabb_render_data(tr.positions, tr.attributes, tr.line_offsets, lw)
+    mesh = mesh_of(tr, lw)
+    rtao = dict(ambient_occlusion_mode="RTAO (Screen Space)", ambient_occlusion_strength=1.0, ambient_occlusion_iterations=1,
+                ambient_occlusion_samples_per_frame=8)
+
+    def frame(mesh_set, **settings):
+        ctx = Case(pts, seg, tfm.standard(), 160, 120, lw, **settings).hip_context()
+        if mesh_set:
+            ctx.set_tube_triangle_mesh(*mesh)
+        img = ctx.render(capi.MODE_RAY_TRACER)
+        ao = ctx.get_ao().copy() if "ambient_occlusion_mode" in settings else None
+        return ctx, img, ao
+
+    # no AO: the reference's roots
+    _, plain, _ = frame(False)
+    assert np.array_equal(plain, frame(False, intersection_form="literal")[1])
+    assert not np.array_equal(plain, frame(False, intersection_form="closest_approach")[1])
+    # RTAO without the mesh: capsules, stable roots
+    ctx, caps, ao_caps = frame(False, **rtao)
+    _, want, ao_want = frame(False, rtao_geometry="capsules", intersection_form="closest_approach", **rtao)
+    assert np.array_equal(caps, want) and np.array_equal(bits(ao_caps), bits(ao_want))
+    ctx.set_option("rtao_geometry", "triangle_tubes")
+    with pytest.raises(capi.LineVisError):
+        ctx.render(capi.MODE_RAY_TRACER)
+    # RTAO with the mesh: the reference's frame
+    ctx, tri, ao_tri = frame(True, **rtao)
+    _, want, ao_want = frame(True, rtao_geometry="triangle_tubes", intersection_form="literal", **rtao)
+    assert np.array_equal(tri, want) and np.array_equal(bits(ao_tri), bits(ao_want))
+    assert not np.array_equal(bits(ao_tri), bits(ao_caps))
+    # new lines drop the mesh
+    ctx.set_lines(pts, seg)
+    assert np.array_equal(ctx.render(capi.MODE_RAY_TRACER), caps)
+    # the plugin's RTAO baker traces the triangle tubes unless told otherwise
+    flow = host_api.LineDataFlow().set_trajectories(tr.positions, tr.attributes, tr.line_offsets)
+    imgs = []
+    for extra in (dict(), dict(rtao_geometry="triangle_tubes"), dict(rtao_geometry="capsules")):
+        r = host_api.HeadlessLineRenderer(capi.MODE_RAY_TRACER)
+        r.set_rendering_resolution(96, 64)
+        r.set_transfer_function(tfm.standard())
+        r.set_line_data(flow)
+        r.set_new_settings(dict(line_width=lw, **rtao, **extra))
+        imgs.append(r.render_frame())
+    assert np.array_equal(imgs[0], imgs[1]) and not np.array_equal(imgs[0], imgs[2])
