@@ -687,6 +687,28 @@ int lv_set_option(lv_ctx* ctx, const char* key, const char* value) {
         if (!parseUint(value, t) || t < 3 || t > 4096) return bad();
         if (t != o.treeletLeaves) { ctx->accelValid = false; ctx->triAccelValid = false; lv_invalidate_bake(ctx); }
         o.treeletLeaves = t;
+    } else if (k == "treelet_lane_leaves") {
+        // build-time tunable of the treelet pass (the tree does not depend on it): ranges of <= this many leaves are built by one lane
+        // each instead of by the whole wave; 0 = the wave splits every range
+        uint32_t t;
+        if (!parseUint(value, t) || t == 1 || t > 64) return bad();
+        if (t != o.treeletLaneLeaves) { ctx->accelValid = false; ctx->triAccelValid = false; lv_invalidate_bake(ctx); }
+        o.treeletLaneLeaves = t;
+    } else if (k == "treelet_group_leaves") {
+        // build-time tunable of the treelet pass (the tree does not depend on it): ranges of <= 8 / 16 leaves are built by groups of
+        // 8 / 16 lanes, 8 / 4 ranges per pass of the wave; 0 = see treelet_lane_leaves
+        uint32_t t;
+        if (!parseUint(value, t) || (t != 0 && t != 8 && t != 16)) return bad();
+        if (t != o.treeletGroupLeaves) { ctx->accelValid = false; ctx->triAccelValid = false; lv_invalidate_bake(ctx); }
+        o.treeletGroupLeaves = t;
+    } else if (k == "treelet_plane_eval") {
+        // how a wave evaluates the 45 split planes of a range (same planes, same costs, same tree): "scan" | "loop"
+        bool sc;
+        if (std::string(value) == "scan") sc = true;
+        else if (std::string(value) == "loop") sc = false;
+        else return bad();
+        if (sc != o.treeletPlaneScan) { ctx->accelValid = false; ctx->triAccelValid = false; lv_invalidate_bake(ctx); }
+        o.treeletPlaneScan = sc;
     } else if (k == "accel_build") {
         // the analogue of the reference's VK_BUILD_ACCELERATION_STRUCTURE_PREFER_FAST_TRACE_BIT_KHR (LineData.cpp:740-741): "fast_trace"
         // (default) rebuilds the LBVH's subtrees of <= treelet_leaves (512) leaves with a binned SAH, "fast_build" keeps the plain LBVH

@@ -270,16 +270,313 @@ __device__ __forceinline__ float lv_wave_max_f(float v) {
     return v;
 }
 
+// Ranges of at most `treelet_lane_leaves` (default 6) leaves are not split by the wave: 480 of the 511 splits of a 512-leaf treelet
+// have fewer leaves than the wave has lanes, and each of them costs the whole wave the same ~11 k cycles.  They are
+// queued instead and built 64 at a time, ONE LANE PER RANGE, by the same algorithm evaluated serially (same bins, same cost expression,
+// same tie rule: lowest axis, lowest plane; a plane whose last left bin is empty repeats its predecessor's cost and is skipped) -- the
+// tree is the same tree, node for node.  Slot numbers no longer follow from the order of the work: the serial order hands a range with
+// n leaves the n - 2 slots that follow its children's, so every queued range carries its own first slot (`vbase`).
+#define LV_TREELET_SYNC() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront")
+#define LV_TREELET_LANE_STACK 6u      // smaller half first: depth <= log2(64)
+#define LV_TREELET_LANE_MAX 64u
+__device__ __forceinline__ uint32_t lv_treelet_bin(const float* b, int ax, float cmn, float scale) {
+    const int bi = int(((b[ax] + b[3 + ax]) - cmn) * scale);
+    return uint32_t(bi < 0 ? 0 : (bi > int(LV_TREELET_BINS) - 1 ? int(LV_TREELET_BINS) - 1 : bi));
+}
+__device__ void lv_treelet_lane_build(const float (*s_box)[6], uint32_t* s_idx, uint32_t* s_tmp, uint32_t* stk, uint32_t a, uint32_t lo,
+                                      uint32_t hi, uint32_t slot, uint32_t v, uint32_t* __restrict__ childL,
+                                      uint32_t* __restrict__ childR) {
+    uint32_t sp = 0;
+    while (true) {
+        const uint32_t n = hi - lo;
+        uint32_t nl;
+        if (n == 2u) {
+            nl = 1u;
+        } else {
+            float cmn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, cmx[3] = {-3.0e38f, -3.0e38f, -3.0e38f}, scale[3];
+            for (uint32_t j = lo; j < hi; j++) {
+                const float* b = s_box[s_idx[j]];
+#pragma unroll
+                for (int k = 0; k < 3; k++) { const float c = b[k] + b[3 + k]; cmn[k] = fminf(cmn[k], c); cmx[k] = fmaxf(cmx[k], c); }
+            }
+#pragma unroll
+            for (int k = 0; k < 3; k++) { const float ext = cmx[k] - cmn[k]; scale[k] = ext > 0.0f ? float(LV_TREELET_BINS) / ext : 0.0f; }
+            float bestCost = 3.0e38f;
+            uint32_t bestAx = 0u, bestPlane = 0u;
+#pragma unroll
+            for (int ax = 0; ax < 3; ax++) {
+                uint32_t occ = 0u;
+                for (uint32_t j = lo; j < hi; j++) occ |= 1u << lv_treelet_bin(s_box[s_idx[j]], ax, cmn[ax], scale[ax]);
+                for (uint32_t plane = 1u; plane < LV_TREELET_BINS; plane++) {
+                    if (!((occ >> (plane - 1u)) & 1u)) continue;   // same left set as the plane before (or none): cannot win the tie
+                    if ((occ >> plane) == 0u) break;               // nothing on the right from here on
+                    float mn[2][3], mx[2][3];
+                    uint32_t cn[2] = {0u, 0u};
+#pragma unroll
+                    for (int h = 0; h < 2; h++)
+#pragma unroll
+                        for (int k = 0; k < 3; k++) { mn[h][k] = 3.0e38f; mx[h][k] = -3.0e38f; }
+                    for (uint32_t j = lo; j < hi; j++) {
+                        const float* b = s_box[s_idx[j]];
+                        const bool right = lv_treelet_bin(b, ax, cmn[ax], scale[ax]) >= plane;
+                        cn[0] += right ? 0u : 1u;
+                        cn[1] += right ? 1u : 0u;
+#pragma unroll
+                        for (int k = 0; k < 3; k++) {
+                            mn[0][k] = right ? mn[0][k] : fminf(mn[0][k], b[k]);
+                            mx[0][k] = right ? mx[0][k] : fmaxf(mx[0][k], b[3 + k]);
+                            mn[1][k] = right ? fminf(mn[1][k], b[k]) : mn[1][k];
+                            mx[1][k] = right ? fmaxf(mx[1][k], b[3 + k]) : mx[1][k];
+                        }
+                    }
+                    float area[2];
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        const float dx = mx[h][0] - mn[h][0], dy = mx[h][1] - mn[h][1], dz = mx[h][2] - mn[h][2];
+                        area[h] = dx * dy + dy * dz + dz * dx;
+                    }
+                    const float cost = area[0] * float(cn[0]) + area[1] * float(cn[1]);
+                    if (cost < bestCost) { bestCost = cost; bestAx = uint32_t(ax); bestPlane = plane; }
+                }
+            }
+            if (bestCost >= 3.0e38f) {
+                nl = n / 2u;
+            } else {
+                const float bc = bestAx == 0u ? cmn[0] : (bestAx == 1u ? cmn[1] : cmn[2]);
+                const float bs = bestAx == 0u ? scale[0] : (bestAx == 1u ? scale[1] : scale[2]);
+                uint32_t cntL = 0u;
+                for (uint32_t j = lo; j < hi; j++) {
+                    const float* b = s_box[s_idx[j]];
+                    const float c2 = bestAx == 0u ? b[0] + b[3] : (bestAx == 1u ? b[1] + b[4] : b[2] + b[5]);
+                    const int bi = int((c2 - bc) * bs);
+                    const uint32_t bn = uint32_t(bi < 0 ? 0 : (bi > int(LV_TREELET_BINS) - 1 ? int(LV_TREELET_BINS) - 1 : bi));
+                    cntL += bn < bestPlane ? 1u : 0u;
+                }
+                nl = cntL;
+                uint32_t runL = 0u, runR = 0u;
+                for (uint32_t j = lo; j < hi; j++) {
+                    const uint32_t e = s_idx[j];
+                    const float* b = s_box[e];
+                    const float c2 = bestAx == 0u ? b[0] + b[3] : (bestAx == 1u ? b[1] + b[4] : b[2] + b[5]);
+                    const int bi = int((c2 - bc) * bs);
+                    const uint32_t bn = uint32_t(bi < 0 ? 0 : (bi > int(LV_TREELET_BINS) - 1 ? int(LV_TREELET_BINS) - 1 : bi));
+                    if (bn < bestPlane) s_tmp[lo + runL++] = e; else s_tmp[lo + nl + runR++] = e;
+                }
+                for (uint32_t j = lo; j < hi; j++) s_idx[j] = s_tmp[j];
+                if (nl == 0u || nl == n) nl = n / 2u;
+            }
+        }
+        const uint32_t nr = n - nl;
+        const bool goL = nl > 1u, goR = nr > 1u;
+        const uint32_t sL = goL ? v++ : 0u, sR = goR ? v++ : 0u;
+        childL[slot] = goL ? sL : ((a + s_idx[lo]) | LV_LEAF_BIT);
+        childR[slot] = goR ? sR : ((a + s_idx[lo + nl]) | LV_LEAF_BIT);
+        if (goL && goR) {
+            const bool leftFirst = nl <= nr;
+            const uint32_t nF = leftFirst ? nl : nr;
+            stk[3u * sp] = (leftFirst ? lo + nl : lo) | ((leftFirst ? hi : lo + nl) << 16);
+            stk[3u * sp + 1u] = leftFirst ? sR : sL;
+            stk[3u * sp + 2u] = v + nF - 2u;
+            sp++;
+            if (leftFirst) { hi = lo + nl; slot = sL; } else { lo = lo + nl; slot = sR; }
+        } else if (goL) {
+            hi = lo + nl; slot = sL;
+        } else if (goR) {
+            lo = lo + nl; slot = sR;
+        } else {
+            if (sp == 0u) break;
+            sp--;
+            lo = stk[3u * sp] & 0xFFFFu; hi = stk[3u * sp] >> 16; slot = stk[3u * sp + 1u]; v = stk[3u * sp + 2u];
+        }
+    }
+}
+
+// GROUP builder: the queued ranges of at most G leaves (G = 8 or 16) are built 64 / G at a time, G lanes per range, one leaf per lane.
+// With so few leaves the bins are not materialised: a leaf's own bin on an axis names the lowest plane that has this leaf and
+// every leaf of a lower or equal bin on its left -- these are all distinct non-trivial partitions of the axis, each under the lowest
+// plane number that produces it, i.e. exactly the candidates that can win under the tie rule (lowest cost, lowest axis, lowest plane).
+// Lane i evaluates its three candidates against the boxes of the group's other leaves (fetched lane to lane), the group's best key
+// (cost bits, 15 axis + plane - 1) decides, the partition is a ballot.  Same bins, same unions, same cost expression: the same tree.
+template <uint32_t G>
+__device__ void lv_treelet_group_build(const float (*s_box)[6], uint32_t* s_idx, const uint32_t* s_items, uint32_t numItems,
+                                       uint32_t* s_gstack, uint32_t a, uint32_t* __restrict__ childL, uint32_t* __restrict__ childR) {
+    constexpr uint32_t NG = 64u / G;
+    const uint32_t lane = threadIdx.x, gi = lane % G, g = lane / G, gbase = g * G;
+    uint32_t* stk = s_gstack + g * 3u * LV_TREELET_LANE_STACK;
+    uint32_t nextItem = 0u;                 // wave-uniform
+    bool has = false;                       // group-uniform state, replicated in the group's lanes
+    uint32_t lo = 0u, hi = 0u, slot = 0u, v = 0u, sp = 0u;
+    while (true) {
+        // groups without a range take the next queued items, in group order
+        {
+            const unsigned long long idle = __ballot(!has && gi == 0u);
+            const uint32_t rank = uint32_t(__popcll(idle & ((1ull << gbase) - 1ull)));
+            if (!has && nextItem + rank < numItems) {
+                const uint32_t it = nextItem + rank;
+                lo = s_items[3u * it] & 0xFFFFu; hi = s_items[3u * it] >> 16; slot = s_items[3u * it + 1u]; v = s_items[3u * it + 2u];
+                sp = 0u;
+                has = true;
+            }
+            nextItem = min(numItems, nextItem + uint32_t(__popcll(idle)));
+        }
+        if (__ballot(has) == 0ull) break;
+        const uint32_t n = has ? hi - lo : 0u;
+        const bool valid = gi < n;
+        uint32_t e = 0u;
+        float b[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        if (valid) {
+            e = s_idx[lo + gi];
+#pragma unroll
+            for (int k = 0; k < 6; k++) b[k] = s_box[e][k];
+        }
+        // bounds of the box centres over the group
+        float cmn[3], cmx[3], scale[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) { const float c = b[k] + b[3 + k]; cmn[k] = valid ? c : 3.0e38f; cmx[k] = valid ? c : -3.0e38f; }
+#pragma unroll
+        for (uint32_t o = 1u; o < G; o <<= 1) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                cmn[k] = fminf(cmn[k], __shfl_xor(cmn[k], int(o), 64));
+                cmx[k] = fmaxf(cmx[k], __shfl_xor(cmx[k], int(o), 64));
+            }
+        }
+        uint32_t bn[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const float ext = cmx[k] - cmn[k];
+            scale[k] = ext > 0.0f ? float(LV_TREELET_BINS) / ext : 0.0f;
+            bn[k] = lv_treelet_bin(b, k, cmn[k], scale[k]);
+        }
+        const uint32_t packed = valid ? (bn[0] | (bn[1] << 4) | (bn[2] << 8) | 0x1000u) : 0u;
+        // the three candidates of this lane: unions of the leaves on either side of "bin <= own bin"
+        float mn[3][2][3], mx[3][2][3];
+        uint32_t cn[3][2];
+#pragma unroll
+        for (int ax = 0; ax < 3; ax++)
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                cn[ax][h] = 0u;
+#pragma unroll
+                for (int k = 0; k < 3; k++) { mn[ax][h][k] = 3.0e38f; mx[ax][h][k] = -3.0e38f; }
+            }
+#pragma unroll
+        for (uint32_t j = 0u; j < G; j++) {
+            const int src = int(gbase + j);
+            const uint32_t pj = uint32_t(__shfl(int(packed), src, 64));
+            float bj[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) bj[k] = __shfl(b[k], src, 64);
+            const bool vj = (pj & 0x1000u) != 0u;
+#pragma unroll
+            for (int ax = 0; ax < 3; ax++) {
+                const uint32_t bjx = (pj >> (4 * ax)) & 15u;
+                const bool left = vj && bjx <= bn[ax], right = vj && bjx > bn[ax];
+                cn[ax][0] += left ? 1u : 0u;
+                cn[ax][1] += right ? 1u : 0u;
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    mn[ax][0][k] = left ? fminf(mn[ax][0][k], bj[k]) : mn[ax][0][k];
+                    mx[ax][0][k] = left ? fmaxf(mx[ax][0][k], bj[3 + k]) : mx[ax][0][k];
+                    mn[ax][1][k] = right ? fminf(mn[ax][1][k], bj[k]) : mn[ax][1][k];
+                    mx[ax][1][k] = right ? fmaxf(mx[ax][1][k], bj[3 + k]) : mx[ax][1][k];
+                }
+            }
+        }
+        unsigned long long key = ~0ull;
+#pragma unroll
+        for (int ax = 0; ax < 3; ax++) {
+            if (valid && cn[ax][1] != 0u) {   // (the left side holds this leaf; plane = own bin + 1 <= 15 because a higher bin exists)
+                float area[2];
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const float dx = mx[ax][h][0] - mn[ax][h][0], dy = mx[ax][h][1] - mn[ax][h][1], dz = mx[ax][h][2] - mn[ax][h][2];
+                    area[h] = dx * dy + dy * dz + dz * dx;
+                }
+                const float cost = area[0] * float(cn[ax][0]) + area[1] * float(cn[ax][1]);
+                if (cost < 3.0e38f) {
+                    const unsigned long long kk = ((unsigned long long)__float_as_uint(cost) << 32) |
+                                                  (uint32_t(ax) * (LV_TREELET_BINS - 1u) + bn[ax]);   // plane - 1 = own bin
+                    key = kk < key ? kk : key;
+                }
+            }
+        }
+#pragma unroll
+        for (uint32_t o = 1u; o < G; o <<= 1) {
+            const unsigned long long ok = (unsigned long long)__shfl_xor((long long)key, int(o), 64);
+            key = ok < key ? ok : key;
+        }
+        uint32_t nl;
+        if (n == 2u) {
+            nl = 1u;
+        } else if (key == ~0ull) {
+            nl = n / 2u;   // every centre in one bin on every axis: split the range in the middle
+        } else {
+            const uint32_t bl = uint32_t(key & 0xFFFFFFFFull), ax = bl / (LV_TREELET_BINS - 1u), plane = bl % (LV_TREELET_BINS - 1u) + 1u;
+            const uint32_t mine = ax == 0u ? bn[0] : (ax == 1u ? bn[1] : bn[2]);
+            const bool left = valid && mine < plane;
+            const uint32_t gm = uint32_t((__ballot(left) >> gbase) & ((1ull << G) - 1ull));
+            const uint32_t gv = uint32_t((__ballot(valid) >> gbase) & ((1ull << G) - 1ull));
+            const uint32_t below = (1u << gi) - 1u;
+            nl = uint32_t(__popc(gm));
+            if (has && valid && n != 2u)
+                s_idx[lo + (left ? uint32_t(__popc(gm & below)) : nl + uint32_t(__popc(gv & ~gm & below)))] = e;   // stable partition, in place
+        }
+        LV_TREELET_SYNC();
+        if (has) {
+            const uint32_t nr = n - nl;
+            const bool goL = nl > 1u, goR = nr > 1u;
+            const uint32_t sL = goL ? v++ : 0u, sR = goR ? v++ : 0u;
+            if (gi == 0u) {
+                childL[slot] = goL ? sL : ((a + s_idx[lo]) | LV_LEAF_BIT);
+                childR[slot] = goR ? sR : ((a + s_idx[lo + nl]) | LV_LEAF_BIT);
+            }
+            if (goL && goR) {
+                const bool leftFirst = nl <= nr;
+                const uint32_t nF = leftFirst ? nl : nr;
+                if (gi == 0u) {
+                    stk[3u * sp] = (leftFirst ? lo + nl : lo) | ((leftFirst ? hi : lo + nl) << 16);
+                    stk[3u * sp + 1u] = leftFirst ? sR : sL;
+                    stk[3u * sp + 2u] = v + nF - 2u;
+                }
+                sp++;
+                if (leftFirst) { hi = lo + nl; slot = sL; } else { lo = lo + nl; slot = sR; }
+            } else if (goL) {
+                hi = lo + nl; slot = sL;
+            } else if (goR) {
+                lo = lo + nl; slot = sR;
+            } else if (sp == 0u) {
+                has = false;
+            } else {
+                sp--;
+                LV_TREELET_SYNC();
+                lo = stk[3u * sp] & 0xFFFFu; hi = stk[3u * sp] >> 16; slot = stk[3u * sp + 1u]; v = stk[3u * sp + 2u];
+            }
+        }
+        LV_TREELET_SYNC();
+    }
+}
+
+// SCAN = false keeps the round-3 form of the plane evaluation (one lane per plane looping over the bins, shuffle reduction): the
+// reference form the tests compare the scan form against (option treelet_plane_eval = loop).
+// The workgroup is ONE wave: its LDS operations execute in order, so the phases are separated by wave-scope fences (compiler ordering)
+// instead of __syncthreads().  Measured with cycle counters per phase (EXPERIMENTS.md 11.5): a split costs ~11 k cycles whatever its
+// size up to 64 leaves -- neither the barriers nor the LDS round trips (scan and loop form of the plane evaluation: 4.6 vs 4.4 ms for
+// the whole build) but the ~1 500 instructions a lone wave issues for it; 70 % of a treelet's splits have <= 8 leaves.
+template <bool SCAN>
 __global__ __launch_bounds__(64) void k_treelet_rebuild(const uint32_t* __restrict__ roots, const uint32_t* __restrict__ rangeLo,
                                                         const uint32_t* __restrict__ rangeHi, const float* __restrict__ leafBox,
-                                                        uint32_t maxLeaves, uint32_t* __restrict__ childL,
-                                                        uint32_t* __restrict__ childR) {
+                                                        uint32_t maxLeaves, uint32_t laneLeaves, uint32_t groupLeaves,
+                                                        uint32_t* __restrict__ childL, uint32_t* __restrict__ childR) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[]; // maxLeaves x (24-byte box + two index arrays)
     float (*s_box)[6] = reinterpret_cast<float (*)[6]>(s_dyn);
     uint32_t* s_idx = reinterpret_cast<uint32_t*>(s_dyn + size_t(maxLeaves) * 24);
     uint32_t* s_tmp = s_idx + maxLeaves;
     __shared__ uint32_t s_bmin[3][LV_TREELET_BINS][3], s_bmax[3][LV_TREELET_BINS][3], s_bcnt[3][LV_TREELET_BINS];
-    __shared__ uint32_t s_stack[3 * 16];
+    __shared__ uint32_t s_stack[4 * 16];
+    __shared__ unsigned long long s_best;
+    __shared__ uint32_t s_small[3 * 64];                                  // queued small ranges: {lo | hi << 16, slot, vbase}
+    __shared__ uint32_t s_lstack[64 * 3 * LV_TREELET_LANE_STACK];         // their builders' stacks, one per lane
     const uint32_t lane = threadIdx.x;
     const unsigned long long below = (1ull << lane) - 1ull;
     const uint32_t root = roots[blockIdx.x];
@@ -289,14 +586,34 @@ __global__ __launch_bounds__(64) void k_treelet_rebuild(const uint32_t* __restri
         for (int k = 0; k < 6; k++) s_box[j][k] = leafBox[6 * size_t(a + j) + k];
         s_idx[j] = j;
     }
-    __syncthreads();
+    LV_TREELET_SYNC();
     // A Karras node is the first or the last leaf index of its range: the subtree's internal nodes are a ... a + m - 2 when the root
     // is a, a + 1 ... a + m - 1 when it is a + m - 1 -- either way the m - 2 nodes below the root are a + 1 ... a + m - 2.
-    uint32_t nextSlot = a + 1u;
-    auto takeSlot = [&]() { return nextSlot++; };
-    uint32_t sp = 0, lo = 0, hi = m, slot = root;
+    uint32_t sp = 0, lo = 0, hi = m, slot = root, v = a + 1u, nSmall = 0u;
+    auto runSmall = [&]() {   // groups of 8 / 16 lanes per queued range (treelet_group_leaves), or one lane per range
+        LV_TREELET_SYNC();
+        if (groupLeaves == 8u) lv_treelet_group_build<8u>(s_box, s_idx, s_small, nSmall, s_lstack, a, childL, childR);
+        else if (groupLeaves == 16u) lv_treelet_group_build<16u>(s_box, s_idx, s_small, nSmall, s_lstack, a, childL, childR);
+        else if (lane < nSmall)
+            lv_treelet_lane_build(s_box, s_idx, s_tmp, &s_lstack[lane * 3u * LV_TREELET_LANE_STACK], a, s_small[3u * lane] & 0xFFFFu,
+                                  s_small[3u * lane] >> 16, s_small[3u * lane + 1u], s_small[3u * lane + 2u], childL, childR);
+        nSmall = 0u;
+        LV_TREELET_SYNC();
+    };
+    if (groupLeaves != 0u) laneLeaves = groupLeaves;   // the queue threshold
     while (true) {
         const uint32_t n = hi - lo;
+        if (laneLeaves != 0u && n <= laneLeaves) {
+            if (lane == 0u) { s_small[3u * nSmall] = lo | (hi << 16); s_small[3u * nSmall + 1u] = slot; s_small[3u * nSmall + 2u] = v; }
+            nSmall++;
+            if (nSmall == 64u) runSmall();
+            if (sp == 0u) break;
+            sp--;
+            LV_TREELET_SYNC();
+            lo = s_stack[4 * sp]; hi = s_stack[4 * sp + 1]; slot = s_stack[4 * sp + 2]; v = s_stack[4 * sp + 3];
+            LV_TREELET_SYNC();
+            continue;
+        }
         uint32_t nl;
         if (n == 2u) {
             nl = 1u;
@@ -322,7 +639,8 @@ __global__ __launch_bounds__(64) void k_treelet_rebuild(const uint32_t* __restri
                 for (int k = 0; k < 3; k++) { s_bmin[ax][bn][k] = 0xFFFFFFFFu; s_bmax[ax][bn][k] = 0u; }
                 s_bcnt[ax][bn] = 0u;
             }
-            __syncthreads();
+            if (lane == 63u) s_best = ~0ull;
+            LV_TREELET_SYNC();
             for (uint32_t j = lo + lane; j < hi; j += 64u) {
                 const float* b = s_box[s_idx[j]];
 #pragma unroll
@@ -337,9 +655,72 @@ __global__ __launch_bounds__(64) void k_treelet_rebuild(const uint32_t* __restri
                     atomicAdd(&s_bcnt[ax][bn], 1u);
                 }
             }
-            __syncthreads();
-            // the 3 x 15 split planes, one per lane: cost = area(left) * count(left) + area(right) * count(right)
+            LV_TREELET_SYNC();
+            // the 3 x 15 split planes: cost = area(left) * count(left) + area(right) * count(right).  Lane (axis, bin) = row of 16 lanes per
+            // axis loads its bin, an inclusive prefix and an inclusive suffix scan over the row (DPP row shifts: no LDS round trips)
+            // give every lane the union of the bins up to / from its own; plane p of an axis = prefix of bin p - 1 | suffix of bin p.
+            // (the round-3 form -- one lane per plane looping over the 16 bins, treelet_plane_eval = loop -- measures the same)
             float cost = 3.0e38f;
+            float bc;
+            uint32_t bl;
+            if constexpr (SCAN) {
+            const uint32_t rowAx = lane / LV_TREELET_BINS, rowBin = lane % LV_TREELET_BINS;
+            {
+                float pmn[3], pmx[3], smn[3], smx[3];
+                uint32_t pc = 0u;
+                if (rowAx < 3u) {
+                    pc = s_bcnt[rowAx][rowBin];
+#pragma unroll
+                    for (int k = 0; k < 3; k++) {
+                        pmn[k] = pc ? lv_ord2f(s_bmin[rowAx][rowBin][k]) : 3.0e38f;
+                        pmx[k] = pc ? lv_ord2f(s_bmax[rowAx][rowBin][k]) : -3.0e38f;
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 3; k++) { pmn[k] = 3.0e38f; pmx[k] = -3.0e38f; }
+                }
+                uint32_t sc = pc;
+#pragma unroll
+                for (int k = 0; k < 3; k++) { smn[k] = pmn[k]; smx[k] = pmx[k]; }
+#define LV_DPP_F(old, v, ctrl) __uint_as_float(uint32_t(__builtin_amdgcn_update_dpp(int(__float_as_uint(old)), int(__float_as_uint(v)), ctrl, 0xF, 0xF, false)))
+#define LV_DPP_U(old, v, ctrl) uint32_t(__builtin_amdgcn_update_dpp(int(old), int(v), ctrl, 0xF, 0xF, false))
+#define LV_SCAN_STEP(d)                                                                                              \
+                {                                                                                                    \
+                    pc += LV_DPP_U(0u, pc, 0x110 + d);                                                               \
+                    sc += LV_DPP_U(0u, sc, 0x100 + d);                                                               \
+                    _Pragma("unroll") for (int k = 0; k < 3; k++) {                                                  \
+                        pmn[k] = fminf(pmn[k], LV_DPP_F(3.0e38f, pmn[k], 0x110 + d));   /* row_shr: from lane - d */  \
+                        pmx[k] = fmaxf(pmx[k], LV_DPP_F(-3.0e38f, pmx[k], 0x110 + d));                               \
+                        smn[k] = fminf(smn[k], LV_DPP_F(3.0e38f, smn[k], 0x100 + d));   /* row_shl: from lane + d */  \
+                        smx[k] = fmaxf(smx[k], LV_DPP_F(-3.0e38f, smx[k], 0x100 + d));                               \
+                    }                                                                                                \
+                }
+                LV_SCAN_STEP(1) LV_SCAN_STEP(2) LV_SCAN_STEP(4) LV_SCAN_STEP(8)
+                // left side of plane rowBin = the prefix of the bin before
+                const uint32_t lc = LV_DPP_U(0u, pc, 0x111);
+                float lmn[3], lmx[3];
+#pragma unroll
+                for (int k = 0; k < 3; k++) { lmn[k] = LV_DPP_F(3.0e38f, pmn[k], 0x111); lmx[k] = LV_DPP_F(-3.0e38f, pmx[k], 0x111); }
+#undef LV_SCAN_STEP
+#undef LV_DPP_U
+#undef LV_DPP_F
+                if (rowAx < 3u && rowBin >= 1u && lc != 0u && sc != 0u) {
+                    const float dx0 = lmx[0] - lmn[0], dy0 = lmx[1] - lmn[1], dz0 = lmx[2] - lmn[2];
+                    const float dx1 = smx[0] - smn[0], dy1 = smx[1] - smn[1], dz1 = smx[2] - smn[2];
+                    const float a0 = dx0 * dy0 + dy0 * dz0 + dz0 * dx0, a1 = dx1 * dy1 + dy1 * dz1 + dz1 * dx1;
+                    cost = a0 * float(lc) + a1 * float(sc);
+                }
+            }
+            // best plane of the wave (lowest cost, ties: lowest axis, then lowest plane): one 64-bit LDS atomicMin on (cost bits, plane
+            // number) -- costs are non-negative, their bit patterns order like the values
+            if (cost < 3.0e38f)
+                atomicMin(&s_best, ((unsigned long long)__float_as_uint(cost) << 32) | (rowAx * (LV_TREELET_BINS - 1u) + rowBin - 1u));
+            LV_TREELET_SYNC();
+            const unsigned long long bestKey = s_best;
+            bc = bestKey == ~0ull ? 3.0e38f : __uint_as_float(uint32_t(bestKey >> 32));
+            bl = uint32_t(bestKey & 0xFFFFFFFFull);
+            } else {
+            // round-3 form: one lane per plane, loop over the bins; best plane by a shuffle reduction (lowest cost, ties: lowest lane)
             if (lane < 3u * (LV_TREELET_BINS - 1u)) {
                 const uint32_t ax = lane / (LV_TREELET_BINS - 1u), plane = lane % (LV_TREELET_BINS - 1u) + 1u;
                 float mn[2][3], mx[2][3];
@@ -369,14 +750,14 @@ __global__ __launch_bounds__(64) void k_treelet_rebuild(const uint32_t* __restri
                     cost = area[0] * float(cn[0]) + area[1] * float(cn[1]);
                 }
             }
-            // best plane of the wave (lowest cost, ties: lowest lane)
-            float bc = cost;
-            uint32_t bl = lane;
+            bc = cost;
+            bl = lane;
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) {
                 const float oc = __shfl_xor(bc, o, 64);
                 const uint32_t ol = uint32_t(__shfl_xor(int(bl), o, 64));
                 if (oc < bc || (oc == bc && ol < bl)) { bc = oc; bl = ol; }
+            }
             }
             if (bc >= 3.0e38f) {
                 nl = n / 2u; // every centre in one bin on every axis: split the range in the middle
@@ -417,25 +798,27 @@ __global__ __launch_bounds__(64) void k_treelet_rebuild(const uint32_t* __restri
                     runL += uint32_t(__popcll(mL));
                     runR += uint32_t(__popcll(mR));
                 }
-                __syncthreads();
+                LV_TREELET_SYNC();
                 for (uint32_t j = lo + lane; j < hi; j += 64u) s_idx[j] = s_tmp[j];
-                __syncthreads();
+                LV_TREELET_SYNC();
                 if (nl == 0u || nl == n) nl = n / 2u; // cannot happen with finite boxes (both sides of the chosen plane hold leaves); NaN input
             }
         }
         // children of `slot`: a single leaf becomes a leaf reference, a longer range gets a slot of its own
         const uint32_t nr = n - nl;
-        const uint32_t sL = nl > 1u ? takeSlot() : 0u, sR = nr > 1u ? takeSlot() : 0u;
-        if (lane == 0u) {
-            childL[slot] = nl > 1u ? sL : ((a + s_idx[lo]) | LV_LEAF_BIT);
-            childR[slot] = nr > 1u ? sR : ((a + s_idx[lo + nl]) | LV_LEAF_BIT);
-        }
-        // continue with the smaller half that still needs a split, stack the other (depth <= log2 of the treelet size)
         const bool goL = nl > 1u, goR = nr > 1u;
+        const uint32_t sL = goL ? v++ : 0u, sR = goR ? v++ : 0u;   // the serial order: both children's slots, then the first half's subtree
+        if (lane == 0u) {
+            childL[slot] = goL ? sL : ((a + s_idx[lo]) | LV_LEAF_BIT);
+            childR[slot] = goR ? sR : ((a + s_idx[lo + nl]) | LV_LEAF_BIT);
+        }
+        // continue with the smaller half that still needs a split, stack the other (depth <= log2 of the treelet size); the stacked
+        // half's slots follow the nF - 2 slots of the first half's subtree
         if (goL && goR) {
             const bool leftFirst = nl <= nr;
             const uint32_t plo = leftFirst ? lo + nl : lo, phi = leftFirst ? hi : lo + nl, pslot = leftFirst ? sR : sL;
-            if (lane == 0u) { s_stack[3 * sp] = plo; s_stack[3 * sp + 1] = phi; s_stack[3 * sp + 2] = pslot; }
+            const uint32_t nF = leftFirst ? nl : nr;
+            if (lane == 0u) { s_stack[4 * sp] = plo; s_stack[4 * sp + 1] = phi; s_stack[4 * sp + 2] = pslot; s_stack[4 * sp + 3] = v + nF - 2u; }
             sp++;
             if (leftFirst) { hi = lo + nl; slot = sL; } else { lo = lo + nl; slot = sR; }
         } else if (goL) {
@@ -445,11 +828,12 @@ __global__ __launch_bounds__(64) void k_treelet_rebuild(const uint32_t* __restri
         } else {
             if (sp == 0u) break;
             sp--;
-            __syncthreads();
-            lo = s_stack[3 * sp]; hi = s_stack[3 * sp + 1]; slot = s_stack[3 * sp + 2];
+            LV_TREELET_SYNC();
+            lo = s_stack[4 * sp]; hi = s_stack[4 * sp + 1]; slot = s_stack[4 * sp + 2]; v = s_stack[4 * sp + 3];
         }
-        __syncthreads();
+        LV_TREELET_SYNC();
     }
+    if (nSmall) runSmall();
 }
 
 // Bottom-up boxes + heights in PASSES: in pass k every internal node whose two children were finished in an EARLIER pass
@@ -753,11 +1137,13 @@ static int lv_bvh_build_core(lv_ctx* ctx, uint32_t n, LvDeviceBuffer& nodesOut, 
                     return lv_fail(ctx, LV_E_INVALID, "treelet_leaves = %u needs %zu bytes of LDS per workgroup, the device has %d",
                                    ctx->opt.treeletLeaves, ldsBytes, maxLds);
                 }
+                auto* kernel = ctx->opt.treeletPlaneScan ? k_treelet_rebuild<true> : k_treelet_rebuild<false>;
                 if (ldsBytes > 48 * 1024) // beyond the default limit of dynamic LDS (gfx950: 160 KB per workgroup)
-                    LV_HIPF(hipFuncSetAttribute((const void*)k_treelet_rebuild, hipFuncAttributeMaxDynamicSharedMemorySize, int(ldsBytes)));
-                k_treelet_rebuild<<<numTreelets, 64, ldsBytes, st>>>(
+                    LV_HIPF(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, int(ldsBytes)));
+                kernel<<<numTreelets, 64, ldsBytes, st>>>(
                         (const uint32_t*)wideIndex.ptr, (const uint32_t*)depth.ptr, (const uint32_t*)evenFlag.ptr,
-                        (const float*)leafBox.ptr, ctx->opt.treeletLeaves, (uint32_t*)childL.ptr, (uint32_t*)childR.ptr);
+                        (const float*)leafBox.ptr, ctx->opt.treeletLeaves, ctx->opt.treeletLaneLeaves, ctx->opt.treeletGroupLeaves,
+                        (uint32_t*)childL.ptr, (uint32_t*)childR.ptr);
             }
         }
         // refit: one pass per level of the binary tree; the root's stamp is polled every 8 passes

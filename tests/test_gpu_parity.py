@@ -156,6 +156,33 @@ def test_every_build_gives_the_same_hits_and_frames(hip_lib):
     assert np.array_equal(a.render(2), b.render(2))
 
 
+def test_treelet_lane_builder_builds_the_same_tree(hip_lib):
+    """treelet_group_leaves / treelet_lane_leaves (small ranges of a treelet built by groups of lanes / one lane per range) and
+    treelet_plane_eval are build-time choices only: the compressed 4-wide tree and the
+    leaf order are byte-identical to the build in which the wave splits every range (0), for small and large treelets, for a scene
+    smaller than one treelet, and with more than 64 queued ranges per treelet (treelet_leaves = 4096, lane ranges of 2 ... 8)."""
+    for scene in (small_case(n_lines=60, pts_per_line=50, seed=5, line_width=0.01),
+                  small_case(n_lines=6, pts_per_line=9, seed=2, line_width=0.02),
+                  small_case(n_lines=150, pts_per_line=80, seed=9, line_width=0.004)):
+        n = len(scene.seg)
+        for tl in (512, 7, 64, 4096):
+            want = None
+            for ll, ev, gl in ((0, "loop", 0), (0, "scan", 0), (2, "scan", 0), (3, "loop", 0), (4, "scan", 0), (8, "scan", 0), (16, "loop", 0),
+                               (33, "scan", 0), (64, "scan", 0), (6, "scan", 8), (6, "loop", 16), (0, "scan", 16)):
+                ctx = scene.hip_context()
+                ctx.set_option("treelet_leaves", tl)
+                ctx.set_option("treelet_lane_leaves", ll)
+                ctx.set_option("treelet_group_leaves", gl)   # 8 / 16: queued ranges built by groups of lanes (the default: 8)
+                ctx.set_option("treelet_plane_eval", ev)   # loop = the round-3 form of the plane evaluation, the reference form
+                ctx.build_accel()
+                nodes, leaf_seg = ctx.get_accel(ctx.stats().num_nodes, n)
+                if want is None:
+                    want = (nodes.copy(), leaf_seg.copy())
+                else:
+                    assert nodes.shape == want[0].shape and np.array_equal(nodes, want[0]), (n, tl, ll, ev, gl)
+                    assert np.array_equal(leaf_seg, want[1]), (n, tl, ll, ev, gl)
+
+
 def test_golden_rtao(hip_lib):
     g, pts, W, H, lw = golden_base()
     c = Case(pts, g["seg"], g["tf"], W, H, lw, ambient_occlusion_mode="RTAO (Screen Space)",

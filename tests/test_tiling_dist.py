@@ -138,3 +138,41 @@ def test_detile_helper():
     frame = tiling.detile(px, tiles, 50, 30, 16)
     yy, xx = np.meshgrid(np.arange(30), np.arange(50), indexing="ij")
     assert np.array_equal(frame, _pattern(xx, yy))
+
+
+_RCCL_WORLD1 = r"""
+import os, sys, torch, torch.distributed as dist
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+try:
+    dist.barrier()
+    c = torch.arange(6, dtype=torch.float64, device=dev)
+    dist.all_reduce(c)                                   # counters of the instrumented frame
+    t = torch.tensor([1.25], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)             # max-over-ranks time
+    out = (torch.arange(3 * 64 * 64 * 4, device=dev) % 251).to(torch.uint8).view(3, 64, 64, 4)
+    got = [torch.empty_like(out)]
+    dist.gather(out, gather_list=got, dst=0)             # the one data-path collective: RGBA8 tiles to rank 0
+    torch.cuda.synchronize()
+    ok = bool(torch.equal(got[0], out)) and float(t.item()) == 1.25 and c.tolist() == [0.0, 1.0, 2.0, 3.0, 4.0, 5.0]
+    print("RCCL_WORLD1_OK" if ok else "RCCL_WORLD1_MISMATCH", dist.get_backend(), dist.get_world_size())
+finally:
+    dist.destroy_process_group()
+"""
+
+
+@pytest.mark.gpu
+def test_torch_rccl_process_group_on_one_gpu():
+    """The collectives bench.py / tiling.ShardedFrame issue with N > 1 (barrier, sum and max all-reduce of float64 scalars, gather of
+    uint8 tiles to rank 0) through torch.distributed's nccl (= RCCL) backend on a 1-rank communicator: everything of the N > 1 path a
+    single MI355X can exercise -- the RCCL library torch ships, communicator set-up under this image's HSA settings, uint8 gather."""
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", _RCCL_WORLD1], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "RCCL_WORLD1_OK" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])

@@ -340,11 +340,11 @@ struct Counters { uint64_t rays = 0, nodes = 0, prims = 0, hits = 0, boxes = 0, 
 // 2 = as stored, 3 = sort-free sign order: children are stored sorted along the axis on which their centroids spread most
 // (2 bits per node) and visited in that order, reversed when the ray runs against the axis
 static int g_order = 0;
-static bool trace(const WTree& W, V3 o, V3 d, float tMin, float tMax, float& tHit, uint32_t& prim, int& kindOut, Counters& C) {
+static bool trace(const WTree& W, V3 o, V3 d, float tMin, float tMax, float& tHit, uint32_t& prim, int& kindOut, Counters& C, int32_t start = 0, bool foundIn = false, bool countRay = true) {
     const float inv[3] = {1.0f / d.x, 1.0f / d.y, 1.0f / d.z}, oo[3] = {o.x, o.y, o.z};
     int32_t stack[256]; float stackT[256]; int sp = 0;
-    int32_t cur = 0; float best = tMax; bool found = false;
-    C.rays++;
+    int32_t cur = start; float best = tMax; bool found = foundIn;
+    if (countRay) C.rays++;
     while (true) {
         if (cur >= 0) {
             const WNode& n = W.nodes[cur];
@@ -449,7 +449,7 @@ static bool trace(const WTree& W, V3 o, V3 d, float tMin, float tMax, float& tHi
         }
     }
     tHit = best;
-    if (found) C.hits++;
+    if (found && countRay) C.hits++;
     return found;
 }
 
@@ -462,6 +462,29 @@ static uint32_t tea(uint32_t v0, uint32_t v1) {
 static float rnd(uint32_t& s) { s = 1664525u * s + 1013904223u; return float(s & 0x00FFFFFFu) / float(0x01000000); }
 
 struct AoRay { V3 o, d; };
+struct AoGroup { V3 hit, N; float off; };   // one per hit pixel: its spp AO rays share the hit point (LAB_CUT)
+struct CutEntry { int32_t c; Box b; };
+// LAB_CUT = L: per-pixel entry cut -- the nodes of wide level L (and the leaves above it) whose boxes meet the sphere (hit, aoRadius + off)
+// and are not entirely behind the tangent plane of the hemisphere; the rays of the pixel start from synthetic 4-wide nodes over the cut
+static void entryCut(const WTree& W, const AoGroup& g, float R, int L, std::vector<CutEntry>& cut, uint64_t& steps) {
+    cut.clear();
+    int32_t st[512]; int sp = 0; st[sp++] = 0;
+    const float c[3] = {g.hit.x, g.hit.y, g.hit.z}, nn[3] = {g.N.x, g.N.y, g.N.z};
+    while (sp) {
+        const WNode& n = W.nodes[st[--sp]]; steps++;
+        for (int k = 0; k < n.n; k++) {
+            float d2 = 0, far = 0;
+            for (int a = 0; a < 3; a++) {
+                const float lo = n.cb[k].mn[a] - c[a], hi = n.cb[k].mx[a] - c[a];
+                const float d = lo > 0 ? lo : (hi < 0 ? -hi : 0.0f); d2 += d * d;
+                far += nn[a] > 0 ? nn[a] * hi : nn[a] * lo;
+            }
+            if (d2 > R * R || far < 0.0f) continue;
+            if (n.c[k] >= 0 && W.nodes[n.c[k]].level < L) st[sp++] = n.c[k];
+            else cut.push_back({n.c[k], n.cb[k]});
+        }
+    }
+}
 
 int main(int argc, char** argv) {
     if (argc < 2) { fprintf(stderr, "usage: bvhlab scene.bin [pixelStride] [spp] [builders]\n"); return 1; }
@@ -511,6 +534,7 @@ int main(int argc, char** argv) {
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
 
     std::vector<AoRay> rays;   // generated once, with the first tree
+    std::vector<AoGroup> groups;
     const int Wd = 1920, Ht = 1080;
     const float aoRadius = 0.1f, corr = std::cos(3.14159265358979f / 6.0f);
     size_t pos = 0;
@@ -556,6 +580,7 @@ int main(int argc, char** argv) {
                         N = norm(hit - lp); Tn = norm(v); off = std::sqrt(dot(lp - hit, lp - hit)) / corr;
                     }
                     const V3 B = cross(N, Tn);
+                    groups.push_back({hit, N, off});
                     for (int sidx = 0; sidx < spp; sidx++) {
                         uint32_t sd = tea(pix, uint32_t(sidx));
                         const float x0 = rnd(sd), x1 = rnd(sd), rs = std::sqrt(1.0f - x0 * x0), ph = 6.2831853f * x1;
@@ -566,6 +591,47 @@ int main(int argc, char** argv) {
                 }
             printf("  primary: %llu rays, %.1f node steps and %.1f leaf tests per ray, %llu hit -> %zu AO rays\n", (unsigned long long)C.rays,
                    double(C.nodes) / C.rays, double(C.prims) / C.rays, (unsigned long long)C.hits, rays.size());
+        }
+        if (getenv("LAB_CUT")) {
+            const int L = atoi(getenv("LAB_CUT"));
+            Counters C; uint64_t cutSteps = 0, cutSize = 0, synth = 0, cutMax = 0; std::vector<uint64_t> hist(65, 0);
+            t0 = now();
+#pragma omp parallel
+            {
+                Counters Lc; uint64_t cs = 0, cz = 0, sy = 0, cm = 0; std::vector<CutEntry> cut; std::vector<uint64_t> h(65, 0);
+#pragma omp for schedule(dynamic, 64)
+                for (size_t gi = 0; gi < groups.size(); gi++) {
+                    entryCut(W, groups[gi], aoRadius + groups[gi].off, L, cut, cs);
+                    cz += cut.size(); cm = std::max<uint64_t>(cm, cut.size()); h[std::min<size_t>(64, cut.size())]++;
+                    for (int sidx = 0; sidx < spp; sidx++) {
+                        const AoRay& r = rays[gi * size_t(spp) + sidx];
+                        const float inv[3] = {1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z}, oo[3] = {r.o.x, r.o.y, r.o.z};
+                        float best = aoRadius; bool found = false; uint32_t prim = 0; int kind = 0;
+                        Lc.rays++;
+                        for (size_t b = 0; b < cut.size(); b += 4) {       // one synthetic node step per four cut entries
+                            sy++;
+                            float key[4]; int idx[4]; int nh = 0;
+                            for (size_t k = b; k < std::min(cut.size(), b + 4); k++) {
+                                float tn = 0.0f, tf = best;
+                                for (int a = 0; a < 3; a++) { float t0 = (cut[k].b.mn[a] - oo[a]) * inv[a], t1 = (cut[k].b.mx[a] - oo[a]) * inv[a]; if (t0 > t1) std::swap(t0, t1); tn = std::max(tn, t0); tf = std::min(tf, t1); }
+                                if (tn <= tf) { key[nh] = tn; idx[nh] = int(k); nh++; }
+                            }
+                            for (int a = 1; a < nh; a++) for (int q = a; q > 0 && key[q] < key[q - 1]; q--) { std::swap(key[q], key[q - 1]); std::swap(idx[q], idx[q - 1]); }
+                            for (int q = 0; q < nh; q++) {
+                                if (key[q] > best) continue;
+                                float t; found = trace(W, r.o, r.d, 0.0f, best, t, prim, kind, Lc, cut[idx[q]].c, found, false); best = t;
+                            }
+                        }
+                        if (found) Lc.hits++;
+                    }
+                }
+#pragma omp critical
+                { C.rays += Lc.rays; C.nodes += Lc.nodes; C.prims += Lc.prims; C.hits += Lc.hits; cutSteps += cs; cutSize += cz; synth += sy; cutMax = std::max(cutMax, cm); for (int k = 0; k < 65; k++) hist[k] += h[k]; }
+            }
+            printf("  AO with a per-pixel entry cut at wide level %d: cut %.1f entries per pixel (max %llu), %.1f node steps per pixel to find it; per ray %.2f synthetic + %.2f tree node steps = %.2f (+ %.2f amortised cut steps), %.2f leaf tests, %.1f %% hit (%.1f s)\n",
+                   L, double(cutSize) / groups.size(), (unsigned long long)cutMax, double(cutSteps) / groups.size(), double(synth) / C.rays, double(C.nodes) / C.rays,
+                   double(synth + C.nodes) / C.rays, double(cutSteps) / C.rays, double(C.prims) / C.rays, 100.0 * C.hits / C.rays, now() - t0);
+            printf("    cut size histogram (pixels):"); for (int k = 0; k < 65; k++) if (hist[k]) printf(" %d:%llu", k, (unsigned long long)hist[k]); printf("\n");
         }
         for (g_order = 0; g_order < (getenv("LAB_ALL_ORDERS") ? 5 : 1); g_order++) {
         Counters C;
