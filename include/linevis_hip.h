@@ -208,8 +208,9 @@ int lv_set_background(lv_ctx* ctx, const float rgba[4]);
  *   accel_build (build-owned; the reference builds its BLAS with VK_BUILD_ACCELERATION_STRUCTURE_PREFER_FAST_TRACE_BIT_KHR,
  *   LineData.cpp:740-741): "fast_trace" (default: LBVH whose subtrees of <= treelet_leaves leaves are rebuilt with a binned
  *   surface-area heuristic) | "fast_build" (the plain LBVH); treelet_leaves (3 ... 4096, default 512),
- *   treelet_lane_leaves (0 | 2 ... 64, default 6; build time only, the tree is the same: ranges of a treelet up to this size
- *   are built one lane per range instead of by the whole wave),
+ *   treelet_group_leaves (0 | 8 | 16, default 16), treelet_lane_leaves (0 | 2 ... 64, default 6; used when the former is 0),
+ *   treelet_plane_eval ("scan" | "loop"): build time only, the tree is the same -- the small ranges of a treelet are built by
+ *   groups of 8 / 16 lanes (or one lane per range) instead of by the whole wave; the form of the wave's plane evaluation,
  *   triangle_leaf_size (build-owned): consecutive triangles per leaf of the triangle LBVH, 1 ... 8 (default 2: a tube face);
  *   changes the acceleration structure only, never a hit,
  *   dispatch_order (build-owned, no counterpart): "cost" (default: the tile kernels start their 64x64-pixel groups heaviest-of-

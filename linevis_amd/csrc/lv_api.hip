@@ -695,8 +695,9 @@ int lv_set_option(lv_ctx* ctx, const char* key, const char* value) {
         if (t != o.treeletLaneLeaves) { ctx->accelValid = false; ctx->triAccelValid = false; lv_invalidate_bake(ctx); }
         o.treeletLaneLeaves = t;
     } else if (k == "treelet_group_leaves") {
-        // build-time tunable of the treelet pass (the tree does not depend on it): ranges of <= 8 / 16 leaves are built by groups of
-        // 8 / 16 lanes, 8 / 4 ranges per pass of the wave; 0 = see treelet_lane_leaves
+        // build-time tunable of the treelet pass (the tree does not depend on it): ranges of <= 8 leaves are built by groups of 8 lanes
+        // (8 ranges per pass of the wave); 16 (default): also those of 9 ... 16 leaves, by groups of 16 lanes that hand their small
+        // children down to the groups of 8; 0 = see treelet_lane_leaves
         uint32_t t;
         if (!parseUint(value, t) || (t != 0 && t != 8 && t != 16)) return bad();
         if (t != o.treeletGroupLeaves) { ctx->accelValid = false; ctx->triAccelValid = false; lv_invalidate_bake(ctx); }

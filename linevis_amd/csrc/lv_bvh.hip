@@ -367,10 +367,12 @@ __device__ void lv_treelet_lane_build(const float (*s_box)[6], uint32_t* s_idx, 
             }
         }
         const uint32_t nr = n - nl;
-        const bool goL = nl > 1u, goR = nr > 1u;
-        const uint32_t sL = goL ? v++ : 0u, sR = goR ? v++ : 0u;
-        childL[slot] = goL ? sL : ((a + s_idx[lo]) | LV_LEAF_BIT);
-        childR[slot] = goR ? sR : ((a + s_idx[lo + nl]) | LV_LEAF_BIT);
+        const uint32_t sL = nl > 1u ? v++ : 0u, sR = nr > 1u ? v++ : 0u;
+        childL[slot] = nl > 1u ? sL : ((a + s_idx[lo]) | LV_LEAF_BIT);
+        childR[slot] = nr > 1u ? sR : ((a + s_idx[lo + nl]) | LV_LEAF_BIT);
+        if (nl == 2u) { childL[sL] = (a + s_idx[lo]) | LV_LEAF_BIT; childR[sL] = (a + s_idx[lo + 1u]) | LV_LEAF_BIT; }
+        if (nr == 2u) { childL[sR] = (a + s_idx[lo + nl]) | LV_LEAF_BIT; childR[sR] = (a + s_idx[lo + nl + 1u]) | LV_LEAF_BIT; }
+        const bool goL = nl > 2u, goR = nr > 2u;
         if (goL && goR) {
             const bool leftFirst = nl <= nr;
             const uint32_t nF = leftFirst ? nl : nr;
@@ -391,15 +393,18 @@ __device__ void lv_treelet_lane_build(const float (*s_box)[6], uint32_t* s_idx, 
     }
 }
 
-// GROUP builder: the queued ranges of at most G leaves (G = 8 or 16) are built 64 / G at a time, G lanes per range, one leaf per lane.
+// GROUP builder (treelet_group_leaves, the default): the queued ranges of at most G leaves (G = 8 or 16) are built 64 / G at a time, G lanes
+// per range, one leaf per lane.  1 M segments: the whole build 4.4 -> 2.4 ms (wave only -> groups of 16 and 8; one lane per range: 3.7).
 // With so few leaves the bins are not materialised: a leaf's own bin on an axis names the lowest plane that has this leaf and
 // every leaf of a lower or equal bin on its left -- these are all distinct non-trivial partitions of the axis, each under the lowest
 // plane number that produces it, i.e. exactly the candidates that can win under the tie rule (lowest cost, lowest axis, lowest plane).
 // Lane i evaluates its three candidates against the boxes of the group's other leaves (fetched lane to lane), the group's best key
 // (cost bits, 15 axis + plane - 1) decides, the partition is a ballot.  Same bins, same unions, same cost expression: the same tree.
-template <uint32_t G>
+// DOWN != 0: a group hands the child ranges of 3 ... DOWN leaves to the list of the next smaller group size (s_out) instead of building them.
+template <uint32_t G, uint32_t DOWN>
 __device__ void lv_treelet_group_build(const float (*s_box)[6], uint32_t* s_idx, const uint32_t* s_items, uint32_t numItems,
-                                       uint32_t* s_gstack, uint32_t a, uint32_t* __restrict__ childL, uint32_t* __restrict__ childR) {
+                                       uint32_t* s_gstack, uint32_t a, uint32_t* __restrict__ childL, uint32_t* __restrict__ childR,
+                                       uint32_t* s_out, uint32_t& outCount) {
     constexpr uint32_t NG = 64u / G;
     const uint32_t lane = threadIdx.x, gi = lane % G, g = lane / G, gbase = g * G;
     uint32_t* stk = s_gstack + g * 3u * LV_TREELET_LANE_STACK;
@@ -523,28 +528,55 @@ __device__ void lv_treelet_group_build(const float (*s_box)[6], uint32_t* s_idx,
                 s_idx[lo + (left ? uint32_t(__popc(gm & below)) : nl + uint32_t(__popc(gv & ~gm & below)))] = e;   // stable partition, in place
         }
         LV_TREELET_SYNC();
+        // children: slots in the serial order (both children's, then the subtree of the half the serial build takes first: the smaller)
+        uint32_t nr = 0u, sL = 0u, sR = 0u, vL = 0u, vR = 0u;
+        bool goL = false, goR = false;
         if (has) {
-            const uint32_t nr = n - nl;
-            const bool goL = nl > 1u, goR = nr > 1u;
-            const uint32_t sL = goL ? v++ : 0u, sR = goR ? v++ : 0u;
+            nr = n - nl;
+            sL = nl > 1u ? v++ : 0u;
+            sR = nr > 1u ? v++ : 0u;
             if (gi == 0u) {
-                childL[slot] = goL ? sL : ((a + s_idx[lo]) | LV_LEAF_BIT);
-                childR[slot] = goR ? sR : ((a + s_idx[lo + nl]) | LV_LEAF_BIT);
+                childL[slot] = nl > 1u ? sL : ((a + s_idx[lo]) | LV_LEAF_BIT);
+                childR[slot] = nr > 1u ? sR : ((a + s_idx[lo + nl]) | LV_LEAF_BIT);
+                // a child of two leaves has one topology: written here, it never becomes a range of its own
+                if (nl == 2u) { childL[sL] = (a + s_idx[lo]) | LV_LEAF_BIT; childR[sL] = (a + s_idx[lo + 1u]) | LV_LEAF_BIT; }
+                if (nr == 2u) { childL[sR] = (a + s_idx[lo + nl]) | LV_LEAF_BIT; childR[sR] = (a + s_idx[lo + nl + 1u]) | LV_LEAF_BIT; }
             }
+            const bool leftFirst = nl <= nr;
+            vL = (nr > 1u && !leftFirst) ? v + nr - 2u : v;
+            vR = (nl > 1u && leftFirst) ? v + nl - 2u : v;
+            goL = nl > 2u;
+            goR = nr > 2u;
+        }
+        if (DOWN != 0u) {
+            const bool dL = goL && nl <= DOWN, dR = goR && nr <= DOWN;
+            const unsigned long long mL = __ballot(dL && gi == 0u), mR = __ballot(dR && gi == 0u), belowLane = (1ull << lane) - 1ull;
+            if (dL && gi == 0u) {
+                const uint32_t ix = outCount + uint32_t(__popcll(mL & belowLane));
+                s_out[3u * ix] = lo | ((lo + nl) << 16); s_out[3u * ix + 1u] = sL; s_out[3u * ix + 2u] = vL;
+            }
+            if (dR && gi == 0u) {
+                const uint32_t ix = outCount + uint32_t(__popcll(mL)) + uint32_t(__popcll(mR & belowLane));
+                s_out[3u * ix] = (lo + nl) | (hi << 16); s_out[3u * ix + 1u] = sR; s_out[3u * ix + 2u] = vR;
+            }
+            outCount += uint32_t(__popcll(mL)) + uint32_t(__popcll(mR));
+            goL = goL && !dL;
+            goR = goR && !dR;
+        }
+        if (has) {
             if (goL && goR) {
                 const bool leftFirst = nl <= nr;
-                const uint32_t nF = leftFirst ? nl : nr;
                 if (gi == 0u) {
                     stk[3u * sp] = (leftFirst ? lo + nl : lo) | ((leftFirst ? hi : lo + nl) << 16);
                     stk[3u * sp + 1u] = leftFirst ? sR : sL;
-                    stk[3u * sp + 2u] = v + nF - 2u;
+                    stk[3u * sp + 2u] = leftFirst ? vR : vL;
                 }
                 sp++;
-                if (leftFirst) { hi = lo + nl; slot = sL; } else { lo = lo + nl; slot = sR; }
+                if (leftFirst) { hi = lo + nl; slot = sL; v = vL; } else { lo = lo + nl; slot = sR; v = vR; }
             } else if (goL) {
-                hi = lo + nl; slot = sL;
+                hi = lo + nl; slot = sL; v = vL;
             } else if (goR) {
-                lo = lo + nl; slot = sR;
+                lo = lo + nl; slot = sR; v = vR;
             } else if (sp == 0u) {
                 has = false;
             } else {
@@ -575,7 +607,8 @@ __global__ __launch_bounds__(64) void k_treelet_rebuild(const uint32_t* __restri
     __shared__ uint32_t s_bmin[3][LV_TREELET_BINS][3], s_bmax[3][LV_TREELET_BINS][3], s_bcnt[3][LV_TREELET_BINS];
     __shared__ uint32_t s_stack[4 * 16];
     __shared__ unsigned long long s_best;
-    __shared__ uint32_t s_small[3 * 64];                                  // queued small ranges: {lo | hi << 16, slot, vbase}
+    __shared__ uint32_t s_small[3 * 160];                                 // queued small ranges: {lo | hi << 16, slot, vbase} (64 + what 16 ranges of 9 ... 16 leaves hand down)
+    __shared__ uint32_t s_mid[3 * 16];                                    // queued ranges of 9 ... 16 leaves (treelet_group_leaves = 16)
     __shared__ uint32_t s_lstack[64 * 3 * LV_TREELET_LANE_STACK];         // their builders' stacks, one per lane
     const uint32_t lane = threadIdx.x;
     const unsigned long long below = (1ull << lane) - 1ull;
@@ -590,13 +623,19 @@ __global__ __launch_bounds__(64) void k_treelet_rebuild(const uint32_t* __restri
     // A Karras node is the first or the last leaf index of its range: the subtree's internal nodes are a ... a + m - 2 when the root
     // is a, a + 1 ... a + m - 1 when it is a + m - 1 -- either way the m - 2 nodes below the root are a + 1 ... a + m - 2.
     uint32_t sp = 0, lo = 0, hi = m, slot = root, v = a + 1u, nSmall = 0u;
-    auto runSmall = [&]() {   // groups of 8 / 16 lanes per queued range (treelet_group_leaves), or one lane per range
+    uint32_t nMid = 0u;
+    auto runSmall = [&]() {   // groups of 16 lanes for the ranges of 9 ... 16 leaves, of 8 lanes for the smaller ones; or one lane per range
         LV_TREELET_SYNC();
-        if (groupLeaves == 8u) lv_treelet_group_build<8u>(s_box, s_idx, s_small, nSmall, s_lstack, a, childL, childR);
-        else if (groupLeaves == 16u) lv_treelet_group_build<16u>(s_box, s_idx, s_small, nSmall, s_lstack, a, childL, childR);
-        else if (lane < nSmall)
+        if (groupLeaves != 0u) {
+            uint32_t none = 0u;
+            if (nMid) lv_treelet_group_build<16u, 8u>(s_box, s_idx, s_mid, nMid, s_lstack, a, childL, childR, s_small, nSmall);
+            nMid = 0u;
+            LV_TREELET_SYNC();
+            if (nSmall) lv_treelet_group_build<8u, 0u>(s_box, s_idx, s_small, nSmall, s_lstack, a, childL, childR, nullptr, none);
+        } else if (lane < nSmall) {
             lv_treelet_lane_build(s_box, s_idx, s_tmp, &s_lstack[lane * 3u * LV_TREELET_LANE_STACK], a, s_small[3u * lane] & 0xFFFFu,
                                   s_small[3u * lane] >> 16, s_small[3u * lane + 1u], s_small[3u * lane + 2u], childL, childR);
+        }
         nSmall = 0u;
         LV_TREELET_SYNC();
     };
@@ -604,9 +643,14 @@ __global__ __launch_bounds__(64) void k_treelet_rebuild(const uint32_t* __restri
     while (true) {
         const uint32_t n = hi - lo;
         if (laneLeaves != 0u && n <= laneLeaves) {
-            if (lane == 0u) { s_small[3u * nSmall] = lo | (hi << 16); s_small[3u * nSmall + 1u] = slot; s_small[3u * nSmall + 2u] = v; }
-            nSmall++;
-            if (nSmall == 64u) runSmall();
+            if (groupLeaves == 16u && n > 8u) {
+                if (lane == 0u) { s_mid[3u * nMid] = lo | (hi << 16); s_mid[3u * nMid + 1u] = slot; s_mid[3u * nMid + 2u] = v; }
+                nMid++;
+            } else {
+                if (lane == 0u) { s_small[3u * nSmall] = lo | (hi << 16); s_small[3u * nSmall + 1u] = slot; s_small[3u * nSmall + 2u] = v; }
+                nSmall++;
+            }
+            if (nSmall == 64u || nMid == 16u) runSmall();
             if (sp == 0u) break;
             sp--;
             LV_TREELET_SYNC();
@@ -806,12 +850,15 @@ __global__ __launch_bounds__(64) void k_treelet_rebuild(const uint32_t* __restri
         }
         // children of `slot`: a single leaf becomes a leaf reference, a longer range gets a slot of its own
         const uint32_t nr = n - nl;
-        const bool goL = nl > 1u, goR = nr > 1u;
-        const uint32_t sL = goL ? v++ : 0u, sR = goR ? v++ : 0u;   // the serial order: both children's slots, then the first half's subtree
+        const uint32_t sL = nl > 1u ? v++ : 0u, sR = nr > 1u ? v++ : 0u;   // the serial order: both children's slots, then the first half's subtree
         if (lane == 0u) {
-            childL[slot] = goL ? sL : ((a + s_idx[lo]) | LV_LEAF_BIT);
-            childR[slot] = goR ? sR : ((a + s_idx[lo + nl]) | LV_LEAF_BIT);
+            childL[slot] = nl > 1u ? sL : ((a + s_idx[lo]) | LV_LEAF_BIT);
+            childR[slot] = nr > 1u ? sR : ((a + s_idx[lo + nl]) | LV_LEAF_BIT);
+            // a child of two leaves has one topology: written here, it never becomes a range of its own
+            if (nl == 2u) { childL[sL] = (a + s_idx[lo]) | LV_LEAF_BIT; childR[sL] = (a + s_idx[lo + 1u]) | LV_LEAF_BIT; }
+            if (nr == 2u) { childL[sR] = (a + s_idx[lo + nl]) | LV_LEAF_BIT; childR[sR] = (a + s_idx[lo + nl + 1u]) | LV_LEAF_BIT; }
         }
+        const bool goL = nl > 2u, goR = nr > 2u;
         // continue with the smaller half that still needs a split, stack the other (depth <= log2 of the treelet size); the stacked
         // half's slots follow the nF - 2 slots of the first half's subtree
         if (goL && goR) {
@@ -833,7 +880,7 @@ __global__ __launch_bounds__(64) void k_treelet_rebuild(const uint32_t* __restri
         }
         LV_TREELET_SYNC();
     }
-    if (nSmall) runSmall();
+    if (nSmall || nMid) runSmall();
 }
 
 // Bottom-up boxes + heights in PASSES: in pass k every internal node whose two children were finished in an EARLIER pass
