@@ -100,7 +100,7 @@ static std::vector<LvDeviceBuffer*> lv_all_buffers(lv_ctx* ctx) {
             &ctx->eawPing, &ctx->eawPong, &ctx->tilesHaloDev, &ctx->fullFrameTile, &ctx->svgf.normalDepth, &ctx->svgf.normalDepthHistory,
             &ctx->svgf.flowFwidth, &ctx->svgf.moments, &ctx->svgf.momentsHistory, &ctx->svgf.colorHistory, &ctx->svgf.tempAccum,
             &ctx->svgf.tempAccumFiltered, &ctx->svgf.ping, &ctx->svgf.pong, &ctx->svgf.result, &ctx->aoGbuf, &ctx->aoList, &ctx->aoSamples,
-            &ctx->counters, &ctx->ppllNodes, &ctx->ppllStart, &ctx->ppllCount, &ctx->ppllScratch, &ctx->prismRecords, &ctx->scanTemp, &ctx->ppllOverflow, &ctx->ppllCoarse, &ctx->flowOccupancy, &ctx->twistTex, &ctx->tilesDev, &ctx->outDev,
+            &ctx->counters, &ctx->ppllNodes, &ctx->ppllStart, &ctx->ppllCount, &ctx->ppllScratch, &ctx->prismRecords, &ctx->scanTemp, &ctx->ppllOverflow, &ctx->ppllCoarse, &ctx->flowOccupancy, &ctx->flowSelfGrid, &ctx->twistTex, &ctx->tilesDev, &ctx->outDev,
             &ctx->scratchRays, &ctx->stackOverflow, &ctx->triIdx, &ctx->triVerts, &ctx->triPoints, &ctx->triNodes, &ctx->tris,
             &ctx->flowVectors, &ctx->flowScalars, &ctx->flowMisc, &ctx->flowSeeds, &ctx->flowOutPos, &ctx->flowOutAtt, &ctx->flowCounts,
             &ctx->bakeBlendingWeights, &ctx->bakeSamplingLocations, &ctx->bakedAo, &ctx->bakeLcgSkip, &ctx->bakedAoPending, &ctx->bakeCounters,
@@ -990,8 +990,8 @@ int lv_trace_streamlines_max_helicity_first(lv_ctx* ctx, const float* helicity_f
         return lv_fail(ctx, LV_E_INVALID, "time_step_scale must be > 0 and max_num_iterations in 1..1e6");
     if (seeding->termination_check_type != 1u)
         return lv_fail(ctx, LV_E_INVALID, "termination_check_type %u is not built (1 = grid-based)", seeding->termination_check_type);
-    if (seeding->loop_check_mode > 1u)
-        return lv_fail(ctx, LV_E_INVALID, "loop_check_mode %u is not built (0 none, 1 start point)", seeding->loop_check_mode);
+    if (seeding->loop_check_mode > 4u)
+        return lv_fail(ctx, LV_E_INVALID, "loop_check_mode %u (0 none, 1 start point, 2 all points, 3 grid, 4 curvature)", seeding->loop_check_mode);
     if (!(seeding->minimum_separation_distance >= 0.0f) || seeding->seeding_subsampling_factor < 1)
         return lv_fail(ctx, LV_E_INVALID, "minimum_separation_distance must be >= 0 and seeding_subsampling_factor >= 1");
     if (!(ctx->flowMaxMagnitude > 0.0f)) return lv_fail(ctx, LV_E_STATE, "the vector field is zero everywhere");

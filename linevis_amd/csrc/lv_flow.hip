@@ -281,12 +281,20 @@ __global__ __launch_bounds__(LV_WAVE) void k_trace_streamlines_seeded(const LvFl
                                                                       uint32_t loopCheckMode, float terminationDistanceStart,
                                                                       const uint8_t* __restrict__ occupancy, uint32_t capacity,
                                                                       float* __restrict__ positions, float* __restrict__ attributes,
-                                                                      uint32_t* __restrict__ counts) {
+                                                                      uint32_t* __restrict__ counts, uint32_t* __restrict__ selfGrid,
+                                                                      uint32_t selfGridWords) {
     const uint32_t t = blockIdx.x * LV_WAVE + threadIdx.x;
     if (t >= numThreads) return;
+    // state of the other loop checks (members of the reference's tracer, reset after every line, :727-737): "Grid" = the cells this line
+    // has visited (one bit per cell, zeroed by the host before the batch) + the last 32 cells it entered (CircularQueue<size_t>(32):
+    // sgl's class, not vendored -- here a FIFO of 32, `contains` = membership); "Curvature" = a double sum and a segment count
+    uint32_t* myGrid = selfGrid ? selfGrid + size_t(t) * selfGridWords : nullptr;
+    uint32_t cellQueue[32];
+    uint32_t queueHead = 0u, queueSize = 0u, oldCell = 0xFFFFFFFFu, segmentSum = 0u;
+    double curvatureSum = 0.0;
     const bool fw = t < firstBackward;
     const uint32_t s = t % numSeeds;
-    f3 cur = mk3(seeds[3 * s], seeds[3 * s + 1], seeds[3 * s + 2]), lastPoint = cur, back = cur, pt0 = cur, pt1 = cur;
+    f3 cur = mk3(seeds[3 * s], seeds[3 * s + 1], seeds[3 * s + 2]), lastPoint = cur, back = cur, pt0 = cur, pt1 = cur, prev = cur;
     uint32_t n = 0;
     bool boundary = false;
     auto push = [&](f3 q) {
@@ -299,6 +307,7 @@ __global__ __launch_bounds__(LV_WAVE) void k_trace_streamlines_seeded(const LvFl
         }
         if (n == 0) pt0 = q;
         if (n == 1) pt1 = q;
+        prev = back;
         back = q;
         n++;
     };
@@ -327,6 +336,49 @@ __global__ __launch_bounds__(LV_WAVE) void k_trace_streamlines_seeded(const LvFl
             const float distToStart = len3(cur - pt0);
             const float planeDistance = dot3(dir0, cur) + (-dot3(dir0, pt0));   // sgl::Plane(normal, point).getDistance
             if (planeDistance < 0.0f && distToStart < terminationDistanceStart && dot3(dir0, dirNow) > 0.0f) break;
+        }
+        if (n > 1 && loopCheckMode == 2u) {   // LoopCheckMode::ALL_POINTS, :609-626: the points this line has pushed after its first one,
+            // each with the direction it was reached in (hashedGridLoop->add, :689-692); sgl::HashedGrid is not vendored: the sphere
+            // query is defined here as distance <= radius, evaluated over the line's own points
+            f3 dirNow = cur - back;
+            const float distNow = len3(dirNow);
+            dirNow = mk3(dirNow.x / distNow, dirNow.y / distNow, dirNow.z / distNow);
+            bool loop = false;
+            const uint32_t stored = n < capacity ? n : capacity;
+            f3 before = pt0;
+            for (uint32_t i = 1; i < stored && !loop; i++) {
+                const float* o = positions + (size_t(i) * numThreads + t) * 3;
+                const f3 p = mk3(o[0], o[1], o[2]);
+                const f3 dir0 = norm3(p - before);
+                before = p;
+                if (!(len3(p - cur) <= terminationDistanceStart)) continue;
+                const float planeDistance = dot3(dir0, cur) + (-dot3(dir0, p));
+                loop = planeDistance < 0.0f && distNow < terminationDistanceStart && dot3(dir0, dirNow) > 0.0f;
+            }
+            if (loop) break;
+        } else if (n > 1 && loopCheckMode == 3u) {   // LoopCheckMode::GRID, :627-649
+            const uint32_t cell = lv_occupancy_cell(g.xs, g.ys, g.zs, g.dx, g.dy, g.dz, cur.x, cur.y, cur.z);
+            const uint32_t word = myGrid[cell >> 5], bit = 1u << (cell & 31u);
+            myGrid[cell >> 5] = word | bit;
+            bool inQueue = false;
+            for (uint32_t i = 0; i < queueSize; i++) inQueue = inQueue || cellQueue[(queueHead + i) & 31u] == cell;
+            if ((word & bit) && !inQueue) break;
+            if (cell != oldCell) {
+                if (queueSize == 32u) { queueHead = (queueHead + 1u) & 31u; queueSize--; }
+                cellQueue[(queueHead + queueSize) & 31u] = cell;
+                queueSize++;
+            }
+            oldCell = cell;
+        } else if (n > 1 && loopCheckMode == 4u) {   // LoopCheckMode::CURVATURE, :650-671 (acos: the build's fixed formula, NaN outside [-1, 1] like std::acos)
+            f3 dir0 = back - prev, dir1 = cur - back;
+            const float length0 = len3(dir0), length1 = len3(dir1);
+            if (length0 > 1e-8f) dir0 = mk3(dir0.x / length0, dir0.y / length0, dir0.z / length0);
+            if (length1 > 1e-8f) dir1 = mk3(dir1.x / length1, dir1.y / length1, dir1.z / length1);
+            const float c = dot3(dir0, dir1);
+            const float ang = fabsf(c) <= 1.0f ? lv_atan2_det(sqrtf((1.0f - c) * (1.0f + c)), c) : __uint_as_float(0x7FC00000u);
+            curvatureSum += double(ang) * double(length0 + length1);
+            segmentSum++;
+            if (segmentSum > 100u && curvatureSum > double(2.5f)) break;
         }
         if (occupancy[lv_occupancy_cell(g.xs, g.ys, g.zs, g.dx, g.dy, g.dz, cur.x, cur.y, cur.z)]) break;
         push(cur);
@@ -556,6 +608,12 @@ int lv_flow_trace_max_helicity_first(lv_ctx* ctx, const float* helicityField, co
     if ((rc = lv_buf_reserve(ctx, ctx->flowOutPos, size_t(capacity) * maxThreads * 12))) return rc;
     if ((rc = lv_buf_reserve(ctx, ctx->flowOutAtt, size_t(capacity) * maxThreads * 4 * (k ? k : 1)))) return rc;
     if ((rc = lv_buf_reserve(ctx, ctx->flowCounts, size_t(maxThreads) * 4))) return rc;
+    // loop check "Grid": one bit per cell and traced line of a batch (the reference keeps ONE such grid, its tracer is sequential)
+    const uint32_t selfGridWords = H->loop_check_mode == 3u ? uint32_t((numCells + 31) / 32) : 0u;
+    if (size_t(selfGridWords) * maxThreads * 4 > (16ull << 30))
+        return lv_fail(ctx, LV_E_CAPACITY, "loop_check_mode 3 would need %llu bytes of per-line cell masks",
+                       (unsigned long long)(size_t(selfGridWords) * maxThreads * 4));
+    if (selfGridWords && (rc = lv_buf_reserve(ctx, ctx->flowSelfGrid, size_t(selfGridWords) * maxThreads * 4))) return rc;
     auto cellOf = [&](const float* q) { return lv_occupancy_cell(xs, ys, zs, g.dx, g.dy, g.dz, q[0], q[1], q[2]); };
     std::vector<float> seeds, hp, ha;
     std::vector<uint32_t> counts;
@@ -574,10 +632,12 @@ int lv_flow_trace_max_helicity_first(lv_ctx* ctx, const float* helicityField, co
         const uint32_t numThreads = numSeeds * dirs;
         const uint32_t firstBackward = S->integration_direction == 0u ? numThreads : (S->integration_direction == 1u ? 0u : numSeeds);
         LV_HIP(ctx, hipMemcpyAsync(ctx->flowSeeds.ptr, seeds.data(), seeds.size() * 4, hipMemcpyHostToDevice, st));
+        if (selfGridWords) LV_HIP(ctx, hipMemsetAsync(ctx->flowSelfGrid.ptr, 0, size_t(selfGridWords) * numThreads * 4, st));
         k_trace_streamlines_seeded<<<(numThreads + LV_WAVE - 1) / LV_WAVE, LV_WAVE, 0, st>>>(
                 g, (const float*)ctx->flowSeeds.ptr, numSeeds, numThreads, firstBackward, S->integration_method, dt, S->time_step_scale,
                 terminationDistance, maxIterations, H->loop_check_mode, terminationDistanceStart, (const uint8_t*)ctx->flowOccupancy.ptr,
-                capacity, (float*)ctx->flowOutPos.ptr, (float*)ctx->flowOutAtt.ptr, (uint32_t*)ctx->flowCounts.ptr);
+                capacity, (float*)ctx->flowOutPos.ptr, (float*)ctx->flowOutAtt.ptr, (uint32_t*)ctx->flowCounts.ptr,
+                selfGridWords ? (uint32_t*)ctx->flowSelfGrid.ptr : nullptr, selfGridWords);
         LV_HIP(ctx, hipGetLastError());
         counts.resize(numThreads);
         LV_HIP(ctx, hipMemcpyAsync(counts.data(), ctx->flowCounts.ptr, size_t(numThreads) * 4, hipMemcpyDeviceToHost, st));

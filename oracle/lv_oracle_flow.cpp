@@ -17,6 +17,9 @@
  * (stated here as v / length(v), like everywhere else in this oracle).
  */
 #include "lv_oracle_common.h"
+#include <algorithm>
+#include <deque>
+#include <limits>
 
 #ifdef _OPENMP
 #include <omp.h>
@@ -567,7 +570,17 @@ static lvo_streamlines* traceMaxHelicityFirst(
     const int MAX_ITERATIONS = std::min(int(roundf(float(S.maxNumIterations) / S.timeStepScale)), S.maxNumIterations * 10) * 10;
     const float terminationDistance = 1e-6f * S.terminationDistance;
     const float terminationDistanceStart = length(dims) / 100.0f * terminationDistanceSelf;
+    // members of the tracer the loop checks use, reset after every call of _traceStreamlineDecreasingHelicity (:727-737)
+    std::vector<bool> selfOccupationGrid(loopCheckMode == 3u ? occupancy.size() : 0, false);
+    std::deque<size_t> cellPositionQueue;
+    size_t oldCellPosition = std::numeric_limits<size_t>::max();
+    double curvatureSum = 0.0;
+    size_t segmentSum = 0;
     auto traceDecreasing = [&](V3 seed, bool fw, Line& line) {
+        struct Reset {   // (runs when the line is finished)
+            std::vector<bool>& g; std::deque<size_t>& q; size_t& o; double& c; size_t& n;
+            ~Reset() { std::fill(g.begin(), g.end(), false); q.clear(); o = std::numeric_limits<size_t>::max(); c = 0.0; n = 0; }
+        } reset{selfOccupationGrid, cellPositionQueue, oldCellPosition, curvatureSum, segmentSum};
         float dt = dt0;
         V3 currentPoint = seed, lastPoint = seed;
         float segmentLength = 0.0f;
@@ -596,6 +609,44 @@ static lvo_streamlines* traceMaxHelicityFirst(
                 const float distToStart = length(currentPoint - pt0);
                 const float planeDistance = dot(dir0, currentPoint) + (-dot(dir0, pt0));
                 if (planeDistance < 0.0f && distToStart < terminationDistanceStart && dot(dir0, dirNow) > 0.0f) break;
+            }
+            if (line.pos.size() > 1 && loopCheckMode == 2u) {
+                // LoopCheckMode::ALL_POINTS, :609-626.  hashedGridLoop holds (point, direction it was reached in) of every point pushed
+                // after the first (:689-692); sgl::HashedGrid::findPointsAndDataInSphere is not vendored: distance <= radius here
+                V3 dirNow = currentPoint - line.pos.back();
+                const float distNow = length(dirNow);
+                dirNow = v3(dirNow.x / distNow, dirNow.y / distNow, dirNow.z / distNow);
+                bool loop = false;
+                for (size_t i = 1; i < line.pos.size() && !loop; i++) {
+                    const V3 pt0 = line.pos[i], dir0 = normalize(line.pos[i] - line.pos[i - 1]);
+                    if (!(length(pt0 - currentPoint) <= terminationDistanceStart)) continue;
+                    const float planeDistance = dot(dir0, currentPoint) + (-dot(dir0, pt0));
+                    loop = planeDistance < 0.0f && distNow < terminationDistanceStart && dot(dir0, dirNow) > 0.0f;
+                }
+                if (loop) break;
+            } else if (line.pos.size() > 1 && loopCheckMode == 3u) {
+                // LoopCheckMode::GRID, :627-649; CircularQueue<size_t>(32) is sgl's (not vendored): a FIFO bounded by the caller
+                const size_t cellPosition = cellOf(currentPoint);
+                const bool occupied = selfOccupationGrid[cellPosition];
+                selfOccupationGrid[cellPosition] = true;
+                if (occupied && std::find(cellPositionQueue.begin(), cellPositionQueue.end(), cellPosition) == cellPositionQueue.end()) break;
+                if (cellPosition != oldCellPosition) {
+                    if (cellPositionQueue.size() == 32) cellPositionQueue.pop_front();
+                    cellPositionQueue.push_back(cellPosition);
+                }
+                oldCellPosition = cellPosition;
+            } else if (line.pos.size() > 1 && loopCheckMode == 4u) {
+                // LoopCheckMode::CURVATURE, :650-671; glm::acos = std::acos (NaN outside [-1, 1]); inside: the build's fixed formula
+                const V3 p0 = line.pos[line.pos.size() - 2], p1 = line.pos[line.pos.size() - 1], p2 = currentPoint;
+                V3 dir0 = p1 - p0, dir1 = p2 - p1;
+                const float length0 = length(dir0), length1 = length(dir1);
+                if (length0 > 1e-8f) dir0 = v3(dir0.x / length0, dir0.y / length0, dir0.z / length0);
+                if (length1 > 1e-8f) dir1 = v3(dir1.x / length1, dir1.y / length1, dir1.z / length1);
+                const float c = dot(dir0, dir1);
+                const float ang = fabsf(c) <= 1.0f ? atan2Det(sqrtf((1.0f - c) * (1.0f + c)), c) : std::numeric_limits<float>::quiet_NaN();
+                curvatureSum += double(ang) * double(length0 + length1);
+                segmentSum++;
+                if (segmentSum > 100 && curvatureSum > 2.5f) break;
             }
             if (occupancy[cellOf(currentPoint)]) break;
             pushPoint(g, line, currentPoint);

@@ -298,3 +298,28 @@ def test_max_helicity_first_seeding_properties():
     assert min(np.abs(q[:, None] - centres[None, :]).min(axis=1).max() for q in s0) < 1e-5     # one point of the first line is a block centre
     none = lvo.trace_streamlines_max_helicity_first(v, sp, [mag], hel, S, minimum_separation_distance=r, loop_check_mode=0)
     assert len(none[0]) >= len(pos)                                                               # no loop check: lines only get longer
+
+
+def test_loop_check_modes_of_the_max_helicity_first_tracer():
+    """Oracle: the five loop check modes (StreamlineTracingGrid.cpp:588-672) on a swirl with closed orbits.  Without a check the orbiting
+    lines run into the iteration limit; each check ends them after about one turn (start point, all points), when the line re-enters a
+    cell it left more than 32 cells ago (grid), or when length-weighted turning angles add up to 2.5 after 100 segments (curvature)."""
+    n = 24
+    sp = (1.0 / (n - 1),) * 3
+    ax = np.arange(n, dtype=np.float32) * np.float32(sp[0])
+    Z, Y, X = np.meshgrid(ax, ax, ax, indexing="ij")
+    c = np.float32(0.5)
+    v = np.stack([-(Y - c), (X - c), np.float32(0.02) * (X - c)], axis=-1).astype(np.float32)
+    mag = np.sqrt((v ** 2).sum(-1)).astype(np.float32)
+    order = (np.sin(7 * X) * np.cos(5 * Y) + Z).astype(np.float32)
+    S = lvo.streamline_settings("Runge-Kutta 4th Order", "Forward", minimum_length=0.3, max_num_iterations=300)
+    longest = {}
+    for mode, tds in ((0, 1.0), (1, 1.0), (2, 4.0), (3, 1.0), (4, 1.0)):
+        pos, att, off = lvo.trace_streamlines_max_helicity_first(v, sp, [mag], order, S, minimum_separation_distance=0.1,
+                                                                 loop_check_mode=mode, termination_distance_self=tds)[:3]
+        longest[mode] = int(np.diff(off).max())
+        assert np.isfinite(pos).all() and (pos >= -1e-6).all() and (pos <= 1.0 + 1e-6).all()
+    assert longest[0] == 3001                                   # MAX_ITERATIONS + 1 points
+    # one turn of the seed's orbit at this step width is ~100 points (forward part only)
+    assert 60 < longest[1] < 200 and 60 < longest[2] < 200
+    assert longest[1] < longest[3] < longest[4] < longest[0]    # grid: a few turns; curvature: 2.5 rad m of turning

@@ -282,3 +282,42 @@ def test_max_helicity_first_seeding_bit_exact(hip_lib, kw):
         ctx.trace_streamlines_max_helicity_first(hel, capi.streamline_settings("Runge-Kutta-Fehlberg", direction), seeding)
     with pytest.raises(Exception):
         ctx.trace_streamlines_max_helicity_first(hel, capi.streamline_settings(method, direction), capi.HelicitySeedingSettings(termination_check_type=0))
+
+
+def rotating_grid(n=24):
+    """A swirl about the z axis with a weak shear: closed or nearly closed orbits, the lines the loop checks exist for."""
+    sp = (1.0 / (n - 1),) * 3
+    ax = np.arange(n, dtype=np.float32) * np.float32(sp[0])
+    Z, Y, X = np.meshgrid(ax, ax, ax, indexing="ij")
+    c = np.float32(0.5)
+    v = np.stack([-(Y - c), (X - c), np.float32(0.02) * (X - c)], axis=-1).astype(np.float32)
+    mag = np.sqrt((v ** 2).sum(-1)).astype(np.float32)
+    order = (np.sin(7 * X) * np.cos(5 * Y) + Z).astype(np.float32)      # the scalar the seeds are ranked by
+    return v, mag, order, sp
+
+
+@pytest.mark.parametrize("mode,tds,direction", [(0, 1.0, "Forward"), (1, 1.0, "Forward & Backward"), (2, 1.0, "Forward & Backward"),
+                                                (2, 4.0, "Backward"), (3, 1.0, "Forward & Backward"), (4, 1.0, "Forward & Backward"),
+                                                (4, 1.0, "Forward")])
+def test_max_helicity_first_loop_checks_bit_exact(hip_lib, mode, tds, direction):
+    """LoopCheckMode none / start point / all points / grid / curvature (StreamlineTracingGrid.cpp:588-672) on a field of closed orbits:
+    the speculative parallel tracer against the oracle's sequential restatement, bit for bit; and the check in question is what ends
+    the long lines (a different number of points from the run without a loop check)."""
+    v, mag, order, sp = rotating_grid()
+    ctx = capi.Context(0)
+    ctx.set_flow_grid(v, sp, [mag, order])
+    S = dict(minimum_length=0.3, max_num_iterations=300)
+    seeding = capi.HelicitySeedingSettings(minimum_separation_distance=0.1, loop_check_mode=mode, termination_distance_self=tds)
+    a = ctx.trace_streamlines_max_helicity_first(order, capi.streamline_settings("Runge-Kutta 4th Order", direction, **S), seeding)
+    b = lvo.trace_streamlines_max_helicity_first(v, sp, [mag, order], order, lvo.streamline_settings("Runge-Kutta 4th Order", direction, **S),
+                                                 minimum_separation_distance=0.1, loop_check_mode=mode, termination_distance_self=tds)
+    assert same(a, b)
+    assert len(a[2]) - 1 > 10
+    none = lvo.trace_streamlines_max_helicity_first(v, sp, [mag, order], order, lvo.streamline_settings("Runge-Kutta 4th Order", direction, **S),
+                                                    minimum_separation_distance=0.1, loop_check_mode=0, termination_distance_self=tds)
+    assert int(np.diff(none[2]).max()) >= 3000                          # without a check the orbits run into the iteration limit
+    if mode != 0:
+        assert len(a[0]) < len(none[0])                                 # the check ended lines earlier
+    with pytest.raises(Exception):
+        ctx.trace_streamlines_max_helicity_first(order, capi.streamline_settings("Runge-Kutta 4th Order", direction),
+                                                 capi.HelicitySeedingSettings(loop_check_mode=5))
