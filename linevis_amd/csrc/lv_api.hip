@@ -702,6 +702,11 @@ int lv_set_option(lv_ctx* ctx, const char* key, const char* value) {
         if (!parseUint(value, t) || (t != 0 && t != 8 && t != 16)) return bad();
         if (t != o.treeletGroupLeaves) { ctx->accelValid = false; ctx->triAccelValid = false; lv_invalidate_bake(ctx); }
         o.treeletGroupLeaves = t;
+    } else if (k == "accel_collapse_top") {
+        // build-time tunable (same tree): the top levels of the 4-wide collapse in one launch ("true", default) or one pass per level
+        const bool b = parseBool(value);
+        if (b != o.collapseTop) { ctx->accelValid = false; ctx->triAccelValid = false; lv_invalidate_bake(ctx); }
+        o.collapseTop = b;
     } else if (k == "treelet_plane_eval") {
         // how a wave evaluates the 45 split planes of a range (same planes, same costs, same tree): "scan" | "loop"
         bool sc;

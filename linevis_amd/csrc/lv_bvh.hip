@@ -989,15 +989,9 @@ __device__ __forceinline__ float lv_box_half_area(const float* b) {
     return (dx * dy + dy * dz) + dz * dx;
 }
 
-__global__ __launch_bounds__(LV_BLOCK) void k_collapse_select(const uint32_t* __restrict__ frontier, uint32_t count,
-                                                              const uint32_t* __restrict__ childL,
-                                                              const uint32_t* __restrict__ childR,
-                                                              const float* __restrict__ nodeBox,
-                                                              uint32_t* __restrict__ slots,
-                                                              uint32_t* __restrict__ internalCount) {
-    const uint32_t i = blockIdx.x * LV_BLOCK + threadIdx.x;
-    if (i >= count) return;
-    const uint32_t r = frontier[i];
+__device__ __forceinline__ uint32_t lv_collapse_select_item(uint32_t r, const uint32_t* __restrict__ childL,
+                                                            const uint32_t* __restrict__ childR, const float* __restrict__ nodeBox,
+                                                            uint32_t* slotsOut) {
     uint32_t s0 = childL[r], s1 = childR[r], s2 = LV_INVALID, s3 = LV_INVALID;
     int ns = 2;
 #pragma unroll
@@ -1020,30 +1014,37 @@ __global__ __launch_bounds__(LV_BLOCK) void k_collapse_select(const uint32_t* __
         if (ns == 2) s2 = cr; else s3 = cr;
         ns++;
     }
-    slots[4 * size_t(i) + 0] = s0; slots[4 * size_t(i) + 1] = s1; slots[4 * size_t(i) + 2] = s2; slots[4 * size_t(i) + 3] = s3;
+    slotsOut[0] = s0; slotsOut[1] = s1; slotsOut[2] = s2; slotsOut[3] = s3;
     uint32_t ni = 0;
     if (!(s0 & LV_LEAF_BIT)) ni++;
     if (!(s1 & LV_LEAF_BIT)) ni++;
     if (s2 != LV_INVALID && !(s2 & LV_LEAF_BIT)) ni++;
     if (s3 != LV_INVALID && !(s3 & LV_LEAF_BIT)) ni++;
-    internalCount[i] = ni;
+    return ni;
 }
 
-__global__ __launch_bounds__(LV_BLOCK) void k_collapse_emit(uint32_t count, uint32_t base, uint32_t nextBase,
-                                                            const uint32_t* __restrict__ slots,
-                                                            const uint32_t* __restrict__ offsets,
-                                                            const float* __restrict__ leafBox,
-                                                            const float* __restrict__ nodeBox,
-                                                            uint32_t* __restrict__ nextFrontier, float4* __restrict__ nodes) {
+__global__ __launch_bounds__(LV_BLOCK) void k_collapse_select(const uint32_t* __restrict__ frontier, uint32_t count,
+                                                              const uint32_t* __restrict__ childL,
+                                                              const uint32_t* __restrict__ childR,
+                                                              const float* __restrict__ nodeBox,
+                                                              uint32_t* __restrict__ slots,
+                                                              uint32_t* __restrict__ internalCount) {
     const uint32_t i = blockIdx.x * LV_BLOCK + threadIdx.x;
     if (i >= count) return;
+    internalCount[i] = lv_collapse_select_item(frontier[i], childL, childR, nodeBox, slots + 4 * size_t(i));
+}
+
+// node `index` of the wide tree from its four slots; its internal slots become entries firstNext ... of the next frontier
+__device__ __forceinline__ void lv_collapse_emit_item(uint32_t index, uint32_t nextBase, const uint32_t* slots4, uint32_t firstNext,
+                                                      const float* __restrict__ leafBox, const float* __restrict__ nodeBox,
+                                                      uint32_t* nextFrontier, float4* __restrict__ nodes) {
     uint32_t slotRef[4];
     float b[4][6];
     int ns = 0;
-    uint32_t j = offsets[i];
+    uint32_t j = firstNext;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const uint32_t c = slots[4 * size_t(i) + k];
+        const uint32_t c = slots4[k];
         slotRef[k] = LV_INVALID;
 #pragma unroll
         for (int a = 0; a < 6; a++) b[k][a] = 0.0f;
@@ -1062,7 +1063,71 @@ __global__ __launch_bounds__(LV_BLOCK) void k_collapse_emit(uint32_t count, uint
         for (int a = 0; a < 6; a++) b[k][a] = src[a];
         ns = k + 1;
     }
-    lv_write_wide_node(nodes + 4 * size_t(base + i), ns, slotRef, b);
+    lv_write_wide_node(nodes + 4 * size_t(index), ns, slotRef, b);
+}
+
+__global__ __launch_bounds__(LV_BLOCK) void k_collapse_emit(uint32_t count, uint32_t base, uint32_t nextBase,
+                                                            const uint32_t* __restrict__ slots,
+                                                            const uint32_t* __restrict__ offsets,
+                                                            const float* __restrict__ leafBox,
+                                                            const float* __restrict__ nodeBox,
+                                                            uint32_t* __restrict__ nextFrontier, float4* __restrict__ nodes) {
+    const uint32_t i = blockIdx.x * LV_BLOCK + threadIdx.x;
+    if (i >= count) return;
+    lv_collapse_emit_item(base + i, nextBase, slots + 4 * size_t(i), offsets[i], leafBox, nodeBox, nextFrontier, nodes);
+}
+
+// The first levels of the wide tree hold 1, 3, 10, 30, 94, ... nodes: ONE workgroup builds them (frontier, slots and offsets in LDS, one
+// block-wide scan per level) up to the first level with more than LV_COLLAPSE_TOP nodes -- five levels of a million-leaf tree that
+// cost five launches and a host round trip each.  Same numbering: the tree is the same, byte for byte (accel_collapse_top = false keeps
+// the pass per level from the root).  Measured, 1 M segments: 2.39 -> 2.31 ms with 256; with 1024 (eight levels, 1 400 nodes quantised by
+// one CU) 2.50 -- the lone workgroup is slower than the launches it saves.
+#define LV_COLLAPSE_TOP 256u
+__global__ __launch_bounds__(LV_BLOCK) void k_collapse_top(const uint32_t* __restrict__ childL, const uint32_t* __restrict__ childR,
+                                                           const float* __restrict__ leafBox, const float* __restrict__ nodeBox,
+                                                           uint32_t* __restrict__ frontierOut, float4* __restrict__ nodes,
+                                                           uint32_t* __restrict__ state /* {count, base, levels} */) {
+    constexpr uint32_t ITEMS = LV_COLLAPSE_TOP / LV_BLOCK;
+    __shared__ uint32_t s_front[2][4 * LV_COLLAPSE_TOP];
+    __shared__ uint32_t s_slots[4 * LV_COLLAPSE_TOP];
+    __shared__ uint32_t s_scan[LV_BLOCK];
+    const uint32_t t = threadIdx.x;
+    uint32_t count = 1u, base = 0u, levels = 0u, cur = 0u;
+    if (t == 0u) s_front[0][0] = 0u;   // the root of the binary tree
+    __syncthreads();
+    while (count > 0u && count <= LV_COLLAPSE_TOP) {
+        uint32_t ni[ITEMS], sum = 0u;
+#pragma unroll
+        for (uint32_t k = 0; k < ITEMS; k++) {
+            const uint32_t i = t * ITEMS + k;
+            ni[k] = i < count ? lv_collapse_select_item(s_front[cur][i], childL, childR, nodeBox, &s_slots[4u * i]) : 0u;
+            sum += ni[k];
+        }
+        // block-wide exclusive scan of the per-thread sums (Hillis-Steele over LDS)
+        s_scan[t] = sum;
+        __syncthreads();
+        for (uint32_t o = 1u; o < LV_BLOCK; o <<= 1) {
+            const uint32_t v = t >= o ? s_scan[t - o] : 0u;
+            __syncthreads();
+            s_scan[t] += v;
+            __syncthreads();
+        }
+        const uint32_t total = s_scan[LV_BLOCK - 1u];
+        uint32_t off = s_scan[t] - sum;
+#pragma unroll
+        for (uint32_t k = 0; k < ITEMS; k++) {
+            const uint32_t i = t * ITEMS + k;
+            if (i < count) lv_collapse_emit_item(base + i, base + count, &s_slots[4u * i], off, leafBox, nodeBox, s_front[cur ^ 1u], nodes);
+            off += ni[k];
+        }
+        base += count;
+        count = total;
+        levels++;
+        cur ^= 1u;
+        __syncthreads();
+    }
+    for (uint32_t i = t; i < count; i += LV_BLOCK) frontierOut[i] = s_front[cur][i];
+    if (t == 0u) { state[0] = count; state[1] = base; state[2] = levels; }
 }
 
 // single-segment scene: one node with one occupied slot
@@ -1208,10 +1273,20 @@ static int lv_bvh_build_core(lv_ctx* ctx, uint32_t n, LvDeviceBuffer& nodesOut, 
         }
             // collapse: one pass per BFS level of the wide tree (see k_collapse_select)
         {
-            LV_HIPF(hipMemsetAsync(depth.ptr, 0, 4, st)); // frontier A = {root = binary node 0}
             uint32_t* frontier = (uint32_t*)depth.ptr;
             uint32_t* nextFrontier = (uint32_t*)evenFlag.ptr;
+            // the small levels at the top in one launch (k_collapse_top), then one pass per level
             uint32_t count = 1, base = 0;
+            if (ctx->opt.collapseTop) {
+                k_collapse_top<<<1, LV_BLOCK, 0, st>>>((const uint32_t*)childL.ptr, (const uint32_t*)childR.ptr, (const float*)leafBox.ptr,
+                                                       (const float*)nodeBox.ptr, frontier, (float4*)nodesOut.ptr,
+                                                       (uint32_t*)bounds.ptr /* free since k_morton */);
+                LV_HIPF(hipMemcpyAsync((void*)ctx->pinned, bounds.ptr, 12, hipMemcpyDeviceToHost, st));
+                LV_HIPF(hipStreamSynchronize(st));
+                count = pin[0]; base = pin[1]; wideLevels = pin[2];
+            } else {
+                LV_HIPF(hipMemsetAsync(depth.ptr, 0, 4, st)); // frontier A = {root = binary node 0}
+            }
             while (count > 0) {
                 k_collapse_select<<<nblocks(count), LV_BLOCK, 0, st>>>(frontier, count, (const uint32_t*)childL.ptr,
                                                                        (const uint32_t*)childR.ptr, (const float*)nodeBox.ptr,

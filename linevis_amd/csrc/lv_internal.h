@@ -45,6 +45,7 @@ struct LvOptions {
     uint32_t treeletLeaves = 512;             // treelet_leaves: largest subtree the fast_trace build rebuilds (3 ... 4096)
     uint32_t treeletLaneLeaves = 6;           // treelet_lane_leaves: ranges of a treelet up to this size are built one lane per range (0 = the wave splits everything; 2 ... 64; measured: 0 4.5 ms, 4 3.8, 6 3.7, 8 3.9, 16 5.5 for the 1 M segments of config 3)
     uint32_t treeletGroupLeaves = 16;         // treelet_group_leaves: 0 | 8 | 16 -- ranges of <= 8 leaves are built by groups of 8 lanes, with 16 also those of 9 ... 16 leaves by groups of 16 (overrides treelet_lane_leaves; 1 M segments: 0 4.4 ms, 8 2.6, 16 2.4)
+    bool collapseTop = true;                  // accel_collapse_top: the levels of the wide tree with <= 1024 nodes in one launch (k_collapse_top)
     bool treeletPlaneScan = true;             // treelet_plane_eval = scan (DPP prefix / suffix scans over the bins) | loop (round-3 form)
     bool accelFastTrace = true;               // accel_build = fast_trace (LBVH + SAH treelets, the reference's PREFER_FAST_TRACE) | fast_build (LBVH)
     bool dispatchByCost = true;               // dispatch_order = cost | as_numbered (tile kernels: heaviest 64x64 group of the last frame first)

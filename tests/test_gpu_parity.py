@@ -167,12 +167,14 @@ def test_treelet_lane_builder_builds_the_same_tree(hip_lib):
         n = len(scene.seg)
         for tl in (512, 7, 64, 4096):
             want = None
-            for ll, ev, gl in ((0, "loop", 0), (0, "scan", 0), (2, "scan", 0), (3, "loop", 0), (4, "scan", 0), (8, "scan", 0), (16, "loop", 0),
+            for ll, ev, gl in ((0, "loop", -1), (0, "loop", 0), (0, "scan", 0), (2, "scan", 0), (3, "loop", 0), (4, "scan", 0), (8, "scan", 0), (16, "loop", 0),
                                (33, "scan", 0), (64, "scan", 0), (6, "scan", 8), (6, "loop", 16), (0, "scan", 16)):
                 ctx = scene.hip_context()
                 ctx.set_option("treelet_leaves", tl)
                 ctx.set_option("treelet_lane_leaves", ll)
-                ctx.set_option("treelet_group_leaves", gl)   # 8 / 16: queued ranges built by groups of lanes (the default: 8)
+                ctx.set_option("accel_collapse_top", gl >= 0)   # (first variant: one pass per level of the wide tree from the root, rounds 1-3)
+                gl = max(gl, 0)
+                ctx.set_option("treelet_group_leaves", gl)   # 8 / 16: queued ranges built by groups of lanes (the default: 16 = two tiers)
                 ctx.set_option("treelet_plane_eval", ev)   # loop = the round-3 form of the plane evaluation, the reference form
                 ctx.build_accel()
                 nodes, leaf_seg = ctx.get_accel(ctx.stats().num_nodes, n)

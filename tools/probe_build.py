@@ -14,6 +14,7 @@ from linevis_amd import camera, capi, host_api, scenes, transfer_function as tfm
 
 EVAL = os.environ.get("LV_PLANE_EVAL", "scan")
 GROUP = int(os.environ.get("LV_GROUP", "0"))
+TOP = os.environ.get("LV_COLLAPSE_TOP", "1") != "0"
 vals = [int(v) for v in sys.argv[1:]] or [0, 4, 8, 16, 32, 64]
 tr = scenes.normalize(scenes.tornado())
 flow = host_api.LineDataFlow().set_trajectories(tr.positions, tr.attributes, tr.line_offsets)
@@ -29,13 +30,14 @@ for ll in vals:
     ctx.set_option("treelet_lane_leaves", ll)
     ctx.set_option("treelet_plane_eval", EVAL)
     ctx.set_option("treelet_group_leaves", GROUP)
+    ctx.set_option("accel_collapse_top", TOP)
     ctx.build_accel()
     t = []
     for _ in range(5):
         ctx.build_accel()
         t.append(float(ctx.stats().ms_accel_build))
     row = {"capsules_ms": round(float(np.median(t)), 3)}
-    out["%d/g%d/%s" % (ll, GROUP, EVAL)] = row
+    out["%d/g%d/%s/top%d" % (ll, GROUP, EVAL, TOP)] = row
     print(ll, row, flush=True)
 os.makedirs(os.path.join(R, "gpurun_out"), exist_ok=True)
 json.dump(out, open(os.path.join(R, "gpurun_out", "probe_build.json"), "w"), indent=1)
