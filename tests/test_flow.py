@@ -323,3 +323,77 @@ def test_loop_check_modes_of_the_max_helicity_first_tracer():
     # one turn of the seed's orbit at this step width is ~100 points (forward part only)
     assert 60 < longest[1] < 200 and 60 < longest[2] < 200
     assert longest[1] < longest[3] < longest[4] < longest[0]    # grid: a few turns; curvature: 2.5 rad m of turning
+
+
+def test_loop_checks_independent_replay():
+    """Independent float64 replay of the loop checks, written from StreamlineTracingGrid.cpp:588-672 (not from the oracle): every point a
+    line holds was pushed AFTER its own check, so replaying the check at each pushed point must never fire (knife-edge cases aside), and
+    the lines the checks cut short must stop within a step of where the replay fires for the first time on the longer line traced
+    without a check."""
+    n = 24
+    sp = (1.0 / (n - 1),) * 3
+    ax = np.arange(n, dtype=np.float32) * np.float32(sp[0])
+    Z, Y, X = np.meshgrid(ax, ax, ax, indexing="ij")
+    c = np.float32(0.5)
+    v = np.stack([-(Y - c), (X - c), np.float32(0.02) * (X - c)], axis=-1).astype(np.float32)
+    mag = np.sqrt((v ** 2).sum(-1)).astype(np.float32)
+    order = (np.sin(7 * X) * np.cos(5 * Y) + Z).astype(np.float32)
+    S = lvo.streamline_settings("Runge-Kutta 4th Order", "Forward", minimum_length=0.3, max_num_iterations=300)
+    diag = float(np.sqrt(3.0))                                   # the box is the unit cube
+    cells = n - 1
+
+    def cell_of(p):
+        g = np.clip((p.astype(np.float64) / np.array(sp)).astype(np.int64), 0, cells - 1)
+        return int(g[0] + g[1] * cells + g[2] * cells * cells)
+
+    def first_fire(mode, pts, tds):
+        """index of the first point at which the check would have stopped the line (None: never)"""
+        P = pts.astype(np.float64)
+        r = diag / 100.0 * tds
+        visited, queue, old = set(), [], None
+        curv, segs = 0.0, 0
+        for j in range(2, len(P)):
+            cur, back = P[j], P[j - 1]
+            if mode == 1:
+                d0 = (P[1] - P[0]) / np.linalg.norm(P[1] - P[0])
+                dn = (cur - back) / np.linalg.norm(cur - back)
+                if np.dot(d0, cur - P[0]) < 0 and np.linalg.norm(cur - P[0]) < r and np.dot(d0, dn) > 0:
+                    return j
+            elif mode == 3:
+                cpos = cell_of(pts[j])
+                occupied = cpos in visited
+                visited.add(cpos)
+                if occupied and cpos not in queue:
+                    return j
+                if cpos != old:
+                    if len(queue) == 32:
+                        queue.pop(0)
+                    queue.append(cpos)
+                old = cpos
+            elif mode == 4:
+                a, b = back - P[j - 2], cur - back
+                la, lb = np.linalg.norm(a), np.linalg.norm(b)
+                if la > 1e-8:
+                    a = a / la
+                if lb > 1e-8:
+                    b = b / lb
+                curv += float(np.arccos(np.clip(np.dot(a, b), -1.0, 1.0))) * (la + lb)
+                segs += 1
+                if segs > 100 and curv > 2.5:
+                    return j
+        return None
+
+    none = lvo.trace_streamlines_max_helicity_first(v, sp, [mag], order, S, minimum_separation_distance=0.1, loop_check_mode=0)
+    for mode in (1, 3, 4):
+        pos, att, off = lvo.trace_streamlines_max_helicity_first(v, sp, [mag], order, S, minimum_separation_distance=0.1,
+                                                                 loop_check_mode=mode, termination_distance_self=1.0)[:3]
+        fired_early = 0
+        for a, b in zip(off[:-1], off[1:]):
+            f = first_fire(mode, pos[a:b], 1.0)
+            fired_early += f is not None and f < (b - a) - 1     # (the last point may sit on the knife edge in float64)
+        assert fired_early == 0, (mode, fired_early)
+        # the first line of both runs starts at the same seed: without a check it runs into the iteration limit, with the check it
+        # ends where the replay of the long line fires for the first time
+        long_line = none[0][none[2][0]:none[2][1]]
+        f = first_fire(mode, long_line, 1.0)
+        assert f is not None and abs((off[1] - off[0]) - f) <= 1, (mode, f, off[1] - off[0])
