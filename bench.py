@@ -255,8 +255,14 @@ def roofline(kernel, pmc_key, ms_launch, algorithmic_bytes, world):
         out["note"] = ("counter-backed figures need profiles/pmc_<tag>_%s.json + profiles/ubench_<tag>.json (tags %s) and a 1-GPU run"
                        % (pmc_key, "/".join(PROFILE_TAGS)))
         return out
-    pmc = json.load(open(ppath))
-    ub = json.load(open(upath))
+    try:   # auxiliary files: a damaged one must never take the bench line down
+        pmc = json.load(open(ppath))
+        ub = json.load(open(upath))
+        ub["valu_ns_per_inst_per_simd"]["node_step_mix"], ub["tcp_lane_requests_per_cu_per_ns"], pmc["kernels"]
+    except Exception as e:   # noqa: BLE001
+        out.update(none)
+        out["note"] = "counter-backed figures unavailable: %s / %s unreadable (%s)" % (os.path.basename(ppath), os.path.basename(upath), e)
+        return out
     kname = [k for k in pmc["kernels"] if k.startswith((kernel + "<", kernel + "_mlat<")) or k == kernel]
     if not kname:
         out.update(none)

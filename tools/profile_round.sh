@@ -11,6 +11,9 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # issue-rate / gather-rate calibration of this box (tools/ubench: built in the CPU container, shipped with the snapshot)
 mkdir -p $R/gpurun_out/ubench_$TAG
+# (the binaries are build artefacts: untracked, gone with a re-created container -- build them here if the snapshot has none)
+mkdir -p $R/tools/ubench/_build
+for u in valu_rates tcp_rates; do [ -x $R/tools/ubench/_build/$u ] || hipcc --offload-arch=gfx950 -O3 -std=c++17 $R/tools/ubench/$u.hip -o $R/tools/ubench/_build/$u 2>> $OUT/ubench_build.err; done
 timeout 600 $R/tools/ubench/_build/valu_rates > $R/gpurun_out/ubench_$TAG/valu_rates.json 2> $OUT/valu_rates.err
 timeout 600 $R/tools/ubench/_build/tcp_rates > $R/gpurun_out/ubench_$TAG/tcp_rates.json 2> $OUT/tcp_rates.err
 python $R/tools/summarize_ubench.py ubench_$TAG $TAG > $OUT/ubench_summary.json 2>> $OUT/valu_rates.err
