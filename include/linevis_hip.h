@@ -209,8 +209,12 @@ int lv_set_background(lv_ctx* ctx, const float rgba[4]);
  *   LineData.cpp:740-741): "fast_trace" (default: LBVH whose subtrees of <= treelet_leaves leaves are rebuilt with a binned
  *   surface-area heuristic) | "fast_build" (the plain LBVH); treelet_leaves (3 ... 4096, default 512),
  *   treelet_group_leaves (0 | 8 | 16, default 16), treelet_lane_leaves (0 | 2 ... 64, default 6; used when the former is 0),
- *   treelet_plane_eval ("scan" | "loop"): build time only, the tree is the same -- the small ranges of a treelet are built by
- *   groups of 8 / 16 lanes (or one lane per range) instead of by the whole wave; the form of the wave's plane evaluation,
+ *   treelet_plane_eval ("scan" | "loop"), accel_collapse_top ("true" | "false"): build time only, the tree is the same -- the
+ *   small ranges of a treelet are built by groups of 8 / 16 lanes (or one lane per range) instead of by the whole wave; the form
+ *   of the wave's plane evaluation; the top levels of the 4-wide collapse in one launch,
+ *   kernel_timers (build-owned): "all" (default) | "none" | comma-separated LV_KERNEL_* numbers and / or "phases" -- which launches
+ *   of a frame are bracketed by HIP events (lv_get_kernel_times; "phases": the ms_* fields of lv_get_stats, 0 otherwise).  An event
+ *   record costs the stream 2 - 4 us: a frame with every kernel and phase bracketed carries a dozen (6 % of a 0.8-ms PPLL frame),
  *   triangle_leaf_size (build-owned): consecutive triangles per leaf of the triangle LBVH, 1 ... 8 (default 2: a tube face);
  *   changes the acceleration structure only, never a hit,
  *   dispatch_order (build-owned, no counterpart): "cost" (default: the tile kernels start their 64x64-pixel groups heaviest-of-

@@ -702,6 +702,26 @@ int lv_set_option(lv_ctx* ctx, const char* key, const char* value) {
         if (!parseUint(value, t) || (t != 0 && t != 8 && t != 16)) return bad();
         if (t != o.treeletGroupLeaves) { ctx->accelValid = false; ctx->triAccelValid = false; lv_invalidate_bake(ctx); }
         o.treeletGroupLeaves = t;
+    } else if (k == "kernel_timers") {
+        // which launches of a frame are bracketed by HIP events (lv_get_kernel_times, the ms_* fields of lv_get_stats): "all" (default)
+        // | "none" | a comma-separated list of LV_KERNEL_* numbers and / or "phases".  Every event record costs the stream 2 - 4 us.
+        const std::string v(value);
+        uint32_t mask = 0u;
+        if (v == "all") mask = 0xFFFFFFFFu;
+        else if (v != "none") {
+            size_t pos = 0;
+            while (pos <= v.size()) {
+                size_t e = v.find(',', pos);
+                if (e == std::string::npos) e = v.size();
+                const std::string t = v.substr(pos, e - pos);
+                pos = e + 1;
+                uint32_t id;
+                if (t == "phases") mask |= 1u << 31;
+                else if (parseUint(t.c_str(), id) && id < 31u) mask |= 1u << id;
+                else return bad();
+            }
+        }
+        o.timerMask = mask;
     } else if (k == "accel_collapse_top") {
         // build-time tunable (same tree): the top levels of the 4-wide collapse in one launch ("true", default) or one pass per level
         const bool b = parseBool(value);
@@ -831,12 +851,15 @@ static int lv_get_stats_impl(lv_ctx* ctx, lv_stats* out, bool aggregate) {
     if (ctx->evBuildValid) s.ms_accel_build = ms(0, 1);
     if (ctx->evFrameValid) {
         // phase marks on the stream: 2 start, 5 depth range done, 7 RTAO done, 11 PPLL lists cleared, 13 gathered, 3 end
-        s.ms_total = ms(2, 3);
-        s.ms_depth_range = ms(2, 5);
-        s.ms_ao = ms(5, 7);
+        s.ms_total = s.ms_depth_range = s.ms_ao = 0.0f;
         s.ms_color = s.ms_ppll_clear = s.ms_ppll_gather = s.ms_ppll_resolve = 0.0f;
-        if (ctx->lastMode == LV_RENDERING_MODE_VULKAN_RAY_TRACER) s.ms_color = ms(7, 3);
-        else { s.ms_ppll_clear = ms(7, 11); s.ms_ppll_gather = ms(11, 13); s.ms_ppll_resolve = ms(13, 3); }
+        if (ctx->evPhaseRecorded) {   // (kernel_timers without the phase marks: the times stay 0, the counters below are still the frame's)
+            s.ms_total = ms(2, 3);
+            s.ms_depth_range = ms(2, 5);
+            s.ms_ao = ms(5, 7);
+            if (ctx->lastMode == LV_RENDERING_MODE_VULKAN_RAY_TRACER) s.ms_color = ms(7, 3);
+            else { s.ms_ppll_clear = ms(7, 11); s.ms_ppll_gather = ms(11, 13); s.ms_ppll_resolve = ms(13, 3); }
+        }
         LvDevCountersHost hc;
         memset(&hc, 0, sizeof(hc));
         if (ctx->counters.ptr) {

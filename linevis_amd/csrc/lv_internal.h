@@ -45,6 +45,8 @@ struct LvOptions {
     uint32_t treeletLeaves = 512;             // treelet_leaves: largest subtree the fast_trace build rebuilds (3 ... 4096)
     uint32_t treeletLaneLeaves = 6;           // treelet_lane_leaves: ranges of a treelet up to this size are built one lane per range (0 = the wave splits everything; 2 ... 64; measured: 0 4.5 ms, 4 3.8, 6 3.7, 8 3.9, 16 5.5 for the 1 M segments of config 3)
     uint32_t treeletGroupLeaves = 16;         // treelet_group_leaves: 0 | 8 | 16 -- ranges of <= 8 leaves are built by groups of 8 lanes, with 16 also those of 9 ... 16 leaves by groups of 16 (overrides treelet_lane_leaves; 1 M segments: 0 4.4 ms, 8 2.6, 16 2.4)
+    uint32_t timerMask = 0xFFFFFFFFu;         // kernel_timers: bit LV_KERNEL_* = that kernel's launches are bracketed by HIP events, bit 31 = the frame's phase marks.
+                                              // An event record costs the stream 2 - 4 us (a barrier packet): 12 of them are 6 % of a config-4 frame, 13 % of a config-2 frame
     bool collapseTop = true;                  // accel_collapse_top: the levels of the wide tree with <= 1024 nodes in one launch (k_collapse_top)
     bool treeletPlaneScan = true;             // treelet_plane_eval = scan (DPP prefix / suffix scans over the bins) | loop (round-3 form)
     bool accelFastTrace = true;               // accel_build = fast_trace (LBVH + SAH treelets, the reference's PREFER_FAST_TRACE) | fast_build (LBVH)
@@ -227,7 +229,7 @@ struct lv_ctx {
     lv_stats stats;
     hipEvent_t ev[16];
     bool evCreated = false;
-    bool evBuildValid = false, evFrameValid = false;
+    bool evBuildValid = false, evFrameValid = false, evPhaseRecorded = false;
     int lastMode = 0;
     // per-kernel launch timers: ring of event pairs per kernel id (LV_KERNEL_*)
     static constexpr int kNumKernels = 8;
@@ -269,10 +271,13 @@ inline hipEvent_t lv_kernel_ev(lv_ctx* ctx, int id, int which) {
 }
 #define LV_TIMED_LAUNCH(ctx, id, launch)                                      \
     do {                                                                      \
-        LV_HIP(ctx, hipEventRecord(lv_kernel_ev(ctx, id, 0), (ctx)->stream)); \
+        const bool lvTimed = (((ctx)->opt.timerMask >> (id)) & 1u) != 0u;     \
+        if (lvTimed) LV_HIP(ctx, hipEventRecord(lv_kernel_ev(ctx, id, 0), (ctx)->stream)); \
         launch;                                                               \
-        LV_HIP(ctx, hipEventRecord(lv_kernel_ev(ctx, id, 1), (ctx)->stream)); \
-        (ctx)->kernelLaunches[id]++;                                          \
+        if (lvTimed) {                                                        \
+            LV_HIP(ctx, hipEventRecord(lv_kernel_ev(ctx, id, 1), (ctx)->stream)); \
+            (ctx)->kernelLaunches[id]++;                                      \
+        }                                                                     \
     } while (0)
 void lv_buf_free(LvDeviceBuffer& b);
 

@@ -2555,7 +2555,7 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
     ctx->aoH = ctx->height;
     LvDevCounters* dc = (LvDevCounters*)ctx->counters.ptr;
 
-    LV_HIP(ctx, hipEventRecord(ctx->ev[2], st));
+    if (ctx->opt.timerMask >> 31) LV_HIP(ctx, hipEventRecord(ctx->ev[2], st));
     // The tile list is usually the same from frame to frame (a rank keeps its tiles): upload it only when it changes, so
     // that consecutive frames need no host synchronisation and the CPU can enqueue frame k+1 while frame k runs.
     const bool sameTiles = ctx->tilesUploaded && ctx->tilesHost.size() == 2 * size_t(numTiles) &&
@@ -2639,7 +2639,7 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
             k_depth_minmax<<<nblocks(ctx->numPoints), LV_BLOCK, 0, st>>>(U, S.points, ctx->numPoints, dc);
         k_depth_finalize<<<1, 64, 0, st>>>(dc, (float*)ctx->depthMinMax.ptr);
     }
-    LV_HIP(ctx, hipEventRecord(ctx->ev[5], st));
+    if (ctx->opt.timerMask >> 31) LV_HIP(ctx, hipEventRecord(ctx->ev[5], st));
 
     // ambientOcclusionBaker->updateIterative(), LineRenderer.cpp:257-264
     ctx->aoNumGroups = 0;
@@ -2660,7 +2660,7 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
         S.bakedAo = (const float*)ctx->bakedAo.ptr;
         S.bakedBlendingWeights = (const float*)ctx->bakeBlendingWeights.ptr;
     }
-    LV_HIP(ctx, hipEventRecord(ctx->ev[7], st));
+    if (ctx->opt.timerMask >> 31) LV_HIP(ctx, hipEventRecord(ctx->ev[7], st));
     // The colour pass of a raster_prism frame with the segment rasteriser has no tile kernel: only its resolve pass could use the
     // dispatch order, and measured it does not (config 4: 0.134 ms as numbered, 0.145 ms heaviest first + 11 us for k_group_order)
     if (mode == LV_RENDERING_MODE_PER_PIXEL_LINKED_LIST && lv_ppll_prism_source(ctx) && !ctx->opt.ppllPrismLbvhWalk &&
@@ -2754,7 +2754,7 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
         k_ppll_clear<<<uint32_t((padded4 + LV_BLOCK - 1) / LV_BLOCK), LV_BLOCK, 0, st>>>(
                 (uint4*)ctx->ppllStart.ptr, (uint4*)ctx->ppllCount.ptr, padded4, dc, allRequested ? 0u : 0xFFFFFFFFu,
                 (allRequested && stats) ? (unsigned long long)U.width * U.height : 0ull);
-        LV_HIP(ctx, hipEventRecord(ctx->ev[11], st));
+        if (ctx->opt.timerMask >> 31) LV_HIP(ctx, hipEventRecord(ctx->ev[11], st));
 #define LV_LAUNCH_GATHER(ST, PR, BA)                                                                             \
     LV_TIMED_LAUNCH(ctx, LV_KERNEL_PPLL_GATHER, (k_ppll_gather<ST, PR, BA><<<gridTiles * numSlices, LV_BLOCK, 0, st>>>( \
             U, S, T, gatherPool, (uint32_t*)ctx->ppllStart.ptr,                                                  \
@@ -2827,7 +2827,7 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
                     U, (uint2*)ctx->ppllNodes.ptr, (uint2*)ctx->prismRecords.ptr, (const uint32_t*)ctx->ppllStart.ptr, blockBase,
                     (const uint32_t*)ctx->ppllCount.ptr, (const uint32_t*)ctx->ppllOverflow.ptr, dc);
         }
-        LV_HIP(ctx, hipEventRecord(ctx->ev[13], st));
+        if (ctx->opt.timerMask >> 31) LV_HIP(ctx, hipEventRecord(ctx->ev[13], st));
         // resolve()
         const uint32_t* prismCount = prismSource ? (const uint32_t*)ctx->ppllCount.ptr : nullptr; // (kept fragments per pixel -> max depth complexity)
         const uint64_t groups64 = uint64_t(numTiles) * (T.blocksX / 4u) * (T.blocksY / 4u) * 64u;   // 8 x 8 cells of the 64 x 64 groups
@@ -2857,8 +2857,9 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
 #undef LV_LAUNCH_RESOLVE
     }
     LV_HIP(ctx, hipGetLastError());
-    LV_HIP(ctx, hipEventRecord(ctx->ev[3], st));
+    if (ctx->opt.timerMask >> 31) LV_HIP(ctx, hipEventRecord(ctx->ev[3], st));
     ctx->evFrameValid = true;
+    ctx->evPhaseRecorded = (ctx->opt.timerMask >> 31) != 0u;
     ctx->lastMode = mode;
     return LV_OK;
 }

@@ -940,3 +940,33 @@ def test_linear_swept_spheres_geometry_mode(hip_lib, kw):
         assert np.array_equal(img, aabb)          # same surface, same shading
     else:
         assert not np.array_equal(img, aabb)      # the swept spheres keep their round ends
+
+
+def test_kernel_timers_option(hip_lib):
+    """kernel_timers: which launches are bracketed by HIP events.  The image and the counters do not depend on it; lv_get_kernel_times only
+    returns the selected kernels' launches, the ms_* phase fields of lv_get_stats stay 0 without the phase marks."""
+    c = small_case(width=96, height=64, transparent=True, **RTAO, ambient_occlusion_iterations=1, ambient_occlusion_samples_per_frame=4)
+    ctx = c.hip_context()
+    ctx.set_option("collect_stats", True)
+    want = (ctx.render(11), ctx.render(2))
+    st_all = ctx.stats()
+    names = capi.KERNEL_NAMES
+    ctx.reset_timers()
+    ctx.render(11)
+    assert len(ctx.kernel_times(names.index("k_ao_rays"))) == 1 and len(ctx.kernel_times(names.index("k_render_rt"))) == 1
+    assert ctx.stats().ms_total > 0.0
+    for value, timed in (("none", []), (str(names.index("k_ao_rays")), ["k_ao_rays"]), ("phases,%d" % names.index("k_render_rt"), ["k_render_rt"])):
+        ctx.set_option("kernel_timers", value)
+        ctx.reset_timers()
+        assert np.array_equal(ctx.render(11), want[0])
+        st = ctx.stats()
+        for k, name in enumerate(names):
+            assert len(ctx.kernel_times(k)) == (1 if name in timed else 0), (value, name)
+        assert (st.ms_total > 0.0) == ("phases" in value)
+        assert st.rays_traced > 0 and st.nodes_visited > 0
+        assert np.array_equal(ctx.render(2), want[1])
+    ctx.set_option("kernel_timers", "all")
+    ctx.render(2)
+    assert ctx.stats().fragments == st_all.fragments and ctx.stats().ms_ppll_resolve > 0.0
+    with pytest.raises(capi.LineVisError):
+        ctx.set_option("kernel_timers", "k_ao_rays")
