@@ -360,7 +360,7 @@ def main_one_process(args):
     tr = scenes.normalize(gen())
     flow = host_api.LineDataFlow().set_trajectories(tr.positions, tr.attributes, tr.line_offsets)
     pts, seg, _ = flow.tube_aabb_render_data(LINE_WIDTH)
-    ctx = capi.Context(devices=list(range(args.gpus)), transport=args.transport)
+    ctx = capi.Context(devices=bench_devices(args.gpus), transport=args.transport)
     ctx.set_lines(pts, seg)
     ctx.set_transfer_function(tfm.standard_transparent() if wl.get("transparent") else tfm.standard(), *flow.attribute_range())
     ctx.set_camera(view, proj, fovy, near, far, W, H)
@@ -369,8 +369,9 @@ def main_one_process(args):
         ctx.set_tube_triangle_mesh(*flow.tube_triangle_render_data(LINE_WIDTH, 6))
     ctx.set_options(wl["settings"])
     ctx.build_accel()
-    torch.cuda.set_device(0)
-    out = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda:0")
+    dev0 = bench_devices(args.gpus)[0]
+    torch.cuda.set_device(dev0)
+    out = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda:%d" % dev0)
     ctx.set_option("collect_stats", True)
     ctx.render_device(out.data_ptr(), mode=wl["mode"])
     st = ctx.stats()                       # synchronises every rank; counters summed over the ranks
@@ -401,6 +402,7 @@ def main_one_process(args):
               "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
               "fps": round(args.steps / elapsed, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
               "frames_in_flight": 1, "data": "synthetic",
+              "launch": os.environ.get("LV_BENCH_LAUNCH", "--one-process: lv_create_multi over %d device(s)" % args.gpus),
               "config": {"workload": wl["name"], "resolution": [W, H], "segments": int(len(seg)), "rays_per_frame": int(rays),
                          "parallelism": "ONE process, lv_create_multi over %d device(s): 64x64 screen tiles in Morton order dealt by measured "
                                         "cost, one %s gather per frame inside the library" % (args.gpus, args.transport),
@@ -409,6 +411,98 @@ def main_one_process(args):
               "roofline": {"bound": None, "note": "per-kernel ceilings are reported by the default (one process per GPU) mode"},
               "cpu_baseline": None}
     print(json.dumps(result), flush=True)
+
+
+def _last_json_line(text):
+    for line in reversed(text.splitlines()):
+        line = line.strip()
+        if line.startswith("{") and line.endswith("}"):
+            try:
+                return json.loads(line)
+            except ValueError:
+                continue
+    return None
+
+
+def _run_child(cmd, env, timeout_s):
+    """Run a launch attempt in its own process group; on timeout the whole group (launcher + ranks) is killed."""
+    import signal
+    import subprocess
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+    try:
+        out, err = p.communicate(timeout=timeout_s)
+        return p.returncode, out, err
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(p.pid, signal.SIGKILL)
+        except ProcessLookupError:
+            pass
+        out, err = p.communicate()
+        return None, out, "timeout after %.0f s\n%s" % (timeout_s, err[-800:])
+
+
+def bench_devices(n):
+    """Device ordinal of every rank: 0 .. N-1, or LV_BENCH_DEVICES="0,0" (a measurement / test knob: several ranks on one GPU work with
+    the library's memcpy transport, not with RCCL, which refuses duplicate devices)."""
+    if os.environ.get("LV_BENCH_DEVICES"):
+        d = [int(x) for x in os.environ["LV_BENCH_DEVICES"].split(",")]
+        if len(d) != n:
+            raise SystemExit("LV_BENCH_DEVICES names %d devices, --gpus %d" % (len(d), n))
+        return d
+    return list(range(n))
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` WITHOUT torchrun (the form the driver uses for N = 1): start the N ranks from here.
+
+    1. re-run this command line under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1` (one
+       process per GPU, torch.distributed over RCCL -- exactly what the driver's own torchrun form starts) and forward rank 0's line;
+    2. if that fails (no JSON line or a non-zero exit): ONE process over the library's multi-device handle (lv_create_multi, RCCL
+       ncclSend / ncclRecv inside the library), then the same with peer memcpy as the gather transport.
+    The line says which path ran (`launch`), and every failed attempt is kept in `launch_attempts`; progress goes to stderr."""
+    import socket
+    attempts = []
+    argv = [a for a in sys.argv[1:]]
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ, LV_BENCH_LAUNCH="self-launched: python -m torch.distributed.run --nproc-per-node %d (one process per GPU, "
+                                           "torch.distributed %s)" % (args.gpus, "gloo, dry run" if args.dry_run else "nccl = RCCL"))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // args.gpus)))
+    print("[bench] --gpus %d without torch.distributed.run: launching %s" % (args.gpus, " ".join(cmd[1:8])), file=sys.stderr, flush=True)
+    timeout_s = float(os.environ.get("LV_BENCH_LAUNCH_TIMEOUT", "1500"))
+    rc, out, err = _run_child(cmd, env, timeout_s)
+    line = _last_json_line(out)
+    if rc == 0 and line is not None:
+        line["launch_attempts"] = attempts
+        sys.stderr.write(err[-4000:])
+        print(json.dumps(line), flush=True)
+        return
+    attempts.append({"path": "torch.distributed.run", "returncode": rc, "stderr_tail": err[-1500:]})
+    print("[bench] torch.distributed.run path failed (rc %s): ...%s" % (rc, err[-300:]), file=sys.stderr, flush=True)
+    if args.dry_run:
+        raise SystemExit("--dry-run --gpus %d: the torch.distributed.run launch failed and the dry run has no one-process form:\n%s"
+                         % (args.gpus, attempts[-1]["stderr_tail"]))
+    # the fallbacks run in child processes too: a failed RCCL bootstrap must not take this process (and the line) down
+    for transport in ([args.transport] if args.transport == "memcpy" else ["rccl", "memcpy"]):
+        print("[bench] falling back to --one-process --transport %s" % transport, file=sys.stderr, flush=True)
+        cmd = [sys.executable, os.path.abspath(__file__)] + argv + ["--one-process", "--transport", transport]
+        env = dict(os.environ, LV_BENCH_LAUNCH="fallback: ONE process, lv_create_multi over %d devices, %s gather inside the library "
+                                               "(the torch.distributed.run launch failed)" % (args.gpus, transport))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        rc, out, err = _run_child(cmd, env, timeout_s)
+        line = _last_json_line(out)
+        if rc == 0 and line is not None:
+            line["launch_attempts"] = attempts
+            print(json.dumps(line), flush=True)
+            return
+        attempts.append({"path": "one-process/" + transport, "returncode": rc, "stderr_tail": err[-1500:]})
+        print("[bench] --one-process --transport %s failed (rc %s): ...%s" % (transport, rc, err[-300:]), file=sys.stderr, flush=True)
+    raise SystemExit("bench.py --gpus %d: every launch path failed:\n%s" % (args.gpus, json.dumps(attempts, indent=1)))
 
 
 def run_states(steps, device=0):
@@ -468,13 +562,13 @@ def main():
         return main_one_process(args)
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`"
-                             % (args.gpus, args.gpus))
+            return self_launch(args)   # plain `python bench.py --gpus N`: start the N ranks ourselves
         raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
     dry = args.dry_run
     if dry:
         device = torch.device("cpu")
     else:
+        local_rank = bench_devices(world)[local_rank]
         torch.cuda.set_device(local_rank)
         device = torch.device("cuda", local_rank)
     if world > 1:
@@ -695,6 +789,31 @@ def main():
                     "note": "medians of 3 untimed frames rendered ONE AT A TIME (host-synchronised between render, gather and "
                             "de-tiling; the timed frames overlap these phases and keep frames_in_flight frames queued); gather_ms of a "
                             "rank includes waiting for the slowest rank's render"}
+            # the N = 1 value of the SAME run: rank 0 renders the whole frame alone (one lv_render_device call per frame, as the
+            # --gpus 1 line does) while the other ranks wait, so that the line carries its own speed-up and efficiency
+            if not dry:
+                single = None
+                if rank == 0:
+                    image1 = torch.empty((H, W, 4), dtype=torch.uint8, device=device)
+                    for _ in range(3):
+                        ctx.render_device(image1.data_ptr(), mode=w["mode"])
+                    torch.cuda.synchronize()
+                    n1 = max(3, min(args.steps, 50))
+                    t1 = time.perf_counter()
+                    for _ in range(n1):
+                        ctx.render_device(image1.data_ptr(), mode=w["mode"])
+                    torch.cuda.synchronize()
+                    ms1 = (time.perf_counter() - t1) / n1 * 1e3
+                    ms_n = elapsed / args.steps * 1e3
+                    single = {"ms_per_step": round(ms1, 4), "value": round(rays_per_frame / ms1 / 1e3, 2), "unit": "Mrays/s",
+                              "steps": n1, "speedup": round(ms1 / ms_n, 4), "efficiency": round(ms1 / ms_n / world, 4),
+                              "frame_identical_to_sharded": bool(frame is not None and torch.equal(image1, frame)),
+                              "note": "rank 0 alone, whole frame in one lv_render_device call per frame, same scene / settings / "
+                                      "build, timed after the sharded region while the other ranks wait at a barrier; "
+                                      "speedup = this ms_per_step / the sharded ms_per_step"}
+                    del image1
+                dist.barrier()
+                diag["single_gpu_same_run"] = single
         frame_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(len(marks) - 1)] if marks else []
         kernels = {}
         if not dry:
@@ -737,6 +856,8 @@ def main():
             "ms_per_step": round(head["elapsed"] / args.steps * 1e3, 4), "fps": round(args.steps / head["elapsed"], 3),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "frames_in_flight": frames_in_flight,
             "data": "synthetic" if not dry else "dry-run (no GPU, stand-in renderer)",
+            "launch": os.environ.get("LV_BENCH_LAUNCH", "one process (N = 1)" if world == 1 else
+                                     "external launcher: %d processes, RANK / WORLD_SIZE from the environment" % world),
             "config": {"workload": wl["name"], "resolution": [W, H], "segments": int(len(seg)) if seg is not None else 0,
                        "rays_per_frame": int(head["rays_per_frame"]), "ao_hit_pixels": int(head["counters"][4].item()),
                        "fragments_per_frame": int(head["counters"][5].item()),

@@ -4,11 +4,15 @@ CPU tests: the deal (longest processing time first) and the Morton tile order as
 Python tiling module the earlier rounds used.  GPU tests (one MI355X): a 1-rank RCCL communicator (ncclSend / ncclRecv to itself) and
 2-4 ranks on the same device over the memcpy transport reproduce the single-device frame byte for byte -- every part of the path
 except the xGMI wire itself."""
+import os
+
 import numpy as np
 import pytest
 
 from common import small_case
 from linevis_amd import capi, tiling
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_tile_deal_matches_the_python_deal():
@@ -240,3 +244,45 @@ def test_plugin_on_several_devices(hip_lib, devices, transport):
             r.rebalance()
             assert np.array_equal(r.render_frame(), imgs[0])
     assert np.array_equal(imgs[0], imgs[1]) and (imgs[0][..., :3] != 255).any()
+
+
+def _bench(args, env_extra=None, timeout=900):
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly ONE JSON line on stdout:\n" + r.stdout[-2000:]
+    return json.loads(lines[0]), r.stderr
+
+
+@pytest.mark.gpu
+def test_bench_one_process_rccl_end_to_end(hip_lib):
+    """`bench.py --gpus 1 --one-process --transport rccl` through a subprocess: the library's multi-device handle with its RCCL
+    communicator (one rank here: everything of that path one MI355X can run), the bench line parsed."""
+    j, _ = _bench(["--gpus", "1", "--one-process", "--transport", "rccl", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"])
+    assert j["n_gpus"] == 1 and j["steps"] == 3 and j["value"] > 100.0 and j["unit"] == "Mrays/s"
+    mg = j["multi_gpu"]
+    assert mg["ranks_observed"] == 1 and mg["transport"] == "rccl" and mg["tiles_per_rank"] == [30 * 17]
+    assert j["config"]["rays_per_frame"] > 2_000_000 and "one-process" in j["launch"]
+
+
+@pytest.mark.gpu
+def test_bench_gpus2_without_torchrun_walks_the_launch_chain(hip_lib):
+    """`python bench.py --gpus 2` (the driver's command form, no torchrun) on a box whose two ranks share ONE GPU
+    (LV_BENCH_DEVICES=0,0): bench.py launches torch.distributed.run itself; RCCL refuses two ranks on one device, so the chain falls
+    through to the one-process handle (RCCL, then peer memcpy) -- whichever path completes, there is exactly one valid line, it
+    names the path that ran, and every failed attempt is recorded with its stderr."""
+    j, err = _bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--workload", "c2"],
+                    {"LV_BENCH_DEVICES": "0,0", "LV_BENCH_LAUNCH_TIMEOUT": "240"}, timeout=1200)
+    assert j["n_gpus"] == 2 and j["steps"] == 3 and j["value"] > 0.0
+    assert isinstance(j["launch_attempts"], list) and j["launch"]
+    for a in j["launch_attempts"]:
+        assert a["path"] and a["stderr_tail"]
+    mg = j["multi_gpu"]
+    assert mg["ranks_observed"] == 2 and len(mg["tiles_per_rank"]) == 2 and sum(mg["tiles_per_rank"]) == 30 * 17
+    if j["launch_attempts"]:
+        assert j["launch"].startswith("fallback") and "[bench]" in err

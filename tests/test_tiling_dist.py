@@ -129,6 +129,37 @@ def test_bench_dry_run_collective_sequence_world2():
     assert j["n_gpus"] == 2 and j["steps"] == 3 and j["scaling"] == "strong" and j["cpu_baseline"] is None
 
 
+def test_bench_gpus2_dry_run_launches_itself():
+    """The driver's command form (`python bench.py --gpus N ...`, no torchrun, WORLD_SIZE unset) must not exit: bench.py starts the N
+    ranks itself under torch.distributed.run and forwards rank 0's line, which names the path that ran."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly ONE JSON line on stdout"
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 3 and j["warmup"] == 1
+    assert j["launch"].startswith("self-launched") and j["launch_attempts"] == []
+    mg = j["multi_gpu"]
+    assert mg["ranks_observed"] == 2 and len(mg["tiles_per_rank"]) == 2 and sum(mg["tiles_per_rank"]) == 30 * 17
+    assert len(mg["render_ms_per_rank"]) == 2 and len(mg["gather_ms_per_rank"]) == 2
+
+
+def test_bench_self_launch_reports_every_failed_path(tmp_path):
+    """When the torch.distributed.run launch fails, the dry run (which has no one-process form) must fail LOUDLY with the attempt's
+    stderr, not silently; here the launch is broken on purpose with an impossible rendezvous timeout of the child."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["LV_BENCH_LAUNCH_TIMEOUT"] = "0.01"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--dry-run"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0 and "torch.distributed.run launch failed" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
 def test_detile_helper():
     tiles = tiling.make_tiles(50, 30, 16)
     px = np.zeros((len(tiles), 16, 16, 4), dtype=np.uint8)
