@@ -229,6 +229,7 @@ int lv_set_lines(lv_ctx* ctx, const lv_line_point* points, uint32_t num_points, 
             return lv_fail(ctx, LV_E_INVALID, "segment %llu references point %u >= num_points %u",
                            (unsigned long long)(i / 2), seg[i], num_points);
     (void)hipSetDevice(ctx->device);
+    lv_invalidate_bake(ctx);   // before any buffer is touched: a bake in flight on the second stream still reads the old ones
     int rc;
     if ((rc = lv_buf_reserve(ctx, ctx->points, size_t(num_points) * sizeof(lv_line_point)))) return rc;
     if ((rc = lv_buf_reserve(ctx, ctx->segIdx, size_t(num_segments) * 8))) return rc;
@@ -269,6 +270,7 @@ int lv_set_tube_triangle_mesh(lv_ctx* ctx, const uint32_t* triangle_indices, uin
             return lv_fail(ctx, LV_E_INVALID, "vertex %u references line point %u >= num_line_points %u", i,
                            vertices[i].vertexLinePointIndex & 0x7FFFFFFFu, num_line_points);
     (void)hipSetDevice(ctx->device);
+    lv_invalidate_bake(ctx);   // waits for a running asynchronous bake BEFORE its inputs are overwritten
     int rc;
     if ((rc = lv_buf_reserve(ctx, ctx->triIdx, size_t(num_triangles) * 12))) return rc;
     if ((rc = lv_buf_reserve(ctx, ctx->triVerts, size_t(num_vertices) * sizeof(lv_tube_vertex)))) return rc;
@@ -306,6 +308,7 @@ int lv_set_ao_parametrization(lv_ctx* ctx, const float* blending_weights, uint32
             return lv_fail(ctx, LV_E_INVALID, "sampling location %u = %g is outside [0, %u)", i,
                            double(sampling_locations[i]), num_line_vertices);
     (void)hipSetDevice(ctx->device);
+    lv_invalidate_bake(ctx);   // waits for a running asynchronous bake BEFORE its inputs are overwritten
     int rc;
     if ((rc = lv_buf_reserve(ctx, ctx->bakeBlendingWeights, size_t(num_line_vertices ? num_line_vertices : 1) * 4))) return rc;
     if ((rc = lv_buf_reserve(ctx, ctx->bakeSamplingLocations, size_t(num_parametrization_vertices ? num_parametrization_vertices : 1) * 4))) return rc;
@@ -519,14 +522,17 @@ int lv_set_option(lv_ctx* ctx, const char* key, const char* value) {
             ctx->aoRestart = true;
         }
     } else if (k == "use_ribbons") {                              // LineDataFlow.cpp:588 (here: USE_BANDS = ribbons on AND band data set)
+        if (parseBool(value) != o.useRibbons) lv_invalidate_bake(ctx);   // the prebaker bakes the band cross-section (k_bake_setup)
         o.useRibbons = parseBool(value);
     } else if (k == "thick_bands") {                              // :592
         o.thickBands = parseBool(value);
     } else if (k == "min_band_thickness") {                       // :596
         if (!parseFloat(value, f) || !(f > 0.0f) || f > 1.0f) return bad();
+        if (f != o.minBandThickness) lv_invalidate_bake(ctx);
         o.minBandThickness = f;
     } else if (k == "band_width") {                               // LineRenderer.cpp:443
         if (!parseFloat(value, f) || !(f > 0.0f)) return bad();
+        if (f != o.bandWidth) lv_invalidate_bake(ctx);
         o.bandWidth = f;
     } else if (k == "use_analytic_elliptic_tubes") {              // "Elliptic Tubes" checkbox, VulkanRayTracer.cpp:198-201
         o.ellipticTubes = parseBool(value);

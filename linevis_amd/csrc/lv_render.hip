@@ -1433,10 +1433,13 @@ __global__ __launch_bounds__(LV_BLOCK, LV_PRISM_RASTER_MIN_WAVES) void k_ppll_ra
                 bool stored = false;
                 if (insertIndex < poolSlots) {
                     const uint32_t rk = atomicAdd(&fragCount[addr], 1u);
-                    if ((rk & 0xFFFFu) < 0xFFFFu) {
+                    // (the FULL word: the high half -- the discard count -- is still 0 in this stage, so once the count saturates every
+                    // later lane fails and undoes its add; testing the low half only let lanes behind the one that hit 0xFFFF wrap
+                    // around to ranks 0, 1, ... a second time)
+                    if (rk < 0xFFFFu) {
                         records[3 * size_t(insertIndex) + 0] = pix;
                         records[3 * size_t(insertIndex) + 1] = leaf | (tt << 26);
-                        records[3 * size_t(insertIndex) + 2] = rk & 0xFFFFu;
+                        records[3 * size_t(insertIndex) + 2] = rk;
                         stored = true;
                     } else {   // (the per-pixel count shares its word with the count of discarded fragments: 16 bits each)
                         atomicSub(&fragCount[addr], 1u);

@@ -88,43 +88,46 @@ void computeAmbientOcclusionParametrization(const std::vector<std::vector<vec3>>
     }
     blendingWeights.assign(vertexOffset[numLines], 0.0f);
     samplingLocations.assign(paramOffset[numLines], 0.0f);
-#pragma omp parallel for schedule(dynamic, 16)
-    for (long lli = 0; lli < long(numLines); lli++) {
-        const size_t li = size_t(lli);
-        const std::vector<vec3>& line = lines[li];
-        const size_t n = line.size();
-        if (n < 2) continue;
-        const uint32_t numLineSubdivs = numSubdivs[li];
-        const float lineSubdivLength = polylineLengths[li] / float(numLineSubdivs);
-        const uint32_t numSubdivVertices = numLineSubdivs + 1;
-        const size_t segmentVertexIdOffset = paramOffset[li];
-        const uint32_t startVertexIdx = uint32_t(vertexOffset[li]);
-        float* bw = blendingWeights.data() + vertexOffset[li];
-        float* sl = samplingLocations.data() + paramOffset[li];
-        // blending weight of every line vertex: arc length in units of the subdivision length
-        bw[0] = float(segmentVertexIdOffset);
-        float currentLength = 0.0f;
-        for (size_t i = 1; i < n; i++) {
-            currentLength += length(line[i] - line[i - 1]);
-            float w = currentLength / lineSubdivLength;
-            bw[i] = float(segmentVertexIdOffset) + std::fmin(std::fmax(w, 0.0f), float(numLineSubdivs) - EPSILON);
-        }
-        // sampling location of every parametrisation vertex: walk the polyline to the segment holding arc length i * L
-        float lastLength = 0.0f;
-        currentLength = length(line[1] - line[0]);
-        size_t currVertexIdx = 1;
-        sl[0] = float(startVertexIdx);
-        for (uint32_t i = 1; i < numSubdivVertices; i++) {
-            uint32_t parametrizationIdx = uint32_t(currentLength / lineSubdivLength);
-            while (i > parametrizationIdx && currVertexIdx < n - 1) {
-                float segLength = length(line[currVertexIdx + 1] - line[currVertexIdx]);
-                lastLength = currentLength;
-                currentLength += segLength;
-                parametrizationIdx = uint32_t(currentLength / lineSubdivLength);
-                currVertexIdx++;
+    // Definition (VulkanAmbientOcclusionBaker.cpp:563-653).  A polyline of n vertices with float32 running arc lengths a_0 = 0,
+    // a_k = a_(k-1) + |v_k - v_(k-1)| is cut into N = numSubdivs pieces of length h = L / N; `first` = index of its first
+    // parametrisation vertex, `v0` = index of its first line vertex.
+    //   blendingWeight(v_k)      = first + clamp(a_k / h, 0, N - eps)                         -- arc length in units of h
+    //   samplingLocation(i), i>0 = v0 + min((j - 1) + (i h - a_(j-1)) / (a_j - a_(j-1)), (n - 1) - eps), where j is the first vertex
+    //                              (1 <= j <= n - 1) whose cell index uint(a_j / h) reaches i, or n - 1 when none does
+    // The cell indices are non-decreasing, so j is a lower bound found by bisection over a per-line prefix table; every quotient is
+    // evaluated in float32 in the order written above, which is what makes the tables bit-identical to the reference's.
+#pragma omp parallel
+    {
+        std::vector<float> arc;        // a_k
+        std::vector<uint32_t> cell;    // uint(a_k / h)
+#pragma omp for schedule(dynamic, 16)
+        for (long lli = 0; lli < long(numLines); lli++) {
+            const std::vector<vec3>& line = lines[size_t(lli)];
+            const size_t n = line.size();
+            if (n < 2) continue;
+            const uint32_t N = numSubdivs[size_t(lli)];
+            const float h = polylineLengths[size_t(lli)] / float(N);
+            const float first = float(paramOffset[size_t(lli)]), v0 = float(uint32_t(vertexOffset[size_t(lli)]));
+            arc.resize(n);
+            cell.resize(n);
+            arc[0] = 0.0f;
+            cell[0] = 0u;
+            for (size_t k = 1; k < n; k++) {
+                arc[k] = arc[k - 1] + length(line[k] - line[k - 1]);
+                cell[k] = uint32_t(arc[k] / h);
             }
-            float samplingLocation = float(currVertexIdx - 1) + (float(i) * lineSubdivLength - lastLength) / (currentLength - lastLength);
-            sl[i] = float(startVertexIdx) + std::min(samplingLocation, float(uint32_t(n) - 1u) - EPSILON);
+            float* bw = blendingWeights.data() + vertexOffset[size_t(lli)];
+            bw[0] = first;
+            const float topWeight = float(N) - EPSILON;
+            for (size_t k = 1; k < n; k++) bw[k] = first + std::fmin(std::fmax(arc[k] / h, 0.0f), topWeight);
+            float* sl = samplingLocations.data() + paramOffset[size_t(lli)];
+            sl[0] = v0;
+            const float topLocation = float(uint32_t(n) - 1u) - EPSILON;
+            for (uint32_t i = 1; i <= N; i++) {
+                const size_t j = std::min(size_t(std::lower_bound(cell.begin() + 1, cell.end(), i) - cell.begin()), n - 1);
+                const float along = (float(i) * h - arc[j - 1]) / (arc[j] - arc[j - 1]);
+                sl[i] = v0 + std::min(float(j - 1) + along, topLocation);
+            }
         }
     }
 }
@@ -414,7 +417,12 @@ bool LineRenderer::uploadFrameState() {
         {   // USE_HELICITY_BANDS_TEXTURE (LineDataFlow.cpp:974-977,2437-2439)
             uint32_t tw = 0, th = 0;
             const std::vector<uint8_t>* tex = lineData->getTwistLineTexture(tw, th);
-            if (!check(lv_set_twist_line_texture(ctx, tex ? tex->data() : nullptr, tw, th), "lv_set_twist_line_texture")) return false;
+            uint64_t hash = 1469598103934665603ull;
+            if (tex) for (uint8_t b : *tex) hash = (hash ^ b) * 1099511628211ull;
+            if (tw != uploadedTwistW || th != uploadedTwistH || hash != uploadedTwistHash) {
+                if (!check(lv_set_twist_line_texture(ctx, tex ? tex->data() : nullptr, tw, th), "lv_set_twist_line_texture")) return false;
+                uploadedTwistW = tw; uploadedTwistH = th; uploadedTwistHash = hash;
+            }
             setOption("use_twist_line_texture", lineData->getUseTwistLineTexture() ? "true" : "false");
             setOption("twist_line_texture_filtering_mode_index", std::to_string(lineData->getTwistLineTextureFilteringModeIndex()));
         }

@@ -248,6 +248,10 @@ protected:
     bool isRasterizer = false;
     bool dirty = true, reRender = true, internalReRender = false;
     bool tfDirty = true, linesDirty = true, triangleMeshDirty = true;
+    // twist-line texture last handed to the library (dimensions + FNV-1a of the pixels): lv_set_twist_line_texture rebuilds a mip chain
+    // and synchronises, so it is called only when the pixels changed, not with every dirty line setting
+    uint32_t uploadedTwistW = 0xFFFFFFFFu, uploadedTwistH = 0xFFFFFFFFu;
+    uint64_t uploadedTwistHash = 0;
 
     // LineRenderer.hpp:220-231 (depth cues default on with strength 0.8 in the GUI application; the headless
     // default is off until "depth_cue_strength" is set, like a fresh SettingsMap-driven benchmark state)

@@ -693,6 +693,77 @@ def test_config2_size_band_data_and_helicity_bands_whole_frames(hip_lib):
 
 
 # ---------------------------------------------------------------- BASELINE.json config 4 at full size
+def _ppll_lists_sorted(nodes, start):
+    """Every linked fragment of every pixel as three arrays (pixel address, depth bits, colour), sorted by (pixel, depth, colour) --
+    the per-pixel multisets in a canonical order -- plus the per-pixel list lengths.  Vectorised list walk: one numpy step per list
+    position."""
+    nxt = nodes[:, 2]
+    pix = np.flatnonzero(start != 0xFFFFFFFF)
+    cur = start[pix].astype(np.int64)
+    pp, ii = [], []
+    while len(pix):
+        pp.append(pix)
+        ii.append(cur)
+        n = nxt[cur]
+        keep = n != 0xFFFFFFFF
+        pix, cur = pix[keep], n[keep].astype(np.int64)
+    pp, ii = np.concatenate(pp), np.concatenate(ii)
+    assert len(np.unique(ii)) == len(ii), "a node is linked twice"
+    length = np.bincount(pp, minlength=len(start))
+    key = np.lexsort((nodes[ii, 0], nodes[ii, 1], pp))
+    return pp[key], nodes[ii[key], 1], nodes[ii[key], 0], length
+
+
+def test_config4_whole_frame_against_the_oracle(hip_lib):
+    """BASELINE config 4, every pixel: the fragment lists of the whole 1920 x 1080 frame of the 1 M-segment
+    set (rasterised prism, the reference's geometry) against the oracle's gather (LinePassProgrammablePullTubes.glsl:87-224,
+    LinkedListGather.glsl:44-71) as per-pixel (depth, colour) multisets bit for bit -- all 2 073 600 pixels, including the > 2 000
+    whose lists overflow MAX_NUM_FRAGS = 64 -- and the resolved frame (LinkedListResolve.glsl:57-105, frontToBackPQ
+    LinkedListSort.glsl:177-238; keep-the-nearest-64 on both sides) <= 2 LSB on every pixel."""
+    tr = scenes.normalize(scenes.tornado())
+    flow = host_api.LineDataFlow().set_trajectories(tr.positions, tr.attributes, tr.line_offsets)
+    pts, seg, _ = flow.tube_aabb_render_data(0.002)
+    W4, H4 = 1920, 1080
+    c = Case(pts, seg, tfm.standard_transparent(), W4, H4, 0.002, ppll_max_num_frags=64,
+             ppll_expected_avg_depth_complexity=20, collect_stats=True)
+    ctx = c.hip_context()
+    lo, hi = flow.attribute_range()
+    ctx.set_transfer_function(c.tf, lo, hi)
+    full = ctx.render(2)
+    st = ctx.stats()
+    pw, ph = c.padded()
+    sc = c.oracle_scene()
+    P = c.oracle_params(sc)
+    assert int(P.ppllFragmentSource) == 1 and int(P.ppllMaxNumFrags) == 64
+    P.attrMin, P.attrMax = lo, hi
+    nodes, start, cnt = ctx.ppll_buffers(pw * ph, int(P.ppllLinkedListSize))
+    whole = (0, 0, W4, H4)
+    on, os_, ocnt = sc.ppll_gather(P, tile=whole, use_bvh=True)
+    assert cnt == ocnt == st.fragments
+    gp, gd, gc_, glen = _ppll_lists_sorted(nodes, start)
+    op, od, oc, olen = _ppll_lists_sorted(on, os_)
+    assert len(gp) == cnt and len(op) == ocnt
+    assert np.array_equal(glen, olen), "list lengths differ on %d pixels" % int((glen != olen).sum())
+    assert np.array_equal(gp, op) and np.array_equal(gd, od), "fragment depths differ"
+    assert np.array_equal(gc_, oc), "fragment colours differ on %d fragments" % int((gc_ != oc).sum())
+    overflow = glen > 64
+    assert overflow.sum() >= 1000 and glen.max() == st.max_depth_complexity > 100
+    # the resolved frame, every pixel; the overflowing pixels are the ones k_ppll_select_nearest touches
+    ref = sc.render_ppll(P, tile=whole, use_bvh=True)
+    diff = np.abs(full.astype(np.int32) - ref.astype(np.int32)).max(axis=2)
+    assert diff.max() <= LSB_TOL, "%d pixels differ by more than %d LSB (max %d)" % (int((diff > LSB_TOL).sum()), LSB_TOL, int(diff.max()))
+    ys, xs = np.mgrid[0:H4, 0:W4]
+    tw, th = int(P.ppllTileW), int(P.ppllTileH)   # TiledAddress.glsl:53-85, vectorised
+    ntx = pw // tw
+    addr = ((ys // th) * ntx + xs // tw) * (tw * th) + (ys % th) * tw + xs % tw
+    assert addr[500, 913] == lvo.ppll_addr(913, 500, pw, tw, th) and addr[1079, 1919] == lvo.ppll_addr(1919, 1079, pw, tw, th)
+    of_px = overflow[addr]
+    assert of_px.sum() == overflow.sum()
+    assert diff[of_px].max() <= LSB_TOL
+    # the oracle resolving the KERNEL's lists must reproduce the kernel's frame too (no dependence on whose lists)
+    assert max_lsb_diff(full, lvo.ppll_resolve(P, nodes, start, tile=whole)) <= 1
+
+
 def test_config4_full_size_ppll_and_mlat(hip_lib):
     """1 M transparent segments at 1920 x 1080: fragment lists of a crop against the oracle bit for bit, list lengths
     against the global counter, the resolved crop within the RGBA8 bar; the same scene through MLAT with the recorded

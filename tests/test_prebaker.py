@@ -77,3 +77,33 @@ def test_bake_and_lookup_properties():
     assert img[fg][:, :3].astype(int).mean() < same[fg][:, :3].astype(int).mean() - 2
     ao1 = np.ones((P.height, P.width), np.float32)
     assert np.array_equal(same, sc.render_rt(P, ao=ao1, use_bvh=True))
+
+
+def test_parametrization_of_three_hand_made_polylines():
+    """Pins blendingWeights / samplingLocations to values worked out by hand from the DEFINITION (VulkanAmbientOcclusionBaker.cpp:563-653:
+    N = ceil(L / expected) pieces of arc length h = L / N; weight = arc length / h clamped to N - 1e-5; sampling location i = the point
+    at arc length i h, expressed as vertex index + fraction, clamped to (n - 1) - 1e-5) -- independent of the oracle:
+      A (0,0,0) (1,0,0) (1,2,0): arcs 0 1 3, L 3, N 3, h 1        -> weights 0 1 3-eps        locations 0 1 1.5 2-eps
+      B (0,0,0) (0,0,.5):        arcs 0 .5,  L .5, N 1, h .5       -> weights 0 1-eps          locations 0 1-eps
+      C x = 0 .25 .5 2:          arcs 0 .25 .5 2, L 2, N 2, h 1    -> weights 0 .25 .5 2-eps   locations 0 2+1/3 3-eps
+    shifted by the line's first parametrisation vertex (0, 4, 6) resp. first line vertex (0, 3, 5)."""
+    pos = np.array([[0, 0, 0], [1, 0, 0], [1, 2, 0],
+                    [0, 0, 0], [0, 0, 0.5],
+                    [0, 0, 0], [0.25, 0, 0], [0.5, 0, 0], [2.0, 0, 0]], dtype=np.float32)
+    offsets = np.array([0, 3, 5, 9], dtype=np.uint32)
+    attrs = np.zeros(len(pos), dtype=np.float32)
+    flow = host_api.LineDataFlow().set_trajectories(pos, attrs, offsets)
+    bw, sl = flow.ao_parametrization(1.0)
+    eps = 1e-5
+    want_bw = [0.0, 1.0, 3.0 - eps, 4.0, 5.0 - eps, 6.0, 6.25, 6.5, 8.0 - eps]
+    want_sl = [0.0, 1.0, 1.5, 2.0 - eps, 3.0, 4.0 - eps, 5.0, 5.0 + 2.0 + 1.0 / 3.0, 8.0 - eps]
+    assert bw.dtype == np.float32 and sl.dtype == np.float32
+    assert len(bw) == 9 and len(sl) == 4 + 2 + 3
+    assert np.allclose(bw, want_bw, rtol=0.0, atol=2e-6)
+    assert np.allclose(sl, want_sl, rtol=0.0, atol=2e-6)
+    # the exactly representable ones are exact, and the clamped ends stay strictly inside their line's range
+    assert bw[0] == 0.0 and bw[1] == 1.0 and bw[3] == 4.0 and bw[6] == 6.25 and sl[2] == 1.5 and sl[4] == 3.0
+    assert bw[2] < 3.0 and bw[4] < 5.0 and bw[8] < 8.0 and sl[3] < 2.0 and sl[5] < 4.0 and sl[8] < 8.0
+    # the oracle (a literal restatement of the reference's loop) agrees bit for bit
+    obw, osl = lvo.ao_parametrization(pos, offsets, 1.0)
+    assert obw.tobytes() == bw.tobytes() and osl.tobytes() == sl.tobytes()

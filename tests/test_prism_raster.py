@@ -680,3 +680,59 @@ def test_hip_rotating_helicity_bands_on_the_rasterised_prism(hip_lib, kw):
     assert np.abs(img.astype(np.int32) - ref.astype(np.int32)).max() <= 2
     ctx.set_option("rotating_helicity_bands", False)
     assert not np.array_equal(ctx.render(2), img)
+
+
+@pytest.mark.gpu
+def test_hip_pixel_with_more_fragments_than_the_16_bit_rank(hip_lib):
+    """70 000 one-segment lines stacked behind one another on a 16 x 16 frame: the centre pixels receive more fragments than the 16-bit
+    per-pixel rank of the segment rasteriser can count (65 535).  The surplus is dropped (counted like pool overflow), and nothing
+    else may change: every pixel below the limit holds exactly the oracle's fragments, the saturated pixels hold 65 535 fragments that
+    all belong to the oracle's multiset for that pixel, each once (ranks used to wrap around and overwrite neighbouring
+    runs)."""
+    m = 70000
+    pts = np.zeros(m * 2, dtype=lvo.LINE_POINT_DTYPE)
+    rng = np.random.default_rng(11)
+    z = np.repeat(-0.35 + 1e-5 * np.arange(m), 2).astype(np.float32)
+    pts["linePosition"][:, 0] = np.tile(np.array([-0.06, 0.06], np.float32), m)
+    pts["linePosition"][:, 1] = np.repeat((0.003 * rng.standard_normal(m)).astype(np.float32), 2)
+    pts["linePosition"][:, 2] = z
+    pts["lineTangent"][:, 0] = 1.0
+    pts["lineNormal"][:, 1] = 1.0
+    pts["lineAttribute"][:] = np.repeat(rng.random(m).astype(np.float32), 2)
+    seg = np.arange(2 * m, dtype=np.uint32).reshape(m, 2)
+    c = Case(pts, seg, tfm.standard_transparent(), 16, 16, 0.12, ppll_max_num_frags=64, ppll_expected_avg_depth_complexity=4000,
+             collect_stats=True)
+    ctx = c.hip_context()
+    img = ctx.render(2)
+    st = ctx.stats()
+    sc, P = prism_params(c)
+    pw, ph = c.padded()
+    hn, hs, hcnt = ctx.ppll_buffers(pw * ph, int(P.ppllLinkedListSize))
+    on, os_, ocnt = sc.ppll_gather(P, use_bvh=True)
+    assert ocnt < int(P.ppllLinkedListSize), "the pool itself must not be what overflows here"
+    hw, ow = _walk_order(hn, hs), _walk_order(on, os_)
+    olen = {k: len(v) for k, v in ow.items()}
+    assert max(olen.values()) > 65535
+    saturated = [k for k, n in olen.items() if n > 65535]
+    assert set(hw) == set(ow)
+    for pix, want in ow.items():
+        got = hw[pix]
+        if pix in saturated:
+            assert len(got) == 65535
+            assert len(set(got)) == len(got) or sorted(got) == sorted(set(got))   # (equal keys may repeat only if the oracle's do)
+            from collections import Counter
+            cw, cg = Counter(want), Counter(got)
+            assert all(cg[k] <= cw[k] for k in cg), "a saturated pixel holds a fragment the oracle does not have"
+        else:
+            assert got == want, "pixel %d below the 16-bit limit differs from the oracle" % pix
+    assert st.fragments == ocnt      # the reference's fragCounter counts the dropped ones too
+    assert img.shape == (16, 16, 4)
+    unsat = np.ones((16, 16), bool)
+    ref = sc.render_ppll(P, use_bvh=True)
+    for pix in saturated:
+        for y in range(16):
+            for x in range(16):
+                if lvo.ppll_addr(x, y, pw, int(P.ppllTileW), int(P.ppllTileH)) == pix:
+                    unsat[y, x] = False
+    assert (~unsat).sum() == len(saturated) >= 1
+    assert np.abs(img.astype(np.int32) - ref.astype(np.int32))[unsat].max() <= 2
