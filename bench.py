@@ -37,7 +37,7 @@ LINE_WIDTH = 0.002
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E vendor peak (MI355X_MICROARCH.md; ~6.3 TB/s attainable)
 L2_PEAK_GBS = 34500.0     # aggregate L2 bandwidth (MI355X_MICROARCH.md "L2")
 NUM_CUS, NUM_SIMDS = 256, 1024
-PROFILE_TAGS = ("r04", "r03", "r02")   # counter files of the newest round that has them (profiles/pmc_<tag>_<workload>.json)
+PROFILE_TAGS = ("r05", "r04", "r03", "r02")   # counter files of the newest round that has them (profiles/pmc_<tag>_<workload>.json)
 CLOCK_GHZ = 2.4                  # MI355X peak engine clock (MI355X_MICROARCH.md)
 SETTINGS = {
     "ambient_occlusion_mode": "RTAO (Screen Space)", "ambient_occlusion_strength": 1.0,
@@ -248,7 +248,8 @@ def roofline(kernel, pmc_key, ms_launch, algorithmic_bytes, world):
         if upath is None and os.path.exists(c2):
             upath = c2
     none = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None, "hbm_frac": None,
-            "valu_frac_datasheet": None, "lane_utilisation": None, "valu_frac_own_mix": None, "pmc_head": None,
+            "valu_frac_datasheet": None, "lane_utilisation": None, "valu_frac_own_mix": None, "valu_busy": None, "clock_ghz_live": None,
+            "pmc_head": None,
             "pmc_matches_build": False}
     if world != 1 or ppath is None or upath is None or ms_launch <= 0:
         out.update(none)
@@ -301,6 +302,17 @@ def roofline(kernel, pmc_key, ms_launch, algorithmic_bytes, world):
     ceil["hbm"] = {"achieved": round(hbm_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_gbs / HBM_PEAK_GBS, 4),
                    "source": "(2 x FETCH_SIZE + WRITE_SIZE) x 1024 / launch time (MI355X_MICROARCH.md HBM: gfx950 FETCH_SIZE "
                              "counts 128-B requests as 64 B; Infinity-Cache hits are included, so this is an upper bound on HBM)"}
+    # hardware-counter figures that need no calibration of ours: VALU busy = quad-cycles the VALUs were active x 4 /
+    # SIMDs / elapsed engine cycles, the engine clock from GRBM_GUI_ACTIVE (summed over the 8 XCDs) over the live launch time
+    valu_busy = clock_live = None
+    if c.get("GRBM_GUI_ACTIVE") and c.get("SQ_ACTIVE_INST_VALU"):
+        cycles = c["GRBM_GUI_ACTIVE"] / 8.0
+        valu_busy = round(4.0 * c["SQ_ACTIVE_INST_VALU"] / NUM_SIMDS / cycles, 4)
+        clock_live = round(cycles / t_ns, 4)
+        ceil["valu_issue"]["valu_busy"] = valu_busy
+        ceil["valu_issue"]["clock_ghz_live"] = clock_live
+        ceil["valu_issue"]["busy_source"] = ("4 x SQ_ACTIVE_INST_VALU / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs): fraction of the engine cycles in "
+                                             "which a SIMD's VALU was executing; clock = those cycles / the launch time of this run")
     fracs = {"hbm": ceil["hbm"]["frac"], "l2": ceil["l2"]["frac"], "vector_l1": ceil["vector_l1"]["frac"],
              "valu_issue": ceil["valu_issue"]["frac_own_mix"]}
     pmc_sha = pmc.get("source_sha")
@@ -308,6 +320,7 @@ def roofline(kernel, pmc_key, ms_launch, algorithmic_bytes, world):
                 "traffic": int(traffic), "hbm_frac": ceil["hbm"]["frac"],
                 "valu_frac_datasheet": ceil["valu_issue"]["frac_datasheet"], "lane_utilisation": ceil["valu_issue"]["lane_utilisation"],
                 "valu_frac_own_mix": ceil["valu_issue"]["frac_own_mix"],
+                "valu_busy": valu_busy, "clock_ghz_live": clock_live,
                 "binding_ceiling": max(fracs, key=lambda k: fracs[k]),
                 "traffic_over_algorithmic": round(traffic / algorithmic_bytes, 4) if algorithmic_bytes else None,
                 "ceilings": ceil, "pmc_file": os.path.relpath(ppath, ROOT), "ubench_file": os.path.relpath(upath, ROOT),
@@ -879,6 +892,9 @@ def main():
         if seg is not None:   # compulsory floor: every node, primitive record and line point once + the outputs
             result["roofline"]["frame_compulsory_bytes"] = int(st.num_nodes * 64 + len(seg) * 32 + len(pts) * 48 + W * H * (4 + 4)
                                                                + (st.num_tube_triangles * (48 + 32) if wl.get("mesh") else 0))
+            if result["roofline"].get("traffic"):   # counter traffic of the dominant kernel against reading everything exactly once
+                result["roofline"]["traffic_over_compulsory"] = round(result["roofline"]["traffic"]
+                                                                      / result["roofline"]["frame_compulsory_bytes"], 3)
         if also is not None:
             sfx = wl.get("also_suffix", "capsules")
             result["value_" + sfx] = round(also["rays_per_frame"] * args.steps / also["elapsed"] / 1e6, 2)

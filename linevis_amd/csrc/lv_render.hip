@@ -322,6 +322,52 @@ __device__ __forceinline__ size_t lv_ao_slot(const uint32_t* __restrict__ tileBa
     return lv_ao_group_base(tileCapacity, lo) + (ordinal - tileBase[lo]);
 }
 
+#ifdef LV_AO_OCTANT_PERM
+// tools/variants.py experiment (EXPERIMENTS.md 12.2): an UPPER BOUND for "ray binning at generation".  A pre-pass
+// (not charged to k_ao_rays) orders the rays of every block of LV_AO_OCTANT_PERM pixels by the octant of their direction; k_ao_rays then
+// takes ray perm[i] where it took ray i, so that the 128-ray chunks a wave pulls hold rays of one or two octants.  Never in the product build.
+__device__ uint32_t* g_aoPerm;
+__global__ __launch_bounds__(256) void k_ao_octant_perm(const LvUniforms U, const float4* __restrict__ gbuf, uint32_t* __restrict__ perm,
+                                                        const LvDevCounters* dc, const uint32_t* __restrict__ tileBase, uint32_t numTiles,
+                                                        const LvAoLayout tileCapacity) {
+    __shared__ unsigned s_cnt[8], s_cur[8];
+    const uint32_t spp = U.aoSamplesPerFrame;
+    const unsigned long long total = (unsigned long long)(dc->aoCount) * spp;
+    const unsigned long long per = (unsigned long long)LV_AO_OCTANT_PERM * spp;
+    for (unsigned long long base = blockIdx.x * per; base < total; base += gridDim.x * per) {
+        if (threadIdx.x < 8) s_cnt[threadIdx.x] = 0u;
+        __syncthreads();
+        const unsigned long long end = base + per < total ? base + per : total;
+        for (int pass = 0; pass < 2; pass++) {
+            for (unsigned long long rr = base + threadIdx.x; rr < end; rr += blockDim.x) {
+                const uint32_t smpIdx = uint32_t(rr % spp);
+                const size_t slot = lv_ao_slot(tileBase, numTiles, tileCapacity, uint32_t(rr / spp));
+                const float4 g1 = gbuf[3 * slot + 1], g2 = gbuf[3 * slot + 2];
+                const f3 T = mk3(g1.x, g1.y, g1.z), N = mk3(g2.x, g2.y, g2.z);
+                const f3 B = cross3(N, T);
+                uint32_t seed = lv_tea(__float_as_uint(g1.w), U.aoGlobalFrameNumber * spp + smpIdx);
+                const float xi0 = lv_rnd(seed), xi1 = lv_rnd(seed);
+                float sn, cs;
+                lv_sincos2pi(xi1, sn, cs);
+                const float rs = sqrtf(1.0f - xi0 * xi0);
+                const f3 smp = mk3(cs * rs, sn * rs, xi0);
+                const f3 d = mk3((T.x * smp.x + B.x * smp.y) + N.x * smp.z, (T.y * smp.x + B.y * smp.y) + N.y * smp.z,
+                                 (T.z * smp.x + B.z * smp.y) + N.z * smp.z);
+                const unsigned oct = (d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u);
+                if (pass == 0) atomicAdd(&s_cnt[oct], 1u);
+                else perm[base + atomicAdd(&s_cur[oct], 1u)] = uint32_t(rr);
+            }
+            __syncthreads();
+            if (pass == 0 && threadIdx.x == 0) { unsigned run = 0; for (int k = 0; k < 8; k++) { s_cur[k] = run; run += s_cnt[k]; } }
+            __syncthreads();
+        }
+    }
+}
+#define LV_AO_RAY_INDEX(i) ((unsigned long long)g_aoPerm[i])
+#else
+#define LV_AO_RAY_INDEX(i) (i)
+#endif
+
 // AO sample rays: PERSISTENT waves that keep three kinds of work apart and run each of them with (nearly) all
 // 64 lanes busy.  AO ray r belongs to compacted pixel r / spp, sample r % spp.
 //
@@ -529,7 +575,7 @@ __global__ __launch_bounds__(LV_AO_BLOCK, LV_AO_MIN_WAVES) void k_ao_rays(const 
                 const unsigned n = left < LV_WAVE ? unsigned(left) : LV_WAVE;
                 if (STATS && lane == 0 && n) { phIt[0]++; phLn[0] += n; }
                 if (lane < n) {
-                    const unsigned long long rr = chunkNext + lane;
+                    const unsigned long long rr = LV_AO_RAY_INDEX(chunkNext + lane);
                     const uint32_t smpIdx = uint32_t(rr % spp);
                     const size_t slot = lv_ao_slot(tileBase, numTiles, tileCapacity, uint32_t(rr / spp));
                     const float4 g0 = gbuf[3 * slot + 0], g1 = gbuf[3 * slot + 1], g2 = gbuf[3 * slot + 2];
@@ -577,7 +623,7 @@ __global__ __launch_bounds__(LV_AO_BLOCK, LV_AO_MIN_WAVES) void k_ao_rays(const 
                     inv = mk3(1.0f / r1.y, 1.0f / r2.x, 1.0f / r2.y);
                     oi = mk3(r0.x * inv.x, r0.y * inv.y, r1.x * inv.z);
                     best = U.aoRadius;
-                    r = genBase + gs;
+                    r = LV_AO_RAY_INDEX(genBase + gs);
                     owner = lane;
                     cur = 0;
                     st.sp = 0;
@@ -2464,6 +2510,16 @@ static int lv_run_ao(lv_ctx* ctx, LvUniforms& U, LvSceneDev& S, const LvTiles& T
         else { if (tri) LV_LAUNCH_AOP(false, LV_PRIM_TRIANGLE); else if (ell) LV_LAUNCH_AOP(false, LV_PRIM_ELLIPTIC); else LV_LAUNCH_AOP(false, LV_PRIM_CAPSULE); }
         k_ao_tile_scan<<<1, LV_BLOCK, 0, st>>>(tileCount, numGroups, tileBase, dc);
         const bool anyHit = !U.aoUseDistance;
+#ifdef LV_AO_OCTANT_PERM
+        {   // experiment only: the permutation is built by a pre-pass outside the timed kernel
+            static uint32_t* permBuf = nullptr;
+            static size_t permCap = 0;
+            const size_t need = size_t(maxPixels) * spp;
+            if (need > permCap) { if (permBuf) (void)hipFree(permBuf); LV_HIP(ctx, hipMalloc(&permBuf, need * 4)); permCap = need; }
+            LV_HIP(ctx, hipMemcpyToSymbolAsync(HIP_SYMBOL(g_aoPerm), &permBuf, sizeof(permBuf), 0, hipMemcpyHostToDevice, st));
+            k_ao_octant_perm<<<4096, 256, 0, st>>>(U, g, permBuf, dc, tileBase, numGroups, tileCap);
+        }
+#endif
         if (stats) { if (anyHit) LV_LAUNCH_AO2(true, true); else LV_LAUNCH_AO2(true, false); }
         else { if (anyHit) LV_LAUNCH_AO2(false, true); else LV_LAUNCH_AO2(false, false); }
 #undef LV_LAUNCH_AO2

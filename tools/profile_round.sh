@@ -4,7 +4,7 @@
 #   rocprofv3 --kernel-trace --stats       -> gpurun_out/prof_<tag>/<workload>_kernel_stats.csv  (same command as the bench line)
 #   PMC counter groups (tools/pmc_collect.sh: full set for c3c / c3t / c4, roofline set for the others) -> gpurun_out/pmc_<tag>/
 #   shard / frames-in-flight probe          -> gpurun_out/shard_probe_<workload>.json
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
@@ -21,7 +21,11 @@ bash $R/tools/pmc_collect.sh $TAG c3c c3t c4 > $OUT/pmc_full.log 2>&1
 LV_PMC_LITE=1 bash $R/tools/pmc_collect.sh $TAG c2 c2e c4c c4m c4l c5 > $OUT/pmc_lite.log 2>&1
 for f in $R/gpurun_out/pmc_$TAG/*.json; do cp $f $R/profiles/pmc_${TAG}_$(basename $f); done   # bench.py reads profiles/
 python $R/bench.py > $OUT/bench_c3.json 2> $OUT/bench_c3.err
-for w in c3c c3t c2 c2e c4 c4c c4m c4l c5; do
+# the CPU baseline beside C2, C3 and C4 (a bounded ~15-s sample each); the variants of those configs without it
+for w in c2 c4; do
+  python $R/bench.py --workload $w --steps 100 --warmup 5 > $OUT/bench_$w.json 2> $OUT/bench_$w.err
+done
+for w in c3c c3t c2e c4c c4m c4l c5; do
   python $R/bench.py --workload $w --steps 100 --warmup 5 --no-cpu-baseline > $OUT/bench_$w.json 2> $OUT/bench_$w.err
 done
 for w in c3 c4 c4m c2; do
