@@ -130,6 +130,7 @@ struct LvDevCounters {
     uint32_t prismDiscards;  // raster_prism: linked nodes the fragment stage turned into dead nodes (discarded fragments)
     uint32_t mlatTraceCount; // records appended to the MLAT visiting-order trace (collect_stats)
     uint32_t ppllOverflowPixels; // raster_prism: pixels with more kept fragments than the sort arrays (k_ppll_pixel_pass's list)
+    uint32_t prismListCount;     // raster_prism on a tile list: segments k_ppll_cull_segments kept for this rank's tiles
     // k_ao_rays leaf-test diagnostics (collect_stats): tests that found a hit inside the interval, tests the conservative
     // axis-distance pre-test lets through, tests axis + bounding-sphere pre-tests let through
     unsigned long long aoPrimHits, aoPrimMayAxis, aoPrimMayBoth;

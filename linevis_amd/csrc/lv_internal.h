@@ -201,6 +201,7 @@ struct lv_ctx {
     uint32_t twistW = 0, twistH = 0, twistLevels = 0;
     LvDeviceBuffer flowOccupancy;             // max-helicity-first seeding: the occupancy grid, one byte per cell
     LvDeviceBuffer flowSelfGrid;              // loop check "Grid": one bit per cell and line of a batch
+    LvDeviceBuffer prismLeafList;             // raster_prism, sharded frames: segments that can touch the frame's tile list (k_ppll_cull_segments)
     LvDeviceBuffer ppllCoarse;                // raster_prism, sharded frames: 32 x 32-pixel cells that hold requested pixels (k_ppll_mark_tiles)
     LvDeviceBuffer ppllOverflow;              // raster_prism: pixel addresses with more kept fragments than ppllMaxNumFrags (k_ppll_pixel_pass)
     bool ppllArrays = false;                  // the last PPLL frame left per-pixel runs (raster_prism), not linked lists

@@ -1383,6 +1383,94 @@ __global__ __launch_bounds__(LV_WAVE) void k_ppll_select_nearest(const LvUniform
     }
 }
 
+// rows x, y, w of proj * view (clip = M * (p, 1)) as the segment rasteriser and its cull pass use them
+__device__ __forceinline__ void lv_clip_rows(const LvUniforms& U, float mx[4], float my[4], float mw[4]) {
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        mx[c] = 0.0f; my[c] = 0.0f; mw[c] = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {   // column-major 4 x 4
+            mx[c] += U.proj[4 * k + 0] * U.view[4 * c + k];
+            my[c] += U.proj[4 * k + 1] * U.view[4 * c + k];
+            mw[c] += U.proj[4 * k + 3] * U.view[4 * c + k];
+        }
+    }
+}
+// Sharded frame (a rank renders a tile list): ONE pass per frame over the segments' 32-B records decides which of them can touch a
+// requested pixel at all and appends those to a list; k_ppll_raster_prism then walks the list, so that the segments of the other ranks'
+// tiles cost this rank 32 B and ~60 instructions each instead of a slot of the rasteriser's waves (frames, oriented box, an empty
+// pixel walk) -- with every rank looping over all segments the rasteriser took 0.20 ms for an eighth of config 4's tiles against 0.29 ms
+// for all of them (profiles/shard_probe_r04_c4.json).  The test is conservative: both line points projected, the prism lies within
+// `radius` of the segment; near the camera plane: undecided = kept.  Order of the list: blocks of <= 64 segments in leaf (= Morton)
+// order, the blocks in the order the waves' appends arrive -- the fragments do not depend on it (the ranks race anyway).
+#define LV_CULL_PER_BLOCK 2048u   // segments per workgroup of k_ppll_cull_segments (one global append each)
+__global__ __launch_bounds__(LV_BLOCK) void k_ppll_cull_segments(const LvUniforms U, const LvSceneDev S, const uint32_t* __restrict__ coarse,
+                                                                 uint32_t* __restrict__ leafList, LvDevCounters* dc) {
+    const LvPrismDev& R = S.prism;
+    float mx[4], my[4], mw[4];
+    lv_clip_rows(U, mx, my, mw);
+    const float halfW = 0.5f * float(U.width), halfH = 0.5f * float(U.height);
+    const float wEps = 1e-3f * U.nearDist;
+    const unsigned lane = lv_lane();
+    // workgroup b owns the LV_CULL_PER_BLOCK consecutive segments from b * LV_CULL_PER_BLOCK: survivors are collected in LDS and
+    // appended with ONE global atomic per workgroup (one per wave and 64 segments: 15.6 K returning atomics on one address at ~13 ns
+    // each = 0.12 ms on config 4, more than the pass saves)
+    __shared__ uint32_t s_keep[LV_CULL_PER_BLOCK];
+    __shared__ uint32_t s_n, s_base;
+    if (threadIdx.x == 0u) s_n = 0u;
+    __syncthreads();
+    const uint32_t first = blockIdx.x * LV_CULL_PER_BLOCK, last = min(first + LV_CULL_PER_BLOCK, S.numSegs);
+    for (uint32_t leafBase = first + (threadIdx.x & ~63u); leafBase < last; leafBase += LV_BLOCK) {
+        const uint32_t leaf = leafBase + lane;
+        bool mine = false;
+        if (leaf < last) {
+            const float4 pa = S.segs[2 * size_t(leaf)], pb = S.segs[2 * size_t(leaf) + 1];
+            const f3 centre[2] = {mk3(pa.x, pa.y, pa.z), mk3(pb.x, pb.y, pb.z)};
+            mine = true;
+            // does the segment project into a coarse cell with requested pixels?  Both line points with a generous bound of the
+            // projected radius
+            float lo[2] = {3.0e38f, 3.0e38f}, hi[2] = {-3.0e38f, -3.0e38f};
+            bool decided = true;
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                const f3 v = centre[e];
+                const float cw = ((mw[0] * v.x + mw[1] * v.y) + mw[2] * v.z) + mw[3];
+                if (!(cw > 4.0f * R.radius + wEps)) { decided = false; continue; }
+                const float ccx = ((mx[0] * v.x + mx[1] * v.y) + mx[2] * v.z) + mx[3];
+                const float ccy = ((my[0] * v.x + my[1] * v.y) + my[2] * v.z) + my[3];
+                const float sx = (ccx / cw + 1.0f) * halfW, sy = (ccy / cw + 1.0f) * halfH;
+                // |d screen| <= f r / (w - r) (1 + |x / w|) for a point within r of the centre: tangent of the off-axis angle from the
+                // centre's own clip coordinates, 25 % and 2 pixels on top
+                const float tanOff = fabsf(ccx / cw) / fabsf(U.proj[0]) + fabsf(ccy / cw) / fabsf(U.proj[5]);
+                const float rp = 1.25f * (1.0f + tanOff) * R.radius * fmaxf(fabsf(U.proj[0]) * halfW, fabsf(U.proj[5]) * halfH) / (cw - R.radius) + 2.0f;
+                lo[0] = fminf(lo[0], sx - rp); hi[0] = fmaxf(hi[0], sx + rp); lo[1] = fminf(lo[1], sy - rp); hi[1] = fmaxf(hi[1], sy + rp);
+            }
+            if (decided) {
+                const float cwid = float((U.width + LV_PRISM_COARSE - 1u) / LV_PRISM_COARSE), chgt = float((U.height + LV_PRISM_COARSE - 1u) / LV_PRISM_COARSE);
+                const float c0x = fmaxf(floorf(lo[0] / float(LV_PRISM_COARSE)), 0.0f), c1x = fminf(floorf(hi[0] / float(LV_PRISM_COARSE)), cwid - 1.0f);
+                const float c0y = fmaxf(floorf(lo[1] / float(LV_PRISM_COARSE)), 0.0f), c1y = fminf(floorf(hi[1] / float(LV_PRISM_COARSE)), chgt - 1.0f);
+                mine = false;
+                if (c1x - c0x <= 3.0f && c1y - c0y <= 3.0f) {
+                    for (float cy = c0y; cy <= c1y; cy += 1.0f)
+                        for (float cx = c0x; cx <= c1x; cx += 1.0f) mine = mine || coarse[uint32_t(cy) * uint32_t(cwid) + uint32_t(cx)] != 0u;
+                } else mine = c0x <= c1x && c0y <= c1y;   // (a large footprint: not worth the look-ups)
+            }
+        }
+        const unsigned long long m = __ballot(mine);
+        if (m) {
+            uint32_t base = 0u;
+            if (lane == 0u) base = atomicAdd(&s_n, uint32_t(__popcll(m)));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (mine) s_keep[base + uint32_t(__popcll(m & ((1ull << lane) - 1ull)))] = leaf;
+        }
+    }
+    __syncthreads();
+    const uint32_t n = s_n;
+    if (threadIdx.x == 0u && n) s_base = atomicAdd(&dc->prismListCount, n);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += LV_BLOCK) leafList[s_base + i] = s_keep[i];
+}
+
 #define LV_PRISM_RASTER_QUEUE 128u   // (pixel, segment) pairs a wave holds between the two stages (>= 2 * LV_WAVE, power of two)
 template <bool STATS, int NT>
 __global__ __launch_bounds__(LV_BLOCK, LV_PRISM_RASTER_MIN_WAVES) void k_ppll_raster_prism(const LvUniforms U, const LvSceneDev S,
@@ -1390,7 +1478,7 @@ __global__ __launch_bounds__(LV_BLOCK, LV_PRISM_RASTER_MIN_WAVES) void k_ppll_ra
                                                                    const uint32_t* __restrict__ startOffset,
                                                                    uint32_t* __restrict__ fragCount, LvDevCounters* dc,
                                                                    uint32_t poolSlots, uint32_t allRequested,
-                                                                   const uint32_t* __restrict__ coarse) {
+                                                                   const uint32_t* __restrict__ leafList) {
     // Two stages per wave, joined by a queue in LDS:
     //  A  one lane per segment: the candidate pixels of its screen rectangle that also lie in the ORIENTED box of the projected ring
     //     vertices (axis = the projected segment; a 1 x 3-pixel segment at 45 degrees fills a third of its rectangle) and in a
@@ -1411,23 +1499,12 @@ __global__ __launch_bounds__(LV_BLOCK, LV_PRISM_RASTER_MIN_WAVES) void k_ppll_ra
     uint32_t* qPix = s_qPix[threadIdx.x >> 6];
     float (*segLds)[LV_WAVE] = s_seg[threadIdx.x >> 6];
     const f3 o = mk3(U.camPos[0], U.camPos[1], U.camPos[2]);
-    // rows of proj * view (clip = M * (p, 1)); x, y and w only
-    float mx[4], my[4], mw[4];
-#pragma unroll
-    for (int c = 0; c < 4; c++) {
-        mx[c] = 0.0f; my[c] = 0.0f; mw[c] = 0.0f;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {   // column-major 4 x 4
-            mx[c] += U.proj[4 * k + 0] * U.view[4 * c + k];
-            my[c] += U.proj[4 * k + 1] * U.view[4 * c + k];
-            mw[c] += U.proj[4 * k + 3] * U.view[4 * c + k];
-        }
-    }
+    float mx[4], my[4], mw[4];   // rows of proj * view (clip = M * (p, 1)); x, y and w only
+    lv_clip_rows(U, mx, my, mw);
     const float halfW = 0.5f * float(U.width), halfH = 0.5f * float(U.height);
     const float wEps = 1e-3f * U.nearDist;
     unsigned allocBase = 0u, allocLeft = 0u;   // this wave's chunk of record slots (wave-uniform)
     unsigned qHead = 0u, qCount = 0u;          // the queue (wave-uniform)
-    uint32_t leafBaseCur = 0u;                 // first segment of the wave's current 64
     unsigned long long tests = 0;
     uint32_t dropped = 0u;
 
@@ -1444,7 +1521,8 @@ __global__ __launch_bounds__(LV_BLOCK, LV_PRISM_RASTER_MIN_WAVES) void k_ppll_ra
             // (no requested-tile test here: a whole-viewport frame requests every pixel, a rank of a sharded frame filters in stage A)
             f3 oo, d;
             lv_primary_ray(U, px, py, 0.5f, 0.5f, oo, d);
-            const uint32_t sl = leaf - leafBaseCur;   // the pair's segment among the wave's 64
+            const uint32_t sl = leaf >> 26;   // the pair's segment among the wave's 64 = the lane that queued it
+            leaf &= 0x03FFFFFFu;
             LvPrismPoint pt[2];
             uint32_t pi[2];
 #pragma unroll
@@ -1506,10 +1584,11 @@ __global__ __launch_bounds__(LV_BLOCK, LV_PRISM_RASTER_MIN_WAVES) void k_ppll_ra
     // 0.49 ms for 64 / 128 / 256 / 512 segments per ticket -- small tickets pay the returning atomic on one address (13 ns each, 15.6 K
     // of them), large ones the variance again -- against 0.29 ms)
     const uint32_t waveId = blockIdx.x * (LV_BLOCK / LV_WAVE) + (threadIdx.x >> 6), numWaves = gridDim.x * (LV_BLOCK / LV_WAVE);
-    for (uint32_t leafBase = waveId * LV_WAVE; leafBase < S.numSegs; leafBase += numWaves * LV_WAVE) {
-        const uint32_t leaf = leafBase + lane;
-        const bool valid = leaf < S.numSegs;
-        leafBaseCur = leafBase;
+    // the work list: every segment (leaf order), or -- a rank of a sharded frame -- the segments k_ppll_cull_segments kept
+    const uint32_t numItems = leafList ? dc->prismListCount : S.numSegs;
+    for (uint32_t itemBase = waveId * LV_WAVE; itemBase < numItems; itemBase += numWaves * LV_WAVE) {
+        const bool valid = itemBase + lane < numItems;
+        const uint32_t leaf = !valid ? 0u : (leafList ? leafList[itemBase + lane] : itemBase + lane);
         int x0 = 0, x1 = -1, y0 = 0, y1 = -1;
         // oriented box: |(pixel centre - c) . a - aMid| <= aHalf and |(pixel centre - c) . n - nMid| <= nHalf, n = (-a.y, a.x)
         float ax = 1.0f, ay = 0.0f, cx0 = 0.0f, cy0 = 0.0f, aMid = 0.0f, aHalf = 3.0e38f, nMid = 0.0f, nHalf = 3.0e38f;
@@ -1518,38 +1597,6 @@ __global__ __launch_bounds__(LV_BLOCK, LV_PRISM_RASTER_MIN_WAVES) void k_ppll_ra
             uint32_t pi[2];
             LvPrismPoint pt[2];
             lv_prism_frames(S, leaf, pa, pb, pt, pi);
-            bool mine = true;
-            if (!allRequested) {
-                // sharded frame: does the segment project into a coarse cell with requested pixels?  Both line points with a generous
-                // bound of the projected radius (the prism lies within `radius` of the segment); near the camera plane: undecided = yes
-                float lo[2] = {3.0e38f, 3.0e38f}, hi[2] = {-3.0e38f, -3.0e38f};
-                bool decided = true;
-#pragma unroll
-                for (int e = 0; e < 2; e++) {
-                    const f3 v = pt[e].centre;
-                    const float cw = ((mw[0] * v.x + mw[1] * v.y) + mw[2] * v.z) + mw[3];
-                    if (!(cw > 4.0f * R.radius + wEps)) { decided = false; continue; }
-                    const float ccx = ((mx[0] * v.x + mx[1] * v.y) + mx[2] * v.z) + mx[3];
-                    const float ccy = ((my[0] * v.x + my[1] * v.y) + my[2] * v.z) + my[3];
-                    const float sx = (ccx / cw + 1.0f) * halfW, sy = (ccy / cw + 1.0f) * halfH;
-                    // |d screen| <= f r / (w - r) (1 + |x / w|) for a point within r of the centre: tangent of the off-axis angle from the
-                    // centre's own clip coordinates, 25 % and 2 pixels on top
-                    const float tanOff = fabsf(ccx / cw) / fabsf(U.proj[0]) + fabsf(ccy / cw) / fabsf(U.proj[5]);
-                    const float rp = 1.25f * (1.0f + tanOff) * R.radius * fmaxf(fabsf(U.proj[0]) * halfW, fabsf(U.proj[5]) * halfH) / (cw - R.radius) + 2.0f;
-                    lo[0] = fminf(lo[0], sx - rp); hi[0] = fmaxf(hi[0], sx + rp); lo[1] = fminf(lo[1], sy - rp); hi[1] = fmaxf(hi[1], sy + rp);
-                }
-                if (decided) {
-                    const float cwid = float((U.width + LV_PRISM_COARSE - 1u) / LV_PRISM_COARSE), chgt = float((U.height + LV_PRISM_COARSE - 1u) / LV_PRISM_COARSE);
-                    const float c0x = fmaxf(floorf(lo[0] / float(LV_PRISM_COARSE)), 0.0f), c1x = fminf(floorf(hi[0] / float(LV_PRISM_COARSE)), cwid - 1.0f);
-                    const float c0y = fmaxf(floorf(lo[1] / float(LV_PRISM_COARSE)), 0.0f), c1y = fminf(floorf(hi[1] / float(LV_PRISM_COARSE)), chgt - 1.0f);
-                    mine = false;
-                    if (c1x - c0x <= 3.0f && c1y - c0y <= 3.0f) {
-                        for (float cy = c0y; cy <= c1y; cy += 1.0f)
-                            for (float cx = c0x; cx <= c1x; cx += 1.0f) mine = mine || coarse[uint32_t(cy) * uint32_t(cwid) + uint32_t(cx)] != 0u;
-                    } else mine = c0x <= c1x && c0y <= c1y;   // (a large footprint: not worth the look-ups)
-                }
-            }
-            if (mine) {
 #pragma unroll
             for (int e = 0; e < 2; e++) {
                 segLds[9 * e + 0][lane] = pt[e].centre.x; segLds[9 * e + 1][lane] = pt[e].centre.y; segLds[9 * e + 2][lane] = pt[e].centre.z;
@@ -1608,7 +1655,6 @@ __global__ __launch_bounds__(LV_BLOCK, LV_PRISM_RASTER_MIN_WAVES) void k_ppll_ra
                 const float fy1 = fminf(floorf(hiy + LV_PRISM_BBOX_MARGIN - 0.5f), float(U.height) - 1.0f);
                 if (fx0 <= fx1 && fy0 <= fy1) { x0 = int(fx0); x1 = int(fx1); y0 = int(fy0); y1 = int(fy1); }
             }
-            }   // mine
         }
         int px = x0, py = y0;
         bool more = valid && x1 >= x0 && y1 >= y0;
@@ -1623,7 +1669,7 @@ __global__ __launch_bounds__(LV_BLOCK, LV_PRISM_RASTER_MIN_WAVES) void k_ppll_ra
             const unsigned long long cm = __ballot(cand);
             if (cand) {
                 const unsigned q = (qHead + qCount + unsigned(__popcll(cm & ((1ull << lane) - 1ull)))) & (LV_PRISM_RASTER_QUEUE - 1u);
-                qLeaf[q] = leaf;
+                qLeaf[q] = leaf | (lane << 26);
                 qPix[q] = uint32_t(px) | (uint32_t(py) << 16);
             }
             qCount += unsigned(__popcll(cm));
@@ -1657,7 +1703,7 @@ __global__ __launch_bounds__(LV_BLOCK) void k_ppll_clear(uint4* __restrict__ sta
         fragCount[i] = make_uint4(0u, 0u, 0u, 0u);
     }
     if (i == 0) {
-        dc->fragCounter = 0u; dc->fragAlloc = 0u; dc->prismDiscards = 0u; dc->ppllOverflowPixels = 0u;
+        dc->fragCounter = 0u; dc->fragAlloc = 0u; dc->prismDiscards = 0u; dc->ppllOverflowPixels = 0u; dc->prismListCount = 0u;
         if (viewingRays) atomicAdd(&dc->rays, viewingRays);
     }
 }
@@ -2850,10 +2896,18 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
 #define LV_LAUNCH_RASTER(ST, NT)                                                                                              \
     LV_TIMED_LAUNCH(ctx, LV_KERNEL_PPLL_RASTER, (k_ppll_raster_prism<ST, NT><<<rasterGrid, LV_BLOCK, 0, st>>>(                \
             U, S, gatherPool, (const uint32_t*)ctx->ppllStart.ptr, (uint32_t*)ctx->ppllCount.ptr, dc, poolSlots,                \
-            allRequested ? 1u : 0u, coarse)))
+            allRequested ? 1u : 0u, leafList)))
+            uint32_t* leafList = nullptr;
             if (allRequested) {}   // (k_ppll_clear marked every pixel)
             else if (stats) k_ppll_mark_tiles<true><<<gridTiles, LV_BLOCK, 0, st>>>(U, T, (uint32_t*)ctx->ppllStart.ptr, coarse, dc);
             else k_ppll_mark_tiles<false><<<gridTiles, LV_BLOCK, 0, st>>>(U, T, (uint32_t*)ctx->ppllStart.ptr, coarse, dc);
+            if (!allRequested && S.numSegs != 0) {
+                // the segments that can touch this tile list (k_ppll_clear zeroed the list's counter)
+                if ((rc = lv_buf_reserve(ctx, ctx->prismLeafList, size_t(S.numSegs) * 4))) return rc;
+                leafList = (uint32_t*)ctx->prismLeafList.ptr;
+                const uint32_t cullGrid = (S.numSegs + LV_CULL_PER_BLOCK - 1u) / LV_CULL_PER_BLOCK;
+                k_ppll_cull_segments<<<cullGrid, LV_BLOCK, 0, st>>>(U, S, coarse, leafList, dc);
+            }
             if (S.numSegs != 0) {
                 if (S.prism.n == 6u) { if (stats) LV_LAUNCH_RASTER(true, 6); else LV_LAUNCH_RASTER(false, 6); }
                 else { if (stats) LV_LAUNCH_RASTER(true, 0); else LV_LAUNCH_RASTER(false, 0); }
