@@ -422,6 +422,12 @@ int lv_get_ao(lv_ctx* ctx, float* out /* viewport_width * viewport_height */);
  * BVH traversal order (undefined); a CPU replay of THIS order must reproduce the frame.  out_records may be NULL
  * (query the count). */
 int lv_get_mlat_trace(lv_ctx* ctx, uint32_t* out_records, uint64_t max_records, uint64_t* out_count);
+/* Parity instrument without a reference counterpart: the shading kernels evaluate normalize(v) = v * r(v . v), r(x) = the IEEE-correct
+ * bits of 1.0f / sqrtf(min(max(x, 2^-60), 2^60)) (the CPU checker states the same rule), through a shortened instruction sequence.
+ * Runs that sequence on ALL 2^32 float arguments on the device against the rule evaluated with the compiler's own division and square
+ * root; out_mismatches = number of arguments whose results differ in any bit (NaN results count as equal to each other),
+ * out_first_argument = the bits of one of them. */
+int lv_selftest_rsqrt(lv_ctx* ctx, uint64_t* out_mismatches, uint32_t* out_first_argument);
 /* PPLL buffers after the last mode-2 render: nodes = 3 uint32 {rgba8, depth bits, next} per node slot (slots are handed
  * out to waves in chunks, so unreferenced slots may lie between the stored fragments), start_offset = padded_w * padded_h
  * heads (0xFFFFFFFF = empty), frag_counter = number of fragments generated.  Either pointer may be NULL. */

@@ -97,7 +97,7 @@ SYMBOLS = ["lv_create", "lv_destroy", "lv_last_error", "lv_version", "lv_set_str
            "lv_render", "lv_render_device", "lv_render_tiles_device", "lv_get_stats", "lv_reset_timers", "lv_get_kernel_times", "lv_get_ao_tile_costs", "lv_get_dispatch_order", "lv_trace_rays",
            "lv_compute_depth_range", "lv_get_ao", "lv_ppll_get_buffers", "lv_ppll_resolve_buffers", "lv_get_accel",
            "lv_set_tube_triangle_mesh", "lv_trace_rays_triangles", "lv_set_flow_grid", "lv_trace_streamlines", "lv_trace_streamlines_max_helicity_first",
-           "lv_get_streamlines", "lv_get_streamline_seed_indices", "lv_set_ao_parametrization", "lv_get_baked_ao", "lv_bake_ao_start", "lv_bake_ao_poll", "lv_get_mlat_trace",
+           "lv_get_streamlines", "lv_get_streamline_seed_indices", "lv_set_ao_parametrization", "lv_get_baked_ao", "lv_bake_ao_start", "lv_bake_ao_poll", "lv_get_mlat_trace", "lv_selftest_rsqrt",
            "lv_create_multi", "lv_multi_ranks", "lv_multi_rank_stats", "lv_multi_rebalance", "lv_multi_deal", "lv_tile_deal", "lv_make_tiles"]
 
 _lib = None
@@ -176,6 +176,7 @@ def load():
         ("lv_set_ao_parametrization", [vp, vp, u32, vp, u32]),
         ("lv_get_baked_ao", [vp, vp, u64]),
         ("lv_get_mlat_trace", [vp, vp, u64, C.POINTER(u64)]),
+        ("lv_selftest_rsqrt", [vp, C.POINTER(u64), C.POINTER(u32)]),
     ]:
         fn = getattr(L, name)
         fn.restype = i32
@@ -423,6 +424,13 @@ class Context:
         rec = np.zeros((max(int(cnt.value), 1), 4), dtype=np.uint32)
         self._ck(self.L.lv_get_mlat_trace(self.h, _p(rec), rec.shape[0], C.byref(cnt)))
         return rec[:int(cnt.value)]
+
+    def selftest_rsqrt(self):
+        """(mismatches, bits of one mismatching argument) of the shading code's 1 / sqrt(x) sequence against IEEE division and square
+        root over all 2^32 float arguments, evaluated on the device."""
+        bad, first = C.c_uint64(), C.c_uint32()
+        self._ck(self.L.lv_selftest_rsqrt(self.h, C.byref(bad), C.byref(first)))
+        return int(bad.value), int(first.value)
 
     def kernel_times(self, kernel_id):
         """Individual launch durations (ms) of one kernel since reset_timers(), oldest first (at most the last 512)."""

@@ -1189,6 +1189,41 @@ int lv_ppll_get_buffers(lv_ctx* ctx, uint32_t* out_nodes, uint64_t max_nodes, ui
     return LV_OK;
 }
 
+namespace {
+// every float argument once: grid-stride over the 2^32 bit patterns
+__global__ __launch_bounds__(256) void k_selftest_rsqrt(unsigned long long* __restrict__ result) {
+    unsigned long long bad = 0ull;
+    uint32_t firstBad = 0u;
+    for (unsigned long long i = blockIdx.x * 256ull + threadIdx.x; i < (1ull << 32); i += gridDim.x * 256ull) {
+        const float x = __uint_as_float(uint32_t(i));
+        // (the argument must not be a compile-time constant of either side; both are plain functions of a loaded bit pattern)
+        const float a = lv_rsqrt_shade(x);
+        float xs = x;
+        asm volatile("" : "+v"(xs));   // keeps the two evaluations apart (no common subexpressions)
+        const float b = lv_rsqrt_shade_reference(xs);
+        const bool same = __float_as_uint(a) == __float_as_uint(b) || (a != a && b != b);
+        if (!same) { if (!bad) firstBad = uint32_t(i); bad++; }
+    }
+    if (bad) { atomicAdd(&result[0], bad); result[1] = firstBad; }
+}
+}   // namespace
+
+int lv_selftest_rsqrt(lv_ctx* ctx, uint64_t* out_mismatches, uint32_t* out_first_argument) {
+    if (!ctx || !out_mismatches) return LV_E_INVALID;
+    (void)hipSetDevice(ctx->device);
+    unsigned long long* dev = nullptr;
+    LV_HIP(ctx, hipMalloc(&dev, 16));
+    LV_HIP(ctx, hipMemsetAsync(dev, 0, 16, ctx->stream));
+    k_selftest_rsqrt<<<uint32_t(ctx->numCUs) * 16u, 256, 0, ctx->stream>>>(dev);
+    unsigned long long host[2] = {0ull, 0ull};
+    LV_HIP(ctx, hipMemcpyAsync(host, dev, 16, hipMemcpyDeviceToHost, ctx->stream));
+    LV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    (void)hipFree(dev);
+    *out_mismatches = host[0];
+    if (out_first_argument) *out_first_argument = uint32_t(host[1]);
+    return LV_OK;
+}
+
 int lv_get_mlat_trace(lv_ctx* ctx, uint32_t* out_records, uint64_t max_records, uint64_t* out_count) {
     if (!ctx) return LV_E_INVALID;
     if (!ctx->mlatTrace.ptr || !ctx->counters.ptr || ctx->lastMode != LV_RENDERING_MODE_VULKAN_RAY_TRACER ||

@@ -412,7 +412,38 @@ __device__ __forceinline__ float lv_log2_det(float x) {
 }
 // normalize(v) of the shading code as v * (1 / length(v)): one IEEE division instead of three (GLSL does not say how normalize
 // divides; the twelve normalisations of computeFragmentColor + blinnPhongShadingTube were a third of the shading instructions)
-__device__ __forceinline__ f3 norm3s(f3 a) { const float r = 1.0f / len3(a); return mk3(a.x * r, a.y * r, a.z * r); }
+// normalize(v) of the shading code: v * r(v . v) with r(x) = 1.0f / sqrtf(min(max(x, 2^-60), 2^60)), the IEEE-correct bits -- the squared
+// length is clamped into a range that holds every length the shading code meets (a zero vector stays a zero vector instead of turning into
+// NaNs; GLSL leaves normalize() of such vectors undefined).  The CPU checker states the same rule (normalizeShade).  What the clamp buys:
+// inside the range the compiler's correctly rounded sqrtf (v_sqrt_f32 + a +-1 ulp correction from two fused residuals, wrapped in a
+// denormal pre-scale and a class fix-up) and its correctly rounded division (v_rcp_f32 + three Newton steps, wrapped in v_div_scale /
+// v_div_fixup) reduce to their cores -- the wrappers do nothing there: 18 branch-free VALU instructions + 2 for the clamp instead of 27
+// and two SGPR-pair compares (k_ppll_shade_prism, 25 normalisations per fragment; EXPERIMENTS.md 12.3 has the forms that did NOT pay:
+// out-of-range lanes through the compiler's sequence by a branch, and NaN outside the range by a compare + select).
+// lv_selftest_rsqrt / tests/test_gpu_math.py compare all 2^32 arguments on the device against the rule evaluated with the compiler's ops.
+#define LV_RSQRT_LO 8.67361737988403547206e-19f   // 2^-60
+#define LV_RSQRT_HI 1152921504606846976.0f        // 2^60
+__device__ __forceinline__ float lv_rsqrt_shade(float x) {
+    x = fminf(fmaxf(x, LV_RSQRT_LO), LV_RSQRT_HI);   // (NaN -> 2^-60: maxNum / minNum return the other operand)
+    float s = __builtin_amdgcn_sqrtf(x);
+    const float sDn = __uint_as_float(__float_as_uint(s) - 1u), sUp = __uint_as_float(__float_as_uint(s) + 1u);
+    const float rDn = __builtin_fmaf(-sDn, s, x), rUp = __builtin_fmaf(-sUp, s, x);
+    s = rDn <= 0.0f ? sDn : s;
+    s = rUp > 0.0f ? sUp : s;
+    const float r0 = __builtin_amdgcn_rcpf(s);
+    const float r1 = __builtin_fmaf(__builtin_fmaf(-s, r0, 1.0f), r0, r0);
+    const float q1 = __builtin_fmaf(__builtin_fmaf(-s, r1, 1.0f), r1, r1);
+    return __builtin_fmaf(__builtin_fmaf(-s, q1, 1.0f), r1, q1);
+}
+// the same rule with the compiler's own division and square root: what lv_selftest_rsqrt compares lv_rsqrt_shade with
+__device__ __forceinline__ float lv_rsqrt_shade_reference(float x) {
+    return 1.0f / sqrtf(fminf(fmaxf(x, LV_RSQRT_LO), LV_RSQRT_HI));
+}
+#ifdef LV_RSQRT_PLAIN   // measurement variant (tools/variants.py): the compiler's division and square root
+__device__ __forceinline__ f3 norm3s(f3 a) { const float r = lv_rsqrt_shade_reference(dot3(a, a)); return mk3(a.x * r, a.y * r, a.z * r); }
+#else
+__device__ __forceinline__ f3 norm3s(f3 a) { const float r = lv_rsqrt_shade(dot3(a, a)); return mk3(a.x * r, a.y * r, a.z * r); }
+#endif
 
 // ---------------------------------------------------------------- wave helpers (wave64)
 __device__ __forceinline__ unsigned lv_lane() { return __lane_id(); }

@@ -10,6 +10,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <vector>
 
 struct LvoAoFeatureSink {
@@ -83,7 +84,13 @@ inline float log2Det(float x) {
     return float(e) + ln * 1.44269504f;
 }
 // normalize(v) of the shading code as v * (1 / length(v)) (norm3s of the HIP library)
-inline V3 normalizeShade(V3 a) { const float r = 1.0f / length(a); return V3{a.x * r, a.y * r, a.z * r}; }
+// -- with the squared length clamped into [2^-60, 2^60] (every length the shading code meets lies inside; a zero vector stays a zero
+// vector; GLSL leaves normalize() of such vectors undefined).  The build owns this rule.
+inline V3 normalizeShade(V3 a) {
+    const float x = fminf(fmaxf(dot(a, a), 0x1p-60f), 0x1p60f);   // (NaN -> 2^-60: fmaxf / fminf return the other operand)
+    const float r = 1.0f / sqrtf(x);
+    return V3{a.x * r, a.y * r, a.z * r};
+}
 
 inline float mixf(float a, float b, float w) { return a * (1.0f - w) + b * w; }
 inline float smoothstepf(float e0, float e1, float x) {
