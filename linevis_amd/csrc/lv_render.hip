@@ -2758,6 +2758,24 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
     }
     if (ctx->opt.timerMask >> 31) LV_HIP(ctx, hipEventRecord(ctx->ev[5], st));
 
+#ifdef LV_PROBE_OVERLAP
+    // tools/variants.py probe (EXPERIMENTS.md 12.4): what overlapping the colour pass' traversal with the RTAO pass could win at most --
+    // the WHOLE colour pass is launched on a second stream before the RTAO pass (it reads the previous frame's AO image: the picture is
+    // wrong, the timing is an upper bound of the gain).  Never in the product build.
+    static hipStream_t st2 = nullptr;
+    static hipEvent_t evA = nullptr, evB = nullptr;
+    if (!st2) {
+        LV_HIP(ctx, hipStreamCreateWithFlags(&st2, hipStreamNonBlocking));
+        LV_HIP(ctx, hipEventCreateWithFlags(&evA, hipEventDisableTiming));
+        LV_HIP(ctx, hipEventCreateWithFlags(&evB, hipEventDisableTiming));
+    }
+    if (mode == LV_RENDERING_MODE_VULKAN_RAY_TRACER) {
+        LV_HIP(ctx, hipEventRecord(evA, st));
+        LV_HIP(ctx, hipStreamWaitEvent(st2, evA, 0));
+        k_render_rt<false, LV_PRIM_CAPSULE, LV_SHADE_PLAIN><<<gridTiles, LV_BLOCK, 0, st2>>>(U, S, T, (uint32_t*)outDevice, dc);
+        LV_HIP(ctx, hipEventRecord(evB, st2));
+    }
+#endif
     // ambientOcclusionBaker->updateIterative(), LineRenderer.cpp:257-264
     ctx->aoNumGroups = 0;
     if (U.useAmbientOcclusion && !U.aoPrebaked)
@@ -2826,7 +2844,11 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
         else if (U.useBands) LV_LAUNCH_RT(ST, LV_PRIM_CAPSULE, LV_SHADE_BANDS);  \
         else LV_LAUNCH_RT(ST, LV_PRIM_CAPSULE, LV_SHADE_PLAIN);                  \
     } while (0)
+#ifdef LV_PROBE_OVERLAP
+        LV_HIP(ctx, hipStreamWaitEvent(st, evB, 0));
+#else
         if (stats) LV_LAUNCH_RT2(true); else LV_LAUNCH_RT2(false);
+#endif
 #undef LV_LAUNCH_RT2
 #undef LV_LAUNCH_RT
         }

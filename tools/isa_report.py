@@ -16,7 +16,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from linevis_amd import build as lv_build  # noqa: E402
 
-HOT = ["k_ao_rays", "k_ao_primary", "k_render_rt", "k_ppll_gather", "k_ppll_resolve", "k_render_rt_mlat", "k_ao_reduce"]
+HOT = ["k_ao_rays", "k_ao_primary", "k_render_rt", "k_ppll_gather", "k_ppll_resolve", "k_render_rt_mlat", "k_ao_reduce",
+       "k_ppll_raster_prism", "k_ppll_shade_prism", "k_ppll_cull_segments", "k_ppll_select_nearest"]
 
 
 def demangle(names):
@@ -116,7 +117,7 @@ def node_step_loop(body):
 
 
 def main():
-    out_path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "isa_r03.txt")
+    out_path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "isa_r05.txt")
     lines = ["# ISA report of the frame kernels (hipcc %s, gfx950); generated by tools/isa_report.py" % " ".join(lv_build.FLAGS), ""]
     with tempfile.TemporaryDirectory() as tmp:
         for src in ("lv_render.hip", "lv_mlat.hip"):
@@ -136,7 +137,8 @@ def main():
             for n in sorted(names, key=lambda x: pretty[x]):
                 p = pretty[n]
                 if not p.startswith(tuple(HOT)) or p.startswith(("k_ao_rays<true", "k_ao_primary<true", "k_render_rt<true",
-                                                                  "k_ppll_gather<true", "k_render_rt_mlat<true")):
+                                                                  "k_ppll_gather<true", "k_render_rt_mlat<true", "k_ppll_raster_prism<true",
+                                                                  "k_ppll_shade_prism<true")):
                     continue
                 body = fns.get(n, [])
                 hist = collections.Counter(mnemonic(t) for _, t in body if t)
