@@ -345,13 +345,19 @@ __global__ __launch_bounds__(LV_WAVE) void k_trace_streamlines_seeded(const LvFl
             dirNow = mk3(dirNow.x / distNow, dirNow.y / distNow, dirNow.z / distNow);
             bool loop = false;
             const uint32_t stored = n < capacity ? n : capacity;
-            f3 before = pt0;
+            // (the scan is O(points) per step -- the reference asks a hashed grid; here the common case of a point is a 12-B load and a
+            // coordinate-wise reject: |p - cur| <= r needs every |component| <= r.  The direction the point was reached in -- three IEEE
+            // divisions and a square root -- is evaluated only for the points inside the sphere, from the point stored before it:
+            // the same values)
             for (uint32_t i = 1; i < stored && !loop; i++) {
                 const float* o = positions + (size_t(i) * numThreads + t) * 3;
                 const f3 p = mk3(o[0], o[1], o[2]);
-                const f3 dir0 = norm3(p - before);
-                before = p;
-                if (!(len3(p - cur) <= terminationDistanceStart)) continue;
+                const f3 dp = p - cur;
+                if (!(fabsf(dp.x) <= terminationDistanceStart && fabsf(dp.y) <= terminationDistanceStart &&
+                      fabsf(dp.z) <= terminationDistanceStart)) continue;
+                if (!(len3(dp) <= terminationDistanceStart)) continue;
+                const float* ob = positions + (size_t(i - 1u) * numThreads + t) * 3;
+                const f3 dir0 = norm3(p - mk3(ob[0], ob[1], ob[2]));
                 const float planeDistance = dot3(dir0, cur) + (-dot3(dir0, p));
                 loop = planeDistance < 0.0f && distNow < terminationDistanceStart && dot3(dir0, dirNow) > 0.0f;
             }
