@@ -311,8 +311,11 @@ def roofline(kernel, pmc_key, ms_launch, algorithmic_bytes, world):
         clock_live = round(cycles / t_ns, 4)
         ceil["valu_issue"]["valu_busy"] = valu_busy
         ceil["valu_issue"]["clock_ghz_live"] = clock_live
-        ceil["valu_issue"]["busy_source"] = ("4 x SQ_ACTIVE_INST_VALU / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs): fraction of the engine cycles in "
-                                             "which a SIMD's VALU was executing; clock = those cycles / the launch time of this run")
+        ceil["valu_issue"]["busy_source"] = ("4 x SQ_ACTIVE_INST_VALU / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs), the definition of VERDICT r04; clock = "
+                                             "those cycles / the launch time of this run.  SQ_ACTIVE_INST_VALU tracks SQ_INSTS_VALU within 1-5 % for "
+                                             "every kernel of the frame (profiles/pmc_*.json): it weighs each wave64 VALU instruction as one 4-cycle "
+                                             "pass, so a mix with shorter passes reads above 1 (capsule k_ao_rays: 1.08) -- 'issue-saturated', not a "
+                                             "utilisation to four digits; GRBM_GUI_ACTIVE comes from another counter pass than the SQ counters")
     fracs = {"hbm": ceil["hbm"]["frac"], "l2": ceil["l2"]["frac"], "vector_l1": ceil["vector_l1"]["frac"],
              "valu_issue": ceil["valu_issue"]["frac_own_mix"]}
     pmc_sha = pmc.get("source_sha")
