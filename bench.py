@@ -571,6 +571,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # LV_BENCH_FORCE_DIST=1 (test knob): run the N > 1 code path -- process group, tile list, gather, de-tiling, per-rank diagnostics, the
+    # N = 1 value of the same run -- with a ONE-rank communicator: everything of a --gpus N run that one GPU can execute
+    dist_on = world > 1 or bool(os.environ.get("LV_BENCH_FORCE_DIST"))
     one_process = args.one_process and not args.dry_run
     if one_process:
         if world != 1:
@@ -587,8 +590,14 @@ def main():
         local_rank = bench_devices(world)[local_rank]
         torch.cuda.set_device(local_rank)
         device = torch.device("cuda", local_rank)
-    if world > 1:
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:   # (only without a launcher, i.e. the forced one-rank group)
+            import socket
+            sk = socket.socket()
+            sk.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+            sk.close()
         if dry:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -607,7 +616,7 @@ def main():
     def sync_all():
         if not dry:
             torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
         if not dry:
             torch.cuda.synchronize()
@@ -685,7 +694,7 @@ def main():
 
         # ONE GPU owns every tile: nothing to gather or de-tile -- the frame is one lv_render_device call straight into the
         # [H, W, 4] image on the context's stream (LV_BENCH_TILED=1 keeps the N > 1 code path: tile list + de-tiling pass)
-        direct = world == 1 and not dry and not os.environ.get("LV_BENCH_TILED")
+        direct = world == 1 and not dist_on and not dry and not os.environ.get("LV_BENCH_TILED")
         mark_stream = None
         if direct:
             image = torch.empty((H, W, 4), dtype=torch.uint8, device=device)
@@ -703,7 +712,7 @@ def main():
         ctx.set_option("collect_stats", False)
         counters = torch.tensor([st.rays_traced, st.nodes_visited, st.prims_tested, st.hits_shaded, st.ao_hit_pixels,
                                  st.fragments], dtype=torch.float64, device=device)
-        if world > 1:
+        if dist_on:
             dist.all_reduce(counters)
         rays_per_frame = float(counters[0].item())
         prim_bytes = 48 if w.get("mesh") else 32   # 48-B triangle record / 32-B segment record
@@ -725,7 +734,7 @@ def main():
                                                 for k in range(3)])
         # ---- re-deal the tiles by the cost this frame measured (RTAO hit pixels per tile x samples + a fixed cost per tile):
         # one small all-reduce outside the timed region; with one GPU the deal is trivial
-        if world > 1:
+        if dist_on:
             if dry:
                 local_cost = [float((int(x0) // TILE * 7 + int(y0) // TILE * 3) % 11) for x0, y0 in sf.local_tiles]
             elif w["kernel"] == "k_ao_rays" and w["settings"].get("ambient_occlusion_denoiser") != "SVGF":
@@ -770,14 +779,14 @@ def main():
         elapsed = time.perf_counter() - t0
         gc.enable()
         tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        if world > 1:
+        if dist_on:
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
         st = ctx.stats()
         # ---- N > 1: three untimed diagnostic frames, one at a time, so that the first SCALE record explains itself: per rank the
         # time to render its tiles, the time it spends in the gather, the tiles it owns, and what torch.distributed reports
         diag = None
-        if world > 1:
+        if dist_on:
             rec = []
             for _ in range(3):
                 sync_all()
@@ -926,7 +935,7 @@ def main():
             gc.collect()
             result["states"] = run_states(min(args.steps, 20), local_rank)
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 

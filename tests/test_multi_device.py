@@ -286,3 +286,21 @@ def test_bench_gpus2_without_torchrun_walks_the_launch_chain(hip_lib):
     assert mg["ranks_observed"] == 2 and len(mg["tiles_per_rank"]) == 2 and sum(mg["tiles_per_rank"]) == 30 * 17
     if j["launch_attempts"]:
         assert j["launch"].startswith("fallback") and "[bench]" in err
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("frames_in_flight", ["1", "2"])
+def test_bench_distributed_code_path_on_a_one_rank_group(hip_lib, frames_in_flight):
+    """Everything of a `--gpus N` run that one GPU can execute, through bench.py itself (LV_BENCH_FORCE_DIST=1): torch.distributed's nccl
+    (= RCCL) process group with one rank, the tile list + cost re-deal, frames in flight, de-tiling, the per-rank diagnostics and the
+    N = 1 value of the same run -- whose whole-frame image must be identical to the frame assembled from the tiles."""
+    j, _ = _bench(["--gpus", "1", "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--workload", "c3c"],
+                  {"LV_BENCH_FORCE_DIST": "1", "LV_FRAMES_IN_FLIGHT": frames_in_flight})
+    assert j["n_gpus"] == 1 and j["steps"] == 4 and j["frames_in_flight"] == int(frames_in_flight)
+    mg = j["multi_gpu"]
+    assert mg["ranks_observed"] == 1 and mg["backend"] == "nccl" and mg["tiles_per_rank"] == [30 * 17]
+    assert len(mg["render_ms_per_rank"]) == 1 and mg["render_ms_per_rank"][0] > 0.5
+    one = mg["single_gpu_same_run"]
+    assert one["frame_identical_to_sharded"] is True
+    assert one["ms_per_step"] > 1.0 and 0.5 < one["speedup"] < 1.5 and one["value"] > 1000.0
+    assert j["config"]["rays_per_frame"] > 20_000_000
