@@ -426,6 +426,18 @@ def main_one_process(args):
               "multi_gpu": multi,
               "roofline": {"bound": None, "note": "per-kernel ceilings are reported by the default (one process per GPU) mode"},
               "cpu_baseline": None}
+    emit_line(result)
+
+
+def emit_line(result):
+    """The ONE JSON line, as the last thing on stdout: native libraries of this process (RCCL prints a version banner through C stdio,
+    which is block-buffered when stdout is a pipe) are flushed first, so that their text cannot land behind the line at exit."""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:   # noqa: BLE001
+        pass
+    sys.stdout.flush()
     print(json.dumps(result), flush=True)
 
 
@@ -934,7 +946,7 @@ def main():
             del head, also
             gc.collect()
             result["states"] = run_states(min(args.steps, 20), local_rank)
-        print(json.dumps(result), flush=True)
+        emit_line(result)
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()

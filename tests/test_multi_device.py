@@ -256,6 +256,7 @@ def _bench(args, env_extra=None, timeout=900):
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, "exactly ONE JSON line on stdout:\n" + r.stdout[-2000:]
+    assert r.stdout.strip().splitlines()[-1] == lines[0], "the JSON line must be the LAST line of stdout:\n" + r.stdout[-1500:]
     return json.loads(lines[0]), r.stderr
 
 
