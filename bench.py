@@ -870,8 +870,22 @@ def main():
                     ks = _stats(ctx.kernel_times(k))
                     if ks and name not in kernels:
                         kernels[name] = dict(ks, source="instrumented pass after the timed region")
+        # the boundary's host-buffer form (lv_render: the same frame + one D2H copy of the RGBA8 image, synchronous): never `value`
+        host = None
+        if direct:
+            buf = np.empty((H, W, 4), dtype=np.uint8)
+            for _ in range(2):
+                ctx.render(mode=w["mode"], out=buf)
+            nh = max(3, min(args.steps, 20))
+            th = time.perf_counter()
+            for _ in range(nh):
+                ctx.render(mode=w["mode"], out=buf)
+            hms = (time.perf_counter() - th) / nh * 1e3
+            host = {"ms_per_step": round(hms, 4), "value": round(rays_per_frame / hms / 1e3, 2), "unit": "Mrays/s", "steps": nh,
+                    "note": "lv_render into a pageable host buffer: frame + %.1f MB device-to-host copy per frame, host-synchronous "
+                            "(no frames in flight); the scene upload happens once per data set, not per frame" % (W * H * 4 / 1e6)}
         del extra
-        return dict(ctx=ctx, frame=frame, elapsed=elapsed, rays_per_frame=rays_per_frame, counters=counters, local=local,
+        return dict(ctx=ctx, frame=frame, host=host, elapsed=elapsed, rays_per_frame=rays_per_frame, counters=counters, local=local,
                     kernel_bytes=kernel_bytes, frame_bytes=frame_bytes, kernels=kernels, frame_ms=_stats(frame_ms),
                     build_ms=build_ms, build_first_ms=build_first_ms, st=st, wkey=wkey, diag=diag)
 
@@ -912,6 +926,8 @@ def main():
         }
         if head.get("diag"):
             result["multi_gpu"] = head["diag"]
+        if head.get("host"):
+            result["pcie_inclusive"] = head["host"]
         result["roofline"]["frame_algorithmic_bytes_rank0"] = int(head["frame_bytes"])
         if seg is not None:   # compulsory floor: every node, primitive record and line point once + the outputs
             result["roofline"]["frame_compulsory_bytes"] = int(st.num_nodes * 64 + len(seg) * 32 + len(pts) * 48 + W * H * (4 + 4)

@@ -315,9 +315,11 @@ class Context:
     def build_accel(self):
         self._ck(self.L.lv_build_accel(self.h))
 
-    def render(self, mode=MODE_RAY_TRACER, tile=None):
+    def render(self, mode=MODE_RAY_TRACER, tile=None, out=None):
         x0, y0, w, h = tile if tile is not None else (0, 0, self.width, self.height)
-        out = np.empty((h, w, 4), dtype=np.uint8)
+        if out is None:
+            out = np.empty((h, w, 4), dtype=np.uint8)
+        assert out.shape == (h, w, 4) and out.dtype == np.uint8 and out.flags["C_CONTIGUOUS"]
         self._ck(self.L.lv_render(self.h, mode, x0, y0, w, h, _p(out)))
         return out
 

@@ -133,6 +133,12 @@ def test_random_ppll_cases(hip_lib, seed):
         if max((len(v) for v in hl.values()), default=0) <= int(c.settings["ppll_max_num_frags"]):
             ref = lvo.ppll_resolve(P, hn, hs)
             assert max_lsb_diff(img, ref) <= LSB_TOL, tag
+        # a random tile rectangle (a rank's share of a sharded frame: requested-pixel marks, the segment cull pass, the list-driven
+        # rasteriser) reproduces its part of the whole frame byte for byte -- unless AO is on: a tile's RTAO pass sees the same pixels
+        # (global seeds), so that too
+        tw, th = int(rng.integers(1, c.width + 1)), int(rng.integers(1, c.height + 1))
+        tx, ty = int(rng.integers(0, c.width - tw + 1)), int(rng.integers(0, c.height - th + 1))
+        assert np.array_equal(ctx.render(2, tile=(tx, ty, tw, th)), img[ty:ty + th, tx:tx + tw]), tag + " tile %s" % ((tx, ty, tw, th),)
         ctx.close()
 
 
