@@ -51,6 +51,11 @@ C3T = (C3 + ", AO rays against the reference's 6-gon triangle tubes (12.06 M tri
       "with the reference's literal ray-capsule roots (intersection_form=literal, RayIntersectionTestsVulkan.glsl:39-119)")
 C3C = (C3 + ", AO rays against the analytic capsules of the segment LBVH (rtao_geometry=capsules), closest-approach ray-capsule "
       "roots in both passes (intersection_form=closest_approach: NOT the reference's formula, DESIGN.md section 4)")
+C5 = ("C5: 5M-segment Rayleigh-Benard-like convection rolls (5000 lines x 1001 points, seed 12345), 3840x2160, colour pass 1 spp + RTAO "
+      "256 spp (1 iteration x 256 samples, radius 0.1, distance based), line width 0.002; BASELINE.json config 5 (meant for 8 GPUs; with "
+      "fewer the same frame takes proportionally longer)")
+C5T = (C5 + ", AO rays against the reference's 6-gon triangle tubes (60.3 M triangles, rtao_geometry=triangle_tubes), colour pass with the "
+       "reference's literal ray-capsule roots (intersection_form=literal)")
 WORKLOADS = {
     # the default: c3t timed as the headline, c3c timed right after it and reported beside it
     "c3": dict(name=C3T + "; the same frame with rtao_geometry=capsules is reported as value_capsules", scene="tornado", mode=11,
@@ -60,11 +65,18 @@ WORKLOADS = {
                 settings=dict(SETTINGS, rtao_geometry="triangle_tubes", intersection_form="literal"), kernel="k_ao_rays", mesh=True),
     "c3c": dict(name=C3C, scene="tornado", mode=11, settings=dict(SETTINGS, rtao_geometry="capsules", intersection_form="closest_approach"),
                 kernel="k_ao_rays"),
-    "c5": dict(name="C5: 5M-segment Rayleigh-Benard-like convection rolls (5000 lines x 1001 points, seed 12345), 3840x2160, "
-                    "colour pass 1 spp + RTAO 256 spp (1 iteration x 256 samples, radius 0.1, distance based, capsules), line "
-                    "width 0.002; BASELINE.json config 5 (meant for 8 GPUs; with fewer the same frame takes proportionally longer)",
-               scene="rayleigh_benard", mode=11, settings=dict(SETTINGS, rtao_geometry="capsules", ambient_occlusion_samples_per_frame=256),
-               kernel="k_ao_rays", resolution=(3840, 2160), ao_spp=256),
+    # BASELINE.json config 5 on the geometry the reference's RTAO pass traces (VulkanRayTracedAmbientOcclusion.cpp:439-461: always the
+    # triangle-tube TLAS) -- like c3's headline; c5c = the same frame on the analytic capsules (what "c5" meant until round 5)
+    "c5": dict(name=C5T, scene="rayleigh_benard", mode=11,
+               settings=dict(SETTINGS, rtao_geometry="triangle_tubes", intersection_form="literal", ambient_occlusion_samples_per_frame=256),
+               kernel="k_ao_rays", resolution=(3840, 2160), ao_spp=256, mesh=True, pmc="c5t", cpu="c3t"),
+    "c5t": dict(name=C5T, scene="rayleigh_benard", mode=11,
+                settings=dict(SETTINGS, rtao_geometry="triangle_tubes", intersection_form="literal", ambient_occlusion_samples_per_frame=256),
+                kernel="k_ao_rays", resolution=(3840, 2160), ao_spp=256, mesh=True, cpu="c3t"),
+    "c5c": dict(name=C5 + ", AO rays against the analytic capsules of the segment LBVH (rtao_geometry=capsules, closest-approach roots: NOT a "
+                     "frame the reference can render, DESIGN.md section 4)",
+                scene="rayleigh_benard", mode=11, settings=dict(SETTINGS, rtao_geometry="capsules", ambient_occlusion_samples_per_frame=256),
+                kernel="k_ao_rays", resolution=(3840, 2160), ao_spp=256, cpu="c3c"),
     "c2": dict(name="C2: 100k-segment helix bundle (100 lines x 1001 points, seed 12345), 1920x1080, primary rays only "
                     "(1 spp, pixel centres, AO off, depth cues off), line width 0.002, the reference's literal ray-capsule roots (the default)",
                scene="helix", mode=11, settings={"num_samples_per_frame": 1, "depth_cue_strength": 0.0}, kernel="k_render_rt"),
@@ -122,7 +134,7 @@ def cpu_baseline(W, H, pts, seg, tf, attr_range, view, proj, fovy, near, far, ta
     cores = host_cores()
     lvo.set_num_threads(cores)
     sc = lvo.Scene(pts, seg, tf)
-    rtao = workload in ("c3c", "c3t", "c5")
+    rtao = workload in ("c3c", "c3t")
     P = lvo.make_params(view, proj, W, H, fovY=fovy, nearDist=near, farDist=far, lineWidth=LINE_WIDTH,
                         useAmbientOcclusion=int(rtao), aoStrength=1.0, aoGamma=1.0, aoSamplesPerFrame=ao_spp,
                         aoIterations=1, aoUseDistance=1, aoJitterPrimary=1, aoRadius=0.1, attrMin=attr_range[0],
@@ -148,7 +160,7 @@ def cpu_baseline(W, H, pts, seg, tf, attr_range, view, proj, fovy, near, far, ta
             sc.render_rt_mlat(P, 8, tile=tile, use_bvh=True, stats=st)
         else:
             ao = None
-            if workload in ("c3c", "c5"):
+            if workload == "c3c":
                 ao = sc.render_ao(P, tile=tile, use_bvh=True, stats=st)
             elif workload == "c3t":
                 ao = tsc.render_ao(P, tile=tile, use_bvh=True, stats=st)
@@ -158,7 +170,7 @@ def cpu_baseline(W, H, pts, seg, tf, attr_range, view, proj, fovy, near, far, ta
     t_all = time.time()
     # the CPU restatement evaluates the capsule roots the timed GPU frame does: the reference's literal ones (intersection_form
     # "auto") except where the frame's RTAO rays hit the analytic capsules (c3c asks for closest_approach, c5 gets it from "auto")
-    lvo.set_default_intersection_form(workload not in ("c3c", "c5"))
+    lvo.set_default_intersection_form(workload != "c3c")
     cw, ch = 96, 54                             # calibration crop, then grow towards ~target_seconds of work
     dt, rays = run(cw, ch)
     for _ in range(3):
@@ -344,8 +356,8 @@ class DryRunContext:
         ao_phase_iterations = [1, 1, 1]
         ms_kernel_avg = [0.0] * 8
         kernel_launches = [0] * 8
-        num_nodes = bvh_depth = num_tube_triangles = 0
-        ms_accel_build = 0.0
+        num_nodes = bvh_depth = num_tube_triangles = num_tri_nodes = 0
+        ms_accel_build = ms_tri_accel_build = ms_tessellate = ms_line_points = 0.0
 
     def set_option(self, *a):
         pass
@@ -635,6 +647,7 @@ def main():
 
     # ---- synthetic input (every rank builds the same replica; deterministic)
     pts = seg = tf = attr_range = mesh = flow = None
+    prep = {}   # data set -> first frame: what a new data set / a line-width change costs outside the frame loop (never part of `value`)
     view, proj, fovy, near, far = camera.default_camera(W, H)
     if not dry:
         from linevis_amd import capi, host_api, scenes
@@ -646,22 +659,32 @@ def main():
             pts, seg, _ = flow.tube_aabb_render_data_elliptic(float(wl["settings"]["band_width"]))
         else:
             flow = host_api.LineDataFlow().set_trajectories(tr.positions, tr.attributes, tr.line_offsets)
+            t_prep = time.perf_counter()
             pts, seg, _ = flow.tube_aabb_render_data(LINE_WIDTH)
+            prep["line_points_host_ms"] = round((time.perf_counter() - t_prep) * 1e3, 1)
         tf = tfm.standard_transparent() if wl.get("transparent") else tfm.standard()
         attr_range = flow.attribute_range()
         if wl.get("mesh"):   # LineData::getLinePassTubeTriangleMeshRenderData -> the RTAO pass' geometry
+            t_prep = time.perf_counter()
             mesh = flow.tube_triangle_render_data(LINE_WIDTH, int(wl["settings"].get("tube_num_subdivisions", 6)))
+            prep["tessellation_host_ms"] = round((time.perf_counter() - t_prep) * 1e3, 1)
 
     def make_context(w, wait_for_consumer=True):
         if dry:
             return DryRunContext(), None
         ctx = capi.Context(local_rank)
+        t_up = time.perf_counter()
         ctx.set_lines(pts, seg)
+        up = {"lines_upload_ms": round((time.perf_counter() - t_up) * 1e3, 2), "lines_upload_MB": round((pts.nbytes + seg.nbytes) / 1e6, 1)}
         ctx.set_transfer_function(tf, *attr_range)
         ctx.set_camera(view, proj, fovy, near, far, W, H)
         ctx.set_option("line_width", LINE_WIDTH)
         if w.get("mesh"):
+            t_up = time.perf_counter()
             ctx.set_tube_triangle_mesh(*mesh)
+            up["mesh_upload_ms"] = round((time.perf_counter() - t_up) * 1e3, 2)   # pageable host arrays -> HBM, incl. the index validation pass
+            up["mesh_upload_MB"] = round(sum(m.nbytes for m in mesh) / 1e6, 1)
+        prep.setdefault("upload", up)
         ctx.set_options(w["settings"])
         fn = tiling.hip_render_tiles_fn(ctx, w["mode"], wait_for_consumer=wait_for_consumer)   # a torch stream per context
         ctx.build_accel()
@@ -918,6 +941,8 @@ def main():
                                        "tile of the instrumented frame; round robin for workloads without RTAO), one RCCL gather per "
                                        "frame" % (TILE, TILE, world)),
                        "accel_build_ms": round(head["build_ms"], 3), "accel_build_first_ms": round(head["build_first_ms"], 3),
+                       "tri_accel_build_ms": round(float(st.ms_tri_accel_build), 3), "tri_accel_nodes": int(st.num_tri_nodes),
+                       "data_preparation": prep,
                        "bvh_depth": int(st.bvh_depth), "tube_triangles": int(st.num_tube_triangles)},
             "frame_ms": head["frame_ms"],
             "kernels_ms": head["kernels"],
@@ -952,7 +977,7 @@ def main():
             from PIL import Image
             Image.fromarray(head["frame"].cpu().numpy()).save(args.save_frame)
         if world == 1 and not args.no_cpu_baseline and not dry:
-            cpu_wl = {"c3": "c3t"}.get(args.workload, args.workload)
+            cpu_wl = wl.get("cpu", {"c3": "c3t"}.get(args.workload, args.workload))   # the oracle leg this workload's frame corresponds to
             result["cpu_baseline"] = cpu_baseline(W, H, pts, seg, tf, attr_range, view, proj, fovy, near, far,
                                                   workload=cpu_wl, mesh=mesh, ao_spp=wl.get("ao_spp", 64),
                                                   capped=str(wl["settings"].get("use_capped_tubes", True)).lower() not in ("false", "0"))

@@ -99,6 +99,13 @@ typedef struct lv_stats {
     uint64_t ao_prim_hits;
     uint64_t ao_prim_may_axis;
     uint64_t ao_prim_may_both;
+    /* data set -> first frame on the device (round 6): the triangle LBVH over the tube mesh (its own event pair: ms_accel_build is the
+     * segment LBVH only), the device tessellation of lv_set_trajectories' lines (k_tess_*: a14) and the device form of
+     * getLinePassTubeAabbRenderData (k_linepoints_*: a2); 0 until the step has run on this context */
+    float ms_tri_accel_build;
+    float ms_tessellate;
+    float ms_line_points;
+    uint32_t num_tri_nodes;        /* 64-byte nodes of the triangle LBVH */
 } lv_stats;
 
 #define LV_KERNEL_AO_PRIMARY 0

@@ -40,7 +40,9 @@ class Stats(C.Structure):
                 ("ao_phase_iterations", C.c_uint64 * 3), ("ao_phase_lanes", C.c_uint64 * 3),
                 ("max_nodes_per_pixel", C.c_uint32), ("num_tube_triangles", C.c_uint32),
                 ("ppll_pool_nodes", C.c_uint64), ("ao_prim_hits", C.c_uint64), ("ao_prim_may_axis", C.c_uint64),
-                ("ao_prim_may_both", C.c_uint64)]
+                ("ao_prim_may_both", C.c_uint64),
+                ("ms_tri_accel_build", C.c_float), ("ms_tessellate", C.c_float), ("ms_line_points", C.c_float),
+                ("num_tri_nodes", C.c_uint32)]
 
     def as_dict(self):
         d = {}

@@ -215,6 +215,7 @@ int lv_set_stream(lv_ctx* ctx, void* hip_stream) {
     LV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->ownStream;
     ctx->evBuildValid = false;
+    ctx->evTriBuildValid = false;
     ctx->evFrameValid = false;
     for (int k = 0; k < lv_ctx::kNumKernels; k++) ctx->kernelLaunches[k] = 0;
     return LV_OK;
@@ -772,6 +773,8 @@ int lv_build_accel(lv_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     int rc = lv_bvh_build(ctx);
     if (rc) return rc;
+    // LineData::getRayTracingTubeTriangleTopLevelAS (LineData.cpp:986-1013): the triangle LBVH of the tube mesh, if there is one
+    if (ctx->triMeshSet && (rc = lv_bvh_build_triangles(ctx))) return rc;
     return lv_forward_to_ranks(ctx, [&](lv_ctx* p) { return lv_build_accel(p); });
 }
 
@@ -855,6 +858,8 @@ static int lv_get_stats_impl(lv_ctx* ctx, lv_stats* out, bool aggregate) {
         return t;
     };
     if (ctx->evBuildValid) s.ms_accel_build = ms(0, 1);
+    if (ctx->evTriBuildValid) s.ms_tri_accel_build = ms(14, 15);
+    s.num_tri_nodes = ctx->numTriNodes;
     if (ctx->evFrameValid) {
         // phase marks on the stream: 2 start, 5 depth range done, 7 RTAO done, 11 PPLL lists cleared, 13 gathered, 3 end
         s.ms_total = s.ms_depth_range = s.ms_ao = 0.0f;

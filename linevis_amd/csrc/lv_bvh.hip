@@ -1155,7 +1155,8 @@ inline uint32_t nblocks(uint64_t n) { return uint32_t((n + LV_BLOCK - 1) / LV_BL
 // same for capsules and triangles.
 template <class BOXES, class LEAVES>
 static int lv_bvh_build_core(lv_ctx* ctx, uint32_t n, LvDeviceBuffer& nodesOut, uint32_t& numNodesOut, uint32_t& depthOut,
-                             uint32_t& wideDepthOut, bool timed, BOXES&& boxes, LEAVES&& leaves) {
+                             uint32_t& wideDepthOut, int evBase /* ctx->ev[evBase], [evBase + 1] bracket the build; -1: untimed */, BOXES&& boxes, LEAVES&& leaves) {
+    const bool timed = evBase >= 0;
     hipStream_t st = ctx->stream;
     const uint32_t nInternal = n > 1 ? n - 1 : 1;
     uint32_t numWide = 1, wideLevels = 0;
@@ -1207,7 +1208,7 @@ static int lv_bvh_build_core(lv_ctx* ctx, uint32_t n, LvDeviceBuffer& nodesOut, 
         for (const Req& r : reqs) { r.t->ptr = (char*)ctx->buildArena.ptr + off; off += (r.bytes + 255) & ~size_t(255); }
     }
 
-    if (timed) LV_HIPF(hipEventRecord(ctx->ev[0], st));
+    if (timed) LV_HIPF(hipEventRecord(ctx->ev[evBase], st));
     // bounds: min slots start at ord(+big) = 0xFFFFFFFF-ish, max slots at 0
     {
         uint32_t* init = ctx->pinned + 8; // words 8..13 of the pinned block (stays valid while the copy is in flight)
@@ -1311,7 +1312,7 @@ static int lv_bvh_build_core(lv_ctx* ctx, uint32_t n, LvDeviceBuffer& nodesOut, 
         }
     }
     LV_HIPF(hipGetLastError());
-    if (timed) LV_HIPF(hipEventRecord(ctx->ev[1], st));
+    if (timed) LV_HIPF(hipEventRecord(ctx->ev[evBase + 1], st));
     depthOut = 1;
     wideDepthOut = wideLevels ? wideLevels : 1u;
     if (n > 1) {
@@ -1350,7 +1351,7 @@ int lv_bvh_build(lv_ctx* ctx) {
     const lv_line_point* points = (const lv_line_point*)ctx->points.ptr;
     const uint32_t* segIdx = (const uint32_t*)ctx->segIdx.ptr;
     rc = lv_bvh_build_core(
-            ctx, n, ctx->nodes, ctx->numNodes, ctx->bvhDepth, ctx->wideDepth, true,
+            ctx, n, ctx->nodes, ctx->numNodes, ctx->bvhDepth, ctx->wideDepth, 0,
             [&](float* boxOrig, uint32_t* bounds) {
                 k_seg_boxes<<<std::min(nblocks(n), 2048u), LV_BLOCK, 0, st>>>(points, segIdx, n, radius, pad, boxOrig, bounds);
             },
@@ -1389,7 +1390,7 @@ int lv_bvh_build_triangles(lv_ctx* ctx) {
     const uint32_t* triIdx = (const uint32_t*)ctx->triIdx.ptr;
     const float pad = ctx->triPad;
     rc = lv_bvh_build_core(
-            ctx, nLeaves, ctx->triNodes, ctx->numTriNodes, ctx->triBvhDepth, ctx->triWideDepth, false,
+            ctx, nLeaves, ctx->triNodes, ctx->numTriNodes, ctx->triBvhDepth, ctx->triWideDepth, 14,
             [&](float* boxOrig, uint32_t* bounds) {
                 k_tri_boxes<<<std::min(nblocks(nLeaves), 2048u), LV_BLOCK, 0, st>>>(verts, triIdx, n, group, nLeaves, pad, boxOrig, bounds);
             },
@@ -1400,5 +1401,6 @@ int lv_bvh_build_triangles(lv_ctx* ctx) {
     if (rc) return rc;
     ctx->triAccelValid = true;
     ctx->triAccelLineWidth = ctx->opt.lineWidth;
+    ctx->evTriBuildValid = true;
     return LV_OK;
 }

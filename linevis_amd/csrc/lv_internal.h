@@ -231,6 +231,7 @@ struct lv_ctx {
     hipEvent_t ev[16];
     bool evCreated = false;
     bool evBuildValid = false, evFrameValid = false, evPhaseRecorded = false;
+    bool evTriBuildValid = false;             // ev[14], ev[15] bracket the last triangle-LBVH build
     int lastMode = 0;
     // per-kernel launch timers: ring of event pairs per kernel id (LV_KERNEL_*)
     static constexpr int kNumKernels = 8;

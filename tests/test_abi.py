@@ -35,8 +35,23 @@ def test_header_cites_reference_interfaces():
         assert needle in text
 
 
-def test_struct_layouts_match_the_header():
-    assert ctypes.sizeof(capi.Stats) == 6 * 8 + 4 * 4 + 8 * 4 + 8 + 8 * 4 + 8 * 4 + 3 * 8 + 6 * 8 + 8 + 4 * 8
+def test_struct_layouts_match_the_header(tmp_path):
+    """sizeof / offsetof of every field of lv_stats as a C99 compiler lays out include/linevis_hip.h = the ctypes mirror."""
+    import subprocess
+    fields = [n for n, _ in capi.Stats._fields_]
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "linevis_hip.h"\nint main(void) {\n'
+                   '  printf("%zu\\n", sizeof(lv_stats));\n'
+                   + "".join('  printf("%%zu\\n", offsetof(lv_stats, %s));\n' % n for n in fields)
+                   + '  printf("%zu %zu %zu\\n", sizeof(lv_line_point), sizeof(lv_tube_vertex), sizeof(lv_streamline_settings));\n'
+                   '  return 0;\n}\n')
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.dirname(capi.HEADER_PATH), str(src), "-o", str(exe)])
+    out = subprocess.check_output([str(exe)], text=True).split()
+    assert int(out[0]) == ctypes.sizeof(capi.Stats)
+    for n, off in zip(fields, out[1:1 + len(fields)]):
+        assert int(off) == getattr(capi.Stats, n).offset, n
+    assert [int(x) for x in out[1 + len(fields):]] == [48, 32, ctypes.sizeof(capi.StreamlineSettings)]
     assert capi.LINE_POINT_DTYPE.itemsize == 48
     assert capi.LINE_POINT_DTYPE.fields["lineNormal"][1] == 32
     assert capi.LINE_POINT_DTYPE.fields["lineStartIndex"][1] == 44

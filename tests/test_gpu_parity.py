@@ -861,7 +861,8 @@ def test_config4_full_size_ppll_and_mlat(hip_lib):
 
 # ---------------------------------------------------------------- BASELINE.json config 5 at full scene size
 def test_config5_scale_tiles(hip_lib):
-    """5 M segments, 3840 x 2160, RTAO 256 spp: the tile list a rank of the 8-GPU run would own is rendered here for
+    """(c5c: config 5 on the analytic capsules -- not a frame the reference renders; the reference-faithful form is c5t below.)
+    5 M segments, 3840 x 2160, RTAO 256 spp: the tile list a rank of the 8-GPU run would own is rendered here for
     two tiles and compared with the oracle (bit-exact AO, frame within 2 LSB); hits of the 5 M-leaf LBVH against the
     oracle's BVH."""
     tr = scenes.normalize(scenes.rayleigh_benard())
@@ -950,6 +951,77 @@ def test_config5_all_eight_tile_lists_reproduce_the_whole_frame(hip_lib):
              ambient_occlusion_samples_per_frame=256)
     whole = _all_tile_lists_reproduce_the_whole_frame(c, 11, 8, 256.0)
     assert (whole[..., :3] != 255).any(axis=2).sum() > 1000000
+
+
+_C5T = {}
+
+
+def _config5_reference_geometry():
+    """BASELINE.json config 5 as the reference renders it: the RTAO pass always traces the triangle-tube TLAS
+    (VulkanRayTracedAmbientOcclusion.cpp:439-461), so 5 M segments = 60.3 M triangles (CappedTriangleTubesCPU.cpp:214-383) + the colour
+    pass on the capsules with the literal roots.  Built once per session (the two tests below share it)."""
+    if not _C5T:
+        tr = scenes.normalize(scenes.rayleigh_benard())
+        flow = host_api.LineDataFlow().set_trajectories(tr.positions, tr.attributes, tr.line_offsets)
+        pts, seg, _ = flow.tube_aabb_render_data(0.002)
+        mesh = flow.tube_triangle_render_data(0.002, 6)
+        assert len(seg) == 5000000 and len(mesh[0]) == 60300000
+        _C5T["case"] = Case(pts, seg, tfm.standard(), 3840, 2160, 0.002, **RTAO, ambient_occlusion_iterations=1,
+                            ambient_occlusion_samples_per_frame=256, rtao_geometry="triangle_tubes")
+        _C5T["mesh"] = mesh
+    return _C5T["case"], _C5T["mesh"]
+
+
+def test_config5_tiles_with_the_reference_rtao_geometry(hip_lib):
+    """c5t: two tiles of rank 3 of 8 against the oracle's triangle scene (its own BVH over the 60.3 M triangles): AO factors bit for
+    bit, the frame within 2 LSB; closest hits of random rays against the 30 M-leaf triangle LBVH bit for bit."""
+    from oracle import lvo
+    import torch
+    c, mesh = _config5_reference_geometry()
+    assert c.literal_form()                       # intersection_form = auto resolves to the reference's literal roots here
+    ctx = c.hip_context()
+    ctx.set_tube_triangle_mesh(*mesh)
+    all_tiles = tiling.make_tiles(c.width, c.height, 64)
+    mine = tiling.assign_tiles(all_tiles, 3, 8)
+    centre = np.argsort(np.abs(mine[:, 0].astype(np.int64) - c.width // 2) + np.abs(mine[:, 1].astype(np.int64) - c.height // 2))[:2]
+    tiles = mine[centre]
+    out = torch.zeros((len(tiles), 64, 64, 4), dtype=torch.uint8, device="cuda:0")
+    ctx.render_tiles_device(out.data_ptr(), tiles, 64, 64, mode=11)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    ao = ctx.get_ao()
+    st = ctx.stats()
+    assert st.num_tube_triangles == 60300000 and st.num_tri_nodes > 5000000 and st.ms_tri_accel_build > 0.0
+    sc = c.oracle_scene()
+    P = c.oracle_params(sc)
+    ts = lvo.TriScene(*mesh, 0.002)
+    hit_pixels = 0
+    for i, (x0, y0) in enumerate(tiles):
+        tile = (int(x0), int(y0), 64, 64)
+        ao_ref = ts.render_ao(P, tile=tile, use_bvh=True)
+        sl = (slice(int(y0), int(y0) + 64), slice(int(x0), int(x0) + 64))
+        assert np.array_equal(bits(ao[sl]), bits(ao_ref[sl]))
+        hit_pixels += int((ao_ref[sl] < 1.0).sum())
+        ref = sc.render_rt(P, ao=ao_ref, tile=tile, use_bvh=True)
+        assert max_lsb_diff(got[i], ref) <= LSB_TOL
+    assert hit_pixels > 500
+    rng = np.random.default_rng(9)
+    o = rng.uniform(-0.25, 0.25, (20000, 3)).astype(np.float32)
+    d = rng.normal(size=(20000, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    a = ctx.trace_rays_triangles(o, d, 0.0, 0.1)
+    b = ts.trace_rays(o, d, 0.0, 0.1, use_bvh=True)
+    assert np.array_equal(a[1], b[1]) and np.array_equal(bits(a[0]), bits(b[0])) and np.array_equal(bits(a[2]), bits(b[2]))
+    assert (a[1] != 0xFFFFFFFF).sum() > 2000 and int(a[1][a[1] != 0xFFFFFFFF].max()) > 50000000   # hits beyond triangle 2^25
+
+
+def test_config5_all_eight_tile_lists_with_the_reference_rtao_geometry(hip_lib):
+    """c5t sharded for 8 ranks (cost-weighted deal as bench.py applies it): the eight tile lists de-tiled = the whole frame, byte for
+    byte, on the 60.3 M-triangle scene."""
+    c, mesh = _config5_reference_geometry()
+    whole = _all_tile_lists_reproduce_the_whole_frame(c, 11, 8, 256.0, mesh=mesh)
+    assert (whole[..., :3] != 255).any(axis=2).sum() > 1000000
+    _C5T.clear()
 
 
 @pytest.mark.parametrize("world", [2, 4, 8])
