@@ -669,25 +669,39 @@ def main():
             mesh = flow.tube_triangle_render_data(LINE_WIDTH, int(wl["settings"].get("tube_num_subdivisions", 6)))
             prep["tessellation_host_ms"] = round((time.perf_counter() - t_prep) * 1e3, 1)
 
-    def make_context(w, wait_for_consumer=True):
+    # the geometry path of the timed contexts: lv_set_trajectories (round 6: the trajectories go to HBM, kernels write the line points,
+    # the index pairs and the triangle tubes) for plain flow lines; LV_BENCH_HOST_GEOMETRY=1 / band data: the host-built arrays
+    device_geometry = not wl.get("ribbons") and not os.environ.get("LV_BENCH_HOST_GEOMETRY")
+    traj_attr = None if dry else np.ascontiguousarray(tr.attributes[0] if np.ndim(tr.attributes) == 2 else tr.attributes, dtype=np.float32)
+
+    def make_context(w, wait_for_consumer=True, host_geometry=False):
         if dry:
             return DryRunContext(), None
         ctx = capi.Context(local_rank)
+        ctx.set_option("line_width", LINE_WIDTH)
         t_up = time.perf_counter()
-        ctx.set_lines(pts, seg)
-        up = {"lines_upload_ms": round((time.perf_counter() - t_up) * 1e3, 2), "lines_upload_MB": round((pts.nbytes + seg.nbytes) / 1e6, 1)}
+        if device_geometry and not host_geometry:
+            ctx.set_trajectories(tr.positions, traj_attr, tr.line_offsets)   # upload + the a2 kernels, host-synchronous
+            up = {"path": "lv_set_trajectories", "set_trajectories_ms": round((time.perf_counter() - t_up) * 1e3, 2),
+                  "line_points_kernels_ms": round(float(ctx.stats().ms_line_points), 3),   # the a2 kernels inside that call
+                  "trajectories_MB": round((tr.positions.nbytes + traj_attr.nbytes + tr.line_offsets.nbytes) / 1e6, 1)}
+        else:
+            ctx.set_lines(pts, seg)
+            up = {"path": "lv_set_lines + lv_set_tube_triangle_mesh (host-built arrays)",
+                  "lines_upload_ms": round((time.perf_counter() - t_up) * 1e3, 2), "lines_upload_MB": round((pts.nbytes + seg.nbytes) / 1e6, 1)}
+            if w.get("mesh"):
+                t_up = time.perf_counter()
+                ctx.set_tube_triangle_mesh(*mesh)
+                up["mesh_upload_ms"] = round((time.perf_counter() - t_up) * 1e3, 2)   # pageable host arrays -> HBM, incl. the index validation pass
+                up["mesh_upload_MB"] = round(sum(m.nbytes for m in mesh) / 1e6, 1)
         ctx.set_transfer_function(tf, *attr_range)
         ctx.set_camera(view, proj, fovy, near, far, W, H)
-        ctx.set_option("line_width", LINE_WIDTH)
-        if w.get("mesh"):
-            t_up = time.perf_counter()
-            ctx.set_tube_triangle_mesh(*mesh)
-            up["mesh_upload_ms"] = round((time.perf_counter() - t_up) * 1e3, 2)   # pageable host arrays -> HBM, incl. the index validation pass
-            up["mesh_upload_MB"] = round(sum(m.nbytes for m in mesh) / 1e6, 1)
-        prep.setdefault("upload", up)
         ctx.set_options(w["settings"])
         fn = tiling.hip_render_tiles_fn(ctx, w["mode"], wait_for_consumer=wait_for_consumer)   # a torch stream per context
+        t_up = time.perf_counter()
         ctx.build_accel()
+        up["first_build_accel_wall_ms"] = round((time.perf_counter() - t_up) * 1e3, 2)   # (tessellation +) both LBVHs, first launch of their kernels
+        prep.setdefault("host_arrays_upload" if host_geometry or not device_geometry else "device", up)
         return ctx, fn
 
     sf = tiling.ShardedFrame(W, H, TILE, rank, world, device)
@@ -716,6 +730,21 @@ def main():
         if not dry:
             ctx.build_accel()                         # what a line-width change / new data costs from then on
         build_ms = ctx.stats().ms_accel_build
+        if not dry and "line_width_change" not in prep:
+            # what `lv_set_option("line_width", ...)` + the next frame's geometry costs: (device tessellation at the new radius +) the
+            # segment LBVH + the triangle LBVH, wall clock incl. the host-synchronous read-backs of the builds; then back again
+            ctx.set_option("line_width", LINE_WIDTH * 1.25)
+            t_lw = time.perf_counter()
+            ctx.build_accel()
+            wall = (time.perf_counter() - t_lw) * 1e3
+            s2 = ctx.stats()
+            prep["line_width_change"] = {"wall_ms": round(wall, 3), "tessellate_ms": round(float(s2.ms_tessellate), 3),
+                                         "accel_build_ms": round(float(s2.ms_accel_build), 3),
+                                         "tri_accel_build_ms": round(float(s2.ms_tri_accel_build), 3) if w.get("mesh") else None,
+                                         "path": "device" if device_geometry else "host arrays: the caller would re-tessellate on the host "
+                                                 "(tessellation_host_ms) and upload the mesh again (mesh_upload_ms) first"}
+            ctx.set_option("line_width", LINE_WIDTH)
+            ctx.build_accel()
         slots = [(sf, render_fn)]
         extra = []
         for _ in range(frames_in_flight - 1):
@@ -912,6 +941,11 @@ def main():
                     kernel_bytes=kernel_bytes, frame_bytes=frame_bytes, kernels=kernels, frame_ms=_stats(frame_ms),
                     build_ms=build_ms, build_first_ms=build_first_ms, st=st, wkey=wkey, diag=diag)
 
+    if not dry and world == 1 and device_geometry and wl.get("mesh") and not os.environ.get("LV_BENCH_SKIP_HOST_UPLOAD"):
+        # for the record only: what the host-built arrays of the same scene cost to upload (the path of rounds 1-5), in a throw-away context
+        c0, _ = make_context(wl, host_geometry=True)
+        del c0
+        gc.collect()
     head = measure(wl, args.workload)
     also = None
     if wl.get("also") and not dry:

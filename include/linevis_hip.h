@@ -144,6 +144,26 @@ int lv_set_tube_triangle_mesh(lv_ctx* ctx, const uint32_t* triangle_indices, uin
                               const lv_tube_vertex* vertices, uint32_t num_vertices,
                               const lv_line_point* line_points, uint32_t num_line_points);
 
+/* The same two inputs WITHOUT the host in between (round 6; plain flow lines -- no band data, no rotating helicity bands):
+ * LineDataFlow::setTrajectoryData's arrays (LineDataFlow.cpp:468-578: positions, the selected attribute, one offset per line) are
+ * copied to HBM (16 bytes per point) and the device writes what lv_set_lines and lv_set_tube_triangle_mesh would have been handed:
+ * the 48-byte line points + index pairs of LineDataFlow::getLinePassTubeAabbRenderData (LineDataFlow.cpp:2112-2277) at once, and the
+ * capped triangle tubes of getLinePassTubeTriangleMeshRenderData (LineDataFlow.cpp:1912-2110 -> createCappedTriangleTubesRenderDataCPU,
+ * CappedTriangleTubesCPU.cpp:214-383) whenever a frame needs them at a line_width / tube_num_subdivisions they have not been
+ * tessellated for -- byte for byte the host layer's output (lv_get_lines / lv_get_tube_triangle_mesh read them back).  A line-width
+ * change then costs a tessellation + two LBVH builds on the device instead of seconds on the host and a GB-sized upload.
+ * positions: 3 floats per point; attribute: 1 float per point or NULL (zeros); line_offsets: num_lines + 1 non-decreasing entries,
+ * [0] = 0.  Replaces the lines and the mesh of earlier lv_set_lines / lv_set_tube_triangle_mesh calls; a later lv_set_lines drops the
+ * trajectories, a later lv_set_tube_triangle_mesh overrides the device tessellation until the next lv_set_trajectories. */
+int lv_set_trajectories(lv_ctx* ctx, const float* positions, const float* attribute, const uint32_t* line_offsets, uint32_t num_lines);
+/* Read-backs of the current line points / index pairs and of the current tube mesh (tessellating it first if lv_set_trajectories'
+ * lines have none for the current settings).  Any output pointer may be NULL (query the counts). */
+int lv_get_lines(lv_ctx* ctx, lv_line_point* out_points, uint32_t max_points, uint32_t* out_segment_point_indices, uint32_t max_segments,
+                 uint32_t* out_num_points, uint32_t* out_num_segments);
+int lv_get_tube_triangle_mesh(lv_ctx* ctx, uint32_t* out_triangle_indices, uint32_t max_triangles, lv_tube_vertex* out_vertices,
+                              uint32_t max_vertices, lv_line_point* out_line_points, uint32_t max_line_points, uint32_t* out_num_triangles,
+                              uint32_t* out_num_vertices, uint32_t* out_num_line_points);
+
 /* Static RTAO prebaking (ambient_occlusion_mode = "RTAO (Prebaker)", VulkanAmbientOcclusionBaker.{hpp,cpp,glsl}): AO
  * factors are baked once per geometry for num_parametrization_vertices points along the lines x
  * rtao_prebaker_num_tube_subdivisions angles and looked up at render time (AmbientOcclusion.glsl:49-75), so AO costs

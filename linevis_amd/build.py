@@ -14,7 +14,7 @@ OUT_DIR = os.path.join(HERE, "_lib")
 LIB = os.path.join(OUT_DIR, "liblinevis_hip.so")
 # (source, object, extra flags): lv_mlat.hip is compiled in four parts (its kernel instantiations dominate the build time)
 SOURCES = [("lv_api.hip", "lv_api.o", []), ("lv_bvh.hip", "lv_bvh.o", []), ("lv_render.hip", "lv_render.o", []),
-           ("lv_flow.hip", "lv_flow.o", []), ("lv_svgf.hip", "lv_svgf.o", []), ("lv_multi.hip", "lv_multi.o", [])] + \
+           ("lv_flow.hip", "lv_flow.o", []), ("lv_lines.hip", "lv_lines.o", []), ("lv_svgf.hip", "lv_svgf.o", []), ("lv_multi.hip", "lv_multi.o", [])] + \
           [("lv_mlat.hip", "lv_mlat_%d.o" % p, ["-DLV_MLAT_PART=%d" % p]) for p in range(4)]
 HEADERS = ["lv_device.h", "lv_trace.h", "lv_prism.h", "lv_tile.h", "lv_internal.h", os.path.join("..", "..", "include", "linevis_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",

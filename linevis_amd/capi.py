@@ -100,6 +100,7 @@ SYMBOLS = ["lv_create", "lv_destroy", "lv_last_error", "lv_version", "lv_set_str
            "lv_compute_depth_range", "lv_get_ao", "lv_ppll_get_buffers", "lv_ppll_resolve_buffers", "lv_get_accel",
            "lv_set_tube_triangle_mesh", "lv_trace_rays_triangles", "lv_set_flow_grid", "lv_trace_streamlines", "lv_trace_streamlines_max_helicity_first",
            "lv_get_streamlines", "lv_get_streamline_seed_indices", "lv_set_ao_parametrization", "lv_get_baked_ao", "lv_bake_ao_start", "lv_bake_ao_poll", "lv_get_mlat_trace", "lv_selftest_rsqrt",
+           "lv_set_trajectories", "lv_get_lines", "lv_get_tube_triangle_mesh",
            "lv_create_multi", "lv_multi_ranks", "lv_multi_rank_stats", "lv_multi_rebalance", "lv_multi_deal", "lv_tile_deal", "lv_make_tiles"]
 
 _lib = None
@@ -168,6 +169,9 @@ def load():
         ("lv_ppll_resolve_buffers", [vp, vp, u64, vp, u64, u32, u32, u32, u32, vp]),
         ("lv_get_accel", [vp, vp, u64, vp, u64]),
         ("lv_set_tube_triangle_mesh", [vp, vp, u32, vp, u32, vp, u32]),
+        ("lv_set_trajectories", [vp, vp, vp, vp, u32]),
+        ("lv_get_lines", [vp, vp, u32, vp, u32, C.POINTER(u32), C.POINTER(u32)]),
+        ("lv_get_tube_triangle_mesh", [vp, vp, u32, vp, u32, vp, u32, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]),
         ("lv_trace_rays_triangles", [vp, vp, vp, f32, f32, u32, vp, vp, vp]),
         ("lv_set_flow_grid", [vp, vp, u32, u32, u32, f32, f32, f32, vp, u32]),
         ("lv_trace_streamlines", [vp, vp, u32, C.POINTER(StreamlineSettings), C.POINTER(u64), C.POINTER(u64)]),
@@ -283,6 +287,34 @@ class Context:
         v = np.ascontiguousarray(vertices, dtype=TUBE_VERTEX_DTYPE)
         pts = np.ascontiguousarray(line_points, dtype=LINE_POINT_DTYPE)
         self._ck(self.L.lv_set_tube_triangle_mesh(self.h, _p(idx), len(idx), _p(v), len(v), _p(pts), len(pts)))
+
+    def set_trajectories(self, positions, attribute, line_offsets):
+        """lv_set_trajectories: the trajectories go to HBM, line points / index pairs / tube mesh are written by kernels."""
+        pos = np.ascontiguousarray(positions, dtype=np.float32).reshape(-1, 3)
+        off = np.ascontiguousarray(line_offsets, dtype=np.uint32)
+        att = None if attribute is None else np.ascontiguousarray(attribute, dtype=np.float32).reshape(-1)
+        if len(off) < 1 or int(off[-1]) != len(pos) or (att is not None and len(att) != len(pos)):
+            raise ValueError("line_offsets[-1] must equal the number of points (and of attribute values)")
+        self._ck(self.L.lv_set_trajectories(self.h, _p(pos), None if att is None else _p(att), _p(off), len(off) - 1))
+
+    def get_lines(self):
+        """(points, segment index pairs) as they sit in HBM (lv_set_lines' input or lv_set_trajectories' device output)."""
+        n, m = C.c_uint32(), C.c_uint32()
+        self._ck(self.L.lv_get_lines(self.h, None, 0, None, 0, C.byref(n), C.byref(m)))
+        pts = np.zeros(n.value, dtype=LINE_POINT_DTYPE)
+        seg = np.zeros((m.value, 2), dtype=np.uint32)
+        self._ck(self.L.lv_get_lines(self.h, _p(pts), n.value, _p(seg), m.value, None, None))
+        return pts, seg
+
+    def get_tube_triangle_mesh(self):
+        """(triangle indices [n, 3], vertices, line points) of the current tube mesh (tessellated on the device if need be)."""
+        nt, nv, npnt = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        self._ck(self.L.lv_get_tube_triangle_mesh(self.h, None, 0, None, 0, None, 0, C.byref(nt), C.byref(nv), C.byref(npnt)))
+        idx = np.zeros((nt.value, 3), dtype=np.uint32)
+        v = np.zeros(nv.value, dtype=TUBE_VERTEX_DTYPE)
+        pts = np.zeros(npnt.value, dtype=LINE_POINT_DTYPE)
+        self._ck(self.L.lv_get_tube_triangle_mesh(self.h, _p(idx), nt.value, _p(v), nv.value, _p(pts), npnt.value, None, None, None))
+        return idx, v, pts
 
     def set_transfer_function(self, rgba, attr_min=0.0, attr_max=1.0):
         tf = np.ascontiguousarray(rgba, dtype=np.float32).reshape(-1, 4)

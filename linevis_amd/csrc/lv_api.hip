@@ -101,7 +101,7 @@ static std::vector<LvDeviceBuffer*> lv_all_buffers(lv_ctx* ctx) {
             &ctx->svgf.flowFwidth, &ctx->svgf.moments, &ctx->svgf.momentsHistory, &ctx->svgf.colorHistory, &ctx->svgf.tempAccum,
             &ctx->svgf.tempAccumFiltered, &ctx->svgf.ping, &ctx->svgf.pong, &ctx->svgf.result, &ctx->aoGbuf, &ctx->aoList, &ctx->aoSamples,
             &ctx->counters, &ctx->ppllNodes, &ctx->ppllStart, &ctx->ppllCount, &ctx->ppllScratch, &ctx->prismRecords, &ctx->scanTemp, &ctx->ppllOverflow, &ctx->ppllCoarse, &ctx->prismLeafList, &ctx->flowOccupancy, &ctx->flowSelfGrid, &ctx->twistTex, &ctx->tilesDev, &ctx->outDev,
-            &ctx->scratchRays, &ctx->stackOverflow, &ctx->triIdx, &ctx->triVerts, &ctx->triPoints, &ctx->triNodes, &ctx->tris,
+            &ctx->scratchRays, &ctx->stackOverflow, &ctx->trajPos, &ctx->trajAttr, &ctx->trajOff, &ctx->trajLineValid, &ctx->trajLineRef, &ctx->trajRecLine, &ctx->trajTess, &ctx->triIdx, &ctx->triVerts, &ctx->triPoints, &ctx->triNodes, &ctx->tris,
             &ctx->flowVectors, &ctx->flowScalars, &ctx->flowMisc, &ctx->flowSeeds, &ctx->flowOutPos, &ctx->flowOutAtt, &ctx->flowCounts,
             &ctx->bakeBlendingWeights, &ctx->bakeSamplingLocations, &ctx->bakedAo, &ctx->bakeLcgSkip, &ctx->bakedAoPending, &ctx->bakeCounters,
             &ctx->bakeGbuf, &ctx->bakeSamples, &ctx->bakeOverflow, &ctx->mlatTrace, &ctx->buildArena,
@@ -216,6 +216,7 @@ int lv_set_stream(lv_ctx* ctx, void* hip_stream) {
     ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->ownStream;
     ctx->evBuildValid = false;
     ctx->evTriBuildValid = false;
+    ctx->evLinePointsValid = ctx->evTessValid = false;
     ctx->evFrameValid = false;
     for (int k = 0; k < lv_ctx::kNumKernels; k++) ctx->kernelLaunches[k] = 0;
     return LV_OK;
@@ -247,6 +248,8 @@ int lv_set_lines(lv_ctx* ctx, const lv_line_point* points, uint32_t num_points, 
     // lines need lv_set_tube_triangle_mesh again before rtao_geometry = auto / triangle_tubes, Triangle Mesh or the prebaker use it
     ctx->triMeshSet = false;
     ctx->triAccelValid = false;
+    ctx->trajSet = false;        // these lines are the caller's: nothing to tessellate from
+    ctx->triMeshFromTraj = false;
     // VulkanRayTracedAmbientOcclusionPass::setLineData (.cpp:437-460): denoiser->resetFrameNumber(), globalFrameNumber = 0,
     // lastFrameViewProjectionMatrix = the current camera's
     ctx->aoGlobalFrameNumber = 0;
@@ -290,8 +293,8 @@ int lv_set_tube_triangle_mesh(lv_ctx* ctx, const uint32_t* triangle_indices, uin
     ctx->numTriVerts = num_vertices;
     ctx->numTriPoints = num_line_points;
     ctx->triMeshSet = true;
+    ctx->triMeshFromTraj = false;
     ctx->triAccelValid = false;
-    lv_invalidate_bake(ctx);
     return lv_forward_to_ranks(ctx, [&](lv_ctx* p) { return lv_set_tube_triangle_mesh(p, triangle_indices, num_triangles, vertices, num_vertices, line_points, num_line_points); });
 }
 
@@ -323,7 +326,6 @@ int lv_set_ao_parametrization(lv_ctx* ctx, const float* blending_weights, uint32
     ctx->bakeNumLineVertices = num_line_vertices;
     ctx->bakeNumParametrizationVertices = num_parametrization_vertices;
     ctx->bakeParamSet = true;
-    lv_invalidate_bake(ctx);
     return lv_forward_to_ranks(ctx, [&](lv_ctx* p) { return lv_set_ao_parametrization(p, blending_weights, num_line_vertices, sampling_locations, num_parametrization_vertices); });
 }
 
@@ -774,6 +776,7 @@ int lv_build_accel(lv_ctx* ctx) {
     int rc = lv_bvh_build(ctx);
     if (rc) return rc;
     // LineData::getRayTracingTubeTriangleTopLevelAS (LineData.cpp:986-1013): the triangle LBVH of the tube mesh, if there is one
+    if ((rc = lv_ensure_tube_mesh(ctx))) return rc;
     if (ctx->triMeshSet && (rc = lv_bvh_build_triangles(ctx))) return rc;
     return lv_forward_to_ranks(ctx, [&](lv_ctx* p) { return lv_build_accel(p); });
 }
@@ -859,6 +862,8 @@ static int lv_get_stats_impl(lv_ctx* ctx, lv_stats* out, bool aggregate) {
     };
     if (ctx->evBuildValid) s.ms_accel_build = ms(0, 1);
     if (ctx->evTriBuildValid) s.ms_tri_accel_build = ms(14, 15);
+    if (ctx->evLinePointsValid) s.ms_line_points = ms(4, 6);
+    if (ctx->evTessValid) s.ms_tessellate = ms(8, 9);
     s.num_tri_nodes = ctx->numTriNodes;
     if (ctx->evFrameValid) {
         // phase marks on the stream: 2 start, 5 depth range done, 7 RTAO done, 11 PPLL lists cleared, 13 gathered, 3 end

@@ -138,6 +138,15 @@ struct lv_ctx {
     LvDeviceBuffer triIdx, triVerts, triPoints; // input order
     LvDeviceBuffer triNodes, tris;              // accel
     bool triMeshSet = false, triAccelValid = false;
+    // lv_set_trajectories (lv_lines.hip): the trajectories themselves in HBM; `points` / `segIdx` are then written by the a2 kernels and
+    // the tube mesh is tessellated on the device whenever a frame needs it at another line width / subdivision count
+    LvDeviceBuffer trajPos, trajAttr, trajOff;      // 3 floats / 1 float per point, numLines + 1 offsets
+    LvDeviceBuffer trajLineValid, trajLineRef, trajRecLine, trajTess; // per line: valid points, LvLineRef; per record: its line; tessellation offsets + tables
+    uint32_t trajNumLines = 0, trajNumPoints = 0;
+    bool trajHasAttr = false, trajSet = false;
+    bool triMeshFromTraj = false;             // the mesh in triIdx / triVerts / triPoints was tessellated here (not passed by the caller)
+    float triMeshLineWidth = -1.0f;
+    uint32_t triMeshSubdivisions = 0;
     float triAccelLineWidth = -1.0f, triPad = 0.0f;
     uint32_t triLeafSize = 1;                 // triangles per leaf of the triangle LBVH as built (opt.triLeafSize at build time)
 
@@ -232,6 +241,7 @@ struct lv_ctx {
     bool evCreated = false;
     bool evBuildValid = false, evFrameValid = false, evPhaseRecorded = false;
     bool evTriBuildValid = false;             // ev[14], ev[15] bracket the last triangle-LBVH build
+    bool evLinePointsValid = false, evTessValid = false; // ev[4], ev[6]: the a2 kernels of lv_set_trajectories; ev[8], ev[9]: the last device tessellation
     int lastMode = 0;
     // per-kernel launch timers: ring of event pairs per kernel id (LV_KERNEL_*)
     static constexpr int kNumKernels = 8;
@@ -246,7 +256,7 @@ int lv_fail(lv_ctx* ctx, int code, const char* fmt, ...);
 // RTAO geometry of the frame: the reference's triangle tubes (VulkanRayTracedAmbientOcclusion traces nothing else) whenever the mesh
 // is there, the analytic capsules of the colour pass otherwise / on request
 inline bool lv_ao_triangle_tubes(const lv_ctx* ctx) {
-    return ctx->opt.rtaoGeometry == 2 || (ctx->opt.rtaoGeometry == 0 && ctx->triMeshSet);
+    return ctx->opt.rtaoGeometry == 2 || (ctx->opt.rtaoGeometry == 0 && (ctx->triMeshSet || ctx->trajSet));
 }
 // the capsule roots in use: the reference's textbook form (RayIntersectionTestsVulkan.glsl:39-119) -- the default -- or the
 // closest-approach form; "auto" leaves the reference's form only where this build traces AO rays against the analytic capsules
@@ -286,6 +296,8 @@ void lv_buf_free(LvDeviceBuffer& b);
 // lv_bvh.hip
 int lv_bvh_build(lv_ctx* ctx);
 int lv_bvh_build_triangles(lv_ctx* ctx);
+// lv_lines.hip: (re)tessellates the tube mesh of lv_set_trajectories' lines if the line width / subdivision count changed; no-op otherwise
+int lv_ensure_tube_mesh(lv_ctx* ctx);
 // lv_multi.hip: one frame over the GPUs of a node behind the same handle
 int lv_multi_create(lv_ctx* handle, const int* devices, int numDevices, const char* transport);
 void lv_multi_destroy(lv_ctx* handle);

@@ -2650,6 +2650,7 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
                                (ctx->opt.useAmbientOcclusion && lv_ao_triangle_tubes(ctx)) ||
                                (ctx->opt.rtTriangleMesh && mode == LV_RENDERING_MODE_VULKAN_RAY_TRACER);
     if (needTriangles) {
+        if ((rc = lv_ensure_tube_mesh(ctx))) return rc;
         if (!ctx->triMeshSet)
             return lv_fail(ctx, LV_E_STATE, "rtao_geometry = triangle_tubes / geometry_mode = Triangle Mesh / the RTAO "
                                             "prebaker need lv_set_tube_triangle_mesh");
@@ -3093,6 +3094,7 @@ int lv_frame_ppll_resolve_only(lv_ctx* ctx, const uint32_t* nodes, uint64_t numN
 int lv_frame_trace_rays_triangles(lv_ctx* ctx, const float* o, const float* d, float tMin, float tMax, uint32_t n,
                                   float* outT, uint32_t* outTri, float* outUV) {
     int rc;
+    if ((rc = lv_ensure_tube_mesh(ctx))) return rc;
     if (!ctx->triMeshSet) return lv_fail(ctx, LV_E_STATE, "lv_set_tube_triangle_mesh has not been called");
     if (!ctx->triAccelValid || ctx->triAccelLineWidth != ctx->opt.lineWidth)
         if ((rc = lv_bvh_build_triangles(ctx))) return rc;
@@ -3129,6 +3131,10 @@ int lv_frame_trace_rays_triangles(lv_ctx* ctx, const float* o, const float* d, f
 // AO, or with the previous table's AO while that is still valid) until lv_bake_poll finds the stream finished and swaps the tables.
 int lv_bake_ambient_occlusion(lv_ctx* ctx, bool async) {
     const LvOptions& o = ctx->opt;
+    {
+        const int rcMesh = lv_ensure_tube_mesh(ctx);
+        if (rcMesh) return rcMesh;
+    }
     if (!ctx->triMeshSet) return lv_fail(ctx, LV_E_STATE, "the RTAO prebaker needs lv_set_tube_triangle_mesh");
     if (!ctx->bakeParamSet) return lv_fail(ctx, LV_E_STATE, "the RTAO prebaker needs lv_set_ao_parametrization");
     if (ctx->bakeNumLineVertices != ctx->numTriPoints)

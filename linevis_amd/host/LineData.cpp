@@ -237,6 +237,7 @@ bool loadFlowTrajectoriesFromFile(const std::string& filename, Trajectories& tra
 void LineData::setSelectedAttributeIndex(int idx) {
     if (idx != selectedAttributeIndex) {
         selectedAttributeIndex = idx;
+        dataGeneration++;
         setTriangleRepresentationDirty();
     }
 }
@@ -455,7 +456,29 @@ void LineDataFlow::setTrajectoryData(const Trajectories& newTrajectories, const 
     modelBoundingBox = computeTrajectoriesAABB3(trajectories);
     cachedAabbDataValid = false;
     cachedTriangleDataValid = false;
+    dataGeneration++;
     dirty = true;
+}
+
+// the arrays lv_set_trajectories takes; band data and the rotating helicity bands (ribbon normals / a rotation that runs on across all
+// lines) keep the host-built render data
+bool LineDataFlow::getTrajectoryArrays(std::vector<float>& positions, std::vector<float>& attribute, std::vector<uint32_t>& lineOffsets) {
+    if ((useRibbons && hasBandsData) || getUseRotatingHelicityBands()) return false;
+    if (numTotalTrajectoryPoints > 0x03FFFFFFu) return false;
+    positions.resize(3 * numTotalTrajectoryPoints);
+    attribute.assign(numTotalTrajectoryPoints, 0.0f);
+    lineOffsets.assign(trajectories.size() + 1, 0u);
+    size_t at = 0;
+    for (size_t li = 0; li < trajectories.size(); li++) {
+        const Trajectory& t = trajectories[li];
+        const size_t n = t.positions.size();
+        if (n) memcpy(positions.data() + 3 * at, t.positions.data(), n * sizeof(vec3));
+        if (!t.attributes.empty() && size_t(selectedAttributeIndex) < t.attributes.size())
+            memcpy(attribute.data() + at, t.attributes[size_t(selectedAttributeIndex)].data(), n * sizeof(float));
+        at += n;
+        lineOffsets[li + 1] = uint32_t(at);
+    }
+    return true;
 }
 
 size_t LineDataFlow::getNumLineSegments() {

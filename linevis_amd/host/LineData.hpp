@@ -138,6 +138,16 @@ public:
     /// Points of all (unfiltered) lines, used for the depth-cue range (LineRenderer.cpp:365-408).
     virtual std::vector<std::vector<vec3>> getFilteredLines(LineRenderer* lineRenderer) = 0;
 
+    /// Device geometry (round 6): plain flow lines (no band data, no rotating helicity bands) can hand their trajectories -- positions,
+    /// the selected attribute, one offset per line: LineDataFlow::setTrajectoryData's arrays, LineDataFlow.cpp:468-578 -- to
+    /// lv_set_trajectories and let kernels write what getLinePassTubeAabbRenderData / getLinePassTubeTriangleMeshRenderData produce.
+    /// false: this data needs the host-built render data.  getDataGeneration() changes whenever the arrays would.
+    virtual bool getTrajectoryArrays(std::vector<float>& positions, std::vector<float>& attribute, std::vector<uint32_t>& lineOffsets) {
+        (void)positions; (void)attribute; (void)lineOffsets;
+        return false;
+    }
+    uint64_t getDataGeneration() const { return dataGeneration; }
+
     /// dataset-side settings keys: attribute, tube_num_subdivisions, use_capped_tubes, use_halos
     /// (src/LineData/LineData.cpp:87-181).  Returns true when renderers must re-fetch geometry/defines.
     virtual bool setNewSettings(const SettingsMap& settings);
@@ -156,6 +166,7 @@ protected:
     bool useHalos = true;
     int tubeNumSubdivisions = 6;     // LineData.cpp:52
     bool dirty = false;
+    uint64_t dataGeneration = 1;     // bumped by new trajectories / another selected attribute
     bool cachedAabbDataValid = false;
     bool cachedTriangleDataValid = false;
 };
@@ -202,6 +213,7 @@ public:
     TubeAabbRenderData getLinePassTubeAabbRenderData(bool isRasterizer, bool ellipticTubes) override;
     TubeTriangleRenderData getLinePassTubeTriangleMeshRenderData(bool isRasterizer, bool vulkanRayTracing) override;
     std::vector<std::vector<vec3>> getFilteredLines(LineRenderer* lineRenderer) override;
+    bool getTrajectoryArrays(std::vector<float>& positions, std::vector<float>& attribute, std::vector<uint32_t>& lineOffsets) override;
 
 private:
     Trajectories trajectories;

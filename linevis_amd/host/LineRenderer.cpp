@@ -315,6 +315,12 @@ bool LineRenderer::setNewSettings(const SettingsMap& settings) {
             linesDirty = true;
         }
     }
+    bool deviceGeometryWanted = useDeviceGeometry;   // build-owned key: false keeps the host-built render data (LineData.cpp / Tubes.cpp)
+    if (settings.getValueOpt("use_device_geometry", deviceGeometryWanted) && deviceGeometryWanted != useDeviceGeometry) {
+        useDeviceGeometry = deviceGeometryWanted;
+        uploadedTrajectoryData = nullptr;
+        linesDirty = true;
+    }
     float newBandWidth = bandWidth;
     if (settings.getValueOpt("band_width", bandWidth)) { // LineRenderer.cpp:442-449
         if (newBandWidth != bandWidth && lineData) {
@@ -397,10 +403,32 @@ bool LineRenderer::uploadFrameState() {
         // elliptic tubes with USE_BANDS; the ray-entry PPLL of this build gathers the entry hits of the analytic elliptic tubelets)
         const bool bands = lineData->getUseBands();
         const bool elliptic = bands && getUseAnalyticEllipticTubes();
-        TubeAabbRenderData d = lineData->getLinePassTubeAabbRenderData(false, elliptic);
-        if (!check(lv_set_lines(ctx, d.linePointDataBuffer.data(), uint32_t(d.linePointDataBuffer.size()),
-                                d.indexBuffer.data(), uint32_t(d.indexBuffer.size() / 2)), "lv_set_lines"))
-            return false;
+        // plain flow lines: the trajectories themselves go to HBM (once per data set) and the device writes the line points, the index
+        // pairs and -- whenever a frame needs them at another line width -- the triangle tubes; everything else: host-built render data
+        deviceGeometry = false;
+        if (useDeviceGeometry && !bands && !lineData->getUseRotatingHelicityBands()) {
+            if (uploadedTrajectoryData == lineData.get() && uploadedTrajectoryGeneration == lineData->getDataGeneration()) {
+                deviceGeometry = true;     // only the line width / the tessellation settings changed: nothing to upload
+            } else {
+                std::vector<float> positions, attribute;
+                std::vector<uint32_t> lineOffsets;
+                if (lineData->getTrajectoryArrays(positions, attribute, lineOffsets)) {
+                    if (!check(lv_set_trajectories(ctx, positions.data(), attribute.data(), lineOffsets.data(), uint32_t(lineOffsets.size() - 1)),
+                               "lv_set_trajectories"))
+                        return false;
+                    uploadedTrajectoryData = lineData.get();
+                    uploadedTrajectoryGeneration = lineData->getDataGeneration();
+                    deviceGeometry = true;
+                }
+            }
+        }
+        if (!deviceGeometry) {
+            uploadedTrajectoryData = nullptr;
+            TubeAabbRenderData d = lineData->getLinePassTubeAabbRenderData(false, elliptic);
+            if (!check(lv_set_lines(ctx, d.linePointDataBuffer.data(), uint32_t(d.linePointDataBuffer.size()),
+                                    d.indexBuffer.data(), uint32_t(d.indexBuffer.size() / 2)), "lv_set_lines"))
+                return false;
+        }
         setOption("use_ribbons", bands ? "true" : "false");
         setOption("use_analytic_elliptic_tubes", elliptic ? "true" : "false");
         setOption("thick_bands", LineData::getRenderThickBands() ? "true" : "false");
@@ -446,6 +474,11 @@ bool LineRenderer::uploadFrameState() {
         wantMesh = wantMesh || static_cast<HipRayTracedAmbientOcclusion*>(ambientOcclusionBaker.get())->useTriangleTubes;
     const bool prebaker = useAmbientOcclusion && ambientOcclusionBaker && ambientOcclusionBaker->getIsStaticPrebaker();
     wantMesh = wantMesh || prebaker; // the baker traces the triangle tubes (VulkanAmbientOcclusionBaker.cpp:480)
+    if (wantMesh && triangleMeshDirty && deviceGeometry) {
+        // lv_set_trajectories' lines: the library tessellates on the device when the frame asks for the mesh (lv_ensure_tube_mesh)
+        triangleMeshDirty = false;
+        if (prebaker) static_cast<HipAmbientOcclusionBaker*>(ambientOcclusionBaker.get())->notifyInputsChanged();
+    }
     if (wantMesh && triangleMeshDirty) {
         TubeTriangleRenderData d = lineData->getLinePassTubeTriangleMeshRenderData(false, true);
         if (!check(lv_set_tube_triangle_mesh(ctx, d.indexBuffer.data(), uint32_t(d.indexBuffer.size() / 3),

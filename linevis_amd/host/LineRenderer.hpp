@@ -248,6 +248,11 @@ protected:
     bool isRasterizer = false;
     bool dirty = true, reRender = true, internalReRender = false;
     bool tfDirty = true, linesDirty = true, triangleMeshDirty = true;
+    // device geometry (lv_set_trajectories): on by default for plain flow lines; use_device_geometry = false keeps the host-built
+    // render data (build-owned key).  uploadedTrajectory*: which data set's arrays sit in HBM
+    bool useDeviceGeometry = true, deviceGeometry = false;
+    const LineData* uploadedTrajectoryData = nullptr;
+    uint64_t uploadedTrajectoryGeneration = 0;
     // twist-line texture last handed to the library (dimensions + FNV-1a of the pixels): lv_set_twist_line_texture rebuilds a mip chain
     // and synchronises, so it is called only when the pixels changed, not with every dirty line setting
     uint32_t uploadedTwistW = 0xFFFFFFFFu, uploadedTwistH = 0xFFFFFFFFu;
