@@ -244,6 +244,12 @@ int lv_set_background(lv_ctx* ctx, const float rgba[4]);
  *   record costs the stream 2 - 4 us: a frame with every kernel and phase bracketed carries a dozen (6 % of a 0.8-ms PPLL frame),
  *   triangle_leaf_size (build-owned): consecutive triangles per leaf of the triangle LBVH, 1 ... 8 (default 2: a tube face);
  *   changes the acceleration structure only, never a hit,
+ *   overlap_primary_passes (build-owned; "auto" (default) | "true" | "false"): in a ray-tracer frame with per-frame RTAO the closest hits of the colour
+ *   pass' rays do not depend on the AO image, only their shading does -- they are traced in ONE launch with the RTAO pass' primary
+ *   rays (two latency-bound passes that a rank owning 1/8 of the tiles cannot fill the GPU with one after the other) and the colour
+ *   kernel after the RTAO pass shades them; "false" = one pass after the other as in VulkanRayTracer::render (VulkanRayTracer.cpp:
+ *   131-154); "auto" = overlapped while the tile list is at most half a 1920 x 1080 frame (a sharded frame's rank), one after the
+ *   other for a whole frame on one GPU, where both passes are throughput-bound.  The frame is byte-identical either way,
  *   dispatch_order (build-owned, no counterpart): "cost" (default: the tile kernels start their 64x64-pixel groups heaviest-of-
  *   the-previous-frame first, see lv_get_dispatch_order) | "as_numbered" (tile-list order); the image is the same,
  *   rtao_prebaker_iterations (128), rtao_prebaker_samples_per_frame (4), rtao_prebaker_num_tube_subdivisions (8): the

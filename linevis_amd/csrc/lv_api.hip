@@ -104,7 +104,7 @@ static std::vector<LvDeviceBuffer*> lv_all_buffers(lv_ctx* ctx) {
             &ctx->scratchRays, &ctx->stackOverflow, &ctx->trajPos, &ctx->trajAttr, &ctx->trajOff, &ctx->trajLineValid, &ctx->trajLineRef, &ctx->trajRecLine, &ctx->trajTess, &ctx->triIdx, &ctx->triVerts, &ctx->triPoints, &ctx->triNodes, &ctx->tris,
             &ctx->flowVectors, &ctx->flowScalars, &ctx->flowMisc, &ctx->flowSeeds, &ctx->flowOutPos, &ctx->flowOutAtt, &ctx->flowCounts,
             &ctx->bakeBlendingWeights, &ctx->bakeSamplingLocations, &ctx->bakedAo, &ctx->bakeLcgSkip, &ctx->bakedAoPending, &ctx->bakeCounters,
-            &ctx->bakeGbuf, &ctx->bakeSamples, &ctx->bakeOverflow, &ctx->mlatTrace, &ctx->buildArena,
+            &ctx->bakeGbuf, &ctx->bakeSamples, &ctx->bakeOverflow, &ctx->mlatTrace, &ctx->buildArena, &ctx->firstHit,
             &ctx->accum, &ctx->groupOrder[0].cost, &ctx->groupOrder[0].order, &ctx->groupOrder[1].cost, &ctx->groupOrder[1].order};
 }
 
@@ -638,6 +638,8 @@ int lv_set_option(lv_ctx* ctx, const char* key, const char* value) {
         o.useCappedTubes = parseBool(value);
     } else if (k == "use_halos") {
         o.useHalos = parseBool(value);
+    } else if (k == "overlap_primary_passes") {
+        o.overlapPrimaryPasses = strcmp(value, "auto") == 0 ? 2 : (parseBool(value) ? 1 : 0);
     } else if (k == "tube_num_subdivisions") {
         if (!parseUint(value, u) || u < 3) return bad();
         o.tubeNumSubdivisions = u;

@@ -51,6 +51,12 @@
 #ifndef LV_AO_CHUNK
 #define LV_AO_CHUNK 128         // AO rays a wave takes from the global queue per atomic (1024: -10 %, the last chunks' tail)
 #endif
+#ifndef LV_AO_CHUNK_SMALL
+#define LV_AO_CHUNK_SMALL 64u   // ... when the launch has fewer than LV_AO_SMALL_CHUNKS chunks of LV_AO_CHUNK per persistent wave
+#endif
+#ifndef LV_AO_SMALL_CHUNKS
+#define LV_AO_SMALL_CHUNKS 12u
+#endif
 #ifndef LV_AO_STAY
 #define LV_AO_STAY 1            // k_ao_rays descend loop: stay while at least this many lanes descend (tools/variants.py experiment)
 #endif

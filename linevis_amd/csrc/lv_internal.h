@@ -50,6 +50,7 @@ struct LvOptions {
     bool collapseTop = true;                  // accel_collapse_top: the levels of the wide tree with <= 1024 nodes in one launch (k_collapse_top)
     bool treeletPlaneScan = true;             // treelet_plane_eval = scan (DPP prefix / suffix scans over the bins) | loop (round-3 form)
     bool accelFastTrace = true;               // accel_build = fast_trace (LBVH + SAH treelets, the reference's PREFER_FAST_TRACE) | fast_build (LBVH)
+    int overlapPrimaryPasses = 2;             // overlap_primary_passes: 0 = false, 1 = true, 2 = auto -- the colour pass' hit traces in one launch with the RTAO primaries (k_primary_pair)
     bool dispatchByCost = true;               // dispatch_order = cost | as_numbered (tile kernels: heaviest 64x64 group of the last frame first)
     bool aoJitterPrimary = true;              // :153
     uint32_t numSamplesPerFrame = 1;          // VulkanRayTracer.hpp:137 has 2 (interactive); offline default 1
@@ -202,6 +203,7 @@ struct lv_ctx {
     bool tilesHaloUploaded = false;
     uint32_t aoNumGroups = 0, aoGroupsPerTile = 0; // geometry of the last RTAO pass' per-group counters (aoList)
     LvDeviceBuffer aoGbuf, aoList, aoSamples; // RTAO wavefront buffers
+    LvDeviceBuffer firstHit;                  // k_primary_pair: {t bits, (leaf << 2) | kind} of the colour pass' first ray per output pixel
     LvDeviceBuffer counters;                  // device counters (LvCounters + misc)
     LvDeviceBuffer ppllNodes, ppllStart, ppllCount, ppllScratch;
     LvDeviceBuffer prismRecords, scanTemp;    // raster_prism: {pixel, leaf | triangle, rank} records of the coverage kernel; k_ppll_scan: block totals, block bases, completion counter

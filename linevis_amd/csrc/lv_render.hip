@@ -28,9 +28,16 @@ namespace {
 // ================================================================ ray tracer colour pass
 // Control flow is wave-uniform around every trace (lv_trace_closest is a wave-cooperative routine): the sample loop and
 // the transparency loop run while ANY lane of the wave still needs a trace; lanes that are done pass active = false.
-template <bool STATS, int PRIM, int BANDS = LV_SHADE_PLAIN>
+// PRE: the hits of every pixel's ray were traced ahead of the RTAO pass (lv_colour_first_hits, launched together with the RTAO
+// primaries: k_primary_pair) and wait in firstHit[k * stride + px.outIndex] = {t bits, (leaf << 2) | kind or LV_INVALID}, k = position in
+// the transparency loop, k < LV_PRE_HITS; the kernel shades them and only traces where a pixel's loop goes deeper than that.  Same hits,
+// same frame, byte for byte: which hit follows which depends on the alpha of the shaded hit, and alpha (transfer function x silhouette
+// coverage) does not depend on the ambient occlusion.
+#define LV_PRE_HITS 4u
+template <bool STATS, int PRIM, int BANDS = LV_SHADE_PLAIN, bool PRE = false>
 __global__ __launch_bounds__(LV_BLOCK, (STATS || PRIM == LV_PRIM_ELLIPTIC) ? 1 : LV_RT_MIN_WAVES) void k_render_rt(const LvUniforms U, const LvSceneDev S, const LvTiles T,
-                                                        uint32_t* __restrict__ out, LvDevCounters* dc) {
+                                                        uint32_t* __restrict__ out, LvDevCounters* dc,
+                                                        const uint2* __restrict__ firstHit = nullptr, const size_t firstHitStride = 0) {
     __shared__ unsigned s_stack[LV_STACK_LDS * LV_BLOCK];
     LV_COOP_SHARED(LV_BLOCK / LV_WAVE);
     LV_COOP_MEM(cm);
@@ -61,7 +68,19 @@ __global__ __launch_bounds__(LV_BLOCK, (STATS || PRIM == LV_PRIM_ELLIPTIC) ? 1 :
         const float tMax = 1000.0f;
         bool tracing = px.inView;
         for (uint32_t hitIdx = 0; hitIdx < U.maxDepthComplexity && __any(tracing); hitIdx++) {
-            LvHit h = lv_trace_closest<STATS, false, PRIM>(S, U.radius, capped, tracing, o, d, tMin, tMax, sm, cm, cnt);
+            LvHit h;
+            if (PRE && hitIdx < LV_PRE_HITS && sampleIdx == 0u) {
+                h.found = false; h.t = 0.0f; h.leaf = 0u; h.kind = 0;
+                if (tracing) {
+                    const uint2 fh = firstHit[size_t(hitIdx) * firstHitStride + px.outIndex];
+                    h.found = fh.y != LV_INVALID;
+                    h.t = __uint_as_float(fh.x);
+                    h.leaf = fh.y >> 2;
+                    h.kind = int(fh.y & 3u);
+                }
+            } else {
+                h = lv_trace_closest<STATS, false, PRIM>(S, U.radius, capped, tracing, o, d, tMin, tMax, sm, cm, cnt);
+            }
             if (tracing) {
                 f4 hc;
                 float payloadHitT;
@@ -120,17 +139,15 @@ __device__ __forceinline__ size_t lv_ao_group_base(const LvAoLayout& L, uint32_t
 // G-buffer entry of a pixel whose primary ray hit: 3 x float4
 //   g0 = {hit position, offsetFactor}, g1 = {surface tangent, pixel index bits}, g2 = {surface normal, 0}
 template <bool STATS, int PRIM>
-__global__ __launch_bounds__(LV_BLOCK) void k_ao_primary(const LvUniforms U, const LvSceneDev S, const LvTiles T,
-                                                         const float* aoIn, float* ao, float4* __restrict__ gbuf,
-                                                         uint32_t* __restrict__ groupCount, LvDevCounters* dc,
-                                                         const float4* featNormalIn, float4* featNormal,
-                                                         const float4* featPositionIn, float4* featPosition,
-                                                         const LvSvgfFeat SF) {
-    __shared__ unsigned s_stack[LV_STACK_LDS * LV_BLOCK];
-    LV_COOP_SHARED(LV_BLOCK / LV_WAVE);
-    LV_COOP_MEM(cm);
+__device__ __forceinline__ void lv_ao_primary_body(const LvUniforms& U, const LvSceneDev& S, const LvTiles& T, uint32_t blockId,
+                                                   unsigned* s_stack, LvCoopMem& cm,
+                                                   const float* aoIn, float* ao, float4* __restrict__ gbuf,
+                                                   uint32_t* __restrict__ groupCount, LvDevCounters* dc,
+                                                   const float4* featNormalIn, float4* featNormal,
+                                                   const float4* featPositionIn, float4* featPosition,
+                                                   const LvSvgfFeat& SF) {
     LvPixel px;
-    if (!lv_block_pixel(U, T, px)) return;
+    if (!lv_block_pixel(U, T, px, blockId)) return;
     const unsigned long long tg0 = lv_group_clock();
     LvCounters cnt = {0, 0, 0, 0};
     bool hasHit = false;
@@ -286,6 +303,94 @@ __global__ __launch_bounds__(LV_BLOCK) void k_ao_primary(const LvUniforms U, con
     if (STATS) lv_flush_counters(cnt, dc);
 }
 
+template <bool STATS, int PRIM>
+__global__ __launch_bounds__(LV_BLOCK) void k_ao_primary(const LvUniforms U, const LvSceneDev S, const LvTiles T,
+                                                         const float* aoIn, float* ao, float4* __restrict__ gbuf,
+                                                         uint32_t* __restrict__ groupCount, LvDevCounters* dc,
+                                                         const float4* featNormalIn, float4* featNormal,
+                                                         const float4* featPositionIn, float4* featPosition,
+                                                         const LvSvgfFeat SF) {
+    __shared__ unsigned s_stack[LV_STACK_LDS * LV_BLOCK];
+    LV_COOP_SHARED(LV_BLOCK / LV_WAVE);
+    LV_COOP_MEM(cm);
+    lv_ao_primary_body<STATS, PRIM>(U, S, T, blockIdx.x, s_stack, cm, aoIn, ao, gbuf, groupCount, dc, featNormalIn, featNormal, featPositionIn,
+                                    featPosition, SF);
+}
+
+// The colour pass' ray of every pixel (sample 0: the pixel centre, or the jittered position of TubeRayTracing.glsl:236-262) against the
+// capsules, through the transparency loop of traceRayTransparent (TubeRayTracing.glsl:61-82) for up to LV_PRE_HITS hits: which hits the
+// loop visits depends on the alpha of the shaded hits, and alpha does not depend on the ambient occlusion (lv_compute_fragment_color_t:
+// out.w = transfer function alpha x silhouette coverage) -- the hits are shaded here WITHOUT ambient occlusion, for their alpha and
+// payload distance only.  firstHit[k * stride + px.outIndex] = {t bits, (leaf << 2) | kind}, LV_INVALID = miss;
+// k_render_rt<..., PRE = true> shades them with the AO image after the RTAO pass.
+template <bool STATS, int BANDS>
+__device__ __forceinline__ void lv_colour_first_hits(const LvUniforms& U, const LvSceneDev& S, const LvTiles& T, uint32_t blockId,
+                                                     unsigned* s_stack, LvCoopMem& cm, uint2* __restrict__ firstHit, size_t stride,
+                                                     LvDevCounters* dc) {
+    LvPixel px;
+    if (!lv_block_pixel(U, T, px, blockId)) return;
+    const unsigned long long tg0 = lv_group_clock();
+    const LvStackMem sm = lv_stack_mem(s_stack, S.stackOverflow);
+    LvCounters cnt = {0, 0, 0, 0};
+    LvUniforms UA = U;            // the same shading without the AO term (S.ao is not there yet)
+    UA.useAmbientOcclusion = 0u;
+    UA.aoProjectLookup = 0u;
+    float xix = 0.5f, xiy = 0.5f;
+    if (U.useJitteredRays) {   // as k_render_rt, sampleIdx = 0
+        uint32_t seed = U.useDeterministicSampling ? lv_tea(19u, U.frameNumber * U.numSamplesPerFrame)
+                                                   : lv_tea(px.x + px.y * U.width, U.frameNumber * U.numSamplesPerFrame);
+        xix = lv_rnd(seed);
+        xiy = lv_rnd(seed);
+    }
+    f3 o, d;
+    lv_primary_ray(U, px.x, px.y, xix, xiy, o, d);
+    const bool capped = U.useCappedTubes != 0 || U.lssGeometry != 0;
+    const float HIT_DISTANCE_EPSILON = 1e-5f;
+    float tMin = 0.0001f, alpha = 0.0f;
+    bool tracing = px.inView;
+    for (uint32_t hitIdx = 0; hitIdx < LV_PRE_HITS && hitIdx < U.maxDepthComplexity && __any(tracing); hitIdx++) {
+        const LvHit h = lv_trace_closest<STATS, false, LV_PRIM_CAPSULE>(S, U.radius, capped, tracing, o, d, tMin, 1000.0f, sm, cm, cnt);
+        if (tracing) {
+            firstHit[size_t(hitIdx) * stride + px.outIndex] =
+                    h.found ? make_uint2(__float_as_uint(h.t), (h.leaf << 2) | uint32_t(h.kind)) : make_uint2(0u, LV_INVALID);
+            if (!h.found) {
+                tracing = false;
+            } else {
+                float payloadHitT;
+                const f4 hc = lv_shade_hit<BANDS>(S, UA, 1.0f, o, d, h, payloadHitT);
+                tMin = payloadHitT + fmaxf(payloadHitT * HIT_DISTANCE_EPSILON, 1e-7f);
+                alpha = alpha + (1.0f - alpha) * hc.w;
+                if (alpha > 0.99f) tracing = false;
+            }
+        }
+    }
+    lv_group_cost_add(T, px, tg0);
+    if (STATS) { lv_flush_max_nodes(cnt, dc); lv_flush_counters(cnt, dc); }
+}
+
+// k_ao_primary and the colour pass' first-hit trace in ONE launch: workgroups [0, gridAo) trace the RTAO primaries (scene SA: the
+// triangle tubes or the capsules, tiles TA), workgroups [gridAo, gridAo + gridColour) the colour rays (scene SC, tiles TC).  Both are
+// latency-bound chains of dependent node fetches with one ray per lane; on a rank that owns 1/8 of the tiles neither fills the GPU
+// (4 waves per SIMD), and run one after the other they were 0.44 of a 1.27-ms frame (profiles/shard_probe_r05_c3t.json).  Together
+// their waves share the CUs and the two chains overlap.
+template <bool STATS, int PRIM, int BANDS>
+__global__ __launch_bounds__(LV_BLOCK) void k_primary_pair(const LvUniforms U, const LvSceneDev SA, const LvTiles TA, const uint32_t gridAo,
+                                                           const float* aoIn, float* ao, float4* __restrict__ gbuf,
+                                                           uint32_t* __restrict__ groupCount, LvDevCounters* dc,
+                                                           const float4* featNormalIn, float4* featNormal,
+                                                           const float4* featPositionIn, float4* featPosition,
+                                                           const LvSvgfFeat SF, const LvSceneDev SC, const LvTiles TC,
+                                                           uint2* __restrict__ firstHit, const size_t firstHitStride) {
+    __shared__ unsigned s_stack[LV_STACK_LDS * LV_BLOCK];
+    LV_COOP_SHARED(LV_BLOCK / LV_WAVE);
+    LV_COOP_MEM(cm);
+    if (blockIdx.x < gridAo)
+        lv_ao_primary_body<STATS, PRIM>(U, SA, TA, blockIdx.x, s_stack, cm, aoIn, ao, gbuf, groupCount, dc, featNormalIn, featNormal,
+                                        featPositionIn, featPosition, SF);
+    else
+        lv_colour_first_hits<STATS, BANDS>(U, SC, TC, blockIdx.x - gridAo, s_stack, cm, firstHit, firstHitStride, dc);
+}
+
 // exclusive prefix sum of the per-tile hit-pixel counts: tileBase[t] = first compacted-pixel ordinal of tile t,
 // tileBase[numTiles] = dc->aoCount = all hit pixels of the launch (one workgroup; numTiles is a few hundred to a few thousand)
 __global__ __launch_bounds__(LV_BLOCK) void k_ao_tile_scan(const uint32_t* __restrict__ tileCount, uint32_t numTiles,
@@ -409,6 +514,11 @@ __global__ __launch_bounds__(LV_AO_BLOCK, LV_AO_MIN_WAVES) void k_ao_rays(const 
 
     const uint32_t spp = U.aoSamplesPerFrame;
     const unsigned long long total = (unsigned long long)(dc->aoCount) * spp;
+    // rays a wave takes from the global queue per atomic: LV_AO_CHUNK, or half of it when the launch holds fewer than LV_AO_SMALL_CHUNKS
+    // such chunks per persistent wave (a rank that owns 1/8 of the tiles: ~4 chunks of 128 per wave -- the last chunk of the slowest
+    // wave is then a quarter of the kernel)
+    const unsigned chunk = total < (unsigned long long)gridDim.x * (LV_AO_BLOCK / LV_WAVE) * LV_AO_CHUNK * LV_AO_SMALL_CHUNKS ? LV_AO_CHUNK_SMALL
+                                                                                                                             : LV_AO_CHUNK;
     const bool capped = U.useCappedTubes != 0;
     const float radius = U.radius;
     const unsigned lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
@@ -565,9 +675,9 @@ __global__ __launch_bounds__(LV_AO_BLOCK, LV_AO_MIN_WAVES) void k_ao_rays(const 
             if (genPos >= genCount) {
                 if (chunkNext >= chunkEnd) {
                     unsigned long long base = 0;
-                    if (lane == 0) base = atomicAdd(&dc->aoQueueHead, (unsigned long long)LV_AO_CHUNK);
+                    if (lane == 0) base = atomicAdd(&dc->aoQueueHead, (unsigned long long)chunk);
                     chunkNext = __shfl(base, 0, 64);
-                    chunkEnd = chunkNext + LV_AO_CHUNK;
+                    chunkEnd = chunkNext + chunk;
                     if (chunkEnd > total) chunkEnd = total;
                     if (chunkNext >= total) { chunkNext = chunkEnd = total; sourceDry = true; }
                 }
@@ -2404,8 +2514,10 @@ static int lv_prepare_overflow(lv_ctx* ctx, LvSceneDev& S, uint64_t gridBlocks, 
     return LV_OK;
 }
 
+// pairColour: the colour pass' scene view when its first-hit trace rides along with the RTAO primaries of the first iteration
+// (k_primary_pair; lv_frame_render decides) -- the hits land in ctx->firstHit, *paired says whether the launch happened
 static int lv_run_ao(lv_ctx* ctx, LvUniforms& U, LvSceneDev& S, const LvTiles& Tcolour, uint32_t gridTilesColour,
-                     uint64_t maxPixelsColour) {
+                     uint64_t maxPixelsColour, const LvSceneDev* pairColour = nullptr, bool* paired = nullptr) {
     hipStream_t st = ctx->stream;
     LvDevCounters* dc = (LvDevCounters*)ctx->counters.ptr;
     const uint32_t spp = U.aoSamplesPerFrame;
@@ -2493,6 +2605,12 @@ static int lv_run_ao(lv_ctx* ctx, LvUniforms& U, LvSceneDev& S, const LvTiles& T
     // RTAO geometry: the capsules of the colour pass, or the reference's triangle tubes (own LBVH, own scene view)
     LvSceneDev SA = tri ? sceneDevTriangles(ctx) : S;
     if ((rc = lv_prepare_overflow(ctx, SA, gridMax, LV_AO_STACK_LDS, tri))) return rc;
+    // the paired launch: gridTiles + gridTilesColour workgroups share one slab (columns are indexed by the launch's global thread id);
+    // lv_frame_render reserved it for that grid and for the deeper of the two trees
+    LvSceneDev SCpair = pairColour ? *pairColour : S;
+    if (pairColour) SCpair.stackOverflow = ctx->stackOverflow.ptr ? (unsigned*)ctx->stackOverflow.ptr : nullptr;
+    LvSceneDev SApair = SA;
+    if (pairColour) SApair.stackOverflow = SCpair.stackOverflow;
     const bool stats = ctx->opt.collectStats;
     // progressive mode (num_accumulated_frames > 1): one RTAO iteration per rendered frame while frame_number <
     // ambient_occlusion_iterations (ambientOcclusionBaker->updateIterative(), LineRenderer.cpp:257-264), accumulated in ctx->ao
@@ -2536,9 +2654,21 @@ static int lv_run_ao(lv_ctx* ctx, LvUniforms& U, LvSceneDev& S, const LvTiles& T
         float4* fnOut = eaw ? (float4*)ctx->featNormalAlt.ptr : nullptr;
         const float4* fpIn = eaw ? (const float4*)ctx->featPosition.ptr : nullptr;
         float4* fpOut = eaw ? (float4*)ctx->featPositionAlt.ptr : nullptr;
+        const bool pairNow = pairColour && iter == iterBegin;
+        if (pairNow && paired) *paired = true;
+#define LV_LAUNCH_PAIR(ST, PR, BA)                                                                            \
+    LV_TIMED_LAUNCH(ctx, LV_KERNEL_AO_PRIMARY, (k_primary_pair<ST, PR, BA><<<gridTiles + gridTilesColour, LV_BLOCK, 0, st>>>( \
+            U, SApair, T, gridTiles, aoIn, ao, (float4*)ctx->aoGbuf.ptr, tileCount, dc, fnIn, fnOut, fpIn, fpOut, SF, SCpair, Tcolour, \
+            (uint2*)ctx->firstHit.ptr, size_t(maxPixelsColour))))
 #define LV_LAUNCH_AOP(ST, PR)                                                                                 \
-    LV_TIMED_LAUNCH(ctx, LV_KERNEL_AO_PRIMARY, (k_ao_primary<ST, PR><<<gridTiles, LV_BLOCK, 0, st>>>(        \
-            U, SA, T, aoIn, ao, (float4*)ctx->aoGbuf.ptr, tileCount, dc, fnIn, fnOut, fpIn, fpOut, SF)))
+    do {                                                                                                      \
+        if (pairNow && U.useHelicityBands) LV_LAUNCH_PAIR(ST, PR, LV_SHADE_HELICITY);                         \
+        else if (pairNow && U.useBands) LV_LAUNCH_PAIR(ST, PR, LV_SHADE_BANDS);                               \
+        else if (pairNow) LV_LAUNCH_PAIR(ST, PR, LV_SHADE_PLAIN);                                             \
+        else                                                                                                  \
+            LV_TIMED_LAUNCH(ctx, LV_KERNEL_AO_PRIMARY, (k_ao_primary<ST, PR><<<gridTiles, LV_BLOCK, 0, st>>>(  \
+                    U, SA, T, aoIn, ao, (float4*)ctx->aoGbuf.ptr, tileCount, dc, fnIn, fnOut, fpIn, fpOut, SF))); \
+    } while (0)
 #define LV_LAUNCH_AO(ST, AH, PR) \
     LV_TIMED_LAUNCH(ctx, LV_KERNEL_AO_RAYS, (k_ao_rays<ST, AH, PR><<<grid, LV_AO_BLOCK, 0, st>>>(U, SA, g, smp, dc, tileBase, numGroups, tileCap)))
 #define LV_LAUNCH_AO_LIT(ST, AH) \
@@ -2572,6 +2702,7 @@ static int lv_run_ao(lv_ctx* ctx, LvUniforms& U, LvSceneDev& S, const LvTiles& T
 #undef LV_LAUNCH_AO_LIT
 #undef LV_LAUNCH_AO
 #undef LV_LAUNCH_AOP
+#undef LV_LAUNCH_PAIR
         if ((spp & 3u) == 0u) {
             const uint64_t rowBlocks = (maxPixels + LV_REDUCE_ROWS - 1) / LV_REDUCE_ROWS;
             const uint64_t cap = uint64_t(ctx->numCUs) * 16u;
@@ -2723,6 +2854,16 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
     const uint32_t gridTiles = uint32_t((nb + 127u) / 128u) * 128u; // multiple of 8 XCDs x LV_XCD_GROUP (lv_block_pixel)
     const uint64_t maxPixels = uint64_t(numTiles) * tileW * tileH;
     const bool stats = ctx->opt.collectStats;
+    // overlap_primary_passes (default on): the colour pass' first-hit trace rides along with the RTAO primaries (k_primary_pair) and the
+    // colour kernel after the RTAO pass only shades.  Where it applies: the ray tracer on the analytic capsules, one sample per pixel
+    // (the first ray of a pixel is then its only first ray), the per-frame RTAO pass on the caller's tiles (SVGF covers the viewport).
+    // "auto": while the colour pass' tile kernel is at most four rounds of workgroups (16 per CU; half a 1920 x 1080 frame) -- a frame
+    // that fills the GPU several times over is throughput-bound in both passes and only pays the second shading (measured, EXPERIMENTS 13.2)
+    const bool pairWanted = ctx->opt.overlapPrimaryPasses == 1 || (ctx->opt.overlapPrimaryPasses == 2 && gridTiles <= 16u * uint32_t(ctx->numCUs));
+    const bool pairPrimaries = pairWanted && mode == LV_RENDERING_MODE_VULKAN_RAY_TRACER && U.useAmbientOcclusion &&
+                               !U.aoPrebaked && !ctx->opt.useMlat && !ctx->opt.rtTriangleMesh && !U.useEllipticTubes &&
+                               !ctx->opt.svgfEnabled && (U.useJitteredRays ? U.numSamplesPerFrame : 1u) == 1u && ctx->numSegs > 0u &&
+                               (ctx->opt.numAccumulatedFrames <= 1u || ctx->opt.frameNumber < ctx->opt.aoIterations);
     {
         // one reservation for every launch geometry of this frame (a later, larger request would free the slab under the
         // scene views built before it)
@@ -2745,6 +2886,16 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
         }
         if (aoBake)
             need = std::max(need, lv_overflow_bytes(ctx, uint64_t(ctx->numCUs) * LV_AO_BLOCKS_PER_CU, LV_AO_STACK_LDS, true));
+        if (pairPrimaries) {
+            // k_primary_pair: the RTAO primaries' workgroups and the colour rays' share one launch and one slab
+            const uint32_t haloPx = (U.aoProjectLookup ? 1u : 0u) +
+                                    ((ctx->opt.eawEnabled && ctx->opt.eawIterations) ? 2u * ((1u << ctx->opt.eawIterations) - 1u) : 0u);
+            const uint64_t tw = tileW + 2u * haloPx, th = tileH + 2u * haloPx;
+            const uint64_t nbAo = uint64_t(numTiles) * (((tw + 63u) / 64u) * 4u) * (((th + 63u) / 64u) * 4u);
+            const uint64_t gridPair = ((nbAo + 127u) / 128u) * 128u + gridTiles;
+            need = std::max(need, lv_overflow_bytes(ctx, gridPair, LV_STACK_LDS, false));
+            if (lv_ao_triangle_tubes(ctx)) need = std::max(need, lv_overflow_bytes(ctx, gridPair, LV_STACK_LDS, true));
+        }
         if (need && (rc = lv_buf_reserve(ctx, ctx->stackOverflow, need))) return rc;
     }
     LvSceneDev S = sceneDev(ctx);
@@ -2779,8 +2930,15 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
 #endif
     // ambientOcclusionBaker->updateIterative(), LineRenderer.cpp:257-264
     ctx->aoNumGroups = 0;
-    if (U.useAmbientOcclusion && !U.aoPrebaked)
-        if ((rc = lv_run_ao(ctx, U, S, T, gridTiles, maxPixels))) return rc;
+    bool firstHitsTraced = false;
+    if (U.useAmbientOcclusion && !U.aoPrebaked) {
+        LvSceneDev SP = S;
+        if (pairPrimaries) {
+            if (U.lssGeometry) SP.literalIntersection = 0u; // as the colour pass below
+            if ((rc = lv_buf_reserve(ctx, ctx->firstHit, size_t(maxPixels) * 8 * LV_PRE_HITS))) return rc;
+        }
+        if ((rc = lv_run_ao(ctx, U, S, T, gridTiles, maxPixels, pairPrimaries ? &SP : nullptr, &firstHitsTraced))) return rc;
+    }
     if (U.aoPrebaked && !ctx->bakeValid && ctx->bakeAsyncPending) {
         // a bake is running on the second stream (lv_bake_ao_start): adopt its table if it has finished; otherwise this frame is
         // rendered without ambient occlusion -- "display the AO once baking has finished" (AmbientOcclusionBaker.hpp:66-70)
@@ -2835,9 +2993,15 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
         if (tri && (rc = lv_prepare_overflow(ctx, SC, gridTiles, LV_STACK_LDS, true))) return rc;
 #define LV_LAUNCH_RT(ST, PR, BA) \
     LV_TIMED_LAUNCH(ctx, LV_KERNEL_RENDER_RT, (k_render_rt<ST, PR, BA><<<gridTiles, LV_BLOCK, 0, st>>>(U, SC, T, out, dc)))
+#define LV_LAUNCH_RT_PRE(ST, BA) \
+    LV_TIMED_LAUNCH(ctx, LV_KERNEL_RENDER_RT, (k_render_rt<ST, LV_PRIM_CAPSULE, BA, true><<<gridTiles, LV_BLOCK, 0, st>>>( \
+            U, SC, T, out, dc, (const uint2*)ctx->firstHit.ptr, size_t(maxPixels))))
 #define LV_LAUNCH_RT2(ST)                                                        \
     do {                                                                         \
-        if (tri && U.useHelicityBands) LV_LAUNCH_RT(ST, LV_PRIM_TRIANGLE, LV_SHADE_HELICITY); \
+        if (firstHitsTraced && U.useHelicityBands) LV_LAUNCH_RT_PRE(ST, LV_SHADE_HELICITY); \
+        else if (firstHitsTraced && U.useBands) LV_LAUNCH_RT_PRE(ST, LV_SHADE_BANDS); \
+        else if (firstHitsTraced) LV_LAUNCH_RT_PRE(ST, LV_SHADE_PLAIN);          \
+        else if (tri && U.useHelicityBands) LV_LAUNCH_RT(ST, LV_PRIM_TRIANGLE, LV_SHADE_HELICITY); \
         else if (tri && U.useBands) LV_LAUNCH_RT(ST, LV_PRIM_TRIANGLE, LV_SHADE_BANDS); \
         else if (tri) LV_LAUNCH_RT(ST, LV_PRIM_TRIANGLE, LV_SHADE_PLAIN);        \
         else if (U.useHelicityBands) LV_LAUNCH_RT(ST, LV_PRIM_CAPSULE, LV_SHADE_HELICITY); \
@@ -2851,6 +3015,7 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
         if (stats) LV_LAUNCH_RT2(true); else LV_LAUNCH_RT2(false);
 #endif
 #undef LV_LAUNCH_RT2
+#undef LV_LAUNCH_RT_PRE
 #undef LV_LAUNCH_RT
         }
     } else {

@@ -1113,3 +1113,41 @@ def test_kernel_timers_option(hip_lib):
     assert ctx.stats().fragments == st_all.fragments and ctx.stats().ms_ppll_resolve > 0.0
     with pytest.raises(capi.LineVisError):
         ctx.set_option("kernel_timers", "k_ao_rays")
+
+
+@pytest.mark.parametrize("settings,transparent", [
+    (dict(RTAO, ambient_occlusion_iterations=2, ambient_occlusion_samples_per_frame=8), False),
+    (dict(RTAO, ambient_occlusion_iterations=1, ambient_occlusion_samples_per_frame=8, depth_cue_strength=0.7), True),
+    (dict(RTAO, ambient_occlusion_iterations=1, ambient_occlusion_samples_per_frame=4, use_jittered_primary_rays=False,
+          ambient_occlusion_denoiser="EAW"), False),
+    (dict(RTAO, ambient_occlusion_iterations=1, ambient_occlusion_samples_per_frame=4, geometry_mode="Linear Swept Spheres"), False),
+])
+def test_overlap_primary_passes_gives_the_same_frames(hip_lib, settings, transparent):
+    """overlap_primary_passes (k_primary_pair: the colour pass' first-hit trace in one launch with the RTAO primaries, shading after the
+    RTAO pass) against the pass order of VulkanRayTracer::render: frames, tile renders and AO images byte for byte; with transparency
+    (the loop goes on tracing behind the pre-traced hit), progressive accumulation (jittered first rays + AO halo) and counters."""
+    c = small_case(width=160, height=96, transparent=transparent, **settings)
+    frames = {}
+    for on in (True, False):
+        ctx = c.hip_context()
+        ctx.set_option("overlap_primary_passes", on)
+        img = ctx.render(11)
+        ao = ctx.get_ao()
+        tile = ctx.render(11, tile=(37, 21, 70, 50))
+        ctx.set_option("collect_stats", True)
+        ctx.render(11)
+        st = ctx.stats()
+        ctx.set_option("collect_stats", False)
+        prog = []
+        ctx.set_options(dict(num_accumulated_frames=3, ambient_occlusion_iterations=2))
+        for f in range(3):
+            ctx.set_option("frame_number", f)
+            prog.append(ctx.render(11).copy())
+        frames[on] = (img, ao, tile, (st.rays_traced, st.hits_shaded, st.ao_hit_pixels), prog)
+    a, b = frames[True], frames[False]
+    assert np.array_equal(a[0], b[0]) and np.array_equal(bits(a[1]), bits(b[1])) and np.array_equal(a[2], b[2])
+    assert np.array_equal(a[2], a[0][21:71, 37:107])
+    assert a[3] == b[3] and a[3][0] > 10000
+    for x, y in zip(a[4], b[4]):
+        assert np.array_equal(x, y)
+    assert max_lsb_diff(a[0], c.oracle_render(11, use_bvh=True)[0]) <= LSB_TOL

@@ -24,6 +24,7 @@ def make():
     if mesh is not None:
         c.set_tube_triangle_mesh(*mesh)
     c.set_options(bench.WORKLOADS[wl]["settings"])
+    c.set_options(dict(kv.split("=", 1) for kv in os.environ.get("LV_PROBE_SET", "").split(",") if kv))   # e.g. overlap_primary_passes=false
     c.build_accel()
     return c
 
@@ -57,7 +58,8 @@ report = {"workload": wl, "what": "per-rank frame time (ms) on ONE MI355X render
           "is not included (unmeasured on hardware: no multi-GPU node)", "worlds": {}}
 t1, k1 = time_tiles(all_tiles, 1)
 report["one_gpu_ms"] = round(t1, 4)
-report["one_gpu_two_frames_in_flight_ms"] = round(time_tiles(all_tiles, 2)[0], 4)
+if max(DEPTHS) >= 2:
+    report["one_gpu_two_frames_in_flight_ms"] = round(time_tiles(all_tiles, 2)[0], 4)
 for world in [int(x) for x in os.environ.get("LV_PROBE_WORLDS", "2,4,8").split(",")]:
     row = {}
     for name, parts in (("round_robin", [np.arange(r, len(all_tiles), world) for r in range(world)]),
@@ -71,4 +73,5 @@ for world in [int(x) for x in os.environ.get("LV_PROBE_WORLDS", "2,4,8").split("
             print(world, key, row[key], flush=True)
     report["worlds"][str(world)] = row
 os.makedirs(os.path.join(R, "gpurun_out"), exist_ok=True)
-json.dump(report, open(os.path.join(R, "gpurun_out", "shard_probe_%s.json" % wl), "w"), indent=1)
+report["settings_override"] = os.environ.get("LV_PROBE_SET", "")
+json.dump(report, open(os.path.join(R, "gpurun_out", "shard_probe_%s%s.json" % (wl, os.environ.get("LV_PROBE_TAG", ""))), "w"), indent=1)
