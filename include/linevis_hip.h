@@ -244,6 +244,13 @@ int lv_set_background(lv_ctx* ctx, const float rgba[4]);
  *   record costs the stream 2 - 4 us: a frame with every kernel and phase bracketed carries a dozen (6 % of a 0.8-ms PPLL frame),
  *   triangle_leaf_size (build-owned): consecutive triangles per leaf of the triangle LBVH, 1 ... 8 (default 2: a tube face);
  *   changes the acceleration structure only, never a hit,
+ *   shading_numerics (build-owned): "exact" (default: every operation of the shading code in IEEE float32 with one fixed evaluation
+ *   order -- frames, AO factors and PPLL fragments are bit-identical to the CPU checker's) | "fast": the hardware's approximate
+ *   reciprocal square root / reciprocal / log2 / exp2 (<= 1 ulp) in arithmetic that only reaches a COLOUR -- the normalisations,
+ *   pow() and divisions of blinnPhongShadingTube (Lighting.glsl:100-191) and, in the raster colour of plain tubes, of the halo
+ *   coordinate (LinePassGeometryShaderTubes.glsl:732-1129).  Hits, coverage, fragment depths, alpha values, list lengths and the
+ *   RTAO factors stay bit-identical; colours move by <= 1 LSB, the contract is +- 2 LSB.  Applies to the ray tracer's capsule colour
+ *   pass and the rasterised prism's fragment stage of plain flow lines; all other variants keep the exact arithmetic,
  *   overlap_primary_passes (build-owned; "auto" (default) | "true" | "false"): in a ray-tracer frame with per-frame RTAO the closest hits of the colour
  *   pass' rays do not depend on the AO image, only their shading does -- they are traced in ONE launch with the RTAO pass' primary
  *   rays (two latency-bound passes that a rank owning 1/8 of the tiles cannot fill the GPU with one after the other) and the colour

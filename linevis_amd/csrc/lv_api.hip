@@ -638,6 +638,10 @@ int lv_set_option(lv_ctx* ctx, const char* key, const char* value) {
         o.useCappedTubes = parseBool(value);
     } else if (k == "use_halos") {
         o.useHalos = parseBool(value);
+    } else if (k == "shading_numerics") {
+        if (strcmp(value, "fast") == 0) o.fastShading = true;
+        else if (strcmp(value, "exact") == 0) o.fastShading = false;
+        else return bad();
     } else if (k == "overlap_primary_passes") {
         o.overlapPrimaryPasses = strcmp(value, "auto") == 0 ? 2 : (parseBool(value) ? 1 : 0);
     } else if (k == "tube_num_subdivisions") {

@@ -451,6 +451,26 @@ __device__ __forceinline__ f3 norm3s(f3 a) { const float r = lv_rsqrt_shade_refe
 __device__ __forceinline__ f3 norm3s(f3 a) { const float r = lv_rsqrt_shade(dot3(a, a)); return mk3(a.x * r, a.y * r, a.z * r); }
 #endif
 
+// shading_numerics = fast (round 6): the hardware's approximate reciprocal square root / reciprocal / log2 / exp2 (v_rsq_f32, v_rcp_f32,
+// v_log_f32, v_exp_f32: <= 1 ulp each) in arithmetic that only ever reaches a COLOUR -- the lighting's normalisations, pow() and
+// divisions.  Nothing that decides a hit, a coverage bit, a fragment's depth, its alpha or the length of a list goes through these
+// (template parameter FAST of the shading routines: 0 = exact, 1 = lighting only, 2 = also the halo coordinate where it cannot reach
+// alpha: the raster colour of plain tubes).  Frames then differ from the exact ones in the last bit of a few channels; the contract is
+// +- 2 LSB (tests: whole C2 / C3 / C4 frames against the exact oracle, profiles/deviations_r06.json).
+__device__ __forceinline__ float lv_rsqrt_fast(float x) { return __builtin_amdgcn_rsqf(fminf(fmaxf(x, LV_RSQRT_LO), LV_RSQRT_HI)); }
+__device__ __forceinline__ f3 norm3f(f3 a) { const float r = lv_rsqrt_fast(dot3(a, a)); return mk3(a.x * r, a.y * r, a.z * r); }
+template <bool FASTN>
+__device__ __forceinline__ f3 norm3q(f3 a) { return FASTN ? norm3f(a) : norm3s(a); }
+__device__ __forceinline__ float lv_div_fast(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+template <bool FASTN>
+__device__ __forceinline__ float lv_divq(float a, float b) { return FASTN ? lv_div_fast(a, b) : a / b; }
+__device__ __forceinline__ float lv_pow_fast(float x, float y) {
+    if (!(x > 1.17549435e-38f)) return y > 0.0f ? 0.0f : (y == 0.0f ? 1.0f : __builtin_inff());   // the same rule as lv_pow_det
+    return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x));
+}
+template <bool FASTN>
+__device__ __forceinline__ float lv_powq(float x, float y) { return FASTN ? lv_pow_fast(x, y) : lv_pow_det(x, y); }
+
 // ---------------------------------------------------------------- wave helpers (wave64)
 __device__ __forceinline__ unsigned lv_lane() { return __lane_id(); }
 __device__ __forceinline__ unsigned long long lv_wave_sum_u64(unsigned long long v) {

@@ -50,6 +50,7 @@ struct LvOptions {
     bool collapseTop = true;                  // accel_collapse_top: the levels of the wide tree with <= 1024 nodes in one launch (k_collapse_top)
     bool treeletPlaneScan = true;             // treelet_plane_eval = scan (DPP prefix / suffix scans over the bins) | loop (round-3 form)
     bool accelFastTrace = true;               // accel_build = fast_trace (LBVH + SAH treelets, the reference's PREFER_FAST_TRACE) | fast_build (LBVH)
+    bool fastShading = false;                 // shading_numerics = fast: approximate hardware rsq / rcp / log2 / exp2 in colour-only arithmetic (lv_device.h)
     int overlapPrimaryPasses = 2;             // overlap_primary_passes: 0 = false, 1 = true, 2 = auto -- the colour pass' hit traces in one launch with the RTAO primaries (k_primary_pair)
     bool dispatchByCost = true;               // dispatch_order = cost | as_numbered (tile kernels: heaviest 64x64 group of the last frame first)
     bool aoJitterPrimary = true;              // :153

@@ -167,8 +167,9 @@ __device__ __forceinline__ bool lv_prism_tri_edges(const LvPrismDev& R, const Lv
                     lv_prism_inside(e[2], T.id[0] < T.id[1]);
     return in && (e[0] + e[1]) + e[2] > 0.0f;
 }
+template <bool FASTN = false>
 __device__ __forceinline__ void lv_prism_weights(const float e[3], float b[3]) {
-    const float rs = 1.0f / ((e[0] + e[1]) + e[2]);
+    const float rs = FASTN ? __builtin_amdgcn_rcpf((e[0] + e[1]) + e[2]) : 1.0f / ((e[0] + e[1]) + e[2]);
     b[0] = e[0] * rs; b[1] = e[1] * rs; b[2] = e[2] * rs;
 }
 __device__ __forceinline__ f3 lv_prism_mix3(const float b[3], f3 a0, f3 a1, f3 a2) { return (b[0] * a0 + b[1] * a1) + b[2] * a2; }
@@ -266,14 +267,15 @@ __device__ __forceinline__ unsigned lv_prism_coverage(const LvSceneDev& S, float
 }
 
 // the raster shader's ribbonPosition of interpolated inputs (no bands, no caps), LinePassGeometryShaderTubes.glsl:771-777,944-963
+template <bool FASTN = false>
 __device__ __forceinline__ float lv_prism_ribbon(f3 cam, f3 fragPos, f3 fragmentNormal, f3 fragmentTangent) {
-    const f3 n = norm3s(fragmentNormal);
-    const f3 v = norm3s(cam - fragPos);
-    const f3 t = norm3s(fragmentTangent);
-    const f3 helperVec = norm3s(cross3(t, v));
-    const f3 newV = norm3s(cross3(helperVec, t));
+    const f3 n = norm3q<FASTN>(fragmentNormal);
+    const f3 v = norm3q<FASTN>(cam - fragPos);
+    const f3 t = norm3q<FASTN>(fragmentTangent);
+    const f3 helperVec = norm3q<FASTN>(cross3(t, v));
+    const f3 newV = norm3q<FASTN>(cross3(helperVec, t));
     const f3 crossProdVn = cross3(newV, n);
-    float ribbonPosition = len3(crossProdVn);
+    float ribbonPosition = FASTN ? __builtin_amdgcn_sqrtf(dot3(crossProdVn, crossProdVn)) : len3(crossProdVn);
     if (dot3(t, crossProdVn) < 0.0f) ribbonPosition = -ribbonPosition;
     return clampf(ribbonPosition, -1.0f, 1.0f);
 }
@@ -298,12 +300,13 @@ __device__ __forceinline__ LvPrismPlanes lv_prism_planes(const LvPrismDev& R, co
 }
 // interpolated inputs of the fragment stage for the ray direction D (helper invocations: weights outside [0, 1])
 struct LvPrismInputs { f3 pos, nrm, tan; float attr; float b[3]; };
+template <bool FASTN = false>   // FASTN: the quad partners' inputs (they only feed fwidth of the halo coordinate)
 __device__ __forceinline__ LvPrismInputs lv_prism_interpolate(const LvPrismTri& T, const f3 nrm[3], const LvPrismPlanes& pl, f3 Dr) {
     const f3 abg = mk3(lv_prism_dot(Dr, pl.P), lv_prism_dot(Dr, pl.Q), lv_prism_dot(Dr, pl.D));
     const float e[3] = {lv_prism_dot(abg, pl.c0), lv_prism_dot(abg, pl.c1), lv_prism_dot(abg, pl.c2)};
     LvPrismInputs I;
     float* b = I.b;
-    lv_prism_weights(e, b);
+    lv_prism_weights<FASTN>(e, b);
     I.pos = lv_prism_mix3(b, T.pos[0], T.pos[1], T.pos[2]);
     I.nrm = lv_prism_mix3(b, nrm[0], nrm[1], nrm[2]);
     I.tan = lv_prism_mix3(b, T.tan[0], T.tan[1], T.tan[2]);

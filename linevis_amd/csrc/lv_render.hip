@@ -34,7 +34,7 @@ namespace {
 // same frame, byte for byte: which hit follows which depends on the alpha of the shaded hit, and alpha (transfer function x silhouette
 // coverage) does not depend on the ambient occlusion.
 #define LV_PRE_HITS 4u
-template <bool STATS, int PRIM, int BANDS = LV_SHADE_PLAIN, bool PRE = false>
+template <bool STATS, int PRIM, int BANDS = LV_SHADE_PLAIN, bool PRE = false, int FAST = 0>
 __global__ __launch_bounds__(LV_BLOCK, (STATS || PRIM == LV_PRIM_ELLIPTIC) ? 1 : LV_RT_MIN_WAVES) void k_render_rt(const LvUniforms U, const LvSceneDev S, const LvTiles T,
                                                         uint32_t* __restrict__ out, LvDevCounters* dc,
                                                         const uint2* __restrict__ firstHit = nullptr, const size_t firstHitStride = 0) {
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(LV_BLOCK, (STATS || PRIM == LV_PRIM_ELLIPTIC) ? 1 :
                 if (h.found) {
                     hc = PRIM == LV_PRIM_TRIANGLE   ? lv_shade_hit_triangle<BANDS>(S, U, aoTexel, o, d, h.leaf, payloadHitT)
                          : PRIM == LV_PRIM_ELLIPTIC ? lv_shade_hit_elliptic(S, U, aoTexel, o, d, h, payloadHitT)
-                                                    : lv_shade_hit<BANDS>(S, U, aoTexel, o, d, h, payloadHitT);
+                                                    : lv_shade_hit<BANDS, FAST>(S, U, aoTexel, o, d, h, payloadHitT);
                     if (STATS) cnt.hits++;
                 } else { // Miss, TubeRayTracing.glsl:290-297
                     hc.x = U.background[0]; hc.y = U.background[1]; hc.z = U.background[2]; hc.w = U.background[3];
@@ -1181,7 +1181,7 @@ __device__ __forceinline__ uint32_t lv_run_start(const uint32_t* __restrict__ st
 // array, so that every pixel's fragments form one contiguous run in the order the coverage kernel met them.  A fragment the shader
 // discards (alpha < 0.001, :34) or the `kept` rules reject leaves a DEAD entry {0, LV_PPLL_DEAD} that the resolve pass steps over,
 // and is counted in the upper 16 bits of the pixel's count word.  No atomics on the pool, none per kept fragment.
-template <bool STATS, int SHADE = LV_SHADE_PLAIN>
+template <bool STATS, int SHADE = LV_SHADE_PLAIN, int FAST = 0>
 __global__ __launch_bounds__(LV_BLOCK, LV_PRISM_SHADE_MIN_WAVES) void k_ppll_shade_prism(const LvUniforms U, const LvSceneDev S,
                                                                    const uint32_t* __restrict__ records, uint2* __restrict__ frags,
                                                                    const uint32_t* __restrict__ pixelOffset,
@@ -1217,7 +1217,7 @@ __global__ __launch_bounds__(LV_BLOCK, LV_PRISM_SHADE_MIN_WAVES) void k_ppll_sha
         const LvRasterQuad rq = lv_make_raster_quad(U, px, py);
         bool kept;
         float depth;
-        const f4 color = lv_shade_prism<SHADE>(S, U, s_prismRing, aoTexel, o, d, tLo, tHi, leaf, tt, rq, U.ppllRasterColour != 0u, depth, kept);
+        const f4 color = lv_shade_prism<SHADE, FAST>(S, U, s_prismRing, aoTexel, o, d, tLo, tHi, leaf, tt, rq, U.ppllRasterColour != 0u, depth, kept);
         if (STATS && kept) hits++;
         const uint32_t addr = lv_ppll_addr(px, py, U.ppllPaddedW, U.ppllTileW, U.ppllTileH);
         const size_t dst = size_t(lv_run_start(pixelOffset, blockBase, addr)) + rank;
@@ -2998,7 +2998,13 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
             U, SC, T, out, dc, (const uint2*)ctx->firstHit.ptr, size_t(maxPixels))))
 #define LV_LAUNCH_RT2(ST)                                                        \
     do {                                                                         \
-        if (firstHitsTraced && U.useHelicityBands) LV_LAUNCH_RT_PRE(ST, LV_SHADE_HELICITY); \
+        if (fastPlain && firstHitsTraced)                                        \
+            LV_TIMED_LAUNCH(ctx, LV_KERNEL_RENDER_RT, (k_render_rt<false, LV_PRIM_CAPSULE, LV_SHADE_PLAIN, true, 1><<<gridTiles, LV_BLOCK, 0, st>>>( \
+                    U, SC, T, out, dc, (const uint2*)ctx->firstHit.ptr, size_t(maxPixels)))); \
+        else if (fastPlain)                                                      \
+            LV_TIMED_LAUNCH(ctx, LV_KERNEL_RENDER_RT, (k_render_rt<false, LV_PRIM_CAPSULE, LV_SHADE_PLAIN, false, 1><<<gridTiles, LV_BLOCK, 0, st>>>( \
+                    U, SC, T, out, dc)));                                        \
+        else if (firstHitsTraced && U.useHelicityBands) LV_LAUNCH_RT_PRE(ST, LV_SHADE_HELICITY); \
         else if (firstHitsTraced && U.useBands) LV_LAUNCH_RT_PRE(ST, LV_SHADE_BANDS); \
         else if (firstHitsTraced) LV_LAUNCH_RT_PRE(ST, LV_SHADE_PLAIN);          \
         else if (tri && U.useHelicityBands) LV_LAUNCH_RT(ST, LV_PRIM_TRIANGLE, LV_SHADE_HELICITY); \
@@ -3009,6 +3015,8 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
         else if (U.useBands) LV_LAUNCH_RT(ST, LV_PRIM_CAPSULE, LV_SHADE_BANDS);  \
         else LV_LAUNCH_RT(ST, LV_PRIM_CAPSULE, LV_SHADE_PLAIN);                  \
     } while (0)
+        // shading_numerics = fast: the capsule colour pass of plain flow lines (lighting through the approximate operations, FAST = 1)
+        const bool fastPlain = ctx->opt.fastShading && !stats && !tri && !U.useHelicityBands && !U.useEllipticTubes && !U.useBands;
 #ifdef LV_PROBE_OVERLAP
         LV_HIP(ctx, hipStreamWaitEvent(st, evB, 0));
 #else
@@ -3133,7 +3141,13 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
     LV_TIMED_LAUNCH(ctx, LV_KERNEL_PPLL_SHADE, (k_ppll_shade_prism<ST><<<shadeGrid, LV_BLOCK, 0, st>>>(                         \
             U, S, (const uint32_t*)ctx->prismRecords.ptr, (uint2*)ctx->ppllNodes.ptr, (const uint32_t*)ctx->ppllStart.ptr,      \
             blockBase, (uint32_t*)ctx->ppllCount.ptr, dc, poolSlots)))
-            if (stats) LV_LAUNCH_SHADE(true); else LV_LAUNCH_SHADE(false);
+            // shading_numerics = fast: the plain-tube fragment stage with the raster colour (the only variant whose alpha cannot follow
+            // the halo coordinate); every other variant keeps the exact arithmetic
+            if (ctx->opt.fastShading && !stats && !S.prism.bands && !U.useHelicityBands && U.ppllRasterColour)
+                LV_TIMED_LAUNCH(ctx, LV_KERNEL_PPLL_SHADE, (k_ppll_shade_prism<false, LV_SHADE_PLAIN, 2><<<shadeGrid, LV_BLOCK, 0, st>>>(
+                        U, S, (const uint32_t*)ctx->prismRecords.ptr, (uint2*)ctx->ppllNodes.ptr, (const uint32_t*)ctx->ppllStart.ptr,
+                        blockBase, (uint32_t*)ctx->ppllCount.ptr, dc, poolSlots)));
+            else if (stats) LV_LAUNCH_SHADE(true); else LV_LAUNCH_SHADE(false);
 #undef LV_LAUNCH_SHADE
             // the listed pixels: their nearest ppllMaxNumFrags fragments to the front of the run
             k_ppll_select_nearest<<<uint32_t(ctx->numCUs) * 16u, LV_WAVE, 0, st>>>(

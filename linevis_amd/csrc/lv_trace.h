@@ -1256,7 +1256,7 @@ __device__ __forceinline__ float lv_bands_ribbon_of_ray(f3 cam, f3 d, f3 linePos
     return lv_bands_ribbon_of_point(cam, linePosition, lineNormal, fragmentTangent, t,
                                     mk3(dot3(lineN, wq) / lineRadius, dot3(lineB, wq) / lineRadius, 1.0f), lineRadius, thickness);
 }
-template <int BANDS>
+template <int BANDS, int FAST = 0>
 __device__ __forceinline__ f4 lv_compute_fragment_color_t(const LvSceneDev& S, const LvUniforms& U, float aoTexel, f3 fragPos,
                                                           f3 fragmentNormal, f3 fragmentTangent, bool isCap,
                                                           float fragmentAttribute, float& payloadHitT, const LvBandArgs& bands);
@@ -1299,7 +1299,7 @@ __device__ __forceinline__ float lv_prebaked_ao_lookup(const LvSceneDev& S, cons
 // ClosestHitTubeAnalytic + computeFragmentColor + blinnPhongShadingTube for flow lines.
 // aoTexel: AO factor of the pixel that launched the ray (lookup definition: DESIGN.md).  Returns payload.hitColor;
 // payloadHitT = length(hit - camera).
-template <int BANDS = LV_SHADE_PLAIN>
+template <int BANDS = LV_SHADE_PLAIN, int FAST = 0>   // FAST: 0 | 1 (lighting only: the ray tracer's alpha follows the halo coordinate)
 __device__ __forceinline__ f4 lv_shade_hit(const LvSceneDev& S, const LvUniforms& U, float aoTexel, f3 o, f3 d,
                                            const LvHit& h, float& payloadHitT, bool raster = false, LvRasterQuad rqv = LvRasterQuad(),
                                            bool rasterApply = true) {
@@ -1416,8 +1416,8 @@ __device__ __forceinline__ f4 lv_shade_hit(const LvSceneDev& S, const LvUniforms
     LvBandArgs none;
     none.useBand = false; none.phi = 0.0f; none.linePosition = mk3(0.0f, 0.0f, 0.0f); none.lineNormal = mk3(0.0f, 0.0f, 0.0f);
     none.rotation = 0.0f; none.separatorScale = 1.0f; none.rasterEpsWhite = rasterEps;
-    return lv_compute_fragment_color_t<LV_SHADE_PLAIN>(S, U, aoTexel, fragPos, fragmentNormal, fragmentTangent, isCap, fragmentAttribute,
-                                                       payloadHitT, none);
+    return lv_compute_fragment_color_t<LV_SHADE_PLAIN, FAST>(S, U, aoTexel, fragPos, fragmentNormal, fragmentTangent, isCap, fragmentAttribute,
+                                                             payloadHitT, none);
 }
 
 // Fragment stage of the rasterised programmable-pull prism (ppll_fragment_source = raster_prism; lv_prism.h):
@@ -1437,10 +1437,14 @@ __device__ __forceinline__ float lv_prism_band_ribbon(const LvPrismDev& R, f3 ca
     return lv_bands_ribbon_of_point(cam, lv_prism_mix3(I.b, c0, c1, c2), lv_prism_mix3(I.b, n0, n1, n2), I.tan, norm3s(I.tan),
                                     mk3(R.thickness * cp, sp, 1.0f), R.radius, R.thickness);
 }
-template <int SHADE = LV_SHADE_PLAIN>
+// FAST = 2 (plain tubes with the raster colour only; the caller checks): vertex normals, the quad partners' inputs, the three halo
+// coordinates and the whole colour through the approximate operations; the own ray's weights, position, attribute, depth and the
+// acceptance rules stay exact -- the fragment's {depth, alpha, kept} are bit for bit those of the exact mode
+template <int SHADE = LV_SHADE_PLAIN, int FAST = 0>
 __device__ __forceinline__ f4 lv_shade_prism(const LvSceneDev& S, const LvUniforms& U, const float* ringTab, float aoTexel, f3 o, f3 d,
                                              float tLo, float tHi, uint32_t leaf, uint32_t tt, const LvRasterQuad& rq, bool rasterApply,
                                              float& payloadHitT, bool& kept) {
+    constexpr bool FH = FAST >= 2 && SHADE == LV_SHADE_PLAIN;
     const LvPrismDev& R = S.prism;
     uint32_t pi[2];
     LvPrismPoint pt[2];
@@ -1448,7 +1452,7 @@ __device__ __forceinline__ f4 lv_shade_prism(const LvSceneDev& S, const LvUnifor
     const LvPrismTri T = lv_prism_tri_setup(ringTab, R.n, pt, pi, R.radius, tt);
     f3 nrm[3];
 #pragma unroll
-    for (int i = 0; i < 3; i++) nrm[i] = norm3s(T.dir[i]);   // vertexNormal = normalize(tangentFrameMatrix * localNormal), :177
+    for (int i = 0; i < 3; i++) nrm[i] = norm3q<FH>(T.dir[i]);   // vertexNormal = normalize(tangentFrameMatrix * localNormal), :177
     const f3 cam = mk3(U.camPos[0], U.camPos[1], U.camPos[2]);
     const LvPrismPlanes pl = lv_prism_planes(R, T, cam, d);   // (o == cam: the pixel's viewing ray starts at the camera)
     const LvPrismInputs I = lv_prism_interpolate(T, nrm, pl, d);
@@ -1475,10 +1479,10 @@ __device__ __forceinline__ f4 lv_shade_prism(const LvSceneDev& S, const LvUnifor
         lv_prism_ao_inputs(T, pt, pi, I.b, R.n, fragmentVertexId, phi);
         aoTexel = lv_prebaked_ao_lookup(S, U, fragmentVertexId, phi);
     }
-    const LvPrismInputs Ix = lv_prism_interpolate(T, nrm, pl, rq.dX), Iy = lv_prism_interpolate(T, nrm, pl, rq.dY);
-    const float f0 = lv_prism_ribbon(cam, I.pos, I.nrm, I.tan);
-    const float fx = lv_prism_ribbon(cam, Ix.pos, Ix.nrm, Ix.tan);
-    const float fy = lv_prism_ribbon(cam, Iy.pos, Iy.nrm, Iy.tan);
+    const LvPrismInputs Ix = lv_prism_interpolate<FH>(T, nrm, pl, rq.dX), Iy = lv_prism_interpolate<FH>(T, nrm, pl, rq.dY);
+    const float f0 = lv_prism_ribbon<FH>(cam, I.pos, I.nrm, I.tan);
+    const float fx = lv_prism_ribbon<FH>(cam, Ix.pos, Ix.nrm, Ix.tan);
+    const float fy = lv_prism_ribbon<FH>(cam, Iy.pos, Iy.nrm, Iy.tan);
     LvBandArgs none;
     none.useBand = false; none.phi = 0.0f; none.linePosition = mk3(0.0f, 0.0f, 0.0f); none.lineNormal = mk3(0.0f, 0.0f, 0.0f);
     none.rotation = 0.0f; none.separatorScale = 1.0f;
@@ -1519,7 +1523,7 @@ __device__ __forceinline__ f4 lv_shade_prism(const LvSceneDev& S, const LvUnifor
         }
         return lv_compute_fragment_color_t<LV_SHADE_HELICITY>(S, U, aoTexel, I.pos, I.nrm, I.tan, false, I.attr, payloadHitT, none);
     }
-    return lv_compute_fragment_color_t<LV_SHADE_PLAIN>(S, U, aoTexel, I.pos, I.nrm, I.tan, false, I.attr, payloadHitT, none);
+    return lv_compute_fragment_color_t<LV_SHADE_PLAIN, FH ? 2 : 0>(S, U, aoTexel, I.pos, I.nrm, I.tan, false, I.attr, payloadHitT, none);
 }
 
 // ClosestHitEllipticTubeAnalytic main(), EllipticTubeRayTracing.glsl:303-441: position in the tubelet frame -> t, phi, rho ->
@@ -1705,17 +1709,22 @@ __device__ __forceinline__ f4 lv_shade_hit_triangle(const LvSceneDev& S, const L
 }
 
 // computeFragmentColor (RayHitCommon.glsl:74-543) for tubes, shared by the analytic and the triangle closest-hit paths
-template <int BANDS>
+// FAST (shading_numerics = fast, lv_device.h): 1 = the lighting (blinnPhongShadingTube, the AO mapping, the depth cue, the white halo's
+// blend weight) through the approximate hardware operations, the halo coordinate and everything else that reaches alpha exact;
+// 2 = the halo coordinate too -- only where alpha cannot depend on it: the raster colour of plain tubes (EPSILON_OUTLINE = 0 and
+// |ribbonPosition| <= 1 by its clamp: coverage is 1 whatever the last bits say)
+template <int BANDS, int FAST>
 __device__ __forceinline__ f4 lv_compute_fragment_color_t(const LvSceneDev& S, const LvUniforms& U, float aoTexel, f3 fragPos,
                                                           f3 fragmentNormal, f3 fragmentTangent, bool isCap,
                                                           float fragmentAttribute, float& payloadHitT, const LvBandArgs& bands) {
+    constexpr bool FL = FAST >= 1, FH = FAST >= 2;
     const f3 cam = mk3(U.camPos[0], U.camPos[1], U.camPos[2]);
     f4 fragmentColor = lv_transfer_function(S, U, fragmentAttribute);
-    f3 n = norm3s(fragmentNormal);
-    f3 vv = norm3s(cam - fragPos);
-    f3 t = norm3s(fragmentTangent);
-    f3 helperVec = norm3s(cross3(t, vv));
-    f3 newV = norm3s(cross3(helperVec, t));
+    f3 n = norm3q<FH>(fragmentNormal);
+    f3 vv = norm3q<FH>(cam - fragPos);
+    f3 t = norm3q<FH>(fragmentTangent);
+    f3 helperVec = norm3q<FH>(cross3(t, vv));
+    f3 newV = norm3q<FH>(cross3(helperVec, t));
 
     float ribbonPosition = 0.0f;
     if (U.useHalos) {
@@ -1740,7 +1749,7 @@ __device__ __forceinline__ f4 lv_compute_fragment_color_t(const LvSceneDev& S, c
                                                       (bands.useBand ? U.bandWidth : U.lineWidth) * 0.5f, thickness);
         } else {
             f3 crossProdVn = cross3(newV, n);
-            ribbonPosition = len3(crossProdVn);
+            ribbonPosition = FH ? __builtin_amdgcn_sqrtf(dot3(crossProdVn, crossProdVn)) : len3(crossProdVn);
             if (dot3(t, crossProdVn) < 0.0f) ribbonPosition = -ribbonPosition;
             ribbonPosition = clampf(ribbonPosition, -1.0f, 1.0f);
         }
@@ -1770,7 +1779,7 @@ __device__ __forceinline__ f4 lv_compute_fragment_color_t(const LvSceneDev& S, c
             const float bot = S.ao[size_t(yb) * U.width + xa] * (1.0f - wx) + S.ao[size_t(yb) * U.width + xb] * wx;
             aoTexel = top * (1.0f - wy) + bot * wy;
         }
-        float a = lv_pow_det(aoTexel, U.aoGamma);
+        float a = lv_powq<FL>(aoTexel, U.aoGamma);
         aoF = fmaxf(0.0f, (1.0f - U.aoStrength) + U.aoStrength * a);
         kA = 0.2f + (1.0f - aoF) * 0.5f;
         kD = 0.9f * aoF;
@@ -1779,17 +1788,17 @@ __device__ __forceinline__ f4 lv_compute_fragment_color_t(const LvSceneDev& S, c
         kD = 0.9f;
     }
     // blinnPhongShadingTube re-normalises its (already unit) arguments, Lighting.glsl:149-151
-    const f3 nB = norm3s(n);
-    const f3 tB = norm3s(t);
+    const f3 nB = norm3q<FL>(n);
+    const f3 tB = norm3q<FL>(t);
     f3 l = vv;
-    f3 hh = norm3s(vv + l);
-    f3 helperVecL = norm3s(cross3(tB, l));
-    f3 newL = norm3s(cross3(helperVecL, tB));
+    f3 hh = norm3q<FL>(vv + l);
+    f3 helperVecL = norm3q<FL>(cross3(tB, l));
+    f3 newL = norm3q<FL>(cross3(helperVecL, tB));
     const float exponent = (BANDS == LV_SHADE_BANDS && bands.useBand) ? 1.0f : 1.7f; // Lighting.glsl:158-162
-    float cosNormal1 = lv_pow_det(clampf(fabsf(dot3(nB, l)), 0.0f, 1.0f), exponent);
-    float cosNormal2 = lv_pow_det(clampf(fabsf(dot3(nB, newL)), 0.0f, 1.0f), exponent);
+    float cosNormal1 = lv_powq<FL>(clampf(fabsf(dot3(nB, l)), 0.0f, 1.0f), exponent);
+    float cosNormal2 = lv_powq<FL>(clampf(fabsf(dot3(nB, newL)), 0.0f, 1.0f), exponent);
     float cosNormalCombined = 0.3f * cosNormal1 + 0.7f * cosNormal2;
-    float spec = kS * lv_pow_det(clampf(fabsf(dot3(nB, hh)), 0.0f, 1.0f), s);
+    float spec = kS * lv_powq<FL>(clampf(fabsf(dot3(nB, hh)), 0.0f, 1.0f), s);
     float base[3] = {fragmentColor.x, fragmentColor.y, fragmentColor.z};
     float phong[3];
 #pragma unroll
@@ -1806,16 +1815,17 @@ __device__ __forceinline__ f4 lv_compute_fragment_color_t(const LvSceneDev& S, c
     if (U.useDepthCues) {
         f4 s4 = mulM4(U.view, fragPos.x, fragPos.y, fragPos.z, 1.0f);
         float minDepth = S.depthMinMax[0], maxDepth = S.depthMinMax[1];
-        float dcf = clampf((-s4.z - minDepth) / (maxDepth - minDepth), 0.0f, 1.0f);
+        float dcf = clampf(lv_divq<FL>(-s4.z - minDepth, maxDepth - minDepth), 0.0f, 1.0f);
         dcf = (dcf * dcf) * U.depthCueStrength;
 #pragma unroll
         for (int k = 0; k < 3; k++) phong[k] = mixf(phong[k], 0.5f, dcf);
     }
 
     float absCoords = U.useHalos ? fabsf(ribbonPosition) : 0.0f;
-    float fragmentDepth = len3(fragPos - cam);
-    float aaO = ((fragmentDepth / U.lineWidth) * 0.05f) / float(U.height) * U.fovY;
-    float aaW = ((fragmentDepth / U.lineWidth) * 2.0f) / float(U.height) * U.fovY;
+    float fragmentDepth = len3(fragPos - cam);   // (= payloadHitT: exact in every mode)
+    // EPSILON_OUTLINE shapes the coverage, i.e. alpha: exact unless the raster variant replaces it by 0 anyway (FAST == 2)
+    float aaO = lv_divq<FH>(lv_divq<FH>(fragmentDepth, U.lineWidth) * 0.05f, float(U.height)) * U.fovY;
+    float aaW = lv_divq<FL>(lv_divq<FL>(fragmentDepth, U.lineWidth) * 2.0f, float(U.height)) * U.fovY;
     if (BANDS == LV_SHADE_BANDS) { // RayHitCommon.glsl:445-448
         const float wdt = bands.useBand ? U.bandWidth : U.lineWidth;
         aaO = aaW = ((fragmentDepth / wdt) * 0.25f) / float(U.height) * U.fovY;
@@ -1858,7 +1868,15 @@ __device__ __forceinline__ f4 lv_compute_fragment_color_t(const LvSceneDev& S, c
     }
     float coverage = U.useHalos ? 1.0f - smoothstepf(1.0f - EPSILON_OUTLINE, 1.0f, absCoords) : 1.0f;
     if (BANDS == LV_SHADE_BANDS && bands.useBand && U.useEllipticTubes) coverage = 1.0f; // ANALYTIC_ELLIPTIC_TUBE_INTERSECTIONS, :499-504
-    float w = smoothstepf(WHITE_THRESHOLD - EPSILON_WHITE, WHITE_THRESHOLD + EPSILON_WHITE, absCoords);
+    float w;   // the white halo's blend weight: colour only
+    if (FL) {
+        const float e0 = WHITE_THRESHOLD - EPSILON_WHITE, e1 = WHITE_THRESHOLD + EPSILON_WHITE;
+        // (e1 == e0, i.e. EPSILON_WHITE == 0, keeps the exact form: its 0 / 0 and x / 0 cases are what the shader relies on)
+        const float tw = e1 > e0 ? clampf(lv_div_fast(absCoords - e0, e1 - e0), 0.0f, 1.0f) : clampf((absCoords - e0) / (e1 - e0), 0.0f, 1.0f);
+        w = tw * tw * (3.0f - 2.0f * tw);
+    } else {
+        w = smoothstepf(WHITE_THRESHOLD - EPSILON_WHITE, WHITE_THRESHOLD + EPSILON_WHITE, absCoords);
+    }
     f4 out;
     out.x = mixf(phong[0], U.foreground[0], w);
     out.y = mixf(phong[1], U.foreground[1], w);

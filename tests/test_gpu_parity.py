@@ -9,7 +9,7 @@ import os
 import numpy as np
 import pytest
 
-from common import GOLDEN_DIR, Case, small_case, max_lsb_diff, scene_arrays
+from common import GOLDEN_DIR, ROOT, Case, small_case, max_lsb_diff, scene_arrays
 from linevis_amd import capi, host_api, scenes, tiling, transfer_function as tfm
 from oracle import lvo
 
@@ -586,6 +586,26 @@ def test_headless_renderer_plugins(hip_lib):
 
 
 # ---------------------------------------------------------------- full-size properties (BASELINE.json config 3)
+def _fast_shading_deviation(name, exact_frame, fast_frame, ref):
+    """shading_numerics = fast against the exact oracle frame `ref` (the gate: <= 2 LSB on EVERY pixel) and against the exact HIP frame;
+    the histogram goes to gpurun_out/deviations_r06_<name>.json (collected into profiles/deviations_r06.json)."""
+    import json
+    d_ref = np.abs(fast_frame.astype(np.int32) - ref.astype(np.int32)).max(axis=2)
+    d_ex = np.abs(fast_frame.astype(np.int32) - exact_frame.astype(np.int32)).max(axis=2)
+    e_ref = np.abs(exact_frame.astype(np.int32) - ref.astype(np.int32)).max(axis=2)
+    out = {"workload": name, "pixels": int(d_ref.size),
+           "fast_vs_exact_oracle_lsb_histogram": np.bincount(d_ref.ravel(), minlength=4)[:8].tolist(),
+           "fast_vs_exact_hip_lsb_histogram": np.bincount(d_ex.ravel(), minlength=4)[:8].tolist(),
+           "exact_hip_vs_exact_oracle_lsb_histogram": np.bincount(e_ref.ravel(), minlength=4)[:8].tolist(),
+           "max_fast_vs_oracle": int(d_ref.max()), "max_fast_vs_exact_hip": int(d_ex.max())}
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(out, open(os.path.join(ROOT, "gpurun_out", "deviations_r06_%s.json" % name), "w"), indent=1)
+    assert d_ref.max() <= LSB_TOL, "%s: %d pixels of the fast frame differ from the exact oracle by more than %d LSB (max %d)" % (
+        name, int((d_ref > LSB_TOL).sum()), LSB_TOL, int(d_ref.max()))
+    return out
+
+
+
 def test_full_size_properties(hip_lib):
     tr = scenes.normalize(scenes.tornado())
     flow = host_api.LineDataFlow().set_trajectories(tr.positions, tr.attributes, tr.line_offsets)
@@ -659,6 +679,8 @@ def test_config2_whole_frame_against_the_oracle(hip_lib):
     P.attrMin, P.attrMax = lo, hi
     ref = sc.render_rt(P, use_bvh=True)
     assert max_lsb_diff(img, ref) <= LSB_TOL and (ref[..., :3] != 255).any(axis=2).sum() > 50000
+    ctx.set_option("shading_numerics", "fast")          # the priced +-2 LSB contract: every pixel against the EXACT oracle
+    _fast_shading_deviation("c2", img, ctx.render(11), ref)
 
 
 def test_config2_size_band_data_and_helicity_bands_whole_frames(hip_lib):
@@ -762,6 +784,25 @@ def test_config4_whole_frame_against_the_oracle(hip_lib):
     assert diff[of_px].max() <= LSB_TOL
     # the oracle resolving the KERNEL's lists must reproduce the kernel's frame too (no dependence on whose lists)
     assert max_lsb_diff(full, lvo.ppll_resolve(P, nodes, start, tile=whole)) <= 1
+    # shading_numerics = fast: the frame within 2 LSB of the EXACT oracle on every pixel; list lengths, fragment depths and alpha bytes
+    # bit for bit those of the exact mode (nothing that decides a fragment goes through the approximate operations)
+    ctx.set_option("collect_stats", False)
+    ctx.set_option("shading_numerics", "fast")
+    fast = ctx.render(2)
+    fn, fs, fcnt = ctx.ppll_buffers(pw * ph, int(P.ppllLinkedListSize))
+    fp, fd, fc, flen = _ppll_lists_sorted(fn, fs)
+    assert fcnt == cnt and np.array_equal(flen, glen) and np.array_equal(fp, gp)
+    assert np.array_equal(np.sort(fd), np.sort(gd)), "fragment depths changed"
+    # per pixel the (depth, alpha) multisets are the same; colours differ by at most 1 LSB per channel
+    ka = (gd.astype(np.uint64) << np.uint64(8)) | (gc_ >> 24).astype(np.uint64)
+    kb = (fd.astype(np.uint64) << np.uint64(8)) | (fc >> 24).astype(np.uint64)
+    oa, ob = np.lexsort((ka, gp)), np.lexsort((kb, fp))
+    assert np.array_equal(ka[oa], kb[ob]), "a fragment's depth or alpha changed"
+    ca, cb = gc_[oa].view(np.uint8).reshape(-1, 4).astype(np.int16), fc[ob].view(np.uint8).reshape(-1, 4).astype(np.int16)
+    same_key = np.concatenate([[False], (ka[oa][1:] == ka[oa][:-1]) & (gp[oa][1:] == gp[oa][:-1])])
+    same_key |= np.concatenate([same_key[1:], [False]])     # (fragments of one pixel with equal depth AND alpha may pair up either way)
+    assert np.abs(ca - cb)[~same_key].max() <= 1
+    _fast_shading_deviation("c4", full, fast, ref)
 
 
 def test_config4_full_size_ppll_and_mlat(hip_lib):
@@ -1151,3 +1192,41 @@ def test_overlap_primary_passes_gives_the_same_frames(hip_lib, settings, transpa
     for x, y in zip(a[4], b[4]):
         assert np.array_equal(x, y)
     assert max_lsb_diff(a[0], c.oracle_render(11, use_bvh=True)[0]) <= LSB_TOL
+
+
+@pytest.mark.parametrize("mode,transparent,settings", [
+    (11, False, dict(RTAO, ambient_occlusion_iterations=1, ambient_occlusion_samples_per_frame=8, depth_cue_strength=0.6)),
+    (11, True, dict(depth_cue_strength=0.0)),
+    (2, True, dict(RTAO, ambient_occlusion_iterations=1, ambient_occlusion_samples_per_frame=4, ppll_fragment_source="raster_prism")),
+    (2, True, dict(use_capped_tubes=False, ppll_fragment_source="raster_prism", depth_cue_strength=0.5)),
+])
+def test_fast_shading_numerics_stay_inside_the_contract(hip_lib, mode, transparent, settings):
+    """shading_numerics = fast (approximate hardware rsq / rcp / log2 / exp2 in colour-only arithmetic): the frame stays within 2 LSB of
+    the EXACT oracle; AO factors, PPLL list lengths, fragment depths and alpha bytes are bit for bit those of the exact mode; the
+    variants the fast mode does not cover (band data, helicity bands, statistics runs) render exactly what they rendered before."""
+    c = small_case(width=192, height=128, transparent=transparent, **settings)
+    ref, _ = c.oracle_render(mode, use_bvh=True)
+    ctx = c.hip_context()
+    exact = ctx.render(mode)
+    ao = ctx.get_ao() if "ambient_occlusion_mode" in settings else None
+    if mode == 2:
+        pw, ph = c.padded()
+        P = c.oracle_params(c.oracle_scene())
+        n0, s0, c0 = ctx.ppll_buffers(pw * ph, int(P.ppllLinkedListSize))
+    ctx.set_option("shading_numerics", "fast")
+    fast = ctx.render(mode)
+    assert max_lsb_diff(exact, ref) <= LSB_TOL and max_lsb_diff(fast, ref) <= LSB_TOL and max_lsb_diff(fast, exact) <= 2
+    if ao is not None:
+        assert np.array_equal(bits(ctx.get_ao()), bits(ao))
+    if mode == 2:
+        n1, s1, c1 = ctx.ppll_buffers(pw * ph, int(P.ppllLinkedListSize))
+        a, b = _ppll_lists_sorted(n0, s0), _ppll_lists_sorted(n1, s1)
+        assert c0 == c1 and np.array_equal(a[3], b[3]) and np.array_equal(a[0], b[0])
+        ka = (a[1].astype(np.uint64) << np.uint64(8)) | (a[2] >> 24).astype(np.uint64)
+        kb = (b[1].astype(np.uint64) << np.uint64(8)) | (b[2] >> 24).astype(np.uint64)
+        assert np.array_equal(ka[np.lexsort((ka, a[0]))], kb[np.lexsort((kb, b[0]))])
+    with pytest.raises(capi.LineVisError):
+        ctx.set_option("shading_numerics", "sloppy")
+    # statistics runs use the exact kernels whatever the option says
+    ctx.set_option("collect_stats", True)
+    assert np.array_equal(ctx.render(mode), exact)

@@ -212,7 +212,14 @@ def test_config3_whole_frame_with_the_reference_rtao_geometry(hip_lib):
     ts = lvo.TriScene(*mesh, lw)
     ao_ref = ts.render_ao(P, use_bvh=True)
     assert np.array_equal(bits(ao), bits(ao_ref)) and (ao_ref < 1.0).sum() > 300000
-    assert max_lsb_diff(img, sc.render_rt(P, ao=ao_ref, use_bvh=True)) <= 2
+    ref = sc.render_rt(P, ao=ao_ref, use_bvh=True)
+    assert max_lsb_diff(img, ref) <= 2
+    # shading_numerics = fast on the headline frame: AO factors untouched, every pixel within 2 LSB of the EXACT oracle
+    from test_gpu_parity import _fast_shading_deviation
+    ctx.set_option("shading_numerics", "fast")
+    fast = ctx.render(capi.MODE_RAY_TRACER)
+    assert np.array_equal(bits(ctx.get_ao()), bits(ao_ref))
+    _fast_shading_deviation("c3", img, fast, ref)
 
 
 def test_triangle_golden_fixture(hip_lib):
