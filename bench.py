@@ -504,25 +504,33 @@ def self_launch(args):
     import socket
     attempts = []
     argv = [a for a in sys.argv[1:]]
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + argv
     env = dict(os.environ, LV_BENCH_LAUNCH="self-launched: python -m torch.distributed.run --nproc-per-node %d (one process per GPU, "
                                            "torch.distributed %s)" % (args.gpus, "gloo, dry run" if args.dry_run else "nccl = RCCL"))
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // args.gpus)))
-    print("[bench] --gpus %d without torch.distributed.run: launching %s" % (args.gpus, " ".join(cmd[1:8])), file=sys.stderr, flush=True)
     timeout_s = float(os.environ.get("LV_BENCH_LAUNCH_TIMEOUT", "1500"))
-    rc, out, err = _run_child(cmd, env, timeout_s)
-    line = _last_json_line(out)
-    if rc == 0 and line is not None:
-        line["launch_attempts"] = attempts
-        sys.stderr.write(err[-4000:])
-        print(json.dumps(line), flush=True)
-        return
+    rc, out, err, line = None, "", "", None
+    for attempt in range(2):
+        # a free port is picked by binding to 0 and releasing it: another process can take it before torchrun binds, so a
+        # launch that dies in the rendezvous is tried once more on a fresh port before the one-process fallback takes over
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + argv
+        print("[bench] --gpus %d without torch.distributed.run: launching %s" % (args.gpus, " ".join(cmd[1:8])), file=sys.stderr, flush=True)
+        rc, out, err = _run_child(cmd, env, timeout_s)
+        line = _last_json_line(out)
+        if rc == 0 and line is not None:
+            line["launch_attempts"] = attempts
+            sys.stderr.write(err[-4000:])
+            print(json.dumps(line), flush=True)
+            return
+        if attempt == 0 and rc is not None and any(k in err for k in ("Address already in use", "EADDRINUSE", "address already in use")):
+            attempts.append({"path": "torch.distributed.run (port %d taken)" % port, "returncode": rc, "stderr_tail": err[-600:]})
+            continue
+        break
     attempts.append({"path": "torch.distributed.run", "returncode": rc, "stderr_tail": err[-1500:]})
     print("[bench] torch.distributed.run path failed (rc %s): ...%s" % (rc, err[-300:]), file=sys.stderr, flush=True)
     if args.dry_run:

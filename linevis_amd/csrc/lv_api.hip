@@ -1227,14 +1227,14 @@ __global__ __launch_bounds__(256) void k_selftest_rsqrt(unsigned long long* __re
 int lv_selftest_rsqrt(lv_ctx* ctx, uint64_t* out_mismatches, uint32_t* out_first_argument) {
     if (!ctx || !out_mismatches) return LV_E_INVALID;
     (void)hipSetDevice(ctx->device);
-    unsigned long long* dev = nullptr;
-    LV_HIP(ctx, hipMalloc(&dev, 16));
+    int rc;
+    if ((rc = lv_buf_reserve(ctx, ctx->counters, sizeof(LvDevCounters)))) return rc;   // scratch the context owns (nothing to leak on an error path)
+    unsigned long long* dev = (unsigned long long*)ctx->counters.ptr;
     LV_HIP(ctx, hipMemsetAsync(dev, 0, 16, ctx->stream));
     k_selftest_rsqrt<<<uint32_t(ctx->numCUs) * 16u, 256, 0, ctx->stream>>>(dev);
     unsigned long long host[2] = {0ull, 0ull};
     LV_HIP(ctx, hipMemcpyAsync(host, dev, 16, hipMemcpyDeviceToHost, ctx->stream));
     LV_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    (void)hipFree(dev);
     *out_mismatches = host[0];
     if (out_first_argument) *out_first_argument = uint32_t(host[1]);
     return LV_OK;

@@ -456,7 +456,7 @@ __device__ __forceinline__ f3 norm3s(f3 a) { const float r = lv_rsqrt_shade(dot3
 // divisions.  Nothing that decides a hit, a coverage bit, a fragment's depth, its alpha or the length of a list goes through these
 // (template parameter FAST of the shading routines: 0 = exact, 1 = lighting only, 2 = also the halo coordinate where it cannot reach
 // alpha: the raster colour of plain tubes).  Frames then differ from the exact ones in the last bit of a few channels; the contract is
-// +- 2 LSB (tests: whole C2 / C3 / C4 frames against the exact oracle, profiles/deviations_r06.json).
+// +- 2 LSB (tests: whole C2 / C3 / C4 frames against the exact CPU checker, profiles/deviations_r06.json).
 __device__ __forceinline__ float lv_rsqrt_fast(float x) { return __builtin_amdgcn_rsqf(fminf(fmaxf(x, LV_RSQRT_LO), LV_RSQRT_HI)); }
 __device__ __forceinline__ f3 norm3f(f3 a) { const float r = lv_rsqrt_fast(dot3(a, a)); return mk3(a.x * r, a.y * r, a.z * r); }
 template <bool FASTN>

@@ -3090,10 +3090,14 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
                 LV_HIP(ctx, hipMemsetAsync(coarse, 0, cells * 4, st));
             }
 #define LV_LAUNCH_RASTER(ST, NT)                                                                                              \
-    LV_TIMED_LAUNCH(ctx, LV_KERNEL_PPLL_RASTER, (k_ppll_raster_prism<ST, NT><<<rasterGrid, LV_BLOCK, 0, st>>>(                \
+    k_ppll_raster_prism<ST, NT><<<rasterGrid, LV_BLOCK, 0, st>>>(                                                             \
             U, S, gatherPool, (const uint32_t*)ctx->ppllStart.ptr, (uint32_t*)ctx->ppllCount.ptr, dc, poolSlots,                \
-            allRequested ? 1u : 0u, leafList)))
+            allRequested ? 1u : 0u, leafList)
             uint32_t* leafList = nullptr;
+            // LV_KERNEL_PPLL_RASTER times the rasteriser WITH what a sharded frame runs in front of it (k_ppll_mark_tiles,
+            // k_ppll_cull_segments): a rank's rasteriser cost is the three together
+            const bool rasterTimed = ((ctx->opt.timerMask >> LV_KERNEL_PPLL_RASTER) & 1u) != 0u;
+            if (rasterTimed) LV_HIP(ctx, hipEventRecord(lv_kernel_ev(ctx, LV_KERNEL_PPLL_RASTER, 0), st));
             if (allRequested) {}   // (k_ppll_clear marked every pixel)
             else if (stats) k_ppll_mark_tiles<true><<<gridTiles, LV_BLOCK, 0, st>>>(U, T, (uint32_t*)ctx->ppllStart.ptr, coarse, dc);
             else k_ppll_mark_tiles<false><<<gridTiles, LV_BLOCK, 0, st>>>(U, T, (uint32_t*)ctx->ppllStart.ptr, coarse, dc);
@@ -3107,6 +3111,10 @@ int lv_frame_render(lv_ctx* ctx, int mode, const uint32_t* tilesXYHost, uint32_t
             if (S.numSegs != 0) {
                 if (S.prism.n == 6u) { if (stats) LV_LAUNCH_RASTER(true, 6); else LV_LAUNCH_RASTER(false, 6); }
                 else { if (stats) LV_LAUNCH_RASTER(true, 0); else LV_LAUNCH_RASTER(false, 0); }
+            }
+            if (rasterTimed) {
+                LV_HIP(ctx, hipEventRecord(lv_kernel_ev(ctx, LV_KERNEL_PPLL_RASTER, 1), st));
+                ctx->kernelLaunches[LV_KERNEL_PPLL_RASTER]++;
             }
 #undef LV_LAUNCH_RASTER
         } else {

@@ -1384,6 +1384,12 @@ float lvo_bands_ribbon_position(const float cam[3], const float linePos[3], cons
     return bandsRibbonPosition(ld3(cam), ld3(linePos), ld3(lineNormal), ld3(tangent), normalize(ld3(tangent)), phi, lineRadius, thickness);
 }
 void lvo_mat4_inverse(const float m[16], float out[16]) { mat4Inverse(m, out); }
+unsigned long long lvo_shade_normalize_out_of_range(int reset) {
+    const unsigned long long n = g_shadeNormalizeOutOfRange.load();
+    if (reset) g_shadeNormalizeOutOfRange.store(0ull);
+    return n;
+}
+
 void lvo_set_num_threads(int n) {
 #ifdef _OPENMP
     omp_set_num_threads(n);

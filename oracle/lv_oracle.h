@@ -156,6 +156,9 @@ void lvo_scene_set_tf(lvo_scene*, const float* rgba, uint32_t n);
 /* CPU LBVH (Morton order + highest-differing-bit splits); optional accelerator. */
 void lvo_scene_build_bvh(lvo_scene*, float lineWidth);
 void lvo_set_num_threads(int n);
+/* normalize() calls of the shading code whose squared length fell outside [2^-60, 2^60] since the last reset -- where the build's
+ * clamped rule is not the reference's normalize(); the parity tests assert 0 on the scenes they compare */
+unsigned long long lvo_shade_normalize_out_of_range(int reset);
 
 /* ---- a7 + closest hit: IntersectionTube (TubeRayTracing.glsl:452-494) over all segments ----
  * useBvh=0: brute force in ascending segment order (ground truth).

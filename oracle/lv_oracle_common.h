@@ -6,6 +6,7 @@
 #include "lv_oracle.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
@@ -86,8 +87,14 @@ inline float log2Det(float x) {
 // normalize(v) of the shading code as v * (1 / length(v)) (norm3s of the HIP library)
 // -- with the squared length clamped into [2^-60, 2^60] (every length the shading code meets lies inside; a zero vector stays a zero
 // vector; GLSL leaves normalize() of such vectors undefined).  The build owns this rule.
+// Where the clamp acts, this is NOT the reference's normalize() (GLSL: NaN / Inf there): every call whose squared length falls outside
+// the range is counted (lvo_shade_normalize_out_of_range), and the parity tests assert that the scenes they compare never get there --
+// so "device == checker" on those scenes is also "device == the reference's normalize()".
+inline std::atomic<unsigned long long> g_shadeNormalizeOutOfRange{0ull};
 inline V3 normalizeShade(V3 a) {
-    const float x = fminf(fmaxf(dot(a, a), 0x1p-60f), 0x1p60f);   // (NaN -> 2^-60: fmaxf / fminf return the other operand)
+    const float x0 = dot(a, a);
+    if (!(x0 >= 0x1p-60f && x0 <= 0x1p60f)) g_shadeNormalizeOutOfRange.fetch_add(1ull, std::memory_order_relaxed);
+    const float x = fminf(fmaxf(x0, 0x1p-60f), 0x1p60f);   // (NaN -> 2^-60: fmaxf / fminf return the other operand)
     const float r = 1.0f / sqrtf(x);
     return V3{a.x * r, a.y * r, a.z * r};
 }

@@ -140,6 +140,8 @@ def lib():
     L.lvo_scene_set_tf.argtypes = [vp, vp, u32]
     L.lvo_scene_build_bvh.argtypes = [vp, f32]
     L.lvo_set_num_threads.argtypes = [i32]
+    L.lvo_shade_normalize_out_of_range.argtypes = [i32]
+    L.lvo_shade_normalize_out_of_range.restype = C.c_uint64
     L.lvo_trace_rays.argtypes = [vp, f32, i32, i32, vp, vp, f32, f32, u32, vp, vp, vp]
     L.lvo_intersect_capsule.restype = i32
     L.lvo_intersect_capsule.argtypes = [vp, vp, vp, vp, f32, i32, C.POINTER(f32), C.POINTER(i32)]
@@ -855,6 +857,11 @@ def ppll_resolve(P, nodes, start_offset, tile=None, literal=False):
 
 def ppll_addr(x, y, padded_w, tile_w, tile_h):
     return int(lib().lvo_ppll_addr(x, y, padded_w, tile_w, tile_h))
+
+
+def shade_normalize_out_of_range(reset=True):
+    """normalize() calls of the shading code outside the clamp range of the build's rule since the last reset (oracle/lv_oracle_common.h)."""
+    return int(lib().lvo_shade_normalize_out_of_range(int(bool(reset))))
 
 
 def set_num_threads(n):

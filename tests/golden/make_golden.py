@@ -467,7 +467,37 @@ def prism_small():
     np.savez_compressed(os.path.join(HERE, "prism_small.npz"), **out)
 
 
+def abi_smoke():
+    """tests/golden/abi_smoke.bin: what tests/abi_smoke.c (plain C99 against the C-ABI) reads -- header, inputs, and the oracle's two
+    frames (mode 11: RTAO 1 x 8 + depth cues; mode 2: PPLL with the transparent transfer function).  Little endian, no padding."""
+    import struct
+    W, H = 96, 64
+    base = small_case(width=W, height=H, n_lines=14, pts_per_line=24, seed=5, line_width=0.02)
+    rt = Case(base.points, base.seg, base.tf, W, H, base.line_width, ambient_occlusion_mode="RTAO (Screen Space)",
+              ambient_occlusion_strength=1.0, ambient_occlusion_iterations=1, ambient_occlusion_samples_per_frame=8,
+              depth_cue_strength=0.8)
+    frame_rt, _ = rt.oracle_render(11)
+    tft = tfm.standard_transparent()
+    pp = Case(base.points, base.seg, tft, W, H, base.line_width)
+    frame_ppll, _ = pp.oracle_render(2)
+    assert base.tf.shape == tft.shape
+    with open(os.path.join(HERE, "abi_smoke.bin"), "wb") as f:
+        f.write(struct.pack("<8I4f", 0x4D53564C, 1, len(base.points), len(base.seg), len(base.tf), W, H, 0,
+                            base.line_width, rt.fovy, rt.near, rt.far))
+        f.write(np.ascontiguousarray(rt.view, dtype=np.float32).tobytes())
+        f.write(np.ascontiguousarray(rt.proj, dtype=np.float32).tobytes())
+        f.write(base.points.tobytes())
+        f.write(np.ascontiguousarray(base.seg, dtype=np.uint32).tobytes())
+        f.write(np.ascontiguousarray(base.tf, dtype=np.float32).tobytes())
+        f.write(np.ascontiguousarray(tft, dtype=np.float32).tobytes())
+        f.write(np.ascontiguousarray(frame_rt, dtype=np.uint8).tobytes())
+        f.write(np.ascontiguousarray(frame_ppll, dtype=np.uint8).tobytes())
+
+
 if __name__ == "__main__":
+    if "--only-abi-smoke" in sys.argv:
+        abi_smoke()
+        sys.exit(0)
     if "--only-prism" in sys.argv:
         prism_small()
         sys.exit(0)
@@ -501,3 +531,4 @@ if __name__ == "__main__":
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print("%-24s %8d bytes" % (f, os.path.getsize(os.path.join(HERE, f))))
+    abi_smoke()

@@ -88,3 +88,37 @@ def test_product_never_touches_the_oracle():
                         bad.append(os.path.join(dirpath, f))
     # LvMath.hpp mentions the word in a comment only
     assert bad == [], bad
+
+
+def _build_abi_smoke(tmp_path):
+    import subprocess
+    lib_dir = os.path.dirname(capi.LIB_PATH)
+    exe = str(tmp_path / "abi_smoke")
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", os.path.dirname(capi.HEADER_PATH),
+                           os.path.join(ROOT, "tests", "abi_smoke.c"), "-L", lib_dir, "-llinevis_hip", "-Wl,-rpath," + lib_dir, "-o", exe])
+    return exe
+
+
+def test_compiled_c_program_links_the_boundary_and_fails_cleanly_without_a_device(tmp_path):
+    """tests/abi_smoke.c is plain C99 (-pedantic -Werror), links nothing but liblinevis_hip.so, and without a GPU lv_create reports
+    LV_E_HIP instead of falling back to anything."""
+    import subprocess
+    import torch
+    capi.load()
+    exe = _build_abi_smoke(tmp_path)
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present; the -m gpu test runs the program")
+    r = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "abi_smoke.bin")], capture_output=True, text=True)
+    assert r.returncode == 4 and "lv_create(0) failed with -2" in r.stderr and r.stdout.startswith("linevis_hip")
+
+
+@pytest.mark.gpu
+def test_compiled_c_program_renders_the_fixture(tmp_path):
+    """The boundary driven from C without Python in between: both renderers on the small fixture, frames within 2 LSB of the CPU
+    checker's (tests/golden/abi_smoke.bin, written by tests/golden/make_golden.py)."""
+    import subprocess
+    capi.load()
+    exe = _build_abi_smoke(tmp_path)
+    r = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "abi_smoke.bin")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "abi_smoke ok" in r.stdout and "mode 11: max difference" in r.stdout and "mode 2: max difference" in r.stdout

@@ -7,10 +7,11 @@ pytestmark = pytest.mark.gpu
 
 
 def test_shortened_rsqrt_gives_the_ieee_bits_for_every_float(hip_lib):
-    """lv_rsqrt_exact (lv_device.h: v_sqrt_f32 + one-ulp correction, v_rcp_f32 + three Newton steps inside [2^-60, 2^60), the
-    compiler's sequence elsewhere) against 1.0f / sqrtf(x) for ALL 2^32 arguments: zeros, denormals, infinities, NaNs, negatives
-    included.  The CPU checker computes 1.0f / sqrtf(x): a single differing bit would show up as a parity failure somewhere else,
-    far from its cause."""
+    """lv_rsqrt_shade (lv_device.h: the argument clamped into [2^-60, 2^60], then v_sqrt_f32 + one-ulp correction and v_rcp_f32 + three
+    Newton steps) against lv_rsqrt_shade_reference -- the same clamp followed by the compiler's own 1.0f / sqrtf(x) -- for ALL 2^32
+    arguments: zeros, denormals, infinities, NaNs, negatives included.  The CPU checker's normalizeShade states the same clamped rule
+    (and counts the calls the clamp acts on: tests/test_oracle.py); a single differing bit would show up as a parity failure
+    somewhere else, far from its cause."""
     ctx = capi.Context(0)
     bad, first = ctx.selftest_rsqrt()
     assert bad == 0, "%d arguments differ, e.g. bits 0x%08x" % (bad, first)

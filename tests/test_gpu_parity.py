@@ -665,6 +665,7 @@ def test_config3_whole_frame_against_the_oracle(hip_lib):
 
 def test_config2_whole_frame_against_the_oracle(hip_lib):
     """BASELINE.json config 2: 100 k-segment helix bundle, 1920 x 1080, primary rays only -- every pixel."""
+    lvo.shade_normalize_out_of_range(reset=True)
     tr = scenes.normalize(scenes.helix_bundle())
     flow = host_api.LineDataFlow().set_trajectories(tr.positions, tr.attributes, tr.line_offsets)
     pts, seg, _ = flow.tube_aabb_render_data(0.002)
@@ -681,6 +682,7 @@ def test_config2_whole_frame_against_the_oracle(hip_lib):
     assert max_lsb_diff(img, ref) <= LSB_TOL and (ref[..., :3] != 255).any(axis=2).sum() > 50000
     ctx.set_option("shading_numerics", "fast")          # the priced +-2 LSB contract: every pixel against the EXACT oracle
     _fast_shading_deviation("c2", img, ctx.render(11), ref)
+    assert lvo.shade_normalize_out_of_range() == 0      # the clamped normalize() rule never acted on this frame (tests/test_oracle.py)
 
 
 def test_config2_size_band_data_and_helicity_bands_whole_frames(hip_lib):
@@ -742,6 +744,7 @@ def test_config4_whole_frame_against_the_oracle(hip_lib):
     LinkedListGather.glsl:44-71) as per-pixel (depth, colour) multisets bit for bit -- all 2 073 600 pixels, including the > 2 000
     whose lists overflow MAX_NUM_FRAGS = 64 -- and the resolved frame (LinkedListResolve.glsl:57-105, frontToBackPQ
     LinkedListSort.glsl:177-238; keep-the-nearest-64 on both sides) <= 2 LSB on every pixel."""
+    lvo.shade_normalize_out_of_range(reset=True)
     tr = scenes.normalize(scenes.tornado())
     flow = host_api.LineDataFlow().set_trajectories(tr.positions, tr.attributes, tr.line_offsets)
     pts, seg, _ = flow.tube_aabb_render_data(0.002)
@@ -803,6 +806,7 @@ def test_config4_whole_frame_against_the_oracle(hip_lib):
     same_key |= np.concatenate([same_key[1:], [False]])     # (fragments of one pixel with equal depth AND alpha may pair up either way)
     assert np.abs(ca - cb)[~same_key].max() <= 1
     _fast_shading_deviation("c4", full, fast, ref)
+    assert lvo.shade_normalize_out_of_range() == 0      # the clamped normalize() rule never acted on this frame (tests/test_oracle.py)
 
 
 def test_config4_full_size_ppll_and_mlat(hip_lib):

@@ -197,6 +197,7 @@ def test_config3_whole_frame_with_the_reference_rtao_geometry(hip_lib):
     """BASELINE.json config 3 with rtao_geometry = triangle_tubes (what the reference's RTAO pass traces): 1 M segments =
     12.06 M triangles, 1920 x 1080, 64 spp -- the AO factors of every pixel bit for bit, the frame within the bar."""
     lw = 0.002
+    lvo.shade_normalize_out_of_range(reset=True)
     tr = scenes.normalize(scenes.tornado())
     flow = host_api.LineDataFlow().set_trajectories(tr.positions, tr.attributes, tr.line_offsets)
     mesh = flow.tube_triangle_render_data(lw, 6)
@@ -220,6 +221,7 @@ def test_config3_whole_frame_with_the_reference_rtao_geometry(hip_lib):
     fast = ctx.render(capi.MODE_RAY_TRACER)
     assert np.array_equal(bits(ctx.get_ao()), bits(ao_ref))
     _fast_shading_deviation("c3", img, fast, ref)
+    assert lvo.shade_normalize_out_of_range() == 0      # the clamped normalize() rule never acted on this frame (tests/test_oracle.py)
 
 
 def test_triangle_golden_fixture(hip_lib):

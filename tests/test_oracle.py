@@ -402,3 +402,27 @@ def test_pow_det_against_float64():
     assert lvo.pow_det(np.float32(0.0), np.float32(1.7))[0] == 0.0 and lvo.pow_det(np.float32(0.0), np.float32(0.0))[0] == 1.0
     assert lvo.pow_det(np.float32(1.0), np.float32(30.0))[0] == 1.0
     assert lvo.pow_det(np.float32(1e-30), np.float32(30.0))[0] == 0.0
+
+
+def test_shading_normalisations_of_the_test_scenes_stay_inside_the_clamp_range():
+    """normalize() of the shading code is v / sqrt(clamp(v . v, 2^-60, 2^60)) on both sides -- where the clamp acts it is
+    not the reference's normalize() (GLSL: NaN / Inf).  The checker counts those calls: on the scenes the parity tests compare
+    (ray tracer with RTAO and depth cues, both PPLL fragment sources, band data) there are none, so device == checker there is also
+    device == the reference's formula; a zero vector is counted."""
+    lvo.shade_normalize_out_of_range(reset=True)
+    rtao = dict(ambient_occlusion_mode="RTAO (Screen Space)", ambient_occlusion_strength=1.0, ambient_occlusion_iterations=1,
+                ambient_occlusion_samples_per_frame=4, depth_cue_strength=0.7)
+    for mode, transparent, settings in [(11, False, rtao), (11, True, {}), (2, True, dict(ppll_fragment_source="raster_prism")),
+                                        (2, True, dict(ppll_fragment_source="capsule_entry"))]:
+        c = small_case(width=96, height=64, transparent=transparent, **settings)
+        img, _ = c.oracle_render(mode, use_bvh=True)
+        assert (img[..., :3] != 255).any(axis=2).sum() > 200
+    assert lvo.shade_normalize_out_of_range(reset=True) == 0
+    # the counter sees what it should: a degenerate segment (p0 == p1) shades with a zero tangent
+    pts = np.zeros(2, dtype=lvo.LINE_POINT_DTYPE)
+    pts["linePosition"] = [[0.0, 0.0, 0.0], [0.0, 0.0, 0.0]]
+    pts["lineTangent"] = [[1.0, 0.0, 0.0], [1.0, 0.0, 0.0]]
+    pts["lineNormal"] = [[0.0, 1.0, 0.0], [0.0, 1.0, 0.0]]
+    c = Case(pts, np.array([[0, 1]], np.uint32), tfm.standard(), 64, 48, 0.2)
+    c.oracle_render(11)
+    assert lvo.shade_normalize_out_of_range(reset=True) > 0
