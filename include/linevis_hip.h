@@ -106,6 +106,8 @@ typedef struct lv_stats {
     float ms_tessellate;
     float ms_line_points;
     uint32_t num_tri_nodes;        /* 64-byte nodes of the triangle LBVH */
+    uint32_t tri_leaf_bytes;       /* leaf data per leaf of the triangle LBVH as built: 64 = a pair record (triangle_leaf_records =
+                                    * pairs), else 48 x triangle_leaf_size; 0 before the build */
 } lv_stats;
 
 #define LV_KERNEL_AO_PRIMARY 0
@@ -244,6 +246,10 @@ int lv_set_background(lv_ctx* ctx, const float rgba[4]);
  *   record costs the stream 2 - 4 us: a frame with every kernel and phase bracketed carries a dozen (6 % of a 0.8-ms PPLL frame),
  *   triangle_leaf_size (build-owned): consecutive triangles per leaf of the triangle LBVH, 1 ... 8 (default 2: a tube face);
  *   changes the acceleration structure only, never a hit,
+ *   triangle_leaf_records (build-owned): "pairs" (default) | "triangles" -- with two triangles per leaf and a mesh in which the
+ *   second triangle of every leaf has at most one vertex index the first one lacks (every mesh the tessellator writes: tube faces,
+ *   cap quads, fan pairs), a leaf stores the four vertices once (64 B) instead of two 48-B triangle records; the ray-triangle test
+ *   runs on the same operands in the same order, so no hit changes; other meshes and "triangles" keep the 48-B records,
  *   shading_numerics (build-owned): "exact" (default: every operation of the shading code in IEEE float32 with one fixed evaluation
  *   order -- frames, AO factors and PPLL fragments are bit-identical to the CPU checker's) | "fast": the hardware's approximate
  *   reciprocal square root / reciprocal / log2 / exp2 (<= 1 ulp) in arithmetic that only reaches a COLOUR -- the normalisations,

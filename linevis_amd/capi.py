@@ -42,7 +42,7 @@ class Stats(C.Structure):
                 ("ppll_pool_nodes", C.c_uint64), ("ao_prim_hits", C.c_uint64), ("ao_prim_may_axis", C.c_uint64),
                 ("ao_prim_may_both", C.c_uint64),
                 ("ms_tri_accel_build", C.c_float), ("ms_tessellate", C.c_float), ("ms_line_points", C.c_float),
-                ("num_tri_nodes", C.c_uint32)]
+                ("num_tri_nodes", C.c_uint32), ("tri_leaf_bytes", C.c_uint32)]
 
     def as_dict(self):
         d = {}

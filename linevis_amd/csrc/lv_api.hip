@@ -101,7 +101,7 @@ static std::vector<LvDeviceBuffer*> lv_all_buffers(lv_ctx* ctx) {
             &ctx->svgf.flowFwidth, &ctx->svgf.moments, &ctx->svgf.momentsHistory, &ctx->svgf.colorHistory, &ctx->svgf.tempAccum,
             &ctx->svgf.tempAccumFiltered, &ctx->svgf.ping, &ctx->svgf.pong, &ctx->svgf.result, &ctx->aoGbuf, &ctx->aoList, &ctx->aoSamples,
             &ctx->counters, &ctx->ppllNodes, &ctx->ppllStart, &ctx->ppllCount, &ctx->ppllScratch, &ctx->prismRecords, &ctx->scanTemp, &ctx->ppllOverflow, &ctx->ppllCoarse, &ctx->prismLeafList, &ctx->flowOccupancy, &ctx->flowSelfGrid, &ctx->twistTex, &ctx->tilesDev, &ctx->outDev,
-            &ctx->scratchRays, &ctx->stackOverflow, &ctx->trajPos, &ctx->trajAttr, &ctx->trajOff, &ctx->trajLineValid, &ctx->trajLineRef, &ctx->trajRecLine, &ctx->trajTess, &ctx->triIdx, &ctx->triVerts, &ctx->triPoints, &ctx->triNodes, &ctx->tris,
+            &ctx->scratchRays, &ctx->stackOverflow, &ctx->trajPos, &ctx->trajAttr, &ctx->trajOff, &ctx->trajLineValid, &ctx->trajLineRef, &ctx->trajRecLine, &ctx->trajTess, &ctx->triIdx, &ctx->triVerts, &ctx->triPoints, &ctx->triNodes, &ctx->tris, &ctx->triPairFlag,
             &ctx->flowVectors, &ctx->flowScalars, &ctx->flowMisc, &ctx->flowSeeds, &ctx->flowOutPos, &ctx->flowOutAtt, &ctx->flowCounts,
             &ctx->bakeBlendingWeights, &ctx->bakeSamplingLocations, &ctx->bakedAo, &ctx->bakeLcgSkip, &ctx->bakedAoPending, &ctx->bakeCounters,
             &ctx->bakeGbuf, &ctx->bakeSamples, &ctx->bakeOverflow, &ctx->mlatTrace, &ctx->buildArena, &ctx->firstHit,
@@ -697,6 +697,15 @@ int lv_set_option(lv_ctx* ctx, const char* key, const char* value) {
         if (!parseUint(value, g) || g < 1 || g > 8) return bad();
         if (g != o.triLeafSize) { ctx->triAccelValid = false; lv_invalidate_bake(ctx); }
         o.triLeafSize = g;
+    } else if (k == "triangle_leaf_records") {
+        // pairs: 64-B records of four vertices for leaves of two triangles that share two (the build falls back to 48-B records
+        // for a mesh with a pair that does not); triangles: always 48-B records.  Build-owned; the hits do not depend on it.
+        bool p;
+        if (std::string(value) == "pairs") p = true;
+        else if (std::string(value) == "triangles") p = false;
+        else return bad();
+        if (p != o.triLeafPairs) { ctx->triAccelValid = false; lv_invalidate_bake(ctx); }
+        o.triLeafPairs = p;
     } else if (k == "treelet_leaves") {
         uint32_t t;
         if (!parseUint(value, t) || t < 3 || t > 4096) return bad();
@@ -871,6 +880,7 @@ static int lv_get_stats_impl(lv_ctx* ctx, lv_stats* out, bool aggregate) {
     if (ctx->evLinePointsValid) s.ms_line_points = ms(4, 6);
     if (ctx->evTessValid) s.ms_tessellate = ms(8, 9);
     s.num_tri_nodes = ctx->numTriNodes;
+    s.tri_leaf_bytes = !ctx->triAccelValid ? 0u : ctx->triLeafPairs ? 64u : 48u * ctx->triLeafSize;
     if (ctx->evFrameValid) {
         // phase marks on the stream: 2 start, 5 depth range done, 7 RTAO done, 11 PPLL lists cleared, 13 gathered, 3 end
         s.ms_total = s.ms_depth_range = s.ms_ao = 0.0f;

@@ -156,8 +156,47 @@ __global__ __launch_bounds__(LV_BLOCK) void k_tri_boxes(const lv_tube_vertex* __
     lv_block_bounds(mn, mx, boundsOrd);
 }
 
+// PAIR RECORDS (64 B per leaf, round 6): the two triangles of a leaf of `triangle_leaf_size` 2 almost always share two vertices
+// -- the tessellator emits a tube face as (a, b, c)(a, c, d), a cap quad as (a, b, c)(b, d, c), two fan triangles as (p, x1, x0)
+// (p, x2, x1) -- so the leaf stores FOUR vertices instead of 2 x 3: {q0.xyz, index of the first triangle}{q1.xyz, code}{q2.xyz, 0}
+// {q3.xyz, 0}; triangle 0 = (q0, q1, q2) in its own vertex order, triangle 1 = (q[code & 3], q[code >> 2 & 3], q[code >> 4 & 3]) in ITS
+// own order (the ray-triangle test is evaluated on exactly the operands of the 48-B records: same bits).  A pair is encodable iff the
+// second triangle has at most one vertex INDEX the first one lacks; k_tri_pairs_check says whether every pair of the mesh is (a
+// caller's arbitrary mesh may not be: the build then keeps the 48-B records).  1 M segments: 579 -> 386 MB of leaf data.
+__device__ __forceinline__ bool lv_tri_pair_code(const uint32_t* __restrict__ triIdx, uint32_t s, uint32_t nTri, uint32_t& code,
+                                                 uint32_t& extra) {
+    const uint32_t a0 = triIdx[3 * size_t(s)], a1 = triIdx[3 * size_t(s) + 1], a2 = triIdx[3 * size_t(s) + 2];
+    code = 0u; extra = a0;
+    if (s + 1u >= nTri) { code = 0xFFFFFFFFu; return true; } // odd triangle count: the last leaf's second slot is empty
+    bool haveExtra = false;
+    for (int k = 0; k < 3; k++) {
+        const uint32_t b = triIdx[3 * size_t(s + 1u) + k];
+        uint32_t sel;
+        if (b == a0) sel = 0u;
+        else if (b == a1) sel = 1u;
+        else if (b == a2) sel = 2u;
+        else {
+            if (haveExtra && b != extra) return false;
+            haveExtra = true; extra = b; sel = 3u;
+        }
+        code |= sel << (2 * k);
+    }
+    return true;
+}
+__global__ __launch_bounds__(LV_BLOCK) void k_tri_pairs_check(const uint32_t* __restrict__ triIdx, uint32_t nTri, uint32_t nLeaves,
+                                                              uint32_t* __restrict__ notEncodable) {
+    bool bad = false;
+    for (uint32_t g = blockIdx.x * LV_BLOCK + threadIdx.x; g < nLeaves; g += gridDim.x * LV_BLOCK) {
+        uint32_t code, extra;
+        bad |= !lv_tri_pair_code(triIdx, 2u * g, nTri, code, extra);
+    }
+    if (__ballot(bad) && (threadIdx.x & 63u) == 0u) atomicOr(notEncodable, 1u);
+}
+
 // 48-byte triangle records, `group` per leaf, leaves in Morton order: {v0.xyz, original triangle index}{v1.xyz, 0}{v2.xyz, 0};
-// the slots an incomplete last group leaves empty hold NaN vertices (the test rejects them: every comparison with NaN fails)
+// the slots an incomplete last group leaves empty hold NaN vertices (the test rejects them: every comparison with NaN fails).
+// PAIRS: the 64-byte pair records above (group == 2, every pair encodable).
+template <bool PAIRS>
 __global__ __launch_bounds__(LV_BLOCK) void k_tri_leaves(const lv_tube_vertex* __restrict__ verts,
                                                          const uint32_t* __restrict__ triIdx,
                                                          const float* __restrict__ boxOrig,
@@ -166,21 +205,41 @@ __global__ __launch_bounds__(LV_BLOCK) void k_tri_leaves(const lv_tube_vertex* _
     uint32_t i = blockIdx.x * LV_BLOCK + threadIdx.x;
     if (i >= nLeaves) return;
     const uint32_t g = sortedVals[i];
-    for (uint32_t j = 0; j < group; j++) {
-        const uint32_t s = g * group + j;
-        float4* rec = tris + 3 * (size_t(i) * group + j);
-        if (s < nTri) {
-            const float* a = verts[triIdx[3 * size_t(s)]].vertexPosition;
-            const float* b = verts[triIdx[3 * size_t(s) + 1]].vertexPosition;
-            const float* c = verts[triIdx[3 * size_t(s) + 2]].vertexPosition;
-            rec[0] = make_float4(a[0], a[1], a[2], __uint_as_float(s));
-            rec[1] = make_float4(b[0], b[1], b[2], 0.0f);
-            rec[2] = make_float4(c[0], c[1], c[2], 0.0f);
+    const float nan = __uint_as_float(0x7FC00000u);
+    if (PAIRS) {
+        const uint32_t s = 2u * g;
+        uint32_t code, extra;
+        lv_tri_pair_code(triIdx, s, nTri, code, extra);
+        const float* a = verts[triIdx[3 * size_t(s)]].vertexPosition;
+        const float* b = verts[triIdx[3 * size_t(s) + 1]].vertexPosition;
+        const float* c = verts[triIdx[3 * size_t(s) + 2]].vertexPosition;
+        float4* rec = tris + 4 * size_t(i);
+        rec[0] = make_float4(a[0], a[1], a[2], __uint_as_float(s));
+        rec[2] = make_float4(c[0], c[1], c[2], 0.0f);
+        if (code == 0xFFFFFFFFu) { // no second triangle: (q3, q3, q3) of NaN vertices is rejected by every comparison of the test
+            rec[1] = make_float4(b[0], b[1], b[2], __uint_as_float(0x3Fu));
+            rec[3] = make_float4(nan, nan, nan, 0.0f);
         } else {
-            const float nan = __uint_as_float(0x7FC00000u);
-            rec[0] = make_float4(nan, nan, nan, __uint_as_float(0xFFFFFFFFu));
-            rec[1] = make_float4(nan, nan, nan, 0.0f);
-            rec[2] = make_float4(nan, nan, nan, 0.0f);
+            const float* d = verts[extra].vertexPosition;
+            rec[1] = make_float4(b[0], b[1], b[2], __uint_as_float(code));
+            rec[3] = make_float4(d[0], d[1], d[2], 0.0f);
+        }
+    } else {
+        for (uint32_t j = 0; j < group; j++) {
+            const uint32_t s = g * group + j;
+            float4* rec = tris + 3 * (size_t(i) * group + j);
+            if (s < nTri) {
+                const float* a = verts[triIdx[3 * size_t(s)]].vertexPosition;
+                const float* b = verts[triIdx[3 * size_t(s) + 1]].vertexPosition;
+                const float* c = verts[triIdx[3 * size_t(s) + 2]].vertexPosition;
+                rec[0] = make_float4(a[0], a[1], a[2], __uint_as_float(s));
+                rec[1] = make_float4(b[0], b[1], b[2], 0.0f);
+                rec[2] = make_float4(c[0], c[1], c[2], 0.0f);
+            } else {
+                rec[0] = make_float4(nan, nan, nan, __uint_as_float(0xFFFFFFFFu));
+                rec[1] = make_float4(nan, nan, nan, 0.0f);
+                rec[2] = make_float4(nan, nan, nan, 0.0f);
+            }
         }
     }
 #pragma unroll
@@ -1385,9 +1444,22 @@ int lv_bvh_build_triangles(lv_ctx* ctx) {
     int rc;
     const uint32_t group = ctx->opt.triLeafSize, nLeaves = (n + group - 1u) / group;
     ctx->triLeafSize = group;
-    if ((rc = lv_buf_reserve(ctx, ctx->tris, size_t(nLeaves) * group * 48))) return rc;
     const lv_tube_vertex* verts = (const lv_tube_vertex*)ctx->triVerts.ptr;
     const uint32_t* triIdx = (const uint32_t*)ctx->triIdx.ptr;
+    // 64-B pair records (k_tri_leaves<true>) when the leaves hold two triangles and every pair of the mesh shares two vertex indices
+    bool pairs = group == 2u && ctx->opt.triLeafPairs;
+    if (pairs) {
+        LvDeviceBuffer& flag = ctx->triPairFlag;
+        if ((rc = lv_buf_reserve(ctx, flag, 4))) return rc;
+        if (!ctx->pinned) LV_HIP(ctx, hipHostMalloc((void**)&ctx->pinned, 64, hipHostMallocDefault));
+        LV_HIP(ctx, hipMemsetAsync(flag.ptr, 0, 4, st));
+        k_tri_pairs_check<<<std::min(nblocks(nLeaves), 4096u), LV_BLOCK, 0, st>>>(triIdx, n, nLeaves, (uint32_t*)flag.ptr);
+        LV_HIP(ctx, hipMemcpyAsync((void*)ctx->pinned, flag.ptr, 4, hipMemcpyDeviceToHost, st));
+        LV_HIP(ctx, hipStreamSynchronize(st));
+        pairs = ctx->pinned[0] == 0u;
+    }
+    ctx->triLeafPairs = pairs;
+    if ((rc = lv_buf_reserve(ctx, ctx->tris, pairs ? size_t(nLeaves) * 64 : size_t(nLeaves) * group * 48))) return rc;
     const float pad = ctx->triPad;
     rc = lv_bvh_build_core(
             ctx, nLeaves, ctx->triNodes, ctx->numTriNodes, ctx->triBvhDepth, ctx->triWideDepth, 14,
@@ -1395,8 +1467,12 @@ int lv_bvh_build_triangles(lv_ctx* ctx) {
                 k_tri_boxes<<<std::min(nblocks(nLeaves), 2048u), LV_BLOCK, 0, st>>>(verts, triIdx, n, group, nLeaves, pad, boxOrig, bounds);
             },
             [&](const uint32_t* sortedVals, const float* boxOrig, float* leafBox) {
-                k_tri_leaves<<<nblocks(nLeaves), LV_BLOCK, 0, st>>>(verts, triIdx, boxOrig, sortedVals, n, group, nLeaves,
-                                                                    (float4*)ctx->tris.ptr, leafBox);
+                if (pairs)
+                    k_tri_leaves<true><<<nblocks(nLeaves), LV_BLOCK, 0, st>>>(verts, triIdx, boxOrig, sortedVals, n, group, nLeaves,
+                                                                              (float4*)ctx->tris.ptr, leafBox);
+                else
+                    k_tri_leaves<false><<<nblocks(nLeaves), LV_BLOCK, 0, st>>>(verts, triIdx, boxOrig, sortedVals, n, group, nLeaves,
+                                                                               (float4*)ctx->tris.ptr, leafBox);
             });
     if (rc) return rc;
     ctx->triAccelValid = true;

@@ -272,12 +272,14 @@ struct LvSceneDev {
     uint32_t literalIntersection; // intersection_form = literal: the reference's textbook roots (lv_intersect_capsule_literal)
     // triangle tubes (the reference's RTAO geometry); in the scene view handed to the triangle kernels `nodes` is the
     // triangle LBVH and numSegs the triangle count
-    const float4* tris;         // 48-B records in Morton order: {v0.xyz, triangle index bits}{v1.xyz, 0}{v2.xyz, 0}
+    const float4* tris;         // 48-B records in Morton order: {v0.xyz, triangle index bits}{v1.xyz, 0}{v2.xyz, 0}; or, with triPairs,
+                                // 64-B pair records {q0.xyz, index}{q1.xyz, code}{q2.xyz, 0}{q3.xyz, 0} (k_tri_leaves<true>, lv_bvh.hip)
     const uint32_t* triIdx;     // 3 vertex indices per triangle, input order
     const lv_tube_vertex* triVerts; // 32-B TubeTriangleVertexData, input order
     const lv_line_point* triPoints; // line points referenced by the vertices
     float triPad;               // padding of a triangle's own AABB (part of the ray-triangle test definition)
     uint32_t triLeafSize;       // triangle records per leaf of the triangle LBVH (lv_bvh_build_triangles)
+    uint32_t triPairs;          // leaves hold pair records (then triLeafSize == 2)
     // static RTAO prebaking: AO factor table [parametrisation vertex][tube subdivision] and the per-line-vertex blending
     // weights (AmbientOcclusionFactorsBuffer / AmbientOcclusionBlendingWeightsBuffer, AmbientOcclusion.glsl:31-38)
     const float* bakedAo;
@@ -285,6 +287,7 @@ struct LvSceneDev {
     const float4* prismFrames;  // per leaf {tangent0, index0}{normal0, start0}{tangent1, index1}{normal1, start1} (k_leaves)
     LvPrismDev prism;           // PPLL gather with ppll_fragment_source = raster_prism
 };
+#define LV_TRI_PAIR_CODE_BODY 0x38u // pair records: the second triangle of a tube face = (q0, q2, q3) (k_tri_leaves<true>, lv_bvh.hip)
 #define LV_PRIM_CAPSULE 0
 #define LV_PRIM_TRIANGLE 1
 #define LV_PRIM_ELLIPTIC 2

@@ -42,6 +42,7 @@ struct LvOptions {
     float aoRadius = 0.1f;                    // :151
     bool aoUseDistance = true;                // :152
     uint32_t triLeafSize = 2;                 // triangle_leaf_size: consecutive triangles per leaf of the triangle LBVH (1 ... 8)
+    bool triLeafPairs = true;                 // triangle_leaf_records = pairs (64-B records of four vertices where every pair of triangles shares two, lv_bvh.hip) | triangles (48-B records)
     uint32_t treeletLeaves = 512;             // treelet_leaves: largest subtree the fast_trace build rebuilds (3 ... 4096)
     uint32_t treeletLaneLeaves = 6;           // treelet_lane_leaves: ranges of a treelet up to this size are built one lane per range (0 = the wave splits everything; 2 ... 64; measured: 0 4.5 ms, 4 3.8, 6 3.7, 8 3.9, 16 5.5 for the 1 M segments of config 3)
     uint32_t treeletGroupLeaves = 16;         // treelet_group_leaves: 0 | 8 | 16 -- ranges of <= 8 leaves are built by groups of 8 lanes, with 16 also those of 9 ... 16 leaves by groups of 16 (overrides treelet_lane_leaves; 1 M segments: 0 4.4 ms, 8 2.6, 16 2.4)
@@ -139,6 +140,8 @@ struct lv_ctx {
     uint32_t numTris = 0, numTriVerts = 0, numTriPoints = 0, numTriNodes = 0, triBvhDepth = 0, triWideDepth = 0;
     LvDeviceBuffer triIdx, triVerts, triPoints; // input order
     LvDeviceBuffer triNodes, tris;              // accel
+    LvDeviceBuffer triPairFlag;                 // k_tri_pairs_check's verdict
+    bool triLeafPairs = false;                  // the leaves of the triangle LBVH as built hold 64-B pair records
     bool triMeshSet = false, triAccelValid = false;
     // lv_set_trajectories (lv_lines.hip): the trajectories themselves in HBM; `points` / `segIdx` are then written by the a2 kernels and
     // the tube mesh is tessellated on the device whenever a frame needs it at another line width / subdivision count

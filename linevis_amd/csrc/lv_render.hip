@@ -2228,7 +2228,7 @@ LvSceneDev sceneDev(const lv_ctx* ctx) {
         S.ellCamPos[1] = ((m[1] * 0.0f + m[5] * 0.0f) + m[9] * 0.0f) + m[13] * 1.0f;
         S.ellCamPos[2] = ((m[2] * 0.0f + m[6] * 0.0f) + m[10] * 0.0f) + m[14] * 1.0f;
     }
-    S.tris = nullptr; S.triIdx = nullptr; S.triVerts = nullptr; S.triPoints = nullptr; S.triPad = 0.0f; S.triLeafSize = 1u;
+    S.tris = nullptr; S.triIdx = nullptr; S.triVerts = nullptr; S.triPoints = nullptr; S.triPad = 0.0f; S.triLeafSize = 1u; S.triPairs = 0u;
     S.bakedAo = (const float*)ctx->bakedAo.ptr;
     S.bakedBlendingWeights = (const float*)ctx->bakeBlendingWeights.ptr;
     return S;
@@ -2245,6 +2245,7 @@ LvSceneDev sceneDevTriangles(const lv_ctx* ctx) {
     S.triPoints = (const lv_line_point*)ctx->triPoints.ptr;
     S.triPad = ctx->triPad;
     S.triLeafSize = ctx->triLeafSize;
+    S.triPairs = ctx->triLeafPairs ? 1u : 0u;
     return S;
 }
 

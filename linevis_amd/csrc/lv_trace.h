@@ -603,12 +603,26 @@ __device__ __forceinline__ bool lv_intersect_elliptic_tube(const LvSceneDev& S, 
     return true;
 }
 
-// one triangle record of the triangle LBVH (leaf * S.triLeafSize + slot); low = original triangle index
-__device__ __forceinline__ bool lv_tri_record_test(const LvSceneDev& S, size_t record, f3 o, f3 d, f3 inv, float& t, unsigned& low) {
-    const float4* rec = S.tris + 3 * record;
-    const float4 a = rec[0], b = rec[1], c = rec[2];
+// one triangle of a leaf of the triangle LBVH (slot < S.triLeafSize); low = original triangle index.  Pair records (S.triPairs, the
+// layout is k_tri_leaves<true>'s, lv_bvh.hip): slot 0 = (q0, q1, q2), slot 1 = the three vertices its code selects, fetched by address
+__device__ __forceinline__ bool lv_tri_record_test(const LvSceneDev& S, unsigned leaf, unsigned slot, f3 o, f3 d, f3 inv, float& t,
+                                                   unsigned& low) {
+    float4 a, b, c;
+    if (S.triPairs) {
+        const float4* rec = S.tris + 4 * size_t(leaf);
+        const float4 q0 = rec[0], q1 = rec[1];
+        low = __float_as_uint(q0.w) + slot;
+        if (slot == 0u) { a = q0; b = q1; c = rec[2]; }
+        else {
+            const unsigned code = __float_as_uint(q1.w);
+            a = rec[code & 3u]; b = rec[(code >> 2) & 3u]; c = rec[(code >> 4) & 3u];
+        }
+    } else {
+        const float4* rec = S.tris + 3 * (size_t(leaf) * S.triLeafSize + slot);
+        a = rec[0]; b = rec[1]; c = rec[2];
+        low = __float_as_uint(a.w);
+    }
     float u, v;
-    low = __float_as_uint(a.w);
     return lv_ray_triangle(o, d, inv, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), S.triPad, t, u, v);
 }
 
@@ -623,10 +637,28 @@ __device__ __forceinline__ bool lv_leaf_test(const LvSceneDev& S, unsigned leaf,
         const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
         bool any = false;
         t = 0.0f; low = 0u;
+        if (S.triPairs) {
+            // pair record: four 16-B loads for both triangles; the second triangle's operands are (q0, q2, q3) for a tube face (all
+            // but the cap leaves) and are fetched again by address only by the waves that hold another code
+            const float4* rec = S.tris + 4 * size_t(leaf);
+            const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
+            const unsigned idx0 = __float_as_uint(q0.w), code = __float_as_uint(q1.w);
+            float tj, u, v;
+            if (lv_ray_triangle(o, d, inv, mk3(q0.x, q0.y, q0.z), mk3(q1.x, q1.y, q1.z), mk3(q2.x, q2.y, q2.z), S.triPad, tj, u, v) &&
+                tj >= tLo && tj <= tHi) { t = tj; low = idx0; any = true; }
+            float4 a = q0, b = q2, c = q3;
+            if (code != LV_TRI_PAIR_CODE_BODY) { a = rec[code & 3u]; b = rec[(code >> 2) & 3u]; c = rec[(code >> 4) & 3u]; }
+            if (lv_ray_triangle(o, d, inv, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), S.triPad, tj, u, v) &&
+                tj >= tLo && tj <= tHi) {
+                if (!any || tj < t) { t = tj; low = idx0 + 1u; } // ties stay with the lower index
+                any = true;
+            }
+            return any;
+        }
         for (uint32_t j = 0; j < S.triLeafSize; j++) {
             float tj;
             unsigned idx;
-            if (lv_tri_record_test(S, size_t(leaf) * S.triLeafSize + j, o, d, inv, tj, idx) && tj >= tLo && tj <= tHi) {
+            if (lv_tri_record_test(S, leaf, j, o, d, inv, tj, idx) && tj >= tLo && tj <= tHi) {
                 if (!any || tj < t || (tj == t && idx < low)) { t = tj; low = idx; }
                 any = true;
             }
@@ -971,7 +1003,7 @@ __device__ __forceinline__ void lv_trace_all(const LvSceneDev& S, float radius, 
                 if (PRIM == LV_PRIM_TRIANGLE) {
                     unsigned low;
                     const f3 dd = mk3(rd.x, rd.y, rd.z);
-                    found = lv_tri_record_test(S, size_t(leaf) * S.triLeafSize + sub, mk3(ro.x, ro.y, ro.z), dd,
+                    found = lv_tri_record_test(S, leaf, sub, mk3(ro.x, ro.y, ro.z), dd,
                                                mk3(1.0f / dd.x, 1.0f / dd.y, 1.0f / dd.z), t, low);
                     kind = int(low);
                 } else if (PRIM == LV_PRIM_ELLIPTIC) {

@@ -350,6 +350,56 @@ def test_triangles_per_leaf_do_not_change_any_hit(hip_lib, leaf_size):
         ctx.set_option("triangle_leaf_size", 9)
 
 
+def _hits_equal_brute_force(ctx, ts, seed=9):
+    o, d = random_rays(20000, seed)
+    for tmin, tmax in [(0.0, 0.1), (0.02, 0.05), (1e-4, 1000.0)]:
+        a = ctx.trace_rays_triangles(o, d, tmin, tmax)
+        b = ts.trace_rays(o, d, tmin, tmax, use_bvh=False)
+        assert np.array_equal(a[1], b[1]) and np.array_equal(bits(a[0]), bits(b[0])) and np.array_equal(bits(a[2]), bits(b[2]))
+    assert (a[1] != 0xFFFFFFFF).sum() > 1000
+
+
+@pytest.mark.parametrize("records,leaf_bytes", [("pairs", 64), ("triangles", 96)])
+def test_pair_records_do_not_change_any_hit(hip_lib, records, leaf_bytes):
+    """triangle_leaf_records: a leaf of two triangles stores its four vertices once (64 B) or as two 48-B records.  Closest hits
+    (t, triangle, barycentrics) against brute force and every AO factor bit for bit in both forms -- body faces (code (q0, q2, q3)),
+    cap quads and the pole fans (other codes) all lie in the rays' way."""
+    lw = 0.02
+    tr = curves(n_lines=31, pts_per_line=9)       # short lines: a third of the triangles belong to caps
+    mesh = mesh_of(tr, lw)
+    case = small_case(line_width=lw, **RTAO_TRI, ambient_occlusion_iterations=2, ambient_occlusion_samples_per_frame=6)
+    ctx = tri_context(case, mesh)
+    ctx.set_option("triangle_leaf_records", records)
+    ts = lvo.TriScene(*mesh, lw)
+    _hits_equal_brute_force(ctx, ts)
+    assert ctx.stats().tri_leaf_bytes == leaf_bytes
+    ctx.render(capi.MODE_RAY_TRACER)
+    P = case.oracle_params(case.oracle_scene())
+    assert np.array_equal(bits(ctx.get_ao()), bits(ts.render_ao(P, use_bvh=False)))
+    with pytest.raises(Exception):
+        ctx.set_option("triangle_leaf_records", "quads")
+
+
+def test_pair_records_on_meshes_the_tessellator_does_not_write(hip_lib):
+    """A caller's mesh (lv_set_tube_triangle_mesh takes any index buffer): (1) an odd triangle count leaves the last pair record
+    half empty; (2) second triangles with rotated vertex order are still encodable -- the test must run on THEIR operand order, as
+    brute force does; (3) a shuffled triangle order has leaves whose triangles share nothing: the build keeps 48-B records."""
+    lw = 0.02
+    tr = curves(n_lines=13, pts_per_line=17)
+    idx, verts, pts = mesh_of(tr, lw)
+    idx = np.ascontiguousarray(idx, dtype=np.uint32).reshape(-1, 3)
+    case = small_case(line_width=lw)
+    rng = np.random.default_rng(4)
+    rotated = idx.copy()
+    rotated[1::2] = np.roll(rotated[1::2], 1, axis=1)            # (a, c, d) -> (d, a, c)
+    flip = rng.random(len(rotated) // 2) < 0.5
+    rotated[1::2][flip] = np.roll(rotated[1::2][flip], 1, axis=1)
+    for name, ind, want in [("odd", idx[:-1], 64), ("rotated", rotated, 64), ("shuffled", idx[rng.permutation(len(idx))], 96)]:
+        ctx = tri_context(case, (ind, verts, pts))
+        _hits_equal_brute_force(ctx, lvo.TriScene(ind, verts, pts, lw))
+        assert ctx.stats().tri_leaf_bytes == want, name
+
+
 def test_defaults_are_the_reference_geometry_and_roots(hip_lib):
     """Library defaults: rtao_geometry = "auto" traces the reference's triangle tubes as soon as the mesh of the current lines is there
     (capsules before, and again after new lines), intersection_form = "auto" is the reference's literal roots in every frame the
