@@ -40,14 +40,31 @@ torch.cuda.synchronize()
 costs = ctx.ao_tile_costs().astype(np.float64) * 64.0 + 4.0 * 64 * 64
 
 
+# LV_PROBE_SUBTILE=WxH: a rank still owns 64 x 64 tiles but hands them to the renderer as W x H rectangles (W, H divide 64).  A tile kernel
+# gives every rectangle a 64 x 64 group of 64 waves, so 32x32 = the same pixels on four times the waves, each a quarter full: a shorter
+# critical path for the primary-ray kernels of a rank that owns few tiles, at the price of more wave-level work
+SUBW, SUBH = [int(x) for x in os.environ.get("LV_PROBE_SUBTILE", "64x64").split("x")]
+
+
+def subdivide(tiles):
+    if (SUBW, SUBH) == (64, 64):
+        return tiles
+    t = np.asarray(tiles, dtype=np.uint32)
+    ox, oy = np.meshgrid(np.arange(0, 64, SUBW, dtype=np.uint32), np.arange(0, 64, SUBH, dtype=np.uint32), indexing="xy")
+    sub = t[:, None, :] + np.stack([ox.reshape(-1), oy.reshape(-1)], axis=1)[None, :, :]
+    sub = sub.reshape(-1, 2)
+    return np.ascontiguousarray(sub[(sub[:, 0] < W) & (sub[:, 1] < H)])
+
+
 def time_tiles(tiles, depth, reps=40):
-    outs = [torch.zeros((len(tiles), 64, 64, 4), dtype=torch.uint8, device="cuda:0") for _ in range(depth)]
+    tiles = subdivide(tiles)
+    outs = [torch.zeros((len(tiles), SUBH, SUBW, 4), dtype=torch.uint8, device="cuda:0") for _ in range(depth)]
     for k in range(4):
-        fns[k % depth](outs[k % depth], tiles, 64, 64)
+        fns[k % depth](outs[k % depth], tiles, SUBW, SUBH)
     torch.cuda.synchronize(); ctx.reset_timers()
     t0 = time.perf_counter()
     for k in range(reps):
-        fns[k % depth](outs[k % depth], tiles, 64, 64)
+        fns[k % depth](outs[k % depth], tiles, SUBW, SUBH)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps * 1e3
     st = ctx.stats()
@@ -74,4 +91,5 @@ for world in [int(x) for x in os.environ.get("LV_PROBE_WORLDS", "2,4,8").split("
     report["worlds"][str(world)] = row
 os.makedirs(os.path.join(R, "gpurun_out"), exist_ok=True)
 report["settings_override"] = os.environ.get("LV_PROBE_SET", "")
+report["subtile"] = [SUBW, SUBH]
 json.dump(report, open(os.path.join(R, "gpurun_out", "shard_probe_%s%s.json" % (wl, os.environ.get("LV_PROBE_TAG", ""))), "w"), indent=1)
