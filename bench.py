@@ -37,7 +37,7 @@ LINE_WIDTH = 0.002
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E vendor peak (MI355X_MICROARCH.md; ~6.3 TB/s attainable)
 L2_PEAK_GBS = 34500.0     # aggregate L2 bandwidth (MI355X_MICROARCH.md "L2")
 NUM_CUS, NUM_SIMDS = 256, 1024
-PROFILE_TAGS = ("r05", "r04", "r03", "r02")   # counter files of the newest round that has them (profiles/pmc_<tag>_<workload>.json)
+PROFILE_TAGS = ("r06", "r05", "r04", "r03", "r02")   # counter files of the newest round that has them (profiles/pmc_<tag>_<workload>.json)
 CLOCK_GHZ = 2.4                  # MI355X peak engine clock (MI355X_MICROARCH.md)
 SETTINGS = {
     "ambient_occlusion_mode": "RTAO (Screen Space)", "ambient_occlusion_strength": 1.0,
@@ -248,7 +248,7 @@ def roofline(kernel, pmc_key, ms_launch, algorithmic_bytes, world):
            "algorithmic_touch_rate_GBs": round(algorithmic_bytes / (ms_launch * 1e-3) / 1e9, 1) if ms_launch > 0 else None,
            "algorithmic_note": ("segment rasteriser: 96 B per segment (record + frames) + 4 B per coverage test + 16 B per fragment "
                                 "(12-B record, count update): compulsory bytes of the launch" if kernel == "k_ppll_raster_prism" else
-                                "SURVEY.md 8(d) byte model: 64 B per node visited + 32/48 B per primitive tested + per-pixel records, "
+                                "SURVEY.md 8(d) byte model: 64 B per node visited + 32 B per primitive tested (48 B per triangle with triangle_leaf_records=triangles) + per-pixel records, "
                                 "'every touch goes to memory'; most of these bytes are served by L1/L2 (see ceilings): NOT a "
                                 "bandwidth and not bounded by the HBM peak"),
            "source_sha": sha}
@@ -788,7 +788,8 @@ def main():
         if dist_on:
             dist.all_reduce(counters)
         rays_per_frame = float(counters[0].item())
-        prim_bytes = 48 if w.get("mesh") else 32   # 48-B triangle record / 32-B segment record
+        # 32-B segment record; triangle tubes: 48-B triangle records, or 32 B per triangle of a 64-B pair record (triangle_leaf_records = pairs)
+        prim_bytes = (32 if getattr(st, "tri_leaf_bytes", 0) == 64 else 48) if w.get("mesh") else 32
         ao_bytes = st.ao_nodes_visited * 64 + st.ao_prims_tested * prim_bytes + st.ao_hit_pixels * 52
         frame_bytes = (st.nodes_visited * 64 + st.prims_tested * 32 + st.hits_shaded * 96 + st.ao_hit_pixels * 52
                        + len(sf.local_tiles) * TILE * TILE * (4 + 4) + st.fragments * (12 + 4 + 4 + 12))
@@ -1006,8 +1007,13 @@ def main():
             result["pcie_inclusive"] = head["host"]
         result["roofline"]["frame_algorithmic_bytes_rank0"] = int(head["frame_bytes"])
         if seg is not None:   # compulsory floor: every node, primitive record and line point once + the outputs
+            tri_rec = 32 if getattr(st, "tri_leaf_bytes", 0) == 64 else 48   # per triangle: half a 64-B pair record, or a 48-B record
             result["roofline"]["frame_compulsory_bytes"] = int(st.num_nodes * 64 + len(seg) * 32 + len(pts) * 48 + W * H * (4 + 4)
-                                                               + (st.num_tube_triangles * (48 + 32) if wl.get("mesh") else 0))
+                                                               + ((st.num_tube_triangles * (tri_rec + 32) + st.num_tri_nodes * 64)
+                                                                  if wl.get("mesh") else 0))
+            result["roofline"]["frame_compulsory_what"] = ("segment LBVH nodes + segment records + line points + outputs" +
+                                                           (" + triangle LBVH nodes + leaf records (%d B per triangle) + 32-B vertices" % tri_rec
+                                                            if wl.get("mesh") else "") + ", each once (until round 5 without the triangle LBVH's nodes)")
             if result["roofline"].get("traffic"):   # counter traffic of the dominant kernel against reading everything exactly once
                 result["roofline"]["traffic_over_compulsory"] = round(result["roofline"]["traffic"]
                                                                       / result["roofline"]["frame_compulsory_bytes"], 3)

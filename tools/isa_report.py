@@ -117,7 +117,7 @@ def node_step_loop(body):
 
 
 def main():
-    out_path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "isa_r05.txt")
+    out_path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "isa_r06.txt")
     lines = ["# ISA report of the frame kernels (hipcc %s, gfx950); generated by tools/isa_report.py" % " ".join(lv_build.FLAGS), ""]
     with tempfile.TemporaryDirectory() as tmp:
         for src in ("lv_render.hip", "lv_mlat.hip"):

@@ -4,7 +4,7 @@
 #   rocprofv3 --kernel-trace --stats       -> gpurun_out/prof_<tag>/<workload>_kernel_stats.csv  (same command as the bench line)
 #   PMC counter groups (tools/pmc_collect.sh: full set for c3c / c3t / c4, roofline set for the others) -> gpurun_out/pmc_<tag>/
 #   shard / frames-in-flight probe          -> gpurun_out/shard_probe_<workload>.json
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
