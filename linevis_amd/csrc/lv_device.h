@@ -247,6 +247,8 @@ struct LvPrismDev {
     float viewZ[4];
     float nearDist, farDist;
     uint32_t n;
+    // coverage direction of a pixel (lv_prism_cov_dir, lv_prism.h): D = covC0 + (x + 0.5) covCx + (y + 0.5) covCy
+    float covC0[3], covCx[3], covCy[3];
 };
 
 // HBM-resident scene (all read-only during rendering)

@@ -16,9 +16,16 @@
 // in the space of the pixel's viewing ray (float32, -ffp-contract=off, fused multiply-adds exactly where written as fmaf; the CPU
 // checker of the test-suite restates the same operations in the same order, an independent float64 screen-space rasteriser in
 // tests/test_prism_raster.py confirms fragments, weights and colours):
-//   viewing ray     the pixel-centre ray (o, d) of the ray generator (TubeRayTracing.glsl:219-226: what gl_FragCoord = pixel + 0.5
-//                   unprojects to); P = cross(R, d), Q = cross(d, P) with R = the camera's right axis: P, Q, d are mutually orthogonal,
-//                   (A . P, A . Q) are -- up to positive factors -- the coordinates of A in the plane perpendicular to the ray
+//   viewing ray     the pixel-centre ray of the ray generator (TubeRayTracing.glsl:219-226: what gl_FragCoord = pixel + 0.5
+//                   unprojects to).  COVERAGE is decided with its direction before the normalisation, written as the affine function of
+//                   the pixel it is (round 6; the edge functions are homogeneous in the direction, and the generator's two divisions
+//                   and its normalisation were a quarter of the coverage stage): target = invProj (ndc.x, ndc.y, 1, 1), dir = invView
+//                   (target.xyz, 0), ndc.x = 2 (x + 0.5) / W - 1  =>  D = C0 + (x + 0.5) Cx + (y + 0.5) Cy with a = invView3 invProj[:,0].xyz,
+//                   b = invView3 invProj[:,1].xyz, c = invView3 (invProj[:,2] + invProj[:,3]).xyz, Cx = a (2 / W), Cy = b (2 / H), C0 =
+//                   (c - a) - b (float32 on the host, lv_prism_cov_constants), D.k = fma(x + 0.5, Cx.k, fma(y + 0.5, Cy.k, C0.k)).
+//                   P = cross(R, D), Q = cross(D, P) with R = the camera's right axis: P, Q, D are mutually orthogonal, (A . P, A . Q)
+//                   are -- up to positive factors -- the coordinates of A in the plane perpendicular to the ray.  Weights, depth and
+//                   the acceptance rules of a covered triangle's fragment use the generator's normalised ray as before.
 //   ring vertex     V = c + r (n cos + b sin) of a line point (c, n, b = cross(t, n)):  x = fma(r, fma(b . P, sin, (n . P) cos), (c - o) . P),
 //                   y likewise with Q (fused dot products): six dot products per (ray, line point), two fmas per coordinate -- a pure
 //                   function of (line point, circle index, ray): both triangles at an edge, both segments at a point see the same bits
@@ -47,6 +54,13 @@
 
 #include "lv_device.h"
 
+// coverage direction of pixel (x, y) (header: "viewing ray")
+__device__ __forceinline__ f3 lv_prism_cov_dir(const LvPrismDev& R, uint32_t x, uint32_t y) {
+    const float fx = float(x) + 0.5f, fy = float(y) + 0.5f;
+    return mk3(__builtin_fmaf(fx, R.covCx[0], __builtin_fmaf(fy, R.covCy[0], R.covC0[0])),
+               __builtin_fmaf(fx, R.covCx[1], __builtin_fmaf(fy, R.covCy[1], R.covC0[1])),
+               __builtin_fmaf(fx, R.covCx[2], __builtin_fmaf(fy, R.covCy[2], R.covC0[2])));
+}
 __device__ __forceinline__ void lv_prism_basis(const LvPrismDev& R, f3 d, f3& P, f3& Q) {
     P = cross3(mk3(R.right[0], R.right[1], R.right[2]), d);
     Q = cross3(d, P);

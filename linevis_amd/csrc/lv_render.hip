@@ -1629,8 +1629,7 @@ __global__ __launch_bounds__(LV_BLOCK, LV_PRISM_RASTER_MIN_WAVES) void k_ppll_ra
             const uint32_t px = pix & 0xFFFFu, py = pix >> 16;
             addr = lv_ppll_addr(px, py, U.ppllPaddedW, U.ppllTileW, U.ppllTileH);
             // (no requested-tile test here: a whole-viewport frame requests every pixel, a rank of a sharded frame filters in stage A)
-            f3 oo, d;
-            lv_primary_ray(U, px, py, 0.5f, 0.5f, oo, d);
+            const f3 d = lv_prism_cov_dir(R, px, py);   // the pixel's coverage direction (unnormalised, lv_prism.h)
             const uint32_t sl = leaf >> 26;   // the pair's segment among the wave's 64 = the lane that queued it
             leaf &= 0x03FFFFFFu;
             LvPrismPoint pt[2];
@@ -2280,6 +2279,25 @@ bool lv_ppll_prism_source(const lv_ctx* ctx) {
     return o.ppllFragmentSource == 2 ? true : built;
 }
 // per-frame constants of the rasterised prism (LvPrismDev)
+// constants of the coverage direction (lv_prism.h "viewing ray"); float32, one fixed order -- the CPU checker of the test-suite states the same
+static void lv_prism_cov_constants(const float* invView, const float* invProj, uint32_t width, uint32_t height, float C0[3], float Cx[3],
+                                   float Cy[3]) {
+    auto mul3 = [&](const float* v, float out[3]) {   // invView3 * v
+        for (int k = 0; k < 3; k++) out[k] = (invView[k] * v[0] + invView[4 + k] * v[1]) + invView[8 + k] * v[2];
+    };
+    const float p23[3] = {invProj[8] + invProj[12], invProj[9] + invProj[13], invProj[10] + invProj[14]};
+    float a[3], b[3], c[3];
+    mul3(invProj, a);
+    mul3(invProj + 4, b);
+    mul3(p23, c);
+    const float sx = 2.0f / float(width), sy = 2.0f / float(height);
+    for (int k = 0; k < 3; k++) {
+        Cx[k] = a[k] * sx;
+        Cy[k] = b[k] * sy;
+        C0[k] = (c[k] - a[k]) - b[k];
+    }
+}
+
 static void lv_fill_prism(const lv_ctx* ctx, const LvUniforms& U, LvPrismDev& R) {
     uint32_t n = ctx->opt.tubeNumSubdivisions;
     if (n < 3u) n = 3u;
@@ -2296,6 +2314,7 @@ static void lv_fill_prism(const lv_ctx* ctx, const LvUniforms& U, LvPrismDev& R)
     R.viewZ[0] = U.view[2]; R.viewZ[1] = U.view[6]; R.viewZ[2] = U.view[10]; R.viewZ[3] = U.view[14];
     R.nearDist = U.nearDist;
     R.farDist = U.farDist;
+    lv_prism_cov_constants(U.invView, U.invProj, U.width, U.height, R.covC0, R.covCx, R.covCy);
 }
 
 void lv_fill_uniforms(const lv_ctx* ctx, LvUniforms& U) {

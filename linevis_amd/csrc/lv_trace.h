@@ -934,9 +934,12 @@ __device__ __forceinline__ void lv_trace_all(const LvSceneDev& S, float radius, 
         if (lane < nB) {
             ref = hq.prismQueue[(pHead + lane) % LV_HITQ_CAP];
             const unsigned ow = ref >> 26, leaf = ref & 0x03FFFFFFu;
-            const float4 ro = cm.ray[2 * ow], rd = cm.ray[2 * ow + 1];
-            mask = S.prism.n == 6u ? lv_prism_coverage<6>(S, radius, leaf, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z))
-                                   : lv_prism_coverage<0>(S, radius, leaf, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z));
+            const float4 ro = cm.ray[2 * ow];
+            // the owner's pixel = its second payload word (k_ppll_gather) -> the pixel's coverage direction (lv_prism.h)
+            const unsigned pxy = unsigned(cm.key[ow] >> 32);
+            const f3 D = lv_prism_cov_dir(S.prism, pxy & 0xFFFFu, pxy >> 16);
+            mask = S.prism.n == 6u ? lv_prism_coverage<6>(S, radius, leaf, mk3(ro.x, ro.y, ro.z), D)
+                                   : lv_prism_coverage<0>(S, radius, leaf, mk3(ro.x, ro.y, ro.z), D);
         }
         pHead += nB;
         while (__ballot(mask != 0u)) {

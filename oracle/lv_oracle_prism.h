@@ -273,6 +273,31 @@ inline void prismSegmentFragments(const lvo_scene& sc, const lvo_params& P, cons
     }
 }
 
+// Coverage direction of pixel (x, y) -- build-owned, like the whole rasteriser definition (the reference's is the fixed-function unit):
+// the direction of the ray generator (TubeRayTracing.glsl:219-226) BEFORE its normalisation, as the affine function of the pixel it is:
+//   target = invProj (ndc.x, ndc.y, 1, 1), dir = invView (target.xyz, 0), ndc.x = 2 (x + 0.5) / W - 1
+//   => D = C0 + (x + 0.5) Cx + (y + 0.5) Cy,  a = invView3 invProj[:,0].xyz, b = invView3 invProj[:,1].xyz, c = invView3 (invProj[:,2] +
+//   invProj[:,3]).xyz, Cx = a (2 / W), Cy = b (2 / H), C0 = (c - a) - b; evaluated with one fma per term.  The edge functions are
+//   homogeneous in the direction, so this decides the same coverage as the normalised ray except where an edge function rounds to a
+//   different side of zero.
+inline V3 prismCoverageDir(const lvo_params& P, const Frame& F, uint32_t x, uint32_t y) {
+    auto mul3 = [&](const float* v, float out[3]) {
+        for (int k = 0; k < 3; k++) out[k] = (F.invView[k] * v[0] + F.invView[4 + k] * v[1]) + F.invView[8 + k] * v[2];
+    };
+    const float p23[3] = {F.invProj[8] + F.invProj[12], F.invProj[9] + F.invProj[13], F.invProj[10] + F.invProj[14]};
+    float a[3], b[3], c[3], D[3];
+    mul3(F.invProj, a);
+    mul3(F.invProj + 4, b);
+    mul3(p23, c);
+    const float sx = 2.0f / float(P.width), sy = 2.0f / float(P.height);
+    const float fx = float(x) + 0.5f, fy = float(y) + 0.5f;
+    for (int k = 0; k < 3; k++) {
+        const float Cx = a[k] * sx, Cy = b[k] * sy, C0 = (c[k] - a[k]) - b[k];
+        D[k] = fmaf(fx, Cx, fmaf(fy, Cy, C0));
+    }
+    return v3(D[0], D[1], D[2]);
+}
+
 // candidate segments of a ray: every segment whose (padded) box the ray meets within [tMin - slack, tMax + slack], ascending
 inline void prismCandidates(const lvo_scene& sc, bool useBvh, V3 o, V3 d, float tMin, float tMax, float slack,
                             std::vector<uint32_t>& out, Counters& cnt) {
@@ -304,7 +329,7 @@ inline void prismPixelFragments(const lvo_scene& sc, const lvo_params& P, const 
     primaryRay(P, F, x, y, 0.5f, 0.5f, o, d);
     cnt.rays++;
     out.clear();
-    const PrismBasis B = prismBasis(F, d);
+    const PrismBasis B = prismBasis(F, prismCoverageDir(P, F, x, y));   // coverage: the unnormalised direction; all else: the ray (o, d)
     const float tMin = 0.0001f, tMax = 1000.0f;   // the gather's ray interval (depth clipping is the near / far test above)
     prismCandidates(sc, useBvh, o, d, tMin, tMax, R.radius / length(d), cand, cnt);
     for (uint32_t seg : cand) {
