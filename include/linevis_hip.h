@@ -426,15 +426,20 @@ int lv_get_streamlines(lv_ctx* ctx, float* positions, float* attributes, uint32_
  * cell within minimum_separation_distance of an earlier line's point, and a sample whose cell is taken is skipped.  The reference
  * traces these lines one after the other on the CPU; here batches of the next seeds are traced speculatively in parallel on the GPU
  * and committed in seeding order on the host, each line cut where an earlier line of its batch claimed the cell first -- the same
- * lines, point for point.  Built: termination_check_type 1 (grid-based, the reference's default), all five loop_check_modes (the
+ * lines, point for point.  Built: all four termination_check_types (1 = grid-based, the reference's default; 0 / 2 / 3 = naive /
+ * k-d tree / hashed grid: a line ends where it comes within minimum_separation_distance of a POINT of an earlier line -- the lines
+ * are cut on the host by that exact predicate, the device tests against the points finished before the batch), all five loop_check_modes (the
  * per-line state of "All Points" / "Grid" / "Curvature" lives in the tracing thread; sgl's HashedGrid and CircularQueue are not
  * vendored: the sphere query is distance <= radius over the line's own points, the queue a FIFO of 32; acos of "Curvature" is the
- * build's fixed formula); not built: the naive / k-d tree / hashed-grid termination checks, Runge-Kutta-Fehlberg (its step width
- * carries over from line to line in the reference).  helicity_field: xs * ys * zs floats (computeHelicityFieldNormalized).
+ * build's fixed formula; getHasPointCloserThan of sgl's KdTree / HashedGrid: distance < r like the naive loop's glm::distance test);
+ * not built: Runge-Kutta-Fehlberg (its step width carries over from line to line in the reference).  helicity_field: xs * ys * zs floats (computeHelicityFieldNormalized).
  * The result is fetched with lv_get_streamlines like lv_trace_streamlines'. */
 typedef struct lv_helicity_seeding_settings {
     float minimum_separation_distance;   /* 0.08, StreamlineTracingDefines.hpp:158 */
-    uint32_t termination_check_type;      /* TerminationCheckType :89-94: 1 = grid-based */
+    uint32_t termination_check_type;      /* TerminationCheckType :89-94: 0 naive, 1 grid-based (the default), 2 k-d tree-based, 3 hashed
+                                           * grid-based.  0 / 2 / 3 are one predicate -- a point of a finished line closer than
+                                           * minimum_separation_distance -- behind three searches in the reference, one here (a uniform
+                                           * grid of the finished points in HBM); 0 does not filter the seeds (StreamlineSeeder.cpp:452) */
     uint32_t loop_check_mode;             /* LoopCheckMode :99-101: 0 none, 1 start point, 2 all points, 3 grid, 4 curvature */
     float termination_distance_self;      /* 1.0 (:156): start-point loop check within |box| / 100 times this */
     int32_t seeding_subsampling_factor;   /* 1 (:174) */

@@ -1048,8 +1048,9 @@ int lv_trace_streamlines_max_helicity_first(lv_ctx* ctx, const float* helicity_f
     if (settings->integration_direction > 2u) return lv_fail(ctx, LV_E_INVALID, "integration direction must be 0, 1 or 2");
     if (!(settings->time_step_scale > 0.0f) || settings->max_num_iterations <= 0 || settings->max_num_iterations > 1000000)
         return lv_fail(ctx, LV_E_INVALID, "time_step_scale must be > 0 and max_num_iterations in 1..1e6");
-    if (seeding->termination_check_type != 1u)
-        return lv_fail(ctx, LV_E_INVALID, "termination_check_type %u is not built (1 = grid-based)", seeding->termination_check_type);
+    if (seeding->termination_check_type > 3u)
+        return lv_fail(ctx, LV_E_INVALID, "termination_check_type %u (0 naive, 1 grid-based, 2 k-d tree-based, 3 hashed grid-based)",
+                       seeding->termination_check_type);
     if (seeding->loop_check_mode > 4u)
         return lv_fail(ctx, LV_E_INVALID, "loop_check_mode %u (0 none, 1 start point, 2 all points, 3 grid, 4 curvature)", seeding->loop_check_mode);
     if (!(seeding->minimum_separation_distance >= 0.0f) || seeding->seeding_subsampling_factor < 1)

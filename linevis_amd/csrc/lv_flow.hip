@@ -268,6 +268,49 @@ __host__ __device__ __forceinline__ uint32_t lv_occupancy_cell(int xs, int ys, i
     return uint32_t(x) + uint32_t(y) * uint32_t(xs - 1) + uint32_t(z) * uint32_t(xs - 1) * uint32_t(ys - 1);
 }
 
+// Point-based termination checks (TerminationCheckType NAIVE / KD_TREE_BASED / HASHED_GRID_BASED, StreamlineTracingGrid.cpp:676-689,
+// StreamlineSeeder.cpp:514-529): "some point of a finished trajectory lies closer than minimumSeparationDistance".  The reference answers it
+// by a loop over every finished point, a k-d tree or a hashed grid (sgl's, not vendored) -- three searches for ONE predicate, here
+// distance(p, q) = sqrt((dx dx + dy dy) + dz dz) < r in float32.  MI355X form: the finished points live in HBM in per-cell linked lists of a
+// uniform grid with cells >= r (a point within r of p lies in the 3 x 3 x 3 cells around p's), appended by k_flow_points_insert after
+// every committed batch; a traced line walks the 27 lists of its new point.
+struct LvFlowPoints {
+    const float* pts;        // 3 floats per finished point
+    const int32_t* next;     // next point of the same cell, -1 = end
+    const int32_t* head;     // first point of a cell, -1 = empty
+    int nx, ny, nz;
+    float invCell, r;
+};
+__host__ __device__ __forceinline__ void lv_flow_points_cell(int nx, int ny, int nz, float invCell, float px, float py, float pz, int& x,
+                                                             int& y, int& z) {
+    x = int(px * invCell); y = int(py * invCell); z = int(pz * invCell);
+    x = x < 0 ? 0 : (x > nx - 1 ? nx - 1 : x);
+    y = y < 0 ? 0 : (y > ny - 1 ? ny - 1 : y);
+    z = z < 0 ? 0 : (z > nz - 1 ? nz - 1 : z);
+}
+__host__ __device__ __forceinline__ bool lv_flow_points_closer(const float* pts, const int32_t* next, const int32_t* head, int nx, int ny,
+                                                               int nz, float invCell, float r, float px, float py, float pz) {
+    int cx, cy, cz;
+    lv_flow_points_cell(nx, ny, nz, invCell, px, py, pz, cx, cy, cz);
+    for (int z = (cz > 0 ? cz - 1 : 0); z <= (cz < nz - 1 ? cz + 1 : nz - 1); z++)
+        for (int y = (cy > 0 ? cy - 1 : 0); y <= (cy < ny - 1 ? cy + 1 : ny - 1); y++)
+            for (int x = (cx > 0 ? cx - 1 : 0); x <= (cx < nx - 1 ? cx + 1 : nx - 1); x++)
+                for (int32_t i = head[(size_t(z) * ny + y) * nx + x]; i >= 0; i = next[i]) {
+                    const float ddx = px - pts[3 * size_t(i)], ddy = py - pts[3 * size_t(i) + 1], ddz = pz - pts[3 * size_t(i) + 2];
+                    if (sqrtf((ddx * ddx + ddy * ddy) + ddz * ddz) < r) return true;
+                }
+    return false;
+}
+__global__ __launch_bounds__(LV_BLOCK) void k_flow_points_insert(const float* __restrict__ pts, int32_t* __restrict__ next,
+                                                                 int32_t* __restrict__ head, int nx, int ny, int nz, float invCell,
+                                                                 uint32_t first, uint32_t count) {
+    const uint32_t i = first + blockIdx.x * LV_BLOCK + threadIdx.x;
+    if (i >= first + count) return;
+    int x, y, z;
+    lv_flow_points_cell(nx, ny, nz, invCell, pts[3 * size_t(i)], pts[3 * size_t(i) + 1], pts[3 * size_t(i) + 2], x, y, z);
+    next[i] = atomicExch(&head[(size_t(z) * ny + y) * nx + x], int32_t(i));
+}
+
 // _traceStreamlineDecreasingHelicity + _isTerminated (StreamlineTracingGrid.cpp:546-738) for a batch of seeds, traced SPECULATIVELY
 // against the occupancy grid as it stood when the batch was formed (lv_flow_trace_max_helicity_first commits the lines in seeding
 // order and cuts each one where a line committed before it has claimed the cell: a point is pushed after its own termination
@@ -282,7 +325,7 @@ __global__ __launch_bounds__(LV_WAVE) void k_trace_streamlines_seeded(const LvFl
                                                                       const uint8_t* __restrict__ occupancy, uint32_t capacity,
                                                                       float* __restrict__ positions, float* __restrict__ attributes,
                                                                       uint32_t* __restrict__ counts, uint32_t* __restrict__ selfGrid,
-                                                                      uint32_t selfGridWords) {
+                                                                      uint32_t selfGridWords, const LvFlowPoints fp) {
     const uint32_t t = blockIdx.x * LV_WAVE + threadIdx.x;
     if (t >= numThreads) return;
     // state of the other loop checks (members of the reference's tracer, reset after every line, :727-737): "Grid" = the cells this line
@@ -386,7 +429,9 @@ __global__ __launch_bounds__(LV_WAVE) void k_trace_streamlines_seeded(const LvFl
             segmentSum++;
             if (segmentSum > 100u && curvatureSum > double(2.5f)) break;
         }
-        if (occupancy[lv_occupancy_cell(g.xs, g.ys, g.zs, g.dx, g.dy, g.dz, cur.x, cur.y, cur.z)]) break;
+        // the termination check against the lines finished before this batch: occupied cell (grid-based), or a finished point closer than r
+        if (occupancy ? occupancy[lv_occupancy_cell(g.xs, g.ys, g.zs, g.dx, g.dy, g.dz, cur.x, cur.y, cur.z)] != 0
+                      : lv_flow_points_closer(fp.pts, fp.next, fp.head, fp.nx, fp.ny, fp.nz, fp.invCell, fp.r, cur.x, cur.y, cur.z)) break;
         push(cur);
         lv_integration_step(g, method, cur, dt, fw, timeStepScale);
         iterationCounter++;
@@ -593,10 +638,36 @@ int lv_flow_trace_max_helicity_first(lv_ctx* ctx, const float* helicityField, co
     // ascending, taken from the back (std::sort in the reference: the order of equal values is unspecified there; here: creation order)
     std::stable_sort(queue.begin(), queue.end(), [](const Sample& a, const Sample& b) { return a.value < b.value; });
     const size_t numCells = size_t(xs - 1) * (ys - 1) * (zs - 1);
-    std::vector<uint8_t> occupancy(numCells, 0);
+    // termination_check_type (TerminationCheckType): 1 = the occupancy grid; 0 / 2 / 3 = naive / k-d tree / hashed grid = the point
+    // predicate above (0 does not filter the seeds: StreamlineMaxHelicityFirstSeeder::hasNextPoint's last branch, StreamlineSeeder.cpp:452-454)
+    const bool gridCheck = H->termination_check_type == 1u;
+    const bool filterSeeds = H->termination_check_type != 0u;
+    std::vector<uint8_t> occupancy(gridCheck ? numCells : 0, 0);
     int rc;
-    if ((rc = lv_buf_reserve(ctx, ctx->flowOccupancy, numCells))) return rc;
-    LV_HIP(ctx, hipMemsetAsync(ctx->flowOccupancy.ptr, 0, numCells, st));
+    if (gridCheck) {
+        if ((rc = lv_buf_reserve(ctx, ctx->flowOccupancy, numCells))) return rc;
+        LV_HIP(ctx, hipMemsetAsync(ctx->flowOccupancy.ptr, 0, numCells, st));
+    }
+    // the finished points' grid: cells of max(r, longest box edge / 128), on the host (exact cut of the speculative lines) and in HBM
+    const float rSep = H->minimum_separation_distance;
+    LvFlowPoints fp{};
+    std::vector<int32_t> fpHead, fpNext;
+    std::vector<float> fpPts;
+    size_t fpOnDevice = 0;
+    if (!gridCheck) {
+        const float cell = std::max(rSep, std::max(g.bx, std::max(g.by, g.bz)) / 128.0f);
+        if (!(cell > 0.0f)) return lv_fail(ctx, LV_E_INVALID, "termination_check_type %u needs a grid with an extent", H->termination_check_type);
+        fp.invCell = 1.0f / cell;
+        fp.r = rSep;
+        fp.nx = std::max(1, int(g.bx * fp.invCell) + 1); fp.ny = std::max(1, int(g.by * fp.invCell) + 1); fp.nz = std::max(1, int(g.bz * fp.invCell) + 1);
+        fpHead.assign(size_t(fp.nx) * fp.ny * fp.nz, -1);
+        if ((rc = lv_buf_reserve(ctx, ctx->flowOccupancy, fpHead.size() * 4))) return rc;   // (the occupancy buffer holds the list heads)
+        LV_HIP(ctx, hipMemsetAsync(ctx->flowOccupancy.ptr, 0xFF, fpHead.size() * 4, st));
+        fp.head = (const int32_t*)ctx->flowOccupancy.ptr;   // (all lists empty: pts / next are not read before the first insert)
+    }
+    auto pointTerminated = [&](const float* q) {
+        return lv_flow_points_closer(fpPts.data(), fpNext.data(), fpHead.data(), fp.nx, fp.ny, fp.nz, fp.invCell, fp.r, q[0], q[1], q[2]);
+    };
     // ---- constants of _traceStreamribbonsDecreasingHelicity / _isTerminated, StreamlineTracingGrid.cpp:553-557,767-773
     const float dt = 1.0f / ctx->flowMaxMagnitude * std::min(g.dx, std::min(g.dy, g.dz)) * S->time_step_scale;
     const float terminationDistance = 1e-6f * S->termination_distance;
@@ -631,7 +702,7 @@ int lv_flow_trace_max_helicity_first(lv_ctx* ctx, const float* helicityField, co
             const Sample sm = queue.back();
             queue.pop_back();
             const float q[3] = {sm.px, sm.py, sm.pz};
-            if (!occupancy[cellOf(q)]) seeds.insert(seeds.end(), q, q + 3);
+            if (gridCheck ? !occupancy[cellOf(q)] : !(filterSeeds && pointTerminated(q))) seeds.insert(seeds.end(), q, q + 3);
         }
         const uint32_t numSeeds = uint32_t(seeds.size() / 3);
         if (numSeeds == 0) break;
@@ -641,9 +712,10 @@ int lv_flow_trace_max_helicity_first(lv_ctx* ctx, const float* helicityField, co
         if (selfGridWords) LV_HIP(ctx, hipMemsetAsync(ctx->flowSelfGrid.ptr, 0, size_t(selfGridWords) * numThreads * 4, st));
         k_trace_streamlines_seeded<<<(numThreads + LV_WAVE - 1) / LV_WAVE, LV_WAVE, 0, st>>>(
                 g, (const float*)ctx->flowSeeds.ptr, numSeeds, numThreads, firstBackward, S->integration_method, dt, S->time_step_scale,
-                terminationDistance, maxIterations, H->loop_check_mode, terminationDistanceStart, (const uint8_t*)ctx->flowOccupancy.ptr,
+                terminationDistance, maxIterations, H->loop_check_mode, terminationDistanceStart,
+                gridCheck ? (const uint8_t*)ctx->flowOccupancy.ptr : nullptr,
                 capacity, (float*)ctx->flowOutPos.ptr, (float*)ctx->flowOutAtt.ptr, (uint32_t*)ctx->flowCounts.ptr,
-                selfGridWords ? (uint32_t*)ctx->flowSelfGrid.ptr : nullptr, selfGridWords);
+                selfGridWords ? (uint32_t*)ctx->flowSelfGrid.ptr : nullptr, selfGridWords, fp);
         LV_HIP(ctx, hipGetLastError());
         counts.resize(numThreads);
         LV_HIP(ctx, hipMemcpyAsync(counts.data(), ctx->flowCounts.ptr, size_t(numThreads) * 4, hipMemcpyDeviceToHost, st));
@@ -664,13 +736,16 @@ int lv_flow_trace_max_helicity_first(lv_ctx* ctx, const float* helicityField, co
         // ---- commit in seeding order
         bool dirty = false;
         for (uint32_t s = 0; s < numSeeds; s++) {
-            if (occupancy[cellOf(&seeds[3 * size_t(s)])]) continue;   // an earlier line of this batch took the seed's cell: hasNextPoint skips it
+            // an earlier line of this batch took the seed's cell / came within r of the seed: hasNextPoint skips it
+            if (gridCheck ? occupancy[cellOf(&seeds[3 * size_t(s)])] != 0 : (filterSeeds && pointTerminated(&seeds[3 * size_t(s)]))) continue;
             // length of a thread's part as the sequential tracer would have produced it: up to the first point in a taken cell
             // (the boundary point is appended without that test)
             auto cut = [&](uint32_t thread) {
                 const uint32_t n = counts[thread] & 0x7FFFFFFFu, tested = (counts[thread] >> 31) ? n - 1u : n;
-                for (uint32_t i = 0; i < tested; i++)
-                    if (occupancy[cellOf(&hp[(size_t(i) * numThreads + thread) * 3])]) return i;
+                for (uint32_t i = 0; i < tested; i++) {
+                    const float* q = &hp[(size_t(i) * numThreads + thread) * 3];
+                    if (gridCheck ? occupancy[cellOf(q)] != 0 : pointTerminated(q)) return i;
+                }
                 return n;
             };
             struct Part { uint32_t thread, begin, end; bool reversed; };
@@ -723,7 +798,18 @@ int lv_flow_trace_max_helicity_first(lv_ctx* ctx, const float* helicityField, co
             ctx->flowSeedIndex.push_back(seedIndex);
             // addFinishedTrajectory, StreamlineSeeder.cpp:464-502: every cell the sphere (point, minimumSeparationDistance) touches
             // (sgl::Sphere::intersects(AABB) is un-vendored; build-owned: squared distance from the centre to the box <= r^2)
-            for (size_t pnt = firstPoint; pnt < ctx->flowPositions.size() / 3; pnt++) {
+            if (!gridCheck) {   // kdTree.build / hashedGrid.add (:503-511), filteredTrajectories.push_back (:819): the line's points join the lists
+                for (size_t pnt = firstPoint; pnt < ctx->flowPositions.size() / 3; pnt++) {
+                    const float* q = &ctx->flowPositions[pnt * 3];
+                    int x, y, z;
+                    lv_flow_points_cell(fp.nx, fp.ny, fp.nz, fp.invCell, q[0], q[1], q[2], x, y, z);
+                    int32_t& hd = fpHead[(size_t(z) * fp.ny + y) * fp.nx + x];
+                    fpNext.push_back(hd);
+                    hd = int32_t(fpPts.size() / 3);
+                    fpPts.insert(fpPts.end(), q, q + 3);
+                }
+            }
+            for (size_t pnt = firstPoint; gridCheck && pnt < ctx->flowPositions.size() / 3; pnt++) {
                 const float* q = &ctx->flowPositions[pnt * 3];
                 auto cellCoord = [](float v, float cell, int hi) { int c = int(v * (1.0f / cell)); return c < 0 ? 0 : (c > hi ? hi : c); };
                 const int x0 = cellCoord(q[0] - r, g.dx, xs - 2), x1 = cellCoord(q[0] + r, g.dx, xs - 2);
@@ -744,9 +830,34 @@ int lv_flow_trace_max_helicity_first(lv_ctx* ctx, const float* helicityField, co
             }
             dirty = true;
         }
-        if (dirty) {
+        if (dirty && gridCheck) {
             LV_HIP(ctx, hipMemcpyAsync(ctx->flowOccupancy.ptr, occupancy.data(), numCells, hipMemcpyHostToDevice, st));
             LV_HIP(ctx, hipStreamSynchronize(st));
+        }
+        if (dirty && !gridCheck) {
+            // the batch's finished points: appended to the device arrays (grown geometrically; the lists are rebuilt after a move) and
+            // linked into their cells' lists
+            const size_t have = fpPts.size() / 3;
+            if (have > 0x7FFFFFF0ull) return lv_fail(ctx, LV_E_CAPACITY, "more than 2^31 finished points");
+            if (have > ctx->flowPointsCapacity) {
+                size_t cap = std::max<size_t>(have * 2, 1u << 16);
+                if ((rc = lv_buf_reserve(ctx, ctx->flowPoints, cap * 12))) return rc;
+                if ((rc = lv_buf_reserve(ctx, ctx->flowPointsNext, cap * 4))) return rc;
+                ctx->flowPointsCapacity = cap;
+                fpOnDevice = 0;
+                LV_HIP(ctx, hipMemsetAsync(ctx->flowOccupancy.ptr, 0xFF, fpHead.size() * 4, st));
+            }
+            LV_HIP(ctx, hipMemcpyAsync((float*)ctx->flowPoints.ptr + 3 * fpOnDevice, fpPts.data() + 3 * fpOnDevice, (have - fpOnDevice) * 12,
+                                       hipMemcpyHostToDevice, st));
+            k_flow_points_insert<<<uint32_t((have - fpOnDevice + LV_BLOCK - 1) / LV_BLOCK), LV_BLOCK, 0, st>>>(
+                    (const float*)ctx->flowPoints.ptr, (int32_t*)ctx->flowPointsNext.ptr, (int32_t*)ctx->flowOccupancy.ptr, fp.nx, fp.ny, fp.nz,
+                    fp.invCell, uint32_t(fpOnDevice), uint32_t(have - fpOnDevice));
+            LV_HIP(ctx, hipGetLastError());
+            LV_HIP(ctx, hipStreamSynchronize(st));
+            fpOnDevice = have;
+            fp.pts = (const float*)ctx->flowPoints.ptr;
+            fp.next = (const int32_t*)ctx->flowPointsNext.ptr;
+            fp.head = (const int32_t*)ctx->flowOccupancy.ptr;
         }
     }
     return LV_OK;

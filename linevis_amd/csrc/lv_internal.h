@@ -214,7 +214,9 @@ struct lv_ctx {
     uint32_t ppllScanBlocks = 0;              // raster_prism: workgroups of the last k_ppll_scan (scanTemp = totals, bases, counter)
     LvDeviceBuffer twistTex;                  // twist-line texture: float4 texels, mip levels back to back
     uint32_t twistW = 0, twistH = 0, twistLevels = 0;
-    LvDeviceBuffer flowOccupancy;             // max-helicity-first seeding: the occupancy grid, one byte per cell
+    LvDeviceBuffer flowOccupancy;             // max-helicity-first seeding: the occupancy grid, one byte per cell (grid-based check) / the list heads of the finished points' grid
+    LvDeviceBuffer flowPoints, flowPointsNext; // point-based termination checks: finished points (12 B) and their per-cell list links
+    size_t flowPointsCapacity = 0;
     LvDeviceBuffer flowSelfGrid;              // loop check "Grid": one bit per cell and line of a batch
     LvDeviceBuffer prismLeafList;             // raster_prism, sharded frames: segments that can touch the frame's tile list (k_ppll_cull_segments)
     LvDeviceBuffer ppllCoarse;                // raster_prism, sharded frames: 32 x 32-pixel cells that hold requested pixels (k_ppll_mark_tiles)

@@ -321,6 +321,11 @@ lvo_streamlines* lvo_trace_streamlines_max_helicity_first(
         const float* vectorField, int xs, int ys, int zs, float dx, float dy, float dz, const float* const* scalarFields,
         uint32_t numScalarFields, const float* helicityField, const lvo_streamline_settings* settings, float minimumSeparationDistance,
         uint32_t loopCheckMode, float terminationDistanceSelf, int seedingSubsamplingFactor);
+/* ... with StreamlineTracingSettings::terminationCheckType: 0 naive, 1 grid-based, 2 k-d tree-based, 3 hashed grid-based */
+lvo_streamlines* lvo_trace_streamlines_max_helicity_first_ex(
+        const float* vectorField, int xs, int ys, int zs, float dx, float dy, float dz, const float* const* scalarFields,
+        uint32_t numScalarFields, const float* helicityField, const lvo_streamline_settings* settings, float minimumSeparationDistance,
+        uint32_t loopCheckMode, float terminationDistanceSelf, int seedingSubsamplingFactor, uint32_t terminationCheckType);
 lvo_streamlines* lvo_trace_streamribbons_max_helicity_first(
         const float* vectorField, int xs, int ys, int zs, float dx, float dy, float dz, const float* const* scalarFields,
         uint32_t numScalarFields, const float* helicityField, const lvo_streamline_settings* settings, float minimumSeparationDistance,

@@ -498,7 +498,21 @@ static lvo_streamlines* traceLines(const float* vectorField, int xs, int ys, int
 static lvo_streamlines* traceMaxHelicityFirst(
         const float* vectorField, int xs, int ys, int zs, float dx, float dy, float dz, const float* const* scalarFields,
         uint32_t numScalarFields, const float* helicityField, const lvo_streamline_settings* settings, float minimumSeparationDistance,
-        uint32_t loopCheckMode, float terminationDistanceSelf, int seedingSubsamplingFactor, const RibbonSettings* ribbons);
+        uint32_t loopCheckMode, float terminationDistanceSelf, int seedingSubsamplingFactor, const RibbonSettings* ribbons,
+        uint32_t terminationCheckType = 1u);
+// TerminationCheckType (StreamlineTracingDefines.hpp:89-94): 0 naive = the loop over every point of every finished trajectory
+// (_isTerminated, StreamlineTracingGrid.cpp:676-684: glm::distance(currentPoint, point) < minimumSeparationDistance), without a filter on
+// the seeds (StreamlineSeeder.cpp:452-454); 2 / 3 = the seeder's k-d tree / hashed grid over the same points (:503-529;
+// getHasPointCloserThan is sgl's, not vendored: distance < r here, like the naive test), which also skips a sample that lies within r of a
+// finished point (:441-451).  All three by the literal loop here.
+lvo_streamlines* lvo_trace_streamlines_max_helicity_first_ex(
+        const float* vectorField, int xs, int ys, int zs, float dx, float dy, float dz, const float* const* scalarFields,
+        uint32_t numScalarFields, const float* helicityField, const lvo_streamline_settings* settings, float minimumSeparationDistance,
+        uint32_t loopCheckMode, float terminationDistanceSelf, int seedingSubsamplingFactor, uint32_t terminationCheckType) {
+    return traceMaxHelicityFirst(vectorField, xs, ys, zs, dx, dy, dz, scalarFields, numScalarFields, helicityField, settings,
+                                 minimumSeparationDistance, loopCheckMode, terminationDistanceSelf, seedingSubsamplingFactor, nullptr,
+                                 terminationCheckType);
+}
 lvo_streamlines* lvo_trace_streamlines_max_helicity_first(
         const float* vectorField, int xs, int ys, int zs, float dx, float dy, float dz, const float* const* scalarFields,
         uint32_t numScalarFields, const float* helicityField, const lvo_streamline_settings* settings, float minimumSeparationDistance,
@@ -527,7 +541,8 @@ lvo_streamlines* lvo_trace_streamribbons_max_helicity_first(
 static lvo_streamlines* traceMaxHelicityFirst(
         const float* vectorField, int xs, int ys, int zs, float dx, float dy, float dz, const float* const* scalarFields,
         uint32_t numScalarFields, const float* helicityField, const lvo_streamline_settings* settings, float minimumSeparationDistance,
-        uint32_t loopCheckMode, float terminationDistanceSelf, int seedingSubsamplingFactor, const RibbonSettings* ribbons) {
+        uint32_t loopCheckMode, float terminationDistanceSelf, int seedingSubsamplingFactor, const RibbonSettings* ribbons,
+        uint32_t terminationCheckType) {
     Grid g;
     g.xs = xs; g.ys = ys; g.zs = zs; g.dx = dx; g.dy = dy; g.dz = dz;
     g.boxMin = v3(0.0f, 0.0f, 0.0f);
@@ -559,6 +574,13 @@ static lvo_streamlines* traceMaxHelicityFirst(
     }
     std::stable_sort(queue.begin(), queue.end(), [](const Sample& a, const Sample& b) { return a.value < b.value; });
     std::vector<bool> occupancy(size_t(xs - 1) * (ys - 1) * (zs - 1), false);
+    const bool gridCheck = terminationCheckType == 1u;
+    std::vector<V3> finishedPoints;   // filteredTrajectories' points = what the seeder's k-d tree / hashed grid hold
+    auto pointTerminated = [&](V3 p) {
+        for (const V3& q : finishedPoints)
+            if (length(p - q) < minimumSeparationDistance) return true;
+        return false;
+    };
     auto cellOf = [&](V3 p) {
         V3 q = p - g.boxMin;
         q = v3(q.x * (1.0f / dx), q.y * (1.0f / dy), q.z * (1.0f / dz));
@@ -648,7 +670,7 @@ static lvo_streamlines* traceMaxHelicityFirst(
                 segmentSum++;
                 if (segmentSum > 100 && curvatureSum > 2.5f) break;
             }
-            if (occupancy[cellOf(currentPoint)]) break;
+            if (gridCheck ? bool(occupancy[cellOf(currentPoint)]) : pointTerminated(currentPoint)) break;
             pushPoint(g, line, currentPoint);
             integrationStep(g, S.integrationMethod, currentPoint, dt, fw, S.timeStepScale);
             iterationCounter++;
@@ -667,7 +689,7 @@ static lvo_streamlines* traceMaxHelicityFirst(
     while (!queue.empty()) {
         const Sample sm = queue.back();      // hasNextPoint
         queue.pop_back();
-        if (occupancy[cellOf(sm.pos)]) continue;
+        if (gridCheck ? bool(occupancy[cellOf(sm.pos)]) : (terminationCheckType != 0u && pointTerminated(sm.pos))) continue;
         Line line;
         bool valid;
         if (S.integrationDirection == 0) {
@@ -707,7 +729,9 @@ static lvo_streamlines* traceMaxHelicityFirst(
         out->offsets.push_back(uint32_t(out->positions.size() / 3));
         // addFinishedTrajectory
         const float r = minimumSeparationDistance;
+        if (!gridCheck) finishedPoints.insert(finishedPoints.end(), line.pos.begin(), line.pos.end());
         for (const V3& q : line.pos) {
+            if (!gridCheck) break;
             auto coord = [](float v, float cell, int hi) { int c = int(v * (1.0f / cell)); return std::min(std::max(c, 0), hi); };
             const int x0 = coord((q.x - r) - g.boxMin.x, dx, xs - 2), x1 = coord((q.x + r) - g.boxMin.x, dx, xs - 2);
             const int y0 = coord((q.y - r) - g.boxMin.y, dy, ys - 2), y1 = coord((q.y + r) - g.boxMin.y, dy, ys - 2);

@@ -195,6 +195,9 @@ def lib():
                                                              f32, u32, f32, i32, i32, f32, vp]
     L.lvo_trace_streamlines_max_helicity_first.argtypes = [vp, i32, i32, i32, f32, f32, f32, vp, u32, vp, C.POINTER(StreamlineSettings),
                                                            f32, u32, f32, i32]
+    L.lvo_trace_streamlines_max_helicity_first_ex.restype = vp
+    L.lvo_trace_streamlines_max_helicity_first_ex.argtypes = [vp, i32, i32, i32, f32, f32, f32, vp, u32, vp, C.POINTER(StreamlineSettings),
+                                                              f32, u32, f32, i32, u32]
     L.lvo_trace_streamlines.argtypes = [vp, i32, i32, i32, f32, f32, f32, vp, u32, vp, u32, C.POINTER(StreamlineSettings)]
     L.lvo_streamlines_sizes.argtypes = [vp, u64p, u64p]
     L.lvo_streamlines_copy.argtypes = [vp, vp, vp, vp]
@@ -370,18 +373,22 @@ def trace_streamlines(vector_field, spacing, scalar_fields, seeds, settings):
 
 
 def trace_streamlines_max_helicity_first(vector_field, spacing, scalar_fields, helicity_field, settings, minimum_separation_distance=0.08,
-                                         loop_check_mode=1, termination_distance_self=1.0, seeding_subsampling_factor=1, ribbons=None):
-    """StreamlineMaxHelicityFirstSeeder + _traceStreamribbonsDecreasingHelicity, sequential: (positions, attributes, line_offsets)."""
+                                         loop_check_mode=1, termination_distance_self=1.0, seeding_subsampling_factor=1, ribbons=None,
+                                         termination_check_type=1):
+    """StreamlineMaxHelicityFirstSeeder + _traceStreamribbonsDecreasingHelicity, sequential: (positions, attributes, line_offsets).
+    termination_check_type: 0 naive, 1 grid-based, 2 k-d tree-based, 3 hashed grid-based (TerminationCheckType)."""
     v = np.ascontiguousarray(vector_field, dtype=np.float32)
     zs, ys, xs = v.shape[:3]
     sf = [np.ascontiguousarray(f, dtype=np.float32) for f in scalar_fields]
     ptrs = (C.c_void_p * max(len(sf), 1))(*[f.ctypes.data for f in sf])
     hf = np.ascontiguousarray(helicity_field, dtype=np.float32)
     if ribbons is None:
-        h = lib().lvo_trace_streamlines_max_helicity_first(_p(v), xs, ys, zs, spacing[0], spacing[1], spacing[2], ptrs, len(sf), _p(hf),
-                                                           C.byref(settings), float(minimum_separation_distance), int(loop_check_mode),
-                                                           float(termination_distance_self), int(seeding_subsampling_factor))
+        h = lib().lvo_trace_streamlines_max_helicity_first_ex(_p(v), xs, ys, zs, spacing[0], spacing[1], spacing[2], ptrs, len(sf), _p(hf),
+                                                              C.byref(settings), float(minimum_separation_distance), int(loop_check_mode),
+                                                              float(termination_distance_self), int(seeding_subsampling_factor),
+                                                              int(termination_check_type))
     else:   # ribbons = dict(use_helicity=, max_helicity_twist=, initial_ribbon_direction=): the STREAMRIBBONS form, + ribbon directions
+        assert termination_check_type == 1
         ird = np.ascontiguousarray(ribbons.get("initial_ribbon_direction", (0.0, 1.0, 0.0)), dtype=np.float32)
         h = lib().lvo_trace_streamribbons_max_helicity_first(_p(v), xs, ys, zs, spacing[0], spacing[1], spacing[2], ptrs, len(sf), _p(hf),
                                                              C.byref(settings), float(minimum_separation_distance), int(loop_check_mode),

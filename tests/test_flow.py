@@ -300,6 +300,43 @@ def test_max_helicity_first_seeding_properties():
     assert len(none[0]) >= len(pos)                                                               # no loop check: lines only get longer
 
 
+@pytest.mark.parametrize("check", [0, 2, 3])
+def test_point_based_termination_checks_properties(check):
+    """TerminationCheckType naive (0) / k-d tree (2) / hashed grid (3) of the oracle's sequential tracer, against the definition stated
+    independently in numpy: no point of a line -- except a boundary point it may end with, appended without the test -- lies closer
+    than minimumSeparationDistance to a point of an EARLIER line (float32, sqrt((dx dx + dy dy) + dz dz) < r); every line ends for a
+    reason (boundary, or its next step would have been too close / the iteration limit); 2 and 3 are the same search and skip seeds
+    within r of a finished point -- which the naive check traces, only to end them at their first point (an empty line fails the
+    minimum length): the three give the same lines, and not the occupancy grid's."""
+    n = 16
+    v = lvo.generate_abc_flow(n, n, n)
+    d = 1.0 / (n - 1)
+    sp = (d, d, d)
+    hel = lvo.helicity_field(v, lvo.vorticity_field(v, sp))
+    mag = np.sqrt((v * v).sum(axis=3)).astype(np.float32)
+    S = lvo.streamline_settings("Runge-Kutta 4th Order", "Forward & Backward", minimum_length=0.3, max_num_iterations=300)
+    r = np.float32(0.06)
+    pos, att, off = lvo.trace_streamlines_max_helicity_first(v, sp, [mag], hel, S, minimum_separation_distance=float(r), termination_check_type=check)
+    assert 10 < len(off) - 1 and att.shape == (1, len(pos))
+    hi = np.float32((n - 1) * d)
+    for l in range(1, len(off) - 1):
+        p = pos[off[l]:off[l + 1]]
+        earlier = pos[:off[l]]
+        dx = p[:, None, 0] - earlier[None, :, 0]; dy = p[:, None, 1] - earlier[None, :, 1]; dz = p[:, None, 2] - earlier[None, :, 2]
+        dist = np.sqrt((dx * dx + dy * dy) + dz * dz)            # float32 throughout
+        close = (dist < r).any(axis=1)
+        ends = np.zeros(len(p), dtype=bool); ends[0] = ends[-1] = True
+        on_boundary = ((p <= 1e-6) | (p >= hi - 1e-6)).any(axis=1)
+        assert not (close & ~(ends & on_boundary)).any(), l
+    same23 = lvo.trace_streamlines_max_helicity_first(v, sp, [mag], hel, S, minimum_separation_distance=float(r), termination_check_type=5 - check if check else 0)
+    if check:
+        assert np.array_equal(same23[0], pos) and np.array_equal(same23[2], off)     # k-d tree and hashed grid: one predicate
+        naive = lvo.trace_streamlines_max_helicity_first(v, sp, [mag], hel, S, minimum_separation_distance=float(r), termination_check_type=0)
+        assert np.array_equal(naive[0], pos) and np.array_equal(naive[2], off)
+    grid = lvo.trace_streamlines_max_helicity_first(v, sp, [mag], hel, S, minimum_separation_distance=float(r))
+    assert not np.array_equal(grid[2], off)                                          # the occupancy grid is a different (coarser) rule
+
+
 def test_loop_check_modes_of_the_max_helicity_first_tracer():
     """Oracle: the five loop check modes (StreamlineTracingGrid.cpp:588-672) on a swirl with closed orbits.  Without a check the orbiting
     lines run into the iteration limit; each check ends them after about one turn (start point, all points), when the line re-enters a

@@ -203,6 +203,12 @@ def test_host_tracer_classes(hip_lib):
     hb = lvo.trace_streamlines_max_helicity_first(v, sp, fields, fields[0], lvo.streamline_settings(minimum_length=0.3),
                                                   minimum_separation_distance=0.1)
     assert same(ha, hb) and len(ha[2]) > 10
+    # ... with StreamlineTracingSettings::terminationCheckType = HASHED_GRID_BASED (3): the point-distance rule instead of the occupancy grid
+    hc = grid.trace_streamlines_max_helicity_first(minimum_length=0.3, minimum_separation_distance=0.1, termination_check_type=3,
+                                                   max_num_iterations=400)
+    hd = lvo.trace_streamlines_max_helicity_first(v, sp, fields, fields[0], lvo.streamline_settings(minimum_length=0.3, max_num_iterations=400),
+                                                  minimum_separation_distance=0.1, termination_check_type=3)
+    assert same(hc, hd) and len(hc[2]) > 10
     for direction in ("Forward", "Backward", "Forward & Backward"):       # ... and its streamribbon form
         ra = grid.trace_streamlines_max_helicity_first(direction=direction, minimum_length=0.3, minimum_separation_distance=0.1, ribbons=True,
                                                        max_helicity_twist=0.5)
@@ -281,7 +287,39 @@ def test_max_helicity_first_seeding_bit_exact(hip_lib, kw):
     with pytest.raises(Exception):
         ctx.trace_streamlines_max_helicity_first(hel, capi.streamline_settings("Runge-Kutta-Fehlberg", direction), seeding)
     with pytest.raises(Exception):
-        ctx.trace_streamlines_max_helicity_first(hel, capi.streamline_settings(method, direction), capi.HelicitySeedingSettings(termination_check_type=0))
+        ctx.trace_streamlines_max_helicity_first(hel, capi.streamline_settings(method, direction), capi.HelicitySeedingSettings(termination_check_type=4))
+
+
+@pytest.mark.parametrize("check,kw", [(0, dict()), (2, dict()), (3, dict(direction="Forward")), (2, dict(direction="Backward", method="Heun")),
+                                      (0, dict(minimum_separation_distance=0.03, seeding_subsampling_factor=3)),
+                                      (3, dict(minimum_separation_distance=0.12, loop_check_mode=0)),
+                                      (2, dict(minimum_separation_distance=0.004, seeding_subsampling_factor=4))])
+def test_max_helicity_first_point_based_termination_bit_exact(hip_lib, check, kw):
+    """TerminationCheckType naive / k-d tree / hashed grid (StreamlineTracingGrid.cpp:676-689, StreamlineSeeder.cpp:428-529): a line ends
+    where it comes within minimum_separation_distance of a point of a finished line; the k-d tree and the hashed grid also skip such
+    seeds, the naive check does not.  The speculative batches on the GPU (finished points in per-cell lists in HBM, exact cut on the
+    host) against the oracle's literal loop over every finished point: the same lines bit for bit -- and not the grid-based check's."""
+    kw = dict(kw)
+    n = 24
+    v, mag, sp = abc_grid(n)
+    hel = lvo.helicity_field(v, lvo.vorticity_field(v, sp))
+    method, direction = kw.pop("method", "Runge-Kutta 4th Order"), kw.pop("direction", "Forward & Backward")
+    ctx = capi.Context(0)
+    ctx.set_flow_grid(v, sp, [mag, hel])
+    seeding = capi.HelicitySeedingSettings(termination_check_type=check, **kw)
+    S = dict(minimum_length=0.3, max_num_iterations=400)
+    a = ctx.trace_streamlines_max_helicity_first(hel, capi.streamline_settings(method, direction, **S), seeding)
+    okw = dict(minimum_separation_distance=seeding.minimum_separation_distance, loop_check_mode=seeding.loop_check_mode,
+               termination_distance_self=seeding.termination_distance_self, seeding_subsampling_factor=seeding.seeding_subsampling_factor)
+    b = lvo.trace_streamlines_max_helicity_first(v, sp, [mag, hel], hel, lvo.streamline_settings(method, direction, **S),
+                                                 termination_check_type=check, **okw)
+    assert same(a, b)
+    assert len(a[2]) - 1 > 10 and len(a[0]) > 500
+    grid = lvo.trace_streamlines_max_helicity_first(v, sp, [mag, hel], hel, lvo.streamline_settings(method, direction, **S), **okw)
+    assert not (len(grid[0]) == len(b[0]) and np.array_equal(grid[0], b[0]))
+    # a second call on the same context starts from an empty point set
+    a2 = ctx.trace_streamlines_max_helicity_first(hel, capi.streamline_settings(method, direction, **S), seeding)
+    assert same(a, a2)
 
 
 def rotating_grid(n=24):
