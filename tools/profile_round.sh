@@ -18,14 +18,14 @@ timeout 600 $R/tools/ubench/_build/valu_rates > $R/gpurun_out/ubench_$TAG/valu_r
 timeout 600 $R/tools/ubench/_build/tcp_rates > $R/gpurun_out/ubench_$TAG/tcp_rates.json 2> $OUT/tcp_rates.err
 python $R/tools/summarize_ubench.py ubench_$TAG $TAG > $OUT/ubench_summary.json 2>> $OUT/valu_rates.err
 bash $R/tools/pmc_collect.sh $TAG c3c c3t c4 > $OUT/pmc_full.log 2>&1
-LV_PMC_LITE=1 bash $R/tools/pmc_collect.sh $TAG c2 c2e c4c c4m c4l c5 > $OUT/pmc_lite.log 2>&1
+LV_PMC_LITE=1 bash $R/tools/pmc_collect.sh $TAG c2 c2e c4c c4m c4l c5 c5c > $OUT/pmc_lite.log 2>&1
 for f in $R/gpurun_out/pmc_$TAG/*.json; do cp $f $R/profiles/pmc_${TAG}_$(basename $f); done   # bench.py reads profiles/
 python $R/bench.py > $OUT/bench_c3.json 2> $OUT/bench_c3.err
 # the CPU baseline beside C2, C3 and C4 (a bounded ~15-s sample each); the variants of those configs without it
 for w in c2 c4; do
   python $R/bench.py --workload $w --steps 100 --warmup 5 > $OUT/bench_$w.json 2> $OUT/bench_$w.err
 done
-for w in c3c c3t c2e c4c c4m c4l c5; do
+for w in c3c c3t c2e c4c c4m c4l c5 c5c; do
   python $R/bench.py --workload $w --steps 100 --warmup 5 --no-cpu-baseline > $OUT/bench_$w.json 2> $OUT/bench_$w.err
 done
 for w in c3 c4 c4m c2; do
@@ -64,3 +64,4 @@ rm -rf $OUT/trace_svgf
 cd $R
 LV_PROBE_DEPTHS=1,2,4 python tools/probe_shard.py c3c > $OUT/shard_c3c.txt 2>&1
 LV_PROBE_DEPTHS=1,2,4 python tools/probe_shard.py c3t > $OUT/shard_c3t.txt 2>&1
+python tools/probe_shard_ppll.py > $OUT/shard_c4.txt 2>&1
