@@ -20,6 +20,7 @@ python $R/tools/summarize_ubench.py ubench_$TAG $TAG > $OUT/ubench_summary.json 
 bash $R/tools/pmc_collect.sh $TAG c3c c3t c4 > $OUT/pmc_full.log 2>&1
 LV_PMC_LITE=1 bash $R/tools/pmc_collect.sh $TAG c2 c2e c4c c4m c4l c5 c5c > $OUT/pmc_lite.log 2>&1
 for f in $R/gpurun_out/pmc_$TAG/*.json; do cp $f $R/profiles/pmc_${TAG}_$(basename $f); done   # bench.py reads profiles/
+cp $R/profiles/pmc_${TAG}_c5.json $R/profiles/pmc_${TAG}_c5t.json   # workload c5 = c5t
 python $R/bench.py > $OUT/bench_c3.json 2> $OUT/bench_c3.err
 # the CPU baseline beside C2, C3 and C4 (a bounded ~15-s sample each); the variants of those configs without it
 for w in c2 c4; do
