@@ -326,6 +326,7 @@ lvo_streamlines* lvo_trace_streamlines_max_helicity_first_ex(
         const float* vectorField, int xs, int ys, int zs, float dx, float dy, float dz, const float* const* scalarFields,
         uint32_t numScalarFields, const float* helicityField, const lvo_streamline_settings* settings, float minimumSeparationDistance,
         uint32_t loopCheckMode, float terminationDistanceSelf, int seedingSubsamplingFactor, uint32_t terminationCheckType);
+void lvo_set_streamribbon_termination_check_type(uint32_t terminationCheckType); /* of the following streamribbon calls; default 1 */
 lvo_streamlines* lvo_trace_streamribbons_max_helicity_first(
         const float* vectorField, int xs, int ys, int zs, float dx, float dy, float dz, const float* const* scalarFields,
         uint32_t numScalarFields, const float* helicityField, const lvo_streamline_settings* settings, float minimumSeparationDistance,

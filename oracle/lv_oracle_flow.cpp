@@ -523,6 +523,8 @@ lvo_streamlines* lvo_trace_streamlines_max_helicity_first(
 // flowPrimitives == STREAMRIBBONS in _traceStreamribbonsDecreasingHelicity (:783-823): _pushRibbonDirections of every valid line's
 // parts -- with forwardMode = true for the backward part too (unlike traceStreamribbons, :479-486) -- then _reverseRibbon /
 // _insertBackwardRibbon.  The twist uses the same helicity field, normalised by its maximum magnitude.
+// (the streamribbon entry point keeps its signature: the termination check type of the NEXT call is set through a global of this test library)
+static uint32_t g_ribbonTerminationCheckType = 1u;
 lvo_streamlines* lvo_trace_streamribbons_max_helicity_first(
         const float* vectorField, int xs, int ys, int zs, float dx, float dy, float dz, const float* const* scalarFields,
         uint32_t numScalarFields, const float* helicityField, const lvo_streamline_settings* settings, float minimumSeparationDistance,
@@ -536,8 +538,10 @@ lvo_streamlines* lvo_trace_streamribbons_max_helicity_first(
     R.maxHelicityMagnitude = 0.0f;
     for (size_t i = 0; i < size_t(xs) * ys * zs; i++) R.maxHelicityMagnitude = std::max(R.maxHelicityMagnitude, fabsf(helicityField[i]));
     return traceMaxHelicityFirst(vectorField, xs, ys, zs, dx, dy, dz, scalarFields, numScalarFields, helicityField, settings,
-                                 minimumSeparationDistance, loopCheckMode, terminationDistanceSelf, seedingSubsamplingFactor, &R);
+                                 minimumSeparationDistance, loopCheckMode, terminationDistanceSelf, seedingSubsamplingFactor, &R,
+                                 g_ribbonTerminationCheckType);
 }
+void lvo_set_streamribbon_termination_check_type(uint32_t terminationCheckType) { g_ribbonTerminationCheckType = terminationCheckType; }
 static lvo_streamlines* traceMaxHelicityFirst(
         const float* vectorField, int xs, int ys, int zs, float dx, float dy, float dz, const float* const* scalarFields,
         uint32_t numScalarFields, const float* helicityField, const lvo_streamline_settings* settings, float minimumSeparationDistance,

@@ -195,6 +195,7 @@ def lib():
                                                              f32, u32, f32, i32, i32, f32, vp]
     L.lvo_trace_streamlines_max_helicity_first.argtypes = [vp, i32, i32, i32, f32, f32, f32, vp, u32, vp, C.POINTER(StreamlineSettings),
                                                            f32, u32, f32, i32]
+    L.lvo_set_streamribbon_termination_check_type.argtypes = [u32]
     L.lvo_trace_streamlines_max_helicity_first_ex.restype = vp
     L.lvo_trace_streamlines_max_helicity_first_ex.argtypes = [vp, i32, i32, i32, f32, f32, f32, vp, u32, vp, C.POINTER(StreamlineSettings),
                                                               f32, u32, f32, i32, u32]
@@ -388,13 +389,14 @@ def trace_streamlines_max_helicity_first(vector_field, spacing, scalar_fields, h
                                                               float(termination_distance_self), int(seeding_subsampling_factor),
                                                               int(termination_check_type))
     else:   # ribbons = dict(use_helicity=, max_helicity_twist=, initial_ribbon_direction=): the STREAMRIBBONS form, + ribbon directions
-        assert termination_check_type == 1
+        lib().lvo_set_streamribbon_termination_check_type(int(termination_check_type))
         ird = np.ascontiguousarray(ribbons.get("initial_ribbon_direction", (0.0, 1.0, 0.0)), dtype=np.float32)
         h = lib().lvo_trace_streamribbons_max_helicity_first(_p(v), xs, ys, zs, spacing[0], spacing[1], spacing[2], ptrs, len(sf), _p(hf),
                                                              C.byref(settings), float(minimum_separation_distance), int(loop_check_mode),
                                                              float(termination_distance_self), int(seeding_subsampling_factor),
                                                              int(ribbons.get("use_helicity", True)), float(ribbons.get("max_helicity_twist", 0.25)),
                                                              _p(ird))
+        lib().lvo_set_streamribbon_termination_check_type(1)
     nl, npt = C.c_uint64(), C.c_uint64()
     lib().lvo_streamlines_sizes(h, C.byref(nl), C.byref(npt))
     pos = np.zeros((npt.value, 3), dtype=np.float32)

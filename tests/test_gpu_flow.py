@@ -216,6 +216,12 @@ def test_host_tracer_classes(hip_lib):
                                                       minimum_separation_distance=0.1, ribbons=dict(max_helicity_twist=0.5))
         assert same(ra[:3], rb[:3]) and np.array_equal(ra[3].view(np.uint32), rb[3].view(np.uint32)), direction
         assert np.abs(np.linalg.norm(ra[3], axis=1) - 1).max() < 1e-3
+    # ... the streamribbon form with the k-d tree termination check
+    ra = grid.trace_streamlines_max_helicity_first(minimum_length=0.3, minimum_separation_distance=0.1, ribbons=True, termination_check_type=2,
+                                                   max_num_iterations=400)
+    rb = lvo.trace_streamlines_max_helicity_first(v, sp, fields, fields[0], lvo.streamline_settings(minimum_length=0.3, max_num_iterations=400),
+                                                  minimum_separation_distance=0.1, ribbons=dict(), termination_check_type=2)
+    assert same(ra[:3], rb[:3]) and np.array_equal(ra[3].view(np.uint32), rb[3].view(np.uint32)) and len(ra[2]) > 10
     # a second vector field / scalar field set by hand, another integrator
     vec, scalars, sp2 = swirl_grid(20, 24, 16)
     grid.set_grid_extent(20, 24, 16, *sp2).add_vector_field(vec).add_scalar_field(scalars[1], "b").add_scalar_field(scalars[0], "a")
