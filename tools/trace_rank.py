@@ -56,13 +56,13 @@ import numpy as np, torch
 import bench
 from linevis_amd import capi, host_api, scenes, camera, tiling, transfer_function as tfm
 wl = sys.argv[1] if len(sys.argv) > 1 else "c3t"
-W, H = 1920, 1080
-tr = scenes.normalize(scenes.tornado())
+W, H = bench.WORKLOADS[wl].get("resolution", (1920, 1080))
+tr = scenes.normalize({"tornado": scenes.tornado, "helix": scenes.helix_bundle, "rayleigh_benard": scenes.rayleigh_benard}[bench.WORKLOADS[wl]["scene"]]())
 flow = host_api.LineDataFlow().set_trajectories(tr.positions, tr.attributes, tr.line_offsets)
 pts, seg, _ = flow.tube_aabb_render_data(0.002)
 view, proj, fovy, near, far = camera.default_camera(W, H)
 c = capi.Context(0)
-c.set_lines(pts, seg); c.set_transfer_function(tfm.standard(), *flow.attribute_range())
+c.set_lines(pts, seg); c.set_transfer_function(tfm.standard_transparent() if bench.WORKLOADS[wl].get("transparent") else tfm.standard(), *flow.attribute_range())
 c.set_camera(view, proj, fovy, near, far, W, H); c.set_option("line_width", 0.002)
 if bench.WORKLOADS[wl].get("mesh"):
     c.set_tube_triangle_mesh(*flow.tube_triangle_render_data(0.002, 6))
