@@ -2968,6 +2968,17 @@ void lvo_prism_ring_vertices(const lvo_line_point* pts, uint64_t nPts, uint32_t 
 }
 /* offsets[w * h + 1]; with segs == NULL only the offsets are filled (call twice).  Per fragment: segment, triangle (< 2 N), the three
  * weights, depth, interpolated position / normal / tangent (3 floats each, may be NULL), attribute, packed colour and alpha. */
+// the coverage direction of pixel (x, y) (prismCoverageDir) next to the ray generator's normalised direction (primaryRay): what
+// tests/test_prism_raster.py compares in float64
+void lvo_prism_coverage_dir(const lvo_params* Pp, uint32_t x, uint32_t y, float* coverageDir, float* rayDir) {
+    const lvo_params& P = *Pp;
+    const Frame F = makeFrame(P);
+    const V3 D = prismCoverageDir(P, F, x, y);
+    V3 o, d;
+    primaryRay(P, F, x, y, 0.5f, 0.5f, o, d);
+    coverageDir[0] = D.x; coverageDir[1] = D.y; coverageDir[2] = D.z;
+    rayDir[0] = d.x; rayDir[1] = d.y; rayDir[2] = d.z;
+}
 void lvo_prism_fragments(const lvo_scene* sc, const lvo_params* Pp, int useBvh, const float* ao, uint32_t x0, uint32_t y0, uint32_t w,
                          uint32_t h, uint64_t* offsets, uint32_t* segs, uint32_t* tris, float* weights, float* depth, float* pos,
                          float* nrm, float* tan, float* attr, uint32_t* colour, float* rgba) {

@@ -244,6 +244,7 @@ void lvo_twist_line_sample(const float* u, const float* dudx, const float* dudy,
 void lvo_set_prism_ring_bands(int useBands, float thickness);
 void lvo_prism_ring_vertices(const lvo_line_point* pts, uint64_t nPts, uint32_t numSubdivisions, float lineWidth, float* outPos,
                              float* outNormal);
+void lvo_prism_coverage_dir(const lvo_params* P, uint32_t x, uint32_t y, float* coverageDir /* 3 */, float* rayDir /* 3 */);
 void lvo_prism_fragments(const lvo_scene* sc, const lvo_params* P, int useBvh, const float* ao, uint32_t x0, uint32_t y0, uint32_t w,
                          uint32_t h, uint64_t* offsets, uint32_t* segs, uint32_t* tris, float* weights, float* depth, float* pos,
                          float* nrm, float* tan, float* attr, uint32_t* colour, float* rgba);

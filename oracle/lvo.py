@@ -373,6 +373,13 @@ def trace_streamlines(vector_field, spacing, scalar_fields, seeds, settings):
     return pos, att, off
 
 
+def prism_coverage_dir(P, x, y):
+    """(coverage direction of pixel (x, y), the ray generator's normalised direction): prismCoverageDir / primaryRay of the checker."""
+    cov, ray = np.zeros(3, np.float32), np.zeros(3, np.float32)
+    lib().lvo_prism_coverage_dir(C.byref(P), int(x), int(y), _p(cov), _p(ray))
+    return cov, ray
+
+
 def trace_streamlines_max_helicity_first(vector_field, spacing, scalar_fields, helicity_field, settings, minimum_separation_distance=0.08,
                                          loop_check_mode=1, termination_distance_self=1.0, seeding_subsampling_factor=1, ribbons=None,
                                          termination_check_type=1):

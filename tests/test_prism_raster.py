@@ -228,6 +228,27 @@ def test_prism_fragment_colours_against_the_float64_raster_shader():
         assert eps.max() > 0.05 and (np.abs(f0) > 0.7).sum() > 50       # the outline exists in the picture
 
 
+def test_coverage_direction_is_the_ray_generators_direction_before_its_normalisation():
+    """Round 6: coverage is decided with D = C0 + (x + 1/2) Cx + (y + 1/2) Cy.  Restated in float64 from the definition -- invView *
+    (invProj * (ndc, 1, 1)).xyz with ndc = 2 (pixel + 1/2) / size - 1 -- D agrees to float32 rounding, points the same way as the ray
+    generator's normalised direction (angle < 1e-6 rad: a ten-thousandth of a pixel), and is affine in the pixel by construction."""
+    for (w, h, eye, target) in [(96, 64, (0.3, 0.2, 1.4), (0.0, 0.0, 0.0)), (1920, 1080, (0.0, 0.0, 1.2), (0.0, 0.05, 0.0)),
+                                (3840, 2160, (-0.7, 0.9, 0.4), (0.1, 0.0, -0.1)), (33, 33, (0.0, 0.0, 1.0), (0.0, 0.0, 0.0))]:
+        c = small_case(width=w, height=h, n_lines=4, pts_per_line=6, line_width=0.05, transparent=True)
+        c.view, c.proj = camera.look_at(eye, target), camera.perspective(c.fovy, float(w) / float(h), c.near, c.far)
+        sc, P = prism_params(c)
+        inv_view = np.linalg.inv(np.asarray(c.view, np.float64).reshape(4, 4).T)      # column-major 16 floats -> matrix
+        inv_proj = np.linalg.inv(np.asarray(c.proj, np.float64).reshape(4, 4).T)
+        rng = np.random.default_rng(w)
+        for x, y in [(0, 0), (w - 1, h - 1), (w // 2, h // 2)] + [(int(rng.integers(w)), int(rng.integers(h))) for _ in range(40)]:
+            cov, ray = lvo.prism_coverage_dir(P, x, y)
+            ndc = np.array([2.0 * (x + 0.5) / w - 1.0, 2.0 * (y + 0.5) / h - 1.0, 1.0, 1.0])
+            want = inv_view[:3, :3] @ (inv_proj @ ndc)[:3]
+            assert np.abs(cov - want).max() <= 4e-6 * np.abs(want).max(), (w, x, y)
+            a = cov.astype(np.float64) / np.linalg.norm(cov.astype(np.float64)); b = ray.astype(np.float64) / np.linalg.norm(ray.astype(np.float64))
+            assert np.linalg.norm(np.cross(a, b)) < 1e-6 and a @ b > 0.999999
+
+
 def test_fill_rule_a_pixel_centre_exactly_on_shared_edges_receives_one_fragment():
     """Straight square tube (N = 4: ring directions exactly +-normal / +-binormal) along y through the origin, camera on the z axis,
     odd image width: the centre column's rays have x = 0 exactly and run along the ridge edge (the longitudinal edges c_k - n_k at
