@@ -9,20 +9,19 @@ sys.path.insert(0, R)
 import bench
 from linevis_amd import capi, host_api, scenes, camera, tiling, transfer_function as tfm
 wl = sys.argv[1] if len(sys.argv) > 1 else "c3c"
-W, H = 1920, 1080
-tr = scenes.normalize(scenes.tornado())
+W, H = bench.WORKLOADS[wl].get("resolution", (1920, 1080))
+tr = scenes.normalize({"tornado": scenes.tornado, "helix": scenes.helix_bundle, "rayleigh_benard": scenes.rayleigh_benard}[bench.WORKLOADS[wl]["scene"]]())
 flow = host_api.LineDataFlow().set_trajectories(tr.positions, tr.attributes, tr.line_offsets)
-pts, seg, _ = flow.tube_aabb_render_data(0.002)
 view, proj, fovy, near, far = camera.default_camera(W, H)
-mesh = flow.tube_triangle_render_data(0.002, 6) if bench.WORKLOADS[wl].get("mesh") else None
+attr = np.ascontiguousarray(tr.attributes[0] if np.ndim(tr.attributes) == 2 else tr.attributes, dtype=np.float32)
 
 
 def make():
     c = capi.Context(0)
-    c.set_lines(pts, seg); c.set_transfer_function(tfm.standard(), *flow.attribute_range())
-    c.set_camera(view, proj, fovy, near, far, W, H); c.set_option("line_width", 0.002)
-    if mesh is not None:
-        c.set_tube_triangle_mesh(*mesh)
+    c.set_option("line_width", 0.002)
+    c.set_trajectories(tr.positions, attr, tr.line_offsets)   # line points, index pairs and the tube mesh are written on the device
+    c.set_transfer_function(tfm.standard(), *flow.attribute_range())
+    c.set_camera(view, proj, fovy, near, far, W, H)
     c.set_options(bench.WORKLOADS[wl]["settings"])
     c.set_options(dict(kv.split("=", 1) for kv in os.environ.get("LV_PROBE_SET", "").split(",") if kv))   # e.g. overlap_primary_passes=false
     c.build_accel()
@@ -56,7 +55,7 @@ def subdivide(tiles):
     return np.ascontiguousarray(sub[(sub[:, 0] < W) & (sub[:, 1] < H)])
 
 
-def time_tiles(tiles, depth, reps=40):
+def time_tiles(tiles, depth, reps=int(os.environ.get("LV_PROBE_REPS", "40"))):
     tiles = subdivide(tiles)
     outs = [torch.zeros((len(tiles), SUBH, SUBW, 4), dtype=torch.uint8, device="cuda:0") for _ in range(depth)]
     for k in range(4):
